@@ -1,0 +1,463 @@
+"""ctypes mirror of include/cookmatch.h (struct layouts and SoA containers).
+
+The containers hold numpy arrays (host SoA) and build the C structs on demand; they keep the arrays alive for the
+duration of a call.  Field names follow the reference's domain: tasks, users, shares (divisors), quotas, offers,
+leases, groups (see include/cookmatch.h for the reference file:line each field comes from).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+NONE_U32 = 0xFFFFFFFF
+DMAX = float(np.finfo(np.float64).max)
+
+_f64p = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class CookParams(C.Structure):
+    _fields_ = [
+        ("dru_mode", C.c_int32),
+        ("max_over_quota_jobs", C.c_int32),
+        ("offensive_max_mem_mb", C.c_double),
+        ("offensive_max_cpus", C.c_double),
+        ("good_enough_fitness", C.c_double),
+        ("host_lifetime_mins", C.c_int64),
+        ("match_algo", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class CookUsage(C.Structure):
+    _fields_ = [("count", C.c_double), ("cpus", C.c_double), ("mem", C.c_double), ("gpus", C.c_double)]
+
+    def as_tuple(self):
+        return (self.count, self.cpus, self.mem, self.gpus)
+
+
+class CookTasks(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("cpus", _f64p), ("mem", _f64p), ("gpus", _f64p),
+        ("user", _u32p), ("priority", _i32p),
+        ("start_ms", _i64p), ("task_id", _i64p), ("job_id", _i64p),
+        ("pending", _u8p), ("host", _u32p),
+    ]
+
+
+class CookUsers(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("div_cpus", _f64p), ("div_mem", _f64p), ("div_gpus", _f64p),
+        ("quota_count", _f64p), ("quota_cpus", _f64p), ("quota_mem", _f64p), ("quota_gpus", _f64p),
+    ]
+
+
+class CookPoolQuota(C.Structure):
+    _fields_ = [
+        ("has_pool_quota", C.c_int32), ("has_group_quota", C.c_int32),
+        ("pool_quota", CookUsage), ("group_quota", CookUsage), ("group_usage", CookUsage),
+        ("pool_usage_given", C.c_int32), ("reserved", C.c_int32),
+        ("pool_usage", CookUsage),
+    ]
+
+
+class CookJobs(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("cpus", _f64p), ("mem", _f64p), ("gpus", _f64p),
+        ("gpu_model", _u32p), ("user", _u32p), ("group", _u32p),
+        ("eq_off", _u32p), ("eq_key", _u32p), ("eq_val", _u32p),
+        ("novel_off", _u32p), ("novel_host", _u32p),
+        ("reserved_host", _i32p), ("ckpt_location", _u32p), ("est_end_ms", _i64p),
+        ("disk_request", _f64p), ("disk_type", _u32p),
+    ]
+
+
+class CookOffers(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("cpus", _f64p), ("mem", _f64p), ("host", _u32p), ("k8s", _u8p),
+        ("gpu_model", _u32p), ("gpu_count", _f64p),
+        ("disk_type", _u32p), ("disk_space", _f64p),
+        ("n_attr_keys", C.c_uint32), ("attr", _u32p),
+        ("max_tasks", _i32p), ("num_tasks", _i32p),
+        ("location", _u32p), ("host_start_s", _i64p),
+        ("run_cpus", _f64p), ("run_mem", _f64p), ("run_count", _i32p),
+    ]
+
+
+class CookGroups(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("type", _u8p), ("attr_key", _u32p), ("minimum", _i32p),
+        ("run_off", _u32p), ("run_host", _u32p), ("run_attr", _u32p),
+    ]
+
+
+class CookRebalanceParams(C.Structure):
+    _fields_ = [("safe_dru_threshold", C.c_double), ("min_dru_diff", C.c_double),
+                ("max_preemption", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CookHostSpare(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("host", _u32p), ("cpus", _f64p), ("mem", _f64p), ("gpus", _f64p)]
+
+
+class CookPreemption(C.Structure):
+    _fields_ = [
+        ("pending_index", C.c_uint32), ("host", C.c_uint32),
+        ("dru", C.c_double), ("cpus", C.c_double), ("mem", C.c_double), ("gpus", C.c_double),
+        ("task_off", C.c_uint32), ("task_n", C.c_uint32),
+    ]
+
+
+_DT = {_f64p: np.float64, _u32p: np.uint32, _i32p: np.int32, _i64p: np.int64, _u8p: np.uint8}
+
+
+def _ptr(arr: Optional[np.ndarray], ptype):
+    if arr is None:
+        return ptype()
+    assert arr.dtype == _DT[ptype] and arr.flags["C_CONTIGUOUS"], (arr.dtype, ptype)
+    return arr.ctypes.data_as(ptype)
+
+
+def _arr(x, dtype, n=None):
+    if x is None:
+        return None
+    a = np.ascontiguousarray(x, dtype=dtype)
+    if n is not None:
+        assert a.shape == (n,), (a.shape, n)
+    return a
+
+
+def default_params(**kw) -> CookParams:
+    """Reference defaults: config.clj:108-116 (fenzo), :413-416 (max-over-quota-jobs 100), :398-407 (task-constraints)."""
+    p = CookParams(dru_mode=0, max_over_quota_jobs=100, offensive_max_mem_mb=float("inf"),
+                   offensive_max_cpus=float("inf"), good_enough_fitness=0.8, host_lifetime_mins=0, match_algo=0,
+                   reserved=0)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+@dataclass
+class Tasks:
+    """running instances ++ synthetic tasks of pending jobs (tools.clj:582-588)."""
+    cpus: np.ndarray
+    mem: np.ndarray
+    user: np.ndarray
+    priority: np.ndarray
+    start_ms: np.ndarray
+    task_id: np.ndarray
+    job_id: np.ndarray
+    pending: np.ndarray
+    gpus: Optional[np.ndarray] = None
+    host: Optional[np.ndarray] = None
+
+    def __post_init__(self):
+        n = len(self.cpus)
+        self.cpus = _arr(self.cpus, np.float64, n)
+        self.mem = _arr(self.mem, np.float64, n)
+        self.gpus = _arr(self.gpus, np.float64, n)
+        self.user = _arr(self.user, np.uint32, n)
+        self.priority = _arr(self.priority, np.int32, n)
+        self.start_ms = _arr(self.start_ms, np.int64, n)
+        self.task_id = _arr(self.task_id, np.int64, n)
+        self.job_id = _arr(self.job_id, np.int64, n)
+        self.pending = _arr(self.pending, np.uint8, n)
+        self.host = _arr(self.host, np.uint32, n)
+
+    @property
+    def n(self):
+        return len(self.cpus)
+
+    def as_struct(self) -> CookTasks:
+        return CookTasks(self.n, _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p), _ptr(self.gpus, _f64p),
+                         _ptr(self.user, _u32p), _ptr(self.priority, _i32p), _ptr(self.start_ms, _i64p),
+                         _ptr(self.task_id, _i64p), _ptr(self.job_id, _i64p), _ptr(self.pending, _u8p),
+                         _ptr(self.host, _u32p))
+
+
+@dataclass
+class Users:
+    """DRU divisors = shares (share.clj:75-119) and quotas (quota.clj:272-295), indexed by user id (= name rank)."""
+    div_cpus: np.ndarray
+    div_mem: np.ndarray
+    div_gpus: Optional[np.ndarray] = None
+    quota_count: Optional[np.ndarray] = None
+    quota_cpus: Optional[np.ndarray] = None
+    quota_mem: Optional[np.ndarray] = None
+    quota_gpus: Optional[np.ndarray] = None
+
+    def __post_init__(self):
+        n = len(self.div_cpus)
+        full = lambda v: np.full(n, v, dtype=np.float64)  # noqa: E731
+        self.div_cpus = _arr(self.div_cpus, np.float64, n)
+        self.div_mem = _arr(self.div_mem, np.float64, n)
+        self.div_gpus = _arr(self.div_gpus if self.div_gpus is not None else full(DMAX), np.float64, n)
+        self.quota_count = _arr(self.quota_count if self.quota_count is not None else full(2.0 ** 31 - 1), np.float64, n)
+        self.quota_cpus = _arr(self.quota_cpus if self.quota_cpus is not None else full(DMAX), np.float64, n)
+        self.quota_mem = _arr(self.quota_mem if self.quota_mem is not None else full(DMAX), np.float64, n)
+        self.quota_gpus = _arr(self.quota_gpus if self.quota_gpus is not None else full(DMAX), np.float64, n)
+
+    @property
+    def n(self):
+        return len(self.div_cpus)
+
+    def as_struct(self) -> CookUsers:
+        return CookUsers(self.n, _ptr(self.div_cpus, _f64p), _ptr(self.div_mem, _f64p), _ptr(self.div_gpus, _f64p),
+                         _ptr(self.quota_count, _f64p), _ptr(self.quota_cpus, _f64p), _ptr(self.quota_mem, _f64p),
+                         _ptr(self.quota_gpus, _f64p))
+
+
+def usage(count=0.0, cpus=0.0, mem=0.0, gpus=0.0) -> CookUsage:
+    return CookUsage(float(count), float(cpus), float(mem), float(gpus))
+
+
+def quota(count=2.0 ** 31 - 1, cpus=DMAX, mem=DMAX, gpus=DMAX) -> CookUsage:
+    return CookUsage(float(count), float(cpus), float(mem), float(gpus))
+
+
+def pool_quota(pool_quota: Optional[CookUsage] = None, group_quota: Optional[CookUsage] = None,
+               group_usage: Optional[CookUsage] = None, pool_usage: Optional[CookUsage] = None) -> CookPoolQuota:
+    q = CookPoolQuota()
+    q.has_pool_quota = int(pool_quota is not None)
+    q.has_group_quota = int(group_quota is not None and group_usage is not None)
+    if pool_quota is not None:
+        q.pool_quota = pool_quota
+    if q.has_group_quota:
+        q.group_quota = group_quota
+        q.group_usage = group_usage
+    q.pool_usage_given = int(pool_usage is not None)
+    if pool_usage is not None:
+        q.pool_usage = pool_usage
+    return q
+
+
+def _csr(lists, n):
+    off = np.zeros(n + 1, dtype=np.uint32)
+    flat = []
+    for i in range(n):
+        flat.extend(lists[i] if lists is not None else [])
+        off[i + 1] = len(flat)
+    return off, flat
+
+
+@dataclass
+class Jobs:
+    """Considerable jobs in rank order = Fenzo TaskRequests (scheduler.clj:456-509)."""
+    cpus: np.ndarray
+    mem: np.ndarray
+    gpus: Optional[np.ndarray] = None
+    gpu_model: Optional[np.ndarray] = None
+    user: Optional[np.ndarray] = None
+    group: Optional[np.ndarray] = None
+    eq_off: Optional[np.ndarray] = None
+    eq_key: Optional[np.ndarray] = None
+    eq_val: Optional[np.ndarray] = None
+    novel_off: Optional[np.ndarray] = None
+    novel_host: Optional[np.ndarray] = None
+    reserved_host: Optional[np.ndarray] = None
+    ckpt_location: Optional[np.ndarray] = None
+    est_end_ms: Optional[np.ndarray] = None
+    disk_request: Optional[np.ndarray] = None
+    disk_type: Optional[np.ndarray] = None
+
+    def __post_init__(self):
+        n = len(self.cpus)
+        self.cpus = _arr(self.cpus, np.float64, n)
+        self.mem = _arr(self.mem, np.float64, n)
+        self.gpus = _arr(self.gpus, np.float64, n)
+        self.gpu_model = _arr(self.gpu_model, np.uint32, n)
+        self.user = _arr(self.user, np.uint32, n)
+        self.group = _arr(self.group, np.uint32, n)
+        self.eq_off = _arr(self.eq_off, np.uint32)
+        self.eq_key = _arr(self.eq_key, np.uint32)
+        self.eq_val = _arr(self.eq_val, np.uint32)
+        self.novel_off = _arr(self.novel_off, np.uint32)
+        self.novel_host = _arr(self.novel_host, np.uint32)
+        self.reserved_host = _arr(self.reserved_host, np.int32, n)
+        self.ckpt_location = _arr(self.ckpt_location, np.uint32, n)
+        self.est_end_ms = _arr(self.est_end_ms, np.int64, n)
+        self.disk_request = _arr(self.disk_request, np.float64, n)
+        self.disk_type = _arr(self.disk_type, np.uint32, n)
+        if self.eq_off is not None:
+            assert len(self.eq_off) == n + 1
+            if self.eq_key is None or len(self.eq_key) == 0:  # keep non-NULL pointers for empty CSR payloads
+                self.eq_key = np.zeros(1, np.uint32)
+                self.eq_val = np.zeros(1, np.uint32)
+        if self.novel_off is not None:
+            assert len(self.novel_off) == n + 1
+            if self.novel_host is None or len(self.novel_host) == 0:
+                self.novel_host = np.zeros(1, np.uint32)
+
+    @staticmethod
+    def with_constraints(cpus, mem, equals=None, novel=None, **kw) -> "Jobs":
+        """equals: per job list of (key, value); novel: per job list of host ids."""
+        n = len(cpus)
+        if equals is not None:
+            off, flat = _csr(equals, n)
+            kw.update(eq_off=off, eq_key=np.array([k for k, _ in flat], dtype=np.uint32),
+                      eq_val=np.array([v for _, v in flat], dtype=np.uint32))
+        if novel is not None:
+            off, flat = _csr(novel, n)
+            kw.update(novel_off=off, novel_host=np.array(flat, dtype=np.uint32))
+        return Jobs(cpus=cpus, mem=mem, **kw)
+
+    @property
+    def n(self):
+        return len(self.cpus)
+
+    def take(self, idx) -> "Jobs":
+        """Jobs re-ordered/subset by index array (used to turn pending jobs into considerable-in-rank-order)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        kw = {}
+        for name in ("cpus", "mem", "gpus", "gpu_model", "user", "group", "reserved_host", "ckpt_location",
+                     "est_end_ms", "disk_request", "disk_type"):
+            a = getattr(self, name)
+            kw[name] = None if a is None else a[idx]
+        if self.eq_off is not None:
+            lists = [list(zip(self.eq_key[self.eq_off[i]:self.eq_off[i + 1]], self.eq_val[self.eq_off[i]:self.eq_off[i + 1]]))
+                     for i in idx]
+            off, flat = _csr(lists, len(idx))
+            kw.update(eq_off=off, eq_key=np.array([k for k, _ in flat], dtype=np.uint32),
+                      eq_val=np.array([v for _, v in flat], dtype=np.uint32))
+        if self.novel_off is not None:
+            lists = [list(self.novel_host[self.novel_off[i]:self.novel_off[i + 1]]) for i in idx]
+            off, flat = _csr(lists, len(idx))
+            kw.update(novel_off=off, novel_host=np.array(flat, dtype=np.uint32))
+        return Jobs(**kw)
+
+    def as_struct(self) -> CookJobs:
+        return CookJobs(self.n, _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p), _ptr(self.gpus, _f64p),
+                        _ptr(self.gpu_model, _u32p), _ptr(self.user, _u32p), _ptr(self.group, _u32p),
+                        _ptr(self.eq_off, _u32p), _ptr(self.eq_key, _u32p), _ptr(self.eq_val, _u32p),
+                        _ptr(self.novel_off, _u32p), _ptr(self.novel_host, _u32p),
+                        _ptr(self.reserved_host, _i32p), _ptr(self.ckpt_location, _u32p),
+                        _ptr(self.est_end_ms, _i64p), _ptr(self.disk_request, _f64p), _ptr(self.disk_type, _u32p))
+
+
+@dataclass
+class Offers:
+    """One lease per host (offer.clj:31-76) plus Fenzo's running-task view of the host."""
+    cpus: np.ndarray
+    mem: np.ndarray
+    host: Optional[np.ndarray] = None
+    k8s: Optional[np.ndarray] = None
+    gpu_model: Optional[np.ndarray] = None
+    gpu_count: Optional[np.ndarray] = None
+    disk_type: Optional[np.ndarray] = None
+    disk_space: Optional[np.ndarray] = None
+    attr: Optional[np.ndarray] = None  # [n, n_attr_keys] uint32, 0 = absent
+    max_tasks: Optional[np.ndarray] = None
+    num_tasks: Optional[np.ndarray] = None
+    location: Optional[np.ndarray] = None
+    host_start_s: Optional[np.ndarray] = None
+    run_cpus: Optional[np.ndarray] = None
+    run_mem: Optional[np.ndarray] = None
+    run_count: Optional[np.ndarray] = None
+
+    def __post_init__(self):
+        n = len(self.cpus)
+        self.cpus = _arr(self.cpus, np.float64, n)
+        self.mem = _arr(self.mem, np.float64, n)
+        self.host = _arr(self.host if self.host is not None else np.arange(n), np.uint32, n)
+        self.k8s = _arr(self.k8s, np.uint8, n)
+        self.gpu_model = _arr(self.gpu_model, np.uint32, n)
+        self.gpu_count = _arr(self.gpu_count, np.float64, n)
+        if self.gpu_model is not None and self.gpu_count is None:
+            self.gpu_count = np.zeros(n)
+        self.disk_type = _arr(self.disk_type, np.uint32, n)
+        self.disk_space = _arr(self.disk_space, np.float64, n)
+        if self.attr is not None:
+            self.attr = np.ascontiguousarray(self.attr, dtype=np.uint32)
+            assert self.attr.ndim == 2 and self.attr.shape[0] == n
+        self.max_tasks = _arr(self.max_tasks, np.int32, n)
+        self.num_tasks = _arr(self.num_tasks, np.int32, n)
+        if self.max_tasks is not None and self.num_tasks is None:
+            self.num_tasks = np.zeros(n, np.int32)
+        self.location = _arr(self.location, np.uint32, n)
+        self.host_start_s = _arr(self.host_start_s, np.int64, n)
+        self.run_cpus = _arr(self.run_cpus, np.float64, n)
+        self.run_mem = _arr(self.run_mem, np.float64, n)
+        self.run_count = _arr(self.run_count, np.int32, n)
+
+    @property
+    def n(self):
+        return len(self.cpus)
+
+    @property
+    def n_attr_keys(self):
+        return 0 if self.attr is None else self.attr.shape[1]
+
+    def as_struct(self) -> CookOffers:
+        attr = None if self.attr is None else self.attr.reshape(-1)
+        return CookOffers(self.n, _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p), _ptr(self.host, _u32p),
+                          _ptr(self.k8s, _u8p), _ptr(self.gpu_model, _u32p), _ptr(self.gpu_count, _f64p),
+                          _ptr(self.disk_type, _u32p), _ptr(self.disk_space, _f64p),
+                          self.n_attr_keys, _ptr(attr, _u32p),
+                          _ptr(self.max_tasks, _i32p), _ptr(self.num_tasks, _i32p),
+                          _ptr(self.location, _u32p), _ptr(self.host_start_s, _i64p),
+                          _ptr(self.run_cpus, _f64p), _ptr(self.run_mem, _f64p), _ptr(self.run_count, _i32p))
+
+
+@dataclass
+class Groups:
+    """Job groups with host-placement constraints (constraints.clj:519-678)."""
+    type: np.ndarray  # 0 all, 1 unique, 2 balanced, 3 attribute-equals
+    attr_key: Optional[np.ndarray] = None
+    minimum: Optional[np.ndarray] = None
+    run_hosts: Optional[list] = None  # per group: host ids of cotasks already running
+    run_attrs: Optional[list] = None  # per group: attr value id of each running cotask's host
+    _run_off: np.ndarray = field(init=False, default=None)
+    _run_host: np.ndarray = field(init=False, default=None)
+    _run_attr: np.ndarray = field(init=False, default=None)
+
+    def __post_init__(self):
+        n = len(self.type)
+        self.type = _arr(self.type, np.uint8, n)
+        self.attr_key = _arr(self.attr_key if self.attr_key is not None else np.full(n, NONE_U32), np.uint32, n)
+        self.minimum = _arr(self.minimum if self.minimum is not None else np.zeros(n), np.int32, n)
+        off, flat = _csr(self.run_hosts, n)
+        _, flat_a = _csr(self.run_attrs, n)
+        if self.run_attrs is None:
+            flat_a = [0] * len(flat)
+        assert len(flat_a) == len(flat)
+        self._run_off = off
+        self._run_host = np.array(flat if flat else [0], dtype=np.uint32)
+        self._run_attr = np.array(flat_a if flat_a else [0], dtype=np.uint32)
+
+    @property
+    def n(self):
+        return len(self.type)
+
+    def as_struct(self) -> CookGroups:
+        return CookGroups(self.n, _ptr(self.type, _u8p), _ptr(self.attr_key, _u32p), _ptr(self.minimum, _i32p),
+                          _ptr(self._run_off, _u32p), _ptr(self._run_host, _u32p), _ptr(self._run_attr, _u32p))
+
+
+@dataclass
+class HostSpare:
+    host: np.ndarray
+    cpus: np.ndarray
+    mem: np.ndarray
+    gpus: Optional[np.ndarray] = None
+
+    def __post_init__(self):
+        n = len(self.host)
+        self.host = _arr(self.host, np.uint32, n)
+        self.cpus = _arr(self.cpus, np.float64, n)
+        self.mem = _arr(self.mem, np.float64, n)
+        self.gpus = _arr(self.gpus if self.gpus is not None else np.zeros(n), np.float64, n)
+
+    def as_struct(self) -> CookHostSpare:
+        return CookHostSpare(len(self.host), _ptr(self.host, _u32p), _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p),
+                             _ptr(self.gpus, _f64p))

@@ -1,0 +1,246 @@
+/*
+ * cookmatch.h — C ABI of libcookmatch.so, the MI355X (gfx950) fair-share match engine.
+ *
+ * This is the drop-in boundary for ONE path of twosigma/Cook: per-cycle DRU ranking, the jobs x offers
+ * feasibility/constraint evaluation, rank-ordered bin-pack placement (what Cook delegates to Netflix Fenzo's
+ * TaskScheduler.scheduleOnce) and the rebalancer's preemption decisions.  The reference has no FFI on this
+ * path; each entry point below names the Clojure function(s) it replaces (paths relative to the reference's
+ * scheduler/ directory).  INTEGRATION.md shows the JNI binding a Cook maintainer would add.
+ *
+ * Conventions
+ *  - Plain C.  No exceptions, no callbacks, no torch types.  All buffers are caller-allocated SoA arrays.
+ *  - Identity: users, hosts, attribute keys/values, gpu models, disk types, groups, locations are dense
+ *    uint32 ids interned by the host (Clojure keeps id->entity tables).  The engine never sees strings.
+ *    USER IDS AND HOST IDS MUST BE ASSIGNED IN ASCENDING NAME ORDER (java String.compareTo): the reference
+ *    breaks ties by user name (dru.clj:123, rebalancer.clj:252-256) and orders hosts by name
+ *    (rebalancer.clj:383).
+ *  - Every function returns COOK_OK (0) or a negative COOK_E_* code; cook_last_error() has the message.
+ *    On error the outputs are "no ranking / no matches / no decisions", so the Clojure caller's
+ *    catch-Throwable path (scheduler.clj:1521-1535) can restore its offers exactly as today.
+ *  - A handle is NOT re-entrant: hold the mutual exclusion the reference holds on the Fenzo object
+ *    ((locking fenzo ...), scheduler.clj:665).  Distinct handles (pools) may be used from distinct threads.
+ *  - The engine is stateless across calls except for buffers it caches on the device; everything that
+ *    Fenzo's TaskTracker would remember (tasks already running on a host) is passed in by the caller.
+ *  - All arithmetic on the path is IEEE fp64, round-to-nearest, no flush-to-zero (share.clj:95 makes
+ *    DRUs of magnitude 1e-305 legal).
+ */
+#ifndef COOKMATCH_H
+#define COOKMATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COOK_OK 0
+#define COOK_E_INVALID (-1) /* bad argument / inconsistent sizes            */
+#define COOK_E_DEVICE (-2)  /* HIP runtime error (message has the hipError) */
+#define COOK_E_NOMEM (-3)
+#define COOK_E_STATE (-4)   /* call order violated (run before stage ...)   */
+
+#define COOK_NONE_U32 0xFFFFFFFFu
+
+typedef struct cook_engine cook_engine; /* opaque; one per pool */
+
+/* ---- knobs (every hot-path configuration value of the reference) ------------------------- */
+typedef struct cook_params {
+  int32_t dru_mode;            /* 0 = :pool.dru-mode/default (cpus,mem), 1 = :pool.dru-mode/gpu (scheduler.clj:2178-2183) */
+  int32_t max_over_quota_jobs; /* config.clj:413-416, default 100 (scheduler.clj:2057-2071)                     */
+  double offensive_max_mem_mb; /* task-constraints :memory-gb * 1024.0 (scheduler.clj:2219); +inf disables      */
+  double offensive_max_cpus;   /* task-constraints :cpus (scheduler.clj:2198-2203); +inf disables               */
+  double good_enough_fitness;  /* config.clj:111 default 0.8; (> fitness x) at scheduler.clj:2312-2314; >=1 = off */
+  int64_t host_lifetime_mins;  /* estimated-completion-config :host-lifetime-mins (constraints.clj:392-397)     */
+  int32_t match_algo;          /* 0 = engine default; see DESIGN.md (all algorithms give identical results)     */
+  int32_t reserved;
+} cook_params;
+
+/* ---- resource 4-vector used for quotas and usage: {count, cpus, mem, gpus} (tools.clj:883-889) ---------- */
+typedef struct cook_usage {
+  double count, cpus, mem, gpus;
+} cook_usage;
+
+/* ---- tasks: running instances ++ synthetic tasks for pending jobs (tools.clj:582-588) ------------------- */
+typedef struct cook_tasks {
+  uint32_t n;
+  const double* cpus;      /* job resources (tools.clj:247-273)                                        */
+  const double* mem;
+  const double* gpus;      /* may be NULL (all 0.0)                                                    */
+  const uint32_t* user;    /* user id = rank of the user name                                          */
+  const int32_t* priority; /* :job/priority, default 50 (tools.clj:612)                                */
+  const int64_t* start_ms; /* :instance/start-time in ms; ignored for pending (treated as Long.MAX)    */
+  const int64_t* task_id;  /* :db/id of the instance; ignored for pending (nil sorts first)            */
+  const int64_t* job_id;   /* :db/id of the job                                                        */
+  const uint8_t* pending;  /* 1 = synthetic task of a waiting job, 0 = running instance                */
+  const uint32_t* host;    /* running: host id (only used by cook_rebalance); may be NULL for cook_rank */
+} cook_tasks;
+
+/* ---- users: DRU divisors (share.clj:75-119,189-210) and quotas (quota.clj:272-295) ---------------------- */
+typedef struct cook_users {
+  uint32_t n;
+  const double* div_cpus; /* share, Double.MAX_VALUE when unset                                         */
+  const double* div_mem;
+  const double* div_gpus;
+  const double* quota_count; /* quota per resource, Double.MAX_VALUE (count: 2^31-1) when unset          */
+  const double* quota_cpus;
+  const double* quota_mem;
+  const double* quota_gpus;
+} cook_users;
+
+/* ---- pool-level quota inputs of filter-based-on-quota (scheduler.clj:2134-2157) ------------------------- */
+typedef struct cook_pool_quota {
+  int32_t has_pool_quota; /* 0: (tools/global-pool-quota pool) is nil -> no filtering (tools.clj:925)    */
+  int32_t has_group_quota;
+  cook_usage pool_quota;
+  cook_usage group_quota;
+  cook_usage group_usage; /* aggregate-quota-groups over the member pools (scheduler.clj:2125-2132);
+                             the cross-pool sum is the only collective on the path (RCCL all-reduce)   */
+  int32_t pool_usage_given; /* 0: engine computes the pool's running usage itself (scheduler.clj:2173)  */
+  int32_t reserved;
+  cook_usage pool_usage;
+} cook_pool_quota;
+
+/* ---- considerable jobs, in rank order (scheduler.clj:729-762, 456-509) ---------------------------------- */
+typedef struct cook_jobs {
+  uint32_t n;
+  const double* cpus;
+  const double* mem;
+  const double* gpus;            /* may be NULL                                                         */
+  const uint32_t* gpu_model;     /* requested model id (constraints.clj:96-103); 0 = none; may be NULL  */
+  const uint32_t* user;          /* may be NULL for cook_match                                          */
+  const uint32_t* group;         /* group id or COOK_NONE_U32; may be NULL                              */
+  const uint32_t* eq_off;        /* CSR [n+1] of user-defined EQUALS constraints (constraints.clj:356)  */
+  const uint32_t* eq_key;        /*   attribute key id                                                  */
+  const uint32_t* eq_val;        /*   required value id                                                 */
+  const uint32_t* novel_off;     /* CSR [n+1] of hosts the job already ran on (constraints.clj:68-94)   */
+  const uint32_t* novel_host;
+  const int32_t* reserved_host;  /* host reserved FOR this job by the rebalancer, -1 none (scheduler.clj:645-653) */
+  const uint32_t* ckpt_location; /* location id of last checkpoint, 0 = none (constraints.clj:201-240)  */
+  const int64_t* est_end_ms;     /* estimated end time, 0 = no constraint (constraints.clj:385-431)     */
+  const double* disk_request;    /* MiB, <0 = constraint not in effect (constraints.clj:164-199)        */
+  const uint32_t* disk_type;
+} cook_jobs;
+
+/* ---- offers, one per host (offer.clj:31-76), plus Fenzo's view of tasks already on that host ------------ */
+typedef struct cook_offers {
+  uint32_t n;
+  const double* cpus;        /* cpuCores of the lease (offer.clj:55)                                    */
+  const double* mem;         /* memoryMB                                                                */
+  const uint32_t* host;      /* host id (hostname rank)                                                 */
+  const uint8_t* k8s;        /* attr "compute-cluster-type" == "kubernetes"; NULL = all 0               */
+  const uint32_t* gpu_model; /* k8s "gpus" text->scalar map, one model per host; 0 = no gpus; may be NULL */
+  const double* gpu_count;
+  const uint32_t* disk_type; /* k8s "disk" map, one type per host; may be NULL                          */
+  const double* disk_space;
+  uint32_t n_attr_keys;      /* attribute table is [n][n_attr_keys], value id 0 = attribute absent      */
+  const uint32_t* attr;
+  const int32_t* max_tasks;  /* COOK_MAX_TASKS_PER_HOST, -1 absent; may be NULL                         */
+  const int32_t* num_tasks;  /* COOK_NUM_TASKS_ON_HOST                                                  */
+  const uint32_t* location;  /* COOK_COMPUTE_CLUSTER_LOCATION id; may be NULL                           */
+  const int64_t* host_start_s; /* "host-start-time", -1 absent; may be NULL                             */
+  const double* run_cpus;    /* sum over tasks Fenzo tracks as running on the host (getTaskAssigner,    */
+  const double* run_mem;     /*   scheduler.clj:877-881); NULL = 0                                      */
+  const int32_t* run_count;
+} cook_offers;
+
+/* ---- job groups with host-placement constraints (constraints.clj:519-678) ------------------------------- */
+typedef struct cook_groups {
+  uint32_t n;
+  const uint8_t* type;      /* 0 all (none), 1 unique, 2 balanced, 3 attribute-equals                    */
+  const uint32_t* attr_key; /* balanced / attribute-equals attribute key id                              */
+  const int32_t* minimum;   /* :host-placement.balanced/minimum                                          */
+  const uint32_t* run_off;  /* CSR [n+1]: cotasks of the group already running per the DB + Fenzo tracker */
+  const uint32_t* run_host; /*   host id of each running cotask                                          */
+  const uint32_t* run_attr; /*   value id of attr_key on that host (0 = absent)                          */
+} cook_groups;
+
+/* ---- rebalancer ---------------------------------------------------------------------------------------- */
+typedef struct cook_rebalance_params { /* rebalancer.clj:535-557 (Datomic :rebalancer/config) */
+  double safe_dru_threshold;
+  double min_dru_diff;
+  int32_t max_preemption;
+  int32_t reserved;
+} cook_rebalance_params;
+
+typedef struct cook_host_spare { /* host->spare-resources from view-incubating-offers (rebalancer.clj:577-582) */
+  uint32_t n;
+  const uint32_t* host;
+  const double* cpus;
+  const double* mem;
+  const double* gpus;
+} cook_host_spare;
+
+typedef struct cook_preemption { /* one preemption decision (rebalancer.clj:384-404) */
+  uint32_t pending_index; /* index into the pending jobs passed in                                       */
+  uint32_t host;          /* :hostname                                                                   */
+  double dru;             /* :dru of the decision (Double.MAX_VALUE = spare resources only)              */
+  double cpus, mem, gpus; /* resources freed on the host                                                 */
+  uint32_t task_off;      /* preempted tasks = preempted[task_off .. task_off+task_n)                    */
+  uint32_t task_n;
+} cook_preemption;
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------ */
+int cook_engine_create(const cook_params* params, int device_id, cook_engine** out);
+void cook_engine_destroy(cook_engine* e);
+int cook_engine_set_params(cook_engine* e, const cook_params* params);
+const char* cook_last_error(const cook_engine* e);
+const char* cook_version(void);
+
+/* ---- RANK: replaces sort-jobs-by-dru-helper + filter-based-on-quota + filter-offensive-jobs --------------
+ * (scheduler.clj:2073-2091, 2134-2157, 2198-2229; dru.clj:50-126; tools.clj:614-641, 917-933).
+ * ranked_pending_idx receives indices into `tasks` of the surviving pending jobs in rank order (capacity =
+ * number of pending tasks); dru_of_task (optional, len tasks->n) receives each task's DRU score, NaN for
+ * tasks cut by the over-quota limiter.
+ * The staged form keeps inputs resident in HBM between cycles: stage (H2D) -> run (kernels only) -> fetch (D2H). */
+int cook_rank(cook_engine* e, const cook_tasks* tasks, const cook_users* users, const cook_pool_quota* quota,
+              uint32_t* ranked_pending_idx, uint32_t* n_out, double* dru_of_task);
+int cook_rank_stage(cook_engine* e, const cook_tasks* tasks, const cook_users* users);
+int cook_rank_set_quota(cook_engine* e, const cook_pool_quota* quota);
+/* running usage of the pool {count,cpus,mem,gpus} (scheduler.clj:2118-2123, 2173): input to the cross-pool all-reduce */
+int cook_rank_pool_usage(cook_engine* e, cook_usage* out);
+int cook_rank_run(cook_engine* e);
+int cook_rank_fetch(cook_engine* e, uint32_t* ranked_pending_idx, uint32_t* n_out, double* dru_of_task);
+
+/* ---- MATCH: replaces the body of match-offer-to-schedule, i.e. TaskScheduler.scheduleOnce -----------------
+ * (scheduler.clj:617-687; Fenzo 0.10.0 pinned at project.clj:46-50; constraints.clj).
+ * job_to_offer[k] = offer index or -1.  head_matched mirrors scheduler.clj:1495 (first considerable job matched,
+ * or nothing matched at all).  fail_code (optional, len K): 0 matched, else first reason no offer accepted it
+ * (bit 0 resources, bit 1 constraints).  reserved_hosts: hosts reserved by the rebalancer for ANY job. */
+int cook_match(cook_engine* e, const cook_jobs* considerable, const cook_offers* offers, const cook_groups* groups,
+               const uint32_t* reserved_hosts, uint32_t n_reserved, int32_t* job_to_offer, uint32_t* fail_code,
+               uint8_t* head_matched);
+int cook_match_stage(cook_engine* e, const cook_jobs* considerable, const cook_offers* offers,
+                     const cook_groups* groups, const uint32_t* reserved_hosts, uint32_t n_reserved);
+int cook_match_run(cook_engine* e);
+int cook_match_fetch(cook_engine* e, int32_t* job_to_offer, uint32_t* fail_code, uint8_t* head_matched);
+
+/* ---- CYCLE: rank followed by match of the first K ranked jobs, without a host round trip ------------------
+ * (pending-jobs->considerable-jobs "take num-considerable", scheduler.clj:751).  `jobs` must describe the same
+ * pending tasks as the staged rank input, indexed by position among the pending tasks (pending ordinal).
+ * job_to_offer is indexed by rank position (len = min(K, n_ranked)). */
+int cook_cycle_stage(cook_engine* e, const cook_tasks* tasks, const cook_users* users, const cook_jobs* pending_jobs,
+                     const cook_offers* offers, const cook_groups* groups, const uint32_t* reserved_hosts,
+                     uint32_t n_reserved);
+int cook_cycle_run(cook_engine* e, uint32_t num_considerable);
+int cook_cycle_fetch(cook_engine* e, uint32_t* ranked_pending_idx, uint32_t* n_ranked, int32_t* job_to_offer,
+                     uint32_t* n_considered, uint8_t* head_matched);
+
+/* ---- REBALANCE: replaces init-state + the rebalance loop's decisions ---------------------------------------
+ * (rebalancer.clj:222-266, 320-407, 270-309, 434-467; dru.clj:128-144).  running: tasks with host ids;
+ * pending: the first max-preemption allowed-to-start pending jobs in rank order (rebalancer.clj:588-590).
+ * decisions capacity = pending->n; preempted capacity = running->n (task indices into `running`). */
+int cook_rebalance(cook_engine* e, const cook_tasks* running, const cook_jobs* pending, const int64_t* pending_job_id,
+                   const int32_t* pending_priority, const cook_users* users, const cook_host_spare* spare,
+                   const cook_rebalance_params* params, cook_preemption* decisions, uint32_t* n_decisions,
+                   uint32_t* preempted, uint32_t* n_preempted);
+
+/* ---- measurement hooks (bench.py): HIP-event time of the last *_run, per stage, in milliseconds ----------- */
+int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms);
+/* named kernel timings of the last run: fills up to cap entries, returns count */
+int cook_kernel_timings(cook_engine* e, const char** names, double* ms, uint32_t* launches, uint32_t cap);
+int cook_set_profiling(cook_engine* e, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COOKMATCH_H */

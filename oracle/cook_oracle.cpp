@@ -1,0 +1,680 @@
+// cook_oracle.cpp — CPU restatement of the reference algorithm for the fair-share match path.
+//
+// TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+// this library; the product path (cook_amd/, libcookmatch.so) never does.
+//
+// Parity status: the Clojure/JVM reference (and the un-vendored jar com.netflix.fenzo:fenzo-core:0.10.0,
+// scheduler/project.clj:46-50) cannot be built or run in this image (no JDK/lein/network), so this
+// restatement is pinned against the known-answer vectors of the reference's own unit tests
+// (tests/golden/*.json, transcribed by tests/golden/make_golden.py from scheduler/test/cook/test/...).
+// Where the reference leaves behaviour undefined (Fenzo VM iteration order, ties between equal-fitness
+// hosts, hash-map order of gpu-mode merges, priority-map order of equal (-dru,user) keys) this file
+// DEFINES it and says so at the spot ("UNPINNED").
+//
+// Every function cites the reference file:line it follows (paths relative to reference scheduler/).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <queue>
+#include <set>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../include/cookmatch.h"
+
+namespace {
+
+constexpr double DMAX = std::numeric_limits<double>::max();
+
+// ---------------------------------------------------------------------------------------------------
+// A.2 per-user order.  tools.clj:614-641 task->feature-vector / same-user-task-comparator:
+//   [(- priority) start-time(or Date Long/MAX) (:db/id task)(nil for synthetic) (:db/id job)], Clojure
+//   vector `compare` = lexicographic, nil sorts before any number.
+struct FeatureKey {
+  int64_t negprio, start, task, job;
+};
+inline FeatureKey feature_key(const cook_tasks* t, uint32_t i) {
+  FeatureKey k;
+  k.negprio = -(int64_t)t->priority[i];
+  bool pend = t->pending[i] != 0;
+  k.start = pend ? std::numeric_limits<int64_t>::max() : t->start_ms[i];
+  k.task = pend ? std::numeric_limits<int64_t>::min() : t->task_id[i];  // nil < everything
+  k.job = t->job_id[i];
+  return k;
+}
+inline bool key_less(const FeatureKey& a, const FeatureKey& b) {
+  if (a.negprio != b.negprio) return a.negprio < b.negprio;
+  if (a.start != b.start) return a.start < b.start;
+  if (a.task != b.task) return a.task < b.task;
+  return a.job < b.job;
+}
+
+// tools.clj:876-881 below-quota?: every usage key <= quota key.
+inline bool below_quota(const cook_usage& q, const cook_usage& u) {
+  return u.count <= q.count && u.cpus <= q.cpus && u.mem <= q.mem && u.gpus <= q.gpus;
+}
+inline double gpus_of(const cook_tasks* t, uint32_t i) { return t->gpus ? t->gpus[i] : 0.0; }
+
+struct Scored {
+  uint32_t task;
+  double dru;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// A.5 sorted-merge, LITERAL restatement of dru.clj:82-104: state = list of non-empty colls; each step
+// stable-sorts the list by head key (Clojure sort-by = java.util.Arrays/sort with comparator = stable
+// merge sort), emits the head of the first coll and conses that coll's remainder at the FRONT.
+// O(N * U log U): used for small inputs and to validate merge_heap.
+void merge_literal(const std::vector<std::vector<Scored>>& colls_in, std::vector<Scored>& out) {
+  struct C {
+    const std::vector<Scored>* v;
+    size_t pos;
+  };
+  std::vector<C> colls;
+  for (auto& c : colls_in)
+    if (!c.empty()) colls.push_back({&c, 0});
+  while (!colls.empty()) {
+    std::stable_sort(colls.begin(), colls.end(),
+                     [](const C& a, const C& b) { return (*a.v)[a.pos].dru < (*b.v)[b.pos].dru; });
+    C first = colls.front();
+    out.push_back((*first.v)[first.pos]);
+    colls.erase(colls.begin());
+    if (first.pos + 1 < first.v->size()) colls.insert(colls.begin(), {first.v, first.pos + 1});
+  }
+}
+
+// The same order in O(N log U).  Derived tie rule (DESIGN.md "sorted-merge tie rule"): among heads with equal
+// key, the coll that emitted most recently comes first; colls that never emitted come last, in initial
+// (user-name) order.  Validated against merge_literal by tests/test_oracle_merge.py.
+void merge_heap(const std::vector<std::vector<Scored>>& colls_in, std::vector<Scored>& out) {
+  struct H {
+    double dru;
+    int64_t recency;  // step of last emission; never emitted: -1 - initial index
+    uint32_t coll;
+  };
+  auto worse = [](const H& a, const H& b) {  // priority_queue keeps the "largest": invert
+    if (a.dru != b.dru) return a.dru > b.dru;
+    return a.recency < b.recency;
+  };
+  std::priority_queue<H, std::vector<H>, decltype(worse)> pq(worse);
+  std::vector<size_t> pos(colls_in.size(), 0);
+  for (uint32_t c = 0; c < colls_in.size(); ++c)
+    if (!colls_in[c].empty()) pq.push({colls_in[c][0].dru, -1 - (int64_t)c, c});
+  int64_t step = 0;
+  while (!pq.empty()) {
+    H h = pq.top();
+    pq.pop();
+    out.push_back(colls_in[h.coll][pos[h.coll]]);
+    if (++pos[h.coll] < colls_in[h.coll].size()) pq.push({colls_in[h.coll][pos[h.coll]].dru, step, h.coll});
+    ++step;
+  }
+}
+
+struct RankResult {
+  std::vector<uint32_t> ranked;  // task indices of surviving pending jobs in rank order
+  std::vector<double> dru;       // per input task, NaN if cut by the limiter
+  std::vector<Scored> merged;    // full merged sequence (running + pending)
+  cook_usage pool_usage;
+};
+
+// scheduler.clj:2118-2123 task-ents->usage over the pool's running tasks (sequential merge-with +).
+cook_usage running_usage(const cook_tasks* t) {
+  cook_usage u{0, 0, 0, 0};
+  for (uint32_t i = 0; i < t->n; ++i)
+    if (!t->pending[i]) {
+      u.count += 1;
+      u.cpus += t->cpus[i];
+      u.mem += t->mem[i];
+      u.gpus += gpus_of(t, i);
+    }
+  return u;
+}
+
+// tools.clj:917-933 filter-based-on-pool-quota via filter-sequential (tools.clj:654-668): the state adds EVERY
+// job seen, kept or not; a job is kept iff the updated usage is below-quota?.
+void pool_quota_filter(const cook_tasks* t, const cook_usage& quota, cook_usage usage, std::vector<uint32_t>& q) {
+  std::vector<uint32_t> keep;
+  for (uint32_t i : q) {
+    usage.count += 1;
+    usage.cpus += t->cpus[i];
+    usage.mem += t->mem[i];
+    usage.gpus += gpus_of(t, i);
+    if (below_quota(quota, usage)) keep.push_back(i);
+  }
+  q.swap(keep);
+}
+
+void rank_impl(const cook_params* p, const cook_tasks* t, const cook_users* u, const cook_pool_quota* pq, bool literal,
+               RankResult& r) {
+  const uint32_t N = t->n, U = u->n;
+  r.dru.assign(N, std::numeric_limits<double>::quiet_NaN());
+  // scheduler.clj:2076,2084-2085: tasks = running ++ pending; group-by user; sort each by the comparator.
+  std::vector<std::vector<uint32_t>> by_user(U);
+  for (uint32_t i = 0; i < N; ++i) by_user[t->user[i]].push_back(i);
+  std::vector<std::vector<Scored>> colls(U);
+  for (uint32_t us = 0; us < U; ++us) {
+    auto& v = by_user[us];
+    if (v.empty()) continue;
+    std::sort(v.begin(), v.end(),
+              [&](uint32_t a, uint32_t b) { return key_less(feature_key(t, a), feature_key(t, b)); });
+    // scheduler.clj:2057-2071 limit-over-quota-jobs: running prefix of job->usage; count prefixes that are
+    // not below-quota?; keep tasks while that count <= max-over-quota-jobs.
+    cook_usage q{u->quota_count[us], u->quota_cpus[us], u->quota_mem[us], u->quota_gpus[us]};
+    cook_usage tot{0, 0, 0, 0};
+    int64_t over = 0;
+    size_t kept = 0;
+    for (uint32_t i : v) {
+      tot.count += 1;
+      tot.cpus += t->cpus[i];
+      tot.mem += t->mem[i];
+      tot.gpus += gpus_of(t, i);
+      if (!below_quota(q, tot)) ++over;
+      if (over > p->max_over_quota_jobs) break;
+      ++kept;
+    }
+    // dru.clj:50-66 (default) / :68-80 (gpu): inclusive prefix sums left to right, divide, max.
+    double cs = 0, ms = 0, gs = 0;
+    auto& c = colls[us];
+    for (size_t k = 0; k < kept; ++k) {
+      uint32_t i = v[k];
+      double d;
+      if (p->dru_mode == 1) {
+        gs = (k == 0) ? gpus_of(t, i) : gs + gpus_of(t, i);
+        d = gs / u->div_gpus[us];
+      } else {
+        cs = (k == 0) ? t->cpus[i] : cs + t->cpus[i];
+        ms = (k == 0) ? t->mem[i] : ms + t->mem[i];
+        d = std::max(ms / u->div_mem[us], cs / u->div_cpus[us]);
+      }
+      r.dru[i] = d;
+      c.push_back({i, d});
+    }
+  }
+  // dru.clj:122-126: (sort-by first) users — ids ARE name ranks — then sorted-merge on :dru.
+  // UNPINNED: the gpu-mode merge (dru.clj:106-112) has no name sort (hash-map order); we use name order too.
+  if (literal)
+    merge_literal(colls, r.merged);
+  else
+    merge_heap(colls, r.merged);
+  // scheduler.clj:2089-2090 keep only pending.
+  std::vector<uint32_t> q;
+  for (auto& s : r.merged)
+    if (t->pending[s.task]) q.push_back(s.task);
+  // scheduler.clj:2134-2157 filter-based-on-quota: pool quota, then quota-group quota on the survivors.
+  r.pool_usage = (pq && pq->pool_usage_given) ? pq->pool_usage : running_usage(t);
+  if (pq && pq->has_pool_quota) pool_quota_filter(t, pq->pool_quota, r.pool_usage, q);
+  if (pq && pq->has_group_quota) pool_quota_filter(t, pq->group_quota, pq->group_usage, q);
+  // scheduler.clj:2198-2229 filter-offensive-jobs.
+  for (uint32_t i : q)
+    if (!(t->mem[i] > p->offensive_max_mem_mb || t->cpus[i] > p->offensive_max_cpus)) r.ranked.push_back(i);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// A.7/A.8 placement.  Restates Fenzo 0.10.0 TaskScheduler.scheduleOnce as Cook drives it (scheduler.clj:617-687,
+// 2301-2324) with BinPackingFitnessCalculators.cpuMemBinPacker (config.clj:108).  Fenzo's source is not in the
+// reference tree: this is its published algorithm as recalled in SURVEY.md Appendix A.7, anchored on Cook's
+// call sites and on the known answers in tests/golden/match_*.json.
+// UNPINNED (defined here): VMs are visited in offer-array order in ONE bucket; best = first strictly greatest
+// fitness; early exit at the first VM whose fitness > good-enough.
+struct MatchState {
+  std::vector<double> ac, am;              // resources assigned this call per offer
+  std::vector<int32_t> acount;             // tasks assigned this call per offer
+  std::vector<std::vector<uint32_t>> ghost, gattr;  // per group: hosts / attr values of same-cycle cotasks
+};
+
+inline uint32_t offer_attr(const cook_offers* o, uint32_t v, uint32_t key) {
+  if (key == COOK_NONE_U32) return o->host[v] + 1;  // "HOSTNAME"
+  if (key >= o->n_attr_keys || !o->attr) return 0;
+  return o->attr[(size_t)v * o->n_attr_keys + key];
+}
+
+// constraints.clj: job constraints in make-fenzo-job-constraints order do not matter for pass/fail.
+bool job_constraints_pass(const cook_params* p, const cook_jobs* j, uint32_t k, const cook_offers* o, uint32_t v,
+                          const MatchState& st, const std::set<uint32_t>& reserved) {
+  const uint32_t host = o->host[v];
+  // novel-host (constraints.clj:68-94)
+  if (j->novel_off)
+    for (uint32_t x = j->novel_off[k]; x < j->novel_off[k + 1]; ++x)
+      if (j->novel_host[x] == host) return false;
+  // gpu-host (constraints.clj:122-157)
+  const double jg = j->gpus ? j->gpus[k] : 0.0;
+  const bool k8s = o->k8s && o->k8s[v];
+  if (k8s) {
+    const uint32_t om = o->gpu_model ? o->gpu_model[v] : 0;
+    if (jg > 0) {
+      const uint32_t jm = j->gpu_model ? j->gpu_model[k] : 0;
+      const double avail = (om != 0 && om == jm) ? o->gpu_count[v] : 0.0;
+      const int32_t on_vm = (o->run_count ? o->run_count[v] : 0) + st.acount[v];
+      if (!(avail == jg && on_vm == 0)) return false;
+    } else if (om != 0) {
+      return false;
+    }
+  } else if (!(jg == 0)) {
+    return false;
+  }
+  // disk-host (constraints.clj:164-199): only when the pool enables it (disk_request >= 0)
+  if (j->disk_request && j->disk_request[k] >= 0 && k8s) {
+    const double space = (o->disk_type && o->disk_type[v] == j->disk_type[k]) ? o->disk_space[v] : 0.0;
+    if (!(space >= j->disk_request[k])) return false;
+  }
+  // user-defined EQUALS (constraints.clj:356-377)
+  if (j->eq_off)
+    for (uint32_t x = j->eq_off[k]; x < j->eq_off[k + 1]; ++x)
+      if (offer_attr(o, v, j->eq_key[x]) != j->eq_val[x]) return false;
+  // estimated-completion (constraints.clj:385-401)
+  if (j->est_end_ms && j->est_end_ms[k] != 0 && o->host_start_s && o->host_start_s[v] >= 0) {
+    const int64_t death = 1000 * o->host_start_s[v] + 60 * 1000 * p->host_lifetime_mins;
+    if (!(j->est_end_ms[k] < death)) return false;
+  }
+  // checkpoint-locality (constraints.clj:218-240)
+  if (j->ckpt_location && j->ckpt_location[k] != 0) {
+    const uint32_t loc = o->location ? o->location[v] : 0;
+    if (loc != j->ckpt_location[k]) return false;
+  }
+  // max-tasks-per-host (constraints.clj:433-456)
+  if (o->max_tasks && o->max_tasks[v] >= 0) {
+    if (!((o->num_tasks ? o->num_tasks[v] : 0) + st.acount[v] < o->max_tasks[v])) return false;
+  }
+  // rebalancer-reservation (constraints.clj:242-252, scheduler.clj:645-653): hosts reserved for OTHER jobs
+  if (!reserved.empty() && reserved.count(host)) {
+    if (!(j->reserved_host && j->reserved_host[k] == (int32_t)host)) return false;
+  }
+  return true;
+}
+
+// constraints.clj:586-644 group constraints over cotasks = DB-running ++ assigned earlier in this call.
+bool group_constraint_pass(const cook_jobs* j, uint32_t k, const cook_offers* o, uint32_t v, const cook_groups* g,
+                           const MatchState& st) {
+  if (!g || !j->group || j->group[k] == COOK_NONE_U32) return true;
+  const uint32_t gi = j->group[k];
+  const uint8_t type = g->type[gi];
+  if (type == 0) return true;
+  const uint32_t r0 = g->run_off ? g->run_off[gi] : 0, r1 = g->run_off ? g->run_off[gi + 1] : 0;
+  if (type == 1) {  // unique (constraints.clj:586-598): hostname present and not used by a cotask
+    const uint32_t host = o->host[v];
+    for (uint32_t x = r0; x < r1; ++x)
+      if (g->run_host[x] == host) return false;
+    for (uint32_t h : st.ghost[gi])
+      if (h == host) return false;
+    return true;
+  }
+  const uint32_t key = g->attr_key[gi];
+  const uint32_t target = offer_attr(o, v, key);
+  std::map<uint32_t, int> freq;  // nil (0) is a legal key of `frequencies`
+  for (uint32_t x = r0; x < r1; ++x) freq[key == COOK_NONE_U32 ? g->run_host[x] + 1 : g->run_attr[x]]++;
+  for (uint32_t a : st.gattr[gi]) freq[a]++;
+  if (freq.empty()) return true;
+  if (type == 2) {  // balanced (constraints.clj:600-626)
+    int mn = std::numeric_limits<int>::max(), mx = 0;
+    for (auto& kv : freq) {
+      mn = std::min(mn, kv.second);
+      mx = std::max(mx, kv.second);
+    }
+    const int minim = (g->minimum[gi] > (int)freq.size()) ? 0 : mn;
+    auto it = freq.find(target);
+    if (it == freq.end()) return true;
+    return minim == mx || it->second < mx;
+  }
+  // attribute-equals (constraints.clj:628-644)
+  return freq.count(target) != 0;
+}
+
+void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, const cook_groups* g,
+                const uint32_t* reserved_hosts, uint32_t n_reserved, int32_t* job_to_offer, uint32_t* fail_code,
+                uint8_t* head_matched, int nthreads) {
+  const uint32_t K = j->n, M = o->n;
+  MatchState st;
+  st.ac.assign(M, 0.0);
+  st.am.assign(M, 0.0);
+  st.acount.assign(M, 0);
+  if (g) {
+    st.ghost.resize(g->n);
+    st.gattr.resize(g->n);
+  }
+  std::set<uint32_t> reserved(reserved_hosts, reserved_hosts + n_reserved);
+  const double ge = p->good_enough_fitness;
+  uint32_t matched = 0;
+  struct Best {
+    double fit;
+    int32_t v;
+    uint32_t fail;
+  };
+  auto eval_range = [&](uint32_t k, uint32_t v0, uint32_t v1, Best& b) {
+    const double c = j->cpus[k], m = j->mem[k];
+    b.fit = -1.0;
+    b.v = -1;
+    b.fail = 0;
+    for (uint32_t v = v0; v < v1; ++v) {
+      // ⚠ Fenzo AssignableVirtualMachine.tryRequest: resources (cpus, mem, named scalars) vs the lease totals
+      // minus what this call already assigned to the VM, then hard constraints, then fitness.
+      if (st.ac[v] + c > o->cpus[v] || st.am[v] + m > o->mem[v]) {
+        b.fail |= 1;
+        continue;
+      }
+      if (!job_constraints_pass(p, j, k, o, v, st, reserved) || !group_constraint_pass(j, k, o, v, g, st)) {
+        b.fail |= 2;
+        continue;
+      }
+      // ⚠ cpuMemBinPacker: (cpuFit + memFit)/2 with fit = (running + assigned-this-call + request) /
+      // (lease total + running) per resource.
+      const double rc = o->run_cpus ? o->run_cpus[v] : 0.0, rm = o->run_mem ? o->run_mem[v] : 0.0;
+      const double fit = ((rc + st.ac[v] + c) / (o->cpus[v] + rc) + (rm + st.am[v] + m) / (o->mem[v] + rm)) / 2.0;
+      if (!(fit > 0.0)) {  // ⚠ fitness 0.0 is a failure in Fenzo
+        b.fail |= 4;
+        continue;
+      }
+      if (fit > b.fit) {
+        b.fit = fit;
+        b.v = (int32_t)v;
+        if (fit > ge) break;  // scheduler.clj:2312-2314
+      }
+    }
+  };
+  std::vector<Best> parts(std::max(1, nthreads));
+  for (uint32_t k = 0; k < K; ++k) {
+    Best b;
+    if (nthreads <= 1 || ge < 1.0 || M < 4096) {
+      eval_range(k, 0, M, b);
+    } else {
+      // multi-thread CPU baseline: hosts bucketed across threads per job (mirrors Fenzo's evaluator pool);
+      // identical result to the single bucket when good-enough is disabled (argmax, lowest index on ties).
+      std::vector<std::thread> th;
+      const uint32_t chunk = (M + nthreads - 1) / nthreads;
+      for (int tix = 0; tix < nthreads; ++tix)
+        th.emplace_back([&, tix] {
+          eval_range(k, std::min(M, tix * chunk), std::min(M, (tix + 1) * chunk), parts[tix]);
+        });
+      for (auto& x : th) x.join();
+      b = parts[0];
+      for (int tix = 1; tix < nthreads; ++tix) {
+        b.fail |= parts[tix].fail;
+        if (parts[tix].v >= 0 && parts[tix].fit > b.fit) {
+          b.fit = parts[tix].fit;
+          b.v = parts[tix].v;
+        }
+      }
+    }
+    job_to_offer[k] = b.v;
+    if (fail_code) fail_code[k] = b.v >= 0 ? 0u : (b.fail ? b.fail : 8u);
+    if (b.v >= 0) {
+      ++matched;
+      st.ac[b.v] += j->cpus[k];
+      st.am[b.v] += j->mem[k];
+      st.acount[b.v] += 1;
+      if (g && j->group && j->group[k] != COOK_NONE_U32) {
+        const uint32_t gi = j->group[k];
+        st.ghost[gi].push_back(o->host[b.v]);
+        st.gattr[gi].push_back(g->type[gi] >= 2 ? offer_attr(o, b.v, g->attr_key[gi]) : 0);
+      }
+    }
+  }
+  // scheduler.clj:1495: matched-head-or-no-matches?
+  if (head_matched) *head_matched = (matched == 0 || (K > 0 && job_to_offer[0] >= 0)) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// A.9 rebalancer (rebalancer.clj).  State = per-user ordered running tasks + their DRUs.
+struct RTask {
+  FeatureKey key;
+  uint32_t user, host;
+  double cpus, mem, gpus, dru;
+  int64_t id;      // >=0: index into `running`; <0: synthetic task of pending job (-1 - pending index)
+  bool alive;
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* oracle_version(void) { return "cook-oracle 1 (CPU restatement; pinned to reference unit-test vectors)"; }
+
+// merge_mode: 0 = O(N log U) heap form, 1 = literal dru.clj:82-104 restatement.
+int oracle_rank(const cook_params* p, const cook_tasks* t, const cook_users* u, const cook_pool_quota* pq,
+                uint32_t* ranked_pending_idx, uint32_t* n_out, double* dru_of_task, int merge_mode) {
+  RankResult r;
+  rank_impl(p, t, u, pq, merge_mode == 1, r);
+  if (ranked_pending_idx) std::copy(r.ranked.begin(), r.ranked.end(), ranked_pending_idx);
+  if (n_out) *n_out = (uint32_t)r.ranked.size();
+  if (dru_of_task) std::copy(r.dru.begin(), r.dru.end(), dru_of_task);
+  return 0;
+}
+
+// Full merged order (running + pending) — used by tests that pin the DRU sequence itself (dru.clj tests).
+int oracle_rank_merged(const cook_params* p, const cook_tasks* t, const cook_users* u, uint32_t* merged_idx,
+                       double* merged_dru, uint32_t* n_out, int merge_mode) {
+  RankResult r;
+  rank_impl(p, t, u, nullptr, merge_mode == 1, r);
+  for (size_t i = 0; i < r.merged.size(); ++i) {
+    merged_idx[i] = r.merged[i].task;
+    merged_dru[i] = r.merged[i].dru;
+  }
+  *n_out = (uint32_t)r.merged.size();
+  return 0;
+}
+
+int oracle_pool_usage(const cook_tasks* t, cook_usage* out) {
+  *out = running_usage(t);
+  return 0;
+}
+
+// Bare sorted-merge over explicit per-coll key lists: coll c holds keys[off[c] .. off[c+1]).  out_coll[i] is
+// the coll the i-th emitted item came from.
+int oracle_sorted_merge(uint32_t n_colls, const uint32_t* off, const double* keys, int literal, uint32_t* out_coll) {
+  std::vector<std::vector<Scored>> colls(n_colls);
+  for (uint32_t c = 0; c < n_colls; ++c)
+    for (uint32_t i = off[c]; i < off[c + 1]; ++i) colls[c].push_back({c, keys[i]});
+  std::vector<Scored> out;
+  if (literal)
+    merge_literal(colls, out);
+  else
+    merge_heap(colls, out);
+  for (size_t i = 0; i < out.size(); ++i) out_coll[i] = out[i].task;
+  return 0;
+}
+
+int oracle_match(const cook_params* p, const cook_jobs* j, const cook_offers* o, const cook_groups* g,
+                 const uint32_t* reserved_hosts, uint32_t n_reserved, int32_t* job_to_offer, uint32_t* fail_code,
+                 uint8_t* head_matched, int nthreads) {
+  match_impl(p, j, o, g, reserved_hosts, n_reserved, job_to_offer, fail_code, head_matched, nthreads);
+  return 0;
+}
+
+// rebalancer.clj:222-266 init-state, :320-407 compute-preemption-decision, :270-309 next-state, :434-467 rebalance.
+// Constraints: this restatement covers resource-only pending jobs plus novel-host / gpu-host(non-k8s: gpus==0)
+// job constraints are NOT evaluated (hosts all pass); see DESIGN.md "rebalancer scope".
+// UNPINNED: order among scored tasks with equal (-dru, user) (priority-map value sets are hash sets): we use the
+// user's task order.
+int oracle_rebalance(const cook_params* p, const cook_tasks* running, const cook_jobs* pending,
+                     const int64_t* pending_job_id, const int32_t* pending_priority, const cook_users* u,
+                     const cook_host_spare* spare_in, const cook_rebalance_params* rp, cook_preemption* decisions,
+                     uint32_t* n_decisions, uint32_t* preempted, uint32_t* n_preempted) {
+  const uint32_t R = running->n, P = pending->n, U = u->n;
+  const bool gpu_mode = p->dru_mode == 1;
+  // user -> ordered tasks (sorted-set-by same-user-task-comparator, rebalancer.clj:241-246)
+  std::vector<std::vector<RTask>> ut(U);
+  for (uint32_t i = 0; i < R; ++i) {
+    RTask x;
+    x.key = feature_key(running, i);
+    x.user = running->user[i];
+    x.host = running->host[i];
+    x.cpus = running->cpus[i];
+    x.mem = running->mem[i];
+    x.gpus = gpus_of(running, i);
+    x.dru = 0;
+    x.id = i;
+    x.alive = true;
+    ut[x.user].push_back(x);
+  }
+  auto rescore = [&](uint32_t us) {  // dru.clj:50-80 over the user's ordered tasks
+    auto& v = ut[us];
+    double cs = 0, ms = 0, gs = 0;
+    bool first = true;
+    for (auto& x : v) {
+      if (gpu_mode) {
+        gs = first ? x.gpus : gs + x.gpus;
+        x.dru = gs / u->div_gpus[us];
+      } else {
+        cs = first ? x.cpus : cs + x.cpus;
+        ms = first ? x.mem : ms + x.mem;
+        x.dru = std::max(ms / u->div_mem[us], cs / u->div_cpus[us]);
+      }
+      first = false;
+    }
+  };
+  for (uint32_t us = 0; us < U; ++us) {
+    std::sort(ut[us].begin(), ut[us].end(), [](const RTask& a, const RTask& b) { return key_less(a.key, b.key); });
+    rescore(us);
+  }
+  std::map<uint32_t, cook_usage> spare;  // host -> spare {cpus,mem,gpus}; count unused
+  for (uint32_t i = 0; i < spare_in->n; ++i)
+    spare[spare_in->host[i]] = cook_usage{0, spare_in->cpus[i], spare_in->mem[i], spare_in->gpus ? spare_in->gpus[i] : 0.0};
+
+  uint32_t nd = 0, np = 0;
+  int32_t remaining = rp->max_preemption;
+  for (uint32_t pj = 0; pj < P && remaining > 0; ++pj) {
+    const uint32_t us = pending->user[pj];
+    const double jc = pending->cpus[pj], jm = pending->mem[pj], jg = pending->gpus ? pending->gpus[pj] : 0.0;
+    const bool job_has_gpus = pending->gpus && pending->gpus[pj] > 0;  // (:gpus resources) present
+    // rebalancer.clj:210-220 job-below-quota: usage of the user's running jobs + this job
+    cook_usage fu{1, jc, jm, jg};
+    for (auto& x : ut[us]) {
+      fu.count += 1;
+      fu.cpus += x.cpus;
+      fu.mem += x.mem;
+      fu.gpus += x.gpus;
+    }
+    const cook_usage q{u->quota_count[us], u->quota_cpus[us], u->quota_mem[us], u->quota_gpus[us]};
+    const bool below = below_quota(q, fu);
+    // rebalancer.clj:157-208 pending job dru: nearest task <= synthetic pending task in the user's order
+    FeatureKey pk;
+    pk.negprio = -(int64_t)pending_priority[pj];
+    pk.start = std::numeric_limits<int64_t>::max();
+    pk.task = std::numeric_limits<int64_t>::min();
+    pk.job = pending_job_id[pj];
+    double near = 0.0;
+    for (auto& x : ut[us]) {
+      if (key_less(pk, x.key)) break;  // x > pending
+      near = x.dru;
+    }
+    const double pdru = gpu_mode ? near + jg / u->div_gpus[us]
+                                 : std::max(near + jm / u->div_mem[us], near + jc / u->div_cpus[us]);
+    // rebalancer.clj:339-349 candidates in priority-map order (-dru, user) ascending, grouped by host
+    struct Cand {
+      double dru;
+      uint32_t user, order;
+      const RTask* t;
+    };
+    std::vector<Cand> cands;
+    for (uint32_t w = 0; w < U; ++w) {
+      uint32_t ord = 0;
+      for (auto& x : ut[w]) {
+        ++ord;
+        if (!(below || w == us)) continue;
+        if (x.dru < rp->safe_dru_threshold) continue;
+        if (!(x.dru - pdru > rp->min_dru_diff)) continue;
+        cands.push_back({x.dru, w, ord, &x});
+      }
+    }
+    std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) {
+      if (a.dru != b.dru) return a.dru > b.dru;
+      if (a.user != b.user) return a.user < b.user;
+      return a.order < b.order;
+    });
+    std::map<uint32_t, std::vector<const RTask*>> by_host;  // sorted by host id = hostname order (:383)
+    for (auto& kv : spare) by_host[kv.first];
+    for (auto& c : cands) by_host[c.t->host].push_back(c.t);
+    // rebalancer.clj:384-404 per-host prefix aggregates; keep those with enough resources; max-key :dru, ties->last
+    bool have = false;
+    double best_dru = 0.0;  // (fnil :dru {:dru 0.0}) nil: the nil seed has dru 0.0
+    uint32_t best_host = 0;
+    size_t best_len = 0;
+    cook_usage best_res{0, 0, 0, 0};
+    bool best_spare = false;
+    for (auto& kv : by_host) {
+      cook_usage agg{0, 0.0, 0.0, 0.0};
+      auto sp = spare.find(kv.first);
+      const bool has_spare = sp != spare.end();
+      auto consider = [&](double d, size_t len) {
+        const bool enough = agg.mem >= jm && agg.cpus >= jc && (job_has_gpus ? agg.gpus >= jg : true);
+        if (enough && d >= best_dru) {
+          have = true;
+          best_dru = d;
+          best_host = kv.first;
+          best_len = len;
+          best_res = agg;
+          best_spare = has_spare;
+        }
+      };
+      if (has_spare) {
+        agg.cpus += sp->second.cpus;
+        agg.mem += sp->second.mem;
+        agg.gpus += sp->second.gpus;
+        consider(DMAX, 0);
+      }
+      size_t len = 0;
+      for (const RTask* x : kv.second) {
+        agg.cpus += x->cpus;
+        agg.mem += x->mem;
+        agg.gpus += x->gpus;
+        consider(x->dru, ++len);
+      }
+    }
+    if (!have) continue;
+    (void)best_spare;
+    // decision + next-state (rebalancer.clj:270-309)
+    cook_preemption& d = decisions[nd++];
+    d.pending_index = pj;
+    d.host = best_host;
+    d.dru = best_dru;
+    d.cpus = best_res.cpus;
+    d.mem = best_res.mem;
+    d.gpus = best_res.gpus;
+    d.task_off = np;
+    d.task_n = 0;
+    std::set<uint32_t> changed;
+    changed.insert(us);
+    {
+      auto& lst = by_host[best_host];
+      std::set<const RTask*> gone(lst.begin(), lst.begin() + best_len);
+      for (const RTask* x : gone) {
+        changed.insert(x->user);
+      }
+      // record in decision order (conj onto vector in candidate order)
+      for (size_t i = 0; i < best_len; ++i) {
+        preempted[np++] = (uint32_t)(lst[i]->id >= 0 ? lst[i]->id : 0xFFFFFFFFu);  // synthetic tasks reported as NONE
+        d.task_n++;
+      }
+      for (uint32_t w : changed) {
+        auto& v = ut[w];
+        v.erase(std::remove_if(v.begin(), v.end(), [&](const RTask& x) { return gone.count(&x) != 0; }), v.end());
+      }
+    }
+    RTask nt;
+    nt.key = pk;
+    nt.user = us;
+    nt.host = best_host;
+    nt.cpus = jc;
+    nt.mem = jm;
+    nt.gpus = jg;
+    nt.dru = 0;
+    nt.id = -1 - (int64_t)pj;
+    nt.alive = true;
+    {
+      auto& v = ut[us];
+      auto it = std::upper_bound(v.begin(), v.end(), nt, [](const RTask& a, const RTask& b) { return key_less(a.key, b.key); });
+      v.insert(it, nt);
+    }
+    for (uint32_t w : changed) rescore(w);
+    spare[best_host] = cook_usage{0, best_res.cpus - jc, best_res.mem - jm, best_res.gpus - jg};
+    --remaining;
+  }
+  *n_decisions = nd;
+  *n_preempted = np;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+"""ctypes front-end of oracle/libcookoracle.so — the CPU restatement of the reference algorithm.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by
+cook_amd/.  Struct layouts come from cook_amd._abi (= include/cookmatch.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from cook_amd import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libcookoracle.so")
+    src = os.path.join(_HERE, "cook_oracle.cpp")
+    hdr = os.path.join(_HERE, "..", "include", "cookmatch.h")
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.oracle_version.restype = C.c_char_p
+    return _LIB
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _f64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def rank(params, tasks: A.Tasks, users: A.Users, quota=None, literal_merge=False):
+    """-> (ranked pending task indices, dru per task)."""
+    out = np.zeros(max(1, tasks.n), dtype=np.uint32)
+    dru = np.zeros(max(1, tasks.n), dtype=np.float64)
+    n = C.c_uint32(0)
+    ts, us = tasks.as_struct(), users.as_struct()
+    rc = lib().oracle_rank(C.byref(params), C.byref(ts), C.byref(us), C.byref(quota) if quota is not None else None,
+                           _u32p(out), C.byref(n), _f64p(dru), int(literal_merge))
+    assert rc == 0
+    return out[: n.value].copy(), dru[: tasks.n].copy()
+
+
+def rank_merged(params, tasks: A.Tasks, users: A.Users, literal_merge=False):
+    """-> (task indices, drus) of the full merged sequence (running and pending), dru.clj:114-126."""
+    idx = np.zeros(max(1, tasks.n), dtype=np.uint32)
+    dru = np.zeros(max(1, tasks.n), dtype=np.float64)
+    n = C.c_uint32(0)
+    ts, us = tasks.as_struct(), users.as_struct()
+    rc = lib().oracle_rank_merged(C.byref(params), C.byref(ts), C.byref(us), _u32p(idx), _f64p(dru), C.byref(n),
+                                  int(literal_merge))
+    assert rc == 0
+    return idx[: n.value].copy(), dru[: n.value].copy()
+
+
+def pool_usage(tasks: A.Tasks) -> A.CookUsage:
+    u = A.CookUsage()
+    ts = tasks.as_struct()
+    lib().oracle_pool_usage(C.byref(ts), C.byref(u))
+    return u
+
+
+def sorted_merge(colls, literal=False):
+    """colls: list of sorted key lists -> sequence of coll indices in emission order (dru.clj:82-104)."""
+    off = np.zeros(len(colls) + 1, dtype=np.uint32)
+    for i, c in enumerate(colls):
+        off[i + 1] = off[i] + len(c)
+    keys = np.array([k for c in colls for k in c] or [0.0], dtype=np.float64)
+    out = np.zeros(max(1, int(off[-1])), dtype=np.uint32)
+    lib().oracle_sorted_merge(len(colls), _u32p(off), _f64p(keys), int(literal), _u32p(out))
+    return out[: int(off[-1])].copy()
+
+
+def match(params, jobs: A.Jobs, offers: A.Offers, groups: A.Groups = None, reserved_hosts=(), nthreads=1):
+    """-> (job_to_offer int32[K], fail_code uint32[K], head_matched bool)  — scheduleOnce restatement."""
+    j2o = np.full(max(1, jobs.n), -1, dtype=np.int32)
+    fail = np.zeros(max(1, jobs.n), dtype=np.uint32)
+    head = C.c_uint8(0)
+    res = np.array(list(reserved_hosts) or [0], dtype=np.uint32)
+    js, os_ = jobs.as_struct(), offers.as_struct()
+    gs = groups.as_struct() if groups is not None else None
+    rc = lib().oracle_match(C.byref(params), C.byref(js), C.byref(os_), C.byref(gs) if gs is not None else None,
+                            _u32p(res), len(reserved_hosts), j2o.ctypes.data_as(C.POINTER(C.c_int32)), _u32p(fail),
+                            C.byref(head), int(nthreads))
+    assert rc == 0
+    return j2o[: jobs.n].copy(), fail[: jobs.n].copy(), bool(head.value)
+
+
+def rebalance(params, running: A.Tasks, pending: A.Jobs, pending_job_id, pending_priority, users: A.Users,
+              spare: A.HostSpare, rparams: A.CookRebalanceParams):
+    """-> list of decisions dicts (rebalancer.clj:434-467)."""
+    P = pending.n
+    dec = (A.CookPreemption * max(1, P))()
+    pre = np.zeros(max(1, running.n + P), dtype=np.uint32)
+    nd, npre = C.c_uint32(0), C.c_uint32(0)
+    jid = np.ascontiguousarray(pending_job_id, dtype=np.int64)
+    pri = np.ascontiguousarray(pending_priority, dtype=np.int32)
+    rs, ps, us, ss = running.as_struct(), pending.as_struct(), users.as_struct(), spare.as_struct()
+    rc = lib().oracle_rebalance(C.byref(params), C.byref(rs), C.byref(ps), jid.ctypes.data_as(C.POINTER(C.c_int64)),
+                                pri.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(us), C.byref(ss), C.byref(rparams),
+                                dec, C.byref(nd), _u32p(pre), C.byref(npre))
+    assert rc == 0
+    out = []
+    for i in range(nd.value):
+        d = dec[i]
+        out.append(dict(pending_index=d.pending_index, host=d.host, dru=d.dru, cpus=d.cpus, mem=d.mem, gpus=d.gpus,
+                        tasks=[int(x) for x in pre[d.task_off: d.task_off + d.task_n]]))
+    return out

@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Transcribes the known-answer vectors of the reference's OWN unit tests for the fair-share match path into
+tests/golden/*.json.  The reference is Clojure (no JVM in this image), so the vectors are transcribed by hand
+from the cited test forms — every case names the reference test file:line it restates (paths relative to
+/root/reference/scheduler/).  Run `python tests/golden/make_golden.py` to regenerate the JSON files.
+
+Conventions of the transcription
+  * entities are listed in creation order; :db/id and :instance/start-time grow with creation order
+    (testutil.clj:234-345: start-time defaults to (java.util.Date.) at creation), so `seq` doubles as both.
+  * users are referred to by NAME; the loader assigns user ids in ascending name order (cookmatch.h contract).
+  * "MAX" stands for Double/MAX_VALUE (share.clj:95 default share, quota defaults).
+"""
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+T_DRU = "test/cook/test/scheduler/dru.clj"
+T_SCHED = "test/cook/test/scheduler/scheduler.clj"
+T_REB = "test/cook/test/rebalancer.clj"
+
+
+def job(name, user, cpus, mem, gpus=0.0, priority=50, running=False, **kw):
+    d = dict(name=name, user=user, cpus=cpus, mem=mem, gpus=gpus, priority=priority, running=running)
+    d.update(kw)
+    return d
+
+
+RANK = [
+    dict(
+        name="compute-task-scored-task-pairs", ref=f"{T_DRU}:30-59", dru_mode=0,
+        jobs=[job("t1", "ljin", 10.0, 10.0, running=True), job("t2", "ljin", 5.0, 5.0, running=True),
+              job("t3", "ljin", 25.0, 15.0, running=True), job("t4", "ljin", 15.0, 25.0, running=True)],
+        shares={"ljin": dict(cpus=25.0, mem=25.0)},
+        expect_merged_names=["t1", "t2", "t3", "t4"], expect_merged_drus=[0.4, 0.6, 1.6, 2.2],
+    ),
+    dict(
+        name="sorted-task-scored-task-pairs", ref=f"{T_DRU}:85-123", dru_mode=0,
+        jobs=[job("l1", "ljin", 10.0, 10.0, running=True), job("l2", "ljin", 5.0, 5.0, running=True),
+              job("l3", "ljin", 25.0, 15.0, running=True), job("l4", "ljin", 15.0, 25.0, running=True),
+              job("w1", "wzhao", 10.0, 10.0, running=True), job("s1", "sunil", 10.0, 10.0, running=True)],
+        shares={u: dict(cpus=10.0, mem=10.0) for u in ("ljin", "wzhao", "sunil")},
+        expect_merged_drus=[1.0, 1.0, 1.0, 1.5, 4.0, 5.5],
+    ),
+    dict(
+        name="sorted-task-scored-task-pairs-with-running", ref=f"{T_DRU}:129-162", dru_mode=0,
+        # job1..job5 created in order; instances created for job4 then job2 (so job4's task sorts first)
+        jobs=[job("job1", "ljin", 10.0, 10.0), job("job2", "ljin", 20.0, 20.0, running=True, inst_seq=2),
+              job("job3", "ljin", 40.0, 40.0), job("job4", "ljin", 80.0, 80.0, running=True, inst_seq=1),
+              job("job5", "ljin", 160.0, 160.0)],
+        shares={"ljin": dict(cpus=10.0, mem=10.0)},
+        expect_merged_names=["job4", "job2", "job1", "job3", "job5"],
+        expect_merged_drus=[8.0, 10.0, 11.0, 15.0, 31.0],
+    ),
+    dict(
+        name="compute-sorted-task-cumulative-gpu-score-pairs", ref=f"{T_DRU}:165-188", dru_mode=1,
+        jobs=[job("t1", "ljin", 1.0, 10.0, gpus=10.0, running=True), job("t2", "ljin", 1.0, 10.0, gpus=5.0, running=True),
+              job("t3", "ljin", 1.0, 10.0, gpus=25.0, running=True), job("t4", "ljin", 1.0, 10.0, gpus=15.0, running=True)],
+        shares={"ljin": dict(cpus="MAX", mem="MAX", gpus=10.0)},
+        expect_merged_names=["t1", "t2", "t3", "t4"], expect_merged_drus=[1.0, 1.5, 4.0, 5.5],
+    ),
+    dict(
+        name="sorted-task-cumulative-gpu-score-pairs", ref=f"{T_DRU}:190-218", dru_mode=1,
+        jobs=[job("l1", "ljin", 1.0, 10.0, gpus=10.0, running=True), job("l2", "ljin", 1.0, 10.0, gpus=5.0, running=True),
+              job("l3", "ljin", 1.0, 10.0, gpus=25.0, running=True), job("l4", "ljin", 1.0, 10.0, gpus=15.0, running=True),
+              job("w1", "wzhao", 1.0, 10.0, gpus=10.0, running=True), job("s1", "sunil", 1.0, 10.0, gpus=10.0, running=True)],
+        shares={"ljin": dict(cpus="MAX", mem="MAX", gpus=5.0), "wzhao": dict(cpus="MAX", mem="MAX", gpus=10.0),
+                "sunil": dict(cpus="MAX", mem="MAX", gpus=2.5)},
+        expect_merged_users=["wzhao", "ljin", "ljin", "sunil", "ljin", "ljin"],
+        expect_merged_drus=[1.0, 2.0, 3.0, 4.0, 8.0, 11.0],
+    ),
+    dict(
+        name="sort-jobs-by-dru default share", ref=f"{T_SCHED}:232-253", dru_mode=0,
+        jobs=[job("j1", "ljin", 1.0, 3.0, running=True, inst_seq=1), job("j2", "ljin", 1.0, 5.0),
+              job("j3", "ljin", 1.0, 2.0), job("j4", "ljin", 5.0, 5.0),
+              job("j5", "wzhao", 6.0, 6.0, running=True, inst_seq=2), job("j6", "wzhao", 5.0, 5.0),
+              job("j7", "sunil", 5.0, 10.0, running=True, inst_seq=3), job("j8", "sunil", 5.0, 10.0)],
+        shares={u: dict(cpus=10.0, mem=10.0) for u in ("ljin", "wzhao", "sunil")},
+        expect_ranked=["j2", "j3", "j6", "j4", "j8"],
+    ),
+    dict(
+        name="sort-jobs-by-dru one user has non-default share", ref=f"{T_SCHED}:255-260", dru_mode=0,
+        jobs=[job("j1", "ljin", 1.0, 3.0, running=True, inst_seq=1), job("j2", "ljin", 1.0, 5.0),
+              job("j3", "ljin", 1.0, 2.0), job("j4", "ljin", 5.0, 5.0),
+              job("j5", "wzhao", 6.0, 6.0, running=True, inst_seq=2), job("j6", "wzhao", 5.0, 5.0),
+              job("j7", "sunil", 5.0, 10.0, running=True, inst_seq=3), job("j8", "sunil", 5.0, 10.0)],
+        shares={"ljin": dict(cpus=10.0, mem=10.0), "wzhao": dict(cpus=10.0, mem=10.0),
+                "sunil": dict(cpus=100.0, mem=100.0)},
+        expect_ranked=["j8", "j2", "j3", "j6", "j4"],
+    ),
+    dict(
+        name="sort-jobs-by-dru normal jobs, Double.MAX_VALUE divisors, priority", ref=f"{T_SCHED}:262-271", dru_mode=0,
+        jobs=[job("j1n", "u1", 1.0, 1000.0), job("j2n", "u1", 1.0, 1000.0, priority=90),
+              job("j3n", "u2", 1.0, 1500.0), job("j4n", "u2", 1.0, 1500.0, priority=30)],
+        shares={"u1": dict(cpus="MAX", mem="MAX"), "u2": dict(cpus="MAX", mem="MAX")},
+        expect_ranked=["j2n", "j3n", "j1n", "j4n"],
+    ),
+    dict(
+        name="sort-jobs-by-dru gpu jobs", ref=f"{T_SCHED}:273-283", dru_mode=1,
+        jobs=[job("j1g", "u1", 1.0, 1000.0, gpus=10.0), job("j2g", "u1", 1.0, 1000.0, gpus=25.0, priority=90),
+              job("j3g", "u2", 1.0, 1500.0, gpus=20.0), job("j4g", "u2", 1.0, 1500.0, gpus=10.0, priority=30)],
+        shares={"u1": dict(cpus="MAX", mem="MAX", gpus="MAX"), "u2": dict(cpus="MAX", mem="MAX", gpus="MAX")},
+        expect_ranked=["j3g", "j2g", "j4g", "j1g"],
+    ),
+    dict(
+        name="sort-jobs-by-dru limit-quota (count quota 1, max-over-quota-jobs 3)", ref=f"{T_SCHED}:300-316",
+        dru_mode=0, max_over_quota_jobs=3,
+        jobs=[job("rj", "test", 1.0, 10.0, running=True, inst_seq=1)] + [job(f"wj{i}", "test", 1.0, 10.0) for i in range(1, 6)],
+        shares={"test": dict(cpus="MAX", mem="MAX")},
+        quotas={"test": dict(count=1)},
+        expect_ranked=["wj1", "wj2", "wj3"],
+    ),
+    dict(
+        name="limit-over-quota-jobs 25 jobs, count 5, limit 10 -> 15", ref=f"{T_SCHED}:2353-2368",
+        dru_mode=0, max_over_quota_jobs=10,
+        jobs=[job(f"j{i}", "u", 1.0, 10.0) for i in range(25)],
+        shares={"u": dict(cpus="MAX", mem="MAX")}, quotas={"u": dict(count=5)},
+        expect_ranked=[f"j{i}" for i in range(15)],
+    ),
+    dict(
+        name="limit-over-quota-jobs no quota -> 25", ref=f"{T_SCHED}:2353-2364",
+        dru_mode=0, max_over_quota_jobs=10,
+        jobs=[job(f"j{i}", "u", 1.0, 10.0) for i in range(25)],
+        shares={"u": dict(cpus="MAX", mem="MAX")}, quotas={"u": dict(count="MAX")},
+        expect_ranked=[f"j{i}" for i in range(25)],
+    ),
+    dict(
+        name="gpu share prioritization: ljin double gpu share", ref=f"{T_SCHED}:1172-1193", dru_mode=1,
+        jobs=[job("ljin-1", "ljin", 5.0, 5.0, gpus=1.0, running=True, inst_seq=1)] +
+             [job(f"ljin-{i}", "ljin", 5.0, 5.0, gpus=1.0) for i in (2, 3, 4)] +
+             [job("wzhao-1", "wzhao", 5.0, 5.0, gpus=1.0), job("wzhao-2", "wzhao", 5.0, 5.0, gpus=1.0)],
+        shares={"ljin": dict(cpus=1.0, mem=2.0, gpus=2.0), "wzhao": dict(cpus=1.0, mem=2.0, gpus=1.0)},
+        expect_ranked=["ljin-2", "wzhao-1", "ljin-3", "ljin-4", "wzhao-2"],
+    ),
+    dict(
+        name="gpu share prioritization: single gpu share (pins the sorted-merge tie rule)", ref=f"{T_SCHED}:1194-1200",
+        dru_mode=1,
+        jobs=[job("ljin-1", "ljin", 5.0, 5.0, gpus=1.0, running=True, inst_seq=1)] +
+             [job(f"ljin-{i}", "ljin", 5.0, 5.0, gpus=1.0) for i in (2, 3, 4)] +
+             [job("wzhao-1", "wzhao", 5.0, 5.0, gpus=1.0), job("wzhao-2", "wzhao", 5.0, 5.0, gpus=1.0)],
+        shares={"ljin": dict(cpus=1.0, mem=2.0, gpus=1.0), "wzhao": dict(cpus=1.0, mem=2.0, gpus=1.0)},
+        expect_ranked=["wzhao-1", "wzhao-2", "ljin-2", "ljin-3", "ljin-4"],
+    ),
+]
+
+# test-rank-obeys-group-global-quota (scheduler.clj:318-402): pools a and b share quota group "s".
+_POOL_A = [job("j1", "ljin", 1.0, 30.0, running=True, inst_seq=1), job("j2", "ljin", 1.0, 50.0),
+           job("j3", "ljin", 1.0, 20.0), job("j4", "ljin", 5.0, 5.0)]
+_POOL_B = [job("j5", "ljin", 6.0, 6.0, running=True, inst_seq=2), job("j6", "ljin", 5.0, 5.0),
+           job("j7", "ljin", 5.0, 10.0, running=True, inst_seq=3), job("j8", "ljin", 5.0, 10.0)]
+_BIG = dict(count=10, mem=10000, cpus=10000, gpus=1000)
+
+
+def _group_case(title, qa, qb, qs, ea, eb, line):
+    return dict(name=f"rank-obeys-group-global-quota: {title}", ref=f"{T_SCHED}:{line}",
+                pools={"a": dict(jobs=_POOL_A, quota=qa, expect_ranked=ea),
+                       "b": dict(jobs=_POOL_B, quota=qb, expect_ranked=eb)},
+                group_quota=qs, shares={"ljin": dict(cpus="MAX", mem="MAX")})
+
+
+RANK_GROUP = [
+    _group_case("no limits hit", _BIG, _BIG, _BIG, ["j2", "j3", "j4"], ["j6", "j8"], "336-343"),
+    _group_case("group count 4", _BIG, _BIG, dict(_BIG, count=4), ["j2"], ["j6"], "344-353"),
+    _group_case("per-pool mem/cpus", dict(_BIG, mem=80, cpus=2), dict(_BIG, mem=21, cpus=16), _BIG, ["j2"], ["j6"], "354-361"),
+    _group_case("group mem 96.1 cpus 17.1", _BIG, _BIG, dict(_BIG, mem=96.1, cpus=17.1), ["j2"], ["j6"], "363-372"),
+    _group_case("pool a count 4", dict(_BIG, count=4), _BIG, _BIG, ["j2", "j3", "j4"], ["j6", "j8"], "374-381"),
+    _group_case("pool b count 3", _BIG, dict(_BIG, count=3), _BIG, ["j2", "j3", "j4"], ["j6"], "382-389"),
+    _group_case("both pools", dict(_BIG, count=4), dict(_BIG, count=3), _BIG, ["j2", "j3", "j4"], ["j6"], "390-397"),
+]
+
+QUOTA_GROUP_AGG = dict(
+    ref=f"{T_SCHED}:222-230", groups={"a": "s", "b": "s"},
+    usage={"a": dict(mem=1, cpus=10, count=100), "b": dict(mem=2, cpus=20, count=200),
+           "c": dict(mem=4, cpus=40, count=400), "d": dict(mem=8, cpus=80, count=800)},
+    expect={"s": dict(count=300, cpus=30, mem=3)},
+)
+
+
+def offer(cpus, mem, **kw):
+    d = dict(cpus=cpus, mem=mem)
+    d.update(kw)
+    return d
+
+
+# Placement (Fenzo scheduleOnce through Cook).  `expect_matched`: set of matched job names; `expect_offers_used`:
+# number of distinct offers with >=1 task; `expect_assignment` only where feasibility forces the mapping.
+_J4 = [job(f"j{i}", "u", 1.0, 1000.0) for i in range(1, 5)]
+_HRO_JOBS = [job("job-1", "u", 3, 2048), job("job-2", "u", 13, 1024), job("job-3", "u", 7, 4096),
+             job("job-4", "u", 11, 1024), job("job-5", "u", 5, 2048, gpus=2, gpu_model="nvidia-tesla-p100"),
+             job("job-6", "u", 19, 1024, gpus=4, gpu_model="nvidia-tesla-p100")]
+_HRO_OFFERS = [offer(10, 2048), offer(20, 16384), offer(30, 8192)]
+MATCH = [
+    dict(name="match-offer-to-schedule: consume nothing (no jobs)", ref=f"{T_SCHED}:560-563", good_enough=1.0,
+         jobs=[], offers=[offer(2, 2000)], expect_matched=[]),
+] + [
+    dict(name=f"match-offer-to-schedule: consume nothing offer({c},{m})", ref=f"{T_SCHED}:560-567", good_enough=1.0,
+         jobs=_J4, offers=[offer(c, m)], expect_matched=[])
+    for c, m in ((0, 0), (0.5, 100), (0.5, 1000), (1, 500))
+] + [
+    dict(name=f"match-offer-to-schedule: partial offer({c},{m})", ref=f"{T_SCHED}:569-575", good_enough=1.0,
+         jobs=_J4, offers=[offer(c, m)], expect_n_matched=1, expect_matched=["j1"])
+    for c, m in ((1, 1000), (1.5, 1500))
+] + [
+    dict(name=f"match-offer-to-schedule: full offer({c},{m})", ref=f"{T_SCHED}:577-584", good_enough=1.0,
+         jobs=_J4, offers=[offer(c, m)], expect_matched=["j1", "j2", "j3", "j4"])
+    for c, m in ((4, 4000), (5, 5000))
+] + [
+    dict(name=f"checkpoint locality offer={ol} ckpt={ck} job-loc={jl}", ref=f"{T_SCHED}:586-658", good_enough=1.0,
+         jobs=[job("j", "u", 1.0, 1000.0, ckpt_location=(jl if ck else None))],
+         offers=[offer(1.0, 1000.0, location=ol)], expect_matched=(["j"] if ok else []))
+    for ol, ck, jl, ok in (("a", True, "a", True), ("a", False, "a", True), ("b", True, "a", False),
+                           ("b", False, "a", True), ("a", True, "b", False), ("b", True, "b", True))
+] + [
+    dict(name="match ordering: rank order respected on a 1-cpu host", ref=f"{T_SCHED}:660-706", good_enough=0.8,
+         jobs=[job("high-priority", "u", 1.0, 1000.0)] + [job(f"low-{i}", "u", 1.0, 1000.0) for i in range(8)],
+         offers=[offer(1.0, 200000.0)], expect_matched=["high-priority"], expect_assignment={"high-priority": 0}),
+    dict(name="handle-resource-offers: enough offers for all normal jobs (K=6)", ref=f"{T_SCHED}:1957-1964",
+         good_enough=0.8, jobs=_HRO_JOBS, offers=_HRO_OFFERS,
+         expect_matched=["job-1", "job-2", "job-3", "job-4"], expect_offers_used=3, expect_head_matched=True,
+         # hand-evaluated in SURVEY.md §8(c): cpuMemBinPacker + strict max
+         expect_assignment={"job-1": 0, "job-2": 1, "job-3": 1, "job-4": 2}),
+    dict(name="handle-resource-offers: K=1", ref=f"{T_SCHED}:1966-1973", good_enough=0.8,
+         jobs=_HRO_JOBS[:1], offers=_HRO_OFFERS, expect_matched=["job-1"], expect_offers_used=1),
+    dict(name="handle-resource-offers: K=2", ref=f"{T_SCHED}:1975-1982", good_enough=0.8,
+         jobs=_HRO_JOBS[:2], offers=_HRO_OFFERS, expect_matched=["job-1", "job-2"], expect_offers_used=2),
+]
+
+# constraints truth tables (test/cook/test/scheduler/constraints.clj)
+T_CON = "test/cook/test/scheduler/constraints.clj"
+
+
+def main():
+    out = dict(rank=RANK, rank_group=RANK_GROUP, quota_group_agg=QUOTA_GROUP_AGG, match=MATCH)
+    for k, v in out.items():
+        with open(os.path.join(HERE, f"{k}.json"), "w") as f:
+            json.dump(v, f, indent=1, sort_keys=True)
+    print("wrote", ", ".join(f"{k}.json" for k in out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+"""Pins the CPU oracle (oracle/cook_oracle.cpp) to the known answers of the reference's own unit tests
+(tests/golden/*.json, transcribed by tests/golden/make_golden.py with reference file:line per case)."""
+import numpy as np
+import pytest
+
+from cook_amd import _abi as A
+from tests import golden_util as G
+
+RANK = G.load("rank")
+RANK_GROUP = G.load("rank_group")
+MATCH = G.load("match")
+
+
+def _params(case, **kw):
+    return A.default_params(dru_mode=case.get("dru_mode", 0),
+                            max_over_quota_jobs=case.get("max_over_quota_jobs", 100), **kw)
+
+
+@pytest.mark.parametrize("literal", [False, True], ids=["heap-merge", "literal-merge"])
+@pytest.mark.parametrize("case", RANK, ids=[c["name"] for c in RANK])
+def test_rank_golden(oracle, case, literal):
+    tasks, users, names, unames = G.build_rank_inputs(case["jobs"], case["shares"], case.get("quotas"))
+    p = _params(case)
+    if "expect_ranked" in case:
+        ranked, _ = oracle.rank(p, tasks, users, literal_merge=literal)
+        assert [names[i] for i in ranked] == case["expect_ranked"], case["ref"]
+    idx, drus = oracle.rank_merged(p, tasks, users, literal_merge=literal)
+    if "expect_merged_drus" in case:
+        assert list(drus) == case["expect_merged_drus"], case["ref"]  # exact equality on doubles, as the reference
+    if "expect_merged_names" in case:
+        assert [names[i] for i in idx] == case["expect_merged_names"], case["ref"]
+    if "expect_merged_users" in case:
+        assert [unames[tasks.user[i]] for i in idx] == case["expect_merged_users"], case["ref"]
+
+
+@pytest.mark.parametrize("case", RANK_GROUP, ids=[c["name"] for c in RANK_GROUP])
+def test_rank_quota_group_golden(oracle, case):
+    # aggregate-quota-groups (scheduler.clj:2125-2132): group usage = sum of the member pools' running usage.
+    usages = {}
+    built = {}
+    for pool, spec in case["pools"].items():
+        tasks, users, names, _ = G.build_rank_inputs(spec["jobs"], case["shares"])
+        built[pool] = (tasks, users, names)
+        usages[pool] = oracle.pool_usage(tasks)
+    gu = A.usage(*[sum(getattr(u, f) for u in usages.values()) for f in ("count", "cpus", "mem", "gpus")])
+    for pool, spec in case["pools"].items():
+        tasks, users, names = built[pool]
+        q = A.pool_quota(pool_quota=G.usage_of(spec["quota"]), group_quota=G.usage_of(case["group_quota"]), group_usage=gu)
+        ranked, _ = oracle.rank(A.default_params(), tasks, users, quota=q)
+        assert [names[i] for i in ranked] == spec["expect_ranked"], (case["ref"], pool)
+
+
+def test_quota_group_aggregate_golden():
+    c = G.load("quota_group_agg")
+    agg = {}
+    for pool, u in c["usage"].items():
+        g = c["groups"].get(pool)
+        if g is None:
+            continue
+        for k, v in u.items():
+            agg.setdefault(g, {}).setdefault(k, 0)
+            agg[g][k] += v
+    assert agg == c["expect"], c["ref"]
+
+
+@pytest.mark.parametrize("case", MATCH, ids=[c["name"] for c in MATCH])
+def test_match_golden(oracle, case):
+    J, O, names = G.build_match_inputs(case)
+    p = A.default_params(good_enough_fitness=case["good_enough"])
+    j2o, fail, head = oracle.match(p, J, O)
+    matched = [names[k] for k in range(J.n) if j2o[k] >= 0]
+    if "expect_n_matched" in case:
+        assert len(matched) == case["expect_n_matched"], case["ref"]
+    assert sorted(matched) == sorted(case["expect_matched"]), case["ref"]
+    if "expect_offers_used" in case:
+        assert len({int(v) for v in j2o if v >= 0}) == case["expect_offers_used"], case["ref"]
+    if "expect_assignment" in case:
+        assert {names[k]: int(j2o[k]) for k in range(J.n) if j2o[k] >= 0} == case["expect_assignment"], case["ref"]
+    if "expect_head_matched" in case:
+        assert head == case["expect_head_matched"]
+    # multi-thread CPU baseline variant gives the same placement when good-enough is disabled
+    if case["good_enough"] >= 1.0 and J.n:
+        j2o8, _, _ = oracle.match(p, J, O, nthreads=4)
+        assert np.array_equal(j2o, j2o8)
