@@ -1,0 +1,943 @@
+// engine.hip — libcookmatch.so: C ABI (include/cookmatch.h) + host orchestration of the HIP kernels.
+// One engine = one pool = one HIP stream.  Built by hipcc for gfx950 only (cook_amd/build.py).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cookmatch.h"
+#include "common.hpp"
+#include "match_kernels.hpp"
+#include "rank_kernels.hpp"
+#include "scan.hpp"
+#include "sort.hpp"
+
+#ifndef HIP_KERNEL_NAME
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+#endif
+
+namespace {
+
+// ---- grow-only device buffers ------------------------------------------------------------------------------
+struct DBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    COOK_HIP(hipMalloc(&p, want));
+    cap = want;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+template <class T>
+struct DArr {
+  DBuf b;
+  T* ptr() { return (T*)b.p; }
+  const T* ptr() const { return (const T*)b.p; }
+  T* ensure(size_t n) {
+    b.ensure((n ? n : 1) * sizeof(T));
+    return ptr();
+  }
+  void release() { b.release(); }
+};
+
+template <class T>
+struct ScanTmp {
+  DArr<SegAgg<T>> agg, carry;
+  DArr<unsigned> first_head;
+};
+
+struct KernelStat {
+  double ms = 0;
+  unsigned launches = 0;
+};
+
+}  // namespace
+
+struct cook_engine {
+  cook_params params;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  struct Pending {
+    const char* name;
+    hipEvent_t a, b;
+  };
+  std::vector<Pending> ev_pending;
+  std::map<std::string, KernelStat> kstats;
+  std::vector<std::string> kstat_names;  // stable storage for cook_kernel_timings
+  hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr};
+  double rank_ms = 0, match_ms = 0;
+  // pinned readback scratch
+  unsigned long long* h_scratch = nullptr;  // 64 words
+  DArr<unsigned long long> d_scratch64;
+  DArr<unsigned> d_counters;
+
+  // ---- rank state ----
+  bool rank_staged = false, rank_done = false;
+  unsigned N = 0, U = 0, n_pending = 0;
+  bool has_gpus = false;
+  cook_pool_quota quota{};
+  DArr<double> t_cpus, t_mem, t_gpus, u_divc, u_divm, u_divg, u_qcount, u_qcpus, u_qmem, u_qgpus;
+  DArr<uint32_t> t_user, permA, permB2, s_user, seg_start, seg_end, inexact_user, rank_of_item, gstart, tpos, titem, tsorted,
+      tsorted2, qitemA, qitemB, ranked, pend_ord, hist;
+  DArr<int32_t> t_prio;
+  DArr<int64_t> t_start, t_task, t_job;
+  DArr<uint8_t> t_pending, s_pending, head, keep, thead;
+  DArr<uint64_t> w0, w1, w2, dkey, nkkey, ckey;
+  DArr<SumU4> s_use, pre, quseA, quseB, qpre, pool_usage;
+  DArr<SumI> scanI;
+  DArr<int> iflag, ones_buf, tied_buf;
+  DArr<double> dru, dru_out;
+  ScanTmp<SumU4> tmpU4;
+  ScanTmp<SumI> tmpI;
+  uint32_t* permB = nullptr;  // final per-user order (points into permA or permB2)
+  uint32_t* permC = nullptr;  // final global order
+  DArr<uint32_t> permC1, permC2;
+  unsigned n_ranked = 0;
+
+  // ---- match state ----
+  bool match_staged = false, match_done = false;
+  unsigned K = 0, M = 0, G = 0, Kjobs = 0;
+  DArr<double> j_cpus, j_mem, j_gpus, j_disk_req, o_cpus, o_mem, o_gpu_count, o_disk_space, o_run_cpus, o_run_mem, m_ac, m_am;
+  DArr<uint32_t> j_gpu_model, j_group, j_eq_off, j_eq_key, j_eq_val, j_novel_off, j_novel_host, j_ckpt, j_disk_type, j_index,
+      o_host, o_gpu_model, o_disk_type, o_attr, o_location, g_attr_key, g_run_off, g_run_host, g_run_attr, reserved_bits,
+      m_fail;
+  DArr<int32_t> j_reserved_host, o_max_tasks, o_num_tasks, o_run_count, g_min, m_acount, m_group_last, m_job_prev, m_j2o;
+  DArr<int64_t> j_est_end, o_host_start;
+  DArr<uint8_t> o_k8s, g_type;
+  DArr<unsigned> m_summary;
+  MatchIn min{};
+  bool cycle_staged = false;
+  unsigned cycle_considered = 0;
+
+  void fail(int code, const std::string& m) { throw cook_error(code, m); }
+};
+
+namespace {
+
+// ---- launch wrapper with optional per-kernel HIP-event timing ------------------------------------------------
+hipEvent_t take_event(cook_engine* e) {
+  if (e->ev_used == e->ev_pool.size()) {
+    hipEvent_t ev;
+    COOK_HIP(hipEventCreate(&ev));
+    e->ev_pool.push_back(ev);
+  }
+  return e->ev_pool[e->ev_used++];
+}
+struct ProfScope {
+  cook_engine* e;
+  hipEvent_t a = nullptr, b = nullptr;
+  const char* name;
+  ProfScope(cook_engine* e_, const char* n) : e(e_), name(n) {
+    if (e->profiling) {
+      a = take_event(e);
+      b = take_event(e);
+      (void)hipEventRecord(a, e->stream);
+    }
+  }
+  ~ProfScope() {
+    if (e->profiling) {
+      (void)hipEventRecord(b, e->stream);
+      e->ev_pending.push_back({name, a, b});
+    }
+  }
+};
+void prof_collect(cook_engine* e) {
+  if (!e->profiling) return;
+  for (auto& p : e->ev_pending) {
+    float ms = 0;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      auto& s = e->kstats[p.name];
+      s.ms += ms;
+      s.launches += 1;
+    }
+  }
+  e->ev_pending.clear();
+  e->ev_used = 0;
+}
+
+#define KL(name, kern, grid, block, ...)                                      \
+  do {                                                                        \
+    ProfScope _ps(e, name);                                                   \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, e->stream, __VA_ARGS__); \
+  } while (0)
+
+template <class T>
+void h2d(cook_engine* e, DArr<T>& d, const T* h, size_t n) {
+  d.ensure(n);
+  if (n) COOK_HIP(hipMemcpyAsync(d.ptr(), h, n * sizeof(T), hipMemcpyHostToDevice, e->stream));
+}
+template <class T>
+const T* h2d_opt(cook_engine* e, DArr<T>& d, const T* h, size_t n) {
+  if (!h) return nullptr;
+  h2d(e, d, h, n);
+  return d.ptr();
+}
+
+void sync(cook_engine* e) { COOK_HIP(hipStreamSynchronize(e->stream)); }
+
+// read back `words` 64-bit words from d_scratch64 (synchronises the stream)
+void readback64(cook_engine* e, unsigned words) {
+  COOK_HIP(hipMemcpyAsync(e->h_scratch, e->d_scratch64.ptr(), words * 8, hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+}
+void readback_counters(cook_engine* e, unsigned* out, unsigned words) {
+  COOK_HIP(hipMemcpyAsync(e->h_scratch, e->d_counters.ptr(), words * 4, hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+  std::memcpy(out, e->h_scratch, words * 4);
+}
+
+// ---- segmented scan driver ------------------------------------------------------------------------------------
+template <class T, class Load>
+void seg_scan(cook_engine* e, const char* tag, Load load, const uint8_t* head, unsigned n, T* out, ScanTmp<T>& tmp) {
+  if (n == 0) return;
+  const unsigned nb = div_up(n, SS_TILE);
+  tmp.agg.ensure(nb);
+  tmp.carry.ensure(nb);
+  tmp.first_head.ensure(nb);
+  auto k_local = seg_scan_local<T, Load>;
+  auto k_sums = seg_scan_blocksums<T>;
+  auto k_prop = seg_scan_propagate<T>;
+  KL(tag, k_local, nb, SS_THREADS, load, head, n, out, tmp.agg.ptr(), tmp.first_head.ptr());
+  if (nb > 1) {
+    KL("seg_scan_blocksums", k_sums, 1, SS_THREADS, (const SegAgg<T>*)tmp.agg.ptr(), nb, tmp.carry.ptr());
+    KL("seg_scan_propagate", k_prop, nb, SS_THREADS, out, n, (const SegAgg<T>*)tmp.carry.ptr(),
+       (const unsigned*)tmp.first_head.ptr());
+  }
+}
+
+// ---- radix sort driver: one stable pass of `perm` by byte `shift/8` of key ------------------------------------
+void radix_pass(cook_engine* e, const uint64_t* key, const uint32_t* in, uint32_t* out, unsigned n, unsigned shift) {
+  const unsigned nb = div_up(n, RS_TILE);
+  e->hist.ensure((size_t)256 * nb);
+  KL("radix_hist", radix_hist, nb, RS_THREADS, key, in, n, shift, nb, e->hist.ptr());
+  KL("radix_scan", excl_scan_u32_single, 1, SCAN1_THREADS, e->hist.ptr(), 256u * nb, (uint32_t*)nullptr);
+  KL("radix_scatter", radix_scatter, nb, RS_THREADS, key, in, out, n, shift, nb, (const uint32_t*)e->hist.ptr());
+}
+// sort by the bytes of `key` selected by `mask` (bits that vary); ping-pongs between a and b; returns final buffer
+uint32_t* radix_sort_masked(cook_engine* e, const uint64_t* key, unsigned long long mask, const uint32_t* cur, uint32_t* a,
+                            uint32_t* b, unsigned n) {
+  const uint32_t* in = cur;
+  uint32_t* last = const_cast<uint32_t*>(cur);
+  for (unsigned byte = 0; byte < 8; ++byte) {
+    if (!((mask >> (8 * byte)) & 0xFFull)) continue;
+    uint32_t* out = (in == a) ? b : a;
+    radix_pass(e, key, in, out, n, 8 * byte);
+    in = out;
+    last = out;
+  }
+  return last;
+}
+
+__global__ void iota_u32(uint32_t* p, unsigned n) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+// =================================================================================================================
+// RANK
+// =================================================================================================================
+void rank_stage(cook_engine* e, const cook_tasks* t, const cook_users* u) {
+  if (!t || !u) e->fail(COOK_E_INVALID, "cook_rank_stage: null tasks/users");
+  const unsigned N = t->n, U = u->n;
+  if (N && (!t->cpus || !t->mem || !t->user || !t->priority || !t->start_ms || !t->task_id || !t->job_id || !t->pending))
+    e->fail(COOK_E_INVALID, "cook_rank_stage: a required task array is NULL");
+  if (U == 0 && N) e->fail(COOK_E_INVALID, "cook_rank_stage: no users");
+  unsigned np = 0;
+  std::vector<uint32_t> pend_ord(N ? N : 1);
+  for (unsigned i = 0; i < N; ++i) {
+    if (t->user[i] >= U) e->fail(COOK_E_INVALID, "cook_rank_stage: user id out of range");
+    pend_ord[i] = np;
+    np += t->pending[i] ? 1u : 0u;
+  }
+  e->N = N;
+  e->U = U;
+  e->n_pending = np;
+  e->has_gpus = t->gpus != nullptr;
+  h2d(e, e->t_cpus, t->cpus, N);
+  h2d(e, e->t_mem, t->mem, N);
+  if (t->gpus) h2d(e, e->t_gpus, t->gpus, N);
+  h2d(e, e->t_user, t->user, N);
+  h2d(e, e->t_prio, t->priority, N);
+  h2d(e, e->t_start, t->start_ms, N);
+  h2d(e, e->t_task, t->task_id, N);
+  h2d(e, e->t_job, t->job_id, N);
+  h2d(e, e->t_pending, t->pending, N);
+  h2d(e, e->pend_ord, pend_ord.data(), N);
+  h2d(e, e->u_divc, u->div_cpus, U);
+  h2d(e, e->u_divm, u->div_mem, U);
+  h2d(e, e->u_divg, u->div_gpus, U);
+  h2d(e, e->u_qcount, u->quota_count, U);
+  h2d(e, e->u_qcpus, u->quota_cpus, U);
+  h2d(e, e->u_qmem, u->quota_mem, U);
+  h2d(e, e->u_qgpus, u->quota_gpus, U);
+  sync(e);  // pend_ord is a host temporary
+  e->rank_staged = true;
+  e->rank_done = false;
+}
+
+void rank_pool_usage(cook_engine* e, cook_usage* out) {
+  if (!e->rank_staged) e->fail(COOK_E_STATE, "cook_rank_pool_usage before cook_rank_stage");
+  e->pool_usage.ensure(1);
+  if (e->N == 0) {
+    *out = cook_usage{0, 0, 0, 0};
+    return;
+  }
+  KL("pool_usage_reduce", pool_usage_reduce, 1, 1024, (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(),
+     e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->N,
+     e->pool_usage.ptr());
+  SumU4 h;
+  COOK_HIP(hipMemcpyAsync(e->h_scratch, e->pool_usage.ptr(), sizeof(SumU4), hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+  std::memcpy(&h, e->h_scratch, sizeof(SumU4));
+  *out = cook_usage{h.count, h.cpus, h.mem, h.gpus};
+}
+
+// one quota filter stage over the queue (tools.clj:917-933); returns new queue length
+unsigned queue_filter_quota(cook_engine* e, unsigned len, const cook_usage& quota, const cook_usage& base, uint32_t*& qitem,
+                            SumU4*& quse, uint32_t*& qitem_other, SumU4*& quse_other) {
+  if (len == 0) return 0;
+  e->qpre.ensure(len);
+  e->iflag.ensure(len);
+  e->scanI.ensure(len);
+  LoadQueueUse ld{quse, SumU4{base.count, base.cpus, base.mem, base.gpus, 0u}};
+  seg_scan<SumU4>(e, "queue_usage_scan", ld, (const uint8_t*)nullptr, len, e->qpre.ptr(), e->tmpU4);
+  unsigned* any_bad = e->d_counters.ptr() + 8;
+  COOK_HIP(hipMemsetAsync(any_bad, 0, 8, e->stream));
+  Usage4 q{quota.count, quota.cpus, quota.mem, quota.gpus};
+  KL("queue_quota_flag", queue_quota_flag, div_up(len, 256), 256, (const SumU4*)e->qpre.ptr(), len, q, e->iflag.ptr(), any_bad);
+  KL("queue_quota_fix", queue_quota_fix, 1, 64, (const SumU4*)quse, len, SumU4{base.count, base.cpus, base.mem, base.gpus, 0u}, q,
+     (const unsigned*)any_bad, e->iflag.ptr());
+  seg_scan<SumI>(e, "queue_compact_scan", LoadI{e->iflag.ptr()}, (const uint8_t*)nullptr, len, e->scanI.ptr(), e->tmpI);
+  unsigned* len_out = e->d_counters.ptr() + 9;
+  KL("queue_compact", queue_compact, div_up(len, 256), 256, (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(),
+     (const SumI*)e->scanI.ptr(), len, qitem_other, quse_other, len_out);
+  unsigned h[2];
+  COOK_HIP(hipMemcpyAsync(e->h_scratch, len_out, 4, hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+  std::memcpy(h, e->h_scratch, 4);
+  std::swap(qitem, qitem_other);
+  std::swap(quse, quse_other);
+  return h[0];
+}
+
+void rank_run(cook_engine* e) {
+  if (!e->rank_staged) e->fail(COOK_E_STATE, "cook_rank_run before cook_rank_stage");
+  const unsigned N = e->N, U = e->U;
+  e->n_ranked = 0;
+  e->rank_done = false;
+  e->ranked.ensure(std::max(1u, e->n_pending));
+  if (N == 0) {
+    e->rank_done = true;
+    return;
+  }
+  const unsigned gN = div_up(N, 256);
+  e->d_scratch64.ensure(64);
+  e->d_counters.ensure(64);
+  // --- per-user order keys -------------------------------------------------------------------------------
+  unsigned long long* mins = e->d_scratch64.ptr();       // [0..2]
+  unsigned long long* masks = e->d_scratch64.ptr() + 4;  // [4..6]
+  COOK_HIP(hipMemsetAsync(mins, 0xFF, 3 * 8, e->stream));
+  COOK_HIP(hipMemsetAsync(masks, 0, 4 * 8, e->stream));
+  e->w0.ensure(N);
+  e->w1.ensure(N);
+  e->w2.ensure(N);
+  KL("rank_key_mins", rank_key_mins, std::min(gN, 1024u), 256, (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(),
+     (const int64_t*)e->t_job.ptr(), (const uint8_t*)e->t_pending.ptr(), N, mins);
+  KL("rank_build_keys", rank_build_keys, gN, 256, (const uint32_t*)e->t_user.ptr(), (const int32_t*)e->t_prio.ptr(),
+     (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(), (const int64_t*)e->t_job.ptr(),
+     (const uint8_t*)e->t_pending.ptr(), N, (const unsigned long long*)mins, e->w0.ptr(), e->w1.ptr(), e->w2.ptr());
+  const unsigned gV = std::min(gN, 1024u);
+  KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w0.ptr(), N, masks + 0);
+  KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w1.ptr(), N, masks + 1);
+  KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w2.ptr(), N, masks + 2);
+  readback64(e, 8);
+  const unsigned long long mk0 = e->h_scratch[4], mk1 = e->h_scratch[5], mk2 = e->h_scratch[6];
+  e->permA.ensure(N);
+  e->permB2.ensure(N);
+  KL("iota", iota_u32, gN, 256, e->permA.ptr(), N);
+  uint32_t* cur = e->permA.ptr();
+  cur = radix_sort_masked(e, e->w2.ptr(), mk2, cur, e->permA.ptr(), e->permB2.ptr(), N);
+  cur = radix_sort_masked(e, e->w1.ptr(), mk1, cur, e->permA.ptr(), e->permB2.ptr(), N);
+  cur = radix_sort_masked(e, e->w0.ptr(), mk0, cur, e->permA.ptr(), e->permB2.ptr(), N);
+  e->permB = cur;
+  // --- gather, per-user prefix sums ----------------------------------------------------------------------
+  e->s_user.ensure(N);
+  e->s_use.ensure(N);
+  e->s_pending.ensure(N);
+  e->head.ensure(N);
+  e->seg_start.ensure(U);
+  e->seg_end.ensure(U);
+  e->pre.ensure(N);
+  e->inexact_user.ensure(U);
+  COOK_HIP(hipMemsetAsync(e->inexact_user.ptr(), 0, U * 4, e->stream));
+  KL("rank_gather", rank_gather, gN, 256, (const uint32_t*)e->permB, N, (const uint32_t*)e->t_user.ptr(),
+     (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(),
+     e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->s_user.ptr(),
+     e->s_use.ptr(), e->s_pending.ptr(), e->head.ptr(), e->seg_start.ptr(), e->seg_end.ptr());
+  seg_scan<SumU4>(e, "user_usage_scan", LoadU4{e->s_use.ptr()}, (const uint8_t*)e->head.ptr(), N, e->pre.ptr(), e->tmpU4);
+  KL("rank_mark_inexact", rank_mark_inexact, gN, 256, (const SumU4*)e->pre.ptr(), (const uint32_t*)e->s_user.ptr(), N,
+     e->inexact_user.ptr());
+  KL("rank_fix_inexact", rank_fix_inexact, div_up(U, 256), 256, (const SumU4*)e->s_use.ptr(), e->pre.ptr(),
+     (const uint32_t*)e->seg_start.ptr(), (const uint32_t*)e->seg_end.ptr(), (const uint32_t*)e->inexact_user.ptr(), U);
+  // --- limiter + DRU ---------------------------------------------------------------------------------------
+  e->iflag.ensure(N);
+  e->scanI.ensure(N);
+  KL("rank_over_flag", rank_over_flag, gN, 256, (const SumU4*)e->pre.ptr(), (const uint32_t*)e->s_user.ptr(), N,
+     (const double*)e->u_qcount.ptr(), (const double*)e->u_qcpus.ptr(), (const double*)e->u_qmem.ptr(),
+     (const double*)e->u_qgpus.ptr(), e->iflag.ptr());
+  seg_scan<SumI>(e, "over_quota_scan", LoadI{e->iflag.ptr()}, (const uint8_t*)e->head.ptr(), N, e->scanI.ptr(), e->tmpI);
+  e->dru.ensure(N);
+  e->dkey.ensure(N);
+  e->keep.ensure(N);
+  unsigned* counters = e->d_counters.ptr();  // [0] n_kept [1] equal-run [2] n_tied
+  unsigned long long* orand = e->d_scratch64.ptr() + 8;
+  COOK_HIP(hipMemsetAsync(counters, 0, 8 * 4, e->stream));
+  COOK_HIP(hipMemsetAsync(orand, 0, 8, e->stream));
+  COOK_HIP(hipMemsetAsync(orand + 1, 0xFF, 8, e->stream));
+  KL("rank_score", rank_score, gN, 256, (const SumU4*)e->pre.ptr(), (const SumI*)e->scanI.ptr(), (const uint32_t*)e->s_user.ptr(), N,
+     (int)e->params.max_over_quota_jobs, (int)e->params.dru_mode, (const double*)e->u_divc.ptr(), (const double*)e->u_divm.ptr(),
+     (const double*)e->u_divg.ptr(), e->dru.ptr(), e->dkey.ptr(), e->keep.ptr(), counters, orand);
+  COOK_HIP(hipMemcpyAsync(e->h_scratch, orand, 16, hipMemcpyDeviceToHost, e->stream));
+  COOK_HIP(hipMemcpyAsync(e->h_scratch + 2, counters, 8, hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+  const unsigned long long vor = e->h_scratch[0], vand = e->h_scratch[1];
+  unsigned hc[2];
+  std::memcpy(hc, e->h_scratch + 2, 8);
+  const unsigned n_kept = hc[0];
+  // --- global DRU order -------------------------------------------------------------------------------------
+  e->permC1.ensure(N);
+  e->permC2.ensure(N);
+  KL("iota", iota_u32, gN, 256, e->permC1.ptr(), N);
+  uint32_t* pc = e->permC1.ptr();
+  if (n_kept) pc = radix_sort_masked(e, e->dkey.ptr(), vor & ~vand, pc, e->permC1.ptr(), e->permC2.ptr(), N);
+  if (n_kept < N) {  // limiter dropped tasks: one extra 1-bit pass moves them behind every kept task
+    e->nkkey.ensure(N);
+    KL("rank_notkept_key", rank_notkept_key, gN, 256, (const uint8_t*)e->keep.ptr(), N, e->nkkey.ptr());
+    pc = radix_sort_masked(e, e->nkkey.ptr(), 1ull, pc, e->permC1.ptr(), e->permC2.ptr(), N);
+  }
+  e->permC = pc;
+  unsigned qlen = 0;
+  uint32_t* qitem = e->qitemA.ensure(std::max(1u, e->n_pending));
+  uint32_t* qitem_o = e->qitemB.ensure(std::max(1u, e->n_pending));
+  SumU4* quse = e->quseA.ensure(std::max(1u, e->n_pending));
+  SumU4* quse_o = e->quseB.ensure(std::max(1u, e->n_pending));
+  if (n_kept) {
+    const unsigned gK = div_up(n_kept, 256);
+    // --- tie groups + sorted-merge tie rule (prefix doubling) ------------------------------------------------
+    e->thead.ensure(n_kept);
+    e->rank_of_item.ensure(N);
+    e->gstart.ensure(n_kept);
+    int* ones = e->ones_buf.ensure(n_kept);
+    int* tied = e->tied_buf.ensure(n_kept);
+    KL("tie_heads", tie_heads, gK, 256, (const uint32_t*)e->permC, (const uint64_t*)e->dkey.ptr(), n_kept,
+       (const uint32_t*)e->s_user.ptr(), e->thead.ptr(), ones, counters);
+    unsigned bits = 1;
+    while ((1ull << bits) <= (unsigned long long)U + N) ++bits;  // rank values <= U + N
+    const unsigned rank_bytes = (bits + 7) / 8;
+    unsigned long long cmask = 0;
+    for (unsigned b = 0; b < rank_bytes; ++b) cmask |= (0xFFull << (8 * b)) | (0xFFull << (8 * (b + 4)));
+    for (int round = 0;; ++round) {
+      seg_scan<SumI>(e, "tie_group_scan", LoadI{ones}, (const uint8_t*)e->thead.ptr(), n_kept, e->scanI.ptr(), e->tmpI);
+      COOK_HIP(hipMemsetAsync(counters + 2, 0, 4, e->stream));
+      KL("tie_assign", tie_assign, gK, 256, (const uint32_t*)e->permC, (const uint8_t*)e->thead.ptr(), (const SumI*)e->scanI.ptr(),
+         n_kept, U, e->rank_of_item.ptr(), e->gstart.ptr(), tied, counters + 2);
+      unsigned h3[3];
+      readback_counters(e, h3, 3);
+      if (h3[1]) e->fail(COOK_E_INVALID, "cook_rank: a user has consecutive tasks with equal DRU (zero-resource task); unsupported");
+      const unsigned n_tied = h3[2];
+      if (n_tied == 0) break;
+      if (round > 31) e->fail(COOK_E_INVALID, "cook_rank: tie refinement did not converge");
+      // compact tied slots, sort them by (group start, secondary), write back, split groups
+      e->tpos.ensure(n_tied);
+      e->titem.ensure(n_tied);
+      e->ckey.ensure(n_tied);
+      e->tsorted.ensure(n_tied);
+      e->tsorted2.ensure(n_tied);
+      seg_scan<SumI>(e, "tie_compact_scan", LoadI{tied}, (const uint8_t*)nullptr, n_kept, e->scanI.ptr(), e->tmpI);
+      KL("tie_build", tie_build, gK, 256, (const uint32_t*)e->permC, (const int*)tied, (const SumI*)e->scanI.ptr(),
+         (const uint32_t*)e->gstart.ptr(), n_kept, U, N, round, (const uint32_t*)e->rank_of_item.ptr(),
+         (const uint32_t*)e->s_user.ptr(), (const uint32_t*)e->seg_start.ptr(), e->tpos.ptr(), e->titem.ptr(), e->ckey.ptr());
+      KL("iota", iota_u32, div_up(n_tied, 256), 256, e->tsorted.ptr(), n_tied);
+      uint32_t* ts = radix_sort_masked(e, e->ckey.ptr(), cmask, e->tsorted.ptr(), e->tsorted.ptr(), e->tsorted2.ptr(), n_tied);
+      KL("tie_writeback", tie_writeback, div_up(n_tied, 256), 256, (const uint32_t*)ts, (const uint32_t*)e->tpos.ptr(),
+         (const uint32_t*)e->titem.ptr(), (const uint64_t*)e->ckey.ptr(), n_tied, e->permC, e->thead.ptr());
+    }
+    // --- queue of pending jobs in rank order ---------------------------------------------------------------
+    int* flag = e->iflag.ptr();
+    KL("queue_flag_pending", queue_flag_pending, gK, 256, (const uint32_t*)e->permC, (const uint8_t*)e->s_pending.ptr(), n_kept, flag);
+    seg_scan<SumI>(e, "queue_pending_scan", LoadI{flag}, (const uint8_t*)nullptr, n_kept, e->scanI.ptr(), e->tmpI);
+    unsigned* dq = e->d_counters.ptr() + 10;
+    COOK_HIP(hipMemsetAsync(dq, 0, 4, e->stream));
+    KL("queue_compact_pending", queue_compact_pending, gK, 256, (const uint32_t*)e->permC, (const int*)flag, (const SumI*)e->scanI.ptr(),
+       n_kept, (const SumU4*)e->s_use.ptr(), qitem, quse, dq);
+    COOK_HIP(hipMemcpyAsync(e->h_scratch, dq, 4, hipMemcpyDeviceToHost, e->stream));
+    sync(e);
+    std::memcpy(&qlen, e->h_scratch, 4);
+  }
+  // --- quota filters (scheduler.clj:2134-2157) -------------------------------------------------------------
+  if (qlen && e->quota.has_pool_quota) {
+    cook_usage base = e->quota.pool_usage;
+    if (!e->quota.pool_usage_given) rank_pool_usage(e, &base);
+    qlen = queue_filter_quota(e, qlen, e->quota.pool_quota, base, qitem, quse, qitem_o, quse_o);
+  }
+  if (qlen && e->quota.has_group_quota)
+    qlen = queue_filter_quota(e, qlen, e->quota.group_quota, e->quota.group_usage, qitem, quse, qitem_o, quse_o);
+  // --- offensive filter (scheduler.clj:2198-2229) -----------------------------------------------------------
+  const bool offensive_on = std::isfinite(e->params.offensive_max_mem_mb) || std::isfinite(e->params.offensive_max_cpus);
+  if (qlen && offensive_on) {
+    e->iflag.ensure(qlen);
+    e->scanI.ensure(qlen);
+    KL("queue_offensive_flag", queue_offensive_flag, div_up(qlen, 256), 256, (const SumU4*)quse, qlen, e->params.offensive_max_mem_mb,
+       e->params.offensive_max_cpus, e->iflag.ptr());
+    seg_scan<SumI>(e, "queue_compact_scan", LoadI{e->iflag.ptr()}, (const uint8_t*)nullptr, qlen, e->scanI.ptr(), e->tmpI);
+    unsigned* len_out = e->d_counters.ptr() + 9;
+    KL("queue_compact", queue_compact, div_up(qlen, 256), 256, (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(),
+       (const SumI*)e->scanI.ptr(), qlen, qitem_o, quse_o, len_out);
+    COOK_HIP(hipMemcpyAsync(e->h_scratch, len_out, 4, hipMemcpyDeviceToHost, e->stream));
+    sync(e);
+    std::memcpy(&qlen, e->h_scratch, 4);
+    std::swap(qitem, qitem_o);
+    std::swap(quse, quse_o);
+  }
+  if (qlen)
+    KL("queue_emit", queue_emit, div_up(qlen, 256), 256, (const uint32_t*)qitem, qlen, (const uint32_t*)e->permB, e->ranked.ptr());
+  e->n_ranked = qlen;
+  e->rank_done = true;
+}
+
+void rank_fetch(cook_engine* e, uint32_t* ranked, uint32_t* n_out, double* dru_of_task) {
+  if (!e->rank_done) e->fail(COOK_E_STATE, "cook_rank_fetch before cook_rank_run");
+  if (n_out) *n_out = e->n_ranked;
+  if (ranked && e->n_ranked)
+    COOK_HIP(hipMemcpyAsync(ranked, e->ranked.ptr(), (size_t)e->n_ranked * 4, hipMemcpyDeviceToHost, e->stream));
+  if (dru_of_task && e->N) {
+    e->dru_out.ensure(e->N);
+    KL("dru_to_task_space", dru_to_task_space, div_up(e->N, 256), 256, (const double*)e->dru.ptr(), (const uint8_t*)e->keep.ptr(),
+       (const uint32_t*)e->permB, e->N, e->dru_out.ptr());
+    COOK_HIP(hipMemcpyAsync(dru_of_task, e->dru_out.ptr(), (size_t)e->N * 8, hipMemcpyDeviceToHost, e->stream));
+  }
+  sync(e);
+}
+
+// =================================================================================================================
+// MATCH
+// =================================================================================================================
+void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o, const cook_groups* g,
+                        const uint32_t* reserved_hosts, uint32_t n_reserved) {
+  if (!j || !o) e->fail(COOK_E_INVALID, "cook_match_stage: null jobs/offers");
+  const unsigned K = j->n, M = o->n, G = g ? g->n : 0;
+  if (K && (!j->cpus || !j->mem)) e->fail(COOK_E_INVALID, "cook_match_stage: jobs need cpus and mem");
+  if (M && (!o->cpus || !o->mem || !o->host)) e->fail(COOK_E_INVALID, "cook_match_stage: offers need cpus, mem and host");
+  if (j->group && !g) {
+    for (unsigned k = 0; k < K; ++k)
+      if (j->group[k] != COOK_NONE_U32) e->fail(COOK_E_INVALID, "cook_match_stage: job has a group but no groups table given");
+  }
+  if (j->group && g)
+    for (unsigned k = 0; k < K; ++k)
+      if (j->group[k] != COOK_NONE_U32 && j->group[k] >= G) e->fail(COOK_E_INVALID, "cook_match_stage: group id out of range");
+  MatchIn& in = e->min;
+  std::memset(&in, 0, sizeof(in));
+  in.K = K;
+  in.M = M;
+  in.G = G;
+  e->Kjobs = K;
+  in.j_cpus = h2d_opt(e, e->j_cpus, j->cpus, K);
+  in.j_mem = h2d_opt(e, e->j_mem, j->mem, K);
+  in.j_gpus = h2d_opt(e, e->j_gpus, j->gpus, K);
+  in.j_gpu_model = h2d_opt(e, e->j_gpu_model, j->gpu_model, K);
+  in.j_group = h2d_opt(e, e->j_group, j->group, K);
+  if (j->eq_off) {
+    in.j_eq_off = h2d_opt(e, e->j_eq_off, j->eq_off, K + 1);
+    const unsigned ne = K ? j->eq_off[K] : 0;
+    in.j_eq_key = h2d_opt(e, e->j_eq_key, j->eq_key, std::max(1u, ne));
+    in.j_eq_val = h2d_opt(e, e->j_eq_val, j->eq_val, std::max(1u, ne));
+  }
+  if (j->novel_off) {
+    in.j_novel_off = h2d_opt(e, e->j_novel_off, j->novel_off, K + 1);
+    const unsigned nn = K ? j->novel_off[K] : 0;
+    in.j_novel_host = h2d_opt(e, e->j_novel_host, j->novel_host, std::max(1u, nn));
+  }
+  in.j_reserved_host = h2d_opt(e, e->j_reserved_host, j->reserved_host, K);
+  in.j_ckpt = h2d_opt(e, e->j_ckpt, j->ckpt_location, K);
+  in.j_est_end = h2d_opt(e, e->j_est_end, j->est_end_ms, K);
+  in.j_disk_req = h2d_opt(e, e->j_disk_req, j->disk_request, K);
+  in.j_disk_type = h2d_opt(e, e->j_disk_type, j->disk_type, K);
+  if (in.j_disk_req && !in.j_disk_type) e->fail(COOK_E_INVALID, "cook_match_stage: disk_request without disk_type");
+  in.o_cpus = h2d_opt(e, e->o_cpus, o->cpus, M);
+  in.o_mem = h2d_opt(e, e->o_mem, o->mem, M);
+  in.o_host = h2d_opt(e, e->o_host, o->host, M);
+  in.o_k8s = h2d_opt(e, e->o_k8s, o->k8s, M);
+  in.o_gpu_model = h2d_opt(e, e->o_gpu_model, o->gpu_model, M);
+  in.o_gpu_count = h2d_opt(e, e->o_gpu_count, o->gpu_count, M);
+  if (in.o_gpu_model && !in.o_gpu_count) e->fail(COOK_E_INVALID, "cook_match_stage: gpu_model without gpu_count");
+  in.o_disk_type = h2d_opt(e, e->o_disk_type, o->disk_type, M);
+  in.o_disk_space = h2d_opt(e, e->o_disk_space, o->disk_space, M);
+  in.n_attr = o->attr ? o->n_attr_keys : 0;
+  in.o_attr = h2d_opt(e, e->o_attr, o->attr, (size_t)M * in.n_attr);
+  in.o_max_tasks = h2d_opt(e, e->o_max_tasks, o->max_tasks, M);
+  in.o_num_tasks = h2d_opt(e, e->o_num_tasks, o->num_tasks, M);
+  in.o_location = h2d_opt(e, e->o_location, o->location, M);
+  in.o_host_start = h2d_opt(e, e->o_host_start, o->host_start_s, M);
+  in.o_run_cpus = h2d_opt(e, e->o_run_cpus, o->run_cpus, M);
+  in.o_run_mem = h2d_opt(e, e->o_run_mem, o->run_mem, M);
+  in.o_run_count = h2d_opt(e, e->o_run_count, o->run_count, M);
+  if (G) {
+    in.g_type = h2d_opt(e, e->g_type, g->type, G);
+    in.g_attr_key = h2d_opt(e, e->g_attr_key, g->attr_key, G);
+    in.g_min = h2d_opt(e, e->g_min, g->minimum, G);
+    if (!in.g_type || !in.g_attr_key || !in.g_min) e->fail(COOK_E_INVALID, "cook_match_stage: groups need type, attr_key, minimum");
+    if (g->run_off) {
+      in.g_run_off = h2d_opt(e, e->g_run_off, g->run_off, G + 1);
+      const unsigned nr = g->run_off[G];
+      in.g_run_host = h2d_opt(e, e->g_run_host, g->run_host, std::max(1u, nr));
+      in.g_run_attr = h2d_opt(e, e->g_run_attr, g->run_attr, std::max(1u, nr));
+    }
+  }
+  std::vector<uint32_t> bits;
+  if (n_reserved) {
+    uint32_t mx = 0;
+    for (unsigned i = 0; i < n_reserved; ++i) mx = std::max(mx, reserved_hosts[i]);
+    bits.assign(mx / 32 + 1, 0u);
+    for (unsigned i = 0; i < n_reserved; ++i) bits[reserved_hosts[i] >> 5] |= 1u << (reserved_hosts[i] & 31);
+    in.reserved_bits = h2d_opt(e, e->reserved_bits, bits.data(), bits.size());
+    in.reserved_words = (unsigned)bits.size();
+  }
+  in.good_enough = e->params.good_enough_fitness;
+  in.host_lifetime_mins = e->params.host_lifetime_mins;
+  sync(e);  // `bits` is a host temporary
+  e->K = K;
+  e->M = M;
+  e->G = G;
+  e->match_staged = true;
+  e->match_done = false;
+}
+
+void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
+  MatchIn in = e->min;
+  in.K = K;
+  in.j_index = j_index;
+  in.good_enough = e->params.good_enough_fitness;
+  in.host_lifetime_mins = e->params.host_lifetime_mins;
+  const unsigned M = in.M, G = in.G;
+  MatchState st;
+  st.ac = e->m_ac.ensure(M);
+  st.am = e->m_am.ensure(M);
+  st.acount = e->m_acount.ensure(M);
+  st.group_last = e->m_group_last.ensure(G);
+  st.job_prev = e->m_job_prev.ensure(K);
+  st.job_to_offer = e->m_j2o.ensure(K);
+  st.fail_code = e->m_fail.ensure(K);
+  st.summary = e->m_summary.ensure(4);
+  if (M) {
+    COOK_HIP(hipMemsetAsync(st.ac, 0, (size_t)M * 8, e->stream));
+    COOK_HIP(hipMemsetAsync(st.am, 0, (size_t)M * 8, e->stream));
+    COOK_HIP(hipMemsetAsync(st.acount, 0, (size_t)M * 4, e->stream));
+  }
+  if (G) COOK_HIP(hipMemsetAsync(st.group_last, 0xFF, (size_t)G * 4, e->stream));
+  if (K) {
+    COOK_HIP(hipMemsetAsync(st.job_prev, 0xFF, (size_t)K * 4, e->stream));
+    COOK_HIP(hipMemsetAsync(st.job_to_offer, 0xFF, (size_t)K * 4, e->stream));
+  }
+  COOK_HIP(hipMemsetAsync(st.summary, 0, 16, e->stream));
+#ifdef __HIP_EMU__
+  auto k_match = match_serial<256>;
+  KL("match_serial", k_match, 1, 256, in, st);
+#else
+  auto k_match = match_serial<1024>;
+  KL("match_serial", k_match, 1, 1024, in, st);
+#endif
+  e->cycle_considered = K;
+  e->match_done = true;
+}
+
+void match_fetch(cook_engine* e, unsigned K, int32_t* job_to_offer, uint32_t* fail_code, uint8_t* head_matched) {
+  if (!e->match_done) e->fail(COOK_E_STATE, "cook_match_fetch before cook_match_run");
+  if (job_to_offer && K) COOK_HIP(hipMemcpyAsync(job_to_offer, e->m_j2o.ptr(), (size_t)K * 4, hipMemcpyDeviceToHost, e->stream));
+  if (fail_code && K) COOK_HIP(hipMemcpyAsync(fail_code, e->m_fail.ptr(), (size_t)K * 4, hipMemcpyDeviceToHost, e->stream));
+  COOK_HIP(hipMemcpyAsync(e->h_scratch, e->m_summary.ptr(), 16, hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+  unsigned s[4];
+  std::memcpy(s, e->h_scratch, 16);
+  if (head_matched) *head_matched = (uint8_t)s[1];
+}
+
+__global__ void cycle_job_index(const uint32_t* __restrict__ ranked, const uint32_t* __restrict__ pend_ord, unsigned k, uint32_t* __restrict__ j_index) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < k) j_index[i] = pend_ord[ranked[i]];
+}
+
+struct StageTimer {
+  cook_engine* e;
+  int slot;
+  double* out;
+  StageTimer(cook_engine* e_, int s, double* o) : e(e_), slot(s), out(o) { (void)hipEventRecord(e->ev_stage[slot], e->stream); }
+  void stop() {
+    (void)hipEventRecord(e->ev_stage[slot + 1], e->stream);
+    (void)hipEventSynchronize(e->ev_stage[slot + 1]);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e->ev_stage[slot], e->ev_stage[slot + 1]);
+    *out = ms;
+  }
+};
+
+template <class F>
+int guarded(cook_engine* e, F&& f) {
+  if (!e) return COOK_E_INVALID;
+  try {
+    COOK_HIP(hipSetDevice(e->device));
+    f();
+    e->err.clear();
+    return COOK_OK;
+  } catch (const cook_error& ce) {
+    e->err = ce.msg;
+    (void)hipStreamSynchronize(e->stream);
+    e->ev_pending.clear();
+    e->ev_used = 0;
+    return ce.code;
+  } catch (const std::exception& ex) {
+    e->err = ex.what();
+    return COOK_E_NOMEM;
+  }
+}
+
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+const char* cook_version(void) {
+#ifdef __HIP_EMU__
+  return "cookmatch 0.1.0 (simt-emu test build)";
+#else
+  return "cookmatch 0.1.0 (hip gfx950)";
+#endif
+}
+
+int cook_engine_create(const cook_params* params, int device_id, cook_engine** out) {
+  if (!params || !out) return COOK_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return COOK_E_DEVICE;  // no GPU: fail loudly, no CPU fallback
+  if (device_id < 0 || device_id >= ndev) return COOK_E_INVALID;
+  cook_engine* e = nullptr;
+  try {
+    e = new cook_engine();
+    e->params = *params;
+    e->device = device_id;
+    COOK_HIP(hipSetDevice(device_id));
+    COOK_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) COOK_HIP(hipEventCreate(&e->ev_stage[i]));
+    COOK_HIP(hipHostMalloc((void**)&e->h_scratch, 64 * 8, hipHostMallocDefault));
+    e->d_scratch64.ensure(64);
+    e->d_counters.ensure(64);
+  } catch (const cook_error&) {
+    delete e;
+    return COOK_E_DEVICE;
+  } catch (...) {
+    delete e;
+    return COOK_E_NOMEM;
+  }
+  *out = e;
+  return COOK_OK;
+}
+
+void cook_engine_destroy(cook_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  // DArr members leak-free teardown: free every device buffer we own
+  DBuf* bufs[] = {&e->d_scratch64.b, &e->d_counters.b, &e->t_cpus.b, &e->t_mem.b, &e->t_gpus.b, &e->u_divc.b, &e->u_divm.b, &e->u_divg.b,
+                  &e->u_qcount.b, &e->u_qcpus.b, &e->u_qmem.b, &e->u_qgpus.b, &e->t_user.b, &e->permA.b, &e->permB2.b, &e->s_user.b,
+                  &e->seg_start.b, &e->seg_end.b, &e->inexact_user.b, &e->rank_of_item.b, &e->gstart.b, &e->tpos.b, &e->titem.b,
+                  &e->tsorted.b, &e->tsorted2.b, &e->qitemA.b, &e->qitemB.b, &e->ranked.b, &e->pend_ord.b, &e->hist.b, &e->t_prio.b,
+                  &e->t_start.b, &e->t_task.b, &e->t_job.b, &e->t_pending.b, &e->s_pending.b, &e->head.b, &e->keep.b, &e->thead.b,
+                  &e->w0.b, &e->w1.b, &e->w2.b, &e->dkey.b, &e->nkkey.b, &e->ckey.b, &e->s_use.b, &e->pre.b, &e->quseA.b, &e->quseB.b,
+                  &e->qpre.b, &e->pool_usage.b, &e->scanI.b, &e->iflag.b, &e->ones_buf.b, &e->tied_buf.b, &e->dru.b, &e->dru_out.b, &e->tmpU4.agg.b, &e->tmpU4.carry.b,
+                  &e->tmpU4.first_head.b, &e->tmpI.agg.b, &e->tmpI.carry.b, &e->tmpI.first_head.b, &e->permC1.b, &e->permC2.b,
+                  &e->j_cpus.b, &e->j_mem.b, &e->j_gpus.b, &e->j_disk_req.b, &e->o_cpus.b, &e->o_mem.b, &e->o_gpu_count.b,
+                  &e->o_disk_space.b, &e->o_run_cpus.b, &e->o_run_mem.b, &e->m_ac.b, &e->m_am.b, &e->j_gpu_model.b, &e->j_group.b,
+                  &e->j_eq_off.b, &e->j_eq_key.b, &e->j_eq_val.b, &e->j_novel_off.b, &e->j_novel_host.b, &e->j_ckpt.b, &e->j_disk_type.b,
+                  &e->j_index.b, &e->o_host.b, &e->o_gpu_model.b, &e->o_disk_type.b, &e->o_attr.b, &e->o_location.b, &e->g_attr_key.b,
+                  &e->g_run_off.b, &e->g_run_host.b, &e->g_run_attr.b, &e->reserved_bits.b, &e->m_fail.b, &e->j_reserved_host.b,
+                  &e->o_max_tasks.b, &e->o_num_tasks.b, &e->o_run_count.b, &e->g_min.b, &e->m_acount.b, &e->m_group_last.b,
+                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b};
+  for (DBuf* b : bufs) b->release();
+  for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+  for (int i = 0; i < 4; ++i)
+    if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]);
+  if (e->h_scratch) (void)hipHostFree(e->h_scratch);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int cook_engine_set_params(cook_engine* e, const cook_params* p) {
+  if (!e || !p) return COOK_E_INVALID;
+  e->params = *p;
+  return COOK_OK;
+}
+
+const char* cook_last_error(const cook_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int cook_rank_stage(cook_engine* e, const cook_tasks* tasks, const cook_users* users) {
+  return guarded(e, [&] { rank_stage(e, tasks, users); });
+}
+int cook_rank_set_quota(cook_engine* e, const cook_pool_quota* q) {
+  if (!e) return COOK_E_INVALID;
+  if (q)
+    e->quota = *q;
+  else
+    std::memset(&e->quota, 0, sizeof(e->quota));
+  return COOK_OK;
+}
+int cook_rank_pool_usage(cook_engine* e, cook_usage* out) {
+  if (!out) return COOK_E_INVALID;
+  return guarded(e, [&] { rank_pool_usage(e, out); });
+}
+int cook_rank_run(cook_engine* e) {
+  return guarded(e, [&] {
+    StageTimer t(e, 0, &e->rank_ms);
+    rank_run(e);
+    t.stop();
+    prof_collect(e);
+  });
+}
+int cook_rank_fetch(cook_engine* e, uint32_t* ranked, uint32_t* n_out, double* dru) {
+  return guarded(e, [&] { rank_fetch(e, ranked, n_out, dru); });
+}
+int cook_rank(cook_engine* e, const cook_tasks* tasks, const cook_users* users, const cook_pool_quota* quota, uint32_t* ranked,
+              uint32_t* n_out, double* dru) {
+  if (n_out) *n_out = 0;
+  int rc = cook_rank_stage(e, tasks, users);
+  if (rc) return rc;
+  cook_rank_set_quota(e, quota);
+  rc = cook_rank_run(e);
+  if (rc) return rc;
+  return cook_rank_fetch(e, ranked, n_out, dru);
+}
+
+int cook_match_stage(cook_engine* e, const cook_jobs* j, const cook_offers* o, const cook_groups* g, const uint32_t* reserved_hosts,
+                     uint32_t n_reserved) {
+  return guarded(e, [&] {
+    match_stage_inputs(e, j, o, g, reserved_hosts, n_reserved);
+    e->cycle_staged = false;
+  });
+}
+int cook_match_run(cook_engine* e) {
+  return guarded(e, [&] {
+    if (!e->match_staged) e->fail(COOK_E_STATE, "cook_match_run before cook_match_stage");
+    StageTimer t(e, 2, &e->match_ms);
+    match_run_device(e, e->K, nullptr);
+    t.stop();
+    prof_collect(e);
+  });
+}
+int cook_match_fetch(cook_engine* e, int32_t* job_to_offer, uint32_t* fail_code, uint8_t* head_matched) {
+  return guarded(e, [&] { match_fetch(e, e->cycle_considered, job_to_offer, fail_code, head_matched); });
+}
+int cook_match(cook_engine* e, const cook_jobs* j, const cook_offers* o, const cook_groups* g, const uint32_t* reserved_hosts,
+               uint32_t n_reserved, int32_t* job_to_offer, uint32_t* fail_code, uint8_t* head_matched) {
+  if (j && job_to_offer)
+    for (uint32_t k = 0; k < j->n; ++k) job_to_offer[k] = -1;  // "no matches" on any error path
+  if (head_matched) *head_matched = 1;
+  int rc = cook_match_stage(e, j, o, g, reserved_hosts, n_reserved);
+  if (rc) return rc;
+  rc = cook_match_run(e);
+  if (rc) return rc;
+  return cook_match_fetch(e, job_to_offer, fail_code, head_matched);
+}
+
+int cook_cycle_stage(cook_engine* e, const cook_tasks* tasks, const cook_users* users, const cook_jobs* pending_jobs,
+                     const cook_offers* offers, const cook_groups* groups, const uint32_t* reserved_hosts, uint32_t n_reserved) {
+  return guarded(e, [&] {
+    rank_stage(e, tasks, users);
+    if (!pending_jobs || pending_jobs->n != e->n_pending)
+      e->fail(COOK_E_INVALID, "cook_cycle_stage: pending_jobs->n must equal the number of pending tasks");
+    match_stage_inputs(e, pending_jobs, offers, groups, reserved_hosts, n_reserved);
+    e->cycle_staged = true;
+  });
+}
+int cook_cycle_run(cook_engine* e, uint32_t num_considerable) {
+  return guarded(e, [&] {
+    if (!e->cycle_staged) e->fail(COOK_E_STATE, "cook_cycle_run before cook_cycle_stage");
+    StageTimer tr(e, 0, &e->rank_ms);
+    rank_run(e);
+    tr.stop();
+    StageTimer tm(e, 2, &e->match_ms);
+    const unsigned K = std::min<unsigned>(num_considerable, e->n_ranked);  // (take num-considerable), scheduler.clj:751
+    e->j_index.ensure(K);
+    if (K)
+      KL("cycle_job_index", cycle_job_index, div_up(K, 256), 256, (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(), K,
+         e->j_index.ptr());
+    match_run_device(e, K, K ? e->j_index.ptr() : nullptr);
+    tm.stop();
+    prof_collect(e);
+  });
+}
+int cook_cycle_fetch(cook_engine* e, uint32_t* ranked, uint32_t* n_ranked, int32_t* job_to_offer, uint32_t* n_considered,
+                     uint8_t* head_matched) {
+  return guarded(e, [&] {
+    rank_fetch(e, ranked, n_ranked, nullptr);
+    if (n_considered) *n_considered = e->cycle_considered;
+    match_fetch(e, e->cycle_considered, job_to_offer, nullptr, head_matched);
+  });
+}
+
+int cook_rebalance(cook_engine* e, const cook_tasks*, const cook_jobs*, const int64_t*, const int32_t*, const cook_users*,
+                   const cook_host_spare*, const cook_rebalance_params*, cook_preemption*, uint32_t* n_decisions, uint32_t*,
+                   uint32_t* n_preempted) {
+  if (n_decisions) *n_decisions = 0;
+  if (n_preempted) *n_preempted = 0;
+  if (!e) return COOK_E_INVALID;
+  e->err = "cook_rebalance: not implemented in this build";
+  return COOK_E_STATE;
+}
+
+int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms) {
+  if (!e) return COOK_E_INVALID;
+  if (rank_ms) *rank_ms = e->rank_ms;
+  if (match_ms) *match_ms = e->match_ms;
+  return COOK_OK;
+}
+int cook_set_profiling(cook_engine* e, int enabled) {
+  if (!e) return COOK_E_INVALID;
+  e->profiling = enabled != 0;
+  e->kstats.clear();
+  return COOK_OK;
+}
+int cook_kernel_timings(cook_engine* e, const char** names, double* ms, uint32_t* launches, uint32_t cap) {
+  if (!e) return COOK_E_INVALID;
+  e->kstat_names.clear();
+  for (auto& kv : e->kstats) e->kstat_names.push_back(kv.first);
+  uint32_t n = 0;
+  for (auto& nm : e->kstat_names) {
+    if (n >= cap) break;
+    names[n] = nm.c_str();
+    ms[n] = e->kstats[nm].ms;
+    launches[n] = e->kstats[nm].launches;
+    ++n;
+  }
+  return (int)n;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// sort.hpp — stable LSD radix sort of a permutation by 64-bit key words, 8-bit digits, wave64.
+//
+// Used for the per-user task order (tools.clj:614-641 feature vector, three key words) and for the global DRU order
+// (dru.clj:82-126, one order-preserving fp64 key word).  Keys stay in place; only the u32 permutation moves, so a
+// pass streams 4 B/item in + 4 B/item out plus an 8 B gather that hits L2 (N*8 B <= 12 MB for 1.4M tasks).
+//
+// One pass = three launches:
+//   radix_hist    : per-block 256-bin digit histogram (LDS atomics)              -> hist[digit][block]
+//   radix_scan    : exclusive scan of hist in (digit-major, block-minor) order    (single workgroup)
+//   radix_scatter : stable placement.  A block's tile is split into one contiguous chunk per wave; per-wave digit
+//                   counts give each wave its base, then every wave walks its chunk 64 items at a time, ranking equal
+//                   digits with 8 ballots (match-any) so earlier positions keep earlier slots.
+// The host skips passes whose digit is constant over the whole input (radix_varying_bits).
+#pragma once
+#include "common.hpp"
+
+constexpr int RS_THREADS = 256;                     // 4 waves
+constexpr int RS_WAVES = RS_THREADS / COOK_WAVE;    // waves per block
+constexpr int RS_IPL = 16;                          // items per lane
+constexpr int RS_WAVE_ITEMS = COOK_WAVE * RS_IPL;   // 1024 contiguous items per wave
+constexpr int RS_TILE = RS_WAVES * RS_WAVE_ITEMS;   // 4096 items per block
+
+static __device__ __forceinline__ unsigned rs_digit(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm_in,
+                                                    unsigned i, unsigned shift) {
+  const unsigned src = perm_in ? perm_in[i] : i;
+  return (unsigned)(key[src] >> shift) & 0xFFu;
+}
+
+__global__ void __launch_bounds__(RS_THREADS) radix_hist(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm_in,
+                                                         unsigned n, unsigned shift, unsigned nblocks,
+                                                         uint32_t* __restrict__ hist) {
+  __shared__ unsigned h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned base = blockIdx.x * RS_TILE;
+  for (int k = 0; k < RS_TILE / RS_THREADS; ++k) {
+    const unsigned i = base + k * RS_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&h[rs_digit(key, perm_in, i, shift)], 1u);
+  }
+  __syncthreads();
+  hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// Exclusive scan of a u32 array by ONE workgroup of 1024 threads (len = 256 * nblocks, a few thousand entries).
+constexpr int SCAN1_THREADS = 1024;
+__global__ void __launch_bounds__(SCAN1_THREADS) excl_scan_u32_single(uint32_t* __restrict__ data, unsigned len,
+                                                                      uint32_t* __restrict__ total_out) {
+  __shared__ unsigned wsum[SCAN1_THREADS / COOK_WAVE];
+  __shared__ unsigned carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const unsigned lane = lane_id(), w = wave_id();
+  for (unsigned tile = 0; tile < len; tile += SCAN1_THREADS) {
+    const unsigned i = tile + threadIdx.x;
+    const unsigned v = i < len ? data[i] : 0u;
+    unsigned inc = v;
+    for (unsigned d = 1; d < COOK_WAVE; d <<= 1) {
+      const unsigned t = __shfl_up(inc, d, COOK_WAVE);
+      if (lane >= d) inc += t;
+    }
+    if (lane == COOK_WAVE - 1) wsum[w] = inc;
+    __syncthreads();
+    unsigned wbase = 0;
+    for (unsigned k = 0; k < w; ++k) wbase += wsum[k];
+    const unsigned carry = carry_s;
+    if (i < len) data[i] = carry + wbase + inc - v;
+    __syncthreads();
+    if (threadIdx.x == SCAN1_THREADS - 1) carry_s = carry + wbase + inc;
+    __syncthreads();
+  }
+  if (total_out && threadIdx.x == 0) *total_out = carry_s;
+}
+
+__global__ void __launch_bounds__(RS_THREADS) radix_scatter(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm_in,
+                                                            uint32_t* __restrict__ perm_out, unsigned n, unsigned shift,
+                                                            unsigned nblocks, const uint32_t* __restrict__ hist_scanned) {
+  __shared__ unsigned whist[RS_WAVES][256];
+  const unsigned lane = lane_id(), w = wave_id();
+  for (int k = 0; k < RS_WAVES; ++k) whist[k][threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned wbase = blockIdx.x * RS_TILE + w * RS_WAVE_ITEMS;
+  // phase 1: per-wave digit counts
+  for (int k = 0; k < RS_IPL; ++k) {
+    const unsigned i = wbase + k * COOK_WAVE + lane;
+    if (i < n) atomicAdd(&whist[w][rs_digit(key, perm_in, i, shift)], 1u);
+  }
+  __syncthreads();
+  // phase 2: digit d = threadIdx.x; turn counts into each wave's starting slot
+  {
+    unsigned base = hist_scanned[threadIdx.x * nblocks + blockIdx.x];
+    for (int k = 0; k < RS_WAVES; ++k) {
+      const unsigned t = whist[k][threadIdx.x];
+      whist[k][threadIdx.x] = base;
+      base += t;
+    }
+  }
+  __syncthreads();
+  // phase 3: stable ranking inside the wave, 64 consecutive positions per step
+  const unsigned long long lt = lanemask_lt();
+  for (int k = 0; k < RS_IPL; ++k) {
+    const unsigned i = wbase + k * COOK_WAVE + lane;
+    const bool valid = i < n;
+    const unsigned src = valid ? (perm_in ? perm_in[i] : i) : 0u;
+    const unsigned d = valid ? (unsigned)(key[src] >> shift) & 0xFFu : 0u;
+    unsigned long long peers = __ballot(valid);
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __ballot(valid && ((d >> b) & 1u));
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    unsigned slot = 0;
+    if (valid) slot = whist[w][d];
+    wave_sync();
+    if (valid) {
+      const unsigned rank = (unsigned)__popcll(peers & lt);
+      if (rank == 0) whist[w][d] = slot + (unsigned)__popcll(peers);  // lowest lane of the peer set
+      perm_out[slot + rank] = src;
+    }
+    wave_sync();
+  }
+}
+
+// OR over all items of (key[i] ^ key[0]) : bits that differ somewhere.  One atomicOr per wave.
+__global__ void __launch_bounds__(256) radix_varying_bits(const uint64_t* __restrict__ key, unsigned n,
+                                                          unsigned long long* __restrict__ out_mask) {
+  const uint64_t k0 = key[0];
+  unsigned long long m = 0;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m |= key[i] ^ k0;
+  for (int d = 32; d >= 1; d >>= 1) m |= __shfl_xor(m, d, COOK_WAVE);
+  if (lane_id() == 0 && m) atomicOr(out_mask, m);
+}

@@ -1,0 +1,202 @@
+"""ctypes binding of libcookmatch.so (include/cookmatch.h).
+
+The product path is the HIP library and nothing else: if the shared object is missing or no MI355X is visible,
+construction raises — there is NO CPU fallback (the CPU oracle under oracle/ is test infrastructure and is never
+imported from this package).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libcookmatch.so")
+
+EXPORTS = [
+    "cook_engine_create", "cook_engine_destroy", "cook_engine_set_params", "cook_last_error", "cook_version",
+    "cook_rank", "cook_rank_stage", "cook_rank_set_quota", "cook_rank_pool_usage", "cook_rank_run", "cook_rank_fetch",
+    "cook_match", "cook_match_stage", "cook_match_run", "cook_match_fetch",
+    "cook_cycle_stage", "cook_cycle_run", "cook_cycle_fetch",
+    "cook_rebalance", "cook_last_timing", "cook_kernel_timings", "cook_set_profiling",
+]
+
+
+class CookError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"cookmatch error {code}: {msg}")
+        self.code = code
+
+
+_LIBS = {}
+
+
+def load_library(path: Optional[str] = None):
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path in _LIBS:
+        return _LIBS[path]
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found: build the HIP extension first (python -m cook_amd.build). "
+            "cook_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError if the ABI is incomplete
+    lib.cook_last_error.restype = C.c_char_p
+    lib.cook_version.restype = C.c_char_p
+    lib.cook_engine_create.argtypes = [C.POINTER(A.CookParams), C.c_int, C.POINTER(C.c_void_p)]
+    lib.cook_engine_destroy.argtypes = [C.c_void_p]
+    lib.cook_last_error.argtypes = [C.c_void_p]
+    _LIBS[path] = lib
+    return lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Engine:
+    """One engine per pool (one HIP stream); not re-entrant (cookmatch.h conventions)."""
+
+    def __init__(self, params: Optional[A.CookParams] = None, device: int = 0, lib_path: Optional[str] = None):
+        self._lib = load_library(lib_path)
+        self.params = params or A.default_params()
+        h = C.c_void_p()
+        rc = self._lib.cook_engine_create(C.byref(self.params), int(device), C.byref(h))
+        if rc != 0 or not h:
+            raise CookError(rc, "cook_engine_create failed (no visible MI355X / HIP runtime error); "
+                                "cook_amd has no CPU fallback")
+        self._h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cook_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def version(self) -> str:
+        return self._lib.cook_version().decode()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise CookError(rc, self._lib.cook_last_error(self._h).decode())
+
+    def set_params(self, params: A.CookParams):
+        self.params = params
+        self._chk(self._lib.cook_engine_set_params(self._h, C.byref(params)))
+
+    # ---- rank --------------------------------------------------------------------------------------------
+    def rank_stage(self, tasks: A.Tasks, users: A.Users):
+        ts, us = tasks.as_struct(), users.as_struct()
+        self._rank_n, self._rank_np = tasks.n, int(tasks.pending.sum()) if tasks.n else 0
+        self._chk(self._lib.cook_rank_stage(self._h, C.byref(ts), C.byref(us)))
+
+    def rank_set_quota(self, quota: Optional[A.CookPoolQuota]):
+        self._chk(self._lib.cook_rank_set_quota(self._h, C.byref(quota) if quota is not None else None))
+
+    def rank_pool_usage(self) -> A.CookUsage:
+        u = A.CookUsage()
+        self._chk(self._lib.cook_rank_pool_usage(self._h, C.byref(u)))
+        return u
+
+    def rank_run(self):
+        self._chk(self._lib.cook_rank_run(self._h))
+
+    def rank_fetch(self, want_dru: bool = True):
+        out = np.zeros(max(1, self._rank_np), dtype=np.uint32)
+        dru = np.zeros(max(1, self._rank_n), dtype=np.float64) if want_dru else None
+        n = C.c_uint32(0)
+        self._chk(self._lib.cook_rank_fetch(self._h, _p(out, C.c_uint32), C.byref(n),
+                                            _p(dru, C.c_double) if want_dru else None))
+        return out[: n.value].copy(), (dru[: self._rank_n].copy() if want_dru else None)
+
+    def rank(self, tasks: A.Tasks, users: A.Users, quota: Optional[A.CookPoolQuota] = None, want_dru: bool = True):
+        """sort-jobs-by-dru-helper + filter-based-on-quota + filter-offensive-jobs -> (ranked task idx, dru per task)."""
+        self.rank_stage(tasks, users)
+        self.rank_set_quota(quota)
+        self.rank_run()
+        return self.rank_fetch(want_dru)
+
+    # ---- match -------------------------------------------------------------------------------------------
+    def match_stage(self, jobs: A.Jobs, offers: A.Offers, groups: Optional[A.Groups] = None,
+                    reserved_hosts: Sequence[int] = ()):
+        js, os_ = jobs.as_struct(), offers.as_struct()
+        gs = groups.as_struct() if groups is not None else None
+        res = np.array(list(reserved_hosts) or [0], dtype=np.uint32)
+        self._match_k = jobs.n
+        self._chk(self._lib.cook_match_stage(self._h, C.byref(js), C.byref(os_), C.byref(gs) if gs is not None else None,
+                                             _p(res, C.c_uint32), len(reserved_hosts)))
+
+    def match_run(self):
+        self._chk(self._lib.cook_match_run(self._h))
+
+    def match_fetch(self, k: Optional[int] = None):
+        k = self._match_k if k is None else k
+        j2o = np.full(max(1, k), -1, dtype=np.int32)
+        fail = np.zeros(max(1, k), dtype=np.uint32)
+        head = C.c_uint8(0)
+        self._chk(self._lib.cook_match_fetch(self._h, _p(j2o, C.c_int32), _p(fail, C.c_uint32), C.byref(head)))
+        return j2o[:k].copy(), fail[:k].copy(), bool(head.value)
+
+    def match(self, jobs: A.Jobs, offers: A.Offers, groups: Optional[A.Groups] = None, reserved_hosts: Sequence[int] = ()):
+        """Body of match-offer-to-schedule: -> (job_to_offer, fail_code, head_matched)."""
+        self.match_stage(jobs, offers, groups, reserved_hosts)
+        self.match_run()
+        return self.match_fetch()
+
+    # ---- rank + match without a host round trip --------------------------------------------------------------
+    def cycle_stage(self, tasks: A.Tasks, users: A.Users, pending_jobs: A.Jobs, offers: A.Offers,
+                    groups: Optional[A.Groups] = None, reserved_hosts: Sequence[int] = ()):
+        ts, us, js, os_ = tasks.as_struct(), users.as_struct(), pending_jobs.as_struct(), offers.as_struct()
+        gs = groups.as_struct() if groups is not None else None
+        res = np.array(list(reserved_hosts) or [0], dtype=np.uint32)
+        self._rank_n, self._rank_np = tasks.n, int(tasks.pending.sum()) if tasks.n else 0
+        self._chk(self._lib.cook_cycle_stage(self._h, C.byref(ts), C.byref(us), C.byref(js), C.byref(os_),
+                                             C.byref(gs) if gs is not None else None, _p(res, C.c_uint32),
+                                             len(reserved_hosts)))
+
+    def cycle_run(self, num_considerable: int):
+        self._chk(self._lib.cook_cycle_run(self._h, int(num_considerable)))
+
+    def cycle_fetch(self):
+        ranked = np.zeros(max(1, self._rank_np), dtype=np.uint32)
+        j2o = np.full(max(1, self._rank_np), -1, dtype=np.int32)
+        n, k = C.c_uint32(0), C.c_uint32(0)
+        head = C.c_uint8(0)
+        self._chk(self._lib.cook_cycle_fetch(self._h, _p(ranked, C.c_uint32), C.byref(n), _p(j2o, C.c_int32),
+                                             C.byref(k), C.byref(head)))
+        return ranked[: n.value].copy(), j2o[: k.value].copy(), bool(head.value)
+
+    # ---- measurement -----------------------------------------------------------------------------------------
+    def last_timing(self):
+        r, m = C.c_double(0), C.c_double(0)
+        self._lib.cook_last_timing(self._h, C.byref(r), C.byref(m))
+        return r.value, m.value
+
+    def set_profiling(self, on: bool):
+        self._lib.cook_set_profiling(self._h, int(bool(on)))
+
+    def kernel_timings(self):
+        cap = 128
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        launches = (C.c_uint32 * cap)()
+        n = self._lib.cook_kernel_timings(self._h, names, ms, launches, cap)
+        return {names[i].decode(): (ms[i], launches[i]) for i in range(max(0, n))}

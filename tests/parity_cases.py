@@ -1,0 +1,92 @@
+"""Parity checks shared by the CPU-emulated build (tests/test_parity_emu.py) and the real HIP build
+(tests/test_parity_gpu.py, -m gpu): the engine behind the C ABI vs the oracle on the same seeded inputs,
+and vs the reference's own golden vectors.  Bit-exact: ranked order (uint32), DRU (fp64 ==), assignments (int32)."""
+import numpy as np
+
+from cook_amd import _abi as A
+from cook_amd import synth
+from oracle import pyoracle
+from tests import golden_util as G
+
+
+def check_rank_golden(make_engine):
+    for case in G.load("rank"):
+        tasks, users, names, _ = G.build_rank_inputs(case["jobs"], case["shares"], case.get("quotas"))
+        p = A.default_params(dru_mode=case.get("dru_mode", 0), max_over_quota_jobs=case.get("max_over_quota_jobs", 100))
+        with make_engine(p) as e:
+            ranked, dru = e.rank(tasks, users)
+        o_ranked, o_dru = pyoracle.rank(p, tasks, users)
+        assert list(ranked) == list(o_ranked), case["name"]
+        assert np.array_equal(dru, o_dru, equal_nan=True), case["name"]
+        if "expect_ranked" in case:
+            assert [names[i] for i in ranked] == case["expect_ranked"], (case["name"], case["ref"])
+
+
+def check_rank_group_golden(make_engine):
+    for case in G.load("rank_group"):
+        built, usages = {}, {}
+        for pool, spec in case["pools"].items():
+            tasks, users, names, _ = G.build_rank_inputs(spec["jobs"], case["shares"])
+            built[pool] = (tasks, users, names)
+            with make_engine(A.default_params()) as e:
+                e.rank_stage(tasks, users)
+                usages[pool] = e.rank_pool_usage()  # device reduction of the pool's running usage
+            assert usages[pool].as_tuple() == pyoracle.pool_usage(tasks).as_tuple()
+        gu = A.usage(*[sum(getattr(u, f) for u in usages.values()) for f in ("count", "cpus", "mem", "gpus")])
+        for pool, spec in case["pools"].items():
+            tasks, users, names = built[pool]
+            q = A.pool_quota(pool_quota=G.usage_of(spec["quota"]), group_quota=G.usage_of(case["group_quota"]), group_usage=gu)
+            with make_engine(A.default_params()) as e:
+                ranked, _ = e.rank(tasks, users, quota=q)
+            assert [names[i] for i in ranked] == spec["expect_ranked"], (case["name"], pool)
+
+
+def check_match_golden(make_engine):
+    for case in G.load("match"):
+        J, O, names = G.build_match_inputs(case)
+        p = A.default_params(good_enough_fitness=case["good_enough"])
+        with make_engine(p) as e:
+            j2o, fail, head = e.match(J, O)
+        o_j2o, o_fail, o_head = pyoracle.match(p, J, O)
+        assert np.array_equal(j2o, o_j2o), case["name"]
+        assert np.array_equal(fail, o_fail), case["name"]
+        assert head == o_head, case["name"]
+        matched = sorted(names[k] for k in range(J.n) if j2o[k] >= 0)
+        assert matched == sorted(case["expect_matched"]), (case["name"], case["ref"])
+
+
+def rank_parity(make_engine, pool: synth.Pool, params, quota=None):
+    with make_engine(params) as e:
+        ranked, dru = e.rank(pool.tasks, pool.users, quota=quota)
+    o_ranked, o_dru = pyoracle.rank(params, pool.tasks, pool.users, quota=quota)
+    assert len(ranked) == len(o_ranked)
+    bad = np.nonzero(ranked != o_ranked)[0]
+    assert len(bad) == 0, f"rank order differs first at {bad[:5]} of {len(ranked)}"
+    assert np.array_equal(dru, o_dru, equal_nan=True)
+    return ranked
+
+
+def match_parity(make_engine, jobs, offers, groups, params, reserved=()):
+    with make_engine(params) as e:
+        j2o, fail, head = e.match(jobs, offers, groups, reserved)
+    o_j2o, o_fail, o_head = pyoracle.match(params, jobs, offers, groups, reserved)
+    bad = np.nonzero(j2o != o_j2o)[0]
+    assert len(bad) == 0, f"assignment differs first at job {bad[:5]}: {j2o[bad[:5]]} vs {o_j2o[bad[:5]]}"
+    assert np.array_equal(fail, o_fail)
+    assert head == o_head
+    return j2o
+
+
+def cycle_parity(make_engine, pool: synth.Pool, params, k):
+    with make_engine(params) as e:
+        e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        e.cycle_run(k)
+        ranked, j2o, head = e.cycle_fetch()
+    o_ranked, _ = pyoracle.rank(params, pool.tasks, pool.users)
+    assert np.array_equal(ranked, o_ranked)
+    pend_ord = np.cumsum(pool.tasks.pending) - 1
+    considerable = pool.pending_jobs.take(pend_ord[o_ranked[:k]])
+    o_j2o, _, o_head = pyoracle.match(params, considerable, pool.offers, pool.groups)
+    assert np.array_equal(j2o, o_j2o)
+    assert head == o_head
+    return ranked, j2o

@@ -1,0 +1,304 @@
+// tests/simt_emu/hip/hip_runtime.h — TEST INFRASTRUCTURE.  A tiny single-process SIMT emulator that stands in
+// for <hip/hip_runtime.h> so the SAME .hip sources of cook_amd/csrc can be compiled with g++ and exercised on
+// a machine without a GPU (this container).  It is NOT a compatibility layer of the product: libcookmatch.so is
+// built by hipcc for gfx950 only; this header exists so that kernel LOGIC (indexing, scans, sort passes, the
+// placement loop) is checked against the oracle before GPU minutes are spent.  It does not model memory
+// ordering, LDS banking, occupancy or timing.
+//
+// Model: one OS thread; every GPU thread of a block is a ucontext fiber; blocks of a grid run one after another
+// (so kernels must not wait on other blocks); a wave is 64 consecutive threads; wave collectives and
+// __syncthreads are rendezvous points at which fibers yield.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __HIP_EMU__ 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __constant__ static
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+struct emuStream {
+  int dummy;
+};
+struct emuEvent {
+  double t;
+};
+typedef emuStream* hipStream_t;
+typedef emuEvent* hipEvent_t;
+struct hipDeviceProp_t {
+  char name[64];
+  int multiProcessorCount;
+  size_t totalGlobalMem;
+  char gcnArchName[64];
+};
+#define hipStreamNonBlocking 1
+#define hipHostMallocDefault 0
+#define hipEventDefault 0
+
+namespace emu {
+struct Group {
+  unsigned size = 0, count = 0;
+  uint64_t gen = 0;
+};
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = true;
+  unsigned tid = 0;
+  dim3 tidx;
+};
+struct State {
+  ucontext_t main_ctx;
+  std::vector<Fiber> fibers;
+  Fiber* cur = nullptr;
+  dim3 blockIdx_, blockDim_, gridDim_;
+  Group block;
+  std::vector<Group> waves;
+  std::vector<uint64_t> xchg;  // 64 slots per wave
+  std::vector<uint64_t> ballot;
+  const std::function<void()>* body = nullptr;
+  uint64_t events = 0;  // rendezvous completions + thread exits (progress detector)
+};
+State& S();
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void arrive(Group& g);
+inline unsigned lane() { return S().cur->tid & 63u; }
+inline unsigned wave() { return S().cur->tid >> 6; }
+inline unsigned wave_size() { return S().waves[wave()].size; }
+
+template <class T>
+inline uint64_t bits_of(T v) {
+  uint64_t b = 0;
+  static_assert(sizeof(T) <= 8, "shfl payload");
+  std::memcpy(&b, &v, sizeof(T));
+  return b;
+}
+template <class T>
+inline T from_bits(uint64_t b) {
+  T v;
+  std::memcpy(&v, &b, sizeof(T));
+  return v;
+}
+template <class T>
+inline T shfl_idx(T v, int src) {
+  State& s = S();
+  const unsigned w = wave(), l = lane();
+  s.xchg[w * 64 + l] = bits_of(v);
+  arrive(s.waves[w]);
+  const unsigned n = s.waves[w].size;
+  T r = (src >= 0 && (unsigned)src < n) ? from_bits<T>(s.xchg[w * 64 + (unsigned)src]) : v;
+  arrive(s.waves[w]);
+  return r;
+}
+}  // namespace emu
+
+#define threadIdx (emu::S().cur->tidx)
+#define blockIdx (emu::S().blockIdx_)
+#define blockDim (emu::S().blockDim_)
+#define gridDim (emu::S().gridDim_)
+static const int warpSize = 64;
+
+inline void __syncthreads() { emu::arrive(emu::S().block); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+template <class T>
+inline T __shfl(T v, int src, int width = 64) {
+  (void)width;
+  return emu::shfl_idx(v, src);
+}
+template <class T>
+inline T __shfl_up(T v, unsigned d, int width = 64) {
+  (void)width;
+  int l = (int)emu::lane();
+  return emu::shfl_idx(v, l - (int)d >= 0 ? l - (int)d : l);
+}
+template <class T>
+inline T __shfl_down(T v, unsigned d, int width = 64) {
+  (void)width;
+  int l = (int)emu::lane();
+  return emu::shfl_idx(v, l + (int)d < 64 ? l + (int)d : l);
+}
+template <class T>
+inline T __shfl_xor(T v, int m, int width = 64) {
+  (void)width;
+  return emu::shfl_idx(v, (int)emu::lane() ^ m);
+}
+inline unsigned long long __ballot(int pred) {
+  emu::State& s = emu::S();
+  const unsigned w = emu::wave(), l = emu::lane();
+  s.xchg[w * 64 + l] = pred ? 1 : 0;
+  emu::arrive(s.waves[w]);
+  unsigned long long m = 0;
+  for (unsigned i = 0; i < s.waves[w].size; ++i) m |= (unsigned long long)(s.xchg[w * 64 + i] & 1) << i;
+  emu::arrive(s.waves[w]);
+  return m;
+}
+inline int __any(int p) { return __ballot(p) != 0; }
+inline int __all(int p) {
+  unsigned n = emu::wave_size();
+  unsigned long long full = n >= 64 ? ~0ull : ((1ull << n) - 1);
+  return __ballot(p) == full;
+}
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
+inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
+inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
+inline long long __double_as_longlong(double d) { return emu::from_bits<long long>(emu::bits_of(d)); }
+inline double __longlong_as_double(long long v) { return emu::from_bits<double>(emu::bits_of(v)); }
+inline unsigned __lane_id() { return emu::lane(); }
+
+template <class T>
+inline T atomicAdd(T* p, T v) {
+  T o = *p;
+  *p = o + v;
+  return o;
+}
+template <class T>
+inline T atomicMax(T* p, T v) {
+  T o = *p;
+  if (v > o) *p = v;
+  return o;
+}
+template <class T>
+inline T atomicMin(T* p, T v) {
+  T o = *p;
+  if (v < o) *p = v;
+  return o;
+}
+template <class T>
+inline T atomicExch(T* p, T v) {
+  T o = *p;
+  *p = v;
+  return o;
+}
+template <class T>
+inline T atomicCAS(T* p, T cmp, T v) {
+  T o = *p;
+  if (o == cmp) *p = v;
+  return o;
+}
+template <class T>
+inline T atomicOr(T* p, T v) {
+  T o = *p;
+  *p = o | v;
+  return o;
+}
+template <class T>
+inline T atomicAnd(T* p, T v) {
+  T o = *p;
+  *p = o & v;
+  return o;
+}
+
+// ---- runtime API ------------------------------------------------------------------------------------
+inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess(emu)" : "hipError(emu)"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) {
+  *n = 1;
+  return hipSuccess;
+}
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+  std::memset(p, 0, sizeof(*p));
+  std::snprintf(p->name, sizeof(p->name), "simt-emu");
+  std::snprintf(p->gcnArchName, sizeof(p->gcnArchName), "emu");
+  p->multiProcessorCount = 4;
+  p->totalGlobalMem = 1ull << 32;
+  return hipSuccess;
+}
+inline hipError_t hipMalloc(void** p, size_t n) {
+  *p = std::malloc(n ? n : 1);
+  if (*p) std::memset(*p, 0xCD, n);  // poison: catches reads of uninitialised device memory
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+template <class T>
+inline hipError_t hipMalloc(T** p, size_t n) {
+  return hipMalloc((void**)p, n);
+}
+inline hipError_t hipFree(void* p) {
+  std::free(p);
+  return hipSuccess;
+}
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) {
+  *p = std::malloc(n ? n : 1);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+template <class T>
+inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) {
+  return hipHostMalloc((void**)p, n, f);
+}
+inline hipError_t hipHostFree(void* p) {
+  std::free(p);
+  return hipSuccess;
+}
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+  if (n) std::memmove(d, s, n);
+  return hipSuccess;
+}
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t = nullptr) {
+  return hipMemcpy(d, s, n, k);
+}
+inline hipError_t hipMemset(void* d, int v, size_t n) {
+  if (n) std::memset(d, v, n);
+  return hipSuccess;
+}
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { return hipMemset(d, v, n); }
+inline hipError_t hipStreamCreate(hipStream_t* s) {
+  *s = new emuStream{0};
+  return hipSuccess;
+}
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+inline hipError_t hipStreamDestroy(hipStream_t s) {
+  delete s;
+  return hipSuccess;
+}
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+double emu_now_ms();
+inline hipError_t hipEventCreate(hipEvent_t* e) {
+  *e = new emuEvent{0};
+  return hipSuccess;
+}
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipEventDestroy(hipEvent_t e) {
+  delete e;
+  return hipSuccess;
+}
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
+  e->t = emu_now_ms();
+  return hipSuccess;
+}
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = (float)(b->t - a->t);
+  return hipSuccess;
+}
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)              \
+  do {                                                                           \
+    std::function<void()> _emu_body = [&]() { kernel(__VA_ARGS__); };            \
+    emu::launch(dim3(grid), dim3(block), _emu_body);                             \
+  } while (0)

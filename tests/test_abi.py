@@ -1,0 +1,60 @@
+"""The C-ABI shared library loads and exports every symbol include/cookmatch.h declares (no compute without a GPU);
+on a machine without a GPU engine creation must fail loudly instead of falling back to the CPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from cook_amd import _abi as A
+from cook_amd import build, engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "cookmatch.h")).read()
+    return sorted(set(re.findall(r"^\s*(?:int|void|const char\*)\s+(cook_\w+)\s*\(", txt, flags=re.M)))
+
+
+def test_header_symbols_exported():
+    so = build.build()
+    lib = C.CDLL(so)
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/cookmatch.h but not exported by libcookmatch.so"
+    assert sorted(engine.EXPORTS) == syms
+
+
+def test_struct_sizes_match_header(tmp_path):
+    # compile a tiny C program against the header and compare sizeof() with the ctypes mirrors
+    src = tmp_path / "sz.c"
+    names = ["cook_params", "cook_usage", "cook_tasks", "cook_users", "cook_pool_quota", "cook_jobs", "cook_offers",
+             "cook_groups", "cook_rebalance_params", "cook_host_spare", "cook_preemption"]
+    src.write_text('#include <stdio.h>\n#include "cookmatch.h"\nint main(){' +
+                   "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}")
+    exe = tmp_path / "sz"
+    import subprocess
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    mirrors = [A.CookParams, A.CookUsage, A.CookTasks, A.CookUsers, A.CookPoolQuota, A.CookJobs, A.CookOffers,
+               A.CookGroups, A.CookRebalanceParams, A.CookHostSpare, A.CookPreemption]
+    assert sizes == [C.sizeof(m) for m in mirrors]
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    build.build()
+    with pytest.raises(engine.CookError):
+        engine.Engine(A.default_params())
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "cook_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "libcookoracle" not in txt and "cook_oracle" not in txt, f

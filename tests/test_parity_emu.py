@@ -1,0 +1,88 @@
+"""C-ABI parity on a machine WITHOUT a GPU: the same cook_amd/csrc sources compiled against the SIMT emulator
+(tests/simt_emu).  Checks kernel logic + host orchestration against the oracle; small sizes (the emulator is slow)."""
+import numpy as np
+import pytest
+
+from cook_amd import _abi as A
+from cook_amd import synth
+from cook_amd.engine import Engine
+from tests import parity_cases as P
+
+
+@pytest.fixture(scope="module")
+def make_engine():
+    from tests.simt_emu import build_emu
+    so = build_emu.build()
+    return lambda params: Engine(params, lib_path=so)
+
+
+def test_rank_golden(make_engine):
+    P.check_rank_golden(make_engine)
+
+
+def test_rank_group_golden(make_engine):
+    P.check_rank_group_golden(make_engine)
+
+
+def test_match_golden(make_engine):
+    P.check_match_golden(make_engine)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(seed=1, n_pending=700, n_running=300, n_users=40, n_offers=50),
+    dict(seed=2, n_pending=5000, n_running=1500, n_users=300, n_offers=50),          # multi-block scans / sorts
+    dict(seed=3, n_pending=900, n_running=300, n_users=25, n_offers=50, tie_heavy=True),
+    dict(seed=4, n_pending=900, n_running=300, n_users=25, n_offers=50, fractional=True),
+    dict(seed=5, n_pending=900, n_running=300, n_users=25, n_offers=50, no_shares=True),
+    dict(seed=6, n_pending=600, n_running=0, n_users=7, n_offers=10, tie_heavy=True, quota_frac=0.5),
+], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items() if k != "n_offers"))
+def test_rank_parity_random(make_engine, kw):
+    pool = synth.make_pool(**kw)
+    P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=10))
+
+
+def test_rank_parity_gpu_mode_and_quota(make_engine):
+    pool = synth.make_pool(seed=11, n_pending=800, n_running=400, n_users=30, n_offers=20, gpus=True)
+    # give every task a gpu so the gpu-mode scores increase strictly
+    pool.tasks.gpus[:] = np.maximum(pool.tasks.gpus, 1.0)
+    P.rank_parity(make_engine, pool, A.default_params(dru_mode=1))
+    q = A.pool_quota(pool_quota=A.quota(count=600, cpus=2500.0), group_quota=A.quota(mem=4.0e6),
+                     group_usage=A.usage(count=10, cpus=100, mem=1.0e6))
+    P.rank_parity(make_engine, pool, A.default_params(offensive_max_mem_mb=16000.0, offensive_max_cpus=6.0), quota=q)
+
+
+def test_rank_edge_cases(make_engine):
+    p = A.default_params()
+    # empty input
+    empty = A.Tasks(cpus=np.zeros(0), mem=np.zeros(0), user=np.zeros(0), priority=np.zeros(0), start_ms=np.zeros(0),
+                    task_id=np.zeros(0), job_id=np.zeros(0), pending=np.zeros(0))
+    users = A.Users(div_cpus=np.ones(1), div_mem=np.ones(1))
+    with make_engine(p) as e:
+        ranked, _ = e.rank(empty, users)
+    assert len(ranked) == 0
+    # only running tasks -> empty queue; a single pending job
+    pool = synth.make_pool(seed=3, n_pending=0, n_running=50, n_users=5, n_offers=4)
+    assert len(P.rank_parity(make_engine, pool, p)) == 0
+    pool = synth.make_pool(seed=3, n_pending=1, n_running=0, n_users=1, n_offers=4)
+    assert len(P.rank_parity(make_engine, pool, p)) == 1
+    # limiter that drops almost everything
+    pool = synth.make_pool(seed=9, n_pending=300, n_running=50, n_users=3, n_offers=4, quota_frac=1.0)
+    P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=0))
+
+
+@pytest.mark.parametrize("ge", [1.0, 0.8])
+def test_match_parity_random(make_engine, ge):
+    pool = synth.make_pool(seed=21, n_pending=400, n_running=100, n_users=20, n_offers=300)
+    P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, A.default_params(good_enough_fitness=ge))
+
+
+def test_match_parity_constraints(make_engine):
+    pool = synth.make_pool(seed=22, n_pending=400, n_running=100, n_users=20, n_offers=200, gpus=True, constraints=True)
+    j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, A.default_params(good_enough_fitness=1.0),
+                         reserved=(3, 7, 150))
+    assert (j2o >= 0).sum() > 50
+
+
+def test_cycle_parity(make_engine):
+    pool = synth.make_pool(seed=31, n_pending=600, n_running=200, n_users=30, n_offers=100, gpus=True, constraints=True)
+    P.cycle_parity(make_engine, pool, A.default_params(good_enough_fitness=1.0), k=150)

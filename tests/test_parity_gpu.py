@@ -1,0 +1,128 @@
+"""Parity tests proper: the HIP engine (cook_amd/libcookmatch.so, gfx950) behind the C ABI vs the CPU oracle and the
+reference's golden vectors.  Run on the GPU box with `pytest -m gpu`.  No CPU fallback: if the extension or the GPU
+is missing these tests FAIL."""
+import numpy as np
+import pytest
+
+from cook_amd import _abi as A
+from cook_amd import synth
+from cook_amd.engine import Engine
+from tests import parity_cases as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def make_engine():
+    from cook_amd import build
+    so = build.build()  # no-op when the in-tree .so is current (hipcc is present on the GPU box too)
+    return lambda params: Engine(params, lib_path=so)
+
+
+def test_engine_is_hip_build(make_engine):
+    with make_engine(A.default_params()) as e:
+        assert "hip gfx950" in e.version
+
+
+def test_rank_golden(make_engine):
+    P.check_rank_golden(make_engine)
+
+
+def test_rank_group_golden(make_engine):
+    P.check_rank_group_golden(make_engine)
+
+
+def test_match_golden(make_engine):
+    P.check_match_golden(make_engine)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(seed=1, n_pending=700, n_running=300, n_users=40, n_offers=50),
+    dict(seed=2, n_pending=50000, n_running=20000, n_users=1000, n_offers=50),          # BASELINE config C2 rank shape
+    dict(seed=3, n_pending=20000, n_running=5000, n_users=200, n_offers=50, tie_heavy=True),
+    dict(seed=4, n_pending=20000, n_running=5000, n_users=200, n_offers=50, fractional=True),
+    dict(seed=5, n_pending=20000, n_running=5000, n_users=200, n_offers=50, no_shares=True),
+    dict(seed=6, n_pending=6000, n_running=0, n_users=7, n_offers=10, tie_heavy=True, quota_frac=0.5),
+    dict(seed=7, n_pending=125000, n_running=50000, n_users=10000, n_offers=50),        # one C4 pool
+], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items() if k != "n_offers"))
+def test_rank_parity_random(make_engine, kw):
+    pool = synth.make_pool(**kw)
+    P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=10))
+
+
+def test_rank_parity_gpu_mode_and_quota(make_engine):
+    pool = synth.make_pool(seed=11, n_pending=8000, n_running=4000, n_users=300, n_offers=20, gpus=True)
+    pool.tasks.gpus[:] = np.maximum(pool.tasks.gpus, 1.0)
+    P.rank_parity(make_engine, pool, A.default_params(dru_mode=1))
+    q = A.pool_quota(pool_quota=A.quota(count=6000, cpus=25000.0), group_quota=A.quota(mem=4.0e7),
+                     group_usage=A.usage(count=10, cpus=100, mem=1.0e6))
+    P.rank_parity(make_engine, pool, A.default_params(offensive_max_mem_mb=16000.0, offensive_max_cpus=6.0), quota=q)
+
+
+def test_rank_edge_cases(make_engine):
+    p = A.default_params()
+    empty = A.Tasks(cpus=np.zeros(0), mem=np.zeros(0), user=np.zeros(0), priority=np.zeros(0), start_ms=np.zeros(0),
+                    task_id=np.zeros(0), job_id=np.zeros(0), pending=np.zeros(0))
+    users = A.Users(div_cpus=np.ones(1), div_mem=np.ones(1))
+    with make_engine(p) as e:
+        ranked, _ = e.rank(empty, users)
+    assert len(ranked) == 0
+    pool = synth.make_pool(seed=3, n_pending=0, n_running=50, n_users=5, n_offers=4)
+    assert len(P.rank_parity(make_engine, pool, p)) == 0
+    pool = synth.make_pool(seed=3, n_pending=1, n_running=0, n_users=1, n_offers=4)
+    assert len(P.rank_parity(make_engine, pool, p)) == 1
+    pool = synth.make_pool(seed=9, n_pending=3000, n_running=500, n_users=3, n_offers=4, quota_frac=1.0)
+    P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=0))
+
+
+@pytest.mark.parametrize("ge", [1.0, 0.8])
+def test_match_parity_c2(make_engine, ge):
+    # BASELINE config C2: cpus+mem only, 5k offers; K = first 3000 pending jobs in input order
+    pool = synth.make_pool(seed=21, n_pending=3000, n_running=100, n_users=200, n_offers=5000)
+    P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, A.default_params(good_enough_fitness=ge))
+
+
+def test_match_parity_c3_constraints(make_engine):
+    # BASELINE config C3 shape: host/attribute constraints + gpu dimension + unique groups (scaled to oracle-seconds)
+    pool = synth.make_pool(seed=22, n_pending=4000, n_running=1000, n_users=200, n_offers=2000, gpus=True, constraints=True)
+    j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, A.default_params(good_enough_fitness=1.0),
+                         reserved=(3, 7, 150))
+    assert (j2o >= 0).sum() > 500
+
+
+def test_match_fills_cluster_then_fails(make_engine):
+    # more demand than capacity: the tail of the queue must fail exactly like the oracle (fail codes included)
+    pool = synth.make_pool(seed=23, n_pending=6000, n_running=0, n_users=50, n_offers=200)
+    j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, A.default_params(good_enough_fitness=1.0))
+    assert (j2o < 0).sum() > 1000
+
+
+def test_cycle_parity(make_engine):
+    pool = synth.make_pool(seed=31, n_pending=20000, n_running=8000, n_users=500, n_offers=2000, gpus=True, constraints=True)
+    P.cycle_parity(make_engine, pool, A.default_params(good_enough_fitness=1.0), k=1000)
+
+
+def test_size_independent_properties_full_pool(make_engine):
+    """One full C4 pool (125k pending x 6250 offers, K=2000): properties that need no oracle at full size."""
+    pool = synth.make_pool(seed=41, n_pending=125000, n_running=50000, n_users=10000, n_offers=6250)
+    p = A.default_params(good_enough_fitness=1.0)
+    with make_engine(p) as e:
+        e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        e.cycle_run(2000)
+        ranked, j2o, head = e.cycle_fetch()
+        _, dru = e.rank_fetch(want_dru=True)
+    # ranked is a permutation of (a subset of) the pending tasks, DRU non-decreasing along it
+    assert len(set(ranked.tolist())) == len(ranked) and pool.tasks.pending[ranked].all()
+    assert np.all(np.diff(dru[ranked]) >= 0)
+    # no offer is over-committed
+    pend_ord = np.cumsum(pool.tasks.pending) - 1
+    jobs = pend_ord[ranked[: len(j2o)]]
+    used_c = np.bincount(j2o[j2o >= 0], weights=pool.pending_jobs.cpus[jobs][j2o >= 0], minlength=pool.offers.n)
+    used_m = np.bincount(j2o[j2o >= 0], weights=pool.pending_jobs.mem[jobs][j2o >= 0], minlength=pool.offers.n)
+    assert np.all(used_c <= pool.offers.cpus) and np.all(used_m <= pool.offers.mem)
+    # idempotence: the same staged inputs give the same answer again
+    with make_engine(p) as e:
+        e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        e.cycle_run(2000)
+        ranked2, j2o2, _ = e.cycle_fetch()
+    assert np.array_equal(ranked, ranked2) and np.array_equal(j2o, j2o2)
