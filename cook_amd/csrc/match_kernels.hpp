@@ -2,7 +2,7 @@
 // Fenzo's TaskScheduler.scheduleOnce (scheduler.clj:617-687, 2301-2324) with cpuMemBinPacker fitness (config.clj:108)
 // and Cook's hard constraints (constraints.clj).
 //
-// Semantics (restated in oracle/cook_oracle.cpp): for each job in rank order, among the
+// Semantics (DESIGN.md "placement"): for each job in rank order, among the
 // offers that still have room and pass every constraint pick the one with the strictly greatest fitness
 //   ((run_cpus + assigned_cpus + job.cpus) / (offer.cpus + run_cpus) + (same for mem)) / 2
 // (lowest offer index on ties; the first offer in array order whose fitness exceeds good-enough wins outright), then

@@ -39,6 +39,13 @@ def load_library(path: Optional[str] = None):
     path = os.path.abspath(path or DEFAULT_LIB)
     if path in _LIBS:
         return _LIBS[path]
+    # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64 (same SONAME as /opt/rocm's).  Whichever HIP
+    # runtime is loaded FIRST serves the whole process, and mixing the two fails at hsa_init.  Every caller of this
+    # package (bench.py, smoke(), the tests) also uses torch for device plumbing, so load torch's runtime first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise FileNotFoundError(
             f"{path} not found: build the HIP extension first (python -m cook_amd.build). "
