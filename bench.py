@@ -237,7 +237,8 @@ def main():
                        "users": args.users, "considerable_per_pool": K, "good_enough_fitness": args.good_enough,
                        "parallelism": f"pools sharded over {world} GPU(s)", "pair_evaluations_per_cycle": considered * n_off},
             "last_cycle": {"ranked": ranked_n, "considered": considered, "matched": matched,
-                           "stage_ms_pool0": {"rank": stage_ms[my_pools[0]][0], "match": stage_ms[my_pools[0]][1]}},
+                           "stage_ms_pool0": {"rank": stage_ms[my_pools[0]][0], "match": stage_ms[my_pools[0]][1]},
+                           "placement_stats_pool0": engines[my_pools[0]].match_stats()},
             "setup_s": gen_s,
             "roofline": roofline, "cpu_baseline": cpu,
         }

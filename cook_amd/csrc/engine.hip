@@ -13,6 +13,7 @@
 #include "../../include/cookmatch.h"
 #include "common.hpp"
 #include "match_kernels.hpp"
+#include "match_window.hpp"
 #include "rank_kernels.hpp"
 #include "scan.hpp"
 #include "sort.hpp"
@@ -124,6 +125,11 @@ struct cook_engine {
   DArr<int64_t> j_est_end, o_host_start;
   DArr<uint8_t> o_k8s, g_type;
   DArr<unsigned> m_summary;
+  DArr<double> w_cand_fit;
+  DArr<int> w_cand_idx, w_ncand, w_ge_idx, w_nge;
+  DArr<unsigned> w_failcnt;
+  DArr<WinCtl> w_ctl;
+  WinCtl last_ctl{};
   MatchIn min{};
   bool cycle_staged = false;
   unsigned cycle_considered = 0;
@@ -658,13 +664,65 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
     COOK_HIP(hipMemsetAsync(st.job_to_offer, 0xFF, (size_t)K * 4, e->stream));
   }
   COOK_HIP(hipMemsetAsync(st.summary, 0, 16, e->stream));
+  st.cutoff = 0x7FFFFFFF;
+  if (e->params.match_algo == 1) {  // one-job-at-a-time sweep by a single workgroup (reference implementation of the chain)
 #ifdef __HIP_EMU__
-  auto k_match = match_serial<256>;
-  KL("match_serial", k_match, 1, 256, in, st);
+    auto k_match = match_serial<256>;
+    KL("match_serial", k_match, 1, 256, in, st);
 #else
-  auto k_match = match_serial<1024>;
-  KL("match_serial", k_match, 1, 1024, in, st);
+    auto k_match = match_serial<1024>;
+    KL("match_serial", k_match, 1, 1024, in, st);
 #endif
+  } else if (K > 0) {  // windowed speculate + in-order resolve (match_window.hpp)
+#ifdef __HIP_EMU__
+    const unsigned wmax = 24;
+#else
+    const unsigned wmax = 512;
+#endif
+    WinBuf wb;
+    wb.cand_fit = e->w_cand_fit.ensure((size_t)wmax * MW_L);
+    wb.cand_idx = e->w_cand_idx.ensure((size_t)wmax * MW_L);
+    wb.ncand = e->w_ncand.ensure(wmax);
+    wb.ge_idx = e->w_ge_idx.ensure((size_t)wmax * MW_L);
+    wb.nge = e->w_nge.ensure(wmax);
+    wb.failcnt = e->w_failcnt.ensure((size_t)wmax * 3);
+    wb.ctl = e->w_ctl.ensure(1);
+    wb.wmax = wmax;
+    WinCtl c0;
+    std::memset(&c0, 0, sizeof(c0));
+    c0.wcur = std::min(wmax, 64u);
+    std::memcpy(e->h_scratch, &c0, sizeof(c0));
+    COOK_HIP(hipMemcpyAsync(wb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
+    unsigned batch = 4;
+    WinCtl hc = c0;
+    unsigned guard = 0;
+    while (hc.head < K) {
+      for (unsigned r = 0; r < batch; ++r) {
+        KL("match_window_eval", match_window_eval, wmax, MW_THREADS, in, st, wb);
+        KL("match_window_resolve", match_window_resolve, 1, COOK_WAVE, in, st, wb);
+      }
+      COOK_HIP(hipMemcpyAsync(e->h_scratch, wb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
+      sync(e);
+      const unsigned prev_head = hc.head, prev_rounds = hc.rounds;
+      std::memcpy(&hc, e->h_scratch, sizeof(WinCtl));
+      if (hc.head >= K) break;
+      // size the next batch from the observed jobs-per-round
+      const double per_round = (double)(hc.head - prev_head) / std::max(1u, hc.rounds - prev_rounds);
+      const double est = (K - hc.head) / std::max(1.0, per_round);
+      batch = (unsigned)std::min(64.0, std::max(2.0, est + 1.0));
+      if (++guard > 4u * K + 64u) e->fail(COOK_E_STATE, "cook_match: window placement made no progress");
+    }
+    e->last_ctl = hc;
+    unsigned sum[4] = {hc.matched, (hc.matched == 0 || hc.head_matched) ? 1u : 0u, hc.rounds, 0u};
+    std::memcpy(e->h_scratch, sum, 16);
+    COOK_HIP(hipMemcpyAsync(st.summary, e->h_scratch, 16, hipMemcpyHostToDevice, e->stream));
+    sync(e);
+  } else {
+    unsigned sum[4] = {0u, 1u, 0u, 0u};
+    std::memcpy(e->h_scratch, sum, 16);
+    COOK_HIP(hipMemcpyAsync(st.summary, e->h_scratch, 16, hipMemcpyHostToDevice, e->stream));
+    sync(e);
+  }
   e->cycle_considered = K;
   e->match_done = true;
 }
@@ -781,7 +839,7 @@ void cook_engine_destroy(cook_engine* e) {
                   &e->j_index.b, &e->o_host.b, &e->o_gpu_model.b, &e->o_disk_type.b, &e->o_attr.b, &e->o_location.b, &e->g_attr_key.b,
                   &e->g_run_off.b, &e->g_run_host.b, &e->g_run_attr.b, &e->reserved_bits.b, &e->m_fail.b, &e->j_reserved_host.b,
                   &e->o_max_tasks.b, &e->o_num_tasks.b, &e->o_run_count.b, &e->g_min.b, &e->m_acount.b, &e->m_group_last.b,
-                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b};
+                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b, &e->w_cand_fit.b, &e->w_cand_idx.b, &e->w_ncand.b, &e->w_ge_idx.b, &e->w_nge.b, &e->w_failcnt.b, &e->w_ctl.b};
   for (DBuf* b : bufs) b->release();
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i)
@@ -917,6 +975,19 @@ int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms) {
   if (!e) return COOK_E_INVALID;
   if (rank_ms) *rank_ms = e->rank_ms;
   if (match_ms) *match_ms = e->match_ms;
+  return COOK_OK;
+}
+int cook_match_stats(cook_engine* e, uint32_t out[8]) {
+  if (!e || !out) return COOK_E_INVALID;
+  const WinCtl& c = e->last_ctl;
+  out[0] = c.rounds;
+  out[1] = c.matched;
+  out[2] = c.stop_list;
+  out[3] = c.stop_full;
+  out[4] = c.stop_group;
+  out[5] = c.stop_window;
+  out[6] = c.wcur;
+  out[7] = c.head;
   return COOK_OK;
 }
 int cook_set_profiling(cook_engine* e, int enabled) {

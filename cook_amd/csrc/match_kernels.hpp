@@ -60,6 +60,7 @@ struct MatchState {
   int32_t* job_to_offer; // [K] output
   uint32_t* fail_code;   // [K] output
   unsigned* summary;     // [0] matched count, [1] head matched flag
+  int cutoff;            // unique-group check ignores placements by jobs with match index >= cutoff (INT_MAX = none)
 };
 
 static __device__ __forceinline__ uint32_t offer_attr_val(const MatchIn& in, unsigned v, uint32_t key) {
@@ -125,7 +126,7 @@ static __device__ __forceinline__ bool constraints_pass(const MatchIn& in, const
         for (unsigned x = r0; x < r1; ++x)
           if (in.g_run_host[x] == host) return false;
         for (int c = ld_agent(&st.group_last[g]); c >= 0; c = ld_agent(&st.job_prev[c]))
-          if (in.o_host[ld_agent(&st.job_to_offer[c])] == host) return false;
+          if (c < st.cutoff && in.o_host[ld_agent(&st.job_to_offer[c])] == host) return false;
       } else {
         // frequencies of the attribute over cotask hosts (running ++ placed in this call); nil (0) is a legal value
         const unsigned target = offer_attr_val(in, v, key);

@@ -22,7 +22,7 @@ EXPORTS = [
     "cook_rank", "cook_rank_stage", "cook_rank_set_quota", "cook_rank_pool_usage", "cook_rank_run", "cook_rank_fetch",
     "cook_match", "cook_match_stage", "cook_match_run", "cook_match_fetch",
     "cook_cycle_stage", "cook_cycle_run", "cook_cycle_fetch",
-    "cook_rebalance", "cook_last_timing", "cook_kernel_timings", "cook_set_profiling",
+    "cook_rebalance", "cook_last_timing", "cook_kernel_timings", "cook_set_profiling", "cook_match_stats",
 ]
 
 
@@ -196,6 +196,12 @@ class Engine:
         r, m = C.c_double(0), C.c_double(0)
         self._lib.cook_last_timing(self._h, C.byref(r), C.byref(m))
         return r.value, m.value
+
+    def match_stats(self):
+        out = (C.c_uint32 * 8)()
+        self._lib.cook_match_stats(self._h, out)
+        keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "window", "resolved")
+        return dict(zip(keys, [int(x) for x in out]))
 
     def set_profiling(self, on: bool):
         self._lib.cook_set_profiling(self._h, int(bool(on)))

@@ -70,17 +70,50 @@ def test_rank_edge_cases(make_engine):
     P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=0))
 
 
-@pytest.mark.parametrize("ge", [1.0, 0.8])
-def test_match_parity_random(make_engine, ge):
+ALGOS = pytest.mark.parametrize("algo", [0, 1], ids=["window", "serial"])
+
+
+@ALGOS
+@pytest.mark.parametrize("ge", [1.0, 0.8, 0.5])
+def test_match_parity_random(make_engine, ge, algo):
     pool = synth.make_pool(seed=21, n_pending=400, n_running=100, n_users=20, n_offers=300)
-    P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, A.default_params(good_enough_fitness=ge))
+    P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, A.default_params(good_enough_fitness=ge, match_algo=algo))
 
 
-def test_match_parity_constraints(make_engine):
+@ALGOS
+def test_match_parity_constraints(make_engine, algo):
     pool = synth.make_pool(seed=22, n_pending=400, n_running=100, n_users=20, n_offers=200, gpus=True, constraints=True)
-    j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, A.default_params(good_enough_fitness=1.0),
-                         reserved=(3, 7, 150))
+    j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups,
+                         A.default_params(good_enough_fitness=1.0, match_algo=algo), reserved=(3, 7, 150))
     assert (j2o >= 0).sum() > 50
+
+
+@ALGOS
+def test_match_overcommitted_cluster(make_engine, algo):
+    # demand >> capacity: hosts fill up, lists run out, the tail of the queue fails (fail codes must match too)
+    pool = synth.make_pool(seed=23, n_pending=500, n_running=0, n_users=10, n_offers=24)
+    j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, A.default_params(good_enough_fitness=1.0, match_algo=algo))
+    assert (j2o < 0).sum() > 100
+
+
+@ALGOS
+def test_match_group_types(make_engine, algo):
+    # balanced / attribute-equals / unique groups incl. running cotasks (constraints.clj:586-644)
+    rng = np.random.default_rng(5)
+    n, m = 120, 40
+    attr = np.zeros((m, 2), dtype=np.uint32)
+    attr[:, 0] = rng.integers(1, 4, m)
+    attr[:, 1] = rng.integers(0, 3, m)  # 0 = attribute absent on some hosts
+    offers = A.Offers(cpus=np.full(m, 8.0), mem=np.full(m, 16000.0), attr=attr, k8s=np.ones(m, dtype=np.uint8))
+    group = rng.integers(0, 6, n).astype(np.uint32)
+    group[rng.random(n) < 0.3] = A.NONE_U32
+    jobs = A.Jobs(cpus=rng.integers(1, 4, n).astype(float), mem=rng.integers(1, 4, n) * 1000.0, group=group)
+    groups = A.Groups(type=np.array([1, 2, 2, 3, 3, 0], dtype=np.uint8),
+                      attr_key=np.array([A.NONE_U32, 0, A.NONE_U32, 1, 0, 0], dtype=np.uint32),
+                      minimum=np.array([0, 3, 10, 0, 0, 0], dtype=np.int32),
+                      run_hosts=[[1, 2], [3], [], [], [5, 6], []],
+                      run_attrs=[[0, 0], [int(attr[3, 0])], [], [], [int(attr[5, 0]), int(attr[6, 0])], []])
+    P.match_parity(make_engine, jobs, offers, groups, A.default_params(good_enough_fitness=1.0, match_algo=algo))
 
 
 def test_cycle_parity(make_engine):
