@@ -198,12 +198,12 @@ def main():
         from oracle import pyoracle
         p0 = my_pools[0]
         pool = pools[p0]
-        cores = args.cpu_threads or (os.cpu_count() or 1)
+        cores = args.cpu_threads or min(16, os.cpu_count() or 1)
         c0 = time.perf_counter()
         o_ranked, _ = pyoracle.rank(params, pool.tasks, pool.users)
         c1 = time.perf_counter()
         # bounded sample of the placement: first k_s considerable jobs, ~<= 2e9 pair evaluations
-        k_s = int(min(min(K, len(o_ranked)), max(1000, 2_000_000_000 // max(1, n_off))))
+        k_s = int(min(min(K, len(o_ranked)), max(1000, 1_000_000_000 // max(1, n_off))))
         pend_ord = np.cumsum(pool.tasks.pending) - 1
         cons = pool.pending_jobs.take(pend_ord[o_ranked[:k_s]])
         c2 = time.perf_counter()

@@ -34,6 +34,13 @@ template <class T>
 static __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
+// constant-rate (100 MHz) device clock for in-kernel phase timing
+#ifdef __HIP_EMU__
+static inline unsigned long long cook_ticks() { return 0ull; }
+#else
+static __device__ __forceinline__ unsigned long long cook_ticks() { return wall_clock64(); }
+#endif
+
 static __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & (COOK_WAVE - 1); }
 static __device__ __forceinline__ unsigned wave_id() { return threadIdx.x >> 6; }
 

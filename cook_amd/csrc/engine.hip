@@ -13,7 +13,7 @@
 #include "../../include/cookmatch.h"
 #include "common.hpp"
 #include "match_kernels.hpp"
-#include "match_window.hpp"
+#include "match_v2.hpp"
 #include "rank_kernels.hpp"
 #include "scan.hpp"
 #include "sort.hpp"
@@ -125,9 +125,13 @@ struct cook_engine {
   DArr<int64_t> j_est_end, o_host_start;
   DArr<uint8_t> o_k8s, g_type;
   DArr<unsigned> m_summary;
-  DArr<double> w_cand_fit;
-  DArr<int> w_cand_idx, w_ncand, w_ge_idx, w_nge;
-  DArr<unsigned> w_failcnt;
+  DArr<OfferA> v_oa;
+  DArr<OfferB> v_ob;
+  DArr<JobRec> v_jr;
+  DArr<double> v_pfit, v_cand_fit;
+  DArr<int> v_pidx, v_pge, v_cand_idx, v_ge_idx;
+  DArr<uint32_t> v_pcnt, v_cinfo;
+  DArr<uint64_t> v_colbits;
   DArr<WinCtl> w_ctl;
   WinCtl last_ctl{};
   MatchIn min{};
@@ -673,35 +677,43 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
     auto k_match = match_serial<1024>;
     KL("match_serial", k_match, 1, 1024, in, st);
 #endif
-  } else if (K > 0) {  // windowed speculate + in-order resolve (match_window.hpp)
-#ifdef __HIP_EMU__
-    const unsigned wmax = 24;
-#else
-    const unsigned wmax = 512;
-#endif
-    WinBuf wb;
-    wb.cand_fit = e->w_cand_fit.ensure((size_t)wmax * MW_L);
-    wb.cand_idx = e->w_cand_idx.ensure((size_t)wmax * MW_L);
-    wb.ncand = e->w_ncand.ensure(wmax);
-    wb.ge_idx = e->w_ge_idx.ensure((size_t)wmax * MW_L);
-    wb.nge = e->w_nge.ensure(wmax);
-    wb.failcnt = e->w_failcnt.ensure((size_t)wmax * 3);
-    wb.ctl = e->w_ctl.ensure(1);
-    wb.wmax = wmax;
+  } else if (K > 0) {  // window rounds: eval -> merge -> resolve (match_v2.hpp)
+    V2Buf vb;
+    const unsigned C = div_up(M ? M : 1u, MV_OCB);
+    vb.C = C;
+    OfferA* oa = e->v_oa.ensure(M);
+    OfferB* ob = e->v_ob.ensure(M);
+    JobRec* jr = e->v_jr.ensure(K);
+    vb.oa = oa;
+    vb.ob = ob;
+    vb.jr = jr;
+    vb.pfit = e->v_pfit.ensure((size_t)MV_WMAX * C * MV_L);
+    vb.pidx = e->v_pidx.ensure((size_t)MV_WMAX * C * MV_L);
+    vb.pge = e->v_pge.ensure((size_t)MV_WMAX * C * MV_LG);
+    vb.pcnt = e->v_pcnt.ensure((size_t)MV_WMAX * C * 4);
+    vb.colbits = e->v_colbits.ensure((size_t)(M ? M : 1u) * MV_JG);
+    vb.cand_fit = e->v_cand_fit.ensure((size_t)MV_WMAX * MV_L);
+    vb.cand_idx = e->v_cand_idx.ensure((size_t)MV_WMAX * MV_L);
+    vb.ge_idx = e->v_ge_idx.ensure((size_t)MV_WMAX * MV_LG);
+    vb.cinfo = e->v_cinfo.ensure((size_t)MV_WMAX * 4);
+    vb.ctl = e->w_ctl.ensure(1);
+    if (M) KL("match_pack_offers", match_pack_offers, div_up(M, 256), 256, in, oa, ob);
+    KL("match_pack_jobs", match_pack_jobs, div_up(K, 256), 256, in, jr);
     WinCtl c0;
     std::memset(&c0, 0, sizeof(c0));
-    c0.wcur = std::min(wmax, 64u);
+    c0.wcur = std::min<unsigned>(MV_WMAX, 64u);
     std::memcpy(e->h_scratch, &c0, sizeof(c0));
-    COOK_HIP(hipMemcpyAsync(wb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
+    COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
     unsigned batch = 4;
     WinCtl hc = c0;
     unsigned guard = 0;
     while (hc.head < K) {
       for (unsigned r = 0; r < batch; ++r) {
-        KL("match_window_eval", match_window_eval, wmax, MW_THREADS, in, st, wb);
-        KL("match_window_resolve", match_window_resolve, 1, COOK_WAVE, in, st, wb);
+        KL("match_eval2", match_eval2, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
+        KL("match_merge2", match_merge2, MV_WMAX, COOK_WAVE, in, vb);
+        KL("match_resolve2", match_resolve2, 1, MV_RTHREADS, in, st, vb);
       }
-      COOK_HIP(hipMemcpyAsync(e->h_scratch, wb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
+      COOK_HIP(hipMemcpyAsync(e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
       sync(e);
       const unsigned prev_head = hc.head, prev_rounds = hc.rounds;
       std::memcpy(&hc, e->h_scratch, sizeof(WinCtl));
@@ -839,7 +851,7 @@ void cook_engine_destroy(cook_engine* e) {
                   &e->j_index.b, &e->o_host.b, &e->o_gpu_model.b, &e->o_disk_type.b, &e->o_attr.b, &e->o_location.b, &e->g_attr_key.b,
                   &e->g_run_off.b, &e->g_run_host.b, &e->g_run_attr.b, &e->reserved_bits.b, &e->m_fail.b, &e->j_reserved_host.b,
                   &e->o_max_tasks.b, &e->o_num_tasks.b, &e->o_run_count.b, &e->g_min.b, &e->m_acount.b, &e->m_group_last.b,
-                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b, &e->w_cand_fit.b, &e->w_cand_idx.b, &e->w_ncand.b, &e->w_ge_idx.b, &e->w_nge.b, &e->w_failcnt.b, &e->w_ctl.b};
+                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b, &e->v_oa.b, &e->v_ob.b, &e->v_jr.b, &e->v_pfit.b, &e->v_cand_fit.b, &e->v_pidx.b, &e->v_pge.b, &e->v_cand_idx.b, &e->v_ge_idx.b, &e->v_pcnt.b, &e->v_cinfo.b, &e->v_colbits.b, &e->w_ctl.b};
   for (DBuf* b : bufs) b->release();
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i)
@@ -977,7 +989,7 @@ int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms) {
   if (match_ms) *match_ms = e->match_ms;
   return COOK_OK;
 }
-int cook_match_stats(cook_engine* e, uint32_t out[8]) {
+int cook_match_stats(cook_engine* e, uint32_t out[12]) {
   if (!e || !out) return COOK_E_INVALID;
   const WinCtl& c = e->last_ctl;
   out[0] = c.rounds;
@@ -986,8 +998,12 @@ int cook_match_stats(cook_engine* e, uint32_t out[8]) {
   out[3] = c.stop_full;
   out[4] = c.stop_group;
   out[5] = c.stop_window;
-  out[6] = c.wcur;
+  out[6] = c.stop_slots;
   out[7] = c.head;
+  out[8] = (uint32_t)(c.t_setup / 100ull);  // microseconds
+  out[9] = (uint32_t)(c.t_seq / 100ull);
+  out[10] = c.touched_sum;
+  out[11] = 0;
   return COOK_OK;
 }
 int cook_set_profiling(cook_engine* e, int enabled) {

@@ -69,9 +69,12 @@ static __device__ __forceinline__ uint32_t offer_attr_val(const MatchIn& in, uns
   return in.o_attr[(size_t)v * in.n_attr + key];
 }
 
-// All static and dynamic constraints of constraints.clj for (job jj, offer v).  `acount_v` = tasks placed on v in this call.
-static __device__ __forceinline__ bool constraints_pass(const MatchIn& in, const MatchState& st, unsigned jj, unsigned v,
-                                                        int acount_v) {
+// The constraints of constraints.clj for (job jj, offer v), split by what they depend on:
+//   static_pass  : job x offer only (novel-host, gpu model/count, disk, EQUALS, estimated completion, checkpoint
+//                  locality, rebalancer reservation)                       -> never changes during a match call
+//   dyn_pass     : also the number of tasks placed on v in this call (gpu "VM must be empty", max-tasks-per-host)
+//   group_pass   : also where the job's cotasks were placed in this call (group host-placement)
+static __device__ __forceinline__ bool static_pass(const MatchIn& in, unsigned jj, unsigned v) {
   const unsigned host = in.o_host[v];
   if (in.j_novel_off) {  // novel-host, constraints.clj:68-94
     for (unsigned x = in.j_novel_off[jj]; x < in.j_novel_off[jj + 1]; ++x)
@@ -79,13 +82,12 @@ static __device__ __forceinline__ bool constraints_pass(const MatchIn& in, const
   }
   const double jg = in.j_gpus ? in.j_gpus[jj] : 0.0;
   const bool k8s = in.o_k8s && in.o_k8s[v];
-  if (k8s) {  // gpu-host, constraints.clj:122-157
+  if (k8s) {  // gpu-host, constraints.clj:122-157 (model / count part)
     const unsigned om = in.o_gpu_model ? in.o_gpu_model[v] : 0u;
     if (jg > 0) {
       const unsigned jm = in.j_gpu_model ? in.j_gpu_model[jj] : 0u;
       const double avail = (om != 0 && om == jm) ? in.o_gpu_count[v] : 0.0;
-      const int on_vm = (in.o_run_count ? in.o_run_count[v] : 0) + acount_v;
-      if (!(avail == jg && on_vm == 0)) return false;
+      if (!(avail == jg)) return false;
     } else if (om != 0) {
       return false;
     }
@@ -108,72 +110,88 @@ static __device__ __forceinline__ bool constraints_pass(const MatchIn& in, const
     const unsigned loc = in.o_location ? in.o_location[v] : 0u;
     if (loc != in.j_ckpt[jj]) return false;
   }
-  if (in.o_max_tasks && in.o_max_tasks[v] >= 0) {  // max-tasks-per-host, constraints.clj:433-456
-    if (!((in.o_num_tasks ? in.o_num_tasks[v] : 0) + acount_v < in.o_max_tasks[v])) return false;
-  }
   if (in.reserved_bits && (host >> 5) < in.reserved_words && ((in.reserved_bits[host >> 5] >> (host & 31)) & 1u)) {
     // rebalancer-reservation, constraints.clj:242-252 + scheduler.clj:645-653
     if (!(in.j_reserved_host && in.j_reserved_host[jj] == (int)host)) return false;
   }
-  // group host-placement, constraints.clj:586-644
-  if (in.j_group && in.j_group[jj] != 0xFFFFFFFFu) {
-    const unsigned g = in.j_group[jj];
-    const unsigned type = in.g_type[g];
-    if (type != 0) {
-      const unsigned r0 = in.g_run_off ? in.g_run_off[g] : 0u, r1 = in.g_run_off ? in.g_run_off[g + 1] : 0u;
-      const unsigned key = in.g_attr_key[g];
-      if (type == 1) {  // unique
-        for (unsigned x = r0; x < r1; ++x)
-          if (in.g_run_host[x] == host) return false;
-        for (int c = ld_agent(&st.group_last[g]); c >= 0; c = ld_agent(&st.job_prev[c]))
-          if (c < st.cutoff && in.o_host[ld_agent(&st.job_to_offer[c])] == host) return false;
-      } else {
-        // frequencies of the attribute over cotask hosts (running ++ placed in this call); nil (0) is a legal value
-        const unsigned target = offer_attr_val(in, v, key);
-        const unsigned n_run = r1 - r0;
-        unsigned n_cyc = 0;
-        for (int c = ld_agent(&st.group_last[g]); c >= 0; c = ld_agent(&st.job_prev[c])) ++n_cyc;
-        const unsigned total = n_run + n_cyc;
-        if (total != 0) {
-          // value of cotask number x (running first, then this call's in reverse placement order)
-          auto val_at = [&](unsigned x) -> unsigned {
-            if (x < n_run) return key == 0xFFFFFFFFu ? in.g_run_host[r0 + x] + 1 : in.g_run_attr[r0 + x];
-            int c = ld_agent(&st.group_last[g]);
-            for (unsigned s = n_run; s < x; ++s) c = ld_agent(&st.job_prev[c]);
-            return offer_attr_val(in, (unsigned)ld_agent(&st.job_to_offer[c]), key);
-          };
-          unsigned tfreq = 0, mn = 0xFFFFFFFFu, mx = 0, distinct = 0;
-          for (unsigned a = 0; a < total; ++a) {
-            const unsigned va = val_at(a);
-            if (va == target) ++tfreq;
-            bool first = true;
-            unsigned cnt = 0;
-            for (unsigned b = 0; b < total; ++b) {
-              const unsigned vb = val_at(b);
-              if (vb == va) {
-                if (b < a) first = false;
-                ++cnt;
-              }
-            }
-            if (first) {
-              ++distinct;
-              mn = cnt < mn ? cnt : mn;
-              mx = cnt > mx ? cnt : mx;
-            }
-          }
-          if (type == 2) {  // balanced
-            if (tfreq != 0) {
-              const unsigned minim = ((unsigned)(in.g_min[g] > 0 ? in.g_min[g] : 0) > distinct) ? 0u : mn;
-              if (!(minim == mx || tfreq < mx)) return false;
-            }
-          } else {  // attribute-equals
-            if (tfreq == 0) return false;
-          }
-        }
-      }
-    }
+  return true;
+}
+
+static __device__ __forceinline__ bool dyn_pass(const MatchIn& in, unsigned jj, unsigned v, int acount_v) {
+  const double jg = in.j_gpus ? in.j_gpus[jj] : 0.0;
+  if (jg > 0 && in.o_k8s && in.o_k8s[v]) {  // gpu-host: no task (running or assigned this cycle) on the VM
+    if ((in.o_run_count ? in.o_run_count[v] : 0) + acount_v != 0) return false;
+  }
+  if (in.o_max_tasks && in.o_max_tasks[v] >= 0) {  // max-tasks-per-host, constraints.clj:433-456
+    if (!((in.o_num_tasks ? in.o_num_tasks[v] : 0) + acount_v < in.o_max_tasks[v])) return false;
   }
   return true;
+}
+
+// group host-placement, constraints.clj:586-644
+static __device__ __forceinline__ bool group_pass(const MatchIn& in, const MatchState& st, unsigned jj, unsigned v) {
+  if (!(in.j_group && in.j_group[jj] != 0xFFFFFFFFu)) return true;
+  const unsigned host = in.o_host[v];
+  const unsigned g = in.j_group[jj];
+  const unsigned type = in.g_type[g];
+  if (type == 0) return true;
+  const unsigned r0 = in.g_run_off ? in.g_run_off[g] : 0u, r1 = in.g_run_off ? in.g_run_off[g + 1] : 0u;
+  const unsigned key = in.g_attr_key[g];
+  if (type == 1) {  // unique
+    for (unsigned x = r0; x < r1; ++x)
+      if (in.g_run_host[x] == host) return false;
+    for (int c = ld_agent(&st.group_last[g]); c >= 0; c = ld_agent(&st.job_prev[c]))
+      if (c < st.cutoff && in.o_host[ld_agent(&st.job_to_offer[c])] == host) return false;
+    return true;
+  }
+  // frequencies of the attribute over cotask hosts (running ++ placed in this call); nil (0) is a legal value
+  const unsigned target = offer_attr_val(in, v, key);
+  const unsigned n_run = r1 - r0;
+  unsigned n_cyc = 0;
+  for (int c = ld_agent(&st.group_last[g]); c >= 0; c = ld_agent(&st.job_prev[c])) ++n_cyc;
+  const unsigned total = n_run + n_cyc;
+  if (total == 0) return true;
+  // value of cotask number x (running first, then this call's in reverse placement order)
+  auto val_at = [&](unsigned x) -> unsigned {
+    if (x < n_run) return key == 0xFFFFFFFFu ? in.g_run_host[r0 + x] + 1 : in.g_run_attr[r0 + x];
+    int c = ld_agent(&st.group_last[g]);
+    for (unsigned s = n_run; s < x; ++s) c = ld_agent(&st.job_prev[c]);
+    return offer_attr_val(in, (unsigned)ld_agent(&st.job_to_offer[c]), key);
+  };
+  unsigned tfreq = 0, mn = 0xFFFFFFFFu, mx = 0, distinct = 0;
+  for (unsigned a = 0; a < total; ++a) {
+    const unsigned va = val_at(a);
+    if (va == target) ++tfreq;
+    bool first = true;
+    unsigned cnt = 0;
+    for (unsigned b = 0; b < total; ++b) {
+      const unsigned vb = val_at(b);
+      if (vb == va) {
+        if (b < a) first = false;
+        ++cnt;
+      }
+    }
+    if (first) {
+      ++distinct;
+      mn = cnt < mn ? cnt : mn;
+      mx = cnt > mx ? cnt : mx;
+    }
+  }
+  if (type == 2) {  // balanced
+    if (tfreq != 0) {
+      const unsigned minim = ((unsigned)(in.g_min[g] > 0 ? in.g_min[g] : 0) > distinct) ? 0u : mn;
+      if (!(minim == mx || tfreq < mx)) return false;
+    }
+  } else {  // attribute-equals
+    if (tfreq == 0) return false;
+  }
+  return true;
+}
+
+// All static and dynamic constraints for (job jj, offer v).  `acount_v` = tasks placed on v in this call.
+static __device__ __forceinline__ bool constraints_pass(const MatchIn& in, const MatchState& st, unsigned jj, unsigned v,
+                                                        int acount_v) {
+  return static_pass(in, jj, v) && dyn_pass(in, jj, v, acount_v) && group_pass(in, st, jj, v);
 }
 
 struct Cand {

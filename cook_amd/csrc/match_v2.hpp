@@ -1,0 +1,851 @@
+// match_v2.hpp — exact rank-ordered placement (Fenzo scheduleOnce semantics, scheduler.clj:617-687) as a pipeline of
+// window rounds.  Placement is sequential by definition — job i+1 sees job i's commitment — but one commitment changes
+// ONE offer.  For a window of W consecutive jobs a round is three launches:
+//
+//   match_eval2    (grid = offer chunks x job groups; lane = job, offers walked in a wave-uniform loop so the offer record
+//                   comes through scalar loads): against the snapshot S of per-offer assignments at round start, every job
+//                   gets the top-L feasible offers of each chunk (fitness desc, index asc), the first LG offers whose
+//                   fitness exceeds good-enough, failure counts, and — for every (job, offer) — one bit "static
+//                   constraints pass" (a ballot over the 64 jobs of the wave = one u64 per offer: colbits[offer][group]).
+//                   The two fp64 divides of the fitness are only executed for pairs whose cheap upper bound
+//                   (multiply by a precomputed reciprocal) can still enter the lane's top-L.
+//   match_merge2   (one wave per job): chunk lists -> the job's global top-L / first-LG / failure counts.
+//   match_resolve2 (ONE workgroup; after a parallel set-up phase wave 0 walks the window in rank order): all the data
+//                   the sequential walk needs is first staged in LDS — job records, candidate lists, and for every
+//                   DISTINCT candidate offer of the window ("slot") its record, snapshot state and colbits column — so
+//                   the per-job critical path is LDS + registers only.  Lanes own the offers committed to in this round
+//                   ("touched"); for job j the winner under the current state S' is
+//                       max( best UNTOUCHED offer under S , best TOUCHED offer re-evaluated under S' )
+//                   and the first entry of j's list that is untouched — or touched and still feasible (its fitness only
+//                   grew, so it dominates every untouched offer) — settles the left term.  If the list (length L, more
+//                   candidates may exist) runs out, a 65th offer would be touched, or the slot table overflowed, the round
+//                   ends there and the next round re-snapshots.
+//
+// The result is bit-identical to the one-job-at-a-time sweep (match_serial) for every input; only speed depends on L/W.
+// Jobs of balanced / attribute-equals groups change the feasibility of UNTOUCHED offers when a cotask is placed, so a
+// round never resolves a second member of such a group after the first one was placed.
+#pragma once
+#include "common.hpp"
+#include "match_kernels.hpp"
+
+constexpr int MV_L = 8;                    // candidate list length per job
+constexpr int MV_LG = 4;                   // good-enough list length per job
+constexpr int MV_OCW = 32;                 // offers per eval wave
+constexpr int MV_EW = 4;                   // waves per eval block (same 64 jobs, consecutive offer sub-chunks)
+constexpr int MV_OCB = MV_OCW * MV_EW;     // offers per eval block
+constexpr int MV_T = COOK_WAVE;            // touched offers per round = lanes of the sequencing wave
+constexpr int MV_RTHREADS = 256;           // threads of the resolve workgroup (set-up phase); wave 0 sequences
+#ifdef __HIP_EMU__
+constexpr int MV_WMAX = 128;               // jobs per round (emulator: small, so that tests run many rounds)
+constexpr int MV_S = 96;                   // distinct candidate offers staged per round
+constexpr int MV_HASH = 512;
+#else
+constexpr int MV_WMAX = 512;
+constexpr int MV_S = 256;
+constexpr int MV_HASH = 1024;
+#endif
+constexpr int MV_JG = MV_WMAX / 64;        // job groups (waves of jobs) per window
+constexpr int MV_JSTEP = MV_S / 16;        // jobs inserted into the slot table per step ((L + LG) <= 16 entries each)
+static_assert(MV_L + MV_LG <= 16, "slot-table step sizing");
+static_assert(MV_OCW <= COOK_WAVE, "one lane stages one offer");
+
+struct OfferA {  // resources of an offer (offer.clj:55-61) + Fenzo's running view; 48 B, read wave-uniformly
+  double oc, om;          // lease cpus / mem
+  double rc, rm;          // resources of tasks Fenzo tracks as running on the host
+  double inv_dc, inv_dm;  // 1 / (oc + rc), 1 / (om + rm): only for the pruning bound, never for the fitness itself
+};
+struct OfferB {  // what the cheap constraint checks need; 32 B
+  uint32_t host, gpu_model;
+  double gpu_count;
+  int32_t run_count, task_slack;  // task_slack = COOK_MAX_TASKS_PER_HOST - COOK_NUM_TASKS_ON_HOST (INT_MAX when absent)
+  uint32_t flags, pad;            // bit0 kubernetes VM, bit1 host is in the rebalancer's reserved set
+};
+struct JobRec {  // one considerable job in match order; 40 B
+  double c, m, g;
+  uint32_t gpu_model;
+  int32_t reserved_host;
+  uint32_t group;  // COOK_NONE_U32 or group id
+  uint32_t flags;  // bit0 has constraints that need the slow static check, bit1 member of a constrained group,
+                   // bits 8..9 group type
+};
+constexpr uint32_t JF_SLOW = 1u, JF_GROUPED = 2u;
+
+struct WinCtl {
+  unsigned head;          // first unresolved job
+  unsigned wcur;          // window size for the next round
+  unsigned rounds;
+  unsigned matched;
+  unsigned head_matched;  // job 0 was matched
+  unsigned stop_list, stop_full, stop_group, stop_window, stop_slots;  // why rounds ended (statistics)
+  unsigned touched_sum;   // sum over rounds of touched offers
+  unsigned long long t_setup, t_seq;  // resolve kernel: ticks (100 MHz wall clock) spent in the set-up / sequential phase
+};
+
+struct V2Buf {
+  const OfferA* oa;
+  const OfferB* ob;
+  const JobRec* jr;
+  double* pfit;        // [wmax][C][L]   chunk lists
+  int* pidx;           // [wmax][C][L]
+  int* pge;            // [wmax][C][LG]
+  uint32_t* pcnt;      // [wmax][C][4]   n | nge << 8, c1, c2, c4
+  uint64_t* colbits;   // [M][JG]        static-constraints-pass bit of (offer, job of the window)
+  double* cand_fit;    // [wmax][L]
+  int* cand_idx;       // [wmax][L]
+  int* ge_idx;         // [wmax][LG]
+  uint32_t* cinfo;     // [wmax][4]      ncand | nge << 8, c1, c2, c4
+  WinCtl* ctl;
+  unsigned C;          // eval blocks along the offers
+};
+
+// ---- once per match call: pack offers and jobs -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) match_pack_offers(MatchIn in, OfferA* __restrict__ oa, OfferB* __restrict__ ob) {
+  const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= in.M) return;
+  OfferA a;
+  a.oc = in.o_cpus[v];
+  a.om = in.o_mem[v];
+  a.rc = in.o_run_cpus ? in.o_run_cpus[v] : 0.0;
+  a.rm = in.o_run_mem ? in.o_run_mem[v] : 0.0;
+  a.inv_dc = 1.0 / (a.oc + a.rc);
+  a.inv_dm = 1.0 / (a.om + a.rm);
+  oa[v] = a;
+  OfferB b;
+  b.host = in.o_host[v];
+  b.gpu_model = in.o_gpu_model ? in.o_gpu_model[v] : 0u;
+  b.gpu_count = (in.o_gpu_model && in.o_gpu_count) ? in.o_gpu_count[v] : 0.0;
+  b.run_count = in.o_run_count ? in.o_run_count[v] : 0;
+  b.task_slack = (in.o_max_tasks && in.o_max_tasks[v] >= 0) ? in.o_max_tasks[v] - (in.o_num_tasks ? in.o_num_tasks[v] : 0) : 0x7FFFFFFF;
+  const bool k8s = in.o_k8s && in.o_k8s[v];
+  const bool rsv = in.reserved_bits && (b.host >> 5) < in.reserved_words && ((in.reserved_bits[b.host >> 5] >> (b.host & 31)) & 1u);
+  b.flags = (k8s ? 1u : 0u) | (rsv ? 2u : 0u);
+  b.pad = 0;
+  ob[v] = b;
+}
+
+__global__ void __launch_bounds__(256) match_pack_jobs(MatchIn in, JobRec* __restrict__ jr) {
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= in.K) return;
+  const unsigned jj = in.j_index ? in.j_index[k] : k;
+  JobRec j;
+  j.c = in.j_cpus[jj];
+  j.m = in.j_mem[jj];
+  j.g = in.j_gpus ? in.j_gpus[jj] : 0.0;
+  j.gpu_model = in.j_gpu_model ? in.j_gpu_model[jj] : 0u;
+  j.reserved_host = in.j_reserved_host ? in.j_reserved_host[jj] : -1;
+  j.group = in.j_group ? in.j_group[jj] : 0xFFFFFFFFu;
+  unsigned f = 0;
+  if (in.j_novel_off && in.j_novel_off[jj + 1] > in.j_novel_off[jj]) f |= JF_SLOW;
+  if (in.j_eq_off && in.j_eq_off[jj + 1] > in.j_eq_off[jj]) f |= JF_SLOW;
+  if (in.j_disk_req && in.j_disk_req[jj] >= 0) f |= JF_SLOW;
+  if (in.j_est_end && in.j_est_end[jj] != 0) f |= JF_SLOW;
+  if (in.j_ckpt && in.j_ckpt[jj] != 0) f |= JF_SLOW;
+  if (j.group != 0xFFFFFFFFu) {
+    const unsigned t = in.g_type[j.group];
+    if (t != 0) f |= JF_GROUPED | (t << 8);
+  }
+  j.flags = f;
+  jr[k] = j;
+}
+
+// ---- the cheap parts of the constraint check, from the packed records only ---------------------------------------------
+// gpu-host model/count (constraints.clj:122-157) + rebalancer reservation (constraints.clj:242-252)
+static __device__ __forceinline__ bool static_fast(const JobRec& j, const OfferB& o) {
+  bool ok;
+  if (o.flags & 1u) {
+    if (j.g > 0) {
+      const double avail = (o.gpu_model != 0 && o.gpu_model == j.gpu_model) ? o.gpu_count : 0.0;
+      ok = avail == j.g;
+    } else {
+      ok = o.gpu_model == 0;
+    }
+  } else {
+    ok = j.g == 0;
+  }
+  if ((o.flags & 2u) && j.reserved_host != (int)o.host) ok = false;
+  return ok;
+}
+// gpu-host "no task on the VM" + max-tasks-per-host (constraints.clj:433-456) under `acount` placements of this call
+static __device__ __forceinline__ bool dyn_fast(const JobRec& j, const OfferB& o, int acount) {
+  if (j.g > 0 && (o.flags & 1u) && o.run_count + acount != 0) return false;
+  return acount < o.task_slack;
+}
+// cpuMemBinPacker (config.clj:108), operation for operation as the oracle computes it
+static __device__ __forceinline__ double fitness_of(const OfferA& a, double ac, double am, double c, double m) {
+  return ((a.rc + ac + c) / (a.oc + a.rc) + (a.rm + am + m) / (a.om + a.rm)) / 2.0;
+}
+
+template <int N>
+static __device__ __forceinline__ void topl_insert(double (&tf)[N], int (&ti)[N], double fit, int idx) {
+  // precondition: (fit, idx) is better than the last entry; bubble it up (strictly better only: earlier index stays first)
+  tf[N - 1] = fit;
+  ti[N - 1] = idx;
+#pragma unroll
+  for (int q = N - 1; q > 0; --q) {
+    const bool sw = tf[q] > tf[q - 1] || (tf[q] == tf[q - 1] && ti[q] >= 0 && (ti[q - 1] < 0 || ti[q] < ti[q - 1]));
+    if (sw) {
+      const double a = tf[q];
+      tf[q] = tf[q - 1];
+      tf[q - 1] = a;
+      const int x = ti[q];
+      ti[q] = ti[q - 1];
+      ti[q - 1] = x;
+    }
+  }
+}
+
+// ---- eval ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, MatchState st, V2Buf vb) {
+  __shared__ double s_fit[MV_EW][COOK_WAVE][MV_L];
+  __shared__ int s_idx[MV_EW][COOK_WAVE][MV_L];
+  __shared__ int s_ge[MV_EW][COOK_WAVE][MV_LG];
+  __shared__ unsigned s_cnt[MV_EW][COOK_WAVE][3];
+  __shared__ OfferA s_oa[MV_EW][MV_OCW];  // this wave's offers, staged once: the offer loop then reads LDS broadcasts only
+  __shared__ OfferB s_ob[MV_EW][MV_OCW];
+  __shared__ double s_oac[MV_EW][MV_OCW], s_oam[MV_EW][MV_OCW];
+  __shared__ int s_oacount[MV_EW][MV_OCW];
+  const unsigned head = vb.ctl->head, wcur = vb.ctl->wcur;
+  const unsigned jg = blockIdx.y, ch = blockIdx.x;
+  if (jg * COOK_WAVE >= wcur || head + jg * COOK_WAVE >= in.K) return;  // block-uniform
+  const unsigned lane = lane_id(), w = wave_id();
+  const unsigned b = jg * COOK_WAVE + lane, k = head + b;
+  const bool valid = b < wcur && k < in.K;
+  JobRec j;
+  j.c = j.m = j.g = 0.0;
+  j.gpu_model = 0;
+  j.reserved_host = -1;
+  j.group = 0xFFFFFFFFu;
+  j.flags = 0;
+  unsigned jj = 0;
+  if (valid) {
+    j = vb.jr[k];
+    jj = in.j_index ? in.j_index[k] : k;
+  }
+  const bool slow = (j.flags & JF_SLOW) != 0, grouped = (j.flags & JF_GROUPED) != 0;
+  const bool use_ge = in.good_enough < 1.0;
+  const double ge = in.good_enough, ge_lo = in.good_enough * (1.0 - 0x1p-40);
+  double tf[MV_L];
+  int ti[MV_L];
+  int gi[MV_LG];
+#pragma unroll
+  for (int q = 0; q < MV_L; ++q) {
+    tf[q] = -1.0;
+    ti[q] = -1;
+  }
+#pragma unroll
+  for (int q = 0; q < MV_LG; ++q) gi[q] = 0x7FFFFFFF;
+  int n_ge = 0;
+  double thr = -1.0;  // pruning threshold: (1 - 2^-40) * current L-th best, valid once the list is full
+  unsigned c1 = 0, c2 = 0, c4 = 0;
+  const unsigned v0 = ch * MV_OCB + w * MV_OCW;
+  const unsigned v1 = (v0 + MV_OCW < in.M) ? v0 + MV_OCW : in.M;
+  if (v0 + lane < v1) {
+    s_oa[w][lane] = vb.oa[v0 + lane];
+    s_ob[w][lane] = vb.ob[v0 + lane];
+    s_oac[w][lane] = st.ac[v0 + lane];
+    s_oam[w][lane] = st.am[v0 + lane];
+    s_oacount[w][lane] = st.acount[v0 + lane];
+  }
+  wave_sync();
+  for (unsigned v = v0; v < v1; ++v) {  // wave-uniform
+    const unsigned vi = v - v0;
+    const OfferA a = s_oa[w][vi];
+    const double ac = s_oac[w][vi], am = s_oam[w][vi];
+    const bool res = valid && !(ac + j.c > a.oc || am + j.m > a.om);
+    if (!__any(res)) {
+      c1 += valid ? 1u : 0u;
+      if (lane == 0) vb.colbits[(size_t)v * MV_JG + jg] = 0ull;
+      continue;
+    }
+    const OfferB o = s_ob[w][vi];
+    const int acount = s_oacount[w][vi];
+    bool stat = res && static_fast(j, o);
+    if (stat && slow) stat = static_pass(in, jj, v);
+    const unsigned long long bits = __ballot(stat);
+    if (lane == 0) vb.colbits[(size_t)v * MV_JG + jg] = bits;
+    bool feas = stat && dyn_fast(j, o, acount);
+    if (feas && grouped) feas = group_pass(in, st, jj, v);
+    c1 += (valid && !res) ? 1u : 0u;
+    c2 += (res && !feas) ? 1u : 0u;
+    if (feas) {
+      const double t1 = (a.rc + ac + j.c) * a.inv_dc, t2 = (a.rm + am + j.m) * a.inv_dm;
+      const double ub = (t1 + t2) * 0.5;
+      bool prune = ti[MV_L - 1] >= 0 && t1 >= 0.0 && t2 >= 0.0 && ub < thr;
+      if (use_ge && n_ge < MV_LG && !(ub < ge_lo)) prune = false;
+      if (!prune) {
+        const double fit = fitness_of(a, ac, am, j.c, j.m);
+        if (!(fit > 0.0)) {
+          c4 += 1u;
+        } else {
+          if (fit > tf[MV_L - 1]) {
+            topl_insert<MV_L>(tf, ti, fit, (int)v);
+            if (ti[MV_L - 1] >= 0) thr = tf[MV_L - 1] * (1.0 - 0x1p-40);
+          }
+          if (use_ge && fit > ge && n_ge < MV_LG) {
+#pragma unroll
+            for (int q = 0; q < MV_LG; ++q)
+              if (q == n_ge) gi[q] = (int)v;
+            ++n_ge;
+          }
+        }
+      }
+    }
+  }
+  // ---- merge the block's MV_EW wave lists per job through LDS -------------------------------------------------------
+#pragma unroll
+  for (int q = 0; q < MV_L; ++q) {
+    s_fit[w][lane][q] = tf[q];
+    s_idx[w][lane][q] = ti[q];
+  }
+#pragma unroll
+  for (int q = 0; q < MV_LG; ++q) s_ge[w][lane][q] = gi[q];
+  s_cnt[w][lane][0] = c1;
+  s_cnt[w][lane][1] = c2;
+  s_cnt[w][lane][2] = c4;
+  __syncthreads();
+  if (w != 0 || !valid) return;
+  int p[MV_EW];
+#pragma unroll
+  for (int x = 0; x < MV_EW; ++x) p[x] = 0;
+  const size_t obase = ((size_t)b * vb.C + ch);
+  int n_out = 0;
+  for (int q = 0; q < MV_L; ++q) {
+    Cand best{-1.0, -1};
+    int bx = -1;
+#pragma unroll
+    for (int x = 0; x < MV_EW; ++x) {
+      if (p[x] < MV_L) {
+        const Cand o{s_fit[x][lane][p[x]], s_idx[x][lane][p[x]]};
+        if (o.idx >= 0 && cand_better(o, best)) {
+          best = o;
+          bx = x;
+        }
+      }
+    }
+    vb.pfit[obase * MV_L + q] = best.fit;
+    vb.pidx[obase * MV_L + q] = best.idx;
+    if (bx < 0) break;
+    ++n_out;
+#pragma unroll
+    for (int x = 0; x < MV_EW; ++x)
+      if (x == bx) ++p[x];
+  }
+  int n_g = 0;
+  if (use_ge) {
+#pragma unroll
+    for (int x = 0; x < MV_EW; ++x) p[x] = 0;
+    for (int q = 0; q < MV_LG; ++q) {
+      int best = 0x7FFFFFFF, bx = -1;
+#pragma unroll
+      for (int x = 0; x < MV_EW; ++x) {
+        if (p[x] < MV_LG) {
+          const int o = s_ge[x][lane][p[x]];
+          if (o < best) {
+            best = o;
+            bx = x;
+          }
+        }
+      }
+      if (bx < 0) break;
+      vb.pge[obase * MV_LG + q] = best;
+      ++n_g;
+#pragma unroll
+      for (int x = 0; x < MV_EW; ++x)
+        if (x == bx) ++p[x];
+    }
+  }
+  unsigned t1 = 0, t2 = 0, t4 = 0;
+#pragma unroll
+  for (int x = 0; x < MV_EW; ++x) {
+    t1 += s_cnt[x][lane][0];
+    t2 += s_cnt[x][lane][1];
+    t4 += s_cnt[x][lane][2];
+  }
+  vb.pcnt[obase * 4 + 0] = (unsigned)n_out | ((unsigned)n_g << 8);
+  vb.pcnt[obase * 4 + 1] = t1;
+  vb.pcnt[obase * 4 + 2] = t2;
+  vb.pcnt[obase * 4 + 3] = t4;
+}
+
+// ---- merge: one wave per job ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(COOK_WAVE) match_merge2(MatchIn in, V2Buf vb) {
+  const unsigned head = vb.ctl->head, wcur = vb.ctl->wcur;
+  const unsigned b = blockIdx.x;
+  if (b >= wcur || head + b >= in.K) return;
+  const unsigned lane = lane_id();
+  const bool use_ge = in.good_enough < 1.0;
+  double tf[MV_L];
+  int ti[MV_L];
+  int gi[MV_LG];
+#pragma unroll
+  for (int q = 0; q < MV_L; ++q) {
+    tf[q] = -1.0;
+    ti[q] = -1;
+  }
+#pragma unroll
+  for (int q = 0; q < MV_LG; ++q) gi[q] = 0x7FFFFFFF;
+  int n_ge = 0;
+  unsigned c1 = 0, c2 = 0, c4 = 0;
+  for (unsigned ch = lane; ch < vb.C; ch += COOK_WAVE) {
+    const size_t base = (size_t)b * vb.C + ch;
+    const unsigned info = vb.pcnt[base * 4 + 0];
+    c1 += vb.pcnt[base * 4 + 1];
+    c2 += vb.pcnt[base * 4 + 2];
+    c4 += vb.pcnt[base * 4 + 3];
+    const int n = (int)(info & 0xFFu), ng = (int)((info >> 8) & 0xFFu);
+    for (int q = 0; q < n; ++q) {
+      const Cand o{vb.pfit[base * MV_L + q], vb.pidx[base * MV_L + q]};
+      if (!cand_better(o, Cand{tf[MV_L - 1], ti[MV_L - 1]})) break;  // chunk list is sorted: nothing further can enter
+      topl_insert<MV_L>(tf, ti, o.fit, o.idx);
+    }
+    if (use_ge)
+      for (int q = 0; q < ng && n_ge < MV_LG; ++q) {  // chunks ascend with ch, entries ascend inside a chunk
+        const int o = vb.pge[base * MV_LG + q];
+#pragma unroll
+        for (int x = 0; x < MV_LG; ++x)
+          if (x == n_ge) gi[x] = o;
+        ++n_ge;
+      }
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    c1 += __shfl_xor(c1, d, COOK_WAVE);
+    c2 += __shfl_xor(c2, d, COOK_WAVE);
+    c4 += __shfl_xor(c4, d, COOK_WAVE);
+  }
+  int n_out = 0;
+  for (int round = 0; round < MV_L; ++round) {
+    Cand best{tf[0], ti[0]};
+    for (int d = 32; d >= 1; d >>= 1) {
+      const Cand o{__shfl_xor(best.fit, d, COOK_WAVE), __shfl_xor(best.idx, d, COOK_WAVE)};
+      if (cand_better(o, best)) best = o;
+    }
+    if (best.idx < 0) break;  // wave-uniform
+    if (lane == 0) {
+      vb.cand_fit[(size_t)b * MV_L + round] = best.fit;
+      vb.cand_idx[(size_t)b * MV_L + round] = best.idx;
+    }
+    ++n_out;
+    if (ti[0] == best.idx) {  // the owner pops its head
+#pragma unroll
+      for (int q = 0; q < MV_L - 1; ++q) {
+        tf[q] = tf[q + 1];
+        ti[q] = ti[q + 1];
+      }
+      tf[MV_L - 1] = -1.0;
+      ti[MV_L - 1] = -1;
+    }
+  }
+  int n_g = 0;
+  if (use_ge) {
+    for (int round = 0; round < MV_LG; ++round) {
+      int best = gi[0];
+      for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(best, d, COOK_WAVE);
+        best = o < best ? o : best;
+      }
+      if (best == 0x7FFFFFFF) break;
+      if (lane == 0) vb.ge_idx[(size_t)b * MV_LG + round] = best;
+      ++n_g;
+      if (gi[0] == best) {
+#pragma unroll
+        for (int q = 0; q < MV_LG - 1; ++q) gi[q] = gi[q + 1];
+        gi[MV_LG - 1] = 0x7FFFFFFF;
+      }
+    }
+  }
+  if (lane == 0) {
+    vb.cinfo[(size_t)b * 4 + 0] = (unsigned)n_out | ((unsigned)n_g << 8);
+    vb.cinfo[(size_t)b * 4 + 1] = c1;
+    vb.cinfo[(size_t)b * 4 + 2] = c2;
+    vb.cinfo[(size_t)b * 4 + 3] = c4;
+  }
+}
+
+// ---- resolve -----------------------------------------------------------------------------------------------------------------
+struct PairEval {
+  double fit;     // valid when bits == 0
+  unsigned bits;  // 0 feasible; 1 resources, 2 constraints, 4 zero fitness (first failing check, as Fenzo reports)
+};
+
+struct SlotRec {  // one distinct candidate offer of the window, staged in LDS
+  OfferA a;
+  OfferB o;
+  double ac, am;  // snapshot state
+  int acount;
+  int offer;
+};
+
+__global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchIn in, MatchState st, V2Buf vb) {
+  __shared__ double s_c[MV_WMAX], s_m[MV_WMAX];
+  __shared__ unsigned s_jflags[MV_WMAX], s_group[MV_WMAX];
+  __shared__ unsigned char s_gpu[MV_WMAX];
+  __shared__ unsigned s_cinfo[MV_WMAX][4];
+  __shared__ double s_cfit[MV_WMAX][MV_L];
+  __shared__ unsigned short s_cslot[MV_WMAX][MV_L];
+  __shared__ unsigned short s_gslot[MV_WMAX][MV_LG];
+  __shared__ SlotRec s_slot[MV_S];
+  __shared__ unsigned long long s_col[MV_S][MV_JG];
+  __shared__ unsigned char s_slot_lane[MV_S];
+  __shared__ int s_cidx[MV_WMAX][MV_L + MV_LG];
+  __shared__ int s_hkey[MV_HASH];
+  __shared__ unsigned short s_hslot[MV_HASH];
+  __shared__ unsigned s_nslots, s_minbad;
+  const unsigned tid = threadIdx.x, lane = lane_id();
+  WinCtl ctl = *vb.ctl;
+  const unsigned head = ctl.head;
+  if (head >= in.K) return;
+  const unsigned long long tk0 = cook_ticks();
+  const unsigned wend = (head + ctl.wcur < in.K) ? head + ctl.wcur : in.K;
+  const unsigned nwin = wend - head;
+  const bool use_ge = in.good_enough < 1.0;
+  // ---- set-up phase (all threads): stage the window in LDS -------------------------------------------------------------
+  for (unsigned x = tid; x < MV_HASH; x += MV_RTHREADS) s_hkey[x] = -1;
+  if (tid == 0) {
+    s_nslots = 0;
+    s_minbad = 0xFFFFFFFFu;
+  }
+  for (unsigned b = tid; b < nwin; b += MV_RTHREADS) {
+    const JobRec j = vb.jr[head + b];
+    s_c[b] = j.c;
+    s_m[b] = j.m;
+    s_jflags[b] = j.flags;
+    s_group[b] = j.group;
+    s_gpu[b] = j.g > 0 ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_cinfo[b][q] = vb.cinfo[(size_t)b * 4 + q];
+  }
+  __syncthreads();
+  // candidate offers of the whole window -> LDS (one parallel pass; the slot-table passes below then never touch HBM)
+  constexpr int EPJ = MV_L + MV_LG;
+  for (unsigned e = tid; e < nwin * EPJ; e += MV_RTHREADS) {
+    const unsigned b = e / EPJ, q = e % EPJ;
+    const unsigned info = s_cinfo[b][0];
+    int idx = -1;
+    if (q < (unsigned)MV_L) {
+      if (q < (info & 0xFFu)) {
+        idx = vb.cand_idx[(size_t)b * MV_L + q];
+        s_cfit[b][q] = vb.cand_fit[(size_t)b * MV_L + q];
+      }
+    } else if (use_ge && q - MV_L < ((info >> 8) & 0xFFu)) {
+      idx = vb.ge_idx[(size_t)b * MV_LG + (q - MV_L)];
+    }
+    s_cidx[b][q] = idx;
+  }
+  __syncthreads();
+  // slot table = the DISTINCT candidate offers.  Optimistic pass: insert every entry of the window at once; if the table
+  // overflows (rare) redo it MV_JSTEP jobs at a time so that the overflow cuts the window at a job boundary (every job
+  // before the cut has all its candidates staged).
+  for (int pass = 0; pass < 2; ++pass) {
+    const unsigned step = pass == 0 ? nwin : (unsigned)MV_JSTEP;
+    bool overflow = false;
+    for (unsigned s0 = 0; s0 < nwin; s0 += step) {
+      const unsigned e1 = ((s0 + step < nwin) ? s0 + step : nwin) * EPJ;
+      for (unsigned e = s0 * EPJ + tid; e < e1; e += MV_RTHREADS) {
+        const int idx = s_cidx[e / EPJ][e % EPJ];
+        if (idx < 0) continue;
+        unsigned h = ((unsigned)idx * 2654435761u) % MV_HASH;
+        for (;;) {
+          const int old = atomicCAS(&s_hkey[h], -1, idx);
+          if (old == -1) {  // creator: allocate the slot
+            const unsigned s = atomicAdd(&s_nslots, 1u);
+            s_hslot[h] = (unsigned short)(s < (unsigned)MV_S ? s : 0xFFFFu);
+            if (s < (unsigned)MV_S) {
+              s_slot[s].offer = idx;
+            } else {
+              atomicMin(&s_minbad, s0);
+            }
+            break;
+          }
+          if (old == idx) break;
+          h = (h + 1) % MV_HASH;
+          if (pass == 0 && s_nslots > (unsigned)MV_S) break;  // the optimistic pass already failed: stop filling the table
+        }
+      }
+      __syncthreads();
+      overflow = s_nslots > (unsigned)MV_S;  // block-uniform: read between two barriers
+      __syncthreads();
+      if (overflow) break;
+    }
+    if (!overflow || pass == 1) break;
+    // overflow in the optimistic pass: reset the table and go stepwise
+    for (unsigned x = tid; x < MV_HASH; x += MV_RTHREADS) s_hkey[x] = -1;
+    if (tid == 0) {
+      s_nslots = 0;
+      s_minbad = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+  }
+  const unsigned weff = s_minbad < nwin ? s_minbad : nwin;  // jobs resolvable in this round
+  for (unsigned e = tid; e < weff * EPJ; e += MV_RTHREADS) {  // candidate offer -> slot
+    const unsigned b = e / EPJ, q = e % EPJ;
+    const int idx = s_cidx[b][q];
+    if (idx < 0) continue;
+    unsigned h = ((unsigned)idx * 2654435761u) % MV_HASH;
+    while (s_hkey[h] != idx) h = (h + 1) % MV_HASH;
+    if (q < (unsigned)MV_L)
+      s_cslot[b][q] = s_hslot[h];
+    else
+      s_gslot[b][q - MV_L] = s_hslot[h];
+  }
+  const unsigned nslots = s_nslots < (unsigned)MV_S ? s_nslots : (unsigned)MV_S;
+  for (unsigned s = tid; s < nslots; s += MV_RTHREADS) {
+    const int v = s_slot[s].offer;
+    s_slot[s].a = vb.oa[v];
+    s_slot[s].o = vb.ob[v];
+    s_slot[s].ac = st.ac[v];
+    s_slot[s].am = st.am[v];
+    s_slot[s].acount = st.acount[v];
+    s_slot_lane[s] = 0xFF;
+  }
+  for (unsigned x = tid; x < nslots * MV_JG; x += MV_RTHREADS) {
+    const unsigned s = x / MV_JG, g = x % MV_JG;
+    s_col[s][g] = (g * COOK_WAVE < nwin) ? vb.colbits[(size_t)s_slot[s].offer * MV_JG + g] : 0ull;
+  }
+  __syncthreads();
+  if (tid >= COOK_WAVE) return;  // wave 0 walks the window
+  const unsigned long long tk1 = cook_ticks();
+  // ---- sequential phase: touched slot of this lane ------------------------------------------------------------------------
+  int t_slot = -1, t_v = -1;
+  OfferA t_a{0, 0, 0, 0, 0, 0};
+  OfferB t_o{0, 0, 0.0, 0, 0, 0, 0};
+  double t_ac = 0, t_am = 0, t_ac0 = 0, t_am0 = 0;
+  int t_acount = 0, t_acount0 = 0;
+  unsigned nT = 0;
+  unsigned b = 0;
+  unsigned stop = 0;  // 1 list exhausted, 2 touched set full, 3 group barrier, 4 slot table cut the window
+  unsigned matched = 0, head_matched = ctl.head_matched;
+  for (; b < weff; ++b) {
+    const unsigned k = head + b;
+    const double c = s_c[b], m = s_m[b];
+    const unsigned jf = s_jflags[b];
+    const bool grouped = (jf & JF_GROUPED) != 0;
+    const unsigned g = s_group[b], gtype = (jf >> 8) & 3u;
+    unsigned jj = 0;
+    if (grouped) {
+      jj = in.j_index ? in.j_index[k] : k;
+      // a second member of a balanced / attribute-equals group after one was placed in this round: re-snapshot first
+      if (gtype >= 2 && ld_agent(&st.group_last[g]) >= (int)head) {
+        stop = 3;
+        break;
+      }
+    }
+    JobRec jr;
+    jr.c = c;
+    jr.m = m;
+    jr.g = s_gpu[b] ? 1.0 : 0.0;  // only the sign matters to dyn_fast
+    jr.gpu_model = 0;
+    jr.reserved_host = -1;
+    jr.group = g;
+    jr.flags = jf;
+    // every touched offer re-evaluated under the current state
+    PairEval pe{0.0, 8u};
+    if (t_slot >= 0) {
+      pe.bits = 0u;
+      if (t_ac + c > t_a.oc || t_am + m > t_a.om) {
+        pe.bits = 1u;
+      } else {
+        bool ok = ((s_col[t_slot][b >> 6] >> (b & 63u)) & 1ull) != 0 && dyn_fast(jr, t_o, t_acount);
+        if (ok && grouped) ok = group_pass(in, st, jj, (unsigned)t_v);
+        if (!ok) {
+          pe.bits = 2u;
+        } else {
+          pe.fit = fitness_of(t_a, t_ac, t_am, c, m);
+          if (!(pe.fit > 0.0)) pe.bits = 4u;
+        }
+      }
+    }
+    const bool t_feas = (t_slot >= 0) && pe.bits == 0;
+#ifdef __HIP_EMU__
+    if (getenv("V2DBG") && lane < 2) fprintf(stderr, "b=%u lane=%u t_slot=%d t_v=%d t_ac=%g oc=%g pe.bits=%u nT=%u weff=%u nslots=%u info=%x\n", b, lane, t_slot, t_v, t_ac, t_a.oc, pe.bits, nT, weff, nslots, s_cinfo[b][0]);
+#endif
+    const unsigned info = s_cinfo[b][0];
+    // --- arg-max path: first list entry that is untouched, or touched and still feasible ------------------------------
+    const int nc = (int)(info & 0xFFu);
+    Cand ucand{-1.0, -1};  // idx = slot
+    bool settled = false;
+    for (int q = 0; q < nc; ++q) {
+      const unsigned s = s_cslot[b][q];
+      const unsigned ol = s_slot_lane[s];
+      if (ol == 0xFFu) {
+        ucand = Cand{s_cfit[b][q], (int)s};
+        settled = true;
+        break;
+      }
+      if (__shfl((int)t_feas, (int)ol, COOK_WAVE)) {
+        settled = true;  // a touched, still feasible offer dominates every untouched one
+        break;
+      }
+    }
+    if (!settled && nc == MV_L) {
+      stop = 1;
+      break;
+    }
+    // --- good-enough path: lowest offer index with fitness > good-enough ------------------------------------------------
+    int ge_pick = 0x7FFFFFFF;  // offer index
+    int ge_slot = -1;
+    if (use_ge) {
+      const int ng = (int)((info >> 8) & 0xFFu);
+      bool ge_settled = false;
+      int last_idx = -1;
+      for (int q = 0; q < ng; ++q) {
+        const unsigned s = s_gslot[b][q];
+        last_idx = s_slot[s].offer;
+        if (s_slot_lane[s] == 0xFFu) {
+          ge_pick = last_idx;
+          ge_slot = (int)s;
+          ge_settled = true;
+          break;
+        }
+      }
+      int tg = (t_feas && pe.fit > in.good_enough) ? t_v : 0x7FFFFFFF;
+      int tgs = t_slot;
+      for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(tg, d, COOK_WAVE), os = __shfl_xor(tgs, d, COOK_WAVE);
+        if (o < tg) {
+          tg = o;
+          tgs = os;
+        }
+      }
+      if (!ge_settled && ng == MV_LG && tg > last_idx) {
+        // untouched good-enough offers beyond the list may exist with an index below the best touched one
+        stop = 1;
+        break;
+      }
+      if (tg < ge_pick) {
+        ge_pick = tg;
+        ge_slot = tgs;
+      }
+    }
+    // --- best touched vs best untouched (compare by offer index on equal fitness) -----------------------------------------
+    Cand best{t_feas ? pe.fit : -1.0, t_feas ? t_v : -1};
+    int best_slot = t_feas ? t_slot : -1;
+    for (int d = 32; d >= 1; d >>= 1) {
+      const Cand o{__shfl_xor(best.fit, d, COOK_WAVE), __shfl_xor(best.idx, d, COOK_WAVE)};
+      const int os = __shfl_xor(best_slot, d, COOK_WAVE);
+      if (cand_better(o, best)) {
+        best = o;
+        best_slot = os;
+      }
+    }
+    if (ucand.idx >= 0) {
+      const Cand u{ucand.fit, s_slot[ucand.idx].offer};
+      if (cand_better(u, best)) {
+        best = u;
+        best_slot = ucand.idx;
+      }
+    }
+    const int win = (ge_pick != 0x7FFFFFFF) ? ge_pick : best.idx;
+    const int win_slot = (ge_pick != 0x7FFFFFFF) ? ge_slot : best_slot;
+    // --- commit --------------------------------------------------------------------------------------------------------------
+    if (win >= 0) {
+      const bool fresh = s_slot_lane[win_slot] == 0xFFu;
+      wave_sync();  // every lane has read the table before the owning lane updates it
+      if (fresh && nT == (unsigned)MV_T) {
+        stop = 2;  // no free lane to track a new touched offer: end the round before this job
+        break;
+      }
+      if (fresh) {
+        if (lane == nT) {
+          const SlotRec r = s_slot[win_slot];
+          t_slot = win_slot;
+          t_v = win;
+          t_a = r.a;
+          t_o = r.o;
+          t_ac0 = r.ac;
+          t_am0 = r.am;
+          t_acount0 = r.acount;
+          t_ac = t_ac0 + c;
+          t_am = t_am0 + m;
+          t_acount = t_acount0 + 1;
+          s_slot_lane[win_slot] = (unsigned char)nT;
+        }
+        ++nT;
+      } else if (t_slot == win_slot) {
+        t_ac += c;
+        t_am += m;
+        t_acount += 1;
+      }
+      ++matched;
+      if (k == 0) head_matched = 1;
+      if (lane == 0) {
+        st_agent(&st.job_to_offer[k], win);
+        if (st.fail_code) st.fail_code[k] = 0u;
+        if (g != 0xFFFFFFFFu) {
+          st_agent(&st.job_prev[k], ld_agent(&st.group_last[g]));
+          st_agent(&st.group_last[g], (int)k);
+        }
+      }
+      // the unique-group check of later jobs reads job_to_offer / group lists written by lane 0, and every lane reads
+      // s_slot_lane written by the owning lane: order them
+      wave_sync();
+    } else {
+      // unmatched: failure summary = OR over offers of the first failing check under the CURRENT state.  Start from the
+      // snapshot counts and swap each touched offer's snapshot verdict for its current one.
+      const unsigned f1 = s_cinfo[b][1], f2 = s_cinfo[b][2], f4 = s_cinfo[b][3];
+      int d1 = 0, d2 = 0, d4 = 0;
+      if (nT != 0) {  // wave-uniform
+        if (t_slot >= 0) {
+          // snapshot view of this offer: state at round start, group placements of this round ignored via the cutoff
+          PairEval p0{0.0, 0u};
+          if (t_ac0 + c > t_a.oc || t_am0 + m > t_a.om) {
+            p0.bits = 1u;
+          } else {
+            bool ok = ((s_col[t_slot][b >> 6] >> (b & 63u)) & 1ull) != 0 && dyn_fast(jr, t_o, t_acount0);
+            if (ok && grouped) {
+              MatchState st0 = st;
+              st0.cutoff = (int)head;
+              ok = group_pass(in, st0, jj, (unsigned)t_v);
+            }
+            if (!ok) {
+              p0.bits = 2u;
+            } else {
+              p0.fit = fitness_of(t_a, t_ac0, t_am0, c, m);
+              if (!(p0.fit > 0.0)) p0.bits = 4u;
+            }
+          }
+          d1 = (int)(pe.bits & 1u) - (int)(p0.bits & 1u);
+          d2 = (int)((pe.bits >> 1) & 1u) - (int)((p0.bits >> 1) & 1u);
+          d4 = (int)((pe.bits >> 2) & 1u) - (int)((p0.bits >> 2) & 1u);
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+          d1 += __shfl_xor(d1, d, COOK_WAVE);
+          d2 += __shfl_xor(d2, d, COOK_WAVE);
+          d4 += __shfl_xor(d4, d, COOK_WAVE);
+        }
+      }
+      const unsigned bits = (((int)f1 + d1) > 0 ? 1u : 0u) | (((int)f2 + d2) > 0 ? 2u : 0u) | (((int)f4 + d4) > 0 ? 4u : 0u);
+      if (lane == 0) {
+        st_agent(&st.job_to_offer[k], -1);
+        if (st.fail_code) st.fail_code[k] = bits ? bits : 8u;
+      }
+    }
+  }
+  if (stop == 0 && weff < nwin) stop = 4;
+  // write the touched offers' state back and publish the new head
+  if (t_slot >= 0) {
+    st.ac[t_v] = t_ac;
+    st.am[t_v] = t_am;
+    st.acount[t_v] = t_acount;
+  }
+  if (lane == 0) {
+    const unsigned resolved = b;
+    ctl.head = head + b;
+    ctl.rounds += 1;
+    ctl.matched += matched;
+    ctl.head_matched = head_matched;
+    ctl.touched_sum += nT;
+    ctl.t_setup += tk1 - tk0;
+    ctl.t_seq += cook_ticks() - tk1;
+    if (stop == 1) ctl.stop_list += 1;
+    if (stop == 2) ctl.stop_full += 1;
+    if (stop == 3) ctl.stop_group += 1;
+    if (stop == 4) ctl.stop_slots += 1;
+    if (stop == 0) ctl.stop_window += 1;
+    // adapt the window: aim at ~2x what a round resolves, within [64, wmax]
+    unsigned wn = stop == 0 ? ctl.wcur * 2 : resolved * 2;
+    if (wn < 64) wn = 64;
+    if (wn > (unsigned)MV_WMAX) wn = MV_WMAX;
+    ctl.wcur = wn;
+    *vb.ctl = ctl;
+  }
+}

@@ -198,9 +198,9 @@ class Engine:
         return r.value, m.value
 
     def match_stats(self):
-        out = (C.c_uint32 * 8)()
+        out = (C.c_uint32 * 12)()
         self._lib.cook_match_stats(self._h, out)
-        keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "window", "resolved")
+        keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "stop_slots", "resolved", "setup_us", "seq_us", "touched", "_")
         return dict(zip(keys, [int(x) for x in out]))
 
     def set_profiling(self, on: bool):

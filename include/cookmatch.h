@@ -239,9 +239,10 @@ int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms);
 /* named kernel timings of the last run: fills up to cap entries, returns count */
 int cook_kernel_timings(cook_engine* e, const char** names, double* ms, uint32_t* launches, uint32_t cap);
 int cook_set_profiling(cook_engine* e, int enabled);
-/* placement statistics of the last match: [0] rounds, [1] matched, [2..5] rounds ended by list-exhausted / touched-set-full /
-   group barrier / window end, [6] last window size, [7] jobs resolved */
-int cook_match_stats(cook_engine* e, uint32_t out[8]);
+/* placement statistics of the last match: [0] rounds, [1] matched, [2..6] rounds ended by list-exhausted / touched-set-full /
+   group barrier / window end / candidate-slot table full, [7] jobs resolved,
+   [8] microseconds the resolve kernels spent staging windows, [9] ... walking them, [10] offers touched (sum over rounds) */
+int cook_match_stats(cook_engine* e, uint32_t out[12]);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@
 //
 // Every function cites the reference file:line it follows (paths relative to reference scheduler/).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -374,23 +375,41 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
       }
     }
   };
-  std::vector<Best> parts(std::max(1, nthreads));
+  // multi-thread CPU baseline: hosts bucketed across PERSISTENT worker threads per job (mirrors Fenzo's evaluator
+  // pool); identical result to the single bucket when good-enough is disabled (argmax, lowest index on ties).
+  const bool mt = nthreads > 1 && !(ge < 1.0) && M >= 4096;
+  const int T = mt ? nthreads : 1;
+  std::vector<Best> parts(T);
+  std::atomic<uint32_t> gen{0}, done{0};
+  std::atomic<bool> quit{false};
+  uint32_t cur_k = 0;
+  const uint32_t chunk = (M + T - 1) / T;
+  std::vector<std::thread> workers;
+  for (int tix = 1; tix < T; ++tix)
+    workers.emplace_back([&, tix] {
+      uint32_t seen = 0;
+      for (;;) {
+        while (gen.load(std::memory_order_acquire) == seen) {
+          if (quit.load(std::memory_order_relaxed)) return;
+          __builtin_ia32_pause();
+        }
+        ++seen;
+        eval_range(cur_k, std::min(M, tix * chunk), std::min(M, (tix + 1) * chunk), parts[tix]);
+        done.fetch_add(1, std::memory_order_release);
+      }
+    });
   for (uint32_t k = 0; k < K; ++k) {
     Best b;
-    if (nthreads <= 1 || ge < 1.0 || M < 4096) {
+    if (!mt) {
       eval_range(k, 0, M, b);
     } else {
-      // multi-thread CPU baseline: hosts bucketed across threads per job (mirrors Fenzo's evaluator pool);
-      // identical result to the single bucket when good-enough is disabled (argmax, lowest index on ties).
-      std::vector<std::thread> th;
-      const uint32_t chunk = (M + nthreads - 1) / nthreads;
-      for (int tix = 0; tix < nthreads; ++tix)
-        th.emplace_back([&, tix] {
-          eval_range(k, std::min(M, tix * chunk), std::min(M, (tix + 1) * chunk), parts[tix]);
-        });
-      for (auto& x : th) x.join();
+      cur_k = k;
+      done.store(0, std::memory_order_relaxed);
+      gen.fetch_add(1, std::memory_order_release);
+      eval_range(k, 0, std::min(M, chunk), parts[0]);
+      while (done.load(std::memory_order_acquire) != (uint32_t)(T - 1)) __builtin_ia32_pause();
       b = parts[0];
-      for (int tix = 1; tix < nthreads; ++tix) {
+      for (int tix = 1; tix < T; ++tix) {
         b.fail |= parts[tix].fail;
         if (parts[tix].v >= 0 && parts[tix].fit > b.fit) {
           b.fit = parts[tix].fit;
@@ -412,6 +431,8 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
       }
     }
   }
+  quit.store(true);
+  for (auto& w : workers) w.join();
   // scheduler.clj:1495: matched-head-or-no-matches?
   if (head_matched) *head_matched = (matched == 0 || (K > 0 && job_to_offer[0] >= 0)) ? 1 : 0;
 }

@@ -90,3 +90,19 @@ def cycle_parity(make_engine, pool: synth.Pool, params, k):
     assert np.array_equal(j2o, o_j2o)
     assert head == o_head
     return ranked, j2o
+
+
+def pinned_jobs_case(seed, n_jobs, n_offers, cardinality):
+    """Jobs pinned by an EQUALS constraint (constraints.clj:356-377) to one value of an attribute with `cardinality`
+    values (0 = host-unique): spreads the candidates of a window over many distinct offers, which is what fills the
+    placement kernel's candidate-slot table (cardinality ~ 64) or its touched set (host-unique)."""
+    rng = np.random.default_rng(seed)
+    attr = np.zeros((n_offers, 1), dtype=np.uint32)
+    attr[:, 0] = (np.arange(n_offers) + 1) if cardinality == 0 else rng.integers(1, cardinality + 1, n_offers)
+    offers = A.Offers(cpus=rng.integers(4, 17, n_offers).astype(float), mem=rng.integers(4, 17, n_offers) * 4096.0, attr=attr,
+                      k8s=np.ones(n_offers, dtype=np.uint8))
+    hi = n_offers if cardinality == 0 else cardinality
+    equals = [[(0, int(rng.integers(1, hi + 1)))] for _ in range(n_jobs)]
+    jobs = A.Jobs.with_constraints(rng.integers(1, 4, n_jobs).astype(float), rng.integers(1, 4, n_jobs) * 1024.0,
+                                   equals=equals, novel=[[] for _ in range(n_jobs)])
+    return jobs, offers

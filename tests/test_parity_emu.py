@@ -116,6 +116,22 @@ def test_match_group_types(make_engine, algo):
     P.match_parity(make_engine, jobs, offers, groups, A.default_params(good_enough_fitness=1.0, match_algo=algo))
 
 
+def test_match_slot_table_and_touched_set_limits(make_engine):
+    # the candidate-slot table overflows (many distinct candidate offers per window) / the touched set fills (every job
+    # lands on its own host): rounds must end early and the result stay exact
+    jobs, offers = P.pinned_jobs_case(7, 300, 900, 48)
+    p = A.default_params(good_enough_fitness=1.0)
+    P.match_parity(make_engine, jobs, offers, None, p)
+    with make_engine(p) as e:
+        e.match(jobs, offers)
+        assert e.match_stats()["stop_slots"] > 0
+    jobs, offers = P.pinned_jobs_case(8, 300, 400, 0)
+    P.match_parity(make_engine, jobs, offers, None, p)
+    with make_engine(p) as e:
+        e.match(jobs, offers)
+        assert e.match_stats()["stop_full"] > 0
+
+
 def test_cycle_parity(make_engine):
     pool = synth.make_pool(seed=31, n_pending=600, n_running=200, n_users=30, n_offers=100, gpus=True, constraints=True)
     P.cycle_parity(make_engine, pool, A.default_params(good_enough_fitness=1.0), k=150)

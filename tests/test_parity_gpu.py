@@ -122,6 +122,20 @@ def test_match_group_types(make_engine, algo):
     P.match_parity(make_engine, jobs, offers, groups, A.default_params(good_enough_fitness=1.0, match_algo=algo))
 
 
+def test_match_slot_table_and_touched_set_limits(make_engine):
+    p = A.default_params(good_enough_fitness=1.0)
+    jobs, offers = P.pinned_jobs_case(7, 3000, 6000, 64)
+    P.match_parity(make_engine, jobs, offers, None, p)
+    with make_engine(p) as e:
+        e.match(jobs, offers)
+        assert e.match_stats()["stop_slots"] > 0
+    jobs, offers = P.pinned_jobs_case(8, 3000, 4000, 0)
+    P.match_parity(make_engine, jobs, offers, None, p)
+    with make_engine(p) as e:
+        e.match(jobs, offers)
+        assert e.match_stats()["stop_full"] > 0
+
+
 def test_cycle_parity(make_engine):
     pool = synth.make_pool(seed=31, n_pending=20000, n_running=8000, n_users=500, n_offers=2000, gpus=True, constraints=True)
     P.cycle_parity(make_engine, pool, A.default_params(good_enough_fitness=1.0), k=1000)
