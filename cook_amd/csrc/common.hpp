@@ -49,6 +49,58 @@ static __device__ __forceinline__ unsigned long long lanemask_lt() {
   return l == 0 ? 0ull : (~0ull >> (64 - l));
 }
 
+// ---- wave-wide max of a u64 key / lane reads without going through LDS ------------------------------------------------
+// ds_bpermute-based shuffles cost ~100+ cycles of latency each; the placement walk is a dependent chain, so its
+// reductions use DPP (row-level VALU data movement) and v_readlane instead.
+#ifdef __HIP_EMU__
+static inline unsigned long long wave_max_u64(unsigned long long x) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long y = __shfl_xor(x, d, COOK_WAVE);
+    x = y > x ? y : x;
+  }
+  return x;
+}
+static inline int wave_read_lane(int v, int src) { return __shfl(v, src, COOK_WAVE); }
+#else
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ unsigned long long dpp_move_u64(unsigned long long x) {
+  int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+// all 64 lanes must be active
+static __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long x) {
+  unsigned long long y;
+  y = dpp_move_u64<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
+  x = y > x ? y : x;
+  y = dpp_move_u64<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
+  x = y > x ? y : x;
+  y = dpp_move_u64<0x141, 0xF>(x);  // row_half_mirror
+  x = y > x ? y : x;
+  y = dpp_move_u64<0x140, 0xF>(x);  // row_mirror
+  x = y > x ? y : x;
+  y = dpp_move_u64<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
+  x = y > x ? y : x;
+  y = dpp_move_u64<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
+  x = y > x ? y : x;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
+  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+}
+// value of v in lane src; src must be wave-uniform
+static __device__ __forceinline__ int wave_read_lane(int v, int src) {
+  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
+}
+#endif
+
+static __device__ __forceinline__ double wave_read_lane_f64(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)wave_read_lane((int)(unsigned)(unsigned long long)b, src);
+  const unsigned hi = (unsigned)wave_read_lane((int)(unsigned)((unsigned long long)b >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+}
+
 // order-preserving map fp64 -> u64 (full 64 bits: DRUs of magnitude 1e-305 must still order, share.clj:95)
 static __host__ __device__ __forceinline__ uint64_t f64_key(double d) {
   uint64_t b;

@@ -133,6 +133,8 @@ struct cook_engine {
   DArr<uint32_t> v_pcnt, v_cinfo;
   DArr<uint64_t> v_colbits;
   DArr<WinCtl> w_ctl;
+  DArr<MatchIn> v_in;
+  void* h_inbuf = nullptr;  // pinned staging copy of MatchIn
   WinCtl last_ctl{};
   MatchIn min{};
   bool cycle_staged = false;
@@ -697,6 +699,13 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
     vb.ge_idx = e->v_ge_idx.ensure((size_t)MV_WMAX * MV_LG);
     vb.cinfo = e->v_cinfo.ensure((size_t)MV_WMAX * 4);
     vb.ctl = e->w_ctl.ensure(1);
+    {
+      MatchIn* din = e->v_in.ensure(1);
+      MatchIn* hin = (MatchIn*)e->h_inbuf;
+      *hin = in;
+      COOK_HIP(hipMemcpyAsync(din, hin, sizeof(MatchIn), hipMemcpyHostToDevice, e->stream));
+      vb.in_dev = din;
+    }
     if (M) KL("match_pack_offers", match_pack_offers, div_up(M, 256), 256, in, oa, ob);
     KL("match_pack_jobs", match_pack_jobs, div_up(K, 256), 256, in, jr);
     WinCtl c0;
@@ -711,7 +720,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
       for (unsigned r = 0; r < batch; ++r) {
         KL("match_eval2", match_eval2, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
         KL("match_merge2", match_merge2, MV_WMAX, COOK_WAVE, in, vb);
-        KL("match_resolve2", match_resolve2, 1, MV_RTHREADS, in, st, vb);
+        KL("match_resolve2", match_resolve2, 1, MV_RTHREADS, st, vb);
       }
       COOK_HIP(hipMemcpyAsync(e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
       sync(e);
@@ -819,6 +828,7 @@ int cook_engine_create(const cook_params* params, int device_id, cook_engine** o
     COOK_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; ++i) COOK_HIP(hipEventCreate(&e->ev_stage[i]));
     COOK_HIP(hipHostMalloc((void**)&e->h_scratch, 64 * 8, hipHostMallocDefault));
+    COOK_HIP(hipHostMalloc((void**)&e->h_inbuf, sizeof(MatchIn), hipHostMallocDefault));
     e->d_scratch64.ensure(64);
     e->d_counters.ensure(64);
   } catch (const cook_error&) {
@@ -851,12 +861,13 @@ void cook_engine_destroy(cook_engine* e) {
                   &e->j_index.b, &e->o_host.b, &e->o_gpu_model.b, &e->o_disk_type.b, &e->o_attr.b, &e->o_location.b, &e->g_attr_key.b,
                   &e->g_run_off.b, &e->g_run_host.b, &e->g_run_attr.b, &e->reserved_bits.b, &e->m_fail.b, &e->j_reserved_host.b,
                   &e->o_max_tasks.b, &e->o_num_tasks.b, &e->o_run_count.b, &e->g_min.b, &e->m_acount.b, &e->m_group_last.b,
-                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b, &e->v_oa.b, &e->v_ob.b, &e->v_jr.b, &e->v_pfit.b, &e->v_cand_fit.b, &e->v_pidx.b, &e->v_pge.b, &e->v_cand_idx.b, &e->v_ge_idx.b, &e->v_pcnt.b, &e->v_cinfo.b, &e->v_colbits.b, &e->w_ctl.b};
+                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b, &e->v_oa.b, &e->v_ob.b, &e->v_jr.b, &e->v_pfit.b, &e->v_cand_fit.b, &e->v_pidx.b, &e->v_pge.b, &e->v_cand_idx.b, &e->v_ge_idx.b, &e->v_pcnt.b, &e->v_cinfo.b, &e->v_colbits.b, &e->w_ctl.b, &e->v_in.b};
   for (DBuf* b : bufs) b->release();
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i)
     if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]);
   if (e->h_scratch) (void)hipHostFree(e->h_scratch);
+  if (e->h_inbuf) (void)hipHostFree(e->h_inbuf);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1003,7 +1014,7 @@ int cook_match_stats(cook_engine* e, uint32_t out[12]) {
   out[8] = (uint32_t)(c.t_setup / 100ull);  // microseconds
   out[9] = (uint32_t)(c.t_seq / 100ull);
   out[10] = c.touched_sum;
-  out[11] = 0;
+  out[11] = c.visited_sum;
   return COOK_OK;
 }
 int cook_set_profiling(cook_engine* e, int enabled) {

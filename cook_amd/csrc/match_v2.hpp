@@ -33,11 +33,11 @@ constexpr int MV_LG = 4;                   // good-enough list length per job
 constexpr int MV_OCW = 32;                 // offers per eval wave
 constexpr int MV_EW = 4;                   // waves per eval block (same 64 jobs, consecutive offer sub-chunks)
 constexpr int MV_OCB = MV_OCW * MV_EW;     // offers per eval block
-constexpr int MV_T = COOK_WAVE;            // touched offers per round = lanes of the sequencing wave
+constexpr int MV_T = COOK_WAVE;            // touched offers per round = lanes of the walking wave
 constexpr int MV_RTHREADS = 256;           // threads of the resolve workgroup (set-up phase); wave 0 sequences
 #ifdef __HIP_EMU__
 constexpr int MV_WMAX = 128;               // jobs per round (emulator: small, so that tests run many rounds)
-constexpr int MV_S = 96;                   // distinct candidate offers staged per round
+constexpr int MV_S = 128;                  // distinct candidate offers staged per round
 constexpr int MV_HASH = 512;
 #else
 constexpr int MV_WMAX = 512;
@@ -78,6 +78,7 @@ struct WinCtl {
   unsigned head_matched;  // job 0 was matched
   unsigned stop_list, stop_full, stop_group, stop_window, stop_slots;  // why rounds ended (statistics)
   unsigned touched_sum;   // sum over rounds of touched offers
+  unsigned visited_sum;   // sum over rounds of jobs the walk had to visit (the rest were settled in parallel)
   unsigned long long t_setup, t_seq;  // resolve kernel: ticks (100 MHz wall clock) spent in the set-up / sequential phase
 };
 
@@ -95,6 +96,7 @@ struct V2Buf {
   int* ge_idx;         // [wmax][LG]
   uint32_t* cinfo;     // [wmax][4]      ncand | nge << 8, c1, c2, c4
   WinCtl* ctl;
+  const MatchIn* in_dev;  // the MatchIn of this call in device memory (the walk only needs it for constrained groups)
   unsigned C;          // eval blocks along the offers
 };
 
@@ -462,11 +464,6 @@ __global__ void __launch_bounds__(COOK_WAVE) match_merge2(MatchIn in, V2Buf vb) 
 }
 
 // ---- resolve -----------------------------------------------------------------------------------------------------------------
-struct PairEval {
-  double fit;     // valid when bits == 0
-  unsigned bits;  // 0 feasible; 1 resources, 2 constraints, 4 zero fitness (first failing check, as Fenzo reports)
-};
-
 struct SlotRec {  // one distinct candidate offer of the window, staged in LDS
   OfferA a;
   OfferB o;
@@ -474,62 +471,110 @@ struct SlotRec {  // one distinct candidate offer of the window, staged in LDS
   int acount;
   int offer;
 };
+struct JobL {  // a job of the window as the walk reads it (one 32-byte LDS record)
+  double c, m;
+  unsigned info;  // bits 0-7 ncand, 8-15 nge, 16 gpu job, 17 member of a constrained group, 18-19 group type
+  unsigned group;
+  unsigned short f1, f2, f4, pad;  // saturated counts of offers failing on resources / constraints / zero fitness under S
+};
+struct EntL {  // candidate-list entry (16 bytes): fitness under S, offer, slot
+  double fit;
+  int off;
+  unsigned short slot, pad;
+};
+struct GEntL {  // good-enough list entry
+  int off;
+  unsigned short slot, pad;
+};
+constexpr unsigned JL_GPU = 1u << 16, JL_GROUPED = 1u << 17;
 
-__global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchIn in, MatchState st, V2Buf vb) {
-  __shared__ double s_c[MV_WMAX], s_m[MV_WMAX];
-  __shared__ unsigned s_jflags[MV_WMAX], s_group[MV_WMAX];
-  __shared__ unsigned char s_gpu[MV_WMAX];
-  __shared__ unsigned s_cinfo[MV_WMAX][4];
-  __shared__ double s_cfit[MV_WMAX][MV_L];
-  __shared__ unsigned short s_cslot[MV_WMAX][MV_L];
-  __shared__ unsigned short s_gslot[MV_WMAX][MV_LG];
+static __device__ __attribute__((noinline)) bool group_pass_dev(const MatchIn* in, MatchState st, unsigned jj, unsigned v) {
+  return group_pass(*in, st, jj, v);
+}
+
+__global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2Buf vb) {
+  __shared__ JobL s_job[MV_WMAX];
+  __shared__ EntL s_ent[MV_WMAX][MV_L];
+  __shared__ GEntL s_gent[MV_WMAX][MV_LG];
   __shared__ SlotRec s_slot[MV_S];
   __shared__ unsigned long long s_col[MV_S][MV_JG];
   __shared__ unsigned char s_slot_lane[MV_S];
-  __shared__ int s_cidx[MV_WMAX][MV_L + MV_LG];
   __shared__ int s_hkey[MV_HASH];
   __shared__ unsigned short s_hslot[MV_HASH];
+  __shared__ int s_j2o[MV_WMAX];               // results of the walk, flushed to HBM once per round: a global store inside
+  __shared__ unsigned char s_fail[MV_WMAX];    // the walk would stall later s_waitcnt vmcnt(0) on its acknowledgement
+  __shared__ unsigned short s_list[MV_WMAX];   // the jobs the walk has to visit, in rank order
+  __shared__ unsigned long long s_visit[MV_JG];
   __shared__ unsigned s_nslots, s_minbad;
   const unsigned tid = threadIdx.x, lane = lane_id();
   WinCtl ctl = *vb.ctl;
   const unsigned head = ctl.head;
-  if (head >= in.K) return;
+  const unsigned K = vb.in_dev->K;
+  if (head >= K) return;
   const unsigned long long tk0 = cook_ticks();
-  const unsigned wend = (head + ctl.wcur < in.K) ? head + ctl.wcur : in.K;
+  const unsigned wend = (head + ctl.wcur < K) ? head + ctl.wcur : K;
   const unsigned nwin = wend - head;
-  const bool use_ge = in.good_enough < 1.0;
+  const double good_enough = vb.in_dev->good_enough;
+  const bool use_ge = good_enough < 1.0;
   // ---- set-up phase (all threads): stage the window in LDS -------------------------------------------------------------
   for (unsigned x = tid; x < MV_HASH; x += MV_RTHREADS) s_hkey[x] = -1;
+  if (tid < MV_JG) s_visit[tid] = 0ull;
   if (tid == 0) {
     s_nslots = 0;
     s_minbad = 0xFFFFFFFFu;
   }
+  __syncthreads();
   for (unsigned b = tid; b < nwin; b += MV_RTHREADS) {
     const JobRec j = vb.jr[head + b];
-    s_c[b] = j.c;
-    s_m[b] = j.m;
-    s_jflags[b] = j.flags;
-    s_group[b] = j.group;
-    s_gpu[b] = j.g > 0 ? 1 : 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s_cinfo[b][q] = vb.cinfo[(size_t)b * 4 + q];
+    const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
+    const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
+    JobL r;
+    r.c = j.c;
+    r.m = j.m;
+    const bool grouped = (j.flags & JF_GROUPED) != 0;
+    r.info = (info & 0xFFFFu) | (j.g > 0 ? JL_GPU : 0u) | (grouped ? JL_GROUPED : 0u) | (((j.flags >> 8) & 3u) << 18);
+    r.group = j.group;
+    r.f1 = (unsigned short)(c1 < 0xFFFFu ? c1 : 0xFFFFu);
+    r.f2 = (unsigned short)(c2 < 0xFFFFu ? c2 : 0xFFFFu);
+    r.f4 = (unsigned short)(c4 < 0xFFFFu ? c4 : 0xFFFFu);
+    r.pad = 0;
+    s_job[b] = r;
+    // A job without any feasible offer under S stays unmatched whatever the jobs before it do (placements only take
+    // capacity away; constrained groups excepted), and its failure summary cannot change when every class it reports is
+    // backed by more offers than a round can touch: such jobs are settled here, in parallel, and the walk skips them.
+    const bool trivial = (info & 0xFFFFu) == 0u && !grouped && c1 > 0u && (c2 == 0u || c2 > (unsigned)MV_T) &&
+                         (c4 == 0u || c4 > (unsigned)MV_T);
+    if (trivial) {
+      s_j2o[b] = -1;
+      s_fail[b] = (unsigned char)(1u | (c2 ? 2u : 0u) | (c4 ? 4u : 0u));
+    } else {
+      atomicOr(&s_visit[b >> 6], 1ull << (b & 63u));
+    }
   }
-  __syncthreads();
-  // candidate offers of the whole window -> LDS (one parallel pass; the slot-table passes below then never touch HBM)
+  // candidate lists of the whole window -> LDS (one parallel pass; the slot-table passes below then never touch HBM)
   constexpr int EPJ = MV_L + MV_LG;
   for (unsigned e = tid; e < nwin * EPJ; e += MV_RTHREADS) {
     const unsigned b = e / EPJ, q = e % EPJ;
-    const unsigned info = s_cinfo[b][0];
-    int idx = -1;
+    const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
     if (q < (unsigned)MV_L) {
+      EntL x;
+      x.fit = -1.0;
+      x.off = -1;
+      x.slot = 0;
+      x.pad = 0;
       if (q < (info & 0xFFu)) {
-        idx = vb.cand_idx[(size_t)b * MV_L + q];
-        s_cfit[b][q] = vb.cand_fit[(size_t)b * MV_L + q];
+        x.off = vb.cand_idx[(size_t)b * MV_L + q];
+        x.fit = vb.cand_fit[(size_t)b * MV_L + q];
       }
-    } else if (use_ge && q - MV_L < ((info >> 8) & 0xFFu)) {
-      idx = vb.ge_idx[(size_t)b * MV_LG + (q - MV_L)];
+      s_ent[b][q] = x;
+    } else {
+      GEntL x;
+      x.off = -1;
+      x.slot = 0;
+      x.pad = 0;
+      if (use_ge && q - MV_L < ((info >> 8) & 0xFFu)) x.off = vb.ge_idx[(size_t)b * MV_LG + (q - MV_L)];
+      s_gent[b][q - MV_L] = x;
     }
-    s_cidx[b][q] = idx;
   }
   __syncthreads();
   // slot table = the DISTINCT candidate offers.  Optimistic pass: insert every entry of the window at once; if the table
@@ -541,7 +586,8 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchIn in, MatchS
     for (unsigned s0 = 0; s0 < nwin; s0 += step) {
       const unsigned e1 = ((s0 + step < nwin) ? s0 + step : nwin) * EPJ;
       for (unsigned e = s0 * EPJ + tid; e < e1; e += MV_RTHREADS) {
-        const int idx = s_cidx[e / EPJ][e % EPJ];
+        const unsigned b = e / EPJ, q = e % EPJ;
+        const int idx = q < (unsigned)MV_L ? s_ent[b][q].off : s_gent[b][q - MV_L].off;
         if (idx < 0) continue;
         unsigned h = ((unsigned)idx * 2654435761u) % MV_HASH;
         for (;;) {
@@ -578,14 +624,14 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchIn in, MatchS
   const unsigned weff = s_minbad < nwin ? s_minbad : nwin;  // jobs resolvable in this round
   for (unsigned e = tid; e < weff * EPJ; e += MV_RTHREADS) {  // candidate offer -> slot
     const unsigned b = e / EPJ, q = e % EPJ;
-    const int idx = s_cidx[b][q];
+    const int idx = q < (unsigned)MV_L ? s_ent[b][q].off : s_gent[b][q - MV_L].off;
     if (idx < 0) continue;
     unsigned h = ((unsigned)idx * 2654435761u) % MV_HASH;
     while (s_hkey[h] != idx) h = (h + 1) % MV_HASH;
     if (q < (unsigned)MV_L)
-      s_cslot[b][q] = s_hslot[h];
+      s_ent[b][q].slot = s_hslot[h];
     else
-      s_gslot[b][q - MV_L] = s_hslot[h];
+      s_gent[b][q - MV_L].slot = s_hslot[h];
   }
   const unsigned nslots = s_nslots < (unsigned)MV_S ? s_nslots : (unsigned)MV_S;
   for (unsigned s = tid; s < nslots; s += MV_RTHREADS) {
@@ -603,237 +649,379 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchIn in, MatchS
   }
   __syncthreads();
   if (tid >= COOK_WAVE) return;  // wave 0 walks the window
+  // the jobs to visit, compacted in rank order
+  unsigned n_list = 0;
+  for (unsigned g = 0; g * COOK_WAVE < weff; ++g) {
+    unsigned long long mk = s_visit[g];
+    if (weff - g * COOK_WAVE < COOK_WAVE) mk &= (1ull << (weff - g * COOK_WAVE)) - 1ull;
+    if ((mk >> lane) & 1ull) s_list[n_list + (unsigned)__popcll(mk & lanemask_lt())] = (unsigned short)(g * COOK_WAVE + lane);
+    n_list += (unsigned)__popcll(mk);
+  }
+  wave_sync();
   const unsigned long long tk1 = cook_ticks();
-  // ---- sequential phase: touched slot of this lane ------------------------------------------------------------------------
+  // ---- sequential phase ---------------------------------------------------------------------------------------------------
+  // The walk is one dependent chain and a single wave issues one instruction at a time, so its cost per job is its
+  // instruction count.  Lanes own the offers touched in this round (state in registers).  Everything a job needs from LDS
+  // is fetched one job ahead; cross-lane traffic is ballots, v_readlane and one DPP max-reduction (no ds_bpermute);
+  // fitness values are first compared through a reciprocal-multiply approximation (relative error < 2^-50) and the two
+  // fp64 divides are only executed when candidates are closer than 2^-38 relative — exactness is unaffected.
   int t_slot = -1, t_v = -1;
-  OfferA t_a{0, 0, 0, 0, 0, 0};
-  OfferB t_o{0, 0, 0.0, 0, 0, 0, 0};
-  double t_ac = 0, t_am = 0, t_ac0 = 0, t_am0 = 0;
-  int t_acount = 0, t_acount0 = 0;
+  double t_oc = 0, t_om = 0, t_rc = 0, t_rm = 0, t_invc = 0, t_invm = 0;
+  double t_ac = 0, t_am = 0, t_basec = 0, t_basem = 0;
+  int t_acount = 0, t_run = 0, t_slack = 0;
+  unsigned t_k8s = 0;
+  unsigned long long t_col = 0ull;
+  unsigned cur_g = 0xFFFFFFFFu;
   unsigned nT = 0;
-  unsigned b = 0;
   unsigned stop = 0;  // 1 list exhausted, 2 touched set full, 3 group barrier, 4 slot table cut the window
   unsigned matched = 0, head_matched = ctl.head_matched;
-  for (; b < weff; ++b) {
-    const unsigned k = head + b;
-    const double c = s_c[b], m = s_m[b];
-    const unsigned jf = s_jflags[b];
-    const bool grouped = (jf & JF_GROUPED) != 0;
-    const unsigned g = s_group[b], gtype = (jf >> 8) & 3u;
+  unsigned resolved = weff;
+  constexpr double EPS_HI = 1.0 + 0x1p-38, EPS_LO = 1.0 - 0x1p-38;
+  struct JobRegs {
+    unsigned b;
+    double c, m;
+    unsigned info, group;
+    EntL e;          // list entry `lane` (lanes >= MV_L idle)
+    unsigned owner;  // lane owning e.slot, 0xFF untouched, 0xFE no entry
+  };
+  auto load_job = [&](unsigned i) {
+    JobRegs r;
+    r.b = i < n_list ? s_list[i] : 0u;
+    const JobL j = s_job[r.b];
+    r.c = j.c;
+    r.m = j.m;
+    r.info = j.info;
+    r.group = j.group;
+    r.e.fit = -1.0;
+    r.e.off = -1;
+    r.e.slot = 0;
+    r.e.pad = 0;
+    r.owner = 0xFEu;
+    if (lane < (unsigned)MV_L) {
+      r.e = s_ent[r.b][lane];
+      if (r.e.off >= 0) r.owner = s_slot_lane[r.e.slot];
+    }
+    return r;
+  };
+  JobRegs nxt = load_job(0);
+  for (unsigned i = 0; i < n_list; ++i) {
+    const JobRegs cur = nxt;
+    nxt = load_job(i + 1);
+    const unsigned b = cur.b, k = head + b, bl = b & 63u;
+    const double c = cur.c, m = cur.m;
+    const bool grouped = (cur.info & JL_GROUPED) != 0;
+    const bool job_gpu = (cur.info & JL_GPU) != 0;
+    const unsigned g = cur.group, gtype = (cur.info >> 18) & 3u;
+    const int nc = (int)(cur.info & 0xFFu);
+    if ((b >> 6) != cur_g) {  // next 64-job group: the touched lanes fetch their colbits word
+      cur_g = b >> 6;
+      if (t_slot >= 0) t_col = s_col[t_slot][cur_g];
+    }
     unsigned jj = 0;
+    bool gok = true;
     if (grouped) {
-      jj = in.j_index ? in.j_index[k] : k;
+      jj = vb.in_dev->j_index ? vb.in_dev->j_index[k] : k;
       // a second member of a balanced / attribute-equals group after one was placed in this round: re-snapshot first
       if (gtype >= 2 && ld_agent(&st.group_last[g]) >= (int)head) {
         stop = 3;
+        resolved = b;
         break;
       }
+      if (t_slot >= 0) gok = group_pass_dev(vb.in_dev, st, jj, (unsigned)t_v);
     }
-    JobRec jr;
-    jr.c = c;
-    jr.m = m;
-    jr.g = s_gpu[b] ? 1.0 : 0.0;  // only the sign matters to dyn_fast
-    jr.gpu_model = 0;
-    jr.reserved_host = -1;
-    jr.group = g;
-    jr.flags = jf;
-    // every touched offer re-evaluated under the current state
-    PairEval pe{0.0, 8u};
-    if (t_slot >= 0) {
-      pe.bits = 0u;
-      if (t_ac + c > t_a.oc || t_am + m > t_a.om) {
-        pe.bits = 1u;
-      } else {
-        bool ok = ((s_col[t_slot][b >> 6] >> (b & 63u)) & 1ull) != 0 && dyn_fast(jr, t_o, t_acount);
-        if (ok && grouped) ok = group_pass(in, st, jj, (unsigned)t_v);
-        if (!ok) {
-          pe.bits = 2u;
-        } else {
-          pe.fit = fitness_of(t_a, t_ac, t_am, c, m);
-          if (!(pe.fit > 0.0)) pe.bits = 4u;
-        }
-      }
-    }
-    const bool t_feas = (t_slot >= 0) && pe.bits == 0;
-#ifdef __HIP_EMU__
-    if (getenv("V2DBG") && lane < 2) fprintf(stderr, "b=%u lane=%u t_slot=%d t_v=%d t_ac=%g oc=%g pe.bits=%u nT=%u weff=%u nslots=%u info=%x\n", b, lane, t_slot, t_v, t_ac, t_a.oc, pe.bits, nT, weff, nslots, s_cinfo[b][0]);
-#endif
-    const unsigned info = s_cinfo[b][0];
-    // --- arg-max path: first list entry that is untouched, or touched and still feasible ------------------------------
-    const int nc = (int)(info & 0xFFu);
-    Cand ucand{-1.0, -1};  // idx = slot
-    bool settled = false;
-    for (int q = 0; q < nc; ++q) {
-      const unsigned s = s_cslot[b][q];
-      const unsigned ol = s_slot_lane[s];
-      if (ol == 0xFFu) {
-        ucand = Cand{s_cfit[b][q], (int)s};
-        settled = true;
-        break;
-      }
-      if (__shfl((int)t_feas, (int)ol, COOK_WAVE)) {
-        settled = true;  // a touched, still feasible offer dominates every untouched one
-        break;
-      }
-    }
-    if (!settled && nc == MV_L) {
+    // every touched offer re-evaluated under the current state: verdict + approximate fitness
+    const bool t_on = t_slot >= 0;
+    const bool res_ok = t_on && !(t_ac + c > t_oc || t_am + m > t_om);
+    bool con_ok = ((t_col >> bl) & 1ull) != 0 && t_acount < t_slack && gok;
+    if (job_gpu && t_k8s && t_run + t_acount != 0) con_ok = false;
+    const double nc_ = t_basec + c, nm_ = t_basem + m;  // (rc + ac) + c, (rm + am) + m
+    const double a1 = nc_ * t_invc, a2 = nm_ * t_invm;
+    const double fa = (a1 + a2) * 0.5;
+    const bool cand = res_ok && con_ok;
+    // the approximation is trusted for ordering only when both terms are non-negative and the result is positive
+    const bool sane = a1 >= 0.0 && a2 >= 0.0 && fa > 0.0;
+    bool need_exact = use_ge || __any(cand && !sane);
+    const unsigned long long cand_mask = __ballot(cand);
+    // --- arg-max path: first list entry that is untouched, or touched and still a candidate -------------------------------
+    // (a touched offer that is still feasible only gained fitness, so it dominates every untouched offer behind it; a
+    //  zero-fitness verdict cannot appear on an offer that was feasible under S)
+    const bool e_valid = cur.owner != 0xFEu;
+    const bool e_untouched = cur.owner == 0xFFu;
+    const bool e_live = e_valid && !e_untouched && ((cand_mask >> (cur.owner & 63u)) & 1ull);
+    const unsigned long long settle_mask = __ballot(e_untouched || e_live), untouched_mask = __ballot(e_untouched);
+    if (settle_mask == 0ull && nc == MV_L) {
       stop = 1;
+      resolved = b;
       break;
     }
-    // --- good-enough path: lowest offer index with fitness > good-enough ------------------------------------------------
-    int ge_pick = 0x7FFFFFFF;  // offer index
-    int ge_slot = -1;
-    if (use_ge) {
-      const int ng = (int)((info >> 8) & 0xFFu);
-      bool ge_settled = false;
-      int last_idx = -1;
-      for (int q = 0; q < ng; ++q) {
-        const unsigned s = s_gslot[b][q];
-        last_idx = s_slot[s].offer;
-        if (s_slot_lane[s] == 0xFFu) {
-          ge_pick = last_idx;
-          ge_slot = (int)s;
-          ge_settled = true;
+    double u_fit = -1.0;  // best untouched candidate: fitness under S, offer, slot
+    int u_off = -1, u_slot = -1;
+    if (settle_mask != 0ull) {
+      const int qs = __ffsll((unsigned long long)settle_mask) - 1;
+      if ((untouched_mask >> qs) & 1ull) {
+        u_fit = wave_read_lane_f64(cur.e.fit, qs);
+        u_off = wave_read_lane(cur.e.off, qs);
+        u_slot = wave_read_lane((int)cur.e.slot, qs);
+      }
+    }
+    // --- best touched candidate ----------------------------------------------------------------------------------------------
+    int win = -1, win_slot = -1, win_lane = -1;  // win_lane >= 0: a touched offer wins
+    bool decided = false;
+    if (!need_exact) {
+      if (cand_mask == 0ull) {
+        win = u_off;
+        win_slot = u_slot;
+        decided = true;
+      } else {
+        const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(fa) : 0ull;  // positive doubles
+        const double mx = __longlong_as_double((long long)wave_max_u64(key));
+        const unsigned long long near = __ballot(cand && fa >= mx * EPS_LO);
+        if ((near & (near - 1ull)) == 0ull) {  // one touched offer clearly ahead of the other touched ones
+          if (u_off < 0 || mx * EPS_LO > u_fit) {
+            win_lane = __ffsll((unsigned long long)near) - 1;
+            decided = true;
+          } else if (mx * EPS_HI < u_fit) {
+            win = u_off;
+            win_slot = u_slot;
+            decided = true;
+          }
+        }
+        if (!decided) need_exact = true;
+      }
+    }
+    unsigned pe_bits = 8u;  // exact verdict of this lane's offer (only when the exact path ran)
+    double pe_fit = 0.0;
+    if (need_exact) {
+      if (t_on) {
+        pe_bits = 0u;
+        if (!res_ok) {
+          pe_bits = 1u;
+        } else if (!con_ok) {
+          pe_bits = 2u;
+        } else {
+          pe_fit = (nc_ / (t_oc + t_rc) + nm_ / (t_om + t_rm)) / 2.0;
+          if (!(pe_fit > 0.0)) pe_bits = 4u;
+        }
+      }
+      const bool t_feas = t_on && pe_bits == 0u;
+      const unsigned long long feas_mask = __ballot(t_feas);
+      // with exact verdicts a list entry settles only if its owner is still FEASIBLE (zero fitness excluded)
+      const bool e_live2 = e_valid && !e_untouched && ((feas_mask >> (cur.owner & 63u)) & 1ull);
+      const unsigned long long settle2 = __ballot(e_untouched || e_live2);
+      if (settle2 == 0ull && nc == MV_L) {
+        stop = 1;
+        resolved = b;
+        break;
+      }
+      u_fit = -1.0;
+      u_off = u_slot = -1;
+      if (settle2 != 0ull) {
+        const int qs = __ffsll((unsigned long long)settle2) - 1;
+        if ((untouched_mask >> qs) & 1ull) {
+          u_fit = wave_read_lane_f64(cur.e.fit, qs);
+          u_off = wave_read_lane(cur.e.off, qs);
+          u_slot = wave_read_lane((int)cur.e.slot, qs);
+        }
+      }
+      // good-enough path: lowest offer index with fitness > good-enough (scheduler.clj:2312-2314)
+      int ge_pick = 0x7FFFFFFF, ge_slot = -1, ge_lane = -1;
+      if (use_ge) {
+        const int ng = (int)((cur.info >> 8) & 0xFFu);
+        GEntL ge;
+        ge.off = -1;
+        ge.slot = 0;
+        ge.pad = 0;
+        unsigned g_owner = 0xFEu;
+        if ((int)lane < ng) {
+          ge = s_gent[b][lane];
+          g_owner = s_slot_lane[ge.slot];
+        }
+        const unsigned long long gun = __ballot(g_owner == 0xFFu);
+        int last_idx = -1;
+        if (ng > 0) last_idx = wave_read_lane(ge.off, ng - 1);
+        if (gun != 0ull) {
+          const int q = __ffsll((unsigned long long)gun) - 1;
+          ge_pick = wave_read_lane(ge.off, q);
+          ge_slot = wave_read_lane((int)ge.slot, q);
+        }
+        // lowest-index touched offer that is feasible with fitness > good-enough
+        const unsigned long long tkey = (t_feas && pe_fit > good_enough)
+                                            ? (((unsigned long long)(unsigned)(0x7FFFFFFF - t_v) << 32) | (unsigned long long)lane)
+                                            : 0ull;
+        const unsigned long long tmx = feas_mask != 0ull ? wave_max_u64(tkey) : 0ull;
+        const int tg = tmx != 0ull ? 0x7FFFFFFF - (int)(unsigned)(tmx >> 32) : 0x7FFFFFFF;
+        if (gun == 0ull && ng == MV_LG && tg > last_idx) {
+          // untouched good-enough offers beyond the list may exist with an index below the best touched one
+          stop = 1;
+          resolved = b;
           break;
         }
-      }
-      int tg = (t_feas && pe.fit > in.good_enough) ? t_v : 0x7FFFFFFF;
-      int tgs = t_slot;
-      for (int d = 32; d >= 1; d >>= 1) {
-        const int o = __shfl_xor(tg, d, COOK_WAVE), os = __shfl_xor(tgs, d, COOK_WAVE);
-        if (o < tg) {
-          tg = o;
-          tgs = os;
+        if (tg < ge_pick) {
+          ge_pick = tg;
+          ge_lane = (int)(unsigned)(tmx & 63ull);
         }
       }
-      if (!ge_settled && ng == MV_LG && tg > last_idx) {
-        // untouched good-enough offers beyond the list may exist with an index below the best touched one
-        stop = 1;
-        break;
-      }
-      if (tg < ge_pick) {
-        ge_pick = tg;
-        ge_slot = tgs;
+      if (ge_pick != 0x7FFFFFFF) {
+        if (ge_lane >= 0) {
+          win_lane = ge_lane;
+        } else {
+          win = ge_pick;
+          win_slot = ge_slot;
+        }
+      } else {
+        // best touched (max fitness, lowest offer index on ties) vs best untouched
+        Cand best{-1.0, -1};
+        int best_lane = -1;
+        if (feas_mask != 0ull) {
+          const unsigned long long key = t_feas ? (unsigned long long)__double_as_longlong(pe_fit) : 0ull;
+          const unsigned long long mx = wave_max_u64(key);
+          unsigned long long tie = __ballot(t_feas && key == mx);
+          int wl = __ffsll((unsigned long long)tie) - 1;
+          int wv = wave_read_lane(t_v, wl);
+          tie &= tie - 1ull;
+          while (tie != 0ull) {  // equal fitness on several touched offers: the lowest offer index wins
+            const int l2 = __ffsll((unsigned long long)tie) - 1;
+            const int v2 = wave_read_lane(t_v, l2);
+            if (v2 < wv) {
+              wv = v2;
+              wl = l2;
+            }
+            tie &= tie - 1ull;
+          }
+          best = Cand{__longlong_as_double((long long)mx), wv};
+          best_lane = wl;
+        }
+        if (u_off >= 0 && cand_better(Cand{u_fit, u_off}, best)) {
+          win = u_off;
+          win_slot = u_slot;
+        } else if (best_lane >= 0) {
+          win_lane = best_lane;
+        }
       }
     }
-    // --- best touched vs best untouched (compare by offer index on equal fitness) -----------------------------------------
-    Cand best{t_feas ? pe.fit : -1.0, t_feas ? t_v : -1};
-    int best_slot = t_feas ? t_slot : -1;
-    for (int d = 32; d >= 1; d >>= 1) {
-      const Cand o{__shfl_xor(best.fit, d, COOK_WAVE), __shfl_xor(best.idx, d, COOK_WAVE)};
-      const int os = __shfl_xor(best_slot, d, COOK_WAVE);
-      if (cand_better(o, best)) {
-        best = o;
-        best_slot = os;
-      }
-    }
-    if (ucand.idx >= 0) {
-      const Cand u{ucand.fit, s_slot[ucand.idx].offer};
-      if (cand_better(u, best)) {
-        best = u;
-        best_slot = ucand.idx;
-      }
-    }
-    const int win = (ge_pick != 0x7FFFFFFF) ? ge_pick : best.idx;
-    const int win_slot = (ge_pick != 0x7FFFFFFF) ? ge_slot : best_slot;
     // --- commit --------------------------------------------------------------------------------------------------------------
-    if (win >= 0) {
-      const bool fresh = s_slot_lane[win_slot] == 0xFFu;
-      wave_sync();  // every lane has read the table before the owning lane updates it
-      if (fresh && nT == (unsigned)MV_T) {
-        stop = 2;  // no free lane to track a new touched offer: end the round before this job
-        break;
-      }
-      if (fresh) {
-        if (lane == nT) {
-          const SlotRec r = s_slot[win_slot];
-          t_slot = win_slot;
-          t_v = win;
-          t_a = r.a;
-          t_o = r.o;
-          t_ac0 = r.ac;
-          t_am0 = r.am;
-          t_acount0 = r.acount;
-          t_ac = t_ac0 + c;
-          t_am = t_am0 + m;
-          t_acount = t_acount0 + 1;
-          s_slot_lane[win_slot] = (unsigned char)nT;
-        }
-        ++nT;
-      } else if (t_slot == win_slot) {
+    if (win_lane >= 0) {  // an offer touched earlier in this round takes the job
+      if ((int)lane == win_lane) {
         t_ac += c;
         t_am += m;
         t_acount += 1;
+        t_basec = t_rc + t_ac;
+        t_basem = t_rm + t_am;
       }
+      win = wave_read_lane(t_v, win_lane);
+    } else if (win >= 0) {  // an untouched offer: the next free lane takes ownership
+      if (nT == (unsigned)MV_T) {
+        stop = 2;  // no free lane to track a new touched offer: end the round before this job
+        resolved = b;
+        break;
+      }
+      if (lane == nT) {
+        const SlotRec r = s_slot[win_slot];
+        t_slot = win_slot;
+        t_v = win;
+        t_oc = r.a.oc;
+        t_om = r.a.om;
+        t_rc = r.a.rc;
+        t_rm = r.a.rm;
+        t_invc = r.a.inv_dc;
+        t_invm = r.a.inv_dm;
+        t_k8s = r.o.flags & 1u;
+        t_run = r.o.run_count;
+        t_slack = r.o.task_slack;
+        t_ac = r.ac + c;
+        t_am = r.am + m;
+        t_acount = r.acount + 1;
+        t_basec = t_rc + t_ac;
+        t_basem = t_rm + t_am;
+        t_col = s_col[win_slot][cur_g];
+        s_slot_lane[win_slot] = (unsigned char)nT;
+      }
+      // the entry of the next job was fetched before this commit: patch its owner
+      if (nxt.owner == 0xFFu && nxt.e.slot == (unsigned short)win_slot) nxt.owner = nT;
+      ++nT;
+      wave_sync();  // the owner table update is visible to the whole wave before the next prefetch reads it
+    }
+    if (win >= 0) {
       ++matched;
       if (k == 0) head_matched = 1;
       if (lane == 0) {
-        st_agent(&st.job_to_offer[k], win);
-        if (st.fail_code) st.fail_code[k] = 0u;
-        if (g != 0xFFFFFFFFu) {
+        s_j2o[b] = win;
+        s_fail[b] = 0;
+        if (g != 0xFFFFFFFFu) {  // cotasks look each other up through HBM (group_pass): publish at once
+          st_agent(&st.job_to_offer[k], win);
           st_agent(&st.job_prev[k], ld_agent(&st.group_last[g]));
           st_agent(&st.group_last[g], (int)k);
         }
       }
-      // the unique-group check of later jobs reads job_to_offer / group lists written by lane 0, and every lane reads
-      // s_slot_lane written by the owning lane: order them
-      wave_sync();
+      if (g != 0xFFFFFFFFu) wave_sync();  // later cotasks of this wave read what lane 0 just published
     } else {
       // unmatched: failure summary = OR over offers of the first failing check under the CURRENT state.  Start from the
-      // snapshot counts and swap each touched offer's snapshot verdict for its current one.
-      const unsigned f1 = s_cinfo[b][1], f2 = s_cinfo[b][2], f4 = s_cinfo[b][3];
+      // snapshot counts and swap each touched offer's snapshot verdict for its current one (exact verdicts needed).
+      const JobL jl = s_job[b];
       int d1 = 0, d2 = 0, d4 = 0;
       if (nT != 0) {  // wave-uniform
-        if (t_slot >= 0) {
-          // snapshot view of this offer: state at round start, group placements of this round ignored via the cutoff
-          PairEval p0{0.0, 0u};
-          if (t_ac0 + c > t_a.oc || t_am0 + m > t_a.om) {
-            p0.bits = 1u;
+        if (pe_bits == 8u && t_on) {  // the exact path did not run for this job
+          pe_bits = 0u;
+          if (!res_ok) {
+            pe_bits = 1u;
+          } else if (!con_ok) {
+            pe_bits = 2u;
           } else {
-            bool ok = ((s_col[t_slot][b >> 6] >> (b & 63u)) & 1ull) != 0 && dyn_fast(jr, t_o, t_acount0);
+            pe_fit = (nc_ / (t_oc + t_rc) + nm_ / (t_om + t_rm)) / 2.0;
+            if (!(pe_fit > 0.0)) pe_bits = 4u;
+          }
+        }
+        unsigned p0 = 0u;  // snapshot verdict: state at round start, group placements of this round ignored via the cutoff
+        if (t_on) {
+          const SlotRec r = s_slot[t_slot];
+          if (r.ac + c > t_oc || r.am + m > t_om) {
+            p0 = 1u;
+          } else {
+            bool ok = ((t_col >> bl) & 1ull) != 0 && r.acount < t_slack;
+            if (job_gpu && t_k8s && t_run + r.acount != 0) ok = false;
             if (ok && grouped) {
               MatchState st0 = st;
               st0.cutoff = (int)head;
-              ok = group_pass(in, st0, jj, (unsigned)t_v);
+              ok = group_pass_dev(vb.in_dev, st0, jj, (unsigned)t_v);
             }
             if (!ok) {
-              p0.bits = 2u;
+              p0 = 2u;
             } else {
-              p0.fit = fitness_of(t_a, t_ac0, t_am0, c, m);
-              if (!(p0.fit > 0.0)) p0.bits = 4u;
+              const double f0 = ((t_rc + r.ac + c) / (t_oc + t_rc) + (t_rm + r.am + m) / (t_om + t_rm)) / 2.0;
+              if (!(f0 > 0.0)) p0 = 4u;
             }
           }
-          d1 = (int)(pe.bits & 1u) - (int)(p0.bits & 1u);
-          d2 = (int)((pe.bits >> 1) & 1u) - (int)((p0.bits >> 1) & 1u);
-          d4 = (int)((pe.bits >> 2) & 1u) - (int)((p0.bits >> 2) & 1u);
         }
-        for (int d = 32; d >= 1; d >>= 1) {
-          d1 += __shfl_xor(d1, d, COOK_WAVE);
-          d2 += __shfl_xor(d2, d, COOK_WAVE);
-          d4 += __shfl_xor(d4, d, COOK_WAVE);
-        }
+        d1 = __popcll(__ballot(t_on && (pe_bits & 1u))) - __popcll(__ballot(t_on && (p0 & 1u)));
+        d2 = __popcll(__ballot(t_on && (pe_bits & 2u))) - __popcll(__ballot(t_on && (p0 & 2u)));
+        d4 = __popcll(__ballot(t_on && (pe_bits & 4u))) - __popcll(__ballot(t_on && (p0 & 4u)));
       }
-      const unsigned bits = (((int)f1 + d1) > 0 ? 1u : 0u) | (((int)f2 + d2) > 0 ? 2u : 0u) | (((int)f4 + d4) > 0 ? 4u : 0u);
+      const unsigned bits = (((int)jl.f1 + d1) > 0 ? 1u : 0u) | (((int)jl.f2 + d2) > 0 ? 2u : 0u) | (((int)jl.f4 + d4) > 0 ? 4u : 0u);
       if (lane == 0) {
-        st_agent(&st.job_to_offer[k], -1);
-        if (st.fail_code) st.fail_code[k] = bits ? bits : 8u;
+        s_j2o[b] = -1;
+        s_fail[b] = (unsigned char)(bits ? bits : 8u);
       }
     }
   }
   if (stop == 0 && weff < nwin) stop = 4;
-  // write the touched offers' state back and publish the new head
+  // flush the results of the jobs resolved, write the touched offers' state back and publish the new head
+  wave_sync();
+  for (unsigned x = lane; x < resolved; x += COOK_WAVE) {
+    st.job_to_offer[head + x] = s_j2o[x];
+    if (st.fail_code) st.fail_code[head + x] = s_fail[x];
+  }
   if (t_slot >= 0) {
     st.ac[t_v] = t_ac;
     st.am[t_v] = t_am;
     st.acount[t_v] = t_acount;
   }
   if (lane == 0) {
-    const unsigned resolved = b;
-    ctl.head = head + b;
+    ctl.head = head + resolved;
     ctl.rounds += 1;
     ctl.matched += matched;
     ctl.head_matched = head_matched;
     ctl.touched_sum += nT;
+    ctl.visited_sum += n_list;
     ctl.t_setup += tk1 - tk0;
     ctl.t_seq += cook_ticks() - tk1;
     if (stop == 1) ctl.stop_list += 1;

@@ -200,7 +200,7 @@ class Engine:
     def match_stats(self):
         out = (C.c_uint32 * 12)()
         self._lib.cook_match_stats(self._h, out)
-        keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "stop_slots", "resolved", "setup_us", "seq_us", "touched", "_")
+        keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "stop_slots", "resolved", "setup_us", "seq_us", "touched", "visited")
         return dict(zip(keys, [int(x) for x in out]))
 
     def set_profiling(self, on: bool):

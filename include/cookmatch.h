@@ -241,7 +241,7 @@ int cook_kernel_timings(cook_engine* e, const char** names, double* ms, uint32_t
 int cook_set_profiling(cook_engine* e, int enabled);
 /* placement statistics of the last match: [0] rounds, [1] matched, [2..6] rounds ended by list-exhausted / touched-set-full /
    group barrier / window end / candidate-slot table full, [7] jobs resolved,
-   [8] microseconds the resolve kernels spent staging windows, [9] ... walking them, [10] offers touched (sum over rounds) */
+   [8] microseconds the resolve kernels spent staging windows, [9] ... walking them, [10] offers touched (sum over rounds), [11] jobs the walk visited (the rest were settled in parallel) */
 int cook_match_stats(cook_engine* e, uint32_t out[12]);
 
 #ifdef __cplusplus

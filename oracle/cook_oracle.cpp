@@ -438,15 +438,6 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// A.9 rebalancer (rebalancer.clj).  State = per-user ordered running tasks + their DRUs.
-struct RTask {
-  FeatureKey key;
-  uint32_t user, host;
-  double cpus, mem, gpus, dru;
-  int64_t id;      // >=0: index into `running`; <0: synthetic task of pending job (-1 - pending index)
-  bool alive;
-};
-
 }  // namespace
 
 extern "C" {
@@ -505,20 +496,160 @@ int oracle_match(const cook_params* p, const cook_jobs* j, const cook_offers* o,
 }
 
 // rebalancer.clj:222-266 init-state, :320-407 compute-preemption-decision, :270-309 next-state, :434-467 rebalance.
-// Constraints: this restatement covers resource-only pending jobs plus novel-host / gpu-host(non-k8s: gpus==0)
-// job constraints are NOT evaluated (hosts all pass); see DESIGN.md "rebalancer scope".
+//
+// host_attrs (optional): the agent-attributes-cache (scheduler.clj:1586-1597) as a cook_offers table, one row per host
+//   whose attribute map is cached (`host[i]` = host id; resource columns are ignored).  A host's attribute map is nil when
+//   it is not cached OR when its hostname cannot be resolved to a slave id: the reference resolves hostname -> slave-id
+//   through the scored tasks (rebalancer.clj:369-375, `into {}` = the LAST task of the host in priority-map order wins);
+//   real instances always carry a slave id, a task placed by an earlier decision of this cycle carries the slave id of
+//   that decision's first preempted task (rebalancer.clj:279-281) — nil for a spare-resources-only decision.
+// groups (optional): pending->group[p] indexes it; run_host = hosts of the group's running cotasks per the DB, minus the
+//   job's own instances (constraints.clj:531-537); their attributes are looked up in host_attrs (run_attr is ignored).
+// The rebalancer evaluates job-constraint-constructors only (constraints.clj:459-466: novel-host, gpu-host, disk-host,
+// user-defined, estimated-completion, checkpoint-locality) through the 3-arity evaluate, i.e. with NO tasks assigned,
+// and group constraints with cohosts = hosts of EVERY task preempted so far this cycle ++ cotask hosts
+// (constraints.clj:680-697).
+// forced_* (test hook, NULL in normal use): apply the given decision for pending job p instead of computing one
+//   (pins next-state, rebalancer.clj:270-309, against the reference's test-next-state vectors).
+// final_* (optional): the scored tasks after the loop in priority-map order (index >= running->n: R + pending index).
 // UNPINNED: order among scored tasks with equal (-dru, user) (priority-map value sets are hash sets): we use the
-// user's task order.
+// user's task order.  gpu-mode pools: compute-preemption-decision reads (:dru score) of a bare number and throws in the
+// reference (rebalancer.clj:252-256, 346); only the pending-job DRU (rebalancer.clj:157-180) is pinned for that mode.
+// test hooks of oracle_rebalance (all optional)
+struct oracle_rebal_hooks {
+  const uint8_t* running_slave_known;  // 0: the instance's slave id has no cached attribute map (a test artefact: random slave ids)
+  const uint32_t* init_preempted_hosts;  // State :preempted-tasks at entry (hosts of tasks preempted earlier this cycle)
+  uint32_t n_init_preempted;
+  const int32_t* forced_host;  // per pending job: -2 compute, -1 forced "no decision", >= 0 forced decision on that host
+  const uint32_t* forced_off;  // CSR of forced task ids (index into running, or R + pending index)
+  const uint32_t* forced_task;
+  const cook_usage* forced_res;  // :cpus :mem :gpus of the forced decision
+  uint32_t* final_order;  // scored tasks after the loop in priority-map order
+  double* final_dru;
+  uint32_t* n_final;
+};
+
+struct RebalAttrs {
+  const cook_offers* t;
+  std::unordered_map<uint32_t, uint32_t> row_of_host;
+  explicit RebalAttrs(const cook_offers* t_) : t(t_) {
+    if (t)
+      for (uint32_t i = 0; i < t->n; ++i) row_of_host[t->host[i]] = i;
+  }
+  int row(uint32_t host) const {
+    auto it = row_of_host.find(host);
+    return it == row_of_host.end() ? -1 : (int)it->second;
+  }
+  // value id of attribute `key` in the map of row r (r < 0: nil map); COOK_NONE_U32 = "HOSTNAME"
+  uint32_t attr(int r, uint32_t key) const {
+    if (r < 0) return 0;
+    if (key == COOK_NONE_U32) return t->host[r] + 1;
+    if (!t->attr || key >= t->n_attr_keys) return 0;
+    return t->attr[(size_t)r * t->n_attr_keys + key];
+  }
+};
+
+// job constraints of the rebalancer on the attribute map of row r (r < 0: nil map)
+static bool rebal_job_constraints_pass(const cook_params* p, const cook_jobs* j, uint32_t k, const RebalAttrs& A, int r) {
+  const cook_offers* o = A.t;
+  // novel-host (constraints.clj:68-94): (get nil "HOSTNAME") is nil, never in the set
+  if (r >= 0 && j->novel_off)
+    for (uint32_t x = j->novel_off[k]; x < j->novel_off[k + 1]; ++x)
+      if (j->novel_host[x] == o->host[r]) return false;
+  // gpu-host (constraints.clj:122-157) with vm-tasks-assigned = []
+  const double jg = j->gpus ? j->gpus[k] : 0.0;
+  const bool k8s = r >= 0 && o->k8s && o->k8s[r];
+  if (k8s) {
+    const uint32_t om = o->gpu_model ? o->gpu_model[r] : 0;
+    if (jg > 0) {
+      const uint32_t jm = j->gpu_model ? j->gpu_model[k] : 0;
+      const double avail = (om != 0 && om == jm) ? o->gpu_count[r] : 0.0;
+      if (!(avail == jg)) return false;
+    } else if (om != 0) {
+      return false;
+    }
+  } else if (!(jg == 0)) {
+    return false;
+  }
+  // disk-host (constraints.clj:164-199)
+  if (j->disk_request && j->disk_request[k] >= 0 && k8s) {
+    const double space = (o->disk_type && o->disk_type[r] == j->disk_type[k]) ? o->disk_space[r] : 0.0;
+    if (!(space >= j->disk_request[k])) return false;
+  }
+  // user-defined EQUALS (constraints.clj:356-377): (= pattern (get nil attribute)) is false
+  if (j->eq_off)
+    for (uint32_t x = j->eq_off[k]; x < j->eq_off[k + 1]; ++x)
+      if (A.attr(r, j->eq_key[x]) != j->eq_val[x]) return false;
+  // estimated-completion (constraints.clj:385-401): no "host-start-time" -> passes
+  if (r >= 0 && j->est_end_ms && j->est_end_ms[k] != 0 && o->host_start_s && o->host_start_s[r] >= 0) {
+    const int64_t death = 1000 * o->host_start_s[r] + 60 * 1000 * p->host_lifetime_mins;
+    if (!(j->est_end_ms[k] < death)) return false;
+  }
+  // checkpoint-locality (constraints.clj:218-240)
+  if (j->ckpt_location && j->ckpt_location[k] != 0) {
+    const uint32_t loc = (r >= 0 && o->location) ? o->location[r] : 0;
+    if (loc != j->ckpt_location[k]) return false;
+  }
+  return true;
+}
+
+// group constraint of the rebalancer (constraints.clj:586-644 through :680-697); cohost_rows = attribute-map rows (-1 nil)
+static bool rebal_group_constraint_pass(const cook_groups* g, uint32_t gi, const RebalAttrs& A, int r,
+                                        const std::vector<int>& cohost_rows) {
+  const uint8_t type = g->type[gi];
+  if (type == 0) return true;
+  if (type == 1) {  // unique: target hostname must be present and not among the cohosts' hostnames
+    const uint32_t target = A.attr(r, COOK_NONE_U32);
+    if (target == 0) return false;
+    for (int c : cohost_rows)
+      if (A.attr(c, COOK_NONE_U32) == target) return false;
+    return true;
+  }
+  const uint32_t key = g->attr_key[gi];
+  std::map<uint32_t, int> freq;
+  for (int c : cohost_rows) freq[A.attr(c, key)]++;
+  if (freq.empty()) return true;
+  const uint32_t target = A.attr(r, key);
+  if (type == 2) {
+    int mn = std::numeric_limits<int>::max(), mx = 0;
+    for (auto& kv : freq) {
+      mn = std::min(mn, kv.second);
+      mx = std::max(mx, kv.second);
+    }
+    const int minim = (g->minimum[gi] > (int)freq.size()) ? 0 : mn;
+    auto it = freq.find(target);
+    if (it == freq.end()) return true;
+    return minim == mx || it->second < mx;
+  }
+  return freq.count(target) != 0;
+}
+
 int oracle_rebalance(const cook_params* p, const cook_tasks* running, const cook_jobs* pending,
                      const int64_t* pending_job_id, const int32_t* pending_priority, const cook_users* u,
-                     const cook_host_spare* spare_in, const cook_rebalance_params* rp, cook_preemption* decisions,
-                     uint32_t* n_decisions, uint32_t* preempted, uint32_t* n_preempted) {
+                     const cook_host_spare* spare_in, const cook_offers* host_attrs, const cook_groups* groups,
+                     const cook_rebalance_params* rp, cook_preemption* decisions, uint32_t* n_decisions,
+                     uint32_t* preempted, uint32_t* n_preempted, double* pending_dru, const oracle_rebal_hooks* hooks) {
   const uint32_t R = running->n, P = pending->n, U = u->n;
+  const int32_t* forced_host = hooks ? hooks->forced_host : nullptr;
+  const uint32_t* forced_off = hooks ? hooks->forced_off : nullptr;
+  const uint32_t* forced_task = hooks ? hooks->forced_task : nullptr;
+  const cook_usage* forced_res = hooks ? hooks->forced_res : nullptr;
+  uint32_t* final_order = hooks ? hooks->final_order : nullptr;
+  double* final_dru = hooks ? hooks->final_dru : nullptr;
+  uint32_t* n_final = hooks ? hooks->n_final : nullptr;
   const bool gpu_mode = p->dru_mode == 1;
+  const RebalAttrs A(host_attrs);
+  struct RT {
+    FeatureKey key;
+    uint32_t user, host;
+    double cpus, mem, gpus, dru;
+    uint32_t id;  // < R: index into `running`; >= R: task placed for pending job id - R
+    bool slave_known;
+  };
   // user -> ordered tasks (sorted-set-by same-user-task-comparator, rebalancer.clj:241-246)
-  std::vector<std::vector<RTask>> ut(U);
+  std::vector<std::vector<RT>> ut(U);
   for (uint32_t i = 0; i < R; ++i) {
-    RTask x;
+    RT x;
     x.key = feature_key(running, i);
     x.user = running->user[i];
     x.host = running->host[i];
@@ -527,14 +658,13 @@ int oracle_rebalance(const cook_params* p, const cook_tasks* running, const cook
     x.gpus = gpus_of(running, i);
     x.dru = 0;
     x.id = i;
-    x.alive = true;
+    x.slave_known = !(hooks && hooks->running_slave_known) || hooks->running_slave_known[i] != 0;
     ut[x.user].push_back(x);
   }
   auto rescore = [&](uint32_t us) {  // dru.clj:50-80 over the user's ordered tasks
-    auto& v = ut[us];
     double cs = 0, ms = 0, gs = 0;
     bool first = true;
-    for (auto& x : v) {
+    for (auto& x : ut[us]) {
       if (gpu_mode) {
         gs = first ? x.gpus : gs + x.gpus;
         x.dru = gs / u->div_gpus[us];
@@ -547,20 +677,44 @@ int oracle_rebalance(const cook_params* p, const cook_tasks* running, const cook
     }
   };
   for (uint32_t us = 0; us < U; ++us) {
-    std::sort(ut[us].begin(), ut[us].end(), [](const RTask& a, const RTask& b) { return key_less(a.key, b.key); });
+    std::sort(ut[us].begin(), ut[us].end(), [](const RT& a, const RT& b) { return key_less(a.key, b.key); });
     rescore(us);
   }
   std::map<uint32_t, cook_usage> spare;  // host -> spare {cpus,mem,gpus}; count unused
   for (uint32_t i = 0; i < spare_in->n; ++i)
-    spare[spare_in->host[i]] = cook_usage{0, spare_in->cpus[i], spare_in->mem[i], spare_in->gpus ? spare_in->gpus[i] : 0.0};
-
+    spare[spare_in->host[i]] =
+        cook_usage{0, spare_in->cpus[i], spare_in->mem[i], spare_in->gpus ? spare_in->gpus[i] : 0.0};
+  // priority-map order: (-dru, user) ascending (rebalancer.clj:252-256); equal keys in the user's task order (UNPINNED)
+  struct Ref {
+    double dru;
+    uint32_t user, order;
+    const RT* t;
+  };
+  auto priority_order = [&](std::vector<Ref>& all) {
+    all.clear();
+    for (uint32_t w = 0; w < U; ++w) {
+      uint32_t ord = 0;
+      for (auto& x : ut[w]) all.push_back({x.dru, w, ord++, &x});
+    }
+    std::stable_sort(all.begin(), all.end(), [](const Ref& a, const Ref& b) {
+      if (a.dru != b.dru) return a.dru > b.dru;
+      if (a.user != b.user) return a.user < b.user;
+      return a.order < b.order;
+    });
+  };
+  std::vector<uint32_t> preempted_hosts;  // hosts of every task preempted so far whose slave id is known
+  if (hooks && hooks->init_preempted_hosts)
+    preempted_hosts.assign(hooks->init_preempted_hosts, hooks->init_preempted_hosts + hooks->n_init_preempted);
+  std::vector<Ref> all;
   uint32_t nd = 0, np = 0;
   int32_t remaining = rp->max_preemption;
+  if (pending_dru)
+    for (uint32_t pj = 0; pj < P; ++pj) pending_dru[pj] = std::numeric_limits<double>::quiet_NaN();
   for (uint32_t pj = 0; pj < P && remaining > 0; ++pj) {
     const uint32_t us = pending->user[pj];
     const double jc = pending->cpus[pj], jm = pending->mem[pj], jg = pending->gpus ? pending->gpus[pj] : 0.0;
     const bool job_has_gpus = pending->gpus && pending->gpus[pj] > 0;  // (:gpus resources) present
-    // rebalancer.clj:210-220 job-below-quota: usage of the user's running jobs + this job
+    // rebalancer.clj:210-220 job-below-quota: (conj running-jobs job) -> the job first, then the user's running jobs
     cook_usage fu{1, jc, jm, jg};
     for (auto& x : ut[us]) {
       fu.count += 1;
@@ -583,69 +737,84 @@ int oracle_rebalance(const cook_params* p, const cook_tasks* running, const cook
     }
     const double pdru = gpu_mode ? near + jg / u->div_gpus[us]
                                  : std::max(near + jm / u->div_mem[us], near + jc / u->div_cpus[us]);
-    // rebalancer.clj:339-349 candidates in priority-map order (-dru, user) ascending, grouped by host
-    struct Cand {
-      double dru;
-      uint32_t user, order;
-      const RTask* t;
-    };
-    std::vector<Cand> cands;
-    for (uint32_t w = 0; w < U; ++w) {
-      uint32_t ord = 0;
-      for (auto& x : ut[w]) {
-        ++ord;
-        if (!(below || w == us)) continue;
-        if (x.dru < rp->safe_dru_threshold) continue;
-        if (!(x.dru - pdru > rp->min_dru_diff)) continue;
-        cands.push_back({x.dru, w, ord, &x});
-      }
-    }
-    std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) {
-      if (a.dru != b.dru) return a.dru > b.dru;
-      if (a.user != b.user) return a.user < b.user;
-      return a.order < b.order;
-    });
-    std::map<uint32_t, std::vector<const RTask*>> by_host;  // sorted by host id = hostname order (:383)
+    if (pending_dru) pending_dru[pj] = pdru;
+    priority_order(all);
+    // hostname -> slave id through the scored tasks, last one wins (rebalancer.clj:369-375)
+    std::unordered_map<uint32_t, bool> host_slave_known;
+    for (auto& r : all) host_slave_known[r.t->host] = r.t->slave_known;
+    // rebalancer.clj:339-349 candidates in priority-map order, grouped by host
+    std::map<uint32_t, std::vector<const RT*>> by_host;  // sorted by host id = hostname order (:383)
     for (auto& kv : spare) by_host[kv.first];
-    for (auto& c : cands) by_host[c.t->host].push_back(c.t);
-    // rebalancer.clj:384-404 per-host prefix aggregates; keep those with enough resources; max-key :dru, ties->last
+    for (auto& c : all) {
+      if (!(below || c.user == us)) continue;
+      if (c.dru < rp->safe_dru_threshold) continue;
+      if (!(c.dru - pdru > rp->min_dru_diff)) continue;
+      by_host[c.t->host].push_back(c.t);
+    }
+    // group cohosts: every task preempted so far ++ the group's running cotasks (constraints.clj:686-689)
+    const bool has_group = groups && pending->group && pending->group[pj] != COOK_NONE_U32;
+    std::vector<int> cohost_rows;
+    if (has_group) {
+      const uint32_t gi = pending->group[pj];
+      for (uint32_t h : preempted_hosts) cohost_rows.push_back(A.row(h));
+      if (groups->run_off)
+        for (uint32_t x = groups->run_off[gi]; x < groups->run_off[gi + 1]; ++x) cohost_rows.push_back(A.row(groups->run_host[x]));
+    }
+    // rebalancer.clj:384-404 per-host prefix aggregates; keep those with enough resources; max-key :dru, ties -> last
     bool have = false;
     double best_dru = 0.0;  // (fnil :dru {:dru 0.0}) nil: the nil seed has dru 0.0
     uint32_t best_host = 0;
     size_t best_len = 0;
     cook_usage best_res{0, 0, 0, 0};
-    bool best_spare = false;
-    for (auto& kv : by_host) {
-      cook_usage agg{0, 0.0, 0.0, 0.0};
-      auto sp = spare.find(kv.first);
-      const bool has_spare = sp != spare.end();
-      auto consider = [&](double d, size_t len) {
-        const bool enough = agg.mem >= jm && agg.cpus >= jc && (job_has_gpus ? agg.gpus >= jg : true);
-        if (enough && d >= best_dru) {
-          have = true;
-          best_dru = d;
-          best_host = kv.first;
-          best_len = len;
-          best_res = agg;
-          best_spare = has_spare;
+    const bool forced = forced_host && forced_host[pj] != -2;
+    if (!forced) {
+      for (auto& kv : by_host) {
+        auto hk = host_slave_known.find(kv.first);
+        const int row = (hk != host_slave_known.end() && hk->second) ? A.row(kv.first) : -1;
+        if (!rebal_job_constraints_pass(p, pending, pj, A, row)) continue;
+        if (has_group && !rebal_group_constraint_pass(groups, pending->group[pj], A, row, cohost_rows)) continue;
+        cook_usage agg{0, 0.0, 0.0, 0.0};
+        auto sp = spare.find(kv.first);
+        auto consider = [&](double d, size_t len) {
+          const bool enough = agg.mem >= jm && agg.cpus >= jc && (job_has_gpus ? agg.gpus >= jg : true);
+          if (enough && d >= best_dru) {
+            have = true;
+            best_dru = d;
+            best_host = kv.first;
+            best_len = len;
+            best_res = agg;
+          }
+        };
+        if (sp != spare.end()) {
+          agg.cpus += sp->second.cpus;
+          agg.mem += sp->second.mem;
+          agg.gpus += sp->second.gpus;
+          consider(DMAX, 0);
         }
-      };
-      if (has_spare) {
-        agg.cpus += sp->second.cpus;
-        agg.mem += sp->second.mem;
-        agg.gpus += sp->second.gpus;
-        consider(DMAX, 0);
+        size_t len = 0;
+        for (const RT* x : kv.second) {
+          agg.cpus += x->cpus;
+          agg.mem += x->mem;
+          agg.gpus += x->gpus;
+          consider(x->dru, ++len);
+        }
       }
-      size_t len = 0;
-      for (const RTask* x : kv.second) {
-        agg.cpus += x->cpus;
-        agg.mem += x->mem;
-        agg.gpus += x->gpus;
-        consider(x->dru, ++len);
-      }
+      if (!have) continue;
     }
-    if (!have) continue;
-    (void)best_spare;
+    // the tasks of the decision, in candidate order
+    std::vector<const RT*> chosen;
+    if (forced) {
+      if (forced_host[pj] < 0) continue;  // forced "no decision"
+      best_host = (uint32_t)forced_host[pj];
+      for (uint32_t x = forced_off[pj]; x < forced_off[pj + 1]; ++x)
+        for (auto& r : all)
+          if (r.t->id == forced_task[x]) chosen.push_back(r.t);
+      best_res = forced_res[pj];  // :mem :cpus :gpus of the decision as given
+      best_dru = 0.0;
+    } else {
+      auto& lst = by_host[best_host];
+      chosen.assign(lst.begin(), lst.begin() + best_len);
+    }
     // decision + next-state (rebalancer.clj:270-309)
     cook_preemption& d = decisions[nd++];
     d.pending_index = pj;
@@ -658,23 +827,20 @@ int oracle_rebalance(const cook_params* p, const cook_tasks* running, const cook
     d.task_n = 0;
     std::set<uint32_t> changed;
     changed.insert(us);
-    {
-      auto& lst = by_host[best_host];
-      std::set<const RTask*> gone(lst.begin(), lst.begin() + best_len);
-      for (const RTask* x : gone) {
-        changed.insert(x->user);
-      }
-      // record in decision order (conj onto vector in candidate order)
-      for (size_t i = 0; i < best_len; ++i) {
-        preempted[np++] = (uint32_t)(lst[i]->id >= 0 ? lst[i]->id : 0xFFFFFFFFu);  // synthetic tasks reported as NONE
-        d.task_n++;
-      }
-      for (uint32_t w : changed) {
-        auto& v = ut[w];
-        v.erase(std::remove_if(v.begin(), v.end(), [&](const RTask& x) { return gone.count(&x) != 0; }), v.end());
-      }
+    std::set<uint32_t> gone;
+    const bool new_slave_known = !chosen.empty() && chosen[0]->slave_known;  // slave id of the first preempted task
+    for (const RT* x : chosen) {
+      changed.insert(x->user);
+      gone.insert(x->id);
+      preempted[np++] = x->id < R ? x->id : COOK_NONE_U32;  // tasks placed this cycle are reported as NONE (:529 skips them)
+      d.task_n++;
+      if (x->slave_known) preempted_hosts.push_back(x->host);
     }
-    RTask nt;
+    for (uint32_t w : changed) {
+      auto& v = ut[w];
+      v.erase(std::remove_if(v.begin(), v.end(), [&](const RT& x) { return gone.count(x.id) != 0; }), v.end());
+    }
+    RT nt;
     nt.key = pk;
     nt.user = us;
     nt.host = best_host;
@@ -682,11 +848,11 @@ int oracle_rebalance(const cook_params* p, const cook_tasks* running, const cook
     nt.mem = jm;
     nt.gpus = jg;
     nt.dru = 0;
-    nt.id = -1 - (int64_t)pj;
-    nt.alive = true;
+    nt.id = R + pj;
+    nt.slave_known = new_slave_known;
     {
       auto& v = ut[us];
-      auto it = std::upper_bound(v.begin(), v.end(), nt, [](const RTask& a, const RTask& b) { return key_less(a.key, b.key); });
+      auto it = std::upper_bound(v.begin(), v.end(), nt, [](const RT& a, const RT& b) { return key_less(a.key, b.key); });
       v.insert(it, nt);
     }
     for (uint32_t w : changed) rescore(w);
@@ -695,6 +861,14 @@ int oracle_rebalance(const cook_params* p, const cook_tasks* running, const cook
   }
   *n_decisions = nd;
   *n_preempted = np;
+  if (final_order && final_dru && n_final) {
+    priority_order(all);
+    for (size_t i = 0; i < all.size(); ++i) {
+      final_order[i] = all[i].t->id;
+      final_dru[i] = all[i].dru;
+    }
+    *n_final = (uint32_t)all.size();
+  }
   return 0;
 }
 

@@ -100,23 +100,78 @@ def match(params, jobs: A.Jobs, offers: A.Offers, groups: A.Groups = None, reser
     return j2o[: jobs.n].copy(), fail[: jobs.n].copy(), bool(head.value)
 
 
+class RebalHooks(C.Structure):
+    _fields_ = [("running_slave_known", C.POINTER(C.c_uint8)), ("init_preempted_hosts", C.POINTER(C.c_uint32)),
+                ("n_init_preempted", C.c_uint32), ("forced_host", C.POINTER(C.c_int32)), ("forced_off", C.POINTER(C.c_uint32)),
+                ("forced_task", C.POINTER(C.c_uint32)), ("forced_res", C.POINTER(A.CookUsage)),
+                ("final_order", C.POINTER(C.c_uint32)), ("final_dru", C.POINTER(C.c_double)), ("n_final", C.POINTER(C.c_uint32))]
+
+
 def rebalance(params, running: A.Tasks, pending: A.Jobs, pending_job_id, pending_priority, users: A.Users,
-              spare: A.HostSpare, rparams: A.CookRebalanceParams):
-    """-> list of decisions dicts (rebalancer.clj:434-467)."""
-    P = pending.n
+              spare: A.HostSpare, rparams: A.CookRebalanceParams, host_attrs: A.Offers = None, groups: A.Groups = None,
+              forced=None, want_final=False, slave_known=None, init_preempted_hosts=()):
+    """-> dict(decisions=[...], pending_dru=array, final=(order, dru))   (rebalancer.clj:434-467).
+    Test hooks: forced = {pending index: None | (host, [task ids], (cpus, mem, gpus))} applies that decision instead of
+    computing one; slave_known / init_preempted_hosts: see oracle_rebal_hooks in cook_oracle.cpp."""
+    P, R = pending.n, running.n
     dec = (A.CookPreemption * max(1, P))()
-    pre = np.zeros(max(1, running.n + P), dtype=np.uint32)
+    pre = np.zeros(max(1, R + P), dtype=np.uint32)
     nd, npre = C.c_uint32(0), C.c_uint32(0)
     jid = np.ascontiguousarray(pending_job_id, dtype=np.int64)
     pri = np.ascontiguousarray(pending_priority, dtype=np.int32)
+    pdru = np.zeros(max(1, P), dtype=np.float64)
     rs, ps, us, ss = running.as_struct(), pending.as_struct(), users.as_struct(), spare.as_struct()
+    hs = host_attrs.as_struct() if host_attrs is not None else None
+    gs = groups.as_struct() if groups is not None else None
+    hooks = RebalHooks()
+    keep = []
+    i32p, u32p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+    if slave_known is not None:
+        sk = np.ascontiguousarray(slave_known, dtype=np.uint8)
+        keep.append(sk)
+        hooks.running_slave_known = sk.ctypes.data_as(u8p)
+    if len(init_preempted_hosts):
+        ip = np.ascontiguousarray(init_preempted_hosts, dtype=np.uint32)
+        keep.append(ip)
+        hooks.init_preempted_hosts = ip.ctypes.data_as(u32p)
+        hooks.n_init_preempted = len(ip)
+    if forced is not None:
+        f_host = np.full(max(1, P), -2, dtype=np.int32)
+        f_off = np.zeros(P + 1, dtype=np.uint32)
+        flat = []
+        f_res = (A.CookUsage * max(1, P))()
+        for pj in range(P):
+            if pj in forced:
+                d = forced[pj]
+                if d is None:
+                    f_host[pj] = -1
+                else:
+                    f_host[pj] = d[0]
+                    flat.extend(d[1])
+                    f_res[pj] = A.usage(0, *d[2])
+            f_off[pj + 1] = len(flat)
+        f_task = np.array(flat or [0], dtype=np.uint32)
+        keep += [f_host, f_off, f_task, f_res]
+        hooks.forced_host = f_host.ctypes.data_as(i32p)
+        hooks.forced_off = f_off.ctypes.data_as(u32p)
+        hooks.forced_task = f_task.ctypes.data_as(u32p)
+        hooks.forced_res = f_res
+    fin_o = np.zeros(max(1, R + P), dtype=np.uint32)
+    fin_d = np.zeros(max(1, R + P), dtype=np.float64)
+    nf = C.c_uint32(0)
+    if want_final:
+        hooks.final_order = fin_o.ctypes.data_as(u32p)
+        hooks.final_dru = fin_d.ctypes.data_as(C.POINTER(C.c_double))
+        hooks.n_final = C.pointer(nf)
     rc = lib().oracle_rebalance(C.byref(params), C.byref(rs), C.byref(ps), jid.ctypes.data_as(C.POINTER(C.c_int64)),
-                                pri.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(us), C.byref(ss), C.byref(rparams),
-                                dec, C.byref(nd), _u32p(pre), C.byref(npre))
+                                pri.ctypes.data_as(i32p), C.byref(us), C.byref(ss),
+                                C.byref(hs) if hs is not None else None, C.byref(gs) if gs is not None else None,
+                                C.byref(rparams), dec, C.byref(nd), _u32p(pre), C.byref(npre), _f64p(pdru), C.byref(hooks))
     assert rc == 0
     out = []
     for i in range(nd.value):
         d = dec[i]
         out.append(dict(pending_index=d.pending_index, host=d.host, dru=d.dru, cpus=d.cpus, mem=d.mem, gpus=d.gpus,
                         tasks=[int(x) for x in pre[d.task_off: d.task_off + d.task_n]]))
-    return out
+    return dict(decisions=out, pending_dru=pdru[:P].copy(),
+                final=(fin_o[: nf.value].copy(), fin_d[: nf.value].copy()) if want_final else None)

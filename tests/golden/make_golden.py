@@ -224,12 +224,192 @@ MATCH = [
          jobs=_HRO_JOBS[:2], offers=_HRO_OFFERS, expect_matched=["job-1", "job-2"], expect_offers_used=2),
 ]
 
+# ---------------------------------------------------------------------------------------------------------------
+# Rebalancer (test/cook/test/rebalancer.clj).  running: instances in creation order (`seq` = :instance/start-time and
+# :db/id order); pending: jobs to make room for, in the order given to rebalance; `job_seq` = creation order of the
+# job entity among ALL jobs of the test (the pending job's sort key, tools.clj:614-641).
+# host_attrs: the agent-attributes-cache by hostname.  `slave_cached: false` on a running task = its (random) slave
+# id is not in the cache (testutil create-dummy-instance gives every instance its own slave id); cotask hosts named
+# "<host>#nocache" likewise stand for cotasks whose slave id has no cached attribute map.
+def run(name, user, cpus, mem, host="localhost", gpus=0.0, priority=50, **kw):
+    d = dict(name=name, user=user, cpus=cpus, mem=mem, host=host, gpus=gpus, priority=priority)
+    d.update(kw)
+    return d
+
+
+def pend(name, user, cpus, mem, job_seq, gpus=0.0, priority=50, **kw):
+    d = dict(name=name, user=user, cpus=cpus, mem=mem, gpus=gpus, priority=priority, job_seq=job_seq)
+    d.update(kw)
+    return d
+
+
+_DEF25 = {"default": dict(cpus=25.0, mem=25.0, gpus=1.0)}
+_R8 = [run("t1", "ljin", 10.0, 10.0), run("t2", "ljin", 5.0, 5.0), run("t3", "ljin", 25.0, 15.0), run("t4", "ljin", 15.0, 25.0),
+       run("t5", "wzhao", 8.0, 8.0), run("t6", "wzhao", 10.0, 10.0), run("t7", "wzhao", 10.0, 10.0), run("t8", "wzhao", 10.0, 10.0)]
+# test-compute-preemption-decision "without group constraints": no job5/job6
+_RD = [run("t1", "ljin", 10.0, 10.0, "hostA"), run("t2", "ljin", 5.0, 5.0, "hostA"), run("t3", "ljin", 25.0, 15.0, "hostB"),
+       run("t4", "ljin", 15.0, 25.0, "hostB"), run("t7", "wzhao", 10.0, 10.0, "hostA"), run("t8", "wzhao", 10.0, 10.0, "hostB")]
+_PD = {"job9": pend("job9", "wzhao", 15.0, 15.0, 7), "job10": pend("job10", "sunil", 15.0, 15.0, 8),
+       "job11": pend("job11", "ljin", 15.0, 15.0, 9), "job12": pend("job12", "sunil", 40.0, 40.0, 10),
+       "job13": pend("job13", "sunil", 45.0, 45.0, 11), "job14": pend("job14", "sunil", 80.0, 80.0, 12)}
+
+
+def _dec(job, spare, min_diff, expect, line):
+    return dict(name=f"compute-preemption-decision {job} spare={spare} min-dru-diff={min_diff}", ref=f"{T_REB}:{line}",
+                shares=_DEF25, running=_RD, pending=[_PD[job]], spare=spare,
+                params=dict(max_preemption=128, safe_dru_threshold=1.0, min_dru_diff=min_diff),
+                expect_decisions=([dict(job=job, **expect)] if expect else []))
+
+
+_PIGS4 = {"pig1": "straw", "pig2": "sticks", "pig3": "bricks", "pig4": "rebar"}
+_HN4 = {h: {"HOSTNAME": h} for h in _PIGS4.values()}
+_AZ4 = {"straw": {"az": "east", "HOSTNAME": "straw"}, "sticks": {"az": "east", "HOSTNAME": "sticks"},
+        "bricks": {"az": "east", "HOSTNAME": "bricks"}, "rebar": {"az": "west", "HOSTNAME": "rebar"}}
+_PIGS8 = {"pig1": "straw", "pig2": "sticks", "pig3": "bricks", "pig4": "rebar", "pig5": "concrete", "pig6": "steel",
+          "pig7": "gold", "pig8": "titanium"}
+_AZ8 = {"straw": "east", "sticks": "west", "bricks": "south", "rebar": "north", "concrete": "east", "steel": "west",
+        "gold": "south", "titanium": "north"}
+_P05 = dict(max_preemption=128, safe_dru_threshold=1.0, min_dru_diff=0.05)
+
+
+def _pigs(pigs, ncpus):
+    return [run(f"{u}-task", u, ncpus, 10.0, h) for u, h in pigs.items()]
+
+
+def _balanced_case(title, group_hosts, preempted_hosts, expect_in, line):
+    cot = [run(f"cotask{i}", "diego", 1.0, 10.0, h) for i, h in enumerate(group_hosts)]
+    return dict(name=f"compute-preemption-decision balanced group: {title}", ref=f"{T_REB}:{line}",
+                shares={"default": dict(cpus=20.0, mem=20.0, gpus=1.0)}, running=_pigs(_PIGS8, 200.0) + cot,
+                pending=[pend("pending", "diego", 1.0, 10.0, 100, group="g")],
+                host_attrs={h: {"az": z, "HOSTNAME": h} for h, z in _AZ8.items()},
+                groups={"g": dict(type="balanced", attribute="az", minimum=4, running_hosts=list(group_hosts))},
+                init_preempted_hosts=preempted_hosts, spare={}, params=_P05, expect_decision_host_in=expect_in)
+
+
+_RL = [run("t1", "ljin", 10.0, 10.0, "hostA"), run("t2", "ljin", 5.0, 5.0, "hostA"), run("t3", "ljin", 25.0, 15.0, "hostB"),
+       run("t4", "ljin", 15.0, 25.0, "hostB"), run("t5", "wzhao", 8.0, 8.0, "hostA"), run("t6", "wzhao", 10.0, 10.0, "hostB"),
+       run("t7", "wzhao", 10.0, 10.0, "hostA"), run("t8", "wzhao", 10.0, 10.0, "hostB")]
+_PW = [pend(f"job{i}", "wzhao", 5.0, 5.0, i) for i in range(9, 19)]
+_PS = [pend(f"job{i}", "sunil", 5.0, 5.0, i) for i in range(19, 29)]
+_PL = dict(max_preemption=128, safe_dru_threshold=1.0, min_dru_diff=0.0)
+_SH25 = {"default": dict(cpus=25.0, mem=25.0)}
+# test-next-state: hosts A/B alternate
+_RN = [run("t1", "ljin", 10.0, 10.0, "hostA"), run("t2", "ljin", 5.0, 5.0, "hostA"), run("t3", "ljin", 25.0, 15.0, "hostB"),
+       run("t4", "ljin", 15.0, 25.0, "hostB"), run("t5", "wzhao", 8.0, 8.0, "hostA"), run("t6", "wzhao", 10.0, 10.0, "hostB"),
+       run("t7", "wzhao", 10.0, 10.0, "hostA"), run("t8", "wzhao", 10.0, 10.0, "hostB")]
+
+REBALANCE = [
+    dict(name="init-state: priority-map order and DRUs", ref=f"{T_REB}:55-113", shares=_DEF25, running=_R8, pending=[], spare={},
+         params=_PL, expect_decisions=[],
+         expect_final_order=["t4", "t3", "t8", "t7", "t6", "t2", "t1", "t5"],
+         expect_final_drus=[2.2, 1.6, 1.52, 1.12, 0.72, 0.6, 0.4, 0.32]),
+    dict(name="compute-pending-default-job-dru", ref=f"{T_REB}:115-160", shares=_DEF25,
+         # job4 and job11 are created with the misspelt key :ucpus, so they get the default 1.0 cpus (testutil.clj:234-250)
+         running=[run("t1", "ljin", 10.0, 10.0), run("t2", "ljin", 5.0, 5.0), run("t3", "ljin", 25.0, 15.0), run("t4", "ljin", 1.0, 25.0),
+                  run("t5", "wzhao", 8.0, 8.0), run("t6", "wzhao", 10.0, 10.0), run("t7", "wzhao", 10.0, 10.0), run("t8", "wzhao", 10.0, 10.0)],
+         pending=[pend("job9", "wzhao", 10.0, 10.0, 9), pend("job10", "sunil", 20.0, 20.0, 10), pend("job11", "ljin", 1.0, 10.0, 11)],
+         spare={}, params=dict(max_preemption=128, safe_dru_threshold="MAX", min_dru_diff=0.0),
+         expect_decisions=[], expect_pending_dru={"job9": 1.92, "job10": 0.8, "job11": 2.6}),
+    dict(name="compute-pending-gpu-job-dru", ref=f"{T_REB}:162-196", dru_mode=1, shares=_DEF25,
+         running=[run(f"t{i}", "ljin" if i <= 4 else "wzhao", 1.0, 10.0, gpus=1.0) for i in range(1, 9)],
+         pending=[pend("job9", "wzhao", 10.0, 10.0, 9, gpus=1.0), pend("job10", "sunil", 20.0, 20.0, 10, gpus=1.0),
+                  pend("job11", "ljin", 1.0, 10.0, 11, gpus=2.0)],
+         spare={}, params=dict(max_preemption=128, safe_dru_threshold="MAX", min_dru_diff=0.0),
+         expect_decisions=[], expect_pending_dru={"job9": 5.0, "job10": 1.0, "job11": 6.0}),
+    _dec("job9", {}, 0.05, dict(host="hostB", dru=2.2, tasks=["t4"], mem=25.0, cpus=15.0, gpus=0.0), "253-266"),
+    _dec("job9", {"hostB": dict(mem=15.0, cpus=15.0)}, 0.5, dict(host="hostB", dru="MAX", tasks=[], mem=15.0, cpus=15.0, gpus=0.0), "268-281"),
+    _dec("job9", {"hostA": dict(mem=20.0, cpus=20.0), "hostB": dict(mem=10.0, cpus=10.0)}, 0.5,
+         dict(host="hostA", dru="MAX", tasks=[], mem=20.0, cpus=20.0, gpus=0.0), "283-297"),
+    _dec("job9", {"hostA": dict(mem=10.0, cpus=10.0), "hostB": dict(mem=10.0, cpus=10.0)}, 0.0,
+         dict(host="hostB", dru=2.2, tasks=["t4"], mem=35.0, cpus=25.0, gpus=0.0), "299-313"),
+    _dec("job10", {}, 0.5, dict(host="hostB", dru=2.2, tasks=["t4"], mem=25.0, cpus=15.0, gpus=0.0), "315-328"),
+    _dec("job11", {}, 0.5, None, "330-343"),
+    _dec("job12", {}, 0.0, None, "345-358"),
+    _dec("job12", {"hostA": dict(mem=40.0, cpus=40.0)}, 0.5, dict(host="hostA", dru="MAX", tasks=[], mem=40.0, cpus=40.0, gpus=0.0), "360-373"),
+    _dec("job12", {"hostA": dict(mem=35.0, cpus=35.0)}, 0.0, None, "375-388"),
+    _dec("job12", {"hostA": dict(mem=35.0, cpus=35.0), "hostB": dict(mem=30.0, cpus=30.0)}, 0.5,
+         dict(host="hostB", dru=2.2, tasks=["t4"], mem=55.0, cpus=45.0, gpus=0.0), "390-404"),
+    _dec("job13", {}, 0.5, None, "406-419"),
+    _dec("job13", {}, 2.0, None, "421-434"),
+    _dec("job14", {}, 0.5, None, "436-440"),
+    dict(name="compute-preemption-decision novel-host: failed everywhere except rebar", ref=f"{T_REB}:441-482",
+         shares={"default": dict(cpus=10.0, mem=10.0, gpus=10.0)}, running=_pigs(_PIGS4, 100.0),
+         pending=[pend("pending", "diego", 1.0, 10.0, 100, novel=["straw", "sticks", "bricks"])],
+         host_attrs=_HN4, spare={}, params=_P05, expect_decision_host_in=["rebar"]),
+    dict(name="compute-preemption-decision novel-host: unconstrained job finds a host", ref=f"{T_REB}:511-530",
+         shares={"default": dict(cpus=10.0, mem=10.0, gpus=10.0)}, running=_pigs(_PIGS4, 100.0),
+         pending=[pend("pending", "diego", 1.0, 10.0, 100)], host_attrs=_HN4, spare={}, params=_P05,
+         expect_decision_host_in=["straw", "sticks", "bricks", "rebar"]),
+    dict(name="compute-preemption-decision unique group: one unconstrained host", ref=f"{T_REB}:532-575",
+         shares={"default": dict(cpus=10.0, mem=10.0, gpus=1.0)},
+         running=_pigs(_PIGS4, 100.0) + [run(f"cotask-{h}", "diego", 1.0, 10.0, h, slave_cached=False) for h in ("straw", "sticks", "bricks")],
+         pending=[pend("pending", "diego", 1.0, 10.0, 100, group="g")], host_attrs=_HN4,
+         groups={"g": dict(type="unique", running_hosts=["straw#nocache", "sticks#nocache", "bricks#nocache"])},
+         spare={}, params=_P05, expect_decision_host_in=["rebar"]),
+    dict(name="compute-preemption-decision unique group: no unconstrained host", ref=f"{T_REB}:577-600",
+         shares={"default": dict(cpus=10.0, mem=10.0, gpus=1.0)},
+         running=_pigs(_PIGS4, 100.0) + [run(f"cotask-{h}", "diego", 1.0, 10.0, h, slave_cached=False) for h in ("straw", "sticks", "bricks", "rebar")],
+         pending=[pend("pending", "diego", 1.0, 10.0, 100, group="g")], host_attrs=_HN4,
+         groups={"g": dict(type="unique", running_hosts=["straw#nocache", "sticks#nocache", "bricks#nocache", "rebar#nocache"])},
+         spare={}, params=_P05, expect_decisions=[]),
+    dict(name="compute-preemption-decision attribute-equals group: az=west", ref=f"{T_REB}:602-650",
+         shares={"default": dict(cpus=10.0, mem=10.0, gpus=1.0)},
+         running=_pigs(_PIGS4, 100.0) + [run("cotask-steel", "diego", 1.0, 10.0, "steel")],
+         pending=[pend("pending", "diego", 1.0, 10.0, 100, group="g")],
+         host_attrs=dict(_AZ4, steel={"az": "west", "HOSTNAME": "steel"}),
+         groups={"g": dict(type="attribute-equals", attribute="az", running_hosts=["steel"])},
+         spare={}, params=_P05, expect_decision_host_in=["rebar"]),
+    dict(name="compute-preemption-decision attribute-equals group: az=south has no host", ref=f"{T_REB}:652-678",
+         shares={"default": dict(cpus=10.0, mem=10.0, gpus=1.0)},
+         running=_pigs(_PIGS4, 100.0) + [run("cotask-steel", "diego", 1.0, 10.0, "steel")],
+         pending=[pend("pending", "diego", 1.0, 10.0, 100, group="g")],
+         host_attrs=dict(_AZ4, steel={"az": "south", "HOSTNAME": "steel"}),
+         groups={"g": dict(type="attribute-equals", attribute="az", running_hosts=["steel"])},
+         spare={}, params=_P05, expect_decisions=[]),
+    _balanced_case("only north is open", ["straw", "sticks", "bricks", "rebar", "concrete", "steel", "gold", "titanium", "straw",
+                                          "sticks", "bricks", "rebar", "concrete", "steel", "gold"], [], ["titanium", "rebar"], "698-738"),
+    _balanced_case("titanium already preempted this cycle -> south", ["straw", "sticks", "bricks", "rebar", "concrete", "steel", "gold",
+                                                                      "titanium", "straw", "sticks", "bricks", "rebar", "concrete", "steel"],
+                   ["titanium"], ["bricks", "gold"], "740-786"),
+    dict(name="compute-preemption-decision user over quota preempts only its own task", ref=f"{T_REB}:788-823",
+         shares={"testA": dict(cpus=1.0, mem=1.0), "testB": dict(cpus=1.0, mem=1.0)}, quotas={"testA": dict(count=1)},
+         running=[run("t1", "testA", 100.0, 100.0, "hostA", priority=1), run("t2", "testB", 200.0, 200.0, "hostA")],
+         pending=[pend("job3", "testA", 1.0, 1.0, 3)], spare={}, params=dict(max_preemption=128, safe_dru_threshold=1.0, min_dru_diff=0.5),
+         expect_decisions=[dict(job="job3", host="hostA", dru=100.0, tasks=["t1"], mem=100.0, cpus=100.0, gpus=0.0)]),
+    dict(name="next-state: job9 preempts t6,t8 on hostB", ref=f"{T_REB}:895-918", shares=_DEF25, running=_RN,
+         pending=[pend("job9", "wzhao", 15.0, 15.0, 9)], spare={"hostA": dict(mem=50.0, cpus=50.0)}, params=_PL,
+         forced={"job9": dict(host="hostB", tasks=["t6", "t8"], mem=20.0, cpus=20.0, gpus=0.0)},
+         expect_final_order=["t4", "t3", "job9", "t7", "t2", "t1", "t5"], expect_final_drus=[2.2, 1.6, 1.32, 0.72, 0.6, 0.4, 0.32]),
+    dict(name="next-state: job10 preempts t2,t7 on hostA", ref=f"{T_REB}:920-944", shares=_DEF25, running=_RN,
+         pending=[pend("job10", "sunil", 15.0, 15.0, 10)], spare={"hostA": dict(mem=50.0, cpus=50.0)}, params=_PL,
+         forced={"job10": dict(host="hostA", tasks=["t2", "t7"], mem=65.0, cpus=65.0, gpus=0.0)},
+         expect_final_order=["t4", "t3", "t8", "t6", "job10", "t1", "t5"], expect_final_drus=[2.0, 1.4, 1.12, 0.72, 0.6, 0.4, 0.32]),
+    dict(name="next-state: job12 takes spare resources only (equal DRUs order by user)", ref=f"{T_REB}:946-988", shares=_DEF25, running=_RN,
+         pending=[pend("job12", "sunil", 40.0, 40.0, 12)], spare={"hostA": dict(mem=50.0, cpus=50.0)}, params=_PL,
+         forced={"job12": dict(host="hostA", tasks=[], mem=50.0, cpus=50.0, gpus=0.0)},
+         expect_final_order=["t4", "t3", "job12", "t8", "t7", "t6", "t2", "t1", "t5"],
+         expect_final_drus=[2.2, 1.6, 1.6, 1.52, 1.12, 0.72, 0.6, 0.4, 0.32]),
+    dict(name="rebalance: simple test", ref=f"{T_REB}:1079-1085", shares=_SH25, running=_RL, pending=_PW, spare={}, params=_PL,
+         expect_jobs_to_run=["job9", "job10", "job11"], expect_tasks_to_preempt=["t4"]),
+    dict(name="rebalance: simple test with available resources", ref=f"{T_REB}:1086-1092", shares=_SH25, running=_RL, pending=_PW,
+         spare={"hostB": dict(mem=0.0, cpus=10.0)}, params=_PL,
+         expect_jobs_to_run=["job9", "job10", "job11", "job12", "job13"], expect_tasks_to_preempt=["t4"]),
+    dict(name="rebalance: simple test 2", ref=f"{T_REB}:1093-1100", shares=_SH25, running=_RL, pending=_PS, spare={}, params=_PL,
+         expect_jobs_to_run=[f"job{i}" for i in range(19, 27)], expect_tasks_to_preempt=["t4", "t3"]),
+    dict(name="rebalance: simple test 2 with available resources", ref=f"{T_REB}:1101-1108", shares=_SH25, running=_RL, pending=_PS,
+         spare={"hostB": dict(mem=25.0, cpus=25.0)}, params=_PL,
+         expect_jobs_to_run=[f"job{i}" for i in range(19, 27)], expect_tasks_to_preempt=["t4"]),
+    dict(name="rebalance: test with share change", ref=f"{T_REB}:1109-1118", shares=dict(_SH25, sunil=dict(cpus=50.0, mem=50.0)),
+         running=_RL, pending=_PS, spare={}, params=_PL,
+         expect_jobs_to_run=[f"job{i}" for i in range(19, 29)], expect_tasks_to_preempt=["t4", "t3", "t8"]),
+]
+
 # constraints truth tables (test/cook/test/scheduler/constraints.clj)
 T_CON = "test/cook/test/scheduler/constraints.clj"
 
 
 def main():
-    out = dict(rank=RANK, rank_group=RANK_GROUP, quota_group_agg=QUOTA_GROUP_AGG, match=MATCH)
+    out = dict(rank=RANK, rank_group=RANK_GROUP, quota_group_agg=QUOTA_GROUP_AGG, match=MATCH, rebalance=REBALANCE)
     for k, v in out.items():
         with open(os.path.join(HERE, f"{k}.json"), "w") as f:
             json.dump(v, f, indent=1, sort_keys=True)

@@ -83,3 +83,98 @@ def build_match_inputs(case):
         location=np.array([intern(locs, o.get("location")) for o in offers], dtype=np.uint32),
     )
     return J, O, [j["name"] for j in jobs]
+
+
+GROUP_TYPE = {"all": 0, "unique": 1, "balanced": 2, "attribute-equals": 3}
+
+
+def build_rebalance_inputs(case):
+    """-> dict of everything cook_rebalance / oracle_rebalance take, plus name tables (tests/golden/rebalance.json)."""
+    running, pending = case["running"], case["pending"]
+    shares, quotas = case["shares"], case.get("quotas", {})
+    unames = sorted(({t["user"] for t in running} | {j["user"] for j in pending} | set(shares) | set(quotas)) - {"default"})
+    uid = {u: i for i, u in enumerate(unames)}
+    groups = case.get("groups", {})
+    hnames = {t["host"] for t in running} | set(case.get("spare", {})) | set(case.get("host_attrs", {}))
+    hnames |= {h for j in pending for h in j.get("novel", [])} | set(case.get("init_preempted_hosts", []))
+    hnames |= {h for g in groups.values() for h in g.get("running_hosts", [])}
+    hnames = sorted(hnames)
+    hid = {h: i for i, h in enumerate(hnames)}
+    R, P = len(running), len(pending)
+    tasks = A.Tasks(
+        cpus=np.array([t["cpus"] for t in running], dtype=np.float64), mem=np.array([t["mem"] for t in running], dtype=np.float64),
+        gpus=np.array([t.get("gpus", 0.0) for t in running], dtype=np.float64),
+        user=np.array([uid[t["user"]] for t in running], dtype=np.uint32),
+        priority=np.array([t.get("priority", 50) for t in running], dtype=np.int32),
+        start_ms=np.array([1_600_000_000_000 + i for i in range(R)], dtype=np.int64),
+        task_id=np.array([17_592_186_050_000 + i for i in range(R)], dtype=np.int64),
+        job_id=np.array([17_592_186_045_000 + i for i in range(R)], dtype=np.int64),
+        pending=np.zeros(R, dtype=np.uint8), host=np.array([hid[t["host"]] for t in running], dtype=np.uint32))
+
+    def share(u, k):
+        return _v(shares.get(u, shares.get("default", {})).get(k, "MAX"))
+
+    def quota(u, k, dflt):
+        return _v(quotas.get(u, {}).get(k, dflt))
+
+    users = A.Users(div_cpus=np.array([share(u, "cpus") for u in unames]), div_mem=np.array([share(u, "mem") for u in unames]),
+                    div_gpus=np.array([share(u, "gpus") for u in unames]),
+                    quota_count=np.array([quota(u, "count", 2.0 ** 31 - 1) for u in unames]),
+                    quota_cpus=np.array([quota(u, "cpus", "MAX") for u in unames]),
+                    quota_mem=np.array([quota(u, "mem", "MAX") for u in unames]),
+                    quota_gpus=np.array([quota(u, "gpus", "MAX") for u in unames]))
+    # attribute interning: key ids by first appearance (HOSTNAME is implicit), value id 0 = absent
+    keys, vals = {}, {}
+    host_attrs = case.get("host_attrs")
+    for m in (host_attrs or {}).values():
+        for k_, v_ in m.items():
+            if k_ != "HOSTNAME":
+                keys.setdefault(k_, len(keys))
+                vals.setdefault(v_, len(vals) + 1)
+    attrs = None
+    if host_attrs is not None:
+        hs = sorted(host_attrs)
+        attr = np.zeros((len(hs), max(1, len(keys))), dtype=np.uint32)
+        for r, h in enumerate(hs):
+            assert host_attrs[h].get("HOSTNAME", h) == h
+            for k_, v_ in host_attrs[h].items():
+                if k_ != "HOSTNAME":
+                    attr[r, keys[k_]] = vals[v_]
+        attrs = A.Offers(cpus=np.zeros(len(hs)), mem=np.zeros(len(hs)), host=np.array([hid[h] for h in hs], dtype=np.uint32), attr=attr)
+    gnames = sorted(groups)
+    gid = {g: i for i, g in enumerate(gnames)}
+    G = None
+    if gnames:
+        G = A.Groups(type=np.array([GROUP_TYPE[groups[g]["type"]] for g in gnames], dtype=np.uint8),
+                     attr_key=np.array([keys[groups[g]["attribute"]] if "attribute" in groups[g] else A.NONE_U32 for g in gnames],
+                                       dtype=np.uint32),
+                     minimum=np.array([groups[g].get("minimum", 0) for g in gnames], dtype=np.int32),
+                     run_hosts=[[hid[h] for h in groups[g].get("running_hosts", [])] for g in gnames])
+    jobs = A.Jobs.with_constraints(
+        np.array([j["cpus"] for j in pending], dtype=np.float64), np.array([j["mem"] for j in pending], dtype=np.float64),
+        novel=[[hid[h] for h in j.get("novel", [])] for j in pending],
+        gpus=np.array([j.get("gpus", 0.0) for j in pending], dtype=np.float64),
+        user=np.array([uid[j["user"]] for j in pending], dtype=np.uint32),
+        group=np.array([gid[j["group"]] if j.get("group") else A.NONE_U32 for j in pending], dtype=np.uint32))
+    spare = case.get("spare", {})
+    sh = sorted(spare)
+    S = A.HostSpare(host=np.array([hid[h] for h in sh], dtype=np.uint32), cpus=np.array([spare[h].get("cpus", 0.0) for h in sh], dtype=np.float64),
+                    mem=np.array([spare[h].get("mem", 0.0) for h in sh], dtype=np.float64),
+                    gpus=np.array([spare[h].get("gpus", 0.0) for h in sh], dtype=np.float64))
+    prm = case["params"]
+    rp = A.CookRebalanceParams(_v(prm["safe_dru_threshold"]), _v(prm["min_dru_diff"]), int(prm["max_preemption"]), 0)
+    tname = {t["name"]: i for i, t in enumerate(running)}
+    pname = {j["name"]: i for i, j in enumerate(pending)}
+    forced = None
+    if "forced" in case:
+        forced = {pname[n]: (None if d is None else (hid[d["host"]], [tname[t] if t in tname else R + pname[t] for t in d["tasks"]],
+                                                     (d["cpus"], d["mem"], d.get("gpus", 0.0))))
+                  for n, d in case["forced"].items()}
+    return dict(params=A.default_params(dru_mode=case.get("dru_mode", 0)), running=tasks, pending=jobs,
+                pending_job_id=np.array([17_592_186_045_000 + 1000 + j["job_seq"] for j in pending], dtype=np.int64),
+                pending_priority=np.array([j.get("priority", 50) for j in pending], dtype=np.int32),
+                users=users, spare=S, rparams=rp, host_attrs=attrs, groups=G, forced=forced,
+                slave_known=np.array([0 if t.get("slave_cached") is False else 1 for t in running], dtype=np.uint8),
+                init_preempted_hosts=[hid[h] for h in case.get("init_preempted_hosts", [])],
+                task_names=[t["name"] for t in running] + [j["name"] for j in pending], host_names=hnames,
+                pending_names=[j["name"] for j in pending])

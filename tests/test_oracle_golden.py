@@ -82,3 +82,46 @@ def test_match_golden(oracle, case):
     if case["good_enough"] >= 1.0 and J.n:
         j2o8, _, _ = oracle.match(p, J, O, nthreads=4)
         assert np.array_equal(j2o, j2o8)
+
+
+REBAL = G.load("rebalance")
+
+
+def check_rebalance_case(case, result, b):
+    """Shared by the oracle test and the GPU parity tests: `result` = dict(decisions, pending_dru[, final])."""
+    names, hosts, pnames = b["task_names"], b["host_names"], b["pending_names"]
+    R = b["running"].n
+    dec = result["decisions"]
+
+    def tname(i):
+        return names[i] if i != A.NONE_U32 else "<placed-this-cycle>"
+
+    if "expect_decisions" in case:
+        assert len(dec) == len(case["expect_decisions"]), case["ref"]
+        for d, e in zip(dec, case["expect_decisions"]):
+            assert pnames[d["pending_index"]] == e["job"], case["ref"]
+            assert hosts[d["host"]] == e["host"], case["ref"]
+            assert d["dru"] == (A.DMAX if e["dru"] == "MAX" else e["dru"]), case["ref"]  # exact, as the reference's (is (= ...))
+            assert [tname(t) for t in d["tasks"]] == e["tasks"], case["ref"]
+            assert (d["mem"], d["cpus"], d["gpus"]) == (e["mem"], e["cpus"], e["gpus"]), case["ref"]
+    if "expect_decision_host_in" in case:
+        assert len(dec) == 1 and hosts[dec[0]["host"]] in case["expect_decision_host_in"], (case["ref"], dec)
+    if "expect_pending_dru" in case:
+        for n, v in case["expect_pending_dru"].items():
+            assert result["pending_dru"][pnames.index(n)] == v, (case["ref"], n)
+    if "expect_jobs_to_run" in case:
+        assert [pnames[d["pending_index"]] for d in dec] == case["expect_jobs_to_run"], case["ref"]
+        assert [tname(t) for d in dec for t in d["tasks"]] == case["expect_tasks_to_preempt"], case["ref"]
+    if "expect_final_order" in case and result.get("final") is not None:
+        order, drus = result["final"]
+        assert [names[i] for i in order] == case["expect_final_order"], case["ref"]
+        assert list(drus) == case["expect_final_drus"], case["ref"]
+
+
+@pytest.mark.parametrize("case", REBAL, ids=[c["name"] for c in REBAL])
+def test_rebalance_golden(oracle, case):
+    b = G.build_rebalance_inputs(case)
+    res = oracle.rebalance(b["params"], b["running"], b["pending"], b["pending_job_id"], b["pending_priority"], b["users"],
+                           b["spare"], b["rparams"], host_attrs=b["host_attrs"], groups=b["groups"], forced=b["forced"],
+                           want_final=True, slave_known=b["slave_known"], init_preempted_hosts=b["init_preempted_hosts"])
+    check_rebalance_case(case, res, b)

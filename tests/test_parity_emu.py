@@ -117,8 +117,8 @@ def test_match_group_types(make_engine, algo):
 
 
 def test_match_slot_table_and_touched_set_limits(make_engine):
-    # the candidate-slot table overflows (many distinct candidate offers per window) / the touched set fills (every job
-    # lands on its own host): rounds must end early and the result stay exact
+    # the candidate-slot table overflows (many distinct candidate offers per window) / every job lands on
+    # its own host (each commit touches a new offer): rounds must end early and the result stay exact
     jobs, offers = P.pinned_jobs_case(7, 300, 900, 48)
     p = A.default_params(good_enough_fitness=1.0)
     P.match_parity(make_engine, jobs, offers, None, p)
