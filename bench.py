@@ -22,7 +22,6 @@ import json
 import os
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -90,7 +89,8 @@ def main():
     from cook_amd.engine import Engine
 
     P = args.pools
-    my_pools = [p for p in range(P) if p % world == rank]
+    from cook_amd.sharding import pools_of_rank
+    my_pools = pools_of_rank(P, world, rank)
     n_pend, n_run, n_off = args.pending // P, args.running // P, args.offers // P
     params = A.default_params(good_enough_fitness=args.good_enough)
     K = args.considerable if args.considerable > 0 else n_pend
@@ -106,26 +106,15 @@ def main():
         engines[p] = e
     gen_s = time.time() - t0
     # quota: every pool has a (non-binding) pool quota and belongs to ONE quota group "s" whose usage is the sum over
-    # all pools of the cluster -> the cross-rank all-reduce (scheduler.clj:2125-2157)
-    pool_q = A.quota(count=10_000_000, cpus=1e9, mem=1e13, gpus=1e8)
-    group_q = A.quota(count=80_000_000, cpus=1e10, mem=1e14, gpus=1e9)
-    tp = ThreadPoolExecutor(max_workers=max(1, len(my_pools)))
+    # all pools of the cluster -> the cross-rank all-reduce (scheduler.clj:2125-2157); cook_amd/sharding.py
+    from cook_amd import sharding
+    qg = sharding.QuotaGroups(pool_group={p: 0 for p in range(P)},
+                              group_quota={0: A.quota(count=80_000_000, cpus=1e10, mem=1e14, gpus=1e9)},
+                              pool_quota={p: A.quota(count=10_000_000, cpus=1e9, mem=1e13, gpus=1e8) for p in range(P)})
+    cluster = sharding.ShardedCluster(engines, qg, world=world, rank=rank, device=dev)
 
     def cycle():
-        # 1. per-pool running usage (device reduction) -> 2. all-reduce into the group usage -> 3. rank + match per pool
-        usages = list(tp.map(lambda p: engines[p].rank_pool_usage().as_tuple(), my_pools))
-        g = torch.tensor(np.sum(np.array(usages, dtype=np.float64).reshape(-1, 4), axis=0), dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        gu = A.usage(*g.tolist())
-
-        def run(i):
-            p = my_pools[i]
-            q = A.pool_quota(pool_quota=pool_q, group_quota=group_q, group_usage=gu, pool_usage=A.usage(*usages[i]))
-            engines[p].rank_set_quota(q)
-            engines[p].cycle_run(K)
-
-        list(tp.map(run, range(len(my_pools))))
+        cluster.cycle(K)
 
     def fence():
         torch.cuda.synchronize()
@@ -165,7 +154,7 @@ def main():
 
     # ---- roofline of the dominant kernel: second pass with per-kernel HIP events on each engine's own stream ----
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:  # every rank runs the pass (cycle() holds a collective); rank 0 reports
         for p in my_pools:
             engines[p].set_profiling(True)
         for _ in range(max(1, min(args.steps, 3))):

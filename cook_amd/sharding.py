@@ -1,0 +1,112 @@
+"""Pools over GPUs: one process per GPU, pool p -> rank p mod world.
+
+Every structure on the hot path is per pool (scheduler.clj:2167-2194 ranks pool by pool, :2488-2506 makes one handler
+and one Fenzo per pool), so the pools of a cluster shard over ranks with NO data-path collective.  The one cross-pool
+reduction is quota-group usage: `aggregate-quota-groups` (scheduler.clj:2125-2132) sums the running usage
+{count, cpus, mem, gpus} of all pools mapped to the same quota group, and `filter-based-on-quota` (:2134-2157) then
+filters each member pool's queue against the group quota.  Here every rank reduces the usage of its own pools on its
+device, and ONE all-reduce(SUM) of a [n_groups x 4] f64 matrix (RCCL over xGMI on the GPU box, gloo in the CPU tests)
+gives every rank the group totals.  The payload is 32 bytes per group: latency-bound, one per cycle.
+
+The per-pool compute is behind the tiny `PoolEngine` protocol so that the same code drives `cook_amd.engine.Engine`
+(bench.py, GPU) and a checker in the tests.
+"""
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Protocol, Sequence
+
+import numpy as np
+
+from . import _abi as A
+
+
+def pools_of_rank(n_pools: int, world: int, rank: int) -> List[int]:
+    """Pool p lives on rank p mod world (one pool per GPU when world == n_pools: BASELINE.json configs[3])."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return [p for p in range(n_pools) if p % world == rank]
+
+
+class PoolEngine(Protocol):
+    def rank_pool_usage(self) -> A.CookUsage: ...
+    def rank_set_quota(self, quota: Optional[A.CookPoolQuota]) -> None: ...
+    def cycle_run(self, num_considerable: int) -> None: ...
+
+
+@dataclass
+class QuotaGroups:
+    """quota-grouping config: pool -> group name, group -> quota (scheduler.clj:2125-2157; config `quota-grouping`)."""
+    pool_group: Dict[int, int] = field(default_factory=dict)      # pool id -> dense group id; absent = no group
+    group_quota: Dict[int, A.CookUsage] = field(default_factory=dict)
+    pool_quota: Dict[int, A.CookUsage] = field(default_factory=dict)  # tools/global-pool-quota; absent = nil
+
+    @property
+    def n_groups(self) -> int:
+        return (max(self.pool_group.values()) + 1) if self.pool_group else 0
+
+
+def group_usage_matrix(groups: QuotaGroups, local_usage: Dict[int, Sequence[float]]) -> np.ndarray:
+    """This rank's contribution: [n_groups, 4] f64, row g = sum of the running usage of the local pools in group g."""
+    m = np.zeros((max(1, groups.n_groups), 4), dtype=np.float64)
+    for p, u in sorted(local_usage.items()):
+        g = groups.pool_group.get(p)
+        if g is not None:
+            m[g] += np.asarray(u, dtype=np.float64)
+    return m
+
+
+def all_reduce_group_usage(local: np.ndarray, world: int, device=None) -> np.ndarray:
+    """The only collective on the path: all-reduce(SUM) of the [n_groups, 4] matrix.  Integer-valued usages (count, and
+    the benchmark's cpus/mem/gpus) sum exactly in any order; the reference sums pools in map order (merge-with +)."""
+    if world <= 1:
+        return local
+    import torch
+    import torch.distributed as dist
+
+    t = torch.from_numpy(np.ascontiguousarray(local))
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+class ShardedCluster:
+    """The pools of one cluster that live on this rank, and one match cycle over them.
+
+    cycle(K): 1. per-pool running usage (device reduction)  2. all-reduce into quota-group usage
+              3. per pool: set quota inputs, rank + take K + match (cook_cycle_run), pools concurrently (one stream each).
+    """
+
+    def __init__(self, engines: Dict[int, PoolEngine], groups: QuotaGroups, world: int = 1, rank: int = 0, device=None):
+        self.engines = dict(engines)
+        self.pools = sorted(self.engines)
+        self.groups = groups
+        self.world, self.rank, self.device = world, rank, device
+        self._tp = ThreadPoolExecutor(max_workers=max(1, len(self.pools)))
+        self.last_group_usage: Optional[np.ndarray] = None
+
+    def close(self):
+        self._tp.shutdown(wait=True)
+
+    def quota_inputs(self, pool: int, pool_usage: Sequence[float], group_usage: np.ndarray) -> Optional[A.CookPoolQuota]:
+        pq = self.groups.pool_quota.get(pool)
+        g = self.groups.pool_group.get(pool)
+        gq = self.groups.group_quota.get(g) if g is not None else None
+        if pq is None and gq is None:
+            return None
+        return A.pool_quota(pool_quota=pq, group_quota=gq,
+                            group_usage=A.usage(*group_usage[g].tolist()) if gq is not None else None,
+                            pool_usage=A.usage(*pool_usage))
+
+    def cycle(self, num_considerable: int):
+        usages = dict(zip(self.pools, self._tp.map(lambda p: self.engines[p].rank_pool_usage().as_tuple(), self.pools)))
+        total = all_reduce_group_usage(group_usage_matrix(self.groups, usages), self.world, self.device)
+        self.last_group_usage = total
+
+        def run(p):
+            self.engines[p].rank_set_quota(self.quota_inputs(p, usages[p], total))
+            self.engines[p].cycle_run(num_considerable)
+
+        list(self._tp.map(run, self.pools))

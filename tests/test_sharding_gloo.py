@@ -1,0 +1,129 @@
+"""N>1 path on CPU: world_size 2 over gloo.  Pools shard over ranks (pool p -> rank p mod world), the ONLY collective is
+the all-reduce of per-pool running usage into quota-group usage (scheduler.clj:2125-2157), and the ranked queues every
+rank produces must equal the ones a single process produces for the same cluster.
+
+The per-pool compute here is the CPU oracle behind the PoolEngine protocol (tests may use the oracle; the product path,
+cook_amd.engine.Engine, needs a GPU) — what is under test is cook_amd/sharding.py: partitioning, the contribution
+matrix, the collective, and the quota inputs each pool's rank stage receives.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from cook_amd import _abi as A  # noqa: E402
+from cook_amd import sharding, synth  # noqa: E402
+
+N_POOLS = 4
+
+
+class OracleEngine:
+    """PoolEngine backed by the oracle: rank + take K (the match is not needed to test the sharding)."""
+
+    def __init__(self, pool, params):
+        from oracle import pyoracle
+        self.o, self.pool, self.params = pyoracle, pool, params
+        self.quota = None
+        self.ranked = None
+
+    def rank_pool_usage(self):
+        return self.o.pool_usage(self.pool.tasks)
+
+    def rank_set_quota(self, q):
+        self.quota = q
+
+    def cycle_run(self, k):
+        r, _ = self.o.rank(self.params, self.pool.tasks, self.pool.users, self.quota)
+        self.ranked = r[:k]
+
+
+def make_cluster():
+    pools = {p: synth.make_pool(seed=0x5A4D + p, n_pending=600, n_running=300 + 50 * p, n_users=25, n_offers=32)
+             for p in range(N_POOLS)}
+    # pools 0,1,3 share quota group 0 with a BINDING count quota; pool 2 has only its own pool quota
+    total_run = sum(pools[p].n_running for p in (0, 1, 3))
+    groups = sharding.QuotaGroups(
+        pool_group={0: 0, 1: 0, 3: 0},
+        group_quota={0: A.quota(count=total_run + 150)},
+        pool_quota={2: A.quota(count=pools[2].n_running + 40), 0: A.quota(count=10_000_000)})
+    return pools, groups
+
+
+def run_rank(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    pools, groups = make_cluster()
+    params = A.default_params()
+    mine = sharding.pools_of_rank(N_POOLS, world, rank)
+    cl = sharding.ShardedCluster({p: OracleEngine(pools[p], params) for p in mine}, groups, world=world, rank=rank)
+    cl.cycle(500)
+    np.savez(os.path.join(out_dir, f"w{world}_r{rank}.npz"), group_usage=cl.last_group_usage,
+             **{f"ranked_{p}": cl.engines[p].ranked for p in mine})
+    cl.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_pools_of_rank_partition():
+    for world in (1, 2, 3, 4, 8):
+        seen = sorted(p for r in range(world) for p in sharding.pools_of_rank(8, world, r))
+        assert seen == list(range(8))
+    assert sharding.pools_of_rank(8, 8, 5) == [5]
+    assert sharding.pools_of_rank(8, 2, 1) == [1, 3, 5, 7]
+    with pytest.raises(ValueError):
+        sharding.pools_of_rank(8, 2, 2)
+
+
+def test_group_usage_matrix():
+    g = sharding.QuotaGroups(pool_group={0: 1, 2: 1, 5: 0})
+    m = sharding.group_usage_matrix(g, {0: (1, 2, 3, 4), 2: (10, 20, 30, 40), 3: (7, 7, 7, 7), 5: (1, 1, 1, 1)})
+    assert m.shape == (2, 4)
+    assert m[1].tolist() == [11, 22, 33, 44] and m[0].tolist() == [1, 1, 1, 1]
+
+
+@pytest.mark.timeout(300)
+def test_world2_gloo_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    run_rank(0, 1, _free_port(), out)  # single process: all pools local, no collective
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=run_rank, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    one = np.load(os.path.join(out, "w1_r0.npz"))
+    got = {}
+    for r in range(2):
+        z = np.load(os.path.join(out, f"w2_r{r}.npz"))
+        assert np.array_equal(z["group_usage"], one["group_usage"])  # every rank holds the cluster-wide group usage
+        got.update({k: z[k] for k in z.files if k.startswith("ranked_")})
+    assert sorted(got) == [f"ranked_{p}" for p in range(N_POOLS)]
+    pools, groups = make_cluster()
+    for p in range(N_POOLS):
+        assert np.array_equal(got[f"ranked_{p}"], one[f"ranked_{p}"]), f"pool {p}"
+    # the group quota is binding: the three member pools together keep at most 150 pending jobs ... per pool the filter
+    # is a prefix condition on that pool's queue against the cluster-wide usage, so each keeps at most 150
+    for p in (0, 1, 3):
+        assert 0 < len(one[f"ranked_{p}"]) <= 150
+    assert 0 < len(one["ranked_2"]) <= 40
