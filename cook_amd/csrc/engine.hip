@@ -15,6 +15,7 @@
 #include "match_kernels.hpp"
 #include "match_v2.hpp"
 #include "rank_kernels.hpp"
+#include "rebalance_kernels.hpp"
 #include "scan.hpp"
 #include "sort.hpp"
 
@@ -42,6 +43,10 @@ struct DBuf {
     p = nullptr;
     cap = 0;
   }
+  DBuf() = default;
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  ~DBuf() { release(); }
 };
 template <class T>
 struct DArr {
@@ -65,6 +70,8 @@ struct KernelStat {
   double ms = 0;
   unsigned launches = 0;
 };
+
+struct RebalBufs;  // rebalance_host.hpp
 
 }  // namespace
 
@@ -139,6 +146,9 @@ struct cook_engine {
   MatchIn min{};
   bool cycle_staged = false;
   unsigned cycle_considered = 0;
+
+  // ---- rebalancer state (allocated on first use) ----
+  RebalBufs* rb = nullptr;
 
   void fail(int code, const std::string& m) { throw cook_error(code, m); }
 };
@@ -778,6 +788,13 @@ struct StageTimer {
   }
 };
 
+#include "rebalance_host.hpp"
+
+RebalBufs& rebal_bufs(cook_engine* e) {
+  if (!e->rb) e->rb = new RebalBufs();
+  return *e->rb;
+}
+
 template <class F>
 int guarded(cook_engine* e, F&& f) {
   if (!e) return COOK_E_INVALID;
@@ -868,6 +885,8 @@ void cook_engine_destroy(cook_engine* e) {
     if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]);
   if (e->h_scratch) (void)hipHostFree(e->h_scratch);
   if (e->h_inbuf) (void)hipHostFree(e->h_inbuf);
+  delete e->rb;
+  e->rb = nullptr;
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -984,14 +1003,47 @@ int cook_cycle_fetch(cook_engine* e, uint32_t* ranked, uint32_t* n_ranked, int32
   });
 }
 
-int cook_rebalance(cook_engine* e, const cook_tasks*, const cook_jobs*, const int64_t*, const int32_t*, const cook_users*,
-                   const cook_host_spare*, const cook_rebalance_params*, cook_preemption*, uint32_t* n_decisions, uint32_t*,
-                   uint32_t* n_preempted) {
+int cook_rebalance_stage(cook_engine* e, const cook_tasks* running, const uint8_t* running_attrs_cached, const cook_jobs* pending,
+                         const int64_t* pending_job_id, const int32_t* pending_priority, const cook_users* users,
+                         const cook_host_spare* spare, const cook_offers* host_attrs, const cook_groups* groups,
+                         const cook_rebalance_params* params) {
+  return guarded(e, [&] {
+    rebalance_stage(e, rebal_bufs(e), running, running_attrs_cached, pending, pending_job_id, pending_priority, users, spare, host_attrs,
+                    groups, params);
+  });
+}
+int cook_rebalance_run(cook_engine* e) {
+  return guarded(e, [&] {
+    RebalBufs& b = rebal_bufs(e);
+    StageTimer t(e, 0, &b.ms);
+    rebalance_run(e, b);
+    t.stop();
+    prof_collect(e);
+  });
+}
+int cook_rebalance_fetch(cook_engine* e, cook_preemption* decisions, uint32_t* n_decisions, uint32_t* preempted, uint32_t* n_preempted,
+                         double* pending_dru) {
   if (n_decisions) *n_decisions = 0;
   if (n_preempted) *n_preempted = 0;
-  if (!e) return COOK_E_INVALID;
-  e->err = "cook_rebalance: not implemented in this build";
-  return COOK_E_STATE;
+  return guarded(e, [&] { rebalance_fetch(e, rebal_bufs(e), decisions, n_decisions, preempted, n_preempted, pending_dru); });
+}
+int cook_rebalance(cook_engine* e, const cook_tasks* running, const uint8_t* running_attrs_cached, const cook_jobs* pending,
+                   const int64_t* pending_job_id, const int32_t* pending_priority, const cook_users* users, const cook_host_spare* spare,
+                   const cook_offers* host_attrs, const cook_groups* groups, const cook_rebalance_params* params,
+                   cook_preemption* decisions, uint32_t* n_decisions, uint32_t* preempted, uint32_t* n_preempted, double* pending_dru) {
+  if (n_decisions) *n_decisions = 0;  // "no decisions" on any error path
+  if (n_preempted) *n_preempted = 0;
+  int rc = cook_rebalance_stage(e, running, running_attrs_cached, pending, pending_job_id, pending_priority, users, spare, host_attrs,
+                                groups, params);
+  if (rc) return rc;
+  rc = cook_rebalance_run(e);
+  if (rc) return rc;
+  return cook_rebalance_fetch(e, decisions, n_decisions, preempted, n_preempted, pending_dru);
+}
+int cook_rebalance_timing(cook_engine* e, double* ms) {
+  if (!e || !ms) return COOK_E_INVALID;
+  *ms = e->rb ? e->rb->ms : 0.0;
+  return COOK_OK;
 }
 
 int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms) {

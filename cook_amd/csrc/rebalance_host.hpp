@@ -1,0 +1,448 @@
+// rebalance_host.hpp — host orchestration of cook_rebalance (included by engine.hip inside its anonymous namespace).
+// Stage: concatenate running tasks ++ the pending jobs' task slots, dense per-host tables, H2D.  Run: per-user order and
+// host grouping by the rank path's radix sort, masked DRU scan, then the decision loop (three kernels + the masked
+// re-scan per pending job) enqueued without host round trips; the budget is read back every RB_CHECK jobs to stop early.
+#pragma once
+
+constexpr unsigned RB_CHECK = 32;
+
+struct RebalBufs {
+  bool staged = false, done = false;
+  unsigned R = 0, P = 0, S = 0, U = 0, H = 0, G = 0, n_attr = 0, co_cap = 0;
+  bool has_attrs = false;
+  cook_rebalance_params rp{};
+  // slot inputs (A space)
+  DArr<double> cpus, mem, gpus;
+  DArr<uint32_t> user, host;
+  DArr<int32_t> prio;
+  DArr<int64_t> start, task, job;
+  DArr<uint8_t> pending, cached;
+  bool has_cached = false;
+  // users
+  DArr<double> divc, divm, divg, qcount, qcpus, qmem, qgpus;
+  // B space
+  DArr<uint32_t> permA, permB2, posB, s_user, seg_start, seg_end, inexact;
+  DArr<uint8_t> s_pending, head, act;
+  DArr<SumU4> s_use, pre;
+  DArr<double> dru;
+  // hosts
+  DArr<uint64_t> hkey;
+  DArr<uint32_t> hpermA, hpermB, hstart, hend;
+  uint32_t* hperm = nullptr;
+  DArr<int32_t> row_of_host;
+  DArr<double> spare_c, spare_m, spare_g;
+  DArr<uint8_t> has_spare;
+  // attribute table
+  DArr<uint32_t> a_host, a_gpu_model, a_disk_type, a_attr, a_location;
+  DArr<uint8_t> a_k8s;
+  DArr<double> a_gpu_count, a_disk_space;
+  DArr<int64_t> a_host_start;
+  bool ha_k8s = false, ha_gpu = false, ha_disk = false, ha_attr = false, ha_loc = false, ha_start = false;
+  // pending jobs
+  DArr<double> j_cpus, j_mem, j_gpus, j_disk_req;
+  DArr<uint32_t> j_gpu_model, j_user, j_group, j_eq_off, j_eq_key, j_eq_val, j_novel_off, j_novel_host, j_ckpt, j_disk_type;
+  DArr<int64_t> j_est_end;
+  bool hj_gpus = false, hj_gpu_model = false, hj_group = false, hj_eq = false, hj_novel = false, hj_ckpt = false, hj_disk = false,
+       hj_est = false;
+  // groups
+  DArr<uint8_t> g_type;
+  DArr<uint32_t> g_attr_key, g_run_off, g_run_host;
+  DArr<int32_t> g_min;
+  bool hg_run = false;
+  // dynamic
+  DArr<uint32_t> x_pj, x_host, pre_hosts, co_val, hres_len, hres_base, srt_slot, gs_posB, gs_slot, gs_ord;
+  DArr<uint8_t> x_known;
+  DArr<unsigned long long> hres_key;
+  DArr<double> hres_dru, hres_c, hres_m, hres_g, gs_dru, gs_cpus, gs_mem, gs_gpus, pending_dru;
+  DArr<cook_preemption> decisions;
+  DArr<uint32_t> preempted;
+  DArr<RebalCtl> ctl;
+  DArr<RebalJob> jobctx;
+  RebalCtl last{};
+  double ms = 0;
+};
+
+void rebalance_stage(cook_engine* e, RebalBufs& b, const cook_tasks* run, const uint8_t* cached, const cook_jobs* pend,
+                     const int64_t* pend_job_id, const int32_t* pend_prio, const cook_users* u, const cook_host_spare* spare,
+                     const cook_offers* attrs, const cook_groups* groups, const cook_rebalance_params* rp) {
+  if (!run || !pend || !u || !rp) e->fail(COOK_E_INVALID, "cook_rebalance: null running/pending/users/params");
+  const unsigned R = run->n, P = pend->n, U = u->n, S = R + P;
+  if (R && (!run->cpus || !run->mem || !run->user || !run->priority || !run->start_ms || !run->task_id || !run->job_id || !run->host))
+    e->fail(COOK_E_INVALID, "cook_rebalance: running tasks need cpus, mem, user, priority, start_ms, task_id, job_id, host");
+  if (P && (!pend->cpus || !pend->mem || !pend->user || !pend_job_id || !pend_prio))
+    e->fail(COOK_E_INVALID, "cook_rebalance: pending jobs need cpus, mem, user, job ids and priorities");
+  if (S && U == 0) e->fail(COOK_E_INVALID, "cook_rebalance: no users");
+  const unsigned G = groups ? groups->n : 0;
+  b.staged = b.done = false;
+  b.R = R, b.P = P, b.S = S, b.U = U, b.G = G;
+  b.rp = *rp;
+  // ---- slots: running ++ one slot per pending job (the task it becomes when placed) ---------------------------------
+  std::vector<double> c(S ? S : 1), m(S ? S : 1), g(S ? S : 1, 0.0);
+  std::vector<uint32_t> us(S ? S : 1);
+  std::vector<int32_t> pr(S ? S : 1);
+  std::vector<int64_t> st(S ? S : 1, 0), tk(S ? S : 1, 0), jb(S ? S : 1);
+  std::vector<uint8_t> pe(S ? S : 1, 0);
+  unsigned maxh = 0;
+  bool any_host = false;
+  auto see_host = [&](uint32_t h) {
+    maxh = std::max(maxh, h);
+    any_host = true;
+  };
+  for (unsigned i = 0; i < R; ++i) {
+    if (run->user[i] >= U) e->fail(COOK_E_INVALID, "cook_rebalance: user id out of range");
+    c[i] = run->cpus[i], m[i] = run->mem[i], g[i] = run->gpus ? run->gpus[i] : 0.0;
+    us[i] = run->user[i], pr[i] = run->priority[i], st[i] = run->start_ms[i], tk[i] = run->task_id[i], jb[i] = run->job_id[i];
+    see_host(run->host[i]);
+  }
+  for (unsigned p = 0; p < P; ++p) {
+    if (pend->user[p] >= U) e->fail(COOK_E_INVALID, "cook_rebalance: user id out of range");
+    const unsigned s = R + p;
+    c[s] = pend->cpus[p], m[s] = pend->mem[p], g[s] = pend->gpus ? pend->gpus[p] : 0.0;
+    us[s] = pend->user[p], pr[s] = pend_prio[p], jb[s] = pend_job_id[p];
+    pe[s] = 1;
+  }
+  if (spare)
+    for (unsigned i = 0; i < spare->n; ++i) see_host(spare->host[i]);
+  if (attrs)
+    for (unsigned i = 0; i < attrs->n; ++i) see_host(attrs->host[i]);
+  if (groups && groups->run_off)
+    for (unsigned i = 0; i < groups->run_off[G]; ++i) see_host(groups->run_host[i]);
+  const unsigned H = any_host ? maxh + 1 : 0;
+  b.H = H;
+  h2d(e, b.cpus, c.data(), S);
+  h2d(e, b.mem, m.data(), S);
+  h2d(e, b.gpus, g.data(), S);
+  h2d(e, b.user, us.data(), S);
+  h2d(e, b.prio, pr.data(), S);
+  h2d(e, b.start, st.data(), S);
+  h2d(e, b.task, tk.data(), S);
+  h2d(e, b.job, jb.data(), S);
+  h2d(e, b.pending, pe.data(), S);
+  h2d(e, b.host, run->host, R);
+  b.has_cached = cached != nullptr;
+  if (cached) h2d(e, b.cached, cached, R);
+  h2d(e, b.divc, u->div_cpus, U);
+  h2d(e, b.divm, u->div_mem, U);
+  h2d(e, b.divg, u->div_gpus, U);
+  h2d(e, b.qcount, u->quota_count, U);
+  h2d(e, b.qcpus, u->quota_cpus, U);
+  h2d(e, b.qmem, u->quota_mem, U);
+  h2d(e, b.qgpus, u->quota_gpus, U);
+  // ---- dense per-host tables -------------------------------------------------------------------------------------------------
+  std::vector<int32_t> row(H ? H : 1, -1);
+  std::vector<double> sc(H ? H : 1, 0.0), sm(H ? H : 1, 0.0), sg(H ? H : 1, 0.0);
+  std::vector<uint8_t> hs(H ? H : 1, 0);
+  if (attrs)
+    for (unsigned i = 0; i < attrs->n; ++i) row[attrs->host[i]] = (int32_t)i;
+  if (spare)
+    for (unsigned i = 0; i < spare->n; ++i) {
+      const unsigned h = spare->host[i];
+      sc[h] = spare->cpus[i], sm[h] = spare->mem[i], sg[h] = spare->gpus ? spare->gpus[i] : 0.0;
+      hs[h] = 1;
+    }
+  h2d(e, b.row_of_host, row.data(), H);
+  h2d(e, b.spare_c, sc.data(), H);
+  h2d(e, b.spare_m, sm.data(), H);
+  h2d(e, b.spare_g, sg.data(), H);
+  h2d(e, b.has_spare, hs.data(), H);
+  // ---- attribute table ----------------------------------------------------------------------------------------------------------
+  b.has_attrs = attrs != nullptr && attrs->n > 0;
+  b.ha_k8s = b.ha_gpu = b.ha_disk = b.ha_attr = b.ha_loc = b.ha_start = false;
+  b.n_attr = 0;
+  if (b.has_attrs) {
+    const unsigned n = attrs->n;
+    h2d(e, b.a_host, attrs->host, n);
+    if ((b.ha_k8s = attrs->k8s != nullptr)) h2d(e, b.a_k8s, attrs->k8s, n);
+    if ((b.ha_gpu = attrs->gpu_model != nullptr)) {
+      if (!attrs->gpu_count) e->fail(COOK_E_INVALID, "cook_rebalance: host_attrs gpu_model without gpu_count");
+      h2d(e, b.a_gpu_model, attrs->gpu_model, n);
+      h2d(e, b.a_gpu_count, attrs->gpu_count, n);
+    }
+    if ((b.ha_disk = attrs->disk_type != nullptr && attrs->disk_space != nullptr)) {
+      h2d(e, b.a_disk_type, attrs->disk_type, n);
+      h2d(e, b.a_disk_space, attrs->disk_space, n);
+    }
+    if ((b.ha_attr = attrs->attr != nullptr && attrs->n_attr_keys > 0)) {
+      b.n_attr = attrs->n_attr_keys;
+      h2d(e, b.a_attr, attrs->attr, (size_t)n * b.n_attr);
+    }
+    if ((b.ha_loc = attrs->location != nullptr)) h2d(e, b.a_location, attrs->location, n);
+    if ((b.ha_start = attrs->host_start_s != nullptr)) h2d(e, b.a_host_start, attrs->host_start_s, n);
+  }
+  // ---- pending jobs ------------------------------------------------------------------------------------------------------------
+  h2d(e, b.j_cpus, pend->cpus, P);
+  h2d(e, b.j_mem, pend->mem, P);
+  h2d(e, b.j_user, pend->user, P);
+  if ((b.hj_gpus = pend->gpus != nullptr)) h2d(e, b.j_gpus, pend->gpus, P);
+  if ((b.hj_gpu_model = pend->gpu_model != nullptr)) h2d(e, b.j_gpu_model, pend->gpu_model, P);
+  if ((b.hj_group = pend->group != nullptr && G > 0)) h2d(e, b.j_group, pend->group, P);
+  if ((b.hj_eq = pend->eq_off != nullptr && P > 0)) {
+    h2d(e, b.j_eq_off, pend->eq_off, P + 1);
+    h2d(e, b.j_eq_key, pend->eq_key, std::max(1u, pend->eq_off[P]));
+    h2d(e, b.j_eq_val, pend->eq_val, std::max(1u, pend->eq_off[P]));
+  }
+  if ((b.hj_novel = pend->novel_off != nullptr && P > 0)) {
+    h2d(e, b.j_novel_off, pend->novel_off, P + 1);
+    h2d(e, b.j_novel_host, pend->novel_host, std::max(1u, pend->novel_off[P]));
+  }
+  if ((b.hj_ckpt = pend->ckpt_location != nullptr)) h2d(e, b.j_ckpt, pend->ckpt_location, P);
+  if ((b.hj_est = pend->est_end_ms != nullptr)) h2d(e, b.j_est_end, pend->est_end_ms, P);
+  if ((b.hj_disk = pend->disk_request != nullptr && pend->disk_type != nullptr)) {
+    h2d(e, b.j_disk_req, pend->disk_request, P);
+    h2d(e, b.j_disk_type, pend->disk_type, P);
+  }
+  if (pend->group && G)
+    for (unsigned p = 0; p < P; ++p)
+      if (pend->group[p] != COOK_NONE_U32 && pend->group[p] >= G) e->fail(COOK_E_INVALID, "cook_rebalance: group id out of range");
+  // ---- groups --------------------------------------------------------------------------------------------------------------------
+  unsigned max_run = 0;
+  b.hg_run = false;
+  if (G) {
+    if (!groups->type || !groups->attr_key || !groups->minimum) e->fail(COOK_E_INVALID, "cook_rebalance: groups need type, attr_key, minimum");
+    h2d(e, b.g_type, groups->type, G);
+    h2d(e, b.g_attr_key, groups->attr_key, G);
+    h2d(e, b.g_min, groups->minimum, G);
+    if ((b.hg_run = groups->run_off != nullptr)) {
+      h2d(e, b.g_run_off, groups->run_off, G + 1);
+      h2d(e, b.g_run_host, groups->run_host, std::max(1u, groups->run_off[G]));
+      for (unsigned x = 0; x < G; ++x) max_run = std::max(max_run, groups->run_off[x + 1] - groups->run_off[x]);
+    }
+  }
+  b.co_cap = S + max_run + 1;
+  sync(e);  // host temporaries
+  b.staged = true;
+}
+
+RebalIn rebalance_args(cook_engine* e, RebalBufs& b) {
+  RebalIn in;
+  std::memset(&in, 0, sizeof(in));
+  in.R = b.R, in.P = b.P, in.S = b.S, in.U = b.U, in.H = b.H;
+  in.dru_mode = e->params.dru_mode;
+  in.host_lifetime_mins = e->params.host_lifetime_mins;
+  in.safe_dru = b.rp.safe_dru_threshold;
+  in.min_diff = b.rp.min_dru_diff;
+  in.slot_user = b.user.ptr();
+  in.slot_cpus = b.cpus.ptr();
+  in.slot_mem = b.mem.ptr();
+  in.slot_gpus = b.gpus.ptr();
+  in.posB = b.posB.ptr();
+  in.attrs_cached = b.has_cached ? b.cached.ptr() : nullptr;
+  in.s_use = b.s_use.ptr();
+  in.seg_start = b.seg_start.ptr();
+  in.seg_end = b.seg_end.ptr();
+  in.act = b.act.ptr();
+  in.dru = b.dru.ptr();
+  in.q_count = b.qcount.ptr(), in.q_cpus = b.qcpus.ptr(), in.q_mem = b.qmem.ptr(), in.q_gpus = b.qgpus.ptr();
+  in.div_cpus = b.divc.ptr(), in.div_mem = b.divm.ptr(), in.div_gpus = b.divg.ptr();
+  in.hperm = b.hperm;
+  in.hstart = b.hstart.ptr(), in.hend = b.hend.ptr();
+  in.row_of_host = b.row_of_host.ptr();
+  in.spare_c = b.spare_c.ptr(), in.spare_m = b.spare_m.ptr(), in.spare_g = b.spare_g.ptr();
+  in.has_spare = b.has_spare.ptr();
+  in.n_attr = b.n_attr;
+  if (b.has_attrs) {
+    in.a_host = b.a_host.ptr();
+    in.a_k8s = b.ha_k8s ? b.a_k8s.ptr() : nullptr;
+    in.a_gpu_model = b.ha_gpu ? b.a_gpu_model.ptr() : nullptr;
+    in.a_gpu_count = b.ha_gpu ? b.a_gpu_count.ptr() : nullptr;
+    in.a_disk_type = b.ha_disk ? b.a_disk_type.ptr() : nullptr;
+    in.a_disk_space = b.ha_disk ? b.a_disk_space.ptr() : nullptr;
+    in.a_attr = b.ha_attr ? b.a_attr.ptr() : nullptr;
+    in.a_location = b.ha_loc ? b.a_location.ptr() : nullptr;
+    in.a_host_start = b.ha_start ? b.a_host_start.ptr() : nullptr;
+  }
+  in.j_cpus = b.j_cpus.ptr(), in.j_mem = b.j_mem.ptr();
+  in.j_gpus = b.hj_gpus ? b.j_gpus.ptr() : nullptr;
+  in.j_gpu_model = b.hj_gpu_model ? b.j_gpu_model.ptr() : nullptr;
+  in.j_user = b.j_user.ptr();
+  in.j_group = b.hj_group ? b.j_group.ptr() : nullptr;
+  in.j_eq_off = b.hj_eq ? b.j_eq_off.ptr() : nullptr;
+  in.j_eq_key = b.hj_eq ? b.j_eq_key.ptr() : nullptr;
+  in.j_eq_val = b.hj_eq ? b.j_eq_val.ptr() : nullptr;
+  in.j_novel_off = b.hj_novel ? b.j_novel_off.ptr() : nullptr;
+  in.j_novel_host = b.hj_novel ? b.j_novel_host.ptr() : nullptr;
+  in.j_ckpt = b.hj_ckpt ? b.j_ckpt.ptr() : nullptr;
+  in.j_est_end = b.hj_est ? b.j_est_end.ptr() : nullptr;
+  in.j_disk_req = b.hj_disk ? b.j_disk_req.ptr() : nullptr;
+  in.j_disk_type = b.hj_disk ? b.j_disk_type.ptr() : nullptr;
+  in.G = b.G;
+  if (b.G) {
+    in.g_type = b.g_type.ptr();
+    in.g_attr_key = b.g_attr_key.ptr();
+    in.g_min = b.g_min.ptr();
+    in.g_run_off = b.hg_run ? b.g_run_off.ptr() : nullptr;
+    in.g_run_host = b.hg_run ? b.g_run_host.ptr() : nullptr;
+  }
+  in.x_pj = b.x_pj.ptr(), in.x_host = b.x_host.ptr(), in.x_known = b.x_known.ptr();
+  in.pre_hosts = b.pre_hosts.ptr(), in.co_val = b.co_val.ptr();
+  in.hres_key = b.hres_key.ptr(), in.hres_len = b.hres_len.ptr(), in.hres_base = b.hres_base.ptr();
+  in.hres_dru = b.hres_dru.ptr(), in.hres_c = b.hres_c.ptr(), in.hres_m = b.hres_m.ptr(), in.hres_g = b.hres_g.ptr();
+  in.srt_slot = b.srt_slot.ptr();
+  in.gs_dru = b.gs_dru.ptr(), in.gs_cpus = b.gs_cpus.ptr(), in.gs_mem = b.gs_mem.ptr(), in.gs_gpus = b.gs_gpus.ptr();
+  in.gs_posB = b.gs_posB.ptr(), in.gs_slot = b.gs_slot.ptr(), in.gs_ord = b.gs_ord.ptr();
+  in.decisions = b.decisions.ptr();
+  in.preempted = b.preempted.ptr();
+  in.pending_dru = b.pending_dru.ptr();
+  in.ctl = b.ctl.ptr();
+  in.job = b.jobctx.ptr();
+  return in;
+}
+
+// masked per-user prefix sums -> DRUs (dru.clj:50-80 over the active slots), exact for any fp64 input
+void rebalance_rescore(cook_engine* e, RebalBufs& b) {
+  const unsigned S = b.S, U = b.U;
+  seg_scan<SumU4>(e, "rebal_usage_scan", LoadMaskedU4{b.s_use.ptr(), b.act.ptr()}, (const uint8_t*)b.head.ptr(), S, b.pre.ptr(), e->tmpU4);
+  KL("rank_mark_inexact", rank_mark_inexact, div_up(S, 256), 256, (const SumU4*)b.pre.ptr(), (const uint32_t*)b.s_user.ptr(), S,
+     b.inexact.ptr());
+  KL("rebal_fix_inexact", rebal_fix_inexact, div_up(U, 256), 256, (const SumU4*)b.s_use.ptr(), (const uint8_t*)b.act.ptr(), b.pre.ptr(),
+     (const uint32_t*)b.seg_start.ptr(), (const uint32_t*)b.seg_end.ptr(), b.inexact.ptr(), U);
+  KL("rebal_score", rebal_score, div_up(S, 256), 256, (const SumU4*)b.pre.ptr(), (const uint32_t*)b.s_user.ptr(), S, (int)e->params.dru_mode,
+     (const double*)b.divc.ptr(), (const double*)b.divm.ptr(), (const double*)b.divg.ptr(), b.dru.ptr());
+}
+
+void rebalance_run(cook_engine* e, RebalBufs& b) {
+  if (!b.staged) e->fail(COOK_E_STATE, "cook_rebalance_run before cook_rebalance_stage");
+  const unsigned R = b.R, P = b.P, S = b.S, U = b.U, H = b.H;
+  b.done = false;
+  std::memset(&b.last, 0, sizeof(b.last));
+  b.decisions.ensure(std::max(1u, P));
+  b.preempted.ensure(std::max(1u, S));
+  b.pending_dru.ensure(std::max(1u, P));
+  if (P == 0 || b.rp.max_preemption <= 0) {
+    if (P) {
+      std::vector<double> nanv(P, std::numeric_limits<double>::quiet_NaN());
+      COOK_HIP(hipMemcpyAsync(b.pending_dru.ptr(), nanv.data(), (size_t)P * 8, hipMemcpyHostToDevice, e->stream));
+      sync(e);
+    }
+    b.done = true;
+    return;
+  }
+  const unsigned gS = div_up(S, 256);
+  e->d_scratch64.ensure(64);
+  // ---- per-user order of all slots (tools.clj:614-641; rebalancer.clj:241-246) ---------------------------------------------
+  unsigned long long* mins = e->d_scratch64.ptr();
+  unsigned long long* masks = e->d_scratch64.ptr() + 4;
+  COOK_HIP(hipMemsetAsync(mins, 0xFF, 3 * 8, e->stream));
+  COOK_HIP(hipMemsetAsync(masks, 0, 4 * 8, e->stream));
+  e->w0.ensure(S);
+  e->w1.ensure(S);
+  e->w2.ensure(S);
+  KL("rank_key_mins", rank_key_mins, std::min(gS, 1024u), 256, (const int64_t*)b.start.ptr(), (const int64_t*)b.task.ptr(),
+     (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, mins);
+  KL("rank_build_keys", rank_build_keys, gS, 256, (const uint32_t*)b.user.ptr(), (const int32_t*)b.prio.ptr(), (const int64_t*)b.start.ptr(),
+     (const int64_t*)b.task.ptr(), (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, (const unsigned long long*)mins,
+     e->w0.ptr(), e->w1.ptr(), e->w2.ptr());
+  const unsigned gV = std::min(gS, 1024u);
+  KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w0.ptr(), S, masks + 0);
+  KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w1.ptr(), S, masks + 1);
+  KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w2.ptr(), S, masks + 2);
+  readback64(e, 8);
+  const unsigned long long mk0 = e->h_scratch[4], mk1 = e->h_scratch[5], mk2 = e->h_scratch[6];
+  b.permA.ensure(S);
+  b.permB2.ensure(S);
+  KL("iota", iota_u32, gS, 256, b.permA.ptr(), S);
+  uint32_t* cur = b.permA.ptr();
+  cur = radix_sort_masked(e, e->w2.ptr(), mk2, cur, b.permA.ptr(), b.permB2.ptr(), S);
+  cur = radix_sort_masked(e, e->w1.ptr(), mk1, cur, b.permA.ptr(), b.permB2.ptr(), S);
+  cur = radix_sort_masked(e, e->w0.ptr(), mk0, cur, b.permA.ptr(), b.permB2.ptr(), S);
+  const uint32_t* permB = cur;
+  b.posB.ensure(S);
+  b.act.ensure(S);
+  b.s_user.ensure(S);
+  b.s_use.ensure(S);
+  b.s_pending.ensure(S);
+  b.head.ensure(S);
+  b.seg_start.ensure(U);
+  b.seg_end.ensure(U);
+  b.pre.ensure(S);
+  b.dru.ensure(S);
+  b.inexact.ensure(U);
+  COOK_HIP(hipMemsetAsync(b.seg_start.ptr(), 0, (size_t)U * 4, e->stream));
+  COOK_HIP(hipMemsetAsync(b.seg_end.ptr(), 0, (size_t)U * 4, e->stream));
+  COOK_HIP(hipMemsetAsync(b.inexact.ptr(), 0, (size_t)U * 4, e->stream));
+  KL("rebal_invert_perm", rebal_invert_perm, gS, 256, permB, S, R, b.posB.ptr(), b.act.ptr());
+  KL("rank_gather", rank_gather, gS, 256, permB, S, (const uint32_t*)b.user.ptr(), (const double*)b.cpus.ptr(), (const double*)b.mem.ptr(),
+     (const double*)b.gpus.ptr(), (const uint8_t*)b.pending.ptr(), b.s_user.ptr(), b.s_use.ptr(), b.s_pending.ptr(), b.head.ptr(),
+     b.seg_start.ptr(), b.seg_end.ptr());
+  // ---- running tasks grouped by host (the group-by of rebalancer.clj:349, done once) --------------------------------------------
+  b.hstart.ensure(std::max(1u, H));
+  b.hend.ensure(std::max(1u, H));
+  COOK_HIP(hipMemsetAsync(b.hstart.ptr(), 0, (size_t)std::max(1u, H) * 4, e->stream));
+  COOK_HIP(hipMemsetAsync(b.hend.ptr(), 0, (size_t)std::max(1u, H) * 4, e->stream));
+  b.hpermA.ensure(std::max(1u, R));
+  b.hpermB.ensure(std::max(1u, R));
+  b.hperm = b.hpermA.ptr();
+  if (R) {
+    b.hkey.ensure(R);
+    const unsigned gR = div_up(R, 256);
+    KL("rebal_host_keys", rebal_host_keys, gR, 256, (const uint32_t*)b.host.ptr(), R, b.hkey.ptr());
+    KL("iota", iota_u32, gR, 256, b.hpermA.ptr(), R);
+    unsigned long long hmask = 0;
+    for (unsigned long long x = H ? H - 1 : 0; x; x >>= 1) hmask = (hmask << 1) | 1ull;
+    b.hperm = radix_sort_masked(e, b.hkey.ptr(), hmask, b.hpermA.ptr(), b.hpermA.ptr(), b.hpermB.ptr(), R);
+    KL("rebal_host_bounds", rebal_host_bounds, gR, 256, (const uint32_t*)b.hperm, (const uint32_t*)b.host.ptr(), R, b.hstart.ptr(),
+       b.hend.ptr());
+  }
+  // ---- dynamic state -----------------------------------------------------------------------------------------------------------
+  b.x_pj.ensure(P);
+  b.x_host.ensure(P);
+  b.x_known.ensure(P);
+  b.pre_hosts.ensure(S);
+  b.co_val.ensure(b.co_cap);
+  b.hres_key.ensure(std::max(1u, H));
+  b.hres_len.ensure(std::max(1u, H));
+  b.hres_base.ensure(std::max(1u, H));
+  b.hres_dru.ensure(std::max(1u, H));
+  b.hres_c.ensure(std::max(1u, H));
+  b.hres_m.ensure(std::max(1u, H));
+  b.hres_g.ensure(std::max(1u, H));
+  b.srt_slot.ensure(S);
+  b.gs_dru.ensure(S), b.gs_cpus.ensure(S), b.gs_mem.ensure(S), b.gs_gpus.ensure(S);
+  b.gs_posB.ensure(S), b.gs_slot.ensure(S), b.gs_ord.ensure(S);
+  b.ctl.ensure(1);
+  b.jobctx.ensure(1);
+  COOK_HIP(hipMemsetAsync(b.hres_key.ptr(), 0, (size_t)std::max(1u, H) * 8, e->stream));
+  RebalCtl c0;
+  std::memset(&c0, 0, sizeof(c0));
+  c0.remaining = b.rp.max_preemption;
+  std::memcpy(e->h_scratch, &c0, sizeof(c0));
+  COOK_HIP(hipMemcpyAsync(b.ctl.ptr(), e->h_scratch, sizeof(c0), hipMemcpyHostToDevice, e->stream));
+  std::vector<double> nanv(P, std::numeric_limits<double>::quiet_NaN());
+  COOK_HIP(hipMemcpyAsync(b.pending_dru.ptr(), nanv.data(), (size_t)P * 8, hipMemcpyHostToDevice, e->stream));
+  sync(e);  // nanv / h_scratch are reused below
+  rebalance_rescore(e, b);
+  // ---- the decision loop (rebalancer.clj:442-458) ---------------------------------------------------------------------------------
+  const RebalIn in = rebalance_args(e, b);
+  const unsigned gH = div_up(std::max(1u, H), RB_WAVES);
+  for (unsigned pj = 0; pj < P; ++pj) {
+    KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, pj);
+    if (H) KL("rebal_decide", rebal_decide, gH, COOK_WAVE * RB_WAVES, in);
+    KL("rebal_apply", rebal_apply, 1, 256, in);
+    rebalance_rescore(e, b);
+    if ((pj + 1) % RB_CHECK == 0 && pj + 1 < P) {
+      COOK_HIP(hipMemcpyAsync(e->h_scratch, b.ctl.ptr(), sizeof(RebalCtl), hipMemcpyDeviceToHost, e->stream));
+      sync(e);
+      RebalCtl c;
+      std::memcpy(&c, e->h_scratch, sizeof(c));
+      if (c.remaining <= 0) break;
+    }
+  }
+  COOK_HIP(hipMemcpyAsync(e->h_scratch, b.ctl.ptr(), sizeof(RebalCtl), hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+  std::memcpy(&b.last, e->h_scratch, sizeof(RebalCtl));
+  b.done = true;
+}
+
+void rebalance_fetch(cook_engine* e, RebalBufs& b, cook_preemption* decisions, uint32_t* n_decisions, uint32_t* preempted,
+                     uint32_t* n_preempted, double* pending_dru) {
+  if (!b.done) e->fail(COOK_E_STATE, "cook_rebalance_fetch before cook_rebalance_run");
+  if (n_decisions) *n_decisions = b.last.nd;
+  if (n_preempted) *n_preempted = b.last.np;
+  if (decisions && b.last.nd)
+    COOK_HIP(hipMemcpyAsync(decisions, b.decisions.ptr(), (size_t)b.last.nd * sizeof(cook_preemption), hipMemcpyDeviceToHost, e->stream));
+  if (preempted && b.last.np)
+    COOK_HIP(hipMemcpyAsync(preempted, b.preempted.ptr(), (size_t)b.last.np * 4, hipMemcpyDeviceToHost, e->stream));
+  if (pending_dru && b.P)
+    COOK_HIP(hipMemcpyAsync(pending_dru, b.pending_dru.ptr(), (size_t)b.P * 8, hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+}

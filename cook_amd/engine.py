@@ -22,7 +22,8 @@ EXPORTS = [
     "cook_rank", "cook_rank_stage", "cook_rank_set_quota", "cook_rank_pool_usage", "cook_rank_run", "cook_rank_fetch",
     "cook_match", "cook_match_stage", "cook_match_run", "cook_match_fetch",
     "cook_cycle_stage", "cook_cycle_run", "cook_cycle_fetch",
-    "cook_rebalance", "cook_last_timing", "cook_kernel_timings", "cook_set_profiling", "cook_match_stats",
+    "cook_rebalance", "cook_rebalance_stage", "cook_rebalance_run", "cook_rebalance_fetch", "cook_rebalance_timing",
+    "cook_last_timing", "cook_kernel_timings", "cook_set_profiling", "cook_match_stats",
 ]
 
 
@@ -190,6 +191,53 @@ class Engine:
         self._chk(self._lib.cook_cycle_fetch(self._h, _p(ranked, C.c_uint32), C.byref(n), _p(j2o, C.c_int32),
                                              C.byref(k), C.byref(head)))
         return ranked[: n.value].copy(), j2o[: k.value].copy(), bool(head.value)
+
+    # ---- rebalancer ------------------------------------------------------------------------------------------
+    def rebalance_stage(self, running: A.Tasks, pending: A.Jobs, pending_job_id, pending_priority, users: A.Users,
+                        spare: A.HostSpare, rparams: A.CookRebalanceParams, host_attrs: Optional[A.Offers] = None,
+                        groups: Optional[A.Groups] = None, attrs_cached=None):
+        rs, ps, us, ss = running.as_struct(), pending.as_struct(), users.as_struct(), spare.as_struct()
+        hs = host_attrs.as_struct() if host_attrs is not None else None
+        gs = groups.as_struct() if groups is not None else None
+        jid = np.ascontiguousarray(pending_job_id, dtype=np.int64)
+        pri = np.ascontiguousarray(pending_priority, dtype=np.int32)
+        ck = np.ascontiguousarray(attrs_cached, dtype=np.uint8) if attrs_cached is not None else None
+        self._rb_p, self._rb_r = pending.n, running.n
+        self._chk(self._lib.cook_rebalance_stage(
+            self._h, C.byref(rs), _p(ck, C.c_uint8) if ck is not None else None, C.byref(ps), _p(jid, C.c_int64),
+            _p(pri, C.c_int32), C.byref(us), C.byref(ss), C.byref(hs) if hs is not None else None,
+            C.byref(gs) if gs is not None else None, C.byref(rparams)))
+
+    def rebalance_run(self):
+        self._chk(self._lib.cook_rebalance_run(self._h))
+
+    def rebalance_fetch(self):
+        P, R = self._rb_p, self._rb_r
+        dec = (A.CookPreemption * max(1, P))()
+        pre = np.zeros(max(1, R + P), dtype=np.uint32)
+        pdru = np.zeros(max(1, P), dtype=np.float64)
+        nd, npre = C.c_uint32(0), C.c_uint32(0)
+        self._chk(self._lib.cook_rebalance_fetch(self._h, dec, C.byref(nd), _p(pre, C.c_uint32), C.byref(npre),
+                                                 _p(pdru, C.c_double)))
+        out = []
+        for i in range(nd.value):
+            d = dec[i]
+            out.append(dict(pending_index=d.pending_index, host=d.host, dru=d.dru, cpus=d.cpus, mem=d.mem, gpus=d.gpus,
+                            tasks=[int(x) for x in pre[d.task_off: d.task_off + d.task_n]]))
+        return dict(decisions=out, pending_dru=pdru[:P].copy(), final=None)
+
+    def rebalance(self, running, pending, pending_job_id, pending_priority, users, spare, rparams, host_attrs=None,
+                  groups=None, attrs_cached=None):
+        """init-state + the rebalance loop (rebalancer.clj:222-467) -> dict(decisions=[...], pending_dru=array)."""
+        self.rebalance_stage(running, pending, pending_job_id, pending_priority, users, spare, rparams, host_attrs,
+                             groups, attrs_cached)
+        self.rebalance_run()
+        return self.rebalance_fetch()
+
+    def rebalance_timing(self) -> float:
+        ms = C.c_double(0)
+        self._lib.cook_rebalance_timing(self._h, C.byref(ms))
+        return ms.value
 
     # ---- measurement -----------------------------------------------------------------------------------------
     def last_timing(self):

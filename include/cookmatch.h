@@ -226,13 +226,33 @@ int cook_cycle_fetch(cook_engine* e, uint32_t* ranked_pending_idx, uint32_t* n_r
                      uint32_t* n_considered, uint8_t* head_matched);
 
 /* ---- REBALANCE: replaces init-state + the rebalance loop's decisions ---------------------------------------
- * (rebalancer.clj:222-266, 320-407, 270-309, 434-467; dru.clj:128-144).  running: tasks with host ids;
- * pending: the first max-preemption allowed-to-start pending jobs in rank order (rebalancer.clj:588-590).
- * decisions capacity = pending->n; preempted capacity = running->n (task indices into `running`). */
-int cook_rebalance(cook_engine* e, const cook_tasks* running, const cook_jobs* pending, const int64_t* pending_job_id,
-                   const int32_t* pending_priority, const cook_users* users, const cook_host_spare* spare,
+ * (rebalancer.clj:222-266, 320-407, 270-309, 434-467; dru.clj:128-144).
+ * running: the pool's running tasks with host ids.  running_attrs_cached (optional, len running->n): 0 = the instance's
+ * slave id has no entry in the agent-attributes-cache (its host then resolves to a nil attribute map when that task is
+ * the last scored task of the host, rebalancer.clj:369-375); NULL = all cached.
+ * pending: the allowed-to-start pending jobs in rank order (rebalancer.clj:588-590); the loop stops after
+ * params->max_preemption decisions.  pending->reserved_host is ignored (the rebalancer evaluates
+ * job-constraint-constructors only, constraints.clj:459-466).
+ * host_attrs (optional): the agent-attributes-cache as a cook_offers table, one row per cached host (host[i] = host id;
+ * cpus/mem and the run_* / *_tasks columns are ignored).  groups (optional): pending->group[p] indexes it; run_host =
+ * hosts of the group's running cotasks (run_attr is ignored: attributes come from host_attrs).
+ * decisions capacity = pending->n; preempted capacity = running->n + pending->n (task indices into `running`;
+ * COOK_NONE_U32 = a job placed earlier in this call, which the caller skips, rebalancer.clj:529).
+ * pending_dru (optional, len pending->n): the pending-job DRU of every job examined (rebalancer.clj:157-208), NaN otherwise. */
+int cook_rebalance(cook_engine* e, const cook_tasks* running, const uint8_t* running_attrs_cached, const cook_jobs* pending,
+                   const int64_t* pending_job_id, const int32_t* pending_priority, const cook_users* users,
+                   const cook_host_spare* spare, const cook_offers* host_attrs, const cook_groups* groups,
                    const cook_rebalance_params* params, cook_preemption* decisions, uint32_t* n_decisions,
-                   uint32_t* preempted, uint32_t* n_preempted);
+                   uint32_t* preempted, uint32_t* n_preempted, double* pending_dru);
+int cook_rebalance_stage(cook_engine* e, const cook_tasks* running, const uint8_t* running_attrs_cached,
+                         const cook_jobs* pending, const int64_t* pending_job_id, const int32_t* pending_priority,
+                         const cook_users* users, const cook_host_spare* spare, const cook_offers* host_attrs,
+                         const cook_groups* groups, const cook_rebalance_params* params);
+int cook_rebalance_run(cook_engine* e);
+int cook_rebalance_fetch(cook_engine* e, cook_preemption* decisions, uint32_t* n_decisions, uint32_t* preempted,
+                         uint32_t* n_preempted, double* pending_dru);
+/* HIP-event time of the last cook_rebalance_run in milliseconds */
+int cook_rebalance_timing(cook_engine* e, double* ms);
 
 /* ---- measurement hooks (bench.py): HIP-event time of the last *_run, per stage, in milliseconds ----------- */
 int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms);

@@ -106,3 +106,119 @@ def pinned_jobs_case(seed, n_jobs, n_offers, cardinality):
     jobs = A.Jobs.with_constraints(rng.integers(1, 4, n_jobs).astype(float), rng.integers(1, 4, n_jobs) * 1024.0,
                                    equals=equals, novel=[[] for _ in range(n_jobs)])
     return jobs, offers
+
+
+# ---- rebalancer ------------------------------------------------------------------------------------------------------
+def _rebal_equal(got, want, tag):
+    assert len(got["decisions"]) == len(want["decisions"]), (tag, len(got["decisions"]), len(want["decisions"]))
+    for i, (d, o) in enumerate(zip(got["decisions"], want["decisions"])):
+        assert d == o, (tag, i, d, o)  # host, dru, resources (fp64 ==), preempted task lists: all exact
+    assert np.array_equal(got["pending_dru"], want["pending_dru"], equal_nan=True), tag
+
+
+def check_rebalance_golden(make_engine):
+    """The reference's own rebalancer vectors (tests/golden/rebalance.json) through the C ABI.  Cases that drive the oracle's
+    test hooks (a forced decision, a State that already holds preempted tasks) have no ABI equivalent and are skipped."""
+    from tests.test_oracle_golden import check_rebalance_case
+    n = 0
+    for case in G.load("rebalance"):
+        if "forced" in case or case.get("init_preempted_hosts"):
+            continue
+        b = G.build_rebalance_inputs(case)
+        with make_engine(b["params"]) as e:
+            res = e.rebalance(b["running"], b["pending"], b["pending_job_id"], b["pending_priority"], b["users"], b["spare"],
+                              b["rparams"], host_attrs=b["host_attrs"], groups=b["groups"], attrs_cached=b["slave_known"])
+        check_rebalance_case(case, res, b)
+        want = pyoracle.rebalance(b["params"], b["running"], b["pending"], b["pending_job_id"], b["pending_priority"], b["users"],
+                                  b["spare"], b["rparams"], host_attrs=b["host_attrs"], groups=b["groups"],
+                                  slave_known=b["slave_known"])
+        _rebal_equal(res, want, case["name"])
+        n += 1
+    assert n >= 25
+
+
+def make_rebalance_case(seed, n_running, n_pending, n_users, n_hosts, *, fractional=False, constraints=False, gpus=False,
+                        spare_frac=0.3, quota_frac=0.1, max_preemption=64, min_dru_diff=0.05, safe_dru=0.0, dru_mode=0):
+    """Random pool for cook_rebalance in the shape of the reference's stress generator (test/cook/test/rebalancer.clj:1152-1187)
+    and BASELINE.json C5: running tasks spread over hosts, pending jobs of the same users, some spare capacity."""
+    rng = np.random.default_rng(seed)
+    R, P = n_running, n_pending
+    n = R + P
+    cpus = np.clip(np.rint(rng.normal(3.0, 1.0, n)), 1, 8)
+    mem = np.clip(np.rint(rng.normal(10240.0, 4096.0, n)), 512, 65536)
+    if fractional:
+        cpus = cpus + rng.integers(0, 10, n) / 10.0
+        mem = mem + rng.integers(0, 10, n) / 10.0
+    g = np.zeros(n)
+    gmodel = np.zeros(n, dtype=np.uint32)
+    if gpus:
+        has = rng.random(n) < 0.15
+        g[has] = rng.choice([1.0, 2.0, 4.0], size=int(has.sum()))
+        gmodel[has] = rng.choice([1, 2], size=int(has.sum()))
+    if dru_mode == 1:  # gpu pools: every running task holds gpus; the pending jobs keep theirs (0 without `gpus`)
+        g[:R] = np.maximum(g[:R], 1.0)
+    p = 1.0 / np.arange(1, n_users + 1) ** 1.1
+    user = rng.permutation(n_users)[rng.choice(n_users, size=n, p=p / p.sum())].astype(np.uint32)
+    prio = rng.integers(0, 101, n).astype(np.int32)
+    base = 17_592_186_044_416
+    running = A.Tasks(cpus=cpus[:R], mem=mem[:R], gpus=g[:R], user=user[:R], priority=prio[:R],
+                      start_ms=(1_600_000_000_000 + rng.integers(0, 86_400_000, R)).astype(np.int64),
+                      task_id=(base + 2_000_000_000 + rng.permutation(R)).astype(np.int64),
+                      job_id=(base + rng.permutation(R)).astype(np.int64), pending=np.zeros(R, dtype=np.uint8),
+                      host=rng.integers(0, n_hosts, R).astype(np.uint32))
+    div_c, div_m, div_g = np.full(n_users, 64.0), np.full(n_users, 262144.0), np.full(n_users, 8.0)
+    big = rng.random(n_users) < 0.1
+    div_c[big] *= 4
+    div_m[big] *= 4
+    qcount = np.full(n_users, 2.0 ** 31 - 1)
+    qcount[rng.random(n_users) < quota_frac] = float(max(2, R // max(1, n_users)))
+    users = A.Users(div_cpus=div_c, div_mem=div_m, div_gpus=div_g, quota_count=qcount)
+    kw = {}
+    host_attrs, groups = None, None
+    if constraints:
+        n_keys = 4
+        card = [2, 3, 8, 0]
+        attr = np.zeros((n_hosts, n_keys), dtype=np.uint32)
+        for k, c in enumerate(card):
+            attr[:, k] = (np.arange(n_hosts) + 1) if c == 0 else rng.integers(0, c + 1, n_hosts)  # 0 = absent on some hosts
+        cached = rng.random(n_hosts) < 0.9  # some hosts are not in the agent-attributes-cache
+        rows = np.nonzero(cached)[0]
+        o_gm = np.zeros(n_hosts, dtype=np.uint32)
+        o_gc = np.zeros(n_hosts)
+        if gpus:
+            gh = rng.random(n_hosts) < 0.3
+            o_gm[gh] = rng.choice([1, 2], size=int(gh.sum()))
+            o_gc[gh] = rng.choice([1.0, 2.0, 4.0], size=int(gh.sum()))
+        host_attrs = A.Offers(cpus=np.zeros(len(rows)), mem=np.zeros(len(rows)), host=rows.astype(np.uint32),
+                              k8s=(rng.random(len(rows)) < 0.8).astype(np.uint8), gpu_model=o_gm[rows], gpu_count=o_gc[rows],
+                              attr=attr[rows])
+        equals = [[(int(rng.integers(0, 3)), int(rng.integers(1, 4)))] if rng.random() < 0.2 else [] for _ in range(P)]
+        novel = [[int(h) for h in rng.integers(0, n_hosts, 2)] if rng.random() < 0.1 else [] for _ in range(P)]
+        grp = np.full(P, A.NONE_U32, dtype=np.uint32)
+        n_g = 6
+        in_g = rng.random(P) < 0.3
+        grp[in_g] = rng.integers(0, n_g, int(in_g.sum()))
+        groups = A.Groups(type=np.array([1, 2, 2, 3, 3, 0], dtype=np.uint8),
+                          attr_key=np.array([A.NONE_U32, 0, 2, 1, 0, 0], dtype=np.uint32),
+                          minimum=np.array([0, 2, 10, 0, 0, 0], dtype=np.int32),
+                          run_hosts=[[int(h) for h in rng.integers(0, n_hosts, int(rng.integers(0, 4)))] for _ in range(n_g)])
+        kw.update(equals=equals, novel=novel, group=grp)
+    jobs = A.Jobs.with_constraints(cpus[R:], mem[R:], gpus=g[R:], gpu_model=gmodel[R:], user=user[R:], **kw)
+    sh = np.nonzero(rng.random(n_hosts) < spare_frac)[0].astype(np.uint32)
+    spare = A.HostSpare(host=sh, cpus=rng.integers(0, 6, len(sh)).astype(np.float64) + (0.5 if fractional else 0.0),
+                        mem=rng.integers(0, 16, len(sh)) * 1024.0, gpus=rng.integers(0, 3, len(sh)).astype(np.float64))
+    rp = A.CookRebalanceParams(safe_dru, min_dru_diff, max_preemption, 0)
+    return dict(params=A.default_params(dru_mode=dru_mode), running=running, pending=jobs,
+                pending_job_id=(base + 10_000_000 + rng.permutation(P)).astype(np.int64), pending_priority=prio[R:], users=users,
+                spare=spare, rparams=rp, host_attrs=host_attrs, groups=groups)
+
+
+def rebalance_parity(make_engine, b, min_decisions=0):
+    with make_engine(b["params"]) as e:
+        got = e.rebalance(b["running"], b["pending"], b["pending_job_id"], b["pending_priority"], b["users"], b["spare"],
+                          b["rparams"], host_attrs=b["host_attrs"], groups=b["groups"])
+    want = pyoracle.rebalance(b["params"], b["running"], b["pending"], b["pending_job_id"], b["pending_priority"], b["users"],
+                              b["spare"], b["rparams"], host_attrs=b["host_attrs"], groups=b["groups"])
+    _rebal_equal(got, want, "random")
+    assert len(got["decisions"]) >= min_decisions, len(got["decisions"])
+    return got

@@ -135,3 +135,19 @@ def test_match_slot_table_and_touched_set_limits(make_engine):
 def test_cycle_parity(make_engine):
     pool = synth.make_pool(seed=31, n_pending=600, n_running=200, n_users=30, n_offers=100, gpus=True, constraints=True)
     P.cycle_parity(make_engine, pool, A.default_params(good_enough_fitness=1.0), k=150)
+
+
+def test_rebalance_golden(make_engine):
+    P.check_rebalance_golden(make_engine)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(seed=51, n_running=400, n_pending=24, n_users=12, n_hosts=30),
+    dict(seed=52, n_running=400, n_pending=24, n_users=12, n_hosts=30, fractional=True),           # exact fix-up paths
+    dict(seed=53, n_running=600, n_pending=30, n_users=20, n_hosts=3, max_preemption=12),          # hosts beyond the LDS cap
+    dict(seed=54, n_running=500, n_pending=40, n_users=15, n_hosts=40, constraints=True, gpus=True),
+    dict(seed=55, n_running=300, n_pending=20, n_users=8, n_hosts=25, dru_mode=1),
+    dict(seed=56, n_running=0, n_pending=10, n_users=3, n_hosts=8, spare_frac=1.0),                # spare resources only
+], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_rebalance_parity_random(make_engine, kw):
+    P.rebalance_parity(make_engine, P.make_rebalance_case(**kw))

@@ -165,3 +165,20 @@ def test_size_independent_properties_full_pool(make_engine):
         e.cycle_run(2000)
         ranked2, j2o2, _ = e.cycle_fetch()
     assert np.array_equal(ranked, ranked2) and np.array_equal(j2o, j2o2)
+
+
+def test_rebalance_golden(make_engine):
+    P.check_rebalance_golden(make_engine)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(seed=51, n_running=4000, n_pending=64, n_users=40, n_hosts=300),
+    dict(seed=52, n_running=4000, n_pending=64, n_users=40, n_hosts=300, fractional=True),
+    dict(seed=53, n_running=10240, n_pending=128, n_users=50, n_hosts=16, max_preemption=48),    # reference stress shape (:1152-1187)
+    dict(seed=54, n_running=5000, n_pending=128, n_users=60, n_hosts=400, constraints=True, gpus=True, max_preemption=128),
+    dict(seed=55, n_running=3000, n_pending=40, n_users=20, n_hosts=250, dru_mode=1),
+    dict(seed=56, n_running=0, n_pending=10, n_users=3, n_hosts=8, spare_frac=1.0),
+    dict(seed=57, n_running=60000, n_pending=32, n_users=500, n_hosts=3000, max_preemption=32),  # multi-block scans / sorts
+], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_rebalance_parity_random(make_engine, kw):
+    P.rebalance_parity(make_engine, P.make_rebalance_case(**kw))
