@@ -30,8 +30,8 @@ struct RebalBufs {
   DArr<uint32_t> hpermA, hpermB, hstart, hend;
   uint32_t* hperm = nullptr;
   DArr<int32_t> row_of_host;
-  DArr<double> spare_c, spare_m, spare_g;
-  DArr<uint8_t> has_spare;
+  DArr<double> spare_c, spare_m, spare_g, spare0_c, spare0_m, spare0_g;  // spare0_*: as staged (a run updates spare_*)
+  DArr<uint8_t> has_spare, has_spare0;
   // attribute table
   DArr<uint32_t> a_host, a_gpu_model, a_disk_type, a_attr, a_location;
   DArr<uint8_t> a_k8s;
@@ -141,10 +141,11 @@ void rebalance_stage(cook_engine* e, RebalBufs& b, const cook_tasks* run, const 
       hs[h] = 1;
     }
   h2d(e, b.row_of_host, row.data(), H);
-  h2d(e, b.spare_c, sc.data(), H);
-  h2d(e, b.spare_m, sm.data(), H);
-  h2d(e, b.spare_g, sg.data(), H);
-  h2d(e, b.has_spare, hs.data(), H);
+  h2d(e, b.spare0_c, sc.data(), H);
+  h2d(e, b.spare0_m, sm.data(), H);
+  h2d(e, b.spare0_g, sg.data(), H);
+  h2d(e, b.has_spare0, hs.data(), H);
+  b.spare_c.ensure(H), b.spare_m.ensure(H), b.spare_g.ensure(H), b.has_spare.ensure(H);
   // ---- attribute table ----------------------------------------------------------------------------------------------------------
   b.has_attrs = attrs != nullptr && attrs->n > 0;
   b.ha_k8s = b.ha_gpu = b.ha_disk = b.ha_attr = b.ha_loc = b.ha_start = false;
@@ -402,6 +403,12 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   b.ctl.ensure(1);
   b.jobctx.ensure(1);
   COOK_HIP(hipMemsetAsync(b.hres_key.ptr(), 0, (size_t)std::max(1u, H) * 8, e->stream));
+  if (H) {  // host->spare-resources as staged: a run is repeatable on the same staged inputs
+    COOK_HIP(hipMemcpyAsync(b.spare_c.ptr(), b.spare0_c.ptr(), (size_t)H * 8, hipMemcpyDeviceToDevice, e->stream));
+    COOK_HIP(hipMemcpyAsync(b.spare_m.ptr(), b.spare0_m.ptr(), (size_t)H * 8, hipMemcpyDeviceToDevice, e->stream));
+    COOK_HIP(hipMemcpyAsync(b.spare_g.ptr(), b.spare0_g.ptr(), (size_t)H * 8, hipMemcpyDeviceToDevice, e->stream));
+    COOK_HIP(hipMemcpyAsync(b.has_spare.ptr(), b.has_spare0.ptr(), (size_t)H, hipMemcpyDeviceToDevice, e->stream));
+  }
   RebalCtl c0;
   std::memset(&c0, 0, sizeof(c0));
   c0.remaining = b.rp.max_preemption;

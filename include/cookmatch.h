@@ -100,6 +100,38 @@ typedef struct cook_pool_quota {
   cook_usage pool_usage;
 } cook_pool_quota;
 
+/* ---- the ranked queue and the per-user state of pending-jobs->considerable-jobs (scheduler.clj:729-762) --- */
+typedef struct cook_queue { /* the pool's pending jobs in rank order (the output of cook_rank) */
+  uint32_t n;
+  const double* cpus;
+  const double* mem;
+  const double* gpus;      /* may be NULL */
+  const uint32_t* user;
+  const uint8_t* eligible; /* job-allowed-to-start? (scheduler.clj:747) AND the launch-plugin filter (:748), both
+                              evaluated by the host; NULL = all eligible */
+} cook_queue;
+
+typedef struct cook_user_state {
+  uint32_t n;                 /* users */
+  const double* quota_count;  /* user->quota (quota.clj:272-295) */
+  const double* quota_cpus;
+  const double* quota_mem;
+  const double* quota_gpus;
+  const double* usage_count;  /* user->usage of the pool's running jobs (scheduler.clj:715-727); 0 for users without any */
+  const double* usage_cpus;
+  const double* usage_mem;
+  const double* usage_gpus;
+  const int64_t* tokens_left; /* ratelimit/get-token-count! of the per-user-per-pool launch rate limiter
+                                 (tools.clj:943-945); NULL = no limiter (every job counts as passed) */
+  int32_t enforce_rate_limit; /* ratelimit/enforce? (tools.clj:936) */
+  int32_t has_pool_quota;     /* 0: (tools/global-pool-quota pool) is nil -> no pool filtering (tools.clj:925) */
+  cook_usage pool_quota;
+  int32_t pool_usage_given;   /* 0: the engine sums the users' usage itself in user-id order (tools.clj:966; the
+                                 reference sums in hash-map order, which only matters for non-integer usages) */
+  int32_t reserved;
+  cook_usage pool_usage;
+} cook_user_state;
+
 /* ---- considerable jobs, in rank order (scheduler.clj:729-762, 456-509) ---------------------------------- */
 typedef struct cook_jobs {
   uint32_t n;
@@ -200,6 +232,20 @@ int cook_rank_set_quota(cook_engine* e, const cook_pool_quota* quota);
 int cook_rank_pool_usage(cook_engine* e, cook_usage* out);
 int cook_rank_run(cook_engine* e);
 int cook_rank_fetch(cook_engine* e, uint32_t* ranked_pending_idx, uint32_t* n_out, double* dru_of_task);
+
+/* ---- CONSIDERABLE: replaces pending-jobs->considerable-jobs + tools/filter-pending-jobs-for-quota ----------
+ * (scheduler.clj:729-762; tools.clj:654-668, 903-973).  In queue order: per-user quota filter seeded with the user's
+ * running usage (state advances on rejected jobs too), launch-rate-limit filter (the n-th surviving job of a user is
+ * limited iff n > tokens_left; dropped only when enforcing), pool quota filter seeded with the pool usage, eligible
+ * mask, take num_considerable.  considerable_idx receives queue positions (capacity min(num_considerable, queue->n)).
+ * rate_limited / passed (optional, len users): per-user counts of the rate-limit stage over the WHOLE queue (the
+ * reference's lazy pipeline only counts the jobs it consumed before `take` was satisfied: unpinned). */
+int cook_considerable(cook_engine* e, const cook_queue* queue, const cook_user_state* users, uint32_t num_considerable,
+                      uint32_t* considerable_idx, uint32_t* n_out, uint32_t* rate_limited, uint32_t* passed);
+/* Same filters inside cook_cycle_run, between rank and match, with no host round trip: `users` as above (copied to the
+ * device now); eligible_by_pending (optional) is indexed by pending ordinal like cook_cycle_stage's pending_jobs, whose
+ * `user` array must be present.  NULL users = plain (take num-considerable) again. */
+int cook_cycle_set_considerable(cook_engine* e, const cook_user_state* users, const uint8_t* eligible_by_pending);
 
 /* ---- MATCH: replaces the body of match-offer-to-schedule, i.e. TaskScheduler.scheduleOnce -----------------
  * (scheduler.clj:617-687; Fenzo 0.10.0 pinned at project.clj:46-50; constraints.clj).

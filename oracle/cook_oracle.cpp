@@ -468,6 +468,65 @@ int oracle_rank_merged(const cook_params* p, const cook_tasks* t, const cook_use
   return 0;
 }
 
+// scheduler.clj:729-762 pending-jobs->considerable-jobs; tools.clj:903-973 filter-pending-jobs-for-quota;
+// tools.clj:654-668 filter-sequential (the state advances on rejected elements too).
+// The reference pipeline is lazy: stages run interleaved and stop once `take` is satisfied.  The surviving jobs are the
+// same either way; the per-user rate-limit counters are computed here over the WHOLE queue (UNPINNED: the lazy original
+// counts only the jobs it consumed).
+int oracle_considerable(const cook_queue* q, const cook_user_state* us, uint32_t num_considerable, uint32_t* out_idx,
+                        uint32_t* n_out, uint32_t* rate_limited, uint32_t* passed) {
+  const uint32_t n = q->n, U = us->n;
+  std::vector<cook_usage> usage(U);
+  for (uint32_t u = 0; u < U; ++u) usage[u] = cook_usage{us->usage_count[u], us->usage_cpus[u], us->usage_mem[u], us->usage_gpus[u]};
+  // tools.clj:966: pool-usage = (reduce (partial merge-with +) (vals user->usage)); map order is UNPINNED -> user-id order
+  cook_usage pool = us->pool_usage;
+  if (!us->pool_usage_given) {
+    pool = cook_usage{0, 0, 0, 0};
+    for (uint32_t u = 0; u < U; ++u) {
+      if (u == 0) {
+        pool = usage[0];
+      } else {
+        pool.count += usage[u].count;
+        pool.cpus += usage[u].cpus;
+        pool.mem += usage[u].mem;
+        pool.gpus += usage[u].gpus;
+      }
+    }
+  }
+  std::vector<uint32_t> seen(U, 0);
+  if (rate_limited) std::fill(rate_limited, rate_limited + U, 0u);
+  if (passed) std::fill(passed, passed + U, 0u);
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t u = q->user[i];
+    const cook_usage ju{1.0, q->cpus[i], q->mem[i], q->gpus ? q->gpus[i] : 0.0};
+    // tools.clj:903-915 filter-based-on-user-quota: usage' = (merge-with + job-usage usage[user])
+    cook_usage& uu = usage[u];
+    uu = cook_usage{ju.count + uu.count, ju.cpus + uu.cpus, ju.mem + uu.mem, ju.gpus + uu.gpus};
+    const cook_usage quota{us->quota_count[u], us->quota_cpus[u], us->quota_mem[u], us->quota_gpus[u]};
+    if (!below_quota(quota, uu)) continue;
+    // tools.clj:935-955 filter-pending-jobs-for-ratelimit
+    const uint32_t so_far = ++seen[u];
+    const bool limited = us->tokens_left ? ((int64_t)so_far > us->tokens_left[u]) : false;
+    if (limited) {
+      if (rate_limited) rate_limited[u]++;
+    } else if (passed) {
+      passed[u]++;
+    }
+    if (limited && us->enforce_rate_limit) continue;
+    // tools.clj:917-933 filter-based-on-pool-quota
+    if (us->has_pool_quota) {
+      pool = cook_usage{ju.count + pool.count, ju.cpus + pool.cpus, ju.mem + pool.mem, ju.gpus + pool.gpus};
+      if (!below_quota(us->pool_quota, pool)) continue;
+    }
+    // scheduler.clj:747-749: job-allowed-to-start?, launch plugin, take
+    if (q->eligible && !q->eligible[i]) continue;
+    if (k < num_considerable) out_idx[k++] = i;
+  }
+  *n_out = k;
+  return 0;
+}
+
 int oracle_pool_usage(const cook_tasks* t, cook_usage* out) {
   *out = running_usage(t);
   return 0;

@@ -25,3 +25,7 @@ if [ "${SKIP_PROF:-0}" != 1 ]; then
   find /tmp/prof -name '*stats*' -exec cp {} "$OUT/" \;
   ls -la /tmp/prof/* | head; ls -la "$OUT"
 fi
+if [ "${SKIP_REBAL:-0}" != 1 ]; then
+  timeout ${REBAL_TIMEOUT:-400} python scripts/bench_rebalance.py ${REBAL_ARGS:---check} > "$OUT/bench_rebalance.json" 2> "$OUT/bench_rebalance.err"
+  echo "rebalance bench exit $?"; tail -c 2000 "$OUT/bench_rebalance.json"; tail -5 "$OUT/bench_rebalance.err"
+fi

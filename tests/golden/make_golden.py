@@ -408,8 +408,71 @@ REBALANCE = [
 T_CON = "test/cook/test/scheduler/constraints.clj"
 
 
+# ---- considerable jobs (scheduler.clj:729-762; tools.clj:903-973) -------------------------------------------------------
+T_TOOLS = "test/cook/test/tools.clj"
+
+
+def qj(name, user, cpus, mem, gpus=0.0, eligible=True):
+    return dict(name=name, user=user, cpus=cpus, mem=mem, gpus=gpus, eligible=eligible)
+
+
+_Q4 = [qj("job-1", "john", 2, 2048), qj("job-2", "john", 1, 1024), qj("job-3", "john", 3, 4096), qj("job-4", "john", 1, 1024)]
+_USE = {"john": dict(count=1, cpus=2, mem=1024)}
+_NG = [qj("job-1", "u", 3, 2048), qj("job-2", "u", 13, 1024), qj("job-3", "u", 7, 4096), qj("job-4", "u", 11, 1024)]
+_GJ = [qj("job-5", "u", 5, 2048, gpus=2), qj("job-6", "u", 19, 1024, gpus=4)]
+_UU = {"u": dict(count=1, cpus=2, mem=1024, gpus=0)}
+_UQ = {"u": dict(count=10, cpus=50, mem=32768, gpus=10)}
+
+
+def _cons(name, line, queue, quota, expect, k=5, usage=None, **kw):
+    return dict(name=name, ref=f"{T_SCHED}:{line}", queue=queue, user_usage=usage or _UU, user_quota=quota, num_considerable=k,
+                expect=expect, **kw)
+
+
+CONSIDERABLE = [
+    # tools.clj tests: the pool filter alone (no user quota), the user filter alone, and both (user filter first)
+    dict(name="filter-based-on-pool-quota: no jobs included", ref=f"{T_TOOLS}:763-772", queue=_Q4, user_usage={}, user_quota={},
+         pool_quota=dict(count=1, cpus=2, mem=1024), pool_usage=dict(count=1, cpus=2, mem=1024), num_considerable=100, expect=[]),
+    dict(name="filter-based-on-pool-quota: all jobs included", ref=f"{T_TOOLS}:773-775", queue=_Q4, user_usage={}, user_quota={},
+         pool_quota=dict(count=10, cpus=20, mem=32768), pool_usage=dict(count=1, cpus=2, mem=1024), num_considerable=100,
+         expect=["job-1", "job-2", "job-3", "job-4"]),
+    dict(name="filter-based-on-pool-quota: room for later jobs not included", ref=f"{T_TOOLS}:776-778", queue=_Q4, user_usage={},
+         user_quota={}, pool_quota=dict(count=4, cpus=20, mem=6144), pool_usage=dict(count=1, cpus=2, mem=1024),
+         num_considerable=100, expect=["job-1", "job-2"]),
+    dict(name="filter-based-on-user-quota: no jobs included", ref=f"{T_TOOLS}:780-791", queue=_Q4, user_usage=_USE,
+         user_quota={"john": dict(count=1, cpus=2, mem=1024)}, num_considerable=100, expect=[]),
+    dict(name="filter-based-on-user-quota: all jobs included", ref=f"{T_TOOLS}:792-794", queue=_Q4, user_usage=_USE,
+         user_quota={"john": dict(count=10, cpus=20, mem=32768)}, num_considerable=100, expect=["job-1", "job-2", "job-3", "job-4"]),
+    dict(name="filter-based-on-user-quota: room for later jobs not included", ref=f"{T_TOOLS}:795-797", queue=_Q4, user_usage=_USE,
+         user_quota={"john": dict(count=4, cpus=20, mem=6144)}, num_considerable=100, expect=["job-1", "job-2"]),
+    dict(name="filter-pending-jobs-for-quota: user quota filters first", ref=f"{T_TOOLS}:799-817",
+         queue=[qj("job-1", "john", 1, 1), qj("job-2", "john", 1, 1), qj("job-3", "john", 1, 1), qj("job-4", "bob", 1, 1)],
+         user_usage={"john": dict(count=1, cpus=1, mem=1), "bob": dict(count=1, cpus=1, mem=1)},
+         user_quota={"john": dict(count=2, cpus=100, mem=100), "bob": dict(count=2, cpus=100, mem=100)},
+         pool_quota=dict(count=4, cpus=100, mem=100), num_considerable=100, expect=["job-1", "job-4"]),
+    # scheduler.clj test-pending-jobs->considerable-jobs
+    _cons("all jobs deferred by the launch plugin", "1586-1598", [dict(j, eligible=False) for j in _NG], _UQ, []),
+    _cons("jobs inside usage quota", "1601-1611", _NG, _UQ, ["job-1", "job-2", "job-3", "job-4"], expect_rate_limited={}),
+    _cons("gpu jobs inside usage quota", "1612-1618", _GJ, _UQ, ["job-5", "job-6"], expect_rate_limited={}),
+    _cons("inside usage quota, beyond rate limit", "1620-1635", _NG, _UQ, ["job-1"], tokens={"u": 1}, enforce=True,
+          expect_rate_limited={"u": 3}),
+    _cons("gpu jobs inside usage quota, beyond rate limit", "1637-1644", _GJ, _UQ, ["job-5"], tokens={"u": 1}, enforce=True,
+          expect_rate_limited={"u": 1}),
+    _cons("num-considerable 3", "1646-1656", _NG, _UQ, ["job-1", "job-2", "job-3"], k=3),
+    _cons("num-considerable 2", "1658-1668", _NG, _UQ, ["job-1", "job-2"], k=2),
+    _cons("num-considerable 2, gpu jobs", "1664-1668", _GJ, _UQ, ["job-5", "job-6"], k=2),
+    _cons("num-considerable 1", "1670-1680", _NG, _UQ, ["job-1"], k=1),
+    _cons("num-considerable 1, gpu jobs", "1676-1680", _GJ, _UQ, ["job-5"], k=1),
+    _cons("some jobs inside usage quota", "1682-1692", _NG, {"u": dict(count=5, cpus=10, mem=4096, gpus=10)}, ["job-1"]),
+    _cons("some gpu jobs inside usage quota", "1688-1692", _GJ, {"u": dict(count=5, cpus=10, mem=4096, gpus=10)}, ["job-5"]),
+    _cons("quota gpus not ignored", "1694-1704", _GJ, {"u": dict(count=5, cpus=10, mem=4096, gpus=0)}, []),
+    _cons("all jobs exceed quota", "1706-1716", _NG, {"u": dict(count=5, cpus=3, mem=4096, gpus=10)}, []),
+    _cons("all gpu jobs exceed quota", "1712-1716", _GJ, {"u": dict(count=5, cpus=3, mem=4096, gpus=10)}, []),
+]
+
+
 def main():
-    out = dict(rank=RANK, rank_group=RANK_GROUP, quota_group_agg=QUOTA_GROUP_AGG, match=MATCH, rebalance=REBALANCE)
+    out = dict(rank=RANK, rank_group=RANK_GROUP, quota_group_agg=QUOTA_GROUP_AGG, match=MATCH, rebalance=REBALANCE, considerable=CONSIDERABLE)
     for k, v in out.items():
         with open(os.path.join(HERE, f"{k}.json"), "w") as f:
             json.dump(v, f, indent=1, sort_keys=True)

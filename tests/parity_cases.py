@@ -215,10 +215,15 @@ def make_rebalance_case(seed, n_running, n_pending, n_users, n_hosts, *, fractio
 
 def rebalance_parity(make_engine, b, min_decisions=0):
     with make_engine(b["params"]) as e:
-        got = e.rebalance(b["running"], b["pending"], b["pending_job_id"], b["pending_priority"], b["users"], b["spare"],
+        e.rebalance_stage(b["running"], b["pending"], b["pending_job_id"], b["pending_priority"], b["users"], b["spare"],
                           b["rparams"], host_attrs=b["host_attrs"], groups=b["groups"])
+        e.rebalance_run()
+        got = e.rebalance_fetch()
+        e.rebalance_run()  # a run must be repeatable on the same staged inputs (it updates spare resources internally)
+        again = e.rebalance_fetch()
     want = pyoracle.rebalance(b["params"], b["running"], b["pending"], b["pending_job_id"], b["pending_priority"], b["users"],
                               b["spare"], b["rparams"], host_attrs=b["host_attrs"], groups=b["groups"])
     _rebal_equal(got, want, "random")
+    _rebal_equal(again, want, "random, second run")
     assert len(got["decisions"]) >= min_decisions, len(got["decisions"])
     return got
