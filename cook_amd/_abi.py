@@ -69,6 +69,20 @@ class CookPoolQuota(C.Structure):
     ]
 
 
+class CookQueue(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("cpus", _f64p), ("mem", _f64p), ("gpus", _f64p), ("user", _u32p), ("eligible", _u8p)]
+
+
+class CookUserState(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("quota_count", _f64p), ("quota_cpus", _f64p), ("quota_mem", _f64p), ("quota_gpus", _f64p),
+        ("usage_count", _f64p), ("usage_cpus", _f64p), ("usage_mem", _f64p), ("usage_gpus", _f64p),
+        ("tokens_left", _i64p), ("enforce_rate_limit", C.c_int32), ("has_pool_quota", C.c_int32),
+        ("pool_quota", CookUsage), ("pool_usage_given", C.c_int32), ("reserved", C.c_int32), ("pool_usage", CookUsage),
+    ]
+
+
 class CookJobs(C.Structure):
     _fields_ = [
         ("n", C.c_uint32),
@@ -216,6 +230,74 @@ class Users:
         return CookUsers(self.n, _ptr(self.div_cpus, _f64p), _ptr(self.div_mem, _f64p), _ptr(self.div_gpus, _f64p),
                          _ptr(self.quota_count, _f64p), _ptr(self.quota_cpus, _f64p), _ptr(self.quota_mem, _f64p),
                          _ptr(self.quota_gpus, _f64p))
+
+
+@dataclass
+class Queue:
+    """The pool's pending jobs in rank order (input of pending-jobs->considerable-jobs, scheduler.clj:729-762)."""
+    cpus: np.ndarray
+    mem: np.ndarray
+    user: np.ndarray
+    gpus: Optional[np.ndarray] = None
+    eligible: Optional[np.ndarray] = None
+
+    def __post_init__(self):
+        n = len(self.cpus)
+        self.cpus = _arr(self.cpus, np.float64, n)
+        self.mem = _arr(self.mem, np.float64, n)
+        self.user = _arr(self.user, np.uint32, n)
+        self.gpus = _arr(self.gpus, np.float64, n)
+        self.eligible = _arr(self.eligible, np.uint8, n)
+
+    @property
+    def n(self):
+        return len(self.cpus)
+
+    def as_struct(self) -> CookQueue:
+        return CookQueue(self.n, _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p), _ptr(self.gpus, _f64p), _ptr(self.user, _u32p),
+                         _ptr(self.eligible, _u8p))
+
+
+@dataclass
+class UserState:
+    """user->quota, user->usage, launch-rate tokens and the pool quota (tools.clj:903-973), indexed by user id."""
+    quota_count: np.ndarray
+    quota_cpus: np.ndarray
+    quota_mem: np.ndarray
+    quota_gpus: np.ndarray
+    usage_count: np.ndarray
+    usage_cpus: np.ndarray
+    usage_mem: np.ndarray
+    usage_gpus: np.ndarray
+    tokens_left: Optional[np.ndarray] = None
+    enforce_rate_limit: bool = False
+    pool_quota: Optional[CookUsage] = None
+    pool_usage: Optional[CookUsage] = None
+
+    def __post_init__(self):
+        n = len(self.quota_count)
+        for f in ("quota_count", "quota_cpus", "quota_mem", "quota_gpus", "usage_count", "usage_cpus", "usage_mem", "usage_gpus"):
+            setattr(self, f, _arr(getattr(self, f), np.float64, n))
+        self.tokens_left = _arr(self.tokens_left, np.int64, n)
+
+    @property
+    def n(self):
+        return len(self.quota_count)
+
+    def as_struct(self) -> CookUserState:
+        s = CookUserState()
+        s.n = self.n
+        for f in ("quota_count", "quota_cpus", "quota_mem", "quota_gpus", "usage_count", "usage_cpus", "usage_mem", "usage_gpus"):
+            setattr(s, f, _ptr(getattr(self, f), _f64p))
+        s.tokens_left = _ptr(self.tokens_left, _i64p)
+        s.enforce_rate_limit = int(bool(self.enforce_rate_limit))
+        s.has_pool_quota = int(self.pool_quota is not None)
+        if self.pool_quota is not None:
+            s.pool_quota = self.pool_quota
+        s.pool_usage_given = int(self.pool_usage is not None)
+        if self.pool_usage is not None:
+            s.pool_usage = self.pool_usage
+        return s
 
 
 def usage(count=0.0, cpus=0.0, mem=0.0, gpus=0.0) -> CookUsage:

@@ -12,6 +12,7 @@
 
 #include "../../include/cookmatch.h"
 #include "common.hpp"
+#include "considerable_kernels.hpp"
 #include "match_kernels.hpp"
 #include "match_v2.hpp"
 #include "rank_kernels.hpp"
@@ -72,6 +73,7 @@ struct KernelStat {
 };
 
 struct RebalBufs;  // rebalance_host.hpp
+struct ConsBufs;   // considerable_host.hpp
 
 }  // namespace
 
@@ -149,6 +151,10 @@ struct cook_engine {
 
   // ---- rebalancer state (allocated on first use) ----
   RebalBufs* rb = nullptr;
+  // ---- considerable-jobs filters (allocated on first use) ----
+  ConsBufs* cb = nullptr;
+  DArr<uint32_t> j_user;
+  bool has_j_user = false;
 
   void fail(int code, const std::string& m) { throw cook_error(code, m); }
 };
@@ -586,6 +592,7 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
   in.j_mem = h2d_opt(e, e->j_mem, j->mem, K);
   in.j_gpus = h2d_opt(e, e->j_gpus, j->gpus, K);
   in.j_gpu_model = h2d_opt(e, e->j_gpu_model, j->gpu_model, K);
+  e->has_j_user = h2d_opt(e, e->j_user, j->user, K) != nullptr;
   in.j_group = h2d_opt(e, e->j_group, j->group, K);
   if (j->eq_off) {
     in.j_eq_off = h2d_opt(e, e->j_eq_off, j->eq_off, K + 1);
@@ -788,7 +795,13 @@ struct StageTimer {
   }
 };
 
+#include "considerable_host.hpp"
 #include "rebalance_host.hpp"
+
+ConsBufs& cons_bufs(cook_engine* e) {
+  if (!e->cb) e->cb = new ConsBufs();
+  return *e->cb;
+}
 
 RebalBufs& rebal_bufs(cook_engine* e) {
   if (!e->rb) e->rb = new RebalBufs();
@@ -887,6 +900,8 @@ void cook_engine_destroy(cook_engine* e) {
   if (e->h_inbuf) (void)hipHostFree(e->h_inbuf);
   delete e->rb;
   e->rb = nullptr;
+  delete e->cb;
+  e->cb = nullptr;
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -984,11 +999,29 @@ int cook_cycle_run(cook_engine* e, uint32_t num_considerable) {
     rank_run(e);
     tr.stop();
     StageTimer tm(e, 2, &e->match_ms);
-    const unsigned K = std::min<unsigned>(num_considerable, e->n_ranked);  // (take num-considerable), scheduler.clj:751
-    e->j_index.ensure(K);
-    if (K)
-      KL("cycle_job_index", cycle_job_index, div_up(K, 256), 256, (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(), K,
-         e->j_index.ptr());
+    unsigned K = std::min<unsigned>(num_considerable, e->n_ranked);  // (take num-considerable), scheduler.clj:751
+    if (e->cb && e->cb->cycle_on) {  // pending-jobs->considerable-jobs between rank and match (scheduler.clj:729-762)
+      ConsBufs& c = *e->cb;
+      if (!e->has_j_user) e->fail(COOK_E_INVALID, "cook_cycle_run: the considerable filters need pending_jobs->user");
+      const unsigned n = e->n_ranked;
+      c.q_cpus.ensure(n), c.q_mem.ensure(n), c.q_gpus.ensure(n), c.q_user.ensure(n), c.q_elig.ensure(n);
+      if (n)
+        KL("cons_gather_queue", cons_gather_queue, div_up(n, 256), 256, (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(),
+           n, e->min.j_cpus, e->min.j_mem, e->min.j_gpus, (const uint32_t*)e->j_user.ptr(),
+           c.has_elig_by_pending ? (const uint8_t*)c.elig_by_pending.ptr() : (const uint8_t*)nullptr, c.q_cpus.ptr(), c.q_mem.ptr(),
+           c.q_gpus.ptr(), c.q_user.ptr(), c.q_elig.ptr());
+      cons_run_device(e, c, n, c.q_cpus.ptr(), c.q_mem.ptr(), c.q_gpus.ptr(), c.q_user.ptr(), c.q_elig.ptr(), num_considerable);
+      K = c.n_result;
+      e->j_index.ensure(K);
+      if (K)
+        KL("cons_job_index", cons_job_index, div_up(K, 256), 256, (const uint32_t*)c.result, (const uint32_t*)e->ranked.ptr(),
+           (const uint32_t*)e->pend_ord.ptr(), K, e->j_index.ptr());
+    } else {
+      e->j_index.ensure(K);
+      if (K)
+        KL("cycle_job_index", cycle_job_index, div_up(K, 256), 256, (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(), K,
+           e->j_index.ptr());
+    }
     match_run_device(e, K, K ? e->j_index.ptr() : nullptr);
     tm.stop();
     prof_collect(e);
@@ -1000,6 +1033,65 @@ int cook_cycle_fetch(cook_engine* e, uint32_t* ranked, uint32_t* n_ranked, int32
     rank_fetch(e, ranked, n_ranked, nullptr);
     if (n_considered) *n_considered = e->cycle_considered;
     match_fetch(e, e->cycle_considered, job_to_offer, nullptr, head_matched);
+  });
+}
+
+int cook_considerable(cook_engine* e, const cook_queue* q, const cook_user_state* us, uint32_t num_considerable, uint32_t* out_idx,
+                      uint32_t* n_out, uint32_t* rate_limited, uint32_t* passed) {
+  if (n_out) *n_out = 0;
+  return guarded(e, [&] {
+    if (!q || !n_out || (!out_idx && num_considerable && q->n)) e->fail(COOK_E_INVALID, "cook_considerable: null queue / outputs");
+    const unsigned n = q->n;
+    if (n && (!q->cpus || !q->mem || !q->user)) e->fail(COOK_E_INVALID, "cook_considerable: the queue needs cpus, mem, user");
+    ConsBufs& c = cons_bufs(e);
+    cons_stage_users(e, c, us);
+    for (unsigned i = 0; i < n; ++i)
+      if (q->user[i] >= c.U) e->fail(COOK_E_INVALID, "cook_considerable: user id out of range");
+    h2d(e, c.q_cpus, q->cpus, n);
+    h2d(e, c.q_mem, q->mem, n);
+    if (q->gpus) h2d(e, c.q_gpus, q->gpus, n);
+    h2d(e, c.q_user, q->user, n);
+    if (q->eligible) h2d(e, c.q_elig, q->eligible, n);
+    cons_run_device(e, c, n, c.q_cpus.ptr(), c.q_mem.ptr(), q->gpus ? (const double*)c.q_gpus.ptr() : (const double*)nullptr,
+                    c.q_user.ptr(), q->eligible ? (const uint8_t*)c.q_elig.ptr() : (const uint8_t*)nullptr, num_considerable);
+    if (c.n_result) COOK_HIP(hipMemcpyAsync(out_idx, c.result, (size_t)c.n_result * 4, hipMemcpyDeviceToHost, e->stream));
+    if (rate_limited && c.U) COOK_HIP(hipMemcpyAsync(rate_limited, c.rate_limited.ptr(), (size_t)c.U * 4, hipMemcpyDeviceToHost, e->stream));
+    if (passed && c.U) COOK_HIP(hipMemcpyAsync(passed, c.passed.ptr(), (size_t)c.U * 4, hipMemcpyDeviceToHost, e->stream));
+    sync(e);
+    *n_out = c.n_result;
+    prof_collect(e);
+  });
+}
+int cook_cycle_set_considerable(cook_engine* e, const cook_user_state* us, const uint8_t* eligible_by_pending) {
+  return guarded(e, [&] {
+    ConsBufs& c = cons_bufs(e);
+    if (!us) {
+      c.cycle_on = false;
+      return;
+    }
+    if (!e->rank_staged) e->fail(COOK_E_STATE, "cook_cycle_set_considerable before cook_cycle_stage");
+    cons_stage_users(e, c, us);
+    if (c.U < e->U) e->fail(COOK_E_INVALID, "cook_cycle_set_considerable: fewer users than the staged rank input");
+    c.has_elig_by_pending = eligible_by_pending != nullptr;
+    if (eligible_by_pending) {
+      h2d(e, c.elig_by_pending, eligible_by_pending, e->n_pending);
+      sync(e);
+    }
+    c.cycle_on = true;
+  });
+}
+int cook_cycle_fetch_considerable(cook_engine* e, uint32_t* rank_pos, uint32_t* n_out) {
+  if (n_out) *n_out = 0;
+  return guarded(e, [&] {
+    if (!e->match_done) e->fail(COOK_E_STATE, "cook_cycle_fetch_considerable before cook_cycle_run");
+    const unsigned K = e->cycle_considered;
+    if (e->cb && e->cb->cycle_on) {
+      if (K && rank_pos) COOK_HIP(hipMemcpyAsync(rank_pos, e->cb->result, (size_t)K * 4, hipMemcpyDeviceToHost, e->stream));
+      sync(e);
+    } else if (rank_pos) {
+      for (unsigned k = 0; k < K; ++k) rank_pos[k] = k;
+    }
+    if (n_out) *n_out = K;
   });
 }
 

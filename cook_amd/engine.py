@@ -22,6 +22,7 @@ EXPORTS = [
     "cook_rank", "cook_rank_stage", "cook_rank_set_quota", "cook_rank_pool_usage", "cook_rank_run", "cook_rank_fetch",
     "cook_match", "cook_match_stage", "cook_match_run", "cook_match_fetch",
     "cook_cycle_stage", "cook_cycle_run", "cook_cycle_fetch",
+    "cook_considerable", "cook_cycle_set_considerable", "cook_cycle_fetch_considerable",
     "cook_rebalance", "cook_rebalance_stage", "cook_rebalance_run", "cook_rebalance_fetch", "cook_rebalance_timing",
     "cook_last_timing", "cook_kernel_timings", "cook_set_profiling", "cook_match_stats",
 ]
@@ -191,6 +192,30 @@ class Engine:
         self._chk(self._lib.cook_cycle_fetch(self._h, _p(ranked, C.c_uint32), C.byref(n), _p(j2o, C.c_int32),
                                              C.byref(k), C.byref(head)))
         return ranked[: n.value].copy(), j2o[: k.value].copy(), bool(head.value)
+
+    # ---- considerable jobs -----------------------------------------------------------------------------------
+    def considerable(self, queue: A.Queue, users: A.UserState, num_considerable: int):
+        """pending-jobs->considerable-jobs (scheduler.clj:729-762) -> (queue positions, rate_limited per user, passed per user)."""
+        out = np.zeros(max(1, min(int(num_considerable), queue.n)), dtype=np.uint32)
+        rl = np.zeros(max(1, users.n), dtype=np.uint32)
+        ps = np.zeros(max(1, users.n), dtype=np.uint32)
+        n = C.c_uint32(0)
+        qs, us = queue.as_struct(), users.as_struct()
+        self._chk(self._lib.cook_considerable(self._h, C.byref(qs), C.byref(us), int(num_considerable), _p(out, C.c_uint32),
+                                              C.byref(n), _p(rl, C.c_uint32), _p(ps, C.c_uint32)))
+        return out[: n.value].copy(), rl[: users.n].copy(), ps[: users.n].copy()
+
+    def cycle_set_considerable(self, users: Optional[A.UserState], eligible_by_pending=None):
+        el = np.ascontiguousarray(eligible_by_pending, dtype=np.uint8) if eligible_by_pending is not None else None
+        us = users.as_struct() if users is not None else None
+        self._chk(self._lib.cook_cycle_set_considerable(self._h, C.byref(us) if us is not None else None,
+                                                        _p(el, C.c_uint8) if el is not None else None))
+
+    def cycle_fetch_considerable(self):
+        out = np.zeros(max(1, self._rank_np), dtype=np.uint32)
+        n = C.c_uint32(0)
+        self._chk(self._lib.cook_cycle_fetch_considerable(self._h, _p(out, C.c_uint32), C.byref(n)))
+        return out[: n.value].copy()
 
     # ---- rebalancer ------------------------------------------------------------------------------------------
     def rebalance_stage(self, running: A.Tasks, pending: A.Jobs, pending_job_id, pending_priority, users: A.Users,

@@ -246,6 +246,9 @@ int cook_considerable(cook_engine* e, const cook_queue* queue, const cook_user_s
  * device now); eligible_by_pending (optional) is indexed by pending ordinal like cook_cycle_stage's pending_jobs, whose
  * `user` array must be present.  NULL users = plain (take num-considerable) again. */
 int cook_cycle_set_considerable(cook_engine* e, const cook_user_state* users, const uint8_t* eligible_by_pending);
+/* rank positions of the jobs the last cook_cycle_run considered: cook_cycle_fetch's job_to_offer[k] belongs to the job at
+ * ranked_pending_idx[rank_pos[k]] (identity when the considerable filters are off). */
+int cook_cycle_fetch_considerable(cook_engine* e, uint32_t* rank_pos, uint32_t* n_out);
 
 /* ---- MATCH: replaces the body of match-offer-to-schedule, i.e. TaskScheduler.scheduleOnce -----------------
  * (scheduler.clj:617-687; Fenzo 0.10.0 pinned at project.clj:46-50; constraints.clj).

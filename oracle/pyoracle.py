@@ -74,6 +74,18 @@ def pool_usage(tasks: A.Tasks) -> A.CookUsage:
     return u
 
 
+def considerable(queue: A.Queue, users: A.UserState, num_considerable: int):
+    """-> (queue positions of the considerable jobs, rate_limited per user, passed per user)   (scheduler.clj:729-762)."""
+    out = np.zeros(max(1, min(num_considerable, queue.n)), dtype=np.uint32)
+    rl = np.zeros(max(1, users.n), dtype=np.uint32)
+    ps = np.zeros(max(1, users.n), dtype=np.uint32)
+    n = C.c_uint32(0)
+    qs, us = queue.as_struct(), users.as_struct()
+    rc = lib().oracle_considerable(C.byref(qs), C.byref(us), int(num_considerable), _u32p(out), C.byref(n), _u32p(rl), _u32p(ps))
+    assert rc == 0
+    return out[: n.value].copy(), rl[: users.n].copy(), ps[: users.n].copy()
+
+
 def sorted_merge(colls, literal=False):
     """colls: list of sorted key lists -> sequence of coll indices in emission order (dru.clj:82-104)."""
     off = np.zeros(len(colls) + 1, dtype=np.uint32)

@@ -178,3 +178,33 @@ def build_rebalance_inputs(case):
                 init_preempted_hosts=[hid[h] for h in case.get("init_preempted_hosts", [])],
                 task_names=[t["name"] for t in running] + [j["name"] for j in pending], host_names=hnames,
                 pending_names=[j["name"] for j in pending])
+
+
+def build_considerable_inputs(case):
+    """-> (Queue, UserState, job names, user names) for tests/golden/considerable.json."""
+    q = case["queue"]
+    unames = sorted({j["user"] for j in q} | set(case["user_usage"]) | set(case["user_quota"]))
+    uid = {u: i for i, u in enumerate(unames)}
+    queue = A.Queue(cpus=np.array([j["cpus"] for j in q], dtype=np.float64), mem=np.array([j["mem"] for j in q], dtype=np.float64),
+                    gpus=np.array([j.get("gpus", 0.0) for j in q], dtype=np.float64),
+                    user=np.array([uid[j["user"]] for j in q], dtype=np.uint32),
+                    eligible=np.array([1 if j.get("eligible", True) else 0 for j in q], dtype=np.uint8))
+
+    def col(table, key, dflt):
+        return np.array([float(table.get(u, {}).get(key, dflt)) for u in unames], dtype=np.float64)
+
+    uq, uu = case["user_quota"], case["user_usage"]
+    # a user without a quota entry: (user->quota user) is nil and below-quota? reads every key as 0 -> nothing passes; the
+    # pool-filter-only vectors have no user filter at all, which an unbounded quota expresses
+    no_user_filter = not uq
+    big = A.DMAX
+    tokens = case.get("tokens")
+    st = A.UserState(
+        quota_count=col(uq, "count", big if no_user_filter else 0.0), quota_cpus=col(uq, "cpus", big if no_user_filter else 0.0),
+        quota_mem=col(uq, "mem", big if no_user_filter else 0.0), quota_gpus=col(uq, "gpus", big if no_user_filter else 0.0),
+        usage_count=col(uu, "count", 0.0), usage_cpus=col(uu, "cpus", 0.0), usage_mem=col(uu, "mem", 0.0), usage_gpus=col(uu, "gpus", 0.0),
+        tokens_left=np.array([tokens.get(u, 1 << 40) for u in unames], dtype=np.int64) if tokens is not None else None,
+        enforce_rate_limit=bool(case.get("enforce", False)),
+        pool_quota=usage_of(case["pool_quota"]) if "pool_quota" in case else None,
+        pool_usage=usage_of(case["pool_usage"]) if "pool_usage" in case else None)
+    return queue, st, [j["name"] for j in q], unames

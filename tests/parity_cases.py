@@ -227,3 +227,76 @@ def rebalance_parity(make_engine, b, min_decisions=0):
     _rebal_equal(again, want, "random, second run")
     assert len(got["decisions"]) >= min_decisions, len(got["decisions"])
     return got
+
+
+# ---- considerable jobs ------------------------------------------------------------------------------------------------
+def check_considerable_golden(make_engine):
+    from tests.test_oracle_golden import check_considerable_case
+    for case in G.load("considerable"):
+        queue, st, names, unames = G.build_considerable_inputs(case)
+        with make_engine(A.default_params()) as e:
+            idx, rl, ps = e.considerable(queue, st, case["num_considerable"])
+        check_considerable_case(case, idx, rl, names, unames)
+        o_idx, o_rl, o_ps = pyoracle.considerable(queue, st, case["num_considerable"])
+        assert np.array_equal(idx, o_idx) and np.array_equal(rl, o_rl) and np.array_equal(ps, o_ps), case["name"]
+
+
+def make_considerable_case(seed, n, n_users, *, fractional=False, tokens=True, enforce=True, pool_quota=True, eligible=True):
+    rng = np.random.default_rng(seed)
+    cpus = np.clip(np.rint(rng.normal(3.0, 1.0, n)), 1, 8)
+    mem = np.clip(np.rint(rng.normal(10240.0, 4096.0, n)), 512, 65536)
+    if fractional:
+        cpus = cpus + rng.integers(0, 10, n) / 10.0
+        mem = mem + rng.integers(0, 10, n) / 10.0
+    gpus = np.where(rng.random(n) < 0.1, rng.choice([1.0, 2.0, 4.0], size=n), 0.0)
+    p = 1.0 / np.arange(1, n_users + 1) ** 1.1
+    user = rng.permutation(n_users)[rng.choice(n_users, size=n, p=p / p.sum())].astype(np.uint32)
+    queue = A.Queue(cpus=cpus, mem=mem, gpus=gpus, user=user,
+                    eligible=(rng.random(n) < 0.9).astype(np.uint8) if eligible else None)
+    per_user = max(1, n // n_users)
+    ucount = rng.integers(0, 20, n_users).astype(np.float64)
+    ucpus = ucount * 3.0 + (0.1 if fractional else 0.0)
+    umem = ucount * 10240.0
+    ugpus = np.zeros(n_users)
+    qcount = np.where(rng.random(n_users) < 0.5, ucount + rng.integers(0, 3 * per_user + 2, n_users), 2.0 ** 31 - 1)
+    qcpus = np.where(rng.random(n_users) < 0.3, ucpus + rng.integers(0, 10 * per_user + 5, n_users), A.DMAX)
+    qmem = np.full(n_users, A.DMAX)
+    qgpus = np.where(rng.random(n_users) < 0.2, 2.0, A.DMAX)
+    st = A.UserState(quota_count=qcount, quota_cpus=qcpus, quota_mem=qmem, quota_gpus=qgpus, usage_count=ucount, usage_cpus=ucpus,
+                     usage_mem=umem, usage_gpus=ugpus,
+                     tokens_left=rng.integers(0, 2 * per_user + 3, n_users).astype(np.int64) if tokens else None,
+                     enforce_rate_limit=enforce,
+                     pool_quota=A.quota(count=float(ucount.sum() + n // 3), cpus=float(ucpus.sum() + n)) if pool_quota else None)
+    return queue, st
+
+
+def considerable_parity(make_engine, queue, st, k):
+    with make_engine(A.default_params()) as e:
+        idx, rl, ps = e.considerable(queue, st, k)
+    o_idx, o_rl, o_ps = pyoracle.considerable(queue, st, k)
+    assert np.array_equal(idx, o_idx), (len(idx), len(o_idx))
+    assert np.array_equal(rl, o_rl) and np.array_equal(ps, o_ps)
+    return idx
+
+
+def cycle_considerable_parity(make_engine, pool: synth.Pool, params, k, st, eligible_by_pending):
+    """rank -> considerable filters -> match on the device vs the same three steps through the oracle."""
+    with make_engine(params) as e:
+        e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        e.cycle_set_considerable(st, eligible_by_pending)
+        e.cycle_run(k)
+        ranked, j2o, head = e.cycle_fetch()
+        pos = e.cycle_fetch_considerable()
+    o_ranked, _ = pyoracle.rank(params, pool.tasks, pool.users)
+    assert np.array_equal(ranked, o_ranked)
+    pend_ord = np.cumsum(pool.tasks.pending) - 1
+    jobs_of_queue = pend_ord[o_ranked]
+    J = pool.pending_jobs
+    queue = A.Queue(cpus=J.cpus[jobs_of_queue], mem=J.mem[jobs_of_queue], gpus=J.gpus[jobs_of_queue] if J.gpus is not None else None,
+                    user=J.user[jobs_of_queue],
+                    eligible=np.asarray(eligible_by_pending, dtype=np.uint8)[jobs_of_queue] if eligible_by_pending is not None else None)
+    o_pos, _, _ = pyoracle.considerable(queue, st, k)
+    assert np.array_equal(pos, o_pos), (len(pos), len(o_pos))
+    o_j2o, _, o_head = pyoracle.match(params, J.take(jobs_of_queue[o_pos]), pool.offers, pool.groups)
+    assert np.array_equal(j2o, o_j2o) and head == o_head
+    return pos, j2o

@@ -125,3 +125,20 @@ def test_rebalance_golden(oracle, case):
                            b["spare"], b["rparams"], host_attrs=b["host_attrs"], groups=b["groups"], forced=b["forced"],
                            want_final=True, slave_known=b["slave_known"], init_preempted_hosts=b["init_preempted_hosts"])
     check_rebalance_case(case, res, b)
+
+
+CONS = G.load("considerable")
+
+
+def check_considerable_case(case, idx, rate_limited, names, unames):
+    assert [names[i] for i in idx] == case["expect"], (case["name"], case["ref"])
+    if "expect_rate_limited" in case:
+        got = {u: int(c) for u, c in zip(unames, rate_limited) if c}
+        assert got == case["expect_rate_limited"], (case["name"], case["ref"])
+
+
+@pytest.mark.parametrize("case", CONS, ids=[c["name"] for c in CONS])
+def test_considerable_golden(oracle, case):
+    queue, st, names, unames = G.build_considerable_inputs(case)
+    idx, rl, _ = oracle.considerable(queue, st, case["num_considerable"])
+    check_considerable_case(case, idx, rl, names, unames)

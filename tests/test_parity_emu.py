@@ -151,3 +151,34 @@ def test_rebalance_golden(make_engine):
 ], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
 def test_rebalance_parity_random(make_engine, kw):
     P.rebalance_parity(make_engine, P.make_rebalance_case(**kw))
+
+
+def test_considerable_golden(make_engine):
+    P.check_considerable_golden(make_engine)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(seed=61, n=900, n_users=12),
+    dict(seed=62, n=3000, n_users=40, fractional=True),                    # exact fix-up path, multi-block scans
+    dict(seed=63, n=900, n_users=12, tokens=False, pool_quota=False, eligible=False),
+    dict(seed=64, n=900, n_users=5, enforce=False),
+    dict(seed=65, n=1, n_users=1),
+], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_considerable_parity_random(make_engine, kw):
+    queue, st = P.make_considerable_case(**kw)
+    for k in (1, 50, 10 ** 6):
+        P.considerable_parity(make_engine, queue, st, k)
+
+
+def test_considerable_empty_queue(make_engine):
+    queue, st = P.make_considerable_case(seed=66, n=0, n_users=3)
+    assert len(P.considerable_parity(make_engine, queue, st, 10)) == 0
+
+
+def test_cycle_with_considerable_filters(make_engine):
+    pool = synth.make_pool(seed=32, n_pending=600, n_running=200, n_users=30, n_offers=100, gpus=True, constraints=True)
+    _, st = P.make_considerable_case(seed=67, n=10, n_users=30)
+    rng = np.random.default_rng(3)
+    elig = (rng.random(pool.n_pending) < 0.9).astype(np.uint8)
+    pos, j2o = P.cycle_considerable_parity(make_engine, pool, A.default_params(good_enough_fitness=1.0), 150, st, elig)
+    assert 0 < len(pos) <= 150 and not np.array_equal(pos, np.arange(len(pos)))
