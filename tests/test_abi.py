@@ -58,3 +58,10 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in txt and "libcookoracle" not in txt and "cook_oracle" not in txt, f
+
+
+def test_jni_shim_typechecks_against_header():
+    # bindings/jni/cookmatch_jni.c calls every C-ABI function with the header's exact signatures (no JDK here: stub jni.h)
+    import subprocess
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "tests", "jni_stub"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "bindings", "jni", "cookmatch_jni.c")])
