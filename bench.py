@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--considerable", type=int, default=0, help="K per pool; 0 = all ranked pending jobs")
     ap.add_argument("--good-enough", type=float, default=1.0, help="1.0 = parity setting (zz_simulator.clj:84)")
     ap.add_argument("--no-constraints", action="store_true")
+    ap.add_argument("--match-algo", type=int, default=0, help="cook_params.match_algo: 0 default (window rounds, one launch per phase), 1 serial, 3 = default + in-place re-evaluation, 4 persistent kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
@@ -92,7 +93,7 @@ def main():
     from cook_amd.sharding import pools_of_rank
     my_pools = pools_of_rank(P, world, rank)
     n_pend, n_run, n_off = args.pending // P, args.running // P, args.offers // P
-    params = A.default_params(good_enough_fitness=args.good_enough)
+    params = A.default_params(good_enough_fitness=args.good_enough, match_algo=args.match_algo)
     K = args.considerable if args.considerable > 0 else n_pend
 
     # ---- synthetic inputs, staged into HBM before the timed region ------------------------------------------

@@ -7,6 +7,9 @@
 #include <string>
 
 #define COOK_WAVE 64
+#ifndef __HIP_EMU__
+#define EMU_SITE(s) ((void)0)  // deadlock diagnostics of the SIMT emulator (tests/simt_emu); nothing on the GPU
+#endif
 
 // ---- wave-level rendezvous ---------------------------------------------------------------------------
 // On the GPU the 64 lanes of a wave run in lockstep and LDS operations of one wave retire in order, so this is a

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -137,11 +139,17 @@ struct cook_engine {
   DArr<OfferA> v_oa;
   DArr<OfferB> v_ob;
   DArr<JobRec> v_jr;
+  DArr<JobCons> v_jcons;
+  DArr<unsigned long long> m_alive, m_jmin;
   DArr<double> v_pfit, v_cand_fit;
   DArr<int> v_pidx, v_pge, v_cand_idx, v_ge_idx;
   DArr<uint32_t> v_pcnt, v_cinfo;
   DArr<uint64_t> v_colbits;
   DArr<WinCtl> w_ctl;
+  DArr<RoundLog> w_rlog;
+  DArr<PersistCtl> w_pctl;
+  int n_cus = 256;
+  unsigned last_persistent = 0, persist_fallbacks = 0;
   DArr<MatchIn> v_in;
   void* h_inbuf = nullptr;  // pinned staging copy of MatchIn
   WinCtl last_ctl{};
@@ -660,6 +668,23 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
   e->match_done = false;
 }
 
+// engines alive per device: sizes the persistent placement kernel so that the kernels of all pools sharing a GPU are resident
+static std::atomic<int> g_engines_on_device[64];
+
+void match_init_state(cook_engine* e, const MatchState& st, unsigned K, unsigned M, unsigned G) {
+  if (M) {
+    COOK_HIP(hipMemsetAsync(st.ac, 0, (size_t)M * 8, e->stream));
+    COOK_HIP(hipMemsetAsync(st.am, 0, (size_t)M * 8, e->stream));
+    COOK_HIP(hipMemsetAsync(st.acount, 0, (size_t)M * 4, e->stream));
+  }
+  if (G) COOK_HIP(hipMemsetAsync(st.group_last, 0xFF, (size_t)G * 4, e->stream));
+  if (K) {
+    COOK_HIP(hipMemsetAsync(st.job_prev, 0xFF, (size_t)K * 4, e->stream));
+    COOK_HIP(hipMemsetAsync(st.job_to_offer, 0xFF, (size_t)K * 4, e->stream));
+  }
+  COOK_HIP(hipMemsetAsync(st.summary, 0, 16, e->stream));
+}
+
 void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
   MatchIn in = e->min;
   in.K = K;
@@ -676,19 +701,13 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
   st.job_to_offer = e->m_j2o.ensure(K);
   st.fail_code = e->m_fail.ensure(K);
   st.summary = e->m_summary.ensure(4);
-  if (M) {
-    COOK_HIP(hipMemsetAsync(st.ac, 0, (size_t)M * 8, e->stream));
-    COOK_HIP(hipMemsetAsync(st.am, 0, (size_t)M * 8, e->stream));
-    COOK_HIP(hipMemsetAsync(st.acount, 0, (size_t)M * 4, e->stream));
-  }
-  if (G) COOK_HIP(hipMemsetAsync(st.group_last, 0xFF, (size_t)G * 4, e->stream));
-  if (K) {
-    COOK_HIP(hipMemsetAsync(st.job_prev, 0xFF, (size_t)K * 4, e->stream));
-    COOK_HIP(hipMemsetAsync(st.job_to_offer, 0xFF, (size_t)K * 4, e->stream));
-  }
-  COOK_HIP(hipMemsetAsync(st.summary, 0, 16, e->stream));
+  st.alive = e->m_alive.ensure((M + 63u) / 64u + 1u);
+  st.jmin = (const double*)e->m_jmin.ensure(2);
+  match_init_state(e, st, K, M, G);
   st.cutoff = 0x7FFFFFFF;
-  if (e->params.match_algo == 1) {  // one-job-at-a-time sweep by a single workgroup (reference implementation of the chain)
+  e->last_persistent = 0;
+  const int algo = e->params.match_algo;
+  if (algo == 1) {  // one-job-at-a-time sweep by a single workgroup (reference implementation of the chain)
 #ifdef __HIP_EMU__
     auto k_match = match_serial<256>;
     KL("match_serial", k_match, 1, 256, in, st);
@@ -698,6 +717,8 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
 #endif
   } else if (K > 0) {  // window rounds: eval -> merge -> resolve (match_v2.hpp)
     V2Buf vb;
+    const char* rlog_path = std::getenv("COOK_ROUND_LOG");  // diagnostics: one CSV line per round of the last match
+    vb.round_log = rlog_path ? e->w_rlog.ensure(MV_ROUND_LOG_CAP) : nullptr;
     const unsigned C = div_up(M ? M : 1u, MV_OCB);
     vb.C = C;
     OfferA* oa = e->v_oa.ensure(M);
@@ -706,6 +727,8 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
     vb.oa = oa;
     vb.ob = ob;
     vb.jr = jr;
+    JobCons* jcons = e->v_jcons.ensure(K);
+    vb.jcons = jcons;
     vb.pfit = e->v_pfit.ensure((size_t)MV_WMAX * C * MV_L);
     vb.pidx = e->v_pidx.ensure((size_t)MV_WMAX * C * MV_L);
     vb.pge = e->v_pge.ensure((size_t)MV_WMAX * C * MV_LG);
@@ -724,33 +747,91 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
       vb.in_dev = din;
     }
     if (M) KL("match_pack_offers", match_pack_offers, div_up(M, 256), 256, in, oa, ob);
-    KL("match_pack_jobs", match_pack_jobs, div_up(K, 256), 256, in, jr);
+    KL("match_pack_jobs", match_pack_jobs, div_up(K, 256), 256, in, jr, jcons);
+    COOK_HIP(hipMemsetAsync(e->m_jmin.ptr(), 0x7F, 16, e->stream));  // > every finite double's bit pattern
+    KL("match_job_minima", match_job_minima, std::min(div_up(K, 256), 256u), 256, (const JobRec*)jr, K, e->m_jmin.ptr());
+    auto init_alive = [&] {
+      if (M) KL("match_init_alive", match_init_alive, div_up(M, 256), 256, (const OfferA*)oa, M, st.jmin, st.alive);
+    };
+    init_alive();
     WinCtl c0;
     std::memset(&c0, 0, sizeof(c0));
     c0.wcur = std::min<unsigned>(MV_WMAX, 64u);
-    std::memcpy(e->h_scratch, &c0, sizeof(c0));
-    COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
-    unsigned batch = 4;
+    {
+      // window growth: with several pools on one GPU the eval phase is compute-bound (evaluate few jobs twice); a pool
+      // that has the GPU to itself is bound by the chain of rounds (prefer fewer, larger rounds)
+      const int sharing = std::max(1, g_engines_on_device[e->device & 63].load());
+      c0.wgrow_pct = sharing >= 4 ? 150u : 200u;
+      if (const char* ev = std::getenv("COOK_WGROW_PCT")) c0.wgrow_pct = (unsigned)std::max(100, std::atoi(ev));
+    }
+    c0.reeval_max = algo == 3 ? 0x7FFFFFFFu : 0u;  // 3: list-exhausted jobs re-evaluated in place instead of ending the round
     WinCtl hc = c0;
-    unsigned guard = 0;
-    while (hc.head < K) {
-      for (unsigned r = 0; r < batch; ++r) {
-        KL("match_eval2", match_eval2, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
-        KL("match_merge2", match_merge2, MV_WMAX, COOK_WAVE, in, vb);
-        KL("match_resolve2", match_resolve2, 1, MV_RTHREADS, st, vb);
-      }
+    bool done = false;
+    if (algo == 4) {  // the persistent kernel: one launch per match call (wins when a pool has the GPU to itself)
+      std::memcpy(e->h_scratch, &c0, sizeof(c0));
+      COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
+      PersistCtl* pc = e->w_pctl.ensure(1);
+      COOK_HIP(hipMemsetAsync(pc, 0, sizeof(PersistCtl), e->stream));
+#ifdef __HIP_EMU__
+      const unsigned nwg = 1;  // the emulator runs one workgroup at a time
+#else
+      const int sharing = std::max(1, g_engines_on_device[e->device & 63].load());
+      // every workgroup holds ~150 KB of LDS = one per CU; leave a quarter of the CUs to the other kernels in flight
+      unsigned nwg = (unsigned)std::max(4, std::min(64, e->n_cus * 3 / (4 * sharing)));
+      nwg = std::min(nwg, std::max(1u, C * (unsigned)MV_JG));
+#endif
+      KL("match_persist", match_persist, nwg, MV_RTHREADS, in, st, vb, pc, 0x7FFFFFFFu);
       COOK_HIP(hipMemcpyAsync(e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
+      COOK_HIP(hipMemcpyAsync(e->h_scratch + 32, pc, sizeof(PersistCtl), hipMemcpyDeviceToHost, e->stream));
       sync(e);
-      const unsigned prev_head = hc.head, prev_rounds = hc.rounds;
+      PersistCtl hp;
       std::memcpy(&hc, e->h_scratch, sizeof(WinCtl));
-      if (hc.head >= K) break;
-      // size the next batch from the observed jobs-per-round
-      const double per_round = (double)(hc.head - prev_head) / std::max(1u, hc.rounds - prev_rounds);
-      const double est = (K - hc.head) / std::max(1.0, per_round);
-      batch = (unsigned)std::min(64.0, std::max(2.0, est + 1.0));
-      if (++guard > 4u * K + 64u) e->fail(COOK_E_STATE, "cook_match: window placement made no progress");
+      std::memcpy(&hp, e->h_scratch + 32, sizeof(PersistCtl));
+      if (hp.error == 0 && hc.head >= K) {
+        done = true;
+        e->last_persistent = 1;
+      } else {  // a grid barrier timed out (workgroups not co-resident): start over with one launch per phase
+        e->persist_fallbacks += 1;
+        match_init_state(e, st, K, M, G);
+        init_alive();
+        hc = c0;
+      }
+    }
+    if (!done) {
+      std::memcpy(e->h_scratch, &c0, sizeof(c0));
+      COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
+      unsigned batch = 8;
+      unsigned guard = 0;
+      while (hc.head < K) {
+        for (unsigned r = 0; r < batch; ++r) {
+          KL("match_eval2", match_eval2, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
+          KL("match_merge2", match_merge2, MV_WMAX, COOK_WAVE, in, vb);
+          KL("match_resolve2", match_resolve2, 1, MV_RTHREADS, st, vb);
+        }
+        COOK_HIP(hipMemcpyAsync(e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
+        sync(e);
+        const unsigned prev_head = hc.head, prev_rounds = hc.rounds;
+        std::memcpy(&hc, e->h_scratch, sizeof(WinCtl));
+        if (hc.head >= K) break;
+        // size the next batch from the observed jobs-per-round
+        const double per_round = (double)(hc.head - prev_head) / std::max(1u, hc.rounds - prev_rounds);
+        const double est = (K - hc.head) / std::max(1.0, per_round);
+        batch = (unsigned)std::min(256.0, std::max(2.0, est * 1.05 + 2.0));  // over-launching is cheap: finished rounds exit at once
+        if (++guard > 4u * K + 64u) e->fail(COOK_E_STATE, "cook_match: window placement made no progress");
+      }
     }
     e->last_ctl = hc;
+    if (rlog_path) {
+      std::vector<RoundLog> h(std::min(hc.rounds, MV_ROUND_LOG_CAP));
+      if (!h.empty()) COOK_HIP(hipMemcpy(h.data(), vb.round_log, h.size() * sizeof(RoundLog), hipMemcpyDeviceToHost));
+      if (FILE* f = std::fopen(rlog_path, "w")) {
+        std::fprintf(f, "head,wcur,resolved,n_list,touched,stop,matched,setup_us,seq_us,nslots\n");
+        for (auto& r : h)
+          std::fprintf(f, "%u,%u,%u,%u,%u,%u,%u,%.2f,%.2f,%u\n", r.head, r.wcur, r.resolved, r.n_list, r.touched, r.stop, r.matched,
+                       r.setup_ticks / 100.0, r.seq_ticks / 100.0, r.nslots);
+        std::fclose(f);
+      }
+    }
     unsigned sum[4] = {hc.matched, (hc.matched == 0 || hc.head_matched) ? 1u : 0u, hc.rounds, 0u};
     std::memcpy(e->h_scratch, sum, 16);
     COOK_HIP(hipMemcpyAsync(st.summary, e->h_scratch, 16, hipMemcpyHostToDevice, e->stream));
@@ -856,6 +937,10 @@ int cook_engine_create(const cook_params* params, int device_id, cook_engine** o
     e->device = device_id;
     COOK_HIP(hipSetDevice(device_id));
     COOK_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount;
+    }
     for (int i = 0; i < 4; ++i) COOK_HIP(hipEventCreate(&e->ev_stage[i]));
     COOK_HIP(hipHostMalloc((void**)&e->h_scratch, 64 * 8, hipHostMallocDefault));
     COOK_HIP(hipHostMalloc((void**)&e->h_inbuf, sizeof(MatchIn), hipHostMallocDefault));
@@ -868,12 +953,14 @@ int cook_engine_create(const cook_params* params, int device_id, cook_engine** o
     delete e;
     return COOK_E_NOMEM;
   }
+  g_engines_on_device[device_id & 63].fetch_add(1);
   *out = e;
   return COOK_OK;
 }
 
 void cook_engine_destroy(cook_engine* e) {
   if (!e) return;
+  g_engines_on_device[e->device & 63].fetch_sub(1);
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
   // DArr members leak-free teardown: free every device buffer we own
@@ -1144,7 +1231,7 @@ int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms) {
   if (match_ms) *match_ms = e->match_ms;
   return COOK_OK;
 }
-int cook_match_stats(cook_engine* e, uint32_t out[12]) {
+int cook_match_stats(cook_engine* e, uint32_t out[16]) {
   if (!e || !out) return COOK_E_INVALID;
   const WinCtl& c = e->last_ctl;
   out[0] = c.rounds;
@@ -1159,6 +1246,10 @@ int cook_match_stats(cook_engine* e, uint32_t out[12]) {
   out[9] = (uint32_t)(c.t_seq / 100ull);
   out[10] = c.touched_sum;
   out[11] = c.visited_sum;
+  out[12] = c.reevals;
+  out[13] = e->last_persistent | (e->persist_fallbacks << 1);
+  out[14] = (uint32_t)(c.t_eval / 100ull);
+  out[15] = (uint32_t)(c.t_merge / 100ull);
   return COOK_OK;
 }
 int cook_set_profiling(cook_engine* e, int enabled) {

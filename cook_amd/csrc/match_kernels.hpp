@@ -61,6 +61,10 @@ struct MatchState {
   uint32_t* fail_code;   // [K] output
   unsigned* summary;     // [0] matched count, [1] head matched flag
   int cutoff;            // unique-group check ignores placements by jobs with match index >= cutoff (INT_MAX = none)
+  // bit v%64 of alive[v/64]: offer v can still take the smallest job of this call.  Cleared for good once
+  // assigned + min job > lease in cpus or mem (placements only add), so the eval loop never looks at the offer again.
+  unsigned long long* alive;
+  const double* jmin;    // [2] minimum cpus / mem over the jobs of this call
 };
 
 static __device__ __forceinline__ uint32_t offer_attr_val(const MatchIn& in, unsigned v, uint32_t key) {

@@ -48,6 +48,7 @@ constexpr int MV_JG = MV_WMAX / 64;        // job groups (waves of jobs) per win
 constexpr int MV_JSTEP = MV_S / 16;        // jobs inserted into the slot table per step ((L + LG) <= 16 entries each)
 static_assert(MV_L + MV_LG <= 16, "slot-table step sizing");
 static_assert(MV_OCW <= COOK_WAVE, "one lane stages one offer");
+static_assert(MV_OCW == 32, "the eval loop reads the alive bits of a wave's offers as half a 64-bit word");
 
 struct OfferA {  // resources of an offer (offer.clj:55-61) + Fenzo's running view; 48 B, read wave-uniformly
   double oc, om;          // lease cpus / mem
@@ -68,7 +69,17 @@ struct JobRec {  // one considerable job in match order; 40 B
   uint32_t flags;  // bit0 has constraints that need the slow static check, bit1 member of a constrained group,
                    // bits 8..9 group type
 };
-constexpr uint32_t JF_SLOW = 1u, JF_GROUPED = 2u;
+constexpr uint32_t JF_SLOW = 1u, JF_GROUPED = 2u, JF_FASTC = 4u;
+// The common job constraints in a form the eval loop checks from registers + LDS only: up to MV_NC user-defined EQUALS
+// pairs on attribute keys < MV_NA (or HOSTNAME) and up to MV_NC novel-host entries.  Jobs with more, or with a disk /
+// estimated-completion / checkpoint constraint, carry JF_SLOW and go through static_pass (global-memory CSR walk).
+constexpr int MV_NC = 4;   // fast constraint slots per kind
+constexpr int MV_NA = 8;   // attribute keys staged in LDS per offer
+constexpr int MV_FH = 8;   // hosts a unique-group job must avoid, kept in registers per tile
+struct JobCons {
+  uint32_t eq_key[MV_NC], eq_val[MV_NC], novel[MV_NC];
+  uint32_t n_eq, n_novel;
+};
 
 struct WinCtl {
   unsigned head;          // first unresolved job
@@ -80,12 +91,24 @@ struct WinCtl {
   unsigned touched_sum;   // sum over rounds of touched offers
   unsigned visited_sum;   // sum over rounds of jobs the walk had to visit (the rest were settled in parallel)
   unsigned long long t_setup, t_seq;  // resolve kernel: ticks (100 MHz wall clock) spent in the set-up / sequential phase
+  unsigned reeval_max;    // list-exhausted jobs re-evaluated in place per round before the round ends (0 = end the round at once)
+  unsigned reevals;       // jobs re-evaluated in place (statistics)
+  unsigned wgrow_pct;     // next window = this percentage of what the round resolved (window ended early) / of the window (it did not)
+  unsigned pad_;
+  unsigned long long t_eval, t_merge;  // persistent kernel: ticks spent in the eval / merge phases (as seen by workgroup 0)
 };
 
+struct RoundLog {  // one record per round (diagnostics; only written when V2Buf::round_log is set)
+  unsigned head, wcur, resolved, n_list, touched, stop, matched, setup_ticks, seq_ticks, nslots, pad0, pad1;
+};
+constexpr unsigned MV_ROUND_LOG_CAP = 8192;
+
 struct V2Buf {
+  RoundLog* round_log;
   const OfferA* oa;
   const OfferB* ob;
   const JobRec* jr;
+  const JobCons* jcons;  // [K] fast constraint slots of the jobs flagged JF_FASTC
   double* pfit;        // [wmax][C][L]   chunk lists
   int* pidx;           // [wmax][C][L]
   int* pge;            // [wmax][C][LG]
@@ -125,7 +148,7 @@ __global__ void __launch_bounds__(256) match_pack_offers(MatchIn in, OfferA* __r
   ob[v] = b;
 }
 
-__global__ void __launch_bounds__(256) match_pack_jobs(MatchIn in, JobRec* __restrict__ jr) {
+__global__ void __launch_bounds__(256) match_pack_jobs(MatchIn in, JobRec* __restrict__ jr, JobCons* __restrict__ jcons) {
   const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= in.K) return;
   const unsigned jj = in.j_index ? in.j_index[k] : k;
@@ -137,8 +160,37 @@ __global__ void __launch_bounds__(256) match_pack_jobs(MatchIn in, JobRec* __res
   j.reserved_host = in.j_reserved_host ? in.j_reserved_host[jj] : -1;
   j.group = in.j_group ? in.j_group[jj] : 0xFFFFFFFFu;
   unsigned f = 0;
-  if (in.j_novel_off && in.j_novel_off[jj + 1] > in.j_novel_off[jj]) f |= JF_SLOW;
-  if (in.j_eq_off && in.j_eq_off[jj + 1] > in.j_eq_off[jj]) f |= JF_SLOW;
+  JobCons jc;
+  jc.n_eq = jc.n_novel = 0;
+#pragma unroll
+  for (int q = 0; q < MV_NC; ++q) jc.eq_key[q] = jc.eq_val[q] = jc.novel[q] = 0u;
+  const unsigned n0 = in.j_novel_off ? in.j_novel_off[jj] : 0u, n1 = in.j_novel_off ? in.j_novel_off[jj + 1] : 0u;
+  const unsigned e0 = in.j_eq_off ? in.j_eq_off[jj] : 0u, e1 = in.j_eq_off ? in.j_eq_off[jj + 1] : 0u;
+  bool fits = (n1 - n0) <= (unsigned)MV_NC && (e1 - e0) <= (unsigned)MV_NC;
+  for (unsigned x = e0; x < e1 && fits; ++x) {
+    const unsigned key = in.j_eq_key[x];
+    if (key != 0xFFFFFFFFu && key >= (unsigned)MV_NA && key < in.n_attr) fits = false;  // beyond the keys staged in LDS
+  }
+  if (fits) {
+    for (unsigned x = n0; x < n1; ++x) {
+#pragma unroll
+      for (int q = 0; q < MV_NC; ++q)
+        if ((unsigned)q == x - n0) jc.novel[q] = in.j_novel_host[x];
+    }
+    for (unsigned x = e0; x < e1; ++x) {
+#pragma unroll
+      for (int q = 0; q < MV_NC; ++q)
+        if ((unsigned)q == x - e0) {
+          jc.eq_key[q] = in.j_eq_key[x];
+          jc.eq_val[q] = in.j_eq_val[x];
+        }
+    }
+    jc.n_novel = n1 - n0;
+    jc.n_eq = e1 - e0;
+    if (jc.n_novel || jc.n_eq) f |= JF_FASTC;
+  } else {
+    f |= JF_SLOW;
+  }
   if (in.j_disk_req && in.j_disk_req[jj] >= 0) f |= JF_SLOW;
   if (in.j_est_end && in.j_est_end[jj] != 0) f |= JF_SLOW;
   if (in.j_ckpt && in.j_ckpt[jj] != 0) f |= JF_SLOW;
@@ -148,6 +200,41 @@ __global__ void __launch_bounds__(256) match_pack_jobs(MatchIn in, JobRec* __res
   }
   j.flags = f;
   jr[k] = j;
+  jcons[k] = jc;
+}
+
+// minimum cpus / mem over the jobs of the call (positive doubles order like their bit patterns; jmin starts at +inf)
+__global__ void __launch_bounds__(256) match_job_minima(const JobRec* __restrict__ jr, unsigned K, unsigned long long* __restrict__ jmin_bits) {
+  double c = __longlong_as_double(0x7FF0000000000000ll), m = c;
+  for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+    const JobRec j = jr[k];
+    c = j.c < c ? j.c : c;
+    m = j.m < m ? j.m : m;
+  }
+  // negative or NaN resources would break the ordering trick: such inputs switch the dead-offer shortcut off (minimum 0)
+  if (!(c >= 0.0)) c = 0.0;
+  if (!(m >= 0.0)) m = 0.0;
+  for (int d = 32; d >= 1; d >>= 1) {
+    const double oc = __shfl_xor(c, d, COOK_WAVE), om = __shfl_xor(m, d, COOK_WAVE);
+    c = oc < c ? oc : c;
+    m = om < m ? om : m;
+  }
+  if (lane_id() == 0) {
+    atomicMin(&jmin_bits[0], (unsigned long long)__double_as_longlong(c));
+    atomicMin(&jmin_bits[1], (unsigned long long)__double_as_longlong(m));
+  }
+}
+// alive bits at the start of a call (nothing assigned yet)
+__global__ void __launch_bounds__(256) match_init_alive(const OfferA* __restrict__ oa, unsigned M, const double* __restrict__ jmin,
+                                                        unsigned long long* __restrict__ alive) {
+  const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
+  bool a = false;
+  if (v < M) {
+    const OfferA o = oa[v];
+    a = !(0.0 + jmin[0] > o.oc || 0.0 + jmin[1] > o.om);
+  }
+  const unsigned long long bits = __ballot(a);
+  if (lane_id() == 0 && (v >> 6) < (M + 63u) / 64u) alive[v >> 6] = bits;
 }
 
 // ---- the cheap parts of the constraint check, from the packed records only ---------------------------------------------
@@ -197,17 +284,33 @@ static __device__ __forceinline__ void topl_insert(double (&tf)[N], int (&ti)[N]
 }
 
 // ---- eval ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, MatchState st, V2Buf vb) {
-  __shared__ double s_fit[MV_EW][COOK_WAVE][MV_L];
-  __shared__ int s_idx[MV_EW][COOK_WAVE][MV_L];
-  __shared__ int s_ge[MV_EW][COOK_WAVE][MV_LG];
-  __shared__ unsigned s_cnt[MV_EW][COOK_WAVE][3];
-  __shared__ OfferA s_oa[MV_EW][MV_OCW];  // this wave's offers, staged once: the offer loop then reads LDS broadcasts only
-  __shared__ OfferB s_ob[MV_EW][MV_OCW];
-  __shared__ double s_oac[MV_EW][MV_OCW], s_oam[MV_EW][MV_OCW];
-  __shared__ int s_oacount[MV_EW][MV_OCW];
-  const unsigned head = vb.ctl->head, wcur = vb.ctl->wcur;
-  const unsigned jg = blockIdx.y, ch = blockIdx.x;
+struct EvalLds {
+  double fit[MV_EW][COOK_WAVE][MV_L];
+  int idx[MV_EW][COOK_WAVE][MV_L];
+  int ge[MV_EW][COOK_WAVE][MV_LG];
+  unsigned cnt[MV_EW][COOK_WAVE][3];
+  OfferA oa[MV_EW][MV_OCW];  // this wave's offers, staged once: the offer loop then reads LDS broadcasts only
+  OfferB ob[MV_EW][MV_OCW];
+  double oac[MV_EW][MV_OCW], oam[MV_EW][MV_OCW];
+  int oacount[MV_EW][MV_OCW];
+  uint32_t attr[MV_EW][MV_OCW][MV_NA];  // the first MV_NA attribute values of this wave's offers (0 = absent)
+};
+
+// One tile = 64 jobs (job group jg of the window) x MV_OCB offers (chunk ch); the whole workgroup (MV_EW waves) takes part.
+// Ends with every thread past its last LDS access only after the caller's next __syncthreads().
+static __device__ __forceinline__ void eval_tile(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
+                                                 unsigned wcur, unsigned ch, unsigned jg) {
+  EvalLds& L = *reinterpret_cast<EvalLds*>(lds);
+  auto& s_fit = L.fit;
+  auto& s_idx = L.idx;
+  auto& s_ge = L.ge;
+  auto& s_cnt = L.cnt;
+  auto& s_oa = L.oa;
+  auto& s_ob = L.ob;
+  auto& s_oac = L.oac;
+  auto& s_oam = L.oam;
+  auto& s_oacount = L.oacount;
+  auto& s_attr = L.attr;
   if (jg * COOK_WAVE >= wcur || head + jg * COOK_WAVE >= in.K) return;  // block-uniform
   const unsigned lane = lane_id(), w = wave_id();
   const unsigned b = jg * COOK_WAVE + lane, k = head + b;
@@ -224,6 +327,36 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, Matc
     jj = in.j_index ? in.j_index[k] : k;
   }
   const bool slow = (j.flags & JF_SLOW) != 0, grouped = (j.flags & JF_GROUPED) != 0;
+  const bool fastc = !slow && (j.flags & JF_FASTC) != 0;
+  JobCons jc;
+  jc.n_eq = jc.n_novel = 0;
+#pragma unroll
+  for (int q = 0; q < MV_NC; ++q) jc.eq_key[q] = jc.eq_val[q] = jc.novel[q] = 0u;
+  if (fastc) jc = vb.jcons[k];
+  // unique host-placement groups (constraints.clj:586-598): the hosts to avoid = running cotasks ++ cotasks placed by
+  // earlier rounds of this call, gathered ONCE per tile into registers (n_fh = -1: not such a job, -2: too many -> slow path)
+  unsigned fh[MV_FH];
+  int n_fh = -1;
+#pragma unroll
+  for (int q = 0; q < MV_FH; ++q) fh[q] = 0xFFFFFFFFu;
+  if (grouped && ((j.flags >> 8) & 3u) == 1u) {
+    n_fh = 0;
+    const unsigned g = j.group;
+    const unsigned r0 = in.g_run_off ? in.g_run_off[g] : 0u, r1 = in.g_run_off ? in.g_run_off[g + 1] : 0u;
+    auto push = [&](unsigned h) {
+      if (n_fh >= 0 && n_fh < MV_FH) {
+#pragma unroll
+        for (int q = 0; q < MV_FH; ++q)
+          if (q == n_fh) fh[q] = h;
+        ++n_fh;
+      } else {
+        n_fh = -2;
+      }
+    };
+    for (unsigned x = r0; x < r1 && n_fh >= 0; ++x) push(in.g_run_host[x]);
+    for (int c = ld_agent(&st.group_last[g]); c >= 0 && n_fh >= 0; c = ld_agent(&st.job_prev[c]))
+      if (c < st.cutoff) push(in.o_host[ld_agent(&st.job_to_offer[c])]);
+  }
   const bool use_ge = in.good_enough < 1.0;
   const double ge = in.good_enough, ge_lo = in.good_enough * (1.0 - 0x1p-40);
   double tf[MV_L];
@@ -247,10 +380,22 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, Matc
     s_oac[w][lane] = st.ac[v0 + lane];
     s_oam[w][lane] = st.am[v0 + lane];
     s_oacount[w][lane] = st.acount[v0 + lane];
+#pragma unroll
+    for (int q = 0; q < MV_NA; ++q)
+      s_attr[w][lane][q] = (in.o_attr && (unsigned)q < in.n_attr) ? in.o_attr[(size_t)(v0 + lane) * in.n_attr + q] : 0u;
   }
   wave_sync();
-  for (unsigned v = v0; v < v1; ++v) {  // wave-uniform
-    const unsigned vi = v - v0;
+  // offers that cannot take even the smallest job of the call any more fail every job on resources: count, never evaluate
+  unsigned long long live = 0ull;
+  if (v0 < v1) {
+    live = (st.alive[v0 >> 6] >> (v0 & 63u)) & 0xFFFFFFFFull;  // MV_OCW = 32 offers = half a word
+    if (v1 - v0 < (unsigned)MV_OCW) live &= (1ull << (v1 - v0)) - 1ull;
+    c1 += valid ? (v1 - v0) - (unsigned)__popcll(live) : 0u;
+  }
+  while (live != 0ull) {  // wave-uniform
+    const unsigned vi = (unsigned)__ffsll((unsigned long long)live) - 1u;
+    live &= live - 1ull;
+    const unsigned v = v0 + vi;
     const OfferA a = s_oa[w][vi];
     const double ac = s_oac[w][vi], am = s_oam[w][vi];
     const bool res = valid && !(ac + j.c > a.oc || am + j.m > a.om);
@@ -262,11 +407,30 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, Matc
     const OfferB o = s_ob[w][vi];
     const int acount = s_oacount[w][vi];
     bool stat = res && static_fast(j, o);
+    if (stat && fastc) {  // novel-host (constraints.clj:68-94) and user-defined EQUALS (:356-377) from registers + LDS
+#pragma unroll
+      for (int q = 0; q < MV_NC; ++q) {
+        if ((unsigned)q < jc.n_novel && jc.novel[q] == o.host) stat = false;
+        if ((unsigned)q < jc.n_eq) {
+          const unsigned key = jc.eq_key[q];
+          const unsigned val = key == 0xFFFFFFFFu ? o.host + 1u : (key < (unsigned)MV_NA ? s_attr[w][vi][key] : 0u);
+          if (val != jc.eq_val[q]) stat = false;
+        }
+      }
+    }
     if (stat && slow) stat = static_pass(in, jj, v);
     const unsigned long long bits = __ballot(stat);
     if (lane == 0) vb.colbits[(size_t)v * MV_JG + jg] = bits;
     bool feas = stat && dyn_fast(j, o, acount);
-    if (feas && grouped) feas = group_pass(in, st, jj, v);
+    if (feas && grouped) {
+      if (n_fh >= 0) {
+#pragma unroll
+        for (int q = 0; q < MV_FH; ++q)
+          if (fh[q] == o.host) feas = false;
+      } else {
+        feas = group_pass(in, st, jj, v);
+      }
+    }
     c1 += (valid && !res) ? 1u : 0u;
     c2 += (res && !feas) ? 1u : 0u;
     if (feas) {
@@ -305,7 +469,7 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, Matc
   s_cnt[w][lane][1] = c2;
   s_cnt[w][lane][2] = c4;
   __syncthreads();
-  if (w != 0 || !valid) return;
+  if (w != 0 || !valid) return;  // (the caller synchronises the workgroup before the LDS is reused)
   int p[MV_EW];
 #pragma unroll
   for (int x = 0; x < MV_EW; ++x) p[x] = 0;
@@ -369,10 +533,13 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, Matc
   vb.pcnt[obase * 4 + 3] = t4;
 }
 
+__global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, MatchState st, V2Buf vb) {
+  __shared__ __attribute__((aligned(16))) char lds[sizeof(EvalLds)];
+  eval_tile(lds, in, st, vb, vb.ctl->head, vb.ctl->wcur, blockIdx.x, blockIdx.y);
+}
+
 // ---- merge: one wave per job ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(COOK_WAVE) match_merge2(MatchIn in, V2Buf vb) {
-  const unsigned head = vb.ctl->head, wcur = vb.ctl->wcur;
-  const unsigned b = blockIdx.x;
+static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf& vb, unsigned head, unsigned wcur, unsigned b) {
   if (b >= wcur || head + b >= in.K) return;
   const unsigned lane = lane_id();
   const bool use_ge = in.good_enough < 1.0;
@@ -463,6 +630,10 @@ __global__ void __launch_bounds__(COOK_WAVE) match_merge2(MatchIn in, V2Buf vb) 
   }
 }
 
+__global__ void __launch_bounds__(COOK_WAVE) match_merge2(MatchIn in, V2Buf vb) {
+  merge_job(in, vb, vb.ctl->head, vb.ctl->wcur, blockIdx.x);
+}
+
 // ---- resolve -----------------------------------------------------------------------------------------------------------------
 struct SlotRec {  // one distinct candidate offer of the window, staged in LDS
   OfferA a;
@@ -492,20 +663,53 @@ static __device__ __attribute__((noinline)) bool group_pass_dev(const MatchIn* i
   return group_pass(*in, st, jj, v);
 }
 
-__global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2Buf vb) {
-  __shared__ JobL s_job[MV_WMAX];
-  __shared__ EntL s_ent[MV_WMAX][MV_L];
-  __shared__ GEntL s_gent[MV_WMAX][MV_LG];
-  __shared__ SlotRec s_slot[MV_S];
-  __shared__ unsigned long long s_col[MV_S][MV_JG];
-  __shared__ unsigned char s_slot_lane[MV_S];
-  __shared__ int s_hkey[MV_HASH];
-  __shared__ unsigned short s_hslot[MV_HASH];
-  __shared__ int s_j2o[MV_WMAX];               // results of the walk, flushed to HBM once per round: a global store inside
-  __shared__ unsigned char s_fail[MV_WMAX];    // the walk would stall later s_waitcnt vmcnt(0) on its acknowledgement
-  __shared__ unsigned short s_list[MV_WMAX];   // the jobs the walk has to visit, in rank order
-  __shared__ unsigned long long s_visit[MV_JG];
-  __shared__ unsigned s_nslots, s_minbad;
+struct ResolveLds {
+  JobL job[MV_WMAX];
+  EntL ent[MV_WMAX][MV_L];
+  GEntL gent[MV_WMAX][MV_LG];
+  SlotRec slot[MV_S];
+  unsigned long long col[MV_S][MV_JG];
+  unsigned long long visit[MV_JG];
+  double tac[MV_T], tam[MV_T];  // current state of the touched offers, by owner lane (published for a re-evaluation)
+  double rfit[MV_RTHREADS / COOK_WAVE];
+  int hkey[MV_HASH];
+  int j2o[MV_WMAX];                 // results of the walk, flushed to HBM once per round: a global store inside the walk
+  int tacount[MV_T];                // would stall later s_waitcnt vmcnt(0) on its acknowledgement
+  int ridx[MV_RTHREADS / COOK_WAVE], rge[MV_RTHREADS / COOK_WAVE];
+  unsigned rc[MV_RTHREADS / COOK_WAVE][3];
+  unsigned nslots, minbad;
+  int cmd;                          // window index of the job to re-evaluate, -1 = the walk is over
+  unsigned short hslot[MV_HASH];
+  unsigned short list[MV_WMAX];     // the jobs the walk has to visit, in rank order
+  unsigned char slot_lane[MV_S];
+  unsigned char fail[MV_WMAX];
+};
+
+// One round of the window walk by ONE workgroup of MV_RTHREADS threads (all of them must call it).
+static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) {
+  ResolveLds& L = *reinterpret_cast<ResolveLds*>(lds);
+  auto& s_job = L.job;
+  auto& s_ent = L.ent;
+  auto& s_gent = L.gent;
+  auto& s_slot = L.slot;
+  auto& s_col = L.col;
+  auto& s_slot_lane = L.slot_lane;
+  auto& s_hkey = L.hkey;
+  auto& s_hslot = L.hslot;
+  auto& s_j2o = L.j2o;
+  auto& s_fail = L.fail;
+  auto& s_list = L.list;
+  auto& s_visit = L.visit;
+  unsigned& s_nslots = L.nslots;
+  unsigned& s_minbad = L.minbad;
+  auto& s_tac = L.tac;
+  auto& s_tam = L.tam;
+  auto& s_tacount = L.tacount;
+  int& s_cmd = L.cmd;
+  auto& s_rfit = L.rfit;
+  auto& s_ridx = L.ridx;
+  auto& s_rge = L.rge;
+  auto& s_rc = L.rc;
   const unsigned tid = threadIdx.x, lane = lane_id();
   WinCtl ctl = *vb.ctl;
   const unsigned head = ctl.head;
@@ -647,8 +851,95 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2B
     const unsigned s = x / MV_JG, g = x % MV_JG;
     s_col[s][g] = (g * COOK_WAVE < nwin) ? vb.colbits[(size_t)s_slot[s].offer * MV_JG + g] : 0ull;
   }
+  if (tid == 0) s_cmd = -1;
   __syncthreads();
-  if (tid >= COOK_WAVE) return;  // wave 0 walks the window
+  // All offers x one job under the CURRENT state (snapshot for untouched offers, s_t* for touched ones): per-wave partial
+  // results go to s_r*; every thread of the workgroup takes part (wave 0 asks for it through s_cmd + two barriers).
+  auto reeval = [&](unsigned b) {
+    const MatchIn& in = *vb.in_dev;
+    const unsigned k = head + b;
+    const JobRec j = vb.jr[k];
+    const unsigned jj = in.j_index ? in.j_index[k] : k;
+    const bool slow = (j.flags & (JF_SLOW | JF_FASTC)) != 0, grouped = (j.flags & JF_GROUPED) != 0;  // any CSR constraint
+    Cand best{-1.0, -1};
+    int ge_idx = 0x7FFFFFFF;
+    unsigned c1 = 0, c2 = 0, c4 = 0;
+    for (unsigned v = tid; v < in.M; v += MV_RTHREADS) {
+      double ac = st.ac[v], am = st.am[v];
+      int acount = st.acount[v];
+      unsigned h = (v * 2654435761u) % MV_HASH;
+      for (;;) {
+        const int key = s_hkey[h];
+        if (key == -1) break;
+        if (key == (int)v) {
+          const unsigned sl = s_hslot[h];
+          if (sl != 0xFFFFu) {
+            const unsigned ln = s_slot_lane[sl];
+            if (ln != 0xFFu) {
+              ac = s_tac[ln];
+              am = s_tam[ln];
+              acount = s_tacount[ln];
+            }
+          }
+          break;
+        }
+        h = (h + 1) % MV_HASH;
+      }
+      const OfferA a = vb.oa[v];
+      if (ac + j.c > a.oc || am + j.m > a.om) {
+        ++c1;
+        continue;
+      }
+      const OfferB o = vb.ob[v];
+      bool ok = static_fast(j, o) && dyn_fast(j, o, acount);
+      if (ok && slow) ok = static_pass(in, jj, v);
+      if (ok && grouped) ok = group_pass(in, st, jj, v);
+      if (!ok) {
+        ++c2;
+        continue;
+      }
+      const double fit = fitness_of(a, ac, am, j.c, j.m);
+      if (!(fit > 0.0)) {
+        ++c4;
+        continue;
+      }
+      if (fit > best.fit) {  // offers ascend with v inside a thread: the first maximum keeps the lowest index
+        best.fit = fit;
+        best.idx = (int)v;
+      }
+      if (fit > good_enough && (int)v < ge_idx) ge_idx = (int)v;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      const Cand o{__shfl_xor(best.fit, d, COOK_WAVE), __shfl_xor(best.idx, d, COOK_WAVE)};
+      if (cand_better(o, best)) best = o;
+      const int og = __shfl_xor(ge_idx, d, COOK_WAVE);
+      ge_idx = og < ge_idx ? og : ge_idx;
+      c1 += __shfl_xor(c1, d, COOK_WAVE);
+      c2 += __shfl_xor(c2, d, COOK_WAVE);
+      c4 += __shfl_xor(c4, d, COOK_WAVE);
+    }
+    if (lane == 0) {
+      const unsigned w = tid >> 6;
+      s_rfit[w] = best.fit;
+      s_ridx[w] = best.idx;
+      s_rge[w] = ge_idx;
+      s_rc[w][0] = c1;
+      s_rc[w][1] = c2;
+      s_rc[w][2] = c4;
+    }
+  };
+  if (tid >= COOK_WAVE) {  // helper waves: sleep at the barrier until wave 0 asks for a re-evaluation or finishes the walk
+    for (;;) {
+      EMU_SITE("resolve: helper waiting");
+      __syncthreads();
+      const int cmd = s_cmd;
+      if (cmd < 0) break;
+      reeval((unsigned)cmd);
+      __syncthreads();
+    }
+    return;
+  }
+  // wave 0 walks the window
   // the jobs to visit, compacted in rank order
   unsigned n_list = 0;
   for (unsigned g = 0; g * COOK_WAVE < weff; ++g) {
@@ -676,6 +967,8 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2B
   unsigned stop = 0;  // 1 list exhausted, 2 touched set full, 3 group barrier, 4 slot table cut the window
   unsigned matched = 0, head_matched = ctl.head_matched;
   unsigned resolved = weff;
+  unsigned nslots_cur = nslots;  // slots staged so far (re-evaluations may add some)
+  unsigned n_exhaust = 0;        // jobs whose list ran out and were re-evaluated
   constexpr double EPS_HI = 1.0 + 0x1p-38, EPS_LO = 1.0 - 0x1p-38;
   struct JobRegs {
     unsigned b;
@@ -683,6 +976,7 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2B
     unsigned info, group;
     EntL e;          // list entry `lane` (lanes >= MV_L idle)
     unsigned owner;  // lane owning e.slot, 0xFF untouched, 0xFE no entry
+    bool no_zero_fit;  // no offer had zero fitness for this job under S
   };
   auto load_job = [&](unsigned i) {
     JobRegs r;
@@ -692,6 +986,7 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2B
     r.m = j.m;
     r.info = j.info;
     r.group = j.group;
+    r.no_zero_fit = j.f4 == 0;
     r.e.fit = -1.0;
     r.e.off = -1;
     r.e.slot = 0;
@@ -705,6 +1000,7 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2B
   };
   JobRegs nxt = load_job(0);
   for (unsigned i = 0; i < n_list; ++i) {
+    EMU_SITE("resolve: walk loop");
     const JobRegs cur = nxt;
     nxt = load_job(i + 1);
     const unsigned b = cur.b, k = head + b, bl = b & 63u;
@@ -742,160 +1038,245 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2B
     const bool sane = a1 >= 0.0 && a2 >= 0.0 && fa > 0.0;
     bool need_exact = use_ge || __any(cand && !sane);
     const unsigned long long cand_mask = __ballot(cand);
-    // --- arg-max path: first list entry that is untouched, or touched and still a candidate -------------------------------
-    // (a touched offer that is still feasible only gained fitness, so it dominates every untouched offer behind it; a
-    //  zero-fitness verdict cannot appear on an offer that was feasible under S)
-    const bool e_valid = cur.owner != 0xFEu;
-    const bool e_untouched = cur.owner == 0xFFu;
-    const bool e_live = e_valid && !e_untouched && ((cand_mask >> (cur.owner & 63u)) & 1ull);
-    const unsigned long long settle_mask = __ballot(e_untouched || e_live), untouched_mask = __ballot(e_untouched);
-    if (settle_mask == 0ull && nc == MV_L) {
-      stop = 1;
-      resolved = b;
-      break;
-    }
-    double u_fit = -1.0;  // best untouched candidate: fitness under S, offer, slot
+    bool exhausted = false;  // the job's list ran out: re-evaluate it against the current state (below)
+    double u_fit = -1.0;     // best untouched candidate: fitness under S, offer, slot
     int u_off = -1, u_slot = -1;
-    if (settle_mask != 0ull) {
-      const int qs = __ffsll((unsigned long long)settle_mask) - 1;
-      if ((untouched_mask >> qs) & 1ull) {
-        u_fit = wave_read_lane_f64(cur.e.fit, qs);
-        u_off = wave_read_lane(cur.e.off, qs);
-        u_slot = wave_read_lane((int)cur.e.slot, qs);
-      }
-    }
-    // --- best touched candidate ----------------------------------------------------------------------------------------------
     int win = -1, win_slot = -1, win_lane = -1;  // win_lane >= 0: a touched offer wins
     bool decided = false;
-    if (!need_exact) {
-      if (cand_mask == 0ull) {
-        win = u_off;
-        win_slot = u_slot;
-        decided = true;
-      } else {
-        const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(fa) : 0ull;  // positive doubles
-        const double mx = __longlong_as_double((long long)wave_max_u64(key));
-        const unsigned long long near = __ballot(cand && fa >= mx * EPS_LO);
-        if ((near & (near - 1ull)) == 0ull) {  // one touched offer clearly ahead of the other touched ones
-          if (u_off < 0 || mx * EPS_LO > u_fit) {
-            win_lane = __ffsll((unsigned long long)near) - 1;
-            decided = true;
-          } else if (mx * EPS_HI < u_fit) {
-            win = u_off;
-            win_slot = u_slot;
-            decided = true;
-          }
-        }
-        if (!decided) need_exact = true;
-      }
-    }
     unsigned pe_bits = 8u;  // exact verdict of this lane's offer (only when the exact path ran)
     double pe_fit = 0.0;
-    if (need_exact) {
-      if (t_on) {
-        pe_bits = 0u;
-        if (!res_ok) {
-          pe_bits = 1u;
-        } else if (!con_ok) {
-          pe_bits = 2u;
-        } else {
-          pe_fit = (nc_ / (t_oc + t_rc) + nm_ / (t_om + t_rm)) / 2.0;
-          if (!(pe_fit > 0.0)) pe_bits = 4u;
-        }
-      }
-      const bool t_feas = t_on && pe_bits == 0u;
-      const unsigned long long feas_mask = __ballot(t_feas);
-      // with exact verdicts a list entry settles only if its owner is still FEASIBLE (zero fitness excluded)
-      const bool e_live2 = e_valid && !e_untouched && ((feas_mask >> (cur.owner & 63u)) & 1ull);
-      const unsigned long long settle2 = __ballot(e_untouched || e_live2);
-      if (settle2 == 0ull && nc == MV_L) {
-        stop = 1;
-        resolved = b;
+    do {
+      // No feasible offer under S, no zero-fitness offer, no constrained group: placements only take capacity away and the
+      // job's constraints can only get worse on a touched offer, so it stays unmatched whatever happened in this round;
+      // only its failure summary may change (handled below from the touched offers' current verdicts).
+      if (nc == 0 && !grouped && cur.no_zero_fit) break;
+      // --- arg-max path: first list entry that is untouched, or touched and still a candidate -------------------------------
+      // (a touched offer that is still feasible only gained fitness, so it dominates every untouched offer behind it; a
+      //  zero-fitness verdict cannot appear on an offer that was feasible under S)
+      const bool e_valid = cur.owner != 0xFEu;
+      const bool e_untouched = cur.owner == 0xFFu;
+      const bool e_live = e_valid && !e_untouched && ((cand_mask >> (cur.owner & 63u)) & 1ull);
+      const unsigned long long settle_mask = __ballot(e_untouched || e_live), untouched_mask = __ballot(e_untouched);
+      if (settle_mask == 0ull && nc == MV_L) {
+        exhausted = true;
         break;
       }
-      u_fit = -1.0;
-      u_off = u_slot = -1;
-      if (settle2 != 0ull) {
-        const int qs = __ffsll((unsigned long long)settle2) - 1;
+      if (settle_mask != 0ull) {
+        const int qs = __ffsll((unsigned long long)settle_mask) - 1;
         if ((untouched_mask >> qs) & 1ull) {
           u_fit = wave_read_lane_f64(cur.e.fit, qs);
           u_off = wave_read_lane(cur.e.off, qs);
           u_slot = wave_read_lane((int)cur.e.slot, qs);
         }
       }
-      // good-enough path: lowest offer index with fitness > good-enough (scheduler.clj:2312-2314)
-      int ge_pick = 0x7FFFFFFF, ge_slot = -1, ge_lane = -1;
-      if (use_ge) {
-        const int ng = (int)((cur.info >> 8) & 0xFFu);
-        GEntL ge;
-        ge.off = -1;
-        ge.slot = 0;
-        ge.pad = 0;
-        unsigned g_owner = 0xFEu;
-        if ((int)lane < ng) {
-          ge = s_gent[b][lane];
-          g_owner = s_slot_lane[ge.slot];
-        }
-        const unsigned long long gun = __ballot(g_owner == 0xFFu);
-        int last_idx = -1;
-        if (ng > 0) last_idx = wave_read_lane(ge.off, ng - 1);
-        if (gun != 0ull) {
-          const int q = __ffsll((unsigned long long)gun) - 1;
-          ge_pick = wave_read_lane(ge.off, q);
-          ge_slot = wave_read_lane((int)ge.slot, q);
-        }
-        // lowest-index touched offer that is feasible with fitness > good-enough
-        const unsigned long long tkey = (t_feas && pe_fit > good_enough)
-                                            ? (((unsigned long long)(unsigned)(0x7FFFFFFF - t_v) << 32) | (unsigned long long)lane)
-                                            : 0ull;
-        const unsigned long long tmx = feas_mask != 0ull ? wave_max_u64(tkey) : 0ull;
-        const int tg = tmx != 0ull ? 0x7FFFFFFF - (int)(unsigned)(tmx >> 32) : 0x7FFFFFFF;
-        if (gun == 0ull && ng == MV_LG && tg > last_idx) {
-          // untouched good-enough offers beyond the list may exist with an index below the best touched one
-          stop = 1;
-          resolved = b;
-          break;
-        }
-        if (tg < ge_pick) {
-          ge_pick = tg;
-          ge_lane = (int)(unsigned)(tmx & 63ull);
-        }
-      }
-      if (ge_pick != 0x7FFFFFFF) {
-        if (ge_lane >= 0) {
-          win_lane = ge_lane;
-        } else {
-          win = ge_pick;
-          win_slot = ge_slot;
-        }
-      } else {
-        // best touched (max fitness, lowest offer index on ties) vs best untouched
-        Cand best{-1.0, -1};
-        int best_lane = -1;
-        if (feas_mask != 0ull) {
-          const unsigned long long key = t_feas ? (unsigned long long)__double_as_longlong(pe_fit) : 0ull;
-          const unsigned long long mx = wave_max_u64(key);
-          unsigned long long tie = __ballot(t_feas && key == mx);
-          int wl = __ffsll((unsigned long long)tie) - 1;
-          int wv = wave_read_lane(t_v, wl);
-          tie &= tie - 1ull;
-          while (tie != 0ull) {  // equal fitness on several touched offers: the lowest offer index wins
-            const int l2 = __ffsll((unsigned long long)tie) - 1;
-            const int v2 = wave_read_lane(t_v, l2);
-            if (v2 < wv) {
-              wv = v2;
-              wl = l2;
-            }
-            tie &= tie - 1ull;
-          }
-          best = Cand{__longlong_as_double((long long)mx), wv};
-          best_lane = wl;
-        }
-        if (u_off >= 0 && cand_better(Cand{u_fit, u_off}, best)) {
+      // --- best touched candidate ----------------------------------------------------------------------------------------------
+      if (!need_exact) {
+        if (cand_mask == 0ull) {
           win = u_off;
           win_slot = u_slot;
-        } else if (best_lane >= 0) {
-          win_lane = best_lane;
+          decided = true;
+        } else {
+          const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(fa) : 0ull;  // positive doubles
+          const double mx = __longlong_as_double((long long)wave_max_u64(key));
+          const unsigned long long near = __ballot(cand && fa >= mx * EPS_LO);
+          if ((near & (near - 1ull)) == 0ull) {  // one touched offer clearly ahead of the other touched ones
+            if (u_off < 0 || mx * EPS_LO > u_fit) {
+              win_lane = __ffsll((unsigned long long)near) - 1;
+              decided = true;
+            } else if (mx * EPS_HI < u_fit) {
+              win = u_off;
+              win_slot = u_slot;
+              decided = true;
+            }
+          }
+          if (!decided) need_exact = true;
+        }
+      }
+      if (need_exact) {
+        if (t_on) {
+          pe_bits = 0u;
+          if (!res_ok) {
+            pe_bits = 1u;
+          } else if (!con_ok) {
+            pe_bits = 2u;
+          } else {
+            pe_fit = (nc_ / (t_oc + t_rc) + nm_ / (t_om + t_rm)) / 2.0;
+            if (!(pe_fit > 0.0)) pe_bits = 4u;
+          }
+        }
+        const bool t_feas = t_on && pe_bits == 0u;
+        const unsigned long long feas_mask = __ballot(t_feas);
+        // with exact verdicts a list entry settles only if its owner is still FEASIBLE (zero fitness excluded)
+        const bool e_live2 = e_valid && !e_untouched && ((feas_mask >> (cur.owner & 63u)) & 1ull);
+        const unsigned long long settle2 = __ballot(e_untouched || e_live2);
+        if (settle2 == 0ull && nc == MV_L) {
+          exhausted = true;
+          break;
+        }
+        u_fit = -1.0;
+        u_off = u_slot = -1;
+        if (settle2 != 0ull) {
+          const int qs = __ffsll((unsigned long long)settle2) - 1;
+          if ((untouched_mask >> qs) & 1ull) {
+            u_fit = wave_read_lane_f64(cur.e.fit, qs);
+            u_off = wave_read_lane(cur.e.off, qs);
+            u_slot = wave_read_lane((int)cur.e.slot, qs);
+          }
+        }
+        // good-enough path: lowest offer index with fitness > good-enough (scheduler.clj:2312-2314)
+        int ge_pick = 0x7FFFFFFF, ge_slot = -1, ge_lane = -1;
+        if (use_ge) {
+          const int ng = (int)((cur.info >> 8) & 0xFFu);
+          GEntL ge;
+          ge.off = -1;
+          ge.slot = 0;
+          ge.pad = 0;
+          unsigned g_owner = 0xFEu;
+          if ((int)lane < ng) {
+            ge = s_gent[b][lane];
+            g_owner = s_slot_lane[ge.slot];
+          }
+          const unsigned long long gun = __ballot(g_owner == 0xFFu);
+          int last_idx = -1;
+          if (ng > 0) last_idx = wave_read_lane(ge.off, ng - 1);
+          if (gun != 0ull) {
+            const int q = __ffsll((unsigned long long)gun) - 1;
+            ge_pick = wave_read_lane(ge.off, q);
+            ge_slot = wave_read_lane((int)ge.slot, q);
+          }
+          // lowest-index touched offer that is feasible with fitness > good-enough
+          const unsigned long long tkey = (t_feas && pe_fit > good_enough)
+                                              ? (((unsigned long long)(unsigned)(0x7FFFFFFF - t_v) << 32) | (unsigned long long)lane)
+                                              : 0ull;
+          const unsigned long long tmx = feas_mask != 0ull ? wave_max_u64(tkey) : 0ull;
+          const int tg = tmx != 0ull ? 0x7FFFFFFF - (int)(unsigned)(tmx >> 32) : 0x7FFFFFFF;
+          if (gun == 0ull && ng == MV_LG && tg > last_idx) {
+            // untouched good-enough offers beyond the list may exist with an index below the best touched one
+            exhausted = true;
+            break;
+          }
+          if (tg < ge_pick) {
+            ge_pick = tg;
+            ge_lane = (int)(unsigned)(tmx & 63ull);
+          }
+        }
+        if (ge_pick != 0x7FFFFFFF) {
+          if (ge_lane >= 0) {
+            win_lane = ge_lane;
+          } else {
+            win = ge_pick;
+            win_slot = ge_slot;
+          }
+        } else {
+          // best touched (max fitness, lowest offer index on ties) vs best untouched
+          Cand best{-1.0, -1};
+          int best_lane = -1;
+          if (feas_mask != 0ull) {
+            const unsigned long long key = t_feas ? (unsigned long long)__double_as_longlong(pe_fit) : 0ull;
+            const unsigned long long mx = wave_max_u64(key);
+            unsigned long long tie = __ballot(t_feas && key == mx);
+            int wl = __ffsll((unsigned long long)tie) - 1;
+            int wv = wave_read_lane(t_v, wl);
+            tie &= tie - 1ull;
+            while (tie != 0ull) {  // equal fitness on several touched offers: the lowest offer index wins
+              const int l2 = __ffsll((unsigned long long)tie) - 1;
+              const int v2 = wave_read_lane(t_v, l2);
+              if (v2 < wv) {
+                wv = v2;
+                wl = l2;
+              }
+              tie &= tie - 1ull;
+            }
+            best = Cand{__longlong_as_double((long long)mx), wv};
+            best_lane = wl;
+          }
+          if (u_off >= 0 && cand_better(Cand{u_fit, u_off}, best)) {
+            win = u_off;
+            win_slot = u_slot;
+          } else if (best_lane >= 0) {
+            win_lane = best_lane;
+          }
+        }
+      }
+    } while (0);
+    // --- list exhausted: the whole workgroup evaluates this one job against the current state ---------------------------------
+    int re_bits = -1;  // >= 0: the exact failure summary of an unmatched re-evaluated job
+    if (exhausted) {
+      if (n_exhaust >= ctl.reeval_max) {  // end the round here: the next round evaluates the rest of the window afresh
+        stop = 1;
+        resolved = b;
+        break;
+      }
+      if (t_slot >= 0) {
+        s_tac[lane] = t_ac;
+        s_tam[lane] = t_am;
+        s_tacount[lane] = t_acount;
+      }
+      if (lane == 0) s_cmd = (int)b;
+      EMU_SITE("resolve: walker asks for a re-evaluation");
+      __syncthreads();
+      reeval(b);
+      EMU_SITE("resolve: walker after re-evaluation");
+      __syncthreads();
+      ++n_exhaust;
+      Cand rb{s_rfit[0], s_ridx[0]};
+      int rg = s_rge[0];
+      unsigned rc1 = s_rc[0][0], rc2 = s_rc[0][1], rc4 = s_rc[0][2];
+      for (int q = 1; q < MV_RTHREADS / COOK_WAVE; ++q) {
+        const Cand o{s_rfit[q], s_ridx[q]};
+        if (cand_better(o, rb)) rb = o;
+        rg = s_rge[q] < rg ? s_rge[q] : rg;
+        rc1 += s_rc[q][0];
+        rc2 += s_rc[q][1];
+        rc4 += s_rc[q][2];
+      }
+      win = win_slot = win_lane = -1;
+      const int pick = rg != 0x7FFFFFFF ? rg : rb.idx;  // scheduler.clj:2312-2314: the first good-enough offer wins outright
+      if (pick < 0) {
+        re_bits = (int)((rc1 ? 1u : 0u) | (rc2 ? 2u : 0u) | (rc4 ? 4u : 0u));
+      } else {
+        // the winner may be touched, staged but untouched, or not staged at all (then it gets a slot now)
+        unsigned h = ((unsigned)pick * 2654435761u) % MV_HASH;
+        int slot = -1;
+        for (;;) {
+          const int key = s_hkey[h];
+          if (key == -1 || key == pick) {
+            if (key == pick && s_hslot[h] != 0xFFFFu) slot = (int)s_hslot[h];
+            break;
+          }
+          h = (h + 1) % MV_HASH;
+        }
+        const int owner_lane = slot >= 0 ? (int)s_slot_lane[slot] : 0xFF;
+        wave_sync();  // every lane has looked the offer up before lane 0 edits the tables
+        if (owner_lane != 0xFF) {
+          win_lane = owner_lane;
+        } else {
+          if (slot < 0) {
+            if (nslots_cur >= (unsigned)MV_S || nslots_cur + 1u >= (unsigned)MV_HASH) {
+              stop = 4;  // no room to stage another offer: end the round before this job
+              resolved = b;
+              break;
+            }
+            slot = (int)nslots_cur++;
+            if (lane == 0) {
+              SlotRec r;
+              r.a = vb.oa[pick];
+              r.o = vb.ob[pick];
+              r.ac = st.ac[pick];
+              r.am = st.am[pick];
+              r.acount = st.acount[pick];
+              r.offer = pick;
+              s_slot[slot] = r;
+              s_slot_lane[slot] = 0xFF;
+              s_hkey[h] = pick;
+              s_hslot[h] = (unsigned short)slot;
+            }
+            if (lane < (unsigned)MV_JG)
+              s_col[slot][lane] = (lane * COOK_WAVE < nwin) ? vb.colbits[(size_t)pick * MV_JG + lane] : 0ull;
+            wave_sync();
+          }
+          win = pick;
+          win_slot = slot;
         }
       }
     }
@@ -996,7 +1377,8 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2B
         d2 = __popcll(__ballot(t_on && (pe_bits & 2u))) - __popcll(__ballot(t_on && (p0 & 2u)));
         d4 = __popcll(__ballot(t_on && (pe_bits & 4u))) - __popcll(__ballot(t_on && (p0 & 4u)));
       }
-      const unsigned bits = (((int)jl.f1 + d1) > 0 ? 1u : 0u) | (((int)jl.f2 + d2) > 0 ? 2u : 0u) | (((int)jl.f4 + d4) > 0 ? 4u : 0u);
+      unsigned bits = (((int)jl.f1 + d1) > 0 ? 1u : 0u) | (((int)jl.f2 + d2) > 0 ? 2u : 0u) | (((int)jl.f4 + d4) > 0 ? 4u : 0u);
+      if (re_bits >= 0) bits = (unsigned)re_bits;  // exact counts from the re-evaluation
       if (lane == 0) {
         s_j2o[b] = -1;
         s_fail[b] = (unsigned char)(bits ? bits : 8u);
@@ -1004,6 +1386,9 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2B
     }
   }
   if (stop == 0 && weff < nwin) stop = 4;
+  if (lane == 0) s_cmd = -1;  // release the helper waves
+  EMU_SITE("resolve: walker done");
+  __syncthreads();
   // flush the results of the jobs resolved, write the touched offers' state back and publish the new head
   wave_sync();
   for (unsigned x = lane; x < resolved; x += COOK_WAVE) {
@@ -1014,6 +1399,8 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2B
     st.ac[t_v] = t_ac;
     st.am[t_v] = t_am;
     st.acount[t_v] = t_acount;
+    if (t_ac + st.jmin[0] > t_oc || t_am + st.jmin[1] > t_om)  // full for every job of this call, for good
+      atomicAnd(&st.alive[(unsigned)t_v >> 6], ~(1ull << ((unsigned)t_v & 63u)));
   }
   if (lane == 0) {
     ctl.head = head + resolved;
@@ -1025,15 +1412,120 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2B
     ctl.t_setup += tk1 - tk0;
     ctl.t_seq += cook_ticks() - tk1;
     if (stop == 1) ctl.stop_list += 1;
+    ctl.reevals += n_exhaust;
+    if (vb.round_log && ctl.rounds <= MV_ROUND_LOG_CAP) {
+      RoundLog r;
+      r.head = head, r.wcur = ctl.wcur, r.resolved = resolved, r.n_list = n_list, r.touched = nT, r.stop = stop, r.matched = matched;
+      r.setup_ticks = (unsigned)(tk1 - tk0), r.seq_ticks = (unsigned)(cook_ticks() - tk1), r.nslots = nslots_cur, r.pad0 = r.pad1 = 0;
+      vb.round_log[ctl.rounds - 1] = r;
+    }
     if (stop == 2) ctl.stop_full += 1;
     if (stop == 3) ctl.stop_group += 1;
     if (stop == 4) ctl.stop_slots += 1;
     if (stop == 0) ctl.stop_window += 1;
     // adapt the window: aim at ~2x what a round resolves, within [64, wmax]
-    unsigned wn = stop == 0 ? ctl.wcur * 2 : resolved * 2;
+    // adapt the window: a multiple of what a round resolves (more = fewer rounds, less = fewer jobs evaluated twice)
+    unsigned wn = stop == 0 ? ctl.wcur * 2 : (unsigned)(((unsigned long long)resolved * ctl.wgrow_pct + 99ull) / 100ull);
     if (wn < 64) wn = 64;
     if (wn > (unsigned)MV_WMAX) wn = MV_WMAX;
     ctl.wcur = wn;
     *vb.ctl = ctl;
   }
+}
+
+__global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2Buf vb) {
+  __shared__ __attribute__((aligned(16))) char lds[sizeof(ResolveLds)];
+  resolve_round(lds, st, vb);
+}
+
+// ---- persistent placement kernel ---------------------------------------------------------------------------------------------
+// The three phases of a round above, looped inside ONE launch: G workgroups share the eval tiles and the merge jobs of a
+// round, workgroup 0 resolves it, and grid-wide barriers (a counter + a generation word in HBM, agent-scope atomics)
+// separate the phases.  No host round trip and no launch per round: a match call is one kernel however many rounds it
+// takes.  All G workgroups must be resident at the same time (the host sizes G for that); should a barrier ever time out
+// the kernel gives up (PersistCtl::error) and the host re-runs the match with one launch per phase.
+struct PersistCtl {
+  unsigned bar_count, bar_gen;
+  unsigned error;   // 1: a grid barrier timed out (not all workgroups were resident)
+  unsigned rounds;  // rounds executed by this launch
+};
+constexpr unsigned long long MV_BARRIER_TIMEOUT_TICKS = 200000000ull;  // 2 s of the 100 MHz clock
+
+union PersistLds {
+  EvalLds e;
+  ResolveLds r;
+};
+
+// returns false on time-out / error (every workgroup then leaves the kernel)
+static __device__ __forceinline__ bool grid_barrier(PersistCtl* pc, unsigned nblocks) {
+  __threadfence();  // every wave: its own stores of the phase have reached L2 before the workgroup arrives
+  __syncthreads();
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    if (nblocks > 1) {
+      __threadfence();  // release: this workgroup's writes of the phase are visible device-wide before it arrives
+      const unsigned gen = ld_agent(&pc->bar_gen);
+      if (atomicAdd(&pc->bar_count, 1u) == nblocks - 1u) {
+        st_agent(&pc->bar_count, 0u);
+        __threadfence();
+        atomicAdd(&pc->bar_gen, 1u);
+      } else {
+        const unsigned long long t0 = cook_ticks();
+        while (ld_agent(&pc->bar_gen) == gen) {
+          if (ld_agent(&pc->error) != 0u) {
+            ok = 0;
+            break;
+          }
+#ifndef __HIP_EMU__
+          __builtin_amdgcn_s_sleep(4);
+#endif
+          if (cook_ticks() - t0 > MV_BARRIER_TIMEOUT_TICKS) {
+            st_agent(&pc->error, 1u);
+            ok = 0;
+            break;
+          }
+        }
+      }
+    }
+    if (ld_agent(&pc->error) != 0u) ok = 0;
+    s_ok = ok;
+  }
+  __syncthreads();
+  __threadfence();  // acquire: drop stale L1 lines before reading what the other workgroups wrote
+  return s_ok != 0;
+}
+
+__global__ void __launch_bounds__(MV_RTHREADS) match_persist(MatchIn in, MatchState st, V2Buf vb, PersistCtl* pc, unsigned max_rounds) {
+  static_assert(MV_RTHREADS == COOK_WAVE * MV_EW, "eval tiles and the resolve workgroup share one block shape");
+  __shared__ __attribute__((aligned(16))) char lds[sizeof(PersistLds)];
+  const unsigned nb = gridDim.x, wg = blockIdx.x;
+  unsigned rounds = 0;
+  for (; rounds < max_rounds; ++rounds) {
+    const unsigned head = ld_agent(&vb.ctl->head), wcur = ld_agent(&vb.ctl->wcur);
+    if (head >= in.K) break;  // the same value in every workgroup: written before the last barrier
+    const unsigned long long t0 = cook_ticks();
+    const unsigned nwin = (head + wcur < in.K) ? wcur : in.K - head;
+    const unsigned njg = (nwin + COOK_WAVE - 1) / COOK_WAVE;
+    const unsigned ntiles = vb.C * njg;
+    for (unsigned t = wg; t < ntiles; t += nb) {
+      eval_tile(lds, in, st, vb, head, wcur, t % vb.C, t / vb.C);
+      __syncthreads();
+    }
+    if (!grid_barrier(pc, nb)) return;
+    const unsigned long long t1 = cook_ticks();
+    for (unsigned b = wg * MV_EW + wave_id(); b < nwin; b += nb * MV_EW) merge_job(in, vb, head, wcur, b);
+    if (!grid_barrier(pc, nb)) return;
+    if (wg == 0) {
+      const unsigned long long t2 = cook_ticks();
+      resolve_round(lds, st, vb);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        vb.ctl->t_eval += t1 - t0;
+        vb.ctl->t_merge += t2 - t1;
+      }
+    }
+    if (!grid_barrier(pc, nb)) return;
+  }
+  if (wg == 0 && threadIdx.x == 0) pc->rounds = rounds;
 }

@@ -271,9 +271,9 @@ class Engine:
         return r.value, m.value
 
     def match_stats(self):
-        out = (C.c_uint32 * 12)()
+        out = (C.c_uint32 * 16)()
         self._lib.cook_match_stats(self._h, out)
-        keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "stop_slots", "resolved", "setup_us", "seq_us", "touched", "visited")
+        keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "stop_slots", "resolved", "setup_us", "seq_us", "touched", "visited", "reevals", "persistent", "eval_us", "merge_us")
         return dict(zip(keys, [int(x) for x in out]))
 
     def set_profiling(self, on: bool):

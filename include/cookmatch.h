@@ -51,7 +51,8 @@ typedef struct cook_params {
   double offensive_max_cpus;   /* task-constraints :cpus (scheduler.clj:2198-2203); +inf disables               */
   double good_enough_fitness;  /* config.clj:111 default 0.8; (> fitness x) at scheduler.clj:2312-2314; >=1 = off */
   int64_t host_lifetime_mins;  /* estimated-completion-config :host-lifetime-mins (constraints.clj:392-397)     */
-  int32_t match_algo;          /* 0 = engine default; see DESIGN.md (all algorithms give identical results)     */
+  int32_t match_algo;          /* 0 = engine default (= 2), 1 serial sweep, 2 window rounds with one launch per phase,
+                                  3 = 2 + in-place re-evaluation, 4 persistent kernel; identical results */
   int32_t reserved;
 } cook_params;
 
@@ -309,9 +310,11 @@ int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms);
 int cook_kernel_timings(cook_engine* e, const char** names, double* ms, uint32_t* launches, uint32_t cap);
 int cook_set_profiling(cook_engine* e, int enabled);
 /* placement statistics of the last match: [0] rounds, [1] matched, [2..6] rounds ended by list-exhausted / touched-set-full /
-   group barrier / window end / candidate-slot table full, [7] jobs resolved,
-   [8] microseconds the resolve kernels spent staging windows, [9] ... walking them, [10] offers touched (sum over rounds), [11] jobs the walk visited (the rest were settled in parallel) */
-int cook_match_stats(cook_engine* e, uint32_t out[12]);
+   group barrier / window end / candidate-slot table full, [7] jobs resolved, [8] microseconds the resolve phase spent staging
+   windows, [9] ... walking them, [10] offers touched (sum over rounds), [11] jobs the walk visited (the rest were settled in
+   parallel), [12] jobs re-evaluated in place, [13] bit 0: the persistent kernel ran this match, bits 1..: times the engine had
+   to fall back from it, [14] / [15] microseconds of the eval / merge phases (persistent kernel only) */
+int cook_match_stats(cook_engine* e, uint32_t out[16]);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Aggregates a rocprofv3 --pmc counter_collection CSV per kernel: mean of every counter per dispatch (+ dispatch count)."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+files = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
+agg = defaultdict(lambda: defaultdict(float))
+cnt = defaultdict(lambda: defaultdict(int))
+for f in files:
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k][r["Counter_Name"]] += 1
+for k in sorted(agg, key=lambda k: -sum(agg[k].values()))[: int(sys.argv[2]) if len(sys.argv) > 2 else 6]:
+    print(k, {c: round(v / cnt[k][c], 1) for c, v in agg[k].items()}, "dispatches", max(cnt[k].values()))

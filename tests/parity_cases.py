@@ -300,3 +300,34 @@ def cycle_considerable_parity(make_engine, pool: synth.Pool, params, k, st, elig
     o_j2o, _, o_head = pyoracle.match(params, J.take(jobs_of_queue[o_pos]), pool.offers, pool.groups)
     assert np.array_equal(j2o, o_j2o) and head == o_head
     return pos, j2o
+
+
+def slow_constraint_case(seed, n, m):
+    """Jobs whose constraints overflow the eval loop's register/LDS fast paths: more than 4 EQUALS pairs, attribute keys
+    beyond the 8 staged in LDS, more than 4 novel hosts, unique groups with more than 8 hosts to avoid."""
+    rng = np.random.default_rng(seed)
+    n_keys = 10
+    attr = rng.integers(1, 3, (m, n_keys)).astype(np.uint32)
+    attr[:, 9] = rng.integers(0, 3, m)  # key 9 absent on some hosts
+    offers = A.Offers(cpus=rng.integers(4, 17, m).astype(float), mem=rng.integers(8, 33, m) * 1024.0, attr=attr,
+                      k8s=np.ones(m, dtype=np.uint8))
+    equals, novel = [], []
+    for _ in range(n):
+        r = rng.random()
+        if r < 0.25:
+            ks = rng.choice(n_keys, size=int(rng.integers(5, 7)), replace=False)      # > 4 pairs
+            equals.append([(int(k), int(rng.integers(1, 3))) for k in ks[:2]] + [(int(k), int(attr[rng.integers(0, m), k])) for k in ks[2:]])
+        elif r < 0.5:
+            equals.append([(int(rng.integers(8, 12)), int(rng.integers(0, 3)))])        # keys 8, 9 (beyond LDS), 10, 11 (beyond the table)
+        elif r < 0.7:
+            equals.append([(int(rng.integers(0, 8)), int(rng.integers(1, 3)))])
+        else:
+            equals.append([])
+        novel.append([int(h) for h in rng.integers(0, m, int(rng.integers(5, 8)))] if rng.random() < 0.3 else [])
+    group = np.full(n, A.NONE_U32, dtype=np.uint32)
+    members = rng.permutation(n)[: n // 3]
+    group[members] = 0
+    jobs = A.Jobs.with_constraints(rng.integers(1, 4, n).astype(float), rng.integers(1, 5, n) * 1024.0, equals=equals, novel=novel,
+                                   group=group)
+    groups = A.Groups(type=np.array([1], dtype=np.uint8), run_hosts=[[int(h) for h in rng.choice(m, 10, replace=False)]])
+    return jobs, offers, groups

@@ -81,6 +81,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
           Fiber& f = s.fibers[t];
           if (!f.stack) f.stack = (char*)std::malloc(kStack);
           f.done = false;
+          f.site = "";
           f.tid = t;
           f.tidx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
           getcontext(&f.ctx);
@@ -104,6 +105,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
           if (s.events == ev0) {
             if (++spins > 1000) {
               std::fprintf(stderr, "emu: deadlock (threads waiting at a rendezvous not all threads reach)\n");
+              for (unsigned t = 0; t < nthreads; ++t)
+                if (!s.fibers[t].done) std::fprintf(stderr, "  live thread %u last site: %s\n", t, s.fibers[t].site);
               std::abort();
             }
           } else {

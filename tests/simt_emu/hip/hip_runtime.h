@@ -66,6 +66,7 @@ struct Fiber {
   bool done = true;
   unsigned tid = 0;
   dim3 tidx;
+  const char* site = "";  // last EMU_SITE() the fiber passed (deadlock diagnostics)
 };
 struct State {
   ucontext_t main_ctx;
@@ -112,6 +113,7 @@ inline T shfl_idx(T v, int src) {
 }
 }  // namespace emu
 
+#define EMU_SITE(s) (emu::S().cur->site = (s))
 #define threadIdx (emu::S().cur->tidx)
 #define blockIdx (emu::S().blockIdx_)
 #define blockDim (emu::S().blockDim_)

@@ -70,7 +70,7 @@ def test_rank_edge_cases(make_engine):
     P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=0))
 
 
-ALGOS = pytest.mark.parametrize("algo", [0, 1], ids=["window", "serial"])
+ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4], ids=["default", "serial", "launches+reeval", "persistent"])
 
 
 @ALGOS
@@ -92,8 +92,16 @@ def test_match_parity_constraints(make_engine, algo):
 def test_match_overcommitted_cluster(make_engine, algo):
     # demand >> capacity: hosts fill up, lists run out, the tail of the queue fails (fail codes must match too)
     pool = synth.make_pool(seed=23, n_pending=500, n_running=0, n_users=10, n_offers=24)
-    j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, A.default_params(good_enough_fitness=1.0, match_algo=algo))
+    p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
+    j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, p)
     assert (j2o < 0).sum() > 100
+    if algo in (3, 4):
+        with make_engine(p) as e:
+            e.match(pool.pending_jobs, pool.offers)
+            stats = e.match_stats()
+        assert (stats["persistent"] & 1) == (1 if algo == 4 else 0)  # the persistent kernel really ran (no silent fallback)
+        if algo == 3:
+            assert stats["reevals"] > 0
 
 
 @ALGOS
@@ -114,6 +122,13 @@ def test_match_group_types(make_engine, algo):
                       run_hosts=[[1, 2], [3], [], [], [5, 6], []],
                       run_attrs=[[0, 0], [int(attr[3, 0])], [], [], [int(attr[5, 0]), int(attr[6, 0])], []])
     P.match_parity(make_engine, jobs, offers, groups, A.default_params(good_enough_fitness=1.0, match_algo=algo))
+
+
+@ALGOS
+def test_match_constraints_beyond_the_fast_paths(make_engine, algo):
+    jobs, offers, groups = P.slow_constraint_case(9, 200, 60)
+    j2o = P.match_parity(make_engine, jobs, offers, groups, A.default_params(good_enough_fitness=1.0, match_algo=algo))
+    assert (j2o >= 0).sum() > 20
 
 
 def test_match_slot_table_and_touched_set_limits(make_engine):

@@ -75,7 +75,7 @@ def test_rank_edge_cases(make_engine):
     P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=0))
 
 
-ALGOS = pytest.mark.parametrize("algo", [0, 1], ids=["window", "serial"])
+ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4], ids=["default", "serial", "launches+reeval", "persistent"])
 
 
 @ALGOS
@@ -99,8 +99,16 @@ def test_match_parity_c3_constraints(make_engine, algo):
 def test_match_fills_cluster_then_fails(make_engine, algo):
     # more demand than capacity: the tail of the queue must fail exactly like the oracle (fail codes included)
     pool = synth.make_pool(seed=23, n_pending=6000, n_running=0, n_users=50, n_offers=200)
-    j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, A.default_params(good_enough_fitness=1.0, match_algo=algo))
+    p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
+    j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, p)
     assert (j2o < 0).sum() > 1000
+    if algo in (3, 4):
+        with make_engine(p) as e:
+            e.match(pool.pending_jobs, pool.offers)
+            stats = e.match_stats()
+        assert stats["persistent"] == (1 if algo == 4 else 0)  # the persistent kernel ran, and never fell back
+        if algo == 3:
+            assert stats["reevals"] > 0
 
 
 @ALGOS
@@ -120,6 +128,13 @@ def test_match_group_types(make_engine, algo):
                       run_hosts=[[1, 2], [3], [], [], [5, 6], []],
                       run_attrs=[[0, 0], [int(attr[3, 0])], [], [], [int(attr[5, 0]), int(attr[6, 0])], []])
     P.match_parity(make_engine, jobs, offers, groups, A.default_params(good_enough_fitness=1.0, match_algo=algo))
+
+
+@ALGOS
+def test_match_constraints_beyond_the_fast_paths(make_engine, algo):
+    jobs, offers, groups = P.slow_constraint_case(9, 3000, 800)
+    j2o = P.match_parity(make_engine, jobs, offers, groups, A.default_params(good_enough_fitness=1.0, match_algo=algo))
+    assert (j2o >= 0).sum() > 300
 
 
 def test_match_slot_table_and_touched_set_limits(make_engine):
