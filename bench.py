@@ -53,17 +53,37 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(kernel, n_tasks, k, m):
-    """Inputs read once + outputs written once per launch, per pool."""
+PLACEMENT_KERNELS = ("match_resolve2", "match_eval2", "match_merge2", "match_persist", "match_serial")
+
+
+def algorithmic_bytes(kernel, n_tasks, k, m, launches_per_match=1.0):
+    """Inputs read once + outputs written once per launch, per pool.
+
+    Placement: the per-job figure of B_feas + B_assign (40 B job vector in, 4 B assignment out, the job's M/8-byte row of the
+    feasibility bit matrix) x the jobs one launch resolves (K / launches of that kernel per match call, empty over-launched
+    rounds included) + the 64 B offer records, which every launch reads once."""
+    if kernel in PLACEMENT_KERNELS:
+        jobs_per_launch = k / max(1.0, launches_per_match)
+        return jobs_per_launch * (40 + 4 + m / 8.0) + 64 * m
     table = {
-        "match_serial": 40 * k + 64 * m + 4 * k,        # job vectors + offer records in, job_to_offer out
-        "match_window": 40 * k + 64 * m + 4 * k,
         "radix_scatter": 16 * n_tasks,                  # 8 B key gather + 4 B perm in + 4 B perm out
         "radix_hist": 12 * n_tasks,
         "user_usage_scan": 73 * n_tasks,                # SumU4 in + out + head flag
         "rank_gather": 57 * n_tasks,
     }
     return table.get(kernel)
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate passes, scripts/profile_traffic.sh), or None when the kernel was not profiled."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None
+    return rec
 
 
 def main():
@@ -75,6 +95,7 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE=1)", file=sys.stderr)
             sys.exit(2)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per pool stream (read at HIP initialisation; see cook_amd/engine.py)
     import torch
     import torch.distributed as dist
 
@@ -170,12 +191,16 @@ def main():
         if agg:
             dom = max(agg, key=lambda k: agg[k][0])
             avg_ms = agg[dom][0] / max(1, agg[dom][1])
-            nbytes = algorithmic_bytes(dom, n_pend + n_run, min(K, n_pend), n_off)
+            n_cycles = max(1, min(args.steps, 3))
+            launches_per_match = agg[dom][1] / (n_cycles * max(1, len(my_pools)))
+            nbytes = algorithmic_bytes(dom, n_pend + n_run, min(K, n_pend), n_off, launches_per_match)
             achieved = (nbytes / (avg_ms * 1e-3) / 1e9) if (nbytes and avg_ms > 0) else None
             total_ms = sum(v[0] for v in agg.values())
+            tr = pmc_traffic(dom)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                        "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": nbytes,
+                        "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                        "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_source": tr["source"] if tr else None,
+                        "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": nbytes, "launches_per_match": launches_per_match,
                         "share_of_kernel_time": agg[dom][0] / total_ms if total_ms else None,
                         "note": "placement is a sequential dependency chain (job i+1 sees job i's commitment): "
                                 "latency-bound, not bandwidth-bound; see DESIGN.md",
@@ -224,7 +249,7 @@ def main():
                                    f"rank all tasks + match K={K} per pool"
                                    + ("" if args.no_constraints else "; gpu dim + EQUALS/novel-host/unique-group constraints"),
                        "pools": P, "pending_total": n_pend * P, "running_total": n_run * P, "offers_total": n_off * P,
-                       "users": args.users, "considerable_per_pool": K, "good_enough_fitness": args.good_enough,
+                       "users": args.users, "considerable_per_pool": K, "good_enough_fitness": args.good_enough, "match_algo": args.match_algo,
                        "parallelism": f"pools sharded over {world} GPU(s)", "pair_evaluations_per_cycle": considered * n_off},
             "last_cycle": {"ranked": ranked_n, "considered": considered, "matched": matched,
                            "stage_ms_pool0": {"rank": stage_ms[my_pools[0]][0], "match": stage_ms[my_pools[0]][1]},

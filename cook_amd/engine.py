@@ -44,6 +44,9 @@ def load_library(path: Optional[str] = None):
     # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64 (same SONAME as /opt/rocm's).  Whichever HIP
     # runtime is loaded FIRST serves the whole process, and mixing the two fails at hsa_init.  Every caller of this
     # package (bench.py, smoke(), the tests) also uses torch for device plumbing, so load torch's runtime first.
+    # One HIP stream per pool: ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share
+    # a queue serialise.  A rank that drives 8 pools wants 8 queues; the setting is read when the HIP runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
         import torch  # noqa: F401
     except ImportError:
