@@ -21,7 +21,7 @@ struct RebalBufs {
   // users
   DArr<double> divc, divm, divg, qcount, qcpus, qmem, qgpus;
   // B space
-  DArr<uint32_t> permA, permB2, posB, s_user, seg_start, seg_end, inexact;
+  DArr<uint32_t> permA, permB2, posB, s_user, seg_start, seg_end, inexact, user_safe;
   DArr<uint8_t> s_pending, head, act;
   DArr<SumU4> s_use, pre;
   DArr<double> dru;
@@ -233,6 +233,8 @@ RebalIn rebalance_args(cook_engine* e, RebalBufs& b) {
   in.seg_end = b.seg_end.ptr();
   in.act = b.act.ptr();
   in.dru = b.dru.ptr();
+  in.pre = b.pre.ptr();
+  in.user_safe = b.user_safe.ptr();
   in.q_count = b.qcount.ptr(), in.q_cpus = b.qcpus.ptr(), in.q_mem = b.qmem.ptr(), in.q_gpus = b.qgpus.ptr();
   in.div_cpus = b.divc.ptr(), in.div_mem = b.divm.ptr(), in.div_gpus = b.divg.ptr();
   in.hperm = b.hperm;
@@ -365,6 +367,14 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   KL("rank_gather", rank_gather, gS, 256, permB, S, (const uint32_t*)b.user.ptr(), (const double*)b.cpus.ptr(), (const double*)b.mem.ptr(),
      (const double*)b.gpus.ptr(), (const uint8_t*)b.pending.ptr(), b.s_user.ptr(), b.s_use.ptr(), b.s_pending.ptr(), b.head.ptr(),
      b.seg_start.ptr(), b.seg_end.ptr());
+  {  // users whose sums are exact in any order (all of them for integer-valued resources)
+    std::vector<uint32_t> ones(std::max(1u, U), 1u);
+    b.user_safe.ensure(std::max(1u, U));
+    COOK_HIP(hipMemcpyAsync(b.user_safe.ptr(), ones.data(), (size_t)std::max(1u, U) * 4, hipMemcpyHostToDevice, e->stream));
+    sync(e);
+    KL("rebal_user_safe", rebal_user_safe, gS, 256, (const uint32_t*)b.user.ptr(), (const double*)b.cpus.ptr(), (const double*)b.mem.ptr(),
+       (const double*)b.gpus.ptr(), S, (const uint32_t*)b.seg_start.ptr(), (const uint32_t*)b.seg_end.ptr(), b.user_safe.ptr());
+  }
   // ---- running tasks grouped by host (the group-by of rebalancer.clj:349, done once) --------------------------------------------
   b.hstart.ensure(std::max(1u, H));
   b.hend.ensure(std::max(1u, H));
@@ -424,7 +434,7 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   for (unsigned pj = 0; pj < P; ++pj) {
     KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, pj);
     if (H) KL("rebal_decide", rebal_decide, gH, COOK_WAVE * RB_WAVES, in);
-    KL("rebal_apply", rebal_apply, 1, 256, in);
+    KL("rebal_apply", rebal_apply, 1, RB_APPLY_THREADS, in);
     rebalance_rescore(e, b);
     if ((pj + 1) % RB_CHECK == 0 && pj + 1 < P) {
       COOK_HIP(hipMemcpyAsync(e->h_scratch, b.ctl.ptr(), sizeof(RebalCtl), hipMemcpyDeviceToHost, e->stream));

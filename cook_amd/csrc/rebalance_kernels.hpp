@@ -63,6 +63,8 @@ struct RebalIn {
   const uint32_t *seg_start, *seg_end;
   uint8_t* act;
   const double* dru;
+  const SumU4* pre;            // masked per-user inclusive prefix sums (exact), refreshed after every decision
+  const uint32_t* user_safe;   // [U] 1: every resource of the user's slots is a small multiple of 2^-10 -> sums exact in ANY order
   // users
   const double *q_count, *q_cpus, *q_mem, *q_gpus, *div_cpus, *div_mem, *div_gpus;
   // hosts
@@ -189,6 +191,23 @@ __global__ void __launch_bounds__(256) rebal_score(const SumU4* __restrict__ pre
   dru[i] = d;
 }
 
+// A user is "safe" when every resource value of its slots is a non-negative multiple of 2^-10 below 2^22 and it has fewer than
+// 2^20 slots: every partial sum of such values is exactly representable, so sums are the same in any association and
+// job-below-quota (the job first, then the user's tasks left to right) may reuse the prefix scan's total.
+__global__ void __launch_bounds__(256) rebal_user_safe(const uint32_t* __restrict__ user, const double* __restrict__ cpus,
+                                                       const double* __restrict__ mem, const double* __restrict__ gpus, unsigned n,
+                                                       const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ seg_end,
+                                                       uint32_t* __restrict__ user_safe) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  auto ok = [](double v) {
+    const double s = v * 1024.0;
+    return v >= 0.0 && v < 4194304.0 && s == (double)(long long)s;
+  };
+  const unsigned u = user[i];
+  if (!(ok(cpus[i]) && ok(mem[i]) && ok(gpus[i])) || seg_end[u] - seg_start[u] >= (1u << 20)) user_safe[u] = 0u;
+}
+
 // posB[slot] = position of the slot in per-user order; act[pos] = slot is a running task
 __global__ void __launch_bounds__(256) rebal_invert_perm(const uint32_t* __restrict__ permB, unsigned n, unsigned R,
                                                          uint32_t* __restrict__ posB, uint8_t* __restrict__ act) {
@@ -235,32 +254,54 @@ __global__ void __launch_bounds__(COOK_WAVE) rebal_job_prep(RebalIn in, unsigned
   const unsigned ppos = in.posB[in.R + pj];
   // rebalancer.clj:210-220: usage of (conj running-jobs job) = the job first, then the user's tasks in order
   const SumU4 seed{1.0, jc, jm, jg, 0u};
-  SumU4 carry = seed;
-  unsigned bad = 0u;
+  SumU4 fu = seed;
   int last = -1;
-  for (unsigned base = s0; base < s1; base += COOK_WAVE) {
-    const unsigned i = base + lane;
-    const bool a = i < s1 && in.act[i] != 0;
-    const SumU4 x = a ? in.s_use[i] : SumU4::zero();
-    const SumU4 t = combine(carry, wave_incl_scan_u4(x));
-    bad |= t.bad;
-    if (a && i < ppos && (int)i > last) last = (int)i;
-    carry = wave_bcast_u4(t, COOK_WAVE - 1);
-  }
-  bad = __any(bad != 0u) ? 1u : 0u;
-  for (int d = 32; d >= 1; d >>= 1) {
-    const int o = __shfl_xor(last, d, COOK_WAVE);
-    last = o > last ? o : last;
-  }
-  SumU4 fu = carry;
-  if (bad) {  // a partial sum rounded: redo left to right like the reference (all lanes compute the same thing)
-    double c = 1.0, cp = jc, m = jm, g = jg;
-    for (unsigned i = s0; i < s1; ++i)
-      if (in.act[i]) {
-        const SumU4 x = in.s_use[i];
-        c += x.count, cp += x.cpus, m += x.mem, g += x.gpus;
-      }
-    fu = SumU4{c, cp, m, g, 0u};
+  auto okv = [](double v) {
+    const double s = v * 1024.0;
+    return v >= 0.0 && v < 4194304.0 && s == (double)(long long)s;
+  };
+  if (in.user_safe[us] && okv(jc) && okv(jm) && okv(jg)) {
+    // every partial sum is exact whatever the association: the job + the scan's total over the user's active tasks
+    if (s1 > s0) {
+      const SumU4 t = in.pre[s1 - 1];
+      fu = SumU4{1.0 + t.count, jc + t.cpus, jm + t.mem, jg + t.gpus, 0u};
+    }
+    // nearest active slot before the job's own: almost always in the first chunk (only preempted tasks are inactive)
+    for (unsigned hi = ppos; hi > s0 && last < 0;) {
+      const unsigned lo = hi - s0 > COOK_WAVE ? hi - COOK_WAVE : s0;
+      const unsigned i = lo + lane;
+      const bool a = i < hi && in.act[i] != 0;
+      const unsigned long long mk = __ballot(a);
+      if (mk != 0ull) last = (int)(lo + 63u - (unsigned)__clzll((unsigned long long)mk));
+      hi = lo;
+    }
+  } else {
+    SumU4 carry = seed;
+    unsigned bad = 0u;
+    for (unsigned base = s0; base < s1; base += COOK_WAVE) {
+      const unsigned i = base + lane;
+      const bool a = i < s1 && in.act[i] != 0;
+      const SumU4 x = a ? in.s_use[i] : SumU4::zero();
+      const SumU4 t = combine(carry, wave_incl_scan_u4(x));
+      bad |= t.bad;
+      if (a && i < ppos && (int)i > last) last = (int)i;
+      carry = wave_bcast_u4(t, COOK_WAVE - 1);
+    }
+    bad = __any(bad != 0u) ? 1u : 0u;
+    for (int d = 32; d >= 1; d >>= 1) {
+      const int o = __shfl_xor(last, d, COOK_WAVE);
+      last = o > last ? o : last;
+    }
+    fu = carry;
+    if (bad) {  // a partial sum rounded: redo left to right like the reference (all lanes compute the same thing)
+      double c = 1.0, cp = jc, m = jm, g = jg;
+      for (unsigned i = s0; i < s1; ++i)
+        if (in.act[i]) {
+          const SumU4 x = in.s_use[i];
+          c += x.count, cp += x.cpus, m += x.mem, g += x.gpus;
+        }
+      fu = SumU4{c, cp, m, g, 0u};
+    }
   }
   jb.active = 1;
   jb.us = us;
@@ -577,15 +618,16 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) 
 }
 
 // ---- arg-max over hosts + next-state (rebalancer.clj:270-309, 404) -----------------------------------------------------------
-__global__ void __launch_bounds__(256) rebal_apply(RebalIn in) {
-  __shared__ unsigned long long s_key[256];
-  __shared__ unsigned s_host[256];
+constexpr int RB_APPLY_THREADS = 1024;
+__global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in) {
+  __shared__ unsigned long long s_key[RB_APPLY_THREADS];
+  __shared__ unsigned s_host[RB_APPLY_THREADS];
   const RebalJob jb = *in.job;
   if (!jb.active) return;
   const unsigned tid = threadIdx.x;
   unsigned long long bk = 0ull;
   unsigned bh = 0;
-  for (unsigned h = tid; h < in.H; h += 256) {
+  for (unsigned h = tid; h < in.H; h += RB_APPLY_THREADS) {
     const unsigned long long k = in.hres_key[h];
     if (k != 0ull && k >= bk) {  // hosts ascend with h: the later host wins ties
       bk = k;
@@ -595,7 +637,7 @@ __global__ void __launch_bounds__(256) rebal_apply(RebalIn in) {
   s_key[tid] = bk;
   s_host[tid] = bh;
   __syncthreads();
-  for (unsigned s = 128; s >= 1; s >>= 1) {
+  for (unsigned s = RB_APPLY_THREADS / 2; s >= 1; s >>= 1) {
     if (tid < s) {
       const unsigned long long ok = s_key[tid + s];
       const unsigned oh = s_host[tid + s];
