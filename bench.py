@@ -56,15 +56,16 @@ def parse():
 PLACEMENT_KERNELS = ("match_resolve2", "match_eval2", "match_merge2", "match_persist", "match_serial")
 
 
-def algorithmic_bytes(kernel, n_tasks, k, m, launches_per_match=1.0):
+def algorithmic_bytes(kernel, n_tasks, k, m, launches_per_match=1.0, pools_per_launch=1.0):
     """Inputs read once + outputs written once per launch, per pool.
 
     Placement: the per-job figure of B_feas + B_assign (40 B job vector in, 4 B assignment out, the job's M/8-byte row of the
     feasibility bit matrix) x the jobs one launch resolves (K / launches of that kernel per match call, empty over-launched
-    rounds included) + the 64 B offer records, which every launch reads once."""
+    rounds included) + the 64 B offer records, which every launch reads once (per pool it serves: a rank with more than four
+    pools runs them in lockstep groups, blockIdx.z = pool)."""
     if kernel in PLACEMENT_KERNELS:
-        jobs_per_launch = k / max(1.0, launches_per_match)
-        return jobs_per_launch * (40 + 4 + m / 8.0) + 64 * m
+        jobs_per_launch = k / max(1e-9, launches_per_match)  # over all the pools a launch serves
+        return jobs_per_launch * (40 + 4 + m / 8.0) + 64 * m * pools_per_launch
     table = {
         "radix_scatter": 16 * n_tasks,                  # 8 B key gather + 4 B perm in + 4 B perm out
         "radix_hist": 12 * n_tasks,
@@ -193,14 +194,16 @@ def main():
             avg_ms = agg[dom][0] / max(1, agg[dom][1])
             n_cycles = max(1, min(args.steps, 3))
             launches_per_match = agg[dom][1] / (n_cycles * max(1, len(my_pools)))
-            nbytes = algorithmic_bytes(dom, n_pend + n_run, min(K, n_pend), n_off, launches_per_match)
+            n_chains = min(len(my_pools), cluster.max_chains) if len(my_pools) > cluster.max_chains else len(my_pools)
+            pools_per_launch = len(my_pools) / max(1, n_chains)
+            nbytes = algorithmic_bytes(dom, n_pend + n_run, min(K, n_pend), n_off, launches_per_match, pools_per_launch)
             achieved = (nbytes / (avg_ms * 1e-3) / 1e9) if (nbytes and avg_ms > 0) else None
             total_ms = sum(v[0] for v in agg.values())
             tr = pmc_traffic(dom)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                         "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_source": tr["source"] if tr else None,
-                        "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": nbytes, "launches_per_match": launches_per_match,
+                        "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": nbytes, "launches_per_match": launches_per_match, "pools_per_launch": pools_per_launch,
                         "share_of_kernel_time": agg[dom][0] / total_ms if total_ms else None,
                         "note": "placement is a sequential dependency chain (job i+1 sees job i's commitment): "
                                 "latency-bound, not bandwidth-bound; see DESIGN.md",
@@ -250,7 +253,7 @@ def main():
                                    + ("" if args.no_constraints else "; gpu dim + EQUALS/novel-host/unique-group constraints"),
                        "pools": P, "pending_total": n_pend * P, "running_total": n_run * P, "offers_total": n_off * P,
                        "users": args.users, "considerable_per_pool": K, "good_enough_fitness": args.good_enough, "match_algo": args.match_algo,
-                       "parallelism": f"pools sharded over {world} GPU(s)", "pair_evaluations_per_cycle": considered * n_off},
+                       "parallelism": f"pools sharded over {world} GPU(s); per rank at most {cluster.max_chains} concurrent launch chains (pools beyond that run in lockstep groups)", "pair_evaluations_per_cycle": considered * n_off},
             "last_cycle": {"ranked": ranked_n, "considered": considered, "matched": matched,
                            "stage_ms_pool0": {"rank": stage_ms[my_pools[0]][0], "match": stage_ms[my_pools[0]][1]},
                            "placement_stats_pool0": engines[my_pools[0]].match_stats()},

@@ -221,6 +221,21 @@ JNIEXPORT jint JNICALL Java_cook_hip_Native_cycleRun(JNIEnv* env, jclass c, jlon
   (void)c;
   return rc ? rc : cook_cycle_run(H(h), (uint32_t)num_considerable);
 }
+/* several pools of one rank in lockstep: cycleRunRank per engine (any threads), then one cycleMatchMulti(handles) */
+JNIEXPORT jint JNICALL Java_cook_hip_Native_cycleRunRank(JNIEnv* env, jclass c, jlong h, jobject quota, jint num_considerable) {
+  int rc = cook_rank_set_quota(H(h), BUF(const cook_pool_quota, quota));
+  (void)c;
+  return rc ? rc : cook_cycle_run_rank(H(h), (uint32_t)num_considerable);
+}
+JNIEXPORT jint JNICALL Java_cook_hip_Native_cycleMatchMulti(JNIEnv* env, jclass c, jobject handles /* direct buffer of n jlong */, jint n) {
+  cook_engine* es[64];
+  const int64_t* hs = BUF(const int64_t, handles);
+  jint i;
+  (void)c;
+  if (!hs || n <= 0 || n > 64) return COOK_E_INVALID;
+  for (i = 0; i < n; ++i) es[i] = H(hs[i]);
+  return cook_cycle_match_multi(es, (uint32_t)n);
+}
 JNIEXPORT jint JNICALL Java_cook_hip_Native_cycleFetch(JNIEnv* env, jclass c, jlong h, jobject ranked_out, jobject n_ranked_out,
                                                        jobject job_to_offer_out, jobject n_considered_out,
                                                        jobject head_matched_out, jobject rank_pos_out) {

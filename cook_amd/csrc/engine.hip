@@ -147,6 +147,12 @@ struct cook_engine {
   DArr<uint64_t> v_colbits;
   DArr<WinCtl> w_ctl;
   DArr<RoundLog> w_rlog;
+  DArr<PoolCtx> w_pctx;      // contexts of a multi-pool match led by this engine
+  PoolCtx deferred{};        // this engine's match, set up but not run (cook_cycle_run_rank)
+  bool has_deferred = false;
+  unsigned deferred_k = 0;
+  WinCtl deferred_c0{};
+  WinCtl* h_multi = nullptr;  // pinned: the pools' WinCtl read-backs
   DArr<PersistCtl> w_pctl;
   int n_cus = 256;
   unsigned last_persistent = 0, persist_fallbacks = 0;
@@ -685,7 +691,9 @@ void match_init_state(cook_engine* e, const MatchState& st, unsigned K, unsigned
   COOK_HIP(hipMemsetAsync(st.summary, 0, 16, e->stream));
 }
 
-void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
+void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, const WinCtl& hc, hipStream_t stream);
+
+void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool defer = false) {
   MatchIn in = e->min;
   in.K = K;
   in.j_index = j_index;
@@ -706,7 +714,9 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
   match_init_state(e, st, K, M, G);
   st.cutoff = 0x7FFFFFFF;
   e->last_persistent = 0;
+  e->has_deferred = false;
   const int algo = e->params.match_algo;
+  if (defer && !((algo == 0 || algo == 2) && K > 0)) defer = false;  // only the default orchestration runs in lockstep
   if (algo == 1) {  // one-job-at-a-time sweep by a single workgroup (reference implementation of the chain)
 #ifdef __HIP_EMU__
     auto k_match = match_serial<256>;
@@ -797,6 +807,20 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
         hc = c0;
       }
     }
+    if (defer) {  // set up only: cook_cycle_match_multi runs the rounds of several pools together
+      std::memcpy(e->h_scratch, &c0, sizeof(c0));
+      COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
+      sync(e);
+      e->deferred.in = in;
+      e->deferred.st = st;
+      e->deferred.vb = vb;
+      e->deferred_k = K;
+      e->deferred_c0 = c0;
+      e->has_deferred = true;
+      e->cycle_considered = K;
+      e->match_done = false;
+      return;
+    }
     if (!done) {
       std::memcpy(e->h_scratch, &c0, sizeof(c0));
       COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
@@ -820,22 +844,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
         if (++guard > 4u * K + 64u) e->fail(COOK_E_STATE, "cook_match: window placement made no progress");
       }
     }
-    e->last_ctl = hc;
-    if (rlog_path) {
-      std::vector<RoundLog> h(std::min(hc.rounds, MV_ROUND_LOG_CAP));
-      if (!h.empty()) COOK_HIP(hipMemcpy(h.data(), vb.round_log, h.size() * sizeof(RoundLog), hipMemcpyDeviceToHost));
-      if (FILE* f = std::fopen(rlog_path, "w")) {
-        std::fprintf(f, "head,wcur,resolved,n_list,touched,stop,matched,setup_us,seq_us,nslots\n");
-        for (auto& r : h)
-          std::fprintf(f, "%u,%u,%u,%u,%u,%u,%u,%.2f,%.2f,%u\n", r.head, r.wcur, r.resolved, r.n_list, r.touched, r.stop, r.matched,
-                       r.setup_ticks / 100.0, r.seq_ticks / 100.0, r.nslots);
-        std::fclose(f);
-      }
-    }
-    unsigned sum[4] = {hc.matched, (hc.matched == 0 || hc.head_matched) ? 1u : 0u, hc.rounds, 0u};
-    std::memcpy(e->h_scratch, sum, 16);
-    COOK_HIP(hipMemcpyAsync(st.summary, e->h_scratch, 16, hipMemcpyHostToDevice, e->stream));
-    sync(e);
+    match_finish_rounds(e, st, vb, hc, e->stream);
   } else {
     unsigned sum[4] = {0u, 1u, 0u, 0u};
     std::memcpy(e->h_scratch, sum, 16);
@@ -844,6 +853,89 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index) {
   }
   e->cycle_considered = K;
   e->match_done = true;
+}
+
+
+// after the last round: statistics, the optional per-round log, the summary words of cook_*_fetch
+void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, const WinCtl& hc, hipStream_t stream) {
+  e->last_ctl = hc;
+  const char* rlog_path = std::getenv("COOK_ROUND_LOG");
+  if (rlog_path && vb.round_log) {
+    std::vector<RoundLog> h(std::min(hc.rounds, MV_ROUND_LOG_CAP));
+    if (!h.empty()) COOK_HIP(hipMemcpy(h.data(), vb.round_log, h.size() * sizeof(RoundLog), hipMemcpyDeviceToHost));
+    if (FILE* f = std::fopen(rlog_path, "w")) {
+      std::fprintf(f, "head,wcur,resolved,n_list,touched,stop,matched,setup_us,seq_us,nslots\n");
+      for (auto& r : h)
+        std::fprintf(f, "%u,%u,%u,%u,%u,%u,%u,%.2f,%.2f,%u\n", r.head, r.wcur, r.resolved, r.n_list, r.touched, r.stop, r.matched,
+                     r.setup_ticks / 100.0, r.seq_ticks / 100.0, r.nslots);
+      std::fclose(f);
+    }
+  }
+  unsigned sum[4] = {hc.matched, (hc.matched == 0 || hc.head_matched) ? 1u : 0u, hc.rounds, 0u};
+  std::memcpy(e->h_scratch, sum, 16);
+  COOK_HIP(hipMemcpyAsync(st.summary, e->h_scratch, 16, hipMemcpyHostToDevice, stream));
+  COOK_HIP(hipStreamSynchronize(stream));
+}
+
+// The placements of n engines (pools of one rank, same device) in lockstep rounds on the lead engine's stream.
+void match_rounds_multi(cook_engine** es, unsigned n) {
+  cook_engine* lead = es[0];
+  std::vector<unsigned> live;  // engines with a deferred match
+  for (unsigned i = 0; i < n; ++i) {
+    if (!es[i] || es[i]->device != lead->device) lead->fail(COOK_E_INVALID, "cook_cycle_match_multi: engines must share one device");
+    if (es[i]->has_deferred) live.push_back(i);
+    else if (!es[i]->match_done) lead->fail(COOK_E_STATE, "cook_cycle_match_multi before cook_cycle_run_rank");
+  }
+  const unsigned L = (unsigned)live.size();
+  if (L == 0) return;
+  if (!lead->h_multi) COOK_HIP(hipHostMalloc((void**)&lead->h_multi, 64 * sizeof(WinCtl), hipHostMallocDefault));
+  if (L > 64) lead->fail(COOK_E_INVALID, "cook_cycle_match_multi: at most 64 pools per call");
+  std::vector<PoolCtx> hctx(L);
+  std::vector<WinCtl> hc(L);
+  unsigned cmax = 1;
+  for (unsigned x = 0; x < L; ++x) {
+    cook_engine* e = es[live[x]];
+    hctx[x] = e->deferred;
+    hc[x] = e->deferred_c0;
+    cmax = std::max(cmax, e->deferred.vb.C);
+  }
+  PoolCtx* dctx = lead->w_pctx.ensure(L);
+  COOK_HIP(hipMemcpyAsync(dctx, hctx.data(), L * sizeof(PoolCtx), hipMemcpyHostToDevice, lead->stream));
+  COOK_HIP(hipStreamSynchronize(lead->stream));  // hctx is pageable
+  cook_engine* e = lead;                         // KL times / launches on the lead engine
+  unsigned batch = 8, guard = 0;
+  auto all_done = [&] {
+    for (unsigned x = 0; x < L; ++x)
+      if (hc[x].head < es[live[x]]->deferred_k) return false;
+    return true;
+  };
+  while (!all_done()) {
+    for (unsigned r = 0; r < batch; ++r) {
+      KL("match_eval2", match_eval2_multi, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx);
+      KL("match_merge2", match_merge2_multi, dim3(MV_WMAX, 1, L), COOK_WAVE, (const PoolCtx*)dctx);
+      KL("match_resolve2", match_resolve2_multi, dim3(1, 1, L), MV_RTHREADS, (const PoolCtx*)dctx);
+    }
+    const std::vector<WinCtl> prev = hc;
+    for (unsigned x = 0; x < L; ++x)
+      COOK_HIP(hipMemcpyAsync(&lead->h_multi[x], hctx[x].vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, lead->stream));
+    COOK_HIP(hipStreamSynchronize(lead->stream));
+    double est = 0;
+    for (unsigned x = 0; x < L; ++x) {
+      hc[x] = lead->h_multi[x];
+      const unsigned K = es[live[x]]->deferred_k;
+      if (hc[x].head >= K) continue;
+      const double per_round = (double)(hc[x].head - prev[x].head) / std::max(1u, hc[x].rounds - prev[x].rounds);
+      est = std::max(est, (K - hc[x].head) / std::max(1.0, per_round));
+    }
+    batch = (unsigned)std::min(256.0, std::max(2.0, est * 1.05 + 2.0));
+    if (++guard > 1000000u) lead->fail(COOK_E_STATE, "cook_cycle_match_multi: placement made no progress");
+  }
+  for (unsigned x = 0; x < L; ++x) {
+    cook_engine* ex = es[live[x]];
+    match_finish_rounds(ex, hctx[x].st, hctx[x].vb, hc[x], lead->stream);
+    ex->has_deferred = false;
+    ex->match_done = true;
+  }
 }
 
 void match_fetch(cook_engine* e, unsigned K, int32_t* job_to_offer, uint32_t* fail_code, uint8_t* head_matched) {
@@ -985,6 +1077,7 @@ void cook_engine_destroy(cook_engine* e) {
     if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]);
   if (e->h_scratch) (void)hipHostFree(e->h_scratch);
   if (e->h_inbuf) (void)hipHostFree(e->h_inbuf);
+  if (e->h_multi) (void)hipHostFree(e->h_multi);
   delete e->rb;
   e->rb = nullptr;
   delete e->cb;
@@ -1079,39 +1172,62 @@ int cook_cycle_stage(cook_engine* e, const cook_tasks* tasks, const cook_users* 
     e->cycle_staged = true;
   });
 }
+// rank -> (considerable filters) -> take K -> the job index array of the match; returns K
+static unsigned cycle_rank_part(cook_engine* e, uint32_t num_considerable) {
+  if (!e->cycle_staged) e->fail(COOK_E_STATE, "cook_cycle_run before cook_cycle_stage");
+  StageTimer tr(e, 0, &e->rank_ms);
+  rank_run(e);
+  tr.stop();
+  unsigned K = std::min<unsigned>(num_considerable, e->n_ranked);  // (take num-considerable), scheduler.clj:751
+  if (e->cb && e->cb->cycle_on) {  // pending-jobs->considerable-jobs between rank and match (scheduler.clj:729-762)
+    ConsBufs& c = *e->cb;
+    if (!e->has_j_user) e->fail(COOK_E_INVALID, "cook_cycle_run: the considerable filters need pending_jobs->user");
+    const unsigned n = e->n_ranked;
+    c.q_cpus.ensure(n), c.q_mem.ensure(n), c.q_gpus.ensure(n), c.q_user.ensure(n), c.q_elig.ensure(n);
+    if (n)
+      KL("cons_gather_queue", cons_gather_queue, div_up(n, 256), 256, (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(),
+         n, e->min.j_cpus, e->min.j_mem, e->min.j_gpus, (const uint32_t*)e->j_user.ptr(),
+         c.has_elig_by_pending ? (const uint8_t*)c.elig_by_pending.ptr() : (const uint8_t*)nullptr, c.q_cpus.ptr(), c.q_mem.ptr(),
+         c.q_gpus.ptr(), c.q_user.ptr(), c.q_elig.ptr());
+    cons_run_device(e, c, n, c.q_cpus.ptr(), c.q_mem.ptr(), c.q_gpus.ptr(), c.q_user.ptr(), c.q_elig.ptr(), num_considerable);
+    K = c.n_result;
+    e->j_index.ensure(K);
+    if (K)
+      KL("cons_job_index", cons_job_index, div_up(K, 256), 256, (const uint32_t*)c.result, (const uint32_t*)e->ranked.ptr(),
+         (const uint32_t*)e->pend_ord.ptr(), K, e->j_index.ptr());
+  } else {
+    e->j_index.ensure(K);
+    if (K)
+      KL("cycle_job_index", cycle_job_index, div_up(K, 256), 256, (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(), K,
+         e->j_index.ptr());
+  }
+  return K;
+}
 int cook_cycle_run(cook_engine* e, uint32_t num_considerable) {
   return guarded(e, [&] {
-    if (!e->cycle_staged) e->fail(COOK_E_STATE, "cook_cycle_run before cook_cycle_stage");
-    StageTimer tr(e, 0, &e->rank_ms);
-    rank_run(e);
-    tr.stop();
+    const unsigned K = cycle_rank_part(e, num_considerable);
     StageTimer tm(e, 2, &e->match_ms);
-    unsigned K = std::min<unsigned>(num_considerable, e->n_ranked);  // (take num-considerable), scheduler.clj:751
-    if (e->cb && e->cb->cycle_on) {  // pending-jobs->considerable-jobs between rank and match (scheduler.clj:729-762)
-      ConsBufs& c = *e->cb;
-      if (!e->has_j_user) e->fail(COOK_E_INVALID, "cook_cycle_run: the considerable filters need pending_jobs->user");
-      const unsigned n = e->n_ranked;
-      c.q_cpus.ensure(n), c.q_mem.ensure(n), c.q_gpus.ensure(n), c.q_user.ensure(n), c.q_elig.ensure(n);
-      if (n)
-        KL("cons_gather_queue", cons_gather_queue, div_up(n, 256), 256, (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(),
-           n, e->min.j_cpus, e->min.j_mem, e->min.j_gpus, (const uint32_t*)e->j_user.ptr(),
-           c.has_elig_by_pending ? (const uint8_t*)c.elig_by_pending.ptr() : (const uint8_t*)nullptr, c.q_cpus.ptr(), c.q_mem.ptr(),
-           c.q_gpus.ptr(), c.q_user.ptr(), c.q_elig.ptr());
-      cons_run_device(e, c, n, c.q_cpus.ptr(), c.q_mem.ptr(), c.q_gpus.ptr(), c.q_user.ptr(), c.q_elig.ptr(), num_considerable);
-      K = c.n_result;
-      e->j_index.ensure(K);
-      if (K)
-        KL("cons_job_index", cons_job_index, div_up(K, 256), 256, (const uint32_t*)c.result, (const uint32_t*)e->ranked.ptr(),
-           (const uint32_t*)e->pend_ord.ptr(), K, e->j_index.ptr());
-    } else {
-      e->j_index.ensure(K);
-      if (K)
-        KL("cycle_job_index", cycle_job_index, div_up(K, 256), 256, (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(), K,
-           e->j_index.ptr());
-    }
     match_run_device(e, K, K ? e->j_index.ptr() : nullptr);
     tm.stop();
     prof_collect(e);
+  });
+}
+int cook_cycle_run_rank(cook_engine* e, uint32_t num_considerable) {
+  return guarded(e, [&] {
+    const unsigned K = cycle_rank_part(e, num_considerable);
+    match_run_device(e, K, K ? e->j_index.ptr() : nullptr, /*defer=*/true);  // set up; the rounds run in cook_cycle_match_multi
+    prof_collect(e);
+  });
+}
+int cook_cycle_match_multi(cook_engine** engines, uint32_t n) {
+  if (!engines || n == 0 || !engines[0]) return COOK_E_INVALID;
+  cook_engine* lead = engines[0];
+  return guarded(lead, [&] {
+    StageTimer tm(lead, 2, &lead->match_ms);
+    match_rounds_multi(engines, n);
+    tm.stop();
+    for (uint32_t i = 1; i < n; ++i) engines[i]->match_ms = lead->match_ms;  // one joint sequence of launches
+    prof_collect(lead);
   });
 }
 int cook_cycle_fetch(cook_engine* e, uint32_t* ranked, uint32_t* n_ranked, int32_t* job_to_offer, uint32_t* n_considered,

@@ -1529,3 +1529,29 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_persist(MatchIn in, MatchSt
   }
   if (wg == 0 && threadIdx.x == 0) pc->rounds = rounds;
 }
+
+
+// ---- several pools in lockstep: the same three phases with blockIdx.z = pool ------------------------------------------------
+// A rank that owns several pools runs their placements as ONE sequence of launches (the pools' rounds advance together, each on
+// its own WinCtl; a pool that has finished exits at once).  Eight independent streams of small kernels interfere badly beyond
+// four streams on MI355X (kernel averages double, profiles/README.md); one stream of 8-pool launches does not.
+struct PoolCtx {
+  MatchIn in;
+  MatchState st;
+  V2Buf vb;
+};
+__global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2_multi(const PoolCtx* __restrict__ ctx) {
+  __shared__ __attribute__((aligned(16))) char lds[sizeof(EvalLds)];
+  const PoolCtx& c = ctx[blockIdx.z];
+  if (blockIdx.x >= c.vb.C) return;  // pools may differ in their number of offers
+  eval_tile(lds, c.in, c.st, c.vb, c.vb.ctl->head, c.vb.ctl->wcur, blockIdx.x, blockIdx.y);
+}
+__global__ void __launch_bounds__(COOK_WAVE) match_merge2_multi(const PoolCtx* __restrict__ ctx) {
+  const PoolCtx& c = ctx[blockIdx.z];
+  merge_job(c.in, c.vb, c.vb.ctl->head, c.vb.ctl->wcur, blockIdx.x);
+}
+__global__ void __launch_bounds__(MV_RTHREADS) match_resolve2_multi(const PoolCtx* __restrict__ ctx) {
+  __shared__ __attribute__((aligned(16))) char lds[sizeof(ResolveLds)];
+  const PoolCtx& c = ctx[blockIdx.z];
+  resolve_round(lds, c.st, c.vb);
+}

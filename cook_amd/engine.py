@@ -21,7 +21,7 @@ EXPORTS = [
     "cook_engine_create", "cook_engine_destroy", "cook_engine_set_params", "cook_last_error", "cook_version",
     "cook_rank", "cook_rank_stage", "cook_rank_set_quota", "cook_rank_pool_usage", "cook_rank_run", "cook_rank_fetch",
     "cook_match", "cook_match_stage", "cook_match_run", "cook_match_fetch",
-    "cook_cycle_stage", "cook_cycle_run", "cook_cycle_fetch",
+    "cook_cycle_stage", "cook_cycle_run", "cook_cycle_fetch", "cook_cycle_run_rank", "cook_cycle_match_multi",
     "cook_considerable", "cook_cycle_set_considerable", "cook_cycle_fetch_considerable",
     "cook_rebalance", "cook_rebalance_stage", "cook_rebalance_run", "cook_rebalance_fetch", "cook_rebalance_timing",
     "cook_last_timing", "cook_kernel_timings", "cook_set_profiling", "cook_match_stats",
@@ -187,6 +187,10 @@ class Engine:
     def cycle_run(self, num_considerable: int):
         self._chk(self._lib.cook_cycle_run(self._h, int(num_considerable)))
 
+    def cycle_run_rank(self, num_considerable: int):
+        """The rank / considerable / take-K part of cycle_run; the placement then runs in cycle_match_multi()."""
+        self._chk(self._lib.cook_cycle_run_rank(self._h, int(num_considerable)))
+
     def cycle_fetch(self):
         ranked = np.zeros(max(1, self._rank_np), dtype=np.uint32)
         j2o = np.full(max(1, self._rank_np), -1, dtype=np.int32)
@@ -289,3 +293,13 @@ class Engine:
         launches = (C.c_uint32 * cap)()
         n = self._lib.cook_kernel_timings(self._h, names, ms, launches, cap)
         return {names[i].decode(): (ms[i], launches[i]) for i in range(max(0, n))}
+
+
+def cycle_match_multi(engines: Sequence[Engine]):
+    """The placements of several engines (pools of one rank, same device) in lockstep rounds: one sequence of launches with
+    blockIdx.z = pool instead of one stream of small kernels per pool (cook_cycle_match_multi)."""
+    if not engines:
+        return
+    arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    lead = engines[0]
+    lead._chk(lead._lib.cook_cycle_match_multi(arr, len(engines)))

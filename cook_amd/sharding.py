@@ -13,6 +13,7 @@ The per-pool compute is behind the tiny `PoolEngine` protocol so that the same c
 """
 from __future__ import annotations
 
+import os
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Protocol, Sequence
@@ -76,7 +77,8 @@ class ShardedCluster:
     """The pools of one cluster that live on this rank, and one match cycle over them.
 
     cycle(K): 1. per-pool running usage (device reduction)  2. all-reduce into quota-group usage
-              3. per pool: set quota inputs, rank + take K + match (cook_cycle_run), pools concurrently (one stream each).
+              3. per pool: set quota inputs, rank + take K (pools concurrently, one stream each), then the placements of all
+                 local pools in lockstep rounds (cook_cycle_match_multi); a single pool runs cook_cycle_run.
     """
 
     def __init__(self, engines: Dict[int, PoolEngine], groups: QuotaGroups, world: int = 1, rank: int = 0, device=None):
@@ -85,6 +87,7 @@ class ShardedCluster:
         self.groups = groups
         self.world, self.rank, self.device = world, rank, device
         self._tp = ThreadPoolExecutor(max_workers=max(1, len(self.pools)))
+        self.max_chains = int(os.environ.get("COOK_MAX_CHAINS", "4"))
         self.last_group_usage: Optional[np.ndarray] = None
 
     def close(self):
@@ -105,8 +108,21 @@ class ShardedCluster:
         total = all_reduce_group_usage(group_usage_matrix(self.groups, usages), self.world, self.device)
         self.last_group_usage = total
 
+        lockstep = len(self.pools) > self.max_chains and all(hasattr(self.engines[p], "cycle_run_rank") for p in self.pools)
+
         def run(p):
             self.engines[p].rank_set_quota(self.quota_inputs(p, usages[p], total))
-            self.engines[p].cycle_run(num_considerable)
+            if lockstep:
+                self.engines[p].cycle_run_rank(num_considerable)  # rank part per pool, in parallel
+            else:
+                self.engines[p].cycle_run(num_considerable)
 
         list(self._tp.map(run, self.pools))
+        if lockstep:
+            # MI355X runs about four independent chains of small kernels at full speed (beyond that the hardware queues
+            # share dispatch pipes: 4 pools 113 ms, 6 or 8 pools 186 ms per cycle), while pools in lockstep pay for the
+            # slowest pool of every round (8 in lockstep: 215 ms).  So: at most MAX_CHAINS streams, pools spread over them.
+            from .engine import cycle_match_multi
+            n_chains = min(len(self.pools), self.max_chains)
+            groups = [[self.engines[p] for p in self.pools[c::n_chains]] for c in range(n_chains)]
+            list(self._tp.map(cycle_match_multi, groups))

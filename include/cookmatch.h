@@ -272,6 +272,13 @@ int cook_cycle_stage(cook_engine* e, const cook_tasks* tasks, const cook_users* 
                      const cook_offers* offers, const cook_groups* groups, const uint32_t* reserved_hosts,
                      uint32_t n_reserved);
 int cook_cycle_run(cook_engine* e, uint32_t num_considerable);
+/* Several pools of one rank (same device) in lockstep: cook_cycle_run_rank does the rank / considerable / take-K part of
+ * cook_cycle_run for ONE engine (call it for each engine, from any threads), then cook_cycle_match_multi runs the placements of
+ * all of them as one sequence of launches (blockIdx.z = pool) on engines[0]'s stream; results are fetched per engine with
+ * cook_cycle_fetch as usual.  Same results as cook_cycle_run on each engine; many independent streams of small kernels
+ * interfere on one GPU, one stream of n-pool launches does not.  Hold every engine's lock across both calls. */
+int cook_cycle_run_rank(cook_engine* e, uint32_t num_considerable);
+int cook_cycle_match_multi(cook_engine** engines, uint32_t n);
 int cook_cycle_fetch(cook_engine* e, uint32_t* ranked_pending_idx, uint32_t* n_ranked, int32_t* job_to_offer,
                      uint32_t* n_considered, uint8_t* head_matched);
 

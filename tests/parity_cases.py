@@ -331,3 +331,27 @@ def slow_constraint_case(seed, n, m):
                                    group=group)
     groups = A.Groups(type=np.array([1], dtype=np.uint8), run_hosts=[[int(h) for h in rng.choice(m, 10, replace=False)]])
     return jobs, offers, groups
+
+
+def multi_pool_parity(make_engine, pools, params, k):
+    """cook_cycle_run_rank per pool + ONE cook_cycle_match_multi for all of them == cook_cycle_run on each pool == oracle."""
+    from cook_amd.engine import cycle_match_multi
+    engines = [make_engine(params) for _ in pools]
+    try:
+        for e, pool in zip(engines, pools):
+            e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+            e.cycle_run_rank(k)
+        cycle_match_multi(engines)
+        got = [e.cycle_fetch() for e in engines]
+        cycle_match_multi(engines)  # nothing deferred any more: a no-op, not an error
+    finally:
+        for e in engines:
+            e.close()
+    for (ranked, j2o, head), pool in zip(got, pools):
+        o_ranked, _ = pyoracle.rank(params, pool.tasks, pool.users)
+        assert np.array_equal(ranked, o_ranked)
+        pend_ord = np.cumsum(pool.tasks.pending) - 1
+        kk = min(k, len(o_ranked))
+        o_j2o, _, o_head = pyoracle.match(params, pool.pending_jobs.take(pend_ord[o_ranked[:kk]]), pool.offers, pool.groups)
+        assert np.array_equal(j2o, o_j2o) and head == o_head
+    return got

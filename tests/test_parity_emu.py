@@ -197,3 +197,11 @@ def test_cycle_with_considerable_filters(make_engine):
     elig = (rng.random(pool.n_pending) < 0.9).astype(np.uint8)
     pos, j2o = P.cycle_considerable_parity(make_engine, pool, A.default_params(good_enough_fitness=1.0), 150, st, elig)
     assert 0 < len(pos) <= 150 and not np.array_equal(pos, np.arange(len(pos)))
+
+
+def test_multi_pool_lockstep(make_engine):
+    # three pools of different sizes (different numbers of offer chunks, rounds and K, one of them with nothing pending)
+    pools = [synth.make_pool(seed=71, n_pending=400, n_running=100, n_users=20, n_offers=300, gpus=True, constraints=True),
+             synth.make_pool(seed=72, n_pending=150, n_running=50, n_users=10, n_offers=40),
+             synth.make_pool(seed=73, n_pending=0, n_running=30, n_users=5, n_offers=20)]
+    P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0), k=300)

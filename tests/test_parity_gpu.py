@@ -228,3 +228,11 @@ def test_cycle_with_considerable_filters(make_engine):
     elig = (rng.random(pool.n_pending) < 0.9).astype(np.uint8)
     pos, j2o = P.cycle_considerable_parity(make_engine, pool, A.default_params(good_enough_fitness=1.0), 1000, st, elig)
     assert 0 < len(pos) <= 1000 and not np.array_equal(pos, np.arange(len(pos)))
+
+
+def test_multi_pool_lockstep(make_engine):
+    pools = [synth.make_pool(seed=71, n_pending=6000, n_running=2000, n_users=100, n_offers=3000, gpus=True, constraints=True),
+             synth.make_pool(seed=72, n_pending=3000, n_running=500, n_users=50, n_offers=400),
+             synth.make_pool(seed=73, n_pending=0, n_running=30, n_users=5, n_offers=20),
+             synth.make_pool(seed=74, n_pending=5000, n_running=0, n_users=80, n_offers=150)]
+    P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0), k=4000)
