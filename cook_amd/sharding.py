@@ -88,10 +88,12 @@ class ShardedCluster:
         self.world, self.rank, self.device = world, rank, device
         self._tp = ThreadPoolExecutor(max_workers=max(1, len(self.pools)))
         self.max_chains = int(os.environ.get("COOK_MAX_CHAINS", "4"))
+        self._tp_rank = ThreadPoolExecutor(max_workers=max(1, min(len(self.pools), int(os.environ.get("COOK_MAX_RANK_CHAINS", str(self.max_chains))))))
         self.last_group_usage: Optional[np.ndarray] = None
 
     def close(self):
         self._tp.shutdown(wait=True)
+        self._tp_rank.shutdown(wait=True)
 
     def quota_inputs(self, pool: int, pool_usage: Sequence[float], group_usage: np.ndarray) -> Optional[A.CookPoolQuota]:
         pq = self.groups.pool_quota.get(pool)
@@ -117,7 +119,7 @@ class ShardedCluster:
             else:
                 self.engines[p].cycle_run(num_considerable)
 
-        list(self._tp.map(run, self.pools))
+        list(self._tp_rank.map(run, self.pools))  # the rank stages are chains of small kernels too: at most max_chains at a time
         if lockstep:
             # MI355X runs about four independent chains of small kernels at full speed (beyond that the hardware queues
             # share dispatch pipes: 4 pools 113 ms, 6 or 8 pools 186 ms per cycle), while pools in lockstep pay for the

@@ -15,7 +15,7 @@ find /tmp/kt -name '*kernel_stats*' -exec cp {} "$OUT/kernel_stats.csv" \;
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --pmc $c -d /tmp/pmc_$c -o p --output-format csv -- python "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2> "$OUT/pmc_$c.err"
-  python "$ROOT/scripts/pmc_summary.py" /tmp/pmc_$c 12 > "$OUT/pmc_$c.txt"
+  python "$ROOT/scripts/pmc_summary.py" /tmp/pmc_$c 40 > "$OUT/pmc_$c.txt"
   cat "$OUT/pmc_$c.txt" | head -5
 done
 head -6 "$OUT/kernel_stats.csv" | cut -c1-160
