@@ -68,7 +68,7 @@ void cons_run_device(cook_engine* e, ConsBufs& c, unsigned n, const double* q_cp
   COOK_HIP(hipMemsetAsync(c.passed.ptr(), 0, (size_t)std::max(1u, U) * 4, e->stream));
   c.n_result = 0;
   c.result = c.qitemA.ensure(std::max(1u, n));
-  if (n == 0 || K == 0) return;
+  if (n == 0) return;  // K == 0 still runs the filters: the per-user rate-limit counters cover the whole queue
   const unsigned gN = div_up(n, 256);
   // ---- stable partition of the queue positions by user -----------------------------------------------------------------
   c.ukey.ensure(n);

@@ -830,7 +830,10 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
         for (unsigned r = 0; r < batch; ++r) {
           KL("match_eval2", match_eval2, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
           KL("match_merge2", match_merge2, MV_WMAX, COOK_WAVE, in, vb);
-          KL("match_resolve2", match_resolve2, 1, MV_RTHREADS, st, vb);
+          if (algo == 3)
+            KL("match_resolve2", match_resolve2_reeval, 1, MV_RTHREADS, st, vb);
+          else
+            KL("match_resolve2", match_resolve2, 1, MV_RTHREADS, st, vb);
         }
         COOK_HIP(hipMemcpyAsync(e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
         sync(e);

@@ -686,6 +686,9 @@ struct ResolveLds {
 };
 
 // One round of the window walk by ONE workgroup of MV_RTHREADS threads (all of them must call it).
+// REEVAL compiles the in-place re-evaluation of list-exhausted jobs in (match_algo 3); without it the helper waves leave after
+// the set-up phase and the walk loop carries none of that machinery (it cost the default path ~10 % of the walk).
+template <bool REEVAL>
 static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) {
   ResolveLds& L = *reinterpret_cast<ResolveLds*>(lds);
   auto& s_job = L.job;
@@ -929,6 +932,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     }
   };
   if (tid >= COOK_WAVE) {  // helper waves: sleep at the barrier until wave 0 asks for a re-evaluation or finishes the walk
+    if constexpr (!REEVAL) return;
     for (;;) {
       EMU_SITE("resolve: helper waiting");
       __syncthreads();
@@ -1202,11 +1206,12 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     // --- list exhausted: the whole workgroup evaluates this one job against the current state ---------------------------------
     int re_bits = -1;  // >= 0: the exact failure summary of an unmatched re-evaluated job
     if (exhausted) {
-      if (n_exhaust >= ctl.reeval_max) {  // end the round here: the next round evaluates the rest of the window afresh
+      if (!REEVAL || n_exhaust >= ctl.reeval_max) {  // end the round here: the next round evaluates the rest of the window afresh
         stop = 1;
         resolved = b;
         break;
       }
+      if constexpr (REEVAL) {
       if (t_slot >= 0) {
         s_tac[lane] = t_ac;
         s_tam[lane] = t_am;
@@ -1279,6 +1284,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
           win_slot = slot;
         }
       }
+      }  // if constexpr (REEVAL)
     }
     // --- commit --------------------------------------------------------------------------------------------------------------
     if (win_lane >= 0) {  // an offer touched earlier in this round takes the job
@@ -1386,9 +1392,11 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     }
   }
   if (stop == 0 && weff < nwin) stop = 4;
-  if (lane == 0) s_cmd = -1;  // release the helper waves
-  EMU_SITE("resolve: walker done");
-  __syncthreads();
+  if constexpr (REEVAL) {
+    if (lane == 0) s_cmd = -1;  // release the helper waves
+    EMU_SITE("resolve: walker done");
+    __syncthreads();
+  }
   // flush the results of the jobs resolved, write the touched offers' state back and publish the new head
   wave_sync();
   for (unsigned x = lane; x < resolved; x += COOK_WAVE) {
@@ -1435,7 +1443,11 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
 
 __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2(MatchState st, V2Buf vb) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(ResolveLds)];
-  resolve_round(lds, st, vb);
+  resolve_round<false>(lds, st, vb);
+}
+__global__ void __launch_bounds__(MV_RTHREADS) match_resolve2_reeval(MatchState st, V2Buf vb) {
+  __shared__ __attribute__((aligned(16))) char lds[sizeof(ResolveLds)];
+  resolve_round<true>(lds, st, vb);
 }
 
 // ---- persistent placement kernel ---------------------------------------------------------------------------------------------
@@ -1518,7 +1530,7 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_persist(MatchIn in, MatchSt
     if (!grid_barrier(pc, nb)) return;
     if (wg == 0) {
       const unsigned long long t2 = cook_ticks();
-      resolve_round(lds, st, vb);
+      resolve_round<false>(lds, st, vb);
       __syncthreads();
       if (threadIdx.x == 0) {
         vb.ctl->t_eval += t1 - t0;
@@ -1553,5 +1565,5 @@ __global__ void __launch_bounds__(COOK_WAVE) match_merge2_multi(const PoolCtx* _
 __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2_multi(const PoolCtx* __restrict__ ctx) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(ResolveLds)];
   const PoolCtx& c = ctx[blockIdx.z];
-  resolve_round(lds, c.st, c.vb);
+  resolve_round<false>(lds, c.st, c.vb);
 }

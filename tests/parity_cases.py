@@ -355,3 +355,35 @@ def multi_pool_parity(make_engine, pools, params, k):
         o_j2o, _, o_head = pyoracle.match(params, pool.pending_jobs.take(pend_ord[o_ranked[:kk]]), pool.offers, pool.groups)
         assert np.array_equal(j2o, o_j2o) and head == o_head
     return got
+
+
+def edge_cases(make_engine):
+    """Empty and degenerate inputs through the C ABI: they must behave like the oracle, not crash."""
+    prm = A.default_params(good_enough_fitness=1.0)
+    pool = synth.make_pool(seed=81, n_pending=40, n_running=10, n_users=5, n_offers=6)
+    none_off = A.Offers(cpus=np.zeros(0), mem=np.zeros(0))
+    none_job = A.Jobs(cpus=np.zeros(0), mem=np.zeros(0))
+    # no offers: every job unmatched, failure code "nothing evaluated" (8); head-matched-or-no-matches is true
+    j2o = match_parity(make_engine, pool.pending_jobs, none_off, None, prm)
+    assert (j2o < 0).all()
+    # no jobs
+    with make_engine(prm) as e:
+        j2o, fail, head = e.match(none_job, pool.offers)
+    assert len(j2o) == 0 and head
+    # offers nobody fits: zero capacity
+    zero = A.Offers(cpus=np.zeros(4), mem=np.zeros(4))
+    assert (match_parity(make_engine, pool.pending_jobs, zero, None, prm) < 0).all()
+    # a cycle that considers nothing
+    with make_engine(prm) as e:
+        e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        e.cycle_run(0)
+        ranked, j2o, head = e.cycle_fetch()
+    assert len(ranked) == pool.n_pending and len(j2o) == 0 and head
+    # rebalancer: nothing pending / no budget
+    b = make_rebalance_case(seed=82, n_running=50, n_pending=0, n_users=4, n_hosts=5)
+    assert rebalance_parity(make_engine, b)["decisions"] == []
+    b = make_rebalance_case(seed=83, n_running=50, n_pending=6, n_users=4, n_hosts=5, max_preemption=0)
+    assert rebalance_parity(make_engine, b)["decisions"] == []
+    # considerable: K = 0
+    queue, st = make_considerable_case(seed=84, n=30, n_users=4)
+    assert len(considerable_parity(make_engine, queue, st, 0)) == 0

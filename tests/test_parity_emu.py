@@ -205,3 +205,7 @@ def test_multi_pool_lockstep(make_engine):
              synth.make_pool(seed=72, n_pending=150, n_running=50, n_users=10, n_offers=40),
              synth.make_pool(seed=73, n_pending=0, n_running=30, n_users=5, n_offers=20)]
     P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0), k=300)
+
+
+def test_edge_cases(make_engine):
+    P.edge_cases(make_engine)

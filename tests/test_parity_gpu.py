@@ -236,3 +236,7 @@ def test_multi_pool_lockstep(make_engine):
              synth.make_pool(seed=73, n_pending=0, n_running=30, n_users=5, n_offers=20),
              synth.make_pool(seed=74, n_pending=5000, n_running=0, n_users=80, n_offers=150)]
     P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0), k=4000)
+
+
+def test_edge_cases(make_engine):
+    P.edge_cases(make_engine)
