@@ -404,8 +404,137 @@ REBALANCE = [
          expect_jobs_to_run=[f"job{i}" for i in range(19, 29)], expect_tasks_to_preempt=["t4", "t3", "t8"]),
 ]
 
-# constraints truth tables (test/cook/test/scheduler/constraints.clj)
+# constraints truth tables (test/cook/test/scheduler/constraints.clj): one job, one VM with ample cpus/mem; the job is matched
+# iff the constraint under test passes.  Extra job fields: equals [[attribute, pattern]], novel [hostnames], disk {request, type}
+# (after the pool's defaulting / type-map, constraints.clj:105-120), est_end_ms, group; offer fields: host, attrs, disk {type: MiB},
+# host_start_s, run_count (tasks running or assigned on the VM); case fields: groups, reserved_hosts, host_lifetime_mins.
 T_CON = "test/cook/test/scheduler/constraints.clj"
+_BIG = dict(cpus=40.0, mem=5000.0)
+_UD = [["is_spot", "true"], ["instance_type", "mem.large"]]
+_P100, _K80 = "nvidia-tesla-p100", "nvidia-tesla-k80"
+
+
+def _one(name, ref, j, o, ok, **kw):
+    return dict(name=name, ref=ref, good_enough=0.8, jobs=[dict(job("j", "u", 5.0, 5.0), **j)], offers=[dict(_BIG, **o)],
+                expect_matched=(["j"] if ok else []), **kw)
+
+
+CONSTRAINTS = [
+    _one(f"user-defined EQUALS vs {attrs}", f"{T_CON}:43-57", dict(equals=_UD), dict(attrs=attrs), ok)
+    for attrs, ok in (({"is_spot": "true", "instance_type": "mem.large"}, True), ({"is_spot": "true", "instance_type": "cpu.large"}, False),
+                      ({"is_spot": "false", "instance_type": "mem.large"}, False), ({"is_spot": "true"}, False),
+                      ({"instance_type": "mem.large"}, False), ({}, False))
+] + [
+    _one("gpu: 1 gpu asked, VM has 4 (count must match exactly)", f"{T_CON}:112-122", dict(gpus=1, gpu_model=_P100),
+         dict(k8s=True, gpu_model=_P100, gpu_count=4), False),
+    _one("gpu: 8 gpus asked, VM has 4", f"{T_CON}:123-132", dict(gpus=8, gpu_model=_P100), dict(k8s=True, gpu_model=_P100, gpu_count=4), False),
+    _one("gpu: right count, wrong model", f"{T_CON}:133-142", dict(gpus=4, gpu_model=_K80), dict(k8s=True, gpu_model=_P100, gpu_count=4), False),
+    _one("gpu: right count and model", f"{T_CON}:143-152", dict(gpus=4, gpu_model=_P100), dict(k8s=True, gpu_model=_P100, gpu_count=4), True),
+    _one("gpu: one GPU job per VM (a task is already assigned)", f"{T_CON}:153-163", dict(gpus=4, gpu_model=_P100),
+         dict(k8s=True, gpu_model=_P100, gpu_count=4, run_count=1), False),
+    _one("gpu: non-gpu job on a gpu VM", f"{T_CON}:164-173", dict(), dict(k8s=True, gpu_model=_P100, gpu_count=4), False),
+    _one("gpu: gpu job on a k8s VM without gpus", f"{T_CON}:174-183", dict(gpus=1, gpu_model=_P100), dict(k8s=True), False),
+    _one("gpu: non-gpu job on a k8s VM without gpus", f"{T_CON}:184-193", dict(), dict(k8s=True), True),
+    _one("gpu: gpu job on a mesos VM", f"{T_CON}:194-203", dict(gpus=1.0), dict(), False),
+    _one("gpu: non-gpu job on a mesos VM", f"{T_CON}:204-213", dict(), dict(), True),
+    _one("disk: enough space, right type (type-map standard -> pd-standard)", f"{T_CON}:262-271", dict(disk=dict(request=10.0, type="pd-standard")),
+         dict(k8s=True, disk={"pd-standard": 50}), True),
+    _one("disk: request == space, default type", f"{T_CON}:272-281", dict(disk=dict(request=50.0, type="pd-standard")),
+         dict(k8s=True, disk={"pd-standard": 50}), True),
+    _one("disk: not enough space", f"{T_CON}:282-291", dict(disk=dict(request=100.0, type="pd-standard")), dict(k8s=True, disk={"pd-standard": 50}), False),
+    _one("disk: wrong type", f"{T_CON}:292-300", dict(disk=dict(request=10.0, type="pd-ssd")), dict(k8s=True, disk={"pd-standard": 50}), False),
+    _one("rebalancer reservation: VM reserved for another job", f"{T_CON}:332-340", dict(), dict(host="hostB"), False, reserved_hosts=["hostB"]),
+    _one("rebalancer reservation: VM not reserved", f"{T_CON}:341-349", dict(), dict(host="hostA"), True, reserved_hosts=["hostB"]),
+    _one("estimated completion: VM without host-start-time", f"{T_CON}:432-437", dict(est_end_ms=100000), dict(), True, host_lifetime_mins=1),
+    _one("estimated completion: host started at 0 s, dies at 60 s < end 100 s", f"{T_CON}:438", dict(est_end_ms=100000), dict(host_start_s=0), False,
+         host_lifetime_mins=1),
+    _one("estimated completion: host started at 51 s, dies at 111 s > end 100 s", f"{T_CON}:439", dict(est_end_ms=100000), dict(host_start_s=51), True,
+         host_lifetime_mins=1),
+]
+
+# group host-placement through Fenzo (test/cook/test/scheduler/scheduler.clj:982-1155): dummy jobs are 1 cpu / 10 MB, test VMs
+# 100 cpus / 100 000 MB, good-enough 0.8 (make-dummy-scheduler, :79-92)
+_VM = dict(cpus=100.0, mem=100000.0)
+
+
+def _dj(i, group=None, cpus=1.0):
+    return dict(job(f"g{i}", "u", cpus, 10.0), group=group)
+
+
+GROUPS_FENZO = [
+    dict(name="unique group: conflicting jobs, different cycles (cotask already runs on the host)", ref=f"{T_SCHED}:986-1013", good_enough=0.8,
+         jobs=[_dj(1, "G")], offers=[dict(_VM, host="test-host")], groups={"G": dict(type="unique", running_hosts=["test-host"])},
+         expect_matched=[]),
+    dict(name="unique group: conflicting jobs, same cycle", ref=f"{T_SCHED}:1014-1041", good_enough=0.8,
+         jobs=[_dj(1, "G"), _dj(2, "G")], offers=[dict(_VM, host="test-host")], groups={"G": dict(type="unique")}, expect_matched=["g1"]),
+    dict(name="no group: both jobs fit the host", ref=f"{T_SCHED}:1042-1049", good_enough=0.8, jobs=[_dj(1), _dj(2)],
+         offers=[dict(_VM, host="test-host")], expect_matched=["g1", "g2"]),
+    dict(name="balanced group (HOSTNAME, minimum 3): 9 jobs on 3 hosts -> 3 each", ref=f"{T_SCHED}:1055-1073", good_enough=0.8,
+         jobs=[_dj(i, "B") for i in range(9)], offers=[dict(_VM, host=h) for h in ("straw", "sticks", "bricks")],
+         groups={"B": dict(type="balanced", attribute="HOSTNAME", minimum=3)}, expect_matched=[f"g{i}" for i in range(9)],
+         expect_counts={"straw": 3, "sticks": 3, "bricks": 3}),
+    dict(name="no group: 9 jobs on 3 hosts are bin-packed, not balanced", ref=f"{T_SCHED}:1074-1086", good_enough=0.8,
+         jobs=[_dj(i) for i in range(9)], offers=[dict(_VM, host=h) for h in ("straw", "sticks", "bricks")],
+         expect_matched=[f"g{i}" for i in range(9)], expect_not_counts={"straw": 3, "sticks": 3, "bricks": 3}),
+    dict(name="attribute-equals group: cotask runs on az=east, 20 jobs pile up on the one east VM (5 cpus)", ref=f"{T_SCHED}:1103-1136", good_enough=0.8,
+         jobs=[_dj(i, "A") for i in range(20)],
+         offers=[dict(cpus=1.0, mem=100000.0, host=f"w{i:02d}", attrs={"az": "west"}) for i in range(20)] + [dict(cpus=5.0, mem=100000.0, host="east1", attrs={"az": "east"})],
+         groups={"A": dict(type="attribute-equals", attribute="az", running_hosts=["east0"], running_attrs=["east"])},
+         expect_n_matched=5, expect_counts={"east1": 5}),
+    dict(name="no group: 20 jobs use every VM", ref=f"{T_SCHED}:1137-1153", good_enough=0.8, jobs=[_dj(i) for i in range(20)],
+         offers=[dict(cpus=1.0, mem=100000.0, host=f"w{i:02d}", attrs={"az": "west"}) for i in range(15)] + [dict(cpus=5.0, mem=100000.0, host="east1", attrs={"az": "east"})],
+         expect_n_matched=20),
+]
+
+# handle-resource-offers! end to end (scheduler.clj:1803-2256): 8 jobs in rank order; with the pool's disk constraint enabled every job
+# carries one (default request 10 000 of type standard -> pd-standard, constraints.clj:105-120)
+_PDS = dict(request=10000.0, type="pd-standard")
+_HRO8 = [dict(job("job-1", "u", 3, 2048), disk=_PDS), dict(job("job-2", "u", 13, 1024), disk=_PDS), dict(job("job-3", "u", 7, 4096), disk=_PDS),
+         dict(job("job-4", "u", 11, 1024), disk=_PDS), dict(job("job-5", "u", 5, 2048, gpus=2, gpu_model=_P100), disk=_PDS),
+         dict(job("job-6", "u", 19, 1024, gpus=4, gpu_model=_P100), disk=_PDS),
+         dict(job("job-7", "u", 1, 2048), disk=dict(request=250000.0, type="pd-ssd")), dict(job("job-8", "u", 2, 2048), disk=dict(request=10000.0, type="pd-ssd"))]
+
+
+def _k8s(c, m, gpus=None, disk=None, host=None):
+    d = dict(cpus=c, mem=m, k8s=True, disk=disk or {"pd-standard": 512000})
+    if gpus:
+        d.update(gpu_model=_P100, gpu_count=gpus)
+    if host:
+        d.update(host=host)
+    return d
+
+
+_KO = {1: _k8s(10, 2048), 2: _k8s(20, 16384), 3: _k8s(30, 8192), 4: _k8s(4, 2048), 5: _k8s(4, 1024), 6: _k8s(10, 4096, gpus=2),
+       7: _k8s(20, 4096, gpus=4), 8: _k8s(30, 16384, gpus=1), 9: _k8s(100, 200000), 10: _k8s(30, 2048, disk={"pd-ssd": 500000}),
+       11: _k8s(30, 2048, disk={"pd-ssd": 200000})}
+_MO = {i: dict(cpus=c, mem=m) for i, (c, m) in enumerate([(10, 2048), (20, 16384), (30, 8192), (4, 2048), (4, 1024), (10, 4096), (20, 4096),
+                                                          (30, 16384), (100, 200000)], start=1)}
+
+
+def _hro(name, line, offers, expect, jobs=None, head=None, **kw):
+    d = dict(name=f"handle-resource-offers: {name}", ref=f"{T_SCHED}:{line}", good_enough=0.8, jobs=jobs or _HRO8, offers=offers,
+             expect_matched=expect, **kw)
+    if head is not None:
+        d["expect_head_matched"] = head
+    return d
+
+
+HRO = [
+    _hro("offer for single job", "2054-2061", [_KO[4]], ["job-1"]),
+    _hro("offer for first three jobs", "2063-2070", [_KO[3]], ["job-1", "job-2", "job-3"]),
+    _hro("offer not fit for any job", "2072-2078", [_KO[5]], []),
+    _hro("will not launch jobs on reserved host", "2110-2118", [dict(_KO[1], host="h1")], [], reserved_hosts=["h1"]),
+    _hro("only launches reserved jobs on reserved host", "2120-2137", [dict(_KO[9], host="h9")], ["job-1", "job-2"], reserved_hosts=["h9"],
+         jobs=[dict(j, reserved_host="h9") if j["name"] in ("job-1", "job-2") else j for j in _HRO8]),
+    _hro("mesos: all offers for all jobs (gpu jobs never match)", "2161-2168", [_MO[i] for i in range(1, 10)],
+         ["job-1", "job-2", "job-3", "job-4", "job-7", "job-8"]),
+    _hro("k8s: all offers for all jobs", "2199-2206", [_KO[i] for i in range(1, 12)], [f"job-{i}" for i in range(1, 9)]),
+    _hro("k8s gpu offers for all gpu jobs", "2208-2215", [_KO[6], _KO[7]], ["job-5", "job-6"], head=False),
+    _hro("k8s gpu offer for single gpu job", "2217-2224", [_KO[6]], ["job-5"], head=False),
+    _hro("k8s gpu offer matching no gpu job", "2226-2232", [_KO[8]], [], head=True),
+    _hro("disk offer matching job requesting same disk type", "2235-2242", [_KO[10]], ["job-7"], head=False),
+    _hro("disk offer matching no job (K = 7)", "2244-2250", [_KO[11]], [], jobs=_HRO8[:7], head=True),
+]
 
 
 # ---- considerable jobs (scheduler.clj:729-762; tools.clj:903-973) -------------------------------------------------------
@@ -472,7 +601,7 @@ CONSIDERABLE = [
 
 
 def main():
-    out = dict(rank=RANK, rank_group=RANK_GROUP, quota_group_agg=QUOTA_GROUP_AGG, match=MATCH, rebalance=REBALANCE, considerable=CONSIDERABLE)
+    out = dict(rank=RANK, rank_group=RANK_GROUP, quota_group_agg=QUOTA_GROUP_AGG, match=MATCH + CONSTRAINTS + GROUPS_FENZO + HRO, rebalance=REBALANCE, considerable=CONSIDERABLE)
     for k, v in out.items():
         with open(os.path.join(HERE, f"{k}.json"), "w") as f:
             json.dump(v, f, indent=1, sort_keys=True)

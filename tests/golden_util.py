@@ -57,32 +57,126 @@ def usage_of(q):
 
 
 def build_match_inputs(case):
+    """-> (Jobs, Offers, job names) — plus, for the extended vectors, build_match_extras(case)."""
+    J, O, names, _ = build_match_all(case)
+    return J, O, names
+
+
+def build_match_all(case):
+    """-> (Jobs, Offers, job names, extras) with extras = dict(groups, reserved (host ids), host_names, params overrides)."""
     jobs, offers = case["jobs"], case["offers"]
-    models, locs = {}, {}
+    models, locs, dtypes, keys, vals = {}, {}, {}, {}, {}
 
     def intern(table, key):
         if key is None:
             return 0
         return table.setdefault(key, len(table) + 1)
 
+    # hosts: named offers first, then hosts that only appear in constraints; ids = name ranks (cookmatch.h contract)
+    hnames = [o.get("host", f"~offer{i:04d}") for i, o in enumerate(offers)]
+    extra_hosts = set(case.get("reserved_hosts", []))
+    for j in jobs:
+        extra_hosts |= set(j.get("novel", []))
+        if j.get("reserved_host"):
+            extra_hosts.add(j["reserved_host"])
+    for gdef in case.get("groups", {}).values():
+        extra_hosts |= set(gdef.get("running_hosts", []))
+    all_hosts = sorted(set(hnames) | extra_hosts)
+    hid = {h: i for i, h in enumerate(all_hosts)}
+    for o in offers:
+        for k_ in o.get("attrs", {}):
+            keys.setdefault(k_, len(keys))
+    for j in jobs:
+        for k_, _v in j.get("equals", []):
+            keys.setdefault(k_, len(keys))
+    for gdef in case.get("groups", {}).values():
+        if gdef.get("attribute") not in (None, "HOSTNAME"):
+            keys.setdefault(gdef["attribute"], len(keys))
+    gnames = sorted(case.get("groups", {}))
+    gid = {n: i for i, n in enumerate(gnames)}
     K = len(jobs)
-    J = A.Jobs(
-        cpus=np.array([float(j["cpus"]) for j in jobs], dtype=np.float64),
-        mem=np.array([float(j["mem"]) for j in jobs], dtype=np.float64),
-        gpus=np.array([float(j.get("gpus", 0.0)) for j in jobs], dtype=np.float64),
-        gpu_model=np.array([intern(models, j.get("gpu_model")) for j in jobs], dtype=np.uint32),
-        ckpt_location=np.array([intern(locs, j.get("ckpt_location")) for j in jobs], dtype=np.uint32),
-    ) if K else A.Jobs(cpus=np.zeros(0), mem=np.zeros(0))
+    if K:
+        J = A.Jobs.with_constraints(
+            np.array([float(j["cpus"]) for j in jobs], dtype=np.float64), np.array([float(j["mem"]) for j in jobs], dtype=np.float64),
+            equals=[[(keys[k_], intern(vals, v_)) for k_, v_ in j.get("equals", [])] for j in jobs],
+            novel=[[hid[h] for h in j.get("novel", [])] for j in jobs],
+            gpus=np.array([float(j.get("gpus", 0.0)) for j in jobs], dtype=np.float64),
+            gpu_model=np.array([intern(models, j.get("gpu_model")) for j in jobs], dtype=np.uint32),
+            ckpt_location=np.array([intern(locs, j.get("ckpt_location")) for j in jobs], dtype=np.uint32),
+            group=np.array([gid[j["group"]] if j.get("group") else A.NONE_U32 for j in jobs], dtype=np.uint32),
+            reserved_host=np.array([hid[j["reserved_host"]] if j.get("reserved_host") else -1 for j in jobs], dtype=np.int32),
+            est_end_ms=np.array([int(j.get("est_end_ms", 0)) for j in jobs], dtype=np.int64),
+            disk_request=np.array([float(j["disk"]["request"]) if j.get("disk") else -1.0 for j in jobs], dtype=np.float64),
+            disk_type=np.array([intern(dtypes, j["disk"]["type"]) if j.get("disk") else 0 for j in jobs], dtype=np.uint32))
+    else:
+        J = A.Jobs(cpus=np.zeros(0), mem=np.zeros(0))
     M = len(offers)
+    n_keys = max(1, len(keys))
+    attr = np.zeros((M, n_keys), dtype=np.uint32)
+    for i, o in enumerate(offers):
+        for k_, v_ in o.get("attrs", {}).items():
+            attr[i, keys[k_]] = intern(vals, v_)
+
+    def one_disk(o):
+        d = o.get("disk") or {}
+        assert len(d) <= 1
+        return next(iter(d.items())) if d else (None, 0.0)
+
     O = A.Offers(
         cpus=np.array([float(o["cpus"]) for o in offers], dtype=np.float64),
         mem=np.array([float(o["mem"]) for o in offers], dtype=np.float64),
+        host=np.array([hid[h] for h in hnames], dtype=np.uint32),
         k8s=np.array([1 if o.get("k8s") else 0 for o in offers], dtype=np.uint8),
         gpu_model=np.array([intern(models, o.get("gpu_model")) for o in offers], dtype=np.uint32),
         gpu_count=np.array([float(o.get("gpu_count", 0.0)) for o in offers], dtype=np.float64),
+        disk_type=np.array([intern(dtypes, one_disk(o)[0]) for o in offers], dtype=np.uint32),
+        disk_space=np.array([float(one_disk(o)[1]) for o in offers], dtype=np.float64),
+        attr=attr,
         location=np.array([intern(locs, o.get("location")) for o in offers], dtype=np.uint32),
+        host_start_s=np.array([int(o["host_start_s"]) if "host_start_s" in o else -1 for o in offers], dtype=np.int64),
+        run_count=np.array([int(o.get("run_count", 0)) for o in offers], dtype=np.int32),
     )
-    return J, O, [j["name"] for j in jobs]
+    G = None
+    if gnames:
+        gd = case["groups"]
+
+        def key_of(g_):
+            a_ = gd[g_].get("attribute")
+            return A.NONE_U32 if a_ in (None, "HOSTNAME") else keys[a_]
+
+        G = A.Groups(type=np.array([GROUP_TYPE[gd[g_]["type"]] for g_ in gnames], dtype=np.uint8),
+                     attr_key=np.array([key_of(g_) for g_ in gnames], dtype=np.uint32),
+                     minimum=np.array([gd[g_].get("minimum", 0) for g_ in gnames], dtype=np.int32),
+                     run_hosts=[[hid[h] for h in gd[g_].get("running_hosts", [])] for g_ in gnames],
+                     run_attrs=[[intern(vals, v_) for v_ in gd[g_].get("running_attrs", [])] or [0] * len(gd[g_].get("running_hosts", []))
+                                for g_ in gnames])
+    extras = dict(groups=G, reserved=[hid[h] for h in case.get("reserved_hosts", [])], host_names=hnames,
+                  params=dict(host_lifetime_mins=int(case["host_lifetime_mins"])) if "host_lifetime_mins" in case else {})
+    return J, O, [j["name"] for j in jobs], extras
+
+
+def check_match_expectations(case, names, host_names, j2o, head):
+    """The reference's assertions on a placement: which jobs matched, how many per host, the head-matched flag."""
+    matched = sorted(names[k] for k in range(len(names)) if j2o[k] >= 0)
+    if "expect_matched" in case and "expect_n_matched" not in case:
+        assert matched == sorted(case["expect_matched"]), (case["name"], case["ref"], matched)
+    if "expect_n_matched" in case:
+        assert len(matched) == case["expect_n_matched"], (case["name"], case["ref"], matched)
+    counts = {}
+    for k in range(len(names)):
+        if j2o[k] >= 0:
+            counts[host_names[j2o[k]]] = counts.get(host_names[j2o[k]], 0) + 1
+    if "expect_counts" in case:
+        assert counts == case["expect_counts"], (case["name"], case["ref"], counts)
+    if "expect_not_counts" in case:
+        assert counts != case["expect_not_counts"], (case["name"], case["ref"], counts)
+    if "expect_head_matched" in case:
+        assert bool(head) == case["expect_head_matched"], (case["name"], case["ref"])
+    if "expect_offers_used" in case:
+        assert len(counts) == case["expect_offers_used"], (case["name"], case["ref"])
+    if "expect_assignment" in case:
+        for n_, o_ in case["expect_assignment"].items():
+            assert j2o[names.index(n_)] == o_, (case["name"], case["ref"])
 
 
 GROUP_TYPE = {"all": 0, "unique": 1, "balanced": 2, "attribute-equals": 3}

@@ -43,16 +43,15 @@ def check_rank_group_golden(make_engine):
 
 def check_match_golden(make_engine):
     for case in G.load("match"):
-        J, O, names = G.build_match_inputs(case)
-        p = A.default_params(good_enough_fitness=case["good_enough"])
+        J, O, names, x = G.build_match_all(case)
+        p = A.default_params(good_enough_fitness=case["good_enough"], **x["params"])
         with make_engine(p) as e:
-            j2o, fail, head = e.match(J, O)
-        o_j2o, o_fail, o_head = pyoracle.match(p, J, O)
+            j2o, fail, head = e.match(J, O, x["groups"], x["reserved"])
+        o_j2o, o_fail, o_head = pyoracle.match(p, J, O, x["groups"], x["reserved"])
         assert np.array_equal(j2o, o_j2o), case["name"]
         assert np.array_equal(fail, o_fail), case["name"]
         assert head == o_head, case["name"]
-        matched = sorted(names[k] for k in range(J.n) if j2o[k] >= 0)
-        assert matched == sorted(case["expect_matched"]), (case["name"], case["ref"])
+        G.check_match_expectations(case, names, x["host_names"], j2o, head)
 
 
 def rank_parity(make_engine, pool: synth.Pool, params, quota=None):

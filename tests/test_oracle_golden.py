@@ -65,22 +65,15 @@ def test_quota_group_aggregate_golden():
 
 @pytest.mark.parametrize("case", MATCH, ids=[c["name"] for c in MATCH])
 def test_match_golden(oracle, case):
-    J, O, names = G.build_match_inputs(case)
-    p = A.default_params(good_enough_fitness=case["good_enough"])
-    j2o, fail, head = oracle.match(p, J, O)
-    matched = [names[k] for k in range(J.n) if j2o[k] >= 0]
-    if "expect_n_matched" in case:
-        assert len(matched) == case["expect_n_matched"], case["ref"]
-    assert sorted(matched) == sorted(case["expect_matched"]), case["ref"]
-    if "expect_offers_used" in case:
-        assert len({int(v) for v in j2o if v >= 0}) == case["expect_offers_used"], case["ref"]
-    if "expect_assignment" in case:
+    J, O, names, x = G.build_match_all(case)
+    p = A.default_params(good_enough_fitness=case["good_enough"], **x["params"])
+    j2o, fail, head = oracle.match(p, J, O, x["groups"], x["reserved"])
+    G.check_match_expectations(case, names, x["host_names"], j2o, head)
+    if "expect_assignment" in case and "expect_n_matched" not in case:
         assert {names[k]: int(j2o[k]) for k in range(J.n) if j2o[k] >= 0} == case["expect_assignment"], case["ref"]
-    if "expect_head_matched" in case:
-        assert head == case["expect_head_matched"]
     # multi-thread CPU baseline variant gives the same placement when good-enough is disabled
     if case["good_enough"] >= 1.0 and J.n:
-        j2o8, _, _ = oracle.match(p, J, O, nthreads=4)
+        j2o8, _, _ = oracle.match(p, J, O, x["groups"], x["reserved"], nthreads=4)
         assert np.array_equal(j2o, j2o8)
 
 
