@@ -273,3 +273,87 @@ JNIEXPORT jint JNICALL Java_cook_hip_Native_rebalance(JNIEnv* env, jclass c, jlo
                         BUF(uint32_t, n_decisions_out), BUF(uint32_t, preempted_out), BUF(uint32_t, n_preempted_out),
                         BUF(double, pending_dru_out));
 }
+
+/* ---- offers: the numeric core of kubernetes.compute-cluster/generate-offers (compute_cluster.clj:68-190) ------------ */
+static cook_nodes nodes_of(JNIEnv* env, jint n, jint n_attr_keys, jobjectArray a) {
+  cook_nodes v;
+  v.n = (uint32_t)n;
+  v.host = EL(const uint32_t, a, 0);
+  v.cpus = EL(const double, a, 1);
+  v.mem = EL(const double, a, 2);
+  v.gpus = EL(const int32_t, a, 3);
+  v.gpu_model = EL(const uint32_t, a, 4);
+  v.disk = EL(const double, a, 5);
+  v.disk_type = EL(const uint32_t, a, 6);
+  v.flags = EL(const uint8_t, a, 7);
+  v.n_attr_keys = (uint32_t)n_attr_keys;
+  v.attr = EL(const uint32_t, a, 8);
+  return v;
+}
+static cook_pods pods_of(JNIEnv* env, jint n, jobjectArray a) {
+  cook_pods p;
+  p.n = (uint32_t)n;
+  p.node = EL(const uint32_t, a, 0);
+  p.cpus = EL(const double, a, 1);
+  p.mem = EL(const double, a, 2);
+  p.gpus = EL(const int32_t, a, 3);
+  p.gpu_model = EL(const uint32_t, a, 4);
+  p.disk = EL(const double, a, 5);
+  p.disk_type = EL(const uint32_t, a, 6);
+  p.flags = EL(const uint8_t, a, 7);
+  return p;
+}
+/* offer_cols: the ten output columns of cook_node_offers as direct buffers, header field order; totals: one direct buffer
+ * holding a cook_offer_totals; by_model_type: {gpu capacity, gpu consumed, disk capacity, disk consumed} buffers or nulls. */
+JNIEXPORT jint JNICALL Java_cook_hip_Native_offersBuild(JNIEnv* env, jclass c, jlong h, jint n_nodes, jint n_attr_keys,
+                                                        jobjectArray nodes, jint n_pods, jobjectArray pods, jobject oparams,
+                                                        jobjectArray offer_cols, jobject n_offers_out, jobject node_status_out,
+                                                        jobject totals_out, jobjectArray by_model_type) {
+  cook_nodes nd = nodes_of(env, n_nodes, n_attr_keys, nodes);
+  cook_pods pd = pods_of(env, n_pods, pods);
+  cook_node_offers o;
+  (void)c;
+  o.node = EL(uint32_t, offer_cols, 0);
+  o.host = EL(uint32_t, offer_cols, 1);
+  o.cpus = EL(double, offer_cols, 2);
+  o.mem = EL(double, offer_cols, 3);
+  o.gpu_model = EL(uint32_t, offer_cols, 4);
+  o.gpu_count = EL(double, offer_cols, 5);
+  o.disk_type = EL(uint32_t, offer_cols, 6);
+  o.disk_space = EL(double, offer_cols, 7);
+  o.num_pods = EL(int32_t, offer_cols, 8);
+  o.attr = EL(uint32_t, offer_cols, 9);
+  return cook_offers_build(H(h), &nd, &pd, BUF(const cook_offer_params, oparams), &o, BUF(uint32_t, n_offers_out),
+                           BUF(uint8_t, node_status_out), BUF(cook_offer_totals, totals_out), EL(int64_t, by_model_type, 0),
+                           EL(int64_t, by_model_type, 1), EL(double, by_model_type, 2), EL(double, by_model_type, 3));
+}
+/* staged form: node / pod state stays resident between cycles, run = kernels only */
+JNIEXPORT jint JNICALL Java_cook_hip_Native_offersStage(JNIEnv* env, jclass c, jlong h, jint n_nodes, jint n_attr_keys, jobjectArray nodes,
+                                                        jint n_pods, jobjectArray pods, jobject oparams) {
+  cook_nodes nd = nodes_of(env, n_nodes, n_attr_keys, nodes);
+  cook_pods pd = pods_of(env, n_pods, pods);
+  (void)c;
+  return cook_offers_stage(H(h), &nd, &pd, BUF(const cook_offer_params, oparams));
+}
+JNIEXPORT jint JNICALL Java_cook_hip_Native_offersRun(JNIEnv* env, jclass c, jlong h) {
+  (void)env, (void)c;
+  return cook_offers_run(H(h));
+}
+JNIEXPORT jint JNICALL Java_cook_hip_Native_offersFetch(JNIEnv* env, jclass c, jlong h, jobjectArray offer_cols, jobject n_offers_out,
+                                                        jobject node_status_out, jobject totals_out, jobjectArray by_model_type) {
+  cook_node_offers o;
+  (void)c;
+  o.node = EL(uint32_t, offer_cols, 0);
+  o.host = EL(uint32_t, offer_cols, 1);
+  o.cpus = EL(double, offer_cols, 2);
+  o.mem = EL(double, offer_cols, 3);
+  o.gpu_model = EL(uint32_t, offer_cols, 4);
+  o.gpu_count = EL(double, offer_cols, 5);
+  o.disk_type = EL(uint32_t, offer_cols, 6);
+  o.disk_space = EL(double, offer_cols, 7);
+  o.num_pods = EL(int32_t, offer_cols, 8);
+  o.attr = EL(uint32_t, offer_cols, 9);
+  return cook_offers_fetch(H(h), &o, BUF(uint32_t, n_offers_out), BUF(uint8_t, node_status_out), BUF(cook_offer_totals, totals_out),
+                           EL(int64_t, by_model_type, 0), EL(int64_t, by_model_type, 1), EL(double, by_model_type, 2),
+                           EL(double, by_model_type, 3));
+}

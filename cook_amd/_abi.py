@@ -543,3 +543,160 @@ class HostSpare:
     def as_struct(self) -> CookHostSpare:
         return CookHostSpare(len(self.host), _ptr(self.host, _u32p), _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p),
                              _ptr(self.gpus, _f64p))
+
+
+# ---- offer construction from node state (kubernetes/compute_cluster.clj:68-190) ---------------------------------------
+NODE_UNSCHEDULABLE, NODE_OTHER_TAINTS, NODE_BLOCKLIST_LABEL, NODE_GPU_TAINT = 1, 2, 4, 8
+POD_SYNTHETIC, POD_NO_REQUESTS = 1, 2
+NODE_ST_OFFER, NODE_ST_CONSUMED, NODE_ST_FOREIGN_GPU, NODE_ST_FOREIGN_DISK = 1, 2, 4, 8
+
+
+class CookNodes(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("host", _u32p), ("cpus", _f64p), ("mem", _f64p), ("gpus", _i32p), ("gpu_model", _u32p),
+        ("disk", _f64p), ("disk_type", _u32p), ("flags", _u8p),
+        ("n_attr_keys", C.c_uint32), ("attr", _u32p),
+    ]
+
+
+class CookPods(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("node", _u32p), ("cpus", _f64p), ("mem", _f64p), ("gpus", _i32p), ("gpu_model", _u32p),
+        ("disk", _f64p), ("disk_type", _u32p), ("flags", _u8p),
+    ]
+
+
+class CookOfferParams(C.Structure):
+    _fields_ = [
+        ("clobber_synthetic_pods", C.c_int32), ("filter_out_unsound_gpu_nodes", C.c_int32),
+        ("max_pods_per_node", C.c_int32), ("n_gpu_models", C.c_uint32), ("n_disk_types", C.c_uint32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class CookNodeOffers(C.Structure):
+    _fields_ = [
+        ("node", _u32p), ("host", _u32p), ("cpus", _f64p), ("mem", _f64p), ("gpu_model", _u32p), ("gpu_count", _f64p),
+        ("disk_type", _u32p), ("disk_space", _f64p), ("num_pods", _i32p), ("attr", _u32p),
+    ]
+
+
+class CookOfferTotals(C.Structure):
+    _fields_ = [
+        ("cpus_capacity", C.c_double), ("mem_capacity", C.c_double), ("cpus_consumed", C.c_double), ("mem_consumed", C.c_double),
+        ("nodes_total", C.c_uint32), ("nodes_schedulable", C.c_uint32),
+    ]
+
+
+@dataclass
+class Nodes:
+    """node-name->node of one pool in ascending node-name order (api.clj:874-884 get-capacity inputs + the host-evaluated
+    predicates of node-schedulable?, api.clj:782-847)."""
+    cpus: np.ndarray
+    mem: np.ndarray
+    host: Optional[np.ndarray] = None
+    gpus: Optional[np.ndarray] = None
+    gpu_model: Optional[np.ndarray] = None
+    disk: Optional[np.ndarray] = None       # < 0 = no allocatable ephemeral-storage
+    disk_type: Optional[np.ndarray] = None
+    flags: Optional[np.ndarray] = None
+    attr: Optional[np.ndarray] = None       # [n, n_attr_keys] label table in the Offers.attr encoding
+
+    def __post_init__(self):
+        n = len(self.cpus)
+        self.cpus = _arr(self.cpus, np.float64, n)
+        self.mem = _arr(self.mem, np.float64, n)
+        self.host = _arr(self.host if self.host is not None else np.arange(n), np.uint32, n)
+        self.gpus = _arr(self.gpus, np.int32, n)
+        self.gpu_model = _arr(self.gpu_model, np.uint32, n)
+        self.disk = _arr(self.disk, np.float64, n)
+        self.disk_type = _arr(self.disk_type, np.uint32, n)
+        self.flags = _arr(self.flags, np.uint8, n)
+        if self.attr is not None:
+            self.attr = np.ascontiguousarray(self.attr, dtype=np.uint32)
+            assert self.attr.ndim == 2 and self.attr.shape[0] == n
+
+    @property
+    def n(self):
+        return len(self.cpus)
+
+    @property
+    def n_attr_keys(self):
+        return 0 if self.attr is None else self.attr.shape[1]
+
+    def as_struct(self) -> CookNodes:
+        attr = None if self.attr is None else self.attr.reshape(-1)
+        return CookNodes(self.n, _ptr(self.host, _u32p), _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p), _ptr(self.gpus, _i32p),
+                         _ptr(self.gpu_model, _u32p), _ptr(self.disk, _f64p), _ptr(self.disk_type, _u32p), _ptr(self.flags, _u8p),
+                         self.n_attr_keys, _ptr(attr, _u32p))
+
+
+@dataclass
+class Pods:
+    """Every pod of node-name->pods (api.clj:886-930 get-consumption inputs): per-pod sums of the containers' requests."""
+    node: np.ndarray                         # index into Nodes, NONE_U32 = no node of this pool
+    cpus: np.ndarray
+    mem: np.ndarray
+    gpus: Optional[np.ndarray] = None
+    gpu_model: Optional[np.ndarray] = None
+    disk: Optional[np.ndarray] = None        # < 0 = no container asks for ephemeral-storage
+    disk_type: Optional[np.ndarray] = None
+    flags: Optional[np.ndarray] = None
+
+    def __post_init__(self):
+        n = len(self.node)
+        self.node = _arr(self.node, np.uint32, n)
+        self.cpus = _arr(self.cpus, np.float64, n)
+        self.mem = _arr(self.mem, np.float64, n)
+        self.gpus = _arr(self.gpus, np.int32, n)
+        self.gpu_model = _arr(self.gpu_model, np.uint32, n)
+        self.disk = _arr(self.disk, np.float64, n)
+        self.disk_type = _arr(self.disk_type, np.uint32, n)
+        self.flags = _arr(self.flags, np.uint8, n)
+
+    @property
+    def n(self):
+        return len(self.node)
+
+    def as_struct(self) -> CookPods:
+        return CookPods(self.n, _ptr(self.node, _u32p), _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p), _ptr(self.gpus, _i32p),
+                        _ptr(self.gpu_model, _u32p), _ptr(self.disk, _f64p), _ptr(self.disk_type, _u32p), _ptr(self.flags, _u8p))
+
+
+def offer_params(clobber_synthetic_pods=False, filter_out_unsound_gpu_nodes=False, max_pods_per_node=2 ** 31 - 1,
+                 n_gpu_models=0, n_disk_types=0) -> CookOfferParams:
+    return CookOfferParams(int(bool(clobber_synthetic_pods)), int(bool(filter_out_unsound_gpu_nodes)), int(max_pods_per_node),
+                           int(n_gpu_models), int(n_disk_types), 0)
+
+
+@dataclass
+class BuiltOffers:
+    """What cook_offers_fetch returns: the offer rows (the cook_offers columns of the same names), the per-node status
+    bits, the gauges and the per-model / per-type totals."""
+    node: np.ndarray
+    host: np.ndarray
+    cpus: np.ndarray
+    mem: np.ndarray
+    gpu_model: np.ndarray
+    gpu_count: np.ndarray
+    disk_type: np.ndarray
+    disk_space: np.ndarray
+    num_pods: np.ndarray
+    attr: Optional[np.ndarray]
+    node_status: np.ndarray
+    totals: dict
+    gpu_capacity_by_model: np.ndarray
+    gpu_consumed_by_model: np.ndarray
+    disk_capacity_by_type: np.ndarray
+    disk_consumed_by_type: np.ndarray
+
+    @property
+    def n(self):
+        return len(self.node)
+
+    def as_offers(self, **kw) -> "Offers":
+        """The rows as match input (offer.clj:31-76: Kubernetes leases carry compute-cluster-type = kubernetes)."""
+        return Offers(cpus=self.cpus, mem=self.mem, host=self.host, k8s=np.ones(self.n, np.uint8), gpu_model=self.gpu_model,
+                      gpu_count=self.gpu_count, disk_type=self.disk_type, disk_space=self.disk_space, attr=self.attr, **kw)

@@ -17,6 +17,7 @@
 #include "considerable_kernels.hpp"
 #include "match_kernels.hpp"
 #include "match_v2.hpp"
+#include "offers_kernels.hpp"
 #include "rank_kernels.hpp"
 #include "rebalance_kernels.hpp"
 #include "scan.hpp"
@@ -76,6 +77,7 @@ struct KernelStat {
 
 struct RebalBufs;  // rebalance_host.hpp
 struct ConsBufs;   // considerable_host.hpp
+struct OfferBufs;  // offers_host.hpp
 
 }  // namespace
 
@@ -167,6 +169,8 @@ struct cook_engine {
   RebalBufs* rb = nullptr;
   // ---- considerable-jobs filters (allocated on first use) ----
   ConsBufs* cb = nullptr;
+  // ---- offer construction (allocated on first use) ----
+  OfferBufs* ofb = nullptr;
   DArr<uint32_t> j_user;
   bool has_j_user = false;
 
@@ -973,10 +977,16 @@ struct StageTimer {
 
 #include "considerable_host.hpp"
 #include "rebalance_host.hpp"
+#include "offers_host.hpp"
 
 ConsBufs& cons_bufs(cook_engine* e) {
   if (!e->cb) e->cb = new ConsBufs();
   return *e->cb;
+}
+
+OfferBufs& offer_bufs(cook_engine* e) {
+  if (!e->ofb) e->ofb = new OfferBufs();
+  return *e->ofb;
 }
 
 RebalBufs& rebal_bufs(cook_engine* e) {
@@ -1085,6 +1095,8 @@ void cook_engine_destroy(cook_engine* e) {
   e->rb = nullptr;
   delete e->cb;
   e->cb = nullptr;
+  delete e->ofb;
+  e->ofb = nullptr;
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1341,6 +1353,45 @@ int cook_rebalance(cook_engine* e, const cook_tasks* running, const uint8_t* run
 int cook_rebalance_timing(cook_engine* e, double* ms) {
   if (!e || !ms) return COOK_E_INVALID;
   *ms = e->rb ? e->rb->ms : 0.0;
+  return COOK_OK;
+}
+
+int cook_offers_stage(cook_engine* e, const cook_nodes* nodes, const cook_pods* pods, const cook_offer_params* params) {
+  return guarded(e, [&] { offers_stage(e, offer_bufs(e), nodes, pods, params); });
+}
+int cook_offers_run(cook_engine* e) {
+  return guarded(e, [&] {
+    OfferBufs& b = offer_bufs(e);
+    StageTimer t(e, 0, &b.ms);
+    offers_run(e, b);
+    t.stop();
+    prof_collect(e);
+  });
+}
+int cook_offers_fetch(cook_engine* e, cook_node_offers* offers, uint32_t* n_offers, uint8_t* node_status, cook_offer_totals* totals,
+                      int64_t* gpu_capacity_by_model, int64_t* gpu_consumed_by_model, double* disk_capacity_by_type,
+                      double* disk_consumed_by_type) {
+  if (n_offers) *n_offers = 0;
+  return guarded(e, [&] {
+    offers_fetch(e, offer_bufs(e), offers, n_offers, node_status, totals, gpu_capacity_by_model, gpu_consumed_by_model,
+                 disk_capacity_by_type, disk_consumed_by_type);
+  });
+}
+int cook_offers_build(cook_engine* e, const cook_nodes* nodes, const cook_pods* pods, const cook_offer_params* params,
+                      cook_node_offers* offers, uint32_t* n_offers, uint8_t* node_status, cook_offer_totals* totals,
+                      int64_t* gpu_capacity_by_model, int64_t* gpu_consumed_by_model, double* disk_capacity_by_type,
+                      double* disk_consumed_by_type) {
+  if (n_offers) *n_offers = 0;  // "no offers" on any error path
+  int rc = cook_offers_stage(e, nodes, pods, params);
+  if (rc) return rc;
+  rc = cook_offers_run(e);
+  if (rc) return rc;
+  return cook_offers_fetch(e, offers, n_offers, node_status, totals, gpu_capacity_by_model, gpu_consumed_by_model, disk_capacity_by_type,
+                           disk_consumed_by_type);
+}
+int cook_offers_timing(cook_engine* e, double* ms) {
+  if (!e || !ms) return COOK_E_INVALID;
+  *ms = e->ofb ? e->ofb->ms : 0.0;
   return COOK_OK;
 }
 

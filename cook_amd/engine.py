@@ -24,6 +24,7 @@ EXPORTS = [
     "cook_cycle_stage", "cook_cycle_run", "cook_cycle_fetch", "cook_cycle_run_rank", "cook_cycle_match_multi",
     "cook_considerable", "cook_cycle_set_considerable", "cook_cycle_fetch_considerable",
     "cook_rebalance", "cook_rebalance_stage", "cook_rebalance_run", "cook_rebalance_fetch", "cook_rebalance_timing",
+    "cook_offers_build", "cook_offers_stage", "cook_offers_run", "cook_offers_fetch", "cook_offers_timing",
     "cook_last_timing", "cook_kernel_timings", "cook_set_profiling", "cook_match_stats",
 ]
 
@@ -269,6 +270,51 @@ class Engine:
     def rebalance_timing(self) -> float:
         ms = C.c_double(0)
         self._lib.cook_rebalance_timing(self._h, C.byref(ms))
+        return ms.value
+
+    # ---- offer construction from node state --------------------------------------------------------------------
+    def offers_stage(self, nodes: A.Nodes, pods: A.Pods, oparams: A.CookOfferParams):
+        ns, ps = nodes.as_struct(), pods.as_struct()
+        self._of_n, self._of_attr, self._of_params = nodes.n, nodes.n_attr_keys, oparams
+        self._chk(self._lib.cook_offers_stage(self._h, C.byref(ns), C.byref(ps), C.byref(oparams)))
+
+    def offers_run(self):
+        self._chk(self._lib.cook_offers_run(self._h))
+
+    def offers_fetch(self) -> A.BuiltOffers:
+        n, na, op = self._of_n, self._of_attr, self._of_params
+        cap = max(1, n)
+        cols = dict(node=np.zeros(cap, np.uint32), host=np.zeros(cap, np.uint32), cpus=np.zeros(cap), mem=np.zeros(cap),
+                    gpu_model=np.zeros(cap, np.uint32), gpu_count=np.zeros(cap), disk_type=np.zeros(cap, np.uint32),
+                    disk_space=np.zeros(cap), num_pods=np.zeros(cap, np.int32))
+        attr = np.zeros((cap, na), np.uint32) if na else None
+        o = A.CookNodeOffers(_p(cols["node"], C.c_uint32), _p(cols["host"], C.c_uint32), _p(cols["cpus"], C.c_double),
+                             _p(cols["mem"], C.c_double), _p(cols["gpu_model"], C.c_uint32), _p(cols["gpu_count"], C.c_double),
+                             _p(cols["disk_type"], C.c_uint32), _p(cols["disk_space"], C.c_double), _p(cols["num_pods"], C.c_int32),
+                             _p(attr.reshape(-1), C.c_uint32) if na else None)
+        status = np.zeros(cap, np.uint8)
+        tot = A.CookOfferTotals()
+        gcap, gcons = np.zeros(op.n_gpu_models + 1, np.int64), np.zeros(op.n_gpu_models + 1, np.int64)
+        dcap, dcons = np.zeros(op.n_disk_types + 1), np.zeros(op.n_disk_types + 1)
+        r = C.c_uint32(0)
+        self._chk(self._lib.cook_offers_fetch(self._h, C.byref(o), C.byref(r), _p(status, C.c_uint8), C.byref(tot),
+                                              _p(gcap, C.c_int64), _p(gcons, C.c_int64), _p(dcap, C.c_double), _p(dcons, C.c_double)))
+        k = r.value
+        totals = {f: getattr(tot, f) for f, _ in A.CookOfferTotals._fields_}
+        return A.BuiltOffers(attr=attr[:k].copy() if na else None, node_status=status[:n].copy(), totals=totals,
+                             gpu_capacity_by_model=gcap, gpu_consumed_by_model=gcons, disk_capacity_by_type=dcap,
+                             disk_consumed_by_type=dcons, **{c: v[:k].copy() for c, v in cols.items()})
+
+    def offers_build(self, nodes: A.Nodes, pods: A.Pods, oparams: A.CookOfferParams) -> A.BuiltOffers:
+        """generate-offers' numeric core (kubernetes/compute_cluster.clj:68-190): available = capacity - consumption per
+        node, the schedulable filter, the offer rows in node order and the capacity / consumption gauges."""
+        self.offers_stage(nodes, pods, oparams)
+        self.offers_run()
+        return self.offers_fetch()
+
+    def offers_timing(self) -> float:
+        ms = C.c_double(0)
+        self._lib.cook_offers_timing(self._h, C.byref(ms))
         return ms.value
 
     # ---- measurement -----------------------------------------------------------------------------------------

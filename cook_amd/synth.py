@@ -143,3 +143,79 @@ def make_pool(seed: int, n_pending: int, n_running: int, n_users: int, n_offers:
                       gpu_model=gmodel[order][pidx] if gpus else None, user=tasks.user[pidx])
     return Pool(tasks=tasks, users=users, pending_jobs=jobs, offers=offers, groups=groups, n_running=n_running,
                 n_pending=n_pending)
+
+
+def make_cluster_state(seed: int, n_nodes: int, n_pods: int, *, gpus: bool = True, disk: bool = False, fractional: bool = True,
+                       n_attr_keys: int = 0, max_pods: int = 32, corrupt: float = 0.0):
+    """Node / pod state of one Kubernetes pool as the offer construction sees it (kubernetes/compute_cluster.clj:68-190).
+    Node shapes follow SURVEY.md §8d's offers (cpus in {16,32,64,96}, mem = cpus x 4096 MiB, 10 % gpu hosts); pod requests
+    follow the job shapes, with the 0.1-cpu sidecar the reference adds to every pod (kubernetes/api.clj:1346-1349 shapes) when
+    `fractional`, so that consumption sums are NOT exact in every order.  `corrupt` = fraction of gpu / disk pods placed on
+    nodes of another model / type.  -> (Nodes, Pods, CookOfferParams)"""
+    rng = np.random.default_rng(seed)
+    cpus = rng.choice([16.0, 32.0, 64.0, 96.0], size=n_nodes, p=[0.2, 0.4, 0.3, 0.1])
+    mem = cpus * 4096.0
+    n_models, n_types = (2 if gpus else 0), (2 if disk else 0)
+    ngpu = np.zeros(n_nodes, np.int32)
+    nmodel = np.zeros(n_nodes, np.uint32)
+    if gpus:
+        is_g = rng.random(n_nodes) < 0.10
+        ngpu[is_g] = rng.choice([1, 2, 4, 8], size=int(is_g.sum()))
+        nmodel[is_g] = rng.choice([1, 2], size=int(is_g.sum()), p=[0.7, 0.3])
+        # a few unsound nodes: gpu taint / label without allocatable gpus
+        odd = rng.random(n_nodes) < 0.01
+        ngpu[odd] = 0
+    ndisk = np.full(n_nodes, -1.0)
+    ndtype = np.zeros(n_nodes, np.uint32)
+    if disk:
+        has = rng.random(n_nodes) < 0.8
+        ndisk[has] = rng.choice([256000.0, 512000.0], size=int(has.sum()))
+        ndtype[has] = rng.choice([1, 2], size=int(has.sum()))
+    flags = np.zeros(n_nodes, np.uint8)
+    for bit, frac in ((A.NODE_UNSCHEDULABLE, 0.02), (A.NODE_OTHER_TAINTS, 0.02), (A.NODE_BLOCKLIST_LABEL, 0.01)):
+        flags[rng.random(n_nodes) < frac] |= bit
+    flags[(nmodel != 0) | (rng.random(n_nodes) < 0.005)] |= A.NODE_GPU_TAINT
+    attr = rng.integers(0, 5, size=(n_nodes, n_attr_keys)).astype(np.uint32) if n_attr_keys else None
+    nodes = A.Nodes(cpus=cpus, mem=mem, host=np.arange(n_nodes) * 2 + 1, gpus=ngpu, gpu_model=nmodel, disk=ndisk, disk_type=ndtype,
+                    flags=flags, attr=attr)
+    # pods: node uniform (a few without a node of this pool), a hot spot so that some nodes hit the pod limit
+    pnode = rng.integers(0, max(1, n_nodes), size=n_pods).astype(np.uint32)
+    hot = rng.random(n_pods) < 0.05
+    pnode[hot] = rng.integers(0, max(1, n_nodes // 50 + 1), size=int(hot.sum()))
+    pnode[rng.random(n_pods) < 0.02] = A.NONE_U32
+    if n_nodes == 0:
+        pnode[:] = A.NONE_U32
+    pc = np.clip(np.round(rng.normal(3, 1, n_pods)), 1, 8)
+    pm = np.clip(np.round(rng.normal(10240, 4096, n_pods)), 512, 65536)
+    if fractional:
+        pc = pc + 0.1                      # sidecar request: 0.1 is not dyadic
+        pm = pm + rng.choice([0.0, 0.5, 100.3], size=n_pods)
+    pg = np.zeros(n_pods, np.int32)
+    pgm = np.zeros(n_pods, np.uint32)
+    if gpus and n_nodes:
+        on = pnode < n_nodes
+        want = on & (nmodel[np.minimum(pnode, n_nodes - 1)] != 0) & (rng.random(n_pods) < 0.5)
+        pg[want] = rng.choice([1, 2, 4], size=int(want.sum()))
+        pgm[want] = nmodel[pnode[want]]
+        bad = want & (rng.random(n_pods) < corrupt)
+        pgm[bad] = 3 - pgm[bad]            # the other model
+        stray = on & ~want & (rng.random(n_pods) < corrupt * 0.1)
+        pg[stray], pgm[stray] = 1, 1       # gpu pods on nodes without (matching) gpus
+    pd = np.full(n_pods, -1.0)
+    pdt = np.zeros(n_pods, np.uint32)
+    if disk and n_nodes:
+        on = pnode < n_nodes
+        want = on & (rng.random(n_pods) < 0.4)
+        pd[want] = rng.choice([10000.0, 50.25, 1000.1], size=int(want.sum()))
+        pdt[want] = ndtype[pnode[want]]
+        pdt[want & (pdt == 0)] = 1
+        bad = want & (rng.random(n_pods) < corrupt)
+        pdt[bad] = 3 - pdt[bad]
+    pf = np.zeros(n_pods, np.uint8)
+    pf[rng.random(n_pods) < 0.05] |= A.POD_SYNTHETIC
+    noreq = (rng.random(n_pods) < 0.03) & (pgm == 0)
+    pf[noreq] |= A.POD_NO_REQUESTS
+    pods = A.Pods(node=pnode, cpus=pc, mem=pm, gpus=pg, gpu_model=pgm, disk=pd, disk_type=pdt, flags=pf)
+    params = A.offer_params(clobber_synthetic_pods=bool(seed & 1), filter_out_unsound_gpu_nodes=bool(seed & 2),
+                            max_pods_per_node=max_pods, n_gpu_models=n_models, n_disk_types=n_types)
+    return nodes, pods, params

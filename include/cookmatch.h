@@ -311,6 +311,96 @@ int cook_rebalance_fetch(cook_engine* e, cook_preemption* decisions, uint32_t* n
 /* HIP-event time of the last cook_rebalance_run in milliseconds */
 int cook_rebalance_timing(cook_engine* e, double* ms);
 
+/* ---- OFFERS: replaces the numeric core of kubernetes.compute-cluster/generate-offers ----------------------
+ * (kubernetes/compute_cluster.clj:68-190: available = capacity - consumption per node, the schedulable filter, the
+ * offer resources and the capacity / consumption totals it publishes; kubernetes/api.clj:747-765 convert-resource-map,
+ * :782-847 node-schedulable?, :849-884 get-capacity, :886-930 get-consumption).  The step BEFORE the match path: its
+ * output rows are the cook_offers columns of the same names.  Quantity parsing, label / taint inspection and name
+ * interning stay with the host; everything numeric is here. */
+#define COOK_NODE_UNSCHEDULABLE 1u   /* .getSpec .getUnschedulable is true (api.clj:795-801)                        */
+#define COOK_NODE_OTHER_TAINTS 2u    /* a taint other than the pool / deletion-candidate / gpu / tenured taints (:803-814) */
+#define COOK_NODE_BLOCKLIST_LABEL 4u /* carries a label of node-blocklist-labels (:825-832)                         */
+#define COOK_NODE_GPU_TAINT 8u       /* carries the gpu-node-taint (:836)                                            */
+typedef struct cook_nodes { /* node-name->node of one pool, rows in ascending node-name order (offers come out in this order) */
+  uint32_t n;
+  const uint32_t* host;      /* host id of the node (hostname rank); copied into the offer rows                  */
+  const double* cpus;        /* allocatable "cpu" (api.clj:752-754), 0.0 when absent                             */
+  const double* mem;         /* allocatable "memory" / memory-multiplier in MiB (:749-751), 0.0 when absent      */
+  const int32_t* gpus;       /* allocatable "nvidia.com/gpu" to-int (:756-758), 0 when absent; may be NULL       */
+  const uint32_t* gpu_model; /* id of the "gpu-type" label, 0 = no label (:879); may be NULL                     */
+  const double* disk;        /* allocatable "ephemeral-storage" / disk-multiplier (:760-762), < 0 = absent; may be NULL */
+  const uint32_t* disk_type; /* id of the pool's disk-type label value, 0 = no label (:880); may be NULL         */
+  const uint8_t* flags;      /* COOK_NODE_* bits, evaluated by the host; may be NULL (all 0)                     */
+  uint32_t n_attr_keys;      /* label table [n][n_attr_keys] in the cook_offers.attr encoding (labels ++ the     */
+  const uint32_t* attr;      /*   "compute-cluster-type" attribute, compute_cluster.clj:165-185); may be NULL    */
+} cook_nodes;
+
+#define COOK_POD_SYNTHETIC 1u   /* pod name has the synthetic-pod prefix (api.clj:77)                                */
+#define COOK_POD_NO_REQUESTS 2u /* no container carries resource requests: the pod's resource map is nil (:908-913) */
+typedef struct cook_pods { /* every pod of node-name->pods; pods of one node must appear in that node's list order */
+  uint32_t n;
+  const uint32_t* node;      /* index into cook_nodes; COOK_NONE_U32 (or >= nodes->n) = no node assigned, or a node
+                                without capacity in this pool: dropped (api.clj:894, compute_cluster.clj:88-90)    */
+  const double* cpus;        /* sum over containers of the "cpu" requests (merge-with +, api.clj:904-911)         */
+  const double* mem;         /* likewise "memory" / memory-multiplier                                             */
+  const int32_t* gpus;       /* likewise "nvidia.com/gpu"; may be NULL                                            */
+  const uint32_t* gpu_model; /* id of nodeSelector "cloud.google.com/gke-accelerator", 0 = none (:914); may be NULL */
+  const double* disk;        /* likewise "ephemeral-storage" / disk-multiplier, < 0 = no container asks; may be NULL */
+  const uint32_t* disk_type; /* id of the nodeSelector disk-type label value, 0 = none (:915); may be NULL         */
+  const uint8_t* flags;      /* COOK_POD_* bits; may be NULL                                                      */
+} cook_pods;
+
+typedef struct cook_offer_params {
+  int32_t clobber_synthetic_pods;       /* (:clobber-synthetic-pods (config/kubernetes)) (compute_cluster.clj:71)  */
+  int32_t filter_out_unsound_gpu_nodes; /* (:filter-out-unsound-gpu-nodes? (config/kubernetes)) (api.clj:839)       */
+  int32_t max_pods_per_node;            /* (cc/max-tasks-per-host compute-cluster) (compute_cluster.clj:49)         */
+  uint32_t n_gpu_models;                /* model ids are 1..n_gpu_models (sizes the per-model totals)               */
+  uint32_t n_disk_types;                /* disk type ids are 1..n_disk_types                                        */
+  int32_t reserved;
+} cook_offer_params;
+
+#define COOK_NODE_ST_OFFER 1u         /* the node is schedulable: an offer row was emitted                           */
+#define COOK_NODE_ST_CONSUMED 2u      /* the node has an entry in node-name->consumed                                */
+#define COOK_NODE_ST_FOREIGN_GPU 4u   /* pods consume gpus of a model the node's capacity does not list: the reference's
+                                         deep-merge-with adds a second key to the offer's "gpus" map; cook_offers holds
+                                         one model per host, so the host must rebuild this (corrupt) node's offer itself */
+#define COOK_NODE_ST_FOREIGN_DISK 8u  /* likewise for disk types                                                     */
+typedef struct cook_node_offers { /* caller-allocated columns, capacity nodes->n rows; any column may be NULL */
+  uint32_t* node;      /* row -> index into cook_nodes (ascending)                                                  */
+  uint32_t* host;      /* nodes->host of that node (:hostname / :slave-id, compute_cluster.clj:175-176)             */
+  double* cpus;        /* (max 0.0 (:cpus available)) (:179)                                                        */
+  double* mem;         /* (max 0.0 (:mem available)) (:178)                                                         */
+  uint32_t* gpu_model; /* the one key of (:gpus available), 0 = empty map (:181)                                    */
+  double* gpu_count;   /*   its value (capacity - consumption; may be negative, the reference does not clamp it)    */
+  uint32_t* disk_type; /* the one key of (:disk available), 0 = empty map (:180)                                    */
+  double* disk_space;
+  int32_t* num_pods;   /* pods on the node (api.clj:816, the pod-limit test; = COOK_NUM_TASKS_ON_HOST's count)      */
+  uint32_t* attr;      /* [rows][nodes->n_attr_keys]: the nodes' label rows, gathered                               */
+} cook_node_offers;
+
+typedef struct cook_offer_totals { /* the gauges generate-offers publishes (compute_cluster.clj:113-160) */
+  double cpus_capacity, mem_capacity;  /* total-resource over node-name->capacity, summed in node order (the reference
+                                          sums in hash-map order: unpinned for non-integer values)                  */
+  double cpus_consumed, mem_consumed;  /* total-resource over node-name->consumed                                    */
+  uint32_t nodes_total, nodes_schedulable;
+} cook_offer_totals;
+
+/* node_status (optional, len nodes->n): COOK_NODE_ST_* bits.  gpu_capacity_by_model / gpu_consumed_by_model (optional,
+ * len n_gpu_models + 1, indexed by model id): total-map-resource of :gpus (compute_cluster.clj:95-96).
+ * disk_capacity_by_type / disk_consumed_by_type (optional, len n_disk_types + 1): likewise for :disk, node order;
+ * consumption under a type the node's capacity does not list is not included (such nodes carry COOK_NODE_ST_FOREIGN_DISK). */
+int cook_offers_build(cook_engine* e, const cook_nodes* nodes, const cook_pods* pods, const cook_offer_params* params,
+                      cook_node_offers* offers, uint32_t* n_offers, uint8_t* node_status, cook_offer_totals* totals,
+                      int64_t* gpu_capacity_by_model, int64_t* gpu_consumed_by_model, double* disk_capacity_by_type,
+                      double* disk_consumed_by_type);
+int cook_offers_stage(cook_engine* e, const cook_nodes* nodes, const cook_pods* pods, const cook_offer_params* params);
+int cook_offers_run(cook_engine* e);
+int cook_offers_fetch(cook_engine* e, cook_node_offers* offers, uint32_t* n_offers, uint8_t* node_status,
+                      cook_offer_totals* totals, int64_t* gpu_capacity_by_model, int64_t* gpu_consumed_by_model,
+                      double* disk_capacity_by_type, double* disk_consumed_by_type);
+/* HIP-event time of the last cook_offers_run in milliseconds */
+int cook_offers_timing(cook_engine* e, double* ms);
+
 /* ---- measurement hooks (bench.py): HIP-event time of the last *_run, per stage, in milliseconds ----------- */
 int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms);
 /* named kernel timings of the last run: fills up to cap entries, returns count */

@@ -1,0 +1,263 @@
+"""CPU restatement of offer construction from node state — TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench cpu baseline).
+
+Follows kubernetes.compute-cluster/generate-offers map for map (paths relative to /root/reference/scheduler/src/cook):
+  convert_resource_map   kubernetes/api.clj:747-765
+  get_capacity           kubernetes/api.clj:849-884  (force-gpu-model / force-disk-type-in-resource-map)
+  get_consumption        kubernetes/api.clj:886-930
+  deep_merge_with        util.clj:208-225
+  node_schedulable       kubernetes/api.clj:782-847  (the boolean; the branch order only matters for its log lines)
+  generate_offers        kubernetes/compute_cluster.clj:68-190
+Pure-Python dicts on purpose: the reference is written over Clojure maps (merge-with, deep-merge-with, dissoc) and the
+quirks live there (a consumed gpu model the node does not list becomes a second key of the offer's "gpus" map).
+Pinned on the reference's own vectors: tests/golden/offers.json (test/cook/test/kubernetes/api.clj:22-114, 842-952 and
+test/cook/test/kubernetes/compute_cluster.clj:120-255).
+
+Input shape (what the host extracts from the V1Node / V1Pod objects; Quantity parsing is not on this path):
+  node = dict(name, allocatable={"cpu": float, "memory": MiB, "nvidia.com/gpu": int, "ephemeral-storage": MiB}
+              (keys optional), gpu_type=str|None (label "gpu-type"), disk_type=str|None (the pool's disk-type label),
+              unschedulable=bool|None, other_taints=bool, blocklist_label=bool, gpu_taint=bool)
+  pod  = dict(name, node=str|None, containers=[{"cpu":..,"memory":..,"nvidia.com/gpu":..,"ephemeral-storage":..}|None ...],
+              gpu_model=str|None (nodeSelector gke-accelerator), disk_type=str|None (nodeSelector disk label), synthetic=bool)
+"""
+from __future__ import annotations
+
+from functools import reduce
+from typing import Dict, List, Optional
+
+import numpy as np
+
+
+def convert_resource_map(m: dict) -> dict:
+    """api.clj:747-765: {:mem :cpus :gpus [:disk]} of one requests / allocatable map (memory and disk already in MiB)."""
+    res = {"mem": float(m["memory"]) if m.get("memory") is not None else 0.0,
+           "cpus": float(m["cpu"]) if m.get("cpu") is not None else 0.0,
+           "gpus": int(m["nvidia.com/gpu"]) if m.get("nvidia.com/gpu") is not None else 0}
+    if m.get("ephemeral-storage") is not None:
+        res["disk"] = float(m["ephemeral-storage"])
+    return res
+
+
+def force_gpu_model(model, rm: Optional[dict]) -> Optional[dict]:
+    """api.clj:849-855"""
+    if rm is None:
+        return None
+    out = dict(rm)
+    if model and out.get("gpus", 0) > 0:
+        out["gpus"] = {model: out["gpus"]}
+    else:
+        out.pop("gpus", None)
+    return out
+
+
+def force_disk_type(dtype, rm: Optional[dict]) -> Optional[dict]:
+    """api.clj:866-872"""
+    if rm is None:
+        return None
+    out = dict(rm)
+    if out.get("disk") is not None and dtype:
+        out["disk"] = {dtype: out["disk"]}
+    else:
+        out.pop("disk", None)
+    return out
+
+
+def merge_with(f, *maps):
+    """clojure.core/merge-with: the first value of a key is kept as it is, later ones are combined left to right."""
+    maps = [m for m in maps if m is not None]
+    if not maps:
+        return None
+    out = dict(maps[0])
+    for m in maps[1:]:
+        for k, v in m.items():
+            out[k] = f(out[k], v) if k in out else v
+    return out
+
+
+def deep_merge_with(f, *maps):
+    """util.clj:208-225"""
+    if not maps:
+        return None
+
+    def merge(*args):
+        if all(isinstance(a, dict) for a in args):
+            return merge_with(merge, *args)
+        return f(*args)
+
+    return merge(*maps) if len(maps) > 1 else maps[0]
+
+
+def get_capacity(node_name_to_node: Dict[str, dict]) -> Dict[str, dict]:
+    """api.clj:874-884"""
+    out = {}
+    for name, node in node_name_to_node.items():
+        rm = convert_resource_map(node.get("allocatable") or {})
+        out[name] = force_disk_type(node.get("disk_type"), force_gpu_model(node.get("gpu_type"), rm))
+    return out
+
+
+def get_consumption(clobber_synthetic_pods: bool, node_name_to_pods: Dict[Optional[str], list]) -> Dict[str, dict]:
+    """api.clj:886-930"""
+    out = {}
+    for name, pods in node_name_to_pods.items():
+        if name is None or not pods:
+            continue
+        maps = []
+        for pod in pods:
+            if clobber_synthetic_pods and pod.get("synthetic"):
+                continue
+            reqs = [convert_resource_map(c) if c is not None else None for c in (pod.get("containers") or [])]
+            rm = merge_with(lambda a, b: a + b, *reqs)
+            rm = force_disk_type(pod.get("disk_type"), force_gpu_model(pod.get("gpu_model"), rm))
+            if rm is not None:
+                maps.append(rm)
+        merged = deep_merge_with(lambda a, b: a + b, *maps)
+        if merged is not None:
+            out[name] = merged
+    return out
+
+
+def node_schedulable(node: Optional[dict], pod_count_capacity: int, node_name_to_pods, filter_out_unsound_gpu_nodes=False) -> bool:
+    """api.clj:782-847 (labels / taints already reduced to booleans by the host)"""
+    if node is None:
+        return False
+    if node.get("unschedulable"):
+        return False
+    if node.get("other_taints"):
+        return False
+    if len((node_name_to_pods or {}).get(node.get("name")) or []) >= pod_count_capacity:
+        return False
+    if node.get("blocklist_label"):
+        return False
+    alloc = node.get("allocatable")
+    has_gpus = alloc is not None and convert_resource_map(alloc)["gpus"] > 0
+    if node.get("gpu_taint") and not has_gpus:
+        return not filter_out_unsound_gpu_nodes
+    return True
+
+
+def total_resource(m: Dict[str, dict], key: str):
+    """compute_cluster.clj:56-60 (map order = insertion order here; the reference's hash-map order is unpinned)"""
+    vals = [v[key] for v in m.values() if v.get(key) is not None]
+    return reduce(lambda a, b: a + b, vals) if vals else 0
+
+
+def total_map_resource(m: Dict[str, dict], key: str) -> dict:
+    """compute_cluster.clj:62-66"""
+    return merge_with(lambda a, b: a + b, *[v.get(key) for v in m.values()]) or {}
+
+
+def clj_max0(x):
+    """(max 0.0 x) through clojure.lang.Numbers: NaN propagates, -0.0 survives"""
+    return 0.0 if 0.0 > x else x
+
+
+def generate_offers(node_name_to_node, node_name_to_pods, clobber_synthetic_pods=False, max_pods_per_node=2 ** 31 - 1,
+                    filter_out_unsound_gpu_nodes=False):
+    """compute_cluster.clj:68-190 -> (offers, gauges); offers keep node_name_to_node's order."""
+    cap = get_capacity(node_name_to_node)
+    consumed = {k: v for k, v in get_consumption(clobber_synthetic_pods, node_name_to_pods).items() if cap.get(k) is not None}
+    available = deep_merge_with(lambda a, b: a - b, cap, consumed) if consumed else dict(cap)
+    offers = []
+    for name, av in available.items():
+        if not node_schedulable(node_name_to_node.get(name), max_pods_per_node, node_name_to_pods, filter_out_unsound_gpu_nodes):
+            continue
+        offers.append(dict(hostname=name, mem=clj_max0(av["mem"]), cpus=clj_max0(av["cpus"]), disk=dict(av.get("disk") or {}),
+                           gpus=dict(av.get("gpus") or {})))
+    gauges = dict(nodes_total=len(node_name_to_node), nodes_schedulable=len(offers),
+                  cpus_capacity=total_resource(cap, "cpus"), mem_capacity=total_resource(cap, "mem"),
+                  cpus_consumed=total_resource(consumed, "cpus"), mem_consumed=total_resource(consumed, "mem"),
+                  gpu_capacity=total_map_resource(cap, "gpus"), gpu_consumed=total_map_resource(consumed, "gpus"),
+                  disk_capacity=total_map_resource(cap, "disk"), disk_consumed=total_map_resource(consumed, "disk"))
+    return offers, gauges, consumed
+
+
+# ---- adapter between the SoA containers of the C ABI and the map form above ---------------------------------------------
+def from_soa(nodes, pods):
+    """cook_amd._abi.Nodes / Pods -> (node-name->node, node-name->pods); names are 'n%07d' so that map order = node order."""
+    nm = lambda i: "n%07d" % i  # noqa: E731
+    n2n = {}
+    for i in range(nodes.n):
+        alloc = {"cpu": float(nodes.cpus[i]), "memory": float(nodes.mem[i])}
+        if nodes.gpus is not None and nodes.gpus[i] != 0:
+            alloc["nvidia.com/gpu"] = int(nodes.gpus[i])
+        if nodes.disk is not None and nodes.disk[i] >= 0:
+            alloc["ephemeral-storage"] = float(nodes.disk[i])
+        f = int(nodes.flags[i]) if nodes.flags is not None else 0
+        n2n[nm(i)] = dict(name=nm(i), allocatable=alloc,
+                          gpu_type=("g%d" % nodes.gpu_model[i]) if nodes.gpu_model is not None and nodes.gpu_model[i] else None,
+                          disk_type=("d%d" % nodes.disk_type[i]) if nodes.disk_type is not None and nodes.disk_type[i] else None,
+                          unschedulable=bool(f & 1), other_taints=bool(f & 2), blocklist_label=bool(f & 4), gpu_taint=bool(f & 8))
+    # keys in node order: the gauges sum node-name->consumed in map order, which the ABI defines as node order
+    n2p: Dict[Optional[str], list] = {nm(int(v)): [] for v in np.unique(pods.node[pods.node < nodes.n])} if pods.n else {}
+    for p in range(pods.n):
+        v = int(pods.node[p])
+        key = nm(v) if v < nodes.n else None
+        f = int(pods.flags[p]) if pods.flags is not None else 0
+        c = {"cpu": float(pods.cpus[p]), "memory": float(pods.mem[p])}
+        if pods.gpus is not None and pods.gpus[p] != 0:
+            c["nvidia.com/gpu"] = int(pods.gpus[p])
+        if pods.disk is not None and pods.disk[p] >= 0:
+            c["ephemeral-storage"] = float(pods.disk[p])
+        n2p.setdefault(key, []).append(dict(
+            name="p%d" % p, node=key, containers=[None] if f & 2 else [c],
+            gpu_model=("g%d" % pods.gpu_model[p]) if pods.gpu_model is not None and pods.gpu_model[p] else None,
+            disk_type=("d%d" % pods.disk_type[p]) if pods.disk_type is not None and pods.disk_type[p] else None,
+            synthetic=bool(f & 1)))
+    return n2n, n2p
+
+
+def build_rows(nodes, pods, oparams):
+    """The expected result of cook_offers_build for SoA inputs, in the ABI's own encoding (see include/cookmatch.h)."""
+    n2n, n2p = from_soa(nodes, pods)
+    offers, gauges, consumed = generate_offers(n2n, n2p, bool(oparams.clobber_synthetic_pods), int(oparams.max_pods_per_node),
+                                               bool(oparams.filter_out_unsound_gpu_nodes))
+    cap = get_capacity(n2n)
+    idx = {name: i for i, name in enumerate(n2n)}
+    status = np.zeros(nodes.n, np.uint8)
+    for name, c in consumed.items():
+        i = idx[name]
+        status[i] |= 2
+        own_g = set((cap[name].get("gpus") or {}).keys())
+        own_d = set((cap[name].get("disk") or {}).keys())
+        if set((c.get("gpus") or {}).keys()) - own_g:
+            status[i] |= 4
+        if set((c.get("disk") or {}).keys()) - own_d:
+            status[i] |= 8
+    rows = dict(node=[], host=[], cpus=[], mem=[], gpu_model=[], gpu_count=[], disk_type=[], disk_space=[], num_pods=[])
+    for o in offers:
+        i = idx[o["hostname"]]
+        status[i] |= 1
+        rows["node"].append(i)
+        rows["host"].append(int(nodes.host[i]))
+        rows["cpus"].append(o["cpus"])
+        rows["mem"].append(o["mem"])
+        own_g = list((cap[o["hostname"]].get("gpus") or {}).keys())
+        own_d = list((cap[o["hostname"]].get("disk") or {}).keys())
+        rows["gpu_model"].append(int(own_g[0][1:]) if own_g else 0)
+        rows["gpu_count"].append(float(o["gpus"][own_g[0]]) if own_g else 0.0)
+        rows["disk_type"].append(int(own_d[0][1:]) if own_d else 0)
+        rows["disk_space"].append(float(o["disk"][own_d[0]]) if own_d else 0.0)
+        rows["num_pods"].append(len(n2p.get(o["hostname"]) or []))
+    ng, ndt = int(oparams.n_gpu_models), int(oparams.n_disk_types)
+    gcap, gcons = np.zeros(ng + 1, np.int64), np.zeros(ng + 1, np.int64)
+    dcap, dcons = np.zeros(ndt + 1), np.zeros(ndt + 1)
+    for k, v in gauges["gpu_capacity"].items():
+        gcap[int(k[1:])] = v
+    for k, v in gauges["gpu_consumed"].items():
+        gcons[int(k[1:])] = v
+    for k, v in gauges["disk_capacity"].items():
+        dcap[int(k[1:])] = v
+    # own-type consumption only, in node order (cookmatch.h: foreign-type consumption is flagged, not totalled)
+    own = {}
+    for name, c in consumed.items():
+        for k, v in (c.get("disk") or {}).items():
+            if k in (cap[name].get("disk") or {}):
+                own[k] = own[k] + v if k in own else v
+    for k, v in own.items():
+        dcons[int(k[1:])] = v
+    return dict(rows={k: np.array(v, dtype={"node": np.uint32, "host": np.uint32, "gpu_model": np.uint32, "disk_type": np.uint32,
+                                            "num_pods": np.int32}.get(k, np.float64)) for k, v in rows.items()},
+                status=status,
+                totals={k: gauges[k] for k in ("cpus_capacity", "mem_capacity", "cpus_consumed", "mem_consumed", "nodes_total",
+                                               "nodes_schedulable")},
+                gpu_capacity_by_model=gcap, gpu_consumed_by_model=gcons, disk_capacity_by_type=dcap, disk_consumed_by_type=dcons)

@@ -600,8 +600,158 @@ CONSIDERABLE = [
 ]
 
 
+# ---- offer construction from node state (kubernetes/compute_cluster.clj:68-190) ------------------------------------------
+T_KAPI = "test/cook/test/kubernetes/api.clj"
+T_KCC = "test/cook/test/kubernetes/compute_cluster.clj"
+P100, K80 = "nvidia-tesla-p100", "nvidia-tesla-k80"
+
+
+def kpod(name, node, *requests, synthetic=False):
+    """testutil.clj:527-567 pod-helper: one container per request map; gpus / disk also set the pod's nodeSelector."""
+    containers, gpu_model, disk_type = [], None, None
+    for r in requests:
+        c = {}
+        if r.get("mem") is not None:
+            c["memory"] = float(r["mem"])
+        if r.get("cpus") is not None:
+            c["cpu"] = float(r["cpus"])
+        if r.get("gpus") is not None and int(r["gpus"]) > 0:
+            c["nvidia.com/gpu"] = int(r["gpus"])
+            gpu_model = r.get("gpu-model") or P100
+        if r.get("disk") is not None:
+            c["ephemeral-storage"] = float(r["disk"].get("disk-request", 10000))
+            disk_type = r["disk"].get("disk-type") or "standard"
+        containers.append(c)
+    return dict(name=name, node=node, containers=containers, gpu_model=gpu_model, disk_type=disk_type, synthetic=synthetic)
+
+
+def knode(name, cpus, mem, gpus=None, gpu_model=None, disk=None, **flags):
+    """testutil.clj:586-628 node-helper"""
+    alloc = {}
+    if cpus is not None:
+        alloc["cpu"] = float(cpus)
+    if mem is not None:
+        alloc["memory"] = float(mem)
+    gt = None
+    if gpus is not None and gpus > 0:
+        alloc["nvidia.com/gpu"] = int(gpus)
+        gt = gpu_model or P100
+    dt = None
+    if disk is not None:
+        alloc["ephemeral-storage"] = float(disk["disk-amount"])
+        dt = disk.get("disk-type") or "standard"
+    d = dict(name=name, allocatable=alloc, gpu_type=gt, disk_type=dt, unschedulable=False, other_taints=False,
+             blocklist_label=False, gpu_taint=False)
+    d.update(flags)
+    return d
+
+
+_AGG_PODS = [
+    kpod("cook-synthetic-pod-podA", "hostA", {"cpus": 1.0, "mem": 100.0, "gpus": "2", "gpu-model": P100}, synthetic=True),
+    kpod("podB", "hostA", {"cpus": 1.0}),
+    kpod("podA", "hostA", {"gpus": "1", "gpu-model": P100}),
+    kpod("podC", "hostB", {"cpus": 1.0}, {"mem": 100.0}),
+    kpod("podC", "hostB", {"cpus": 2.0}, {"mem": 30.0, "gpus": "1", "gpu-model": K80,
+                                        "disk": {"disk-request": 10.0, "disk-limit": 50.0, "disk-type": "standard"}}),
+    kpod("podD", "hostC", {"cpus": 1.0, "disk": {"disk-request": 100.0, "disk-type": "pd-ssd"}}),
+    kpod("podD", "hostC", {"cpus": 1.0, "disk": {"disk-type": "pd-ssd"}}),
+    kpod("podE", None, {"cpus": 12.0}),
+]
+_AGG_REST = {"hostB": {"cpus": 3.0, "mem": 130.0, "gpus": {K80: 1}, "disk": {"standard": 10.0}},
+             "hostC": {"cpus": 2.0, "mem": 0.0, "disk": {"pd-ssd": 10100.0}}}
+
+K8S_CONSUMPTION = [
+    dict(name="single pod without gpus", ref=f"{T_KAPI}:23-29", clobber=False,
+         pods=[kpod("podA", "hostA", {"cpus": 1.0, "mem": 100.0})], expect={"hostA": {"cpus": 1.0, "mem": 100.0}}),
+    dict(name="single pod with gpus", ref=f"{T_KAPI}:31-38", clobber=False,
+         pods=[kpod("podA", "hostA", {"cpus": 1.0, "mem": 100.0, "gpus": "2", "gpu-model": P100})],
+         expect={"hostA": {"cpus": 1.0, "mem": 100.0, "gpus": {P100: 2}}}),
+    dict(name="multiple containers without gpus", ref=f"{T_KAPI}:40-48", clobber=False,
+         pods=[kpod("podA", "hostA", {"cpus": 1.0, "mem": 100.0, "gpus": "0"}, {"cpus": 1.0, "mem": 0.0}, {"mem": 100.0})],
+         expect={"hostA": {"cpus": 2.0, "mem": 200.0}}),
+    dict(name="multiple containers with gpus", ref=f"{T_KAPI}:50-59", clobber=False,
+         pods=[kpod("podA", "hostA", {"cpus": 1.0, "mem": 100.0, "gpus": "1", "gpu-model": P100},
+                    {"cpus": 1.0, "mem": 0.0, "gpus": "4", "gpu-model": P100}, {"mem": 100.0})],
+         expect={"hostA": {"cpus": 2.0, "mem": 200.0, "gpus": {P100: 5}}}),
+    dict(name="aggregates pods by node name", ref=f"{T_KAPI}:61-93", clobber=False, pods=_AGG_PODS,
+         expect=dict({"hostA": {"cpus": 2.0, "mem": 100.0, "gpus": {P100: 3}}}, **_AGG_REST)),
+    dict(name="aggregates pods by node name, synthetic pods clobbered", ref=f"{T_KAPI}:94-98", clobber=True, pods=_AGG_PODS,
+         expect=dict({"hostA": {"cpus": 1.0, "mem": 0.0, "gpus": {P100: 1}}}, **_AGG_REST)),
+]
+
+K8S_CAPACITY = [
+    dict(name="capacity with and without gpus", ref=f"{T_KAPI}:100-109",
+         nodes=[knode("nodeA", 1.0, 100.0, 2, P100), knode("nodeB", 1.0, None), knode("nodeC", None, 100.0, 5, P100),
+                knode("nodeD", None, None, 7, P100)],
+         expect={"nodeA": {"cpus": 1.0, "mem": 100.0, "gpus": {P100: 2}}, "nodeB": {"cpus": 1.0, "mem": 0.0},
+                 "nodeC": {"cpus": 0.0, "mem": 100.0, "gpus": {P100: 5}}, "nodeD": {"cpus": 0.0, "mem": 0.0, "gpus": {P100: 7}}}),
+    dict(name="capacity with disk", ref=f"{T_KAPI}:110-114",
+         nodes=[knode("nodeA", 1.0, 100.0, 2, P100, {"disk-amount": 10000, "disk-type": "standard"}),
+                knode("nodeB", 2.0, 100.0, None, None, {"disk-amount": 10000, "disk-type": "pd-ssd"})],
+         expect={"nodeA": {"cpus": 1.0, "mem": 100.0, "gpus": {P100: 2}, "disk": {"standard": 10000.0}},
+                 "nodeB": {"cpus": 2.0, "mem": 100.0, "disk": {"pd-ssd": 10000.0}}}),
+]
+
+
+def _bare(**flags):
+    d = dict(name="NodeName", allocatable=None, gpu_type=None, disk_type=None, unschedulable=False, other_taints=False,
+             blocklist_label=False, gpu_taint=False)
+    d.update(flags)
+    return d
+
+
+# api/num-pods-on-node is redefined to 1 and the pod-count capacity is 30 throughout (api.clj:844); label / taint matching is
+# the host's job, so each case carries the predicate values the cited form sets up
+K8S_SCHEDULABLE = [
+    dict(ref=f"{T_KAPI}:855", node=_bare(blocklist_label=True), filter_unsound=False, expect=False),
+    dict(ref=f"{T_KAPI}:856", node=_bare(), filter_unsound=False, expect=True),
+    dict(ref=f"{T_KAPI}:872", node=_bare(), filter_unsound=False, expect=True),            # the pool's own taint
+    dict(ref=f"{T_KAPI}:873", node=_bare(other_taints=True), filter_unsound=False, expect=False),
+    dict(ref=f"{T_KAPI}:889", node=_bare(other_taints=True), filter_unsound=False, expect=False),
+    dict(ref=f"{T_KAPI}:908", node=_bare(gpu_taint=True, allocatable={"nvidia.com/gpu": 1}), filter_unsound=False, expect=True),
+    dict(ref=f"{T_KAPI}:918", node=_bare(unschedulable=True), filter_unsound=False, expect=False),
+    dict(ref=f"{T_KAPI}:928", node=_bare(unschedulable=None), filter_unsound=False, expect=True),
+    dict(ref=f"{T_KAPI}:937", node=_bare(), filter_unsound=False, expect=True),
+    dict(ref=f"{T_KAPI}:946", node=_bare(gpu_taint=True), filter_unsound=False, expect=True),
+    dict(ref=f"{T_KAPI}:948", node=_bare(gpu_taint=True), filter_unsound=True, expect=False),
+    dict(ref=f"{T_KAPI}:952", node=_bare(gpu_taint=True, allocatable={"nvidia.com/gpu": 0}), filter_unsound=True, expect=False),
+]
+
+_GO_NODES = [knode("nodeA", 1.0, 1000.0, 10, P100), knode("nodeB", 1.0, 1000.0, 25, P100), knode("nodeC", 1.0, 1000.0),
+             knode("nodeE", 2.0, 1100.0, None, None, {"disk-amount": 256000, "disk-type": "pd-standard"}),
+             knode("my.fake.host", 1.0, 1000.0)]
+# pods of the test + the two starting pods that (cc/launch-tasks ...) registered for task-1 / task-2 on "my.fake.host"
+# (dummy jobs of 0.1 and 0.2 cpus, 10 MiB each: add-starting-pods, compute_cluster.clj:148-170 of the test)
+_GO_PODS = [
+    kpod("podA", "nodeA", {"cpus": 0.25, "mem": 250.0, "gpus": "9", "gpu-model": P100}, {"cpus": 0.1, "mem": 100.0}),
+    kpod("podB", "nodeA", {"cpus": 0.25, "mem": 250.0, "gpus": "1", "gpu-model": P100}),
+    kpod("podC", "nodeB", {"cpus": 1.0, "mem": 1100.0, "gpus": "10", "gpu-model": P100}),
+    kpod("podD", "nodeD", {"cpus": 1.0, "mem": 1100.0, "gpus": "10", "gpu-model": P100}),
+    kpod("podE", "nodeE", {"cpus": 1.0, "mem": 1100.0, "disk": {"disk-request": 50, "disk-limit": 70, "disk-type": "pd-standard"}}),
+    kpod("task-1", "my.fake.host", {"cpus": 0.1, "mem": 10.0}),
+    kpod("task-2", "my.fake.host", {"cpus": 0.2, "mem": 10.0}),
+]
+_GO_A_FULL = dict(mem=1000.0, cpus=1.0, disk={}, gpus={P100: 10})
+
+K8S_OFFERS = [
+    dict(name="test-generate-offers", ref=f"{T_KCC}:120-215", nodes=_GO_NODES, pods=_GO_PODS, max_pods=3, n_offers=5,
+         expect={"nodeA": dict(mem=400.0, cpus=0.4, disk={}, gpus={P100: 0}),
+                 "nodeB": dict(mem=0.0, cpus=0.0, disk={}, gpus={P100: 15}),
+                 "my.fake.host": dict(mem=980.0, cpus=0.7, disk={}, gpus={}),
+                 "nodeE": dict(mem=0.0, cpus=1.0, disk={"pd-standard": 255950.0}, gpus={})}),
+    dict(name="node with empty pod list", ref=f"{T_KCC}:221-231", nodes=_GO_NODES, pods=[p for p in _GO_PODS if p["node"] != "nodeA"],
+         max_pods=3, n_offers=5, expect={"nodeA": _GO_A_FULL}),
+    dict(name="node whose pods have no resource requests", ref=f"{T_KCC}:243-253", nodes=_GO_NODES,
+         pods=[p for p in _GO_PODS if p["node"] != "nodeA"] +
+              [dict(name="bare1", node="nodeA", containers=[], gpu_model=None, disk_type=None, synthetic=False),
+               dict(name="bare2", node="nodeA", containers=[], gpu_model=None, disk_type=None, synthetic=False)],
+         max_pods=3, n_offers=5, expect={"nodeA": _GO_A_FULL}),
+]
+
+
 def main():
-    out = dict(rank=RANK, rank_group=RANK_GROUP, quota_group_agg=QUOTA_GROUP_AGG, match=MATCH + CONSTRAINTS + GROUPS_FENZO + HRO, rebalance=REBALANCE, considerable=CONSIDERABLE)
+    out = dict(rank=RANK, rank_group=RANK_GROUP, quota_group_agg=QUOTA_GROUP_AGG, match=MATCH + CONSTRAINTS + GROUPS_FENZO + HRO, rebalance=REBALANCE, considerable=CONSIDERABLE,
+               offers=dict(consumption=K8S_CONSUMPTION, capacity=K8S_CAPACITY, schedulable=K8S_SCHEDULABLE, generate=K8S_OFFERS))
     for k, v in out.items():
         with open(os.path.join(HERE, f"{k}.json"), "w") as f:
             json.dump(v, f, indent=1, sort_keys=True)

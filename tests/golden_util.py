@@ -302,3 +302,41 @@ def build_considerable_inputs(case):
         pool_quota=usage_of(case["pool_quota"]) if "pool_quota" in case else None,
         pool_usage=usage_of(case["pool_usage"]) if "pool_usage" in case else None)
     return queue, st, [j["name"] for j in q], unames
+
+
+# ---- offer construction (tests/golden/offers.json) -----------------------------------------------------------------------
+def build_offers_inputs(case):
+    """map-level vector -> (Nodes, Pods, CookOfferParams, node names in row order, gpu model names, disk type names).
+    The host's part of the boundary: nodes in ascending name order, names interned to dense ids (0 = none), one row per
+    pod with the containers' requests summed (merge-with +, api.clj:904-911)."""
+    nodes = sorted(case["nodes"], key=lambda n: n["name"])
+    names = [n["name"] for n in nodes]
+    idx = {n: i for i, n in enumerate(names)}
+    pods = case["pods"]
+    gm = sorted({n["gpu_type"] for n in nodes if n.get("gpu_type")} | {p["gpu_model"] for p in pods if p.get("gpu_model")})
+    dt = sorted({n["disk_type"] for n in nodes if n.get("disk_type")} | {p["disk_type"] for p in pods if p.get("disk_type")})
+    gid = {m: i + 1 for i, m in enumerate(gm)}
+    did = {t: i + 1 for i, t in enumerate(dt)}
+    alloc = lambda n, k, d: (n.get("allocatable") or {}).get(k, d)  # noqa: E731
+    flags = [(A.NODE_UNSCHEDULABLE if n.get("unschedulable") else 0) | (A.NODE_OTHER_TAINTS if n.get("other_taints") else 0) |
+             (A.NODE_BLOCKLIST_LABEL if n.get("blocklist_label") else 0) | (A.NODE_GPU_TAINT if n.get("gpu_taint") else 0) for n in nodes]
+    N = A.Nodes(cpus=[alloc(n, "cpu", 0.0) for n in nodes], mem=[alloc(n, "memory", 0.0) for n in nodes],
+                gpus=[alloc(n, "nvidia.com/gpu", 0) for n in nodes], gpu_model=[gid.get(n.get("gpu_type"), 0) for n in nodes],
+                disk=[alloc(n, "ephemeral-storage", -1.0) for n in nodes], disk_type=[did.get(n.get("disk_type"), 0) for n in nodes],
+                flags=flags)
+    rows = dict(node=[], cpus=[], mem=[], gpus=[], gpu_model=[], disk=[], disk_type=[], flags=[])
+    for p in pods:
+        cs = [c for c in (p.get("containers") or []) if c is not None]
+        tot = lambda k: sum(c[k] for c in cs if k in c)  # noqa: E731  (exact for the vectors' values, any order)
+        rows["node"].append(idx.get(p.get("node"), A.NONE_U32))
+        rows["cpus"].append(float(tot("cpu")))
+        rows["mem"].append(float(tot("memory")))
+        rows["gpus"].append(int(tot("nvidia.com/gpu")))
+        rows["gpu_model"].append(gid.get(p.get("gpu_model"), 0))
+        rows["disk"].append(float(tot("ephemeral-storage")) if any("ephemeral-storage" in c for c in cs) else -1.0)
+        rows["disk_type"].append(did.get(p.get("disk_type"), 0))
+        rows["flags"].append((A.POD_SYNTHETIC if p.get("synthetic") else 0) | (0 if cs else A.POD_NO_REQUESTS))
+    P = A.Pods(**{k: np.array(v) for k, v in rows.items()})
+    params = A.offer_params(clobber_synthetic_pods=case.get("clobber", False), max_pods_per_node=case.get("max_pods", 2 ** 31 - 1),
+                            filter_out_unsound_gpu_nodes=case.get("filter_unsound", False), n_gpu_models=len(gm), n_disk_types=len(dt))
+    return N, P, params, names, gm, dt

@@ -386,3 +386,115 @@ def edge_cases(make_engine):
     # considerable: K = 0
     queue, st = make_considerable_case(seed=84, n=30, n_users=4)
     assert len(considerable_parity(make_engine, queue, st, 0)) == 0
+
+
+# ---- offer construction from node state (cook_offers_build vs oracle/k8s_offers.py) ---------------------------------------
+def _offers_equal(got: A.BuiltOffers, want, tag):
+    for k, v in want["rows"].items():
+        g = getattr(got, k)
+        assert g.dtype == v.dtype and np.array_equal(g, v), (tag, k, g[:8], v[:8])  # fp64 ==: bit-exact sums
+    assert np.array_equal(got.node_status, want["status"]), (tag, "status")
+    for k, v in want["totals"].items():
+        assert got.totals[k] == v, (tag, k, got.totals[k], v)
+    for k in ("gpu_capacity_by_model", "gpu_consumed_by_model", "disk_capacity_by_type", "disk_consumed_by_type"):
+        assert np.array_equal(getattr(got, k), want[k]), (tag, k, getattr(got, k), want[k])
+
+
+def offers_parity(make_engine, nodes, pods, oparams, tag=""):
+    from oracle import k8s_offers
+    with make_engine(A.default_params()) as e:
+        got = e.offers_build(nodes, pods, oparams)
+        e.offers_run()  # repeatable on staged inputs
+        again = e.offers_fetch()
+    want = k8s_offers.build_rows(nodes, pods, oparams)
+    _offers_equal(got, want, tag)
+    _offers_equal(again, want, tag + " (second run)")
+    if nodes.attr is not None:
+        assert np.array_equal(got.attr, nodes.attr[got.node]), (tag, "attr rows")
+    return got
+
+
+def check_offers_golden(make_engine):
+    """the reference's own generate-offers / get-consumption vectors through the C ABI"""
+    from oracle import k8s_offers
+    gold = G.load("offers")
+    for case in gold["generate"]:
+        nodes, pods, op, names, gm, dt = G.build_offers_inputs(case)
+        got = offers_parity(make_engine, nodes, pods, op, case["name"])
+        assert got.n == case["n_offers"], case["name"]
+        by = {names[v]: r for r, v in enumerate(got.node)}
+        for host, exp in case["expect"].items():
+            r = by[host]
+            assert got.cpus[r] == exp["cpus"] and got.mem[r] == exp["mem"], (case["name"], host, got.cpus[r], got.mem[r])
+            gpus = {gm[got.gpu_model[r] - 1]: got.gpu_count[r]} if got.gpu_model[r] else {}
+            disk = {dt[got.disk_type[r] - 1]: got.disk_space[r]} if got.disk_type[r] else {}
+            assert gpus == exp["gpus"] and disk == exp["disk"], (case["name"], host, gpus, disk)
+    # get-consumption vectors: every host gets an ample node, so consumption = capacity - available
+    for case in gold["consumption"]:
+        hosts = sorted({p["node"] for p in case["pods"] if p["node"]})
+        big = dict(cpu=64.0, memory=65536.0)
+        nodes_l = []
+        for h in hosts:
+            exp = case["expect"].get(h, {})
+            alloc = dict(big)
+            gt = next(iter(exp.get("gpus", {})), None)
+            dty = next(iter(exp.get("disk", {})), None)
+            if gt:
+                alloc["nvidia.com/gpu"] = 16
+            if dty:
+                alloc["ephemeral-storage"] = 1048576.0
+            nodes_l.append(dict(name=h, allocatable=alloc, gpu_type=gt, disk_type=dty))
+        nodes, pods, op, names, gm, dt = G.build_offers_inputs(dict(nodes=nodes_l, pods=case["pods"], clobber=case["clobber"]))
+        got = offers_parity(make_engine, nodes, pods, op, case["name"])
+        for r, v in enumerate(got.node):
+            exp = case["expect"][names[v]]
+            assert 64.0 - got.cpus[r] == exp["cpus"] and 65536.0 - got.mem[r] == exp["mem"], (case["name"], names[v])
+            if exp.get("gpus"):
+                assert 16 - got.gpu_count[r] == next(iter(exp["gpus"].values())), (case["name"], names[v])
+            if exp.get("disk"):
+                assert 1048576.0 - got.disk_space[r] == next(iter(exp["disk"].values())), (case["name"], names[v])
+    for case in gold["schedulable"]:
+        n = dict(case["node"])
+        n["allocatable"] = dict(n.get("allocatable") or {}, cpu=1.0, memory=1.0)
+        nodes, pods, op, *_ = G.build_offers_inputs(dict(nodes=[n], pods=[dict(name="p", node=n["name"], containers=[{"cpu": 0.5}])],
+                                                         max_pods=30, filter_unsound=case["filter_unsound"]))
+        got = offers_parity(make_engine, nodes, pods, op, case["ref"])
+        assert (got.n == 1) == case["expect"], case["ref"]
+    assert k8s_offers is not None
+
+
+def offers_edge_cases(make_engine):
+    op = A.offer_params(max_pods_per_node=4, n_gpu_models=2, n_disk_types=2)
+    none = A.Pods(node=np.zeros(0), cpus=np.zeros(0), mem=np.zeros(0))
+    # no nodes at all; nodes without pods; pods without nodes; a node exactly at / below the pod limit
+    got = offers_parity(make_engine, A.Nodes(cpus=np.zeros(0), mem=np.zeros(0)), none, op, "no nodes")
+    assert got.n == 0 and got.totals["cpus_capacity"] == 0.0
+    nodes = A.Nodes(cpus=[4.0, 8.0, 2.0], mem=[1024.0, 2048.0, 512.0], gpus=[0, 2, 0], gpu_model=[0, 1, 0])
+    assert offers_parity(make_engine, nodes, none, op, "no pods").n == 3
+    stray = A.Pods(node=[A.NONE_U32, 7, 3], cpus=[1.0, 1.0, 1.0], mem=[1.0, 1.0, 1.0])
+    got = offers_parity(make_engine, nodes, stray, op, "pods without a node of the pool")
+    assert got.n == 3 and got.totals["cpus_consumed"] == 0.0
+    limit = A.Pods(node=[0, 0, 0, 0, 1, 1, 1], cpus=[0.1] * 7, mem=[0.3] * 7)
+    got = offers_parity(make_engine, nodes, limit, op, "pod limit")
+    assert list(got.node) == [1, 2] and got.num_pods[0] == 3
+    # over-committed node: negative availability clamps to 0.0 for cpus / mem, gpu count goes negative as in the reference
+    over = A.Pods(node=[1, 1], cpus=[6.0, 6.0], mem=[4096.0, 1.0], gpus=[2, 1], gpu_model=[1, 1])
+    got = offers_parity(make_engine, nodes, over, op, "over-committed")
+    assert got.cpus[1] == 0.0 and got.mem[1] == 0.0 and got.gpu_count[1] == -1.0
+
+
+def offers_feed_match(make_engine, n_nodes=120, n_pods=700, n_jobs=300):
+    """offer rows built on the device are valid match input: placing jobs on them gives the assignments the oracle's match
+    gives on the oracle's offers"""
+    from oracle import k8s_offers
+    nodes, pods, op = synth.make_cluster_state(seed=11, n_nodes=n_nodes, n_pods=n_pods, n_attr_keys=8, fractional=False)
+    pool = synth.make_pool(seed=12, n_pending=n_jobs, n_running=0, n_users=30, n_offers=10, gpus=True)
+    p = A.default_params(good_enough_fitness=1.0)
+    with make_engine(p) as e:
+        built = e.offers_build(nodes, pods, op)
+        j2o, _, head = e.match(pool.pending_jobs, built.as_offers(), None)
+    want = k8s_offers.build_rows(nodes, pods, op)["rows"]
+    o_offers = A.Offers(cpus=want["cpus"], mem=want["mem"], host=want["host"], k8s=np.ones(len(want["cpus"]), np.uint8),
+                        gpu_model=want["gpu_model"], gpu_count=want["gpu_count"], attr=nodes.attr[want["node"]])
+    o_j2o, _, o_head = pyoracle.match(p, pool.pending_jobs, o_offers, None)
+    assert np.array_equal(j2o, o_j2o) and head == o_head and (j2o >= 0).sum() > n_jobs // 10

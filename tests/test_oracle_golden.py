@@ -135,3 +135,43 @@ def test_considerable_golden(oracle, case):
     queue, st, names, unames = G.build_considerable_inputs(case)
     idx, rl, _ = oracle.considerable(queue, st, case["num_considerable"])
     check_considerable_case(case, idx, rl, names, unames)
+
+
+# ---- offer construction from node state (oracle/k8s_offers.py vs the reference's kubernetes tests) -------------------------
+def _n2p(pods):
+    out = {}
+    for p in pods:
+        out.setdefault(p["node"], []).append(p)
+    return out
+
+
+def test_k8s_consumption_golden():
+    from oracle import k8s_offers as K
+    for c in G.load("offers")["consumption"]:
+        assert K.get_consumption(c["clobber"], _n2p(c["pods"])) == c["expect"], c["name"]
+
+
+def test_k8s_capacity_golden():
+    from oracle import k8s_offers as K
+    for c in G.load("offers")["capacity"]:
+        assert K.get_capacity({n["name"]: n for n in c["nodes"]}) == c["expect"], c["name"]
+
+
+def test_k8s_node_schedulable_golden():
+    from oracle import k8s_offers as K
+    for c in G.load("offers")["schedulable"]:
+        n2p = {c["node"]["name"]: [dict(name="p")]}  # num-pods-on-node redefined to 1, capacity 30 (api.clj:844)
+        assert K.node_schedulable(c["node"], 30, n2p, c["filter_unsound"]) == c["expect"], c["ref"]
+    assert K.node_schedulable(None, 30, {}) is False  # api.clj:789-790
+
+
+def test_k8s_generate_offers_golden():
+    from oracle import k8s_offers as K
+    for c in G.load("offers")["generate"]:
+        offers, gauges, _ = K.generate_offers({n["name"]: n for n in c["nodes"]}, _n2p(c["pods"]), max_pods_per_node=c["max_pods"])
+        assert len(offers) == c["n_offers"], c["name"]
+        by = {o["hostname"]: o for o in offers}
+        for host, exp in c["expect"].items():
+            got = {k: by[host][k] for k in ("mem", "cpus", "disk", "gpus")}
+            assert got == exp, (c["name"], host, got)
+        assert gauges["nodes_total"] == 5 and gauges["nodes_schedulable"] == 5

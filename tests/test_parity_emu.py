@@ -209,3 +209,27 @@ def test_multi_pool_lockstep(make_engine):
 
 def test_edge_cases(make_engine):
     P.edge_cases(make_engine)
+
+
+# ---- offer construction from node state ---------------------------------------------------------------------------------------
+def test_offers_golden(make_engine):
+    P.check_offers_golden(make_engine)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(seed=1, n_nodes=300, n_pods=2500),
+    dict(seed=2, n_nodes=700, n_pods=9000, disk=True, corrupt=0.05, n_attr_keys=5),       # multi-block sort, foreign models / types
+    dict(seed=3, n_nodes=64, n_pods=3000, disk=True, max_pods=40),                        # long pod lists, pod limit
+    dict(seed=4, n_nodes=500, n_pods=40, gpus=False, fractional=False),                   # mostly idle nodes
+], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_offers_parity_random(make_engine, kw):
+    nodes, pods, op = synth.make_cluster_state(**kw)
+    P.offers_parity(make_engine, nodes, pods, op, str(kw))
+
+
+def test_offers_edge_cases(make_engine):
+    P.offers_edge_cases(make_engine)
+
+
+def test_offers_feed_the_match(make_engine):
+    P.offers_feed_match(make_engine)
