@@ -357,3 +357,19 @@ JNIEXPORT jint JNICALL Java_cook_hip_Native_offersFetch(JNIEnv* env, jclass c, j
                            EL(int64_t, by_model_type, 0), EL(int64_t, by_model_type, 1), EL(double, by_model_type, 2),
                            EL(double, by_model_type, 3));
 }
+
+/* ---- consumers of the placement's by-products ----------------------------------------------------------------------- */
+/* fenzo-utils/summarize-placement-failure (fenzo_utils.clj:33-55): counts_out = direct buffer of n x COOK_WHY_SLOTS uint32 */
+JNIEXPORT jint JNICALL Java_cook_hip_Native_matchExplain(JNIEnv* env, jclass c, jlong h, jobject job_pos, jint n, jobject counts_out) {
+  (void)c;
+  return cook_match_explain(H(h), BUF(const uint32_t, job_pos), (uint32_t)n, BUF(uint32_t, counts_out));
+}
+/* handle-match-cycle-metrics (scheduler.clj:1210-1280): metrics_out = direct buffer holding a cook_cycle_metrics */
+JNIEXPORT jint JNICALL Java_cook_hip_Native_matchMetrics(JNIEnv* env, jclass c, jlong h, jobject metrics_out, jobject user_considerable_out,
+                                                         jobject user_matched_out, jint n_users, jobject job_gpus_out,
+                                                         jobject offer_gpus_out, jint n_gpu_models) {
+  (void)c;
+  return cook_match_metrics(H(h), BUF(cook_cycle_metrics, metrics_out), BUF(uint32_t, user_considerable_out),
+                            BUF(uint32_t, user_matched_out), (uint32_t)n_users, BUF(int64_t, job_gpus_out), BUF(int64_t, offer_gpus_out),
+                            (uint32_t)n_gpu_models);
+}

@@ -700,3 +700,42 @@ class BuiltOffers:
         """The rows as match input (offer.clj:31-76: Kubernetes leases carry compute-cluster-type = kubernetes)."""
         return Offers(cpus=self.cpus, mem=self.mem, host=self.host, k8s=np.ones(self.n, np.uint8), gpu_model=self.gpu_model,
                       gpu_count=self.gpu_count, disk_type=self.disk_type, disk_space=self.disk_space, attr=self.attr, **kw)
+
+
+# ---- why-unscheduled summaries and match-cycle metrics ------------------------------------------------------------------------
+WHY_SLOTS = 16
+WHY_NAMES = {  # slot -> the key of fenzo-utils/summarize-placement-failure's map (fenzo_utils.clj:33-55)
+    0: (":resources", "cpus"), 1: (":resources", "mem"), 2: (":resources", "fitness"),
+    3: (":constraints", "checkpoint_locality_constraint"), 4: (":constraints", "estimated_completion_constraint"),
+    5: (":constraints", "user_defined_constraint"), 6: (":constraints", "disk_host_constraint"),
+    7: (":constraints", "gpu_host_constraint"), 8: (":constraints", "novel_host_constraint"),
+    9: (":constraints", "max_tasks_per_host"), 10: (":constraints", "rebalancer_reservation_constraint"),
+    11: (":constraints", "unique_host_placement_group_constraint"),
+    12: (":constraints", "balanced_host_placement_group_constraint"),
+    13: (":constraints", "attribute_equals_host_placement_group_constraint"),
+}
+
+
+def why_summary(row) -> dict:
+    """one COOK_WHY_* row -> the reference's {:resources {...} :constraints {...}} map (zero counts omitted)"""
+    out: dict = {}
+    for slot, (kind, name) in WHY_NAMES.items():
+        if row[slot]:
+            out.setdefault(kind, {})[name] = int(row[slot])
+    return out
+
+
+class CookResourceStats(C.Structure):
+    _fields_ = [("total_cpus", C.c_double), ("total_mem", C.c_double),
+                ("p50_cpus", C.c_double), ("p95_cpus", C.c_double), ("p100_cpus", C.c_double),
+                ("p50_mem", C.c_double), ("p95_mem", C.c_double), ("p100_mem", C.c_double),
+                ("largest_by_cpus", C.c_uint32), ("largest_by_mem", C.c_uint32)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class CookCycleMetrics(C.Structure):
+    _fields_ = [("considerable", C.c_uint32), ("matched", C.c_uint32), ("unmatched", C.c_uint32),
+                ("offers", C.c_uint32), ("offers_scheduled", C.c_uint32), ("head_matched", C.c_uint32),
+                ("reserved", C.c_uint32 * 2), ("jobs", CookResourceStats), ("offer_stats", CookResourceStats)]

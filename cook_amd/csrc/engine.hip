@@ -18,6 +18,7 @@
 #include "match_kernels.hpp"
 #include "match_v2.hpp"
 #include "offers_kernels.hpp"
+#include "explain_kernels.hpp"
 #include "rank_kernels.hpp"
 #include "rebalance_kernels.hpp"
 #include "scan.hpp"
@@ -78,6 +79,7 @@ struct KernelStat {
 struct RebalBufs;  // rebalance_host.hpp
 struct ConsBufs;   // considerable_host.hpp
 struct OfferBufs;  // offers_host.hpp
+struct ExplainBufs;  // explain_host.hpp
 
 }  // namespace
 
@@ -171,6 +173,10 @@ struct cook_engine {
   ConsBufs* cb = nullptr;
   // ---- offer construction (allocated on first use) ----
   OfferBufs* ofb = nullptr;
+  // ---- why-unscheduled summaries / match-cycle metrics (allocated on first use) ----
+  ExplainBufs* xb = nullptr;
+  MatchIn last_in{};  // the MatchIn of the last match run (K, j_index as used)
+  bool last_in_valid = false;
   DArr<uint32_t> j_user;
   bool has_j_user = false;
 
@@ -704,6 +710,8 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
   in.good_enough = e->params.good_enough_fitness;
   in.host_lifetime_mins = e->params.host_lifetime_mins;
   const unsigned M = in.M, G = in.G;
+  e->last_in = in;
+  e->last_in_valid = true;
   MatchState st;
   st.ac = e->m_ac.ensure(M);
   st.am = e->m_am.ensure(M);
@@ -978,10 +986,16 @@ struct StageTimer {
 #include "considerable_host.hpp"
 #include "rebalance_host.hpp"
 #include "offers_host.hpp"
+#include "explain_host.hpp"
 
 ConsBufs& cons_bufs(cook_engine* e) {
   if (!e->cb) e->cb = new ConsBufs();
   return *e->cb;
+}
+
+ExplainBufs& explain_bufs(cook_engine* e) {
+  if (!e->xb) e->xb = new ExplainBufs();
+  return *e->xb;
 }
 
 OfferBufs& offer_bufs(cook_engine* e) {
@@ -1097,6 +1111,8 @@ void cook_engine_destroy(cook_engine* e) {
   e->cb = nullptr;
   delete e->ofb;
   e->ofb = nullptr;
+  delete e->xb;
+  e->xb = nullptr;
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1354,6 +1370,20 @@ int cook_rebalance_timing(cook_engine* e, double* ms) {
   if (!e || !ms) return COOK_E_INVALID;
   *ms = e->rb ? e->rb->ms : 0.0;
   return COOK_OK;
+}
+
+int cook_match_explain(cook_engine* e, const uint32_t* job_pos, uint32_t n, uint32_t* counts) {
+  return guarded(e, [&] {
+    match_explain(e, explain_bufs(e), job_pos, n, counts);
+    prof_collect(e);
+  });
+}
+int cook_match_metrics(cook_engine* e, cook_cycle_metrics* out, uint32_t* user_considerable, uint32_t* user_matched, uint32_t n_users,
+                       int64_t* job_gpus_by_model, int64_t* offer_gpus_by_model, uint32_t n_gpu_models) {
+  return guarded(e, [&] {
+    match_metrics(e, explain_bufs(e), out, user_considerable, user_matched, n_users, job_gpus_by_model, offer_gpus_by_model, n_gpu_models);
+    prof_collect(e);
+  });
 }
 
 int cook_offers_stage(cook_engine* e, const cook_nodes* nodes, const cook_pods* pods, const cook_offer_params* params) {

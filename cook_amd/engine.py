@@ -24,6 +24,7 @@ EXPORTS = [
     "cook_cycle_stage", "cook_cycle_run", "cook_cycle_fetch", "cook_cycle_run_rank", "cook_cycle_match_multi",
     "cook_considerable", "cook_cycle_set_considerable", "cook_cycle_fetch_considerable",
     "cook_rebalance", "cook_rebalance_stage", "cook_rebalance_run", "cook_rebalance_fetch", "cook_rebalance_timing",
+    "cook_match_explain", "cook_match_metrics",
     "cook_offers_build", "cook_offers_stage", "cook_offers_run", "cook_offers_fetch", "cook_offers_timing",
     "cook_last_timing", "cook_kernel_timings", "cook_set_profiling", "cook_match_stats",
 ]
@@ -271,6 +272,31 @@ class Engine:
         ms = C.c_double(0)
         self._lib.cook_rebalance_timing(self._h, C.byref(ms))
         return ms.value
+
+    # ---- consumers of the placement's by-products ----------------------------------------------------------------
+    def match_explain(self, job_pos) -> np.ndarray:
+        """fenzo-utils/summarize-placement-failure (fenzo_utils.clj:33-55) for the given job positions of the LAST match:
+        -> uint32 [n, WHY_SLOTS] host counts (A.why_summary turns a row into the reference's map)."""
+        pos = np.ascontiguousarray(job_pos, dtype=np.uint32)
+        out = np.zeros((max(1, len(pos)), A.WHY_SLOTS), dtype=np.uint32)
+        self._chk(self._lib.cook_match_explain(self._h, _p(pos, C.c_uint32) if len(pos) else None, len(pos),
+                                               _p(out.reshape(-1), C.c_uint32)))
+        return out[: len(pos)].copy()
+
+    def match_metrics(self, n_users: int = 0, n_gpu_models: int = 0) -> dict:
+        """handle-match-cycle-metrics' numbers (scheduler.clj:1210-1280) for the LAST match."""
+        m = A.CookCycleMetrics()
+        uc = np.zeros(max(1, n_users), np.uint32)
+        um = np.zeros(max(1, n_users), np.uint32)
+        jg = np.zeros(n_gpu_models + 1, np.int64)
+        og = np.zeros(n_gpu_models + 1, np.int64)
+        self._chk(self._lib.cook_match_metrics(self._h, C.byref(m), _p(uc, C.c_uint32) if n_users else None,
+                                               _p(um, C.c_uint32) if n_users else None, n_users, _p(jg, C.c_int64), _p(og, C.c_int64),
+                                               n_gpu_models))
+        return dict(considerable=m.considerable, matched=m.matched, unmatched=m.unmatched, offers=m.offers,
+                    offers_scheduled=m.offers_scheduled, head_matched=bool(m.head_matched), jobs=m.jobs.as_dict(),
+                    offers_stats=m.offer_stats.as_dict(), user_considerable=uc[:n_users].copy(), user_matched=um[:n_users].copy(),
+                    job_gpus_by_model=jg, offer_gpus_by_model=og)
 
     # ---- offer construction from node state --------------------------------------------------------------------
     def offers_stage(self, nodes: A.Nodes, pods: A.Pods, oparams: A.CookOfferParams):

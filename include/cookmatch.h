@@ -311,6 +311,58 @@ int cook_rebalance_fetch(cook_engine* e, cook_preemption* decisions, uint32_t* n
 /* HIP-event time of the last cook_rebalance_run in milliseconds */
 int cook_rebalance_timing(cook_engine* e, double* ms);
 
+/* ---- EXPLAIN: the placement-failure summary of a job ("why unscheduled") --------------------------------------------
+ * Replaces fenzo-utils/summarize-placement-failure over the TaskAssignmentResults Fenzo returns for an unassigned task
+ * (scheduler/fenzo_utils.clj:33-55, written to :job/last-fenzo-placement-failure at :71-89 and read back by
+ * unscheduled.clj:95-110).  For every job position of job_pos (an index into the jobs of the engine's LAST match: cook_match_run,
+ * cook_cycle_run or the lockstep pair) and every offer, against the state that job saw (the placements of the jobs ranked
+ * before it): the resources that did not fit ("cpus" / "mem", one count each per host) or else the FIRST failing hard constraint
+ * in the order Fenzo walks them ((into (list) constraints), scheduler.clj:493-501: checkpoint-locality, estimated-completion,
+ * user-defined, disk-host, gpu-host, novel-host, max_tasks_per_host, rebalancer-reservation, the group constraint) or else a zero
+ * fitness.  counts is [n][COOK_WHY_SLOTS] host counts; the reference's map is {:resources {"cpus" c0 "mem" c1} :constraints
+ * {<name> count ...}} over the non-zero slots.  For a job that was matched the row describes the hosts that refused it. */
+#define COOK_WHY_CPUS 0                /* :resources "cpus"                                        */
+#define COOK_WHY_MEM 1                 /* :resources "mem"                                         */
+#define COOK_WHY_FITNESS 2             /* fitness calculator returned 0.0                          */
+#define COOK_WHY_CHECKPOINT_LOCALITY 3 /* "checkpoint_locality_constraint" (constraints.clj:218)  */
+#define COOK_WHY_ESTIMATED_COMPLETION 4 /* "estimated_completion_constraint" (:385)                */
+#define COOK_WHY_USER_DEFINED 5        /* "user_defined_constraint" (:356)                         */
+#define COOK_WHY_DISK_HOST 6           /* "disk_host_constraint" (:164)                            */
+#define COOK_WHY_GPU_HOST 7            /* "gpu_host_constraint" (:122)                             */
+#define COOK_WHY_NOVEL_HOST 8          /* "novel_host_constraint" (:68)                            */
+#define COOK_WHY_MAX_TASKS 9           /* "max_tasks_per_host" (:438)                              */
+#define COOK_WHY_RESERVATION 10        /* "rebalancer_reservation_constraint" (:242)               */
+#define COOK_WHY_GROUP_UNIQUE 11       /* "unique_host_placement_group_constraint" (:586)          */
+#define COOK_WHY_GROUP_BALANCED 12     /* "balanced_host_placement_group_constraint" (:600)        */
+#define COOK_WHY_GROUP_ATTR_EQUALS 13  /* "attribute_equals_host_placement_group_constraint" (:628) */
+#define COOK_WHY_SLOTS 16
+int cook_match_explain(cook_engine* e, const uint32_t* job_pos, uint32_t n, uint32_t* counts);
+
+/* ---- METRICS: the numbers of handle-match-cycle-metrics (scheduler.clj:1210-1280) from the last match, on the device -----
+ * resource-maps->stats (scheduler.clj:547-582) of "cpus" and "mem": :totals summed in collection order (bit-identical to the
+ * reference's reduce), :percentiles by nearest rank over the sorted values (task_stats.clj:59-80), :largest-by = the last
+ * element of the stable sort by that resource (index in collection order).  An empty collection gives NaN / COOK_NONE_U32. */
+typedef struct cook_resource_stats {
+  double total_cpus, total_mem;
+  double p50_cpus, p95_cpus, p100_cpus;
+  double p50_mem, p95_mem, p100_mem;
+  uint32_t largest_by_cpus, largest_by_mem;
+} cook_resource_stats;
+typedef struct cook_cycle_metrics {
+  uint32_t considerable, matched, unmatched; /* number-considerable-jobs / -matched-jobs / -unmatched-jobs (:1383-1385)     */
+  uint32_t offers, offers_scheduled;         /* (count offers), (count offers-scheduled) = leases used (:1372-1374)        */
+  uint32_t head_matched;                     /* matched-considerable-jobs-head? (:1381): job 0 is among the matched         */
+  uint32_t reserved[2];
+  cook_resource_stats jobs;                  /* jobs->stats of the considerable jobs (:594-600)                            */
+  cook_resource_stats offer_stats;           /* offers->stats (:584-592)                                                   */
+} cook_cycle_metrics;
+/* user_considerable / user_matched (optional, len n_users): frequencies of the jobs' users (:1216-1227; needs the jobs' user
+ * column).  job_gpus_by_model / offer_gpus_by_model (optional, len n_gpu_models + 1, by model id; jobs without a model under
+ * 0): the "gpus/<model>" entries of :totals.  match-percent, queue-was-full? and the unmatched-cycles bookkeeping
+ * (:1404-1486) are host arithmetic on these numbers. */
+int cook_match_metrics(cook_engine* e, cook_cycle_metrics* out, uint32_t* user_considerable, uint32_t* user_matched, uint32_t n_users,
+                       int64_t* job_gpus_by_model, int64_t* offer_gpus_by_model, uint32_t n_gpu_models);
+
 /* ---- OFFERS: replaces the numeric core of kubernetes.compute-cluster/generate-offers ----------------------
  * (kubernetes/compute_cluster.clj:68-190: available = capacity - consumption per node, the schedulable filter, the
  * offer resources and the capacity / consumption totals it publishes; kubernetes/api.clj:747-765 convert-resource-map,

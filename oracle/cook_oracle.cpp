@@ -324,11 +324,69 @@ bool group_constraint_pass(const cook_jobs* j, uint32_t k, const cook_offers* o,
   return freq.count(target) != 0;
 }
 
+// The hard constraints in the order Fenzo walks them: make-task-request builds (into (list) constraints) from
+// (conj (make-fenzo-job-constraints job) reservation) ++ group constraints (scheduler.clj:493-501); conj on a seq prepends
+// and (into (list) ...) reverses, so the list Fenzo sees is
+//   checkpoint-locality, estimated-completion, user-defined, disk-host, gpu-host, novel-host   (constraints.clj:459-464 reversed)
+//   max_tasks_per_host (constraints.clj:433-456), rebalancer-reservation (:242-252), then the job's group constraint.
+// Returns the COOK_WHY_* slot of the FIRST failing constraint (the one Fenzo's ConstraintFailure names), -1 if all pass.
+int first_failed_constraint(const cook_params* p, const cook_jobs* j, uint32_t k, const cook_offers* o, uint32_t v,
+                            const cook_groups* g, const MatchState& st, const std::set<uint32_t>& reserved) {
+  const uint32_t host = o->host[v];
+  const bool k8s = o->k8s && o->k8s[v];
+  if (j->ckpt_location && j->ckpt_location[k] != 0) {  // checkpoint_locality_constraint
+    const uint32_t loc = o->location ? o->location[v] : 0;
+    if (loc != j->ckpt_location[k]) return 3;
+  }
+  if (j->est_end_ms && j->est_end_ms[k] != 0 && o->host_start_s && o->host_start_s[v] >= 0) {  // estimated_completion_constraint
+    const int64_t death = 1000 * o->host_start_s[v] + 60 * 1000 * p->host_lifetime_mins;
+    if (!(j->est_end_ms[k] < death)) return 4;
+  }
+  if (j->eq_off)  // user_defined_constraint
+    for (uint32_t x = j->eq_off[k]; x < j->eq_off[k + 1]; ++x)
+      if (offer_attr(o, v, j->eq_key[x]) != j->eq_val[x]) return 5;
+  if (j->disk_request && j->disk_request[k] >= 0 && k8s) {  // disk_host_constraint
+    const double space = (o->disk_type && o->disk_type[v] == j->disk_type[k]) ? o->disk_space[v] : 0.0;
+    if (!(space >= j->disk_request[k])) return 6;
+  }
+  {  // gpu_host_constraint
+    const double jg = j->gpus ? j->gpus[k] : 0.0;
+    if (k8s) {
+      const uint32_t om = o->gpu_model ? o->gpu_model[v] : 0;
+      if (jg > 0) {
+        const uint32_t jm = j->gpu_model ? j->gpu_model[k] : 0;
+        const double avail = (om != 0 && om == jm) ? o->gpu_count[v] : 0.0;
+        const int32_t on_vm = (o->run_count ? o->run_count[v] : 0) + st.acount[v];
+        if (!(avail == jg && on_vm == 0)) return 7;
+      } else if (om != 0) {
+        return 7;
+      }
+    } else if (!(jg == 0)) {
+      return 7;
+    }
+  }
+  if (j->novel_off)  // novel_host_constraint
+    for (uint32_t x = j->novel_off[k]; x < j->novel_off[k + 1]; ++x)
+      if (j->novel_host[x] == host) return 8;
+  if (o->max_tasks && o->max_tasks[v] >= 0)  // max_tasks_per_host
+    if (!((o->num_tasks ? o->num_tasks[v] : 0) + st.acount[v] < o->max_tasks[v])) return 9;
+  if (!reserved.empty() && reserved.count(host))  // rebalancer_reservation_constraint
+    if (!(j->reserved_host && j->reserved_host[k] == (int32_t)host)) return 10;
+  if (!group_constraint_pass(j, k, o, v, g, st)) return 10 + g->type[j->group[k]];  // 11 unique, 12 balanced, 13 attribute-equals
+  return -1;
+}
+
 void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, const cook_groups* g,
                 const uint32_t* reserved_hosts, uint32_t n_reserved, int32_t* job_to_offer, uint32_t* fail_code,
-                uint8_t* head_matched, int nthreads) {
+                uint8_t* head_matched, int nthreads, const uint32_t* explain_pos = nullptr, uint32_t n_explain = 0,
+                uint32_t* explain_counts = nullptr) {
   const uint32_t K = j->n, M = o->n;
   MatchState st;
+  std::map<uint32_t, std::vector<uint32_t>> explain_rows;  // job position -> rows of explain_counts
+  for (uint32_t q = 0; q < n_explain; ++q) {
+    explain_rows[explain_pos[q]].push_back(q);
+    for (int s2 = 0; s2 < 16; ++s2) explain_counts[(size_t)q * 16 + s2] = 0;
+  }
   st.ac.assign(M, 0.0);
   st.am.assign(M, 0.0);
   st.acount.assign(M, 0);
@@ -399,6 +457,33 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
       }
     });
   for (uint32_t k = 0; k < K; ++k) {
+    // fenzo-utils/summarize-placement-failure (fenzo_utils.clj:33-55) over the TaskAssignmentResults of job k: per host the
+    // resources that do not fit (message "cpus" / "mem", one count each) or else the first failing hard constraint's name
+    auto ex = explain_rows.find(k);
+    if (ex != explain_rows.end()) {
+      uint32_t cnt[16] = {0};
+      const double c = j->cpus[k], m = j->mem[k];
+      for (uint32_t v = 0; v < M; ++v) {
+        const bool fc = st.ac[v] + c > o->cpus[v], fm = st.am[v] + m > o->mem[v];
+        if (fc || fm) {
+          cnt[0] += fc ? 1 : 0;
+          cnt[1] += fm ? 1 : 0;
+          continue;
+        }
+        const int why = first_failed_constraint(p, j, k, o, v, g, st, reserved);
+        const bool pass = job_constraints_pass(p, j, k, o, v, st, reserved) && group_constraint_pass(j, k, o, v, g, st);
+        if ((why < 0) != pass) std::abort();  // the ordered walk and the unordered check must agree
+        if (why >= 0) {
+          cnt[why] += 1;
+          continue;
+        }
+        const double rc = o->run_cpus ? o->run_cpus[v] : 0.0, rm = o->run_mem ? o->run_mem[v] : 0.0;
+        const double fit = ((rc + st.ac[v] + c) / (o->cpus[v] + rc) + (rm + st.am[v] + m) / (o->mem[v] + rm)) / 2.0;
+        if (!(fit > 0.0)) cnt[2] += 1;
+      }
+      for (uint32_t q : ex->second)
+        for (int s2 = 0; s2 < 16; ++s2) explain_counts[(size_t)q * 16 + s2] = cnt[s2];
+    }
     Best b;
     if (!mt) {
       eval_range(k, 0, M, b);
@@ -551,6 +636,14 @@ int oracle_match(const cook_params* p, const cook_jobs* j, const cook_offers* o,
                  const uint32_t* reserved_hosts, uint32_t n_reserved, int32_t* job_to_offer, uint32_t* fail_code,
                  uint8_t* head_matched, int nthreads) {
   match_impl(p, j, o, g, reserved_hosts, n_reserved, job_to_offer, fail_code, head_matched, nthreads);
+  return 0;
+}
+
+// the same placement, plus for each job position of explain_pos the 16 COOK_WHY_* counts of cook_match_explain
+int oracle_match_explain(const cook_params* p, const cook_jobs* j, const cook_offers* o, const cook_groups* g,
+                         const uint32_t* reserved_hosts, uint32_t n_reserved, int32_t* job_to_offer, const uint32_t* explain_pos,
+                         uint32_t n_explain, uint32_t* explain_counts) {
+  match_impl(p, j, o, g, reserved_hosts, n_reserved, job_to_offer, nullptr, nullptr, 1, explain_pos, n_explain, explain_counts);
   return 0;
 }
 

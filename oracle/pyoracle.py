@@ -112,6 +112,44 @@ def match(params, jobs: A.Jobs, offers: A.Offers, groups: A.Groups = None, reser
     return j2o[: jobs.n].copy(), fail[: jobs.n].copy(), bool(head.value)
 
 
+def match_explain(params, jobs: A.Jobs, offers: A.Offers, groups: A.Groups = None, reserved_hosts=(), job_pos=()):
+    """-> (job_to_offer, counts uint32[n, 16]): the placement plus, per job position, the placement-failure summary of
+    fenzo_utils.clj:33-55 in the COOK_WHY_* slots of include/cookmatch.h."""
+    j2o = np.full(max(1, jobs.n), -1, dtype=np.int32)
+    res = np.array(list(reserved_hosts) or [0], dtype=np.uint32)
+    pos = np.ascontiguousarray(job_pos, dtype=np.uint32)
+    counts = np.zeros((max(1, len(pos)), 16), dtype=np.uint32)
+    js, os_ = jobs.as_struct(), offers.as_struct()
+    gs = groups.as_struct() if groups is not None else None
+    rc = lib().oracle_match_explain(C.byref(params), C.byref(js), C.byref(os_), C.byref(gs) if gs is not None else None,
+                                    _u32p(res), len(reserved_hosts), j2o.ctypes.data_as(C.POINTER(C.c_int32)),
+                                    _u32p(pos if len(pos) else np.zeros(1, np.uint32)), len(pos), _u32p(counts.reshape(-1)))
+    assert rc == 0
+    return j2o[: jobs.n].copy(), counts[: len(pos)].copy()
+
+
+def resource_stats(cpus, mem) -> dict:
+    """resource-maps->stats (scheduler.clj:547-582) of the "cpus" and "mem" columns: :totals = left-to-right sums,
+    :percentiles by nearest rank (task_stats.clj:59-80: index ceil(p/100 * n) - 1 in exact ratio arithmetic),
+    :largest-by = the last element of the stable sort by that resource."""
+    from fractions import Fraction
+    import math
+    out = {}
+    n = len(cpus)
+    for name, col in (("cpus", np.asarray(cpus, np.float64)), ("mem", np.asarray(mem, np.float64))):
+        if n == 0:
+            out.update({f"total_{name}": 0.0, f"p50_{name}": float("nan"), f"p95_{name}": float("nan"), f"p100_{name}": float("nan"),
+                        f"largest_by_{name}": A.NONE_U32})
+            continue
+        order = np.argsort(col, kind="stable")
+        srt = col[order]
+        out[f"total_{name}"] = float(np.add.accumulate(col)[-1])  # sequential, like (reduce (partial merge-with +))
+        for p in (50, 95, 100):
+            out[f"p{p}_{name}"] = float(srt[math.ceil(Fraction(p, 100) * n) - 1])
+        out[f"largest_by_{name}"] = int(order[-1])
+    return out
+
+
 class RebalHooks(C.Structure):
     _fields_ = [("running_slave_known", C.POINTER(C.c_uint8)), ("init_preempted_hosts", C.POINTER(C.c_uint32)),
                 ("n_init_preempted", C.c_uint32), ("forced_host", C.POINTER(C.c_int32)), ("forced_off", C.POINTER(C.c_uint32)),

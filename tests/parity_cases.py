@@ -498,3 +498,77 @@ def offers_feed_match(make_engine, n_nodes=120, n_pods=700, n_jobs=300):
                         gpu_model=want["gpu_model"], gpu_count=want["gpu_count"], attr=nodes.attr[want["node"]])
     o_j2o, _, o_head = pyoracle.match(p, pool.pending_jobs, o_offers, None)
     assert np.array_equal(j2o, o_j2o) and head == o_head and (j2o >= 0).sum() > n_jobs // 10
+
+
+# ---- why-unscheduled summaries and match-cycle metrics (consumers of the placement's by-products) --------------------------
+def explain_parity(make_engine, jobs, offers, groups, params, reserved=(), max_pos=48, tag=""):
+    """cook_match_explain after a match == the oracle's summary taken DURING its sweep (fenzo_utils.clj:33-55)"""
+    with make_engine(params) as e:
+        j2o, fail, _ = e.match(jobs, offers, groups, reserved)
+        unm = np.nonzero(j2o < 0)[0]
+        mat = np.nonzero(j2o >= 0)[0]
+        pos = np.concatenate([unm[:: max(1, len(unm) // max_pos)][:max_pos], mat[:: max(1, len(mat) // 8)][:8], unm[-1:]]).astype(np.uint32)
+        counts = e.match_explain(pos)
+        again = e.match_explain(pos[::-1].copy())[::-1]
+    o_j2o, o_counts = pyoracle.match_explain(params, jobs, offers, groups, reserved, pos)
+    assert np.array_equal(j2o, o_j2o), tag
+    bad = np.nonzero((counts != o_counts).any(axis=1))[0]
+    assert len(bad) == 0, (tag, pos[bad[:3]], counts[bad[:3]], o_counts[bad[:3]])
+    assert np.array_equal(again, counts), (tag, "order of the positions must not matter")
+    # every host shows up in exactly one class, except that a host short of cpus AND mem counts under both
+    for q, k in enumerate(pos):
+        row = counts[q]
+        accepted = offers.n - (int(row[2:].sum()) + int(max(row[0], row[1])))
+        assert accepted >= 0 and int(row[:2].sum()) + int(row[2:].sum()) >= offers.n - accepted, (tag, k, row)
+        if j2o[k] < 0:  # the fail code of the match is the OR of the classes seen
+            want = (1 if row[0] or row[1] else 0) | (2 if row[3:].any() else 0) | (4 if row[2] else 0)
+            assert fail[k] == (want if want else 8), (tag, k, fail[k], row)
+    return pos, counts
+
+
+def metrics_parity(make_engine, jobs, offers, groups, params, n_users=0, n_models=2, tag=""):
+    """cook_match_metrics == handle-match-cycle-metrics' numbers recomputed from the oracle's placement"""
+    with make_engine(params) as e:
+        j2o, _, head = e.match(jobs, offers, groups)
+        m = e.match_metrics(n_users=n_users if jobs.user is not None else 0, n_gpu_models=n_models)
+    o_j2o, _, o_head = pyoracle.match(params, jobs, offers, groups)
+    assert np.array_equal(j2o, o_j2o)
+    assert m["considerable"] == jobs.n and m["matched"] == int((o_j2o >= 0).sum()) and m["unmatched"] == int((o_j2o < 0).sum()), tag
+    assert m["offers"] == offers.n and m["offers_scheduled"] == len(set(o_j2o[o_j2o >= 0].tolist())), tag
+    assert m["head_matched"] == (bool(o_j2o[0] >= 0) if jobs.n else False), tag
+    for got, cols in ((m["jobs"], (jobs.cpus, jobs.mem)), (m["offers_stats"], (offers.cpus, offers.mem))):
+        want = pyoracle.resource_stats(*cols)
+        for k, v in want.items():
+            assert got[k] == v or (np.isnan(v) and np.isnan(got[k])), (tag, k, got[k], v)
+    if jobs.user is not None and n_users:
+        assert np.array_equal(m["user_considerable"], np.bincount(jobs.user, minlength=n_users)), tag
+        assert np.array_equal(m["user_matched"], np.bincount(jobs.user[o_j2o >= 0], minlength=n_users)), tag
+    if jobs.gpus is not None:
+        jm = jobs.gpu_model if jobs.gpu_model is not None else np.zeros(jobs.n, np.uint32)
+        want = np.bincount(jm[jobs.gpus > 0], weights=jobs.gpus[jobs.gpus > 0], minlength=n_models + 1)[: n_models + 1]
+        assert np.array_equal(m["job_gpus_by_model"], want.astype(np.int64)), tag
+    if offers.gpu_model is not None:
+        sel = offers.gpu_model != 0
+        want = np.bincount(offers.gpu_model[sel], weights=offers.gpu_count[sel], minlength=n_models + 1)[: n_models + 1]
+        assert np.array_equal(m["offer_gpus_by_model"], want.astype(np.int64)), tag
+    return m
+
+
+def cycle_explain_parity(make_engine, pool: synth.Pool, params, k, n_users):
+    """explain / metrics after cook_cycle_run: the jobs of the match are the first k ranked jobs (j_index indirection)"""
+    with make_engine(params) as e:
+        e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        e.cycle_run(k)
+        ranked, j2o, _ = e.cycle_fetch()
+        unm = np.nonzero(j2o < 0)[0]
+        pos = np.concatenate([unm[:24], [0]]).astype(np.uint32)
+        counts = e.match_explain(pos)
+        m = e.match_metrics(n_users=n_users, n_gpu_models=2)
+    pend_ord = np.cumsum(pool.tasks.pending) - 1
+    considerable = pool.pending_jobs.take(pend_ord[ranked[:k]])
+    o_j2o, o_counts = pyoracle.match_explain(params, considerable, pool.offers, pool.groups, (), pos)
+    assert np.array_equal(j2o, o_j2o) and np.array_equal(counts, o_counts)
+    assert m["matched"] == int((o_j2o >= 0).sum()) and m["considerable"] == len(o_j2o)
+    assert np.array_equal(m["user_considerable"], np.bincount(considerable.user, minlength=n_users))
+    want = pyoracle.resource_stats(considerable.cpus, considerable.mem)
+    assert all(m["jobs"][key] == v for key, v in want.items())

@@ -32,7 +32,8 @@ def test_struct_sizes_match_header(tmp_path):
     src = tmp_path / "sz.c"
     names = ["cook_params", "cook_usage", "cook_tasks", "cook_users", "cook_pool_quota", "cook_jobs", "cook_offers",
              "cook_groups", "cook_rebalance_params", "cook_host_spare", "cook_preemption", "cook_queue", "cook_user_state",
-             "cook_nodes", "cook_pods", "cook_offer_params", "cook_node_offers", "cook_offer_totals"]
+             "cook_nodes", "cook_pods", "cook_offer_params", "cook_node_offers", "cook_offer_totals", "cook_resource_stats",
+             "cook_cycle_metrics"]
     src.write_text('#include <stdio.h>\n#include "cookmatch.h"\nint main(){' +
                    "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}")
     exe = tmp_path / "sz"
@@ -41,7 +42,8 @@ def test_struct_sizes_match_header(tmp_path):
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     mirrors = [A.CookParams, A.CookUsage, A.CookTasks, A.CookUsers, A.CookPoolQuota, A.CookJobs, A.CookOffers,
                A.CookGroups, A.CookRebalanceParams, A.CookHostSpare, A.CookPreemption, A.CookQueue, A.CookUserState,
-               A.CookNodes, A.CookPods, A.CookOfferParams, A.CookNodeOffers, A.CookOfferTotals]
+               A.CookNodes, A.CookPods, A.CookOfferParams, A.CookNodeOffers, A.CookOfferTotals, A.CookResourceStats,
+               A.CookCycleMetrics]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 

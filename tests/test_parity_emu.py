@@ -233,3 +233,67 @@ def test_offers_edge_cases(make_engine):
 
 def test_offers_feed_the_match(make_engine):
     P.offers_feed_match(make_engine)
+
+
+# ---- why-unscheduled summaries and match-cycle metrics ------------------------------------------------------------------------
+def _group_case():
+    rng = np.random.default_rng(5)
+    n, m = 160, 40
+    attr = np.zeros((m, 2), dtype=np.uint32)
+    attr[:, 0] = rng.integers(1, 4, m)
+    attr[:, 1] = rng.integers(0, 3, m)
+    offers = A.Offers(cpus=np.full(m, 8.0), mem=np.full(m, 16000.0), attr=attr, k8s=np.ones(m, dtype=np.uint8),
+                      max_tasks=np.full(m, 6, np.int32), num_tasks=rng.integers(0, 5, m).astype(np.int32))
+    group = rng.integers(0, 6, n).astype(np.uint32)
+    group[rng.random(n) < 0.3] = A.NONE_U32
+    jobs = A.Jobs(cpus=rng.integers(1, 4, n).astype(float), mem=rng.integers(1, 4, n) * 1000.0, group=group)
+    groups = A.Groups(type=np.array([1, 2, 2, 3, 3, 0], dtype=np.uint8),
+                      attr_key=np.array([A.NONE_U32, 0, A.NONE_U32, 1, 0, 0], dtype=np.uint32),
+                      minimum=np.array([0, 3, 10, 0, 0, 0], dtype=np.int32),
+                      run_hosts=[[1, 2], [3], [], [], [5, 6], []],
+                      run_attrs=[[0, 0], [int(attr[3, 0])], [], [], [int(attr[5, 0]), int(attr[6, 0])], []])
+    return jobs, offers, groups
+
+
+@pytest.mark.parametrize("algo", [0, 1], ids=["default", "serial"])
+def test_explain_parity(make_engine, algo):
+    p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
+    pool = synth.make_pool(seed=22, n_pending=400, n_running=100, n_users=20, n_offers=120, gpus=True, constraints=True)
+    pos, counts = P.explain_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, reserved=(3, 7, 90), tag="constraints")
+    assert counts[:, 0].any() and counts[:, 7].any()  # resources and the gpu-host constraint both occur
+    pool = synth.make_pool(seed=23, n_pending=500, n_running=0, n_users=10, n_offers=24)
+    P.explain_parity(make_engine, pool.pending_jobs, pool.offers, None, p, tag="over-committed")
+    jobs, offers, groups = _group_case()
+    pos, counts = P.explain_parity(make_engine, jobs, offers, groups, p, tag="groups")
+    assert counts[:, 9].any() and counts[:, 11:14].any()  # max-tasks-per-host and group constraints occur
+    jobs, offers, groups = P.slow_constraint_case(9, 200, 60)
+    pos, counts = P.explain_parity(make_engine, jobs, offers, groups, p, tag="slow constraints")
+    assert counts[:, 5].any() and counts[:, 8].any()
+
+
+def test_explain_is_the_references_map():
+    # unscheduled.clj's vector (test/cook/test/unscheduled.clj:57-72) and fenzo_utils' reduction (test/.../fenzo_utils.clj:76-91)
+    row = np.zeros(A.WHY_SLOTS, np.uint32)
+    row[[0, 1, 8]] = (8, 14, 3)
+    assert A.why_summary(row) == {":constraints": {"novel_host_constraint": 3}, ":resources": {"mem": 14, "cpus": 8}}
+    assert A.why_summary(np.zeros(A.WHY_SLOTS, np.uint32)) == {}
+
+
+def test_metrics_parity(make_engine):
+    p = A.default_params(good_enough_fitness=1.0)
+    pool = synth.make_pool(seed=24, n_pending=700, n_running=0, n_users=25, n_offers=90, gpus=True, constraints=True)
+    m = P.metrics_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, n_users=25, tag="integers")
+    assert 0 < m["matched"] < 700
+    pool = synth.make_pool(seed=25, n_pending=3000, n_running=0, n_users=40, n_offers=150, fractional=True)
+    pool.pending_jobs.cpus[:] = pool.pending_jobs.cpus + 0.1    # non-dyadic: the totals need the in-order fold
+    P.metrics_parity(make_engine, pool.pending_jobs, pool.offers, None, p, n_users=40, tag="fractional")
+    # nothing considered / nothing offered
+    none = A.Jobs(cpus=np.zeros(0), mem=np.zeros(0))
+    P.metrics_parity(make_engine, none, pool.offers, None, p, tag="no jobs")
+    one = A.Jobs(cpus=np.array([1.0]), mem=np.array([1.0]))
+    P.metrics_parity(make_engine, one, A.Offers(cpus=np.zeros(0), mem=np.zeros(0)), None, p, tag="no offers")
+
+
+def test_explain_after_a_cycle(make_engine):
+    pool = synth.make_pool(seed=31, n_pending=600, n_running=200, n_users=30, n_offers=60, gpus=True, constraints=True)
+    P.cycle_explain_parity(make_engine, pool, A.default_params(good_enough_fitness=1.0), k=300, n_users=30)

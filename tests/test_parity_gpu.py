@@ -264,3 +264,33 @@ def test_offers_edge_cases(make_engine):
 
 def test_offers_feed_the_match(make_engine):
     P.offers_feed_match(make_engine, n_nodes=2000, n_pods=12000, n_jobs=6000)
+
+
+# ---- why-unscheduled summaries and match-cycle metrics (cook_match_explain / cook_match_metrics) ------------------------------
+@pytest.mark.parametrize("algo", [0, 1], ids=["default", "serial"])
+def test_explain_parity(make_engine, algo):
+    p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
+    pool = synth.make_pool(seed=22, n_pending=3000, n_running=100, n_users=20, n_offers=1500, gpus=True, constraints=True)
+    pos, counts = P.explain_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, reserved=(3, 7, 90), tag="constraints")
+    assert counts[:, 0].any() and counts[:, 7].any()
+    pool = synth.make_pool(seed=23, n_pending=2000, n_running=0, n_users=10, n_offers=100)
+    P.explain_parity(make_engine, pool.pending_jobs, pool.offers, None, p, tag="over-committed")
+    jobs, offers, groups = P.slow_constraint_case(9, 600, 200)
+    pos, counts = P.explain_parity(make_engine, jobs, offers, groups, p, tag="slow constraints")
+    assert counts[:, 5].any() and counts[:, 8].any()
+
+
+def test_metrics_parity(make_engine):
+    p = A.default_params(good_enough_fitness=1.0)
+    pool = synth.make_pool(seed=24, n_pending=6000, n_running=0, n_users=50, n_offers=2000, gpus=True, constraints=True)
+    m = P.metrics_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, n_users=50, tag="integers")
+    assert 0 < m["matched"] < 6000
+    pool = synth.make_pool(seed=25, n_pending=20000, n_running=0, n_users=40, n_offers=1000, fractional=True)
+    pool.pending_jobs.cpus[:] = pool.pending_jobs.cpus + 0.1
+    P.metrics_parity(make_engine, pool.pending_jobs, pool.offers, None, p, n_users=40, tag="fractional")
+    P.metrics_parity(make_engine, A.Jobs(cpus=np.zeros(0), mem=np.zeros(0)), pool.offers, None, p, tag="no jobs")
+
+
+def test_explain_after_a_cycle(make_engine):
+    pool = synth.make_pool(seed=31, n_pending=6000, n_running=2000, n_users=30, n_offers=500, gpus=True, constraints=True)
+    P.cycle_explain_parity(make_engine, pool, A.default_params(good_enough_fitness=1.0), k=3000, n_users=30)
