@@ -227,7 +227,8 @@ __global__ void metrics_pick(const uint32_t* __restrict__ perm, const double* __
 }
 // :totals (reduce (partial merge-with +)) in collection order.  The tracked scan formed EVERY prefix; if none of its additions
 // rounded, every prefix is exact, hence equal to the left-to-right sum, and the last element is the answer.  Otherwise the
-// in-order fold (one wave, 64 values per step through v_readlane).
+// in-order fold below.
+constexpr int MT_TILE = 2048;
 __global__ void __launch_bounds__(1024) metrics_totals(const SumU4* __restrict__ scan, const double* __restrict__ a,
                                                        const double* __restrict__ b, unsigned n, double* __restrict__ ta,
                                                        double* __restrict__ tb) {
@@ -245,18 +246,24 @@ __global__ void __launch_bounds__(1024) metrics_totals(const SumU4* __restrict__
     }
     return;
   }
-  if (wave_id() != 0) return;
-  const unsigned lane = lane_id();
-  double acc[2] = {-0.0, -0.0};
-  for (unsigned base = 0; base < n; base += COOK_WAVE) {
-    const unsigned i = base + lane;
-    const double x[2] = {i < n ? a[i] : 0.0, i < n ? b[i] : 0.0};
-    offers_fold_chunk<2>(acc, x, n - base < (unsigned)COOK_WAVE ? n - base : (unsigned)COOK_WAVE);
+  // the in-order fold: the workgroup stages tiles of both columns in LDS, wave 0 / 1 fold one column each (one fp64 add
+  // latency per element; LDS broadcast reads)
+  __shared__ double s_val[2][MT_TILE];
+  const unsigned w = wave_id();
+  double acc = -0.0;
+  for (unsigned base = 0; base < n; base += MT_TILE) {
+    const unsigned cnt = n - base < (unsigned)MT_TILE ? n - base : (unsigned)MT_TILE;
+    for (unsigned x = threadIdx.x; x < 2u * MT_TILE; x += blockDim.x) {
+      const unsigned col = x / MT_TILE, i = x % MT_TILE;
+      s_val[col][i] = i < cnt ? (col ? b[base + i] : a[base + i]) : 0.0;
+    }
+    __syncthreads();
+    if (w < 2) {
+      acc = fold_lds_in_order(&s_val[w][0], cnt, acc);
+    }
+    __syncthreads();
   }
-  if (lane == 0) {
-    *ta = acc[0];
-    *tb = acc[1];
-  }
+  if (w < 2 && lane_id() == 0) *(w ? tb : ta) = acc;
 }
 // frequencies of users over the considerable / matched jobs (scheduler.clj:1216-1227), gpus per model over the jobs
 __global__ void __launch_bounds__(256) metrics_job_counts(MatchIn in, const int32_t* __restrict__ j2o, const uint32_t* __restrict__ j_user,

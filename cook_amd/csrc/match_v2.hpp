@@ -28,7 +28,10 @@
 #include "common.hpp"
 #include "match_kernels.hpp"
 
-constexpr int MV_L = 8;                    // candidate list length per job
+#ifndef COOK_MV_L
+#define COOK_MV_L 8
+#endif
+constexpr int MV_L = COOK_MV_L;            // candidate list length per job (-DCOOK_MV_L=n builds a variant for tuning runs)
 constexpr int MV_LG = 4;                   // good-enough list length per job
 constexpr int MV_OCW = 32;                 // offers per eval wave
 constexpr int MV_EW = 4;                   // waves per eval block (same 64 jobs, consecutive offer sub-chunks)

@@ -17,7 +17,8 @@ struct OfferBufs {
   const uint32_t* d_attr = nullptr;
   // work
   DArr<uint64_t> key;
-  DArr<uint32_t> permA, permB, seg_start, seg_end, flag;
+  DArr<uint32_t> permA, permB, seg_start, seg_end, block_offers;
+  DArr<PodRec> podrec;
   DArr<double> a_cpus, a_mem, a_cons_cpus, a_cons_mem, a_gpu_count, a_disk_space, a_disk_cons;
   DArr<int32_t> a_num_pods;
   DArr<uint8_t> a_status;
@@ -85,8 +86,9 @@ void offers_run(cook_engine* e, OfferBufs& b) {
   b.seg_end.ensure(Nn);
   COOK_HIP(hipMemsetAsync(b.seg_start.ptr(), 0, (size_t)Nn * 4, e->stream));
   COOK_HIP(hipMemsetAsync(b.seg_end.ptr(), 0, (size_t)Nn * 4, e->stream));
-  const uint32_t* perm = nullptr;
+  PodRec* podrec = b.podrec.ensure(Np);
   if (Np) {
+    const uint32_t* perm = nullptr;
     const unsigned gP = div_up(Np, 256);
     b.key.ensure(Np);
     b.permA.ensure(Np);
@@ -97,22 +99,23 @@ void offers_run(cook_engine* e, OfferBufs& b) {
     for (unsigned long long x = Nn; x; x >>= 1) mask = (mask << 1) | 1ull;  // keys are 0..Nn
     perm = radix_sort_masked(e, b.key.ptr(), mask, b.permA.ptr(), b.permA.ptr(), b.permB.ptr(), Np);
     KL("offers_seg_bounds", offers_seg_bounds, gP, 256, perm, (const uint64_t*)b.key.ptr(), Np, Nn, b.seg_start.ptr(), b.seg_end.ptr());
+    KL("offers_gather_pods", offers_gather_pods, gP, 256, b.pd, perm, podrec);
   }
   // ---- per node: capacity, consumption, available, schedulable --------------------------------------------------------------
   NodeAvail av{b.a_cpus.ensure(Nn),       b.a_mem.ensure(Nn),       b.a_cons_cpus.ensure(Nn), b.a_cons_mem.ensure(Nn), b.a_gpu_count.ensure(Nn),
-               b.a_disk_space.ensure(Nn), b.a_disk_cons.ensure(Nn), b.flag.ensure(Nn),        b.a_num_pods.ensure(Nn), b.a_status.ensure(Nn)};
-  KL("offers_node_eval", offers_node_eval, gN, 256, b.nd, b.pd, perm, (const uint32_t*)b.seg_start.ptr(), (const uint32_t*)b.seg_end.ptr(),
-     b.params.clobber_synthetic_pods, b.params.filter_out_unsound_gpu_nodes, b.params.max_pods_per_node, b.params.n_gpu_models, av,
-     b.gpu_cap.ptr(), b.gpu_cons.ptr());
+               b.a_disk_space.ensure(Nn), b.a_disk_cons.ensure(Nn), b.a_num_pods.ensure(Nn), b.a_status.ensure(Nn)};
+  b.block_offers.ensure(gN);
+  KL("offers_node_eval", offers_node_eval, gN, 256, b.nd, (const PodRec*)podrec, (const uint32_t*)b.seg_start.ptr(),
+     (const uint32_t*)b.seg_end.ptr(), b.params.clobber_synthetic_pods, b.params.filter_out_unsound_gpu_nodes, b.params.max_pods_per_node,
+     b.params.n_gpu_models, av, b.gpu_cap.ptr(), b.gpu_cons.ptr(), b.block_offers.ptr());
   // ---- gauges ------------------------------------------------------------------------------------------------------------------
-  KL("offers_totals", offers_totals, 1, 1024, b.nd, av, b.params.n_disk_types, b.totals.ptr(), b.disk_cap.ptr(), b.disk_cons.ptr());
+  KL("offers_totals", offers_totals, 1, OT_THREADS, b.nd, av, b.params.n_disk_types, b.totals.ptr(), b.disk_cap.ptr(), b.disk_cons.ptr());
   // ---- offer rows of the schedulable nodes, node order ----------------------------------------------------------------------------
   unsigned* d_total = e->d_counters.ptr() + 13;
-  KL("offers_compact_scan", excl_scan_u32_single, 1, SCAN1_THREADS, b.flag.ptr(), Nn, d_total);
   OfferRows rows{b.o_node.ensure(Nn),      b.o_host.ensure(Nn),       b.o_cpus.ensure(Nn),     b.o_mem.ensure(Nn),
                  b.o_gpu_model.ensure(Nn), b.o_gpu_count.ensure(Nn),  b.o_disk_type.ensure(Nn), b.o_disk_space.ensure(Nn),
                  b.o_num_pods.ensure(Nn),  b.o_attr.ensure((size_t)Nn * std::max(1u, b.n_attr))};
-  KL("offers_emit", offers_emit, gN, 256, b.nd, b.d_host, av, (const uint32_t*)b.flag.ptr(), b.d_attr, b.n_attr, rows);
+  KL("offers_emit", offers_emit, gN, 256, b.nd, b.d_host, av, (const uint32_t*)b.block_offers.ptr(), b.d_attr, b.n_attr, rows, d_total);
   COOK_HIP(hipMemcpyAsync(e->h_scratch, d_total, 4, hipMemcpyDeviceToHost, e->stream));
   sync(e);
   std::memcpy(&b.n_offers, e->h_scratch, 4);
