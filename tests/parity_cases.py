@@ -572,3 +572,52 @@ def cycle_explain_parity(make_engine, pool: synth.Pool, params, k, n_users):
     assert np.array_equal(m["user_considerable"], np.bincount(considerable.user, minlength=n_users))
     want = pyoracle.resource_stats(considerable.cpus, considerable.mem)
     assert all(m["jobs"][key] == v for key, v in want.items())
+
+
+# ---- trace replay (cook_amd/replay.py): the simulator loop over the engine vs the same loop over the oracle ----------------
+class OracleBackend:
+    """the CPU oracle behind the replay harness' backend interface (test infrastructure)"""
+
+    def rank(self, params, tasks, users):
+        return pyoracle.rank(params, tasks, users)[0]
+
+    def match(self, params, jobs, offers):
+        return pyoracle.match(params, jobs, offers)[0]
+
+    def rebalance(self, params, running, pending, job_ids, priorities, users, spare, rparams):
+        return pyoracle.rebalance(params, running, pending, job_ids, priorities, users, spare, rparams)["decisions"]
+
+
+def make_trace(seed, n_jobs, n_hosts, n_users=5, span_ms=3_600_000, fail_frac=0.05):
+    """a trace / hosts pair in the format of the reference's simulator_files (example-trace.json, example-hosts.json);
+    job shapes as simulator/src/main/cook/sim/schedule.clj:58-83"""
+    rng = np.random.default_rng(seed)
+    submit = np.sort(rng.integers(0, span_ms, n_jobs))
+    users = [chr(ord("a") + i) for i in range(n_users)]
+    weights = 1.0 / np.arange(1, n_users + 1)
+    trace = []
+    for i in range(n_jobs):
+        trace.append({
+            "run-time-ms": int(rng.integers(60_000, 1_800_000)), "submit-time-ms": int(submit[i]), "job/priority": int(rng.integers(0, 101)),
+            "job/resource": [{"resource/type": "resource.type/cpus", "resource/amount": float(rng.integers(1, 5))},
+                             {"resource/type": "resource.type/mem", "resource/amount": float(rng.integers(512, 4096))}],
+            "job/max-retries": 5, "job/name": "dummy_job", "job/uuid": "591c97d8-0000-4000-8000-%012d" % i,
+            "job/user": users[int(rng.choice(n_users, p=weights / weights.sum()))], "job/expected-runtime": 100,
+            "status": "failed" if rng.random() < fail_frac else "finished"})
+    hosts = [{"hostname": "%03d" % h, "attributes": {}, "slave-id": "slave-%03d" % h,
+              "resources": {"cpus": {"*": 10}, "mem": {"*": 10000}}} for h in range(n_hosts)]
+    return trace, hosts
+
+
+def replay_parity(make_engine, trace, hosts, config, min_preempted=0, max_cycles=10 ** 9):
+    from cook_amd import replay
+    with make_engine(A.default_params()) as e:
+        got = replay.simulate(trace, hosts, config, replay.EngineBackend(e), max_cycles)
+    want = replay.simulate(trace, hosts, config, OracleBackend(), max_cycles)
+    assert got.cycles == want.cycles and got.log == want.log, [(a, b) for a, b in zip(got.log, want.log) if a != b][:3]
+    rg, rw = got.rows(), want.rows()
+    assert rg == rw, next((a, b) for a, b in zip(rg, rw) if a != b)
+    assert sum(r["matched"] for r in got.log) >= min(len(trace) // 2, 10)
+    assert sum(r["preempted"] for r in got.log) >= min_preempted
+    assert set(rg[0].keys()) == set(replay.CSV_HEADERS)
+    return got
