@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--match-algo", type=int, default=0, help="cook_params.match_algo: 0 default (window rounds, one launch per phase), 1 serial, 3 = default + in-place re-evaluation, 4 persistent kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-adjacent", action="store_true", help="skip the timings of the rows next to the hot path (offers, explain, metrics)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--check", action="store_true", help="verify pool 0 of rank 0 against the oracle (slow)")
     return ap.parse_args()
@@ -240,6 +241,29 @@ def main():
             assert np.array_equal(r, o_ranked), "rank differs from oracle"
             assert np.array_equal(j2o[:k_s], o_j2o), "assignments differ from oracle"
 
+    # ---- the rows either side of the path, timed once on rank 0's first pool; not part of `value` ----
+    adjacent = None
+    if rank == 0 and not args.no_adjacent:
+        e0 = engines[my_pools[0]]
+        _, j2o0, _ = e0.cycle_fetch()
+        unm = np.nonzero(j2o0 < 0)[0][:64].astype(np.uint32)
+        e0.match_explain(unm[:1])  # first call allocates
+        a0 = time.perf_counter()
+        why = e0.match_explain(unm)
+        a1 = time.perf_counter()
+        e0.match_metrics(n_users=args.users, n_gpu_models=2)
+        a2 = time.perf_counter()
+        met = e0.match_metrics(n_users=args.users, n_gpu_models=2)
+        a3 = time.perf_counter()
+        nodes, pods_, op = synth.make_cluster_state(seed=0xC00C, n_nodes=n_off, n_pods=n_run, disk=True, n_attr_keys=8, max_pods=110)
+        e0.offers_stage(nodes, pods_, op)
+        e0.offers_run()
+        e0.offers_run()
+        adjacent = {"explain_64_unmatched_jobs_ms": (a1 - a0) * 1e3, "explain_hosts_refusing_first_job": int(why[0].sum()) if len(why) else 0,
+                    "metrics_ms": (a3 - a2) * 1e3, "metrics_matched": met["matched"],
+                    "offers_build_ms": e0.offers_timing(), "offers_build_shape": f"{n_off} nodes x {n_run} pods (one pool)",
+                    "note": "cook_match_explain / cook_match_metrics / cook_offers_run on pool 0 after the timed region (host wall time incl. sync; offers: HIP events)"}
+
     if rank == 0:
         value = args.steps / elapsed
         lat_ms = sorted(x * 1e3 for x in lat)
@@ -258,7 +282,7 @@ def main():
                            "stage_ms_pool0": {"rank": stage_ms[my_pools[0]][0], "match": stage_ms[my_pools[0]][1]},
                            "placement_stats_pool0": engines[my_pools[0]].match_stats()},
             "setup_s": gen_s,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "adjacent_rows": adjacent,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]

@@ -33,7 +33,10 @@
 #endif
 constexpr int MV_L = COOK_MV_L;            // candidate list length per job (-DCOOK_MV_L=n builds a variant for tuning runs)
 constexpr int MV_LG = 4;                   // good-enough list length per job
-constexpr int MV_OCW = 32;                 // offers per eval wave
+#ifndef COOK_MV_OCW
+#define COOK_MV_OCW 32
+#endif
+constexpr int MV_OCW = COOK_MV_OCW;        // offers per eval wave (a power of two <= 64; -DCOOK_MV_OCW=n builds a tuning variant)
 constexpr int MV_EW = 4;                   // waves per eval block (same 64 jobs, consecutive offer sub-chunks)
 constexpr int MV_OCB = MV_OCW * MV_EW;     // offers per eval block
 constexpr int MV_T = COOK_WAVE;            // touched offers per round = lanes of the walking wave
@@ -51,7 +54,7 @@ constexpr int MV_JG = MV_WMAX / 64;        // job groups (waves of jobs) per win
 constexpr int MV_JSTEP = MV_S / 16;        // jobs inserted into the slot table per step ((L + LG) <= 16 entries each)
 static_assert(MV_L + MV_LG <= 16, "slot-table step sizing");
 static_assert(MV_OCW <= COOK_WAVE, "one lane stages one offer");
-static_assert(MV_OCW == 32, "the eval loop reads the alive bits of a wave's offers as half a 64-bit word");
+static_assert(MV_OCW == 64 || MV_OCW == 32 || MV_OCW == 16 || MV_OCW == 8, "a wave's alive bits are an aligned slice of one 64-bit word");
 
 struct OfferA {  // resources of an offer (offer.clj:55-61) + Fenzo's running view; 48 B, read wave-uniformly
   double oc, om;          // lease cpus / mem
@@ -391,7 +394,7 @@ static __device__ __forceinline__ void eval_tile(char* lds, const MatchIn& in, c
   // offers that cannot take even the smallest job of the call any more fail every job on resources: count, never evaluate
   unsigned long long live = 0ull;
   if (v0 < v1) {
-    live = (st.alive[v0 >> 6] >> (v0 & 63u)) & 0xFFFFFFFFull;  // MV_OCW = 32 offers = half a word
+    live = (st.alive[v0 >> 6] >> (v0 & 63u)) & (MV_OCW == 64 ? ~0ull : ((1ull << (MV_OCW & 63)) - 1ull));  // an aligned slice of one word
     if (v1 - v0 < (unsigned)MV_OCW) live &= (1ull << (v1 - v0)) - 1ull;
     c1 += valid ? (v1 - v0) - (unsigned)__popcll(live) : 0u;
   }

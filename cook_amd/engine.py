@@ -15,7 +15,7 @@ import numpy as np
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "libcookmatch.so")
+DEFAULT_LIB = os.environ.get("COOK_LIB") or os.path.join(_HERE, "libcookmatch.so")  # COOK_LIB: a tuning variant of the same library
 
 EXPORTS = [
     "cook_engine_create", "cook_engine_destroy", "cook_engine_set_params", "cook_last_error", "cook_version",

@@ -258,7 +258,7 @@ def _group_case():
 @pytest.mark.parametrize("algo", [0, 1], ids=["default", "serial"])
 def test_explain_parity(make_engine, algo):
     p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
-    pool = synth.make_pool(seed=22, n_pending=400, n_running=100, n_users=20, n_offers=120, gpus=True, constraints=True)
+    pool = synth.make_pool(seed=22, n_pending=300, n_running=100, n_users=20, n_offers=100, gpus=True, constraints=True)
     pos, counts = P.explain_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, reserved=(3, 7, 90), tag="constraints")
     assert counts[:, 0].any() and counts[:, 7].any()  # resources and the gpu-host constraint both occur
     pool = synth.make_pool(seed=23, n_pending=500, n_running=0, n_users=10, n_offers=24)
@@ -284,7 +284,7 @@ def test_metrics_parity(make_engine):
     pool = synth.make_pool(seed=24, n_pending=700, n_running=0, n_users=25, n_offers=90, gpus=True, constraints=True)
     m = P.metrics_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, n_users=25, tag="integers")
     assert 0 < m["matched"] < 700
-    pool = synth.make_pool(seed=25, n_pending=3000, n_running=0, n_users=40, n_offers=150, fractional=True)
+    pool = synth.make_pool(seed=25, n_pending=2200, n_running=0, n_users=40, n_offers=40, fractional=True)
     pool.pending_jobs.cpus[:] = pool.pending_jobs.cpus + 0.1    # non-dyadic: the totals need the in-order fold
     P.metrics_parity(make_engine, pool.pending_jobs, pool.offers, None, p, n_users=40, tag="fractional")
     # nothing considered / nothing offered

@@ -7,6 +7,7 @@ import pytest
 from cook_amd import _abi as A
 from cook_amd import synth
 from cook_amd.engine import Engine
+from oracle import pyoracle
 from tests import parity_cases as P
 
 pytestmark = pytest.mark.gpu
@@ -294,3 +295,41 @@ def test_metrics_parity(make_engine):
 def test_explain_after_a_cycle(make_engine):
     pool = synth.make_pool(seed=31, n_pending=6000, n_running=2000, n_users=30, n_offers=500, gpus=True, constraints=True)
     P.cycle_explain_parity(make_engine, pool, A.default_params(good_enough_fitness=1.0), k=3000, n_users=30)
+
+
+# ---- BASELINE.json's configurations at FULL size: rank + placement of every pending job, bit-exact against the oracle -------
+def _full_cycle_parity(make_engine, pool, ge=1.0, threads=16):
+    p = A.default_params(good_enough_fitness=ge)
+    with make_engine(p) as e:
+        e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        e.cycle_run(pool.n_pending)
+        ranked, j2o, head = e.cycle_fetch()
+        _, dru = e.rank_fetch(want_dru=True)
+    o_ranked, o_dru = pyoracle.rank(p, pool.tasks, pool.users)
+    assert np.array_equal(ranked, o_ranked) and np.array_equal(dru, o_dru, equal_nan=True)
+    pend_ord = np.cumsum(pool.tasks.pending) - 1
+    o_j2o, _, o_head = pyoracle.match(p, pool.pending_jobs.take(pend_ord[o_ranked]), pool.offers, pool.groups, nthreads=threads)
+    bad = np.nonzero(j2o != o_j2o)[0]
+    assert len(bad) == 0 and head == o_head, f"assignment differs first at rank position {bad[:5]}"
+    return j2o
+
+
+def test_c2_full_size(make_engine):
+    """configs[1]: 50k pending x 5k offers, cpus + mem only, single pool (+ 20k running tasks, 1000 users)"""
+    pool = synth.make_pool(seed=0xC00C0002, n_pending=50000, n_running=20000, n_users=1000, n_offers=5000)
+    j2o = _full_cycle_parity(make_engine, pool)
+    assert 5000 < (j2o >= 0).sum() < 50000
+
+
+def test_c3_full_size(make_engine):
+    """configs[2]: 200k pending x 20k offers with host / attribute constraints + the gpu dimension (80k running, 2000 users)"""
+    pool = synth.make_pool(seed=0xC00C0003, n_pending=200000, n_running=80000, n_users=2000, n_offers=20000, gpus=True, constraints=True)
+    j2o = _full_cycle_parity(make_engine, pool)
+    assert 20000 < (j2o >= 0).sum() < 200000
+
+
+def test_c4_one_pool_full_size(make_engine):
+    """configs[3], one of its 8 pools = what one GPU of the 8-GPU configuration runs: 125k pending x 6250 offers, 10k users"""
+    pool = synth.make_pool(seed=0xC00C0004, n_pending=125000, n_running=50000, n_users=10000, n_offers=6250, gpus=True, constraints=True)
+    j2o = _full_cycle_parity(make_engine, pool)
+    assert 10000 < (j2o >= 0).sum() < 125000

@@ -47,7 +47,7 @@ def test_replay_oracle_is_deterministic_and_conserves_resources():
 
 
 def test_replay_parity_emulated(emu_engine, tmp_path):
-    trace, hosts = P.make_trace(2, 60, 3, span_ms=900_000)
+    trace, hosts = P.make_trace(2, 40, 3, span_ms=500_000)
     sim = P.replay_parity(emu_engine, trace, hosts, CONFIG)
     out = tmp_path / "out-trace.csv"
     sim.write_csv(str(out))
@@ -56,7 +56,7 @@ def test_replay_parity_emulated(emu_engine, tmp_path):
 
 
 def test_replay_parity_emulated_with_preemption(emu_engine):
-    trace, hosts = P.make_trace(3, 90, 2, span_ms=600_000)
+    trace, hosts = P.make_trace(3, 60, 2, span_ms=360_000)
     P.replay_parity(emu_engine, trace, hosts, TIGHT, min_preempted=1)
 
 
