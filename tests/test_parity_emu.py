@@ -297,3 +297,23 @@ def test_metrics_parity(make_engine):
 def test_explain_after_a_cycle(make_engine):
     pool = synth.make_pool(seed=31, n_pending=600, n_running=200, n_users=30, n_offers=60, gpus=True, constraints=True)
     P.cycle_explain_parity(make_engine, pool, A.default_params(good_enough_fitness=1.0), k=300, n_users=30)
+
+
+def test_new_entry_points_fail_loudly(make_engine):
+    from cook_amd.engine import CookError
+    p = A.default_params(good_enough_fitness=1.0)
+    with make_engine(p) as e:
+        for call in (lambda: e.match_explain([0]), lambda: e.match_metrics(), lambda: e.offers_run()):
+            with pytest.raises(CookError) as ei:  # nothing staged / no match ran: COOK_E_STATE, outputs untouched
+                call()
+            assert ei.value.code == -4
+        jobs = A.Jobs(cpus=np.array([1.0, 2.0]), mem=np.array([1.0, 2.0]))
+        e.match(jobs, A.Offers(cpus=np.array([4.0]), mem=np.array([4.0])))
+        with pytest.raises(CookError) as ei:  # a position beyond the jobs of the last match
+            e.match_explain([2])
+        assert ei.value.code == -1
+        with pytest.raises(CookError) as ei:  # per-user counts without the jobs' user column
+            e.match_metrics(n_users=3)
+        assert ei.value.code == -1
+        assert e.match_explain([]).shape == (0, A.WHY_SLOTS)
+        assert e.match_metrics()["matched"] == 2  # the engine is still usable after the errors
