@@ -72,24 +72,33 @@ static __device__ __forceinline__ unsigned long long dpp_move_u64(unsigned long 
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
   return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
 }
-// all 64 lanes must be active
+// all 64 lanes must be active.  A u64 max has no DPP form (each step = two DPP moves, a 64-bit compare and two selects: 54
+// instructions on the walk's critical path); a u32 max does (v_max_u32 with a DPP source).  So: the maximum of the high words
+// first, then — among the lanes that hold it — of the low words (read from the one lane when the high word is unique).
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ unsigned dpp_max_u32(unsigned x) {
+  const unsigned y = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROW_MASK, 0xF, false);
+  return y > x ? y : x;
+}
+static __device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
+  x = dpp_max_u32<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
+  x = dpp_max_u32<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
+  x = dpp_max_u32<0x141, 0xF>(x);  // row_half_mirror
+  x = dpp_max_u32<0x140, 0xF>(x);  // row_mirror
+  x = dpp_max_u32<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
+  x = dpp_max_u32<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
 static __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long x) {
-  unsigned long long y;
-  y = dpp_move_u64<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
-  x = y > x ? y : x;
-  y = dpp_move_u64<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
-  x = y > x ? y : x;
-  y = dpp_move_u64<0x141, 0xF>(x);  // row_half_mirror
-  x = y > x ? y : x;
-  y = dpp_move_u64<0x140, 0xF>(x);  // row_mirror
-  x = y > x ? y : x;
-  y = dpp_move_u64<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
-  x = y > x ? y : x;
-  y = dpp_move_u64<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
-  x = y > x ? y : x;
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 63);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
-  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+  const unsigned hi = (unsigned)(x >> 32), lo = (unsigned)x;
+  const unsigned mh = wave_max_u32(hi);
+  const unsigned long long top = __ballot(hi == mh);
+  unsigned ml;
+  if ((top & (top - 1ull)) == 0ull)  // wave-uniform: one lane holds the greatest high word
+    ml = (unsigned)__builtin_amdgcn_readlane((int)lo, __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)top) - 1));
+  else
+    ml = wave_max_u32(hi == mh ? lo : 0u);
+  return ((unsigned long long)mh << 32) | (unsigned long long)ml;
 }
 // value of v in lane src; src must be wave-uniform
 static __device__ __forceinline__ int wave_read_lane(int v, int src) {
