@@ -802,7 +802,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       unsigned nwg = (unsigned)std::max(4, std::min(64, e->n_cus * 3 / (4 * sharing)));
       nwg = std::min(nwg, std::max(1u, C * (unsigned)MV_JG));
 #endif
-      KL("match_persist", match_persist, nwg, MV_RTHREADS, in, st, vb, pc, 0x7FFFFFFFu);
+      KL("match_persist", match_persist, nwg, COOK_WAVE * MV_EW, in, st, vb, pc, 0x7FFFFFFFu);
       COOK_HIP(hipMemcpyAsync(e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
       COOK_HIP(hipMemcpyAsync(e->h_scratch + 32, pc, sizeof(PersistCtl), hipMemcpyDeviceToHost, e->stream));
       sync(e);

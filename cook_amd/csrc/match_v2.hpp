@@ -37,10 +37,23 @@ constexpr int MV_LG = 4;                   // good-enough list length per job
 #define COOK_MV_OCW 32
 #endif
 constexpr int MV_OCW = COOK_MV_OCW;        // offers per eval wave (a power of two <= 64; -DCOOK_MV_OCW=n builds a tuning variant)
-constexpr int MV_EW = 4;                   // waves per eval block (same 64 jobs, consecutive offer sub-chunks)
+#ifndef COOK_MV_EW
+#define COOK_MV_EW 4
+#endif
+constexpr int MV_EW = COOK_MV_EW;          // waves per eval block (same 64 jobs, consecutive offer sub-chunks)
 constexpr int MV_OCB = MV_OCW * MV_EW;     // offers per eval block
 constexpr int MV_T = COOK_WAVE;            // touched offers per round = lanes of the walking wave
-constexpr int MV_RTHREADS = 256;           // threads of the resolve workgroup (set-up phase); wave 0 sequences
+#ifndef COOK_MV_RTHREADS
+#ifdef __HIP_EMU__
+#define COOK_MV_RTHREADS 256  // fewer fibers per block: the emulated tests stay fast (the strides are blockDim.x either way)
+#else
+#define COOK_MV_RTHREADS 512
+#endif
+#endif
+constexpr int MV_RTHREADS = COOK_MV_RTHREADS;  // threads of the resolve workgroup: the set-up phase is parallel over them (512: 9.2 -> 6.0 ms
+                                               // per C4 pool), wave 0 walks.  resolve_round strides by blockDim.x, so the persistent
+                                               // kernel may run it with its own (eval-tile) block shape.
+constexpr int MV_RWAVES_MAX = (MV_RTHREADS > COOK_WAVE * MV_EW ? MV_RTHREADS : COOK_WAVE * MV_EW) / COOK_WAVE;
 #ifdef __HIP_EMU__
 constexpr int MV_WMAX = 128;               // jobs per round (emulator: small, so that tests run many rounds)
 constexpr int MV_S = 128;                  // distinct candidate offers staged per round
@@ -677,12 +690,12 @@ struct ResolveLds {
   unsigned long long col[MV_S][MV_JG];
   unsigned long long visit[MV_JG];
   double tac[MV_T], tam[MV_T];  // current state of the touched offers, by owner lane (published for a re-evaluation)
-  double rfit[MV_RTHREADS / COOK_WAVE];
+  double rfit[MV_RWAVES_MAX];
   int hkey[MV_HASH];
   int j2o[MV_WMAX];                 // results of the walk, flushed to HBM once per round: a global store inside the walk
   int tacount[MV_T];                // would stall later s_waitcnt vmcnt(0) on its acknowledgement
-  int ridx[MV_RTHREADS / COOK_WAVE], rge[MV_RTHREADS / COOK_WAVE];
-  unsigned rc[MV_RTHREADS / COOK_WAVE][3];
+  int ridx[MV_RWAVES_MAX], rge[MV_RWAVES_MAX];
+  unsigned rc[MV_RWAVES_MAX][3];
   unsigned nslots, minbad;
   int cmd;                          // window index of the job to re-evaluate, -1 = the walk is over
   unsigned short hslot[MV_HASH];
@@ -719,7 +732,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   auto& s_ridx = L.ridx;
   auto& s_rge = L.rge;
   auto& s_rc = L.rc;
-  const unsigned tid = threadIdx.x, lane = lane_id();
+  const unsigned tid = threadIdx.x, lane = lane_id(), NT = blockDim.x;
   WinCtl ctl = *vb.ctl;
   const unsigned head = ctl.head;
   const unsigned K = vb.in_dev->K;
@@ -730,14 +743,14 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   const double good_enough = vb.in_dev->good_enough;
   const bool use_ge = good_enough < 1.0;
   // ---- set-up phase (all threads): stage the window in LDS -------------------------------------------------------------
-  for (unsigned x = tid; x < MV_HASH; x += MV_RTHREADS) s_hkey[x] = -1;
+  for (unsigned x = tid; x < MV_HASH; x += NT) s_hkey[x] = -1;
   if (tid < MV_JG) s_visit[tid] = 0ull;
   if (tid == 0) {
     s_nslots = 0;
     s_minbad = 0xFFFFFFFFu;
   }
   __syncthreads();
-  for (unsigned b = tid; b < nwin; b += MV_RTHREADS) {
+  for (unsigned b = tid; b < nwin; b += NT) {
     const JobRec j = vb.jr[head + b];
     const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
     const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
@@ -766,7 +779,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   }
   // candidate lists of the whole window -> LDS (one parallel pass; the slot-table passes below then never touch HBM)
   constexpr int EPJ = MV_L + MV_LG;
-  for (unsigned e = tid; e < nwin * EPJ; e += MV_RTHREADS) {
+  for (unsigned e = tid; e < nwin * EPJ; e += NT) {
     const unsigned b = e / EPJ, q = e % EPJ;
     const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
     if (q < (unsigned)MV_L) {
@@ -798,7 +811,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     bool overflow = false;
     for (unsigned s0 = 0; s0 < nwin; s0 += step) {
       const unsigned e1 = ((s0 + step < nwin) ? s0 + step : nwin) * EPJ;
-      for (unsigned e = s0 * EPJ + tid; e < e1; e += MV_RTHREADS) {
+      for (unsigned e = s0 * EPJ + tid; e < e1; e += NT) {
         const unsigned b = e / EPJ, q = e % EPJ;
         const int idx = q < (unsigned)MV_L ? s_ent[b][q].off : s_gent[b][q - MV_L].off;
         if (idx < 0) continue;
@@ -827,7 +840,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     }
     if (!overflow || pass == 1) break;
     // overflow in the optimistic pass: reset the table and go stepwise
-    for (unsigned x = tid; x < MV_HASH; x += MV_RTHREADS) s_hkey[x] = -1;
+    for (unsigned x = tid; x < MV_HASH; x += NT) s_hkey[x] = -1;
     if (tid == 0) {
       s_nslots = 0;
       s_minbad = 0xFFFFFFFFu;
@@ -835,7 +848,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     __syncthreads();
   }
   const unsigned weff = s_minbad < nwin ? s_minbad : nwin;  // jobs resolvable in this round
-  for (unsigned e = tid; e < weff * EPJ; e += MV_RTHREADS) {  // candidate offer -> slot
+  for (unsigned e = tid; e < weff * EPJ; e += NT) {  // candidate offer -> slot
     const unsigned b = e / EPJ, q = e % EPJ;
     const int idx = q < (unsigned)MV_L ? s_ent[b][q].off : s_gent[b][q - MV_L].off;
     if (idx < 0) continue;
@@ -847,7 +860,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       s_gent[b][q - MV_L].slot = s_hslot[h];
   }
   const unsigned nslots = s_nslots < (unsigned)MV_S ? s_nslots : (unsigned)MV_S;
-  for (unsigned s = tid; s < nslots; s += MV_RTHREADS) {
+  for (unsigned s = tid; s < nslots; s += NT) {
     const int v = s_slot[s].offer;
     s_slot[s].a = vb.oa[v];
     s_slot[s].o = vb.ob[v];
@@ -856,7 +869,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     s_slot[s].acount = st.acount[v];
     s_slot_lane[s] = 0xFF;
   }
-  for (unsigned x = tid; x < nslots * MV_JG; x += MV_RTHREADS) {
+  for (unsigned x = tid; x < nslots * MV_JG; x += NT) {
     const unsigned s = x / MV_JG, g = x % MV_JG;
     s_col[s][g] = (g * COOK_WAVE < nwin) ? vb.colbits[(size_t)s_slot[s].offer * MV_JG + g] : 0ull;
   }
@@ -873,7 +886,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     Cand best{-1.0, -1};
     int ge_idx = 0x7FFFFFFF;
     unsigned c1 = 0, c2 = 0, c4 = 0;
-    for (unsigned v = tid; v < in.M; v += MV_RTHREADS) {
+    for (unsigned v = tid; v < in.M; v += NT) {
       double ac = st.ac[v], am = st.am[v];
       int acount = st.acount[v];
       unsigned h = (v * 2654435761u) % MV_HASH;
@@ -1233,7 +1246,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       Cand rb{s_rfit[0], s_ridx[0]};
       int rg = s_rge[0];
       unsigned rc1 = s_rc[0][0], rc2 = s_rc[0][1], rc4 = s_rc[0][2];
-      for (int q = 1; q < MV_RTHREADS / COOK_WAVE; ++q) {
+      for (int q = 1; q < (int)(NT / COOK_WAVE); ++q) {
         const Cand o{s_rfit[q], s_ridx[q]};
         if (cand_better(o, rb)) rb = o;
         rg = s_rge[q] < rg ? s_rge[q] : rg;
@@ -1514,8 +1527,7 @@ static __device__ __forceinline__ bool grid_barrier(PersistCtl* pc, unsigned nbl
   return s_ok != 0;
 }
 
-__global__ void __launch_bounds__(MV_RTHREADS) match_persist(MatchIn in, MatchState st, V2Buf vb, PersistCtl* pc, unsigned max_rounds) {
-  static_assert(MV_RTHREADS == COOK_WAVE * MV_EW, "eval tiles and the resolve workgroup share one block shape");
+__global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_persist(MatchIn in, MatchState st, V2Buf vb, PersistCtl* pc, unsigned max_rounds) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(PersistLds)];
   const unsigned nb = gridDim.x, wg = blockIdx.x;
   unsigned rounds = 0;
