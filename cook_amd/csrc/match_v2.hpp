@@ -47,10 +47,10 @@ constexpr int MV_T = COOK_WAVE;            // touched offers per round = lanes o
 #ifdef __HIP_EMU__
 #define COOK_MV_RTHREADS 256  // fewer fibers per block: the emulated tests stay fast (the strides are blockDim.x either way)
 #else
-#define COOK_MV_RTHREADS 512
+#define COOK_MV_RTHREADS 768
 #endif
 #endif
-constexpr int MV_RTHREADS = COOK_MV_RTHREADS;  // threads of the resolve workgroup: the set-up phase is parallel over them (512: 9.2 -> 6.0 ms
+constexpr int MV_RTHREADS = COOK_MV_RTHREADS;  // threads of the resolve workgroup: the set-up phase is parallel over them (256 -> 768: 9.2 -> 5.1 ms
                                                // per C4 pool), wave 0 walks.  resolve_round strides by blockDim.x, so the persistent
                                                // kernel may run it with its own (eval-tile) block shape.
 constexpr int MV_RWAVES_MAX = (MV_RTHREADS > COOK_WAVE * MV_EW ? MV_RTHREADS : COOK_WAVE * MV_EW) / COOK_WAVE;
