@@ -65,13 +65,6 @@ static inline unsigned long long wave_max_u64(unsigned long long x) {
 }
 static inline int wave_read_lane(int v, int src) { return __shfl(v, src, COOK_WAVE); }
 #else
-template <int CTRL, int ROW_MASK>
-static __device__ __forceinline__ unsigned long long dpp_move_u64(unsigned long long x) {
-  int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
-  return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
-}
 // all 64 lanes must be active.  A u64 max has no DPP form (each step = two DPP moves, a 64-bit compare and two selects: 54
 // instructions on the walk's critical path); a u32 max does (v_max_u32 with a DPP source).  So: the maximum of the high words
 // first, then — among the lanes that hold it — of the low words (read from the one lane when the high word is unique).

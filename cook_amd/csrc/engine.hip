@@ -177,6 +177,7 @@ struct cook_engine {
   ExplainBufs* xb = nullptr;
   MatchIn last_in{};  // the MatchIn of the last match run (K, j_index as used)
   bool last_in_valid = false;
+  unsigned rlog_id = 0;  // suffix of this engine's COOK_ROUND_LOG file
   DArr<uint32_t> j_user;
   bool has_j_user = false;
 
@@ -878,7 +879,14 @@ void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, 
   if (rlog_path && vb.round_log) {
     std::vector<RoundLog> h(std::min(hc.rounds, MV_ROUND_LOG_CAP));
     if (!h.empty()) COOK_HIP(hipMemcpy(h.data(), vb.round_log, h.size() * sizeof(RoundLog), hipMemcpyDeviceToHost));
-    if (FILE* f = std::fopen(rlog_path, "w")) {
+    // one file per engine when the path ends in '@' (several pools in one process): "<path minus @>.<engine number>"
+    static std::atomic<unsigned> g_rlog_seq{0};
+    std::string path = rlog_path;
+    if (!path.empty() && path.back() == '@') {
+      if (e->rlog_id == 0) e->rlog_id = ++g_rlog_seq;
+      path = path.substr(0, path.size() - 1) + "." + std::to_string(e->rlog_id);
+    }
+    if (FILE* f = std::fopen(path.c_str(), "w")) {
       std::fprintf(f, "head,wcur,resolved,n_list,touched,stop,matched,setup_us,seq_us,nslots\n");
       for (auto& r : h)
         std::fprintf(f, "%u,%u,%u,%u,%u,%u,%u,%.2f,%.2f,%u\n", r.head, r.wcur, r.resolved, r.n_list, r.touched, r.stop, r.matched,

@@ -352,20 +352,3 @@ __global__ void __launch_bounds__(OT_THREADS) offers_totals(NodeCols nd, NodeAva
     __syncthreads();
   }
 }
-
-// in-order fold of NV columns, 64 values per step through v_readlane (used by the metrics' fallback path)
-template <int NV>
-static __device__ __forceinline__ void offers_fold_chunk(double (&acc)[NV], const double (&x)[NV], unsigned cnt) {
-  if (cnt == (unsigned)COOK_WAVE) {
-#pragma unroll
-    for (int k = 0; k < COOK_WAVE; ++k) {
-#pragma unroll
-      for (int q = 0; q < NV; ++q) acc[q] = acc[q] + wave_read_lane_f64(x[q], k);
-    }
-  } else {
-    for (unsigned k = 0; k < cnt; ++k) {
-#pragma unroll
-      for (int q = 0; q < NV; ++q) acc[q] = acc[q] + wave_read_lane_f64(x[q], (int)k);
-    }
-  }
-}

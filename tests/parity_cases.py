@@ -621,3 +621,24 @@ def replay_parity(make_engine, trace, hosts, config, min_preempted=0, max_cycles
     assert sum(r["preempted"] for r in got.log) >= min_preempted
     assert set(rg[0].keys()) == set(replay.CSV_HEADERS)
     return got
+
+
+def offers_many_models_and_types(make_engine):
+    """more gpu models than the kernel totals in LDS (global-atomic path) and more disk types than one pass of the gauge
+    kernel folds (several passes of 8 quantities)"""
+    rng = np.random.default_rng(77)
+    n, p, n_models, n_types = 900, 5000, 70, 6
+    gm = rng.integers(0, n_models + 1, n).astype(np.uint32)
+    gp = np.where(gm > 0, rng.integers(1, 9, n), 0).astype(np.int32)
+    dt = rng.integers(0, n_types + 1, n).astype(np.uint32)
+    nodes = A.Nodes(cpus=rng.integers(8, 65, n).astype(float), mem=rng.integers(8, 65, n) * 1024.0, gpus=gp, gpu_model=gm,
+                    disk=np.where(dt > 0, 100000.0 + rng.integers(0, 50, n) * 0.1, -1.0), disk_type=dt)
+    pn = rng.integers(0, n, p).astype(np.uint32)
+    want_g = (gm[pn] > 0) & (rng.random(p) < 0.5)
+    want_d = (dt[pn] > 0) & (rng.random(p) < 0.5)
+    pods = A.Pods(node=pn, cpus=rng.integers(1, 4, p) + 0.1, mem=rng.integers(100, 900, p) + 0.3,
+                  gpus=np.where(want_g, 1, 0).astype(np.int32), gpu_model=np.where(want_g, gm[pn], 0).astype(np.uint32),
+                  disk=np.where(want_d, 10.7, -1.0), disk_type=np.where(want_d, dt[pn], 0).astype(np.uint32))
+    op = A.offer_params(max_pods_per_node=64, n_gpu_models=n_models, n_disk_types=n_types)
+    got = offers_parity(make_engine, nodes, pods, op, "many models / types")
+    assert (got.gpu_consumed_by_model > 0).sum() > 40 and (got.disk_consumed_by_type > 0).sum() == n_types

@@ -317,3 +317,7 @@ def test_new_entry_points_fail_loudly(make_engine):
         assert ei.value.code == -1
         assert e.match_explain([]).shape == (0, A.WHY_SLOTS)
         assert e.match_metrics()["matched"] == 2  # the engine is still usable after the errors
+
+
+def test_offers_many_models_and_types(make_engine):
+    P.offers_many_models_and_types(make_engine)

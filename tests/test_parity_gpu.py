@@ -333,3 +333,7 @@ def test_c4_one_pool_full_size(make_engine):
     pool = synth.make_pool(seed=0xC00C0004, n_pending=125000, n_running=50000, n_users=10000, n_offers=6250, gpus=True, constraints=True)
     j2o = _full_cycle_parity(make_engine, pool)
     assert 10000 < (j2o >= 0).sum() < 125000
+
+
+def test_offers_many_models_and_types(make_engine):
+    P.offers_many_models_and_types(make_engine)
