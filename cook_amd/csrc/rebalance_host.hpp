@@ -27,7 +27,11 @@ struct RebalBufs {
   DArr<double> dru;
   // hosts
   DArr<uint64_t> hkey;
-  DArr<uint32_t> hpermA, hpermB, hstart, hend;
+  DArr<uint32_t> hpermA, hpermB, hstart, hend, h_pb, h_user, hidx, chg, chg_tile, chg_bad, chg_mark;
+  DArr<SumU4> tile_agg, tile_carry;
+  DArr<uint32_t> x_before, x_cnt;
+  DArr<double> h_cpus, h_mem, h_gpus, h_dru;
+  DArr<uint8_t> h_act;
   uint32_t* hperm = nullptr;
   DArr<int32_t> row_of_host;
   DArr<double> spare_c, spare_m, spare_g, spare0_c, spare0_m, spare0_g;  // spare0_*: as staged (a run updates spare_*)
@@ -288,6 +292,21 @@ RebalIn rebalance_args(cook_engine* e, RebalBufs& b) {
   in.pending_dru = b.pending_dru.ptr();
   in.ctl = b.ctl.ptr();
   in.job = b.jobctx.ptr();
+  in.h_pb = b.h_pb.ptr(), in.h_user = b.h_user.ptr();
+  in.h_cpus = b.h_cpus.ptr(), in.h_mem = b.h_mem.ptr(), in.h_gpus = b.h_gpus.ptr();
+  in.h_dru = b.h_dru.ptr();
+  in.h_act = b.h_act.ptr();
+  in.hidx = b.hidx.ptr();
+  in.chg = b.chg.ptr();
+  in.chg_tile = b.chg_tile.ptr();
+  in.chg_bad = b.chg_bad.ptr();
+  in.chg_mark = b.chg_mark.ptr();
+  in.tile_agg = b.tile_agg.ptr();
+  in.tile_carry = b.tile_carry.ptr();
+  in.x_before = b.x_before.ptr();
+  in.x_cnt = b.x_cnt.ptr();
+  in.pre_w = b.pre.ptr();
+  in.dru_w = b.dru.ptr();
   return in;
 }
 
@@ -394,6 +413,22 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
     KL("rebal_host_bounds", rebal_host_bounds, gR, 256, (const uint32_t*)b.hperm, (const uint32_t*)b.host.ptr(), R, b.hstart.ptr(),
        b.hend.ptr());
   }
+  // host-ordered mirrors of the running slots' columns (static ones now, the DRUs after the first scoring)
+  b.h_pb.ensure(std::max(1u, R)), b.h_user.ensure(std::max(1u, R));
+  b.h_cpus.ensure(std::max(1u, R)), b.h_mem.ensure(std::max(1u, R)), b.h_gpus.ensure(std::max(1u, R)), b.h_dru.ensure(std::max(1u, R));
+  b.h_act.ensure(std::max(1u, R));
+  b.hidx.ensure(S);
+  b.chg.ensure(S + 1), b.chg_tile.ensure(S + 2), b.chg_bad.ensure(S + 1), b.chg_mark.ensure(std::max(1u, U));
+  b.tile_agg.ensure(S / RB_RS_TILE + S + 2), b.tile_carry.ensure(S / RB_RS_TILE + S + 2);  // every listed user adds at most one partial tile
+  b.x_before.ensure(std::max(1u, H)), b.x_cnt.ensure(std::max(1u, H));
+  COOK_HIP(hipMemsetAsync(b.chg_mark.ptr(), 0, (size_t)std::max(1u, U) * 4, e->stream));
+  COOK_HIP(hipMemsetAsync(b.x_before.ptr(), 0, (size_t)std::max(1u, H) * 4, e->stream));
+  COOK_HIP(hipMemsetAsync(b.x_cnt.ptr(), 0, (size_t)std::max(1u, H) * 4, e->stream));
+  COOK_HIP(hipMemsetAsync(b.hidx.ptr(), 0xFF, (size_t)S * 4, e->stream));
+  if (R)
+    KL("rebal_host_mirror", rebal_host_mirror, div_up(R, 256), 256, (const uint32_t*)b.hperm, (const uint32_t*)b.posB.ptr(),
+       (const uint32_t*)b.user.ptr(), (const double*)b.cpus.ptr(), (const double*)b.mem.ptr(), (const double*)b.gpus.ptr(), R, b.h_pb.ptr(),
+       b.h_user.ptr(), b.h_cpus.ptr(), b.h_mem.ptr(), b.h_gpus.ptr(), b.h_act.ptr(), b.hidx.ptr());
   // ---- dynamic state -----------------------------------------------------------------------------------------------------------
   b.x_pj.ensure(P);
   b.x_host.ensure(P);
@@ -427,7 +462,8 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   std::vector<double> nanv(P, std::numeric_limits<double>::quiet_NaN());
   COOK_HIP(hipMemcpyAsync(b.pending_dru.ptr(), nanv.data(), (size_t)P * 8, hipMemcpyHostToDevice, e->stream));
   sync(e);  // nanv / h_scratch are reused below
-  rebalance_rescore(e, b);
+  rebalance_rescore(e, b);  // every user once; after a decision only the users it touched (rebal_rescore_users)
+  if (R) KL("rebal_mirror_dru", rebal_mirror_dru, div_up(R, 256), 256, (const uint32_t*)b.h_pb.ptr(), (const double*)b.dru.ptr(), R, b.h_dru.ptr());
   // ---- the decision loop (rebalancer.clj:442-458) ---------------------------------------------------------------------------------
   const RebalIn in = rebalance_args(e, b);
   const unsigned gH = div_up(std::max(1u, H), RB_WAVES);
@@ -435,7 +471,10 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
     KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, pj);
     if (H) KL("rebal_decide", rebal_decide, gH, COOK_WAVE * RB_WAVES, in);
     KL("rebal_apply", rebal_apply, 1, RB_APPLY_THREADS, in);
-    rebalance_rescore(e, b);
+    KL("rebal_rs_local", rebal_rs_local, RB_RS_GRID, RB_RS_TILE, in);
+    KL("rebal_rs_carry", rebal_rs_carry, RB_RS_USERS, COOK_WAVE, in);
+    KL("rebal_rs_finish", rebal_rs_finish, RB_RS_GRID, RB_RS_TILE, in);
+    KL("rebal_rs_fix", rebal_rs_fix, RB_RS_USERS, 256, in);
     if ((pj + 1) % RB_CHECK == 0 && pj + 1 < P) {
       COOK_HIP(hipMemcpyAsync(e->h_scratch, b.ctl.ptr(), sizeof(RebalCtl), hipMemcpyDeviceToHost, e->stream));
       sync(e);

@@ -34,7 +34,9 @@ struct RebalCtl {
   unsigned nd, np;      // decisions / preempted tasks emitted
   unsigned n_pre_hosts; // hosts of the tasks preempted so far whose attribute map is known (constraints.clj:686-689)
   unsigned n_x;         // jobs placed so far this cycle (x_pj, sorted by host)
-  unsigned pad[3];
+  unsigned n_changed;   // users whose active set the last decision changed (chg[])
+  unsigned n_tiles;     // tiles of RB_RS_TILE slots their segments are cut into (chg_tile[])
+  unsigned pad[1];
 };
 
 struct RebalJob {  // context of the pending job being decided (written by rebal_job_prep)
@@ -70,6 +72,20 @@ struct RebalIn {
   // hosts
   const uint32_t* hperm;          // [R] running slots grouped by host
   const uint32_t *hstart, *hend;  // [H]
+  // the running slots' columns mirrored in HOST order (index = position in hperm): rebal_decide streams a host's tasks
+  // instead of chasing slot -> position-in-user-order -> value through three dependent random loads
+  const uint32_t *h_pb, *h_user;  // position in per-user order (static), user (static)
+  const double *h_cpus, *h_mem, *h_gpus;
+  double* h_dru;                  // refreshed by the re-scoring of the users a decision touched
+  uint8_t* h_act;                 // cleared when a task is preempted
+  const uint32_t* hidx;           // [S] B position -> index in host order (running slots), COOK_NONE otherwise
+  uint32_t* chg;                  // [S + 1] users to re-score after the last decision (each once)
+  uint32_t* chg_tile;             // [S + 2] first tile of each of them, total at [n_changed]
+  uint32_t* chg_bad;              // [S + 1] an addition rounded while re-scoring that user
+  uint32_t* chg_mark;             // [U] stamp of the decision that last listed the user (deduplication)
+  SumU4 *tile_agg, *tile_carry;   // [S / RB_RS_TILE + S + 2] tile totals / carries
+  SumU4* pre_w;                   // writable aliases of pre / dru
+  double* dru_w;
   const int32_t* row_of_host;     // [H] row of the host in the attribute table, -1 = not cached
   double *spare_c, *spare_m, *spare_g;
   uint8_t* has_spare;
@@ -99,6 +115,7 @@ struct RebalIn {
   uint32_t* x_pj;       // [P] placed jobs sorted by host
   uint32_t* x_host;     // [P] by pj
   uint8_t* x_known;     // [P] by pj: the placed task carries a slave id whose attributes are cached
+  uint32_t *x_before, *x_cnt;  // [H] placed jobs on hosts before this one / on this one
   uint32_t* pre_hosts;  // [S]
   uint32_t* co_val;     // cohost values of the current job's group
   // per-host results of rebal_decide
@@ -231,6 +248,148 @@ __global__ void __launch_bounds__(256) rebal_host_bounds(const uint32_t* __restr
   if (i == n - 1 || host[hperm[i + 1]] != h) hend[h] = i + 1;
 }
 
+// host-ordered mirrors of the running slots (built once per run, after both orders are known)
+__global__ void __launch_bounds__(256) rebal_host_mirror(const uint32_t* __restrict__ hperm, const uint32_t* __restrict__ posB,
+                                                         const uint32_t* __restrict__ slot_user, const double* __restrict__ cpus,
+                                                         const double* __restrict__ mem, const double* __restrict__ gpus, unsigned R,
+                                                         uint32_t* __restrict__ h_pb, uint32_t* __restrict__ h_user,
+                                                         double* __restrict__ h_cpus, double* __restrict__ h_mem, double* __restrict__ h_gpus,
+                                                         uint8_t* __restrict__ h_act, uint32_t* __restrict__ hidx) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const unsigned slot = hperm[i], pb = posB[slot];
+  h_pb[i] = pb;
+  h_user[i] = slot_user[slot];
+  h_cpus[i] = cpus[slot];
+  h_mem[i] = mem[slot];
+  h_gpus[i] = gpus[slot];
+  h_act[i] = 1;
+  hidx[pb] = i;
+}
+__global__ void __launch_bounds__(256) rebal_mirror_dru(const uint32_t* __restrict__ h_pb, const double* __restrict__ dru, unsigned R,
+                                                        double* __restrict__ h_dru) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < R) h_dru[i] = dru[h_pb[i]];
+}
+
+// Re-scoring after a decision (dru.clj:128-144 recomputes the changed users only).  rebal_apply lists the users whose active
+// set changed (in.chg) and cuts their segments of the per-user order into tiles of RB_RS_TILE slots (in.chg_tile: first tile of
+// each user, in.ctl->n_tiles in all): a heavy user's hundred thousand slots are scanned by many workgroups, a light user's by
+// one.  Masked prefix sums with exactness tracking in three steps (tile-local scans, per-user scan of the tile totals, carry +
+// DRU) — any association is the left-to-right sum when no addition rounded; a user where one did is redone sequentially
+// (rebal_rs_fix, as rebal_fix_inexact does).  The DRUs also go to the host-ordered mirror.
+constexpr int RB_RS_TILE = 1024, RB_RS_GRID = 256, RB_RS_USERS = 64;
+static __device__ __forceinline__ unsigned rebal_rs_user_of_tile(const RebalIn& in, unsigned n_chg, unsigned tile) {
+  unsigned lo = 0, hi = n_chg;  // last x with chg_tile[x] <= tile
+  while (hi - lo > 1) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (in.chg_tile[mid] <= tile)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+static __device__ __forceinline__ double rebal_dru_of(const RebalIn& in, unsigned u, const SumU4& sm) {
+  if (in.dru_mode == 1) return sm.gpus / in.div_gpus[u];
+  const double a = sm.mem / in.div_mem[u], b = sm.cpus / in.div_cpus[u];
+  return a > b ? a : b;
+}
+// step 1: tile-local masked inclusive scans -> pre (without the carry), tile totals
+__global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_local(RebalIn in) {
+  __shared__ SumU4 s_tot[RB_RS_TILE / COOK_WAVE];
+  const unsigned n_chg = in.ctl->n_changed, n_tiles = in.ctl->n_tiles;
+  if (n_chg == 0u) return;
+  const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const unsigned x = rebal_rs_user_of_tile(in, n_chg, tile), u = in.chg[x];
+    const unsigned s1 = in.seg_end[u], i = in.seg_start[u] + (tile - in.chg_tile[x]) * RB_RS_TILE + tid;
+    const bool in_seg = i < s1;
+    const SumU4 v = wave_incl_scan_u4((in_seg && in.act[i]) ? in.s_use[i] : SumU4::zero());
+    if (lane == COOK_WAVE - 1) s_tot[w] = v;
+    __syncthreads();
+    SumU4 pre = SumU4::zero();
+    for (unsigned k = 0; k < w; ++k) pre = combine(pre, s_tot[k]);
+    const SumU4 t = combine(pre, v);
+    if (in_seg) in.pre_w[i] = t;
+    if (tid == RB_RS_TILE - 1) in.tile_agg[tile] = t;  // the tile's total (zeros beyond the segment)
+    if (t.bad) in.chg_bad[x] = 1u;
+    __syncthreads();
+  }
+}
+// step 2: per changed user, exclusive scan of its tile totals (one wave; a user has few tiles)
+__global__ void __launch_bounds__(COOK_WAVE) rebal_rs_carry(RebalIn in) {
+  const unsigned n_chg = in.ctl->n_changed;
+  const unsigned lane = lane_id();
+  for (unsigned x = blockIdx.x; x < n_chg; x += gridDim.x) {
+    const unsigned t0 = in.chg_tile[x], t1 = in.chg_tile[x + 1];
+    SumU4 carry = SumU4::zero();
+    unsigned bad = 0u;
+    for (unsigned base = t0; base < t1; base += COOK_WAVE) {
+      const unsigned t = base + lane;
+      const SumU4 v = t < t1 ? in.tile_agg[t] : SumU4::zero();
+      const SumU4 inc = combine(carry, wave_incl_scan_u4(v));
+      // exclusive = inclusive of the previous lane
+      SumU4 ex = shfl_up_v(inc, 1);
+      if (lane == 0) ex = carry;
+      if (t < t1) in.tile_carry[t] = ex;
+      bad |= inc.bad;
+      carry = wave_bcast_u4(inc, COOK_WAVE - 1);
+    }
+    if (__any(bad != 0u) && lane == 0) in.chg_bad[x] = 1u;
+  }
+}
+// step 3: carry + local prefix -> pre, DRU, host-ordered mirror
+__global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_finish(RebalIn in) {
+  const unsigned n_chg = in.ctl->n_changed, n_tiles = in.ctl->n_tiles;
+  if (n_chg == 0u) return;
+  const unsigned tid = threadIdx.x;
+  for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const unsigned x = rebal_rs_user_of_tile(in, n_chg, tile), u = in.chg[x];
+    const unsigned i = in.seg_start[u] + (tile - in.chg_tile[x]) * RB_RS_TILE + tid;
+    if (i >= in.seg_end[u]) continue;
+    const SumU4 t = combine(in.tile_carry[tile], in.pre_w[i]);
+    if (t.bad) in.chg_bad[x] = 1u;
+    in.pre_w[i] = SumU4{t.count, t.cpus, t.mem, t.gpus, 0u};
+    const double d = rebal_dru_of(in, u, t);
+    in.dru_w[i] = d;
+    const unsigned hi = in.hidx[i];
+    if (hi != 0xFFFFFFFFu) in.h_dru[hi] = d;
+  }
+}
+// step 4: users where an addition rounded: left to right, exactly as the reference's reductions, then their DRUs again
+__global__ void __launch_bounds__(256) rebal_rs_fix(RebalIn in) {
+  const unsigned n_chg = in.ctl->n_changed;
+  for (unsigned x = blockIdx.x; x < n_chg; x += gridDim.x) {
+    if (!in.chg_bad[x]) continue;  // block-uniform
+    const unsigned u = in.chg[x], s0 = in.seg_start[u], s1 = in.seg_end[u];
+    if (threadIdx.x == 0) {
+      double c = 0.0, cp = 0.0, m = 0.0, g = 0.0;
+      bool first = true;
+      for (unsigned i = s0; i < s1; ++i) {
+        if (in.act[i]) {
+          const SumU4 v = in.s_use[i];
+          if (first) {
+            c = v.count, cp = v.cpus, m = v.mem, g = v.gpus;
+            first = false;
+          } else {
+            c += v.count, cp += v.cpus, m += v.mem, g += v.gpus;
+          }
+        }
+        in.pre_w[i] = SumU4{c, cp, m, g, 0u};
+      }
+    }
+    __syncthreads();
+    for (unsigned i = s0 + threadIdx.x; i < s1; i += blockDim.x) {
+      const double d = rebal_dru_of(in, u, in.pre_w[i]);
+      in.dru_w[i] = d;
+      const unsigned hi = in.hidx[i];
+      if (hi != 0xFFFFFFFFu) in.h_dru[hi] = d;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- per pending job: quota test, pending DRU, group cohosts -------------------------------------------------------------
 __global__ void __launch_bounds__(COOK_WAVE) rebal_job_prep(RebalIn in, unsigned pj) {
   const unsigned lane = lane_id();
@@ -244,6 +403,7 @@ __global__ void __launch_bounds__(COOK_WAVE) rebal_job_prep(RebalIn in, unsigned
   jb.minim = jb.maxfreq = 0;
   jb.pad0 = jb.pad1 = 0;
   jb.pdru = jb.c = jb.m = jb.g = 0.0;
+  if (lane == 0) in.ctl->n_changed = 0u;  // nothing to re-score unless rebal_apply takes a decision
   if (in.ctl->remaining <= 0) {
     if (lane == 0) *in.job = jb;
     return;
@@ -441,8 +601,9 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) 
   const unsigned h = blockIdx.x * RB_WAVES + w;
   if (h >= in.H) return;
   const unsigned hs = in.hstart[h], n_seg = in.hend[h] - hs;
-  const unsigned nx_all = in.ctl->n_x;
-  const unsigned xs = rebal_x_lower(in, nx_all, h), xe = rebal_x_lower(in, nx_all, h + 1);
+  // jobs placed on this host earlier in the cycle = x_pj[xs, xe): the placed list is sorted by host and rebal_apply keeps, per
+  // host, the number of entries before it (two dependent binary searches per wave cost more than the rest of the kernel)
+  const unsigned xs = in.x_before[h], xe = xs + in.x_cnt[h];
   const unsigned n = n_seg + (xe - xs);
   const bool sp = in.has_spare[h] != 0;
   if (lane == 0) in.hres_key[h] = 0ull;
@@ -463,8 +624,15 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) 
     unsigned slot = 0, pb = 0, usr = 0;
     bool a = false;
     double d = 0.0;
-    if (valid) {
-      slot = t < n_seg ? in.hperm[hs + t] : in.R + in.x_pj[xs + (t - n_seg)];
+    const bool mirrored = valid && t < n_seg;  // a running slot: its columns lie at hs + t of the host-ordered mirrors
+    if (mirrored) {
+      slot = in.hperm[hs + t];
+      pb = in.h_pb[hs + t];
+      a = in.h_act[hs + t] != 0;
+      usr = in.h_user[hs + t];
+      if (a) d = in.h_dru[hs + t];
+    } else if (valid) {  // a job placed earlier in this cycle
+      slot = in.R + in.x_pj[xs + (t - n_seg)];
       pb = in.posB[slot];
       a = in.act[pb] != 0;
       usr = in.slot_user[slot];
@@ -482,12 +650,15 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) 
       st_agent(&c_dru[idx], d);
       st_agent(&c_posB[idx], pb);
       st_agent(&c_slot[idx], slot);
-      st_agent(&c_cpus[idx], in.slot_cpus[slot]);
-      st_agent(&c_mem[idx], in.slot_mem[slot]);
-      st_agent(&c_gpus[idx], in.slot_gpus[slot]);
+      const double xc = mirrored ? in.h_cpus[hs + t] : in.slot_cpus[slot], xm = mirrored ? in.h_mem[hs + t] : in.slot_mem[slot];
+      const double xg = mirrored ? in.h_gpus[hs + t] : in.slot_gpus[slot];
+      st_agent(&c_cpus[idx], xc);
+      st_agent(&c_mem[idx], xm);
+      st_agent(&c_gpus[idx], xg);
     }
     n_c += (unsigned)__popcll(mk);
   }
+  if (n_c == 0 && !sp) return;  // nothing to preempt and nothing spare: no prefix exists (wave-uniform)
   // the LAST scored task of the host decides which slave id (hence attribute map) the host resolves to
   for (int dd = 32; dd >= 1; dd >>= 1) {
     const double od = __shfl_xor(last_d, dd, COOK_WAVE);
@@ -648,8 +819,11 @@ __global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in) {
     }
     __syncthreads();
   }
-  if (tid != 0 || s_key[0] == 0ull) return;  // no host can take the job: no decision, state unchanged (rebalancer.clj:455-458)
+  if (s_key[0] == 0ull) return;  // no host can take the job: no decision, state unchanged (rebalancer.clj:455-458)
   const unsigned h = s_host[0];
+  for (unsigned hh = h + 1 + tid; hh < in.H; hh += RB_APPLY_THREADS) in.x_before[hh] += 1u;  // the job is about to join x_pj at host h
+  if (tid != 0) return;
+  in.x_cnt[h] += 1u;
   const unsigned len = in.hres_len[h], base = in.hres_base[h];
   RebalCtl c = *in.ctl;
   cook_preemption d;
@@ -663,9 +837,24 @@ __global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in) {
   d.task_n = len;
   in.decisions[c.nd++] = d;
   bool first_known = false;
+  unsigned n_chg = 0, n_tiles = 0;
+  const unsigned stamp = c.nd;  // decisions are numbered from 1 here (nd was just incremented): 0 = never listed
+  auto changed = [&](unsigned u) {
+    if (in.chg_mark[u] == stamp) return;  // listed already by this decision
+    in.chg_mark[u] = stamp;
+    in.chg[n_chg] = u;
+    in.chg_bad[n_chg] = 0u;
+    in.chg_tile[n_chg] = n_tiles;
+    n_tiles += (in.seg_end[u] - in.seg_start[u] + RB_RS_TILE - 1) / RB_RS_TILE;
+    ++n_chg;
+  };
+  changed(jb.us);
   for (unsigned k = 0; k < len; ++k) {
     const unsigned slot = in.srt_slot[base + k];
-    in.act[in.posB[slot]] = 0;
+    const unsigned pbk = in.posB[slot];
+    in.act[pbk] = 0;
+    if (slot < in.R) in.h_act[in.hidx[pbk]] = 0;
+    changed(in.slot_user[slot]);
     in.preempted[c.np++] = slot < in.R ? slot : 0xFFFFFFFFu;  // a task placed this cycle is reported as NONE (rebalancer.clj:529)
     const bool known = slot < in.R ? (in.attrs_cached ? in.attrs_cached[slot] != 0 : true) : in.x_known[slot - in.R] != 0;
     if (k == 0) first_known = known;
@@ -687,5 +876,8 @@ __global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in) {
   in.spare_g[h] = d.gpus - jb.g;
   in.has_spare[h] = 1;
   c.remaining -= 1;
+  in.chg_tile[n_chg] = n_tiles;
+  c.n_changed = n_chg;
+  c.n_tiles = n_tiles;
   *in.ctl = c;
 }

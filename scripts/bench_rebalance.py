@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--kernels", action="store_true", help="one more profiled call: per-kernel microseconds and launches")
     args = ap.parse_args()
     import torch
     assert torch.cuda.is_available(), "needs an MI355X (no CPU fallback)"
@@ -52,6 +53,12 @@ def main():
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / args.steps
         got = e.rebalance_fetch()
+        kern = None
+        if args.kernels:
+            e.set_profiling(True)
+            e.rebalance_run()
+            kern = {k: [round(v[0] * 1e3, 1), v[1]] for k, v in sorted(e.kernel_timings().items(), key=lambda kv: -kv[1][0])[:14]}
+            e.set_profiling(False)
     nd = len(got["decisions"])
     nbytes = 52 * args.running + args.pending * 40 * args.running
     out = {"metric": "rebalancer sweep: cook_rebalance_run calls/sec", "value": 1.0 / wall, "unit": "calls/s",
@@ -60,7 +67,7 @@ def main():
            "config": {"workload": f"{args.running} running tasks + {args.pending} pending jobs examined, {args.users} users, "
                                   f"{args.hosts} hosts", "decisions": nd,
                       "preempted": sum(len(d["tasks"]) for d in got["decisions"])},
-           "stage_s": stage_s,
+           "stage_s": stage_s, "kernels_us_and_launches_per_call": kern,
            "roofline": {"bound": "hbm", "achieved": nbytes / wall / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": nbytes / wall / 1e9 / 8000.0, "algorithmic_bytes_per_call": nbytes, "traffic": None}}
     if args.check:
