@@ -76,7 +76,7 @@ ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4], ids=["default", "serial", 
 @ALGOS
 @pytest.mark.parametrize("ge", [1.0, 0.8, 0.5])
 def test_match_parity_random(make_engine, ge, algo):
-    pool = synth.make_pool(seed=21, n_pending=400, n_running=100, n_users=20, n_offers=300)
+    pool = synth.make_pool(seed=21, n_pending=260, n_running=100, n_users=20, n_offers=200)
     P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, A.default_params(good_enough_fitness=ge, match_algo=algo))
 
 
@@ -163,8 +163,8 @@ def test_rebalance_golden(make_engine):
     dict(seed=54, n_running=500, n_pending=40, n_users=15, n_hosts=40, constraints=True, gpus=True),
     dict(seed=55, n_running=300, n_pending=20, n_users=8, n_hosts=25, dru_mode=1),
     dict(seed=56, n_running=0, n_pending=10, n_users=3, n_hosts=8, spare_frac=1.0),                # spare resources only
-    dict(seed=57, n_running=3600, n_pending=10, n_users=2, n_hosts=90),                            # users of several re-scoring tiles
-    dict(seed=58, n_running=2600, n_pending=8, n_users=2, n_hosts=70, fractional=True),            # ... redone sequentially
+    dict(seed=57, n_running=2400, n_pending=8, n_users=2, n_hosts=60),                             # users of several re-scoring tiles
+    dict(seed=58, n_running=2200, n_pending=6, n_users=2, n_hosts=60, fractional=True),            # ... redone sequentially
 ], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
 def test_rebalance_parity_random(make_engine, kw):
     P.rebalance_parity(make_engine, P.make_rebalance_case(**kw))
