@@ -373,3 +373,24 @@ JNIEXPORT jint JNICALL Java_cook_hip_Native_matchMetrics(JNIEnv* env, jclass c, 
                             BUF(uint32_t, user_matched_out), (uint32_t)n_users, BUF(int64_t, job_gpus_out), BUF(int64_t, offer_gpus_out),
                             (uint32_t)n_gpu_models);
 }
+/* the rows of the last offersRun as the offers of a match / cycle, in place on the device */
+JNIEXPORT jint JNICALL Java_cook_hip_Native_matchStageBuiltOffers(JNIEnv* env, jclass c, jlong h, jint k, jobjectArray jobs, jint n_groups,
+                                                                  jobjectArray groups, jobject reserved_hosts, jint n_reserved,
+                                                                  jint with_task_limits) {
+  cook_jobs j = jobs_of(env, k, jobs);
+  cook_groups g = groups_of(env, n_groups, groups);
+  (void)c;
+  return cook_match_stage_built_offers(H(h), &j, groups ? &g : 0, BUF(const uint32_t, reserved_hosts), (uint32_t)n_reserved, with_task_limits);
+}
+JNIEXPORT jint JNICALL Java_cook_hip_Native_cycleStageBuiltOffers(JNIEnv* env, jclass c, jlong h, jint n, jobjectArray tasks, jint n_users,
+                                                                  jobjectArray users, jint n_pending, jobjectArray pending_jobs,
+                                                                  jint n_groups, jobjectArray groups, jobject reserved_hosts,
+                                                                  jint n_reserved, jint with_task_limits) {
+  cook_tasks t = tasks_of(env, n, tasks);
+  cook_users u = users_of(env, n_users, users);
+  cook_jobs j = jobs_of(env, n_pending, pending_jobs);
+  cook_groups g = groups_of(env, n_groups, groups);
+  (void)c;
+  return cook_cycle_stage_built_offers(H(h), &t, &u, &j, groups ? &g : 0, BUF(const uint32_t, reserved_hosts), (uint32_t)n_reserved,
+                                       with_task_limits);
+}

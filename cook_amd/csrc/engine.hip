@@ -300,6 +300,10 @@ uint32_t* radix_sort_masked(cook_engine* e, const uint64_t* key, unsigned long l
   return last;
 }
 
+__global__ void fill_i32(int32_t* p, unsigned n, int32_t v) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
 __global__ void iota_u32(uint32_t* p, unsigned n) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
@@ -594,8 +598,9 @@ void rank_fetch(cook_engine* e, uint32_t* ranked, uint32_t* n_out, double* dru_o
 // =================================================================================================================
 // MATCH
 // =================================================================================================================
+// offers_dev: the pointers of `o` are DEVICE columns (the rows of cook_offers_run): used in place, nothing is copied
 void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o, const cook_groups* g,
-                        const uint32_t* reserved_hosts, uint32_t n_reserved) {
+                        const uint32_t* reserved_hosts, uint32_t n_reserved, bool offers_dev = false) {
   if (!j || !o) e->fail(COOK_E_INVALID, "cook_match_stage: null jobs/offers");
   const unsigned K = j->n, M = o->n, G = g ? g->n : 0;
   if (K && (!j->cpus || !j->mem)) e->fail(COOK_E_INVALID, "cook_match_stage: jobs need cpus and mem");
@@ -636,24 +641,24 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
   in.j_disk_req = h2d_opt(e, e->j_disk_req, j->disk_request, K);
   in.j_disk_type = h2d_opt(e, e->j_disk_type, j->disk_type, K);
   if (in.j_disk_req && !in.j_disk_type) e->fail(COOK_E_INVALID, "cook_match_stage: disk_request without disk_type");
-  in.o_cpus = h2d_opt(e, e->o_cpus, o->cpus, M);
-  in.o_mem = h2d_opt(e, e->o_mem, o->mem, M);
-  in.o_host = h2d_opt(e, e->o_host, o->host, M);
-  in.o_k8s = h2d_opt(e, e->o_k8s, o->k8s, M);
-  in.o_gpu_model = h2d_opt(e, e->o_gpu_model, o->gpu_model, M);
-  in.o_gpu_count = h2d_opt(e, e->o_gpu_count, o->gpu_count, M);
+  in.o_cpus = (offers_dev ? o->cpus : h2d_opt(e, e->o_cpus, o->cpus, M));
+  in.o_mem = (offers_dev ? o->mem : h2d_opt(e, e->o_mem, o->mem, M));
+  in.o_host = (offers_dev ? o->host : h2d_opt(e, e->o_host, o->host, M));
+  in.o_k8s = (offers_dev ? o->k8s : h2d_opt(e, e->o_k8s, o->k8s, M));
+  in.o_gpu_model = (offers_dev ? o->gpu_model : h2d_opt(e, e->o_gpu_model, o->gpu_model, M));
+  in.o_gpu_count = (offers_dev ? o->gpu_count : h2d_opt(e, e->o_gpu_count, o->gpu_count, M));
   if (in.o_gpu_model && !in.o_gpu_count) e->fail(COOK_E_INVALID, "cook_match_stage: gpu_model without gpu_count");
-  in.o_disk_type = h2d_opt(e, e->o_disk_type, o->disk_type, M);
-  in.o_disk_space = h2d_opt(e, e->o_disk_space, o->disk_space, M);
+  in.o_disk_type = (offers_dev ? o->disk_type : h2d_opt(e, e->o_disk_type, o->disk_type, M));
+  in.o_disk_space = (offers_dev ? o->disk_space : h2d_opt(e, e->o_disk_space, o->disk_space, M));
   in.n_attr = o->attr ? o->n_attr_keys : 0;
-  in.o_attr = h2d_opt(e, e->o_attr, o->attr, (size_t)M * in.n_attr);
-  in.o_max_tasks = h2d_opt(e, e->o_max_tasks, o->max_tasks, M);
-  in.o_num_tasks = h2d_opt(e, e->o_num_tasks, o->num_tasks, M);
-  in.o_location = h2d_opt(e, e->o_location, o->location, M);
-  in.o_host_start = h2d_opt(e, e->o_host_start, o->host_start_s, M);
-  in.o_run_cpus = h2d_opt(e, e->o_run_cpus, o->run_cpus, M);
-  in.o_run_mem = h2d_opt(e, e->o_run_mem, o->run_mem, M);
-  in.o_run_count = h2d_opt(e, e->o_run_count, o->run_count, M);
+  in.o_attr = (offers_dev ? o->attr : h2d_opt(e, e->o_attr, o->attr, (size_t)M * in.n_attr));
+  in.o_max_tasks = (offers_dev ? o->max_tasks : h2d_opt(e, e->o_max_tasks, o->max_tasks, M));
+  in.o_num_tasks = (offers_dev ? o->num_tasks : h2d_opt(e, e->o_num_tasks, o->num_tasks, M));
+  in.o_location = (offers_dev ? o->location : h2d_opt(e, e->o_location, o->location, M));
+  in.o_host_start = (offers_dev ? o->host_start_s : h2d_opt(e, e->o_host_start, o->host_start_s, M));
+  in.o_run_cpus = (offers_dev ? o->run_cpus : h2d_opt(e, e->o_run_cpus, o->run_cpus, M));
+  in.o_run_mem = (offers_dev ? o->run_mem : h2d_opt(e, e->o_run_mem, o->run_mem, M));
+  in.o_run_count = (offers_dev ? o->run_count : h2d_opt(e, e->o_run_count, o->run_count, M));
   if (G) {
     in.g_type = h2d_opt(e, e->g_type, g->type, G);
     in.g_attr_key = h2d_opt(e, e->g_attr_key, g->attr_key, G);
@@ -1175,6 +1180,59 @@ int cook_match_stage(cook_engine* e, const cook_jobs* j, const cook_offers* o, c
   return guarded(e, [&] {
     match_stage_inputs(e, j, o, g, reserved_hosts, n_reserved);
     e->cycle_staged = false;
+  });
+}
+namespace {
+// the rows of the last cook_offers_run as a cook_offers of device columns (offer.clj:31-76: Kubernetes leases; COOK_MAX_TASKS_PER_HOST
+// = the cluster's max pods per node, COOK_NUM_TASKS_ON_HOST = the node's pod count)
+cook_offers built_offers_view(cook_engine* e, int with_task_limits) {
+  if (!e->ofb || !e->ofb->done) e->fail(COOK_E_STATE, "built offers requested before cook_offers_run");
+  OfferBufs& b = *e->ofb;
+  const unsigned M = b.n_offers;
+  b.o_k8s.ensure(std::max(1u, M));
+  b.o_max_tasks.ensure(std::max(1u, M));
+  if (M) {
+    COOK_HIP(hipMemsetAsync(b.o_k8s.ptr(), 1, M, e->stream));
+    KL("fill_i32", fill_i32, div_up(M, 256), 256, b.o_max_tasks.ptr(), M, (int32_t)b.params.max_pods_per_node);
+  }
+  cook_offers o;
+  std::memset(&o, 0, sizeof(o));
+  o.n = M;
+  o.cpus = b.o_cpus.ptr();
+  o.mem = b.o_mem.ptr();
+  o.host = b.o_host.ptr();
+  o.k8s = b.o_k8s.ptr();
+  o.gpu_model = b.o_gpu_model.ptr();
+  o.gpu_count = b.o_gpu_count.ptr();
+  o.disk_type = b.o_disk_type.ptr();
+  o.disk_space = b.o_disk_space.ptr();
+  o.n_attr_keys = b.n_attr;
+  o.attr = b.n_attr ? b.o_attr.ptr() : nullptr;
+  if (with_task_limits) {
+    o.max_tasks = b.o_max_tasks.ptr();
+    o.num_tasks = b.o_num_pods.ptr();
+  }
+  return o;
+}
+}  // namespace
+
+int cook_match_stage_built_offers(cook_engine* e, const cook_jobs* j, const cook_groups* g, const uint32_t* reserved_hosts,
+                                  uint32_t n_reserved, int with_task_limits) {
+  return guarded(e, [&] {
+    const cook_offers o = built_offers_view(e, with_task_limits);
+    match_stage_inputs(e, j, &o, g, reserved_hosts, n_reserved, true);
+    e->cycle_staged = false;
+  });
+}
+int cook_cycle_stage_built_offers(cook_engine* e, const cook_tasks* tasks, const cook_users* users, const cook_jobs* pending_jobs,
+                                  const cook_groups* groups, const uint32_t* reserved_hosts, uint32_t n_reserved, int with_task_limits) {
+  return guarded(e, [&] {
+    const cook_offers o = built_offers_view(e, with_task_limits);
+    rank_stage(e, tasks, users);
+    if (!pending_jobs || pending_jobs->n != e->n_pending)
+      e->fail(COOK_E_INVALID, "cook_cycle_stage_built_offers: pending_jobs->n must equal the number of pending tasks");
+    match_stage_inputs(e, pending_jobs, &o, groups, reserved_hosts, n_reserved, true);
+    e->cycle_staged = true;
   });
 }
 int cook_match_run(cook_engine* e) {

@@ -28,7 +28,8 @@ struct OfferBufs {
   // output rows
   DArr<uint32_t> o_node, o_host, o_gpu_model, o_disk_type, o_attr;
   DArr<double> o_cpus, o_mem, o_gpu_count, o_disk_space;
-  DArr<int32_t> o_num_pods;
+  DArr<int32_t> o_num_pods, o_max_tasks;
+  DArr<uint8_t> o_k8s;  // the two columns every Kubernetes lease carries, filled when the rows feed a match in place
 };
 
 void offers_stage(cook_engine* e, OfferBufs& b, const cook_nodes* nodes, const cook_pods* pods, const cook_offer_params* params) {

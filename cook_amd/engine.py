@@ -26,6 +26,7 @@ EXPORTS = [
     "cook_rebalance", "cook_rebalance_stage", "cook_rebalance_run", "cook_rebalance_fetch", "cook_rebalance_timing",
     "cook_match_explain", "cook_match_metrics",
     "cook_offers_build", "cook_offers_stage", "cook_offers_run", "cook_offers_fetch", "cook_offers_timing",
+    "cook_match_stage_built_offers", "cook_cycle_stage_built_offers",
     "cook_last_timing", "cook_kernel_timings", "cook_set_profiling", "cook_match_stats",
 ]
 
@@ -337,6 +338,27 @@ class Engine:
         self.offers_stage(nodes, pods, oparams)
         self.offers_run()
         return self.offers_fetch()
+
+    def match_stage_built_offers(self, jobs: A.Jobs, groups: Optional[A.Groups] = None, reserved_hosts: Sequence[int] = (),
+                                 with_task_limits: bool = False):
+        """cook_match_stage with the rows of the last offers_run as offers, in place on the device (no host round trip)."""
+        js = jobs.as_struct()
+        gs = groups.as_struct() if groups is not None else None
+        res = np.array(list(reserved_hosts) or [0], dtype=np.uint32)
+        self._match_k = jobs.n
+        self._chk(self._lib.cook_match_stage_built_offers(self._h, C.byref(js), C.byref(gs) if gs is not None else None,
+                                                          _p(res, C.c_uint32), len(reserved_hosts), int(bool(with_task_limits))))
+
+    def cycle_stage_built_offers(self, tasks: A.Tasks, users: A.Users, pending_jobs: A.Jobs, groups: Optional[A.Groups] = None,
+                                 reserved_hosts: Sequence[int] = (), with_task_limits: bool = False):
+        """cook_cycle_stage with the rows of the last offers_run as offers, in place on the device."""
+        ts, us, js = tasks.as_struct(), users.as_struct(), pending_jobs.as_struct()
+        gs = groups.as_struct() if groups is not None else None
+        res = np.array(list(reserved_hosts) or [0], dtype=np.uint32)
+        self._rank_n, self._rank_np = tasks.n, int(tasks.pending.sum()) if tasks.n else 0
+        self._chk(self._lib.cook_cycle_stage_built_offers(self._h, C.byref(ts), C.byref(us), C.byref(js),
+                                                          C.byref(gs) if gs is not None else None, _p(res, C.c_uint32),
+                                                          len(reserved_hosts), int(bool(with_task_limits))))
 
     def offers_timing(self) -> float:
         ms = C.c_double(0)

@@ -452,6 +452,16 @@ int cook_offers_fetch(cook_engine* e, cook_node_offers* offers, uint32_t* n_offe
                       double* disk_capacity_by_type, double* disk_consumed_by_type);
 /* HIP-event time of the last cook_offers_run in milliseconds */
 int cook_offers_timing(cook_engine* e, double* ms);
+/* The rows of the engine's last cook_offers_run as the offers of a match / cycle IN PLACE (device columns, no host round trip and
+ * no copy): cpus, mem, host, compute-cluster-type = kubernetes, the gpu / disk columns and the label rows; with_task_limits != 0
+ * adds COOK_MAX_TASKS_PER_HOST = max_pods_per_node and COOK_NUM_TASKS_ON_HOST = the node's pod count (offer.clj:38-46); Fenzo's
+ * running-task view (run_*) is empty.  Otherwise exactly cook_match_stage / cook_cycle_stage.  The rows must stay untouched until
+ * the match has run: a later cook_offers_run on the same engine invalidates the staging. */
+int cook_match_stage_built_offers(cook_engine* e, const cook_jobs* considerable, const cook_groups* groups,
+                                  const uint32_t* reserved_hosts, uint32_t n_reserved, int with_task_limits);
+int cook_cycle_stage_built_offers(cook_engine* e, const cook_tasks* tasks, const cook_users* users, const cook_jobs* pending_jobs,
+                                  const cook_groups* groups, const uint32_t* reserved_hosts, uint32_t n_reserved,
+                                  int with_task_limits);
 
 /* ---- measurement hooks (bench.py): HIP-event time of the last *_run, per stage, in milliseconds ----------- */
 int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms);

@@ -484,20 +484,41 @@ def offers_edge_cases(make_engine):
 
 
 def offers_feed_match(make_engine, n_nodes=120, n_pods=700, n_jobs=300):
-    """offer rows built on the device are valid match input: placing jobs on them gives the assignments the oracle's match
-    gives on the oracle's offers"""
+    """offer rows built on the device are valid match input — through the host (BuiltOffers.as_offers) and IN PLACE
+    (cook_match_stage_built_offers / cook_cycle_stage_built_offers): both give the assignments the oracle's match gives on the
+    oracle's offers"""
     from oracle import k8s_offers
-    nodes, pods, op = synth.make_cluster_state(seed=11, n_nodes=n_nodes, n_pods=n_pods, n_attr_keys=8, fractional=False)
-    pool = synth.make_pool(seed=12, n_pending=n_jobs, n_running=0, n_users=30, n_offers=10, gpus=True)
+    nodes, pods, op = synth.make_cluster_state(seed=11, n_nodes=n_nodes, n_pods=n_pods, n_attr_keys=8, fractional=False, max_pods=12)
+    pool = synth.make_pool(seed=12, n_pending=n_jobs, n_running=n_jobs // 3, n_users=30, n_offers=10, gpus=True)
+    pend = pool.pending_jobs
     p = A.default_params(good_enough_fitness=1.0)
     with make_engine(p) as e:
         built = e.offers_build(nodes, pods, op)
-        j2o, _, head = e.match(pool.pending_jobs, built.as_offers(), None)
+        j2o, _, head = e.match(pend, built.as_offers(), None)
+        e.offers_run()
+        e.match_stage_built_offers(pend)                      # device columns in place, no task limits
+        e.match_run()
+        j2o_dev, _, head_dev = e.match_fetch()
+        e.match_stage_built_offers(pend, with_task_limits=True)  # + COOK_MAX_TASKS_PER_HOST / COOK_NUM_TASKS_ON_HOST
+        e.match_run()
+        j2o_lim, _, _ = e.match_fetch()
+        e.cycle_stage_built_offers(pool.tasks, pool.users, pend, None, with_task_limits=True)
+        e.cycle_run(n_jobs)
+        ranked, j2o_cyc, _ = e.cycle_fetch()
     want = k8s_offers.build_rows(nodes, pods, op)["rows"]
-    o_offers = A.Offers(cpus=want["cpus"], mem=want["mem"], host=want["host"], k8s=np.ones(len(want["cpus"]), np.uint8),
-                        gpu_model=want["gpu_model"], gpu_count=want["gpu_count"], attr=nodes.attr[want["node"]])
-    o_j2o, _, o_head = pyoracle.match(p, pool.pending_jobs, o_offers, None)
+    kw = dict(cpus=want["cpus"], mem=want["mem"], host=want["host"], k8s=np.ones(len(want["cpus"]), np.uint8),
+              gpu_model=want["gpu_model"], gpu_count=want["gpu_count"], disk_type=want["disk_type"], disk_space=want["disk_space"],
+              attr=nodes.attr[want["node"]])
+    o_j2o, _, o_head = pyoracle.match(p, pend, A.Offers(**kw), None)
     assert np.array_equal(j2o, o_j2o) and head == o_head and (j2o >= 0).sum() > n_jobs // 10
+    assert np.array_equal(j2o_dev, o_j2o) and head_dev == o_head
+    lim = A.Offers(max_tasks=np.full(len(want["cpus"]), op.max_pods_per_node, np.int32), num_tasks=want["num_pods"], **kw)
+    o_lim, _, _ = pyoracle.match(p, pend, lim, None)
+    assert np.array_equal(j2o_lim, o_lim) and not np.array_equal(o_lim, o_j2o)  # the pod limit binds somewhere
+    o_ranked, _ = pyoracle.rank(p, pool.tasks, pool.users)
+    pend_ord = np.cumsum(pool.tasks.pending) - 1
+    o_cyc, _, _ = pyoracle.match(p, pend.take(pend_ord[o_ranked]), lim, None)
+    assert np.array_equal(ranked, o_ranked) and np.array_equal(j2o_cyc, o_cyc)
 
 
 # ---- why-unscheduled summaries and match-cycle metrics (consumers of the placement's by-products) --------------------------
