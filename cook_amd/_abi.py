@@ -739,3 +739,19 @@ class CookCycleMetrics(C.Structure):
     _fields_ = [("considerable", C.c_uint32), ("matched", C.c_uint32), ("unmatched", C.c_uint32),
                 ("offers", C.c_uint32), ("offers_scheduled", C.c_uint32), ("head_matched", C.c_uint32),
                 ("reserved", C.c_uint32 * 2), ("jobs", CookResourceStats), ("offer_stats", CookResourceStats)]
+
+
+CONSTRAINT_MESSAGES = {  # unscheduled.clj:71-75 constraint-name->message
+    "novel_host_constraint": "Job already ran on this host.",
+    "gpu_host_constraint": "Host has no GPU support.",
+    "non_gpu_host_constraint": "Host is reserved for jobs that need GPU support.",
+    "attribute-equals-host-placement-group-constraint": "Host had a different attribute than other jobs in the group.",
+}
+
+
+def why_reasons(summary: dict) -> list:
+    """unscheduled/fenzo-failures-for-user (unscheduled.clj:77-93): the summary map -> [{:reason .. :host_count ..} ...],
+    resources first, then constraints (unknown constraint names are shown as they are)."""
+    out = [dict(reason=f"Not enough {k} available.", host_count=v) for k, v in summary.get(":resources", {}).items()]
+    out += [dict(reason=CONSTRAINT_MESSAGES.get(k, k), host_count=v) for k, v in summary.get(":constraints", {}).items()]
+    return out

@@ -279,6 +279,10 @@ def test_explain_is_the_references_map():
     row[[0, 1, 8]] = (8, 14, 3)
     assert A.why_summary(row) == {":constraints": {"novel_host_constraint": 3}, ":resources": {"mem": 14, "cpus": 8}}
     assert A.why_summary(np.zeros(A.WHY_SLOTS, np.uint32)) == {}
+    # ... and what the user sees (test/cook/test/unscheduled.clj:66-72; the vector lists mem before cpus)
+    shown = A.why_reasons({":resources": {"mem": 14, "cpus": 8}, ":constraints": {"novel_host_constraint": 3}})
+    assert shown == [dict(reason="Not enough mem available.", host_count=14), dict(reason="Not enough cpus available.", host_count=8),
+                     dict(reason="Job already ran on this host.", host_count=3)]
 
 
 def test_metrics_parity(make_engine):
