@@ -61,7 +61,8 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
-                assert "pyoracle" not in txt and "libcookoracle" not in txt and "cook_oracle" not in txt, f
+                assert "pyoracle" not in txt and "libcookoracle" not in txt and "cook_oracle" not in txt and "k8s_offers" not in txt, f
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f  # no module of oracle/ at all
 
 
 def test_jni_shim_typechecks_against_header():
