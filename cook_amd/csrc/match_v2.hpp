@@ -32,7 +32,10 @@
 #define COOK_MV_L 8
 #endif
 constexpr int MV_L = COOK_MV_L;            // candidate list length per job (-DCOOK_MV_L=n builds a variant for tuning runs)
-constexpr int MV_LG = 4;                   // good-enough list length per job
+#ifndef COOK_MV_LG
+#define COOK_MV_LG 4
+#endif
+constexpr int MV_LG = COOK_MV_LG;          // good-enough list length per job
 #ifndef COOK_MV_OCW
 #define COOK_MV_OCW 32
 #endif
@@ -54,7 +57,11 @@ constexpr int MV_RTHREADS = COOK_MV_RTHREADS;  // threads of the resolve workgro
                                                // per C4 pool), wave 0 walks.  resolve_round strides by blockDim.x, so the persistent
                                                // kernel may run it with its own (eval-tile) block shape.
 constexpr int MV_RWAVES_MAX = (MV_RTHREADS > COOK_WAVE * MV_EW ? MV_RTHREADS : COOK_WAVE * MV_EW) / COOK_WAVE;
-#ifdef __HIP_EMU__
+#if defined(COOK_MV_WMAX)  // a study build (rounds per match against list length / window / slot table; scripts/study_rounds.py)
+constexpr int MV_WMAX = COOK_MV_WMAX;
+constexpr int MV_S = COOK_MV_S;
+constexpr int MV_HASH = 4 * COOK_MV_S;
+#elif defined(__HIP_EMU__)
 constexpr int MV_WMAX = 128;               // jobs per round (emulator: small, so that tests run many rounds)
 constexpr int MV_S = 128;                  // distinct candidate offers staged per round
 constexpr int MV_HASH = 512;
@@ -64,8 +71,9 @@ constexpr int MV_S = 256;
 constexpr int MV_HASH = 1024;
 #endif
 constexpr int MV_JG = MV_WMAX / 64;        // job groups (waves of jobs) per window
-constexpr int MV_JSTEP = MV_S / 16;        // jobs inserted into the slot table per step ((L + LG) <= 16 entries each)
-static_assert(MV_L + MV_LG <= 16, "slot-table step sizing");
+constexpr int MV_EPJ_MAX = (MV_L + MV_LG) > 16 ? (MV_L + MV_LG) : 16;
+constexpr int MV_JSTEP = MV_S / MV_EPJ_MAX;  // jobs inserted into the slot table per step (at most MV_EPJ_MAX entries each)
+static_assert(MV_JSTEP >= 1, "slot-table step sizing");
 static_assert(MV_OCW <= COOK_WAVE, "one lane stages one offer");
 static_assert(MV_OCW == 64 || MV_OCW == 32 || MV_OCW == 16 || MV_OCW == 8, "a wave's alive bits are an aligned slice of one 64-bit word");
 
