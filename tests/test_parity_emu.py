@@ -91,7 +91,7 @@ def test_match_parity_constraints(make_engine, algo):
 @ALGOS
 def test_match_overcommitted_cluster(make_engine, algo):
     # demand >> capacity: hosts fill up, lists run out, the tail of the queue fails (fail codes must match too)
-    pool = synth.make_pool(seed=23, n_pending=500, n_running=0, n_users=10, n_offers=24)
+    pool = synth.make_pool(seed=23, n_pending=700, n_running=0, n_users=10, n_offers=48)  # more offers than a list holds
     p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
     j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, p)
     assert (j2o < 0).sum() > 100
