@@ -133,6 +133,7 @@ class Simulator:
         self.used_cpus = np.zeros(len(hosts))
         self.used_mem = np.zeros(len(hosts))
         self.count = np.zeros(len(hosts), np.int32)
+        self.offer_order = np.arange(len(hosts))[::-1].copy()  # offer index -> host id (see _offers)
         self.user_names = sorted({j["job/user"] for j in trace})  # user ids = name ranks
         self.uid = {u: i for i, u in enumerate(self.user_names)}
         self.jobs: List[_Job] = []
@@ -165,9 +166,13 @@ class Simulator:
         return t, [r[0] for r in rows]
 
     def _offers(self) -> A.Offers:
-        """what the Mesos mock offers: the unused part of every host; Fenzo's view of the tasks it placed there"""
-        return A.Offers(cpus=self.host_cpus - self.used_cpus, mem=self.host_mem - self.used_mem, host=np.arange(len(self.host_names)),
-                        run_cpus=self.used_cpus.copy(), run_mem=self.used_mem.copy(), run_count=self.count.copy())
+        """what the Mesos mock offers: the unused part of every host; Fenzo's view of the tasks it placed there.
+        Offer ORDER: the engine breaks fitness ties by the lowest offer index; the recorded run of the reference
+        (simulator_files/example-out-trace.csv: five identical hosts) resolves them towards the LAST hostname, so the offers are
+        presented in descending hostname order (`offer_order`; the host ids in the `host` column stay the name ranks)."""
+        o = self.offer_order
+        return A.Offers(cpus=(self.host_cpus - self.used_cpus)[o], mem=(self.host_mem - self.used_mem)[o], host=o.astype(np.uint32),
+                        run_cpus=self.used_cpus[o], run_mem=self.used_mem[o], run_count=self.count[o])
 
     def _jobs_soa(self, jobs: List[_Job]) -> A.Jobs:
         novel = [sorted({i["host"] for i in j.instances if i["reason"] != "preempted-by-rebalancer"}) for j in jobs]
@@ -227,6 +232,7 @@ class Simulator:
             for job, v in zip(considerable, j2o):
                 if v < 0:
                     continue
+                v = int(self.offer_order[v])  # offer index -> host id
                 job.state = "running"
                 job.instances.append(dict(task_id=self.next_task_id, instance_id=str(_uuid.UUID(int=self.next_task_id)), host=int(v),
                                           start_ms=now, end_ms=None, status="running", reason=""))

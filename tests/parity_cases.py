@@ -663,3 +663,33 @@ def offers_many_models_and_types(make_engine):
     op = A.offer_params(max_pods_per_node=64, n_gpu_models=n_models, n_disk_types=n_types)
     got = offers_parity(make_engine, nodes, pods, op, "many models / types")
     assert (got.gpu_consumed_by_model > 0).sum() > 40 and (got.disk_consumed_by_type > 0).sum() == n_types
+
+
+def check_replay_recorded(backend, max_cycles=10 ** 9):
+    """The reference's OWN recorded simulator run (tests/golden/replay_example.json <- simulator_files/example-*): the replay
+    reproduces every recorded task row — job, hostname, slave id, user, resources, status, the cycle it started in and the cycle it
+    was seen finished in (up to `max_cycles` cycles of the run)."""
+    import json
+    import math
+    import os
+    from cook_amd import replay
+    g = json.load(open(os.path.join(G.GOLDEN, "replay_example.json")))
+    sim = replay.simulate(g["trace"], g["hosts"], g["config"], backend, max_cycles)
+    step = g["config"]["cycle-step-ms"]
+    rows = {r["job_id"]: r for r in sim.rows()}
+    t0 = min(r["start_time_ms"] for r in rows.values()) if rows else 0  # cycles are counted from the first task start, as in the fixture
+    n = 0
+    for job_id, e in g["expect"].items():
+        if e["start_cycle"] >= max_cycles - 1:
+            continue
+        r = rows[job_id]
+        sc = round((r["start_time_ms"] - t0) / step)
+        assert (r["hostname"], r["slave_id"], r["user"], r["mem"], r["cpus"], sc) == \
+               (e["hostname"], e["slave_id"], e["user"], e["mem"], e["cpus"], e["start_cycle"]), (job_id, r, e)
+        if max_cycles >= 10 ** 9:
+            ec = math.ceil((r["end_time_ms"] - t0) / step) if r["end_time_ms"] != "" else None
+            assert (r["status"], ec) == (e["status"], e["end_cycle"]), (job_id, r, e)
+        n += 1
+    if max_cycles >= 10 ** 9:
+        assert n == len(g["expect"]) == len(rows) == 115
+    return n

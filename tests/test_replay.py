@@ -75,6 +75,25 @@ def test_replay_reference_example_trace(emu_engine):
     P.replay_parity(emu_engine, trace, hosts, CONFIG, max_cycles=12)  # and its first cycles through the (emulated) engine
 
 
+def test_replay_reproduces_the_recorded_reference_run():
+    """every task row of the reference's recorded example-out-trace.csv (real Clojure scheduler + real Fenzo), oracle-driven"""
+    assert P.check_replay_recorded(P.OracleBackend()) == 115
+
+
+def test_replay_recorded_run_through_the_emulated_engine(emu_engine):
+    with emu_engine(A.default_params()) as e:
+        assert P.check_replay_recorded(replay.EngineBackend(e), max_cycles=16) >= 5  # the first cycles only (the emulator is slow)
+
+
+@pytest.mark.gpu
+def test_replay_recorded_run_gpu():
+    """... and through libcookmatch.so on the MI355X: all 243 cycles, all 115 recorded rows"""
+    from cook_amd import build
+    from cook_amd.engine import Engine
+    with Engine(A.default_params(), lib_path=build.build()) as e:
+        assert P.check_replay_recorded(replay.EngineBackend(e)) == 115
+
+
 @pytest.mark.gpu
 def test_replay_parity_gpu():
     from cook_amd import build
