@@ -10,6 +10,61 @@ State& S() { return g_state; }
 
 static const size_t kStack = 256 * 1024;
 
+#ifdef EMU_FAST_SWITCH
+// save the callee-saved registers on the current stack, publish its pointer, adopt the other stack, restore, return into it
+extern "C" void emu_switch(void** from_sp, void* to_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch, .-emu_switch
+)");
+static void fiber_entry();
+extern "C" void emu_fiber_start() {  // first activation of a fiber: never returns (fiber_entry ends with a switch to main)
+  fiber_entry();
+  std::abort();
+}
+static inline void to_main(Fiber* f, State& s) { emu_switch(&f->sp, s.main_sp); }
+static inline void to_fiber(State& s, Fiber& f) { emu_switch(&s.main_sp, f.sp); }
+static inline void prepare(Fiber& f) {
+  // stack image emu_switch pops: r15 r14 r13 r12 rbx rbp, then the return address; at the entry of emu_fiber_start the stack
+  // pointer must be 8 below a 16-byte boundary, as after a call
+  uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+  void** sp = (void**)(top - 64);
+  for (int i = 0; i < 6; ++i) sp[i] = nullptr;
+  sp[6] = (void*)&emu_fiber_start;
+  sp[7] = nullptr;
+  f.sp = sp;
+}
+#else
+static void fiber_entry();
+static inline void to_main(Fiber* f, State& s) { swapcontext(&f->ctx, &s.main_ctx); }
+static inline void to_fiber(State& s, Fiber& f) { swapcontext(&s.main_ctx, &f.ctx); }
+static inline void prepare(Fiber& f) {
+  getcontext(&f.ctx);
+  f.ctx.uc_stack.ss_sp = f.stack;
+  f.ctx.uc_stack.ss_size = kStack;
+  f.ctx.uc_link = nullptr;
+  makecontext(&f.ctx, fiber_entry, 0);
+}
+#endif
+
 static void fiber_entry() {
   State& s = S();
   Fiber* f = s.cur;
@@ -34,7 +89,7 @@ static void fiber_entry() {
       ++s.events;
     }
   }
-  swapcontext(&f->ctx, &s.main_ctx);
+  to_main(f, s);
 }
 
 void arrive(Group& g) {
@@ -48,7 +103,7 @@ void arrive(Group& g) {
     return;
   }
   while (g.gen == my) {
-    swapcontext(&f->ctx, &s.main_ctx);
+    to_main(f, s);
     s.cur = f;
   }
 }
@@ -84,11 +139,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
           f.site = "";
           f.tid = t;
           f.tidx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-          getcontext(&f.ctx);
-          f.ctx.uc_stack.ss_sp = f.stack;
-          f.ctx.uc_stack.ss_size = kStack;
-          f.ctx.uc_link = nullptr;
-          makecontext(&f.ctx, fiber_entry, 0);
+          prepare(f);
         }
         unsigned remaining = nthreads;
         unsigned spins = 0;
@@ -98,7 +149,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             Fiber& f = s.fibers[t];
             if (f.done) continue;
             s.cur = &f;
-            swapcontext(&s.main_ctx, &f.ctx);
+            to_fiber(s, f);
             if (f.done) --remaining;
           }
           // deadlock guard: every live fiber is parked and no rendezvous can complete

@@ -60,8 +60,15 @@ struct Group {
   unsigned size = 0, count = 0;
   uint64_t gen = 0;
 };
+// Context switches: glibc's swapcontext saves and restores the signal mask = two system calls per switch, and the emulator
+// switches at every rendezvous of every thread.  On x86-64 a fiber is just a saved stack pointer (callee-saved registers on its
+// stack, emu.cpp); elsewhere ucontext.
+#if defined(__x86_64__)
+#define EMU_FAST_SWITCH 1
+#endif
 struct Fiber {
   ucontext_t ctx;
+  void* sp = nullptr;  // EMU_FAST_SWITCH: the fiber's saved stack pointer
   char* stack = nullptr;
   bool done = true;
   unsigned tid = 0;
@@ -70,6 +77,7 @@ struct Fiber {
 };
 struct State {
   ucontext_t main_ctx;
+  void* main_sp = nullptr;
   std::vector<Fiber> fibers;
   Fiber* cur = nullptr;
   dim3 blockIdx_, blockDim_, gridDim_;
