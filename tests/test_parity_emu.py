@@ -76,7 +76,7 @@ ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4], ids=["default", "serial", 
 @ALGOS
 @pytest.mark.parametrize("ge", [1.0, 0.8, 0.5])
 def test_match_parity_random(make_engine, ge, algo):
-    pool = synth.make_pool(seed=21, n_pending=260, n_running=100, n_users=20, n_offers=200)
+    pool = synth.make_pool(seed=21, n_pending=400, n_running=100, n_users=20, n_offers=300)
     P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, A.default_params(good_enough_fitness=ge, match_algo=algo))
 
 
@@ -163,8 +163,8 @@ def test_rebalance_golden(make_engine):
     dict(seed=54, n_running=500, n_pending=40, n_users=15, n_hosts=40, constraints=True, gpus=True),
     dict(seed=55, n_running=300, n_pending=20, n_users=8, n_hosts=25, dru_mode=1),
     dict(seed=56, n_running=0, n_pending=10, n_users=3, n_hosts=8, spare_frac=1.0),                # spare resources only
-    dict(seed=57, n_running=2400, n_pending=8, n_users=2, n_hosts=60),                             # users of several re-scoring tiles
-    dict(seed=58, n_running=2200, n_pending=6, n_users=2, n_hosts=60, fractional=True),            # ... redone sequentially
+    dict(seed=57, n_running=3600, n_pending=10, n_users=2, n_hosts=90),                            # users of several re-scoring tiles
+    dict(seed=58, n_running=2600, n_pending=8, n_users=2, n_hosts=70, fractional=True),            # ... redone sequentially
 ], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
 def test_rebalance_parity_random(make_engine, kw):
     P.rebalance_parity(make_engine, P.make_rebalance_case(**kw))
@@ -260,7 +260,7 @@ def _group_case():
 @pytest.mark.parametrize("algo", [0, 1], ids=["default", "serial"])
 def test_explain_parity(make_engine, algo):
     p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
-    pool = synth.make_pool(seed=22, n_pending=300, n_running=100, n_users=20, n_offers=100, gpus=True, constraints=True)
+    pool = synth.make_pool(seed=22, n_pending=400, n_running=100, n_users=20, n_offers=120, gpus=True, constraints=True)
     pos, counts = P.explain_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, reserved=(3, 7, 90), tag="constraints")
     assert counts[:, 0].any() and counts[:, 7].any()  # resources and the gpu-host constraint both occur
     pool = synth.make_pool(seed=23, n_pending=500, n_running=0, n_users=10, n_offers=24)
@@ -290,7 +290,7 @@ def test_metrics_parity(make_engine):
     pool = synth.make_pool(seed=24, n_pending=700, n_running=0, n_users=25, n_offers=90, gpus=True, constraints=True)
     m = P.metrics_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, n_users=25, tag="integers")
     assert 0 < m["matched"] < 700
-    pool = synth.make_pool(seed=25, n_pending=2200, n_running=0, n_users=40, n_offers=40, fractional=True)
+    pool = synth.make_pool(seed=25, n_pending=3000, n_running=0, n_users=40, n_offers=150, fractional=True)
     pool.pending_jobs.cpus[:] = pool.pending_jobs.cpus + 0.1    # non-dyadic: the totals need the in-order fold
     P.metrics_parity(make_engine, pool.pending_jobs, pool.offers, None, p, n_users=40, tag="fractional")
     # nothing considered / nothing offered

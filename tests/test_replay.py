@@ -47,7 +47,7 @@ def test_replay_oracle_is_deterministic_and_conserves_resources():
 
 
 def test_replay_parity_emulated(emu_engine, tmp_path):
-    trace, hosts = P.make_trace(2, 40, 3, span_ms=500_000)
+    trace, hosts = P.make_trace(2, 120, 4)
     sim = P.replay_parity(emu_engine, trace, hosts, CONFIG)
     out = tmp_path / "out-trace.csv"
     sim.write_csv(str(out))
@@ -56,23 +56,26 @@ def test_replay_parity_emulated(emu_engine, tmp_path):
 
 
 def test_replay_parity_emulated_with_preemption(emu_engine):
-    trace, hosts = P.make_trace(3, 60, 2, span_ms=360_000)
+    trace, hosts = P.make_trace(3, 160, 3, span_ms=1_200_000)
     P.replay_parity(emu_engine, trace, hosts, TIGHT, min_preempted=1)
 
 
-def test_replay_reference_example_trace(emu_engine):
-    """the reference's own example inputs, when the checkout is present (this container only; never on the GPU box)"""
+def test_replay_fixture_is_the_reference_checkout():
+    """tests/golden/replay_example.json == what tests/golden/make_replay_golden.py derives from the reference's files now
+    (this container only; the GPU box has no checkout and uses the committed fixture)"""
     base = "/root/reference/scheduler/simulator_files"
-    if not os.path.exists(os.path.join(base, "example-trace.json")):
+    if not os.path.exists(os.path.join(base, "example-out-trace.csv")):
         pytest.skip("reference checkout not present")
+    import csv
+    import json
+    from tests import golden_util as G
+    fx = json.load(open(os.path.join(G.GOLDEN, "replay_example.json")))
     trace = replay.load_trace(os.path.join(base, "example-trace.json"))
-    hosts = replay.load_hosts(os.path.join(base, "example-hosts.json"))
-    full = replay.simulate(trace, hosts, CONFIG, P.OracleBackend())  # the whole trace through the oracle-driven loop
-    assert len(full.jobs) == 119 and len(full.host_names) == 5 and sum(r["matched"] for r in full.log) >= 100
-    # 115 task instances start before the loop ends; the recorded example-out-trace.csv of the reference also holds 115 task
-    # rows (its job uuids differ from example-trace.json's, so the two cannot be compared row by row)
-    assert len(full.rows()) == 115 and full.cycles == 243
-    P.replay_parity(emu_engine, trace, hosts, CONFIG, max_cycles=12)  # and its first cycles through the (emulated) engine
+    assert [j["job/uuid"] for j in fx["trace"]] == [j["job/uuid"] for j in trace] and len(trace) == 119
+    assert [j["submit-time-ms"] for j in fx["trace"]] == [j["submit-time-ms"] for j in trace]
+    rows = list(csv.DictReader(open(os.path.join(base, "example-out-trace.csv"))))
+    assert len(rows) == 115 and {r["job_id"] for r in rows} == set(fx["expect"])
+    assert all(fx["expect"][r["job_id"]]["hostname"] == r["hostname"] and fx["expect"][r["job_id"]]["status"] == r["status"] for r in rows)
 
 
 def test_replay_reproduces_the_recorded_reference_run():
@@ -82,7 +85,7 @@ def test_replay_reproduces_the_recorded_reference_run():
 
 def test_replay_recorded_run_through_the_emulated_engine(emu_engine):
     with emu_engine(A.default_params()) as e:
-        assert P.check_replay_recorded(replay.EngineBackend(e), max_cycles=16) >= 5  # the first cycles only (the emulator is slow)
+        assert P.check_replay_recorded(replay.EngineBackend(e)) == 115  # all 243 cycles, all 115 recorded rows
 
 
 @pytest.mark.gpu
