@@ -27,7 +27,7 @@ struct RebalBufs {
   DArr<double> dru;
   // hosts
   DArr<uint64_t> hkey;
-  DArr<uint32_t> hpermA, hpermB, hstart, hend, h_pb, h_user, hidx, chg, chg_tile, chg_bad, chg_mark;
+  DArr<uint32_t> hpermA, hpermB, hstart, hend, hbase, h_pb, h_user, hidx, chg, chg_tile, chg_bad, chg_mark;
   DArr<SumU4> tile_agg, tile_carry;
   DArr<uint32_t> x_before, x_cnt;
   DArr<double> h_cpus, h_mem, h_gpus, h_dru;
@@ -292,6 +292,7 @@ RebalIn rebalance_args(cook_engine* e, RebalBufs& b) {
   in.pending_dru = b.pending_dru.ptr();
   in.ctl = b.ctl.ptr();
   in.job = b.jobctx.ptr();
+  in.hbase = b.hbase.ptr();
   in.h_pb = b.h_pb.ptr(), in.h_user = b.h_user.ptr();
   in.h_cpus = b.h_cpus.ptr(), in.h_mem = b.h_mem.ptr(), in.h_gpus = b.h_gpus.ptr();
   in.h_dru = b.h_dru.ptr();
@@ -412,6 +413,11 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
     b.hperm = radix_sort_masked(e, b.hkey.ptr(), hmask, b.hpermA.ptr(), b.hpermA.ptr(), b.hpermB.ptr(), R);
     KL("rebal_host_bounds", rebal_host_bounds, gR, 256, (const uint32_t*)b.hperm, (const uint32_t*)b.host.ptr(), R, b.hstart.ptr(),
        b.hend.ptr());
+  }
+  b.hbase.ensure(std::max(1u, H));
+  if (H) {
+    KL("rebal_host_sizes", rebal_host_sizes, div_up(H, 256), 256, (const uint32_t*)b.hstart.ptr(), (const uint32_t*)b.hend.ptr(), H, b.hbase.ptr());
+    KL("rebal_hbase_scan", excl_scan_u32_single, 1, SCAN1_THREADS, b.hbase.ptr(), H, (uint32_t*)nullptr);
   }
   // host-ordered mirrors of the running slots' columns (static ones now, the DRUs after the first scoring)
   b.h_pb.ensure(std::max(1u, R)), b.h_user.ensure(std::max(1u, R));

@@ -72,6 +72,7 @@ struct RebalIn {
   // hosts
   const uint32_t* hperm;          // [R] running slots grouped by host
   const uint32_t *hstart, *hend;  // [H]
+  const uint32_t* hbase;          // [H] running tasks on the hosts before this one (exclusive scan of the hosts' sizes)
   // the running slots' columns mirrored in HOST order (index = position in hperm): rebal_decide streams a host's tasks
   // instead of chasing slot -> position-in-user-order -> value through three dependent random loads
   const uint32_t *h_pb, *h_user;  // position in per-user order (static), user (static)
@@ -238,6 +239,11 @@ __global__ void __launch_bounds__(256) rebal_invert_perm(const uint32_t* __restr
 __global__ void __launch_bounds__(256) rebal_host_keys(const uint32_t* __restrict__ host, unsigned n, uint64_t* __restrict__ key) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) key[i] = host[i];
+}
+__global__ void __launch_bounds__(256) rebal_host_sizes(const uint32_t* __restrict__ hstart, const uint32_t* __restrict__ hend, unsigned H,
+                                                        uint32_t* __restrict__ size) {
+  const unsigned h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h < H) size[h] = hend[h] - hstart[h];
 }
 __global__ void __launch_bounds__(256) rebal_host_bounds(const uint32_t* __restrict__ hperm, const uint32_t* __restrict__ host,
                                                          unsigned n, uint32_t* __restrict__ hstart, uint32_t* __restrict__ hend) {
@@ -612,7 +618,9 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) 
   const bool sp = in.has_spare[h] != 0;
   if (lane == 0) in.hres_key[h] = 0ull;
   if (n == 0 && !sp) return;
-  const unsigned base = hs + xs;
+  // the host's region of the scratch arrays starts after the running tasks of the hosts before it and the jobs placed on them.
+  // (hstart is only meaningful for hosts that HAVE running tasks: an empty host's 0 made its region collide with another host's.)
+  const unsigned base = in.hbase[h] + xs;
   const bool big = n > (unsigned)RB_CAP;
   double *c_dru = big ? in.gs_dru + base : l_dru[w], *c_cpus = big ? in.gs_cpus + base : l_cpus[w];
   double *c_mem = big ? in.gs_mem + base : l_mem[w], *c_gpus = big ? in.gs_gpus + base : l_gpus[w];

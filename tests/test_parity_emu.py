@@ -162,7 +162,8 @@ def test_rebalance_golden(make_engine):
     dict(seed=53, n_running=600, n_pending=30, n_users=20, n_hosts=3, max_preemption=12),          # hosts beyond the LDS cap
     dict(seed=54, n_running=500, n_pending=40, n_users=15, n_hosts=40, constraints=True, gpus=True),
     dict(seed=55, n_running=300, n_pending=20, n_users=8, n_hosts=25, dru_mode=1),
-    dict(seed=56, n_running=0, n_pending=10, n_users=3, n_hosts=8, spare_frac=1.0),                # spare resources only
+    dict(seed=56, n_running=0, n_pending=10, n_users=3, n_hosts=8, spare_frac=1.0),
+    dict(seed=707730441, n_running=2, n_pending=29, n_users=9, n_hosts=23, fractional=True, gpus=True, spare_frac=1.0),  # hosts without running tasks that take placed jobs (found by the fuzz sweep)                # spare resources only
     dict(seed=57, n_running=3600, n_pending=10, n_users=2, n_hosts=90),                            # users of several re-scoring tiles
     dict(seed=58, n_running=2600, n_pending=8, n_users=2, n_hosts=70, fractional=True),            # ... redone sequentially
 ], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
@@ -327,3 +328,45 @@ def test_new_entry_points_fail_loudly(make_engine):
 
 def test_offers_many_models_and_types(make_engine):
     P.offers_many_models_and_types(make_engine)
+
+
+def test_fuzz_rank_cycle_match_explain(make_engine):
+    """seeded sweep over small random configurations (sizes, gpus / constraints / fractional / tie-heavy / no-shares inputs,
+    quotas, good-enough 1.0-0.3, every match_algo, reserved hosts): rank, cycle, match and explain against the oracle"""
+    rng = np.random.default_rng(20260923)
+    for _ in range(24):
+        kw = dict(seed=int(rng.integers(1, 1 << 30)), n_pending=int(rng.integers(1, 300)), n_running=int(rng.integers(0, 150)),
+                  n_users=int(rng.integers(1, 30)), n_offers=int(rng.integers(1, 100)), gpus=bool(rng.integers(0, 2)),
+                  constraints=bool(rng.integers(0, 2)), fractional=bool(rng.integers(0, 2)), tie_heavy=bool(rng.integers(0, 2)),
+                  no_shares=bool(rng.integers(0, 4) == 0), quota_frac=float(rng.choice([0.0, 0.02, 0.5])))
+        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5, 0.3])), match_algo=int(rng.choice([0, 1, 3, 4])),
+                             max_over_quota_jobs=int(rng.choice([0, 3, 100])))
+        pool = synth.make_pool(**kw)
+        P.rank_parity(make_engine, pool, p)
+        P.cycle_parity(make_engine, pool, p, int(rng.integers(1, kw["n_pending"] + 1)))
+        reserved = tuple(int(x) for x in rng.integers(0, kw["n_offers"], int(rng.integers(0, 3))))
+        j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, reserved=reserved)
+        if (j2o < 0).any():
+            P.explain_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, max_pos=6, tag=str(kw))
+
+
+def test_fuzz_offers_considerable_rebalance(make_engine):
+    """seeded sweep over small random configurations of the other entry points (this sweep found the scratch-region collision of
+    hosts without running tasks in the rebalancer)"""
+    rng = np.random.default_rng(20260924)
+    for _ in range(20):
+        seed = int(rng.integers(1, 1 << 30))
+        nodes, pods, op = synth.make_cluster_state(seed=seed, n_nodes=int(rng.integers(1, 300)), n_pods=int(rng.integers(0, 2000)),
+                                                   gpus=bool(rng.integers(0, 2)), disk=bool(rng.integers(0, 2)),
+                                                   fractional=bool(rng.integers(0, 2)), n_attr_keys=int(rng.choice([0, 3, 8])),
+                                                   max_pods=int(rng.choice([4, 16, 110])), corrupt=float(rng.choice([0.0, 0.05])))
+        P.offers_parity(make_engine, nodes, pods, op, f"offers {seed}")
+        n = int(rng.integers(1, 1000))
+        q, st = P.make_considerable_case(seed, n, int(rng.integers(1, 50)), fractional=bool(rng.integers(0, 2)),
+                                         tokens=bool(rng.integers(0, 2)), enforce=bool(rng.integers(0, 2)),
+                                         pool_quota=bool(rng.integers(0, 2)), eligible=bool(rng.integers(0, 2)))
+        P.considerable_parity(make_engine, q, st, int(rng.integers(0, n + 5)))
+        P.rebalance_parity(make_engine, P.make_rebalance_case(
+            seed=seed, n_running=int(rng.integers(0, 500)), n_pending=int(rng.integers(1, 30)), n_users=int(rng.integers(1, 20)),
+            n_hosts=int(rng.integers(1, 60)), fractional=bool(rng.integers(0, 2)), constraints=bool(rng.integers(0, 2)),
+            gpus=bool(rng.integers(0, 2)), dru_mode=int(rng.integers(0, 2)), spare_frac=float(rng.choice([0.0, 0.2, 1.0]))))

@@ -194,6 +194,7 @@ def test_rebalance_golden(make_engine):
     dict(seed=54, n_running=5000, n_pending=128, n_users=60, n_hosts=400, constraints=True, gpus=True, max_preemption=128),
     dict(seed=55, n_running=3000, n_pending=40, n_users=20, n_hosts=250, dru_mode=1),
     dict(seed=56, n_running=0, n_pending=10, n_users=3, n_hosts=8, spare_frac=1.0),
+    dict(seed=707730441, n_running=2, n_pending=29, n_users=9, n_hosts=23, fractional=True, gpus=True, spare_frac=1.0),  # hosts without running tasks that take placed jobs (found by the fuzz sweep)
     dict(seed=57, n_running=60000, n_pending=32, n_users=500, n_hosts=3000, max_preemption=32),  # multi-block scans / sorts
     dict(seed=58, n_running=30000, n_pending=16, n_users=4, n_hosts=900, fractional=True),       # heavy users: many re-scoring tiles, redone sequentially
 ], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
