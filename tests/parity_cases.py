@@ -630,7 +630,7 @@ def make_trace(seed, n_jobs, n_hosts, n_users=5, span_ms=3_600_000, fail_frac=0.
     return trace, hosts
 
 
-def replay_parity(make_engine, trace, hosts, config, min_preempted=0, max_cycles=10 ** 9):
+def replay_parity(make_engine, trace, hosts, config, min_preempted=0, max_cycles=10 ** 9, min_matched=None):
     from cook_amd import replay
     with make_engine(A.default_params()) as e:
         got = replay.simulate(trace, hosts, config, replay.EngineBackend(e), max_cycles)
@@ -638,7 +638,7 @@ def replay_parity(make_engine, trace, hosts, config, min_preempted=0, max_cycles
     assert got.cycles == want.cycles and got.log == want.log, [(a, b) for a, b in zip(got.log, want.log) if a != b][:3]
     rg, rw = got.rows(), want.rows()
     assert rg == rw, next((a, b) for a, b in zip(rg, rw) if a != b)
-    assert sum(r["matched"] for r in got.log) >= min(len(trace) // 2, 10)
+    assert sum(r["matched"] for r in got.log) >= (min(len(trace) // 2, 10) if min_matched is None else min_matched)
     assert sum(r["preempted"] for r in got.log) >= min_preempted
     assert set(rg[0].keys()) == set(replay.CSV_HEADERS)
     return got

@@ -370,3 +370,40 @@ def test_fuzz_offers_considerable_rebalance(make_engine):
             seed=seed, n_running=int(rng.integers(0, 500)), n_pending=int(rng.integers(1, 30)), n_users=int(rng.integers(1, 20)),
             n_hosts=int(rng.integers(1, 60)), fractional=bool(rng.integers(0, 2)), constraints=bool(rng.integers(0, 2)),
             gpus=bool(rng.integers(0, 2)), dru_mode=int(rng.integers(0, 2)), spare_frac=float(rng.choice([0.0, 0.2, 1.0]))))
+
+
+def test_fuzz_groups_constraints_metrics_replay(make_engine):
+    """seeded sweep: random group tables (unique / balanced / attribute-equals with running cotasks, task limits), constraints beyond
+    the fast paths, metrics, and the replay loop over random traces — engine vs oracle"""
+    from tests.test_replay import CONFIG, TIGHT
+    rng = np.random.default_rng(20260925)
+    for _ in range(10):
+        seed = int(rng.integers(1, 1 << 30))
+        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5])), match_algo=int(rng.choice([0, 1, 3, 4])))
+        n, m = int(rng.integers(5, 200)), int(rng.integers(3, 60))
+        attr = np.zeros((m, 2), dtype=np.uint32)
+        attr[:, 0] = rng.integers(1, 4, m)
+        attr[:, 1] = rng.integers(0, 3, m)
+        offers = A.Offers(cpus=rng.integers(2, 12, m).astype(float), mem=rng.integers(2, 20, m) * 1000.0, attr=attr, k8s=np.ones(m, dtype=np.uint8),
+                          max_tasks=np.full(m, int(rng.integers(2, 8)), np.int32), num_tasks=rng.integers(0, 4, m).astype(np.int32))
+        group = rng.integers(0, 6, n).astype(np.uint32)
+        group[rng.random(n) < 0.3] = A.NONE_U32
+        jobs = A.Jobs(cpus=rng.integers(1, 4, n).astype(float), mem=rng.integers(1, 4, n) * 1000.0, group=group)
+        keys = [A.NONE_U32, 0, A.NONE_U32, 1, 0, 0]
+        rh = [[int(x) for x in rng.integers(0, m, int(rng.integers(0, 3)))] for _ in range(6)]
+        ra = [[int(attr[h, k]) if k != A.NONE_U32 else 0 for h in hs] for hs, k in zip(rh, keys)]
+        groups = A.Groups(type=np.array([1, 2, 2, 3, 3, 0], dtype=np.uint8), attr_key=np.array(keys, dtype=np.uint32),
+                          minimum=np.array([0, int(rng.integers(0, 5)), 10, 0, 0, 0], dtype=np.int32), run_hosts=rh, run_attrs=ra)
+        j2o = P.match_parity(make_engine, jobs, offers, groups, p)
+        if (j2o < 0).any():
+            P.explain_parity(make_engine, jobs, offers, groups, p, max_pos=5, tag=f"groups {seed}")
+        jobs, offers, groups = P.slow_constraint_case(seed, int(rng.integers(5, 250)), int(rng.integers(12, 80)))
+        j2o = P.match_parity(make_engine, jobs, offers, groups, p)
+        if (j2o < 0).any():
+            P.explain_parity(make_engine, jobs, offers, groups, p, max_pos=5, tag=f"slow {seed}")
+        pool = synth.make_pool(seed=seed, n_pending=int(rng.integers(1, 500)), n_running=0, n_users=int(rng.integers(1, 30)),
+                               n_offers=int(rng.integers(1, 90)), gpus=bool(rng.integers(0, 2)), constraints=bool(rng.integers(0, 2)),
+                               fractional=bool(rng.integers(0, 2)))
+        P.metrics_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, A.default_params(good_enough_fitness=1.0), n_users=30)
+        trace, hosts = P.make_trace(seed, int(rng.integers(5, 60)), int(rng.integers(1, 5)), span_ms=int(rng.integers(60_000, 600_000)))
+        P.replay_parity(make_engine, trace, hosts, TIGHT if rng.integers(0, 2) else CONFIG, min_matched=0)
