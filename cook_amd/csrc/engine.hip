@@ -1518,6 +1518,15 @@ int cook_match_stats(cook_engine* e, uint32_t out[16]) {
   out[15] = (uint32_t)(c.t_merge / 100ull);
   return COOK_OK;
 }
+#ifdef __HIP_EMU__
+// emulated build only (design studies): the walk statistics of match_v2.hpp, cumulative; reset != 0 clears them afterwards
+int cook_emu_walk_stats(unsigned long long out[8], int reset) {
+  for (int i = 0; i < 8; ++i) out[i] = g_walk_stats[i];
+  if (reset)
+    for (int i = 0; i < 8; ++i) g_walk_stats[i] = 0;
+  return COOK_OK;
+}
+#endif
 int cook_set_profiling(cook_engine* e, int enabled) {
   if (!e) return COOK_E_INVALID;
   e->profiling = enabled != 0;

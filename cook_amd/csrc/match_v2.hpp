@@ -690,6 +690,17 @@ static __device__ __attribute__((noinline)) bool group_pass_dev(const MatchIn* i
   return group_pass(*in, st, jj, v);
 }
 
+#ifdef __HIP_EMU__
+// walk statistics of the emulated build (design studies, scripts/study_rounds.py): [0] jobs walked, [1] settled by the shortcut
+// (no candidate under S), [2] went through the exact path, [3] won by an offer touched earlier in the round, [4] won by an
+// untouched offer (a new touched lane), [5] walked and unmatched, [6] sum of touched lanes at decision time, [7] sum of the list
+// position that settled the job
+inline unsigned long long g_walk_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define WALK_STAT(i, v) do { if (lane == 0) g_walk_stats[i] += (v); } while (0)
+#else
+#define WALK_STAT(i, v) ((void)0)
+#endif
+
 struct ResolveLds {
   JobL job[MV_WMAX];
   EntL ent[MV_WMAX][MV_L];
@@ -1080,7 +1091,12 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       // No feasible offer under S, no zero-fitness offer, no constrained group: placements only take capacity away and the
       // job's constraints can only get worse on a touched offer, so it stays unmatched whatever happened in this round;
       // only its failure summary may change (handled below from the touched offers' current verdicts).
-      if (nc == 0 && !grouped && cur.no_zero_fit) break;
+      WALK_STAT(0, 1);
+      WALK_STAT(6, nT);
+      if (nc == 0 && !grouped && cur.no_zero_fit) {
+        WALK_STAT(1, 1);
+        break;
+      }
       // --- arg-max path: first list entry that is untouched, or touched and still a candidate -------------------------------
       // (a touched offer that is still feasible only gained fitness, so it dominates every untouched offer behind it; a
       //  zero-fitness verdict cannot appear on an offer that was feasible under S)
@@ -1124,6 +1140,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         }
       }
       if (need_exact) {
+        WALK_STAT(2, 1);
         if (t_on) {
           pe_bits = 0u;
           if (!res_ok) {
@@ -1314,6 +1331,9 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       }  // if constexpr (REEVAL)
     }
     // --- commit --------------------------------------------------------------------------------------------------------------
+    if (win_lane >= 0) WALK_STAT(3, 1);
+    else if (win >= 0) WALK_STAT(4, 1);
+    else WALK_STAT(5, 1);
     if (win_lane >= 0) {  // an offer touched earlier in this round takes the job
       if ((int)lane == win_lane) {
         t_ac += c;
