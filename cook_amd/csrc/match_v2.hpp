@@ -693,9 +693,10 @@ static __device__ __attribute__((noinline)) bool group_pass_dev(const MatchIn* i
 #ifdef __HIP_EMU__
 // walk statistics of the emulated build (design studies, scripts/study_rounds.py): [0] jobs walked, [1] settled by the shortcut
 // (no candidate under S), [2] went through the exact path, [3] won by an offer touched earlier in the round, [4] won by an
-// untouched offer (a new touched lane), [5] walked and unmatched, [6] sum of touched lanes at decision time, [7] sum of the list
-// position that settled the job
+// untouched offer (a new touched lane), [5] walked and unmatched, [6] sum of touched lanes at decision time, [7] won by the very
+// lane that took the previous walked job
 inline unsigned long long g_walk_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+inline int g_walk_prev_lane = -1;  // lane that took the previous walked job of the round ([7]: a touched offer won AND it is that lane)
 #define WALK_STAT(i, v) do { if (lane == 0) g_walk_stats[i] += (v); } while (0)
 #else
 #define WALK_STAT(i, v) ((void)0)
@@ -1334,6 +1335,13 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     if (win_lane >= 0) WALK_STAT(3, 1);
     else if (win >= 0) WALK_STAT(4, 1);
     else WALK_STAT(5, 1);
+#ifdef __HIP_EMU__
+    if (lane == 0) {
+      if (i == 0) g_walk_prev_lane = -1;
+      if (win_lane >= 0 && win_lane == g_walk_prev_lane) g_walk_stats[7] += 1;
+      g_walk_prev_lane = win_lane >= 0 ? win_lane : (win >= 0 ? (int)nT : -1);
+    }
+#endif
     if (win_lane >= 0) {  // an offer touched earlier in this round takes the job
       if ((int)lane == win_lane) {
         t_ac += c;
