@@ -255,7 +255,10 @@ int cook_cycle_fetch_considerable(cook_engine* e, uint32_t* rank_pos, uint32_t* 
  * (scheduler.clj:617-687; Fenzo 0.10.0 pinned at project.clj:46-50; constraints.clj).
  * job_to_offer[k] = offer index or -1.  head_matched mirrors scheduler.clj:1495 (first considerable job matched,
  * or nothing matched at all).  fail_code (optional, len K): 0 matched, else first reason no offer accepted it
- * (bit 0 resources, bit 1 constraints).  reserved_hosts: hosts reserved by the rebalancer for ANY job. */
+ * (bit 0 resources, bit 1 constraints).  reserved_hosts: hosts reserved by the rebalancer for ANY job.
+ * Ties between offers of equal fitness go to the lowest offer INDEX (array position).  The reference's recorded simulator run
+ * (simulator_files/example-out-trace.csv) is reproduced row for row when the offers of a cycle are passed in DESCENDING hostname
+ * order (ascending order yields the mirror image on identical hosts): that is the order a binding should use. */
 int cook_match(cook_engine* e, const cook_jobs* considerable, const cook_offers* offers, const cook_groups* groups,
                const uint32_t* reserved_hosts, uint32_t n_reserved, int32_t* job_to_offer, uint32_t* fail_code,
                uint8_t* head_matched);
