@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-adjacent", action="store_true", help="skip the timings of the rows next to the hot path (offers, explain, metrics)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
-    ap.add_argument("--check", action="store_true", help="verify pool 0 of rank 0 against the oracle (slow)")
+    ap.add_argument("--no-check", action="store_true", help="skip the parity check of the timed configuration (rank 0's first and last pool vs the oracle, after the timed region)")
     return ap.parse_args()
 
 
@@ -113,9 +113,12 @@ def main():
     from cook_amd.engine import Engine
 
     P = args.pools
+    from cook_amd import workload
     from cook_amd.sharding import pools_of_rank
     my_pools = pools_of_rank(P, world, rank)
-    n_pend, n_run, n_off = args.pending // P, args.running // P, args.offers // P
+    spec = workload.ClusterSpec(pools=P, pending=args.pending, running=args.running, offers=args.offers, users=args.users,
+                                constraints=not args.no_constraints)
+    n_pend, n_run, n_off = spec.per_pool
     params = A.default_params(good_enough_fitness=args.good_enough, match_algo=args.match_algo)
     K = args.considerable if args.considerable > 0 else n_pend
 
@@ -123,8 +126,7 @@ def main():
     t0 = time.time()
     pools, engines = {}, {}
     for p in my_pools:
-        pools[p] = synth.make_pool(seed=0xC00C0004 + p, n_pending=n_pend, n_running=n_run, n_users=args.users, n_offers=n_off,
-                                   gpus=not args.no_constraints, constraints=not args.no_constraints)
+        pools[p] = workload.make_pool(spec, p)
         e = Engine(params, device=local_rank)
         e.cycle_stage(pools[p].tasks, pools[p].users, pools[p].pending_jobs, pools[p].offers, pools[p].groups)
         engines[p] = e
@@ -132,9 +134,7 @@ def main():
     # quota: every pool has a (non-binding) pool quota and belongs to ONE quota group "s" whose usage is the sum over
     # all pools of the cluster -> the cross-rank all-reduce (scheduler.clj:2125-2157); cook_amd/sharding.py
     from cook_amd import sharding
-    qg = sharding.QuotaGroups(pool_group={p: 0 for p in range(P)},
-                              group_quota={0: A.quota(count=80_000_000, cpus=1e10, mem=1e14, gpus=1e9)},
-                              pool_quota={p: A.quota(count=10_000_000, cpus=1e9, mem=1e13, gpus=1e8) for p in range(P)})
+    qg = workload.quota_groups(spec)
     cluster = sharding.ShardedCluster(engines, qg, world=world, rank=rank, device=dev)
 
     def cycle():
@@ -165,8 +165,10 @@ def main():
     # results of the last cycle (for the record + sanity)
     matched = considered = ranked_n = 0
     stage_ms = {}
+    fetched = {}
     for p in my_pools:
         r, j2o, head = engines[p].cycle_fetch()
+        fetched[p] = (r, j2o)
         ranked_n += len(r)
         considered += len(j2o)
         matched += int((j2o >= 0).sum())
@@ -212,14 +214,19 @@ def main():
                                                  sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]}}
 
     # ---- CPU baseline: the oracle (kind "port") on rank 0's first pool, bounded sample ---------------------------
+    # ---- + parity of the TIMED configuration: the results of the last timed cycle (as fetched above, before the profiled
+    #      pass) of rank 0's first pool (first slot of a launch chain) and last pool (last slot of another chain) against
+    #      the oracle, bit-exact.  A fast wrong answer must not produce a number: a mismatch raises.
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    parity_checked, parity_pools = False, []
+    if rank == 0 and not (args.no_cpu_baseline and args.no_check):
         from oracle import pyoracle
         p0 = my_pools[0]
         pool = pools[p0]
         cores = args.cpu_threads or min(16, os.cpu_count() or 1)
+        q0 = cluster.quota_inputs(p0, cluster.last_pool_usage[p0], cluster.last_group_usage)
         c0 = time.perf_counter()
-        o_ranked, _ = pyoracle.rank(params, pool.tasks, pool.users)
+        o_ranked, _ = pyoracle.rank(params, pool.tasks, pool.users, quota=q0)
         c1 = time.perf_counter()
         # bounded sample of the placement: first k_s considerable jobs, ~<= 2e9 pair evaluations
         k_s = int(min(min(K, len(o_ranked)), max(1000, 1_000_000_000 // max(1, n_off))))
@@ -236,10 +243,18 @@ def main():
                "sample": f"oracle on pool {p0} of {P}: rank of {pool.tasks.n} tasks ({c1 - c0:.2f} s) + placement of the first "
                          f"{k_s} of {k_full} considerable jobs x {n_off} offers ({c3 - c2:.2f} s), scaled linearly to K and x{P} pools",
                "rank_s": c1 - c0, "match_sample_s": c3 - c2}
-        if args.check:
-            r, j2o, _ = engines[p0].cycle_fetch()
-            assert np.array_equal(r, o_ranked), "rank differs from oracle"
-            assert np.array_equal(j2o[:k_s], o_j2o), "assignments differ from oracle"
+        if not args.no_check:
+            r, j2o = fetched[p0]
+            assert np.array_equal(r, o_ranked), f"PARITY: rank of pool {p0} differs from the oracle"
+            assert np.array_equal(j2o[:k_s], o_j2o), f"PARITY: assignments of pool {p0} differ from the oracle"
+            parity_pools.append({"pool": p0, "jobs_checked": int(k_s)})
+            if len(my_pools) > 1:  # a pool from another chain, in its last lockstep slot
+                from oracle import checks
+                pl = my_pools[-1]
+                ql = cluster.quota_inputs(pl, cluster.last_pool_usage[pl], cluster.last_group_usage)
+                checks.check_pool_against_oracle(params, pools[pl], ql, fetched[pl][0], fetched[pl][1], K, threads=cores)
+                parity_pools.append({"pool": pl, "jobs_checked": int(len(fetched[pl][1]))})
+            parity_checked = True
 
     # ---- the rows either side of the path, timed once on rank 0's first pool; not part of `value` ----
     adjacent = None
@@ -283,6 +298,7 @@ def main():
                            "placement_stats_pool0": engines[my_pools[0]].match_stats()},
             "setup_s": gen_s,
             "roofline": roofline, "cpu_baseline": cpu, "adjacent_rows": adjacent,
+            "parity_checked": parity_checked, "parity": {"against": "oracle (bit-exact rank order + every assignment)", "pools": parity_pools},
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]

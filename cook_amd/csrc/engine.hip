@@ -120,7 +120,13 @@ struct cook_engine {
   DArr<uint64_t> w0, w1, w2, dkey, nkkey, ckey;
   DArr<SumU4> s_use, pre, quseA, quseB, qpre, pool_usage;
   DArr<SumI> scanI;
-  DArr<int> iflag, ones_buf, tied_buf;
+  DArr<int> iflag, ones_buf, tied_buf, run_isf, run_nonf, run_posf;
+  DArr<SumI> run_scan, run_scan2;
+  DArr<uint32_t> run_user, run_orig, run_seg, run_b2c, run_perm;
+  DArr<uint64_t> run_dkey;
+  DArr<double> uu_out;
+  DArr<uint8_t> uu_has;
+  DArr<SumU4> uu_pre;
   DArr<double> dru, dru_out;
   ScanTmp<SumU4> tmpU4;
   ScanTmp<SumI> tmpI;
@@ -368,6 +374,29 @@ void rank_pool_usage(cook_engine* e, cook_usage* out) {
   *out = cook_usage{h.count, h.cpus, h.mem, h.gpus};
 }
 
+// per-user running usage [U x 3] of the pool, from the per-user order of the last rank run (rank_kernels.hpp)
+void rank_user_usage(cook_engine* e, double* out, bool out_is_device) {
+  if (!e->rank_done) e->fail(COOK_E_STATE, "cook_rank_user_usage before cook_rank_run");
+  if (!out) e->fail(COOK_E_INVALID, "cook_rank_user_usage: null output");
+  const unsigned N = e->N, U = e->U;
+  if (U == 0) return;
+  double* dst = out_is_device ? out : e->uu_out.ensure((size_t)U * 3);
+  uint8_t* has = e->uu_has.ensure(U);
+  COOK_HIP(hipMemsetAsync(has, 0, U, e->stream));
+  if (N) {
+    SumU4* rp = e->uu_pre.ensure(N);
+    KL("user_mark_present", user_mark_present, div_up(N, 256), 256, (const uint32_t*)e->s_user.ptr(), N, has);
+    seg_scan<SumU4>(e, "user_running_scan", LoadRunningU4{e->s_use.ptr(), e->s_pending.ptr()}, (const uint8_t*)e->head.ptr(), N, rp,
+                    e->tmpU4);
+    KL("user_usage_extract", user_usage_extract, div_up(U, 256), 256, (const SumU4*)rp, (const SumU4*)e->s_use.ptr(),
+       (const uint8_t*)e->s_pending.ptr(), (const uint32_t*)e->seg_start.ptr(), (const uint32_t*)e->seg_end.ptr(), (const uint8_t*)has, U, dst);
+  } else {
+    COOK_HIP(hipMemsetAsync(dst, 0, (size_t)U * 24, e->stream));
+  }
+  if (!out_is_device) COOK_HIP(hipMemcpyAsync(out, dst, (size_t)U * 24, hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+}
+
 // one quota filter stage over the queue (tools.clj:917-933); returns new queue length
 unsigned queue_filter_quota(cook_engine* e, unsigned len, const cook_usage& quota, const cook_usage& base, uint32_t*& qitem,
                             SumU4*& quse, uint32_t*& qitem_other, SumU4*& quse_other) {
@@ -500,43 +529,87 @@ void rank_run(cook_engine* e) {
   if (n_kept) {
     const unsigned gK = div_up(n_kept, 256);
     // --- tie groups + sorted-merge tie rule (prefix doubling) ------------------------------------------------
-    e->thead.ensure(n_kept);
-    e->rank_of_item.ensure(N);
-    e->gstart.ensure(n_kept);
-    int* ones = e->ones_buf.ensure(n_kept);
-    int* tied = e->tied_buf.ensure(n_kept);
-    KL("tie_heads", tie_heads, gK, 256, (const uint32_t*)e->permC, (const uint64_t*)e->dkey.ptr(), n_kept,
-       (const uint32_t*)e->s_user.ptr(), e->thead.ptr(), ones, counters);
     unsigned bits = 1;
     while ((1ull << bits) <= (unsigned long long)U + N) ++bits;  // rank values <= U + N
     const unsigned rank_bytes = (bits + 7) / 8;
     unsigned long long cmask = 0;
     for (unsigned b = 0; b < rank_bytes; ++b) cmask |= (0xFFull << (8 * b)) | (0xFFull << (8 * (b + 4)));
-    for (int round = 0;; ++round) {
-      seg_scan<SumI>(e, "tie_group_scan", LoadI{ones}, (const uint8_t*)e->thead.ptr(), n_kept, e->scanI.ptr(), e->tmpI);
-      COOK_HIP(hipMemsetAsync(counters + 2, 0, 4, e->stream));
-      KL("tie_assign", tie_assign, gK, 256, (const uint32_t*)e->permC, (const uint8_t*)e->thead.ptr(), (const SumI*)e->scanI.ptr(),
-         n_kept, U, e->rank_of_item.ptr(), e->gstart.ptr(), tied, counters + 2);
-      unsigned h3[3];
-      readback_counters(e, h3, 3);
-      if (h3[1]) e->fail(COOK_E_INVALID, "cook_rank: a user has consecutive tasks with equal DRU (zero-resource task); unsupported");
-      const unsigned n_tied = h3[2];
-      if (n_tied == 0) break;
-      if (round > 31) e->fail(COOK_E_INVALID, "cook_rank: tie refinement did not converge");
-      // compact tied slots, sort them by (group start, secondary), write back, split groups
-      e->tpos.ensure(n_tied);
-      e->titem.ensure(n_tied);
-      e->ckey.ensure(n_tied);
-      e->tsorted.ensure(n_tied);
-      e->tsorted2.ensure(n_tied);
-      seg_scan<SumI>(e, "tie_compact_scan", LoadI{tied}, (const uint8_t*)nullptr, n_kept, e->scanI.ptr(), e->tmpI);
-      KL("tie_build", tie_build, gK, 256, (const uint32_t*)e->permC, (const int*)tied, (const SumI*)e->scanI.ptr(),
-         (const uint32_t*)e->gstart.ptr(), n_kept, U, N, round, (const uint32_t*)e->rank_of_item.ptr(),
-         (const uint32_t*)e->s_user.ptr(), (const uint32_t*)e->seg_start.ptr(), e->tpos.ptr(), e->titem.ptr(), e->ckey.ptr());
-      KL("iota", iota_u32, div_up(n_tied, 256), 256, e->tsorted.ptr(), n_tied);
-      uint32_t* ts = radix_sort_masked(e, e->ckey.ptr(), cmask, e->tsorted.ptr(), e->tsorted.ptr(), e->tsorted2.ptr(), n_tied);
-      KL("tie_writeback", tie_writeback, div_up(n_tied, 256), 256, (const uint32_t*)ts, (const uint32_t*)e->tpos.ptr(),
-         (const uint32_t*)e->titem.ptr(), (const uint64_t*)e->ckey.ptr(), n_tied, e->permC, e->thead.ptr());
+    // refines `perm` (nk items of an index space with n_items items, per-user lists contiguous) in place; returns false when a
+    // user has consecutive items with equal keys (the caller collapses those runs and calls again on the collapsed space)
+    auto tie_refine = [&](uint32_t* perm, const uint64_t* key, const uint32_t* user_of, const uint32_t* seg_first, unsigned nk,
+                          unsigned n_items) -> bool {
+      const unsigned gK = div_up(nk, 256);
+      e->thead.ensure(nk);
+      e->rank_of_item.ensure(n_items);
+      e->gstart.ensure(nk);
+      int* ones = e->ones_buf.ensure(nk);
+      int* tied = e->tied_buf.ensure(nk);
+      e->scanI.ensure(nk);
+      COOK_HIP(hipMemsetAsync(counters + 1, 0, 4, e->stream));
+      KL("tie_heads", tie_heads, gK, 256, (const uint32_t*)perm, key, nk, user_of, e->thead.ptr(), ones, counters);
+      for (int round = 0;; ++round) {
+        seg_scan<SumI>(e, "tie_group_scan", LoadI{ones}, (const uint8_t*)e->thead.ptr(), nk, e->scanI.ptr(), e->tmpI);
+        COOK_HIP(hipMemsetAsync(counters + 2, 0, 4, e->stream));
+        KL("tie_assign", tie_assign, gK, 256, (const uint32_t*)perm, (const uint8_t*)e->thead.ptr(), (const SumI*)e->scanI.ptr(), nk, U,
+           e->rank_of_item.ptr(), e->gstart.ptr(), tied, counters + 2);
+        unsigned h3[3];
+        readback_counters(e, h3, 3);
+        if (h3[1]) return false;
+        const unsigned n_tied = h3[2];
+        if (n_tied == 0) break;
+        if (round > 31) e->fail(COOK_E_INVALID, "cook_rank: tie refinement did not converge");
+        // compact tied slots, sort them by (group start, secondary), write back, split groups
+        e->tpos.ensure(n_tied);
+        e->titem.ensure(n_tied);
+        e->ckey.ensure(n_tied);
+        e->tsorted.ensure(n_tied);
+        e->tsorted2.ensure(n_tied);
+        seg_scan<SumI>(e, "tie_compact_scan", LoadI{tied}, (const uint8_t*)nullptr, nk, e->scanI.ptr(), e->tmpI);
+        KL("tie_build", tie_build, gK, 256, (const uint32_t*)perm, (const int*)tied, (const SumI*)e->scanI.ptr(),
+           (const uint32_t*)e->gstart.ptr(), nk, U, n_items, round, (const uint32_t*)e->rank_of_item.ptr(), user_of, seg_first,
+           e->tpos.ptr(), e->titem.ptr(), e->ckey.ptr());
+        KL("iota", iota_u32, div_up(n_tied, 256), 256, e->tsorted.ptr(), n_tied);
+        uint32_t* ts = radix_sort_masked(e, e->ckey.ptr(), cmask, e->tsorted.ptr(), e->tsorted.ptr(), e->tsorted2.ptr(), n_tied);
+        KL("tie_writeback", tie_writeback, div_up(n_tied, 256), 256, (const uint32_t*)ts, (const uint32_t*)e->tpos.ptr(),
+           (const uint32_t*)e->titem.ptr(), (const uint64_t*)e->ckey.ptr(), n_tied, perm, e->thead.ptr());
+      }
+      return true;
+    };
+    if (!tie_refine(e->permC, e->dkey.ptr(), e->s_user.ptr(), e->seg_start.ptr(), n_kept, N)) {
+      // some user has a run of equal DRUs (a zero-resource task, a gpu-less task in gpu mode, a request absorbed by the sum): the
+      // merge emits such a run back to back (rank_kernels.hpp, run_*), so collapse the runs, refine the heads, re-insert the rest
+      int* isf = e->run_isf.ensure(N);
+      int* nonf = e->run_nonf.ensure(N);
+      SumI* nonf_incl = e->run_scan.ensure(N);
+      KL("run_follower_flag", run_follower_flag, gN, 256, (const uint32_t*)e->s_user.ptr(), (const uint64_t*)e->dkey.ptr(),
+         (const uint8_t*)e->keep.ptr(), N, isf, nonf);
+      seg_scan<SumI>(e, "run_scan", LoadI{nonf}, (const uint8_t*)nullptr, N, nonf_incl, e->tmpI);
+      COOK_HIP(hipMemcpyAsync(e->h_scratch, &nonf_incl[N - 1], 4, hipMemcpyDeviceToHost, e->stream));
+      sync(e);
+      int n2i = 0;
+      std::memcpy(&n2i, e->h_scratch, 4);
+      const unsigned N2 = (unsigned)n2i, n_kept2 = n_kept - (N - N2);  // followers are kept items
+      uint32_t* c_user = e->run_user.ensure(N2);
+      uint64_t* c_dkey = e->run_dkey.ensure(N2);
+      uint32_t* c_orig = e->run_orig.ensure(N2 + 1);
+      uint32_t* c_seg = e->run_seg.ensure(U);
+      uint32_t* b_to_c = e->run_b2c.ensure(N);
+      KL("run_compact_items", run_compact_items, gN, 256, (const int*)nonf, (const SumI*)nonf_incl, N, (const uint32_t*)e->s_user.ptr(),
+         (const uint64_t*)e->dkey.ptr(), (const uint8_t*)e->head.ptr(), c_user, c_dkey, c_orig, c_seg, b_to_c);
+      KL("run_compact_sentinel", run_compact_sentinel, 1, 1, (const SumI*)nonf_incl, N, c_orig);
+      int* posf = e->run_posf.ensure(n_kept);
+      SumI* posf_incl = e->run_scan2.ensure(n_kept);
+      KL("run_flag_positions", run_flag_positions, gK, 256, (const uint32_t*)e->permC, (const int*)isf, n_kept, posf);
+      seg_scan<SumI>(e, "run_scan", LoadI{posf}, (const uint8_t*)nullptr, n_kept, posf_incl, e->tmpI);
+      uint32_t* perm2 = e->run_perm.ensure(n_kept2);
+      KL("run_compact_positions", run_compact_positions, gK, 256, (const uint32_t*)e->permC, (const int*)posf, (const SumI*)posf_incl,
+         n_kept, (const uint32_t*)b_to_c, perm2);
+      if (!tie_refine(perm2, c_dkey, c_user, c_seg, n_kept2, N2)) e->fail(COOK_E_STATE, "cook_rank: equal-DRU runs survived the collapse");
+      const unsigned gK2 = div_up(n_kept2, 256);
+      KL("run_count_followers", run_count_followers, gK2, 256, (const uint32_t*)perm2, (const uint32_t*)c_orig, n_kept2, posf);
+      seg_scan<SumI>(e, "run_scan", LoadI{posf}, (const uint8_t*)nullptr, n_kept2, posf_incl, e->tmpI);
+      KL("run_expand", run_expand, gK2, 256, (const uint32_t*)perm2, (const uint32_t*)c_orig, (const int*)posf, (const SumI*)posf_incl,
+         n_kept2, e->permC);
     }
     // --- queue of pending jobs in rank order ---------------------------------------------------------------
     int* flag = e->iflag.ptr();
@@ -899,6 +972,15 @@ void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, 
       std::fclose(f);
     }
   }
+#ifdef COOK_WALK_PROF
+  {
+    static const char* cat[8] = {"shortcut", "touched_wins", "new_lane", "unmatched", "grouped", "exact", "-", "-"};
+    std::fprintf(stderr, "WALKPROF rounds=%u", hc.rounds);
+    for (int i = 0; i < 6; ++i)
+      std::fprintf(stderr, " %s:n=%u,cyc/job=%.0f", cat[i], hc.prof_cnt[i], hc.prof_cnt[i] ? (double)hc.prof_cyc[i] / hc.prof_cnt[i] : 0.0);
+    std::fprintf(stderr, "\n");
+  }
+#endif
   unsigned sum[4] = {hc.matched, (hc.matched == 0 || hc.head_matched) ? 1u : 0u, hc.rounds, 0u};
   std::memcpy(e->h_scratch, sum, 16);
   COOK_HIP(hipMemcpyAsync(st.summary, e->h_scratch, 16, hipMemcpyHostToDevice, stream));
@@ -1038,6 +1120,9 @@ int guarded(cook_engine* e, F&& f) {
   } catch (const std::exception& ex) {
     e->err = ex.what();
     return COOK_E_NOMEM;
+  } catch (...) {  // nothing may cross the C boundary
+    e->err = "unknown exception";
+    return COOK_E_STATE;
   }
 }
 
@@ -1152,6 +1237,9 @@ int cook_rank_set_quota(cook_engine* e, const cook_pool_quota* q) {
 int cook_rank_pool_usage(cook_engine* e, cook_usage* out) {
   if (!out) return COOK_E_INVALID;
   return guarded(e, [&] { rank_pool_usage(e, out); });
+}
+int cook_rank_user_usage(cook_engine* e, double* usage, int usage_is_device) {
+  return guarded(e, [&] { rank_user_usage(e, usage, usage_is_device != 0); });
 }
 int cook_rank_run(cook_engine* e) {
   return guarded(e, [&] {

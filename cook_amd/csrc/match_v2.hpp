@@ -123,6 +123,11 @@ struct WinCtl {
   unsigned wgrow_pct;     // next window = this percentage of what the round resolved (window ended early) / of the window (it did not)
   unsigned pad_;
   unsigned long long t_eval, t_merge;  // persistent kernel: ticks spent in the eval / merge phases (as seen by workgroup 0)
+#ifdef COOK_WALK_PROF  // measurement build: shader cycles / jobs of the walk by outcome (0 shortcut, 1 touched offer wins, 2 new lane,
+                       // 3 walked and unmatched, 4 member of a constrained group, 5 exact path ran)
+  unsigned long long prof_cyc[8];
+  unsigned prof_cnt[8];
+#endif
 };
 
 struct RoundLog {  // one record per round (diagnostics; only written when V2Buf::round_log is set)
@@ -1044,6 +1049,10 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   JobRegs nxt = load_job(0);
   for (unsigned i = 0; i < n_list; ++i) {
     EMU_SITE("resolve: walk loop");
+#ifdef COOK_WALK_PROF
+    const unsigned long long pk0 = __builtin_readcyclecounter();
+    unsigned pcat = 0;
+#endif
     const JobRegs cur = nxt;
     nxt = load_job(i + 1);
     const unsigned b = cur.b, k = head + b, bl = b & 63u;
@@ -1342,6 +1351,9 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       g_walk_prev_lane = win_lane >= 0 ? win_lane : (win >= 0 ? (int)nT : -1);
     }
 #endif
+#ifdef COOK_WALK_PROF
+    pcat = grouped ? 4u : (need_exact ? 5u : (win_lane >= 0 ? 1u : (win >= 0 ? 2u : ((nc == 0 && cur.no_zero_fit) ? 0u : 3u))));
+#endif
     if (win_lane >= 0) {  // an offer touched earlier in this round takes the job
       if ((int)lane == win_lane) {
         t_ac += c;
@@ -1445,6 +1457,13 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         s_fail[b] = (unsigned char)(bits ? bits : 8u);
       }
     }
+#ifdef COOK_WALK_PROF
+    {
+      const unsigned long long pk1 = __builtin_readcyclecounter();
+      ctl.prof_cyc[pcat] += pk1 - pk0;
+      ctl.prof_cnt[pcat] += 1u;
+    }
+#endif
   }
   if (stop == 0 && weff < nwin) stop = 4;
   if constexpr (REEVAL) {

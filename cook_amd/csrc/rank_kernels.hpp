@@ -254,6 +254,77 @@ __global__ void __launch_bounds__(256) tie_writeback(const uint32_t* __restrict_
   if (j > 0 && ckey[sorted_j[j - 1]] != ckey[sj]) thead[p] = 1;
 }
 
+// ---- equal consecutive DRUs inside one user (a zero-resource task, a gpu-less task in gpu mode, a request absorbed by the sum) ---
+// The literal merge (dru.clj:92-94) re-conses an emitting coll at the FRONT: when the next head of that user carries the SAME
+// key it is the first minimum of the next stable sort, so a run of equal keys inside a user is emitted back to back, in the
+// user's task order.  The prefix-doubling scheme above assumes strictly increasing keys per user (an item's predecessor lives
+// in an EARLIER tie group), so such runs are collapsed first: only a run's head takes part in the tie refinement (in an index
+// space without the followers), and the followers are re-inserted right behind their head afterwards.
+// follower flag over B: kept, same user and same key as the item before it
+__global__ void __launch_bounds__(256) run_follower_flag(const uint32_t* __restrict__ s_user, const uint64_t* __restrict__ dkey,
+                                                         const uint8_t* __restrict__ keep, unsigned n, int* __restrict__ isf,
+                                                         int* __restrict__ nonf) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool f = keep[i] && i > 0 && s_user[i - 1] == s_user[i] && dkey[i - 1] == dkey[i];
+  isf[i] = f ? 1 : 0;
+  nonf[i] = f ? 0 : 1;
+}
+// compacted copies of the per-item arrays (index space B' = B without followers)
+__global__ void __launch_bounds__(256) run_compact_items(const int* __restrict__ nonf, const SumI* __restrict__ nonf_incl, unsigned n,
+                                                         const uint32_t* __restrict__ s_user, const uint64_t* __restrict__ dkey,
+                                                         const uint8_t* __restrict__ head, uint32_t* __restrict__ c_user,
+                                                         uint64_t* __restrict__ c_dkey, uint32_t* __restrict__ c_orig,
+                                                         uint32_t* __restrict__ c_seg_start, uint32_t* __restrict__ b_to_c) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned ci = (unsigned)nonf_incl[i].v - 1u;  // for a follower: the compact index of its run head
+  b_to_c[i] = ci;
+  if (!nonf[i]) return;
+  c_user[ci] = s_user[i];
+  c_dkey[ci] = dkey[i];
+  c_orig[ci] = i;
+  if (head[i]) c_seg_start[s_user[i]] = ci;  // a user's first item is never a follower
+}
+// sentinel behind the last compact item (its follower count = n - c_orig[last] - 1)
+__global__ void run_compact_sentinel(const SumI* __restrict__ nonf_incl, unsigned n, uint32_t* __restrict__ c_orig) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) c_orig[(unsigned)nonf_incl[n - 1].v] = n;
+}
+// flag over C positions [0, n_kept): the item at this position is a follower
+__global__ void __launch_bounds__(256) run_flag_positions(const uint32_t* __restrict__ permC, const int* __restrict__ isf, unsigned n_kept,
+                                                          int* __restrict__ posf) {
+  const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n_kept) posf[p] = isf[permC[p]];
+}
+// permC' = permC without the followers, in compact indices
+__global__ void __launch_bounds__(256) run_compact_positions(const uint32_t* __restrict__ permC, const int* __restrict__ posf,
+                                                             const SumI* __restrict__ posf_incl, unsigned n_kept,
+                                                             const uint32_t* __restrict__ b_to_c, uint32_t* __restrict__ permC2) {
+  const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_kept || posf[p]) return;
+  permC2[p - (unsigned)posf_incl[p].v] = b_to_c[permC[p]];
+}
+// followers per position of the refined compact order (input of the expansion scan)
+__global__ void __launch_bounds__(256) run_count_followers(const uint32_t* __restrict__ permC2, const uint32_t* __restrict__ c_orig,
+                                                           unsigned n2, int* __restrict__ nfol) {
+  const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n2) return;
+  const unsigned ci = permC2[p];
+  // everything between two non-followers of B is a follower of the first (followers are kept by definition)
+  nfol[p] = (int)(c_orig[ci + 1] - c_orig[ci] - 1u);
+}
+// final order: every run head followed by its followers
+__global__ void __launch_bounds__(256) run_expand(const uint32_t* __restrict__ permC2, const uint32_t* __restrict__ c_orig,
+                                                  const int* __restrict__ nfol, const SumI* __restrict__ nfol_incl, unsigned n2,
+                                                  uint32_t* __restrict__ permC) {
+  const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n2) return;
+  const unsigned i = c_orig[permC2[p]];
+  const unsigned f = (unsigned)nfol[p];
+  const unsigned o = p + (unsigned)nfol_incl[p].v - f;  // p + exclusive prefix of the follower counts
+  for (unsigned t = 0; t <= f; ++t) permC[o + t] = i + t;
+}
+
 // ---- A.6 queue of pending jobs in rank order and the quota filters ------------------------------------------
 __global__ void __launch_bounds__(256) queue_flag_pending(const uint32_t* __restrict__ permC, const uint8_t* __restrict__ s_pending,
                                                           unsigned n_kept, int* __restrict__ flag) {
@@ -344,6 +415,53 @@ __global__ void __launch_bounds__(256) dru_to_task_space(const double* __restric
                                                          const uint32_t* __restrict__ permB, unsigned n, double* __restrict__ out) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[permB[i]] = keep[i] ? dru[i] : __longlong_as_double(0x7FF8000000000000ll);
+}
+
+// ---- per-user running usage of the pool: the [U x 3] vector of the cross-pool all-reduce (BASELINE.json north_star; ----------
+// SURVEY.md §8e).  Sum of {cpus, mem, gpus} over the user's RUNNING tasks in the user's task order (tools.clj:614-641; the
+// reference's own per-user usage maps reduce in query order, which is not defined): a masked segmented scan over the
+// per-user order the rank already holds, exactness tracked and fixed up like the DRU prefixes.
+struct LoadRunningU4 {
+  const SumU4* use;
+  const uint8_t* pending;
+  __device__ __forceinline__ SumU4 operator()(unsigned i) const {
+    if (pending[i]) return SumU4::zero();
+    return use[i];
+  }
+};
+__global__ void __launch_bounds__(256) user_usage_extract(const SumU4* __restrict__ run_pre, const SumU4* __restrict__ s_use,
+                                                          const uint8_t* __restrict__ s_pending, const uint32_t* __restrict__ seg_start,
+                                                          const uint32_t* __restrict__ seg_end, const uint8_t* __restrict__ has_tasks,
+                                                          unsigned n_users, double* __restrict__ out /*[U][3]*/) {
+  const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_users) return;
+  double c = 0.0, m = 0.0, g = 0.0;
+  if (has_tasks[u]) {
+    const unsigned a = seg_start[u], b = seg_end[u];
+    const SumU4 t = run_pre[b - 1];
+    if (!t.bad) {
+      c = t.cpus, m = t.mem, g = t.gpus;
+    } else {  // an addition of the parallel scan rounded: left to right, as a sequential reduce would
+      bool first = true;
+      for (unsigned i = a; i < b; ++i) {
+        if (s_pending[i]) continue;
+        const SumU4 x = s_use[i];
+        if (first) {
+          c = x.cpus, m = x.mem, g = x.gpus;
+          first = false;
+        } else {
+          c += x.cpus, m += x.mem, g += x.gpus;
+        }
+      }
+    }
+  }
+  out[(size_t)u * 3 + 0] = c;
+  out[(size_t)u * 3 + 1] = m;
+  out[(size_t)u * 3 + 2] = g;
+}
+__global__ void __launch_bounds__(256) user_mark_present(const uint32_t* __restrict__ s_user, unsigned n, uint8_t* __restrict__ has_tasks) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) has_tasks[s_user[i]] = 1;
 }
 
 // ---- pool running usage (scheduler.clj:2118-2123, 2173): one workgroup, exactness tracked ----------------------

@@ -19,7 +19,7 @@ DEFAULT_LIB = os.environ.get("COOK_LIB") or os.path.join(_HERE, "libcookmatch.so
 
 EXPORTS = [
     "cook_engine_create", "cook_engine_destroy", "cook_engine_set_params", "cook_last_error", "cook_version",
-    "cook_rank", "cook_rank_stage", "cook_rank_set_quota", "cook_rank_pool_usage", "cook_rank_run", "cook_rank_fetch",
+    "cook_rank", "cook_rank_stage", "cook_rank_set_quota", "cook_rank_pool_usage", "cook_rank_user_usage", "cook_rank_run", "cook_rank_fetch",
     "cook_match", "cook_match_stage", "cook_match_run", "cook_match_fetch",
     "cook_cycle_stage", "cook_cycle_run", "cook_cycle_fetch", "cook_cycle_run_rank", "cook_cycle_match_multi",
     "cook_considerable", "cook_cycle_set_considerable", "cook_cycle_fetch_considerable",
@@ -130,6 +130,16 @@ class Engine:
         u = A.CookUsage()
         self._chk(self._lib.cook_rank_pool_usage(self._h, C.byref(u)))
         return u
+
+    def rank_user_usage(self, n_users: int, device_ptr: Optional[int] = None):
+        """[U, 3] = {cpus, mem, gpus} of every user's running tasks in this pool (cook_rank_user_usage).  With `device_ptr` (the
+        address of a device buffer of U x 3 doubles, e.g. a torch tensor's data_ptr()) nothing comes back to the host."""
+        if device_ptr is not None:
+            self._chk(self._lib.cook_rank_user_usage(self._h, C.c_void_p(device_ptr), 1))
+            return None
+        out = np.zeros((max(1, n_users), 3), dtype=np.float64)
+        self._chk(self._lib.cook_rank_user_usage(self._h, _p(out, C.c_double), 0))
+        return out[:n_users]
 
     def rank_run(self):
         self._chk(self._lib.cook_rank_run(self._h))

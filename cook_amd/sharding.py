@@ -58,10 +58,11 @@ def group_usage_matrix(groups: QuotaGroups, local_usage: Dict[int, Sequence[floa
     return m
 
 
-def all_reduce_group_usage(local: np.ndarray, world: int, device=None) -> np.ndarray:
-    """The only collective on the path: all-reduce(SUM) of the [n_groups, 4] matrix.  Integer-valued usages (count, and
-    the benchmark's cpus/mem/gpus) sum exactly in any order; the reference sums pools in map order (merge-with +)."""
-    if world <= 1:
+def all_reduce_group_usage(local: np.ndarray, world: int, device=None, force: bool = False) -> np.ndarray:
+    """The collective the reference's path needs: all-reduce(SUM) of the [n_groups, 4] matrix.  Integer-valued usages (count,
+    and the benchmark's cpus/mem/gpus) sum exactly in any order; the reference sums pools in map order (merge-with +).
+    `force` runs the collective even at world 1 (the single-rank RCCL test on the GPU box)."""
+    if world <= 1 and not force:
         return local
     import torch
     import torch.distributed as dist
@@ -71,6 +72,28 @@ def all_reduce_group_usage(local: np.ndarray, world: int, device=None) -> np.nda
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+def all_reduce_user_usage(engines: Sequence, n_users: int, world: int, device=None, force: bool = False) -> np.ndarray:
+    """BASELINE.json north_star's collective: the cross-pool per-user usage totals.  Every local pool writes its [U, 3] vector
+    {cpus, mem, gpus of the user's running tasks} (cook_rank_user_usage) — on a GPU rank straight into a device tensor, so the
+    payload never visits the host —, the rank adds its pools, and ONE all-reduce(SUM) over RCCL / gloo gives every rank the
+    totals (10k users = 240 KB: latency-bound on xGMI).  Dividing by the users' shares gives the cross-pool DRU totals."""
+    import torch
+    import torch.distributed as dist
+
+    on_gpu = device is not None and getattr(device, "type", "cpu") == "cuda"
+    acc = torch.zeros((n_users, 3), dtype=torch.float64, device=device if on_gpu else "cpu")
+    buf = torch.empty_like(acc)
+    for e in engines:
+        if on_gpu:
+            e.rank_user_usage(n_users, device_ptr=buf.data_ptr())  # synchronises the engine's stream before returning
+            acc += buf
+        else:
+            acc += torch.from_numpy(np.ascontiguousarray(e.rank_user_usage(n_users)))
+    if world > 1 or force:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    return acc.cpu().numpy()
 
 
 class ShardedCluster:
@@ -90,6 +113,9 @@ class ShardedCluster:
         self.max_chains = int(os.environ.get("COOK_MAX_CHAINS", "4"))
         self._tp_rank = ThreadPoolExecutor(max_workers=max(1, min(len(self.pools), int(os.environ.get("COOK_MAX_RANK_CHAINS", str(self.max_chains))))))
         self.last_group_usage: Optional[np.ndarray] = None
+        self.last_pool_usage: Dict[int, Sequence[float]] = {}
+        self.n_users = 0                      # > 0: every cycle also all-reduces the cross-pool per-user usage [U, 3]
+        self.last_user_usage: Optional[np.ndarray] = None
 
     def close(self):
         self._tp.shutdown(wait=True)
@@ -99,6 +125,11 @@ class ShardedCluster:
         pq = self.groups.pool_quota.get(pool)
         g = self.groups.pool_group.get(pool)
         gq = self.groups.group_quota.get(g) if g is not None else None
+        # pool-name->usage only holds pools WITH running tasks, so a group none of whose pools runs anything has no usage
+        # entry and filter-based-on-quota skips the group filter: (and quota-group-quota quota-group-usage),
+        # scheduler.clj:2134-2157.  The reduced task count tells the two cases apart.
+        if gq is not None and not (group_usage[g][0] > 0):
+            gq = None
         if pq is None and gq is None:
             return None
         return A.pool_quota(pool_quota=pq, group_quota=gq,
@@ -109,6 +140,7 @@ class ShardedCluster:
         usages = dict(zip(self.pools, self._tp.map(lambda p: self.engines[p].rank_pool_usage().as_tuple(), self.pools)))
         total = all_reduce_group_usage(group_usage_matrix(self.groups, usages), self.world, self.device)
         self.last_group_usage = total
+        self.last_pool_usage = usages
 
         lockstep = len(self.pools) > self.max_chains and all(hasattr(self.engines[p], "cycle_run_rank") for p in self.pools)
 
@@ -128,3 +160,5 @@ class ShardedCluster:
             n_chains = min(len(self.pools), self.max_chains)
             groups = [[self.engines[p] for p in self.pools[c::n_chains]] for c in range(n_chains)]
             list(self._tp.map(cycle_match_multi, groups))
+        if self.n_users and all(hasattr(self.engines[p], "rank_user_usage") for p in self.pools):
+            self.last_user_usage = all_reduce_user_usage([self.engines[p] for p in self.pools], self.n_users, self.world, self.device)

@@ -232,6 +232,12 @@ int cook_rank_set_quota(cook_engine* e, const cook_pool_quota* quota);
 /* running usage of the pool {count,cpus,mem,gpus} (scheduler.clj:2118-2123, 2173): input to the cross-pool all-reduce */
 int cook_rank_pool_usage(cook_engine* e, cook_usage* out);
 int cook_rank_run(cook_engine* e);
+/* per-user running usage of the pool after cook_rank_run / cook_cycle_run*: usage[u*3 + {0,1,2}] = {cpus, mem, gpus} summed over user
+ * u's RUNNING tasks in the user's task order (tools.clj:614-641).  This is the [U x 3] vector BASELINE.json's north_star
+ * all-reduces across pools ("cross-pool per-user DRU totals": divide by the user's share, share.clj:189-210); Cook itself
+ * keeps usage per pool (scheduler.clj:2167-2194), so no reference function consumes the cross-pool sum.  usage_is_device != 0:
+ * `usage` is a DEVICE pointer (e.g. the buffer of the collective): nothing is copied to the host. */
+int cook_rank_user_usage(cook_engine* e, double* usage, int usage_is_device);
 int cook_rank_fetch(cook_engine* e, uint32_t* ranked_pending_idx, uint32_t* n_out, double* dru_of_task);
 
 /* ---- CONSIDERABLE: replaces pending-jobs->considerable-jobs + tools/filter-pending-jobs-for-quota ----------

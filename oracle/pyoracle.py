@@ -67,6 +67,28 @@ def rank_merged(params, tasks: A.Tasks, users: A.Users, literal_merge=False):
     return idx[: n.value].copy(), dru[: n.value].copy()
 
 
+def user_usage(tasks: A.Tasks, n_users: int) -> np.ndarray:
+    """[U, 3] = {cpus, mem, gpus} summed over every user's RUNNING tasks, left to right in the user's task order
+    (tools.clj:614-641: -priority, start time, task id).  Oracle-defined order: the reference's per-user usage maps reduce in
+    query order (unpinned); the cross-pool sum of this vector is BASELINE.json north_star's all-reduce payload."""
+    out = np.zeros((n_users, 3), dtype=np.float64)
+    run = np.nonzero(np.asarray(tasks.pending) == 0)[0]
+    order = sorted(run.tolist(), key=lambda i: (int(tasks.user[i]), -int(tasks.priority[i]), int(tasks.start_ms[i]), int(tasks.task_id[i]), int(tasks.job_id[i])))
+    seen = set()
+    g = tasks.gpus if tasks.gpus is not None else None
+    for i in order:
+        u = int(tasks.user[i])
+        c, m, gg = float(tasks.cpus[i]), float(tasks.mem[i]), (float(g[i]) if g is not None else 0.0)
+        if u not in seen:
+            out[u] = (c, m, gg)
+            seen.add(u)
+        else:
+            out[u, 0] += c
+            out[u, 1] += m
+            out[u, 2] += gg
+    return out
+
+
 def pool_usage(tasks: A.Tasks) -> A.CookUsage:
     u = A.CookUsage()
     ts = tasks.as_struct()

@@ -65,6 +65,49 @@ def rank_parity(make_engine, pool: synth.Pool, params, quota=None):
     return ranked
 
 
+def equal_dru_run_cases(make_engine):
+    """Users with runs of EQUAL consecutive DRUs (rank_run refused such pools).  The literal merge (dru.clj:92-94)
+    re-conses the emitting user at the front, so a run is emitted back to back; the oracle's literal and heap forms agree."""
+    # (a) zero-resource and absorbed (1e-17) requests in the default mode, tie-heavy so that runs sit inside big tie groups
+    pool = synth.make_pool(seed=71, n_pending=900, n_running=300, n_users=25, n_offers=10, tie_heavy=True)
+    rng = np.random.default_rng(5)
+    z = rng.random(pool.tasks.n) < 0.15
+    pool.tasks.cpus[z] = 1e-17
+    pool.tasks.mem[z] = 1e-17
+    z2 = rng.random(pool.tasks.n) < 0.05
+    pool.tasks.cpus[z2] = 0.0
+    pool.tasks.mem[z2] = 0.0
+    rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=10))
+    o_lit, _ = pyoracle.rank(A.default_params(max_over_quota_jobs=10), pool.tasks, pool.users, literal_merge=True)
+    o_heap, _ = pyoracle.rank(A.default_params(max_over_quota_jobs=10), pool.tasks, pool.users)
+    assert np.array_equal(o_lit, o_heap)
+    # (b) gpu mode with gpu-less tasks: cumulative gpus stay put over long runs, incl. runs at a user's head (DRU 0)
+    pool = synth.make_pool(seed=72, n_pending=1500, n_running=500, n_users=40, n_offers=10, gpus=True)
+    rank_parity(make_engine, pool, A.default_params(dru_mode=1))
+    # (c) runs cut by the over-quota limiter, and a quota filter behind them
+    pool = synth.make_pool(seed=73, n_pending=700, n_running=200, n_users=9, n_offers=10, tie_heavy=True, quota_frac=0.5)
+    z = np.random.default_rng(6).random(pool.tasks.n) < 0.3
+    pool.tasks.cpus[z] = 0.0
+    pool.tasks.mem[z] = 0.0
+    q = A.pool_quota(pool_quota=A.quota(count=500, cpus=900.0))
+    rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=3), quota=q)
+    # (d) everything equal: one user, all-zero tasks; and two users with nothing but zeros
+    for n_users in (1, 2):
+        pool = synth.make_pool(seed=74, n_pending=130, n_running=70, n_users=n_users, n_offers=10)
+        pool.tasks.cpus[:] = 0.0
+        pool.tasks.mem[:] = 0.0
+        rank_parity(make_engine, pool, A.default_params())
+
+
+def user_usage_parity(make_engine, pool: synth.Pool, n_users):
+    with make_engine(A.default_params()) as e:
+        e.rank(pool.tasks, pool.users)
+        got = e.rank_user_usage(n_users)
+    want = pyoracle.user_usage(pool.tasks, n_users)
+    assert np.array_equal(got, want), np.nonzero((got != want).any(axis=1))[0][:5]
+    return got
+
+
 def match_parity(make_engine, jobs, offers, groups, params, reserved=()):
     with make_engine(params) as e:
         j2o, fail, head = e.match(jobs, offers, groups, reserved)

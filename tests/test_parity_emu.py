@@ -51,6 +51,17 @@ def test_rank_parity_gpu_mode_and_quota(make_engine):
     P.rank_parity(make_engine, pool, A.default_params(offensive_max_mem_mb=16000.0, offensive_max_cpus=6.0), quota=q)
 
 
+def test_rank_equal_dru_runs(make_engine):
+    P.equal_dru_run_cases(make_engine)
+
+
+def test_rank_user_usage(make_engine):
+    got = P.user_usage_parity(make_engine, synth.make_pool(seed=81, n_pending=900, n_running=700, n_users=40, n_offers=10, gpus=True), 40)
+    assert got[:, 0].sum() > 0 and got[:, 2].sum() > 0
+    P.user_usage_parity(make_engine, synth.make_pool(seed=82, n_pending=500, n_running=2500, n_users=7, n_offers=10, fractional=True), 7)
+    P.user_usage_parity(make_engine, synth.make_pool(seed=83, n_pending=50, n_running=0, n_users=5, n_offers=10), 5)
+
+
 def test_rank_edge_cases(make_engine):
     p = A.default_params()
     # empty input

@@ -38,6 +38,9 @@ class OracleEngine:
     def rank_set_quota(self, q):
         self.quota = q
 
+    def rank_user_usage(self, n_users, device_ptr=None):
+        return self.o.user_usage(self.pool.tasks, n_users)
+
     def cycle_run(self, k):
         r, _ = self.o.rank(self.params, self.pool.tasks, self.pool.users, self.quota)
         self.ranked = r[:k]
@@ -65,8 +68,9 @@ def run_rank(rank, world, port, out_dir):
     params = A.default_params()
     mine = sharding.pools_of_rank(N_POOLS, world, rank)
     cl = sharding.ShardedCluster({p: OracleEngine(pools[p], params) for p in mine}, groups, world=world, rank=rank)
+    cl.n_users = 25
     cl.cycle(500)
-    np.savez(os.path.join(out_dir, f"w{world}_r{rank}.npz"), group_usage=cl.last_group_usage,
+    np.savez(os.path.join(out_dir, f"w{world}_r{rank}.npz"), group_usage=cl.last_group_usage, user_usage=cl.last_user_usage,
              **{f"ranked_{p}": cl.engines[p].ranked for p in mine})
     cl.close()
     if world > 1:
@@ -117,9 +121,13 @@ def test_world2_gloo_equals_single_process(tmp_path):
     for r in range(2):
         z = np.load(os.path.join(out, f"w2_r{r}.npz"))
         assert np.array_equal(z["group_usage"], one["group_usage"])  # every rank holds the cluster-wide group usage
+        assert np.array_equal(z["user_usage"], one["user_usage"])    # ... and the cross-pool per-user usage totals [U, 3]
         got.update({k: z[k] for k in z.files if k.startswith("ranked_")})
     assert sorted(got) == [f"ranked_{p}" for p in range(N_POOLS)]
     pools, groups = make_cluster()
+    from oracle import pyoracle
+    want = sum(pyoracle.user_usage(pools[p].tasks, 25) for p in range(N_POOLS))
+    assert one["user_usage"].shape == (25, 3) and np.array_equal(one["user_usage"], want) and want[:, 0].sum() > 0
     for p in range(N_POOLS):
         assert np.array_equal(got[f"ranked_{p}"], one[f"ranked_{p}"]), f"pool {p}"
     # the group quota is binding: the three member pools together keep at most 150 pending jobs ... per pool the filter
@@ -127,3 +135,24 @@ def test_world2_gloo_equals_single_process(tmp_path):
     for p in (0, 1, 3):
         assert 0 < len(one[f"ranked_{p}"]) <= 150
     assert 0 < len(one["ranked_2"]) <= 40
+
+
+def test_group_without_running_tasks_skips_the_group_filter():
+    """filter-based-on-quota applies the group filter only when (and quota-group-quota quota-group-usage)
+    (scheduler.clj:2134-2157); pool-name->usage has no entry for pools without running tasks, so at cold start the group
+    usage is nil and the queue is NOT cut at the group quota."""
+    pools = {p: synth.make_pool(seed=0x77 + p, n_pending=300, n_running=0, n_users=9, n_offers=8) for p in range(2)}
+    groups = sharding.QuotaGroups(pool_group={0: 0, 1: 0}, group_quota={0: A.quota(count=50)})
+    params = A.default_params()
+    cl = sharding.ShardedCluster({p: OracleEngine(pools[p], params) for p in pools}, groups)
+    cl.cycle(10_000)
+    for p in pools:
+        assert cl.quota_inputs(p, cl.last_pool_usage[p], cl.last_group_usage) is None
+        assert len(cl.engines[p].ranked) == 300
+    cl.close()
+    # one running task anywhere in the group switches the filter on for every member pool
+    pools[1] = synth.make_pool(seed=0x79, n_pending=300, n_running=1, n_users=9, n_offers=8)
+    cl = sharding.ShardedCluster({p: OracleEngine(pools[p], params) for p in pools}, groups)
+    cl.cycle(10_000)
+    assert all(len(cl.engines[p].ranked) == 49 for p in pools)
+    cl.close()
