@@ -44,6 +44,29 @@ static inline unsigned long long cook_ticks() { return 0ull; }
 static __device__ __forceinline__ unsigned long long cook_ticks() { return wall_clock64(); }
 #endif
 
+// Scheduling helpers of the placement walk.  OPAQUE_V hides a value's origin from the compiler (a wave-uniform LDS address would
+// otherwise turn the loaded record into scalar registers through v_readfirstlane RIGHT AFTER the load, i.e. a full LDS round
+// trip on the critical path instead of a prefetch); wave_uniform_u32 moves a value every lane holds into a scalar register where
+// the code wants it (branch conditions).
+// WAIT_LDS: an explicit s_waitcnt lgkmcnt(0) inside a RARE branch that reloads a loop-carried register from LDS, so that the
+// compiler does not put a conservative full wait in front of the register's use on the common path (where it would also wait
+// for the prefetches just issued).  The compiler places waits lazily, right before the first use: for a software pipeline
+// that means at the TOP of the next iteration, behind the next prefetches.  An explicit wait at the END of an iteration (when
+// the prefetches issued at its top have long arrived) tells it that nothing is pending across the back edge.
+#ifdef __HIP_EMU__
+#define OPAQUE_V(x) ((void)0)
+#define WAIT_LDS() ((void)0)
+#define WAIT_LDS_BUT_LAST() ((void)0)
+#define WAIT_ALL_MEM() ((void)0)
+static inline unsigned wave_uniform_u32(unsigned v) { return v; }
+#else
+#define OPAQUE_V(x) asm volatile("" : "+v"(x))
+#define WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)
+#define WAIT_LDS_BUT_LAST() __builtin_amdgcn_s_waitcnt(0xC17F)  // lgkmcnt(1): LDS operations retire in order, the newest may still fly
+#define WAIT_ALL_MEM() __builtin_amdgcn_s_waitcnt(0x0070)     // vmcnt(0) lgkmcnt(0)
+static __device__ __forceinline__ unsigned wave_uniform_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+#endif
+
 static __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & (COOK_WAVE - 1); }
 static __device__ __forceinline__ unsigned wave_id() { return threadIdx.x >> 6; }
 
@@ -64,6 +87,13 @@ static inline unsigned long long wave_max_u64(unsigned long long x) {
   return x;
 }
 static inline int wave_read_lane(int v, int src) { return __shfl(v, src, COOK_WAVE); }
+static inline float wave_max_f32(float x) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float y = __shfl_xor(x, d, COOK_WAVE);
+    x = y > x ? y : x;
+  }
+  return x;
+}
 #else
 // all 64 lanes must be active.  A u64 max has no DPP form (each step = two DPP moves, a 64-bit compare and two selects: 54
 // instructions on the walk's critical path); a u32 max does (v_max_u32 with a DPP source).  So: the maximum of the high words
@@ -92,6 +122,27 @@ static __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long 
   else
     ml = wave_max_u32(hi == mh ? lo : 0u);
   return ((unsigned long long)mh << 32) | (unsigned long long)ml;
+}
+// Wave-wide maximum of non-negative floats (all 64 lanes active).  Hand-placed: one fused v_max_f32 with a DPP source per
+// step and the two wait states a DPP read of a just-written VGPR needs — the compiler's form (copy, nop, v_mov_dpp, v_max per
+// step) measured 166 cycles for the six steps on MI355X, against ~25 per step here (scripts/ubench_wave.hip).
+static __device__ __forceinline__ float wave_max_f32(float x) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      : "+v"(x));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 // value of v in lane src; src must be wave-uniform
 static __device__ __forceinline__ int wave_read_lane(int v, int src) {

@@ -1608,10 +1608,10 @@ int cook_match_stats(cook_engine* e, uint32_t out[16]) {
 }
 #ifdef __HIP_EMU__
 // emulated build only (design studies): the walk statistics of match_v2.hpp, cumulative; reset != 0 clears them afterwards
-int cook_emu_walk_stats(unsigned long long out[8], int reset) {
-  for (int i = 0; i < 8; ++i) out[i] = g_walk_stats[i];
+int cook_emu_walk_stats(unsigned long long out[12], int reset) {
+  for (int i = 0; i < 12; ++i) out[i] = g_walk_stats[i];
   if (reset)
-    for (int i = 0; i < 8; ++i) g_walk_stats[i] = 0;
+    for (int i = 0; i < 12; ++i) g_walk_stats[i] = 0;
   return COOK_OK;
 }
 #endif

@@ -678,7 +678,8 @@ struct JobL {  // a job of the window as the walk reads it (one 32-byte LDS reco
   double c, m;
   unsigned info;  // bits 0-7 ncand, 8-15 nge, 16 gpu job, 17 member of a constrained group, 18-19 group type
   unsigned group;
-  unsigned short f1, f2, f4, pad;  // saturated counts of offers failing on resources / constraints / zero fitness under S
+  unsigned short f1, f2, f4;  // saturated counts of offers failing on resources / constraints / zero fitness under S
+  unsigned short b;           // window position of the job (the record itself sits at its WALK position)
 };
 struct EntL {  // candidate-list entry (16 bytes): fitness under S, offer, slot
   double fit;
@@ -689,7 +690,7 @@ struct GEntL {  // good-enough list entry
   int off;
   unsigned short slot, pad;
 };
-constexpr unsigned JL_GPU = 1u << 16, JL_GROUPED = 1u << 17;
+constexpr unsigned JL_GPU = 1u << 16, JL_GROUPED = 1u << 17, JL_HASGROUP = 1u << 20;  // (bits 18-19: group type)
 
 static __device__ __attribute__((noinline)) bool group_pass_dev(const MatchIn* in, MatchState st, unsigned jj, unsigned v) {
   return group_pass(*in, st, jj, v);
@@ -700,7 +701,7 @@ static __device__ __attribute__((noinline)) bool group_pass_dev(const MatchIn* i
 // (no candidate under S), [2] went through the exact path, [3] won by an offer touched earlier in the round, [4] won by an
 // untouched offer (a new touched lane), [5] walked and unmatched, [6] sum of touched lanes at decision time, [7] won by the very
 // lane that took the previous walked job
-inline unsigned long long g_walk_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+inline unsigned long long g_walk_stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [8] decided by the fast path
 inline int g_walk_prev_lane = -1;  // lane that took the previous walked job of the round ([7]: a touched offer won AND it is that lane)
 #define WALK_STAT(i, v) do { if (lane == 0) g_walk_stats[i] += (v); } while (0)
 #else
@@ -708,8 +709,8 @@ inline int g_walk_prev_lane = -1;  // lane that took the previous walked job of 
 #endif
 
 struct ResolveLds {
-  JobL job[MV_WMAX];
-  EntL ent[MV_WMAX][MV_L];
+  JobL job[MV_WMAX];          // the jobs the walk visits, in rank order (walk position i; JobL::b = window position)
+  EntL ent[MV_WMAX][MV_L];    // their candidate lists, by walk position
   GEntL gent[MV_WMAX][MV_LG];
   SlotRec slot[MV_S];
   unsigned long long col[MV_S][MV_JG];
@@ -721,10 +722,10 @@ struct ResolveLds {
   int tacount[MV_T];                // would stall later s_waitcnt vmcnt(0) on its acknowledgement
   int ridx[MV_RWAVES_MAX], rge[MV_RWAVES_MAX];
   unsigned rc[MV_RWAVES_MAX][3];
+  unsigned vbase[MV_JG + 1];        // walk position of the first visited job of each 64-job group
   unsigned nslots, minbad;
   int cmd;                          // window index of the job to re-evaluate, -1 = the walk is over
   unsigned short hslot[MV_HASH];
-  unsigned short list[MV_WMAX];     // the jobs the walk has to visit, in rank order
   unsigned char slot_lane[MV_S];
   unsigned char fail[MV_WMAX];
 };
@@ -732,6 +733,17 @@ struct ResolveLds {
 // One round of the window walk by ONE workgroup of MV_RTHREADS threads (all of them must call it).
 // REEVAL compiles the in-place re-evaluation of list-exhausted jobs in (match_algo 3); without it the helper waves leave after
 // the set-up phase and the walk loop carries none of that machinery (it cost the default path ~10 % of the walk).
+//
+// The walk is one dependent chain run by a single wave, so what it costs per job is latency: measured on MI355X
+// (scripts/ubench_wave.hip) a dependent LDS read is 60-68 cycles, a 6-step DPP reduction 166 (compiler form), a ballot -> ffs ->
+// readlane hop 62, a wave-uniform branch ~25, against 48 for the fp64 evaluation of a touched offer itself.  The loop is
+// therefore organised as (1) a two-deep software pipeline over walk records that are laid out by WALK position (no dependent
+// address chain: record and list entries of job i+2 and the owner look-up of job i+1 are in flight while job i is decided),
+// (2) a FAST PATH for the common job — no constrained group, good-enough disabled, finite positive fitness values — that
+// orders the touched offers by an fp32 image of the approximate fitness (one hand-placed DPP reduction, common.hpp) and falls
+// back to (3) the GENERAL PATH below it whenever the order is not certain at fp32 resolution (two touched offers within 2^-20,
+// touched and untouched best within 2^-38), the job is unmatched, or anything unusual is involved.  Both paths produce the same
+// decision; only the general path knows every rule.
 template <bool REEVAL>
 static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) {
   ResolveLds& L = *reinterpret_cast<ResolveLds*>(lds);
@@ -745,8 +757,8 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   auto& s_hslot = L.hslot;
   auto& s_j2o = L.j2o;
   auto& s_fail = L.fail;
-  auto& s_list = L.list;
   auto& s_visit = L.visit;
+  auto& s_vbase = L.vbase;
   unsigned& s_nslots = L.nslots;
   unsigned& s_minbad = L.minbad;
   auto& s_tac = L.tac;
@@ -767,6 +779,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   const unsigned nwin = wend - head;
   const double good_enough = vb.in_dev->good_enough;
   const bool use_ge = good_enough < 1.0;
+  const uint32_t* const j_index = vb.in_dev->j_index;
   // ---- set-up phase (all threads): stage the window in LDS -------------------------------------------------------------
   for (unsigned x = tid; x < MV_HASH; x += NT) s_hkey[x] = -1;
   if (tid < MV_JG) s_visit[tid] = 0ull;
@@ -775,39 +788,60 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     s_minbad = 0xFFFFFFFFu;
   }
   __syncthreads();
+  // A job without any feasible offer under S stays unmatched whatever the jobs before it do (placements only take
+  // capacity away; constrained groups excepted), and its failure summary cannot change when every class it reports is
+  // backed by more offers than a round can touch: such jobs are settled here, in parallel, and the walk skips them.
   for (unsigned b = tid; b < nwin; b += NT) {
-    const JobRec j = vb.jr[head + b];
+    const unsigned flags = vb.jr[head + b].flags;
     const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
     const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
-    JobL r;
-    r.c = j.c;
-    r.m = j.m;
-    const bool grouped = (j.flags & JF_GROUPED) != 0;
-    r.info = (info & 0xFFFFu) | (j.g > 0 ? JL_GPU : 0u) | (grouped ? JL_GROUPED : 0u) | (((j.flags >> 8) & 3u) << 18);
-    r.group = j.group;
-    r.f1 = (unsigned short)(c1 < 0xFFFFu ? c1 : 0xFFFFu);
-    r.f2 = (unsigned short)(c2 < 0xFFFFu ? c2 : 0xFFFFu);
-    r.f4 = (unsigned short)(c4 < 0xFFFFu ? c4 : 0xFFFFu);
-    r.pad = 0;
-    s_job[b] = r;
-    // A job without any feasible offer under S stays unmatched whatever the jobs before it do (placements only take
-    // capacity away; constrained groups excepted), and its failure summary cannot change when every class it reports is
-    // backed by more offers than a round can touch: such jobs are settled here, in parallel, and the walk skips them.
+    const bool grouped = (flags & JF_GROUPED) != 0;
     const bool trivial = (info & 0xFFFFu) == 0u && !grouped && c1 > 0u && (c2 == 0u || c2 > (unsigned)MV_T) &&
                          (c4 == 0u || c4 > (unsigned)MV_T);
     if (trivial) {
       s_j2o[b] = -1;
       s_fail[b] = (unsigned char)(1u | (c2 ? 2u : 0u) | (c4 ? 4u : 0u));
     } else {
+      s_fail[b] = 0;  // a visited job that gets matched leaves it at that
       atomicOr(&s_visit[b >> 6], 1ull << (b & 63u));
     }
   }
-  // candidate lists of the whole window -> LDS (one parallel pass; the slot-table passes below then never touch HBM)
+  __syncthreads();
+  if (tid == 0) {
+    unsigned acc = 0;
+    for (unsigned g = 0; g < (unsigned)MV_JG; ++g) {
+      s_vbase[g] = acc;
+      acc += (unsigned)__popcll(s_visit[g]);
+    }
+    s_vbase[MV_JG] = acc;
+  }
+  __syncthreads();
+  const unsigned n_list = s_vbase[MV_JG];  // jobs the walk has to visit
+  // walk records + candidate lists of the visited jobs -> LDS, by walk position (one parallel pass; the slot-table passes below
+  // then never touch HBM)
   constexpr int EPJ = MV_L + MV_LG;
-  for (unsigned e = tid; e < nwin * EPJ; e += NT) {
-    const unsigned b = e / EPJ, q = e % EPJ;
+  for (unsigned e = tid; e < nwin * (EPJ + 1); e += NT) {
+    const unsigned b = e / (EPJ + 1), q = e % (EPJ + 1);
+    const unsigned long long vw = s_visit[b >> 6];
+    if (!((vw >> (b & 63u)) & 1ull)) continue;
+    const unsigned i = s_vbase[b >> 6] + (unsigned)__popcll(vw & ((1ull << (b & 63u)) - 1ull));
     const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
-    if (q < (unsigned)MV_L) {
+    if (q == (unsigned)EPJ) {
+      const JobRec j = vb.jr[head + b];
+      const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
+      JobL r;
+      r.c = j.c;
+      r.m = j.m;
+      const bool grouped = (j.flags & JF_GROUPED) != 0;
+      r.info = (info & 0xFFFFu) | (j.g > 0 ? JL_GPU : 0u) | (grouped ? JL_GROUPED : 0u) | (((j.flags >> 8) & 3u) << 18) |
+               (j.group != 0xFFFFFFFFu ? JL_HASGROUP : 0u);
+      r.group = j.group;
+      r.f1 = (unsigned short)(c1 < 0xFFFFu ? c1 : 0xFFFFu);
+      r.f2 = (unsigned short)(c2 < 0xFFFFu ? c2 : 0xFFFFu);
+      r.f4 = (unsigned short)(c4 < 0xFFFFu ? c4 : 0xFFFFu);
+      r.b = (unsigned short)b;
+      s_job[i] = r;
+    } else if (q < (unsigned)MV_L) {
       EntL x;
       x.fit = -1.0;
       x.off = -1;
@@ -817,28 +851,28 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         x.off = vb.cand_idx[(size_t)b * MV_L + q];
         x.fit = vb.cand_fit[(size_t)b * MV_L + q];
       }
-      s_ent[b][q] = x;
+      s_ent[i][q] = x;
     } else {
       GEntL x;
       x.off = -1;
       x.slot = 0;
       x.pad = 0;
       if (use_ge && q - MV_L < ((info >> 8) & 0xFFu)) x.off = vb.ge_idx[(size_t)b * MV_LG + (q - MV_L)];
-      s_gent[b][q - MV_L] = x;
+      s_gent[i][q - MV_L] = x;
     }
   }
   __syncthreads();
   // slot table = the DISTINCT candidate offers.  Optimistic pass: insert every entry of the window at once; if the table
-  // overflows (rare) redo it MV_JSTEP jobs at a time so that the overflow cuts the window at a job boundary (every job
+  // overflows (rare) redo it MV_JSTEP jobs at a time so that the overflow cuts the walk at a job boundary (every job
   // before the cut has all its candidates staged).
   for (int pass = 0; pass < 2; ++pass) {
-    const unsigned step = pass == 0 ? nwin : (unsigned)MV_JSTEP;
+    const unsigned step = pass == 0 ? (n_list ? n_list : 1u) : (unsigned)MV_JSTEP;
     bool overflow = false;
-    for (unsigned s0 = 0; s0 < nwin; s0 += step) {
-      const unsigned e1 = ((s0 + step < nwin) ? s0 + step : nwin) * EPJ;
+    for (unsigned s0 = 0; s0 < n_list; s0 += step) {
+      const unsigned e1 = ((s0 + step < n_list) ? s0 + step : n_list) * EPJ;
       for (unsigned e = s0 * EPJ + tid; e < e1; e += NT) {
-        const unsigned b = e / EPJ, q = e % EPJ;
-        const int idx = q < (unsigned)MV_L ? s_ent[b][q].off : s_gent[b][q - MV_L].off;
+        const unsigned i = e / EPJ, q = e % EPJ;
+        const int idx = q < (unsigned)MV_L ? s_ent[i][q].off : s_gent[i][q - MV_L].off;
         if (idx < 0) continue;
         unsigned h = ((unsigned)idx * 2654435761u) % MV_HASH;
         for (;;) {
@@ -872,17 +906,17 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     }
     __syncthreads();
   }
-  const unsigned weff = s_minbad < nwin ? s_minbad : nwin;  // jobs resolvable in this round
-  for (unsigned e = tid; e < weff * EPJ; e += NT) {  // candidate offer -> slot
-    const unsigned b = e / EPJ, q = e % EPJ;
-    const int idx = q < (unsigned)MV_L ? s_ent[b][q].off : s_gent[b][q - MV_L].off;
+  const unsigned n_eff = s_minbad < n_list ? s_minbad : n_list;  // walk positions resolvable in this round
+  for (unsigned e = tid; e < n_eff * EPJ; e += NT) {  // candidate offer -> slot
+    const unsigned i = e / EPJ, q = e % EPJ;
+    const int idx = q < (unsigned)MV_L ? s_ent[i][q].off : s_gent[i][q - MV_L].off;
     if (idx < 0) continue;
     unsigned h = ((unsigned)idx * 2654435761u) % MV_HASH;
     while (s_hkey[h] != idx) h = (h + 1) % MV_HASH;
     if (q < (unsigned)MV_L)
-      s_ent[b][q].slot = s_hslot[h];
+      s_ent[i][q].slot = s_hslot[h];
     else
-      s_gent[b][q - MV_L].slot = s_hslot[h];
+      s_gent[i][q - MV_L].slot = s_hslot[h];
   }
   const unsigned nslots = s_nslots < (unsigned)MV_S ? s_nslots : (unsigned)MV_S;
   for (unsigned s = tid; s < nslots; s += NT) {
@@ -988,22 +1022,11 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     return;
   }
   // wave 0 walks the window
-  // the jobs to visit, compacted in rank order
-  unsigned n_list = 0;
-  for (unsigned g = 0; g * COOK_WAVE < weff; ++g) {
-    unsigned long long mk = s_visit[g];
-    if (weff - g * COOK_WAVE < COOK_WAVE) mk &= (1ull << (weff - g * COOK_WAVE)) - 1ull;
-    if ((mk >> lane) & 1ull) s_list[n_list + (unsigned)__popcll(mk & lanemask_lt())] = (unsigned short)(g * COOK_WAVE + lane);
-    n_list += (unsigned)__popcll(mk);
-  }
-  wave_sync();
   const unsigned long long tk1 = cook_ticks();
   // ---- sequential phase ---------------------------------------------------------------------------------------------------
-  // The walk is one dependent chain and a single wave issues one instruction at a time, so its cost per job is its
-  // instruction count.  Lanes own the offers touched in this round (state in registers).  Everything a job needs from LDS
-  // is fetched one job ahead; cross-lane traffic is ballots, v_readlane and one DPP max-reduction (no ds_bpermute);
-  // fitness values are first compared through a reciprocal-multiply approximation (relative error < 2^-50) and the two
-  // fp64 divides are only executed when candidates are closer than 2^-38 relative — exactness is unaffected.
+  // Lanes own the offers touched in this round (state in registers).  Cross-lane traffic is ballots, v_readlane and DPP
+  // reductions (no ds_bpermute); fitness values are first compared through a reciprocal-multiply approximation (relative error
+  // < 2^-50) and the two fp64 divides are only executed when candidates are closer than 2^-38 relative — exactness is unaffected.
   int t_slot = -1, t_v = -1;
   double t_oc = 0, t_om = 0, t_rc = 0, t_rm = 0, t_invc = 0, t_invm = 0;
   double t_ac = 0, t_am = 0, t_basec = 0, t_basem = 0;
@@ -1014,249 +1037,395 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   unsigned nT = 0;
   unsigned stop = 0;  // 1 list exhausted, 2 touched set full, 3 group barrier, 4 slot table cut the window
   unsigned matched = 0, head_matched = ctl.head_matched;
-  unsigned resolved = weff;
+  unsigned resolved = n_eff < n_list ? (unsigned)s_job[n_eff].b : nwin;
   unsigned nslots_cur = nslots;  // slots staged so far (re-evaluations may add some)
   unsigned n_exhaust = 0;        // jobs whose list ran out and were re-evaluated
   constexpr double EPS_HI = 1.0 + 0x1p-38, EPS_LO = 1.0 - 0x1p-38;
-  struct JobRegs {
-    unsigned b;
+  struct JobRegs {   // exactly what the LDS loads deliver: nothing is decoded before the job's own iteration (a decode right after
+                     // the load would wait for it)
     double c, m;
     unsigned info, group;
-    EntL e;          // list entry `lane` (lanes >= MV_L idle)
-    unsigned owner;  // lane owning e.slot, 0xFF untouched, 0xFE no entry
-    bool no_zero_fit;  // no offer had zero fitness for this job under S
+    unsigned f4b;      // JobL::f4 | JobL::b << 16
+    double e_fit;      // list entry `lane` (lanes >= MV_L: none)
+    int e_off;
+    unsigned e_slotw;  // EntL::slot | pad << 16
+    unsigned owner;    // lane owning the entry's slot, 0xFF untouched, 0xFE no entry
   };
-  auto load_job = [&](unsigned i) {
+  // record + list entry of walk position i: addresses depend on i only, so the loads of job i+2 are issued two iterations
+  // ahead and nothing waits for them (OPAQUE_V: see common.hpp)
+  auto load_rec = [&](unsigned i) {
     JobRegs r;
-    r.b = i < n_list ? s_list[i] : 0u;
-    const JobL j = s_job[r.b];
-    r.c = j.c;
-    r.m = j.m;
-    r.info = j.info;
-    r.group = j.group;
-    r.no_zero_fit = j.f4 == 0;
-    r.e.fit = -1.0;
-    r.e.off = -1;
-    r.e.slot = 0;
-    r.e.pad = 0;
+    unsigned ii = i < n_eff ? i : 0u;
+    OPAQUE_V(ii);
+    const JobL* jp = &s_job[ii];
+    r.c = jp->c;
+    r.m = jp->m;
+    r.info = jp->info;
+    r.group = jp->group;
+    r.f4b = *reinterpret_cast<const unsigned*>(&jp->f4);
+    r.e_fit = -1.0;
+    r.e_off = -1;
+    r.e_slotw = 0;
     r.owner = 0xFEu;
     if (lane < (unsigned)MV_L) {
-      r.e = s_ent[r.b][lane];
-      if (r.e.off >= 0) r.owner = s_slot_lane[r.e.slot];
+      const EntL* ep = &s_ent[ii][lane];
+      r.e_fit = ep->fit;
+      r.e_off = ep->off;
+      r.e_slotw = *reinterpret_cast<const unsigned*>(&ep->slot);
     }
     return r;
   };
-  JobRegs nxt = load_job(0);
-  for (unsigned i = 0; i < n_list; ++i) {
+  // the owner look-up needs the entry's slot: issued one iteration ahead (a commit in between patches it, see below)
+  auto load_owner = [&](JobRegs& r) {
+    if (lane < (unsigned)MV_L && r.e_off >= 0) r.owner = s_slot_lane[r.e_slotw & 0xFFFFu];
+  };
+  JobRegs cur = load_rec(0);
+  load_owner(cur);
+  JobRegs nxt = load_rec(1);
+  WAIT_LDS();  // nothing pending at loop entry either (the loop's own waits sit at the END of its iterations)
+  for (unsigned i = 0; i < n_eff; ++i) {
     EMU_SITE("resolve: walk loop");
 #ifdef COOK_WALK_PROF
     const unsigned long long pk0 = __builtin_readcyclecounter();
     unsigned pcat = 0;
+#define WALK_END(cat)                                                \
+  do {                                                               \
+    const unsigned long long pk1_ = __builtin_readcyclecounter();    \
+    ctl.prof_cyc[cat] += pk1_ - pk0;                                 \
+    ctl.prof_cnt[cat] += 1u;                                         \
+  } while (0)
+#else
+    unsigned pcat = 0;
+    (void)pcat;
+#define WALK_END(cat) ((void)0)
 #endif
-    const JobRegs cur = nxt;
-    nxt = load_job(i + 1);
-    const unsigned b = cur.b, k = head + b, bl = b & 63u;
+    JobRegs nn = load_rec(i + 2);  // in flight while job i is decided
+    load_owner(nxt);
+    const unsigned cinfo_u = wave_uniform_u32(cur.info), cb_u = wave_uniform_u32(cur.f4b) >> 16;
+    const bool cur_no_zero_fit = (wave_uniform_u32(cur.f4b) & 0xFFFFu) == 0u;  // no offer had zero fitness for this job under S
+    const unsigned cur_slot = cur.e_slotw & 0xFFFFu;
+    const unsigned b = cb_u, k = head + b, bl = b & 63u;
     const double c = cur.c, m = cur.m;
-    const bool grouped = (cur.info & JL_GROUPED) != 0;
-    const bool job_gpu = (cur.info & JL_GPU) != 0;
-    const unsigned g = cur.group, gtype = (cur.info >> 18) & 3u;
-    const int nc = (int)(cur.info & 0xFFu);
+    const bool grouped = (cinfo_u & JL_GROUPED) != 0;
+    const bool job_gpu = (cinfo_u & JL_GPU) != 0;
+    const bool has_group = (cinfo_u & JL_HASGROUP) != 0;
+    const unsigned g = has_group ? wave_uniform_u32(cur.group) : 0xFFFFFFFFu, gtype = (cinfo_u >> 18) & 3u;
+    const int nc = (int)(cinfo_u & 0xFFu);
     if ((b >> 6) != cur_g) {  // next 64-job group: the touched lanes fetch their colbits word
       cur_g = b >> 6;
       if (t_slot >= 0) t_col = s_col[t_slot][cur_g];
+      WAIT_LDS();
     }
-    unsigned jj = 0;
-    bool gok = true;
-    if (grouped) {
-      jj = vb.in_dev->j_index ? vb.in_dev->j_index[k] : k;
-      // a second member of a balanced / attribute-equals group after one was placed in this round: re-snapshot first
-      if (gtype >= 2 && ld_agent(&st.group_last[g]) >= (int)head) {
-        stop = 3;
-        resolved = b;
-        break;
-      }
-      if (t_slot >= 0) gok = group_pass_dev(vb.in_dev, st, jj, (unsigned)t_v);
-    }
-    // every touched offer re-evaluated under the current state: verdict + approximate fitness
     const bool t_on = t_slot >= 0;
-    const bool res_ok = t_on && !(t_ac + c > t_oc || t_am + m > t_om);
-    bool con_ok = ((t_col >> bl) & 1ull) != 0 && t_acount < t_slack && gok;
-    if (job_gpu && t_k8s && t_run + t_acount != 0) con_ok = false;
-    const double nc_ = t_basec + c, nm_ = t_basem + m;  // (rc + ac) + c, (rm + am) + m
-    const double a1 = nc_ * t_invc, a2 = nm_ * t_invm;
-    const double fa = (a1 + a2) * 0.5;
-    const bool cand = res_ok && con_ok;
-    // the approximation is trusted for ordering only when both terms are non-negative and the result is positive
-    const bool sane = a1 >= 0.0 && a2 >= 0.0 && fa > 0.0;
-    bool need_exact = use_ge || __any(cand && !sane);
-    const unsigned long long cand_mask = __ballot(cand);
-    bool exhausted = false;  // the job's list ran out: re-evaluate it against the current state (below)
-    double u_fit = -1.0;     // best untouched candidate: fitness under S, offer, slot
-    int u_off = -1, u_slot = -1;
-    int win = -1, win_slot = -1, win_lane = -1;  // win_lane >= 0: a touched offer wins
-    bool decided = false;
-    unsigned pe_bits = 8u;  // exact verdict of this lane's offer (only when the exact path ran)
-    double pe_fit = 0.0;
-    do {
-      // No feasible offer under S, no zero-fitness offer, no constrained group: placements only take capacity away and the
-      // job's constraints can only get worse on a touched offer, so it stays unmatched whatever happened in this round;
-      // only its failure summary may change (handled below from the touched offers' current verdicts).
-      WALK_STAT(0, 1);
-      WALK_STAT(6, nT);
-      if (nc == 0 && !grouped && cur.no_zero_fit) {
-        WALK_STAT(1, 1);
-        break;
+    // ======== FAST PATH ======================================================================================================
+    // self-contained: decision AND commit, then straight on to the next job (its control flow never joins the general path's)
+    if (!(cinfo_u & (JL_GROUPED | JL_HASGROUP)) && !use_ge) {
+      const bool res_ok = t_on && !(t_ac + c > t_oc || t_am + m > t_om);
+      bool con_ok = ((t_col >> bl) & 1ull) != 0 && t_acount < t_slack;
+      if (job_gpu && t_k8s && t_run + t_acount != 0) con_ok = false;
+      const double a1 = (t_basec + c) * t_invc, a2 = (t_basem + m) * t_invm;
+      const double fa = (a1 + a2) * 0.5;
+      const bool cand = res_ok && con_ok;
+      // fp32 image of the approximate fitness: monotone in fa; a candidate whose approximation cannot be trusted for ordering
+      // (negative terms, zero, below fp32's normal range) takes +inf, which sends the job to the general path
+      const bool sane = a1 >= 0.0 && a2 >= 0.0 && fa > 0x1p-100;
+      const float kf = cand ? (sane ? (float)fa : __int_as_float(0x7F800000)) : 0.0f;
+      const float mx = wave_max_f32(kf);
+      // first untouched entry of the list: the best untouched offer under S (a touched entry that is still feasible and sits in
+      // front of it only gained fitness: it beats this one in the comparison below, so "first untouched" is all the list has to give)
+      const unsigned long long untouched_mask = __ballot(cur.owner == 0xFFu);
+      double u_fit = -1.0;
+      int u_off = -1, u_slot = -1;
+      if (untouched_mask != 0ull) {
+        const int qs = __ffsll((unsigned long long)untouched_mask) - 1;
+        u_fit = wave_read_lane_f64(cur.e_fit, qs);
+        u_off = wave_read_lane(cur.e_off, qs);
+        u_slot = wave_read_lane((int)cur_slot, qs);
       }
-      // --- arg-max path: first list entry that is untouched, or touched and still a candidate -------------------------------
-      // (a touched offer that is still feasible only gained fitness, so it dominates every untouched offer behind it; a
-      //  zero-fitness verdict cannot appear on an offer that was feasible under S)
-      const bool e_valid = cur.owner != 0xFEu;
-      const bool e_untouched = cur.owner == 0xFFu;
-      const bool e_live = e_valid && !e_untouched && ((cand_mask >> (cur.owner & 63u)) & 1ull);
-      const unsigned long long settle_mask = __ballot(e_untouched || e_live), untouched_mask = __ballot(e_untouched);
-      if (settle_mask == 0ull && nc == MV_L) {
-        exhausted = true;
-        break;
-      }
-      if (settle_mask != 0ull) {
-        const int qs = __ffsll((unsigned long long)settle_mask) - 1;
-        if ((untouched_mask >> qs) & 1ull) {
-          u_fit = wave_read_lane_f64(cur.e.fit, qs);
-          u_off = wave_read_lane(cur.e.off, qs);
-          u_slot = wave_read_lane((int)cur.e.slot, qs);
-        }
-      }
-      // --- best touched candidate ----------------------------------------------------------------------------------------------
-      if (!need_exact) {
-        if (cand_mask == 0ull) {
-          win = u_off;
-          win_slot = u_slot;
-          decided = true;
-        } else {
-          const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(fa) : 0ull;  // positive doubles
-          const double mx = __longlong_as_double((long long)wave_max_u64(key));
-          const unsigned long long near = __ballot(cand && fa >= mx * EPS_LO);
-          if ((near & (near - 1ull)) == 0ull) {  // one touched offer clearly ahead of the other touched ones
-            if (u_off < 0 || mx * EPS_LO > u_fit) {
-              win_lane = __ffsll((unsigned long long)near) - 1;
-              decided = true;
-            } else if (mx * EPS_HI < u_fit) {
-              win = u_off;
-              win_slot = u_slot;
-              decided = true;
+      int f_lane = -1;      // >= 0: that touched offer wins
+      bool f_new = false;   // the untouched offer (u_off, u_slot) wins
+      if (mx == 0.0f) {  // no touched offer can take the job
+        f_new = u_off >= 0;  // else: unmatched or list exhausted -> general path
+      } else if (mx < __int_as_float(0x7F800000)) {
+        const unsigned long long near = __ballot(kf >= mx * (1.0f - 0x1p-20f));
+        if ((near & (near - 1ull)) == 0ull) {  // one touched offer clearly ahead of the other touched ones
+          const int wl = __ffsll((unsigned long long)near) - 1;
+          const double fw = wave_read_lane_f64(fa, wl);
+          if (u_off < 0) {
+            // no untouched entry: fine unless the list is full and none of its entries is still a candidate (then better
+            // untouched offers may exist beyond the list: exhausted, general path)
+            bool ok = nc < MV_L;
+            if (!ok) {
+              const unsigned long long cand_mask = __ballot(cand);
+              const bool e_live = cur.owner < 0xFEu && ((cand_mask >> (cur.owner & 63u)) & 1ull);
+              ok = __any(e_live);
             }
+            if (ok) f_lane = wl;
+          } else if (fw * EPS_LO > u_fit) {
+            f_lane = wl;
+          } else if (fw * EPS_HI < u_fit) {
+            f_new = true;
           }
-          if (!decided) need_exact = true;
         }
       }
-      if (need_exact) {
-        WALK_STAT(2, 1);
-        if (t_on) {
-          pe_bits = 0u;
-          if (!res_ok) {
-            pe_bits = 1u;
-          } else if (!con_ok) {
-            pe_bits = 2u;
-          } else {
-            pe_fit = (nc_ / (t_oc + t_rc) + nm_ / (t_om + t_rm)) / 2.0;
-            if (!(pe_fit > 0.0)) pe_bits = 4u;
-          }
+      if (f_lane >= 0) {  // an offer touched earlier in this round takes the job
+        if ((int)lane == f_lane) {
+          t_ac += c;
+          t_am += m;
+          t_acount += 1;
+          t_basec = t_rc + t_ac;
+          t_basem = t_rm + t_am;
         }
-        const bool t_feas = t_on && pe_bits == 0u;
-        const unsigned long long feas_mask = __ballot(t_feas);
-        // with exact verdicts a list entry settles only if its owner is still FEASIBLE (zero fitness excluded)
-        const bool e_live2 = e_valid && !e_untouched && ((feas_mask >> (cur.owner & 63u)) & 1ull);
-        const unsigned long long settle2 = __ballot(e_untouched || e_live2);
-        if (settle2 == 0ull && nc == MV_L) {
+        const int w = wave_read_lane(t_v, f_lane);
+        ++matched;
+        if (k == 0) head_matched = 1;
+        if (lane == 0) s_j2o[b] = w;  // (s_fail[b] = 0 since the set-up)
+        WALK_STAT(3, 1);
+        WALK_STAT(8, 1);
+        WALK_END(1u);
+        WAIT_LDS_BUT_LAST();  // the prefetches of this iteration have arrived (see common.hpp); the result store may still fly
+        cur = nxt;
+        nxt = nn;
+        continue;
+      }
+      if (f_new && nT < (unsigned)MV_T) {  // an untouched offer: the next free lane takes ownership
+        if (lane == nT) {
+          const SlotRec r = s_slot[u_slot];
+          t_slot = u_slot;
+          t_v = u_off;
+          t_oc = r.a.oc;
+          t_om = r.a.om;
+          t_rc = r.a.rc;
+          t_rm = r.a.rm;
+          t_invc = r.a.inv_dc;
+          t_invm = r.a.inv_dm;
+          t_k8s = r.o.flags & 1u;
+          t_run = r.o.run_count;
+          t_slack = r.o.task_slack;
+          t_ac = r.ac + c;
+          t_am = r.am + m;
+          t_acount = r.acount + 1;
+          t_basec = t_rc + t_ac;
+          t_basem = t_rm + t_am;
+          t_col = s_col[u_slot][cur_g];
+          s_slot_lane[u_slot] = (unsigned char)nT;
+        }
+        WAIT_LDS();
+        // the owner look-up of the next job was issued before this commit: patch it
+        if (nxt.owner == 0xFFu && (nxt.e_slotw & 0xFFFFu) == (unsigned)u_slot) nxt.owner = nT;
+        ++nT;
+        ++matched;
+        if (k == 0) head_matched = 1;
+        if (lane == 0) s_j2o[b] = u_off;
+        wave_sync();  // the owner table update is visible to the whole wave before the next look-up reads it
+        WALK_STAT(4, 1);
+        WALK_STAT(8, 1);
+        WALK_END(2u);
+        WAIT_LDS_BUT_LAST();
+        cur = nxt;
+        nxt = nn;
+        continue;
+      }
+    }
+    int win = -1, win_slot = -1, win_lane = -1;  // win_lane >= 0: a touched offer wins
+    bool need_exact = false;
+    bool exhausted = false;  // the job's list ran out: re-evaluate it against the current state (below)
+    unsigned pe_bits = 8u;   // exact verdict of this lane's offer (only when the exact path ran)
+    double pe_fit = 0.0;
+    unsigned jj = 0;
+    // values of the general path that the unmatched branch of the commit reads
+    bool res_ok_g = false, con_ok_g = false;
+    double nc_g = 0.0, nm_g = 0.0;
+    // ======== GENERAL PATH ===================================================================================================
+    {
+      bool gok = true;
+      if (grouped) {
+        jj = j_index ? j_index[k] : k;
+        // a second member of a balanced / attribute-equals group after one was placed in this round: re-snapshot first
+        if (gtype >= 2 && ld_agent(&st.group_last[g]) >= (int)head) {
+          stop = 3;
+          resolved = b;
+          break;
+        }
+        if (t_slot >= 0) gok = group_pass_dev(vb.in_dev, st, jj, (unsigned)t_v);
+      }
+      // every touched offer re-evaluated under the current state: verdict + approximate fitness
+      const bool res_ok = t_on && !(t_ac + c > t_oc || t_am + m > t_om);
+      bool con_ok = ((t_col >> bl) & 1ull) != 0 && t_acount < t_slack && gok;
+      if (job_gpu && t_k8s && t_run + t_acount != 0) con_ok = false;
+      const double nc_ = t_basec + c, nm_ = t_basem + m;  // (rc + ac) + c, (rm + am) + m
+      const double a1 = nc_ * t_invc, a2 = nm_ * t_invm;
+      const double fa = (a1 + a2) * 0.5;
+      const bool cand = res_ok && con_ok;
+      res_ok_g = res_ok, con_ok_g = con_ok, nc_g = nc_, nm_g = nm_;
+      // the approximation is trusted for ordering only when both terms are non-negative and the result is positive
+      const bool sane = a1 >= 0.0 && a2 >= 0.0 && fa > 0.0;
+      need_exact = use_ge || __any(cand && !sane);
+      const unsigned long long cand_mask = __ballot(cand);
+      double u_fit = -1.0;     // best untouched candidate: fitness under S, offer, slot
+      int u_off = -1, u_slot = -1;
+      bool decided = false;
+      do {
+        // No feasible offer under S, no zero-fitness offer, no constrained group: placements only take capacity away and the
+        // job's constraints can only get worse on a touched offer, so it stays unmatched whatever happened in this round;
+        // only its failure summary may change (handled below from the touched offers' current verdicts).
+        WALK_STAT(0, 1);
+        WALK_STAT(6, nT);
+        if (nc == 0 && !grouped && cur_no_zero_fit) {
+          WALK_STAT(1, 1);
+          break;
+        }
+        // --- arg-max path: first list entry that is untouched, or touched and still a candidate -------------------------------
+        // (a touched offer that is still feasible only gained fitness, so it dominates every untouched offer behind it; a
+        //  zero-fitness verdict cannot appear on an offer that was feasible under S)
+        const bool e_valid = cur.owner != 0xFEu;
+        const bool e_untouched = cur.owner == 0xFFu;
+        const bool e_live = e_valid && !e_untouched && ((cand_mask >> (cur.owner & 63u)) & 1ull);
+        const unsigned long long settle_mask = __ballot(e_untouched || e_live), untouched_mask = __ballot(e_untouched);
+        if (settle_mask == 0ull && nc == MV_L) {
           exhausted = true;
           break;
         }
-        u_fit = -1.0;
-        u_off = u_slot = -1;
-        if (settle2 != 0ull) {
-          const int qs = __ffsll((unsigned long long)settle2) - 1;
+        if (settle_mask != 0ull) {
+          const int qs = __ffsll((unsigned long long)settle_mask) - 1;
           if ((untouched_mask >> qs) & 1ull) {
-            u_fit = wave_read_lane_f64(cur.e.fit, qs);
-            u_off = wave_read_lane(cur.e.off, qs);
-            u_slot = wave_read_lane((int)cur.e.slot, qs);
+            u_fit = wave_read_lane_f64(cur.e_fit, qs);
+            u_off = wave_read_lane(cur.e_off, qs);
+            u_slot = wave_read_lane((int)cur_slot, qs);
           }
         }
-        // good-enough path: lowest offer index with fitness > good-enough (scheduler.clj:2312-2314)
-        int ge_pick = 0x7FFFFFFF, ge_slot = -1, ge_lane = -1;
-        if (use_ge) {
-          const int ng = (int)((cur.info >> 8) & 0xFFu);
-          GEntL ge;
-          ge.off = -1;
-          ge.slot = 0;
-          ge.pad = 0;
-          unsigned g_owner = 0xFEu;
-          if ((int)lane < ng) {
-            ge = s_gent[b][lane];
-            g_owner = s_slot_lane[ge.slot];
+        // --- best touched candidate ----------------------------------------------------------------------------------------------
+        if (!need_exact) {
+          if (cand_mask == 0ull) {
+            win = u_off;
+            win_slot = u_slot;
+            decided = true;
+          } else {
+            const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(fa) : 0ull;  // positive doubles
+            const double mx = __longlong_as_double((long long)wave_max_u64(key));
+            const unsigned long long near = __ballot(cand && fa >= mx * EPS_LO);
+            if ((near & (near - 1ull)) == 0ull) {  // one touched offer clearly ahead of the other touched ones
+              if (u_off < 0 || mx * EPS_LO > u_fit) {
+                win_lane = __ffsll((unsigned long long)near) - 1;
+                decided = true;
+              } else if (mx * EPS_HI < u_fit) {
+                win = u_off;
+                win_slot = u_slot;
+                decided = true;
+              }
+            }
+            if (!decided) need_exact = true;
           }
-          const unsigned long long gun = __ballot(g_owner == 0xFFu);
-          int last_idx = -1;
-          if (ng > 0) last_idx = wave_read_lane(ge.off, ng - 1);
-          if (gun != 0ull) {
-            const int q = __ffsll((unsigned long long)gun) - 1;
-            ge_pick = wave_read_lane(ge.off, q);
-            ge_slot = wave_read_lane((int)ge.slot, q);
+        }
+        if (need_exact) {
+          WALK_STAT(2, 1);
+          if (t_on) {
+            pe_bits = 0u;
+            if (!res_ok) {
+              pe_bits = 1u;
+            } else if (!con_ok) {
+              pe_bits = 2u;
+            } else {
+              pe_fit = (nc_ / (t_oc + t_rc) + nm_ / (t_om + t_rm)) / 2.0;
+              if (!(pe_fit > 0.0)) pe_bits = 4u;
+            }
           }
-          // lowest-index touched offer that is feasible with fitness > good-enough
-          const unsigned long long tkey = (t_feas && pe_fit > good_enough)
-                                              ? (((unsigned long long)(unsigned)(0x7FFFFFFF - t_v) << 32) | (unsigned long long)lane)
-                                              : 0ull;
-          const unsigned long long tmx = feas_mask != 0ull ? wave_max_u64(tkey) : 0ull;
-          const int tg = tmx != 0ull ? 0x7FFFFFFF - (int)(unsigned)(tmx >> 32) : 0x7FFFFFFF;
-          if (gun == 0ull && ng == MV_LG && tg > last_idx) {
-            // untouched good-enough offers beyond the list may exist with an index below the best touched one
+          const bool t_feas = t_on && pe_bits == 0u;
+          const unsigned long long feas_mask = __ballot(t_feas);
+          // with exact verdicts a list entry settles only if its owner is still FEASIBLE (zero fitness excluded)
+          const bool e_live2 = e_valid && !e_untouched && ((feas_mask >> (cur.owner & 63u)) & 1ull);
+          const unsigned long long settle2 = __ballot(e_untouched || e_live2);
+          if (settle2 == 0ull && nc == MV_L) {
             exhausted = true;
             break;
           }
-          if (tg < ge_pick) {
-            ge_pick = tg;
-            ge_lane = (int)(unsigned)(tmx & 63ull);
-          }
-        }
-        if (ge_pick != 0x7FFFFFFF) {
-          if (ge_lane >= 0) {
-            win_lane = ge_lane;
-          } else {
-            win = ge_pick;
-            win_slot = ge_slot;
-          }
-        } else {
-          // best touched (max fitness, lowest offer index on ties) vs best untouched
-          Cand best{-1.0, -1};
-          int best_lane = -1;
-          if (feas_mask != 0ull) {
-            const unsigned long long key = t_feas ? (unsigned long long)__double_as_longlong(pe_fit) : 0ull;
-            const unsigned long long mx = wave_max_u64(key);
-            unsigned long long tie = __ballot(t_feas && key == mx);
-            int wl = __ffsll((unsigned long long)tie) - 1;
-            int wv = wave_read_lane(t_v, wl);
-            tie &= tie - 1ull;
-            while (tie != 0ull) {  // equal fitness on several touched offers: the lowest offer index wins
-              const int l2 = __ffsll((unsigned long long)tie) - 1;
-              const int v2 = wave_read_lane(t_v, l2);
-              if (v2 < wv) {
-                wv = v2;
-                wl = l2;
-              }
-              tie &= tie - 1ull;
+          u_fit = -1.0;
+          u_off = u_slot = -1;
+          if (settle2 != 0ull) {
+            const int qs = __ffsll((unsigned long long)settle2) - 1;
+            if ((untouched_mask >> qs) & 1ull) {
+              u_fit = wave_read_lane_f64(cur.e_fit, qs);
+              u_off = wave_read_lane(cur.e_off, qs);
+              u_slot = wave_read_lane((int)cur_slot, qs);
             }
-            best = Cand{__longlong_as_double((long long)mx), wv};
-            best_lane = wl;
           }
-          if (u_off >= 0 && cand_better(Cand{u_fit, u_off}, best)) {
-            win = u_off;
-            win_slot = u_slot;
-          } else if (best_lane >= 0) {
-            win_lane = best_lane;
+          // good-enough path: lowest offer index with fitness > good-enough (scheduler.clj:2312-2314)
+          int ge_pick = 0x7FFFFFFF, ge_slot = -1, ge_lane = -1;
+          if (use_ge) {
+            const int ng = (int)((cinfo_u >> 8) & 0xFFu);
+            GEntL ge;
+            ge.off = -1;
+            ge.slot = 0;
+            ge.pad = 0;
+            unsigned g_owner = 0xFEu;
+            if ((int)lane < ng) {
+              ge = s_gent[i][lane];
+              g_owner = s_slot_lane[ge.slot];
+            }
+            const unsigned long long gun = __ballot(g_owner == 0xFFu);
+            int last_idx = -1;
+            if (ng > 0) last_idx = wave_read_lane(ge.off, ng - 1);
+            if (gun != 0ull) {
+              const int q = __ffsll((unsigned long long)gun) - 1;
+              ge_pick = wave_read_lane(ge.off, q);
+              ge_slot = wave_read_lane((int)ge.slot, q);
+            }
+            // lowest-index touched offer that is feasible with fitness > good-enough
+            const unsigned long long tkey = (t_feas && pe_fit > good_enough)
+                                                ? (((unsigned long long)(unsigned)(0x7FFFFFFF - t_v) << 32) | (unsigned long long)lane)
+                                                : 0ull;
+            const unsigned long long tmx = feas_mask != 0ull ? wave_max_u64(tkey) : 0ull;
+            const int tg = tmx != 0ull ? 0x7FFFFFFF - (int)(unsigned)(tmx >> 32) : 0x7FFFFFFF;
+            if (gun == 0ull && ng == MV_LG && tg > last_idx) {
+              // untouched good-enough offers beyond the list may exist with an index below the best touched one
+              exhausted = true;
+              break;
+            }
+            if (tg < ge_pick) {
+              ge_pick = tg;
+              ge_lane = (int)(unsigned)(tmx & 63ull);
+            }
+          }
+          if (ge_pick != 0x7FFFFFFF) {
+            if (ge_lane >= 0) {
+              win_lane = ge_lane;
+            } else {
+              win = ge_pick;
+              win_slot = ge_slot;
+            }
+          } else {
+            // best touched (max fitness, lowest offer index on ties) vs best untouched
+            Cand best{-1.0, -1};
+            int best_lane = -1;
+            if (feas_mask != 0ull) {
+              const unsigned long long key = t_feas ? (unsigned long long)__double_as_longlong(pe_fit) : 0ull;
+              const unsigned long long mx = wave_max_u64(key);
+              unsigned long long tie = __ballot(t_feas && key == mx);
+              int wl = __ffsll((unsigned long long)tie) - 1;
+              int wv = wave_read_lane(t_v, wl);
+              tie &= tie - 1ull;
+              while (tie != 0ull) {  // equal fitness on several touched offers: the lowest offer index wins
+                const int l2 = __ffsll((unsigned long long)tie) - 1;
+                const int v2 = wave_read_lane(t_v, l2);
+                if (v2 < wv) {
+                  wv = v2;
+                  wl = l2;
+                }
+                tie &= tie - 1ull;
+              }
+              best = Cand{__longlong_as_double((long long)mx), wv};
+              best_lane = wl;
+            }
+            if (u_off >= 0 && cand_better(Cand{u_fit, u_off}, best)) {
+              win = u_off;
+              win_slot = u_slot;
+            } else if (best_lane >= 0) {
+              win_lane = best_lane;
+            }
           }
         }
-      }
-    } while (0);
+      } while (0);
+    }
     // --- list exhausted: the whole workgroup evaluates this one job against the current state ---------------------------------
     int re_bits = -1;  // >= 0: the exact failure summary of an unmatched re-evaluated job
     if (exhausted) {
@@ -1352,7 +1521,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     }
 #endif
 #ifdef COOK_WALK_PROF
-    pcat = grouped ? 4u : (need_exact ? 5u : (win_lane >= 0 ? 1u : (win >= 0 ? 2u : ((nc == 0 && cur.no_zero_fit) ? 0u : 3u))));
+    pcat = grouped ? 4u : (win >= 0 || win_lane >= 0 ? 5u : 3u);
 #endif
     if (win_lane >= 0) {  // an offer touched earlier in this round takes the job
       if ((int)lane == win_lane) {
@@ -1390,10 +1559,11 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         t_col = s_col[win_slot][cur_g];
         s_slot_lane[win_slot] = (unsigned char)nT;
       }
-      // the entry of the next job was fetched before this commit: patch its owner
-      if (nxt.owner == 0xFFu && nxt.e.slot == (unsigned short)win_slot) nxt.owner = nT;
+      WAIT_LDS();
+      // the owner look-up of the next job was issued before this commit: patch it
+      if (nxt.owner == 0xFFu && (nxt.e_slotw & 0xFFFFu) == (unsigned)win_slot) nxt.owner = nT;
       ++nT;
-      wave_sync();  // the owner table update is visible to the whole wave before the next prefetch reads it
+      wave_sync();  // the owner table update is visible to the whole wave before the next look-up reads it
     }
     if (win >= 0) {
       ++matched;
@@ -1411,17 +1581,18 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     } else {
       // unmatched: failure summary = OR over offers of the first failing check under the CURRENT state.  Start from the
       // snapshot counts and swap each touched offer's snapshot verdict for its current one (exact verdicts needed).
-      const JobL jl = s_job[b];
+      // (only the general path gets here: the fast path never leaves a job unmatched)
+      const JobL jl = s_job[i];
       int d1 = 0, d2 = 0, d4 = 0;
       if (nT != 0) {  // wave-uniform
         if (pe_bits == 8u && t_on) {  // the exact path did not run for this job
           pe_bits = 0u;
-          if (!res_ok) {
+          if (!res_ok_g) {
             pe_bits = 1u;
-          } else if (!con_ok) {
+          } else if (!con_ok_g) {
             pe_bits = 2u;
           } else {
-            pe_fit = (nc_ / (t_oc + t_rc) + nm_ / (t_om + t_rm)) / 2.0;
+            pe_fit = (nc_g / (t_oc + t_rc) + nm_g / (t_om + t_rm)) / 2.0;
             if (!(pe_fit > 0.0)) pe_bits = 4u;
           }
         }
@@ -1457,15 +1628,12 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         s_fail[b] = (unsigned char)(bits ? bits : 8u);
       }
     }
-#ifdef COOK_WALK_PROF
-    {
-      const unsigned long long pk1 = __builtin_readcyclecounter();
-      ctl.prof_cyc[pcat] += pk1 - pk0;
-      ctl.prof_cnt[pcat] += 1u;
-    }
-#endif
+    WALK_END(pcat);
+    WAIT_ALL_MEM();
+    cur = nxt;
+    nxt = nn;
   }
-  if (stop == 0 && weff < nwin) stop = 4;
+  if (stop == 0 && n_eff < n_list) stop = 4;
   if constexpr (REEVAL) {
     if (lane == 0) s_cmd = -1;  // release the helper waves
     EMU_SITE("resolve: walker done");
@@ -1505,7 +1673,6 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     if (stop == 3) ctl.stop_group += 1;
     if (stop == 4) ctl.stop_slots += 1;
     if (stop == 0) ctl.stop_window += 1;
-    // adapt the window: aim at ~2x what a round resolves, within [64, wmax]
     // adapt the window: a multiple of what a round resolves (more = fewer rounds, less = fewer jobs evaluated twice)
     unsigned wn = stop == 0 ? ctl.wcur * 2 : (unsigned)(((unsigned long long)resolved * ctl.wgrow_pct + 99ull) / 100ull);
     if (wn < 64) wn = 64;

@@ -179,6 +179,8 @@ inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 inline long long __double_as_longlong(double d) { return emu::from_bits<long long>(emu::bits_of(d)); }
 inline double __longlong_as_double(long long v) { return emu::from_bits<double>(emu::bits_of(v)); }
 inline unsigned __lane_id() { return emu::lane(); }
+inline float __int_as_float(int v) { return emu::from_bits<float>(emu::bits_of(v)); }
+inline int __float_as_int(float v) { return emu::from_bits<int>(emu::bits_of(v)); }
 
 template <class T>
 inline T atomicAdd(T* p, T v) {
