@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--considerable", type=int, default=0, help="K per pool; 0 = all ranked pending jobs")
     ap.add_argument("--good-enough", type=float, default=1.0, help="1.0 = parity setting (zz_simulator.clj:84)")
     ap.add_argument("--no-constraints", action="store_true")
-    ap.add_argument("--match-algo", type=int, default=0, help="cook_params.match_algo: 0 default (window rounds, one launch per phase), 1 serial, 3 = default + in-place re-evaluation, 4 persistent kernel")
+    ap.add_argument("--match-algo", type=int, default=0, help="cook_params.match_algo: 0/2 window rounds with one launch per phase, 1 serial, 3 = 2 + in-place re-evaluation, 4 persistent kernel with grid barriers, 5 = ONE persistent launch for all pools of the rank (match_world)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-adjacent", action="store_true", help="skip the timings of the rows next to the hot path (offers, explain, metrics)")
@@ -54,7 +54,7 @@ def parse():
     return ap.parse_args()
 
 
-PLACEMENT_KERNELS = ("match_resolve2", "match_eval2", "match_merge2", "match_persist", "match_serial")
+PLACEMENT_KERNELS = ("match_world", "match_resolve2", "match_eval2", "match_merge2", "match_persist", "match_serial")
 
 
 def algorithmic_bytes(kernel, n_tasks, k, m, launches_per_match=1.0, pools_per_launch=1.0):

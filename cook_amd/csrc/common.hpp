@@ -15,7 +15,7 @@
 // On the GPU the 64 lanes of a wave run in lockstep and LDS operations of one wave retire in order, so this is a
 // compiler scheduling barrier only.  (tests/simt_emu runs lanes as independent fibers and maps it to a rendezvous.)
 #ifdef __HIP_EMU__
-static inline void wave_sync() { emu::arrive(emu::S().waves[emu::wave()]); }
+static inline void wave_sync() { emu::arrive(emu::wave_group()); }
 #else
 static __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -29,12 +29,53 @@ static __device__ __forceinline__ void wave_sync() {
 template <class T>
 static inline T ld_agent(const T* p) { return *p; }
 template <class T>
-static inline void st_agent(T* p, T v) { *p = v; }
+static inline void st_agent(T* p, T v) { *p = v; emu::progress(); }
 #else
 template <class T>
 static __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T>
 static __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
+// ---- cross-workgroup hand-off inside one launch (the persistent placement kernel, match_world.hpp) ---------------------------------
+// The tested forms of MI355X_MICROARCH.md: producer = plain stores -> agent_release() -> relaxed agent-scope flag store;
+// consumer = relaxed poll of the flag -> ONE agent_acquire() -> plain loads.  The inline-asm wait is deliberate: ROCm 7.2 drops the
+// s_waitcnt after buffer_wbl2 when it can prove the wave's vmcnt scoreboard empty, and the flag then overtakes the write-back.
+#ifdef __HIP_EMU__
+static inline void agent_release() {}
+static inline void agent_acquire() {}
+static inline void drain_stores() {}
+template <class T>
+static inline T ld_wg(const T* p) { return *p; }
+template <class T>
+static inline void st_wg(T* p, T v) { *p = v; emu::progress(); }
+#define SPIN_PAUSE() emu::yield()
+#define SPIN_PAUSE_SHORT() emu::yield()
+static inline void lds_release() {}
+static inline void lds_acquire() {}
+#define COOK_BLOCK_LDS(name, bytes) char* name = emu::block_lds(bytes)
+#define COOK_LAUNCH_COOP(kernel, grid, block, stream, ...) emuLaunchCoop(kernel, grid, block, __VA_ARGS__)
+#else
+static __device__ __forceinline__ void agent_release() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+static __device__ __forceinline__ void agent_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// after write-through (sc1) stores: once the wave's store counter drains they are in memory — no L2 write-back fence needed
+static __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// LDS words that waves of one workgroup exchange WITHOUT a barrier (the poller's mirror of the phase words)
+template <class T>
+static __device__ __forceinline__ T ld_wg(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <class T>
+static __device__ __forceinline__ void st_wg(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
+#define SPIN_PAUSE_SHORT() __builtin_amdgcn_s_sleep(1)
+// LDS hand-off between waves of one workgroup without a workgroup barrier (the evaluator teams' barrier)
+static __device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+static __device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#define COOK_BLOCK_LDS(name, bytes) __shared__ __attribute__((aligned(16))) char name[bytes]
+// every workgroup of the grid must be resident at once; the host sizes the grid for that (one workgroup per CU)
+#define COOK_LAUNCH_COOP(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #endif
 
 // constant-rate (100 MHz) device clock for in-kernel phase timing

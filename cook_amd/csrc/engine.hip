@@ -17,6 +17,7 @@
 #include "considerable_kernels.hpp"
 #include "match_kernels.hpp"
 #include "match_v2.hpp"
+#include "match_world.hpp"
 #include "offers_kernels.hpp"
 #include "explain_kernels.hpp"
 #include "rank_kernels.hpp"
@@ -151,9 +152,10 @@ struct cook_engine {
   DArr<JobRec> v_jr;
   DArr<JobCons> v_jcons;
   DArr<unsigned long long> m_alive, m_jmin;
-  DArr<double> v_pfit, v_cand_fit;
-  DArr<int> v_pidx, v_pge, v_cand_idx, v_ge_idx;
-  DArr<uint32_t> v_pcnt, v_cinfo;
+  DArr<double> v_cand_fit;
+  DArr<ChunkRec> v_prec;
+  DArr<int> v_cand_idx, v_ge_idx;
+  DArr<uint32_t> v_cinfo;
   DArr<uint64_t> v_colbits;
   DArr<WinCtl> w_ctl;
   DArr<RoundLog> w_rlog;
@@ -164,6 +166,10 @@ struct cook_engine {
   WinCtl deferred_c0{};
   WinCtl* h_multi = nullptr;  // pinned: the pools' WinCtl read-backs
   DArr<PersistCtl> w_pctl;
+  DArr<WorldPool> w_wpool;   // persistent multi-pool placement (match_world.hpp), led by this engine
+  DArr<WorldCtl> w_wctl;
+  unsigned world_runs = 0, world_fallbacks = 0;
+  unsigned long long world_wait_eval = 0, world_wait_merge = 0;  // pool 0's walker, last run (100 MHz ticks)
   int n_cus = 256;
   unsigned last_persistent = 0, persist_fallbacks = 0;
   DArr<MatchIn> v_in;
@@ -781,6 +787,8 @@ void match_init_state(cook_engine* e, const MatchState& st, unsigned K, unsigned
 }
 
 void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, const WinCtl& hc, hipStream_t stream);
+void match_rounds_multi(cook_engine** es, unsigned n);
+bool match_rounds_world(cook_engine** es, unsigned n);
 
 void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool defer = false) {
   MatchIn in = e->min;
@@ -807,7 +815,9 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
   e->last_persistent = 0;
   e->has_deferred = false;
   const int algo = e->params.match_algo;
-  if (defer && !((algo == 0 || algo == 2) && K > 0)) defer = false;  // only the default orchestration runs in lockstep
+  const bool world_solo = algo == 5 && K > 0 && !defer;  // one pool through the persistent kernel: set up as deferred, run at once
+  if (world_solo) defer = true;
+  if (defer && !((algo == 0 || algo == 2 || algo == 5) && K > 0)) defer = false;  // only the window-round orchestrations run several pools
   if (algo == 1) {  // one-job-at-a-time sweep by a single workgroup (reference implementation of the chain)
 #ifdef __HIP_EMU__
     auto k_match = match_serial<256>;
@@ -830,10 +840,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     vb.jr = jr;
     JobCons* jcons = e->v_jcons.ensure(K);
     vb.jcons = jcons;
-    vb.pfit = e->v_pfit.ensure((size_t)MV_WMAX * C * MV_L);
-    vb.pidx = e->v_pidx.ensure((size_t)MV_WMAX * C * MV_L);
-    vb.pge = e->v_pge.ensure((size_t)MV_WMAX * C * MV_LG);
-    vb.pcnt = e->v_pcnt.ensure((size_t)MV_WMAX * C * 4);
+    vb.prec = e->v_prec.ensure((size_t)MV_WMAX * C);
     vb.colbits = e->v_colbits.ensure((size_t)(M ? M : 1u) * MV_JG);
     vb.cand_fit = e->v_cand_fit.ensure((size_t)MV_WMAX * MV_L);
     vb.cand_idx = e->v_cand_idx.ensure((size_t)MV_WMAX * MV_L);
@@ -910,6 +917,10 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       e->has_deferred = true;
       e->cycle_considered = K;
       e->match_done = false;
+      if (world_solo) {
+        cook_engine* self = e;
+        if (!match_rounds_world(&self, 1)) match_rounds_multi(&self, 1);
+      }
       return;
     }
     if (!done) {
@@ -1046,6 +1057,95 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
     ex->has_deferred = false;
     ex->match_done = true;
   }
+}
+
+// a deferred match back to its initial state (after a persistent launch gave up half way)
+void match_reset_deferred(cook_engine* e, hipStream_t stream) {
+  const PoolCtx& d = e->deferred;
+  hipStream_t keep = e->stream;
+  e->stream = stream;
+  match_init_state(e, d.st, d.in.K, d.in.M, d.in.G);
+  if (d.in.M) KL("match_init_alive", match_init_alive, div_up(d.in.M, 256), 256, d.vb.oa, d.in.M, d.st.jmin, d.st.alive);
+  e->stream = keep;
+  COOK_HIP(hipMemcpyAsync(d.vb.ctl, &e->deferred_c0, sizeof(WinCtl), hipMemcpyHostToDevice, stream));
+  COOK_HIP(hipStreamSynchronize(stream));
+}
+
+// The placements of n engines (pools of one rank, same device) in ONE persistent launch (match_world.hpp): every pool advances on
+// its own.  Returns false when the launch gave up (not all workgroups resident / a wait timed out): the matches are then reset and
+// the caller runs them with one launch per phase.
+bool match_rounds_world(cook_engine** es, unsigned n) {
+  cook_engine* lead = es[0];
+  std::vector<unsigned> live;
+  for (unsigned i = 0; i < n; ++i) {
+    if (!es[i] || es[i]->device != lead->device) lead->fail(COOK_E_INVALID, "cook_cycle_match_multi: engines must share one device");
+    if (es[i]->has_deferred) live.push_back(i);
+    else if (!es[i]->match_done) lead->fail(COOK_E_STATE, "cook_cycle_match_multi before cook_cycle_run_rank");
+  }
+  const unsigned L = (unsigned)live.size();
+  if (L == 0) return true;
+  if (L > MW_MAX_POOLS || L > 64) return false;
+  for (unsigned x = 0; x < L; ++x)
+    if (es[live[x]]->deferred_k >= (1u << 22) || MV_WMAX > 1024) return false;  // world_pack's field widths
+#ifdef __HIP_EMU__
+  const unsigned n_eval = 2;
+#else
+  // one workgroup per CU (the walker's LDS): all of them resident at once, a few CUs left to whatever else runs on the GPU
+  int want = lead->n_cus - (int)L - 8;
+  if (const char* ev = std::getenv("COOK_WORLD_EVAL_WGS")) want = std::atoi(ev);
+  if (want < 4) return false;
+  const unsigned n_eval = (unsigned)want;
+#endif
+  if (!lead->h_multi) COOK_HIP(hipHostMalloc((void**)&lead->h_multi, 64 * sizeof(WinCtl), hipHostMallocDefault));
+  std::vector<PoolCtx> hctx(L);
+  for (unsigned x = 0; x < L; ++x) hctx[x] = es[live[x]]->deferred;
+  PoolCtx* dctx = lead->w_pctx.ensure(L);
+  WorldPool* dwp = lead->w_wpool.ensure(L);
+  WorldCtl* dwc = lead->w_wctl.ensure(1);
+  WorldCtl hwc;
+  std::memset(&hwc, 0, sizeof(hwc));
+  hwc.n_pools = L;
+  hwc.n_eval_wg = n_eval;
+  COOK_HIP(hipMemcpyAsync(dctx, hctx.data(), L * sizeof(PoolCtx), hipMemcpyHostToDevice, lead->stream));
+  COOK_HIP(hipMemsetAsync(dwp, 0, L * sizeof(WorldPool), lead->stream));
+  COOK_HIP(hipMemcpyAsync(dwc, &hwc, sizeof(hwc), hipMemcpyHostToDevice, lead->stream));
+  COOK_HIP(hipStreamSynchronize(lead->stream));  // hctx / hwc are pageable
+  cook_engine* e = lead;
+  {
+    ProfScope _ps(e, "match_world");
+    COOK_LAUNCH_COOP(match_world, L + n_eval, MW_THREADS, lead->stream, (const PoolCtx*)dctx, dwp, dwc);
+  }
+  for (unsigned x = 0; x < L; ++x)
+    COOK_HIP(hipMemcpyAsync(&lead->h_multi[x], hctx[x].vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, lead->stream));
+  COOK_HIP(hipMemcpyAsync(&hwc, dwc, sizeof(hwc), hipMemcpyDeviceToHost, lead->stream));
+  COOK_HIP(hipStreamSynchronize(lead->stream));
+  lead->world_runs += 1;
+  bool ok = hwc.error == 0;
+  for (unsigned x = 0; x < L && ok; ++x) ok = lead->h_multi[x].head >= es[live[x]]->deferred_k;
+  if (!ok) {
+    lead->world_fallbacks += 1;
+    for (unsigned x = 0; x < L; ++x) match_reset_deferred(es[live[x]], lead->stream);
+    return false;
+  }
+#ifdef COOK_WORLD_PROF
+  for (int ph = 0; ph < 2; ++ph) {
+    const unsigned long long* q = hwc.prof[ph];
+    const double n = q[0] ? (double)q[0] : 1.0;
+    std::fprintf(stderr, "WORLDPROF %s items=%llu notice avg %.1f us max %.1f us | work avg %.1f us max %.1f us | drain+add avg %.1f us | publish->done max %.1f us\n",
+                 ph == 0 ? "eval " : "merge", q[0], q[1] / n / 100.0, q[2] / 100.0, q[3] / n / 100.0, q[4] / 100.0, q[5] / n / 100.0, q[6] / 100.0);
+  }
+  std::fprintf(stderr, "WORLDPROF walker0 waits: eval %.1f ms merge %.1f ms\n", hwc.t_wait_eval / 1e5, hwc.t_wait_merge / 1e5);
+#endif
+  lead->world_wait_eval = hwc.t_wait_eval;
+  lead->world_wait_merge = hwc.t_wait_merge;
+  for (unsigned x = 0; x < L; ++x) {
+    cook_engine* ex = es[live[x]];
+    match_finish_rounds(ex, hctx[x].st, hctx[x].vb, lead->h_multi[x], lead->stream);
+    ex->last_persistent = 2;
+    ex->has_deferred = false;
+    ex->match_done = true;
+  }
+  return true;
 }
 
 void match_fetch(cook_engine* e, unsigned K, int32_t* job_to_offer, uint32_t* fail_code, uint8_t* head_matched) {
@@ -1195,7 +1295,7 @@ void cook_engine_destroy(cook_engine* e) {
                   &e->j_index.b, &e->o_host.b, &e->o_gpu_model.b, &e->o_disk_type.b, &e->o_attr.b, &e->o_location.b, &e->g_attr_key.b,
                   &e->g_run_off.b, &e->g_run_host.b, &e->g_run_attr.b, &e->reserved_bits.b, &e->m_fail.b, &e->j_reserved_host.b,
                   &e->o_max_tasks.b, &e->o_num_tasks.b, &e->o_run_count.b, &e->g_min.b, &e->m_acount.b, &e->m_group_last.b,
-                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b, &e->v_oa.b, &e->v_ob.b, &e->v_jr.b, &e->v_pfit.b, &e->v_cand_fit.b, &e->v_pidx.b, &e->v_pge.b, &e->v_cand_idx.b, &e->v_ge_idx.b, &e->v_pcnt.b, &e->v_cinfo.b, &e->v_colbits.b, &e->w_ctl.b, &e->v_in.b};
+                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b, &e->v_oa.b, &e->v_ob.b, &e->v_jr.b, &e->v_prec.b, &e->v_cand_fit.b, &e->v_cand_idx.b, &e->v_ge_idx.b, &e->v_cinfo.b, &e->v_colbits.b, &e->w_ctl.b, &e->v_in.b};
   for (DBuf* b : bufs) b->release();
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i)
@@ -1409,7 +1509,7 @@ int cook_cycle_match_multi(cook_engine** engines, uint32_t n) {
   cook_engine* lead = engines[0];
   return guarded(lead, [&] {
     StageTimer tm(lead, 2, &lead->match_ms);
-    match_rounds_multi(engines, n);
+    if (!(lead->params.match_algo == 5 && match_rounds_world(engines, n))) match_rounds_multi(engines, n);
     tm.stop();
     for (uint32_t i = 1; i < n; ++i) engines[i]->match_ms = lead->match_ms;  // one joint sequence of launches
     prof_collect(lead);
@@ -1601,9 +1701,9 @@ int cook_match_stats(cook_engine* e, uint32_t out[16]) {
   out[10] = c.touched_sum;
   out[11] = c.visited_sum;
   out[12] = c.reevals;
-  out[13] = e->last_persistent | (e->persist_fallbacks << 1);
-  out[14] = (uint32_t)(c.t_eval / 100ull);
-  out[15] = (uint32_t)(c.t_merge / 100ull);
+  out[13] = e->last_persistent | ((e->persist_fallbacks + e->world_fallbacks) << 4);  // 1 = match_persist, 2 = match_world ran; fallbacks so far
+  out[14] = (uint32_t)((c.t_eval + e->world_wait_eval) / 100ull);    // match_persist: eval phase; match_world: the walker's wait for it
+  out[15] = (uint32_t)((c.t_merge + e->world_wait_merge) / 100ull);
   return COOK_OK;
 }
 #ifdef __HIP_EMU__

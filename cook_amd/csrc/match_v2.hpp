@@ -135,16 +135,48 @@ struct RoundLog {  // one record per round (diagnostics; only written when V2Buf
 };
 constexpr unsigned MV_ROUND_LOG_CAP = 8192;
 
+// One offer chunk's candidates for one job, as ONE aligned record (128 bytes at L = 8, LG = 4) that the evaluating lane writes
+// and the merging lane reads in 16-byte pieces: whole lines, so the persistent kernel can publish it with write-through stores
+// (MI355X_MICROARCH.md "publish-large": write-through + drained flag beats plain stores + an L2 write-back fence per producer).
+struct alignas(16) ChunkRec {
+  double fit[MV_L];   // fitness desc, offer index asc
+  int idx[MV_L];      // -1 = no entry
+  int ge[MV_LG];      // first offers (ascending index) whose fitness exceeds good-enough; 0x7FFFFFFF = none
+  unsigned cnt[4];    // n | nge << 8, offers failing on resources / constraints / zero fitness
+};
+static_assert(sizeof(ChunkRec) % 16 == 0, "ChunkRec is moved in 16-byte pieces");
+#ifdef __HIP_EMU__
+static inline void chunk_store(ChunkRec* dst, const ChunkRec& r, bool) { *dst = r; }
+#else
+// through: write-through (sc1) stores — the record is in memory, visible to every XCD, once the wave's vmcnt drains
+static __device__ __forceinline__ void chunk_store(ChunkRec* dst, const ChunkRec& r, bool through) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr unsigned NP = sizeof(ChunkRec) / 16;
+  u32x4 piece[NP];
+  __builtin_memcpy(piece, &r, sizeof(ChunkRec));  // (not a pointer cast: the record's fields are doubles and ints)
+  u32x4* d = reinterpret_cast<u32x4*>(dst);
+#pragma unroll
+  for (unsigned x = 0; x < NP; ++x) {
+    if (through) {
+      u32x4* a = d + x;
+      // s_nop: a VMEM store of more than 64 bits reads its data registers AFTER issue, and the compiler's hazard recogniser does
+      // not see into inline asm — without the wait state it re-used the data registers for the next address (seen in the ISA:
+      // v_lshl_add_u64 into v[4:5] right behind a store of v[4:7]) and the records went out corrupted
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(a), "v"(piece[x]) : "memory");
+    } else {
+      d[x] = piece[x];
+    }
+  }
+}
+#endif
+
 struct V2Buf {
   RoundLog* round_log;
   const OfferA* oa;
   const OfferB* ob;
   const JobRec* jr;
   const JobCons* jcons;  // [K] fast constraint slots of the jobs flagged JF_FASTC
-  double* pfit;        // [wmax][C][L]   chunk lists
-  int* pidx;           // [wmax][C][L]
-  int* pge;            // [wmax][C][LG]
-  uint32_t* pcnt;      // [wmax][C][4]   n | nge << 8, c1, c2, c4
+  ChunkRec* prec;      // [wmax][C]      chunk lists: one record per (job of the window, offer chunk)
   uint64_t* colbits;   // [M][JG]        static-constraints-pass bit of (offer, job of the window)
   double* cand_fit;    // [wmax][L]
   int* cand_idx;       // [wmax][L]
@@ -316,240 +348,302 @@ static __device__ __forceinline__ void topl_insert(double (&tf)[N], int (&ti)[N]
 }
 
 // ---- eval ------------------------------------------------------------------------------------------------------------------
+struct EvalWaveLds {  // what ONE wave stages for the offers it walks (MV_OCW at a time): the offer loop then reads LDS broadcasts only
+  OfferA oa[MV_OCW];
+  OfferB ob[MV_OCW];
+  double oac[MV_OCW], oam[MV_OCW];
+  int oacount[MV_OCW];
+  uint32_t attr[MV_OCW][MV_NA];  // the first MV_NA attribute values of the offers (0 = absent)
+};
 struct EvalLds {
   double fit[MV_EW][COOK_WAVE][MV_L];
   int idx[MV_EW][COOK_WAVE][MV_L];
   int ge[MV_EW][COOK_WAVE][MV_LG];
   unsigned cnt[MV_EW][COOK_WAVE][3];
-  OfferA oa[MV_EW][MV_OCW];  // this wave's offers, staged once: the offer loop then reads LDS broadcasts only
-  OfferB ob[MV_EW][MV_OCW];
-  double oac[MV_EW][MV_OCW], oam[MV_EW][MV_OCW];
-  int oacount[MV_EW][MV_OCW];
-  uint32_t attr[MV_EW][MV_OCW][MV_NA];  // the first MV_NA attribute values of this wave's offers (0 = absent)
+  EvalWaveLds wave[MV_EW];
 };
 
-// One tile = 64 jobs (job group jg of the window) x MV_OCB offers (chunk ch); the whole workgroup (MV_EW waves) takes part.
-// Ends with every thread past its last LDS access only after the caller's next __syncthreads().
-static __device__ __forceinline__ void eval_tile(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
-                                                 unsigned wcur, unsigned ch, unsigned jg) {
-  EvalLds& L = *reinterpret_cast<EvalLds*>(lds);
-  auto& s_fit = L.fit;
-  auto& s_idx = L.idx;
-  auto& s_ge = L.ge;
-  auto& s_cnt = L.cnt;
-  auto& s_oa = L.oa;
-  auto& s_ob = L.ob;
-  auto& s_oac = L.oac;
-  auto& s_oam = L.oam;
-  auto& s_oacount = L.oacount;
-  auto& s_attr = L.attr;
-  if (jg * COOK_WAVE >= wcur || head + jg * COOK_WAVE >= in.K) return;  // block-uniform
-  const unsigned lane = lane_id(), w = wave_id();
-  const unsigned b = jg * COOK_WAVE + lane, k = head + b;
-  const bool valid = b < wcur && k < in.K;
+// the job of one lane and its running results over the offers seen so far
+struct EvalLane {
+  bool valid, slow, grouped, fastc, use_ge;
   JobRec j;
-  j.c = j.m = j.g = 0.0;
-  j.gpu_model = 0;
-  j.reserved_host = -1;
-  j.group = 0xFFFFFFFFu;
-  j.flags = 0;
-  unsigned jj = 0;
-  if (valid) {
-    j = vb.jr[k];
-    jj = in.j_index ? in.j_index[k] : k;
-  }
-  const bool slow = (j.flags & JF_SLOW) != 0, grouped = (j.flags & JF_GROUPED) != 0;
-  const bool fastc = !slow && (j.flags & JF_FASTC) != 0;
+  unsigned jj;
   JobCons jc;
-  jc.n_eq = jc.n_novel = 0;
-#pragma unroll
-  for (int q = 0; q < MV_NC; ++q) jc.eq_key[q] = jc.eq_val[q] = jc.novel[q] = 0u;
-  if (fastc) jc = vb.jcons[k];
-  // unique host-placement groups (constraints.clj:586-598): the hosts to avoid = running cotasks ++ cotasks placed by
-  // earlier rounds of this call, gathered ONCE per tile into registers (n_fh = -1: not such a job, -2: too many -> slow path)
   unsigned fh[MV_FH];
-  int n_fh = -1;
-#pragma unroll
-  for (int q = 0; q < MV_FH; ++q) fh[q] = 0xFFFFFFFFu;
-  if (grouped && ((j.flags >> 8) & 3u) == 1u) {
-    n_fh = 0;
-    const unsigned g = j.group;
-    const unsigned r0 = in.g_run_off ? in.g_run_off[g] : 0u, r1 = in.g_run_off ? in.g_run_off[g + 1] : 0u;
-    auto push = [&](unsigned h) {
-      if (n_fh >= 0 && n_fh < MV_FH) {
-#pragma unroll
-        for (int q = 0; q < MV_FH; ++q)
-          if (q == n_fh) fh[q] = h;
-        ++n_fh;
-      } else {
-        n_fh = -2;
-      }
-    };
-    for (unsigned x = r0; x < r1 && n_fh >= 0; ++x) push(in.g_run_host[x]);
-    for (int c = ld_agent(&st.group_last[g]); c >= 0 && n_fh >= 0; c = ld_agent(&st.job_prev[c]))
-      if (c < st.cutoff) push(in.o_host[ld_agent(&st.job_to_offer[c])]);
-  }
-  const bool use_ge = in.good_enough < 1.0;
-  const double ge = in.good_enough, ge_lo = in.good_enough * (1.0 - 0x1p-40);
+  int n_fh;
+  double ge, ge_lo;
   double tf[MV_L];
   int ti[MV_L];
   int gi[MV_LG];
+  int n_ge;
+  double thr;  // pruning threshold: (1 - 2^-40) * current L-th best, valid once the list is full
+  unsigned c1, c2, c4;
+};
+
+// lane = job `b` of the window (64 consecutive jobs per wave): load it and gather what its constraints need
+static __device__ __forceinline__ void eval_lane_setup(EvalLane& E, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
+                                                       unsigned wcur, unsigned jg) {
+  const unsigned lane = lane_id();
+  const unsigned b = jg * COOK_WAVE + lane, k = head + b;
+  E.valid = b < wcur && k < in.K;
+  E.j.c = E.j.m = E.j.g = 0.0;
+  E.j.gpu_model = 0;
+  E.j.reserved_host = -1;
+  E.j.group = 0xFFFFFFFFu;
+  E.j.flags = 0;
+  E.jj = 0;
+  if (E.valid) {
+    E.j = vb.jr[k];
+    E.jj = in.j_index ? in.j_index[k] : k;
+  }
+  E.slow = (E.j.flags & JF_SLOW) != 0;
+  E.grouped = (E.j.flags & JF_GROUPED) != 0;
+  E.fastc = !E.slow && (E.j.flags & JF_FASTC) != 0;
+  E.jc.n_eq = E.jc.n_novel = 0;
+#pragma unroll
+  for (int q = 0; q < MV_NC; ++q) E.jc.eq_key[q] = E.jc.eq_val[q] = E.jc.novel[q] = 0u;
+  if (E.fastc) E.jc = vb.jcons[k];
+  // unique host-placement groups (constraints.clj:586-598): the hosts to avoid = running cotasks ++ cotasks placed by
+  // earlier rounds of this call, gathered ONCE per tile into registers (n_fh = -1: not such a job, -2: too many -> slow path)
+  E.n_fh = -1;
+#pragma unroll
+  for (int q = 0; q < MV_FH; ++q) E.fh[q] = 0xFFFFFFFFu;
+  if (E.grouped && ((E.j.flags >> 8) & 3u) == 1u) {
+    E.n_fh = 0;
+    const unsigned g = E.j.group;
+    const unsigned r0 = in.g_run_off ? in.g_run_off[g] : 0u, r1 = in.g_run_off ? in.g_run_off[g + 1] : 0u;
+    auto push = [&](unsigned h) {
+      if (E.n_fh >= 0 && E.n_fh < MV_FH) {
+#pragma unroll
+        for (int q = 0; q < MV_FH; ++q)
+          if (q == E.n_fh) E.fh[q] = h;
+        ++E.n_fh;
+      } else {
+        E.n_fh = -2;
+      }
+    };
+    for (unsigned x = r0; x < r1 && E.n_fh >= 0; ++x) push(in.g_run_host[x]);
+    for (int c = ld_agent(&st.group_last[g]); c >= 0 && E.n_fh >= 0; c = ld_agent(&st.job_prev[c]))
+      if (c < st.cutoff) push(in.o_host[ld_agent(&st.job_to_offer[c])]);
+  }
+  E.use_ge = in.good_enough < 1.0;
+  E.ge = in.good_enough;
+  E.ge_lo = in.good_enough * (1.0 - 0x1p-40);
 #pragma unroll
   for (int q = 0; q < MV_L; ++q) {
-    tf[q] = -1.0;
-    ti[q] = -1;
+    E.tf[q] = -1.0;
+    E.ti[q] = -1;
   }
 #pragma unroll
-  for (int q = 0; q < MV_LG; ++q) gi[q] = 0x7FFFFFFF;
-  int n_ge = 0;
-  double thr = -1.0;  // pruning threshold: (1 - 2^-40) * current L-th best, valid once the list is full
-  unsigned c1 = 0, c2 = 0, c4 = 0;
-  const unsigned v0 = ch * MV_OCB + w * MV_OCW;
+  for (int q = 0; q < MV_LG; ++q) E.gi[q] = 0x7FFFFFFF;
+  E.n_ge = 0;
+  E.thr = -1.0;
+  E.c1 = E.c2 = E.c4 = 0;
+}
+
+// the offers [v0, v0 + MV_OCW) against the wave's 64 jobs: stage them in the wave's LDS, then walk them in a wave-uniform loop
+template <bool THROUGH>
+static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds& W, const MatchIn& in, const MatchState& st, const V2Buf& vb,
+                                                        unsigned v0, unsigned jg) {
+  const unsigned lane = lane_id();
   const unsigned v1 = (v0 + MV_OCW < in.M) ? v0 + MV_OCW : in.M;
   if (v0 + lane < v1) {
-    s_oa[w][lane] = vb.oa[v0 + lane];
-    s_ob[w][lane] = vb.ob[v0 + lane];
-    s_oac[w][lane] = st.ac[v0 + lane];
-    s_oam[w][lane] = st.am[v0 + lane];
-    s_oacount[w][lane] = st.acount[v0 + lane];
+    W.oa[lane] = vb.oa[v0 + lane];
+    W.ob[lane] = vb.ob[v0 + lane];
+    W.oac[lane] = st.ac[v0 + lane];
+    W.oam[lane] = st.am[v0 + lane];
+    W.oacount[lane] = st.acount[v0 + lane];
 #pragma unroll
     for (int q = 0; q < MV_NA; ++q)
-      s_attr[w][lane][q] = (in.o_attr && (unsigned)q < in.n_attr) ? in.o_attr[(size_t)(v0 + lane) * in.n_attr + q] : 0u;
+      W.attr[lane][q] = (in.o_attr && (unsigned)q < in.n_attr) ? in.o_attr[(size_t)(v0 + lane) * in.n_attr + q] : 0u;
   }
   wave_sync();
+  const bool valid = E.valid;
+  const JobRec& j = E.j;
   // offers that cannot take even the smallest job of the call any more fail every job on resources: count, never evaluate
   unsigned long long live = 0ull;
   if (v0 < v1) {
     live = (st.alive[v0 >> 6] >> (v0 & 63u)) & (MV_OCW == 64 ? ~0ull : ((1ull << (MV_OCW & 63)) - 1ull));  // an aligned slice of one word
     if (v1 - v0 < (unsigned)MV_OCW) live &= (1ull << (v1 - v0)) - 1ull;
-    c1 += valid ? (v1 - v0) - (unsigned)__popcll(live) : 0u;
+    E.c1 += valid ? (v1 - v0) - (unsigned)__popcll(live) : 0u;
   }
   while (live != 0ull) {  // wave-uniform
     const unsigned vi = (unsigned)__ffsll((unsigned long long)live) - 1u;
     live &= live - 1ull;
     const unsigned v = v0 + vi;
-    const OfferA a = s_oa[w][vi];
-    const double ac = s_oac[w][vi], am = s_oam[w][vi];
+    const OfferA a = W.oa[vi];
+    const double ac = W.oac[vi], am = W.oam[vi];
     const bool res = valid && !(ac + j.c > a.oc || am + j.m > a.om);
     if (!__any(res)) {
-      c1 += valid ? 1u : 0u;
-      if (lane == 0) vb.colbits[(size_t)v * MV_JG + jg] = 0ull;
+      E.c1 += valid ? 1u : 0u;
+      if (lane == 0) {
+        if (THROUGH) st_agent(&vb.colbits[(size_t)v * MV_JG + jg], (uint64_t)0ull);
+        else vb.colbits[(size_t)v * MV_JG + jg] = 0ull;
+      }
       continue;
     }
-    const OfferB o = s_ob[w][vi];
-    const int acount = s_oacount[w][vi];
+    const OfferB o = W.ob[vi];
+    const int acount = W.oacount[vi];
     bool stat = res && static_fast(j, o);
-    if (stat && fastc) {  // novel-host (constraints.clj:68-94) and user-defined EQUALS (:356-377) from registers + LDS
+    if (stat && E.fastc) {  // novel-host (constraints.clj:68-94) and user-defined EQUALS (:356-377) from registers + LDS
 #pragma unroll
       for (int q = 0; q < MV_NC; ++q) {
-        if ((unsigned)q < jc.n_novel && jc.novel[q] == o.host) stat = false;
-        if ((unsigned)q < jc.n_eq) {
-          const unsigned key = jc.eq_key[q];
-          const unsigned val = key == 0xFFFFFFFFu ? o.host + 1u : (key < (unsigned)MV_NA ? s_attr[w][vi][key] : 0u);
-          if (val != jc.eq_val[q]) stat = false;
+        if ((unsigned)q < E.jc.n_novel && E.jc.novel[q] == o.host) stat = false;
+        if ((unsigned)q < E.jc.n_eq) {
+          const unsigned key = E.jc.eq_key[q];
+          const unsigned val = key == 0xFFFFFFFFu ? o.host + 1u : (key < (unsigned)MV_NA ? W.attr[vi][key] : 0u);
+          if (val != E.jc.eq_val[q]) stat = false;
         }
       }
     }
-    if (stat && slow) stat = static_pass(in, jj, v);
+    if (stat && E.slow) stat = static_pass(in, E.jj, v);
     const unsigned long long bits = __ballot(stat);
-    if (lane == 0) vb.colbits[(size_t)v * MV_JG + jg] = bits;
+    if (lane == 0) {
+      if (THROUGH) st_agent(&vb.colbits[(size_t)v * MV_JG + jg], (uint64_t)bits);
+      else vb.colbits[(size_t)v * MV_JG + jg] = bits;
+    }
     bool feas = stat && dyn_fast(j, o, acount);
-    if (feas && grouped) {
-      if (n_fh >= 0) {
+    if (feas && E.grouped) {
+      if (E.n_fh >= 0) {
 #pragma unroll
         for (int q = 0; q < MV_FH; ++q)
-          if (fh[q] == o.host) feas = false;
+          if (E.fh[q] == o.host) feas = false;
       } else {
-        feas = group_pass(in, st, jj, v);
+        feas = group_pass(in, st, E.jj, v);
       }
     }
-    c1 += (valid && !res) ? 1u : 0u;
-    c2 += (res && !feas) ? 1u : 0u;
+    E.c1 += (valid && !res) ? 1u : 0u;
+    E.c2 += (res && !feas) ? 1u : 0u;
     if (feas) {
       const double t1 = (a.rc + ac + j.c) * a.inv_dc, t2 = (a.rm + am + j.m) * a.inv_dm;
       const double ub = (t1 + t2) * 0.5;
-      bool prune = ti[MV_L - 1] >= 0 && t1 >= 0.0 && t2 >= 0.0 && ub < thr;
-      if (use_ge && n_ge < MV_LG && !(ub < ge_lo)) prune = false;
+      bool prune = E.ti[MV_L - 1] >= 0 && t1 >= 0.0 && t2 >= 0.0 && ub < E.thr;
+      if (E.use_ge && E.n_ge < MV_LG && !(ub < E.ge_lo)) prune = false;
       if (!prune) {
         const double fit = fitness_of(a, ac, am, j.c, j.m);
         if (!(fit > 0.0)) {
-          c4 += 1u;
+          E.c4 += 1u;
         } else {
-          if (fit > tf[MV_L - 1]) {
-            topl_insert<MV_L>(tf, ti, fit, (int)v);
-            if (ti[MV_L - 1] >= 0) thr = tf[MV_L - 1] * (1.0 - 0x1p-40);
+          if (fit > E.tf[MV_L - 1]) {
+            topl_insert<MV_L>(E.tf, E.ti, fit, (int)v);
+            if (E.ti[MV_L - 1] >= 0) E.thr = E.tf[MV_L - 1] * (1.0 - 0x1p-40);
           }
-          if (use_ge && fit > ge && n_ge < MV_LG) {
+          if (E.use_ge && fit > E.ge && E.n_ge < MV_LG) {
 #pragma unroll
             for (int q = 0; q < MV_LG; ++q)
-              if (q == n_ge) gi[q] = (int)v;
-            ++n_ge;
+              if (q == E.n_ge) E.gi[q] = (int)v;
+            ++E.n_ge;
           }
         }
       }
     }
   }
+  wave_sync();  // every lane is done with the staged offers before the wave stages the next ones
+}
+
+// One tile = 64 jobs (job group jg of the window) x MV_OCB offers (chunk ch); the whole workgroup (MV_EW waves) takes part.
+// Ends with every thread past its last LDS access only after the caller's next __syncthreads().
+// The MV_EW waves may be a whole workgroup (w = wave_id(), sync = __syncthreads) or a TEAM of waves inside a larger workgroup of
+// the persistent kernel (match_world.hpp: w = wave in team, sync = the team's LDS barrier, THROUGH = write-through stores).
+template <bool THROUGH, class Sync>
+static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
+                                                   unsigned wcur, unsigned ch, unsigned jg, unsigned w, Sync sync) {
+  EvalLds& L = *reinterpret_cast<EvalLds*>(lds);
+  auto& s_fit = L.fit;
+  auto& s_idx = L.idx;
+  auto& s_ge = L.ge;
+  auto& s_cnt = L.cnt;
+  if (jg * COOK_WAVE >= wcur || head + jg * COOK_WAVE >= in.K) return;  // uniform over the waves of the tile
+  const unsigned lane = lane_id();
+  const unsigned b = jg * COOK_WAVE + lane;
+  EvalLane E;
+  eval_lane_setup(E, in, st, vb, head, wcur, jg);
+  eval_scan_offers<THROUGH>(E, L.wave[w], in, st, vb, ch * MV_OCB + w * MV_OCW, jg);
+  const bool valid = E.valid, use_ge = E.use_ge;
   // ---- merge the block's MV_EW wave lists per job through LDS -------------------------------------------------------
 #pragma unroll
   for (int q = 0; q < MV_L; ++q) {
-    s_fit[w][lane][q] = tf[q];
-    s_idx[w][lane][q] = ti[q];
+    s_fit[w][lane][q] = E.tf[q];
+    s_idx[w][lane][q] = E.ti[q];
   }
 #pragma unroll
-  for (int q = 0; q < MV_LG; ++q) s_ge[w][lane][q] = gi[q];
-  s_cnt[w][lane][0] = c1;
-  s_cnt[w][lane][1] = c2;
-  s_cnt[w][lane][2] = c4;
-  __syncthreads();
-  if (w != 0 || !valid) return;  // (the caller synchronises the workgroup before the LDS is reused)
+  for (int q = 0; q < MV_LG; ++q) s_ge[w][lane][q] = E.gi[q];
+  s_cnt[w][lane][0] = E.c1;
+  s_cnt[w][lane][1] = E.c2;
+  s_cnt[w][lane][2] = E.c4;
+  sync();
+  if (w != 0 || !valid) return;  // (the caller synchronises the waves before the LDS is reused)
   int p[MV_EW];
 #pragma unroll
   for (int x = 0; x < MV_EW; ++x) p[x] = 0;
-  const size_t obase = ((size_t)b * vb.C + ch);
+  ChunkRec R;
   int n_out = 0;
-  for (int q = 0; q < MV_L; ++q) {
-    Cand best{-1.0, -1};
-    int bx = -1;
 #pragma unroll
-    for (int x = 0; x < MV_EW; ++x) {
-      if (p[x] < MV_L) {
-        const Cand o{s_fit[x][lane][p[x]], s_idx[x][lane][p[x]]};
-        if (o.idx >= 0 && cand_better(o, best)) {
-          best = o;
-          bx = x;
+  for (int q = 0; q < MV_L; ++q) {
+    R.fit[q] = -1.0;
+    R.idx[q] = -1;
+  }
+#pragma unroll
+  for (int q = 0; q < MV_LG; ++q) R.ge[q] = 0x7FFFFFFF;
+  {
+    bool more = true;
+#pragma unroll
+    for (int q = 0; q < MV_L; ++q) {
+      Cand best{-1.0, -1};
+      int bx = -1;
+      if (more) {
+#pragma unroll
+        for (int x = 0; x < MV_EW; ++x) {
+          if (p[x] < MV_L) {
+            const Cand o{s_fit[x][lane][p[x]], s_idx[x][lane][p[x]]};
+            if (o.idx >= 0 && cand_better(o, best)) {
+              best = o;
+              bx = x;
+            }
+          }
         }
       }
-    }
-    vb.pfit[obase * MV_L + q] = best.fit;
-    vb.pidx[obase * MV_L + q] = best.idx;
-    if (bx < 0) break;
-    ++n_out;
+      if (bx < 0) {
+        more = false;
+      } else {
+        R.fit[q] = best.fit;
+        R.idx[q] = best.idx;
+        ++n_out;
 #pragma unroll
-    for (int x = 0; x < MV_EW; ++x)
-      if (x == bx) ++p[x];
+        for (int x = 0; x < MV_EW; ++x)
+          if (x == bx) ++p[x];
+      }
+    }
   }
   int n_g = 0;
   if (use_ge) {
 #pragma unroll
     for (int x = 0; x < MV_EW; ++x) p[x] = 0;
+    bool more = true;
+#pragma unroll
     for (int q = 0; q < MV_LG; ++q) {
       int best = 0x7FFFFFFF, bx = -1;
+      if (more) {
 #pragma unroll
-      for (int x = 0; x < MV_EW; ++x) {
-        if (p[x] < MV_LG) {
-          const int o = s_ge[x][lane][p[x]];
-          if (o < best) {
-            best = o;
-            bx = x;
+        for (int x = 0; x < MV_EW; ++x) {
+          if (p[x] < MV_LG) {
+            const int o = s_ge[x][lane][p[x]];
+            if (o < best) {
+              best = o;
+              bx = x;
+            }
           }
         }
       }
-      if (bx < 0) break;
-      vb.pge[obase * MV_LG + q] = best;
-      ++n_g;
+      if (bx < 0) {
+        more = false;
+      } else {
+        R.ge[q] = best;
+        ++n_g;
 #pragma unroll
-      for (int x = 0; x < MV_EW; ++x)
-        if (x == bx) ++p[x];
+        for (int x = 0; x < MV_EW; ++x)
+          if (x == bx) ++p[x];
+      }
     }
   }
   unsigned t1 = 0, t2 = 0, t4 = 0;
@@ -559,10 +653,50 @@ static __device__ __forceinline__ void eval_tile(char* lds, const MatchIn& in, c
     t2 += s_cnt[x][lane][1];
     t4 += s_cnt[x][lane][2];
   }
-  vb.pcnt[obase * 4 + 0] = (unsigned)n_out | ((unsigned)n_g << 8);
-  vb.pcnt[obase * 4 + 1] = t1;
-  vb.pcnt[obase * 4 + 2] = t2;
-  vb.pcnt[obase * 4 + 3] = t4;
+  R.cnt[0] = (unsigned)n_out | ((unsigned)n_g << 8);
+  R.cnt[1] = t1;
+  R.cnt[2] = t2;
+  R.cnt[3] = t4;
+  chunk_store(&vb.prec[(size_t)b * vb.C + ch], R, THROUGH);
+}
+static __device__ __forceinline__ void eval_tile(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
+                                                 unsigned wcur, unsigned ch, unsigned jg) {
+  eval_tile_t<false>(lds, in, st, vb, head, wcur, ch, jg, wave_id(), [] { __syncthreads(); });
+}
+
+// The same tile by ONE wave on its own (the persistent placement kernel's evaluator waves, match_world.hpp): 64 jobs x the
+// MV_OCB offers of chunk ch in MV_EW batches of MV_OCW; no workgroup barrier anywhere, the chunk list goes straight to HBM.
+static __device__ __forceinline__ void eval_tile_wave(EvalWaveLds& W, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
+                                                      unsigned wcur, unsigned ch, unsigned jg) {
+  if (jg * COOK_WAVE >= wcur || head + jg * COOK_WAVE >= in.K) return;  // wave-uniform
+  const unsigned lane = lane_id();
+  const unsigned b = jg * COOK_WAVE + lane;
+  EvalLane E;
+  eval_lane_setup(E, in, st, vb, head, wcur, jg);
+  for (int s = 0; s < MV_EW; ++s) {
+    const unsigned v0 = ch * MV_OCB + (unsigned)s * MV_OCW;
+    if (v0 >= in.M) break;
+    eval_scan_offers<true>(E, W, in, st, vb, v0, jg);
+  }
+  if (!E.valid) return;
+  ChunkRec R;
+  int n_out = 0, n_g = 0;
+#pragma unroll
+  for (int q = 0; q < MV_L; ++q) {
+    R.fit[q] = E.tf[q];
+    R.idx[q] = E.ti[q];
+    n_out += E.ti[q] >= 0 ? 1 : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < MV_LG; ++q) {
+    R.ge[q] = E.gi[q];
+    n_g += E.gi[q] != 0x7FFFFFFF ? 1 : 0;
+  }
+  R.cnt[0] = (unsigned)n_out | ((unsigned)n_g << 8);
+  R.cnt[1] = E.c1;
+  R.cnt[2] = E.c2;
+  R.cnt[3] = E.c4;
+  chunk_store(&vb.prec[(size_t)b * vb.C + ch], R, true);
 }
 
 __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, MatchState st, V2Buf vb) {
@@ -571,6 +705,7 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, Matc
 }
 
 // ---- merge: one wave per job ---------------------------------------------------------------------------------------------
+template <bool THROUGH>
 static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf& vb, unsigned head, unsigned wcur, unsigned b) {
   if (b >= wcur || head + b >= in.K) return;
   const unsigned lane = lane_id();
@@ -588,20 +723,24 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
   int n_ge = 0;
   unsigned c1 = 0, c2 = 0, c4 = 0;
   for (unsigned ch = lane; ch < vb.C; ch += COOK_WAVE) {
-    const size_t base = (size_t)b * vb.C + ch;
-    const unsigned info = vb.pcnt[base * 4 + 0];
-    c1 += vb.pcnt[base * 4 + 1];
-    c2 += vb.pcnt[base * 4 + 2];
-    c4 += vb.pcnt[base * 4 + 3];
+    const ChunkRec R = vb.prec[(size_t)b * vb.C + ch];  // eight 16-byte loads, all in flight together
+    const unsigned info = R.cnt[0];
+    c1 += R.cnt[1];
+    c2 += R.cnt[2];
+    c4 += R.cnt[3];
     const int n = (int)(info & 0xFFu), ng = (int)((info >> 8) & 0xFFu);
-    for (int q = 0; q < n; ++q) {
-      const Cand o{vb.pfit[base * MV_L + q], vb.pidx[base * MV_L + q]};
+#pragma unroll
+    for (int q = 0; q < MV_L; ++q) {
+      if (q >= n) break;
+      const Cand o{R.fit[q], R.idx[q]};
       if (!cand_better(o, Cand{tf[MV_L - 1], ti[MV_L - 1]})) break;  // chunk list is sorted: nothing further can enter
       topl_insert<MV_L>(tf, ti, o.fit, o.idx);
     }
     if (use_ge)
-      for (int q = 0; q < ng && n_ge < MV_LG; ++q) {  // chunks ascend with ch, entries ascend inside a chunk
-        const int o = vb.pge[base * MV_LG + q];
+#pragma unroll
+      for (int q = 0; q < MV_LG; ++q) {  // chunks ascend with ch, entries ascend inside a chunk
+        if (q >= ng || n_ge >= MV_LG) break;
+        const int o = R.ge[q];
 #pragma unroll
         for (int x = 0; x < MV_LG; ++x)
           if (x == n_ge) gi[x] = o;
@@ -622,8 +761,13 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
     }
     if (best.idx < 0) break;  // wave-uniform
     if (lane == 0) {
-      vb.cand_fit[(size_t)b * MV_L + round] = best.fit;
-      vb.cand_idx[(size_t)b * MV_L + round] = best.idx;
+      if (THROUGH) {
+        st_agent(&vb.cand_fit[(size_t)b * MV_L + round], best.fit);
+        st_agent(&vb.cand_idx[(size_t)b * MV_L + round], best.idx);
+      } else {
+        vb.cand_fit[(size_t)b * MV_L + round] = best.fit;
+        vb.cand_idx[(size_t)b * MV_L + round] = best.idx;
+      }
     }
     ++n_out;
     if (ti[0] == best.idx) {  // the owner pops its head
@@ -645,7 +789,10 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
         best = o < best ? o : best;
       }
       if (best == 0x7FFFFFFF) break;
-      if (lane == 0) vb.ge_idx[(size_t)b * MV_LG + round] = best;
+      if (lane == 0) {
+        if (THROUGH) st_agent(&vb.ge_idx[(size_t)b * MV_LG + round], best);
+        else vb.ge_idx[(size_t)b * MV_LG + round] = best;
+      }
       ++n_g;
       if (gi[0] == best) {
 #pragma unroll
@@ -655,15 +802,22 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
     }
   }
   if (lane == 0) {
-    vb.cinfo[(size_t)b * 4 + 0] = (unsigned)n_out | ((unsigned)n_g << 8);
-    vb.cinfo[(size_t)b * 4 + 1] = c1;
-    vb.cinfo[(size_t)b * 4 + 2] = c2;
-    vb.cinfo[(size_t)b * 4 + 3] = c4;
+    if (THROUGH) {
+      st_agent(&vb.cinfo[(size_t)b * 4 + 0], (uint32_t)((unsigned)n_out | ((unsigned)n_g << 8)));
+      st_agent(&vb.cinfo[(size_t)b * 4 + 1], (uint32_t)c1);
+      st_agent(&vb.cinfo[(size_t)b * 4 + 2], (uint32_t)c2);
+      st_agent(&vb.cinfo[(size_t)b * 4 + 3], (uint32_t)c4);
+    } else {
+      vb.cinfo[(size_t)b * 4 + 0] = (unsigned)n_out | ((unsigned)n_g << 8);
+      vb.cinfo[(size_t)b * 4 + 1] = c1;
+      vb.cinfo[(size_t)b * 4 + 2] = c2;
+      vb.cinfo[(size_t)b * 4 + 3] = c4;
+    }
   }
 }
 
 __global__ void __launch_bounds__(COOK_WAVE) match_merge2(MatchIn in, V2Buf vb) {
-  merge_job(in, vb, vb.ctl->head, vb.ctl->wcur, blockIdx.x);
+  merge_job<false>(in, vb, vb.ctl->head, vb.ctl->wcur, blockIdx.x);
 }
 
 // ---- resolve -----------------------------------------------------------------------------------------------------------------
@@ -1766,7 +1920,7 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_persist(MatchIn in, Ma
     }
     if (!grid_barrier(pc, nb)) return;
     const unsigned long long t1 = cook_ticks();
-    for (unsigned b = wg * MV_EW + wave_id(); b < nwin; b += nb * MV_EW) merge_job(in, vb, head, wcur, b);
+    for (unsigned b = wg * MV_EW + wave_id(); b < nwin; b += nb * MV_EW) merge_job<false>(in, vb, head, wcur, b);
     if (!grid_barrier(pc, nb)) return;
     if (wg == 0) {
       const unsigned long long t2 = cook_ticks();
@@ -1800,7 +1954,7 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2_multi(const Pool
 }
 __global__ void __launch_bounds__(COOK_WAVE) match_merge2_multi(const PoolCtx* __restrict__ ctx) {
   const PoolCtx& c = ctx[blockIdx.z];
-  merge_job(c.in, c.vb, c.vb.ctl->head, c.vb.ctl->wcur, blockIdx.x);
+  merge_job<false>(c.in, c.vb, c.vb.ctl->head, c.vb.ctl->wcur, blockIdx.x);
 }
 __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2_multi(const PoolCtx* __restrict__ ctx) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(ResolveLds)];

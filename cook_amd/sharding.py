@@ -142,7 +142,10 @@ class ShardedCluster:
         self.last_group_usage = total
         self.last_pool_usage = usages
 
-        lockstep = len(self.pools) > self.max_chains and all(hasattr(self.engines[p], "cycle_run_rank") for p in self.pools)
+        multi = all(hasattr(self.engines[p], "cycle_run_rank") for p in self.pools)
+        # match_algo 5: ONE persistent launch places all local pools, every pool advancing on its own (match_world.hpp)
+        world = multi and all(getattr(getattr(self.engines[p], "params", None), "match_algo", 0) == 5 for p in self.pools)
+        lockstep = world or (multi and len(self.pools) > self.max_chains)
 
         def run(p):
             self.engines[p].rank_set_quota(self.quota_inputs(p, usages[p], total))
@@ -157,8 +160,12 @@ class ShardedCluster:
             # share dispatch pipes: 4 pools 113 ms, 6 or 8 pools 186 ms per cycle), while pools in lockstep pay for the
             # slowest pool of every round (8 in lockstep: 215 ms).  So: at most MAX_CHAINS streams, pools spread over them.
             from .engine import cycle_match_multi
-            n_chains = min(len(self.pools), self.max_chains)
-            groups = [[self.engines[p] for p in self.pools[c::n_chains]] for c in range(n_chains)]
-            list(self._tp.map(cycle_match_multi, groups))
+            if world:
+                cycle_match_multi([self.engines[p] for p in self.pools])
+                n_chains = 0
+            n_chains = min(len(self.pools), self.max_chains) if not world else 0
+            if n_chains:
+                groups = [[self.engines[p] for p in self.pools[c::n_chains]] for c in range(n_chains)]
+                list(self._tp.map(cycle_match_multi, groups))
         if self.n_users and all(hasattr(self.engines[p], "rank_user_usage") for p in self.pools):
             self.last_user_usage = all_reduce_user_usage([self.engines[p] for p in self.pools], self.n_users, self.world, self.device)

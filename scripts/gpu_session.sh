@@ -14,7 +14,7 @@ mkdir -p "$OUT"
 cd "$ROOT"
 STEPS=${STEPS:-"ubench tests one all"}
 LIBS=${LIBS:-default}
-ONE_ARGS="--pools 1 --pending 125000 --running 50000 --offers 6250 --steps 4 --warmup 1 --no-cpu-baseline --no-adjacent --no-check"
+ONE_ARGS="${ONE_PRE:-} --pools 1 --pending 125000 --running 50000 --offers 6250 --steps 4 --warmup 1 --no-cpu-baseline --no-adjacent --no-check"
 ALL_ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-adjacent --no-check"
 for S in $STEPS; do
   case $S in
@@ -29,7 +29,7 @@ for S in $STEPS; do
         if [ "$LIB" = default ]; then unset COOK_LIB; else export COOK_LIB=$ROOT/$LIB; fi
         if [ $S = one ]; then ARGS="$ONE_ARGS ${ONE_EXTRA:-}"; else ARGS="$ALL_ARGS ${ALL_EXTRA:-}"; fi
         timeout 180 python bench.py $ARGS > "$OUT/${S}_$NAME.json" 2> "$OUT/${S}_$NAME.err"
-        echo "$S $NAME exit $?"; grep WALKPROF "$OUT/${S}_$NAME.err" | tail -2
+        echo "$S $NAME exit $?"; grep -E "WALKPROF|WORLDPROF" "$OUT/${S}_$NAME.err" | tail -4
         python - <<PY
 import json
 try:

@@ -72,7 +72,8 @@ static void fiber_entry() {
   f->done = true;
   ++s.events;
   // a finished thread no longer takes part in rendezvous (terminated waves leave the barrier count)
-  Group& w = s.waves[f->tid >> 6];
+  BlockCtx& b = *f->blk;
+  Group& w = b.waves[f->tid >> 6];
   if (w.size) {
     --w.size;
     if (w.size && w.count == w.size) {
@@ -81,11 +82,11 @@ static void fiber_entry() {
       ++s.events;
     }
   }
-  if (s.block.size) {
-    --s.block.size;
-    if (s.block.size && s.block.count == s.block.size) {
-      s.block.count = 0;
-      ++s.block.gen;
+  if (b.block.size) {
+    --b.block.size;
+    if (b.block.size && b.block.count == b.block.size) {
+      b.block.count = 0;
+      ++b.block.gen;
       ++s.events;
     }
   }
@@ -108,63 +109,98 @@ void arrive(Group& g) {
   }
 }
 
-void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+void yield() {
+  State& s = S();
+  Fiber* f = s.cur;
+  to_main(f, s);
+  s.cur = f;
+}
+
+char* block_lds(size_t bytes) {
+  BlockCtx& b = B();
+  if (b.lds.size() < bytes) b.lds.resize(bytes);  // first caller of the block sizes it (every thread asks for the same amount)
+  return b.lds.data();
+}
+
+// run the blocks [b0, b1) of s.blocks concurrently until all their threads have finished
+static void run_blocks(State& s, unsigned b0, unsigned b1, unsigned nthreads, dim3 block) {
+  const unsigned nwaves = (nthreads + 63) / 64;
+  const size_t nf = (size_t)(b1 - b0) * nthreads;
+  if (s.fibers.size() < nf) s.fibers.resize(nf);
+  for (unsigned bi = b0; bi < b1; ++bi) {
+    BlockCtx& b = s.blocks[bi];
+    b.block = Group();
+    b.block.size = nthreads;
+    b.waves.assign(nwaves, Group());
+    b.xchg.assign((size_t)nwaves * 64, 0);
+    for (unsigned w = 0; w < nwaves; ++w) b.waves[w].size = std::min(64u, nthreads - w * 64);
+    for (unsigned t = 0; t < nthreads; ++t) {
+      Fiber& f = s.fibers[(size_t)(bi - b0) * nthreads + t];
+      if (!f.stack) f.stack = (char*)std::malloc(kStack);
+      f.done = false;
+      f.site = "";
+      f.tid = t;
+      f.tidx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+      f.blk = &b;
+      prepare(f);
+    }
+  }
+  size_t remaining = nf;
+  unsigned spins = 0;
+  while (remaining) {
+    const uint64_t ev0 = s.events;
+    for (size_t x = 0; x < nf; ++x) {
+      Fiber& f = s.fibers[x];
+      if (f.done) continue;
+      s.cur = &f;
+      to_fiber(s, f);
+      if (f.done) --remaining;
+    }
+    // deadlock guard: every live fiber is parked (rendezvous or spin loop) and nothing changed during a whole pass
+    if (s.events == ev0) {
+      if (++spins > 2000) {
+        std::fprintf(stderr, "emu: deadlock (threads waiting at a rendezvous not all threads reach, or spinning on a word nobody writes)\n");
+        unsigned shown = 0;
+        for (size_t x = 0; x < nf && shown < 40; ++x)
+          if (!s.fibers[x].done) {
+            std::fprintf(stderr, "  live thread %u of block %u last site: %s\n", s.fibers[x].tid, s.fibers[x].blk->bidx.x, s.fibers[x].site);
+            ++shown;
+          }
+        std::abort();
+      }
+    } else {
+      spins = 0;
+    }
+  }
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body, bool coop) {
   State& s = S();
   const unsigned nthreads = block.x * block.y * block.z;
   if (nthreads == 0 || nthreads > 1024) {
     std::fprintf(stderr, "emu: bad block size %u\n", nthreads);
     std::abort();
   }
-  if (s.fibers.size() < nthreads) s.fibers.resize(nthreads);
-  const unsigned nwaves = (nthreads + 63) / 64;
-  s.waves.assign(nwaves, Group());
-  s.xchg.assign((size_t)nwaves * 64, 0);
   s.blockDim_ = block;
   s.gridDim_ = grid;
   s.body = &body;
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
-        s.blockIdx_ = dim3(bx, by, bz);
-        s.block = Group();
-        s.block.size = nthreads;
-        for (unsigned w = 0; w < nwaves; ++w) {
-          s.waves[w] = Group();
-          s.waves[w].size = std::min(64u, nthreads - w * 64);
+  const unsigned nblocks = grid.x * grid.y * grid.z;
+  if (coop) {
+    s.blocks.assign(nblocks, BlockCtx());
+    unsigned bi = 0;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+      for (unsigned by = 0; by < grid.y; ++by)
+        for (unsigned bx = 0; bx < grid.x; ++bx) s.blocks[bi++].bidx = dim3(bx, by, bz);
+    run_blocks(s, 0, nblocks, nthreads, block);
+  } else {  // one block after another, in one reusable context
+    if (s.blocks.size() != 1) s.blocks.assign(1, BlockCtx());
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+      for (unsigned by = 0; by < grid.y; ++by)
+        for (unsigned bx = 0; bx < grid.x; ++bx) {
+          s.blocks[0].bidx = dim3(bx, by, bz);
+          run_blocks(s, 0, 1, nthreads, block);
         }
-        for (unsigned t = 0; t < nthreads; ++t) {
-          Fiber& f = s.fibers[t];
-          if (!f.stack) f.stack = (char*)std::malloc(kStack);
-          f.done = false;
-          f.site = "";
-          f.tid = t;
-          f.tidx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-          prepare(f);
-        }
-        unsigned remaining = nthreads;
-        unsigned spins = 0;
-        while (remaining) {
-          const uint64_t ev0 = s.events;
-          for (unsigned t = 0; t < nthreads; ++t) {
-            Fiber& f = s.fibers[t];
-            if (f.done) continue;
-            s.cur = &f;
-            to_fiber(s, f);
-            if (f.done) --remaining;
-          }
-          // deadlock guard: every live fiber is parked and no rendezvous can complete
-          if (s.events == ev0) {
-            if (++spins > 1000) {
-              std::fprintf(stderr, "emu: deadlock (threads waiting at a rendezvous not all threads reach)\n");
-              for (unsigned t = 0; t < nthreads; ++t)
-                if (!s.fibers[t].done) std::fprintf(stderr, "  live thread %u last site: %s\n", t, s.fibers[t].site);
-              std::abort();
-            }
-          } else {
-            spins = 0;
-          }
-        }
-      }
+  }
   s.body = nullptr;
   s.cur = nullptr;
 }

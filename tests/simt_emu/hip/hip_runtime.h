@@ -6,8 +6,10 @@
 // ordering, LDS banking, occupancy or timing.
 //
 // Model: one OS thread; every GPU thread of a block is a ucontext fiber; blocks of a grid run one after another
-// (so kernels must not wait on other blocks); a wave is 64 consecutive threads; wave collectives and
-// __syncthreads are rendezvous points at which fibers yield.
+// (so kernels must not wait on other blocks) — except for a CO-SCHEDULED launch (emu::launch with coop = true, used for the
+// persistent placement kernel), whose blocks all run concurrently, each with its own LDS (emu::block_lds), and whose spin loops
+// hand the processor on through emu::yield(); a wave is 64 consecutive threads; wave collectives and __syncthreads are
+// rendezvous points at which fibers yield.
 #pragma once
 #include <ucontext.h>
 
@@ -66,6 +68,13 @@ struct Group {
 #if defined(__x86_64__)
 #define EMU_FAST_SWITCH 1
 #endif
+struct BlockCtx {  // one resident block
+  dim3 bidx;
+  Group block;
+  std::vector<Group> waves;
+  std::vector<uint64_t> xchg;  // 64 slots per wave
+  std::vector<char> lds;       // emu::block_lds storage (co-scheduled kernels: `static` shared arrays would be shared by all blocks)
+};
 struct Fiber {
   ucontext_t ctx;
   void* sp = nullptr;  // EMU_FAST_SWITCH: the fiber's saved stack pointer
@@ -73,6 +82,7 @@ struct Fiber {
   bool done = true;
   unsigned tid = 0;
   dim3 tidx;
+  BlockCtx* blk = nullptr;
   const char* site = "";  // last EMU_SITE() the fiber passed (deadlock diagnostics)
 };
 struct State {
@@ -80,20 +90,22 @@ struct State {
   void* main_sp = nullptr;
   std::vector<Fiber> fibers;
   Fiber* cur = nullptr;
-  dim3 blockIdx_, blockDim_, gridDim_;
-  Group block;
-  std::vector<Group> waves;
-  std::vector<uint64_t> xchg;  // 64 slots per wave
-  std::vector<uint64_t> ballot;
+  dim3 blockDim_, gridDim_;
+  std::vector<BlockCtx> blocks;
   const std::function<void()>* body = nullptr;
-  uint64_t events = 0;  // rendezvous completions + thread exits (progress detector)
+  uint64_t events = 0;  // rendezvous completions + thread exits + global stores of spin-waited words (progress detector)
 };
 State& S();
-void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void launch(dim3 grid, dim3 block, const std::function<void()>& body, bool coop = false);
 void arrive(Group& g);
+void yield();                    // a spin loop hands the processor to the other fibers (co-scheduled launches)
+inline void progress() { ++S().events; }
+char* block_lds(size_t bytes);   // this block's LDS (same pointer for every thread of the block)
+inline BlockCtx& B() { return *S().cur->blk; }
 inline unsigned lane() { return S().cur->tid & 63u; }
 inline unsigned wave() { return S().cur->tid >> 6; }
-inline unsigned wave_size() { return S().waves[wave()].size; }
+inline unsigned wave_size() { return B().waves[wave()].size; }
+inline Group& wave_group() { return B().waves[wave()]; }
 
 template <class T>
 inline uint64_t bits_of(T v) {
@@ -110,7 +122,7 @@ inline T from_bits(uint64_t b) {
 }
 template <class T>
 inline T shfl_idx(T v, int src) {
-  State& s = S();
+  BlockCtx& s = B();
   const unsigned w = wave(), l = lane();
   s.xchg[w * 64 + l] = bits_of(v);
   arrive(s.waves[w]);
@@ -123,12 +135,12 @@ inline T shfl_idx(T v, int src) {
 
 #define EMU_SITE(s) (emu::S().cur->site = (s))
 #define threadIdx (emu::S().cur->tidx)
-#define blockIdx (emu::S().blockIdx_)
+#define blockIdx (emu::B().bidx)
 #define blockDim (emu::S().blockDim_)
 #define gridDim (emu::S().gridDim_)
 static const int warpSize = 64;
 
-inline void __syncthreads() { emu::arrive(emu::S().block); }
+inline void __syncthreads() { emu::arrive(emu::B().block); }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 
@@ -155,7 +167,7 @@ inline T __shfl_xor(T v, int m, int width = 64) {
   return emu::shfl_idx(v, (int)emu::lane() ^ m);
 }
 inline unsigned long long __ballot(int pred) {
-  emu::State& s = emu::S();
+  emu::BlockCtx& s = emu::B();
   const unsigned w = emu::wave(), l = emu::lane();
   s.xchg[w * 64 + l] = pred ? 1 : 0;
   emu::arrive(s.waves[w]);
@@ -184,6 +196,7 @@ inline int __float_as_int(float v) { return emu::from_bits<int>(emu::bits_of(v))
 
 template <class T>
 inline T atomicAdd(T* p, T v) {
+  emu::progress();
   T o = *p;
   *p = o + v;
   return o;
@@ -208,6 +221,7 @@ inline T atomicExch(T* p, T v) {
 }
 template <class T>
 inline T atomicCAS(T* p, T cmp, T v) {
+  emu::progress();
   T o = *p;
   if (o == cmp) *p = v;
   return o;
@@ -313,4 +327,10 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   do {                                                                           \
     std::function<void()> _emu_body = [&]() { kernel(__VA_ARGS__); };            \
     emu::launch(dim3(grid), dim3(block), _emu_body);                             \
+  } while (0)
+// all blocks of the grid resident at once (what the persistent placement kernel needs)
+#define emuLaunchCoop(kernel, grid, block, ...)                                  \
+  do {                                                                           \
+    std::function<void()> _emu_body = [&]() { kernel(__VA_ARGS__); };            \
+    emu::launch(dim3(grid), dim3(block), _emu_body, true);                       \
   } while (0)

@@ -81,7 +81,7 @@ def test_rank_edge_cases(make_engine):
     P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=0))
 
 
-ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4], ids=["default", "serial", "launches+reeval", "persistent"])
+ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4, 5], ids=["default", "serial", "launches+reeval", "persistent", "world"])
 
 
 @ALGOS
@@ -106,11 +106,11 @@ def test_match_overcommitted_cluster(make_engine, algo):
     p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
     j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, p)
     assert (j2o < 0).sum() > 100
-    if algo in (3, 4):
+    if algo in (3, 4, 5):
         with make_engine(p) as e:
             e.match(pool.pending_jobs, pool.offers)
             stats = e.match_stats()
-        assert (stats["persistent"] & 1) == (1 if algo == 4 else 0)  # the persistent kernel really ran (no silent fallback)
+        assert stats["persistent"] == {3: 0, 4: 1, 5: 2}[algo]  # the persistent kernel really ran (no silent fallback)
         if algo == 3:
             assert stats["reevals"] > 0
 
@@ -213,12 +213,21 @@ def test_cycle_with_considerable_filters(make_engine):
     assert 0 < len(pos) <= 150 and not np.array_equal(pos, np.arange(len(pos)))
 
 
-def test_multi_pool_lockstep(make_engine):
-    # three pools of different sizes (different numbers of offer chunks, rounds and K, one of them with nothing pending)
+@pytest.mark.parametrize("algo", [2, 5], ids=["lockstep-launches", "world"])
+def test_multi_pool(make_engine, algo):
+    # three pools of different sizes (different numbers of offer chunks, rounds and K, one of them with nothing pending): in lockstep
+    # launches (blockIdx.z = pool) and as independent walkers of ONE persistent launch (match_world.hpp)
     pools = [synth.make_pool(seed=71, n_pending=400, n_running=100, n_users=20, n_offers=300, gpus=True, constraints=True),
              synth.make_pool(seed=72, n_pending=150, n_running=50, n_users=10, n_offers=40),
              synth.make_pool(seed=73, n_pending=0, n_running=30, n_users=5, n_offers=20)]
-    P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0), k=300)
+    P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0, match_algo=algo), k=300, want_persistent=2 if algo == 5 else 0)
+
+
+def test_world_many_pools_good_enough(make_engine):
+    # five walkers at once, good-enough 0.8 (the reference's default), groups of every type in one of the pools
+    pools = [synth.make_pool(seed=171 + i, n_pending=250 + 60 * i, n_running=40, n_users=12, n_offers=90 + 40 * i, gpus=(i % 2 == 0),
+                             constraints=(i % 2 == 0)) for i in range(5)]
+    P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=0.8, match_algo=5), k=400, want_persistent=2)
 
 
 def test_edge_cases(make_engine):
@@ -350,7 +359,7 @@ def test_fuzz_rank_cycle_match_explain(make_engine):
                   n_users=int(rng.integers(1, 30)), n_offers=int(rng.integers(1, 100)), gpus=bool(rng.integers(0, 2)),
                   constraints=bool(rng.integers(0, 2)), fractional=bool(rng.integers(0, 2)), tie_heavy=bool(rng.integers(0, 2)),
                   no_shares=bool(rng.integers(0, 4) == 0), quota_frac=float(rng.choice([0.0, 0.02, 0.5])))
-        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5, 0.3])), match_algo=int(rng.choice([0, 1, 3, 4])),
+        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5, 0.3])), match_algo=int(rng.choice([0, 1, 3, 4, 5])),
                              max_over_quota_jobs=int(rng.choice([0, 3, 100])))
         pool = synth.make_pool(**kw)
         P.rank_parity(make_engine, pool, p)
@@ -390,7 +399,7 @@ def test_fuzz_groups_constraints_metrics_replay(make_engine):
     rng = np.random.default_rng(20260925)
     for _ in range(10):
         seed = int(rng.integers(1, 1 << 30))
-        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5])), match_algo=int(rng.choice([0, 1, 3, 4])))
+        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5])), match_algo=int(rng.choice([0, 1, 3, 4, 5])))
         n, m = int(rng.integers(5, 200)), int(rng.integers(3, 60))
         attr = np.zeros((m, 2), dtype=np.uint32)
         attr[:, 0] = rng.integers(1, 4, m)

@@ -76,7 +76,7 @@ def test_rank_edge_cases(make_engine):
     P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=0))
 
 
-ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4], ids=["default", "serial", "launches+reeval", "persistent"])
+ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4, 5], ids=["default", "serial", "launches+reeval", "persistent", "world"])
 
 
 @ALGOS
@@ -103,11 +103,11 @@ def test_match_fills_cluster_then_fails(make_engine, algo):
     p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
     j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, p)
     assert (j2o < 0).sum() > 1000
-    if algo in (3, 4):
+    if algo in (3, 4, 5):
         with make_engine(p) as e:
             e.match(pool.pending_jobs, pool.offers)
             stats = e.match_stats()
-        assert stats["persistent"] == (1 if algo == 4 else 0)  # the persistent kernel ran, and never fell back
+        assert stats["persistent"] == {3: 0, 4: 1, 5: 2}[algo]  # the persistent kernel ran, and never fell back
         if algo == 3:
             assert stats["reevals"] > 0
 
@@ -243,12 +243,13 @@ def test_cycle_with_considerable_filters(make_engine):
     assert 0 < len(pos) <= 1000 and not np.array_equal(pos, np.arange(len(pos)))
 
 
-def test_multi_pool_lockstep(make_engine):
+@pytest.mark.parametrize("algo", [2, 5], ids=["lockstep-launches", "world"])
+def test_multi_pool(make_engine, algo):
     pools = [synth.make_pool(seed=71, n_pending=6000, n_running=2000, n_users=100, n_offers=3000, gpus=True, constraints=True),
              synth.make_pool(seed=72, n_pending=3000, n_running=500, n_users=50, n_offers=400),
              synth.make_pool(seed=73, n_pending=0, n_running=30, n_users=5, n_offers=20),
              synth.make_pool(seed=74, n_pending=5000, n_running=0, n_users=80, n_offers=150)]
-    P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0), k=4000)
+    P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0, match_algo=algo), k=4000, want_persistent=2 if algo == 5 else 0)
 
 
 def test_edge_cases(make_engine):
