@@ -840,12 +840,13 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     vb.jr = jr;
     JobCons* jcons = e->v_jcons.ensure(K);
     vb.jcons = jcons;
-    vb.prec = e->v_prec.ensure((size_t)MV_WMAX * C);
-    vb.colbits = e->v_colbits.ensure((size_t)(M ? M : 1u) * MV_JG);
-    vb.cand_fit = e->v_cand_fit.ensure((size_t)MV_WMAX * MV_L);
-    vb.cand_idx = e->v_cand_idx.ensure((size_t)MV_WMAX * MV_L);
-    vb.ge_idx = e->v_ge_idx.ensure((size_t)MV_WMAX * MV_LG);
-    vb.cinfo = e->v_cinfo.ensure((size_t)MV_WMAX * 4);
+    // sized for a LONG window (MV_WLONG jobs, match_v2.hpp): 128 bytes per (job, offer chunk) = 26 MB for a C4 pool
+    vb.prec = e->v_prec.ensure((size_t)MV_WLONG * C);
+    vb.colbits = e->v_colbits.ensure((size_t)(M ? M : 1u) * MV_JGL);
+    vb.cand_fit = e->v_cand_fit.ensure((size_t)MV_WLONG * MV_L);
+    vb.cand_idx = e->v_cand_idx.ensure((size_t)MV_WLONG * MV_L);
+    vb.ge_idx = e->v_ge_idx.ensure((size_t)MV_WLONG * MV_LG);
+    vb.cinfo = e->v_cinfo.ensure((size_t)MV_WLONG * 4);
     vb.ctl = e->w_ctl.ensure(1);
     {
       MatchIn* din = e->v_in.ensure(1);
@@ -872,6 +873,8 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       c0.wgrow_pct = sharing >= 4 ? 150u : 200u;
       if (const char* ev = std::getenv("COOK_WGROW_PCT")) c0.wgrow_pct = (unsigned)std::max(100, std::atoi(ev));
     }
+    c0.wlong_cap = (unsigned)MV_WLONG;
+    if (const char* ev = std::getenv("COOK_WLONG")) c0.wlong_cap = std::atoi(ev) ? (unsigned)MV_WLONG : (unsigned)MV_WMAX;
     c0.reeval_max = algo == 3 ? 0x7FFFFFFFu : 0u;  // 3: list-exhausted jobs re-evaluated in place instead of ending the round
     WinCtl hc = c0;
     bool done = false;
@@ -1086,7 +1089,7 @@ bool match_rounds_world(cook_engine** es, unsigned n) {
   if (L == 0) return true;
   if (L > MW_MAX_POOLS || L > 64) return false;
   for (unsigned x = 0; x < L; ++x)
-    if (es[live[x]]->deferred_k >= (1u << 22) || MV_WMAX > 1024) return false;  // world_pack's field widths
+    if (es[live[x]]->deferred_k >= (1u << 22) || MV_WLONG > 4096) return false;  // world_pack's field widths
 #ifdef __HIP_EMU__
   const unsigned n_eval = 2;
 #else

@@ -70,7 +70,13 @@ constexpr int MV_WMAX = 512;
 constexpr int MV_S = 256;
 constexpr int MV_HASH = 1024;
 #endif
-constexpr int MV_JG = MV_WMAX / 64;        // job groups (waves of jobs) per window
+constexpr int MV_JG = MV_WMAX / 64;        // job groups (waves of jobs) per window whose walk data fits the resolve workgroup's LDS
+// A window may grow to MV_WLONG jobs once next to nothing of it has to be WALKED: when the cluster is full almost every job is
+// settled in the parallel phase of the resolve kernel (no feasible offer under the snapshot, however the jobs before it fare) and
+// needs no LDS at all — only the jobs the walk visits are staged (at most MV_WMAX of them, by walk position).  One C4 pool spent
+// 152 of its 604 rounds resolving 512 such jobs each; with long windows that tail takes about 20 rounds.
+constexpr int MV_WLONG = MV_WMAX * 8;
+constexpr int MV_JGL = MV_WLONG / 64;      // job groups of a long window (stride of colbits)
 constexpr int MV_EPJ_MAX = (MV_L + MV_LG) > 16 ? (MV_L + MV_LG) : 16;
 constexpr int MV_JSTEP = MV_S / MV_EPJ_MAX;  // jobs inserted into the slot table per step (at most MV_EPJ_MAX entries each)
 static_assert(MV_JSTEP >= 1, "slot-table step sizing");
@@ -121,7 +127,7 @@ struct WinCtl {
   unsigned reeval_max;    // list-exhausted jobs re-evaluated in place per round before the round ends (0 = end the round at once)
   unsigned reevals;       // jobs re-evaluated in place (statistics)
   unsigned wgrow_pct;     // next window = this percentage of what the round resolved (window ended early) / of the window (it did not)
-  unsigned pad_;
+  unsigned wlong_cap;     // largest window the launch sequence allows (MV_WLONG, or MV_WMAX when long windows are switched off)
   unsigned long long t_eval, t_merge;  // persistent kernel: ticks spent in the eval / merge phases (as seen by workgroup 0)
 #ifdef COOK_WALK_PROF  // measurement build: shader cycles / jobs of the walk by outcome (0 shortcut, 1 touched offer wins, 2 new lane,
                        // 3 walked and unmatched, 4 member of a constrained group, 5 exact path ran)
@@ -477,8 +483,8 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
     if (!__any(res)) {
       E.c1 += valid ? 1u : 0u;
       if (lane == 0) {
-        if (THROUGH) st_agent(&vb.colbits[(size_t)v * MV_JG + jg], (uint64_t)0ull);
-        else vb.colbits[(size_t)v * MV_JG + jg] = 0ull;
+        if (THROUGH) st_agent(&vb.colbits[(size_t)v * MV_JGL + jg], (uint64_t)0ull);
+        else vb.colbits[(size_t)v * MV_JGL + jg] = 0ull;
       }
       continue;
     }
@@ -499,8 +505,8 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
     if (stat && E.slow) stat = static_pass(in, E.jj, v);
     const unsigned long long bits = __ballot(stat);
     if (lane == 0) {
-      if (THROUGH) st_agent(&vb.colbits[(size_t)v * MV_JG + jg], (uint64_t)bits);
-      else vb.colbits[(size_t)v * MV_JG + jg] = bits;
+      if (THROUGH) st_agent(&vb.colbits[(size_t)v * MV_JGL + jg], (uint64_t)bits);
+      else vb.colbits[(size_t)v * MV_JGL + jg] = bits;
     }
     bool feas = stat && dyn_fast(j, o, acount);
     if (feas && E.grouped) {
@@ -699,9 +705,14 @@ static __device__ __forceinline__ void eval_tile_wave(EvalWaveLds& W, const Matc
   chunk_store(&vb.prec[(size_t)b * vb.C + ch], R, true);
 }
 
+// grid = (offer chunks, MV_JG): a long window's further job groups are taken by the same blocks, one after the other
 __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, MatchState st, V2Buf vb) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(EvalLds)];
-  eval_tile(lds, in, st, vb, vb.ctl->head, vb.ctl->wcur, blockIdx.x, blockIdx.y);
+  const unsigned head = vb.ctl->head, wcur = vb.ctl->wcur;
+  for (unsigned jg = blockIdx.y; jg * COOK_WAVE < wcur; jg += gridDim.y) {
+    eval_tile(lds, in, st, vb, head, wcur, blockIdx.x, jg);
+    __syncthreads();
+  }
 }
 
 // ---- merge: one wave per job ---------------------------------------------------------------------------------------------
@@ -817,7 +828,8 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
 }
 
 __global__ void __launch_bounds__(COOK_WAVE) match_merge2(MatchIn in, V2Buf vb) {
-  merge_job<false>(in, vb, vb.ctl->head, vb.ctl->wcur, blockIdx.x);
+  const unsigned head = vb.ctl->head, wcur = vb.ctl->wcur;
+  for (unsigned b = blockIdx.x; b < wcur; b += gridDim.x) merge_job<false>(in, vb, head, wcur, b);
 }
 
 // ---- resolve -----------------------------------------------------------------------------------------------------------------
@@ -868,20 +880,20 @@ struct ResolveLds {
   GEntL gent[MV_WMAX][MV_LG];
   SlotRec slot[MV_S];
   unsigned long long col[MV_S][MV_JG];
-  unsigned long long visit[MV_JG];
+  unsigned long long visit[MV_JGL];
   double tac[MV_T], tam[MV_T];  // current state of the touched offers, by owner lane (published for a re-evaluation)
   double rfit[MV_RWAVES_MAX];
   int hkey[MV_HASH];
-  int j2o[MV_WMAX];                 // results of the walk, flushed to HBM once per round: a global store inside the walk
-  int tacount[MV_T];                // would stall later s_waitcnt vmcnt(0) on its acknowledgement
+  int j2o[MV_WMAX];                 // results of the walk BY WALK POSITION, flushed to HBM once per round: a global store inside
+  int tacount[MV_T];                // the walk would stall later s_waitcnt vmcnt(0) on its acknowledgement
   int ridx[MV_RWAVES_MAX], rge[MV_RWAVES_MAX];
   unsigned rc[MV_RWAVES_MAX][3];
-  unsigned vbase[MV_JG + 1];        // walk position of the first visited job of each 64-job group
+  unsigned vbase[MV_JGL + 1];       // walk position of the first visited job of each 64-job group
   unsigned nslots, minbad;
   int cmd;                          // window index of the job to re-evaluate, -1 = the walk is over
   unsigned short hslot[MV_HASH];
   unsigned char slot_lane[MV_S];
-  unsigned char fail[MV_WMAX];
+  unsigned char fail[MV_WMAX];      // by walk position
 };
 
 // One round of the window walk by ONE workgroup of MV_RTHREADS threads (all of them must call it).
@@ -936,7 +948,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   const uint32_t* const j_index = vb.in_dev->j_index;
   // ---- set-up phase (all threads): stage the window in LDS -------------------------------------------------------------
   for (unsigned x = tid; x < MV_HASH; x += NT) s_hkey[x] = -1;
-  if (tid < MV_JG) s_visit[tid] = 0ull;
+  if (tid < MV_JGL) s_visit[tid] = 0ull;
   if (tid == 0) {
     s_nslots = 0;
     s_minbad = 0xFFFFFFFFu;
@@ -953,24 +965,25 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     const bool trivial = (info & 0xFFFFu) == 0u && !grouped && c1 > 0u && (c2 == 0u || c2 > (unsigned)MV_T) &&
                          (c4 == 0u || c4 > (unsigned)MV_T);
     if (trivial) {
-      s_j2o[b] = -1;
-      s_fail[b] = (unsigned char)(1u | (c2 ? 2u : 0u) | (c4 ? 4u : 0u));
+      // final whatever this round does, also for a job behind the point where the round stops: job_to_offer keeps the -1 it was
+      // initialised with; should the job still be unresolved next round, its summary is simply rewritten under the newer snapshot
+      if (st.fail_code) st.fail_code[head + b] = 1u | (c2 ? 2u : 0u) | (c4 ? 4u : 0u);
     } else {
-      s_fail[b] = 0;  // a visited job that gets matched leaves it at that
       atomicOr(&s_visit[b >> 6], 1ull << (b & 63u));
     }
   }
   __syncthreads();
   if (tid == 0) {
     unsigned acc = 0;
-    for (unsigned g = 0; g < (unsigned)MV_JG; ++g) {
+    for (unsigned g = 0; g < (unsigned)MV_JGL; ++g) {
       s_vbase[g] = acc;
       acc += (unsigned)__popcll(s_visit[g]);
     }
-    s_vbase[MV_JG] = acc;
+    s_vbase[MV_JGL] = acc;
   }
   __syncthreads();
-  const unsigned n_list = s_vbase[MV_JG];  // jobs the walk has to visit
+  const unsigned n_list = s_vbase[MV_JGL];  // jobs the walk has to visit
+  const unsigned n_walk = n_list < (unsigned)MV_WMAX ? n_list : (unsigned)MV_WMAX;  // ... and can stage in this round
   // walk records + candidate lists of the visited jobs -> LDS, by walk position (one parallel pass; the slot-table passes below
   // then never touch HBM)
   constexpr int EPJ = MV_L + MV_LG;
@@ -979,8 +992,10 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     const unsigned long long vw = s_visit[b >> 6];
     if (!((vw >> (b & 63u)) & 1ull)) continue;
     const unsigned i = s_vbase[b >> 6] + (unsigned)__popcll(vw & ((1ull << (b & 63u)) - 1ull));
+    if (i >= n_walk) continue;
     const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
     if (q == (unsigned)EPJ) {
+      s_fail[i] = 0;  // a visited job that gets matched leaves it at that
       const JobRec j = vb.jr[head + b];
       const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
       JobL r;
@@ -1020,10 +1035,10 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   // overflows (rare) redo it MV_JSTEP jobs at a time so that the overflow cuts the walk at a job boundary (every job
   // before the cut has all its candidates staged).
   for (int pass = 0; pass < 2; ++pass) {
-    const unsigned step = pass == 0 ? (n_list ? n_list : 1u) : (unsigned)MV_JSTEP;
+    const unsigned step = pass == 0 ? (n_walk ? n_walk : 1u) : (unsigned)MV_JSTEP;
     bool overflow = false;
-    for (unsigned s0 = 0; s0 < n_list; s0 += step) {
-      const unsigned e1 = ((s0 + step < n_list) ? s0 + step : n_list) * EPJ;
+    for (unsigned s0 = 0; s0 < n_walk; s0 += step) {
+      const unsigned e1 = ((s0 + step < n_walk) ? s0 + step : n_walk) * EPJ;
       for (unsigned e = s0 * EPJ + tid; e < e1; e += NT) {
         const unsigned i = e / EPJ, q = e % EPJ;
         const int idx = q < (unsigned)MV_L ? s_ent[i][q].off : s_gent[i][q - MV_L].off;
@@ -1060,7 +1075,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     }
     __syncthreads();
   }
-  const unsigned n_eff = s_minbad < n_list ? s_minbad : n_list;  // walk positions resolvable in this round
+  const unsigned n_eff = s_minbad < n_walk ? s_minbad : n_walk;  // walk positions resolvable in this round
   for (unsigned e = tid; e < n_eff * EPJ; e += NT) {  // candidate offer -> slot
     const unsigned i = e / EPJ, q = e % EPJ;
     const int idx = q < (unsigned)MV_L ? s_ent[i][q].off : s_gent[i][q - MV_L].off;
@@ -1084,7 +1099,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   }
   for (unsigned x = tid; x < nslots * MV_JG; x += NT) {
     const unsigned s = x / MV_JG, g = x % MV_JG;
-    s_col[s][g] = (g * COOK_WAVE < nwin) ? vb.colbits[(size_t)s_slot[s].offer * MV_JG + g] : 0ull;
+    s_col[s][g] = (g * COOK_WAVE < nwin) ? vb.colbits[(size_t)s_slot[s].offer * MV_JGL + g] : 0ull;
   }
   if (tid == 0) s_cmd = -1;
   __syncthreads();
@@ -1191,7 +1206,15 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   unsigned nT = 0;
   unsigned stop = 0;  // 1 list exhausted, 2 touched set full, 3 group barrier, 4 slot table cut the window
   unsigned matched = 0, head_matched = ctl.head_matched;
-  unsigned resolved = n_eff < n_list ? (unsigned)s_job[n_eff].b : nwin;
+  // window position of walk position i (for the one position the records do not hold: the first job beyond the staged ones)
+  auto walkpos_to_b = [&](unsigned i) {
+    unsigned g = 0;
+    while (g + 1 < (unsigned)MV_JGL && s_vbase[g + 1] <= i) ++g;
+    unsigned long long m = s_visit[g];
+    for (unsigned r = i - s_vbase[g]; r > 0; --r) m &= m - 1ull;
+    return g * COOK_WAVE + (unsigned)__ffsll((unsigned long long)m) - 1u;
+  };
+  unsigned resolved = n_eff < n_walk ? (unsigned)s_job[n_eff].b : (n_eff < n_list ? walkpos_to_b(n_eff) : nwin);
   unsigned nslots_cur = nslots;  // slots staged so far (re-evaluations may add some)
   unsigned n_exhaust = 0;        // jobs whose list ran out and were re-evaluated
   constexpr double EPS_HI = 1.0 + 0x1p-38, EPS_LO = 1.0 - 0x1p-38;
@@ -1237,7 +1260,8 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   load_owner(cur);
   JobRegs nxt = load_rec(1);
   WAIT_LDS();  // nothing pending at loop entry either (the loop's own waits sit at the END of its iterations)
-  for (unsigned i = 0; i < n_eff; ++i) {
+  unsigned i = 0;  // walk position; after the loop: the number of walk positions done
+  for (; i < n_eff; ++i) {
     EMU_SITE("resolve: walk loop");
 #ifdef COOK_WALK_PROF
     const unsigned long long pk0 = __builtin_readcyclecounter();
@@ -1267,8 +1291,9 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     const int nc = (int)(cinfo_u & 0xFFu);
     if ((b >> 6) != cur_g) {  // next 64-job group: the touched lanes fetch their colbits word
       cur_g = b >> 6;
-      if (t_slot >= 0) t_col = s_col[t_slot][cur_g];
-      WAIT_LDS();
+      // (a long window's job groups beyond the LDS-staged ones: from the feasibility matrix in HBM; such windows walk next to nothing)
+      if (t_slot >= 0) t_col = cur_g < (unsigned)MV_JG ? s_col[t_slot][cur_g] : vb.colbits[(size_t)t_v * MV_JGL + cur_g];
+      WAIT_ALL_MEM();
     }
     const bool t_on = t_slot >= 0;
     // ======== FAST PATH ======================================================================================================
@@ -1333,7 +1358,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         const int w = wave_read_lane(t_v, f_lane);
         ++matched;
         if (k == 0) head_matched = 1;
-        if (lane == 0) s_j2o[b] = w;  // (s_fail[b] = 0 since the set-up)
+        if (lane == 0) s_j2o[i] = w;  // (s_fail[i] = 0 since the set-up)
         WALK_STAT(3, 1);
         WALK_STAT(8, 1);
         WALK_END(1u);
@@ -1361,16 +1386,16 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
           t_acount = r.acount + 1;
           t_basec = t_rc + t_ac;
           t_basem = t_rm + t_am;
-          t_col = s_col[u_slot][cur_g];
+          t_col = cur_g < (unsigned)MV_JG ? s_col[u_slot][cur_g] : vb.colbits[(size_t)u_off * MV_JGL + cur_g];
           s_slot_lane[u_slot] = (unsigned char)nT;
         }
-        WAIT_LDS();
+        WAIT_ALL_MEM();
         // the owner look-up of the next job was issued before this commit: patch it
         if (nxt.owner == 0xFFu && (nxt.e_slotw & 0xFFFFu) == (unsigned)u_slot) nxt.owner = nT;
         ++nT;
         ++matched;
         if (k == 0) head_matched = 1;
-        if (lane == 0) s_j2o[b] = u_off;
+        if (lane == 0) s_j2o[i] = u_off;
         wave_sync();  // the owner table update is visible to the whole wave before the next look-up reads it
         WALK_STAT(4, 1);
         WALK_STAT(8, 1);
@@ -1654,7 +1679,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
               s_hslot[h] = (unsigned short)slot;
             }
             if (lane < (unsigned)MV_JG)
-              s_col[slot][lane] = (lane * COOK_WAVE < nwin) ? vb.colbits[(size_t)pick * MV_JG + lane] : 0ull;
+              s_col[slot][lane] = (lane * COOK_WAVE < nwin) ? vb.colbits[(size_t)pick * MV_JGL + lane] : 0ull;
             wave_sync();
           }
           win = pick;
@@ -1710,10 +1735,10 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         t_acount = r.acount + 1;
         t_basec = t_rc + t_ac;
         t_basem = t_rm + t_am;
-        t_col = s_col[win_slot][cur_g];
+        t_col = cur_g < (unsigned)MV_JG ? s_col[win_slot][cur_g] : vb.colbits[(size_t)win * MV_JGL + cur_g];
         s_slot_lane[win_slot] = (unsigned char)nT;
       }
-      WAIT_LDS();
+      WAIT_ALL_MEM();
       // the owner look-up of the next job was issued before this commit: patch it
       if (nxt.owner == 0xFFu && (nxt.e_slotw & 0xFFFFu) == (unsigned)win_slot) nxt.owner = nT;
       ++nT;
@@ -1723,8 +1748,8 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       ++matched;
       if (k == 0) head_matched = 1;
       if (lane == 0) {
-        s_j2o[b] = win;
-        s_fail[b] = 0;
+        s_j2o[i] = win;
+        s_fail[i] = 0;
         if (g != 0xFFFFFFFFu) {  // cotasks look each other up through HBM (group_pass): publish at once
           st_agent(&st.job_to_offer[k], win);
           st_agent(&st.job_prev[k], ld_agent(&st.group_last[g]));
@@ -1778,8 +1803,8 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       unsigned bits = (((int)jl.f1 + d1) > 0 ? 1u : 0u) | (((int)jl.f2 + d2) > 0 ? 2u : 0u) | (((int)jl.f4 + d4) > 0 ? 4u : 0u);
       if (re_bits >= 0) bits = (unsigned)re_bits;  // exact counts from the re-evaluation
       if (lane == 0) {
-        s_j2o[b] = -1;
-        s_fail[b] = (unsigned char)(bits ? bits : 8u);
+        s_j2o[i] = -1;
+        s_fail[i] = (unsigned char)(bits ? bits : 8u);
       }
     }
     WALK_END(pcat);
@@ -1795,9 +1820,10 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   }
   // flush the results of the jobs resolved, write the touched offers' state back and publish the new head
   wave_sync();
-  for (unsigned x = lane; x < resolved; x += COOK_WAVE) {
-    st.job_to_offer[head + x] = s_j2o[x];
-    if (st.fail_code) st.fail_code[head + x] = s_fail[x];
+  for (unsigned x = lane; x < i; x += COOK_WAVE) {  // the walked jobs (the others were settled, and written, in the set-up phase)
+    const unsigned bx = s_job[x].b;
+    st.job_to_offer[head + bx] = s_j2o[x];
+    if (st.fail_code) st.fail_code[head + bx] = s_fail[x];
   }
   if (t_slot >= 0) {
     st.ac[t_v] = t_ac;
@@ -1830,7 +1856,11 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     // adapt the window: a multiple of what a round resolves (more = fewer rounds, less = fewer jobs evaluated twice)
     unsigned wn = stop == 0 ? ctl.wcur * 2 : (unsigned)(((unsigned long long)resolved * ctl.wgrow_pct + 99ull) / 100ull);
     if (wn < 64) wn = 64;
-    if (wn > (unsigned)MV_WMAX) wn = MV_WMAX;
+    // past MV_WMAX only while next to nothing of a window has to be walked (see MV_WLONG), and never beyond what this launch
+    // sequence sized its buffers and grids for
+    unsigned cap = (unsigned)MV_WMAX;
+    if (stop == 0 && nwin >= (unsigned)MV_WMAX && n_list * 8u <= nwin) cap = ctl.wlong_cap > cap ? ctl.wlong_cap : cap;
+    if (wn > cap) wn = cap;
     ctl.wcur = wn;
     *vb.ctl = ctl;
   }
@@ -1950,11 +1980,16 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2_multi(const Pool
   __shared__ __attribute__((aligned(16))) char lds[sizeof(EvalLds)];
   const PoolCtx& c = ctx[blockIdx.z];
   if (blockIdx.x >= c.vb.C) return;  // pools may differ in their number of offers
-  eval_tile(lds, c.in, c.st, c.vb, c.vb.ctl->head, c.vb.ctl->wcur, blockIdx.x, blockIdx.y);
+  const unsigned head = c.vb.ctl->head, wcur = c.vb.ctl->wcur;
+  for (unsigned jg = blockIdx.y; jg * COOK_WAVE < wcur; jg += gridDim.y) {
+    eval_tile(lds, c.in, c.st, c.vb, head, wcur, blockIdx.x, jg);
+    __syncthreads();
+  }
 }
 __global__ void __launch_bounds__(COOK_WAVE) match_merge2_multi(const PoolCtx* __restrict__ ctx) {
   const PoolCtx& c = ctx[blockIdx.z];
-  merge_job<false>(c.in, c.vb, c.vb.ctl->head, c.vb.ctl->wcur, blockIdx.x);
+  const unsigned head = c.vb.ctl->head, wcur = c.vb.ctl->wcur;
+  for (unsigned b = blockIdx.x; b < wcur; b += gridDim.x) merge_job<false>(c.in, c.vb, head, wcur, b);
 }
 __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2_multi(const PoolCtx* __restrict__ ctx) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(ResolveLds)];

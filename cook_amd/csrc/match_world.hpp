@@ -34,16 +34,17 @@
 constexpr int MW_THREADS = COOK_MW_THREADS;
 constexpr int MW_WAVES = MW_THREADS / COOK_WAVE;
 constexpr unsigned MW_MAX_POOLS = 32;
-constexpr unsigned MW_DONE = 0xFFFFFFFFu;
+constexpr unsigned MW_DONE = 0x3FFFFFFFu;  // (30 bits: see world_pack)
 constexpr unsigned long long MW_TIMEOUT_TICKS = 300000000ull;  // 3 s of the 100 MHz clock
 
 // What a walker publishes is ONE 64-bit word per pool — phase and window together, so that a reader can never pair the phase of
 // one round with the window of another (a worker wave that has nothing to do in a round may look at it arbitrarily late):
-//   bits 63..32 phase: 2r-1 = evaluate the window of round r, 2r = merge it, MW_DONE = the pool is finished
-//   bits 31..22 window size - 1, bits 21..0 head (first unresolved job)  -> K < 2^22, windows <= 1024 (the host checks)
+//   bits 63..34 phase: 2r-1 = evaluate the window of round r, 2r = merge it, MW_DONE = the pool is finished
+//   bits 33..22 window size - 1, bits 21..0 head (first unresolved job)  -> K < 2^22, windows <= 4096 (the host checks)
 static __host__ __device__ __forceinline__ unsigned long long world_pack(unsigned phase, unsigned head, unsigned wcur) {
-  return ((unsigned long long)phase << 32) | ((unsigned long long)((wcur - 1u) & 1023u) << 22) | (unsigned long long)(head & 0x3FFFFFu);
+  return ((unsigned long long)(phase & 0x3FFFFFFFu) << 34) | ((unsigned long long)((wcur - 1u) & 4095u) << 22) | (unsigned long long)(head & 0x3FFFFFu);
 }
+static __host__ __device__ __forceinline__ unsigned world_phase(unsigned long long pb) { return (unsigned)(pb >> 34); }
 struct WorldPool {  // per pool, 128 bytes: completion counters of two pools never share a line
   unsigned done;    // items completed over ALL phases so far, cumulative (evaluators -> walker): never reset, so no reset can race an add
   unsigned pad[31];
@@ -206,7 +207,7 @@ static __device__ __forceinline__ void world_evaluator(char* lds, const PoolCtx*
     }
     tsync();
     const unsigned long long pb_l = lane < nP ? T.view[lane] : 0ull;
-    const unsigned ph_l = lane < nP ? (unsigned)(pb_l >> 32) : MW_DONE;
+    const unsigned ph_l = lane < nP ? world_phase(pb_l) : MW_DONE;
     if (T.err != 0u || !__any(lane < nP && ph_l != MW_DONE)) break;  // error, or every pool is finished
     const unsigned long long todo = __ballot(lane < nP && ph_l != seen && ph_l != 0u);
     if (todo == 0ull) {
@@ -220,12 +221,13 @@ static __device__ __forceinline__ void world_evaluator(char* lds, const PoolCtx*
     const unsigned p = (unsigned)__ffsll((unsigned long long)(hi ? hi : todo)) - 1u;
     const unsigned ph = (unsigned)wave_read_lane((int)ph_l, (int)p);
     const unsigned lo = (unsigned)wave_read_lane((int)(unsigned)pb_l, (int)p);
+    const unsigned hi32 = (unsigned)wave_read_lane((int)(unsigned)(pb_l >> 32), (int)p);
     tsync();  // (as above)
     if (ph != MW_DONE) {
       const PoolCtx& c = ctx[p];
       // the window comes out of the SAME word as the phase: if this team is late and the round is over, it had no item in it
       // (the walker waits for every item), and the loops below find none
-      const unsigned head = lo & 0x3FFFFFu, wcur = (lo >> 22) + 1u;
+      const unsigned head = lo & 0x3FFFFFu, wcur = (((lo >> 22) | (hi32 << 10)) & 4095u) + 1u;
       const unsigned K = c.in.K;
       const unsigned nwin = head < K ? ((head + wcur < K) ? wcur : K - head) : 0u;
       const unsigned off = (unsigned)(((unsigned long long)p * NT) / nP);  // pools start their item -> team map at different teams

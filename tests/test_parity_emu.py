@@ -1,5 +1,7 @@
 """C-ABI parity on a machine WITHOUT a GPU: the same cook_amd/csrc sources compiled against the SIMT emulator
 (tests/simt_emu).  Checks kernel logic + host orchestration against the oracle; small sizes (the emulator is slow)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -113,6 +115,31 @@ def test_match_overcommitted_cluster(make_engine, algo):
         assert stats["persistent"] == {3: 0, 4: 1, 5: 2}[algo]  # the persistent kernel really ran (no silent fallback)
         if algo == 3:
             assert stats["reevals"] > 0
+
+
+@pytest.mark.parametrize("algo", [0, 5], ids=["default", "world"])
+def test_match_long_windows(make_engine, algo):
+    # a cluster that is full after a few hundred jobs: from then on nearly every job is settled in the parallel phase of the resolve
+    # kernel, the window grows past the LDS-staged size (MV_WLONG) and only the few jobs that still need the walk are staged —
+    # gpu jobs, constrained jobs and group members keep some of those in every window
+    # (more than MV_T = 64 gpu hosts: a job that only fits hosts of the wrong kind must fail on MORE offers than a round can touch
+    # for its summary to be final, see the `trivial` rule of resolve_round)
+    pool = synth.make_pool(seed=29, n_pending=9000, n_running=0, n_users=30, n_offers=800, gpus=True, constraints=True)
+    pool.offers.cpus[:] = np.minimum(pool.offers.cpus, 12.0)  # small hosts: the cluster is full after ~2000 jobs
+    pool.offers.mem[:] = np.minimum(pool.offers.mem, 40000.0)
+    p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
+    P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p)
+    with make_engine(p) as e:
+        e.match(pool.pending_jobs, pool.offers, pool.groups)
+        long_rounds = e.match_stats()["rounds"]
+    os.environ["COOK_WLONG"] = "0"
+    try:
+        with make_engine(p) as e:
+            e.match(pool.pending_jobs, pool.offers, pool.groups)
+            short_rounds = e.match_stats()["rounds"]
+    finally:
+        del os.environ["COOK_WLONG"]
+    assert long_rounds * 5 < short_rounds * 4, (long_rounds, short_rounds)
 
 
 @ALGOS

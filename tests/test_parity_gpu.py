@@ -1,6 +1,8 @@
 """Parity tests proper: the HIP engine (cook_amd/libcookmatch.so, gfx950) behind the C ABI vs the CPU oracle and the
 reference's golden vectors.  Run on the GPU box with `pytest -m gpu`.  No CPU fallback: if the extension or the GPU
 is missing these tests FAIL."""
+import os
+
 import numpy as np
 import pytest
 
@@ -110,6 +112,29 @@ def test_match_fills_cluster_then_fails(make_engine, algo):
         assert stats["persistent"] == {3: 0, 4: 1, 5: 2}[algo]  # the persistent kernel ran, and never fell back
         if algo == 3:
             assert stats["reevals"] > 0
+
+
+@pytest.mark.parametrize("algo", [0, 5], ids=["default", "world"])
+def test_match_long_windows(make_engine, algo):
+    # a cluster that is full after a few hundred jobs: from then on nearly every job is settled in the parallel phase of the resolve
+    # kernel, the window grows past the LDS-staged size (MV_WLONG) and only the few jobs that still need the walk are staged —
+    # gpu jobs, constrained jobs and group members keep some of those in every window
+    pool = synth.make_pool(seed=29, n_pending=60000, n_running=0, n_users=300, n_offers=1500, gpus=True, constraints=True)
+    pool.offers.cpus[:] = np.minimum(pool.offers.cpus, 12.0)  # small hosts: the cluster is full after a few thousand jobs
+    pool.offers.mem[:] = np.minimum(pool.offers.mem, 40000.0)
+    p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
+    P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p)
+    with make_engine(p) as e:
+        e.match(pool.pending_jobs, pool.offers, pool.groups)
+        long_rounds = e.match_stats()["rounds"]
+    os.environ["COOK_WLONG"] = "0"
+    try:
+        with make_engine(p) as e:
+            e.match(pool.pending_jobs, pool.offers, pool.groups)
+            short_rounds = e.match_stats()["rounds"]
+    finally:
+        del os.environ["COOK_WLONG"]
+    assert long_rounds * 2 < short_rounds, (long_rounds, short_rounds)
 
 
 @ALGOS
