@@ -155,7 +155,7 @@ struct cook_engine {
   DArr<double> v_cand_fit;
   DArr<ChunkRec> v_prec;
   DArr<int> v_cand_idx, v_ge_idx;
-  DArr<uint32_t> v_cinfo;
+  DArr<uint32_t> v_cinfo, v_jfh;
   DArr<uint64_t> v_colbits;
   DArr<WinCtl> w_ctl;
   DArr<RoundLog> w_rlog;
@@ -761,6 +761,13 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
   }
   in.good_enough = e->params.good_enough_fitness;
   in.host_lifetime_mins = e->params.host_lifetime_mins;
+  // two offers on one host?  (offers built on the device are one per node: never)
+  in.host_dup = 0;
+  if (!offers_dev && M) {
+    std::vector<uint32_t> hs(o->host, o->host + M);
+    std::sort(hs.begin(), hs.end());
+    in.host_dup = std::adjacent_find(hs.begin(), hs.end()) != hs.end() ? 1u : 0u;
+  }
   sync(e);  // `bits` is a host temporary
   e->K = K;
   e->M = M;
@@ -847,6 +854,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     vb.cand_idx = e->v_cand_idx.ensure((size_t)MV_WLONG * MV_L);
     vb.ge_idx = e->v_ge_idx.ensure((size_t)MV_WLONG * MV_LG);
     vb.cinfo = e->v_cinfo.ensure((size_t)MV_WLONG * 4);
+    vb.jfh = e->v_jfh.ensure((size_t)MV_WLONG * (MV_FH + 2));
     vb.ctl = e->w_ctl.ensure(1);
     {
       MatchIn* din = e->v_in.ensure(1);
@@ -934,7 +942,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       while (hc.head < K) {
         for (unsigned r = 0; r < batch; ++r) {
           KL("match_eval2", match_eval2, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
-          KL("match_merge2", match_merge2, MV_WMAX, COOK_WAVE, in, vb);
+          KL("match_merge2", match_merge2, MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, vb);
           if (algo == 3)
             KL("match_resolve2", match_resolve2_reeval, 1, MV_RTHREADS, st, vb);
           else
@@ -1036,7 +1044,7 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
   while (!all_done()) {
     for (unsigned r = 0; r < batch; ++r) {
       KL("match_eval2", match_eval2_multi, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx);
-      KL("match_merge2", match_merge2_multi, dim3(MV_WMAX, 1, L), COOK_WAVE, (const PoolCtx*)dctx);
+      KL("match_merge2", match_merge2_multi, dim3(MV_WMAX / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, (const PoolCtx*)dctx);
       KL("match_resolve2", match_resolve2_multi, dim3(1, 1, L), MV_RTHREADS, (const PoolCtx*)dctx);
     }
     const std::vector<WinCtl> prev = hc;

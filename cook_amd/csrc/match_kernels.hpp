@@ -50,6 +50,9 @@ struct MatchIn {
   // params
   double good_enough;
   long long host_lifetime_mins;
+  // != 0: two offers of the call share a host (then a placement can forbid, for a unique host-placement group, an offer OTHER
+  // than the one it was made on, and the placement walk sends every group member through its general path)
+  unsigned host_dup;
 };
 
 struct MatchState {

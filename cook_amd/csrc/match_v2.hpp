@@ -25,6 +25,8 @@
 // Jobs of balanced / attribute-equals groups change the feasibility of UNTOUCHED offers when a cotask is placed, so a
 // round never resolves a second member of such a group after the first one was placed.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 #include "match_kernels.hpp"
 
@@ -183,7 +185,10 @@ struct V2Buf {
   const JobRec* jr;
   const JobCons* jcons;  // [K] fast constraint slots of the jobs flagged JF_FASTC
   ChunkRec* prec;      // [wmax][C]      chunk lists: one record per (job of the window, offer chunk)
-  uint64_t* colbits;   // [M][JG]        static-constraints-pass bit of (offer, job of the window)
+  uint64_t* colbits;   // [M][JGL]       static-constraints-pass bit of (offer, job of the window)
+  unsigned* jfh;       // [wlong][MV_FH + 2]  group members: the hosts their cotasks occupy under the snapshot (unique groups), how many
+                       //                (int: -1 not gathered, -2 more than MV_FH), the group's last placed job — what the walk's fast
+                       //                path needs, gathered ONCE by the evaluation (the tile of chunk 0 writes it)
   double* cand_fit;    // [wmax][L]
   int* cand_idx;       // [wmax][L]
   int* ge_idx;         // [wmax][LG]
@@ -377,6 +382,7 @@ struct EvalLane {
   JobCons jc;
   unsigned fh[MV_FH];
   int n_fh;
+  int glast;  // the group's last placed job under the snapshot (-1 none; members of a group only)
   double ge, ge_lo;
   double tf[MV_L];
   int ti[MV_L];
@@ -412,8 +418,10 @@ static __device__ __forceinline__ void eval_lane_setup(EvalLane& E, const MatchI
   // unique host-placement groups (constraints.clj:586-598): the hosts to avoid = running cotasks ++ cotasks placed by
   // earlier rounds of this call, gathered ONCE per tile into registers (n_fh = -1: not such a job, -2: too many -> slow path)
   E.n_fh = -1;
+  E.glast = -1;
 #pragma unroll
   for (int q = 0; q < MV_FH; ++q) E.fh[q] = 0xFFFFFFFFu;
+  if (E.valid && E.j.group != 0xFFFFFFFFu) E.glast = ld_agent(&st.group_last[E.j.group]);
   if (E.grouped && ((E.j.flags >> 8) & 3u) == 1u) {
     E.n_fh = 0;
     const unsigned g = E.j.group;
@@ -429,7 +437,7 @@ static __device__ __forceinline__ void eval_lane_setup(EvalLane& E, const MatchI
       }
     };
     for (unsigned x = r0; x < r1 && E.n_fh >= 0; ++x) push(in.g_run_host[x]);
-    for (int c = ld_agent(&st.group_last[g]); c >= 0 && E.n_fh >= 0; c = ld_agent(&st.job_prev[c]))
+    for (int c = E.glast; c >= 0 && E.n_fh >= 0; c = ld_agent(&st.job_prev[c]))
       if (c < st.cutoff) push(in.o_host[ld_agent(&st.job_to_offer[c])]);
   }
   E.use_ge = in.good_enough < 1.0;
@@ -547,6 +555,25 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
   wave_sync();  // every lane is done with the staged offers before the wave stages the next ones
 }
 
+// the group data of the lane's job for the walk (the tile of chunk 0 writes it, once per round)
+template <bool THROUGH>
+static __device__ __forceinline__ void eval_store_group(const EvalLane& E, const V2Buf& vb, unsigned b) {
+  if (E.j.group == 0xFFFFFFFFu) return;
+  unsigned* row = vb.jfh + (size_t)b * (MV_FH + 2);
+#pragma unroll
+  for (int q = 0; q < MV_FH; ++q) {
+    if (THROUGH) st_agent(&row[q], E.fh[q]);
+    else row[q] = E.fh[q];
+  }
+  if (THROUGH) {
+    st_agent(&row[MV_FH], (unsigned)E.n_fh);
+    st_agent(&row[MV_FH + 1], (unsigned)E.glast);
+  } else {
+    row[MV_FH] = (unsigned)E.n_fh;
+    row[MV_FH + 1] = (unsigned)E.glast;
+  }
+}
+
 // One tile = 64 jobs (job group jg of the window) x MV_OCB offers (chunk ch); the whole workgroup (MV_EW waves) takes part.
 // Ends with every thread past its last LDS access only after the caller's next __syncthreads().
 // The MV_EW waves may be a whole workgroup (w = wave_id(), sync = __syncthreads) or a TEAM of waves inside a larger workgroup of
@@ -579,6 +606,7 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
   s_cnt[w][lane][2] = E.c4;
   sync();
   if (w != 0 || !valid) return;  // (the caller synchronises the waves before the LDS is reused)
+  if (ch == 0) eval_store_group<THROUGH>(E, vb, b);
   int p[MV_EW];
 #pragma unroll
   for (int x = 0; x < MV_EW; ++x) p[x] = 0;
@@ -672,6 +700,7 @@ static __device__ __forceinline__ void eval_tile(char* lds, const MatchIn& in, c
 
 // The same tile by ONE wave on its own (the persistent placement kernel's evaluator waves, match_world.hpp): 64 jobs x the
 // MV_OCB offers of chunk ch in MV_EW batches of MV_OCW; no workgroup barrier anywhere, the chunk list goes straight to HBM.
+template <bool THROUGH>
 static __device__ __forceinline__ void eval_tile_wave(EvalWaveLds& W, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
                                                       unsigned wcur, unsigned ch, unsigned jg) {
   if (jg * COOK_WAVE >= wcur || head + jg * COOK_WAVE >= in.K) return;  // wave-uniform
@@ -682,9 +711,10 @@ static __device__ __forceinline__ void eval_tile_wave(EvalWaveLds& W, const Matc
   for (int s = 0; s < MV_EW; ++s) {
     const unsigned v0 = ch * MV_OCB + (unsigned)s * MV_OCW;
     if (v0 >= in.M) break;
-    eval_scan_offers<true>(E, W, in, st, vb, v0, jg);
+    eval_scan_offers<THROUGH>(E, W, in, st, vb, v0, jg);
   }
   if (!E.valid) return;
+  if (ch == 0) eval_store_group<THROUGH>(E, vb, b);
   ChunkRec R;
   int n_out = 0, n_g = 0;
 #pragma unroll
@@ -702,17 +732,26 @@ static __device__ __forceinline__ void eval_tile_wave(EvalWaveLds& W, const Matc
   R.cnt[1] = E.c1;
   R.cnt[2] = E.c2;
   R.cnt[3] = E.c4;
-  chunk_store(&vb.prec[(size_t)b * vb.C + ch], R, true);
+  chunk_store(&vb.prec[(size_t)b * vb.C + ch], R, THROUGH);
 }
 
-// grid = (offer chunks, MV_JG): a long window's further job groups are taken by the same blocks, one after the other
+// What one block of the eval grid (offer chunks x MV_JG) does.  A window of the usual size: the block's MV_EW waves share ONE tile
+// (job group gy of chunk ch, a batch of offers each).  A LONG window (more job groups than the grid has rows; nearly all its offers
+// are dead by then, so a tile is little more than its prologue): every wave takes a job group of its own and walks the whole chunk,
+// eval_tile_wave — MV_EW job groups per pass instead of one.
+static __device__ __forceinline__ void eval_block(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
+                                                  unsigned wcur, unsigned ch, unsigned gy, unsigned ny) {
+  if (wcur <= ny * COOK_WAVE) {
+    eval_tile(lds, in, st, vb, head, wcur, ch, gy);
+    return;
+  }
+  EvalLds& L = *reinterpret_cast<EvalLds*>(lds);
+  const unsigned w = wave_id();
+  for (unsigned jg = gy * MV_EW + w; jg * COOK_WAVE < wcur; jg += ny * MV_EW) eval_tile_wave<false>(L.wave[w], in, st, vb, head, wcur, ch, jg);
+}
 __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, MatchState st, V2Buf vb) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(EvalLds)];
-  const unsigned head = vb.ctl->head, wcur = vb.ctl->wcur;
-  for (unsigned jg = blockIdx.y; jg * COOK_WAVE < wcur; jg += gridDim.y) {
-    eval_tile(lds, in, st, vb, head, wcur, blockIdx.x, jg);
-    __syncthreads();
-  }
+  eval_block(lds, in, st, vb, vb.ctl->head, vb.ctl->wcur, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // ---- merge: one wave per job ---------------------------------------------------------------------------------------------
@@ -827,9 +866,11 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
   }
 }
 
-__global__ void __launch_bounds__(COOK_WAVE) match_merge2(MatchIn in, V2Buf vb) {
+// one wave per job; a block of MV_MW waves takes MV_MW jobs per pass (a long window needs several passes)
+constexpr int MV_MW = 4;
+__global__ void __launch_bounds__(COOK_WAVE* MV_MW) match_merge2(MatchIn in, V2Buf vb) {
   const unsigned head = vb.ctl->head, wcur = vb.ctl->wcur;
-  for (unsigned b = blockIdx.x; b < wcur; b += gridDim.x) merge_job<false>(in, vb, head, wcur, b);
+  for (unsigned b = blockIdx.x * MV_MW + wave_id(); b < wcur; b += gridDim.x * MV_MW) merge_job<false>(in, vb, head, wcur, b);
 }
 
 // ---- resolve -----------------------------------------------------------------------------------------------------------------
@@ -857,6 +898,8 @@ struct GEntL {  // good-enough list entry
   unsigned short slot, pad;
 };
 constexpr unsigned JL_GPU = 1u << 16, JL_GROUPED = 1u << 17, JL_HASGROUP = 1u << 20;  // (bits 18-19: group type)
+constexpr unsigned JL_GSLOT_SHIFT = 21, JL_GSLOT_NONE = 0x7Fu;  // bits 21-27: the job's row of ResolveLds::gfh, or none
+constexpr int MV_GMAX = 64;  // group members per round whose hosts-to-avoid are staged for the walk's fast path
 
 static __device__ __attribute__((noinline)) bool group_pass_dev(const MatchIn* in, MatchState st, unsigned jj, unsigned v) {
   return group_pass(*in, st, jj, v);
@@ -879,7 +922,7 @@ struct ResolveLds {
   EntL ent[MV_WMAX][MV_L];    // their candidate lists, by walk position
   GEntL gent[MV_WMAX][MV_LG];
   SlotRec slot[MV_S];
-  unsigned long long col[MV_S][MV_JG];
+  unsigned long long col[MV_S][MV_JG];  // static-constraints-pass bits of (slot, walked job), by WALK position (bit i & 63 of word i >> 6)
   unsigned long long visit[MV_JGL];
   double tac[MV_T], tam[MV_T];  // current state of the touched offers, by owner lane (published for a re-evaluation)
   double rfit[MV_RWAVES_MAX];
@@ -889,6 +932,11 @@ struct ResolveLds {
   int ridx[MV_RWAVES_MAX], rge[MV_RWAVES_MAX];
   unsigned rc[MV_RWAVES_MAX][3];
   unsigned vbase[MV_JGL + 1];       // walk position of the first visited job of each 64-job group
+  // members of unique (or unconstrained) host-placement groups among the walked jobs: the hosts their cotasks occupied when the round
+  // began (running ++ placed by earlier rounds; 0xFFFFFFFF = unused) and the group's last placed job then
+  unsigned gfh[MV_GMAX][MV_FH];
+  int glast[MV_GMAX];
+  unsigned n_gslots;
   unsigned nslots, minbad;
   int cmd;                          // window index of the job to re-evaluate, -1 = the walk is over
   unsigned short hslot[MV_HASH];
@@ -925,6 +973,9 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   auto& s_fail = L.fail;
   auto& s_visit = L.visit;
   auto& s_vbase = L.vbase;
+  auto& s_gfh = L.gfh;
+  auto& s_glast = L.glast;
+  unsigned& s_ngslots = L.n_gslots;
   unsigned& s_nslots = L.nslots;
   unsigned& s_minbad = L.minbad;
   auto& s_tac = L.tac;
@@ -952,6 +1003,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   if (tid == 0) {
     s_nslots = 0;
     s_minbad = 0xFFFFFFFFu;
+    s_ngslots = 0;
   }
   __syncthreads();
   // A job without any feasible offer under S stays unmatched whatever the jobs before it do (placements only take
@@ -961,8 +1013,10 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     const unsigned flags = vb.jr[head + b].flags;
     const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
     const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
-    const bool grouped = (flags & JF_GROUPED) != 0;
-    const bool trivial = (info & 0xFFFFu) == 0u && !grouped && c1 > 0u && (c2 == 0u || c2 > (unsigned)MV_T) &&
+    // members of balanced / attribute-equals groups excepted: a cotask's placement can make an offer FEASIBLE for them; a unique
+    // group only ever takes hosts away (constraints.clj:586-598), like a resource
+    const bool opens = (flags & JF_GROUPED) != 0 && ((flags >> 8) & 3u) != 1u;
+    const bool trivial = (info & 0xFFFFu) == 0u && !opens && c1 > 0u && (c2 == 0u || c2 > (unsigned)MV_T) &&
                          (c4 == 0u || c4 > (unsigned)MV_T);
     if (trivial) {
       // final whatever this round does, also for a job behind the point where the round stops: job_to_offer keeps the -1 it was
@@ -975,11 +1029,12 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   __syncthreads();
   if (tid == 0) {
     unsigned acc = 0;
-    for (unsigned g = 0; g < (unsigned)MV_JGL; ++g) {
+    const unsigned ng = (nwin + COOK_WAVE - 1) / COOK_WAVE;
+    for (unsigned g = 0; g < ng; ++g) {
       s_vbase[g] = acc;
       acc += (unsigned)__popcll(s_visit[g]);
     }
-    s_vbase[MV_JGL] = acc;
+    for (unsigned g = ng; g <= (unsigned)MV_JGL; ++g) s_vbase[g] = acc;  // (walkpos_to_b scans on; [MV_JGL] = the total)
   }
   __syncthreads();
   const unsigned n_list = s_vbase[MV_JGL];  // jobs the walk has to visit
@@ -1004,6 +1059,24 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       const bool grouped = (j.flags & JF_GROUPED) != 0;
       r.info = (info & 0xFFFFu) | (j.g > 0 ? JL_GPU : 0u) | (grouped ? JL_GROUPED : 0u) | (((j.flags >> 8) & 3u) << 18) |
                (j.group != 0xFFFFFFFFu ? JL_HASGROUP : 0u);
+      // a member of a unique (type 1) or unconstrained (type 0) group: stage what the walk's fast path needs — the hosts to avoid
+      // as the round begins and the group's last placed job (for the chain link) — so that it never has to go to HBM for them
+      unsigned gslot = JL_GSLOT_NONE;
+      const unsigned gt = (j.flags >> 8) & 3u;
+      if (j.group != 0xFFFFFFFFu && gt <= 1u && !use_ge && vb.in_dev->host_dup == 0u) {
+        const unsigned* row = vb.jfh + (size_t)b * (MV_FH + 2);  // gathered by the evaluation of this round
+        const int nfh = (int)row[MV_FH];
+        if (gt == 0u || (nfh >= 0 && nfh <= MV_FH)) {
+          const unsigned gs = atomicAdd(&s_ngslots, 1u);
+          if (gs < (unsigned)MV_GMAX) {
+#pragma unroll
+            for (int x = 0; x < MV_FH; ++x) s_gfh[gs][x] = gt == 1u ? row[x] : 0xFFFFFFFFu;
+            s_glast[gs] = (int)row[MV_FH + 1];
+            gslot = gs;
+          }
+        }
+      }
+      r.info |= gslot << JL_GSLOT_SHIFT;
       r.group = j.group;
       r.f1 = (unsigned short)(c1 < 0xFFFFu ? c1 : 0xFFFFu);
       r.f2 = (unsigned short)(c2 < 0xFFFFu ? c2 : 0xFFFFu);
@@ -1097,9 +1170,44 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     s_slot[s].acount = st.acount[v];
     s_slot_lane[s] = 0xFF;
   }
-  for (unsigned x = tid; x < nslots * MV_JG; x += NT) {
-    const unsigned s = x / MV_JG, g = x % MV_JG;
-    s_col[s][g] = (g * COOK_WAVE < nwin) ? vb.colbits[(size_t)s_slot[s].offer * MV_JGL + g] : 0ull;
+  // colbits columns of the slots.  A window of the usual size: as they are, by window position.  A LONG window (its job groups
+  // do not fit the LDS array): compacted to the WALKED jobs — word g of a column holds the 64 jobs of window group g; the bits of
+  // the visited ones (s_visit[g]) go to walk positions s_vbase[g] ... in order.
+  const bool lw = nwin > (unsigned)MV_WMAX;
+  const unsigned ngrp = (nwin + COOK_WAVE - 1) / COOK_WAVE;
+  if (!lw) {
+    for (unsigned x = tid; x < nslots * MV_JG; x += NT) {
+      const unsigned sl = x / MV_JG, g = x % MV_JG;
+      s_col[sl][g] = (g * COOK_WAVE < nwin) ? vb.colbits[(size_t)s_slot[sl].offer * MV_JGL + g] : 0ull;
+    }
+  }
+  for (unsigned sl = tid; lw && sl < nslots; sl += NT) {  // one thread per slot: no atomics, no extra barrier
+    unsigned long long acc[MV_JG];
+#pragma unroll
+    for (int w = 0; w < MV_JG; ++w) acc[w] = 0ull;
+    const uint64_t* colp = vb.colbits + (size_t)s_slot[sl].offer * MV_JGL;
+    for (unsigned g = 0; g < ngrp; ++g) {
+      const unsigned long long V = s_visit[g];
+      const unsigned base = s_vbase[g];
+      if (V == 0ull || base >= n_walk) continue;
+      const unsigned long long Wd = colp[g];
+      unsigned long long packed;
+      if (V == ~0ull) {
+        packed = Wd;
+      } else {  // parallel bit extract of Wd under V
+        packed = 0ull;
+        unsigned o = 0;
+        for (unsigned long long m = V; m != 0ull; m &= m - 1ull, ++o) packed |= ((Wd >> (__ffsll((unsigned long long)m) - 1)) & 1ull) << o;
+      }
+      const unsigned w0 = base >> 6, sh = base & 63u;
+#pragma unroll
+      for (int w = 0; w < MV_JG; ++w) {
+        if ((unsigned)w == w0) acc[w] |= packed << sh;
+        if (sh != 0u && (unsigned)w == w0 + 1u) acc[w] |= packed >> (64u - sh);
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < MV_JG; ++w) s_col[sl][w] = acc[w];
   }
   if (tid == 0) s_cmd = -1;
   __syncthreads();
@@ -1200,8 +1308,12 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   double t_oc = 0, t_om = 0, t_rc = 0, t_rm = 0, t_invc = 0, t_invm = 0;
   double t_ac = 0, t_am = 0, t_basec = 0, t_basem = 0;
   int t_acount = 0, t_run = 0, t_slack = 0;
-  unsigned t_k8s = 0;
+  unsigned t_k8s = 0, t_host = 0;
   unsigned long long t_col = 0ull;
+  // group members placed in THIS round, one per lane in placement order (group, host, match index): what a later member of the same
+  // group has to avoid / link to, without asking HBM.  n_log > 64: the log overflowed, no fast path for group members any more
+  unsigned lg_group = 0xFFFFFFFFu, lg_host = 0u, n_log = 0u;
+  int lg_k = -1;
   unsigned cur_g = 0xFFFFFFFFu;
   unsigned nT = 0;
   unsigned stop = 0;  // 1 list exhausted, 2 touched set full, 3 group barrier, 4 slot table cut the window
@@ -1282,26 +1394,62 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     const unsigned cinfo_u = wave_uniform_u32(cur.info), cb_u = wave_uniform_u32(cur.f4b) >> 16;
     const bool cur_no_zero_fit = (wave_uniform_u32(cur.f4b) & 0xFFFFu) == 0u;  // no offer had zero fitness for this job under S
     const unsigned cur_slot = cur.e_slotw & 0xFFFFu;
-    const unsigned b = cb_u, k = head + b, bl = b & 63u;
+    const unsigned b = cb_u, k = head + b;
+    const unsigned cpos = lw ? i : b, bl = cpos & 63u;  // the job's bit in the staged colbits columns: by window position, or (long window) by walk position
     const double c = cur.c, m = cur.m;
     const bool grouped = (cinfo_u & JL_GROUPED) != 0;
     const bool job_gpu = (cinfo_u & JL_GPU) != 0;
     const bool has_group = (cinfo_u & JL_HASGROUP) != 0;
     const unsigned g = has_group ? wave_uniform_u32(cur.group) : 0xFFFFFFFFu, gtype = (cinfo_u >> 18) & 3u;
     const int nc = (int)(cinfo_u & 0xFFu);
-    if ((b >> 6) != cur_g) {  // next 64-job group: the touched lanes fetch their colbits word
-      cur_g = b >> 6;
-      // (a long window's job groups beyond the LDS-staged ones: from the feasibility matrix in HBM; such windows walk next to nothing)
-      if (t_slot >= 0) t_col = cur_g < (unsigned)MV_JG ? s_col[t_slot][cur_g] : vb.colbits[(size_t)t_v * MV_JGL + cur_g];
-      WAIT_ALL_MEM();
+    if ((cpos >> 6) != cur_g) {  // next word of the columns: the touched lanes fetch theirs
+      cur_g = cpos >> 6;
+      if (t_slot >= 0) t_col = s_col[t_slot][cur_g];
+      WAIT_LDS();
     }
     const bool t_on = t_slot >= 0;
     // ======== FAST PATH ======================================================================================================
-    // self-contained: decision AND commit, then straight on to the next job (its control flow never joins the general path's)
-    if (!(cinfo_u & (JL_GROUPED | JL_HASGROUP)) && !use_ge) {
+    // self-contained: decision AND commit, then straight on to the next job (its control flow never joins the general path's).
+    // Two instantiations: plain jobs, and members of unique / unconstrained groups whose hosts-to-avoid the set-up phase staged
+    // (JL_GSLOT) — kept apart so that the group code costs the plain jobs nothing.
+    const unsigned gslot = (cinfo_u >> JL_GSLOT_SHIFT) & JL_GSLOT_NONE;
+    auto fast_path = [&](auto group_tag) -> bool {
+      constexpr bool GROUP = decltype(group_tag)::value;
       const bool res_ok = t_on && !(t_ac + c > t_oc || t_am + m > t_om);
       bool con_ok = ((t_col >> bl) & 1ull) != 0 && t_acount < t_slack;
       if (job_gpu && t_k8s && t_run + t_acount != 0) con_ok = false;
+      unsigned long long ghits = 0ull;  // log entries of this job's group
+      if constexpr (GROUP) {
+        ghits = __ballot(lane < n_log && lg_group == g);
+        if (gtype == 1u) {  // unique host placement (constraints.clj:586-598): not where a cotask runs or was placed
+          unsigned fhv[MV_FH];
+#pragma unroll
+          for (int q = 0; q < MV_FH; ++q) fhv[q] = s_gfh[gslot][q];
+          bool forb = false;
+#pragma unroll
+          for (int q = 0; q < MV_FH; ++q) forb = forb | (t_host == fhv[q]);
+          for (unsigned long long hm = ghits; hm != 0ull; hm &= hm - 1ull) {
+            const unsigned h = (unsigned)wave_read_lane((int)lg_host, __ffsll((unsigned long long)hm) - 1);  // (every lane takes part)
+            forb = forb | (t_host == h);
+          }
+          con_ok = con_ok & !forb;
+        }
+      }
+      // publish a placed group member: the chain in HBM (later rounds' evaluation and the general path read it) and the round's log
+      auto publish_member = [&](int w_offer, unsigned w_host) {
+        const int prev = ghits != 0ull ? wave_read_lane(lg_k, 63 - __clzll((long long)ghits)) : s_glast[gslot];
+        if (lane == 0) {
+          st_agent(&st.job_to_offer[k], w_offer);
+          st_agent(&st.job_prev[k], prev);
+          st_agent(&st.group_last[g], (int)k);
+        }
+        if (lane == n_log) {
+          lg_group = g;
+          lg_host = w_host;
+          lg_k = (int)k;
+        }
+        ++n_log;
+      };
       const double a1 = (t_basec + c) * t_invc, a2 = (t_basem + m) * t_invm;
       const double fa = (a1 + a2) * 0.5;
       const bool cand = res_ok && con_ok;
@@ -1359,13 +1507,11 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         ++matched;
         if (k == 0) head_matched = 1;
         if (lane == 0) s_j2o[i] = w;  // (s_fail[i] = 0 since the set-up)
+        if constexpr (GROUP) publish_member(w, (unsigned)wave_read_lane((int)t_host, f_lane));
         WALK_STAT(3, 1);
         WALK_STAT(8, 1);
-        WALK_END(1u);
-        WAIT_LDS_BUT_LAST();  // the prefetches of this iteration have arrived (see common.hpp); the result store may still fly
-        cur = nxt;
-        nxt = nn;
-        continue;
+        WALK_END(GROUP ? 4u : 1u);
+        return true;
       }
       if (f_new && nT < (unsigned)MV_T) {  // an untouched offer: the next free lane takes ownership
         if (lane == nT) {
@@ -1379,6 +1525,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
           t_invc = r.a.inv_dc;
           t_invm = r.a.inv_dm;
           t_k8s = r.o.flags & 1u;
+          t_host = r.o.host;
           t_run = r.o.run_count;
           t_slack = r.o.task_slack;
           t_ac = r.ac + c;
@@ -1386,10 +1533,11 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
           t_acount = r.acount + 1;
           t_basec = t_rc + t_ac;
           t_basem = t_rm + t_am;
-          t_col = cur_g < (unsigned)MV_JG ? s_col[u_slot][cur_g] : vb.colbits[(size_t)u_off * MV_JGL + cur_g];
           s_slot_lane[u_slot] = (unsigned char)nT;
         }
-        WAIT_ALL_MEM();
+        if (lane == nT) t_col = s_col[u_slot][cur_g];
+        WAIT_LDS();
+        if constexpr (GROUP) publish_member(u_off, (unsigned)wave_read_lane((int)t_host, (int)nT));
         // the owner look-up of the next job was issued before this commit: patch it
         if (nxt.owner == 0xFFu && (nxt.e_slotw & 0xFFFFu) == (unsigned)u_slot) nxt.owner = nT;
         ++nT;
@@ -1399,8 +1547,19 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         wave_sync();  // the owner table update is visible to the whole wave before the next look-up reads it
         WALK_STAT(4, 1);
         WALK_STAT(8, 1);
-        WALK_END(2u);
-        WAIT_LDS_BUT_LAST();
+        WALK_END(GROUP ? 4u : 2u);
+        return true;
+      }
+      return false;
+    };
+    if (!use_ge) {
+      bool fast_done = false;
+      if (!(cinfo_u & (JL_GROUPED | JL_HASGROUP)))
+        fast_done = fast_path(std::false_type{});
+      else if (gslot != JL_GSLOT_NONE && n_log < (unsigned)COOK_WAVE)
+        fast_done = fast_path(std::true_type{});
+      if (fast_done) {
+        WAIT_LDS_BUT_LAST();  // the prefetches of this iteration have arrived (see common.hpp); the result store may still fly
         cur = nxt;
         nxt = nn;
         continue;
@@ -1679,7 +1838,20 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
               s_hslot[h] = (unsigned short)slot;
             }
             if (lane < (unsigned)MV_JG)
-              s_col[slot][lane] = (lane * COOK_WAVE < nwin) ? vb.colbits[(size_t)pick * MV_JGL + lane] : 0ull;
+              s_col[slot][lane] = (!lw && lane * COOK_WAVE < nwin) ? vb.colbits[(size_t)pick * MV_JGL + lane] : 0ull;
+            wave_sync();
+            for (unsigned g = lane; lw && g < ngrp; g += COOK_WAVE) {  // (long window) the new slot's column, compacted like the others
+              const unsigned long long V = s_visit[g];
+              const unsigned base = s_vbase[g];
+              if (V == 0ull || base >= n_walk) continue;
+              const unsigned long long Wd = vb.colbits[(size_t)pick * MV_JGL + g];
+              unsigned long long packed = 0ull;
+              unsigned o = 0;
+              for (unsigned long long m = V; m != 0ull; m &= m - 1ull, ++o) packed |= ((Wd >> (__ffsll((unsigned long long)m) - 1)) & 1ull) << o;
+              const unsigned w0 = base >> 6, sh = base & 63u;
+              atomicOr(&s_col[slot][w0], packed << sh);
+              if (sh != 0u && w0 + 1u < (unsigned)MV_JG) atomicOr(&s_col[slot][w0 + 1u], packed >> (64u - sh));
+            }
             wave_sync();
           }
           win = pick;
@@ -1728,6 +1900,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         t_invc = r.a.inv_dc;
         t_invm = r.a.inv_dm;
         t_k8s = r.o.flags & 1u;
+        t_host = r.o.host;
         t_run = r.o.run_count;
         t_slack = r.o.task_slack;
         t_ac = r.ac + c;
@@ -1735,10 +1908,10 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         t_acount = r.acount + 1;
         t_basec = t_rc + t_ac;
         t_basem = t_rm + t_am;
-        t_col = cur_g < (unsigned)MV_JG ? s_col[win_slot][cur_g] : vb.colbits[(size_t)win * MV_JGL + cur_g];
         s_slot_lane[win_slot] = (unsigned char)nT;
       }
-      WAIT_ALL_MEM();
+      if (lane == nT) t_col = s_col[win_slot][cur_g];
+      WAIT_LDS();
       // the owner look-up of the next job was issued before this commit: patch it
       if (nxt.owner == 0xFFu && (nxt.e_slotw & 0xFFFFu) == (unsigned)win_slot) nxt.owner = nT;
       ++nT;
@@ -1756,7 +1929,22 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
           st_agent(&st.group_last[g], (int)k);
         }
       }
-      if (g != 0xFFFFFFFFu) wave_sync();  // later cotasks of this wave read what lane 0 just published
+      if (g != 0xFFFFFFFFu) {
+        wave_sync();  // later cotasks of this wave read what lane 0 just published
+        // ... and the round's log, for the members that take the fast path (the owner lane of the winning offer knows its host)
+        const int ol = win_lane >= 0 ? win_lane : (int)nT - 1;
+        const unsigned w_host = (unsigned)wave_read_lane((int)t_host, ol);
+        if (n_log < (unsigned)COOK_WAVE) {
+          if (lane == n_log) {
+            lg_group = g;
+            lg_host = w_host;
+            lg_k = (int)k;
+          }
+          ++n_log;
+        } else {
+          n_log = COOK_WAVE + 1u;  // overflow: the log is incomplete from here on
+        }
+      }
     } else {
       // unmatched: failure summary = OR over offers of the first failing check under the CURRENT state.  Start from the
       // snapshot counts and swap each touched offer's snapshot verdict for its current one (exact verdicts needed).
@@ -1980,16 +2168,12 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2_multi(const Pool
   __shared__ __attribute__((aligned(16))) char lds[sizeof(EvalLds)];
   const PoolCtx& c = ctx[blockIdx.z];
   if (blockIdx.x >= c.vb.C) return;  // pools may differ in their number of offers
-  const unsigned head = c.vb.ctl->head, wcur = c.vb.ctl->wcur;
-  for (unsigned jg = blockIdx.y; jg * COOK_WAVE < wcur; jg += gridDim.y) {
-    eval_tile(lds, c.in, c.st, c.vb, head, wcur, blockIdx.x, jg);
-    __syncthreads();
-  }
+  eval_block(lds, c.in, c.st, c.vb, c.vb.ctl->head, c.vb.ctl->wcur, blockIdx.x, blockIdx.y, gridDim.y);
 }
-__global__ void __launch_bounds__(COOK_WAVE) match_merge2_multi(const PoolCtx* __restrict__ ctx) {
+__global__ void __launch_bounds__(COOK_WAVE* MV_MW) match_merge2_multi(const PoolCtx* __restrict__ ctx) {
   const PoolCtx& c = ctx[blockIdx.z];
   const unsigned head = c.vb.ctl->head, wcur = c.vb.ctl->wcur;
-  for (unsigned b = blockIdx.x; b < wcur; b += gridDim.x) merge_job<false>(c.in, c.vb, head, wcur, b);
+  for (unsigned b = blockIdx.x * MV_MW + wave_id(); b < wcur; b += gridDim.x * MV_MW) merge_job<false>(c.in, c.vb, head, wcur, b);
 }
 __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2_multi(const PoolCtx* __restrict__ ctx) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(ResolveLds)];
