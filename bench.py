@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-adjacent", action="store_true", help="skip the timings of the rows next to the hot path (offers, explain, metrics)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    ap.add_argument("--no-extras", action="store_true", help="skip SURVEY.md §8d's reporting matrix (K = 1000 / 1e5, good-enough 0.8, C2, C3) under extra_configs")
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of the timed configuration (rank 0's first and last pool vs the oracle, after the timed region)")
     return ap.parse_args()
 
@@ -256,6 +257,133 @@ def main():
                 parity_pools.append({"pool": pl, "jobs_checked": int(len(fetched[pl][1]))})
             parity_checked = True
 
+    # ---- SURVEY.md §8d's reporting matrix, beside the headline (never instead of it): the reference's default cap K = 1000
+    #      (config.clj:113: launch / latency-bound, p50 and p95 in microseconds), K = 1e5, the reference's DEFAULT good-enough
+    #      fitness 0.8 (config.clj:111), and BASELINE.json configs[1] / configs[2] as single pools.  N = 1 only.
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extra = {}
+
+        def timed(fn, n, warm=1):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(n):
+                a = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - a)
+            ts.sort()
+            return ts
+
+        def pct(ts, q):
+            return ts[min(len(ts) - 1, int(q * len(ts)))]
+
+        ts = timed(lambda: cluster.cycle(1000), 40, warm=3)
+        extra["K=1000"] = {"what": f"the same {P}-pool cluster, 1000 considerable jobs per pool (config.clj:113)", "cycles": len(ts),
+                           "p50_cycle_us": pct(ts, 0.5) * 1e6, "p95_cycle_us": pct(ts, 0.95) * 1e6,
+                           "stage_ms_pool0": dict(zip(("rank", "match"), engines[my_pools[0]].last_timing()))}
+        ts = timed(lambda: cluster.cycle(100_000), 4)
+        extra["K=1e5"] = {"what": f"the same cluster, 100000 considerable jobs per pool", "cycles": len(ts), "p50_cycle_ms": pct(ts, 0.5) * 1e3,
+                          "p95_cycle_ms": pct(ts, 0.95) * 1e3}
+        p08 = A.default_params(good_enough_fitness=0.8, match_algo=args.match_algo)
+        for e in engines.values():
+            e.set_params(p08)
+        ts = timed(lambda: cluster.cycle(K), 3)
+        m08 = sum(int((engines[p].cycle_fetch()[1] >= 0).sum()) for p in my_pools)
+        extra["good_enough=0.8"] = {"what": f"the same cluster, K = {K} per pool, good-enough-fitness 0.8 (the reference's default, config.clj:111; "
+                                            "the winner among equally good-enough hosts is oracle-defined: first in offer order)",
+                                    "cycles": len(ts), "p50_cycle_ms": pct(ts, 0.5) * 1e3, "matched": m08}
+        for e in engines.values():
+            e.set_params(params)
+        for name, kw in (("C2", dict(seed=0xC00C0002, n_pending=50000, n_running=20000, n_users=1000, n_offers=5000)),
+                         ("C3", dict(seed=0xC00C0003, n_pending=200000, n_running=80000, n_users=2000, n_offers=20000, gpus=True,
+                                     constraints=True))):
+            pool_x = synth.make_pool(**kw)
+            with Engine(params, device=local_rank) as ex:
+                ex.cycle_stage(pool_x.tasks, pool_x.users, pool_x.pending_jobs, pool_x.offers, pool_x.groups)
+                ts = timed(lambda: ex.cycle_run(pool_x.n_pending), 3)
+                _, j2o_x, _ = ex.cycle_fetch()
+                extra[name] = {"what": f"BASELINE.json configs[{1 if name == 'C2' else 2}]: single pool, {kw['n_pending']} pending x {kw['n_offers']} offers"
+                                       + ("" if name == "C2" else ", gpu dimension + host / attribute / group constraints") + ", K = all pending",
+                               "cycles": len(ts), "p50_cycle_ms": pct(ts, 0.5) * 1e3, "matched": int((j2o_x >= 0).sum()),
+                               "pair_evaluations": int(len(j2o_x)) * kw["n_offers"],
+                               "stage_ms": dict(zip(("rank", "match"), ex.last_timing())), "placement_stats": ex.match_stats()}
+            del pool_x
+
+    # ---- the boundary, not just the core (never `value`): what a cycle costs when the host hands over what CHANGED since the last
+    #      one and takes the assignments back.  cook_cycle_update per pool (1 % of the tasks leave, as many arrive — half of them new
+    #      submissions —, fresh offers) from page-locked columns, the cycle, cook_cycle_fetch into page-locked buffers; beside it the
+    #      cost of restaging EVERYTHING from pageable and from page-locked memory (cook_cycle_stage).
+    boundary = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        from cook_amd.engine import PinnedArena
+        arena = PinnedArena()
+        try:
+            rng = np.random.default_rng(7)
+            n_delta = max(1, (n_pend + n_run) // 100)
+            deltas, pinned_pools, outs = {}, {}, {}
+            for p in my_pools:
+                extra_pool = synth.make_pool(seed=0xD0000 + p, n_pending=n_delta // 2, n_running=n_delta - n_delta // 2, n_users=args.users,
+                                             n_offers=n_off, gpus=not args.no_constraints, constraints=not args.no_constraints,
+                                             id_base=27_592_186_044_416)
+                aj = extra_pool.pending_jobs
+                ng = pools[p].groups.n if pools[p].groups is not None else 0
+                if aj.group is not None:
+                    aj.group = np.where((aj.group != A.NONE_U32) & (ng > 0), aj.group % max(1, ng), A.NONE_U32).astype(np.uint32)
+                deltas[p] = (arena.copy(np.sort(rng.choice(n_pend + n_run, size=n_delta, replace=False)).astype(np.uint32)),
+                             arena.pin(extra_pool.tasks), arena.pin(aj), arena.pin(pools[p].offers))
+                pinned_pools[p] = (arena.pin(pools[p].tasks), arena.pin(pools[p].pending_jobs), arena.pin(pools[p].offers))
+                outs[p] = (arena.empty(n_pend + n_delta, np.uint32), arena.empty(n_pend + n_delta, np.int32))
+
+            def restage(pinned):
+                for p in my_pools:
+                    t_, j_, o_ = pinned_pools[p] if pinned else (pools[p].tasks, pools[p].pending_jobs, pools[p].offers)
+                    engines[p].cycle_stage(t_, pools[p].users, j_, o_, pools[p].groups)
+                torch.cuda.synchronize()
+
+            b0 = time.perf_counter()
+            restage(False)
+            b1 = time.perf_counter()
+            restage(True)
+            b2 = time.perf_counter()
+            staged_bytes = sum(sum(a.nbytes for a in vars(x).values() if isinstance(a, np.ndarray))
+                               for p in my_pools for x in pinned_pools[p])
+            cluster.cycle(K)
+            torch.cuda.synchronize()
+            t_upd = t_cyc = t_fetch = 0.0
+            n_b = 3
+            for it in range(n_b):
+                c0 = time.perf_counter()
+                for p in my_pools:
+                    engines[p].cycle_update(*deltas[p])
+                torch.cuda.synchronize()
+                c1 = time.perf_counter()
+                cluster.cycle(K)
+                torch.cuda.synchronize()
+                c2 = time.perf_counter()
+                for p in my_pools:
+                    engines[p].cycle_fetch(out=outs[p])
+                c3 = time.perf_counter()
+                t_upd += c1 - c0
+                t_cyc += c2 - c1
+                t_fetch += c3 - c2
+                if it + 1 < n_b:  # back to the benchmark's state for the next measurement: a full restage (not timed)
+                    restage(True)
+            boundary = {"ms_per_step_incl_transfers": (t_upd + t_cyc + t_fetch) / n_b * 1e3,
+                        "update_ms": t_upd / n_b * 1e3, "cycle_ms": t_cyc / n_b * 1e3, "fetch_ms": t_fetch / n_b * 1e3,
+                        "delta": f"per pool: {n_delta} task rows leave, {n_delta} arrive ({n_delta // 2} of them pending jobs), {n_off} fresh offers",
+                        "restage_all_pageable_ms": (b1 - b0) * 1e3, "restage_all_pinned_ms": (b2 - b1) * 1e3,
+                        "restage_bytes": int(staged_bytes), "restage_pinned_GBps": staged_bytes / max(1e-9, b2 - b1) / 1e9,
+                        "note": "host wall time around the C ABI calls (cook_cycle_update / the cycle / cook_cycle_fetch); page-locked "
+                                "memory from cook_host_alloc"}
+            restage(True)  # leave the engines on the benchmark's own inputs, with a finished cycle (the rows below read its results)
+            cluster.cycle(K)
+            torch.cuda.synchronize()
+        finally:
+            arena.close()  # (the engine reads host arrays only during a call)
+
     # ---- the rows either side of the path, timed once on rank 0's first pool; not part of `value` ----
     adjacent = None
     if rank == 0 and not args.no_adjacent:
@@ -297,7 +425,7 @@ def main():
                            "stage_ms_pool0": {"rank": stage_ms[my_pools[0]][0], "match": stage_ms[my_pools[0]][1]},
                            "placement_stats_pool0": engines[my_pools[0]].match_stats()},
             "setup_s": gen_s,
-            "roofline": roofline, "cpu_baseline": cpu, "adjacent_rows": adjacent,
+            "roofline": roofline, "cpu_baseline": cpu, "adjacent_rows": adjacent, "extra_configs": extra, "boundary": boundary,
             "parity_checked": parity_checked, "parity": {"against": "oracle (bit-exact rank order + every assignment)", "pools": parity_pools},
         }
         if cpu:

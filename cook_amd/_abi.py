@@ -108,6 +108,11 @@ class CookOffers(C.Structure):
     ]
 
 
+class CookCycleDelta(C.Structure):  # cook_cycle_update
+    _fields_ = [("n_remove", C.c_uint32), ("remove_task", C.POINTER(C.c_uint32)), ("add_tasks", C.POINTER(CookTasks)),
+                ("add_pending", C.POINTER(CookJobs)), ("offers", C.POINTER(CookOffers))]
+
+
 class CookGroups(C.Structure):
     _fields_ = [
         ("n", C.c_uint32),

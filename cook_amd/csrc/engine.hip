@@ -81,6 +81,7 @@ struct RebalBufs;  // rebalance_host.hpp
 struct ConsBufs;   // considerable_host.hpp
 struct OfferBufs;  // offers_host.hpp
 struct ExplainBufs;  // explain_host.hpp
+struct UpdateBufs;   // cycle_update.hpp
 
 }  // namespace
 
@@ -187,6 +188,7 @@ struct cook_engine {
   OfferBufs* ofb = nullptr;
   // ---- why-unscheduled summaries / match-cycle metrics (allocated on first use) ----
   ExplainBufs* xb = nullptr;
+  UpdateBufs* ub = nullptr;  // cook_cycle_update (allocated on first use)
   MatchIn last_in{};  // the MatchIn of the last match run (K, j_index as used)
   bool last_in_valid = false;
   unsigned rlog_id = 0;  // suffix of this engine's COOK_ROUND_LOG file
@@ -677,6 +679,44 @@ void rank_fetch(cook_engine* e, uint32_t* ranked, uint32_t* n_out, double* dru_o
 // =================================================================================================================
 // MATCH
 // =================================================================================================================
+// the offer columns of a staged match (cook_match_stage / cook_cycle_stage / cook_cycle_update)
+void match_stage_offers(cook_engine* e, const cook_offers* o, bool offers_dev) {
+  MatchIn& in = e->min;
+  const unsigned M = o->n;
+  if (M && (!o->cpus || !o->mem || !o->host)) e->fail(COOK_E_INVALID, "cook_match_stage: offers need cpus, mem and host");
+  in.M = M;
+  e->M = M;
+  in.o_cpus = (offers_dev ? o->cpus : h2d_opt(e, e->o_cpus, o->cpus, M));
+  in.o_mem = (offers_dev ? o->mem : h2d_opt(e, e->o_mem, o->mem, M));
+  in.o_host = (offers_dev ? o->host : h2d_opt(e, e->o_host, o->host, M));
+  in.o_k8s = (offers_dev ? o->k8s : h2d_opt(e, e->o_k8s, o->k8s, M));
+  in.o_gpu_model = (offers_dev ? o->gpu_model : h2d_opt(e, e->o_gpu_model, o->gpu_model, M));
+  in.o_gpu_count = (offers_dev ? o->gpu_count : h2d_opt(e, e->o_gpu_count, o->gpu_count, M));
+  if (in.o_gpu_model && !in.o_gpu_count) e->fail(COOK_E_INVALID, "cook_match_stage: gpu_model without gpu_count");
+  in.o_disk_type = (offers_dev ? o->disk_type : h2d_opt(e, e->o_disk_type, o->disk_type, M));
+  in.o_disk_space = (offers_dev ? o->disk_space : h2d_opt(e, e->o_disk_space, o->disk_space, M));
+  in.n_attr = o->attr ? o->n_attr_keys : 0;
+  in.o_attr = (offers_dev ? o->attr : h2d_opt(e, e->o_attr, o->attr, (size_t)M * in.n_attr));
+  in.o_max_tasks = (offers_dev ? o->max_tasks : h2d_opt(e, e->o_max_tasks, o->max_tasks, M));
+  in.o_num_tasks = (offers_dev ? o->num_tasks : h2d_opt(e, e->o_num_tasks, o->num_tasks, M));
+  in.o_location = (offers_dev ? o->location : h2d_opt(e, e->o_location, o->location, M));
+  in.o_host_start = (offers_dev ? o->host_start_s : h2d_opt(e, e->o_host_start, o->host_start_s, M));
+  in.o_run_cpus = (offers_dev ? o->run_cpus : h2d_opt(e, e->o_run_cpus, o->run_cpus, M));
+  in.o_run_mem = (offers_dev ? o->run_mem : h2d_opt(e, e->o_run_mem, o->run_mem, M));
+  in.o_run_count = (offers_dev ? o->run_count : h2d_opt(e, e->o_run_count, o->run_count, M));
+  // two offers on one host?  (offers built on the device are one per node: never)
+  in.host_dup = 0;
+  if (!offers_dev && M) {
+    std::vector<uint32_t> hs(o->host, o->host + M);
+    std::sort(hs.begin(), hs.end());
+    in.host_dup = std::adjacent_find(hs.begin(), hs.end()) != hs.end() ? 1u : 0u;
+  }
+}
+void match_stage_offers(cook_engine* e, const cook_offers* o) {
+  match_stage_offers(e, o, false);
+  sync(e);
+}
+
 // offers_dev: the pointers of `o` are DEVICE columns (the rows of cook_offers_run): used in place, nothing is copied
 void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o, const cook_groups* g,
                         const uint32_t* reserved_hosts, uint32_t n_reserved, bool offers_dev = false) {
@@ -720,24 +760,7 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
   in.j_disk_req = h2d_opt(e, e->j_disk_req, j->disk_request, K);
   in.j_disk_type = h2d_opt(e, e->j_disk_type, j->disk_type, K);
   if (in.j_disk_req && !in.j_disk_type) e->fail(COOK_E_INVALID, "cook_match_stage: disk_request without disk_type");
-  in.o_cpus = (offers_dev ? o->cpus : h2d_opt(e, e->o_cpus, o->cpus, M));
-  in.o_mem = (offers_dev ? o->mem : h2d_opt(e, e->o_mem, o->mem, M));
-  in.o_host = (offers_dev ? o->host : h2d_opt(e, e->o_host, o->host, M));
-  in.o_k8s = (offers_dev ? o->k8s : h2d_opt(e, e->o_k8s, o->k8s, M));
-  in.o_gpu_model = (offers_dev ? o->gpu_model : h2d_opt(e, e->o_gpu_model, o->gpu_model, M));
-  in.o_gpu_count = (offers_dev ? o->gpu_count : h2d_opt(e, e->o_gpu_count, o->gpu_count, M));
-  if (in.o_gpu_model && !in.o_gpu_count) e->fail(COOK_E_INVALID, "cook_match_stage: gpu_model without gpu_count");
-  in.o_disk_type = (offers_dev ? o->disk_type : h2d_opt(e, e->o_disk_type, o->disk_type, M));
-  in.o_disk_space = (offers_dev ? o->disk_space : h2d_opt(e, e->o_disk_space, o->disk_space, M));
-  in.n_attr = o->attr ? o->n_attr_keys : 0;
-  in.o_attr = (offers_dev ? o->attr : h2d_opt(e, e->o_attr, o->attr, (size_t)M * in.n_attr));
-  in.o_max_tasks = (offers_dev ? o->max_tasks : h2d_opt(e, e->o_max_tasks, o->max_tasks, M));
-  in.o_num_tasks = (offers_dev ? o->num_tasks : h2d_opt(e, e->o_num_tasks, o->num_tasks, M));
-  in.o_location = (offers_dev ? o->location : h2d_opt(e, e->o_location, o->location, M));
-  in.o_host_start = (offers_dev ? o->host_start_s : h2d_opt(e, e->o_host_start, o->host_start_s, M));
-  in.o_run_cpus = (offers_dev ? o->run_cpus : h2d_opt(e, e->o_run_cpus, o->run_cpus, M));
-  in.o_run_mem = (offers_dev ? o->run_mem : h2d_opt(e, e->o_run_mem, o->run_mem, M));
-  in.o_run_count = (offers_dev ? o->run_count : h2d_opt(e, e->o_run_count, o->run_count, M));
+  match_stage_offers(e, o, offers_dev);
   if (G) {
     in.g_type = h2d_opt(e, e->g_type, g->type, G);
     in.g_attr_key = h2d_opt(e, e->g_attr_key, g->attr_key, G);
@@ -761,13 +784,6 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
   }
   in.good_enough = e->params.good_enough_fitness;
   in.host_lifetime_mins = e->params.host_lifetime_mins;
-  // two offers on one host?  (offers built on the device are one per node: never)
-  in.host_dup = 0;
-  if (!offers_dev && M) {
-    std::vector<uint32_t> hs(o->host, o->host + M);
-    std::sort(hs.begin(), hs.end());
-    in.host_dup = std::adjacent_find(hs.begin(), hs.end()) != hs.end() ? 1u : 0u;
-  }
   sync(e);  // `bits` is a host temporary
   e->K = K;
   e->M = M;
@@ -1193,6 +1209,7 @@ struct StageTimer {
 #include "rebalance_host.hpp"
 #include "offers_host.hpp"
 #include "explain_host.hpp"
+#include "cycle_update.hpp"
 
 ConsBufs& cons_bufs(cook_engine* e) {
   if (!e->cb) e->cb = new ConsBufs();
@@ -1322,6 +1339,8 @@ void cook_engine_destroy(cook_engine* e) {
   e->ofb = nullptr;
   delete e->xb;
   e->xb = nullptr;
+  delete e->ub;
+  e->ub = nullptr;
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1498,6 +1517,21 @@ static unsigned cycle_rank_part(cook_engine* e, uint32_t num_considerable) {
          e->j_index.ptr());
   }
   return K;
+}
+int cook_cycle_update(cook_engine* e, const cook_cycle_delta* delta) {
+  return guarded(e, [&] {
+    if (!e->ub) e->ub = new UpdateBufs();
+    cycle_update(e, *e->ub, delta);
+    prof_collect(e);
+  });
+}
+void* cook_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void cook_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 int cook_cycle_run(cook_engine* e, uint32_t num_considerable) {
   return guarded(e, [&] {

@@ -21,7 +21,8 @@ EXPORTS = [
     "cook_engine_create", "cook_engine_destroy", "cook_engine_set_params", "cook_last_error", "cook_version",
     "cook_rank", "cook_rank_stage", "cook_rank_set_quota", "cook_rank_pool_usage", "cook_rank_user_usage", "cook_rank_run", "cook_rank_fetch",
     "cook_match", "cook_match_stage", "cook_match_run", "cook_match_fetch",
-    "cook_cycle_stage", "cook_cycle_run", "cook_cycle_fetch", "cook_cycle_run_rank", "cook_cycle_match_multi",
+    "cook_cycle_stage", "cook_cycle_update", "cook_cycle_run", "cook_cycle_fetch", "cook_cycle_run_rank", "cook_cycle_match_multi",
+    "cook_host_alloc", "cook_host_free",
     "cook_considerable", "cook_cycle_set_considerable", "cook_cycle_fetch_considerable",
     "cook_rebalance", "cook_rebalance_stage", "cook_rebalance_run", "cook_rebalance_fetch", "cook_rebalance_timing",
     "cook_match_explain", "cook_match_metrics",
@@ -66,6 +67,9 @@ def load_library(path: Optional[str] = None):
     lib.cook_engine_create.argtypes = [C.POINTER(A.CookParams), C.c_int, C.POINTER(C.c_void_p)]
     lib.cook_engine_destroy.argtypes = [C.c_void_p]
     lib.cook_last_error.argtypes = [C.c_void_p]
+    lib.cook_host_alloc.restype = C.c_void_p
+    lib.cook_host_alloc.argtypes = [C.c_size_t]
+    lib.cook_host_free.argtypes = [C.c_void_p]
     _LIBS[path] = lib
     return lib
 
@@ -197,6 +201,23 @@ class Engine:
                                              C.byref(gs) if gs is not None else None, _p(res, C.c_uint32),
                                              len(reserved_hosts)))
 
+    def cycle_update(self, remove_task=(), add_tasks: Optional[A.Tasks] = None, add_pending: Optional[A.Jobs] = None,
+                     offers: Optional[A.Offers] = None):
+        """What changed since the last cycle (cook_cycle_update): task rows to remove (indices into the CURRENT arrays), task /
+        pending-job rows to append, optionally fresh offers.  The resident columns are edited on the device."""
+        rem = np.ascontiguousarray(np.asarray(list(remove_task) if not isinstance(remove_task, np.ndarray) else remove_task, dtype=np.uint32))
+        ts = add_tasks.as_struct() if add_tasks is not None else None
+        js = add_pending.as_struct() if add_pending is not None else None
+        os_ = offers.as_struct() if offers is not None else None
+        d = A.CookCycleDelta(len(rem), _p(rem, C.c_uint32) if len(rem) else None, C.pointer(ts) if ts is not None else None,
+                             C.pointer(js) if js is not None else None, C.pointer(os_) if os_ is not None else None)
+        self._chk(self._lib.cook_cycle_update(self._h, C.byref(d)))
+        n_add = add_tasks.n if add_tasks is not None else 0
+        p_add = int(add_tasks.pending.sum()) if n_add else 0
+        # the mirror's sizes for the fetch buffers: upper bounds (removed rows only shrink them)
+        self._rank_n = self._rank_n + n_add
+        self._rank_np = self._rank_np + p_add
+
     def cycle_run(self, num_considerable: int):
         self._chk(self._lib.cook_cycle_run(self._h, int(num_considerable)))
 
@@ -204,14 +225,22 @@ class Engine:
         """The rank / considerable / take-K part of cycle_run; the placement then runs in cycle_match_multi()."""
         self._chk(self._lib.cook_cycle_run_rank(self._h, int(num_considerable)))
 
-    def cycle_fetch(self):
-        ranked = np.zeros(max(1, self._rank_np), dtype=np.uint32)
-        j2o = np.full(max(1, self._rank_np), -1, dtype=np.int32)
+    def cycle_fetch(self, out=None):
+        """-> (ranked task indices, job_to_offer by rank position, head matched).  `out` = (u32 buffer, i32 buffer) to fetch into
+        (e.g. page-locked arrays of a PinnedArena, each with room for every pending task): views of them are returned."""
+        if out is None:
+            ranked = np.zeros(max(1, self._rank_np), dtype=np.uint32)
+            j2o = np.full(max(1, self._rank_np), -1, dtype=np.int32)
+        else:
+            ranked, j2o = out
+            assert len(ranked) >= self._rank_np and len(j2o) >= self._rank_np
         n, k = C.c_uint32(0), C.c_uint32(0)
         head = C.c_uint8(0)
         self._chk(self._lib.cook_cycle_fetch(self._h, _p(ranked, C.c_uint32), C.byref(n), _p(j2o, C.c_int32),
                                              C.byref(k), C.byref(head)))
-        return ranked[: n.value].copy(), j2o[: k.value].copy(), bool(head.value)
+        if out is None:
+            return ranked[: n.value].copy(), j2o[: k.value].copy(), bool(head.value)
+        return ranked[: n.value], j2o[: k.value], bool(head.value)
 
     # ---- considerable jobs -----------------------------------------------------------------------------------
     def considerable(self, queue: A.Queue, users: A.UserState, num_considerable: int):
@@ -397,6 +426,53 @@ class Engine:
         launches = (C.c_uint32 * cap)()
         n = self._lib.cook_kernel_timings(self._h, names, ms, launches, cap)
         return {names[i].decode(): (ms[i], launches[i]) for i in range(max(0, n))}
+
+
+class PinnedArena:
+    """numpy arrays in page-locked host memory (cook_host_alloc): copies to and from the device run at link speed.  The
+    arena owns the memory; arrays made by it must not outlive it."""
+
+    def __init__(self, lib_path: Optional[str] = None):
+        self._lib = load_library(lib_path)
+        self._blocks = []
+
+    def empty(self, shape, dtype) -> np.ndarray:
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+        nbytes = max(1, n * dt.itemsize)
+        p = self._lib.cook_host_alloc(nbytes)
+        if not p:
+            raise MemoryError("cook_host_alloc failed")
+        self._blocks.append(p)
+        buf = (C.c_char * nbytes).from_address(p)
+        return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+    def copy(self, a: np.ndarray) -> np.ndarray:
+        out = self.empty(a.shape, a.dtype)
+        out[...] = a
+        return out
+
+    def pin(self, obj):
+        """A copy of a dataclass of columns (A.Tasks, A.Jobs, A.Offers, ...) whose numpy arrays live in this arena."""
+        import copy as _copy
+        import dataclasses
+        new = _copy.copy(obj)
+        for f in dataclasses.fields(obj):
+            v = getattr(obj, f.name)
+            if isinstance(v, np.ndarray):
+                object.__setattr__(new, f.name, self.copy(np.ascontiguousarray(v)))
+        return new
+
+    def close(self):
+        for p in self._blocks:
+            self._lib.cook_host_free(p)
+        self._blocks = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def cycle_match_multi(engines: Sequence[Engine]):

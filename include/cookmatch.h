@@ -27,6 +27,7 @@
 #ifndef COOKMATCH_H
 #define COOKMATCH_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -280,6 +281,28 @@ int cook_match_fetch(cook_engine* e, int32_t* job_to_offer, uint32_t* fail_code,
 int cook_cycle_stage(cook_engine* e, const cook_tasks* tasks, const cook_users* users, const cook_jobs* pending_jobs,
                      const cook_offers* offers, const cook_groups* groups, const uint32_t* reserved_hosts,
                      uint32_t n_reserved);
+
+/* What changed between two match cycles of a pool whose inputs are RESIDENT (cook_cycle_stage once, then one delta per cycle):
+ * handle-resource-offers! (scheduler.clj:1339-1385) meets almost the same pool every cycle — instances finished or were killed
+ * (their task rows leave), jobs were submitted (new pending rows) or launched (the pending row leaves, a running row arrives), and
+ * the offers are fresh.  The columns are edited on the device: a STABLE compaction, then the new rows at the end.  Task indices
+ * reported afterwards (cook_cycle_fetch's ranked_pending_idx) refer to the updated arrays: row i of the old arrays that was kept is
+ * now at i minus the number of removed rows in front of it; add_tasks[r] is at n_kept + r.  add_pending describes the pending tasks
+ * of add_tasks, in order, and may only carry optional columns that the staged jobs carry too (else restage).  Users, groups and
+ * reserved hosts stay as staged. */
+typedef struct cook_cycle_delta {
+  uint32_t n_remove;
+  const uint32_t* remove_task;  /* indices into the current task arrays, each at most once */
+  const cook_tasks* add_tasks;  /* may be NULL */
+  const cook_jobs* add_pending; /* may be NULL when no added task is pending */
+  const cook_offers* offers;    /* NULL: the staged offers stay; else they are replaced wholesale */
+} cook_cycle_delta;
+int cook_cycle_update(cook_engine* e, const cook_cycle_delta* delta);
+
+/* Page-locked host memory for input columns and result buffers: copies from / to it run at link speed (pageable memory goes
+ * through a bounce buffer at a fraction of it).  NULL on failure. */
+void* cook_host_alloc(size_t bytes);
+void cook_host_free(void* p);
 int cook_cycle_run(cook_engine* e, uint32_t num_considerable);
 /* Several pools of one rank (same device) in lockstep: cook_cycle_run_rank does the rank / considerable / take-K part of
  * cook_cycle_run for ONE engine (call it for each engine, from any threads), then cook_cycle_match_multi runs the placements of

@@ -740,3 +740,77 @@ def check_replay_recorded(backend, max_cycles=10 ** 9):
     if max_cycles >= 10 ** 9:
         assert n == len(g["expect"]) == len(rows) == 115
     return n
+
+
+def _concat_jobs(a: A.Jobs, b: A.Jobs) -> A.Jobs:
+    """rows of a followed by rows of b (optional columns: taken from whoever has them, defaults for the other)"""
+    kw = {}
+    na, nb = a.n, b.n
+    defaults = dict(gpus=0.0, gpu_model=0, user=0, group=A.NONE_U32, reserved_host=-1, ckpt_location=0, est_end_ms=0, disk_request=-1.0, disk_type=0)
+    for name in ("cpus", "mem", "gpus", "gpu_model", "user", "group", "reserved_host", "ckpt_location", "est_end_ms", "disk_request", "disk_type"):
+        xa, xb = getattr(a, name), getattr(b, name)
+        if xa is None and xb is None:
+            continue
+        ref = xa if xa is not None else xb
+        fa = xa if xa is not None else np.full(na, defaults[name], dtype=ref.dtype)
+        fb = xb if xb is not None else np.full(nb, defaults[name], dtype=ref.dtype)
+        kw[name] = np.concatenate([fa, fb])
+    for off, vals in (("eq_off", ("eq_key", "eq_val")), ("novel_off", ("novel_host",))):
+        oa, ob = getattr(a, off), getattr(b, off)
+        if oa is None and ob is None:
+            continue
+        oa = oa if oa is not None else np.zeros(na + 1, np.uint32)
+        ob = ob if ob is not None else np.zeros(nb + 1, np.uint32)
+        kw[off] = np.concatenate([oa[:na + 1], ob[1:nb + 1] + oa[na]]).astype(np.uint32)
+        for v in vals:
+            va = getattr(a, v) if getattr(a, off) is not None else np.zeros(0, np.uint32)
+            vb_ = getattr(b, v) if getattr(b, off) is not None else np.zeros(0, np.uint32)
+            kw[v] = np.concatenate([va[:oa[na]], vb_[:ob[nb]]]).astype(np.uint32)
+    return A.Jobs(**kw)
+
+
+def cycle_update_parity(make_engine, seed, n_pending=900, n_running=400, n_users=30, n_offers=120, n_remove=150, n_add=200, new_offers=True, k=10 ** 9):
+    """cook_cycle_update(delta) on resident inputs == cook_cycle_stage of the updated arrays (fresh engine) == oracle."""
+    rng = np.random.default_rng(seed)
+    p = A.default_params(good_enough_fitness=1.0)
+    pool = synth.make_pool(seed=seed, n_pending=n_pending, n_running=n_running, n_users=n_users, n_offers=n_offers, gpus=True, constraints=True)
+    extra = synth.make_pool(seed=seed + 1000, n_pending=n_add // 2, n_running=n_add - n_add // 2, n_users=n_users, n_offers=max(8, n_offers // 2 + 7),
+                            gpus=True, constraints=True, id_base=27_592_186_044_416)
+    # group ids of the added jobs must exist in the staged group table: map them into it (or none)
+    ng = pool.groups.n if pool.groups is not None else 0
+    add_jobs = extra.pending_jobs
+    if add_jobs.group is not None:
+        add_jobs.group = np.where((add_jobs.group != A.NONE_U32) & (ng > 0), add_jobs.group % max(1, ng), A.NONE_U32).astype(np.uint32)
+    remove = np.sort(rng.choice(pool.tasks.n, size=min(n_remove, pool.tasks.n), replace=False)).astype(np.uint32)
+    offers2 = extra.offers if new_offers else None
+    # ---- the updated arrays, on the host --------------------------------------------------------------------------------------
+    keep = np.ones(pool.tasks.n, bool)
+    keep[remove] = False
+    T, X = pool.tasks, extra.tasks
+    cat = lambda a, b: np.concatenate([a[keep], b])
+    tasks2 = A.Tasks(cpus=cat(T.cpus, X.cpus), mem=cat(T.mem, X.mem), gpus=cat(T.gpus, X.gpus), user=cat(T.user, X.user),
+                     priority=cat(T.priority, X.priority), start_ms=cat(T.start_ms, X.start_ms), task_id=cat(T.task_id, X.task_id),
+                     job_id=cat(T.job_id, X.job_id), pending=cat(T.pending, X.pending))
+    pend_idx = np.nonzero(T.pending)[0]
+    keep_p = keep[pend_idx]
+    jobs2 = _concat_jobs(pool.pending_jobs.take(np.nonzero(keep_p)[0]), add_jobs)
+    off_final = offers2 if offers2 is not None else pool.offers
+    with make_engine(p) as e:
+        e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        e.cycle_run(k)       # a cycle on the old state first: the update must not depend on a fresh stage
+        e.cycle_update(remove, extra.tasks, add_jobs, offers2)
+        e.cycle_run(k)
+        got = e.cycle_fetch()
+    with make_engine(p) as e:
+        e.cycle_stage(tasks2, pool.users, jobs2, off_final, pool.groups)
+        e.cycle_run(k)
+        want = e.cycle_fetch()
+    assert np.array_equal(got[0], want[0]), "ranked order after the update differs from a restage"
+    assert np.array_equal(got[1], want[1]) and got[2] == want[2], "placements after the update differ from a restage"
+    o_ranked, _ = pyoracle.rank(p, tasks2, pool.users)
+    assert np.array_equal(got[0], o_ranked)
+    pend_ord = np.cumsum(tasks2.pending) - 1
+    kk = min(k, len(o_ranked))
+    o_j2o, _, o_head = pyoracle.match(p, jobs2.take(pend_ord[o_ranked[:kk]]), off_final, pool.groups)
+    assert np.array_equal(got[1], o_j2o) and got[2] == o_head
+    return got

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     txt = open(os.path.join(ROOT, "include", "cookmatch.h")).read()
-    return sorted(set(re.findall(r"^\s*(?:int|void|const char\*)\s+(cook_\w+)\s*\(", txt, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|void\*?|const char\*)\s+(cook_\w+)\s*\(", txt, flags=re.M)))
 
 
 def test_header_symbols_exported():
@@ -33,7 +33,7 @@ def test_struct_sizes_match_header(tmp_path):
     names = ["cook_params", "cook_usage", "cook_tasks", "cook_users", "cook_pool_quota", "cook_jobs", "cook_offers",
              "cook_groups", "cook_rebalance_params", "cook_host_spare", "cook_preemption", "cook_queue", "cook_user_state",
              "cook_nodes", "cook_pods", "cook_offer_params", "cook_node_offers", "cook_offer_totals", "cook_resource_stats",
-             "cook_cycle_metrics"]
+             "cook_cycle_metrics", "cook_cycle_delta"]
     src.write_text('#include <stdio.h>\n#include "cookmatch.h"\nint main(){' +
                    "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}")
     exe = tmp_path / "sz"
@@ -43,7 +43,7 @@ def test_struct_sizes_match_header(tmp_path):
     mirrors = [A.CookParams, A.CookUsage, A.CookTasks, A.CookUsers, A.CookPoolQuota, A.CookJobs, A.CookOffers,
                A.CookGroups, A.CookRebalanceParams, A.CookHostSpare, A.CookPreemption, A.CookQueue, A.CookUserState,
                A.CookNodes, A.CookPods, A.CookOfferParams, A.CookNodeOffers, A.CookOfferTotals, A.CookResourceStats,
-               A.CookCycleMetrics]
+               A.CookCycleMetrics, A.CookCycleDelta]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 

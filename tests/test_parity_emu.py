@@ -257,6 +257,17 @@ def test_world_many_pools_good_enough(make_engine):
     P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=0.8, match_algo=5), k=400, want_persistent=2)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(seed=401),
+    dict(seed=402, n_remove=0, n_add=60),                        # only submissions
+    dict(seed=403, n_remove=300, n_add=0, new_offers=False),     # only departures, the offers stay
+    dict(seed=404, n_pending=60, n_running=0, n_remove=60, n_add=40, n_offers=20),  # everything staged goes
+    dict(seed=405, n_pending=2500, n_running=900, n_remove=700, n_add=650, k=400),
+], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_cycle_update(make_engine, kw):
+    P.cycle_update_parity(make_engine, **kw)
+
+
 def test_edge_cases(make_engine):
     P.edge_cases(make_engine)
 

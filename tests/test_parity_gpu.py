@@ -277,6 +277,15 @@ def test_multi_pool(make_engine, algo):
     P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0, match_algo=algo), k=4000, want_persistent=2 if algo == 5 else 0)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(seed=401),
+    dict(seed=403, n_remove=300, n_add=0, new_offers=False),
+    dict(seed=406, n_pending=60000, n_running=25000, n_users=800, n_offers=3000, n_remove=9000, n_add=8000, k=20000),
+], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_cycle_update(make_engine, kw):
+    P.cycle_update_parity(make_engine, **kw)
+
+
 def test_edge_cases(make_engine):
     P.edge_cases(make_engine)
 
