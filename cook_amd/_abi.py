@@ -92,6 +92,7 @@ class CookJobs(C.Structure):
         ("novel_off", _u32p), ("novel_host", _u32p),
         ("reserved_host", _i32p), ("ckpt_location", _u32p), ("est_end_ms", _i64p),
         ("disk_request", _f64p), ("disk_type", _u32p),
+        ("ports", _i32p), ("n_scalars", C.c_uint32), ("reserved_", C.c_uint32), ("scalars", _f64p),
     ]
 
 
@@ -105,6 +106,8 @@ class CookOffers(C.Structure):
         ("max_tasks", _i32p), ("num_tasks", _i32p),
         ("location", _u32p), ("host_start_s", _i64p),
         ("run_cpus", _f64p), ("run_mem", _f64p), ("run_count", _i32p),
+        ("gpu_slots", C.c_uint32), ("disk_slots", C.c_uint32), ("ports", _i32p),
+        ("n_scalars", C.c_uint32), ("reserved_", C.c_uint32), ("scalars", _f64p),
     ]
 
 
@@ -138,6 +141,7 @@ class CookPreemption(C.Structure):
     ]
 
 
+MAX_SCALARS, MAX_RES_SLOTS = 3, 4  # COOK_MAX_SCALARS, COOK_MAX_RES_SLOTS
 _DT = {_f64p: np.float64, _u32p: np.uint32, _i32p: np.int32, _i64p: np.int64, _u8p: np.uint8}
 
 
@@ -155,6 +159,17 @@ def _arr(x, dtype, n=None):
     if n is not None:
         assert a.shape == (n,), (a.shape, n)
     return a
+
+
+def _table(x, dtype, n, max_cols):
+    """[n] or [n, cols] -> ([n, cols] C-contiguous, cols)"""
+    if x is None:
+        return None, 0
+    a = np.ascontiguousarray(x, dtype=dtype)
+    if a.ndim == 1:
+        a = a.reshape(n, 1)
+    assert a.ndim == 2 and a.shape[0] == n and 1 <= a.shape[1] <= max_cols, (a.shape, n, max_cols)
+    return a, a.shape[1]
 
 
 def default_params(**kw) -> CookParams:
@@ -357,11 +372,15 @@ class Jobs:
     est_end_ms: Optional[np.ndarray] = None
     disk_request: Optional[np.ndarray] = None
     disk_type: Optional[np.ndarray] = None
+    ports: Optional[np.ndarray] = None    # number of ports asked for (scheduler.clj:466)
+    scalars: Optional[np.ndarray] = None  # [n, n_scalars] named scalar requests, NaN = none (scheduler.clj:177-189)
 
     def __post_init__(self):
         n = len(self.cpus)
         self.cpus = _arr(self.cpus, np.float64, n)
         self.mem = _arr(self.mem, np.float64, n)
+        self.ports = _arr(self.ports, np.int32, n)
+        self.scalars, self.n_scalars = _table(self.scalars, np.float64, n, MAX_SCALARS)
         self.gpus = _arr(self.gpus, np.float64, n)
         self.gpu_model = _arr(self.gpu_model, np.uint32, n)
         self.user = _arr(self.user, np.uint32, n)
@@ -408,7 +427,7 @@ class Jobs:
         idx = np.asarray(idx, dtype=np.int64)
         kw = {}
         for name in ("cpus", "mem", "gpus", "gpu_model", "user", "group", "reserved_host", "ckpt_location",
-                     "est_end_ms", "disk_request", "disk_type"):
+                     "est_end_ms", "disk_request", "disk_type", "ports", "scalars"):
             a = getattr(self, name)
             kw[name] = None if a is None else a[idx]
         if self.eq_off is not None:
@@ -423,13 +442,21 @@ class Jobs:
             kw.update(novel_off=off, novel_host=np.array(flat, dtype=np.uint32))
         return Jobs(**kw)
 
+    def _scalar_cols(self):
+        if self.scalars is None:
+            return None
+        self._cols = np.ascontiguousarray(self.scalars.T).reshape(-1)  # the ABI takes one contiguous column per name
+        return self._cols
+
     def as_struct(self) -> CookJobs:
         return CookJobs(self.n, _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p), _ptr(self.gpus, _f64p),
                         _ptr(self.gpu_model, _u32p), _ptr(self.user, _u32p), _ptr(self.group, _u32p),
                         _ptr(self.eq_off, _u32p), _ptr(self.eq_key, _u32p), _ptr(self.eq_val, _u32p),
                         _ptr(self.novel_off, _u32p), _ptr(self.novel_host, _u32p),
                         _ptr(self.reserved_host, _i32p), _ptr(self.ckpt_location, _u32p),
-                        _ptr(self.est_end_ms, _i64p), _ptr(self.disk_request, _f64p), _ptr(self.disk_type, _u32p))
+                        _ptr(self.est_end_ms, _i64p), _ptr(self.disk_request, _f64p), _ptr(self.disk_type, _u32p),
+                        _ptr(self.ports, _i32p), self.n_scalars, 0,
+                        _ptr(self._scalar_cols(), _f64p))
 
 
 @dataclass
@@ -451,6 +478,8 @@ class Offers:
     run_cpus: Optional[np.ndarray] = None
     run_mem: Optional[np.ndarray] = None
     run_count: Optional[np.ndarray] = None
+    ports: Optional[np.ndarray] = None    # ports in the lease's ranges (offer.clj:71-73)
+    scalars: Optional[np.ndarray] = None  # [n, n_scalars] lease getScalarValues under the jobs' scalar names (offer.clj:57-65)
 
     def __post_init__(self):
         n = len(self.cpus)
@@ -458,12 +487,21 @@ class Offers:
         self.mem = _arr(self.mem, np.float64, n)
         self.host = _arr(self.host if self.host is not None else np.arange(n), np.uint32, n)
         self.k8s = _arr(self.k8s, np.uint8, n)
-        self.gpu_model = _arr(self.gpu_model, np.uint32, n)
-        self.gpu_count = _arr(self.gpu_count, np.float64, n)
+        self.ports = _arr(self.ports, np.int32, n)
+        self.scalars, self.n_scalars = _table(self.scalars, np.float64, n, MAX_SCALARS)
+        # gpu_model / gpu_count (disk_type / disk_space): [n], or [n, slots] for hosts whose k8s map has several entries
+        self.gpu_model, self.gpu_slots = _table(self.gpu_model, np.uint32, n, MAX_RES_SLOTS)
+        self.gpu_count, gc = _table(self.gpu_count, np.float64, n, MAX_RES_SLOTS)
         if self.gpu_model is not None and self.gpu_count is None:
-            self.gpu_count = np.zeros(n)
-        self.disk_type = _arr(self.disk_type, np.uint32, n)
-        self.disk_space = _arr(self.disk_space, np.float64, n)
+            self.gpu_count = np.zeros((n, self.gpu_slots))
+        assert self.gpu_model is None or self.gpu_count.shape == self.gpu_model.shape
+        self.disk_type, self.disk_slots = _table(self.disk_type, np.uint32, n, MAX_RES_SLOTS)
+        self.disk_space, ds = _table(self.disk_space, np.float64, n, MAX_RES_SLOTS)
+        assert (self.disk_type is None) == (self.disk_space is None) and (self.disk_type is None or self.disk_space.shape == self.disk_type.shape)
+        for name in ("gpu_model", "gpu_count", "disk_type", "disk_space"):  # the plain per-host columns stay 1-d
+            a = getattr(self, name)
+            if a is not None and a.shape[1] == 1:
+                setattr(self, name, a.reshape(n))
         if self.attr is not None:
             self.attr = np.ascontiguousarray(self.attr, dtype=np.uint32)
             assert self.attr.ndim == 2 and self.attr.shape[0] == n
@@ -485,15 +523,24 @@ class Offers:
     def n_attr_keys(self):
         return 0 if self.attr is None else self.attr.shape[1]
 
+    def _scalar_cols(self):
+        if self.scalars is None:
+            return None
+        self._cols = np.ascontiguousarray(self.scalars.T).reshape(-1)
+        return self._cols
+
     def as_struct(self) -> CookOffers:
         attr = None if self.attr is None else self.attr.reshape(-1)
+        flat = lambda a: None if a is None else a.reshape(-1)
         return CookOffers(self.n, _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p), _ptr(self.host, _u32p),
-                          _ptr(self.k8s, _u8p), _ptr(self.gpu_model, _u32p), _ptr(self.gpu_count, _f64p),
-                          _ptr(self.disk_type, _u32p), _ptr(self.disk_space, _f64p),
+                          _ptr(self.k8s, _u8p), _ptr(flat(self.gpu_model), _u32p), _ptr(flat(self.gpu_count), _f64p),
+                          _ptr(flat(self.disk_type), _u32p), _ptr(flat(self.disk_space), _f64p),
                           self.n_attr_keys, _ptr(attr, _u32p),
                           _ptr(self.max_tasks, _i32p), _ptr(self.num_tasks, _i32p),
                           _ptr(self.location, _u32p), _ptr(self.host_start_s, _i64p),
-                          _ptr(self.run_cpus, _f64p), _ptr(self.run_mem, _f64p), _ptr(self.run_count, _i32p))
+                          _ptr(self.run_cpus, _f64p), _ptr(self.run_mem, _f64p), _ptr(self.run_count, _i32p),
+                          self.gpu_slots if self.gpu_model is not None else 0, self.disk_slots if self.disk_type is not None else 0,
+                          _ptr(self.ports, _i32p), self.n_scalars, 0, _ptr(self._scalar_cols(), _f64p))
 
 
 @dataclass
@@ -577,7 +624,7 @@ class CookOfferParams(C.Structure):
     _fields_ = [
         ("clobber_synthetic_pods", C.c_int32), ("filter_out_unsound_gpu_nodes", C.c_int32),
         ("max_pods_per_node", C.c_int32), ("n_gpu_models", C.c_uint32), ("n_disk_types", C.c_uint32),
-        ("reserved", C.c_int32),
+        ("gpu_slots", C.c_uint32), ("disk_slots", C.c_uint32),
     ]
 
 
@@ -671,9 +718,11 @@ class Pods:
 
 
 def offer_params(clobber_synthetic_pods=False, filter_out_unsound_gpu_nodes=False, max_pods_per_node=2 ** 31 - 1,
-                 n_gpu_models=0, n_disk_types=0) -> CookOfferParams:
+                 n_gpu_models=0, n_disk_types=0, gpu_slots=1, disk_slots=1) -> CookOfferParams:
+    """gpu_slots / disk_slots: entries per offer row of the "gpus" / "disk" maps (the node's own model plus the models only its
+    pods name); 1 = the plain per-host columns"""
     return CookOfferParams(int(bool(clobber_synthetic_pods)), int(bool(filter_out_unsound_gpu_nodes)), int(max_pods_per_node),
-                           int(n_gpu_models), int(n_disk_types), 0)
+                           int(n_gpu_models), int(n_disk_types), int(gpu_slots), int(disk_slots))
 
 
 @dataclass
@@ -708,7 +757,8 @@ class BuiltOffers:
 
 
 # ---- why-unscheduled summaries and match-cycle metrics ------------------------------------------------------------------------
-WHY_SLOTS = 16
+WHY_SLOTS = 20
+WHY_SCALAR0, WHY_PORTS = 14, 17
 WHY_NAMES = {  # slot -> the key of fenzo-utils/summarize-placement-failure's map (fenzo_utils.clj:33-55)
     0: (":resources", "cpus"), 1: (":resources", "mem"), 2: (":resources", "fitness"),
     3: (":constraints", "checkpoint_locality_constraint"), 4: (":constraints", "estimated_completion_constraint"),
@@ -721,12 +771,19 @@ WHY_NAMES = {  # slot -> the key of fenzo-utils/summarize-placement-failure's ma
 }
 
 
-def why_summary(row) -> dict:
-    """one COOK_WHY_* row -> the reference's {:resources {...} :constraints {...}} map (zero counts omitted)"""
+def why_summary(row, scalar_names=()) -> dict:
+    """one COOK_WHY_* row -> the reference's {:resources {...} :constraints {...}} map (zero counts omitted).  scalar_names: the
+    caller's named-scalar table (cook_jobs.scalars columns); a name of "cpus" / "mem" replaces the cpus / mem slot (the summary's
+    "cpus" / "mem" entries ARE the named-scalar failures: the message field, fenzo_utils.clj:21-45)."""
     out: dict = {}
+    named = {name: WHY_SCALAR0 + s for s, name in enumerate(scalar_names)}
     for slot, (kind, name) in WHY_NAMES.items():
-        if row[slot]:
-            out.setdefault(kind, {})[name] = int(row[slot])
+        src = named.get(name, slot) if kind == ":resources" else slot
+        if row[src]:
+            out.setdefault(kind, {})[name] = int(row[src])
+    for name, slot in named.items():
+        if name not in ("cpus", "mem") and row[slot]:
+            out.setdefault(":resources", {})[name] = int(row[slot])
     return out
 
 

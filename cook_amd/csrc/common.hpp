@@ -254,3 +254,21 @@ struct cook_error {
 };
 
 static inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+// (get model->count model 0) / (count model->count) over a host's k8s "gpus" or "disk" map (constraints.clj:136-142, 178): the
+// map is the row's non-empty slots; a job without a model asks for key nil, which no map holds
+static __device__ __forceinline__ double map_get_dev(const uint32_t* __restrict__ keys, const double* __restrict__ vals, unsigned slots,
+                                                     unsigned v, unsigned key) {
+  double r = 0.0;
+  if (keys && vals && key != 0u)
+    for (unsigned s = 0; s < slots; ++s)
+      if (keys[(size_t)v * slots + s] == key) r = vals[(size_t)v * slots + s];
+  return r;
+}
+static __device__ __forceinline__ unsigned map_count_dev(const uint32_t* __restrict__ keys, unsigned slots, unsigned v) {
+  unsigned n = 0;
+  if (keys)
+    for (unsigned s = 0; s < slots; ++s) n += keys[(size_t)v * slots + s] != 0u ? 1u : 0u;
+  return n;
+}
+

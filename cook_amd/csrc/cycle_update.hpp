@@ -162,7 +162,8 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
   // a column the delta brings but the stage did not have cannot be added row-wise: the host restages (cook_cycle_stage)
   if (p_add && ((aj->gpus && !in.j_gpus) || (aj->gpu_model && !in.j_gpu_model) || (aj->group && !in.j_group) || (aj->eq_off && !in.j_eq_off) ||
                 (aj->novel_off && !in.j_novel_off) || (aj->reserved_host && !in.j_reserved_host) || (aj->ckpt_location && !in.j_ckpt) ||
-                (aj->est_end_ms && !in.j_est_end) || (aj->disk_request && !in.j_disk_req) || (aj->user && !e->has_j_user)))
+                (aj->est_end_ms && !in.j_est_end) || (aj->disk_request && !in.j_disk_req) || (aj->user && !e->has_j_user) ||
+                (aj->ports && !in.j_ports) || (aj->scalars && aj->n_scalars > in.n_scal)))
     e->fail(COOK_E_INVALID, "cook_cycle_update: add_pending carries a column the staged jobs do not have (restage with cook_cycle_stage)");
   if (n_add && at->gpus && !e->has_gpus) e->fail(COOK_E_INVALID, "cook_cycle_update: add_tasks carries gpus but the staged tasks do not");
   if (p_add && aj->group)
@@ -244,6 +245,15 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
     in.j_disk_req = e->j_disk_req.ptr();
     in.j_disk_type = e->j_disk_type.ptr();
   }
+  // ports / named scalars (a new job asking for one switches the extra resource tests on)
+  if (in.j_ports) upd_column<int32_t>(e, ub, e->j_ports, keep_p, incl_p, P, p_keep, aj ? aj->ports : nullptr, p_add, true, 0), in.j_ports = e->j_ports.ptr();
+  for (unsigned sc = 0; sc < in.n_scal; ++sc) {
+    const double* col = (aj && aj->scalars && sc < aj->n_scalars) ? aj->scalars + (size_t)sc * p_add : nullptr;
+    upd_column<double>(e, ub, e->j_scal[sc], keep_p, incl_p, P, p_keep, col, p_add, true, __builtin_nan(""));
+    in.j_scal[sc] = e->j_scal[sc].ptr();
+    for (unsigned r = 0; col && r < p_add && !in.has_x; ++r) in.has_x = col[r] == col[r];
+  }
+  for (unsigned r = 0; aj && aj->ports && r < p_add && !in.has_x; ++r) in.has_x = aj->ports[r] > 0;
   if (in.j_eq_off) {
     upd_csr(e, ub, e->j_eq_off, e->j_eq_key, &e->j_eq_val, keep_p, incl_p, P, p_keep, aj ? aj->eq_off : nullptr, aj ? aj->eq_key : nullptr,
             aj ? aj->eq_val : nullptr, p_add);

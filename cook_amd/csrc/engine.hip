@@ -140,6 +140,8 @@ struct cook_engine {
   // ---- match state ----
   bool match_staged = false, match_done = false;
   unsigned K = 0, M = 0, G = 0, Kjobs = 0;
+  DArr<double> j_scal[3], o_scal[3], m_xscal;
+  DArr<int32_t> j_ports, o_ports, m_xports;
   DArr<double> j_cpus, j_mem, j_gpus, j_disk_req, o_cpus, o_mem, o_gpu_count, o_disk_space, o_run_cpus, o_run_mem, m_ac, m_am;
   DArr<uint32_t> j_gpu_model, j_group, j_eq_off, j_eq_key, j_eq_val, j_novel_off, j_novel_host, j_ckpt, j_disk_type, j_index,
       o_host, o_gpu_model, o_disk_type, o_attr, o_location, g_attr_key, g_run_off, g_run_host, g_run_attr, reserved_bits,
@@ -260,6 +262,12 @@ const T* h2d_opt(cook_engine* e, DArr<T>& d, const T* h, size_t n) {
 }
 
 void sync(cook_engine* e) { COOK_HIP(hipStreamSynchronize(e->stream)); }
+
+// entries per host of a k8s "gpus" / "disk" map column pair (cookmatch.h cook_offers.gpu_slots): 0 means 1
+unsigned res_slots(cook_engine* e, uint32_t slots, const char* what) {
+  if (slots > COOK_MAX_RES_SLOTS) e->fail(COOK_E_INVALID, std::string(what) + " > COOK_MAX_RES_SLOTS");
+  return slots ? slots : 1u;
+}
 
 // read back `words` 64-bit words from d_scratch64 (synchronises the stream)
 void readback64(cook_engine* e, unsigned words) {
@@ -690,11 +698,20 @@ void match_stage_offers(cook_engine* e, const cook_offers* o, bool offers_dev) {
   in.o_mem = (offers_dev ? o->mem : h2d_opt(e, e->o_mem, o->mem, M));
   in.o_host = (offers_dev ? o->host : h2d_opt(e, e->o_host, o->host, M));
   in.o_k8s = (offers_dev ? o->k8s : h2d_opt(e, e->o_k8s, o->k8s, M));
-  in.o_gpu_model = (offers_dev ? o->gpu_model : h2d_opt(e, e->o_gpu_model, o->gpu_model, M));
-  in.o_gpu_count = (offers_dev ? o->gpu_count : h2d_opt(e, e->o_gpu_count, o->gpu_count, M));
+  in.gpu_slots = res_slots(e, o->gpu_slots, "cook_match_stage: gpu_slots");
+  in.disk_slots = res_slots(e, o->disk_slots, "cook_match_stage: disk_slots");
+  in.o_gpu_model = (offers_dev ? o->gpu_model : h2d_opt(e, e->o_gpu_model, o->gpu_model, (size_t)M * in.gpu_slots));
+  in.o_gpu_count = (offers_dev ? o->gpu_count : h2d_opt(e, e->o_gpu_count, o->gpu_count, (size_t)M * in.gpu_slots));
   if (in.o_gpu_model && !in.o_gpu_count) e->fail(COOK_E_INVALID, "cook_match_stage: gpu_model without gpu_count");
-  in.o_disk_type = (offers_dev ? o->disk_type : h2d_opt(e, e->o_disk_type, o->disk_type, M));
-  in.o_disk_space = (offers_dev ? o->disk_space : h2d_opt(e, e->o_disk_space, o->disk_space, M));
+  in.o_disk_type = (offers_dev ? o->disk_type : h2d_opt(e, e->o_disk_type, o->disk_type, (size_t)M * in.disk_slots));
+  in.o_disk_space = (offers_dev ? o->disk_space : h2d_opt(e, e->o_disk_space, o->disk_space, (size_t)M * in.disk_slots));
+  // ports / named scalars of the leases (offer.clj:57-73); jobs' names beyond the offers' columns find a total of 0
+  if (o->scalars && o->n_scalars > COOK_MAX_SCALARS) e->fail(COOK_E_INVALID, "cook_match_stage: more than COOK_MAX_SCALARS named scalars");
+  in.o_ports = (offers_dev ? o->ports : h2d_opt(e, e->o_ports, o->ports, M));
+  for (unsigned sc = 0; sc < COOK_MAX_SCALARS; ++sc) {
+    const double* col = (o->scalars && sc < o->n_scalars) ? o->scalars + (size_t)sc * M : nullptr;
+    in.o_scal[sc] = (offers_dev ? col : h2d_opt(e, e->o_scal[sc], col, M));
+  }
   in.n_attr = o->attr ? o->n_attr_keys : 0;
   in.o_attr = (offers_dev ? o->attr : h2d_opt(e, e->o_attr, o->attr, (size_t)M * in.n_attr));
   in.o_max_tasks = (offers_dev ? o->max_tasks : h2d_opt(e, e->o_max_tasks, o->max_tasks, M));
@@ -760,7 +777,21 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
   in.j_disk_req = h2d_opt(e, e->j_disk_req, j->disk_request, K);
   in.j_disk_type = h2d_opt(e, e->j_disk_type, j->disk_type, K);
   if (in.j_disk_req && !in.j_disk_type) e->fail(COOK_E_INVALID, "cook_match_stage: disk_request without disk_type");
+  // ports / named scalar requests (scheduler.clj:466, 177-189): has_x = some job asks for any
+  if (j->scalars && j->n_scalars > COOK_MAX_SCALARS) e->fail(COOK_E_INVALID, "cook_match_stage: more than COOK_MAX_SCALARS named scalars");
+  unsigned has_x = 0;
+  in.j_ports = h2d_opt(e, e->j_ports, j->ports, K);
+  if (j->ports)
+    for (unsigned k = 0; k < K && !has_x; ++k) has_x = j->ports[k] > 0;
+  const unsigned n_scal = j->scalars ? j->n_scalars : 0u;
+  for (unsigned sc = 0; sc < n_scal; ++sc) {
+    const double* col = j->scalars + (size_t)sc * K;
+    in.j_scal[sc] = h2d_opt(e, e->j_scal[sc], col, K);
+    for (unsigned k = 0; k < K && !has_x; ++k) has_x = col[k] == col[k];
+  }
   match_stage_offers(e, o, offers_dev);
+  in.n_scal = n_scal;
+  in.has_x = has_x;
   if (G) {
     in.g_type = h2d_opt(e, e->g_type, g->type, G);
     in.g_attr_key = h2d_opt(e, e->g_attr_key, g->attr_key, G);
@@ -796,6 +827,10 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
 static std::atomic<int> g_engines_on_device[64];
 
 void match_init_state(cook_engine* e, const MatchState& st, unsigned K, unsigned M, unsigned G) {
+  if (M && st.xports) {
+    COOK_HIP(hipMemsetAsync(st.xports, 0, (size_t)M * 4, e->stream));
+    COOK_HIP(hipMemsetAsync(st.xscal, 0, (size_t)M * 8 * COOK_MAX_SCALARS, e->stream));
+  }
   if (M) {
     COOK_HIP(hipMemsetAsync(st.ac, 0, (size_t)M * 8, e->stream));
     COOK_HIP(hipMemsetAsync(st.am, 0, (size_t)M * 8, e->stream));
@@ -833,6 +868,8 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
   st.summary = e->m_summary.ensure(4);
   st.alive = e->m_alive.ensure((M + 63u) / 64u + 1u);
   st.jmin = (const double*)e->m_jmin.ensure(2);
+  st.xports = in.has_x ? e->m_xports.ensure(M) : nullptr;
+  st.xscal = in.has_x ? e->m_xscal.ensure((size_t)M * COOK_MAX_SCALARS) : nullptr;
   match_init_state(e, st, K, M, G);
   st.cutoff = 0x7FFFFFFF;
   e->last_persistent = 0;
@@ -1424,6 +1461,8 @@ cook_offers built_offers_view(cook_engine* e, int with_task_limits) {
   o.gpu_count = b.o_gpu_count.ptr();
   o.disk_type = b.o_disk_type.ptr();
   o.disk_space = b.o_disk_space.ptr();
+  o.gpu_slots = b.gpu_slots;
+  o.disk_slots = b.disk_slots;
   o.n_attr_keys = b.n_attr;
   o.attr = b.n_attr ? b.o_attr.ptr() : nullptr;
   if (with_task_limits) {
@@ -1464,6 +1503,13 @@ int cook_match_run(cook_engine* e) {
 }
 int cook_match_fetch(cook_engine* e, int32_t* job_to_offer, uint32_t* fail_code, uint8_t* head_matched) {
   return guarded(e, [&] { match_fetch(e, e->cycle_considered, job_to_offer, fail_code, head_matched); });
+}
+int cook_match_count(cook_engine* e, uint32_t* n_jobs) {
+  return guarded(e, [&] {
+    if (!n_jobs) e->fail(COOK_E_INVALID, "cook_match_count: null n_jobs");
+    if (!e->match_done) e->fail(COOK_E_STATE, "cook_match_count before a match has run");
+    *n_jobs = e->cycle_considered;
+  });
 }
 int cook_match(cook_engine* e, const cook_jobs* j, const cook_offers* o, const cook_groups* g, const uint32_t* reserved_hosts,
                uint32_t n_reserved, int32_t* job_to_offer, uint32_t* fail_code, uint8_t* head_matched) {

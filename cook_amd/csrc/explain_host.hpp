@@ -131,7 +131,7 @@ void match_metrics(cook_engine* e, ExplainBufs& x, cook_cycle_metrics* out, uint
     KL("metrics_keys", metrics_keys, div_up(M, 256), 256, in.o_cpus, in.o_mem, M, x.kc.ptr(), x.km.ptr());
     resource_stats(e, x, in.o_cpus, in.o_mem, x.kc.ptr(), x.km.ptr(), M, x.out.ptr() + 8, x.largest.ptr() + 2);
     KL("metrics_offer_counts", metrics_offer_counts, div_up(M, 256), 256, (const int32_t*)st.acount, M, d_sched, in.o_gpu_model,
-       in.o_gpu_count, n_models, offer_gpus_by_model ? x.ogpus.ptr() : (unsigned long long*)nullptr);
+       in.o_gpu_count, in.gpu_slots ? in.gpu_slots : 1u, n_models, offer_gpus_by_model ? x.ogpus.ptr() : (unsigned long long*)nullptr);
   }
   double h[16];
   uint32_t hl[4];

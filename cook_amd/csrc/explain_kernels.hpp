@@ -10,7 +10,7 @@
 
 // slots of a summary row (cookmatch.h COOK_WHY_*)
 constexpr int WHY_CPUS = 0, WHY_MEM = 1, WHY_FITNESS = 2, WHY_CKPT = 3, WHY_EST = 4, WHY_USER = 5, WHY_DISK = 6, WHY_GPU = 7,
-              WHY_NOVEL = 8, WHY_MAX_TASKS = 9, WHY_RESERVED = 10, WHY_GROUP_UNIQUE = 11, WHY_SLOTS = 16;
+              WHY_NOVEL = 8, WHY_MAX_TASKS = 9, WHY_RESERVED = 10, WHY_GROUP_UNIQUE = 11, WHY_SCALAR0 = 14, WHY_PORTS = 17, WHY_SLOTS = 20;
 
 // sort key of a job position = the offer it was placed on; unmatched jobs go behind every offer
 __global__ void __launch_bounds__(256) explain_offer_keys(const int32_t* __restrict__ j2o, unsigned K, unsigned M, uint64_t* __restrict__ key) {
@@ -109,19 +109,17 @@ static __device__ __forceinline__ int first_failed_constraint(const MatchIn& in,
       if (offer_attr_val(in, v, in.j_eq_key[x]) != in.j_eq_val[x]) return WHY_USER;
   }
   if (in.j_disk_req && in.j_disk_req[jj] >= 0 && k8s) {
-    const double space = (in.o_disk_type && in.o_disk_type[v] == in.j_disk_type[jj]) ? in.o_disk_space[v] : 0.0;
+    const double space = map_get_dev(in.o_disk_type, in.o_disk_space, in.disk_slots, v, in.j_disk_type[jj]);
     if (!(space >= in.j_disk_req[jj])) return WHY_DISK;
   }
   {
     const double jg = in.j_gpus ? in.j_gpus[jj] : 0.0;
     if (k8s) {
-      const unsigned om = in.o_gpu_model ? in.o_gpu_model[v] : 0u;
       if (jg > 0) {
-        const unsigned jm = in.j_gpu_model ? in.j_gpu_model[jj] : 0u;
-        const double avail = (om != 0 && om == jm) ? in.o_gpu_count[v] : 0.0;
+        const double avail = map_get_dev(in.o_gpu_model, in.o_gpu_count, in.gpu_slots, v, in.j_gpu_model ? in.j_gpu_model[jj] : 0u);
         const int on_vm = (in.o_run_count ? in.o_run_count[v] : 0) + acount_v;
         if (!(avail == jg && on_vm == 0)) return WHY_GPU;
-      } else if (om != 0) {
+      } else if (map_count_dev(in.o_gpu_model, in.gpu_slots, v) != 0u) {
         return WHY_GPU;
       }
     } else if (!(jg == 0)) {
@@ -155,8 +153,9 @@ __global__ void __launch_bounds__(256) explain_classify(MatchIn in, MatchState s
   if (v < in.M && k < in.K) {
     const unsigned jj = in.j_index ? in.j_index[k] : k;
     const double c = in.j_cpus[jj], m = in.j_mem[jj];
-    double ac = 0.0, am = 0.0;
+    double ac = 0.0, am = 0.0, as[3] = {0.0, 0.0, 0.0};
     int acount = 0;
+    long long aports = 0;
     for (unsigned i = ostart[v]; i < oend[v]; ++i) {
       const unsigned kk = plist[i];
       if (kk >= k) break;
@@ -164,11 +163,32 @@ __global__ void __launch_bounds__(256) explain_classify(MatchIn in, MatchState s
       ac += in.j_cpus[j2];  // the placement accumulated them in this very order
       am += in.j_mem[j2];
       ++acount;
+      if (in.has_x) {
+        aports += in.j_ports ? in.j_ports[j2] : 0;
+        _Pragma("unroll") for (unsigned s = 0; s < 3u; ++s) {
+          if (s >= in.n_scal) break;
+          const double r = in.j_scal[s][j2];
+          if (r == r) as[s] += r;
+        }
+      }
     }
     const bool fc = ac + c > in.o_cpus[v], fm = am + m > in.o_mem[v];
-    if (fc || fm) {
+    unsigned fx = 0;
+    if (in.has_x) {
+      const int jp = in.j_ports ? in.j_ports[jj] : 0;
+      if (jp > 0 && aports + jp > (long long)(in.o_ports ? in.o_ports[v] : 0)) fx |= 1u;
+      _Pragma("unroll") for (unsigned s = 0; s < 3u; ++s) {
+        if (s >= in.n_scal) break;
+        const double r = in.j_scal[s][jj];
+        if (r == r && as[s] + r > (in.o_scal[s] ? in.o_scal[s][v] : 0.0)) fx |= 2u << s;
+      }
+    }
+    if (fc || fm || fx) {
       if (fc) atomicAdd(&s_cnt[WHY_CPUS], 1u);
       if (fm) atomicAdd(&s_cnt[WHY_MEM], 1u);
+      if (fx & 1u) atomicAdd(&s_cnt[WHY_PORTS], 1u);
+      for (unsigned s = 0; s < 3u; ++s)
+        if ((fx >> (1u + s)) & 1u) atomicAdd(&s_cnt[WHY_SCALAR0 + s], 1u);
     } else {
       const int why = first_failed_constraint(in, st, jj, v, acount, (int)k);
       if (why >= 0) {
@@ -290,14 +310,17 @@ __global__ void __launch_bounds__(256) metrics_job_counts(MatchIn in, const int3
 // offers-scheduled = leases Fenzo used (scheduler.clj:1372-1374); "gpus/<model>" totals of offers->resource-maps (tools.clj:1032-1058)
 __global__ void __launch_bounds__(256) metrics_offer_counts(const int32_t* __restrict__ acount, unsigned M, unsigned* __restrict__ scheduled,
                                                             const uint32_t* __restrict__ o_gpu_model, const double* __restrict__ o_gpu_count,
-                                                            unsigned n_models, unsigned long long* __restrict__ offer_gpus_by_model) {
+                                                            unsigned gpu_slots, unsigned n_models,
+                                                            unsigned long long* __restrict__ offer_gpus_by_model) {
   const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
   const bool used = v < M && acount[v] > 0;
   const unsigned long long b = __ballot(used);
   if (lane_id() == 0 && b) atomicAdd(scheduled, (unsigned)__popcll(b));
   if (v < M && offer_gpus_by_model && o_gpu_model && o_gpu_count) {
-    const unsigned md = o_gpu_model[v];
-    // whole numbers (possibly negative on an over-committed node): summed exactly as two's-complement integers
-    if (md != 0 && md <= n_models) atomicAdd(&offer_gpus_by_model[md], (unsigned long long)(long long)o_gpu_count[v]);
+    for (unsigned q = 0; q < gpu_slots; ++q) {  // every entry of the host's map (tools.clj:1032-1058)
+      const unsigned md = o_gpu_model[(size_t)v * gpu_slots + q];
+      // whole numbers (possibly negative on an over-committed node): summed exactly as two's-complement integers
+      if (md != 0 && md <= n_models) atomicAdd(&offer_gpus_by_model[md], (unsigned long long)(long long)o_gpu_count[(size_t)v * gpu_slots + q]);
+    }
   }
 }

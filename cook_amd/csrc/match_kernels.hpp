@@ -53,6 +53,12 @@ struct MatchIn {
   // != 0: two offers of the call share a host (then a placement can forbid, for a unique host-placement group, an offer OTHER
   // than the one it was made on, and the placement walk sends every group member through its general path)
   unsigned host_dup;
+  // entries per host in the k8s "gpus" / "disk" maps (>= 1; o_gpu_model / o_gpu_count are [M][gpu_slots], model 0 = empty slot)
+  unsigned gpu_slots, disk_slots;
+  // Fenzo's other additive resources (cookmatch.h cook_jobs.ports / .scalars): has_x == 0 when no job of the call asks for any
+  unsigned has_x, n_scal;
+  const int32_t *j_ports, *o_ports;
+  const double *j_scal[3], *o_scal[3];  // one column per named scalar
 };
 
 struct MatchState {
@@ -68,7 +74,46 @@ struct MatchState {
   // assigned + min job > lease in cpus or mem (placements only add), so the eval loop never looks at the offer again.
   unsigned long long* alive;
   const double* jmin;    // [2] minimum cpus / mem over the jobs of this call
+  int32_t* xports;       // [M] ports assigned in this call       } only when MatchIn::has_x; written by the one thread that
+  double* xscal;         // [3][M] named scalars assigned in this call } commits a job, with agent-scope accesses
 };
+
+// Fenzo's resource fit beyond cpus / mem for (job jj, offer v) under the call's placements so far: ports (the request's port COUNT
+// against the free ports of the lease's ranges; scheduler.clj:466, offer.clj:71-73) and each named scalar request as
+// used + request > total against the lease's scalar of that name (scheduler.clj:177-189, offer.clj:57-65).
+// -> bit 0: ports do not fit, bit 1 + s: named scalar s does not fit. 
+static __device__ __forceinline__ unsigned xres_fail_bits(const MatchIn& in, const MatchState& st, unsigned jj, unsigned v) {
+  unsigned bits = 0;
+  const int jp = in.j_ports ? in.j_ports[jj] : 0;
+  if (jp > 0 && (long long)ld_agent(&st.xports[v]) + jp > (long long)(in.o_ports ? in.o_ports[v] : 0)) bits |= 1u;
+  _Pragma("unroll") for (unsigned s = 0; s < 3u; ++s) {
+    if (s >= in.n_scal) break;
+    const double r = in.j_scal[s][jj];
+    if (r != r) continue;  // no request under this name
+    const double t = in.o_scal[s] ? in.o_scal[s][v] : 0.0;
+    if (ld_agent(&st.xscal[(size_t)s * in.M + v]) + r > t) bits |= 2u << s;
+  }
+  return bits;
+}
+static __device__ __forceinline__ bool job_has_xres(const MatchIn& in, unsigned jj) {
+  bool x = in.j_ports && in.j_ports[jj] > 0;
+  _Pragma("unroll") for (unsigned s = 0; s < 3u; ++s) {
+    if (s >= in.n_scal) break;
+    const double r = in.j_scal[s][jj];
+    x = x || r == r;
+  }
+  return x;
+}
+// the one thread that commits job jj to offer v
+static __device__ __forceinline__ void xres_commit(const MatchIn& in, const MatchState& st, unsigned jj, unsigned v) {
+  const int jp = in.j_ports ? in.j_ports[jj] : 0;
+  if (jp > 0) st_agent(&st.xports[v], ld_agent(&st.xports[v]) + jp);
+  _Pragma("unroll") for (unsigned s = 0; s < 3u; ++s) {
+    if (s >= in.n_scal) break;
+    const double r = in.j_scal[s][jj];
+    if (r == r) st_agent(&st.xscal[(size_t)s * in.M + v], ld_agent(&st.xscal[(size_t)s * in.M + v]) + r);
+  }
+}
 
 static __device__ __forceinline__ uint32_t offer_attr_val(const MatchIn& in, unsigned v, uint32_t key) {
   if (key == 0xFFFFFFFFu) return in.o_host[v] + 1;  // "HOSTNAME"
@@ -90,19 +135,17 @@ static __device__ __forceinline__ bool static_pass(const MatchIn& in, unsigned j
   const double jg = in.j_gpus ? in.j_gpus[jj] : 0.0;
   const bool k8s = in.o_k8s && in.o_k8s[v];
   if (k8s) {  // gpu-host, constraints.clj:122-157 (model / count part)
-    const unsigned om = in.o_gpu_model ? in.o_gpu_model[v] : 0u;
     if (jg > 0) {
-      const unsigned jm = in.j_gpu_model ? in.j_gpu_model[jj] : 0u;
-      const double avail = (om != 0 && om == jm) ? in.o_gpu_count[v] : 0.0;
+      const double avail = map_get_dev(in.o_gpu_model, in.o_gpu_count, in.gpu_slots, v, in.j_gpu_model ? in.j_gpu_model[jj] : 0u);
       if (!(avail == jg)) return false;
-    } else if (om != 0) {
+    } else if (map_count_dev(in.o_gpu_model, in.gpu_slots, v) != 0u) {
       return false;
     }
   } else if (!(jg == 0)) {
     return false;
   }
   if (in.j_disk_req && in.j_disk_req[jj] >= 0 && k8s) {  // disk-host, constraints.clj:164-199
-    const double space = (in.o_disk_type && in.o_disk_type[v] == in.j_disk_type[jj]) ? in.o_disk_space[v] : 0.0;
+    const double space = map_get_dev(in.o_disk_type, in.o_disk_space, in.disk_slots, v, in.j_disk_type[jj]);
     if (!(space >= in.j_disk_req[jj])) return false;
   }
   if (in.j_eq_off) {  // user-defined EQUALS, constraints.clj:356-377
@@ -230,7 +273,7 @@ __global__ void __launch_bounds__(THREADS) match_serial(MatchIn in, MatchState s
     unsigned fail = 0;
     for (unsigned v = tid; v < in.M; v += THREADS) {
       const double ac = st.ac[v], am = st.am[v];
-      if (ac + c > in.o_cpus[v] || am + m > in.o_mem[v]) {
+      if (ac + c > in.o_cpus[v] || am + m > in.o_mem[v] || (in.has_x && xres_fail_bits(in, st, jj, v) != 0u)) {
         fail |= 1u;
         continue;
       }
@@ -295,6 +338,7 @@ __global__ void __launch_bounds__(THREADS) match_serial(MatchIn in, MatchState s
       st.ac[win] += c;
       st.am[win] += m;
       st.acount[win] += 1;
+      if (in.has_x) xres_commit(in, st, jj, (unsigned)win);
     }
     // next iteration's first LDS write happens after its own __syncthreads pair; s_win is re-read only after the next barrier
   }

@@ -94,7 +94,8 @@ struct OfferB {  // what the cheap constraint checks need; 32 B
   uint32_t host, gpu_model;
   double gpu_count;
   int32_t run_count, task_slack;  // task_slack = COOK_MAX_TASKS_PER_HOST - COOK_NUM_TASKS_ON_HOST (INT_MAX when absent)
-  uint32_t flags, pad;            // bit0 kubernetes VM, bit1 host is in the rebalancer's reserved set
+  uint32_t flags, pad;            // bit0 kubernetes VM, bit1 host is in the rebalancer's reserved set, bit2 the host's "gpus" map has
+                                  // several entries (gpu_model = one of them; the constraint reads the table)
 };
 struct JobRec {  // one considerable job in match order; 40 B
   double c, m, g;
@@ -104,7 +105,7 @@ struct JobRec {  // one considerable job in match order; 40 B
   uint32_t flags;  // bit0 has constraints that need the slow static check, bit1 member of a constrained group,
                    // bits 8..9 group type
 };
-constexpr uint32_t JF_SLOW = 1u, JF_GROUPED = 2u, JF_FASTC = 4u;
+constexpr uint32_t JF_SLOW = 1u, JF_GROUPED = 2u, JF_FASTC = 4u, JF_XRES = 8u;  // JF_XRES: asks for ports / named scalars
 // The common job constraints in a form the eval loop checks from registers + LDS only: up to MV_NC user-defined EQUALS
 // pairs on attribute keys < MV_NA (or HOSTNAME) and up to MV_NC novel-host entries.  Jobs with more, or with a disk /
 // estimated-completion / checkpoint constraint, carry JF_SLOW and go through static_pass (global-memory CSR walk).
@@ -212,13 +213,24 @@ __global__ void __launch_bounds__(256) match_pack_offers(MatchIn in, OfferA* __r
   oa[v] = a;
   OfferB b;
   b.host = in.o_host[v];
-  b.gpu_model = in.o_gpu_model ? in.o_gpu_model[v] : 0u;
-  b.gpu_count = (in.o_gpu_model && in.o_gpu_count) ? in.o_gpu_count[v] : 0.0;
+  b.gpu_model = 0u;  // the one entry of the host's "gpus" map (or, bit2, one of several)
+  b.gpu_count = 0.0;
+  unsigned n_keys = 0;
+  for (unsigned q = 0; in.o_gpu_model && q < in.gpu_slots; ++q) {
+    const unsigned md = in.o_gpu_model[(size_t)v * in.gpu_slots + q];
+    if (md != 0u) {
+      if (n_keys == 0) {
+        b.gpu_model = md;
+        b.gpu_count = in.o_gpu_count ? in.o_gpu_count[(size_t)v * in.gpu_slots + q] : 0.0;
+      }
+      ++n_keys;
+    }
+  }
   b.run_count = in.o_run_count ? in.o_run_count[v] : 0;
   b.task_slack = (in.o_max_tasks && in.o_max_tasks[v] >= 0) ? in.o_max_tasks[v] - (in.o_num_tasks ? in.o_num_tasks[v] : 0) : 0x7FFFFFFF;
   const bool k8s = in.o_k8s && in.o_k8s[v];
   const bool rsv = in.reserved_bits && (b.host >> 5) < in.reserved_words && ((in.reserved_bits[b.host >> 5] >> (b.host & 31)) & 1u);
-  b.flags = (k8s ? 1u : 0u) | (rsv ? 2u : 0u);
+  b.flags = (k8s ? 1u : 0u) | (rsv ? 2u : 0u) | (n_keys > 1u ? 4u : 0u);
   b.pad = 0;
   ob[v] = b;
 }
@@ -269,6 +281,7 @@ __global__ void __launch_bounds__(256) match_pack_jobs(MatchIn in, JobRec* __res
   if (in.j_disk_req && in.j_disk_req[jj] >= 0) f |= JF_SLOW;
   if (in.j_est_end && in.j_est_end[jj] != 0) f |= JF_SLOW;
   if (in.j_ckpt && in.j_ckpt[jj] != 0) f |= JF_SLOW;
+  if (in.has_x && job_has_xres(in, jj)) f |= JF_XRES;
   if (j.group != 0xFFFFFFFFu) {
     const unsigned t = in.g_type[j.group];
     if (t != 0) f |= JF_GROUPED | (t << 8);
@@ -314,11 +327,12 @@ __global__ void __launch_bounds__(256) match_init_alive(const OfferA* __restrict
 
 // ---- the cheap parts of the constraint check, from the packed records only ---------------------------------------------
 // gpu-host model/count (constraints.clj:122-157) + rebalancer reservation (constraints.clj:242-252)
-static __device__ __forceinline__ bool static_fast(const JobRec& j, const OfferB& o) {
+static __device__ __forceinline__ bool static_fast(const JobRec& j, const OfferB& o, const MatchIn& in, unsigned v) {
   bool ok;
   if (o.flags & 1u) {
     if (j.g > 0) {
-      const double avail = (o.gpu_model != 0 && o.gpu_model == j.gpu_model) ? o.gpu_count : 0.0;
+      double avail = (o.gpu_model != 0 && o.gpu_model == j.gpu_model) ? o.gpu_count : 0.0;
+      if (o.flags & 4u) avail = map_get_dev(in.o_gpu_model, in.o_gpu_count, in.gpu_slots, v, j.gpu_model);
       ok = avail == j.g;
     } else {
       ok = o.gpu_model == 0;
@@ -487,7 +501,10 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
     const unsigned v = v0 + vi;
     const OfferA a = W.oa[vi];
     const double ac = W.oac[vi], am = W.oam[vi];
-    const bool res = valid && !(ac + j.c > a.oc || am + j.m > a.om);
+    bool res = valid && !(ac + j.c > a.oc || am + j.m > a.om);
+    if (in.has_x) {  // ports / named scalars (rare): the jobs that ask for any read the offer's counters
+      if (res && (j.flags & JF_XRES)) res = xres_fail_bits(in, st, E.jj, v) == 0u;
+    }
     if (!__any(res)) {
       E.c1 += valid ? 1u : 0u;
       if (lane == 0) {
@@ -498,7 +515,7 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
     }
     const OfferB o = W.ob[vi];
     const int acount = W.oacount[vi];
-    bool stat = res && static_fast(j, o);
+    bool stat = res && static_fast(j, o, in, v);
     if (stat && E.fastc) {  // novel-host (constraints.clj:68-94) and user-defined EQUALS (:356-377) from registers + LDS
 #pragma unroll
       for (int q = 0; q < MV_NC; ++q) {
@@ -898,6 +915,7 @@ struct GEntL {  // good-enough list entry
   unsigned short slot, pad;
 };
 constexpr unsigned JL_GPU = 1u << 16, JL_GROUPED = 1u << 17, JL_HASGROUP = 1u << 20;  // (bits 18-19: group type)
+constexpr unsigned JL_XRES = 1u << 28;  // asks for ports / named scalars: general path only
 constexpr unsigned JL_GSLOT_SHIFT = 21, JL_GSLOT_NONE = 0x7Fu;  // bits 21-27: the job's row of ResolveLds::gfh, or none
 constexpr int MV_GMAX = 64;  // group members per round whose hosts-to-avoid are staged for the walk's fast path
 
@@ -942,6 +960,11 @@ struct ResolveLds {
   unsigned short hslot[MV_HASH];
   unsigned char slot_lane[MV_S];
   unsigned char fail[MV_WMAX];      // by walk position
+  // ports / named scalars assigned on a touched offer when the round began, by owner lane: saved by the first job of the round
+  // that moves them (the failure summary of an unmatched job compares against the round's snapshot)
+  double x0s[MV_T][3];
+  int x0p[MV_T];
+  unsigned char x0set[MV_T];
 };
 
 // One round of the window walk by ONE workgroup of MV_RTHREADS threads (all of them must call it).
@@ -1000,6 +1023,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   // ---- set-up phase (all threads): stage the window in LDS -------------------------------------------------------------
   for (unsigned x = tid; x < MV_HASH; x += NT) s_hkey[x] = -1;
   if (tid < MV_JGL) s_visit[tid] = 0ull;
+  if (tid < (unsigned)MV_T) L.x0set[tid] = 0;
   if (tid == 0) {
     s_nslots = 0;
     s_minbad = 0xFFFFFFFFu;
@@ -1058,12 +1082,12 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       r.m = j.m;
       const bool grouped = (j.flags & JF_GROUPED) != 0;
       r.info = (info & 0xFFFFu) | (j.g > 0 ? JL_GPU : 0u) | (grouped ? JL_GROUPED : 0u) | (((j.flags >> 8) & 3u) << 18) |
-               (j.group != 0xFFFFFFFFu ? JL_HASGROUP : 0u);
+               (j.group != 0xFFFFFFFFu ? JL_HASGROUP : 0u) | ((j.flags & JF_XRES) ? JL_XRES : 0u);
       // a member of a unique (type 1) or unconstrained (type 0) group: stage what the walk's fast path needs — the hosts to avoid
       // as the round begins and the group's last placed job (for the chain link) — so that it never has to go to HBM for them
       unsigned gslot = JL_GSLOT_NONE;
       const unsigned gt = (j.flags >> 8) & 3u;
-      if (j.group != 0xFFFFFFFFu && gt <= 1u && !use_ge && vb.in_dev->host_dup == 0u) {
+      if (j.group != 0xFFFFFFFFu && gt <= 1u && !use_ge && vb.in_dev->host_dup == 0u && !(j.flags & JF_XRES)) {
         const unsigned* row = vb.jfh + (size_t)b * (MV_FH + 2);  // gathered by the evaluation of this round
         const int nfh = (int)row[MV_FH];
         if (gt == 0u || (nfh >= 0 && nfh <= MV_FH)) {
@@ -1244,12 +1268,12 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         h = (h + 1) % MV_HASH;
       }
       const OfferA a = vb.oa[v];
-      if (ac + j.c > a.oc || am + j.m > a.om) {
+      if (ac + j.c > a.oc || am + j.m > a.om || ((j.flags & JF_XRES) && xres_fail_bits(in, st, jj, v) != 0u)) {
         ++c1;
         continue;
       }
       const OfferB o = vb.ob[v];
-      bool ok = static_fast(j, o) && dyn_fast(j, o, acount);
+      bool ok = static_fast(j, o, in, v) && dyn_fast(j, o, acount);
       if (ok && slow) ok = static_pass(in, jj, v);
       if (ok && grouped) ok = group_pass(in, st, jj, v);
       if (!ok) {
@@ -1554,7 +1578,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     };
     if (!use_ge) {
       bool fast_done = false;
-      if (!(cinfo_u & (JL_GROUPED | JL_HASGROUP)))
+      if (!(cinfo_u & (JL_GROUPED | JL_HASGROUP | JL_XRES)))
         fast_done = fast_path(std::false_type{});
       else if (gslot != JL_GSLOT_NONE && n_log < (unsigned)COOK_WAVE)
         fast_done = fast_path(std::true_type{});
@@ -1588,7 +1612,11 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         if (t_slot >= 0) gok = group_pass_dev(vb.in_dev, st, jj, (unsigned)t_v);
       }
       // every touched offer re-evaluated under the current state: verdict + approximate fitness
-      const bool res_ok = t_on && !(t_ac + c > t_oc || t_am + m > t_om);
+      bool res_ok = t_on && !(t_ac + c > t_oc || t_am + m > t_om);
+      if (cinfo_u & JL_XRES) {  // ports / named scalars: the counters of the call live in HBM (only such jobs move them)
+        jj = j_index ? j_index[k] : k;
+        if (res_ok) res_ok = xres_fail_bits(*vb.in_dev, st, jj, (unsigned)t_v) == 0u;
+      }
       bool con_ok = ((t_col >> bl) & 1ull) != 0 && t_acount < t_slack && gok;
       if (job_gpu && t_k8s && t_run + t_acount != 0) con_ok = false;
       const double nc_ = t_basec + c, nm_ = t_basem + m;  // (rc + ac) + c, (rm + am) + m
@@ -1920,6 +1948,19 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     if (win >= 0) {
       ++matched;
       if (k == 0) head_matched = 1;
+      if (cinfo_u & JL_XRES) {  // the offer's owner lane books the job's ports / named scalars
+        const int ol = win_lane >= 0 ? win_lane : (int)nT - 1;
+        if ((int)lane == ol) {
+          const MatchIn& in = *vb.in_dev;
+          if (!L.x0set[lane]) {
+            L.x0set[lane] = 1;
+            L.x0p[lane] = ld_agent(&st.xports[win]);
+            _Pragma("unroll") for (unsigned sc = 0; sc < 3u; ++sc)
+              if (sc < in.n_scal) L.x0s[lane][sc] = ld_agent(&st.xscal[(size_t)sc * in.M + (unsigned)win]);
+          }
+          xres_commit(in, st, jj, (unsigned)win);
+        }
+      }
       if (lane == 0) {
         s_j2o[i] = win;
         s_fail[i] = 0;
@@ -1966,7 +2007,21 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         unsigned p0 = 0u;  // snapshot verdict: state at round start, group placements of this round ignored via the cutoff
         if (t_on) {
           const SlotRec r = s_slot[t_slot];
-          if (r.ac + c > t_oc || r.am + m > t_om) {
+          bool x0_fail = false;
+          if (cinfo_u & JL_XRES) {  // ports / named scalars as the round began: saved if a job of this round moved them, else current
+            const MatchIn& in = *vb.in_dev;
+            const bool sv = L.x0set[lane] != 0;
+            const int jp = in.j_ports ? in.j_ports[jj] : 0;
+            const long long up = sv ? L.x0p[lane] : ld_agent(&st.xports[t_v]);
+            if (jp > 0 && up + jp > (long long)(in.o_ports ? in.o_ports[t_v] : 0)) x0_fail = true;
+            _Pragma("unroll") for (unsigned sc = 0; sc < 3u; ++sc) {
+              if (sc >= in.n_scal) break;
+              const double rq = in.j_scal[sc][jj];
+              const double us = sv ? L.x0s[lane][sc] : ld_agent(&st.xscal[(size_t)sc * in.M + (unsigned)t_v]);
+              if (rq == rq && us + rq > (in.o_scal[sc] ? in.o_scal[sc][t_v] : 0.0)) x0_fail = true;
+            }
+          }
+          if (r.ac + c > t_oc || r.am + m > t_om || x0_fail) {
             p0 = 1u;
           } else {
             bool ok = ((t_col >> bl) & 1ull) != 0 && r.acount < t_slack;

@@ -20,6 +20,8 @@ struct OfferBufs {
   DArr<uint32_t> permA, permB, seg_start, seg_end, block_offers;
   DArr<PodRec> podrec;
   DArr<double> a_cpus, a_mem, a_cons_cpus, a_cons_mem, a_gpu_count, a_disk_space, a_disk_cons;
+  DArr<uint32_t> a_gpu_model, a_disk_type;
+  unsigned gpu_slots = 1, disk_slots = 1;
   DArr<int32_t> a_num_pods;
   DArr<uint8_t> a_status;
   DArr<unsigned long long> gpu_cap, gpu_cons;
@@ -43,6 +45,8 @@ void offers_stage(cook_engine* e, OfferBufs& b, const cook_nodes* nodes, const c
   b.Nn = Nn;
   b.Np = Np;
   b.params = *params;
+  b.gpu_slots = res_slots(e, params->gpu_slots, "cook_offers_stage: gpu_slots");
+  b.disk_slots = res_slots(e, params->disk_slots, "cook_offers_stage: disk_slots");
   b.n_attr = nodes->attr ? nodes->n_attr_keys : 0u;
   h2d(e, b.n_cpus, nodes->cpus, Nn);
   h2d(e, b.n_mem, nodes->mem, Nn);
@@ -103,20 +107,30 @@ void offers_run(cook_engine* e, OfferBufs& b) {
     KL("offers_gather_pods", offers_gather_pods, gP, 256, b.pd, perm, podrec);
   }
   // ---- per node: capacity, consumption, available, schedulable --------------------------------------------------------------
-  NodeAvail av{b.a_cpus.ensure(Nn),       b.a_mem.ensure(Nn),       b.a_cons_cpus.ensure(Nn), b.a_cons_mem.ensure(Nn), b.a_gpu_count.ensure(Nn),
-               b.a_disk_space.ensure(Nn), b.a_disk_cons.ensure(Nn), b.a_num_pods.ensure(Nn), b.a_status.ensure(Nn)};
+  const unsigned GS = b.gpu_slots, DS = b.disk_slots;
+  NodeAvail av{b.a_cpus.ensure(Nn),
+               b.a_mem.ensure(Nn),
+               b.a_cons_cpus.ensure(Nn),
+               b.a_cons_mem.ensure(Nn),
+               b.a_gpu_model.ensure((size_t)Nn * GS),
+               b.a_gpu_count.ensure((size_t)Nn * GS),
+               b.a_disk_type.ensure((size_t)Nn * DS),
+               b.a_disk_space.ensure((size_t)Nn * DS),
+               b.a_disk_cons.ensure(Nn),
+               b.a_num_pods.ensure(Nn),
+               b.a_status.ensure(Nn)};
   b.block_offers.ensure(gN);
   KL("offers_node_eval", offers_node_eval, gN, 256, b.nd, (const PodRec*)podrec, (const uint32_t*)b.seg_start.ptr(),
      (const uint32_t*)b.seg_end.ptr(), b.params.clobber_synthetic_pods, b.params.filter_out_unsound_gpu_nodes, b.params.max_pods_per_node,
-     b.params.n_gpu_models, av, b.gpu_cap.ptr(), b.gpu_cons.ptr(), b.block_offers.ptr());
+     b.params.n_gpu_models, GS, DS, av, b.gpu_cap.ptr(), b.gpu_cons.ptr(), b.block_offers.ptr());
   // ---- gauges ------------------------------------------------------------------------------------------------------------------
   KL("offers_totals", offers_totals, 1, OT_THREADS, b.nd, av, b.params.n_disk_types, b.totals.ptr(), b.disk_cap.ptr(), b.disk_cons.ptr());
   // ---- offer rows of the schedulable nodes, node order ----------------------------------------------------------------------------
   unsigned* d_total = e->d_counters.ptr() + 13;
   OfferRows rows{b.o_node.ensure(Nn),      b.o_host.ensure(Nn),       b.o_cpus.ensure(Nn),     b.o_mem.ensure(Nn),
-                 b.o_gpu_model.ensure(Nn), b.o_gpu_count.ensure(Nn),  b.o_disk_type.ensure(Nn), b.o_disk_space.ensure(Nn),
+                 b.o_gpu_model.ensure((size_t)Nn * GS), b.o_gpu_count.ensure((size_t)Nn * GS),  b.o_disk_type.ensure((size_t)Nn * DS), b.o_disk_space.ensure((size_t)Nn * DS),
                  b.o_num_pods.ensure(Nn),  b.o_attr.ensure((size_t)Nn * std::max(1u, b.n_attr))};
-  KL("offers_emit", offers_emit, gN, 256, b.nd, b.d_host, av, (const uint32_t*)b.block_offers.ptr(), b.d_attr, b.n_attr, rows, d_total);
+  KL("offers_emit", offers_emit, gN, 256, b.nd, b.d_host, av, (const uint32_t*)b.block_offers.ptr(), b.d_attr, b.n_attr, GS, DS, rows, d_total);
   COOK_HIP(hipMemcpyAsync(e->h_scratch, d_total, 4, hipMemcpyDeviceToHost, e->stream));
   sync(e);
   std::memcpy(&b.n_offers, e->h_scratch, 4);
@@ -138,10 +152,10 @@ void offers_fetch(cook_engine* e, OfferBufs& b, cook_node_offers* o, uint32_t* n
     offers_d2h(e, o->host, (const uint32_t*)b.o_host.ptr(), R);
     offers_d2h(e, o->cpus, (const double*)b.o_cpus.ptr(), R);
     offers_d2h(e, o->mem, (const double*)b.o_mem.ptr(), R);
-    offers_d2h(e, o->gpu_model, (const uint32_t*)b.o_gpu_model.ptr(), R);
-    offers_d2h(e, o->gpu_count, (const double*)b.o_gpu_count.ptr(), R);
-    offers_d2h(e, o->disk_type, (const uint32_t*)b.o_disk_type.ptr(), R);
-    offers_d2h(e, o->disk_space, (const double*)b.o_disk_space.ptr(), R);
+    offers_d2h(e, o->gpu_model, (const uint32_t*)b.o_gpu_model.ptr(), (size_t)R * b.gpu_slots);
+    offers_d2h(e, o->gpu_count, (const double*)b.o_gpu_count.ptr(), (size_t)R * b.gpu_slots);
+    offers_d2h(e, o->disk_type, (const uint32_t*)b.o_disk_type.ptr(), (size_t)R * b.disk_slots);
+    offers_d2h(e, o->disk_space, (const double*)b.o_disk_space.ptr(), (size_t)R * b.disk_slots);
     offers_d2h(e, o->num_pods, (const int32_t*)b.o_num_pods.ptr(), R);
     if (b.n_attr) offers_d2h(e, o->attr, (const uint32_t*)b.o_attr.ptr(), (size_t)R * b.n_attr);
   }

@@ -59,7 +59,9 @@ struct NodeAvail {  // per node, before compaction
   double* mem;
   double* cons_cpus;  // node-name->consumed entries (0.0 when the node has none)
   double* cons_mem;
-  double* gpu_count;
+  uint32_t* gpu_model;  // [n][gpu_slots] (:gpus available) as a small table: the node's own model first, then the models only its
+  double* gpu_count;    //   pods name, in the order the pods list them (model 0 = empty slot)
+  uint32_t* disk_type;  // [n][disk_slots] (:disk available), likewise
   double* disk_space;
   double* disk_cons;  // consumption under the node's own disk type
   int32_t* num_pods;
@@ -119,10 +121,11 @@ static __host__ __device__ __forceinline__ double clj_max0(double x) { return 0.
 // flight at once) and every lane folds the part of its own segment that lies in the chunk — no lane chases global memory.
 constexpr int ON_CHUNK = 1024;  // pod records per LDS chunk (40 KB)
 constexpr int ON_MODELS = 64;   // gpu models totalled in LDS (more than that: global atomics)
+constexpr int ON_SLOTS = 4;     // COOK_MAX_RES_SLOTS: entries of a host's "gpus" / "disk" map
 __global__ void __launch_bounds__(256) offers_node_eval(NodeCols nd, const PodRec* __restrict__ pods,
                                                         const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ seg_end,
                                                         int clobber_synthetic, int filter_unsound_gpu, int max_pods, unsigned n_gpu_models,
-                                                        NodeAvail out, unsigned long long* __restrict__ gpu_cap_by_model,
+                                                        unsigned gpu_slots, unsigned disk_slots, NodeAvail out, unsigned long long* __restrict__ gpu_cap_by_model,
                                                         unsigned long long* __restrict__ gpu_cons_by_model,
                                                         uint32_t* __restrict__ block_offers) {
   __shared__ PodRec s_pod[ON_CHUNK];
@@ -156,6 +159,15 @@ __global__ void __launch_bounds__(256) offers_node_eval(NodeCols nd, const PodRe
   bool any = false, any_d = false, foreign_g = false, foreign_d = false;
   double cc = 0.0, cm = 0.0, own_d = 0.0;
   long long own_g = 0;
+  // what the pods consume under a model / type the node's capacity does not list: deep-merge-with finds the key in ONE map only and
+  // keeps the value as it is (util.clj:208-225), so (:gpus available) gains an entry {model consumed-count}.  Up to ON_SLOTS of
+  // them, in first-appearance order; more than the caller's table holds sets COOK_NODE_ST_FOREIGN_*.
+  unsigned fg_model[ON_SLOTS], fd_type[ON_SLOTS], n_fg = 0, n_fd = 0;
+  long long fg_cnt[ON_SLOTS];
+  double fd_val[ON_SLOTS];
+#pragma unroll
+  for (int q = 0; q < ON_SLOTS; ++q) fg_model[q] = fd_type[q] = 0u, fg_cnt[q] = 0, fd_val[q] = 0.0;
+  const unsigned fg_room = live ? gpu_slots - (cap_has_gpu ? 1u : 0u) : 0u, fd_room = live ? disk_slots - (cap_has_disk ? 1u : 0u) : 0u;
   __syncthreads();
   const unsigned lo = s_lo, hi = s_hi;  // block-uniform; lo > hi when the block's nodes have no pods
   for (unsigned c0 = lo; c0 < hi; c0 += ON_CHUNK) {
@@ -180,8 +192,24 @@ __global__ void __launch_bounds__(256) offers_node_eval(NodeCols nd, const PodRe
       const int pg = pr.gpus;
       const unsigned pgm = pr.gpu_model;
       if (pgm != 0u && pg > 0) {
-        if (cap_has_gpu && pgm == node_gm) own_g += pg;
-        else foreign_g = true;
+        if (cap_has_gpu && pgm == node_gm) {
+          own_g += pg;
+        } else {
+          bool found = false;
+#pragma unroll
+          for (int q = 0; q < ON_SLOTS; ++q)
+            if ((unsigned)q < n_fg && fg_model[q] == pgm) fg_cnt[q] += pg, found = true;
+          if (!found) {
+            if (n_fg < fg_room) {
+#pragma unroll
+              for (int q = 0; q < ON_SLOTS; ++q)
+                if ((unsigned)q == n_fg) fg_model[q] = pgm, fg_cnt[q] = pg;
+              ++n_fg;
+            } else {
+              foreign_g = true;
+            }
+          }
+        }
         if (gpu_cons_by_model && pgm <= n_gpu_models) atomicAdd(lds_models ? &s_gcons[pgm] : &gpu_cons_by_model[pgm], (unsigned long long)pg);
       }
       const double pdk = pr.disk;
@@ -191,7 +219,20 @@ __global__ void __launch_bounds__(256) offers_node_eval(NodeCols nd, const PodRe
           own_d = any_d ? own_d + pdk : pdk;
           any_d = true;
         } else {
-          foreign_d = true;
+          bool found = false;
+#pragma unroll
+          for (int q = 0; q < ON_SLOTS; ++q)
+            if ((unsigned)q < n_fd && fd_type[q] == pdt) fd_val[q] = fd_val[q] + pdk, found = true;  // merge-with +: first kept, then added
+          if (!found) {
+            if (n_fd < fd_room) {
+#pragma unroll
+              for (int q = 0; q < ON_SLOTS; ++q)
+                if ((unsigned)q == n_fd) fd_type[q] = pdt, fd_val[q] = pdk;
+              ++n_fd;
+            } else {
+              foreign_d = true;
+            }
+          }
         }
       }
     }
@@ -204,8 +245,28 @@ __global__ void __launch_bounds__(256) offers_node_eval(NodeCols nd, const PodRe
     out.mem[v] = any ? cap_m - cm : cap_m;
     out.cons_cpus[v] = any ? cc : 0.0;
     out.cons_mem[v] = any ? cm : 0.0;
-    out.gpu_count[v] = cap_has_gpu ? (double)((long long)node_g - own_g) : 0.0;
-    out.disk_space[v] = cap_has_disk ? (any_d ? node_d - own_d : node_d) : 0.0;
+    {
+      unsigned w = 0;
+      if (cap_has_gpu) {
+        out.gpu_model[(size_t)v * gpu_slots] = node_gm;
+        out.gpu_count[(size_t)v * gpu_slots] = (double)((long long)node_g - own_g);
+        w = 1;
+      }
+#pragma unroll
+      for (int q = 0; q < ON_SLOTS; ++q)
+        if ((unsigned)q < n_fg) out.gpu_model[(size_t)v * gpu_slots + w] = fg_model[q], out.gpu_count[(size_t)v * gpu_slots + w] = (double)fg_cnt[q], ++w;
+      for (; w < gpu_slots; ++w) out.gpu_model[(size_t)v * gpu_slots + w] = 0u, out.gpu_count[(size_t)v * gpu_slots + w] = 0.0;
+      w = 0;
+      if (cap_has_disk) {
+        out.disk_type[(size_t)v * disk_slots] = node_dt;
+        out.disk_space[(size_t)v * disk_slots] = any_d ? node_d - own_d : node_d;
+        w = 1;
+      }
+#pragma unroll
+      for (int q = 0; q < ON_SLOTS; ++q)
+        if ((unsigned)q < n_fd) out.disk_type[(size_t)v * disk_slots + w] = fd_type[q], out.disk_space[(size_t)v * disk_slots + w] = fd_val[q], ++w;
+      for (; w < disk_slots; ++w) out.disk_type[(size_t)v * disk_slots + w] = 0u, out.disk_space[(size_t)v * disk_slots + w] = 0.0;
+    }
     out.disk_cons[v] = (cap_has_disk && any_d) ? own_d : 0.0;
     if (cap_has_gpu && gpu_cap_by_model && node_gm <= n_gpu_models)
       atomicAdd(lds_models ? &s_gcap[node_gm] : &gpu_cap_by_model[node_gm], (unsigned long long)node_g);
@@ -244,7 +305,8 @@ struct OfferRows {  // compacted offer rows (device)
 // scan launch: a block sums the offer counts of the blocks before it (a few hundred words), ranks its own nodes by ballots.
 __global__ void __launch_bounds__(256) offers_emit(NodeCols nd, const uint32_t* __restrict__ node_host, NodeAvail av,
                                                    const uint32_t* __restrict__ block_offers, const uint32_t* __restrict__ node_attr,
-                                                   unsigned n_attr, OfferRows o, unsigned* __restrict__ total) {
+                                                   unsigned n_attr, unsigned gpu_slots, unsigned disk_slots, OfferRows o,
+                                                   unsigned* __restrict__ total) {
   __shared__ unsigned s_base, s_wave[4];
   if (threadIdx.x == 0) s_base = 0;
   __syncthreads();
@@ -266,16 +328,14 @@ __global__ void __launch_bounds__(256) offers_emit(NodeCols nd, const uint32_t* 
   o.host[r] = node_host ? node_host[v] : v;
   o.cpus[r] = clj_max0(av.cpus[v]);
   o.mem[r] = clj_max0(av.mem[v]);
-  const int node_g = nd.gpus ? nd.gpus[v] : 0;
-  const unsigned node_gm = nd.gpu_model ? nd.gpu_model[v] : 0u;
-  const bool cap_has_gpu = node_gm != 0u && node_g > 0;
-  o.gpu_model[r] = cap_has_gpu ? node_gm : 0u;
-  o.gpu_count[r] = av.gpu_count[v];
-  const double node_d = nd.disk ? nd.disk[v] : -1.0;
-  const unsigned node_dt = nd.disk_type ? nd.disk_type[v] : 0u;
-  const bool cap_has_disk = node_d >= 0.0 && node_dt != 0u;
-  o.disk_type[r] = cap_has_disk ? node_dt : 0u;
-  o.disk_space[r] = av.disk_space[v];
+  for (unsigned q = 0; q < gpu_slots; ++q) {
+    o.gpu_model[(size_t)r * gpu_slots + q] = av.gpu_model[(size_t)v * gpu_slots + q];
+    o.gpu_count[(size_t)r * gpu_slots + q] = av.gpu_count[(size_t)v * gpu_slots + q];
+  }
+  for (unsigned q = 0; q < disk_slots; ++q) {
+    o.disk_type[(size_t)r * disk_slots + q] = av.disk_type[(size_t)v * disk_slots + q];
+    o.disk_space[(size_t)r * disk_slots + q] = av.disk_space[(size_t)v * disk_slots + q];
+  }
   o.num_pods[r] = av.num_pods[v];
   for (unsigned q = 0; q < n_attr; ++q) o.attr[(size_t)r * n_attr + q] = node_attr[(size_t)v * n_attr + q];
 }

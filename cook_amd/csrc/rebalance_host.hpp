@@ -46,6 +46,7 @@ struct RebalBufs {
   DArr<double> j_cpus, j_mem, j_gpus, j_disk_req;
   DArr<uint32_t> j_gpu_model, j_user, j_group, j_eq_off, j_eq_key, j_eq_val, j_novel_off, j_novel_host, j_ckpt, j_disk_type;
   DArr<int64_t> j_est_end;
+  unsigned a_gpu_slots = 1, a_disk_slots = 1;
   bool hj_gpus = false, hj_gpu_model = false, hj_group = false, hj_eq = false, hj_novel = false, hj_ckpt = false, hj_disk = false,
        hj_est = false;
   // groups
@@ -160,12 +161,14 @@ void rebalance_stage(cook_engine* e, RebalBufs& b, const cook_tasks* run, const 
     if ((b.ha_k8s = attrs->k8s != nullptr)) h2d(e, b.a_k8s, attrs->k8s, n);
     if ((b.ha_gpu = attrs->gpu_model != nullptr)) {
       if (!attrs->gpu_count) e->fail(COOK_E_INVALID, "cook_rebalance: host_attrs gpu_model without gpu_count");
-      h2d(e, b.a_gpu_model, attrs->gpu_model, n);
-      h2d(e, b.a_gpu_count, attrs->gpu_count, n);
+      b.a_gpu_slots = res_slots(e, attrs->gpu_slots, "cook_rebalance: host_attrs gpu_slots");
+      h2d(e, b.a_gpu_model, attrs->gpu_model, (size_t)n * b.a_gpu_slots);
+      h2d(e, b.a_gpu_count, attrs->gpu_count, (size_t)n * b.a_gpu_slots);
     }
     if ((b.ha_disk = attrs->disk_type != nullptr && attrs->disk_space != nullptr)) {
-      h2d(e, b.a_disk_type, attrs->disk_type, n);
-      h2d(e, b.a_disk_space, attrs->disk_space, n);
+      b.a_disk_slots = res_slots(e, attrs->disk_slots, "cook_rebalance: host_attrs disk_slots");
+      h2d(e, b.a_disk_type, attrs->disk_type, (size_t)n * b.a_disk_slots);
+      h2d(e, b.a_disk_space, attrs->disk_space, (size_t)n * b.a_disk_slots);
     }
     if ((b.ha_attr = attrs->attr != nullptr && attrs->n_attr_keys > 0)) {
       b.n_attr = attrs->n_attr_keys;
@@ -254,6 +257,8 @@ RebalIn rebalance_args(cook_engine* e, RebalBufs& b) {
     in.a_gpu_count = b.ha_gpu ? b.a_gpu_count.ptr() : nullptr;
     in.a_disk_type = b.ha_disk ? b.a_disk_type.ptr() : nullptr;
     in.a_disk_space = b.ha_disk ? b.a_disk_space.ptr() : nullptr;
+    in.a_gpu_slots = b.a_gpu_slots;
+    in.a_disk_slots = b.a_disk_slots;
     in.a_attr = b.ha_attr ? b.a_attr.ptr() : nullptr;
     in.a_location = b.ha_loc ? b.a_location.ptr() : nullptr;
     in.a_host_start = b.ha_start ? b.a_host_start.ptr() : nullptr;

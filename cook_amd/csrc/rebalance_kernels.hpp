@@ -98,6 +98,7 @@ struct RebalIn {
   const double* a_gpu_count;
   const uint32_t* a_disk_type;
   const double* a_disk_space;
+  unsigned a_gpu_slots, a_disk_slots;  // entries per host in the k8s "gpus" / "disk" maps (>= 1)
   const uint32_t* a_attr;
   const uint32_t* a_location;
   const int64_t* a_host_start;
@@ -545,19 +546,17 @@ static __device__ __forceinline__ bool rebal_job_constraints(const RebalIn& in, 
       if (in.j_novel_host[x] == in.a_host[r]) return false;
   const bool k8s = r >= 0 && in.a_k8s && in.a_k8s[r];
   if (k8s) {  // gpu-host, constraints.clj:122-157
-    const unsigned om = in.a_gpu_model ? in.a_gpu_model[r] : 0u;
     if (jg > 0) {
-      const unsigned jm = in.j_gpu_model ? in.j_gpu_model[k] : 0u;
-      const double avail = (om != 0 && om == jm && in.a_gpu_count) ? in.a_gpu_count[r] : 0.0;
+      const double avail = map_get_dev(in.a_gpu_model, in.a_gpu_count, in.a_gpu_slots, (unsigned)r, in.j_gpu_model ? in.j_gpu_model[k] : 0u);
       if (!(avail == jg)) return false;
-    } else if (om != 0) {
+    } else if (map_count_dev(in.a_gpu_model, in.a_gpu_slots, (unsigned)r) != 0u) {
       return false;
     }
   } else if (!(jg == 0)) {
     return false;
   }
   if (in.j_disk_req && in.j_disk_req[k] >= 0 && k8s) {  // disk-host, constraints.clj:164-199
-    const double space = (in.a_disk_type && in.a_disk_space && in.a_disk_type[r] == in.j_disk_type[k]) ? in.a_disk_space[r] : 0.0;
+    const double space = map_get_dev(in.a_disk_type, in.a_disk_space, in.a_disk_slots, (unsigned)r, in.j_disk_type[k]);
     if (!(space >= in.j_disk_req[k])) return false;
   }
   if (in.j_eq_off)  // user-defined EQUALS: (= pattern (get nil attribute)) is false

@@ -13,23 +13,12 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _abi as A
+from ._protos import PROTOS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.environ.get("COOK_LIB") or os.path.join(_HERE, "libcookmatch.so")  # COOK_LIB: a tuning variant of the same library
 
-EXPORTS = [
-    "cook_engine_create", "cook_engine_destroy", "cook_engine_set_params", "cook_last_error", "cook_version",
-    "cook_rank", "cook_rank_stage", "cook_rank_set_quota", "cook_rank_pool_usage", "cook_rank_user_usage", "cook_rank_run", "cook_rank_fetch",
-    "cook_match", "cook_match_stage", "cook_match_run", "cook_match_fetch",
-    "cook_cycle_stage", "cook_cycle_update", "cook_cycle_run", "cook_cycle_fetch", "cook_cycle_run_rank", "cook_cycle_match_multi",
-    "cook_host_alloc", "cook_host_free",
-    "cook_considerable", "cook_cycle_set_considerable", "cook_cycle_fetch_considerable",
-    "cook_rebalance", "cook_rebalance_stage", "cook_rebalance_run", "cook_rebalance_fetch", "cook_rebalance_timing",
-    "cook_match_explain", "cook_match_metrics",
-    "cook_offers_build", "cook_offers_stage", "cook_offers_run", "cook_offers_fetch", "cook_offers_timing",
-    "cook_match_stage_built_offers", "cook_cycle_stage_built_offers",
-    "cook_last_timing", "cook_kernel_timings", "cook_set_profiling", "cook_match_stats",
-]
+EXPORTS = list(PROTOS)  # every function include/cookmatch.h declares (cook_amd/_protos.py is generated from the header)
 
 
 class CookError(RuntimeError):
@@ -60,16 +49,10 @@ def load_library(path: Optional[str] = None):
             f"{path} not found: build the HIP extension first (python -m cook_amd.build). "
             "cook_amd has no CPU fallback.")
     lib = C.CDLL(path)
-    for name in EXPORTS:
-        getattr(lib, name)  # AttributeError if the ABI is incomplete
-    lib.cook_last_error.restype = C.c_char_p
-    lib.cook_version.restype = C.c_char_p
-    lib.cook_engine_create.argtypes = [C.POINTER(A.CookParams), C.c_int, C.POINTER(C.c_void_p)]
-    lib.cook_engine_destroy.argtypes = [C.c_void_p]
-    lib.cook_last_error.argtypes = [C.c_void_p]
-    lib.cook_host_alloc.restype = C.c_void_p
-    lib.cook_host_alloc.argtypes = [C.c_size_t]
-    lib.cook_host_free.argtypes = [C.c_void_p]
+    for name, (restype, argtypes) in PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = restype
+        fn.argtypes = argtypes   # pointers are c_void_p: ctypes checks the argument COUNT and pointer-vs-scalar for every call
     _LIBS[path] = lib
     return lib
 
@@ -176,10 +159,17 @@ class Engine:
     def match_run(self):
         self._chk(self._lib.cook_match_run(self._h))
 
+    def match_count(self) -> int:
+        """jobs of the engine's last match = the length cook_match_fetch / cook_cycle_fetch write"""
+        n = C.c_uint32(0)
+        self._chk(self._lib.cook_match_count(self._h, C.byref(n)))
+        return n.value
+
     def match_fetch(self, k: Optional[int] = None):
-        k = self._match_k if k is None else k
-        j2o = np.full(max(1, k), -1, dtype=np.int32)
-        fail = np.zeros(max(1, k), dtype=np.uint32)
+        n = self.match_count()  # the engine's own count sizes the buffers (a cycle takes at most num_considerable jobs)
+        k = n if k is None else min(k, n)
+        j2o = np.full(max(1, n), -1, dtype=np.int32)
+        fail = np.zeros(max(1, n), dtype=np.uint32)
         head = C.c_uint8(0)
         self._chk(self._lib.cook_match_fetch(self._h, _p(j2o, C.c_int32), _p(fail, C.c_uint32), C.byref(head)))
         return j2o[:k].copy(), fail[:k].copy(), bool(head.value)
@@ -350,13 +340,16 @@ class Engine:
     def offers_fetch(self) -> A.BuiltOffers:
         n, na, op = self._of_n, self._of_attr, self._of_params
         cap = max(1, n)
+        gs, ds = max(1, int(op.gpu_slots)), max(1, int(op.disk_slots))
+        tab = lambda k, dt: np.zeros(cap, dt) if k == 1 else np.zeros((cap, k), dt)  # noqa: E731
         cols = dict(node=np.zeros(cap, np.uint32), host=np.zeros(cap, np.uint32), cpus=np.zeros(cap), mem=np.zeros(cap),
-                    gpu_model=np.zeros(cap, np.uint32), gpu_count=np.zeros(cap), disk_type=np.zeros(cap, np.uint32),
-                    disk_space=np.zeros(cap), num_pods=np.zeros(cap, np.int32))
+                    gpu_model=tab(gs, np.uint32), gpu_count=tab(gs, np.float64), disk_type=tab(ds, np.uint32),
+                    disk_space=tab(ds, np.float64), num_pods=np.zeros(cap, np.int32))
         attr = np.zeros((cap, na), np.uint32) if na else None
         o = A.CookNodeOffers(_p(cols["node"], C.c_uint32), _p(cols["host"], C.c_uint32), _p(cols["cpus"], C.c_double),
-                             _p(cols["mem"], C.c_double), _p(cols["gpu_model"], C.c_uint32), _p(cols["gpu_count"], C.c_double),
-                             _p(cols["disk_type"], C.c_uint32), _p(cols["disk_space"], C.c_double), _p(cols["num_pods"], C.c_int32),
+                             _p(cols["mem"], C.c_double), _p(cols["gpu_model"].reshape(-1), C.c_uint32),
+                             _p(cols["gpu_count"].reshape(-1), C.c_double), _p(cols["disk_type"].reshape(-1), C.c_uint32),
+                             _p(cols["disk_space"].reshape(-1), C.c_double), _p(cols["num_pods"], C.c_int32),
                              _p(attr.reshape(-1), C.c_uint32) if na else None)
         status = np.zeros(cap, np.uint8)
         tot = A.CookOfferTotals()

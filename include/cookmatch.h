@@ -153,7 +153,23 @@ typedef struct cook_jobs {
   const int64_t* est_end_ms;     /* estimated end time, 0 = no constraint (constraints.clj:385-431)     */
   const double* disk_request;    /* MiB, <0 = constraint not in effect (constraints.clj:164-199)        */
   const uint32_t* disk_type;
+  /* Fenzo's remaining additive resource dimensions (TaskRequestAdapter getPorts / getScalarRequests, scheduler.clj:456-471) */
+  const int32_t* ports;          /* (:ports resources) = :job/ports, the NUMBER of ports asked for (tools.clj:271); may be
+                                    NULL (all 0)                                                        */
+  uint32_t n_scalars;            /* named scalar requests (job->scalar-request, scheduler.clj:177-189): column s is the
+                                    request under name s of the caller's name table (<= COOK_MAX_SCALARS names)        */
+  uint32_t reserved_;
+  const double* scalars;         /* n_scalars columns of n doubles (column s at scalars + s * n); NaN = the job has no
+                                    request under that name; may be NULL                                               */
 } cook_jobs;
+/* Which named scalars a binding has to pass: job->scalar-request yields every :job/resource that carries :resource/amount
+ * except gpus, i.e. "cpus" and "mem" (the disk resource stores :resource.disk/request, not an amount: api.clj:818-830), and
+ * whatever legacy or custom resource types a deployment's database holds ("disk" among them).  Fenzo tests each as
+ * used + request > total against the lease's getScalarValues (offer.clj:57-65) and sums the placed requests by name.  For "cpus"
+ * and "mem" that is the SAME comparison on the SAME operands as the cpus / mem test when the TaskRequest's cpus / mem are the
+ * job's own (no job-resource-adjustments for the pool, scheduler.clj:473-479): such columns are redundant and need not be
+ * passed.  With an adjuster, pass the un-adjusted amounts as scalars 0 / 1 and the adjusted ones as cpus / mem. */
+#define COOK_MAX_SCALARS 3
 
 /* ---- offers, one per host (offer.clj:31-76), plus Fenzo's view of tasks already on that host ------------ */
 typedef struct cook_offers {
@@ -175,7 +191,19 @@ typedef struct cook_offers {
   const double* run_cpus;    /* sum over tasks Fenzo tracks as running on the host (getTaskAssigner,    */
   const double* run_mem;     /*   scheduler.clj:877-881); NULL = 0                                      */
   const int32_t* run_count;
+  /* more than one entry in the k8s "gpus" / "disk" maps of a host (constraints.clj:122-157 reads (get model->count model 0)
+     and (count model->count); :164-199 likewise for disk): gpu_model / gpu_count are then [n][gpu_slots] row-major, model 0 =
+     empty slot, models distinct within a row; 0 means 1 (the plain per-host columns).  At most COOK_MAX_RES_SLOTS. */
+  uint32_t gpu_slots;
+  uint32_t disk_slots;       /* likewise disk_type / disk_space as [n][disk_slots]                      */
+  const int32_t* ports;      /* number of ports in the lease's "ports" ranges (portRanges, offer.clj:71-73: sum of
+                                end - begin + 1); may be NULL (no ports: a job asking for any never fits) */
+  uint32_t n_scalars;        /* lease getScalarValues (offer.clj:57-65) under the names of cook_jobs.scalars */
+  uint32_t reserved_;
+  const double* scalars;     /* n_scalars columns of n doubles: the totals, 0.0 = the lease has no scalar of that name;
+                                may be NULL (all 0)                                                      */
 } cook_offers;
+#define COOK_MAX_RES_SLOTS 4
 
 /* ---- job groups with host-placement constraints (constraints.clj:519-678) ------------------------------- */
 typedef struct cook_groups {
@@ -367,7 +395,12 @@ int cook_rebalance_timing(cook_engine* e, double* ms);
 #define COOK_WHY_GROUP_UNIQUE 11       /* "unique_host_placement_group_constraint" (:586)          */
 #define COOK_WHY_GROUP_BALANCED 12     /* "balanced_host_placement_group_constraint" (:600)        */
 #define COOK_WHY_GROUP_ATTR_EQUALS 13  /* "attribute_equals_host_placement_group_constraint" (:628) */
-#define COOK_WHY_SLOTS 16
+#define COOK_WHY_SCALAR0 14            /* :resources <name of scalar 0>; 15, 16: scalars 1, 2 (the failure's message is the name,
+                                          fenzo_utils.clj:21-45).  COOK_WHY_CPUS / _MEM are the cpus / mem tests, which are
+                                          the named "cpus" / "mem" tests unless a pool adjuster makes them differ */
+#define COOK_WHY_PORTS 17              /* ports did not fit.  Fenzo's PORTS failure carries no message, so the reference's
+                                          summary has no entry for it (count-resource-failure skips it); kept for operators */
+#define COOK_WHY_SLOTS 20
 int cook_match_explain(cook_engine* e, const uint32_t* job_pos, uint32_t n, uint32_t* counts);
 
 /* ---- METRICS: the numbers of handle-match-cycle-metrics (scheduler.clj:1210-1280) from the last match, on the device -----
@@ -440,23 +473,30 @@ typedef struct cook_offer_params {
   int32_t max_pods_per_node;            /* (cc/max-tasks-per-host compute-cluster) (compute_cluster.clj:49)         */
   uint32_t n_gpu_models;                /* model ids are 1..n_gpu_models (sizes the per-model totals)               */
   uint32_t n_disk_types;                /* disk type ids are 1..n_disk_types                                        */
-  int32_t reserved;
+  uint32_t gpu_slots;                   /* entries per row of cook_node_offers.gpu_model / gpu_count (0 = 1, at most
+                                           COOK_MAX_RES_SLOTS): see cook_node_offers                                 */
+  uint32_t disk_slots;                  /* likewise disk_type / disk_space                                           */
 } cook_offer_params;
 
 #define COOK_NODE_ST_OFFER 1u         /* the node is schedulable: an offer row was emitted                           */
 #define COOK_NODE_ST_CONSUMED 2u      /* the node has an entry in node-name->consumed                                */
-#define COOK_NODE_ST_FOREIGN_GPU 4u   /* pods consume gpus of a model the node's capacity does not list: the reference's
-                                         deep-merge-with adds a second key to the offer's "gpus" map; cook_offers holds
-                                         one model per host, so the host must rebuild this (corrupt) node's offer itself */
+#define COOK_NODE_ST_FOREIGN_GPU 4u   /* pods consume gpus under more models than the row's gpu_slots hold (see below): the
+                                         row lists the first ones; ask again with more slots (COOK_MAX_RES_SLOTS covers
+                                         three models beyond the node's own)                                         */
 #define COOK_NODE_ST_FOREIGN_DISK 8u  /* likewise for disk types                                                     */
+/* (:gpus available) / (:disk available) of a node are MAPS (compute_cluster.clj:91, 180-181): the node's own model -> capacity
+ * minus what its pods consume under that model, plus one entry per model only the pods name -- deep-merge-with finds such a
+ * key in the consumption map alone and keeps its value as it is (util.clj:208-225), i.e. {model consumed-count}.  A row holds
+ * them as gpu_slots (model, count) pairs: the node's own model first, then the others in the order the node's pod list names
+ * them, model 0 = empty slot.  The rows feed cook_offers.gpu_model / gpu_count / gpu_slots unchanged. */
 typedef struct cook_node_offers { /* caller-allocated columns, capacity nodes->n rows; any column may be NULL */
   uint32_t* node;      /* row -> index into cook_nodes (ascending)                                                  */
   uint32_t* host;      /* nodes->host of that node (:hostname / :slave-id, compute_cluster.clj:175-176)             */
   double* cpus;        /* (max 0.0 (:cpus available)) (:179)                                                        */
   double* mem;         /* (max 0.0 (:mem available)) (:178)                                                         */
-  uint32_t* gpu_model; /* the one key of (:gpus available), 0 = empty map (:181)                                    */
-  double* gpu_count;   /*   its value (capacity - consumption; may be negative, the reference does not clamp it)    */
-  uint32_t* disk_type; /* the one key of (:disk available), 0 = empty map (:180)                                    */
+  uint32_t* gpu_model; /* [rows][gpu_slots] keys of (:gpus available), 0 = empty slot (:181)                        */
+  double* gpu_count;   /*   their values (capacity - consumption; may be negative, the reference does not clamp it) */
+  uint32_t* disk_type; /* [rows][disk_slots] keys of (:disk available) (:180)                                       */
   double* disk_space;
   int32_t* num_pods;   /* pods on the node (api.clj:816, the pod-limit test; = COOK_NUM_TASKS_ON_HOST's count)      */
   uint32_t* attr;      /* [rows][nodes->n_attr_keys]: the nodes' label rows, gathered                               */
@@ -494,6 +534,10 @@ int cook_match_stage_built_offers(cook_engine* e, const cook_jobs* considerable,
 int cook_cycle_stage_built_offers(cook_engine* e, const cook_tasks* tasks, const cook_users* users, const cook_jobs* pending_jobs,
                                   const cook_groups* groups, const uint32_t* reserved_hosts, uint32_t n_reserved,
                                   int with_task_limits);
+
+/* Number of jobs of the engine's last match (cook_match_run: the staged jobs; cook_cycle_run / the lockstep calls: the
+ * considerable jobs actually taken, <= num_considerable): the length cook_match_fetch / cook_cycle_fetch write. */
+int cook_match_count(cook_engine* e, uint32_t* n_jobs);
 
 /* ---- measurement hooks (bench.py): HIP-event time of the last *_run, per stage, in milliseconds ----------- */
 int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms);

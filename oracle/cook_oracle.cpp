@@ -224,6 +224,8 @@ void rank_impl(const cook_params* p, const cook_tasks* t, const cook_users* u, c
 struct MatchState {
   std::vector<double> ac, am;              // resources assigned this call per offer
   std::vector<int32_t> acount;             // tasks assigned this call per offer
+  std::vector<int64_t> aports;             // ports assigned this call per offer
+  std::vector<double> ascalar;             // [M][COOK_MAX_SCALARS] named scalars assigned this call per offer
   std::vector<std::vector<uint32_t>> ghost, gattr;  // per group: hosts / attr values of same-cycle cotasks
 };
 
@@ -231,6 +233,47 @@ inline uint32_t offer_attr(const cook_offers* o, uint32_t v, uint32_t key) {
   if (key == COOK_NONE_U32) return o->host[v] + 1;  // "HOSTNAME"
   if (key >= o->n_attr_keys || !o->attr) return 0;
   return o->attr[(size_t)v * o->n_attr_keys + key];
+}
+
+// (get model->count model 0) and (count model->count) over a host's k8s "gpus" / "disk" map (constraints.clj:136-142, 178):
+// the map is the row's non-empty slots; a job without a model asks for key nil, which no map holds.
+inline double map_get(const uint32_t* keys, const double* vals, uint32_t slots, uint32_t v, uint32_t key) {
+  if (!keys || !vals || key == 0) return 0.0;
+  const uint32_t S = slots ? slots : 1;
+  for (uint32_t s2 = 0; s2 < S; ++s2)
+    if (keys[(size_t)v * S + s2] == key) return vals[(size_t)v * S + s2];
+  return 0.0;
+}
+inline uint32_t map_count(const uint32_t* keys, uint32_t slots, uint32_t v) {
+  if (!keys) return 0;
+  const uint32_t S = slots ? slots : 1;
+  uint32_t n = 0;
+  for (uint32_t s2 = 0; s2 < S; ++s2) n += keys[(size_t)v * S + s2] != 0 ? 1 : 0;
+  return n;
+}
+
+// ⚠ Fenzo AssignableVirtualMachine.tryRequest beyond cpus / mem: ports (PortRanges.hasPorts: the request's port COUNT against
+// the free ports of the lease's ranges; TaskRequestAdapter getPorts, scheduler.clj:466; lease portRanges, offer.clj:71-73) and
+// every named scalar request (getScalarRequests = job->scalar-request, scheduler.clj:177-189) as used + request > total against
+// the lease's getScalarValues (offer.clj:57-65).  Returns bit 0 = ports do not fit, bit 1 + s = named scalar s does not fit.
+inline uint32_t xres_fail_bits(const cook_jobs* j, uint32_t k, const cook_offers* o, uint32_t v, const MatchState& st) {
+  uint32_t bits = 0;
+  const int64_t jp = j->ports ? j->ports[k] : 0;
+  if (jp > 0 && st.aports[v] + jp > (int64_t)(o->ports ? o->ports[v] : 0)) bits |= 1u;
+  for (uint32_t s2 = 0; j->scalars && s2 < j->n_scalars && s2 < COOK_MAX_SCALARS; ++s2) {
+    const double r = j->scalars[(size_t)s2 * j->n + k];
+    if (r != r) continue;  // the job has no request under this name
+    const double t = (o->scalars && s2 < o->n_scalars) ? o->scalars[(size_t)s2 * o->n + v] : 0.0;
+    if (st.ascalar[(size_t)v * COOK_MAX_SCALARS + s2] + r > t) bits |= 2u << s2;
+  }
+  return bits;
+}
+inline void xres_commit(const cook_jobs* j, uint32_t k, uint32_t v, MatchState& st) {
+  st.aports[v] += j->ports ? j->ports[k] : 0;
+  for (uint32_t s2 = 0; j->scalars && s2 < j->n_scalars && s2 < COOK_MAX_SCALARS; ++s2) {
+    const double r = j->scalars[(size_t)s2 * j->n + k];
+    if (r == r) st.ascalar[(size_t)v * COOK_MAX_SCALARS + s2] += r;
+  }
 }
 
 // constraints.clj: job constraints in make-fenzo-job-constraints order do not matter for pass/fail.
@@ -245,13 +288,11 @@ bool job_constraints_pass(const cook_params* p, const cook_jobs* j, uint32_t k, 
   const double jg = j->gpus ? j->gpus[k] : 0.0;
   const bool k8s = o->k8s && o->k8s[v];
   if (k8s) {
-    const uint32_t om = o->gpu_model ? o->gpu_model[v] : 0;
     if (jg > 0) {
-      const uint32_t jm = j->gpu_model ? j->gpu_model[k] : 0;
-      const double avail = (om != 0 && om == jm) ? o->gpu_count[v] : 0.0;
+      const double avail = map_get(o->gpu_model, o->gpu_count, o->gpu_slots, v, j->gpu_model ? j->gpu_model[k] : 0);
       const int32_t on_vm = (o->run_count ? o->run_count[v] : 0) + st.acount[v];
       if (!(avail == jg && on_vm == 0)) return false;
-    } else if (om != 0) {
+    } else if (map_count(o->gpu_model, o->gpu_slots, v) != 0) {
       return false;
     }
   } else if (!(jg == 0)) {
@@ -259,7 +300,7 @@ bool job_constraints_pass(const cook_params* p, const cook_jobs* j, uint32_t k, 
   }
   // disk-host (constraints.clj:164-199): only when the pool enables it (disk_request >= 0)
   if (j->disk_request && j->disk_request[k] >= 0 && k8s) {
-    const double space = (o->disk_type && o->disk_type[v] == j->disk_type[k]) ? o->disk_space[v] : 0.0;
+    const double space = map_get(o->disk_type, o->disk_space, o->disk_slots, v, j->disk_type[k]);
     if (!(space >= j->disk_request[k])) return false;
   }
   // user-defined EQUALS (constraints.clj:356-377)
@@ -346,19 +387,17 @@ int first_failed_constraint(const cook_params* p, const cook_jobs* j, uint32_t k
     for (uint32_t x = j->eq_off[k]; x < j->eq_off[k + 1]; ++x)
       if (offer_attr(o, v, j->eq_key[x]) != j->eq_val[x]) return 5;
   if (j->disk_request && j->disk_request[k] >= 0 && k8s) {  // disk_host_constraint
-    const double space = (o->disk_type && o->disk_type[v] == j->disk_type[k]) ? o->disk_space[v] : 0.0;
+    const double space = map_get(o->disk_type, o->disk_space, o->disk_slots, v, j->disk_type[k]);
     if (!(space >= j->disk_request[k])) return 6;
   }
   {  // gpu_host_constraint
     const double jg = j->gpus ? j->gpus[k] : 0.0;
     if (k8s) {
-      const uint32_t om = o->gpu_model ? o->gpu_model[v] : 0;
       if (jg > 0) {
-        const uint32_t jm = j->gpu_model ? j->gpu_model[k] : 0;
-        const double avail = (om != 0 && om == jm) ? o->gpu_count[v] : 0.0;
+        const double avail = map_get(o->gpu_model, o->gpu_count, o->gpu_slots, v, j->gpu_model ? j->gpu_model[k] : 0);
         const int32_t on_vm = (o->run_count ? o->run_count[v] : 0) + st.acount[v];
         if (!(avail == jg && on_vm == 0)) return 7;
-      } else if (om != 0) {
+      } else if (map_count(o->gpu_model, o->gpu_slots, v) != 0) {
         return 7;
       }
     } else if (!(jg == 0)) {
@@ -385,8 +424,10 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
   std::map<uint32_t, std::vector<uint32_t>> explain_rows;  // job position -> rows of explain_counts
   for (uint32_t q = 0; q < n_explain; ++q) {
     explain_rows[explain_pos[q]].push_back(q);
-    for (int s2 = 0; s2 < 16; ++s2) explain_counts[(size_t)q * 16 + s2] = 0;
+    for (int s2 = 0; s2 < COOK_WHY_SLOTS; ++s2) explain_counts[(size_t)q * COOK_WHY_SLOTS + s2] = 0;
   }
+  st.aports.assign(M, 0);
+  st.ascalar.assign((size_t)M * COOK_MAX_SCALARS, 0.0);
   st.ac.assign(M, 0.0);
   st.am.assign(M, 0.0);
   st.acount.assign(M, 0);
@@ -410,7 +451,7 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
     for (uint32_t v = v0; v < v1; ++v) {
       // ⚠ Fenzo AssignableVirtualMachine.tryRequest: resources (cpus, mem, named scalars) vs the lease totals
       // minus what this call already assigned to the VM, then hard constraints, then fitness.
-      if (st.ac[v] + c > o->cpus[v] || st.am[v] + m > o->mem[v]) {
+      if (st.ac[v] + c > o->cpus[v] || st.am[v] + m > o->mem[v] || xres_fail_bits(j, k, o, v, st) != 0) {
         b.fail |= 1;
         continue;
       }
@@ -461,13 +502,16 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
     // resources that do not fit (message "cpus" / "mem", one count each) or else the first failing hard constraint's name
     auto ex = explain_rows.find(k);
     if (ex != explain_rows.end()) {
-      uint32_t cnt[16] = {0};
+      uint32_t cnt[COOK_WHY_SLOTS] = {0};
       const double c = j->cpus[k], m = j->mem[k];
       for (uint32_t v = 0; v < M; ++v) {
         const bool fc = st.ac[v] + c > o->cpus[v], fm = st.am[v] + m > o->mem[v];
-        if (fc || fm) {
-          cnt[0] += fc ? 1 : 0;
-          cnt[1] += fm ? 1 : 0;
+        const uint32_t fx = xres_fail_bits(j, k, o, v, st);
+        if (fc || fm || fx) {  // ⚠ every resource that does not fit adds its own AssignmentFailure
+          cnt[COOK_WHY_CPUS] += fc ? 1 : 0;
+          cnt[COOK_WHY_MEM] += fm ? 1 : 0;
+          cnt[COOK_WHY_PORTS] += (fx & 1u) ? 1 : 0;
+          for (int s2 = 0; s2 < COOK_MAX_SCALARS; ++s2) cnt[COOK_WHY_SCALAR0 + s2] += ((fx >> (1 + s2)) & 1u) ? 1 : 0;
           continue;
         }
         const int why = first_failed_constraint(p, j, k, o, v, g, st, reserved);
@@ -482,7 +526,7 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
         if (!(fit > 0.0)) cnt[2] += 1;
       }
       for (uint32_t q : ex->second)
-        for (int s2 = 0; s2 < 16; ++s2) explain_counts[(size_t)q * 16 + s2] = cnt[s2];
+        for (int s2 = 0; s2 < COOK_WHY_SLOTS; ++s2) explain_counts[(size_t)q * COOK_WHY_SLOTS + s2] = cnt[s2];
     }
     Best b;
     if (!mt) {
@@ -509,6 +553,7 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
       st.ac[b.v] += j->cpus[k];
       st.am[b.v] += j->mem[k];
       st.acount[b.v] += 1;
+      xres_commit(j, k, (uint32_t)b.v, st);
       if (g && j->group && j->group[k] != COOK_NONE_U32) {
         const uint32_t gi = j->group[k];
         st.ghost[gi].push_back(o->host[b.v]);
@@ -712,12 +757,10 @@ static bool rebal_job_constraints_pass(const cook_params* p, const cook_jobs* j,
   const double jg = j->gpus ? j->gpus[k] : 0.0;
   const bool k8s = r >= 0 && o->k8s && o->k8s[r];
   if (k8s) {
-    const uint32_t om = o->gpu_model ? o->gpu_model[r] : 0;
     if (jg > 0) {
-      const uint32_t jm = j->gpu_model ? j->gpu_model[k] : 0;
-      const double avail = (om != 0 && om == jm) ? o->gpu_count[r] : 0.0;
+      const double avail = map_get(o->gpu_model, o->gpu_count, o->gpu_slots, (uint32_t)r, j->gpu_model ? j->gpu_model[k] : 0);
       if (!(avail == jg)) return false;
-    } else if (om != 0) {
+    } else if (map_count(o->gpu_model, o->gpu_slots, (uint32_t)r) != 0) {
       return false;
     }
   } else if (!(jg == 0)) {
@@ -725,7 +768,7 @@ static bool rebal_job_constraints_pass(const cook_params* p, const cook_jobs* j,
   }
   // disk-host (constraints.clj:164-199)
   if (j->disk_request && j->disk_request[k] >= 0 && k8s) {
-    const double space = (o->disk_type && o->disk_type[r] == j->disk_type[k]) ? o->disk_space[r] : 0.0;
+    const double space = map_get(o->disk_type, o->disk_space, o->disk_slots, (uint32_t)r, j->disk_type[k]);
     if (!(space >= j->disk_request[k])) return false;
   }
   // user-defined EQUALS (constraints.clj:356-377): (= pattern (get nil attribute)) is false

@@ -213,30 +213,51 @@ def build_rows(nodes, pods, oparams):
                                                bool(oparams.filter_out_unsound_gpu_nodes))
     cap = get_capacity(n2n)
     idx = {name: i for i, name in enumerate(n2n)}
+    gs, ds = max(1, int(getattr(oparams, "gpu_slots", 1))), max(1, int(getattr(oparams, "disk_slots", 1)))
+
+    def table(av_map, own_keys, pods_of_node, pod_key, slots):
+        """the (:gpus / :disk available) map as the ABI's slot table: own key first, then the keys only the pods name, in the
+        order the node's pod list names them; -> (keys, values, overflow)"""
+        order = list(own_keys)
+        for pod in pods_of_node:
+            k = pod.get(pod_key)
+            if k is not None and k in av_map and k not in order:
+                order.append(k)
+        assert set(order) == set(av_map.keys()), (order, av_map)
+        keys = [int(k[1:]) for k in order[:slots]] + [0] * (slots - min(slots, len(order)))
+        vals = [float(av_map[k]) for k in order[:slots]] + [0.0] * (slots - min(slots, len(order)))
+        return keys, vals, len(order) > slots
+
+    available = deep_merge_with(lambda a, b: a - b, cap, consumed) if consumed else dict(cap)
     status = np.zeros(nodes.n, np.uint8)
-    for name, c in consumed.items():
+    tables = {}
+    for name in n2n:
         i = idx[name]
-        status[i] |= 2
-        own_g = set((cap[name].get("gpus") or {}).keys())
-        own_d = set((cap[name].get("disk") or {}).keys())
-        if set((c.get("gpus") or {}).keys()) - own_g:
+        av = available[name]
+        own_g = list((cap[name].get("gpus") or {}).keys())
+        own_d = list((cap[name].get("disk") or {}).keys())
+        gk, gv, g_over = table(av.get("gpus") or {}, own_g, n2p.get(name) or [], "gpu_model", gs)
+        dk, dv, d_over = table(av.get("disk") or {}, own_d, n2p.get(name) or [], "disk_type", ds)
+        tables[name] = (gk, gv, dk, dv)
+        if name in consumed:
+            status[i] |= 2
+        if g_over:
             status[i] |= 4
-        if set((c.get("disk") or {}).keys()) - own_d:
+        if d_over:
             status[i] |= 8
     rows = dict(node=[], host=[], cpus=[], mem=[], gpu_model=[], gpu_count=[], disk_type=[], disk_space=[], num_pods=[])
     for o in offers:
         i = idx[o["hostname"]]
         status[i] |= 1
+        gk, gv, dk, dv = tables[o["hostname"]]
         rows["node"].append(i)
         rows["host"].append(int(nodes.host[i]))
         rows["cpus"].append(o["cpus"])
         rows["mem"].append(o["mem"])
-        own_g = list((cap[o["hostname"]].get("gpus") or {}).keys())
-        own_d = list((cap[o["hostname"]].get("disk") or {}).keys())
-        rows["gpu_model"].append(int(own_g[0][1:]) if own_g else 0)
-        rows["gpu_count"].append(float(o["gpus"][own_g[0]]) if own_g else 0.0)
-        rows["disk_type"].append(int(own_d[0][1:]) if own_d else 0)
-        rows["disk_space"].append(float(o["disk"][own_d[0]]) if own_d else 0.0)
+        rows["gpu_model"].append(gk if gs > 1 else gk[0])
+        rows["gpu_count"].append(gv if gs > 1 else gv[0])
+        rows["disk_type"].append(dk if ds > 1 else dk[0])
+        rows["disk_space"].append(dv if ds > 1 else dv[0])
         rows["num_pods"].append(len(n2p.get(o["hostname"]) or []))
     ng, ndt = int(oparams.n_gpu_models), int(oparams.n_disk_types)
     gcap, gcons = np.zeros(ng + 1, np.int64), np.zeros(ng + 1, np.int64)

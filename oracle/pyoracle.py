@@ -135,12 +135,12 @@ def match(params, jobs: A.Jobs, offers: A.Offers, groups: A.Groups = None, reser
 
 
 def match_explain(params, jobs: A.Jobs, offers: A.Offers, groups: A.Groups = None, reserved_hosts=(), job_pos=()):
-    """-> (job_to_offer, counts uint32[n, 16]): the placement plus, per job position, the placement-failure summary of
+    """-> (job_to_offer, counts uint32[n, COOK_WHY_SLOTS]): the placement plus, per job position, the placement-failure summary of
     fenzo_utils.clj:33-55 in the COOK_WHY_* slots of include/cookmatch.h."""
     j2o = np.full(max(1, jobs.n), -1, dtype=np.int32)
     res = np.array(list(reserved_hosts) or [0], dtype=np.uint32)
     pos = np.ascontiguousarray(job_pos, dtype=np.uint32)
-    counts = np.zeros((max(1, len(pos)), 16), dtype=np.uint32)
+    counts = np.zeros((max(1, len(pos)), 20), dtype=np.uint32)
     js, os_ = jobs.as_struct(), offers.as_struct()
     gs = groups.as_struct() if groups is not None else None
     rc = lib().oracle_match_explain(C.byref(params), C.byref(js), C.byref(os_), C.byref(gs) if gs is not None else None,

@@ -465,3 +465,42 @@ def test_fuzz_groups_constraints_metrics_replay(make_engine):
         P.metrics_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, A.default_params(good_enough_fitness=1.0), n_users=30)
         trace, hosts = P.make_trace(seed, int(rng.integers(5, 60)), int(rng.integers(1, 5)), span_ms=int(rng.integers(60_000, 600_000)))
         P.replay_parity(make_engine, trace, hosts, TIGHT if rng.integers(0, 2) else CONFIG, min_matched=0)
+
+
+# ---- ports, named scalars, several entries per host in the k8s "gpus" / "disk" maps (scheduler.clj:456-471, 177-189) -----------
+def test_xres_known_answers(make_engine):
+    P.xres_known_answers(make_engine)
+
+
+@ALGOS
+@pytest.mark.parametrize("kw", [
+    dict(seed=71, n=500, m=60),
+    dict(seed=72, n=500, m=90, groups=True, constraints=True),
+    dict(seed=73, n=500, m=60, ports=False, scalars=3),
+    dict(seed=74, n=500, m=90, slots=3, scalars=0, ports=False),
+    dict(seed=75, n=500, m=90, slots=4, groups=True),
+], ids=["ports+scalars", "with-groups-and-constraints", "three-scalars", "gpu-and-disk-maps", "everything"])
+def test_match_ports_scalars_maps(make_engine, kw, algo):
+    kw = dict(kw)
+    jobs, offers, groups = P.xres_random_case(kw.pop("seed"), kw.pop("n"), kw.pop("m"), **kw)
+    j2o = P.match_parity(make_engine, jobs, offers, groups, A.default_params(match_algo=algo))
+    assert (j2o >= 0).sum() > 20 and (j2o < 0).sum() > 5
+
+
+@pytest.mark.parametrize("ge", [0.8, 0.4])
+def test_match_ports_scalars_good_enough_and_explain(make_engine, ge):
+    jobs, offers, groups = P.xres_random_case(76, 500, 60, groups=True, slots=2)
+    p = A.default_params(good_enough_fitness=ge)
+    P.match_parity(make_engine, jobs, offers, groups, p)
+    P.explain_parity(make_engine, jobs, offers, groups, p, tag="xres")
+    P.metrics_parity(make_engine, jobs, offers, groups, p, n_models=4, tag="xres")
+
+
+def test_offers_slot_tables(make_engine):
+    P.offers_slot_tables(make_engine)
+
+
+def test_rebalance_gpu_maps_with_several_models(make_engine):
+    got = P.rebalance_parity(make_engine, P.make_rebalance_case(seed=59, n_running=500, n_pending=60, n_users=15, n_hosts=40, constraints=True,
+                                                                gpus=True, gpu_slots=2))
+    assert len(got["decisions"]) > 0
