@@ -215,14 +215,21 @@ def build_rows(nodes, pods, oparams):
     idx = {name: i for i, name in enumerate(n2n)}
     gs, ds = max(1, int(getattr(oparams, "gpu_slots", 1))), max(1, int(getattr(oparams, "disk_slots", 1)))
 
-    def table(av_map, own_keys, pods_of_node, pod_key, slots):
-        """the (:gpus / :disk available) map as the ABI's slot table: own key first, then the keys only the pods name, in the
-        order the node's pod list names them; -> (keys, values, overflow)"""
+    def pod_map(pod):
+        """the pod's resource map as get-consumption merges it (api.clj:899-919), None when the pod is skipped"""
+        if bool(oparams.clobber_synthetic_pods) and pod.get("synthetic"):
+            return None
+        reqs = [convert_resource_map(c) if c is not None else None for c in (pod.get("containers") or [])]
+        return force_disk_type(pod.get("disk_type"), force_gpu_model(pod.get("gpu_model"), merge_with(lambda a, b: a + b, *reqs)))
+
+    def table(av_map, own_keys, pods_of_node, res_key, slots):
+        """the (:gpus / :disk available) map as the ABI's slot table: own key first, then the keys only the pods consume under, in
+        the order the node's pod list brings them in; -> (keys, values, overflow)"""
         order = list(own_keys)
         for pod in pods_of_node:
-            k = pod.get(pod_key)
-            if k is not None and k in av_map and k not in order:
-                order.append(k)
+            for k in ((pod_map(pod) or {}).get(res_key) or {}):
+                if k not in order:
+                    order.append(k)
         assert set(order) == set(av_map.keys()), (order, av_map)
         keys = [int(k[1:]) for k in order[:slots]] + [0] * (slots - min(slots, len(order)))
         vals = [float(av_map[k]) for k in order[:slots]] + [0.0] * (slots - min(slots, len(order)))
@@ -236,8 +243,8 @@ def build_rows(nodes, pods, oparams):
         av = available[name]
         own_g = list((cap[name].get("gpus") or {}).keys())
         own_d = list((cap[name].get("disk") or {}).keys())
-        gk, gv, g_over = table(av.get("gpus") or {}, own_g, n2p.get(name) or [], "gpu_model", gs)
-        dk, dv, d_over = table(av.get("disk") or {}, own_d, n2p.get(name) or [], "disk_type", ds)
+        gk, gv, g_over = table(av.get("gpus") or {}, own_g, n2p.get(name) or [], "gpus", gs)
+        dk, dv, d_over = table(av.get("disk") or {}, own_d, n2p.get(name) or [], "disk", ds)
         tables[name] = (gk, gv, dk, dv)
         if name in consumed:
             status[i] |= 2

@@ -20,5 +20,8 @@ struct JNINativeInterface_ {
   jsize (*GetArrayLength)(JNIEnv*, jobjectArray);
   jobject (*GetObjectArrayElement)(JNIEnv*, jobjectArray, jsize);
   jstring (*NewStringUTF)(JNIEnv*, const char*);
+  jlong (*GetDirectBufferCapacity)(JNIEnv*, jobject);
+  void (*DeleteLocalRef)(JNIEnv*, jobject);
+  jobject (*NewDirectByteBuffer)(JNIEnv*, void*, jlong);
 };
 #endif

@@ -955,6 +955,12 @@ def offers_slot_tables(make_engine):
     assert got.gpu_model.tolist() == [[1, 2, 3], [3, 0, 0]] and got.gpu_count.tolist() == [[3.0, 3.0, 1.0], [2.0, 0.0, 0.0]]
     assert got.disk_type.tolist() == [[1, 2], [2, 0]] and got.disk_space.tolist() == [[989.5, 20.75], [7.0, 0.0]]
     assert got.node_status.tolist() == [3, 3]  # nothing left for the host to rebuild
+    # the order of the entries follows the pods that CONSUME: a pod without resource requests (api.clj:908-913) names type 1 first
+    # but brings nothing in, so type 2 takes the node's one slot and type 1 overflows
+    n1 = A.Nodes(cpus=[8.0], mem=[1024.0])
+    p1 = A.Pods(node=[0, 0, 0], cpus=[1.0] * 3, mem=[1.0] * 3, disk=[5.0, 50.25, 7.0], disk_type=[1, 2, 1], flags=[A.POD_NO_REQUESTS, 0, 0])
+    g1 = offers_parity(make_engine, n1, p1, A.offer_params(n_disk_types=2), "consuming order")
+    assert g1.disk_type.tolist() == [2] and g1.disk_space.tolist() == [50.25] and g1.node_status.tolist() == [1 | 2 | 8]
     # the same nodes through one-entry rows: the second model does not fit and the node is flagged
     one = offers_parity(make_engine, nodes, pods, A.offer_params(n_gpu_models=3, n_disk_types=2), "one slot")
     assert one.gpu_model.tolist() == [1, 3] and one.node_status.tolist() == [3 | 4 | 8, 3]

@@ -70,3 +70,30 @@ def test_jni_shim_typechecks_against_header():
     import subprocess
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "tests", "jni_stub"),
                            "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "bindings", "jni", "cookmatch_jni.c")])
+
+
+def test_ctypes_prototypes_are_generated_from_the_header():
+    # cook_amd/_protos.py (restype / argtypes of every export) is in sync with include/cookmatch.h
+    import subprocess
+    import sys
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "scripts", "gen_protos.py"), "--check"]) == 0, \
+        "run python scripts/gen_protos.py after editing include/cookmatch.h"
+    lib = engine.load_library(build.build())
+    for name, (restype, argtypes) in engine.PROTOS.items():
+        fn = getattr(lib, name)
+        assert fn.restype == restype and list(fn.argtypes) == list(argtypes), name
+    with pytest.raises(C.ArgumentError):
+        lib.cook_match_count(C.c_void_p(0), 1.5)  # a float where a pointer belongs is refused before the call
+    with pytest.raises(TypeError):
+        lib.cook_cycle_run(C.c_void_p(0))  # wrong argument count
+
+
+def test_jni_shim_binds_the_hot_path_entry_points():
+    # every entry point of the rank -> considerable -> match -> rebalance path has a JNI export; buffers are size-checked
+    txt = open(os.path.join(ROOT, "bindings", "jni", "cookmatch_jni.c")).read()
+    for fn in ("cook_rank", "cook_rank_user_usage", "cook_considerable", "cook_match", "cook_match_count", "cook_cycle_stage",
+               "cook_cycle_update", "cook_cycle_run", "cook_cycle_run_rank", "cook_cycle_match_multi", "cook_cycle_fetch",
+               "cook_rebalance", "cook_offers_build", "cook_match_explain", "cook_match_metrics", "cook_host_alloc", "cook_host_free"):
+        assert re.search(r"\b%s\(" % fn, txt), fn
+    assert "GetDirectBufferCapacity" in txt and "DeleteLocalRef" in txt
+    assert not re.search(r"GetObjectArrayElement\([^;]*;\s*\n\s*return", txt)  # no element reference is leaked
