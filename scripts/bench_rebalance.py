@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--hosts", type=int, default=50_000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spare-frac", type=float, default=0.0, help="hosts with spare capacity; 0 = every decision has to preempt")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--kernels", action="store_true", help="one more profiled call: per-kernel microseconds and launches")
     args = ap.parse_args()
@@ -36,7 +37,7 @@ def main():
     from tests import parity_cases as P
 
     b = P.make_rebalance_case(seed=0xC00C0005, n_running=args.running, n_pending=args.pending, n_users=args.users,
-                              n_hosts=args.hosts, max_preemption=args.pending, quota_frac=0.02, spare_frac=0.2)
+                              n_hosts=args.hosts, max_preemption=args.pending, quota_frac=0.02, spare_frac=args.spare_frac)
     with Engine(b["params"]) as e:
         t0 = time.perf_counter()
         e.rebalance_stage(b["running"], b["pending"], b["pending_job_id"], b["pending_priority"], b["users"], b["spare"],
