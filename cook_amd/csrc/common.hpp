@@ -272,3 +272,69 @@ static __device__ __forceinline__ unsigned map_count_dev(const uint32_t* __restr
   return n;
 }
 
+// ---- row-shift steps of a wave scan ---------------------------------------------------------------------------------------------------
+// scan_fetch<STEP>(x): the value a Kogge-Stone step combines into this lane, fetched with a DPP move (a few cycles; a ds_bpermute
+// shuffle costs ~100): steps 0..3 = the lane 1, 2, 4, 8 places down INSIDE its row of 16; step 4 = lane 15 of the previous row for the
+// odd rows; step 5 = lane 31 for the upper half.  Lanes without a source get 0 bits (the identity of the sums scanned with it).
+// After the six steps every lane holds the inclusive scan of the wave.
+#ifdef __HIP_EMU__
+template <int STEP>
+static inline int scan_fetch_u32(int x) {
+  const unsigned lane = lane_id();
+  if (STEP < 4) {
+    const int v = __shfl_up(x, 1u << STEP, COOK_WAVE);
+    return (lane & 15u) >= (1u << STEP) ? v : 0;
+  }
+  if (STEP == 4) {
+    const int v = __shfl(x, (int)((lane & ~15u) - 1u) & 63, COOK_WAVE);
+    return ((lane >> 4) & 1u) ? v : 0;
+  }
+  const int v = __shfl(x, 31, COOK_WAVE);
+  return lane >= 32u ? v : 0;
+}
+#else
+template <int STEP>
+static __device__ __forceinline__ int scan_fetch_u32(int x) {
+  if (STEP == 0) return __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+  if (STEP == 1) return __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+  if (STEP == 2) return __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+  if (STEP == 3) return __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8
+  if (STEP == 4) return __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  return __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);                 // row_bcast:31 into rows 2 and 3
+}
+#endif
+template <int STEP>
+static __device__ __forceinline__ double scan_fetch_f64(double x) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = (unsigned)scan_fetch_u32<STEP>((int)(unsigned)(unsigned long long)b);
+  const unsigned hi = (unsigned)scan_fetch_u32<STEP>((int)(unsigned)((unsigned long long)b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+}
+
+// maximum of x over the lane's HALF of the wave (lanes 0..31 / 32..63), returned to every lane of that half; all 64 lanes active
+#ifdef __HIP_EMU__
+static inline unsigned half_max_u32(unsigned x) {
+  for (int d = 16; d >= 1; d >>= 1) {
+    const unsigned y = __shfl_xor(x, d, COOK_WAVE);
+    x = y > x ? y : x;
+  }
+  return x;
+}
+#else
+static __device__ __forceinline__ unsigned half_max_u32(unsigned x) {
+  x = dpp_max_u32<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
+  x = dpp_max_u32<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
+  x = dpp_max_u32<0x141, 0xF>(x);  // row_half_mirror
+  x = dpp_max_u32<0x140, 0xF>(x);  // row_mirror: every lane holds its row's maximum
+  x = dpp_max_u32<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3: lanes 31 / 63 hold their half's
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)x, 31), hi = (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+  return lane_id() < 32u ? lo : hi;
+}
+#endif
+static __device__ __forceinline__ unsigned long long half_max_u64(unsigned long long x) {
+  const unsigned hi = (unsigned)(x >> 32), lo = (unsigned)x;
+  const unsigned mh = half_max_u32(hi);
+  const unsigned ml = half_max_u32(hi == mh ? lo : 0u);
+  return ((unsigned long long)mh << 32) | (unsigned long long)ml;
+}
+

@@ -29,7 +29,7 @@ struct RebalBufs {
   DArr<uint64_t> hkey;
   DArr<uint32_t> hpermA, hpermB, hstart, hend, hbase, h_pb, h_user, hidx, chg, chg_tile, chg_bad, chg_mark;
   DArr<SumU4> tile_agg, tile_carry;
-  DArr<uint32_t> x_before, x_cnt;
+  DArr<uint32_t> x_head, x_cnt, x_next, big_list;
   DArr<double> h_cpus, h_mem, h_gpus, h_dru;
   DArr<uint8_t> h_act;
   uint32_t* hperm = nullptr;
@@ -47,6 +47,7 @@ struct RebalBufs {
   DArr<uint32_t> j_gpu_model, j_user, j_group, j_eq_off, j_eq_key, j_eq_val, j_novel_off, j_novel_host, j_ckpt, j_disk_type;
   DArr<int64_t> j_est_end;
   unsigned a_gpu_slots = 1, a_disk_slots = 1;
+  unsigned max_seg = 0;  // running tasks on the fullest host
   bool hj_gpus = false, hj_gpu_model = false, hj_group = false, hj_eq = false, hj_novel = false, hj_ckpt = false, hj_disk = false,
        hj_est = false;
   // groups
@@ -114,6 +115,11 @@ void rebalance_stage(cook_engine* e, RebalBufs& b, const cook_tasks* run, const 
     for (unsigned i = 0; i < groups->run_off[G]; ++i) see_host(groups->run_host[i]);
   const unsigned H = any_host ? maxh + 1 : 0;
   b.H = H;
+  {  // running tasks on the fullest host: decides whether rebal_decide_big is ever needed
+    std::vector<uint32_t> cnt(H ? H : 1, 0u);
+    for (unsigned i = 0; i < R; ++i) cnt[run->host[i]] += 1u;
+    b.max_seg = *std::max_element(cnt.begin(), cnt.end());
+  }
   h2d(e, b.cpus, c.data(), S);
   h2d(e, b.mem, m.data(), S);
   h2d(e, b.gpus, g.data(), S);
@@ -309,7 +315,9 @@ RebalIn rebalance_args(cook_engine* e, RebalBufs& b) {
   in.chg_mark = b.chg_mark.ptr();
   in.tile_agg = b.tile_agg.ptr();
   in.tile_carry = b.tile_carry.ptr();
-  in.x_before = b.x_before.ptr();
+  in.x_head = b.x_head.ptr();
+  in.x_next = b.x_next.ptr();
+  in.big_list = b.big_list.ptr();
   in.x_cnt = b.x_cnt.ptr();
   in.pre_w = b.pre.ptr();
   in.dru_w = b.dru.ptr();
@@ -431,9 +439,9 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   b.hidx.ensure(S);
   b.chg.ensure(S + 1), b.chg_tile.ensure(S + 2), b.chg_bad.ensure(S + 1), b.chg_mark.ensure(std::max(1u, U));
   b.tile_agg.ensure(S / RB_RS_TILE + S + 2), b.tile_carry.ensure(S / RB_RS_TILE + S + 2);  // every listed user adds at most one partial tile
-  b.x_before.ensure(std::max(1u, H)), b.x_cnt.ensure(std::max(1u, H));
+  b.x_head.ensure(std::max(1u, H)), b.x_cnt.ensure(std::max(1u, H)), b.x_next.ensure(std::max(1u, P)), b.big_list.ensure(std::max(1u, H));
   COOK_HIP(hipMemsetAsync(b.chg_mark.ptr(), 0, (size_t)std::max(1u, U) * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(b.x_before.ptr(), 0, (size_t)std::max(1u, H) * 4, e->stream));
+  COOK_HIP(hipMemsetAsync(b.x_head.ptr(), 0xFF, (size_t)std::max(1u, H) * 4, e->stream));
   COOK_HIP(hipMemsetAsync(b.x_cnt.ptr(), 0, (size_t)std::max(1u, H) * 4, e->stream));
   COOK_HIP(hipMemsetAsync(b.hidx.ptr(), 0xFF, (size_t)S * 4, e->stream));
   if (R)
@@ -473,6 +481,7 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   std::vector<double> nanv(P, std::numeric_limits<double>::quiet_NaN());
   COOK_HIP(hipMemcpyAsync(b.pending_dru.ptr(), nanv.data(), (size_t)P * 8, hipMemcpyHostToDevice, e->stream));
   sync(e);  // nanv / h_scratch are reused below
+  if (H) KL("rebal_big_init", rebal_big_init, div_up(H, 256), 256, (const uint32_t*)b.hstart.ptr(), (const uint32_t*)b.hend.ptr(), H, b.big_list.ptr(), b.ctl.ptr());
   rebalance_rescore(e, b);  // every user once; after a decision only the users it touched (rebal_rescore_users)
   if (R) KL("rebal_mirror_dru", rebal_mirror_dru, div_up(R, 256), 256, (const uint32_t*)b.h_pb.ptr(), (const double*)b.dru.ptr(), R, b.h_dru.ptr());
   // ---- the decision loop (rebalancer.clj:442-458) ---------------------------------------------------------------------------------
@@ -480,7 +489,8 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   const unsigned gH = div_up(std::max(1u, H), RB_WAVES);
   for (unsigned pj = 0; pj < P; ++pj) {
     KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, pj);
-    if (H) KL("rebal_decide", rebal_decide, gH, COOK_WAVE * RB_WAVES, in);
+    if (H) KL("rebal_decide", rebal_decide, div_up(div_up(H, 2u), RB_WAVES), COOK_WAVE * RB_WAVES, in);
+    if (H && b.max_seg + pj > (unsigned)COOK_WAVE) KL("rebal_decide_big", rebal_decide_big, 32, COOK_WAVE * RB_WAVES, in);  // (pj jobs placed at most)
     KL("rebal_apply", rebal_apply, 1, RB_APPLY_THREADS, in);
     KL("rebal_rs_local", rebal_rs_local, RB_RS_GRID, RB_RS_TILE, in);
     KL("rebal_rs_carry", rebal_rs_carry, RB_RS_USERS, COOK_WAVE, in);

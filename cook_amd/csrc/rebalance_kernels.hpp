@@ -33,10 +33,10 @@ struct RebalCtl {
   int remaining;        // max-preemption budget left (rebalancer.clj:442)
   unsigned nd, np;      // decisions / preempted tasks emitted
   unsigned n_pre_hosts; // hosts of the tasks preempted so far whose attribute map is known (constraints.clj:686-689)
-  unsigned n_x;         // jobs placed so far this cycle (x_pj, sorted by host)
+  unsigned n_x;         // jobs placed so far this cycle (x_pj)
   unsigned n_changed;   // users whose active set the last decision changed (chg[])
   unsigned n_tiles;     // tiles of RB_RS_TILE slots their segments are cut into (chg_tile[])
-  unsigned pad[1];
+  unsigned n_big;       // hosts listed in big_list
 };
 
 struct RebalJob {  // context of the pending job being decided (written by rebal_job_prep)
@@ -114,10 +114,12 @@ struct RebalIn {
   const int32_t* g_min;
   const uint32_t *g_run_off, *g_run_host;
   // dynamic lists
-  uint32_t* x_pj;       // [P] placed jobs sorted by host
+  uint32_t* x_pj;       // [P] placed jobs in placement order
   uint32_t* x_host;     // [P] by pj
   uint8_t* x_known;     // [P] by pj: the placed task carries a slave id whose attributes are cached
-  uint32_t *x_before, *x_cnt;  // [H] placed jobs on hosts before this one / on this one
+  uint32_t *x_head, *x_cnt;    // [H] newest placed job on the host (chain through x_next), number of them
+  uint32_t* x_next;            // [P] by pj: the next older placed job on the same host
+  uint32_t* big_list;          // [H] hosts that hold (or held) more than 64 items: rebal_decide_big's work list
   uint32_t* pre_hosts;  // [S]
   uint32_t* co_val;     // cohost values of the current job's group
   // per-host results of rebal_decide
@@ -158,6 +160,28 @@ static __device__ __forceinline__ SumU4 wave_bcast_u4(const SumU4& v, int src) {
   r.gpus = __shfl(v.gpus, src, COOK_WAVE);
   r.bad = __shfl(v.bad, src, COOK_WAVE);
   return r;
+}
+
+// inclusive wave scan of usage vectors whose count field is not needed, by DPP row shifts (common.hpp scan_fetch): `steps` = 4, 5 or 6
+// covers the first 16, 32 or 64 lanes (wave-uniform)
+template <int STEP>
+static __device__ __forceinline__ SumU4 scan_step_u4(const SumU4& v) {
+  SumU4 p;
+  p.count = 0.0;
+  p.cpus = scan_fetch_f64<STEP>(v.cpus);
+  p.mem = scan_fetch_f64<STEP>(v.mem);
+  p.gpus = scan_fetch_f64<STEP>(v.gpus);
+  p.bad = (unsigned)scan_fetch_u32<STEP>((int)v.bad);
+  return combine(p, v);  // lanes without a source fetched zeros: x + 0.0 == x, nothing rounds
+}
+static __device__ __forceinline__ SumU4 wave_incl_scan_u4_rows(SumU4 v, unsigned lanes) {
+  v = scan_step_u4<0>(v);
+  v = scan_step_u4<1>(v);
+  v = scan_step_u4<2>(v);
+  v = scan_step_u4<3>(v);
+  if (lanes > 16u) v = scan_step_u4<4>(v);
+  if (lanes > 32u) v = scan_step_u4<5>(v);
+  return v;
 }
 
 // value of attribute `key` in the map of row r (r < 0: nil map -> 0 = absent); COOK_NONE_U32 = "HOSTNAME"
@@ -587,44 +611,380 @@ static __device__ __forceinline__ bool rebal_group_constraint(const RebalIn& in,
   return cnt != 0u;  // attribute-equals
 }
 
-// first index i in [0, n) with host(x_pj[i]) >= h
-static __device__ __forceinline__ unsigned rebal_x_lower(const RebalIn& in, unsigned n, unsigned h) {
-  unsigned lo = 0, hi = n;
-  while (lo < hi) {
-    const unsigned mid = (lo + hi) >> 1;
-    if (in.x_host[in.x_pj[mid]] < h)
-      lo = mid + 1;
-    else
-      hi = mid;
+// ---- per host: candidates, priority order, prefix aggregates, best feasible prefix ------------------------------------------
+struct HostBest {  // best feasible prefix of a host for the current job
+  unsigned long long key;  // f64_key(dru), 0 = none
+  unsigned len;
+  double dru, c, m, g;
+};
+// Jobs placed earlier in this cycle form one chain per host (x_head[h] -> x_next[pj] -> ...), newest first; x_cnt[h] = its length.
+// The order inside a host does not matter: the host's items are ordered by (dru desc, position in B asc) anyway.
+static __device__ __forceinline__ unsigned rebal_chain_at(const RebalIn& in, unsigned h, unsigned q) {
+  unsigned cur = in.x_head[h];
+  for (unsigned s = 0; s < q; ++s) cur = in.x_next[cur];
+  return cur;
+}
+// placed jobs on hosts before h (the host's offset into the global scratch, slow path only): a count over the <= P placed jobs
+static __device__ __forceinline__ unsigned rebal_x_before(const RebalIn& in, unsigned h) {
+  const unsigned n_x = in.ctl->n_x;
+  unsigned c = 0;
+  for (unsigned i = lane_id(); i < n_x; i += COOK_WAVE) c += in.x_host[in.x_pj[i]] < h ? 1u : 0u;
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, COOK_WAVE);
+  return c;
+}
+// the host's last scored task in priority-map order (rebalancer.clj:369-375) decides which attribute map the host resolves to
+static __device__ __forceinline__ int rebal_host_row(const RebalIn& in, unsigned h, double last_d, unsigned last_pb, unsigned last_slot) {
+  for (int dd = 32; dd >= 1; dd >>= 1) {
+    const double od = __shfl_xor(last_d, dd, COOK_WAVE);
+    const unsigned opb = __shfl_xor(last_pb, dd, COOK_WAVE), osl = __shfl_xor(last_slot, dd, COOK_WAVE);
+    if (osl != 0xFFFFFFFFu && (last_slot == 0xFFFFFFFFu || od < last_d || (od == last_d && opb > last_pb))) {
+      last_d = od;
+      last_pb = opb;
+      last_slot = osl;
+    }
   }
-  return lo;
+  bool known = false;
+  if (last_slot != 0xFFFFFFFFu)
+    known = last_slot < in.R ? (in.attrs_cached ? in.attrs_cached[last_slot] != 0 : true) : in.x_known[last_slot - in.R] != 0;
+  return known ? in.row_of_host[h] : -1;
 }
 
-// ---- per host: candidates, priority order, prefix aggregates, best feasible prefix ------------------------------------------
+// A host with at most 64 items (running tasks + jobs placed this cycle), one item per lane, everything in registers: filter
+// (rebalancer.clj:339-349), rank by (dru desc, position in B asc) with wave broadcasts, prefix aggregates seeded with the spare
+// resources (:384-403), best feasible prefix (:404).  l_rank = 64 words of LDS owned by this wave.  -> out.key != 0 when the host can
+// take the job; sorted_slot = lane k's slot of the k-th candidate in priority order (the preempted tasks are a prefix of it).
+static __device__ __forceinline__ void rebal_host_small(const RebalIn& in, const RebalJob& jb, unsigned h, unsigned hs, unsigned n_seg, unsigned n_here,
+                                                       bool sp, uint32_t* l_rank, HostBest& out, unsigned& sorted_slot) {
+  const unsigned lane = lane_id(), t = lane, n = n_seg + n_here;
+  out.key = 0ull;
+  out.len = 0;
+  out.dru = out.c = out.m = out.g = 0.0;
+  sorted_slot = 0xFFFFFFFFu;
+  const bool valid = t < n, mirrored = t < n_seg;
+  unsigned my_pj = 0;
+  if (n_here) {  // wave-uniform
+    unsigned cur = in.x_head[h];
+    for (unsigned q = 0; q < n_here; ++q) {
+      if (t == n_seg + q) my_pj = cur;
+      cur = in.x_next[cur];
+    }
+  }
+  unsigned slot = 0, pb = 0, usr = 0;
+  bool a = false;
+  double d = 0.0, xc = 0.0, xm = 0.0, xg = 0.0;
+  if (mirrored) {  // a running slot: its columns lie at hs + t of the host-ordered mirrors
+    slot = in.hperm[hs + t];
+    pb = in.h_pb[hs + t];
+    a = in.h_act[hs + t] != 0;
+    usr = in.h_user[hs + t];
+    d = in.h_dru[hs + t];
+    xc = in.h_cpus[hs + t], xm = in.h_mem[hs + t], xg = in.h_gpus[hs + t];
+  } else if (valid) {  // a job placed earlier in this cycle
+    slot = in.R + my_pj;
+    pb = in.posB[slot];
+    a = in.act[pb] != 0;
+    usr = in.slot_user[slot];
+    d = in.dru[pb];
+    xc = in.slot_cpus[slot], xm = in.slot_mem[slot], xg = in.slot_gpus[slot];
+  }
+  if (!a) d = 0.0;
+#if defined(RB_CUT) && RB_CUT == 1
+  if (d == 123.456) out.key = 1ull;
+  return;
+#endif
+  const bool cand = a && (jb.below || usr == jb.us) && !(d < in.safe_dru) && (d - jb.pdru > in.min_diff);
+  const unsigned long long mask = __ballot(cand);
+  const unsigned n_c = (unsigned)__popcll(mask);
+  if (n_c == 0 && !sp) return;  // nothing to preempt and nothing spare: no prefix exists (wave-uniform)
+  // which attribute map the host resolves to: its last scored task's (rebalancer.clj:369-375).  When every running task's slave id is
+  // cached and no placed job sits on the host, any active item gives the same answer
+  int row;
+  if (!in.attrs_cached && n_here == 0)
+    row = __ballot(a) != 0ull ? in.row_of_host[h] : -1;
+  else
+    row = rebal_host_row(in, h, d, pb, a ? slot : 0xFFFFFFFFu);
+  if (!rebal_job_constraints(in, jb.pj, row, jb.g)) return;
+  if (jb.gtype && !rebal_group_constraint(in, jb, row)) return;
+#if defined(RB_CUT) && RB_CUT == 2
+  if (d == 123.456) out.key = 1ull;
+  return;
+#endif
+  // priority-map order inside the host = (dru desc, position in B asc): rank by counting, the other items broadcast one by one
+  unsigned r = 0;
+  for (unsigned long long m = mask; m != 0ull; m &= m - 1ull) {
+    const int j = __ffsll((unsigned long long)m) - 1;
+    const double dj = wave_read_lane_f64(d, j);
+    const unsigned pjx = (unsigned)wave_read_lane((int)pb, j);
+    r += (dj > d || (dj == d && pjx < pb)) ? 1u : 0u;
+  }
+  if (cand) l_rank[r] = lane;
+  wave_sync();
+  const unsigned src = lane < n_c ? l_rank[lane] : 0u;
+  wave_sync();  // (the next call of this wave reuses l_rank)
+  const bool vk = lane < n_c;
+  const double sd = __shfl(d, (int)src, COOK_WAVE);
+  SumU4 x = SumU4{0.0, __shfl(xc, (int)src, COOK_WAVE), __shfl(xm, (int)src, COOK_WAVE), __shfl(xg, (int)src, COOK_WAVE), 0u};
+  sorted_slot = (unsigned)__shfl((int)slot, (int)src, COOK_WAVE);
+  if (!vk) {
+    x = SumU4::zero();
+    sorted_slot = 0xFFFFFFFFu;
+  }
+#if defined(RB_CUT) && RB_CUT == 3
+  if (sd == 123.456) out.key = 1ull;
+  return;
+#endif
+  // prefix aggregates seeded with the spare resources, best feasible prefix: key (f64_key(dru), len) lexicographic max; len 0 = the
+  // spare pseudo-entry alone
+  const double jc = jb.c, jm = jb.m, jg = jb.g;
+  const bool need_g = jb.has_gpus != 0;
+  SumU4 seed = SumU4::zero();
+  if (sp) seed = SumU4{0.0, 0.0 + in.spare_c[h], 0.0 + in.spare_m[h], 0.0 + in.spare_g[h], 0u};
+  const double DMAXV = 1.7976931348623157e308;
+  unsigned long long bk = 0ull;
+  unsigned bl = 0;
+  double bd = 0.0, bc = 0.0, bm = 0.0, bg = 0.0;
+  const bool spare_alone = sp && seed.mem >= jm && seed.cpus >= jc && (need_g ? seed.gpus >= jg : true);
+  const SumU4 tt = combine(seed, wave_incl_scan_u4_rows(x, n_c));
+  if (__any(vk && tt.bad != 0u)) {  // a partial sum rounded: left to right, exactly as the reference's reductions (all lanes alike)
+    double ac = seed.cpus, am = seed.mem, ag = seed.gpus;
+    if (spare_alone) bk = f64_key(DMAXV), bd = DMAXV, bc = ac, bm = am, bg = ag;
+    for (unsigned k = 0; k < n_c; ++k) {
+      ac += __shfl(x.cpus, (int)k, COOK_WAVE);
+      am += __shfl(x.mem, (int)k, COOK_WAVE);
+      ag += __shfl(x.gpus, (int)k, COOK_WAVE);
+      const double dk = __shfl(sd, (int)k, COOK_WAVE);
+      if (am >= jm && ac >= jc && (need_g ? ag >= jg : true) && dk >= 0.0 && f64_key(dk) >= bk) bk = f64_key(dk), bl = k + 1, bd = dk, bc = ac, bm = am, bg = ag;
+    }
+  } else {
+    if (lane == 0 && spare_alone) bk = f64_key(DMAXV), bd = DMAXV, bc = seed.cpus, bm = seed.mem, bg = seed.gpus;
+    const bool enough = vk && tt.mem >= jm && tt.cpus >= jc && (need_g ? tt.gpus >= jg : true) && sd >= 0.0;
+    if (enough && f64_key(sd) >= bk) bk = f64_key(sd), bl = lane + 1, bd = sd, bc = tt.cpus, bm = tt.mem, bg = tt.gpus;  // later prefix wins ties (max-key, :404)
+    // wave arg-max of (bk, bl): the greatest key, and among equal keys the longest prefix = the highest lane (lane k holds prefix
+    // k + 1; the spare pseudo-entry, length 0, sits in lane 0 under the greatest key there is)
+    const unsigned long long mk = wave_max_u64(bk);
+    if (mk == 0ull) return;
+    const unsigned long long own = __ballot(bk == mk);
+    const int wl = 63 - __clzll((unsigned long long)own);
+    bk = mk;
+    bl = (unsigned)wave_read_lane((int)bl, wl);
+    bd = wave_read_lane_f64(bd, wl), bc = wave_read_lane_f64(bc, wl), bm = wave_read_lane_f64(bm, wl), bg = wave_read_lane_f64(bg, wl);
+  }
+  out.key = bk;
+  out.len = bl;
+  out.dru = bd, out.c = bc, out.m = bm, out.g = bg;
+}
+
+// Two hosts with at most 32 items each in ONE wave, a half per host (lanes 0..31: host h0, lanes 32..63: host h0 + 1): the launch is
+// bound by the instructions its 50k waves issue, and a typical host fills a third of a wave.  Same steps as rebal_host_small with every
+// cross-lane operation confined to the half.  The job must not belong to a constrained group (that check is wave-cooperative).
+// -> lanes 0 and 32 hold the result of their host.
+static __device__ __forceinline__ void rebal_host_pair(const RebalIn& in, const RebalJob& jb, unsigned h0, uint32_t* l_rank, HostBest& out) {
+  const unsigned lane = lane_id(), sub = lane >> 5, t = lane & 31u, hb = sub << 5;
+  const unsigned h = h0 + sub;
+  const bool hv = h < in.H;
+  const unsigned hs = hv ? in.hstart[h] : 0u, n_seg = hv ? in.hend[h] - hs : 0u, n_here = hv ? in.x_cnt[h] : 0u;
+  const unsigned n = n_seg + n_here;
+  const bool sp = hv && in.has_spare[h] != 0;
+  out.key = 0ull;
+  out.len = 0;
+  out.dru = out.c = out.m = out.g = 0.0;
+  const bool valid = t < n, mirrored = t < n_seg;
+  unsigned slot = 0, pb = 0, usr = 0;
+  bool a = false;
+  double d = 0.0, xc = 0.0, xm = 0.0, xg = 0.0;
+  if (mirrored) {
+    slot = in.hperm[hs + t];
+    pb = in.h_pb[hs + t];
+    a = in.h_act[hs + t] != 0;
+    usr = in.h_user[hs + t];
+    d = in.h_dru[hs + t];
+    xc = in.h_cpus[hs + t], xm = in.h_mem[hs + t], xg = in.h_gpus[hs + t];
+  } else if (valid) {  // a job placed earlier in this cycle: the (t - n_seg)-th of the host's chain
+    slot = in.R + rebal_chain_at(in, h, t - n_seg);
+    pb = in.posB[slot];
+    a = in.act[pb] != 0;
+    usr = in.slot_user[slot];
+    d = in.dru[pb];
+    xc = in.slot_cpus[slot], xm = in.slot_mem[slot], xg = in.slot_gpus[slot];
+  }
+  if (!a) d = 0.0;
+  const bool cand = a && (jb.below || usr == jb.us) && !(d < in.safe_dru) && (d - jb.pdru > in.min_diff);
+  const unsigned long long mask = __ballot(cand);
+  const unsigned hmask = (unsigned)(mask >> hb);
+  const unsigned n_c = (unsigned)__popc(hmask);
+  bool alive = hv && !(n_c == 0 && !sp);
+  // which attribute map the host resolves to (see rebal_host_small)
+  int row = -1;
+  if (__any(in.attrs_cached != nullptr || n_here != 0u)) {  // wave-uniform: the general rule, reduced over the half
+    double last_d = d;
+    unsigned last_pb = pb, last_slot = a ? slot : 0xFFFFFFFFu;
+    for (int dd = 16; dd >= 1; dd >>= 1) {
+      const double od = __shfl_xor(last_d, dd, COOK_WAVE);
+      const unsigned opb = __shfl_xor(last_pb, dd, COOK_WAVE), osl = __shfl_xor(last_slot, dd, COOK_WAVE);
+      if (osl != 0xFFFFFFFFu && (last_slot == 0xFFFFFFFFu || od < last_d || (od == last_d && opb > last_pb))) last_d = od, last_pb = opb, last_slot = osl;
+    }
+    bool known = false;
+    if (last_slot != 0xFFFFFFFFu)
+      known = last_slot < in.R ? (in.attrs_cached ? in.attrs_cached[last_slot] != 0 : true) : in.x_known[last_slot - in.R] != 0;
+    row = (known && hv) ? in.row_of_host[h] : -1;
+  } else {
+    const unsigned amask = (unsigned)(__ballot(a) >> hb);
+    row = (amask != 0u && hv) ? in.row_of_host[h] : -1;
+  }
+  if (alive && !rebal_job_constraints(in, jb.pj, row, jb.g)) alive = false;
+  if (!__any(alive)) return;
+  // rank inside the half by counting; item jj of both halves is broadcast in one step
+  unsigned r = 0;
+  const unsigned either = (unsigned)mask | (unsigned)(mask >> 32);
+  for (unsigned m = either; m != 0u; m &= m - 1u) {
+    const int jj = __ffs((int)m) - 1;
+    const int src = (int)hb + jj;
+    const double dj = __shfl(d, src, COOK_WAVE);
+    const unsigned pjx = (unsigned)__shfl((int)pb, src, COOK_WAVE);
+    const bool cj = ((hmask >> jj) & 1u) != 0u;
+    r += (cj && (dj > d || (dj == d && pjx < pb))) ? 1u : 0u;
+  }
+  if (cand) l_rank[hb + r] = lane;
+  wave_sync();
+  const bool vk = t < n_c;
+  const unsigned src = vk ? l_rank[hb + t] : lane;
+  wave_sync();
+  const double sd = __shfl(d, (int)src, COOK_WAVE);
+  SumU4 x = SumU4{0.0, __shfl(xc, (int)src, COOK_WAVE), __shfl(xm, (int)src, COOK_WAVE), __shfl(xg, (int)src, COOK_WAVE), 0u};
+  if (!vk) x = SumU4::zero();
+  const double jc = jb.c, jm = jb.m, jg = jb.g;
+  const bool need_g = jb.has_gpus != 0;
+  SumU4 seed = SumU4::zero();
+  if (sp) seed = SumU4{0.0, 0.0 + in.spare_c[h], 0.0 + in.spare_m[h], 0.0 + in.spare_g[h], 0u};
+  const double DMAXV = 1.7976931348623157e308;
+  unsigned long long bk = 0ull;
+  unsigned bl = 0;
+  double bd = 0.0, bc = 0.0, bm = 0.0, bg = 0.0;
+  const bool spare_alone = sp && seed.mem >= jm && seed.cpus >= jc && (need_g ? seed.gpus >= jg : true);
+  // inclusive scan inside the half: four row steps + the row-to-row step (rows 0 -> 1 and 2 -> 3)
+  SumU4 sc = scan_step_u4<0>(x);
+  sc = scan_step_u4<1>(sc);
+  sc = scan_step_u4<2>(sc);
+  sc = scan_step_u4<3>(sc);
+  sc = scan_step_u4<4>(sc);
+  const SumU4 tt = combine(seed, sc);
+  const unsigned hbad = (unsigned)(__ballot(vk && tt.bad != 0u) >> hb);
+  if (__any(hbad != 0u)) {  // a partial sum rounded in some half: that half redoes it left to right like the reference (every lane of it alike)
+    double ac = seed.cpus, am = seed.mem, ag = seed.gpus;
+    unsigned long long k2 = 0ull;
+    unsigned l2 = 0;
+    double d2 = 0.0, c2 = 0.0, m2 = 0.0, g2 = 0.0;
+    if (spare_alone) k2 = f64_key(DMAXV), d2 = DMAXV, c2 = ac, m2 = am, g2 = ag;
+    for (unsigned k = 0; k < 32u; ++k) {
+      if (!__any(k < n_c)) break;
+      const double ck = __shfl(x.cpus, (int)(hb + k), COOK_WAVE), mk2 = __shfl(x.mem, (int)(hb + k), COOK_WAVE), gk = __shfl(x.gpus, (int)(hb + k), COOK_WAVE);
+      const double dk = __shfl(sd, (int)(hb + k), COOK_WAVE);
+      if (k < n_c) {
+        ac += ck, am += mk2, ag += gk;
+        if (am >= jm && ac >= jc && (need_g ? ag >= jg : true) && dk >= 0.0 && f64_key(dk) >= k2) k2 = f64_key(dk), l2 = k + 1, d2 = dk, c2 = ac, m2 = am, g2 = ag;
+      }
+    }
+    if (hbad != 0u) {
+      if (alive && t == 0) out.key = k2, out.len = l2, out.dru = d2, out.c = c2, out.m = m2, out.g = g2;
+      alive = false;  // this half is done
+    }
+  }
+  if (t == 0 && spare_alone) bk = f64_key(DMAXV), bd = DMAXV, bc = seed.cpus, bm = seed.mem, bg = seed.gpus;
+  const bool enough = vk && tt.mem >= jm && tt.cpus >= jc && (need_g ? tt.gpus >= jg : true) && sd >= 0.0;
+  if (enough && f64_key(sd) >= bk) bk = f64_key(sd), bl = t + 1, bd = sd, bc = tt.cpus, bm = tt.mem, bg = tt.gpus;  // later prefix wins ties (:404)
+  // arg-max of (bk, bl) over the half: the greatest key, among equal keys the highest lane (= the longest prefix)
+  const unsigned long long mk = half_max_u64(bk);
+  const unsigned own = (unsigned)(__ballot(bk == mk) >> hb);
+  const int wl = (int)hb + 31 - __clz((int)own);  // own != 0: the lane holding the maximum is among them
+  const unsigned wlen = (unsigned)__shfl((int)bl, wl, COOK_WAVE);
+  const double wd = __shfl(bd, wl, COOK_WAVE), wc = __shfl(bc, wl, COOK_WAVE), wm = __shfl(bm, wl, COOK_WAVE), wg = __shfl(bg, wl, COOK_WAVE);
+  if (alive && t == 0 && mk != 0ull) out.key = mk, out.len = wlen, out.dru = wd, out.c = wc, out.m = wm, out.g = wg;
+}
+
+// hosts with at most 64 items (running tasks + jobs placed this cycle): a wave takes two neighbouring hosts, half a wave each when
+// both hold at most 32 items (rebal_host_pair), else one after the other.  No LDS beyond 64 words per wave, few registers.  The launch
+// is bound by the instructions its waves issue.  Larger hosts are left to rebal_decide_big.
 __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) {
-  __shared__ double l_dru[RB_WAVES][RB_CAP], l_cpus[RB_WAVES][RB_CAP], l_mem[RB_WAVES][RB_CAP], l_gpus[RB_WAVES][RB_CAP];
-  __shared__ uint32_t l_posB[RB_WAVES][RB_CAP], l_slot[RB_WAVES][RB_CAP], l_ord[RB_WAVES][RB_CAP];
+  __shared__ uint32_t l_rank[RB_WAVES][COOK_WAVE];
   const RebalJob jb = *in.job;
   if (!jb.active) return;
   const unsigned lane = lane_id(), w = wave_id();
-  const unsigned h = blockIdx.x * RB_WAVES + w;
-  if (h >= in.H) return;
+  const unsigned h0 = (blockIdx.x * RB_WAVES + w) * 2u;
+  if (h0 >= in.H) return;
+  const bool two = h0 + 1u < in.H;
+  const unsigned n0 = in.hend[h0] - in.hstart[h0] + in.x_cnt[h0];
+  const unsigned n1 = two ? in.hend[h0 + 1u] - in.hstart[h0 + 1u] + in.x_cnt[h0 + 1u] : 0u;
+  if (n0 <= 32u && n1 <= 32u && jb.gtype == 0u) {
+    HostBest hb;
+    rebal_host_pair(in, jb, h0, l_rank[w], hb);
+    if ((lane & 31u) == 0u && h0 + (lane >> 5) < in.H) {
+      const unsigned h = h0 + (lane >> 5);
+      in.hres_key[h] = hb.key;
+      if (hb.key != 0ull) {
+        in.hres_len[h] = hb.len;
+        in.hres_base[h] = 0xFFFFFFFFu;  // rebal_apply re-derives the preempted prefix of a small host itself
+        in.hres_dru[h] = hb.dru;
+        in.hres_c[h] = hb.c;
+        in.hres_m[h] = hb.m;
+        in.hres_g[h] = hb.g;
+      }
+    }
+    return;
+  }
+  for (unsigned q = 0; q < (two ? 2u : 1u); ++q) {
+    const unsigned h = h0 + q;
+    const unsigned hs = in.hstart[h], n_seg = in.hend[h] - hs;
+    const unsigned n_here = in.x_cnt[h];  // jobs placed on this host earlier in the cycle
+    const unsigned n = n_seg + n_here;
+    const bool sp = in.has_spare[h] != 0;
+    if (n > (unsigned)COOK_WAVE) continue;  // rebal_decide_big's
+    HostBest hb;
+    hb.key = 0ull;
+    if (n != 0 || sp) {
+      unsigned ss;
+      rebal_host_small(in, jb, h, hs, n_seg, n_here, sp, l_rank[w], hb, ss);
+    }
+    if (lane == 0) {
+      in.hres_key[h] = hb.key;
+      if (hb.key != 0ull) {
+        in.hres_len[h] = hb.len;
+        in.hres_base[h] = 0xFFFFFFFFu;
+        in.hres_dru[h] = hb.dru;
+        in.hres_c[h] = hb.c;
+        in.hres_m[h] = hb.m;
+        in.hres_g[h] = hb.g;
+      }
+    }
+  }
+}
+
+// hosts with more than 64 items: lists in LDS (<= RB_CAP) or in the host's region of the global scratch.  Such hosts are few or none
+// (a million tasks on 50k hosts: none): they are kept in a list (big_list: the hosts whose running tasks alone exceed 64, plus the ones
+// rebal_apply pushes over that mark) that a small fixed grid walks, a wave per host.
+struct BigLds {
+  double dru[RB_CAP], cpus[RB_CAP], mem[RB_CAP], gpus[RB_CAP];
+  uint32_t posB[RB_CAP], slot[RB_CAP], ord[RB_CAP];
+};
+__global__ void __launch_bounds__(256) rebal_big_init(const uint32_t* __restrict__ hstart, const uint32_t* __restrict__ hend, unsigned H,
+                                                      uint32_t* __restrict__ big_list, RebalCtl* __restrict__ ctl) {
+  const unsigned h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h < H && hend[h] - hstart[h] > (unsigned)COOK_WAVE) big_list[atomicAdd(&ctl->n_big, 1u)] = h;
+}
+static __device__ void rebal_host_big(const RebalIn& in, const RebalJob& jb, unsigned h, BigLds& L) {
+  const unsigned lane = lane_id();
   const unsigned hs = in.hstart[h], n_seg = in.hend[h] - hs;
-  // jobs placed on this host earlier in the cycle = x_pj[xs, xe): the placed list is sorted by host and rebal_apply keeps, per
-  // host, the number of entries before it (two dependent binary searches per wave cost more than the rest of the kernel)
-  const unsigned xs = in.x_before[h], xe = xs + in.x_cnt[h];
-  const unsigned n = n_seg + (xe - xs);
+  const unsigned n_here = in.x_cnt[h];
+  const unsigned n = n_seg + n_here;
   const bool sp = in.has_spare[h] != 0;
   if (lane == 0) in.hres_key[h] = 0ull;
-  if (n == 0 && !sp) return;
-  // the host's region of the scratch arrays starts after the running tasks of the hosts before it and the jobs placed on them.
+  // the region starts after the running tasks of the hosts before it and the jobs placed on them.
   // (hstart is only meaningful for hosts that HAVE running tasks: an empty host's 0 made its region collide with another host's.)
-  const unsigned base = in.hbase[h] + xs;
   const bool big = n > (unsigned)RB_CAP;
-  double *c_dru = big ? in.gs_dru + base : l_dru[w], *c_cpus = big ? in.gs_cpus + base : l_cpus[w];
-  double *c_mem = big ? in.gs_mem + base : l_mem[w], *c_gpus = big ? in.gs_gpus + base : l_gpus[w];
-  uint32_t *c_posB = big ? in.gs_posB + base : l_posB[w], *c_slot = big ? in.gs_slot + base : l_slot[w];
-  uint32_t* c_ord = big ? in.gs_ord + base : l_ord[w];
+  const unsigned base = in.hbase[h] + rebal_x_before(in, h);
+  double *c_dru = big ? in.gs_dru + base : L.dru, *c_cpus = big ? in.gs_cpus + base : L.cpus;
+  double *c_mem = big ? in.gs_mem + base : L.mem, *c_gpus = big ? in.gs_gpus + base : L.gpus;
+  uint32_t *c_posB = big ? in.gs_posB + base : L.posB, *c_slot = big ? in.gs_slot + base : L.slot;
+  uint32_t* c_ord = big ? in.gs_ord + base : L.ord;
   // ---- pass A: filter (rebalancer.clj:339-349) + the host's last scored task in priority-map order (:369-375) ----------
   unsigned n_c = 0;
   double last_d = 0.0;
@@ -643,7 +1003,7 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) 
       usr = in.h_user[hs + t];
       if (a) d = in.h_dru[hs + t];
     } else if (valid) {  // a job placed earlier in this cycle
-      slot = in.R + in.x_pj[xs + (t - n_seg)];
+      slot = in.R + rebal_chain_at(in, h, t - n_seg);
       pb = in.posB[slot];
       a = in.act[pb] != 0;
       usr = in.slot_user[slot];
@@ -670,20 +1030,7 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) 
     n_c += (unsigned)__popcll(mk);
   }
   if (n_c == 0 && !sp) return;  // nothing to preempt and nothing spare: no prefix exists (wave-uniform)
-  // the LAST scored task of the host decides which slave id (hence attribute map) the host resolves to
-  for (int dd = 32; dd >= 1; dd >>= 1) {
-    const double od = __shfl_xor(last_d, dd, COOK_WAVE);
-    const unsigned opb = __shfl_xor(last_pb, dd, COOK_WAVE), osl = __shfl_xor(last_slot, dd, COOK_WAVE);
-    if (osl != 0xFFFFFFFFu && (last_slot == 0xFFFFFFFFu || od < last_d || (od == last_d && opb > last_pb))) {
-      last_d = od;
-      last_pb = opb;
-      last_slot = osl;
-    }
-  }
-  bool known = false;
-  if (last_slot != 0xFFFFFFFFu)
-    known = last_slot < in.R ? (in.attrs_cached ? in.attrs_cached[last_slot] != 0 : true) : in.x_known[last_slot - in.R] != 0;
-  const int row = known ? in.row_of_host[h] : -1;
+  const int row = rebal_host_row(in, h, last_d, last_pb, last_slot);
   if (!rebal_job_constraints(in, jb.pj, row, jb.g)) return;
   if (jb.gtype && !rebal_group_constraint(in, jb, row)) return;
   if (big) __threadfence();
@@ -799,43 +1146,71 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) 
   }
 }
 
+__global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide_big(RebalIn in) {
+  __shared__ BigLds s_l[RB_WAVES];
+  const RebalJob jb = *in.job;
+  if (!jb.active) return;
+  const unsigned n_big = in.ctl->n_big;
+  for (unsigned x = blockIdx.x * RB_WAVES + wave_id(); x < n_big; x += gridDim.x * RB_WAVES) {
+    const unsigned h = in.big_list[x];
+    if (in.hend[h] - in.hstart[h] + in.x_cnt[h] > (unsigned)COOK_WAVE) rebal_host_big(in, jb, h, s_l[wave_id()]);
+    wave_sync();  // the wave's lists are free again
+  }
+}
+
 // ---- arg-max over hosts + next-state (rebalancer.clj:270-309, 404) -----------------------------------------------------------
 constexpr int RB_APPLY_THREADS = 1024;
 __global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in) {
-  __shared__ unsigned long long s_key[RB_APPLY_THREADS];
-  __shared__ unsigned s_host[RB_APPLY_THREADS];
+  __shared__ unsigned long long s_key[RB_APPLY_THREADS / COOK_WAVE];
+  __shared__ unsigned s_host[RB_APPLY_THREADS / COOK_WAVE];
+  __shared__ uint32_t s_rank[COOK_WAVE], s_pre[COOK_WAVE];
   const RebalJob jb = *in.job;
   if (!jb.active) return;
-  const unsigned tid = threadIdx.x;
+  const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  // arg-max of the hosts' keys, the later host winning ties (max-key, rebalancer.clj:404).  Eight independent loads in flight per
+  // thread: a dependent one-load-per-iteration loop over 50k hosts was the larger half of this kernel.
   unsigned long long bk = 0ull;
   unsigned bh = 0;
-  for (unsigned h = tid; h < in.H; h += RB_APPLY_THREADS) {
-    const unsigned long long k = in.hres_key[h];
-    if (k != 0ull && k >= bk) {  // hosts ascend with h: the later host wins ties
-      bk = k;
-      bh = h;
+  for (unsigned h0 = tid; h0 < in.H; h0 += 8u * RB_APPLY_THREADS) {
+    unsigned long long k[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned h = h0 + (unsigned)q * RB_APPLY_THREADS;
+      k[q] = h < in.H ? in.hres_key[h] : 0ull;
     }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (k[q] != 0ull && k[q] >= bk) bk = k[q], bh = h0 + (unsigned)q * RB_APPLY_THREADS;  // hosts ascend: the later host wins ties
   }
-  s_key[tid] = bk;
-  s_host[tid] = bh;
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long ok = __shfl_xor(bk, d, COOK_WAVE);
+    const unsigned oh = __shfl_xor(bh, d, COOK_WAVE);
+    if (ok > bk || (ok == bk && ok != 0ull && oh > bh)) bk = ok, bh = oh;
+  }
+  if (lane == 0) s_key[w] = bk, s_host[w] = bh;
   __syncthreads();
-  for (unsigned s = RB_APPLY_THREADS / 2; s >= 1; s >>= 1) {
-    if (tid < s) {
-      const unsigned long long ok = s_key[tid + s];
-      const unsigned oh = s_host[tid + s];
-      if (ok > s_key[tid] || (ok == s_key[tid] && ok != 0ull && oh > s_host[tid])) {
-        s_key[tid] = ok;
-        s_host[tid] = oh;
-      }
-    }
-    __syncthreads();
+  if (w != 0) return;
+  bk = lane < RB_APPLY_THREADS / COOK_WAVE ? s_key[lane] : 0ull;
+  bh = lane < RB_APPLY_THREADS / COOK_WAVE ? s_host[lane] : 0u;
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long ok = __shfl_xor(bk, d, COOK_WAVE);
+    const unsigned oh = __shfl_xor(bh, d, COOK_WAVE);
+    if (ok > bk || (ok == bk && ok != 0ull && oh > bh)) bk = ok, bh = oh;
   }
-  if (s_key[0] == 0ull) return;  // no host can take the job: no decision, state unchanged (rebalancer.clj:455-458)
-  const unsigned h = s_host[0];
-  for (unsigned hh = h + 1 + tid; hh < in.H; hh += RB_APPLY_THREADS) in.x_before[hh] += 1u;  // the job is about to join x_pj at host h
-  if (tid != 0) return;
-  in.x_cnt[h] += 1u;
+  if (bk == 0ull) return;  // no host can take the job: no decision, state unchanged (rebalancer.clj:455-458)
+  const unsigned h = bh;
   const unsigned len = in.hres_len[h], base = in.hres_base[h];
+  // the preempted tasks = the first `len` candidates of the host in priority order: a small host's are re-derived here (one wave,
+  // registers), a large host's were listed by rebal_decide
+  if (base == 0xFFFFFFFFu) {
+    const unsigned hs = in.hstart[h];
+    HostBest hb;
+    unsigned ss;
+    rebal_host_small(in, jb, h, hs, in.hend[h] - hs, in.x_cnt[h], in.has_spare[h] != 0, s_rank, hb, ss);
+    s_pre[lane] = ss;
+  }
+  wave_sync();
+  if (lane != 0) return;
   RebalCtl c = *in.ctl;
   cook_preemption d;
   d.pending_index = jb.pj;
@@ -861,7 +1236,7 @@ __global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in) {
   };
   changed(jb.us);
   for (unsigned k = 0; k < len; ++k) {
-    const unsigned slot = in.srt_slot[base + k];
+    const unsigned slot = base == 0xFFFFFFFFu ? s_pre[k] : in.srt_slot[base + k];
     const unsigned pbk = in.posB[slot];
     in.act[pbk] = 0;
     if (slot < in.R) in.h_act[in.hidx[pbk]] = 0;
@@ -875,12 +1250,12 @@ __global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in) {
   in.act[in.posB[in.R + jb.pj]] = 1;
   in.x_host[jb.pj] = h;
   in.x_known[jb.pj] = (len > 0 && first_known) ? 1 : 0;
-  unsigned pos = c.n_x;
-  while (pos > 0 && in.x_host[in.x_pj[pos - 1]] > h) {
-    in.x_pj[pos] = in.x_pj[pos - 1];
-    --pos;
-  }
-  in.x_pj[pos] = jb.pj;
+  in.x_next[jb.pj] = in.x_head[h];  // joins the host's chain of placed jobs
+  in.x_head[h] = jb.pj;
+  in.x_cnt[h] += 1u;
+  if (in.hend[h] - in.hstart[h] <= (unsigned)COOK_WAVE && in.hend[h] - in.hstart[h] + in.x_cnt[h] == (unsigned)COOK_WAVE + 1u)
+    in.big_list[c.n_big++] = h;  // this placement takes the host past 64 items
+  in.x_pj[c.n_x] = jb.pj;            // ... and the list of all of them (placement order)
   c.n_x += 1;
   in.spare_c[h] = d.cpus - jb.c;  // rebalancer.clj:302-305
   in.spare_m[h] = d.mem - jb.m;

@@ -41,8 +41,11 @@ __global__ void __launch_bounds__(RS_THREADS) radix_hist(const uint64_t* __restr
   hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// Exclusive scan of a u32 array by ONE workgroup of 1024 threads (len = 256 * nblocks, a few thousand entries).
+// Exclusive scan of a u32 array by ONE workgroup of 1024 threads (len = 256 * nblocks: 11k entries for a pool's 175k tasks, 63k for a
+// million).  Every thread takes SCAN1_IPT consecutive entries per step, so a million-task sort needs 8 steps of the
+// barrier-and-shuffle sequence instead of 62 (70 us -> 12 us per radix pass).
 constexpr int SCAN1_THREADS = 1024;
+constexpr int SCAN1_IPT = 8;
 __global__ void __launch_bounds__(SCAN1_THREADS) excl_scan_u32_single(uint32_t* __restrict__ data, unsigned len,
                                                                       uint32_t* __restrict__ total_out) {
   __shared__ unsigned wsum[SCAN1_THREADS / COOK_WAVE];
@@ -50,10 +53,16 @@ __global__ void __launch_bounds__(SCAN1_THREADS) excl_scan_u32_single(uint32_t* 
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   const unsigned lane = lane_id(), w = wave_id();
-  for (unsigned tile = 0; tile < len; tile += SCAN1_THREADS) {
-    const unsigned i = tile + threadIdx.x;
-    const unsigned v = i < len ? data[i] : 0u;
-    unsigned inc = v;
+  for (unsigned tile = 0; tile < len; tile += SCAN1_THREADS * SCAN1_IPT) {
+    const unsigned i0 = tile + threadIdx.x * SCAN1_IPT;
+    unsigned v[SCAN1_IPT];
+    unsigned tot = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN1_IPT; ++q) {
+      v[q] = i0 + q < len ? data[i0 + q] : 0u;
+      tot += v[q];
+    }
+    unsigned inc = tot;
     for (unsigned d = 1; d < COOK_WAVE; d <<= 1) {
       const unsigned t = __shfl_up(inc, d, COOK_WAVE);
       if (lane >= d) inc += t;
@@ -63,7 +72,12 @@ __global__ void __launch_bounds__(SCAN1_THREADS) excl_scan_u32_single(uint32_t* 
     unsigned wbase = 0;
     for (unsigned k = 0; k < w; ++k) wbase += wsum[k];
     const unsigned carry = carry_s;
-    if (i < len) data[i] = carry + wbase + inc - v;
+    unsigned run = carry + wbase + inc - tot;  // exclusive prefix of this thread's first entry
+#pragma unroll
+    for (int q = 0; q < SCAN1_IPT; ++q) {
+      if (i0 + q < len) data[i0 + q] = run;
+      run += v[q];
+    }
     __syncthreads();
     if (threadIdx.x == SCAN1_THREADS - 1) carry_s = carry + wbase + inc;
     __syncthreads();

@@ -197,7 +197,8 @@ def test_rebalance_golden(make_engine):
 @pytest.mark.parametrize("kw", [
     dict(seed=51, n_running=400, n_pending=24, n_users=12, n_hosts=30),
     dict(seed=52, n_running=400, n_pending=24, n_users=12, n_hosts=30, fractional=True),           # exact fix-up paths
-    dict(seed=53, n_running=600, n_pending=30, n_users=20, n_hosts=3, max_preemption=12),          # hosts beyond the LDS cap
+    dict(seed=53, n_running=600, n_pending=30, n_users=20, n_hosts=3, max_preemption=12),
+    dict(seed=60, n_running=800, n_pending=30, n_users=20, n_hosts=8, max_preemption=16, spare_frac=0.0),     # 65..128 items per host: lists in LDS          # hosts beyond the LDS cap
     dict(seed=54, n_running=500, n_pending=40, n_users=15, n_hosts=40, constraints=True, gpus=True),
     dict(seed=55, n_running=300, n_pending=20, n_users=8, n_hosts=25, dru_mode=1),
     dict(seed=56, n_running=0, n_pending=10, n_users=3, n_hosts=8, spare_frac=1.0),

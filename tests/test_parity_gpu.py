@@ -216,6 +216,7 @@ def test_rebalance_golden(make_engine):
     dict(seed=51, n_running=4000, n_pending=64, n_users=40, n_hosts=300),
     dict(seed=52, n_running=4000, n_pending=64, n_users=40, n_hosts=300, fractional=True),
     dict(seed=53, n_running=10240, n_pending=128, n_users=50, n_hosts=16, max_preemption=48),    # reference stress shape (:1152-1187)
+    dict(seed=60, n_running=8000, n_pending=60, n_users=40, n_hosts=80, max_preemption=32, spare_frac=0.0),    # 65..128 items per host: lists in LDS
     dict(seed=54, n_running=5000, n_pending=128, n_users=60, n_hosts=400, constraints=True, gpus=True, max_preemption=128),
     dict(seed=55, n_running=3000, n_pending=40, n_users=20, n_hosts=250, dru_mode=1),
     dict(seed=56, n_running=0, n_pending=10, n_users=3, n_hosts=8, spare_frac=1.0),
