@@ -78,9 +78,9 @@ def algorithmic_bytes(kernel, n_tasks, k, m, launches_per_match=1.0, pools_per_l
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate passes, scripts/profile_traffic.sh), or None when the kernel was not profiled."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate passes, scripts/profile_round2.sh), or None when the kernel was not profiled."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)["kernels"].get(kernel)

@@ -937,6 +937,8 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     c0.wlong_cap = (unsigned)MV_WLONG;
     if (const char* ev = std::getenv("COOK_WLONG")) c0.wlong_cap = std::atoi(ev) ? (unsigned)MV_WLONG : (unsigned)MV_WMAX;
     c0.reeval_max = algo == 3 ? 0x7FFFFFFFu : 0u;  // 3: list-exhausted jobs re-evaluated in place instead of ending the round
+    if (const char* ev = std::getenv("COOK_REEVAL_MAX"))  // tuning: a bounded number of in-place re-evaluations per round
+      if (algo == 0 || algo == 2) c0.reeval_max = (unsigned)std::max(0, std::atoi(ev));
     WinCtl hc = c0;
     bool done = false;
     if (algo == 4) {  // the persistent kernel: one launch per match call (wins when a pool has the GPU to itself)
@@ -996,7 +998,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
         for (unsigned r = 0; r < batch; ++r) {
           KL("match_eval2", match_eval2, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
           KL("match_merge2", match_merge2, MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, vb);
-          if (algo == 3)
+          if (c0.reeval_max != 0u)
             KL("match_resolve2", match_resolve2_reeval, 1, MV_RTHREADS, st, vb);
           else
             KL("match_resolve2", match_resolve2, 1, MV_RTHREADS, st, vb);
@@ -1098,7 +1100,10 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
     for (unsigned r = 0; r < batch; ++r) {
       KL("match_eval2", match_eval2_multi, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx);
       KL("match_merge2", match_merge2_multi, dim3(MV_WMAX / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, (const PoolCtx*)dctx);
-      KL("match_resolve2", match_resolve2_multi, dim3(1, 1, L), MV_RTHREADS, (const PoolCtx*)dctx);
+      if (es[live[0]]->deferred_c0.reeval_max != 0u)
+        KL("match_resolve2", match_resolve2_multi_reeval, dim3(1, 1, L), MV_RTHREADS, (const PoolCtx*)dctx);
+      else
+        KL("match_resolve2", match_resolve2_multi, dim3(1, 1, L), MV_RTHREADS, (const PoolCtx*)dctx);
     }
     const std::vector<WinCtl> prev = hc;
     for (unsigned x = 0; x < L; ++x)

@@ -2235,3 +2235,8 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2_multi(const PoolCt
   const PoolCtx& c = ctx[blockIdx.z];
   resolve_round<false>(lds, c.st, c.vb);
 }
+__global__ void __launch_bounds__(MV_RTHREADS) match_resolve2_multi_reeval(const PoolCtx* __restrict__ ctx) {
+  __shared__ __attribute__((aligned(16))) char lds[sizeof(ResolveLds)];
+  const PoolCtx& c = ctx[blockIdx.z];
+  resolve_round<true>(lds, c.st, c.vb);
+}

@@ -42,47 +42,57 @@ __global__ void __launch_bounds__(RS_THREADS) radix_hist(const uint64_t* __restr
 }
 
 // Exclusive scan of a u32 array by ONE workgroup of 1024 threads (len = 256 * nblocks: 11k entries for a pool's 175k tasks, 63k for a
-// million).  Every thread takes SCAN1_IPT consecutive entries per step, so a million-task sort needs 8 steps of the
-// barrier-and-shuffle sequence instead of 62 (70 us -> 12 us per radix pass).
+// million).  The entries were written by the previous kernel on other XCDs, so every load is a trip to memory (~2 us): a step that
+// loads, scans and stores 1024 entries at a time spent 57 us on the 63k entries (rocprofv3, profiles/r02i).  Here a thread takes
+// SCAN1_IPT consecutive entries per step and the loads of SCAN1_NS steps are issued before the first step runs: one memory latency
+// per 64k entries instead of 62.
 constexpr int SCAN1_THREADS = 1024;
 constexpr int SCAN1_IPT = 8;
+constexpr int SCAN1_NS = 8;
 __global__ void __launch_bounds__(SCAN1_THREADS) excl_scan_u32_single(uint32_t* __restrict__ data, unsigned len,
                                                                       uint32_t* __restrict__ total_out) {
-  __shared__ unsigned wsum[SCAN1_THREADS / COOK_WAVE];
-  __shared__ unsigned carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
+  __shared__ unsigned wsum[2][SCAN1_THREADS / COOK_WAVE];
+  unsigned carry = 0;  // every thread tracks the running total itself (read from LDS once per step)
   const unsigned lane = lane_id(), w = wave_id();
-  for (unsigned tile = 0; tile < len; tile += SCAN1_THREADS * SCAN1_IPT) {
-    const unsigned i0 = tile + threadIdx.x * SCAN1_IPT;
-    unsigned v[SCAN1_IPT];
-    unsigned tot = 0;
+  constexpr unsigned STEP = SCAN1_THREADS * SCAN1_IPT;
+  for (unsigned super = 0; super < len; super += STEP * SCAN1_NS) {
+    unsigned v[SCAN1_NS][SCAN1_IPT];
 #pragma unroll
-    for (int q = 0; q < SCAN1_IPT; ++q) {
-      v[q] = i0 + q < len ? data[i0 + q] : 0u;
-      tot += v[q];
-    }
-    unsigned inc = tot;
-    for (unsigned d = 1; d < COOK_WAVE; d <<= 1) {
-      const unsigned t = __shfl_up(inc, d, COOK_WAVE);
-      if (lane >= d) inc += t;
-    }
-    if (lane == COOK_WAVE - 1) wsum[w] = inc;
-    __syncthreads();
-    unsigned wbase = 0;
-    for (unsigned k = 0; k < w; ++k) wbase += wsum[k];
-    const unsigned carry = carry_s;
-    unsigned run = carry + wbase + inc - tot;  // exclusive prefix of this thread's first entry
+    for (int s = 0; s < SCAN1_NS; ++s) {
+      const unsigned i0 = super + (unsigned)s * STEP + threadIdx.x * SCAN1_IPT;
 #pragma unroll
-    for (int q = 0; q < SCAN1_IPT; ++q) {
-      if (i0 + q < len) data[i0 + q] = run;
-      run += v[q];
+      for (int q = 0; q < SCAN1_IPT; ++q) v[s][q] = i0 + q < len ? data[i0 + q] : 0u;
     }
-    __syncthreads();
-    if (threadIdx.x == SCAN1_THREADS - 1) carry_s = carry + wbase + inc;
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < SCAN1_NS; ++s) {
+      if (super + (unsigned)s * STEP >= len) break;  // block-uniform
+      const unsigned i0 = super + (unsigned)s * STEP + threadIdx.x * SCAN1_IPT;
+      unsigned tot = 0;
+#pragma unroll
+      for (int q = 0; q < SCAN1_IPT; ++q) tot += v[s][q];
+      unsigned inc = tot;
+      for (unsigned d = 1; d < COOK_WAVE; d <<= 1) {
+        const unsigned t = __shfl_up(inc, d, COOK_WAVE);
+        if (lane >= d) inc += t;
+      }
+      if (lane == COOK_WAVE - 1) wsum[s & 1][w] = inc;  // double-buffered: one barrier per step
+      __syncthreads();
+      unsigned wbase = 0, all = 0;
+      for (unsigned k = 0; k < SCAN1_THREADS / COOK_WAVE; ++k) {
+        const unsigned x = wsum[s & 1][k];
+        wbase += k < w ? x : 0u;
+        all += x;
+      }
+      unsigned run = carry + wbase + inc - tot;  // exclusive prefix of this thread's first entry
+#pragma unroll
+      for (int q = 0; q < SCAN1_IPT; ++q) {
+        if (i0 + q < len) data[i0 + q] = run;
+        run += v[s][q];
+      }
+      carry += all;
+    }
   }
-  if (total_out && threadIdx.x == 0) *total_out = carry_s;
+  if (total_out && threadIdx.x == 0) *total_out = carry;
 }
 
 __global__ void __launch_bounds__(RS_THREADS) radix_scatter(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm_in,
