@@ -879,13 +879,9 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
   if (world_solo) defer = true;
   if (defer && !((algo == 0 || algo == 2 || algo == 5) && K > 0)) defer = false;  // only the window-round orchestrations run several pools
   if (algo == 1) {  // one-job-at-a-time sweep by a single workgroup (reference implementation of the chain)
-#ifdef __HIP_EMU__
-    auto k_match = match_serial<256>;
-    KL("match_serial", k_match, 1, 256, in, st);
-#else
-    auto k_match = match_serial<1024>;
-    KL("match_serial", k_match, 1, 1024, in, st);
-#endif
+    constexpr int SERIAL_THREADS = COOK_SHAPE(1024, 256);
+    auto k_match = match_serial<SERIAL_THREADS>;
+    KL("match_serial", k_match, 1, SERIAL_THREADS, in, st);
   } else if (K > 0) {  // window rounds: eval -> merge -> resolve (match_v2.hpp)
     V2Buf vb;
     const char* rlog_path = std::getenv("COOK_ROUND_LOG");  // diagnostics: one CSV line per round of the last match
@@ -946,14 +942,11 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
       PersistCtl* pc = e->w_pctl.ensure(1);
       COOK_HIP(hipMemsetAsync(pc, 0, sizeof(PersistCtl), e->stream));
-#ifdef __HIP_EMU__
-      const unsigned nwg = 1;  // the emulator runs one workgroup at a time
-#else
-      const int sharing = std::max(1, g_engines_on_device[e->device & 63].load());
       // every workgroup holds ~150 KB of LDS = one per CU; leave a quarter of the CUs to the other kernels in flight
+      const int sharing = std::max(1, g_engines_on_device[e->device & 63].load());
       unsigned nwg = (unsigned)std::max(4, std::min(64, e->n_cus * 3 / (4 * sharing)));
       nwg = std::min(nwg, std::max(1u, C * (unsigned)MV_JG));
-#endif
+      if (!COOK_COOP_GRIDS) nwg = 1;  // (a build whose launches run one workgroup at a time)
       KL("match_persist", match_persist, nwg, COOK_WAVE * MV_EW, in, st, vb, pc, 0x7FFFFFFFu);
       COOK_HIP(hipMemcpyAsync(e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
       COOK_HIP(hipMemcpyAsync(e->h_scratch + 32, pc, sizeof(PersistCtl), hipMemcpyDeviceToHost, e->stream));
@@ -1156,15 +1149,11 @@ bool match_rounds_world(cook_engine** es, unsigned n) {
   if (L > MW_MAX_POOLS || L > 64) return false;
   for (unsigned x = 0; x < L; ++x)
     if (es[live[x]]->deferred_k >= (1u << 22) || MV_WLONG > 4096) return false;  // world_pack's field widths
-#ifdef __HIP_EMU__
-  const unsigned n_eval = 2;
-#else
   // one workgroup per CU (the walker's LDS): all of them resident at once, a few CUs left to whatever else runs on the GPU
-  int want = lead->n_cus - (int)L - 8;
+  int want = COOK_COOP_GRIDS ? lead->n_cus - (int)L - 8 : 2;
   if (const char* ev = std::getenv("COOK_WORLD_EVAL_WGS")) want = std::atoi(ev);
-  if (want < 4) return false;
+  if (want < (COOK_COOP_GRIDS ? 4 : 1)) return false;
   const unsigned n_eval = (unsigned)want;
-#endif
   if (!lead->h_multi) COOK_HIP(hipHostMalloc((void**)&lead->h_multi, 64 * sizeof(WinCtl), hipHostMallocDefault));
   std::vector<PoolCtx> hctx(L);
   for (unsigned x = 0; x < L; ++x) hctx[x] = es[live[x]]->deferred;
@@ -1304,11 +1293,7 @@ int guarded(cook_engine* e, F&& f) {
 extern "C" {
 
 const char* cook_version(void) {
-#ifdef __HIP_EMU__
-  return "cookmatch 0.1.0 (simt-emu test build)";
-#else
-  return "cookmatch 0.1.0 (hip gfx950)";
-#endif
+  return "cookmatch 0.2.0 (" COOK_BUILD_NAME ")";
 }
 
 int cook_engine_create(const cook_params* params, int device_id, cook_engine** out) {
@@ -1802,15 +1787,7 @@ int cook_match_stats(cook_engine* e, uint32_t out[16]) {
   out[15] = (uint32_t)((c.t_merge + e->world_wait_merge) / 100ull);
   return COOK_OK;
 }
-#ifdef __HIP_EMU__
-// emulated build only (design studies): the walk statistics of match_v2.hpp, cumulative; reset != 0 clears them afterwards
-int cook_emu_walk_stats(unsigned long long out[12], int reset) {
-  for (int i = 0; i < 12; ++i) out[i] = g_walk_stats[i];
-  if (reset)
-    for (int i = 0; i < 12; ++i) g_walk_stats[i] = 0;
-  return COOK_OK;
-}
-#endif
+COOK_EMU_EXTRA_EXPORTS
 int cook_set_profiling(cook_engine* e, int enabled) {
   if (!e) return COOK_E_INVALID;
   e->profiling = enabled != 0;

@@ -49,11 +49,7 @@ constexpr int MV_EW = COOK_MV_EW;          // waves per eval block (same 64 jobs
 constexpr int MV_OCB = MV_OCW * MV_EW;     // offers per eval block
 constexpr int MV_T = COOK_WAVE;            // touched offers per round = lanes of the walking wave
 #ifndef COOK_MV_RTHREADS
-#ifdef __HIP_EMU__
-#define COOK_MV_RTHREADS 256  // fewer fibers per block: the emulated tests stay fast (the strides are blockDim.x either way)
-#else
-#define COOK_MV_RTHREADS 768
-#endif
+#define COOK_MV_RTHREADS COOK_SHAPE(768, 256)  // (the emulated tests: fewer fibers per block; the strides are blockDim.x either way)
 #endif
 constexpr int MV_RTHREADS = COOK_MV_RTHREADS;  // threads of the resolve workgroup: the set-up phase is parallel over them (256 -> 768: 9.2 -> 5.1 ms
                                                // per C4 pool), wave 0 walks.  resolve_round strides by blockDim.x, so the persistent
@@ -63,14 +59,10 @@ constexpr int MV_RWAVES_MAX = (MV_RTHREADS > COOK_WAVE * MV_EW ? MV_RTHREADS : C
 constexpr int MV_WMAX = COOK_MV_WMAX;
 constexpr int MV_S = COOK_MV_S;
 constexpr int MV_HASH = 4 * COOK_MV_S;
-#elif defined(__HIP_EMU__)
-constexpr int MV_WMAX = 128;               // jobs per round (emulator: small, so that tests run many rounds)
-constexpr int MV_S = 128;                  // distinct candidate offers staged per round
-constexpr int MV_HASH = 512;
 #else
-constexpr int MV_WMAX = 512;
-constexpr int MV_S = 256;
-constexpr int MV_HASH = 1024;
+constexpr int MV_WMAX = COOK_SHAPE(512, 128);  // jobs per round (the emulated tests: small, so that small inputs run many rounds)
+constexpr int MV_S = COOK_SHAPE(256, 128);     // distinct candidate offers staged per round
+constexpr int MV_HASH = COOK_SHAPE(1024, 512);
 #endif
 constexpr int MV_JG = MV_WMAX / 64;        // job groups (waves of jobs) per window whose walk data fits the resolve workgroup's LDS
 // A window may grow to MV_WLONG jobs once next to nothing of it has to be WALKED: when the cluster is full almost every job is
@@ -154,30 +146,7 @@ struct alignas(16) ChunkRec {
   unsigned cnt[4];    // n | nge << 8, offers failing on resources / constraints / zero fitness
 };
 static_assert(sizeof(ChunkRec) % 16 == 0, "ChunkRec is moved in 16-byte pieces");
-#ifdef __HIP_EMU__
-static inline void chunk_store(ChunkRec* dst, const ChunkRec& r, bool) { *dst = r; }
-#else
-// through: write-through (sc1) stores — the record is in memory, visible to every XCD, once the wave's vmcnt drains
-static __device__ __forceinline__ void chunk_store(ChunkRec* dst, const ChunkRec& r, bool through) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  constexpr unsigned NP = sizeof(ChunkRec) / 16;
-  u32x4 piece[NP];
-  __builtin_memcpy(piece, &r, sizeof(ChunkRec));  // (not a pointer cast: the record's fields are doubles and ints)
-  u32x4* d = reinterpret_cast<u32x4*>(dst);
-#pragma unroll
-  for (unsigned x = 0; x < NP; ++x) {
-    if (through) {
-      u32x4* a = d + x;
-      // s_nop: a VMEM store of more than 64 bits reads its data registers AFTER issue, and the compiler's hazard recogniser does
-      // not see into inline asm — without the wait state it re-used the data registers for the next address (seen in the ISA:
-      // v_lshl_add_u64 into v[4:5] right behind a store of v[4:7]) and the records went out corrupted
-      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(a), "v"(piece[x]) : "memory");
-    } else {
-      d[x] = piece[x];
-    }
-  }
-}
-#endif
+// (chunk_store: platform.hpp)
 
 struct V2Buf {
   RoundLog* round_log;
@@ -821,12 +790,17 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
   }
   int n_out = 0;
   for (int round = 0; round < MV_L; ++round) {
-    Cand best{tf[0], ti[0]};
-    for (int d = 32; d >= 1; d >>= 1) {
-      const Cand o{__shfl_xor(best.fit, d, COOK_WAVE), __shfl_xor(best.idx, d, COOK_WAVE)};
-      if (cand_better(o, best)) best = o;
-    }
-    if (best.idx < 0) break;  // wave-uniform
+    // the best head over the lanes: greatest fitness (positive doubles order like their bit patterns), lowest offer index among
+    // equal ones — two DPP reductions instead of six rounds of three ds_bpermute shuffles
+    const unsigned long long key = ti[0] >= 0 ? (unsigned long long)__double_as_longlong(tf[0]) : 0ull;
+    const unsigned long long mk = wave_max_u64(key);
+    if (mk == 0ull) break;  // wave-uniform
+    const unsigned long long tie = __ballot(key == mk);
+    Cand best{__longlong_as_double((long long)mk), 0};
+    if ((tie & (tie - 1ull)) == 0ull)
+      best.idx = wave_read_lane(ti[0], __ffsll((unsigned long long)tie) - 1);
+    else
+      best.idx = (int)(0x7FFFFFFFu - wave_max_u32(key == mk ? 0x7FFFFFFFu - (unsigned)ti[0] : 0u));
     if (lane == 0) {
       if (THROUGH) {
         st_agent(&vb.cand_fit[(size_t)b * MV_L + round], best.fit);
@@ -923,17 +897,7 @@ static __device__ __attribute__((noinline)) bool group_pass_dev(const MatchIn* i
   return group_pass(*in, st, jj, v);
 }
 
-#ifdef __HIP_EMU__
-// walk statistics of the emulated build (design studies, scripts/study_rounds.py): [0] jobs walked, [1] settled by the shortcut
-// (no candidate under S), [2] went through the exact path, [3] won by an offer touched earlier in the round, [4] won by an
-// untouched offer (a new touched lane), [5] walked and unmatched, [6] sum of touched lanes at decision time, [7] won by the very
-// lane that took the previous walked job
-inline unsigned long long g_walk_stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [8] decided by the fast path
-inline int g_walk_prev_lane = -1;  // lane that took the previous walked job of the round ([7]: a touched offer won AND it is that lane)
-#define WALK_STAT(i, v) do { if (lane == 0) g_walk_stats[i] += (v); } while (0)
-#else
-#define WALK_STAT(i, v) ((void)0)
-#endif
+// (WALK_STAT: platform.hpp — counters of the emulated build's design studies, nothing on the GPU)
 
 struct ResolveLds {
   JobL job[MV_WMAX];          // the jobs the walk visits, in rank order (walk position i; JobL::b = window position)
@@ -1892,13 +1856,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     if (win_lane >= 0) WALK_STAT(3, 1);
     else if (win >= 0) WALK_STAT(4, 1);
     else WALK_STAT(5, 1);
-#ifdef __HIP_EMU__
-    if (lane == 0) {
-      if (i == 0) g_walk_prev_lane = -1;
-      if (win_lane >= 0 && win_lane == g_walk_prev_lane) g_walk_stats[7] += 1;
-      g_walk_prev_lane = win_lane >= 0 ? win_lane : (win >= 0 ? (int)nT : -1);
-    }
-#endif
+    WALK_STAT_PREV_LANE(i, win_lane, win, nT);
 #ifdef COOK_WALK_PROF
     pcat = grouped ? 4u : (win >= 0 || win_lane >= 0 ? 5u : 3u);
 #endif
@@ -2157,9 +2115,7 @@ static __device__ __forceinline__ bool grid_barrier(PersistCtl* pc, unsigned nbl
             ok = 0;
             break;
           }
-#ifndef __HIP_EMU__
-          __builtin_amdgcn_s_sleep(4);
-#endif
+          SPIN_PAUSE_LONG();
           if (cook_ticks() - t0 > MV_BARRIER_TIMEOUT_TICKS) {
             st_agent(&pc->error, 1u);
             ok = 0;

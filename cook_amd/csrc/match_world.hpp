@@ -24,12 +24,9 @@
 #include "match_v2.hpp"
 
 #ifndef COOK_MW_THREADS
-#ifdef __HIP_EMU__
-#define COOK_MW_THREADS 256  // fewer fibers per block (the emulator runs every block of this kernel at the same time): ONE team
-#else
-#define COOK_MW_THREADS 512  // 2 waves per SIMD: 256 VGPRs each.  At 768 threads (168 VGPRs) the evaluator's lane state spilled
-                             // (752 bytes of scratch per lane)
-#endif
+// 512: 2 waves per SIMD, 256 VGPRs each.  At 768 threads (168 VGPRs) the evaluator's lane state spilled (752 bytes of scratch per
+// lane).  (The emulated tests: 256 = ONE team; the emulator runs every block of this kernel at the same time.)
+#define COOK_MW_THREADS COOK_SHAPE(512, 256)
 #endif
 constexpr int MW_THREADS = COOK_MW_THREADS;
 constexpr int MW_WAVES = MW_THREADS / COOK_WAVE;

@@ -486,7 +486,6 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   if (R) KL("rebal_mirror_dru", rebal_mirror_dru, div_up(R, 256), 256, (const uint32_t*)b.h_pb.ptr(), (const double*)b.dru.ptr(), R, b.h_dru.ptr());
   // ---- the decision loop (rebalancer.clj:442-458) ---------------------------------------------------------------------------------
   const RebalIn in = rebalance_args(e, b);
-  const unsigned gH = div_up(std::max(1u, H), RB_WAVES);
   for (unsigned pj = 0; pj < P; ++pj) {
     KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, pj);
     if (H) KL("rebal_decide", rebal_decide, div_up(div_up(H, 2u), RB_WAVES), COOK_WAVE * RB_WAVES, in);

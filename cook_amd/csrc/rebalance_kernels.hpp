@@ -309,11 +309,8 @@ __global__ void __launch_bounds__(256) rebal_mirror_dru(const uint32_t* __restri
 // one.  Masked prefix sums with exactness tracking in three steps (tile-local scans, per-user scan of the tile totals, carry +
 // DRU) — any association is the left-to-right sum when no addition rounded; a user where one did is redone sequentially
 // (rebal_rs_fix, as rebal_fix_inexact does).  The DRUs also go to the host-ordered mirror.
-#ifdef __HIP_EMU__
-constexpr int RB_RS_TILE = 256, RB_RS_GRID = 4, RB_RS_USERS = 4;  // few fibers per launch; small tiles = many-tile users in small tests
-#else
-constexpr int RB_RS_TILE = 1024, RB_RS_GRID = 256, RB_RS_USERS = 64;
-#endif
+// (the emulated tests: few fibers per launch; small tiles = many-tile users in small tests)
+constexpr int RB_RS_TILE = COOK_SHAPE(1024, 256), RB_RS_GRID = COOK_SHAPE(256, 4), RB_RS_USERS = COOK_SHAPE(64, 4);
 static __device__ __forceinline__ unsigned rebal_rs_user_of_tile(const RebalIn& in, unsigned n_chg, unsigned tile) {
   unsigned lo = 0, hi = n_chg;  // last x with chg_tile[x] <= tile
   while (hi - lo > 1) {

@@ -274,8 +274,11 @@ int cook_rank_fetch(cook_engine* e, uint32_t* ranked_pending_idx, uint32_t* n_ou
  * running usage (state advances on rejected jobs too), launch-rate-limit filter (the n-th surviving job of a user is
  * limited iff n > tokens_left; dropped only when enforcing), pool quota filter seeded with the pool usage, eligible
  * mask, take num_considerable.  considerable_idx receives queue positions (capacity min(num_considerable, queue->n)).
- * rate_limited / passed (optional, len users): per-user counts of the rate-limit stage over the WHOLE queue (the
- * reference's lazy pipeline only counts the jobs it consumed before `take` was satisfied: unpinned). */
+ * rate_limited / passed (optional, len users): per-user counts of the rate-limit stage over the WHOLE queue.  These are UPPER
+ * BOUNDS of what the reference stores in pool->user->num-rate-limited-jobs: its lazy pipeline only counts the jobs it consumed
+ * (in chunks of 32) before `take num-considerable` was satisfied, so for a queue longer than that the reference's counts stop
+ * early.  The considerable jobs themselves do not depend on it.  A caller that shows the counts (the /unscheduled_jobs reason)
+ * should present them as "at least one job rate-limited" rather than as exact numbers (oracle-defined). */
 int cook_considerable(cook_engine* e, const cook_queue* queue, const cook_user_state* users, uint32_t num_considerable,
                       uint32_t* considerable_idx, uint32_t* n_out, uint32_t* rate_limited, uint32_t* passed);
 /* Same filters inside cook_cycle_run, between rank and match, with no host round trip: `users` as above (copied to the

@@ -7,19 +7,27 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "libcookmatch_emu.so")
+OUT_SHIPPED = os.path.join(HERE, "libcookmatch_emu_shipped.so")  # the shipped launch shapes (window 512, 256 slots, 768-thread resolve ...)
 SRC = os.path.join(ROOT, "cook_amd", "csrc", "engine.hip")
 DEPS = [os.path.join(ROOT, "cook_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "cook_amd", "csrc"))] + [
-    os.path.join(HERE, "emu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "cookmatch.h")]
+    os.path.join(HERE, "emu.cpp"), os.path.join(HERE, "emu_prims.hpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
+    os.path.join(ROOT, "include", "cookmatch.h")]
 
 
-def build(force=False):
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in DEPS):
-        return OUT
+def build(force=False, shipped_shapes=False):
+    """shipped_shapes: compile with the launch shapes of the GPU build (cook_amd/csrc/platform.hpp COOK_SHAPE) instead of the small
+    ones the emulated suite normally runs with — slower (768 fibers per resolve block), used by tests/test_parity_emu_shipped.py"""
+    out = OUT_SHIPPED if shipped_shapes else OUT
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in DEPS):
+        return out
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-I", HERE, "-x", "c++", SRC,
-           os.path.join(HERE, "emu.cpp"), "-o", OUT]
+           os.path.join(HERE, "emu.cpp"), "-o", out]
+    if shipped_shapes:
+        cmd.insert(1, "-DCOOK_EMU_SHIPPED_SHAPES")
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force=True))
+    import sys
+    print(build(force=True, shipped_shapes="--shipped" in sys.argv))
