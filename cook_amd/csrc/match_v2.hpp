@@ -765,12 +765,18 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
     c2 += R.cnt[2];
     c4 += R.cnt[3];
     const int n = (int)(info & 0xFFu), ng = (int)((info >> 8) & 0xFFu);
+    if (ch < (unsigned)COOK_WAVE) {  // the lane's first chunk (its only one up to 64 chunks = 8 192 offers): the sorted list as it is
 #pragma unroll
-    for (int q = 0; q < MV_L; ++q) {
-      if (q >= n) break;
-      const Cand o{R.fit[q], R.idx[q]};
-      if (!cand_better(o, Cand{tf[MV_L - 1], ti[MV_L - 1]})) break;  // chunk list is sorted: nothing further can enter
-      topl_insert<MV_L>(tf, ti, o.fit, o.idx);
+      for (int q = 0; q < MV_L; ++q)
+        if (q < n) tf[q] = R.fit[q], ti[q] = R.idx[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < MV_L; ++q) {
+        if (q >= n) break;
+        const Cand o{R.fit[q], R.idx[q]};
+        if (!cand_better(o, Cand{tf[MV_L - 1], ti[MV_L - 1]})) break;  // chunk list is sorted: nothing further can enter
+        topl_insert<MV_L>(tf, ti, o.fit, o.idx);
+      }
     }
     if (use_ge)
 #pragma unroll

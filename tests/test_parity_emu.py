@@ -505,3 +505,13 @@ def test_rebalance_gpu_maps_with_several_models(make_engine):
     got = P.rebalance_parity(make_engine, P.make_rebalance_case(seed=59, n_running=500, n_pending=60, n_users=15, n_hosts=40, constraints=True,
                                                                 gpus=True, gpu_slots=2))
     assert len(got["decisions"]) > 0
+
+
+def test_match_more_offer_chunks_than_lanes(make_engine):
+    # more than 64 chunks of 128 offers: a merge lane folds several chunk lists (the first as it is, the rest by insertion)
+    rng = np.random.default_rng(81)
+    m, n = 8500, 160
+    offers = A.Offers(cpus=rng.integers(1, 9, m).astype(float), mem=rng.integers(1, 9, m) * 1024.0)
+    jobs = A.Jobs(cpus=rng.integers(1, 5, n).astype(float), mem=rng.integers(1, 5, n) * 1024.0)
+    for ge in (1.0, 0.7):
+        P.match_parity(make_engine, jobs, offers, None, A.default_params(good_enough_fitness=ge))
