@@ -989,7 +989,35 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       unsigned guard = 0;
       while (hc.head < K) {
         for (unsigned r = 0; r < batch; ++r) {
+#ifdef COOK_EVAL_TRACE
+          {
+            static int launches = 0;
+            static DArr<unsigned long long> tr;
+            ++launches;
+            vb.eval_trace = tr.ensure((size_t)C * MV_JG * 19 + 3);
+            if (launches == 60 || launches == 300) COOK_HIP(hipMemsetAsync(vb.eval_trace, 0, (size_t)C * MV_JG * 19 * 8, e->stream));
+            KL("match_eval2", match_eval2, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
+            if (launches == 60 || launches == 300) {
+              std::vector<unsigned long long> h((size_t)C * MV_JG * 19);
+              sync(e);
+              COOK_HIP(hipMemcpy(h.data(), vb.eval_trace, h.size() * 8, hipMemcpyDeviceToHost));
+              unsigned long long tmin = ~0ull, tmax = 0;
+              const size_t nb3 = (size_t)C * MV_JG * 3;
+              for (size_t x = 0; x < nb3; x += 3)
+                if (h[x]) tmin = std::min(tmin, h[x]), tmax = std::max(tmax, h[x + 1]);
+              std::fprintf(stderr, "EVALTRACE launch %d blocks %u span %.2f us\n", launches, C * MV_JG, (tmax - tmin) / 100.0);
+              for (size_t bq = 0; bq < (size_t)C * MV_JG; ++bq)
+                for (int wv = 0; wv < 4; ++wv) {
+                  const unsigned long long* q = &h[nb3 + bq * 16 + wv * 4];
+                  if (q[0]) std::fprintf(stderr, "EVALPHASE blk %zu wave %d setup %.2f scan %.2f merge %.2f (start %.2f)\n", bq, wv, (q[1] - q[0]) / 100.0, (q[2] - q[1]) / 100.0, q[3] ? (q[3] - q[2]) / 100.0 : -1.0, (q[0] - tmin) / 100.0);
+                }
+              for (size_t x = 0; x < nb3; x += 3)
+                if (h[x]) std::fprintf(stderr, "EVALTRACE blk %zu start %.2f end %.2f hwid %llx\n", x / 3, (h[x] - tmin) / 100.0, (h[x + 1] - tmin) / 100.0, h[x + 2]);
+            }
+          }
+#else
           KL("match_eval2", match_eval2, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
+#endif
           KL("match_merge2", match_merge2, MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, vb);
           if (c0.reeval_max != 0u)
             KL("match_resolve2", match_resolve2_reeval, 1, MV_RTHREADS, st, vb);

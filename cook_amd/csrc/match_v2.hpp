@@ -30,6 +30,13 @@
 #include "common.hpp"
 #include "match_kernels.hpp"
 
+// waves per SIMD the eval kernels are compiled for (-DCOOK_EVAL_WAVES=n builds a tuning variant: fewer registers, more waves)
+#ifdef COOK_EVAL_WAVES
+#define COOK_EVAL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(COOK_EVAL_WAVES, COOK_EVAL_WAVES)))
+#else
+#define COOK_EVAL_OCCUPANCY
+#endif
+
 #ifndef COOK_MV_L
 #define COOK_MV_L 8
 #endif
@@ -150,6 +157,9 @@ static_assert(sizeof(ChunkRec) % 16 == 0, "ChunkRec is moved in 16-byte pieces")
 
 struct V2Buf {
   RoundLog* round_log;
+#ifdef COOK_EVAL_TRACE
+  unsigned long long* eval_trace;  // timing study build: per eval block [start, end] ticks of the 100 MHz clock + HW_ID
+#endif
   const OfferA* oa;
   const OfferB* ob;
   const JobRec* jr;
@@ -341,6 +351,23 @@ static __device__ __forceinline__ void topl_insert(double (&tf)[N], int (&ti)[N]
   }
 }
 
+// The same for a lane that meets its offers in ASCENDING index order (a wave's walk over its offer batch): a new entry only passes
+// entries it beats strictly, so position = number of entries it beats — N independent compares and a shift by selects, no
+// dependent compare-swap chain (the insertion was a third of the eval wave's time).
+template <int N>
+static __device__ __forceinline__ void topl_insert_ascending(double (&tf)[N], int (&ti)[N], double fit, int idx) {
+  bool g[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) g[q] = fit > tf[q];  // monotone in q: the list descends (empty entries hold -1)
+#pragma unroll
+  for (int q = N - 1; q > 0; --q) {
+    tf[q] = g[q - 1] ? tf[q - 1] : (g[q] ? fit : tf[q]);
+    ti[q] = g[q - 1] ? ti[q - 1] : (g[q] ? idx : ti[q]);
+  }
+  tf[0] = g[0] ? fit : tf[0];
+  ti[0] = g[0] ? idx : ti[0];
+}
+
 // ---- eval ------------------------------------------------------------------------------------------------------------------
 struct EvalWaveLds {  // what ONE wave stages for the offers it walks (MV_OCW at a time): the offer loop then reads LDS broadcasts only
   OfferA oa[MV_OCW];
@@ -362,7 +389,13 @@ struct EvalLane {
   bool valid, slow, grouped, fastc, use_ge;
   JobRec j;
   unsigned jj;
-  JobCons jc;
+  // the job's fast constraints (JobCons) in the form the offer loop checks without a per-lane LDS look-up: per attribute key staged
+  // in LDS the required value and an all-ones mask when the key is constrained (the offer's values are wave-uniform), the required
+  // HOSTNAME value, the hosts to avoid (0xFFFFFFFF = unused), and "cannot be satisfied by any offer"
+  unsigned req[MV_NA], wild[MV_NA];
+  unsigned req_host, wild_host;
+  unsigned novel[MV_NC];
+  bool impossible;
   unsigned fh[MV_FH];
   int n_fh;
   int glast;  // the group's last placed job under the snapshot (-1 none; members of a group only)
@@ -394,10 +427,37 @@ static __device__ __forceinline__ void eval_lane_setup(EvalLane& E, const MatchI
   E.slow = (E.j.flags & JF_SLOW) != 0;
   E.grouped = (E.j.flags & JF_GROUPED) != 0;
   E.fastc = !E.slow && (E.j.flags & JF_FASTC) != 0;
-  E.jc.n_eq = E.jc.n_novel = 0;
 #pragma unroll
-  for (int q = 0; q < MV_NC; ++q) E.jc.eq_key[q] = E.jc.eq_val[q] = E.jc.novel[q] = 0u;
-  if (E.fastc) E.jc = vb.jcons[k];
+  for (int q = 0; q < MV_NA; ++q) E.req[q] = E.wild[q] = 0u;
+  E.req_host = E.wild_host = 0u;
+#pragma unroll
+  for (int q = 0; q < MV_NC; ++q) E.novel[q] = 0xFFFFFFFFu;
+  E.impossible = false;
+  if (E.fastc) {
+    const JobCons jc = vb.jcons[k];
+#pragma unroll
+    for (int q = 0; q < MV_NC; ++q) {
+      if ((unsigned)q < jc.n_novel) E.novel[q] = jc.novel[q];
+      if ((unsigned)q < jc.n_eq) {
+        const unsigned key = jc.eq_key[q], val = jc.eq_val[q];
+        if (key == 0xFFFFFFFFu) {  // "HOSTNAME" (value = host id + 1)
+          if (E.wild_host && E.req_host != val) E.impossible = true;
+          E.req_host = val;
+          E.wild_host = 0xFFFFFFFFu;
+        } else if (key >= (unsigned)MV_NA) {  // beyond the offers' attribute table: every offer reads as absent (0)
+          if (val != 0u) E.impossible = true;
+        } else {
+#pragma unroll
+          for (int a = 0; a < MV_NA; ++a)
+            if ((unsigned)a == key) {
+              if (E.wild[a] && E.req[a] != val) E.impossible = true;
+              E.req[a] = val;
+              E.wild[a] = 0xFFFFFFFFu;
+            }
+        }
+      }
+    }
+  }
   // unique host-placement groups (constraints.clj:586-598): the hosts to avoid = running cotasks ++ cotasks placed by
   // earlier rounds of this call, gathered ONCE per tile into registers (n_fh = -1: not such a job, -2: too many -> slow path)
   E.n_fh = -1;
@@ -485,16 +545,14 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
     const OfferB o = W.ob[vi];
     const int acount = W.oacount[vi];
     bool stat = res && static_fast(j, o, in, v);
-    if (stat && E.fastc) {  // novel-host (constraints.clj:68-94) and user-defined EQUALS (:356-377) from registers + LDS
+    {  // novel-host (constraints.clj:68-94) and user-defined EQUALS (:356-377): the offer's host and attribute values are wave-uniform
+      unsigned diff = (E.req_host ^ (o.host + 1u)) & E.wild_host;
 #pragma unroll
-      for (int q = 0; q < MV_NC; ++q) {
-        if ((unsigned)q < E.jc.n_novel && E.jc.novel[q] == o.host) stat = false;
-        if ((unsigned)q < E.jc.n_eq) {
-          const unsigned key = E.jc.eq_key[q];
-          const unsigned val = key == 0xFFFFFFFFu ? o.host + 1u : (key < (unsigned)MV_NA ? W.attr[vi][key] : 0u);
-          if (val != E.jc.eq_val[q]) stat = false;
-        }
-      }
+      for (int a = 0; a < MV_NA; ++a) diff |= (E.req[a] ^ W.attr[vi][a]) & E.wild[a];
+      bool hit = E.impossible;
+#pragma unroll
+      for (int q = 0; q < MV_NC; ++q) hit = hit | (E.novel[q] == o.host);
+      stat = stat && diff == 0u && !hit;
     }
     if (stat && E.slow) stat = static_pass(in, E.jj, v);
     const unsigned long long bits = __ballot(stat);
@@ -503,14 +561,14 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
       else vb.colbits[(size_t)v * MV_JGL + jg] = bits;
     }
     bool feas = stat && dyn_fast(j, o, acount);
-    if (feas && E.grouped) {
-      if (E.n_fh >= 0) {
+    {  // unique host-placement groups: the hosts to avoid sit in registers (0xFFFFFFFF for everybody else)
+      bool taken = false;
 #pragma unroll
-        for (int q = 0; q < MV_FH; ++q)
-          if (E.fh[q] == o.host) feas = false;
-      } else {
-        feas = group_pass(in, st, E.jj, v);
-      }
+      for (int q = 0; q < MV_FH; ++q) taken = taken | (E.fh[q] == o.host);
+      feas = feas && !taken;
+    }
+    if (__any(E.grouped && E.n_fh < 0)) {  // (wave-uniform) balanced / attribute-equals groups, or too many hosts: the general walk
+      if (feas && E.grouped && E.n_fh < 0) feas = group_pass(in, st, E.jj, v);
     }
     E.c1 += (valid && !res) ? 1u : 0u;
     E.c2 += (res && !feas) ? 1u : 0u;
@@ -525,7 +583,7 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
           E.c4 += 1u;
         } else {
           if (fit > E.tf[MV_L - 1]) {
-            topl_insert<MV_L>(E.tf, E.ti, fit, (int)v);
+            topl_insert_ascending<MV_L>(E.tf, E.ti, fit, (int)v);
             if (E.ti[MV_L - 1] >= 0) E.thr = E.tf[MV_L - 1] * (1.0 - 0x1p-40);
           }
           if (E.use_ge && fit > E.ge && E.n_ge < MV_LG) {
@@ -576,8 +634,18 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
   const unsigned lane = lane_id();
   const unsigned b = jg * COOK_WAVE + lane;
   EvalLane E;
+#ifdef COOK_EVAL_TRACE
+  unsigned long long* trp = vb.eval_trace ? vb.eval_trace + (size_t)vb.C * MV_JG * 3 + ((size_t)jg * vb.C + ch) * 16 + w * 4 : nullptr;
+  if (trp && lane == 0) trp[0] = cook_ticks();
+#endif
   eval_lane_setup(E, in, st, vb, head, wcur, jg);
+#ifdef COOK_EVAL_TRACE
+  if (trp && lane == 0) trp[1] = cook_ticks();
+#endif
   eval_scan_offers<THROUGH>(E, L.wave[w], in, st, vb, ch * MV_OCB + w * MV_OCW, jg);
+#ifdef COOK_EVAL_TRACE
+  if (trp && lane == 0) trp[2] = cook_ticks();
+#endif
   const bool valid = E.valid, use_ge = E.use_ge;
   // ---- merge the block's MV_EW wave lists per job through LDS -------------------------------------------------------
 #pragma unroll
@@ -678,6 +746,9 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
   R.cnt[2] = t2;
   R.cnt[3] = t4;
   chunk_store(&vb.prec[(size_t)b * vb.C + ch], R, THROUGH);
+#ifdef COOK_EVAL_TRACE
+  if (trp && lane == 0) trp[3] = cook_ticks();
+#endif
 }
 static __device__ __forceinline__ void eval_tile(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
                                                  unsigned wcur, unsigned ch, unsigned jg) {
@@ -735,9 +806,21 @@ static __device__ __forceinline__ void eval_block(char* lds, const MatchIn& in, 
   const unsigned w = wave_id();
   for (unsigned jg = gy * MV_EW + w; jg * COOK_WAVE < wcur; jg += ny * MV_EW) eval_tile_wave<false>(L.wave[w], in, st, vb, head, wcur, ch, jg);
 }
-__global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2(MatchIn in, MatchState st, V2Buf vb) {
+__global__ void __launch_bounds__(COOK_WAVE* MV_EW) COOK_EVAL_OCCUPANCY match_eval2(MatchIn in, MatchState st, V2Buf vb) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(EvalLds)];
+#ifdef COOK_EVAL_TRACE
+  const unsigned long long t0 = cook_ticks();
+#endif
   eval_block(lds, in, st, vb, vb.ctl->head, vb.ctl->wcur, blockIdx.x, blockIdx.y, gridDim.y);
+#ifdef COOK_EVAL_TRACE
+  __syncthreads();
+  if (vb.eval_trace && threadIdx.x == 0) {
+    const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
+    vb.eval_trace[blk * 3 + 0] = t0;
+    vb.eval_trace[blk * 3 + 1] = cook_ticks();
+    vb.eval_trace[blk * 3 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+  }
+#endif
 }
 
 // ---- merge: one wave per job ---------------------------------------------------------------------------------------------
@@ -2181,7 +2264,7 @@ struct PoolCtx {
   MatchState st;
   V2Buf vb;
 };
-__global__ void __launch_bounds__(COOK_WAVE* MV_EW) match_eval2_multi(const PoolCtx* __restrict__ ctx) {
+__global__ void __launch_bounds__(COOK_WAVE* MV_EW) COOK_EVAL_OCCUPANCY match_eval2_multi(const PoolCtx* __restrict__ ctx) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(EvalLds)];
   const PoolCtx& c = ctx[blockIdx.z];
   if (blockIdx.x >= c.vb.C) return;  // pools may differ in their number of offers
