@@ -9,7 +9,6 @@
 #define COOK_WAVE 64
 
 static __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & (COOK_WAVE - 1); }
-static __device__ __forceinline__ unsigned wave_id() { return threadIdx.x >> 6; }
 
 static __device__ __forceinline__ unsigned long long lanemask_lt() {
   const unsigned l = lane_id();
@@ -17,6 +16,11 @@ static __device__ __forceinline__ unsigned long long lanemask_lt() {
 }
 
 #include "platform.hpp"
+
+// the wave's index in its workgroup, IN A SCALAR REGISTER: threadIdx.x >> 6 is the same in all 64 lanes, but the compiler cannot
+// know that, and everything derived from it (which offers / hosts / jobs the wave works on) would be per-lane address arithmetic,
+// vector loads and exec-mask loops instead of scalar loads and scalar branches
+static __device__ __forceinline__ unsigned wave_id() { return wave_uniform_u32(threadIdx.x >> 6); }
 
 static __device__ __forceinline__ double wave_read_lane_f64(double v, int src) {
   const long long b = __double_as_longlong(v);

@@ -368,6 +368,17 @@ static __device__ __forceinline__ void topl_insert_ascending(double (&tf)[N], in
   ti[0] = g[0] ? idx : ti[0];
 }
 
+// The rare paths of the offer loops as real calls on the device copy of MatchIn: inlined, their CSR walks kept some forty kernel
+// arguments alive across the loop and the compiler spilled scalar registers into VGPR lanes (281 v_readlane restores per offer
+// iteration of the eval kernel).
+static __device__ __attribute__((noinline)) bool group_pass_dev(const MatchIn* in, MatchState st, unsigned jj, unsigned v) {
+  return group_pass(*in, st, jj, v);
+}
+static __device__ __attribute__((noinline)) bool static_pass_dev(const MatchIn* in, unsigned jj, unsigned v) { return static_pass(*in, jj, v); }
+static __device__ __attribute__((noinline)) unsigned xres_fail_dev(const MatchIn* in, MatchState st, unsigned jj, unsigned v) {
+  return xres_fail_bits(*in, st, jj, v);
+}
+
 // ---- eval ------------------------------------------------------------------------------------------------------------------
 struct EvalWaveLds {  // what ONE wave stages for the offers it walks (MV_OCW at a time): the offer loop then reads LDS broadcasts only
   OfferA oa[MV_OCW];
@@ -528,11 +539,18 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
     const unsigned vi = (unsigned)__ffsll((unsigned long long)live) - 1u;
     live &= live - 1ull;
     const unsigned v = v0 + vi;
+    // every LDS read of this offer is issued here, in one batch (one round trip instead of three: the reads after the first branch
+    // and the attribute row used to start their own)
     const OfferA a = W.oa[vi];
     const double ac = W.oac[vi], am = W.oam[vi];
+    const OfferB o = W.ob[vi];
+    const int acount = W.oacount[vi];
+    unsigned arow[MV_NA];
+#pragma unroll
+    for (int x = 0; x < MV_NA; ++x) arow[x] = W.attr[vi][x];
     bool res = valid && !(ac + j.c > a.oc || am + j.m > a.om);
     if (in.has_x) {  // ports / named scalars (rare): the jobs that ask for any read the offer's counters
-      if (res && (j.flags & JF_XRES)) res = xres_fail_bits(in, st, E.jj, v) == 0u;
+      if (res && (j.flags & JF_XRES)) res = xres_fail_dev(vb.in_dev, st, E.jj, v) == 0u;
     }
     if (!__any(res)) {
       E.c1 += valid ? 1u : 0u;
@@ -542,19 +560,17 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
       }
       continue;
     }
-    const OfferB o = W.ob[vi];
-    const int acount = W.oacount[vi];
     bool stat = res && static_fast(j, o, in, v);
     {  // novel-host (constraints.clj:68-94) and user-defined EQUALS (:356-377): the offer's host and attribute values are wave-uniform
       unsigned diff = (E.req_host ^ (o.host + 1u)) & E.wild_host;
 #pragma unroll
-      for (int a = 0; a < MV_NA; ++a) diff |= (E.req[a] ^ W.attr[vi][a]) & E.wild[a];
+      for (int x = 0; x < MV_NA; ++x) diff |= (E.req[x] ^ arow[x]) & E.wild[x];
       bool hit = E.impossible;
 #pragma unroll
       for (int q = 0; q < MV_NC; ++q) hit = hit | (E.novel[q] == o.host);
       stat = stat && diff == 0u && !hit;
     }
-    if (stat && E.slow) stat = static_pass(in, E.jj, v);
+    if (stat && E.slow) stat = static_pass_dev(vb.in_dev, E.jj, v);
     const unsigned long long bits = __ballot(stat);
     if (lane == 0) {
       if (THROUGH) st_agent(&vb.colbits[(size_t)v * MV_JGL + jg], (uint64_t)bits);
@@ -568,7 +584,7 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
       feas = feas && !taken;
     }
     if (__any(E.grouped && E.n_fh < 0)) {  // (wave-uniform) balanced / attribute-equals groups, or too many hosts: the general walk
-      if (feas && E.grouped && E.n_fh < 0) feas = group_pass(in, st, E.jj, v);
+      if (feas && E.grouped && E.n_fh < 0) feas = group_pass_dev(vb.in_dev, st, E.jj, v);
     }
     E.c1 += (valid && !res) ? 1u : 0u;
     E.c2 += (res && !feas) ? 1u : 0u;
@@ -982,9 +998,7 @@ constexpr unsigned JL_XRES = 1u << 28;  // asks for ports / named scalars: gener
 constexpr unsigned JL_GSLOT_SHIFT = 21, JL_GSLOT_NONE = 0x7Fu;  // bits 21-27: the job's row of ResolveLds::gfh, or none
 constexpr int MV_GMAX = 64;  // group members per round whose hosts-to-avoid are staged for the walk's fast path
 
-static __device__ __attribute__((noinline)) bool group_pass_dev(const MatchIn* in, MatchState st, unsigned jj, unsigned v) {
-  return group_pass(*in, st, jj, v);
-}
+
 
 // (WALK_STAT: platform.hpp — counters of the emulated build's design studies, nothing on the GPU)
 
