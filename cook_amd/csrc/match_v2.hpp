@@ -509,12 +509,25 @@ static __device__ __forceinline__ void eval_lane_setup(EvalLane& E, const MatchI
   E.c1 = E.c2 = E.c4 = 0;
 }
 
-// the offers [v0, v0 + MV_OCW) against the wave's 64 jobs: stage them in the wave's LDS, then walk them in a wave-uniform loop
+// When a window has fewer job groups than the eval grid has rows (the filling phase resolves ~100 jobs per round: 2 of 8 rows), the
+// idle rows take a share of the OFFERS instead: with A active job groups, row gy serves job group gy % A and part gy / A of the
+// R = eval_split(wcur) parts every wave's offer batch is cut into, and a chunk contributes R partial lists per job ("virtual
+// chunks" ch * R + part; the merge kernel derives the same R from the same window).  R = 1 is the plain layout.
+constexpr int MV_SPLIT_MAX = 4;  // a wave keeps at least MV_OCW / 4 offers
+static __device__ __forceinline__ unsigned eval_split(unsigned wcur) {
+  const unsigned active = (wcur + COOK_WAVE - 1) / COOK_WAVE;
+  unsigned r = 1;
+  while (r < (unsigned)MV_SPLIT_MAX && r * 2u * active <= (unsigned)MV_JG && (unsigned)MV_OCW / (r * 2u) >= 8u) r *= 2u;
+  return r;
+}
+
+// the offers [v0, v0 + nsub) against the wave's 64 jobs (nsub = MV_OCW, or a power-of-two share of it): stage them in the wave's LDS,
+// then walk them in a wave-uniform loop
 template <bool THROUGH>
 static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds& W, const MatchIn& in, const MatchState& st, const V2Buf& vb,
-                                                        unsigned v0, unsigned jg) {
+                                                        unsigned v0, unsigned jg, unsigned nsub = MV_OCW) {
   const unsigned lane = lane_id();
-  const unsigned v1 = (v0 + MV_OCW < in.M) ? v0 + MV_OCW : in.M;
+  const unsigned v1 = (v0 + nsub < in.M) ? v0 + nsub : in.M;
   if (v0 + lane < v1) {
     W.oa[lane] = vb.oa[v0 + lane];
     W.ob[lane] = vb.ob[v0 + lane];
@@ -531,8 +544,8 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
   // offers that cannot take even the smallest job of the call any more fail every job on resources: count, never evaluate
   unsigned long long live = 0ull;
   if (v0 < v1) {
-    live = (st.alive[v0 >> 6] >> (v0 & 63u)) & (MV_OCW == 64 ? ~0ull : ((1ull << (MV_OCW & 63)) - 1ull));  // an aligned slice of one word
-    if (v1 - v0 < (unsigned)MV_OCW) live &= (1ull << (v1 - v0)) - 1ull;
+    live = (st.alive[v0 >> 6] >> (v0 & 63u)) & (nsub == 64u ? ~0ull : ((1ull << (nsub & 63u)) - 1ull));  // an aligned slice of one word
+    if (v1 - v0 < nsub) live &= (1ull << (v1 - v0)) - 1ull;
     E.c1 += valid ? (v1 - v0) - (unsigned)__popcll(live) : 0u;
   }
   while (live != 0ull) {  // wave-uniform
@@ -640,7 +653,8 @@ static __device__ __forceinline__ void eval_store_group(const EvalLane& E, const
 // the persistent kernel (match_world.hpp: w = wave in team, sync = the team's LDS barrier, THROUGH = write-through stores).
 template <bool THROUGH, class Sync>
 static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
-                                                   unsigned wcur, unsigned ch, unsigned jg, unsigned w, Sync sync) {
+                                                   unsigned wcur, unsigned ch, unsigned jg, unsigned w, Sync sync, unsigned part = 0,
+                                                   unsigned split = 1) {
   EvalLds& L = *reinterpret_cast<EvalLds*>(lds);
   auto& s_fit = L.fit;
   auto& s_idx = L.idx;
@@ -658,7 +672,7 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
 #ifdef COOK_EVAL_TRACE
   if (trp && lane == 0) trp[1] = cook_ticks();
 #endif
-  eval_scan_offers<THROUGH>(E, L.wave[w], in, st, vb, ch * MV_OCB + w * MV_OCW, jg);
+  eval_scan_offers<THROUGH>(E, L.wave[w], in, st, vb, ch * MV_OCB + w * MV_OCW + part * ((unsigned)MV_OCW / split), jg, (unsigned)MV_OCW / split);
 #ifdef COOK_EVAL_TRACE
   if (trp && lane == 0) trp[2] = cook_ticks();
 #endif
@@ -676,7 +690,7 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
   s_cnt[w][lane][2] = E.c4;
   sync();
   if (w != 0 || !valid) return;  // (the caller synchronises the waves before the LDS is reused)
-  if (ch == 0) eval_store_group<THROUGH>(E, vb, b);
+  if (ch == 0 && part == 0) eval_store_group<THROUGH>(E, vb, b);
   int p[MV_EW];
 #pragma unroll
   for (int x = 0; x < MV_EW; ++x) p[x] = 0;
@@ -761,14 +775,14 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
   R.cnt[1] = t1;
   R.cnt[2] = t2;
   R.cnt[3] = t4;
-  chunk_store(&vb.prec[(size_t)b * vb.C + ch], R, THROUGH);
+  chunk_store(&vb.prec[(size_t)b * (vb.C * split) + ch * split + part], R, THROUGH);
 #ifdef COOK_EVAL_TRACE
   if (trp && lane == 0) trp[3] = cook_ticks();
 #endif
 }
 static __device__ __forceinline__ void eval_tile(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
-                                                 unsigned wcur, unsigned ch, unsigned jg) {
-  eval_tile_t<false>(lds, in, st, vb, head, wcur, ch, jg, wave_id(), [] { __syncthreads(); });
+                                                 unsigned wcur, unsigned ch, unsigned jg, unsigned part = 0, unsigned split = 1) {
+  eval_tile_t<false>(lds, in, st, vb, head, wcur, ch, jg, wave_id(), [] { __syncthreads(); }, part, split);
 }
 
 // The same tile by ONE wave on its own (the persistent placement kernel's evaluator waves, match_world.hpp): 64 jobs x the
@@ -815,7 +829,13 @@ static __device__ __forceinline__ void eval_tile_wave(EvalWaveLds& W, const Matc
 static __device__ __forceinline__ void eval_block(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
                                                   unsigned wcur, unsigned ch, unsigned gy, unsigned ny) {
   if (wcur <= ny * COOK_WAVE) {
-    eval_tile(lds, in, st, vb, head, wcur, ch, gy);
+    const unsigned split = ny == (unsigned)MV_JG ? eval_split(wcur) : 1u;  // (the grid's rows are MV_JG in every launch path)
+    if (split == 1u) {
+      eval_tile(lds, in, st, vb, head, wcur, ch, gy);
+    } else {
+      const unsigned active = (wcur + COOK_WAVE - 1) / COOK_WAVE;
+      if (gy < active * split) eval_tile(lds, in, st, vb, head, wcur, ch, gy % active, gy / active, split);
+    }
     return;
   }
   EvalLds& L = *reinterpret_cast<EvalLds*>(lds);
@@ -841,7 +861,8 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) COOK_EVAL_OCCUPANCY match_ev
 
 // ---- merge: one wave per job ---------------------------------------------------------------------------------------------
 template <bool THROUGH>
-static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf& vb, unsigned head, unsigned wcur, unsigned b) {
+static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf& vb, unsigned head, unsigned wcur, unsigned b,
+                                                 unsigned split = 1) {  // split: eval_split(wcur) behind the launch path's eval grid
   if (b >= wcur || head + b >= in.K) return;
   const unsigned lane = lane_id();
   const bool use_ge = in.good_enough < 1.0;
@@ -857,8 +878,9 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
   for (int q = 0; q < MV_LG; ++q) gi[q] = 0x7FFFFFFF;
   int n_ge = 0;
   unsigned c1 = 0, c2 = 0, c4 = 0;
-  for (unsigned ch = lane; ch < vb.C; ch += COOK_WAVE) {
-    const ChunkRec R = vb.prec[(size_t)b * vb.C + ch];  // eight 16-byte loads, all in flight together
+  const unsigned cv = vb.C * split;  // chunk lists per job (virtual chunks, eval_split)
+  for (unsigned ch = lane; ch < cv; ch += COOK_WAVE) {
+    const ChunkRec R = vb.prec[(size_t)b * cv + ch];  // eight 16-byte loads, all in flight together
     const unsigned info = R.cnt[0];
     c1 += R.cnt[1];
     c2 += R.cnt[2];
@@ -966,7 +988,8 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
 constexpr int MV_MW = 4;
 __global__ void __launch_bounds__(COOK_WAVE* MV_MW) match_merge2(MatchIn in, V2Buf vb) {
   const unsigned head = vb.ctl->head, wcur = vb.ctl->wcur;
-  for (unsigned b = blockIdx.x * MV_MW + wave_id(); b < wcur; b += gridDim.x * MV_MW) merge_job<false>(in, vb, head, wcur, b);
+  const unsigned split = wcur <= (unsigned)MV_WMAX ? eval_split(wcur) : 1u;  // as match_eval2's grid cut the offers
+  for (unsigned b = blockIdx.x * MV_MW + wave_id(); b < wcur; b += gridDim.x * MV_MW) merge_job<false>(in, vb, head, wcur, b, split);
 }
 
 // ---- resolve -----------------------------------------------------------------------------------------------------------------
@@ -1335,7 +1358,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         h = (h + 1) % MV_HASH;
       }
       const OfferA a = vb.oa[v];
-      if (ac + j.c > a.oc || am + j.m > a.om || ((j.flags & JF_XRES) && xres_fail_bits(in, st, jj, v) != 0u)) {
+      if (ac + j.c > a.oc || am + j.m > a.om || ((j.flags & JF_XRES) && xres_fail_dev(vb.in_dev, st, jj, v) != 0u)) {
         ++c1;
         continue;
       }
@@ -1682,7 +1705,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       bool res_ok = t_on && !(t_ac + c > t_oc || t_am + m > t_om);
       if (cinfo_u & JL_XRES) {  // ports / named scalars: the counters of the call live in HBM (only such jobs move them)
         jj = j_index ? j_index[k] : k;
-        if (res_ok) res_ok = xres_fail_bits(*vb.in_dev, st, jj, (unsigned)t_v) == 0u;
+        if (res_ok) res_ok = xres_fail_dev(vb.in_dev, st, jj, (unsigned)t_v) == 0u;
       }
       bool con_ok = ((t_col >> bl) & 1ull) != 0 && t_acount < t_slack && gok;
       if (job_gpu && t_k8s && t_run + t_acount != 0) con_ok = false;
@@ -2287,7 +2310,8 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) COOK_EVAL_OCCUPANCY match_ev
 __global__ void __launch_bounds__(COOK_WAVE* MV_MW) match_merge2_multi(const PoolCtx* __restrict__ ctx) {
   const PoolCtx& c = ctx[blockIdx.z];
   const unsigned head = c.vb.ctl->head, wcur = c.vb.ctl->wcur;
-  for (unsigned b = blockIdx.x * MV_MW + wave_id(); b < wcur; b += gridDim.x * MV_MW) merge_job<false>(c.in, c.vb, head, wcur, b);
+  const unsigned split = wcur <= (unsigned)MV_WMAX ? eval_split(wcur) : 1u;
+  for (unsigned b = blockIdx.x * MV_MW + wave_id(); b < wcur; b += gridDim.x * MV_MW) merge_job<false>(c.in, c.vb, head, wcur, b, split);
 }
 __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2_multi(const PoolCtx* __restrict__ ctx) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(ResolveLds)];
