@@ -905,6 +905,13 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     vb.cinfo = e->v_cinfo.ensure((size_t)MV_WLONG * 4);
     vb.jfh = e->v_jfh.ensure((size_t)MV_WLONG * (MV_FH + 2));
     vb.ctl = e->w_ctl.ensure(1);
+    {  // idle rows of the eval grid take a share of the offers (eval_split) when the pool has the GPU to itself; measured on
+       // MI355X: one C4 pool 66.3 -> 64.7 ms with splits up to 4, eight pools on the GPU 103 -> 113 ms (twice the chunk lists to merge,
+       // more blocks than fit beside the other chains)
+      const int sharing = std::max(1, g_engines_on_device[e->device & 63].load());
+      vb.split_max = sharing == 1 ? (unsigned)MV_SPLIT_MAX : 1u;
+      if (const char* ev = std::getenv("COOK_EVAL_SPLIT")) vb.split_max = (unsigned)std::max(1, std::min(MV_SPLIT_MAX, std::atoi(ev)));
+    }
     {
       MatchIn* din = e->v_in.ensure(1);
       MatchIn* hin = (MatchIn*)e->h_inbuf;

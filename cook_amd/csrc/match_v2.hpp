@@ -157,6 +157,7 @@ static_assert(sizeof(ChunkRec) % 16 == 0, "ChunkRec is moved in 16-byte pieces")
 
 struct V2Buf {
   RoundLog* round_log;
+  unsigned split_max;  // cap of eval_split (1 = never cut a wave's offer batch)
 #ifdef COOK_EVAL_TRACE
   unsigned long long* eval_trace;  // timing study build: per eval block [start, end] ticks of the 100 MHz clock + HW_ID
 #endif
@@ -513,11 +514,12 @@ static __device__ __forceinline__ void eval_lane_setup(EvalLane& E, const MatchI
 // idle rows take a share of the OFFERS instead: with A active job groups, row gy serves job group gy % A and part gy / A of the
 // R = eval_split(wcur) parts every wave's offer batch is cut into, and a chunk contributes R partial lists per job ("virtual
 // chunks" ch * R + part; the merge kernel derives the same R from the same window).  R = 1 is the plain layout.
-constexpr int MV_SPLIT_MAX = 4;  // a wave keeps at least MV_OCW / 4 offers
-static __device__ __forceinline__ unsigned eval_split(unsigned wcur) {
+constexpr int MV_SPLIT_MAX = 4;  // a wave keeps at least MV_OCW / 4 offers; V2Buf::split_max (host) caps it: sharing a GPU with other pools'
+                                 // launches, the extra blocks and the R-fold chunk lists cost more than the shorter tiles save
+static __device__ __forceinline__ unsigned eval_split(unsigned wcur, unsigned split_max) {
   const unsigned active = (wcur + COOK_WAVE - 1) / COOK_WAVE;
   unsigned r = 1;
-  while (r < (unsigned)MV_SPLIT_MAX && r * 2u * active <= (unsigned)MV_JG && (unsigned)MV_OCW / (r * 2u) >= 8u) r *= 2u;
+  while (r * 2u <= split_max && r * 2u * active <= (unsigned)MV_JG && (unsigned)MV_OCW / (r * 2u) >= 8u) r *= 2u;
   return r;
 }
 
@@ -829,7 +831,7 @@ static __device__ __forceinline__ void eval_tile_wave(EvalWaveLds& W, const Matc
 static __device__ __forceinline__ void eval_block(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
                                                   unsigned wcur, unsigned ch, unsigned gy, unsigned ny) {
   if (wcur <= ny * COOK_WAVE) {
-    const unsigned split = ny == (unsigned)MV_JG ? eval_split(wcur) : 1u;  // (the grid's rows are MV_JG in every launch path)
+    const unsigned split = ny == (unsigned)MV_JG ? eval_split(wcur, vb.split_max) : 1u;  // (the grid's rows are MV_JG in every launch path)
     if (split == 1u) {
       eval_tile(lds, in, st, vb, head, wcur, ch, gy);
     } else {
@@ -988,7 +990,7 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
 constexpr int MV_MW = 4;
 __global__ void __launch_bounds__(COOK_WAVE* MV_MW) match_merge2(MatchIn in, V2Buf vb) {
   const unsigned head = vb.ctl->head, wcur = vb.ctl->wcur;
-  const unsigned split = wcur <= (unsigned)MV_WMAX ? eval_split(wcur) : 1u;  // as match_eval2's grid cut the offers
+  const unsigned split = wcur <= (unsigned)MV_WMAX ? eval_split(wcur, vb.split_max) : 1u;  // as match_eval2's grid cut the offers
   for (unsigned b = blockIdx.x * MV_MW + wave_id(); b < wcur; b += gridDim.x * MV_MW) merge_job<false>(in, vb, head, wcur, b, split);
 }
 
@@ -2310,7 +2312,7 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) COOK_EVAL_OCCUPANCY match_ev
 __global__ void __launch_bounds__(COOK_WAVE* MV_MW) match_merge2_multi(const PoolCtx* __restrict__ ctx) {
   const PoolCtx& c = ctx[blockIdx.z];
   const unsigned head = c.vb.ctl->head, wcur = c.vb.ctl->wcur;
-  const unsigned split = wcur <= (unsigned)MV_WMAX ? eval_split(wcur) : 1u;
+  const unsigned split = wcur <= (unsigned)MV_WMAX ? eval_split(wcur, c.vb.split_max) : 1u;
   for (unsigned b = blockIdx.x * MV_MW + wave_id(); b < wcur; b += gridDim.x * MV_MW) merge_job<false>(c.in, c.vb, head, wcur, b, split);
 }
 __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2_multi(const PoolCtx* __restrict__ ctx) {

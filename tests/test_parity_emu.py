@@ -515,3 +515,12 @@ def test_match_more_offer_chunks_than_lanes(make_engine):
     jobs = A.Jobs(cpus=rng.integers(1, 5, n).astype(float), mem=rng.integers(1, 5, n) * 1024.0)
     for ge in (1.0, 0.7):
         P.match_parity(make_engine, jobs, offers, None, A.default_params(good_enough_fitness=ge))
+
+
+@pytest.mark.parametrize("split", [1, 2, 4])
+def test_match_eval_offer_split_levels(make_engine, monkeypatch, split):
+    # idle rows of the eval grid take shares of the offers (eval_split): every cap gives the oracle's placement
+    monkeypatch.setenv("COOK_EVAL_SPLIT", str(split))
+    pool = synth.make_pool(seed=83, n_pending=300, n_running=100, n_users=20, n_offers=260, gpus=True, constraints=True)
+    for ge in (1.0, 0.6):
+        P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, A.default_params(good_enough_fitness=ge))

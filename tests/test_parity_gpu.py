@@ -496,3 +496,12 @@ def test_rebalance_gpu_maps_with_several_models(make_engine):
     got = P.rebalance_parity(make_engine, P.make_rebalance_case(seed=59, n_running=500, n_pending=60, n_users=15, n_hosts=40, constraints=True,
                                                                 gpus=True, gpu_slots=2))
     assert len(got["decisions"]) > 0
+
+
+@pytest.mark.parametrize("split", [1, 2, 4])
+def test_match_eval_offer_split_levels(make_engine, monkeypatch, split):
+    # idle rows of the eval grid take shares of the offers (eval_split): every cap gives the oracle's placement
+    monkeypatch.setenv("COOK_EVAL_SPLIT", str(split))
+    pool = synth.make_pool(seed=83, n_pending=5000, n_running=100, n_users=20, n_offers=3000, gpus=True, constraints=True)
+    for ge in (1.0, 0.6):
+        P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, A.default_params(good_enough_fitness=ge))
