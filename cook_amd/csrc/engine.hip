@@ -909,7 +909,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
        // MI355X: one C4 pool 66.3 -> 64.7 ms with splits up to 4, eight pools on the GPU 103 -> 113 ms (twice the chunk lists to merge,
        // more blocks than fit beside the other chains)
       const int sharing = std::max(1, g_engines_on_device[e->device & 63].load());
-      vb.split_max = sharing == 1 ? (unsigned)MV_SPLIT_MAX : 1u;
+      vb.split_max = sharing == 1 ? (unsigned)MV_SPLIT_MAX : (sharing <= 4 ? 2u : 1u);  // (2 / 4 pools on the GPU: 69.4 -> 67.5, 72.9 -> 72.0 ms with 2)
       if (const char* ev = std::getenv("COOK_EVAL_SPLIT")) vb.split_max = (unsigned)std::max(1, std::min(MV_SPLIT_MAX, std::atoi(ev)));
     }
     {

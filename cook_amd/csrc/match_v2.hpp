@@ -892,13 +892,13 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
 #pragma unroll
       for (int q = 0; q < MV_L; ++q)
         if (q < n) tf[q] = R.fit[q], ti[q] = R.idx[q];
-    } else {
+    } else {  // a later (virtual) chunk holds higher offer indices than everything the lane has seen: an entry only passes entries it
+              // beats strictly, and equal-fitness entries of its own list arrive in index order
 #pragma unroll
       for (int q = 0; q < MV_L; ++q) {
         if (q >= n) break;
-        const Cand o{R.fit[q], R.idx[q]};
-        if (!cand_better(o, Cand{tf[MV_L - 1], ti[MV_L - 1]})) break;  // chunk list is sorted: nothing further can enter
-        topl_insert<MV_L>(tf, ti, o.fit, o.idx);
+        if (!(R.fit[q] > tf[MV_L - 1])) break;  // chunk list is sorted: nothing further can enter
+        topl_insert_ascending<MV_L>(tf, ti, R.fit[q], R.idx[q]);
       }
     }
     if (use_ge)
