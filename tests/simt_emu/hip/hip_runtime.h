@@ -31,6 +31,9 @@
 #define __launch_bounds__(...)
 #define __constant__ static
 
+struct alignas(16) uint4 {
+  unsigned x, y, z, w;
+};
 struct dim3 {
   unsigned x, y, z;
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
