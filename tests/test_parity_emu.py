@@ -129,6 +129,8 @@ def test_match_long_windows(make_engine, algo):
     pool.offers.mem[:] = np.minimum(pool.offers.mem, 40000.0)
     p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
     P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p)
+    if algo != 0:
+        return  # (the round counts are compared once, on the launch path)
     with make_engine(p) as e:
         e.match(pool.pending_jobs, pool.offers, pool.groups)
         long_rounds = e.match_stats()["rounds"]
