@@ -380,9 +380,13 @@ void rank_pool_usage(cook_engine* e, cook_usage* out) {
     *out = cook_usage{0, 0, 0, 0};
     return;
   }
-  KL("pool_usage_reduce", pool_usage_reduce, 1, 1024, (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(),
+  e->pool_usage.ensure(1 + POOL_USAGE_BLOCKS);
+  KL("pool_usage_partial", pool_usage_partial, POOL_USAGE_BLOCKS, 256, (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(),
      e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->N,
-     e->pool_usage.ptr());
+     e->pool_usage.ptr() + 1);
+  KL("pool_usage_reduce", pool_usage_reduce, 1, COOK_WAVE, (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(),
+     e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->N,
+     (const SumU4*)(e->pool_usage.ptr() + 1), (unsigned)POOL_USAGE_BLOCKS, e->pool_usage.ptr());
   SumU4 h;
   COOK_HIP(hipMemcpyAsync(e->h_scratch, e->pool_usage.ptr(), sizeof(SumU4), hipMemcpyDeviceToHost, e->stream));
   sync(e);
@@ -462,12 +466,12 @@ void rank_run(cook_engine* e) {
   e->w0.ensure(N);
   e->w1.ensure(N);
   e->w2.ensure(N);
-  KL("rank_key_mins", rank_key_mins, std::min(gN, 1024u), 256, (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(),
+  KL("rank_key_mins", rank_key_mins, std::min(gN, 64u), 256, (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(),
      (const int64_t*)e->t_job.ptr(), (const uint8_t*)e->t_pending.ptr(), N, mins);
   KL("rank_build_keys", rank_build_keys, gN, 256, (const uint32_t*)e->t_user.ptr(), (const int32_t*)e->t_prio.ptr(),
      (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(), (const int64_t*)e->t_job.ptr(),
      (const uint8_t*)e->t_pending.ptr(), N, (const unsigned long long*)mins, e->w0.ptr(), e->w1.ptr(), e->w2.ptr());
-  const unsigned gV = std::min(gN, 1024u);
+  const unsigned gV = std::min(gN, 64u);
   KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w0.ptr(), N, masks + 0);
   KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w1.ptr(), N, masks + 1);
   KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w2.ptr(), N, masks + 2);

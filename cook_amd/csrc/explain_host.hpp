@@ -80,7 +80,7 @@ void resource_stats(cook_engine* e, ExplainBufs& x, const double* a, const doubl
     const uint64_t* key = col ? kb : ka;
     unsigned long long* dmask = e->d_scratch64.ensure(8);
     COOK_HIP(hipMemsetAsync(dmask, 0, 8, e->stream));
-    KL("radix_varying_bits", radix_varying_bits, std::min(g, 1024u), 256, key, n, dmask);
+    KL("radix_varying_bits", radix_varying_bits, std::min(g, 64u), 256, key, n, dmask);
     readback64(e, 1);
     const unsigned long long mask = e->h_scratch[0];
     KL("iota", iota_u32, g, 256, x.permA.ptr(), n);

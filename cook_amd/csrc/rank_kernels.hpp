@@ -29,10 +29,14 @@ __global__ void __launch_bounds__(256) rank_key_mins(const int64_t* __restrict__
     m1 = b < m1 ? b : m1;
     m2 = c < m2 ? c : m2;
   }
-  if (lane_id() == 0) {
-    atomicMin(&mins[0], m0);
-    atomicMin(&mins[1], m1);
-    atomicMin(&mins[2], m2);
+  // one set of atomics per BLOCK (a few dozen blocks): thousands of same-address atomics from every wave cost 96 us for 175k tasks
+  __shared__ unsigned long long s_m[3][256 / COOK_WAVE];
+  if (lane_id() == 0) s_m[0][wave_id()] = m0, s_m[1][wave_id()] = m1, s_m[2][wave_id()] = m2;
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    unsigned long long m = s_m[threadIdx.x][0];
+    for (unsigned w = 1; w < blockDim.x / COOK_WAVE; ++w) m = s_m[threadIdx.x][w] < m ? s_m[threadIdx.x][w] : m;
+    atomicMin(&mins[threadIdx.x], m);
   }
 }
 
@@ -157,10 +161,20 @@ __global__ void __launch_bounds__(256) rank_score(const SumU4* __restrict__ pre,
     o |= __shfl_xor(o, dd, COOK_WAVE);
     a &= __shfl_xor(a, dd, COOK_WAVE);
   }
-  if (lane_id() == 0 && kept) {
-    atomicAdd(&counters[0], (unsigned)__popcll(kept));
-    atomicOr(&or_and[0], o);
-    atomicAnd(&or_and[1], a);
+  // per block, not per wave (same-address atomics serialise)
+  __shared__ unsigned s_n[256 / COOK_WAVE];
+  __shared__ unsigned long long s_o[256 / COOK_WAVE], s_a[256 / COOK_WAVE];
+  if (lane_id() == 0) s_n[wave_id()] = (unsigned)__popcll(kept), s_o[wave_id()] = o, s_a[wave_id()] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned nk = 0;
+    unsigned long long bo = 0ull, ba = ~0ull;
+    for (unsigned w = 0; w < blockDim.x / COOK_WAVE; ++w) nk += s_n[w], bo |= s_o[w], ba &= s_a[w];
+    if (nk) {
+      atomicAdd(&counters[0], nk);
+      atomicOr(&or_and[0], bo);
+      atomicAnd(&or_and[1], ba);
+    }
   }
 }
 
@@ -465,12 +479,15 @@ __global__ void __launch_bounds__(256) user_mark_present(const uint32_t* __restr
 }
 
 // ---- pool running usage (scheduler.clj:2118-2123, 2173): one workgroup, exactness tracked ----------------------
-__global__ void __launch_bounds__(1024) pool_usage_reduce(const double* __restrict__ cpus, const double* __restrict__ mem,
+// stage 1: POOL_USAGE_BLOCKS blocks fold strided slices (a single 1024-thread block took 153 us for 175k tasks: 171 dependent
+// iterations); stage 2 (pool_usage_reduce) combines the partial sums, or redoes the sum left to right when one of them rounded
+constexpr int POOL_USAGE_BLOCKS = 64;
+__global__ void __launch_bounds__(256) pool_usage_partial(const double* __restrict__ cpus, const double* __restrict__ mem,
                                                           const double* __restrict__ gpus, const uint8_t* __restrict__ pending,
-                                                          unsigned n, SumU4* __restrict__ out) {
-  __shared__ SumU4 ws[1024 / COOK_WAVE];
+                                                          unsigned n, SumU4* __restrict__ part) {
+  __shared__ SumU4 ws[256 / COOK_WAVE];
   SumU4 acc = SumU4::zero();
-  for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     if (!pending[i]) acc = combine(acc, SumU4{1.0, cpus[i], mem[i], gpus ? gpus[i] : 0.0, 0u});
   for (int d = 32; d >= 1; d >>= 1) {
     SumU4 o;
@@ -486,16 +503,25 @@ __global__ void __launch_bounds__(1024) pool_usage_reduce(const double* __restri
   if (threadIdx.x == 0) {
     SumU4 t = ws[0];
     for (unsigned k = 1; k < blockDim.x / COOK_WAVE; ++k) t = combine(t, ws[k]);
-    if (t.bad) {  // some partial sum rounded: redo left to right like the reference
-      t = SumU4::zero();
-      for (unsigned i = 0; i < n; ++i)
-        if (!pending[i]) {
-          t.count += 1.0;
-          t.cpus += cpus[i];
-          t.mem += mem[i];
-          t.gpus += gpus ? gpus[i] : 0.0;
-        }
-    }
-    *out = t;
+    part[blockIdx.x] = t;
   }
+}
+__global__ void __launch_bounds__(COOK_WAVE) pool_usage_reduce(const double* __restrict__ cpus, const double* __restrict__ mem,
+                                                               const double* __restrict__ gpus, const uint8_t* __restrict__ pending,
+                                                               unsigned n, const SumU4* __restrict__ part, unsigned n_part,
+                                                               SumU4* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  SumU4 t = part[0];
+  for (unsigned k = 1; k < n_part; ++k) t = combine(t, part[k]);
+  if (t.bad) {  // some partial sum rounded: redo left to right like the reference
+    t = SumU4::zero();
+    for (unsigned i = 0; i < n; ++i)
+      if (!pending[i]) {
+        t.count += 1.0;
+        t.cpus += cpus[i];
+        t.mem += mem[i];
+        t.gpus += gpus ? gpus[i] : 0.0;
+      }
+  }
+  *out = t;
 }

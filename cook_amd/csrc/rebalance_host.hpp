@@ -363,12 +363,12 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   e->w0.ensure(S);
   e->w1.ensure(S);
   e->w2.ensure(S);
-  KL("rank_key_mins", rank_key_mins, std::min(gS, 1024u), 256, (const int64_t*)b.start.ptr(), (const int64_t*)b.task.ptr(),
+  KL("rank_key_mins", rank_key_mins, std::min(gS, 128u), 256, (const int64_t*)b.start.ptr(), (const int64_t*)b.task.ptr(),
      (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, mins);
   KL("rank_build_keys", rank_build_keys, gS, 256, (const uint32_t*)b.user.ptr(), (const int32_t*)b.prio.ptr(), (const int64_t*)b.start.ptr(),
      (const int64_t*)b.task.ptr(), (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, (const unsigned long long*)mins,
      e->w0.ptr(), e->w1.ptr(), e->w2.ptr());
-  const unsigned gV = std::min(gS, 1024u);
+  const unsigned gV = std::min(gS, 128u);
   KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w0.ptr(), S, masks + 0);
   KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w1.ptr(), S, masks + 1);
   KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w2.ptr(), S, masks + 2);

@@ -160,12 +160,19 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter(const uint64_t* __re
   }
 }
 
-// OR over all items of (key[i] ^ key[0]) : bits that differ somewhere.  One atomicOr per wave.
+// OR over all items of (key[i] ^ key[0]) : bits that differ somewhere.  One atomicOr per block; launched with a few dozen blocks.
 __global__ void __launch_bounds__(256) radix_varying_bits(const uint64_t* __restrict__ key, unsigned n,
                                                           unsigned long long* __restrict__ out_mask) {
   const uint64_t k0 = key[0];
   unsigned long long m = 0;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m |= key[i] ^ k0;
   for (int d = 32; d >= 1; d >>= 1) m |= __shfl_xor(m, d, COOK_WAVE);
-  if (lane_id() == 0 && m) atomicOr(out_mask, m);
+  __shared__ unsigned long long s_m[256 / COOK_WAVE];  // one atomic per block
+  if (lane_id() == 0) s_m[wave_id()] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long b = 0ull;
+    for (unsigned w = 0; w < blockDim.x / COOK_WAVE; ++w) b |= s_m[w];
+    if (b) atomicOr(out_mask, b);
+  }
 }
