@@ -476,6 +476,7 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   RebalCtl c0;
   std::memset(&c0, 0, sizeof(c0));
   c0.remaining = b.rp.max_preemption;
+  c0.max_items = b.max_seg;
   std::memcpy(e->h_scratch, &c0, sizeof(c0));
   COOK_HIP(hipMemcpyAsync(b.ctl.ptr(), e->h_scratch, sizeof(c0), hipMemcpyHostToDevice, e->stream));
   std::vector<double> nanv(P, std::numeric_limits<double>::quiet_NaN());
@@ -486,10 +487,12 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   if (R) KL("rebal_mirror_dru", rebal_mirror_dru, div_up(R, 256), 256, (const uint32_t*)b.h_pb.ptr(), (const double*)b.dru.ptr(), R, b.h_dru.ptr());
   // ---- the decision loop (rebalancer.clj:442-458) ---------------------------------------------------------------------------------
   const RebalIn in = rebalance_args(e, b);
+  unsigned known_max = b.max_seg, known_at = 0;  // items of the fullest host when the control block was last read back
   for (unsigned pj = 0; pj < P; ++pj) {
     KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, pj);
     if (H) KL("rebal_decide", rebal_decide, div_up(div_up(H, 2u), RB_WAVES), COOK_WAVE * RB_WAVES, in);
-    if (H && b.max_seg + pj > (unsigned)COOK_WAVE) KL("rebal_decide_big", rebal_decide_big, 32, COOK_WAVE * RB_WAVES, in);  // (pj jobs placed at most)
+    // hosts beyond 64 items: only when one can exist (the fullest host as last read back + the jobs placed since then)
+    if (H && known_max + (pj - known_at) > (unsigned)COOK_WAVE) KL("rebal_decide_big", rebal_decide_big, 32, COOK_WAVE * RB_WAVES, in);
     KL("rebal_apply", rebal_apply, 1, RB_APPLY_THREADS, in);
     KL("rebal_rs_local", rebal_rs_local, RB_RS_GRID, RB_RS_TILE, in);
     KL("rebal_rs_carry", rebal_rs_carry, RB_RS_USERS, COOK_WAVE, in);
@@ -501,6 +504,8 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
       RebalCtl c;
       std::memcpy(&c, e->h_scratch, sizeof(c));
       if (c.remaining <= 0) break;
+      known_max = c.max_items;
+      known_at = pj + 1;
     }
   }
   COOK_HIP(hipMemcpyAsync(e->h_scratch, b.ctl.ptr(), sizeof(RebalCtl), hipMemcpyDeviceToHost, e->stream));

@@ -37,6 +37,9 @@ struct RebalCtl {
   unsigned n_changed;   // users whose active set the last decision changed (chg[])
   unsigned n_tiles;     // tiles of RB_RS_TILE slots their segments are cut into (chg_tile[])
   unsigned n_big;       // hosts listed in big_list
+  unsigned max_items;   // running tasks + placed jobs of the fullest host so far (the host decides from it whether rebal_decide_big
+                        // can have work: read back with the budget)
+  unsigned pad_;
 };
 
 struct RebalJob {  // context of the pending job being decided (written by rebal_job_prep)
@@ -343,7 +346,18 @@ __global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_local(RebalIn in) {
     SumU4 pre = SumU4::zero();
     for (unsigned k = 0; k < w; ++k) pre = combine(pre, s_tot[k]);
     const SumU4 t = combine(pre, v);
-    if (in_seg) in.pre_w[i] = t;
+    const bool single = in.chg_tile[x + 1] - in.chg_tile[x] == 1u;  // the user's only tile: no carry to wait for, finish here
+    if (in_seg) {
+      if (single) {
+        in.pre_w[i] = SumU4{t.count, t.cpus, t.mem, t.gpus, 0u};
+        const double d = rebal_dru_of(in, u, t);
+        in.dru_w[i] = d;
+        const unsigned hi = in.hidx[i];
+        if (hi != 0xFFFFFFFFu) in.h_dru[hi] = d;
+      } else {
+        in.pre_w[i] = t;
+      }
+    }
     if (tid == RB_RS_TILE - 1) in.tile_agg[tile] = t;  // the tile's total (zeros beyond the segment)
     if (t.bad) in.chg_bad[x] = 1u;
     __syncthreads();
@@ -355,6 +369,7 @@ __global__ void __launch_bounds__(COOK_WAVE) rebal_rs_carry(RebalIn in) {
   const unsigned lane = lane_id();
   for (unsigned x = blockIdx.x; x < n_chg; x += gridDim.x) {
     const unsigned t0 = in.chg_tile[x], t1 = in.chg_tile[x + 1];
+    if (t1 - t0 <= 1u) continue;  // finished by rebal_rs_local
     SumU4 carry = SumU4::zero();
     unsigned bad = 0u;
     for (unsigned base = t0; base < t1; base += COOK_WAVE) {
@@ -378,6 +393,7 @@ __global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_finish(RebalIn in) {
   const unsigned tid = threadIdx.x;
   for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const unsigned x = rebal_rs_user_of_tile(in, n_chg, tile), u = in.chg[x];
+    if (in.chg_tile[x + 1] - in.chg_tile[x] <= 1u) continue;  // finished by rebal_rs_local
     const unsigned i = in.seg_start[u] + (tile - in.chg_tile[x]) * RB_RS_TILE + tid;
     if (i >= in.seg_end[u]) continue;
     const SumU4 t = combine(in.tile_carry[tile], in.pre_w[i]);
@@ -1250,6 +1266,7 @@ __global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in) {
   in.x_next[jb.pj] = in.x_head[h];  // joins the host's chain of placed jobs
   in.x_head[h] = jb.pj;
   in.x_cnt[h] += 1u;
+  if (in.hend[h] - in.hstart[h] + in.x_cnt[h] > c.max_items) c.max_items = in.hend[h] - in.hstart[h] + in.x_cnt[h];
   if (in.hend[h] - in.hstart[h] <= (unsigned)COOK_WAVE && in.hend[h] - in.hstart[h] + in.x_cnt[h] == (unsigned)COOK_WAVE + 1u)
     in.big_list[c.n_big++] = h;  // this placement takes the host past 64 items
   in.x_pj[c.n_x] = jb.pj;            // ... and the list of all of them (placement order)
