@@ -403,6 +403,14 @@ def test_fuzz_rank_cycle_match_explain(make_engine):
         p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5, 0.3])), match_algo=int(rng.choice([0, 1, 3, 4, 5])),
                              max_over_quota_jobs=int(rng.choice([0, 3, 100])))
         pool = synth.make_pool(**kw)
+        if rng.integers(0, 3) == 0:  # ports and named scalars on a third of the configurations (also through the cycle's job columns)
+            n, m = pool.pending_jobs.n, pool.offers.n
+            sc = rng.integers(1, 30, (n, 2)).astype(np.float64) * 0.5
+            sc[rng.random((n, 2)) < 0.5] = np.nan
+            pool.pending_jobs.ports = np.where(rng.random(n) < 0.3, rng.integers(1, 4, n), 0).astype(np.int32)
+            pool.pending_jobs.scalars, pool.pending_jobs.n_scalars = sc, 2
+            pool.offers.ports = rng.integers(0, 7, m).astype(np.int32)
+            pool.offers.scalars, pool.offers.n_scalars = rng.integers(0, 120, (m, 2)) * 0.5, 2
         P.rank_parity(make_engine, pool, p)
         P.cycle_parity(make_engine, pool, p, int(rng.integers(1, kw["n_pending"] + 1)))
         reserved = tuple(int(x) for x in rng.integers(0, kw["n_offers"], int(rng.integers(0, 3))))
