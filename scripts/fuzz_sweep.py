@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Seeded random sweep of the engine against the oracle (TEST TOOL): small random configurations of rank / cycle / match / explain
+and of the rebalancer, every match_algo, eval split caps, ports / named scalars, k8s gpu maps with several entries.
+`--emu` runs the SIMT-emulator build on the CPU, otherwise libcookmatch.so on the GPU.  Prints one line; exit 1 on the first
+difference (with the configuration that produced it)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--match", type=int, default=60, help="match / cycle configurations")
+    ap.add_argument("--rebalance", type=int, default=60, help="rebalancer configurations")
+    ap.add_argument("--emu", action="store_true")
+    ap.add_argument("--scale", type=float, default=1.0, help="size factor of the configurations")
+    args = ap.parse_args()
+    from cook_amd import _abi as A
+    from cook_amd import synth
+    from cook_amd.engine import Engine
+    from tests import parity_cases as P
+    if args.emu:
+        from tests.simt_emu import build_emu
+        so = build_emu.build()
+    else:
+        from cook_amd import build
+        so = build.build()
+    make_engine = lambda params: Engine(params, lib_path=so)  # noqa: E731
+    rng = np.random.default_rng(args.seed)
+    sc = args.scale
+    for it in range(args.match):
+        kw = dict(seed=int(rng.integers(1, 1 << 30)), n_pending=int(rng.integers(1, int(600 * sc))), n_running=int(rng.integers(0, int(150 * sc))),
+                  n_users=int(rng.integers(1, 30)), n_offers=int(rng.integers(1, int(400 * sc))), gpus=bool(rng.integers(0, 2)),
+                  constraints=bool(rng.integers(0, 2)), fractional=bool(rng.integers(0, 2)), tie_heavy=bool(rng.integers(0, 2)),
+                  no_shares=bool(rng.integers(0, 4) == 0), quota_frac=float(rng.choice([0.0, 0.02, 0.5])))
+        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 1.0, 0.8, 0.5, 0.3])), match_algo=int(rng.choice([0, 0, 0, 1, 3, 4, 5])),
+                             max_over_quota_jobs=int(rng.choice([0, 3, 100])))
+        os.environ["COOK_EVAL_SPLIT"] = str(int(rng.choice([1, 2, 4])))
+        pool = synth.make_pool(**kw)
+        if rng.integers(0, 3) == 0:
+            n, m = pool.pending_jobs.n, pool.offers.n
+            s2 = rng.integers(1, 30, (n, 2)).astype(np.float64) * 0.5
+            s2[rng.random((n, 2)) < 0.5] = np.nan
+            pool.pending_jobs.ports = np.where(rng.random(n) < 0.3, rng.integers(1, 4, n), 0).astype(np.int32)
+            pool.pending_jobs.scalars, pool.pending_jobs.n_scalars = s2, 2
+            pool.offers.ports = rng.integers(0, 7, m).astype(np.int32)
+            pool.offers.scalars, pool.offers.n_scalars = rng.integers(0, 120, (m, 2)) * 0.5, 2
+        try:
+            P.rank_parity(make_engine, pool, p)
+            P.cycle_parity(make_engine, pool, p, int(rng.integers(1, kw["n_pending"] + 1)))
+            reserved = tuple(int(x) for x in rng.integers(0, kw["n_offers"], int(rng.integers(0, 3))))
+            j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, reserved=reserved)
+            if (j2o < 0).any():
+                P.explain_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, max_pos=6, tag=str(kw))
+        except AssertionError as ex:
+            print("FAIL match", it, kw, p.match_algo, p.good_enough_fitness, os.environ["COOK_EVAL_SPLIT"], str(ex)[:300])
+            sys.exit(1)
+    os.environ.pop("COOK_EVAL_SPLIT", None)
+    for it in range(args.rebalance):
+        kw = dict(seed=int(rng.integers(1, 1 << 30)), n_running=int(rng.integers(0, int(900 * sc))), n_pending=int(rng.integers(1, 40)),
+                  n_users=int(rng.integers(1, 25)), n_hosts=int(rng.integers(1, int(70 * sc))), fractional=bool(rng.integers(0, 2)),
+                  constraints=bool(rng.integers(0, 2)), gpus=bool(rng.integers(0, 2)), spare_frac=float(rng.choice([0.0, 0.3, 1.0])),
+                  quota_frac=float(rng.choice([0.0, 0.1, 0.5])), max_preemption=int(rng.choice([4, 16, 64])), dru_mode=int(rng.integers(0, 2)),
+                  gpu_slots=int(rng.choice([1, 1, 2])))
+        if not kw["constraints"]:
+            kw["gpu_slots"] = 1
+        try:
+            P.rebalance_parity(make_engine, P.make_rebalance_case(**kw))
+        except AssertionError as ex:
+            print("FAIL rebalance", it, kw, str(ex)[:300])
+            sys.exit(1)
+    print(f"fuzz ok: {args.match} match / cycle configurations, {args.rebalance} rebalancer configurations, seed {args.seed}, "
+          f"{'emulator' if args.emu else 'gpu'}")
+
+
+if __name__ == "__main__":
+    main()
