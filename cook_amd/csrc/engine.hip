@@ -299,25 +299,32 @@ void seg_scan(cook_engine* e, const char* tag, Load load, const uint8_t* head, u
   }
 }
 
-// ---- radix sort driver: one stable pass of `perm` by byte `shift/8` of key ------------------------------------
-void radix_pass(cook_engine* e, const uint64_t* key, const uint32_t* in, uint32_t* out, unsigned n, unsigned shift) {
-  const unsigned nb = div_up(n, RS_TILE);
+// ---- radix sort driver: one stable pass of `perm` by the 8 key bits from `shift` up --------------------------------------
+template <int IPL>
+static void radix_pass_t(cook_engine* e, const uint64_t* key, const uint32_t* in, uint32_t* out, unsigned n, unsigned shift, bool fused) {
+  const unsigned nb = div_up(n, rs_tile(IPL));
   e->hist.ensure((size_t)256 * nb);
-  KL("radix_hist", radix_hist, nb, RS_THREADS, key, in, n, shift, nb, e->hist.ptr());
-  KL("radix_scan", excl_scan_u32_single, 1, SCAN1_THREADS, e->hist.ptr(), 256u * nb, (uint32_t*)nullptr);
-  KL("radix_scatter", radix_scatter, nb, RS_THREADS, key, in, out, n, shift, nb, (const uint32_t*)e->hist.ptr());
+  KL("radix_hist", radix_hist<IPL>, nb, RS_THREADS, key, in, n, shift, nb, fused ? 1u : 0u, e->hist.ptr());
+  if (!fused) KL("radix_scan", excl_scan_u32_single, 1, SCAN1_THREADS, e->hist.ptr(), 256u * nb, (uint32_t*)nullptr);
+  KL("radix_scatter", radix_scatter<IPL>, nb, RS_THREADS, key, in, out, n, shift, nb, fused ? 1u : 0u, (const uint32_t*)e->hist.ptr());
 }
-// sort by the bytes of `key` selected by `mask` (bits that vary); ping-pongs between a and b; returns final buffer
+void radix_pass(cook_engine* e, const uint64_t* key, const uint32_t* in, uint32_t* out, unsigned n, unsigned shift) {
+  if (div_up(n, rs_tile(RS_IPL_SMALL)) <= RS_FUSED_BLOCKS) radix_pass_t<RS_IPL_SMALL>(e, key, in, out, n, shift, true);
+  else radix_pass_t<RS_IPL_LARGE>(e, key, in, out, n, shift, false);
+}
+// sort by the bits of `key` selected by `mask` (bits that vary); ping-pongs between a and b; returns final buffer.  A digit starts at
+// the lowest varying bit not sorted yet (bits that never vary in between cost nothing).
 uint32_t* radix_sort_masked(cook_engine* e, const uint64_t* key, unsigned long long mask, const uint32_t* cur, uint32_t* a,
                             uint32_t* b, unsigned n) {
   const uint32_t* in = cur;
   uint32_t* last = const_cast<uint32_t*>(cur);
-  for (unsigned byte = 0; byte < 8; ++byte) {
-    if (!((mask >> (8 * byte)) & 0xFFull)) continue;
+  while (mask) {
+    const unsigned shift = (unsigned)__builtin_ctzll(mask);
     uint32_t* out = (in == a) ? b : a;
-    radix_pass(e, key, in, out, n, 8 * byte);
+    radix_pass(e, key, in, out, n, shift);
     in = out;
     last = out;
+    mask = shift + 8 >= 64 ? 0ull : mask & ~((1ull << (shift + 8)) - 1ull);
   }
   return last;
 }

@@ -4,21 +4,27 @@
 // (dru.clj:82-126, one order-preserving fp64 key word).  Keys stay in place; only the u32 permutation moves, so a
 // pass streams 4 B/item in + 4 B/item out plus an 8 B gather that hits L2 (N*8 B <= 12 MB for 1.4M tasks).
 //
-// One pass = three launches:
+// One pass of a LARGE input = three launches:
 //   radix_hist    : per-block 256-bin digit histogram (LDS atomics)              -> hist[digit][block]
 //   radix_scan    : exclusive scan of hist in (digit-major, block-minor) order    (single workgroup)
 //   radix_scatter : stable placement.  A block's tile is split into one contiguous chunk per wave; per-wave digit
 //                   counts give each wave its base, then every wave walks its chunk 64 items at a time, ranking equal
 //                   digits with 8 ballots (match-any) so earlier positions keep earlier slots.
-// The host skips passes whose digit is constant over the whole input (radix_varying_bits).
+// One pass of a pool-sized input (at most RS_FUSED_BLOCKS tiles of 2048: a pool's 175k tasks are 86) = two launches: the histogram is
+// kept [block][digit] and every scatter block sums the columns itself (thread d adds the counts of digit d over the earlier blocks
+// and over all blocks: nblocks coalesced loads, all in flight together) — the single-workgroup scan and its launch gap were a third
+// of a pass (9.6 + ~5 us of 45 + 15, profiles/r02k), and a chain of passes is what the rank stage is made of.
+// The host skips digits that are constant over the whole input (radix_varying_bits) and starts every digit at the lowest
+// varying bit not sorted yet, so sparse varying bits do not cost a pass per byte they touch.
 #pragma once
 #include "common.hpp"
 
 constexpr int RS_THREADS = 256;                     // 4 waves
 constexpr int RS_WAVES = RS_THREADS / COOK_WAVE;    // waves per block
-constexpr int RS_IPL = 16;                          // items per lane
-constexpr int RS_WAVE_ITEMS = COOK_WAVE * RS_IPL;   // 1024 contiguous items per wave
-constexpr int RS_TILE = RS_WAVES * RS_WAVE_ITEMS;   // 4096 items per block
+constexpr int RS_IPL_LARGE = 16;                    // items per lane: 4096 items per block
+constexpr int RS_IPL_SMALL = 8;                     // pool-sized inputs: 2048 items per block, twice the blocks (86 on 256 CUs for 175k)
+constexpr unsigned RS_FUSED_BLOCKS = COOK_SHAPE(128, 2);  // up to this many small tiles the scatter derives its bases itself
+constexpr unsigned rs_tile(int ipl) { return (unsigned)(RS_WAVES * COOK_WAVE * ipl); }
 
 static __device__ __forceinline__ unsigned rs_digit(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm_in,
                                                     unsigned i, unsigned shift) {
@@ -26,19 +32,25 @@ static __device__ __forceinline__ unsigned rs_digit(const uint64_t* __restrict__
   return (unsigned)(key[src] >> shift) & 0xFFu;
 }
 
+template <int IPL>
 __global__ void __launch_bounds__(RS_THREADS) radix_hist(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm_in,
-                                                         unsigned n, unsigned shift, unsigned nblocks,
+                                                         unsigned n, unsigned shift, unsigned nblocks, unsigned fused,
                                                          uint32_t* __restrict__ hist) {
   __shared__ unsigned h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
-  const unsigned base = blockIdx.x * RS_TILE;
-  for (int k = 0; k < RS_TILE / RS_THREADS; ++k) {
+  const unsigned base = blockIdx.x * rs_tile(IPL);
+  unsigned d[rs_tile(IPL) / RS_THREADS];
+#pragma unroll
+  for (unsigned k = 0; k < rs_tile(IPL) / RS_THREADS; ++k) {  // every gather in flight before the first LDS atomic
     const unsigned i = base + k * RS_THREADS + threadIdx.x;
-    if (i < n) atomicAdd(&h[rs_digit(key, perm_in, i, shift)], 1u);
+    d[k] = i < n ? rs_digit(key, perm_in, i, shift) : 0xFFFFFFFFu;
   }
+#pragma unroll
+  for (unsigned k = 0; k < rs_tile(IPL) / RS_THREADS; ++k)
+    if (d[k] != 0xFFFFFFFFu) atomicAdd(&h[d[k]], 1u);
   __syncthreads();
-  hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+  hist[fused ? blockIdx.x * 256u + threadIdx.x : threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // Exclusive scan of a u32 array by ONE workgroup of 1024 threads (len = 256 * nblocks: 11k entries for a pool's 175k tasks, 63k for a
@@ -112,23 +124,55 @@ __global__ void __launch_bounds__(SCAN1_THREADS) excl_scan_u32_single(uint32_t* 
   if (total_out && threadIdx.x == 0) *total_out = carry;
 }
 
+template <int IPL>
 __global__ void __launch_bounds__(RS_THREADS) radix_scatter(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm_in,
                                                             uint32_t* __restrict__ perm_out, unsigned n, unsigned shift,
-                                                            unsigned nblocks, const uint32_t* __restrict__ hist_scanned) {
+                                                            unsigned nblocks, unsigned fused, const uint32_t* __restrict__ hist) {
   __shared__ unsigned whist[RS_WAVES][256];
+  __shared__ unsigned wtot[RS_WAVES];
   const unsigned lane = lane_id(), w = wave_id();
   for (int k = 0; k < RS_WAVES; ++k) whist[k][threadIdx.x] = 0;
-  __syncthreads();
-  const unsigned wbase = blockIdx.x * RS_TILE + w * RS_WAVE_ITEMS;
-  // phase 1: per-wave digit counts
-  for (int k = 0; k < RS_IPL; ++k) {
-    const unsigned i = wbase + k * COOK_WAVE + lane;
-    if (i < n) atomicAdd(&whist[w][rs_digit(key, perm_in, i, shift)], 1u);
+  // fused: digit d = threadIdx.x; its count in the blocks before this one, and in all blocks (the loads do not wait for the LDS)
+  unsigned below = 0, total = 0;
+  if (fused) {
+    for (unsigned t = 0; t < nblocks; ++t) {
+      const unsigned v = hist[t * 256u + threadIdx.x];
+      total += v;
+      below += t < blockIdx.x ? v : 0u;
+    }
   }
   __syncthreads();
+  const unsigned wbase = blockIdx.x * rs_tile(IPL) + w * (COOK_WAVE * IPL);
+  // phase 1: the wave's items (kept in registers for phase 3) and its digit counts
+  unsigned src[IPL], dg[IPL];
+#pragma unroll
+  for (int k = 0; k < IPL; ++k) {
+    const unsigned i = wbase + k * COOK_WAVE + lane;
+    src[k] = i < n ? (perm_in ? perm_in[i] : i) : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int k = 0; k < IPL; ++k) dg[k] = src[k] != 0xFFFFFFFFu ? (unsigned)(key[src[k]] >> shift) & 0xFFu : 0u;
+#pragma unroll
+  for (int k = 0; k < IPL; ++k)
+    if (src[k] != 0xFFFFFFFFu) atomicAdd(&whist[w][dg[k]], 1u);
+  if (fused) {  // exclusive scan of the digit totals over the 256 threads
+    unsigned inc = total;
+    for (unsigned d = 1; d < COOK_WAVE; d <<= 1) {
+      const unsigned t = __shfl_up(inc, d, COOK_WAVE);
+      if (lane >= d) inc += t;
+    }
+    if (lane == COOK_WAVE - 1) wtot[w] = inc;
+    __syncthreads();
+    unsigned before = 0;
+    for (unsigned k = 0; k < (unsigned)RS_WAVES; ++k) before += k < w ? wtot[k] : 0u;
+    below += before + inc - total;
+  } else {
+    __syncthreads();
+    below = hist[threadIdx.x * nblocks + blockIdx.x];
+  }
   // phase 2: digit d = threadIdx.x; turn counts into each wave's starting slot
   {
-    unsigned base = hist_scanned[threadIdx.x * nblocks + blockIdx.x];
+    unsigned base = below;
     for (int k = 0; k < RS_WAVES; ++k) {
       const unsigned t = whist[k][threadIdx.x];
       whist[k][threadIdx.x] = base;
@@ -138,11 +182,10 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter(const uint64_t* __re
   __syncthreads();
   // phase 3: stable ranking inside the wave, 64 consecutive positions per step
   const unsigned long long lt = lanemask_lt();
-  for (int k = 0; k < RS_IPL; ++k) {
-    const unsigned i = wbase + k * COOK_WAVE + lane;
-    const bool valid = i < n;
-    const unsigned src = valid ? (perm_in ? perm_in[i] : i) : 0u;
-    const unsigned d = valid ? (unsigned)(key[src] >> shift) & 0xFFu : 0u;
+#pragma unroll
+  for (int k = 0; k < IPL; ++k) {
+    const bool valid = src[k] != 0xFFFFFFFFu;
+    const unsigned d = dg[k];
     unsigned long long peers = __ballot(valid);
     for (int b = 0; b < 8; ++b) {
       const unsigned long long m = __ballot(valid && ((d >> b) & 1u));
@@ -154,7 +197,7 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter(const uint64_t* __re
     if (valid) {
       const unsigned rank = (unsigned)__popcll(peers & lt);
       if (rank == 0) whist[w][d] = slot + (unsigned)__popcll(peers);  // lowest lane of the peer set
-      perm_out[slot + rank] = src;
+      perm_out[slot + rank] = src[k];
     }
     wave_sync();
   }
