@@ -151,11 +151,13 @@ def main():
         cycle()
     fence()
     lat = []
+    phases = []
     t_start = time.perf_counter()
     for _ in range(args.steps):
         t1 = time.perf_counter()
         cycle()
         lat.append(time.perf_counter() - t1)
+        phases.append(cluster.last_phase_ms)
     fence()
     elapsed = time.perf_counter() - t_start
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -424,6 +426,8 @@ def main():
             "last_cycle": {"ranked": ranked_n, "considered": considered, "matched": matched,
                            "stage_ms_pool0": {"rank": stage_ms[my_pools[0]][0], "match": stage_ms[my_pools[0]][1]},
                            "placement_stats_pool0": engines[my_pools[0]].match_stats()},
+            "phase_ms": dict(zip(("pool_usage_allreduce", "rank", "placement", "user_usage_allreduce"),
+                                 (float(np.median([ph[x] for ph in phases])) for x in range(4)))),
             "setup_s": gen_s,
             "roofline": roofline, "cpu_baseline": cpu, "adjacent_rows": adjacent, "extra_configs": extra, "boundary": boundary,
             "parity_checked": parity_checked, "parity": {"against": "oracle (bit-exact rank order + every assignment)", "pools": parity_pools},

@@ -29,6 +29,9 @@ struct RebalBufs {
   DArr<uint64_t> hkey;
   DArr<uint32_t> hpermA, hpermB, hstart, hend, hbase, h_pb, h_user, hidx, chg, chg_tile, chg_bad, chg_mark;
   DArr<SumU4> tile_agg, tile_carry;
+  DArr<uint32_t> dl_pos;
+  DArr<int32_t> dl_sign;
+  std::vector<uint32_t> user_safe_h;  // read back once per run: all ones = the re-scoring takes the one-launch path (rebal_rs_delta)
   DArr<uint32_t> x_head, x_cnt, x_next, big_list;
   DArr<double> h_cpus, h_mem, h_gpus, h_dru;
   DArr<uint8_t> h_act;
@@ -321,6 +324,8 @@ RebalIn rebalance_args(cook_engine* e, RebalBufs& b) {
   in.x_cnt = b.x_cnt.ptr();
   in.pre_w = b.pre.ptr();
   in.dru_w = b.dru.ptr();
+  in.dl_pos = b.dl_pos.ptr();
+  in.dl_sign = b.dl_sign.ptr();
   return in;
 }
 
@@ -407,6 +412,8 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
     sync(e);
     KL("rebal_user_safe", rebal_user_safe, gS, 256, (const uint32_t*)b.user.ptr(), (const double*)b.cpus.ptr(), (const double*)b.mem.ptr(),
        (const double*)b.gpus.ptr(), S, (const uint32_t*)b.seg_start.ptr(), (const uint32_t*)b.seg_end.ptr(), b.user_safe.ptr());
+    b.user_safe_h.assign(std::max(1u, U), 1u);
+    COOK_HIP(hipMemcpyAsync(b.user_safe_h.data(), b.user_safe.ptr(), (size_t)std::max(1u, U) * 4, hipMemcpyDeviceToHost, e->stream));  // read after the sync below
   }
   // ---- running tasks grouped by host (the group-by of rebalancer.clj:349, done once) --------------------------------------------
   b.hstart.ensure(std::max(1u, H));
@@ -439,6 +446,7 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   b.hidx.ensure(S);
   b.chg.ensure(S + 1), b.chg_tile.ensure(S + 2), b.chg_bad.ensure(S + 1), b.chg_mark.ensure(std::max(1u, U));
   b.tile_agg.ensure(S / RB_RS_TILE + S + 2), b.tile_carry.ensure(S / RB_RS_TILE + S + 2);  // every listed user adds at most one partial tile
+  b.dl_pos.ensure(S + 1), b.dl_sign.ensure(S + 1);
   b.x_head.ensure(std::max(1u, H)), b.x_cnt.ensure(std::max(1u, H)), b.x_next.ensure(std::max(1u, P)), b.big_list.ensure(std::max(1u, H));
   COOK_HIP(hipMemsetAsync(b.chg_mark.ptr(), 0, (size_t)std::max(1u, U) * 4, e->stream));
   COOK_HIP(hipMemsetAsync(b.x_head.ptr(), 0xFF, (size_t)std::max(1u, H) * 4, e->stream));
@@ -488,16 +496,27 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   // ---- the decision loop (rebalancer.clj:442-458) ---------------------------------------------------------------------------------
   const RebalIn in = rebalance_args(e, b);
   unsigned known_max = b.max_seg, known_at = 0;  // items of the fullest host when the control block was last read back
+  // every user safe (integer-valued resources, the usual case): the changed users are re-scored by ONE launch from the slots the decision
+  // flipped (rebal_rs_delta) and rebal_apply prepares the next job itself — 3 launches per pending job instead of 7.  Otherwise the general
+  // path: tile scans with exactness tracking, left-to-right redo of the users where an addition rounded.
+  bool all_safe = std::getenv("COOK_REBAL_GENERAL") == nullptr;
+  for (unsigned u = 0; u < U && all_safe; ++u) all_safe = b.user_safe_h[u] != 0u;
+  if (all_safe && P) KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, 0u);
   for (unsigned pj = 0; pj < P; ++pj) {
-    KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, pj);
+    if (!all_safe) KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, pj);
     if (H) KL("rebal_decide", rebal_decide, div_up(div_up(H, 2u), RB_WAVES), COOK_WAVE * RB_WAVES, in);
     // hosts beyond 64 items: only when one can exist (the fullest host as last read back + the jobs placed since then)
     if (H && known_max + (pj - known_at) > (unsigned)COOK_WAVE) KL("rebal_decide_big", rebal_decide_big, 32, COOK_WAVE * RB_WAVES, in);
-    KL("rebal_apply", rebal_apply, 1, RB_APPLY_THREADS, in);
-    KL("rebal_rs_local", rebal_rs_local, RB_RS_GRID, RB_RS_TILE, in);
-    KL("rebal_rs_carry", rebal_rs_carry, RB_RS_USERS, COOK_WAVE, in);
-    KL("rebal_rs_finish", rebal_rs_finish, RB_RS_GRID, RB_RS_TILE, in);
-    KL("rebal_rs_fix", rebal_rs_fix, RB_RS_USERS, 256, in);
+    if (all_safe) {
+      KL("rebal_apply", rebal_apply, 1, RB_APPLY_THREADS, in, pj + 1 < P ? pj + 1 : 0xFFFFFFFFu);
+      KL("rebal_rs_delta", rebal_rs_delta, RB_RS_GRID, RB_RS_TILE, in);
+    } else {
+      KL("rebal_apply", rebal_apply, 1, RB_APPLY_THREADS, in, 0xFFFFFFFFu);
+      KL("rebal_rs_local", rebal_rs_local, RB_RS_GRID, RB_RS_TILE, in);
+      KL("rebal_rs_carry", rebal_rs_carry, RB_RS_USERS, COOK_WAVE, in);
+      KL("rebal_rs_finish", rebal_rs_finish, RB_RS_GRID, RB_RS_TILE, in);
+      KL("rebal_rs_fix", rebal_rs_fix, RB_RS_USERS, 256, in);
+    }
     if ((pj + 1) % RB_CHECK == 0 && pj + 1 < P) {
       COOK_HIP(hipMemcpyAsync(e->h_scratch, b.ctl.ptr(), sizeof(RebalCtl), hipMemcpyDeviceToHost, e->stream));
       sync(e);

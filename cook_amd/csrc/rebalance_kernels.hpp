@@ -39,7 +39,7 @@ struct RebalCtl {
   unsigned n_big;       // hosts listed in big_list
   unsigned max_items;   // running tasks + placed jobs of the fullest host so far (the host decides from it whether rebal_decide_big
                         // can have work: read back with the budget)
-  unsigned pad_;
+  unsigned n_delta;     // slots whose active flag the last decision flipped (dl_pos / dl_sign)
 };
 
 struct RebalJob {  // context of the pending job being decided (written by rebal_job_prep)
@@ -90,6 +90,8 @@ struct RebalIn {
   SumU4 *tile_agg, *tile_carry;   // [S / RB_RS_TILE + S + 2] tile totals / carries
   SumU4* pre_w;                   // writable aliases of pre / dru
   double* dru_w;
+  uint32_t* dl_pos;               // [S + 1] B positions whose active flag the last decision flipped ...
+  int32_t* dl_sign;               // [S + 1] ... -1: a preempted task left, +1: the placed job joined (rebal_rs_delta)
   const int32_t* row_of_host;     // [H] row of the host in the attribute table, -1 = not cached
   double *spare_c, *spare_m, *spare_g;
   uint8_t* has_spare;
@@ -438,8 +440,81 @@ __global__ void __launch_bounds__(256) rebal_rs_fix(RebalIn in) {
   }
 }
 
+// Re-scoring when EVERY user is safe (rebal_user_safe: all sums exact in any association — integer-valued resources, the usual
+// case): the masked prefix sums after a decision are the ones before it plus the usage of the slots that joined, minus the usage of
+// the slots that left, at or before each position — exact, so bit-identical to scanning again.  One launch over the tiles of the
+// changed users instead of four (local scans, carries, finish, fix), no dependency between tiles, and tiles before a user's first
+// flipped slot are skipped.  The flipped slots (one per preempted task + the placed job: a handful) are listed by rebal_apply.
+constexpr int RB_DL_LDS = 64;  // flips staged in LDS; a longer list is read from memory
+static __device__ __forceinline__ SumU4 rebal_delta_upto(const RebalIn& in, const uint32_t* pos, const int32_t* sign, unsigned n_dl, unsigned s0,
+                                                         unsigned upto) {
+  // flips of the user whose segment starts at s0, at positions s0..upto (a segment is contiguous in B: position alone tells the user)
+  SumU4 add = SumU4::zero();
+  for (unsigned k = 0; k < n_dl; ++k) {
+    const unsigned p = pos[k];
+    if (p < s0 || p > upto) continue;
+    const SumU4 v = in.s_use[p];
+    if (sign[k] < 0) add.count -= v.count, add.cpus -= v.cpus, add.mem -= v.mem, add.gpus -= v.gpus;
+    else add.count += v.count, add.cpus += v.cpus, add.mem += v.mem, add.gpus += v.gpus;
+  }
+  return add;
+}
+__global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_delta(RebalIn in) {
+  __shared__ uint32_t s_pos[RB_DL_LDS];
+  __shared__ int32_t s_sign[RB_DL_LDS];
+  __shared__ SumU4 s_val[RB_DL_LDS];
+  const unsigned n_chg = in.ctl->n_changed, n_tiles = in.ctl->n_tiles, n_dl = in.ctl->n_delta;
+  if (n_chg == 0u || n_dl == 0u) return;
+  const unsigned tid = threadIdx.x;
+  const bool staged = n_dl <= (unsigned)RB_DL_LDS;
+  if (staged && tid < n_dl) {
+    const unsigned p = in.dl_pos[tid];
+    s_pos[tid] = p;
+    s_sign[tid] = in.dl_sign[tid];
+    s_val[tid] = in.s_use[p];
+  }
+  __syncthreads();
+  for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const unsigned x = rebal_rs_user_of_tile(in, n_chg, tile), u = in.chg[x];
+    const unsigned s0 = in.seg_start[u], s1 = in.seg_end[u];
+    const unsigned i0 = s0 + (tile - in.chg_tile[x]) * RB_RS_TILE, i = i0 + tid;
+    SumU4 add = SumU4::zero();
+    bool any = false;
+    if (staged) {
+      for (unsigned k = 0; k < n_dl; ++k) {
+        const unsigned p = s_pos[k];
+        if (p < s0 || p >= s1 || p > i) continue;  // another user's, or behind this slot
+        any = true;
+        const SumU4 v = s_val[k];
+        if (s_sign[k] < 0) add.count -= v.count, add.cpus -= v.cpus, add.mem -= v.mem, add.gpus -= v.gpus;
+        else add.count += v.count, add.cpus += v.cpus, add.mem += v.mem, add.gpus += v.gpus;
+      }
+    } else {
+      for (unsigned k = 0; k < n_dl; ++k) {
+        const unsigned p = in.dl_pos[k];
+        if (p < s0 || p >= s1 || p > i) continue;
+        any = true;
+        const SumU4 v = in.s_use[p];
+        if (in.dl_sign[k] < 0) add.count -= v.count, add.cpus -= v.cpus, add.mem -= v.mem, add.gpus -= v.gpus;
+        else add.count += v.count, add.cpus += v.cpus, add.mem += v.mem, add.gpus += v.gpus;
+      }
+    }
+    if (i < s1 && any) {
+      const SumU4 o = in.pre[i];
+      const SumU4 t{o.count + add.count, o.cpus + add.cpus, o.mem + add.mem, o.gpus + add.gpus, 0u};
+      in.pre_w[i] = t;
+      const double d = rebal_dru_of(in, u, t);
+      in.dru_w[i] = d;
+      const unsigned hi = in.hidx[i];
+      if (hi != 0xFFFFFFFFu) in.h_dru[hi] = d;
+    }
+  }
+}
+
 // ---- per pending job: quota test, pending DRU, group cohosts -------------------------------------------------------------
-__global__ void __launch_bounds__(COOK_WAVE) rebal_job_prep(RebalIn in, unsigned pj) {
+// n_dl > 0 (only from rebal_apply, every user safe): the prefix sums and DRUs in memory are the ones BEFORE the decision just taken
+// — rebal_rs_delta runs after this — so the two values read from them are corrected by the flips at or before their positions.
+static __device__ __forceinline__ void rebal_job_prep_dev(const RebalIn& in, unsigned pj, unsigned n_dl) {
   const unsigned lane = lane_id();
   RebalJob jb;
   jb.active = 0;
@@ -451,7 +526,6 @@ __global__ void __launch_bounds__(COOK_WAVE) rebal_job_prep(RebalIn in, unsigned
   jb.minim = jb.maxfreq = 0;
   jb.pad0 = jb.pad1 = 0;
   jb.pdru = jb.c = jb.m = jb.g = 0.0;
-  if (lane == 0) in.ctl->n_changed = 0u;  // nothing to re-score unless rebal_apply takes a decision
   if (in.ctl->remaining <= 0) {
     if (lane == 0) *in.job = jb;
     return;
@@ -471,7 +545,11 @@ __global__ void __launch_bounds__(COOK_WAVE) rebal_job_prep(RebalIn in, unsigned
   if (in.user_safe[us] && okv(jc) && okv(jm) && okv(jg)) {
     // every partial sum is exact whatever the association: the job + the scan's total over the user's active tasks
     if (s1 > s0) {
-      const SumU4 t = in.pre[s1 - 1];
+      SumU4 t = in.pre[s1 - 1];
+      if (n_dl) {
+        const SumU4 a = rebal_delta_upto(in, in.dl_pos, in.dl_sign, n_dl, s0, s1 - 1);
+        t = SumU4{t.count + a.count, t.cpus + a.cpus, t.mem + a.mem, t.gpus + a.gpus, 0u};
+      }
       fu = SumU4{1.0 + t.count, jc + t.cpus, jm + t.mem, jg + t.gpus, 0u};
     }
     // nearest active slot before the job's own: almost always in the first chunk (only preempted tasks are inactive)
@@ -519,7 +597,12 @@ __global__ void __launch_bounds__(COOK_WAVE) rebal_job_prep(RebalIn in, unsigned
   jb.m = jm;
   jb.g = jg;
   // rebalancer.clj:157-208: nearest task at or before the synthetic pending task in the user's order
-  const double near = last >= 0 ? in.dru[last] : 0.0;
+  double near = last >= 0 ? in.dru[last] : 0.0;
+  if (n_dl && last >= 0) {
+    const SumU4 a = rebal_delta_upto(in, in.dl_pos, in.dl_sign, n_dl, s0, (unsigned)last);
+    const SumU4 o = in.pre[last];
+    near = rebal_dru_of(in, us, SumU4{o.count + a.count, o.cpus + a.cpus, o.mem + a.mem, o.gpus + a.gpus, 0u});
+  }
   if (in.dru_mode == 1) {
     jb.pdru = near + jg / in.div_gpus[us];
   } else {
@@ -573,6 +656,10 @@ __global__ void __launch_bounds__(COOK_WAVE) rebal_job_prep(RebalIn in, unsigned
     *in.job = jb;
     if (in.pending_dru) in.pending_dru[pj] = jb.pdru;
   }
+}
+__global__ void __launch_bounds__(COOK_WAVE) rebal_job_prep(RebalIn in, unsigned pj) {
+  if (lane_id() == 0) in.ctl->n_changed = 0u, in.ctl->n_delta = 0u;  // nothing to re-score unless rebal_apply takes a decision
+  rebal_job_prep_dev(in, pj, 0u);
 }
 
 // job constraints of the rebalancer on the attribute map of row r (r < 0: nil map); constraints.clj:459-466 through the
@@ -1173,12 +1260,14 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide_big(RebalIn 
 
 // ---- arg-max over hosts + next-state (rebalancer.clj:270-309, 404) -----------------------------------------------------------
 constexpr int RB_APPLY_THREADS = 1024;
-__global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in) {
+// pj_next != COOK_NONE (every user safe, rebalance_run): the workgroup goes on to prepare the NEXT pending job (rebal_job_prep_dev
+// with this decision's flips) — one launch less per pending job; the re-scoring of the changed users follows as rebal_rs_delta.
+__global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in, unsigned pj_next) {
   __shared__ unsigned long long s_key[RB_APPLY_THREADS / COOK_WAVE];
   __shared__ unsigned s_host[RB_APPLY_THREADS / COOK_WAVE];
   __shared__ uint32_t s_rank[COOK_WAVE], s_pre[COOK_WAVE];
   const RebalJob jb = *in.job;
-  if (!jb.active) return;
+  if (!jb.active) return;  // the budget is spent: the next job stays inactive too
   const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
   // arg-max of the hosts' keys, the later host winning ties (max-key, rebalancer.clj:404).  Eight independent loads in flight per
   // thread: a dependent one-load-per-iteration loop over 50k hosts was the larger half of this kernel.
@@ -1210,74 +1299,91 @@ __global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in) {
     const unsigned oh = __shfl_xor(bh, d, COOK_WAVE);
     if (ok > bk || (ok == bk && ok != 0ull && oh > bh)) bk = ok, bh = oh;
   }
-  if (bk == 0ull) return;  // no host can take the job: no decision, state unchanged (rebalancer.clj:455-458)
-  const unsigned h = bh;
-  const unsigned len = in.hres_len[h], base = in.hres_base[h];
-  // the preempted tasks = the first `len` candidates of the host in priority order: a small host's are re-derived here (one wave,
-  // registers), a large host's were listed by rebal_decide
-  if (base == 0xFFFFFFFFu) {
-    const unsigned hs = in.hstart[h];
-    HostBest hb;
-    unsigned ss;
-    rebal_host_small(in, jb, h, hs, in.hend[h] - hs, in.x_cnt[h], in.has_spare[h] != 0, s_rank, hb, ss);
-    s_pre[lane] = ss;
+  unsigned n_dl = 0;
+  if (bk != 0ull) {  // (wave-uniform)  0: no host can take the job — no decision, state unchanged (rebalancer.clj:455-458)
+    const unsigned h = bh;
+    const unsigned len = in.hres_len[h], base = in.hres_base[h];
+    // the preempted tasks = the first `len` candidates of the host in priority order: a small host's are re-derived here (one wave,
+    // registers), a large host's were listed by rebal_decide
+    if (base == 0xFFFFFFFFu) {
+      const unsigned hs = in.hstart[h];
+      HostBest hb;
+      unsigned ss;
+      rebal_host_small(in, jb, h, hs, in.hend[h] - hs, in.x_cnt[h], in.has_spare[h] != 0, s_rank, hb, ss);
+      s_pre[lane] = ss;
+    }
+    wave_sync();
+    if (lane == 0) {
+      RebalCtl c = *in.ctl;
+      cook_preemption d;
+      d.pending_index = jb.pj;
+      d.host = h;
+      d.dru = in.hres_dru[h];
+      d.cpus = in.hres_c[h];
+      d.mem = in.hres_m[h];
+      d.gpus = in.hres_g[h];
+      d.task_off = c.np;
+      d.task_n = len;
+      in.decisions[c.nd++] = d;
+      bool first_known = false;
+      unsigned n_chg = 0, n_tiles = 0;
+      const unsigned stamp = c.nd;  // decisions are numbered from 1 here (nd was just incremented): 0 = never listed
+      auto changed = [&](unsigned u) {
+        if (in.chg_mark[u] == stamp) return;  // listed already by this decision
+        in.chg_mark[u] = stamp;
+        in.chg[n_chg] = u;
+        in.chg_bad[n_chg] = 0u;
+        in.chg_tile[n_chg] = n_tiles;
+        n_tiles += (in.seg_end[u] - in.seg_start[u] + RB_RS_TILE - 1) / RB_RS_TILE;
+        ++n_chg;
+      };
+      changed(jb.us);
+      for (unsigned k = 0; k < len; ++k) {
+        const unsigned slot = base == 0xFFFFFFFFu ? s_pre[k] : in.srt_slot[base + k];
+        const unsigned pbk = in.posB[slot];
+        in.act[pbk] = 0;
+        in.dl_pos[n_dl] = pbk, in.dl_sign[n_dl] = -1;
+        ++n_dl;
+        if (slot < in.R) in.h_act[in.hidx[pbk]] = 0;
+        changed(in.slot_user[slot]);
+        in.preempted[c.np++] = slot < in.R ? slot : 0xFFFFFFFFu;  // a task placed this cycle is reported as NONE (rebalancer.clj:529)
+        const bool known = slot < in.R ? (in.attrs_cached ? in.attrs_cached[slot] != 0 : true) : in.x_known[slot - in.R] != 0;
+        if (k == 0) first_known = known;
+        if (known) in.pre_hosts[c.n_pre_hosts++] = h;
+      }
+      // the job becomes a task of its user on that host, carrying the slave id of the first preempted task (:279-281)
+      const unsigned pbj = in.posB[in.R + jb.pj];
+      in.act[pbj] = 1;
+      in.dl_pos[n_dl] = pbj, in.dl_sign[n_dl] = 1;
+      ++n_dl;
+      in.x_host[jb.pj] = h;
+      in.x_known[jb.pj] = (len > 0 && first_known) ? 1 : 0;
+      in.x_next[jb.pj] = in.x_head[h];  // joins the host's chain of placed jobs
+      in.x_head[h] = jb.pj;
+      in.x_cnt[h] += 1u;
+      if (in.hend[h] - in.hstart[h] + in.x_cnt[h] > c.max_items) c.max_items = in.hend[h] - in.hstart[h] + in.x_cnt[h];
+      if (in.hend[h] - in.hstart[h] <= (unsigned)COOK_WAVE && in.hend[h] - in.hstart[h] + in.x_cnt[h] == (unsigned)COOK_WAVE + 1u)
+        in.big_list[c.n_big++] = h;  // this placement takes the host past 64 items
+      in.x_pj[c.n_x] = jb.pj;            // ... and the list of all of them (placement order)
+      c.n_x += 1;
+      in.spare_c[h] = d.cpus - jb.c;  // rebalancer.clj:302-305
+      in.spare_m[h] = d.mem - jb.m;
+      in.spare_g[h] = d.gpus - jb.g;
+      in.has_spare[h] = 1;
+      c.remaining -= 1;
+      in.chg_tile[n_chg] = n_tiles;
+      c.n_changed = n_chg;
+      c.n_tiles = n_tiles;
+      c.n_delta = n_dl;
+      *in.ctl = c;
+    }
+  } else if (lane == 0 && pj_next != 0xFFFFFFFFu) {
+    in.ctl->n_changed = 0u;  // (the stand-alone rebal_job_prep resets these before the decision)
+    in.ctl->n_delta = 0u;
   }
+  if (pj_next == 0xFFFFFFFFu) return;
+  __threadfence();  // lane 0's writes (active flags, the flip list, the control block) before the whole wave reads them
+  n_dl = (unsigned)wave_read_lane((int)n_dl, 0);
   wave_sync();
-  if (lane != 0) return;
-  RebalCtl c = *in.ctl;
-  cook_preemption d;
-  d.pending_index = jb.pj;
-  d.host = h;
-  d.dru = in.hres_dru[h];
-  d.cpus = in.hres_c[h];
-  d.mem = in.hres_m[h];
-  d.gpus = in.hres_g[h];
-  d.task_off = c.np;
-  d.task_n = len;
-  in.decisions[c.nd++] = d;
-  bool first_known = false;
-  unsigned n_chg = 0, n_tiles = 0;
-  const unsigned stamp = c.nd;  // decisions are numbered from 1 here (nd was just incremented): 0 = never listed
-  auto changed = [&](unsigned u) {
-    if (in.chg_mark[u] == stamp) return;  // listed already by this decision
-    in.chg_mark[u] = stamp;
-    in.chg[n_chg] = u;
-    in.chg_bad[n_chg] = 0u;
-    in.chg_tile[n_chg] = n_tiles;
-    n_tiles += (in.seg_end[u] - in.seg_start[u] + RB_RS_TILE - 1) / RB_RS_TILE;
-    ++n_chg;
-  };
-  changed(jb.us);
-  for (unsigned k = 0; k < len; ++k) {
-    const unsigned slot = base == 0xFFFFFFFFu ? s_pre[k] : in.srt_slot[base + k];
-    const unsigned pbk = in.posB[slot];
-    in.act[pbk] = 0;
-    if (slot < in.R) in.h_act[in.hidx[pbk]] = 0;
-    changed(in.slot_user[slot]);
-    in.preempted[c.np++] = slot < in.R ? slot : 0xFFFFFFFFu;  // a task placed this cycle is reported as NONE (rebalancer.clj:529)
-    const bool known = slot < in.R ? (in.attrs_cached ? in.attrs_cached[slot] != 0 : true) : in.x_known[slot - in.R] != 0;
-    if (k == 0) first_known = known;
-    if (known) in.pre_hosts[c.n_pre_hosts++] = h;
-  }
-  // the job becomes a task of its user on that host, carrying the slave id of the first preempted task (:279-281)
-  in.act[in.posB[in.R + jb.pj]] = 1;
-  in.x_host[jb.pj] = h;
-  in.x_known[jb.pj] = (len > 0 && first_known) ? 1 : 0;
-  in.x_next[jb.pj] = in.x_head[h];  // joins the host's chain of placed jobs
-  in.x_head[h] = jb.pj;
-  in.x_cnt[h] += 1u;
-  if (in.hend[h] - in.hstart[h] + in.x_cnt[h] > c.max_items) c.max_items = in.hend[h] - in.hstart[h] + in.x_cnt[h];
-  if (in.hend[h] - in.hstart[h] <= (unsigned)COOK_WAVE && in.hend[h] - in.hstart[h] + in.x_cnt[h] == (unsigned)COOK_WAVE + 1u)
-    in.big_list[c.n_big++] = h;  // this placement takes the host past 64 items
-  in.x_pj[c.n_x] = jb.pj;            // ... and the list of all of them (placement order)
-  c.n_x += 1;
-  in.spare_c[h] = d.cpus - jb.c;  // rebalancer.clj:302-305
-  in.spare_m[h] = d.mem - jb.m;
-  in.spare_g[h] = d.gpus - jb.g;
-  in.has_spare[h] = 1;
-  c.remaining -= 1;
-  in.chg_tile[n_chg] = n_tiles;
-  c.n_changed = n_chg;
-  c.n_tiles = n_tiles;
-  *in.ctl = c;
+  rebal_job_prep_dev(in, pj_next, n_dl);
 }

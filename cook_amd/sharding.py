@@ -14,6 +14,7 @@ The per-pool compute is behind the tiny `PoolEngine` protocol so that the same c
 from __future__ import annotations
 
 import os
+import time
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Protocol, Sequence
@@ -116,6 +117,8 @@ class ShardedCluster:
         self.last_pool_usage: Dict[int, Sequence[float]] = {}
         self.n_users = 0                      # > 0: every cycle also all-reduces the cross-pool per-user usage [U, 3]
         self.last_user_usage: Optional[np.ndarray] = None
+        self.last_phase_ms = (0.0, 0.0, 0.0, 0.0)
+        self.chain_whole_cycle = os.environ.get("COOK_CHAIN_WHOLE_CYCLE", "0") != "0"
 
     def close(self):
         self._tp.shutdown(wait=True)
@@ -137,11 +140,13 @@ class ShardedCluster:
                             pool_usage=A.usage(*pool_usage))
 
     def cycle(self, num_considerable: int):
+        t0 = time.perf_counter()
         usages = dict(zip(self.pools, self._tp.map(lambda p: self.engines[p].rank_pool_usage().as_tuple(), self.pools)))
         total = all_reduce_group_usage(group_usage_matrix(self.groups, usages), self.world, self.device)
         self.last_group_usage = total
         self.last_pool_usage = usages
 
+        t1 = time.perf_counter()
         multi = all(hasattr(self.engines[p], "cycle_run_rank") for p in self.pools)
         # match_algo 5: ONE persistent launch places all local pools, every pool advancing on its own (match_world.hpp)
         world = multi and all(getattr(getattr(self.engines[p], "params", None), "match_algo", 0) == 5 for p in self.pools)
@@ -154,18 +159,35 @@ class ShardedCluster:
             else:
                 self.engines[p].cycle_run(num_considerable)
 
-        list(self._tp_rank.map(run, self.pools))  # the rank stages are chains of small kernels too: at most max_chains at a time
-        if lockstep:
+        n_chains = min(len(self.pools), self.max_chains)
+        if lockstep and not world and self.chain_whole_cycle:
             # MI355X runs about four independent chains of small kernels at full speed (beyond that the hardware queues
             # share dispatch pipes: 4 pools 113 ms, 6 or 8 pools 186 ms per cycle), while pools in lockstep pay for the
-            # slowest pool of every round (8 in lockstep: 215 ms).  So: at most MAX_CHAINS streams, pools spread over them.
+            # slowest pool of every round (8 in lockstep: 215 ms).  So: at most MAX_CHAINS chains, pools spread over them;
+            # a chain ranks its pools one after the other and goes straight on to their placement rounds.
             from .engine import cycle_match_multi
-            if world:
-                cycle_match_multi([self.engines[p] for p in self.pools])
-                n_chains = 0
-            n_chains = min(len(self.pools), self.max_chains) if not world else 0
-            if n_chains:
-                groups = [[self.engines[p] for p in self.pools[c::n_chains]] for c in range(n_chains)]
-                list(self._tp.map(cycle_match_multi, groups))
+
+            def chain(c):
+                mine = self.pools[c::n_chains]
+                for p in mine:
+                    run(p)
+                cycle_match_multi([self.engines[p] for p in mine])
+
+            list(self._tp.map(chain, range(n_chains)))
+            t2 = time.perf_counter()
+        else:
+            list(self._tp_rank.map(run, self.pools))  # the rank stages are chains of small kernels too: at most max_chains at a time
+            t2 = time.perf_counter()
+            if lockstep:
+                from .engine import cycle_match_multi
+                if world:
+                    cycle_match_multi([self.engines[p] for p in self.pools])
+                else:
+                    groups = [[self.engines[p] for p in self.pools[c::n_chains]] for c in range(n_chains)]
+                    list(self._tp.map(cycle_match_multi, groups))
+        t3 = time.perf_counter()
         if self.n_users and all(hasattr(self.engines[p], "rank_user_usage") for p in self.pools):
             self.last_user_usage = all_reduce_user_usage([self.engines[p] for p in self.pools], self.n_users, self.world, self.device)
+        # host wall time of the phases: pool usage + all-reduce, rank (+ the whole cycle of pools that run on their own chain),
+        # lockstep placement, per-user usage all-reduce
+        self.last_phase_ms = tuple(1e3 * x for x in (t1 - t0, t2 - t1, t3 - t2, time.perf_counter() - t3))

@@ -289,6 +289,40 @@ def rebalance_parity(make_engine, b, min_decisions=0):
     return got
 
 
+def rebalance_paths(make_engine):
+    """Which re-scoring path ran (cook_kernel_timings): integer-valued resources -> one launch from the flipped slots
+    (rebal_rs_delta, the next job prepared inside rebal_apply); a fractional resource -> tile scans + left-to-right redo; and the
+    general path forced on the integer inputs gives the same decisions."""
+    import os
+
+    def run(b):
+        with make_engine(b["params"]) as e:
+            e.set_profiling(True)
+            e.rebalance_stage(b["running"], b["pending"], b["pending_job_id"], b["pending_priority"], b["users"], b["spare"],
+                              b["rparams"], host_attrs=b["host_attrs"], groups=b["groups"])
+            e.rebalance_run()
+            got = e.rebalance_fetch()
+            names = set(e.kernel_timings())
+        want = pyoracle.rebalance(b["params"], b["running"], b["pending"], b["pending_job_id"], b["pending_priority"], b["users"],
+                                  b["spare"], b["rparams"], host_attrs=b["host_attrs"], groups=b["groups"])
+        _rebal_equal(got, want, "paths")
+        assert len(got["decisions"]) >= 3
+        return names
+    for kw in (dict(seed=57, n_running=3600, n_pending=10, n_users=2, n_hosts=90),
+               dict(seed=54, n_running=500, n_pending=40, n_users=15, n_hosts=40, constraints=True, gpus=True)):
+        integer = make_rebalance_case(**kw)
+        names = run(integer)
+        assert "rebal_rs_delta" in names and "rebal_rs_local" not in names, names
+        os.environ["COOK_REBAL_GENERAL"] = "1"
+        try:
+            names = run(integer)
+        finally:
+            del os.environ["COOK_REBAL_GENERAL"]
+        assert "rebal_rs_local" in names and "rebal_rs_delta" not in names, names
+    names = run(make_rebalance_case(seed=58, n_running=2600, n_pending=8, n_users=2, n_hosts=70, fractional=True))
+    assert "rebal_rs_local" in names and "rebal_rs_delta" not in names, names
+
+
 # ---- considerable jobs ------------------------------------------------------------------------------------------------
 def check_considerable_golden(make_engine):
     from tests.test_oracle_golden import check_considerable_case

@@ -212,6 +212,10 @@ def test_rebalance_parity_random(make_engine, kw):
     P.rebalance_parity(make_engine, P.make_rebalance_case(**kw))
 
 
+def test_rebalance_rescoring_paths(make_engine):
+    P.rebalance_paths(make_engine)
+
+
 def test_considerable_golden(make_engine):
     P.check_considerable_golden(make_engine)
 
@@ -251,6 +255,42 @@ def test_multi_pool(make_engine, algo):
              synth.make_pool(seed=72, n_pending=150, n_running=50, n_users=10, n_offers=40),
              synth.make_pool(seed=73, n_pending=0, n_running=30, n_users=5, n_offers=20)]
     P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0, match_algo=algo), k=300, want_persistent=2 if algo == 5 else 0)
+
+
+@pytest.mark.parametrize("whole", [True, False], ids=["chain-runs-rank-and-placement", "rank-barrier-placement"])
+def test_sharded_cluster_lockstep_chains(make_engine, whole):
+    # ShardedCluster.cycle as bench.py drives it, five pools on two launch chains (slots 3 + 2): quota inputs, rank per pool,
+    # lockstep placement per chain; every pool against the oracle, on a repeated cycle
+    from cook_amd import sharding, workload
+    from oracle import checks
+    spec = workload.ClusterSpec(pools=5, pending=1500, running=500, offers=400, users=40)
+    params = A.default_params(good_enough_fitness=1.0)
+    pools = workload.make_pools(spec, range(spec.pools))
+    engines = {}
+    try:
+        for p, pool in pools.items():
+            engines[p] = make_engine(params)
+            engines[p].cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        cl = sharding.ShardedCluster(engines, workload.quota_groups(spec))
+        cl.max_chains, cl.chain_whole_cycle = 2, whole
+        cl.close()
+
+        class Serial:  # the emulator runs one launch at a time (one process-wide fiber scheduler): the chains take turns here
+            map = staticmethod(lambda fn, xs: [fn(x) for x in xs])
+            shutdown = staticmethod(lambda wait=True: None)
+        cl._tp = cl._tp_rank = Serial()
+        K = spec.per_pool[0]
+        cl.cycle(K)
+        cl.cycle(K)
+        assert cl.last_phase_ms[1] > 0.0
+        for p in pools:
+            ranked, j2o, _ = engines[p].cycle_fetch()
+            q = cl.quota_inputs(p, cl.last_pool_usage[p], cl.last_group_usage)
+            checks.check_pool_against_oracle(params, pools[p], q, ranked, j2o, K)
+        cl.close()
+    finally:
+        for e in engines.values():
+            e.close()
 
 
 def test_world_many_pools_good_enough(make_engine):

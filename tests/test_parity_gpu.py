@@ -228,6 +228,10 @@ def test_rebalance_parity_random(make_engine, kw):
     P.rebalance_parity(make_engine, P.make_rebalance_case(**kw))
 
 
+def test_rebalance_rescoring_paths(make_engine):
+    P.rebalance_paths(make_engine)
+
+
 def test_considerable_golden(make_engine):
     P.check_considerable_golden(make_engine)
 
