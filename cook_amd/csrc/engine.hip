@@ -310,7 +310,7 @@ static void radix_pass_t(cook_engine* e, const uint64_t* key, const uint32_t* in
 }
 void radix_pass(cook_engine* e, const uint64_t* key, const uint32_t* in, uint32_t* out, unsigned n, unsigned shift) {
   if (div_up(n, rs_tile(RS_IPL_SMALL)) <= RS_FUSED_BLOCKS) radix_pass_t<RS_IPL_SMALL>(e, key, in, out, n, shift, true);
-  else radix_pass_t<RS_IPL_LARGE>(e, key, in, out, n, shift, false);
+  else radix_pass_t<RS_IPL_LARGE>(e, key, in, out, n, shift, div_up(n, rs_tile(RS_IPL_LARGE)) <= RS_FUSED_BLOCKS_LARGE);
 }
 // sort by the bits of `key` selected by `mask` (bits that vary); ping-pongs between a and b; returns final buffer.  A digit starts at
 // the lowest varying bit not sorted yet (bits that never vary in between cost nothing).

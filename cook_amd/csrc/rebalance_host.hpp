@@ -31,6 +31,7 @@ struct RebalBufs {
   DArr<SumU4> tile_agg, tile_carry;
   DArr<uint32_t> dl_pos;
   DArr<int32_t> dl_sign;
+  bool spare_safe = false;
   std::vector<uint32_t> user_safe_h;  // read back once per run: all ones = the re-scoring takes the one-launch path (rebal_rs_delta)
   DArr<uint32_t> x_head, x_cnt, x_next, big_list;
   DArr<double> h_cpus, h_mem, h_gpus, h_dru;
@@ -154,6 +155,14 @@ void rebalance_stage(cook_engine* e, RebalBufs& b, const cook_tasks* run, const 
       sc[h] = spare->cpus[i], sm[h] = spare->mem[i], sg[h] = spare->gpus ? spare->gpus[i] : 0.0;
       hs[h] = 1;
     }
+  {  // spare resources that cannot make a sum round (rebal_decide<SAFE>, with every user safe)
+    auto okv = [](double v) {
+      const double s = v * 1024.0;
+      return v >= 0.0 && v < 4194304.0 && s == (double)(long long)s;
+    };
+    b.spare_safe = true;
+    for (unsigned h = 0; h < H && b.spare_safe; ++h) b.spare_safe = okv(sc[h]) && okv(sm[h]) && okv(sg[h]);
+  }
   h2d(e, b.row_of_host, row.data(), H);
   h2d(e, b.spare0_c, sc.data(), H);
   h2d(e, b.spare0_m, sm.data(), H);
@@ -504,7 +513,8 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   if (all_safe && P) KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, 0u);
   for (unsigned pj = 0; pj < P; ++pj) {
     if (!all_safe) KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, pj);
-    if (H) KL("rebal_decide", rebal_decide, div_up(div_up(H, 2u), RB_WAVES), COOK_WAVE * RB_WAVES, in);
+    if (H && all_safe && b.spare_safe) KL("rebal_decide", rebal_decide<true>, div_up(div_up(H, 2u), RB_WAVES), COOK_WAVE * RB_WAVES, in);
+    else if (H) KL("rebal_decide", rebal_decide<false>, div_up(div_up(H, 2u), RB_WAVES), COOK_WAVE * RB_WAVES, in);
     // hosts beyond 64 items: only when one can exist (the fullest host as last read back + the jobs placed since then)
     if (H && known_max + (pj - known_at) > (unsigned)COOK_WAVE) KL("rebal_decide_big", rebal_decide_big, 32, COOK_WAVE * RB_WAVES, in);
     if (all_safe) {

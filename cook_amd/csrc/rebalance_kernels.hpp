@@ -169,23 +169,32 @@ static __device__ __forceinline__ SumU4 wave_bcast_u4(const SumU4& v, int src) {
 
 // inclusive wave scan of usage vectors whose count field is not needed, by DPP row shifts (common.hpp scan_fetch): `steps` = 4, 5 or 6
 // covers the first 16, 32 or 64 lanes (wave-uniform)
-template <int STEP>
+// SAFE: every value that can meet in a sum is a non-negative multiple of 2^-10 below 2^22 (rebal_user_safe over the slots, the spare
+// resources checked at staging; differences of such values stay such values) and a host holds at most 64 of them: no addition can
+// round, so the TwoSum exactness bit (25 fp64 instructions per combine against 3) and the left-to-right fall-back are compiled out.
+template <bool SAFE>
+static __device__ __forceinline__ SumU4 combine_t(const SumU4& a, const SumU4& b) {
+  if (SAFE) return SumU4{a.count + b.count, a.cpus + b.cpus, a.mem + b.mem, a.gpus + b.gpus, 0u};
+  return combine(a, b);
+}
+template <int STEP, bool SAFE = false>
 static __device__ __forceinline__ SumU4 scan_step_u4(const SumU4& v) {
   SumU4 p;
   p.count = 0.0;
   p.cpus = scan_fetch_f64<STEP>(v.cpus);
   p.mem = scan_fetch_f64<STEP>(v.mem);
   p.gpus = scan_fetch_f64<STEP>(v.gpus);
-  p.bad = (unsigned)scan_fetch_u32<STEP>((int)v.bad);
-  return combine(p, v);  // lanes without a source fetched zeros: x + 0.0 == x, nothing rounds
+  p.bad = SAFE ? 0u : (unsigned)scan_fetch_u32<STEP>((int)v.bad);
+  return combine_t<SAFE>(p, v);  // lanes without a source fetched zeros: x + 0.0 == x, nothing rounds
 }
+template <bool SAFE = false>
 static __device__ __forceinline__ SumU4 wave_incl_scan_u4_rows(SumU4 v, unsigned lanes) {
-  v = scan_step_u4<0>(v);
-  v = scan_step_u4<1>(v);
-  v = scan_step_u4<2>(v);
-  v = scan_step_u4<3>(v);
-  if (lanes > 16u) v = scan_step_u4<4>(v);
-  if (lanes > 32u) v = scan_step_u4<5>(v);
+  v = scan_step_u4<0, SAFE>(v);
+  v = scan_step_u4<1, SAFE>(v);
+  v = scan_step_u4<2, SAFE>(v);
+  v = scan_step_u4<3, SAFE>(v);
+  if (lanes > 16u) v = scan_step_u4<4, SAFE>(v);
+  if (lanes > 32u) v = scan_step_u4<5, SAFE>(v);
   return v;
 }
 
@@ -753,6 +762,7 @@ static __device__ __forceinline__ int rebal_host_row(const RebalIn& in, unsigned
 // (rebalancer.clj:339-349), rank by (dru desc, position in B asc) with wave broadcasts, prefix aggregates seeded with the spare
 // resources (:384-403), best feasible prefix (:404).  l_rank = 64 words of LDS owned by this wave.  -> out.key != 0 when the host can
 // take the job; sorted_slot = lane k's slot of the k-th candidate in priority order (the preempted tasks are a prefix of it).
+template <bool SAFE = false>
 static __device__ __forceinline__ void rebal_host_small(const RebalIn& in, const RebalJob& jb, unsigned h, unsigned hs, unsigned n_seg, unsigned n_here,
                                                        bool sp, uint32_t* l_rank, HostBest& out, unsigned& sorted_slot) {
   const unsigned lane = lane_id(), t = lane, n = n_seg + n_here;
@@ -844,8 +854,8 @@ static __device__ __forceinline__ void rebal_host_small(const RebalIn& in, const
   unsigned bl = 0;
   double bd = 0.0, bc = 0.0, bm = 0.0, bg = 0.0;
   const bool spare_alone = sp && seed.mem >= jm && seed.cpus >= jc && (need_g ? seed.gpus >= jg : true);
-  const SumU4 tt = combine(seed, wave_incl_scan_u4_rows(x, n_c));
-  if (__any(vk && tt.bad != 0u)) {  // a partial sum rounded: left to right, exactly as the reference's reductions (all lanes alike)
+  const SumU4 tt = combine_t<SAFE>(seed, wave_incl_scan_u4_rows<SAFE>(x, n_c));
+  if (!SAFE && __any(vk && tt.bad != 0u)) {  // a partial sum rounded: left to right, exactly as the reference's reductions (all lanes alike)
     double ac = seed.cpus, am = seed.mem, ag = seed.gpus;
     if (spare_alone) bk = f64_key(DMAXV), bd = DMAXV, bc = ac, bm = am, bg = ag;
     for (unsigned k = 0; k < n_c; ++k) {
@@ -878,6 +888,7 @@ static __device__ __forceinline__ void rebal_host_small(const RebalIn& in, const
 // bound by the instructions its 50k waves issue, and a typical host fills a third of a wave.  Same steps as rebal_host_small with every
 // cross-lane operation confined to the half.  The job must not belong to a constrained group (that check is wave-cooperative).
 // -> lanes 0 and 32 hold the result of their host.
+template <bool SAFE = false>
 static __device__ __forceinline__ void rebal_host_pair(const RebalIn& in, const RebalJob& jb, unsigned h0, uint32_t* l_rank, HostBest& out) {
   const unsigned lane = lane_id(), sub = lane >> 5, t = lane & 31u, hb = sub << 5;
   const unsigned h = h0 + sub;
@@ -962,14 +973,14 @@ static __device__ __forceinline__ void rebal_host_pair(const RebalIn& in, const 
   double bd = 0.0, bc = 0.0, bm = 0.0, bg = 0.0;
   const bool spare_alone = sp && seed.mem >= jm && seed.cpus >= jc && (need_g ? seed.gpus >= jg : true);
   // inclusive scan inside the half: four row steps + the row-to-row step (rows 0 -> 1 and 2 -> 3)
-  SumU4 sc = scan_step_u4<0>(x);
-  sc = scan_step_u4<1>(sc);
-  sc = scan_step_u4<2>(sc);
-  sc = scan_step_u4<3>(sc);
-  sc = scan_step_u4<4>(sc);
-  const SumU4 tt = combine(seed, sc);
-  const unsigned hbad = (unsigned)(__ballot(vk && tt.bad != 0u) >> hb);
-  if (__any(hbad != 0u)) {  // a partial sum rounded in some half: that half redoes it left to right like the reference (every lane of it alike)
+  SumU4 sc = scan_step_u4<0, SAFE>(x);
+  sc = scan_step_u4<1, SAFE>(sc);
+  sc = scan_step_u4<2, SAFE>(sc);
+  sc = scan_step_u4<3, SAFE>(sc);
+  sc = scan_step_u4<4, SAFE>(sc);
+  const SumU4 tt = combine_t<SAFE>(seed, sc);
+  const unsigned hbad = SAFE ? 0u : (unsigned)(__ballot(vk && tt.bad != 0u) >> hb);
+  if (!SAFE && __any(hbad != 0u)) {  // a partial sum rounded in some half: that half redoes it left to right like the reference (every lane of it alike)
     double ac = seed.cpus, am = seed.mem, ag = seed.gpus;
     unsigned long long k2 = 0ull;
     unsigned l2 = 0;
@@ -1004,6 +1015,7 @@ static __device__ __forceinline__ void rebal_host_pair(const RebalIn& in, const 
 // hosts with at most 64 items (running tasks + jobs placed this cycle): a wave takes two neighbouring hosts, half a wave each when
 // both hold at most 32 items (rebal_host_pair), else one after the other.  No LDS beyond 64 words per wave, few registers.  The launch
 // is bound by the instructions its waves issue.  Larger hosts are left to rebal_decide_big.
+template <bool SAFE>
 __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) {
   __shared__ uint32_t l_rank[RB_WAVES][COOK_WAVE];
   const RebalJob jb = *in.job;
@@ -1016,7 +1028,7 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) 
   const unsigned n1 = two ? in.hend[h0 + 1u] - in.hstart[h0 + 1u] + in.x_cnt[h0 + 1u] : 0u;
   if (n0 <= 32u && n1 <= 32u && jb.gtype == 0u) {
     HostBest hb;
-    rebal_host_pair(in, jb, h0, l_rank[w], hb);
+    rebal_host_pair<SAFE>(in, jb, h0, l_rank[w], hb);
     if ((lane & 31u) == 0u && h0 + (lane >> 5) < in.H) {
       const unsigned h = h0 + (lane >> 5);
       in.hres_key[h] = hb.key;
@@ -1042,7 +1054,7 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) 
     hb.key = 0ull;
     if (n != 0 || sp) {
       unsigned ss;
-      rebal_host_small(in, jb, h, hs, n_seg, n_here, sp, l_rank[w], hb, ss);
+      rebal_host_small<SAFE>(in, jb, h, hs, n_seg, n_here, sp, l_rank[w], hb, ss);
     }
     if (lane == 0) {
       in.hres_key[h] = hb.key;

@@ -10,10 +10,11 @@
 //   radix_scatter : stable placement.  A block's tile is split into one contiguous chunk per wave; per-wave digit
 //                   counts give each wave its base, then every wave walks its chunk 64 items at a time, ranking equal
 //                   digits with 8 ballots (match-any) so earlier positions keep earlier slots.
-// One pass of a pool-sized input (at most RS_FUSED_BLOCKS tiles of 2048: a pool's 175k tasks are 86) = two launches: the histogram is
-// kept [block][digit] and every scatter block sums the columns itself (thread d adds the counts of digit d over the earlier blocks
-// and over all blocks: nblocks coalesced loads, all in flight together) — the single-workgroup scan and its launch gap were a third
-// of a pass (9.6 + ~5 us of 45 + 15, profiles/r02k), and a chain of passes is what the rank stage is made of.
+// One pass of an input of up to 2M items (RS_FUSED_BLOCKS tiles of 2048: a pool's 175k tasks are 86; or RS_FUSED_BLOCKS_LARGE tiles of
+// 4096) = two launches: the histogram is
+// kept [block][digit] and every scatter block sums the columns itself (the counts of each digit over the earlier blocks and over all
+// blocks: 16-byte loads, a wave per fourth of the rows) — the single-workgroup scan and its launch gap were a third of a pass
+// (9.6 + ~5 us of 45 + 15, profiles/r02k), and a chain of passes is what the rank stage is made of.
 // The host skips digits that are constant over the whole input (radix_varying_bits) and starts every digit at the lowest
 // varying bit not sorted yet, so sparse varying bits do not cost a pass per byte they touch.
 #pragma once
@@ -23,7 +24,9 @@ constexpr int RS_THREADS = 256;                     // 4 waves
 constexpr int RS_WAVES = RS_THREADS / COOK_WAVE;    // waves per block
 constexpr int RS_IPL_LARGE = 16;                    // items per lane: 4096 items per block
 constexpr int RS_IPL_SMALL = 8;                     // pool-sized inputs: 2048 items per block, twice the blocks (86 on 256 CUs for 175k)
-constexpr unsigned RS_FUSED_BLOCKS = COOK_SHAPE(128, 2);  // up to this many small tiles the scatter derives its bases itself
+constexpr unsigned RS_FUSED_BLOCKS = COOK_SHAPE(128, 2);  // up to this many small tiles the scatter derives its bases itself ...
+constexpr unsigned RS_FUSED_BLOCKS_LARGE = COOK_SHAPE(512, 3);  // ... and up to this many large ones (the rebalancer's million slots are 245:
+                                                                // 245 KB of L2 reads per block against a 13 us scan launch and its gap)
 constexpr unsigned rs_tile(int ipl) { return (unsigned)(RS_WAVES * COOK_WAVE * ipl); }
 
 static __device__ __forceinline__ unsigned rs_digit(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm_in,
@@ -130,18 +133,33 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter(const uint64_t* __re
                                                             unsigned nblocks, unsigned fused, const uint32_t* __restrict__ hist) {
   __shared__ unsigned whist[RS_WAVES][256];
   __shared__ unsigned wtot[RS_WAVES];
+  __shared__ uint4 s_tot[RS_WAVES][COOK_WAVE], s_bel[RS_WAVES][COOK_WAVE];
   const unsigned lane = lane_id(), w = wave_id();
   for (int k = 0; k < RS_WAVES; ++k) whist[k][threadIdx.x] = 0;
-  // fused: digit d = threadIdx.x; its count in the blocks before this one, and in all blocks (the loads do not wait for the LDS)
+  // fused: the count of every digit in the blocks before this one, and in all blocks.  Wave w takes the rows w, w + RS_WAVES, ...;
+  // a lane four digits as one 16-byte load (a thread per digit issued nblocks 4-byte loads: 245 of them for a million items took
+  // longer than the scan launch they replaced), eight rows in flight; the waves' partial sums meet in LDS.
   unsigned below = 0, total = 0;
   if (fused) {
-    for (unsigned t = 0; t < nblocks; ++t) {
-      const unsigned v = hist[t * 256u + threadIdx.x];
-      total += v;
-      below += t < blockIdx.x ? v : 0u;
+    uint4 tot{0u, 0u, 0u, 0u}, bel{0u, 0u, 0u, 0u};
+#pragma unroll 8
+    for (unsigned t = w; t < nblocks; t += RS_WAVES) {
+      const uint4 v = *reinterpret_cast<const uint4*>(hist + (size_t)t * 256u + 4u * lane);
+      tot.x += v.x, tot.y += v.y, tot.z += v.z, tot.w += v.w;
+      if (t < blockIdx.x) bel.x += v.x, bel.y += v.y, bel.z += v.z, bel.w += v.w;
     }
+    s_tot[w][lane] = tot;
+    s_bel[w][lane] = bel;
   }
   __syncthreads();
+  if (fused) {  // digit d = threadIdx.x
+    const unsigned* pt = reinterpret_cast<const unsigned*>(&s_tot[0][0]);
+    const unsigned* pb = reinterpret_cast<const unsigned*>(&s_bel[0][0]);
+    for (int k = 0; k < RS_WAVES; ++k) {
+      total += pt[k * 256 + threadIdx.x];
+      below += pb[k * 256 + threadIdx.x];
+    }
+  }
   const unsigned wbase = blockIdx.x * rs_tile(IPL) + w * (COOK_WAVE * IPL);
   // phase 1: the wave's items (kept in registers for phase 3) and its digit counts
   unsigned src[IPL], dg[IPL];
