@@ -558,9 +558,9 @@ void rank_run(cook_engine* e) {
     // --- tie groups + sorted-merge tie rule (prefix doubling) ------------------------------------------------
     unsigned bits = 1;
     while ((1ull << bits) <= (unsigned long long)U + N) ++bits;  // rank values <= U + N
-    const unsigned rank_bytes = (bits + 7) / 8;
-    unsigned long long cmask = 0;
-    for (unsigned b = 0; b < rank_bytes; ++b) cmask |= (0xFFull << (8 * b)) | (0xFFull << (8 * (b + 4)));
+    // composite key of a tied item = (start of its group, secondary rank), the two packed back to back: 2 * bits key bits, 36 for a
+    // pool's 175k tasks = 5 radix passes (two 32-bit halves cost a pass more)
+    const unsigned long long cmask = 2 * bits >= 64 ? ~0ull : (1ull << (2 * bits)) - 1ull;
     // refines `perm` (nk items of an index space with n_items items, per-user lists contiguous) in place; returns false when a
     // user has consecutive items with equal keys (the caller collapses those runs and calls again on the collapsed space)
     auto tie_refine = [&](uint32_t* perm, const uint64_t* key, const uint32_t* user_of, const uint32_t* seg_first, unsigned nk,
@@ -583,6 +583,7 @@ void rank_run(cook_engine* e) {
         readback_counters(e, h3, 3);
         if (h3[1]) return false;
         const unsigned n_tied = h3[2];
+        if (std::getenv("COOK_TIE_TRACE")) std::fprintf(stderr, "tie round %d: %u tied of %u\n", round, n_tied, nk);
         if (n_tied == 0) break;
         if (round > 31) e->fail(COOK_E_INVALID, "cook_rank: tie refinement did not converge");
         // compact tied slots, sort them by (group start, secondary), write back, split groups
@@ -593,7 +594,7 @@ void rank_run(cook_engine* e) {
         e->tsorted2.ensure(n_tied);
         seg_scan<SumI>(e, "tie_compact_scan", LoadI{tied}, (const uint8_t*)nullptr, nk, e->scanI.ptr(), e->tmpI);
         KL("tie_build", tie_build, gK, 256, (const uint32_t*)perm, (const int*)tied, (const SumI*)e->scanI.ptr(),
-           (const uint32_t*)e->gstart.ptr(), nk, U, n_items, round, (const uint32_t*)e->rank_of_item.ptr(), user_of, seg_first,
+           (const uint32_t*)e->gstart.ptr(), nk, U, n_items, round, bits, (const uint32_t*)e->rank_of_item.ptr(), user_of, seg_first,
            e->tpos.ptr(), e->titem.ptr(), e->ckey.ptr());
         KL("iota", iota_u32, div_up(n_tied, 256), 256, e->tsorted.ptr(), n_tied);
         uint32_t* ts = radix_sort_masked(e, e->ckey.ptr(), cmask, e->tsorted.ptr(), e->tsorted.ptr(), e->tsorted2.ptr(), n_tied);

@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) tie_assign(const uint32_t* __restrict__ p
 // compact the tied C-positions (excl = exclusive prefix of `tied`) and build their composite keys for round k
 __global__ void __launch_bounds__(256) tie_build(const uint32_t* __restrict__ permC, const int* __restrict__ tied,
                                                  const SumI* __restrict__ tied_incl, const uint32_t* __restrict__ gstart,
-                                                 unsigned n_kept, unsigned n_users, unsigned n_items, int round,
+                                                 unsigned n_kept, unsigned n_users, unsigned n_items, int round, unsigned key_bits,
                                                  const uint32_t* __restrict__ rank_of_item, const uint32_t* __restrict__ s_user,
                                                  const uint32_t* __restrict__ seg_start, uint32_t* __restrict__ tpos,
                                                  uint32_t* __restrict__ titem, uint64_t* __restrict__ ckey) {
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) tie_build(const uint32_t* __restrict__ pe
   }
   tpos[j] = p;
   titem[j] = i;
-  ckey[j] = ((uint64_t)gstart[p] << 32) | sec;
+  ckey[j] = ((uint64_t)gstart[p] << key_bits) | sec;  // both below 2^key_bits
 }
 
 // after sorting the tied items by composite key: write them back into their (contiguous) group slots and split groups
