@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-adjacent", action="store_true", help="skip the timings of the rows next to the hot path (offers, explain, metrics)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--no-extras", action="store_true", help="skip SURVEY.md §8d's reporting matrix (K = 1000 / 1e5, good-enough 0.8, C2, C3) under extra_configs")
+    ap.add_argument("--as-rank-of", type=int, default=0, help="single process: time only the pools rank 0 of an N-GPU job would hold (the per-GPU load behind DESIGN.md's scaling prediction; not a bench line)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of the timed configuration (rank 0's first and last pool vs the oracle, after the timed region)")
     return ap.parse_args()
 
@@ -116,7 +117,7 @@ def main():
     P = args.pools
     from cook_amd import workload
     from cook_amd.sharding import pools_of_rank
-    my_pools = pools_of_rank(P, world, rank)
+    my_pools = pools_of_rank(P, world, rank) if not args.as_rank_of else pools_of_rank(P, args.as_rank_of, 0)
     spec = workload.ClusterSpec(pools=P, pending=args.pending, running=args.running, offers=args.offers, users=args.users,
                                 constraints=not args.no_constraints)
     n_pend, n_run, n_off = spec.per_pool
