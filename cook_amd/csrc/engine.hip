@@ -1015,7 +1015,8 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
             ++launches;
             vb.eval_trace = tr.ensure((size_t)C * MV_JG * 19 + 3);
             if (launches == 60 || launches == 300) COOK_HIP(hipMemsetAsync(vb.eval_trace, 0, (size_t)C * MV_JG * 19 * 8, e->stream));
-            KL("match_eval2", match_eval2, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
+            if (in.good_enough < 1.0) KL("match_eval2", match_eval2<true>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
+          else KL("match_eval2", match_eval2<false>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
             if (launches == 60 || launches == 300) {
               std::vector<unsigned long long> h((size_t)C * MV_JG * 19);
               sync(e);
@@ -1035,7 +1036,8 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
             }
           }
 #else
-          KL("match_eval2", match_eval2, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
+          if (in.good_enough < 1.0) KL("match_eval2", match_eval2<true>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
+          else KL("match_eval2", match_eval2<false>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
 #endif
           KL("match_merge2", match_merge2, MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, vb);
           if (c0.reeval_max != 0u)
@@ -1130,6 +1132,8 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
   COOK_HIP(hipMemcpyAsync(dctx, hctx.data(), L * sizeof(PoolCtx), hipMemcpyHostToDevice, lead->stream));
   COOK_HIP(hipStreamSynchronize(lead->stream));  // hctx is pageable
   cook_engine* e = lead;                         // KL times / launches on the lead engine
+  bool any_ge = false;  // some pool of the launch runs with good-enough-fitness below 1 (match_eval2<GE>)
+  for (unsigned x = 0; x < L; ++x) any_ge = any_ge || hctx[x].in.good_enough < 1.0;
   unsigned batch = 8, guard = 0;
   auto all_done = [&] {
     for (unsigned x = 0; x < L; ++x)
@@ -1138,7 +1142,8 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
   };
   while (!all_done()) {
     for (unsigned r = 0; r < batch; ++r) {
-      KL("match_eval2", match_eval2_multi, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx);
+      if (any_ge) KL("match_eval2", match_eval2_multi<true>, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx);
+      else KL("match_eval2", match_eval2_multi<false>, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx);
       KL("match_merge2", match_merge2_multi, dim3(MV_WMAX / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, (const PoolCtx*)dctx);
       if (es[live[0]]->deferred_c0.reeval_max != 0u)
         KL("match_resolve2", match_resolve2_multi_reeval, dim3(1, 1, L), MV_RTHREADS, (const PoolCtx*)dctx);

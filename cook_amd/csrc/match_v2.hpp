@@ -401,13 +401,7 @@ struct EvalLane {
   bool valid, slow, grouped, fastc, use_ge;
   JobRec j;
   unsigned jj;
-  // the job's fast constraints (JobCons) in the form the offer loop checks without a per-lane LDS look-up: per attribute key staged
-  // in LDS the required value and an all-ones mask when the key is constrained (the offer's values are wave-uniform), the required
-  // HOSTNAME value, the hosts to avoid (0xFFFFFFFF = unused), and "cannot be satisfied by any offer"
-  unsigned req[MV_NA], wild[MV_NA];
-  unsigned req_host, wild_host;
-  unsigned novel[MV_NC];
-  bool impossible;
+  unsigned k;  // the job's index in match order (vb.jr / vb.jcons)
   unsigned fh[MV_FH];
   int n_fh;
   int glast;  // the group's last placed job under the snapshot (-1 none; members of a group only)
@@ -421,31 +415,24 @@ struct EvalLane {
 };
 
 // lane = job `b` of the window (64 consecutive jobs per wave): load it and gather what its constraints need
-static __device__ __forceinline__ void eval_lane_setup(EvalLane& E, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
-                                                       unsigned wcur, unsigned jg) {
-  const unsigned lane = lane_id();
-  const unsigned b = jg * COOK_WAVE + lane, k = head + b;
-  E.valid = b < wcur && k < in.K;
-  E.j.c = E.j.m = E.j.g = 0.0;
-  E.j.gpu_model = 0;
-  E.j.reserved_host = -1;
-  E.j.group = 0xFFFFFFFFu;
-  E.j.flags = 0;
-  E.jj = 0;
-  if (E.valid) {
-    E.j = vb.jr[k];
-    E.jj = in.j_index ? in.j_index[k] : k;
-  }
-  E.slow = (E.j.flags & JF_SLOW) != 0;
-  E.grouped = (E.j.flags & JF_GROUPED) != 0;
-  E.fastc = !E.slow && (E.j.flags & JF_FASTC) != 0;
+// The job's fast constraints (JobCons) in the form the offer loop checks without a per-lane LDS look-up: per attribute key staged in LDS
+// the required value and an all-ones mask when the key is constrained (the offer's values are wave-uniform), the required HOSTNAME
+// value, the hosts to avoid (0xFFFFFFFF = unused), and "cannot be satisfied by any offer".  Lives only inside the constraint pass of
+// eval_scan_offers (22 registers that the fitness pass does not carry).
+struct EvalCons {
+  unsigned req[MV_NA], wild[MV_NA];
+  unsigned req_host, wild_host;
+  unsigned novel[MV_NC];
+  bool impossible;
+};
+static __device__ __forceinline__ void eval_cons_setup(EvalCons& E, bool fastc, const V2Buf& vb, unsigned k) {
 #pragma unroll
   for (int q = 0; q < MV_NA; ++q) E.req[q] = E.wild[q] = 0u;
   E.req_host = E.wild_host = 0u;
 #pragma unroll
   for (int q = 0; q < MV_NC; ++q) E.novel[q] = 0xFFFFFFFFu;
   E.impossible = false;
-  if (E.fastc) {
+  if (fastc) {
     const JobCons jc = vb.jcons[k];
 #pragma unroll
     for (int q = 0; q < MV_NC; ++q) {
@@ -470,6 +457,30 @@ static __device__ __forceinline__ void eval_lane_setup(EvalLane& E, const MatchI
       }
     }
   }
+}
+
+// GE = false: the launch was made for good-enough-fitness 1.0 (plain best fit, the parity setting): the good-enough list, its
+// threshold and counters are compiled out of the offer loop (10 vector registers)
+template <bool GE = true>
+static __device__ __forceinline__ void eval_lane_setup(EvalLane& E, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
+                                                       unsigned wcur, unsigned jg) {
+  const unsigned lane = lane_id();
+  const unsigned b = jg * COOK_WAVE + lane, k = head + b;
+  E.valid = b < wcur && k < in.K;
+  E.j.c = E.j.m = E.j.g = 0.0;
+  E.j.gpu_model = 0;
+  E.j.reserved_host = -1;
+  E.j.group = 0xFFFFFFFFu;
+  E.j.flags = 0;
+  E.jj = 0;
+  E.k = k;
+  if (E.valid) {
+    E.j = vb.jr[k];
+    E.jj = in.j_index ? in.j_index[k] : k;
+  }
+  E.slow = (E.j.flags & JF_SLOW) != 0;
+  E.grouped = (E.j.flags & JF_GROUPED) != 0;
+  E.fastc = !E.slow && (E.j.flags & JF_FASTC) != 0;
   // unique host-placement groups (constraints.clj:586-598): the hosts to avoid = running cotasks ++ cotasks placed by
   // earlier rounds of this call, gathered ONCE per tile into registers (n_fh = -1: not such a job, -2: too many -> slow path)
   E.n_fh = -1;
@@ -495,7 +506,7 @@ static __device__ __forceinline__ void eval_lane_setup(EvalLane& E, const MatchI
     for (int c = E.glast; c >= 0 && E.n_fh >= 0; c = ld_agent(&st.job_prev[c]))
       if (c < st.cutoff) push(in.o_host[ld_agent(&st.job_to_offer[c])]);
   }
-  E.use_ge = in.good_enough < 1.0;
+  E.use_ge = GE && in.good_enough < 1.0;
   E.ge = in.good_enough;
   E.ge_lo = in.good_enough * (1.0 - 0x1p-40);
 #pragma unroll
@@ -525,7 +536,7 @@ static __device__ __forceinline__ unsigned eval_split(unsigned wcur, unsigned sp
 
 // the offers [v0, v0 + nsub) against the wave's 64 jobs (nsub = MV_OCW, or a power-of-two share of it): stage them in the wave's LDS,
 // then walk them in a wave-uniform loop
-template <bool THROUGH>
+template <bool THROUGH, bool GE = true>
 static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds& W, const MatchIn& in, const MatchState& st, const V2Buf& vb,
                                                         unsigned v0, unsigned jg, unsigned nsub = MV_OCW) {
   const unsigned lane = lane_id();
@@ -548,49 +559,67 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
   if (v0 < v1) {
     live = (st.alive[v0 >> 6] >> (v0 & 63u)) & (nsub == 64u ? ~0ull : ((1ull << (nsub & 63u)) - 1ull));  // an aligned slice of one word
     if (v1 - v0 < nsub) live &= (1ull << (v1 - v0)) - 1ull;
-    E.c1 += valid ? (v1 - v0) - (unsigned)__popcll(live) : 0u;
   }
-  while (live != 0ull) {  // wave-uniform
-    const unsigned vi = (unsigned)__ffsll((unsigned long long)live) - 1u;
-    live &= live - 1ull;
+  // Two passes over the live offers, so that neither carries the other's registers (one loop held 197 VGPRs = two waves per SIMD
+  // while 57 % of its wave cycles were waits): the CONSTRAINT pass — resources under the snapshot, the static checks, the colbits
+  // ballot — leaves a bit per offer in two lane masks; the FITNESS pass reads the masks and never sees the constraint form.
+  unsigned long long resm = 0ull, statm = 0ull;  // bit vi: the lane's job fits offer v0 + vi on resources / also passes the static checks
+  {
+    EvalCons Cn;
+    eval_cons_setup(Cn, E.fastc, vb, E.k);
+    for (unsigned long long m = live; m != 0ull;) {  // wave-uniform
+      const unsigned vi = (unsigned)__ffsll((unsigned long long)m) - 1u;
+      m &= m - 1ull;
+      const unsigned v = v0 + vi;
+      // every LDS read of this offer is issued here, in one batch
+      const double oc = W.oa[vi].oc, om = W.oa[vi].om;
+      const double ac = W.oac[vi], am = W.oam[vi];
+      const OfferB o = W.ob[vi];
+      unsigned arow[MV_NA];
+#pragma unroll
+      for (int x = 0; x < MV_NA; ++x) arow[x] = W.attr[vi][x];
+      bool res = valid && !(ac + j.c > oc || am + j.m > om);
+      if (in.has_x) {  // ports / named scalars (rare): the jobs that ask for any read the offer's counters
+        if (res && (j.flags & JF_XRES)) res = xres_fail_dev(vb.in_dev, st, E.jj, v) == 0u;
+      }
+      if (!__any(res)) {
+        if (lane == 0) {
+          if (THROUGH) st_agent(&vb.colbits[(size_t)v * MV_JGL + jg], (uint64_t)0ull);
+          else vb.colbits[(size_t)v * MV_JGL + jg] = 0ull;
+        }
+        continue;
+      }
+      bool stat = res && static_fast(j, o, in, v);
+      {  // novel-host (constraints.clj:68-94) and user-defined EQUALS (:356-377): the offer's host and attribute values are wave-uniform
+        unsigned diff = (Cn.req_host ^ (o.host + 1u)) & Cn.wild_host;
+#pragma unroll
+        for (int x = 0; x < MV_NA; ++x) diff |= (Cn.req[x] ^ arow[x]) & Cn.wild[x];
+        bool hit = Cn.impossible;
+#pragma unroll
+        for (int q = 0; q < MV_NC; ++q) hit = hit | (Cn.novel[q] == o.host);
+        stat = stat && diff == 0u && !hit;
+      }
+      if (stat && E.slow) stat = static_pass_dev(vb.in_dev, E.jj, v);
+      const unsigned long long bits = __ballot(stat);
+      if (lane == 0) {
+        if (THROUGH) st_agent(&vb.colbits[(size_t)v * MV_JGL + jg], (uint64_t)bits);
+        else vb.colbits[(size_t)v * MV_JGL + jg] = bits;
+      }
+      resm |= res ? 1ull << vi : 0ull;
+      statm |= stat ? 1ull << vi : 0ull;
+    }
+  }
+  unsigned long long feasm = 0ull;
+  for (unsigned long long m = live; m != 0ull;) {  // wave-uniform
+    const unsigned vi = (unsigned)__ffsll((unsigned long long)m) - 1u;
+    m &= m - 1ull;
+    const bool stat = ((statm >> vi) & 1ull) != 0ull;
+    if (!__any(stat)) continue;
     const unsigned v = v0 + vi;
-    // every LDS read of this offer is issued here, in one batch (one round trip instead of three: the reads after the first branch
-    // and the attribute row used to start their own)
     const OfferA a = W.oa[vi];
     const double ac = W.oac[vi], am = W.oam[vi];
     const OfferB o = W.ob[vi];
     const int acount = W.oacount[vi];
-    unsigned arow[MV_NA];
-#pragma unroll
-    for (int x = 0; x < MV_NA; ++x) arow[x] = W.attr[vi][x];
-    bool res = valid && !(ac + j.c > a.oc || am + j.m > a.om);
-    if (in.has_x) {  // ports / named scalars (rare): the jobs that ask for any read the offer's counters
-      if (res && (j.flags & JF_XRES)) res = xres_fail_dev(vb.in_dev, st, E.jj, v) == 0u;
-    }
-    if (!__any(res)) {
-      E.c1 += valid ? 1u : 0u;
-      if (lane == 0) {
-        if (THROUGH) st_agent(&vb.colbits[(size_t)v * MV_JGL + jg], (uint64_t)0ull);
-        else vb.colbits[(size_t)v * MV_JGL + jg] = 0ull;
-      }
-      continue;
-    }
-    bool stat = res && static_fast(j, o, in, v);
-    {  // novel-host (constraints.clj:68-94) and user-defined EQUALS (:356-377): the offer's host and attribute values are wave-uniform
-      unsigned diff = (E.req_host ^ (o.host + 1u)) & E.wild_host;
-#pragma unroll
-      for (int x = 0; x < MV_NA; ++x) diff |= (E.req[x] ^ arow[x]) & E.wild[x];
-      bool hit = E.impossible;
-#pragma unroll
-      for (int q = 0; q < MV_NC; ++q) hit = hit | (E.novel[q] == o.host);
-      stat = stat && diff == 0u && !hit;
-    }
-    if (stat && E.slow) stat = static_pass_dev(vb.in_dev, E.jj, v);
-    const unsigned long long bits = __ballot(stat);
-    if (lane == 0) {
-      if (THROUGH) st_agent(&vb.colbits[(size_t)v * MV_JGL + jg], (uint64_t)bits);
-      else vb.colbits[(size_t)v * MV_JGL + jg] = bits;
-    }
     bool feas = stat && dyn_fast(j, o, acount);
     {  // unique host-placement groups: the hosts to avoid sit in registers (0xFFFFFFFF for everybody else)
       bool taken = false;
@@ -601,13 +630,12 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
     if (__any(E.grouped && E.n_fh < 0)) {  // (wave-uniform) balanced / attribute-equals groups, or too many hosts: the general walk
       if (feas && E.grouped && E.n_fh < 0) feas = group_pass_dev(vb.in_dev, st, E.jj, v);
     }
-    E.c1 += (valid && !res) ? 1u : 0u;
-    E.c2 += (res && !feas) ? 1u : 0u;
+    feasm |= feas ? 1ull << vi : 0ull;
     if (feas) {
       const double t1 = (a.rc + ac + j.c) * a.inv_dc, t2 = (a.rm + am + j.m) * a.inv_dm;
       const double ub = (t1 + t2) * 0.5;
       bool prune = E.ti[MV_L - 1] >= 0 && t1 >= 0.0 && t2 >= 0.0 && ub < E.thr;
-      if (E.use_ge && E.n_ge < MV_LG && !(ub < E.ge_lo)) prune = false;
+      if (GE && E.use_ge && E.n_ge < MV_LG && !(ub < E.ge_lo)) prune = false;
       if (!prune) {
         const double fit = fitness_of(a, ac, am, j.c, j.m);
         if (!(fit > 0.0)) {
@@ -617,7 +645,7 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
             topl_insert_ascending<MV_L>(E.tf, E.ti, fit, (int)v);
             if (E.ti[MV_L - 1] >= 0) E.thr = E.tf[MV_L - 1] * (1.0 - 0x1p-40);
           }
-          if (E.use_ge && fit > E.ge && E.n_ge < MV_LG) {
+          if (GE && E.use_ge && fit > E.ge && E.n_ge < MV_LG) {
 #pragma unroll
             for (int q = 0; q < MV_LG; ++q)
               if (q == E.n_ge) E.gi[q] = (int)v;
@@ -627,6 +655,10 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
       }
     }
   }
+  // failure classes: offers failing on resources (the dead ones too), offers fitting on resources but infeasible (a constraint)
+  const unsigned n_res = (unsigned)__popcll(resm);
+  E.c1 += valid ? (v1 > v0 ? v1 - v0 : 0u) - n_res : 0u;
+  E.c2 += n_res - (unsigned)__popcll(feasm);
   wave_sync();  // every lane is done with the staged offers before the wave stages the next ones
 }
 
@@ -653,7 +685,7 @@ static __device__ __forceinline__ void eval_store_group(const EvalLane& E, const
 // Ends with every thread past its last LDS access only after the caller's next __syncthreads().
 // The MV_EW waves may be a whole workgroup (w = wave_id(), sync = __syncthreads) or a TEAM of waves inside a larger workgroup of
 // the persistent kernel (match_world.hpp: w = wave in team, sync = the team's LDS barrier, THROUGH = write-through stores).
-template <bool THROUGH, class Sync>
+template <bool THROUGH, bool GE = true, class Sync>
 static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
                                                    unsigned wcur, unsigned ch, unsigned jg, unsigned w, Sync sync, unsigned part = 0,
                                                    unsigned split = 1) {
@@ -670,15 +702,15 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
   unsigned long long* trp = vb.eval_trace ? vb.eval_trace + (size_t)vb.C * MV_JG * 3 + ((size_t)jg * vb.C + ch) * 16 + w * 4 : nullptr;
   if (trp && lane == 0) trp[0] = cook_ticks();
 #endif
-  eval_lane_setup(E, in, st, vb, head, wcur, jg);
+  eval_lane_setup<GE>(E, in, st, vb, head, wcur, jg);
 #ifdef COOK_EVAL_TRACE
   if (trp && lane == 0) trp[1] = cook_ticks();
 #endif
-  eval_scan_offers<THROUGH>(E, L.wave[w], in, st, vb, ch * MV_OCB + w * MV_OCW + part * ((unsigned)MV_OCW / split), jg, (unsigned)MV_OCW / split);
+  eval_scan_offers<THROUGH, GE>(E, L.wave[w], in, st, vb, ch * MV_OCB + w * MV_OCW + part * ((unsigned)MV_OCW / split), jg, (unsigned)MV_OCW / split);
 #ifdef COOK_EVAL_TRACE
   if (trp && lane == 0) trp[2] = cook_ticks();
 #endif
-  const bool valid = E.valid, use_ge = E.use_ge;
+  const bool valid = E.valid, use_ge = GE && E.use_ge;
   // ---- merge the block's MV_EW wave lists per job through LDS -------------------------------------------------------
 #pragma unroll
   for (int q = 0; q < MV_L; ++q) {
@@ -782,25 +814,26 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
   if (trp && lane == 0) trp[3] = cook_ticks();
 #endif
 }
+template <bool GE = true>
 static __device__ __forceinline__ void eval_tile(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
                                                  unsigned wcur, unsigned ch, unsigned jg, unsigned part = 0, unsigned split = 1) {
-  eval_tile_t<false>(lds, in, st, vb, head, wcur, ch, jg, wave_id(), [] { __syncthreads(); }, part, split);
+  eval_tile_t<false, GE>(lds, in, st, vb, head, wcur, ch, jg, wave_id(), [] { __syncthreads(); }, part, split);
 }
 
 // The same tile by ONE wave on its own (the persistent placement kernel's evaluator waves, match_world.hpp): 64 jobs x the
 // MV_OCB offers of chunk ch in MV_EW batches of MV_OCW; no workgroup barrier anywhere, the chunk list goes straight to HBM.
-template <bool THROUGH>
+template <bool THROUGH, bool GE = true>
 static __device__ __forceinline__ void eval_tile_wave(EvalWaveLds& W, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
                                                       unsigned wcur, unsigned ch, unsigned jg) {
   if (jg * COOK_WAVE >= wcur || head + jg * COOK_WAVE >= in.K) return;  // wave-uniform
   const unsigned lane = lane_id();
   const unsigned b = jg * COOK_WAVE + lane;
   EvalLane E;
-  eval_lane_setup(E, in, st, vb, head, wcur, jg);
+  eval_lane_setup<GE>(E, in, st, vb, head, wcur, jg);
   for (int s = 0; s < MV_EW; ++s) {
     const unsigned v0 = ch * MV_OCB + (unsigned)s * MV_OCW;
     if (v0 >= in.M) break;
-    eval_scan_offers<THROUGH>(E, W, in, st, vb, v0, jg);
+    eval_scan_offers<THROUGH, GE>(E, W, in, st, vb, v0, jg);
   }
   if (!E.valid) return;
   if (ch == 0) eval_store_group<THROUGH>(E, vb, b);
@@ -828,28 +861,30 @@ static __device__ __forceinline__ void eval_tile_wave(EvalWaveLds& W, const Matc
 // (job group gy of chunk ch, a batch of offers each).  A LONG window (more job groups than the grid has rows; nearly all its offers
 // are dead by then, so a tile is little more than its prologue): every wave takes a job group of its own and walks the whole chunk,
 // eval_tile_wave — MV_EW job groups per pass instead of one.
+template <bool GE = true>
 static __device__ __forceinline__ void eval_block(char* lds, const MatchIn& in, const MatchState& st, const V2Buf& vb, unsigned head,
                                                   unsigned wcur, unsigned ch, unsigned gy, unsigned ny) {
   if (wcur <= ny * COOK_WAVE) {
     const unsigned split = ny == (unsigned)MV_JG ? eval_split(wcur, vb.split_max) : 1u;  // (the grid's rows are MV_JG in every launch path)
     if (split == 1u) {
-      eval_tile(lds, in, st, vb, head, wcur, ch, gy);
+      eval_tile<GE>(lds, in, st, vb, head, wcur, ch, gy);
     } else {
       const unsigned active = (wcur + COOK_WAVE - 1) / COOK_WAVE;
-      if (gy < active * split) eval_tile(lds, in, st, vb, head, wcur, ch, gy % active, gy / active, split);
+      if (gy < active * split) eval_tile<GE>(lds, in, st, vb, head, wcur, ch, gy % active, gy / active, split);
     }
     return;
   }
   EvalLds& L = *reinterpret_cast<EvalLds*>(lds);
   const unsigned w = wave_id();
-  for (unsigned jg = gy * MV_EW + w; jg * COOK_WAVE < wcur; jg += ny * MV_EW) eval_tile_wave<false>(L.wave[w], in, st, vb, head, wcur, ch, jg);
+  for (unsigned jg = gy * MV_EW + w; jg * COOK_WAVE < wcur; jg += ny * MV_EW) eval_tile_wave<false, GE>(L.wave[w], in, st, vb, head, wcur, ch, jg);
 }
+template <bool GE>
 __global__ void __launch_bounds__(COOK_WAVE* MV_EW) COOK_EVAL_OCCUPANCY match_eval2(MatchIn in, MatchState st, V2Buf vb) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(EvalLds)];
 #ifdef COOK_EVAL_TRACE
   const unsigned long long t0 = cook_ticks();
 #endif
-  eval_block(lds, in, st, vb, vb.ctl->head, vb.ctl->wcur, blockIdx.x, blockIdx.y, gridDim.y);
+  eval_block<GE>(lds, in, st, vb, vb.ctl->head, vb.ctl->wcur, blockIdx.x, blockIdx.y, gridDim.y);
 #ifdef COOK_EVAL_TRACE
   __syncthreads();
   if (vb.eval_trace && threadIdx.x == 0) {
@@ -2303,11 +2338,12 @@ struct PoolCtx {
   MatchState st;
   V2Buf vb;
 };
+template <bool GE>
 __global__ void __launch_bounds__(COOK_WAVE* MV_EW) COOK_EVAL_OCCUPANCY match_eval2_multi(const PoolCtx* __restrict__ ctx) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(EvalLds)];
   const PoolCtx& c = ctx[blockIdx.z];
   if (blockIdx.x >= c.vb.C) return;  // pools may differ in their number of offers
-  eval_block(lds, c.in, c.st, c.vb, c.vb.ctl->head, c.vb.ctl->wcur, blockIdx.x, blockIdx.y, gridDim.y);
+  eval_block<GE>(lds, c.in, c.st, c.vb, c.vb.ctl->head, c.vb.ctl->wcur, blockIdx.x, blockIdx.y, gridDim.y);
 }
 __global__ void __launch_bounds__(COOK_WAVE* MV_MW) match_merge2_multi(const PoolCtx* __restrict__ ctx) {
   const PoolCtx& c = ctx[blockIdx.z];

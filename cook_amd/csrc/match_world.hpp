@@ -236,7 +236,7 @@ static __device__ __forceinline__ void world_evaluator(char* lds, const PoolCtx*
       if (ph & 1u) {
         const unsigned ntiles = c.vb.C * ((nwin + COOK_WAVE - 1u) / COOK_WAVE);
         for (unsigned t = first; t < ntiles; t += NT) {
-          eval_tile_t<true>(elds, c.in, c.st, c.vb, head, wcur, t % c.vb.C, t / c.vb.C, tw, tsync);
+          eval_tile_t<true, true>(elds, c.in, c.st, c.vb, head, wcur, t % c.vb.C, t / c.vb.C, tw, tsync);
           tsync();  // the leader is done with the team's lists before the next tile overwrites them
           ++count;
         }
