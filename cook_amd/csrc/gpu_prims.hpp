@@ -71,21 +71,6 @@ static __device__ __forceinline__ unsigned long long cook_ticks() { return wall_
 #define WAIT_ALL_MEM() __builtin_amdgcn_s_waitcnt(0x0070)     // vmcnt(0) lgkmcnt(0)
 static __device__ __forceinline__ unsigned wave_uniform_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
-// A record every lane of the wave reads at the SAME index, from memory no kernel of this launch writes: through the constant address
-// space, which the back end turns into scalar loads (s_load_dwordxN) — the record lives in scalar registers, not in 64 copies
-// across a vector register each.  `i` must be wave-uniform (the caller passes it through wave_uniform_u32 when the compiler cannot know).
-template <class T>
-static __device__ __forceinline__ T uniform_load(const T* p, size_t i) {
-  static_assert(sizeof(T) % 4 == 0, "dword records");
-  typedef const uint32_t __attribute__((address_space(4))) * CP;
-  const CP s = (CP)(const void*)(p + i);
-  T out;
-  uint32_t* o = reinterpret_cast<uint32_t*>(&out);
-#pragma unroll
-  for (unsigned k = 0; k < sizeof(T) / 4; ++k) o[k] = s[k];
-  return out;
-}
-
 // ---- wave-wide max of a u64 key / lane reads without going through LDS ------------------------------------------------
 // ds_bpermute-based shuffles cost ~100+ cycles of latency each; the placement walk is a dependent chain, so its
 // reductions use DPP (row-level VALU data movement) and v_readlane instead.

@@ -63,10 +63,6 @@ static inline unsigned long long cook_ticks() { return 0ull; }
 #define WAIT_ALL_MEM() ((void)0)
 static inline unsigned wave_uniform_u32(unsigned v) { return v; }
 
-// (the GPU form reads the record through the constant address space into scalar registers)
-template <class T>
-static inline T uniform_load(const T* p, size_t i) { return p[i]; }
-
 // ---- wave-wide max of a u64 key / lane reads without going through LDS ------------------------------------------------
 // ds_bpermute-based shuffles cost ~100+ cycles of latency each; the placement walk is a dependent chain, so its
 // reductions use DPP (row-level VALU data movement) and v_readlane instead.
