@@ -119,6 +119,7 @@ class ShardedCluster:
         self.last_user_usage: Optional[np.ndarray] = None
         self.last_phase_ms = (0.0, 0.0, 0.0, 0.0)
         self.chain_whole_cycle = os.environ.get("COOK_CHAIN_WHOLE_CYCLE", "0") != "0"
+        self.force_multi = os.environ.get("COOK_FORCE_MULTI", "0") != "0"  # every pool through the multi-pool launch path, one per chain (measurement)
 
     def close(self):
         self._tp.shutdown(wait=True)
@@ -150,7 +151,7 @@ class ShardedCluster:
         multi = all(hasattr(self.engines[p], "cycle_run_rank") for p in self.pools)
         # match_algo 5: ONE persistent launch places all local pools, every pool advancing on its own (match_world.hpp)
         world = multi and all(getattr(getattr(self.engines[p], "params", None), "match_algo", 0) == 5 for p in self.pools)
-        lockstep = world or (multi and len(self.pools) > self.max_chains)
+        lockstep = world or (multi and (len(self.pools) > self.max_chains or self.force_multi))
 
         def run(p):
             self.engines[p].rank_set_quota(self.quota_inputs(p, usages[p], total))
@@ -159,7 +160,7 @@ class ShardedCluster:
             else:
                 self.engines[p].cycle_run(num_considerable)
 
-        n_chains = min(len(self.pools), self.max_chains)
+        n_chains = max(1, min(len(self.pools), self.max_chains))
         if lockstep and not world and self.chain_whole_cycle:
             # MI355X runs about four independent chains of small kernels at full speed (beyond that the hardware queues
             # share dispatch pipes: 4 pools 113 ms, 6 or 8 pools 186 ms per cycle), while pools in lockstep pay for the
