@@ -34,10 +34,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
-           "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-o", OUT, SRC]
+           "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-o", OUT + f".{os.getpid()}.tmp", SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+    try:  # concurrent builders each write their own file; the rename is atomic
+        subprocess.check_call(cmd)
+        os.replace(cmd[-2], OUT)
+    finally:
+        if os.path.exists(cmd[-2]):
+            os.remove(cmd[-2])
     return OUT
 
 

@@ -20,11 +20,17 @@ def build(force=False, shipped_shapes=False):
     out = OUT_SHIPPED if shipped_shapes else OUT
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in DEPS):
         return out
+    tmp = f"{out}.{os.getpid()}.tmp"  # several test processes may build at once (pytest -n): each writes its own file, the rename is atomic
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-I", HERE, "-x", "c++", SRC,
-           os.path.join(HERE, "emu.cpp"), "-o", out]
+           os.path.join(HERE, "emu.cpp"), "-o", tmp]
     if shipped_shapes:
         cmd.insert(1, "-DCOOK_EMU_SHIPPED_SHAPES")
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return out
 
 
