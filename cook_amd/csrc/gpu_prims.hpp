@@ -154,9 +154,11 @@ static __device__ __forceinline__ unsigned half_max_u32(unsigned x) {
 }
 
 // a record of 16-byte pieces to global memory; through: write-through (sc1) stores — the record is in memory, visible to every
-// XCD, once the wave's vmcnt drains
+// XCD, once the wave's vmcnt drains.  first: the lane's first piece to store (an EMPTY candidate list goes out as its 16-byte
+// count piece alone: late in a cycle most (job, chunk) lists are empty, and 128 bytes each made the evaluation write 8x its
+// algorithmic bytes)
 template <class Rec>
-static __device__ __forceinline__ void chunk_store(Rec* dst, const Rec& r, bool through) {
+static __device__ __forceinline__ void chunk_store(Rec* dst, const Rec& r, bool through, unsigned first = 0u) {
   static_assert(sizeof(Rec) % 16 == 0, "moved in 16-byte pieces");
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   constexpr unsigned NP = sizeof(Rec) / 16;
@@ -165,6 +167,7 @@ static __device__ __forceinline__ void chunk_store(Rec* dst, const Rec& r, bool 
   u32x4* d = reinterpret_cast<u32x4*>(dst);
 #pragma unroll
   for (unsigned x = 0; x < NP; ++x) {
+    if (x < first) continue;
     if (through) {
       u32x4* a = d + x;
       // s_nop: a VMEM store of more than 64 bits reads its data registers AFTER issue, and the compiler's hazard recogniser does

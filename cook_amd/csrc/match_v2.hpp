@@ -153,6 +153,8 @@ struct alignas(16) ChunkRec {
   unsigned cnt[4];    // n | nge << 8, offers failing on resources / constraints / zero fitness
 };
 static_assert(sizeof(ChunkRec) % 16 == 0, "ChunkRec is moved in 16-byte pieces");
+static_assert(offsetof(ChunkRec, cnt) % 16 == 0 && offsetof(ChunkRec, cnt) + 16 == sizeof(ChunkRec), "the counts are the record's last 16-byte piece");
+constexpr unsigned CHUNK_COUNT_PIECE = offsetof(ChunkRec, cnt) / 16;  // an empty list is stored from here on (chunk_store): the merge reads n = 0 and ignores the rest
 // (chunk_store: platform.hpp)
 
 struct V2Buf {
@@ -809,7 +811,7 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
   R.cnt[1] = t1;
   R.cnt[2] = t2;
   R.cnt[3] = t4;
-  chunk_store(&vb.prec[(size_t)b * (vb.C * split) + ch * split + part], R, THROUGH);
+  chunk_store(&vb.prec[(size_t)b * (vb.C * split) + ch * split + part], R, THROUGH, (n_out | n_g) == 0 ? CHUNK_COUNT_PIECE : 0u);
 #ifdef COOK_EVAL_TRACE
   if (trp && lane == 0) trp[3] = cook_ticks();
 #endif
@@ -854,7 +856,7 @@ static __device__ __forceinline__ void eval_tile_wave(EvalWaveLds& W, const Matc
   R.cnt[1] = E.c1;
   R.cnt[2] = E.c2;
   R.cnt[3] = E.c4;
-  chunk_store(&vb.prec[(size_t)b * vb.C + ch], R, THROUGH);
+  chunk_store(&vb.prec[(size_t)b * vb.C + ch], R, THROUGH, (n_out | n_g) == 0 ? CHUNK_COUNT_PIECE : 0u);
 }
 
 // What one block of the eval grid (offer chunks x MV_JG) does.  A window of the usual size: the block's MV_EW waves share ONE tile

@@ -118,7 +118,9 @@ static inline unsigned half_max_u32(unsigned x) {
 }
 
 template <class Rec>
-static inline void chunk_store(Rec* dst, const Rec& r, bool) { *dst = r; }
+static inline void chunk_store(Rec* dst, const Rec& r, bool, unsigned first = 0u) {
+  __builtin_memcpy(reinterpret_cast<char*>(dst) + 16u * first, reinterpret_cast<const char*>(&r) + 16u * first, sizeof(Rec) - 16u * first);
+}
 
 // walk statistics of the emulated build (design studies, scripts/study_rounds.py): [0] jobs walked, [1] settled by the shortcut
 // (no candidate under S), [2] went through the exact path, [3] won by an offer touched earlier in the round, [4] won by an
