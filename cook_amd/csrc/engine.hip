@@ -911,8 +911,8 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     // sized for a LONG window (MV_WLONG jobs, match_v2.hpp): 128 bytes per (job, offer chunk) = 26 MB for a C4 pool
     vb.prec = e->v_prec.ensure((size_t)MV_WLONG * C);
     vb.colbits = e->v_colbits.ensure((size_t)(M ? M : 1u) * MV_JGL);
-    vb.cand_fit = e->v_cand_fit.ensure((size_t)MV_WLONG * MV_L);
-    vb.cand_idx = e->v_cand_idx.ensure((size_t)MV_WLONG * MV_L);
+    vb.cand_fit = e->v_cand_fit.ensure((size_t)MV_WLONG * MV_LM);
+    vb.cand_idx = e->v_cand_idx.ensure((size_t)MV_WLONG * MV_LM);
     vb.ge_idx = e->v_ge_idx.ensure((size_t)MV_WLONG * MV_LG);
     vb.cinfo = e->v_cinfo.ensure((size_t)MV_WLONG * 4);
     vb.jfh = e->v_jfh.ensure((size_t)MV_WLONG * (MV_FH + 2));

@@ -40,7 +40,17 @@
 #ifndef COOK_MV_L
 #define COOK_MV_L 8
 #endif
-constexpr int MV_L = COOK_MV_L;            // candidate list length per job (-DCOOK_MV_L=n builds a variant for tuning runs)
+constexpr int MV_L = COOK_MV_L;            // candidate list length per job and chunk (-DCOOK_MV_L=n builds a variant for tuning runs)
+// Length of a job's MERGED list (what the walk sees).  A job's per-chunk top-L lists determine its global top-LM exactly as long as no
+// chunk has contributed all L of its entries (that chunk may hide an (L+1)-th): the merge stops there and marks the list truncated.
+// 12 entries with a window of 384 jobs is what fits the walk's 160 KB of LDS: a C4 pool takes 365 rounds instead of the 476 of
+// (8 entries, 512 jobs), the eight-pool cycle 82.9 ms instead of 92.6.  -DCOOK_MV_LM=8 builds the old layout's lists.
+#ifndef COOK_MV_LM
+#define COOK_MV_LM 12
+#endif
+constexpr int MV_LM = COOK_MV_LM;
+constexpr bool MV_LM_EXT = MV_LM > MV_L;
+static_assert(MV_LM >= MV_L && MV_LM <= 64, "the walk holds one merged-list entry per lane");
 #ifndef COOK_MV_LG
 #define COOK_MV_LG 4
 #endif
@@ -67,7 +77,7 @@ constexpr int MV_WMAX = COOK_MV_WMAX;
 constexpr int MV_S = COOK_MV_S;
 constexpr int MV_HASH = 4 * COOK_MV_S;
 #else
-constexpr int MV_WMAX = COOK_SHAPE(512, 128);  // jobs per round (the emulated tests: small, so that small inputs run many rounds)
+constexpr int MV_WMAX = COOK_SHAPE(384, 128);  // jobs per round (the emulated tests: small, so that small inputs run many rounds)
 constexpr int MV_S = COOK_SHAPE(256, 128);     // distinct candidate offers staged per round
 constexpr int MV_HASH = COOK_SHAPE(1024, 512);
 #endif
@@ -78,7 +88,7 @@ constexpr int MV_JG = MV_WMAX / 64;        // job groups (waves of jobs) per win
 // 152 of its 604 rounds resolving 512 such jobs each; with long windows that tail takes about 20 rounds.
 constexpr int MV_WLONG = MV_WMAX * 8;
 constexpr int MV_JGL = MV_WLONG / 64;      // job groups of a long window (stride of colbits)
-constexpr int MV_EPJ_MAX = (MV_L + MV_LG) > 16 ? (MV_L + MV_LG) : 16;
+constexpr int MV_EPJ_MAX = (MV_LM + MV_LG) > 16 ? (MV_LM + MV_LG) : 16;
 constexpr int MV_JSTEP = MV_S / MV_EPJ_MAX;  // jobs inserted into the slot table per step (at most MV_EPJ_MAX entries each)
 static_assert(MV_JSTEP >= 1, "slot-table step sizing");
 static_assert(MV_OCW <= COOK_WAVE, "one lane stages one offer");
@@ -917,6 +927,8 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
   for (int q = 0; q < MV_LG; ++q) gi[q] = 0x7FFFFFFF;
   int n_ge = 0;
   unsigned c1 = 0, c2 = 0, c4 = 0;
+  int n_seen = 0;     // (MV_LM_EXT) entries of all the lane's chunks
+  bool hide = false;  // (MV_LM_EXT) see MV_LM
   const unsigned cv = vb.C * split;  // chunk lists per job (virtual chunks, eval_split)
   for (unsigned ch = lane; ch < cv; ch += COOK_WAVE) {
     const ChunkRec R = vb.prec[(size_t)b * cv + ch];  // eight 16-byte loads, all in flight together
@@ -925,6 +937,10 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
     c2 += R.cnt[2];
     c4 += R.cnt[3];
     const int n = (int)(info & 0xFFu), ng = (int)((info >> 8) & 0xFFu);
+    if (MV_LM_EXT) {  // this lane's list may end before the chunk's (or chunks') feasible offers do
+      n_seen += n;
+      hide = hide || n == MV_L || n_seen > MV_L;
+    }
     if (ch < (unsigned)COOK_WAVE) {  // the lane's first chunk (its only one up to 64 chunks = 8 192 offers): the sorted list as it is
 #pragma unroll
       for (int q = 0; q < MV_L; ++q)
@@ -955,7 +971,8 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
     c4 += __shfl_xor(c4, d, COOK_WAVE);
   }
   int n_out = 0;
-  for (int round = 0; round < MV_L; ++round) {
+  bool trunc = false;  // (MV_LM_EXT) the merged list may not hold every feasible offer
+  for (int round = 0; round < MV_LM; ++round) {
     // the best head over the lanes: greatest fitness (positive doubles order like their bit patterns), lowest offer index among
     // equal ones — two DPP reductions instead of six rounds of three ds_bpermute shuffles
     const unsigned long long key = ti[0] >= 0 ? (unsigned long long)__double_as_longlong(tf[0]) : 0ull;
@@ -969,14 +986,15 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
       best.idx = (int)(0x7FFFFFFFu - wave_max_u32(key == mk ? 0x7FFFFFFFu - (unsigned)ti[0] : 0u));
     if (lane == 0) {
       if (THROUGH) {
-        st_agent(&vb.cand_fit[(size_t)b * MV_L + round], best.fit);
-        st_agent(&vb.cand_idx[(size_t)b * MV_L + round], best.idx);
+        st_agent(&vb.cand_fit[(size_t)b * MV_LM + round], best.fit);
+        st_agent(&vb.cand_idx[(size_t)b * MV_LM + round], best.idx);
       } else {
-        vb.cand_fit[(size_t)b * MV_L + round] = best.fit;
-        vb.cand_idx[(size_t)b * MV_L + round] = best.idx;
+        vb.cand_fit[(size_t)b * MV_LM + round] = best.fit;
+        vb.cand_idx[(size_t)b * MV_LM + round] = best.idx;
       }
     }
     ++n_out;
+    bool emptied = false;
     if (ti[0] == best.idx) {  // the owner pops its head
 #pragma unroll
       for (int q = 0; q < MV_L - 1; ++q) {
@@ -985,8 +1003,14 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
       }
       tf[MV_L - 1] = -1.0;
       ti[MV_L - 1] = -1;
+      emptied = ti[0] < 0 && hide;
+    }
+    if (MV_LM_EXT && __any(emptied)) {  // a list that may continue beyond what the lane holds just ran out: stop here
+      trunc = true;
+      break;
     }
   }
+  if (MV_LM_EXT && !trunc) trunc = __any(ti[0] >= 0);  // LM entries emitted and some lane still holds more
   int n_g = 0;
   if (use_ge) {
     for (int round = 0; round < MV_LG; ++round) {
@@ -1010,12 +1034,12 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
   }
   if (lane == 0) {
     if (THROUGH) {
-      st_agent(&vb.cinfo[(size_t)b * 4 + 0], (uint32_t)((unsigned)n_out | ((unsigned)n_g << 8)));
+      st_agent(&vb.cinfo[(size_t)b * 4 + 0], (uint32_t)((unsigned)n_out | ((unsigned)n_g << 8) | ((MV_LM_EXT && trunc) ? 1u << 16 : 0u)));
       st_agent(&vb.cinfo[(size_t)b * 4 + 1], (uint32_t)c1);
       st_agent(&vb.cinfo[(size_t)b * 4 + 2], (uint32_t)c2);
       st_agent(&vb.cinfo[(size_t)b * 4 + 3], (uint32_t)c4);
     } else {
-      vb.cinfo[(size_t)b * 4 + 0] = (unsigned)n_out | ((unsigned)n_g << 8);
+      vb.cinfo[(size_t)b * 4 + 0] = (unsigned)n_out | ((unsigned)n_g << 8) | ((MV_LM_EXT && trunc) ? 1u << 16 : 0u);
       vb.cinfo[(size_t)b * 4 + 1] = c1;
       vb.cinfo[(size_t)b * 4 + 2] = c2;
       vb.cinfo[(size_t)b * 4 + 3] = c4;
@@ -1057,6 +1081,15 @@ struct GEntL {  // good-enough list entry
 };
 constexpr unsigned JL_GPU = 1u << 16, JL_GROUPED = 1u << 17, JL_HASGROUP = 1u << 20;  // (bits 18-19: group type)
 constexpr unsigned JL_XRES = 1u << 28;  // asks for ports / named scalars: general path only
+constexpr unsigned JL_TRUNC = 1u << 29;  // (MV_LM_EXT) the merged list may not hold every feasible offer (cinfo bit 16)
+// "entries may exist beyond the job's list" / "the list holds every feasible offer" inside the walk (cinfo_u, nc: the walk's locals)
+#if COOK_MV_LM > COOK_MV_L
+#define COOK_L_TRUNC() ((cinfo_u & JL_TRUNC) != 0u)
+#define COOK_L_COMPLETE() ((cinfo_u & JL_TRUNC) == 0u)
+#else
+#define COOK_L_TRUNC() (nc == MV_L)
+#define COOK_L_COMPLETE() (nc < MV_L)
+#endif
 constexpr unsigned JL_GSLOT_SHIFT = 21, JL_GSLOT_NONE = 0x7Fu;  // bits 21-27: the job's row of ResolveLds::gfh, or none
 constexpr int MV_GMAX = 64;  // group members per round whose hosts-to-avoid are staged for the walk's fast path
 
@@ -1066,7 +1099,7 @@ constexpr int MV_GMAX = 64;  // group members per round whose hosts-to-avoid are
 
 struct ResolveLds {
   JobL job[MV_WMAX];          // the jobs the walk visits, in rank order (walk position i; JobL::b = window position)
-  EntL ent[MV_WMAX][MV_L];    // their candidate lists, by walk position
+  EntL ent[MV_WMAX][MV_LM];   // their candidate lists, by walk position
   GEntL gent[MV_WMAX][MV_LG];
   SlotRec slot[MV_S];
   unsigned long long col[MV_S][MV_JG];  // static-constraints-pass bits of (slot, walked job), by WALK position (bit i & 63 of word i >> 6)
@@ -1194,7 +1227,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   const unsigned n_walk = n_list < (unsigned)MV_WMAX ? n_list : (unsigned)MV_WMAX;  // ... and can stage in this round
   // walk records + candidate lists of the visited jobs -> LDS, by walk position (one parallel pass; the slot-table passes below
   // then never touch HBM)
-  constexpr int EPJ = MV_L + MV_LG;
+  constexpr int EPJ = MV_LM + MV_LG;
   for (unsigned e = tid; e < nwin * (EPJ + 1); e += NT) {
     const unsigned b = e / (EPJ + 1), q = e % (EPJ + 1);
     const unsigned long long vw = s_visit[b >> 6];
@@ -1211,7 +1244,8 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       r.m = j.m;
       const bool grouped = (j.flags & JF_GROUPED) != 0;
       r.info = (info & 0xFFFFu) | (j.g > 0 ? JL_GPU : 0u) | (grouped ? JL_GROUPED : 0u) | (((j.flags >> 8) & 3u) << 18) |
-               (j.group != 0xFFFFFFFFu ? JL_HASGROUP : 0u) | ((j.flags & JF_XRES) ? JL_XRES : 0u);
+               (j.group != 0xFFFFFFFFu ? JL_HASGROUP : 0u) | ((j.flags & JF_XRES) ? JL_XRES : 0u) |
+               ((MV_LM_EXT && (info & (1u << 16))) ? JL_TRUNC : 0u);
       // a member of a unique (type 1) or unconstrained (type 0) group: stage what the walk's fast path needs — the hosts to avoid
       // as the round begins and the group's last placed job (for the chain link) — so that it never has to go to HBM for them
       unsigned gslot = JL_GSLOT_NONE;
@@ -1236,15 +1270,15 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       r.f4 = (unsigned short)(c4 < 0xFFFFu ? c4 : 0xFFFFu);
       r.b = (unsigned short)b;
       s_job[i] = r;
-    } else if (q < (unsigned)MV_L) {
+    } else if (q < (unsigned)MV_LM) {
       EntL x;
       x.fit = -1.0;
       x.off = -1;
       x.slot = 0;
       x.pad = 0;
       if (q < (info & 0xFFu)) {
-        x.off = vb.cand_idx[(size_t)b * MV_L + q];
-        x.fit = vb.cand_fit[(size_t)b * MV_L + q];
+        x.off = vb.cand_idx[(size_t)b * MV_LM + q];
+        x.fit = vb.cand_fit[(size_t)b * MV_LM + q];
       }
       s_ent[i][q] = x;
     } else {
@@ -1252,8 +1286,8 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       x.off = -1;
       x.slot = 0;
       x.pad = 0;
-      if (use_ge && q - MV_L < ((info >> 8) & 0xFFu)) x.off = vb.ge_idx[(size_t)b * MV_LG + (q - MV_L)];
-      s_gent[i][q - MV_L] = x;
+      if (use_ge && q - MV_LM < ((info >> 8) & 0xFFu)) x.off = vb.ge_idx[(size_t)b * MV_LG + (q - MV_LM)];
+      s_gent[i][q - MV_LM] = x;
     }
   }
   __syncthreads();
@@ -1267,7 +1301,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       const unsigned e1 = ((s0 + step < n_walk) ? s0 + step : n_walk) * EPJ;
       for (unsigned e = s0 * EPJ + tid; e < e1; e += NT) {
         const unsigned i = e / EPJ, q = e % EPJ;
-        const int idx = q < (unsigned)MV_L ? s_ent[i][q].off : s_gent[i][q - MV_L].off;
+        const int idx = q < (unsigned)MV_LM ? s_ent[i][q].off : s_gent[i][q - MV_LM].off;
         if (idx < 0) continue;
         unsigned h = ((unsigned)idx * 2654435761u) % MV_HASH;
         for (;;) {
@@ -1304,14 +1338,14 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   const unsigned n_eff = s_minbad < n_walk ? s_minbad : n_walk;  // walk positions resolvable in this round
   for (unsigned e = tid; e < n_eff * EPJ; e += NT) {  // candidate offer -> slot
     const unsigned i = e / EPJ, q = e % EPJ;
-    const int idx = q < (unsigned)MV_L ? s_ent[i][q].off : s_gent[i][q - MV_L].off;
+    const int idx = q < (unsigned)MV_LM ? s_ent[i][q].off : s_gent[i][q - MV_LM].off;
     if (idx < 0) continue;
     unsigned h = ((unsigned)idx * 2654435761u) % MV_HASH;
     while (s_hkey[h] != idx) h = (h + 1) % MV_HASH;
-    if (q < (unsigned)MV_L)
+    if (q < (unsigned)MV_LM)
       s_ent[i][q].slot = s_hslot[h];
     else
-      s_gent[i][q - MV_L].slot = s_hslot[h];
+      s_gent[i][q - MV_LM].slot = s_hslot[h];
   }
   const unsigned nslots = s_nslots < (unsigned)MV_S ? s_nslots : (unsigned)MV_S;
   for (unsigned s = tid; s < nslots; s += NT) {
@@ -1488,7 +1522,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     double c, m;
     unsigned info, group;
     unsigned f4b;      // JobL::f4 | JobL::b << 16
-    double e_fit;      // list entry `lane` (lanes >= MV_L: none)
+    double e_fit;      // list entry `lane` (lanes >= MV_LM: none)
     int e_off;
     unsigned e_slotw;  // EntL::slot | pad << 16
     unsigned owner;    // lane owning the entry's slot, 0xFF untouched, 0xFE no entry
@@ -1509,7 +1543,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     r.e_off = -1;
     r.e_slotw = 0;
     r.owner = 0xFEu;
-    if (lane < (unsigned)MV_L) {
+    if (lane < (unsigned)MV_LM) {
       const EntL* ep = &s_ent[ii][lane];
       r.e_fit = ep->fit;
       r.e_off = ep->off;
@@ -1519,7 +1553,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   };
   // the owner look-up needs the entry's slot: issued one iteration ahead (a commit in between patches it, see below)
   auto load_owner = [&](JobRegs& r) {
-    if (lane < (unsigned)MV_L && r.e_off >= 0) r.owner = s_slot_lane[r.e_slotw & 0xFFFFu];
+    if (lane < (unsigned)MV_LM && r.e_off >= 0) r.owner = s_slot_lane[r.e_slotw & 0xFFFFu];
   };
   JobRegs cur = load_rec(0);
   load_owner(cur);
@@ -1555,6 +1589,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     const bool has_group = (cinfo_u & JL_HASGROUP) != 0;
     const unsigned g = has_group ? wave_uniform_u32(cur.group) : 0xFFFFFFFFu, gtype = (cinfo_u >> 18) & 3u;
     const int nc = (int)(cinfo_u & 0xFFu);
+
     if ((cpos >> 6) != cur_g) {  // next word of the columns: the touched lanes fetch theirs
       cur_g = cpos >> 6;
       if (t_slot >= 0) t_col = s_col[t_slot][cur_g];
@@ -1634,7 +1669,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
           if (u_off < 0) {
             // no untouched entry: fine unless the list is full and none of its entries is still a candidate (then better
             // untouched offers may exist beyond the list: exhausted, general path)
-            bool ok = nc < MV_L;
+            bool ok = COOK_L_COMPLETE();
             if (!ok) {
               const unsigned long long cand_mask = __ballot(cand);
               const bool e_live = cur.owner < 0xFEu && ((cand_mask >> (cur.owner & 63u)) & 1ull);
@@ -1777,7 +1812,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         const bool e_untouched = cur.owner == 0xFFu;
         const bool e_live = e_valid && !e_untouched && ((cand_mask >> (cur.owner & 63u)) & 1ull);
         const unsigned long long settle_mask = __ballot(e_untouched || e_live), untouched_mask = __ballot(e_untouched);
-        if (settle_mask == 0ull && nc == MV_L) {
+        if (settle_mask == 0ull && COOK_L_TRUNC()) {
           exhausted = true;
           break;
         }
@@ -1830,7 +1865,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
           // with exact verdicts a list entry settles only if its owner is still FEASIBLE (zero fitness excluded)
           const bool e_live2 = e_valid && !e_untouched && ((feas_mask >> (cur.owner & 63u)) & 1ull);
           const unsigned long long settle2 = __ballot(e_untouched || e_live2);
-          if (settle2 == 0ull && nc == MV_L) {
+          if (settle2 == 0ull && COOK_L_TRUNC()) {
             exhausted = true;
             break;
           }

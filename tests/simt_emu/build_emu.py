@@ -16,8 +16,14 @@ DEPS = [os.path.join(ROOT, "cook_amd", "csrc", f) for f in os.listdir(os.path.jo
 
 def build(force=False, shipped_shapes=False):
     """shipped_shapes: compile with the launch shapes of the GPU build (cook_amd/csrc/platform.hpp COOK_SHAPE) instead of the small
-    ones the emulated suite normally runs with — slower (768 fibers per resolve block), used by tests/test_parity_emu_shipped.py"""
+    ones the emulated suite normally runs with — slower (768 fibers per resolve block), used by tests/test_parity_emu_shipped.py.
+    COOK_EMU_DEFS (environment): extra -D definitions for a study build of the whole suite, e.g. COOK_EMU_DEFS=-DCOOK_MV_LM=12
+    (the library then gets its own file name)."""
     out = OUT_SHIPPED if shipped_shapes else OUT
+    defs = os.environ.get("COOK_EMU_DEFS", "").split()
+    if defs:
+        tag = "".join(c if c.isalnum() else "_" for c in "".join(defs))
+        out = out[:-3] + tag + ".so"
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in DEPS):
         return out
     tmp = f"{out}.{os.getpid()}.tmp"  # several test processes may build at once (pytest -n): each writes its own file, the rename is atomic
@@ -25,6 +31,7 @@ def build(force=False, shipped_shapes=False):
            os.path.join(HERE, "emu.cpp"), "-o", tmp]
     if shipped_shapes:
         cmd.insert(1, "-DCOOK_EMU_SHIPPED_SHAPES")
+    cmd[1:1] = defs
     try:
         subprocess.check_call(cmd)
         os.replace(tmp, out)
