@@ -157,6 +157,11 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
     p_add += at->pending[i] ? 1u : 0u;
   }
   if (p_add != (aj ? aj->n : 0u)) e->fail(COOK_E_INVALID, "cook_cycle_update: add_pending->n must equal the number of pending tasks of add_tasks");
+  if (p_add && (!aj->cpus || !aj->mem)) e->fail(COOK_E_INVALID, "cook_cycle_update: add_pending needs cpus and mem");
+  if (p_add && e->has_j_user && !aj->user)  // (the considerable filters read the staged jobs' users: a missing column would read as user 0)
+    e->fail(COOK_E_INVALID, "cook_cycle_update: the staged jobs carry a user column, add_pending must too");
+  for (unsigned r = 0; p_add && aj->ports && r < p_add; ++r)
+    if (aj->ports[r] < 0) e->fail(COOK_E_INVALID, "cook_cycle_update: negative port count");
   if (d->n_remove && !d->remove_task) e->fail(COOK_E_INVALID, "cook_cycle_update: remove_task is NULL");
   MatchIn& in = e->min;
   // a column the delta brings but the stage did not have cannot be added row-wise: the host restages (cook_cycle_stage)
@@ -264,6 +269,10 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
             nullptr, p_add);
     in.j_novel_off = e->j_novel_off.ptr(), in.j_novel_host = e->j_novel_host.ptr();
   }
+  // the eligible mask of cook_cycle_set_considerable is indexed by pending ordinal like the job columns: it moves with them; the
+  // jobs the delta adds are eligible until the host says otherwise (a fresh mask through cook_cycle_set_considerable)
+  if (e->cb && e->cb->has_elig_by_pending)
+    upd_column<uint8_t>(e, ub, e->cb->elig_by_pending, keep_p, incl_p, P, p_keep, nullptr, p_add, true, (uint8_t)1);
   sync(e);
   e->N = N2;
   e->n_pending = P2;

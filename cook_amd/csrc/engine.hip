@@ -794,7 +794,10 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
   unsigned has_x = 0;
   in.j_ports = h2d_opt(e, e->j_ports, j->ports, K);
   if (j->ports)
-    for (unsigned k = 0; k < K && !has_x; ++k) has_x = j->ports[k] > 0;
+    for (unsigned k = 0; k < K; ++k) {
+      if (j->ports[k] < 0) e->fail(COOK_E_INVALID, "cook_match_stage: negative port count");
+      has_x |= j->ports[k] > 0;
+    }
   const unsigned n_scal = j->scalars ? j->n_scalars : 0u;
   for (unsigned sc = 0; sc < n_scal; ++sc) {
     const double* col = j->scalars + (size_t)sc * K;
@@ -1345,8 +1348,9 @@ int guarded(cook_engine* e, F&& f) {
 extern "C" {
 
 const char* cook_version(void) {
-  return "cookmatch 0.2.0 (" COOK_BUILD_NAME ")";
+  return "cookmatch 0.3.0 (" COOK_BUILD_NAME ")";
 }
+int cook_abi_version(void) { return COOK_ABI_VERSION; }
 
 int cook_engine_create(const cook_params* params, int device_id, cook_engine** out) {
   if (!params || !out) return COOK_E_INVALID;
@@ -1838,6 +1842,19 @@ int cook_match_stats(cook_engine* e, uint32_t out[16]) {
   out[14] = (uint32_t)((c.t_eval + e->world_wait_eval) / 100ull);    // match_persist: eval phase; match_world: the walker's wait for it
   out[15] = (uint32_t)((c.t_merge + e->world_wait_merge) / 100ull);
   return COOK_OK;
+}
+int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap) {
+  if (!e || !out) return COOK_E_INVALID;
+  uint32_t v[COOK_MATCH_STATS_EX_N];
+  for (auto& x : v) x = 0u;
+  const int rc = cook_match_stats(e, v);
+  if (rc) return rc;
+  const WinCtl& c = e->last_ctl;
+  v[16] = c.trunc_lists;
+  v[17] = c.trunc_stops;
+  uint32_t n = 0;
+  for (; n < cap && n < (uint32_t)COOK_MATCH_STATS_EX_N; ++n) out[n] = v[n];
+  return (int)n;
 }
 COOK_EMU_EXTRA_EXPORTS
 int cook_set_profiling(cook_engine* e, int enabled) {

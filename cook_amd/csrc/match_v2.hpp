@@ -138,6 +138,8 @@ struct WinCtl {
   unsigned long long t_setup, t_seq;  // resolve kernel: ticks (100 MHz wall clock) spent in the set-up / sequential phase
   unsigned reeval_max;    // list-exhausted jobs re-evaluated in place per round before the round ends (0 = end the round at once)
   unsigned reevals;       // jobs re-evaluated in place (statistics)
+  unsigned trunc_lists;   // walked jobs whose merged list carried the truncated flag (MV_LM > MV_L: the merge stopped on a full chunk list)
+  unsigned trunc_stops;   // rounds that ended on such a list running out
   unsigned wgrow_pct;     // next window = this percentage of what the round resolved (window ended early) / of the window (it did not)
   unsigned wlong_cap;     // largest window the launch sequence allows (MV_WLONG, or MV_WMAX when long windows are switched off)
   unsigned long long t_eval, t_merge;  // persistent kernel: ticks spent in the eval / merge phases (as seen by workgroup 0)
@@ -1516,6 +1518,8 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   unsigned resolved = n_eff < n_walk ? (unsigned)s_job[n_eff].b : (n_eff < n_list ? walkpos_to_b(n_eff) : nwin);
   unsigned nslots_cur = nslots;  // slots staged so far (re-evaluations may add some)
   unsigned n_exhaust = 0;        // jobs whose list ran out and were re-evaluated
+  unsigned n_trunc = 0;          // walked jobs with a truncated merged list (statistics)
+  bool stop_on_trunc = false;    // the round ended on a TRUNCATED list running out (an untruncated full list cannot: it is complete)
   constexpr double EPS_HI = 1.0 + 0x1p-38, EPS_LO = 1.0 - 0x1p-38;
   struct JobRegs {   // exactly what the LDS loads deliver: nothing is decoded before the job's own iteration (a decode right after
                      // the load would wait for it)
@@ -1589,6 +1593,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     const bool has_group = (cinfo_u & JL_HASGROUP) != 0;
     const unsigned g = has_group ? wave_uniform_u32(cur.group) : 0xFFFFFFFFu, gtype = (cinfo_u >> 18) & 3u;
     const int nc = (int)(cinfo_u & 0xFFu);
+    n_trunc += (cinfo_u & JL_TRUNC) ? 1u : 0u;  // (scalar: cinfo_u is wave-uniform)
 
     if ((cpos >> 6) != cur_g) {  // next word of the columns: the touched lanes fetch theirs
       cur_g = cpos >> 6;
@@ -1962,6 +1967,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       if (!REEVAL || n_exhaust >= ctl.reeval_max) {  // end the round here: the next round evaluates the rest of the window afresh
         stop = 1;
         resolved = b;
+        stop_on_trunc = (cinfo_u & JL_TRUNC) != 0u;
         break;
       }
       if constexpr (REEVAL) {
@@ -2244,6 +2250,8 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     ctl.t_seq += cook_ticks() - tk1;
     if (stop == 1) ctl.stop_list += 1;
     ctl.reevals += n_exhaust;
+    ctl.trunc_lists += n_trunc;
+    ctl.trunc_stops += stop_on_trunc ? 1u : 0u;
     if (vb.round_log && ctl.rounds <= MV_ROUND_LOG_CAP) {
       RoundLog r;
       r.head = head, r.wcur = ctl.wcur, r.resolved = resolved, r.n_list = n_list, r.touched = nT, r.stop = stop, r.matched = matched;

@@ -404,10 +404,11 @@ class Engine:
         return r.value, m.value
 
     def match_stats(self):
-        out = (C.c_uint32 * 16)()
-        self._lib.cook_match_stats(self._h, out)
-        keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "stop_slots", "resolved", "setup_us", "seq_us", "touched", "visited", "reevals", "persistent", "eval_us", "merge_us")
-        return dict(zip(keys, [int(x) for x in out]))
+        out = (C.c_uint32 * 32)()
+        n = self._lib.cook_match_stats_ex(self._h, out, 32)
+        keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "stop_slots", "resolved", "setup_us", "seq_us", "touched", "visited", "reevals", "persistent", "eval_us", "merge_us",
+                "trunc_lists", "trunc_stops")
+        return dict(zip(keys, [int(x) for x in out[:max(0, n)]]))
 
     def set_profiling(self, on: bool):
         self._lib.cook_set_profiling(self._h, int(bool(on)))

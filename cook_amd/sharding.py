@@ -75,7 +75,7 @@ def all_reduce_group_usage(local: np.ndarray, world: int, device=None, force: bo
     return t.cpu().numpy()
 
 
-def all_reduce_user_usage(engines: Sequence, n_users: int, world: int, device=None, force: bool = False) -> np.ndarray:
+def all_reduce_user_usage(engines: Sequence, n_users: int, world: int, device=None, force: bool = False, to_host: bool = True):
     """BASELINE.json north_star's collective: the cross-pool per-user usage totals.  Every local pool writes its [U, 3] vector
     {cpus, mem, gpus of the user's running tasks} (cook_rank_user_usage) — on a GPU rank straight into a device tensor, so the
     payload never visits the host —, the rank adds its pools, and ONE all-reduce(SUM) over RCCL / gloo gives every rank the
@@ -84,17 +84,21 @@ def all_reduce_user_usage(engines: Sequence, n_users: int, world: int, device=No
     import torch.distributed as dist
 
     on_gpu = device is not None and getattr(device, "type", "cpu") == "cuda"
-    acc = torch.zeros((n_users, 3), dtype=torch.float64, device=device if on_gpu else "cpu")
-    buf = torch.empty_like(acc)
-    for e in engines:
-        if on_gpu:
-            e.rank_user_usage(n_users, device_ptr=buf.data_ptr())  # synchronises the engine's stream before returning
-            acc += buf
-        else:
+    engines = list(engines)
+    if on_gpu:
+        # one slice per engine: every engine writes its own rows on its own stream (and synchronises that stream before returning),
+        # torch reads them only afterwards — no buffer is reused while another stream may still be reading it
+        parts = torch.empty((max(1, len(engines)), n_users, 3), dtype=torch.float64, device=device)
+        for i, e in enumerate(engines):
+            e.rank_user_usage(n_users, device_ptr=parts[i].data_ptr())
+        acc = parts[:len(engines)].sum(dim=0) if engines else torch.zeros((n_users, 3), dtype=torch.float64, device=device)
+    else:
+        acc = torch.zeros((n_users, 3), dtype=torch.float64)
+        for e in engines:
             acc += torch.from_numpy(np.ascontiguousarray(e.rank_user_usage(n_users)))
     if world > 1 or force:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
-    return acc.cpu().numpy()
+    return acc.cpu().numpy() if to_host else acc  # to_host=False: the totals stay where the collective left them (no sync, no copy)
 
 
 class ShardedCluster:
@@ -116,10 +120,18 @@ class ShardedCluster:
         self.last_group_usage: Optional[np.ndarray] = None
         self.last_pool_usage: Dict[int, Sequence[float]] = {}
         self.n_users = 0                      # > 0: every cycle also all-reduces the cross-pool per-user usage [U, 3]
-        self.last_user_usage: Optional[np.ndarray] = None
+        self._last_user_usage = None          # torch tensor on the collective's device (or numpy); see last_user_usage
         self.last_phase_ms = (0.0, 0.0, 0.0, 0.0)
         self.chain_whole_cycle = os.environ.get("COOK_CHAIN_WHOLE_CYCLE", "0") != "0"
         self.force_multi = os.environ.get("COOK_FORCE_MULTI", "0") != "0"  # every pool through the multi-pool launch path, one per chain (measurement)
+
+    @property
+    def last_user_usage(self) -> Optional[np.ndarray]:
+        """cross-pool per-user usage [U, 3] of the last cycle (copied to the host on demand: the cycle leaves it on the device)"""
+        u = self._last_user_usage
+        if u is None or isinstance(u, np.ndarray):
+            return u
+        return u.cpu().numpy()
 
     def close(self):
         self._tp.shutdown(wait=True)
@@ -188,7 +200,8 @@ class ShardedCluster:
                     list(self._tp.map(cycle_match_multi, groups))
         t3 = time.perf_counter()
         if self.n_users and all(hasattr(self.engines[p], "rank_user_usage") for p in self.pools):
-            self.last_user_usage = all_reduce_user_usage([self.engines[p] for p in self.pools], self.n_users, self.world, self.device)
+            self._last_user_usage = all_reduce_user_usage([self.engines[p] for p in self.pools], self.n_users, self.world, self.device,
+                                                          to_host=False)
         # host wall time of the phases: pool usage + all-reduce, rank (+ the whole cycle of pools that run on their own chain),
         # lockstep placement, per-user usage all-reduce
         self.last_phase_ms = tuple(1e3 * x for x in (t1 - t0, t2 - t1, t3 - t2, time.perf_counter() - t3))

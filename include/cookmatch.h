@@ -247,6 +247,11 @@ void cook_engine_destroy(cook_engine* e);
 int cook_engine_set_params(cook_engine* e, const cook_params* params);
 const char* cook_last_error(const cook_engine* e);
 const char* cook_version(void);
+/* Layout version of the structs and buffer sizes of this header (cook_jobs / cook_offers / cook_offer_params / COOK_WHY_SLOTS changed
+ * in 2: ports, named scalars, gpu / disk slot tables, 20 why-slots; 3 adds cook_match_stats_ex and the mask rule of
+ * cook_cycle_update).  A binding compares its compiled-in COOK_ABI_VERSION with the library's before the first call. */
+#define COOK_ABI_VERSION 3
+int cook_abi_version(void);
 
 /* ---- RANK: replaces sort-jobs-by-dru-helper + filter-based-on-quota + filter-offensive-jobs --------------
  * (scheduler.clj:2073-2091, 2134-2157, 2198-2229; dru.clj:50-126; tools.clj:614-641, 917-933).
@@ -319,8 +324,10 @@ int cook_cycle_stage(cook_engine* e, const cook_tasks* tasks, const cook_users* 
  * the offers are fresh.  The columns are edited on the device: a STABLE compaction, then the new rows at the end.  Task indices
  * reported afterwards (cook_cycle_fetch's ranked_pending_idx) refer to the updated arrays: row i of the old arrays that was kept is
  * now at i minus the number of removed rows in front of it; add_tasks[r] is at n_kept + r.  add_pending describes the pending tasks
- * of add_tasks, in order, and may only carry optional columns that the staged jobs carry too (else restage).  Users, groups and
- * reserved hosts stay as staged. */
+ * of add_tasks, in order, and may only carry optional columns that the staged jobs carry too (else restage); cpus and mem are
+ * required, and so is `user` when the staged jobs carry one.  Users, groups and reserved hosts stay as staged.  The eligible mask
+ * of cook_cycle_set_considerable moves with the job rows (the jobs a delta adds start out eligible; send a fresh mask to say
+ * otherwise).  ABI note: the struct layouts of this header are versioned by COOK_ABI_VERSION (cook_abi_version()). */
 typedef struct cook_cycle_delta {
   uint32_t n_remove;
   const uint32_t* remove_task;  /* indices into the current task arrays, each at most once */
@@ -553,6 +560,11 @@ int cook_set_profiling(cook_engine* e, int enabled);
    parallel), [12] jobs re-evaluated in place, [13] bit 0: the persistent kernel ran this match, bits 1..: times the engine had
    to fall back from it, [14] / [15] microseconds of the eval / merge phases (persistent kernel only) */
 int cook_match_stats(cook_engine* e, uint32_t out[16]);
+/* the same, open-ended: fills min(cap, COOK_MATCH_STATS_EX_N) words and returns how many.  [0..15] as cook_match_stats;
+   [16] walked jobs whose merged candidate list was cut short because one offer chunk had contributed all its entries (the list
+   may not hold every feasible offer), [17] rounds that ended on such a list running out */
+#define COOK_MATCH_STATS_EX_N 32
+int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap);
 
 #ifdef __cplusplus
 }

@@ -269,7 +269,7 @@ inline uint32_t xres_fail_bits(const cook_jobs* j, uint32_t k, const cook_offers
   return bits;
 }
 inline void xres_commit(const cook_jobs* j, uint32_t k, uint32_t v, MatchState& st) {
-  st.aports[v] += j->ports ? j->ports[k] : 0;
+  st.aports[v] += (j->ports && j->ports[k] > 0) ? j->ports[k] : 0;  // (the ABI rejects negative counts; only positive ones are requests)
   for (uint32_t s2 = 0; j->scalars && s2 < j->n_scalars && s2 < COOK_MAX_SCALARS; ++s2) {
     const double r = j->scalars[(size_t)s2 * j->n + k];
     if (r == r) st.ascalar[(size_t)v * COOK_MAX_SCALARS + s2] += r;

@@ -19,6 +19,7 @@ ALL_ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-adjacent --no-check"
 for S in $STEPS; do
   case $S in
     ubench)
+      [ -x scripts/ubench_wave ] || hipcc -O3 --offload-arch=gfx950 -o scripts/ubench_wave scripts/ubench_wave.hip
       timeout 60 scripts/ubench_wave > "$OUT/ubench.json" 2> "$OUT/ubench.err"; echo "ubench exit $?"; cat "$OUT/ubench.json";;
     tests)
       timeout ${TEST_TIMEOUT:-900} python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} > "$OUT/pytest_gpu.log" 2>&1
