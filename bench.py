@@ -103,7 +103,7 @@ def pmc_traffic(kernel):
     return rec, name
 
 
-def extra_c5(device, check=True, steps=3):
+def extra_c5(device, check=True, steps=3, sizes=(1_000_000, 500_000, 10_000, 50_000, 128)):
     """BASELINE.json configs[4] as the reference runs it (rebalancer.clj:574-590): the rebalancer takes its jobs from the RANKED
     queue of the pool — cook_rank over 1M running + 500k pending tasks — keeps the first max-preemption (128) of them, then the
     preemption sweep (init-state + compute-preemption-decision + next-state per job, rebalancer.clj:222-467) over the 1M running
@@ -112,7 +112,7 @@ def extra_c5(device, check=True, steps=3):
     from cook_amd import _abi as A
     from cook_amd import synth
     from cook_amd.engine import Engine
-    R, PEND, U, H, MAXP = 1_000_000, 500_000, 10_000, 50_000, 128
+    R, PEND, U, H, MAXP = sizes
     pool = synth.make_pool(seed=0xC00C0005, n_pending=PEND, n_running=R, n_users=U, n_offers=H)
     params = A.default_params()
     out = {"what": f"BASELINE.json configs[4]: rank of {R} running + {PEND} pending tasks of one pool ({U} users), then the preemption sweep "
@@ -416,7 +416,12 @@ def main():
                                "pair_evaluations": int(len(j2o_x)) * kw["n_offers"],
                                "stage_ms": dict(zip(("rank", "match"), ex.last_timing())), "placement_stats": ex.match_stats()}
             del pool_x
-        extra["C5"] = extra_c5(local_rank, check=not args.no_check)
+        try:
+            extra["C5"] = extra_c5(local_rank, check=not args.no_check)
+        except AssertionError:
+            raise  # a parity failure must not produce a bench line
+        except Exception as ex:  # (an extra must never cost the headline its line)
+            extra["C5"] = {"error": repr(ex)}
 
     # ---- the boundary, not just the core (never `value`): what a cycle costs when the host hands over what CHANGED since the last
     #      one and takes the assignments back.  cook_cycle_update per pool (1 % of the tasks leave, as many arrive — half of them new
