@@ -18,6 +18,7 @@
 #include "match_kernels.hpp"
 #include "match_v2.hpp"
 #include "match_world.hpp"
+#include "match_v3.hpp"
 #include "offers_kernels.hpp"
 #include "explain_kernels.hpp"
 #include "rank_kernels.hpp"
@@ -178,6 +179,14 @@ struct cook_engine {
   DArr<MatchIn> v_in;
   void* h_inbuf = nullptr;  // pinned staging copy of MatchIn
   WinCtl last_ctl{};
+  // match_v3 (one persistent workgroup per pool)
+  DArr<V3Ctl> v3_ctl;
+  DArr<PoolCtx3> v3_ctx;
+  DArr<int32_t> v3_group_snap;
+  void* h_v3 = nullptr;      // pinned: PoolCtx3 going out, V3Ctl coming back
+  V3Ctl last_v3{};
+  bool groups_simple = true;  // no balanced / attribute-equals group staged (cook_match_stage)
+  unsigned v3_refused = 0;    // calls the v3 kernel handed back to the window rounds
   MatchIn min{};
   bool cycle_staged = false;
   unsigned cycle_considered = 0;
@@ -807,6 +816,9 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
   match_stage_offers(e, o, offers_dev);
   in.n_scal = n_scal;
   in.has_x = has_x;
+  e->groups_simple = true;
+  for (unsigned x = 0; x < G; ++x)
+    if (g->type && g->type[x] >= 2) e->groups_simple = false;
   if (G) {
     in.g_type = h2d_opt(e, e->g_type, g->type, G);
     in.g_attr_key = h2d_opt(e, e->g_attr_key, g->attr_key, G);
@@ -863,6 +875,55 @@ void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, 
 void match_rounds_multi(cook_engine** es, unsigned n);
 bool match_rounds_world(cook_engine** es, unsigned n);
 
+// match_algo 6 (match_v3.hpp): may this call go to the persistent per-pool workgroup?  Best fit only, no ports / named scalars, no
+// group whose constraint can OPEN an offer, one offer per host, the offers must fit the workgroup's LDS order.
+bool match_v3_eligible(const cook_engine* e, const MatchIn& in) {
+  return in.good_enough >= 1.0 && !in.has_x && in.host_dup == 0u && e->groups_simple && in.M >= 1u && in.M <= (unsigned)V3_MMAX && in.K >= 1u;
+}
+// -> false: the kernel refused the input before placing anything (the caller re-initialises the state and runs the window rounds)
+bool match_v3_run(cook_engine* e, const MatchIn& in, const MatchState& st, const OfferA* oa, const OfferB* ob, const JobRec* jr, const JobCons* jcons,
+                  const MatchIn* din) {
+  PoolCtx3 h;
+  h.in = in;
+  h.st = st;
+  h.vb.oa = oa, h.vb.ob = ob, h.vb.jr = jr, h.vb.jcons = jcons, h.vb.in_dev = din;
+  h.vb.ctl = e->v3_ctl.ensure(1);
+  h.vb.group_snap = e->v3_group_snap.ensure(std::max(1u, in.G));
+  h.vb.job_flags = e->m_jmin.ptr();
+  if (!e->h_v3) COOK_HIP(hipHostMalloc(&e->h_v3, sizeof(PoolCtx3) + sizeof(V3Ctl), hipHostMallocDefault));
+  std::memcpy(e->h_v3, &h, sizeof(h));
+  PoolCtx3* dctx = e->v3_ctx.ensure(1);
+  COOK_HIP(hipMemcpyAsync(dctx, e->h_v3, sizeof(PoolCtx3), hipMemcpyHostToDevice, e->stream));
+  COOK_HIP(hipMemsetAsync(h.vb.ctl, 0, sizeof(V3Ctl), e->stream));
+  KL("match_v3", match_v3, 1, V3_THREADS, (const PoolCtx3*)dctx);
+  V3Ctl* hc = (V3Ctl*)((char*)e->h_v3 + sizeof(PoolCtx3));
+  COOK_HIP(hipMemcpyAsync(hc, h.vb.ctl, sizeof(V3Ctl), hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+  e->last_v3 = *hc;
+  if (hc->error != 0u) {
+    e->v3_refused += 1;
+    return false;
+  }
+  WinCtl c;
+  std::memset(&c, 0, sizeof(c));
+  c.head = in.K;
+  c.rounds = hc->generations;
+  c.matched = hc->matched;
+  c.head_matched = hc->head_matched;
+  c.stop_list = hc->stop_list, c.stop_full = hc->stop_full, c.stop_group = hc->stop_log;
+  c.touched_sum = hc->opens;
+  c.visited_sum = hc->walked;
+  c.t_setup = hc->t_regen;
+  c.t_seq = hc->t_total - hc->t_regen;
+  e->last_ctl = c;
+  e->last_persistent = 3;
+  unsigned sum[4] = {c.matched, (c.matched == 0 || c.head_matched) ? 1u : 0u, c.rounds, 0u};
+  std::memcpy(e->h_scratch, sum, 16);
+  COOK_HIP(hipMemcpyAsync(st.summary, e->h_scratch, 16, hipMemcpyHostToDevice, e->stream));
+  sync(e);
+  return true;
+}
+
 void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool defer = false) {
   MatchIn in = e->min;
   in.K = K;
@@ -882,7 +943,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
   st.fail_code = e->m_fail.ensure(K);
   st.summary = e->m_summary.ensure(4);
   st.alive = e->m_alive.ensure((M + 63u) / 64u + 1u);
-  st.jmin = (const double*)e->m_jmin.ensure(2);
+  st.jmin = (const double*)e->m_jmin.ensure(4);
   st.xports = in.has_x ? e->m_xports.ensure(M) : nullptr;
   st.xscal = in.has_x ? e->m_xscal.ensure((size_t)M * COOK_MAX_SCALARS) : nullptr;
   match_init_state(e, st, K, M, G);
@@ -892,7 +953,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
   const int algo = e->params.match_algo;
   const bool world_solo = algo == 5 && K > 0 && !defer;  // one pool through the persistent kernel: set up as deferred, run at once
   if (world_solo) defer = true;
-  if (defer && !((algo == 0 || algo == 2 || algo == 5) && K > 0)) defer = false;  // only the window-round orchestrations run several pools
+  if (defer && !((algo == 0 || algo == 2 || algo == 5) && K > 0)) defer = false;  // (6: the pool's own launch, at once, on its own stream)  // only the window-round orchestrations run several pools
   if (algo == 1) {  // one-job-at-a-time sweep by a single workgroup (reference implementation of the chain)
     constexpr int SERIAL_THREADS = COOK_SHAPE(1024, 256);
     auto k_match = match_serial<SERIAL_THREADS>;
@@ -937,11 +998,21 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     if (M) KL("match_pack_offers", match_pack_offers, div_up(M, 256), 256, in, oa, ob);
     KL("match_pack_jobs", match_pack_jobs, div_up(K, 256), 256, in, jr, jcons);
     COOK_HIP(hipMemsetAsync(e->m_jmin.ptr(), 0x7F, 16, e->stream));  // > every finite double's bit pattern
+    COOK_HIP(hipMemsetAsync(e->m_jmin.ptr() + 2, 0, 16, e->stream));   // [2]: a job with a negative / non-finite request was seen
     KL("match_job_minima", match_job_minima, std::min(div_up(K, 256), 256u), 256, (const JobRec*)jr, K, e->m_jmin.ptr());
     auto init_alive = [&] {
       if (M) KL("match_init_alive", match_init_alive, div_up(M, 256), 256, (const OfferA*)oa, M, st.jmin, st.alive);
     };
     init_alive();
+    if (algo == 6 && match_v3_eligible(e, in)) {  // ONE persistent workgroup places the whole call (match_v3.hpp)
+      if (match_v3_run(e, in, st, oa, ob, jr, jcons, vb.in_dev)) {
+        e->cycle_considered = K;
+        e->match_done = true;
+        return;
+      }
+      match_init_state(e, st, K, M, G);  // refused before anything was placed: the window rounds take the call
+      init_alive();
+    }
     WinCtl c0;
     std::memset(&c0, 0, sizeof(c0));
     c0.wcur = std::min<unsigned>(MV_WMAX, 64u);
@@ -1413,6 +1484,7 @@ void cook_engine_destroy(cook_engine* e) {
     if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]);
   if (e->h_scratch) (void)hipHostFree(e->h_scratch);
   if (e->h_inbuf) (void)hipHostFree(e->h_inbuf);
+  if (e->h_v3) (void)hipHostFree(e->h_v3);
   if (e->h_multi) (void)hipHostFree(e->h_multi);
   delete e->rb;
   e->rb = nullptr;
@@ -1852,6 +1924,14 @@ int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap) {
   const WinCtl& c = e->last_ctl;
   v[16] = c.trunc_lists;
   v[17] = c.trunc_stops;
+  if (e->last_persistent == 3) {  // match_v3: generations, jobs walked / settled by the helpers, blocks the helpers visited, lanes opened,
+                                  // microseconds total / rebuilding orders / the walker waiting for a prepared job, why generations ended
+    const V3Ctl& q = e->last_v3;
+    v[18] = q.generations, v[19] = q.walked, v[20] = q.settled, v[21] = q.scan_steps, v[22] = q.opens;
+    v[23] = (uint32_t)(q.t_total / 100ull), v[24] = (uint32_t)(q.t_regen / 100ull), v[25] = (uint32_t)(q.t_walk_wait / 100ull);
+    v[26] = q.stop_full, v[27] = q.stop_list, v[28] = q.stop_log;
+  }
+  v[29] = e->v3_refused;
   uint32_t n = 0;
   for (; n < cap && n < (uint32_t)COOK_MATCH_STATS_EX_N; ++n) out[n] = v[n];
   return (int)n;

@@ -288,11 +288,14 @@ __global__ void __launch_bounds__(256) match_pack_jobs(MatchIn in, JobRec* __res
 // minimum cpus / mem over the jobs of the call (positive doubles order like their bit patterns; jmin starts at +inf)
 __global__ void __launch_bounds__(256) match_job_minima(const JobRec* __restrict__ jr, unsigned K, unsigned long long* __restrict__ jmin_bits) {
   double c = __longlong_as_double(0x7FF0000000000000ll), m = c;
+  bool odd = false;  // a negative or non-finite request (jmin_bits[2]: match_v3 leaves such calls to the window rounds)
   for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
     const JobRec j = jr[k];
     c = j.c < c ? j.c : c;
     m = j.m < m ? j.m : m;
+    odd = odd || !(j.c >= 0.0 && j.m >= 0.0 && j.c < 1e300 && j.m < 1e300);
   }
+  if (__any(odd) && lane_id() == 0) atomicOr(&jmin_bits[2], 1ull);
   // negative or NaN resources would break the ordering trick: such inputs switch the dead-offer shortcut off (minimum 0)
   if (!(c >= 0.0)) c = 0.0;
   if (!(m >= 0.0)) m = 0.0;
