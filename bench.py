@@ -56,7 +56,7 @@ def parse():
     return ap.parse_args()
 
 
-PLACEMENT_KERNELS = ("match_world", "match_resolve2", "match_eval2", "match_merge2", "match_persist", "match_serial")
+PLACEMENT_KERNELS = ("match_v3", "match_world", "match_resolve2", "match_eval2", "match_merge2", "match_persist", "match_serial")
 
 
 def algorithmic_bytes(kernel, n_tasks, k, m, launches_per_match=1.0, pools_per_launch=1.0):
@@ -282,6 +282,8 @@ def main():
             n_cycles = max(1, min(args.steps, 3))
             launches_per_match = agg[dom][1] / (n_cycles * max(1, len(my_pools)))
             n_chains = min(len(my_pools), cluster.max_chains) if len(my_pools) > cluster.max_chains else len(my_pools)
+            if dom == "match_v3":
+                n_chains = len(my_pools)  # one launch per pool
             pools_per_launch = len(my_pools) / max(1, n_chains)
             nbytes = algorithmic_bytes(dom, n_pend + n_run, min(K, n_pend), n_off, launches_per_match, pools_per_launch)
             achieved = (nbytes / (avg_ms * 1e-3) / 1e9) if (nbytes and avg_ms > 0) else None

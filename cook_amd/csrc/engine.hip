@@ -900,6 +900,7 @@ bool match_v3_run(cook_engine* e, const MatchIn& in, const MatchState& st, const
   COOK_HIP(hipMemcpyAsync(hc, h.vb.ctl, sizeof(V3Ctl), hipMemcpyDeviceToHost, e->stream));
   sync(e);
   e->last_v3 = *hc;
+  if (hc->error == 2u) e->fail(COOK_E_STATE, "match_v3: the walker waited for a prepared job for more than a second (internal error)");
   if (hc->error != 0u) {
     e->v3_refused += 1;
     return false;

@@ -101,7 +101,9 @@ struct V3Lds {
   unsigned gen_first;                 // first job of this generation (cutoff of the group chains)
   unsigned gen_stop, done;
   unsigned sort_n;
+  unsigned abort;                     // the walker waited for a prepared job longer than V3_WAIT_TICKS (a bug, never the input): give up loudly
 };
+constexpr unsigned long long V3_WAIT_TICKS = 150000000ull;  // 1.5 s of the 100 MHz clock
 static_assert(sizeof(V3Job) * V3_R <= sizeof(unsigned long long) * V3_MMAX, "the ring lives in the sort buffer");
 static __device__ __forceinline__ V3Job* v3_ring(V3Lds& L) { return reinterpret_cast<V3Job*>(L.skey); }
 
@@ -334,7 +336,7 @@ static __device__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState&
   for (int q = 0; q < V3_L; ++q) tf[q] = -1.0, ti[q] = -1;
   unsigned n_res = 0, n_feas = 0, n_zero = 0, steps = 0;
   bool more = false;  // blocks were left unvisited that may hold feasible offers
-  for (;;) {
+  for (unsigned guard = 0; guard < 4u * (unsigned)V3_NBMAX; ++guard) {
     // the next (up to) V3_BATCH blocks by bound
     unsigned bsel[V3_BATCH];
     int nsel = 0;
@@ -633,6 +635,14 @@ static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const
           continue;
         }
         if (ready & 1ull) break;
+        if (cook_ticks() - t0 > V3_WAIT_TICKS) {
+          if (lane == 0) {
+            st_wg(&L.abort, 1u);
+            st_wg(&L.done, 1u);
+            st_wg(&L.gen_stop, 1u);
+          }
+          return;
+        }
         EMU_SITE("v3 walker: waiting for a prepared job");
         SPIN_PAUSE_SHORT();
       }
@@ -962,6 +972,7 @@ __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3* __restric
     L.next = 0u;
     L.walk_pos = 0u;
     L.gen_first = 0u;
+    L.abort = 0u;
     L.sort_n = vb.job_flags[2] != 0ull ? 1u : 0u;  // (borrowed as the "bad input" flag until the first regeneration)
   }
   __syncthreads();
@@ -1009,6 +1020,10 @@ __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3* __restric
     }
     if (L.done != 0u) break;
     __syncthreads();
+  }
+  if (L.abort != 0u) {
+    if (tid == 0) vb.ctl->error = 2u;
+    return;
   }
   // ---- statistics ---------------------------------------------------------------------------------------------------------------------
   for (int d = 32; d >= 1; d >>= 1) {

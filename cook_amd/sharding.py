@@ -163,7 +163,10 @@ class ShardedCluster:
         multi = all(hasattr(self.engines[p], "cycle_run_rank") for p in self.pools)
         # match_algo 5: ONE persistent launch places all local pools, every pool advancing on its own (match_world.hpp)
         world = multi and all(getattr(getattr(self.engines[p], "params", None), "match_algo", 0) == 5 for p in self.pools)
-        lockstep = world or (multi and (len(self.pools) > self.max_chains or self.force_multi))
+        # match_algo 6 (match_v3): a pool's placement is ONE persistent workgroup on the pool's own stream — no launch chain to share
+        # dispatch pipes with, so every pool runs its whole cycle on its own thread and stream, all pools at once
+        solo = all(getattr(getattr(self.engines[p], "params", None), "match_algo", 0) == 6 for p in self.pools)
+        lockstep = not solo and (world or (multi and (len(self.pools) > self.max_chains or self.force_multi)))
 
         def run(p):
             self.engines[p].rank_set_quota(self.quota_inputs(p, usages[p], total))
@@ -189,7 +192,9 @@ class ShardedCluster:
             list(self._tp.map(chain, range(n_chains)))
             t2 = time.perf_counter()
         else:
-            list(self._tp_rank.map(run, self.pools))  # the rank stages are chains of small kernels too: at most max_chains at a time
+            # the rank stages are chains of small kernels too: at most max_chains at a time (all at once with match_v3: a pool's
+            # thread then spends most of its time waiting for the one placement kernel)
+            list((self._tp if solo else self._tp_rank).map(run, self.pools))
             t2 = time.perf_counter()
             if lockstep:
                 from .engine import cycle_match_multi

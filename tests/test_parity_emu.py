@@ -83,7 +83,7 @@ def test_rank_edge_cases(make_engine):
     P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=0))
 
 
-ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4, 5], ids=["default", "serial", "launches+reeval", "persistent", "world"])
+ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4, 5, 6], ids=["default", "serial", "launches+reeval", "persistent", "world", "v3"])
 
 
 @ALGOS
@@ -440,7 +440,7 @@ def test_fuzz_rank_cycle_match_explain(make_engine):
                   n_users=int(rng.integers(1, 30)), n_offers=int(rng.integers(1, 100)), gpus=bool(rng.integers(0, 2)),
                   constraints=bool(rng.integers(0, 2)), fractional=bool(rng.integers(0, 2)), tie_heavy=bool(rng.integers(0, 2)),
                   no_shares=bool(rng.integers(0, 4) == 0), quota_frac=float(rng.choice([0.0, 0.02, 0.5])))
-        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5, 0.3])), match_algo=int(rng.choice([0, 1, 3, 4, 5])),
+        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5, 0.3])), match_algo=int(rng.choice([0, 1, 3, 4, 5, 6, 6])),
                              max_over_quota_jobs=int(rng.choice([0, 3, 100])))
         pool = synth.make_pool(**kw)
         if rng.integers(0, 3) == 0:  # ports and named scalars on a third of the configurations (also through the cycle's job columns)
@@ -488,7 +488,7 @@ def test_fuzz_groups_constraints_metrics_replay(make_engine):
     rng = np.random.default_rng(20260925)
     for _ in range(10):
         seed = int(rng.integers(1, 1 << 30))
-        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5])), match_algo=int(rng.choice([0, 1, 3, 4, 5])))
+        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5])), match_algo=int(rng.choice([0, 1, 3, 4, 5, 6, 6])))
         n, m = int(rng.integers(5, 200)), int(rng.integers(3, 60))
         attr = np.zeros((m, 2), dtype=np.uint32)
         attr[:, 0] = rng.integers(1, 4, m)

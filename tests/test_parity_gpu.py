@@ -78,7 +78,7 @@ def test_rank_edge_cases(make_engine):
     P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=0))
 
 
-ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4, 5], ids=["default", "serial", "launches+reeval", "persistent", "world"])
+ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4, 5, 6], ids=["default", "serial", "launches+reeval", "persistent", "world", "v3"])
 
 
 @ALGOS
@@ -350,9 +350,9 @@ def test_explain_after_a_cycle(make_engine):
 
 
 # ---- BASELINE.json's configurations at FULL size: rank + placement of every pending job, bit-exact against the oracle -------
-def _full_cycle_parity(make_engine, pool, ge=1.0, threads=16, k=None, stats=None):
+def _full_cycle_parity(make_engine, pool, ge=1.0, threads=16, k=None, stats=None, algo=0):
     """rank of every task + placement of the first k ranked jobs (default: all pending) of one pool, bit-exact against the oracle"""
-    p = A.default_params(good_enough_fitness=ge)
+    p = A.default_params(good_enough_fitness=ge, match_algo=algo)
     with make_engine(p) as e:
         e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
         e.cycle_run(pool.n_pending if k is None else k)
@@ -414,6 +414,23 @@ def test_c4_one_pool_good_enough_08_full_size(make_engine):
 def test_c4_one_pool_k1000(make_engine, ge):
     """fenzo-max-jobs-considered 1000 (config.clj:113) on a full C4 pool: the cycle Cook runs on day one.  VERDICT r2 item 1b."""
     j2o = _full_cycle_parity(make_engine, _c4_pool(), ge=ge, k=1000)
+    assert len(j2o) == 1000 and (j2o >= 0).sum() > 500
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C4"])
+def test_full_size_v3(make_engine, cfg):
+    """match_algo 6 (match_v3.hpp: one persistent workgroup per pool, candidate lists from block bounds of the offers' fullness order) at
+    BASELINE.json's sizes: every pending job of configs[1] and of one pool of configs[3], bit-exact against the oracle, and the
+    kernel really placed the call (no hand-back to the window rounds)."""
+    pool = (synth.make_pool(seed=0xC00C0002, n_pending=50000, n_running=20000, n_users=1000, n_offers=5000) if cfg == "C2" else _c4_pool())
+    stats = {}
+    j2o = _full_cycle_parity(make_engine, pool, stats=stats, algo=6)
+    assert stats["persistent"] == 3 and stats["v3_refused"] == 0, stats
+    assert 5000 < (j2o >= 0).sum() < pool.n_pending
+
+
+def test_c4_one_pool_k1000_v3(make_engine):
+    j2o = _full_cycle_parity(make_engine, _c4_pool(), k=1000, algo=6)
     assert len(j2o) == 1000 and (j2o >= 0).sum() > 500
 
 
