@@ -890,6 +890,15 @@ bool match_v3_run(cook_engine* e, const MatchIn& in, const MatchState& st, const
   h.vb.ctl = e->v3_ctl.ensure(1);
   h.vb.group_snap = e->v3_group_snap.ensure(std::max(1u, in.G));
   h.vb.job_flags = e->m_jmin.ptr();
+  {
+    static const unsigned la = [] {  // jobs the helpers may run ahead of the walker (tuning runs: COOK_V3_LA)
+      const char* s = std::getenv("COOK_V3_LA");
+      const long v = s ? std::atol(s) : 0;
+      return (unsigned)(v >= 1 && v <= V3_R ? v : (V3_R < 32 ? V3_R : 32));
+    }();
+    h.vb.look_ahead = la;
+    h.vb.pad = 0;
+  }
   if (!e->h_v3) COOK_HIP(hipHostMalloc(&e->h_v3, sizeof(PoolCtx3) + sizeof(V3Ctl), hipHostMallocDefault));
   std::memcpy(e->h_v3, &h, sizeof(h));
   PoolCtx3* dctx = e->v3_ctx.ensure(1);
@@ -1931,6 +1940,7 @@ int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap) {
     v[18] = q.generations, v[19] = q.walked, v[20] = q.settled, v[21] = q.scan_steps, v[22] = q.opens;
     v[23] = (uint32_t)(q.t_total / 100ull), v[24] = (uint32_t)(q.t_regen / 100ull), v[25] = (uint32_t)(q.t_walk_wait / 100ull);
     v[26] = q.stop_full, v[27] = q.stop_list, v[28] = q.stop_log;
+    v[30] = q.fast, v[31] = q.visits;
   }
   v[29] = e->v3_refused;
   uint32_t n = 0;

@@ -4,50 +4,61 @@
 // What makes it cheap: cpuMemBinPacker (config.clj:108) is "fullness after the placement", and in exact arithmetic
 //     2 * fitness(j, o) = G(o) + c_j / D_c(o) + m_j / D_m(o),      G(o) = used_cpus / D_c + used_mem / D_m  (job-independent),
 // while "o has room for j" implies G(o) <= 2 - (c_j / D_c + m_j / D_m).  So the workgroup keeps, in LDS, ONE order of the live
-// offers — grouped by (D_c, D_m, gpu signature), fullest first inside a group — cut into blocks of 64 with a summary each (key
-// range, largest free cpus / mem, range of the denominators).  For a job, the summaries bound the best fitness any offer of a block
-// could reach and tell which blocks cannot hold an offer with room; a HELPER wave visits the few blocks that can matter in the
-// order of their bounds (lane = offer, every value exact fp64, operation for operation as the oracle computes it) and stops as soon
-// as the entries it holds beat the bound of everything unvisited.  Bounds only PRUNE: every decision is taken on exact values,
-// so the result is bit-identical to the one-job-at-a-time sweep for every input.
+// offers — grouped by (D_c, D_m, gpu signature), fullest first inside a group — with, per position, the sort key and the offer's free
+// cpus / mem (two bf16, rounded up), and per block of 64 positions a summary (key range, largest free cpus / mem, range of the
+// denominators).  For a job the summaries bound the best fitness any offer of a block could reach and tell which blocks cannot
+// hold an offer with room; a HELPER wave looks at the few blocks that can matter, best bounds first: the per-position free
+// resources (LDS) say which lanes are worth a look, only those read the offer's records (lane = offer, every value exact fp64,
+// operation for operation as the oracle computes it), and the wave stops as soon as the entries it holds beat the bound of
+// everything it has not looked at.  Bounds only PRUNE: every decision is taken on exact values, so the result is bit-identical to
+// the one-job-at-a-time sweep for every input.
 //
 // Wave 0 WALKS the jobs in rank order exactly as match_v2's resolve kernel does — lanes own the offers committed to since the
-// order was built ("touched", state in registers), the winner is max(best untouched offer of the job's list, best touched offer
-// re-evaluated under the current state) — but it is fed through an LDS ring by the helper waves of its own workgroup, which run
-// ahead of it against the same snapshot.  When the touched set is full (or a list ran out) the workgroup writes the touched state
-// back, rebuilds the order (a "generation") and goes on: a generation boundary costs a sort in LDS, not three kernel launches.
+// order was last updated ("touched", state in registers), the winner is max(best untouched offer of the job's list, best touched
+// offer re-evaluated under the current state) — but it is fed through an LDS ring by the helper waves of its own workgroup, which
+// run a bounded number of jobs ahead of it.  A helper leaves the offers that are touched when it looks OUT of the list (they are
+// the walker's business), so a list goes stale only through the few offers opened between its preparation and its use.  When a
+// list does run out, the ring is flushed and prepared again (an "epoch": two barriers, the walker keeps its lanes); when the
+// touched set is full the walker writes its lanes back and the order is UPDATED IN PLACE — the <= 64 moved offers are taken out
+// and merged back in at their new keys (a "generation": a few microseconds, not a sort, not three kernel launches).
 //
 // Scope (the host checks it and runs match_v2 otherwise): best fit (good-enough-fitness >= 1), no ports / named scalars, no
-// balanced / attribute-equals groups, one offer per host, at most V3_MMAX offers, no reserved hosts / multi-entry gpu maps.
+// balanced / attribute-equals groups, one offer per host, at most V3_MMAX offers.
 #pragma once
 #include "match_v2.hpp"
 
 #ifndef COOK_V3_THREADS
-#define COOK_V3_THREADS COOK_SHAPE(1024, 128)
+#define COOK_V3_THREADS COOK_SHAPE(768, 128)
 #endif
 constexpr int V3_THREADS = COOK_V3_THREADS;           // wave 0 walks, the others prepare jobs
 constexpr int V3_WAVES = V3_THREADS / COOK_WAVE;
-constexpr int V3_MMAX = 8192;                          // offers per pool (positions are 13 bits of the sort key, u16 in the order)
+constexpr int V3_MMAX = 8192;                          // offers per pool (the offer index is 13 bits of the sort key)
 constexpr int V3_NBMAX = V3_MMAX / COOK_WAVE;          // blocks of the order
 constexpr int V3_BPL = V3_NBMAX / COOK_WAVE;           // blocks per lane when a wave looks at every summary (2)
+constexpr int V3_PPT = (V3_MMAX + V3_THREADS - 1) / V3_THREADS;  // positions per thread when the whole order moves
 #ifndef COOK_V3_L
 #define COOK_V3_L 8
 #endif
-constexpr int V3_L = COOK_V3_L;                        // list entries per job
-constexpr int V3_R = COOK_SHAPE(128, 8);               // ring entries (the emulated tests: small, so that the ring wraps all the time)
+constexpr int V3_L = COOK_V3_L;                        // list entries per job (<= 16: the list lives in the first row of a wave)
+#ifndef COOK_V3_R
+#define COOK_V3_R COOK_SHAPE(64, 8)
+#endif
+constexpr int V3_R = COOK_V3_R;                        // ring entries (the emulated tests: small, so that the ring wraps all the time)
 constexpr int V3_T = COOK_WAVE;                        // touched offers per generation = lanes of the walking wave
-constexpr int V3_BATCH = 4;                            // blocks a helper visits per batch (their loads are in flight together)
-static_assert(V3_L <= COOK_WAVE && V3_BPL >= 1, "shapes");
+constexpr int V3_BATCH = 4;                            // blocks a helper looks at per step (their loads are in flight together)
+static_assert(V3_L <= 16 && V3_BPL == 2 && V3_R <= COOK_WAVE, "shapes");
 
-struct V3Ent {  // candidate-list entry: exact fitness under the generation's snapshot, offer
+struct V3Ent {  // candidate-list entry: exact fitness under the generation's snapshot, offer, its position in the order
   double fit;
   int off;
-  unsigned pad;
+  unsigned pos;
 };
-constexpr unsigned V3I_TRUNC = 1u << 8;     // feasible offers may exist beyond the list
+constexpr unsigned V3I_TRUNC = 1u << 8;     // feasible untouched offers may exist beyond the list
+constexpr unsigned V3I_NOFEAS = 1u << 9;    // no offer at all (touched ones included) was feasible under the snapshot
 constexpr unsigned V3I_GPU = 1u << 16, V3I_GROUPED = 1u << 17, V3I_HASGROUP = 1u << 20, V3I_FASTC = 1u << 21, V3I_SLOW = 1u << 22,
                    V3I_GFAST = 1u << 23;  // bits 18-19: group type; GFAST: the hosts to avoid are staged (gfh / n_fh / glast)
-struct V3Job {  // one prepared job (a ring entry)
+struct alignas(16) V3Job {  // one prepared job (a ring entry)
+  V3Ent ent[V3_L];
   double c, m, g;
   unsigned info;          // bits 0-7 entries, V3I_*
   unsigned k;             // match position
@@ -58,14 +69,13 @@ struct V3Job {  // one prepared job (a ring entry)
   unsigned req[MV_NA], wild[MV_NA], req_host, wild_host, novel[MV_NC], impossible;  // (V3I_FASTC) EvalCons
   unsigned gfh[MV_FH];    // (V3I_GFAST) hosts the job's cotasks occupied when the generation began
   int n_fh, glast;
-  V3Ent ent[V3_L];
 };
 
 struct V3BlockSum {  // summary of one block of 64 positions of the order (floats rounded towards the safe side)
-  float kmax, kmin;      // >= the greatest / smallest key G of the block
+  float kmax, kmin;      // >= the greatest / <= the smallest key G of the block
   float maxc, maxm;      // >= the greatest free cpus / mem under the snapshot
-  float min_dc, min_dm;  // <= the smallest denominators
-  float max_dc, max_dm;  // >= the greatest
+  float ri_dc, ri_dm;    // >= 1 / (smallest denominator)
+  float rx_dc, rx_dm;    // <= 1 / (greatest denominator)
 };
 
 struct V3Ctl {  // in global memory: results and statistics of one call
@@ -74,7 +84,9 @@ struct V3Ctl {  // in global memory: results and statistics of one call
   unsigned walked, settled, scan_steps, opens;
   unsigned long long t_total, t_regen, t_walk_wait;  // 100 MHz ticks
   unsigned error;  // != 0: the kernel refused the input before placing anything (the host runs match_v2)
-  unsigned pad;
+  unsigned epochs; // ring flushes + generations
+  unsigned fast, visits;  // jobs decided by the walker's fast path; blocks whose offers' records a helper read
+  unsigned long long t_flush;
 };
 
 struct V3Buf {
@@ -86,14 +98,22 @@ struct V3Buf {
   V3Ctl* ctl;
   int32_t* group_snap;          // [G] st.group_last as the generation began (the helpers' view; the walker publishes to the live array)
   const unsigned long long* job_flags;  // [0..1] jmin bits, [2] != 0: some job has a negative / non-finite request
+  unsigned look_ahead;          // jobs the helpers may run ahead of the walker (1 .. V3_R)
+  unsigned pad;
 };
 
 struct V3Lds {
-  unsigned long long skey[V3_MMAX];   // sort buffer; between regenerations its space holds the ring (see v3_ring)
-  unsigned short ord[V3_MMAX];        // position -> offer
-  float okey[V3_MMAX];                // position -> key (>= G of the offer under the snapshot)
+  unsigned long long skey[V3_MMAX];   // position -> sort key: class hash (19) | NOT key bits (32: fullest first) | offer (13)
+  unsigned fcm[V3_MMAX];              // position -> free cpus << 16 | free mem under the snapshot, two bf16 rounded UP
   unsigned char owner[V3_MMAX];       // offer -> lane of the walker that owns it in this generation, 0xFF none
   V3BlockSum bsum[V3_NBMAX];
+  unsigned long long tbits[V3_NBMAX];    // block -> positions touched in this generation
+  unsigned long long rembits[V3_NBMAX];  // (generation change) positions that leave / arrive
+  unsigned long long insbits[V3_NBMAX + 1];
+  unsigned rempre[V3_NBMAX], inspre[V3_NBMAX + 1];
+  unsigned long long ins_key[V3_T], ins_sorted[V3_T];
+  unsigned ins_fcm[V3_T], ins_fcm_sorted[V3_T];
+  V3Job ring[V3_R];
   unsigned rstate[V3_R];              // (position + 1) << 2 | 1 ready / 2 settled
   unsigned n_pos, n_blocks;           // live offers in the order
   unsigned next;                      // next job position a helper takes
@@ -101,11 +121,11 @@ struct V3Lds {
   unsigned gen_first;                 // first job of this generation (cutoff of the group chains)
   unsigned gen_stop, done;
   unsigned sort_n;
+  unsigned n_rem, n_ins;              // lanes the walker hands back / offers that return to the order
+  unsigned stop_reason;               // why the epoch ended: 1 list ran out, 2 touched set full, 3 group log full
   unsigned abort;                     // the walker waited for a prepared job longer than V3_WAIT_TICKS (a bug, never the input): give up loudly
 };
 constexpr unsigned long long V3_WAIT_TICKS = 150000000ull;  // 1.5 s of the 100 MHz clock
-static_assert(sizeof(V3Job) * V3_R <= sizeof(unsigned long long) * V3_MMAX, "the ring lives in the sort buffer");
-static __device__ __forceinline__ V3Job* v3_ring(V3Lds& L) { return reinterpret_cast<V3Job*>(L.skey); }
 
 // float >= d / <= d (the summaries must err on the safe side)
 static __device__ __forceinline__ float v3_f32_up(double d) {
@@ -118,6 +138,17 @@ static __device__ __forceinline__ float v3_f32_down(double d) {
   if ((double)f > d) f = __int_as_float(__float_as_int(f) + (f > 0.0f ? -1 : 1));
   return f;
 }
+// bf16 >= f for f >= 0 (anything else -> 0); an overflow becomes +inf, which is on the safe side
+static __device__ __forceinline__ unsigned v3_bf16_up(float f) {
+  if (!(f > 0.0f)) return 0u;
+  const unsigned b = (unsigned)__float_as_int(f);
+  return (b >> 16) + ((b & 0xFFFFu) ? 1u : 0u);
+}
+static __device__ __forceinline__ unsigned v3_pack_free(double fc, double fm) { return (v3_bf16_up(v3_f32_up(fc)) << 16) | v3_bf16_up(v3_f32_up(fm)); }
+static __device__ __forceinline__ float v3_free_c(unsigned w) { return __int_as_float((int)(w & 0xFFFF0000u)); }
+static __device__ __forceinline__ float v3_free_m(unsigned w) { return __int_as_float((int)(w << 16)); }
+static __device__ __forceinline__ float v3_key_f32(unsigned long long sk) { return __int_as_float((int)~(unsigned)((sk >> 13) & 0xFFFFFFFFull)); }
+
 static __device__ __forceinline__ unsigned v3_hash(unsigned long long a, unsigned long long b, unsigned c, unsigned long long d) {
   unsigned long long h = a * 0x9E3779B97F4A7C15ull;
   h ^= (b + 0x7F4A7C159E3779B9ull) * 0xC2B2AE3D27D4EB4Full;
@@ -129,12 +160,11 @@ static __device__ __forceinline__ unsigned v3_hash(unsigned long long a, unsigne
   return (unsigned)h;
 }
 // key of an offer in the order: group hash (19 bits) | NOT key bits (32: fullest first) | offer (13)
-static __device__ __forceinline__ unsigned long long v3_sort_key(const OfferA& a, const OfferB& b, double ac, double am, unsigned v, float* key_out) {
+static __device__ __forceinline__ unsigned long long v3_sort_key(const OfferA& a, const OfferB& b, double ac, double am, unsigned v) {
   const double dc = a.oc + a.rc, dm = a.om + a.rm;
   const double G = (a.rc + ac) / dc + (a.rm + am) / dm;
   float kf = v3_f32_up(G * (1.0 + 0x1p-40));
   if (!(kf >= 0.0f)) kf = 0.0f;
-  *key_out = kf;
   const unsigned h = v3_hash((unsigned long long)__double_as_longlong(dc), (unsigned long long)__double_as_longlong(dm),
                              b.gpu_model * 2u + (b.flags & 1u), (unsigned long long)__double_as_longlong(b.gpu_count)) & 0x7FFFFu;
   return ((unsigned long long)h << 45) | ((unsigned long long)(~(unsigned)__float_as_int(kf)) << 13) | (unsigned long long)v;
@@ -159,13 +189,48 @@ static __device__ void v3_sort(V3Lds& L, unsigned n2) {
   }
 }
 
-// ---- a generation: snapshot the state, (re)build the order and its block summaries -------------------------------------------------
-// The touched offers' state has been written back to st.ac / st.am / st.acount / st.alive before (by the walker).
-static __device__ void v3_regen(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb) {
+// ---- block summaries of the order (one wave per block, lane = position); ends with a barrier -------------------------------------------
+static __device__ void v3_summaries(V3Lds& L, const V3Buf& vb) {
+  const unsigned lane = lane_id(), NW = blockDim.x / COOK_WAVE;
+  const unsigned n = L.n_pos, nb = (n + COOK_WAVE - 1) / COOK_WAVE;
+  for (unsigned b = wave_id(); b < nb; b += NW) {
+    const unsigned p = b * COOK_WAVE + lane;
+    float key = 0.0f, fc = 0.0f, fm = 0.0f, idc = 0.0f, idm = 0.0f;
+    unsigned nkey = 0u, nidc = 0u, nidm = 0u;  // NOT bits of the values whose minimum is wanted (non-negative floats order like their bits)
+    if (p < n) {
+      const unsigned long long sk = L.skey[p];
+      const unsigned w = L.fcm[p];
+      const OfferA a = vb.oa[(unsigned)(sk & 0x1FFFull)];
+      key = v3_key_f32(sk);
+      fc = v3_free_c(w);
+      fm = v3_free_m(w);
+      const double rdc = 1.0 / (a.oc + a.rc), rdm = 1.0 / (a.om + a.rm);
+      idc = v3_f32_up(rdc * (1.0 + 0x1p-50));
+      idm = v3_f32_up(rdm * (1.0 + 0x1p-50));
+      nkey = ~(unsigned)__float_as_int(key);
+      nidc = ~(unsigned)__float_as_int(v3_f32_down(rdc * (1.0 - 0x1p-50)));
+      nidm = ~(unsigned)__float_as_int(v3_f32_down(rdm * (1.0 - 0x1p-50)));
+    }
+    const float kmax = wave_max_f32(key), maxc = wave_max_f32(fc), maxm = wave_max_f32(fm), ri_dc = wave_max_f32(idc), ri_dm = wave_max_f32(idm);
+    const unsigned xkey = wave_max_u32(nkey), xidc = wave_max_u32(nidc), xidm = wave_max_u32(nidm);
+    if (lane == 0) {
+      V3BlockSum s;
+      s.kmax = kmax, s.kmin = __int_as_float((int)~xkey), s.maxc = maxc, s.maxm = maxm;
+      s.ri_dc = ri_dc, s.ri_dm = ri_dm, s.rx_dc = __int_as_float((int)~xidc), s.rx_dm = __int_as_float((int)~xidm);
+      L.bsum[b] = s;
+    }
+  }
+  if (threadIdx.x == 0) L.n_blocks = nb;
+  __syncthreads();
+}
+
+// ---- the first generation: every live offer sorted into the order ------------------------------------------------------------------------
+static __device__ void v3_build(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb) {
   const unsigned tid = threadIdx.x, NT = blockDim.x, lane = lane_id();
   const unsigned M = in.M;
   if (tid == 0) L.sort_n = 0;
   for (unsigned v = tid; v < (unsigned)V3_MMAX; v += NT) L.owner[v] = 0xFF;
+  for (unsigned b = tid; b < (unsigned)V3_NBMAX; b += NT) L.tbits[b] = 0ull;
   __syncthreads();
   // live offers -> sort keys (dead ones cannot take the smallest job of the call: they never come back)
   for (unsigned v0 = 0; v0 < M; v0 += NT) {
@@ -174,10 +239,7 @@ static __device__ void v3_regen(V3Lds& L, const MatchIn& in, const MatchState& s
     unsigned long long sk = ~0ull;
     if (v < M) {
       live = ((st.alive[v >> 6] >> (v & 63u)) & 1ull) != 0ull;
-      if (live) {
-        float kf;
-        sk = v3_sort_key(vb.oa[v], vb.ob[v], st.ac[v], st.am[v], v, &kf);
-      }
+      if (live) sk = v3_sort_key(vb.oa[v], vb.ob[v], st.ac[v], st.am[v], v);
     }
     const unsigned long long bal = __ballot(live);
     unsigned base = 0;
@@ -193,54 +255,175 @@ static __device__ void v3_regen(V3Lds& L, const MatchIn& in, const MatchState& s
   __syncthreads();
   v3_sort(L, n2);
   for (unsigned p = tid; p < n; p += NT) {
-    const unsigned long long sk = L.skey[p];
-    L.ord[p] = (unsigned short)(sk & 0x1FFFull);
-    L.okey[p] = __int_as_float((int)~(unsigned)((sk >> 13) & 0xFFFFFFFFull));
+    const unsigned v = (unsigned)(L.skey[p] & 0x1FFFull);
+    const OfferA a = vb.oa[v];
+    L.fcm[p] = v3_pack_free(a.oc - st.ac[v], a.om - st.am[v]);
   }
-  if (tid == 0) {
-    L.n_pos = n;
-    L.n_blocks = (n + COOK_WAVE - 1) / COOK_WAVE;
+  if (tid == 0) L.n_pos = n;
+  __syncthreads();
+  v3_summaries(L, vb);
+}
+
+// ---- a later generation: the walker's lanes leave their old positions and come back at their new keys ---------------------------------
+// Before the call (wave 0, then a barrier): rembits = the positions of the touched offers, n_rem their number, ins_key / ins_fcm [lane]
+// = new key and free resources of the lane's offer, ~0 for a lane without an offer or with a dead one.
+static __device__ void v3_update(V3Lds& L, const V3Buf& vb) {
+  const unsigned tid = threadIdx.x, NT = blockDim.x, lane = lane_id(), w = wave_id();
+  const unsigned n = L.n_pos, nb = (n + COOK_WAVE - 1) / COOK_WAVE;
+  // wave 0: prefix counts of the leaving positions per block; wave 1 (or 0 again): the arriving keys sorted by rank counting
+  if (w == 0) {
+    unsigned c0 = lane < nb ? (unsigned)__popcll(L.rembits[lane]) : 0u, c1 = lane + 64u < nb ? (unsigned)__popcll(L.rembits[lane + 64u]) : 0u;
+    unsigned s0 = c0, s1 = c1;
+    for (int d = 1; d < COOK_WAVE; d <<= 1) {
+      const unsigned y0 = (unsigned)__shfl_up((int)s0, (unsigned)d, COOK_WAVE), y1 = (unsigned)__shfl_up((int)s1, (unsigned)d, COOK_WAVE);
+      if ((int)lane >= d) s0 += y0, s1 += y1;
+    }
+    const unsigned tot0 = (unsigned)__shfl((int)s0, 63, COOK_WAVE);
+    L.rempre[lane] = s0 - c0;
+    L.rempre[lane + 64u] = tot0 + s1 - c1;
+  }
+  if (w == (NT > (unsigned)COOK_WAVE ? 1u : 0u)) {
+    const unsigned long long key = L.ins_key[lane];
+    unsigned rank = 0;
+    for (unsigned j = 0; j < (unsigned)COOK_WAVE; ++j) {
+      const unsigned long long kj = L.ins_key[j];
+      rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u;
+    }
+    L.ins_sorted[rank] = key;
+    L.ins_fcm_sorted[rank] = L.ins_fcm[lane];
+    const unsigned long long live = __ballot(key != ~0ull);
+    if (lane == 0) L.n_ins = (unsigned)__popcll(live);
+  }
+  for (unsigned b = tid; b < (unsigned)V3_NBMAX + 1u; b += NT) L.insbits[b] = 0ull;
+  __syncthreads();
+  // pass 1: the order without the leaving positions
+  unsigned long long rk[V3_PPT];
+  unsigned rf[V3_PPT], rp[V3_PPT];
+#pragma unroll
+  for (int i = 0; i < V3_PPT; ++i) {
+    const unsigned p = tid + (unsigned)i * NT;
+    rp[i] = 0xFFFFFFFFu;
+    if (p < n) {
+      const unsigned b = p >> 6;
+      const unsigned long long bits = L.rembits[b];
+      if (!((bits >> (p & 63u)) & 1ull)) {
+        rk[i] = L.skey[p];
+        rf[i] = L.fcm[p];
+        rp[i] = p - (L.rempre[b] + (unsigned)__popcll(bits & ((1ull << (p & 63u)) - 1ull)));
+      }
+    }
   }
   __syncthreads();
-  // block summaries: one wave per block, lane = position
-  const unsigned nb = (n + COOK_WAVE - 1) / COOK_WAVE;
-  for (unsigned b = wave_id(); b < nb; b += NT / COOK_WAVE) {
-    const unsigned p = b * COOK_WAVE + lane;
-    float kmax = 0.0f, kmin = 3.0e38f, maxc = 0.0f, maxm = 0.0f, ndc = 3.0e38f, ndm = 3.0e38f, xdc = 0.0f, xdm = 0.0f;
-    if (p < n) {
-      const unsigned v = L.ord[p];
-      const OfferA a = vb.oa[v];
-      const double ac = st.ac[v], am = st.am[v];
-      kmax = kmin = L.okey[p];
-      maxc = v3_f32_up(a.oc - ac);
-      maxm = v3_f32_up(a.om - am);
-      ndc = v3_f32_down(a.oc + a.rc);
-      ndm = v3_f32_down(a.om + a.rm);
-      xdc = v3_f32_up(a.oc + a.rc);
-      xdm = v3_f32_up(a.om + a.rm);
+#pragma unroll
+  for (int i = 0; i < V3_PPT; ++i)
+    if (rp[i] != 0xFFFFFFFFu) {
+      L.skey[rp[i]] = rk[i];
+      L.fcm[rp[i]] = rf[i];
     }
-    for (int d = 32; d >= 1; d >>= 1) {
-      kmax = fmaxf(kmax, __shfl_xor(kmax, d, COOK_WAVE));
-      kmin = fminf(kmin, __shfl_xor(kmin, d, COOK_WAVE));
-      maxc = fmaxf(maxc, __shfl_xor(maxc, d, COOK_WAVE));
-      maxm = fmaxf(maxm, __shfl_xor(maxm, d, COOK_WAVE));
-      ndc = fminf(ndc, __shfl_xor(ndc, d, COOK_WAVE));
-      ndm = fminf(ndm, __shfl_xor(ndm, d, COOK_WAVE));
-      xdc = fmaxf(xdc, __shfl_xor(xdc, d, COOK_WAVE));
-      xdm = fmaxf(xdm, __shfl_xor(xdm, d, COOK_WAVE));
+  __syncthreads();
+  const unsigned n1 = n - L.n_rem, n_ins = L.n_ins;
+  // where the arriving keys go: destination = rank + number of staying keys below
+  if (tid < n_ins) {
+    const unsigned long long key = L.ins_sorted[tid];
+    unsigned lo = 0, hi = n1;
+    while (lo < hi) {
+      const unsigned mid = (lo + hi) >> 1;
+      if (L.skey[mid] < key)
+        lo = mid + 1;
+      else
+        hi = mid;
     }
-    if (lane == 0) {
-      V3BlockSum s;
-      s.kmax = kmax, s.kmin = kmin, s.maxc = maxc, s.maxm = maxm, s.min_dc = ndc, s.min_dm = ndm, s.max_dc = xdc, s.max_dm = xdm;
-      L.bsum[b] = s;
+    const unsigned d = lo + tid;
+    atomicOr(&L.insbits[d >> 6], 1ull << (d & 63u));
+  }
+  __syncthreads();
+  const unsigned n2 = n1 + n_ins, nb2 = (n2 + COOK_WAVE - 1) / COOK_WAVE;
+  if (w == 0) {
+    unsigned c0 = lane < nb2 ? (unsigned)__popcll(L.insbits[lane]) : 0u, c1 = lane + 64u < nb2 ? (unsigned)__popcll(L.insbits[lane + 64u]) : 0u;
+    unsigned s0 = c0, s1 = c1;
+    for (int d = 1; d < COOK_WAVE; d <<= 1) {
+      const unsigned y0 = (unsigned)__shfl_up((int)s0, (unsigned)d, COOK_WAVE), y1 = (unsigned)__shfl_up((int)s1, (unsigned)d, COOK_WAVE);
+      if ((int)lane >= d) s0 += y0, s1 += y1;
+    }
+    const unsigned tot0 = (unsigned)__shfl((int)s0, 63, COOK_WAVE);
+    L.inspre[lane] = s0 - c0;
+    L.inspre[lane + 64u] = tot0 + s1 - c1;
+  }
+  __syncthreads();
+  // pass 2: every destination takes an arriving key or the staying key that many places down
+#pragma unroll
+  for (int i = 0; i < V3_PPT; ++i) {
+    const unsigned d = tid + (unsigned)i * NT;
+    rp[i] = 0xFFFFFFFFu;
+    if (d < n2) {
+      const unsigned b = d >> 6;
+      const unsigned long long bits = L.insbits[b];
+      const unsigned before = L.inspre[b] + (unsigned)__popcll(bits & ((1ull << (d & 63u)) - 1ull));
+      if ((bits >> (d & 63u)) & 1ull) {
+        rk[i] = L.ins_sorted[before];
+        rf[i] = L.ins_fcm_sorted[before];
+      } else {
+        rk[i] = L.skey[d - before];
+        rf[i] = L.fcm[d - before];
+      }
+      rp[i] = d;
     }
   }
-  __syncthreads();  // (the sort buffer is free from here on: the ring may be written)
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < V3_PPT; ++i)
+    if (rp[i] != 0xFFFFFFFFu) {
+      L.skey[rp[i]] = rk[i];
+      L.fcm[rp[i]] = rf[i];
+    }
+  for (unsigned b = tid; b < (unsigned)V3_NBMAX; b += NT) {
+    L.tbits[b] = 0ull;
+    L.rembits[b] = 0ull;
+  }
+  if (tid == 0) L.n_pos = n2;
+  __syncthreads();
+  v3_summaries(L, vb);
 }
 
 // ---- a helper wave prepares job k: candidate list + failure counts under the generation's snapshot ----------------------------------
-// Returns false when the generation was stopped while the wave was waiting for a ring slot (nothing was published).
-static __device__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned k, V3Job& J, unsigned* steps_out) {
+// The list lives in lanes 0 .. V3_L - 1 of the wave (one entry each, best first) while it is built.
+struct V3List {
+  double fit;
+  int off;
+  unsigned pos;
+};
+// (cf, ci, cp) wave-uniform.  -> true when the list changed or the candidate was dropped for good (either way it is dealt with)
+static __device__ __forceinline__ void v3_list_insert(V3List& e, unsigned& n_list, bool& more, double cf, int ci, unsigned cp) {
+  const unsigned lane = lane_id();
+  const bool better = lane < n_list && (e.fit > cf || (e.fit == cf && e.off < ci));
+  const unsigned pos = (unsigned)__popcll(__ballot(better));
+  if (pos >= (unsigned)V3_L) {  // (wave-uniform) beyond a full list
+    more = true;
+    return;
+  }
+  const long long fb = __double_as_longlong(e.fit);
+  const unsigned s_lo = (unsigned)scan_fetch_u32<0>((int)(unsigned)(unsigned long long)fb);
+  const unsigned s_hi = (unsigned)scan_fetch_u32<0>((int)(unsigned)((unsigned long long)fb >> 32));
+  const int s_off = scan_fetch_u32<0>(e.off);
+  const unsigned s_pos = (unsigned)scan_fetch_u32<0>((int)e.pos);
+  if (lane > pos && lane < (unsigned)V3_L) {
+    e.fit = __longlong_as_double((long long)(((unsigned long long)s_hi << 32) | (unsigned long long)s_lo));
+    e.off = s_off;
+    e.pos = s_pos;
+  }
+  if (lane == pos) {
+    e.fit = cf;
+    e.off = ci;
+    e.pos = cp;
+  }
+  if (n_list == (unsigned)V3_L)
+    more = true;  // the last entry fell off
+  else
+    ++n_list;
+}
+
+static __device__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned k, V3Job& J, unsigned* steps_out,
+                                  unsigned* visits_out) {
   const unsigned lane = lane_id();
   const JobRec j = vb.jr[k];
   const unsigned jj = in.j_index ? in.j_index[k] : k;
@@ -306,83 +489,104 @@ static __device__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState&
   MatchState st_cut = st;  // the general group check under the snapshot: the chains as the generation began
   st_cut.cutoff = cutoff;
   st_cut.group_last = vb.group_snap;
-  // ---- which blocks can matter, and how good an offer of each could be -----------------------------------------------------------
-  const unsigned nb = L.n_blocks;
-  double ub[V3_BPL];
+  // ---- which blocks can matter, and how good an offer of each could be (floats, every rounding towards "may matter") ------------------
+  const unsigned nb = L.n_blocks, n_pos = L.n_pos;
+  const float c_up = v3_f32_up(j.c), m_up = v3_f32_up(j.m), c_dn = v3_f32_down(j.c), m_dn = v3_f32_down(j.m);
+  float ub[V3_BPL];
 #pragma unroll
   for (int q = 0; q < V3_BPL; ++q) {
     const unsigned b = (unsigned)q * COOK_WAVE + lane;
-    ub[q] = -1.0;
+    ub[q] = 0.0f;
     if (b < nb) {
       const V3BlockSum s = L.bsum[b];
-      const double need_lo = (j.c / (double)s.max_dc + j.m / (double)s.max_dm) * (1.0 - 0x1p-30);
-      const double need_hi = (j.c / (double)s.min_dc + j.m / (double)s.min_dm) * (1.0 + 0x1p-30);
-      const double thr = 2.0 - need_lo;
+      const float need_hi = (c_up * s.ri_dc + m_up * s.ri_dm) * (1.0f + 0x1p-20f);
+      const float need_lo = (c_dn * s.rx_dc + m_dn * s.rx_dm) * (1.0f - 0x1p-20f);
       // an offer with room has G <= 2 - need (used = D - free): a block whose smallest key exceeds that holds none
-      const bool room = (double)s.maxc >= j.c && (double)s.maxm >= j.m && (double)s.kmin * (1.0 - 0x1p-21) <= thr;
+      const float thr = (2.0f - need_lo) * (1.0f + 0x1p-20f);
+      const bool room = s.maxc >= c_dn && s.maxm >= m_dn && s.kmin <= thr;
       if (room) {
-        double u = ((double)s.kmax + need_hi) * 0.5;
-        if (u > 1.0) u = 1.0;  // (room implies fitness <= 1)
-        ub[q] = u * (1.0 + 0x1p-30) + 0x1p-60;
+        float u = (fminf(s.kmax, thr) + need_hi) * 0.5f * (1.0f + 0x1p-20f) + 0x1p-100f;
+        if (!(u < 1.0f)) u = 1.0f;  // (room implies fitness <= 1; also catches a NaN)
+        ub[q] = u;                  // > 0
       }
     }
   }
-  // ---- visit the blocks in the order of their bounds -----------------------------------------------------------------------------
-  double lf[V3_BATCH];  // this lane's candidates of the current batch
-  int lv[V3_BATCH];
-  double tf[V3_L];      // the job's list so far (wave-uniform)
-  int ti[V3_L];
-#pragma unroll
-  for (int q = 0; q < V3_L; ++q) tf[q] = -1.0, ti[q] = -1;
-  unsigned n_res = 0, n_feas = 0, n_zero = 0, steps = 0;
-  bool more = false;  // blocks were left unvisited that may hold feasible offers
-  for (unsigned guard = 0; guard < 4u * (unsigned)V3_NBMAX; ++guard) {
-    // the next (up to) V3_BATCH blocks by bound
+  // ---- look at the blocks, best bounds first ------------------------------------------------------------------------------------------------
+  V3List e;
+  e.fit = -1.0, e.off = -1, e.pos = 0u;
+  unsigned n_list = 0;
+  bool more = false;  // feasible untouched offers exist (or may exist) beyond the list
+  unsigned n_res = 0, n_feas = 0, n_zero = 0, steps = 0, visits = 0;
+  for (unsigned guard = 0; guard < 2u * (unsigned)V3_NBMAX; ++guard) {
+    const float mx = wave_max_f32(fmaxf(ub[0], ub[1]));
+    if (!(mx > 0.0f)) break;  // every block that could matter has been looked at
+    double tail = -1.0;
+    if (n_list == (unsigned)V3_L) {
+      tail = wave_read_lane_f64(e.fit, V3_L - 1);
+      if ((double)mx < tail) {  // nothing left can enter the list (an equal bound could, through a lower offer index)
+        more = true;
+        break;
+      }
+    }
+    // the blocks whose bound is close to the best one, at most V3_BATCH of them
+    const float cut = mx * (1.0f - 0x1p-6f);
+    unsigned long long s0 = __ballot(ub[0] >= cut && ub[0] > 0.0f && (double)ub[0] >= tail), s1 = __ballot(ub[1] >= cut && ub[1] > 0.0f && (double)ub[1] >= tail);
     unsigned bsel[V3_BATCH];
     int nsel = 0;
-    double next_ub = -1.0;
 #pragma unroll
-    for (int s = 0; s < V3_BATCH + 1; ++s) {
-      double best = -1.0;
-      int bq = -1;
-#pragma unroll
-      for (int q = 0; q < V3_BPL; ++q)
-        if (ub[q] > best) best = ub[q], bq = q;
-      const unsigned long long key = best > 0.0 ? (((unsigned long long)__double_as_longlong(best)) & ~0xFFull) | (unsigned long long)(255u - (unsigned)(bq * COOK_WAVE + (int)lane)) : 0ull;
-      const unsigned long long mk = wave_max_u64(key);
-      if (mk == 0ull) break;  // wave-uniform
-      const unsigned b = 255u - (unsigned)(mk & 0xFFull);
-      const double bu = __longlong_as_double((long long)(mk & ~0xFFull)) ;
-      if (s == V3_BATCH) {  // the best of what stays behind: only its bound is needed
-        next_ub = bu + 0x1p-40;
-        break;
-      }
-      // enough entries that all beat this block's bound: nothing left can enter the list
-      if (ti[V3_L - 1] >= 0 && tf[V3_L - 1] > bu + 0x1p-40) {
-        next_ub = bu + 0x1p-40;
-        break;
-      }
-      bsel[nsel++] = b;
-      if ((b & 63u) == lane) {
-#pragma unroll
-        for (int q = 0; q < V3_BPL; ++q)
-          if ((unsigned)q == (b >> 6)) ub[q] = -1.0;
+    for (int s = 0; s < V3_BATCH; ++s) {
+      bsel[s] = 0u;
+      if (s0 != 0ull) {
+        bsel[s] = (unsigned)__ffsll((unsigned long long)s0) - 1u;
+        s0 &= s0 - 1ull;
+        nsel = s + 1;
+      } else if (s1 != 0ull) {
+        bsel[s] = 64u + (unsigned)__ffsll((unsigned long long)s1) - 1u;
+        s1 &= s1 - 1ull;
+        nsel = s + 1;
       }
     }
-    if (nsel == 0) {
-      more = next_ub > 0.0;
-      break;
+#pragma unroll
+    for (int s = 0; s < V3_BATCH; ++s)
+      if (s < nsel && (bsel[s] & 63u) == lane) {
+        if (bsel[s] < 64u)
+          ub[0] = 0.0f;
+        else
+          ub[1] = 0.0f;
+      }
+    // which lanes are worth a look: free resources of the position (rounded up) cover the request
+    unsigned long long rmask[V3_BATCH];
+    bool touched[V3_BATCH];
+    unsigned lv_[V3_BATCH];
+#pragma unroll
+    for (int s = 0; s < V3_BATCH; ++s) {
+      rmask[s] = 0ull;
+      touched[s] = false;
+      lv_[s] = 0u;
+      if (s < nsel) {
+        const unsigned p = bsel[s] * COOK_WAVE + lane;
+        bool room = false;
+        if (p < n_pos) {
+          const unsigned w = L.fcm[p];
+          room = v3_free_c(w) >= c_dn && v3_free_m(w) >= m_dn;
+          lv_[s] = (unsigned)(L.skey[p] & 0x1FFFull);
+          touched[s] = ((ld_wg(&L.tbits[bsel[s]]) >> lane) & 1ull) != 0ull;
+        }
+        rmask[s] = __ballot(room);
+        ++steps;
+      }
     }
-    // evaluate the selected blocks: lane = offer, exact values
+    // evaluate them: lane = offer, exact values
+    double lf[V3_BATCH];
+    int lv[V3_BATCH];
 #pragma unroll
     for (int s = 0; s < V3_BATCH; ++s) {
       lf[s] = -1.0;
       lv[s] = -1;
-      if (s < nsel) {
-        const unsigned p = bsel[s] * COOK_WAVE + lane;
+      if (s < nsel && rmask[s] != 0ull) {  // (wave-uniform)
         bool res = false, feas = false, zero = false;
-        if (p < L.n_pos) {
-          const unsigned v = L.ord[p];
+        if ((rmask[s] >> lane) & 1ull) {
+          const unsigned v = lv_[s];
           const OfferA a = vb.oa[v];
           const double ac = st.ac[v], am = st.am[v];
           res = !(ac + j.c > a.oc || am + j.m > a.om);
@@ -414,8 +618,10 @@ static __device__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState&
               const double fit = fitness_of(a, ac, am, j.c, j.m);
               if (fit > 0.0) {
                 feas = true;
-                lf[s] = fit;
-                lv[s] = (int)v;
+                if (!touched[s]) {  // a touched offer is the walker's business: it stays out of the list
+                  lf[s] = fit;
+                  lv[s] = (int)v;
+                }
               } else {
                 zero = true;
               }
@@ -425,95 +631,55 @@ static __device__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState&
         n_res += (unsigned)__popcll(__ballot(res));
         n_feas += (unsigned)__popcll(__ballot(feas));
         n_zero += (unsigned)__popcll(__ballot(zero));
-        ++steps;
+        ++visits;
       }
     }
-    // merge the batch into the list: repeatedly the best candidate over lanes and batch slots (fitness desc, offer asc)
-    for (int r = 0; r < V3_L; ++r) {
-      double best = -1.0;
-      int bv = -1, bs = -1;
+    // merge the candidates into the list: whoever can still enter it, lowest lane first (within a block that is fullest first)
 #pragma unroll
-      for (int s = 0; s < V3_BATCH; ++s)
-        if (lv[s] >= 0 && (lf[s] > best || (lf[s] == best && lv[s] < bv))) best = lf[s], bv = lv[s], bs = s;
-      const unsigned long long key = bv >= 0 ? (unsigned long long)__double_as_longlong(best) : 0ull;
-      const unsigned long long mk = wave_max_u64(key);
-      if (mk == 0ull) break;  // no candidate left
-      const double mf = __longlong_as_double((long long)mk);
-      if (!(ti[V3_L - 1] < 0 || mf > tf[V3_L - 1])) {
-        // cannot enter a full list (an equal fitness with a lower offer index could: compare indices)
-        if (!(mf == tf[V3_L - 1])) break;
-      }
-      const unsigned long long tie = __ballot(key == mk);
-      int widx;
-      if ((tie & (tie - 1ull)) == 0ull)
-        widx = wave_read_lane(bv, __ffsll((unsigned long long)tie) - 1);
-      else
-        widx = (int)(0x7FFFFFFFu - wave_max_u32(key == mk ? 0x7FFFFFFFu - (unsigned)bv : 0u));
-      if (key == mk && bv == widx) {  // the owner drops it
-#pragma unroll
-        for (int s = 0; s < V3_BATCH; ++s)
-          if (s == bs) lv[s] = -1;
-      }
-      // insert (mf, widx) into the uniform list if it beats the last entry
-      const bool enters = ti[V3_L - 1] < 0 || mf > tf[V3_L - 1] || (mf == tf[V3_L - 1] && widx < ti[V3_L - 1]);
-      if (!enters) break;
-      tf[V3_L - 1] = mf;
-      ti[V3_L - 1] = widx;
-#pragma unroll
-      for (int q = V3_L - 1; q > 0; --q) {
-        const bool sw = ti[q - 1] < 0 || tf[q] > tf[q - 1] || (tf[q] == tf[q - 1] && ti[q] < ti[q - 1]);
-        if (sw) {
-          const double a = tf[q];
-          tf[q] = tf[q - 1];
-          tf[q - 1] = a;
-          const int x = ti[q];
-          ti[q] = ti[q - 1];
-          ti[q - 1] = x;
+    for (int s = 0; s < V3_BATCH; ++s) {
+      if (s < nsel && rmask[s] != 0ull) {
+        for (;;) {
+          double t_fit = -1.0;
+          int t_off = -1;
+          if (n_list == (unsigned)V3_L) {
+            t_fit = wave_read_lane_f64(e.fit, V3_L - 1);
+            t_off = wave_read_lane(e.off, V3_L - 1);
+          }
+          const bool cand = lv[s] >= 0;
+          const bool enters = cand && (n_list < (unsigned)V3_L || lf[s] > t_fit || (lf[s] == t_fit && lv[s] < t_off));
+          const unsigned long long em = __ballot(enters);
+          if (em == 0ull) {
+            if (__any(cand)) more = true;  // feasible untouched offers that did not make the list
+            break;
+          }
+          const int src = __ffsll((unsigned long long)em) - 1;
+          const double cf = wave_read_lane_f64(lf[s], src);
+          const int ci = wave_read_lane(lv[s], src);
+          if ((int)lane == src) lv[s] = -1;
+          v3_list_insert(e, n_list, more, cf, ci, bsel[s] * COOK_WAVE + (unsigned)src);
         }
       }
     }
-    // candidates of this batch that did not make the list are feasible offers beyond it
-    {
-      bool left = false;
-#pragma unroll
-      for (int s = 0; s < V3_BATCH; ++s) left = left | (lv[s] >= 0);
-      if (__any(left)) more = true;
-    }
-    if (next_ub <= 0.0) {  // nothing was left behind by the selection
-      bool any = false;
-#pragma unroll
-      for (int q = 0; q < V3_BPL; ++q) any = any | (ub[q] > 0.0);
-      if (!__any(any)) break;
-    }
-    // stop once the list is full and its last entry beats every unvisited block's bound
-    if (ti[V3_L - 1] >= 0) {
-      double rest = -1.0;
-#pragma unroll
-      for (int q = 0; q < V3_BPL; ++q) rest = ub[q] > rest ? ub[q] : rest;
-      const unsigned long long rk = wave_max_u64(rest > 0.0 ? (unsigned long long)__double_as_longlong(rest) : 0ull);
-      if (rk == 0ull) break;
-      if (tf[V3_L - 1] > __longlong_as_double((long long)rk)) {
-        more = true;
-        break;
-      }
-    }
   }
-  // a list that is not full holds EVERY feasible offer only if no block that might hold one was skipped: the loop above only
-  // skips blocks once the list is full, so a short list is complete
-  int n_out = 0;
-#pragma unroll
-  for (int q = 0; q < V3_L; ++q) n_out += ti[q] >= 0 ? 1 : 0;
-  const bool trunc = n_out == V3_L && more;
+  // a list that is not full holds EVERY feasible untouched offer: the loop above only leaves blocks out once the list is full
+  const bool trunc = n_list == (unsigned)V3_L && more;
   const unsigned M = in.M;
-  const unsigned c1 = M - n_res, c2 = n_res - n_feas - n_zero, c4 = n_zero;  // exact when the scan visited every block with room (n_out < V3_L)
+  const unsigned c1 = M - n_res, c2 = n_res - n_feas - n_zero, c4 = n_zero;  // exact when every block with room was looked at (!trunc)
+  if (lane < (unsigned)V3_L) {
+    V3Ent x;
+    x.fit = lane < n_list ? e.fit : -1.0;
+    x.off = lane < n_list ? e.off : -1;
+    x.pos = e.pos;
+    J.ent[lane] = x;
+  }
   if (lane == 0) {
     J.c = j.c, J.m = j.m, J.g = j.g;
     J.k = k, J.jj = jj;
     J.gpu_model = j.gpu_model;
     J.reserved_host = j.reserved_host;
     J.group = j.group;
-    J.info = (unsigned)n_out | (trunc ? V3I_TRUNC : 0u) | (j.g > 0 ? V3I_GPU : 0u) | (grouped ? V3I_GROUPED : 0u) | (gtype << 18) |
-             (j.group != 0xFFFFFFFFu ? V3I_HASGROUP : 0u) | (fastc ? V3I_FASTC : 0u) | (slow ? V3I_SLOW : 0u) |
+    J.info = n_list | (trunc ? V3I_TRUNC : 0u) | ((!trunc && n_feas == 0u) ? V3I_NOFEAS : 0u) | (j.g > 0 ? V3I_GPU : 0u) | (grouped ? V3I_GROUPED : 0u) |
+             (gtype << 18) | (j.group != 0xFFFFFFFFu ? V3I_HASGROUP : 0u) | (fastc ? V3I_FASTC : 0u) | (slow ? V3I_SLOW : 0u) |
              ((j.group != 0xFFFFFFFFu && gtype <= 1u && (gtype == 0u || n_fh >= 0)) ? V3I_GFAST : 0u);
     J.f1 = (unsigned short)(c1 < 0xFFFFu ? c1 : 0xFFFFu);
     J.f2 = (unsigned short)(c2 < 0xFFFFu ? c2 : 0xFFFFu);
@@ -528,35 +694,32 @@ static __device__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState&
 #pragma unroll
     for (int q = 0; q < MV_FH; ++q) J.gfh[q] = fh[q];
     J.n_fh = n_fh, J.glast = glast;
-#pragma unroll
-    for (int q = 0; q < V3_L; ++q) {
-      V3Ent e;
-      e.fit = tf[q], e.off = ti[q], e.pad = 0;
-      J.ent[q] = e;
-    }
   }
   *steps_out = steps;
+  *visits_out = visits;
 }
 
-// ---- the helper waves of a generation: take job positions, prepare them, publish them through the ring ---------------------------
-static __device__ void v3_helper(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned* n_steps, unsigned* n_settled) {
+// ---- the helper waves of an epoch: take job positions, prepare them, publish them through the ring --------------------------------
+static __device__ void v3_helper(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned* n_steps, unsigned* n_visits,
+                                 unsigned* n_settled) {
   const unsigned lane = lane_id();
   const unsigned K = in.K;
+  const unsigned la = vb.look_ahead < 1u ? 1u : (vb.look_ahead > (unsigned)V3_R ? (unsigned)V3_R : vb.look_ahead);
   for (;;) {
     if (ld_wg(&L.gen_stop) != 0u) return;
     unsigned p = 0;
     if (lane == 0) p = atomicAdd(&L.next, 1u);
     p = (unsigned)__shfl((int)p, 0, COOK_WAVE);
-    if (p >= K) {  // nothing left to prepare: wait for the end of the generation
+    if (p >= K) {  // nothing left to prepare: wait for the end of the epoch
       while (ld_wg(&L.gen_stop) == 0u) {
         EMU_SITE("v3 helper: idle");
         SPIN_PAUSE();
       }
       return;
     }
-    // a free ring slot: the walker is at most V3_R - 1 jobs behind
+    // not too far ahead of the walker (and a free ring slot)
     bool stopped = false;
-    while (p - ld_wg(&L.walk_pos) >= (unsigned)V3_R) {
+    while (p - ld_wg(&L.walk_pos) >= la) {
       if (ld_wg(&L.gen_stop) != 0u) {
         stopped = true;
         break;
@@ -565,11 +728,12 @@ static __device__ void v3_helper(V3Lds& L, const MatchIn& in, const MatchState& 
       SPIN_PAUSE();
     }
     if (stopped) return;
-    V3Job& J = v3_ring(L)[p % (unsigned)V3_R];
-    unsigned steps = 0;
-    v3_prepare(L, in, st, vb, p, J, &steps);
+    V3Job& J = L.ring[p % (unsigned)V3_R];
+    unsigned steps = 0, visits = 0;
+    v3_prepare(L, in, st, vb, p, J, &steps, &visits);
     wave_sync();
     *n_steps += steps;
+    *n_visits += visits;
     // settled here, for good: no feasible offer under the snapshot (placements only take capacity away; unique groups only take hosts
     // away), every failure class backed by more offers than a generation can touch
     unsigned info = 0, c1 = 0, c2 = 0, c4 = 0;
@@ -581,7 +745,7 @@ static __device__ void v3_helper(V3Lds& L, const MatchIn& in, const MatchState& 
     c1 = (unsigned)__shfl((int)c1, 0, COOK_WAVE);
     c2 = (unsigned)__shfl((int)c2, 0, COOK_WAVE);
     c4 = (unsigned)__shfl((int)c4, 0, COOK_WAVE);
-    const bool trivial = (info & 0xFFu) == 0u && c1 > 0u && (c2 == 0u || c2 > (unsigned)V3_T) && c4 == 0u;
+    const bool trivial = (info & V3I_NOFEAS) != 0u && c1 > 0u && (c2 == 0u || c2 > (unsigned)V3_T) && c4 == 0u;
     if (trivial) {
       if (lane == 0 && st.fail_code) st.fail_code[p] = 1u | (c2 ? 2u : 0u) | (c4 ? 4u : 0u);
       *n_settled += 1u;
@@ -591,36 +755,73 @@ static __device__ void v3_helper(V3Lds& L, const MatchIn& in, const MatchState& 
   }
 }
 
-// ---- the walker: one generation ------------------------------------------------------------------------------------------------------
-struct V3WalkStats {
-  unsigned matched, head_matched, walked, opens, stop;  // stop: 1 list ran out, 2 touched set full, 3 group log full, 0 all jobs done
+// ---- the walker ------------------------------------------------------------------------------------------------------------------------------
+struct V3Walker {  // the walking wave's registers: they live across epochs, a generation change writes them back
+  int t_v;         // the touched offer of this lane, -1 none
+  unsigned t_pos;  // its position in the order
+  double t_oc, t_om, t_rc, t_rm, t_invc, t_invm;
+  double t_ac, t_am, t_basec, t_basem, t_ac0, t_am0;
+  int t_acount, t_acount0;
+  OfferB t_o;
+  unsigned t_attr[MV_NA];
+  unsigned lg_group, lg_host, n_log;  // group members placed in this generation (one per lane, in placement order)
+  int lg_k;
+  unsigned nT;
+  unsigned matched, head_matched, walked, opens, fast;
   unsigned long long wait_ticks;
 };
-static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const V3Buf& vb, V3WalkStats& ws) {
+static __device__ __forceinline__ void v3_walker_reset(V3Walker& W) {
+  W.t_v = -1;
+  W.t_pos = 0u;
+  W.t_oc = W.t_om = W.t_rc = W.t_rm = W.t_invc = W.t_invm = 0.0;
+  W.t_ac = W.t_am = W.t_basec = W.t_basem = W.t_ac0 = W.t_am0 = 0.0;
+  W.t_acount = W.t_acount0 = 0;
+  W.t_o.host = 0, W.t_o.gpu_model = 0, W.t_o.gpu_count = 0.0, W.t_o.run_count = 0, W.t_o.task_slack = 0x7FFFFFFF, W.t_o.flags = 0, W.t_o.pad = 0;
+#pragma unroll
+  for (int x = 0; x < MV_NA; ++x) W.t_attr[x] = 0u;
+  W.lg_group = 0xFFFFFFFFu, W.lg_host = 0u, W.n_log = 0u;
+  W.lg_k = -1;
+  W.nT = 0u;
+}
+
+// the touched offers' state back to HBM, and what the order needs to take them back (v3_update)
+static __device__ void v3_walker_writeback(V3Lds& L, const MatchState& st, const V3Buf& vb, V3Walker& W) {
+  const unsigned lane = lane_id();
+  unsigned long long nkey = ~0ull;
+  unsigned nfcm = 0u;
+  if (W.t_v >= 0) {
+    st.ac[W.t_v] = W.t_ac;
+    st.am[W.t_v] = W.t_am;
+    st.acount[W.t_v] = W.t_acount;
+    L.owner[W.t_v] = 0xFF;
+    if (W.t_ac + st.jmin[0] > W.t_oc || W.t_am + st.jmin[1] > W.t_om) {
+      atomicAnd(&st.alive[(unsigned)W.t_v >> 6], ~(1ull << ((unsigned)W.t_v & 63u)));
+    } else {
+      OfferA a;
+      a.oc = W.t_oc, a.om = W.t_om, a.rc = W.t_rc, a.rm = W.t_rm, a.inv_dc = W.t_invc, a.inv_dm = W.t_invm;
+      nkey = v3_sort_key(a, W.t_o, W.t_ac, W.t_am, (unsigned)W.t_v);
+      nfcm = v3_pack_free(W.t_oc - W.t_ac, W.t_om - W.t_am);
+    }
+    atomicOr(&L.rembits[W.t_pos >> 6], 1ull << (W.t_pos & 63u));
+  }
+  L.ins_key[lane] = nkey;
+  L.ins_fcm[lane] = nfcm;
+  if (lane == 0) L.n_rem = W.nT;
+  v3_walker_reset(W);
+}
+
+// One epoch of the walk: until the jobs are used up (L.done), a list ran out (stop 1), the touched set (2) or the group log (3) is full.
+static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const V3Buf& vb, V3Walker& W) {
   const unsigned lane = lane_id();
   const unsigned K = in.K;
-  const uint32_t* const j_index = in.j_index;
-  // the touched offer of this lane
-  int t_v = -1;
-  double t_oc = 0, t_om = 0, t_rc = 0, t_rm = 0, t_invc = 0, t_invm = 0;
-  double t_ac = 0, t_am = 0, t_basec = 0, t_basem = 0, t_ac0 = 0, t_am0 = 0;
-  int t_acount = 0, t_acount0 = 0;
-  OfferB t_o;
-  t_o.host = 0, t_o.gpu_model = 0, t_o.gpu_count = 0.0, t_o.run_count = 0, t_o.task_slack = 0x7FFFFFFF, t_o.flags = 0, t_o.pad = 0;
-  unsigned t_attr[MV_NA];
-#pragma unroll
-  for (int x = 0; x < MV_NA; ++x) t_attr[x] = 0u;
-  // group members placed in this generation (one per lane, in placement order)
-  unsigned lg_group = 0xFFFFFFFFu, lg_host = 0u, n_log = 0u;
-  int lg_k = -1;
-  unsigned nT = 0;
   unsigned p = L.walk_pos;
   constexpr double EPS_HI = 1.0 + 0x1p-38, EPS_LO = 1.0 - 0x1p-38;
-  ws.stop = 0;
+  unsigned stop = 0;
   while (p < K) {
     // ---- skip the jobs the helpers settled; wait for the next prepared one ----------------------------------------------------------
     {
       const unsigned long long t0 = cook_ticks();
+      bool waited = false;
       for (;;) {
         const unsigned q = p + lane;
         unsigned s = 0;
@@ -635,6 +836,7 @@ static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const
           continue;
         }
         if (ready & 1ull) break;
+        waited = true;
         if (cook_ticks() - t0 > V3_WAIT_TICKS) {
           if (lane == 0) {
             st_wg(&L.abort, 1u);
@@ -646,230 +848,294 @@ static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const
         EMU_SITE("v3 walker: waiting for a prepared job");
         SPIN_PAUSE_SHORT();
       }
-      ws.wait_ticks += cook_ticks() - t0;
+      if (waited) W.wait_ticks += cook_ticks() - t0;
       if (p >= K) break;
     }
     lds_acquire();
-    const V3Job& J = v3_ring(L)[p % (unsigned)V3_R];
-    const unsigned info = J.info, k = p;
+    const V3Job& J = L.ring[p % (unsigned)V3_R];
+    const unsigned info = wave_uniform_u32(J.info), k = p;
     const double c = J.c, m = J.m;
     const int nc = (int)(info & 0xFFu);
-    const bool job_gpu = (info & V3I_GPU) != 0u, grouped = (info & V3I_GROUPED) != 0u, has_group = (info & V3I_HASGROUP) != 0u;
-    const unsigned gtype = (info >> 18) & 3u, g = has_group ? J.group : 0xFFFFFFFFu;
+    const bool grouped = (info & V3I_GROUPED) != 0u, has_group = (info & V3I_HASGROUP) != 0u;
+    const unsigned g = has_group ? wave_uniform_u32(J.group) : 0xFFFFFFFFu;
     const bool trunc = (info & V3I_TRUNC) != 0u;
-    ws.walked += 1u;
+    W.walked += 1u;
     // list entry `lane`
     double e_fit = -1.0;
     int e_off = -1;
-    unsigned owner = 0xFEu;
+    unsigned e_pos = 0u, owner = 0xFEu;
     if ((int)lane < nc) {
-      e_fit = J.ent[lane].fit;
-      e_off = J.ent[lane].off;
+      const V3Ent x = J.ent[lane];
+      e_fit = x.fit;
+      e_off = x.off;
+      e_pos = x.pos;
       owner = L.owner[e_off];
     }
     // ---- every touched offer under the current state ----------------------------------------------------------------------------------
-    const bool t_on = t_v >= 0;
+    const bool t_on = W.t_v >= 0;
     JobRec jr;
     jr.c = c, jr.m = m, jr.g = J.g, jr.gpu_model = J.gpu_model, jr.reserved_host = J.reserved_host, jr.group = J.group, jr.flags = 0;
-    const bool res_ok = t_on && !(t_ac + c > t_oc || t_am + m > t_om);
-    bool con_ok = t_on && static_fast(jr, t_o, in, (unsigned)(t_on ? t_v : 0)) && dyn_fast(jr, t_o, t_acount);
+    const bool res_ok = t_on && !(W.t_ac + c > W.t_oc || W.t_am + m > W.t_om);
+    bool con_ok = t_on && static_fast(jr, W.t_o, in, (unsigned)(t_on ? W.t_v : 0)) && dyn_fast(jr, W.t_o, W.t_acount);
     if (info & V3I_FASTC) {  // (wave-uniform)
-      unsigned diff = (J.req_host ^ (t_o.host + 1u)) & J.wild_host;
+      unsigned diff = (J.req_host ^ (W.t_o.host + 1u)) & J.wild_host;
 #pragma unroll
-      for (int x = 0; x < MV_NA; ++x) diff |= (J.req[x] ^ t_attr[x]) & J.wild[x];
+      for (int x = 0; x < MV_NA; ++x) diff |= (J.req[x] ^ W.t_attr[x]) & J.wild[x];
       bool hit = J.impossible != 0u;
 #pragma unroll
-      for (int q = 0; q < MV_NC; ++q) hit = hit | (J.novel[q] == t_o.host);
+      for (int q = 0; q < MV_NC; ++q) hit = hit | (J.novel[q] == W.t_o.host);
       con_ok = con_ok && diff == 0u && !hit;
     }
-    if ((info & V3I_SLOW) && con_ok) con_ok = static_pass_dev(vb.in_dev, J.jj, (unsigned)t_v);
+    if ((info & V3I_SLOW) && con_ok) con_ok = static_pass_dev(vb.in_dev, J.jj, (unsigned)W.t_v);
     unsigned long long ghits = 0ull;  // log entries of this job's group
     bool g_general = false;            // the group check goes through the chains in HBM
     if (has_group) {
-      ghits = __ballot(lane < n_log && lg_group == g);
+      ghits = __ballot(lane < W.n_log && W.lg_group == g);
       if (grouped) {
-        if ((info & V3I_GFAST) && J.n_fh >= 0 && n_log <= (unsigned)COOK_WAVE) {
+        if ((info & V3I_GFAST) && J.n_fh >= 0 && W.n_log <= (unsigned)COOK_WAVE) {
           bool forb = false;
 #pragma unroll
-          for (int q = 0; q < MV_FH; ++q) forb = forb | (t_o.host == J.gfh[q]);
+          for (int q = 0; q < MV_FH; ++q) forb = forb | (W.t_o.host == J.gfh[q]);
           for (unsigned long long hm = ghits; hm != 0ull; hm &= hm - 1ull) {
-            const unsigned h = (unsigned)wave_read_lane((int)lg_host, __ffsll((unsigned long long)hm) - 1);
-            forb = forb | (t_o.host == h);
+            const unsigned h = (unsigned)wave_read_lane((int)W.lg_host, __ffsll((unsigned long long)hm) - 1);
+            forb = forb | (W.t_o.host == h);
           }
           con_ok = con_ok && !forb;
         } else {
           g_general = true;
-          if (con_ok) con_ok = group_pass_dev(vb.in_dev, st, J.jj, (unsigned)t_v);
+          if (con_ok) con_ok = group_pass_dev(vb.in_dev, st, J.jj, (unsigned)W.t_v);
         }
       }
     }
-    const double nc_ = t_basec + c, nm_ = t_basem + m;
-    const double a1 = nc_ * t_invc, a2 = nm_ * t_invm;
+    const double nc_ = W.t_basec + c, nm_ = W.t_basem + m;
+    const double a1 = nc_ * W.t_invc, a2 = nm_ * W.t_invm;
     const double fa = (a1 + a2) * 0.5;
     const bool cand = res_ok && con_ok;
-    const bool sane = a1 >= 0.0 && a2 >= 0.0 && fa > 0.0;
-    bool need_exact = __any(cand && !sane);
-    const unsigned long long cand_mask = __ballot(cand);
     int win = -1, win_lane = -1;
-    double u_fit = -1.0;
-    int u_off = -1;
+    unsigned win_pos = 0u;
     bool exhausted = false;
     unsigned pe_bits = 8u;
     double pe_fit = 0.0;
-    do {
-      // no feasible offer under the snapshot and none of zero fitness (a placement could lift that one): stays unmatched, only the
-      // summary may move
-      if (nc == 0 && !grouped && J.f4 == 0) break;
-      const bool e_valid = owner != 0xFEu, e_untouched = owner == 0xFFu;
-      const bool e_live = e_valid && !e_untouched && ((cand_mask >> (owner & 63u)) & 1ull);
-      const unsigned long long settle_mask = __ballot(e_untouched || e_live), untouched_mask = __ballot(e_untouched);
-      if (settle_mask == 0ull && trunc) {
-        exhausted = true;
-        break;
+    bool decided = false;
+    // ======== FAST PATH: the touched offers ordered by an fp32 image of the approximate fitness (one DPP max chain) ==================
+    {
+      const bool sane = a1 >= 0.0 && a2 >= 0.0 && fa > 0x1p-100;
+      const float kf = cand ? (sane ? (float)fa : __int_as_float(0x7F800000)) : 0.0f;
+      const float mx = wave_max_f32(kf);
+      const unsigned long long untouched_mask = __ballot(owner == 0xFFu);
+      double u_fit = -1.0;
+      int u_off = -1;
+      unsigned u_pos = 0u;
+      if (untouched_mask != 0ull) {
+        const int qs = __ffsll((unsigned long long)untouched_mask) - 1;
+        u_fit = wave_read_lane_f64(e_fit, qs);
+        u_off = wave_read_lane(e_off, qs);
+        u_pos = (unsigned)wave_read_lane((int)e_pos, qs);
       }
-      if (settle_mask != 0ull) {
-        const int qs = __ffsll((unsigned long long)settle_mask) - 1;
-        if ((untouched_mask >> qs) & 1ull) {
-          u_fit = wave_read_lane_f64(e_fit, qs);
-          u_off = wave_read_lane(e_off, qs);
-        }
-      }
-      bool decided = false;
-      if (!need_exact) {
-        if (cand_mask == 0ull) {
+      if (mx == 0.0f) {  // no touched offer can take the job
+        if (u_off >= 0) {
           win = u_off;
+          win_pos = u_pos;
           decided = true;
-        } else {
-          const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(fa) : 0ull;
-          const double mx = __longlong_as_double((long long)wave_max_u64(key));
-          const unsigned long long near = __ballot(cand && fa >= mx * EPS_LO);
-          if ((near & (near - 1ull)) == 0ull) {
-            if (u_off < 0 || mx * EPS_LO > u_fit) {
-              win_lane = __ffsll((unsigned long long)near) - 1;
-              decided = true;
-            } else if (mx * EPS_HI < u_fit) {
-              win = u_off;
+        }  // else: unmatched or list exhausted -> general path
+      } else if (mx < __int_as_float(0x7F800000)) {
+        const unsigned long long near = __ballot(kf >= mx * (1.0f - 0x1p-20f));
+        if ((near & (near - 1ull)) == 0ull) {  // one touched offer clearly ahead of the other touched ones
+          const int wl = __ffsll((unsigned long long)near) - 1;
+          const double fw = wave_read_lane_f64(fa, wl);
+          if (u_off < 0) {
+            // no untouched entry: fine unless untouched offers may exist beyond the list and none of its entries is still a candidate
+            bool ok = !trunc;
+            if (!ok) {
+              const unsigned long long cand_mask = __ballot(cand);
+              const bool e_live = owner < 0xFEu && ((cand_mask >> (owner & 63u)) & 1ull);
+              ok = __any(e_live);
+            }
+            if (ok) {
+              win_lane = wl;
               decided = true;
             }
+          } else if (fw * EPS_LO > u_fit) {
+            win_lane = wl;
+            decided = true;
+          } else if (fw * EPS_HI < u_fit) {
+            win = u_off;
+            win_pos = u_pos;
+            decided = true;
           }
         }
-        if (!decided) need_exact = true;
       }
-      if (need_exact) {
-        if (t_on) {
-          pe_bits = 0u;
-          if (!res_ok) {
-            pe_bits = 1u;
-          } else if (!con_ok) {
-            pe_bits = 2u;
-          } else {
-            pe_fit = (nc_ / (t_oc + t_rc) + nm_ / (t_om + t_rm)) / 2.0;
-            if (!(pe_fit > 0.0)) pe_bits = 4u;
-          }
-        }
-        const bool t_feas = t_on && pe_bits == 0u;
-        const unsigned long long feas_mask = __ballot(t_feas);
-        const bool e_live2 = e_valid && !e_untouched && ((feas_mask >> (owner & 63u)) & 1ull);
-        const unsigned long long settle2 = __ballot(e_untouched || e_live2);
-        if (settle2 == 0ull && trunc) {
+      if (decided) W.fast += 1u;
+    }
+    // ======== GENERAL PATH ===================================================================================================================
+    if (!decided) {
+      const bool sane = a1 >= 0.0 && a2 >= 0.0 && fa > 0.0;
+      bool need_exact = __any(cand && !sane);
+      const unsigned long long cand_mask = __ballot(cand);
+      double u_fit = -1.0;
+      int u_off = -1;
+      unsigned u_pos = 0u;
+      do {
+        // no feasible offer under the snapshot and none of zero fitness (a placement could lift that one): stays unmatched, only the
+        // summary may move
+        if ((info & V3I_NOFEAS) && !grouped && J.f4 == 0) break;
+        const bool e_valid = owner != 0xFEu, e_untouched = owner == 0xFFu;
+        const bool e_live = e_valid && !e_untouched && ((cand_mask >> (owner & 63u)) & 1ull);
+        const unsigned long long settle_mask = __ballot(e_untouched || e_live), untouched_mask = __ballot(e_untouched);
+        if (settle_mask == 0ull && trunc) {
           exhausted = true;
           break;
         }
-        u_fit = -1.0;
-        u_off = -1;
-        if (settle2 != 0ull) {
-          const int qs = __ffsll((unsigned long long)settle2) - 1;
+        if (settle_mask != 0ull) {
+          const int qs = __ffsll((unsigned long long)settle_mask) - 1;
           if ((untouched_mask >> qs) & 1ull) {
             u_fit = wave_read_lane_f64(e_fit, qs);
             u_off = wave_read_lane(e_off, qs);
+            u_pos = (unsigned)wave_read_lane((int)e_pos, qs);
           }
         }
-        Cand best{-1.0, -1};
-        int best_lane = -1;
-        if (feas_mask != 0ull) {
-          const unsigned long long key = t_feas ? (unsigned long long)__double_as_longlong(pe_fit) : 0ull;
-          const unsigned long long mx = wave_max_u64(key);
-          unsigned long long tie = __ballot(t_feas && key == mx);
-          int wl = __ffsll((unsigned long long)tie) - 1;
-          int wv = wave_read_lane(t_v, wl);
-          tie &= tie - 1ull;
-          while (tie != 0ull) {
-            const int l2 = __ffsll((unsigned long long)tie) - 1;
-            const int v2 = wave_read_lane(t_v, l2);
-            if (v2 < wv) wv = v2, wl = l2;
+        bool dec2 = false;
+        if (!need_exact) {
+          if (cand_mask == 0ull) {
+            win = u_off;
+            win_pos = u_pos;
+            dec2 = true;
+          } else {
+            const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(fa) : 0ull;
+            const double mx = __longlong_as_double((long long)wave_max_u64(key));
+            const unsigned long long near = __ballot(cand && fa >= mx * EPS_LO);
+            if ((near & (near - 1ull)) == 0ull) {
+              if (u_off < 0 || mx * EPS_LO > u_fit) {
+                win_lane = __ffsll((unsigned long long)near) - 1;
+                dec2 = true;
+              } else if (mx * EPS_HI < u_fit) {
+                win = u_off;
+                win_pos = u_pos;
+                dec2 = true;
+              }
+            }
+          }
+          if (!dec2) need_exact = true;
+        }
+        if (need_exact) {
+          if (t_on) {
+            pe_bits = 0u;
+            if (!res_ok) {
+              pe_bits = 1u;
+            } else if (!con_ok) {
+              pe_bits = 2u;
+            } else {
+              pe_fit = (nc_ / (W.t_oc + W.t_rc) + nm_ / (W.t_om + W.t_rm)) / 2.0;
+              if (!(pe_fit > 0.0)) pe_bits = 4u;
+            }
+          }
+          const bool t_feas = t_on && pe_bits == 0u;
+          const unsigned long long feas_mask = __ballot(t_feas);
+          const bool e_live2 = e_valid && !e_untouched && ((feas_mask >> (owner & 63u)) & 1ull);
+          const unsigned long long settle2 = __ballot(e_untouched || e_live2);
+          if (settle2 == 0ull && trunc) {
+            exhausted = true;
+            break;
+          }
+          u_fit = -1.0;
+          u_off = -1;
+          if (settle2 != 0ull) {
+            const int qs = __ffsll((unsigned long long)settle2) - 1;
+            if ((untouched_mask >> qs) & 1ull) {
+              u_fit = wave_read_lane_f64(e_fit, qs);
+              u_off = wave_read_lane(e_off, qs);
+              u_pos = (unsigned)wave_read_lane((int)e_pos, qs);
+            }
+          }
+          Cand best{-1.0, -1};
+          int best_lane = -1;
+          if (feas_mask != 0ull) {
+            const unsigned long long key = t_feas ? (unsigned long long)__double_as_longlong(pe_fit) : 0ull;
+            const unsigned long long mx = wave_max_u64(key);
+            unsigned long long tie = __ballot(t_feas && key == mx);
+            int wl = __ffsll((unsigned long long)tie) - 1;
+            int wv = wave_read_lane(W.t_v, wl);
             tie &= tie - 1ull;
+            while (tie != 0ull) {
+              const int l2 = __ffsll((unsigned long long)tie) - 1;
+              const int v2 = wave_read_lane(W.t_v, l2);
+              if (v2 < wv) wv = v2, wl = l2;
+              tie &= tie - 1ull;
+            }
+            best = Cand{__longlong_as_double((long long)mx), wv};
+            best_lane = wl;
           }
-          best = Cand{__longlong_as_double((long long)mx), wv};
-          best_lane = wl;
+          if (u_off >= 0 && cand_better(Cand{u_fit, u_off}, best))
+            win = u_off, win_pos = u_pos, win_lane = -1;
+          else if (best_lane >= 0)
+            win_lane = best_lane, win = -1;
+          else
+            win = win_lane = -1;
         }
-        if (u_off >= 0 && cand_better(Cand{u_fit, u_off}, best))
-          win = u_off, win_lane = -1;
-        else if (best_lane >= 0)
-          win_lane = best_lane, win = -1;
-        else
-          win = win_lane = -1;
-      }
-    } while (0);
+      } while (0);
+    }
     if (exhausted) {
-      ws.stop = 1;
+      stop = 1;
       break;
     }
     // ---- commit ---------------------------------------------------------------------------------------------------------------------------
-    if (win_lane < 0 && win >= 0 && nT == (unsigned)V3_T) {
-      ws.stop = 2;  // no free lane for another touched offer: a new generation starts with this job
+    if (win_lane < 0 && win >= 0 && W.nT == (unsigned)V3_T) {
+      stop = 2;  // no free lane for another touched offer: a new generation starts with this job
       break;
     }
-    if ((win_lane >= 0 || win >= 0) && has_group && n_log >= (unsigned)COOK_WAVE) {
-      ws.stop = 3;  // the log of this generation's group placements is full
+    if ((win_lane >= 0 || win >= 0) && has_group && W.n_log >= (unsigned)COOK_WAVE) {
+      stop = 3;  // the log of this generation's group placements is full
       break;
     }
     if (win_lane >= 0) {
       if ((int)lane == win_lane) {
-        t_ac += c;
-        t_am += m;
-        t_acount += 1;
-        t_basec = t_rc + t_ac;
-        t_basem = t_rm + t_am;
+        W.t_ac += c;
+        W.t_am += m;
+        W.t_acount += 1;
+        W.t_basec = W.t_rc + W.t_ac;
+        W.t_basem = W.t_rm + W.t_am;
       }
-      win = wave_read_lane(t_v, win_lane);
+      win = wave_read_lane(W.t_v, win_lane);
     } else if (win >= 0) {
-      if (lane == nT) {  // the next free lane takes ownership: the offer's record from HBM (untouched: the snapshot is its state)
+      if (lane == W.nT) {  // the next free lane takes ownership: the offer's record from HBM (untouched: the snapshot is its state)
         const OfferA a = vb.oa[win];
-        t_o = vb.ob[win];
-        t_v = win;
-        t_oc = a.oc, t_om = a.om, t_rc = a.rc, t_rm = a.rm, t_invc = a.inv_dc, t_invm = a.inv_dm;
-        t_ac0 = st.ac[win], t_am0 = st.am[win], t_acount0 = st.acount[win];
-        t_ac = t_ac0 + c;
-        t_am = t_am0 + m;
-        t_acount = t_acount0 + 1;
-        t_basec = t_rc + t_ac;
-        t_basem = t_rm + t_am;
+        W.t_o = vb.ob[win];
+        W.t_v = win;
+        W.t_pos = win_pos;
+        W.t_oc = a.oc, W.t_om = a.om, W.t_rc = a.rc, W.t_rm = a.rm, W.t_invc = a.inv_dc, W.t_invm = a.inv_dm;
+        W.t_ac0 = st.ac[win], W.t_am0 = st.am[win], W.t_acount0 = st.acount[win];
+        W.t_ac = W.t_ac0 + c;
+        W.t_am = W.t_am0 + m;
+        W.t_acount = W.t_acount0 + 1;
+        W.t_basec = W.t_rc + W.t_ac;
+        W.t_basem = W.t_rm + W.t_am;
 #pragma unroll
-        for (int x = 0; x < MV_NA; ++x) t_attr[x] = (in.o_attr && (unsigned)x < in.n_attr) ? in.o_attr[(size_t)win * in.n_attr + x] : 0u;
-        L.owner[win] = (unsigned char)nT;
+        for (int x = 0; x < MV_NA; ++x) W.t_attr[x] = (in.o_attr && (unsigned)x < in.n_attr) ? in.o_attr[(size_t)win * in.n_attr + x] : 0u;
+        L.owner[win] = (unsigned char)W.nT;
+        st_wg(&L.tbits[win_pos >> 6], L.tbits[win_pos >> 6] | (1ull << (win_pos & 63u)));  // (this wave is the only writer)
       }
-      win_lane = (int)nT;
-      ++nT;
-      ws.opens += 1u;
+      win_lane = (int)W.nT;
+      ++W.nT;
+      W.opens += 1u;
       wave_sync();  // the owner table update is visible to the whole wave before the next look-up reads it
     }
     if (win >= 0) {
-      ws.matched += 1u;
-      if (k == 0) ws.head_matched = 1u;
+      W.matched += 1u;
+      if (k == 0) W.head_matched = 1u;
       if (has_group) {  // publish a placed group member: the chains in HBM and the generation's log
-        const int prev = ghits != 0ull ? wave_read_lane(lg_k, 63 - __clzll((long long)ghits)) : J.glast;
-        const unsigned w_host = (unsigned)wave_read_lane((int)t_o.host, win_lane);
+        const int prev = ghits != 0ull ? wave_read_lane(W.lg_k, 63 - __clzll((long long)ghits)) : J.glast;
+        const unsigned w_host = (unsigned)wave_read_lane((int)W.t_o.host, win_lane);
         if (lane == 0) {
           st_agent(&st.job_to_offer[k], win);
           st_agent(&st.job_prev[k], prev);
           st_agent(&st.group_last[g], (int)k);
         }
-        if (lane == n_log) {
-          lg_group = g;
-          lg_host = w_host;
-          lg_k = (int)k;
+        if (lane == W.n_log) {
+          W.lg_group = g;
+          W.lg_host = w_host;
+          W.lg_k = (int)k;
         }
-        ++n_log;
+        ++W.n_log;
         if (g_general) wave_sync();
       } else if (lane == 0) {
         st.job_to_offer[k] = win;
@@ -879,7 +1145,7 @@ static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const
       // unmatched: failure summary = OR over offers of the first failing check under the CURRENT state: the snapshot counts, with each
       // touched offer's snapshot verdict swapped for its current one
       int d1 = 0, d2 = 0, d4 = 0;
-      if (nT != 0u) {
+      if (W.nT != 0u) {
         if (pe_bits == 8u && t_on) {
           pe_bits = 0u;
           if (!res_ok) {
@@ -887,35 +1153,35 @@ static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const
           } else if (!con_ok) {
             pe_bits = 2u;
           } else {
-            pe_fit = (nc_ / (t_oc + t_rc) + nm_ / (t_om + t_rm)) / 2.0;
+            pe_fit = (nc_ / (W.t_oc + W.t_rc) + nm_ / (W.t_om + W.t_rm)) / 2.0;
             if (!(pe_fit > 0.0)) pe_bits = 4u;
           }
         }
         unsigned p0 = 0u;
         if (t_on) {
-          if (t_ac0 + c > t_oc || t_am0 + m > t_om) {
+          if (W.t_ac0 + c > W.t_oc || W.t_am0 + m > W.t_om) {
             p0 = 1u;
           } else {
-            bool ok = static_fast(jr, t_o, in, (unsigned)t_v) && dyn_fast(jr, t_o, t_acount0);
+            bool ok = static_fast(jr, W.t_o, in, (unsigned)W.t_v) && dyn_fast(jr, W.t_o, W.t_acount0);
             if (ok && (info & V3I_FASTC)) {
-              unsigned diff = (J.req_host ^ (t_o.host + 1u)) & J.wild_host;
+              unsigned diff = (J.req_host ^ (W.t_o.host + 1u)) & J.wild_host;
 #pragma unroll
-              for (int x = 0; x < MV_NA; ++x) diff |= (J.req[x] ^ t_attr[x]) & J.wild[x];
+              for (int x = 0; x < MV_NA; ++x) diff |= (J.req[x] ^ W.t_attr[x]) & J.wild[x];
               bool hit = J.impossible != 0u;
 #pragma unroll
-              for (int q = 0; q < MV_NC; ++q) hit = hit | (J.novel[q] == t_o.host);
+              for (int q = 0; q < MV_NC; ++q) hit = hit | (J.novel[q] == W.t_o.host);
               ok = diff == 0u && !hit;
             }
-            if (ok && (info & V3I_SLOW)) ok = static_pass_dev(vb.in_dev, J.jj, (unsigned)t_v);
+            if (ok && (info & V3I_SLOW)) ok = static_pass_dev(vb.in_dev, J.jj, (unsigned)W.t_v);
             if (ok && grouped) {  // the group check as the generation began
               MatchState st0 = st;
               st0.cutoff = (int)L.gen_first;
-              ok = group_pass_dev(vb.in_dev, st0, J.jj, (unsigned)t_v);
+              ok = group_pass_dev(vb.in_dev, st0, J.jj, (unsigned)W.t_v);
             }
             if (!ok) {
               p0 = 2u;
             } else {
-              const double f0 = ((t_rc + t_ac0 + c) / (t_oc + t_rc) + (t_rm + t_am0 + m) / (t_om + t_rm)) / 2.0;
+              const double f0 = ((W.t_rc + W.t_ac0 + c) / (W.t_oc + W.t_rc) + (W.t_rm + W.t_am0 + m) / (W.t_om + W.t_rm)) / 2.0;
               if (!(f0 > 0.0)) p0 = 4u;
             }
           }
@@ -933,16 +1199,12 @@ static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const
     ++p;
     if (lane == 0) st_wg(&L.walk_pos, p);
   }
-  // ---- end of the generation: the touched offers' state back to HBM ----------------------------------------------------------------------
-  if (t_v >= 0) {
-    st.ac[t_v] = t_ac;
-    st.am[t_v] = t_am;
-    st.acount[t_v] = t_acount;
-    if (t_ac + st.jmin[0] > t_oc || t_am + st.jmin[1] > t_om) atomicAnd(&st.alive[(unsigned)t_v >> 6], ~(1ull << ((unsigned)t_v & 63u)));
-  }
+  // ---- end of the epoch -----------------------------------------------------------------------------------------------------------------------
+  if (stop >= 2u || p >= K) v3_walker_writeback(L, st, vb, W);  // (at the end of the call too: the state arrays are the call's result)
   if (lane == 0) {
     st_wg(&L.walk_pos, p);
-    st_wg(&L.gen_first, p);
+    if (stop >= 2u) st_wg(&L.gen_first, p);
+    st_wg(&L.stop_reason, stop);
     if (p >= K) st_wg(&L.done, 1u);
     lds_release();
     st_wg(&L.gen_stop, 1u);
@@ -973,8 +1235,11 @@ __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3* __restric
     L.walk_pos = 0u;
     L.gen_first = 0u;
     L.abort = 0u;
-    L.sort_n = vb.job_flags[2] != 0ull ? 1u : 0u;  // (borrowed as the "bad input" flag until the first regeneration)
+    L.stop_reason = 0u;
+    L.n_rem = L.n_ins = 0u;
+    L.sort_n = vb.job_flags[2] != 0ull ? 1u : 0u;  // (borrowed as the "bad input" flag until the first generation)
   }
+  for (unsigned b = tid; b < (unsigned)V3_NBMAX; b += NT) L.rembits[b] = 0ull;
   __syncthreads();
   {
     bool bad = false;
@@ -991,33 +1256,44 @@ __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3* __restric
     return;
   }
   __syncthreads();
-  V3WalkStats ws;
-  ws.matched = ws.head_matched = ws.walked = ws.opens = ws.stop = 0u;
-  ws.wait_ticks = 0ull;
-  unsigned n_steps = 0, n_settled = 0, gens = 0, s_full = 0, s_list = 0, s_log = 0;
-  unsigned long long t_regen = 0ull;
+  V3Walker W;
+  v3_walker_reset(W);
+  W.matched = W.head_matched = W.walked = W.opens = W.fast = 0u;
+  W.wait_ticks = 0ull;
+  unsigned n_steps = 0, n_visits = 0, n_settled = 0, gens = 0, epochs = 0, s_full = 0, s_list = 0, s_log = 0;
+  unsigned long long t_regen = 0ull, t_flush = 0ull;
+  unsigned reason = 2u;  // (the first epoch builds the order)
   for (;;) {
-    // ---- a generation: snapshot, order, ring reset ------------------------------------------------------------------------------------
+    // ---- between epochs: a new generation (order rebuilt or updated) or only a ring flush -----------------------------------------------
     const unsigned long long tr0 = cook_ticks();
-    for (unsigned x = tid; x < in.G; x += NT) vb.group_snap[x] = ld_agent(&st.group_last[x]);
+    if (reason >= 2u) {
+      for (unsigned x = tid; x < in.G; x += NT) vb.group_snap[x] = ld_agent(&st.group_last[x]);
+      if (gens == 0u)
+        v3_build(L, in, st, vb);  // (ends with a barrier)
+      else
+        v3_update(L, vb);
+      ++gens;
+    }
     for (unsigned x = tid; x < (unsigned)V3_R; x += NT) L.rstate[x] = 0u;
     if (tid == 0) {
       L.next = L.walk_pos;
       L.gen_stop = 0u;
     }
-    v3_regen(L, in, st, vb);  // (ends with a barrier)
-    t_regen += cook_ticks() - tr0;
-    ++gens;
-    if (tid < COOK_WAVE)
-      v3_walk(L, in, st, vb, ws);
-    else
-      v3_helper(L, in, st, vb, &n_steps, &n_settled);
     __syncthreads();
-    if (tid < COOK_WAVE) {
-      s_list += ws.stop == 1u ? 1u : 0u;
-      s_full += ws.stop == 2u ? 1u : 0u;
-      s_log += ws.stop == 3u ? 1u : 0u;
-    }
+    if (reason >= 2u)
+      t_regen += cook_ticks() - tr0;
+    else
+      t_flush += cook_ticks() - tr0;
+    ++epochs;
+    if (tid < COOK_WAVE)
+      v3_walk(L, in, st, vb, W);
+    else
+      v3_helper(L, in, st, vb, &n_steps, &n_visits, &n_settled);
+    __syncthreads();
+    reason = L.stop_reason;
+    s_list += reason == 1u ? 1u : 0u;
+    s_full += reason == 2u ? 1u : 0u;
+    s_log += reason == 3u ? 1u : 0u;
     if (L.done != 0u) break;
     __syncthreads();
   }
@@ -1026,25 +1302,25 @@ __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3* __restric
     return;
   }
   // ---- statistics ---------------------------------------------------------------------------------------------------------------------
-  for (int d = 32; d >= 1; d >>= 1) {
-    n_steps += (unsigned)__shfl_xor((int)n_steps, d, COOK_WAVE);
-    n_settled += (unsigned)__shfl_xor((int)n_settled, d, COOK_WAVE);
-  }
   if (lane == 0 && tid >= COOK_WAVE) {  // (every lane of a helper wave carries the same counts: the wave's)
-    atomicAdd(&vb.ctl->scan_steps, n_steps / COOK_WAVE);
-    atomicAdd(&vb.ctl->settled, n_settled / COOK_WAVE);
+    atomicAdd(&vb.ctl->scan_steps, n_steps);
+    atomicAdd(&vb.ctl->visits, n_visits);
+    atomicAdd(&vb.ctl->settled, n_settled);
   }
   if (tid == 0) {
     V3Ctl* c = vb.ctl;
     c->head = in.K;
-    c->matched = ws.matched;
-    c->head_matched = ws.head_matched;
+    c->matched = W.matched;
+    c->head_matched = W.head_matched;
     c->generations = gens;
+    c->epochs = epochs;
     c->stop_full = s_full, c->stop_list = s_list, c->stop_log = s_log, c->stop_other = 0;
-    c->walked = ws.walked;
-    c->opens = ws.opens;
+    c->walked = W.walked;
+    c->opens = W.opens;
+    c->fast = W.fast;
     c->t_total = cook_ticks() - tk0;
     c->t_regen = t_regen;
-    c->t_walk_wait = ws.wait_ticks;
+    c->t_flush = t_flush;
+    c->t_walk_wait = W.wait_ticks;
   }
 }
