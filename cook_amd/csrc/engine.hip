@@ -181,7 +181,7 @@ struct cook_engine {
   WinCtl last_ctl{};
   // match_v3 (one persistent workgroup per pool)
   DArr<V3Ctl> v3_ctl;
-  DArr<PoolCtx3> v3_ctx;
+  DArr<char> v3_pos;          // the offers' records in position order (V3Pos)
   DArr<int32_t> v3_group_snap;
   void* h_v3 = nullptr;      // pinned: PoolCtx3 going out, V3Ctl coming back
   V3Ctl last_v3{};
@@ -897,18 +897,33 @@ bool match_v3_run(cook_engine* e, const MatchIn& in, const MatchState& st, const
       return (unsigned)(v >= 1 && v <= V3_R ? v : (V3_R < 32 ? V3_R : 32));
     }();
     h.vb.look_ahead = la;
-    h.vb.pad = 0;
+    static const unsigned rg = [] {  // generations between rebuilds of the order (tuning runs: COOK_V3_REBUILD)
+      const char* s = std::getenv("COOK_V3_REBUILD");
+      const long v = s ? std::atol(s) : 0;
+      return (unsigned)(v >= 1 ? v : 16);
+    }();
+    h.vb.rebuild_gens = rg;
+    h.vb.P = v3_pos_carve(e->v3_pos.ensure(V3_POS_BYTES));
   }
   if (!e->h_v3) COOK_HIP(hipHostMalloc(&e->h_v3, sizeof(PoolCtx3) + sizeof(V3Ctl), hipHostMallocDefault));
-  std::memcpy(e->h_v3, &h, sizeof(h));
-  PoolCtx3* dctx = e->v3_ctx.ensure(1);
-  COOK_HIP(hipMemcpyAsync(dctx, e->h_v3, sizeof(PoolCtx3), hipMemcpyHostToDevice, e->stream));
   COOK_HIP(hipMemsetAsync(h.vb.ctl, 0, sizeof(V3Ctl), e->stream));
-  KL("match_v3", match_v3, 1, V3_THREADS, (const PoolCtx3*)dctx);
+  KL("match_v3", match_v3, 1, V3_THREADS, h);
   V3Ctl* hc = (V3Ctl*)((char*)e->h_v3 + sizeof(PoolCtx3));
   COOK_HIP(hipMemcpyAsync(hc, h.vb.ctl, sizeof(V3Ctl), hipMemcpyDeviceToHost, e->stream));
   sync(e);
   e->last_v3 = *hc;
+#ifdef COOK_V3_PROF
+  if (const char* pf = std::getenv("COOK_V3_PROF_FILE")) {  // measurement build: the phase counters of this call, one JSON line
+    if (FILE* f = std::fopen(pf, "a")) {
+      std::fprintf(f, "{\"K\": %u, \"M\": %u, \"total_us\": %llu, \"cyc\": [", in.K, in.M, (unsigned long long)(hc->t_total / 100ull));
+      for (int i = 0; i < V3_NPROF; ++i) std::fprintf(f, "%s%llu", i ? ", " : "", (unsigned long long)hc->prof_cyc[i]);
+      std::fprintf(f, "], \"cnt\": [");
+      for (int i = 0; i < V3_NPROF; ++i) std::fprintf(f, "%s%llu", i ? ", " : "", (unsigned long long)hc->prof_cnt[i]);
+      std::fprintf(f, "]}\n");
+      std::fclose(f);
+    }
+  }
+#endif
   if (hc->error == 2u) e->fail(COOK_E_STATE, "match_v3: the walker waited for a prepared job for more than a second (internal error)");
   if (hc->error != 0u) {
     e->v3_refused += 1;

@@ -47,8 +47,10 @@ static __device__ __forceinline__ void st_wg(T* p, T v) { __hip_atomic_store(p, 
 #define SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
 #define SPIN_PAUSE_SHORT() __builtin_amdgcn_s_sleep(1)
 // LDS hand-off between waves of one workgroup without a workgroup barrier (the evaluator teams' barrier)
-static __device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
-static __device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// (fences of the LDS address space only: a plain workgroup fence also waits for the wave's outstanding GLOBAL stores — a result store to
+// HBM takes over a thousand cycles to be acknowledged, and the placement walk has one in flight at every hand-off)
+static __device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
+static __device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
 #define COOK_BLOCK_LDS(name, bytes) __shared__ __attribute__((aligned(16))) char name[bytes]
 // every workgroup of the grid must be resident at once; the host sizes the grid for that (one workgroup per CU)
 #define COOK_LAUNCH_COOP(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)

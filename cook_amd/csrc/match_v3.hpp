@@ -19,8 +19,12 @@
 // run a bounded number of jobs ahead of it.  A helper leaves the offers that are touched when it looks OUT of the list (they are
 // the walker's business), so a list goes stale only through the few offers opened between its preparation and its use.  When a
 // list does run out, the ring is flushed and prepared again (an "epoch": two barriers, the walker keeps its lanes); when the
-// touched set is full the walker writes its lanes back and the order is UPDATED IN PLACE — the <= 64 moved offers are taken out
-// and merged back in at their new keys (a "generation": a few microseconds, not a sort, not three kernel launches).
+// touched set is full the walker writes its lanes back IN PLACE (a "generation": the <= 64 offers keep their positions, their keys
+// and free resources are replaced and the summaries of their blocks recomputed — the bounds stay valid for any arrangement, and
+// since best fit fills the offers roughly in the order they stand in, the order decays slowly); every few generations the order
+// is rebuilt by a sort.  The offers' records live in global memory IN POSITION ORDER as a structure of arrays (V3Pos), so a
+// helper's "lane = position" reads are coalesced: a gather of 64 scattered offer records costs the CU's one texture-address
+// unit about a thousand cache-line requests per block, the same block in position order under a hundred.
 //
 // Scope (the host checks it and runs match_v2 otherwise): best fit (good-enough-fitness >= 1), no ports / named scalars, no
 // balanced / attribute-equals groups, one offer per host, at most V3_MMAX offers.
@@ -76,8 +80,21 @@ struct V3BlockSum {  // summary of one block of 64 positions of the order (float
   float maxc, maxm;      // >= the greatest free cpus / mem under the snapshot
   float ri_dc, ri_dm;    // >= 1 / (smallest denominator)
   float rx_dc, rx_dm;    // <= 1 / (greatest denominator)
+  unsigned sig, pad;     // which kinds of gpu request the block's offers can serve (v3_offer_sig, OR over the block)
 };
+// bit 0: takes jobs without gpus; bit 1: a k8s "gpus" map with several entries (may serve any gpu job); bits 2..31: a hash of the
+// one (model, count) a gpu job must ask for (constraints.clj:122-157 as static_fast evaluates it)
+static __device__ __forceinline__ unsigned v3_gpu_bit(unsigned model, double count) {
+  unsigned long long h = ((unsigned long long)__double_as_longlong(count) + model) * 0x9E3779B97F4A7C15ull;
+  return 1u << (2u + (unsigned)(h >> 59) % 30u);
+}
+static __device__ __forceinline__ unsigned v3_offer_sig(unsigned flags, unsigned gpu_model, double gpu_count) {
+  if (!(flags & 1u)) return 1u;
+  if (flags & 4u) return 2u;
+  return gpu_model == 0u ? 1u : v3_gpu_bit(gpu_model, gpu_count);
+}
 
+constexpr int V3_NPROF = 24;
 struct V3Ctl {  // in global memory: results and statistics of one call
   unsigned head, matched, head_matched, generations;
   unsigned stop_full, stop_list, stop_log, stop_other;
@@ -87,9 +104,52 @@ struct V3Ctl {  // in global memory: results and statistics of one call
   unsigned epochs; // ring flushes + generations
   unsigned fast, visits;  // jobs decided by the walker's fast path; blocks whose offers' records a helper read
   unsigned long long t_flush;
+  unsigned long long prof_cyc[V3_NPROF];  // (COOK_V3_PROF builds) shader cycles / events by phase, summed over the waves
+  unsigned long long prof_cnt[V3_NPROF];
 };
 
+// -DCOOK_V3_PROF: a measurement build — shader cycles by phase.  Helper phases: 0 job record + constraint form + group hosts, 1 block
+// bounds, 2 block selection, 3 free-resource look-up (LDS), 4 offer evaluation (records from HBM), 5 list merge, 6 publish, 7 waiting
+// for the walker (look-ahead window), 8 insertions (count only).  Walker phases: 16 waiting / skipping, 17 job load + touched offers,
+// 18 fast decision, 19 general decision, 20 commit on a touched lane, 21 commit on a new lane, 22 unmatched.
+#ifdef COOK_V3_PROF
+#define V3P_DECL() unsigned long long pk_ = __builtin_readcyclecounter()
+#define V3P_MARK(pc, pn, i)                                      \
+  do {                                                           \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    (pc)[i] += now_ - pk_;                                       \
+    (pn)[i] += 1u;                                               \
+    pk_ = now_;                                                  \
+  } while (0)
+#define V3P_COUNT(pn, i, v) ((pn)[i] += (v))
+#else
+#define V3P_DECL() ((void)0)
+#define V3P_MARK(pc, pn, i) ((void)0)
+#define V3P_COUNT(pn, i, v) ((void)0)
+#endif
+
+struct V3Pos {  // the offers of the order BY POSITION (structure of arrays, V3_MMAX entries each)
+  double *oc, *om, *rc, *rm;  // lease cpus / mem, Fenzo's running cpus / mem
+  double *ac, *am;            // assigned in this call (as of the last generation change)
+  double* gpu_count;
+  unsigned *off, *host, *gpu_model, *flags;
+  int *run_count, *slack, *acount;
+  unsigned* attr;             // [MV_NA][V3_MMAX]
+};
+constexpr size_t V3_POS_BYTES = (size_t)V3_MMAX * (7 * 8 + 4 * 4 + 3 * 4 + MV_NA * 4);
+static inline V3Pos v3_pos_carve(char* base) {  // (host) the arrays inside one allocation of V3_POS_BYTES
+  V3Pos P;
+  double* d = reinterpret_cast<double*>(base);
+  P.oc = d, P.om = d + V3_MMAX, P.rc = d + 2 * V3_MMAX, P.rm = d + 3 * V3_MMAX, P.ac = d + 4 * V3_MMAX, P.am = d + 5 * V3_MMAX, P.gpu_count = d + 6 * V3_MMAX;
+  unsigned* u = reinterpret_cast<unsigned*>(d + 7 * V3_MMAX);
+  P.off = u, P.host = u + V3_MMAX, P.gpu_model = u + 2 * V3_MMAX, P.flags = u + 3 * V3_MMAX;
+  P.run_count = reinterpret_cast<int*>(u + 4 * V3_MMAX), P.slack = reinterpret_cast<int*>(u + 5 * V3_MMAX), P.acount = reinterpret_cast<int*>(u + 6 * V3_MMAX);
+  P.attr = u + 7 * V3_MMAX;
+  return P;
+}
+
 struct V3Buf {
+  V3Pos P;
   const OfferA* oa;
   const OfferB* ob;
   const JobRec* jr;
@@ -99,29 +159,31 @@ struct V3Buf {
   int32_t* group_snap;          // [G] st.group_last as the generation began (the helpers' view; the walker publishes to the live array)
   const unsigned long long* job_flags;  // [0..1] jmin bits, [2] != 0: some job has a negative / non-finite request
   unsigned look_ahead;          // jobs the helpers may run ahead of the walker (1 .. V3_R)
-  unsigned pad;
+  unsigned rebuild_gens;        // the order is rebuilt by a sort every that many generations (>= 1)
 };
 
+static_assert(sizeof(float) * V3_MMAX + sizeof(V3Job) * V3_R + 2 * V3_WAVES * COOK_WAVE <= sizeof(unsigned long long) * V3_MMAX, "the ring lives in the sort buffer");
 struct V3Lds {
-  unsigned long long skey[V3_MMAX];   // position -> sort key: class hash (19) | NOT key bits (32: fullest first) | offer (13)
-  unsigned fcm[V3_MMAX];              // position -> free cpus << 16 | free mem under the snapshot, two bf16 rounded UP
+  union {
+    unsigned long long skey[V3_MMAX];   // sort buffer of a rebuild: class hash (19) | NOT key bits (32: fullest first) | offer (13)
+    struct {                            // between rebuilds the same bytes hold:
+      float okey[V3_MMAX];              //   position -> key (>= G of the offer under the snapshot; < 0: dead)
+      V3Job ring[V3_R];
+      unsigned short cand[V3_WAVES][COOK_WAVE];  //   a helper wave's candidate positions of a pass
+    };
+  };
+  unsigned fcm[V3_MMAX];              // position -> free cpus << 16 | free mem under the snapshot, two bf16 rounded UP (0 0: dead)
   unsigned char owner[V3_MMAX];       // offer -> lane of the walker that owns it in this generation, 0xFF none
   V3BlockSum bsum[V3_NBMAX];
   unsigned long long tbits[V3_NBMAX];    // block -> positions touched in this generation
-  unsigned long long rembits[V3_NBMAX];  // (generation change) positions that leave / arrive
-  unsigned long long insbits[V3_NBMAX + 1];
-  unsigned rempre[V3_NBMAX], inspre[V3_NBMAX + 1];
-  unsigned long long ins_key[V3_T], ins_sorted[V3_T];
-  unsigned ins_fcm[V3_T], ins_fcm_sorted[V3_T];
-  V3Job ring[V3_R];
+  unsigned long long dirty[V3_BPL];      // blocks whose summaries the generation change must recompute
   unsigned rstate[V3_R];              // (position + 1) << 2 | 1 ready / 2 settled
-  unsigned n_pos, n_blocks;           // live offers in the order
+  unsigned n_pos, n_blocks;           // positions of the order (dead ones included until the next rebuild)
   unsigned next;                      // next job position a helper takes
   unsigned walk_pos;                  // first job the walker has not consumed
   unsigned gen_first;                 // first job of this generation (cutoff of the group chains)
   unsigned gen_stop, done;
   unsigned sort_n;
-  unsigned n_rem, n_ins;              // lanes the walker hands back / offers that return to the order
   unsigned stop_reason;               // why the epoch ended: 1 list ran out, 2 touched set full, 3 group log full
   unsigned abort;                     // the walker waited for a prepared job longer than V3_WAIT_TICKS (a bug, never the input): give up loudly
 };
@@ -171,7 +233,7 @@ static __device__ __forceinline__ unsigned long long v3_sort_key(const OfferA& a
 }
 
 // ---- bitonic sort of L.skey[0 .. n2) (n2 a power of two), ascending; every thread of the workgroup takes part --------------------
-static __device__ void v3_sort(V3Lds& L, unsigned n2) {
+static __device__ __forceinline__ void v3_sort(V3Lds& L, unsigned n2) {
   const unsigned tid = threadIdx.x, NT = blockDim.x;
   for (unsigned k = 2; k <= n2; k <<= 1) {
     for (unsigned j = k >> 1; j > 0; j >>= 1) {
@@ -190,47 +252,64 @@ static __device__ void v3_sort(V3Lds& L, unsigned n2) {
 }
 
 // ---- block summaries of the order (one wave per block, lane = position); ends with a barrier -------------------------------------------
-static __device__ void v3_summaries(V3Lds& L, const V3Buf& vb) {
+// full: every block, denominators and gpu signatures included (after a rebuild); else only the blocks of L.dirty, and only what a
+// placement changes (keys, free resources).
+static __device__ __forceinline__ void v3_summaries(V3Lds& L, const V3Buf& vb, bool full) {
   const unsigned lane = lane_id(), NW = blockDim.x / COOK_WAVE;
+  const V3Pos& P = vb.P;
   const unsigned n = L.n_pos, nb = (n + COOK_WAVE - 1) / COOK_WAVE;
   for (unsigned b = wave_id(); b < nb; b += NW) {
+    if (!full && !((L.dirty[b >> 6] >> (b & 63u)) & 1ull)) continue;  // (wave-uniform)
     const unsigned p = b * COOK_WAVE + lane;
-    float key = 0.0f, fc = 0.0f, fm = 0.0f, idc = 0.0f, idm = 0.0f;
-    unsigned nkey = 0u, nidc = 0u, nidm = 0u;  // NOT bits of the values whose minimum is wanted (non-negative floats order like their bits)
+    float key = 0.0f, fc = 0.0f, fm = 0.0f;
+    unsigned nkey = 0u;  // NOT bits of the values whose minimum is wanted (non-negative floats order like their bits)
     if (p < n) {
-      const unsigned long long sk = L.skey[p];
+      const float k0 = L.okey[p];
       const unsigned w = L.fcm[p];
-      const OfferA a = vb.oa[(unsigned)(sk & 0x1FFFull)];
-      key = v3_key_f32(sk);
-      fc = v3_free_c(w);
-      fm = v3_free_m(w);
-      const double rdc = 1.0 / (a.oc + a.rc), rdm = 1.0 / (a.om + a.rm);
-      idc = v3_f32_up(rdc * (1.0 + 0x1p-50));
-      idm = v3_f32_up(rdm * (1.0 + 0x1p-50));
-      nkey = ~(unsigned)__float_as_int(key);
-      nidc = ~(unsigned)__float_as_int(v3_f32_down(rdc * (1.0 - 0x1p-50)));
-      nidm = ~(unsigned)__float_as_int(v3_f32_down(rdm * (1.0 - 0x1p-50)));
+      if (k0 >= 0.0f) {
+        key = k0;
+        nkey = ~(unsigned)__float_as_int(k0);
+        fc = v3_free_c(w);
+        fm = v3_free_m(w);
+      }
     }
-    const float kmax = wave_max_f32(key), maxc = wave_max_f32(fc), maxm = wave_max_f32(fm), ri_dc = wave_max_f32(idc), ri_dm = wave_max_f32(idm);
-    const unsigned xkey = wave_max_u32(nkey), xidc = wave_max_u32(nidc), xidm = wave_max_u32(nidm);
-    if (lane == 0) {
-      V3BlockSum s;
-      s.kmax = kmax, s.kmin = __int_as_float((int)~xkey), s.maxc = maxc, s.maxm = maxm;
-      s.ri_dc = ri_dc, s.ri_dm = ri_dm, s.rx_dc = __int_as_float((int)~xidc), s.rx_dm = __int_as_float((int)~xidm);
-      L.bsum[b] = s;
+    const float kmax = wave_max_f32(key), maxc = wave_max_f32(fc), maxm = wave_max_f32(fm);
+    const unsigned xkey = wave_max_u32(nkey);
+    V3BlockSum s;
+    if (full) {
+      float idc = 0.0f, idm = 0.0f;
+      unsigned nidc = 0u, nidm = 0u, sig = 0u;
+      if (p < n) {
+        const double rdc = 1.0 / (P.oc[p] + P.rc[p]), rdm = 1.0 / (P.om[p] + P.rm[p]);
+        idc = v3_f32_up(rdc * (1.0 + 0x1p-50));
+        idm = v3_f32_up(rdm * (1.0 + 0x1p-50));
+        nidc = ~(unsigned)__float_as_int(v3_f32_down(rdc * (1.0 - 0x1p-50)));
+        nidm = ~(unsigned)__float_as_int(v3_f32_down(rdm * (1.0 - 0x1p-50)));
+        sig = v3_offer_sig(P.flags[p], P.gpu_model[p], P.gpu_count[p]);
+      }
+      s.ri_dc = wave_max_f32(idc), s.ri_dm = wave_max_f32(idm);
+      s.rx_dc = __int_as_float((int)~wave_max_u32(nidc)), s.rx_dm = __int_as_float((int)~wave_max_u32(nidm));
+      for (int d = 32; d >= 1; d >>= 1) sig |= (unsigned)__shfl_xor((int)sig, d, COOK_WAVE);
+      s.sig = sig, s.pad = 0u;
+    } else {
+      s = L.bsum[b];
     }
+    s.kmax = kmax, s.kmin = __int_as_float((int)~xkey), s.maxc = maxc, s.maxm = maxm;  // (a block of dead offers: kmin = NaN bits of ~0 -> no room)
+    if (lane == 0) L.bsum[b] = s;
   }
   if (threadIdx.x == 0) L.n_blocks = nb;
   __syncthreads();
 }
 
-// ---- the first generation: every live offer sorted into the order ------------------------------------------------------------------------
-static __device__ void v3_build(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb) {
+// ---- a rebuild: every live offer sorted into the order, its records written out in position order -----------------------------------
+static __device__ __forceinline__ void v3_build(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb) {
   const unsigned tid = threadIdx.x, NT = blockDim.x, lane = lane_id();
   const unsigned M = in.M;
+  const V3Pos& P = vb.P;
   if (tid == 0) L.sort_n = 0;
   for (unsigned v = tid; v < (unsigned)V3_MMAX; v += NT) L.owner[v] = 0xFF;
   for (unsigned b = tid; b < (unsigned)V3_NBMAX; b += NT) L.tbits[b] = 0ull;
+  if (tid < (unsigned)V3_BPL) L.dirty[tid] = 0ull;
   __syncthreads();
   // live offers -> sort keys (dead ones cannot take the smallest job of the call: they never come back)
   for (unsigned v0 = 0; v0 < M; v0 += NT) {
@@ -254,177 +333,44 @@ static __device__ void v3_build(V3Lds& L, const MatchIn& in, const MatchState& s
   for (unsigned x = n + tid; x < n2; x += NT) L.skey[x] = ~0ull;
   __syncthreads();
   v3_sort(L, n2);
-  for (unsigned p = tid; p < n; p += NT) {
-    const unsigned v = (unsigned)(L.skey[p] & 0x1FFFull);
-    const OfferA a = vb.oa[v];
-    L.fcm[p] = v3_pack_free(a.oc - st.ac[v], a.om - st.am[v]);
-  }
-  if (tid == 0) L.n_pos = n;
-  __syncthreads();
-  v3_summaries(L, vb);
-}
-
-// ---- a later generation: the walker's lanes leave their old positions and come back at their new keys ---------------------------------
-// Before the call (wave 0, then a barrier): rembits = the positions of the touched offers, n_rem their number, ins_key / ins_fcm [lane]
-// = new key and free resources of the lane's offer, ~0 for a lane without an offer or with a dead one.
-static __device__ void v3_update(V3Lds& L, const V3Buf& vb) {
-  const unsigned tid = threadIdx.x, NT = blockDim.x, lane = lane_id(), w = wave_id();
-  const unsigned n = L.n_pos, nb = (n + COOK_WAVE - 1) / COOK_WAVE;
-  // wave 0: prefix counts of the leaving positions per block; wave 1 (or 0 again): the arriving keys sorted by rank counting
-  if (w == 0) {
-    unsigned c0 = lane < nb ? (unsigned)__popcll(L.rembits[lane]) : 0u, c1 = lane + 64u < nb ? (unsigned)__popcll(L.rembits[lane + 64u]) : 0u;
-    unsigned s0 = c0, s1 = c1;
-    for (int d = 1; d < COOK_WAVE; d <<= 1) {
-      const unsigned y0 = (unsigned)__shfl_up((int)s0, (unsigned)d, COOK_WAVE), y1 = (unsigned)__shfl_up((int)s1, (unsigned)d, COOK_WAVE);
-      if ((int)lane >= d) s0 += y0, s1 += y1;
-    }
-    const unsigned tot0 = (unsigned)__shfl((int)s0, 63, COOK_WAVE);
-    L.rempre[lane] = s0 - c0;
-    L.rempre[lane + 64u] = tot0 + s1 - c1;
-  }
-  if (w == (NT > (unsigned)COOK_WAVE ? 1u : 0u)) {
-    const unsigned long long key = L.ins_key[lane];
-    unsigned rank = 0;
-    for (unsigned j = 0; j < (unsigned)COOK_WAVE; ++j) {
-      const unsigned long long kj = L.ins_key[j];
-      rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u;
-    }
-    L.ins_sorted[rank] = key;
-    L.ins_fcm_sorted[rank] = L.ins_fcm[lane];
-    const unsigned long long live = __ballot(key != ~0ull);
-    if (lane == 0) L.n_ins = (unsigned)__popcll(live);
-  }
-  for (unsigned b = tid; b < (unsigned)V3_NBMAX + 1u; b += NT) L.insbits[b] = 0ull;
-  __syncthreads();
-  // pass 1: the order without the leaving positions
-  unsigned long long rk[V3_PPT];
-  unsigned rf[V3_PPT], rp[V3_PPT];
+  // (the keys by position and the ring share the sort buffer's bytes: every thread takes its sort keys out first)
+  unsigned long long sk_[V3_PPT];
 #pragma unroll
   for (int i = 0; i < V3_PPT; ++i) {
     const unsigned p = tid + (unsigned)i * NT;
-    rp[i] = 0xFFFFFFFFu;
-    if (p < n) {
-      const unsigned b = p >> 6;
-      const unsigned long long bits = L.rembits[b];
-      if (!((bits >> (p & 63u)) & 1ull)) {
-        rk[i] = L.skey[p];
-        rf[i] = L.fcm[p];
-        rp[i] = p - (L.rempre[b] + (unsigned)__popcll(bits & ((1ull << (p & 63u)) - 1ull)));
-      }
-    }
+    sk_[i] = p < n ? L.skey[p] : ~0ull;
   }
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < V3_PPT; ++i)
-    if (rp[i] != 0xFFFFFFFFu) {
-      L.skey[rp[i]] = rk[i];
-      L.fcm[rp[i]] = rf[i];
-    }
-  __syncthreads();
-  const unsigned n1 = n - L.n_rem, n_ins = L.n_ins;
-  // where the arriving keys go: destination = rank + number of staying keys below
-  if (tid < n_ins) {
-    const unsigned long long key = L.ins_sorted[tid];
-    unsigned lo = 0, hi = n1;
-    while (lo < hi) {
-      const unsigned mid = (lo + hi) >> 1;
-      if (L.skey[mid] < key)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    const unsigned d = lo + tid;
-    atomicOr(&L.insbits[d >> 6], 1ull << (d & 63u));
-  }
-  __syncthreads();
-  const unsigned n2 = n1 + n_ins, nb2 = (n2 + COOK_WAVE - 1) / COOK_WAVE;
-  if (w == 0) {
-    unsigned c0 = lane < nb2 ? (unsigned)__popcll(L.insbits[lane]) : 0u, c1 = lane + 64u < nb2 ? (unsigned)__popcll(L.insbits[lane + 64u]) : 0u;
-    unsigned s0 = c0, s1 = c1;
-    for (int d = 1; d < COOK_WAVE; d <<= 1) {
-      const unsigned y0 = (unsigned)__shfl_up((int)s0, (unsigned)d, COOK_WAVE), y1 = (unsigned)__shfl_up((int)s1, (unsigned)d, COOK_WAVE);
-      if ((int)lane >= d) s0 += y0, s1 += y1;
-    }
-    const unsigned tot0 = (unsigned)__shfl((int)s0, 63, COOK_WAVE);
-    L.inspre[lane] = s0 - c0;
-    L.inspre[lane + 64u] = tot0 + s1 - c1;
-  }
-  __syncthreads();
-  // pass 2: every destination takes an arriving key or the staying key that many places down
 #pragma unroll
   for (int i = 0; i < V3_PPT; ++i) {
-    const unsigned d = tid + (unsigned)i * NT;
-    rp[i] = 0xFFFFFFFFu;
-    if (d < n2) {
-      const unsigned b = d >> 6;
-      const unsigned long long bits = L.insbits[b];
-      const unsigned before = L.inspre[b] + (unsigned)__popcll(bits & ((1ull << (d & 63u)) - 1ull));
-      if ((bits >> (d & 63u)) & 1ull) {
-        rk[i] = L.ins_sorted[before];
-        rf[i] = L.ins_fcm_sorted[before];
-      } else {
-        rk[i] = L.skey[d - before];
-        rf[i] = L.fcm[d - before];
-      }
-      rp[i] = d;
-    }
-  }
-  __syncthreads();
+    const unsigned p = tid + (unsigned)i * NT;
+    if (p >= n) continue;
+    const unsigned long long sk = sk_[i];
+    const unsigned v = (unsigned)(sk & 0x1FFFull);
+    const OfferA a = vb.oa[v];
+    const OfferB o = vb.ob[v];
+    const double ac = st.ac[v], am = st.am[v];
+    P.oc[p] = a.oc, P.om[p] = a.om, P.rc[p] = a.rc, P.rm[p] = a.rm;
+    P.ac[p] = ac, P.am[p] = am;
+    P.gpu_count[p] = o.gpu_count;
+    P.off[p] = v, P.host[p] = o.host, P.gpu_model[p] = o.gpu_model, P.flags[p] = o.flags;
+    P.run_count[p] = o.run_count, P.slack[p] = o.task_slack, P.acount[p] = st.acount[v];
 #pragma unroll
-  for (int i = 0; i < V3_PPT; ++i)
-    if (rp[i] != 0xFFFFFFFFu) {
-      L.skey[rp[i]] = rk[i];
-      L.fcm[rp[i]] = rf[i];
-    }
-  for (unsigned b = tid; b < (unsigned)V3_NBMAX; b += NT) {
-    L.tbits[b] = 0ull;
-    L.rembits[b] = 0ull;
+    for (int x = 0; x < MV_NA; ++x) P.attr[(size_t)x * V3_MMAX + p] = (in.o_attr && (unsigned)x < in.n_attr) ? in.o_attr[(size_t)v * in.n_attr + x] : 0u;
+    L.okey[p] = v3_key_f32(sk);
+    L.fcm[p] = v3_pack_free(a.oc - ac, a.om - am);
   }
-  if (tid == 0) L.n_pos = n2;
+  if (tid == 0) L.n_pos = n;
+  __threadfence_block();
   __syncthreads();
-  v3_summaries(L, vb);
+  v3_summaries(L, vb, true);
 }
 
 // ---- a helper wave prepares job k: candidate list + failure counts under the generation's snapshot ----------------------------------
-// The list lives in lanes 0 .. V3_L - 1 of the wave (one entry each, best first) while it is built.
-struct V3List {
-  double fit;
-  int off;
-  unsigned pos;
-};
-// (cf, ci, cp) wave-uniform.  -> true when the list changed or the candidate was dropped for good (either way it is dealt with)
-static __device__ __forceinline__ void v3_list_insert(V3List& e, unsigned& n_list, bool& more, double cf, int ci, unsigned cp) {
+static __device__ __forceinline__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned k, V3Job& J, unsigned* steps_out,
+                                  unsigned* visits_out, unsigned long long* pc, unsigned long long* pn) {
   const unsigned lane = lane_id();
-  const bool better = lane < n_list && (e.fit > cf || (e.fit == cf && e.off < ci));
-  const unsigned pos = (unsigned)__popcll(__ballot(better));
-  if (pos >= (unsigned)V3_L) {  // (wave-uniform) beyond a full list
-    more = true;
-    return;
-  }
-  const long long fb = __double_as_longlong(e.fit);
-  const unsigned s_lo = (unsigned)scan_fetch_u32<0>((int)(unsigned)(unsigned long long)fb);
-  const unsigned s_hi = (unsigned)scan_fetch_u32<0>((int)(unsigned)((unsigned long long)fb >> 32));
-  const int s_off = scan_fetch_u32<0>(e.off);
-  const unsigned s_pos = (unsigned)scan_fetch_u32<0>((int)e.pos);
-  if (lane > pos && lane < (unsigned)V3_L) {
-    e.fit = __longlong_as_double((long long)(((unsigned long long)s_hi << 32) | (unsigned long long)s_lo));
-    e.off = s_off;
-    e.pos = s_pos;
-  }
-  if (lane == pos) {
-    e.fit = cf;
-    e.off = ci;
-    e.pos = cp;
-  }
-  if (n_list == (unsigned)V3_L)
-    more = true;  // the last entry fell off
-  else
-    ++n_list;
-}
-
-static __device__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned k, V3Job& J, unsigned* steps_out,
-                                  unsigned* visits_out) {
-  const unsigned lane = lane_id();
+  V3P_DECL();
   const JobRec j = vb.jr[k];
   const unsigned jj = in.j_index ? in.j_index[k] : k;
   const bool slow = (j.flags & JF_SLOW) != 0, grouped = (j.flags & JF_GROUPED) != 0, fastc = !slow && (j.flags & JF_FASTC) != 0;
@@ -489,52 +435,84 @@ static __device__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState&
   MatchState st_cut = st;  // the general group check under the snapshot: the chains as the generation began
   st_cut.cutoff = cutoff;
   st_cut.group_last = vb.group_snap;
+  V3P_MARK(pc, pn, 0);
   // ---- which blocks can matter, and how good an offer of each could be (floats, every rounding towards "may matter") ------------------
   const unsigned nb = L.n_blocks, n_pos = L.n_pos;
+  const V3Pos& P = vb.P;
   const float c_up = v3_f32_up(j.c), m_up = v3_f32_up(j.m), c_dn = v3_f32_down(j.c), m_dn = v3_f32_down(j.m);
-  float ub[V3_BPL];
+  const unsigned need_sig = j.g > 0 ? (2u | v3_gpu_bit(j.gpu_model, j.g)) : 1u;
+  float ub[V3_BPL], nh[V3_BPL], th[V3_BPL];  // the lane's blocks: bound of the best fitness (0: cannot matter), need (upper), key threshold of "room"
+  bool dfr[V3_BPL];                          // room by the summary, but no offer of the block serves the job's kind of gpu request
+  bool any_nores = n_pos < in.M;             // some offer fails on resources (the dead ones do)
 #pragma unroll
   for (int q = 0; q < V3_BPL; ++q) {
     const unsigned b = (unsigned)q * COOK_WAVE + lane;
-    ub[q] = 0.0f;
+    ub[q] = nh[q] = th[q] = 0.0f;
+    dfr[q] = false;
     if (b < nb) {
       const V3BlockSum s = L.bsum[b];
       const float need_hi = (c_up * s.ri_dc + m_up * s.ri_dm) * (1.0f + 0x1p-20f);
       const float need_lo = (c_dn * s.rx_dc + m_dn * s.rx_dm) * (1.0f - 0x1p-20f);
       // an offer with room has G <= 2 - need (used = D - free): a block whose smallest key exceeds that holds none
-      const float thr = (2.0f - need_lo) * (1.0f + 0x1p-20f);
+      const float thr = (2.0f - need_lo) * (1.0f + 0x1p-20f) + 0x1p-20f;
       const bool room = s.maxc >= c_dn && s.maxm >= m_dn && s.kmin <= thr;
       if (room) {
         float u = (fminf(s.kmax, thr) + need_hi) * 0.5f * (1.0f + 0x1p-20f) + 0x1p-100f;
         if (!(u < 1.0f)) u = 1.0f;  // (room implies fitness <= 1; also catches a NaN)
-        ub[q] = u;                  // > 0
+        nh[q] = need_hi;
+        th[q] = thr;
+        if (s.sig & need_sig)
+          ub[q] = u;  // > 0
+        else
+          dfr[q] = true;  // every offer of the block fails the gpu-host constraint (or on resources): only the failure counts care
+      } else {
+        any_nores = true;
       }
     }
   }
-  // ---- look at the blocks, best bounds first ------------------------------------------------------------------------------------------------
-  V3List e;
-  e.fit = -1.0, e.off = -1, e.pos = 0u;
+  any_nores = __any(any_nores);
+  V3P_MARK(pc, pn, 1);
+  // ---- the search: lane = CANDIDATE.  Blocks are loaded a group at a time (free resources + keys from LDS give every position an
+  // upper bound `a` of its fitness, 0 = no room); the positions that can still enter the list are packed into the wave's lanes,
+  // evaluated exactly from the position-ordered records, and ranked together with the entries the list already holds.
+  constexpr int NBL = 8;                       // blocks of a group
+  constexpr unsigned CAP = COOK_WAVE - V3_L;   // candidates of a pass (the last V3_L lanes carry the list so far)
+  unsigned short* const cbuf = L.cand[wave_id()];
   unsigned n_list = 0;
+  double t8 = -1.0;   // (fitness, offer) of the list's last entry once it is full
+  int t8_off = -1;
   bool more = false;  // feasible untouched offers exist (or may exist) beyond the list
   unsigned n_res = 0, n_feas = 0, n_zero = 0, steps = 0, visits = 0;
-  for (unsigned guard = 0; guard < 2u * (unsigned)V3_NBMAX; ++guard) {
+  bool counting = false;  // second phase: the deferred blocks, for the failure counts only
+  for (unsigned guard = 0; guard < 4u * (unsigned)V3_NBMAX; ++guard) {
     const float mx = wave_max_f32(fmaxf(ub[0], ub[1]));
-    if (!(mx > 0.0f)) break;  // every block that could matter has been looked at
-    double tail = -1.0;
-    if (n_list == (unsigned)V3_L) {
-      tail = wave_read_lane_f64(e.fit, V3_L - 1);
-      if ((double)mx < tail) {  // nothing left can enter the list (an equal bound could, through a lower offer index)
-        more = true;
-        break;
-      }
+    if (!(mx > 0.0f)) {
+      // every block that could hold a candidate has been dealt with.  The failure counts of a list that claims to be complete must be
+      // exact up to V3_T: the blocks left out for their gpu signature hold offers that fail on constraints if they have room
+      const bool trunc0 = n_list == (unsigned)V3_L && more;
+      if (counting || trunc0) break;
+      const unsigned c2now = n_res - n_feas - n_zero;
+      if (c2now > (unsigned)V3_T && any_nores) break;
+      if (!__any(dfr[0] || dfr[1])) break;
+      counting = true;
+#pragma unroll
+      for (int q = 0; q < V3_BPL; ++q)
+        if (dfr[q]) ub[q] = 0x1p-100f, dfr[q] = false;
+      continue;
     }
-    // the blocks whose bound is close to the best one, at most V3_BATCH of them
-    const float cut = mx * (1.0f - 0x1p-6f);
-    unsigned long long s0 = __ballot(ub[0] >= cut && ub[0] > 0.0f && (double)ub[0] >= tail), s1 = __ballot(ub[1] >= cut && ub[1] > 0.0f && (double)ub[1] >= tail);
-    unsigned bsel[V3_BATCH];
+    if (!counting && n_list == (unsigned)V3_L && (double)mx < t8) {  // nothing left can enter the list (an equal bound could, through a lower offer index)
+      more = true;
+      break;
+    }
+    if (counting && (n_res - n_feas - n_zero) > (unsigned)V3_T && any_nores) break;  // the counts are settled
+    // ---- a group: the blocks whose bound is close to the best one, at most NBL of them -----------------------------------------------
+    const float cut = mx * (1.0f - 0x1p-5f);
+    const double lo0 = (!counting && n_list == (unsigned)V3_L) ? t8 : -1.0;
+    unsigned long long s0 = __ballot(ub[0] >= cut && ub[0] > 0.0f && (double)ub[0] >= lo0), s1 = __ballot(ub[1] >= cut && ub[1] > 0.0f && (double)ub[1] >= lo0);
+    unsigned bsel[NBL];
     int nsel = 0;
 #pragma unroll
-    for (int s = 0; s < V3_BATCH; ++s) {
+    for (int s = 0; s < NBL; ++s) {
       bsel[s] = 0u;
       if (s0 != 0ull) {
         bsel[s] = (unsigned)__ffsll((unsigned long long)s0) - 1u;
@@ -546,130 +524,187 @@ static __device__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState&
         nsel = s + 1;
       }
     }
+    float a[NBL];  // bound of the fitness of position (block s, this lane); 0: no room / nothing there
 #pragma unroll
-    for (int s = 0; s < V3_BATCH; ++s)
-      if (s < nsel && (bsel[s] & 63u) == lane) {
-        if (bsel[s] < 64u)
-          ub[0] = 0.0f;
-        else
-          ub[1] = 0.0f;
-      }
-    // which lanes are worth a look: free resources of the position (rounded up) cover the request
-    unsigned long long rmask[V3_BATCH];
-    bool touched[V3_BATCH];
-    unsigned lv_[V3_BATCH];
-#pragma unroll
-    for (int s = 0; s < V3_BATCH; ++s) {
-      rmask[s] = 0ull;
-      touched[s] = false;
-      lv_[s] = 0u;
-      if (s < nsel) {
-        const unsigned p = bsel[s] * COOK_WAVE + lane;
+    for (int s = 0; s < NBL; ++s) {
+      a[s] = 0.0f;
+      if (s < nsel) {  // (wave-uniform)
+        const unsigned b = bsel[s], src = b & 63u;
+        const float nh_b = __int_as_float(wave_read_lane(__float_as_int(b < 64u ? nh[0] : nh[1]), (int)src));
+        const float th_b = __int_as_float(wave_read_lane(__float_as_int(b < 64u ? th[0] : th[1]), (int)src));
+        if (src == lane) {
+          if (b < 64u)
+            ub[0] = 0.0f;
+          else
+            ub[1] = 0.0f;
+        }
+        const unsigned p = b * COOK_WAVE + lane;
         bool room = false;
         if (p < n_pos) {
           const unsigned w = L.fcm[p];
-          room = v3_free_c(w) >= c_dn && v3_free_m(w) >= m_dn;
-          lv_[s] = (unsigned)(L.skey[p] & 0x1FFFull);
-          touched[s] = ((ld_wg(&L.tbits[bsel[s]]) >> lane) & 1ull) != 0ull;
+          const float kf = L.okey[p];
+          room = v3_free_c(w) >= c_dn && v3_free_m(w) >= m_dn && kf >= 0.0f;
+          if (room) {
+            float u = (fminf(kf, th_b) + nh_b) * 0.5f * (1.0f + 0x1p-20f) + 0x1p-100f;
+            if (!(u < 1.0f)) u = 1.0f;
+            a[s] = u;
+          }
         }
-        rmask[s] = __ballot(room);
+        if (__any(p < n_pos && !room)) any_nores = true;
         ++steps;
       }
     }
-    // evaluate them: lane = offer, exact values
-    double lf[V3_BATCH];
-    int lv[V3_BATCH];
+    V3P_MARK(pc, pn, 2);
+    // ---- passes over the group: whoever can still enter the list -------------------------------------------------------------------------
+    for (unsigned pass = 0; pass < 2u * (unsigned)NBL * COOK_WAVE; ++pass) {
+      if (counting && (n_res - n_feas - n_zero) > (unsigned)V3_T && any_nores) break;  // the counts are settled
+      // (a >= fitness >= t8 is needed to enter a full list; the counting phase wants every position that has room)
+      const float lo_f = (!counting && n_list == (unsigned)V3_L) ? v3_f32_down(t8) : 0.0f;
+      unsigned long long pm[NBL];
+      unsigned total = 0;
 #pragma unroll
-    for (int s = 0; s < V3_BATCH; ++s) {
-      lf[s] = -1.0;
-      lv[s] = -1;
-      if (s < nsel && rmask[s] != 0ull) {  // (wave-uniform)
-        bool res = false, feas = false, zero = false;
-        if ((rmask[s] >> lane) & 1ull) {
-          const unsigned v = lv_[s];
-          const OfferA a = vb.oa[v];
-          const double ac = st.ac[v], am = st.am[v];
-          res = !(ac + j.c > a.oc || am + j.m > a.om);
-          if (res) {
-            const OfferB o = vb.ob[v];
-            bool ok = static_fast(j, o, in, v);
-            if (ok && fastc) {
-              unsigned diff = (E.req_host ^ (o.host + 1u)) & E.wild_host;
+      for (int s = 0; s < NBL; ++s) {
+        pm[s] = __ballot(a[s] > 0.0f && a[s] >= lo_f);
+        total += (unsigned)__popcll(pm[s]);
+      }
+      if (total == 0u) break;
+      if (total > 12u && !counting) {  // the best ones first: a threshold near the group's best bound, widened until enough positions pass
+        float theta = mx * (1.0f - 0x1p-7f);
+        for (int w = 0; w < 3; ++w) {
+          unsigned cnt = 0;
 #pragma unroll
-              for (int x = 0; x < MV_NA; ++x) {
-                const unsigned av = (in.o_attr && (unsigned)x < in.n_attr) ? in.o_attr[(size_t)v * in.n_attr + x] : 0u;
-                diff |= (E.req[x] ^ av) & E.wild[x];
-              }
-              bool hit = E.impossible;
+          for (int s = 0; s < NBL; ++s) cnt += (unsigned)__popcll(__ballot(a[s] >= theta && a[s] > 0.0f && a[s] >= lo_f));
+          if (cnt >= 8u) break;
+          theta = w == 0 ? mx * (1.0f - 0x1p-5f) : (w == 1 ? mx * (1.0f - 0x1p-3f) : 0.0f);
+        }
 #pragma unroll
-              for (int q = 0; q < MV_NC; ++q) hit = hit | (E.novel[q] == o.host);
-              ok = diff == 0u && !hit;
-            }
-            if (ok && slow) ok = static_pass_dev(vb.in_dev, jj, v);
-            if (ok) ok = dyn_fast(j, o, st.acount[v]);
-            if (ok && n_fh > 0) {
-              bool taken = false;
+        for (int s = 0; s < NBL; ++s) pm[s] = __ballot(a[s] >= theta && a[s] > 0.0f && a[s] >= lo_f);
+      }
+      // pack the chosen positions into the lanes (at most CAP; the rest waits for the next pass)
+      unsigned base = 0;
 #pragma unroll
-              for (int q = 0; q < MV_FH; ++q) taken = taken | (fh[q] == o.host);
-              ok = !taken;
-            }
-            if (ok && grouped && n_fh == -2) ok = group_pass_dev(vb.in_dev, st_cut, jj, v);
-            if (ok) {
-              const double fit = fitness_of(a, ac, am, j.c, j.m);
-              if (fit > 0.0) {
-                feas = true;
-                if (!touched[s]) {  // a touched offer is the walker's business: it stays out of the list
-                  lf[s] = fit;
-                  lv[s] = (int)v;
-                }
-              } else {
-                zero = true;
-              }
+      for (int s = 0; s < NBL; ++s) {
+        const unsigned r = base + (unsigned)__popcll(pm[s] & lanemask_lt());
+        const bool take = ((pm[s] >> lane) & 1ull) != 0ull && r < CAP;
+        if (take) {
+          cbuf[r] = (unsigned short)(bsel[s] * COOK_WAVE + lane);
+          a[s] = 0.0f;  // dealt with
+        }
+        base += (unsigned)__popcll(pm[s]);
+      }
+      const unsigned ncand = base < CAP ? base : CAP;
+      wave_sync();
+      V3P_MARK(pc, pn, 3);
+      // ---- exact evaluation: lane = candidate (records by position: a handful of cache lines per array) --------------------------------
+      bool res = false, feas = false, zero = false, pv = false;
+      double fit = -1.0;
+      int off = -1;
+      unsigned pos = 0u;
+      if (lane < ncand) {
+        const unsigned p = cbuf[lane];
+        pos = p;
+        OfferA oa_;
+        oa_.oc = P.oc[p], oa_.om = P.om[p], oa_.rc = P.rc[p], oa_.rm = P.rm[p];
+        const double ac = P.ac[p], am = P.am[p];
+        OfferB o;
+        o.host = P.host[p], o.gpu_model = P.gpu_model[p], o.gpu_count = P.gpu_count[p], o.run_count = P.run_count[p], o.task_slack = P.slack[p],
+        o.flags = P.flags[p], o.pad = 0u;
+        const int acount = P.acount[p];
+        const unsigned v = P.off[p];
+        const bool touched = ((ld_wg(&L.tbits[p >> 6]) >> (p & 63u)) & 1ull) != 0ull;
+        unsigned av[MV_NA];
+#pragma unroll
+        for (int x = 0; x < MV_NA; ++x) av[x] = 0u;
+        if (fastc) {
+#pragma unroll
+          for (int x = 0; x < MV_NA; ++x) av[x] = P.attr[(size_t)x * V3_MMAX + p];
+        }
+        res = !(ac + j.c > oa_.oc || am + j.m > oa_.om);
+        if (res) {
+          bool ok = static_fast(j, o, in, v);
+          if (ok && fastc) {
+            unsigned diff = (E.req_host ^ (o.host + 1u)) & E.wild_host;
+#pragma unroll
+            for (int x = 0; x < MV_NA; ++x) diff |= (E.req[x] ^ av[x]) & E.wild[x];
+            bool hit = E.impossible;
+#pragma unroll
+            for (int q = 0; q < MV_NC; ++q) hit = hit | (E.novel[q] == o.host);
+            ok = diff == 0u && !hit;
+          }
+          if (ok && slow) ok = static_pass_dev(vb.in_dev, jj, v);
+          if (ok) ok = dyn_fast(j, o, acount);
+          if (ok && n_fh > 0) {
+            bool taken = false;
+#pragma unroll
+            for (int q = 0; q < MV_FH; ++q) taken = taken | (fh[q] == o.host);
+            ok = !taken;
+          }
+          if (ok && grouped && n_fh == -2) ok = group_pass_dev(vb.in_dev, st_cut, jj, v);
+          if (ok) {
+            fit = fitness_of(oa_, ac, am, j.c, j.m);
+            if (fit > 0.0) {
+              feas = true;
+              off = (int)v;
+              pv = !touched;  // a touched offer is the walker's business: it stays out of the list
+            } else {
+              zero = true;
             }
           }
         }
-        n_res += (unsigned)__popcll(__ballot(res));
-        n_feas += (unsigned)__popcll(__ballot(feas));
-        n_zero += (unsigned)__popcll(__ballot(zero));
-        ++visits;
       }
-    }
-    // merge the candidates into the list: whoever can still enter it, lowest lane first (within a block that is fullest first)
-#pragma unroll
-    for (int s = 0; s < V3_BATCH; ++s) {
-      if (s < nsel && rmask[s] != 0ull) {
-        for (;;) {
-          double t_fit = -1.0;
-          int t_off = -1;
-          if (n_list == (unsigned)V3_L) {
-            t_fit = wave_read_lane_f64(e.fit, V3_L - 1);
-            t_off = wave_read_lane(e.off, V3_L - 1);
-          }
-          const bool cand = lv[s] >= 0;
-          const bool enters = cand && (n_list < (unsigned)V3_L || lf[s] > t_fit || (lf[s] == t_fit && lv[s] < t_off));
-          const unsigned long long em = __ballot(enters);
-          if (em == 0ull) {
-            if (__any(cand)) more = true;  // feasible untouched offers that did not make the list
-            break;
-          }
-          const int src = __ffsll((unsigned long long)em) - 1;
-          const double cf = wave_read_lane_f64(lf[s], src);
-          const int ci = wave_read_lane(lv[s], src);
-          if ((int)lane == src) lv[s] = -1;
-          v3_list_insert(e, n_list, more, cf, ci, bsel[s] * COOK_WAVE + (unsigned)src);
+      const unsigned n_res_p = (unsigned)__popcll(__ballot(res));
+      n_res += n_res_p;
+      n_feas += (unsigned)__popcll(__ballot(feas));
+      n_zero += (unsigned)__popcll(__ballot(zero));
+      if (n_res_p < ncand) any_nores = true;
+      ++visits;
+      V3P_MARK(pc, pn, 4);
+      // ---- the list so far joins in the last lanes; rank the survivors; the best V3_L are the new list ----------------------------------
+      if (lane >= CAP && lane - CAP < n_list) {
+        const V3Ent x = J.ent[lane - CAP];
+        fit = x.fit, off = x.off, pos = x.pos;
+        pv = true;
+      }
+      const bool beats = pv && (n_list < (unsigned)V3_L || lane >= CAP || fit > t8 || (fit == t8 && off < t8_off));
+      const unsigned long long sm = __ballot(beats);
+      if (__any(pv && !beats)) more = true;  // a feasible untouched offer that did not make the list
+      if ((sm & ((1ull << CAP) - 1ull)) != 0ull) {  // (some candidate enters: otherwise the list stays as it is)
+        unsigned rank = 0;
+        for (unsigned long long mm = sm; mm != 0ull; mm &= mm - 1ull) {
+          const int src = __ffsll((unsigned long long)mm) - 1;
+          const double bf = wave_read_lane_f64(fit, src);
+          const int bo = wave_read_lane(off, src);
+          rank += (beats && (int)lane != src && (bf > fit || (bf == fit && bo < off))) ? 1u : 0u;
+          V3P_COUNT(pn, 8, 1u);
         }
+        const unsigned n_surv = (unsigned)__popcll(sm);
+        wave_sync();  // (the old entries have been read)
+        if (beats && rank < (unsigned)V3_L) {
+          V3Ent x;
+          x.fit = fit, x.off = off, x.pos = pos;
+          J.ent[rank] = x;
+        }
+        if (n_surv > (unsigned)V3_L) more = true;
+        n_list = n_surv < (unsigned)V3_L ? n_surv : (unsigned)V3_L;
+        if (n_list == (unsigned)V3_L) {
+          const unsigned long long lm = __ballot(beats && rank == (unsigned)V3_L - 1u);
+          const int src = __ffsll((unsigned long long)lm) - 1;
+          t8 = wave_read_lane_f64(fit, src);
+          t8_off = wave_read_lane(off, src);
+        }
+        wave_sync();
       }
+      V3P_MARK(pc, pn, 5);
     }
   }
-  // a list that is not full holds EVERY feasible untouched offer: the loop above only leaves blocks out once the list is full
+  // a list that is not full holds EVERY feasible untouched offer: the search only leaves positions out once the list is full
   const bool trunc = n_list == (unsigned)V3_L && more;
-  const unsigned M = in.M;
-  const unsigned c1 = M - n_res, c2 = n_res - n_feas - n_zero, c4 = n_zero;  // exact when every block with room was looked at (!trunc)
-  if (lane < (unsigned)V3_L) {
+  // failure counts under the snapshot, as far as the walker needs them (exact when !trunc): does ANY offer fail on resources; offers
+  // that have room but fail a constraint — exact up to V3_T, "more than V3_T" beyond; offers of zero fitness
+  const unsigned c1 = any_nores ? 1u : 0u, c2 = n_res - n_feas - n_zero, c4 = n_zero;
+  if (lane < (unsigned)V3_L && lane >= n_list) {
     V3Ent x;
-    x.fit = lane < n_list ? e.fit : -1.0;
-    x.off = lane < n_list ? e.off : -1;
-    x.pos = e.pos;
+    x.fit = -1.0, x.off = -1, x.pos = 0u;
     J.ent[lane] = x;
   }
   if (lane == 0) {
@@ -697,11 +732,12 @@ static __device__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState&
   }
   *steps_out = steps;
   *visits_out = visits;
+  V3P_MARK(pc, pn, 6);
 }
 
 // ---- the helper waves of an epoch: take job positions, prepare them, publish them through the ring --------------------------------
-static __device__ void v3_helper(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned* n_steps, unsigned* n_visits,
-                                 unsigned* n_settled) {
+static __device__ __forceinline__ void v3_helper(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned* n_steps, unsigned* n_visits,
+                                 unsigned* n_settled, unsigned long long* pc, unsigned long long* pn) {
   const unsigned lane = lane_id();
   const unsigned K = in.K;
   const unsigned la = vb.look_ahead < 1u ? 1u : (vb.look_ahead > (unsigned)V3_R ? (unsigned)V3_R : vb.look_ahead);
@@ -719,6 +755,7 @@ static __device__ void v3_helper(V3Lds& L, const MatchIn& in, const MatchState& 
     }
     // not too far ahead of the walker (and a free ring slot)
     bool stopped = false;
+    V3P_DECL();
     while (p - ld_wg(&L.walk_pos) >= la) {
       if (ld_wg(&L.gen_stop) != 0u) {
         stopped = true;
@@ -728,9 +765,10 @@ static __device__ void v3_helper(V3Lds& L, const MatchIn& in, const MatchState& 
       SPIN_PAUSE();
     }
     if (stopped) return;
+    V3P_MARK(pc, pn, 7);
     V3Job& J = L.ring[p % (unsigned)V3_R];
     unsigned steps = 0, visits = 0;
-    v3_prepare(L, in, st, vb, p, J, &steps, &visits);
+    v3_prepare(L, in, st, vb, p, J, &steps, &visits, pc, pn);
     wave_sync();
     *n_steps += steps;
     *n_visits += visits;
@@ -784,40 +822,45 @@ static __device__ __forceinline__ void v3_walker_reset(V3Walker& W) {
   W.nT = 0u;
 }
 
-// the touched offers' state back to HBM, and what the order needs to take them back (v3_update)
-static __device__ void v3_walker_writeback(V3Lds& L, const MatchState& st, const V3Buf& vb, V3Walker& W) {
-  const unsigned lane = lane_id();
-  unsigned long long nkey = ~0ull;
-  unsigned nfcm = 0u;
+// the touched offers' state back to HBM (by offer: the call's result; by position: the helpers' view), new keys and free resources
+// in place, their blocks marked for new summaries
+static __device__ __forceinline__ void v3_walker_writeback(V3Lds& L, const MatchState& st, const V3Buf& vb, V3Walker& W) {
+  const V3Pos& P = vb.P;
   if (W.t_v >= 0) {
     st.ac[W.t_v] = W.t_ac;
     st.am[W.t_v] = W.t_am;
     st.acount[W.t_v] = W.t_acount;
+    P.ac[W.t_pos] = W.t_ac;
+    P.am[W.t_pos] = W.t_am;
+    P.acount[W.t_pos] = W.t_acount;
     L.owner[W.t_v] = 0xFF;
     if (W.t_ac + st.jmin[0] > W.t_oc || W.t_am + st.jmin[1] > W.t_om) {
       atomicAnd(&st.alive[(unsigned)W.t_v >> 6], ~(1ull << ((unsigned)W.t_v & 63u)));
+      L.okey[W.t_pos] = -1.0f;
+      L.fcm[W.t_pos] = 0u;
     } else {
       OfferA a;
       a.oc = W.t_oc, a.om = W.t_om, a.rc = W.t_rc, a.rm = W.t_rm, a.inv_dc = W.t_invc, a.inv_dm = W.t_invm;
-      nkey = v3_sort_key(a, W.t_o, W.t_ac, W.t_am, (unsigned)W.t_v);
-      nfcm = v3_pack_free(W.t_oc - W.t_ac, W.t_om - W.t_am);
+      L.okey[W.t_pos] = v3_key_f32(v3_sort_key(a, W.t_o, W.t_ac, W.t_am, (unsigned)W.t_v));
+      L.fcm[W.t_pos] = v3_pack_free(W.t_oc - W.t_ac, W.t_om - W.t_am);
     }
-    atomicOr(&L.rembits[W.t_pos >> 6], 1ull << (W.t_pos & 63u));
+    const unsigned b = W.t_pos >> 6;
+    atomicOr(&L.dirty[b >> 6], 1ull << (b & 63u));
+    L.tbits[b] = 0ull;
   }
-  L.ins_key[lane] = nkey;
-  L.ins_fcm[lane] = nfcm;
-  if (lane == 0) L.n_rem = W.nT;
   v3_walker_reset(W);
 }
 
 // One epoch of the walk: until the jobs are used up (L.done), a list ran out (stop 1), the touched set (2) or the group log (3) is full.
-static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const V3Buf& vb, V3Walker& W) {
+static __device__ __forceinline__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const V3Buf& vb, V3Walker& W, unsigned long long* pc,
+                                               unsigned long long* pn) {
   const unsigned lane = lane_id();
   const unsigned K = in.K;
   unsigned p = L.walk_pos;
   constexpr double EPS_HI = 1.0 + 0x1p-38, EPS_LO = 1.0 - 0x1p-38;
   unsigned stop = 0;
   while (p < K) {
+    V3P_DECL();
     // ---- skip the jobs the helpers settled; wait for the next prepared one ----------------------------------------------------------
     {
       const unsigned long long t0 = cook_ticks();
@@ -852,6 +895,7 @@ static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const
       if (p >= K) break;
     }
     lds_acquire();
+    V3P_MARK(pc, pn, 16);
     const V3Job& J = L.ring[p % (unsigned)V3_R];
     const unsigned info = wave_uniform_u32(J.info), k = p;
     const double c = J.c, m = J.m;
@@ -917,6 +961,7 @@ static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const
     unsigned pe_bits = 8u;
     double pe_fit = 0.0;
     bool decided = false;
+    V3P_MARK(pc, pn, 17);
     // ======== FAST PATH: the touched offers ordered by an fp32 image of the approximate fitness (one DPP max chain) ==================
     {
       const bool sane = a1 >= 0.0 && a2 >= 0.0 && fa > 0x1p-100;
@@ -967,6 +1012,7 @@ static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const
       }
       if (decided) W.fast += 1u;
     }
+    V3P_MARK(pc, pn, 18);
     // ======== GENERAL PATH ===================================================================================================================
     if (!decided) {
       const bool sane = a1 >= 0.0 && a2 >= 0.0 && fa > 0.0;
@@ -1074,10 +1120,13 @@ static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const
         }
       } while (0);
     }
+    if (!decided || exhausted) V3P_MARK(pc, pn, 19);
     if (exhausted) {
       stop = 1;
       break;
     }
+    const bool prof_new_ = win_lane < 0 && win >= 0;
+    (void)prof_new_;
     // ---- commit ---------------------------------------------------------------------------------------------------------------------------
     if (win_lane < 0 && win >= 0 && W.nT == (unsigned)V3_T) {
       stop = 2;  // no free lane for another touched offer: a new generation starts with this job
@@ -1097,20 +1146,23 @@ static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const
       }
       win = wave_read_lane(W.t_v, win_lane);
     } else if (win >= 0) {
-      if (lane == W.nT) {  // the next free lane takes ownership: the offer's record from HBM (untouched: the snapshot is its state)
-        const OfferA a = vb.oa[win];
-        W.t_o = vb.ob[win];
+      if (lane == W.nT) {  // the next free lane takes ownership: the offer's records by position (untouched: the snapshot is its state)
+        const V3Pos& P = vb.P;
+        const unsigned q = win_pos;
         W.t_v = win;
-        W.t_pos = win_pos;
-        W.t_oc = a.oc, W.t_om = a.om, W.t_rc = a.rc, W.t_rm = a.rm, W.t_invc = a.inv_dc, W.t_invm = a.inv_dm;
-        W.t_ac0 = st.ac[win], W.t_am0 = st.am[win], W.t_acount0 = st.acount[win];
+        W.t_pos = q;
+        W.t_oc = P.oc[q], W.t_om = P.om[q], W.t_rc = P.rc[q], W.t_rm = P.rm[q];
+        W.t_ac0 = P.ac[q], W.t_am0 = P.am[q], W.t_acount0 = P.acount[q];
+        W.t_o.host = P.host[q], W.t_o.gpu_model = P.gpu_model[q], W.t_o.gpu_count = P.gpu_count[q], W.t_o.run_count = P.run_count[q],
+        W.t_o.task_slack = P.slack[q], W.t_o.flags = P.flags[q], W.t_o.pad = 0u;
+#pragma unroll
+        for (int x = 0; x < MV_NA; ++x) W.t_attr[x] = P.attr[(size_t)x * V3_MMAX + q];
+        W.t_invc = 1.0 / (W.t_oc + W.t_rc), W.t_invm = 1.0 / (W.t_om + W.t_rm);  // (as match_pack_offers computes OfferA::inv_dc / inv_dm)
         W.t_ac = W.t_ac0 + c;
         W.t_am = W.t_am0 + m;
         W.t_acount = W.t_acount0 + 1;
         W.t_basec = W.t_rc + W.t_ac;
         W.t_basem = W.t_rm + W.t_am;
-#pragma unroll
-        for (int x = 0; x < MV_NA; ++x) W.t_attr[x] = (in.o_attr && (unsigned)x < in.n_attr) ? in.o_attr[(size_t)win * in.n_attr + x] : 0u;
         L.owner[win] = (unsigned char)W.nT;
         st_wg(&L.tbits[win_pos >> 6], L.tbits[win_pos >> 6] | (1ull << (win_pos & 63u)));  // (this wave is the only writer)
       }
@@ -1198,6 +1250,7 @@ static __device__ void v3_walk(V3Lds& L, const MatchIn& in, MatchState st, const
     }
     ++p;
     if (lane == 0) st_wg(&L.walk_pos, p);
+    V3P_MARK(pc, pn, (win < 0 ? 22 : (prof_new_ ? 21 : 20)));
   }
   // ---- end of the epoch -----------------------------------------------------------------------------------------------------------------------
   if (stop >= 2u || p >= K) v3_walker_writeback(L, st, vb, W);  // (at the end of the call too: the state arrays are the call's result)
@@ -1218,10 +1271,11 @@ struct PoolCtx3 {
 };
 
 // ---- one workgroup per pool (blockIdx.x = pool), one launch per match call -----------------------------------------------------------
-__global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3* __restrict__ ctx) {
+// (the context travels BY VALUE: pointers that arrive as kernel arguments are known to be global memory, pointers loaded from a context
+// record in memory are not, and every access through them would be a flat one)
+__global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3 C) {
   COOK_BLOCK_LDS(lds, sizeof(V3Lds));
   V3Lds& L = *reinterpret_cast<V3Lds*>(lds);
-  const PoolCtx3& C = ctx[blockIdx.x];
   const MatchIn& in = C.in;
   const MatchState st = C.st;
   const V3Buf vb = C.vb;
@@ -1236,10 +1290,8 @@ __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3* __restric
     L.gen_first = 0u;
     L.abort = 0u;
     L.stop_reason = 0u;
-    L.n_rem = L.n_ins = 0u;
     L.sort_n = vb.job_flags[2] != 0ull ? 1u : 0u;  // (borrowed as the "bad input" flag until the first generation)
   }
-  for (unsigned b = tid; b < (unsigned)V3_NBMAX; b += NT) L.rembits[b] = 0ull;
   __syncthreads();
   {
     bool bad = false;
@@ -1256,22 +1308,26 @@ __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3* __restric
     return;
   }
   __syncthreads();
-  V3Walker W;
-  v3_walker_reset(W);
-  W.matched = W.head_matched = W.walked = W.opens = W.fast = 0u;
-  W.wait_ticks = 0ull;
+  // Wave 0 walks, the others prepare; the two roles run their own copy of the epoch loop (same barriers, same collective steps), so
+  // that the walker's lanes — registers that live across epochs — are no burden on the helpers' code.
   unsigned n_steps = 0, n_visits = 0, n_settled = 0, gens = 0, epochs = 0, s_full = 0, s_list = 0, s_log = 0;
   unsigned long long t_regen = 0ull, t_flush = 0ull;
-  unsigned reason = 2u;  // (the first epoch builds the order)
-  for (;;) {
-    // ---- between epochs: a new generation (order rebuilt or updated) or only a ring flush -----------------------------------------------
+  unsigned long long pc[V3_NPROF], pn[V3_NPROF];
+  for (int i = 0; i < V3_NPROF; ++i) pc[i] = pn[i] = 0ull;
+  const unsigned rebuild_gens = vb.rebuild_gens < 1u ? 1u : vb.rebuild_gens;
+  unsigned w_matched = 0, w_head = 0, w_walked = 0, w_opens = 0, w_fast = 0;
+  unsigned long long w_wait = 0ull;
+  // between epochs: a new generation (order rebuilt or updated) or only a ring flush; ends with a barrier
+  auto between = [&](unsigned reason) {
     const unsigned long long tr0 = cook_ticks();
     if (reason >= 2u) {
       for (unsigned x = tid; x < in.G; x += NT) vb.group_snap[x] = ld_agent(&st.group_last[x]);
-      if (gens == 0u)
+      if (gens % rebuild_gens == 0u) {
         v3_build(L, in, st, vb);  // (ends with a barrier)
-      else
-        v3_update(L, vb);
+      } else {
+        v3_summaries(L, vb, false);
+        if (tid < (unsigned)V3_BPL) L.dirty[tid] = 0ull;
+      }
       ++gens;
     }
     for (unsigned x = tid; x < (unsigned)V3_R; x += NT) L.rstate[x] = 0u;
@@ -1285,17 +1341,38 @@ __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3* __restric
     else
       t_flush += cook_ticks() - tr0;
     ++epochs;
-    if (tid < COOK_WAVE)
-      v3_walk(L, in, st, vb, W);
-    else
-      v3_helper(L, in, st, vb, &n_steps, &n_visits, &n_settled);
+  };
+  auto after = [&]() -> unsigned {  // -> why the epoch ended
     __syncthreads();
-    reason = L.stop_reason;
+    const unsigned reason = L.stop_reason;
     s_list += reason == 1u ? 1u : 0u;
     s_full += reason == 2u ? 1u : 0u;
     s_log += reason == 3u ? 1u : 0u;
-    if (L.done != 0u) break;
-    __syncthreads();
+    return reason;
+  };
+  if (tid < COOK_WAVE) {
+    V3Walker W;
+    v3_walker_reset(W);
+    W.matched = W.head_matched = W.walked = W.opens = W.fast = 0u;
+    W.wait_ticks = 0ull;
+    unsigned reason = 2u;  // (the first epoch builds the order)
+    for (;;) {
+      between(reason);
+      v3_walk(L, in, st, vb, W, pc, pn);
+      reason = after();
+      if (L.done != 0u) break;
+      __syncthreads();
+    }
+    w_matched = W.matched, w_head = W.head_matched, w_walked = W.walked, w_opens = W.opens, w_fast = W.fast, w_wait = W.wait_ticks;
+  } else {
+    unsigned reason = 2u;
+    for (;;) {
+      between(reason);
+      v3_helper(L, in, st, vb, &n_steps, &n_visits, &n_settled, pc, pn);
+      reason = after();
+      if (L.done != 0u) break;
+      __syncthreads();
+    }
   }
   if (L.abort != 0u) {
     if (tid == 0) vb.ctl->error = 2u;
@@ -1307,20 +1384,27 @@ __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3* __restric
     atomicAdd(&vb.ctl->visits, n_visits);
     atomicAdd(&vb.ctl->settled, n_settled);
   }
+#ifdef COOK_V3_PROF
+  if (lane == 0)
+    for (int i = 0; i < V3_NPROF; ++i) {
+      if (pc[i]) atomicAdd(&vb.ctl->prof_cyc[i], pc[i]);
+      if (pn[i]) atomicAdd(&vb.ctl->prof_cnt[i], pn[i]);
+    }
+#endif
   if (tid == 0) {
     V3Ctl* c = vb.ctl;
     c->head = in.K;
-    c->matched = W.matched;
-    c->head_matched = W.head_matched;
+    c->matched = w_matched;
+    c->head_matched = w_head;
     c->generations = gens;
     c->epochs = epochs;
     c->stop_full = s_full, c->stop_list = s_list, c->stop_log = s_log, c->stop_other = 0;
-    c->walked = W.walked;
-    c->opens = W.opens;
-    c->fast = W.fast;
+    c->walked = w_walked;
+    c->opens = w_opens;
+    c->fast = w_fast;
     c->t_total = cook_ticks() - tk0;
     c->t_regen = t_regen;
     c->t_flush = t_flush;
-    c->t_walk_wait = W.wait_ticks;
+    c->t_walk_wait = w_wait;
   }
 }
