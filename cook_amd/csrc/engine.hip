@@ -182,6 +182,7 @@ struct cook_engine {
   // match_v3 (one persistent workgroup per pool)
   DArr<V3Ctl> v3_ctl;
   DArr<char> v3_pos;          // the offers' records in position order (V3Pos)
+  DArr<char> v3_glob;         // what the walker workgroup and the helper workgroups share (V3Glob)
   DArr<int32_t> v3_group_snap;
   void* h_v3 = nullptr;      // pinned: PoolCtx3 going out, V3Ctl coming back
   V3Ctl last_v3{};
@@ -904,10 +905,24 @@ bool match_v3_run(cook_engine* e, const MatchIn& in, const MatchState& st, const
     }();
     h.vb.rebuild_gens = rg;
     h.vb.P = v3_pos_carve(e->v3_pos.ensure(V3_POS_BYTES));
+    char* gbase = e->v3_glob.ensure(V3_GLOB_BYTES);
+    h.vb.G = v3_glob_carve(gbase);
+    COOK_HIP(hipMemsetAsync(gbase + V3_GLOB_CTL_OFF, 0, V3_GLOB_CTL_BYTES, e->stream));  // flags, control words, acknowledgements
   }
+  static const unsigned n_hwg = [] {  // helper workgroups of the launch (tuning runs: COOK_V3_HELPERS)
+    const char* s = std::getenv("COOK_V3_HELPERS");
+    const long v = s ? std::atol(s) : 0;
+    const long cap = V3_HW_MAX / V3_WAVES;
+    return (unsigned)(v >= 1 ? (v > cap ? cap : v) : COOK_SHAPE(6, 2));
+  }();
+  h.vb.n_helper_waves = n_hwg * (unsigned)V3_WAVES;
+  h.vb.pad = 0;
   if (!e->h_v3) COOK_HIP(hipHostMalloc(&e->h_v3, sizeof(PoolCtx3) + sizeof(V3Ctl), hipHostMallocDefault));
   COOK_HIP(hipMemsetAsync(h.vb.ctl, 0, sizeof(V3Ctl), e->stream));
-  KL("match_v3", match_v3, 1, V3_THREADS, h);
+  {  // workgroup 0 walks, the others prepare: they talk through global memory, so all of them must be resident at once
+    ProfScope _ps(e, "match_v3");
+    COOK_LAUNCH_COOP(match_v3, 1u + n_hwg, V3_THREADS, e->stream, h);
+  }
   V3Ctl* hc = (V3Ctl*)((char*)e->h_v3 + sizeof(PoolCtx3));
   COOK_HIP(hipMemcpyAsync(hc, h.vb.ctl, sizeof(V3Ctl), hipMemcpyDeviceToHost, e->stream));
   sync(e);

@@ -46,6 +46,7 @@ template <class T>
 static __device__ __forceinline__ void st_wg(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
 #define SPIN_PAUSE_SHORT() __builtin_amdgcn_s_sleep(1)
+#define SPIN_PAUSE_FAR() __builtin_amdgcn_s_sleep(6)  // between polls of a word in global memory (another workgroup writes it)
 // LDS hand-off between waves of one workgroup without a workgroup barrier (the evaluator teams' barrier)
 // (fences of the LDS address space only: a plain workgroup fence also waits for the wave's outstanding GLOBAL stores — a result store to
 // HBM takes over a thousand cycles to be acknowledged, and the placement walk has one in flight at every hand-off)

@@ -32,9 +32,9 @@
 #include "match_v2.hpp"
 
 #ifndef COOK_V3_THREADS
-#define COOK_V3_THREADS COOK_SHAPE(768, 128)
+#define COOK_V3_THREADS COOK_SHAPE(256, 128)
 #endif
-constexpr int V3_THREADS = COOK_V3_THREADS;           // wave 0 walks, the others prepare jobs
+constexpr int V3_THREADS = COOK_V3_THREADS;           // threads of a workgroup (workgroup 0: wave 0 walks, the others feed it; the rest: helpers)
 constexpr int V3_WAVES = V3_THREADS / COOK_WAVE;
 constexpr int V3_MMAX = 8192;                          // offers per pool (the offer index is 13 bits of the sort key)
 constexpr int V3_NBMAX = V3_MMAX / COOK_WAVE;          // blocks of the order
@@ -49,6 +49,15 @@ constexpr int V3_L = COOK_V3_L;                        // list entries per job (
 #endif
 constexpr int V3_R = COOK_V3_R;                        // ring entries (the emulated tests: small, so that the ring wraps all the time)
 constexpr int V3_T = COOK_WAVE;                        // touched offers per generation = lanes of the walking wave
+#ifndef COOK_V3_GR
+#define COOK_V3_GR COOK_SHAPE(256, 16)
+#endif
+constexpr int V3_GR = COOK_V3_GR;                      // entries of a bank of the global ring (helpers -> walker workgroup)
+constexpr int V3_NBANK = 4;                            // banks: epoch e uses bank e % 4, so a straggler of epoch e - 1 .. e - 3 cannot clash
+constexpr int V3_HW_MAX = 512;                         // helper waves of a launch, at most
+constexpr unsigned V3_E_DONE = 0xFFFFFFFFu;            // "epoch" that tells the helpers the call is over
+constexpr int V3_JOB_WORDS = 40;                       // sizeof(V3Job) / 8
+constexpr int V3_DLOG = 16;                            // generations whose dirty-block masks are kept for helpers that fell behind
 constexpr int V3_BATCH = 4;                            // blocks a helper looks at per step (their loads are in flight together)
 static_assert(V3_L <= 16 && V3_BPL == 2 && V3_R <= COOK_WAVE, "shapes");
 
@@ -148,8 +157,48 @@ static inline V3Pos v3_pos_carve(char* base) {  // (host) the arrays inside one 
   return P;
 }
 
+// What the walker workgroup and the helper workgroups share (global memory, one allocation per engine).  Payload that changes only at
+// a generation change (fcm .. gen_first) is written with plain stores and handed over by an agent-scope release / acquire pair; the
+// ring, its flags and the control words are sc1 (write-through, L1-bypassing) accesses on both sides: no fences on the per-job path.
+struct V3Glob {
+  unsigned* fcm;                // [V3_MMAX] master copies of the helpers' LDS arrays
+  float* okey;                  // [V3_MMAX]
+  V3BlockSum* bsum;             // [V3_NBMAX]
+  unsigned long long* tbits;    // [V3_NBMAX] positions touched in this generation (sc1)
+  unsigned long long* dlog;     // [V3_DLOG][V3_BPL] blocks a generation changed (all ones: everything)
+  unsigned* hdr;                // [0] n_pos, [1] gen_first  (payload)
+  V3Job* ring;                  // [V3_NBANK][V3_GR]
+  unsigned long long* rflag;    // [V3_NBANK][V3_GR]: (job + 1) | (epoch << 5 | failure bits << 2 | 1 ready / 2 settled) << 32
+  unsigned long long* next64;   // epoch << 32 | next job position (helpers fetch-and-add it); epoch 0: not started
+  unsigned* walk_pos;           // first job the walker has not consumed (published by the walker workgroup's feeder wave)
+  unsigned* gen;                // generation number
+  unsigned* ack;                // [V3_HW_MAX] the epoch each helper wave last took a job in
+};
+constexpr size_t V3_GLOB_CTL_OFF = (size_t)V3_MMAX * 8 + sizeof(V3BlockSum) * V3_NBMAX + 8 * V3_NBMAX + 8 * V3_DLOG * V3_BPL + 64 + sizeof(V3Job) * V3_NBANK * V3_GR;
+constexpr size_t V3_GLOB_CTL_BYTES = 8 * (size_t)V3_NBANK * V3_GR + 64 + 4 * V3_HW_MAX;  // flags + control words: zeroed before every call
+constexpr size_t V3_GLOB_BYTES = V3_GLOB_CTL_OFF + V3_GLOB_CTL_BYTES;
+static inline V3Glob v3_glob_carve(char* base) {  // (host)
+  V3Glob G;
+  char* q = base;
+  G.fcm = reinterpret_cast<unsigned*>(q), q += (size_t)V3_MMAX * 4;
+  G.okey = reinterpret_cast<float*>(q), q += (size_t)V3_MMAX * 4;
+  G.bsum = reinterpret_cast<V3BlockSum*>(q), q += sizeof(V3BlockSum) * V3_NBMAX;
+  G.tbits = reinterpret_cast<unsigned long long*>(q), q += 8 * V3_NBMAX;
+  G.dlog = reinterpret_cast<unsigned long long*>(q), q += 8 * V3_DLOG * V3_BPL;
+  G.hdr = reinterpret_cast<unsigned*>(q), q += 64;
+  G.ring = reinterpret_cast<V3Job*>(q), q += sizeof(V3Job) * V3_NBANK * V3_GR;
+  // ---- zeroed before every call from here on (V3_GLOB_CTL_OFF) ----
+  G.rflag = reinterpret_cast<unsigned long long*>(q), q += 8 * (size_t)V3_NBANK * V3_GR;
+  G.next64 = reinterpret_cast<unsigned long long*>(q);
+  G.walk_pos = reinterpret_cast<unsigned*>(q + 8);
+  G.gen = reinterpret_cast<unsigned*>(q + 12), q += 64;
+  G.ack = reinterpret_cast<unsigned*>(q);
+  return G;
+}
+
 struct V3Buf {
   V3Pos P;
+  V3Glob G;
   const OfferA* oa;
   const OfferB* ob;
   const JobRec* jr;
@@ -160,18 +209,18 @@ struct V3Buf {
   const unsigned long long* job_flags;  // [0..1] jmin bits, [2] != 0: some job has a negative / non-finite request
   unsigned look_ahead;          // jobs the helpers may run ahead of the walker (1 .. V3_R)
   unsigned rebuild_gens;        // the order is rebuilt by a sort every that many generations (>= 1)
+  unsigned n_helper_waves;      // (gridDim.x - 1) * waves per workgroup
+  unsigned pad;
 };
 
-static_assert(sizeof(float) * V3_MMAX + sizeof(V3Job) * V3_R + 2 * V3_WAVES * COOK_WAVE <= sizeof(unsigned long long) * V3_MMAX, "the ring lives in the sort buffer");
+static_assert(sizeof(V3Job) * V3_R <= sizeof(unsigned long long) * V3_MMAX, "the ring lives in the sort buffer");
+static_assert(sizeof(V3Job) == 8 * V3_JOB_WORDS, "a ring entry moves as 40 8-byte words");
 struct V3Lds {
   union {
     unsigned long long skey[V3_MMAX];   // sort buffer of a rebuild: class hash (19) | NOT key bits (32: fullest first) | offer (13)
-    struct {                            // between rebuilds the same bytes hold:
-      float okey[V3_MMAX];              //   position -> key (>= G of the offer under the snapshot; < 0: dead)
-      V3Job ring[V3_R];
-      unsigned short cand[V3_WAVES][COOK_WAVE];  //   a helper wave's candidate positions of a pass
-    };
+    V3Job ring[V3_R];                   // between rebuilds the same bytes hold the ring
   };
+  float okey[V3_MMAX];                  // position -> key (>= G of the offer under the snapshot; < 0: dead)
   unsigned fcm[V3_MMAX];              // position -> free cpus << 16 | free mem under the snapshot, two bf16 rounded UP (0 0: dead)
   unsigned char owner[V3_MMAX];       // offer -> lane of the walker that owns it in this generation, 0xFF none
   V3BlockSum bsum[V3_NBMAX];
@@ -186,6 +235,16 @@ struct V3Lds {
   unsigned sort_n;
   unsigned stop_reason;               // why the epoch ended: 1 list ran out, 2 touched set full, 3 group log full
   unsigned abort;                     // the walker waited for a prepared job longer than V3_WAIT_TICKS (a bug, never the input): give up loudly
+};
+struct V3HLds {  // a helper workgroup: its copy of what the search reads, refreshed at every generation change
+  float okey[V3_MMAX];
+  unsigned fcm[V3_MMAX];
+  V3BlockSum bsum[V3_NBMAX];
+  V3Job stage[V3_WAVES];                     // a wave builds its entry here before it goes out
+  unsigned short cand[V3_WAVES][COOK_WAVE];  // a wave's candidate positions of a pass
+  unsigned n_pos, n_blocks, gen_first;
+  unsigned gen_loaded;                       // generation the copy stands for
+  unsigned lock;                             // the wave that refreshes the copy holds it
 };
 constexpr unsigned long long V3_WAIT_TICKS = 150000000ull;  // 1.5 s of the 100 MHz clock
 
@@ -333,19 +392,8 @@ static __device__ __forceinline__ void v3_build(V3Lds& L, const MatchIn& in, con
   for (unsigned x = n + tid; x < n2; x += NT) L.skey[x] = ~0ull;
   __syncthreads();
   v3_sort(L, n2);
-  // (the keys by position and the ring share the sort buffer's bytes: every thread takes its sort keys out first)
-  unsigned long long sk_[V3_PPT];
-#pragma unroll
-  for (int i = 0; i < V3_PPT; ++i) {
-    const unsigned p = tid + (unsigned)i * NT;
-    sk_[i] = p < n ? L.skey[p] : ~0ull;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < V3_PPT; ++i) {
-    const unsigned p = tid + (unsigned)i * NT;
-    if (p >= n) continue;
-    const unsigned long long sk = sk_[i];
+  for (unsigned p = tid; p < n; p += NT) {
+    const unsigned long long sk = L.skey[p];
     const unsigned v = (unsigned)(sk & 0x1FFFull);
     const OfferA a = vb.oa[v];
     const OfferB o = vb.ob[v];
@@ -367,7 +415,7 @@ static __device__ __forceinline__ void v3_build(V3Lds& L, const MatchIn& in, con
 }
 
 // ---- a helper wave prepares job k: candidate list + failure counts under the generation's snapshot ----------------------------------
-static __device__ __forceinline__ void v3_prepare(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned k, V3Job& J, unsigned* steps_out,
+static __device__ __forceinline__ void v3_prepare(V3HLds& H, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned k, V3Job& J, unsigned* steps_out,
                                   unsigned* visits_out, unsigned long long* pc, unsigned long long* pn) {
   const unsigned lane = lane_id();
   V3P_DECL();
@@ -413,7 +461,7 @@ static __device__ __forceinline__ void v3_prepare(V3Lds& L, const MatchIn& in, c
   int n_fh = -1, glast = -1;
 #pragma unroll
   for (int q = 0; q < MV_FH; ++q) fh[q] = 0xFFFFFFFFu;
-  const int cutoff = (int)L.gen_first;
+  const int cutoff = (int)H.gen_first;
   if (j.group != 0xFFFFFFFFu) glast = vb.group_snap[j.group];  // the group's last job placed BEFORE this generation (later ones: the walker's log)
   if (grouped && gtype == 1u) {
     n_fh = 0;
@@ -437,7 +485,7 @@ static __device__ __forceinline__ void v3_prepare(V3Lds& L, const MatchIn& in, c
   st_cut.group_last = vb.group_snap;
   V3P_MARK(pc, pn, 0);
   // ---- which blocks can matter, and how good an offer of each could be (floats, every rounding towards "may matter") ------------------
-  const unsigned nb = L.n_blocks, n_pos = L.n_pos;
+  const unsigned nb = H.n_blocks, n_pos = H.n_pos;
   const V3Pos& P = vb.P;
   const float c_up = v3_f32_up(j.c), m_up = v3_f32_up(j.m), c_dn = v3_f32_down(j.c), m_dn = v3_f32_down(j.m);
   const unsigned need_sig = j.g > 0 ? (2u | v3_gpu_bit(j.gpu_model, j.g)) : 1u;
@@ -450,7 +498,7 @@ static __device__ __forceinline__ void v3_prepare(V3Lds& L, const MatchIn& in, c
     ub[q] = nh[q] = th[q] = 0.0f;
     dfr[q] = false;
     if (b < nb) {
-      const V3BlockSum s = L.bsum[b];
+      const V3BlockSum s = H.bsum[b];
       const float need_hi = (c_up * s.ri_dc + m_up * s.ri_dm) * (1.0f + 0x1p-20f);
       const float need_lo = (c_dn * s.rx_dc + m_dn * s.rx_dm) * (1.0f - 0x1p-20f);
       // an offer with room has G <= 2 - need (used = D - free): a block whose smallest key exceeds that holds none
@@ -477,7 +525,7 @@ static __device__ __forceinline__ void v3_prepare(V3Lds& L, const MatchIn& in, c
   // evaluated exactly from the position-ordered records, and ranked together with the entries the list already holds.
   constexpr int NBL = 8;                       // blocks of a group
   constexpr unsigned CAP = COOK_WAVE - V3_L;   // candidates of a pass (the last V3_L lanes carry the list so far)
-  unsigned short* const cbuf = L.cand[wave_id()];
+  unsigned short* const cbuf = H.cand[wave_id()];
   unsigned n_list = 0;
   double t8 = -1.0;   // (fitness, offer) of the list's last entry once it is full
   int t8_off = -1;
@@ -541,8 +589,8 @@ static __device__ __forceinline__ void v3_prepare(V3Lds& L, const MatchIn& in, c
         const unsigned p = b * COOK_WAVE + lane;
         bool room = false;
         if (p < n_pos) {
-          const unsigned w = L.fcm[p];
-          const float kf = L.okey[p];
+          const unsigned w = H.fcm[p];
+          const float kf = H.okey[p];
           room = v3_free_c(w) >= c_dn && v3_free_m(w) >= m_dn && kf >= 0.0f;
           if (room) {
             float u = (fminf(kf, th_b) + nh_b) * 0.5f * (1.0f + 0x1p-20f) + 0x1p-100f;
@@ -611,7 +659,7 @@ static __device__ __forceinline__ void v3_prepare(V3Lds& L, const MatchIn& in, c
         o.flags = P.flags[p], o.pad = 0u;
         const int acount = P.acount[p];
         const unsigned v = P.off[p];
-        const bool touched = ((ld_wg(&L.tbits[p >> 6]) >> (p & 63u)) & 1ull) != 0ull;
+        const bool touched = ((ld_agent(&vb.G.tbits[p >> 6]) >> (p & 63u)) & 1ull) != 0ull;
         unsigned av[MV_NA];
 #pragma unroll
         for (int x = 0; x < MV_NA; ++x) av[x] = 0u;
@@ -735,40 +783,109 @@ static __device__ __forceinline__ void v3_prepare(V3Lds& L, const MatchIn& in, c
   V3P_MARK(pc, pn, 6);
 }
 
-// ---- the helper waves of an epoch: take job positions, prepare them, publish them through the ring --------------------------------
-static __device__ __forceinline__ void v3_helper(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned* n_steps, unsigned* n_visits,
-                                 unsigned* n_settled, unsigned long long* pc, unsigned long long* pn) {
+// ---- a helper wave (any workgroup but 0): take job positions, prepare them, publish them through the global ring ---------------------
+// the workgroup's copy of the order: brought up to generation g by the first wave that notices (the others wait for it; a wave still
+// searching under the old generation reads a torn copy, but its job belongs to an epoch that is over and is thrown away)
+static __device__ __forceinline__ void v3_helper_refresh(V3HLds& H, const V3Buf& vb, unsigned g) {
   const unsigned lane = lane_id();
-  const unsigned K = in.K;
-  const unsigned la = vb.look_ahead < 1u ? 1u : (vb.look_ahead > (unsigned)V3_R ? (unsigned)V3_R : vb.look_ahead);
-  for (;;) {
-    if (ld_wg(&L.gen_stop) != 0u) return;
-    unsigned p = 0;
-    if (lane == 0) p = atomicAdd(&L.next, 1u);
-    p = (unsigned)__shfl((int)p, 0, COOK_WAVE);
-    if (p >= K) {  // nothing left to prepare: wait for the end of the epoch
-      while (ld_wg(&L.gen_stop) == 0u) {
-        EMU_SITE("v3 helper: idle");
-        SPIN_PAUSE();
-      }
-      return;
-    }
-    // not too far ahead of the walker (and a free ring slot)
-    bool stopped = false;
-    V3P_DECL();
-    while (p - ld_wg(&L.walk_pos) >= la) {
-      if (ld_wg(&L.gen_stop) != 0u) {
-        stopped = true;
-        break;
-      }
-      EMU_SITE("v3 helper: ring full");
+  const V3Glob& G = vb.G;
+  unsigned got = 0;
+  if (lane == 0) got = atomicCAS(&H.lock, 0u, 1u) == 0u ? 1u : 0u;
+  got = (unsigned)__shfl((int)got, 0, COOK_WAVE);
+  if (!got) {
+    while (ld_wg(&H.gen_loaded) != g) {
+      EMU_SITE("v3 helper: waiting for the workgroup's copy");
       SPIN_PAUSE();
     }
-    if (stopped) return;
+    lds_acquire();
+    return;
+  }
+  const unsigned have = ld_wg(&H.gen_loaded);
+  if (have != g) {
+    agent_acquire();
+    // the blocks that changed since generation `have` (everything when the log no longer reaches back that far)
+    unsigned long long d0 = 0ull, d1 = 0ull;
+    if (g - have > (unsigned)V3_DLOG) {
+      d0 = d1 = ~0ull;
+    } else {
+      for (unsigned x = have + 1u; x != g + 1u; ++x) {
+        d0 |= G.dlog[(x % (unsigned)V3_DLOG) * V3_BPL + 0];
+        d1 |= G.dlog[(x % (unsigned)V3_DLOG) * V3_BPL + 1];
+      }
+    }
+    const unsigned n_pos = G.hdr[0], nb = (n_pos + COOK_WAVE - 1) / COOK_WAVE;
+    for (unsigned b = 0; b < nb; ++b) {
+      if (!(((b < 64u ? d0 : d1) >> (b & 63u)) & 1ull)) continue;  // (wave-uniform)
+      const unsigned p = b * COOK_WAVE + lane;
+      H.fcm[p] = G.fcm[p];
+      H.okey[p] = G.okey[p];
+    }
+    for (unsigned b = lane; b < nb; b += COOK_WAVE) H.bsum[b] = G.bsum[b];
+    if (lane == 0) {
+      H.n_pos = n_pos;
+      H.n_blocks = nb;
+      H.gen_first = G.hdr[1];
+    }
+    wave_sync();  // (every lane's part of the copy is in place)
+    lds_release();
+    if (lane == 0) st_wg(&H.gen_loaded, g);
+  }
+  if (lane == 0) st_wg(&H.lock, 0u);
+}
+
+static __device__ __forceinline__ void v3_helper(V3HLds& H, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned my, unsigned* n_steps,
+                                                 unsigned* n_visits, unsigned* n_settled, unsigned long long* pc, unsigned long long* pn) {
+  const unsigned lane = lane_id();
+  const unsigned K = in.K;
+  const V3Glob& G = vb.G;
+  const unsigned la = vb.look_ahead < 1u ? 1u : (vb.look_ahead > (unsigned)V3_GR ? (unsigned)V3_GR : vb.look_ahead);
+  unsigned e_seen = 0u;
+  V3Job& J = H.stage[wave_id()];
+  const unsigned long long t_start = cook_ticks();
+  for (;;) {
+    // a job position of the current epoch (one fetch-and-add gives both)
+    unsigned long long t = 0ull;
+    if (lane == 0) {
+      t = ld_agent(G.next64);
+      if ((unsigned)(t >> 32) != 0u && (unsigned)(t >> 32) != V3_E_DONE) t = atomicAdd(G.next64, 1ull);
+    }
+    const unsigned e = (unsigned)__shfl((int)(unsigned)(t >> 32), 0, COOK_WAVE), p = (unsigned)__shfl((int)(unsigned)t, 0, COOK_WAVE);
+    if (e == V3_E_DONE) return;
+    if (e == 0u) {  // the walker workgroup has not started the first epoch yet
+      if (cook_ticks() - t_start > V3_WAIT_TICKS) return;  // (it never came up: the launch was not co-resident; the host sees the walker's verdict)
+      EMU_SITE("v3 helper: waiting for the first epoch");
+      SPIN_PAUSE_FAR();
+      continue;
+    }
+    if (e != e_seen) {
+      e_seen = e;
+      if (lane == 0) st_agent(&G.ack[my], e);
+      const unsigned g = ld_agent(G.gen);
+      if (g != ld_wg(&H.gen_loaded)) v3_helper_refresh(H, vb, g);
+    }
+    auto epoch_now = [&]() -> unsigned { return (unsigned)(ld_agent(G.next64) >> 32); };
+    if (p >= K) {  // nothing left to prepare in this epoch
+      while (epoch_now() == e) {
+        EMU_SITE("v3 helper: idle");
+        SPIN_PAUSE_FAR();
+      }
+      continue;
+    }
+    // not too far ahead of the walker
+    bool stale = false;
+    V3P_DECL();
+    while (p - ld_agent(G.walk_pos) >= la) {
+      if (epoch_now() != e) {
+        stale = true;
+        break;
+      }
+      EMU_SITE("v3 helper: window");
+      SPIN_PAUSE_FAR();
+    }
+    if (stale) continue;
     V3P_MARK(pc, pn, 7);
-    V3Job& J = L.ring[p % (unsigned)V3_R];
     unsigned steps = 0, visits = 0;
-    v3_prepare(L, in, st, vb, p, J, &steps, &visits, pc, pn);
+    v3_prepare(H, in, st, vb, p, J, &steps, &visits, pc, pn);
     wave_sync();
     *n_steps += steps;
     *n_visits += visits;
@@ -784,12 +901,63 @@ static __device__ __forceinline__ void v3_helper(V3Lds& L, const MatchIn& in, co
     c2 = (unsigned)__shfl((int)c2, 0, COOK_WAVE);
     c4 = (unsigned)__shfl((int)c4, 0, COOK_WAVE);
     const bool trivial = (info & V3I_NOFEAS) != 0u && c1 > 0u && (c2 == 0u || c2 > (unsigned)V3_T) && c4 == 0u;
-    if (trivial) {
-      if (lane == 0 && st.fail_code) st.fail_code[p] = 1u | (c2 ? 2u : 0u) | (c4 ? 4u : 0u);
-      *n_settled += 1u;
+    if (epoch_now() != e) continue;  // (the epoch ended meanwhile: nobody will look at the entry)
+    // (a settled job's failure summary travels in the flag: the walker workgroup writes every result, so that a straggler of an old
+    //  epoch can never overwrite a newer verdict)
+    const unsigned fbits = 1u | (c2 ? 2u : 0u) | (c4 ? 4u : 0u);
+    if (trivial) *n_settled += 1u;
+    // the entry goes out: sc1 stores, drained, then the flag
+    const unsigned slot = (e % (unsigned)V3_NBANK) * (unsigned)V3_GR + p % (unsigned)V3_GR;
+    if (!trivial && lane < (unsigned)V3_JOB_WORDS)
+      st_agent(reinterpret_cast<unsigned long long*>(&G.ring[slot]) + lane, reinterpret_cast<const unsigned long long*>(&J)[lane]);
+    drain_stores();
+    wave_sync();  // (every lane's words are out)
+    if (lane == 0) st_agent(&G.rflag[slot], (unsigned long long)(p + 1u) | ((unsigned long long)((e << 5) | (fbits << 2) | (trivial ? 2u : 1u)) << 32));
+    wave_sync();
+    V3P_MARK(pc, pn, 6);
+  }
+}
+
+// ---- the feeder waves of the walker workgroup (waves 1 ..): global ring -> LDS ring, in job order ------------------------------------
+// wave 1 + x takes the jobs q with q % n_feeders == x; the walker's own window (V3_R LDS slots) bounds how far they run ahead.
+static __device__ __forceinline__ void v3_feeder(V3Lds& L, const MatchIn& in, const MatchState& st, const V3Buf& vb, unsigned epoch) {
+  const unsigned lane = lane_id();
+  const unsigned K = in.K;
+  const V3Glob& G = vb.G;
+  const unsigned nf = blockDim.x / COOK_WAVE - 1u, me = wave_id() - 1u;
+  unsigned q = L.walk_pos;
+  q += (me + nf - q % nf) % nf;  // first job >= walk_pos that is this wave's
+  const unsigned bank = (epoch % (unsigned)V3_NBANK) * (unsigned)V3_GR;
+  for (;;) {
+    if (ld_wg(&L.gen_stop) != 0u) return;
+    const unsigned wp = ld_wg(&L.walk_pos);
+    if (me == 0u && lane == 0) st_agent(G.walk_pos, wp);  // (the helpers' window follows the walker)
+    if (q >= K || q - wp >= (unsigned)V3_R) {
+      EMU_SITE("v3 feeder: window");
+      SPIN_PAUSE();
+      continue;
     }
+    const unsigned long long f = ld_agent(&G.rflag[bank + q % (unsigned)V3_GR]);
+    const unsigned state = (unsigned)(f >> 32);
+    if ((unsigned)f != q + 1u || (state >> 5) != epoch) {
+      EMU_SITE("v3 feeder: waiting for a helper");
+      SPIN_PAUSE_SHORT();
+      continue;
+    }
+    if ((state & 3u) == 1u) {
+      unsigned long long w = 0ull;
+      if (lane < (unsigned)V3_JOB_WORDS) w = ld_agent(reinterpret_cast<const unsigned long long*>(&G.ring[bank + q % (unsigned)V3_GR]) + lane);
+      if (lane < (unsigned)V3_JOB_WORDS) reinterpret_cast<unsigned long long*>(&L.ring[q % (unsigned)V3_R])[lane] = w;
+    } else if (lane == 0 && st.fail_code) {
+      st.fail_code[q] = (state >> 2) & 7u;
+    }
+    wave_sync();  // (every lane's words are in the LDS ring)
+#ifdef V3_DEBUG_PRINT
+    if (lane == 0 && q < 3) { const V3Job& D = L.ring[q % (unsigned)V3_R]; printf("feed q=%u state=%u info=%x c=%g m=%g ent0=(%g,%d,%u) ent1=(%g,%d,%u) f=%u %u %u\n", q, state&3u, D.info, D.c, D.m, D.ent[0].fit, D.ent[0].off, D.ent[0].pos, D.ent[1].fit, D.ent[1].off, D.ent[1].pos, D.f1, D.f2, D.f4); }
+#endif
     lds_release();
-    if (lane == 0) st_wg(&L.rstate[p % (unsigned)V3_R], ((p + 1u) << 2) | (trivial ? 2u : 1u));
+    if (lane == 0) st_wg(&L.rstate[q % (unsigned)V3_R], ((q + 1u) << 2) | (state & 3u));
+    q += nf;
   }
 }
 
@@ -1164,7 +1332,9 @@ static __device__ __forceinline__ void v3_walk(V3Lds& L, const MatchIn& in, Matc
         W.t_basec = W.t_rc + W.t_ac;
         W.t_basem = W.t_rm + W.t_am;
         L.owner[win] = (unsigned char)W.nT;
-        st_wg(&L.tbits[win_pos >> 6], L.tbits[win_pos >> 6] | (1ull << (win_pos & 63u)));  // (this wave is the only writer)
+        const unsigned long long tb_ = L.tbits[win_pos >> 6] | (1ull << (win_pos & 63u));  // (this wave is the only writer)
+        L.tbits[win_pos >> 6] = tb_;
+        st_agent(&vb.G.tbits[win_pos >> 6], tb_);  // the helpers leave touched offers out of their lists
       }
       win_lane = (int)W.nT;
       ++W.nT;
@@ -1270,17 +1440,52 @@ struct PoolCtx3 {
   V3Buf vb;
 };
 
-// ---- one workgroup per pool (blockIdx.x = pool), one launch per match call -----------------------------------------------------------
-// (the context travels BY VALUE: pointers that arrive as kernel arguments are known to be global memory, pointers loaded from a context
-// record in memory are not, and every access through them would be a flat one)
+// ---- one launch per match call: workgroup 0 walks (wave 0) and feeds the walk from the global ring (waves 1 ..), every other
+// workgroup is helper waves.  (The context travels BY VALUE: pointers that arrive as kernel arguments are known to be global memory,
+// pointers loaded from a context record in memory are not, and every access through them would be a flat one.)
+constexpr size_t V3_LDS_BYTES = sizeof(V3Lds) > sizeof(V3HLds) ? sizeof(V3Lds) : sizeof(V3HLds);
 __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3 C) {
-  COOK_BLOCK_LDS(lds, sizeof(V3Lds));
-  V3Lds& L = *reinterpret_cast<V3Lds*>(lds);
+  COOK_BLOCK_LDS(lds, V3_LDS_BYTES);
   const MatchIn& in = C.in;
   const MatchState st = C.st;
   const V3Buf vb = C.vb;
+  const V3Glob& G = vb.G;
   const unsigned tid = threadIdx.x, NT = blockDim.x, lane = lane_id();
   const unsigned long long tk0 = cook_ticks();
+  unsigned long long pc[V3_NPROF], pn[V3_NPROF];
+  for (int i = 0; i < V3_NPROF; ++i) pc[i] = pn[i] = 0ull;
+  if (blockIdx.x != 0u) {
+    // ======== a helper workgroup ==================================================================================================
+    V3HLds& H = *reinterpret_cast<V3HLds*>(lds);
+    if (tid == 0) {
+      H.gen_loaded = 0u;  // (generation numbers start at 1)
+      H.lock = 0u;
+      H.n_pos = H.n_blocks = H.gen_first = 0u;
+    }
+    __syncthreads();
+    unsigned n_steps = 0, n_visits = 0, n_settled = 0;
+    v3_helper(H, in, st, vb, (blockIdx.x - 1u) * (NT / COOK_WAVE) + wave_id(), &n_steps, &n_visits, &n_settled, pc, pn);
+    if (lane == 0) {
+      atomicAdd(&vb.ctl->scan_steps, n_steps);
+      atomicAdd(&vb.ctl->visits, n_visits);
+      atomicAdd(&vb.ctl->settled, n_settled);
+#ifdef COOK_V3_PROF
+      for (int i = 0; i < V3_NPROF; ++i) {
+        if (pc[i]) atomicAdd(&vb.ctl->prof_cyc[i], pc[i]);
+        if (pn[i]) atomicAdd(&vb.ctl->prof_cnt[i], pn[i]);
+      }
+#endif
+    }
+    return;
+  }
+  // ======== the walker workgroup ======================================================================================================
+  V3Lds& L = *reinterpret_cast<V3Lds*>(lds);
+  auto finish = [&](unsigned err) {  // tell the helpers the call is over (err != 0: before anything was placed)
+    if (tid == 0) {
+      if (err) vb.ctl->error = err;
+      st_agent(G.next64, (unsigned long long)V3_E_DONE << 32);
+    }
+  };
   // ---- refuse what the bounds do not cover (the host then runs match_v2): negative / non-finite resources ------------------------------
   if (tid == 0) {
     L.gen_stop = 0u;
@@ -1303,44 +1508,82 @@ __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3 C) {
     if (__any(bad) && lane == 0) atomicOr(&L.sort_n, 1u);
   }
   __syncthreads();
-  if (L.sort_n != 0u || in.M > (unsigned)V3_MMAX) {
-    if (tid == 0) vb.ctl->error = 1u;
+  if (L.sort_n != 0u || in.M > (unsigned)V3_MMAX || NT < 2u * COOK_WAVE || vb.n_helper_waves == 0u || vb.n_helper_waves > (unsigned)V3_HW_MAX) {
+    finish(1u);
     return;
   }
   __syncthreads();
-  // Wave 0 walks, the others prepare; the two roles run their own copy of the epoch loop (same barriers, same collective steps), so
-  // that the walker's lanes — registers that live across epochs — are no burden on the helpers' code.
-  unsigned n_steps = 0, n_visits = 0, n_settled = 0, gens = 0, epochs = 0, s_full = 0, s_list = 0, s_log = 0;
+  unsigned gens = 0, epochs = 0, s_full = 0, s_list = 0, s_log = 0;
   unsigned long long t_regen = 0ull, t_flush = 0ull;
-  unsigned long long pc[V3_NPROF], pn[V3_NPROF];
-  for (int i = 0; i < V3_NPROF; ++i) pc[i] = pn[i] = 0ull;
   const unsigned rebuild_gens = vb.rebuild_gens < 1u ? 1u : vb.rebuild_gens;
   unsigned w_matched = 0, w_head = 0, w_walked = 0, w_opens = 0, w_fast = 0;
   unsigned long long w_wait = 0ull;
-  // between epochs: a new generation (order rebuilt or updated) or only a ring flush; ends with a barrier
+  // between epochs: a new generation (order rebuilt, or the touched offers' keys replaced in place) or only a ring flush; what the
+  // helpers need goes out to global memory, then the next epoch is opened for them.  Ends with a barrier.
   auto between = [&](unsigned reason) {
     const unsigned long long tr0 = cook_ticks();
     if (reason >= 2u) {
       for (unsigned x = tid; x < in.G; x += NT) vb.group_snap[x] = ld_agent(&st.group_last[x]);
-      if (gens % rebuild_gens == 0u) {
+      const bool rebuild = gens % rebuild_gens == 0u;
+      if (rebuild) {
         v3_build(L, in, st, vb);  // (ends with a barrier)
       } else {
         v3_summaries(L, vb, false);
-        if (tid < (unsigned)V3_BPL) L.dirty[tid] = 0ull;
       }
       ++gens;
+      // the helpers' view: changed blocks of fcm / okey, every summary, the touched bits cleared, the header, the log of what changed
+      const unsigned n = L.n_pos, nb = (n + COOK_WAVE - 1) / COOK_WAVE;
+      const unsigned long long d0 = rebuild ? ~0ull : L.dirty[0], d1 = rebuild ? ~0ull : L.dirty[1];
+      for (unsigned pp = tid; pp < nb * COOK_WAVE; pp += NT) {
+        const unsigned b = pp >> 6;
+        if (!(((b < 64u ? d0 : d1) >> (b & 63u)) & 1ull)) continue;
+        G.fcm[pp] = pp < n ? L.fcm[pp] : 0u;
+        G.okey[pp] = pp < n ? L.okey[pp] : -1.0f;
+      }
+      for (unsigned b = tid; b < (unsigned)V3_NBMAX; b += NT) {
+        if (b < nb) G.bsum[b] = L.bsum[b];
+        st_agent(&G.tbits[b], 0ull);
+      }
+      if (tid == 0) {
+        G.hdr[0] = n;
+        G.hdr[1] = L.gen_first;
+        G.dlog[(gens % (unsigned)V3_DLOG) * V3_BPL + 0] = d0;
+        G.dlog[(gens % (unsigned)V3_DLOG) * V3_BPL + 1] = d1;
+      }
+      __syncthreads();  // (every thread's stores have left the CU)
+      if (tid < (unsigned)V3_BPL) L.dirty[tid] = 0ull;
+      if (tid == 0) {
+        agent_release();
+        st_agent(G.gen, gens);
+      }
     }
     for (unsigned x = tid; x < (unsigned)V3_R; x += NT) L.rstate[x] = 0u;
+    ++epochs;
     if (tid == 0) {
       L.next = L.walk_pos;
       L.gen_stop = 0u;
+      // no helper may still be working for the epoch that used this bank last (epochs - V3_NBANK): everyone has taken a job since
+      if (epochs > (unsigned)V3_NBANK) {
+        const unsigned long long t0 = cook_ticks();
+        for (unsigned h = 0; h < vb.n_helper_waves; ++h)
+          while (ld_agent(&G.ack[h]) + (unsigned)V3_NBANK <= epochs) {
+            if (cook_ticks() - t0 > V3_WAIT_TICKS) {
+              L.abort = 1u;
+              break;
+            }
+            EMU_SITE("v3 walker workgroup: waiting for a straggling helper");
+            SPIN_PAUSE();
+          }
+      }
+      st_agent(G.walk_pos, L.walk_pos);
+      drain_stores();
+      st_agent(G.next64, ((unsigned long long)epochs << 32) | (unsigned long long)L.walk_pos);  // the helpers may go
     }
     __syncthreads();
     if (reason >= 2u)
       t_regen += cook_ticks() - tr0;
     else
       t_flush += cook_ticks() - tr0;
-    ++epochs;
   };
   auto after = [&]() -> unsigned {  // -> why the epoch ended
     __syncthreads();
@@ -1350,40 +1593,28 @@ __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3 C) {
     s_log += reason == 3u ? 1u : 0u;
     return reason;
   };
-  if (tid < COOK_WAVE) {
-    V3Walker W;
-    v3_walker_reset(W);
-    W.matched = W.head_matched = W.walked = W.opens = W.fast = 0u;
-    W.wait_ticks = 0ull;
-    unsigned reason = 2u;  // (the first epoch builds the order)
-    for (;;) {
-      between(reason);
+  // (one loop for both roles of the workgroup: the walker's lanes are dead weight in the feeders' registers, but the feeders' code is
+  //  small, and the generation change — the bulk of the code — exists once)
+  V3Walker W;
+  v3_walker_reset(W);
+  W.matched = W.head_matched = W.walked = W.opens = W.fast = 0u;
+  W.wait_ticks = 0ull;
+  unsigned reason = 2u;  // (the first epoch builds the order)
+  for (;;) {
+    between(reason);
+    if (L.abort != 0u) break;
+    if (tid < COOK_WAVE)
       v3_walk(L, in, st, vb, W, pc, pn);
-      reason = after();
-      if (L.done != 0u) break;
-      __syncthreads();
-    }
-    w_matched = W.matched, w_head = W.head_matched, w_walked = W.walked, w_opens = W.opens, w_fast = W.fast, w_wait = W.wait_ticks;
-  } else {
-    unsigned reason = 2u;
-    for (;;) {
-      between(reason);
-      v3_helper(L, in, st, vb, &n_steps, &n_visits, &n_settled, pc, pn);
-      reason = after();
-      if (L.done != 0u) break;
-      __syncthreads();
-    }
+    else
+      v3_feeder(L, in, st, vb, epochs);
+    reason = after();
+    if (L.done != 0u) break;
+    __syncthreads();
   }
-  if (L.abort != 0u) {
-    if (tid == 0) vb.ctl->error = 2u;
-    return;
-  }
+  w_matched = W.matched, w_head = W.head_matched, w_walked = W.walked, w_opens = W.opens, w_fast = W.fast, w_wait = W.wait_ticks;
+  finish(L.abort != 0u ? 2u : 0u);
+  if (L.abort != 0u) return;
   // ---- statistics ---------------------------------------------------------------------------------------------------------------------
-  if (lane == 0 && tid >= COOK_WAVE) {  // (every lane of a helper wave carries the same counts: the wave's)
-    atomicAdd(&vb.ctl->scan_steps, n_steps);
-    atomicAdd(&vb.ctl->visits, n_visits);
-    atomicAdd(&vb.ctl->settled, n_settled);
-  }
 #ifdef COOK_V3_PROF
   if (lane == 0)
     for (int i = 0; i < V3_NPROF; ++i) {

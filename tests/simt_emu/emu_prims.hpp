@@ -40,6 +40,7 @@ template <class T>
 static inline void st_wg(T* p, T v) { *p = v; emu::progress(); }
 #define SPIN_PAUSE() emu::yield()
 #define SPIN_PAUSE_SHORT() emu::yield()
+#define SPIN_PAUSE_FAR() emu::yield()
 static inline void lds_release() {}
 static inline void lds_acquire() {}
 #define COOK_BLOCK_LDS(name, bytes) char* name = emu::block_lds(bytes)
