@@ -57,6 +57,9 @@ constexpr int V3_NBANK = 4;                            // banks: epoch e uses ba
 constexpr int V3_HW_MAX = 512;                         // helper waves of a launch, at most
 constexpr unsigned V3_E_DONE = 0xFFFFFFFFu;            // "epoch" that tells the helpers the call is over
 constexpr int V3_JOB_WORDS = 40;                       // sizeof(V3Job) / 8
+#ifndef V3_FORCE_FULL
+#define V3_FORCE_FULL 0
+#endif
 constexpr int V3_DLOG = 16;                            // generations whose dirty-block masks are kept for helpers that fell behind
 constexpr int V3_BATCH = 4;                            // blocks a helper looks at per step (their loads are in flight together)
 static_assert(V3_L <= 16 && V3_BPL == 2 && V3_R <= COOK_WAVE, "shapes");
@@ -68,6 +71,7 @@ struct V3Ent {  // candidate-list entry: exact fitness under the generation's sn
 };
 constexpr unsigned V3I_TRUNC = 1u << 8;     // feasible untouched offers may exist beyond the list
 constexpr unsigned V3I_NOFEAS = 1u << 9;    // no offer at all (touched ones included) was feasible under the snapshot
+constexpr unsigned V3I_PLAIN = 1u << 10;    // no gpus, no constraints of its own, no group, no reserved host: the walker's short path
 constexpr unsigned V3I_GPU = 1u << 16, V3I_GROUPED = 1u << 17, V3I_HASGROUP = 1u << 20, V3I_FASTC = 1u << 21, V3I_SLOW = 1u << 22,
                    V3I_GFAST = 1u << 23;  // bits 18-19: group type; GFAST: the hosts to avoid are staged (gfh / n_fh / glast)
 struct alignas(16) V3Job {  // one prepared job (a ring entry)
@@ -227,6 +231,9 @@ struct V3Lds {
   unsigned long long tbits[V3_NBMAX];    // block -> positions touched in this generation
   unsigned long long dirty[V3_BPL];      // blocks whose summaries the generation change must recompute
   unsigned rstate[V3_R];              // (position + 1) << 2 | 1 ready / 2 settled
+  int res_j2o[V3_R];                  // the walker's verdicts by ring slot; a feeder wave writes them out behind the walker
+  unsigned res_fail[V3_R];            // 0xFFFFFFFF: nothing to write (settled by a helper / a group member, written at once)
+  unsigned flushed;                   // jobs below this position have their results in HBM
   unsigned n_pos, n_blocks;           // positions of the order (dead ones included until the next rebuild)
   unsigned next;                      // next job position a helper takes
   unsigned walk_pos;                  // first job the walker has not consumed
@@ -248,6 +255,24 @@ struct V3HLds {  // a helper workgroup: its copy of what the search reads, refre
 };
 constexpr unsigned long long V3_WAIT_TICKS = 150000000ull;  // 1.5 s of the 100 MHz clock
 
+// One lane reads a word other waves write, every lane gets that value: on the GPU a wave-wide load of one address is uniform anyway,
+// but lanes that are fibers (the emulated build) would each read at their own time and could take different branches.
+static __device__ __forceinline__ unsigned v3_ld_agent_u(const unsigned* p) {
+  unsigned v = 0;
+  if (lane_id() == 0) v = ld_agent(p);
+  return (unsigned)__shfl((int)v, 0, COOK_WAVE);
+}
+static __device__ __forceinline__ unsigned long long v3_ld_agent_u64(const unsigned long long* p) {
+  unsigned long long v = 0;
+  if (lane_id() == 0) v = ld_agent(p);
+  const unsigned lo = (unsigned)__shfl((int)(unsigned)v, 0, COOK_WAVE), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), 0, COOK_WAVE);
+  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+}
+static __device__ __forceinline__ unsigned v3_ld_wg_u(const unsigned* p) {
+  unsigned v = 0;
+  if (lane_id() == 0) v = ld_wg(p);
+  return (unsigned)__shfl((int)v, 0, COOK_WAVE);
+}
 // float >= d / <= d (the summaries must err on the safe side)
 static __device__ __forceinline__ float v3_f32_up(double d) {
   float f = (float)d;
@@ -761,7 +786,8 @@ static __device__ __forceinline__ void v3_prepare(V3HLds& H, const MatchIn& in, 
     J.gpu_model = j.gpu_model;
     J.reserved_host = j.reserved_host;
     J.group = j.group;
-    J.info = n_list | (trunc ? V3I_TRUNC : 0u) | ((!trunc && n_feas == 0u) ? V3I_NOFEAS : 0u) | (j.g > 0 ? V3I_GPU : 0u) | (grouped ? V3I_GROUPED : 0u) |
+    const bool plain = !(j.g > 0) && !(j.g < 0) && !fastc && !slow && j.group == 0xFFFFFFFFu && j.reserved_host < 0;
+    J.info = n_list | (trunc ? V3I_TRUNC : 0u) | ((!trunc && n_feas == 0u) ? V3I_NOFEAS : 0u) | (plain ? V3I_PLAIN : 0u) | (j.g > 0 ? V3I_GPU : 0u) | (grouped ? V3I_GROUPED : 0u) |
              (gtype << 18) | (j.group != 0xFFFFFFFFu ? V3I_HASGROUP : 0u) | (fastc ? V3I_FASTC : 0u) | (slow ? V3I_SLOW : 0u) |
              ((j.group != 0xFFFFFFFFu && gtype <= 1u && (gtype == 0u || n_fh >= 0)) ? V3I_GFAST : 0u);
     J.f1 = (unsigned short)(c1 < 0xFFFFu ? c1 : 0xFFFFu);
@@ -793,19 +819,19 @@ static __device__ __forceinline__ void v3_helper_refresh(V3HLds& H, const V3Buf&
   if (lane == 0) got = atomicCAS(&H.lock, 0u, 1u) == 0u ? 1u : 0u;
   got = (unsigned)__shfl((int)got, 0, COOK_WAVE);
   if (!got) {
-    while (ld_wg(&H.gen_loaded) != g) {
+    while (v3_ld_wg_u(&H.gen_loaded) != g) {
       EMU_SITE("v3 helper: waiting for the workgroup's copy");
       SPIN_PAUSE();
     }
     lds_acquire();
     return;
   }
-  const unsigned have = ld_wg(&H.gen_loaded);
+  const unsigned have = v3_ld_wg_u(&H.gen_loaded);
   if (have != g) {
     agent_acquire();
     // the blocks that changed since generation `have` (everything when the log no longer reaches back that far)
     unsigned long long d0 = 0ull, d1 = 0ull;
-    if (g - have > (unsigned)V3_DLOG) {
+    if (g - have > (unsigned)V3_DLOG || V3_FORCE_FULL) {
       d0 = d1 = ~0ull;
     } else {
       for (unsigned x = have + 1u; x != g + 1u; ++x) {
@@ -860,10 +886,10 @@ static __device__ __forceinline__ void v3_helper(V3HLds& H, const MatchIn& in, c
     if (e != e_seen) {
       e_seen = e;
       if (lane == 0) st_agent(&G.ack[my], e);
-      const unsigned g = ld_agent(G.gen);
-      if (g != ld_wg(&H.gen_loaded)) v3_helper_refresh(H, vb, g);
+      const unsigned g = v3_ld_agent_u(G.gen);
+      if (g != v3_ld_wg_u(&H.gen_loaded)) v3_helper_refresh(H, vb, g);
     }
-    auto epoch_now = [&]() -> unsigned { return (unsigned)(ld_agent(G.next64) >> 32); };
+    auto epoch_now = [&]() -> unsigned { return (unsigned)(v3_ld_agent_u64(G.next64) >> 32); };
     if (p >= K) {  // nothing left to prepare in this epoch
       while (epoch_now() == e) {
         EMU_SITE("v3 helper: idle");
@@ -874,7 +900,7 @@ static __device__ __forceinline__ void v3_helper(V3HLds& H, const MatchIn& in, c
     // not too far ahead of the walker
     bool stale = false;
     V3P_DECL();
-    while (p - ld_agent(G.walk_pos) >= la) {
+    while (p - v3_ld_agent_u(G.walk_pos) >= la) {
       if (epoch_now() != e) {
         stale = true;
         break;
@@ -928,16 +954,38 @@ static __device__ __forceinline__ void v3_feeder(V3Lds& L, const MatchIn& in, co
   unsigned q = L.walk_pos;
   q += (me + nf - q % nf) % nf;  // first job >= walk_pos that is this wave's
   const unsigned bank = (epoch % (unsigned)V3_NBANK) * (unsigned)V3_GR;
+  // feeder 0 also writes the walker's verdicts out (the walker itself never waits for a store to HBM) and tells the helpers where the
+  // walker is; a ring slot is reused only once its verdict is out
+  auto flush = [&](unsigned upto) {
+    unsigned fl = L.flushed;  // (only this wave writes it)
+    while (fl < upto) {
+      const unsigned x = fl + lane;
+      if (x < upto) {
+        const unsigned code = L.res_fail[x % (unsigned)V3_R];
+        if (code != 0xFFFFFFFFu) {
+          st.job_to_offer[x] = L.res_j2o[x % (unsigned)V3_R];
+          if (st.fail_code) st.fail_code[x] = code;
+        }
+      }
+      fl = upto - fl > (unsigned)COOK_WAVE ? fl + (unsigned)COOK_WAVE : upto;
+    }
+    wave_sync();
+    if (lane == 0) st_wg(&L.flushed, upto);
+  };
   for (;;) {
-    if (ld_wg(&L.gen_stop) != 0u) return;
-    const unsigned wp = ld_wg(&L.walk_pos);
-    if (me == 0u && lane == 0) st_agent(G.walk_pos, wp);  // (the helpers' window follows the walker)
-    if (q >= K || q - wp >= (unsigned)V3_R) {
+    const unsigned stopped = v3_ld_wg_u(&L.gen_stop);
+    const unsigned wp = v3_ld_wg_u(&L.walk_pos);
+    if (me == 0u) {
+      if (lane == 0) st_agent(G.walk_pos, wp);  // (the helpers' window follows the walker)
+      if (v3_ld_wg_u(&L.flushed) < wp) flush(wp);
+    }
+    if (stopped != 0u) return;  // (the walker's last verdicts of the epoch are out: walk_pos was read after the stop flag)
+    if (q >= K || q - v3_ld_wg_u(&L.flushed) >= (unsigned)V3_R) {
       EMU_SITE("v3 feeder: window");
       SPIN_PAUSE();
       continue;
     }
-    const unsigned long long f = ld_agent(&G.rflag[bank + q % (unsigned)V3_GR]);
+    const unsigned long long f = v3_ld_agent_u64(&G.rflag[bank + q % (unsigned)V3_GR]);
     const unsigned state = (unsigned)(f >> 32);
     if ((unsigned)f != q + 1u || (state >> 5) != epoch) {
       EMU_SITE("v3 feeder: waiting for a helper");
@@ -948,13 +996,12 @@ static __device__ __forceinline__ void v3_feeder(V3Lds& L, const MatchIn& in, co
       unsigned long long w = 0ull;
       if (lane < (unsigned)V3_JOB_WORDS) w = ld_agent(reinterpret_cast<const unsigned long long*>(&G.ring[bank + q % (unsigned)V3_GR]) + lane);
       if (lane < (unsigned)V3_JOB_WORDS) reinterpret_cast<unsigned long long*>(&L.ring[q % (unsigned)V3_R])[lane] = w;
-    } else if (lane == 0 && st.fail_code) {
-      st.fail_code[q] = (state >> 2) & 7u;
+      if (lane == 0) L.res_fail[q % (unsigned)V3_R] = 0xFFFFFFFFu;  // (the walker's verdict goes here)
+    } else if (lane == 0) {
+      L.res_j2o[q % (unsigned)V3_R] = -1;  // settled by the helper: its summary travelled in the flag
+      L.res_fail[q % (unsigned)V3_R] = (state >> 2) & 7u;
     }
     wave_sync();  // (every lane's words are in the LDS ring)
-#ifdef V3_DEBUG_PRINT
-    if (lane == 0 && q < 3) { const V3Job& D = L.ring[q % (unsigned)V3_R]; printf("feed q=%u state=%u info=%x c=%g m=%g ent0=(%g,%d,%u) ent1=(%g,%d,%u) f=%u %u %u\n", q, state&3u, D.info, D.c, D.m, D.ent[0].fit, D.ent[0].off, D.ent[0].pos, D.ent[1].fit, D.ent[1].off, D.ent[1].pos, D.f1, D.f2, D.f4); }
-#endif
     lds_release();
     if (lane == 0) st_wg(&L.rstate[q % (unsigned)V3_R], ((q + 1u) << 2) | (state & 3u));
     q += nf;
@@ -969,6 +1016,7 @@ struct V3Walker {  // the walking wave's registers: they live across epochs, a g
   double t_ac, t_am, t_basec, t_basem, t_ac0, t_am0;
   int t_acount, t_acount0;
   OfferB t_o;
+  bool t_plain_ok;  // the offer takes jobs without gpus / constraints / reserved host (static_fast for such a job)
   unsigned t_attr[MV_NA];
   unsigned lg_group, lg_host, n_log;  // group members placed in this generation (one per lane, in placement order)
   int lg_k;
@@ -983,6 +1031,7 @@ static __device__ __forceinline__ void v3_walker_reset(V3Walker& W) {
   W.t_ac = W.t_am = W.t_basec = W.t_basem = W.t_ac0 = W.t_am0 = 0.0;
   W.t_acount = W.t_acount0 = 0;
   W.t_o.host = 0, W.t_o.gpu_model = 0, W.t_o.gpu_count = 0.0, W.t_o.run_count = 0, W.t_o.task_slack = 0x7FFFFFFF, W.t_o.flags = 0, W.t_o.pad = 0;
+  W.t_plain_ok = false;
 #pragma unroll
   for (int x = 0; x < MV_NA; ++x) W.t_attr[x] = 0u;
   W.lg_group = 0xFFFFFFFFu, W.lg_host = 0u, W.n_log = 0u;
@@ -1027,10 +1076,41 @@ static __device__ __forceinline__ void v3_walk(V3Lds& L, const MatchIn& in, Matc
   unsigned p = L.walk_pos;
   constexpr double EPS_HI = 1.0 + 0x1p-38, EPS_LO = 1.0 - 0x1p-38;
   unsigned stop = 0;
+  // The walk is a software pipeline over the LDS ring: the record of job p + 2 and the owner look-up of job p + 1 are in flight
+  // while job p is decided.  A record is read speculatively, its state word first (LDS operations retire in order): it is used
+  // only if every lane saw "ready" for exactly that job; otherwise the pipeline is refilled the slow way (scan, wait).
+  struct V3Rec {
+    unsigned state, info;
+    double c, m;
+    double e_fit;
+    int e_off;
+    unsigned e_pos, owner;
+  };
+  auto load_rec = [&](unsigned q) -> V3Rec {
+    V3Rec r;
+    const V3Job& Q = L.ring[q % (unsigned)V3_R];
+    r.state = L.rstate[q % (unsigned)V3_R];
+    asm volatile("" ::: "memory");  // (the compiler keeps the state read in front of the record's)
+    r.info = Q.info;
+    r.c = Q.c, r.m = Q.m;
+    r.e_fit = -1.0, r.e_off = -1, r.e_pos = 0u, r.owner = 0xFEu;
+    if (lane < (unsigned)V3_L) {
+      const V3Ent x = Q.ent[lane];
+      r.e_fit = x.fit, r.e_off = x.off, r.e_pos = x.pos;
+    }
+    return r;
+  };
+  auto load_owner = [&](V3Rec& r) {
+    if (lane < (unsigned)V3_L && r.e_off >= 0 && r.e_off < V3_MMAX) r.owner = L.owner[r.e_off];
+  };
+  bool have = false;
+  V3Rec cur, nxt;
+  cur.state = cur.info = 0u, cur.c = cur.m = 0.0, cur.e_fit = -1.0, cur.e_off = -1, cur.e_pos = 0u, cur.owner = 0xFEu;
+  nxt = cur;
   while (p < K) {
     V3P_DECL();
-    // ---- skip the jobs the helpers settled; wait for the next prepared one ----------------------------------------------------------
-    {
+    if (!have) {
+      // ---- skip the jobs the helpers settled; wait for the next prepared one ----------------------------------------------------------
       const unsigned long long t0 = cook_ticks();
       bool waited = false;
       for (;;) {
@@ -1061,61 +1141,66 @@ static __device__ __forceinline__ void v3_walk(V3Lds& L, const MatchIn& in, Matc
       }
       if (waited) W.wait_ticks += cook_ticks() - t0;
       if (p >= K) break;
+      lds_acquire();
+      wave_sync();
+      cur = load_rec(p);
+      load_owner(cur);
+      nxt = load_rec(p + 1u);
     }
-    lds_acquire();
+    V3Rec nn = load_rec(p + 2u);  // in flight while job p is decided
+    load_owner(nxt);
     V3P_MARK(pc, pn, 16);
     const V3Job& J = L.ring[p % (unsigned)V3_R];
-    const unsigned info = wave_uniform_u32(J.info), k = p;
-    const double c = J.c, m = J.m;
+    const unsigned info = wave_uniform_u32(cur.info), k = p;
+    const double c = cur.c, m = cur.m;
     const int nc = (int)(info & 0xFFu);
     const bool grouped = (info & V3I_GROUPED) != 0u, has_group = (info & V3I_HASGROUP) != 0u;
     const unsigned g = has_group ? wave_uniform_u32(J.group) : 0xFFFFFFFFu;
     const bool trunc = (info & V3I_TRUNC) != 0u;
     W.walked += 1u;
-    // list entry `lane`
-    double e_fit = -1.0;
-    int e_off = -1;
-    unsigned e_pos = 0u, owner = 0xFEu;
-    if ((int)lane < nc) {
-      const V3Ent x = J.ent[lane];
-      e_fit = x.fit;
-      e_off = x.off;
-      e_pos = x.pos;
-      owner = L.owner[e_off];
-    }
+    // list entry `lane` (unused entries hold offer -1)
+    const double e_fit = cur.e_fit;
+    const int e_off = cur.e_off;
+    const unsigned e_pos = cur.e_pos, owner = cur.owner;
     // ---- every touched offer under the current state ----------------------------------------------------------------------------------
     const bool t_on = W.t_v >= 0;
-    JobRec jr;
-    jr.c = c, jr.m = m, jr.g = J.g, jr.gpu_model = J.gpu_model, jr.reserved_host = J.reserved_host, jr.group = J.group, jr.flags = 0;
     const bool res_ok = t_on && !(W.t_ac + c > W.t_oc || W.t_am + m > W.t_om);
-    bool con_ok = t_on && static_fast(jr, W.t_o, in, (unsigned)(t_on ? W.t_v : 0)) && dyn_fast(jr, W.t_o, W.t_acount);
-    if (info & V3I_FASTC) {  // (wave-uniform)
-      unsigned diff = (J.req_host ^ (W.t_o.host + 1u)) & J.wild_host;
-#pragma unroll
-      for (int x = 0; x < MV_NA; ++x) diff |= (J.req[x] ^ W.t_attr[x]) & J.wild[x];
-      bool hit = J.impossible != 0u;
-#pragma unroll
-      for (int q = 0; q < MV_NC; ++q) hit = hit | (J.novel[q] == W.t_o.host);
-      con_ok = con_ok && diff == 0u && !hit;
-    }
-    if ((info & V3I_SLOW) && con_ok) con_ok = static_pass_dev(vb.in_dev, J.jj, (unsigned)W.t_v);
+    bool con_ok;
     unsigned long long ghits = 0ull;  // log entries of this job's group
     bool g_general = false;            // the group check goes through the chains in HBM
-    if (has_group) {
-      ghits = __ballot(lane < W.n_log && W.lg_group == g);
-      if (grouped) {
-        if ((info & V3I_GFAST) && J.n_fh >= 0 && W.n_log <= (unsigned)COOK_WAVE) {
-          bool forb = false;
+    JobRec jr;
+    jr.c = c, jr.m = m, jr.g = 0.0, jr.gpu_model = 0u, jr.reserved_host = -1, jr.group = 0xFFFFFFFFu, jr.flags = 0;
+    if (info & V3I_PLAIN) {  // (wave-uniform) nothing of the job's own to check: the lane knows whether it takes such jobs
+      con_ok = t_on && W.t_plain_ok && W.t_acount < W.t_o.task_slack;
+    } else {
+      jr.g = J.g, jr.gpu_model = J.gpu_model, jr.reserved_host = J.reserved_host, jr.group = J.group;
+      con_ok = t_on && static_fast(jr, W.t_o, in, (unsigned)(t_on ? W.t_v : 0)) && dyn_fast(jr, W.t_o, W.t_acount);
+      if (info & V3I_FASTC) {  // (wave-uniform)
+        unsigned diff = (J.req_host ^ (W.t_o.host + 1u)) & J.wild_host;
 #pragma unroll
-          for (int q = 0; q < MV_FH; ++q) forb = forb | (W.t_o.host == J.gfh[q]);
-          for (unsigned long long hm = ghits; hm != 0ull; hm &= hm - 1ull) {
-            const unsigned h = (unsigned)wave_read_lane((int)W.lg_host, __ffsll((unsigned long long)hm) - 1);
-            forb = forb | (W.t_o.host == h);
+        for (int x = 0; x < MV_NA; ++x) diff |= (J.req[x] ^ W.t_attr[x]) & J.wild[x];
+        bool hit = J.impossible != 0u;
+#pragma unroll
+        for (int q = 0; q < MV_NC; ++q) hit = hit | (J.novel[q] == W.t_o.host);
+        con_ok = con_ok && diff == 0u && !hit;
+      }
+      if ((info & V3I_SLOW) && con_ok) con_ok = static_pass_dev(vb.in_dev, J.jj, (unsigned)W.t_v);
+      if (has_group) {
+        ghits = __ballot(lane < W.n_log && W.lg_group == g);
+        if (grouped) {
+          if ((info & V3I_GFAST) && J.n_fh >= 0 && W.n_log <= (unsigned)COOK_WAVE) {
+            bool forb = false;
+#pragma unroll
+            for (int q = 0; q < MV_FH; ++q) forb = forb | (W.t_o.host == J.gfh[q]);
+            for (unsigned long long hm = ghits; hm != 0ull; hm &= hm - 1ull) {
+              const unsigned h = (unsigned)wave_read_lane((int)W.lg_host, __ffsll((unsigned long long)hm) - 1);
+              forb = forb | (W.t_o.host == h);
+            }
+            con_ok = con_ok && !forb;
+          } else {
+            g_general = true;
+            if (con_ok) con_ok = group_pass_dev(vb.in_dev, st, J.jj, (unsigned)W.t_v);
           }
-          con_ok = con_ok && !forb;
-        } else {
-          g_general = true;
-          if (con_ok) con_ok = group_pass_dev(vb.in_dev, st, J.jj, (unsigned)W.t_v);
         }
       }
     }
@@ -1326,6 +1411,7 @@ static __device__ __forceinline__ void v3_walk(V3Lds& L, const MatchIn& in, Matc
 #pragma unroll
         for (int x = 0; x < MV_NA; ++x) W.t_attr[x] = P.attr[(size_t)x * V3_MMAX + q];
         W.t_invc = 1.0 / (W.t_oc + W.t_rc), W.t_invm = 1.0 / (W.t_om + W.t_rm);  // (as match_pack_offers computes OfferA::inv_dc / inv_dm)
+        W.t_plain_ok = ((W.t_o.flags & 1u) ? W.t_o.gpu_model == 0u : true) && !(W.t_o.flags & 2u);
         W.t_ac = W.t_ac0 + c;
         W.t_am = W.t_am0 + m;
         W.t_acount = W.t_acount0 + 1;
@@ -1336,6 +1422,8 @@ static __device__ __forceinline__ void v3_walk(V3Lds& L, const MatchIn& in, Matc
         L.tbits[win_pos >> 6] = tb_;
         st_agent(&vb.G.tbits[win_pos >> 6], tb_);  // the helpers leave touched offers out of their lists
       }
+      // the owner look-up of the next job was issued before this commit: patch it
+      if (nxt.owner == 0xFFu && nxt.e_off == win) nxt.owner = W.nT;
       win_lane = (int)W.nT;
       ++W.nT;
       W.opens += 1u;
@@ -1359,26 +1447,27 @@ static __device__ __forceinline__ void v3_walk(V3Lds& L, const MatchIn& in, Matc
         }
         ++W.n_log;
         if (g_general) wave_sync();
-      } else if (lane == 0) {
-        st.job_to_offer[k] = win;
       }
-      if (lane == 0 && st.fail_code) st.fail_code[k] = 0u;
+      if (lane == 0) {  // (the verdict goes to HBM behind the walker: a feeder wave writes the ring's results out)
+        L.res_j2o[k % (unsigned)V3_R] = win;
+        L.res_fail[k % (unsigned)V3_R] = 0u;
+      }
     } else {
       // unmatched: failure summary = OR over offers of the first failing check under the CURRENT state: the snapshot counts, with each
-      // touched offer's snapshot verdict swapped for its current one
-      int d1 = 0, d2 = 0, d4 = 0;
-      if (W.nT != 0u) {
-        if (pe_bits == 8u && t_on) {
-          pe_bits = 0u;
-          if (!res_ok) {
-            pe_bits = 1u;
-          } else if (!con_ok) {
-            pe_bits = 2u;
-          } else {
-            pe_fit = (nc_ / (W.t_oc + W.t_rc) + nm_ / (W.t_om + W.t_rm)) / 2.0;
-            if (!(pe_fit > 0.0)) pe_bits = 4u;
-          }
-        }
+      // touched offer's snapshot verdict swapped for its current one.  A touched offer only got fuller, so "fails on resources" can
+      // only have been added; the other two classes need the snapshot verdicts of the touched offers only when the snapshot count
+      // is small enough for the touched offers to matter (0 < count <= V3_T)
+      const unsigned f1 = J.f1, f2 = J.f2, f4 = J.f4;
+      const unsigned long long now1 = __ballot(t_on && !res_ok), now2 = __ballot(t_on && res_ok && !con_ok);
+      unsigned long long now4 = 0ull;  // passes both, fitness not positive
+      if (__any(t_on && res_ok && con_ok)) {
+        const double pf = (nc_ / (W.t_oc + W.t_rc) + nm_ / (W.t_om + W.t_rm)) / 2.0;
+        now4 = __ballot(t_on && res_ok && con_ok && !(pf > 0.0));
+      }
+      unsigned bits = ((f1 > 0u || now1 != 0ull) ? 1u : 0u);
+      const bool exact2 = f2 > 0u && f2 <= (unsigned)V3_T, exact4 = f4 > 0u && f4 <= (unsigned)V3_T;
+      if (W.nT != 0u && (exact2 || exact4)) {
+        if (info & V3I_PLAIN) jr.g = 0.0;  // (jr holds the plain job's values already)
         unsigned p0 = 0u;
         if (t_on) {
           if (W.t_ac0 + c > W.t_oc || W.t_am0 + m > W.t_om) {
@@ -1408,19 +1497,32 @@ static __device__ __forceinline__ void v3_walk(V3Lds& L, const MatchIn& in, Matc
             }
           }
         }
-        d1 = __popcll(__ballot(t_on && (pe_bits & 1u))) - __popcll(__ballot(t_on && (p0 & 1u)));
-        d2 = __popcll(__ballot(t_on && (pe_bits & 2u))) - __popcll(__ballot(t_on && (p0 & 2u)));
-        d4 = __popcll(__ballot(t_on && (pe_bits & 4u))) - __popcll(__ballot(t_on && (p0 & 4u)));
+        const int d2 = __popcll(now2) - __popcll(__ballot(t_on && (p0 & 2u))), d4 = __popcll(now4) - __popcll(__ballot(t_on && (p0 & 4u)));
+        bits |= (((int)f2 + d2) > 0 ? 2u : 0u) | (((int)f4 + d4) > 0 ? 4u : 0u);
+      } else {
+        // no snapshot count in the delicate range: a zero count can only grow by what the touched offers show now, a large one
+        // cannot be used up by them
+        bits |= ((f2 > (unsigned)V3_T || (f2 == 0u && now2 != 0ull) || (exact2 && W.nT == 0u)) ? 2u : 0u) |
+                ((f4 > (unsigned)V3_T || (f4 == 0u && now4 != 0ull) || (exact4 && W.nT == 0u)) ? 4u : 0u);
       }
-      const unsigned bits = (((int)J.f1 + d1) > 0 ? 1u : 0u) | (((int)J.f2 + d2) > 0 ? 2u : 0u) | (((int)J.f4 + d4) > 0 ? 4u : 0u);
       if (lane == 0) {
-        st.job_to_offer[k] = -1;
-        if (st.fail_code) st.fail_code[k] = bits ? bits : 8u;
+        L.res_j2o[k % (unsigned)V3_R] = -1;
+        L.res_fail[k % (unsigned)V3_R] = bits ? bits : 8u;
       }
     }
     ++p;
     if (lane == 0) st_wg(&L.walk_pos, p);
-    V3P_MARK(pc, pn, (win < 0 ? 22 : (prof_new_ ? 21 : 20)));
+    if (win < 0) {  // (constant indices: the counters stay in registers)
+      V3P_MARK(pc, pn, 22);
+    } else if (prof_new_) {
+      V3P_MARK(pc, pn, 21);
+    } else {
+      V3P_MARK(pc, pn, 20);
+    }
+    // ---- the pipeline moves on: is the record read ahead the next job, and was it ready when it was read? -----------------------------
+    have = __all((nxt.state >> 2) == p + 1u && (nxt.state & 3u) == 1u) != 0;
+    cur = nxt;
+    nxt = nn;
   }
   // ---- end of the epoch -----------------------------------------------------------------------------------------------------------------------
   if (stop >= 2u || p >= K) v3_walker_writeback(L, st, vb, W);  // (at the end of the call too: the state arrays are the call's result)
@@ -1495,6 +1597,7 @@ __global__ void __launch_bounds__(V3_THREADS) match_v3(const PoolCtx3 C) {
     L.gen_first = 0u;
     L.abort = 0u;
     L.stop_reason = 0u;
+    L.flushed = 0u;
     L.sort_n = vb.job_flags[2] != 0ull ? 1u : 0u;  // (borrowed as the "bad input" flag until the first generation)
   }
   __syncthreads();

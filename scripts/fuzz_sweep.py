@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the configurations")
     ap.add_argument("--algo", type=int, default=-1, help="force cook_params.match_algo (default: drawn per configuration)")
     ap.add_argument("--ge", type=float, default=-1.0, help="force good-enough-fitness (default: drawn per configuration)")
+    ap.add_argument("--only", type=int, default=-1, help="run only that match configuration (the random draws of the others are still made)")
     args = ap.parse_args()
     from cook_amd import _abi as A
     from cook_amd import synth
@@ -59,9 +60,12 @@ def main():
             pool.offers.ports = rng.integers(0, 7, m).astype(np.int32)
             pool.offers.scalars, pool.offers.n_scalars = rng.integers(0, 120, (m, 2)) * 0.5, 2
         try:
-            P.rank_parity(make_engine, pool, p)
-            P.cycle_parity(make_engine, pool, p, int(rng.integers(1, kw["n_pending"] + 1)))
+            k_cycle = int(rng.integers(1, kw["n_pending"] + 1))
             reserved = tuple(int(x) for x in rng.integers(0, kw["n_offers"], int(rng.integers(0, 3))))
+            if args.only >= 0 and it != args.only:
+                continue
+            P.rank_parity(make_engine, pool, p)
+            P.cycle_parity(make_engine, pool, p, k_cycle)
             j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, reserved=reserved)
             if p.match_algo == 6 and p.good_enough_fitness >= 1.0:
                 with make_engine(p) as e_:
