@@ -873,6 +873,15 @@ void match_init_state(cook_engine* e, const MatchState& st, unsigned K, unsigned
 }
 
 void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, const WinCtl& hc, hipStream_t stream);
+// good-enough-fitness < 1: the resolve kernel whose fast path knows the rule (COOK_GE_FAST=0: the general path decides every job, as
+// before — kept for A/B measurements)
+static bool ge_fast_path() {
+  static const bool on = [] {
+    const char* s = std::getenv("COOK_GE_FAST");
+    return !(s && std::atoi(s) == 0);
+  }();
+  return on;
+}
 void match_rounds_multi(cook_engine** es, unsigned n);
 bool match_rounds_world(cook_engine** es, unsigned n);
 
@@ -1013,11 +1022,14 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     JobCons* jcons = e->v_jcons.ensure(K);
     vb.jcons = jcons;
     // sized for a LONG window (MV_WLONG jobs, match_v2.hpp): 128 bytes per (job, offer chunk) = 26 MB for a C4 pool
-    vb.prec = e->v_prec.ensure((size_t)MV_WLONG * C);
+    // (launches for good-enough-fitness < 1 use the v2ge list shape, match_v2.hpp: its chunk records and good-enough lists are longer)
+    constexpr size_t PREC_SCALE_NUM = (sizeof(v2ge::ChunkRec) + sizeof(ChunkRec) - 1) / sizeof(ChunkRec);
+    vb.prec = e->v_prec.ensure((size_t)MV_WLONG * C * PREC_SCALE_NUM);
     vb.colbits = e->v_colbits.ensure((size_t)(M ? M : 1u) * MV_JGL);
     vb.cand_fit = e->v_cand_fit.ensure((size_t)MV_WLONG * MV_LM);
     vb.cand_idx = e->v_cand_idx.ensure((size_t)MV_WLONG * MV_LM);
-    vb.ge_idx = e->v_ge_idx.ensure((size_t)MV_WLONG * MV_LG);
+    vb.ge_idx = e->v_ge_idx.ensure((size_t)MV_WLONG * (MV_LG > v2ge::MV_LG ? MV_LG : v2ge::MV_LG));
+    static_assert(v2ge::MV_LM <= MV_LM, "cand_fit / cand_idx are sized for the default shape");
     vb.cinfo = e->v_cinfo.ensure((size_t)MV_WLONG * 4);
     vb.jfh = e->v_jfh.ensure((size_t)MV_WLONG * (MV_FH + 2));
     vb.ctl = e->w_ctl.ensure(1);
@@ -1120,6 +1132,11 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
       unsigned batch = 8;
       unsigned guard = 0;
+      // good-enough-fitness < 1: the kernels of the v2ge list shape, whose walk also knows the "first offer above the threshold" rule
+      const bool ge_shape = in.good_enough < 1.0 && ge_fast_path() && c0.reeval_max == 0u;
+      v2ge::V2Buf gvb;
+      std::memcpy(&gvb, &vb, sizeof(vb));
+      (void)ge_shape;
       while (hc.head < K) {
         for (unsigned r = 0; r < batch; ++r) {
 #ifdef COOK_EVAL_TRACE
@@ -1150,6 +1167,12 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
             }
           }
 #else
+          if (ge_shape) {
+            KL("match_eval2", v2ge::match_eval2<true>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, gvb);
+            KL("match_merge2", v2ge::match_merge2, MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, gvb);
+            KL("match_resolve2", v2ge::match_resolve2_ge, 1, MV_RTHREADS, st, gvb);
+            continue;
+          }
           if (in.good_enough < 1.0) KL("match_eval2", match_eval2<true>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
           else KL("match_eval2", match_eval2<false>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
 #endif
@@ -1256,6 +1279,12 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
   };
   while (!all_done()) {
     for (unsigned r = 0; r < batch; ++r) {
+      if (any_ge && ge_fast_path() && es[live[0]]->deferred_c0.reeval_max == 0u) {  // the v2ge list shape (match_v2.hpp)
+        KL("match_eval2", v2ge::match_eval2_multi<true>, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const v2ge::PoolCtx*)dctx);
+        KL("match_merge2", v2ge::match_merge2_multi, dim3(MV_WMAX / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, (const v2ge::PoolCtx*)dctx);
+        KL("match_resolve2", v2ge::match_resolve2_multi_ge, dim3(1, 1, L), MV_RTHREADS, (const v2ge::PoolCtx*)dctx);
+        continue;
+      }
       if (any_ge) KL("match_eval2", match_eval2_multi<true>, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx);
       else KL("match_eval2", match_eval2_multi<false>, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx);
       KL("match_merge2", match_merge2_multi, dim3(MV_WMAX / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, (const PoolCtx*)dctx);
