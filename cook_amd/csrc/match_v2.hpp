@@ -40,12 +40,20 @@
 // image are sized by them).  The host picks the set per match call (engine.hip).
 #include "match_v2_body.inc"
 
+#ifndef COOK_V2GE_L
+#define COOK_V2GE_L 8    // (tuning builds may set the second shape: per-chunk / merged best-fit entries, good-enough entries)
+#define COOK_V2GE_LM 8
+#define COOK_V2GE_LG 12
+#endif
+#pragma push_macro("COOK_MV_L")
 #pragma push_macro("COOK_MV_LM")
 #pragma push_macro("COOK_MV_LG")
+#undef COOK_MV_L
 #undef COOK_MV_LM
 #undef COOK_MV_LG
-#define COOK_MV_LM 8
-#define COOK_MV_LG 12
+#define COOK_MV_L COOK_V2GE_L
+#define COOK_MV_LM COOK_V2GE_LM
+#define COOK_MV_LG COOK_V2GE_LG
 #define COOK_V2_BODY_SECOND
 namespace v2ge {
 #include "match_v2_body.inc"
@@ -53,6 +61,7 @@ namespace v2ge {
 #undef COOK_V2_BODY_SECOND
 #pragma pop_macro("COOK_MV_LG")
 #pragma pop_macro("COOK_MV_LM")
+#pragma pop_macro("COOK_MV_L")
 #undef COOK_L_TRUNC
 #undef COOK_L_COMPLETE
 #if COOK_MV_LM > COOK_MV_L
