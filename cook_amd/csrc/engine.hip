@@ -1137,6 +1137,21 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       v2ge::V2Buf gvb;
       std::memcpy(&gvb, &vb, sizeof(vb));
       (void)ge_shape;
+      // many offers: the shape with the larger slot table (COOK_BIG_SHAPE=0 switches it off for A/B runs)
+      static const bool big_on = [] {
+        const char* s = std::getenv("COOK_BIG_SHAPE");
+        return !(s && std::atoi(s) == 0);
+      }();
+      const bool big_shape = big_on && !ge_shape && in.good_enough >= 1.0 && M >= V2BIG_MIN_OFFERS && c0.reeval_max == 0u;
+      v2big::V2Buf bvb;
+      std::memcpy(&bvb, &vb, sizeof(vb));
+      if (big_shape) {
+        c0.wcur = std::min<unsigned>(v2big::MV_WMAX, 64u);
+        c0.wlong_cap = std::min<unsigned>(c0.wlong_cap, (unsigned)v2big::MV_WLONG);
+        hc = c0;
+        std::memcpy(e->h_scratch, &c0, sizeof(c0));
+        COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
+      }
       while (hc.head < K) {
         for (unsigned r = 0; r < batch; ++r) {
 #ifdef COOK_EVAL_TRACE
@@ -1167,6 +1182,12 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
             }
           }
 #else
+          if (big_shape) {
+            KL("match_eval2", v2big::match_eval2<false>, dim3(C, v2big::MV_JG), COOK_WAVE * MV_EW, in, st, bvb);
+            KL("match_merge2", v2big::match_merge2, v2big::MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, bvb);
+            KL("match_resolve2", v2big::match_resolve2, 1, MV_RTHREADS, st, bvb);
+            continue;
+          }
           if (ge_shape) {
             KL("match_eval2", v2ge::match_eval2<true>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, gvb);
             KL("match_merge2", v2ge::match_merge2, MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, gvb);

@@ -62,6 +62,23 @@ namespace v2ge {
 #pragma pop_macro("COOK_MV_LG")
 #pragma pop_macro("COOK_MV_LM")
 #pragma pop_macro("COOK_MV_L")
+// A third shape for pools with many offers (BASELINE.json configs[2]: 20 000): there most rounds ended because the window's jobs named
+// more DISTINCT candidate offers than the walk's slot table holds (729 of 1 124 rounds at 256 slots); 512 slots with a window of 256
+// jobs fit the same LDS (155 KB): 1 124 -> 903 rounds, 218 -> 180 ms on MI355X.  Best fit only.
+#pragma push_macro("COOK_MV_WMAX")
+#pragma push_macro("COOK_MV_S")
+#undef COOK_MV_WMAX
+#undef COOK_MV_S
+#define COOK_MV_WMAX COOK_SHAPE(256, 64)
+#define COOK_MV_S COOK_SHAPE(512, 192)
+#define COOK_V2_BODY_SECOND
+namespace v2big {
+#include "match_v2_body.inc"
+}
+#undef COOK_V2_BODY_SECOND
+#pragma pop_macro("COOK_MV_S")
+#pragma pop_macro("COOK_MV_WMAX")
+constexpr unsigned V2BIG_MIN_OFFERS = COOK_SHAPE(12288, 450);  // pools with at least that many offers take the v2big shape
 #undef COOK_L_TRUNC
 #undef COOK_L_COMPLETE
 #if COOK_MV_LM > COOK_MV_L
@@ -71,5 +88,7 @@ namespace v2ge {
 #define COOK_L_TRUNC() (nc == MV_L)
 #define COOK_L_COMPLETE() (nc < MV_L)
 #endif
-static_assert(sizeof(v2ge::V2Buf) == sizeof(V2Buf) && sizeof(v2ge::PoolCtx) == sizeof(PoolCtx) && sizeof(v2ge::WinCtl) == sizeof(WinCtl),
-              "the two shapes share their argument records");
+static_assert(sizeof(v2ge::V2Buf) == sizeof(V2Buf) && sizeof(v2ge::PoolCtx) == sizeof(PoolCtx) && sizeof(v2ge::WinCtl) == sizeof(WinCtl) &&
+                  sizeof(v2big::V2Buf) == sizeof(V2Buf) && sizeof(v2big::WinCtl) == sizeof(WinCtl),
+              "the shapes share their argument records");
+static_assert(v2big::MV_WLONG <= MV_WLONG && v2big::MV_JGL <= MV_JGL && v2ge::MV_WLONG == MV_WLONG, "the host sizes the buffers for the default shape");
