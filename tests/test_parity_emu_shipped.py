@@ -1,4 +1,4 @@
-"""The emulated build compiled with the SHIPPED launch shapes (window 384 / 256 candidate slots / 768-thread resolve workgroup /
+"""The emulated build compiled with the SHIPPED launch shapes (window 320 / 384 candidate slots / 768-thread resolve workgroup /
 1024-slot re-scoring tiles ...): the day-to-day emulated suite (test_parity_emu.py) runs small shapes so that small inputs take many
 rounds; this module runs a few parity cases through exactly the constants the GPU executes, sized so that the shapes matter (more
 than one window, more candidate offers than slots, users of several tiles).  What only the GPU suite covers after that is the
