@@ -404,6 +404,29 @@ def main():
             extra["good_enough=0.8"]["parity"] = {"pool": pc, "jobs_checked": int(len(f08[pc][1])), "against": "oracle, single thread, bit-exact"}
         for e in engines.values():
             e.set_params(params)
+        # the other orchestration of the same placement (match_algo 6, match_v3.hpp: one walker workgroup fed by helper workgroups, the
+        # candidate order kept across rounds) on rank 0's first pool alone, next to the shipped one on the same pool: measured, slower,
+        # kept as a tested alternative.  Its assignments are compared with the shipped orchestration's.
+        try:
+            pc = my_pools[0]
+            e0 = engines[pc]
+            e0.set_params(A.default_params(good_enough_fitness=1.0, match_algo=0))
+            t0s = timed(lambda: e0.cycle_run(K), 2)
+            _, j0, _ = e0.cycle_fetch()
+            e0.set_params(A.default_params(good_enough_fitness=1.0, match_algo=6))
+            t6s = timed(lambda: e0.cycle_run(K), 2)
+            _, j6, _ = e0.cycle_fetch()
+            st6 = e0.match_stats()
+            extra["match_v3"] = {"what": f"pool {pc} alone, K = {K}: match_algo 6 (persistent walker workgroup + helper workgroups) against the "
+                                         "shipped window rounds on the same pool",
+                                 "window_rounds_ms": pct(t0s, 0.5) * 1e3, "match_v3_ms": pct(t6s, 0.5) * 1e3,
+                                 "same_assignments": bool(np.array_equal(j0, j6)),
+                                 "generations": st6.get("v3_generations"), "walked": st6.get("v3_walked"), "settled_by_helpers": st6.get("v3_settled"),
+                                 "walker_wait_us": st6.get("v3_wait_us"), "refused": st6.get("v3_refused")}
+        except Exception as ex:  # (an extra must never cost the headline)
+            extra["match_v3"] = {"error": str(ex)[:300]}
+        for e in engines.values():
+            e.set_params(params)
         for name, kw in (("C2", dict(seed=0xC00C0002, n_pending=50000, n_running=20000, n_users=1000, n_offers=5000)),
                          ("C3", dict(seed=0xC00C0003, n_pending=200000, n_running=80000, n_users=2000, n_offers=20000, gpus=True,
                                      constraints=True))):
