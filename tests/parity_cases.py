@@ -1028,3 +1028,26 @@ def offers_slot_tables(make_engine):
         flagged = int(((got.node_status & 12) != 0).sum())
         assert (flagged > 0) == (slots < 4), (slots, flagged)
     assert k8s_offers is not None
+
+
+def metrics_known_answers(make_engine):
+    """cook_match_metrics' :percentiles / :totals / :largest-by against HAND-DERIVED answers (the reference holds no vector of
+    resource-maps->stats, scheduler.clj:547-582, or task-stats/percentiles, task_stats.clj:59-80: the values follow from the code —
+    see tests/test_oracle_golden.py::test_resource_stats_known_answers, which pins the oracle on the same cases)."""
+    cases = [
+        ([35.0, 20.0, 15.0, 50.0, 40.0], [1.0, 2.0, 3.0, 4.0, 5.0], dict(p50_cpus=35.0, p95_cpus=50.0, p100_cpus=50.0, p50_mem=3.0, p95_mem=5.0,
+                                                                        p100_mem=5.0, total_cpus=160.0, total_mem=15.0, largest_by_cpus=3, largest_by_mem=4)),
+        ([float(x) for x in range(1, 21)], [float(x) for x in range(20, 0, -1)], dict(p50_cpus=10.0, p95_cpus=19.0, p100_cpus=20.0, p50_mem=10.0,
+                                                                                      p95_mem=19.0, largest_by_cpus=19, largest_by_mem=0)),
+        ([4.0, 9.0, 9.0, 1.0], [7.0, 7.0, 2.0, 7.0], dict(largest_by_cpus=2, largest_by_mem=3, p50_cpus=4.0, p100_mem=7.0)),
+        ([0.1, 0.2, 0.3], [0.3, 0.2, 0.1], dict(total_cpus=(0.1 + 0.2) + 0.3, total_mem=(0.3 + 0.2) + 0.1)),
+    ]
+    p = A.default_params(good_enough_fitness=1.0)
+    for cpus, mem, want in cases:
+        jobs = A.Jobs(cpus=cpus, mem=mem)
+        offers = A.Offers(cpus=[1000.0], mem=[1e6], host=np.arange(1, dtype=np.uint32))
+        with make_engine(p) as e:
+            e.match(jobs, offers)
+            m = e.match_metrics()
+        for k, v in want.items():
+            assert m["jobs"][k] == v, (cpus, k, m["jobs"][k], v)

@@ -175,3 +175,39 @@ def test_k8s_generate_offers_golden():
             got = {k: by[host][k] for k in ("mem", "cpus", "disk", "gpus")}
             assert got == exp, (c["name"], host, got)
         assert gauges["nodes_total"] == 5 and gauges["nodes_schedulable"] == 5
+
+
+def test_resource_stats_known_answers():
+    """oracle/pyoracle.resource_stats (row n3) pinned BY RULE: the reference holds no vector of resource-maps->stats
+    (scheduler/src/cook/scheduler/scheduler.clj:547-582) or task-stats/percentiles (task_stats.clj:59-80), so the expected values are
+    derived by hand from the code: percentile p of the sorted values = (nth sorted (dec (ceil (* (/ p 100) n)))) in exact ratio
+    arithmetic (Nearest Rank), :totals = (reduce +) left to right, :largest-by = the LAST element of a stable sort by the resource
+    (among equal maxima the one that comes last in the input)."""
+    from oracle import pyoracle
+    # five values (the Nearest Rank article's example): n = 5 -> p50 index ceil(2.5) - 1 = 2, p95 index ceil(4.75) - 1 = 4, p100 index 4
+    s = pyoracle.resource_stats([35.0, 20.0, 15.0, 50.0, 40.0], [1.0, 2.0, 3.0, 4.0, 5.0])
+    assert (s["p50_cpus"], s["p95_cpus"], s["p100_cpus"]) == (35.0, 50.0, 50.0)
+    assert (s["p50_mem"], s["p95_mem"], s["p100_mem"]) == (3.0, 5.0, 5.0)
+    assert s["total_cpus"] == 160.0 and s["total_mem"] == 15.0
+    assert s["largest_by_cpus"] == 3 and s["largest_by_mem"] == 4
+    # ten values: p50 -> index ceil(5) - 1 = 4 (the LOWER median: (* 1/2 10) is exactly 5, no float fuzz), p95 -> ceil(9.5) - 1 = 9
+    v = [3.0, 6.0, 7.0, 8.0, 8.0, 10.0, 13.0, 15.0, 16.0, 20.0]
+    s = pyoracle.resource_stats(v[::-1], v)
+    assert (s["p50_cpus"], s["p95_cpus"], s["p100_cpus"]) == (8.0, 20.0, 20.0)
+    assert s["largest_by_cpus"] == 0 and s["largest_by_mem"] == 9
+    # 20 values 1..20: p95 -> index ceil(19) - 1 = 18 -> 19 (95/100 * 20 is exactly 19 as a ratio; as a double product it is
+    # 19.000000000000004 -> 20: the oracle must use the ratio, as Clojure does)
+    v = [float(x) for x in range(1, 21)]
+    s = pyoracle.resource_stats(v, v)
+    assert (s["p50_cpus"], s["p95_cpus"], s["p100_cpus"]) == (10.0, 19.0, 20.0)
+    # a tie at the maximum: (last (sort-by ...)) of a stable sort is the later one
+    s = pyoracle.resource_stats([4.0, 9.0, 9.0, 1.0], [7.0, 7.0, 2.0, 7.0])
+    assert s["largest_by_cpus"] == 2 and s["largest_by_mem"] == 3
+    # totals are left-to-right fp64 sums (reduce +): 0.1 + 0.2 + 0.3 is 0.6000000000000001, not 0.6
+    s = pyoracle.resource_stats([0.1, 0.2, 0.3], [0.3, 0.2, 0.1])
+    assert s["total_cpus"] == (0.1 + 0.2) + 0.3 and s["total_mem"] == (0.3 + 0.2) + 0.1 and s["total_cpus"] != s["total_mem"]
+    # one value; no value
+    s = pyoracle.resource_stats([2.5], [8.0])
+    assert (s["p50_cpus"], s["p95_cpus"], s["p100_cpus"], s["largest_by_cpus"]) == (2.5, 2.5, 2.5, 0)
+    s = pyoracle.resource_stats([], [])
+    assert s["total_cpus"] == 0.0 and s["p50_cpus"] != s["p50_cpus"]

@@ -387,6 +387,10 @@ def test_explain_is_the_references_map():
                      dict(reason="Job already ran on this host.", host_count=3)]
 
 
+def test_metrics_known_answers(make_engine):
+    P.metrics_known_answers(make_engine)
+
+
 def test_metrics_parity(make_engine):
     p = A.default_params(good_enough_fitness=1.0)
     pool = synth.make_pool(seed=24, n_pending=700, n_running=0, n_users=25, n_offers=90, gpus=True, constraints=True)

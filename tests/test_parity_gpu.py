@@ -333,6 +333,10 @@ def test_explain_parity(make_engine, algo):
     assert counts[:, 5].any() and counts[:, 8].any()
 
 
+def test_metrics_known_answers(make_engine):
+    P.metrics_known_answers(make_engine)
+
+
 def test_metrics_parity(make_engine):
     p = A.default_params(good_enough_fitness=1.0)
     pool = synth.make_pool(seed=24, n_pending=6000, n_running=0, n_users=50, n_offers=2000, gpus=True, constraints=True)
