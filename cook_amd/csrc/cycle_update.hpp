@@ -74,6 +74,9 @@ struct UpdateBufs {
   DArr<SumI> incl, incl_p, len_incl;
   DArr<unsigned> bad;
   DBuf tmp;  // the compacted copy of one column (swapped with the column afterwards)
+  // buffers that used to be allocated and freed inside every call (hipFree synchronises the whole device: eight pools updating at once
+  // serialised on it): the removal list and the new CSR arrays (swapped with the columns like `tmp`)
+  DArr<uint32_t> rem, n_off, n_a, n_b;
 };
 
 // (included inside engine.hip's anonymous namespace)
@@ -107,7 +110,7 @@ void upd_csr(cook_engine* e, UpdateBufs& ub, DArr<uint32_t>& off, DArr<uint32_t>
   int* len = ub.len.ensure(std::max(1u, p_old));
   SumI* len_incl = ub.len_incl.ensure(std::max(1u, p_old));
   unsigned kept_vals = 0;
-  DArr<uint32_t> n_off, n_a, n_b;
+  DArr<uint32_t>&n_off = ub.n_off, &n_a = ub.n_a, &n_b = ub.n_b;
   n_off.ensure(p_new + 1);
   if (p_old) {
     KL("upd_csr_len", upd_csr_len, div_up(p_old, 256), 256, (const uint32_t*)off.ptr(), keep_p, p_old, len);
@@ -186,10 +189,9 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
     KL("upd_fill_ones", upd_fill_ones, div_up(N, 256), 256, keep, N);
     if (P) KL("upd_fill_ones", upd_fill_ones, div_up(P, 256), 256, keep_p, P);
     if (d->n_remove) {
-      DArr<uint32_t> rem;
+      DArr<uint32_t>& rem = ub.rem;
       h2d(e, rem, d->remove_task, d->n_remove);
       KL("upd_mark_removed", upd_mark_removed, div_up(d->n_remove, 256), 256, (const uint32_t*)rem.ptr(), d->n_remove, N, keep, bad);
-      sync(e);  // `rem` dies with this scope
     }
     KL("upd_pending_keep", upd_pending_keep, div_up(N, 256), 256, (const uint8_t*)e->t_pending.ptr(), (const uint32_t*)e->pend_ord.ptr(),
        (const int*)keep, N, keep_p);
