@@ -904,7 +904,7 @@ bool match_v3_run(cook_engine* e, const MatchIn& in, const MatchState& st, const
     static const unsigned la = [] {  // jobs the helpers may run ahead of the walker (tuning runs: COOK_V3_LA)
       const char* s = std::getenv("COOK_V3_LA");
       const long v = s ? std::atol(s) : 0;
-      return (unsigned)(v >= 1 && v <= V3_R ? v : (V3_R < 32 ? V3_R : 32));
+      return (unsigned)(v >= 1 && v <= V3_GR ? v : (V3_R < 64 ? V3_R : 64));  // (64 measured best on MI355X: 32 / 64 / 128 -> 275 / 250 / 273 ms)
     }();
     h.vb.look_ahead = la;
     static const unsigned rg = [] {  // generations between rebuilds of the order (tuning runs: COOK_V3_REBUILD)
@@ -922,7 +922,7 @@ bool match_v3_run(cook_engine* e, const MatchIn& in, const MatchState& st, const
     const char* s = std::getenv("COOK_V3_HELPERS");
     const long v = s ? std::atol(s) : 0;
     const long cap = V3_HW_MAX / V3_WAVES;
-    return (unsigned)(v >= 1 ? (v > cap ? cap : v) : COOK_SHAPE(6, 2));
+    return (unsigned)(v >= 1 ? (v > cap ? cap : v) : COOK_SHAPE(12, 2));  // (3 / 6 / 12 / 24 helper workgroups: 315 / 250 / 239 / 244 ms per C4 pool)
   }();
   h.vb.n_helper_waves = n_hwg * (unsigned)V3_WAVES;
   h.vb.pad = 0;
