@@ -188,6 +188,7 @@ struct cook_engine {
   V3Ctl last_v3{};
   bool groups_simple = true;  // no balanced / attribute-equals group staged (cook_match_stage)
   unsigned v3_refused = 0;    // calls the v3 kernel handed back to the window rounds
+  bool deferred_small = false;  // the deferred call was set up for the v2small list shape
   MatchIn min{};
   bool cycle_staged = false;
   unsigned cycle_considered = 0;
@@ -875,6 +876,13 @@ void match_init_state(cook_engine* e, const MatchState& st, unsigned K, unsigned
 void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, const WinCtl& hc, hipStream_t stream);
 // good-enough-fitness < 1: the resolve kernel whose fast path knows the rule (COOK_GE_FAST=0: the general path decides every job, as
 // before — kept for A/B measurements)
+static bool small_shape_on() {
+  static const bool on = [] {
+    const char* s = std::getenv("COOK_SMALL_SHAPE");
+    return !(s && std::atoi(s) == 0);
+  }();
+  return on;
+}
 static bool ge_fast_path() {
   static const bool on = [] {
     const char* s = std::getenv("COOK_GE_FAST");
@@ -1026,8 +1034,10 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     constexpr size_t PREC_SCALE_NUM = (sizeof(v2ge::ChunkRec) + sizeof(ChunkRec) - 1) / sizeof(ChunkRec);
     vb.prec = e->v_prec.ensure((size_t)MV_WLONG * C * PREC_SCALE_NUM);
     vb.colbits = e->v_colbits.ensure((size_t)(M ? M : 1u) * MV_JGL);
-    vb.cand_fit = e->v_cand_fit.ensure((size_t)MV_WLONG * MV_LM);
-    vb.cand_idx = e->v_cand_idx.ensure((size_t)MV_WLONG * MV_LM);
+    constexpr size_t CAND_ELEMS = (size_t)MV_WLONG * MV_LM > (size_t)v2small::MV_WLONG * v2small::MV_LM ? (size_t)MV_WLONG * MV_LM
+                                                                                                          : (size_t)v2small::MV_WLONG * v2small::MV_LM;
+    vb.cand_fit = e->v_cand_fit.ensure(CAND_ELEMS);
+    vb.cand_idx = e->v_cand_idx.ensure(CAND_ELEMS);
     vb.ge_idx = e->v_ge_idx.ensure((size_t)MV_WLONG * (MV_LG > v2ge::MV_LG ? MV_LG : v2ge::MV_LG));
     static_assert(v2ge::MV_LM <= MV_LM, "cand_fit / cand_idx are sized for the default shape");
     vb.cinfo = e->v_cinfo.ensure((size_t)MV_WLONG * 4);
@@ -1080,6 +1090,14 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     c0.reeval_max = algo == 3 ? 0x7FFFFFFFu : 0u;  // 3: list-exhausted jobs re-evaluated in place instead of ending the round
     if (const char* ev = std::getenv("COOK_REEVAL_MAX"))  // tuning: a bounded number of in-place re-evaluations per round
       if (algo == 0 || algo == 2) c0.reeval_max = (unsigned)std::max(0, std::atoi(ev));
+    // few considerable jobs, best fit: the shape with the long merged lists (COOK_SMALL_SHAPE=0 switches it off for A/B runs)
+    const bool small_shape = small_shape_on() && (algo == 0 || algo == 2) && in.good_enough >= 1.0 && K <= V2SMALL_MAX_JOBS && c0.reeval_max == 0u &&
+                             !(M >= V2BIG_MIN_OFFERS);
+    if (small_shape) {
+      c0.wcur = std::min<unsigned>(v2small::MV_WMAX, 64u);
+      c0.wlong_cap = std::min<unsigned>(c0.wlong_cap, (unsigned)v2small::MV_WLONG);
+    }
+    e->deferred_small = small_shape;
     WinCtl hc = c0;
     bool done = false;
     if (algo == 4) {  // the persistent kernel: one launch per match call (wins when a pool has the GPU to itself)
@@ -1145,6 +1163,8 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       const bool big_shape = big_on && !ge_shape && in.good_enough >= 1.0 && M >= V2BIG_MIN_OFFERS && c0.reeval_max == 0u;
       v2big::V2Buf bvb;
       std::memcpy(&bvb, &vb, sizeof(vb));
+      v2small::V2Buf svb;
+      std::memcpy(&svb, &vb, sizeof(vb));
       if (big_shape) {
         c0.wcur = std::min<unsigned>(v2big::MV_WMAX, 64u);
         c0.wlong_cap = std::min<unsigned>(c0.wlong_cap, (unsigned)v2big::MV_WLONG);
@@ -1182,6 +1202,12 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
             }
           }
 #else
+          if (small_shape) {
+            KL("match_eval2", v2small::match_eval2<false>, dim3(C, v2small::MV_JG), COOK_WAVE * MV_EW, in, st, svb);
+            KL("match_merge2", v2small::match_merge2, v2small::MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, svb);
+            KL("match_resolve2", v2small::match_resolve2, 1, MV_RTHREADS, st, svb);
+            continue;
+          }
           if (big_shape) {
             KL("match_eval2", v2big::match_eval2<false>, dim3(C, v2big::MV_JG), COOK_WAVE * MV_EW, in, st, bvb);
             KL("match_merge2", v2big::match_merge2, v2big::MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, bvb);
@@ -1292,6 +1318,8 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
   cook_engine* e = lead;                         // KL times / launches on the lead engine
   bool any_ge = false;  // some pool of the launch runs with good-enough-fitness below 1 (match_eval2<GE>)
   for (unsigned x = 0; x < L; ++x) any_ge = any_ge || hctx[x].in.good_enough < 1.0;
+  bool all_small = true;  // (a chain whose pools disagree runs the default shape: every pool was set up with a window it can hold)
+  for (unsigned x = 0; x < L; ++x) all_small = all_small && es[live[x]]->deferred_small;
   unsigned batch = 8, guard = 0;
   auto all_done = [&] {
     for (unsigned x = 0; x < L; ++x)
@@ -1300,6 +1328,12 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
   };
   while (!all_done()) {
     for (unsigned r = 0; r < batch; ++r) {
+      if (all_small) {  // every pool of the chain set up for the v2small list shape (few considerable jobs)
+        KL("match_eval2", v2small::match_eval2_multi<false>, dim3(cmax, v2small::MV_JG, L), COOK_WAVE * MV_EW, (const v2small::PoolCtx*)dctx);
+        KL("match_merge2", v2small::match_merge2_multi, dim3(v2small::MV_WMAX / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, (const v2small::PoolCtx*)dctx);
+        KL("match_resolve2", v2small::match_resolve2_multi, dim3(1, 1, L), MV_RTHREADS, (const v2small::PoolCtx*)dctx);
+        continue;
+      }
       if (any_ge && ge_fast_path() && es[live[0]]->deferred_c0.reeval_max == 0u) {  // the v2ge list shape (match_v2.hpp)
         KL("match_eval2", v2ge::match_eval2_multi<true>, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const v2ge::PoolCtx*)dctx);
         KL("match_merge2", v2ge::match_merge2_multi, dim3(MV_WMAX / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, (const v2ge::PoolCtx*)dctx);

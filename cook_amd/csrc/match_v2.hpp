@@ -79,6 +79,28 @@ namespace v2big {
 #pragma pop_macro("COOK_MV_S")
 #pragma pop_macro("COOK_MV_WMAX")
 constexpr unsigned V2BIG_MIN_OFFERS = COOK_SHAPE(12288, 450);  // pools with at least that many offers take the v2big shape
+// A fourth shape for calls with FEW considerable jobs (config.clj:113 ships fenzo-max-jobs-considered 1000): on a cluster whose offers are
+// mostly full every job opens an offer of its own, so a job's list dies with its predecessors' placements and rounds end on an
+// exhausted list long before the 64 lanes are used up (20 of 25 rounds at K = 1000).  A short window leaves the LDS image room for
+// merged lists of 32 entries and 512 slots.  Best fit only.
+#pragma push_macro("COOK_MV_WMAX")
+#pragma push_macro("COOK_MV_S")
+#pragma push_macro("COOK_MV_LM")
+#undef COOK_MV_WMAX
+#undef COOK_MV_S
+#undef COOK_MV_LM
+#define COOK_MV_WMAX COOK_SHAPE(128, 64)
+#define COOK_MV_S COOK_SHAPE(512, 192)
+#define COOK_MV_LM 32
+#define COOK_V2_BODY_SECOND
+namespace v2small {
+#include "match_v2_body.inc"
+}
+#undef COOK_V2_BODY_SECOND
+#pragma pop_macro("COOK_MV_LM")
+#pragma pop_macro("COOK_MV_S")
+#pragma pop_macro("COOK_MV_WMAX")
+constexpr unsigned V2SMALL_MAX_JOBS = COOK_SHAPE(4096, 150);  // calls with at most that many considerable jobs take the v2small shape
 #undef COOK_L_TRUNC
 #undef COOK_L_COMPLETE
 #if COOK_MV_LM > COOK_MV_L
@@ -89,6 +111,9 @@ constexpr unsigned V2BIG_MIN_OFFERS = COOK_SHAPE(12288, 450);  // pools with at 
 #define COOK_L_COMPLETE() (nc < MV_L)
 #endif
 static_assert(sizeof(v2ge::V2Buf) == sizeof(V2Buf) && sizeof(v2ge::PoolCtx) == sizeof(PoolCtx) && sizeof(v2ge::WinCtl) == sizeof(WinCtl) &&
-                  sizeof(v2big::V2Buf) == sizeof(V2Buf) && sizeof(v2big::WinCtl) == sizeof(WinCtl),
+                  sizeof(v2big::V2Buf) == sizeof(V2Buf) && sizeof(v2big::WinCtl) == sizeof(WinCtl) && sizeof(v2small::V2Buf) == sizeof(V2Buf) &&
+                  sizeof(v2small::PoolCtx) == sizeof(PoolCtx),
               "the shapes share their argument records");
-static_assert(v2big::MV_WLONG <= MV_WLONG && v2big::MV_JGL <= MV_JGL && v2ge::MV_WLONG == MV_WLONG, "the host sizes the buffers for the default shape");
+#ifndef COOK_MV_WMAX  // (a study build may shrink the default window below the other shapes': it must not run those calls)
+static_assert(v2big::MV_WLONG <= MV_WLONG && v2big::MV_JGL <= MV_JGL && v2ge::MV_WLONG == MV_WLONG && v2small::MV_WLONG <= MV_WLONG && v2small::MV_JGL <= MV_JGL, "the host sizes the buffers for the default shape");
+#endif
