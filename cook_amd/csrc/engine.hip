@@ -876,6 +876,17 @@ void match_init_state(cook_engine* e, const MatchState& st, unsigned K, unsigned
 void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, const WinCtl& hc, hipStream_t stream);
 // good-enough-fitness < 1: the resolve kernel whose fast path knows the rule (COOK_GE_FAST=0: the general path decides every job, as
 // before — kept for A/B measurements)
+// rounds launched between two looks at the pools' progress.  The estimate comes from the rate of the last batch; when the cluster
+// fills up in the middle of a batch the rest of the queue settles thousands of jobs per round and what is left of the batch are
+// launches that exit at once (145 of a chain's 520 rounds at a cap of 256): cheap each, not free together.
+static unsigned batch_cap() {
+  static const unsigned cap = [] {
+    const char* s = std::getenv("COOK_BATCH_CAP");
+    const long v = s ? std::atol(s) : 0;
+    return (unsigned)(v >= 2 ? v : 64);  // (256 / 96 / 48 / 24: eight pools 82.7 / 81.9 / 82.0 / 82.8 ms, one pool 57.5 / 57.1 / 56.9 / 56.6)
+  }();
+  return cap;
+}
 static bool small_shape_on() {
   static const bool on = [] {
     const char* s = std::getenv("COOK_SMALL_SHAPE");
@@ -1237,7 +1248,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
         // size the next batch from the observed jobs-per-round
         const double per_round = (double)(hc.head - prev_head) / std::max(1u, hc.rounds - prev_rounds);
         const double est = (K - hc.head) / std::max(1.0, per_round);
-        batch = (unsigned)std::min(256.0, std::max(2.0, est * 1.05 + 2.0));  // over-launching is cheap: finished rounds exit at once
+        batch = (unsigned)std::min((double)batch_cap(), std::max(2.0, est * 1.05 + 2.0));  // over-launching is cheap: finished rounds exit at once
         if (++guard > 4u * K + 64u) e->fail(COOK_E_STATE, "cook_match: window placement made no progress");
       }
     }
@@ -1360,7 +1371,7 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
       const double per_round = (double)(hc[x].head - prev[x].head) / std::max(1u, hc[x].rounds - prev[x].rounds);
       est = std::max(est, (K - hc[x].head) / std::max(1.0, per_round));
     }
-    batch = (unsigned)std::min(256.0, std::max(2.0, est * 1.05 + 2.0));
+    batch = (unsigned)std::min((double)batch_cap(), std::max(2.0, est * 1.05 + 2.0));
     if (++guard > 1000000u) lead->fail(COOK_E_STATE, "cook_cycle_match_multi: placement made no progress");
   }
   for (unsigned x = 0; x < L; ++x) {

@@ -101,6 +101,23 @@ def all_reduce_user_usage(engines: Sequence, n_users: int, world: int, device=No
     return acc.cpu().numpy() if to_host else acc  # to_host=False: the totals stay where the collective left them (no sync, no copy)
 
 
+def reduce_user_usage_parts(parts, pools, n_users: int, world: int, on_gpu: bool):
+    """The tail of all_reduce_user_usage when the pools' [U, 3] vectors have been extracted already (ShardedCluster.cycle does that
+    in the pools' threads): sum the local pools, ONE all-reduce(SUM); the totals stay where the collective left them."""
+    import torch
+    import torch.distributed as dist
+
+    if on_gpu:
+        acc = parts.sum(dim=0)
+    else:
+        acc = torch.zeros((n_users, 3), dtype=torch.float64)
+        for p in pools:
+            acc += torch.from_numpy(np.ascontiguousarray(parts[p]))
+    if world > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    return acc
+
+
 class ShardedCluster:
     """The pools of one cluster that live on this rank, and one match cycle over them.
 
@@ -121,6 +138,7 @@ class ShardedCluster:
         self.last_pool_usage: Dict[int, Sequence[float]] = {}
         self.n_users = 0                      # > 0: every cycle also all-reduces the cross-pool per-user usage [U, 3]
         self._last_user_usage = None          # torch tensor on the collective's device (or numpy); see last_user_usage
+        self._user_parts = None               # [pools, U, 3] device tensor the pools write their usage vectors into
         self.last_phase_ms = (0.0, 0.0, 0.0, 0.0)
         self.chain_whole_cycle = os.environ.get("COOK_CHAIN_WHOLE_CYCLE", "0") != "0"
         self.force_multi = os.environ.get("COOK_FORCE_MULTI", "0") != "0"  # every pool through the multi-pool launch path, one per chain (measurement)
@@ -168,12 +186,31 @@ class ShardedCluster:
         solo = all(getattr(getattr(self.engines[p], "params", None), "match_algo", 0) == 6 for p in self.pools)
         lockstep = not solo and (world or (multi and (len(self.pools) > self.max_chains or self.force_multi)))
 
+        # the per-user usage vectors of the local pools (north_star's collective payload) are extracted by the pools' own threads right
+        # after their rank stage — in parallel, overlapped with the other pools' work — so that the end of the cycle only sums and reduces
+        want_users = bool(self.n_users) and all(hasattr(self.engines[p], "rank_user_usage") for p in self.pools)
+        on_gpu = self.device is not None and getattr(self.device, "type", "cpu") == "cuda"
+        user_parts = None
+        if want_users:
+            if on_gpu:
+                import torch
+                if self._user_parts is None or tuple(self._user_parts.shape) != (len(self.pools), self.n_users, 3):
+                    self._user_parts = torch.empty((len(self.pools), self.n_users, 3), dtype=torch.float64, device=self.device)
+                user_parts = self._user_parts
+            else:
+                user_parts = {}
+
         def run(p):
             self.engines[p].rank_set_quota(self.quota_inputs(p, usages[p], total))
             if lockstep:
                 self.engines[p].cycle_run_rank(num_considerable)  # rank part per pool, in parallel
             else:
                 self.engines[p].cycle_run(num_considerable)
+            if want_users:
+                if on_gpu:
+                    self.engines[p].rank_user_usage(self.n_users, device_ptr=user_parts[self.pools.index(p)].data_ptr())
+                else:
+                    user_parts[p] = self.engines[p].rank_user_usage(self.n_users)
 
         n_chains = max(1, min(len(self.pools), self.max_chains))
         if lockstep and not world and self.chain_whole_cycle:
@@ -204,9 +241,8 @@ class ShardedCluster:
                     groups = [[self.engines[p] for p in self.pools[c::n_chains]] for c in range(n_chains)]
                     list(self._tp.map(cycle_match_multi, groups))
         t3 = time.perf_counter()
-        if self.n_users and all(hasattr(self.engines[p], "rank_user_usage") for p in self.pools):
-            self._last_user_usage = all_reduce_user_usage([self.engines[p] for p in self.pools], self.n_users, self.world, self.device,
-                                                          to_host=False)
+        if want_users:
+            self._last_user_usage = reduce_user_usage_parts(user_parts, self.pools, self.n_users, self.world, on_gpu)
         # host wall time of the phases: pool usage + all-reduce, rank (+ the whole cycle of pools that run on their own chain),
         # lockstep placement, per-user usage all-reduce
         self.last_phase_ms = tuple(1e3 * x for x in (t1 - t0, t2 - t1, t3 - t2, time.perf_counter() - t3))
