@@ -901,6 +901,14 @@ static bool ge_fast_path() {
   }();
   return on;
 }
+// COOK_PACK_ARGS=0: the multi-pool launches read their contexts from memory even when they would fit the kernel arguments (A/B switch)
+static bool pack_args() {
+  static const bool on = [] {
+    const char* s = std::getenv("COOK_PACK_ARGS");
+    return !(s && std::atoi(s) == 0);
+  }();
+  return on;
+}
 void match_rounds_multi(cook_engine** es, unsigned n);
 bool match_rounds_world(cook_engine** es, unsigned n);
 
@@ -1337,8 +1345,45 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
       if (hc[x].head < es[live[x]]->deferred_k) return false;
     return true;
   };
+  // up to MV_PACK pools: their contexts travel in the kernel arguments (match_v2_body.inc: PoolPack)
+  const bool packed = L <= (unsigned)MV_PACK && pack_args();
+  PoolPack<2> pk2{};
+  PoolPack<MV_PACK> pk4{};
+  for (unsigned x = 0; x < (unsigned)MV_PACK; ++x) {
+    if (x < 2) pk2.c[x] = hctx[x < L ? x : 0];
+    pk4.c[x] = hctx[x < L ? x : 0];
+  }
+// one round of launches of namespace NS (the list shape) with the contexts packed: N = 2 or MV_PACK
+#define COOK_PACK_ROUND(NS, GE, REEVAL, GEF, WMAXV, JGV)                                                                                      \
+  do {                                                                                                                                      \
+    if (L <= 2u) {                                                                                                                          \
+      const auto& P = reinterpret_cast<const NS::PoolPack<2>&>(pk2);                                                                        \
+      KL("match_eval2", (NS::match_eval2_pack<GE, 2>), dim3(cmax, JGV, L), COOK_WAVE * MV_EW, P);                                           \
+      KL("match_merge2", (NS::match_merge2_pack<2>), dim3(WMAXV / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, P);                                  \
+      KL("match_resolve2", (NS::match_resolve2_pack<REEVAL, GEF, 2>), dim3(1, 1, L), MV_RTHREADS, P);                                       \
+    } else {                                                                                                                                \
+      const auto& P = reinterpret_cast<const NS::PoolPack<MV_PACK>&>(pk4);                                                                  \
+      KL("match_eval2", (NS::match_eval2_pack<GE, MV_PACK>), dim3(cmax, JGV, L), COOK_WAVE * MV_EW, P);                                     \
+      KL("match_merge2", (NS::match_merge2_pack<MV_PACK>), dim3(WMAXV / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, P);                            \
+      KL("match_resolve2", (NS::match_resolve2_pack<REEVAL, GEF, MV_PACK>), dim3(1, 1, L), MV_RTHREADS, P);                                 \
+    }                                                                                                                                       \
+  } while (0)
   while (!all_done()) {
     for (unsigned r = 0; r < batch; ++r) {
+      if (packed) {
+        if (all_small) {
+          COOK_PACK_ROUND(v2small, false, false, false, v2small::MV_WMAX, v2small::MV_JG);
+        } else if (any_ge && ge_fast_path() && es[live[0]]->deferred_c0.reeval_max == 0u) {
+          COOK_PACK_ROUND(v2ge, true, false, true, MV_WMAX, MV_JG);
+        } else if (es[live[0]]->deferred_c0.reeval_max != 0u) {
+          if (any_ge) COOK_PACK_ROUND(, true, true, false, MV_WMAX, MV_JG);
+          else COOK_PACK_ROUND(, false, true, false, MV_WMAX, MV_JG);
+        } else {
+          if (any_ge) COOK_PACK_ROUND(, true, false, false, MV_WMAX, MV_JG);
+          else COOK_PACK_ROUND(, false, false, false, MV_WMAX, MV_JG);
+        }
+        continue;
+      }
       if (all_small) {  // every pool of the chain set up for the v2small list shape (few considerable jobs)
         KL("match_eval2", v2small::match_eval2_multi<false>, dim3(cmax, v2small::MV_JG, L), COOK_WAVE * MV_EW, (const v2small::PoolCtx*)dctx);
         KL("match_merge2", v2small::match_merge2_multi, dim3(v2small::MV_WMAX / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, (const v2small::PoolCtx*)dctx);

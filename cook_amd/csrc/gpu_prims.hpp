@@ -71,8 +71,15 @@ static __device__ __forceinline__ unsigned long long cook_ticks() { return wall_
 #define OPAQUE_V(x) asm volatile("" : "+v"(x))
 #define WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)
 #define WAIT_LDS_BUT_LAST() __builtin_amdgcn_s_waitcnt(0xC17F)  // lgkmcnt(1): LDS operations retire in order, the newest may still fly
+#define WAIT_LDS_BUT_2() __builtin_amdgcn_s_waitcnt(0xC27F)     // lgkmcnt(2)
 #define WAIT_ALL_MEM() __builtin_amdgcn_s_waitcnt(0x0070)     // vmcnt(0) lgkmcnt(0)
 static __device__ __forceinline__ unsigned wave_uniform_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+static __device__ __forceinline__ unsigned long long wave_uniform_u64(unsigned long long v) {
+  return ((unsigned long long)wave_uniform_u32((unsigned)(v >> 32)) << 32) | (unsigned long long)wave_uniform_u32((unsigned)v);
+}
+static __device__ __forceinline__ double wave_uniform_f64(double v) { return __longlong_as_double((long long)wave_uniform_u64((unsigned long long)__double_as_longlong(v))); }
+template <class T>
+static __device__ __forceinline__ T* wave_uniform_ptr(T* p) { return reinterpret_cast<T*>(wave_uniform_u64(reinterpret_cast<unsigned long long>(p))); }
 
 // ---- wave-wide max of a u64 key / lane reads without going through LDS ------------------------------------------------
 // ds_bpermute-based shuffles cost ~100+ cycles of latency each; the placement walk is a dependent chain, so its

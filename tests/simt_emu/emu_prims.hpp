@@ -61,8 +61,13 @@ static inline unsigned long long cook_ticks() { return 0ull; }
 #define OPAQUE_V(x) ((void)0)
 #define WAIT_LDS() ((void)0)
 #define WAIT_LDS_BUT_LAST() ((void)0)
+#define WAIT_LDS_BUT_2() ((void)0)
 #define WAIT_ALL_MEM() ((void)0)
 static inline unsigned wave_uniform_u32(unsigned v) { return v; }
+static inline unsigned long long wave_uniform_u64(unsigned long long v) { return v; }
+static inline double wave_uniform_f64(double v) { return v; }
+template <class T>
+static inline T* wave_uniform_ptr(T* p) { return p; }
 
 // ---- wave-wide max of a u64 key / lane reads without going through LDS ------------------------------------------------
 // ds_bpermute-based shuffles cost ~100+ cycles of latency each; the placement walk is a dependent chain, so its
