@@ -18,7 +18,7 @@ def read(name):
     for line in open(os.path.join(src, name)):
         m = re.match(r"^(.*?) (\{.*\}) dispatches (\d+)$", line.strip())
         if m:
-            k = re.sub(r"^void ", "", m.group(1)).split("<")[0].replace("_multi", "")
+            k = re.sub(r"(_multi|_pack)$", "", re.sub(r"^void ", "", m.group(1)).split("<")[0])  # (the lockstep / packed-context launches of a kernel)
             out[k] = (ast.literal_eval(m.group(2)), int(m.group(3)))
     return out
 

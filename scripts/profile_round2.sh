@@ -27,7 +27,7 @@ pmc() {  # name, counters, command...
   local name=$1 ctr=$2; shift 2
   rm -rf /tmp/pmc_$name
   timeout 400 rocprofv3 --pmc $ctr -d /tmp/pmc_$name -o p --output-format csv -- "$@" > /dev/null 2> "$OUT/pmc_$name.err"
-  python "$ROOT/scripts/pmc_summary.py" /tmp/pmc_$name 12 > "$OUT/pmc_$name.txt"
+  python "$ROOT/scripts/pmc_summary.py" /tmp/pmc_$name 24 > "$OUT/pmc_$name.txt"
   head -4 "$OUT/pmc_$name.txt" | cut -c1-400
 }
 for S in ${STEPS:-kt8 kt1 pmc8 sq1 ktrb}; do
