@@ -257,6 +257,15 @@ def test_multi_pool(make_engine, algo):
     P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0, match_algo=algo), k=300, want_persistent=2 if algo == 5 else 0)
 
 
+@pytest.mark.parametrize("n,ge", [(2, 1.0), (4, 1.0), (6, 1.0), (4, 0.8), (6, 0.8)])
+def test_multi_pool_context_forms(make_engine, n, ge):
+    # how the lockstep launches get their pools' contexts: in the kernel arguments for up to four pools (PoolPack<2> / PoolPack<4>,
+    # picked by blockIdx.z), from a context record in memory beyond that — same placements either way, best fit and good-enough
+    pools = [synth.make_pool(seed=170 + i, n_pending=220 + 40 * i, n_running=60, n_users=12, n_offers=50 + 30 * i, gpus=(i % 2 == 1),
+                             constraints=(i % 3 == 0)) for i in range(n)]
+    P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=ge, match_algo=2), k=10 ** 9)
+
+
 @pytest.mark.parametrize("whole", [True, False], ids=["chain-runs-rank-and-placement", "rank-barrier-placement"])
 def test_sharded_cluster_lockstep_chains(make_engine, whole):
     # ShardedCluster.cycle as bench.py drives it, five pools on two launch chains (slots 3 + 2): quota inputs, rank per pool,

@@ -273,6 +273,14 @@ def test_cycle_with_considerable_filters(make_engine):
     assert 0 < len(pos) <= 1000 and not np.array_equal(pos, np.arange(len(pos)))
 
 
+@pytest.mark.parametrize("n,ge", [(2, 1.0), (4, 1.0), (6, 1.0), (4, 0.8), (6, 0.8)])
+def test_multi_pool_context_forms(make_engine, n, ge):
+    # the lockstep launches with their pools' contexts in the kernel arguments (PoolPack<2> / <4>) and, beyond four pools, read from memory
+    pools = [synth.make_pool(seed=170 + i, n_pending=2500 + 500 * i, n_running=600, n_users=40, n_offers=300 + 250 * i, gpus=(i % 2 == 1),
+                             constraints=(i % 3 == 0)) for i in range(n)]
+    P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=ge, match_algo=2), k=10 ** 9)
+
+
 @pytest.mark.parametrize("algo", [2, 5], ids=["lockstep-launches", "world"])
 def test_multi_pool(make_engine, algo):
     pools = [synth.make_pool(seed=71, n_pending=6000, n_running=2000, n_users=100, n_offers=3000, gpus=True, constraints=True),
