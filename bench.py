@@ -49,10 +49,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-adjacent", action="store_true", help="skip the timings of the rows next to the hot path (offers, explain, metrics)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="cap on the oracle threads of the cpu_baseline leg; 0 = os.cpu_count()")
     ap.add_argument("--no-extras", action="store_true", help="skip SURVEY.md §8d's reporting matrix (K = 1000 / 1e5, good-enough 0.8, C2, C3) under extra_configs")
     ap.add_argument("--as-rank-of", type=int, default=0, help="single process: time only the pools rank 0 of an N-GPU job would hold (the per-GPU load behind DESIGN.md's scaling prediction; not a bench line)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of the timed configuration (rank 0's first and last pool vs the oracle, after the timed region)")
+    # rehearsal of the multi-process path on a machine without GPUs (tests/test_sharding_gloo.py): the engines load the given build of
+    # the library (the SIMT emulator, test infrastructure) and the collectives run over gloo.  Never a bench line: `data` says so.
+    ap.add_argument("--engine-lib", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"), help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -169,25 +173,114 @@ def extra_c5(device, check=True, steps=3, sizes=(1_000_000, 500_000, 10_000, 50_
     return out
 
 
+def cpu_baseline_leg(args, params, cluster, pools, my_pools, K, n_off):
+    """The oracle ("port": C++ restatement of the reference algorithm, TEST INFRASTRUCTURE used here only as the timed CPU leg and as
+    the checker) on this box's host cores, over the whole cycle of the pools held by this process.  -> (cpu_baseline dict,
+    {pool: (ranked, j2o)} of the oracle for the parity check)."""
+    import threading
+    from oracle import pyoracle
+    host_cores = os.cpu_count() or 1
+    P = len(my_pools)
+    quota = {p: cluster.quota_inputs(p, cluster.last_pool_usage[p], cluster.last_group_usage) for p in my_pools}
+    threaded_ok = args.good_enough >= 1.0  # (the oracle's host-bucketed form is best fit only)
+
+    def one_pool(p, nt, out):
+        c0 = time.perf_counter()
+        o_ranked, _ = pyoracle.rank(params, pools[p].tasks, pools[p].users, quota=quota[p])
+        c1 = time.perf_counter()
+        kk = min(K, len(o_ranked))
+        pend_ord = np.cumsum(pools[p].tasks.pending) - 1
+        cons = pools[p].pending_jobs.take(pend_ord[o_ranked[:kk]])
+        c2 = time.perf_counter()
+        o_j2o, _, _ = pyoracle.match(params, cons, pools[p].offers, pools[p].groups, nthreads=nt)
+        c3 = time.perf_counter()
+        out[p] = (o_ranked, o_j2o, c1 - c0, c3 - c2)
+
+    def concurrent(nt):
+        out = {}
+        ths = [threading.Thread(target=one_pool, args=(p, nt, out)) for p in my_pools]
+        a = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        wall = time.perf_counter() - a
+        assert len(out) == P, "an oracle thread failed"
+        return wall, out
+
+    variants = []
+    cap = args.cpu_threads or host_cores
+    wall1, ref = concurrent(1)
+    variants.append({"form": "pools concurrent", "pools_at_once": P, "threads_per_pool": 1, "cores": min(P, host_cores), "cycle_s": wall1,
+                     "cycles_per_s": 1.0 / wall1})
+    t_per = min(16, max(1, cap // max(1, P)))
+    if threaded_ok and t_per > 1:
+        wall_t, out_t = concurrent(t_per)
+        for p in my_pools:
+            if not (np.array_equal(out_t[p][0], ref[p][0]) and np.array_equal(out_t[p][1], ref[p][1])):
+                raise AssertionError("oracle: threaded and single-thread placements differ")
+        variants.append({"form": "pools concurrent", "pools_at_once": P, "threads_per_pool": t_per, "cores": min(P * t_per, host_cores),
+                         "cycle_s": wall_t, "cycles_per_s": 1.0 / wall_t})
+    nt_serial = min(16, cap)
+    if threaded_ok and nt_serial > 1:  # the previous rounds' form: one pool at a time, hosts bucketed over up to 16 threads
+        one = {}
+        one_pool(my_pools[0], nt_serial, one)
+        _, _, rank_s, match_s = one[my_pools[0]]
+        variants.append({"form": "pools one after the other (pool 0 timed, x pools)", "pools_at_once": 1, "threads_per_pool": nt_serial,
+                         "cores": nt_serial, "cycle_s": (rank_s + match_s) * P, "cycles_per_s": 1.0 / ((rank_s + match_s) * P)})
+    best = max(variants, key=lambda v: v["cycles_per_s"])
+    cpu = {"value": best["cycles_per_s"], "unit": "cycles/s", "cores": best["cores"], "kind": "port",
+           "sample": f"the whole cycle (not a sample): oracle rank + placement of all K = {K} considerable jobs x {n_off} offers of each of the {P} "
+                     f"pools; fastest form: {best['form']}, {best['threads_per_pool']} thread(s) per pool, {best['cycle_s']:.2f} s per cycle",
+           "variants": variants, "host_cores": host_cores,
+           "rank_s_pool0": ref[my_pools[0]][2], "match_s_pool0_single_thread": ref[my_pools[0]][3],
+           "note": "C++ restatement (-O2) of the reference algorithm; the JVM reference cannot run here (no JDK, Fenzo jar absent). The reference "
+                   "runs one match handler per pool concurrently (tools.clj:799-806), which the 'pools concurrent' forms reproduce; the "
+                   "threads-per-pool form synchronises its workers once per job (barrier-bound at 6 250 hosts per job)."}
+    return cpu, {p: (ref[p][0], ref[p][1]) for p in my_pools}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` from a plain shell: launch ourselves as one process per GPU (the driver's form is
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`, which arrives here with WORLD_SIZE set)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE=1)", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per pool stream (read at HIP initialisation; see cook_amd/engine.py)
     import torch
     import torch.distributed as dist
 
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rehearsal = args.engine_lib is not None  # the emulator build on CPU: plumbing only, no number
+    if not rehearsal:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    on_gpu = torch.cuda.is_available() and not rehearsal
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+
+    def device_sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if on_gpu:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from cook_amd import _abi as A
     from cook_amd import synth
@@ -208,7 +301,7 @@ def main():
     pools, engines = {}, {}
     for p in my_pools:
         pools[p] = workload.make_pool(spec, p)
-        e = Engine(params, device=local_rank)
+        e = Engine(params, device=0, lib_path=args.engine_lib) if rehearsal else Engine(params, device=local_rank)  # (the emulator has one device)
         e.cycle_stage(pools[p].tasks, pools[p].users, pools[p].pending_jobs, pools[p].offers, pools[p].groups)
         engines[p] = e
     gen_s = time.time() - t0
@@ -216,17 +309,17 @@ def main():
     # all pools of the cluster -> the cross-rank all-reduce (scheduler.clj:2125-2157); cook_amd/sharding.py
     from cook_amd import sharding
     qg = workload.quota_groups(spec)
-    cluster = sharding.ShardedCluster(engines, qg, world=world, rank=rank, device=dev)
+    cluster = sharding.ShardedCluster(engines, qg, world=world, rank=rank, device=dev, serial=rehearsal)  # (the emulator runs one launch at a time)
     cluster.n_users = args.users  # every timed cycle runs north_star's collective: the all-reduce of the cross-pool per-user usage [U x 3]
 
     def cycle():
         cluster.cycle(K)
 
     def fence():
-        torch.cuda.synchronize()
+        device_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     for _ in range(args.warmup):
         cycle()
@@ -299,61 +392,36 @@ def main():
                         "kernels_ms_per_cycle": {k: round(v[0] / max(1, min(args.steps, 3)), 4) for k, v in
                                                  sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]}}
 
-    # ---- CPU baseline: the oracle (kind "port") on rank 0's first pool, bounded sample ---------------------------
-    # ---- + parity of the TIMED configuration: the results of the last timed cycle (as fetched above, before the profiled
-    #      pass) of rank 0's first pool (first slot of a launch chain) and last pool (last slot of another chain) against
-    #      the oracle, bit-exact.  A fast wrong answer must not produce a number: a mismatch raises.
+    # ---- CPU baseline: the oracle (kind "port") on the box's host cores, the WHOLE cycle of rank 0's pools ------------------
+    # The reference runs every pool's match handler on its own thread (tools.clj:799-806 chime-at per pool, scheduler.clj:2425-2435),
+    # so the faithful use of a many-core host is all pools CONCURRENTLY: one oracle thread group per pool (ctypes releases the GIL),
+    # total threads <= os.cpu_count().  Variants: (a) pools concurrent x 1 thread, (b) pools concurrent x t threads (hosts bucketed
+    # per job, Fenzo's executor-per-CPU form; t = cores // pools, capped at 16), (c) the pools one after the other with up to 16
+    # threads each (one pool timed, x pools).  `value` = the fastest; nothing is scaled in (a) / (b): they time the full K of every
+    # pool (~2 s per pool of single-thread work).
+    # ---- + parity of the TIMED configuration: the results of the last timed cycle (as fetched above, before the profiled pass)
+    #      against the oracle, bit-exact — every pool of rank 0 when the concurrent baseline ran (its outputs are reused), else the
+    #      first pool (first slot of a launch chain) and the last (last slot of another chain).  A fast wrong answer must not
+    #      produce a number: a mismatch raises.
     cpu = None
     parity_checked, parity_pools = False, []
     if rank == 0 and not (args.no_cpu_baseline and args.no_check):
-        from oracle import pyoracle
-        p0 = my_pools[0]
-        pool = pools[p0]
-        cores = args.cpu_threads or min(16, os.cpu_count() or 1)
-        q0 = cluster.quota_inputs(p0, cluster.last_pool_usage[p0], cluster.last_group_usage)
-        c0 = time.perf_counter()
-        o_ranked, _ = pyoracle.rank(params, pool.tasks, pool.users, quota=q0)
-        c1 = time.perf_counter()
-        # bounded sample of the placement: first k_s considerable jobs, ~<= 2e9 pair evaluations
-        k_s = int(min(min(K, len(o_ranked)), max(1000, 1_000_000_000 // max(1, n_off))))
-        pend_ord = np.cumsum(pool.tasks.pending) - 1
-        cons = pool.pending_jobs.take(pend_ord[o_ranked[:k_s]])
-        # the restatement timed (a) single-thread and (b) with the hosts bucketed over threads per job (Fenzo's
-        # executor-per-CPU evaluation); (b) synchronises its workers once per JOB, so at 6 250 hosts per job it measures barrier
-        # latency as much as arithmetic — `value` quotes whichever is faster, both are in `variants`
-        k_full = min(K, len(o_ranked))
-        variants = []
-        o_j2o = None
-        thread_counts = [1] if args.good_enough < 1.0 else sorted({1, min(8, cores), cores})
-        for nt in thread_counts:
-            c2 = time.perf_counter()
-            o_j2o_nt, _, _ = pyoracle.match(params, cons, pool.offers, pool.groups, nthreads=nt)
-            c3 = time.perf_counter()
-            if o_j2o is None:
-                o_j2o = o_j2o_nt
-            elif not np.array_equal(o_j2o, o_j2o_nt):
-                raise AssertionError("oracle: threaded and single-thread placements differ")
-            pool_s = (c1 - c0) + (c3 - c2) * (k_full / max(1, k_s))  # placement cost is ~linear in K while the cluster has room
-            variants.append({"threads": nt, "match_sample_s": c3 - c2, "cycles_per_s": 1.0 / (pool_s * P)})
-        best = max(variants, key=lambda v: v["cycles_per_s"])
-        cpu = {"value": best["cycles_per_s"], "unit": "cycles/s", "cores": best["threads"], "kind": "port",
-               "sample": f"oracle on pool {p0} of {P}: rank of {pool.tasks.n} tasks ({c1 - c0:.2f} s) + placement of the first "
-                         f"{k_s} of {k_full} considerable jobs x {n_off} offers ({best['match_sample_s']:.2f} s with {best['threads']} thread(s)), "
-                         f"scaled linearly to K and x{P} pools",
-               "rank_s": c1 - c0, "match_sample_s": best["match_sample_s"], "variants": variants, "host_cores": os.cpu_count(),
-               "note": "C++ restatement (-O2) of the reference algorithm; the JVM reference cannot run here (no JDK, Fenzo jar absent). "
-                       "The threaded form synchronises per job (barrier-bound), the single-thread form is the plain sweep."}
+        cpu, oracle_out = (None, {})
+        if not args.no_cpu_baseline and world == 1 and not args.as_rank_of:
+            cpu, oracle_out = cpu_baseline_leg(args, params, cluster, pools, my_pools, K, n_off)
         if not args.no_check:
-            r, j2o = fetched[p0]
-            assert np.array_equal(r, o_ranked), f"PARITY: rank of pool {p0} differs from the oracle"
-            assert np.array_equal(j2o[:k_s], o_j2o), f"PARITY: assignments of pool {p0} differ from the oracle"
-            parity_pools.append({"pool": p0, "jobs_checked": int(k_s)})
-            if len(my_pools) > 1:  # a pool from another chain, in its last lockstep slot
-                from oracle import checks
-                pl = my_pools[-1]
-                ql = cluster.quota_inputs(pl, cluster.last_pool_usage[pl], cluster.last_group_usage)
-                checks.check_pool_against_oracle(params, pools[pl], ql, fetched[pl][0], fetched[pl][1], K, threads=cores)
-                parity_pools.append({"pool": pl, "jobs_checked": int(len(fetched[pl][1]))})
+            from oracle import checks
+            check_pools = list(my_pools) if oracle_out else sorted({my_pools[0], my_pools[-1]})
+            for pc in check_pools:
+                r, j2o = fetched[pc]
+                if pc in oracle_out:
+                    o_ranked, o_j2o = oracle_out[pc]
+                    assert np.array_equal(r, o_ranked), f"PARITY: rank of pool {pc} differs from the oracle"
+                    assert np.array_equal(j2o, o_j2o), f"PARITY: assignments of pool {pc} differ from the oracle"
+                else:
+                    qc = cluster.quota_inputs(pc, cluster.last_pool_usage[pc], cluster.last_group_usage)
+                    checks.check_pool_against_oracle(params, pools[pc], qc, r, j2o, K, threads=min(16, os.cpu_count() or 1))
+                parity_pools.append({"pool": pc, "jobs_checked": int(len(j2o))})
             parity_checked = True
 
     # ---- SURVEY.md §8d's reporting matrix, beside the headline (never instead of it): the reference's default cap K = 1000
@@ -550,7 +618,7 @@ def main():
             "metric": "match-cycles/sec at 1M pending x 50k offers", "value": value, "unit": "cycles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "p50_cycle_latency_ms": lat_ms[len(lat_ms) // 2], "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL on the SIMT emulator (CPU, gloo): plumbing only, not a measurement",
             "config": {"workload": f"{P} pools x ({n_pend} pending + {n_run} running tasks, {n_off} offers), {args.users} users; "
                                    f"rank all tasks + match K={K} per pool"
                                    + ("" if args.no_constraints else "; gpu dim + EQUALS/novel-host/unique-group constraints"),

@@ -118,6 +118,18 @@ def reduce_user_usage_parts(parts, pools, n_users: int, world: int, on_gpu: bool
     return acc
 
 
+class _SerialExecutor:
+    """map / shutdown of a ThreadPoolExecutor, on the calling thread"""
+
+    @staticmethod
+    def map(fn, xs):
+        return [fn(x) for x in xs]
+
+    @staticmethod
+    def shutdown(wait=True):
+        return None
+
+
 class ShardedCluster:
     """The pools of one cluster that live on this rank, and one match cycle over them.
 
@@ -126,19 +138,26 @@ class ShardedCluster:
                  local pools in lockstep rounds (cook_cycle_match_multi); a single pool runs cook_cycle_run.
     """
 
-    def __init__(self, engines: Dict[int, PoolEngine], groups: QuotaGroups, world: int = 1, rank: int = 0, device=None):
+    def __init__(self, engines: Dict[int, PoolEngine], groups: QuotaGroups, world: int = 1, rank: int = 0, device=None, serial: bool = False):
+        """serial: the pools of this rank take turns on the calling thread instead of running on one thread each (engines that
+        cannot be called concurrently: the single-process SIMT emulator of the tests)."""
         self.engines = dict(engines)
         self.pools = sorted(self.engines)
         self.groups = groups
         self.world, self.rank, self.device = world, rank, device
-        self._tp = ThreadPoolExecutor(max_workers=max(1, len(self.pools)))
         self.max_chains = int(os.environ.get("COOK_MAX_CHAINS", "4"))
-        self._tp_rank = ThreadPoolExecutor(max_workers=max(1, min(len(self.pools), int(os.environ.get("COOK_MAX_RANK_CHAINS", str(self.max_chains))))))
+        if serial:
+            self._tp = self._tp_rank = _SerialExecutor()
+        else:
+            self._tp = ThreadPoolExecutor(max_workers=max(1, len(self.pools)))
+            self._tp_rank = ThreadPoolExecutor(max_workers=max(1, min(len(self.pools), int(os.environ.get("COOK_MAX_RANK_CHAINS", str(self.max_chains))))))
         self.last_group_usage: Optional[np.ndarray] = None
         self.last_pool_usage: Dict[int, Sequence[float]] = {}
         self.n_users = 0                      # > 0: every cycle also all-reduces the cross-pool per-user usage [U, 3]
         self._last_user_usage = None          # torch tensor on the collective's device (or numpy); see last_user_usage
-        self._user_parts = None               # [pools, U, 3] device tensor the pools write their usage vectors into
+        self._user_parts = [None, None]       # two [pools, U, 3] device tensors the pools write their usage vectors into, used in turn:
+        self._user_parts_turn = 0             # the sum / all-reduce of cycle c (torch's stream) may still read one while the engines'
+                                              # own streams fill the other in cycle c + 1
         self.last_phase_ms = (0.0, 0.0, 0.0, 0.0)
         self.chain_whole_cycle = os.environ.get("COOK_CHAIN_WHOLE_CYCLE", "0") != "0"
         self.force_multi = os.environ.get("COOK_FORCE_MULTI", "0") != "0"  # every pool through the multi-pool launch path, one per chain (measurement)
@@ -194,9 +213,10 @@ class ShardedCluster:
         if want_users:
             if on_gpu:
                 import torch
-                if self._user_parts is None or tuple(self._user_parts.shape) != (len(self.pools), self.n_users, 3):
-                    self._user_parts = torch.empty((len(self.pools), self.n_users, 3), dtype=torch.float64, device=self.device)
-                user_parts = self._user_parts
+                turn = self._user_parts_turn = self._user_parts_turn ^ 1
+                if self._user_parts[turn] is None or tuple(self._user_parts[turn].shape) != (len(self.pools), self.n_users, 3):
+                    self._user_parts[turn] = torch.empty((len(self.pools), self.n_users, 3), dtype=torch.float64, device=self.device)
+                user_parts = self._user_parts[turn]
             else:
                 user_parts = {}
 

@@ -156,3 +156,40 @@ def test_group_without_running_tasks_skips_the_group_filter():
     cl.cycle(10_000)
     assert all(len(cl.engines[p].ranked) == 49 for p in pools)
     cl.close()
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launches_world2_over_gloo():
+    """`python bench.py --gpus 2` from a plain shell (no WORLD_SIZE): bench.py re-executes itself under torch.distributed.run, one
+    process per rank; both ranks run the sharded cycle (quota-group + per-user all-reduces over gloo here, RCCL on the GPU box), rank 0
+    prints the one JSON line with the whole-job rate and checks its pools against the oracle.  The engines are the SIMT-emulator build
+    of the library (test infrastructure) at a small cluster: what is rehearsed is the launch / reporting / collective plumbing."""
+    import json
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests", "simt_emu"))
+    import build_emu
+    lib = build_emu.build()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pools", "4", "--pending", "1600",
+           "--running", "800", "--offers", "96", "--users", "20", "--no-extras", "--no-adjacent", "--engine-lib", lib, "--dist-backend", "gloo"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line, rank 1 none
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["steps"] == 2 and doc["value"] > 0 and doc["scaling"] == "strong"
+    assert doc["parity_checked"] is True and [p["pool"] for p in doc["parity"]["pools"]] == [0, 2]  # rank 0 of 2 holds pools 0 and 2
+    assert doc["cpu_baseline"] is None  # N = 1 only
+    assert "REHEARSAL" in doc["data"]
+    assert doc["last_cycle"]["considered"] > 0 and doc["phase_ms"]["user_usage_allreduce"] >= 0
+    # N = 1 through the same entry point: all pools local, the concurrent cpu_baseline leg and the parity of every pool
+    cmd1 = [c for c in cmd]
+    cmd1[cmd1.index("--gpus") + 1] = "1"
+    r1 = subprocess.run(cmd1, env=env, capture_output=True, text=True, timeout=800)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and [p["pool"] for p in d1["parity"]["pools"]] == [0, 1, 2, 3]
+    cb = d1["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["variants"][0]["form"] == "pools concurrent" and cb["variants"][0]["pools_at_once"] == 4
+    assert cb["value"] == max(v["cycles_per_s"] for v in cb["variants"]) and cb["cores"] >= 1
+    assert d1["last_cycle"]["matched"] == doc["last_cycle"]["matched"]  # the sharded job places what the single process places
