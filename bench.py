@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--considerable", type=int, default=0, help="K per pool; 0 = all ranked pending jobs")
     ap.add_argument("--good-enough", type=float, default=1.0, help="1.0 = parity setting (zz_simulator.clj:84)")
     ap.add_argument("--no-constraints", action="store_true")
-    ap.add_argument("--match-algo", type=int, default=0, help="cook_params.match_algo: 0/2 window rounds with one launch per phase, 1 serial, 3 = 2 + in-place re-evaluation, 4 persistent kernel with grid barriers, 5 = ONE persistent launch for all pools of the rank (match_world)")
+    ap.add_argument("--match-algo", type=int, default=0, help="cook_params.match_algo: 0 / 2 window rounds (eval, merge, resolve launches), 1 = the one-job-at-a-time sweep by a single workgroup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-adjacent", action="store_true", help="skip the timings of the rows next to the hot path (offers, explain, metrics)")
@@ -60,7 +60,7 @@ def parse():
     return ap.parse_args()
 
 
-PLACEMENT_KERNELS = ("match_v3", "match_world", "match_resolve2", "match_eval2", "match_merge2", "match_persist", "match_serial")
+PLACEMENT_KERNELS = ("match_resolve2", "match_eval2", "match_merge2", "match_serial")
 
 
 def algorithmic_bytes(kernel, n_tasks, k, m, launches_per_match=1.0, pools_per_launch=1.0):
@@ -375,8 +375,6 @@ def main():
             n_cycles = max(1, min(args.steps, 3))
             launches_per_match = agg[dom][1] / (n_cycles * max(1, len(my_pools)))
             n_chains = min(len(my_pools), cluster.max_chains) if len(my_pools) > cluster.max_chains else len(my_pools)
-            if dom == "match_v3":
-                n_chains = len(my_pools)  # one launch per pool
             pools_per_launch = len(my_pools) / max(1, n_chains)
             nbytes = algorithmic_bytes(dom, n_pend + n_run, min(K, n_pend), n_off, launches_per_match, pools_per_launch)
             achieved = (nbytes / (avg_ms * 1e-3) / 1e9) if (nbytes and avg_ms > 0) else None
@@ -470,29 +468,6 @@ def main():
             checks.check_pool_against_oracle(p08, pools[pc], qc, f08[pc][0], f08[pc][1], K, threads=1)
             extra["good_enough=0.8"]["parity_checked"] = True
             extra["good_enough=0.8"]["parity"] = {"pool": pc, "jobs_checked": int(len(f08[pc][1])), "against": "oracle, single thread, bit-exact"}
-        for e in engines.values():
-            e.set_params(params)
-        # the other orchestration of the same placement (match_algo 6, match_v3.hpp: one walker workgroup fed by helper workgroups, the
-        # candidate order kept across rounds) on rank 0's first pool alone, next to the shipped one on the same pool: measured, slower,
-        # kept as a tested alternative.  Its assignments are compared with the shipped orchestration's.
-        try:
-            pc = my_pools[0]
-            e0 = engines[pc]
-            e0.set_params(A.default_params(good_enough_fitness=1.0, match_algo=0))
-            t0s = timed(lambda: e0.cycle_run(K), 2)
-            _, j0, _ = e0.cycle_fetch()
-            e0.set_params(A.default_params(good_enough_fitness=1.0, match_algo=6))
-            t6s = timed(lambda: e0.cycle_run(K), 2)
-            _, j6, _ = e0.cycle_fetch()
-            st6 = e0.match_stats()
-            extra["match_v3"] = {"what": f"pool {pc} alone, K = {K}: match_algo 6 (persistent walker workgroup + helper workgroups) against the "
-                                         "shipped window rounds on the same pool",
-                                 "window_rounds_ms": pct(t0s, 0.5) * 1e3, "match_v3_ms": pct(t6s, 0.5) * 1e3,
-                                 "same_assignments": bool(np.array_equal(j0, j6)),
-                                 "generations": st6.get("v3_generations"), "walked": st6.get("v3_walked"), "settled_by_helpers": st6.get("v3_settled"),
-                                 "walker_wait_us": st6.get("v3_wait_us"), "refused": st6.get("v3_refused")}
-        except Exception as ex:  # (an extra must never cost the headline)
-            extra["match_v3"] = {"error": str(ex)[:300]}
         for e in engines.values():
             e.set_params(params)
         for name, kw in (("C2", dict(seed=0xC00C0002, n_pending=50000, n_running=20000, n_users=1000, n_offers=5000)),

@@ -17,8 +17,6 @@
 #include "considerable_kernels.hpp"
 #include "match_kernels.hpp"
 #include "match_v2.hpp"
-#include "match_world.hpp"
-#include "match_v3.hpp"
 #include "offers_kernels.hpp"
 #include "explain_kernels.hpp"
 #include "rank_kernels.hpp"
@@ -157,7 +155,7 @@ struct cook_engine {
   DArr<JobCons> v_jcons;
   DArr<unsigned long long> m_alive, m_jmin;
   DArr<double> v_cand_fit;
-  DArr<ChunkRec> v_prec;
+  DArr<char> v_prec;
   DArr<int> v_cand_idx, v_ge_idx;
   DArr<uint32_t> v_cinfo, v_jfh;
   DArr<uint64_t> v_colbits;
@@ -169,26 +167,12 @@ struct cook_engine {
   unsigned deferred_k = 0;
   WinCtl deferred_c0{};
   WinCtl* h_multi = nullptr;  // pinned: the pools' WinCtl read-backs
-  DArr<PersistCtl> w_pctl;
-  DArr<WorldPool> w_wpool;   // persistent multi-pool placement (match_world.hpp), led by this engine
-  DArr<WorldCtl> w_wctl;
-  unsigned world_runs = 0, world_fallbacks = 0;
-  unsigned long long world_wait_eval = 0, world_wait_merge = 0;  // pool 0's walker, last run (100 MHz ticks)
   int n_cus = 256;
-  unsigned last_persistent = 0, persist_fallbacks = 0;
   DArr<MatchIn> v_in;
   void* h_inbuf = nullptr;  // pinned staging copy of MatchIn
   WinCtl last_ctl{};
-  // match_v3 (one persistent workgroup per pool)
-  DArr<V3Ctl> v3_ctl;
-  DArr<char> v3_pos;          // the offers' records in position order (V3Pos)
-  DArr<char> v3_glob;         // what the walker workgroup and the helper workgroups share (V3Glob)
-  DArr<int32_t> v3_group_snap;
-  void* h_v3 = nullptr;      // pinned: PoolCtx3 going out, V3Ctl coming back
-  V3Ctl last_v3{};
   bool groups_simple = true;  // no balanced / attribute-equals group staged (cook_match_stage)
-  unsigned v3_refused = 0;    // calls the v3 kernel handed back to the window rounds
-  bool deferred_small = false;  // the deferred call was set up for the v2small list shape
+  bool deferred_ge = false;   // the deferred call needs the GE launches (good-enough-fitness < 1)
   MatchIn min{};
   bool cycle_staged = false;
   unsigned cycle_considered = 0;
@@ -887,20 +871,6 @@ static unsigned batch_cap() {
   }();
   return cap;
 }
-static bool small_shape_on() {
-  static const bool on = [] {
-    const char* s = std::getenv("COOK_SMALL_SHAPE");
-    return !(s && std::atoi(s) == 0);
-  }();
-  return on;
-}
-static bool ge_fast_path() {
-  static const bool on = [] {
-    const char* s = std::getenv("COOK_GE_FAST");
-    return !(s && std::atoi(s) == 0);
-  }();
-  return on;
-}
 // COOK_PACK_ARGS=0: the multi-pool launches read their contexts from memory even when they would fit the kernel arguments (A/B switch)
 static bool pack_args() {
   static const bool on = [] {
@@ -910,94 +880,12 @@ static bool pack_args() {
   return on;
 }
 void match_rounds_multi(cook_engine** es, unsigned n);
-bool match_rounds_world(cook_engine** es, unsigned n);
-
-// match_algo 6 (match_v3.hpp): may this call go to the persistent per-pool workgroup?  Best fit only, no ports / named scalars, no
-// group whose constraint can OPEN an offer, one offer per host, the offers must fit the workgroup's LDS order.
-bool match_v3_eligible(const cook_engine* e, const MatchIn& in) {
-  return in.good_enough >= 1.0 && !in.has_x && in.host_dup == 0u && e->groups_simple && in.M >= 1u && in.M <= (unsigned)V3_MMAX && in.K >= 1u;
-}
-// -> false: the kernel refused the input before placing anything (the caller re-initialises the state and runs the window rounds)
-bool match_v3_run(cook_engine* e, const MatchIn& in, const MatchState& st, const OfferA* oa, const OfferB* ob, const JobRec* jr, const JobCons* jcons,
-                  const MatchIn* din) {
-  PoolCtx3 h;
-  h.in = in;
-  h.st = st;
-  h.vb.oa = oa, h.vb.ob = ob, h.vb.jr = jr, h.vb.jcons = jcons, h.vb.in_dev = din;
-  h.vb.ctl = e->v3_ctl.ensure(1);
-  h.vb.group_snap = e->v3_group_snap.ensure(std::max(1u, in.G));
-  h.vb.job_flags = e->m_jmin.ptr();
-  {
-    static const unsigned la = [] {  // jobs the helpers may run ahead of the walker (tuning runs: COOK_V3_LA)
-      const char* s = std::getenv("COOK_V3_LA");
-      const long v = s ? std::atol(s) : 0;
-      return (unsigned)(v >= 1 && v <= V3_GR ? v : (V3_R < 64 ? V3_R : 64));  // (64 measured best on MI355X: 32 / 64 / 128 -> 275 / 250 / 273 ms)
-    }();
-    h.vb.look_ahead = la;
-    static const unsigned rg = [] {  // generations between rebuilds of the order (tuning runs: COOK_V3_REBUILD)
-      const char* s = std::getenv("COOK_V3_REBUILD");
-      const long v = s ? std::atol(s) : 0;
-      return (unsigned)(v >= 1 ? v : 16);
-    }();
-    h.vb.rebuild_gens = rg;
-    h.vb.P = v3_pos_carve(e->v3_pos.ensure(V3_POS_BYTES));
-    char* gbase = e->v3_glob.ensure(V3_GLOB_BYTES);
-    h.vb.G = v3_glob_carve(gbase);
-    COOK_HIP(hipMemsetAsync(gbase + V3_GLOB_CTL_OFF, 0, V3_GLOB_CTL_BYTES, e->stream));  // flags, control words, acknowledgements
-  }
-  static const unsigned n_hwg = [] {  // helper workgroups of the launch (tuning runs: COOK_V3_HELPERS)
-    const char* s = std::getenv("COOK_V3_HELPERS");
-    const long v = s ? std::atol(s) : 0;
-    const long cap = V3_HW_MAX / V3_WAVES;
-    return (unsigned)(v >= 1 ? (v > cap ? cap : v) : COOK_SHAPE(12, 2));  // (3 / 6 / 12 / 24 helper workgroups: 315 / 250 / 239 / 244 ms per C4 pool)
-  }();
-  h.vb.n_helper_waves = n_hwg * (unsigned)V3_WAVES;
-  h.vb.pad = 0;
-  if (!e->h_v3) COOK_HIP(hipHostMalloc(&e->h_v3, sizeof(PoolCtx3) + sizeof(V3Ctl), hipHostMallocDefault));
-  COOK_HIP(hipMemsetAsync(h.vb.ctl, 0, sizeof(V3Ctl), e->stream));
-  {  // workgroup 0 walks, the others prepare: they talk through global memory, so all of them must be resident at once
-    ProfScope _ps(e, "match_v3");
-    COOK_LAUNCH_COOP(match_v3, 1u + n_hwg, V3_THREADS, e->stream, h);
-  }
-  V3Ctl* hc = (V3Ctl*)((char*)e->h_v3 + sizeof(PoolCtx3));
-  COOK_HIP(hipMemcpyAsync(hc, h.vb.ctl, sizeof(V3Ctl), hipMemcpyDeviceToHost, e->stream));
-  sync(e);
-  e->last_v3 = *hc;
-#ifdef COOK_V3_PROF
-  if (const char* pf = std::getenv("COOK_V3_PROF_FILE")) {  // measurement build: the phase counters of this call, one JSON line
-    if (FILE* f = std::fopen(pf, "a")) {
-      std::fprintf(f, "{\"K\": %u, \"M\": %u, \"total_us\": %llu, \"cyc\": [", in.K, in.M, (unsigned long long)(hc->t_total / 100ull));
-      for (int i = 0; i < V3_NPROF; ++i) std::fprintf(f, "%s%llu", i ? ", " : "", (unsigned long long)hc->prof_cyc[i]);
-      std::fprintf(f, "], \"cnt\": [");
-      for (int i = 0; i < V3_NPROF; ++i) std::fprintf(f, "%s%llu", i ? ", " : "", (unsigned long long)hc->prof_cnt[i]);
-      std::fprintf(f, "]}\n");
-      std::fclose(f);
-    }
-  }
-#endif
-  if (hc->error == 2u) e->fail(COOK_E_STATE, "match_v3: the walker waited for a prepared job for more than a second (internal error)");
-  if (hc->error != 0u) {
-    e->v3_refused += 1;
-    return false;
-  }
-  WinCtl c;
-  std::memset(&c, 0, sizeof(c));
-  c.head = in.K;
-  c.rounds = hc->generations;
-  c.matched = hc->matched;
-  c.head_matched = hc->head_matched;
-  c.stop_list = hc->stop_list, c.stop_full = hc->stop_full, c.stop_group = hc->stop_log;
-  c.touched_sum = hc->opens;
-  c.visited_sum = hc->walked;
-  c.t_setup = hc->t_regen;
-  c.t_seq = hc->t_total - hc->t_regen;
-  e->last_ctl = c;
-  e->last_persistent = 3;
-  unsigned sum[4] = {c.matched, (c.matched == 0 || c.head_matched) ? 1u : 0u, c.rounds, 0u};
-  std::memcpy(e->h_scratch, sum, 16);
-  COOK_HIP(hipMemcpyAsync(st.summary, e->h_scratch, 16, hipMemcpyHostToDevice, e->stream));
-  sync(e);
-  return true;
+// one round of launches on the engine's stream, for ONE pool: GE = the call runs with good-enough-fitness < 1
+template <bool GE>
+static void launch_round(cook_engine* e, const MatchIn& in, const MatchState& st, const V2Buf& vb) {
+  KL("match_eval2", match_eval2<GE>, dim3(vb.C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
+  KL("match_merge2", match_merge2<GE>, MV_MERGE_BLOCKS, COOK_WAVE * MV_MW, in, vb);
+  KL("match_resolve2", match_resolve2<GE>, 1, MV_RTHREADS, st, vb);
 }
 
 void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool defer = false) {
@@ -1024,17 +912,18 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
   st.xscal = in.has_x ? e->m_xscal.ensure((size_t)M * COOK_MAX_SCALARS) : nullptr;
   match_init_state(e, st, K, M, G);
   st.cutoff = 0x7FFFFFFF;
-  e->last_persistent = 0;
   e->has_deferred = false;
   const int algo = e->params.match_algo;
-  const bool world_solo = algo == 5 && K > 0 && !defer;  // one pool through the persistent kernel: set up as deferred, run at once
-  if (world_solo) defer = true;
-  if (defer && !((algo == 0 || algo == 2 || algo == 5) && K > 0)) defer = false;  // (6: the pool's own launch, at once, on its own stream)  // only the window-round orchestrations run several pools
+  if (!(algo == 0 || algo == 1 || algo == 2)) e->fail(COOK_E_INVALID, "cook_params.match_algo: 0 / 2 = window rounds, 1 = serial sweep");
+  if (defer && !(algo != 1 && K > 0)) defer = false;  // only the window rounds run several pools in one launch
+  const bool ge = in.good_enough < 1.0;
   if (algo == 1) {  // one-job-at-a-time sweep by a single workgroup (reference implementation of the chain)
     constexpr int SERIAL_THREADS = COOK_SHAPE(1024, 256);
     auto k_match = match_serial<SERIAL_THREADS>;
     KL("match_serial", k_match, 1, SERIAL_THREADS, in, st);
   } else if (K > 0) {  // window rounds: eval -> merge -> resolve (match_v2.hpp)
+    if ((ge ? resolve_wseg<true>(M) : resolve_wseg<false>(M)) < MV_WSEG_MIN)
+      e->fail(COOK_E_INVALID, "cook_match: too many offers in one pool for the placement walk's offer table (about 150 000)");
     V2Buf vb;
     const char* rlog_path = std::getenv("COOK_ROUND_LOG");  // diagnostics: one CSV line per round of the last match
     vb.round_log = rlog_path ? e->w_rlog.ensure(MV_ROUND_LOG_CAP) : nullptr;
@@ -1048,17 +937,12 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     vb.jr = jr;
     JobCons* jcons = e->v_jcons.ensure(K);
     vb.jcons = jcons;
-    // sized for a LONG window (MV_WLONG jobs, match_v2.hpp): 128 bytes per (job, offer chunk) = 26 MB for a C4 pool
-    // (launches for good-enough-fitness < 1 use the v2ge list shape, match_v2.hpp: its chunk records and good-enough lists are longer)
-    constexpr size_t PREC_SCALE_NUM = (sizeof(v2ge::ChunkRec) + sizeof(ChunkRec) - 1) / sizeof(ChunkRec);
-    vb.prec = e->v_prec.ensure((size_t)MV_WLONG * C * PREC_SCALE_NUM);
+    // sized for a LONG window (MV_WLONG jobs, match_v2.hpp) and the eval grid's largest offer split: 128 / 160 bytes per (job, offer chunk)
+    vb.prec = e->v_prec.ensure((size_t)MV_WLONG * C * sizeof(ChunkRecT<true>));  // (a split window holds at most MV_WEVAL / split jobs)
     vb.colbits = e->v_colbits.ensure((size_t)(M ? M : 1u) * MV_JGL);
-    constexpr size_t CAND_ELEMS = (size_t)MV_WLONG * MV_LM > (size_t)v2small::MV_WLONG * v2small::MV_LM ? (size_t)MV_WLONG * MV_LM
-                                                                                                          : (size_t)v2small::MV_WLONG * v2small::MV_LM;
-    vb.cand_fit = e->v_cand_fit.ensure(CAND_ELEMS);
-    vb.cand_idx = e->v_cand_idx.ensure(CAND_ELEMS);
-    vb.ge_idx = e->v_ge_idx.ensure((size_t)MV_WLONG * (MV_LG > v2ge::MV_LG ? MV_LG : v2ge::MV_LG));
-    static_assert(v2ge::MV_LM <= MV_LM, "cand_fit / cand_idx are sized for the default shape");
+    vb.cand_fit = e->v_cand_fit.ensure((size_t)MV_WLONG * MV_LM_MAX);
+    vb.cand_idx = e->v_cand_idx.ensure((size_t)MV_WLONG * MV_LM_MAX);
+    vb.ge_idx = e->v_ge_idx.ensure((size_t)MV_WLONG * MV_LG_MAX);
     vb.cinfo = e->v_cinfo.ensure((size_t)MV_WLONG * 4);
     vb.jfh = e->v_jfh.ensure((size_t)MV_WLONG * (MV_FH + 2));
     vb.ctl = e->w_ctl.ensure(1);
@@ -1081,22 +965,10 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     COOK_HIP(hipMemsetAsync(e->m_jmin.ptr(), 0x7F, 16, e->stream));  // > every finite double's bit pattern
     COOK_HIP(hipMemsetAsync(e->m_jmin.ptr() + 2, 0, 16, e->stream));   // [2]: a job with a negative / non-finite request was seen
     KL("match_job_minima", match_job_minima, std::min(div_up(K, 256), 256u), 256, (const JobRec*)jr, K, e->m_jmin.ptr());
-    auto init_alive = [&] {
-      if (M) KL("match_init_alive", match_init_alive, div_up(M, 256), 256, (const OfferA*)oa, M, st.jmin, st.alive);
-    };
-    init_alive();
-    if (algo == 6 && match_v3_eligible(e, in)) {  // ONE persistent workgroup places the whole call (match_v3.hpp)
-      if (match_v3_run(e, in, st, oa, ob, jr, jcons, vb.in_dev)) {
-        e->cycle_considered = K;
-        e->match_done = true;
-        return;
-      }
-      match_init_state(e, st, K, M, G);  // refused before anything was placed: the window rounds take the call
-      init_alive();
-    }
+    if (M) KL("match_init_alive", match_init_alive, div_up(M, 256), 256, (const OfferA*)oa, M, st.jmin, st.alive);
     WinCtl c0;
     std::memset(&c0, 0, sizeof(c0));
-    c0.wcur = std::min<unsigned>(MV_WMAX, 64u);
+    c0.wcur = std::min<unsigned>(MV_WEVAL, 64u);
     {
       // window growth: with several pools on one GPU the eval phase is compute-bound (evaluate few jobs twice); a pool
       // that has the GPU to itself is bound by the chain of rounds (prefer fewer, larger rounds)
@@ -1105,160 +977,40 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       if (const char* ev = std::getenv("COOK_WGROW_PCT")) c0.wgrow_pct = (unsigned)std::max(100, std::atoi(ev));
     }
     c0.wlong_cap = (unsigned)MV_WLONG;
-    if (const char* ev = std::getenv("COOK_WLONG")) c0.wlong_cap = std::atoi(ev) ? (unsigned)MV_WLONG : (unsigned)MV_WMAX;
-    c0.reeval_max = algo == 3 ? 0x7FFFFFFFu : 0u;  // 3: list-exhausted jobs re-evaluated in place instead of ending the round
-    if (const char* ev = std::getenv("COOK_REEVAL_MAX"))  // tuning: a bounded number of in-place re-evaluations per round
-      if (algo == 0 || algo == 2) c0.reeval_max = (unsigned)std::max(0, std::atoi(ev));
-    // few considerable jobs, best fit: the shape with the long merged lists (COOK_SMALL_SHAPE=0 switches it off for A/B runs)
-    const bool small_shape = small_shape_on() && (algo == 0 || algo == 2) && in.good_enough >= 1.0 && K <= V2SMALL_MAX_JOBS && c0.reeval_max == 0u &&
-                             !(M >= V2BIG_MIN_OFFERS);
-    if (small_shape) {
-      c0.wcur = std::min<unsigned>(v2small::MV_WMAX, 64u);
-      c0.wlong_cap = std::min<unsigned>(c0.wlong_cap, (unsigned)v2small::MV_WLONG);
-    }
-    e->deferred_small = small_shape;
+    if (const char* ev = std::getenv("COOK_WLONG")) c0.wlong_cap = std::atoi(ev) ? (unsigned)MV_WLONG : (unsigned)MV_WEVAL;
     WinCtl hc = c0;
-    bool done = false;
-    if (algo == 4) {  // the persistent kernel: one launch per match call (wins when a pool has the GPU to itself)
-      std::memcpy(e->h_scratch, &c0, sizeof(c0));
-      COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
-      PersistCtl* pc = e->w_pctl.ensure(1);
-      COOK_HIP(hipMemsetAsync(pc, 0, sizeof(PersistCtl), e->stream));
-      // every workgroup holds ~150 KB of LDS = one per CU; leave a quarter of the CUs to the other kernels in flight
-      const int sharing = std::max(1, g_engines_on_device[e->device & 63].load());
-      unsigned nwg = (unsigned)std::max(4, std::min(64, e->n_cus * 3 / (4 * sharing)));
-      nwg = std::min(nwg, std::max(1u, C * (unsigned)MV_JG));
-      if (!COOK_COOP_GRIDS) nwg = 1;  // (a build whose launches run one workgroup at a time)
-      KL("match_persist", match_persist, nwg, COOK_WAVE * MV_EW, in, st, vb, pc, 0x7FFFFFFFu);
-      COOK_HIP(hipMemcpyAsync(e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
-      COOK_HIP(hipMemcpyAsync(e->h_scratch + 32, pc, sizeof(PersistCtl), hipMemcpyDeviceToHost, e->stream));
-      sync(e);
-      PersistCtl hp;
-      std::memcpy(&hc, e->h_scratch, sizeof(WinCtl));
-      std::memcpy(&hp, e->h_scratch + 32, sizeof(PersistCtl));
-      if (hp.error == 0 && hc.head >= K) {
-        done = true;
-        e->last_persistent = 1;
-      } else {  // a grid barrier timed out (workgroups not co-resident): start over with one launch per phase
-        e->persist_fallbacks += 1;
-        match_init_state(e, st, K, M, G);
-        init_alive();
-        hc = c0;
-      }
-    }
+    std::memcpy(e->h_scratch, &c0, sizeof(c0));
+    COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
     if (defer) {  // set up only: cook_cycle_match_multi runs the rounds of several pools together
-      std::memcpy(e->h_scratch, &c0, sizeof(c0));
-      COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
       sync(e);
       e->deferred.in = in;
       e->deferred.st = st;
       e->deferred.vb = vb;
       e->deferred_k = K;
       e->deferred_c0 = c0;
+      e->deferred_ge = ge;
       e->has_deferred = true;
       e->cycle_considered = K;
       e->match_done = false;
-      if (world_solo) {
-        cook_engine* self = e;
-        if (!match_rounds_world(&self, 1)) match_rounds_multi(&self, 1);
-      }
       return;
     }
-    if (!done) {
-      std::memcpy(e->h_scratch, &c0, sizeof(c0));
-      COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
-      unsigned batch = 8;
-      unsigned guard = 0;
-      // good-enough-fitness < 1: the kernels of the v2ge list shape, whose walk also knows the "first offer above the threshold" rule
-      const bool ge_shape = in.good_enough < 1.0 && ge_fast_path() && c0.reeval_max == 0u;
-      v2ge::V2Buf gvb;
-      std::memcpy(&gvb, &vb, sizeof(vb));
-      (void)ge_shape;
-      // many offers: the shape with the larger slot table (COOK_BIG_SHAPE=0 switches it off for A/B runs)
-      static const bool big_on = [] {
-        const char* s = std::getenv("COOK_BIG_SHAPE");
-        return !(s && std::atoi(s) == 0);
-      }();
-      const bool big_shape = big_on && !ge_shape && in.good_enough >= 1.0 && M >= V2BIG_MIN_OFFERS && c0.reeval_max == 0u;
-      v2big::V2Buf bvb;
-      std::memcpy(&bvb, &vb, sizeof(vb));
-      v2small::V2Buf svb;
-      std::memcpy(&svb, &vb, sizeof(vb));
-      if (big_shape) {
-        c0.wcur = std::min<unsigned>(v2big::MV_WMAX, 64u);
-        c0.wlong_cap = std::min<unsigned>(c0.wlong_cap, (unsigned)v2big::MV_WLONG);
-        hc = c0;
-        std::memcpy(e->h_scratch, &c0, sizeof(c0));
-        COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
+    unsigned batch = 8;
+    unsigned guard = 0;
+    while (hc.head < K) {
+      for (unsigned r = 0; r < batch; ++r) {
+        if (ge) launch_round<true>(e, in, st, vb);
+        else launch_round<false>(e, in, st, vb);
       }
-      while (hc.head < K) {
-        for (unsigned r = 0; r < batch; ++r) {
-#ifdef COOK_EVAL_TRACE
-          {
-            static int launches = 0;
-            static DArr<unsigned long long> tr;
-            ++launches;
-            vb.eval_trace = tr.ensure((size_t)C * MV_JG * 19 + 3);
-            if (launches == 60 || launches == 300) COOK_HIP(hipMemsetAsync(vb.eval_trace, 0, (size_t)C * MV_JG * 19 * 8, e->stream));
-            if (in.good_enough < 1.0) KL("match_eval2", match_eval2<true>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
-          else KL("match_eval2", match_eval2<false>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
-            if (launches == 60 || launches == 300) {
-              std::vector<unsigned long long> h((size_t)C * MV_JG * 19);
-              sync(e);
-              COOK_HIP(hipMemcpy(h.data(), vb.eval_trace, h.size() * 8, hipMemcpyDeviceToHost));
-              unsigned long long tmin = ~0ull, tmax = 0;
-              const size_t nb3 = (size_t)C * MV_JG * 3;
-              for (size_t x = 0; x < nb3; x += 3)
-                if (h[x]) tmin = std::min(tmin, h[x]), tmax = std::max(tmax, h[x + 1]);
-              std::fprintf(stderr, "EVALTRACE launch %d blocks %u span %.2f us\n", launches, C * MV_JG, (tmax - tmin) / 100.0);
-              for (size_t bq = 0; bq < (size_t)C * MV_JG; ++bq)
-                for (int wv = 0; wv < 4; ++wv) {
-                  const unsigned long long* q = &h[nb3 + bq * 16 + wv * 4];
-                  if (q[0]) std::fprintf(stderr, "EVALPHASE blk %zu wave %d setup %.2f scan %.2f merge %.2f (start %.2f)\n", bq, wv, (q[1] - q[0]) / 100.0, (q[2] - q[1]) / 100.0, q[3] ? (q[3] - q[2]) / 100.0 : -1.0, (q[0] - tmin) / 100.0);
-                }
-              for (size_t x = 0; x < nb3; x += 3)
-                if (h[x]) std::fprintf(stderr, "EVALTRACE blk %zu start %.2f end %.2f hwid %llx\n", x / 3, (h[x] - tmin) / 100.0, (h[x + 1] - tmin) / 100.0, h[x + 2]);
-            }
-          }
-#else
-          if (small_shape) {
-            KL("match_eval2", v2small::match_eval2<false>, dim3(C, v2small::MV_JG), COOK_WAVE * MV_EW, in, st, svb);
-            KL("match_merge2", v2small::match_merge2, v2small::MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, svb);
-            KL("match_resolve2", v2small::match_resolve2, 1, MV_RTHREADS, st, svb);
-            continue;
-          }
-          if (big_shape) {
-            KL("match_eval2", v2big::match_eval2<false>, dim3(C, v2big::MV_JG), COOK_WAVE * MV_EW, in, st, bvb);
-            KL("match_merge2", v2big::match_merge2, v2big::MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, bvb);
-            KL("match_resolve2", v2big::match_resolve2, 1, MV_RTHREADS, st, bvb);
-            continue;
-          }
-          if (ge_shape) {
-            KL("match_eval2", v2ge::match_eval2<true>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, gvb);
-            KL("match_merge2", v2ge::match_merge2, MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, gvb);
-            KL("match_resolve2", v2ge::match_resolve2_ge, 1, MV_RTHREADS, st, gvb);
-            continue;
-          }
-          if (in.good_enough < 1.0) KL("match_eval2", match_eval2<true>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
-          else KL("match_eval2", match_eval2<false>, dim3(C, MV_JG), COOK_WAVE * MV_EW, in, st, vb);
-#endif
-          KL("match_merge2", match_merge2, MV_WMAX / MV_MW * 2, COOK_WAVE * MV_MW, in, vb);
-          if (c0.reeval_max != 0u)
-            KL("match_resolve2", match_resolve2_reeval, 1, MV_RTHREADS, st, vb);
-          else
-            KL("match_resolve2", match_resolve2, 1, MV_RTHREADS, st, vb);
-        }
-        COOK_HIP(hipMemcpyAsync(e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
-        sync(e);
-        const unsigned prev_head = hc.head, prev_rounds = hc.rounds;
-        std::memcpy(&hc, e->h_scratch, sizeof(WinCtl));
-        if (hc.head >= K) break;
-        // size the next batch from the observed jobs-per-round
-        const double per_round = (double)(hc.head - prev_head) / std::max(1u, hc.rounds - prev_rounds);
-        const double est = (K - hc.head) / std::max(1.0, per_round);
-        batch = (unsigned)std::min((double)batch_cap(), std::max(2.0, est * 1.05 + 2.0));  // over-launching is cheap: finished rounds exit at once
-        if (++guard > 4u * K + 64u) e->fail(COOK_E_STATE, "cook_match: window placement made no progress");
-      }
+      COOK_HIP(hipMemcpyAsync(e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
+      sync(e);
+      const unsigned prev_head = hc.head, prev_rounds = hc.rounds;
+      std::memcpy(&hc, e->h_scratch, sizeof(WinCtl));
+      if (hc.head >= K) break;
+      // size the next batch from the observed jobs-per-round
+      const double per_round = (double)(hc.head - prev_head) / std::max(1u, hc.rounds - prev_rounds);
+      const double est = (K - hc.head) / std::max(1.0, per_round);
+      batch = (unsigned)std::min((double)batch_cap(), std::max(2.0, est * 1.05 + 2.0));  // over-launching is cheap: finished rounds exit at once
+      if (++guard > 4u * K + 64u) e->fail(COOK_E_STATE, "cook_match: window placement made no progress");
     }
     match_finish_rounds(e, st, vb, hc, e->stream);
   } else {
@@ -1287,10 +1039,10 @@ void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, 
       path = path.substr(0, path.size() - 1) + "." + std::to_string(e->rlog_id);
     }
     if (FILE* f = std::fopen(path.c_str(), "w")) {
-      std::fprintf(f, "head,wcur,resolved,n_list,touched,stop,matched,setup_us,seq_us,nslots\n");
+      std::fprintf(f, "head,wcur,resolved,n_list,touched,stop,matched,setup_us,seq_us,segments\n");
       for (auto& r : h)
         std::fprintf(f, "%u,%u,%u,%u,%u,%u,%u,%.2f,%.2f,%u\n", r.head, r.wcur, r.resolved, r.n_list, r.touched, r.stop, r.matched,
-                     r.setup_ticks / 100.0, r.seq_ticks / 100.0, r.nslots);
+                     r.setup_ticks / 100.0, r.seq_ticks / 100.0, r.segments);
       std::fclose(f);
     }
   }
@@ -1335,17 +1087,16 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
   COOK_HIP(hipMemcpyAsync(dctx, hctx.data(), L * sizeof(PoolCtx), hipMemcpyHostToDevice, lead->stream));
   COOK_HIP(hipStreamSynchronize(lead->stream));  // hctx is pageable
   cook_engine* e = lead;                         // KL times / launches on the lead engine
-  bool any_ge = false;  // some pool of the launch runs with good-enough-fitness below 1 (match_eval2<GE>)
-  for (unsigned x = 0; x < L; ++x) any_ge = any_ge || hctx[x].in.good_enough < 1.0;
-  bool all_small = true;  // (a chain whose pools disagree runs the default shape: every pool was set up with a window it can hold)
-  for (unsigned x = 0; x < L; ++x) all_small = all_small && es[live[x]]->deferred_small;
+  bool any_ge = false;  // some pool of the launch runs with good-enough-fitness below 1: the GE launches for the whole chain (a pool at
+                        // 1.0 in it is placed by best fit all the same, from the GE shape's shorter best-fit lists)
+  for (unsigned x = 0; x < L; ++x) any_ge = any_ge || es[live[x]]->deferred_ge;
   unsigned batch = 8, guard = 0;
   auto all_done = [&] {
     for (unsigned x = 0; x < L; ++x)
       if (hc[x].head < es[live[x]]->deferred_k) return false;
     return true;
   };
-  // up to MV_PACK pools: their contexts travel in the kernel arguments (match_v2_body.inc: PoolPack)
+  // up to MV_PACK pools: their contexts travel in the kernel arguments (match_v2.hpp: PoolPack)
   const bool packed = L <= (unsigned)MV_PACK && pack_args();
   PoolPack<2> pk2{};
   PoolPack<MV_PACK> pk4{};
@@ -1353,56 +1104,26 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
     if (x < 2) pk2.c[x] = hctx[x < L ? x : 0];
     pk4.c[x] = hctx[x < L ? x : 0];
   }
-// one round of launches of namespace NS (the list shape) with the contexts packed: N = 2 or MV_PACK
-#define COOK_PACK_ROUND(NS, GE, REEVAL, GEF, WMAXV, JGV)                                                                                      \
-  do {                                                                                                                                      \
-    if (L <= 2u) {                                                                                                                          \
-      const auto& P = reinterpret_cast<const NS::PoolPack<2>&>(pk2);                                                                        \
-      KL("match_eval2", (NS::match_eval2_pack<GE, 2>), dim3(cmax, JGV, L), COOK_WAVE * MV_EW, P);                                           \
-      KL("match_merge2", (NS::match_merge2_pack<2>), dim3(WMAXV / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, P);                                  \
-      KL("match_resolve2", (NS::match_resolve2_pack<REEVAL, GEF, 2>), dim3(1, 1, L), MV_RTHREADS, P);                                       \
-    } else {                                                                                                                                \
-      const auto& P = reinterpret_cast<const NS::PoolPack<MV_PACK>&>(pk4);                                                                  \
-      KL("match_eval2", (NS::match_eval2_pack<GE, MV_PACK>), dim3(cmax, JGV, L), COOK_WAVE * MV_EW, P);                                     \
-      KL("match_merge2", (NS::match_merge2_pack<MV_PACK>), dim3(WMAXV / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, P);                            \
-      KL("match_resolve2", (NS::match_resolve2_pack<REEVAL, GEF, MV_PACK>), dim3(1, 1, L), MV_RTHREADS, P);                                 \
-    }                                                                                                                                       \
-  } while (0)
+  auto round = [&](auto ge_tag) {
+    constexpr bool GE = decltype(ge_tag)::value;
+    if (packed && L <= 2u) {
+      KL("match_eval2", (match_eval2_pack<GE, 2>), dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, pk2);
+      KL("match_merge2", (match_merge2_pack<GE, 2>), dim3(MV_MERGE_BLOCKS, 1, L), COOK_WAVE * MV_MW, pk2);
+      KL("match_resolve2", (match_resolve2_pack<GE, 2>), dim3(1, 1, L), MV_RTHREADS, pk2);
+    } else if (packed) {
+      KL("match_eval2", (match_eval2_pack<GE, MV_PACK>), dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, pk4);
+      KL("match_merge2", (match_merge2_pack<GE, MV_PACK>), dim3(MV_MERGE_BLOCKS, 1, L), COOK_WAVE * MV_MW, pk4);
+      KL("match_resolve2", (match_resolve2_pack<GE, MV_PACK>), dim3(1, 1, L), MV_RTHREADS, pk4);
+    } else {
+      KL("match_eval2", match_eval2_multi<GE>, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx);
+      KL("match_merge2", match_merge2_multi<GE>, dim3(MV_MERGE_BLOCKS, 1, L), COOK_WAVE * MV_MW, (const PoolCtx*)dctx);
+      KL("match_resolve2", match_resolve2_multi<GE>, dim3(1, 1, L), MV_RTHREADS, (const PoolCtx*)dctx);
+    }
+  };
   while (!all_done()) {
     for (unsigned r = 0; r < batch; ++r) {
-      if (packed) {
-        if (all_small) {
-          COOK_PACK_ROUND(v2small, false, false, false, v2small::MV_WMAX, v2small::MV_JG);
-        } else if (any_ge && ge_fast_path() && es[live[0]]->deferred_c0.reeval_max == 0u) {
-          COOK_PACK_ROUND(v2ge, true, false, true, MV_WMAX, MV_JG);
-        } else if (es[live[0]]->deferred_c0.reeval_max != 0u) {
-          if (any_ge) COOK_PACK_ROUND(, true, true, false, MV_WMAX, MV_JG);
-          else COOK_PACK_ROUND(, false, true, false, MV_WMAX, MV_JG);
-        } else {
-          if (any_ge) COOK_PACK_ROUND(, true, false, false, MV_WMAX, MV_JG);
-          else COOK_PACK_ROUND(, false, false, false, MV_WMAX, MV_JG);
-        }
-        continue;
-      }
-      if (all_small) {  // every pool of the chain set up for the v2small list shape (few considerable jobs)
-        KL("match_eval2", v2small::match_eval2_multi<false>, dim3(cmax, v2small::MV_JG, L), COOK_WAVE * MV_EW, (const v2small::PoolCtx*)dctx);
-        KL("match_merge2", v2small::match_merge2_multi, dim3(v2small::MV_WMAX / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, (const v2small::PoolCtx*)dctx);
-        KL("match_resolve2", v2small::match_resolve2_multi, dim3(1, 1, L), MV_RTHREADS, (const v2small::PoolCtx*)dctx);
-        continue;
-      }
-      if (any_ge && ge_fast_path() && es[live[0]]->deferred_c0.reeval_max == 0u) {  // the v2ge list shape (match_v2.hpp)
-        KL("match_eval2", v2ge::match_eval2_multi<true>, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const v2ge::PoolCtx*)dctx);
-        KL("match_merge2", v2ge::match_merge2_multi, dim3(MV_WMAX / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, (const v2ge::PoolCtx*)dctx);
-        KL("match_resolve2", v2ge::match_resolve2_multi_ge, dim3(1, 1, L), MV_RTHREADS, (const v2ge::PoolCtx*)dctx);
-        continue;
-      }
-      if (any_ge) KL("match_eval2", match_eval2_multi<true>, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx);
-      else KL("match_eval2", match_eval2_multi<false>, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx);
-      KL("match_merge2", match_merge2_multi, dim3(MV_WMAX / MV_MW * 2, 1, L), COOK_WAVE * MV_MW, (const PoolCtx*)dctx);
-      if (es[live[0]]->deferred_c0.reeval_max != 0u)
-        KL("match_resolve2", match_resolve2_multi_reeval, dim3(1, 1, L), MV_RTHREADS, (const PoolCtx*)dctx);
-      else
-        KL("match_resolve2", match_resolve2_multi, dim3(1, 1, L), MV_RTHREADS, (const PoolCtx*)dctx);
+      if (any_ge) round(std::true_type{});
+      else round(std::false_type{});
     }
     const std::vector<WinCtl> prev = hc;
     for (unsigned x = 0; x < L; ++x)
@@ -1425,91 +1146,6 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
     ex->has_deferred = false;
     ex->match_done = true;
   }
-}
-
-// a deferred match back to its initial state (after a persistent launch gave up half way)
-void match_reset_deferred(cook_engine* e, hipStream_t stream) {
-  const PoolCtx& d = e->deferred;
-  hipStream_t keep = e->stream;
-  e->stream = stream;
-  match_init_state(e, d.st, d.in.K, d.in.M, d.in.G);
-  if (d.in.M) KL("match_init_alive", match_init_alive, div_up(d.in.M, 256), 256, d.vb.oa, d.in.M, d.st.jmin, d.st.alive);
-  e->stream = keep;
-  COOK_HIP(hipMemcpyAsync(d.vb.ctl, &e->deferred_c0, sizeof(WinCtl), hipMemcpyHostToDevice, stream));
-  COOK_HIP(hipStreamSynchronize(stream));
-}
-
-// The placements of n engines (pools of one rank, same device) in ONE persistent launch (match_world.hpp): every pool advances on
-// its own.  Returns false when the launch gave up (not all workgroups resident / a wait timed out): the matches are then reset and
-// the caller runs them with one launch per phase.
-bool match_rounds_world(cook_engine** es, unsigned n) {
-  cook_engine* lead = es[0];
-  std::vector<unsigned> live;
-  for (unsigned i = 0; i < n; ++i) {
-    if (!es[i] || es[i]->device != lead->device) lead->fail(COOK_E_INVALID, "cook_cycle_match_multi: engines must share one device");
-    if (es[i]->has_deferred) live.push_back(i);
-    else if (!es[i]->match_done) lead->fail(COOK_E_STATE, "cook_cycle_match_multi before cook_cycle_run_rank");
-  }
-  const unsigned L = (unsigned)live.size();
-  if (L == 0) return true;
-  if (L > MW_MAX_POOLS || L > 64) return false;
-  for (unsigned x = 0; x < L; ++x)
-    if (es[live[x]]->deferred_k >= (1u << 22) || MV_WLONG > 4096) return false;  // world_pack's field widths
-  // one workgroup per CU (the walker's LDS): all of them resident at once, a few CUs left to whatever else runs on the GPU
-  int want = COOK_COOP_GRIDS ? lead->n_cus - (int)L - 8 : 2;
-  if (const char* ev = std::getenv("COOK_WORLD_EVAL_WGS")) want = std::atoi(ev);
-  if (want < (COOK_COOP_GRIDS ? 4 : 1)) return false;
-  const unsigned n_eval = (unsigned)want;
-  if (!lead->h_multi) COOK_HIP(hipHostMalloc((void**)&lead->h_multi, 64 * sizeof(WinCtl), hipHostMallocDefault));
-  std::vector<PoolCtx> hctx(L);
-  for (unsigned x = 0; x < L; ++x) hctx[x] = es[live[x]]->deferred;
-  PoolCtx* dctx = lead->w_pctx.ensure(L);
-  WorldPool* dwp = lead->w_wpool.ensure(L);
-  WorldCtl* dwc = lead->w_wctl.ensure(1);
-  WorldCtl hwc;
-  std::memset(&hwc, 0, sizeof(hwc));
-  hwc.n_pools = L;
-  hwc.n_eval_wg = n_eval;
-  COOK_HIP(hipMemcpyAsync(dctx, hctx.data(), L * sizeof(PoolCtx), hipMemcpyHostToDevice, lead->stream));
-  COOK_HIP(hipMemsetAsync(dwp, 0, L * sizeof(WorldPool), lead->stream));
-  COOK_HIP(hipMemcpyAsync(dwc, &hwc, sizeof(hwc), hipMemcpyHostToDevice, lead->stream));
-  COOK_HIP(hipStreamSynchronize(lead->stream));  // hctx / hwc are pageable
-  cook_engine* e = lead;
-  {
-    ProfScope _ps(e, "match_world");
-    COOK_LAUNCH_COOP(match_world, L + n_eval, MW_THREADS, lead->stream, (const PoolCtx*)dctx, dwp, dwc);
-  }
-  for (unsigned x = 0; x < L; ++x)
-    COOK_HIP(hipMemcpyAsync(&lead->h_multi[x], hctx[x].vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, lead->stream));
-  COOK_HIP(hipMemcpyAsync(&hwc, dwc, sizeof(hwc), hipMemcpyDeviceToHost, lead->stream));
-  COOK_HIP(hipStreamSynchronize(lead->stream));
-  lead->world_runs += 1;
-  bool ok = hwc.error == 0;
-  for (unsigned x = 0; x < L && ok; ++x) ok = lead->h_multi[x].head >= es[live[x]]->deferred_k;
-  if (!ok) {
-    lead->world_fallbacks += 1;
-    for (unsigned x = 0; x < L; ++x) match_reset_deferred(es[live[x]], lead->stream);
-    return false;
-  }
-#ifdef COOK_WORLD_PROF
-  for (int ph = 0; ph < 2; ++ph) {
-    const unsigned long long* q = hwc.prof[ph];
-    const double n = q[0] ? (double)q[0] : 1.0;
-    std::fprintf(stderr, "WORLDPROF %s items=%llu notice avg %.1f us max %.1f us | work avg %.1f us max %.1f us | drain+add avg %.1f us | publish->done max %.1f us\n",
-                 ph == 0 ? "eval " : "merge", q[0], q[1] / n / 100.0, q[2] / 100.0, q[3] / n / 100.0, q[4] / 100.0, q[5] / n / 100.0, q[6] / 100.0);
-  }
-  std::fprintf(stderr, "WORLDPROF walker0 waits: eval %.1f ms merge %.1f ms\n", hwc.t_wait_eval / 1e5, hwc.t_wait_merge / 1e5);
-#endif
-  lead->world_wait_eval = hwc.t_wait_eval;
-  lead->world_wait_merge = hwc.t_wait_merge;
-  for (unsigned x = 0; x < L; ++x) {
-    cook_engine* ex = es[live[x]];
-    match_finish_rounds(ex, hctx[x].st, hctx[x].vb, lead->h_multi[x], lead->stream);
-    ex->last_persistent = 2;
-    ex->has_deferred = false;
-    ex->match_done = true;
-  }
-  return true;
 }
 
 void match_fetch(cook_engine* e, unsigned K, int32_t* job_to_offer, uint32_t* fail_code, uint8_t* head_matched) {
@@ -1664,7 +1300,6 @@ void cook_engine_destroy(cook_engine* e) {
     if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]);
   if (e->h_scratch) (void)hipHostFree(e->h_scratch);
   if (e->h_inbuf) (void)hipHostFree(e->h_inbuf);
-  if (e->h_v3) (void)hipHostFree(e->h_v3);
   if (e->h_multi) (void)hipHostFree(e->h_multi);
   delete e->rb;
   e->rb = nullptr;
@@ -1898,7 +1533,7 @@ int cook_cycle_match_multi(cook_engine** engines, uint32_t n) {
   cook_engine* lead = engines[0];
   return guarded(lead, [&] {
     StageTimer tm(lead, 2, &lead->match_ms);
-    if (!(lead->params.match_algo == 5 && match_rounds_world(engines, n))) match_rounds_multi(engines, n);
+    match_rounds_multi(engines, n);
     tm.stop();
     for (uint32_t i = 1; i < n; ++i) engines[i]->match_ms = lead->match_ms;  // one joint sequence of launches
     prof_collect(lead);
@@ -2083,16 +1718,13 @@ int cook_match_stats(cook_engine* e, uint32_t out[16]) {
   out[3] = c.stop_full;
   out[4] = c.stop_group;
   out[5] = c.stop_window;
-  out[6] = c.stop_slots;
+  out[6] = c.segments;
   out[7] = c.head;
   out[8] = (uint32_t)(c.t_setup / 100ull);  // microseconds
   out[9] = (uint32_t)(c.t_seq / 100ull);
   out[10] = c.touched_sum;
   out[11] = c.visited_sum;
-  out[12] = c.reevals;
-  out[13] = e->last_persistent | ((e->persist_fallbacks + e->world_fallbacks) << 4);  // 1 = match_persist, 2 = match_world ran; fallbacks so far
-  out[14] = (uint32_t)((c.t_eval + e->world_wait_eval) / 100ull);    // match_persist: eval phase; match_world: the walker's wait for it
-  out[15] = (uint32_t)((c.t_merge + e->world_wait_merge) / 100ull);
+  out[12] = out[13] = out[14] = out[15] = 0u;
   return COOK_OK;
 }
 int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap) {
@@ -2103,16 +1735,6 @@ int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap) {
   if (rc) return rc;
   const WinCtl& c = e->last_ctl;
   v[16] = c.trunc_lists;
-  v[17] = c.trunc_stops;
-  if (e->last_persistent == 3) {  // match_v3: generations, jobs walked / settled by the helpers, blocks the helpers visited, lanes opened,
-                                  // microseconds total / rebuilding orders / the walker waiting for a prepared job, why generations ended
-    const V3Ctl& q = e->last_v3;
-    v[18] = q.generations, v[19] = q.walked, v[20] = q.settled, v[21] = q.scan_steps, v[22] = q.opens;
-    v[23] = (uint32_t)(q.t_total / 100ull), v[24] = (uint32_t)(q.t_regen / 100ull), v[25] = (uint32_t)(q.t_walk_wait / 100ull);
-    v[26] = q.stop_full, v[27] = q.stop_list, v[28] = q.stop_log;
-    v[30] = q.fast, v[31] = q.visits;
-  }
-  v[29] = e->v3_refused;
   uint32_t n = 0;
   for (; n < cap && n < (uint32_t)COOK_MATCH_STATS_EX_N; ++n) out[n] = v[n];
   return (int)n;

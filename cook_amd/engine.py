@@ -406,10 +406,9 @@ class Engine:
     def match_stats(self):
         out = (C.c_uint32 * 32)()
         n = self._lib.cook_match_stats_ex(self._h, out, 32)
-        keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "stop_slots", "resolved", "setup_us", "seq_us", "touched", "visited", "reevals", "persistent", "eval_us", "merge_us",
-                "trunc_lists", "trunc_stops", "v3_generations", "v3_walked", "v3_settled", "v3_scan_steps", "v3_opens", "v3_total_us", "v3_regen_us",
-                "v3_wait_us", "v3_stop_full", "v3_stop_list", "v3_stop_log", "v3_refused", "v3_fast", "v3_visits")
-        return dict(zip(keys, [int(x) for x in out[:max(0, n)]]))
+        keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "segments", "resolved", "setup_us", "seq_us", "touched", "visited",
+                "_12", "_13", "_14", "_15", "trunc_lists")
+        return {k: int(x) for k, x in zip(keys, out[:max(0, n)]) if not k.startswith("_")}
 
     def set_profiling(self, on: bool):
         self._lib.cook_set_profiling(self._h, int(bool(on)))

@@ -198,12 +198,7 @@ class ShardedCluster:
 
         t1 = time.perf_counter()
         multi = all(hasattr(self.engines[p], "cycle_run_rank") for p in self.pools)
-        # match_algo 5: ONE persistent launch places all local pools, every pool advancing on its own (match_world.hpp)
-        world = multi and all(getattr(getattr(self.engines[p], "params", None), "match_algo", 0) == 5 for p in self.pools)
-        # match_algo 6 (match_v3): a pool's placement is ONE persistent workgroup on the pool's own stream — no launch chain to share
-        # dispatch pipes with, so every pool runs its whole cycle on its own thread and stream, all pools at once
-        solo = all(getattr(getattr(self.engines[p], "params", None), "match_algo", 0) == 6 for p in self.pools)
-        lockstep = not solo and (world or (multi and (len(self.pools) > self.max_chains or self.force_multi)))
+        lockstep = multi and (len(self.pools) > self.max_chains or self.force_multi)
 
         # the per-user usage vectors of the local pools (north_star's collective payload) are extracted by the pools' own threads right
         # after their rank stage — in parallel, overlapped with the other pools' work — so that the end of the cycle only sums and reduces
@@ -233,7 +228,7 @@ class ShardedCluster:
                     user_parts[p] = self.engines[p].rank_user_usage(self.n_users)
 
         n_chains = max(1, min(len(self.pools), self.max_chains))
-        if lockstep and not world and self.chain_whole_cycle:
+        if lockstep and self.chain_whole_cycle:
             # MI355X runs about four independent chains of small kernels at full speed (beyond that the hardware queues
             # share dispatch pipes: 4 pools 113 ms, 6 or 8 pools 186 ms per cycle), while pools in lockstep pay for the
             # slowest pool of every round (8 in lockstep: 215 ms).  So: at most MAX_CHAINS chains, pools spread over them;
@@ -249,17 +244,13 @@ class ShardedCluster:
             list(self._tp.map(chain, range(n_chains)))
             t2 = time.perf_counter()
         else:
-            # the rank stages are chains of small kernels too: at most max_chains at a time (all at once with match_v3: a pool's
-            # thread then spends most of its time waiting for the one placement kernel)
-            list((self._tp if solo else self._tp_rank).map(run, self.pools))
+            # the rank stages are chains of small kernels too: at most max_chains at a time
+            list(self._tp_rank.map(run, self.pools))
             t2 = time.perf_counter()
             if lockstep:
                 from .engine import cycle_match_multi
-                if world:
-                    cycle_match_multi([self.engines[p] for p in self.pools])
-                else:
-                    groups = [[self.engines[p] for p in self.pools[c::n_chains]] for c in range(n_chains)]
-                    list(self._tp.map(cycle_match_multi, groups))
+                groups = [[self.engines[p] for p in self.pools[c::n_chains]] for c in range(n_chains)]
+                list(self._tp.map(cycle_match_multi, groups))
         t3 = time.perf_counter()
         if want_users:
             self._last_user_usage = reduce_user_usage_parts(user_parts, self.pools, self.n_users, self.world, on_gpu)

@@ -51,7 +51,7 @@ def main():
             ref = j2o
         same = bool((ref == j2o).all())
         print(f"W={wmax} S={slots} L={L}: rounds {st['rounds']} (list {st['stop_list']} full {st['stop_full']} window {st['stop_window']} "
-              f"slots {st['stop_slots']}) visited {st['visited']} matched {st['matched']} same_result {same}  [{time.time() - t0:.0f} s]", flush=True)
+              f"segments {st['segments']}) visited {st['visited']} matched {st['matched']} same_result {same}  [{time.time() - t0:.0f} s]", flush=True)
 
 
 if __name__ == "__main__":

@@ -427,7 +427,7 @@ def slow_constraint_case(seed, n, m):
     return jobs, offers, groups
 
 
-def multi_pool_parity(make_engine, pools, params, k, want_persistent=None):
+def multi_pool_parity(make_engine, pools, params, k):
     """cook_cycle_run_rank per pool + ONE cook_cycle_match_multi for all of them == cook_cycle_run on each pool == oracle."""
     from cook_amd.engine import cycle_match_multi
     engines = [make_engine(params) for _ in pools]
@@ -437,10 +437,6 @@ def multi_pool_parity(make_engine, pools, params, k, want_persistent=None):
             e.cycle_run_rank(k)
         cycle_match_multi(engines)
         got = [e.cycle_fetch() for e in engines]
-        if want_persistent is not None:  # which orchestration really ran (2 = match_world, no fallback)
-            for e, pool in zip(engines, pools):
-                if pool.n_pending and len(e.cycle_fetch()[1]):
-                    assert e.match_stats()["persistent"] == want_persistent, e.match_stats()
         cycle_match_multi(engines)  # nothing deferred any more: a no-op, not an error
     finally:
         for e in engines:

@@ -24,8 +24,7 @@ def test_the_library_reports_its_shapes(make_engine):
         assert "shipped launch shapes" in e.version
 
 
-@pytest.mark.parametrize("algo", [0, 5], ids=["default", "world"])
-def test_match_spans_several_windows(make_engine, algo):
+def test_match_spans_several_windows(make_engine, algo=0):
     pool = synth.make_pool(seed=31, n_pending=1800, n_running=100, n_users=40, n_offers=420, gpus=True, constraints=True)
     j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, A.default_params(match_algo=algo), reserved=(3, 7))
     assert (j2o >= 0).sum() > 200 and (j2o < 0).sum() > 100

@@ -78,7 +78,7 @@ def test_rank_edge_cases(make_engine):
     P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=0))
 
 
-ALGOS = pytest.mark.parametrize("algo", [0, 1, 3, 4, 5, 6], ids=["default", "serial", "launches+reeval", "persistent", "world", "v3"])
+ALGOS = pytest.mark.parametrize("algo", [0, 1], ids=["default", "serial"])  # window rounds (shipped) / the one-job-at-a-time sweep
 
 
 @ALGOS
@@ -105,17 +105,9 @@ def test_match_fills_cluster_then_fails(make_engine, algo):
     p = A.default_params(good_enough_fitness=1.0, match_algo=algo)
     j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, None, p)
     assert (j2o < 0).sum() > 1000
-    if algo in (3, 4, 5):
-        with make_engine(p) as e:
-            e.match(pool.pending_jobs, pool.offers)
-            stats = e.match_stats()
-        assert stats["persistent"] == {3: 0, 4: 1, 5: 2}[algo]  # the persistent kernel ran, and never fell back
-        if algo == 3:
-            assert stats["reevals"] > 0
 
 
-@pytest.mark.parametrize("algo", [0, 5], ids=["default", "world"])
-def test_match_long_windows(make_engine, algo):
+def test_match_long_windows(make_engine, algo=0):
     # a cluster that is full after a few hundred jobs: from then on nearly every job is settled in the parallel phase of the resolve
     # kernel, the window grows past the LDS-staged size (MV_WLONG) and only the few jobs that still need the walk are staged —
     # gpu jobs, constrained jobs and group members keep some of those in every window
@@ -169,7 +161,8 @@ def test_match_slot_table_and_touched_set_limits(make_engine):
     P.match_parity(make_engine, jobs, offers, None, p)
     with make_engine(p) as e:
         e.match(jobs, offers)
-        assert e.match_stats()["stop_slots"] > 0
+        st_ = e.match_stats()
+        assert st_["segments"] >= st_["rounds"] > 0, st_
     jobs, offers = P.pinned_jobs_case(8, 3000, 4000, 0)
     P.match_parity(make_engine, jobs, offers, None, p)
     with make_engine(p) as e:
@@ -281,13 +274,12 @@ def test_multi_pool_context_forms(make_engine, n, ge):
     P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=ge, match_algo=2), k=10 ** 9)
 
 
-@pytest.mark.parametrize("algo", [2, 5], ids=["lockstep-launches", "world"])
-def test_multi_pool(make_engine, algo):
+def test_multi_pool(make_engine, algo=2):
     pools = [synth.make_pool(seed=71, n_pending=6000, n_running=2000, n_users=100, n_offers=3000, gpus=True, constraints=True),
              synth.make_pool(seed=72, n_pending=3000, n_running=500, n_users=50, n_offers=400),
              synth.make_pool(seed=73, n_pending=0, n_running=30, n_users=5, n_offers=20),
              synth.make_pool(seed=74, n_pending=5000, n_running=0, n_users=80, n_offers=150)]
-    P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0, match_algo=algo), k=4000, want_persistent=2 if algo == 5 else 0)
+    P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=1.0, match_algo=algo), k=4000)
 
 
 @pytest.mark.parametrize("kw", [
@@ -407,7 +399,7 @@ def test_c4_one_pool_full_size(make_engine):
     assert 10000 < (j2o >= 0).sum() < 125000
     # the merged lists of MV_LM entries out of per-chunk lists of MV_L: the early stop on a full chunk list (JL_TRUNC) is exercised at
     # the shipped shapes, and rounds do end on such lists
-    assert stats["trunc_lists"] > 0 and stats["trunc_stops"] > 0, stats
+    assert stats["trunc_lists"] > 0 and stats["stop_list"] > 0, stats
 
 
 def _c4_pool():
@@ -426,23 +418,6 @@ def test_c4_one_pool_good_enough_08_full_size(make_engine):
 def test_c4_one_pool_k1000(make_engine, ge):
     """fenzo-max-jobs-considered 1000 (config.clj:113) on a full C4 pool: the cycle Cook runs on day one.  VERDICT r2 item 1b."""
     j2o = _full_cycle_parity(make_engine, _c4_pool(), ge=ge, k=1000)
-    assert len(j2o) == 1000 and (j2o >= 0).sum() > 500
-
-
-@pytest.mark.parametrize("cfg", ["C2", "C4"])
-def test_full_size_v3(make_engine, cfg):
-    """match_algo 6 (match_v3.hpp: one persistent workgroup per pool, candidate lists from block bounds of the offers' fullness order) at
-    BASELINE.json's sizes: every pending job of configs[1] and of one pool of configs[3], bit-exact against the oracle, and the
-    kernel really placed the call (no hand-back to the window rounds)."""
-    pool = (synth.make_pool(seed=0xC00C0002, n_pending=50000, n_running=20000, n_users=1000, n_offers=5000) if cfg == "C2" else _c4_pool())
-    stats = {}
-    j2o = _full_cycle_parity(make_engine, pool, stats=stats, algo=6)
-    assert stats["persistent"] == 3 and stats["v3_refused"] == 0, stats
-    assert 5000 < (j2o >= 0).sum() < pool.n_pending
-
-
-def test_c4_one_pool_k1000_v3(make_engine):
-    j2o = _full_cycle_parity(make_engine, _c4_pool(), k=1000, algo=6)
     assert len(j2o) == 1000 and (j2o >= 0).sum() > 500
 
 
