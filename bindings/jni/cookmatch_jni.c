@@ -178,6 +178,7 @@ JNIEXPORT jlong JNICALL Java_cook_hip_Native_create(JNIEnv* env, jclass c, jobje
   const cook_params* p = BUF(const cook_params, params);
   (void)c;
   if (bad) return (jlong)COOK_E_INVALID;
+  if (cook_abi_version() != COOK_ABI_VERSION) return (jlong)COOK_E_INVALID; /* a library of another struct layout */
   rc = cook_engine_create(p, device, &e);
   return rc == COOK_OK ? (jlong)(intptr_t)e : (jlong)rc; /* negative = COOK_E_* */
 }

@@ -13,6 +13,7 @@ from typing import Optional
 import numpy as np
 
 NONE_U32 = 0xFFFFFFFF
+ABI_VERSION = 4  # COOK_ABI_VERSION of include/cookmatch.h whose struct layouts this module mirrors (tests/test_abi.py compares)
 DMAX = float(np.finfo(np.float64).max)
 
 _f64p = C.POINTER(C.c_double)

@@ -33,8 +33,12 @@ def stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return OUT
+    # exports: the C functions of include/cookmatch.h and nothing else (-fvisibility=hidden for the library's own code, a linker
+    # version script for what the C++ runtime's headers force to default visibility: std:: template instantiations)
+    vmap = os.path.join(HERE, "csrc", "exports.map")
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
-           "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-o", OUT + f".{os.getpid()}.tmp", SRC]
+           "-ffp-contract=off", "-fvisibility=hidden", "-fvisibility-inlines-hidden", f"-Wl,--version-script={vmap}", "-Wall",
+           "-Wno-unused-function", "-o", OUT + f".{os.getpid()}.tmp", SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     try:  # concurrent builders each write their own file; the rename is atomic

@@ -979,19 +979,15 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
     }
     if constexpr (GE) {
       if (use_ge) {
-        ghide = ghide || ng == MV_LGC;
+        ghide = ghide || ng == MV_LGC || n_ge + ng > LG;  // (entries that do not fit the lane's list are dropped: it hides them)
 #pragma unroll
         for (int q = 0; q < MV_LGC; ++q) {  // chunks ascend with ch, entries ascend inside a chunk
-          if (q >= ng) break;
-          if (n_ge >= LG) {
-            ghide = true;
-            break;
-          }
+          const bool take = q < ng && n_ge < LG;
           const int o = R.ge[q];
 #pragma unroll
           for (int x = 0; x < LG; ++x)
-            if (x == n_ge) gi[x] = o;
-          ++n_ge;
+            if (take && x == n_ge) gi[x] = o;
+          n_ge += take ? 1 : 0;
         }
       }
     }
@@ -1213,6 +1209,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     L.off_none = -1;
     L.owner_none[0] = L.owner_none[1] = L.owner_none[2] = L.owner_none[3] = 0xFE;
     L.cmd = 0;
+    s_ngslots = 0;
   }
   __syncthreads();
   // A job without any feasible offer under S stays unmatched whatever the jobs before it do (placements only take
@@ -1236,88 +1233,89 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     }
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid <= (unsigned)MV_JGL) {  // walk position of the first visited job of group tid ([MV_JGL] = the total): every thread sums its own prefix
     unsigned acc = 0;
-    const unsigned ng = (nwin + COOK_WAVE - 1) / COOK_WAVE;
-    for (unsigned g = 0; g < ng; ++g) {
-      s_vbase[g] = acc;
-      acc += (unsigned)__popcll(s_visit[g]);
-    }
-    for (unsigned g = ng; g <= (unsigned)MV_JGL; ++g) s_vbase[g] = acc;  // ([MV_JGL] = the total)
+    for (unsigned g = 0; g < tid; ++g) acc += (unsigned)__popcll(s_visit[g]);  // (groups beyond the window hold no bits)
+    s_vbase[tid] = acc;
   }
   __syncthreads();
   const unsigned n_list = wave_uniform_u32(s_vbase[MV_JGL]);  // jobs the walk has to visit
   const unsigned ngrp = (nwin + COOK_WAVE - 1) / COOK_WAVE;
   // ---- the segment [lo, lo + n_seg) of walk positions -> LDS, by walk position (all threads) --------------------------------
-  auto stage_segment = [&](unsigned lo) -> unsigned {
+  auto stage_segment = [&](unsigned lo) -> unsigned {  // (s_ngslots = 0 and a barrier behind it: the caller's)
     const unsigned hi = lo + wseg < n_list ? lo + wseg : n_list;
-    if (tid == 0) s_ngslots = 0;
-    __syncthreads();
     // the job groups of the window that hold walk positions of the segment
     unsigned g0 = 0;
     while (g0 + 1 < ngrp && s_vbase[g0 + 1] <= lo) ++g0;
-    constexpr int EPJ = LM + LG;
-    for (unsigned e = g0 * COOK_WAVE * (EPJ + 1) + tid;; e += NT) {
-      const unsigned b = e / (EPJ + 1), q = e % (EPJ + 1);
-      if (b >= nwin || s_vbase[b >> 6] >= hi) break;
+    // pass 1, thread = window position: the records of the visited jobs, compacted to walk positions
+    for (unsigned b = g0 * COOK_WAVE + tid; b < nwin && s_vbase[b >> 6] < hi; b += NT) {
       const unsigned long long vw = s_visit[b >> 6];
       if (!((vw >> (b & 63u)) & 1ull)) continue;
       const unsigned i = s_vbase[b >> 6] + (unsigned)__popcll(vw & ((1ull << (b & 63u)) - 1ull));
       if (i < lo || i >= hi) continue;
       const unsigned x = i - lo;
       const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
-      if (q == (unsigned)EPJ) {
-        s_fail[x] = 0;  // a visited job that gets matched leaves it at that
-        const JobRec j = vb.jr[head + b];
-        const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
-        JobL r;
-        r.c = j.c;
-        r.m = j.m;
-        const bool grouped = (j.flags & JF_GROUPED) != 0;
-        r.info = (info & 0xFFFFu) | (j.g > 0 ? JL_GPU : 0u) | (grouped ? JL_GROUPED : 0u) | (((j.flags >> 8) & 3u) << 18) |
-                 (j.group != 0xFFFFFFFFu ? JL_HASGROUP : 0u) | ((j.flags & JF_XRES) ? JL_XRES : 0u) |
-                 ((info & (1u << 16)) ? JL_TRUNC : 0u) | ((info & (1u << 17)) ? JL_GTRUNC : 0u);
-        // a member of a unique (type 1) or unconstrained (type 0) group: stage what the walk's fast path needs — the hosts to avoid
-        // as the round begins and the group's last placed job (for the chain link) — so that it never has to go to HBM for them
-        unsigned gslot = JL_GSLOT_NONE;
-        const unsigned gt = (j.flags >> 8) & 3u;
-        if (j.group != 0xFFFFFFFFu && gt <= 1u && !use_ge && vb.in_dev->host_dup == 0u && !(j.flags & JF_XRES)) {
-          const unsigned* row = vb.jfh + (size_t)b * (MV_FH + 2);  // gathered by the evaluation of this round
-          const int nfh = (int)row[MV_FH];
-          if (gt == 0u || (nfh >= 0 && nfh <= MV_FH)) {
-            const unsigned gs = atomicAdd(&s_ngslots, 1u);
-            if (gs < (unsigned)MV_GMAX) {
+      const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
+      const JobRec j = vb.jr[head + b];
+      s_fail[x] = 0;  // a visited job that gets matched leaves it at that
+      JobL r;
+      r.c = j.c;
+      r.m = j.m;
+      const bool grouped = (j.flags & JF_GROUPED) != 0;
+      r.info = (info & 0xFFFFu) | (j.g > 0 ? JL_GPU : 0u) | (grouped ? JL_GROUPED : 0u) | (((j.flags >> 8) & 3u) << 18) |
+               (j.group != 0xFFFFFFFFu ? JL_HASGROUP : 0u) | ((j.flags & JF_XRES) ? JL_XRES : 0u) |
+               ((info & (1u << 16)) ? JL_TRUNC : 0u) | ((info & (1u << 17)) ? JL_GTRUNC : 0u);
+      // a member of a unique (type 1) or unconstrained (type 0) group: stage what the walk's fast path needs — the hosts to avoid
+      // as the round begins and the group's last placed job (for the chain link) — so that it never has to go to HBM for them
+      unsigned gslot = JL_GSLOT_NONE;
+      const unsigned gt = (j.flags >> 8) & 3u;
+      if (j.group != 0xFFFFFFFFu && gt <= 1u && !(good_enough < 1.0) && vb.in_dev->host_dup == 0u && !(j.flags & JF_XRES)) {
+        const unsigned* row = vb.jfh + (size_t)b * (MV_FH + 2);  // gathered by the evaluation of this round
+        const int nfh = (int)row[MV_FH];
+        if (gt == 0u || (nfh >= 0 && nfh <= MV_FH)) {
+          const unsigned gs = atomicAdd(&s_ngslots, 1u);
+          if (gs < (unsigned)MV_GMAX) {
 #pragma unroll
-              for (int y = 0; y < MV_FH; ++y) s_gfh[gs][y] = gt == 1u ? row[y] : 0xFFFFFFFFu;
-              s_glast[gs] = (int)row[MV_FH + 1];
-              gslot = gs;
-            }
+            for (int y = 0; y < MV_FH; ++y) s_gfh[gs][y] = gt == 1u ? row[y] : 0xFFFFFFFFu;
+            s_glast[gs] = (int)row[MV_FH + 1];
+            gslot = gs;
           }
         }
-        r.info |= gslot << JL_GSLOT_SHIFT;
-        r.group = j.group;
-        r.f1 = (unsigned short)(c1 < 0xFFFFu ? c1 : 0xFFFFu);
-        r.f2 = (unsigned short)(c2 < 0xFFFFu ? c2 : 0xFFFFu);
-        r.f4 = (unsigned short)(c4 < 0xFFFFu ? c4 : 0xFFFFu);
-        r.b = (unsigned short)b;
-        s_job[x] = r;
-      } else if (q < (unsigned)LM) {
-        double f = -1.0;
-        int o = -1;
-        if (q < (info & 0xFFu)) {
-          o = vb.cand_idx[(size_t)b * LM + q];
-          f = vb.cand_fit[(size_t)b * LM + q];
-        }
-        s_efit[(size_t)x * LM + q] = f;
-        s_eoff[(size_t)x * LM + q] = o;
-      } else if (LG > 0) {
-        int o = -1;
-        if (use_ge && q - LM < ((info >> 8) & 0xFFu)) o = vb.ge_idx[(size_t)b * LG + (q - LM)];
-        s_goff[(size_t)x * LG + (q - LM)] = o;
+      }
+      r.info |= gslot << JL_GSLOT_SHIFT;
+      r.group = j.group;
+      r.f1 = (unsigned short)(c1 < 0xFFFFu ? c1 : 0xFFFFu);
+      r.f2 = (unsigned short)(c2 < 0xFFFFu ? c2 : 0xFFFFu);
+      r.f4 = (unsigned short)(c4 < 0xFFFFu ? c4 : 0xFFFFu);
+      r.b = (unsigned short)b;
+      s_job[x] = r;
+    }
+    __syncthreads();
+    // pass 2, thread = list entry: the candidate lists by walk position.  The loads do not wait for the job's counts (the arrays are
+    // sized for every entry of every job of a window: entries beyond a list hold stale values, replaced by "none" behind the load)
+    const unsigned n = hi - lo;
+#pragma unroll 4
+    for (unsigned e = tid; e < n * (unsigned)LM; e += NT) {
+      const unsigned x = e / (unsigned)LM, q = e % (unsigned)LM;
+      const JobL* jl = &s_job[x];
+      const unsigned b = jl->b, nl = jl->info & 0xFFu;
+      const int o = vb.cand_idx[(size_t)b * LM + q];
+      const double f = vb.cand_fit[(size_t)b * LM + q];
+      s_efit[e] = q < nl ? f : -1.0;
+      s_eoff[e] = q < nl ? o : -1;
+    }
+    if constexpr (LG > 0) {
+#pragma unroll 4
+      for (unsigned e = tid; e < n * (unsigned)LG; e += NT) {
+        const unsigned x = e / (unsigned)LG, q = e % (unsigned)LG;
+        const JobL* jl = &s_job[x];
+        const unsigned b = jl->b, ngl = (jl->info >> 8) & 0xFFu;
+        const int o = vb.ge_idx[(size_t)b * LG + q];
+        s_goff[e] = (use_ge && q < ngl) ? o : -1;
       }
     }
     __syncthreads();
-    return hi - lo;
+    return n;
   };
   unsigned seg_lo = 0;
   unsigned n_eff = stage_segment(0);  // walk positions of the segment
@@ -1345,6 +1343,8 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   int t_acount = 0, t_run = 0, t_slack = 0;
   unsigned t_k8s = 0, t_host = 0;
   unsigned long long t_col = 0ull;  // the offer's static-constraints-pass bits of job group cur_g of the window (colbits)
+  unsigned long long t_coln = 0ull;  // ... and of group col_next, fetched when the walk entered cur_g (nothing waits for it)
+  unsigned col_next = 0xFFFFFFFFu;
   // group members placed in THIS round, one per lane in placement order (group, host, match index): what a later member of the same
   // group has to avoid / link to, without asking HBM.  n_log > 64: the log overflowed, no fast path for group members any more
   unsigned lg_group = 0xFFFFFFFFu, lg_host = 0u, n_log = 0u;
@@ -1422,10 +1422,23 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   };
   // The colbits word of job group g of the window for the lane's offer (0 for a lane without one): one gather from global memory when
   // the walk enters a new group of 64 window positions (at most nwin / 64 times per round).
-  auto fetch_col = [&](unsigned g) {
+  auto fetch_col = [&](unsigned g) -> unsigned long long {
     const unsigned v = t_v >= 0 ? (unsigned)t_v : 0u;
     const unsigned long long w = vb.colbits[(size_t)v * MV_JGL + g];
-    t_col = t_v >= 0 ? w : 0ull;
+    return t_v >= 0 ? w : 0ull;
+  };
+  // the walk enters group g of the window: its word from the prefetch if that is the group fetched ahead, and the word of the group
+  // after it ordered now (a long window's visited jobs may skip groups: then the word is fetched on the spot)
+  auto enter_group = [&](unsigned g) {
+    if (g == col_next) {
+      t_col = t_coln;
+    } else if (nT != 0u) {
+      t_col = fetch_col(g);
+      WAIT_ALL_MEM();
+    }
+    cur_g = g;
+    col_next = g + 1u < (unsigned)MV_JGL ? g + 1u : g;
+    if (nT != 0u) t_coln = fetch_col(col_next);
   };
   // Lane nT becomes the owner of the untouched offer `off` that takes a job of (c, m).  Its record, snapshot state and colbits word come
   // from GLOBAL memory (wave-uniform addresses: every lane reads them, one transaction each, a single round trip for all of them).
@@ -1439,7 +1452,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     const OfferB o = vb.ob[v];
     const double ac0 = st.ac[v], am0 = st.am[v];
     const int acount0 = st.acount[v];
-    const unsigned long long colw = vb.colbits[(size_t)v * MV_JGL + cur_g];
+    const unsigned long long colw = vb.colbits[(size_t)v * MV_JGL + cur_g], colwn = vb.colbits[(size_t)v * MV_JGL + col_next];
     const bool me = lane == nT;
     t_v = me ? off : t_v;
     t_oc = me ? a.oc : t_oc;
@@ -1458,6 +1471,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     t_basec = t_rc + t_ac;
     t_basem = t_rm + t_am;
     t_col = me ? colw : t_col;
+    t_coln = me ? colwn : t_coln;
     unsigned char* const p = me ? &s_owner[v] : &L.sinkb[lane];
     *p = (unsigned char)nT;
   };
@@ -1540,11 +1554,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       WALK_PROF_BEGIN();
       nxt = load_rec(i + 1);  // in flight while job i is decided (its owner look-up follows at the end of this turn, when the entry's offer is there)
       WALK_DECODE();
-      if ((b >> 6) != cur_g) {  // next word of the columns: the touched lanes fetch theirs
-        cur_g = b >> 6;
-        fetch_col(cur_g);
-        WAIT_ALL_MEM();
-      }
+      if ((b >> 6) != cur_g) enter_group(b >> 6);  // next word of the columns
     // ======== FAST PATH ======================================================================================================
     // self-contained: decision AND commit, then straight on to the next job (its control flow never joins the general path's).
     // Two instantiations: plain jobs, and members of unique / unconstrained groups whose hosts-to-avoid the staging gathered
@@ -2102,6 +2112,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   if (lane == 0) {
     L.seg_lo = seg_lo;
     L.cmd = 1;
+    s_ngslots = 0;
   }
   {
     const unsigned long long ts0 = cook_ticks();

@@ -53,6 +53,11 @@ def load_library(path: Optional[str] = None):
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = restype
         fn.argtypes = argtypes   # pointers are c_void_p: ctypes checks the argument COUNT and pointer-vs-scalar for every call
+    # the struct layouts of cook_amd._abi mirror include/cookmatch.h at COOK_ABI_VERSION: a library of another layout is refused before
+    # the first call passes it a struct
+    if lib.cook_abi_version() != A.ABI_VERSION:
+        raise CookError(-1,
+                        f"{path} has ABI version {lib.cook_abi_version()}, this binding was written for {A.ABI_VERSION}")
     _LIBS[path] = lib
     return lib
 

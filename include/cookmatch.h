@@ -33,6 +33,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the functions declared here are the library's ONLY exports: libcookmatch.so is built with -fvisibility=hidden */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define COOK_OK 0
 #define COOK_E_INVALID (-1) /* bad argument / inconsistent sizes            */
@@ -52,8 +56,9 @@ typedef struct cook_params {
   double offensive_max_cpus;   /* task-constraints :cpus (scheduler.clj:2198-2203); +inf disables               */
   double good_enough_fitness;  /* config.clj:111 default 0.8; (> fitness x) at scheduler.clj:2312-2314; >=1 = off */
   int64_t host_lifetime_mins;  /* estimated-completion-config :host-lifetime-mins (constraints.clj:392-397)     */
-  int32_t match_algo;          /* 0 = engine default (= 2), 1 serial sweep, 2 window rounds with one launch per phase,
-                                  3 = 2 + in-place re-evaluation, 4 persistent kernel; identical results */
+  int32_t match_algo;          /* 0 = engine default (= 2), 1 serial sweep (one workgroup, one job at a time: the reference form of the
+                                  chain), 2 window rounds (eval / merge / resolve launches).  Other values: COOK_E_INVALID.
+                                  Identical results */
   int32_t reserved;
 } cook_params;
 
@@ -249,8 +254,10 @@ const char* cook_last_error(const cook_engine* e);
 const char* cook_version(void);
 /* Layout version of the structs and buffer sizes of this header (cook_jobs / cook_offers / cook_offer_params / COOK_WHY_SLOTS changed
  * in 2: ports, named scalars, gpu / disk slot tables, 20 why-slots; 3 adds cook_match_stats_ex and the mask rule of
- * cook_cycle_update).  A binding compares its compiled-in COOK_ABI_VERSION with the library's before the first call. */
-#define COOK_ABI_VERSION 3
+ * cook_cycle_update; 4: cook_params.match_algo takes 0 / 1 / 2 only, the words [6], [12..17] of the placement statistics changed).
+ * A binding compares its compiled-in COOK_ABI_VERSION with the library's before the first call (cook_amd/engine.py load_library,
+ * bindings/jni/cookmatch_jni.c Native.create). */
+#define COOK_ABI_VERSION 4
 int cook_abi_version(void);
 
 /* ---- RANK: replaces sort-jobs-by-dru-helper + filter-based-on-quota + filter-offensive-jobs --------------
@@ -554,18 +561,20 @@ int cook_last_timing(cook_engine* e, double* rank_ms, double* match_ms);
 /* named kernel timings of the last run: fills up to cap entries, returns count */
 int cook_kernel_timings(cook_engine* e, const char** names, double* ms, uint32_t* launches, uint32_t cap);
 int cook_set_profiling(cook_engine* e, int enabled);
-/* placement statistics of the last match: [0] rounds, [1] matched, [2..6] rounds ended by list-exhausted / touched-set-full /
-   group barrier / window end / candidate-slot table full, [7] jobs resolved, [8] microseconds the resolve phase spent staging
+/* placement statistics of the last match: [0] rounds, [1] matched, [2..5] rounds ended by list-exhausted / touched-set-full /
+   group barrier / window end, [6] segments of windows staged for the walk (>= rounds; the excess went on without a launch), [7] jobs resolved, [8] microseconds the resolve phase spent staging
    windows, [9] ... walking them, [10] offers touched (sum over rounds), [11] jobs the walk visited (the rest were settled in
-   parallel), [12] jobs re-evaluated in place, [13] bit 0: the persistent kernel ran this match, bits 1..: times the engine had
-   to fall back from it, [14] / [15] microseconds of the eval / merge phases (persistent kernel only) */
+   parallel), [12..15] reserved (0) */
 int cook_match_stats(cook_engine* e, uint32_t out[16]);
 /* the same, open-ended: fills min(cap, COOK_MATCH_STATS_EX_N) words and returns how many.  [0..15] as cook_match_stats;
    [16] walked jobs whose merged candidate list was cut short because one offer chunk had contributed all its entries (the list
-   may not hold every feasible offer), [17] rounds that ended on such a list running out */
+   may not hold every feasible offer); [17..31] reserved (0) */
 #define COOK_MATCH_STATS_EX_N 32
 int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

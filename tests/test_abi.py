@@ -25,6 +25,14 @@ def test_header_symbols_exported():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/cookmatch.h but not exported by libcookmatch.so"
     assert sorted(engine.EXPORTS) == syms
+    # ... and NOTHING else: the library is built with -fvisibility=hidden, the header's declarations carry default visibility
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TW")
+    assert exported == syms, sorted(set(exported) ^ set(syms))[:10]
+    # the binding checks the struct-layout version before its first call (cook_amd/engine.py load_library)
+    hdr = open(os.path.join(ROOT, "include", "cookmatch.h")).read()
+    assert int(re.search(r"#define COOK_ABI_VERSION (\d+)", hdr).group(1)) == A.ABI_VERSION == lib.cook_abi_version()
 
 
 def test_struct_sizes_match_header(tmp_path):
