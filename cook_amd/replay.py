@@ -121,7 +121,7 @@ class EngineBackend:
 
 
 class Simulator:
-    def __init__(self, trace: List[dict], hosts: List[dict], config: dict, backend):
+    def __init__(self, trace: List[dict], hosts: List[dict], config: dict, backend, offer_order: str = "descending"):
         self.cfg = config_from_edn_keys(config) if any("-" in k for k in config) else {**DEFAULTS, **config}
         self.backend = backend
         self.trace = trace
@@ -133,7 +133,9 @@ class Simulator:
         self.used_cpus = np.zeros(len(hosts))
         self.used_mem = np.zeros(len(hosts))
         self.count = np.zeros(len(hosts), np.int32)
-        self.offer_order = np.arange(len(hosts))[::-1].copy()  # offer index -> host id (see _offers)
+        # offer index -> host id (see _offers): "descending" hostname order is the binding's contract; "ascending" exists
+        # so that a test can show what the other order does to the recorded run
+        self.offer_order = np.arange(len(hosts))[::-1].copy() if offer_order == "descending" else np.arange(len(hosts))
         self.user_names = sorted({j["job/user"] for j in trace})  # user ids = name ranks
         self.uid = {u: i for i, u in enumerate(self.user_names)}
         self.jobs: List[_Job] = []
@@ -311,7 +313,7 @@ class Simulator:
             w.writerows(self.rows())
 
 
-def simulate(trace, hosts, config, backend, max_cycles: int = 10 ** 9) -> Simulator:
-    sim = Simulator([dict(j) for j in trace], hosts, config, backend)
+def simulate(trace, hosts, config, backend, max_cycles: int = 10 ** 9, offer_order: str = "descending") -> Simulator:
+    sim = Simulator([dict(j) for j in trace], hosts, config, backend, offer_order=offer_order)
     sim.run(max_cycles)
     return sim

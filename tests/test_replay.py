@@ -83,6 +83,30 @@ def test_replay_reproduces_the_recorded_reference_run():
     assert P.check_replay_recorded(P.OracleBackend()) == 115
 
 
+def test_offer_order_contract_against_the_recorded_run():
+    """INTEGRATION.md 3 "Offer order": the engine (and the oracle) break equal-fitness ties towards the lowest offer INDEX; the
+    reference's recorded run (real Fenzo, five identical hosts) breaks them towards the LAST hostname.  Rows of `cook_offers` in
+    DESCENDING hostname order reproduce all 115 recorded rows (the test above); in ASCENDING order the replay places every task in
+    the same cycle but on the mirror-image host — this test counts the rows that diverge, so that a binding that forgets the rule is
+    caught by the recorded run and not in production."""
+    import json
+    from tests import golden_util as G
+    g = json.load(open(os.path.join(G.GOLDEN, "replay_example.json")))
+    names = sorted(h["hostname"] for h in g["hosts"])
+    out = {}
+    for order in ("descending", "ascending"):
+        sim = replay.simulate(g["trace"], g["hosts"], g["config"], P.OracleBackend(), offer_order=order)
+        rows = {r["job_id"]: r for r in sim.rows()}
+        assert set(rows) == set(g["expect"])
+        out[order] = rows
+    diverging = [j for j, e in g["expect"].items() if out["ascending"][j]["hostname"] != e["hostname"]]
+    assert not [j for j, e in g["expect"].items() if out["descending"][j]["hostname"] != e["hostname"]]
+    assert len(diverging) > 57, len(diverging)  # far more than half of the 115 rows (the rest sit on the middle host of five, or are forced)
+    for j in diverging:  # ... and every diverging row is the MIRROR host: host h <-> host 4 - h, same start
+        assert names.index(out["ascending"][j]["hostname"]) == len(names) - 1 - names.index(g["expect"][j]["hostname"]), j
+        assert out["ascending"][j]["start_time_ms"] == out["descending"][j]["start_time_ms"]
+
+
 def test_replay_recorded_run_through_the_emulated_engine(emu_engine):
     with emu_engine(A.default_params()) as e:
         assert P.check_replay_recorded(replay.EngineBackend(e)) == 115  # all 243 cycles, all 115 recorded rows
