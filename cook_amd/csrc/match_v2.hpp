@@ -52,7 +52,7 @@ constexpr int MV_LGC = 12;                 // good-enough list length per job an
 //   GE (good-enough-fitness < 1; config.clj:111 ships 0.8): there the "first offers above the threshold" list is the one that runs
 //     out — 16 entries of it, 12 best-fit entries for the jobs nothing clears the threshold for.
 #ifndef COOK_MV_LM
-#define COOK_MV_LM 24
+#define COOK_MV_LM 48
 #endif
 template <bool GE>
 struct VShape {
@@ -148,7 +148,7 @@ struct WinCtl {
   unsigned trunc_lists;   // walked jobs whose merged list carried the truncated flag (the merge stopped on a full chunk list)
   unsigned wgrow_pct;     // next window = this percentage of what the round resolved (window ended early) / of the window (it did not)
   unsigned wlong_cap;     // largest window the launch sequence allows (MV_WLONG, or MV_WEVAL when long windows are switched off)
-  unsigned pad0;
+  unsigned no_retire;     // the next round gives no lanes of dead offers away (the last one used few lanes: see resolve_round)
 #ifdef COOK_WALK_PROF  // measurement build: shader cycles / jobs of the walk by outcome (0 shortcut, 1 touched offer wins, 2 new lane,
                        // 3 walked and unmatched, 4 member of a constrained group, 5 exact path ran)
   unsigned long long prof_cyc[8];
@@ -1098,6 +1098,13 @@ constexpr unsigned JL_GTRUNC = 1u << 30;  // the good-enough list may not hold e
 #define COOK_L_COMPLETE() ((cinfo_u & JL_TRUNC) == 0u)
 constexpr unsigned JL_GSLOT_SHIFT = 21, JL_GSLOT_NONE = 0x7Fu;  // bits 21-27: the job's row of ResolveFixed::gfh, or none
 constexpr int MV_GMAX = 64;  // group members per segment whose hosts-to-avoid are staged for the walk's fast path
+// Offers a round may touch beyond its 64 lanes: when every lane is taken, a lane whose offer is DEAD — it cannot take even the smallest
+// job of the call any more, so no later job can go there — is given to the next offer (the dead offer's state is written back at once,
+// its byte in the owner table says "dead": list entries that name it are skipped like touched offers that do not fit).  On the
+// benchmark's pools 40-50 of the 64 lanes are dead when the 65th offer is asked for (best fit fills offers to the brim).
+constexpr unsigned MV_RETIRE_CAP = 192;
+constexpr unsigned MV_TMAX = (unsigned)MV_T + MV_RETIRE_CAP;  // offers one round can touch at most
+constexpr unsigned OWNER_UNTOUCHED = 0xFFu, OWNER_NONE = 0xFEu, OWNER_DEAD = 0xFDu;  // values of the owner table / of JobRegs::owner beside lane numbers
 
 // (WALK_STAT: platform.hpp — counters of the emulated build's design studies, nothing on the GPU)
 
@@ -1184,6 +1191,13 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   const double good_enough = wave_uniform_f64(vb.in_dev->good_enough);
   const bool use_ge = GE && good_enough < 1.0;
   const uint32_t* const j_index = wave_uniform_ptr(vb.in_dev->j_index);
+  // dead lanes are given away (MV_RETIRE_CAP) unless jobs of the call move ports / named scalars (their per-lane snapshots would go with the lane)
+  // ... and unless the previous round used few of its lanes: a round that may touch MV_TMAX offers must WALK every unmatched job whose
+  // failure classes are backed by no more offers than that, and once the cluster is full (rounds that touch a handful of offers, windows
+  // of thousands of jobs settled in parallel) those would be most of the queue
+  const bool can_retire = wave_uniform_u32(vb.in_dev->has_x) == 0u && wave_uniform_u32(ctl.no_retire) == 0u;
+  const unsigned t_max = can_retire ? MV_TMAX : (unsigned)MV_T;  // offers this round can touch at most
+  const double jmin_c = wave_uniform_f64(st.jmin[0]), jmin_m = wave_uniform_f64(st.jmin[1]);
   // the run-time part of the LDS
   const unsigned wseg = resolve_wseg<GE>(M);
   char* carve = lds + ((sizeof(ResolveFixed) + 15u) / 16u * 16u);
@@ -1222,8 +1236,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     // members of balanced / attribute-equals groups excepted: a cotask's placement can make an offer FEASIBLE for them; a unique
     // group only ever takes hosts away (constraints.clj:586-598), like a resource
     const bool opens = (flags & JF_GROUPED) != 0 && ((flags >> 8) & 3u) != 1u;
-    const bool trivial = (info & 0xFFFFu) == 0u && !opens && c1 > 0u && (c2 == 0u || c2 > (unsigned)MV_T) &&
-                         (c4 == 0u || c4 > (unsigned)MV_T);
+    const bool trivial = (info & 0xFFFFu) == 0u && !opens && c1 > 0u && (c2 == 0u || c2 > t_max) && (c4 == 0u || c4 > t_max);
     if (trivial) {
       // final whatever this round does, also for a job behind the point where the round stops: job_to_offer keeps the -1 it was
       // initialised with; should the job still be unresolved next round, its summary is simply rewritten under the newer snapshot
@@ -1351,7 +1364,8 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   int lg_k = -1;
   unsigned cur_g = 0xFFFFFFFFu;
   unsigned nT = 0;
-  unsigned stop = 0;  // 1 list exhausted, 2 touched set full, 3 group barrier
+  unsigned n_retired = 0;  // dead offers whose lanes were given away in this round
+  unsigned stop = 0;  // 1 list exhausted, 2 touched set full, 3 group barrier, 5 an unmatched job's summary needs a fresh snapshot
   unsigned matched = 0, head_matched = ctl.head_matched;
   unsigned resolved = nwin;
   unsigned n_trunc = 0;          // walked jobs with a truncated merged list (statistics)
@@ -1446,14 +1460,14 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   // the loads were masked writes into a second set of registers: the compiler kept the walker's state in two homes from then on and
   // moved all of it from one to the other and back in every iteration (~45 v_mov per job on the path of a job that goes to an offer
   // touched before, which never opens a lane).
-  auto open_lane = [&](int off, double jc, double jm) {
+  auto open_lane = [&](unsigned nl, int off, double jc, double jm) {
     const unsigned v = wave_uniform_u32((unsigned)off);
     const OfferA a = vb.oa[v];
     const OfferB o = vb.ob[v];
     const double ac0 = st.ac[v], am0 = st.am[v];
     const int acount0 = st.acount[v];
     const unsigned long long colw = vb.colbits[(size_t)v * MV_JGL + cur_g], colwn = vb.colbits[(size_t)v * MV_JGL + col_next];
-    const bool me = lane == nT;
+    const bool me = lane == nl;
     t_v = me ? off : t_v;
     t_oc = me ? a.oc : t_oc;
     t_om = me ? a.om : t_om;
@@ -1473,7 +1487,32 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     t_col = me ? colw : t_col;
     t_coln = me ? colwn : t_coln;
     unsigned char* const p = me ? &s_owner[v] : &L.sinkb[lane];
-    *p = (unsigned char)nT;
+    *p = (unsigned char)nl;
+  };
+  // the lane for a newly touched offer: the next free one, or — all 64 taken — the lane of a DEAD offer, which is retired first: its
+  // state goes to global memory now (nothing reads it before the next round), its alive bit is cleared, the owner table says "dead".
+  // -> MV_T: none (the round ends).  `nxt`'s owner look-up was issued before: patched here.
+  auto alloc_lane = [&](JobRegs& nxt) -> unsigned {
+    if (nT < (unsigned)MV_T) return nT;
+    if (!can_retire || n_retired >= MV_RETIRE_CAP) return (unsigned)MV_T;
+    const bool dead = t_ac + jmin_c > t_oc || t_am + jmin_m > t_om;  // (all 64 lanes own an offer)
+    const unsigned long long dm = __ballot(dead);
+    if (dm == 0ull) return (unsigned)MV_T;
+    const unsigned nl = (unsigned)__ffsll((unsigned long long)dm) - 1u;
+    if (lane == nl) {
+      st.ac[t_v] = t_ac;
+      st.am[t_v] = t_am;
+      st.acount[t_v] = t_acount;
+      atomicAnd(&st.alive[(unsigned)t_v >> 6], ~(1ull << ((unsigned)t_v & 63u)));
+      s_owner[(unsigned)t_v] = (unsigned char)OWNER_DEAD;
+    }
+    if (nxt.owner == nl) nxt.owner = OWNER_DEAD;
+    if constexpr (GEF) {
+      if (nxt.g_owner == nl) nxt.g_owner = OWNER_DEAD;
+    }
+    ++n_retired;
+    wave_sync();
+    return nl;
   };
   // The owner lane of a touched offer books a job of (jc, jm) — through selects as well: a branch on the lane number anywhere in the fast
   // path makes its whole region "divergent control flow" for the compiler, which then rebuilds it with flow blocks whose undefined
@@ -1654,7 +1693,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
             bool ok = COOK_L_COMPLETE();
             if (!ok) {
               const unsigned long long cand_mask = __ballot(cand);
-              const bool e_live = cur.owner < 0xFEu && ((cand_mask >> (cur.owner & 63u)) & 1ull);
+              const bool e_live = cur.owner < (unsigned)MV_T && ((cand_mask >> (cur.owner & 63u)) & 1ull);
               ok = __any(e_live);
             }
             if (ok) f_lane = wl;
@@ -1677,7 +1716,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         WALK_END(GROUP ? 4u : 1u);
         return true;
       }
-      if (f_new && nT < (unsigned)MV_T) {  // an untouched offer: the next free lane takes ownership — outside this loop (see below)
+      if (f_new && (nT < (unsigned)MV_T || can_retire)) {  // an untouched offer: a lane takes ownership — outside this loop (see below)
         open_off = u_off;
         open_group = GROUP;
       }
@@ -1725,15 +1764,21 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       const unsigned g = open_group ? wave_uniform_u32(cur.group) : 0xFFFFFFFFu;
       const unsigned gslot = (cinfo_u >> JL_GSLOT_SHIFT) & JL_GSLOT_NONE;
       const unsigned long long ghits = open_group ? __ballot(lane < n_log && lg_group == g) : 0ull;
-      open_lane(open_off, c, m);
-      WAIT_ALL_MEM();
-      if (open_group) publish_group_member(ghits, gslot, g, k, open_off, (unsigned)wave_read_lane((int)t_host, (int)nT));
-      // the owner look-up of the next job was issued before this commit: patch it
-      if (nxt.owner == 0xFFu && nxt.e_off == open_off) nxt.owner = nT;
-      if constexpr (GEF) {
-        if (nxt.g_owner == 0xFFu && nxt.g_off == open_off) nxt.g_owner = nT;
+      const unsigned nl = alloc_lane(nxt);
+      if (nl == (unsigned)MV_T) {
+        stop = 2;  // no lane to track a new touched offer: end the round before this job (the fast path booked nothing for it)
+        resolved = b;
+        break;
       }
-      ++nT;
+      open_lane(nl, open_off, c, m);
+      WAIT_ALL_MEM();
+      if (open_group) publish_group_member(ghits, gslot, g, k, open_off, (unsigned)wave_read_lane((int)t_host, (int)nl));
+      // the owner look-up of the next job was issued before this commit: patch it
+      if (nxt.owner == 0xFFu && nxt.e_off == open_off) nxt.owner = nl;
+      if constexpr (GEF) {
+        if (nxt.g_owner == 0xFFu && nxt.g_off == open_off) nxt.g_owner = nl;
+      }
+      nT += nT < (unsigned)MV_T ? 1u : 0u;
       store_result(i, open_off);
       wave_sync();  // the owner table update is visible to the whole wave before the next look-up reads it
       WALK_STAT(4, 1);
@@ -1804,7 +1849,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         //  zero-fitness verdict cannot appear on an offer that was feasible under S)
         const bool e_valid = cur.owner != 0xFEu;
         const bool e_untouched = cur.owner == 0xFFu;
-        const bool e_live = e_valid && !e_untouched && ((cand_mask >> (cur.owner & 63u)) & 1ull);
+        const bool e_live = cur.owner < (unsigned)MV_T && ((cand_mask >> (cur.owner & 63u)) & 1ull);
         const unsigned long long settle_mask = __ballot(e_untouched || e_live), untouched_mask = __ballot(e_untouched);
         if (settle_mask == 0ull && COOK_L_TRUNC()) {
           exhausted = true;
@@ -1854,7 +1899,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
           const bool t_feas = t_on && pe_bits == 0u;
           const unsigned long long feas_mask = __ballot(t_feas);
           // with exact verdicts a list entry settles only if its owner is still FEASIBLE (zero fitness excluded)
-          const bool e_live2 = e_valid && !e_untouched && ((feas_mask >> (cur.owner & 63u)) & 1ull);
+          const bool e_live2 = cur.owner < (unsigned)MV_T && ((feas_mask >> (cur.owner & 63u)) & 1ull);
           const unsigned long long settle2 = __ballot(e_untouched || e_live2);
           if (settle2 == 0ull && COOK_L_TRUNC()) {
             exhausted = true;
@@ -1958,28 +2003,30 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
 #ifdef COOK_WALK_PROF
     pcat = grouped ? 4u : (win >= 0 || win_lane >= 0 ? 5u : 3u);
 #endif
+    unsigned new_lane = (unsigned)MV_T;  // the lane an untouched winner was given
     if (win_lane >= 0) {  // an offer touched earlier in this round takes the job
       take_job((int)lane == win_lane, c, m);
       win = wave_read_lane(t_v, win_lane);
-    } else if (win >= 0) {  // an untouched offer: the next free lane takes ownership
-      if (nT == (unsigned)MV_T) {
-        stop = 2;  // no free lane to track a new touched offer: end the round before this job
+    } else if (win >= 0) {  // an untouched offer: a lane takes ownership
+      new_lane = alloc_lane(nxt);
+      if (new_lane == (unsigned)MV_T) {
+        stop = 2;  // no lane to track a new touched offer: end the round before this job
         resolved = b;
         break;
       }
-      open_lane(win, c, m);
+      open_lane(new_lane, win, c, m);
       WAIT_ALL_MEM();
       // the owner look-up of the next job was issued before this commit: patch it
-      if (nxt.owner == 0xFFu && nxt.e_off == win) nxt.owner = nT;
+      if (nxt.owner == 0xFFu && nxt.e_off == win) nxt.owner = new_lane;
       if constexpr (GEF) {
-        if (nxt.g_owner == 0xFFu && nxt.g_off == win) nxt.g_owner = nT;
+        if (nxt.g_owner == 0xFFu && nxt.g_off == win) nxt.g_owner = new_lane;
       }
-      ++nT;
+      nT += nT < (unsigned)MV_T ? 1u : 0u;
       wave_sync();  // the owner table update is visible to the whole wave before the next look-up reads it
     }
     if (win >= 0) {
       if (cinfo_u & JL_XRES) {  // the offer's owner lane books the job's ports / named scalars
-        const int ol = win_lane >= 0 ? win_lane : (int)nT - 1;
+        const int ol = win_lane >= 0 ? win_lane : (int)new_lane;
         if ((int)lane == ol) {
           const MatchIn& in = *vb.in_dev;
           if (!L.x0set[lane]) {
@@ -2001,7 +2048,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         }
         wave_sync();  // later cotasks of this wave read what lane 0 just published
         // ... and the round's log, for the members that take the fast path (the owner lane of the winning offer knows its host)
-        const int ol = win_lane >= 0 ? win_lane : (int)nT - 1;
+        const int ol = win_lane >= 0 ? win_lane : (int)new_lane;
         const unsigned w_host = (unsigned)wave_read_lane((int)t_host, ol);
         if (n_log < (unsigned)COOK_WAVE) {
           if (lane == n_log) {
@@ -2073,6 +2120,20 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         d2 = __popcll(__ballot(t_on && (pe_bits & 2u))) - __popcll(__ballot(t_on && (p0 & 2u)));
         d4 = __popcll(__ballot(t_on && (pe_bits & 4u))) - __popcll(__ballot(t_on && (p0 & 4u)));
       }
+      // ... and the RETIRED offers of the round: each fails on resources now (dead), so class 1 is not empty; what class each was in
+      // under S for THIS job nobody kept, so classes 2 / 4 are only certain when the snapshot count is zero (no retired offer can have
+      // been in the class) or larger than every offer that may have left it.  Anything in between needs a fresh snapshot: the round
+      // ends before this job (rare: unmatched jobs that are walked at all are, and only after a round's 65th offer).
+      if (n_retired != 0u) {
+        const int hi2 = (int)jl.f2 + d2, hi4 = (int)jl.f4 + d4;  // (upper bounds: the retired offers can only take away)
+        const bool amb2 = jl.f2 != 0 && hi2 > 0 && hi2 - (int)n_retired <= 0, amb4 = jl.f4 != 0 && hi4 > 0 && hi4 - (int)n_retired <= 0;
+        if (amb2 || amb4) {
+          stop = 5;
+          resolved = b;
+          break;
+        }
+        d1 += (int)n_retired;
+      }
       const unsigned bits = (((int)jl.f1 + d1) > 0 ? 1u : 0u) | (((int)jl.f2 + d2) > 0 ? 2u : 0u) | (((int)jl.f4 + d4) > 0 ? 4u : 0u);
       store_result(i, -1);  // (branch-free like the fast path's: this is the last statement before the paths of the iteration meet)
       store_fail(i, (unsigned char)(bits ? bits : 8u));
@@ -2140,7 +2201,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     ctl.rounds += 1;
     ctl.matched += matched;
     ctl.head_matched = head_matched;
-    ctl.touched_sum += nT;
+    ctl.touched_sum += nT + n_retired;
     ctl.visited_sum += n_list;
     ctl.segments += n_segments;
     ctl.t_setup += t_stage;
@@ -2149,11 +2210,11 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     ctl.trunc_lists += n_trunc;
     if (vb.round_log && ctl.rounds <= MV_ROUND_LOG_CAP) {
       RoundLog r;
-      r.head = head, r.wcur = ctl.wcur, r.resolved = resolved, r.n_list = n_list, r.touched = nT, r.stop = stop, r.matched = matched;
+      r.head = head, r.wcur = ctl.wcur, r.resolved = resolved, r.n_list = n_list, r.touched = nT + n_retired, r.stop = stop, r.matched = matched;
       r.setup_ticks = (unsigned)t_stage, r.seq_ticks = (unsigned)((cook_ticks() - tk0) - t_stage), r.segments = n_segments, r.pad0 = r.pad1 = 0;
       vb.round_log[ctl.rounds - 1] = r;
     }
-    if (stop == 2) ctl.stop_full += 1;
+    if (stop == 2 || stop == 5) ctl.stop_full += 1;
     if (stop == 3) ctl.stop_group += 1;
     if (stop == 0) ctl.stop_window += 1;
     // adapt the window: a multiple of what a round resolves (more = fewer rounds, less = fewer jobs evaluated twice)
@@ -2165,6 +2226,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     if (stop == 0 && nwin >= (unsigned)MV_WEVAL && n_list * 8u <= nwin) cap = ctl.wlong_cap > cap ? ctl.wlong_cap : cap;
     if (wn > cap) wn = cap;
     ctl.wcur = wn;
+    ctl.no_retire = nT + n_retired < (unsigned)MV_T * 3u / 4u ? 1u : 0u;
     *vb.ctl = ctl;
   }
 }
