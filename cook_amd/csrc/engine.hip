@@ -938,7 +938,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     JobCons* jcons = e->v_jcons.ensure(K);
     vb.jcons = jcons;
     // sized for a LONG window (MV_WLONG jobs, match_v2.hpp) and the eval grid's largest offer split: 128 / 160 bytes per (job, offer chunk)
-    vb.prec = e->v_prec.ensure((size_t)MV_WLONG * C * sizeof(ChunkRecT<true>));  // (a split window holds at most MV_WEVAL / split jobs)
+    vb.prec = e->v_prec.ensure((size_t)MV_WLONG * C * (sizeof(ChunkRecT<true>) > sizeof(ChunkRecT<false>) ? sizeof(ChunkRecT<true>) : sizeof(ChunkRecT<false>)));  // (a split window holds at most MV_WEVAL / split jobs)
     vb.colbits = e->v_colbits.ensure((size_t)(M ? M : 1u) * MV_JGL);
     vb.cand_fit = e->v_cand_fit.ensure((size_t)MV_WLONG * MV_LM_MAX);
     vb.cand_idx = e->v_cand_idx.ensure((size_t)MV_WLONG * MV_LM_MAX);
@@ -952,6 +952,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       const int sharing = std::max(1, g_engines_on_device[e->device & 63].load());
       vb.split_max = sharing == 1 ? (unsigned)MV_SPLIT_MAX : (sharing <= 4 ? 2u : 1u);  // (2 / 4 pools on the GPU: 69.4 -> 67.5, 72.9 -> 72.0 ms with 2)
       if (const char* ev = std::getenv("COOK_EVAL_SPLIT")) vb.split_max = (unsigned)std::max(1, std::min(MV_SPLIT_MAX, std::atoi(ev)));
+      if (ge) vb.split_max = 1u;  // (the good-enough bits of a chunk are laid out for whole wave batches: match_v2.hpp ChunkRecT::gm)
     }
     {
       MatchIn* din = e->v_in.ensure(1);

@@ -43,24 +43,27 @@
 #define COOK_MV_L 8
 #endif
 constexpr int MV_L = COOK_MV_L;            // candidate list length per job and chunk (-DCOOK_MV_L=n builds a variant for tuning runs)
-constexpr int MV_LGC = 12;                 // good-enough list length per job and chunk (launches made for good-enough-fitness < 1 only)
 // Two LIST SHAPES of the merged lists (what the walk sees), chosen by the launch's template flag GE:
 //   best fit (good-enough-fitness >= 1, the parity setting): 24 best-fit entries, no good-enough list.  A job's per-chunk top-L
 //     lists determine its global top-LM exactly as long as no chunk has contributed all L of its entries (that chunk may hide an
 //     (L+1)-th): the merge stops there and marks the list truncated.  Rounds per quarter-scale C4 pool against LM with nothing else
 //     in the way (emulator): 12 -> 90 (the round-3 layout, 384 slots), 24 -> 62, 32 -> 60, 48 -> 59.
 //   GE (good-enough-fitness < 1; config.clj:111 ships 0.8): there the "first offers above the threshold" list is the one that runs
-//     out — 16 entries of it, 12 best-fit entries for the jobs nothing clears the threshold for.
+//     out: every job of a window wants the SAME lowest-index offers above the threshold, so a round gets as far as that list reaches —
+//     64 entries of it (one per lane of the walk), 32 best-fit entries for the jobs nothing clears the threshold for (rounds per quarter-scale
+//     C4 pool at 0.8: 76 with round 3's lists of 16 / 12, 63 with 64 / 12, 41 with 64 / 24, 36 with 64 / 32).  The evaluation
+//     hands the offers above the threshold over as a BIT per offer and chunk (complete: the merged list is exact to its last entry;
+//     round 3's per-chunk lists of 12 cut the merged list at the first chunk with more than 12 such offers, usually the first).
 #ifndef COOK_MV_LM
 #define COOK_MV_LM 48
 #endif
 template <bool GE>
 struct VShape {
-  static constexpr int LM = GE ? 12 : COOK_MV_LM;  // merged best-fit entries per job
-  static constexpr int LG = GE ? 16 : 0;           // merged good-enough entries per job
-  static constexpr int LGS = GE ? 16 : 1;          // (array bound: never zero)
+  static constexpr int LM = GE ? 32 : COOK_MV_LM;  // merged best-fit entries per job
+  static constexpr int LG = GE ? 64 : 0;           // merged good-enough entries per job
+  static constexpr int LGS = GE ? 64 : 1;          // (array bound: never zero)
 };
-constexpr int MV_LM_MAX = COOK_MV_LM > 12 ? COOK_MV_LM : 12, MV_LG_MAX = 16;
+constexpr int MV_LM_MAX = COOK_MV_LM > 32 ? COOK_MV_LM : 32, MV_LG_MAX = 64;
 static_assert(VShape<false>::LM <= MV_LM_MAX && VShape<true>::LM <= MV_LM_MAX && VShape<true>::LG <= MV_LG_MAX, "buffer sizing");
 static_assert(MV_LM_MAX <= 64 && MV_LG_MAX <= 64, "the walk holds one merged-list entry per lane");
 #ifndef COOK_MV_OCW
@@ -161,13 +164,13 @@ struct RoundLog {  // one record per round (diagnostics; only written when V2Buf
 };
 constexpr unsigned MV_ROUND_LOG_CAP = 8192;
 
-// One offer chunk's candidates for one job, as ONE aligned record (128 bytes for best fit, 160 with the good-enough entries) that the
+// One offer chunk's candidates for one job, as ONE aligned record (128 bytes for best fit, 144 with the good-enough bits) that the
 // evaluating lane writes and the merging lane reads in 16-byte pieces.
 template <bool GE>
 struct alignas(16) ChunkRecT {
   double fit[MV_L];         // fitness desc, offer index asc
   int idx[MV_L];            // -1 = no entry
-  int ge[GE ? MV_LGC : 4];  // (GE) first offers (ascending index) whose fitness exceeds good-enough; 0x7FFFFFFF = none
+  unsigned long long gm[GE ? MV_EW : 2];  // (GE) bit i of word w: the fitness of offer chunk * MV_OCB + w * MV_OCW + i exceeds good-enough
   unsigned cnt[4];          // n | nge << 8, offers failing on resources / constraints / zero fitness
 };
 static_assert(sizeof(ChunkRecT<false>) % 16 == 0 && sizeof(ChunkRecT<true>) % 16 == 0, "ChunkRec is moved in 16-byte pieces");
@@ -418,7 +421,7 @@ template <bool GE>
 struct EvalLds {
   double fit[MV_EW][COOK_WAVE][MV_L];
   int idx[MV_EW][COOK_WAVE][MV_L];
-  int ge[MV_EW][COOK_WAVE][GE ? MV_LGC : 1];
+  unsigned long long ge[MV_EW][COOK_WAVE];  // (GE) the waves' good-enough bits
   unsigned cnt[MV_EW][COOK_WAVE][3];
   EvalWaveLds wave[MV_EW];
 };
@@ -435,8 +438,7 @@ struct EvalLane {
   double ge, ge_lo;
   double tf[MV_L];
   int ti[MV_L];
-  int gi[MV_LGC];  // (GE launches only)
-  int n_ge;
+  unsigned long long gm[MV_EW];  // (GE launches only) good-enough bits of the batches this lane's wave walked (one batch in a shared tile)
   double thr;  // pruning threshold: (1 - 2^-40) * current L-th best, valid once the list is full
   unsigned c1, c2, c4;
 };
@@ -541,11 +543,8 @@ static __device__ __forceinline__ void eval_lane_setup(EvalLane& E, const MatchI
     E.tf[q] = -1.0;
     E.ti[q] = -1;
   }
-  if (GE) {
 #pragma unroll
-    for (int q = 0; q < MV_LGC; ++q) E.gi[q] = 0x7FFFFFFF;
-  }
-  E.n_ge = 0;
+  for (int q = 0; q < MV_EW; ++q) E.gm[q] = 0ull;
   E.thr = -1.0;
   E.c1 = E.c2 = E.c4 = 0;
 }
@@ -567,7 +566,7 @@ static __device__ __forceinline__ unsigned eval_split(unsigned wcur, unsigned sp
 // then walk them in a wave-uniform loop
 template <bool THROUGH, bool GE = true>
 static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds& W, const MatchIn& in, const MatchState& st, const V2Buf& vb,
-                                                        unsigned v0, unsigned jg, unsigned nsub = MV_OCW) {
+                                                        unsigned v0, unsigned jg, unsigned nsub = MV_OCW, unsigned slot = 0) {  // slot: E.gm word of this batch
   const unsigned lane = lane_id();
   const unsigned v1 = (v0 + nsub < in.M) ? v0 + nsub : in.M;
   if (v0 + lane < v1) {
@@ -638,7 +637,7 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
       statm |= stat ? 1ull << vi : 0ull;
     }
   }
-  unsigned long long feasm = 0ull;
+  unsigned long long feasm = 0ull, gem = 0ull;  // gem: bit vi = the fitness on offer v0 + vi exceeds good-enough
   for (unsigned long long m = live; m != 0ull;) {  // wave-uniform
     const unsigned vi = (unsigned)__ffsll((unsigned long long)m) - 1u;
     m &= m - 1ull;
@@ -664,7 +663,7 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
       const double t1 = (a.rc + ac + j.c) * a.inv_dc, t2 = (a.rm + am + j.m) * a.inv_dm;
       const double ub = (t1 + t2) * 0.5;
       bool prune = E.ti[MV_L - 1] >= 0 && t1 >= 0.0 && t2 >= 0.0 && ub < E.thr;
-      if (GE && E.use_ge && E.n_ge < MV_LGC && !(ub < E.ge_lo)) prune = false;
+      if (GE && E.use_ge && !(ub < E.ge_lo)) prune = false;  // (it may clear the threshold: the exact value decides)
       if (!prune) {
         const double fit = fitness_of(a, ac, am, j.c, j.m);
         if (!(fit > 0.0)) {
@@ -674,12 +673,7 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
             topl_insert_ascending<MV_L>(E.tf, E.ti, fit, (int)v);
             if (E.ti[MV_L - 1] >= 0) E.thr = E.tf[MV_L - 1] * (1.0 - 0x1p-40);
           }
-          if (GE && E.use_ge && fit > E.ge && E.n_ge < MV_LGC) {
-#pragma unroll
-            for (int q = 0; q < MV_LGC; ++q)
-              if (q == E.n_ge) E.gi[q] = (int)v;
-            ++E.n_ge;
-          }
+          if (GE && E.use_ge && fit > E.ge) gem |= 1ull << vi;
         }
       }
     }
@@ -688,6 +682,11 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
   const unsigned n_res = (unsigned)__popcll(resm);
   E.c1 += valid ? (v1 > v0 ? v1 - v0 : 0u) - n_res : 0u;
   E.c2 += n_res - (unsigned)__popcll(feasm);
+  if (GE) {
+#pragma unroll
+    for (int q = 0; q < MV_EW; ++q)
+      if ((unsigned)q == slot) E.gm[q] = gem;
+  }
   wave_sync();  // every lane is done with the staged offers before the wave stages the next ones
 }
 
@@ -746,10 +745,7 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
     s_fit[w][lane][q] = E.tf[q];
     s_idx[w][lane][q] = E.ti[q];
   }
-  if constexpr (GE) {
-#pragma unroll
-    for (int q = 0; q < MV_LGC; ++q) s_ge[w][lane][q] = E.gi[q];
-  }
+  if constexpr (GE) s_ge[w][lane] = E.gm[0];
   s_cnt[w][lane][0] = E.c1;
   s_cnt[w][lane][1] = E.c2;
   s_cnt[w][lane][2] = E.c4;
@@ -767,7 +763,7 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
     R.idx[q] = -1;
   }
 #pragma unroll
-  for (int q = 0; q < (GE ? MV_LGC : 4); ++q) R.ge[q] = 0x7FFFFFFF;
+  for (int q = 0; q < (GE ? MV_EW : 2); ++q) R.gm[q] = 0ull;
   {
     bool more = true;
 #pragma unroll
@@ -799,34 +795,14 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
     }
   }
   int n_g = 0;
-  if constexpr (GE) if (use_ge) {
+  if constexpr (GE) {
+    if (use_ge) {
 #pragma unroll
-    for (int x = 0; x < MV_EW; ++x) p[x] = 0;
-    bool more = true;
-#pragma unroll
-    for (int q = 0; q < MV_LGC; ++q) {
-      int best = 0x7FFFFFFF, bx = -1;
-      if (more) {
-#pragma unroll
-        for (int x = 0; x < MV_EW; ++x) {
-          if (p[x] < MV_LGC) {
-            const int o = s_ge[x][lane][p[x]];
-            if (o < best) {
-              best = o;
-              bx = x;
-            }
-          }
-        }
+      for (int x = 0; x < MV_EW; ++x) {
+        R.gm[x] = s_ge[x][lane];
+        n_g += __popcll(R.gm[x]);
       }
-      if (bx < 0) {
-        more = false;
-      } else {
-        R.ge[q] = best;
-        ++n_g;
-#pragma unroll
-        for (int x = 0; x < MV_EW; ++x)
-          if (x == bx) ++p[x];
-      }
+      n_g = n_g < 255 ? n_g : 255;
     }
   }
   unsigned t1 = 0, t2 = 0, t4 = 0;
@@ -864,7 +840,7 @@ static __device__ __forceinline__ void eval_tile_wave(EvalWaveLds& W, const Matc
   for (int s = 0; s < MV_EW; ++s) {
     const unsigned v0 = ch * MV_OCB + (unsigned)s * MV_OCW;
     if (v0 >= in.M) break;
-    eval_scan_offers<THROUGH, GE>(E, W, in, st, vb, v0, jg);
+    eval_scan_offers<THROUGH, GE>(E, W, in, st, vb, v0, jg, MV_OCW, (unsigned)s);
   }
   if (!E.valid) return;
   if (ch == 0) eval_store_group<THROUGH>(E, vb, b);
@@ -877,10 +853,11 @@ static __device__ __forceinline__ void eval_tile_wave(EvalWaveLds& W, const Matc
     n_out += E.ti[q] >= 0 ? 1 : 0;
   }
 #pragma unroll
-  for (int q = 0; q < (GE ? MV_LGC : 4); ++q) {
-    R.ge[q] = GE ? E.gi[q < MV_LGC ? q : 0] : 0x7FFFFFFF;
-    n_g += (GE && E.gi[q < MV_LGC ? q : 0] != 0x7FFFFFFF) ? 1 : 0;
+  for (int q = 0; q < (GE ? MV_EW : 2); ++q) {
+    R.gm[q] = GE ? E.gm[q < MV_EW ? q : 0] : 0ull;
+    n_g += GE ? __popcll(R.gm[q]) : 0;
   }
+  n_g = n_g < 255 ? n_g : 255;
   R.cnt[0] = (unsigned)n_out | ((unsigned)n_g << 8);
   R.cnt[1] = E.c1;
   R.cnt[2] = E.c2;
@@ -929,42 +906,44 @@ __global__ void __launch_bounds__(COOK_WAVE* MV_EW) COOK_EVAL_OCCUPANCY match_ev
 
 // ---- merge: one wave per job ---------------------------------------------------------------------------------------------
 // lane = offer chunk (its per-chunk list as it is; further chunks of the same lane by the ascending insertion).  The merged best-fit
-// list is cut — and marked truncated — the moment a lane whose chunk list(s) may continue beyond what it holds pops its last entry;
-// the good-enough list (ascending offer index: chunks in order) is cut the same way behind a chunk whose own list was full.
+// list is cut — and marked truncated — the moment a lane whose chunk list(s) may continue beyond what it holds pops its last entry.
+// The good-enough list is the first LG set bits of the chunks' masks in offer order (a prefix sum of the chunks' bit counts gives
+// every lane the list positions of its offers): exact to its last entry, truncated only when more than LG offers clear the threshold.
 template <bool GE>
 static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf& vb, unsigned head, unsigned wcur, unsigned b,
                                                  unsigned split = 1) {  // split: eval_split(wcur) behind the launch path's eval grid
   if (b >= wcur || head + b >= in.K) return;
-  constexpr int LM = VShape<GE>::LM, LG = VShape<GE>::LG, LGS = VShape<GE>::LGS;
+  constexpr int LM = VShape<GE>::LM, LG = VShape<GE>::LG;
   const unsigned lane = lane_id();
   const bool use_ge = GE && in.good_enough < 1.0;
   double tf[MV_L];
   int ti[MV_L];
-  int gi[LGS];
 #pragma unroll
   for (int q = 0; q < MV_L; ++q) {
     tf[q] = -1.0;
     ti[q] = -1;
   }
-#pragma unroll
-  for (int q = 0; q < LGS; ++q) gi[q] = 0x7FFFFFFF;
-  int n_ge = 0;
-  bool ghide = false;  // the lane's good-enough entries may continue beyond what it holds
+  unsigned n_g_total = 0;  // (GE) offers above the threshold seen so far, over all chunks (wave-uniform)
   unsigned c1 = 0, c2 = 0, c4 = 0;
   int n_seen = 0;     // entries of all the lane's chunks
   bool hide = false;  // the lane's best-fit list may end before its chunks' feasible offers do
   const unsigned cv = vb.C * split;  // chunk lists per job (virtual chunks, eval_split)
   const ChunkRecT<GE>* const prec = reinterpret_cast<const ChunkRecT<GE>*>(vb.prec);
-  for (unsigned ch = lane; ch < cv; ch += COOK_WAVE) {
-    const ChunkRecT<GE> R = prec[(size_t)b * cv + ch];  // 16-byte loads, all in flight together
-    const unsigned info = R.cnt[0];
-    c1 += R.cnt[1];
-    c2 += R.cnt[2];
-    c4 += R.cnt[3];
-    const int n = (int)(info & 0xFFu), ng = (int)((info >> 8) & 0xFFu);
+  for (unsigned ch0 = 0; ch0 < cv; ch0 += COOK_WAVE) {  // (wave-uniform: the good-enough part scans over the lanes)
+    const unsigned ch = ch0 + lane;
+    const bool have = ch < cv;
+    ChunkRecT<GE> R;
+    if (have) R = prec[(size_t)b * cv + ch];  // 16-byte loads, all in flight together
+    const unsigned info = have ? R.cnt[0] : 0u;
+    if (have) {
+      c1 += R.cnt[1];
+      c2 += R.cnt[2];
+      c4 += R.cnt[3];
+    }
+    const int n = (int)(info & 0xFFu);
     n_seen += n;
     hide = hide || n == MV_L || n_seen > MV_L;
-    if (ch < (unsigned)COOK_WAVE) {  // the lane's first chunk (its only one up to 64 chunks = 8 192 offers): the sorted list as it is
+    if (ch0 == 0u) {  // the lane's first chunk (its only one up to 64 chunks = 8 192 offers): the sorted list as it is
 #pragma unroll
       for (int q = 0; q < MV_L; ++q)
         if (q < n) tf[q] = R.fit[q], ti[q] = R.idx[q];
@@ -978,17 +957,25 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
       }
     }
     if constexpr (GE) {
-      if (use_ge) {
-        ghide = ghide || ng == MV_LGC || n_ge + ng > LG;  // (entries that do not fit the lane's list are dropped: it hides them)
+      if (use_ge && n_g_total < (unsigned)LG) {  // (wave-uniform) chunks ascend with the lane, offers with the word and the bit
+        const bool any_bits = have && ((info >> 8) & 0xFFu) != 0u;
+        unsigned cnt = 0;
 #pragma unroll
-        for (int q = 0; q < MV_LGC; ++q) {  // chunks ascend with ch, entries ascend inside a chunk
-          const bool take = q < ng && n_ge < LG;
-          const int o = R.ge[q];
-#pragma unroll
-          for (int x = 0; x < LG; ++x)
-            if (take && x == n_ge) gi[x] = o;
-          n_ge += take ? 1 : 0;
+        for (int x = 0; x < MV_EW; ++x) cnt += any_bits ? (unsigned)__popcll(R.gm[x]) : 0u;
+        unsigned incl = cnt;  // inclusive prefix sum over the lanes
+        for (unsigned d = 1; d < (unsigned)COOK_WAVE; d <<= 1) {
+          const unsigned o = (unsigned)__shfl_up((int)incl, d, COOK_WAVE);
+          if (lane >= d) incl += o;
         }
+        unsigned pos = n_g_total + incl - cnt;  // list position of this lane's first offer
+        if (cnt != 0u && pos < (unsigned)LG) {
+#pragma unroll
+          for (int x = 0; x < MV_EW; ++x) {
+            for (unsigned long long m = R.gm[x]; m != 0ull && pos < (unsigned)LG; m &= m - 1ull, ++pos)
+              vb.ge_idx[(size_t)b * LG + pos] = (int)(ch * (unsigned)MV_OCB + (unsigned)x * (unsigned)MV_OCW + (unsigned)__ffsll((unsigned long long)m) - 1u);
+          }
+        }
+        n_g_total += (unsigned)__shfl((int)incl, COOK_WAVE - 1, COOK_WAVE);
       }
     }
   }
@@ -1033,34 +1020,12 @@ static __device__ __forceinline__ void merge_job(const MatchIn& in, const V2Buf&
     }
   }
   if (!trunc) trunc = __any(ti[0] >= 0);  // LM entries emitted and some lane still holds more
-  int n_g = 0;
-  bool gtrunc = false;
-  if constexpr (GE) {
-    if (use_ge) {
-      for (int round = 0; round < LG; ++round) {
-        const unsigned gk = gi[0] == 0x7FFFFFFF ? 0u : 0x7FFFFFFFu - (unsigned)gi[0];
-        const unsigned mg = wave_max_u32(gk);
-        if (mg == 0u) break;  // wave-uniform
-        const int best = (int)(0x7FFFFFFFu - mg);
-        if (lane == 0) vb.ge_idx[(size_t)b * LG + round] = best;
-        ++n_g;
-        bool emptied = false;
-        if (gi[0] == best) {
-#pragma unroll
-          for (int q = 0; q < LG - 1; ++q) gi[q] = gi[q + 1];
-          gi[LG - 1] = 0x7FFFFFFF;
-          emptied = gi[0] == 0x7FFFFFFF && ghide;
-        }
-        if (__any(emptied)) {  // offers above the threshold may follow in this lane's chunk, below every later chunk's: stop here
-          gtrunc = true;
-          break;
-        }
-      }
-      if (!gtrunc) gtrunc = __any(gi[0] != 0x7FFFFFFF);
-    }
-  }
+  const unsigned n_g = GE ? (n_g_total < (unsigned)LG ? n_g_total : (unsigned)LG) : 0u;
+  // (the chunks' bit counts saturate at 255 only in the record's count byte, never in the masks; once LG offers are listed the scan
+  //  above stops, so "more than LG" is all n_g_total can say beyond that point)
+  const bool gtrunc = GE && n_g_total >= (unsigned)LG && LG > 0;
   if (lane == 0) {
-    vb.cinfo[(size_t)b * 4 + 0] = (unsigned)n_out | ((unsigned)n_g << 8) | (trunc ? 1u << 16 : 0u) | (gtrunc ? 1u << 17 : 0u);
+    vb.cinfo[(size_t)b * 4 + 0] = (unsigned)n_out | (n_g << 8) | (trunc ? 1u << 16 : 0u) | (gtrunc ? 1u << 17 : 0u);
     vb.cinfo[(size_t)b * 4 + 1] = c1;
     vb.cinfo[(size_t)b * 4 + 2] = c2;
     vb.cinfo[(size_t)b * 4 + 3] = c4;
@@ -1847,7 +1812,6 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         // --- arg-max path: first list entry that is untouched, or touched and still a candidate -------------------------------
         // (a touched offer that is still feasible only gained fitness, so it dominates every untouched offer behind it; a
         //  zero-fitness verdict cannot appear on an offer that was feasible under S)
-        const bool e_valid = cur.owner != 0xFEu;
         const bool e_untouched = cur.owner == 0xFFu;
         const bool e_live = cur.owner < (unsigned)MV_T && ((cand_mask >> (cur.owner & 63u)) & 1ull);
         const unsigned long long settle_mask = __ballot(e_untouched || e_live), untouched_mask = __ballot(e_untouched);
