@@ -535,8 +535,7 @@ def main():
             n_b = 3
             for it in range(n_b):
                 c0 = time.perf_counter()
-                for p in my_pools:
-                    engines[p].cycle_update(*deltas[p])
+                cluster.update(deltas)  # (the pools' updates side by side, one host thread and stream each)
                 torch.cuda.synchronize()
                 c1 = time.perf_counter()
                 cluster.cycle(K)

@@ -151,6 +151,7 @@ struct cook_engine {
   DArr<unsigned> m_summary;
   DArr<OfferA> v_oa;
   DArr<OfferB> v_ob;
+  DArr<OfferW> v_ow;
   DArr<JobRec> v_jr;
   DArr<JobCons> v_jcons;
   DArr<unsigned long long> m_alive, m_jmin;
@@ -934,6 +935,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     JobRec* jr = e->v_jr.ensure(K);
     vb.oa = oa;
     vb.ob = ob;
+    vb.ow = e->v_ow.ensure(std::max(1u, M));
     vb.jr = jr;
     JobCons* jcons = e->v_jcons.ensure(K);
     vb.jcons = jcons;
@@ -961,7 +963,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       COOK_HIP(hipMemcpyAsync(din, hin, sizeof(MatchIn), hipMemcpyHostToDevice, e->stream));
       vb.in_dev = din;
     }
-    if (M) KL("match_pack_offers", match_pack_offers, div_up(M, 256), 256, in, oa, ob);
+    if (M) KL("match_pack_offers", match_pack_offers, div_up(M, 256), 256, in, oa, ob, vb.ow);
     KL("match_pack_jobs", match_pack_jobs, div_up(K, 256), 256, in, jr, jcons);
     COOK_HIP(hipMemsetAsync(e->m_jmin.ptr(), 0x7F, 16, e->stream));  // > every finite double's bit pattern
     COOK_HIP(hipMemsetAsync(e->m_jmin.ptr() + 2, 0, 16, e->stream));   // [2]: a job with a negative / non-finite request was seen
@@ -969,7 +971,9 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     if (M) KL("match_init_alive", match_init_alive, div_up(M, 256), 256, (const OfferA*)oa, M, st.jmin, st.alive);
     WinCtl c0;
     std::memset(&c0, 0, sizeof(c0));
-    c0.wcur = std::min<unsigned>(MV_WEVAL, 64u);
+    // the first window: a call of few jobs (config.clj:113 ships fenzo-max-jobs-considered 1000) in one go — a round that stops early costs it
+    // little —, a long queue with a short one (the window then follows what the rounds resolve)
+    c0.wcur = K <= (unsigned)MV_WEVAL ? std::max(K, 1u) : std::min<unsigned>(MV_WEVAL, 128u);
     {
       // window growth: with several pools on one GPU the eval phase is compute-bound (evaluate few jobs twice); a pool
       // that has the GPU to itself is bound by the chain of rounds (prefer fewer, larger rounds)
@@ -1294,7 +1298,7 @@ void cook_engine_destroy(cook_engine* e) {
                   &e->j_index.b, &e->o_host.b, &e->o_gpu_model.b, &e->o_disk_type.b, &e->o_attr.b, &e->o_location.b, &e->g_attr_key.b,
                   &e->g_run_off.b, &e->g_run_host.b, &e->g_run_attr.b, &e->reserved_bits.b, &e->m_fail.b, &e->j_reserved_host.b,
                   &e->o_max_tasks.b, &e->o_num_tasks.b, &e->o_run_count.b, &e->g_min.b, &e->m_acount.b, &e->m_group_last.b,
-                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b, &e->v_oa.b, &e->v_ob.b, &e->v_jr.b, &e->v_prec.b, &e->v_cand_fit.b, &e->v_cand_idx.b, &e->v_ge_idx.b, &e->v_cinfo.b, &e->v_colbits.b, &e->w_ctl.b, &e->v_in.b};
+                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b, &e->v_oa.b, &e->v_ob.b, &e->v_ow.b, &e->v_jr.b, &e->v_prec.b, &e->v_cand_fit.b, &e->v_cand_idx.b, &e->v_ge_idx.b, &e->v_cinfo.b, &e->v_colbits.b, &e->w_ctl.b, &e->v_in.b};
   for (DBuf* b : bufs) b->release();
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i)

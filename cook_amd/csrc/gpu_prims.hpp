@@ -73,6 +73,11 @@ static __device__ __forceinline__ unsigned long long cook_ticks() { return wall_
 #define WAIT_LDS_BUT_LAST() __builtin_amdgcn_s_waitcnt(0xC17F)  // lgkmcnt(1): LDS operations retire in order, the newest may still fly
 #define WAIT_LDS_BUT_2() __builtin_amdgcn_s_waitcnt(0xC27F)     // lgkmcnt(2)
 #define WAIT_ALL_MEM() __builtin_amdgcn_s_waitcnt(0x0070)     // vmcnt(0) lgkmcnt(0)
+// Fire-and-forget load of one word: pulls the word's cache line towards the CU (L2 of its XCD, L1) for a LATER reader and waits for
+// nothing.  The compiler does not track a load issued by inline asm, so the destination is a register the caller keeps for nothing else
+// (`sink`, read-write in every use: one live range, one physical register) until PREFETCH_DRAIN has waited for the loads.
+#define PREFETCH_WORD(sink, ptr) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(ptr) : "memory")
+#define PREFETCH_DRAIN(sink) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory")
 static __device__ __forceinline__ unsigned wave_uniform_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 static __device__ __forceinline__ unsigned long long wave_uniform_u64(unsigned long long v) {
   return ((unsigned long long)wave_uniform_u32((unsigned)(v >> 32)) << 32) | (unsigned long long)wave_uniform_u32((unsigned)v);

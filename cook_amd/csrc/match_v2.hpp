@@ -116,6 +116,18 @@ struct OfferB {  // what the cheap constraint checks need; 32 B
   uint32_t flags, pad;            // bit0 kubernetes VM, bit1 host is in the rebalancer's reserved set, bit2 the host's "gpus" map has
                                   // several entries (gpu_model = one of them; the constraint reads the table)
 };
+// What a lane of the placement walk needs when it becomes the owner of an offer, as ONE cache line: the offer's record and its state as
+// of the last round's end (the resolve kernel keeps the state fields current next to MatchState's arrays, which the evaluation reads).
+// Opening an offer was five cache lines (OfferA, OfferB, three state arrays) and ~1 000 cycles of the one walking wave per opened offer.
+struct alignas(128) OfferW {
+  double oc, om, rc, rm, inv_dc, inv_dm;  // = OfferA
+  uint32_t host, k8s;                     // OfferB::host, flags bit 0
+  int32_t run_count, task_slack;
+  double ac, am;                          // assigned by the rounds so far
+  int32_t acount;
+  uint32_t pad[11];
+};
+static_assert(sizeof(OfferW) == 128, "one cache line per offer");
 struct JobRec {  // one considerable job in match order; 40 B
   double c, m, g;
   uint32_t gpu_model;
@@ -189,6 +201,7 @@ struct V2Buf {
 #endif
   const OfferA* oa;
   const OfferB* ob;
+  OfferW* ow;          // [M] the walk's one-line records (state fields written by the resolve kernel)
   const JobRec* jr;
   const JobCons* jcons;  // [K] fast constraint slots of the jobs flagged JF_FASTC
   void* prec;          // [wlong][C]     chunk lists: one ChunkRecT<GE> per (job of the window, offer chunk)
@@ -206,7 +219,7 @@ struct V2Buf {
 };
 
 // ---- once per match call: pack offers and jobs -----------------------------------------------------------------------
-__global__ void __launch_bounds__(256) match_pack_offers(MatchIn in, OfferA* __restrict__ oa, OfferB* __restrict__ ob) {
+__global__ void __launch_bounds__(256) match_pack_offers(MatchIn in, OfferA* __restrict__ oa, OfferB* __restrict__ ob, OfferW* __restrict__ ow) {
   const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= in.M) return;
   OfferA a;
@@ -239,6 +252,13 @@ __global__ void __launch_bounds__(256) match_pack_offers(MatchIn in, OfferA* __r
   b.flags = (k8s ? 1u : 0u) | (rsv ? 2u : 0u) | (n_keys > 1u ? 4u : 0u);
   b.pad = 0;
   ob[v] = b;
+  OfferW w;
+  w.oc = a.oc, w.om = a.om, w.rc = a.rc, w.rm = a.rm, w.inv_dc = a.inv_dc, w.inv_dm = a.inv_dm;
+  w.host = b.host, w.k8s = b.flags & 1u, w.run_count = b.run_count, w.task_slack = b.task_slack;
+  w.ac = 0.0, w.am = 0.0, w.acount = 0;  // (nothing assigned yet: a match call starts from the offers as staged)
+#pragma unroll
+  for (int q = 0; q < 11; ++q) w.pad[q] = 0u;
+  ow[v] = w;
 }
 
 __global__ void __launch_bounds__(256) match_pack_jobs(MatchIn in, JobRec* __restrict__ jr, JobCons* __restrict__ jcons) {
@@ -1067,6 +1087,11 @@ constexpr int MV_GMAX = 64;  // group members per segment whose hosts-to-avoid a
 // job of the call any more, so no later job can go there — is given to the next offer (the dead offer's state is written back at once,
 // its byte in the owner table says "dead": list entries that name it are skipped like touched offers that do not fit).  On the
 // benchmark's pools 40-50 of the 64 lanes are dead when the 65th offer is asked for (best fit fills offers to the brim).
+// List entries per job whose OfferW line and colbits word the STAGING of a segment touches, so that the walk's open_lane finds them in
+// the L2 of the XCD the workgroup runs on (they were last written / read by evaluation blocks all over the chip): 70 % of the offers a
+// walk opens are among the first four entries of the job's list, 80 % among the first eight (emulator, C4 pool).  Costs the walking
+// wave nothing: the other waves of the workgroup issue the loads while they stage.
+constexpr int MV_PF = 8;
 constexpr unsigned MV_RETIRE_CAP = 192;
 constexpr unsigned MV_TMAX = (unsigned)MV_T + MV_RETIRE_CAP;  // offers one round can touch at most
 constexpr unsigned OWNER_UNTOUCHED = 0xFFu, OWNER_NONE = 0xFEu, OWNER_DEAD = 0xFDu;  // values of the owner table / of JobRegs::owner beside lane numbers
@@ -1097,6 +1122,10 @@ struct ResolveFixed {
   double x0s[MV_T][3];
   int x0p[MV_T];
   unsigned char x0set[MV_T];
+  // the state of a touched offer as the round began, by owner lane (the failure summary of an unmatched job swaps each touched offer's
+  // verdict under the snapshot for its current one)
+  double ac0[MV_T], am0[MV_T];
+  int acount0[MV_T];
 };
 constexpr unsigned MV_RLDS_BYTES = 160u * 1024u - 2048u;  // the workgroup's static LDS array (the CU has 160 KB)
 template <bool GE>
@@ -1295,16 +1324,30 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     __syncthreads();
     return n;
   };
+  // (MV_PF) the waves that do not walk touch what opening the first entries of the segment's lists would read — behind the staging's
+  // last barrier, i.e. while wave 0 already walks
+  auto prefetch_segment = [&](unsigned n) {
+    unsigned pf_sink = 0u;
+    for (unsigned e = tid - COOK_WAVE; e < n * (unsigned)MV_PF; e += NT - COOK_WAVE) {
+      const unsigned x = e / (unsigned)MV_PF, q = e % (unsigned)MV_PF;
+      const int o = s_eoff[(size_t)x * LM + q];
+      if (o < 0) continue;
+      PREFETCH_WORD(pf_sink, &vb.ow[(unsigned)o]);
+      PREFETCH_WORD(pf_sink, &vb.colbits[(size_t)(unsigned)o * MV_JGL + ((unsigned)s_job[x].b >> 6)]);
+    }
+    PREFETCH_DRAIN(pf_sink);
+  };
   unsigned seg_lo = 0;
   unsigned n_eff = stage_segment(0);  // walk positions of the segment
   unsigned n_segments = 1;
   if (tid >= COOK_WAVE) {  // the other waves: asleep at the barrier until wave 0 asks for the next segment or ends the round
     for (;;) {
+      prefetch_segment(n_eff);
       EMU_SITE("resolve: helper waiting");
       __syncthreads();
       if (L.cmd == 0) break;
       seg_lo = wave_uniform_u32(L.seg_lo);
-      (void)stage_segment(seg_lo);
+      n_eff = stage_segment(seg_lo);
     }
     return;
   }
@@ -1427,30 +1470,30 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   // touched before, which never opens a lane).
   auto open_lane = [&](unsigned nl, int off, double jc, double jm) {
     const unsigned v = wave_uniform_u32((unsigned)off);
-    const OfferA a = vb.oa[v];
-    const OfferB o = vb.ob[v];
-    const double ac0 = st.ac[v], am0 = st.am[v];
-    const int acount0 = st.acount[v];
+    const OfferW w = vb.ow[v];  // one cache line (pulled into this XCD's L2 when the segment was staged)
     const unsigned long long colw = vb.colbits[(size_t)v * MV_JGL + cur_g], colwn = vb.colbits[(size_t)v * MV_JGL + col_next];
     const bool me = lane == nl;
     t_v = me ? off : t_v;
-    t_oc = me ? a.oc : t_oc;
-    t_om = me ? a.om : t_om;
-    t_rc = me ? a.rc : t_rc;
-    t_rm = me ? a.rm : t_rm;
-    t_invc = me ? a.inv_dc : t_invc;
-    t_invm = me ? a.inv_dm : t_invm;
-    t_k8s = me ? (o.flags & 1u) : t_k8s;
-    t_host = me ? o.host : t_host;
-    t_run = me ? o.run_count : t_run;
-    t_slack = me ? o.task_slack : t_slack;
-    t_ac = me ? ac0 + jc : t_ac;
-    t_am = me ? am0 + jm : t_am;
-    t_acount = me ? acount0 + 1 : t_acount;
+    t_oc = me ? w.oc : t_oc;
+    t_om = me ? w.om : t_om;
+    t_rc = me ? w.rc : t_rc;
+    t_rm = me ? w.rm : t_rm;
+    t_invc = me ? w.inv_dc : t_invc;
+    t_invm = me ? w.inv_dm : t_invm;
+    t_k8s = me ? w.k8s : t_k8s;
+    t_host = me ? w.host : t_host;
+    t_run = me ? w.run_count : t_run;
+    t_slack = me ? w.task_slack : t_slack;
+    t_ac = me ? w.ac + jc : t_ac;
+    t_am = me ? w.am + jm : t_am;
+    t_acount = me ? w.acount + 1 : t_acount;
     t_basec = t_rc + t_ac;
     t_basem = t_rm + t_am;
     t_col = me ? colw : t_col;
     t_coln = me ? colwn : t_coln;
+    L.ac0[nl] = w.ac;  // (every lane, same value)
+    L.am0[nl] = w.am;
+    L.acount0[nl] = w.acount;
     unsigned char* const p = me ? &s_owner[v] : &L.sinkb[lane];
     *p = (unsigned char)nl;
   };
@@ -1468,6 +1511,9 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       st.ac[t_v] = t_ac;
       st.am[t_v] = t_am;
       st.acount[t_v] = t_acount;
+      vb.ow[t_v].ac = t_ac;
+      vb.ow[t_v].am = t_am;
+      vb.ow[t_v].acount = t_acount;
       atomicAnd(&st.alive[(unsigned)t_v >> 6], ~(1ull << ((unsigned)t_v & 63u)));
       s_owner[(unsigned)t_v] = (unsigned char)OWNER_DEAD;
     }
@@ -2045,9 +2091,8 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         }
         unsigned p0 = 0u;  // snapshot verdict: state at round start, group placements of this round ignored via the cutoff
         if (t_on) {
-          // the offer's state as the round began: still what global memory holds (the touched lanes write back when the round ends)
-          const double ac0 = st.ac[t_v], am0 = st.am[t_v];
-          const int acount0 = st.acount[t_v];
+          const double ac0 = L.ac0[lane], am0 = L.am0[lane];  // the offer's state as the round began
+          const int acount0 = L.acount0[lane];
           bool x0_fail = false;
           if (cinfo_u & JL_XRES) {  // ports / named scalars as the round began: saved if a job of this round moved them, else current
             const MatchIn& in = *vb.in_dev;
@@ -2157,6 +2202,9 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     st.ac[t_v] = t_ac;
     st.am[t_v] = t_am;
     st.acount[t_v] = t_acount;
+    vb.ow[t_v].ac = t_ac;
+    vb.ow[t_v].am = t_am;
+    vb.ow[t_v].acount = t_acount;
     if (t_ac + st.jmin[0] > t_oc || t_am + st.jmin[1] > t_om)  // full for every job of this call, for good
       atomicAnd(&st.alive[(unsigned)t_v >> 6], ~(1ull << ((unsigned)t_v & 63u)));
   }

@@ -189,6 +189,11 @@ class ShardedCluster:
                             group_usage=A.usage(*group_usage[g].tolist()) if gq is not None else None,
                             pool_usage=A.usage(*pool_usage))
 
+    def update(self, deltas: Dict[int, tuple]):
+        """cook_cycle_update for the local pools, every pool on its own thread and stream (the reference applies a pool's changes in that
+        pool's own handler thread, scheduler.clj:2425-2435): deltas[pool] = the arguments of Engine.cycle_update."""
+        list(self._tp.map(lambda p: self.engines[p].cycle_update(*deltas[p]), [p for p in self.pools if p in deltas]))
+
     def cycle(self, num_considerable: int):
         t0 = time.perf_counter()
         usages = dict(zip(self.pools, self._tp.map(lambda p: self.engines[p].rank_pool_usage().as_tuple(), self.pools)))

@@ -63,6 +63,8 @@ static inline unsigned long long cook_ticks() { return 0ull; }
 #define WAIT_LDS_BUT_LAST() ((void)0)
 #define WAIT_LDS_BUT_2() ((void)0)
 #define WAIT_ALL_MEM() ((void)0)
+#define PREFETCH_WORD(sink, ptr) ((void)(sink), (void)(ptr))  // (a cache hint: nothing to emulate)
+#define PREFETCH_DRAIN(sink) ((void)(sink))
 static inline unsigned wave_uniform_u32(unsigned v) { return v; }
 static inline unsigned long long wave_uniform_u64(unsigned long long v) { return v; }
 static inline double wave_uniform_f64(double v) { return v; }
