@@ -1276,7 +1276,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       // as the round begins and the group's last placed job (for the chain link) — so that it never has to go to HBM for them
       unsigned gslot = JL_GSLOT_NONE;
       const unsigned gt = (j.flags >> 8) & 3u;
-      if (j.group != 0xFFFFFFFFu && gt <= 1u && !(good_enough < 1.0) && vb.in_dev->host_dup == 0u && !(j.flags & JF_XRES)) {
+      if (j.group != 0xFFFFFFFFu && gt <= 1u && (GE || !(good_enough < 1.0)) && vb.in_dev->host_dup == 0u && !(j.flags & JF_XRES)) {
         const unsigned* row = vb.jfh + (size_t)b * (MV_FH + 2);  // gathered by the evaluation of this round
         const int nfh = (int)row[MV_FH];
         if (gt == 0u || (nfh >= 0 && nfh <= MV_FH)) {
@@ -1642,7 +1642,10 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       // (negative terms, zero, below fp32's normal range) takes +inf, which sends the job to the general path
       const bool sane = a1 >= 0.0 && a2 >= 0.0 && fa > 0x1p-100;
       const float kf = cand ? (sane ? (float)fa : __int_as_float(0x7F800000)) : 0.0f;
-      const float mx = wave_max_f32(kf);
+      // (best-fit launches reduce here; launches with the good-enough rule only once that rule has left the job undecided — most of
+      //  their jobs go to an offer above the threshold, and a reduction they never look at is ~25 instructions of the walking wave)
+      float mx = 0.0f;
+      if constexpr (!GEF) mx = wave_max_f32(kf);
       // first untouched entry of the list: the best untouched offer under S (a touched entry that is still feasible and sits in
       // front of it only gained fitness: it beats this one in the comparison below, so "first untouched" is all the list has to give)
       const unsigned long long untouched_mask = __ballot(cur.owner == 0xFFu);
@@ -1667,7 +1670,10 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
           if (__any(maybe)) return false;
           const unsigned tkey = above ? 0x7FFFFFFFu - (unsigned)t_v : 0u;
           const unsigned long long above_mask = __ballot(above);
-          const unsigned tmx = above_mask != 0ull ? wave_max_u32(tkey) : 0u;
+          // (one touched offer above the threshold — the common case — needs no reduction)
+          const unsigned tmx = above_mask == 0ull ? 0u
+                               : ((above_mask & (above_mask - 1ull)) == 0ull ? (unsigned)wave_read_lane((int)tkey, __ffsll((unsigned long long)above_mask) - 1)
+                                                                             : wave_max_u32(tkey));
           const int tg = tmx != 0u ? 0x7FFFFFFF - (int)tmx : 0x7FFFFFFF;  // lowest offer index among the touched offers above the threshold
           const int ng = (int)((cinfo_u >> 8) & 0xFFu);
           const unsigned long long gun = __ballot((int)lane < ng && cur.g_owner == 0xFFu);
@@ -1688,6 +1694,9 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
             ge_done = true;
           }  // else: nobody above the threshold — best fit among what is below it
         }
+      }
+      if constexpr (GEF) {
+        if (!ge_done) mx = wave_max_f32(kf);
       }
       if (ge_done) {
         // (decided above)

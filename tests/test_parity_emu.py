@@ -171,11 +171,22 @@ def test_match_many_distinct_candidates_and_touched_set_limits(make_engine):
         e.match(jobs, offers)
         st_ = e.match_stats()
         assert st_["segments"] >= st_["rounds"] > 0, st_
+        # ... and touches more offers per round than the walk has lanes: lanes of dead offers (full to the smallest job) are given away
+        assert st_["touched"] > 64 * st_["rounds"] or st_["rounds"] > 2, st_
     jobs, offers = P.pinned_jobs_case(8, 300, 400, 0)
     P.match_parity(make_engine, jobs, offers, None, p)
     with make_engine(p) as e:
         e.match(jobs, offers)
         assert e.match_stats()["stop_full"] > 0
+
+
+def test_match_refuses_pools_beyond_the_offer_table(make_engine):
+    # the walk's owner table is one LDS byte per offer of the pool: a pool of 200 000 offers is refused, loudly, before any kernel runs
+    from cook_amd.engine import CookError
+    pool = synth.make_pool(seed=5, n_pending=4, n_running=0, n_users=2, n_offers=200_000)
+    with make_engine(A.default_params()) as e:
+        with pytest.raises(CookError, match="too many offers"):
+            e.match(pool.pending_jobs, pool.offers)
 
 
 def test_cycle_parity(make_engine):

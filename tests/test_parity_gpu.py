@@ -163,6 +163,8 @@ def test_match_slot_table_and_touched_set_limits(make_engine):
         e.match(jobs, offers)
         st_ = e.match_stats()
         assert st_["segments"] >= st_["rounds"] > 0, st_
+        # ... and touches more offers per round than the walk has lanes: lanes of dead offers (full to the smallest job) are given away
+        assert st_["touched"] > 64 * st_["rounds"] or st_["rounds"] > 2, st_
     jobs, offers = P.pinned_jobs_case(8, 3000, 4000, 0)
     P.match_parity(make_engine, jobs, offers, None, p)
     with make_engine(p) as e:
