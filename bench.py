@@ -460,7 +460,8 @@ def main():
         m08 = sum(int((f08[p][1] >= 0).sum()) for p in my_pools)
         extra["good_enough=0.8"] = {"what": f"the same cluster, K = {K} per pool, good-enough-fitness 0.8 (the reference's default, config.clj:111; "
                                             "the winner among equally good-enough hosts is oracle-defined: first in offer order)",
-                                    "cycles": len(ts), "p50_cycle_ms": pct(ts, 0.5) * 1e3, "matched": m08, "parity_checked": False}
+                                    "cycles": len(ts), "p50_cycle_ms": pct(ts, 0.5) * 1e3, "matched": m08, "parity_checked": False,
+                                    "placement_stats_pool0": engines[my_pools[0]].match_stats()}
         if not args.no_check:  # the timed 0.8 cycle of rank 0's first pool against the single-thread oracle, every assignment
             from oracle import checks
             pc = my_pools[0]

@@ -1,13 +1,11 @@
 // gpu_prims.hpp — the gfx950 (CDNA4, wave64) forms of the primitives the kernels are written against: wave rendezvous, agent- and
-// workgroup-scope accesses, the cross-workgroup hand-off, DPP reductions and row shifts, scheduling hints, and the launch shapes of
+// workgroup-scope accesses, DPP reductions and row shifts, scheduling hints, and the launch shapes of
 // the shipped build.  Included through platform.hpp, which is the only place that knows about the emulated test build.
 #pragma once
 
 #define EMU_SITE(s) ((void)0)  // deadlock diagnostics of the SIMT emulator (tests/simt_emu); nothing on the GPU
 #define COOK_SHAPE(gpu, emu) (gpu)  // a launch shape: the shipped value (the emulated build may substitute a small one)
 #define COOK_BUILD_NAME "hip gfx950"
-constexpr bool COOK_COOP_GRIDS = true;  // co-resident grids exist (the emulator runs one workgroup at a time unless told otherwise)
-#define SPIN_PAUSE_LONG() __builtin_amdgcn_s_sleep(4)
 // walk statistics are an emulated-build facility (design studies)
 #define WALK_STAT(i, v) ((void)0)
 #define WALK_STAT_PREV_LANE(i, win_lane, win, nT) ((void)0)
@@ -27,34 +25,6 @@ template <class T>
 static __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T>
 static __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// ---- cross-workgroup hand-off inside one launch (the persistent placement kernel, match_world.hpp) ---------------------------------
-// The tested forms of MI355X_MICROARCH.md: producer = plain stores -> agent_release() -> relaxed agent-scope flag store;
-// consumer = relaxed poll of the flag -> ONE agent_acquire() -> plain loads.  The inline-asm wait is deliberate: ROCm 7.2 drops the
-// s_waitcnt after buffer_wbl2 when it can prove the wave's vmcnt scoreboard empty, and the flag then overtakes the write-back.
-static __device__ __forceinline__ void agent_release() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-static __device__ __forceinline__ void agent_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-// after write-through (sc1) stores: once the wave's store counter drains they are in memory — no L2 write-back fence needed
-static __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// LDS words that waves of one workgroup exchange WITHOUT a barrier (the poller's mirror of the phase words)
-template <class T>
-static __device__ __forceinline__ T ld_wg(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-template <class T>
-static __device__ __forceinline__ void st_wg(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#define SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
-#define SPIN_PAUSE_SHORT() __builtin_amdgcn_s_sleep(1)
-#define SPIN_PAUSE_FAR() __builtin_amdgcn_s_sleep(6)  // between polls of a word in global memory (another workgroup writes it)
-// LDS hand-off between waves of one workgroup without a workgroup barrier (the evaluator teams' barrier)
-// (fences of the LDS address space only: a plain workgroup fence also waits for the wave's outstanding GLOBAL stores — a result store to
-// HBM takes over a thousand cycles to be acknowledged, and the placement walk has one in flight at every hand-off)
-static __device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
-static __device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
-#define COOK_BLOCK_LDS(name, bytes) __shared__ __attribute__((aligned(16))) char name[bytes]
-// every workgroup of the grid must be resident at once; the host sizes the grid for that (one workgroup per CU)
-#define COOK_LAUNCH_COOP(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 
 // constant-rate (100 MHz) device clock for in-kernel phase timing
 static __device__ __forceinline__ unsigned long long cook_ticks() { return wall_clock64(); }

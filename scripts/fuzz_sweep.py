@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Seeded random sweep of the engine against the oracle (TEST TOOL): small random configurations of rank / cycle / match / explain
-and of the rebalancer, every match_algo, eval split caps, ports / named scalars, k8s gpu maps with several entries.
+and of the rebalancer, both match_algo values, eval split caps, ports / named scalars, k8s gpu maps with several entries.
 `--emu` runs the SIMT-emulator build on the CPU, otherwise libcookmatch.so on the GPU.  Prints one line; exit 1 on the first
 difference (with the configuration that produced it)."""
 import argparse
@@ -37,13 +37,12 @@ def main():
     make_engine = lambda params: Engine(params, lib_path=so)  # noqa: E731
     rng = np.random.default_rng(args.seed)
     sc = args.scale
-    n_v3 = 0
     for it in range(args.match):
         kw = dict(seed=int(rng.integers(1, 1 << 30)), n_pending=int(rng.integers(1, int(600 * sc))), n_running=int(rng.integers(0, int(150 * sc))),
                   n_users=int(rng.integers(1, 30)), n_offers=int(rng.integers(1, int(400 * sc))), gpus=bool(rng.integers(0, 2)),
                   constraints=bool(rng.integers(0, 2)), fractional=bool(rng.integers(0, 2)), tie_heavy=bool(rng.integers(0, 2)),
                   no_shares=bool(rng.integers(0, 4) == 0), quota_frac=float(rng.choice([0.0, 0.02, 0.5])))
-        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 1.0, 0.8, 0.5, 0.3])), match_algo=int(rng.choice([0, 0, 6, 6, 6, 1, 3, 4, 5])),
+        p = A.default_params(good_enough_fitness=float(rng.choice([1.0, 1.0, 0.8, 0.5, 0.3])), match_algo=int(rng.choice([0, 0, 0, 0, 1])),
                              max_over_quota_jobs=int(rng.choice([0, 3, 100])))
         if args.algo >= 0:
             p.match_algo = args.algo
@@ -51,7 +50,7 @@ def main():
             p.good_enough_fitness = args.ge
         os.environ["COOK_EVAL_SPLIT"] = str(int(rng.choice([1, 2, 4])))
         pool = synth.make_pool(**kw)
-        if rng.integers(0, 3) == 0 and args.algo != 6:  # (ports / named scalars: match_v3 hands such calls to the window rounds)
+        if rng.integers(0, 3) == 0:  # ports / named scalars
             n, m = pool.pending_jobs.n, pool.offers.n
             s2 = rng.integers(1, 30, (n, 2)).astype(np.float64) * 0.5
             s2[rng.random((n, 2)) < 0.5] = np.nan
@@ -67,10 +66,6 @@ def main():
             P.rank_parity(make_engine, pool, p)
             P.cycle_parity(make_engine, pool, p, k_cycle)
             j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, reserved=reserved)
-            if p.match_algo == 6 and p.good_enough_fitness >= 1.0:
-                with make_engine(p) as e_:
-                    e_.match(pool.pending_jobs, pool.offers, pool.groups, reserved_hosts=reserved)
-                    n_v3 += e_.match_stats()["persistent"] == 3
             if (j2o < 0).any():
                 P.explain_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, max_pos=6, tag=str(kw))
         except AssertionError as ex:
@@ -90,7 +85,7 @@ def main():
         except AssertionError as ex:
             print("FAIL rebalance", it, kw, str(ex)[:300])
             sys.exit(1)
-    print(f"fuzz ok: {args.match} match / cycle configurations ({n_v3} placed by match_v3), {args.rebalance} rebalancer configurations, seed {args.seed}, "
+    print(f"fuzz ok: {args.match} match / cycle configurations, {args.rebalance} rebalancer configurations, seed {args.seed}, "
           f"{'emulator' if args.emu else 'gpu'}")
 
 

@@ -12,8 +12,6 @@
 #define COOK_SHAPE(gpu, emu) (emu)
 #define COOK_BUILD_NAME "simt-emu test build"
 #endif
-constexpr bool COOK_COOP_GRIDS = false;  // one workgroup at a time unless a launch asks for co-scheduling (emuLaunchCoop)
-#define SPIN_PAUSE_LONG() ((void)0)
 
 // ---- wave-level rendezvous ---------------------------------------------------------------------------
 // On the GPU the 64 lanes of a wave run in lockstep and LDS operations of one wave retire in order, so this is a
@@ -26,25 +24,6 @@ template <class T>
 static inline T ld_agent(const T* p) { return *p; }
 template <class T>
 static inline void st_agent(T* p, T v) { *p = v; emu::progress(); }
-
-// ---- cross-workgroup hand-off inside one launch (the persistent placement kernel, match_world.hpp) ---------------------------------
-// The tested forms of MI355X_MICROARCH.md: producer = plain stores -> agent_release() -> relaxed agent-scope flag store;
-// consumer = relaxed poll of the flag -> ONE agent_acquire() -> plain loads.  The inline-asm wait is deliberate: ROCm 7.2 drops the
-// s_waitcnt after buffer_wbl2 when it can prove the wave's vmcnt scoreboard empty, and the flag then overtakes the write-back.
-static inline void agent_release() {}
-static inline void agent_acquire() {}
-static inline void drain_stores() {}
-template <class T>
-static inline T ld_wg(const T* p) { return *p; }
-template <class T>
-static inline void st_wg(T* p, T v) { *p = v; emu::progress(); }
-#define SPIN_PAUSE() emu::yield()
-#define SPIN_PAUSE_SHORT() emu::yield()
-#define SPIN_PAUSE_FAR() emu::yield()
-static inline void lds_release() {}
-static inline void lds_acquire() {}
-#define COOK_BLOCK_LDS(name, bytes) char* name = emu::block_lds(bytes)
-#define COOK_LAUNCH_COOP(kernel, grid, block, stream, ...) emuLaunchCoop(kernel, grid, block, __VA_ARGS__)
 
 // constant-rate (100 MHz) device clock for in-kernel phase timing
 static inline unsigned long long cook_ticks() { return 0ull; }
