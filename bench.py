@@ -536,7 +536,7 @@ def main():
             n_b = 3
             for it in range(n_b):
                 c0 = time.perf_counter()
-                cluster.update(deltas)  # (the pools' updates side by side, one host thread and stream each)
+                cluster.update(deltas)
                 torch.cuda.synchronize()
                 c1 = time.perf_counter()
                 cluster.cycle(K)
