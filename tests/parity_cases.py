@@ -451,6 +451,80 @@ def multi_pool_parity(make_engine, pools, params, k):
     return got
 
 
+def mixed_chain_parity(make_engine, pools, params_list, ks):
+    """One lockstep chain whose pools DISAGREE: good-enough-fitness below 1 next to best fit (the whole chain then runs the good-enough
+    launches: a best-fit pool is placed by best fit all the same, from that flavour's shorter best-fit lists), and different numbers
+    of considerable jobs.  Every pool against the oracle under ITS parameters."""
+    from cook_amd.engine import cycle_match_multi
+    engines = [make_engine(p) for p in params_list]
+    try:
+        for e, pool, k in zip(engines, pools, ks):
+            e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+            e.cycle_run_rank(k)
+        cycle_match_multi(engines)
+        got = [e.cycle_fetch() for e in engines]
+    finally:
+        for e in engines:
+            e.close()
+    for (ranked, j2o, head), pool, p, k in zip(got, pools, params_list, ks):
+        o_ranked, _ = pyoracle.rank(p, pool.tasks, pool.users)
+        assert np.array_equal(ranked, o_ranked)
+        pend_ord = np.cumsum(pool.tasks.pending) - 1
+        kk = min(k, len(o_ranked))
+        o_j2o, _, o_head = pyoracle.match(p, pool.pending_jobs.take(pend_ord[o_ranked[:kk]]), pool.offers, pool.groups)
+        assert np.array_equal(j2o, o_j2o) and head == o_head, (p.good_enough_fitness, k)
+    return got
+
+
+def cycle_update_mask_parity(make_engine, seed, n_pending=700, n_running=300, n_users=25, n_offers=100, n_remove=120, n_add=160):
+    """The eligible mask of cook_cycle_set_considerable travels through cook_cycle_update: rows of removed pending jobs leave it, added
+    pending jobs are eligible (1) — the next cycle equals a restage of the updated arrays with the moved mask set explicitly."""
+    rng = np.random.default_rng(seed)
+    p = A.default_params(good_enough_fitness=1.0)
+    pool = synth.make_pool(seed=seed, n_pending=n_pending, n_running=n_running, n_users=n_users, n_offers=n_offers, gpus=True, constraints=True)
+    extra = synth.make_pool(seed=seed + 1000, n_pending=n_add // 2, n_running=n_add - n_add // 2, n_users=n_users, n_offers=8, gpus=True,
+                            constraints=True, id_base=27_592_186_044_416)
+    ng = pool.groups.n if pool.groups is not None else 0
+    add_jobs = extra.pending_jobs
+    if add_jobs.group is not None:
+        add_jobs.group = np.where((add_jobs.group != A.NONE_U32) & (ng > 0), add_jobs.group % max(1, ng), A.NONE_U32).astype(np.uint32)
+    remove = np.sort(rng.choice(pool.tasks.n, size=min(n_remove, pool.tasks.n), replace=False)).astype(np.uint32)
+    mask = (rng.random(pool.n_pending) < 0.7).astype(np.uint8)  # by pending ordinal
+    keep = np.ones(pool.tasks.n, bool)
+    keep[remove] = False
+    T, X = pool.tasks, extra.tasks
+    cat = lambda a, b: np.concatenate([a[keep], b])  # noqa: E731
+    tasks2 = A.Tasks(cpus=cat(T.cpus, X.cpus), mem=cat(T.mem, X.mem), gpus=cat(T.gpus, X.gpus), user=cat(T.user, X.user),
+                     priority=cat(T.priority, X.priority), start_ms=cat(T.start_ms, X.start_ms), task_id=cat(T.task_id, X.task_id),
+                     job_id=cat(T.job_id, X.job_id), pending=cat(T.pending, X.pending))
+    keep_p = keep[np.nonzero(T.pending)[0]]
+    jobs2 = _concat_jobs(pool.pending_jobs.take(np.nonzero(keep_p)[0]), add_jobs)
+    mask2 = np.concatenate([mask[keep_p], np.ones(add_jobs.n, np.uint8)])
+    k = 10 ** 9
+    big = np.full(n_users, 1e15)
+    st = A.UserState(quota_count=big, quota_cpus=big, quota_mem=big, quota_gpus=big, usage_count=np.zeros(n_users), usage_cpus=np.zeros(n_users),
+                     usage_mem=np.zeros(n_users), usage_gpus=np.zeros(n_users))  # (quotas that never bind: the mask alone filters)
+    with make_engine(p) as e:
+        e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        e.cycle_set_considerable(st, mask)
+        e.cycle_run(k)
+        e.cycle_update(remove, extra.tasks, add_jobs, None)
+        e.cycle_run(k)
+        got = e.cycle_fetch()
+        got_pos = e.cycle_fetch_considerable()
+    with make_engine(p) as e:
+        e.cycle_stage(tasks2, pool.users, jobs2, pool.offers, pool.groups)
+        e.cycle_set_considerable(st, mask2)
+        e.cycle_run(k)
+        want = e.cycle_fetch()
+        want_pos = e.cycle_fetch_considerable()
+    assert np.array_equal(got_pos, want_pos), "the considerable jobs after the update differ from a restage with the moved mask"
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+    # ... and the mask really bites: fewer considerable jobs than ranked ones
+    assert 0 < len(got_pos) < len(got[0])
+    return got
+
+
 def edge_cases(make_engine):
     """Empty and degenerate inputs through the C ABI: they must behave like the oracle, not crash."""
     prm = A.default_params(good_enough_fitness=1.0)

@@ -249,6 +249,48 @@ def test_cycle_with_considerable_filters(make_engine):
     assert 0 < len(pos) <= 150 and not np.array_equal(pos, np.arange(len(pos)))
 
 
+def test_lockstep_chain_of_pools_that_disagree(make_engine):
+    # good-enough 0.8 next to best fit, K = 120 next to all pending, in ONE lockstep chain (two pools: contexts in the kernel arguments;
+    # five: from memory)
+    for n in (2, 5):
+        pools = [synth.make_pool(seed=270 + i, n_pending=260 + 50 * i, n_running=60, n_users=12, n_offers=60 + 35 * i, gpus=(i % 2 == 0),
+                                 constraints=(i % 2 == 1)) for i in range(n)]
+        params = [A.default_params(good_enough_fitness=(0.8 if i % 2 == 0 else 1.0), match_algo=2) for i in range(n)]
+        P.mixed_chain_parity(make_engine, pools, params, [120 if i % 3 == 0 else 10 ** 9 for i in range(n)])
+
+
+def test_cycle_update_rejects_rows_it_cannot_append(make_engine):
+    # cook_cycle_update validates the appended rows before it touches the resident columns: a user id beyond the staged users, a
+    # pending job without its user column when the staged jobs carry one, a pending-job count that disagrees with add_tasks
+    from cook_amd.engine import CookError
+    p = A.default_params()
+    pool = synth.make_pool(seed=91, n_pending=120, n_running=40, n_users=9, n_offers=20, constraints=True)
+    extra = synth.make_pool(seed=92, n_pending=6, n_running=4, n_users=9, n_offers=4, constraints=True, id_base=27_592_186_044_416)
+    extra.pending_jobs.group = None
+    with make_engine(p) as e:
+        e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        e.cycle_run(10 ** 9)
+        want = e.cycle_fetch()
+        bad = synth.make_pool(seed=92, n_pending=6, n_running=4, n_users=9, n_offers=4, constraints=True, id_base=27_592_186_044_416)
+        bad.tasks.user = bad.tasks.user.copy()
+        bad.tasks.user[0] = 500  # no such user
+        with pytest.raises(CookError, match="user id out of range"):
+            e.cycle_update((), bad.tasks, bad.pending_jobs, None)
+        nouser = extra.pending_jobs.take(np.arange(extra.pending_jobs.n))
+        nouser.user = None
+        with pytest.raises(CookError, match="user column"):
+            e.cycle_update((), extra.tasks, nouser, None)
+        with pytest.raises(CookError, match="must equal"):
+            e.cycle_update((), extra.tasks, extra.pending_jobs.take(np.arange(3)), None)
+        e.cycle_run(10 ** 9)  # the refused updates left the resident state as it was
+        again = e.cycle_fetch()
+    assert np.array_equal(want[0], again[0]) and np.array_equal(want[1], again[1])
+
+
+def test_cycle_update_moves_the_eligible_mask(make_engine):
+    P.cycle_update_mask_parity(make_engine, seed=77)
+
+
 def test_multi_pool(make_engine, algo=2):
     # three pools of different sizes (different numbers of offer chunks, rounds and K, one of them with nothing pending): in lockstep
     # launches (blockIdx.z = pool)

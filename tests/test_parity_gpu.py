@@ -276,6 +276,20 @@ def test_multi_pool_context_forms(make_engine, n, ge):
     P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=ge, match_algo=2), k=10 ** 9)
 
 
+def test_lockstep_chain_of_pools_that_disagree(make_engine):
+    # good-enough 0.8 next to best fit, K = 120 next to all pending, in ONE lockstep chain (two pools: contexts in the kernel arguments;
+    # five: from memory)
+    for n in (2, 5):
+        pools = [synth.make_pool(seed=270 + i, n_pending=260 + 50 * i, n_running=60, n_users=12, n_offers=60 + 35 * i, gpus=(i % 2 == 0),
+                                 constraints=(i % 2 == 1)) for i in range(n)]
+        params = [A.default_params(good_enough_fitness=(0.8 if i % 2 == 0 else 1.0), match_algo=2) for i in range(n)]
+        P.mixed_chain_parity(make_engine, pools, params, [120 if i % 3 == 0 else 10 ** 9 for i in range(n)])
+
+
+def test_cycle_update_moves_the_eligible_mask(make_engine):
+    P.cycle_update_mask_parity(make_engine, seed=77)
+
+
 def test_multi_pool(make_engine, algo=2):
     pools = [synth.make_pool(seed=71, n_pending=6000, n_running=2000, n_users=100, n_offers=3000, gpus=True, constraints=True),
              synth.make_pool(seed=72, n_pending=3000, n_running=500, n_users=50, n_offers=400),
