@@ -1143,7 +1143,225 @@ static __host__ __device__ __forceinline__ unsigned resolve_wseg(unsigned M) {
 }
 constexpr unsigned MV_WSEG_MIN = 16;  // pools whose owner table leaves less than that per segment are refused (about 150 000 offers)
 
-// One round of the window walk by ONE workgroup of MV_RTHREADS threads (all of them must call it).
+// The run-time part of the resolve workgroup's LDS, carved behind ResolveFixed (resolve_wseg sizes it)
+template <bool GE>
+struct SegLds {
+  JobL* job;             // [wseg] the segment's jobs, in rank order (walk position - seg_lo; JobL::b = window position)
+  double* efit;          // [wseg][LM] fitness under S of the candidate entries, by walk position
+  int* eoff;             // [wseg][LM] offer of the entry, -1 = none
+  int* goff;             // [wseg][LG] (GE) good-enough entries: offer, -1 = none
+  int* j2o;              // [wseg] results of the walk BY WALK POSITION, flushed to HBM once per segment: a global store inside the
+                         //        walk would stall later s_waitcnt vmcnt(0) on its acknowledgement
+  unsigned char* fail;   // [wseg] failure codes, by walk position
+  unsigned char* owner;  // [M] owner lane of an offer, OWNER_UNTOUCHED / OWNER_DEAD
+  unsigned wseg;
+  __device__ __forceinline__ SegLds(char* lds, unsigned M) {
+    constexpr int LM = VShape<GE>::LM, LG = VShape<GE>::LG;
+    wseg = resolve_wseg<GE>(M);
+    char* carve = lds + ((sizeof(ResolveFixed) + 15u) / 16u * 16u);
+    job = reinterpret_cast<JobL*>(carve);
+    carve += (size_t)wseg * sizeof(JobL);
+    efit = reinterpret_cast<double*>(carve);
+    carve += (size_t)wseg * LM * 8u;
+    eoff = reinterpret_cast<int*>(carve);
+    carve += (size_t)wseg * LM * 4u;
+    goff = reinterpret_cast<int*>(carve);
+    carve += (size_t)wseg * LG * 4u;
+    j2o = reinterpret_cast<int*>(carve);
+    carve += (size_t)wseg * 4u;
+    fail = reinterpret_cast<unsigned char*>(carve);
+    carve += ((size_t)wseg + 15u) / 16u * 16u;
+    owner = reinterpret_cast<unsigned char*>(carve);
+  }
+};
+
+// ---- once per round (all threads): the owner table, the jobs the walk can skip ---------------------------------------------------
+// A job without any feasible offer under S stays unmatched whatever the jobs before it do (placements only take capacity away;
+// constrained groups excepted), and its failure summary cannot change when every class it reports is backed by more offers than the
+// round can touch (t_max): such jobs are settled here, in parallel, and the walk skips them.  -> the number of jobs the walk must visit
+// (L.visit: their bits by window position, L.vbase: walk position of the first visited job of each 64-job group).
+template <bool GE>
+static __device__ __forceinline__ unsigned resolve_settle(ResolveFixed& L, const SegLds<GE>& S, const MatchState& st, const V2Buf& vb, unsigned head,
+                                                          unsigned nwin, unsigned M, unsigned t_max) {
+  const unsigned tid = threadIdx.x, NT = blockDim.x;
+  for (unsigned x = tid; x < (M + 3u) / 4u; x += NT) reinterpret_cast<unsigned*>(S.owner)[x] = 0xFFFFFFFFu;
+  if (tid < MV_JGL) L.visit[tid] = 0ull;
+  if (tid < (unsigned)MV_T) L.x0set[tid] = 0;
+  if (tid == 0) {
+    L.fit_none = -1.0;
+    L.off_none = -1;
+    L.owner_none[0] = L.owner_none[1] = L.owner_none[2] = L.owner_none[3] = (unsigned char)OWNER_NONE;
+    L.cmd = 0;
+    L.n_gslots = 0;
+  }
+  __syncthreads();
+  for (unsigned b = tid; b < nwin; b += NT) {
+    const unsigned flags = vb.jr[head + b].flags;
+    const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
+    const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
+    // members of balanced / attribute-equals groups excepted: a cotask's placement can make an offer FEASIBLE for them; a unique
+    // group only ever takes hosts away (constraints.clj:586-598), like a resource
+    const bool opens = (flags & JF_GROUPED) != 0 && ((flags >> 8) & 3u) != 1u;
+    const bool trivial = (info & 0xFFFFu) == 0u && !opens && c1 > 0u && (c2 == 0u || c2 > t_max) && (c4 == 0u || c4 > t_max);
+    if (trivial) {
+      // final whatever this round does, also for a job behind the point where the round stops: job_to_offer keeps the -1 it was
+      // initialised with; should the job still be unresolved next round, its summary is simply rewritten under the newer snapshot
+      if (st.fail_code) st.fail_code[head + b] = 1u | (c2 ? 2u : 0u) | (c4 ? 4u : 0u);
+    } else {
+      atomicOr(&L.visit[b >> 6], 1ull << (b & 63u));
+    }
+  }
+  __syncthreads();
+  if (tid <= (unsigned)MV_JGL) {  // every thread sums its own prefix ([MV_JGL] = the total)
+    unsigned acc = 0;
+    for (unsigned g = 0; g < tid; ++g) acc += (unsigned)__popcll(L.visit[g]);  // (groups beyond the window hold no bits)
+    L.vbase[tid] = acc;
+  }
+  __syncthreads();
+  return wave_uniform_u32(L.vbase[MV_JGL]);
+}
+
+// ---- the segment [lo, lo + n) of walk positions -> LDS, by walk position (all threads; L.n_gslots = 0 and a barrier behind it are
+// ---- the caller's) -> n ------------------------------------------------------------------------------------------------------
+template <bool GE>
+static __device__ __forceinline__ unsigned resolve_stage_segment(ResolveFixed& L, const SegLds<GE>& S, const V2Buf& vb, unsigned head, unsigned nwin,
+                                                                 unsigned n_list, unsigned lo, double good_enough) {
+  constexpr int LM = VShape<GE>::LM, LG = VShape<GE>::LG;
+  const unsigned tid = threadIdx.x, NT = blockDim.x;
+  const bool use_ge = GE && good_enough < 1.0;
+  const unsigned ngrp = (nwin + COOK_WAVE - 1) / COOK_WAVE;
+  const unsigned hi = lo + S.wseg < n_list ? lo + S.wseg : n_list;
+  // the job groups of the window that hold walk positions of the segment
+  unsigned g0 = 0;
+  while (g0 + 1 < ngrp && L.vbase[g0 + 1] <= lo) ++g0;
+  // pass 1, thread = window position: the records of the visited jobs, compacted to walk positions
+  for (unsigned b = g0 * COOK_WAVE + tid; b < nwin && L.vbase[b >> 6] < hi; b += NT) {
+    const unsigned long long vw = L.visit[b >> 6];
+    if (!((vw >> (b & 63u)) & 1ull)) continue;
+    const unsigned i = L.vbase[b >> 6] + (unsigned)__popcll(vw & ((1ull << (b & 63u)) - 1ull));
+    if (i < lo || i >= hi) continue;
+    const unsigned x = i - lo;
+    const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
+    const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
+    const JobRec j = vb.jr[head + b];
+    S.fail[x] = 0;  // a visited job that gets matched leaves it at that
+    JobL r;
+    r.c = j.c;
+    r.m = j.m;
+    const bool grouped = (j.flags & JF_GROUPED) != 0;
+    r.info = (info & 0xFFFFu) | (j.g > 0 ? JL_GPU : 0u) | (grouped ? JL_GROUPED : 0u) | (((j.flags >> 8) & 3u) << 18) |
+             (j.group != 0xFFFFFFFFu ? JL_HASGROUP : 0u) | ((j.flags & JF_XRES) ? JL_XRES : 0u) |
+             ((info & (1u << 16)) ? JL_TRUNC : 0u) | ((info & (1u << 17)) ? JL_GTRUNC : 0u);
+    // a member of a unique (type 1) or unconstrained (type 0) group: stage what the walk's fast path needs — the hosts to avoid
+    // as the round begins and the group's last placed job (for the chain link) — so that it never has to go to HBM for them
+    unsigned gslot = JL_GSLOT_NONE;
+    const unsigned gt = (j.flags >> 8) & 3u;
+    if (j.group != 0xFFFFFFFFu && gt <= 1u && (GE || !(good_enough < 1.0)) && vb.in_dev->host_dup == 0u && !(j.flags & JF_XRES)) {
+      const unsigned* row = vb.jfh + (size_t)b * (MV_FH + 2);  // gathered by the evaluation of this round
+      const int nfh = (int)row[MV_FH];
+      if (gt == 0u || (nfh >= 0 && nfh <= MV_FH)) {
+        const unsigned gs = atomicAdd(&L.n_gslots, 1u);
+        if (gs < (unsigned)MV_GMAX) {
+#pragma unroll
+          for (int y = 0; y < MV_FH; ++y) L.gfh[gs][y] = gt == 1u ? row[y] : 0xFFFFFFFFu;
+          L.glast[gs] = (int)row[MV_FH + 1];
+          gslot = gs;
+        }
+      }
+    }
+    r.info |= gslot << JL_GSLOT_SHIFT;
+    r.group = j.group;
+    r.f1 = (unsigned short)(c1 < 0xFFFFu ? c1 : 0xFFFFu);
+    r.f2 = (unsigned short)(c2 < 0xFFFFu ? c2 : 0xFFFFu);
+    r.f4 = (unsigned short)(c4 < 0xFFFFu ? c4 : 0xFFFFu);
+    r.b = (unsigned short)b;
+    S.job[x] = r;
+  }
+  __syncthreads();
+  // pass 2, thread = list entry: the candidate lists by walk position.  The loads do not wait for the job's counts (the arrays are
+  // sized for every entry of every job of a window: entries beyond a list hold stale values, replaced by "none" behind the load)
+  const unsigned n = hi - lo;
+#pragma unroll 4
+  for (unsigned e = tid; e < n * (unsigned)LM; e += NT) {
+    const unsigned x = e / (unsigned)LM, q = e % (unsigned)LM;
+    const JobL* jl = &S.job[x];
+    const unsigned b = jl->b, nl = jl->info & 0xFFu;
+    const int o = vb.cand_idx[(size_t)b * LM + q];
+    const double f = vb.cand_fit[(size_t)b * LM + q];
+    S.efit[e] = q < nl ? f : -1.0;
+    S.eoff[e] = q < nl ? o : -1;
+  }
+  if constexpr (LG > 0) {
+#pragma unroll 4
+    for (unsigned e = tid; e < n * (unsigned)LG; e += NT) {
+      const unsigned x = e / (unsigned)LG, q = e % (unsigned)LG;
+      const JobL* jl = &S.job[x];
+      const unsigned b = jl->b, ngl = (jl->info >> 8) & 0xFFu;
+      const int o = vb.ge_idx[(size_t)b * LG + q];
+      S.goff[e] = (use_ge && q < ngl) ? o : -1;
+    }
+  }
+  __syncthreads();
+  return n;
+}
+
+// (MV_PF) the waves that do not walk touch what opening the first entries of the segment's lists would read — behind the staging's
+// last barrier, i.e. while wave 0 already walks
+template <bool GE>
+static __device__ __forceinline__ void resolve_prefetch_segment(const SegLds<GE>& S, const V2Buf& vb, unsigned n) {
+  constexpr int LM = VShape<GE>::LM;
+  const unsigned tid = threadIdx.x, NT = blockDim.x;
+  unsigned pf_sink = 0u;
+  for (unsigned e = tid - COOK_WAVE; e < n * (unsigned)MV_PF; e += NT - COOK_WAVE) {
+    const unsigned x = e / (unsigned)MV_PF, q = e % (unsigned)MV_PF;
+    const int o = S.eoff[(size_t)x * LM + q];
+    if (o < 0) continue;
+    PREFETCH_WORD(pf_sink, &vb.ow[(unsigned)o]);
+    PREFETCH_WORD(pf_sink, &vb.colbits[(size_t)(unsigned)o * MV_JGL + ((unsigned)S.job[x].b >> 6)]);
+  }
+  PREFETCH_DRAIN(pf_sink);
+}
+
+// ---- the end of a round (lane 0 of the walking wave): statistics, the window of the next round, the control block back to HBM -----
+static __device__ __forceinline__ void resolve_finish(WinCtl& ctl, const V2Buf& vb, unsigned head, unsigned nwin, unsigned resolved, unsigned stop,
+                                                      unsigned matched, unsigned head_matched, unsigned touched, unsigned n_list,
+                                                      unsigned n_segments, unsigned n_trunc, unsigned long long t_stage, unsigned long long t_all) {
+  ctl.head = head + resolved;
+  ctl.rounds += 1;
+  ctl.matched += matched;
+  ctl.head_matched = head_matched;
+  ctl.touched_sum += touched;
+  ctl.visited_sum += n_list;
+  ctl.segments += n_segments;
+  ctl.t_setup += t_stage;
+  ctl.t_seq += t_all - t_stage;
+  ctl.trunc_lists += n_trunc;
+  if (vb.round_log && ctl.rounds <= MV_ROUND_LOG_CAP) {
+    RoundLog r;
+    r.head = head, r.wcur = ctl.wcur, r.resolved = resolved, r.n_list = n_list, r.touched = touched, r.stop = stop, r.matched = matched;
+    r.setup_ticks = (unsigned)t_stage, r.seq_ticks = (unsigned)(t_all - t_stage), r.segments = n_segments, r.pad0 = r.pad1 = 0;
+    vb.round_log[ctl.rounds - 1] = r;
+  }
+  if (stop == 1) ctl.stop_list += 1;
+  if (stop == 2 || stop == 5) ctl.stop_full += 1;
+  if (stop == 3) ctl.stop_group += 1;
+  if (stop == 0) ctl.stop_window += 1;
+  // adapt the window: a multiple of what a round resolves (more = fewer rounds, less = fewer jobs evaluated twice)
+  unsigned wn = stop == 0 ? ctl.wcur * 2 : (unsigned)(((unsigned long long)resolved * ctl.wgrow_pct + 99ull) / 100ull);
+  if (wn < 64) wn = 64;
+  // past MV_WEVAL only while next to nothing of a window has to be walked (see MV_WLONG), and never beyond what this launch
+  // sequence sized its buffers and grids for
+  unsigned cap = (unsigned)MV_WEVAL;
+  if (stop == 0 && nwin >= (unsigned)MV_WEVAL && n_list * 8u <= nwin) cap = ctl.wlong_cap > cap ? ctl.wlong_cap : cap;
+  if (wn > cap) wn = cap;
+  ctl.wcur = wn;
+  ctl.no_retire = touched < (unsigned)MV_T * 3u / 4u ? 1u : 0u;
+  *vb.ctl = ctl;
+}
+
+// One round of the window walk by ONE workgroup of MV_RTHREADS threads (all of them must call it): resolve_settle, then per segment
+// resolve_stage_segment (all threads) / resolve_prefetch_segment (the waves that do not walk) and the walk below (wave 0),
+// resolve_finish at the end.
 //
 // The walk is one dependent chain run by a single wave.  What it costs per job is the number of INSTRUCTIONS on the job's path — a
 // wave issues one every fourth cycle or so: 945 cycles for the ~200 instructions of a job that goes to an offer touched before
@@ -1163,12 +1381,10 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   constexpr int LM = VShape<GE>::LM, LG = VShape<GE>::LG;
   constexpr bool GEF = GE;
   ResolveFixed& L = *reinterpret_cast<ResolveFixed*>(lds);
-  auto& s_visit = L.visit;
-  auto& s_vbase = L.vbase;
   auto& s_gfh = L.gfh;
   auto& s_glast = L.glast;
   unsigned& s_ngslots = L.n_gslots;
-  const unsigned tid = threadIdx.x, lane = lane_id(), NT = blockDim.x;
+  const unsigned tid = threadIdx.x, lane = lane_id();
   WinCtl ctl = *vb.ctl;
   // (the launch's scalars through scalar registers, explicitly: in the multi-pool kernels `vb` and `st` are read from a context record
   //  in memory, their pointers are generic pointers to the compiler, and whatever is loaded through a generic pointer counts as a
@@ -1193,150 +1409,18 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   const unsigned t_max = can_retire ? MV_TMAX : (unsigned)MV_T;  // offers this round can touch at most
   const double jmin_c = wave_uniform_f64(st.jmin[0]), jmin_m = wave_uniform_f64(st.jmin[1]);
   // the run-time part of the LDS
-  const unsigned wseg = resolve_wseg<GE>(M);
-  char* carve = lds + ((sizeof(ResolveFixed) + 15u) / 16u * 16u);
-  JobL* const s_job = reinterpret_cast<JobL*>(carve);                    // the segment's jobs, in rank order (walk position - seg_lo; JobL::b = window position)
-  carve += (size_t)wseg * sizeof(JobL);
-  double* const s_efit = reinterpret_cast<double*>(carve);               // [wseg][LM] fitness under S of the candidate entries, by walk position
-  carve += (size_t)wseg * LM * 8u;
-  int* const s_eoff = reinterpret_cast<int*>(carve);                     // [wseg][LM] offer of the entry, -1 = none
-  carve += (size_t)wseg * LM * 4u;
-  int* const s_goff = reinterpret_cast<int*>(carve);                     // [wseg][LG] (GE) good-enough entries: offer, -1 = none
-  carve += (size_t)wseg * LG * 4u;
-  int* const s_j2o = reinterpret_cast<int*>(carve);                      // results of the walk BY WALK POSITION, flushed to HBM once per segment: a global
-  carve += (size_t)wseg * 4u;                                            // store inside the walk would stall later s_waitcnt vmcnt(0) on its acknowledgement
-  unsigned char* const s_fail = reinterpret_cast<unsigned char*>(carve);
-  carve += ((size_t)wseg + 15u) / 16u * 16u;
-  unsigned char* const s_owner = reinterpret_cast<unsigned char*>(carve);  // [M] owner lane of an offer, 0xFF = untouched
-  // ---- once per round (all threads): what the walk can skip, the owner table -------------------------------------------
-  for (unsigned x = tid; x < (M + 3u) / 4u; x += NT) reinterpret_cast<unsigned*>(s_owner)[x] = 0xFFFFFFFFu;
-  if (tid < MV_JGL) s_visit[tid] = 0ull;
-  if (tid < (unsigned)MV_T) L.x0set[tid] = 0;
-  if (tid == 0) {
-    L.fit_none = -1.0;
-    L.off_none = -1;
-    L.owner_none[0] = L.owner_none[1] = L.owner_none[2] = L.owner_none[3] = 0xFE;
-    L.cmd = 0;
-    s_ngslots = 0;
-  }
-  __syncthreads();
-  // A job without any feasible offer under S stays unmatched whatever the jobs before it do (placements only take
-  // capacity away; constrained groups excepted), and its failure summary cannot change when every class it reports is
-  // backed by more offers than a round can touch: such jobs are settled here, in parallel, and the walk skips them.
-  for (unsigned b = tid; b < nwin; b += NT) {
-    const unsigned flags = vb.jr[head + b].flags;
-    const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
-    const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
-    // members of balanced / attribute-equals groups excepted: a cotask's placement can make an offer FEASIBLE for them; a unique
-    // group only ever takes hosts away (constraints.clj:586-598), like a resource
-    const bool opens = (flags & JF_GROUPED) != 0 && ((flags >> 8) & 3u) != 1u;
-    const bool trivial = (info & 0xFFFFu) == 0u && !opens && c1 > 0u && (c2 == 0u || c2 > t_max) && (c4 == 0u || c4 > t_max);
-    if (trivial) {
-      // final whatever this round does, also for a job behind the point where the round stops: job_to_offer keeps the -1 it was
-      // initialised with; should the job still be unresolved next round, its summary is simply rewritten under the newer snapshot
-      if (st.fail_code) st.fail_code[head + b] = 1u | (c2 ? 2u : 0u) | (c4 ? 4u : 0u);
-    } else {
-      atomicOr(&s_visit[b >> 6], 1ull << (b & 63u));
-    }
-  }
-  __syncthreads();
-  if (tid <= (unsigned)MV_JGL) {  // walk position of the first visited job of group tid ([MV_JGL] = the total): every thread sums its own prefix
-    unsigned acc = 0;
-    for (unsigned g = 0; g < tid; ++g) acc += (unsigned)__popcll(s_visit[g]);  // (groups beyond the window hold no bits)
-    s_vbase[tid] = acc;
-  }
-  __syncthreads();
-  const unsigned n_list = wave_uniform_u32(s_vbase[MV_JGL]);  // jobs the walk has to visit
-  const unsigned ngrp = (nwin + COOK_WAVE - 1) / COOK_WAVE;
-  // ---- the segment [lo, lo + n_seg) of walk positions -> LDS, by walk position (all threads) --------------------------------
-  auto stage_segment = [&](unsigned lo) -> unsigned {  // (s_ngslots = 0 and a barrier behind it: the caller's)
-    const unsigned hi = lo + wseg < n_list ? lo + wseg : n_list;
-    // the job groups of the window that hold walk positions of the segment
-    unsigned g0 = 0;
-    while (g0 + 1 < ngrp && s_vbase[g0 + 1] <= lo) ++g0;
-    // pass 1, thread = window position: the records of the visited jobs, compacted to walk positions
-    for (unsigned b = g0 * COOK_WAVE + tid; b < nwin && s_vbase[b >> 6] < hi; b += NT) {
-      const unsigned long long vw = s_visit[b >> 6];
-      if (!((vw >> (b & 63u)) & 1ull)) continue;
-      const unsigned i = s_vbase[b >> 6] + (unsigned)__popcll(vw & ((1ull << (b & 63u)) - 1ull));
-      if (i < lo || i >= hi) continue;
-      const unsigned x = i - lo;
-      const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
-      const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
-      const JobRec j = vb.jr[head + b];
-      s_fail[x] = 0;  // a visited job that gets matched leaves it at that
-      JobL r;
-      r.c = j.c;
-      r.m = j.m;
-      const bool grouped = (j.flags & JF_GROUPED) != 0;
-      r.info = (info & 0xFFFFu) | (j.g > 0 ? JL_GPU : 0u) | (grouped ? JL_GROUPED : 0u) | (((j.flags >> 8) & 3u) << 18) |
-               (j.group != 0xFFFFFFFFu ? JL_HASGROUP : 0u) | ((j.flags & JF_XRES) ? JL_XRES : 0u) |
-               ((info & (1u << 16)) ? JL_TRUNC : 0u) | ((info & (1u << 17)) ? JL_GTRUNC : 0u);
-      // a member of a unique (type 1) or unconstrained (type 0) group: stage what the walk's fast path needs — the hosts to avoid
-      // as the round begins and the group's last placed job (for the chain link) — so that it never has to go to HBM for them
-      unsigned gslot = JL_GSLOT_NONE;
-      const unsigned gt = (j.flags >> 8) & 3u;
-      if (j.group != 0xFFFFFFFFu && gt <= 1u && (GE || !(good_enough < 1.0)) && vb.in_dev->host_dup == 0u && !(j.flags & JF_XRES)) {
-        const unsigned* row = vb.jfh + (size_t)b * (MV_FH + 2);  // gathered by the evaluation of this round
-        const int nfh = (int)row[MV_FH];
-        if (gt == 0u || (nfh >= 0 && nfh <= MV_FH)) {
-          const unsigned gs = atomicAdd(&s_ngslots, 1u);
-          if (gs < (unsigned)MV_GMAX) {
-#pragma unroll
-            for (int y = 0; y < MV_FH; ++y) s_gfh[gs][y] = gt == 1u ? row[y] : 0xFFFFFFFFu;
-            s_glast[gs] = (int)row[MV_FH + 1];
-            gslot = gs;
-          }
-        }
-      }
-      r.info |= gslot << JL_GSLOT_SHIFT;
-      r.group = j.group;
-      r.f1 = (unsigned short)(c1 < 0xFFFFu ? c1 : 0xFFFFu);
-      r.f2 = (unsigned short)(c2 < 0xFFFFu ? c2 : 0xFFFFu);
-      r.f4 = (unsigned short)(c4 < 0xFFFFu ? c4 : 0xFFFFu);
-      r.b = (unsigned short)b;
-      s_job[x] = r;
-    }
-    __syncthreads();
-    // pass 2, thread = list entry: the candidate lists by walk position.  The loads do not wait for the job's counts (the arrays are
-    // sized for every entry of every job of a window: entries beyond a list hold stale values, replaced by "none" behind the load)
-    const unsigned n = hi - lo;
-#pragma unroll 4
-    for (unsigned e = tid; e < n * (unsigned)LM; e += NT) {
-      const unsigned x = e / (unsigned)LM, q = e % (unsigned)LM;
-      const JobL* jl = &s_job[x];
-      const unsigned b = jl->b, nl = jl->info & 0xFFu;
-      const int o = vb.cand_idx[(size_t)b * LM + q];
-      const double f = vb.cand_fit[(size_t)b * LM + q];
-      s_efit[e] = q < nl ? f : -1.0;
-      s_eoff[e] = q < nl ? o : -1;
-    }
-    if constexpr (LG > 0) {
-#pragma unroll 4
-      for (unsigned e = tid; e < n * (unsigned)LG; e += NT) {
-        const unsigned x = e / (unsigned)LG, q = e % (unsigned)LG;
-        const JobL* jl = &s_job[x];
-        const unsigned b = jl->b, ngl = (jl->info >> 8) & 0xFFu;
-        const int o = vb.ge_idx[(size_t)b * LG + q];
-        s_goff[e] = (use_ge && q < ngl) ? o : -1;
-      }
-    }
-    __syncthreads();
-    return n;
-  };
-  // (MV_PF) the waves that do not walk touch what opening the first entries of the segment's lists would read — behind the staging's
-  // last barrier, i.e. while wave 0 already walks
-  auto prefetch_segment = [&](unsigned n) {
-    unsigned pf_sink = 0u;
-    for (unsigned e = tid - COOK_WAVE; e < n * (unsigned)MV_PF; e += NT - COOK_WAVE) {
-      const unsigned x = e / (unsigned)MV_PF, q = e % (unsigned)MV_PF;
-      const int o = s_eoff[(size_t)x * LM + q];
-      if (o < 0) continue;
-      PREFETCH_WORD(pf_sink, &vb.ow[(unsigned)o]);
-      PREFETCH_WORD(pf_sink, &vb.colbits[(size_t)(unsigned)o * MV_JGL + ((unsigned)s_job[x].b >> 6)]);
-    }
-    PREFETCH_DRAIN(pf_sink);
-  };
+  const SegLds<GE> S(lds, M);
+  JobL* const s_job = S.job;
+  double* const s_efit = S.efit;
+  int* const s_eoff = S.eoff;
+  int* const s_goff = S.goff;
+  int* const s_j2o = S.j2o;
+  unsigned char* const s_fail = S.fail;
+  unsigned char* const s_owner = S.owner;
+  // ---- once per round (all threads): what the walk can skip, the owner table -------------------------------------------------------
+  const unsigned n_list = resolve_settle<GE>(L, S, st, vb, head, nwin, M, t_max);  // jobs the walk has to visit
+  auto stage_segment = [&](unsigned lo) -> unsigned { return resolve_stage_segment<GE>(L, S, vb, head, nwin, n_list, lo, good_enough); };
+  auto prefetch_segment = [&](unsigned n) { resolve_prefetch_segment<GE>(S, vb, n); };
   unsigned seg_lo = 0;
   unsigned n_eff = stage_segment(0);  // walk positions of the segment
   unsigned n_segments = 1;
@@ -2217,39 +2301,9 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     if (t_ac + st.jmin[0] > t_oc || t_am + st.jmin[1] > t_om)  // full for every job of this call, for good
       atomicAnd(&st.alive[(unsigned)t_v >> 6], ~(1ull << ((unsigned)t_v & 63u)));
   }
-  if (lane == 0) {
-    ctl.head = head + resolved;
-    ctl.rounds += 1;
-    ctl.matched += matched;
-    ctl.head_matched = head_matched;
-    ctl.touched_sum += nT + n_retired;
-    ctl.visited_sum += n_list;
-    ctl.segments += n_segments;
-    ctl.t_setup += t_stage;
-    ctl.t_seq += (cook_ticks() - tk0) - t_stage;
-    if (stop == 1) ctl.stop_list += 1;
-    ctl.trunc_lists += n_trunc;
-    if (vb.round_log && ctl.rounds <= MV_ROUND_LOG_CAP) {
-      RoundLog r;
-      r.head = head, r.wcur = ctl.wcur, r.resolved = resolved, r.n_list = n_list, r.touched = nT + n_retired, r.stop = stop, r.matched = matched;
-      r.setup_ticks = (unsigned)t_stage, r.seq_ticks = (unsigned)((cook_ticks() - tk0) - t_stage), r.segments = n_segments, r.pad0 = r.pad1 = 0;
-      vb.round_log[ctl.rounds - 1] = r;
-    }
-    if (stop == 2 || stop == 5) ctl.stop_full += 1;
-    if (stop == 3) ctl.stop_group += 1;
-    if (stop == 0) ctl.stop_window += 1;
-    // adapt the window: a multiple of what a round resolves (more = fewer rounds, less = fewer jobs evaluated twice)
-    unsigned wn = stop == 0 ? ctl.wcur * 2 : (unsigned)(((unsigned long long)resolved * ctl.wgrow_pct + 99ull) / 100ull);
-    if (wn < 64) wn = 64;
-    // past MV_WEVAL only while next to nothing of a window has to be walked (see MV_WLONG), and never beyond what this launch
-    // sequence sized its buffers and grids for
-    unsigned cap = (unsigned)MV_WEVAL;
-    if (stop == 0 && nwin >= (unsigned)MV_WEVAL && n_list * 8u <= nwin) cap = ctl.wlong_cap > cap ? ctl.wlong_cap : cap;
-    if (wn > cap) wn = cap;
-    ctl.wcur = wn;
-    ctl.no_retire = nT + n_retired < (unsigned)MV_T * 3u / 4u ? 1u : 0u;
-    *vb.ctl = ctl;
-  }
+  if (lane == 0)
+    resolve_finish(ctl, vb, head, nwin, resolved, stop, matched, head_matched, nT + n_retired, n_list, n_segments, n_trunc, t_stage,
+                   cook_ticks() - tk0);
 }
 
 template <bool GE>
