@@ -9,7 +9,7 @@ ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("o
 
 
 def main():
-    pat = sys.argv[1] if len(sys.argv) > 1 else "match_v3"
+    pat = sys.argv[1] if len(sys.argv) > 1 else "match_resolve2"
     extra = sys.argv[2:]
     out = "/tmp/engine_isa.s"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",

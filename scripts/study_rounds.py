@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Rounds per match against the placement's compile-time shape (list length L, window, slot table) on the SIMT emulator:
-hardware-independent statistics (rounds, why they ended, jobs per round) for design decisions that LDS forbids trying on the GPU
-as it is.  TEST INFRASTRUCTURE (builds emulator variants into /tmp); results in DESIGN.md §13.
+"""Rounds per match against the placement's compile-time shape (evaluated window, jobs per segment, merged list length) on the SIMT
+emulator built with the shipped launch shapes: hardware-independent statistics (rounds, why they ended) for design decisions.
+TEST INFRASTRUCTURE (builds emulator variants into /tmp); results in DESIGN.md §15.
 
-  python scripts/study_rounds.py --scale 0.25 --variants 512:256:8 512:256:12 512:512:16 256:256:16
+  python scripts/study_rounds.py --scale 0.25 --variants 960:384:24 960:384:48 960:192:64 1920:384:48      (WEVAL:WSEG:LM)
 """
 import argparse
 import os
@@ -16,19 +16,19 @@ sys.path.insert(0, ROOT)
 EMU = os.path.join(ROOT, "tests", "simt_emu")
 
 
-def build(wmax, slots, L):
-    out = f"/tmp/libcookmatch_emu_w{wmax}_s{slots}_l{L}.so"
+def build(weval, wseg, lm):
+    out = f"/tmp/libcookmatch_emu_w{weval}_s{wseg}_lm{lm}.so"
     if not os.path.exists(out):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-I", EMU, f"-DCOOK_MV_WMAX={wmax}",
-                               f"-DCOOK_MV_S={slots}", f"-DCOOK_MV_L={L}", "-x", "c++", os.path.join(ROOT, "cook_amd", "csrc", "engine.hip"),
-                               os.path.join(EMU, "emu.cpp"), "-o", out])
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-I", EMU, "-DCOOK_EMU_SHIPPED_SHAPES",
+                               f"-DCOOK_MV_WEVAL={weval}", f"-DCOOK_MV_WSEG={wseg}", f"-DCOOK_MV_LM={lm}", "-x", "c++",
+                               os.path.join(ROOT, "cook_amd", "csrc", "engine.hip"), os.path.join(EMU, "emu.cpp"), "-o", out])
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=float, default=0.25, help="fraction of a C4 pool (125k pending x 6250 offers)")
-    ap.add_argument("--variants", nargs="+", default=["512:256:8"])
+    ap.add_argument("--variants", nargs="+", default=["960:384:48"])
     a = ap.parse_args()
     from cook_amd import _abi as A
     from cook_amd import synth
@@ -39,8 +39,8 @@ def main():
     p = A.default_params(good_enough_fitness=1.0)
     ref = None
     for v in a.variants:
-        wmax, slots, L = (int(x) for x in v.split(":"))
-        so = build(wmax, slots, L)
+        weval, wseg, lm = (int(x) for x in v.split(":"))
+        so = build(weval, wseg, lm)
         t0 = time.time()
         with Engine(p, lib_path=so) as e:
             e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
@@ -50,7 +50,7 @@ def main():
         if ref is None:
             ref = j2o
         same = bool((ref == j2o).all())
-        print(f"W={wmax} S={slots} L={L}: rounds {st['rounds']} (list {st['stop_list']} full {st['stop_full']} window {st['stop_window']} "
+        print(f"WEVAL={weval} WSEG={wseg} LM={lm}: rounds {st['rounds']} (list {st['stop_list']} full {st['stop_full']} window {st['stop_window']} "
               f"segments {st['segments']}) visited {st['visited']} matched {st['matched']} same_result {same}  [{time.time() - t0:.0f} s]", flush=True)
 
 
