@@ -1536,7 +1536,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   // the walk enters group g of the window: its word from the prefetch if that is the group fetched ahead, and the word of the group
   // after it ordered now (a long window's visited jobs may skip groups: then the word is fetched on the spot)
   auto enter_group = [&](unsigned g) {
-    if (g == col_next) {
+    if (__builtin_expect(g == col_next, 1)) {
       t_col = t_coln;
     } else if (nT != 0u) {
       t_col = fetch_col(g);
@@ -1585,7 +1585,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   // state goes to global memory now (nothing reads it before the next round), its alive bit is cleared, the owner table says "dead".
   // -> MV_T: none (the round ends).  `nxt`'s owner look-up was issued before: patched here.
   auto alloc_lane = [&](JobRegs& nxt) -> unsigned {
-    if (nT < (unsigned)MV_T) return nT;
+    if (__builtin_expect(nT < (unsigned)MV_T, 1)) return nT;
     if (!can_retire || n_retired >= MV_RETIRE_CAP) return (unsigned)MV_T;
     const bool dead = t_ac + jmin_c > t_oc || t_am + jmin_m > t_om;  // (all 64 lanes own an offer)
     const unsigned long long dm = __ballot(dead);
@@ -1683,12 +1683,12 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   int open_off = -1;  // >= 0: the fast path gave the job to an untouched offer (committed below the loop)
   bool open_group = false;
   auto fast_turn = [&](JobRegs& cur, JobRegs& nxt) __attribute__((always_inline)) -> int {
-      if (i >= n_eff) return 1;
+      if (__builtin_expect(i >= n_eff, 0)) return 1;
       EMU_SITE("resolve: walk loop");
       WALK_PROF_BEGIN();
       nxt = load_rec(i + 1);  // in flight while job i is decided (its owner look-up follows at the end of this turn, when the entry's offer is there)
       WALK_DECODE();
-      if ((b >> 6) != cur_g) enter_group(b >> 6);  // next word of the columns
+      if (__builtin_expect((b >> 6) != cur_g, 0)) enter_group(b >> 6);  // next word of the columns
     // ======== FAST PATH ======================================================================================================
     // self-contained: decision AND commit, then straight on to the next job (its control flow never joins the general path's).
     // Two instantiations: plain jobs, and members of unique / unconstrained groups whose hosts-to-avoid the staging gathered
@@ -1735,7 +1735,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       const unsigned long long untouched_mask = __ballot(cur.owner == 0xFFu);
       double u_fit = -1.0;
       int u_off = -1;
-      if (untouched_mask != 0ull) {
+      if (__builtin_expect(untouched_mask != 0ull, 1)) {
         const int qs = __ffsll((unsigned long long)untouched_mask) - 1;
         u_fit = wave_read_lane_f64(cur.e_fit, qs);
         u_off = wave_read_lane(cur.e_off, qs);
@@ -1751,7 +1751,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
           // between (or a list that may not reach far enough) goes to the general path and its exact divisions
           const bool above = cand && sane && eps_lo(fa) > good_enough;
           const bool maybe = cand && !above && (!sane || eps_hi(fa) > good_enough);
-          if (__any(maybe)) return false;
+          if (__builtin_expect(__any(maybe), 0)) return false;
           const unsigned tkey = above ? 0x7FFFFFFFu - (unsigned)t_v : 0u;
           const unsigned long long above_mask = __ballot(above);
           // (one touched offer above the threshold — the common case — needs no reduction)
@@ -1762,7 +1762,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
           const int ng = (int)((cinfo_u >> 8) & 0xFFu);
           const unsigned long long gun = __ballot((int)lane < ng && cur.g_owner == 0xFFu);
           int ge_pick = 0x7FFFFFFF;
-          if (gun != 0ull) {
+          if (__builtin_expect(gun != 0ull, 1)) {
             const int q = __ffsll((unsigned long long)gun) - 1;
             ge_pick = wave_read_lane(cur.g_off, q);
           } else if (cinfo_u & JL_GTRUNC) {
@@ -1784,14 +1784,14 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       }
       if (ge_done) {
         // (decided above)
-      } else if (mx == 0.0f) {  // no touched offer can take the job
+      } else if (__builtin_expect(mx == 0.0f, 0)) {  // no touched offer can take the job
         f_new = u_off >= 0;  // else: unmatched or list exhausted -> general path
-      } else if (mx < __int_as_float(0x7F800000)) {
+      } else if (__builtin_expect(mx < __int_as_float(0x7F800000), 1)) {
         const unsigned long long near = __ballot(kf >= mx * (1.0f - 0x1p-20f));
-        if ((near & (near - 1ull)) == 0ull) {  // one touched offer clearly ahead of the other touched ones
+        if (__builtin_expect((near & (near - 1ull)) == 0ull, 1)) {  // one touched offer clearly ahead of the other touched ones
           const int wl = __ffsll((unsigned long long)near) - 1;
           const double fw = wave_read_lane_f64(fa, wl);
-          if (u_off < 0) {
+          if (__builtin_expect(u_off < 0, 0)) {
             // no untouched entry: fine unless the list is truncated and none of its entries is still a candidate (then better
             // untouched offers may exist beyond the list: exhausted, general path)
             bool ok = COOK_L_COMPLETE();
@@ -1801,7 +1801,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
               ok = __any(e_live);
             }
             if (ok) f_lane = wl;
-          } else if (eps_lo(fw) > u_fit) {
+          } else if (__builtin_expect(eps_lo(fw) > u_fit, 1)) {
             f_lane = wl;
           } else if (eps_hi(fw) < u_fit) {
             f_new = true;
@@ -1811,7 +1811,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       // the booking by the winner's lane, on EVERY way out of here (f_lane = -1: no lane): as a statement of the branch below the booked
       // fields met their unbooked selves where the fast path's exits join, and were moved between two sets of registers for it
       take_job((int)lane == f_lane, c, m);
-      if (f_lane >= 0) {  // an offer touched earlier in this round takes the job
+      if (__builtin_expect(f_lane >= 0, 1)) {  // an offer touched earlier in this round takes the job
         const int w = wave_read_lane(t_v, f_lane);
         store_result(i, w);  // (s_fail[i] = 0 since the staging)
         if constexpr (GROUP) publish_member(w, (unsigned)wave_read_lane((int)t_host, f_lane));
@@ -1820,7 +1820,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         WALK_END(GROUP ? 4u : 1u);
         return true;
       }
-      if (f_new && (nT < (unsigned)MV_T || can_retire)) {  // an untouched offer: a lane takes ownership — outside this loop (see below)
+      if (__builtin_expect(f_new && (nT < (unsigned)MV_T || can_retire), 1)) {  // an untouched offer: a lane takes ownership — outside this loop (see below)
         open_off = u_off;
         open_group = GROUP;
       }
@@ -1828,13 +1828,13 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     };
     bool fast_done = false;
     if (GEF || !(good_enough < 1.0)) {
-      if (!(cinfo_u & (JL_GROUPED | JL_HASGROUP | JL_XRES)))
+      if (__builtin_expect(!(cinfo_u & (JL_GROUPED | JL_HASGROUP | JL_XRES)), 1))
         fast_done = fast_path(std::false_type{});
       else if (gslot != JL_GSLOT_NONE && n_log < (unsigned)COOK_WAVE)
         fast_done = fast_path(std::true_type{});
     }
     load_owner(nxt);  // (before a commit of the paths below: they patch it)
-    if (!fast_done) return 2;
+    if (__builtin_expect(!fast_done, 0)) return 2;
     WAIT_LDS_BUT_2();  // the record of the next job has arrived (see common.hpp); the result store and the owner look-up may still fly
     ++i;
     return 0;
@@ -1845,8 +1845,8 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
     open_group = false;
     for (;;) {  // ---- fast loop ----
       int r = fast_turn(cur, nxt);
-      if (r == 0) r = fast_turn(nxt, cur) | 4;  // (bit 2: the register sets are swapped)
-      if ((r & 3) == 0) continue;
+      if (__builtin_expect(r == 0, 1)) r = fast_turn(nxt, cur) | 4;  // (bit 2: the register sets are swapped)
+      if (__builtin_expect((r & 3) == 0, 1)) continue;
       walk_over = (r & 3) == 1;
       if (r & 4) {  // back to `cur` = this job, `nxt` = the next one
         const JobRegs t = cur;
@@ -1855,13 +1855,13 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       }
       break;
     }  // ---- fast loop ----
-    if (walk_over) break;
+    if (__builtin_expect(walk_over, 0)) break;
     // (prefetches and the column word of the job in `cur` are in place: the fast loop's turn for it issued them)
     WALK_PROF_BEGIN();
     unsigned pcat = 0;
     (void)pcat;
     WALK_DECODE();
-    if (open_off >= 0) {
+    if (__builtin_expect(open_off >= 0, 1)) {
       // ---- the fast path's other verdict: an untouched offer takes the job and the next free lane becomes its owner.  Committed HERE,
       // outside the fast loop: the fields open_lane writes (an offer's totals, reciprocals, host ...) are then loop-invariant inside
       // it, and only there does the compiler keep them in ONE set of registers without moving them about
@@ -1869,7 +1869,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
       const unsigned gslot = (cinfo_u >> JL_GSLOT_SHIFT) & JL_GSLOT_NONE;
       const unsigned long long ghits = open_group ? __ballot(lane < n_log && lg_group == g) : 0ull;
       const unsigned nl = alloc_lane(nxt);
-      if (nl == (unsigned)MV_T) {
+      if (__builtin_expect(nl == (unsigned)MV_T, 0)) {
         stop = 2;  // no lane to track a new touched offer: end the round before this job (the fast path booked nothing for it)
         resolved = b;
         break;
