@@ -20,6 +20,7 @@
 #include "offers_kernels.hpp"
 #include "explain_kernels.hpp"
 #include "rank_kernels.hpp"
+#include "tile_sort.hpp"
 #include "rebalance_kernels.hpp"
 #include "scan.hpp"
 #include "sort.hpp"
@@ -117,7 +118,8 @@ struct cook_engine {
       tsorted2, qitemA, qitemB, ranked, pend_ord, hist;
   DArr<int32_t> t_prio;
   DArr<int64_t> t_start, t_task, t_job;
-  DArr<uint8_t> t_pending, s_pending, head, keep, thead;
+  DArr<uint8_t> t_pending, s_pending, head, keep, thead, dhead;
+  DArr<TieCtl> tie_ctl;
   DArr<uint64_t> w0, w1, w2, dkey, nkkey, ckey;
   DArr<SumU4> s_use, pre, quseA, quseB, qpre, pool_usage;
   DArr<SumI> scanI;
@@ -288,7 +290,10 @@ void seg_scan(cook_engine* e, const char* tag, Load load, const uint8_t* head, u
   auto k_sums = seg_scan_blocksums<T>;
   auto k_prop = seg_scan_propagate<T>;
   KL(tag, k_local, nb, SS_THREADS, load, head, n, out, tmp.agg.ptr(), tmp.first_head.ptr());
-  if (nb > 1) {
+  if (nb > 1 && nb <= (unsigned)SS_THREADS) {
+    auto k_fused = seg_scan_propagate_fused<T>;
+    KL("seg_scan_propagate", k_fused, nb, SS_THREADS, out, n, (const SegAgg<T>*)tmp.agg.ptr(), (const unsigned*)tmp.first_head.ptr());
+  } else if (nb > 1) {
     KL("seg_scan_blocksums", k_sums, 1, SS_THREADS, (const SegAgg<T>*)tmp.agg.ptr(), nb, tmp.carry.ptr());
     KL("seg_scan_propagate", k_prop, nb, SS_THREADS, out, n, (const SegAgg<T>*)tmp.carry.ptr(),
        (const unsigned*)tmp.first_head.ptr());
@@ -312,7 +317,7 @@ void radix_pass(cook_engine* e, const uint64_t* key, const uint32_t* in, uint32_
 // the lowest varying bit not sorted yet (bits that never vary in between cost nothing).
 uint32_t* radix_sort_masked(cook_engine* e, const uint64_t* key, unsigned long long mask, const uint32_t* cur, uint32_t* a,
                             uint32_t* b, unsigned n) {
-  const uint32_t* in = cur;
+  const uint32_t* in = cur;  // null: the identity (the first pass reads positions instead of a permutation)
   uint32_t* last = const_cast<uint32_t*>(cur);
   while (mask) {
     const unsigned shift = (unsigned)__builtin_ctzll(mask);
@@ -462,10 +467,10 @@ void rank_run(cook_engine* e) {
   e->d_scratch64.ensure(64);
   e->d_counters.ensure(64);
   // --- per-user order keys -------------------------------------------------------------------------------
-  unsigned long long* mins = e->d_scratch64.ptr();       // [0..2]
-  unsigned long long* masks = e->d_scratch64.ptr() + 4;  // [4..6]
-  COOK_HIP(hipMemsetAsync(mins, 0xFF, 3 * 8, e->stream));
-  COOK_HIP(hipMemsetAsync(masks, 0, 4 * 8, e->stream));
+  const bool radix_only = std::getenv("COOK_RANK_RADIX") != nullptr;  // the tie rule as radix passes (the tests run both forms)
+  unsigned long long* mins = e->d_scratch64.ptr();      // [0..2]
+  unsigned long long* same = e->d_scratch64.ptr() + 4;  // [4..6] bits on which all keys of a word agree
+  COOK_HIP(hipMemsetAsync(mins, 0xFF, 7 * 8, e->stream));
   e->w0.ensure(N);
   e->w1.ensure(N);
   e->w2.ensure(N);
@@ -473,21 +478,23 @@ void rank_run(cook_engine* e) {
      (const int64_t*)e->t_job.ptr(), (const uint8_t*)e->t_pending.ptr(), N, mins);
   KL("rank_build_keys", rank_build_keys, gN, 256, (const uint32_t*)e->t_user.ptr(), (const int32_t*)e->t_prio.ptr(),
      (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(), (const int64_t*)e->t_job.ptr(),
-     (const uint8_t*)e->t_pending.ptr(), N, (const unsigned long long*)mins, e->w0.ptr(), e->w1.ptr(), e->w2.ptr());
-  const unsigned gV = std::min(gN, 64u);
-  KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w0.ptr(), N, masks + 0);
-  KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w1.ptr(), N, masks + 1);
-  KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w2.ptr(), N, masks + 2);
+     (const uint8_t*)e->t_pending.ptr(), N, (const unsigned long long*)mins, e->w0.ptr(), e->w1.ptr(), e->w2.ptr(), same);
   readback64(e, 8);
-  const unsigned long long mk0 = e->h_scratch[4], mk1 = e->h_scratch[5], mk2 = e->h_scratch[6];
+  const unsigned long long mk0 = ~e->h_scratch[4], mk1 = ~e->h_scratch[5], mk2 = ~e->h_scratch[6];
   e->permA.ensure(N);
   e->permB2.ensure(N);
-  KL("iota", iota_u32, gN, 256, e->permA.ptr(), N);
-  uint32_t* cur = e->permA.ptr();
+  const uint32_t* cur = nullptr;  // the identity
   cur = radix_sort_masked(e, e->w2.ptr(), mk2, cur, e->permA.ptr(), e->permB2.ptr(), N);
   cur = radix_sort_masked(e, e->w1.ptr(), mk1, cur, e->permA.ptr(), e->permB2.ptr(), N);
   cur = radix_sort_masked(e, e->w0.ptr(), mk0, cur, e->permA.ptr(), e->permB2.ptr(), N);
-  e->permB = cur;
+  if (!cur) {  // every task has the same key words
+    KL("iota", iota_u32, gN, 256, e->permA.ptr(), N);
+    cur = e->permA.ptr();
+  }
+  e->permB = const_cast<uint32_t*>(cur);
+  unsigned n_kept = 0;
+  unsigned long long vor = 0, vand = 0;
+  unsigned* counters = e->d_counters.ptr();  // [0] n_kept [1] equal-run [2] n_tied
   // --- gather, per-user prefix sums ----------------------------------------------------------------------
   e->s_user.ensure(N);
   e->s_use.ensure(N);
@@ -517,31 +524,31 @@ void rank_run(cook_engine* e) {
   e->dru.ensure(N);
   e->dkey.ensure(N);
   e->keep.ensure(N);
-  unsigned* counters = e->d_counters.ptr();  // [0] n_kept [1] equal-run [2] n_tied
-  unsigned long long* orand = e->d_scratch64.ptr() + 8;
-  COOK_HIP(hipMemsetAsync(counters, 0, 8 * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(orand, 0, 8, e->stream));
-  COOK_HIP(hipMemsetAsync(orand + 1, 0xFF, 8, e->stream));
+  unsigned long long* orand = reinterpret_cast<unsigned long long*>(counters + 8);  // [0] OR of the kept keys, [1] OR of their complements
+  COOK_HIP(hipMemsetAsync(counters, 0, 12 * 4, e->stream));  // ([8..11] serve the queue filters later)
   KL("rank_score", rank_score, gN, 256, (const SumU4*)e->pre.ptr(), (const SumI*)e->scanI.ptr(), (const uint32_t*)e->s_user.ptr(), N,
      (int)e->params.max_over_quota_jobs, (int)e->params.dru_mode, (const double*)e->u_divc.ptr(), (const double*)e->u_divm.ptr(),
      (const double*)e->u_divg.ptr(), e->dru.ptr(), e->dkey.ptr(), e->keep.ptr(), counters, orand);
   COOK_HIP(hipMemcpyAsync(e->h_scratch, orand, 16, hipMemcpyDeviceToHost, e->stream));
   COOK_HIP(hipMemcpyAsync(e->h_scratch + 2, counters, 8, hipMemcpyDeviceToHost, e->stream));
   sync(e);
-  const unsigned long long vor = e->h_scratch[0], vand = e->h_scratch[1];
+  vor = e->h_scratch[0], vand = ~e->h_scratch[1];
   unsigned hc[2];
   std::memcpy(hc, e->h_scratch + 2, 8);
-  const unsigned n_kept = hc[0];
+  n_kept = hc[0];
   // --- global DRU order -------------------------------------------------------------------------------------
   e->permC1.ensure(N);
   e->permC2.ensure(N);
-  KL("iota", iota_u32, gN, 256, e->permC1.ptr(), N);
-  uint32_t* pc = e->permC1.ptr();
+  uint32_t* pc = nullptr;  // the identity
   if (n_kept) pc = radix_sort_masked(e, e->dkey.ptr(), vor & ~vand, pc, e->permC1.ptr(), e->permC2.ptr(), N);
   if (n_kept < N) {  // limiter dropped tasks: one extra 1-bit pass moves them behind every kept task
     e->nkkey.ensure(N);
     KL("rank_notkept_key", rank_notkept_key, gN, 256, (const uint8_t*)e->keep.ptr(), N, e->nkkey.ptr());
     pc = radix_sort_masked(e, e->nkkey.ptr(), 1ull, pc, e->permC1.ptr(), e->permC2.ptr(), N);
+  }
+  if (!pc) {  // all kept keys equal
+    KL("iota", iota_u32, gN, 256, e->permC1.ptr(), N);
+    pc = e->permC1.ptr();
   }
   e->permC = pc;
   unsigned qlen = 0;
@@ -559,8 +566,8 @@ void rank_run(cook_engine* e) {
     const unsigned long long cmask = 2 * bits >= 64 ? ~0ull : (1ull << (2 * bits)) - 1ull;
     // refines `perm` (nk items of an index space with n_items items, per-user lists contiguous) in place; returns false when a
     // user has consecutive items with equal keys (the caller collapses those runs and calls again on the collapsed space)
-    auto tie_refine = [&](uint32_t* perm, const uint64_t* key, const uint32_t* user_of, const uint32_t* seg_first, unsigned nk,
-                          unsigned n_items) -> bool {
+    auto tie_refine_radix = [&](uint32_t* perm, const uint64_t* key, const uint32_t* user_of, const uint32_t* seg_first, unsigned nk,
+                                unsigned n_items) -> bool {
       const unsigned gK = div_up(nk, 256);
       e->thead.ensure(nk);
       e->rank_of_item.ensure(n_items);
@@ -569,7 +576,7 @@ void rank_run(cook_engine* e) {
       int* tied = e->tied_buf.ensure(nk);
       e->scanI.ensure(nk);
       COOK_HIP(hipMemsetAsync(counters + 1, 0, 4, e->stream));
-      KL("tie_heads", tie_heads, gK, 256, (const uint32_t*)perm, key, nk, user_of, e->thead.ptr(), ones, counters);
+      KL("tie_heads", tie_heads, gK, 256, (const uint32_t*)perm, key, nk, user_of, e->thead.ptr(), (uint8_t*)nullptr, ones, counters + 1);
       for (int round = 0;; ++round) {
         seg_scan<SumI>(e, "tie_group_scan", LoadI{ones}, (const uint8_t*)e->thead.ptr(), nk, e->scanI.ptr(), e->tmpI);
         COOK_HIP(hipMemsetAsync(counters + 2, 0, 4, e->stream));
@@ -598,6 +605,41 @@ void rank_run(cook_engine* e) {
            (const uint32_t*)e->titem.ptr(), (const uint64_t*)e->ckey.ptr(), n_tied, perm, e->thead.ptr());
       }
       return true;
+    };
+    // the same refinement with the groups sorted in LDS tiles (tile_sort.hpp): two launches per doubling round, four rounds enqueued
+    // per look at the counters (rounds past the last one exit at once); a tie group too long for a tile sends the call to the radix form,
+    // which starts over from the keys (the order inside a group of equal keys is free when the refinement starts)
+    auto tie_refine = [&](uint32_t* perm, const uint64_t* key, const uint32_t* user_of, const uint32_t* seg_first, unsigned nk,
+                          unsigned n_items) -> bool {
+      if (radix_only) return tie_refine_radix(perm, key, user_of, seg_first, nk, n_items);
+      const unsigned gK = div_up(nk, 256);
+      e->thead.ensure(nk);
+      e->dhead.ensure(nk);
+      e->rank_of_item.ensure(n_items);
+      TieCtl* ctl = e->tie_ctl.ensure(1);
+      COOK_HIP(hipMemsetAsync(ctl, 0, sizeof(TieCtl), e->stream));
+      KL("tie_heads", tie_heads, gK, 256, (const uint32_t*)perm, key, nk, user_of, e->thead.ptr(), e->dhead.ptr(), (int*)nullptr,
+         &ctl->equal_runs);
+      constexpr int LOOK = 4;
+      for (int r0 = 0; r0 < 32; r0 += LOOK) {
+        for (int round = r0; round < r0 + LOOK; ++round) {
+          KL("tie_rank_assign", tie_rank_assign, gK, 256, (const uint32_t*)perm, (const uint8_t*)e->thead.ptr(), nk, U, round,
+             (const TieCtl*)ctl, e->rank_of_item.ptr());
+          KL("tie_sort_tiles", tie_sort_tiles, div_up(nk, TS_NOMINAL), TS_THREADS, perm, e->thead.ptr(), (const uint8_t*)e->dhead.ptr(), nk,
+             U, n_items, round, (const uint32_t*)e->rank_of_item.ptr(), user_of, seg_first, ctl);
+        }
+        TieCtl h;
+        COOK_HIP(hipMemcpyAsync(e->h_scratch, ctl, sizeof(TieCtl), hipMemcpyDeviceToHost, e->stream));
+        sync(e);
+        std::memcpy(&h, e->h_scratch, sizeof(TieCtl));
+        if (std::getenv("COOK_TIE_TRACE"))
+          for (int round = r0; round < r0 + LOOK; ++round) std::fprintf(stderr, "tie round %d: %u tied after, of %u\n", round, h.tied_after[round], nk);
+        if (h.equal_runs) return false;
+        if (h.overflow) return tie_refine_radix(perm, key, user_of, seg_first, nk, n_items);
+        if (h.tied_after[r0 + LOOK - 1] == 0) return true;
+      }
+      e->fail(COOK_E_INVALID, "cook_rank: tie refinement did not converge");
+      return false;
     };
     if (!tie_refine(e->permC, e->dkey.ptr(), e->s_user.ptr(), e->seg_start.ptr(), n_kept, N)) {
       // some user has a run of equal DRUs (a zero-resource task, a gpu-less task in gpu mode, a request absorbed by the sum): the
@@ -1298,7 +1340,8 @@ void cook_engine_destroy(cook_engine* e) {
                   &e->j_index.b, &e->o_host.b, &e->o_gpu_model.b, &e->o_disk_type.b, &e->o_attr.b, &e->o_location.b, &e->g_attr_key.b,
                   &e->g_run_off.b, &e->g_run_host.b, &e->g_run_attr.b, &e->reserved_bits.b, &e->m_fail.b, &e->j_reserved_host.b,
                   &e->o_max_tasks.b, &e->o_num_tasks.b, &e->o_run_count.b, &e->g_min.b, &e->m_acount.b, &e->m_group_last.b,
-                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b, &e->v_oa.b, &e->v_ob.b, &e->v_ow.b, &e->v_jr.b, &e->v_prec.b, &e->v_cand_fit.b, &e->v_cand_idx.b, &e->v_ge_idx.b, &e->v_cinfo.b, &e->v_colbits.b, &e->w_ctl.b, &e->v_in.b};
+                  &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b, &e->v_oa.b, &e->v_ob.b, &e->v_ow.b, &e->v_jr.b, &e->v_prec.b, &e->v_cand_fit.b, &e->v_cand_idx.b, &e->v_ge_idx.b, &e->v_cinfo.b, &e->v_colbits.b, &e->w_ctl.b, &e->v_in.b,
+                  &e->dhead.b, &e->tie_ctl.b};
   for (DBuf* b : bufs) b->release();
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i)

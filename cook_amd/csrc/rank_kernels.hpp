@@ -48,14 +48,39 @@ __global__ void __launch_bounds__(256) rank_build_keys(const uint32_t* __restric
                                                        const int64_t* __restrict__ start_ms, const int64_t* __restrict__ task_id,
                                                        const int64_t* __restrict__ job_id, const uint8_t* __restrict__ pending,
                                                        unsigned n, const unsigned long long* __restrict__ mins,
-                                                       uint64_t* __restrict__ w0, uint64_t* __restrict__ w1, uint64_t* __restrict__ w2) {
+                                                       uint64_t* __restrict__ w0, uint64_t* __restrict__ w1, uint64_t* __restrict__ w2,
+                                                       unsigned long long* __restrict__ same /*[3], preset to all ones*/) {
+  // same[k] keeps the bits of word k on which every task agrees with task 0 (the radix passes skip them, sort.hpp)
+  auto words = [&](unsigned i, uint64_t& a, uint64_t& b, uint64_t& c) {
+    const bool p = pending[i] != 0;
+    const uint32_t np = ((uint32_t)(0x40000000 - priority[i])) & 0x7FFFFFFFu;  // -priority, biased (|priority| < 2^30)
+    a = ((uint64_t)user[i] << 32) | ((uint64_t)np << 1) | (p ? 1u : 0u);
+    b = p ? (i64_key(job_id[i]) - mins[1]) : (i64_key(start_ms[i]) - mins[0]);
+    c = p ? 0ull : (i64_key(task_id[i]) - mins[2]);
+  };
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const bool p = pending[i] != 0;
-  const uint32_t np = ((uint32_t)(0x40000000 - priority[i])) & 0x7FFFFFFFu;  // -priority, biased (|priority| < 2^30)
-  w0[i] = ((uint64_t)user[i] << 32) | ((uint64_t)np << 1) | (p ? 1u : 0u);
-  w1[i] = p ? (i64_key(job_id[i]) - mins[1]) : (i64_key(start_ms[i]) - mins[0]);
-  w2[i] = p ? 0ull : (i64_key(task_id[i]) - mins[2]);
+  uint64_t r0, r1, r2;
+  words(0, r0, r1, r2);
+  unsigned long long d0 = 0, d1 = 0, d2 = 0;
+  if (i < n) {
+    uint64_t a, b, c;
+    words(i, a, b, c);
+    w0[i] = a, w1[i] = b, w2[i] = c;
+    d0 = a ^ r0, d1 = b ^ r1, d2 = c ^ r2;
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    d0 |= __shfl_xor(d0, d, COOK_WAVE);
+    d1 |= __shfl_xor(d1, d, COOK_WAVE);
+    d2 |= __shfl_xor(d2, d, COOK_WAVE);
+  }
+  __shared__ unsigned long long s_d[3][256 / COOK_WAVE];  // one set of atomics per block
+  if (lane_id() == 0) s_d[0][wave_id()] = d0, s_d[1][wave_id()] = d1, s_d[2][wave_id()] = d2;
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    unsigned long long m = 0ull;
+    for (unsigned w = 0; w < blockDim.x / COOK_WAVE; ++w) m |= s_d[threadIdx.x][w];
+    if (m) atomicAnd(&same[threadIdx.x], ~m);
+  }
 }
 
 // ---- gather into per-user order, segment heads and bounds ------------------------------------------------
@@ -135,7 +160,7 @@ __global__ void __launch_bounds__(256) rank_score(const SumU4* __restrict__ pre,
                                                   const double* __restrict__ div_gpus, double* __restrict__ dru,
                                                   uint64_t* __restrict__ dkey, uint8_t* __restrict__ keep,
                                                   unsigned* __restrict__ counters /*[0]=n_kept, [1]=equal-run violations*/,
-                                                  unsigned long long* __restrict__ or_and /*[0]=OR, [1]=AND of kept keys*/) {
+                                                  unsigned long long* __restrict__ or_and /*[0] = OR of the kept keys, [1] = OR of their complements*/) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   bool k = false;
   uint64_t key = ~0ull;
@@ -173,7 +198,7 @@ __global__ void __launch_bounds__(256) rank_score(const SumU4* __restrict__ pre,
     if (nk) {
       atomicAdd(&counters[0], nk);
       atomicOr(&or_and[0], bo);
-      atomicAnd(&or_and[1], ba);
+      atomicOr(&or_and[1], ~ba);
     }
   }
 }
@@ -193,16 +218,19 @@ __global__ void __launch_bounds__(256) rank_notkept_key(const uint8_t* __restric
 //   rank_0 = tie group by d;  key_1 = (rank_0(j), MAXR - rank_0(j-1));  key_{k+1} = (rank_k(j), rank_k(j - 2^k)), k >= 1.
 // Ranks are "U + first C-position of the item's tie group"; virtual items take ranks U-1-u (all below any real rank).
 __global__ void __launch_bounds__(256) tie_heads(const uint32_t* __restrict__ permC, const uint64_t* __restrict__ dkey, unsigned n_kept,
-                                                 const uint32_t* __restrict__ s_user, uint8_t* __restrict__ thead, int* __restrict__ ones,
-                                                 unsigned* __restrict__ counters) {
+                                                 const uint32_t* __restrict__ s_user, uint8_t* __restrict__ thead,
+                                                 uint8_t* __restrict__ dhead /*a second copy that stays, or null*/,
+                                                 int* __restrict__ ones /*or null*/, unsigned* __restrict__ equal_runs) {
   const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_kept) return;
   const unsigned i = permC[p];
-  thead[p] = (p == 0 || dkey[i] != dkey[permC[p - 1]]) ? 1 : 0;
-  ones[p] = 1;
+  const uint8_t h = (p == 0 || dkey[i] != dkey[permC[p - 1]]) ? 1 : 0;
+  thead[p] = h;
+  if (dhead) dhead[p] = h;
+  if (ones) ones[p] = 1;
   // a user's DRUs must increase strictly along its list (positive resources); equal neighbours are counted so the
   // host can refuse instead of mis-ordering them ("equal consecutive DRUs")
-  if (i > 0 && s_user[i - 1] == s_user[i] && dkey[i - 1] == dkey[i]) atomicAdd(&counters[1], 1u);
+  if (i > 0 && s_user[i - 1] == s_user[i] && dkey[i - 1] == dkey[i]) atomicAdd(equal_runs, 1u);
 }
 
 // idx_in_group (1-based, from the segmented scan of ones) -> group start, rank of the item, tied flag, tied count

@@ -371,9 +371,8 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   e->d_scratch64.ensure(64);
   // ---- per-user order of all slots (tools.clj:614-641; rebalancer.clj:241-246) ---------------------------------------------
   unsigned long long* mins = e->d_scratch64.ptr();
-  unsigned long long* masks = e->d_scratch64.ptr() + 4;
-  COOK_HIP(hipMemsetAsync(mins, 0xFF, 3 * 8, e->stream));
-  COOK_HIP(hipMemsetAsync(masks, 0, 4 * 8, e->stream));
+  unsigned long long* same = e->d_scratch64.ptr() + 4;  // bits on which all keys of a word agree
+  COOK_HIP(hipMemsetAsync(mins, 0xFF, 7 * 8, e->stream));
   e->w0.ensure(S);
   e->w1.ensure(S);
   e->w2.ensure(S);
@@ -381,20 +380,19 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
      (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, mins);
   KL("rank_build_keys", rank_build_keys, gS, 256, (const uint32_t*)b.user.ptr(), (const int32_t*)b.prio.ptr(), (const int64_t*)b.start.ptr(),
      (const int64_t*)b.task.ptr(), (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, (const unsigned long long*)mins,
-     e->w0.ptr(), e->w1.ptr(), e->w2.ptr());
-  const unsigned gV = std::min(gS, 128u);
-  KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w0.ptr(), S, masks + 0);
-  KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w1.ptr(), S, masks + 1);
-  KL("radix_varying_bits", radix_varying_bits, gV, 256, (const uint64_t*)e->w2.ptr(), S, masks + 2);
+     e->w0.ptr(), e->w1.ptr(), e->w2.ptr(), same);
   readback64(e, 8);
-  const unsigned long long mk0 = e->h_scratch[4], mk1 = e->h_scratch[5], mk2 = e->h_scratch[6];
+  const unsigned long long mk0 = ~e->h_scratch[4], mk1 = ~e->h_scratch[5], mk2 = ~e->h_scratch[6];
   b.permA.ensure(S);
   b.permB2.ensure(S);
-  KL("iota", iota_u32, gS, 256, b.permA.ptr(), S);
-  uint32_t* cur = b.permA.ptr();
+  const uint32_t* cur = nullptr;  // the identity
   cur = radix_sort_masked(e, e->w2.ptr(), mk2, cur, b.permA.ptr(), b.permB2.ptr(), S);
   cur = radix_sort_masked(e, e->w1.ptr(), mk1, cur, b.permA.ptr(), b.permB2.ptr(), S);
   cur = radix_sort_masked(e, e->w0.ptr(), mk0, cur, b.permA.ptr(), b.permB2.ptr(), S);
+  if (!cur) {
+    KL("iota", iota_u32, gS, 256, b.permA.ptr(), S);
+    cur = b.permA.ptr();
+  }
   const uint32_t* permB = cur;
   b.posB.ensure(S);
   b.act.ensure(S);

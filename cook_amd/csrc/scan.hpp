@@ -204,3 +204,27 @@ __global__ void __launch_bounds__(SS_THREADS) seg_scan_propagate(T* __restrict__
     if (i < n && i < fh) out[i] = combine(c.v, out[i]);
   }
 }
+
+// the same for up to SS_THREADS blocks without the launch in between: every block folds the aggregates in front of it itself
+// (171 of them for a pool's 175k items; the association differs from seg_scan_blocksums', which is free: a partial sum that is not
+// exact is flagged whatever the tree, common.hpp "exact-sum tracking")
+template <class T>
+__global__ void __launch_bounds__(SS_THREADS) seg_scan_propagate_fused(T* __restrict__ out, unsigned n,
+                                                                       const SegAgg<T>* __restrict__ block_agg,
+                                                                       const unsigned* __restrict__ block_first_head) {
+  __shared__ SegAgg<T> lds_wave[SS_THREADS / COOK_WAVE];
+  const unsigned b = blockIdx.x;
+  if (b == 0) return;
+  SegAgg<T> mine{T::zero(), 0u};
+  if (threadIdx.x < b) mine = block_agg[threadIdx.x];
+  SegAgg<T> c;
+  (void)block_seg_exclusive<T, SS_THREADS>(mine, lds_wave, c);
+  const unsigned fh = block_first_head[b];
+  const unsigned base = b * SS_TILE;
+#pragma unroll
+  for (int k = 0; k < SS_IPT; ++k) {
+    const unsigned i = base + k * SS_THREADS + threadIdx.x;
+    if (i < n && i < fh) out[i] = combine(c.v, out[i]);
+  }
+}
+

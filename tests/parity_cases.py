@@ -78,6 +78,39 @@ def rank_parity(make_engine, pool: synth.Pool, params, quota=None):
     return ranked
 
 
+def tie_rule_forms(make_engine, monkeypatch, n_users=400, per_user=6):
+    """The sorted-merge tie rule in both of the engine's forms (cook_amd/csrc/tile_sort.hpp: tie groups sorted in LDS tiles; engine.hip
+    tie_refine_radix: radix passes over the tied items), on the same pools.  Many users with the SAME tasks in the same order make tie
+    groups of n_users items that stay tied until the users' name order decides (deep doubling rounds); with the emulated suite's small
+    tiles such a group does not fit one and the call has to fall back on its own."""
+    pool = synth.make_pool(seed=81, n_pending=n_users * per_user, n_running=0, n_users=n_users, n_offers=4, tie_heavy=True)
+    t = pool.tasks
+    t.user[:] = np.arange(t.n) % n_users
+    order = np.argsort(t.user, kind="stable")
+    within = np.zeros(t.n, dtype=np.int64)
+    for u in range(n_users):
+        idx = order[t.user[order] == u]
+        within[idx] = np.arange(len(idx))
+    t.cpus[:] = 1.0 + (within % 3)
+    t.mem[:] = 512.0 * (1 + (within % 2))
+    t.priority[:] = 50
+    pool.users.div_cpus[:] = 40.0  # equal shares: the k-th tasks of all users carry the same DRU
+    pool.users.div_mem[:] = 16384.0
+    params = A.default_params(max_over_quota_jobs=10_000)
+    a = rank_parity(make_engine, pool, params)
+    monkeypatch.setenv("COOK_RANK_RADIX", "1")
+    b = rank_parity(make_engine, pool, params)
+    monkeypatch.delenv("COOK_RANK_RADIX")
+    assert np.array_equal(a, b)
+    # an ordinary tie-heavy pool (short groups: the tiles take it) through both forms as well
+    pool = synth.make_pool(seed=82, n_pending=1200, n_running=400, n_users=60, n_offers=4, tie_heavy=True)
+    a = rank_parity(make_engine, pool, A.default_params())
+    monkeypatch.setenv("COOK_RANK_RADIX", "1")
+    b = rank_parity(make_engine, pool, A.default_params())
+    monkeypatch.delenv("COOK_RANK_RADIX")
+    assert np.array_equal(a, b)
+
+
 def equal_dru_run_cases(make_engine):
     """Users with runs of EQUAL consecutive DRUs (rank_run refused such pools).  The literal merge (dru.clj:92-94)
     re-conses the emitting user at the front, so a run is emitted back to back; the oracle's literal and heap forms agree."""

@@ -57,6 +57,11 @@ def test_rank_equal_dru_runs(make_engine):
     P.equal_dru_run_cases(make_engine)
 
 
+def test_rank_tie_rule_in_tiles_and_as_radix_passes(make_engine, monkeypatch):
+    P.tie_rule_forms(make_engine, monkeypatch)
+    P.tie_rule_forms(make_engine, monkeypatch, n_users=150, per_user=5)
+
+
 def test_rank_user_usage(make_engine):
     got = P.user_usage_parity(make_engine, synth.make_pool(seed=81, n_pending=900, n_running=700, n_users=40, n_offers=10, gpus=True), 40)
     assert got[:, 0].sum() > 0 and got[:, 2].sum() > 0
