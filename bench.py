@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-adjacent", action="store_true", help="skip the timings of the rows next to the hot path (offers, explain, metrics)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cap on the oracle threads of the cpu_baseline leg; 0 = os.cpu_count()")
     ap.add_argument("--no-extras", action="store_true", help="skip SURVEY.md §8d's reporting matrix (K = 1000 / 1e5, good-enough 0.8, C2, C3) under extra_configs")
+    ap.add_argument("--boundary", action="store_true", help="run the boundary leg (cook_cycle_update from page-locked columns) even with --no-extras")
     ap.add_argument("--as-rank-of", type=int, default=0, help="single process: time only the pools rank 0 of an N-GPU job would hold (the per-GPU load behind DESIGN.md's scaling prediction; not a bench line)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of the timed configuration (rank 0's first and last pool vs the oracle, after the timed region)")
     # rehearsal of the multi-process path on a machine without GPUs (tests/test_sharding_gloo.py): the engines load the given build of
@@ -497,7 +498,7 @@ def main():
     #      submissions —, fresh offers) from page-locked columns, the cycle, cook_cycle_fetch into page-locked buffers; beside it the
     #      cost of restaging EVERYTHING from pageable and from page-locked memory (cook_cycle_stage).
     boundary = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and (args.boundary or not args.no_extras):
         from cook_amd.engine import PinnedArena
         arena = PinnedArena()
         try:
@@ -532,8 +533,14 @@ def main():
                                for p in my_pools for x in pinned_pools[p])
             cluster.cycle(K)
             torch.cuda.synchronize()
+            cluster.update(deltas)  # one untimed update: the first call of an engine allocates the columns' second buffers
+            torch.cuda.synchronize()
+            restage(True)
+            cluster.cycle(K)
+            torch.cuda.synchronize()
             t_upd = t_cyc = t_fetch = 0.0
-            n_b = 3
+            upd_samples = []
+            n_b = 5
             for it in range(n_b):
                 c0 = time.perf_counter()
                 cluster.update(deltas)
@@ -546,17 +553,19 @@ def main():
                     engines[p].cycle_fetch(out=outs[p])
                 c3 = time.perf_counter()
                 t_upd += c1 - c0
+                upd_samples.append(round((c1 - c0) * 1e3, 3))
                 t_cyc += c2 - c1
                 t_fetch += c3 - c2
                 if it + 1 < n_b:  # back to the benchmark's state for the next measurement: a full restage (not timed)
                     restage(True)
-            boundary = {"ms_per_step_incl_transfers": (t_upd + t_cyc + t_fetch) / n_b * 1e3,
-                        "update_ms": t_upd / n_b * 1e3, "cycle_ms": t_cyc / n_b * 1e3, "fetch_ms": t_fetch / n_b * 1e3,
+            upd_med = float(np.median(upd_samples))  # (the median: one call in a few takes 10+ ms when a buffer has to grow)
+            boundary = {"ms_per_step_incl_transfers": upd_med + (t_cyc + t_fetch) / n_b * 1e3,
+                        "update_ms": upd_med, "update_ms_mean": t_upd / n_b * 1e3, "update_ms_samples": upd_samples, "cycle_ms": t_cyc / n_b * 1e3, "fetch_ms": t_fetch / n_b * 1e3,
                         "delta": f"per pool: {n_delta} task rows leave, {n_delta} arrive ({n_delta // 2} of them pending jobs), {n_off} fresh offers",
                         "restage_all_pageable_ms": (b1 - b0) * 1e3, "restage_all_pinned_ms": (b2 - b1) * 1e3,
                         "restage_bytes": int(staged_bytes), "restage_pinned_GBps": staged_bytes / max(1e-9, b2 - b1) / 1e9,
-                        "note": "host wall time around the C ABI calls (cook_cycle_update / the cycle / cook_cycle_fetch); page-locked "
-                                "memory from cook_host_alloc"}
+                        "note": "host wall time around the C ABI calls (cook_cycle_update / the cycle / cook_cycle_fetch) after one untimed "
+                                "update; page-locked memory from cook_host_alloc"}
             restage(True)  # leave the engines on the benchmark's own inputs, with a finished cycle (the rows below read its results)
             cluster.cycle(K)
             torch.cuda.synchronize()

@@ -153,6 +153,22 @@ def _ptr(arr: Optional[np.ndarray], ptype):
     return arr.ctypes.data_as(ptype)
 
 
+def _memo_struct(obj, build):
+    """The ctypes view of a column set, rebuilt only when one of its arrays was replaced (a struct is ~20 pointer conversions, 55 us of
+    interpreter time under the GIL; a rank drives eight pools per cycle).  In-place edits of the arrays keep the pointers valid; the
+    memo holds the arrays, so an address cannot be reused while it is cached."""
+    if getattr(obj, "scalars", None) is not None:  # (passed as a transposed COPY: an edit in place would not reach a cached one)
+        return build()
+    arrays = [v for k, v in vars(obj).items() if isinstance(v, np.ndarray) and not k.startswith("_")]
+    key = tuple(map(id, arrays))
+    memo = obj.__dict__.get("_struct_memo")
+    if memo is not None and memo[0] == key:
+        return memo[1]
+    st = build()
+    obj.__dict__["_struct_memo"] = (key, st, arrays)
+    return st
+
+
 def _arr(x, dtype, n=None):
     if x is None:
         return None
@@ -215,6 +231,9 @@ class Tasks:
         return len(self.cpus)
 
     def as_struct(self) -> CookTasks:
+        return _memo_struct(self, self._build_struct)
+
+    def _build_struct(self) -> CookTasks:
         return CookTasks(self.n, _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p), _ptr(self.gpus, _f64p),
                          _ptr(self.user, _u32p), _ptr(self.priority, _i32p), _ptr(self.start_ms, _i64p),
                          _ptr(self.task_id, _i64p), _ptr(self.job_id, _i64p), _ptr(self.pending, _u8p),
@@ -450,6 +469,9 @@ class Jobs:
         return self._cols
 
     def as_struct(self) -> CookJobs:
+        return _memo_struct(self, self._build_struct)
+
+    def _build_struct(self) -> CookJobs:
         return CookJobs(self.n, _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p), _ptr(self.gpus, _f64p),
                         _ptr(self.gpu_model, _u32p), _ptr(self.user, _u32p), _ptr(self.group, _u32p),
                         _ptr(self.eq_off, _u32p), _ptr(self.eq_key, _u32p), _ptr(self.eq_val, _u32p),
@@ -531,6 +553,9 @@ class Offers:
         return self._cols
 
     def as_struct(self) -> CookOffers:
+        return _memo_struct(self, self._build_struct)
+
+    def _build_struct(self) -> CookOffers:
         attr = None if self.attr is None else self.attr.reshape(-1)
         flat = lambda a: None if a is None else a.reshape(-1)
         return CookOffers(self.n, _ptr(self.cpus, _f64p), _ptr(self.mem, _f64p), _ptr(self.host, _u32p),

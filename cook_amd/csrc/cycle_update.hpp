@@ -4,146 +4,246 @@
 // killed, a few jobs were submitted or launched, the offers are new.  cook_cycle_stage copies everything (140 MB for the benchmark
 // cluster); this entry point takes the DELTA — task rows to remove, task / pending-job rows to append, optionally a fresh set of
 // offers — and edits the resident columns on the device: a stable compaction (rows keep their relative order, so task indices stay
-// meaningful to the host: removed rows close up, new rows go to the end) followed by the copy of the new rows only.
+// meaningful to the host: removed rows close up, new rows go to the end) followed by the new rows.
+//
+// The call is a chain of small launches and copies, and that — not the bytes — is what it costs (rounds 2-4: one compaction launch
+// and one copy per column, four read-backs: 110 launches and copies, 0.64 ms per pool, eight pools 5-6.7 ms).  Now:
+//   * everything the delta brings is packed by the host into ONE page-locked block and copied once; the kernels read it there;
+//   * ALL task columns are compacted by one launch and all pending-job columns by another (a table of column descriptors in the
+//     kernel arguments), into second buffers that are swapped in only when the call has succeeded — a removal list that names a row
+//     twice or out of range leaves the resident state as it was;
+//   * row counts stay on the device until one read-back at the end (buffers are sized by what the host knows: N - n_remove + n_add
+//     rows when the list is valid, every old value of a CSR column plus the new ones);
+//   * the fresh offers are one block too, used in place (match_stage_offers_block).
 // Included by engine.hip (uses its DArr / KL / seg_scan helpers).
 #pragma once
 
-__global__ void __launch_bounds__(256) upd_fill_ones(int* p, unsigned n) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = 1;
+constexpr unsigned UPD_MAX_COLS = 24;
+struct UpdCol {
+  const void* src;  // resident column (old rows)
+  void* dst;        // its second buffer
+  const void* add;  // the new rows in the delta block (device), or null: dflt
+  unsigned long long dflt;  // bit pattern of the default element
+  unsigned esize;           // 1, 4 or 8
+};
+struct UpdColSet {
+  UpdCol c[UPD_MAX_COLS];
+  unsigned n_cols;
+};
+struct UpdOut {  // what the host reads back at the end
+  unsigned n_keep, p_keep, bad, kept_vals[2];
+};
+
+static __device__ __forceinline__ void upd_copy_elem(void* dst, size_t di, const void* src, size_t si, unsigned esize) {
+  if (esize == 8) ((uint64_t*)dst)[di] = ((const uint64_t*)src)[si];
+  else if (esize == 4) ((uint32_t*)dst)[di] = ((const uint32_t*)src)[si];
+  else ((uint8_t*)dst)[di] = ((const uint8_t*)src)[si];
 }
-__global__ void __launch_bounds__(256) upd_mark_removed(const uint32_t* __restrict__ rem, unsigned n_rem, unsigned n, int* __restrict__ keep,
-                                                        unsigned* __restrict__ bad) {
+static __device__ __forceinline__ void upd_store_elem(void* dst, size_t di, unsigned long long v, unsigned esize) {
+  if (esize == 8) ((uint64_t*)dst)[di] = v;
+  else if (esize == 4) ((uint32_t*)dst)[di] = (uint32_t)v;
+  else ((uint8_t*)dst)[di] = (uint8_t)v;
+}
+
+// rm[i] = 1 for the rows the delta removes (rm zeroed before); out->bad counts indices out of range or named twice
+__global__ void __launch_bounds__(256) upd_mark_removed(const uint32_t* __restrict__ rem, unsigned n_rem, unsigned n, int* __restrict__ rm,
+                                                        UpdOut* __restrict__ out) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rem) return;
   const unsigned r = rem[i];
-  if (r >= n || atomicExch(&keep[r], 0) == 0) atomicAdd(bad, 1u);  // out of range, or named twice
+  if (r >= n || atomicExch(&rm[r], 1) != 0) atomicAdd(&out->bad, 1u);
 }
-// keep flags of the pending jobs (by pending ordinal) from the keep flags of their tasks
-__global__ void __launch_bounds__(256) upd_pending_keep(const uint8_t* __restrict__ pending, const uint32_t* __restrict__ pend_ord,
-                                                        const int* __restrict__ keep, unsigned n, int* __restrict__ keep_p) {
+struct LoadKeep {  // 1 for a row that stays
+  const int* rm;
+  __device__ __forceinline__ SumI operator()(unsigned i) const { return SumI{rm[i] ? 0 : 1}; }
+};
+// removal flags of the pending jobs (by pending ordinal) from those of their tasks (rm_p zeroed before)
+__global__ void __launch_bounds__(256) upd_pending_removed(const uint8_t* __restrict__ pending, const uint32_t* __restrict__ pend_ord,
+                                                           const int* __restrict__ rm, unsigned n, int* __restrict__ rm_p) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && pending[i]) keep_p[pend_ord[i]] = keep[i];
+  if (i < n && pending[i] && rm[i]) rm_p[pend_ord[i]] = 1;
 }
-template <class T>
-__global__ void __launch_bounds__(256) upd_compact(const T* __restrict__ in, const int* __restrict__ keep, const SumI* __restrict__ incl,
-                                                   unsigned n, T* __restrict__ out) {
+// every column of one table at once: thread i < n_old moves row i (if it stays) to its new place, thread n_old + r appends new row r
+__global__ void __launch_bounds__(256) upd_compact_cols(UpdColSet cs, const int* __restrict__ rm, const SumI* __restrict__ incl, unsigned n_old,
+                                                        unsigned n_add, unsigned which /*0 tasks, 1 pending jobs*/, UpdOut* __restrict__ out) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && keep[i]) out[(unsigned)incl[i].v - 1u] = in[i];
-}
-// rows of width `w` (the offer attribute table is not touched here; this is for per-job tables should one appear)
-__global__ void __launch_bounds__(256) upd_csr_len(const uint32_t* __restrict__ off, const int* __restrict__ keep, unsigned n, int* __restrict__ len) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) len[i] = keep[i] ? (int)(off[i + 1] - off[i]) : 0;
-}
-// new offsets of the kept rows (exclusive prefix of their lengths) + the total behind the last one
-__global__ void __launch_bounds__(256) upd_csr_off(const int* __restrict__ keep, const SumI* __restrict__ row_incl, const int* __restrict__ len,
-                                                   const SumI* __restrict__ len_incl, unsigned n, uint32_t* __restrict__ off_out,
-                                                   unsigned n_rows_out) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && keep[i]) off_out[(unsigned)row_incl[i].v - 1u] = (uint32_t)(len_incl[i].v - len[i]);
-  if (i == n - 1) off_out[n_rows_out] = (uint32_t)len_incl[i].v;
-}
-__global__ void __launch_bounds__(256) upd_csr_vals(const uint32_t* __restrict__ off, const int* __restrict__ keep, const int* __restrict__ len,
-                                                    const SumI* __restrict__ len_incl, unsigned n, const uint32_t* __restrict__ a,
-                                                    const uint32_t* __restrict__ b, uint32_t* __restrict__ a_out, uint32_t* __restrict__ b_out) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !keep[i]) return;
-  const unsigned dst = (unsigned)(len_incl[i].v - len[i]);
-  for (unsigned x = 0; x < (unsigned)len[i]; ++x) {
-    a_out[dst + x] = a[off[i] + x];
-    if (b) b_out[dst + x] = b[off[i] + x];
+  const unsigned n_keep = n_old ? (unsigned)incl[n_old - 1].v : 0u;
+  if (i == 0) (which ? out->p_keep : out->n_keep) = n_keep;
+  if (i < n_old) {
+    if (rm[i]) return;
+    const unsigned o = (unsigned)incl[i].v - 1u;
+    for (unsigned k = 0; k < cs.n_cols; ++k) upd_copy_elem(cs.c[k].dst, o, cs.c[k].src, i, cs.c[k].esize);
+  } else if (i < n_old + n_add) {
+    const unsigned r = i - n_old;
+    for (unsigned k = 0; k < cs.n_cols; ++k) {
+      if (cs.c[k].add) upd_copy_elem(cs.c[k].dst, (size_t)n_keep + r, cs.c[k].add, r, cs.c[k].esize);
+      else upd_store_elem(cs.c[k].dst, (size_t)n_keep + r, cs.c[k].dflt, cs.c[k].esize);
+    }
   }
 }
-__global__ void __launch_bounds__(256) upd_pending_flag(const uint8_t* __restrict__ pending, unsigned n, int* __restrict__ flag) {
+struct LoadPendingFlag {
+  const uint8_t* pending;
+  __device__ __forceinline__ SumI operator()(unsigned i) const { return SumI{pending[i] ? 1 : 0}; }
+};
+__global__ void __launch_bounds__(256) upd_pend_ord(const uint8_t* __restrict__ pending, const SumI* __restrict__ incl, unsigned n,
+                                                    uint32_t* __restrict__ pend_ord) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flag[i] = pending[i] ? 1 : 0;
+  if (i < n) pend_ord[i] = (uint32_t)(incl[i].v - (pending[i] ? 1 : 0));
 }
-__global__ void __launch_bounds__(256) upd_pend_ord(const int* __restrict__ flag, const SumI* __restrict__ incl, unsigned n, uint32_t* __restrict__ pend_ord) {
+// a CSR column pair (offsets per pending job, one or two value arrays): lengths of the rows that stay
+struct LoadCsrLen {
+  const uint32_t* off;
+  const int* rm_p;
+  __device__ __forceinline__ SumI operator()(unsigned i) const { return SumI{rm_p[i] ? 0 : (int)(off[i + 1] - off[i])}; }
+};
+// thread i < p_old: row i (if it stays) -> its new offset and its values; thread p_old + r, r <= p_add: offset of new row r (shifted by
+// the values that stay; r == p_add: the end); thread p_old + p_add + 1 + x: new value x
+__global__ void __launch_bounds__(256) upd_csr(const uint32_t* __restrict__ off, const int* __restrict__ rm_p, const SumI* __restrict__ row_incl,
+                                               const SumI* __restrict__ len_incl, unsigned p_old, const uint32_t* __restrict__ a,
+                                               const uint32_t* __restrict__ b, const uint32_t* __restrict__ add_off, const uint32_t* __restrict__ add_a,
+                                               const uint32_t* __restrict__ add_b, unsigned p_add, unsigned add_vals, uint32_t* __restrict__ off_out,
+                                               uint32_t* __restrict__ a_out, uint32_t* __restrict__ b_out, unsigned which, UpdOut* __restrict__ out) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) pend_ord[i] = (uint32_t)(incl[i].v - flag[i]);
-}
-template <class T>
-__global__ void __launch_bounds__(256) upd_fill(T* p, unsigned n, T v) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
+  const unsigned p_keep = p_old ? (unsigned)row_incl[p_old - 1].v : 0u;
+  const unsigned kept_vals = p_old ? (unsigned)len_incl[p_old - 1].v : 0u;
+  if (i == 0) out->kept_vals[which] = kept_vals;
+  if (i < p_old) {
+    if (rm_p[i]) return;
+    const unsigned len = off[i + 1] - off[i];
+    const unsigned dst = (unsigned)len_incl[i].v - len;
+    off_out[(unsigned)row_incl[i].v - 1u] = dst;
+    for (unsigned x = 0; x < len; ++x) {
+      a_out[dst + x] = a[off[i] + x];
+      if (b) b_out[dst + x] = b[off[i] + x];
+    }
+  } else if (i <= p_old + p_add) {
+    const unsigned r = i - p_old;
+    off_out[p_keep + r] = kept_vals + (add_off ? add_off[r] : 0u);
+  } else if (i < p_old + p_add + 1u + add_vals) {
+    const unsigned x = i - (p_old + p_add + 1u);
+    a_out[kept_vals + x] = add_a[x];
+    if (b_out && add_b) b_out[kept_vals + x] = add_b[x];
+  }
 }
 
 struct UpdateBufs {
-  DArr<int> keep, keep_p, len, flag;
-  DArr<SumI> incl, incl_p, len_incl;
-  DArr<unsigned> bad;
-  DBuf tmp;  // the compacted copy of one column (swapped with the column afterwards)
-  // buffers that used to be allocated and freed inside every call (hipFree synchronises the whole device: eight pools updating at once
-  // serialised on it): the removal list and the new CSR arrays (swapped with the columns like `tmp`)
-  DArr<uint32_t> rem, n_off, n_a, n_b;
+  DArr<int> rm, rm_p;
+  DArr<SumI> incl, incl_p, len_incl, fincl;
+  DArr<UpdOut> out;
+  DBuf alt[2 * UPD_MAX_COLS];  // second buffers of the columns (tasks: [0, UPD_MAX_COLS), pending jobs behind them)
+  DArr<uint32_t> n_off[2], n_a[2], n_b[2], pend_ord_alt;
+  unsigned csr_vals[2] = {0, 0};  // values the two CSR columns hold (eq, novel); 0xFFFFFFFF = not known yet (read from the offsets)
+  bool csr_known = false;
+  // the delta, packed: page-locked on the host, one copy to the device
+  void* h_block = nullptr;
+  size_t h_cap = 0;
+  DBuf d_block;
+  // the fresh offers, packed (used in place by the match until the next delta brings others)
+  void* h_offers = nullptr;
+  size_t h_offers_cap = 0;
+  DBuf d_offers;
+  ~UpdateBufs() {
+    if (h_block) (void)hipHostFree(h_block);
+    if (h_offers) (void)hipHostFree(h_offers);
+  }
 };
 
 // (included inside engine.hip's anonymous namespace)
-// stable compaction of one resident column + the new rows behind it; `col` ends up with n_keep + n_add rows
-template <class T>
-void upd_column(cook_engine* e, UpdateBufs& ub, DArr<T>& col, const int* keep, const SumI* incl, unsigned n_old, unsigned n_keep,
-                const T* add, unsigned n_add, bool have_default, T dflt) {
-  const unsigned n_new = n_keep + n_add;
-  ub.tmp.ensure((size_t)(n_new ? n_new : 1) * sizeof(T));
-  T* out = (T*)ub.tmp.p;
-  if (n_old) {
-    auto k = upd_compact<T>;
-    KL("upd_compact", k, div_up(n_old, 256), 256, (const T*)col.ptr(), keep, incl, n_old, out);
+struct BlockWriter {  // lays arrays out in a host block, 16-byte aligned; first pass (base == nullptr) only measures
+  char* base;
+  size_t used = 0;
+  explicit BlockWriter(char* b) : base(b) {}
+  template <class T>
+  size_t put(const T* src, size_t n) {  // returns the offset, or (size_t)-1 for a null source
+    if (!src) return (size_t)-1;
+    const size_t at = used;
+    if (base && n) std::memcpy(base + at, src, n * sizeof(T));
+    used = (used + n * sizeof(T) + 15) & ~(size_t)15;
+    return at;
   }
-  if (n_add) {
-    if (add) {
-      COOK_HIP(hipMemcpyAsync(out + n_keep, add, (size_t)n_add * sizeof(T), hipMemcpyHostToDevice, e->stream));
-    } else if (have_default) {
-      auto k = upd_fill<T>;
-      KL("upd_fill", k, div_up(n_add, 256), 256, out + n_keep, n_add, dflt);
+};
+static void pinned_reserve(void** p, size_t* cap, size_t bytes) {
+  if (bytes <= *cap) return;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  const size_t want = bytes + bytes / 2 + 4096;
+  COOK_HIP(hipHostMalloc(p, want, hipHostMallocDefault));
+  *cap = want;
+}
+
+// the offers of a delta: every column the host gave into one block, one copy, used where it lands
+void match_stage_offers_block(cook_engine* e, UpdateBufs& ub, const cook_offers* o) {
+  MatchIn& in = e->min;
+  const unsigned M = o->n;
+  if (M && (!o->cpus || !o->mem || !o->host)) e->fail(COOK_E_INVALID, "cook_match_stage: offers need cpus, mem and host");
+  if (o->scalars && o->n_scalars > COOK_MAX_SCALARS) e->fail(COOK_E_INVALID, "cook_match_stage: more than COOK_MAX_SCALARS named scalars");
+  const unsigned gs = res_slots(e, o->gpu_slots, "cook_match_stage: gpu_slots"), ds = res_slots(e, o->disk_slots, "cook_match_stage: disk_slots");
+  if (o->gpu_model && !o->gpu_count) e->fail(COOK_E_INVALID, "cook_match_stage: gpu_model without gpu_count");
+  const unsigned n_attr = o->attr ? o->n_attr_keys : 0;
+  size_t off[32];
+  for (int pass = 0; pass < 2; ++pass) {
+    BlockWriter w(pass ? (char*)ub.h_offers : nullptr);
+    int k = 0;
+    off[k++] = w.put(o->cpus, M);
+    off[k++] = w.put(o->mem, M);
+    off[k++] = w.put(o->host, M);
+    off[k++] = w.put(o->k8s, M);
+    off[k++] = w.put(o->gpu_model, (size_t)M * gs);
+    off[k++] = w.put(o->gpu_count, (size_t)M * gs);
+    off[k++] = w.put(o->disk_type, (size_t)M * ds);
+    off[k++] = w.put(o->disk_space, (size_t)M * ds);
+    off[k++] = w.put(o->ports, M);
+    for (unsigned sc = 0; sc < COOK_MAX_SCALARS; ++sc)
+      off[k++] = w.put((o->scalars && sc < o->n_scalars) ? o->scalars + (size_t)sc * M : (const double*)nullptr, M);
+    off[k++] = w.put(o->attr, (size_t)M * n_attr);
+    off[k++] = w.put(o->max_tasks, M);
+    off[k++] = w.put(o->num_tasks, M);
+    off[k++] = w.put(o->location, M);
+    off[k++] = w.put(o->host_start_s, M);
+    off[k++] = w.put(o->run_cpus, M);
+    off[k++] = w.put(o->run_mem, M);
+    off[k++] = w.put(o->run_count, M);
+    if (!pass) {
+      pinned_reserve(&ub.h_offers, &ub.h_offers_cap, w.used + 16);
+      ub.d_offers.ensure(w.used + 16);
+    } else if (w.used) {
+      COOK_HIP(hipMemcpyAsync(ub.d_offers.p, ub.h_offers, w.used, hipMemcpyHostToDevice, e->stream));
     }
   }
-  std::swap(col.b.p, ub.tmp.p);
-  std::swap(col.b.cap, ub.tmp.cap);
+  const char* d = (const char*)ub.d_offers.p;
+  auto at = [&](size_t o_) -> const void* { return o_ == (size_t)-1 ? nullptr : (const void*)(d + o_); };
+  int k = 0;
+  in.M = M;
+  e->M = M;
+  in.o_cpus = (const double*)at(off[k++]);
+  in.o_mem = (const double*)at(off[k++]);
+  in.o_host = (const uint32_t*)at(off[k++]);
+  in.o_k8s = (const uint8_t*)at(off[k++]);
+  in.gpu_slots = gs;
+  in.disk_slots = ds;
+  in.o_gpu_model = (const uint32_t*)at(off[k++]);
+  in.o_gpu_count = (const double*)at(off[k++]);
+  in.o_disk_type = (const uint32_t*)at(off[k++]);
+  in.o_disk_space = (const double*)at(off[k++]);
+  in.o_ports = (const int32_t*)at(off[k++]);
+  for (unsigned sc = 0; sc < COOK_MAX_SCALARS; ++sc) in.o_scal[sc] = (const double*)at(off[k++]);
+  in.n_attr = n_attr;
+  in.o_attr = (const uint32_t*)at(off[k++]);
+  in.o_max_tasks = (const int32_t*)at(off[k++]);
+  in.o_num_tasks = (const int32_t*)at(off[k++]);
+  in.o_location = (const uint32_t*)at(off[k++]);
+  in.o_host_start = (const int64_t*)at(off[k++]);
+  in.o_run_cpus = (const double*)at(off[k++]);
+  in.o_run_mem = (const double*)at(off[k++]);
+  in.o_run_count = (const int32_t*)at(off[k++]);
+  in.host_dup = 0;
+  if (M) {  // two offers on one host?
+    std::vector<uint32_t> hs(o->host, o->host + M);
+    std::sort(hs.begin(), hs.end());
+    in.host_dup = std::adjacent_find(hs.begin(), hs.end()) != hs.end() ? 1u : 0u;
+  }
 }
-
-void upd_csr(cook_engine* e, UpdateBufs& ub, DArr<uint32_t>& off, DArr<uint32_t>& va, DArr<uint32_t>* vb, const int* keep_p, const SumI* incl_p,
-             unsigned p_old, unsigned p_keep, const uint32_t* add_off, const uint32_t* add_a, const uint32_t* add_b, unsigned p_add) {
-  // lengths of the kept rows -> new offsets; values gathered row by row; then the new rows with their offsets shifted
-  const unsigned p_new = p_keep + p_add;
-  int* len = ub.len.ensure(std::max(1u, p_old));
-  SumI* len_incl = ub.len_incl.ensure(std::max(1u, p_old));
-  unsigned kept_vals = 0;
-  DArr<uint32_t>&n_off = ub.n_off, &n_a = ub.n_a, &n_b = ub.n_b;
-  n_off.ensure(p_new + 1);
-  if (p_old) {
-    KL("upd_csr_len", upd_csr_len, div_up(p_old, 256), 256, (const uint32_t*)off.ptr(), keep_p, p_old, len);
-    seg_scan<SumI>(e, "upd_scan", LoadI{len}, (const uint8_t*)nullptr, p_old, len_incl, e->tmpI);
-    COOK_HIP(hipMemcpyAsync(e->h_scratch, &len_incl[p_old - 1], 4, hipMemcpyDeviceToHost, e->stream));
-    sync(e);
-    int t = 0;
-    std::memcpy(&t, e->h_scratch, 4);
-    kept_vals = (unsigned)t;
-  }
-  const unsigned add_vals = (p_add && add_off) ? add_off[p_add] : 0u;
-  n_a.ensure(std::max(1u, kept_vals + add_vals));
-  if (vb) n_b.ensure(std::max(1u, kept_vals + add_vals));
-  if (p_old) {
-    KL("upd_csr_off", upd_csr_off, div_up(p_old, 256), 256, keep_p, incl_p, (const int*)len, (const SumI*)len_incl, p_old, n_off.ptr(), p_keep);
-    KL("upd_csr_vals", upd_csr_vals, div_up(p_old, 256), 256, (const uint32_t*)off.ptr(), keep_p, (const int*)len, (const SumI*)len_incl, p_old,
-       (const uint32_t*)va.ptr(), vb ? (const uint32_t*)vb->ptr() : (const uint32_t*)nullptr, n_a.ptr(), vb ? n_b.ptr() : (uint32_t*)nullptr);
-  } else {
-    COOK_HIP(hipMemsetAsync(n_off.ptr(), 0, 4, e->stream));
-  }
-  std::vector<uint32_t> shifted(p_add + 1);
-  for (unsigned r = 0; r <= p_add; ++r) shifted[r] = kept_vals + (add_off ? add_off[r] : 0u);
-  COOK_HIP(hipMemcpyAsync(n_off.ptr() + p_keep, shifted.data(), (size_t)(p_add + 1) * 4, hipMemcpyHostToDevice, e->stream));
-  if (add_vals) {
-    COOK_HIP(hipMemcpyAsync(n_a.ptr() + kept_vals, add_a, (size_t)add_vals * 4, hipMemcpyHostToDevice, e->stream));
-    if (vb) COOK_HIP(hipMemcpyAsync(n_b.ptr() + kept_vals, add_b, (size_t)add_vals * 4, hipMemcpyHostToDevice, e->stream));
-  }
-  sync(e);  // `shifted` is a host temporary
-  std::swap(off.b.p, n_off.b.p), std::swap(off.b.cap, n_off.b.cap);
-  std::swap(va.b.p, n_a.b.p), std::swap(va.b.cap, n_a.b.cap);
-  if (vb) std::swap(vb->b.p, n_b.b.p), std::swap(vb->b.cap, n_b.b.cap);
-}
-
 
 void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
   if (!d) e->fail(COOK_E_INVALID, "cook_cycle_update: null delta");
@@ -166,6 +266,8 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
   for (unsigned r = 0; p_add && aj->ports && r < p_add; ++r)
     if (aj->ports[r] < 0) e->fail(COOK_E_INVALID, "cook_cycle_update: negative port count");
   if (d->n_remove && !d->remove_task) e->fail(COOK_E_INVALID, "cook_cycle_update: remove_task is NULL");
+  if (d->n_remove && !N) e->fail(COOK_E_INVALID, "cook_cycle_update: nothing staged to remove from");
+  if (d->n_remove > N) e->fail(COOK_E_INVALID, "cook_cycle_update: remove_task holds an index out of range or twice");
   MatchIn& in = e->min;
   // a column the delta brings but the stage did not have cannot be added row-wise: the host restages (cook_cycle_stage)
   if (p_add && ((aj->gpus && !in.j_gpus) || (aj->gpu_model && !in.j_gpu_model) || (aj->group && !in.j_group) || (aj->eq_off && !in.j_eq_off) ||
@@ -177,105 +279,197 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
   if (p_add && aj->group)
     for (unsigned r = 0; r < p_add; ++r)
       if (aj->group[r] != COOK_NONE_U32 && aj->group[r] >= e->G) e->fail(COOK_E_INVALID, "cook_cycle_update: group id out of range");
-  // ---- keep flags and their prefix sums --------------------------------------------------------------------------------
-  int* keep = ub.keep.ensure(std::max(1u, N));
-  int* keep_p = ub.keep_p.ensure(std::max(1u, P));
+  if (in.j_disk_req && p_add && aj->disk_request && !aj->disk_type) e->fail(COOK_E_INVALID, "cook_cycle_update: disk_request without disk_type");
+  const unsigned N2 = N - d->n_remove + n_add;  // (when the removal list is valid; the device says at the end)
+  const unsigned P_hi = P + p_add;              // the pending jobs can only be bounded until then
+  // ---- the delta as one block -----------------------------------------------------------------------------------------------
+  struct Offs {
+    size_t rem, t[9], j[12 + COOK_MAX_SCALARS], eq_off, eq_key, eq_val, nv_off, nv_host;
+  } o{};
+  const unsigned add_eq = (p_add && aj->eq_off && in.j_eq_off) ? aj->eq_off[p_add] : 0u;
+  const unsigned add_nv = (p_add && aj->novel_off && in.j_novel_off) ? aj->novel_off[p_add] : 0u;
+  for (int pass = 0; pass < 2; ++pass) {
+    BlockWriter w(pass ? (char*)ub.h_block : nullptr);
+    o.rem = w.put(d->remove_task, d->n_remove);
+    if (n_add) {
+      o.t[0] = w.put(at->cpus, n_add), o.t[1] = w.put(at->mem, n_add), o.t[2] = w.put(at->gpus, n_add), o.t[3] = w.put(at->user, n_add);
+      o.t[4] = w.put(at->priority, n_add), o.t[5] = w.put(at->start_ms, n_add), o.t[6] = w.put(at->task_id, n_add);
+      o.t[7] = w.put(at->job_id, n_add), o.t[8] = w.put(at->pending, n_add);
+    }
+    if (p_add) {
+      int k = 0;
+      o.j[k++] = w.put(aj->cpus, p_add), o.j[k++] = w.put(aj->mem, p_add), o.j[k++] = w.put(aj->gpus, p_add);
+      o.j[k++] = w.put(aj->gpu_model, p_add), o.j[k++] = w.put(aj->user, p_add), o.j[k++] = w.put(aj->group, p_add);
+      o.j[k++] = w.put(aj->reserved_host, p_add), o.j[k++] = w.put(aj->ckpt_location, p_add), o.j[k++] = w.put(aj->est_end_ms, p_add);
+      o.j[k++] = w.put(aj->disk_request, p_add), o.j[k++] = w.put(aj->disk_type, p_add), o.j[k++] = w.put(aj->ports, p_add);
+      for (unsigned sc = 0; sc < COOK_MAX_SCALARS; ++sc)
+        o.j[k++] = w.put((aj->scalars && sc < aj->n_scalars) ? aj->scalars + (size_t)sc * p_add : (const double*)nullptr, p_add);
+      o.eq_off = w.put(in.j_eq_off ? aj->eq_off : (const uint32_t*)nullptr, p_add + 1);
+      o.eq_key = w.put(add_eq ? aj->eq_key : (const uint32_t*)nullptr, add_eq);
+      o.eq_val = w.put(add_eq ? aj->eq_val : (const uint32_t*)nullptr, add_eq);
+      o.nv_off = w.put(in.j_novel_off ? aj->novel_off : (const uint32_t*)nullptr, p_add + 1);
+      o.nv_host = w.put(add_nv ? aj->novel_host : (const uint32_t*)nullptr, add_nv);
+    }
+    if (!pass) {
+      pinned_reserve(&ub.h_block, &ub.h_cap, w.used + 16);
+      ub.d_block.ensure(w.used + 16);
+    } else if (w.used) {
+      COOK_HIP(hipMemcpyAsync(ub.d_block.p, ub.h_block, w.used, hipMemcpyHostToDevice, e->stream));
+    }
+  }
+  const char* blk = (const char*)ub.d_block.p;
+  auto dev = [&](size_t off, bool have) -> const void* { return (!have || off == (size_t)-1) ? nullptr : (const void*)(blk + off); };
+  // ---- which rows stay, and where they go -----------------------------------------------------------------------------------
+  int* rm = ub.rm.ensure(std::max(1u, N));
+  int* rm_p = ub.rm_p.ensure(std::max(1u, P));
   SumI* incl = ub.incl.ensure(std::max(1u, N));
   SumI* incl_p = ub.incl_p.ensure(std::max(1u, P));
-  unsigned* bad = ub.bad.ensure(1);
-  COOK_HIP(hipMemsetAsync(bad, 0, 4, e->stream));
-  unsigned n_keep = 0, p_keep = 0;
-  if (N) {
-    KL("upd_fill_ones", upd_fill_ones, div_up(N, 256), 256, keep, N);
-    if (P) KL("upd_fill_ones", upd_fill_ones, div_up(P, 256), 256, keep_p, P);
-    if (d->n_remove) {
-      DArr<uint32_t>& rem = ub.rem;
-      h2d(e, rem, d->remove_task, d->n_remove);
-      KL("upd_mark_removed", upd_mark_removed, div_up(d->n_remove, 256), 256, (const uint32_t*)rem.ptr(), d->n_remove, N, keep, bad);
-    }
-    KL("upd_pending_keep", upd_pending_keep, div_up(N, 256), 256, (const uint8_t*)e->t_pending.ptr(), (const uint32_t*)e->pend_ord.ptr(),
-       (const int*)keep, N, keep_p);
-    seg_scan<SumI>(e, "upd_scan", LoadI{keep}, (const uint8_t*)nullptr, N, incl, e->tmpI);
-    if (P) seg_scan<SumI>(e, "upd_scan", LoadI{keep_p}, (const uint8_t*)nullptr, P, incl_p, e->tmpI);
-    COOK_HIP(hipMemcpyAsync(e->h_scratch, &incl[N - 1], 4, hipMemcpyDeviceToHost, e->stream));
-    if (P) COOK_HIP(hipMemcpyAsync((char*)e->h_scratch + 4, &incl_p[P - 1], 4, hipMemcpyDeviceToHost, e->stream));
-    COOK_HIP(hipMemcpyAsync((char*)e->h_scratch + 8, bad, 4, hipMemcpyDeviceToHost, e->stream));
-    sync(e);
-    int t[3] = {0, 0, 0};
-    std::memcpy(t, e->h_scratch, 12);
-    if (t[2]) e->fail(COOK_E_INVALID, "cook_cycle_update: remove_task holds an index out of range or twice");
-    n_keep = (unsigned)t[0];
-    p_keep = P ? (unsigned)t[1] : 0u;
-  } else if (d->n_remove) {
-    e->fail(COOK_E_INVALID, "cook_cycle_update: nothing staged to remove from");
+  UpdOut* out = ub.out.ensure(1);
+  COOK_HIP(hipMemsetAsync(out, 0, sizeof(UpdOut), e->stream));
+  if (N) COOK_HIP(hipMemsetAsync(rm, 0, (size_t)N * 4, e->stream));
+  if (P) COOK_HIP(hipMemsetAsync(rm_p, 0, (size_t)P * 4, e->stream));
+  if (d->n_remove) {
+    KL("upd_mark_removed", upd_mark_removed, div_up(d->n_remove, 256), 256, (const uint32_t*)dev(o.rem, true), d->n_remove, N, rm, out);
+    if (P)
+      KL("upd_pending_removed", upd_pending_removed, div_up(N, 256), 256, (const uint8_t*)e->t_pending.ptr(), (const uint32_t*)e->pend_ord.ptr(),
+         (const int*)rm, N, rm_p);
   }
-  const unsigned N2 = n_keep + n_add, P2 = p_keep + p_add;
-  // ---- task columns (rank inputs) ----------------------------------------------------------------------------------------
-  upd_column<double>(e, ub, e->t_cpus, keep, incl, N, n_keep, at ? at->cpus : nullptr, n_add, false, 0.0);
-  upd_column<double>(e, ub, e->t_mem, keep, incl, N, n_keep, at ? at->mem : nullptr, n_add, false, 0.0);
-  if (e->has_gpus) upd_column<double>(e, ub, e->t_gpus, keep, incl, N, n_keep, at ? at->gpus : nullptr, n_add, true, 0.0);
-  upd_column<uint32_t>(e, ub, e->t_user, keep, incl, N, n_keep, at ? at->user : nullptr, n_add, false, 0u);
-  upd_column<int32_t>(e, ub, e->t_prio, keep, incl, N, n_keep, at ? at->priority : nullptr, n_add, false, 0);
-  upd_column<int64_t>(e, ub, e->t_start, keep, incl, N, n_keep, at ? at->start_ms : nullptr, n_add, false, 0);
-  upd_column<int64_t>(e, ub, e->t_task, keep, incl, N, n_keep, at ? at->task_id : nullptr, n_add, false, 0);
-  upd_column<int64_t>(e, ub, e->t_job, keep, incl, N, n_keep, at ? at->job_id : nullptr, n_add, false, 0);
-  upd_column<uint8_t>(e, ub, e->t_pending, keep, incl, N, n_keep, at ? at->pending : nullptr, n_add, false, (uint8_t)0);
-  // pending ordinals of the new array: exclusive count of pending rows in front
-  e->pend_ord.ensure(std::max(1u, N2));
+  if (N) seg_scan<SumI>(e, "upd_scan", LoadKeep{rm}, (const uint8_t*)nullptr, N, incl, e->tmpI);
+  if (P) seg_scan<SumI>(e, "upd_scan", LoadKeep{rm_p}, (const uint8_t*)nullptr, P, incl_p, e->tmpI);
+  // ---- the columns, into their second buffers ---------------------------------------------------------------------------------
+  struct Swap {
+    DBuf* col;
+    DBuf* alt;
+  };
+  std::vector<Swap> swaps;
+  auto add_col = [&](UpdColSet& cs, unsigned base, DBuf& col, unsigned esize, const void* add, unsigned long long dflt, size_t rows_hi) {
+    if (cs.n_cols >= UPD_MAX_COLS) e->fail(COOK_E_STATE, "cook_cycle_update: column table full");
+    DBuf& alt = ub.alt[base + cs.n_cols];
+    alt.ensure(std::max<size_t>(1, rows_hi) * esize);
+    cs.c[cs.n_cols++] = UpdCol{col.p, alt.p, add, dflt, esize};
+    swaps.push_back(Swap{&col, &alt});
+  };
+  auto bits64 = [](double v) {
+    unsigned long long b;
+    std::memcpy(&b, &v, 8);
+    return b;
+  };
+  UpdColSet ts{};
+  add_col(ts, 0, e->t_cpus.b, 8, dev(o.t[0], n_add), 0, N2);
+  add_col(ts, 0, e->t_mem.b, 8, dev(o.t[1], n_add), 0, N2);
+  if (e->has_gpus) add_col(ts, 0, e->t_gpus.b, 8, dev(o.t[2], n_add), bits64(0.0), N2);
+  add_col(ts, 0, e->t_user.b, 4, dev(o.t[3], n_add), 0, N2);
+  add_col(ts, 0, e->t_prio.b, 4, dev(o.t[4], n_add), 0, N2);
+  add_col(ts, 0, e->t_start.b, 8, dev(o.t[5], n_add), 0, N2);
+  add_col(ts, 0, e->t_task.b, 8, dev(o.t[6], n_add), 0, N2);
+  add_col(ts, 0, e->t_job.b, 8, dev(o.t[7], n_add), 0, N2);
+  add_col(ts, 0, e->t_pending.b, 1, dev(o.t[8], n_add), 0, N2);
+  if (N + n_add) KL("upd_compact_cols", upd_compact_cols, div_up(N + n_add, 256), 256, ts, (const int*)rm, (const SumI*)incl, N, n_add, 0u, out);
+  // pending ordinals of the new task array: exclusive count of pending rows in front (reads the NEW pending column)
+  uint32_t* pend_ord_new = ub.pend_ord_alt.ensure(std::max(1u, N2));
+  const uint8_t* pending_new = (const uint8_t*)ub.alt[ts.n_cols - 1].p;
   if (N2) {
-    int* flag = ub.flag.ensure(N2);
-    SumI* fincl = ub.incl.ensure(N2);
-    KL("upd_pending_flag", upd_pending_flag, div_up(N2, 256), 256, (const uint8_t*)e->t_pending.ptr(), N2, flag);
-    seg_scan<SumI>(e, "upd_scan", LoadI{flag}, (const uint8_t*)nullptr, N2, fincl, e->tmpI);
-    KL("upd_pend_ord", upd_pend_ord, div_up(N2, 256), 256, (const int*)flag, (const SumI*)fincl, N2, e->pend_ord.ptr());
+    SumI* fincl = ub.fincl.ensure(N2);
+    seg_scan<SumI>(e, "upd_scan", LoadPendingFlag{pending_new}, (const uint8_t*)nullptr, N2, fincl, e->tmpI);
+    KL("upd_pend_ord", upd_pend_ord, div_up(N2, 256), 256, pending_new, (const SumI*)fincl, N2, pend_ord_new);
   }
-  // ---- pending-job columns (match inputs, by pending ordinal) ------------------------------------------------------------
-  upd_column<double>(e, ub, e->j_cpus, keep_p, incl_p, P, p_keep, aj ? aj->cpus : nullptr, p_add, false, 0.0);
-  upd_column<double>(e, ub, e->j_mem, keep_p, incl_p, P, p_keep, aj ? aj->mem : nullptr, p_add, false, 0.0);
-  in.j_cpus = e->j_cpus.ptr();
-  in.j_mem = e->j_mem.ptr();
-  if (in.j_gpus) upd_column<double>(e, ub, e->j_gpus, keep_p, incl_p, P, p_keep, aj ? aj->gpus : nullptr, p_add, true, 0.0), in.j_gpus = e->j_gpus.ptr();
-  if (in.j_gpu_model)
-    upd_column<uint32_t>(e, ub, e->j_gpu_model, keep_p, incl_p, P, p_keep, aj ? aj->gpu_model : nullptr, p_add, true, 0u), in.j_gpu_model = e->j_gpu_model.ptr();
-  if (e->has_j_user) upd_column<uint32_t>(e, ub, e->j_user, keep_p, incl_p, P, p_keep, aj ? aj->user : nullptr, p_add, true, 0u);
-  if (in.j_group)
-    upd_column<uint32_t>(e, ub, e->j_group, keep_p, incl_p, P, p_keep, aj ? aj->group : nullptr, p_add, true, 0xFFFFFFFFu), in.j_group = e->j_group.ptr();
-  if (in.j_reserved_host)
-    upd_column<int32_t>(e, ub, e->j_reserved_host, keep_p, incl_p, P, p_keep, aj ? aj->reserved_host : nullptr, p_add, true, -1),
-        in.j_reserved_host = e->j_reserved_host.ptr();
-  if (in.j_ckpt) upd_column<uint32_t>(e, ub, e->j_ckpt, keep_p, incl_p, P, p_keep, aj ? aj->ckpt_location : nullptr, p_add, true, 0u), in.j_ckpt = e->j_ckpt.ptr();
-  if (in.j_est_end)
-    upd_column<int64_t>(e, ub, e->j_est_end, keep_p, incl_p, P, p_keep, aj ? aj->est_end_ms : nullptr, p_add, true, (int64_t)0), in.j_est_end = e->j_est_end.ptr();
-  if (in.j_disk_req) {
-    upd_column<double>(e, ub, e->j_disk_req, keep_p, incl_p, P, p_keep, aj ? aj->disk_request : nullptr, p_add, true, -1.0);
-    upd_column<uint32_t>(e, ub, e->j_disk_type, keep_p, incl_p, P, p_keep, aj ? aj->disk_type : nullptr, p_add, true, 0u);
-    in.j_disk_req = e->j_disk_req.ptr();
-    in.j_disk_type = e->j_disk_type.ptr();
+  UpdColSet js{};
+  {
+    int k = 0;
+    const bool pa = p_add != 0;
+    add_col(js, UPD_MAX_COLS, e->j_cpus.b, 8, dev(o.j[k++], pa), 0, P_hi);
+    add_col(js, UPD_MAX_COLS, e->j_mem.b, 8, dev(o.j[k++], pa), 0, P_hi);
+    if (in.j_gpus) add_col(js, UPD_MAX_COLS, e->j_gpus.b, 8, dev(o.j[k], pa), bits64(0.0), P_hi);
+    ++k;
+    if (in.j_gpu_model) add_col(js, UPD_MAX_COLS, e->j_gpu_model.b, 4, dev(o.j[k], pa), 0, P_hi);
+    ++k;
+    if (e->has_j_user) add_col(js, UPD_MAX_COLS, e->j_user.b, 4, dev(o.j[k], pa), 0, P_hi);
+    ++k;
+    if (in.j_group) add_col(js, UPD_MAX_COLS, e->j_group.b, 4, dev(o.j[k], pa), 0xFFFFFFFFull, P_hi);
+    ++k;
+    if (in.j_reserved_host) add_col(js, UPD_MAX_COLS, e->j_reserved_host.b, 4, dev(o.j[k], pa), 0xFFFFFFFFull /* -1 */, P_hi);
+    ++k;
+    if (in.j_ckpt) add_col(js, UPD_MAX_COLS, e->j_ckpt.b, 4, dev(o.j[k], pa), 0, P_hi);
+    ++k;
+    if (in.j_est_end) add_col(js, UPD_MAX_COLS, e->j_est_end.b, 8, dev(o.j[k], pa), 0, P_hi);
+    ++k;
+    if (in.j_disk_req) add_col(js, UPD_MAX_COLS, e->j_disk_req.b, 8, dev(o.j[k], pa), bits64(-1.0), P_hi);
+    ++k;
+    if (in.j_disk_req) add_col(js, UPD_MAX_COLS, e->j_disk_type.b, 4, dev(o.j[k], pa), 0, P_hi);
+    ++k;
+    if (in.j_ports) add_col(js, UPD_MAX_COLS, e->j_ports.b, 4, dev(o.j[k], pa), 0, P_hi);
+    ++k;
+    for (unsigned sc = 0; sc < COOK_MAX_SCALARS; ++sc, ++k)
+      if (sc < in.n_scal) add_col(js, UPD_MAX_COLS, e->j_scal[sc].b, 8, dev(o.j[k], pa), bits64(__builtin_nan("")), P_hi);
+    // the eligible mask of cook_cycle_set_considerable is indexed by pending ordinal like the job columns: it moves with them; the
+    // jobs the delta adds are eligible until the host says otherwise (a fresh mask through cook_cycle_set_considerable)
+    if (e->cb && e->cb->has_elig_by_pending) add_col(js, UPD_MAX_COLS, e->cb->elig_by_pending.b, 1, nullptr, 1ull, P_hi);
   }
-  // ports / named scalars (a new job asking for one switches the extra resource tests on)
-  if (in.j_ports) upd_column<int32_t>(e, ub, e->j_ports, keep_p, incl_p, P, p_keep, aj ? aj->ports : nullptr, p_add, true, 0), in.j_ports = e->j_ports.ptr();
-  for (unsigned sc = 0; sc < in.n_scal; ++sc) {
-    const double* col = (aj && aj->scalars && sc < aj->n_scalars) ? aj->scalars + (size_t)sc * p_add : nullptr;
-    upd_column<double>(e, ub, e->j_scal[sc], keep_p, incl_p, P, p_keep, col, p_add, true, __builtin_nan(""));
-    in.j_scal[sc] = e->j_scal[sc].ptr();
-    for (unsigned r = 0; col && r < p_add && !in.has_x; ++r) in.has_x = col[r] == col[r];
+  if (P + p_add) KL("upd_compact_cols", upd_compact_cols, div_up(P + p_add, 256), 256, js, (const int*)rm_p, (const SumI*)incl_p, P, p_add, 1u, out);
+  // ---- the two CSR columns (EQUALS constraints; hosts to avoid) ----------------------------------------------------------------
+  if (!ub.csr_known) {  // how many values the staged columns hold: the last offset (once per stage)
+    ub.csr_vals[0] = ub.csr_vals[1] = 0;
+    uint32_t* h = (uint32_t*)e->h_scratch;
+    h[0] = h[1] = 0;
+    if (in.j_eq_off && P) COOK_HIP(hipMemcpyAsync(&h[0], e->j_eq_off.ptr() + P, 4, hipMemcpyDeviceToHost, e->stream));
+    if (in.j_novel_off && P) COOK_HIP(hipMemcpyAsync(&h[1], e->j_novel_off.ptr() + P, 4, hipMemcpyDeviceToHost, e->stream));
+    sync(e);
+    ub.csr_vals[0] = h[0], ub.csr_vals[1] = h[1];
+    ub.csr_known = true;
   }
-  for (unsigned r = 0; aj && aj->ports && r < p_add && !in.has_x; ++r) in.has_x = aj->ports[r] > 0;
+  auto csr = [&](unsigned which, DArr<uint32_t>& off, DArr<uint32_t>& va, DArr<uint32_t>* vb, size_t o_off, size_t o_a, size_t o_b, unsigned add_vals) {
+    const unsigned old_vals = ub.csr_vals[which];
+    SumI* len_incl = ub.len_incl.ensure(std::max(1u, P));
+    uint32_t* n_off = ub.n_off[which].ensure((size_t)P_hi + 1);
+    uint32_t* n_a = ub.n_a[which].ensure(std::max<size_t>(1, (size_t)old_vals + add_vals));
+    uint32_t* n_b = vb ? ub.n_b[which].ensure(std::max<size_t>(1, (size_t)old_vals + add_vals)) : nullptr;
+    if (P) seg_scan<SumI>(e, "upd_scan", LoadCsrLen{off.ptr(), rm_p}, (const uint8_t*)nullptr, P, len_incl, e->tmpI);
+    KL("upd_csr", upd_csr, div_up(P + p_add + 1 + add_vals, 256), 256, (const uint32_t*)off.ptr(), (const int*)rm_p, (const SumI*)incl_p,
+       (const SumI*)len_incl, P, (const uint32_t*)va.ptr(), vb ? (const uint32_t*)vb->ptr() : (const uint32_t*)nullptr,
+       (const uint32_t*)dev(o_off, p_add != 0), (const uint32_t*)dev(o_a, add_vals != 0), (const uint32_t*)dev(o_b, add_vals != 0 && vb), p_add, add_vals,
+       n_off, n_a, n_b, which, out);
+  };
+  if (in.j_eq_off) csr(0, e->j_eq_off, e->j_eq_key, &e->j_eq_val, o.eq_off, o.eq_key, o.eq_val, add_eq);
+  if (in.j_novel_off) csr(1, e->j_novel_off, e->j_novel_host, nullptr, o.nv_off, o.nv_host, (size_t)-1, add_nv);
+  // ---- the one look at the device --------------------------------------------------------------------------------------------
+  UpdOut h{};
+  COOK_HIP(hipMemcpyAsync(e->h_scratch, out, sizeof(UpdOut), hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+  std::memcpy(&h, e->h_scratch, sizeof(UpdOut));
+  if (h.bad) e->fail(COOK_E_INVALID, "cook_cycle_update: remove_task holds an index out of range or twice");  // nothing was swapped in
+  const unsigned n_keep = N ? h.n_keep : 0u, p_keep = P ? h.p_keep : 0u;
+  if (n_keep + n_add != N2) e->fail(COOK_E_STATE, "cook_cycle_update: row count mismatch");
+  const unsigned P2 = p_keep + p_add;
+  for (const Swap& s : swaps) std::swap(s.col->p, s.alt->p), std::swap(s.col->cap, s.alt->cap);
+  std::swap(e->pend_ord.b.p, ub.pend_ord_alt.b.p), std::swap(e->pend_ord.b.cap, ub.pend_ord_alt.b.cap);
+  auto swap_arr = [](DArr<uint32_t>& a, DArr<uint32_t>& b) { std::swap(a.b.p, b.b.p), std::swap(a.b.cap, b.b.cap); };
   if (in.j_eq_off) {
-    upd_csr(e, ub, e->j_eq_off, e->j_eq_key, &e->j_eq_val, keep_p, incl_p, P, p_keep, aj ? aj->eq_off : nullptr, aj ? aj->eq_key : nullptr,
-            aj ? aj->eq_val : nullptr, p_add);
+    swap_arr(e->j_eq_off, ub.n_off[0]), swap_arr(e->j_eq_key, ub.n_a[0]), swap_arr(e->j_eq_val, ub.n_b[0]);
+    ub.csr_vals[0] = h.kept_vals[0] + add_eq;
     in.j_eq_off = e->j_eq_off.ptr(), in.j_eq_key = e->j_eq_key.ptr(), in.j_eq_val = e->j_eq_val.ptr();
   }
   if (in.j_novel_off) {
-    upd_csr(e, ub, e->j_novel_off, e->j_novel_host, nullptr, keep_p, incl_p, P, p_keep, aj ? aj->novel_off : nullptr, aj ? aj->novel_host : nullptr,
-            nullptr, p_add);
+    swap_arr(e->j_novel_off, ub.n_off[1]), swap_arr(e->j_novel_host, ub.n_a[1]);
+    ub.csr_vals[1] = h.kept_vals[1] + add_nv;
     in.j_novel_off = e->j_novel_off.ptr(), in.j_novel_host = e->j_novel_host.ptr();
   }
-  // the eligible mask of cook_cycle_set_considerable is indexed by pending ordinal like the job columns: it moves with them; the
-  // jobs the delta adds are eligible until the host says otherwise (a fresh mask through cook_cycle_set_considerable)
-  if (e->cb && e->cb->has_elig_by_pending)
-    upd_column<uint8_t>(e, ub, e->cb->elig_by_pending, keep_p, incl_p, P, p_keep, nullptr, p_add, true, (uint8_t)1);
-  sync(e);
+  in.j_cpus = e->j_cpus.ptr();
+  in.j_mem = e->j_mem.ptr();
+  if (in.j_gpus) in.j_gpus = e->j_gpus.ptr();
+  if (in.j_gpu_model) in.j_gpu_model = e->j_gpu_model.ptr();
+  if (in.j_group) in.j_group = e->j_group.ptr();
+  if (in.j_reserved_host) in.j_reserved_host = e->j_reserved_host.ptr();
+  if (in.j_ckpt) in.j_ckpt = e->j_ckpt.ptr();
+  if (in.j_est_end) in.j_est_end = e->j_est_end.ptr();
+  if (in.j_disk_req) in.j_disk_req = e->j_disk_req.ptr(), in.j_disk_type = e->j_disk_type.ptr();
+  if (in.j_ports) in.j_ports = e->j_ports.ptr();
+  for (unsigned sc = 0; sc < in.n_scal; ++sc) in.j_scal[sc] = e->j_scal[sc].ptr();
+  // ports / named scalars: a new job asking for one switches the extra resource tests on
+  for (unsigned sc = 0; sc < in.n_scal && !in.has_x; ++sc) {
+    const double* col = (aj && aj->scalars && sc < aj->n_scalars) ? aj->scalars + (size_t)sc * p_add : nullptr;
+    for (unsigned r = 0; col && r < p_add && !in.has_x; ++r) in.has_x = col[r] == col[r];
+  }
+  for (unsigned r = 0; aj && aj->ports && r < p_add && !in.has_x; ++r) in.has_x = aj->ports[r] > 0;
   e->N = N2;
   e->n_pending = P2;
   e->Kjobs = P2;
@@ -284,5 +478,8 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
   e->rank_done = false;
   e->match_done = false;
   e->has_deferred = false;
-  if (d->offers) match_stage_offers(e, d->offers);
+  if (d->offers) {
+    match_stage_offers_block(e, ub, d->offers);
+    sync(e);
+  }
 }

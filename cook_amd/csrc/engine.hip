@@ -1471,6 +1471,7 @@ int cook_cycle_stage_built_offers(cook_engine* e, const cook_tasks* tasks, const
       e->fail(COOK_E_INVALID, "cook_cycle_stage_built_offers: pending_jobs->n must equal the number of pending tasks");
     match_stage_inputs(e, pending_jobs, &o, groups, reserved_hosts, n_reserved, true);
     e->cycle_staged = true;
+    if (e->ub) e->ub->csr_known = false;  // (cycle_update.hpp: the staged CSR columns' sizes are looked up again)
   });
 }
 int cook_match_run(cook_engine* e) {
@@ -1512,6 +1513,7 @@ int cook_cycle_stage(cook_engine* e, const cook_tasks* tasks, const cook_users* 
       e->fail(COOK_E_INVALID, "cook_cycle_stage: pending_jobs->n must equal the number of pending tasks");
     match_stage_inputs(e, pending_jobs, offers, groups, reserved_hosts, n_reserved);
     e->cycle_staged = true;
+    if (e->ub) e->ub->csr_known = false;  // (cycle_update.hpp: the staged CSR columns' sizes are looked up again)
   });
 }
 // rank -> (considerable filters) -> take K -> the job index array of the match; returns K

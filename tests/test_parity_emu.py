@@ -287,6 +287,11 @@ def test_cycle_update_rejects_rows_it_cannot_append(make_engine):
             e.cycle_update((), extra.tasks, nouser, None)
         with pytest.raises(CookError, match="must equal"):
             e.cycle_update((), extra.tasks, extra.pending_jobs.take(np.arange(3)), None)
+        # a removal list is checked on the device, after the compactions ran into the columns' second buffers: nothing is swapped in
+        with pytest.raises(CookError, match="out of range or twice"):
+            e.cycle_update(np.array([3, 17, 3], np.uint32), extra.tasks, extra.pending_jobs, pool.offers)
+        with pytest.raises(CookError, match="out of range or twice"):
+            e.cycle_update(np.array([5, pool.tasks.n], np.uint32), None, None, None)
         e.cycle_run(10 ** 9)  # the refused updates left the resident state as it was
         again = e.cycle_fetch()
     assert np.array_equal(want[0], again[0]) and np.array_equal(want[1], again[1])
