@@ -136,7 +136,7 @@ void cons_run_device(cook_engine* e, ConsBufs& c, unsigned n, const double* q_cp
     if (U) std::memcpy(&h, e->h_scratch + 8, sizeof(SumU4));
     base = cook_usage{h.count, h.cpus, h.mem, h.gpus};
   }
-  if (len && c.has_pool_quota) len = queue_filter_quota(e, len, c.pool_quota, base, qitem, quse, qitem_o, quse_o);
+  if (len && c.has_pool_quota) len = queue_filter_quota(e, 2, len, c.pool_quota, base, qitem, quse, qitem_o, quse_o);
   // ---- job-allowed-to-start? + launch plugin (host-evaluated mask), then take K (scheduler.clj:747-749) --------------------------------
   if (len && q_elig) {
     e->iflag.ensure(len);

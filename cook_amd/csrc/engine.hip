@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -128,7 +129,6 @@ struct cook_engine {
   DArr<uint32_t> run_user, run_orig, run_seg, run_b2c, run_perm;
   DArr<uint64_t> run_dkey;
   DArr<double> uu_out;
-  DArr<uint8_t> uu_has;
   DArr<SumU4> uu_pre;
   DArr<double> dru, dru_out;
   ScanTmp<SumU4> tmpU4;
@@ -259,7 +259,20 @@ const T* h2d_opt(cook_engine* e, DArr<T>& d, const T* h, size_t n) {
   return d.ptr();
 }
 
-void sync(cook_engine* e) { COOK_HIP(hipStreamSynchronize(e->stream)); }
+// COOK_SYNC_TRACE=1: what the stream synchronisations of a call cost the host (stderr, per cook_rank_run)
+static const bool g_sync_trace = std::getenv("COOK_SYNC_TRACE") != nullptr;
+static thread_local double tl_sync_ms = 0.0;
+static thread_local unsigned tl_syncs = 0;
+void sync(cook_engine* e) {
+  if (!g_sync_trace) {
+    COOK_HIP(hipStreamSynchronize(e->stream));
+    return;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  COOK_HIP(hipStreamSynchronize(e->stream));
+  tl_sync_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ++tl_syncs;
+}
 
 // entries per host of a k8s "gpus" / "disk" map column pair (cookmatch.h cook_offers.gpu_slots): 0 means 1
 unsigned res_slots(cook_engine* e, uint32_t slots, const char* what) {
@@ -409,15 +422,12 @@ void rank_user_usage(cook_engine* e, double* out, bool out_is_device) {
   const unsigned N = e->N, U = e->U;
   if (U == 0) return;
   double* dst = out_is_device ? out : e->uu_out.ensure((size_t)U * 3);
-  uint8_t* has = e->uu_has.ensure(U);
-  COOK_HIP(hipMemsetAsync(has, 0, U, e->stream));
   if (N) {
     SumU4* rp = e->uu_pre.ensure(N);
-    KL("user_mark_present", user_mark_present, div_up(N, 256), 256, (const uint32_t*)e->s_user.ptr(), N, has);
     seg_scan<SumU4>(e, "user_running_scan", LoadRunningU4{e->s_use.ptr(), e->s_pending.ptr()}, (const uint8_t*)e->head.ptr(), N, rp,
                     e->tmpU4);
     KL("user_usage_extract", user_usage_extract, div_up(U, 256), 256, (const SumU4*)rp, (const SumU4*)e->s_use.ptr(),
-       (const uint8_t*)e->s_pending.ptr(), (const uint32_t*)e->seg_start.ptr(), (const uint32_t*)e->seg_end.ptr(), (const uint8_t*)has, U, dst);
+       (const uint8_t*)e->s_pending.ptr(), (const uint32_t*)e->seg_start.ptr(), (const uint32_t*)e->seg_end.ptr(), U, dst);
   } else {
     COOK_HIP(hipMemsetAsync(dst, 0, (size_t)U * 24, e->stream));
   }
@@ -426,7 +436,7 @@ void rank_user_usage(cook_engine* e, double* out, bool out_is_device) {
 }
 
 // one quota filter stage over the queue (tools.clj:917-933); returns new queue length
-unsigned queue_filter_quota(cook_engine* e, unsigned len, const cook_usage& quota, const cook_usage& base, uint32_t*& qitem,
+unsigned queue_filter_quota(cook_engine* e, unsigned stage, unsigned len, const cook_usage& quota, const cook_usage& base, uint32_t*& qitem,
                             SumU4*& quse, uint32_t*& qitem_other, SumU4*& quse_other) {
   if (len == 0) return 0;
   e->qpre.ensure(len);
@@ -434,14 +444,16 @@ unsigned queue_filter_quota(cook_engine* e, unsigned len, const cook_usage& quot
   e->scanI.ensure(len);
   LoadQueueUse ld{quse, SumU4{base.count, base.cpus, base.mem, base.gpus, 0u}};
   seg_scan<SumU4>(e, "queue_usage_scan", ld, (const uint8_t*)nullptr, len, e->qpre.ptr(), e->tmpU4);
-  unsigned* any_bad = e->d_counters.ptr() + 8;
-  COOK_HIP(hipMemsetAsync(any_bad, 0, 8, e->stream));
+  // [32 + 2 * stage]: a prefix rounded, [33 + 2 * stage]: the new length.  Stages 0 / 1 are rank_run's (zeroed by rank_init), stage 2 is
+  // the considerable filters' (which may run without a rank before them: cleared here)
+  unsigned* any_bad = e->d_counters.ptr() + 32 + 2 * stage;
+  if (stage >= 2) COOK_HIP(hipMemsetAsync(any_bad, 0, 8, e->stream));
   Usage4 q{quota.count, quota.cpus, quota.mem, quota.gpus};
   KL("queue_quota_flag", queue_quota_flag, div_up(len, 256), 256, (const SumU4*)e->qpre.ptr(), len, q, e->iflag.ptr(), any_bad);
   KL("queue_quota_fix", queue_quota_fix, 1, 64, (const SumU4*)quse, len, SumU4{base.count, base.cpus, base.mem, base.gpus, 0u}, q,
      (const unsigned*)any_bad, e->iflag.ptr());
   seg_scan<SumI>(e, "queue_compact_scan", LoadI{e->iflag.ptr()}, (const uint8_t*)nullptr, len, e->scanI.ptr(), e->tmpI);
-  unsigned* len_out = e->d_counters.ptr() + 9;
+  unsigned* len_out = any_bad + 1;
   KL("queue_compact", queue_compact, div_up(len, 256), 256, (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(),
      (const SumI*)e->scanI.ptr(), len, qitem_other, quse_other, len_out);
   unsigned h[2];
@@ -455,6 +467,8 @@ unsigned queue_filter_quota(cook_engine* e, unsigned len, const cook_usage& quot
 
 void rank_run(cook_engine* e) {
   if (!e->rank_staged) e->fail(COOK_E_STATE, "cook_rank_run before cook_rank_stage");
+  const auto t_call = std::chrono::steady_clock::now();
+  if (g_sync_trace) tl_sync_ms = 0.0, tl_syncs = 0;
   const unsigned N = e->N, U = e->U;
   e->n_ranked = 0;
   e->rank_done = false;
@@ -470,7 +484,13 @@ void rank_run(cook_engine* e) {
   const bool radix_only = std::getenv("COOK_RANK_RADIX") != nullptr;  // the tie rule as radix passes (the tests run both forms)
   unsigned long long* mins = e->d_scratch64.ptr();      // [0..2]
   unsigned long long* same = e->d_scratch64.ptr() + 4;  // [4..6] bits on which all keys of a word agree
-  COOK_HIP(hipMemsetAsync(mins, 0xFF, 7 * 8, e->stream));
+  e->seg_start.ensure(U);
+  e->seg_end.ensure(U);
+  e->inexact_user.ensure(U);
+  TieCtl* tie_ctl0 = e->tie_ctl.ensure(1);
+  bool tie_ctl_clean = true;  // until the first refinement has used it
+  KL("rank_init", rank_init, std::max(1u, std::min(div_up(U, 256), 64u)), 256, e->d_scratch64.ptr(), e->d_counters.ptr(), 40u, e->inexact_user.ptr(),
+     e->seg_end.ptr(), U, reinterpret_cast<unsigned*>(tie_ctl0), (unsigned)(sizeof(TieCtl) / 4));
   e->w0.ensure(N);
   e->w1.ensure(N);
   e->w2.ensure(N);
@@ -503,8 +523,6 @@ void rank_run(cook_engine* e) {
   e->seg_start.ensure(U);
   e->seg_end.ensure(U);
   e->pre.ensure(N);
-  e->inexact_user.ensure(U);
-  COOK_HIP(hipMemsetAsync(e->inexact_user.ptr(), 0, U * 4, e->stream));
   KL("rank_gather", rank_gather, gN, 256, (const uint32_t*)e->permB, N, (const uint32_t*)e->t_user.ptr(),
      (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(),
      e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->s_user.ptr(),
@@ -525,16 +543,14 @@ void rank_run(cook_engine* e) {
   e->dkey.ensure(N);
   e->keep.ensure(N);
   unsigned long long* orand = reinterpret_cast<unsigned long long*>(counters + 8);  // [0] OR of the kept keys, [1] OR of their complements
-  COOK_HIP(hipMemsetAsync(counters, 0, 12 * 4, e->stream));  // ([8..11] serve the queue filters later)
   KL("rank_score", rank_score, gN, 256, (const SumU4*)e->pre.ptr(), (const SumI*)e->scanI.ptr(), (const uint32_t*)e->s_user.ptr(), N,
      (int)e->params.max_over_quota_jobs, (int)e->params.dru_mode, (const double*)e->u_divc.ptr(), (const double*)e->u_divm.ptr(),
      (const double*)e->u_divg.ptr(), e->dru.ptr(), e->dkey.ptr(), e->keep.ptr(), counters, orand);
-  COOK_HIP(hipMemcpyAsync(e->h_scratch, orand, 16, hipMemcpyDeviceToHost, e->stream));
-  COOK_HIP(hipMemcpyAsync(e->h_scratch + 2, counters, 8, hipMemcpyDeviceToHost, e->stream));
+  COOK_HIP(hipMemcpyAsync(e->h_scratch, counters, 12 * 4, hipMemcpyDeviceToHost, e->stream));  // the counts and, behind them, the two key words
   sync(e);
-  vor = e->h_scratch[0], vand = ~e->h_scratch[1];
+  vor = e->h_scratch[4], vand = ~e->h_scratch[5];
   unsigned hc[2];
-  std::memcpy(hc, e->h_scratch + 2, 8);
+  std::memcpy(hc, e->h_scratch, 8);
   n_kept = hc[0];
   // --- global DRU order -------------------------------------------------------------------------------------
   e->permC1.ensure(N);
@@ -616,8 +632,9 @@ void rank_run(cook_engine* e) {
       e->thead.ensure(nk);
       e->dhead.ensure(nk);
       e->rank_of_item.ensure(n_items);
-      TieCtl* ctl = e->tie_ctl.ensure(1);
-      COOK_HIP(hipMemsetAsync(ctl, 0, sizeof(TieCtl), e->stream));
+      TieCtl* ctl = tie_ctl0;
+      if (!tie_ctl_clean) COOK_HIP(hipMemsetAsync(ctl, 0, sizeof(TieCtl), e->stream));  // (rank_init cleared it for the first refinement)
+      tie_ctl_clean = false;
       KL("tie_heads", tie_heads, gK, 256, (const uint32_t*)perm, key, nk, user_of, e->thead.ptr(), e->dhead.ptr(), (int*)nullptr,
          &ctl->equal_runs);
       constexpr int LOOK = 4;
@@ -681,8 +698,7 @@ void rank_run(cook_engine* e) {
     int* flag = e->iflag.ptr();
     KL("queue_flag_pending", queue_flag_pending, gK, 256, (const uint32_t*)e->permC, (const uint8_t*)e->s_pending.ptr(), n_kept, flag);
     seg_scan<SumI>(e, "queue_pending_scan", LoadI{flag}, (const uint8_t*)nullptr, n_kept, e->scanI.ptr(), e->tmpI);
-    unsigned* dq = e->d_counters.ptr() + 10;
-    COOK_HIP(hipMemsetAsync(dq, 0, 4, e->stream));
+    unsigned* dq = e->d_counters.ptr() + 38;  // (zeroed by rank_init)
     KL("queue_compact_pending", queue_compact_pending, gK, 256, (const uint32_t*)e->permC, (const int*)flag, (const SumI*)e->scanI.ptr(),
        n_kept, (const SumU4*)e->s_use.ptr(), qitem, quse, dq);
     COOK_HIP(hipMemcpyAsync(e->h_scratch, dq, 4, hipMemcpyDeviceToHost, e->stream));
@@ -693,10 +709,10 @@ void rank_run(cook_engine* e) {
   if (qlen && e->quota.has_pool_quota) {
     cook_usage base = e->quota.pool_usage;
     if (!e->quota.pool_usage_given) rank_pool_usage(e, &base);
-    qlen = queue_filter_quota(e, qlen, e->quota.pool_quota, base, qitem, quse, qitem_o, quse_o);
+    qlen = queue_filter_quota(e, 0, qlen, e->quota.pool_quota, base, qitem, quse, qitem_o, quse_o);
   }
   if (qlen && e->quota.has_group_quota)
-    qlen = queue_filter_quota(e, qlen, e->quota.group_quota, e->quota.group_usage, qitem, quse, qitem_o, quse_o);
+    qlen = queue_filter_quota(e, 1, qlen, e->quota.group_quota, e->quota.group_usage, qitem, quse, qitem_o, quse_o);
   // --- offensive filter (scheduler.clj:2198-2229) -----------------------------------------------------------
   const bool offensive_on = std::isfinite(e->params.offensive_max_mem_mb) || std::isfinite(e->params.offensive_max_cpus);
   if (qlen && offensive_on) {
@@ -718,6 +734,11 @@ void rank_run(cook_engine* e) {
     KL("queue_emit", queue_emit, div_up(qlen, 256), 256, (const uint32_t*)qitem, qlen, (const uint32_t*)e->permB, e->ranked.ptr());
   e->n_ranked = qlen;
   e->rank_done = true;
+  if (g_sync_trace) {
+    std::fprintf(stderr, "cook_rank_run: %u stream synchronisations, %.3f ms waiting in them, %.3f ms in the call\n", tl_syncs, tl_sync_ms,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
+    tl_sync_ms = 0.0, tl_syncs = 0;
+  }
 }
 
 void rank_fetch(cook_engine* e, uint32_t* ranked, uint32_t* n_out, double* dru_of_task) {
@@ -882,22 +903,28 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
 // engines alive per device: sizes the persistent placement kernel so that the kernels of all pools sharing a GPU are resident
 static std::atomic<int> g_engines_on_device[64];
 
+// the state a match call starts from, in ONE launch (nine memsets before round 5: each is a launch, and the set-up of a pool's match sits
+// in the chain of small launches a cycle begins with): nothing assigned, no job placed, jmin = {max, max, 0, 0}
+__global__ void __launch_bounds__(256) match_init_state_kernel(MatchState st, unsigned long long* __restrict__ jmin, unsigned K, unsigned M, unsigned G) {
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) {
+    st.ac[i] = 0.0, st.am[i] = 0.0, st.acount[i] = 0;
+    if (st.xports) {
+      st.xports[i] = 0;
+      for (unsigned s = 0; s < (unsigned)COOK_MAX_SCALARS; ++s) st.xscal[(size_t)s * M + i] = 0.0;
+    }
+  }
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += stride) st.group_last[i] = -1;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += stride) st.job_prev[i] = -1, st.job_to_offer[i] = -1;
+  if (blockIdx.x == 0 && threadIdx.x < 4) {
+    st.summary[threadIdx.x] = 0u;
+    jmin[threadIdx.x] = threadIdx.x < 2 ? 0x7F7F7F7F7F7F7F7Full : 0ull;  // [0..1] > every finite double's bit pattern; [2] a job with a
+                                                                             // negative / non-finite request was seen
+  }
+}
 void match_init_state(cook_engine* e, const MatchState& st, unsigned K, unsigned M, unsigned G) {
-  if (M && st.xports) {
-    COOK_HIP(hipMemsetAsync(st.xports, 0, (size_t)M * 4, e->stream));
-    COOK_HIP(hipMemsetAsync(st.xscal, 0, (size_t)M * 8 * COOK_MAX_SCALARS, e->stream));
-  }
-  if (M) {
-    COOK_HIP(hipMemsetAsync(st.ac, 0, (size_t)M * 8, e->stream));
-    COOK_HIP(hipMemsetAsync(st.am, 0, (size_t)M * 8, e->stream));
-    COOK_HIP(hipMemsetAsync(st.acount, 0, (size_t)M * 4, e->stream));
-  }
-  if (G) COOK_HIP(hipMemsetAsync(st.group_last, 0xFF, (size_t)G * 4, e->stream));
-  if (K) {
-    COOK_HIP(hipMemsetAsync(st.job_prev, 0xFF, (size_t)K * 4, e->stream));
-    COOK_HIP(hipMemsetAsync(st.job_to_offer, 0xFF, (size_t)K * 4, e->stream));
-  }
-  COOK_HIP(hipMemsetAsync(st.summary, 0, 16, e->stream));
+  const unsigned n = std::max(std::max(K, M), std::max(G, 1u));
+  KL("match_init_state", match_init_state_kernel, std::min(div_up(n, 256), 512u), 256, st, e->m_jmin.ptr(), K, M, G);
 }
 
 void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, const WinCtl& hc, hipStream_t stream);
@@ -1007,8 +1034,6 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     }
     if (M) KL("match_pack_offers", match_pack_offers, div_up(M, 256), 256, in, oa, ob, vb.ow);
     KL("match_pack_jobs", match_pack_jobs, div_up(K, 256), 256, in, jr, jcons);
-    COOK_HIP(hipMemsetAsync(e->m_jmin.ptr(), 0x7F, 16, e->stream));  // > every finite double's bit pattern
-    COOK_HIP(hipMemsetAsync(e->m_jmin.ptr() + 2, 0, 16, e->stream));   // [2]: a job with a negative / non-finite request was seen
     KL("match_job_minima", match_job_minima, std::min(div_up(K, 256), 256u), 256, (const JobRec*)jr, K, e->m_jmin.ptr());
     if (M) KL("match_init_alive", match_init_alive, div_up(M, 256), 256, (const OfferA*)oa, M, st.jmin, st.alive);
     WinCtl c0;

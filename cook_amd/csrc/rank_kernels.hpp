@@ -7,6 +7,21 @@
 #include "common.hpp"
 #include "scan.hpp"
 
+// ---- what a rank run wants cleared or preset, in ONE launch (each memset is a launch: the stage is bound by their number) -----------
+// scratch64[0..6] = all ones (the key minima and the words' agreeing bits), counters[0..n_counters) = 0, per-user words = 0
+__global__ void __launch_bounds__(256) rank_init(unsigned long long* __restrict__ scratch64, unsigned* __restrict__ counters, unsigned n_counters,
+                                                 uint32_t* __restrict__ inexact_user, uint32_t* __restrict__ seg_end, unsigned n_users,
+                                                 unsigned* __restrict__ tie_ctl, unsigned tie_ctl_words) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 7) scratch64[i] = ~0ull;
+  if (i < n_counters) counters[i] = 0u;
+  if (i < tie_ctl_words) tie_ctl[i] = 0u;
+  for (unsigned u = i; u < n_users; u += gridDim.x * blockDim.x) {
+    inexact_user[u] = 0u;
+    seg_end[u] = 0u;  // stays 0 for a user without tasks (rank_gather writes the others): cook_rank_user_usage reads it as "absent"
+  }
+}
+
 // ---- A.2 per-user order keys (tools.clj:614-641) --------------------------------------------------------
 // mins[0] = min start over running, mins[1] = min job id over pending, mins[2] = min task id over running
 __global__ void __launch_bounds__(256) rank_key_mins(const int64_t* __restrict__ start_ms, const int64_t* __restrict__ task_id,
@@ -473,12 +488,12 @@ struct LoadRunningU4 {
 };
 __global__ void __launch_bounds__(256) user_usage_extract(const SumU4* __restrict__ run_pre, const SumU4* __restrict__ s_use,
                                                           const uint8_t* __restrict__ s_pending, const uint32_t* __restrict__ seg_start,
-                                                          const uint32_t* __restrict__ seg_end, const uint8_t* __restrict__ has_tasks,
-                                                          unsigned n_users, double* __restrict__ out /*[U][3]*/) {
+                                                          const uint32_t* __restrict__ seg_end, unsigned n_users,
+                                                          double* __restrict__ out /*[U][3]*/) {
   const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_users) return;
   double c = 0.0, m = 0.0, g = 0.0;
-  if (has_tasks[u]) {
+  if (seg_end[u] != 0u) {  // (rank_init: 0 = the user has no task in this pool)
     const unsigned a = seg_start[u], b = seg_end[u];
     const SumU4 t = run_pre[b - 1];
     if (!t.bad) {
@@ -501,11 +516,6 @@ __global__ void __launch_bounds__(256) user_usage_extract(const SumU4* __restric
   out[(size_t)u * 3 + 1] = m;
   out[(size_t)u * 3 + 2] = g;
 }
-__global__ void __launch_bounds__(256) user_mark_present(const uint32_t* __restrict__ s_user, unsigned n, uint8_t* __restrict__ has_tasks) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) has_tasks[s_user[i]] = 1;
-}
-
 // ---- pool running usage (scheduler.clj:2118-2123, 2173): one workgroup, exactness tracked ----------------------
 // stage 1: POOL_USAGE_BLOCKS blocks fold strided slices (a single 1024-thread block took 153 us for 175k tasks: 171 dependent
 // iterations); stage 2 (pool_usage_reduce) combines the partial sums, or redoes the sum left to right when one of them rounded

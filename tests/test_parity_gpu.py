@@ -566,10 +566,9 @@ def test_match_eval_offer_split_levels(make_engine, monkeypatch, split):
     monkeypatch.setenv("COOK_EVAL_SPLIT", str(split))
     pool = synth.make_pool(seed=83, n_pending=5000, n_running=100, n_users=20, n_offers=3000, gpus=True, constraints=True)
     for ge in (1.0, 0.6):
-        P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, A.default_params(good_enough_fitness=ge))@pytest.mark.gpu
+        P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, A.default_params(good_enough_fitness=ge))
+
+
 def test_rank_tie_rule_in_tiles_and_as_radix_passes(make_engine, monkeypatch):
     P.tie_rule_forms(make_engine, monkeypatch, n_users=9000, per_user=3)  # one tie group per position, 9 000 items each: beyond a tile
     P.tie_rule_forms(make_engine, monkeypatch, n_users=150, per_user=5)
-
-
-
