@@ -29,6 +29,12 @@ static __device__ __forceinline__ double wave_read_lane_f64(double v, int src) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
 }
 
+static __device__ __forceinline__ unsigned long long wave_read_lane_u64(unsigned long long v, int src) {
+  const unsigned lo = (unsigned)wave_read_lane((int)(unsigned)v, src);
+  const unsigned hi = (unsigned)wave_read_lane((int)(unsigned)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+}
+
 // order-preserving map fp64 -> u64 (full 64 bits: DRUs of magnitude 1e-305 must still order, share.clj:95)
 static __host__ __device__ __forceinline__ uint64_t f64_key(double d) {
   uint64_t b;

@@ -1040,7 +1040,8 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     std::memset(&c0, 0, sizeof(c0));
     // the first window: a call of few jobs (config.clj:113 ships fenzo-max-jobs-considered 1000) in one go — a round that stops early costs it
     // little —, a long queue with a short one (the window then follows what the rounds resolve)
-    c0.wcur = K <= (unsigned)MV_WEVAL ? std::max(K, 1u) : std::min<unsigned>(MV_WEVAL, 128u);
+    // (up to two windows' worth: the default 1000 is forty jobs more than one evaluation covers)
+    c0.wcur = K <= 2u * (unsigned)MV_WEVAL ? std::max(std::min<unsigned>(K, MV_WEVAL), 1u) : std::min<unsigned>(MV_WEVAL, 128u);
     {
       // window growth: with several pools on one GPU the eval phase is compute-bound (evaluate few jobs twice); a pool
       // that has the GPU to itself is bound by the chain of rounds (prefer fewer, larger rounds)

@@ -62,7 +62,8 @@ struct RebalBufs {
   // dynamic
   DArr<uint32_t> x_pj, x_host, pre_hosts, co_val, hres_len, hres_base, srt_slot, gs_posB, gs_slot, gs_ord;
   DArr<uint8_t> x_known;
-  DArr<unsigned long long> hres_key;
+  DArr<unsigned long long> hres_key, blk_key;
+  DArr<uint32_t> blk_host;
   DArr<double> hres_dru, hres_c, hres_m, hres_g, gs_dru, gs_cpus, gs_mem, gs_gpus, pending_dru;
   DArr<cook_preemption> decisions;
   DArr<uint32_t> preempted;
@@ -306,6 +307,7 @@ RebalIn rebalance_args(cook_engine* e, RebalBufs& b) {
   in.x_pj = b.x_pj.ptr(), in.x_host = b.x_host.ptr(), in.x_known = b.x_known.ptr();
   in.pre_hosts = b.pre_hosts.ptr(), in.co_val = b.co_val.ptr();
   in.hres_key = b.hres_key.ptr(), in.hres_len = b.hres_len.ptr(), in.hres_base = b.hres_base.ptr();
+  in.blk_key = b.blk_key.ptr(), in.blk_host = b.blk_host.ptr(), in.n_blk = in.H ? div_up(div_up(in.H, 2u), RB_WAVES) : 0u;
   in.hres_dru = b.hres_dru.ptr(), in.hres_c = b.hres_c.ptr(), in.hres_m = b.hres_m.ptr(), in.hres_g = b.hres_g.ptr();
   in.srt_slot = b.srt_slot.ptr();
   in.gs_dru = b.gs_dru.ptr(), in.gs_cpus = b.gs_cpus.ptr(), in.gs_mem = b.gs_mem.ptr(), in.gs_gpus = b.gs_gpus.ptr();
@@ -470,6 +472,8 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   b.pre_hosts.ensure(S);
   b.co_val.ensure(b.co_cap);
   b.hres_key.ensure(std::max(1u, H));
+  b.blk_key.ensure(std::max(1u, div_up(div_up(std::max(1u, H), 2u), RB_WAVES)));
+  b.blk_host.ensure(std::max(1u, div_up(div_up(std::max(1u, H), 2u), RB_WAVES)));
   b.hres_len.ensure(std::max(1u, H));
   b.hres_base.ensure(std::max(1u, H));
   b.hres_dru.ensure(std::max(1u, H));

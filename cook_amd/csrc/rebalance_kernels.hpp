@@ -129,6 +129,10 @@ struct RebalIn {
   uint32_t* co_val;     // cohost values of the current job's group
   // per-host results of rebal_decide
   unsigned long long* hres_key;  // f64_key(dru) of the host's best prefix, 0 = none
+  // the best host of every rebal_decide workgroup (greatest key, the later host on ties): what rebal_apply scans instead of all hosts
+  unsigned long long* blk_key;
+  uint32_t* blk_host;
+  unsigned n_blk;
   uint32_t *hres_len, *hres_base;
   double *hres_dru, *hres_c, *hres_m, *hres_g;
   uint32_t* srt_slot;  // [S] the host's candidates in priority order at [hres_base ...]
@@ -1018,11 +1022,31 @@ static __device__ __forceinline__ void rebal_host_pair(const RebalIn& in, const 
 template <bool SAFE>
 __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) {
   __shared__ uint32_t l_rank[RB_WAVES][COOK_WAVE];
+  __shared__ unsigned long long s_bk[RB_WAVES];
+  __shared__ unsigned s_bh[RB_WAVES];
   const RebalJob jb = *in.job;
   if (!jb.active) return;
   const unsigned lane = lane_id(), w = wave_id();
   const unsigned h0 = (blockIdx.x * RB_WAVES + w) * 2u;
-  if (h0 >= in.H) return;
+  // the wave's better host (the later one on ties), then the workgroup's: rebal_apply's arg-max reads one entry per workgroup
+  unsigned long long wk = 0ull;
+  unsigned wh = 0u;
+  auto publish = [&] {
+    if (lane == 0) s_bk[w] = wk, s_bh[w] = wh;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long bk = 0ull;
+      unsigned bh = 0u;
+      for (int k = 0; k < RB_WAVES; ++k)
+        if (s_bk[k] != 0ull && s_bk[k] >= bk) bk = s_bk[k], bh = s_bh[k];
+      in.blk_key[blockIdx.x] = bk;
+      in.blk_host[blockIdx.x] = bh;
+    }
+  };
+  if (h0 >= in.H) {
+    publish();
+    return;
+  }
   const bool two = h0 + 1u < in.H;
   const unsigned n0 = in.hend[h0] - in.hstart[h0] + in.x_cnt[h0];
   const unsigned n1 = two ? in.hend[h0 + 1u] - in.hstart[h0 + 1u] + in.x_cnt[h0 + 1u] : 0u;
@@ -1041,6 +1065,10 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) 
         in.hres_g[h] = hb.g;
       }
     }
+    const unsigned long long k0 = wave_read_lane_u64(hb.key, 0), k1 = two ? wave_read_lane_u64(hb.key, 32) : 0ull;
+    if (k1 != 0ull && k1 >= k0) wk = k1, wh = h0 + 1u;
+    else wk = k0, wh = h0;
+    publish();
     return;
   }
   for (unsigned q = 0; q < (two ? 2u : 1u); ++q) {
@@ -1067,7 +1095,9 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) 
         in.hres_g[h] = hb.g;
       }
     }
+    if (hb.key != 0ull && hb.key >= wk) wk = hb.key, wh = h;  // (wave-uniform)
   }
+  publish();
 }
 
 // hosts with more than 64 items: lists in LDS (<= RB_CAP) or in the host's region of the global scratch.  Such hosts are few or none
@@ -1285,16 +1315,24 @@ __global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in, unsi
   // thread: a dependent one-load-per-iteration loop over 50k hosts was the larger half of this kernel.
   unsigned long long bk = 0ull;
   unsigned bh = 0;
-  for (unsigned h0 = tid; h0 < in.H; h0 += 8u * RB_APPLY_THREADS) {
+  for (unsigned b0 = tid; b0 < in.n_blk; b0 += 8u * RB_APPLY_THREADS) {  // one entry per rebal_decide workgroup (eight hosts)
     unsigned long long k[8];
+    unsigned hh[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const unsigned h = h0 + (unsigned)q * RB_APPLY_THREADS;
-      k[q] = h < in.H ? in.hres_key[h] : 0ull;
+      const unsigned b = b0 + (unsigned)q * RB_APPLY_THREADS;
+      k[q] = b < in.n_blk ? in.blk_key[b] : 0ull;
+      hh[q] = b < in.n_blk ? in.blk_host[b] : 0u;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      if (k[q] != 0ull && k[q] >= bk) bk = k[q], bh = h0 + (unsigned)q * RB_APPLY_THREADS;  // hosts ascend: the later host wins ties
+      if (k[q] != 0ull && k[q] >= bk) bk = k[q], bh = hh[q];  // workgroups ascend with their hosts: the later host wins ties
+  }
+  // hosts of more than 64 items are rebal_decide_big's: their keys are not in any workgroup's entry
+  for (unsigned x = tid; x < in.ctl->n_big; x += RB_APPLY_THREADS) {
+    const unsigned h = in.big_list[x];
+    const unsigned long long k = in.hres_key[h];
+    if (k != 0ull && in.hend[h] - in.hstart[h] + in.x_cnt[h] > (unsigned)COOK_WAVE && (k > bk || (k == bk && h > bh))) bk = k, bh = h;
   }
   for (int d = 32; d >= 1; d >>= 1) {
     const unsigned long long ok = __shfl_xor(bk, d, COOK_WAVE);
