@@ -16,24 +16,12 @@
 
 constexpr unsigned TS_THREADS = COOK_SHAPE(1024, 256);
 constexpr unsigned TS_NOMINAL = COOK_SHAPE(1024, 64);   // positions per workgroup before the spill of its last segment
-constexpr unsigned TS_CAP = COOK_SHAPE(8192, 256);      // 12 B of LDS per item
+constexpr unsigned TS_CAP = COOK_SHAPE(8192, 256);      // 12 B of LDS per item (tiles of 512 / 4096 with 512 threads: 54 us per launch against 39 — the launch lasts as long as the tile with the longest group)
 constexpr unsigned TS_LIDX_BITS = 13;
 static_assert(TS_CAP <= (1u << TS_LIDX_BITS), "a local index is 13 bits of the sort keys");
 static_assert((TS_CAP & (TS_CAP - 1)) == 0, "bitonic network sizes");
 constexpr unsigned TS_MAX_GROUP = TS_CAP - TS_NOMINAL + 1;  // the longest segment a tile takes for certain
 
-// first position >= pos that starts a segment (n when there is none); wave-uniform, every lane of the calling wave takes part
-static __device__ __forceinline__ unsigned ts_next_head(const uint8_t* __restrict__ head, unsigned pos, unsigned n) {
-  for (;; pos += COOK_WAVE) {
-    if (pos >= n) return n;
-    const unsigned p = pos + lane_id();
-    const unsigned long long m = __ballot(p >= n || head[p] != 0);
-    if (m) {
-      const unsigned r = pos + (unsigned)__ffsll(m) - 1u;
-      return r < n ? r : n;
-    }
-  }
-}
 // last position <= pos that starts a segment (position 0 always does)
 static __device__ __forceinline__ unsigned ts_prev_head(const uint8_t* __restrict__ head, unsigned pos) {
   for (;;) {
@@ -45,14 +33,28 @@ static __device__ __forceinline__ unsigned ts_prev_head(const uint8_t* __restric
   }
 }
 
-// the tile of workgroup b: [lo, hi) = the segments whose first position lies in [b * nominal, (b + 1) * nominal)
-static __device__ __forceinline__ void ts_tile_bounds(const uint8_t* __restrict__ head, unsigned n, unsigned nominal, unsigned* s_b /*[2] LDS*/) {
-  if (wave_id() == 0) {
-    const unsigned a = blockIdx.x * nominal;
-    const unsigned lo = blockIdx.x == 0 ? 0u : ts_next_head(head, a, n);
-    const unsigned hi = ts_next_head(head, a + nominal, n);
-    if (lane_id() == 0) s_b[0] = lo, s_b[1] = hi;
+// the tile of workgroup b: [lo, hi) = the segments whose first position lies in [b * nominal, (b + 1) * nominal).  The whole workgroup
+// looks for the two heads, blockDim positions per step: a wave stepping through a 2 271-item group 64 positions at a time was a chain
+// of 36 dependent loads, 25 of the launch's 39 us (the launch lasts as long as its slowest tile).
+static __device__ __forceinline__ unsigned ts_block_next_head(const uint8_t* __restrict__ head, unsigned pos, unsigned n, unsigned* s_min) {
+  for (;; pos += blockDim.x) {
+    if (threadIdx.x == 0) *s_min = 0xFFFFFFFFu;
+    __syncthreads();
+    const unsigned p = pos + threadIdx.x;
+    const bool hit = p >= n || head[p] != 0;
+    const unsigned long long m = __ballot(hit);
+    if (m && lane_id() == (unsigned)__ffsll(m) - 1u) atomicMin(s_min, p < n ? p : n);  // one atomic per wave
+    __syncthreads();
+    const unsigned r = *s_min;
+    __syncthreads();  // (everyone has read it before the next step resets it)
+    if (r != 0xFFFFFFFFu) return r;
   }
+}
+static __device__ __forceinline__ void ts_tile_bounds(const uint8_t* __restrict__ head, unsigned n, unsigned nominal, unsigned* s_b /*[3] LDS*/) {
+  const unsigned a = blockIdx.x * nominal;
+  const unsigned lo = blockIdx.x == 0 ? 0u : ts_block_next_head(head, a, n, &s_b[2]);
+  const unsigned hi = a + nominal >= n ? n : ts_block_next_head(head, a + nominal, n, &s_b[2]);
+  if (threadIdx.x == 0) s_b[0] = lo, s_b[1] = hi;
   __syncthreads();
 }
 
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(TS_THREADS) tie_sort_tiles(uint32_t* __restric
   if (ctl->equal_runs || (round > 0 && ctl->tied_after[round - 1] == 0)) return;
   __shared__ uint64_t s_key[TS_CAP];
   __shared__ uint32_t s_item[TS_CAP];
-  __shared__ unsigned s_b[2], s_any;
+  __shared__ unsigned s_b[3], s_any;
   if (threadIdx.x == 0) s_any = 0;
   ts_tile_bounds(dhead, nk, TS_NOMINAL, s_b);  // tiles follow the groups of EQUAL KEYS: the refined heads move while other tiles look
   const unsigned lo = s_b[0], hi = s_b[1];
