@@ -925,7 +925,67 @@ def _concat_jobs(a: A.Jobs, b: A.Jobs) -> A.Jobs:
             va = getattr(a, v) if getattr(a, off) is not None else np.zeros(0, np.uint32)
             vb_ = getattr(b, v) if getattr(b, off) is not None else np.zeros(0, np.uint32)
             kw[v] = np.concatenate([va[:oa[na]], vb_[:ob[nb]]]).astype(np.uint32)
+    for name, dflt in (("ports", 0), ("scalars", np.nan)):
+        xa, xb = getattr(a, name), getattr(b, name)
+        if xa is None and xb is None:
+            continue
+        ref = xa if xa is not None else xb
+        shape = lambda n: (n,) + ref.shape[1:]  # noqa: E731
+        fa = xa if xa is not None else np.full(shape(na), dflt, dtype=ref.dtype)
+        fb = xb if xb is not None else np.full(shape(nb), dflt, dtype=ref.dtype)
+        kw[name] = np.concatenate([fa, fb])
     return A.Jobs(**kw)
+
+
+def cycle_update_xres_parity(make_engine, seed, n=260, m=60, n_add=70, n_remove=50):
+    """cook_cycle_update with every optional column on both sides of the delta: jobs with ports, two named scalars, gpu models, disk
+    requests, EQUALS / novel-host constraints; fresh offers with ports, scalars, slot tables of two gpu models / disk types and an
+    attribute column.  The delta travels as ONE block (cycle_update.hpp): a column laid out wrongly in it shows here.
+    == cook_cycle_stage of the updated arrays (fresh engine) == oracle."""
+    rng = np.random.default_rng(seed)
+    p = A.default_params()
+    J1, O1, _ = xres_random_case(seed, n, m, ports=True, scalars=2, slots=2, constraints=True)
+    J2, O2, _ = xres_random_case(seed + 1, n_add, m + 9, ports=True, scalars=2, slots=2, constraints=True)
+    n_users = 9
+    J1.user = rng.integers(0, n_users, n).astype(np.uint32)
+    J2.user = rng.integers(0, n_users, n_add).astype(np.uint32)
+
+    def tasks_of(J, base):
+        k = J.n
+        return A.Tasks(cpus=J.cpus, mem=J.mem, gpus=J.gpus, user=J.user, priority=rng.integers(0, 100, k).astype(np.int32),
+                       start_ms=np.zeros(k, np.int64), task_id=np.zeros(k, np.int64), job_id=(base + np.arange(k)).astype(np.int64),
+                       pending=np.ones(k, np.uint8))
+    T1, T2 = tasks_of(J1, 1000), tasks_of(J2, 9000)
+    users = A.Users(div_cpus=np.full(n_users, 40.0), div_mem=np.full(n_users, 65536.0), div_gpus=np.full(n_users, 4.0))
+    remove = np.sort(rng.choice(n, size=n_remove, replace=False)).astype(np.uint32)
+    keep = np.ones(n, bool)
+    keep[remove] = False
+    cat = lambda a, b: np.concatenate([a[keep], b])  # noqa: E731
+    T12 = A.Tasks(cpus=cat(T1.cpus, T2.cpus), mem=cat(T1.mem, T2.mem), gpus=cat(T1.gpus, T2.gpus), user=cat(T1.user, T2.user),
+                  priority=cat(T1.priority, T2.priority), start_ms=cat(T1.start_ms, T2.start_ms), task_id=cat(T1.task_id, T2.task_id),
+                  job_id=cat(T1.job_id, T2.job_id), pending=cat(T1.pending, T2.pending))
+    J12 = _concat_jobs(J1.take(np.nonzero(keep)[0]), J2)
+    with make_engine(p) as e:
+        e.cycle_stage(T1, users, J1, O1, None)
+        e.cycle_run(10 ** 9)
+        e.cycle_update(remove, T2, J2, O2)
+        e.cycle_run(10 ** 9)
+        got = e.cycle_fetch()
+        e.cycle_update(np.zeros(0, np.uint32), None, None, O1)  # the offers alone, back to the first set
+        e.cycle_run(10 ** 9)
+        got_b = e.cycle_fetch()
+    for off, got_x in ((O2, got), (O1, got_b)):
+        with make_engine(p) as e:
+            e.cycle_stage(T12, users, J12, off, None)
+            e.cycle_run(10 ** 9)
+            want = e.cycle_fetch()
+        assert np.array_equal(got_x[0], want[0]) and np.array_equal(got_x[1], want[1]) and got_x[2] == want[2]
+        o_ranked, _ = pyoracle.rank(p, T12, users)
+        assert np.array_equal(got_x[0], o_ranked)
+        o_j2o, _, o_head = pyoracle.match(p, J12.take(o_ranked), off, None)
+        assert np.array_equal(got_x[1], o_j2o) and got_x[2] == o_head
+    assert (got[1] >= 0).sum() > 0
+    return got
 
 
 def cycle_update_parity(make_engine, seed, n_pending=900, n_running=400, n_users=30, n_offers=120, n_remove=150, n_add=200, new_offers=True, k=10 ** 9):

@@ -297,6 +297,11 @@ def test_cycle_update_rejects_rows_it_cannot_append(make_engine):
     assert np.array_equal(want[0], again[0]) and np.array_equal(want[1], again[1])
 
 
+@pytest.mark.parametrize("seed", [611, 612])
+def test_cycle_update_with_every_optional_column(make_engine, seed):
+    P.cycle_update_xres_parity(make_engine, seed)
+
+
 def test_cycle_update_moves_the_eligible_mask(make_engine):
     P.cycle_update_mask_parity(make_engine, seed=77)
 

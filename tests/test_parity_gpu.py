@@ -286,6 +286,11 @@ def test_lockstep_chain_of_pools_that_disagree(make_engine):
         P.mixed_chain_parity(make_engine, pools, params, [120 if i % 3 == 0 else 10 ** 9 for i in range(n)])
 
 
+@pytest.mark.parametrize("seed", [611, 612])
+def test_cycle_update_with_every_optional_column(make_engine, seed):
+    P.cycle_update_xres_parity(make_engine, seed)
+
+
 def test_cycle_update_moves_the_eligible_mask(make_engine):
     P.cycle_update_mask_parity(make_engine, seed=77)
 
