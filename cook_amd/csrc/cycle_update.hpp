@@ -12,8 +12,8 @@
 //   * ALL task columns are compacted by one launch and all pending-job columns by another (a table of column descriptors in the
 //     kernel arguments), into second buffers that are swapped in only when the call has succeeded — a removal list that names a row
 //     twice or out of range leaves the resident state as it was;
-//   * row counts stay on the device until one read-back at the end (buffers are sized by what the host knows: N - n_remove + n_add
-//     rows when the list is valid, every old value of a CSR column plus the new ones);
+//   * row counts stay on the device until one read-back at the end (buffers are sized by bounds the host knows whatever the removal
+//     list holds: every old row plus the new ones, every old value of a CSR column plus the new ones);
 //   * the fresh offers are one block too, used in place (match_stage_offers_block).
 // Included by engine.hip (uses its DArr / KL / seg_scan helpers).
 #pragma once
@@ -281,6 +281,7 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
       if (aj->group[r] != COOK_NONE_U32 && aj->group[r] >= e->G) e->fail(COOK_E_INVALID, "cook_cycle_update: group id out of range");
   if (in.j_disk_req && p_add && aj->disk_request && !aj->disk_type) e->fail(COOK_E_INVALID, "cook_cycle_update: disk_request without disk_type");
   const unsigned N2 = N - d->n_remove + n_add;  // (when the removal list is valid; the device says at the end)
+  const unsigned N_hi = N + n_add;              // rows the compaction can write whatever the list holds (an entry named twice removes one row)
   const unsigned P_hi = P + p_add;              // the pending jobs can only be bounded until then
   // ---- the delta as one block -----------------------------------------------------------------------------------------------
   struct Offs {
@@ -355,18 +356,18 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
     return b;
   };
   UpdColSet ts{};
-  add_col(ts, 0, e->t_cpus.b, 8, dev(o.t[0], n_add), 0, N2);
-  add_col(ts, 0, e->t_mem.b, 8, dev(o.t[1], n_add), 0, N2);
-  if (e->has_gpus) add_col(ts, 0, e->t_gpus.b, 8, dev(o.t[2], n_add), bits64(0.0), N2);
-  add_col(ts, 0, e->t_user.b, 4, dev(o.t[3], n_add), 0, N2);
-  add_col(ts, 0, e->t_prio.b, 4, dev(o.t[4], n_add), 0, N2);
-  add_col(ts, 0, e->t_start.b, 8, dev(o.t[5], n_add), 0, N2);
-  add_col(ts, 0, e->t_task.b, 8, dev(o.t[6], n_add), 0, N2);
-  add_col(ts, 0, e->t_job.b, 8, dev(o.t[7], n_add), 0, N2);
-  add_col(ts, 0, e->t_pending.b, 1, dev(o.t[8], n_add), 0, N2);
+  add_col(ts, 0, e->t_cpus.b, 8, dev(o.t[0], n_add), 0, N_hi);
+  add_col(ts, 0, e->t_mem.b, 8, dev(o.t[1], n_add), 0, N_hi);
+  if (e->has_gpus) add_col(ts, 0, e->t_gpus.b, 8, dev(o.t[2], n_add), bits64(0.0), N_hi);
+  add_col(ts, 0, e->t_user.b, 4, dev(o.t[3], n_add), 0, N_hi);
+  add_col(ts, 0, e->t_prio.b, 4, dev(o.t[4], n_add), 0, N_hi);
+  add_col(ts, 0, e->t_start.b, 8, dev(o.t[5], n_add), 0, N_hi);
+  add_col(ts, 0, e->t_task.b, 8, dev(o.t[6], n_add), 0, N_hi);
+  add_col(ts, 0, e->t_job.b, 8, dev(o.t[7], n_add), 0, N_hi);
+  add_col(ts, 0, e->t_pending.b, 1, dev(o.t[8], n_add), 0, N_hi);
   if (N + n_add) KL("upd_compact_cols", upd_compact_cols, div_up(N + n_add, 256), 256, ts, (const int*)rm, (const SumI*)incl, N, n_add, 0u, out);
   // pending ordinals of the new task array: exclusive count of pending rows in front (reads the NEW pending column)
-  uint32_t* pend_ord_new = ub.pend_ord_alt.ensure(std::max(1u, N2));
+  uint32_t* pend_ord_new = ub.pend_ord_alt.ensure(std::max(1u, N_hi));
   const uint8_t* pending_new = (const uint8_t*)ub.alt[ts.n_cols - 1].p;
   if (N2) {
     SumI* fincl = ub.fincl.ensure(N2);

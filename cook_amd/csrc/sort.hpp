@@ -15,7 +15,8 @@
 // kept [block][digit] and every scatter block sums the columns itself (the counts of each digit over the earlier blocks and over all
 // blocks: 16-byte loads, a wave per fourth of the rows) — the single-workgroup scan and its launch gap were a third of a pass
 // (9.6 + ~5 us of 45 + 15, profiles/r02k), and a chain of passes is what the rank stage is made of.
-// The host skips digits that are constant over the whole input (radix_varying_bits) and starts every digit at the lowest
+// The host skips digits that are constant over the whole input (radix_varying_bits, or the kernel that builds the keys:
+// rank_build_keys) and starts every digit at the lowest
 // varying bit not sorted yet, so sparse varying bits do not cost a pass per byte they touch.
 #pragma once
 #include "common.hpp"

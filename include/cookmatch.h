@@ -334,7 +334,9 @@ int cook_cycle_stage(cook_engine* e, const cook_tasks* tasks, const cook_users* 
  * of add_tasks, in order, and may only carry optional columns that the staged jobs carry too (else restage); cpus and mem are
  * required, and so is `user` when the staged jobs carry one.  Users, groups and reserved hosts stay as staged.  The eligible mask
  * of cook_cycle_set_considerable moves with the job rows (the jobs a delta adds start out eligible; send a fresh mask to say
- * otherwise).  ABI note: the struct layouts of this header are versioned by COOK_ABI_VERSION (cook_abi_version()). */
+ * otherwise).  The call is all-or-nothing: a delta it refuses (COOK_E_INVALID — a row it cannot append, a remove_task entry out of
+ * range or named twice, which the device finds) leaves the resident state as it was; the host arrays are read during the call only.
+ * ABI note: the struct layouts of this header are versioned by COOK_ABI_VERSION (cook_abi_version()). */
 typedef struct cook_cycle_delta {
   uint32_t n_remove;
   const uint32_t* remove_task;  /* indices into the current task arrays, each at most once */
