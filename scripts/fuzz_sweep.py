@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Seeded random sweep of the engine against the oracle (TEST TOOL): small random configurations of rank / cycle / match / explain
-and of the rebalancer, both match_algo values, eval split caps, ports / named scalars, k8s gpu maps with several entries.
+"""Seeded random sweep of the engine against the oracle (TEST TOOL): small random configurations of rank / cycle / match / explain /
+cycle update and of the rebalancer, both match_algo values, eval split caps, ports / named scalars, k8s gpu maps with several entries.
 `--emu` runs the SIMT-emulator build on the CPU, otherwise libcookmatch.so on the GPU.  Prints one line; exit 1 on the first
 difference (with the configuration that produced it)."""
 import argparse
@@ -68,6 +68,12 @@ def main():
             j2o = P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, reserved=reserved)
             if (j2o < 0).any():
                 P.explain_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, p, max_pos=6, tag=str(kw))
+            if it % 4 == 0:  # cook_cycle_update against a restage of the updated arrays and the oracle
+                npd, nrn = int(rng.integers(1, int(500 * sc))), int(rng.integers(0, int(200 * sc)))
+                P.cycle_update_parity(make_engine, seed=int(rng.integers(1, 1 << 30)), n_pending=npd, n_running=nrn, n_users=int(rng.integers(1, 30)),
+                                      n_offers=int(rng.integers(1, int(200 * sc))), n_remove=int(rng.integers(0, npd + nrn + 1)),
+                                      n_add=int(rng.integers(0, int(300 * sc))), new_offers=bool(rng.integers(0, 2)),
+                                      k=int(rng.choice([10 ** 9, 50])))
         except AssertionError as ex:
             print("FAIL match", it, kw, p.match_algo, p.good_enough_fitness, os.environ["COOK_EVAL_SPLIT"], str(ex)[:300])
             sys.exit(1)
