@@ -261,6 +261,7 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per pool stream (read at HIP initialisation; see cook_amd/engine.py)
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # (the default of this ROCm build; see cook_amd/engine.py)
     import torch
     import torch.distributed as dist
 
