@@ -177,67 +177,92 @@ def extra_c5(device, check=True, steps=3, sizes=(1_000_000, 500_000, 10_000, 50_
 def cpu_baseline_leg(args, params, cluster, pools, my_pools, K, n_off):
     """The oracle ("port": C++ restatement of the reference algorithm, TEST INFRASTRUCTURE used here only as the timed CPU leg and as
     the checker) on this box's host cores, over the whole cycle of the pools held by this process.  -> (cpu_baseline dict,
-    {pool: (ranked, j2o)} of the oracle for the parity check)."""
+    {pool: (ranked, j2o)} of the oracle for the parity check).
+
+    The reference runs one match handler per pool concurrently (tools.clj:799-806, scheduler.clj:2425-2435) and Fenzo spreads a
+    job's host evaluation over an executor per CPU (built at scheduler.clj:2301-2324), so the forms timed are `a` pools at once x
+    `t` evaluator threads per pool for every (a, t) with a x t <= the host's cores; `value` = the fastest.  Inside the timed region
+    a pool thread makes ONE library call (oracle_cycle: rank -> gather -> placement) — the interpreter lock is released for all of
+    it; the call's own clocks (rank / gather / match seconds per pool) are reported next to the wall time."""
     import threading
     from oracle import pyoracle
     host_cores = os.cpu_count() or 1
+    try:
+        host_cores = min(host_cores, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
     P = len(my_pools)
     quota = {p: cluster.quota_inputs(p, cluster.last_pool_usage[p], cluster.last_group_usage) for p in my_pools}
     threaded_ok = args.good_enough >= 1.0  # (the oracle's host-bucketed form is best fit only)
+    cap = max(1, min(args.cpu_threads or host_cores, host_cores))
+    for p in my_pools:  # ctypes views of the columns built once, outside every timed region
+        pools[p].tasks.as_struct(), pools[p].pending_jobs.as_struct(), pools[p].offers.as_struct()
 
     def one_pool(p, nt, out):
-        c0 = time.perf_counter()
-        o_ranked, _ = pyoracle.rank(params, pools[p].tasks, pools[p].users, quota=quota[p])
-        c1 = time.perf_counter()
-        kk = min(K, len(o_ranked))
-        pend_ord = np.cumsum(pools[p].tasks.pending) - 1
-        cons = pools[p].pending_jobs.take(pend_ord[o_ranked[:kk]])
-        c2 = time.perf_counter()
-        o_j2o, _, _ = pyoracle.match(params, cons, pools[p].offers, pools[p].groups, nthreads=nt)
-        c3 = time.perf_counter()
-        out[p] = (o_ranked, o_j2o, c1 - c0, c3 - c2)
+        out[p] = pyoracle.cycle(params, pools[p].tasks, pools[p].users, pools[p].pending_jobs, pools[p].offers, pools[p].groups,
+                                quota=quota[p], K=K, nthreads=nt)
 
-    def concurrent(nt):
+    def batch(which, nt):
         out = {}
-        ths = [threading.Thread(target=one_pool, args=(p, nt, out)) for p in my_pools]
+        ths = [threading.Thread(target=one_pool, args=(p, nt, out)) for p in which]
         a = time.perf_counter()
         for t in ths:
             t.start()
         for t in ths:
             t.join()
         wall = time.perf_counter() - a
-        assert len(out) == P, "an oracle thread failed"
+        assert len(out) == len(which), "an oracle thread failed"
         return wall, out
 
-    variants = []
-    cap = args.cpu_threads or host_cores
-    wall1, ref = concurrent(1)
-    variants.append({"form": "pools concurrent", "pools_at_once": P, "threads_per_pool": 1, "cores": min(P, host_cores), "cycle_s": wall1,
-                     "cycles_per_s": 1.0 / wall1})
-    t_per = min(16, max(1, cap // max(1, P)))
-    if threaded_ok and t_per > 1:
-        wall_t, out_t = concurrent(t_per)
-        for p in my_pools:
-            if not (np.array_equal(out_t[p][0], ref[p][0]) and np.array_equal(out_t[p][1], ref[p][1])):
-                raise AssertionError("oracle: threaded and single-thread placements differ")
-        variants.append({"form": "pools concurrent", "pools_at_once": P, "threads_per_pool": t_per, "cores": min(P * t_per, host_cores),
-                         "cycle_s": wall_t, "cycles_per_s": 1.0 / wall_t})
-    nt_serial = min(16, cap)
-    if threaded_ok and nt_serial > 1:  # the previous rounds' form: one pool at a time, hosts bucketed over up to 16 threads
-        one = {}
-        one_pool(my_pools[0], nt_serial, one)
-        _, _, rank_s, match_s = one[my_pools[0]]
-        variants.append({"form": "pools one after the other (pool 0 timed, x pools)", "pools_at_once": 1, "threads_per_pool": nt_serial,
-                         "cores": nt_serial, "cycle_s": (rank_s + match_s) * P, "cycles_per_s": 1.0 / ((rank_s + match_s) * P)})
+    def run_form(at_once, nt):
+        """All of this process's pools, `at_once` of them side by side, the batches one after the other."""
+        wall, out, slack = 0.0, {}, 0.0
+        for b in range(0, P, at_once):
+            w, o = batch(my_pools[b:b + at_once], nt)
+            wall += w
+            out.update(o)
+            slack = max(slack, w / max(1e-9, max(sum(o[p][2].values()) for p in o)))
+        return wall, out, slack
+
+    forms, a = [], P
+    while a >= 1:  # pools at once: P, P/2, ... 1;  threads per pool: 1, 2, 4, ... while a x t fits the cores
+        t = 1
+        while a * t <= cap and t <= 64:
+            if (threaded_ok or t == 1) and not (a < P and t == 1):
+                forms.append((a, t))
+            t *= 2
+        a //= 2
+    if (P, 1) not in forms and P > cap:  # fewer cores than pools: as many pools at once as there are cores
+        forms.insert(0, (cap, 1))
+    variants, ref, budget_s = [], None, 90.0
+    t_begin = time.perf_counter()
+    for at_once, nt in forms:
+        if variants and time.perf_counter() - t_begin > budget_s:
+            break
+        wall, out, slack = run_form(at_once, nt)
+        if slack > 1.1:  # the wall time must be the slowest pool's library call, not the harness: once more before it is reported as is
+            wall, out, slack = run_form(at_once, nt)
+        if ref is None:
+            ref = out
+        else:
+            for p in my_pools:
+                if not (np.array_equal(out[p][0], ref[p][0]) and np.array_equal(out[p][1], ref[p][1])):
+                    raise AssertionError("oracle: threaded and single-thread placements differ")
+        variants.append({"form": "pools concurrent" if at_once >= P else f"{at_once} pool(s) at a time", "pools_at_once": at_once,
+                         "threads_per_pool": nt, "cores": min(at_once * nt, host_cores), "cycle_s": wall, "cycles_per_s": 1.0 / wall,
+                         "wall_over_slowest_library_call": round(slack, 3),
+                         "slowest_pool_s": {k: round(max(out[p][2][k] for p in my_pools), 4) for k in ("rank", "gather", "match")}})
     best = max(variants, key=lambda v: v["cycles_per_s"])
+    p0 = ref[my_pools[0]][2]
     cpu = {"value": best["cycles_per_s"], "unit": "cycles/s", "cores": best["cores"], "kind": "port",
            "sample": f"the whole cycle (not a sample): oracle rank + placement of all K = {K} considerable jobs x {n_off} offers of each of the {P} "
-                     f"pools; fastest form: {best['form']}, {best['threads_per_pool']} thread(s) per pool, {best['cycle_s']:.2f} s per cycle",
-           "variants": variants, "host_cores": host_cores,
-           "rank_s_pool0": ref[my_pools[0]][2], "match_s_pool0_single_thread": ref[my_pools[0]][3],
-           "note": "C++ restatement (-O2) of the reference algorithm; the JVM reference cannot run here (no JDK, Fenzo jar absent). The reference "
-                   "runs one match handler per pool concurrently (tools.clj:799-806), which the 'pools concurrent' forms reproduce; the "
-                   "threads-per-pool form synchronises its workers once per job (barrier-bound at 6 250 hosts per job)."}
+                     f"pools; fastest form: {best['pools_at_once']} pool(s) at once x {best['threads_per_pool']} thread(s) per pool = "
+                     f"{best['cores']} cores, {best['cycle_s']:.3f} s per cycle",
+           "variants": variants, "host_cores": host_cores, "harness_overhead_ok": all(v["wall_over_slowest_library_call"] <= 1.1 for v in variants),
+           "rank_s_pool0": p0["rank"], "gather_s_pool0": p0["gather"], "match_s_pool0_single_thread": p0["match"],
+           "note": "C++ restatement (-O2) of the reference algorithm; the JVM reference cannot run here (no JDK, Fenzo jar absent). One library "
+                   "call per pool thread inside the timed region (rank -> gather -> placement, interpreter lock released); the threads-per-pool "
+                   "forms bucket a job's hosts over persistent workers that meet once per job (Fenzo's executor-per-CPU evaluation)."}
     return cpu, {p: (ref[p][0], ref[p][1]) for p in my_pools}
 
 
@@ -399,12 +424,10 @@ def main():
                                                  sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]}}
 
     # ---- CPU baseline: the oracle (kind "port") on the box's host cores, the WHOLE cycle of rank 0's pools ------------------
-    # The reference runs every pool's match handler on its own thread (tools.clj:799-806 chime-at per pool, scheduler.clj:2425-2435),
-    # so the faithful use of a many-core host is all pools CONCURRENTLY: one oracle thread group per pool (ctypes releases the GIL),
-    # total threads <= os.cpu_count().  Variants: (a) pools concurrent x 1 thread, (b) pools concurrent x t threads (hosts bucketed
-    # per job, Fenzo's executor-per-CPU form; t = cores // pools, capped at 16), (c) the pools one after the other with up to 16
-    # threads each (one pool timed, x pools).  `value` = the fastest; nothing is scaled in (a) / (b): they time the full K of every
-    # pool (~2 s per pool of single-thread work).
+    # The reference runs every pool's match handler on its own thread (tools.clj:799-806 chime-at per pool, scheduler.clj:2425-2435)
+    # and Fenzo evaluates a job's hosts on an executor per CPU (scheduler.clj:2301-2324): the forms timed are `a` pools at once x `t`
+    # evaluator threads per pool, a x t <= the host's cores, every one the FULL K of every pool; `value` = the fastest
+    # (cpu_baseline_leg).  One library call per pool thread: no interpreter work inside the timed region.
     # ---- + parity of the TIMED configuration: the results of the last timed cycle (as fetched above, before the profiled pass)
     #      against the oracle, bit-exact — every pool of rank 0 when the concurrent baseline ran (its outputs are reused), else the
     #      first pool (first slot of a launch chain) and the last (last slot of another chain).  A fast wrong answer must not

@@ -373,6 +373,16 @@ def _csr(lists, n):
     return off, flat
 
 
+def _csr_take(off, cols, idx):
+    """Rows `idx` of a CSR table (offsets `off`, payload columns `cols`) -> (new offsets, new columns); no per-row Python."""
+    off = off.astype(np.int64)
+    starts, lens = off[idx], off[idx + 1] - off[idx]
+    new_off = np.zeros(len(idx) + 1, dtype=np.int64)
+    np.cumsum(lens, out=new_off[1:])
+    pos = np.arange(new_off[-1], dtype=np.int64) + np.repeat(starts - new_off[:-1], lens)
+    return new_off.astype(np.uint32), tuple(np.ascontiguousarray(c[pos], dtype=np.uint32) for c in cols)
+
+
 @dataclass
 class Jobs:
     """Considerable jobs in rank order = Fenzo TaskRequests (scheduler.clj:456-509)."""
@@ -451,15 +461,9 @@ class Jobs:
             a = getattr(self, name)
             kw[name] = None if a is None else a[idx]
         if self.eq_off is not None:
-            lists = [list(zip(self.eq_key[self.eq_off[i]:self.eq_off[i + 1]], self.eq_val[self.eq_off[i]:self.eq_off[i + 1]]))
-                     for i in idx]
-            off, flat = _csr(lists, len(idx))
-            kw.update(eq_off=off, eq_key=np.array([k for k, _ in flat], dtype=np.uint32),
-                      eq_val=np.array([v for _, v in flat], dtype=np.uint32))
+            kw["eq_off"], (kw["eq_key"], kw["eq_val"]) = _csr_take(self.eq_off, (self.eq_key, self.eq_val), idx)
         if self.novel_off is not None:
-            lists = [list(self.novel_host[self.novel_off[i]:self.novel_off[i + 1]]) for i in idx]
-            off, flat = _csr(lists, len(idx))
-            kw.update(novel_off=off, novel_host=np.array(flat, dtype=np.uint32))
+            kw["novel_off"], (kw["novel_host"],) = _csr_take(self.novel_off, (self.novel_host,), idx)
         return Jobs(**kw)
 
     def _scalar_cols(self):

@@ -14,6 +14,7 @@
 // Every function cites the reference file:line it follows (paths relative to reference scheduler/).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -22,6 +23,7 @@
 #include <queue>
 #include <set>
 #include <thread>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -443,7 +445,8 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
     int32_t v;
     uint32_t fail;
   };
-  auto eval_range = [&](uint32_t k, uint32_t v0, uint32_t v1, Best& b) {
+  auto eval_range = [&](uint32_t k, uint32_t v0, uint32_t v1) -> Best {
+    Best b;  // a local of the evaluating thread: published once per job, never updated in place (no shared cache line in the loop)
     const double c = j->cpus[k], m = j->mem[k];
     b.fit = -1.0;
     b.v = -1;
@@ -473,13 +476,22 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
         if (fit > ge) break;  // scheduler.clj:2312-2314
       }
     }
+    return b;
   };
   // multi-thread CPU baseline: hosts bucketed across PERSISTENT worker threads per job (mirrors Fenzo's evaluator
-  // pool); identical result to the single bucket when good-enough is disabled (argmax, lowest index on ties).
-  const bool mt = nthreads > 1 && !(ge < 1.0) && M >= 4096;
+  // pool, built at scheduler.clj:2301-2324); identical result to the single bucket when good-enough is disabled (argmax, lowest
+  // index on ties).  Every worker evaluates its bucket into a local and publishes it ONCE into its own 128-byte slot; the
+  // generation / completion counters sit on cache lines of their own.
+  const bool mt = nthreads > 1 && !(ge < 1.0) && M >= 1024;
   const int T = mt ? nthreads : 1;
-  std::vector<Best> parts(T);
-  std::atomic<uint32_t> gen{0}, done{0};
+  struct alignas(128) Slot {
+    Best b;
+  };
+  struct alignas(128) Counter {
+    std::atomic<uint32_t> v{0};
+  };
+  std::vector<Slot> parts(T);
+  Counter gen, done;
   std::atomic<bool> quit{false};
   uint32_t cur_k = 0;
   const uint32_t chunk = (M + T - 1) / T;
@@ -488,13 +500,13 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
     workers.emplace_back([&, tix] {
       uint32_t seen = 0;
       for (;;) {
-        while (gen.load(std::memory_order_acquire) == seen) {
+        while (gen.v.load(std::memory_order_acquire) == seen) {
           if (quit.load(std::memory_order_relaxed)) return;
           __builtin_ia32_pause();
         }
         ++seen;
-        eval_range(cur_k, std::min(M, tix * chunk), std::min(M, (tix + 1) * chunk), parts[tix]);
-        done.fetch_add(1, std::memory_order_release);
+        parts[tix].b = eval_range(cur_k, std::min(M, tix * chunk), std::min(M, (tix + 1) * chunk));
+        done.v.fetch_add(1, std::memory_order_release);
       }
     });
   for (uint32_t k = 0; k < K; ++k) {
@@ -530,19 +542,19 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
     }
     Best b;
     if (!mt) {
-      eval_range(k, 0, M, b);
+      b = eval_range(k, 0, M);
     } else {
       cur_k = k;
-      done.store(0, std::memory_order_relaxed);
-      gen.fetch_add(1, std::memory_order_release);
-      eval_range(k, 0, std::min(M, chunk), parts[0]);
-      while (done.load(std::memory_order_acquire) != (uint32_t)(T - 1)) __builtin_ia32_pause();
-      b = parts[0];
+      done.v.store(0, std::memory_order_relaxed);
+      gen.v.fetch_add(1, std::memory_order_release);
+      b = eval_range(k, 0, std::min(M, chunk));
+      while (done.v.load(std::memory_order_acquire) != (uint32_t)(T - 1)) __builtin_ia32_pause();
       for (int tix = 1; tix < T; ++tix) {
-        b.fail |= parts[tix].fail;
-        if (parts[tix].v >= 0 && parts[tix].fit > b.fit) {
-          b.fit = parts[tix].fit;
-          b.v = parts[tix].v;
+        const Best& q = parts[tix].b;
+        b.fail |= q.fail;
+        if (q.v >= 0 && q.fit > b.fit) {
+          b.fit = q.fit;
+          b.v = q.v;
         }
       }
     }
@@ -681,6 +693,92 @@ int oracle_match(const cook_params* p, const cook_jobs* j, const cook_offers* o,
                  const uint32_t* reserved_hosts, uint32_t n_reserved, int32_t* job_to_offer, uint32_t* fail_code,
                  uint8_t* head_matched, int nthreads) {
   match_impl(p, j, o, g, reserved_hosts, n_reserved, job_to_offer, fail_code, head_matched, nthreads);
+  return 0;
+}
+
+// One pool's whole match cycle in ONE call (bench.py's cpu_baseline leg: no interpreter between the phases, so pool threads never
+// meet on Python's lock): rank (scheduler.clj:2073-2091 ...) -> the first K ranked pending jobs gathered into considerable order
+// (scheduler.clj:729-762's take) -> placement (scheduler.clj:617-687).  `pending_jobs` holds the pool's pending jobs in the order
+// their tasks appear among t's pending rows (the q-th pending task is job q).  phase_s = {rank, gather, match} seconds.
+int oracle_cycle(const cook_params* p, const cook_tasks* t, const cook_users* u, const cook_pool_quota* pq,
+                 const cook_jobs* pending_jobs, const cook_offers* o, const cook_groups* g, uint32_t K, int nthreads,
+                 uint32_t* ranked_pending_idx, uint32_t* n_ranked, int32_t* job_to_offer, uint32_t* n_considerable,
+                 double* phase_s) {
+  using clk = std::chrono::steady_clock;
+  auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  const auto t0 = clk::now();
+  RankResult r;
+  rank_impl(p, t, u, pq, false, r);
+  const auto t1 = clk::now();
+  const uint32_t kk = std::min<uint32_t>(K, (uint32_t)r.ranked.size());
+  std::vector<uint32_t> pend_ord(t->n);
+  uint32_t q = 0;
+  for (uint32_t i = 0; i < t->n; ++i) pend_ord[i] = t->pending[i] ? q++ : 0u;
+  std::vector<uint32_t> idx(kk);
+  for (uint32_t i = 0; i < kk; ++i) idx[i] = pend_ord[r.ranked[i]];
+  const cook_jobs* pj = pending_jobs;
+  cook_jobs c = *pj;
+  c.n = kk;
+  auto take = [&](auto* src, auto& dst) {
+    using T = std::remove_cv_t<std::remove_pointer_t<decltype(src)>>;
+    if (!src) return (const T*)nullptr;
+    dst.resize(std::max<uint32_t>(1, kk));
+    for (uint32_t i = 0; i < kk; ++i) dst[i] = src[idx[i]];
+    return (const T*)dst.data();
+  };
+  std::vector<double> v_cpus, v_mem, v_gpus, v_disk, v_scal;
+  std::vector<uint32_t> v_model, v_user, v_group, v_ckpt, v_dtype, v_eqoff, v_eqk, v_eqv, v_nvoff, v_nvh;
+  std::vector<int32_t> v_res, v_ports;
+  std::vector<int64_t> v_est;
+  c.cpus = take(pj->cpus, v_cpus);
+  c.mem = take(pj->mem, v_mem);
+  c.gpus = take(pj->gpus, v_gpus);
+  c.gpu_model = take(pj->gpu_model, v_model);
+  c.user = take(pj->user, v_user);
+  c.group = take(pj->group, v_group);
+  c.reserved_host = take(pj->reserved_host, v_res);
+  c.ckpt_location = take(pj->ckpt_location, v_ckpt);
+  c.est_end_ms = take(pj->est_end_ms, v_est);
+  c.disk_request = take(pj->disk_request, v_disk);
+  c.disk_type = take(pj->disk_type, v_dtype);
+  c.ports = take(pj->ports, v_ports);
+  if (pj->scalars && pj->n_scalars) {
+    v_scal.resize((size_t)std::max<uint32_t>(1, kk) * pj->n_scalars);
+    for (uint32_t s2 = 0; s2 < pj->n_scalars; ++s2)
+      for (uint32_t i = 0; i < kk; ++i) v_scal[(size_t)s2 * kk + i] = pj->scalars[(size_t)s2 * pj->n + idx[i]];
+    c.scalars = v_scal.data();
+  }
+  auto take_csr = [&](const uint32_t* off, std::vector<uint32_t>& noff, std::initializer_list<std::pair<const uint32_t*, std::vector<uint32_t>*>> cols) {
+    noff.assign(kk + 1, 0);
+    for (uint32_t i = 0; i < kk; ++i) noff[i + 1] = noff[i] + (off[idx[i] + 1] - off[idx[i]]);
+    for (auto& cv : cols) {
+      cv.second->resize(std::max<uint32_t>(1, noff[kk]));
+      for (uint32_t i = 0; i < kk; ++i)
+        std::copy(cv.first + off[idx[i]], cv.first + off[idx[i] + 1], cv.second->begin() + noff[i]);
+    }
+  };
+  if (pj->eq_off) {
+    take_csr(pj->eq_off, v_eqoff, {{pj->eq_key, &v_eqk}, {pj->eq_val, &v_eqv}});
+    c.eq_off = v_eqoff.data();
+    c.eq_key = v_eqk.data();
+    c.eq_val = v_eqv.data();
+  }
+  if (pj->novel_off) {
+    take_csr(pj->novel_off, v_nvoff, {{pj->novel_host, &v_nvh}});
+    c.novel_off = v_nvoff.data();
+    c.novel_host = v_nvh.data();
+  }
+  const auto t2 = clk::now();
+  match_impl(p, &c, o, g, nullptr, 0, job_to_offer, nullptr, nullptr, nthreads);
+  const auto t3 = clk::now();
+  if (ranked_pending_idx) std::copy(r.ranked.begin(), r.ranked.end(), ranked_pending_idx);
+  if (n_ranked) *n_ranked = (uint32_t)r.ranked.size();
+  if (n_considerable) *n_considerable = kk;
+  if (phase_s) {
+    phase_s[0] = secs(t0, t1);
+    phase_s[1] = secs(t1, t2);
+    phase_s[2] = secs(t2, t3);
+  }
   return 0;
 }
 

@@ -134,6 +134,26 @@ def match(params, jobs: A.Jobs, offers: A.Offers, groups: A.Groups = None, reser
     return j2o[: jobs.n].copy(), fail[: jobs.n].copy(), bool(head.value)
 
 
+def cycle(params, tasks: A.Tasks, users: A.Users, pending_jobs: A.Jobs, offers: A.Offers, groups: A.Groups = None, quota=None,
+          K=None, nthreads=1):
+    """One pool's whole match cycle in ONE library call (oracle_cycle: rank -> first K ranked jobs gathered -> placement), for
+    bench.py's cpu_baseline leg: the interpreter lock is released for the whole call, so pool threads run side by side.
+    -> (ranked pending task indices, job_to_offer int32[min(K, ranked)], {rank, gather, match} seconds)."""
+    n_pend = pending_jobs.n
+    K = n_pend if K is None else int(K)
+    ranked = np.zeros(max(1, tasks.n), dtype=np.uint32)
+    j2o = np.full(max(1, min(K, n_pend)), -1, dtype=np.int32)
+    nr, nk = C.c_uint32(0), C.c_uint32(0)
+    phase = np.zeros(3, dtype=np.float64)
+    ts, us, js, os_ = tasks.as_struct(), users.as_struct(), pending_jobs.as_struct(), offers.as_struct()
+    gs = groups.as_struct() if groups is not None else None
+    rc = lib().oracle_cycle(C.byref(params), C.byref(ts), C.byref(us), C.byref(quota) if quota is not None else None, C.byref(js),
+                            C.byref(os_), C.byref(gs) if gs is not None else None, C.c_uint32(K), int(nthreads), _u32p(ranked),
+                            C.byref(nr), j2o.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nk), _f64p(phase))
+    assert rc == 0
+    return ranked[: nr.value].copy(), j2o[: nk.value].copy(), {"rank": float(phase[0]), "gather": float(phase[1]), "match": float(phase[2])}
+
+
 def match_explain(params, jobs: A.Jobs, offers: A.Offers, groups: A.Groups = None, reserved_hosts=(), job_pos=()):
     """-> (job_to_offer, counts uint32[n, COOK_WHY_SLOTS]): the placement plus, per job position, the placement-failure summary of
     fenzo_utils.clj:33-55 in the COOK_WHY_* slots of include/cookmatch.h."""
