@@ -388,6 +388,28 @@ def main():
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     matched, considered, ranked_n = [int(x) for x in cnt.tolist()]
 
+    # ---- what the collectives saw (the line proves that N ranks took part): every rank reports its pools and their running usage, rank 0
+    #      re-adds them on the host and compares with what the timed cycle's all-reduce left on it (scheduler.clj:2125-2157: the group
+    #      usage is the sum over ALL pools of the group, whichever rank holds them; :2488-2506: one handler per pool) -----------------
+    mine = {"rank": rank, "pools": list(my_pools), "device": str(dev),
+            "pool_usage": {int(p): [float(x) for x in cluster.last_pool_usage[p]] for p in my_pools}}
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+    else:
+        everyone = [mine]
+    collective = None
+    if rank == 0:
+        all_usage = {int(p): u for r in everyone for p, u in r["pool_usage"].items()}
+        assert sorted(all_usage) == list(range(P)), f"the ranks hold pools {sorted(all_usage)}, the cluster has {P}"
+        want = sharding.group_usage_matrix(qg, all_usage)
+        assert np.array_equal(want, np.asarray(cluster.last_group_usage)), "the all-reduced quota-group usage is not the sum over all pools"
+        collective = {"backend": (dist.get_backend() if world > 1 else None), "world_size": (dist.get_world_size() if world > 1 else 1),
+                      "pools_of_rank": [r["pools"] for r in sorted(everyone, key=lambda r: r["rank"])],
+                      "devices": [r["device"] for r in sorted(everyone, key=lambda r: r["rank"])],
+                      "group_usage_allreduced": np.asarray(cluster.last_group_usage).tolist(), "group_usage_equals_sum_over_all_pools": True,
+                      "per_cycle": ["all_reduce(SUM) f64 [n_groups x 4] quota-group usage", f"all_reduce(SUM) f64 [{args.users} x 3] per-user usage"]}
+
     # ---- roofline of the dominant kernel: second pass with per-kernel HIP events on each engine's own stream ----
     roofline = None
     if not args.no_roofline:  # every rank runs the pass (cycle() holds a collective); rank 0 reports
@@ -648,7 +670,7 @@ def main():
             "phase_ms": dict(zip(("pool_usage_allreduce", "rank", "placement", "user_usage_allreduce"),
                                  (float(np.median([ph[x] for ph in phases])) for x in range(4)))),
             "setup_s": gen_s,
-            "roofline": roofline, "cpu_baseline": cpu, "adjacent_rows": adjacent, "extra_configs": extra, "boundary": boundary,
+            "collective": collective, "roofline": roofline, "cpu_baseline": cpu, "adjacent_rows": adjacent, "extra_configs": extra, "boundary": boundary,
             "parity_checked": parity_checked, "parity": {"against": "oracle (bit-exact rank order + every assignment)", "pools": parity_pools},
         }
         if cpu:

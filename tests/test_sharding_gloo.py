@@ -182,6 +182,11 @@ def test_bench_self_launches_world2_over_gloo():
     assert doc["cpu_baseline"] is None  # N = 1 only
     assert "REHEARSAL" in doc["data"]
     assert doc["last_cycle"]["considered"] > 0 and doc["phase_ms"]["user_usage_allreduce"] >= 0
+    # the line proves who took part: backend, world size as the process group saw it, every rank's pools, and that the all-reduced
+    # quota-group matrix is the sum over ALL pools' running usage (gathered from every rank, re-added on rank 0)
+    co = doc["collective"]
+    assert co["backend"] == "gloo" and co["world_size"] == 2 and co["pools_of_rank"] == [[0, 2], [1, 3]]
+    assert co["group_usage_equals_sum_over_all_pools"] is True and co["group_usage_allreduced"][0][0] == 800  # 4 pools x 200 running tasks
     # N = 1 through the same entry point: all pools local, the concurrent cpu_baseline leg and the parity of every pool
     cmd1 = [c for c in cmd]
     cmd1[cmd1.index("--gpus") + 1] = "1"
@@ -191,5 +196,8 @@ def test_bench_self_launches_world2_over_gloo():
     assert d1["n_gpus"] == 1 and [p["pool"] for p in d1["parity"]["pools"]] == [0, 1, 2, 3]
     cb = d1["cpu_baseline"]
     assert cb["kind"] == "port" and cb["variants"][0]["form"] == "pools concurrent" and cb["variants"][0]["pools_at_once"] == 4
+    assert cb["variants"][0]["threads_per_pool"] == 1 and all(v["pools_at_once"] * v["threads_per_pool"] <= cb["host_cores"] for v in cb["variants"])
+    assert all(set(v["slowest_pool_s"]) == {"rank", "gather", "match"} for v in cb["variants"])  # the library call's own clocks, per form
+    assert d1["collective"]["world_size"] == 1 and d1["collective"]["pools_of_rank"] == [[0, 1, 2, 3]]
     assert cb["value"] == max(v["cycles_per_s"] for v in cb["variants"]) and cb["cores"] >= 1
     assert d1["last_cycle"]["matched"] == doc["last_cycle"]["matched"]  # the sharded job places what the single process places
