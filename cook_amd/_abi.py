@@ -160,7 +160,10 @@ def _memo_struct(obj, build):
     if getattr(obj, "scalars", None) is not None:  # (passed as a transposed COPY: an edit in place would not reach a cached one)
         return build()
     arrays = [v for k, v in vars(obj).items() if isinstance(v, np.ndarray) and not k.startswith("_")]
-    key = tuple(map(id, arrays))
+    # the key: the object itself (a copy.copy() carries the memo over, its struct must not), its arrays, and the plain fields the
+    # builders bake into the struct (n_attr_keys, gpu_slots, disk_slots, n_scalars, ...)
+    plain = tuple((k, v) for k, v in vars(obj).items() if isinstance(v, (int, bool, np.integer)) and not k.startswith("_"))
+    key = (id(obj), tuple(map(id, arrays)), plain)
     memo = obj.__dict__.get("_struct_memo")
     if memo is not None and memo[0] == key:
         return memo[1]

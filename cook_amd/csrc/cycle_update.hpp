@@ -14,7 +14,7 @@
 //     twice or out of range leaves the resident state as it was;
 //   * row counts stay on the device until one read-back at the end (buffers are sized by bounds the host knows whatever the removal
 //     list holds: every old row plus the new ones, every old value of a CSR column plus the new ones);
-//   * the fresh offers are one block too, used in place (match_stage_offers_block).
+//   * the fresh offers are one block too, used in place (offers_block_plan / offers_block_commit).
 // Included by engine.hip (uses its DArr / KL / seg_scan helpers).
 #pragma once
 
@@ -141,7 +141,8 @@ struct UpdateBufs {
   // the fresh offers, packed (used in place by the match until the next delta brings others)
   void* h_offers = nullptr;
   size_t h_offers_cap = 0;
-  DBuf d_offers;
+  DBuf d_offers[2];    // two blocks, used in turn: a call that fails leaves the resident offers (in d_offers[d_offers_cur]) as they were
+  int d_offers_cur = 0;
   ~UpdateBufs() {
     if (h_block) (void)hipHostFree(h_block);
     if (h_offers) (void)hipHostFree(h_offers);
@@ -172,46 +173,65 @@ static void pinned_reserve(void** p, size_t* cap, size_t bytes) {
   *cap = want;
 }
 
-// the offers of a delta: every column the host gave into one block, one copy, used where it lands
-void match_stage_offers_block(cook_engine* e, UpdateBufs& ub, const cook_offers* o) {
-  MatchIn& in = e->min;
+// the offers of a delta: every column the host gave into one block, one copy, used where it lands.  Two steps so that
+// cook_cycle_update stays all-or-nothing: offers_block_plan validates the struct and reserves every byte the staging needs (it may
+// refuse or fail; nothing resident has been touched), offers_block_commit copies and points the match at the new block.
+struct OffersPlan {
+  size_t off[32];
+  unsigned gs, ds, n_attr;
+};
+template <class W>
+static void offers_block_layout(W& w, const cook_offers* o, OffersPlan& pl) {
+  const unsigned M = o->n;
+  int k = 0;
+  pl.off[k++] = w.put(o->cpus, M);
+  pl.off[k++] = w.put(o->mem, M);
+  pl.off[k++] = w.put(o->host, M);
+  pl.off[k++] = w.put(o->k8s, M);
+  pl.off[k++] = w.put(o->gpu_model, (size_t)M * pl.gs);
+  pl.off[k++] = w.put(o->gpu_count, (size_t)M * pl.gs);
+  pl.off[k++] = w.put(o->disk_type, (size_t)M * pl.ds);
+  pl.off[k++] = w.put(o->disk_space, (size_t)M * pl.ds);
+  pl.off[k++] = w.put(o->ports, M);
+  for (unsigned sc = 0; sc < COOK_MAX_SCALARS; ++sc)
+    pl.off[k++] = w.put((o->scalars && sc < o->n_scalars) ? o->scalars + (size_t)sc * M : (const double*)nullptr, M);
+  pl.off[k++] = w.put(o->attr, (size_t)M * pl.n_attr);
+  pl.off[k++] = w.put(o->max_tasks, M);
+  pl.off[k++] = w.put(o->num_tasks, M);
+  pl.off[k++] = w.put(o->location, M);
+  pl.off[k++] = w.put(o->host_start_s, M);
+  pl.off[k++] = w.put(o->run_cpus, M);
+  pl.off[k++] = w.put(o->run_mem, M);
+  pl.off[k++] = w.put(o->run_count, M);
+}
+OffersPlan offers_block_plan(cook_engine* e, UpdateBufs& ub, const cook_offers* o) {
   const unsigned M = o->n;
   if (M && (!o->cpus || !o->mem || !o->host)) e->fail(COOK_E_INVALID, "cook_match_stage: offers need cpus, mem and host");
   if (o->scalars && o->n_scalars > COOK_MAX_SCALARS) e->fail(COOK_E_INVALID, "cook_match_stage: more than COOK_MAX_SCALARS named scalars");
-  const unsigned gs = res_slots(e, o->gpu_slots, "cook_match_stage: gpu_slots"), ds = res_slots(e, o->disk_slots, "cook_match_stage: disk_slots");
+  OffersPlan pl{};
+  pl.gs = res_slots(e, o->gpu_slots, "cook_match_stage: gpu_slots");
+  pl.ds = res_slots(e, o->disk_slots, "cook_match_stage: disk_slots");
   if (o->gpu_model && !o->gpu_count) e->fail(COOK_E_INVALID, "cook_match_stage: gpu_model without gpu_count");
-  const unsigned n_attr = o->attr ? o->n_attr_keys : 0;
-  size_t off[32];
-  for (int pass = 0; pass < 2; ++pass) {
-    BlockWriter w(pass ? (char*)ub.h_offers : nullptr);
-    int k = 0;
-    off[k++] = w.put(o->cpus, M);
-    off[k++] = w.put(o->mem, M);
-    off[k++] = w.put(o->host, M);
-    off[k++] = w.put(o->k8s, M);
-    off[k++] = w.put(o->gpu_model, (size_t)M * gs);
-    off[k++] = w.put(o->gpu_count, (size_t)M * gs);
-    off[k++] = w.put(o->disk_type, (size_t)M * ds);
-    off[k++] = w.put(o->disk_space, (size_t)M * ds);
-    off[k++] = w.put(o->ports, M);
-    for (unsigned sc = 0; sc < COOK_MAX_SCALARS; ++sc)
-      off[k++] = w.put((o->scalars && sc < o->n_scalars) ? o->scalars + (size_t)sc * M : (const double*)nullptr, M);
-    off[k++] = w.put(o->attr, (size_t)M * n_attr);
-    off[k++] = w.put(o->max_tasks, M);
-    off[k++] = w.put(o->num_tasks, M);
-    off[k++] = w.put(o->location, M);
-    off[k++] = w.put(o->host_start_s, M);
-    off[k++] = w.put(o->run_cpus, M);
-    off[k++] = w.put(o->run_mem, M);
-    off[k++] = w.put(o->run_count, M);
-    if (!pass) {
-      pinned_reserve(&ub.h_offers, &ub.h_offers_cap, w.used + 16);
-      ub.d_offers.ensure(w.used + 16);
-    } else if (w.used) {
-      COOK_HIP(hipMemcpyAsync(ub.d_offers.p, ub.h_offers, w.used, hipMemcpyHostToDevice, e->stream));
-    }
-  }
-  const char* d = (const char*)ub.d_offers.p;
+  if (o->disk_type && !o->disk_space) e->fail(COOK_E_INVALID, "cook_match_stage: disk_type without disk_space");
+  match_check_offer_count(e, M);  // the walk's owner table holds one byte per offer of the pool
+  pl.n_attr = o->attr ? o->n_attr_keys : 0;
+  BlockWriter w(nullptr);
+  offers_block_layout(w, o, pl);
+  pinned_reserve(&ub.h_offers, &ub.h_offers_cap, w.used + 16);
+  ub.d_offers[ub.d_offers_cur ^ 1].ensure(w.used + 16);
+  return pl;
+}
+void offers_block_commit(cook_engine* e, UpdateBufs& ub, const cook_offers* o, OffersPlan& pl) {
+  MatchIn& in = e->min;
+  const unsigned M = o->n;
+  DBuf& blk = ub.d_offers[ub.d_offers_cur ^ 1];
+  BlockWriter w((char*)ub.h_offers);
+  offers_block_layout(w, o, pl);
+  if (w.used) COOK_HIP(hipMemcpyAsync(blk.p, ub.h_offers, w.used, hipMemcpyHostToDevice, e->stream));
+  ub.d_offers_cur ^= 1;
+  const char* d = (const char*)blk.p;
+  const size_t* off = pl.off;
+  const unsigned gs = pl.gs, ds = pl.ds, n_attr = pl.n_attr;
   auto at = [&](size_t o_) -> const void* { return o_ == (size_t)-1 ? nullptr : (const void*)(d + o_); };
   int k = 0;
   in.M = M;
@@ -280,6 +300,20 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
     for (unsigned r = 0; r < p_add; ++r)
       if (aj->group[r] != COOK_NONE_U32 && aj->group[r] >= e->G) e->fail(COOK_E_INVALID, "cook_cycle_update: group id out of range");
   if (in.j_disk_req && p_add && aj->disk_request && !aj->disk_type) e->fail(COOK_E_INVALID, "cook_cycle_update: disk_request without disk_type");
+  // the CSR constraint columns of the delta: offsets from 0, non-decreasing, and values behind every non-empty list
+  auto csr_ok = [&](const uint32_t* off, const void* a, const void* b, const char* what) {
+    if (!off) return;
+    if (off[0] != 0) e->fail(COOK_E_INVALID, what);
+    for (unsigned r = 0; r < p_add; ++r)
+      if (off[r + 1] < off[r]) e->fail(COOK_E_INVALID, what);
+    if (off[p_add] && (!a || !b)) e->fail(COOK_E_INVALID, what);
+  };
+  if (p_add && in.j_eq_off) csr_ok(aj->eq_off, aj->eq_key, aj->eq_val, "cook_cycle_update: add_pending eq_off must start at 0 and not decrease, with eq_key / eq_val behind it");
+  if (p_add && in.j_novel_off) csr_ok(aj->novel_off, aj->novel_host, aj->novel_host, "cook_cycle_update: add_pending novel_off must start at 0 and not decrease, with novel_host behind it");
+  // the fresh offers are checked, and everything their staging needs is reserved, BEFORE anything resident changes: a refused
+  // offers struct (or an allocation that fails) leaves tasks, jobs and offers as they were
+  OffersPlan offers_plan{};
+  if (d->offers) offers_plan = offers_block_plan(e, ub, d->offers);
   const unsigned N2 = N - d->n_remove + n_add;  // (when the removal list is valid; the device says at the end)
   const unsigned N_hi = N + n_add;              // rows the compaction can write whatever the list holds (an entry named twice removes one row)
   const unsigned P_hi = P + p_add;              // the pending jobs can only be bounded until then
@@ -480,7 +514,7 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
   e->match_done = false;
   e->has_deferred = false;
   if (d->offers) {
-    match_stage_offers_block(e, ub, d->offers);
+    offers_block_commit(e, ub, d->offers, offers_plan);
     sync(e);
   }
 }

@@ -275,6 +275,13 @@ void sync(cook_engine* e) {
 }
 
 // entries per host of a k8s "gpus" / "disk" map column pair (cookmatch.h cook_offers.gpu_slots): 0 means 1
+// The placement walk keeps one LDS byte per offer of the pool.  A pool in a lockstep chain runs the good-enough flavour of the kernels
+// whenever ANY pool of its chain has good-enough < 1 (match_rounds_multi), so the table must leave room for segments in both.
+void match_check_offer_count(cook_engine* e, unsigned M) {
+  if (e->params.match_algo == 1) return;  // (the one-job-at-a-time sweep has no such table)
+  if (std::min(resolve_wseg<true>(M), resolve_wseg<false>(M)) < MV_WSEG_MIN)
+    e->fail(COOK_E_INVALID, "cook_match: too many offers in one pool for the placement walk's offer table (about 150 000)");
+}
 unsigned res_slots(cook_engine* e, uint32_t slots, const char* what) {
   if (slots > COOK_MAX_RES_SLOTS) e->fail(COOK_E_INVALID, std::string(what) + " > COOK_MAX_RES_SLOTS");
   return slots ? slots : 1u;
@@ -992,8 +999,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     auto k_match = match_serial<SERIAL_THREADS>;
     KL("match_serial", k_match, 1, SERIAL_THREADS, in, st);
   } else if (K > 0) {  // window rounds: eval -> merge -> resolve (match_v2.hpp)
-    if ((ge ? resolve_wseg<true>(M) : resolve_wseg<false>(M)) < MV_WSEG_MIN)
-      e->fail(COOK_E_INVALID, "cook_match: too many offers in one pool for the placement walk's offer table (about 150 000)");
+    match_check_offer_count(e, M);
     V2Buf vb;
     const char* rlog_path = std::getenv("COOK_ROUND_LOG");  // diagnostics: one CSV line per round of the last match
     vb.round_log = rlog_path ? e->w_rlog.ensure(MV_ROUND_LOG_CAP) : nullptr;

@@ -292,9 +292,32 @@ def test_cycle_update_rejects_rows_it_cannot_append(make_engine):
             e.cycle_update(np.array([3, 17, 3], np.uint32), extra.tasks, extra.pending_jobs, pool.offers)
         with pytest.raises(CookError, match="out of range or twice"):
             e.cycle_update(np.array([5, pool.tasks.n], np.uint32), None, None, None)
+        # fresh offers the engine refuses (a gpu model table without its counts; offers without mem): checked BEFORE the task / job
+        # delta is applied — a caller that retries must not remove the same rows twice
+        import copy
+        bad_offers = copy.copy(pool.offers)
+        bad_offers.gpu_model, bad_offers.gpu_slots, bad_offers.gpu_count = np.ones((pool.offers.n, 1), np.uint32), 1, None
+        with pytest.raises(CookError, match="gpu_model without gpu_count"):
+            e.cycle_update(np.array([3, 17], np.uint32), extra.tasks, extra.pending_jobs, bad_offers)
+        # CSR constraint columns of the delta: offsets that decrease, or values missing behind a non-empty list -> refused, not a fault
+        broken = extra.pending_jobs.take(np.arange(extra.pending_jobs.n))
+        broken.eq_off = broken.eq_off.copy()
+        broken.eq_off[0] = 1
+        with pytest.raises(CookError, match="eq_off must start at 0"):
+            e.cycle_update((), extra.tasks, broken, None)
         e.cycle_run(10 ** 9)  # the refused updates left the resident state as it was
         again = e.cycle_fetch()
-    assert np.array_equal(want[0], again[0]) and np.array_equal(want[1], again[1])
+        assert np.array_equal(want[0], again[0]) and np.array_equal(want[1], again[1])
+        # ... and the same delta with good offers is then applied once, exactly as on an engine that never saw the refused calls
+        e.cycle_update(np.array([3, 17], np.uint32), extra.tasks, extra.pending_jobs, pool.offers)
+        e.cycle_run(10 ** 9)
+        after = e.cycle_fetch()
+    with make_engine(p) as e2:
+        e2.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        e2.cycle_update(np.array([3, 17], np.uint32), extra.tasks, extra.pending_jobs, pool.offers)
+        e2.cycle_run(10 ** 9)
+        clean = e2.cycle_fetch()
+    assert np.array_equal(after[0], clean[0]) and np.array_equal(after[1], clean[1])
 
 
 @pytest.mark.parametrize("seed", [611, 612])
