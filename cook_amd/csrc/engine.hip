@@ -170,6 +170,16 @@ struct cook_engine {
   unsigned deferred_k = 0;
   WinCtl deferred_c0{};
   WinCtl* h_multi = nullptr;  // pinned: the pools' WinCtl read-backs
+  // served walkers (match_rounds_served): the two streams of a served match led by this engine, its control blocks, what it did
+  hipStream_t s_walk = nullptr, s_serve = nullptr;
+  DArr<ServeSlot> w_slots;
+  DArr<ServeCtl> w_sctl;
+  ServeHost* h_serve = nullptr;  // pinned
+  struct ServedStats {
+    unsigned mode = 0;  // 0 not served, 1 walkers beside serve launches, 2 stepping form
+    unsigned pools = 0, iterations = 0, empty_iterations = 0, pools_served = 0, fell_back = 0;
+    double latch_wait_ms = 0;
+  } served;
   int n_cus = 256;
   DArr<MatchIn> v_in;
   void* h_inbuf = nullptr;  // pinned staging copy of MatchIn
@@ -213,16 +223,17 @@ struct ProfScope {
   cook_engine* e;
   hipEvent_t a = nullptr, b = nullptr;
   const char* name;
-  ProfScope(cook_engine* e_, const char* n) : e(e_), name(n) {
+  hipStream_t stream;
+  ProfScope(cook_engine* e_, const char* n, hipStream_t s = nullptr) : e(e_), name(n), stream(s ? s : e_->stream) {
     if (e->profiling) {
       a = take_event(e);
       b = take_event(e);
-      (void)hipEventRecord(a, e->stream);
+      (void)hipEventRecord(a, stream);
     }
   }
   ~ProfScope() {
     if (e->profiling) {
-      (void)hipEventRecord(b, e->stream);
+      (void)hipEventRecord(b, stream);
       e->ev_pending.push_back({name, a, b});
     }
   }
@@ -245,6 +256,13 @@ void prof_collect(cook_engine* e) {
   do {                                                                        \
     ProfScope _ps(e, name);                                                   \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, e->stream, __VA_ARGS__); \
+  } while (0)
+
+// the same on a given stream (timed, when profiling, with events on THAT stream)
+#define KLS(name, stream_, kern, grid, block, ...)                               \
+  do {                                                                        \
+    ProfScope _ps(e, name, stream_);                                          \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream_, __VA_ARGS__); \
   } while (0)
 
 template <class T>
@@ -1227,6 +1245,159 @@ void match_rounds_multi(cook_engine** es, unsigned n) {
   }
 }
 
+// COOK_MATCH_SERVED=0: cook_cycle_match_multi always runs its pools in lockstep launches (match_rounds_multi); default: served walkers
+static bool served_enabled() {
+  const char* s = std::getenv("COOK_MATCH_SERVED");
+  return !(s && std::atoi(s) == 0);
+}
+// the stepping form (nothing waits on the device; the host alternates walker launches, latches and serve iterations): always in the
+// emulated build, whose launches run one after the other; COOK_SERVE_STEP=1 forces it on the GPU (A/B, debugging)
+static bool served_stepping() {
+#ifdef __HIP_EMU__
+  return true;
+#else
+  const char* s = std::getenv("COOK_SERVE_STEP");
+  return s && std::atoi(s) != 0;
+#endif
+}
+static unsigned long long env_ticks(const char* name, double dflt_us) {
+  const char* s = std::getenv(name);
+  const double us = s ? std::atof(s) : dflt_us;
+  return (unsigned long long)(std::max(0.0, us) * 100.0);  // 100 MHz
+}
+
+// The placements of n engines (pools of one rank, same device) by persistent walkers — one workgroup per pool, ONE launch — beside
+// serve iterations (evaluation + merge for the pools that asked) on a second stream: match_v2.hpp "served walkers".  -> false: the
+// served match gave up (a walker was not served in time); the pools are in a consistent state and the caller finishes them in lockstep.
+bool match_rounds_served(cook_engine** es, unsigned n) {
+  cook_engine* lead = es[0];
+  cook_engine* e = lead;  // KL / KLS time and launch on the lead engine
+  std::vector<unsigned> live;
+  for (unsigned i = 0; i < n; ++i) {
+    if (!es[i] || es[i]->device != lead->device) lead->fail(COOK_E_INVALID, "cook_cycle_match_multi: engines must share one device");
+    if (es[i]->has_deferred) live.push_back(i);
+    else if (!es[i]->match_done) lead->fail(COOK_E_STATE, "cook_cycle_match_multi before cook_cycle_run_rank");
+  }
+  const unsigned L = (unsigned)live.size();
+  lead->served = cook_engine::ServedStats{};
+  if (L == 0) return true;
+  if (L > MV_SERVE_MAX) return false;
+  if (!lead->s_walk) {  // created back to back: two different hardware queues
+    COOK_HIP(hipStreamCreateWithFlags(&lead->s_walk, hipStreamNonBlocking));
+    COOK_HIP(hipStreamCreateWithFlags(&lead->s_serve, hipStreamNonBlocking));
+    COOK_HIP(hipHostMalloc((void**)&lead->h_serve, sizeof(ServeHost), hipHostMallocDefault));
+  }
+  if (!lead->h_multi) COOK_HIP(hipHostMalloc((void**)&lead->h_multi, 64 * sizeof(WinCtl), hipHostMallocDefault));
+  std::vector<PoolCtx> hctx(L);
+  unsigned cmax = 1;
+  bool any_ge = false;
+  for (unsigned x = 0; x < L; ++x) {
+    hctx[x] = es[live[x]]->deferred;
+    cmax = std::max(cmax, hctx[x].vb.C);
+    any_ge = any_ge || es[live[x]]->deferred_ge;
+  }
+  PoolCtx* dctx = lead->w_pctx.ensure(L);
+  ServeSlot* slots = lead->w_slots.ensure(L);
+  ServeCtl* sctl = lead->w_sctl.ensure(1);
+  std::vector<ServeSlot> hslots(L);
+  for (unsigned x = 0; x < L; ++x) {
+    std::memset((void*)&hslots[x], 0, sizeof(ServeSlot));
+    hslots[x].req = 1u;  // the first window of every pool: asked for here
+  }
+  ServeCtl hs;
+  std::memset(&hs, 0, sizeof(hs));
+  hs.n_pools = L;
+  hs.n_latched = L;
+  for (unsigned x = 0; x < L; ++x) hs.latched_pool[x] = x, hs.latched_seq[x] = 1u;
+  ServeHost* hh = lead->h_serve;
+  std::memset(hh, 0, sizeof(*hh));
+  COOK_HIP(hipMemcpyAsync(dctx, hctx.data(), L * sizeof(PoolCtx), hipMemcpyHostToDevice, lead->s_serve));
+  COOK_HIP(hipMemcpyAsync(slots, hslots.data(), L * sizeof(ServeSlot), hipMemcpyHostToDevice, lead->s_serve));
+  COOK_HIP(hipMemcpyAsync(sctl, &hs, sizeof(hs), hipMemcpyHostToDevice, lead->s_serve));
+  COOK_HIP(hipStreamSynchronize(lead->s_serve));  // (pageable sources; and the walkers must find their slots initialised)
+  WalkPack<MV_WALK_PACK> wp{};
+  const bool packed = L <= (unsigned)MV_WALK_PACK && pack_args();
+  for (unsigned x = 0; x < (unsigned)MV_WALK_PACK; ++x) {
+    wp.c[x].st = hctx[x < L ? x : 0].st;
+    wp.c[x].vb = hctx[x < L ? x : 0].vb;
+  }
+  const bool stepping = served_stepping();
+  const unsigned long long spin = stepping ? 0ull : env_ticks("COOK_SERVE_WALK_TIMEOUT_US", 2.0e6);  // a walker not served for 2 s gives up
+  const unsigned long long poll = stepping ? 0ull : env_ticks("COOK_SERVE_POLL_US", 40.0);          // the latch waits that long for a request
+  auto walkers = [&](auto ge_tag) {
+    constexpr bool GE = decltype(ge_tag)::value;
+    if (packed) KLS("match_walkers", lead->s_walk, (match_walkers_pack<GE, MV_WALK_PACK>), L, MV_RTHREADS, wp, slots, sctl, spin);
+    else KLS("match_walkers", lead->s_walk, match_walkers<GE>, L, MV_RTHREADS, (const PoolCtx*)dctx, slots, sctl, spin);
+  };
+  auto serve = [&](auto ge_tag) {
+    constexpr bool GE = decltype(ge_tag)::value;
+    KLS("match_serve_eval", lead->s_serve, match_serve_eval<GE>, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx, (const ServeCtl*)sctl);
+    KLS("match_serve_merge", lead->s_serve, match_serve_merge<GE>, dim3(MV_MERGE_BLOCKS, 1, L), COOK_WAVE * MV_MW, (const PoolCtx*)dctx, sctl, slots, hh, poll);
+  };
+  auto launch_walkers = [&] { any_ge ? walkers(std::true_type{}) : walkers(std::false_type{}); };
+  auto launch_serve = [&] { any_ge ? serve(std::true_type{}) : serve(std::false_type{}); };
+  unsigned launched = 0;
+  if (stepping) {
+    unsigned guard = 0;
+    for (;;) {
+      launch_serve();     // evaluates what the latch put together (first: every pool's first window), publishes, finds nothing new
+      ++launched;
+      launch_walkers();   // every pool walks the windows it has been served, asks for the next, returns
+      KLS("match_serve_latch", lead->s_serve, match_serve_latch, 1, COOK_WAVE, sctl, slots, hh);
+      ++launched;
+      COOK_HIP(hipStreamSynchronize(lead->s_walk));
+      COOK_HIP(hipStreamSynchronize(lead->s_serve));
+      if (hh->all_done || hh->error) break;
+      if (++guard > 4000000u) lead->fail(COOK_E_STATE, "cook_cycle_match_multi: served placement made no progress");
+    }
+  } else {
+    launch_walkers();
+    // serve iterations, a few ahead of the device: each ends with the latch waiting (bounded) for the next request, so the chain is
+    // paced by the walkers; iter_done / all_done arrive in page-locked memory
+    constexpr unsigned DEPTH = 3;
+    unsigned long long spins = 0;
+    volatile ServeHost* vh = hh;
+    while (!vh->all_done && !vh->error) {
+      if (launched - vh->iter_done >= DEPTH) {
+        if (++spins > 40000000000ull) lead->fail(COOK_E_STATE, "cook_cycle_match_multi: the serve launches stopped finishing");
+        continue;
+      }
+      launch_serve();
+      ++launched;
+    }
+    COOK_HIP(hipStreamSynchronize(lead->s_serve));
+    COOK_HIP(hipStreamSynchronize(lead->s_walk));
+  }
+  // what the pools reached
+  std::vector<WinCtl> hc(L);
+  for (unsigned x = 0; x < L; ++x) COOK_HIP(hipMemcpyAsync(&lead->h_multi[x], hctx[x].vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, lead->s_serve));
+  COOK_HIP(hipMemcpyAsync(&hs, sctl, sizeof(hs), hipMemcpyDeviceToHost, lead->s_serve));
+  COOK_HIP(hipStreamSynchronize(lead->s_serve));
+  bool complete = true;
+  for (unsigned x = 0; x < L; ++x) {
+    hc[x] = lead->h_multi[x];
+    es[live[x]]->deferred_c0 = hc[x];  // (where a lockstep continuation would start)
+    complete = complete && hc[x].head >= es[live[x]]->deferred_k;
+  }
+  lead->served.mode = stepping ? 2u : 1u;
+  lead->served.pools = L;
+  lead->served.iterations = hs.iterations;
+  lead->served.empty_iterations = hs.empty_iterations;
+  lead->served.pools_served = hs.pools_served;
+  lead->served.latch_wait_ms = (double)hs.wait_ticks / 1.0e5;
+  if (!complete) {
+    lead->served.fell_back = 1;
+    return false;
+  }
+  for (unsigned x = 0; x < L; ++x) {
+    cook_engine* ex = es[live[x]];
+    match_finish_rounds(ex, hctx[x].st, hctx[x].vb, hc[x], lead->s_serve);
+    ex->has_deferred = false;
+    ex->match_done = true;
+  }
+  return true;
+}
+
 void match_fetch(cook_engine* e, unsigned K, int32_t* job_to_offer, uint32_t* fail_code, uint8_t* head_matched) {
   if (!e->match_done) e->fail(COOK_E_STATE, "cook_match_fetch before cook_match_run");
   if (job_to_offer && K) COOK_HIP(hipMemcpyAsync(job_to_offer, e->m_j2o.ptr(), (size_t)K * 4, hipMemcpyDeviceToHost, e->stream));
@@ -1381,6 +1552,9 @@ void cook_engine_destroy(cook_engine* e) {
   if (e->h_scratch) (void)hipHostFree(e->h_scratch);
   if (e->h_inbuf) (void)hipHostFree(e->h_inbuf);
   if (e->h_multi) (void)hipHostFree(e->h_multi);
+  if (e->h_serve) (void)hipHostFree(e->h_serve);
+  if (e->s_walk) (void)hipStreamDestroy(e->s_walk);
+  if (e->s_serve) (void)hipStreamDestroy(e->s_serve);
   delete e->rb;
   e->rb = nullptr;
   delete e->cb;
@@ -1615,7 +1789,9 @@ int cook_cycle_match_multi(cook_engine** engines, uint32_t n) {
   cook_engine* lead = engines[0];
   return guarded(lead, [&] {
     StageTimer tm(lead, 2, &lead->match_ms);
-    match_rounds_multi(engines, n);
+    // served walkers (one persistent walker workgroup per pool beside serve launches); lockstep launches when switched off, for more
+    // pools than a served call takes, or to finish a served match that gave up
+    if (!(served_enabled() && match_rounds_served(engines, n))) match_rounds_multi(engines, n);
     tm.stop();
     for (uint32_t i = 1; i < n; ++i) engines[i]->match_ms = lead->match_ms;  // one joint sequence of launches
     prof_collect(lead);
@@ -1817,6 +1993,8 @@ int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap) {
   if (rc) return rc;
   const WinCtl& c = e->last_ctl;
   v[16] = c.trunc_lists;
+  v[17] = e->served.mode, v[18] = e->served.pools, v[19] = e->served.iterations, v[20] = e->served.empty_iterations;
+  v[21] = e->served.pools_served, v[22] = (uint32_t)(e->served.latch_wait_ms * 1000.0), v[23] = e->served.fell_back;
   uint32_t n = 0;
   for (; n < cap && n < (uint32_t)COOK_MATCH_STATS_EX_N; ++n) out[n] = v[n];
   return (int)n;

@@ -26,6 +26,20 @@ static __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_l
 template <class T>
 static __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// ---- hand-off between workgroups of DIFFERENT launches that run side by side (the served walkers, match_v2.hpp) ----------------------
+// The tested forms of MI355X_MICROARCH.md: producer = plain stores -> agent_release() -> relaxed agent-scope flag store; consumer =
+// relaxed poll of the flag -> ONE agent_acquire() -> plain loads.  The inline-asm wait is deliberate: ROCm 7.2 drops the s_waitcnt
+// after buffer_wbl2 when it can prove the wave's vmcnt scoreboard empty, and the flag then overtakes the write-back.
+static __device__ __forceinline__ void agent_release() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+static __device__ __forceinline__ void agent_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+#define SPIN_PAUSE_FAR() __builtin_amdgcn_s_sleep(8)  // between polls of a word in global memory that another workgroup writes
+// a word in page-locked HOST memory that the host polls
+template <class T>
+static __device__ __forceinline__ void st_system(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 // constant-rate (100 MHz) device clock for in-kernel phase timing
 static __device__ __forceinline__ unsigned long long cook_ticks() { return wall_clock64(); }
 

@@ -2363,3 +2363,199 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2_pack(const PoolPac
   const PoolCtx& c = p.c[blockIdx.z];
   resolve_round<GE>(lds, c.st, c.vb);
 }
+
+// ---- served walkers: the pools of a rank DECOUPLED -------------------------------------------------------------------------------
+// The lockstep launches above make every pool of a chain wait for the slowest walk of the round and for the evaluation of all its
+// neighbours.  Here every pool has ONE persistent walker workgroup — match_walkers, one launch per match of the whole rank, on a
+// stream of its own — that runs resolve_round after resolve_round; between two rounds it posts "my next window wants evaluating"
+// (ServeSlot::req) and waits for "lists ready" (ServeSlot::ready).  A second stream carries SERVE ITERATIONS — match_serve_eval +
+// match_serve_merge, the same evaluation and merge as above — for whichever pools had a request open when the iteration was put
+// together (the LATCH: taken by the last workgroup of the previous iteration's merge, so that every workgroup of an iteration
+// agrees on the pools it serves).  That workgroup also publishes the iteration's results and then WAITS (bounded) for the next
+// request, so the chain of serve launches is paced by the walkers: two streams per GPU, whatever the number of pools.
+//
+// Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility): walker -> server: plain stores, agent_release(), relaxed agent store
+// of req; the latch reads req with agent loads and the NEXT launch's kernel-start acquire makes the walker's stores visible to its
+// workgroups on every XCD.  server -> walker: every merge workgroup releases before it takes its arrival ticket, the last arriver
+// stores ready, the walker polls it, acquires once, and reads with plain loads.  Every wait is bounded: a walker that is not served
+// within `spin_ticks` raises ServeCtl::error and leaves, the pool's state is consistent (the last finished round), and the host
+// finishes the match with lockstep launches.
+//
+// STEPPING form (spin_ticks == 0; the SIMT emulator of the test suite, which runs one launch at a time, and COOK_SERVE_STEP=1 on the
+// GPU): nothing waits — a walker that finds its window not served yet returns, and the host alternates walker launches, latch
+// launches and serve iterations.  Same kernels, same words, same results.
+struct alignas(128) ServeSlot {  // per pool; the walker's words and the server's on lines of their own
+  unsigned req;   // [walker -> server] windows asked for so far (the first one by the host: 1)
+  unsigned done;  // [walker -> server] 1 = every job of the pool is resolved, 2 = the walker gave up (ServeCtl::error)
+  unsigned pad0[30];
+  unsigned ready;  // [server -> walker] windows served so far
+  unsigned pad1[31];
+};
+constexpr unsigned MV_SERVE_MAX = 16;  // pools per served call
+struct ServeCtl {
+  unsigned n_pools;
+  unsigned n_latched;  // pools the next serve iteration evaluates, and the request numbers it serves
+  unsigned latched_pool[MV_SERVE_MAX], latched_seq[MV_SERVE_MAX];
+  unsigned served[MV_SERVE_MAX];  // = ServeSlot::ready of every pool (the latch's own copy)
+  unsigned ticket;                // arrivals of the merge workgroups of the running iteration
+  unsigned all_done;              // no walker is left
+  unsigned error;                 // a walker gave up
+  unsigned iterations, empty_iterations, pools_served;  // statistics
+  unsigned long long wait_ticks;  // 100 MHz ticks the latch spent waiting for a request
+};
+struct ServeHost {  // page-locked host memory, written by the latch with system-scope stores, polled by the host
+  unsigned iter_done;  // serve iterations finished
+  unsigned all_done, error, pad;
+};
+
+// the latch (one wave): publish what the iteration served, then put the next iteration together
+static __device__ __forceinline__ void serve_latch(ServeCtl* sc, ServeSlot* slots, ServeHost* host, unsigned long long poll_ticks) {
+  const unsigned lane = lane_id();
+  const unsigned n = wave_uniform_u32(sc->n_pools), nl = wave_uniform_u32(sc->n_latched);
+  if (lane < nl) {
+    const unsigned p = sc->latched_pool[lane], q = sc->latched_seq[lane];
+    sc->served[p] = q;
+    st_agent(&slots[p].ready, q);
+  }
+  wave_sync();
+  const unsigned mine = lane < n ? sc->served[lane] : 0u;
+  const unsigned long long t0 = cook_ticks();
+  unsigned rq = 0, dn = 0;
+  unsigned long long pend, alive;
+  for (;;) {
+    if (lane < n) {
+      rq = ld_agent(&slots[lane].req);
+      dn = ld_agent(&slots[lane].done);
+    }
+    alive = __ballot(lane < n && dn == 0u);
+    pend = __ballot(lane < n && dn == 0u && rq != mine);
+    if (pend != 0ull || alive == 0ull || poll_ticks == 0ull || cook_ticks() - t0 > poll_ticks) break;
+    SPIN_PAUSE_FAR();
+  }
+  const unsigned long long waited = cook_ticks() - t0;
+  if ((pend >> lane) & 1ull) {
+    const unsigned x = (unsigned)__popcll(pend & ((1ull << lane) - 1ull));
+    sc->latched_pool[x] = lane;
+    sc->latched_seq[x] = rq;
+  }
+  if (lane == 0) {
+    const unsigned np = (unsigned)__popcll(pend);
+    sc->n_latched = np;
+    sc->ticket = 0u;
+    sc->iterations += 1u;
+    sc->empty_iterations += nl == 0u ? 1u : 0u;
+    sc->pools_served += nl;
+    sc->wait_ticks += waited;
+    const unsigned err = ld_agent(&sc->error);
+    if (alive == 0ull) sc->all_done = 1u;
+    if (alive == 0ull) st_system(&host->all_done, 1u);
+    if (err != 0u) st_system(&host->error, err);
+    st_system(&host->iter_done, sc->iterations);
+  }
+}
+__global__ void __launch_bounds__(COOK_WAVE) match_serve_latch(ServeCtl* sc, ServeSlot* slots, ServeHost* host) {
+  serve_latch(sc, slots, host, 0ull);  // (stepping form: the walkers have just run, nothing to wait for)
+}
+template <bool GE>
+__global__ void __launch_bounds__(COOK_WAVE* MV_EW) COOK_EVAL_OCCUPANCY match_serve_eval(const PoolCtx* __restrict__ ctx, const ServeCtl* __restrict__ sc) {
+  __shared__ __attribute__((aligned(16))) char lds[sizeof(EvalLds<GE>)];
+  if (blockIdx.z >= sc->n_latched) return;
+  const PoolCtx& c = ctx[sc->latched_pool[blockIdx.z]];
+  if (blockIdx.x >= c.vb.C) return;
+  eval_block<GE>(lds, c.in, c.st, c.vb, c.vb.ctl->head, c.vb.ctl->wcur, blockIdx.x, blockIdx.y, gridDim.y);
+}
+template <bool GE>
+__global__ void __launch_bounds__(COOK_WAVE* MV_MW) match_serve_merge(const PoolCtx* __restrict__ ctx, ServeCtl* sc, ServeSlot* slots, ServeHost* host,
+                                                                      unsigned long long poll_ticks) {
+  __shared__ unsigned s_last;
+  const unsigned nl = sc->n_latched;
+  if (nl == 0u ? (blockIdx.x | blockIdx.z) != 0u : blockIdx.z >= nl) return;  // (an empty iteration: block 0 is the latch)
+  if (nl != 0u) {
+    const PoolCtx& c = ctx[sc->latched_pool[blockIdx.z]];
+    merge_block<GE>(c.in, c.vb);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned last = 1u;
+    if (nl != 0u) {
+      agent_release();  // this workgroup's lists are in memory before its arrival counts
+      last = atomicAdd(&sc->ticket, 1u) == gridDim.x * nl - 1u ? 1u : 0u;
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last == 0u || threadIdx.x >= (unsigned)COOK_WAVE) return;
+  serve_latch(sc, slots, host, poll_ticks);
+}
+
+struct WalkCtx {  // what resolve_round needs of a pool (MatchIn through vb.in_dev): small enough for MV_WALK_PACK of them in the kernel arguments
+  MatchState st;
+  V2Buf vb;
+};
+constexpr int MV_WALK_PACK = 8;
+template <int N>
+struct WalkPack {
+  WalkCtx c[N];
+};
+// one walker workgroup's life: rounds until the pool is placed (or, stepping form, until a window is not served yet)
+template <bool GE>
+static __device__ __forceinline__ void walk_pool(char* lds, int& s_go, const MatchState& st, const V2Buf& vb, ServeSlot* slot, ServeCtl* sc,
+                                                 unsigned long long spin_ticks) {
+  const unsigned K = vb.in_dev->K;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      int go = 0;
+      const unsigned want = ld_agent(&slot->req);  // (this workgroup's own word, or the host's first request)
+      if (ld_agent(&slot->done) == 0u) {
+        const unsigned long long t0 = cook_ticks();
+        for (;;) {
+          if (ld_agent(&slot->ready) == want) {
+            go = 1;
+            break;
+          }
+          if (spin_ticks == 0ull) break;  // stepping form: come back when served
+          if (ld_agent(&sc->error) != 0u || cook_ticks() - t0 > spin_ticks) {
+            st_agent(&sc->error, 1u);
+            st_agent(&slot->done, 2u);
+            break;
+          }
+          SPIN_PAUSE_FAR();
+        }
+        if (go == 1) agent_acquire();  // ONE acquire for the workgroup: the merged lists, colbits, group rows
+      }
+      s_go = go;
+    }
+    EMU_SITE("walker: served?");
+    __syncthreads();
+    if (s_go != 1) return;
+    resolve_round<GE>(lds, st, vb);
+    EMU_SITE("walker: round done");
+    __syncthreads();  // the walk is over (the helper waves wait here), its stores are issued
+    if (threadIdx.x == 0) {
+      const unsigned head = vb.ctl->head;  // (written by this thread, resolve_finish)
+      agent_release();  // offer state, results, group chains, the control block: in memory before the request is
+      if (head >= K) {
+        st_agent(&slot->done, 1u);
+        s_go = 0;
+      } else {
+        st_agent(&slot->req, ld_agent(&slot->req) + 1u);
+      }
+    }
+    __syncthreads();
+    if (s_go != 1) return;
+  }
+}
+template <bool GE, int N>
+__global__ void __launch_bounds__(MV_RTHREADS) match_walkers_pack(const WalkPack<N> p, ServeSlot* slots, ServeCtl* sc, unsigned long long spin_ticks) {
+  __shared__ __attribute__((aligned(16))) char lds[MV_RLDS_BYTES];
+  __shared__ int s_go;
+  const WalkCtx& c = p.c[blockIdx.x];
+  walk_pool<GE>(lds, s_go, c.st, c.vb, &slots[blockIdx.x], sc, spin_ticks);
+}
+template <bool GE>
+__global__ void __launch_bounds__(MV_RTHREADS) match_walkers(const PoolCtx* __restrict__ ctx, ServeSlot* slots, ServeCtl* sc, unsigned long long spin_ticks) {
+  __shared__ __attribute__((aligned(16))) char lds[MV_RLDS_BYTES];
+  __shared__ int s_go;
+  const PoolCtx& c = ctx[blockIdx.x];
+  walk_pool<GE>(lds, s_go, c.st, c.vb, &slots[blockIdx.x], sc, spin_ticks);
+}

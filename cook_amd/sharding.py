@@ -135,7 +135,8 @@ class ShardedCluster:
 
     cycle(K): 1. per-pool running usage (device reduction)  2. all-reduce into quota-group usage
               3. per pool: set quota inputs, rank + take K (pools concurrently, one stream each), then the placements of all
-                 local pools in lockstep rounds (cook_cycle_match_multi); a single pool runs cook_cycle_run.
+                 local pools in ONE cook_cycle_match_multi call (served walkers: a persistent walker workgroup per pool beside
+                 serve launches); with COOK_MATCH_SERVED=0 as lockstep chains of launches, a single pool through cook_cycle_run.
     """
 
     def __init__(self, engines: Dict[int, PoolEngine], groups: QuotaGroups, world: int = 1, rank: int = 0, device=None, serial: bool = False):
@@ -161,6 +162,9 @@ class ShardedCluster:
         self.last_phase_ms = (0.0, 0.0, 0.0, 0.0)
         self.chain_whole_cycle = os.environ.get("COOK_CHAIN_WHOLE_CYCLE", "0") != "0"
         self.force_multi = os.environ.get("COOK_FORCE_MULTI", "0") != "0"  # every pool through the multi-pool launch path, one per chain (measurement)
+        # served walkers (match_v2.hpp): ALL pools of the rank in one cook_cycle_match_multi call — one persistent walker workgroup per
+        # pool beside serve launches, two streams per GPU whatever the number of pools.  COOK_MATCH_SERVED=0: lockstep chains as before.
+        self.served = os.environ.get("COOK_MATCH_SERVED", "1") != "0"
 
     @property
     def last_user_usage(self) -> Optional[np.ndarray]:
@@ -204,7 +208,8 @@ class ShardedCluster:
 
         t1 = time.perf_counter()
         multi = all(hasattr(self.engines[p], "cycle_run_rank") for p in self.pools)
-        lockstep = multi and (len(self.pools) > self.max_chains or self.force_multi)
+        served = multi and self.served and len(self.pools) <= 16
+        lockstep = multi and (len(self.pools) > self.max_chains or self.force_multi or served)
 
         # the per-user usage vectors of the local pools (north_star's collective payload) are extracted by the pools' own threads right
         # after their rank stage — in parallel, overlapped with the other pools' work — so that the end of the cycle only sums and reduces
@@ -234,7 +239,12 @@ class ShardedCluster:
                     user_parts[p] = self.engines[p].rank_user_usage(self.n_users)
 
         n_chains = max(1, min(len(self.pools), self.max_chains))
-        if lockstep and self.chain_whole_cycle:
+        if served:
+            from .engine import cycle_match_multi
+            list(self._tp_rank.map(run, self.pools))
+            t2 = time.perf_counter()
+            cycle_match_multi([self.engines[p] for p in self.pools])  # (falls back to lockstep launches inside the library if it must)
+        elif lockstep and self.chain_whole_cycle:
             # MI355X runs about four independent chains of small kernels at full speed (beyond that the hardware queues
             # share dispatch pipes: 4 pools 113 ms, 6 or 8 pools 186 ms per cycle), while pools in lockstep pay for the
             # slowest pool of every round (8 in lockstep: 215 ms).  So: at most MAX_CHAINS chains, pools spread over them;

@@ -17,3 +17,11 @@ def oracle():
     from oracle import pyoracle
     pyoracle.lib()
     return pyoracle
+
+
+@pytest.fixture(params=["served", "lockstep"])
+def multi_mode(request, monkeypatch):
+    """How cook_cycle_match_multi places several pools: served walkers (one persistent walker workgroup per pool beside serve launches;
+    the default) or lockstep launches (COOK_MATCH_SERVED=0, also what finishes a served match that gave up).  Same results either way."""
+    monkeypatch.setenv("COOK_MATCH_SERVED", "1" if request.param == "served" else "0")
+    return request.param

@@ -25,6 +25,14 @@ static inline T ld_agent(const T* p) { return *p; }
 template <class T>
 static inline void st_agent(T* p, T v) { *p = v; emu::progress(); }
 
+// hand-off between workgroups of different launches (the served walkers): memory is sequentially consistent here, and launches run
+// one after the other, so nothing ever waits — the served path runs in its STEPPING form (match_v2.hpp)
+static inline void agent_release() {}
+static inline void agent_acquire() {}
+#define SPIN_PAUSE_FAR() emu::yield()
+template <class T>
+static inline void st_system(T* p, T v) { *p = v; }
+
 // constant-rate (100 MHz) device clock for in-kernel phase timing
 static inline unsigned long long cook_ticks() { return 0ull; }
 

@@ -254,7 +254,7 @@ def test_cycle_with_considerable_filters(make_engine):
     assert 0 < len(pos) <= 150 and not np.array_equal(pos, np.arange(len(pos)))
 
 
-def test_lockstep_chain_of_pools_that_disagree(make_engine):
+def test_lockstep_chain_of_pools_that_disagree(make_engine, multi_mode):
     # good-enough 0.8 next to best fit, K = 120 next to all pending, in ONE lockstep chain (two pools: contexts in the kernel arguments;
     # five: from memory)
     for n in (2, 5):
@@ -329,7 +329,7 @@ def test_cycle_update_moves_the_eligible_mask(make_engine):
     P.cycle_update_mask_parity(make_engine, seed=77)
 
 
-def test_multi_pool(make_engine, algo=2):
+def test_multi_pool(make_engine, multi_mode, algo=2):
     # three pools of different sizes (different numbers of offer chunks, rounds and K, one of them with nothing pending): in lockstep
     # launches (blockIdx.z = pool)
     pools = [synth.make_pool(seed=71, n_pending=400, n_running=100, n_users=20, n_offers=300, gpus=True, constraints=True),
@@ -339,7 +339,7 @@ def test_multi_pool(make_engine, algo=2):
 
 
 @pytest.mark.parametrize("n,ge", [(2, 1.0), (4, 1.0), (6, 1.0), (4, 0.8), (6, 0.8)])
-def test_multi_pool_context_forms(make_engine, n, ge):
+def test_multi_pool_context_forms(make_engine, n, ge, multi_mode):
     # how the lockstep launches get their pools' contexts: in the kernel arguments for up to four pools (PoolPack<2> / PoolPack<4>,
     # picked by blockIdx.z), from a context record in memory beyond that — same placements either way, best fit and good-enough
     pools = [synth.make_pool(seed=170 + i, n_pending=220 + 40 * i, n_running=60, n_users=12, n_offers=50 + 30 * i, gpus=(i % 2 == 1),
@@ -347,12 +347,13 @@ def test_multi_pool_context_forms(make_engine, n, ge):
     P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=ge, match_algo=2), k=10 ** 9)
 
 
-@pytest.mark.parametrize("whole", [True, False], ids=["chain-runs-rank-and-placement", "rank-barrier-placement"])
-def test_sharded_cluster_lockstep_chains(make_engine, whole):
+@pytest.mark.parametrize("whole", [True, False, None], ids=["chain-runs-rank-and-placement", "rank-barrier-placement", "served-walkers"])
+def test_sharded_cluster_lockstep_chains(make_engine, whole, monkeypatch):
     # ShardedCluster.cycle as bench.py drives it, five pools on two launch chains (slots 3 + 2): quota inputs, rank per pool,
     # lockstep placement per chain; every pool against the oracle, on a repeated cycle
     from cook_amd import sharding, workload
     from oracle import checks
+    monkeypatch.setenv("COOK_MATCH_SERVED", "1" if whole is None else "0")  # (read by ShardedCluster and by the library)
     spec = workload.ClusterSpec(pools=5, pending=1500, running=500, offers=400, users=40)
     params = A.default_params(good_enough_fitness=1.0)
     pools = workload.make_pools(spec, range(spec.pools))
@@ -362,7 +363,8 @@ def test_sharded_cluster_lockstep_chains(make_engine, whole):
             engines[p] = make_engine(params)
             engines[p].cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
         cl = sharding.ShardedCluster(engines, workload.quota_groups(spec))
-        cl.max_chains, cl.chain_whole_cycle = 2, whole
+        cl.max_chains, cl.chain_whole_cycle = 2, bool(whole)
+        assert cl.served == (whole is None)  # (None: all five pools in one served call)
         cl.close()
 
         class Serial:  # the emulator runs one launch at a time (one process-wide fiber scheduler): the chains take turns here
@@ -373,6 +375,7 @@ def test_sharded_cluster_lockstep_chains(make_engine, whole):
         cl.cycle(K)
         cl.cycle(K)
         assert cl.last_phase_ms[1] > 0.0
+        assert engines[0].match_stats()["served_mode"] == (2 if whole is None else 0)  # (2: the stepping form, all the emulator can run)
         for p in pools:
             ranked, j2o, _ = engines[p].cycle_fetch()
             q = cl.quota_inputs(p, cl.last_pool_usage[p], cl.last_group_usage)
@@ -383,7 +386,7 @@ def test_sharded_cluster_lockstep_chains(make_engine, whole):
             e.close()
 
 
-def test_many_pools_good_enough(make_engine):
+def test_many_pools_good_enough(make_engine, multi_mode):
     # five pools in one lockstep chain (contexts from memory: more than a PoolPack holds), good-enough 0.8 (the reference's default),
     # groups of every type in some of the pools
     pools = [synth.make_pool(seed=171 + i, n_pending=250 + 60 * i, n_running=40, n_users=12, n_offers=90 + 40 * i, gpus=(i % 2 == 0),

@@ -269,14 +269,14 @@ def test_cycle_with_considerable_filters(make_engine):
 
 
 @pytest.mark.parametrize("n,ge", [(2, 1.0), (4, 1.0), (6, 1.0), (4, 0.8), (6, 0.8)])
-def test_multi_pool_context_forms(make_engine, n, ge):
+def test_multi_pool_context_forms(make_engine, n, ge, multi_mode):
     # the lockstep launches with their pools' contexts in the kernel arguments (PoolPack<2> / <4>) and, beyond four pools, read from memory
     pools = [synth.make_pool(seed=170 + i, n_pending=2500 + 500 * i, n_running=600, n_users=40, n_offers=300 + 250 * i, gpus=(i % 2 == 1),
                              constraints=(i % 3 == 0)) for i in range(n)]
     P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=ge, match_algo=2), k=10 ** 9)
 
 
-def test_lockstep_chain_of_pools_that_disagree(make_engine):
+def test_lockstep_chain_of_pools_that_disagree(make_engine, multi_mode):
     # good-enough 0.8 next to best fit, K = 120 next to all pending, in ONE lockstep chain (two pools: contexts in the kernel arguments;
     # five: from memory)
     for n in (2, 5):
@@ -295,7 +295,7 @@ def test_cycle_update_moves_the_eligible_mask(make_engine):
     P.cycle_update_mask_parity(make_engine, seed=77)
 
 
-def test_multi_pool(make_engine, algo=2):
+def test_multi_pool(make_engine, multi_mode, algo=2):
     pools = [synth.make_pool(seed=71, n_pending=6000, n_running=2000, n_users=100, n_offers=3000, gpus=True, constraints=True),
              synth.make_pool(seed=72, n_pending=3000, n_running=500, n_users=50, n_offers=400),
              synth.make_pool(seed=73, n_pending=0, n_running=30, n_users=5, n_offers=20),
