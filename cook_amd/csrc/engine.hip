@@ -1355,11 +1355,16 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
     // serve iterations, a few ahead of the device: each ends with the latch waiting (bounded) for the next request, so the chain is
     // paced by the walkers; iter_done / all_done arrive in page-locked memory
     constexpr unsigned DEPTH = 3;
-    unsigned long long spins = 0;
     volatile ServeHost* vh = hh;
+    const auto t_begin = std::chrono::steady_clock::now();
+    unsigned long long spins = 0;
+    bool stuck = false;
     while (!vh->all_done && !vh->error) {
       if (launched - vh->iter_done >= DEPTH) {
-        if (++spins > 40000000000ull) lead->fail(COOK_E_STATE, "cook_cycle_match_multi: the serve launches stopped finishing");
+        if ((++spins & 0xFFFFull) == 0ull && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 30.0) {
+          stuck = true;  // (the walkers give up on their own after COOK_SERVE_WALK_TIMEOUT_US without being served)
+          break;
+        }
         continue;
       }
       launch_serve();
@@ -1367,6 +1372,7 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
     }
     COOK_HIP(hipStreamSynchronize(lead->s_serve));
     COOK_HIP(hipStreamSynchronize(lead->s_walk));
+    if (stuck) lead->fail(COOK_E_STATE, "cook_cycle_match_multi: the serve launches stopped finishing");
   }
   // what the pools reached
   std::vector<WinCtl> hc(L);

@@ -2412,13 +2412,13 @@ struct ServeHost {  // page-locked host memory, written by the latch with system
 static __device__ __forceinline__ void serve_latch(ServeCtl* sc, ServeSlot* slots, ServeHost* host, unsigned long long poll_ticks) {
   const unsigned lane = lane_id();
   const unsigned n = wave_uniform_u32(sc->n_pools), nl = wave_uniform_u32(sc->n_latched);
-  if (lane < nl) {
-    const unsigned p = sc->latched_pool[lane], q = sc->latched_seq[lane];
-    sc->served[p] = q;
-    st_agent(&slots[p].ready, q);
+  unsigned mine = lane < n ? sc->served[lane] : 0u;  // (lane = pool; the previous latch's values)
+  for (unsigned x = 0; x < nl; ++x) {                  // ... brought up to date from the iteration that just ran, without a trip through memory
+    const unsigned p = wave_uniform_u32(sc->latched_pool[x]), q = wave_uniform_u32(sc->latched_seq[x]);
+    if (lane == p) mine = q;
   }
-  wave_sync();
-  const unsigned mine = lane < n ? sc->served[lane] : 0u;
+  if (lane < n) sc->served[lane] = mine;
+  if (lane < nl) st_agent(&slots[sc->latched_pool[lane]].ready, sc->latched_seq[lane]);
   const unsigned long long t0 = cook_ticks();
   unsigned rq = 0, dn = 0;
   unsigned long long pend, alive;
