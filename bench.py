@@ -399,7 +399,7 @@ def main():
     else:
         everyone = [mine]
     collective = None
-    if rank == 0:
+    if rank == 0 and not args.as_rank_of:  # (--as-rank-of times one rank's share of the pools in a single process: no collective to report)
         all_usage = {int(p): u for r in everyone for p, u in r["pool_usage"].items()}
         assert sorted(all_usage) == list(range(P)), f"the ranks hold pools {sorted(all_usage)}, the cluster has {P}"
         want = sharding.group_usage_matrix(qg, all_usage)

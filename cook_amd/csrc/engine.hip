@@ -1340,12 +1340,14 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
   if (stepping) {
     unsigned guard = 0;
     for (;;) {
+      // (one phase at a time, on the GPU too: the latch launch publishes nothing and expects to find every open request unlatched)
       launch_serve();     // evaluates what the latch put together (first: every pool's first window), publishes, finds nothing new
       ++launched;
+      COOK_HIP(hipStreamSynchronize(lead->s_serve));
       launch_walkers();   // every pool walks the windows it has been served, asks for the next, returns
+      COOK_HIP(hipStreamSynchronize(lead->s_walk));
       KLS("match_serve_latch", lead->s_serve, match_serve_latch, 1, COOK_WAVE, sctl, slots, hh);
       ++launched;
-      COOK_HIP(hipStreamSynchronize(lead->s_walk));
       COOK_HIP(hipStreamSynchronize(lead->s_serve));
       if (hh->all_done || hh->error) break;
       if (++guard > 4000000u) lead->fail(COOK_E_STATE, "cook_cycle_match_multi: served placement made no progress");

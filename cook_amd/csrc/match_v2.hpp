@@ -437,13 +437,19 @@ struct EvalWaveLds {  // what ONE wave stages for the offers it walks (MV_OCW at
   int oacount[MV_OCW];
   uint32_t attr[MV_OCW][MV_NA];  // the first MV_NA attribute values of the offers (0 = absent)
 };
+// One workgroup's LDS: the offers its waves stage while they scan, and — in the SAME bytes, behind a workgroup barrier — the waves'
+// lists for the tile's epilogue (as two regions a block took 46.6 KB: three blocks per CU whatever the register count).
 template <bool GE>
 struct EvalLds {
-  double fit[MV_EW][COOK_WAVE][MV_L];
-  int idx[MV_EW][COOK_WAVE][MV_L];
-  unsigned long long ge[MV_EW][COOK_WAVE];  // (GE) the waves' good-enough bits
-  unsigned cnt[MV_EW][COOK_WAVE][3];
-  EvalWaveLds wave[MV_EW];
+  union {
+    EvalWaveLds wave[MV_EW];
+    struct {
+      double fit[MV_EW][COOK_WAVE][MV_L];
+      int idx[MV_EW][COOK_WAVE][MV_L];
+      unsigned long long ge[MV_EW][COOK_WAVE];  // (GE) the waves' good-enough bits
+      unsigned cnt[MV_EW][COOK_WAVE][3];
+    };
+  };
 };
 
 // the job of one lane and its running results over the offers seen so far
@@ -760,6 +766,7 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
 #endif
   const bool valid = E.valid, use_ge = GE && E.use_ge;
   // ---- merge the block's MV_EW wave lists per job through LDS -------------------------------------------------------
+  sync();  // (the lists go where the waves' staged offers were: every wave of the tile is done scanning)
 #pragma unroll
   for (int q = 0; q < MV_L; ++q) {
     s_fit[w][lane][q] = E.tf[q];
