@@ -171,13 +171,14 @@ struct cook_engine {
   WinCtl deferred_c0{};
   WinCtl* h_multi = nullptr;  // pinned: the pools' WinCtl read-backs
   // served walkers (match_rounds_served): the two streams of a served match led by this engine, its control blocks, what it did
-  hipStream_t s_walk = nullptr, s_serve = nullptr;
+  static constexpr unsigned kMaxServers = 4;
+  hipStream_t s_walk = nullptr, s_serve[kMaxServers] = {nullptr, nullptr, nullptr, nullptr};
   DArr<ServeSlot> w_slots;
   DArr<ServeCtl> w_sctl;
-  ServeHost* h_serve = nullptr;  // pinned
+  ServeHost* h_serve = nullptr;  // pinned, one per server
   struct ServedStats {
     unsigned mode = 0;  // 0 not served, 1 walkers beside serve launches, 2 stepping form
-    unsigned pools = 0, iterations = 0, empty_iterations = 0, pools_served = 0, fell_back = 0;
+    unsigned pools = 0, servers = 0, iterations = 0, empty_iterations = 0, pools_served = 0, fell_back = 0;
     double latch_wait_ms = 0;
   } served;
   int n_cus = 256;
@@ -1282,12 +1283,19 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
   lead->served = cook_engine::ServedStats{};
   if (L == 0) return true;
   if (L > MV_SERVE_MAX) return false;
-  if (!lead->s_walk) {  // created back to back: two different hardware queues
+  constexpr unsigned MAXS = cook_engine::kMaxServers;
+  if (!lead->s_walk) {  // created back to back: different hardware queues
     COOK_HIP(hipStreamCreateWithFlags(&lead->s_walk, hipStreamNonBlocking));
-    COOK_HIP(hipStreamCreateWithFlags(&lead->s_serve, hipStreamNonBlocking));
-    COOK_HIP(hipHostMalloc((void**)&lead->h_serve, sizeof(ServeHost), hipHostMallocDefault));
+    for (unsigned sv = 0; sv < MAXS; ++sv) COOK_HIP(hipStreamCreateWithFlags(&lead->s_serve[sv], hipStreamNonBlocking));
+    COOK_HIP(hipHostMalloc((void**)&lead->h_serve, MAXS * sizeof(ServeHost), hipHostMallocDefault));
   }
   if (!lead->h_multi) COOK_HIP(hipHostMalloc((void**)&lead->h_multi, 64 * sizeof(WinCtl), hipHostMallocDefault));
+  // SERVERS: streams of serve iterations, each for its own share of the pools (pool x -> server x mod S).  An iteration is a chain of
+  // latency-bound launches that leaves most of the chip idle (a window of 300 jobs is 980 waves for 4 096 slots), so two or three of
+  // them side by side serve the walkers sooner than one; the walkers' launch makes S + 1 streams.
+  unsigned S = 2;
+  if (const char* ev = std::getenv("COOK_SERVE_STREAMS")) S = (unsigned)std::max(1, std::atoi(ev));
+  S = std::min(std::min(S, MAXS), L);
   std::vector<PoolCtx> hctx(L);
   unsigned cmax = 1;
   bool any_ge = false;
@@ -1298,23 +1306,30 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
   }
   PoolCtx* dctx = lead->w_pctx.ensure(L);
   ServeSlot* slots = lead->w_slots.ensure(L);
-  ServeCtl* sctl = lead->w_sctl.ensure(1);
+  ServeCtl* sctl = lead->w_sctl.ensure(MAXS);
   std::vector<ServeSlot> hslots(L);
   for (unsigned x = 0; x < L; ++x) {
     std::memset((void*)&hslots[x], 0, sizeof(ServeSlot));
     hslots[x].req = 1u;  // the first window of every pool: asked for here
   }
-  ServeCtl hs;
-  std::memset(&hs, 0, sizeof(hs));
-  hs.n_pools = L;
-  hs.n_latched = L;
-  for (unsigned x = 0; x < L; ++x) hs.latched_pool[x] = x, hs.latched_seq[x] = 1u;
+  std::vector<ServeCtl> hs(S);
+  unsigned zmax = 1;
+  for (unsigned sv = 0; sv < S; ++sv) {
+    std::memset(&hs[sv], 0, sizeof(ServeCtl));
+    hs[sv].pool_first = sv;
+    hs[sv].pool_stride = S;
+    unsigned cnt = 0;
+    for (unsigned x = sv; x < L; x += S) hs[sv].latched_pool[cnt] = x, hs[sv].latched_seq[cnt] = 1u, ++cnt;
+    hs[sv].n_pools = hs[sv].n_latched = cnt;
+    zmax = std::max(zmax, cnt);
+  }
   ServeHost* hh = lead->h_serve;
-  std::memset(hh, 0, sizeof(*hh));
-  COOK_HIP(hipMemcpyAsync(dctx, hctx.data(), L * sizeof(PoolCtx), hipMemcpyHostToDevice, lead->s_serve));
-  COOK_HIP(hipMemcpyAsync(slots, hslots.data(), L * sizeof(ServeSlot), hipMemcpyHostToDevice, lead->s_serve));
-  COOK_HIP(hipMemcpyAsync(sctl, &hs, sizeof(hs), hipMemcpyHostToDevice, lead->s_serve));
-  COOK_HIP(hipStreamSynchronize(lead->s_serve));  // (pageable sources; and the walkers must find their slots initialised)
+  std::memset(hh, 0, MAXS * sizeof(ServeHost));
+  hipStream_t s0 = lead->s_serve[0];
+  COOK_HIP(hipMemcpyAsync(dctx, hctx.data(), L * sizeof(PoolCtx), hipMemcpyHostToDevice, s0));
+  COOK_HIP(hipMemcpyAsync(slots, hslots.data(), L * sizeof(ServeSlot), hipMemcpyHostToDevice, s0));
+  COOK_HIP(hipMemcpyAsync(sctl, hs.data(), S * sizeof(ServeCtl), hipMemcpyHostToDevice, s0));
+  COOK_HIP(hipStreamSynchronize(s0));  // (pageable sources; and the walkers must find their slots initialised)
   WalkPack<MV_WALK_PACK> wp{};
   const bool packed = L <= (unsigned)MV_WALK_PACK && pack_args();
   for (unsigned x = 0; x < (unsigned)MV_WALK_PACK; ++x) {
@@ -1329,58 +1344,72 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
     if (packed) KLS("match_walkers", lead->s_walk, (match_walkers_pack<GE, MV_WALK_PACK>), L, MV_RTHREADS, wp, slots, sctl, spin);
     else KLS("match_walkers", lead->s_walk, match_walkers<GE>, L, MV_RTHREADS, (const PoolCtx*)dctx, slots, sctl, spin);
   };
-  auto serve = [&](auto ge_tag) {
+  auto serve = [&](auto ge_tag, unsigned sv) {
     constexpr bool GE = decltype(ge_tag)::value;
-    KLS("match_serve_eval", lead->s_serve, match_serve_eval<GE>, dim3(cmax, MV_JG, L), COOK_WAVE * MV_EW, (const PoolCtx*)dctx, (const ServeCtl*)sctl);
-    KLS("match_serve_merge", lead->s_serve, match_serve_merge<GE>, dim3(MV_MERGE_BLOCKS, 1, L), COOK_WAVE * MV_MW, (const PoolCtx*)dctx, sctl, slots, hh, poll);
+    hipStream_t st_ = lead->s_serve[sv];
+    KLS("match_serve_eval", st_, match_serve_eval<GE>, dim3(cmax, MV_JG, zmax), COOK_WAVE * MV_EW, (const PoolCtx*)dctx, (const ServeCtl*)(sctl + sv));
+    KLS("match_serve_merge", st_, match_serve_merge<GE>, dim3(MV_MERGE_BLOCKS, 1, zmax), COOK_WAVE * MV_MW, (const PoolCtx*)dctx, sctl + sv, slots, hh + sv, poll);
   };
   auto launch_walkers = [&] { any_ge ? walkers(std::true_type{}) : walkers(std::false_type{}); };
-  auto launch_serve = [&] { any_ge ? serve(std::true_type{}) : serve(std::false_type{}); };
-  unsigned launched = 0;
+  auto launch_serve = [&](unsigned sv) { any_ge ? serve(std::true_type{}, sv) : serve(std::false_type{}, sv); };
+  volatile ServeHost* vh = hh;
+  auto all_done = [&] {
+    for (unsigned sv = 0; sv < S; ++sv)
+      if (!vh[sv].all_done) return false;
+    return true;
+  };
+  auto any_error = [&] {
+    for (unsigned sv = 0; sv < S; ++sv)
+      if (vh[sv].error) return true;
+    return false;
+  };
+  auto sync_servers = [&] {
+    for (unsigned sv = 0; sv < S; ++sv) COOK_HIP(hipStreamSynchronize(lead->s_serve[sv]));
+  };
+  std::vector<unsigned> launched(S, 0u);
+  bool stuck = false;
   if (stepping) {
     unsigned guard = 0;
     for (;;) {
       // (one phase at a time, on the GPU too: the latch launch publishes nothing and expects to find every open request unlatched)
-      launch_serve();     // evaluates what the latch put together (first: every pool's first window), publishes, finds nothing new
-      ++launched;
-      COOK_HIP(hipStreamSynchronize(lead->s_serve));
+      for (unsigned sv = 0; sv < S; ++sv) launch_serve(sv);  // evaluates what the latch put together (first: every pool's first window), publishes
+      sync_servers();
       launch_walkers();   // every pool walks the windows it has been served, asks for the next, returns
       COOK_HIP(hipStreamSynchronize(lead->s_walk));
-      KLS("match_serve_latch", lead->s_serve, match_serve_latch, 1, COOK_WAVE, sctl, slots, hh);
-      ++launched;
-      COOK_HIP(hipStreamSynchronize(lead->s_serve));
-      if (hh->all_done || hh->error) break;
+      for (unsigned sv = 0; sv < S; ++sv) KLS("match_serve_latch", lead->s_serve[sv], match_serve_latch, 1, COOK_WAVE, sctl + sv, slots, hh + sv);
+      sync_servers();
+      if (all_done() || any_error()) break;
       if (++guard > 4000000u) lead->fail(COOK_E_STATE, "cook_cycle_match_multi: served placement made no progress");
     }
   } else {
     launch_walkers();
-    // serve iterations, a few ahead of the device: each ends with the latch waiting (bounded) for the next request, so the chain is
-    // paced by the walkers; iter_done / all_done arrive in page-locked memory
+    // serve iterations, a few ahead of the device: each ends with the latch waiting (bounded) for the next request, so every server's chain
+    // is paced by its walkers; iter_done / all_done arrive in page-locked memory
     constexpr unsigned DEPTH = 3;
-    volatile ServeHost* vh = hh;
     const auto t_begin = std::chrono::steady_clock::now();
     unsigned long long spins = 0;
-    bool stuck = false;
-    while (!vh->all_done && !vh->error) {
-      if (launched - vh->iter_done >= DEPTH) {
-        if ((++spins & 0xFFFFull) == 0ull && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 30.0) {
-          stuck = true;  // (the walkers give up on their own after COOK_SERVE_WALK_TIMEOUT_US without being served)
-          break;
-        }
-        continue;
+    while (!all_done() && !any_error()) {
+      bool any = false;
+      for (unsigned sv = 0; sv < S; ++sv) {
+        if (vh[sv].all_done || launched[sv] - vh[sv].iter_done >= DEPTH) continue;
+        launch_serve(sv);
+        ++launched[sv];
+        any = true;
       }
-      launch_serve();
-      ++launched;
+      if (!any && (++spins & 0xFFFFull) == 0ull && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 30.0) {
+        stuck = true;  // (the walkers give up on their own after COOK_SERVE_WALK_TIMEOUT_US without being served)
+        break;
+      }
     }
-    COOK_HIP(hipStreamSynchronize(lead->s_serve));
+    sync_servers();
     COOK_HIP(hipStreamSynchronize(lead->s_walk));
     if (stuck) lead->fail(COOK_E_STATE, "cook_cycle_match_multi: the serve launches stopped finishing");
   }
   // what the pools reached
   std::vector<WinCtl> hc(L);
-  for (unsigned x = 0; x < L; ++x) COOK_HIP(hipMemcpyAsync(&lead->h_multi[x], hctx[x].vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, lead->s_serve));
-  COOK_HIP(hipMemcpyAsync(&hs, sctl, sizeof(hs), hipMemcpyDeviceToHost, lead->s_serve));
-  COOK_HIP(hipStreamSynchronize(lead->s_serve));
+  for (unsigned x = 0; x < L; ++x) COOK_HIP(hipMemcpyAsync(&lead->h_multi[x], hctx[x].vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, s0));
+  COOK_HIP(hipMemcpyAsync(hs.data(), sctl, S * sizeof(ServeCtl), hipMemcpyDeviceToHost, s0));
+  COOK_HIP(hipStreamSynchronize(s0));
   bool complete = true;
   for (unsigned x = 0; x < L; ++x) {
     hc[x] = lead->h_multi[x];
@@ -1389,17 +1418,20 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
   }
   lead->served.mode = stepping ? 2u : 1u;
   lead->served.pools = L;
-  lead->served.iterations = hs.iterations;
-  lead->served.empty_iterations = hs.empty_iterations;
-  lead->served.pools_served = hs.pools_served;
-  lead->served.latch_wait_ms = (double)hs.wait_ticks / 1.0e5;
+  lead->served.servers = S;
+  for (unsigned sv = 0; sv < S; ++sv) {
+    lead->served.iterations += hs[sv].iterations;
+    lead->served.empty_iterations += hs[sv].empty_iterations;
+    lead->served.pools_served += hs[sv].pools_served;
+    lead->served.latch_wait_ms += (double)hs[sv].wait_ticks / 1.0e5;
+  }
   if (!complete) {
     lead->served.fell_back = 1;
     return false;
   }
   for (unsigned x = 0; x < L; ++x) {
     cook_engine* ex = es[live[x]];
-    match_finish_rounds(ex, hctx[x].st, hctx[x].vb, hc[x], lead->s_serve);
+    match_finish_rounds(ex, hctx[x].st, hctx[x].vb, hc[x], s0);
     ex->has_deferred = false;
     ex->match_done = true;
   }
@@ -1562,7 +1594,8 @@ void cook_engine_destroy(cook_engine* e) {
   if (e->h_multi) (void)hipHostFree(e->h_multi);
   if (e->h_serve) (void)hipHostFree(e->h_serve);
   if (e->s_walk) (void)hipStreamDestroy(e->s_walk);
-  if (e->s_serve) (void)hipStreamDestroy(e->s_serve);
+  for (hipStream_t sv : e->s_serve)
+    if (sv) (void)hipStreamDestroy(sv);
   delete e->rb;
   e->rb = nullptr;
   delete e->cb;
@@ -2002,7 +2035,7 @@ int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap) {
   const WinCtl& c = e->last_ctl;
   v[16] = c.trunc_lists;
   v[17] = e->served.mode, v[18] = e->served.pools, v[19] = e->served.iterations, v[20] = e->served.empty_iterations;
-  v[21] = e->served.pools_served, v[22] = (uint32_t)(e->served.latch_wait_ms * 1000.0), v[23] = e->served.fell_back;
+  v[21] = e->served.pools_served, v[22] = (uint32_t)(e->served.latch_wait_ms * 1000.0), v[23] = e->served.fell_back, v[24] = e->served.servers;
   uint32_t n = 0;
   for (; n < cap && n < (uint32_t)COOK_MATCH_STATS_EX_N; ++n) out[n] = v[n];
   return (int)n;

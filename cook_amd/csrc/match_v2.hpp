@@ -2399,8 +2399,8 @@ struct alignas(128) ServeSlot {  // per pool; the walker's words and the server'
   unsigned pad1[31];
 };
 constexpr unsigned MV_SERVE_MAX = 16;  // pools per served call
-struct ServeCtl {
-  unsigned n_pools;
+struct ServeCtl {  // one per SERVER (a stream of serve iterations): it serves the pools first, first + stride, ... (n_pools of them)
+  unsigned n_pools, pool_first, pool_stride;
   unsigned n_latched;  // pools the next serve iteration evaluates, and the request numbers it serves
   unsigned latched_pool[MV_SERVE_MAX], latched_seq[MV_SERVE_MAX];
   unsigned served[MV_SERVE_MAX];  // = ServeSlot::ready of every pool (the latch's own copy)
@@ -2419,10 +2419,11 @@ struct ServeHost {  // page-locked host memory, written by the latch with system
 static __device__ __forceinline__ void serve_latch(ServeCtl* sc, ServeSlot* slots, ServeHost* host, unsigned long long poll_ticks) {
   const unsigned lane = lane_id();
   const unsigned n = wave_uniform_u32(sc->n_pools), nl = wave_uniform_u32(sc->n_latched);
-  unsigned mine = lane < n ? sc->served[lane] : 0u;  // (lane = pool; the previous latch's values)
+  const unsigned my_pool = wave_uniform_u32(sc->pool_first) + lane * wave_uniform_u32(sc->pool_stride);  // lane = the server's lane-th pool
+  unsigned mine = lane < n ? sc->served[lane] : 0u;  // (the previous latch's values)
   for (unsigned x = 0; x < nl; ++x) {                  // ... brought up to date from the iteration that just ran, without a trip through memory
     const unsigned p = wave_uniform_u32(sc->latched_pool[x]), q = wave_uniform_u32(sc->latched_seq[x]);
-    if (lane == p) mine = q;
+    if (my_pool == p) mine = q;
   }
   if (lane < n) sc->served[lane] = mine;
   if (lane < nl) st_agent(&slots[sc->latched_pool[lane]].ready, sc->latched_seq[lane]);
@@ -2431,8 +2432,8 @@ static __device__ __forceinline__ void serve_latch(ServeCtl* sc, ServeSlot* slot
   unsigned long long pend, alive;
   for (;;) {
     if (lane < n) {
-      rq = ld_agent(&slots[lane].req);
-      dn = ld_agent(&slots[lane].done);
+      rq = ld_agent(&slots[my_pool].req);
+      dn = ld_agent(&slots[my_pool].done);
     }
     alive = __ballot(lane < n && dn == 0u);
     pend = __ballot(lane < n && dn == 0u && rq != mine);
@@ -2442,7 +2443,7 @@ static __device__ __forceinline__ void serve_latch(ServeCtl* sc, ServeSlot* slot
   const unsigned long long waited = cook_ticks() - t0;
   if ((pend >> lane) & 1ull) {
     const unsigned x = (unsigned)__popcll(pend & ((1ull << lane) - 1ull));
-    sc->latched_pool[x] = lane;
+    sc->latched_pool[x] = my_pool;
     sc->latched_seq[x] = rq;
   }
   if (lane == 0) {
