@@ -1137,10 +1137,10 @@ void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, 
       path = path.substr(0, path.size() - 1) + "." + std::to_string(e->rlog_id);
     }
     if (FILE* f = std::fopen(path.c_str(), "w")) {
-      std::fprintf(f, "head,wcur,resolved,n_list,touched,stop,matched,setup_us,seq_us,segments\n");
+      std::fprintf(f, "head,wcur,resolved,n_list,touched,stop,matched,setup_us,seq_us,segments,h_cinfo,h_state,h_alive,h_col\n");
       for (auto& r : h)
-        std::fprintf(f, "%u,%u,%u,%u,%u,%u,%u,%.2f,%.2f,%u\n", r.head, r.wcur, r.resolved, r.n_list, r.touched, r.stop, r.matched,
-                     r.setup_ticks / 100.0, r.seq_ticks / 100.0, r.segments);
+        std::fprintf(f, "%u,%u,%u,%u,%u,%u,%u,%.2f,%.2f,%u,%08x,%08x,%08x,%08x\n", r.head, r.wcur, r.resolved, r.n_list, r.touched, r.stop, r.matched,
+                     r.setup_ticks / 100.0, r.seq_ticks / 100.0, r.segments, r.h_cinfo, r.h_state, r.h_alive, r.h_col);
       std::fclose(f);
     }
   }
@@ -1318,9 +1318,14 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
     std::memset(&hs[sv], 0, sizeof(ServeCtl));
     hs[sv].pool_first = sv;
     hs[sv].pool_stride = S;
+    hs[sv].dbg_fence = std::getenv("COOK_SERVE_FENCE") && std::atoi(std::getenv("COOK_SERVE_FENCE")) ? 1u : 0u;
     unsigned cnt = 0;
-    for (unsigned x = sv; x < L; x += S) hs[sv].latched_pool[cnt] = x, hs[sv].latched_seq[cnt] = 1u, ++cnt;
-    hs[sv].n_pools = hs[sv].n_latched = cnt;
+    for (unsigned x = sv; x < L; x += S) hs[sv].latch[0].pool[cnt] = x, hs[sv].latch[0].seq[cnt] = 1u, ++cnt;
+    hs[sv].n_pools = hs[sv].latch[0].n = cnt;
+    hs[sv].latch[0].ticket_target = cnt * (unsigned)MV_MERGE_BLOCKS;
+    hs[sv].dbg_delay[0] = (unsigned)env_ticks("COOK_SERVE_DELAY_PUBLISH_US", 0.0);
+    hs[sv].dbg_delay[1] = (unsigned)env_ticks("COOK_SERVE_DELAY_ACQ_US", 0.0);
+    hs[sv].dbg_delay[2] = (unsigned)env_ticks("COOK_SERVE_DELAY_READ_US", 0.0);
     zmax = std::max(zmax, cnt);
   }
   ServeHost* hh = lead->h_serve;
@@ -1337,8 +1342,10 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
     wp.c[x].vb = hctx[x < L ? x : 0].vb;
   }
   const bool stepping = served_stepping();
+  const bool one_stream = std::getenv("COOK_SERVE_ONE_STREAM") && std::atoi(std::getenv("COOK_SERVE_ONE_STREAM"));  // (diagnostics: the servers' iterations all on one stream)
   const unsigned long long spin = stepping ? 0ull : env_ticks("COOK_SERVE_WALK_TIMEOUT_US", 2.0e6);  // a walker not served for 2 s gives up
   const unsigned long long poll = stepping ? 0ull : env_ticks("COOK_SERVE_POLL_US", 40.0);          // the latch waits that long for a request
+  std::vector<unsigned> launched(S, 0u);  // serve iterations launched, per server
   auto walkers = [&](auto ge_tag) {
     constexpr bool GE = decltype(ge_tag)::value;
     if (packed) KLS("match_walkers", lead->s_walk, (match_walkers_pack<GE, MV_WALK_PACK>), L, MV_RTHREADS, wp, slots, sctl, spin);
@@ -1346,9 +1353,11 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
   };
   auto serve = [&](auto ge_tag, unsigned sv) {
     constexpr bool GE = decltype(ge_tag)::value;
-    hipStream_t st_ = lead->s_serve[sv];
-    KLS("match_serve_eval", st_, match_serve_eval<GE>, dim3(cmax, MV_JG, zmax), COOK_WAVE * MV_EW, (const PoolCtx*)dctx, (const ServeCtl*)(sctl + sv));
-    KLS("match_serve_merge", st_, match_serve_merge<GE>, dim3(MV_MERGE_BLOCKS, 1, zmax), COOK_WAVE * MV_MW, (const PoolCtx*)dctx, sctl + sv, slots, hh + sv, poll);
+    hipStream_t st_ = lead->s_serve[one_stream ? 0u : sv];
+    const unsigned it = launched[sv];  // the iteration's number picks its latch list (ServeLatch)
+    KLS("match_serve_eval", st_, match_serve_eval<GE>, dim3(cmax, MV_JG, zmax), COOK_WAVE * MV_EW, (const PoolCtx*)dctx, (const ServeCtl*)(sctl + sv), it);
+    KLS("match_serve_merge", st_, match_serve_merge<GE>, dim3(MV_MERGE_BLOCKS, 1, zmax), COOK_WAVE * MV_MW, (const PoolCtx*)dctx, sctl + sv, slots, hh + sv, poll, it);
+    ++launched[sv];
   };
   auto launch_walkers = [&] { any_ge ? walkers(std::true_type{}) : walkers(std::false_type{}); };
   auto launch_serve = [&](unsigned sv) { any_ge ? serve(std::true_type{}, sv) : serve(std::false_type{}, sv); };
@@ -1366,7 +1375,6 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
   auto sync_servers = [&] {
     for (unsigned sv = 0; sv < S; ++sv) COOK_HIP(hipStreamSynchronize(lead->s_serve[sv]));
   };
-  std::vector<unsigned> launched(S, 0u);
   bool stuck = false;
   if (stepping) {
     unsigned guard = 0;
@@ -1376,7 +1384,7 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
       sync_servers();
       launch_walkers();   // every pool walks the windows it has been served, asks for the next, returns
       COOK_HIP(hipStreamSynchronize(lead->s_walk));
-      for (unsigned sv = 0; sv < S; ++sv) KLS("match_serve_latch", lead->s_serve[sv], match_serve_latch, 1, COOK_WAVE, sctl + sv, slots, hh + sv);
+      for (unsigned sv = 0; sv < S; ++sv) KLS("match_serve_latch", lead->s_serve[sv], match_serve_latch, 1, COOK_WAVE, sctl + sv, slots, hh + sv, launched[sv] - 1u);
       sync_servers();
       if (all_done() || any_error()) break;
       if (++guard > 4000000u) lead->fail(COOK_E_STATE, "cook_cycle_match_multi: served placement made no progress");
@@ -1393,7 +1401,6 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
       for (unsigned sv = 0; sv < S; ++sv) {
         if (vh[sv].all_done || launched[sv] - vh[sv].iter_done >= DEPTH) continue;
         launch_serve(sv);
-        ++launched[sv];
         any = true;
       }
       if (!any && (++spins & 0xFFFFull) == 0ull && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 30.0) {

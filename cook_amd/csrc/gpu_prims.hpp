@@ -35,6 +35,11 @@ static __device__ __forceinline__ void agent_release() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 static __device__ __forceinline__ void agent_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// Every wave of a workgroup, BEFORE the barrier that precedes one thread's agent_release(): the wave's own stores have been acknowledged.
+// __syncthreads() waits for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier — seen in the ISA), so another wave's global stores can still
+// be in flight when the releasing thread's buffer_wbl2 runs; they then land in the XCD's L2 BEHIND the write-back and stay there.  Under
+// light load nobody notices; with four serve streams at once the walkers read stale list entries (profiles/r05c_probe.txt).
+static __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #define SPIN_PAUSE_FAR() __builtin_amdgcn_s_sleep(8)  // between polls of a word in global memory that another workgroup writes
 // a word in page-locked HOST memory that the host polls
 template <class T>

@@ -172,7 +172,10 @@ struct WinCtl {
 };
 
 struct RoundLog {  // one record per round (diagnostics; only written when V2Buf::round_log is set)
-  unsigned head, wcur, resolved, n_list, touched, stop, matched, setup_ticks, seq_ticks, segments, pad0, pad1;
+  unsigned head, wcur, resolved, n_list, touched, stop, matched, setup_ticks, seq_ticks, segments;
+  // what the round was GIVEN, as checksums (only computed when a log is kept): the merged lists' summary words of the window, the offer
+  // state and the alive bits the window was evaluated against, the static-constraint bits of the window's job groups
+  unsigned h_cinfo, h_state, h_alive, h_col;
 };
 constexpr unsigned MV_ROUND_LOG_CAP = 8192;
 
@@ -1116,6 +1119,7 @@ struct ResolveFixed {
   unsigned gfh[MV_GMAX][MV_FH];
   int glast[MV_GMAX];
   unsigned n_gslots;
+  unsigned dbg_h[4];                // (round log only) checksums of the round's inputs, see RoundLog
   int cmd;                          // the walker's word to the other waves: 1 = stage the next segment, 0 = the round is over
   unsigned seg_lo;                  // first walk position of the segment being staged
   int sink[COOK_WAVE];              // where lanes 1..63 put their copy of a result the walk stores (see store_result)
@@ -1200,12 +1204,33 @@ static __device__ __forceinline__ unsigned resolve_settle(ResolveFixed& L, const
     L.owner_none[0] = L.owner_none[1] = L.owner_none[2] = L.owner_none[3] = (unsigned char)OWNER_NONE;
     L.cmd = 0;
     L.n_gslots = 0;
+    L.dbg_h[0] = L.dbg_h[1] = L.dbg_h[2] = L.dbg_h[3] = 0u;
   }
   __syncthreads();
+  if (vb.round_log) {  // diagnostics: what this round was given
+    const unsigned ngrp = (nwin + COOK_WAVE - 1) / COOK_WAVE;
+    unsigned hs = 0, ha = 0, hc = 0;
+    for (unsigned v = tid; v < M; v += NT) {
+      const unsigned long long a = (unsigned long long)__double_as_longlong(st.ac[v]), m2 = (unsigned long long)__double_as_longlong(st.am[v]);
+      hs += (unsigned)(a >> 20) * (v + 1u) + (unsigned)(m2 >> 20) * (v + 7u) + (unsigned)st.acount[v] * 131u;
+      for (unsigned g = 0; g < ngrp; ++g) {
+        const unsigned long long w = vb.colbits[(size_t)v * MV_JGL + g];
+        hc += ((unsigned)w ^ (unsigned)(w >> 32)) * (v * 31u + g + 1u);
+      }
+    }
+    for (unsigned w2 = tid; w2 < (M + 63u) / 64u; w2 += NT) {
+      const unsigned long long w = st.alive[w2];
+      ha += ((unsigned)w ^ (unsigned)(w >> 32)) * (w2 + 1u);
+    }
+    atomicAdd(&L.dbg_h[1], hs);
+    atomicAdd(&L.dbg_h[2], ha);
+    atomicAdd(&L.dbg_h[3], hc);
+  }
   for (unsigned b = tid; b < nwin; b += NT) {
     const unsigned flags = vb.jr[head + b].flags;
     const unsigned info = vb.cinfo[(size_t)b * 4 + 0];
     const unsigned c1 = vb.cinfo[(size_t)b * 4 + 1], c2 = vb.cinfo[(size_t)b * 4 + 2], c4 = vb.cinfo[(size_t)b * 4 + 3];
+    if (vb.round_log) atomicAdd(&L.dbg_h[0], (info * 31u + c1 * 7u + c2 * 3u + c4) * (b + 1u));
     // members of balanced / attribute-equals groups excepted: a cotask's placement can make an offer FEASIBLE for them; a unique
     // group only ever takes hosts away (constraints.clj:586-598), like a resource
     const bool opens = (flags & JF_GROUPED) != 0 && ((flags >> 8) & 3u) != 1u;
@@ -1332,7 +1357,8 @@ static __device__ __forceinline__ void resolve_prefetch_segment(const SegLds<GE>
 // ---- the end of a round (lane 0 of the walking wave): statistics, the window of the next round, the control block back to HBM -----
 static __device__ __forceinline__ void resolve_finish(WinCtl& ctl, const V2Buf& vb, unsigned head, unsigned nwin, unsigned resolved, unsigned stop,
                                                       unsigned matched, unsigned head_matched, unsigned touched, unsigned n_list,
-                                                      unsigned n_segments, unsigned n_trunc, unsigned long long t_stage, unsigned long long t_all) {
+                                                      unsigned n_segments, unsigned n_trunc, unsigned long long t_stage, unsigned long long t_all,
+                                                      const unsigned* dbg_h) {
   ctl.head = head + resolved;
   ctl.rounds += 1;
   ctl.matched += matched;
@@ -1346,7 +1372,8 @@ static __device__ __forceinline__ void resolve_finish(WinCtl& ctl, const V2Buf& 
   if (vb.round_log && ctl.rounds <= MV_ROUND_LOG_CAP) {
     RoundLog r;
     r.head = head, r.wcur = ctl.wcur, r.resolved = resolved, r.n_list = n_list, r.touched = touched, r.stop = stop, r.matched = matched;
-    r.setup_ticks = (unsigned)t_stage, r.seq_ticks = (unsigned)(t_all - t_stage), r.segments = n_segments, r.pad0 = r.pad1 = 0;
+    r.setup_ticks = (unsigned)t_stage, r.seq_ticks = (unsigned)(t_all - t_stage), r.segments = n_segments;
+    r.h_cinfo = dbg_h[0], r.h_state = dbg_h[1], r.h_alive = dbg_h[2], r.h_col = dbg_h[3];
     vb.round_log[ctl.rounds - 1] = r;
   }
   if (stop == 1) ctl.stop_list += 1;
@@ -2310,7 +2337,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   }
   if (lane == 0)
     resolve_finish(ctl, vb, head, nwin, resolved, stop, matched, head_matched, nT + n_retired, n_list, n_segments, n_trunc, t_stage,
-                   cook_ticks() - tk0);
+                   cook_ticks() - tk0, L.dbg_h);
 }
 
 template <bool GE>
@@ -2399,34 +2426,54 @@ struct alignas(128) ServeSlot {  // per pool; the walker's words and the server'
   unsigned pad1[31];
 };
 constexpr unsigned MV_SERVE_MAX = 16;  // pools per served call
-struct ServeCtl {  // one per SERVER (a stream of serve iterations): it serves the pools first, first + stride, ... (n_pools of them)
+// What ONE serve iteration works on: the pools that had a request open when the iteration was put together, the request numbers it
+// serves, and the arrival count that completes its merge.  Two of them, used in turn (iteration `it` reads latch[it & 1], its last
+// merge workgroup writes latch[(it + 1) & 1]): workgroups of an iteration that START late — behind the latch, which happens when another
+// server's evaluation holds the chip's wave slots — still find the iteration's own list.  (With one list a late workgroup read the NEXT
+// iteration's pools, merged windows nobody had evaluated into lists a walker was reading, and took an arrival ticket it was not counted
+// for: profiles/r05i_probe.txt.)
+struct ServeLatch {
+  unsigned n;
+  unsigned ticket_target;  // cumulative: the arrival counter is never reset
+  unsigned pool[MV_SERVE_MAX], seq[MV_SERVE_MAX];
+};
+// one per SERVER (a stream of serve iterations): it serves the pools first, first + stride, ... (n_pools of them).  On cache lines of
+// its own, the arrival counter on another.
+struct alignas(256) ServeCtl {
   unsigned n_pools, pool_first, pool_stride;
-  unsigned n_latched;  // pools the next serve iteration evaluates, and the request numbers it serves
-  unsigned latched_pool[MV_SERVE_MAX], latched_seq[MV_SERVE_MAX];
+  unsigned dbg_fence;     // (diagnostics, COOK_SERVE_FENCE=1) every hand-off with full agent-scope fences by every workgroup
+  unsigned dbg_delay[3];  // (diagnostics) 100 MHz ticks to wait [0] before publishing, [1] between seeing ready and the acquire, [2] behind the acquire
+  ServeLatch latch[2];
   unsigned served[MV_SERVE_MAX];  // = ServeSlot::ready of every pool (the latch's own copy)
-  unsigned ticket;                // arrivals of the merge workgroups of the running iteration
   unsigned all_done;              // no walker is left
   unsigned error;                 // a walker gave up
   unsigned iterations, empty_iterations, pools_served;  // statistics
   unsigned long long wait_ticks;  // 100 MHz ticks the latch spent waiting for a request
+  alignas(128) unsigned ticket;   // arrivals of merge workgroups so far (agent-scope atomics only; zeroed by the host)
 };
-struct ServeHost {  // page-locked host memory, written by the latch with system-scope stores, polled by the host
+struct alignas(128) ServeHost {  // page-locked host memory, written by the latch with system-scope stores, polled by the host
   unsigned iter_done;  // serve iterations finished
   unsigned all_done, error, pad;
 };
 
-// the latch (one wave): publish what the iteration served, then put the next iteration together
-static __device__ __forceinline__ void serve_latch(ServeCtl* sc, ServeSlot* slots, ServeHost* host, unsigned long long poll_ticks) {
+// the latch of iteration `it` (one wave): publish what the iteration served, then put the next iteration together
+static __device__ __forceinline__ void serve_latch(ServeCtl* sc, ServeSlot* slots, ServeHost* host, unsigned long long poll_ticks, unsigned it) {
   const unsigned lane = lane_id();
-  const unsigned n = wave_uniform_u32(sc->n_pools), nl = wave_uniform_u32(sc->n_latched);
+  const ServeLatch& cur = sc->latch[it & 1u];
+  ServeLatch& nxt = sc->latch[(it + 1u) & 1u];
+  const unsigned n = wave_uniform_u32(sc->n_pools), nl = wave_uniform_u32(cur.n);
   const unsigned my_pool = wave_uniform_u32(sc->pool_first) + lane * wave_uniform_u32(sc->pool_stride);  // lane = the server's lane-th pool
   unsigned mine = lane < n ? sc->served[lane] : 0u;  // (the previous latch's values)
   for (unsigned x = 0; x < nl; ++x) {                  // ... brought up to date from the iteration that just ran, without a trip through memory
-    const unsigned p = wave_uniform_u32(sc->latched_pool[x]), q = wave_uniform_u32(sc->latched_seq[x]);
+    const unsigned p = wave_uniform_u32(cur.pool[x]), q = wave_uniform_u32(cur.seq[x]);
     if (my_pool == p) mine = q;
   }
   if (lane < n) sc->served[lane] = mine;
-  if (lane < nl) st_agent(&slots[sc->latched_pool[lane]].ready, sc->latched_seq[lane]);
+  if (sc->dbg_delay[0] != 0u) {
+    const unsigned long long d0 = cook_ticks();
+    while (cook_ticks() - d0 < sc->dbg_delay[0]) SPIN_PAUSE_FAR();
+  }
+  if (lane < nl) st_agent(&slots[cur.pool[lane]].ready, cur.seq[lane]);
   const unsigned long long t0 = cook_ticks();
   unsigned rq = 0, dn = 0;
   unsigned long long pend, alive;
@@ -2443,13 +2490,13 @@ static __device__ __forceinline__ void serve_latch(ServeCtl* sc, ServeSlot* slot
   const unsigned long long waited = cook_ticks() - t0;
   if ((pend >> lane) & 1ull) {
     const unsigned x = (unsigned)__popcll(pend & ((1ull << lane) - 1ull));
-    sc->latched_pool[x] = my_pool;
-    sc->latched_seq[x] = rq;
+    nxt.pool[x] = my_pool;
+    nxt.seq[x] = rq;
   }
   if (lane == 0) {
     const unsigned np = (unsigned)__popcll(pend);
-    sc->n_latched = np;
-    sc->ticket = 0u;
+    nxt.n = np;
+    nxt.ticket_target = cur.ticket_target + np * (unsigned)MV_MERGE_BLOCKS;
     sc->iterations += 1u;
     sc->empty_iterations += nl == 0u ? 1u : 0u;
     sc->pools_served += nl;
@@ -2461,39 +2508,61 @@ static __device__ __forceinline__ void serve_latch(ServeCtl* sc, ServeSlot* slot
     st_system(&host->iter_done, sc->iterations);
   }
 }
-__global__ void __launch_bounds__(COOK_WAVE) match_serve_latch(ServeCtl* sc, ServeSlot* slots, ServeHost* host) {
-  serve_latch(sc, slots, host, 0ull);  // (stepping form: the walkers have just run, nothing to wait for)
+// (stepping form) behind a walker launch: the latch of iteration `it` once more — it publishes the same numbers again and now finds the
+// requests the walkers have just posted
+__global__ void __launch_bounds__(COOK_WAVE) match_serve_latch(ServeCtl* sc, ServeSlot* slots, ServeHost* host, unsigned it) {
+  serve_latch(sc, slots, host, 0ull, it);
 }
 template <bool GE>
-__global__ void __launch_bounds__(COOK_WAVE* MV_EW) COOK_EVAL_OCCUPANCY match_serve_eval(const PoolCtx* __restrict__ ctx, const ServeCtl* __restrict__ sc) {
+__global__ void __launch_bounds__(COOK_WAVE* MV_EW) COOK_EVAL_OCCUPANCY match_serve_eval(const PoolCtx* __restrict__ ctx, const ServeCtl* __restrict__ sc, unsigned it) {
   __shared__ __attribute__((aligned(16))) char lds[sizeof(EvalLds<GE>)];
-  if (blockIdx.z >= sc->n_latched) return;
-  const PoolCtx& c = ctx[sc->latched_pool[blockIdx.z]];
+  const ServeLatch& cur = sc->latch[it & 1u];
+  if (blockIdx.z >= cur.n) return;
+  const PoolCtx& c = ctx[cur.pool[blockIdx.z]];
   if (blockIdx.x >= c.vb.C) return;
+  const bool dbg = sc->dbg_fence != 0u;
+  if (dbg) {
+    agent_acquire();
+    __syncthreads();
+  }
   eval_block<GE>(lds, c.in, c.st, c.vb, c.vb.ctl->head, c.vb.ctl->wcur, blockIdx.x, blockIdx.y, gridDim.y);
+  if (dbg) {
+    drain_stores();
+    agent_release();
+  }
 }
 template <bool GE>
 __global__ void __launch_bounds__(COOK_WAVE* MV_MW) match_serve_merge(const PoolCtx* __restrict__ ctx, ServeCtl* sc, ServeSlot* slots, ServeHost* host,
-                                                                      unsigned long long poll_ticks) {
+                                                                      unsigned long long poll_ticks, unsigned it) {
   __shared__ unsigned s_last;
-  const unsigned nl = sc->n_latched;
+  const ServeLatch& cur = sc->latch[it & 1u];  // (stable for the whole launch: the latch writes the OTHER one)
+  const unsigned nl = cur.n;
   if (nl == 0u ? (blockIdx.x | blockIdx.z) != 0u : blockIdx.z >= nl) return;  // (an empty iteration: block 0 is the latch)
   if (nl != 0u) {
-    const PoolCtx& c = ctx[sc->latched_pool[blockIdx.z]];
+    const PoolCtx& c = ctx[cur.pool[blockIdx.z]];
+    if (sc->dbg_fence != 0u) {
+      agent_acquire();
+      __syncthreads();
+    }
     merge_block<GE>(c.in, c.vb);
+    if (sc->dbg_fence != 0u) {
+      drain_stores();
+      agent_release();
+    }
   }
+  drain_stores();  // (every wave: its list entries are in the L2 before thread 0 writes the L2 back)
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned last = 1u;
     if (nl != 0u) {
       agent_release();  // this workgroup's lists are in memory before its arrival counts
-      last = atomicAdd(&sc->ticket, 1u) == gridDim.x * nl - 1u ? 1u : 0u;
+      last = atomicAdd(&sc->ticket, 1u) + 1u == cur.ticket_target ? 1u : 0u;
     }
     s_last = last;
   }
   __syncthreads();
   if (s_last == 0u || threadIdx.x >= (unsigned)COOK_WAVE) return;
-  serve_latch(sc, slots, host, poll_ticks);
+  serve_latch(sc, slots, host, poll_ticks, it);
 }
 
 struct WalkCtx {  // what resolve_round needs of a pool (MatchIn through vb.in_dev): small enough for MV_WALK_PACK of them in the kernel arguments
@@ -2529,16 +2598,32 @@ static __device__ __forceinline__ void walk_pool(char* lds, int& s_go, const Mat
           }
           SPIN_PAUSE_FAR();
         }
-        if (go == 1) agent_acquire();  // ONE acquire for the workgroup: the merged lists, colbits, group rows
+        if (go == 1) {
+          if (sc->dbg_delay[1] != 0u) {
+            const unsigned long long d0 = cook_ticks();
+            while (cook_ticks() - d0 < sc->dbg_delay[1]) SPIN_PAUSE_FAR();
+          }
+          agent_acquire();  // ONE acquire for the workgroup: the merged lists, colbits, group rows
+          if (sc->dbg_delay[2] != 0u) {
+            const unsigned long long d0 = cook_ticks();
+            while (cook_ticks() - d0 < sc->dbg_delay[2]) SPIN_PAUSE_FAR();
+          }
+        }
       }
       s_go = go;
     }
     EMU_SITE("walker: served?");
     __syncthreads();
     if (s_go != 1) return;
+    if (sc->dbg_fence != 0u) {
+      agent_acquire();
+      __syncthreads();
+    }
     resolve_round<GE>(lds, st, vb);
     EMU_SITE("walker: round done");
-    __syncthreads();  // the walk is over (the helper waves wait here), its stores are issued
+    drain_stores();   // (every wave: see drain_stores)
+    if (sc->dbg_fence != 0u) agent_release();
+    __syncthreads();  // the walk is over (the helper waves wait here), every store of the round has been acknowledged
     if (threadIdx.x == 0) {
       const unsigned head = vb.ctl->head;  // (written by this thread, resolve_finish)
       agent_release();  // offer state, results, group chains, the control block: in memory before the request is

@@ -33,13 +33,32 @@ for lib in libs:
         cl = sharding.ShardedCluster(engines, workload.quota_groups(spec))
         cl.cycle(K)
         torch.cuda.synchronize()
-        ts = []
-        for _ in range(4):
+        ts, bad = [], []
+        saved_logs = False
+        n_cycles = int(os.environ.get("PROBE_CYCLES", "4"))
+        for cyc in range(n_cycles):
             a = time.perf_counter()
             cl.cycle(K)
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - a) * 1e3)
-        out = [engines[p].cycle_fetch()[1] for p in pools]
+            out = [engines[p].cycle_fetch()[1] for p in pools]
+            rl = os.environ.get("COOK_ROUND_LOG")
+            if rl and ref is None and cyc == 0:  # the reference run's round logs
+                import glob, shutil
+                for f in glob.glob(rl[:-1] + ".*"):
+                    shutil.copy(f, f.replace("rlog.", "ref_rlog."))
+            if ref is not None:  # EVERY cycle against the reference run
+                for p, (x, y) in enumerate(zip(out, ref)):
+                    if not np.array_equal(x, y):
+                        bad.append((cyc, p, int(np.nonzero(x != y)[0][0]), int((x != y).sum())))
+            if rl and bad and not saved_logs:
+                import glob, shutil
+                saved_logs = True
+                tag = st.replace(" ", "_").replace("=", "")
+                for f in glob.glob(rl[:-1] + ".*"):
+                    shutil.copy(f, f.replace("rlog.", f"bad_{tag}_c{cyc}_rlog."))
+        if bad:
+            print("  MISMATCH (cycle, pool, first differing job, differing jobs):", bad[:12], flush=True)
         if ref is None:
             ref = out
             from oracle import checks  # (the first run against the oracle: first and last pool; every later run against the first)

@@ -29,6 +29,7 @@ static inline void st_agent(T* p, T v) { *p = v; emu::progress(); }
 // one after the other, so nothing ever waits — the served path runs in its STEPPING form (match_v2.hpp)
 static inline void agent_release() {}
 static inline void agent_acquire() {}
+static inline void drain_stores() {}
 #define SPIN_PAUSE_FAR() emu::yield()
 template <class T>
 static inline void st_system(T* p, T v) { *p = v; }
