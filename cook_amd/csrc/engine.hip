@@ -1293,7 +1293,7 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
   // SERVERS: streams of serve iterations, each for its own share of the pools (pool x -> server x mod S).  An iteration is a chain of
   // latency-bound launches that leaves most of the chip idle (a window of 300 jobs is 980 waves for 4 096 slots), so two or three of
   // them side by side serve the walkers sooner than one; the walkers' launch makes S + 1 streams.
-  unsigned S = 2;
+  unsigned S = 3;  // (eight pools on MI355X: 1 / 2 / 3 / 4 servers 56.6 / 53.7 / 52.7 / 57.3 ms: walkers + three servers are the four streams the part runs at full speed)
   if (const char* ev = std::getenv("COOK_SERVE_STREAMS")) S = (unsigned)std::max(1, std::atoi(ev));
   S = std::min(std::min(S, MAXS), L);
   std::vector<PoolCtx> hctx(L);

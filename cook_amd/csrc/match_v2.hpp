@@ -32,8 +32,14 @@
 #include "common.hpp"
 #include "match_kernels.hpp"
 
-// waves per SIMD the eval kernels are compiled for (-DCOOK_EVAL_WAVES=n builds a tuning variant: fewer registers, more waves)
-#ifdef COOK_EVAL_WAVES
+// waves per SIMD the eval kernels are compiled for (-DCOOK_EVAL_WAVES=n builds a tuning variant).  Four since round 5: the block's LDS
+// is 27.6 KB (EvalLds), so a fourth wave per SIMD is there for the taking at 128 VGPRs; the compiler spills 39 (best fit) / 62 (good-enough
+// launches) of the 158 / 161 registers it would like, and the cycle is still faster — eight pools 57.8 against 59.8 ms in lockstep pairs,
+// 52.2 against 52.9 ms with served walkers (profiles/r05q_probe8.txt); 0 = the compiler's choice (three waves)
+#ifndef COOK_EVAL_WAVES
+#define COOK_EVAL_WAVES 4
+#endif
+#if COOK_EVAL_WAVES > 0
 #define COOK_EVAL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(COOK_EVAL_WAVES, COOK_EVAL_WAVES)))
 #else
 #define COOK_EVAL_OCCUPANCY

@@ -208,7 +208,9 @@ class ShardedCluster:
 
         t1 = time.perf_counter()
         multi = all(hasattr(self.engines[p], "cycle_run_rank") for p in self.pools)
-        served = multi and self.served and len(self.pools) <= 16
+        # (measured on MI355X, profiles/r05q_pools_per_gpu.txt: 8 pools 52.9 ms served against 59.8 in lockstep pairs; 4 pools 45.9 against 44.9
+        #  as four chains of one pool each, 2 and 1 pools the same either way — up to max_chains pools every pool has a chain to itself)
+        served = multi and self.served and self.max_chains < len(self.pools) <= 16
         lockstep = multi and (len(self.pools) > self.max_chains or self.force_multi or served)
 
         # the per-user usage vectors of the local pools (north_star's collective payload) are extracted by the pools' own threads right
