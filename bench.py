@@ -61,7 +61,9 @@ def parse():
     return ap.parse_args()
 
 
-PLACEMENT_KERNELS = ("match_resolve2", "match_eval2", "match_merge2", "match_serial")
+# match_walkers / match_serve_*: the served form of the same three phases (one persistent walker workgroup per pool, ONE launch per cycle,
+# beside evaluation + merge launches for the pools that asked: cook_amd/csrc/match_v2.hpp "served walkers")
+PLACEMENT_KERNELS = ("match_resolve2", "match_eval2", "match_merge2", "match_serial", "match_walkers", "match_serve_eval", "match_serve_merge")
 
 
 def algorithmic_bytes(kernel, n_tasks, k, m, launches_per_match=1.0, pools_per_launch=1.0):
@@ -431,6 +433,9 @@ def main():
             launches_per_match = agg[dom][1] / (n_cycles * max(1, len(my_pools)))
             n_chains = min(len(my_pools), cluster.max_chains) if len(my_pools) > cluster.max_chains else len(my_pools)
             pools_per_launch = len(my_pools) / max(1, n_chains)
+            served_mode = engines[my_pools[0]].match_stats().get("served_mode", 0)
+            if served_mode and dom == "match_walkers":
+                pools_per_launch = float(len(my_pools))  # ONE walker launch per cycle places every pool of the rank
             nbytes = algorithmic_bytes(dom, n_pend + n_run, min(K, n_pend), n_off, launches_per_match, pools_per_launch)
             achieved = (nbytes / (avg_ms * 1e-3) / 1e9) if (nbytes and avg_ms > 0) else None
             total_ms = sum(v[0] for v in agg.values())
@@ -441,7 +446,9 @@ def main():
                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": nbytes, "launches_per_match": launches_per_match, "pools_per_launch": pools_per_launch,
                         "share_of_kernel_time": agg[dom][0] / total_ms if total_ms else None,
                         "note": "placement is a sequential dependency chain (job i+1 sees job i's commitment): "
-                                "latency-bound, not bandwidth-bound; see DESIGN.md",
+                                "latency-bound, not bandwidth-bound; see DESIGN.md"
+                                + ("; match_walkers is ONE persistent launch per cycle (a walker workgroup per pool) whose duration includes the time its "
+                                   "walkers wait for their windows to be evaluated" if dom == "match_walkers" else ""),
                         "kernels_ms_per_cycle": {k: round(v[0] / max(1, min(args.steps, 3)), 4) for k, v in
                                                  sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]}}
 
@@ -663,7 +670,8 @@ def main():
                                    + ("" if args.no_constraints else "; gpu dim + EQUALS/novel-host/unique-group constraints"),
                        "pools": P, "pending_total": n_pend * P, "running_total": n_run * P, "offers_total": n_off * P,
                        "users": args.users, "considerable_per_pool": K, "good_enough_fitness": args.good_enough, "match_algo": args.match_algo,
-                       "parallelism": f"pools sharded over {world} GPU(s); per rank at most {cluster.max_chains} concurrent launch chains (pools beyond that run in lockstep groups)", "pair_evaluations_per_cycle": considered * n_off},
+                       "parallelism": f"pools sharded over {world} GPU(s); per rank up to {cluster.max_chains} pools as launch chains of their own, more than that as served walkers "
+                                      f"(one persistent walker workgroup per pool beside evaluation launches)" + ("" if cluster.served else "; COOK_MATCH_SERVED=0: lockstep groups instead"), "pair_evaluations_per_cycle": considered * n_off},
             "last_cycle": {"ranked": ranked_n, "considered": considered, "matched": matched,
                            "stage_ms_pool0": {"rank": stage_ms[my_pools[0]][0], "match": stage_ms[my_pools[0]][1]},
                            "placement_stats_pool0": engines[my_pools[0]].match_stats()},

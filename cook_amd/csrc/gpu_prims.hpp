@@ -6,6 +6,7 @@
 #define EMU_SITE(s) ((void)0)  // deadlock diagnostics of the SIMT emulator (tests/simt_emu); nothing on the GPU
 #define COOK_SHAPE(gpu, emu) (gpu)  // a launch shape: the shipped value (the emulated build may substitute a small one)
 #define COOK_BUILD_NAME "hip gfx950"
+#define COOK_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))  // a kernel compiled for exactly n waves per SIMD
 // walk statistics are an emulated-build facility (design studies)
 #define WALK_STAT(i, v) ((void)0)
 #define WALK_STAT_PREV_LANE(i, win_lane, win, nT) ((void)0)

@@ -40,7 +40,7 @@
 #define COOK_EVAL_WAVES 4
 #endif
 #if COOK_EVAL_WAVES > 0
-#define COOK_EVAL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(COOK_EVAL_WAVES, COOK_EVAL_WAVES)))
+#define COOK_EVAL_OCCUPANCY COOK_WAVES_PER_SIMD(COOK_EVAL_WAVES)
 #else
 #define COOK_EVAL_OCCUPANCY
 #endif

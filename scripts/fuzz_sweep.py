@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--match", type=int, default=60, help="match / cycle configurations")
     ap.add_argument("--rebalance", type=int, default=60, help="rebalancer configurations")
+    ap.add_argument("--multi", type=int, default=0, help="multi-pool configurations (2-8 random pools through ONE cook_cycle_match_multi: served walkers with "
+                                                          "1-3 serve streams, or lockstep launches; pools that disagree on good-enough / K)")
     ap.add_argument("--emu", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the configurations")
     ap.add_argument("--algo", type=int, default=-1, help="force cook_params.match_algo (default: drawn per configuration)")
@@ -78,6 +80,27 @@ def main():
             print("FAIL match", it, kw, p.match_algo, p.good_enough_fitness, os.environ["COOK_EVAL_SPLIT"], str(ex)[:300])
             sys.exit(1)
     os.environ.pop("COOK_EVAL_SPLIT", None)
+    for it in range(args.multi):
+        n = int(rng.integers(2, 9))
+        pools, params, ks = [], [], []
+        ge_all = float(rng.choice([1.0, 1.0, 0.8, 0.5]))
+        mixed = bool(rng.integers(0, 3) == 0)
+        for i in range(n):
+            npd = int(rng.integers(1, int(1500 * sc)))
+            pools.append(synth.make_pool(seed=int(rng.integers(1, 1 << 30)), n_pending=npd, n_running=int(rng.integers(0, int(300 * sc))),
+                                         n_users=int(rng.integers(1, 30)), n_offers=int(rng.integers(1, int(500 * sc))), gpus=bool(rng.integers(0, 2)),
+                                         constraints=bool(rng.integers(0, 2)), fractional=bool(rng.integers(0, 2)), tie_heavy=bool(rng.integers(0, 2))))
+            params.append(A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5])) if mixed else ge_all, match_algo=2))
+            ks.append(int(rng.choice([10 ** 9, 10 ** 9, int(rng.integers(1, npd + 1))])))
+        os.environ["COOK_MATCH_SERVED"] = str(int(rng.integers(0, 4) != 0))
+        os.environ["COOK_SERVE_STREAMS"] = str(int(rng.integers(1, 4)))
+        try:
+            P.mixed_chain_parity(make_engine, pools, params, ks)
+        except AssertionError as ex:
+            print("FAIL multi", it, n, os.environ["COOK_MATCH_SERVED"], os.environ["COOK_SERVE_STREAMS"], str(ex)[:300])
+            sys.exit(1)
+    os.environ.pop("COOK_MATCH_SERVED", None)
+    os.environ.pop("COOK_SERVE_STREAMS", None)
     for it in range(args.rebalance):
         kw = dict(seed=int(rng.integers(1, 1 << 30)), n_running=int(rng.integers(0, int(900 * sc))), n_pending=int(rng.integers(1, 40)),
                   n_users=int(rng.integers(1, 25)), n_hosts=int(rng.integers(1, int(70 * sc))), fractional=bool(rng.integers(0, 2)),
@@ -91,7 +114,7 @@ def main():
         except AssertionError as ex:
             print("FAIL rebalance", it, kw, str(ex)[:300])
             sys.exit(1)
-    print(f"fuzz ok: {args.match} match / cycle configurations, {args.rebalance} rebalancer configurations, seed {args.seed}, "
+    print(f"fuzz ok: {args.match} match / cycle configurations, {args.multi} multi-pool configurations, {args.rebalance} rebalancer configurations, seed {args.seed}, "
           f"{'emulator' if args.emu else 'gpu'}")
 
 

@@ -13,6 +13,8 @@
 #define COOK_BUILD_NAME "simt-emu test build"
 #endif
 
+#define COOK_WAVES_PER_SIMD(n)  // (an occupancy request to the GPU compiler: nothing to emulate)
+
 // ---- wave-level rendezvous ---------------------------------------------------------------------------
 // On the GPU the 64 lanes of a wave run in lockstep and LDS operations of one wave retire in order, so this is a
 // compiler scheduling barrier only.  (tests/simt_emu runs lanes as independent fibers and maps it to a rendezvous.)

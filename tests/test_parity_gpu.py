@@ -450,11 +450,12 @@ def test_rank_c5_queue_size(make_engine):
     assert len(ranked) > 100_000
 
 
-def test_timed_configuration_parity(make_engine):
+def test_timed_configuration_parity(make_engine, multi_mode):
     """The configuration bench.py TIMES, driven exactly as bench.py drives it (cook_amd/workload.py builds it for both): the 8
     pools of configs[3] on one rank, ShardedCluster.cycle = quota-group all-reduce inputs + rank per pool + the placements of
-    all pools through the rank's multi-pool path (launch chains x lockstep slots).  Checked bit-exact against the oracle: pools
-    from DIFFERENT chains, and the first AND the second slot of a chain."""
+    all pools through the rank's multi-pool path — served walkers (the default: ONE persistent walker launch for the eight pools
+    beside three streams of evaluation launches, LIVE on the GPU) and launch chains x lockstep slots (COOK_MATCH_SERVED=0).
+    Checked bit-exact against the oracle on a repeated cycle: pools of different servers / chains, first and second slots."""
     from cook_amd import sharding, workload
     from oracle import checks
     spec = workload.ClusterSpec()
@@ -469,6 +470,8 @@ def test_timed_configuration_parity(make_engine):
         K = spec.per_pool[0]
         cl.cycle(K)
         cl.cycle(K)  # the timed region repeats cycles on resident inputs: check a repeat, not the first call
+        st0 = engines[0].match_stats()
+        assert st0["served_mode"] == (1 if multi_mode == "served" else 0) and st0["served_fell_back"] == 0
         n_chains = min(spec.pools, cl.max_chains)
         check = sorted({0, 1 % spec.pools, (n_chains + 1) % spec.pools, spec.pools - 1})  # chains 0, 1, 1 (second slot), last (second slot)
         for p in check:
@@ -479,6 +482,43 @@ def test_timed_configuration_parity(make_engine):
         cl.close()
     finally:
         for e in engines.values():
+            e.close()
+
+
+def test_served_walkers_ragged_pools_many_cycles(make_engine, monkeypatch):
+    """Served walkers LIVE, the case the emulator cannot run: six pools of very different sizes (walkers that finish at different
+    times, serve iterations with one to three pools, long stretches where a server only polls), 1 to 3 serve streams, eight cycles
+    each — every cycle of every pool against the lockstep launches' result of the same inputs (which the rest of the suite pins to
+    the oracle).  This is the shape that exposed the late-workgroup race of the first served version."""
+    from cook_amd.engine import cycle_match_multi
+    sizes = [(30000, 1500), (900, 60), (12000, 3000), (150, 20), (20000, 800), (5000, 5000)]
+    pools = [synth.make_pool(seed=900 + i, n_pending=npd, n_running=npd // 4, n_users=200, n_offers=m, gpus=(i % 2 == 0), constraints=(i % 3 != 1))
+             for i, (npd, m) in enumerate(sizes)]
+    params = A.default_params(good_enough_fitness=1.0)
+    engines = [make_engine(params) for _ in pools]
+    try:
+        for e, pool in zip(engines, pools):
+            e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+
+        def cycle():
+            for e in engines:
+                e.cycle_run_rank(10 ** 9)
+            cycle_match_multi(engines)
+            return [e.cycle_fetch() for e in engines]
+        monkeypatch.setenv("COOK_MATCH_SERVED", "0")
+        want = cycle()
+        assert engines[0].match_stats()["served_mode"] == 0
+        monkeypatch.setenv("COOK_MATCH_SERVED", "1")
+        for streams in (1, 2, 3):
+            monkeypatch.setenv("COOK_SERVE_STREAMS", str(streams))
+            for c in range(8):
+                got = cycle()
+                st_ = engines[0].match_stats()
+                assert st_["served_mode"] == 1 and st_["served_fell_back"] == 0 and st_["serve_streams"] == streams
+                for i, (a, b) in enumerate(zip(got, want)):
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], (streams, c, i)
+    finally:
+        for e in engines:
             e.close()
 
 
