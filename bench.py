@@ -200,13 +200,13 @@ def cpu_baseline_leg(args, params, cluster, pools, my_pools, K, n_off):
     for p in my_pools:  # ctypes views of the columns built once, outside every timed region
         pools[p].tasks.as_struct(), pools[p].pending_jobs.as_struct(), pools[p].offers.as_struct()
 
-    def one_pool(p, nt, out):
+    def one_pool(p, nt, out, deadline):
         out[p] = pyoracle.cycle(params, pools[p].tasks, pools[p].users, pools[p].pending_jobs, pools[p].offers, pools[p].groups,
-                                quota=quota[p], K=K, nthreads=nt)
+                                quota=quota[p], K=K, nthreads=nt, deadline_s=deadline)
 
-    def batch(which, nt):
+    def batch(which, nt, deadline):
         out = {}
-        ths = [threading.Thread(target=one_pool, args=(p, nt, out)) for p in which]
+        ths = [threading.Thread(target=one_pool, args=(p, nt, out, deadline)) for p in which]
         a = time.perf_counter()
         for t in ths:
             t.start()
@@ -216,34 +216,53 @@ def cpu_baseline_leg(args, params, cluster, pools, my_pools, K, n_off):
         assert len(out) == len(which), "an oracle thread failed"
         return wall, out
 
-    def run_form(at_once, nt):
-        """All of this process's pools, `at_once` of them side by side, the batches one after the other."""
+    def run_form(at_once, nt, deadline):
+        """All of this process's pools, `at_once` of them side by side, the batches one after the other.  -> (wall, outputs, wall over the
+        slowest library call) or None when a pool's placement ran into the deadline (a form that oversubscribes the cores the process may
+        really use: its evaluator threads meet once per job)."""
         wall, out, slack = 0.0, {}, 0.0
         for b in range(0, P, at_once):
-            w, o = batch(my_pools[b:b + at_once], nt)
+            w, o = batch(my_pools[b:b + at_once], nt, deadline)
+            if any(o[p][0] is None for p in o):
+                return None
             wall += w
             out.update(o)
             slack = max(slack, w / max(1e-9, max(sum(o[p][2].values()) for p in o)))
         return wall, out, slack
 
-    forms, a = [], P
-    while a >= 1:  # pools at once: P, P/2, ... 1;  threads per pool: 1, 2, 4, ... while a x t fits the cores
-        t = 1
-        while a * t <= cap and t <= 64:
-            if (threaded_ok or t == 1) and not (a < P and t == 1):
-                forms.append((a, t))
-            t *= 2
+    # the forms: every pool at once x t evaluator threads per pool (t = 1, 2, 4, ... while P x t fits the cores, at most 32: the reference's
+    # shape on a many-core host), then fewer pools at once with the threads that frees (P/2 x 2t_max, ..., 1 pool x up to 64 threads)
+    forms = []
+    a0 = min(P, cap)
+    t = 1
+    while a0 * t <= cap and t <= 32:
+        if threaded_ok or t == 1:
+            forms.append((a0, t))
+        t *= 2
+    a, tmax = a0 // 2, (forms[-1][1] if forms else 1) * 2
+    while a >= 1 and threaded_ok:
+        if a * tmax <= cap and tmax <= 64:
+            forms.append((a, tmax))
+            tmax *= 2
         a //= 2
-    if (P, 1) not in forms and P > cap:  # fewer cores than pools: as many pools at once as there are cores
-        forms.insert(0, (cap, 1))
-    variants, ref, budget_s = [], None, 90.0
+    variants, skipped, ref, budget_s = [], [], None, 75.0
     t_begin = time.perf_counter()
+    base_s = None
     for at_once, nt in forms:
         if variants and time.perf_counter() - t_begin > budget_s:
-            break
-        wall, out, slack = run_form(at_once, nt)
-        if slack > 1.1:  # the wall time must be the slowest pool's library call, not the harness: once more before it is reported as is
-            wall, out, slack = run_form(at_once, nt)
+            skipped.append({"pools_at_once": at_once, "threads_per_pool": nt, "why": "the leg's time budget was used up"})
+            continue
+        deadline = 0.0 if base_s is None else max(8.0, 2.5 * base_s)  # (per library call; the first form — 1 thread per pool — has none)
+        print(f"bench.py: cpu_baseline form {at_once} pool(s) at once x {nt} thread(s)", file=sys.stderr, flush=True)
+        res = run_form(at_once, nt, deadline)
+        if res is not None and res[2] > 1.1:  # the wall time must be the slowest pool's library call, not the harness: once more before it is reported as is
+            res = run_form(at_once, nt, deadline) or res
+        if res is None:
+            skipped.append({"pools_at_once": at_once, "threads_per_pool": nt, "why": f"a pool's placement had not finished after {deadline:.0f} s (oversubscribed cores)"})
+            continue
+        wall, out, slack = res
+        if base_s is None:
+            base_s = wall
         if ref is None:
             ref = out
         else:
@@ -260,7 +279,7 @@ def cpu_baseline_leg(args, params, cluster, pools, my_pools, K, n_off):
            "sample": f"the whole cycle (not a sample): oracle rank + placement of all K = {K} considerable jobs x {n_off} offers of each of the {P} "
                      f"pools; fastest form: {best['pools_at_once']} pool(s) at once x {best['threads_per_pool']} thread(s) per pool = "
                      f"{best['cores']} cores, {best['cycle_s']:.3f} s per cycle",
-           "variants": variants, "host_cores": host_cores, "harness_overhead_ok": all(v["wall_over_slowest_library_call"] <= 1.1 for v in variants),
+           "variants": variants, "forms_not_reported": skipped, "host_cores": host_cores, "harness_overhead_ok": all(v["wall_over_slowest_library_call"] <= 1.1 for v in variants),
            "rank_s_pool0": p0["rank"], "gather_s_pool0": p0["gather"], "match_s_pool0_single_thread": p0["match"],
            "note": "C++ restatement (-O2) of the reference algorithm; the JVM reference cannot run here (no JDK, Fenzo jar absent). One library "
                    "call per pool thread inside the timed region (rank -> gather -> placement, interpreter lock released); the threads-per-pool "
@@ -353,6 +372,11 @@ def main():
     # (the interpreter's cyclic collector stays out of the timed regions, as in timeit: a generation-2 pass over this process's object
     #  graph is a 10+ ms pause of whichever thread holds the lock; the host of a deployment is a JVM, not this harness)
     import gc
+    def mark(what):
+        if rank == 0:
+            print(f"bench.py [{time.time() - t0:7.1f} s] {what}", file=sys.stderr, flush=True)
+
+    mark("inputs staged; warm-up + timed region")
     gc.collect()
     gc.disable()
     for _ in range(args.warmup):
@@ -412,6 +436,7 @@ def main():
                       "group_usage_allreduced": np.asarray(cluster.last_group_usage).tolist(), "group_usage_equals_sum_over_all_pools": True,
                       "per_cycle": ["all_reduce(SUM) f64 [n_groups x 4] quota-group usage", f"all_reduce(SUM) f64 [{args.users} x 3] per-user usage"]}
 
+    mark("timed region done; roofline pass")
     # ---- roofline of the dominant kernel: second pass with per-kernel HIP events on each engine's own stream ----
     roofline = None
     if not args.no_roofline:  # every rank runs the pass (cycle() holds a collective); rank 0 reports
@@ -461,6 +486,7 @@ def main():
     #      against the oracle, bit-exact — every pool of rank 0 when the concurrent baseline ran (its outputs are reused), else the
     #      first pool (first slot of a launch chain) and the last (last slot of another chain).  A fast wrong answer must not
     #      produce a number: a mismatch raises.
+    mark("cpu_baseline leg + parity of the timed configuration")
     cpu = None
     parity_checked, parity_pools = False, []
     if rank == 0 and not (args.no_cpu_baseline and args.no_check):
@@ -485,6 +511,7 @@ def main():
     # ---- SURVEY.md §8d's reporting matrix, beside the headline (never instead of it): the reference's default cap K = 1000
     #      (config.clj:113: launch / latency-bound, p50 and p95 in microseconds), K = 1e5, the reference's DEFAULT good-enough
     #      fitness 0.8 (config.clj:111), and BASELINE.json configs[1] / configs[2] as single pools.  N = 1 only.
+    mark("extra configurations")
     extra = None
     if rank == 0 and world == 1 and not args.no_extras:
         extra = {}
@@ -556,6 +583,7 @@ def main():
     #      one and takes the assignments back.  cook_cycle_update per pool (1 % of the tasks leave, as many arrive — half of them new
     #      submissions —, fresh offers) from page-locked columns, the cycle, cook_cycle_fetch into page-locked buffers; beside it the
     #      cost of restaging EVERYTHING from pageable and from page-locked memory (cook_cycle_stage).
+    mark("boundary leg")
     boundary = None
     if rank == 0 and world == 1 and (args.boundary or not args.no_extras):
         from cook_amd.engine import PinnedArena
@@ -634,6 +662,7 @@ def main():
         finally:
             arena.close()  # (the engine reads host arrays only during a call)
 
+    mark("adjacent rows")
     # ---- the rows either side of the path, timed once on rank 0's first pool; not part of `value` ----
     adjacent = None
     if rank == 0 and not args.no_adjacent:

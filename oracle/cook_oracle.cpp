@@ -417,10 +417,13 @@ int first_failed_constraint(const cook_params* p, const cook_jobs* j, uint32_t k
   return -1;
 }
 
-void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, const cook_groups* g,
+// deadline_s > 0 (bench.py's cpu_baseline leg only): give up — return false, outputs incomplete — once the call has run that long
+bool match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, const cook_groups* g,
                 const uint32_t* reserved_hosts, uint32_t n_reserved, int32_t* job_to_offer, uint32_t* fail_code,
                 uint8_t* head_matched, int nthreads, const uint32_t* explain_pos = nullptr, uint32_t n_explain = 0,
-                uint32_t* explain_counts = nullptr) {
+                uint32_t* explain_counts = nullptr, double deadline_s = 0.0) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  bool finished = true;
   const uint32_t K = j->n, M = o->n;
   MatchState st;
   std::map<uint32_t, std::vector<uint32_t>> explain_rows;  // job position -> rows of explain_counts
@@ -500,9 +503,10 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
     workers.emplace_back([&, tix] {
       uint32_t seen = 0;
       for (;;) {
-        while (gen.v.load(std::memory_order_acquire) == seen) {
+        for (unsigned spins = 0; gen.v.load(std::memory_order_acquire) == seen; ++spins) {
           if (quit.load(std::memory_order_relaxed)) return;
-          __builtin_ia32_pause();
+          if (spins < 4096u) __builtin_ia32_pause();
+          else std::this_thread::yield();  // (more threads than the process may run at once: do not spin the others out of their turn)
         }
         ++seen;
         parts[tix].b = eval_range(cur_k, std::min(M, tix * chunk), std::min(M, (tix + 1) * chunk));
@@ -510,6 +514,10 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
       }
     });
   for (uint32_t k = 0; k < K; ++k) {
+    if (deadline_s > 0.0 && (k & 255u) == 0u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > deadline_s) {
+      finished = false;
+      break;
+    }
     // fenzo-utils/summarize-placement-failure (fenzo_utils.clj:33-55) over the TaskAssignmentResults of job k: per host the
     // resources that do not fit (message "cpus" / "mem", one count each) or else the first failing hard constraint's name
     auto ex = explain_rows.find(k);
@@ -548,7 +556,10 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
       done.v.store(0, std::memory_order_relaxed);
       gen.v.fetch_add(1, std::memory_order_release);
       b = eval_range(k, 0, std::min(M, chunk));
-      while (done.v.load(std::memory_order_acquire) != (uint32_t)(T - 1)) __builtin_ia32_pause();
+      for (unsigned spins = 0; done.v.load(std::memory_order_acquire) != (uint32_t)(T - 1); ++spins) {
+        if (spins < 4096u) __builtin_ia32_pause();
+        else std::this_thread::yield();
+      }
       for (int tix = 1; tix < T; ++tix) {
         const Best& q = parts[tix].b;
         b.fail |= q.fail;
@@ -577,6 +588,7 @@ void match_impl(const cook_params* p, const cook_jobs* j, const cook_offers* o, 
   for (auto& w : workers) w.join();
   // scheduler.clj:1495: matched-head-or-no-matches?
   if (head_matched) *head_matched = (matched == 0 || (K > 0 && job_to_offer[0] >= 0)) ? 1 : 0;
+  return finished;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -703,7 +715,7 @@ int oracle_match(const cook_params* p, const cook_jobs* j, const cook_offers* o,
 int oracle_cycle(const cook_params* p, const cook_tasks* t, const cook_users* u, const cook_pool_quota* pq,
                  const cook_jobs* pending_jobs, const cook_offers* o, const cook_groups* g, uint32_t K, int nthreads,
                  uint32_t* ranked_pending_idx, uint32_t* n_ranked, int32_t* job_to_offer, uint32_t* n_considerable,
-                 double* phase_s) {
+                 double* phase_s, double deadline_s) {
   using clk = std::chrono::steady_clock;
   auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   const auto t0 = clk::now();
@@ -769,7 +781,7 @@ int oracle_cycle(const cook_params* p, const cook_tasks* t, const cook_users* u,
     c.novel_host = v_nvh.data();
   }
   const auto t2 = clk::now();
-  match_impl(p, &c, o, g, nullptr, 0, job_to_offer, nullptr, nullptr, nthreads);
+  const bool finished = match_impl(p, &c, o, g, nullptr, 0, job_to_offer, nullptr, nullptr, nthreads, nullptr, 0, nullptr, deadline_s);
   const auto t3 = clk::now();
   if (ranked_pending_idx) std::copy(r.ranked.begin(), r.ranked.end(), ranked_pending_idx);
   if (n_ranked) *n_ranked = (uint32_t)r.ranked.size();
@@ -779,7 +791,7 @@ int oracle_cycle(const cook_params* p, const cook_tasks* t, const cook_users* u,
     phase_s[1] = secs(t1, t2);
     phase_s[2] = secs(t2, t3);
   }
-  return 0;
+  return finished ? 0 : 1;  // 1: gave up at the deadline (the outputs are incomplete)
 }
 
 // the same placement, plus for each job position of explain_pos the 16 COOK_WHY_* counts of cook_match_explain

@@ -135,10 +135,11 @@ def match(params, jobs: A.Jobs, offers: A.Offers, groups: A.Groups = None, reser
 
 
 def cycle(params, tasks: A.Tasks, users: A.Users, pending_jobs: A.Jobs, offers: A.Offers, groups: A.Groups = None, quota=None,
-          K=None, nthreads=1):
+          K=None, nthreads=1, deadline_s=0.0):
     """One pool's whole match cycle in ONE library call (oracle_cycle: rank -> first K ranked jobs gathered -> placement), for
     bench.py's cpu_baseline leg: the interpreter lock is released for the whole call, so pool threads run side by side.
-    -> (ranked pending task indices, job_to_offer int32[min(K, ranked)], {rank, gather, match} seconds)."""
+    -> (ranked pending task indices, job_to_offer int32[min(K, ranked)], {rank, gather, match} seconds); with deadline_s > 0 the
+    placement gives up after that many seconds: -> (None, None, seconds)."""
     n_pend = pending_jobs.n
     K = n_pend if K is None else int(K)
     ranked = np.zeros(max(1, tasks.n), dtype=np.uint32)
@@ -149,8 +150,10 @@ def cycle(params, tasks: A.Tasks, users: A.Users, pending_jobs: A.Jobs, offers: 
     gs = groups.as_struct() if groups is not None else None
     rc = lib().oracle_cycle(C.byref(params), C.byref(ts), C.byref(us), C.byref(quota) if quota is not None else None, C.byref(js),
                             C.byref(os_), C.byref(gs) if gs is not None else None, C.c_uint32(K), int(nthreads), _u32p(ranked),
-                            C.byref(nr), j2o.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nk), _f64p(phase))
-    assert rc == 0
+                            C.byref(nr), j2o.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nk), _f64p(phase), C.c_double(deadline_s))
+    assert rc in (0, 1)
+    if rc == 1:
+        return None, None, {"rank": float(phase[0]), "gather": float(phase[1]), "match": float(phase[2])}
     return ranked[: nr.value].copy(), j2o[: nk.value].copy(), {"rank": float(phase[0]), "gather": float(phase[1]), "match": float(phase[2])}
 
 
