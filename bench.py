@@ -193,6 +193,15 @@ def cpu_baseline_leg(args, params, cluster, pools, my_pools, K, n_off):
         host_cores = min(host_cores, len(os.sched_getaffinity(0)))
     except (AttributeError, OSError):
         pass
+    logical_cpus, quota_note = host_cores, None
+    try:  # a container's CPU quota: the cores the process may really use at once (the GPU boxes of this pool: 256 logical CPUs, quota 16)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+            if quota < host_cores:
+                host_cores, quota_note = quota, f"cgroup cpu.max {q} {per} = {quota} CPUs of {logical_cpus} logical"
+    except (OSError, ValueError):
+        pass
     P = len(my_pools)
     quota = {p: cluster.quota_inputs(p, cluster.last_pool_usage[p], cluster.last_group_usage) for p in my_pools}
     threaded_ok = args.good_enough >= 1.0  # (the oracle's host-bucketed form is best fit only)
@@ -279,7 +288,7 @@ def cpu_baseline_leg(args, params, cluster, pools, my_pools, K, n_off):
            "sample": f"the whole cycle (not a sample): oracle rank + placement of all K = {K} considerable jobs x {n_off} offers of each of the {P} "
                      f"pools; fastest form: {best['pools_at_once']} pool(s) at once x {best['threads_per_pool']} thread(s) per pool = "
                      f"{best['cores']} cores, {best['cycle_s']:.3f} s per cycle",
-           "variants": variants, "forms_not_reported": skipped, "host_cores": host_cores, "harness_overhead_ok": all(v["wall_over_slowest_library_call"] <= 1.1 for v in variants),
+           "variants": variants, "forms_not_reported": skipped, "host_cores": host_cores, "host_logical_cpus": logical_cpus, "host_cpu_quota": quota_note, "harness_overhead_ok": all(v["wall_over_slowest_library_call"] <= 1.1 for v in variants),
            "rank_s_pool0": p0["rank"], "gather_s_pool0": p0["gather"], "match_s_pool0_single_thread": p0["match"],
            "note": "C++ restatement (-O2) of the reference algorithm; the JVM reference cannot run here (no JDK, Fenzo jar absent). One library "
                    "call per pool thread inside the timed region (rank -> gather -> placement, interpreter lock released); the threads-per-pool "
@@ -453,6 +462,11 @@ def main():
             engines[p].set_profiling(False)
         if agg:
             dom = max(agg, key=lambda k: agg[k][0])
+            if "match_walkers" in agg:
+                # served walkers: the kernel that places the jobs is the ONE persistent walker launch of the cycle.  (The serve launches'
+                # event durations include the bounded wait of their latch for the next request — idle polling by one wave, up to
+                # COOK_SERVE_POLL_US per empty iteration —, so their sums say nothing about work.)
+                dom = "match_walkers"
             avg_ms = agg[dom][0] / max(1, agg[dom][1])
             n_cycles = max(1, min(args.steps, 3))
             launches_per_match = agg[dom][1] / (n_cycles * max(1, len(my_pools)))

@@ -28,6 +28,14 @@ kern = {}
 for k in sorted(set(f) & set(w)):
     fk, wk = f[k][0]["FETCH_SIZE"], w[k][0]["WRITE_SIZE"]
     kern[k] = {"fetch_kb_per_launch": fk, "write_kb_per_launch": wk, "hbm_bytes_per_launch": int((fk + wk) * 1024), "dispatches": f[k][1]}
+if "match_resolve2" in kern and "match_walkers" not in kern:
+    # the served walkers' ONE launch per cycle = every round of every pool: the resolve launches of the counted cycle (lockstep form,
+    # two pools per launch), summed.  Derived, and labelled so.
+    r = kern["match_resolve2"]
+    kern["match_walkers"] = {"fetch_kb_per_launch": r["fetch_kb_per_launch"] * r["dispatches"], "write_kb_per_launch": r["write_kb_per_launch"] * r["dispatches"],
+                             "hbm_bytes_per_launch": r["hbm_bytes_per_launch"] * r["dispatches"], "dispatches": 1,
+                             "derived": "match_resolve2 per launch x its dispatches in the counted cycle (the counter passes run the pools in lockstep "
+                                        "launches: rocprofv3 serialises counted dispatches, which a walker waiting for a serve launch cannot survive)"}
 doc = {"kernel_rev": open(os.path.join(src, "kernel_rev.txt")).read().strip(),
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes: the TCC counter slots of gfx950) of `bench.py --steps 1 "
                "--warmup 0 --no-cpu-baseline --no-check --no-extras --no-adjacent --no-roofline` (8 pools on one MI355X), mean per dispatch "

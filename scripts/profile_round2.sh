@@ -6,6 +6,9 @@
 #   4. SQ pass on one pool alone (instruction mix / wait cycles of the placement kernels without neighbours)
 #   5. kernel-trace --stats of the rebalancer sweep (C5)                       -> kernel_stats_rebalance.csv
 # Counter passes carry no trace domain other than the kernel list (gpurun refuses pmc + sys/hip traces).
+# Counter passes run the eight pools in LOCKSTEP launches (COOK_MATCH_SERVED=0): rocprofv3 serialises the dispatches it counts, and a
+# served walker waits for launches that would then never start (it gives up after its time-out and lockstep launches finish the match
+# anyway: slow, and not what one wants to count).  Same device functions either way: match_resolve2 is one round of the walker.
 set -u
 TAG=${1:-r02prof}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -26,7 +29,7 @@ kt() {  # name, command...
 pmc() {  # name, counters, command...
   local name=$1 ctr=$2; shift 2
   rm -rf /tmp/pmc_$name
-  timeout 400 rocprofv3 --pmc $ctr -d /tmp/pmc_$name -o p --output-format csv -- "$@" > /dev/null 2> "$OUT/pmc_$name.err"
+  COOK_MATCH_SERVED=0 timeout 400 rocprofv3 --pmc $ctr -d /tmp/pmc_$name -o p --output-format csv -- "$@" > /dev/null 2> "$OUT/pmc_$name.err"
   python "$ROOT/scripts/pmc_summary.py" /tmp/pmc_$name 24 > "$OUT/pmc_$name.txt"
   head -4 "$OUT/pmc_$name.txt" | cut -c1-400
 }
