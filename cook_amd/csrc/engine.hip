@@ -1094,10 +1094,53 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     }
     unsigned batch = 8;
     unsigned guard = 0;
+#ifdef COOK_EVAL_TRACE  // timing-study build: the waves' phase stamps of the evaluation of round COOK_EVAL_TRACE_ROUND, to stderr
+    const int trace_round = std::getenv("COOK_EVAL_TRACE_ROUND") ? std::atoi(std::getenv("COOK_EVAL_TRACE_ROUND")) : -1;
+    const size_t trace_words = (size_t)C * MV_JG * 3 + (size_t)C * MV_JG * 32;
+    vb.eval_trace = nullptr;
+    DArr<unsigned long long> d_trace;
+    if (trace_round >= 0) batch = 1;
+#endif
     while (hc.head < K) {
       for (unsigned r = 0; r < batch; ++r) {
+#ifdef COOK_EVAL_TRACE
+        if (trace_round >= 0 && (int)hc.rounds == trace_round) {
+          vb.eval_trace = d_trace.ensure(trace_words);
+          COOK_HIP(hipMemsetAsync(vb.eval_trace, 0, trace_words * 8, e->stream));
+        } else {
+          vb.eval_trace = nullptr;
+        }
+#endif
         if (ge) launch_round<true>(e, in, st, vb);
         else launch_round<false>(e, in, st, vb);
+#ifdef COOK_EVAL_TRACE
+        if (vb.eval_trace) {
+          std::vector<unsigned long long> h(trace_words);
+          COOK_HIP(hipMemcpy(h.data(), vb.eval_trace, trace_words * 8, hipMemcpyDeviceToHost));
+          double ph[5] = {0, 0, 0, 0, 0}, tot = 0, kmin = 1e30, kmax = 0;
+          unsigned nw = 0, nb = 0;
+          unsigned long long k0 = ~0ull, k1 = 0;
+          for (unsigned blk = 0; blk < C * (unsigned)MV_JG; ++blk) {
+            const unsigned long long a = h[blk * 3], b2 = h[blk * 3 + 1];
+            if (!a || !b2) continue;
+            k0 = std::min(k0, a), k1 = std::max(k1, b2);
+            kmin = std::min(kmin, (double)(b2 - a)), kmax = std::max(kmax, (double)(b2 - a));
+            ++nb;
+          }
+          for (size_t t = 0; t < (size_t)C * MV_JG * 4; ++t) {
+            const unsigned long long* w8 = &h[(size_t)C * MV_JG * 3 + t * 8];
+            if (!w8[0] || !w8[4]) continue;
+            for (int x = 0; x < 4; ++x) ph[x] += (double)(w8[x + 1] - w8[x]);
+            if (w8[5]) ph[4] += (double)(w8[5] - w8[4]);
+            tot += (double)((w8[5] ? w8[5] : w8[4]) - w8[0]);
+            ++nw;
+          }
+          std::fprintf(stderr, "EVALTRACE round %d head %u wcur %u: %u blocks over %.2f us (block %.2f..%.2f us); %u waves, mean us: lane setup %.2f, stage offers %.2f, "
+                               "constraint pass %.2f, fitness pass %.2f, epilogue (wave 0; /4 waves) %.2f, wave total %.2f\n",
+                       trace_round, hc.head, hc.wcur, nb, (k1 - k0) / 100.0, kmin / 100.0, kmax / 100.0, nw, ph[0] / nw / 100.0, ph[1] / nw / 100.0, ph[2] / nw / 100.0,
+                       ph[3] / nw / 100.0, ph[4] / nw / 100.0, tot / nw / 100.0);
+        }
+#endif
       }
       COOK_HIP(hipMemcpyAsync(e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
       sync(e);

@@ -104,7 +104,12 @@ static_assert(MV_WEVAL % 64 == 0 && MV_JG >= 1, "whole job groups");
 // settled in the parallel phase of the resolve kernel (no feasible offer under the snapshot, however the jobs before it fare) and
 // needs no LDS at all.  One C4 pool spent 152 of its 604 rounds resolving 512 such jobs each; with long windows that tail takes
 // about 20 rounds.
-constexpr int MV_WLONG = COOK_SHAPE(2560, 1024);
+// (round 5: 10 240 instead of 2 560 — the tail of a C4 pool, 60 000 jobs that no offer can take any more, is 5 rounds instead of 25; one pool
+//  42.1 -> 41.1 ms, eight pools 52.2 -> 50.7 ms; 5 120 / 20 480 measured 41.4 / 41.4 and 51.1 / 50.7: profiles/r05w_wlong_sweep.txt)
+#ifndef COOK_MV_WLONG
+#define COOK_MV_WLONG COOK_SHAPE(10240, 1024)
+#endif
+constexpr int MV_WLONG = COOK_MV_WLONG;
 constexpr int MV_JGL = MV_WLONG / 64;      // job groups of a long window (stride of colbits)
 static_assert(MV_WLONG % 64 == 0 && MV_WLONG >= MV_WEVAL && MV_WLONG < 65536, "JobL::b is 16 bits");
 static_assert(MV_OCW <= COOK_WAVE, "one lane stages one offer");
@@ -601,7 +606,9 @@ static __device__ __forceinline__ unsigned eval_split(unsigned wcur, unsigned sp
 // then walk them in a wave-uniform loop
 template <bool THROUGH, bool GE = true>
 static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds& W, const MatchIn& in, const MatchState& st, const V2Buf& vb,
-                                                        unsigned v0, unsigned jg, unsigned nsub = MV_OCW, unsigned slot = 0) {  // slot: E.gm word of this batch
+                                                        unsigned v0, unsigned jg, unsigned nsub = MV_OCW, unsigned slot = 0,  // slot: E.gm word of this batch
+                                                        unsigned long long* trp = nullptr) {  // (COOK_EVAL_TRACE builds: where the wave's time stamps go)
+  (void)trp;
   const unsigned lane = lane_id();
   const unsigned v1 = (v0 + nsub < in.M) ? v0 + nsub : in.M;
   if (v0 + lane < v1) {
@@ -615,6 +622,9 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
       W.attr[lane][q] = (in.o_attr && (unsigned)q < in.n_attr) ? in.o_attr[(size_t)(v0 + lane) * in.n_attr + q] : 0u;
   }
   wave_sync();
+#ifdef COOK_EVAL_TRACE
+  if (trp && lane == 0) trp[2] = cook_ticks();
+#endif
   const bool valid = E.valid;
   const JobRec& j = E.j;
   // offers that cannot take even the smallest job of the call any more fail every job on resources: count, never evaluate
@@ -672,6 +682,9 @@ static __device__ __forceinline__ void eval_scan_offers(EvalLane& E, EvalWaveLds
       statm |= stat ? 1ull << vi : 0ull;
     }
   }
+#ifdef COOK_EVAL_TRACE
+  if (trp && lane == 0) trp[3] = cook_ticks();
+#endif
   unsigned long long feasm = 0ull, gem = 0ull;  // gem: bit vi = the fitness on offer v0 + vi exceeds good-enough
   for (unsigned long long m = live; m != 0ull;) {  // wave-uniform
     const unsigned vi = (unsigned)__ffsll((unsigned long long)m) - 1u;
@@ -762,16 +775,18 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
   const unsigned b = jg * COOK_WAVE + lane;
   EvalLane E;
 #ifdef COOK_EVAL_TRACE
-  unsigned long long* trp = vb.eval_trace ? vb.eval_trace + (size_t)vb.C * MV_JG * 3 + ((size_t)jg * vb.C + ch) * 16 + w * 4 : nullptr;
+  unsigned long long* trp = vb.eval_trace ? vb.eval_trace + (size_t)vb.C * MV_JG * 3 + ((size_t)jg * vb.C + ch) * 32 + w * 8 : nullptr;
   if (trp && lane == 0) trp[0] = cook_ticks();
 #endif
   eval_lane_setup<GE>(E, in, st, vb, head, wcur, jg);
 #ifdef COOK_EVAL_TRACE
   if (trp && lane == 0) trp[1] = cook_ticks();
 #endif
-  eval_scan_offers<THROUGH, GE>(E, L.wave[w], in, st, vb, ch * MV_OCB + w * MV_OCW + part * ((unsigned)MV_OCW / split), jg, (unsigned)MV_OCW / split);
 #ifdef COOK_EVAL_TRACE
-  if (trp && lane == 0) trp[2] = cook_ticks();
+  eval_scan_offers<THROUGH, GE>(E, L.wave[w], in, st, vb, ch * MV_OCB + w * MV_OCW + part * ((unsigned)MV_OCW / split), jg, (unsigned)MV_OCW / split, 0, trp);
+  if (trp && lane == 0) trp[4] = cook_ticks();
+#else
+  eval_scan_offers<THROUGH, GE>(E, L.wave[w], in, st, vb, ch * MV_OCB + w * MV_OCW + part * ((unsigned)MV_OCW / split), jg, (unsigned)MV_OCW / split);
 #endif
   const bool valid = E.valid, use_ge = GE && E.use_ge;
   // ---- merge the block's MV_EW wave lists per job through LDS -------------------------------------------------------
@@ -854,7 +869,7 @@ static __device__ __forceinline__ void eval_tile_t(char* lds, const MatchIn& in,
   R.cnt[3] = t4;
   chunk_store(&reinterpret_cast<ChunkRecT<GE>*>(vb.prec)[(size_t)b * (vb.C * split) + ch * split + part], R, THROUGH, (n_out | n_g) == 0 ? chunk_count_piece<GE>() : 0u);
 #ifdef COOK_EVAL_TRACE
-  if (trp && lane == 0) trp[3] = cook_ticks();
+  if (trp && lane == 0) trp[5] = cook_ticks();
 #endif
 }
 template <bool GE = true>
