@@ -172,7 +172,7 @@ struct cook_engine {
   WinCtl* h_multi = nullptr;  // pinned: the pools' WinCtl read-backs
   // served walkers (match_rounds_served): the two streams of a served match led by this engine, its control blocks, what it did
   static constexpr unsigned kMaxServers = 4;
-  hipStream_t s_walk = nullptr, s_serve[kMaxServers] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t s_walk = nullptr, s_serve[kMaxServers] = {};
   DArr<ServeSlot> w_slots;
   DArr<ServeCtl> w_sctl;
   ServeHost* h_serve = nullptr;  // pinned, one per server
@@ -1151,6 +1151,9 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       const double per_round = (double)(hc.head - prev_head) / std::max(1u, hc.rounds - prev_rounds);
       const double est = (K - hc.head) / std::max(1.0, per_round);
       batch = (unsigned)std::min((double)batch_cap(), std::max(2.0, est * 1.05 + 2.0));  // over-launching is cheap: finished rounds exit at once
+#ifdef COOK_EVAL_TRACE
+      if (trace_round >= 0) batch = 1;  // (one round per look: the round whose stamps are wanted is found by its number)
+#endif
       if (++guard > 4u * K + 64u) e->fail(COOK_E_STATE, "cook_match: window placement made no progress");
     }
     match_finish_rounds(e, st, vb, hc, e->stream);
@@ -1327,9 +1330,14 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
   if (L == 0) return true;
   if (L > MV_SERVE_MAX) return false;
   constexpr unsigned MAXS = cook_engine::kMaxServers;
-  if (!lead->s_walk) {  // created back to back: different hardware queues
-    COOK_HIP(hipStreamCreateWithFlags(&lead->s_walk, hipStreamNonBlocking));
-    for (unsigned sv = 0; sv < MAXS; ++sv) COOK_HIP(hipStreamCreateWithFlags(&lead->s_serve[sv], hipStreamNonBlocking));
+  if (!lead->s_walk) {
+    // The walkers' stream must never share a HARDWARE queue with a serve stream: a serve launch queued behind the persistent walker
+    // launch would wait for walkers that wait for it (seen with eight serve streams on GPU_MAX_HW_QUEUES=8: every cycle ran into the
+    // walkers' time-out).  HIP hands streams of different priorities queues of different pools, so the walkers get the only
+    // high-priority stream of the process; the serve streams are ordinary ones (two of them on one queue would only take turns).
+    int prio_least = 0, prio_greatest = 0;
+    COOK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    COOK_HIP(hipStreamCreateWithPriority(&lead->s_walk, hipStreamNonBlocking, prio_greatest));
     COOK_HIP(hipHostMalloc((void**)&lead->h_serve, MAXS * sizeof(ServeHost), hipHostMallocDefault));
   }
   if (!lead->h_multi) COOK_HIP(hipHostMalloc((void**)&lead->h_multi, 64 * sizeof(WinCtl), hipHostMallocDefault));
@@ -1339,6 +1347,8 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
   unsigned S = 3;  // (eight pools on MI355X: 1 / 2 / 3 / 4 servers 56.6 / 53.7 / 52.7 / 57.3 ms: walkers + three servers are the four streams the part runs at full speed)
   if (const char* ev = std::getenv("COOK_SERVE_STREAMS")) S = (unsigned)std::max(1, std::atoi(ev));
   S = std::min(std::min(S, MAXS), L);
+  for (unsigned sv = 0; sv < S; ++sv)
+    if (!lead->s_serve[sv]) COOK_HIP(hipStreamCreateWithFlags(&lead->s_serve[sv], hipStreamNonBlocking));
   std::vector<PoolCtx> hctx(L);
   unsigned cmax = 1;
   bool any_ge = false;
@@ -1386,7 +1396,7 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
   }
   const bool stepping = served_stepping();
   const bool one_stream = std::getenv("COOK_SERVE_ONE_STREAM") && std::atoi(std::getenv("COOK_SERVE_ONE_STREAM"));  // (diagnostics: the servers' iterations all on one stream)
-  const unsigned long long spin = stepping ? 0ull : env_ticks("COOK_SERVE_WALK_TIMEOUT_US", 2.0e6);  // a walker not served for 2 s gives up
+  const unsigned long long spin = stepping ? 0ull : env_ticks("COOK_SERVE_WALK_TIMEOUT_US", 2.5e5);  // a walker not served for 250 ms gives up (a cycle is 50)
   const unsigned long long poll = stepping ? 0ull : env_ticks("COOK_SERVE_POLL_US", 40.0);          // the latch waits that long for a request
   std::vector<unsigned> launched(S, 0u);  // serve iterations launched, per server
   auto walkers = [&](auto ge_tag) {

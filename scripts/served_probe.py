@@ -17,7 +17,7 @@ ge = float(os.environ.get("PROBE_GE", "1.0"))
 spec = workload.ClusterSpec()
 pools = workload.make_pools(spec, range(n_pools))
 params = A.default_params(good_enough_fitness=ge)
-K = spec.per_pool[0]
+K = int(os.environ.get("PROBE_K", spec.per_pool[0]))
 ref = None
 for lib in libs:
     path = os.path.join(ROOT, "cook_amd", lib) if lib != "default" else None

@@ -300,6 +300,11 @@ inline hipError_t hipStreamCreate(hipStream_t* s) {
   return hipSuccess;
 }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) {
+  *least = 0, *greatest = -1;
+  return hipSuccess;
+}
 inline hipError_t hipStreamDestroy(hipStream_t s) {
   delete s;
   return hipSuccess;
