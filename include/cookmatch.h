@@ -351,11 +351,14 @@ int cook_cycle_update(cook_engine* e, const cook_cycle_delta* delta);
 void* cook_host_alloc(size_t bytes);
 void cook_host_free(void* p);
 int cook_cycle_run(cook_engine* e, uint32_t num_considerable);
-/* Several pools of one rank (same device) in lockstep: cook_cycle_run_rank does the rank / considerable / take-K part of
- * cook_cycle_run for ONE engine (call it for each engine, from any threads), then cook_cycle_match_multi runs the placements of
- * all of them as one sequence of launches (blockIdx.z = pool) on engines[0]'s stream; results are fetched per engine with
- * cook_cycle_fetch as usual.  Same results as cook_cycle_run on each engine; many independent streams of small kernels
- * interfere on one GPU, one stream of n-pool launches does not.  Hold every engine's lock across both calls. */
+/* Several pools of one rank (same device) in ONE placement call: cook_cycle_run_rank does the rank / considerable / take-K part of
+ * cook_cycle_run for ONE engine (call it for each engine, from any threads), then cook_cycle_match_multi places all of them; results
+ * are fetched per engine with cook_cycle_fetch as usual.  Same results as cook_cycle_run on each engine.  How: served walkers — one
+ * persistent walker workgroup per pool (one launch per call) beside up to three streams of evaluation launches for whichever pools
+ * have a window waiting — or, with COOK_MATCH_SERVED=0 in the environment and as the library's own fall-back, one
+ * sequence of launches with blockIdx.z = pool on engines[0]'s stream (pools in lockstep).  Many independent streams of small kernels
+ * interfere on one GPU; either form keeps to four.  The call occupies the calling thread until every pool is placed.  Hold every
+ * engine's lock across both calls. */
 int cook_cycle_run_rank(cook_engine* e, uint32_t num_considerable);
 int cook_cycle_match_multi(cook_engine** engines, uint32_t n);
 int cook_cycle_fetch(cook_engine* e, uint32_t* ranked_pending_idx, uint32_t* n_ranked, int32_t* job_to_offer,
