@@ -63,13 +63,16 @@ constexpr int MV_L = COOK_MV_L;            // candidate list length per job and 
 #ifndef COOK_MV_LM
 #define COOK_MV_LM 48
 #endif
+#ifndef COOK_MV_LM_GE
+#define COOK_MV_LM_GE 32
+#endif
 template <bool GE>
 struct VShape {
-  static constexpr int LM = GE ? 32 : COOK_MV_LM;  // merged best-fit entries per job
+  static constexpr int LM = GE ? COOK_MV_LM_GE : COOK_MV_LM;  // merged best-fit entries per job
   static constexpr int LG = GE ? 64 : 0;           // merged good-enough entries per job
   static constexpr int LGS = GE ? 64 : 1;          // (array bound: never zero)
 };
-constexpr int MV_LM_MAX = COOK_MV_LM > 32 ? COOK_MV_LM : 32, MV_LG_MAX = 64;
+constexpr int MV_LM_MAX = COOK_MV_LM > COOK_MV_LM_GE ? COOK_MV_LM : COOK_MV_LM_GE, MV_LG_MAX = 64;
 static_assert(VShape<false>::LM <= MV_LM_MAX && VShape<true>::LM <= MV_LM_MAX && VShape<true>::LG <= MV_LG_MAX, "buffer sizing");
 static_assert(MV_LM_MAX <= 64 && MV_LG_MAX <= 64, "the walk holds one merged-list entry per lane");
 #ifndef COOK_MV_OCW
@@ -1122,7 +1125,10 @@ constexpr int MV_GMAX = 64;  // group members per segment whose hosts-to-avoid a
 // the L2 of the XCD the workgroup runs on (they were last written / read by evaluation blocks all over the chip): 70 % of the offers a
 // walk opens are among the first four entries of the job's list, 80 % among the first eight (emulator, C4 pool).  Costs the walking
 // wave nothing: the other waves of the workgroup issue the loads while they stage.
-constexpr int MV_PF = 8;
+#ifndef COOK_MV_PF
+#define COOK_MV_PF 8
+#endif
+constexpr int MV_PF = COOK_MV_PF;
 constexpr unsigned MV_RETIRE_CAP = 192;
 constexpr unsigned MV_TMAX = (unsigned)MV_T + MV_RETIRE_CAP;  // offers one round can touch at most
 constexpr unsigned OWNER_UNTOUCHED = 0xFFu, OWNER_NONE = 0xFEu, OWNER_DEAD = 0xFDu;  // values of the owner table / of JobRegs::owner beside lane numbers
@@ -1929,6 +1935,57 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         resolved = b;
         break;
       }
+#ifdef COOK_STUDY_OPEN  // (emulated build, design study) how well do the opening job's / the next job's further untouched entries predict the NEXT opened offer?
+      if (lane == 0) {
+        static int pred_a[8], pred_b[8], n_a = 0, n_b = 0;
+        static unsigned long long opens = 0, hit_a[4] = {0, 0, 0, 0}, hit_b[4] = {0, 0, 0, 0}, hit_ab = 0;
+        ++opens;
+        bool ha = false, hb = false;
+        for (int q = 0; q < n_a; ++q)
+          if (pred_a[q] == open_off) {
+            ha = true;
+            for (int z = 0; z < 4; ++z) hit_a[z] += q < (1 << z) ? 1u : 0u;
+          }
+        for (int q = 0; q < n_b; ++q)
+          if (pred_b[q] == open_off) {
+            hb = true;
+            for (int z = 0; z < 4; ++z) hit_b[z] += q < (1 << z) ? 1u : 0u;
+          }
+        bool hab = false;
+        for (int q = 0; q < n_a && q < 2; ++q) hab = hab || pred_a[q] == open_off;
+        for (int q = 0; q < n_b && q < 2; ++q) hab = hab || pred_b[q] == open_off;
+        hit_ab += hab ? 1u : 0u;
+        (void)ha, (void)hb;
+        n_a = n_b = 0;
+        // A: first untouched entry of each of the next 16 jobs (distinct, in job order); B: the first TWO untouched of each of the next 8
+        for (unsigned x = i + 1; x < n_eff && x <= i + 16 && n_a < 8; ++x)
+          for (int q = 0; q < LM; ++q) {
+            const int o = s_eoff[(size_t)x * LM + q];
+            if (o >= 0 && o != open_off && s_owner[o] == 0xFFu) {
+              bool dup = false;
+              for (int z = 0; z < n_a; ++z) dup = dup || pred_a[z] == o;
+              if (!dup) pred_a[n_a++] = o;
+              break;
+            }
+          }
+        for (unsigned x = i + 1; x < n_eff && x <= i + 8 && n_b < 8; ++x) {
+          int taken = 0;
+          for (int q = 0; q < LM && taken < 2 && n_b < 8; ++q) {
+            const int o = s_eoff[(size_t)x * LM + q];
+            if (o >= 0 && o != open_off && s_owner[o] == 0xFFu) {
+              bool dup = false;
+              for (int z = 0; z < n_b; ++z) dup = dup || pred_b[z] == o;
+              if (!dup) pred_b[n_b++] = o;
+              ++taken;
+            }
+          }
+        }
+        if ((opens & 1023u) == 0u)
+          std::fprintf(stderr, "STUDY_OPEN opens %llu  A(job's own next untouched) top1/2/4/8 %.3f %.3f %.3f %.3f  B(next job's) %.3f %.3f %.3f %.3f  A2+B2 %.3f\n", opens,
+                       (double)hit_a[0] / opens, (double)hit_a[1] / opens, (double)hit_a[2] / opens, (double)hit_a[3] / opens, (double)hit_b[0] / opens,
+                       (double)hit_b[1] / opens, (double)hit_b[2] / opens, (double)hit_b[3] / opens, (double)hit_ab / opens);
+      }
+#endif
       open_lane(nl, open_off, c, m);
       WAIT_ALL_MEM();
       if (open_group) publish_group_member(ghits, gslot, g, k, open_off, (unsigned)wave_read_lane((int)t_host, (int)nl));

@@ -576,7 +576,9 @@ int cook_match_stats(cook_engine* e, uint32_t out[16]);
    may not hold every feasible offer); [17..24] the last cook_cycle_match_multi LED by this engine: [17] how it ran (0 lockstep
    launches, 1 served walkers — one persistent walker workgroup per pool beside serve launches —, 2 the same in its stepping form), [18] pools,
    [19] serve iterations, [20] of them empty, [21] pool windows served, [22] microseconds the latch waited for requests, [23] 1 = the
-   served match gave up and lockstep launches finished it, [24] streams of serve iterations; [25..31] reserved (0) */
+   served match gave up and lockstep launches finished it, [24] streams of serve iterations; [25] with COOK_GUARD=1 in the
+   environment (diagnostics: every device buffer sits between two bands of a pattern) the writes found outside a buffer so far, process-wide —
+   the call looks at this engine's bands first —, else 0; [26..31] reserved (0) */
 #define COOK_MATCH_STATS_EX_N 32
 int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap);
 

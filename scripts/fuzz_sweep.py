@@ -24,8 +24,11 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the configurations")
     ap.add_argument("--algo", type=int, default=-1, help="force cook_params.match_algo (default: drawn per configuration)")
     ap.add_argument("--ge", type=float, default=-1.0, help="force good-enough-fitness (default: drawn per configuration)")
+    ap.add_argument("--guard", action="store_true", help="run under COOK_GUARD=1 (every device buffer between two bands of a pattern) and fail on any write found outside a buffer")
     ap.add_argument("--only", type=int, default=-1, help="run only that match configuration (the random draws of the others are still made)")
     args = ap.parse_args()
+    if args.guard:
+        os.environ["COOK_GUARD"] = "1"  # read once when the library is loaded
     from cook_amd import _abi as A
     from cook_amd import synth
     from cook_amd.engine import Engine
@@ -114,8 +117,19 @@ def main():
         except AssertionError as ex:
             print("FAIL rebalance", it, kw, str(ex)[:300])
             sys.exit(1)
+    guard = ""
+    if args.guard:
+        import gc
+        gc.collect()  # the bands are looked at when a buffer is freed
+        e = make_engine(A.default_params())
+        hits = e.match_stats().get("guard_hits", -1)
+        del e
+        if hits != 0:
+            print(f"FAIL guard: {hits} writes outside a device buffer (COOK_GUARD lines on stderr)")
+            sys.exit(1)
+        guard = ", COOK_GUARD=1: no write outside a device buffer"
     print(f"fuzz ok: {args.match} match / cycle configurations, {args.multi} multi-pool configurations, {args.rebalance} rebalancer configurations, seed {args.seed}, "
-          f"{'emulator' if args.emu else 'gpu'}")
+          f"{'emulator' if args.emu else 'gpu'}{guard}")
 
 
 if __name__ == "__main__":

@@ -672,3 +672,33 @@ def test_match_eval_offer_split_levels(make_engine, monkeypatch, split):
     pool = synth.make_pool(seed=83, n_pending=300, n_running=100, n_users=20, n_offers=260, gpus=True, constraints=True)
     for ge in (1.0, 0.6):
         P.match_parity(make_engine, pool.pending_jobs, pool.offers, pool.groups, A.default_params(good_enough_fitness=ge))
+
+
+def test_guard_bands_report_a_write_past_a_buffer():
+    """COOK_GUARD=1 (scripts/fuzz_sweep.py --guard): every device buffer sits between two bands of a pattern that are looked at when
+    the buffer is freed.  A clean match reports nothing; the built-in self-test (one byte past the placement column at destroy) is
+    reported on stderr — so a sweep that prints no COOK_GUARD line really had no write outside a buffer."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tests.simt_emu import build_emu\n"
+            "from cook_amd import _abi as A, synth\n"
+            "from cook_amd.engine import Engine\n"
+            "pool = synth.make_pool(seed=5, n_pending=200, n_running=50, n_users=9, n_offers=60, constraints=True, gpus=True)\n"
+            "e = Engine(A.default_params(), lib_path=build_emu.build())\n"
+            "e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)\n"
+            "e.cycle_run(200)\n"
+            "e.cycle_fetch()\n"
+            "print('hits', e.match_stats()['guard_hits'])\n"
+            "del e\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for selftest, want_line in (("", False), ("1", True)):
+        env = dict(os.environ, COOK_GUARD="1")
+        env.pop("COOK_GUARD_SELFTEST", None)
+        if selftest:
+            env["COOK_GUARD_SELFTEST"] = selftest
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "hits 0" in r.stdout
+        assert ("COOK_GUARD: " in r.stderr) == want_line, r.stderr[-2000:]
+        if want_line:
+            assert "PAST its end" in r.stderr
