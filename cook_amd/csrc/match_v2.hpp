@@ -1935,57 +1935,6 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         resolved = b;
         break;
       }
-#ifdef COOK_STUDY_OPEN  // (emulated build, design study) how well do the opening job's / the next job's further untouched entries predict the NEXT opened offer?
-      if (lane == 0) {
-        static int pred_a[8], pred_b[8], n_a = 0, n_b = 0;
-        static unsigned long long opens = 0, hit_a[4] = {0, 0, 0, 0}, hit_b[4] = {0, 0, 0, 0}, hit_ab = 0;
-        ++opens;
-        bool ha = false, hb = false;
-        for (int q = 0; q < n_a; ++q)
-          if (pred_a[q] == open_off) {
-            ha = true;
-            for (int z = 0; z < 4; ++z) hit_a[z] += q < (1 << z) ? 1u : 0u;
-          }
-        for (int q = 0; q < n_b; ++q)
-          if (pred_b[q] == open_off) {
-            hb = true;
-            for (int z = 0; z < 4; ++z) hit_b[z] += q < (1 << z) ? 1u : 0u;
-          }
-        bool hab = false;
-        for (int q = 0; q < n_a && q < 2; ++q) hab = hab || pred_a[q] == open_off;
-        for (int q = 0; q < n_b && q < 2; ++q) hab = hab || pred_b[q] == open_off;
-        hit_ab += hab ? 1u : 0u;
-        (void)ha, (void)hb;
-        n_a = n_b = 0;
-        // A: first untouched entry of each of the next 16 jobs (distinct, in job order); B: the first TWO untouched of each of the next 8
-        for (unsigned x = i + 1; x < n_eff && x <= i + 16 && n_a < 8; ++x)
-          for (int q = 0; q < LM; ++q) {
-            const int o = s_eoff[(size_t)x * LM + q];
-            if (o >= 0 && o != open_off && s_owner[o] == 0xFFu) {
-              bool dup = false;
-              for (int z = 0; z < n_a; ++z) dup = dup || pred_a[z] == o;
-              if (!dup) pred_a[n_a++] = o;
-              break;
-            }
-          }
-        for (unsigned x = i + 1; x < n_eff && x <= i + 8 && n_b < 8; ++x) {
-          int taken = 0;
-          for (int q = 0; q < LM && taken < 2 && n_b < 8; ++q) {
-            const int o = s_eoff[(size_t)x * LM + q];
-            if (o >= 0 && o != open_off && s_owner[o] == 0xFFu) {
-              bool dup = false;
-              for (int z = 0; z < n_b; ++z) dup = dup || pred_b[z] == o;
-              if (!dup) pred_b[n_b++] = o;
-              ++taken;
-            }
-          }
-        }
-        if ((opens & 1023u) == 0u)
-          std::fprintf(stderr, "STUDY_OPEN opens %llu  A(job's own next untouched) top1/2/4/8 %.3f %.3f %.3f %.3f  B(next job's) %.3f %.3f %.3f %.3f  A2+B2 %.3f\n", opens,
-                       (double)hit_a[0] / opens, (double)hit_a[1] / opens, (double)hit_a[2] / opens, (double)hit_a[3] / opens, (double)hit_b[0] / opens,
-                       (double)hit_b[1] / opens, (double)hit_b[2] / opens, (double)hit_b[3] / opens, (double)hit_ab / opens);
-      }
-#endif
       open_lane(nl, open_off, c, m);
       WAIT_ALL_MEM();
       if (open_group) publish_group_member(ghits, gslot, g, k, open_off, (unsigned)wave_read_lane((int)t_host, (int)nl));

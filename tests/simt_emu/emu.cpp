@@ -160,12 +160,18 @@ static void run_blocks(State& s, unsigned b0, unsigned b1, unsigned nthreads, di
     if (s.events == ev0) {
       if (++spins > 2000) {
         std::fprintf(stderr, "emu: deadlock (threads waiting at a rendezvous not all threads reach, or spinning on a word nobody writes)\n");
-        unsigned shown = 0;
-        for (size_t x = 0; x < nf && shown < 40; ++x)
-          if (!s.fibers[x].done) {
-            std::fprintf(stderr, "  live thread %u of block %u last site: %s\n", s.fibers[x].tid, s.fibers[x].blk->bidx.x, s.fibers[x].site);
-            ++shown;
+        unsigned shown = 0;  // one line per run of threads at the same site
+        for (size_t x = 0; x < nf && shown < 40;) {
+          if (s.fibers[x].done) {
+            ++x;
+            continue;
           }
+          size_t y = x;
+          while (y + 1 < nf && !s.fibers[y + 1].done && s.fibers[y + 1].site == s.fibers[x].site && s.fibers[y + 1].blk == s.fibers[x].blk) ++y;
+          std::fprintf(stderr, "  live threads %u..%u of block %u last site: %s\n", s.fibers[x].tid, s.fibers[y].tid, s.fibers[x].blk->bidx.x, s.fibers[x].site);
+          ++shown;
+          x = y + 1;
+        }
         std::abort();
       }
     } else {
