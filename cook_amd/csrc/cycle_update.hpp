@@ -506,6 +506,7 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
   }
   for (unsigned r = 0; aj && aj->ports && r < p_add && !in.has_x; ++r) in.has_x = aj->ports[r] > 0;
   e->N = N2;
+  e->pool_usage_known = false;
   e->n_pending = P2;
   e->Kjobs = P2;
   e->K = P2;

@@ -147,6 +147,8 @@ struct cook_engine {
 
   // ---- rank state ----
   bool rank_staged = false, rank_done = false;
+  bool pool_usage_known = false;  // pool_usage_val is the running usage of the resident task table (it only changes when the table does)
+  cook_usage pool_usage_val{0, 0, 0, 0};
   unsigned N = 0, U = 0, n_pending = 0;
   bool has_gpus = false;
   cook_pool_quota quota{};
@@ -453,11 +455,16 @@ void rank_stage(cook_engine* e, const cook_tasks* t, const cook_users* u) {
   h2d(e, e->u_qgpus, u->quota_gpus, U);
   sync(e);  // pend_ord is a host temporary
   e->rank_staged = true;
+  e->pool_usage_known = false;
   e->rank_done = false;
 }
 
 void rank_pool_usage(cook_engine* e, cook_usage* out) {
   if (!e->rank_staged) e->fail(COOK_E_STATE, "cook_rank_pool_usage before cook_rank_stage");
+  if (e->pool_usage_known) {  // summed for this very table already (cook_rank_stage / cook_cycle_update forget it)
+    *out = e->pool_usage_val;
+    return;
+  }
   e->pool_usage.ensure(1);
   if (e->N == 0) {
     *out = cook_usage{0, 0, 0, 0};
@@ -475,6 +482,8 @@ void rank_pool_usage(cook_engine* e, cook_usage* out) {
   sync(e);
   std::memcpy(&h, e->h_scratch, sizeof(SumU4));
   *out = cook_usage{h.count, h.cpus, h.mem, h.gpus};
+  e->pool_usage_val = *out;
+  e->pool_usage_known = true;
 }
 
 // per-user running usage [U x 3] of the pool, from the per-user order of the last rank run (rank_kernels.hpp)

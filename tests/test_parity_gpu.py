@@ -617,3 +617,16 @@ def test_match_eval_offer_split_levels(make_engine, monkeypatch, split):
 def test_rank_tie_rule_in_tiles_and_as_radix_passes(make_engine, monkeypatch):
     P.tie_rule_forms(make_engine, monkeypatch, n_users=9000, per_user=3)  # one tie group per position, 9 000 items each: beyond a tile
     P.tie_rule_forms(make_engine, monkeypatch, n_users=150, per_user=5)
+
+
+def test_guarded_fuzz_sweep():
+    """A seeded sweep of small random configurations (rank / cycle / match / update / multi-pool served walkers / rebalancer) with every
+    device buffer between two guard bands (COOK_GUARD=1, read when the library is loaded: hence a process of its own): bit-identical to
+    the oracle and no write outside a buffer.  2 050 configurations of the same sweep: profiles/r05z_fuzz_guard_2050.txt."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_sweep.py"), "--guard", "--match", "120", "--rebalance", "40", "--multi", "30",
+                        "--seed", "5150"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "no write outside a device buffer" in r.stdout and "COOK_GUARD: " not in r.stderr, (r.stdout[-500:], r.stderr[-1500:])
