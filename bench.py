@@ -85,6 +85,16 @@ def algorithmic_bytes(kernel, n_tasks, k, m, launches_per_match=1.0, pools_per_l
     return table.get(kernel)
 
 
+def cpu_stat():
+    """nr_throttled / throttled_usec of the container's CPU controller (a process over its quota is stopped until the period ends)"""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as f:
+            kv = dict(l.split() for l in f.read().strip().splitlines())
+        return {k: int(kv[k]) for k in ("nr_periods", "nr_throttled", "throttled_usec") if k in kv}
+    except (OSError, ValueError):
+        return None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate passes, scripts/profile_round2.sh + scripts/make_pmc_traffic.py).  The file records the revision
@@ -94,16 +104,21 @@ def pmc_traffic(kernel):
     if not files:
         return None, "no profiles/r*_pmc_traffic.json"
     try:
-        with open(files[-1]) as f:
-            doc = json.load(f)
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         from kernel_rev import kernel_rev
         rev = kernel_rev()
+        docs = []
+        for fn in files:
+            with open(fn) as f:
+                docs.append((fn, json.load(f)))
     except (OSError, ValueError, ImportError) as ex:
         return None, f"unreadable: {ex}"
-    name = os.path.relpath(files[-1], ROOT)
-    if doc.get("kernel_rev") != rev:
-        return None, f"{name} was taken at kernel revision {doc.get('kernel_rev')}, this binary is {rev}"
+    match = [(fn, d) for fn, d in docs if d.get("kernel_rev") == rev]  # (the passes of THIS revision, whatever the file is called)
+    if not match:
+        fn, d = max(docs, key=lambda x: os.path.getmtime(x[0]))
+        return None, f"{os.path.relpath(fn, ROOT)} was taken at kernel revision {d.get('kernel_rev')}, this binary is {rev} (no file of {len(docs)} matches)"
+    fn, doc = match[-1]
+    name = os.path.relpath(fn, ROOT)
     rec = doc.get("kernels", {}).get(kernel)
     if rec is None:
         return None, f"{name} holds no pass for {kernel}"
@@ -641,6 +656,8 @@ def main():
             torch.cuda.synchronize()
             t_upd = t_cyc = t_fetch = 0.0
             upd_samples = []
+            upd_outliers = []
+            cpu_stat0 = cpu_stat()
             n_b = 50  # (fifty samples of the update: an occasional slow call — 10 ms against 1 — was seen in round 4; max / median is in the line)
             gc.collect()
             gc.disable()
@@ -657,6 +674,16 @@ def main():
                 c3 = time.perf_counter()
                 t_upd += c1 - c0
                 upd_samples.append(round((c1 - c0) * 1e3, 3))
+                if len(upd_samples) > 5 and upd_samples[-1] > 2.0 * float(np.median(upd_samples)):
+                    # a slow call: where its time went, per pool (cook_match_stats_ex [26..28]: the library times every update call)
+                    st_ = {p: engines[p].match_stats() for p in my_pools}
+                    upd_outliers.append({"sample": it, "ms": upd_samples[-1],
+                                         "per_pool_us_in_call": [st_[p].get("update_us") for p in my_pools],
+                                         "per_pool_us_in_stream_syncs": [st_[p].get("update_sync_us") for p in my_pools],
+                                         "per_pool_device_allocations": [st_[p].get("update_allocs") for p in my_pools],
+                                         "per_pool_slowest_phase": [st_[p].get("update_slowest_phase") for p in my_pools],
+                                         "per_pool_slowest_phase_us": [st_[p].get("update_slowest_phase_us") for p in my_pools],
+                                         "cgroup_cpu_stat": cpu_stat()})
                 t_cyc += c2 - c1
                 t_fetch += c3 - c2
                 if it + 1 < n_b:  # back to the benchmark's state for the next measurement: a full restage (not timed)
@@ -664,7 +691,7 @@ def main():
             gc.enable()
             upd_med = float(np.median(upd_samples))  # (the median; the samples are in the line)
             boundary = {"ms_per_step_incl_transfers": upd_med + (t_cyc + t_fetch) / n_b * 1e3,
-                        "update_ms": upd_med, "update_ms_mean": t_upd / n_b * 1e3, "update_ms_max": float(max(upd_samples)), "update_ms_max_over_median": float(max(upd_samples)) / max(1e-9, upd_med), "update_ms_samples": upd_samples, "cycle_ms": t_cyc / n_b * 1e3, "fetch_ms": t_fetch / n_b * 1e3,
+                        "update_ms": upd_med, "update_ms_mean": t_upd / n_b * 1e3, "update_ms_max": float(max(upd_samples)), "update_ms_max_over_median": float(max(upd_samples)) / max(1e-9, upd_med), "update_outliers": upd_outliers, "cgroup_cpu_stat_before_after": [cpu_stat0, cpu_stat()], "update_ms_samples": upd_samples, "cycle_ms": t_cyc / n_b * 1e3, "fetch_ms": t_fetch / n_b * 1e3,
                         "delta": f"per pool: {n_delta} task rows leave, {n_delta} arrive ({n_delta // 2} of them pending jobs), {n_off} fresh offers",
                         "restage_all_pageable_ms": (b1 - b0) * 1e3, "restage_all_pinned_ms": (b2 - b1) * 1e3,
                         "restage_bytes": int(staged_bytes), "restage_pinned_GBps": staged_bytes / max(1e-9, b2 - b1) / 1e9,

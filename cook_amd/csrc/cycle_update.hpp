@@ -163,6 +163,17 @@ struct BlockWriter {  // lays arrays out in a host block, 16-byte aligned; first
     return at;
   }
 };
+// A block of page-locked HOST memory into device memory by a KERNEL that reads it over the link.  hipMemcpyAsync does these transfers on the
+// SDMA engines, and once in a while such a copy — and every other one issued at that moment, from any thread — sits in the call for 7–8 ms
+// (profiles/r05ac_update_outliers.txt: 3 of 300 updates of eight pools; none with HSA_ENABLE_SDMA=0, which costs every copy of the process its
+// engine instead).  The blocks of a delta are a few hundred KB: a kernel moves them in the time the engine needs to start.
+__global__ void __launch_bounds__(256) upd_block_in(uint4* __restrict__ dst, const uint4* __restrict__ src_host, unsigned n16) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src_host[i];
+}
+static void block_to_device(cook_engine* e, void* dst, const void* src_host, size_t bytes) {  // (both sides hold 16 bytes beyond `bytes`)
+  const unsigned n16 = (unsigned)((bytes + 15) / 16);
+  if (n16) KL("upd_block_in", upd_block_in, std::min(div_up(n16, 256u), 512u), 256, (uint4*)dst, (const uint4*)src_host, n16);
+}
 static void pinned_reserve(void** p, size_t* cap, size_t bytes) {
   if (bytes <= *cap) return;
   if (*p) (void)hipHostFree(*p);
@@ -227,7 +238,7 @@ void offers_block_commit(cook_engine* e, UpdateBufs& ub, const cook_offers* o, O
   DBuf& blk = ub.d_offers[ub.d_offers_cur ^ 1];
   BlockWriter w((char*)ub.h_offers);
   offers_block_layout(w, o, pl);
-  if (w.used) COOK_HIP(hipMemcpyAsync(blk.p, ub.h_offers, w.used, hipMemcpyHostToDevice, e->stream));
+  block_to_device(e, blk.p, ub.h_offers, w.used);
   ub.d_offers_cur ^= 1;
   const char* d = (const char*)blk.p;
   const size_t* off = pl.off;
@@ -266,6 +277,15 @@ void offers_block_commit(cook_engine* e, UpdateBufs& ub, const cook_offers* o, O
 }
 
 void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
+  // the host's time by phase (cook_match_stats_ex [29..30]: the longest one): 0 checks, 1 the delta's block (host copies, one transfer), 2 marks + scans,
+  // 3 column compactions, 4 the CSR columns (one stream synchronisation), 5 the look at the device (the other), 6 swaps + offers
+  auto t_prev = std::chrono::steady_clock::now();
+  for (unsigned& x : e->upd_phase_us) x = 0u;
+  auto stamp = [&](int k) {
+    const auto t = std::chrono::steady_clock::now();
+    e->upd_phase_us[k] += (unsigned)std::chrono::duration<double, std::micro>(t - t_prev).count();
+    t_prev = t;
+  };
   if (!d) e->fail(COOK_E_INVALID, "cook_cycle_update: null delta");
   if (!e->cycle_staged) e->fail(COOK_E_STATE, "cook_cycle_update before cook_cycle_stage");
   const unsigned N = e->N, P = e->n_pending, U = e->U;
@@ -317,6 +337,7 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
   const unsigned N2 = N - d->n_remove + n_add;  // (when the removal list is valid; the device says at the end)
   const unsigned N_hi = N + n_add;              // rows the compaction can write whatever the list holds (an entry named twice removes one row)
   const unsigned P_hi = P + p_add;              // the pending jobs can only be bounded until then
+  stamp(0);
   // ---- the delta as one block -----------------------------------------------------------------------------------------------
   struct Offs {
     size_t rem, t[9], j[12 + COOK_MAX_SCALARS], eq_off, eq_key, eq_val, nv_off, nv_host;
@@ -349,11 +370,12 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
       pinned_reserve(&ub.h_block, &ub.h_cap, w.used + 16);
       ub.d_block.ensure(w.used + 16);
     } else if (w.used) {
-      COOK_HIP(hipMemcpyAsync(ub.d_block.p, ub.h_block, w.used, hipMemcpyHostToDevice, e->stream));
+      block_to_device(e, ub.d_block.p, ub.h_block, w.used);
     }
   }
   const char* blk = (const char*)ub.d_block.p;
   auto dev = [&](size_t off, bool have) -> const void* { return (!have || off == (size_t)-1) ? nullptr : (const void*)(blk + off); };
+  stamp(1);
   // ---- which rows stay, and where they go -----------------------------------------------------------------------------------
   int* rm = ub.rm.ensure(std::max(1u, N));
   int* rm_p = ub.rm_p.ensure(std::max(1u, P));
@@ -371,6 +393,7 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
   }
   if (N) seg_scan<SumI>(e, "upd_scan", LoadKeep{rm}, (const uint8_t*)nullptr, N, incl, e->tmpI);
   if (P) seg_scan<SumI>(e, "upd_scan", LoadKeep{rm_p}, (const uint8_t*)nullptr, P, incl_p, e->tmpI);
+  stamp(2);
   // ---- the columns, into their second buffers ---------------------------------------------------------------------------------
   struct Swap {
     DBuf* col;
@@ -441,6 +464,7 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
     if (e->cb && e->cb->has_elig_by_pending) add_col(js, UPD_MAX_COLS, e->cb->elig_by_pending.b, 1, nullptr, 1ull, P_hi);
   }
   if (P + p_add) KL("upd_compact_cols", upd_compact_cols, div_up(P + p_add, 256), 256, js, (const int*)rm_p, (const SumI*)incl_p, P, p_add, 1u, out);
+  stamp(3);
   // ---- the two CSR columns (EQUALS constraints; hosts to avoid) ----------------------------------------------------------------
   if (!ub.csr_known) {  // how many values the staged columns hold: the last offset (once per stage)
     ub.csr_vals[0] = ub.csr_vals[1] = 0;
@@ -466,11 +490,13 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
   };
   if (in.j_eq_off) csr(0, e->j_eq_off, e->j_eq_key, &e->j_eq_val, o.eq_off, o.eq_key, o.eq_val, add_eq);
   if (in.j_novel_off) csr(1, e->j_novel_off, e->j_novel_host, nullptr, o.nv_off, o.nv_host, (size_t)-1, add_nv);
+  stamp(4);
   // ---- the one look at the device --------------------------------------------------------------------------------------------
   UpdOut h{};
   COOK_HIP(hipMemcpyAsync(e->h_scratch, out, sizeof(UpdOut), hipMemcpyDeviceToHost, e->stream));
   sync(e);
   std::memcpy(&h, e->h_scratch, sizeof(UpdOut));
+  stamp(5);
   if (h.bad) e->fail(COOK_E_INVALID, "cook_cycle_update: remove_task holds an index out of range or twice");  // nothing was swapped in
   const unsigned n_keep = N ? h.n_keep : 0u, p_keep = P ? h.p_keep : 0u;
   if (n_keep + n_add != N2) e->fail(COOK_E_STATE, "cook_cycle_update: row count mismatch");
@@ -518,4 +544,5 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
     offers_block_commit(e, ub, d->offers, offers_plan);
     sync(e);
   }
+  stamp(6);
 }

@@ -41,6 +41,7 @@ static const bool g_guard = [] {
   return s && std::atoi(s) != 0;
 }();
 static std::atomic<unsigned> g_guard_hits{0};
+static thread_local unsigned tl_dbuf_allocs = 0;  // device allocations made by this thread (cook_match_stats_ex [28]: a call that grows a buffer pays hipFree + hipMalloc)
 constexpr size_t GUARD_BYTES = 4096;
 struct DBuf {
   void* p = nullptr;
@@ -70,6 +71,7 @@ struct DBuf {
   }
   void ensure(size_t bytes) {
     if (bytes <= cap) return;
+    ++tl_dbuf_allocs;
     free_now();
     if (g_guard) {
       const size_t want = (bytes + 15) & ~(size_t)15;
@@ -147,6 +149,8 @@ struct cook_engine {
 
   // ---- rank state ----
   bool rank_staged = false, rank_done = false;
+  unsigned upd_phase_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ... by phase (cycle_update.hpp)
+  uint32_t upd_us = 0, upd_sync_us = 0, upd_allocs = 0;  // the last cook_cycle_update: microseconds in the call, of them in stream synchronisations, device buffers (re)allocated
   bool pool_usage_known = false;  // pool_usage_val is the running usage of the resident task table (it only changes when the table does)
   cook_usage pool_usage_val{0, 0, 0, 0};
   unsigned N = 0, U = 0, n_pending = 0;
@@ -320,11 +324,7 @@ const T* h2d_opt(cook_engine* e, DArr<T>& d, const T* h, size_t n) {
 static const bool g_sync_trace = std::getenv("COOK_SYNC_TRACE") != nullptr;
 static thread_local double tl_sync_ms = 0.0;
 static thread_local unsigned tl_syncs = 0;
-void sync(cook_engine* e) {
-  if (!g_sync_trace) {
-    COOK_HIP(hipStreamSynchronize(e->stream));
-    return;
-  }
+void sync(cook_engine* e) {  // (always timed: two clock reads against a stream synchronisation)
   const auto t0 = std::chrono::steady_clock::now();
   COOK_HIP(hipStreamSynchronize(e->stream));
   tl_sync_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1905,11 +1905,21 @@ static unsigned cycle_rank_part(cook_engine* e, uint32_t num_considerable) {
   return K;
 }
 int cook_cycle_update(cook_engine* e, const cook_cycle_delta* delta) {
-  return guarded(e, [&] {
+  // where the call's time went, for cook_match_stats_ex [26..28] (an occasional 9 ms call among 1 ms ones: bench.py boundary.update_ms_samples)
+  const auto t0 = std::chrono::steady_clock::now();
+  const double sync0 = tl_sync_ms;
+  const unsigned alloc0 = tl_dbuf_allocs;
+  const int rc = guarded(e, [&] {
     if (!e->ub) e->ub = new UpdateBufs();
     cycle_update(e, *e->ub, delta);
     prof_collect(e);
   });
+  if (e) {
+    e->upd_us = (uint32_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    e->upd_sync_us = (uint32_t)((tl_sync_ms - sync0) * 1000.0);
+    e->upd_allocs = tl_dbuf_allocs - alloc0;
+  }
+  return rc;
 }
 void* cook_host_alloc(size_t bytes) {
   void* p = nullptr;
@@ -2146,6 +2156,9 @@ int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap) {
   v[16] = c.trunc_lists;
   v[17] = e->served.mode, v[18] = e->served.pools, v[19] = e->served.iterations, v[20] = e->served.empty_iterations;
   v[21] = e->served.pools_served, v[22] = (uint32_t)(e->served.latch_wait_ms * 1000.0), v[23] = e->served.fell_back, v[24] = e->served.servers;
+  v[26] = e->upd_us, v[27] = e->upd_sync_us, v[28] = e->upd_allocs;
+  for (unsigned k = 0; k < 8u; ++k)
+    if (e->upd_phase_us[k] > v[30]) v[29] = k, v[30] = e->upd_phase_us[k];
   if (g_guard) {  // COOK_GUARD=1: look at this engine's bands now; the count is process-wide and includes buffers already freed
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);

@@ -416,7 +416,7 @@ class Engine:
         n = self._lib.cook_match_stats_ex(self._h, out, 32)
         keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "segments", "resolved", "setup_us", "seq_us", "touched", "visited",
                 "_12", "_13", "_14", "_15", "trunc_lists", "served_mode", "served_pools", "serve_iterations", "serve_empty_iterations",
-                "serve_pool_windows", "serve_latch_wait_us", "served_fell_back", "serve_streams", "guard_hits")
+                "serve_pool_windows", "serve_latch_wait_us", "served_fell_back", "serve_streams", "guard_hits", "update_us", "update_sync_us", "update_allocs", "update_slowest_phase", "update_slowest_phase_us")
         return {k: int(x) for k, x in zip(keys, out[:max(0, n)]) if not k.startswith("_")}
 
     def set_profiling(self, on: bool):

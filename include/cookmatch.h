@@ -578,7 +578,9 @@ int cook_match_stats(cook_engine* e, uint32_t out[16]);
    [19] serve iterations, [20] of them empty, [21] pool windows served, [22] microseconds the latch waited for requests, [23] 1 = the
    served match gave up and lockstep launches finished it, [24] streams of serve iterations; [25] with COOK_GUARD=1 in the
    environment (diagnostics: every device buffer sits between two bands of a pattern) the writes found outside a buffer so far, process-wide —
-   the call looks at this engine's bands first —, else 0; [26..31] reserved (0) */
+   the call looks at this engine's bands first —, else 0; [26..28] the last cook_cycle_update of this engine: microseconds in the call, microseconds of those the host waited in
+   stream synchronisations, device buffers it had to (re)allocate, [29..30] the phase of the call that took the host longest (0 checks, 1 the delta's block,
+   2 marks and scans, 3 column compactions, 4 CSR columns, 5 the look at the device, 6 swaps and offers) and its microseconds; [31] reserved (0) */
 #define COOK_MATCH_STATS_EX_N 32
 int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap);
 
