@@ -165,6 +165,7 @@ class ShardedCluster:
         # served walkers (match_v2.hpp): ALL pools of the rank in one cook_cycle_match_multi call — one persistent walker workgroup per
         # pool beside serve launches, two streams per GPU whatever the number of pools.  COOK_MATCH_SERVED=0: lockstep chains as before.
         self.served = os.environ.get("COOK_MATCH_SERVED", "1") != "0"
+        self._usage_warm = False  # the engines have summed their pools' usage for the tables they hold (see cycle)
 
     @property
     def last_user_usage(self) -> Optional[np.ndarray]:
@@ -197,11 +198,18 @@ class ShardedCluster:
         """cook_cycle_update for the local pools, deltas[pool] = the arguments of Engine.cycle_update.  The update is a short chain of
         small kernels per pool: at most max_chains of them at a time, like the rank stages (eight at once measured SLOWER than one after
         the other on MI355X, 5.6 against 5.1 ms for eight pools: more than four streams of small kernels serialise)."""
+        self._usage_warm = False
         list(self._tp_rank.map(lambda p: self.engines[p].cycle_update(*deltas[p]), [p for p in self.pools if p in deltas]))
 
     def cycle(self, num_considerable: int):
         t0 = time.perf_counter()
-        usages = dict(zip(self.pools, self._tp.map(lambda p: self.engines[p].rank_pool_usage().as_tuple(), self.pools)))
+        # (the library keeps a pool's usage until its task table changes: after the first cycle on a table the calls return at once, and
+        #  handing them to the thread pool would cost more than making them — 0.25 ms of the benchmark's cycle)
+        if self._usage_warm:
+            usages = {p: self.engines[p].rank_pool_usage().as_tuple() for p in self.pools}
+        else:
+            usages = dict(zip(self.pools, self._tp.map(lambda p: self.engines[p].rank_pool_usage().as_tuple(), self.pools)))
+            self._usage_warm = True
         total = all_reduce_group_usage(group_usage_matrix(self.groups, usages), self.world, self.device)
         self.last_group_usage = total
         self.last_pool_usage = usages
