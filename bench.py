@@ -339,17 +339,21 @@ def main():
     if not rehearsal:
         assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     on_gpu = torch.cuda.is_available() and not rehearsal
+    # (COOK_BENCH_ONE_DEVICE=1, a TEST aid: every rank on cuda:0 — with --dist-backend gloo the whole multi-process path, real HIP engines
+    #  and real collectives, runs on a box with one GPU: tests/test_parity_gpu.py.  Not a measurement.)
+    dev_index = 0 if os.environ.get("COOK_BENCH_ONE_DEVICE") == "1" else local_rank
     if on_gpu:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+        torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index) if on_gpu else torch.device("cpu")
 
     def device_sync():
         if on_gpu:
             torch.cuda.synchronize()
 
+    cdev = dev if (on_gpu and args.dist_backend == "nccl") else torch.device("cpu")  # where the collectives' tensors live (gloo: on the host)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if on_gpu:
+        if on_gpu and args.dist_backend == "nccl":
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
@@ -373,7 +377,7 @@ def main():
     pools, engines = {}, {}
     for p in my_pools:
         pools[p] = workload.make_pool(spec, p)
-        e = Engine(params, device=0, lib_path=args.engine_lib) if rehearsal else Engine(params, device=local_rank)  # (the emulator has one device)
+        e = Engine(params, device=0, lib_path=args.engine_lib) if rehearsal else Engine(params, device=dev_index)  # (the emulator has one device)
         e.cycle_stage(pools[p].tasks, pools[p].users, pools[p].pending_jobs, pools[p].offers, pools[p].groups)
         engines[p] = e
     gen_s = time.time() - t0
@@ -381,7 +385,7 @@ def main():
     # all pools of the cluster -> the cross-rank all-reduce (scheduler.clj:2125-2157); cook_amd/sharding.py
     from cook_amd import sharding
     qg = workload.quota_groups(spec)
-    cluster = sharding.ShardedCluster(engines, qg, world=world, rank=rank, device=dev, serial=rehearsal)  # (the emulator runs one launch at a time)
+    cluster = sharding.ShardedCluster(engines, qg, world=world, rank=rank, device=cdev, serial=rehearsal)  # (the emulator runs one launch at a time)
     cluster.n_users = args.users  # every timed cycle runs north_star's collective: the all-reduce of the cross-pool per-user usage [U x 3]
 
     def cycle():
@@ -417,7 +421,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_start
     gc.enable()
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
@@ -433,7 +437,7 @@ def main():
         considered += len(j2o)
         matched += int((j2o >= 0).sum())
         stage_ms[p] = engines[p].last_timing()
-    cnt = torch.tensor([matched, considered, ranked_n], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([matched, considered, ranked_n], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     matched, considered, ranked_n = [int(x) for x in cnt.tolist()]
@@ -591,7 +595,7 @@ def main():
                          ("C3", dict(seed=0xC00C0003, n_pending=200000, n_running=80000, n_users=2000, n_offers=20000, gpus=True,
                                      constraints=True))):
             pool_x = synth.make_pool(**kw)
-            with Engine(params, device=local_rank) as ex:
+            with Engine(params, device=dev_index) as ex:
                 ex.cycle_stage(pool_x.tasks, pool_x.users, pool_x.pending_jobs, pool_x.offers, pool_x.groups)
                 ts = timed(lambda: ex.cycle_run(pool_x.n_pending), 3)
                 _, j2o_x, _ = ex.cycle_fetch()
@@ -602,7 +606,7 @@ def main():
                                "stage_ms": dict(zip(("rank", "match"), ex.last_timing())), "placement_stats": ex.match_stats()}
             del pool_x
         try:
-            extra["C5"] = extra_c5(local_rank, check=not args.no_check)
+            extra["C5"] = extra_c5(dev_index, check=not args.no_check)
         except AssertionError:
             raise  # a parity failure must not produce a bench line
         except Exception as ex:  # (an extra must never cost the headline its line)

@@ -630,3 +630,32 @@ def test_guarded_fuzz_sweep():
                         "--seed", "5150"], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "no write outside a device buffer" in r.stdout and "COOK_GUARD: " not in r.stderr, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The multi-process path END TO END on real HIP engines: bench.py as two ranks (torch.distributed.run), both on cuda:0
+    (COOK_BENCH_ONE_DEVICE=1, a test aid), the cycle's collectives over gloo — pools sharded p mod world, the quota-group all-reduce, the
+    per-user all-reduce, the max-over-ranks timing, the parity check of every rank's pools against the oracle after the timed region,
+    and the line's `collective` record.  (RCCL needs a GPU per rank; the single-rank RCCL collectives are test_rccl_single_rank_collectives.)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, COOK_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo", "--no-cpu-baseline", "--no-extras",
+           "--no-adjacent", "--no-roofline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["parity_checked"] is True
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2
+    assert c["pools_of_rank"] == [[0, 2, 4, 6], [1, 3, 5, 7]]
+    assert c["group_usage_equals_sum_over_all_pools"] is True
+    assert d["last_cycle"]["considered"] > 900_000 and d["last_cycle"]["matched"] > 300_000
