@@ -1237,9 +1237,9 @@ void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, 
   }
 #ifdef COOK_WALK_PROF
   {
-    static const char* cat[8] = {"shortcut", "touched_wins", "new_lane", "unmatched", "grouped", "exact", "-", "-"};
+    static const char* cat[8] = {"shortcut", "touched_wins", "new_lane", "unmatched", "grouped", "exact", "touched_wins_by_good_enough", "fast_turn_that_left_the_loop"};
     std::fprintf(stderr, "WALKPROF rounds=%u", hc.rounds);
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 8; ++i)
       std::fprintf(stderr, " %s:n=%u,cyc/job=%.0f", cat[i], hc.prof_cnt[i], hc.prof_cnt[i] ? (double)hc.prof_cyc[i] / hc.prof_cnt[i] : 0.0);
     std::fprintf(stderr, "\n");
   }

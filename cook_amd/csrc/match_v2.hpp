@@ -1525,6 +1525,9 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
   // guard bands of the approximate fitness (relative 2^-38; the approximation is good to ~2^-50): x - x * 2^-38 and x + x * 2^-38 through
   // v_ldexp_f64 with an inline exponent — as multiplications by 1 -+ 2^-38 the two fp64 constants lived in VGPRs, were spilled, and the
   // walk's fast path reloaded them from scratch memory for every job (two dependent scratch loads on the critical path)
+  // fp32 threshold below which a touched offer's approximate fitness cannot be "above good-enough" nor "maybe above" (rounding to fp32 is
+  // monotone; the margin of 2^-30 covers the 2^-38 guard band): the fast path's first look in launches with the good-enough rule
+  const float ge_near_f = (float)(good_enough - ldexp(good_enough < 0.0 ? -good_enough : good_enough, -30));
   auto eps_lo = [](double x) { return x - ldexp(x, -38); };
   auto eps_hi = [](double x) { return x + ldexp(x, -38); };
   struct JobRegs {   // exactly what the LDS loads deliver: nothing is decoded before the job's own iteration (a decode right after
@@ -1810,28 +1813,43 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
           // the fitness they had under S, so their part of that order is the job's good-enough list; a touched offer is above the
           // threshold for sure when its approximate fitness clears it with a margin, below for sure the other way round — anything in
           // between (or a list that may not reach far enough) goes to the general path and its exact divisions
-          const bool above = cand && sane && eps_lo(fa) > good_enough;
-          const bool maybe = cand && !above && (!sane || eps_hi(fa) > good_enough);
-          if (__builtin_expect(__any(maybe), 0)) return false;
-          const unsigned tkey = above ? 0x7FFFFFFFu - (unsigned)t_v : 0u;
-          const unsigned long long above_mask = __ballot(above);
-          // (one touched offer above the threshold — the common case — needs no reduction)
-          const unsigned tmx = above_mask == 0ull ? 0u
-                               : ((above_mask & (above_mask - 1ull)) == 0ull ? (unsigned)wave_read_lane((int)tkey, __ffsll((unsigned long long)above_mask) - 1)
-                                                                             : wave_max_u32(tkey));
-          const int tg = tmx != 0u ? 0x7FFFFFFF - (int)tmx : 0x7FFFFFFF;  // lowest offer index among the touched offers above the threshold
+          // (first a look through the fp32 image the best-fit reduction uses anyway: while no touched offer comes near the threshold — the
+          //  filling phase of a cycle: two thirds of the walked jobs of a C4 pool at 0.8 — the exact tests and the index reduction are skipped)
+          int tg = 0x7FFFFFFF;  // lowest offer index among the touched offers above the threshold
+          int tl = -1;          // ... and its lane
+          if (__ballot(kf >= ge_near_f) != 0ull) {
+            const bool above = cand && sane && eps_lo(fa) > good_enough;
+            const bool maybe = cand && !above && (!sane || eps_hi(fa) > good_enough);
+            if (__builtin_expect(__any(maybe), 0)) return false;
+            const unsigned long long above_mask = __ballot(above);
+            if (above_mask != 0ull) {
+              if ((above_mask & (above_mask - 1ull)) == 0ull) {  // one touched offer above the threshold — the common case — needs no reduction
+                tl = __ffsll((unsigned long long)above_mask) - 1;
+                tg = wave_read_lane(t_v, tl);
+              } else {
+                const unsigned tkey = above ? 0x7FFFFFFFu - (unsigned)t_v : 0u;
+                const unsigned tmx = wave_max_u32(tkey);
+                tg = 0x7FFFFFFF - (int)tmx;
+                tl = __ffsll((unsigned long long)__ballot(above && tkey == tmx)) - 1;
+              }
+            }
+          }
           const int ng = (int)((cinfo_u >> 8) & 0xFFu);
-          const unsigned long long gun = __ballot((int)lane < ng && cur.g_owner == 0xFFu);
           int ge_pick = 0x7FFFFFFF;
-          if (__builtin_expect(gun != 0ull, 1)) {
-            const int q = __ffsll((unsigned long long)gun) - 1;
-            ge_pick = wave_read_lane(cur.g_off, q);
+          if (ng != 0) {
+            const unsigned long long gun = __ballot((int)lane < ng && cur.g_owner == 0xFFu);
+            if (__builtin_expect(gun != 0ull, 1)) {
+              const int q = __ffsll((unsigned long long)gun) - 1;
+              ge_pick = wave_read_lane(cur.g_off, q);
+            } else if (cinfo_u & JL_GTRUNC) {
+              // every listed offer is touched by now: untouched ones above the threshold may exist beyond the list, below the best touched index or not
+              if (tg > wave_read_lane(cur.g_off, ng - 1)) return false;
+            }
           } else if (cinfo_u & JL_GTRUNC) {
-            // every listed offer is touched by now: untouched ones above the threshold may exist beyond the list, below the best touched index or not
-            if (ng == 0 || tg > wave_read_lane(cur.g_off, ng - 1)) return false;
+            return false;
           }
           if (tg < ge_pick) {
-            f_lane = __ffsll((unsigned long long)__ballot(above && tkey == tmx)) - 1;
+            f_lane = tl;
             ge_done = true;
           } else if (ge_pick != 0x7FFFFFFF) {
             f_new = true;
@@ -1878,7 +1896,7 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         if constexpr (GROUP) publish_member(w, (unsigned)wave_read_lane((int)t_host, f_lane));
         WALK_STAT(3, 1);
         WALK_STAT(8, 1);
-        WALK_END(GROUP ? 4u : 1u);
+        WALK_END(GROUP ? 4u : ((GEF && ge_done) ? 6u : 1u));
         return true;
       }
       if (__builtin_expect(f_new && (nT < (unsigned)MV_T || can_retire), 1)) {  // an untouched offer: a lane takes ownership — outside this loop (see below)
@@ -1895,7 +1913,10 @@ static __device__ void resolve_round(char* lds, MatchState st, const V2Buf& vb) 
         fast_done = fast_path(std::true_type{});
     }
     load_owner(nxt);  // (before a commit of the paths below: they patch it)
-    if (__builtin_expect(!fast_done, 0)) return 2;
+    if (__builtin_expect(!fast_done, 0)) {
+      WALK_END(7u);  // (measurement build: the turn's share of a job that the paths below the loop finish)
+      return 2;
+    }
     WAIT_LDS_BUT_2();  // the record of the next job has arrived (see common.hpp); the result store and the owner look-up may still fly
     ++i;
     return 0;
