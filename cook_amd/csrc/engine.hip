@@ -1409,7 +1409,13 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
   for (unsigned x = 0; x < L; ++x) {
     std::memset((void*)&hslots[x], 0, sizeof(ServeSlot));
     hslots[x].req = 1u;  // the first window of every pool: asked for here
+    hslots[x].claim = 1u;  // ... and given to a server here (the first iterations' lists below)
   }
+  // DYNAMIC assignment (default; COOK_SERVE_DYNAMIC=0: pool x belongs to server x mod S for the whole call): every server looks at every pool and
+  // takes the open requests it sees first — a walker's request no longer queues behind its neighbours' on ONE server while another polls an empty list
+  // (measured: 133 us from request to lists on the servers with three pools, 107-123 on the one with two: profiles/r05zz_serve_trace.txt)
+  const bool dynamic = !(std::getenv("COOK_SERVE_DYNAMIC") && std::atoi(std::getenv("COOK_SERVE_DYNAMIC")) == 0);
+  const unsigned claim_max = std::max(1u, div_up(L, S));
   std::vector<ServeCtl> hs(S);
   unsigned zmax = 1;
   for (unsigned sv = 0; sv < S; ++sv) {
@@ -1421,11 +1427,13 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
     for (unsigned x = sv; x < L; x += S) hs[sv].latch[0].pool[cnt] = x, hs[sv].latch[0].seq[cnt] = 1u, ++cnt;
     hs[sv].n_pools = hs[sv].latch[0].n = cnt;
     hs[sv].latch[0].ticket_target = cnt * (unsigned)MV_MERGE_BLOCKS;
+    if (dynamic) hs[sv].n_pools = L, hs[sv].pool_first = 0u, hs[sv].pool_stride = 1u, hs[sv].claim_max = claim_max;
     hs[sv].dbg_delay[0] = (unsigned)env_ticks("COOK_SERVE_DELAY_PUBLISH_US", 0.0);
     hs[sv].dbg_delay[1] = (unsigned)env_ticks("COOK_SERVE_DELAY_ACQ_US", 0.0);
     hs[sv].dbg_delay[2] = (unsigned)env_ticks("COOK_SERVE_DELAY_READ_US", 0.0);
     zmax = std::max(zmax, cnt);
   }
+  if (dynamic) zmax = std::max(zmax, std::min(L, claim_max));
   ServeHost* hh = lead->h_serve;
   std::memset(hh, 0, MAXS * sizeof(ServeHost));
   hipStream_t s0 = lead->s_serve[0];
@@ -1514,7 +1522,20 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
   std::vector<WinCtl> hc(L);
   for (unsigned x = 0; x < L; ++x) COOK_HIP(hipMemcpyAsync(&lead->h_multi[x], hctx[x].vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, s0));
   COOK_HIP(hipMemcpyAsync(hs.data(), sctl, S * sizeof(ServeCtl), hipMemcpyDeviceToHost, s0));
+  static const bool serve_trace = std::getenv("COOK_SERVE_TRACE") != nullptr;
+  if (serve_trace) COOK_HIP(hipMemcpyAsync(hslots.data(), slots, L * sizeof(ServeSlot), hipMemcpyDeviceToHost, s0));
   COOK_HIP(hipStreamSynchronize(s0));
+  if (serve_trace) {  // the walkers' and the servers' own accounts of the call (100 MHz ticks -> microseconds)
+    for (unsigned x = 0; x < L; ++x)
+      std::fprintf(stderr, "SERVETRACE pool %u: %u windows waited for, %.1f us each from request to lists, %.1f us from the end of a round to its request\n", x,
+                   hslots[x].waits, hslots[x].waits ? hslots[x].wait_ticks / 100.0 / hslots[x].waits : 0.0,
+                   hslots[x].waits ? hslots[x].post_ticks / 100.0 / hslots[x].waits : 0.0);
+    for (unsigned sv = 0; sv < S; ++sv) {
+      const unsigned work = hs[sv].iterations - hs[sv].empty_iterations;
+      std::fprintf(stderr, "SERVETRACE server %u: %u iterations with work (%u pool windows), %.1f us each from its list to its results; %u empty iterations, %.1f ms waiting for requests\n",
+                   sv, work, hs[sv].pools_served, work ? hs[sv].busy_ticks / 100.0 / work : 0.0, hs[sv].empty_iterations, hs[sv].wait_ticks / 1.0e5);
+    }
+  }
   bool complete = true;
   for (unsigned x = 0; x < L; ++x) {
     hc[x] = lead->h_multi[x];

@@ -2469,9 +2469,14 @@ __global__ void __launch_bounds__(MV_RTHREADS) match_resolve2_pack(const PoolPac
 struct alignas(128) ServeSlot {  // per pool; the walker's words and the server's on lines of their own
   unsigned req;   // [walker -> server] windows asked for so far (the first one by the host: 1)
   unsigned done;  // [walker -> server] 1 = every job of the pool is resolved, 2 = the walker gave up (ServeCtl::error)
-  unsigned pad0[30];
+  // the walker's own account (100 MHz ticks; COOK_SERVE_TRACE=1 prints it): from posting a request to seeing its lists, and from the end
+  // of a round to the posting of the next request (drain, barrier, L2 write-back)
+  unsigned long long wait_ticks, post_ticks;
+  unsigned waits, pad0[25];
   unsigned ready;  // [server -> walker] windows served so far
-  unsigned pad1[31];
+  unsigned claim;  // [server <-> server] the last request of this pool that a server has taken (dynamic assignment: whichever latch sees a
+                   // request first takes it with a compare-and-swap from req - 1 to req)
+  unsigned pad1[30];
 };
 constexpr unsigned MV_SERVE_MAX = 16;  // pools per served call
 // What ONE serve iteration works on: the pools that had a request open when the iteration was put together, the request numbers it
@@ -2489,6 +2494,8 @@ struct ServeLatch {
 // its own, the arrival counter on another.
 struct alignas(256) ServeCtl {
   unsigned n_pools, pool_first, pool_stride;
+  unsigned claim_max;     // > 0: DYNAMIC assignment — this server looks at every pool of the call (first 0, stride 1) and takes up to claim_max
+                          // open requests per iteration, first come first served among the servers (ServeSlot::claim); 0: its own pools only
   unsigned dbg_fence;     // (diagnostics, COOK_SERVE_FENCE=1) every hand-off with full agent-scope fences by every workgroup
   unsigned dbg_delay[3];  // (diagnostics) 100 MHz ticks to wait [0] before publishing, [1] between seeing ready and the acquire, [2] behind the acquire
   ServeLatch latch[2];
@@ -2497,6 +2504,7 @@ struct alignas(256) ServeCtl {
   unsigned error;                 // a walker gave up
   unsigned iterations, empty_iterations, pools_served;  // statistics
   unsigned long long wait_ticks;  // 100 MHz ticks the latch spent waiting for a request
+  unsigned long long formed_tick, busy_ticks;  // when the running iteration's list was put together; ticks from there to the publishing of its results (iterations with work)
   alignas(128) unsigned ticket;   // arrivals of merge workgroups so far (agent-scope atomics only; zeroed by the host)
 };
 struct alignas(128) ServeHost {  // page-locked host memory, written by the latch with system-scope stores, polled by the host
@@ -2523,15 +2531,25 @@ static __device__ __forceinline__ void serve_latch(ServeCtl* sc, ServeSlot* slot
   }
   if (lane < nl) st_agent(&slots[cur.pool[lane]].ready, cur.seq[lane]);
   const unsigned long long t0 = cook_ticks();
+  if (lane == 0 && nl != 0u && sc->formed_tick != 0ull) sc->busy_ticks += t0 - sc->formed_tick;
   unsigned rq = 0, dn = 0;
   unsigned long long pend, alive;
+  const unsigned claim_max = wave_uniform_u32(sc->claim_max);
   for (;;) {
+    unsigned cl = mine;
     if (lane < n) {
       rq = ld_agent(&slots[my_pool].req);
       dn = ld_agent(&slots[my_pool].done);
+      if (claim_max != 0u) cl = ld_agent(&slots[my_pool].claim);
     }
     alive = __ballot(lane < n && dn == 0u);
-    pend = __ballot(lane < n && dn == 0u && rq != mine);
+    pend = __ballot(lane < n && dn == 0u && rq != cl);
+    if (claim_max != 0u && pend != 0ull) {  // dynamic: take what nobody has taken yet, at most claim_max of them (the others are some other server's)
+      const bool mine_to_try = ((pend >> lane) & 1ull) != 0ull && (unsigned)__popcll(pend & ((1ull << lane) - 1ull)) < claim_max;
+      bool won = false;
+      if (mine_to_try) won = atomicCAS(&slots[my_pool].claim, cl, rq) == cl;
+      pend = __ballot(won);
+    }
     if (pend != 0ull || alive == 0ull || poll_ticks == 0ull || cook_ticks() - t0 > poll_ticks) break;
     SPIN_PAUSE_FAR();
   }
@@ -2549,6 +2567,7 @@ static __device__ __forceinline__ void serve_latch(ServeCtl* sc, ServeSlot* slot
     sc->empty_iterations += nl == 0u ? 1u : 0u;
     sc->pools_served += nl;
     sc->wait_ticks += waited;
+    sc->formed_tick = cook_ticks();
     const unsigned err = ld_agent(&sc->error);
     if (alive == 0ull) sc->all_done = 1u;
     if (alive == 0ull) st_system(&host->all_done, 1u);
@@ -2647,6 +2666,8 @@ static __device__ __forceinline__ void walk_pool(char* lds, int& s_go, const Mat
           SPIN_PAUSE_FAR();
         }
         if (go == 1) {
+          slot->wait_ticks += cook_ticks() - t0;
+          slot->waits += 1u;
           if (sc->dbg_delay[1] != 0u) {
             const unsigned long long d0 = cook_ticks();
             while (cook_ticks() - d0 < sc->dbg_delay[1]) SPIN_PAUSE_FAR();
@@ -2668,6 +2689,7 @@ static __device__ __forceinline__ void walk_pool(char* lds, int& s_go, const Mat
       __syncthreads();
     }
     resolve_round<GE>(lds, st, vb);
+    const unsigned long long t_round_end = cook_ticks();
     EMU_SITE("walker: round done");
     drain_stores();   // (every wave: see drain_stores)
     if (sc->dbg_fence != 0u) agent_release();
@@ -2679,6 +2701,7 @@ static __device__ __forceinline__ void walk_pool(char* lds, int& s_go, const Mat
         st_agent(&slot->done, 1u);
         s_go = 0;
       } else {
+        slot->post_ticks += cook_ticks() - t_round_end;
         st_agent(&slot->req, ld_agent(&slot->req) + 1u);
       }
     }
