@@ -64,8 +64,8 @@ void cons_run_device(cook_engine* e, ConsBufs& c, unsigned n, const double* q_cp
   const unsigned U = c.U;
   c.rate_limited.ensure(std::max(1u, U));
   c.passed.ensure(std::max(1u, U));
-  COOK_HIP(hipMemsetAsync(c.rate_limited.ptr(), 0, (size_t)std::max(1u, U) * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(c.passed.ptr(), 0, (size_t)std::max(1u, U) * 4, e->stream));
+  memset_async(e, c.rate_limited.ptr(), 0, (size_t)std::max(1u, U) * 4);
+  memset_async(e, c.passed.ptr(), 0, (size_t)std::max(1u, U) * 4);
   c.n_result = 0;
   c.result = c.qitemA.ensure(std::max(1u, n));
   if (n == 0) return;  // K == 0 still runs the filters: the per-user rate-limit counters cover the whole queue
@@ -74,8 +74,8 @@ void cons_run_device(cook_engine* e, ConsBufs& c, unsigned n, const double* q_cp
   c.ukey.ensure(n);
   c.permA.ensure(n);
   c.permB.ensure(n);
-  KL("cons_user_keys", cons_user_keys, gN, 256, q_user, n, c.ukey.ptr());
-  KL("iota", iota_u32, gN, 256, c.permA.ptr(), n);
+  KM<cons_user_keys, 256>(e, "cons_user_keys", gN, q_user, n, c.ukey.ptr());
+  KM<iota_u32, 256>(e, "iota", gN, c.permA.ptr(), n);
   unsigned long long umask = 0;
   for (unsigned long long x = U ? U - 1 : 0; x; x >>= 1) umask = (umask << 1) | 1ull;
   const uint32_t* permU = radix_sort_masked(e, c.ukey.ptr(), umask, c.permA.ptr(), c.permA.ptr(), c.permB.ptr(), n);
@@ -86,27 +86,20 @@ void cons_run_device(cook_engine* e, ConsBufs& c, unsigned n, const double* q_cp
   c.seg_end.ensure(std::max(1u, U));
   c.inexact.ensure(std::max(1u, U));
   c.pre.ensure(n);
-  COOK_HIP(hipMemsetAsync(c.inexact.ptr(), 0, (size_t)std::max(1u, U) * 4, e->stream));
-  KL("cons_gather", cons_gather, gN, 256, permU, n, q_user, q_cpus, q_mem, q_gpus, c.g_user.ptr(), c.g_use.ptr(), c.head.ptr(),
-     c.seg_start.ptr(), c.seg_end.ptr());
+  memset_async(e, c.inexact.ptr(), 0, (size_t)std::max(1u, U) * 4);
+  KM<cons_gather, 256>(e, "cons_gather", gN, permU, n, q_user, q_cpus, q_mem, q_gpus, c.g_user.ptr(), c.g_use.ptr(), c.head.ptr(), c.seg_start.ptr(), c.seg_end.ptr());
   // ---- (i) per-user quota filter, seeded with the users' running usage (tools.clj:903-915) -------------------------------
   LoadUserSeeded ld{c.g_use.ptr(), c.head.ptr(), c.g_user.ptr(), c.ucount.ptr(), c.ucpus.ptr(), c.umem.ptr(), c.ugpus.ptr()};
   seg_scan<SumU4>(e, "cons_user_usage_scan", ld, (const uint8_t*)c.head.ptr(), n, c.pre.ptr(), e->tmpU4);
-  KL("rank_mark_inexact", rank_mark_inexact, gN, 256, (const SumU4*)c.pre.ptr(), (const uint32_t*)c.g_user.ptr(), n, c.inexact.ptr());
-  KL("cons_fix_inexact", cons_fix_inexact, div_up(std::max(1u, U), 256), 256, (const SumU4*)c.g_use.ptr(), c.pre.ptr(),
-     (const uint32_t*)c.seg_start.ptr(), (const uint32_t*)c.seg_end.ptr(), (const uint32_t*)c.inexact.ptr(), U,
-     (const double*)c.ucount.ptr(), (const double*)c.ucpus.ptr(), (const double*)c.umem.ptr(), (const double*)c.ugpus.ptr());
+  KM<rank_mark_inexact, 256>(e, "rank_mark_inexact", gN, (const SumU4*)c.pre.ptr(), (const uint32_t*)c.g_user.ptr(), n, c.inexact.ptr());
+  KM<cons_fix_inexact, 256>(e, "cons_fix_inexact", div_up(std::max(1u, U), 256), (const SumU4*)c.g_use.ptr(), c.pre.ptr(), (const uint32_t*)c.seg_start.ptr(), (const uint32_t*)c.seg_end.ptr(), (const uint32_t*)c.inexact.ptr(), U, (const double*)c.ucount.ptr(), (const double*)c.ucpus.ptr(), (const double*)c.umem.ptr(), (const double*)c.ugpus.ptr());
   c.flag1.ensure(n);
   c.keep_q.ensure(n);
   c.scan.ensure(n);
-  KL("cons_user_quota_flag", cons_user_quota_flag, gN, 256, (const SumU4*)c.pre.ptr(), (const uint32_t*)c.g_user.ptr(), n,
-     (const double*)c.qcount.ptr(), (const double*)c.qcpus.ptr(), (const double*)c.qmem.ptr(), (const double*)c.qgpus.ptr(),
-     c.flag1.ptr());
+  KM<cons_user_quota_flag, 256>(e, "cons_user_quota_flag", gN, (const SumU4*)c.pre.ptr(), (const uint32_t*)c.g_user.ptr(), n, (const double*)c.qcount.ptr(), (const double*)c.qcpus.ptr(), (const double*)c.qmem.ptr(), (const double*)c.qgpus.ptr(), c.flag1.ptr());
   // ---- (ii) launch-rate limit: index of the job among its user's survivors (tools.clj:935-955) -----------------------------
   seg_scan<SumI>(e, "cons_user_index_scan", LoadI{c.flag1.ptr()}, (const uint8_t*)c.head.ptr(), n, c.scan.ptr(), e->tmpI);
-  KL("cons_rate_limit", cons_rate_limit, gN, 256, (const int*)c.flag1.ptr(), (const SumI*)c.scan.ptr(), (const uint32_t*)c.g_user.ptr(),
-     permU, n, c.has_tokens ? (const int64_t*)c.tokens.ptr() : (const int64_t*)nullptr, c.enforce, c.keep_q.ptr(),
-     c.rate_limited.ptr(), c.passed.ptr());
+  KM<cons_rate_limit, 256>(e, "cons_rate_limit", gN, (const int*)c.flag1.ptr(), (const SumI*)c.scan.ptr(), (const uint32_t*)c.g_user.ptr(), permU, n, c.has_tokens ? (const int64_t*)c.tokens.ptr() : (const int64_t*)nullptr, c.enforce, c.keep_q.ptr(), c.rate_limited.ptr(), c.passed.ptr());
   // ---- survivors back in queue order ---------------------------------------------------------------------------------------------
   uint32_t* qitem = c.qitemA.ensure(n);
   uint32_t* qitem_o = c.qitemB.ensure(n);
@@ -114,20 +107,18 @@ void cons_run_device(cook_engine* e, ConsBufs& c, unsigned n, const double* q_cp
   SumU4* quse_o = c.quseB.ensure(n);
   seg_scan<SumI>(e, "cons_compact_scan", LoadI{c.keep_q.ptr()}, (const uint8_t*)nullptr, n, c.scan.ptr(), e->tmpI);
   unsigned* dlen = e->d_counters.ptr() + 12;
-  COOK_HIP(hipMemsetAsync(dlen, 0, 4, e->stream));
-  KL("cons_compact_queue", cons_compact_queue, gN, 256, (const int*)c.keep_q.ptr(), (const SumI*)c.scan.ptr(), n, q_cpus, q_mem, q_gpus,
-     qitem, quse, dlen);
+  memset_async(e, dlen, 0, 4);
+  KM<cons_compact_queue, 256>(e, "cons_compact_queue", gN, (const int*)c.keep_q.ptr(), (const SumI*)c.scan.ptr(), n, q_cpus, q_mem, q_gpus, qitem, quse, dlen);
   // ---- (iii) pool quota, seeded with the pool usage (tools.clj:917-933, 966) -------------------------------------------------------
   cook_usage base = c.pool_usage;
   if (c.has_pool_quota && !c.pool_usage_given) {
     c.pusage.ensure(1);
     if (U) {
-      KL("cons_pool_usage", cons_pool_usage, 1, 1024, (const double*)c.ucount.ptr(), (const double*)c.ucpus.ptr(),
-         (const double*)c.umem.ptr(), (const double*)c.ugpus.ptr(), U, c.pusage.ptr());
-      COOK_HIP(hipMemcpyAsync(e->h_scratch + 8, c.pusage.ptr(), sizeof(SumU4), hipMemcpyDeviceToHost, e->stream));
+      KM<cons_pool_usage, 1024>(e, "cons_pool_usage", 1, (const double*)c.ucount.ptr(), (const double*)c.ucpus.ptr(), (const double*)c.umem.ptr(), (const double*)c.ugpus.ptr(), U, c.pusage.ptr());
+      pinned_copy(e, e->h_scratch + 8, c.pusage.ptr(), sizeof(SumU4), hipMemcpyDeviceToHost);
     }
   }
-  COOK_HIP(hipMemcpyAsync(e->h_scratch, dlen, 4, hipMemcpyDeviceToHost, e->stream));
+  pinned_copy(e, e->h_scratch, dlen, 4, hipMemcpyDeviceToHost);
   sync(e);
   unsigned len = 0;
   std::memcpy(&len, e->h_scratch, 4);
@@ -141,12 +132,11 @@ void cons_run_device(cook_engine* e, ConsBufs& c, unsigned n, const double* q_cp
   if (len && q_elig) {
     e->iflag.ensure(len);
     e->scanI.ensure(len);
-    KL("cons_eligible_flag", cons_eligible_flag, div_up(len, 256), 256, (const uint32_t*)qitem, len, q_elig, e->iflag.ptr());
+    KM<cons_eligible_flag, 256>(e, "cons_eligible_flag", div_up(len, 256), (const uint32_t*)qitem, len, q_elig, e->iflag.ptr());
     seg_scan<SumI>(e, "queue_compact_scan", LoadI{e->iflag.ptr()}, (const uint8_t*)nullptr, len, e->scanI.ptr(), e->tmpI);
     unsigned* len_out = e->d_counters.ptr() + 9;
-    KL("queue_compact", queue_compact, div_up(len, 256), 256, (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(),
-       (const SumI*)e->scanI.ptr(), len, qitem_o, quse_o, len_out);
-    COOK_HIP(hipMemcpyAsync(e->h_scratch, len_out, 4, hipMemcpyDeviceToHost, e->stream));
+    KM<queue_compact, 256>(e, "queue_compact", div_up(len, 256), (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(), (const SumI*)e->scanI.ptr(), len, qitem_o, quse_o, len_out);
+    pinned_copy(e, e->h_scratch, len_out, 4, hipMemcpyDeviceToHost);
     sync(e);
     std::memcpy(&len, e->h_scratch, 4);
     std::swap(qitem, qitem_o);

@@ -10,13 +10,13 @@
 #include "common.hpp"
 #include "scan.hpp"
 
-__global__ void __launch_bounds__(256) cons_user_keys(const uint32_t* __restrict__ user, unsigned n, uint64_t* __restrict__ key) {
+COOK_KERNEL void cons_user_keys(const uint32_t* __restrict__ user, unsigned n, uint64_t* __restrict__ key) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) key[i] = user[i];
 }
 
 // queue arrays of a cycle: position q of the ranked queue is pending job pend_ord[ranked[q]]
-__global__ void __launch_bounds__(256) cons_gather_queue(const uint32_t* __restrict__ ranked, const uint32_t* __restrict__ pend_ord,
+COOK_KERNEL void cons_gather_queue(const uint32_t* __restrict__ ranked, const uint32_t* __restrict__ pend_ord,
                                                          unsigned n, const double* __restrict__ j_cpus, const double* __restrict__ j_mem,
                                                          const double* __restrict__ j_gpus, const uint32_t* __restrict__ j_user,
                                                          const uint8_t* __restrict__ elig_by_pending, double* __restrict__ q_cpus,
@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) cons_gather_queue(const uint32_t* __restr
 }
 
 // per-user order of the queue: usage of each job, segment heads and bounds
-__global__ void __launch_bounds__(256) cons_gather(const uint32_t* __restrict__ permU, unsigned n, const uint32_t* __restrict__ user,
+COOK_KERNEL void cons_gather(const uint32_t* __restrict__ permU, unsigned n, const uint32_t* __restrict__ user,
                                                    const double* __restrict__ cpus, const double* __restrict__ mem,
                                                    const double* __restrict__ gpus, uint32_t* __restrict__ g_user,
                                                    SumU4* __restrict__ g_use, uint8_t* __restrict__ head,
@@ -63,7 +63,7 @@ struct LoadUserSeeded {  // (merge-with + job-usage usage[user]), tools.clj:908:
   }
 };
 
-__global__ void __launch_bounds__(256) cons_fix_inexact(const SumU4* __restrict__ g_use, SumU4* __restrict__ pre,
+COOK_KERNEL void cons_fix_inexact(const SumU4* __restrict__ g_use, SumU4* __restrict__ pre,
                                                         const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ seg_end,
                                                         const uint32_t* __restrict__ inexact_user, unsigned n_users,
                                                         const double* __restrict__ uc, const double* __restrict__ ucpus,
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) cons_fix_inexact(const SumU4* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(256) cons_user_quota_flag(const SumU4* __restrict__ pre, const uint32_t* __restrict__ g_user, unsigned n,
+COOK_KERNEL void cons_user_quota_flag(const SumU4* __restrict__ pre, const uint32_t* __restrict__ g_user, unsigned n,
                                                             const double* __restrict__ q_count, const double* __restrict__ q_cpus,
                                                             const double* __restrict__ q_mem, const double* __restrict__ q_gpus,
                                                             int* __restrict__ flag) {
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) cons_user_quota_flag(const SumU4* __restr
 
 // tools.clj:935-955: the n-th job of a user that reaches this stage is rate limited iff n > tokens-left; it is dropped only
 // when the limiter is enforcing.  Writes the verdict back in QUEUE order.
-__global__ void __launch_bounds__(256) cons_rate_limit(const int* __restrict__ flag1, const SumI* __restrict__ idx1,
+COOK_KERNEL void cons_rate_limit(const int* __restrict__ flag1, const SumI* __restrict__ idx1,
                                                        const uint32_t* __restrict__ g_user, const uint32_t* __restrict__ permU, unsigned n,
                                                        const int64_t* __restrict__ tokens, int enforce, int* __restrict__ keep_q,
                                                        uint32_t* __restrict__ rate_limited, uint32_t* __restrict__ passed) {
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) cons_rate_limit(const int* __restrict__ f
 }
 
 // survivors in queue order -> (queue position, usage) lists for the pool-quota scan
-__global__ void __launch_bounds__(256) cons_compact_queue(const int* __restrict__ flag, const SumI* __restrict__ incl, unsigned n,
+COOK_KERNEL void cons_compact_queue(const int* __restrict__ flag, const SumI* __restrict__ incl, unsigned n,
                                                           const double* __restrict__ cpus, const double* __restrict__ mem,
                                                           const double* __restrict__ gpus, uint32_t* __restrict__ qitem,
                                                           SumU4* __restrict__ quse, unsigned* __restrict__ len_out) {
@@ -128,14 +128,14 @@ __global__ void __launch_bounds__(256) cons_compact_queue(const int* __restrict_
   if (q == n - 1) *len_out = (unsigned)incl[q].v;
 }
 
-__global__ void __launch_bounds__(256) cons_eligible_flag(const uint32_t* __restrict__ qitem, unsigned len, const uint8_t* __restrict__ elig,
+COOK_KERNEL void cons_eligible_flag(const uint32_t* __restrict__ qitem, unsigned len, const uint8_t* __restrict__ elig,
                                                           int* __restrict__ flag) {
   const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < len) flag[q] = elig[qitem[q]] ? 1 : 0;
 }
 
 // tools.clj:966 pool-usage = sum of the users' usage (user-id order); one workgroup, exactness tracked
-__global__ void __launch_bounds__(1024) cons_pool_usage(const double* __restrict__ uc, const double* __restrict__ ucpus,
+COOK_KERNEL void cons_pool_usage(const double* __restrict__ uc, const double* __restrict__ ucpus,
                                                         const double* __restrict__ umem, const double* __restrict__ ugpus, unsigned n,
                                                         SumU4* __restrict__ out) {
   __shared__ SumU4 ws[1024 / COOK_WAVE];
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(1024) cons_pool_usage(const double* __restrict
 }
 
 // job k of the match = pending job pend_ord[ranked[cons_idx[k]]]
-__global__ void __launch_bounds__(256) cons_job_index(const uint32_t* __restrict__ cons_idx, const uint32_t* __restrict__ ranked,
+COOK_KERNEL void cons_job_index(const uint32_t* __restrict__ cons_idx, const uint32_t* __restrict__ ranked,
                                                       const uint32_t* __restrict__ pend_ord, unsigned k, uint32_t* __restrict__ j_index) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < k) j_index[i] = pend_ord[ranked[cons_idx[i]]];

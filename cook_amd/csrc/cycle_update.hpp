@@ -382,9 +382,9 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
   SumI* incl = ub.incl.ensure(std::max(1u, N));
   SumI* incl_p = ub.incl_p.ensure(std::max(1u, P));
   UpdOut* out = ub.out.ensure(1);
-  COOK_HIP(hipMemsetAsync(out, 0, sizeof(UpdOut), e->stream));
-  if (N) COOK_HIP(hipMemsetAsync(rm, 0, (size_t)N * 4, e->stream));
-  if (P) COOK_HIP(hipMemsetAsync(rm_p, 0, (size_t)P * 4, e->stream));
+  memset_async(e, out, 0, sizeof(UpdOut));
+  if (N) memset_async(e, rm, 0, (size_t)N * 4);
+  if (P) memset_async(e, rm_p, 0, (size_t)P * 4);
   if (d->n_remove) {
     KL("upd_mark_removed", upd_mark_removed, div_up(d->n_remove, 256), 256, (const uint32_t*)dev(o.rem, true), d->n_remove, N, rm, out);
     if (P)
@@ -470,8 +470,8 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
     ub.csr_vals[0] = ub.csr_vals[1] = 0;
     uint32_t* h = (uint32_t*)e->h_scratch;
     h[0] = h[1] = 0;
-    if (in.j_eq_off && P) COOK_HIP(hipMemcpyAsync(&h[0], e->j_eq_off.ptr() + P, 4, hipMemcpyDeviceToHost, e->stream));
-    if (in.j_novel_off && P) COOK_HIP(hipMemcpyAsync(&h[1], e->j_novel_off.ptr() + P, 4, hipMemcpyDeviceToHost, e->stream));
+    if (in.j_eq_off && P) copy_async(e, &h[0], e->j_eq_off.ptr() + P, 4, hipMemcpyDeviceToHost);
+    if (in.j_novel_off && P) copy_async(e, &h[1], e->j_novel_off.ptr() + P, 4, hipMemcpyDeviceToHost);
     sync(e);
     ub.csr_vals[0] = h[0], ub.csr_vals[1] = h[1];
     ub.csr_known = true;
@@ -493,7 +493,7 @@ void cycle_update(cook_engine* e, UpdateBufs& ub, const cook_cycle_delta* d) {
   stamp(4);
   // ---- the one look at the device --------------------------------------------------------------------------------------------
   UpdOut h{};
-  COOK_HIP(hipMemcpyAsync(e->h_scratch, out, sizeof(UpdOut), hipMemcpyDeviceToHost, e->stream));
+  copy_async(e, e->h_scratch, out, sizeof(UpdOut), hipMemcpyDeviceToHost);
   sync(e);
   std::memcpy(&h, e->h_scratch, sizeof(UpdOut));
   stamp(5);

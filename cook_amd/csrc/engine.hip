@@ -1,6 +1,7 @@
 // engine.hip — libcookmatch.so: C ABI (include/cookmatch.h) + host orchestration of the HIP kernels.
 // One engine = one pool = one HIP stream.  Built by hipcc for gfx950 only (cook_amd/build.py).
 #include <hip/hip_runtime.h>
+#include <ucontext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -9,12 +10,15 @@
 #include <chrono>
 #include <cstring>
 #include <limits>
+#include <functional>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/cookmatch.h"
 #include "common.hpp"
+#include "multi.hpp"
 #include "considerable_kernels.hpp"
 #include "match_kernels.hpp"
 #include "match_v2.hpp"
@@ -43,6 +47,8 @@ static const bool g_guard = [] {
 static std::atomic<unsigned> g_guard_hits{0};
 static thread_local unsigned tl_dbuf_allocs = 0;  // device allocations made by this thread (cook_match_stats_ex [28]: a call that grows a buffer pays hipFree + hipMalloc)
 constexpr size_t GUARD_BYTES = 4096;
+// a pool batch (below, "pool batches") holds launches back until its pools meet at a synchronisation: a buffer must not be freed under them
+static void batch_drain_before_free();
 struct DBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -64,6 +70,7 @@ struct DBuf {
   }
   void free_now() {
     if (!p) return;
+    batch_drain_before_free();
     check_guard();
     (void)hipFree(g_guard ? (void*)((char*)p - GUARD_BYTES) : p);
     p = nullptr;
@@ -177,6 +184,7 @@ struct cook_engine {
   ScanTmp<SumI> tmpI;
   uint32_t* permB = nullptr;  // final per-user order (points into permA or permB2)
   uint32_t* permC = nullptr;  // final global order
+  unsigned batch_stats[5] = {0, 0, 0, 0, 0};  // the last cook_cycle_run_rank_multi led by this engine: pools, launches, of them for several pools, operations issued alone, synchronisations
   DArr<uint32_t> permC1, permC2;
   unsigned n_ranked = 0;
 
@@ -295,23 +303,163 @@ void prof_collect(cook_engine* e) {
   e->ev_used = 0;
 }
 
-#define KL(name, kern, grid, block, ...)                                      \
-  do {                                                                        \
-    ProfScope _ps(e, name);                                                   \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, e->stream, __VA_ARGS__); \
+// ---- pool batches: the flows of several pools on ONE stream, the same kernel of all of them in ONE launch ---------------------------
+// cook_cycle_run_rank_multi runs the rank part of a cycle for every pool of a GPU.  Each pool's flow is the code a single pool runs
+// (rank_run, the considerable filters, the set-up of the match), on a fiber of its own: while a flow runs, KM / KL / copy_async /
+// memset_async RECORD what they would enqueue, and sync() — every point at which the host needs to read something back — parks the flow.
+// When every flow is parked (or finished) the scheduler issues what was recorded: operations of the same kernel that stand at the front
+// of several flows become one `cook_multi` launch (multi.hpp: blockIdx.y = pool), everything else is issued as recorded, each flow's
+// order kept; then ONE stream synchronisation, and the flows go on.  The flows' decisions (radix digits, tie rounds, queue lengths)
+// stay per pool: a pool that needs a pass the others do not simply has a record of its own at that point.
+constexpr unsigned BATCH_ARG_BYTES = 496;
+struct BatchOp {
+  const void* key = nullptr;  // the group launcher of (kernel, block size); null: an operation issued on its own
+  void (*launch)(cook_engine* lead, hipStream_t s, const char* name, const BatchOp* const* ops, unsigned n) = nullptr;
+  const char* name = "";
+  unsigned grid = 0;
+  alignas(16) unsigned char args[BATCH_ARG_BYTES];
+  std::function<void(cook_engine*, hipStream_t)> generic;
+};
+struct PoolFlow {
+  cook_engine* e = nullptr;
+  ucontext_t ctx;
+  char* stack = nullptr;
+  std::vector<BatchOp> ops;
+  size_t cur = 0;
+  int state = 0;  // 0 ready to run, 1 parked at a synchronisation, 2 finished
+  int rc = COOK_OK;
+  std::function<void()> body;
+};
+struct PoolBatch {
+  cook_engine* lead = nullptr;
+  hipStream_t stream = nullptr;
+  std::vector<PoolFlow> flows;
+  ucontext_t main_ctx;
+  unsigned launches = 0, grouped = 0, singles = 0, syncs = 0;  // launches made, of them for more than one pool; operations issued alone
+};
+static thread_local PoolBatch* tl_batch = nullptr;
+static thread_local PoolFlow* tl_flow = nullptr;  // the flow running on this thread (null: none, or the scheduler itself)
+static inline bool recording() { return tl_flow != nullptr; }
+static BatchOp& batch_new_op() {
+  tl_flow->ops.emplace_back();
+  return tl_flow->ops.back();
+}
+static void batch_park() {  // the running flow waits until everything recorded so far has run
+  PoolFlow* f = tl_flow;
+  f->state = 1;
+  tl_flow = nullptr;
+  swapcontext(&f->ctx, &tl_batch->main_ctx);
+}
+static void batch_drain_before_free() {
+  if (recording() && !tl_flow->ops.empty()) batch_park();
+}
+
+template <class Fp>
+struct KernelSig;
+template <class... A>
+struct KernelSig<void (*)(A...)> {
+  using Pack = ArgPack<A...>;
+  using Args = MultiArgs<A...>;
+  template <auto F, int B>
+  static void launch_group(cook_engine* lead, hipStream_t s, const char* name, const BatchOp* const* ops, unsigned n) {
+    for (unsigned i0 = 0; i0 < n; i0 += Args::PER) {
+      const unsigned c = std::min<unsigned>(Args::PER, n - i0);
+      Args m{};
+      unsigned gmax = 0;
+      for (unsigned i = 0; i < c; ++i) {
+        m.grid[i] = ops[i0 + i]->grid;
+        std::memcpy(&m.a[i], ops[i0 + i]->args, sizeof(Pack));
+        gmax = std::max(gmax, m.grid[i]);
+      }
+      ProfScope _ps(lead, name, s);
+      hipLaunchKernelGGL((cook_multi<F, B, A...>), dim3(gmax, c), dim3(B), 0, s, m);
+    }
+  }
+};
+// launch of a COOK_KERNEL (a 1-D grid of `grid` blocks of B threads) on the engine's stream — or its record, inside a pool batch
+template <auto F, int B, class... X>
+void KM(cook_engine* e, const char* name, unsigned grid, const X&... x) {
+  using Sig = KernelSig<decltype(F)>;
+  static_assert(sizeof(typename Sig::Pack) <= BATCH_ARG_BYTES, "a batched kernel's arguments: pass large structures by pointer");
+  if (grid == 0) return;
+  const typename Sig::Pack p = Sig::Pack::make(x...);
+  BatchOp local;
+  BatchOp& op = recording() ? batch_new_op() : local;
+  op.key = (const void*)&Sig::template launch_group<F, B>;
+  op.launch = &Sig::template launch_group<F, B>;
+  op.name = name;
+  op.grid = grid;
+  std::memcpy(op.args, &p, sizeof(p));
+  if (recording()) return;
+  const BatchOp* one[1] = {&op};
+  op.launch(e, e->stream, name, one, 1);
+}
+
+// a __global__ kernel of its own (arguments evaluated here and now; inside a pool batch the launch is recorded and issued alone)
+#define KL(name, kern, grid, block, ...)                                                                     \
+  do {                                                                                                       \
+    if (recording()) {                                                                                       \
+      const auto _a = std::make_tuple(__VA_ARGS__);                                                          \
+      const dim3 _g(grid), _b(block);                                                                        \
+      const char* _n = name;                                                                                 \
+      batch_new_op().generic = [=](cook_engine* lead_, hipStream_t s_) {                                     \
+        ProfScope _ps(lead_, _n, s_);                                                                        \
+        std::apply([&](const auto&... x_) { hipLaunchKernelGGL(kern, _g, _b, 0, s_, x_...); }, _a);          \
+      };                                                                                                     \
+    } else {                                                                                                 \
+      ProfScope _ps(e, name);                                                                                \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, e->stream, __VA_ARGS__);                          \
+    }                                                                                                        \
   } while (0)
 
-// the same on a given stream (timed, when profiling, with events on THAT stream)
+// the same on a given stream (timed, when profiling, with events on THAT stream); never part of a pool batch
 #define KLS(name, stream_, kern, grid, block, ...)                               \
   do {                                                                        \
     ProfScope _ps(e, name, stream_);                                          \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream_, __VA_ARGS__); \
   } while (0)
 
+// copies and fills on the engine's stream (recorded inside a pool batch: a source in host memory must stay as it is until the flow's
+// next synchronisation, which is what an asynchronous copy asks for anyway)
+void copy_async(cook_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  if (!bytes) return;
+  if (recording()) {
+    batch_new_op().generic = [=](cook_engine*, hipStream_t s_) { COOK_HIP(hipMemcpyAsync(dst, src, bytes, kind, s_)); };
+    return;
+  }
+  COOK_HIP(hipMemcpyAsync(dst, src, bytes, kind, e->stream));
+}
+void memset_async(cook_engine* e, void* dst, int value, size_t bytes) {
+  if (!bytes) return;
+  if (recording()) {
+    batch_new_op().generic = [=](cook_engine*, hipStream_t s_) { COOK_HIP(hipMemsetAsync(dst, value, bytes, s_)); };
+    return;
+  }
+  COOK_HIP(hipMemsetAsync(dst, value, bytes, e->stream));
+}
+
+// a few words between device memory and PAGE-LOCKED host memory (read-backs of counters into h_scratch, a control block on its way in).
+// Inside a pool batch they are moved by a kernel — the device reads and writes page-locked host memory over the link — so that the eight
+// copies of eight pools are one launch and not eight calls of the runtime (COOK_BATCH_COPY_KERNEL=0: recorded copies, issued one by one)
+COOK_KERNEL void copy_words_k(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, unsigned nwords) {
+  for (unsigned i = threadIdx.x; i < nwords; i += blockDim.x) dst[i] = src[i];
+}
+static const bool g_batch_copy_kernel = [] {
+  const char* s = std::getenv("COOK_BATCH_COPY_KERNEL");
+  return !(s && std::atoi(s) == 0);
+}();
+void pinned_copy(cook_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  if (recording() && g_batch_copy_kernel && bytes % 4 == 0 && bytes <= 4096 && ((uintptr_t)dst | (uintptr_t)src) % 4 == 0) {
+    KM<copy_words_k, COOK_WAVE>(e, "copy_words", 1, (uint32_t*)dst, (const uint32_t*)src, (unsigned)(bytes / 4));
+    return;
+  }
+  copy_async(e, dst, src, bytes, kind);
+}
+
 template <class T>
 void h2d(cook_engine* e, DArr<T>& d, const T* h, size_t n) {
   d.ensure(n);
-  if (n) COOK_HIP(hipMemcpyAsync(d.ptr(), h, n * sizeof(T), hipMemcpyHostToDevice, e->stream));
+  copy_async(e, d.ptr(), h, n * sizeof(T), hipMemcpyHostToDevice);
 }
 template <class T>
 const T* h2d_opt(cook_engine* e, DArr<T>& d, const T* h, size_t n) {
@@ -325,10 +473,120 @@ static const bool g_sync_trace = std::getenv("COOK_SYNC_TRACE") != nullptr;
 static thread_local double tl_sync_ms = 0.0;
 static thread_local unsigned tl_syncs = 0;
 void sync(cook_engine* e) {  // (always timed: two clock reads against a stream synchronisation)
+  if (recording()) {  // inside a pool batch: the flow goes on once every pool's flow has come to such a point and the stream has drained
+    batch_park();
+    return;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   COOK_HIP(hipStreamSynchronize(e->stream));
   tl_sync_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ++tl_syncs;
+}
+
+// issues what the flows have recorded: operations without a key as they stand, the same kernel at the front of several flows as one launch
+static void batch_flush(PoolBatch& b) {
+  const unsigned P = (unsigned)b.flows.size();
+  const BatchOp* group[COOK_MULTI_MAX * 8];
+  for (;;) {
+    for (auto& f : b.flows)
+      while (f.cur < f.ops.size() && !f.ops[f.cur].key) {
+        f.ops[f.cur].generic(b.lead, b.stream);
+        ++f.cur;
+        ++b.singles;
+      }
+    const void* best = nullptr;
+    unsigned best_n = 0;
+    for (unsigned i = 0; i < P; ++i) {
+      const PoolFlow& f = b.flows[i];
+      if (f.cur >= f.ops.size()) continue;
+      const void* k = f.ops[f.cur].key;
+      unsigned c = 0;
+      for (unsigned j = 0; j < P; ++j) c += (b.flows[j].cur < b.flows[j].ops.size() && b.flows[j].ops[b.flows[j].cur].key == k) ? 1u : 0u;
+      if (c > best_n) best_n = c, best = k;
+    }
+    if (!best) break;
+    unsigned n = 0;
+    const BatchOp* first = nullptr;
+    for (auto& f : b.flows)
+      if (f.cur < f.ops.size() && f.ops[f.cur].key == best && n < COOK_MULTI_MAX * 8) {
+        group[n++] = &f.ops[f.cur];
+        if (!first) first = &f.ops[f.cur];
+        ++f.cur;
+      }
+    first->launch(b.lead, b.stream, first->name, group, n);
+    ++b.launches;
+    if (n > 1) ++b.grouped;
+  }
+  for (auto& f : b.flows) f.ops.clear(), f.cur = 0;
+}
+
+static void flow_entry() {
+  PoolFlow* f = tl_flow;
+  cook_engine* e = f->e;
+  try {
+    f->body();
+    e->err.clear();
+    f->rc = COOK_OK;
+  } catch (const cook_error& ce) {
+    e->err = ce.msg;
+    f->rc = ce.code;
+  } catch (const std::exception& ex) {
+    e->err = ex.what();
+    f->rc = COOK_E_NOMEM;
+  } catch (...) {
+    e->err = "unknown exception";
+    f->rc = COOK_E_STATE;
+  }
+  f->state = 2;
+  tl_flow = nullptr;
+  swapcontext(&f->ctx, &tl_batch->main_ctx);  // (never resumed)
+}
+constexpr size_t FLOW_STACK_BYTES = 2u << 20;
+static thread_local std::vector<char*> tl_flow_stacks;  // kept for the thread's next batch
+// runs the flows to completion; returns the first flow's error code that is not COOK_OK (every engine keeps its own message)
+static int batch_run(PoolBatch& b) {
+  const unsigned P = (unsigned)b.flows.size();
+  while (tl_flow_stacks.size() < P) {
+    char* st = (char*)std::malloc(FLOW_STACK_BYTES);
+    if (!st) throw cook_error(COOK_E_NOMEM, "pool batch: no memory for a flow's stack");
+    tl_flow_stacks.push_back(st);
+  }
+  for (unsigned i = 0; i < P; ++i) {
+    PoolFlow& f = b.flows[i];
+    f.stack = tl_flow_stacks[i];
+    f.state = 0;
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = FLOW_STACK_BYTES;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, flow_entry, 0);
+  }
+  struct Reset {
+    ~Reset() { tl_batch = nullptr, tl_flow = nullptr; }
+  } reset;
+  tl_batch = &b;
+  for (;;) {
+    for (auto& f : b.flows)
+      if (f.state == 0) {
+        tl_flow = &f;
+        swapcontext(&b.main_ctx, &f.ctx);
+        tl_flow = nullptr;
+      }
+    batch_flush(b);
+    bool parked = false;
+    for (auto& f : b.flows) parked = parked || f.state == 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    COOK_HIP(hipStreamSynchronize(b.stream));
+    tl_sync_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ++tl_syncs;
+    ++b.syncs;
+    if (!parked) break;
+    for (auto& f : b.flows)
+      if (f.state == 1) f.state = 0;
+  }
+  for (auto& f : b.flows)
+    if (f.rc != COOK_OK) return f.rc;
+  return COOK_OK;
 }
 
 // entries per host of a k8s "gpus" / "disk" map column pair (cookmatch.h cook_offers.gpu_slots): 0 means 1
@@ -346,11 +604,11 @@ unsigned res_slots(cook_engine* e, uint32_t slots, const char* what) {
 
 // read back `words` 64-bit words from d_scratch64 (synchronises the stream)
 void readback64(cook_engine* e, unsigned words) {
-  COOK_HIP(hipMemcpyAsync(e->h_scratch, e->d_scratch64.ptr(), words * 8, hipMemcpyDeviceToHost, e->stream));
+  pinned_copy(e, e->h_scratch, e->d_scratch64.ptr(), words * 8, hipMemcpyDeviceToHost);
   sync(e);
 }
 void readback_counters(cook_engine* e, unsigned* out, unsigned words) {
-  COOK_HIP(hipMemcpyAsync(e->h_scratch, e->d_counters.ptr(), words * 4, hipMemcpyDeviceToHost, e->stream));
+  pinned_copy(e, e->h_scratch, e->d_counters.ptr(), words * 4, hipMemcpyDeviceToHost);
   sync(e);
   std::memcpy(out, e->h_scratch, words * 4);
 }
@@ -363,17 +621,12 @@ void seg_scan(cook_engine* e, const char* tag, Load load, const uint8_t* head, u
   tmp.agg.ensure(nb);
   tmp.carry.ensure(nb);
   tmp.first_head.ensure(nb);
-  auto k_local = seg_scan_local<T, Load>;
-  auto k_sums = seg_scan_blocksums<T>;
-  auto k_prop = seg_scan_propagate<T>;
-  KL(tag, k_local, nb, SS_THREADS, load, head, n, out, tmp.agg.ptr(), tmp.first_head.ptr());
+  KM<seg_scan_local<T, Load>, SS_THREADS>(e, tag, nb, load, head, n, out, tmp.agg.ptr(), tmp.first_head.ptr());
   if (nb > 1 && nb <= (unsigned)SS_THREADS) {
-    auto k_fused = seg_scan_propagate_fused<T>;
-    KL("seg_scan_propagate", k_fused, nb, SS_THREADS, out, n, (const SegAgg<T>*)tmp.agg.ptr(), (const unsigned*)tmp.first_head.ptr());
+    KM<seg_scan_propagate_fused<T>, SS_THREADS>(e, "seg_scan_propagate", nb, out, n, (const SegAgg<T>*)tmp.agg.ptr(), (const unsigned*)tmp.first_head.ptr());
   } else if (nb > 1) {
-    KL("seg_scan_blocksums", k_sums, 1, SS_THREADS, (const SegAgg<T>*)tmp.agg.ptr(), nb, tmp.carry.ptr());
-    KL("seg_scan_propagate", k_prop, nb, SS_THREADS, out, n, (const SegAgg<T>*)tmp.carry.ptr(),
-       (const unsigned*)tmp.first_head.ptr());
+    KM<seg_scan_blocksums<T>, SS_THREADS>(e, "seg_scan_blocksums", 1, (const SegAgg<T>*)tmp.agg.ptr(), nb, tmp.carry.ptr());
+    KM<seg_scan_propagate<T>, SS_THREADS>(e, "seg_scan_propagate", nb, out, n, (const SegAgg<T>*)tmp.carry.ptr(), (const unsigned*)tmp.first_head.ptr());
   }
 }
 
@@ -382,9 +635,9 @@ template <int IPL>
 static void radix_pass_t(cook_engine* e, const uint64_t* key, const uint32_t* in, uint32_t* out, unsigned n, unsigned shift, bool fused) {
   const unsigned nb = div_up(n, rs_tile(IPL));
   e->hist.ensure((size_t)256 * nb);
-  KL("radix_hist", radix_hist<IPL>, nb, RS_THREADS, key, in, n, shift, nb, fused ? 1u : 0u, e->hist.ptr());
-  if (!fused) KL("radix_scan", excl_scan_u32_single, 1, SCAN1_THREADS, e->hist.ptr(), 256u * nb, (uint32_t*)nullptr);
-  KL("radix_scatter", radix_scatter<IPL>, nb, RS_THREADS, key, in, out, n, shift, nb, fused ? 1u : 0u, (const uint32_t*)e->hist.ptr());
+  KM<radix_hist<IPL>, RS_THREADS>(e, "radix_hist", nb, key, in, n, shift, nb, fused ? 1u : 0u, e->hist.ptr());
+  if (!fused) KM<excl_scan_u32_single, SCAN1_THREADS>(e, "radix_scan", 1, e->hist.ptr(), 256u * nb, (uint32_t*)nullptr);
+  KM<radix_scatter<IPL>, RS_THREADS>(e, "radix_scatter", nb, key, in, out, n, shift, nb, fused ? 1u : 0u, (const uint32_t*)e->hist.ptr());
 }
 void radix_pass(cook_engine* e, const uint64_t* key, const uint32_t* in, uint32_t* out, unsigned n, unsigned shift) {
   if (div_up(n, rs_tile(RS_IPL_SMALL)) <= RS_FUSED_BLOCKS) radix_pass_t<RS_IPL_SMALL>(e, key, in, out, n, shift, true);
@@ -407,11 +660,11 @@ uint32_t* radix_sort_masked(cook_engine* e, const uint64_t* key, unsigned long l
   return last;
 }
 
-__global__ void fill_i32(int32_t* p, unsigned n, int32_t v) {
+COOK_KERNEL void fill_i32(int32_t* p, unsigned n, int32_t v) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
-__global__ void iota_u32(uint32_t* p, unsigned n) {
+COOK_KERNEL void iota_u32(uint32_t* p, unsigned n) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
 }
@@ -471,14 +724,10 @@ void rank_pool_usage(cook_engine* e, cook_usage* out) {
     return;
   }
   e->pool_usage.ensure(1 + POOL_USAGE_BLOCKS);
-  KL("pool_usage_partial", pool_usage_partial, POOL_USAGE_BLOCKS, 256, (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(),
-     e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->N,
-     e->pool_usage.ptr() + 1);
-  KL("pool_usage_reduce", pool_usage_reduce, 1, COOK_WAVE, (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(),
-     e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->N,
-     (const SumU4*)(e->pool_usage.ptr() + 1), (unsigned)POOL_USAGE_BLOCKS, e->pool_usage.ptr());
+  KM<pool_usage_partial, 256>(e, "pool_usage_partial", POOL_USAGE_BLOCKS, (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(), e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->N, e->pool_usage.ptr() + 1, (unsigned)POOL_USAGE_BLOCKS);
+  KM<pool_usage_reduce, COOK_WAVE>(e, "pool_usage_reduce", 1, (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(), e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->N, (const SumU4*)(e->pool_usage.ptr() + 1), (unsigned)POOL_USAGE_BLOCKS, e->pool_usage.ptr());
   SumU4 h;
-  COOK_HIP(hipMemcpyAsync(e->h_scratch, e->pool_usage.ptr(), sizeof(SumU4), hipMemcpyDeviceToHost, e->stream));
+  pinned_copy(e, e->h_scratch, e->pool_usage.ptr(), sizeof(SumU4), hipMemcpyDeviceToHost);
   sync(e);
   std::memcpy(&h, e->h_scratch, sizeof(SumU4));
   *out = cook_usage{h.count, h.cpus, h.mem, h.gpus};
@@ -497,12 +746,11 @@ void rank_user_usage(cook_engine* e, double* out, bool out_is_device) {
     SumU4* rp = e->uu_pre.ensure(N);
     seg_scan<SumU4>(e, "user_running_scan", LoadRunningU4{e->s_use.ptr(), e->s_pending.ptr()}, (const uint8_t*)e->head.ptr(), N, rp,
                     e->tmpU4);
-    KL("user_usage_extract", user_usage_extract, div_up(U, 256), 256, (const SumU4*)rp, (const SumU4*)e->s_use.ptr(),
-       (const uint8_t*)e->s_pending.ptr(), (const uint32_t*)e->seg_start.ptr(), (const uint32_t*)e->seg_end.ptr(), U, dst);
+    KM<user_usage_extract, 256>(e, "user_usage_extract", div_up(U, 256), (const SumU4*)rp, (const SumU4*)e->s_use.ptr(), (const uint8_t*)e->s_pending.ptr(), (const uint32_t*)e->seg_start.ptr(), (const uint32_t*)e->seg_end.ptr(), U, dst);
   } else {
-    COOK_HIP(hipMemsetAsync(dst, 0, (size_t)U * 24, e->stream));
+    memset_async(e, dst, 0, (size_t)U * 24);
   }
-  if (!out_is_device) COOK_HIP(hipMemcpyAsync(out, dst, (size_t)U * 24, hipMemcpyDeviceToHost, e->stream));
+  if (!out_is_device) copy_async(e, out, dst, (size_t)U * 24, hipMemcpyDeviceToHost);
   sync(e);
 }
 
@@ -518,17 +766,15 @@ unsigned queue_filter_quota(cook_engine* e, unsigned stage, unsigned len, const 
   // [32 + 2 * stage]: a prefix rounded, [33 + 2 * stage]: the new length.  Stages 0 / 1 are rank_run's (zeroed by rank_init), stage 2 is
   // the considerable filters' (which may run without a rank before them: cleared here)
   unsigned* any_bad = e->d_counters.ptr() + 32 + 2 * stage;
-  if (stage >= 2) COOK_HIP(hipMemsetAsync(any_bad, 0, 8, e->stream));
+  if (stage >= 2) memset_async(e, any_bad, 0, 8);
   Usage4 q{quota.count, quota.cpus, quota.mem, quota.gpus};
-  KL("queue_quota_flag", queue_quota_flag, div_up(len, 256), 256, (const SumU4*)e->qpre.ptr(), len, q, e->iflag.ptr(), any_bad);
-  KL("queue_quota_fix", queue_quota_fix, 1, 64, (const SumU4*)quse, len, SumU4{base.count, base.cpus, base.mem, base.gpus, 0u}, q,
-     (const unsigned*)any_bad, e->iflag.ptr());
+  KM<queue_quota_flag, 256>(e, "queue_quota_flag", div_up(len, 256), (const SumU4*)e->qpre.ptr(), len, q, e->iflag.ptr(), any_bad);
+  KM<queue_quota_fix, 64>(e, "queue_quota_fix", 1, (const SumU4*)quse, len, SumU4{base.count, base.cpus, base.mem, base.gpus, 0u}, q, (const unsigned*)any_bad, e->iflag.ptr());
   seg_scan<SumI>(e, "queue_compact_scan", LoadI{e->iflag.ptr()}, (const uint8_t*)nullptr, len, e->scanI.ptr(), e->tmpI);
   unsigned* len_out = any_bad + 1;
-  KL("queue_compact", queue_compact, div_up(len, 256), 256, (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(),
-     (const SumI*)e->scanI.ptr(), len, qitem_other, quse_other, len_out);
+  KM<queue_compact, 256>(e, "queue_compact", div_up(len, 256), (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(), (const SumI*)e->scanI.ptr(), len, qitem_other, quse_other, len_out);
   unsigned h[2];
-  COOK_HIP(hipMemcpyAsync(e->h_scratch, len_out, 4, hipMemcpyDeviceToHost, e->stream));
+  pinned_copy(e, e->h_scratch, len_out, 4, hipMemcpyDeviceToHost);
   sync(e);
   std::memcpy(h, e->h_scratch, 4);
   std::swap(qitem, qitem_other);
@@ -560,16 +806,12 @@ void rank_run(cook_engine* e) {
   e->inexact_user.ensure(U);
   TieCtl* tie_ctl0 = e->tie_ctl.ensure(1);
   bool tie_ctl_clean = true;  // until the first refinement has used it
-  KL("rank_init", rank_init, std::max(1u, std::min(div_up(U, 256), 64u)), 256, e->d_scratch64.ptr(), e->d_counters.ptr(), 40u, e->inexact_user.ptr(),
-     e->seg_end.ptr(), U, reinterpret_cast<unsigned*>(tie_ctl0), (unsigned)(sizeof(TieCtl) / 4));
+  KM<rank_init, 256>(e, "rank_init", std::max(1u, std::min(div_up(U, 256), 64u)), e->d_scratch64.ptr(), e->d_counters.ptr(), 40u, e->inexact_user.ptr(), e->seg_end.ptr(), U, reinterpret_cast<unsigned*>(tie_ctl0), (unsigned)(sizeof(TieCtl) / 4), std::max(1u, std::min(div_up(U, 256), 64u)));
   e->w0.ensure(N);
   e->w1.ensure(N);
   e->w2.ensure(N);
-  KL("rank_key_mins", rank_key_mins, std::min(gN, 64u), 256, (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(),
-     (const int64_t*)e->t_job.ptr(), (const uint8_t*)e->t_pending.ptr(), N, mins);
-  KL("rank_build_keys", rank_build_keys, gN, 256, (const uint32_t*)e->t_user.ptr(), (const int32_t*)e->t_prio.ptr(),
-     (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(), (const int64_t*)e->t_job.ptr(),
-     (const uint8_t*)e->t_pending.ptr(), N, (const unsigned long long*)mins, e->w0.ptr(), e->w1.ptr(), e->w2.ptr(), same);
+  KM<rank_key_mins, 256>(e, "rank_key_mins", std::min(gN, 64u), (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(), (const int64_t*)e->t_job.ptr(), (const uint8_t*)e->t_pending.ptr(), N, mins, std::min(gN, 64u));
+  KM<rank_build_keys, 256>(e, "rank_build_keys", gN, (const uint32_t*)e->t_user.ptr(), (const int32_t*)e->t_prio.ptr(), (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(), (const int64_t*)e->t_job.ptr(), (const uint8_t*)e->t_pending.ptr(), N, (const unsigned long long*)mins, e->w0.ptr(), e->w1.ptr(), e->w2.ptr(), same);
   readback64(e, 8);
   const unsigned long long mk0 = ~e->h_scratch[4], mk1 = ~e->h_scratch[5], mk2 = ~e->h_scratch[6];
   e->permA.ensure(N);
@@ -579,7 +821,7 @@ void rank_run(cook_engine* e) {
   cur = radix_sort_masked(e, e->w1.ptr(), mk1, cur, e->permA.ptr(), e->permB2.ptr(), N);
   cur = radix_sort_masked(e, e->w0.ptr(), mk0, cur, e->permA.ptr(), e->permB2.ptr(), N);
   if (!cur) {  // every task has the same key words
-    KL("iota", iota_u32, gN, 256, e->permA.ptr(), N);
+    KM<iota_u32, 256>(e, "iota", gN, e->permA.ptr(), N);
     cur = e->permA.ptr();
   }
   e->permB = const_cast<uint32_t*>(cur);
@@ -594,30 +836,21 @@ void rank_run(cook_engine* e) {
   e->seg_start.ensure(U);
   e->seg_end.ensure(U);
   e->pre.ensure(N);
-  KL("rank_gather", rank_gather, gN, 256, (const uint32_t*)e->permB, N, (const uint32_t*)e->t_user.ptr(),
-     (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(),
-     e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->s_user.ptr(),
-     e->s_use.ptr(), e->s_pending.ptr(), e->head.ptr(), e->seg_start.ptr(), e->seg_end.ptr());
+  KM<rank_gather, 256>(e, "rank_gather", gN, (const uint32_t*)e->permB, N, (const uint32_t*)e->t_user.ptr(), (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(), e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->s_user.ptr(), e->s_use.ptr(), e->s_pending.ptr(), e->head.ptr(), e->seg_start.ptr(), e->seg_end.ptr());
   seg_scan<SumU4>(e, "user_usage_scan", LoadU4{e->s_use.ptr()}, (const uint8_t*)e->head.ptr(), N, e->pre.ptr(), e->tmpU4);
-  KL("rank_mark_inexact", rank_mark_inexact, gN, 256, (const SumU4*)e->pre.ptr(), (const uint32_t*)e->s_user.ptr(), N,
-     e->inexact_user.ptr());
-  KL("rank_fix_inexact", rank_fix_inexact, div_up(U, 256), 256, (const SumU4*)e->s_use.ptr(), e->pre.ptr(),
-     (const uint32_t*)e->seg_start.ptr(), (const uint32_t*)e->seg_end.ptr(), (const uint32_t*)e->inexact_user.ptr(), U);
+  KM<rank_mark_inexact, 256>(e, "rank_mark_inexact", gN, (const SumU4*)e->pre.ptr(), (const uint32_t*)e->s_user.ptr(), N, e->inexact_user.ptr());
+  KM<rank_fix_inexact, 256>(e, "rank_fix_inexact", div_up(U, 256), (const SumU4*)e->s_use.ptr(), e->pre.ptr(), (const uint32_t*)e->seg_start.ptr(), (const uint32_t*)e->seg_end.ptr(), (const uint32_t*)e->inexact_user.ptr(), U);
   // --- limiter + DRU ---------------------------------------------------------------------------------------
   e->iflag.ensure(N);
   e->scanI.ensure(N);
-  KL("rank_over_flag", rank_over_flag, gN, 256, (const SumU4*)e->pre.ptr(), (const uint32_t*)e->s_user.ptr(), N,
-     (const double*)e->u_qcount.ptr(), (const double*)e->u_qcpus.ptr(), (const double*)e->u_qmem.ptr(),
-     (const double*)e->u_qgpus.ptr(), e->iflag.ptr());
+  KM<rank_over_flag, 256>(e, "rank_over_flag", gN, (const SumU4*)e->pre.ptr(), (const uint32_t*)e->s_user.ptr(), N, (const double*)e->u_qcount.ptr(), (const double*)e->u_qcpus.ptr(), (const double*)e->u_qmem.ptr(), (const double*)e->u_qgpus.ptr(), e->iflag.ptr());
   seg_scan<SumI>(e, "over_quota_scan", LoadI{e->iflag.ptr()}, (const uint8_t*)e->head.ptr(), N, e->scanI.ptr(), e->tmpI);
   e->dru.ensure(N);
   e->dkey.ensure(N);
   e->keep.ensure(N);
   unsigned long long* orand = reinterpret_cast<unsigned long long*>(counters + 8);  // [0] OR of the kept keys, [1] OR of their complements
-  KL("rank_score", rank_score, gN, 256, (const SumU4*)e->pre.ptr(), (const SumI*)e->scanI.ptr(), (const uint32_t*)e->s_user.ptr(), N,
-     (int)e->params.max_over_quota_jobs, (int)e->params.dru_mode, (const double*)e->u_divc.ptr(), (const double*)e->u_divm.ptr(),
-     (const double*)e->u_divg.ptr(), e->dru.ptr(), e->dkey.ptr(), e->keep.ptr(), counters, orand);
-  COOK_HIP(hipMemcpyAsync(e->h_scratch, counters, 12 * 4, hipMemcpyDeviceToHost, e->stream));  // the counts and, behind them, the two key words
+  KM<rank_score, 256>(e, "rank_score", gN, (const SumU4*)e->pre.ptr(), (const SumI*)e->scanI.ptr(), (const uint32_t*)e->s_user.ptr(), N, (int)e->params.max_over_quota_jobs, (int)e->params.dru_mode, (const double*)e->u_divc.ptr(), (const double*)e->u_divm.ptr(), (const double*)e->u_divg.ptr(), e->dru.ptr(), e->dkey.ptr(), e->keep.ptr(), counters, orand);
+  pinned_copy(e, e->h_scratch, counters, 12 * 4, hipMemcpyDeviceToHost);  // the counts and, behind them, the two key words
   sync(e);
   vor = e->h_scratch[4], vand = ~e->h_scratch[5];
   unsigned hc[2];
@@ -630,11 +863,11 @@ void rank_run(cook_engine* e) {
   if (n_kept) pc = radix_sort_masked(e, e->dkey.ptr(), vor & ~vand, pc, e->permC1.ptr(), e->permC2.ptr(), N);
   if (n_kept < N) {  // limiter dropped tasks: one extra 1-bit pass moves them behind every kept task
     e->nkkey.ensure(N);
-    KL("rank_notkept_key", rank_notkept_key, gN, 256, (const uint8_t*)e->keep.ptr(), N, e->nkkey.ptr());
+    KM<rank_notkept_key, 256>(e, "rank_notkept_key", gN, (const uint8_t*)e->keep.ptr(), N, e->nkkey.ptr());
     pc = radix_sort_masked(e, e->nkkey.ptr(), 1ull, pc, e->permC1.ptr(), e->permC2.ptr(), N);
   }
   if (!pc) {  // all kept keys equal
-    KL("iota", iota_u32, gN, 256, e->permC1.ptr(), N);
+    KM<iota_u32, 256>(e, "iota", gN, e->permC1.ptr(), N);
     pc = e->permC1.ptr();
   }
   e->permC = pc;
@@ -662,13 +895,12 @@ void rank_run(cook_engine* e) {
       int* ones = e->ones_buf.ensure(nk);
       int* tied = e->tied_buf.ensure(nk);
       e->scanI.ensure(nk);
-      COOK_HIP(hipMemsetAsync(counters + 1, 0, 4, e->stream));
-      KL("tie_heads", tie_heads, gK, 256, (const uint32_t*)perm, key, nk, user_of, e->thead.ptr(), (uint8_t*)nullptr, ones, counters + 1);
+      memset_async(e, counters + 1, 0, 4);
+      KM<tie_heads, 256>(e, "tie_heads", gK, (const uint32_t*)perm, key, nk, user_of, e->thead.ptr(), (uint8_t*)nullptr, ones, counters + 1);
       for (int round = 0;; ++round) {
         seg_scan<SumI>(e, "tie_group_scan", LoadI{ones}, (const uint8_t*)e->thead.ptr(), nk, e->scanI.ptr(), e->tmpI);
-        COOK_HIP(hipMemsetAsync(counters + 2, 0, 4, e->stream));
-        KL("tie_assign", tie_assign, gK, 256, (const uint32_t*)perm, (const uint8_t*)e->thead.ptr(), (const SumI*)e->scanI.ptr(), nk, U,
-           e->rank_of_item.ptr(), e->gstart.ptr(), tied, counters + 2);
+        memset_async(e, counters + 2, 0, 4);
+        KM<tie_assign, 256>(e, "tie_assign", gK, (const uint32_t*)perm, (const uint8_t*)e->thead.ptr(), (const SumI*)e->scanI.ptr(), nk, U, e->rank_of_item.ptr(), e->gstart.ptr(), tied, counters + 2);
         unsigned h3[3];
         readback_counters(e, h3, 3);
         if (h3[1]) return false;
@@ -683,13 +915,10 @@ void rank_run(cook_engine* e) {
         e->tsorted.ensure(n_tied);
         e->tsorted2.ensure(n_tied);
         seg_scan<SumI>(e, "tie_compact_scan", LoadI{tied}, (const uint8_t*)nullptr, nk, e->scanI.ptr(), e->tmpI);
-        KL("tie_build", tie_build, gK, 256, (const uint32_t*)perm, (const int*)tied, (const SumI*)e->scanI.ptr(),
-           (const uint32_t*)e->gstart.ptr(), nk, U, n_items, round, bits, (const uint32_t*)e->rank_of_item.ptr(), user_of, seg_first,
-           e->tpos.ptr(), e->titem.ptr(), e->ckey.ptr());
-        KL("iota", iota_u32, div_up(n_tied, 256), 256, e->tsorted.ptr(), n_tied);
+        KM<tie_build, 256>(e, "tie_build", gK, (const uint32_t*)perm, (const int*)tied, (const SumI*)e->scanI.ptr(), (const uint32_t*)e->gstart.ptr(), nk, U, n_items, round, bits, (const uint32_t*)e->rank_of_item.ptr(), user_of, seg_first, e->tpos.ptr(), e->titem.ptr(), e->ckey.ptr());
+        KM<iota_u32, 256>(e, "iota", div_up(n_tied, 256), e->tsorted.ptr(), n_tied);
         uint32_t* ts = radix_sort_masked(e, e->ckey.ptr(), cmask, e->tsorted.ptr(), e->tsorted.ptr(), e->tsorted2.ptr(), n_tied);
-        KL("tie_writeback", tie_writeback, div_up(n_tied, 256), 256, (const uint32_t*)ts, (const uint32_t*)e->tpos.ptr(),
-           (const uint32_t*)e->titem.ptr(), (const uint64_t*)e->ckey.ptr(), n_tied, perm, e->thead.ptr());
+        KM<tie_writeback, 256>(e, "tie_writeback", div_up(n_tied, 256), (const uint32_t*)ts, (const uint32_t*)e->tpos.ptr(), (const uint32_t*)e->titem.ptr(), (const uint64_t*)e->ckey.ptr(), n_tied, perm, e->thead.ptr());
       }
       return true;
     };
@@ -704,20 +933,17 @@ void rank_run(cook_engine* e) {
       e->dhead.ensure(nk);
       e->rank_of_item.ensure(n_items);
       TieCtl* ctl = tie_ctl0;
-      if (!tie_ctl_clean) COOK_HIP(hipMemsetAsync(ctl, 0, sizeof(TieCtl), e->stream));  // (rank_init cleared it for the first refinement)
+      if (!tie_ctl_clean) memset_async(e, ctl, 0, sizeof(TieCtl));  // (rank_init cleared it for the first refinement)
       tie_ctl_clean = false;
-      KL("tie_heads", tie_heads, gK, 256, (const uint32_t*)perm, key, nk, user_of, e->thead.ptr(), e->dhead.ptr(), (int*)nullptr,
-         &ctl->equal_runs);
+      KM<tie_heads, 256>(e, "tie_heads", gK, (const uint32_t*)perm, key, nk, user_of, e->thead.ptr(), e->dhead.ptr(), (int*)nullptr, &ctl->equal_runs);
       constexpr int LOOK = 4;
       for (int r0 = 0; r0 < 32; r0 += LOOK) {
         for (int round = r0; round < r0 + LOOK; ++round) {
-          KL("tie_rank_assign", tie_rank_assign, gK, 256, (const uint32_t*)perm, (const uint8_t*)e->thead.ptr(), nk, U, round,
-             (const TieCtl*)ctl, e->rank_of_item.ptr());
-          KL("tie_sort_tiles", tie_sort_tiles, div_up(nk, TS_NOMINAL), TS_THREADS, perm, e->thead.ptr(), (const uint8_t*)e->dhead.ptr(), nk,
-             U, n_items, round, (const uint32_t*)e->rank_of_item.ptr(), user_of, seg_first, ctl);
+          KM<tie_rank_assign, 256>(e, "tie_rank_assign", gK, (const uint32_t*)perm, (const uint8_t*)e->thead.ptr(), nk, U, round, (const TieCtl*)ctl, e->rank_of_item.ptr());
+          KM<tie_sort_tiles, TS_THREADS>(e, "tie_sort_tiles", div_up(nk, TS_NOMINAL), perm, e->thead.ptr(), (const uint8_t*)e->dhead.ptr(), nk, U, n_items, round, (const uint32_t*)e->rank_of_item.ptr(), user_of, seg_first, ctl);
         }
         TieCtl h;
-        COOK_HIP(hipMemcpyAsync(e->h_scratch, ctl, sizeof(TieCtl), hipMemcpyDeviceToHost, e->stream));
+        pinned_copy(e, e->h_scratch, ctl, sizeof(TieCtl), hipMemcpyDeviceToHost);
         sync(e);
         std::memcpy(&h, e->h_scratch, sizeof(TieCtl));
         if (std::getenv("COOK_TIE_TRACE"))
@@ -735,10 +961,9 @@ void rank_run(cook_engine* e) {
       int* isf = e->run_isf.ensure(N);
       int* nonf = e->run_nonf.ensure(N);
       SumI* nonf_incl = e->run_scan.ensure(N);
-      KL("run_follower_flag", run_follower_flag, gN, 256, (const uint32_t*)e->s_user.ptr(), (const uint64_t*)e->dkey.ptr(),
-         (const uint8_t*)e->keep.ptr(), N, isf, nonf);
+      KM<run_follower_flag, 256>(e, "run_follower_flag", gN, (const uint32_t*)e->s_user.ptr(), (const uint64_t*)e->dkey.ptr(), (const uint8_t*)e->keep.ptr(), N, isf, nonf);
       seg_scan<SumI>(e, "run_scan", LoadI{nonf}, (const uint8_t*)nullptr, N, nonf_incl, e->tmpI);
-      COOK_HIP(hipMemcpyAsync(e->h_scratch, &nonf_incl[N - 1], 4, hipMemcpyDeviceToHost, e->stream));
+      pinned_copy(e, e->h_scratch, &nonf_incl[N - 1], 4, hipMemcpyDeviceToHost);
       sync(e);
       int n2i = 0;
       std::memcpy(&n2i, e->h_scratch, 4);
@@ -748,31 +973,27 @@ void rank_run(cook_engine* e) {
       uint32_t* c_orig = e->run_orig.ensure(N2 + 1);
       uint32_t* c_seg = e->run_seg.ensure(U);
       uint32_t* b_to_c = e->run_b2c.ensure(N);
-      KL("run_compact_items", run_compact_items, gN, 256, (const int*)nonf, (const SumI*)nonf_incl, N, (const uint32_t*)e->s_user.ptr(),
-         (const uint64_t*)e->dkey.ptr(), (const uint8_t*)e->head.ptr(), c_user, c_dkey, c_orig, c_seg, b_to_c);
-      KL("run_compact_sentinel", run_compact_sentinel, 1, 1, (const SumI*)nonf_incl, N, c_orig);
+      KM<run_compact_items, 256>(e, "run_compact_items", gN, (const int*)nonf, (const SumI*)nonf_incl, N, (const uint32_t*)e->s_user.ptr(), (const uint64_t*)e->dkey.ptr(), (const uint8_t*)e->head.ptr(), c_user, c_dkey, c_orig, c_seg, b_to_c);
+      KM<run_compact_sentinel, 1>(e, "run_compact_sentinel", 1, (const SumI*)nonf_incl, N, c_orig);
       int* posf = e->run_posf.ensure(n_kept);
       SumI* posf_incl = e->run_scan2.ensure(n_kept);
-      KL("run_flag_positions", run_flag_positions, gK, 256, (const uint32_t*)e->permC, (const int*)isf, n_kept, posf);
+      KM<run_flag_positions, 256>(e, "run_flag_positions", gK, (const uint32_t*)e->permC, (const int*)isf, n_kept, posf);
       seg_scan<SumI>(e, "run_scan", LoadI{posf}, (const uint8_t*)nullptr, n_kept, posf_incl, e->tmpI);
       uint32_t* perm2 = e->run_perm.ensure(n_kept2);
-      KL("run_compact_positions", run_compact_positions, gK, 256, (const uint32_t*)e->permC, (const int*)posf, (const SumI*)posf_incl,
-         n_kept, (const uint32_t*)b_to_c, perm2);
+      KM<run_compact_positions, 256>(e, "run_compact_positions", gK, (const uint32_t*)e->permC, (const int*)posf, (const SumI*)posf_incl, n_kept, (const uint32_t*)b_to_c, perm2);
       if (!tie_refine(perm2, c_dkey, c_user, c_seg, n_kept2, N2)) e->fail(COOK_E_STATE, "cook_rank: equal-DRU runs survived the collapse");
       const unsigned gK2 = div_up(n_kept2, 256);
-      KL("run_count_followers", run_count_followers, gK2, 256, (const uint32_t*)perm2, (const uint32_t*)c_orig, n_kept2, posf);
+      KM<run_count_followers, 256>(e, "run_count_followers", gK2, (const uint32_t*)perm2, (const uint32_t*)c_orig, n_kept2, posf);
       seg_scan<SumI>(e, "run_scan", LoadI{posf}, (const uint8_t*)nullptr, n_kept2, posf_incl, e->tmpI);
-      KL("run_expand", run_expand, gK2, 256, (const uint32_t*)perm2, (const uint32_t*)c_orig, (const int*)posf, (const SumI*)posf_incl,
-         n_kept2, e->permC);
+      KM<run_expand, 256>(e, "run_expand", gK2, (const uint32_t*)perm2, (const uint32_t*)c_orig, (const int*)posf, (const SumI*)posf_incl, n_kept2, e->permC);
     }
     // --- queue of pending jobs in rank order ---------------------------------------------------------------
     int* flag = e->iflag.ptr();
-    KL("queue_flag_pending", queue_flag_pending, gK, 256, (const uint32_t*)e->permC, (const uint8_t*)e->s_pending.ptr(), n_kept, flag);
+    KM<queue_flag_pending, 256>(e, "queue_flag_pending", gK, (const uint32_t*)e->permC, (const uint8_t*)e->s_pending.ptr(), n_kept, flag);
     seg_scan<SumI>(e, "queue_pending_scan", LoadI{flag}, (const uint8_t*)nullptr, n_kept, e->scanI.ptr(), e->tmpI);
     unsigned* dq = e->d_counters.ptr() + 38;  // (zeroed by rank_init)
-    KL("queue_compact_pending", queue_compact_pending, gK, 256, (const uint32_t*)e->permC, (const int*)flag, (const SumI*)e->scanI.ptr(),
-       n_kept, (const SumU4*)e->s_use.ptr(), qitem, quse, dq);
-    COOK_HIP(hipMemcpyAsync(e->h_scratch, dq, 4, hipMemcpyDeviceToHost, e->stream));
+    KM<queue_compact_pending, 256>(e, "queue_compact_pending", gK, (const uint32_t*)e->permC, (const int*)flag, (const SumI*)e->scanI.ptr(), n_kept, (const SumU4*)e->s_use.ptr(), qitem, quse, dq);
+    pinned_copy(e, e->h_scratch, dq, 4, hipMemcpyDeviceToHost);
     sync(e);
     std::memcpy(&qlen, e->h_scratch, 4);
   }
@@ -789,20 +1010,18 @@ void rank_run(cook_engine* e) {
   if (qlen && offensive_on) {
     e->iflag.ensure(qlen);
     e->scanI.ensure(qlen);
-    KL("queue_offensive_flag", queue_offensive_flag, div_up(qlen, 256), 256, (const SumU4*)quse, qlen, e->params.offensive_max_mem_mb,
-       e->params.offensive_max_cpus, e->iflag.ptr());
+    KM<queue_offensive_flag, 256>(e, "queue_offensive_flag", div_up(qlen, 256), (const SumU4*)quse, qlen, e->params.offensive_max_mem_mb, e->params.offensive_max_cpus, e->iflag.ptr());
     seg_scan<SumI>(e, "queue_compact_scan", LoadI{e->iflag.ptr()}, (const uint8_t*)nullptr, qlen, e->scanI.ptr(), e->tmpI);
     unsigned* len_out = e->d_counters.ptr() + 9;
-    KL("queue_compact", queue_compact, div_up(qlen, 256), 256, (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(),
-       (const SumI*)e->scanI.ptr(), qlen, qitem_o, quse_o, len_out);
-    COOK_HIP(hipMemcpyAsync(e->h_scratch, len_out, 4, hipMemcpyDeviceToHost, e->stream));
+    KM<queue_compact, 256>(e, "queue_compact", div_up(qlen, 256), (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(), (const SumI*)e->scanI.ptr(), qlen, qitem_o, quse_o, len_out);
+    pinned_copy(e, e->h_scratch, len_out, 4, hipMemcpyDeviceToHost);
     sync(e);
     std::memcpy(&qlen, e->h_scratch, 4);
     std::swap(qitem, qitem_o);
     std::swap(quse, quse_o);
   }
   if (qlen)
-    KL("queue_emit", queue_emit, div_up(qlen, 256), 256, (const uint32_t*)qitem, qlen, (const uint32_t*)e->permB, e->ranked.ptr());
+    KM<queue_emit, 256>(e, "queue_emit", div_up(qlen, 256), (const uint32_t*)qitem, qlen, (const uint32_t*)e->permB, e->ranked.ptr());
   e->n_ranked = qlen;
   e->rank_done = true;
   if (g_sync_trace) {
@@ -816,12 +1035,11 @@ void rank_fetch(cook_engine* e, uint32_t* ranked, uint32_t* n_out, double* dru_o
   if (!e->rank_done) e->fail(COOK_E_STATE, "cook_rank_fetch before cook_rank_run");
   if (n_out) *n_out = e->n_ranked;
   if (ranked && e->n_ranked)
-    COOK_HIP(hipMemcpyAsync(ranked, e->ranked.ptr(), (size_t)e->n_ranked * 4, hipMemcpyDeviceToHost, e->stream));
+    copy_async(e, ranked, e->ranked.ptr(), (size_t)e->n_ranked * 4, hipMemcpyDeviceToHost);
   if (dru_of_task && e->N) {
     e->dru_out.ensure(e->N);
-    KL("dru_to_task_space", dru_to_task_space, div_up(e->N, 256), 256, (const double*)e->dru.ptr(), (const uint8_t*)e->keep.ptr(),
-       (const uint32_t*)e->permB, e->N, e->dru_out.ptr());
-    COOK_HIP(hipMemcpyAsync(dru_of_task, e->dru_out.ptr(), (size_t)e->N * 8, hipMemcpyDeviceToHost, e->stream));
+    KM<dru_to_task_space, 256>(e, "dru_to_task_space", div_up(e->N, 256), (const double*)e->dru.ptr(), (const uint8_t*)e->keep.ptr(), (const uint32_t*)e->permB, e->N, e->dru_out.ptr());
+    copy_async(e, dru_of_task, e->dru_out.ptr(), (size_t)e->N * 8, hipMemcpyDeviceToHost);
   }
   sync(e);
 }
@@ -976,8 +1194,8 @@ static std::atomic<int> g_engines_on_device[64];
 
 // the state a match call starts from, in ONE launch (nine memsets before round 5: each is a launch, and the set-up of a pool's match sits
 // in the chain of small launches a cycle begins with): nothing assigned, no job placed, jmin = {max, max, 0, 0}
-__global__ void __launch_bounds__(256) match_init_state_kernel(MatchState st, unsigned long long* __restrict__ jmin, unsigned K, unsigned M, unsigned G) {
-  const unsigned stride = gridDim.x * blockDim.x;
+COOK_KERNEL void match_init_state_kernel(MatchState st, unsigned long long* __restrict__ jmin, unsigned K, unsigned M, unsigned G, unsigned nblk) {
+  const unsigned stride = nblk * blockDim.x;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) {
     st.ac[i] = 0.0, st.am[i] = 0.0, st.acount[i] = 0;
     if (st.xports) {
@@ -995,7 +1213,7 @@ __global__ void __launch_bounds__(256) match_init_state_kernel(MatchState st, un
 }
 void match_init_state(cook_engine* e, const MatchState& st, unsigned K, unsigned M, unsigned G) {
   const unsigned n = std::max(std::max(K, M), std::max(G, 1u));
-  KL("match_init_state", match_init_state_kernel, std::min(div_up(n, 256), 512u), 256, st, e->m_jmin.ptr(), K, M, G);
+  KM<match_init_state_kernel, 256>(e, "match_init_state", std::min(div_up(n, 256), 512u), st, e->m_jmin.ptr(), K, M, G, std::min(div_up(n, 256), 512u));
 }
 
 void match_finish_rounds(cook_engine* e, const MatchState& st, const V2Buf& vb, const WinCtl& hc, hipStream_t stream);
@@ -1099,13 +1317,13 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
       MatchIn* din = e->v_in.ensure(1);
       MatchIn* hin = (MatchIn*)e->h_inbuf;
       *hin = in;
-      COOK_HIP(hipMemcpyAsync(din, hin, sizeof(MatchIn), hipMemcpyHostToDevice, e->stream));
+      pinned_copy(e, din, hin, sizeof(MatchIn), hipMemcpyHostToDevice);
       vb.in_dev = din;
     }
-    if (M) KL("match_pack_offers", match_pack_offers, div_up(M, 256), 256, in, oa, ob, vb.ow);
-    KL("match_pack_jobs", match_pack_jobs, div_up(K, 256), 256, in, jr, jcons);
-    KL("match_job_minima", match_job_minima, std::min(div_up(K, 256), 256u), 256, (const JobRec*)jr, K, e->m_jmin.ptr());
-    if (M) KL("match_init_alive", match_init_alive, div_up(M, 256), 256, (const OfferA*)oa, M, st.jmin, st.alive);
+    if (M) KM<match_pack_offers, 256>(e, "match_pack_offers", div_up(M, 256), (const MatchIn*)vb.in_dev, oa, ob, vb.ow);
+    KM<match_pack_jobs, 256>(e, "match_pack_jobs", div_up(K, 256), (const MatchIn*)vb.in_dev, jr, jcons);
+    KM<match_job_minima, 256>(e, "match_job_minima", std::min(div_up(K, 256), 256u), (const JobRec*)jr, K, e->m_jmin.ptr(), std::min(div_up(K, 256), 256u));
+    if (M) KM<match_init_alive, 256>(e, "match_init_alive", div_up(M, 256), (const OfferA*)oa, M, st.jmin, st.alive);
     WinCtl c0;
     std::memset(&c0, 0, sizeof(c0));
     // the first window: a call of few jobs (config.clj:113 ships fenzo-max-jobs-considered 1000) in one go — a round that stops early costs it
@@ -1123,7 +1341,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     if (const char* ev = std::getenv("COOK_WLONG")) c0.wlong_cap = std::atoi(ev) ? (unsigned)MV_WLONG : (unsigned)MV_WEVAL;
     WinCtl hc = c0;
     std::memcpy(e->h_scratch, &c0, sizeof(c0));
-    COOK_HIP(hipMemcpyAsync(vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice, e->stream));
+    pinned_copy(e, vb.ctl, e->h_scratch, sizeof(WinCtl), hipMemcpyHostToDevice);
     if (defer) {  // set up only: cook_cycle_match_multi runs the rounds of several pools together
       sync(e);
       e->deferred.in = in;
@@ -1151,7 +1369,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
 #ifdef COOK_EVAL_TRACE
         if (trace_round >= 0 && (int)hc.rounds == trace_round) {
           vb.eval_trace = d_trace.ensure(trace_words);
-          COOK_HIP(hipMemsetAsync(vb.eval_trace, 0, trace_words * 8, e->stream));
+          memset_async(e, vb.eval_trace, 0, trace_words * 8);
         } else {
           vb.eval_trace = nullptr;
         }
@@ -1187,7 +1405,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
         }
 #endif
       }
-      COOK_HIP(hipMemcpyAsync(e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost, e->stream));
+      copy_async(e, e->h_scratch, vb.ctl, sizeof(WinCtl), hipMemcpyDeviceToHost);
       sync(e);
       const unsigned prev_head = hc.head, prev_rounds = hc.rounds;
       std::memcpy(&hc, e->h_scratch, sizeof(WinCtl));
@@ -1205,7 +1423,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
   } else {
     unsigned sum[4] = {0u, 1u, 0u, 0u};
     std::memcpy(e->h_scratch, sum, 16);
-    COOK_HIP(hipMemcpyAsync(st.summary, e->h_scratch, 16, hipMemcpyHostToDevice, e->stream));
+    copy_async(e, st.summary, e->h_scratch, 16, hipMemcpyHostToDevice);
     sync(e);
   }
   e->cycle_considered = K;
@@ -1566,16 +1784,16 @@ bool match_rounds_served(cook_engine** es, unsigned n) {
 
 void match_fetch(cook_engine* e, unsigned K, int32_t* job_to_offer, uint32_t* fail_code, uint8_t* head_matched) {
   if (!e->match_done) e->fail(COOK_E_STATE, "cook_match_fetch before cook_match_run");
-  if (job_to_offer && K) COOK_HIP(hipMemcpyAsync(job_to_offer, e->m_j2o.ptr(), (size_t)K * 4, hipMemcpyDeviceToHost, e->stream));
-  if (fail_code && K) COOK_HIP(hipMemcpyAsync(fail_code, e->m_fail.ptr(), (size_t)K * 4, hipMemcpyDeviceToHost, e->stream));
-  COOK_HIP(hipMemcpyAsync(e->h_scratch, e->m_summary.ptr(), 16, hipMemcpyDeviceToHost, e->stream));
+  if (job_to_offer && K) copy_async(e, job_to_offer, e->m_j2o.ptr(), (size_t)K * 4, hipMemcpyDeviceToHost);
+  if (fail_code && K) copy_async(e, fail_code, e->m_fail.ptr(), (size_t)K * 4, hipMemcpyDeviceToHost);
+  copy_async(e, e->h_scratch, e->m_summary.ptr(), 16, hipMemcpyDeviceToHost);
   sync(e);
   unsigned s[4];
   std::memcpy(s, e->h_scratch, 16);
   if (head_matched) *head_matched = (uint8_t)s[1];
 }
 
-__global__ void cycle_job_index(const uint32_t* __restrict__ ranked, const uint32_t* __restrict__ pend_ord, unsigned k, uint32_t* __restrict__ j_index) {
+COOK_KERNEL void cycle_job_index(const uint32_t* __restrict__ ranked, const uint32_t* __restrict__ pend_ord, unsigned k, uint32_t* __restrict__ j_index) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < k) j_index[i] = pend_ord[ranked[i]];
 }
@@ -1806,8 +2024,8 @@ cook_offers built_offers_view(cook_engine* e, int with_task_limits) {
   b.o_k8s.ensure(std::max(1u, M));
   b.o_max_tasks.ensure(std::max(1u, M));
   if (M) {
-    COOK_HIP(hipMemsetAsync(b.o_k8s.ptr(), 1, M, e->stream));
-    KL("fill_i32", fill_i32, div_up(M, 256), 256, b.o_max_tasks.ptr(), M, (int32_t)b.params.max_pods_per_node);
+    memset_async(e, b.o_k8s.ptr(), 1, M);
+    KM<fill_i32, 256>(e, "fill_i32", div_up(M, 256), b.o_max_tasks.ptr(), M, (int32_t)b.params.max_pods_per_node);
   }
   cook_offers o;
   std::memset(&o, 0, sizeof(o));
@@ -1897,9 +2115,13 @@ int cook_cycle_stage(cook_engine* e, const cook_tasks* tasks, const cook_users* 
 // rank -> (considerable filters) -> take K -> the job index array of the match; returns K
 static unsigned cycle_rank_part(cook_engine* e, uint32_t num_considerable) {
   if (!e->cycle_staged) e->fail(COOK_E_STATE, "cook_cycle_run before cook_cycle_stage");
-  StageTimer tr(e, 0, &e->rank_ms);
-  rank_run(e);
-  tr.stop();
+  if (recording()) {  // (a pool batch times its joint sequence of launches itself)
+    rank_run(e);
+  } else {
+    StageTimer tr(e, 0, &e->rank_ms);
+    rank_run(e);
+    tr.stop();
+  }
   unsigned K = std::min<unsigned>(num_considerable, e->n_ranked);  // (take num-considerable), scheduler.clj:751
   if (e->cb && e->cb->cycle_on) {  // pending-jobs->considerable-jobs between rank and match (scheduler.clj:729-762)
     ConsBufs& c = *e->cb;
@@ -1907,21 +2129,16 @@ static unsigned cycle_rank_part(cook_engine* e, uint32_t num_considerable) {
     const unsigned n = e->n_ranked;
     c.q_cpus.ensure(n), c.q_mem.ensure(n), c.q_gpus.ensure(n), c.q_user.ensure(n), c.q_elig.ensure(n);
     if (n)
-      KL("cons_gather_queue", cons_gather_queue, div_up(n, 256), 256, (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(),
-         n, e->min.j_cpus, e->min.j_mem, e->min.j_gpus, (const uint32_t*)e->j_user.ptr(),
-         c.has_elig_by_pending ? (const uint8_t*)c.elig_by_pending.ptr() : (const uint8_t*)nullptr, c.q_cpus.ptr(), c.q_mem.ptr(),
-         c.q_gpus.ptr(), c.q_user.ptr(), c.q_elig.ptr());
+      KM<cons_gather_queue, 256>(e, "cons_gather_queue", div_up(n, 256), (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(), n, e->min.j_cpus, e->min.j_mem, e->min.j_gpus, (const uint32_t*)e->j_user.ptr(), c.has_elig_by_pending ? (const uint8_t*)c.elig_by_pending.ptr() : (const uint8_t*)nullptr, c.q_cpus.ptr(), c.q_mem.ptr(), c.q_gpus.ptr(), c.q_user.ptr(), c.q_elig.ptr());
     cons_run_device(e, c, n, c.q_cpus.ptr(), c.q_mem.ptr(), c.q_gpus.ptr(), c.q_user.ptr(), c.q_elig.ptr(), num_considerable);
     K = c.n_result;
     e->j_index.ensure(K);
     if (K)
-      KL("cons_job_index", cons_job_index, div_up(K, 256), 256, (const uint32_t*)c.result, (const uint32_t*)e->ranked.ptr(),
-         (const uint32_t*)e->pend_ord.ptr(), K, e->j_index.ptr());
+      KM<cons_job_index, 256>(e, "cons_job_index", div_up(K, 256), (const uint32_t*)c.result, (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(), K, e->j_index.ptr());
   } else {
     e->j_index.ensure(K);
     if (K)
-      KL("cycle_job_index", cycle_job_index, div_up(K, 256), 256, (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(), K,
-         e->j_index.ptr());
+      KM<cycle_job_index, 256>(e, "cycle_job_index", div_up(K, 256), (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(), K, e->j_index.ptr());
   }
   return K;
 }
@@ -1966,6 +2183,54 @@ int cook_cycle_run_rank(cook_engine* e, uint32_t num_considerable) {
     prof_collect(e);
   });
 }
+// the rank part of a cycle for every pool of a GPU: one flow per pool in a pool batch (above)
+static const bool g_rank_batch = [] {
+  const char* s = std::getenv("COOK_RANK_BATCH");
+  return !(s && std::atoi(s) == 0);
+}();
+int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, uint32_t num_considerable, double* const* user_usage, int usage_is_device) {
+  if (!engines || n == 0) return COOK_E_INVALID;
+  for (uint32_t i = 0; i < n; ++i)
+    if (!engines[i] || (user_usage && !user_usage[i])) return COOK_E_INVALID;
+  cook_engine* lead = engines[0];
+  bool same_device = true;
+  for (uint32_t i = 1; i < n; ++i) same_device = same_device && engines[i]->device == lead->device;
+  if (n == 1 || !g_rank_batch || !same_device || g_sync_trace || tl_flow) {
+    int first = COOK_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+      int rc = cook_cycle_run_rank(engines[i], num_considerable);
+      if (rc == COOK_OK && user_usage) rc = cook_rank_user_usage(engines[i], user_usage[i], usage_is_device);
+      if (rc != COOK_OK && first == COOK_OK) first = rc;
+    }
+    return first;
+  }
+  int flows_rc = COOK_OK;
+  const int rc = guarded(lead, [&] {
+    for (uint32_t i = 0; i < n; ++i) COOK_HIP(hipStreamSynchronize(engines[i]->stream));  // (whatever a call before this one left running)
+    PoolBatch b;
+    b.lead = lead;
+    b.stream = lead->stream;
+    b.flows.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      cook_engine* e = engines[i];
+      double* uu = user_usage ? user_usage[i] : nullptr;
+      b.flows[i].e = e;
+      b.flows[i].body = [e, num_considerable, uu, usage_is_device] {
+        const unsigned K = cycle_rank_part(e, num_considerable);
+        if (uu) rank_user_usage(e, uu, usage_is_device != 0);
+        match_run_device(e, K, K ? e->j_index.ptr() : nullptr, /*defer=*/true);
+      };
+    }
+    StageTimer tr(lead, 0, &lead->rank_ms);
+    flows_rc = batch_run(b);
+    tr.stop();
+    for (uint32_t i = 1; i < n; ++i) engines[i]->rank_ms = lead->rank_ms;  // one joint sequence of launches
+    lead->batch_stats[0] = n, lead->batch_stats[1] = b.launches, lead->batch_stats[2] = b.grouped, lead->batch_stats[3] = b.singles,
+    lead->batch_stats[4] = b.syncs;
+    prof_collect(lead);
+  });
+  return rc != COOK_OK ? rc : flows_rc;
+}
 int cook_cycle_match_multi(cook_engine** engines, uint32_t n) {
   if (!engines || n == 0 || !engines[0]) return COOK_E_INVALID;
   cook_engine* lead = engines[0];
@@ -2006,9 +2271,9 @@ int cook_considerable(cook_engine* e, const cook_queue* q, const cook_user_state
     if (q->eligible) h2d(e, c.q_elig, q->eligible, n);
     cons_run_device(e, c, n, c.q_cpus.ptr(), c.q_mem.ptr(), q->gpus ? (const double*)c.q_gpus.ptr() : (const double*)nullptr,
                     c.q_user.ptr(), q->eligible ? (const uint8_t*)c.q_elig.ptr() : (const uint8_t*)nullptr, num_considerable);
-    if (c.n_result) COOK_HIP(hipMemcpyAsync(out_idx, c.result, (size_t)c.n_result * 4, hipMemcpyDeviceToHost, e->stream));
-    if (rate_limited && c.U) COOK_HIP(hipMemcpyAsync(rate_limited, c.rate_limited.ptr(), (size_t)c.U * 4, hipMemcpyDeviceToHost, e->stream));
-    if (passed && c.U) COOK_HIP(hipMemcpyAsync(passed, c.passed.ptr(), (size_t)c.U * 4, hipMemcpyDeviceToHost, e->stream));
+    if (c.n_result) copy_async(e, out_idx, c.result, (size_t)c.n_result * 4, hipMemcpyDeviceToHost);
+    if (rate_limited && c.U) copy_async(e, rate_limited, c.rate_limited.ptr(), (size_t)c.U * 4, hipMemcpyDeviceToHost);
+    if (passed && c.U) copy_async(e, passed, c.passed.ptr(), (size_t)c.U * 4, hipMemcpyDeviceToHost);
     sync(e);
     *n_out = c.n_result;
     prof_collect(e);
@@ -2038,7 +2303,7 @@ int cook_cycle_fetch_considerable(cook_engine* e, uint32_t* rank_pos, uint32_t* 
     if (!e->match_done) e->fail(COOK_E_STATE, "cook_cycle_fetch_considerable before cook_cycle_run");
     const unsigned K = e->cycle_considered;
     if (e->cb && e->cb->cycle_on) {
-      if (K && rank_pos) COOK_HIP(hipMemcpyAsync(rank_pos, e->cb->result, (size_t)K * 4, hipMemcpyDeviceToHost, e->stream));
+      if (K && rank_pos) copy_async(e, rank_pos, e->cb->result, (size_t)K * 4, hipMemcpyDeviceToHost);
       sync(e);
     } else if (rank_pos) {
       for (unsigned k = 0; k < K; ++k) rank_pos[k] = k;
@@ -2180,6 +2445,7 @@ int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap) {
   v[26] = e->upd_us, v[27] = e->upd_sync_us, v[28] = e->upd_allocs;
   for (unsigned k = 0; k < 8u; ++k)
     if (e->upd_phase_us[k] > v[30]) v[29] = k, v[30] = e->upd_phase_us[k];
+  for (unsigned k = 0; k < 5u; ++k) v[32 + k] = e->batch_stats[k];
   if (g_guard) {  // COOK_GUARD=1: look at this engine's bands now; the count is process-wide and includes buffers already freed
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);

@@ -46,24 +46,24 @@ void match_explain(cook_engine* e, ExplainBufs& x, const uint32_t* job_pos, unsi
   x.permB.ensure(K);
   x.ostart.ensure(M);
   x.oend.ensure(M);
-  COOK_HIP(hipMemsetAsync(x.ostart.ptr(), 0, (size_t)M * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(x.oend.ptr(), 0, (size_t)M * 4, e->stream));
+  memset_async(e, x.ostart.ptr(), 0, (size_t)M * 4);
+  memset_async(e, x.oend.ptr(), 0, (size_t)M * 4);
   const unsigned gK = div_up(K, 256);
   KL("explain_offer_keys", explain_offer_keys, gK, 256, (const int32_t*)st.job_to_offer, K, M, x.key.ptr());
-  KL("iota", iota_u32, gK, 256, x.permA.ptr(), K);
+  KM<iota_u32, 256>(e, "iota", gK, x.permA.ptr(), K);
   unsigned long long mask = 0;
   for (unsigned long long t = M; t; t >>= 1) mask = (mask << 1) | 1ull;
   const uint32_t* plist = radix_sort_masked(e, x.key.ptr(), mask, x.permA.ptr(), x.permA.ptr(), x.permB.ptr(), K);
   KL("explain_seg_bounds", offers_seg_bounds, gK, 256, plist, (const uint64_t*)x.key.ptr(), K, M, x.ostart.ptr(), x.oend.ptr());
   h2d(e, x.pos, job_pos, n);
   x.counts.ensure((size_t)n * WHY_SLOTS);
-  COOK_HIP(hipMemsetAsync(x.counts.ptr(), 0, (size_t)n * WHY_SLOTS * 4, e->stream));
+  memset_async(e, x.counts.ptr(), 0, (size_t)n * WHY_SLOTS * 4);
   for (unsigned q0 = 0; q0 < n; q0 += 65535u) {  // gridDim.y limit
     const unsigned nq = std::min(65535u, n - q0);
     KL("explain_classify", explain_classify, dim3(div_up(M, 256), nq), 256, in, st, (const uint32_t*)x.pos.ptr() + q0, plist,
        (const uint32_t*)x.ostart.ptr(), (const uint32_t*)x.oend.ptr(), x.counts.ptr() + (size_t)q0 * WHY_SLOTS);
   }
-  COOK_HIP(hipMemcpyAsync(counts, x.counts.ptr(), (size_t)n * WHY_SLOTS * 4, hipMemcpyDeviceToHost, e->stream));
+  copy_async(e, counts, x.counts.ptr(), (size_t)n * WHY_SLOTS * 4, hipMemcpyDeviceToHost);
   sync(e);
 }
 
@@ -79,11 +79,11 @@ void resource_stats(cook_engine* e, ExplainBufs& x, const double* a, const doubl
   for (int col = 0; col < 2; ++col) {
     const uint64_t* key = col ? kb : ka;
     unsigned long long* dmask = e->d_scratch64.ensure(8);
-    COOK_HIP(hipMemsetAsync(dmask, 0, 8, e->stream));
-    KL("radix_varying_bits", radix_varying_bits, std::min(g, 64u), 256, key, n, dmask);
+    memset_async(e, dmask, 0, 8);
+    KM<radix_varying_bits, 256>(e, "radix_varying_bits", std::min(g, 64u), key, n, dmask, std::min(g, 64u));
     readback64(e, 1);
     const unsigned long long mask = e->h_scratch[0];
-    KL("iota", iota_u32, g, 256, x.permA.ptr(), n);
+    KM<iota_u32, 256>(e, "iota", g, x.permA.ptr(), n);
     const uint32_t* perm = radix_sort_masked(e, key, mask, x.permA.ptr(), x.permA.ptr(), x.permB.ptr(), n);
     KL("metrics_pick", metrics_pick, 1, 64, perm, col ? b : a, n, out + 2 + 3 * col, out + 3 + 3 * col, out + 4 + 3 * col, largest + col);
   }
@@ -108,12 +108,12 @@ void match_metrics(cook_engine* e, ExplainBufs& x, cook_cycle_metrics* out, uint
   x.user_match.ensure(std::max(1u, n_users));
   x.jgpus.ensure(n_models + 1u);
   x.ogpus.ensure(n_models + 1u);
-  COOK_HIP(hipMemsetAsync(x.user_cons.ptr(), 0, (size_t)std::max(1u, n_users) * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(x.user_match.ptr(), 0, (size_t)std::max(1u, n_users) * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(x.jgpus.ptr(), 0, (size_t)(n_models + 1u) * 8, e->stream));
-  COOK_HIP(hipMemsetAsync(x.ogpus.ptr(), 0, (size_t)(n_models + 1u) * 8, e->stream));
+  memset_async(e, x.user_cons.ptr(), 0, (size_t)std::max(1u, n_users) * 4);
+  memset_async(e, x.user_match.ptr(), 0, (size_t)std::max(1u, n_users) * 4);
+  memset_async(e, x.jgpus.ptr(), 0, (size_t)(n_models + 1u) * 8);
+  memset_async(e, x.ogpus.ptr(), 0, (size_t)(n_models + 1u) * 8);
   unsigned* d_sched = e->d_counters.ptr() + 14;
-  COOK_HIP(hipMemsetAsync(d_sched, 0, 4, e->stream));
+  memset_async(e, d_sched, 0, 4);
   if (K) {
     x.jc.ensure(K);
     x.jm.ensure(K);
@@ -136,18 +136,18 @@ void match_metrics(cook_engine* e, ExplainBufs& x, cook_cycle_metrics* out, uint
   double h[16];
   uint32_t hl[4];
   unsigned hs[2] = {0, 0};
-  COOK_HIP(hipMemcpyAsync(h, x.out.ptr(), sizeof(h), hipMemcpyDeviceToHost, e->stream));
-  COOK_HIP(hipMemcpyAsync(hl, x.largest.ptr(), sizeof(hl), hipMemcpyDeviceToHost, e->stream));
-  COOK_HIP(hipMemcpyAsync(&hs[0], d_sched, 4, hipMemcpyDeviceToHost, e->stream));
-  COOK_HIP(hipMemcpyAsync(&hs[1], st.summary, 4, hipMemcpyDeviceToHost, e->stream));
+  copy_async(e, h, x.out.ptr(), sizeof(h), hipMemcpyDeviceToHost);
+  copy_async(e, hl, x.largest.ptr(), sizeof(hl), hipMemcpyDeviceToHost);
+  copy_async(e, &hs[0], d_sched, 4, hipMemcpyDeviceToHost);
+  copy_async(e, &hs[1], st.summary, 4, hipMemcpyDeviceToHost);
   int head_offer = -1;  // matched-considerable-jobs-head? = the first considerable job is among the matched (scheduler.clj:1381)
-  if (K) COOK_HIP(hipMemcpyAsync(&head_offer, st.job_to_offer, 4, hipMemcpyDeviceToHost, e->stream));
+  if (K) copy_async(e, &head_offer, st.job_to_offer, 4, hipMemcpyDeviceToHost);
   if (user_considerable && n_users)
-    COOK_HIP(hipMemcpyAsync(user_considerable, x.user_cons.ptr(), (size_t)n_users * 4, hipMemcpyDeviceToHost, e->stream));
-  if (user_matched && n_users) COOK_HIP(hipMemcpyAsync(user_matched, x.user_match.ptr(), (size_t)n_users * 4, hipMemcpyDeviceToHost, e->stream));
-  if (job_gpus_by_model) COOK_HIP(hipMemcpyAsync(job_gpus_by_model, x.jgpus.ptr(), (size_t)(n_models + 1u) * 8, hipMemcpyDeviceToHost, e->stream));
+    copy_async(e, user_considerable, x.user_cons.ptr(), (size_t)n_users * 4, hipMemcpyDeviceToHost);
+  if (user_matched && n_users) copy_async(e, user_matched, x.user_match.ptr(), (size_t)n_users * 4, hipMemcpyDeviceToHost);
+  if (job_gpus_by_model) copy_async(e, job_gpus_by_model, x.jgpus.ptr(), (size_t)(n_models + 1u) * 8, hipMemcpyDeviceToHost);
   if (offer_gpus_by_model)
-    COOK_HIP(hipMemcpyAsync(offer_gpus_by_model, x.ogpus.ptr(), (size_t)(n_models + 1u) * 8, hipMemcpyDeviceToHost, e->stream));
+    copy_async(e, offer_gpus_by_model, x.ogpus.ptr(), (size_t)(n_models + 1u) * 8, hipMemcpyDeviceToHost);
   sync(e);
   auto fill = [&](cook_resource_stats& r, const double* d, const uint32_t* l) {
     r.total_cpus = d[0];

@@ -236,7 +236,8 @@ struct V2Buf {
 };
 
 // ---- once per match call: pack offers and jobs -----------------------------------------------------------------------
-__global__ void __launch_bounds__(256) match_pack_offers(MatchIn in, OfferA* __restrict__ oa, OfferB* __restrict__ ob, OfferW* __restrict__ ow) {
+COOK_KERNEL void match_pack_offers(const MatchIn* __restrict__ inp /* device copy of the call's MatchIn */, OfferA* __restrict__ oa, OfferB* __restrict__ ob, OfferW* __restrict__ ow) {
+  const MatchIn& in = *inp;
   const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= in.M) return;
   OfferA a;
@@ -278,7 +279,8 @@ __global__ void __launch_bounds__(256) match_pack_offers(MatchIn in, OfferA* __r
   ow[v] = w;
 }
 
-__global__ void __launch_bounds__(256) match_pack_jobs(MatchIn in, JobRec* __restrict__ jr, JobCons* __restrict__ jcons) {
+COOK_KERNEL void match_pack_jobs(const MatchIn* __restrict__ inp, JobRec* __restrict__ jr, JobCons* __restrict__ jcons) {
+  const MatchIn& in = *inp;
   const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= in.K) return;
   const unsigned jj = in.j_index ? in.j_index[k] : k;
@@ -335,10 +337,10 @@ __global__ void __launch_bounds__(256) match_pack_jobs(MatchIn in, JobRec* __res
 }
 
 // minimum cpus / mem over the jobs of the call (positive doubles order like their bit patterns; jmin starts at +inf)
-__global__ void __launch_bounds__(256) match_job_minima(const JobRec* __restrict__ jr, unsigned K, unsigned long long* __restrict__ jmin_bits) {
+COOK_KERNEL void match_job_minima(const JobRec* __restrict__ jr, unsigned K, unsigned long long* __restrict__ jmin_bits, unsigned nblk /* blocks of this launch */) {
   double c = __longlong_as_double(0x7FF0000000000000ll), m = c;
   bool odd = false;  // a negative or non-finite request (jmin_bits[2]: match_v3 leaves such calls to the window rounds)
-  for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+  for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += nblk * blockDim.x) {
     const JobRec j = jr[k];
     c = j.c < c ? j.c : c;
     m = j.m < m ? j.m : m;
@@ -359,7 +361,7 @@ __global__ void __launch_bounds__(256) match_job_minima(const JobRec* __restrict
   }
 }
 // alive bits at the start of a call (nothing assigned yet)
-__global__ void __launch_bounds__(256) match_init_alive(const OfferA* __restrict__ oa, unsigned M, const double* __restrict__ jmin,
+COOK_KERNEL void match_init_alive(const OfferA* __restrict__ oa, unsigned M, const double* __restrict__ jmin,
                                                         unsigned long long* __restrict__ alive) {
   const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
   bool a = false;

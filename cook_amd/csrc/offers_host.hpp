@@ -76,11 +76,11 @@ void offers_run(cook_engine* e, OfferBufs& b) {
   b.disk_cap.ensure(D);
   b.disk_cons.ensure(D);
   b.totals.ensure(1);
-  COOK_HIP(hipMemsetAsync(b.gpu_cap.ptr(), 0, (size_t)G * 8, e->stream));
-  COOK_HIP(hipMemsetAsync(b.gpu_cons.ptr(), 0, (size_t)G * 8, e->stream));
-  COOK_HIP(hipMemsetAsync(b.disk_cap.ptr(), 0, (size_t)D * 8, e->stream));
-  COOK_HIP(hipMemsetAsync(b.disk_cons.ptr(), 0, (size_t)D * 8, e->stream));
-  COOK_HIP(hipMemsetAsync(b.totals.ptr(), 0, sizeof(OfferTotalsDev), e->stream));
+  memset_async(e, b.gpu_cap.ptr(), 0, (size_t)G * 8);
+  memset_async(e, b.gpu_cons.ptr(), 0, (size_t)G * 8);
+  memset_async(e, b.disk_cap.ptr(), 0, (size_t)D * 8);
+  memset_async(e, b.disk_cons.ptr(), 0, (size_t)D * 8);
+  memset_async(e, b.totals.ptr(), 0, sizeof(OfferTotalsDev));
   if (Nn == 0) {
     b.done = true;
     return;
@@ -89,8 +89,8 @@ void offers_run(cook_engine* e, OfferBufs& b) {
   // ---- pods stably partitioned by node: within a node the list order of node-name->pods survives ----------------------------
   b.seg_start.ensure(Nn);
   b.seg_end.ensure(Nn);
-  COOK_HIP(hipMemsetAsync(b.seg_start.ptr(), 0, (size_t)Nn * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(b.seg_end.ptr(), 0, (size_t)Nn * 4, e->stream));
+  memset_async(e, b.seg_start.ptr(), 0, (size_t)Nn * 4);
+  memset_async(e, b.seg_end.ptr(), 0, (size_t)Nn * 4);
   PodRec* podrec = b.podrec.ensure(Np);
   if (Np) {
     const uint32_t* perm = nullptr;
@@ -99,7 +99,7 @@ void offers_run(cook_engine* e, OfferBufs& b) {
     b.permA.ensure(Np);
     b.permB.ensure(Np);
     KL("offers_pod_keys", offers_pod_keys, gP, 256, b.pd.node, Np, Nn, b.key.ptr());
-    KL("iota", iota_u32, gP, 256, b.permA.ptr(), Np);
+    KM<iota_u32, 256>(e, "iota", gP, b.permA.ptr(), Np);
     unsigned long long mask = 0;
     for (unsigned long long x = Nn; x; x >>= 1) mask = (mask << 1) | 1ull;  // keys are 0..Nn
     perm = radix_sort_masked(e, b.key.ptr(), mask, b.permA.ptr(), b.permA.ptr(), b.permB.ptr(), Np);
@@ -131,7 +131,7 @@ void offers_run(cook_engine* e, OfferBufs& b) {
                  b.o_gpu_model.ensure((size_t)Nn * GS), b.o_gpu_count.ensure((size_t)Nn * GS),  b.o_disk_type.ensure((size_t)Nn * DS), b.o_disk_space.ensure((size_t)Nn * DS),
                  b.o_num_pods.ensure(Nn),  b.o_attr.ensure((size_t)Nn * std::max(1u, b.n_attr))};
   KL("offers_emit", offers_emit, gN, 256, b.nd, b.d_host, av, (const uint32_t*)b.block_offers.ptr(), b.d_attr, b.n_attr, GS, DS, rows, d_total);
-  COOK_HIP(hipMemcpyAsync(e->h_scratch, d_total, 4, hipMemcpyDeviceToHost, e->stream));
+  copy_async(e, e->h_scratch, d_total, 4, hipMemcpyDeviceToHost);
   sync(e);
   std::memcpy(&b.n_offers, e->h_scratch, 4);
   b.done = true;
@@ -139,7 +139,7 @@ void offers_run(cook_engine* e, OfferBufs& b) {
 
 template <class T>
 void offers_d2h(cook_engine* e, T* dst, const T* src, size_t n) {
-  if (dst && n) COOK_HIP(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, e->stream));
+  if (dst && n) copy_async(e, dst, src, n * sizeof(T), hipMemcpyDeviceToHost);
 }
 
 void offers_fetch(cook_engine* e, OfferBufs& b, cook_node_offers* o, uint32_t* n_offers, uint8_t* node_status, cook_offer_totals* totals,
@@ -165,7 +165,7 @@ void offers_fetch(cook_engine* e, OfferBufs& b, cook_node_offers* o, uint32_t* n
   offers_d2h(e, (unsigned long long*)gpu_cons, (const unsigned long long*)b.gpu_cons.ptr(), G);
   offers_d2h(e, disk_cap, (const double*)b.disk_cap.ptr(), D);
   offers_d2h(e, disk_cons, (const double*)b.disk_cons.ptr(), D);
-  if (totals) COOK_HIP(hipMemcpyAsync(&t, b.totals.ptr(), sizeof(t), hipMemcpyDeviceToHost, e->stream));
+  if (totals) copy_async(e, &t, b.totals.ptr(), sizeof(t), hipMemcpyDeviceToHost);
   sync(e);
   if (n_offers) *n_offers = R;
   if (totals) {

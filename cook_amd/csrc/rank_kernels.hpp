@@ -9,14 +9,14 @@
 
 // ---- what a rank run wants cleared or preset, in ONE launch (each memset is a launch: the stage is bound by their number) -----------
 // scratch64[0..6] = all ones (the key minima and the words' agreeing bits), counters[0..n_counters) = 0, per-user words = 0
-__global__ void __launch_bounds__(256) rank_init(unsigned long long* __restrict__ scratch64, unsigned* __restrict__ counters, unsigned n_counters,
+COOK_KERNEL void rank_init(unsigned long long* __restrict__ scratch64, unsigned* __restrict__ counters, unsigned n_counters,
                                                  uint32_t* __restrict__ inexact_user, uint32_t* __restrict__ seg_end, unsigned n_users,
-                                                 unsigned* __restrict__ tie_ctl, unsigned tie_ctl_words) {
+                                                 unsigned* __restrict__ tie_ctl, unsigned tie_ctl_words, unsigned nblk /* blocks of this launch */) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 7) scratch64[i] = ~0ull;
   if (i < n_counters) counters[i] = 0u;
   if (i < tie_ctl_words) tie_ctl[i] = 0u;
-  for (unsigned u = i; u < n_users; u += gridDim.x * blockDim.x) {
+  for (unsigned u = i; u < n_users; u += nblk * blockDim.x) {
     inexact_user[u] = 0u;
     seg_end[u] = 0u;  // stays 0 for a user without tasks (rank_gather writes the others): cook_rank_user_usage reads it as "absent"
   }
@@ -24,11 +24,11 @@ __global__ void __launch_bounds__(256) rank_init(unsigned long long* __restrict_
 
 // ---- A.2 per-user order keys (tools.clj:614-641) --------------------------------------------------------
 // mins[0] = min start over running, mins[1] = min job id over pending, mins[2] = min task id over running
-__global__ void __launch_bounds__(256) rank_key_mins(const int64_t* __restrict__ start_ms, const int64_t* __restrict__ task_id,
+COOK_KERNEL void rank_key_mins(const int64_t* __restrict__ start_ms, const int64_t* __restrict__ task_id,
                                                      const int64_t* __restrict__ job_id, const uint8_t* __restrict__ pending,
-                                                     unsigned n, unsigned long long* __restrict__ mins /*[3] as i64_key*/) {
+                                                     unsigned n, unsigned long long* __restrict__ mins /*[3] as i64_key*/, unsigned nblk) {
   unsigned long long m0 = ~0ull, m1 = ~0ull, m2 = ~0ull;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nblk * blockDim.x) {
     if (pending[i]) {
       const unsigned long long k = i64_key(job_id[i]);
       m1 = k < m1 ? k : m1;
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) rank_key_mins(const int64_t* __restrict__
 // [user, -priority, start|MAX, task|nil, job] (pending tasks all share start=MAX and task=nil, so they order by job id;
 // running tasks have unique task ids, so the job id never decides).  Subtracting the per-class minimum keeps the number
 // of varying bytes (= radix passes) small.
-__global__ void __launch_bounds__(256) rank_build_keys(const uint32_t* __restrict__ user, const int32_t* __restrict__ priority,
+COOK_KERNEL void rank_build_keys(const uint32_t* __restrict__ user, const int32_t* __restrict__ priority,
                                                        const int64_t* __restrict__ start_ms, const int64_t* __restrict__ task_id,
                                                        const int64_t* __restrict__ job_id, const uint8_t* __restrict__ pending,
                                                        unsigned n, const unsigned long long* __restrict__ mins,
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) rank_build_keys(const uint32_t* __restric
 }
 
 // ---- gather into per-user order, segment heads and bounds ------------------------------------------------
-__global__ void __launch_bounds__(256) rank_gather(const uint32_t* __restrict__ permB, unsigned n, const uint32_t* __restrict__ user,
+COOK_KERNEL void rank_gather(const uint32_t* __restrict__ permB, unsigned n, const uint32_t* __restrict__ user,
                                                    const double* __restrict__ cpus, const double* __restrict__ mem,
                                                    const double* __restrict__ gpus, const uint8_t* __restrict__ pending,
                                                    uint32_t* __restrict__ s_user, SumU4* __restrict__ s_use,
@@ -128,13 +128,13 @@ struct LoadI {
 };
 
 // users whose prefix sums involved an inexact addition
-__global__ void __launch_bounds__(256) rank_mark_inexact(const SumU4* __restrict__ pre, const uint32_t* __restrict__ s_user,
+COOK_KERNEL void rank_mark_inexact(const SumU4* __restrict__ pre, const uint32_t* __restrict__ s_user,
                                                          unsigned n, uint32_t* __restrict__ inexact_user) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && pre[i].bad) inexact_user[s_user[i]] = 1u;
 }
 // ... recomputed left to right exactly as the reference's `reductions` (dru.clj:43-48); one thread per flagged user.
-__global__ void __launch_bounds__(256) rank_fix_inexact(const SumU4* __restrict__ s_use, SumU4* __restrict__ pre,
+COOK_KERNEL void rank_fix_inexact(const SumU4* __restrict__ s_use, SumU4* __restrict__ pre,
                                                         const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ seg_end,
                                                         const uint32_t* __restrict__ inexact_user, unsigned n_users) {
   const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) rank_fix_inexact(const SumU4* __restrict_
 }
 
 // ---- A.3 limiter (scheduler.clj:2057-2071) and A.4 DRU (dru.clj:50-80) ------------------------------------
-__global__ void __launch_bounds__(256) rank_over_flag(const SumU4* __restrict__ pre, const uint32_t* __restrict__ s_user, unsigned n,
+COOK_KERNEL void rank_over_flag(const SumU4* __restrict__ pre, const uint32_t* __restrict__ s_user, unsigned n,
                                                       const double* __restrict__ q_count, const double* __restrict__ q_cpus,
                                                       const double* __restrict__ q_mem, const double* __restrict__ q_gpus,
                                                       int* __restrict__ over) {
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) rank_over_flag(const SumU4* __restrict__ 
 }
 
 // keep while the running count of over-quota prefixes <= max-over-quota-jobs; score the survivors.
-__global__ void __launch_bounds__(256) rank_score(const SumU4* __restrict__ pre, const SumI* __restrict__ over_cnt,
+COOK_KERNEL void rank_score(const SumU4* __restrict__ pre, const SumI* __restrict__ over_cnt,
                                                   const uint32_t* __restrict__ s_user, unsigned n, int limit, int dru_mode,
                                                   const double* __restrict__ div_cpus, const double* __restrict__ div_mem,
                                                   const double* __restrict__ div_gpus, double* __restrict__ dru,
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256) rank_score(const SumU4* __restrict__ pre,
 }
 
 // dropped tasks must sort behind every kept one: one extra 1-bit pass key
-__global__ void __launch_bounds__(256) rank_notkept_key(const uint8_t* __restrict__ keep, unsigned n, uint64_t* __restrict__ k) {
+COOK_KERNEL void rank_notkept_key(const uint8_t* __restrict__ keep, unsigned n, uint64_t* __restrict__ k) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) k[i] = keep[i] ? 0ull : 1ull;
 }
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) rank_notkept_key(const uint8_t* __restric
 // compared lexicographically.  We resolve it by prefix doubling over ranks (as in suffix-array construction):
 //   rank_0 = tie group by d;  key_1 = (rank_0(j), MAXR - rank_0(j-1));  key_{k+1} = (rank_k(j), rank_k(j - 2^k)), k >= 1.
 // Ranks are "U + first C-position of the item's tie group"; virtual items take ranks U-1-u (all below any real rank).
-__global__ void __launch_bounds__(256) tie_heads(const uint32_t* __restrict__ permC, const uint64_t* __restrict__ dkey, unsigned n_kept,
+COOK_KERNEL void tie_heads(const uint32_t* __restrict__ permC, const uint64_t* __restrict__ dkey, unsigned n_kept,
                                                  const uint32_t* __restrict__ s_user, uint8_t* __restrict__ thead,
                                                  uint8_t* __restrict__ dhead /*a second copy that stays, or null*/,
                                                  int* __restrict__ ones /*or null*/, unsigned* __restrict__ equal_runs) {
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) tie_heads(const uint32_t* __restrict__ pe
 }
 
 // idx_in_group (1-based, from the segmented scan of ones) -> group start, rank of the item, tied flag, tied count
-__global__ void __launch_bounds__(256) tie_assign(const uint32_t* __restrict__ permC, const uint8_t* __restrict__ thead,
+COOK_KERNEL void tie_assign(const uint32_t* __restrict__ permC, const uint8_t* __restrict__ thead,
                                                   const SumI* __restrict__ idx_in_group, unsigned n_kept, unsigned n_users,
                                                   uint32_t* __restrict__ rank_of_item /*[B]*/, uint32_t* __restrict__ gstart /*[C]*/,
                                                   int* __restrict__ tied /*[C]*/, unsigned* __restrict__ n_tied) {
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256) tie_assign(const uint32_t* __restrict__ p
 }
 
 // compact the tied C-positions (excl = exclusive prefix of `tied`) and build their composite keys for round k
-__global__ void __launch_bounds__(256) tie_build(const uint32_t* __restrict__ permC, const int* __restrict__ tied,
+COOK_KERNEL void tie_build(const uint32_t* __restrict__ permC, const int* __restrict__ tied,
                                                  const SumI* __restrict__ tied_incl, const uint32_t* __restrict__ gstart,
                                                  unsigned n_kept, unsigned n_users, unsigned n_items, int round, unsigned key_bits,
                                                  const uint32_t* __restrict__ rank_of_item, const uint32_t* __restrict__ s_user,
@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) tie_build(const uint32_t* __restrict__ pe
 }
 
 // after sorting the tied items by composite key: write them back into their (contiguous) group slots and split groups
-__global__ void __launch_bounds__(256) tie_writeback(const uint32_t* __restrict__ sorted_j, const uint32_t* __restrict__ tpos,
+COOK_KERNEL void tie_writeback(const uint32_t* __restrict__ sorted_j, const uint32_t* __restrict__ tpos,
                                                      const uint32_t* __restrict__ titem, const uint64_t* __restrict__ ckey,
                                                      unsigned n_tied, uint32_t* __restrict__ permC, uint8_t* __restrict__ thead) {
   const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256) tie_writeback(const uint32_t* __restrict_
 // in an EARLIER tie group), so such runs are collapsed first: only a run's head takes part in the tie refinement (in an index
 // space without the followers), and the followers are re-inserted right behind their head afterwards.
 // follower flag over B: kept, same user and same key as the item before it
-__global__ void __launch_bounds__(256) run_follower_flag(const uint32_t* __restrict__ s_user, const uint64_t* __restrict__ dkey,
+COOK_KERNEL void run_follower_flag(const uint32_t* __restrict__ s_user, const uint64_t* __restrict__ dkey,
                                                          const uint8_t* __restrict__ keep, unsigned n, int* __restrict__ isf,
                                                          int* __restrict__ nonf) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) run_follower_flag(const uint32_t* __restr
   nonf[i] = f ? 0 : 1;
 }
 // compacted copies of the per-item arrays (index space B' = B without followers)
-__global__ void __launch_bounds__(256) run_compact_items(const int* __restrict__ nonf, const SumI* __restrict__ nonf_incl, unsigned n,
+COOK_KERNEL void run_compact_items(const int* __restrict__ nonf, const SumI* __restrict__ nonf_incl, unsigned n,
                                                          const uint32_t* __restrict__ s_user, const uint64_t* __restrict__ dkey,
                                                          const uint8_t* __restrict__ head, uint32_t* __restrict__ c_user,
                                                          uint64_t* __restrict__ c_dkey, uint32_t* __restrict__ c_orig,
@@ -344,17 +344,17 @@ __global__ void __launch_bounds__(256) run_compact_items(const int* __restrict__
   if (head[i]) c_seg_start[s_user[i]] = ci;  // a user's first item is never a follower
 }
 // sentinel behind the last compact item (its follower count = n - c_orig[last] - 1)
-__global__ void run_compact_sentinel(const SumI* __restrict__ nonf_incl, unsigned n, uint32_t* __restrict__ c_orig) {
+COOK_KERNEL void run_compact_sentinel(const SumI* __restrict__ nonf_incl, unsigned n, uint32_t* __restrict__ c_orig) {
   if (blockIdx.x == 0 && threadIdx.x == 0) c_orig[(unsigned)nonf_incl[n - 1].v] = n;
 }
 // flag over C positions [0, n_kept): the item at this position is a follower
-__global__ void __launch_bounds__(256) run_flag_positions(const uint32_t* __restrict__ permC, const int* __restrict__ isf, unsigned n_kept,
+COOK_KERNEL void run_flag_positions(const uint32_t* __restrict__ permC, const int* __restrict__ isf, unsigned n_kept,
                                                           int* __restrict__ posf) {
   const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n_kept) posf[p] = isf[permC[p]];
 }
 // permC' = permC without the followers, in compact indices
-__global__ void __launch_bounds__(256) run_compact_positions(const uint32_t* __restrict__ permC, const int* __restrict__ posf,
+COOK_KERNEL void run_compact_positions(const uint32_t* __restrict__ permC, const int* __restrict__ posf,
                                                              const SumI* __restrict__ posf_incl, unsigned n_kept,
                                                              const uint32_t* __restrict__ b_to_c, uint32_t* __restrict__ permC2) {
   const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256) run_compact_positions(const uint32_t* __r
   permC2[p - (unsigned)posf_incl[p].v] = b_to_c[permC[p]];
 }
 // followers per position of the refined compact order (input of the expansion scan)
-__global__ void __launch_bounds__(256) run_count_followers(const uint32_t* __restrict__ permC2, const uint32_t* __restrict__ c_orig,
+COOK_KERNEL void run_count_followers(const uint32_t* __restrict__ permC2, const uint32_t* __restrict__ c_orig,
                                                            unsigned n2, int* __restrict__ nfol) {
   const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n2) return;
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256) run_count_followers(const uint32_t* __res
   nfol[p] = (int)(c_orig[ci + 1] - c_orig[ci] - 1u);
 }
 // final order: every run head followed by its followers
-__global__ void __launch_bounds__(256) run_expand(const uint32_t* __restrict__ permC2, const uint32_t* __restrict__ c_orig,
+COOK_KERNEL void run_expand(const uint32_t* __restrict__ permC2, const uint32_t* __restrict__ c_orig,
                                                   const int* __restrict__ nfol, const SumI* __restrict__ nfol_incl, unsigned n2,
                                                   uint32_t* __restrict__ permC) {
   const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -383,14 +383,14 @@ __global__ void __launch_bounds__(256) run_expand(const uint32_t* __restrict__ p
 }
 
 // ---- A.6 queue of pending jobs in rank order and the quota filters ------------------------------------------
-__global__ void __launch_bounds__(256) queue_flag_pending(const uint32_t* __restrict__ permC, const uint8_t* __restrict__ s_pending,
+COOK_KERNEL void queue_flag_pending(const uint32_t* __restrict__ permC, const uint8_t* __restrict__ s_pending,
                                                           unsigned n_kept, int* __restrict__ flag) {
   const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n_kept) flag[p] = s_pending[permC[p]] ? 1 : 0;
 }
 
 // L[q] = B-index of the q-th pending job in rank order; its usage for the quota scans
-__global__ void __launch_bounds__(256) queue_compact_pending(const uint32_t* __restrict__ permC, const int* __restrict__ flag,
+COOK_KERNEL void queue_compact_pending(const uint32_t* __restrict__ permC, const int* __restrict__ flag,
                                                              const SumI* __restrict__ incl, unsigned n_kept,
                                                              const SumU4* __restrict__ s_use, uint32_t* __restrict__ qitem,
                                                              SumU4* __restrict__ quse, unsigned* __restrict__ qlen) {
@@ -415,7 +415,7 @@ struct LoadQueueUse {  // element 0 carries the starting usage: ((base + j0) + j
 };
 
 // tools.clj:917-933: keep iff the updated usage is below-quota?.  Also notes whether any prefix was inexact.
-__global__ void __launch_bounds__(256) queue_quota_flag(const SumU4* __restrict__ pre, unsigned len, Usage4 quota, int* __restrict__ flag,
+COOK_KERNEL void queue_quota_flag(const SumU4* __restrict__ pre, unsigned len, Usage4 quota, int* __restrict__ flag,
                                                         unsigned* __restrict__ any_bad) {
   const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= len) return;
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(256) queue_quota_flag(const SumU4* __restrict_
 }
 
 // exact sequential recomputation of a queue prefix (one thread; only runs when a parallel partial sum was inexact)
-__global__ void queue_quota_fix(const SumU4* __restrict__ quse, unsigned len, SumU4 base, Usage4 quota, const unsigned* __restrict__ any_bad,
+COOK_KERNEL void queue_quota_fix(const SumU4* __restrict__ quse, unsigned len, SumU4 base, Usage4 quota, const unsigned* __restrict__ any_bad,
                                 int* __restrict__ flag) {
   if (blockIdx.x != 0 || threadIdx.x != 0 || !*any_bad) return;
   double c = base.count, cp = base.cpus, m = base.mem, g = base.gpus;
@@ -440,7 +440,7 @@ __global__ void queue_quota_fix(const SumU4* __restrict__ quse, unsigned len, Su
 }
 
 // offensive filter folded into the last stage (scheduler.clj:2198-2229): applied AFTER the quota filters saw the job
-__global__ void __launch_bounds__(256) queue_offensive_flag(const SumU4* __restrict__ quse, unsigned len, double max_mem, double max_cpus,
+COOK_KERNEL void queue_offensive_flag(const SumU4* __restrict__ quse, unsigned len, double max_mem, double max_cpus,
                                                             int* __restrict__ flag) {
   const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= len) return;
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) queue_offensive_flag(const SumU4* __restr
   flag[q] = (x.mem > max_mem || x.cpus > max_cpus) ? 0 : 1;
 }
 
-__global__ void __launch_bounds__(256) queue_compact(const uint32_t* __restrict__ qitem_in, const SumU4* __restrict__ quse_in,
+COOK_KERNEL void queue_compact(const uint32_t* __restrict__ qitem_in, const SumU4* __restrict__ quse_in,
                                                      const int* __restrict__ flag, const SumI* __restrict__ incl, unsigned len,
                                                      uint32_t* __restrict__ qitem_out, SumU4* __restrict__ quse_out,
                                                      unsigned* __restrict__ len_out) {
@@ -463,12 +463,12 @@ __global__ void __launch_bounds__(256) queue_compact(const uint32_t* __restrict_
 }
 
 // final: B-index -> caller's task index; DRU back into A space
-__global__ void __launch_bounds__(256) queue_emit(const uint32_t* __restrict__ qitem, unsigned len, const uint32_t* __restrict__ permB,
+COOK_KERNEL void queue_emit(const uint32_t* __restrict__ qitem, unsigned len, const uint32_t* __restrict__ permB,
                                                   uint32_t* __restrict__ ranked) {
   const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < len) ranked[q] = permB[qitem[q]];
 }
-__global__ void __launch_bounds__(256) dru_to_task_space(const double* __restrict__ dru, const uint8_t* __restrict__ keep,
+COOK_KERNEL void dru_to_task_space(const double* __restrict__ dru, const uint8_t* __restrict__ keep,
                                                          const uint32_t* __restrict__ permB, unsigned n, double* __restrict__ out) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[permB[i]] = keep[i] ? dru[i] : __longlong_as_double(0x7FF8000000000000ll);
@@ -486,7 +486,7 @@ struct LoadRunningU4 {
     return use[i];
   }
 };
-__global__ void __launch_bounds__(256) user_usage_extract(const SumU4* __restrict__ run_pre, const SumU4* __restrict__ s_use,
+COOK_KERNEL void user_usage_extract(const SumU4* __restrict__ run_pre, const SumU4* __restrict__ s_use,
                                                           const uint8_t* __restrict__ s_pending, const uint32_t* __restrict__ seg_start,
                                                           const uint32_t* __restrict__ seg_end, unsigned n_users,
                                                           double* __restrict__ out /*[U][3]*/) {
@@ -520,12 +520,12 @@ __global__ void __launch_bounds__(256) user_usage_extract(const SumU4* __restric
 // stage 1: POOL_USAGE_BLOCKS blocks fold strided slices (a single 1024-thread block took 153 us for 175k tasks: 171 dependent
 // iterations); stage 2 (pool_usage_reduce) combines the partial sums, or redoes the sum left to right when one of them rounded
 constexpr int POOL_USAGE_BLOCKS = 64;
-__global__ void __launch_bounds__(256) pool_usage_partial(const double* __restrict__ cpus, const double* __restrict__ mem,
+COOK_KERNEL void pool_usage_partial(const double* __restrict__ cpus, const double* __restrict__ mem,
                                                           const double* __restrict__ gpus, const uint8_t* __restrict__ pending,
-                                                          unsigned n, SumU4* __restrict__ part) {
+                                                          unsigned n, SumU4* __restrict__ part, unsigned nblk) {
   __shared__ SumU4 ws[256 / COOK_WAVE];
   SumU4 acc = SumU4::zero();
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nblk * blockDim.x)
     if (!pending[i]) acc = combine(acc, SumU4{1.0, cpus[i], mem[i], gpus ? gpus[i] : 0.0, 0u});
   for (int d = 32; d >= 1; d >>= 1) {
     SumU4 o;
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(256) pool_usage_partial(const double* __restri
     part[blockIdx.x] = t;
   }
 }
-__global__ void __launch_bounds__(COOK_WAVE) pool_usage_reduce(const double* __restrict__ cpus, const double* __restrict__ mem,
+COOK_KERNEL void pool_usage_reduce(const double* __restrict__ cpus, const double* __restrict__ mem,
                                                                const double* __restrict__ gpus, const uint8_t* __restrict__ pending,
                                                                unsigned n, const SumU4* __restrict__ part, unsigned n_part,
                                                                SumU4* __restrict__ out) {

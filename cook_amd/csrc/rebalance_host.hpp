@@ -344,8 +344,7 @@ RebalIn rebalance_args(cook_engine* e, RebalBufs& b) {
 void rebalance_rescore(cook_engine* e, RebalBufs& b) {
   const unsigned S = b.S, U = b.U;
   seg_scan<SumU4>(e, "rebal_usage_scan", LoadMaskedU4{b.s_use.ptr(), b.act.ptr()}, (const uint8_t*)b.head.ptr(), S, b.pre.ptr(), e->tmpU4);
-  KL("rank_mark_inexact", rank_mark_inexact, div_up(S, 256), 256, (const SumU4*)b.pre.ptr(), (const uint32_t*)b.s_user.ptr(), S,
-     b.inexact.ptr());
+  KM<rank_mark_inexact, 256>(e, "rank_mark_inexact", div_up(S, 256), (const SumU4*)b.pre.ptr(), (const uint32_t*)b.s_user.ptr(), S, b.inexact.ptr());
   KL("rebal_fix_inexact", rebal_fix_inexact, div_up(U, 256), 256, (const SumU4*)b.s_use.ptr(), (const uint8_t*)b.act.ptr(), b.pre.ptr(),
      (const uint32_t*)b.seg_start.ptr(), (const uint32_t*)b.seg_end.ptr(), b.inexact.ptr(), U);
   KL("rebal_score", rebal_score, div_up(S, 256), 256, (const SumU4*)b.pre.ptr(), (const uint32_t*)b.s_user.ptr(), S, (int)e->params.dru_mode,
@@ -363,7 +362,7 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   if (P == 0 || b.rp.max_preemption <= 0) {
     if (P) {
       std::vector<double> nanv(P, std::numeric_limits<double>::quiet_NaN());
-      COOK_HIP(hipMemcpyAsync(b.pending_dru.ptr(), nanv.data(), (size_t)P * 8, hipMemcpyHostToDevice, e->stream));
+      copy_async(e, b.pending_dru.ptr(), nanv.data(), (size_t)P * 8, hipMemcpyHostToDevice);
       sync(e);
     }
     b.done = true;
@@ -374,15 +373,12 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   // ---- per-user order of all slots (tools.clj:614-641; rebalancer.clj:241-246) ---------------------------------------------
   unsigned long long* mins = e->d_scratch64.ptr();
   unsigned long long* same = e->d_scratch64.ptr() + 4;  // bits on which all keys of a word agree
-  COOK_HIP(hipMemsetAsync(mins, 0xFF, 7 * 8, e->stream));
+  memset_async(e, mins, 0xFF, 7 * 8);
   e->w0.ensure(S);
   e->w1.ensure(S);
   e->w2.ensure(S);
-  KL("rank_key_mins", rank_key_mins, std::min(gS, 128u), 256, (const int64_t*)b.start.ptr(), (const int64_t*)b.task.ptr(),
-     (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, mins);
-  KL("rank_build_keys", rank_build_keys, gS, 256, (const uint32_t*)b.user.ptr(), (const int32_t*)b.prio.ptr(), (const int64_t*)b.start.ptr(),
-     (const int64_t*)b.task.ptr(), (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, (const unsigned long long*)mins,
-     e->w0.ptr(), e->w1.ptr(), e->w2.ptr(), same);
+  KM<rank_key_mins, 256>(e, "rank_key_mins", std::min(gS, 128u), (const int64_t*)b.start.ptr(), (const int64_t*)b.task.ptr(), (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, mins, std::min(gS, 128u));
+  KM<rank_build_keys, 256>(e, "rank_build_keys", gS, (const uint32_t*)b.user.ptr(), (const int32_t*)b.prio.ptr(), (const int64_t*)b.start.ptr(), (const int64_t*)b.task.ptr(), (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, (const unsigned long long*)mins, e->w0.ptr(), e->w1.ptr(), e->w2.ptr(), same);
   readback64(e, 8);
   const unsigned long long mk0 = ~e->h_scratch[4], mk1 = ~e->h_scratch[5], mk2 = ~e->h_scratch[6];
   b.permA.ensure(S);
@@ -392,7 +388,7 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   cur = radix_sort_masked(e, e->w1.ptr(), mk1, cur, b.permA.ptr(), b.permB2.ptr(), S);
   cur = radix_sort_masked(e, e->w0.ptr(), mk0, cur, b.permA.ptr(), b.permB2.ptr(), S);
   if (!cur) {
-    KL("iota", iota_u32, gS, 256, b.permA.ptr(), S);
+    KM<iota_u32, 256>(e, "iota", gS, b.permA.ptr(), S);
     cur = b.permA.ptr();
   }
   const uint32_t* permB = cur;
@@ -407,28 +403,26 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   b.pre.ensure(S);
   b.dru.ensure(S);
   b.inexact.ensure(U);
-  COOK_HIP(hipMemsetAsync(b.seg_start.ptr(), 0, (size_t)U * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(b.seg_end.ptr(), 0, (size_t)U * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(b.inexact.ptr(), 0, (size_t)U * 4, e->stream));
+  memset_async(e, b.seg_start.ptr(), 0, (size_t)U * 4);
+  memset_async(e, b.seg_end.ptr(), 0, (size_t)U * 4);
+  memset_async(e, b.inexact.ptr(), 0, (size_t)U * 4);
   KL("rebal_invert_perm", rebal_invert_perm, gS, 256, permB, S, R, b.posB.ptr(), b.act.ptr());
-  KL("rank_gather", rank_gather, gS, 256, permB, S, (const uint32_t*)b.user.ptr(), (const double*)b.cpus.ptr(), (const double*)b.mem.ptr(),
-     (const double*)b.gpus.ptr(), (const uint8_t*)b.pending.ptr(), b.s_user.ptr(), b.s_use.ptr(), b.s_pending.ptr(), b.head.ptr(),
-     b.seg_start.ptr(), b.seg_end.ptr());
+  KM<rank_gather, 256>(e, "rank_gather", gS, permB, S, (const uint32_t*)b.user.ptr(), (const double*)b.cpus.ptr(), (const double*)b.mem.ptr(), (const double*)b.gpus.ptr(), (const uint8_t*)b.pending.ptr(), b.s_user.ptr(), b.s_use.ptr(), b.s_pending.ptr(), b.head.ptr(), b.seg_start.ptr(), b.seg_end.ptr());
   {  // users whose sums are exact in any order (all of them for integer-valued resources)
     std::vector<uint32_t> ones(std::max(1u, U), 1u);
     b.user_safe.ensure(std::max(1u, U));
-    COOK_HIP(hipMemcpyAsync(b.user_safe.ptr(), ones.data(), (size_t)std::max(1u, U) * 4, hipMemcpyHostToDevice, e->stream));
+    copy_async(e, b.user_safe.ptr(), ones.data(), (size_t)std::max(1u, U) * 4, hipMemcpyHostToDevice);
     sync(e);
     KL("rebal_user_safe", rebal_user_safe, gS, 256, (const uint32_t*)b.user.ptr(), (const double*)b.cpus.ptr(), (const double*)b.mem.ptr(),
        (const double*)b.gpus.ptr(), S, (const uint32_t*)b.seg_start.ptr(), (const uint32_t*)b.seg_end.ptr(), b.user_safe.ptr());
     b.user_safe_h.assign(std::max(1u, U), 1u);
-    COOK_HIP(hipMemcpyAsync(b.user_safe_h.data(), b.user_safe.ptr(), (size_t)std::max(1u, U) * 4, hipMemcpyDeviceToHost, e->stream));  // read after the sync below
+    copy_async(e, b.user_safe_h.data(), b.user_safe.ptr(), (size_t)std::max(1u, U) * 4, hipMemcpyDeviceToHost);  // read after the sync below
   }
   // ---- running tasks grouped by host (the group-by of rebalancer.clj:349, done once) --------------------------------------------
   b.hstart.ensure(std::max(1u, H));
   b.hend.ensure(std::max(1u, H));
-  COOK_HIP(hipMemsetAsync(b.hstart.ptr(), 0, (size_t)std::max(1u, H) * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(b.hend.ptr(), 0, (size_t)std::max(1u, H) * 4, e->stream));
+  memset_async(e, b.hstart.ptr(), 0, (size_t)std::max(1u, H) * 4);
+  memset_async(e, b.hend.ptr(), 0, (size_t)std::max(1u, H) * 4);
   b.hpermA.ensure(std::max(1u, R));
   b.hpermB.ensure(std::max(1u, R));
   b.hperm = b.hpermA.ptr();
@@ -436,7 +430,7 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
     b.hkey.ensure(R);
     const unsigned gR = div_up(R, 256);
     KL("rebal_host_keys", rebal_host_keys, gR, 256, (const uint32_t*)b.host.ptr(), R, b.hkey.ptr());
-    KL("iota", iota_u32, gR, 256, b.hpermA.ptr(), R);
+    KM<iota_u32, 256>(e, "iota", gR, b.hpermA.ptr(), R);
     unsigned long long hmask = 0;
     for (unsigned long long x = H ? H - 1 : 0; x; x >>= 1) hmask = (hmask << 1) | 1ull;
     b.hperm = radix_sort_masked(e, b.hkey.ptr(), hmask, b.hpermA.ptr(), b.hpermA.ptr(), b.hpermB.ptr(), R);
@@ -446,7 +440,7 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   b.hbase.ensure(std::max(1u, H));
   if (H) {
     KL("rebal_host_sizes", rebal_host_sizes, div_up(H, 256), 256, (const uint32_t*)b.hstart.ptr(), (const uint32_t*)b.hend.ptr(), H, b.hbase.ptr());
-    KL("rebal_hbase_scan", excl_scan_u32_single, 1, SCAN1_THREADS, b.hbase.ptr(), H, (uint32_t*)nullptr);
+    KM<excl_scan_u32_single, SCAN1_THREADS>(e, "rebal_hbase_scan", 1, b.hbase.ptr(), H, (uint32_t*)nullptr);
   }
   // host-ordered mirrors of the running slots' columns (static ones now, the DRUs after the first scoring)
   b.h_pb.ensure(std::max(1u, R)), b.h_user.ensure(std::max(1u, R));
@@ -457,10 +451,10 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   b.tile_agg.ensure(S / RB_RS_TILE + S + 2), b.tile_carry.ensure(S / RB_RS_TILE + S + 2);  // every listed user adds at most one partial tile
   b.dl_pos.ensure(S + 1), b.dl_sign.ensure(S + 1);
   b.x_head.ensure(std::max(1u, H)), b.x_cnt.ensure(std::max(1u, H)), b.x_next.ensure(std::max(1u, P)), b.big_list.ensure(std::max(1u, H));
-  COOK_HIP(hipMemsetAsync(b.chg_mark.ptr(), 0, (size_t)std::max(1u, U) * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(b.x_head.ptr(), 0xFF, (size_t)std::max(1u, H) * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(b.x_cnt.ptr(), 0, (size_t)std::max(1u, H) * 4, e->stream));
-  COOK_HIP(hipMemsetAsync(b.hidx.ptr(), 0xFF, (size_t)S * 4, e->stream));
+  memset_async(e, b.chg_mark.ptr(), 0, (size_t)std::max(1u, U) * 4);
+  memset_async(e, b.x_head.ptr(), 0xFF, (size_t)std::max(1u, H) * 4);
+  memset_async(e, b.x_cnt.ptr(), 0, (size_t)std::max(1u, H) * 4);
+  memset_async(e, b.hidx.ptr(), 0xFF, (size_t)S * 4);
   if (R)
     KL("rebal_host_mirror", rebal_host_mirror, div_up(R, 256), 256, (const uint32_t*)b.hperm, (const uint32_t*)b.posB.ptr(),
        (const uint32_t*)b.user.ptr(), (const double*)b.cpus.ptr(), (const double*)b.mem.ptr(), (const double*)b.gpus.ptr(), R, b.h_pb.ptr(),
@@ -485,21 +479,21 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   b.gs_posB.ensure(S), b.gs_slot.ensure(S), b.gs_ord.ensure(S);
   b.ctl.ensure(1);
   b.jobctx.ensure(1);
-  COOK_HIP(hipMemsetAsync(b.hres_key.ptr(), 0, (size_t)std::max(1u, H) * 8, e->stream));
+  memset_async(e, b.hres_key.ptr(), 0, (size_t)std::max(1u, H) * 8);
   if (H) {  // host->spare-resources as staged: a run is repeatable on the same staged inputs
-    COOK_HIP(hipMemcpyAsync(b.spare_c.ptr(), b.spare0_c.ptr(), (size_t)H * 8, hipMemcpyDeviceToDevice, e->stream));
-    COOK_HIP(hipMemcpyAsync(b.spare_m.ptr(), b.spare0_m.ptr(), (size_t)H * 8, hipMemcpyDeviceToDevice, e->stream));
-    COOK_HIP(hipMemcpyAsync(b.spare_g.ptr(), b.spare0_g.ptr(), (size_t)H * 8, hipMemcpyDeviceToDevice, e->stream));
-    COOK_HIP(hipMemcpyAsync(b.has_spare.ptr(), b.has_spare0.ptr(), (size_t)H, hipMemcpyDeviceToDevice, e->stream));
+    copy_async(e, b.spare_c.ptr(), b.spare0_c.ptr(), (size_t)H * 8, hipMemcpyDeviceToDevice);
+    copy_async(e, b.spare_m.ptr(), b.spare0_m.ptr(), (size_t)H * 8, hipMemcpyDeviceToDevice);
+    copy_async(e, b.spare_g.ptr(), b.spare0_g.ptr(), (size_t)H * 8, hipMemcpyDeviceToDevice);
+    copy_async(e, b.has_spare.ptr(), b.has_spare0.ptr(), (size_t)H, hipMemcpyDeviceToDevice);
   }
   RebalCtl c0;
   std::memset(&c0, 0, sizeof(c0));
   c0.remaining = b.rp.max_preemption;
   c0.max_items = b.max_seg;
   std::memcpy(e->h_scratch, &c0, sizeof(c0));
-  COOK_HIP(hipMemcpyAsync(b.ctl.ptr(), e->h_scratch, sizeof(c0), hipMemcpyHostToDevice, e->stream));
+  copy_async(e, b.ctl.ptr(), e->h_scratch, sizeof(c0), hipMemcpyHostToDevice);
   std::vector<double> nanv(P, std::numeric_limits<double>::quiet_NaN());
-  COOK_HIP(hipMemcpyAsync(b.pending_dru.ptr(), nanv.data(), (size_t)P * 8, hipMemcpyHostToDevice, e->stream));
+  copy_async(e, b.pending_dru.ptr(), nanv.data(), (size_t)P * 8, hipMemcpyHostToDevice);
   sync(e);  // nanv / h_scratch are reused below
   if (H) KL("rebal_big_init", rebal_big_init, div_up(H, 256), 256, (const uint32_t*)b.hstart.ptr(), (const uint32_t*)b.hend.ptr(), H, b.big_list.ptr(), b.ctl.ptr());
   rebalance_rescore(e, b);  // every user once; after a decision only the users it touched (rebal_rescore_users)
@@ -530,7 +524,7 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
       KL("rebal_rs_fix", rebal_rs_fix, RB_RS_USERS, 256, in);
     }
     if ((pj + 1) % RB_CHECK == 0 && pj + 1 < P) {
-      COOK_HIP(hipMemcpyAsync(e->h_scratch, b.ctl.ptr(), sizeof(RebalCtl), hipMemcpyDeviceToHost, e->stream));
+      copy_async(e, e->h_scratch, b.ctl.ptr(), sizeof(RebalCtl), hipMemcpyDeviceToHost);
       sync(e);
       RebalCtl c;
       std::memcpy(&c, e->h_scratch, sizeof(c));
@@ -539,7 +533,7 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
       known_at = pj + 1;
     }
   }
-  COOK_HIP(hipMemcpyAsync(e->h_scratch, b.ctl.ptr(), sizeof(RebalCtl), hipMemcpyDeviceToHost, e->stream));
+  copy_async(e, e->h_scratch, b.ctl.ptr(), sizeof(RebalCtl), hipMemcpyDeviceToHost);
   sync(e);
   std::memcpy(&b.last, e->h_scratch, sizeof(RebalCtl));
   b.done = true;
@@ -551,10 +545,10 @@ void rebalance_fetch(cook_engine* e, RebalBufs& b, cook_preemption* decisions, u
   if (n_decisions) *n_decisions = b.last.nd;
   if (n_preempted) *n_preempted = b.last.np;
   if (decisions && b.last.nd)
-    COOK_HIP(hipMemcpyAsync(decisions, b.decisions.ptr(), (size_t)b.last.nd * sizeof(cook_preemption), hipMemcpyDeviceToHost, e->stream));
+    copy_async(e, decisions, b.decisions.ptr(), (size_t)b.last.nd * sizeof(cook_preemption), hipMemcpyDeviceToHost);
   if (preempted && b.last.np)
-    COOK_HIP(hipMemcpyAsync(preempted, b.preempted.ptr(), (size_t)b.last.np * 4, hipMemcpyDeviceToHost, e->stream));
+    copy_async(e, preempted, b.preempted.ptr(), (size_t)b.last.np * 4, hipMemcpyDeviceToHost);
   if (pending_dru && b.P)
-    COOK_HIP(hipMemcpyAsync(pending_dru, b.pending_dru.ptr(), (size_t)b.P * 8, hipMemcpyDeviceToHost, e->stream));
+    copy_async(e, pending_dru, b.pending_dru.ptr(), (size_t)b.P * 8, hipMemcpyDeviceToHost);
   sync(e);
 }

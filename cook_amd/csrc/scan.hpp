@@ -105,7 +105,7 @@ static __device__ __forceinline__ SegAgg<T> block_seg_exclusive(SegAgg<T> mine, 
 
 // head[i] != 0 starts a new segment at i (head == nullptr: one segment = plain scan).
 template <class T, class Load>
-__global__ void __launch_bounds__(SS_THREADS) seg_scan_local(Load load, const uint8_t* __restrict__ head, unsigned n,
+COOK_KERNEL void seg_scan_local(Load load, const uint8_t* __restrict__ head, unsigned n,
                                                              T* __restrict__ out, SegAgg<T>* __restrict__ block_agg,
                                                              unsigned* __restrict__ block_first_head) {
   __shared__ SegAgg<T> lds_wave[SS_THREADS / COOK_WAVE];
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(SS_THREADS) seg_scan_local(Load load, const ui
 
 // carry[b] = exclusive segmented prefix over block aggregates; single workgroup, tiles of SS_THREADS blocks.
 template <class T>
-__global__ void __launch_bounds__(SS_THREADS) seg_scan_blocksums(const SegAgg<T>* __restrict__ block_agg, unsigned nblocks,
+COOK_KERNEL void seg_scan_blocksums(const SegAgg<T>* __restrict__ block_agg, unsigned nblocks,
                                                                  SegAgg<T>* __restrict__ carry) {
   __shared__ SegAgg<T> lds_wave[SS_THREADS / COOK_WAVE];
   __shared__ SegAgg<T> run_s;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(SS_THREADS) seg_scan_blocksums(const SegAgg<T>
 }
 
 template <class T>
-__global__ void __launch_bounds__(SS_THREADS) seg_scan_propagate(T* __restrict__ out, unsigned n,
+COOK_KERNEL void seg_scan_propagate(T* __restrict__ out, unsigned n,
                                                                  const SegAgg<T>* __restrict__ carry,
                                                                  const unsigned* __restrict__ block_first_head) {
   const unsigned b = blockIdx.x;
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(SS_THREADS) seg_scan_propagate(T* __restrict__
 // (171 of them for a pool's 175k items; the association differs from seg_scan_blocksums', which is free: a partial sum that is not
 // exact is flagged whatever the tree, common.hpp "exact-sum tracking")
 template <class T>
-__global__ void __launch_bounds__(SS_THREADS) seg_scan_propagate_fused(T* __restrict__ out, unsigned n,
+COOK_KERNEL void seg_scan_propagate_fused(T* __restrict__ out, unsigned n,
                                                                        const SegAgg<T>* __restrict__ block_agg,
                                                                        const unsigned* __restrict__ block_first_head) {
   __shared__ SegAgg<T> lds_wave[SS_THREADS / COOK_WAVE];

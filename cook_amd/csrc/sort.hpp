@@ -37,7 +37,7 @@ static __device__ __forceinline__ unsigned rs_digit(const uint64_t* __restrict__
 }
 
 template <int IPL>
-__global__ void __launch_bounds__(RS_THREADS) radix_hist(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm_in,
+COOK_KERNEL void radix_hist(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm_in,
                                                          unsigned n, unsigned shift, unsigned nblocks, unsigned fused,
                                                          uint32_t* __restrict__ hist) {
   __shared__ unsigned h[256];
@@ -66,7 +66,7 @@ constexpr int SCAN1_THREADS = 1024;
 constexpr int SCAN1_IPT = 8;
 constexpr int SCAN1_NS = 8;
 static_assert(SCAN1_IPT == 8, "a thread moves its entries as two 16-byte vectors");
-__global__ void __launch_bounds__(SCAN1_THREADS) excl_scan_u32_single(uint32_t* __restrict__ data, unsigned len,
+COOK_KERNEL void excl_scan_u32_single(uint32_t* __restrict__ data, unsigned len,
                                                                       uint32_t* __restrict__ total_out) {
   __shared__ unsigned wsum[2][SCAN1_THREADS / COOK_WAVE];
   unsigned carry = 0;  // every thread tracks the running total itself (read from LDS once per step)
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(SCAN1_THREADS) excl_scan_u32_single(uint32_t* 
 }
 
 template <int IPL>
-__global__ void __launch_bounds__(RS_THREADS) radix_scatter(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm_in,
+COOK_KERNEL void radix_scatter(const uint64_t* __restrict__ key, const uint32_t* __restrict__ perm_in,
                                                             uint32_t* __restrict__ perm_out, unsigned n, unsigned shift,
                                                             unsigned nblocks, unsigned fused, const uint32_t* __restrict__ hist) {
   __shared__ unsigned whist[RS_WAVES][256];
@@ -223,11 +223,11 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter(const uint64_t* __re
 }
 
 // OR over all items of (key[i] ^ key[0]) : bits that differ somewhere.  One atomicOr per block; launched with a few dozen blocks.
-__global__ void __launch_bounds__(256) radix_varying_bits(const uint64_t* __restrict__ key, unsigned n,
-                                                          unsigned long long* __restrict__ out_mask) {
+COOK_KERNEL void radix_varying_bits(const uint64_t* __restrict__ key, unsigned n,
+                                                          unsigned long long* __restrict__ out_mask, unsigned nblk) {
   const uint64_t k0 = key[0];
   unsigned long long m = 0;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m |= key[i] ^ k0;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nblk * blockDim.x) m |= key[i] ^ k0;
   for (int d = 32; d >= 1; d >>= 1) m |= __shfl_xor(m, d, COOK_WAVE);
   __shared__ unsigned long long s_m[256 / COOK_WAVE];  // one atomic per block
   if (lane_id() == 0) s_m[wave_id()] = m;

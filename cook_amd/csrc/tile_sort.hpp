@@ -92,7 +92,7 @@ struct TieCtl {
 };
 
 // rank of every item under the current groups: U + first position of its group
-__global__ void __launch_bounds__(256) tie_rank_assign(const uint32_t* __restrict__ perm, const uint8_t* __restrict__ thead, unsigned nk,
+COOK_KERNEL void tie_rank_assign(const uint32_t* __restrict__ perm, const uint8_t* __restrict__ thead, unsigned nk,
                                                        unsigned n_users, int round, const TieCtl* __restrict__ ctl,
                                                        uint32_t* __restrict__ rank_of_item) {
   if (ctl->equal_runs || (round > 0 && ctl->tied_after[round - 1] == 0)) return;
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) tie_rank_assign(const uint32_t* __restric
   if (p < nk) rank_of_item[perm[p]] = n_users + start;
 }
 
-__global__ void __launch_bounds__(TS_THREADS) tie_sort_tiles(uint32_t* __restrict__ perm, uint8_t* __restrict__ thead,
+COOK_KERNEL void tie_sort_tiles(uint32_t* __restrict__ perm, uint8_t* __restrict__ thead,
                                                              const uint8_t* __restrict__ dhead, unsigned nk, unsigned n_users,
                                                              unsigned n_items, int round, const uint32_t* __restrict__ rank_of_item,
                                                              const uint32_t* __restrict__ user_of,

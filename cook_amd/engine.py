@@ -412,11 +412,12 @@ class Engine:
         return r.value, m.value
 
     def match_stats(self):
-        out = (C.c_uint32 * 32)()
-        n = self._lib.cook_match_stats_ex(self._h, out, 32)
+        out = (C.c_uint32 * 40)()
+        n = self._lib.cook_match_stats_ex(self._h, out, 40)
         keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "segments", "resolved", "setup_us", "seq_us", "touched", "visited",
                 "_12", "_13", "_14", "_15", "trunc_lists", "served_mode", "served_pools", "serve_iterations", "serve_empty_iterations",
-                "serve_pool_windows", "serve_latch_wait_us", "served_fell_back", "serve_streams", "guard_hits", "update_us", "update_sync_us", "update_allocs", "update_slowest_phase", "update_slowest_phase_us")
+                "serve_pool_windows", "serve_latch_wait_us", "served_fell_back", "serve_streams", "guard_hits", "update_us", "update_sync_us", "update_allocs", "update_slowest_phase", "update_slowest_phase_us", "_31",
+                "rank_batch_pools", "rank_batch_launches", "rank_batch_grouped_launches", "rank_batch_single_ops", "rank_batch_syncs")
         return {k: int(x) for k, x in zip(keys, out[:max(0, n)]) if not k.startswith("_")}
 
     def set_profiling(self, on: bool):
@@ -476,6 +477,34 @@ class PinnedArena:
 
     def __exit__(self, *a):
         self.close()
+
+
+def cycle_run_rank_multi(engines: Sequence[Engine], num_considerable: int, user_usage_ptrs: Optional[Sequence[int]] = None,
+                         n_users: int = 0):
+    """cycle_run_rank of several engines (pools of one rank, same device) in ONE call: the pools' rank flows side by side on one stream,
+    the same kernel of several pools in one launch (cook_cycle_run_rank_multi; same results as the calls one by one).
+    user_usage_ptrs: device addresses of one [U, 3] float64 buffer per engine -> rank_user_usage(device_ptr=...) of each, in the same
+    call; n_users > 0 without pointers: the usage comes back as a list of [U, 3] host arrays."""
+    if not engines:
+        return None
+    lib = engines[0]._lib
+    arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    outs = None
+    if user_usage_ptrs is not None:
+        uu = (C.c_void_p * len(engines))(*[C.c_void_p(int(p)) for p in user_usage_ptrs])
+        rc = lib.cook_cycle_run_rank_multi(arr, len(engines), int(num_considerable), uu, 1)
+    elif n_users:
+        outs = [np.zeros((max(1, n_users), 3), dtype=np.float64) for _ in engines]
+        uu = (C.c_void_p * len(engines))(*[o.ctypes.data for o in outs])
+        rc = lib.cook_cycle_run_rank_multi(arr, len(engines), int(num_considerable), uu, 0)
+    else:
+        rc = lib.cook_cycle_run_rank_multi(arr, len(engines), int(num_considerable), None, 0)
+    if rc != 0:
+        for e in engines:  # the message is with the engine whose flow failed
+            if e._lib.cook_last_error(e._h):
+                e._chk(rc)
+        engines[0]._chk(rc)
+    return [o[:n_users] for o in outs] if outs is not None else None
 
 
 def cycle_match_multi(engines: Sequence[Engine]):

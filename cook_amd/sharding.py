@@ -134,7 +134,9 @@ class ShardedCluster:
     """The pools of one cluster that live on this rank, and one match cycle over them.
 
     cycle(K): 1. per-pool running usage (device reduction)  2. all-reduce into quota-group usage
-              3. per pool: set quota inputs, rank + take K (pools concurrently, one stream each), then the placements of all
+              3. per pool: set quota inputs; rank + take K of all local pools in ONE cook_cycle_run_rank_multi call (the pools' flows
+                 side by side on one stream, the same kernel of several pools in one launch; COOK_RANK_BATCH=0: pools concurrently, one
+                 stream each), then the placements of all
                  local pools in ONE cook_cycle_match_multi call (served walkers: a persistent walker workgroup per pool beside
                  serve launches); with COOK_MATCH_SERVED=0 as lockstep chains of launches, a single pool through cook_cycle_run.
     """
@@ -166,6 +168,9 @@ class ShardedCluster:
         # pool beside serve launches, two streams per GPU whatever the number of pools.  COOK_MATCH_SERVED=0: lockstep chains as before.
         self.served = os.environ.get("COOK_MATCH_SERVED", "1") != "0"
         self._usage_warm = False  # the engines have summed their pools' usage for the tables they hold (see cycle)
+        # the rank parts of all local pools in ONE cook_cycle_run_rank_multi call (one thread, one stream, the same kernel of several pools
+        # in one launch) instead of a thread per pool: the stage is bound by the number of launches the host makes
+        self.rank_batch = os.environ.get("COOK_RANK_BATCH", "1") != "0"
 
     @property
     def last_user_usage(self) -> Optional[np.ndarray]:
@@ -248,10 +253,28 @@ class ShardedCluster:
                 else:
                     user_parts[p] = self.engines[p].rank_user_usage(self.n_users)
 
+        batch_rank = lockstep and self.rank_batch and len(self.pools) > 1 and all(hasattr(self.engines[p], "_h") for p in self.pools)
+
+        def rank_all():
+            nonlocal user_parts
+            if not batch_rank:
+                list(self._tp_rank.map(run, self.pools))  # (the rank stages are chains of small kernels: at most max_chains at a time)
+                return
+            from .engine import cycle_run_rank_multi
+            engs = [self.engines[p] for p in self.pools]
+            for p in self.pools:
+                self.engines[p].rank_set_quota(self.quota_inputs(p, usages[p], total))
+            if want_users and on_gpu:
+                cycle_run_rank_multi(engs, num_considerable, user_usage_ptrs=[user_parts[i].data_ptr() for i in range(len(engs))])
+            elif want_users:
+                user_parts = dict(zip(self.pools, cycle_run_rank_multi(engs, num_considerable, n_users=self.n_users)))
+            else:
+                cycle_run_rank_multi(engs, num_considerable)
+
         n_chains = max(1, min(len(self.pools), self.max_chains))
         if served:
             from .engine import cycle_match_multi
-            list(self._tp_rank.map(run, self.pools))
+            rank_all()
             t2 = time.perf_counter()
             cycle_match_multi([self.engines[p] for p in self.pools])  # (falls back to lockstep launches inside the library if it must)
         elif lockstep and self.chain_whole_cycle:
@@ -270,8 +293,7 @@ class ShardedCluster:
             list(self._tp.map(chain, range(n_chains)))
             t2 = time.perf_counter()
         else:
-            # the rank stages are chains of small kernels too: at most max_chains at a time
-            list(self._tp_rank.map(run, self.pools))
+            rank_all()
             t2 = time.perf_counter()
             if lockstep:
                 from .engine import cycle_match_multi

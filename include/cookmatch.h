@@ -360,6 +360,16 @@ int cook_cycle_run(cook_engine* e, uint32_t num_considerable);
  * interfere on one GPU; either form keeps to four.  The call occupies the calling thread until every pool is placed.  Hold every
  * engine's lock across both calls. */
 int cook_cycle_run_rank(cook_engine* e, uint32_t num_considerable);
+/* cook_cycle_run_rank for n engines of one device in ONE call from ONE thread (replaces scheduler.clj:2425-2435's thread per pool for
+ * the rank part; same results per engine as n separate calls).  A pool's rank is a chain of about a hundred small launches and the
+ * stage is bound by their number: here the pools' flows run side by side on engines[0]'s stream and a kernel that stands at the same
+ * point of several flows is launched ONCE for all of them (blockIdx.y = pool), with one stream synchronisation where each flow would
+ * have had its own.  user_usage != NULL: user_usage[i] also receives engine i's per-user running usage [U x 3] exactly as
+ * cook_rank_user_usage(engines[i], user_usage[i], usage_is_device) would deliver it after the rank (the collective's payload), inside the
+ * same joint sequence.  COOK_RANK_BATCH=0 in the environment: the engines one after another, as cook_cycle_run_rank (+ cook_rank_user_usage).
+ * Returns the first engine's error that is not COOK_OK; every engine keeps its own message (cook_last_error). */
+int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, uint32_t num_considerable, double* const* user_usage,
+                              int usage_is_device);
 int cook_cycle_match_multi(cook_engine** engines, uint32_t n);
 int cook_cycle_fetch(cook_engine* e, uint32_t* ranked_pending_idx, uint32_t* n_ranked, int32_t* job_to_offer,
                      uint32_t* n_considered, uint8_t* head_matched);
@@ -580,8 +590,10 @@ int cook_match_stats(cook_engine* e, uint32_t out[16]);
    environment (diagnostics: every device buffer sits between two bands of a pattern) the writes found outside a buffer so far, process-wide —
    the call looks at this engine's bands first —, else 0; [26..28] the last cook_cycle_update of this engine: microseconds in the call, microseconds of those the host waited in
    stream synchronisations, device buffers it had to (re)allocate, [29..30] the phase of the call that took the host longest (0 checks, 1 the delta's block,
-   2 marks and scans, 3 column compactions, 4 CSR columns, 5 the look at the device, 6 swaps and offers) and its microseconds; [31] reserved (0) */
-#define COOK_MATCH_STATS_EX_N 32
+   2 marks and scans, 3 column compactions, 4 CSR columns, 5 the look at the device, 6 swaps and offers) and its microseconds; [31] reserved (0);
+   [32..36] the last cook_cycle_run_rank_multi LED by this engine: pools, launches made, of them for more than one pool, operations
+   issued on their own (copies, fills, kernels outside the batched path), stream synchronisations; [37..39] reserved (0) */
+#define COOK_MATCH_STATS_EX_N 40
 int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap);
 
 #if defined(__GNUC__)

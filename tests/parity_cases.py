@@ -460,14 +460,21 @@ def slow_constraint_case(seed, n, m):
     return jobs, offers, groups
 
 
-def multi_pool_parity(make_engine, pools, params, k):
-    """cook_cycle_run_rank per pool + ONE cook_cycle_match_multi for all of them == cook_cycle_run on each pool == oracle."""
-    from cook_amd.engine import cycle_match_multi
+def multi_pool_parity(make_engine, pools, params, k, rank_batched=True):
+    """The rank part of every pool — ONE cook_cycle_run_rank_multi for all of them (rank_batched: the pools' flows side by side, the same
+    kernel of several pools in one launch) or cook_cycle_run_rank per pool — + ONE cook_cycle_match_multi for all of them
+    == cook_cycle_run on each pool == oracle."""
+    from cook_amd.engine import cycle_match_multi, cycle_run_rank_multi
     engines = [make_engine(params) for _ in pools]
     try:
         for e, pool in zip(engines, pools):
             e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
-            e.cycle_run_rank(k)
+            if not rank_batched:
+                e.cycle_run_rank(k)
+        if rank_batched:
+            cycle_run_rank_multi(engines, k)
+            st = engines[0].match_stats()
+            assert st["rank_batch_pools"] == len(engines) or len(engines) == 1, st
         cycle_match_multi(engines)
         got = [e.cycle_fetch() for e in engines]
         cycle_match_multi(engines)  # nothing deferred any more: a no-op, not an error
