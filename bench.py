@@ -751,6 +751,9 @@ def main():
                            "placement_stats_pool0": engines[my_pools[0]].match_stats()},
             "phase_ms": dict(zip(("pool_usage_allreduce", "rank", "placement", "user_usage_allreduce"),
                                  (float(np.median([ph[x] for ph in phases])) for x in range(4)))),
+            # the rank parts of the rank's pools as ONE joint sequence of launches (cook_cycle_run_rank_multi; COOK_RANK_BATCH=0: a thread and a
+            # stream per pool): launches made, of them for more than one pool, operations issued on their own, stream synchronisations
+            "rank_batch": {k[len("rank_batch_"):]: v for k, v in engines[my_pools[0]].match_stats().items() if k.startswith("rank_batch_")},
             "setup_s": gen_s,
             "collective": collective, "roofline": roofline, "cpu_baseline": cpu, "adjacent_rows": adjacent, "extra_configs": extra, "boundary": boundary,
             "parity_checked": parity_checked, "parity": {"against": "oracle (bit-exact rank order + every assignment)", "pools": parity_pools},

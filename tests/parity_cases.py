@@ -491,6 +491,119 @@ def multi_pool_parity(make_engine, pools, params, k, rank_batched=True):
     return got
 
 
+def rank_batch_parity(make_engine, cases, k, n_users=0, min_grouped=1):
+    """ONE cook_cycle_run_rank_multi over pools whose rank flows DIFFER (sizes, tie rounds, equal-DRU runs, quotas, considerable filters,
+    DRU mode ...) + one cook_cycle_match_multi == cook_cycle_run on a fresh engine per pool (ranked order, considerable positions,
+    placement, per-user usage) — and the rank order == oracle.  cases: dicts with pool, params, and optionally quota, cons = (user state,
+    eligible mask by pending job)."""
+    from cook_amd.engine import cycle_match_multi, cycle_run_rank_multi
+    want = []
+    for c in cases:
+        with make_engine(c["params"]) as e:
+            pool = c["pool"]
+            e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+            if c.get("cons"):
+                e.cycle_set_considerable(*c["cons"])
+            e.rank_set_quota(c.get("quota"))
+            e.cycle_run(k)
+            uu = e.rank_user_usage(n_users) if n_users else None
+            want.append((e.cycle_fetch(), e.cycle_fetch_considerable(), uu))
+    engines = [make_engine(c["params"]) for c in cases]
+    try:
+        for e, c in zip(engines, cases):
+            pool = c["pool"]
+            e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+            if c.get("cons"):
+                e.cycle_set_considerable(*c["cons"])
+            e.rank_set_quota(c.get("quota"))
+        stats = []
+        for _ in range(2):  # (the second call finds every buffer at its size: no flow has to wait for a reallocation)
+            uus = cycle_run_rank_multi(engines, k, n_users=n_users)
+            stats.append(engines[0].match_stats())
+            cycle_match_multi(engines)
+            got = [(e.cycle_fetch(), e.cycle_fetch_considerable(), uu) for e, uu in zip(engines, uus or [None] * len(engines))]
+            for i, ((g_f, g_pos, g_uu), (w_f, w_pos, w_uu), c) in enumerate(zip(got, want, cases)):
+                assert np.array_equal(g_f[0], w_f[0]), ("ranked", i)
+                assert np.array_equal(g_pos, w_pos), ("considerable positions", i)
+                assert np.array_equal(g_f[1], w_f[1]) and g_f[2] == w_f[2], ("placement", i)
+                if n_users:
+                    assert np.array_equal(g_uu, w_uu), ("user usage", i)
+    finally:
+        for e in engines:
+            e.close()
+    for c, (w_f, _, _) in zip(cases, want):
+        o_ranked, _ = pyoracle.rank(c["params"], c["pool"].tasks, c["pool"].users, quota=c.get("quota"))
+        assert np.array_equal(w_f[0], o_ranked)
+    st = stats[-1]
+    if len(cases) > 1:  # (a call for ONE engine is cook_cycle_run_rank)
+        assert st["rank_batch_pools"] == len(cases) and st["rank_batch_grouped_launches"] >= min_grouped, st
+    return stats
+
+
+def rank_batch_cases(scale=1):
+    """pools whose rank flows differ: multi-block sizes, tie-heavy, fractional (inexact prefixes), equal-DRU runs, gpu mode with
+    good-enough-fitness below 1, pool / group quota + offensive filter, no running task, considerable filters"""
+    rng = np.random.default_rng(5)
+    cases = []
+    cases.append(dict(pool=synth.make_pool(seed=201, n_pending=5000 * scale, n_running=1500 * scale, n_users=300, n_offers=60, gpus=True, constraints=True),
+                      params=A.default_params(good_enough_fitness=1.0, match_algo=2, max_over_quota_jobs=10)))  # multi-block scans / sorts
+    cases.append(dict(pool=synth.make_pool(seed=202, n_pending=900 * scale, n_running=300 * scale, n_users=25, n_offers=40, tie_heavy=True),
+                      params=A.default_params(good_enough_fitness=1.0, match_algo=2)))
+    cases.append(dict(pool=synth.make_pool(seed=203, n_pending=700 * scale, n_running=300 * scale, n_users=25, n_offers=40, fractional=True),
+                      params=A.default_params(good_enough_fitness=1.0, match_algo=2)))
+    runs = synth.make_pool(seed=204, n_pending=900 * scale, n_running=300 * scale, n_users=25, n_offers=40, tie_heavy=True)  # equal-DRU runs: the collapse path
+    z = rng.random(runs.tasks.n) < 0.2
+    runs.tasks.cpus[z] = 1e-17
+    runs.tasks.mem[z] = 1e-17
+    cases.append(dict(pool=runs, params=A.default_params(good_enough_fitness=1.0, match_algo=2, max_over_quota_jobs=10)))
+    gp = synth.make_pool(seed=205, n_pending=800 * scale, n_running=400 * scale, n_users=30, n_offers=40, gpus=True)
+    cases.append(dict(pool=gp, params=A.default_params(good_enough_fitness=0.8, match_algo=2, dru_mode=1)))
+    cases.append(dict(pool=synth.make_pool(seed=206, n_pending=800 * scale, n_running=400 * scale, n_users=30, n_offers=40, gpus=True),
+                      params=A.default_params(good_enough_fitness=1.0, match_algo=2, offensive_max_mem_mb=16000.0, offensive_max_cpus=6.0),
+                      quota=A.pool_quota(pool_quota=A.quota(count=600 * scale, cpus=2500.0 * scale), group_quota=A.quota(mem=4.0e6 * scale),
+                                         group_usage=A.usage(count=10, cpus=100, mem=1.0e6))))
+    cases.append(dict(pool=synth.make_pool(seed=207, n_pending=600 * scale, n_running=0 * scale, n_users=7, n_offers=20, tie_heavy=True, quota_frac=0.5),
+                      params=A.default_params(good_enough_fitness=1.0, match_algo=2)))
+    cp = synth.make_pool(seed=208, n_pending=700 * scale, n_running=300 * scale, n_users=12, n_offers=40)
+    _, st = make_considerable_case(seed=61, n=10, n_users=12)
+    elig = (rng.random(700 * scale) < 0.8).astype(np.uint8)
+    cases.append(dict(pool=cp, params=A.default_params(good_enough_fitness=1.0, match_algo=2), cons=(st, elig)))
+    return cases
+
+
+class _raises:
+    def __init__(self, exc, text):
+        self.exc, self.text = exc, text
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        assert et is not None and issubclass(et, self.exc) and self.text in str(ev), (et, ev)
+        return True
+
+
+def rank_batch_one_flow_fails(make_engine):
+    """an engine that was never staged fails in ITS flow; the others' results are complete and right"""
+    from cook_amd.engine import CookError, cycle_match_multi, cycle_run_rank_multi
+    cases = rank_batch_cases()[1:4]
+    engines = [make_engine(c["params"]) for c in cases] + [make_engine(A.default_params())]
+    try:
+        for e, c in zip(engines, cases):
+            pool = c["pool"]
+            e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+        with _raises(CookError, "before cook_cycle_stage"):
+            cycle_run_rank_multi(engines, 10 ** 9)
+        cycle_match_multi(engines[:3])
+        for e, c in zip(engines, cases):
+            ranked, j2o, head = e.cycle_fetch()
+            o_ranked, _ = pyoracle.rank(c["params"], c["pool"].tasks, c["pool"].users)
+            assert np.array_equal(ranked, o_ranked)
+    finally:
+        for e in engines:
+            e.close()
+
+
 def mixed_chain_parity(make_engine, pools, params_list, ks):
     """One lockstep chain whose pools DISAGREE: good-enough-fitness below 1 next to best fit (the whole chain then runs the good-enough
     launches: a best-fit pool is placed by best fit all the same, from that flavour's shorter best-fit lists), and different numbers

@@ -702,3 +702,23 @@ def test_guard_bands_report_a_write_past_a_buffer():
         assert ("COOK_GUARD: " in r.stderr) == want_line, r.stderr[-2000:]
         if want_line:
             assert "PAST its end" in r.stderr
+
+
+# ---- the rank parts of several pools in one call (cook_cycle_run_rank_multi: pool batches, engine.hip) ------------------------------------
+def test_rank_batch_diverging_flows(make_engine):
+    stats = P.rank_batch_parity(make_engine, P.rank_batch_cases(), k=300, n_users=300, min_grouped=20)
+    assert stats[-1]["rank_batch_single_ops"] <= stats[-1]["rank_batch_launches"], stats[-1]
+
+
+def test_rank_batch_tie_rule_as_radix_passes(make_engine, monkeypatch):
+    monkeypatch.setenv("COOK_RANK_RADIX", "1")
+    P.rank_batch_parity(make_engine, P.rank_batch_cases()[1:5], k=10 ** 9)
+
+
+def test_rank_batch_of_one_pool(make_engine):
+    """a call for ONE engine is cook_cycle_run_rank (+ cook_rank_user_usage)"""
+    P.rank_batch_parity(make_engine, P.rank_batch_cases()[2:3], k=200, n_users=40)
+
+
+def test_rank_batch_one_flow_fails(make_engine):
+    P.rank_batch_one_flow_fails(make_engine)

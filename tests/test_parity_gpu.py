@@ -472,6 +472,7 @@ def test_timed_configuration_parity(make_engine, multi_mode):
         cl.cycle(K)  # the timed region repeats cycles on resident inputs: check a repeat, not the first call
         st0 = engines[0].match_stats()
         assert st0["served_mode"] == (1 if multi_mode == "served" else 0) and st0["served_fell_back"] == 0
+        assert st0["rank_batch_pools"] == spec.pools and st0["rank_batch_single_ops"] == 0, st0  # the eight ranks were ONE joint sequence of launches
         n_chains = min(spec.pools, cl.max_chains)
         check = sorted({0, 1 % spec.pools, (n_chains + 1) % spec.pools, spec.pools - 1})  # chains 0, 1, 1 (second slot), last (second slot)
         for p in check:
@@ -483,6 +484,21 @@ def test_timed_configuration_parity(make_engine, multi_mode):
     finally:
         for e in engines.values():
             e.close()
+
+
+def test_rank_batch_diverging_flows(make_engine):
+    """cook_cycle_run_rank_multi on the GPU: eight pools whose rank flows differ (130k tasks beside 12k; tie-heavy, fractional, equal-DRU
+    runs, gpu mode, quotas + offensive filter, no running task, considerable filters) in ONE call — ranked order, considerable positions,
+    placements and per-user usage equal to cook_cycle_run on a fresh engine per pool, the order equal to the oracle's."""
+    stats = P.rank_batch_parity(make_engine, P.rank_batch_cases(scale=20), k=3000, n_users=300, min_grouped=40)
+    assert stats[-1]["rank_batch_single_ops"] == 0, stats[-1]  # (every operation of the path is a batched kernel, the read-backs too)
+
+
+def test_rank_batch_small_and_failing_flows(make_engine, monkeypatch):
+    P.rank_batch_parity(make_engine, P.rank_batch_cases(), k=300, n_users=300)
+    P.rank_batch_one_flow_fails(make_engine)
+    monkeypatch.setenv("COOK_RANK_RADIX", "1")
+    P.rank_batch_parity(make_engine, P.rank_batch_cases(scale=4)[1:5], k=10 ** 9)
 
 
 def test_served_walkers_ragged_pools_many_cycles(make_engine, monkeypatch):
