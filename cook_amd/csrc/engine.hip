@@ -396,18 +396,20 @@ void KM(cook_engine* e, const char* name, unsigned grid, const X&... x) {
 }
 
 // a __global__ kernel of its own (arguments evaluated here and now; inside a pool batch the launch is recorded and issued alone)
-#define KL(name, kern, grid, block, ...)                                                                     \
+#define KL(name_, kern, grid, block, ...)                                                                     \
   do {                                                                                                       \
     if (recording()) {                                                                                       \
       const auto _a = std::make_tuple(__VA_ARGS__);                                                          \
       const dim3 _g(grid), _b(block);                                                                        \
-      const char* _n = name;                                                                                 \
-      batch_new_op().generic = [=](cook_engine* lead_, hipStream_t s_) {                                     \
+      const char* _n = name_;                                                                                 \
+      BatchOp& _op = batch_new_op();                                                                         \
+      _op.name = _n;                                                                                         \
+      _op.generic = [=](cook_engine* lead_, hipStream_t s_) {                                                \
         ProfScope _ps(lead_, _n, s_);                                                                        \
         std::apply([&](const auto&... x_) { hipLaunchKernelGGL(kern, _g, _b, 0, s_, x_...); }, _a);          \
       };                                                                                                     \
     } else {                                                                                                 \
-      ProfScope _ps(e, name);                                                                                \
+      ProfScope _ps(e, name_);                                                                               \
       hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, e->stream, __VA_ARGS__);                          \
     }                                                                                                        \
   } while (0)
@@ -424,7 +426,9 @@ void KM(cook_engine* e, const char* name, unsigned grid, const X&... x) {
 void copy_async(cook_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
   if (!bytes) return;
   if (recording()) {
-    batch_new_op().generic = [=](cook_engine*, hipStream_t s_) { COOK_HIP(hipMemcpyAsync(dst, src, bytes, kind, s_)); };
+    BatchOp& op = batch_new_op();
+    op.name = "copy";
+    op.generic = [=](cook_engine*, hipStream_t s_) { COOK_HIP(hipMemcpyAsync(dst, src, bytes, kind, s_)); };
     return;
   }
   COOK_HIP(hipMemcpyAsync(dst, src, bytes, kind, e->stream));
@@ -432,7 +436,9 @@ void copy_async(cook_engine* e, void* dst, const void* src, size_t bytes, hipMem
 void memset_async(cook_engine* e, void* dst, int value, size_t bytes) {
   if (!bytes) return;
   if (recording()) {
-    batch_new_op().generic = [=](cook_engine*, hipStream_t s_) { COOK_HIP(hipMemsetAsync(dst, value, bytes, s_)); };
+    BatchOp& op = batch_new_op();
+    op.name = "fill";
+    op.generic = [=](cook_engine*, hipStream_t s_) { COOK_HIP(hipMemsetAsync(dst, value, bytes, s_)); };
     return;
   }
   COOK_HIP(hipMemsetAsync(dst, value, bytes, e->stream));
@@ -444,10 +450,13 @@ void memset_async(cook_engine* e, void* dst, int value, size_t bytes) {
 COOK_KERNEL void copy_words_k(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, unsigned nwords) {
   for (unsigned i = threadIdx.x; i < nwords; i += blockDim.x) dst[i] = src[i];
 }
-static const bool g_batch_copy_kernel = [] {
-  const char* s = std::getenv("COOK_BATCH_COPY_KERNEL");
+// (a plain function: hipcc gave a second namespace-scope lambda initialiser in this anonymous namespace the body of the first — COOK_GUARD's —,
+//  found in the disassembly of the library's static initialisers after the switch had read as "off" on the GPU box)
+static bool env_switch_on_unless_zero(const char* name) {
+  const char* s = std::getenv(name);
   return !(s && std::atoi(s) == 0);
-}();
+}
+static const bool g_batch_copy_kernel = env_switch_on_unless_zero("COOK_BATCH_COPY_KERNEL");
 void pinned_copy(cook_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
   if (recording() && g_batch_copy_kernel && bytes % 4 == 0 && bytes <= 4096 && ((uintptr_t)dst | (uintptr_t)src) % 4 == 0) {
     KM<copy_words_k, COOK_WAVE>(e, "copy_words", 1, (uint32_t*)dst, (const uint32_t*)src, (unsigned)(bytes / 4));
@@ -484,12 +493,15 @@ void sync(cook_engine* e) {  // (always timed: two clock reads against a stream 
 }
 
 // issues what the flows have recorded: operations without a key as they stand, the same kernel at the front of several flows as one launch
+// COOK_BATCH_TRACE=1: every operation a pool batch issues, to stderr (name x pools; "alone" = issued on its own)
+static const bool g_batch_trace = std::getenv("COOK_BATCH_TRACE") != nullptr;
 static void batch_flush(PoolBatch& b) {
   const unsigned P = (unsigned)b.flows.size();
   const BatchOp* group[COOK_MULTI_MAX * 8];
   for (;;) {
     for (auto& f : b.flows)
       while (f.cur < f.ops.size() && !f.ops[f.cur].key) {
+        if (g_batch_trace) std::fprintf(stderr, "batch: %s alone\n", f.ops[f.cur].name);
         f.ops[f.cur].generic(b.lead, b.stream);
         ++f.cur;
         ++b.singles;
@@ -513,6 +525,7 @@ static void batch_flush(PoolBatch& b) {
         if (!first) first = &f.ops[f.cur];
         ++f.cur;
       }
+    if (g_batch_trace) std::fprintf(stderr, "batch: %s x %u (grid %u)\n", first->name, n, first->grid);
     first->launch(b.lead, b.stream, first->name, group, n);
     ++b.launches;
     if (n > 1) ++b.grouped;
@@ -576,6 +589,7 @@ static int batch_run(PoolBatch& b) {
     bool parked = false;
     for (auto& f : b.flows) parked = parked || f.state == 1;
     const auto t0 = std::chrono::steady_clock::now();
+    if (g_batch_trace) std::fprintf(stderr, "batch: synchronise\n");
     COOK_HIP(hipStreamSynchronize(b.stream));
     tl_sync_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ++tl_syncs;
@@ -2184,10 +2198,7 @@ int cook_cycle_run_rank(cook_engine* e, uint32_t num_considerable) {
   });
 }
 // the rank part of a cycle for every pool of a GPU: one flow per pool in a pool batch (above)
-static const bool g_rank_batch = [] {
-  const char* s = std::getenv("COOK_RANK_BATCH");
-  return !(s && std::atoi(s) == 0);
-}();
+static const bool g_rank_batch = env_switch_on_unless_zero("COOK_RANK_BATCH");
 int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, uint32_t num_considerable, double* const* user_usage, int usage_is_device) {
   if (!engines || n == 0) return COOK_E_INVALID;
   for (uint32_t i = 0; i < n; ++i)

@@ -171,6 +171,7 @@ class ShardedCluster:
         # the rank parts of all local pools in ONE cook_cycle_run_rank_multi call (one thread, one stream, the same kernel of several pools
         # in one launch) instead of a thread per pool: the stage is bound by the number of launches the host makes
         self.rank_batch = os.environ.get("COOK_RANK_BATCH", "1") != "0"
+        self.rank_batches = int(os.environ.get("COOK_RANK_BATCHES", "1"))
 
     @property
     def last_user_usage(self) -> Optional[np.ndarray]:
@@ -261,15 +262,30 @@ class ShardedCluster:
                 list(self._tp_rank.map(run, self.pools))  # (the rank stages are chains of small kernels: at most max_chains at a time)
                 return
             from .engine import cycle_run_rank_multi
-            engs = [self.engines[p] for p in self.pools]
             for p in self.pools:
                 self.engines[p].rank_set_quota(self.quota_inputs(p, usages[p], total))
-            if want_users and on_gpu:
-                cycle_run_rank_multi(engs, num_considerable, user_usage_ptrs=[user_parts[i].data_ptr() for i in range(len(engs))])
-            elif want_users:
-                user_parts = dict(zip(self.pools, cycle_run_rank_multi(engs, num_considerable, n_users=self.n_users)))
+            # COOK_RANK_BATCHES > 1: the pools in that many batches, each from a thread of its own (every batch has its own stream): two
+            # sequences of launches can overlap where one leaves the GPU idle between dependent kernels (measured: DESIGN.md 3a)
+            nb = max(1, min(self.rank_batches, len(self.pools) // 2)) if not isinstance(self._tp_rank, _SerialExecutor) else 1
+            host_parts = {}
+
+            def one(b):
+                idx = list(range(b, len(self.pools), nb))
+                engs = [self.engines[self.pools[i]] for i in idx]
+                if want_users and on_gpu:
+                    cycle_run_rank_multi(engs, num_considerable, user_usage_ptrs=[user_parts[i].data_ptr() for i in idx])
+                elif want_users:
+                    for i, u in zip(idx, cycle_run_rank_multi(engs, num_considerable, n_users=self.n_users)):
+                        host_parts[self.pools[i]] = u
+                else:
+                    cycle_run_rank_multi(engs, num_considerable)
+
+            if nb == 1:
+                one(0)
             else:
-                cycle_run_rank_multi(engs, num_considerable)
+                list(self._tp_rank.map(one, range(nb)))
+            if want_users and not on_gpu:
+                user_parts = host_parts
 
         n_chains = max(1, min(len(self.pools), self.max_chains))
         if served:
