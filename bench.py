@@ -66,6 +66,15 @@ def parse():
 PLACEMENT_KERNELS = ("match_resolve2", "match_eval2", "match_merge2", "match_serial", "match_walkers", "match_serve_eval", "match_serve_merge")
 
 
+def rank_batch_report(stats):
+    """what the rank's pool batches of the last cycle did, summed over the batches' lead engines (sharding.py: up to four batches)"""
+    leads = [st for st in stats if st.get("rank_batch_pools", 0) > 0]
+    out = {"batches": len(leads)}
+    for k in ("pools", "launches", "grouped_launches", "single_ops", "syncs"):
+        out[k] = sum(st["rank_batch_" + k] for st in leads)
+    return out
+
+
 def algorithmic_bytes(kernel, n_tasks, k, m, launches_per_match=1.0, pools_per_launch=1.0):
     """Inputs read once + outputs written once per launch, per pool.
 
@@ -753,7 +762,7 @@ def main():
                                  (float(np.median([ph[x] for ph in phases])) for x in range(4)))),
             # the rank parts of the rank's pools as ONE joint sequence of launches (cook_cycle_run_rank_multi; COOK_RANK_BATCH=0: a thread and a
             # stream per pool): launches made, of them for more than one pool, operations issued on their own, stream synchronisations
-            "rank_batch": {k[len("rank_batch_"):]: v for k, v in engines[my_pools[0]].match_stats().items() if k.startswith("rank_batch_")},
+            "rank_batch": rank_batch_report([engines[p].match_stats() for p in my_pools]),
             "setup_s": gen_s,
             "collective": collective, "roofline": roofline, "cpu_baseline": cpu, "adjacent_rows": adjacent, "extra_configs": extra, "boundary": boundary,
             "parity_checked": parity_checked, "parity": {"against": "oracle (bit-exact rank order + every assignment)", "pools": parity_pools},

@@ -16,10 +16,11 @@
 
 constexpr unsigned TS_THREADS = COOK_SHAPE(1024, 256);
 constexpr unsigned TS_NOMINAL = COOK_SHAPE(1024, 64);   // positions per workgroup before the spill of its last segment
-constexpr unsigned TS_CAP = COOK_SHAPE(8192, 256);      // 12 B of LDS per item (tiles of 512 / 4096 with 512 threads: 54 us per launch against 39 — the launch lasts as long as the tile with the longest group)
+constexpr unsigned TS_CAP = COOK_SHAPE(8192, 256);      // 8 B of LDS per item (tiles of 512 / 4096 with 512 threads: 54 us per launch against 39 — the launch lasts as long as the tile with the longest group)
 constexpr unsigned TS_LIDX_BITS = 13;
 static_assert(TS_CAP <= (1u << TS_LIDX_BITS), "a local index is 13 bits of the sort keys");
 static_assert((TS_CAP & (TS_CAP - 1)) == 0, "bitonic network sizes");
+static_assert(TS_CAP % TS_THREADS == 0, "the write-back holds TS_CAP / TS_THREADS items per thread");
 constexpr unsigned TS_MAX_GROUP = TS_CAP - TS_NOMINAL + 1;  // the longest segment a tile takes for certain
 
 // last position <= pos that starts a segment (position 0 always does)
@@ -128,8 +129,10 @@ COOK_KERNEL void tie_sort_tiles(uint32_t* __restrict__ perm, uint8_t* __restrict
                                                              const uint32_t* __restrict__ user_of,
                                                              const uint32_t* __restrict__ seg_first, TieCtl* __restrict__ ctl) {
   if (ctl->equal_runs || (round > 0 && ctl->tied_after[round - 1] == 0)) return;
+  // 8 B of LDS per item = 64 KB: TWO workgroups per CU (the items themselves stay in `perm`: a key carries its position in the tile, and the
+  // write-back reads through it before anything is written — with a third array of 4 B per item a CU held one workgroup, and a launch
+  // for the eight pools of a GPU, 1 360 tiles, went through the chip in six waves: 142 us)
   __shared__ uint64_t s_key[TS_CAP];
-  __shared__ uint32_t s_item[TS_CAP];
   __shared__ unsigned s_b[3], s_any;
   if (threadIdx.x == 0) s_any = 0;
   ts_tile_bounds(dhead, nk, TS_NOMINAL, s_b);  // tiles follow the groups of EQUAL KEYS: the refined heads move while other tiles look
@@ -167,7 +170,6 @@ COOK_KERNEL void tie_sort_tiles(uint32_t* __restrict__ perm, uint8_t* __restrict
         else
           sec = 0;  // the item's sequence already ended inside the rank: it is alone in its group
       }
-      s_item[r] = i;
       key = ((uint64_t)gl << (32 + TS_LIDX_BITS)) | ((uint64_t)sec << TS_LIDX_BITS) | (uint64_t)r;
     }
     s_key[r] = key;
@@ -177,15 +179,24 @@ COOK_KERNEL void tie_sort_tiles(uint32_t* __restrict__ perm, uint8_t* __restrict
     const uint64_t x = s_key[a], y = s_key[b];
     if ((x > y) == up) s_key[a] = y, s_key[b] = x;
   });
+  constexpr unsigned PER = TS_CAP / TS_THREADS;  // items of a tile per thread
+  uint32_t moved[PER];                          // the items that end up at this thread's positions, read before any position is written
+#pragma unroll
+  for (unsigned q = 0; q < PER; ++q) {
+    const unsigned r = q * TS_THREADS + threadIdx.x;
+    moved[q] = r < len ? perm[lo + ((unsigned)s_key[r] & ((1u << TS_LIDX_BITS) - 1u))] : 0u;
+  }
+  __syncthreads();
   unsigned tied = 0;
-  for (unsigned r0 = 0; r0 < len; r0 += blockDim.x) {  // uniform trip count: the ballot below wants whole waves
-    const unsigned r = r0 + threadIdx.x;
+#pragma unroll
+  for (unsigned q = 0; q < PER; ++q) {  // uniform trip count: the ballot below wants whole waves
+    const unsigned r = q * TS_THREADS + threadIdx.x;
     bool t = false;
     if (r < len) {
       const uint64_t k = s_key[r];
       const bool h = r == 0 || (k >> TS_LIDX_BITS) != (s_key[r - 1] >> TS_LIDX_BITS);
       const bool next_same = r + 1 < len && (s_key[r + 1] >> TS_LIDX_BITS) == (k >> TS_LIDX_BITS);
-      perm[lo + r] = s_item[(unsigned)k & ((1u << TS_LIDX_BITS) - 1u)];
+      perm[lo + r] = moved[q];
       thead[lo + r] = h ? 1 : 0;
       t = !h || next_same;
     }

@@ -171,7 +171,10 @@ class ShardedCluster:
         # the rank parts of all local pools in ONE cook_cycle_run_rank_multi call (one thread, one stream, the same kernel of several pools
         # in one launch) instead of a thread per pool: the stage is bound by the number of launches the host makes
         self.rank_batch = os.environ.get("COOK_RANK_BATCH", "1") != "0"
-        self.rank_batches = int(os.environ.get("COOK_RANK_BATCHES", "1"))
+        # ... in up to four batches of at least two pools, each from a thread of its own (measured on MI355X, eight pools: 1 / 2 / 4 batches =
+        # 2.6 / 2.3 / 2.2 ms of the cycle's rank phase against 3.3 for a thread and a stream per pool: the batched launches are bound by the GPU,
+        # and two or four sequences fill what one leaves idle between dependent kernels — profiles/r05rd_rank_batch.txt)
+        self.rank_batches = int(os.environ.get("COOK_RANK_BATCHES", "4"))
 
     @property
     def last_user_usage(self) -> Optional[np.ndarray]:

@@ -23,7 +23,20 @@ kt() {  # name, command...
   local name=$1; shift
   rm -rf /tmp/kt_$name
   timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt_$name -o kt --output-format csv -- "$@" > "$OUT/bench_under_rocprof_$name.json" 2> "$OUT/kt_$name.err"
-  find /tmp/kt_$name -name '*kernel_stats*' -exec cp {} "$OUT/kernel_stats_$name.csv" \;
+  find /tmp/kt_$name -name '*kernel_stats*' -exec cp {} "$OUT/kernel_stats_$name.raw.csv" \;
+  # the batched path's kernels are instances of ONE template (cook_multi<&kernel, ...>), printed mangled: the inner name in front
+  python - "$OUT/kernel_stats_$name.raw.csv" "$OUT/kernel_stats_$name.csv" "$ROOT/scripts" <<'PY'
+import csv, sys
+sys.path.insert(0, sys.argv[3])
+from kernel_names import short_kernel_name
+rows = list(csv.DictReader(open(sys.argv[1])))
+if rows:
+    w = csv.DictWriter(open(sys.argv[2], "w", newline=""), fieldnames=["Kernel"] + list(rows[0].keys()), quoting=csv.QUOTE_ALL)
+    w.writeheader()
+    for r in rows:
+        w.writerow({"Kernel": short_kernel_name(r["Name"]), **r})
+PY
+  rm -f "$OUT/kernel_stats_$name.raw.csv"
   head -8 "$OUT/kernel_stats_$name.csv" | cut -c1-150
 }
 pmc() {  # name, counters, command...

@@ -21,5 +21,20 @@ print("ms/step", d["ms_per_step"], "value", d["value"], "roofline", {k: d["roofl
 print("phase", d["phase_ms"], "boundary", {k: v for k, v in d["boundary"].items() if k.startswith("update_ms") and k != "update_ms_samples"})
 print("extras", {k: (v.get("p50_cycle_ms") or v.get("p50_cycle_us") or v.get("ms_total")) for k, v in d["extra_configs"].items()})
 PY
+# the rank parts as pool batches against a thread and a stream per pool, at this revision (the cycle, and the reference's default K = 1000)
+for v in "COOK_RANK_BATCHES=4" "COOK_RANK_BATCHES=1" "COOK_RANK_BATCH=0"; do
+  for k in 0 1000; do
+    env $v timeout 200 python bench.py --no-cpu-baseline --no-adjacent --no-extras --no-roofline --steps 30 --warmup 3 --considerable $k > "$OUT/ab.json" 2> "$OUT/ab.err"
+    python - "$v" "$k" "$OUT/ab.json" <<'PY' | tee -a "$OUT/rank_batch.txt"
+import json, sys
+try:
+    d = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+    print(sys.argv[1], "K =", sys.argv[2] if sys.argv[2] != "0" else "all", "ms/cycle %.3f" % d["ms_per_step"], "phase", {k: round(v, 3) for k, v in d["phase_ms"].items()}, "parity", d.get("parity_checked"), "batch", d.get("rank_batch"))
+except Exception as ex:
+    print(sys.argv[1], sys.argv[2], "FAILED", ex)
+PY
+  done
+done
+rm -f "$OUT/ab.json" "$OUT/ab.err"
 ( time timeout 900 python -m pytest tests -m gpu -x -q ) > "$OUT/pytest_gpu.log" 2>&1; tail -4 "$OUT/pytest_gpu.log"
 ( time timeout 600 python scripts/fuzz_sweep.py --guard --match 300 --rebalance 100 --multi 100 --seed 31337 ) > "$OUT/fuzz_gpu.txt" 2>&1; tail -5 "$OUT/fuzz_gpu.txt"

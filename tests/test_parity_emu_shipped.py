@@ -49,3 +49,16 @@ def test_rebalance_users_of_several_tiles(make_engine):
     got = P.rebalance_parity(make_engine, P.make_rebalance_case(seed=34, n_running=6000, n_pending=24, n_users=3, n_hosts=400, fractional=True))
     assert len(got["decisions"]) > 0
     P.rebalance_parity(make_engine, P.make_rebalance_case(seed=35, n_running=3000, n_pending=40, n_users=30, n_hosts=20, constraints=True, gpus=True))
+
+
+def test_rank_tie_tiles_of_several_items_per_thread(make_engine, monkeypatch):
+    """the tie rule's tiles at their shipped size (1 024 threads, up to 8 192 items: a thread moves up to eight items of a tile, read
+    before the first is written — tile_sort.hpp): tie-heavy pools whose groups spill over the nominal stretch, and the same pools with the
+    tie rule as radix passes"""
+    for seed, nu in ((51, 300), (52, 40)):
+        pool = synth.make_pool(seed=seed, n_pending=9000, n_running=3000, n_users=nu, n_offers=16, tie_heavy=True)
+        a = P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=10))
+        monkeypatch.setenv("COOK_RANK_RADIX", "1")
+        b = P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=10))
+        monkeypatch.delenv("COOK_RANK_RADIX")
+        assert np.array_equal(a, b)
