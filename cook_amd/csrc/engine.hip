@@ -2216,6 +2216,7 @@ int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, uint32_t num_co
     return first;
   }
   int flows_rc = COOK_OK;
+  std::vector<std::pair<int, std::string>> flow_err(n, {COOK_OK, std::string()});  // (guarded() clears the lead's message on its way out)
   const int rc = guarded(lead, [&] {
     for (uint32_t i = 0; i < n; ++i) COOK_HIP(hipStreamSynchronize(engines[i]->stream));  // (whatever a call before this one left running)
     PoolBatch b;
@@ -2234,12 +2235,16 @@ int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, uint32_t num_co
     }
     StageTimer tr(lead, 0, &lead->rank_ms);
     flows_rc = batch_run(b);
+    for (uint32_t i = 0; i < n; ++i)
+      if (b.flows[i].rc != COOK_OK) flow_err[i] = {b.flows[i].rc, engines[i]->err};
     tr.stop();
     for (uint32_t i = 1; i < n; ++i) engines[i]->rank_ms = lead->rank_ms;  // one joint sequence of launches
     lead->batch_stats[0] = n, lead->batch_stats[1] = b.launches, lead->batch_stats[2] = b.grouped, lead->batch_stats[3] = b.singles,
     lead->batch_stats[4] = b.syncs;
     prof_collect(lead);
   });
+  for (uint32_t i = 0; i < n; ++i)
+    if (flow_err[i].first != COOK_OK) engines[i]->err = flow_err[i].second;  // every engine whose flow failed keeps its own message
   return rc != COOK_OK ? rc : flows_rc;
 }
 int cook_cycle_match_multi(cook_engine** engines, uint32_t n) {

@@ -594,6 +594,8 @@ def rank_batch_one_flow_fails(make_engine):
             e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
         with _raises(CookError, "before cook_cycle_stage"):
             cycle_run_rank_multi(engines, 10 ** 9)
+        with _raises(CookError, "before cook_cycle_stage"):  # ... also when the failing engine leads the call (its message survives the call's own epilogue)
+            cycle_run_rank_multi(engines[::-1], 10 ** 9)
         cycle_match_multi(engines[:3])
         for e, c in zip(engines, cases):
             ranked, j2o, head = e.cycle_fetch()
