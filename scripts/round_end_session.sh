@@ -36,5 +36,8 @@ PY
   done
 done
 rm -f "$OUT/ab.json" "$OUT/ab.err"
+# the load of ONE rank of an N-GPU job (8 / 4 / 2 / 1 pools of the cluster), on this one GPU: what DESIGN.md 8's scaling prediction rests on
+( echo "scripts/pools_per_gpu.sh at kernel revision $(cat "$OUT/kernel_rev.txt") (bench.py --as-rank-of N: the pools rank 0 of an N-GPU job holds; 6 steps)"; bash scripts/pools_per_gpu.sh ) > "$OUT/pools_per_gpu.txt" 2>&1
+cat "$OUT/pools_per_gpu.txt"
 ( time timeout 900 python -m pytest tests -m gpu -x -q ) > "$OUT/pytest_gpu.log" 2>&1; tail -4 "$OUT/pytest_gpu.log"
 ( time timeout 600 python scripts/fuzz_sweep.py --guard --match 300 --rebalance 100 --multi 100 --seed 31337 ) > "$OUT/fuzz_gpu.txt" 2>&1; tail -5 "$OUT/fuzz_gpu.txt"
