@@ -359,20 +359,21 @@ JNIEXPORT jint JNICALL Java_cook_hip_Native_cycleRunRank(JNIEnv* env, jclass c, 
  * several pools in one launch): quotas = direct buffer of n cook_pool_quota, or NULL when no pool has one; a pool without quota inputs
  * carries has_pool_quota = has_group_quota = 0 in its entry */
 JNIEXPORT jint JNICALL Java_cook_hip_Native_cycleRunRankMulti(JNIEnv* env, jclass c, jobject handles /* direct buffer of n jlong */, jint n,
-                                                              jobject quotas, jint num_considerable) {
+                                                              jobject quotas, jobject num_considerable /* direct buffer of n jint: every pool its own K */) {
   cook_engine* es[64];
   int bad = 0, rc;
   const int64_t* hs = BUFN(const int64_t, handles, n > 0 ? n : 0);
   const cook_pool_quota* qs = BUFN(const cook_pool_quota, quotas, n > 0 ? n : 0);
+  const uint32_t* ks = BUFN(const uint32_t, num_considerable, n > 0 ? n : 0);
   jint i;
   (void)c;
-  if (bad || !hs || n <= 0 || n > 64) return COOK_E_INVALID;
+  if (bad || !hs || !ks || n <= 0 || n > 64) return COOK_E_INVALID;
   for (i = 0; i < n; ++i) {
     es[i] = H(hs[i]);
     rc = cook_rank_set_quota(es[i], qs ? &qs[i] : 0);
     if (rc) return rc;
   }
-  return cook_cycle_run_rank_multi(es, (uint32_t)n, (uint32_t)num_considerable, 0, 0);
+  return cook_cycle_run_rank_multi(es, (uint32_t)n, ks, 0, 0);
 }
 JNIEXPORT jint JNICALL Java_cook_hip_Native_cycleMatchMulti(JNIEnv* env, jclass c, jobject handles /* direct buffer of n jlong */, jint n) {
   cook_engine* es[64];

@@ -87,19 +87,24 @@ void cons_run_device(cook_engine* e, ConsBufs& c, unsigned n, const double* q_cp
   c.inexact.ensure(std::max(1u, U));
   c.pre.ensure(n);
   memset_async(e, c.inexact.ptr(), 0, (size_t)std::max(1u, U) * 4);
-  KM<cons_gather, 256>(e, "cons_gather", gN, permU, n, q_user, q_cpus, q_mem, q_gpus, c.g_user.ptr(), c.g_use.ptr(), c.head.ptr(), c.seg_start.ptr(), c.seg_end.ptr());
+  KM<cons_gather, 256>(e, "cons_gather", gN, permU, n, q_user, q_cpus, q_mem, q_gpus, c.g_user.ptr(), c.g_use.ptr(), c.head.ptr(), c.seg_start.ptr(),
+      c.seg_end.ptr());
   // ---- (i) per-user quota filter, seeded with the users' running usage (tools.clj:903-915) -------------------------------
   LoadUserSeeded ld{c.g_use.ptr(), c.head.ptr(), c.g_user.ptr(), c.ucount.ptr(), c.ucpus.ptr(), c.umem.ptr(), c.ugpus.ptr()};
   seg_scan<SumU4>(e, "cons_user_usage_scan", ld, (const uint8_t*)c.head.ptr(), n, c.pre.ptr(), e->tmpU4);
   KM<rank_mark_inexact, 256>(e, "rank_mark_inexact", gN, (const SumU4*)c.pre.ptr(), (const uint32_t*)c.g_user.ptr(), n, c.inexact.ptr());
-  KM<cons_fix_inexact, 256>(e, "cons_fix_inexact", div_up(std::max(1u, U), 256), (const SumU4*)c.g_use.ptr(), c.pre.ptr(), (const uint32_t*)c.seg_start.ptr(), (const uint32_t*)c.seg_end.ptr(), (const uint32_t*)c.inexact.ptr(), U, (const double*)c.ucount.ptr(), (const double*)c.ucpus.ptr(), (const double*)c.umem.ptr(), (const double*)c.ugpus.ptr());
+  KM<cons_fix_inexact, 256>(e, "cons_fix_inexact", div_up(std::max(1u, U), 256), (const SumU4*)c.g_use.ptr(), c.pre.ptr(),
+      (const uint32_t*)c.seg_start.ptr(), (const uint32_t*)c.seg_end.ptr(), (const uint32_t*)c.inexact.ptr(), U, (const double*)c.ucount.ptr(),
+      (const double*)c.ucpus.ptr(), (const double*)c.umem.ptr(), (const double*)c.ugpus.ptr());
   c.flag1.ensure(n);
   c.keep_q.ensure(n);
   c.scan.ensure(n);
-  KM<cons_user_quota_flag, 256>(e, "cons_user_quota_flag", gN, (const SumU4*)c.pre.ptr(), (const uint32_t*)c.g_user.ptr(), n, (const double*)c.qcount.ptr(), (const double*)c.qcpus.ptr(), (const double*)c.qmem.ptr(), (const double*)c.qgpus.ptr(), c.flag1.ptr());
+  KM<cons_user_quota_flag, 256>(e, "cons_user_quota_flag", gN, (const SumU4*)c.pre.ptr(), (const uint32_t*)c.g_user.ptr(), n,
+      (const double*)c.qcount.ptr(), (const double*)c.qcpus.ptr(), (const double*)c.qmem.ptr(), (const double*)c.qgpus.ptr(), c.flag1.ptr());
   // ---- (ii) launch-rate limit: index of the job among its user's survivors (tools.clj:935-955) -----------------------------
   seg_scan<SumI>(e, "cons_user_index_scan", LoadI{c.flag1.ptr()}, (const uint8_t*)c.head.ptr(), n, c.scan.ptr(), e->tmpI);
-  KM<cons_rate_limit, 256>(e, "cons_rate_limit", gN, (const int*)c.flag1.ptr(), (const SumI*)c.scan.ptr(), (const uint32_t*)c.g_user.ptr(), permU, n, c.has_tokens ? (const int64_t*)c.tokens.ptr() : (const int64_t*)nullptr, c.enforce, c.keep_q.ptr(), c.rate_limited.ptr(), c.passed.ptr());
+  KM<cons_rate_limit, 256>(e, "cons_rate_limit", gN, (const int*)c.flag1.ptr(), (const SumI*)c.scan.ptr(), (const uint32_t*)c.g_user.ptr(), permU, n,
+      c.has_tokens ? (const int64_t*)c.tokens.ptr() : (const int64_t*)nullptr, c.enforce, c.keep_q.ptr(), c.rate_limited.ptr(), c.passed.ptr());
   // ---- survivors back in queue order ---------------------------------------------------------------------------------------------
   uint32_t* qitem = c.qitemA.ensure(n);
   uint32_t* qitem_o = c.qitemB.ensure(n);
@@ -114,7 +119,8 @@ void cons_run_device(cook_engine* e, ConsBufs& c, unsigned n, const double* q_cp
   if (c.has_pool_quota && !c.pool_usage_given) {
     c.pusage.ensure(1);
     if (U) {
-      KM<cons_pool_usage, 1024>(e, "cons_pool_usage", 1, (const double*)c.ucount.ptr(), (const double*)c.ucpus.ptr(), (const double*)c.umem.ptr(), (const double*)c.ugpus.ptr(), U, c.pusage.ptr());
+      KM<cons_pool_usage, 1024>(e, "cons_pool_usage", 1, (const double*)c.ucount.ptr(), (const double*)c.ucpus.ptr(), (const double*)c.umem.ptr(),
+          (const double*)c.ugpus.ptr(), U, c.pusage.ptr());
       pinned_copy(e, e->h_scratch + 8, c.pusage.ptr(), sizeof(SumU4), hipMemcpyDeviceToHost);
     }
   }
@@ -135,7 +141,8 @@ void cons_run_device(cook_engine* e, ConsBufs& c, unsigned n, const double* q_cp
     KM<cons_eligible_flag, 256>(e, "cons_eligible_flag", div_up(len, 256), (const uint32_t*)qitem, len, q_elig, e->iflag.ptr());
     seg_scan<SumI>(e, "queue_compact_scan", LoadI{e->iflag.ptr()}, (const uint8_t*)nullptr, len, e->scanI.ptr(), e->tmpI);
     unsigned* len_out = e->d_counters.ptr() + 9;
-    KM<queue_compact, 256>(e, "queue_compact", div_up(len, 256), (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(), (const SumI*)e->scanI.ptr(), len, qitem_o, quse_o, len_out);
+    KM<queue_compact, 256>(e, "queue_compact", div_up(len, 256), (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(),
+        (const SumI*)e->scanI.ptr(), len, qitem_o, quse_o, len_out);
     pinned_copy(e, e->h_scratch, len_out, 4, hipMemcpyDeviceToHost);
     sync(e);
     std::memcpy(&len, e->h_scratch, 4);

@@ -184,7 +184,8 @@ struct cook_engine {
   ScanTmp<SumI> tmpI;
   uint32_t* permB = nullptr;  // final per-user order (points into permA or permB2)
   uint32_t* permC = nullptr;  // final global order
-  unsigned batch_stats[5] = {0, 0, 0, 0, 0};  // the last cook_cycle_run_rank_multi led by this engine: pools, launches, of them for several pools, operations issued alone, synchronisations
+  // the last cook_cycle_run_rank_multi led by this engine: pools, launches, of them for several pools, operations issued alone, synchronisations
+  unsigned batch_stats[5] = {0, 0, 0, 0, 0};
   DArr<uint32_t> permC1, permC2;
   unsigned n_ranked = 0;
 
@@ -738,8 +739,12 @@ void rank_pool_usage(cook_engine* e, cook_usage* out) {
     return;
   }
   e->pool_usage.ensure(1 + POOL_USAGE_BLOCKS);
-  KM<pool_usage_partial, 256>(e, "pool_usage_partial", POOL_USAGE_BLOCKS, (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(), e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->N, e->pool_usage.ptr() + 1, (unsigned)POOL_USAGE_BLOCKS);
-  KM<pool_usage_reduce, COOK_WAVE>(e, "pool_usage_reduce", 1, (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(), e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->N, (const SumU4*)(e->pool_usage.ptr() + 1), (unsigned)POOL_USAGE_BLOCKS, e->pool_usage.ptr());
+  KM<pool_usage_partial, 256>(e, "pool_usage_partial", POOL_USAGE_BLOCKS, (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(),
+      e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->N, e->pool_usage.ptr() + 1,
+      (unsigned)POOL_USAGE_BLOCKS);
+  KM<pool_usage_reduce, COOK_WAVE>(e, "pool_usage_reduce", 1, (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(),
+      e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->N,
+      (const SumU4*)(e->pool_usage.ptr() + 1), (unsigned)POOL_USAGE_BLOCKS, e->pool_usage.ptr());
   SumU4 h;
   pinned_copy(e, e->h_scratch, e->pool_usage.ptr(), sizeof(SumU4), hipMemcpyDeviceToHost);
   sync(e);
@@ -760,7 +765,8 @@ void rank_user_usage(cook_engine* e, double* out, bool out_is_device) {
     SumU4* rp = e->uu_pre.ensure(N);
     seg_scan<SumU4>(e, "user_running_scan", LoadRunningU4{e->s_use.ptr(), e->s_pending.ptr()}, (const uint8_t*)e->head.ptr(), N, rp,
                     e->tmpU4);
-    KM<user_usage_extract, 256>(e, "user_usage_extract", div_up(U, 256), (const SumU4*)rp, (const SumU4*)e->s_use.ptr(), (const uint8_t*)e->s_pending.ptr(), (const uint32_t*)e->seg_start.ptr(), (const uint32_t*)e->seg_end.ptr(), U, dst);
+    KM<user_usage_extract, 256>(e, "user_usage_extract", div_up(U, 256), (const SumU4*)rp, (const SumU4*)e->s_use.ptr(),
+        (const uint8_t*)e->s_pending.ptr(), (const uint32_t*)e->seg_start.ptr(), (const uint32_t*)e->seg_end.ptr(), U, dst);
   } else {
     memset_async(e, dst, 0, (size_t)U * 24);
   }
@@ -783,10 +789,12 @@ unsigned queue_filter_quota(cook_engine* e, unsigned stage, unsigned len, const 
   if (stage >= 2) memset_async(e, any_bad, 0, 8);
   Usage4 q{quota.count, quota.cpus, quota.mem, quota.gpus};
   KM<queue_quota_flag, 256>(e, "queue_quota_flag", div_up(len, 256), (const SumU4*)e->qpre.ptr(), len, q, e->iflag.ptr(), any_bad);
-  KM<queue_quota_fix, 64>(e, "queue_quota_fix", 1, (const SumU4*)quse, len, SumU4{base.count, base.cpus, base.mem, base.gpus, 0u}, q, (const unsigned*)any_bad, e->iflag.ptr());
+  KM<queue_quota_fix, 64>(e, "queue_quota_fix", 1, (const SumU4*)quse, len, SumU4{base.count, base.cpus, base.mem, base.gpus, 0u}, q,
+      (const unsigned*)any_bad, e->iflag.ptr());
   seg_scan<SumI>(e, "queue_compact_scan", LoadI{e->iflag.ptr()}, (const uint8_t*)nullptr, len, e->scanI.ptr(), e->tmpI);
   unsigned* len_out = any_bad + 1;
-  KM<queue_compact, 256>(e, "queue_compact", div_up(len, 256), (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(), (const SumI*)e->scanI.ptr(), len, qitem_other, quse_other, len_out);
+  KM<queue_compact, 256>(e, "queue_compact", div_up(len, 256), (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(),
+      (const SumI*)e->scanI.ptr(), len, qitem_other, quse_other, len_out);
   unsigned h[2];
   pinned_copy(e, e->h_scratch, len_out, 4, hipMemcpyDeviceToHost);
   sync(e);
@@ -820,12 +828,17 @@ void rank_run(cook_engine* e) {
   e->inexact_user.ensure(U);
   TieCtl* tie_ctl0 = e->tie_ctl.ensure(1);
   bool tie_ctl_clean = true;  // until the first refinement has used it
-  KM<rank_init, 256>(e, "rank_init", std::max(1u, std::min(div_up(U, 256), 64u)), e->d_scratch64.ptr(), e->d_counters.ptr(), 40u, e->inexact_user.ptr(), e->seg_end.ptr(), U, reinterpret_cast<unsigned*>(tie_ctl0), (unsigned)(sizeof(TieCtl) / 4), std::max(1u, std::min(div_up(U, 256), 64u)));
+  KM<rank_init, 256>(e, "rank_init", std::max(1u, std::min(div_up(U, 256), 64u)), e->d_scratch64.ptr(), e->d_counters.ptr(), 40u,
+      e->inexact_user.ptr(), e->seg_end.ptr(), U, reinterpret_cast<unsigned*>(tie_ctl0), (unsigned)(sizeof(TieCtl) / 4), std::max(1u,
+      std::min(div_up(U, 256), 64u)));
   e->w0.ensure(N);
   e->w1.ensure(N);
   e->w2.ensure(N);
-  KM<rank_key_mins, 256>(e, "rank_key_mins", std::min(gN, 64u), (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(), (const int64_t*)e->t_job.ptr(), (const uint8_t*)e->t_pending.ptr(), N, mins, std::min(gN, 64u));
-  KM<rank_build_keys, 256>(e, "rank_build_keys", gN, (const uint32_t*)e->t_user.ptr(), (const int32_t*)e->t_prio.ptr(), (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(), (const int64_t*)e->t_job.ptr(), (const uint8_t*)e->t_pending.ptr(), N, (const unsigned long long*)mins, e->w0.ptr(), e->w1.ptr(), e->w2.ptr(), same);
+  KM<rank_key_mins, 256>(e, "rank_key_mins", std::min(gN, 64u), (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(),
+      (const int64_t*)e->t_job.ptr(), (const uint8_t*)e->t_pending.ptr(), N, mins, std::min(gN, 64u));
+  KM<rank_build_keys, 256>(e, "rank_build_keys", gN, (const uint32_t*)e->t_user.ptr(), (const int32_t*)e->t_prio.ptr(),
+      (const int64_t*)e->t_start.ptr(), (const int64_t*)e->t_task.ptr(), (const int64_t*)e->t_job.ptr(), (const uint8_t*)e->t_pending.ptr(), N,
+      (const unsigned long long*)mins, e->w0.ptr(), e->w1.ptr(), e->w2.ptr(), same);
   readback64(e, 8);
   const unsigned long long mk0 = ~e->h_scratch[4], mk1 = ~e->h_scratch[5], mk2 = ~e->h_scratch[6];
   e->permA.ensure(N);
@@ -850,20 +863,26 @@ void rank_run(cook_engine* e) {
   e->seg_start.ensure(U);
   e->seg_end.ensure(U);
   e->pre.ensure(N);
-  KM<rank_gather, 256>(e, "rank_gather", gN, (const uint32_t*)e->permB, N, (const uint32_t*)e->t_user.ptr(), (const double*)e->t_cpus.ptr(), (const double*)e->t_mem.ptr(), e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(), e->s_user.ptr(), e->s_use.ptr(), e->s_pending.ptr(), e->head.ptr(), e->seg_start.ptr(), e->seg_end.ptr());
+  KM<rank_gather, 256>(e, "rank_gather", gN, (const uint32_t*)e->permB, N, (const uint32_t*)e->t_user.ptr(), (const double*)e->t_cpus.ptr(),
+      (const double*)e->t_mem.ptr(), e->has_gpus ? (const double*)e->t_gpus.ptr() : (const double*)nullptr, (const uint8_t*)e->t_pending.ptr(),
+      e->s_user.ptr(), e->s_use.ptr(), e->s_pending.ptr(), e->head.ptr(), e->seg_start.ptr(), e->seg_end.ptr());
   seg_scan<SumU4>(e, "user_usage_scan", LoadU4{e->s_use.ptr()}, (const uint8_t*)e->head.ptr(), N, e->pre.ptr(), e->tmpU4);
   KM<rank_mark_inexact, 256>(e, "rank_mark_inexact", gN, (const SumU4*)e->pre.ptr(), (const uint32_t*)e->s_user.ptr(), N, e->inexact_user.ptr());
-  KM<rank_fix_inexact, 256>(e, "rank_fix_inexact", div_up(U, 256), (const SumU4*)e->s_use.ptr(), e->pre.ptr(), (const uint32_t*)e->seg_start.ptr(), (const uint32_t*)e->seg_end.ptr(), (const uint32_t*)e->inexact_user.ptr(), U);
+  KM<rank_fix_inexact, 256>(e, "rank_fix_inexact", div_up(U, 256), (const SumU4*)e->s_use.ptr(), e->pre.ptr(), (const uint32_t*)e->seg_start.ptr(),
+      (const uint32_t*)e->seg_end.ptr(), (const uint32_t*)e->inexact_user.ptr(), U);
   // --- limiter + DRU ---------------------------------------------------------------------------------------
   e->iflag.ensure(N);
   e->scanI.ensure(N);
-  KM<rank_over_flag, 256>(e, "rank_over_flag", gN, (const SumU4*)e->pre.ptr(), (const uint32_t*)e->s_user.ptr(), N, (const double*)e->u_qcount.ptr(), (const double*)e->u_qcpus.ptr(), (const double*)e->u_qmem.ptr(), (const double*)e->u_qgpus.ptr(), e->iflag.ptr());
+  KM<rank_over_flag, 256>(e, "rank_over_flag", gN, (const SumU4*)e->pre.ptr(), (const uint32_t*)e->s_user.ptr(), N, (const double*)e->u_qcount.ptr(),
+      (const double*)e->u_qcpus.ptr(), (const double*)e->u_qmem.ptr(), (const double*)e->u_qgpus.ptr(), e->iflag.ptr());
   seg_scan<SumI>(e, "over_quota_scan", LoadI{e->iflag.ptr()}, (const uint8_t*)e->head.ptr(), N, e->scanI.ptr(), e->tmpI);
   e->dru.ensure(N);
   e->dkey.ensure(N);
   e->keep.ensure(N);
   unsigned long long* orand = reinterpret_cast<unsigned long long*>(counters + 8);  // [0] OR of the kept keys, [1] OR of their complements
-  KM<rank_score, 256>(e, "rank_score", gN, (const SumU4*)e->pre.ptr(), (const SumI*)e->scanI.ptr(), (const uint32_t*)e->s_user.ptr(), N, (int)e->params.max_over_quota_jobs, (int)e->params.dru_mode, (const double*)e->u_divc.ptr(), (const double*)e->u_divm.ptr(), (const double*)e->u_divg.ptr(), e->dru.ptr(), e->dkey.ptr(), e->keep.ptr(), counters, orand);
+  KM<rank_score, 256>(e, "rank_score", gN, (const SumU4*)e->pre.ptr(), (const SumI*)e->scanI.ptr(), (const uint32_t*)e->s_user.ptr(), N,
+      (int)e->params.max_over_quota_jobs, (int)e->params.dru_mode, (const double*)e->u_divc.ptr(), (const double*)e->u_divm.ptr(),
+      (const double*)e->u_divg.ptr(), e->dru.ptr(), e->dkey.ptr(), e->keep.ptr(), counters, orand);
   pinned_copy(e, e->h_scratch, counters, 12 * 4, hipMemcpyDeviceToHost);  // the counts and, behind them, the two key words
   sync(e);
   vor = e->h_scratch[4], vand = ~e->h_scratch[5];
@@ -914,7 +933,8 @@ void rank_run(cook_engine* e) {
       for (int round = 0;; ++round) {
         seg_scan<SumI>(e, "tie_group_scan", LoadI{ones}, (const uint8_t*)e->thead.ptr(), nk, e->scanI.ptr(), e->tmpI);
         memset_async(e, counters + 2, 0, 4);
-        KM<tie_assign, 256>(e, "tie_assign", gK, (const uint32_t*)perm, (const uint8_t*)e->thead.ptr(), (const SumI*)e->scanI.ptr(), nk, U, e->rank_of_item.ptr(), e->gstart.ptr(), tied, counters + 2);
+        KM<tie_assign, 256>(e, "tie_assign", gK, (const uint32_t*)perm, (const uint8_t*)e->thead.ptr(), (const SumI*)e->scanI.ptr(), nk, U,
+            e->rank_of_item.ptr(), e->gstart.ptr(), tied, counters + 2);
         unsigned h3[3];
         readback_counters(e, h3, 3);
         if (h3[1]) return false;
@@ -929,10 +949,13 @@ void rank_run(cook_engine* e) {
         e->tsorted.ensure(n_tied);
         e->tsorted2.ensure(n_tied);
         seg_scan<SumI>(e, "tie_compact_scan", LoadI{tied}, (const uint8_t*)nullptr, nk, e->scanI.ptr(), e->tmpI);
-        KM<tie_build, 256>(e, "tie_build", gK, (const uint32_t*)perm, (const int*)tied, (const SumI*)e->scanI.ptr(), (const uint32_t*)e->gstart.ptr(), nk, U, n_items, round, bits, (const uint32_t*)e->rank_of_item.ptr(), user_of, seg_first, e->tpos.ptr(), e->titem.ptr(), e->ckey.ptr());
+        KM<tie_build, 256>(e, "tie_build", gK, (const uint32_t*)perm, (const int*)tied, (const SumI*)e->scanI.ptr(),
+            (const uint32_t*)e->gstart.ptr(), nk, U, n_items, round, bits, (const uint32_t*)e->rank_of_item.ptr(), user_of, seg_first, e->tpos.ptr(),
+            e->titem.ptr(), e->ckey.ptr());
         KM<iota_u32, 256>(e, "iota", div_up(n_tied, 256), e->tsorted.ptr(), n_tied);
         uint32_t* ts = radix_sort_masked(e, e->ckey.ptr(), cmask, e->tsorted.ptr(), e->tsorted.ptr(), e->tsorted2.ptr(), n_tied);
-        KM<tie_writeback, 256>(e, "tie_writeback", div_up(n_tied, 256), (const uint32_t*)ts, (const uint32_t*)e->tpos.ptr(), (const uint32_t*)e->titem.ptr(), (const uint64_t*)e->ckey.ptr(), n_tied, perm, e->thead.ptr());
+        KM<tie_writeback, 256>(e, "tie_writeback", div_up(n_tied, 256), (const uint32_t*)ts, (const uint32_t*)e->tpos.ptr(),
+            (const uint32_t*)e->titem.ptr(), (const uint64_t*)e->ckey.ptr(), n_tied, perm, e->thead.ptr());
       }
       return true;
     };
@@ -953,8 +976,10 @@ void rank_run(cook_engine* e) {
       constexpr int LOOK = 4;
       for (int r0 = 0; r0 < 32; r0 += LOOK) {
         for (int round = r0; round < r0 + LOOK; ++round) {
-          KM<tie_rank_assign, 256>(e, "tie_rank_assign", gK, (const uint32_t*)perm, (const uint8_t*)e->thead.ptr(), nk, U, round, (const TieCtl*)ctl, e->rank_of_item.ptr());
-          KM<tie_sort_tiles, TS_THREADS>(e, "tie_sort_tiles", div_up(nk, TS_NOMINAL), perm, e->thead.ptr(), (const uint8_t*)e->dhead.ptr(), nk, U, n_items, round, (const uint32_t*)e->rank_of_item.ptr(), user_of, seg_first, ctl);
+          KM<tie_rank_assign, 256>(e, "tie_rank_assign", gK, (const uint32_t*)perm, (const uint8_t*)e->thead.ptr(), nk, U, round, (const TieCtl*)ctl,
+              e->rank_of_item.ptr());
+          KM<tie_sort_tiles, TS_THREADS>(e, "tie_sort_tiles", div_up(nk, TS_NOMINAL), perm, e->thead.ptr(), (const uint8_t*)e->dhead.ptr(), nk, U,
+              n_items, round, (const uint32_t*)e->rank_of_item.ptr(), user_of, seg_first, ctl);
         }
         TieCtl h;
         pinned_copy(e, e->h_scratch, ctl, sizeof(TieCtl), hipMemcpyDeviceToHost);
@@ -975,7 +1000,8 @@ void rank_run(cook_engine* e) {
       int* isf = e->run_isf.ensure(N);
       int* nonf = e->run_nonf.ensure(N);
       SumI* nonf_incl = e->run_scan.ensure(N);
-      KM<run_follower_flag, 256>(e, "run_follower_flag", gN, (const uint32_t*)e->s_user.ptr(), (const uint64_t*)e->dkey.ptr(), (const uint8_t*)e->keep.ptr(), N, isf, nonf);
+      KM<run_follower_flag, 256>(e, "run_follower_flag", gN, (const uint32_t*)e->s_user.ptr(), (const uint64_t*)e->dkey.ptr(),
+          (const uint8_t*)e->keep.ptr(), N, isf, nonf);
       seg_scan<SumI>(e, "run_scan", LoadI{nonf}, (const uint8_t*)nullptr, N, nonf_incl, e->tmpI);
       pinned_copy(e, e->h_scratch, &nonf_incl[N - 1], 4, hipMemcpyDeviceToHost);
       sync(e);
@@ -987,14 +1013,16 @@ void rank_run(cook_engine* e) {
       uint32_t* c_orig = e->run_orig.ensure(N2 + 1);
       uint32_t* c_seg = e->run_seg.ensure(U);
       uint32_t* b_to_c = e->run_b2c.ensure(N);
-      KM<run_compact_items, 256>(e, "run_compact_items", gN, (const int*)nonf, (const SumI*)nonf_incl, N, (const uint32_t*)e->s_user.ptr(), (const uint64_t*)e->dkey.ptr(), (const uint8_t*)e->head.ptr(), c_user, c_dkey, c_orig, c_seg, b_to_c);
+      KM<run_compact_items, 256>(e, "run_compact_items", gN, (const int*)nonf, (const SumI*)nonf_incl, N, (const uint32_t*)e->s_user.ptr(),
+          (const uint64_t*)e->dkey.ptr(), (const uint8_t*)e->head.ptr(), c_user, c_dkey, c_orig, c_seg, b_to_c);
       KM<run_compact_sentinel, 1>(e, "run_compact_sentinel", 1, (const SumI*)nonf_incl, N, c_orig);
       int* posf = e->run_posf.ensure(n_kept);
       SumI* posf_incl = e->run_scan2.ensure(n_kept);
       KM<run_flag_positions, 256>(e, "run_flag_positions", gK, (const uint32_t*)e->permC, (const int*)isf, n_kept, posf);
       seg_scan<SumI>(e, "run_scan", LoadI{posf}, (const uint8_t*)nullptr, n_kept, posf_incl, e->tmpI);
       uint32_t* perm2 = e->run_perm.ensure(n_kept2);
-      KM<run_compact_positions, 256>(e, "run_compact_positions", gK, (const uint32_t*)e->permC, (const int*)posf, (const SumI*)posf_incl, n_kept, (const uint32_t*)b_to_c, perm2);
+      KM<run_compact_positions, 256>(e, "run_compact_positions", gK, (const uint32_t*)e->permC, (const int*)posf, (const SumI*)posf_incl, n_kept,
+          (const uint32_t*)b_to_c, perm2);
       if (!tie_refine(perm2, c_dkey, c_user, c_seg, n_kept2, N2)) e->fail(COOK_E_STATE, "cook_rank: equal-DRU runs survived the collapse");
       const unsigned gK2 = div_up(n_kept2, 256);
       KM<run_count_followers, 256>(e, "run_count_followers", gK2, (const uint32_t*)perm2, (const uint32_t*)c_orig, n_kept2, posf);
@@ -1006,7 +1034,8 @@ void rank_run(cook_engine* e) {
     KM<queue_flag_pending, 256>(e, "queue_flag_pending", gK, (const uint32_t*)e->permC, (const uint8_t*)e->s_pending.ptr(), n_kept, flag);
     seg_scan<SumI>(e, "queue_pending_scan", LoadI{flag}, (const uint8_t*)nullptr, n_kept, e->scanI.ptr(), e->tmpI);
     unsigned* dq = e->d_counters.ptr() + 38;  // (zeroed by rank_init)
-    KM<queue_compact_pending, 256>(e, "queue_compact_pending", gK, (const uint32_t*)e->permC, (const int*)flag, (const SumI*)e->scanI.ptr(), n_kept, (const SumU4*)e->s_use.ptr(), qitem, quse, dq);
+    KM<queue_compact_pending, 256>(e, "queue_compact_pending", gK, (const uint32_t*)e->permC, (const int*)flag, (const SumI*)e->scanI.ptr(), n_kept,
+        (const SumU4*)e->s_use.ptr(), qitem, quse, dq);
     pinned_copy(e, e->h_scratch, dq, 4, hipMemcpyDeviceToHost);
     sync(e);
     std::memcpy(&qlen, e->h_scratch, 4);
@@ -1024,10 +1053,12 @@ void rank_run(cook_engine* e) {
   if (qlen && offensive_on) {
     e->iflag.ensure(qlen);
     e->scanI.ensure(qlen);
-    KM<queue_offensive_flag, 256>(e, "queue_offensive_flag", div_up(qlen, 256), (const SumU4*)quse, qlen, e->params.offensive_max_mem_mb, e->params.offensive_max_cpus, e->iflag.ptr());
+    KM<queue_offensive_flag, 256>(e, "queue_offensive_flag", div_up(qlen, 256), (const SumU4*)quse, qlen, e->params.offensive_max_mem_mb,
+        e->params.offensive_max_cpus, e->iflag.ptr());
     seg_scan<SumI>(e, "queue_compact_scan", LoadI{e->iflag.ptr()}, (const uint8_t*)nullptr, qlen, e->scanI.ptr(), e->tmpI);
     unsigned* len_out = e->d_counters.ptr() + 9;
-    KM<queue_compact, 256>(e, "queue_compact", div_up(qlen, 256), (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(), (const SumI*)e->scanI.ptr(), qlen, qitem_o, quse_o, len_out);
+    KM<queue_compact, 256>(e, "queue_compact", div_up(qlen, 256), (const uint32_t*)qitem, (const SumU4*)quse, (const int*)e->iflag.ptr(),
+        (const SumI*)e->scanI.ptr(), qlen, qitem_o, quse_o, len_out);
     pinned_copy(e, e->h_scratch, len_out, 4, hipMemcpyDeviceToHost);
     sync(e);
     std::memcpy(&qlen, e->h_scratch, 4);
@@ -1052,7 +1083,8 @@ void rank_fetch(cook_engine* e, uint32_t* ranked, uint32_t* n_out, double* dru_o
     copy_async(e, ranked, e->ranked.ptr(), (size_t)e->n_ranked * 4, hipMemcpyDeviceToHost);
   if (dru_of_task && e->N) {
     e->dru_out.ensure(e->N);
-    KM<dru_to_task_space, 256>(e, "dru_to_task_space", div_up(e->N, 256), (const double*)e->dru.ptr(), (const uint8_t*)e->keep.ptr(), (const uint32_t*)e->permB, e->N, e->dru_out.ptr());
+    KM<dru_to_task_space, 256>(e, "dru_to_task_space", div_up(e->N, 256), (const double*)e->dru.ptr(), (const uint8_t*)e->keep.ptr(),
+        (const uint32_t*)e->permB, e->N, e->dru_out.ptr());
     copy_async(e, dru_of_task, e->dru_out.ptr(), (size_t)e->N * 8, hipMemcpyDeviceToHost);
   }
   sync(e);
@@ -2143,12 +2175,16 @@ static unsigned cycle_rank_part(cook_engine* e, uint32_t num_considerable) {
     const unsigned n = e->n_ranked;
     c.q_cpus.ensure(n), c.q_mem.ensure(n), c.q_gpus.ensure(n), c.q_user.ensure(n), c.q_elig.ensure(n);
     if (n)
-      KM<cons_gather_queue, 256>(e, "cons_gather_queue", div_up(n, 256), (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(), n, e->min.j_cpus, e->min.j_mem, e->min.j_gpus, (const uint32_t*)e->j_user.ptr(), c.has_elig_by_pending ? (const uint8_t*)c.elig_by_pending.ptr() : (const uint8_t*)nullptr, c.q_cpus.ptr(), c.q_mem.ptr(), c.q_gpus.ptr(), c.q_user.ptr(), c.q_elig.ptr());
+      KM<cons_gather_queue, 256>(e, "cons_gather_queue", div_up(n, 256), (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(), n,
+          e->min.j_cpus, e->min.j_mem, e->min.j_gpus, (const uint32_t*)e->j_user.ptr(),
+          c.has_elig_by_pending ? (const uint8_t*)c.elig_by_pending.ptr() : (const uint8_t*)nullptr, c.q_cpus.ptr(), c.q_mem.ptr(), c.q_gpus.ptr(),
+          c.q_user.ptr(), c.q_elig.ptr());
     cons_run_device(e, c, n, c.q_cpus.ptr(), c.q_mem.ptr(), c.q_gpus.ptr(), c.q_user.ptr(), c.q_elig.ptr(), num_considerable);
     K = c.n_result;
     e->j_index.ensure(K);
     if (K)
-      KM<cons_job_index, 256>(e, "cons_job_index", div_up(K, 256), (const uint32_t*)c.result, (const uint32_t*)e->ranked.ptr(), (const uint32_t*)e->pend_ord.ptr(), K, e->j_index.ptr());
+      KM<cons_job_index, 256>(e, "cons_job_index", div_up(K, 256), (const uint32_t*)c.result, (const uint32_t*)e->ranked.ptr(),
+          (const uint32_t*)e->pend_ord.ptr(), K, e->j_index.ptr());
   } else {
     e->j_index.ensure(K);
     if (K)
@@ -2199,8 +2235,8 @@ int cook_cycle_run_rank(cook_engine* e, uint32_t num_considerable) {
 }
 // the rank part of a cycle for every pool of a GPU: one flow per pool in a pool batch (above)
 static const bool g_rank_batch = env_switch_on_unless_zero("COOK_RANK_BATCH");
-int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, uint32_t num_considerable, double* const* user_usage, int usage_is_device) {
-  if (!engines || n == 0) return COOK_E_INVALID;
+int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, const uint32_t* num_considerable, double* const* user_usage, int usage_is_device) {
+  if (!engines || n == 0 || !num_considerable) return COOK_E_INVALID;
   for (uint32_t i = 0; i < n; ++i)
     if (!engines[i] || (user_usage && !user_usage[i])) return COOK_E_INVALID;
   cook_engine* lead = engines[0];
@@ -2209,7 +2245,7 @@ int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, uint32_t num_co
   if (n == 1 || !g_rank_batch || !same_device || g_sync_trace || tl_flow) {
     int first = COOK_OK;
     for (uint32_t i = 0; i < n; ++i) {
-      int rc = cook_cycle_run_rank(engines[i], num_considerable);
+      int rc = cook_cycle_run_rank(engines[i], num_considerable[i]);
       if (rc == COOK_OK && user_usage) rc = cook_rank_user_usage(engines[i], user_usage[i], usage_is_device);
       if (rc != COOK_OK && first == COOK_OK) first = rc;
     }
@@ -2226,9 +2262,10 @@ int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, uint32_t num_co
     for (uint32_t i = 0; i < n; ++i) {
       cook_engine* e = engines[i];
       double* uu = user_usage ? user_usage[i] : nullptr;
+      const uint32_t nc = num_considerable[i];
       b.flows[i].e = e;
-      b.flows[i].body = [e, num_considerable, uu, usage_is_device] {
-        const unsigned K = cycle_rank_part(e, num_considerable);
+      b.flows[i].body = [e, nc, uu, usage_is_device] {
+        const unsigned K = cycle_rank_part(e, nc);
         if (uu) rank_user_usage(e, uu, usage_is_device != 0);
         match_run_device(e, K, K ? e->j_index.ptr() : nullptr, /*defer=*/true);
       };

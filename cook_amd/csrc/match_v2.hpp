@@ -236,7 +236,8 @@ struct V2Buf {
 };
 
 // ---- once per match call: pack offers and jobs -----------------------------------------------------------------------
-COOK_KERNEL void match_pack_offers(const MatchIn* __restrict__ inp /* device copy of the call's MatchIn */, OfferA* __restrict__ oa, OfferB* __restrict__ ob, OfferW* __restrict__ ow) {
+COOK_KERNEL void match_pack_offers(const MatchIn* __restrict__ inp /* device copy of the call's MatchIn */, OfferA* __restrict__ oa,
+                                   OfferB* __restrict__ ob, OfferW* __restrict__ ow) {
   const MatchIn& in = *inp;
   const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= in.M) return;

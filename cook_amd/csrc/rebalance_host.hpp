@@ -377,8 +377,11 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   e->w0.ensure(S);
   e->w1.ensure(S);
   e->w2.ensure(S);
-  KM<rank_key_mins, 256>(e, "rank_key_mins", std::min(gS, 128u), (const int64_t*)b.start.ptr(), (const int64_t*)b.task.ptr(), (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, mins, std::min(gS, 128u));
-  KM<rank_build_keys, 256>(e, "rank_build_keys", gS, (const uint32_t*)b.user.ptr(), (const int32_t*)b.prio.ptr(), (const int64_t*)b.start.ptr(), (const int64_t*)b.task.ptr(), (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, (const unsigned long long*)mins, e->w0.ptr(), e->w1.ptr(), e->w2.ptr(), same);
+  KM<rank_key_mins, 256>(e, "rank_key_mins", std::min(gS, 128u), (const int64_t*)b.start.ptr(), (const int64_t*)b.task.ptr(),
+      (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, mins, std::min(gS, 128u));
+  KM<rank_build_keys, 256>(e, "rank_build_keys", gS, (const uint32_t*)b.user.ptr(), (const int32_t*)b.prio.ptr(), (const int64_t*)b.start.ptr(),
+      (const int64_t*)b.task.ptr(), (const int64_t*)b.job.ptr(), (const uint8_t*)b.pending.ptr(), S, (const unsigned long long*)mins, e->w0.ptr(),
+      e->w1.ptr(), e->w2.ptr(), same);
   readback64(e, 8);
   const unsigned long long mk0 = ~e->h_scratch[4], mk1 = ~e->h_scratch[5], mk2 = ~e->h_scratch[6];
   b.permA.ensure(S);
@@ -407,7 +410,9 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   memset_async(e, b.seg_end.ptr(), 0, (size_t)U * 4);
   memset_async(e, b.inexact.ptr(), 0, (size_t)U * 4);
   KL("rebal_invert_perm", rebal_invert_perm, gS, 256, permB, S, R, b.posB.ptr(), b.act.ptr());
-  KM<rank_gather, 256>(e, "rank_gather", gS, permB, S, (const uint32_t*)b.user.ptr(), (const double*)b.cpus.ptr(), (const double*)b.mem.ptr(), (const double*)b.gpus.ptr(), (const uint8_t*)b.pending.ptr(), b.s_user.ptr(), b.s_use.ptr(), b.s_pending.ptr(), b.head.ptr(), b.seg_start.ptr(), b.seg_end.ptr());
+  KM<rank_gather, 256>(e, "rank_gather", gS, permB, S, (const uint32_t*)b.user.ptr(), (const double*)b.cpus.ptr(), (const double*)b.mem.ptr(),
+      (const double*)b.gpus.ptr(), (const uint8_t*)b.pending.ptr(), b.s_user.ptr(), b.s_use.ptr(), b.s_pending.ptr(), b.head.ptr(),
+      b.seg_start.ptr(), b.seg_end.ptr());
   {  // users whose sums are exact in any order (all of them for integer-valued resources)
     std::vector<uint32_t> ones(std::max(1u, U), 1u);
     b.user_safe.ensure(std::max(1u, U));

@@ -479,26 +479,29 @@ class PinnedArena:
         self.close()
 
 
-def cycle_run_rank_multi(engines: Sequence[Engine], num_considerable: int, user_usage_ptrs: Optional[Sequence[int]] = None,
+def cycle_run_rank_multi(engines: Sequence[Engine], num_considerable, user_usage_ptrs: Optional[Sequence[int]] = None,
                          n_users: int = 0):
     """cycle_run_rank of several engines (pools of one rank, same device) in ONE call: the pools' rank flows side by side on one stream,
     the same kernel of several pools in one launch (cook_cycle_run_rank_multi; same results as the calls one by one).
-    user_usage_ptrs: device addresses of one [U, 3] float64 buffer per engine -> rank_user_usage(device_ptr=...) of each, in the same
+    num_considerable: one K for all, or one per engine.  user_usage_ptrs: device addresses of one [U, 3] float64 buffer per engine -> rank_user_usage(device_ptr=...) of each, in the same
     call; n_users > 0 without pointers: the usage comes back as a list of [U, 3] host arrays."""
     if not engines:
         return None
     lib = engines[0]._lib
     arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    ks = [int(num_considerable)] * len(engines) if np.isscalar(num_considerable) else [int(k) for k in num_considerable]
+    assert len(ks) == len(engines)
+    ks = (C.c_uint32 * len(engines))(*[min(k, 0xFFFFFFFF) for k in ks])
     outs = None
     if user_usage_ptrs is not None:
         uu = (C.c_void_p * len(engines))(*[C.c_void_p(int(p)) for p in user_usage_ptrs])
-        rc = lib.cook_cycle_run_rank_multi(arr, len(engines), int(num_considerable), uu, 1)
+        rc = lib.cook_cycle_run_rank_multi(arr, len(engines), ks, uu, 1)
     elif n_users:
         outs = [np.zeros((max(1, n_users), 3), dtype=np.float64) for _ in engines]
         uu = (C.c_void_p * len(engines))(*[o.ctypes.data for o in outs])
-        rc = lib.cook_cycle_run_rank_multi(arr, len(engines), int(num_considerable), uu, 0)
+        rc = lib.cook_cycle_run_rank_multi(arr, len(engines), ks, uu, 0)
     else:
-        rc = lib.cook_cycle_run_rank_multi(arr, len(engines), int(num_considerable), None, 0)
+        rc = lib.cook_cycle_run_rank_multi(arr, len(engines), ks, None, 0)
     if rc != 0:
         for e in engines:  # the message is with the engine whose flow failed
             if e._lib.cook_last_error(e._h):

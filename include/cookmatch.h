@@ -361,15 +361,16 @@ int cook_cycle_run(cook_engine* e, uint32_t num_considerable);
  * engine's lock across both calls. */
 int cook_cycle_run_rank(cook_engine* e, uint32_t num_considerable);
 /* cook_cycle_run_rank for n engines of one device in ONE call from ONE thread (replaces scheduler.clj:2425-2435's thread per pool for
- * the rank part; same results per engine as n separate calls).  A pool's rank is a chain of about a hundred small launches and the
+ * the rank part; same results per engine as n separate calls; num_considerable[i] is engine i's K — the head-of-queue scaleback,
+ * scheduler.clj:1613-1651, moves it per pool).  A pool's rank is a chain of about a hundred small launches and the
  * stage is bound by their number: here the pools' flows run side by side on engines[0]'s stream and a kernel that stands at the same
  * point of several flows is launched ONCE for all of them (blockIdx.y = pool), with one stream synchronisation where each flow would
  * have had its own.  user_usage != NULL: user_usage[i] also receives engine i's per-user running usage [U x 3] exactly as
  * cook_rank_user_usage(engines[i], user_usage[i], usage_is_device) would deliver it after the rank (the collective's payload), inside the
  * same joint sequence.  COOK_RANK_BATCH=0 in the environment: the engines one after another, as cook_cycle_run_rank (+ cook_rank_user_usage).
  * Returns the first engine's error that is not COOK_OK; every engine keeps its own message (cook_last_error). */
-int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, uint32_t num_considerable, double* const* user_usage,
-                              int usage_is_device);
+int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, const uint32_t* num_considerable /* [n]: every pool its own K */,
+                              double* const* user_usage, int usage_is_device);
 int cook_cycle_match_multi(cook_engine** engines, uint32_t n);
 int cook_cycle_fetch(cook_engine* e, uint32_t* ranked_pending_idx, uint32_t* n_ranked, int32_t* job_to_offer,
                      uint32_t* n_considered, uint8_t* head_matched);

@@ -98,9 +98,9 @@ def main():
         os.environ["COOK_MATCH_SERVED"] = str(int(rng.integers(0, 4) != 0))
         os.environ["COOK_SERVE_STREAMS"] = str(int(rng.integers(1, 4)))
         try:
-            P.mixed_chain_parity(make_engine, pools, params, ks)
+            P.mixed_chain_parity(make_engine, pools, params, ks, rank_batched=bool(it % 2))  # (every other one: the rank parts as one pool batch)
         except AssertionError as ex:
-            print("FAIL multi", it, n, os.environ["COOK_MATCH_SERVED"], os.environ["COOK_SERVE_STREAMS"], str(ex)[:300])
+            print("FAIL multi", it, n, os.environ["COOK_MATCH_SERVED"], os.environ["COOK_SERVE_STREAMS"], it % 2, str(ex)[:300])
             sys.exit(1)
     os.environ.pop("COOK_MATCH_SERVED", None)
     os.environ.pop("COOK_SERVE_STREAMS", None)

@@ -606,16 +606,19 @@ def rank_batch_one_flow_fails(make_engine):
             e.close()
 
 
-def mixed_chain_parity(make_engine, pools, params_list, ks):
+def mixed_chain_parity(make_engine, pools, params_list, ks, rank_batched=False):
     """One lockstep chain whose pools DISAGREE: good-enough-fitness below 1 next to best fit (the whole chain then runs the good-enough
     launches: a best-fit pool is placed by best fit all the same, from that flavour's shorter best-fit lists), and different numbers
     of considerable jobs.  Every pool against the oracle under ITS parameters."""
-    from cook_amd.engine import cycle_match_multi
+    from cook_amd.engine import cycle_match_multi, cycle_run_rank_multi
     engines = [make_engine(p) for p in params_list]
     try:
         for e, pool, k in zip(engines, pools, ks):
             e.cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
-            e.cycle_run_rank(k)
+            if not rank_batched:
+                e.cycle_run_rank(k)
+        if rank_batched:  # ONE call for the rank parts, every pool with its own K (cook_cycle_run_rank_multi)
+            cycle_run_rank_multi(engines, ks)
         cycle_match_multi(engines)
         got = [e.cycle_fetch() for e in engines]
     finally:

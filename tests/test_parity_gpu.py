@@ -284,6 +284,7 @@ def test_lockstep_chain_of_pools_that_disagree(make_engine, multi_mode):
                                  constraints=(i % 2 == 1)) for i in range(n)]
         params = [A.default_params(good_enough_fitness=(0.8 if i % 2 == 0 else 1.0), match_algo=2) for i in range(n)]
         P.mixed_chain_parity(make_engine, pools, params, [120 if i % 3 == 0 else 10 ** 9 for i in range(n)])
+        P.mixed_chain_parity(make_engine, pools, params, [120 if i % 3 == 0 else 10 ** 9 for i in range(n)], rank_batched=True)  # every pool its own K in ONE rank call
 
 
 @pytest.mark.parametrize("seed", [611, 612])
