@@ -285,8 +285,11 @@ class ShardedCluster:
 
             if nb == 1:
                 one(0)
-            else:
-                list(self._tp_rank.map(one, range(nb)))
+            else:  # (the calling thread takes a batch itself: handing one to the pool costs 30-45 us before its first launch, per-dispatch trace)
+                futs = [self._tp_rank.submit(one, b) for b in range(1, nb)]
+                one(0)
+                for f in futs:
+                    f.result()
             if want_users and not on_gpu:
                 user_parts = host_parts
 

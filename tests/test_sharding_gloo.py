@@ -158,6 +158,55 @@ def test_group_without_running_tasks_skips_the_group_filter():
     cl.close()
 
 
+def test_rank_batches_from_several_threads(monkeypatch):
+    """ShardedCluster.cycle with eight pools: the rank parts as FOUR pool batches of two pools (cook_cycle_run_rank_multi), one on the calling
+    thread and three handed to the pool's threads, every pool's per-user usage collected — against the same cluster with one batch of
+    eight.  Real engines on the SIMT emulator (one launch at a time: a lock stands in for the GPU's concurrency)."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from cook_amd import engine as E, workload
+    from tests.simt_emu import build_emu
+    so = build_emu.build()
+    spec = workload.ClusterSpec(pools=8, pending=4000, running=1600, offers=320, users=60)
+    pools = workload.make_pools(spec, range(spec.pools))
+    params = A.default_params(good_enough_fitness=1.0)
+    lock, calls = threading.Lock(), []
+    real = E.cycle_run_rank_multi
+
+    def guarded(engines, *a, **kw):
+        with lock:
+            calls.append((threading.get_ident(), len(engines)))
+            return real(engines, *a, **kw)
+    monkeypatch.setattr(E, "cycle_run_rank_multi", guarded)
+    results = {}
+    for batches in (4, 1):
+        monkeypatch.setenv("COOK_RANK_BATCHES", str(batches))
+        engines = {p: E.Engine(params, lib_path=so) for p in pools}
+        try:
+            for p, pool in pools.items():
+                engines[p].cycle_stage(pool.tasks, pool.users, pool.pending_jobs, pool.offers, pool.groups)
+            cl = sharding.ShardedCluster(engines, workload.quota_groups(spec), serial=True)
+            if batches > 1:
+                cl._tp_rank = ThreadPoolExecutor(max_workers=4)  # (everything else of the cycle stays on the calling thread)
+            cl.n_users = spec.users
+            del calls[:]
+            cl.cycle(spec.per_pool[0])
+            assert sorted(n for _, n in calls) == ([2, 2, 2, 2] if batches == 4 else [8]), calls
+            if batches == 4:
+                assert len({t for t, _ in calls}) >= 2 and threading.get_ident() in {t for t, _ in calls}, calls
+            results[batches] = ([engines[p].cycle_fetch() for p in pools], np.array(cl.last_user_usage), np.array(cl.last_group_usage))
+            cl.close()
+        finally:
+            for e in engines.values():
+                e.close()
+    for (a, b) in zip(results[4][0], results[1][0]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert np.array_equal(results[4][1], results[1][1]) and np.array_equal(results[4][2], results[1][2])
+    from oracle import pyoracle
+    want = sum(pyoracle.user_usage(pools[p].tasks, spec.users) for p in pools)
+    assert np.array_equal(results[4][1], want)
+
+
 @pytest.mark.timeout(900)
 def test_bench_self_launches_world2_over_gloo():
     """`python bench.py --gpus 2` from a plain shell (no WORLD_SIZE): bench.py re-executes itself under torch.distributed.run, one
