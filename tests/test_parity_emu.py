@@ -723,3 +723,39 @@ def test_rank_batch_of_one_pool(make_engine):
 
 def test_rank_batch_one_flow_fails(make_engine):
     P.rank_batch_one_flow_fails(make_engine)
+
+
+def test_rank_batch_switched_off_in_a_fresh_process():
+    """COOK_RANK_BATCH=0 / COOK_BATCH_COPY_KERNEL=0 are read when the library is loaded: in a process of their own the multi call is a loop
+    over its engines (no batch statistics), resp. the read-backs are recorded copies issued alone — same results either way."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+from cook_amd import _abi as A, synth
+from cook_amd.engine import Engine, cycle_run_rank_multi, cycle_match_multi
+from tests.simt_emu import build_emu
+so = build_emu.build()
+p = A.default_params(good_enough_fitness=1.0, match_algo=2)
+pools = [synth.make_pool(seed=300 + i, n_pending=500 + 40 * i, n_running=200, n_users=20, n_offers=40, gpus=True, constraints=True) for i in range(3)]
+engines = [Engine(p, lib_path=so) for _ in pools]
+for e, pl in zip(engines, pools):
+    e.cycle_stage(pl.tasks, pl.users, pl.pending_jobs, pl.offers, pl.groups)
+cycle_run_rank_multi(engines, [10 ** 9, 200, 10 ** 9])
+st = engines[0].match_stats()
+cycle_match_multi(engines)
+out = [[a.tolist() for a in e.cycle_fetch()[:2]] for e in engines]
+print(json.dumps({"stats": {k: v for k, v in st.items() if k.startswith("rank_batch")}, "out": out}))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, env in (("batch", {}), ("off", {"COOK_RANK_BATCH": "0"}), ("copies", {"COOK_BATCH_COPY_KERNEL": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["batch"]["stats"]["rank_batch_pools"] == 3 and got["batch"]["stats"]["rank_batch_single_ops"] == 0
+    assert got["off"]["stats"]["rank_batch_pools"] == 0
+    assert got["copies"]["stats"]["rank_batch_pools"] == 3 and got["copies"]["stats"]["rank_batch_single_ops"] > 0
+    assert got["batch"]["out"] == got["off"]["out"] == got["copies"]["out"]
