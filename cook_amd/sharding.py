@@ -269,7 +269,7 @@ class ShardedCluster:
                 self.engines[p].rank_set_quota(self.quota_inputs(p, usages[p], total))
             # COOK_RANK_BATCHES > 1: the pools in that many batches, each from a thread of its own (every batch has its own stream): two
             # sequences of launches can overlap where one leaves the GPU idle between dependent kernels (measured: DESIGN.md 3a)
-            nb = max(1, min(self.rank_batches, len(self.pools) // 2)) if not isinstance(self._tp_rank, _SerialExecutor) else 1
+            nb = max(1, min(self.rank_batches, len(self.pools) // 2)) if hasattr(self._tp_rank, "submit") else 1  # (a serial executor only maps)
             host_parts = {}
 
             def one(b):
