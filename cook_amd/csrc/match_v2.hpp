@@ -60,8 +60,12 @@ constexpr int MV_L = COOK_MV_L;            // candidate list length per job and 
 //     C4 pool at 0.8: 76 with round 3's lists of 16 / 12, 63 with 64 / 12, 41 with 64 / 24, 36 with 64 / 32).  The evaluation
 //     hands the offers above the threshold over as a BIT per offer and chunk (complete: the merged list is exact to its last entry;
 //     round 3's per-chunk lists of 12 cut the merged list at the first chunk with more than 12 such offers, usually the first).
+// (64 since the end of round 5 — one entry per lane of the walk, 48 before: the reference's default K = 1000 4.79 -> 4.66 ms (7 -> 5 rounds per
+//  pool: on an empty cluster best fit piles consecutive jobs onto the same offers and a list is stale after ~200 jobs), one C4 pool alone — one
+//  GPU of the 8-GPU configuration — 40.9 -> 39.7 ms, eight pools on one GPU +- 0, C2 -1 %, C3 +1 %: profiles/r05zk_lm64_probe.txt,
+//  r05y_variant_sweeps.txt; a staged job's LDS row grows from 613 to 805 bytes, segments get shorter and more)
 #ifndef COOK_MV_LM
-#define COOK_MV_LM 48
+#define COOK_MV_LM 64
 #endif
 #ifndef COOK_MV_LM_GE
 #define COOK_MV_LM_GE 32
