@@ -33,7 +33,7 @@ struct OvEntry {
 };
 enum { ST_WALKED, ST_PRESETTLED, ST_MATCHED, ST_OV_WIN, ST_OPEN, ST_GPU_PLACE, ST_EPOCHS, ST_SCANS, ST_EMPTY_SCANS, ST_CRIT_SCANS, ST_BAND, ST_LITERAL, ST_TIGHTEN,
        ST_SLOW_JOBS, ST_SLOW_SCANS, ST_CLASSES, ST_CHUNKS, ST_WAVES, ST_WALKED_UNMATCHED, ST_CRIT_SCANS_UNMATCHED, ST_MAX_CRIT, ST_DEAD_DROPS, ST_OPEN_DEAD,
-       ST_KC, ST_KM, ST_GPU_UNMATCHED, ST_CRIT_STEPS_MATCHED, ST_CRIT_STEPS_UNMATCHED, ST_N };
+       ST_KC, ST_KM, ST_GPU_UNMATCHED, ST_CRIT_STEPS_MATCHED, ST_CRIT_STEPS_UNMATCHED, ST_SLOW_UNMATCHED, ST_N };
 
 static int fixed_shift(const std::vector<const double*>& cols, const std::vector<uint32_t>& ns) {
   for (int k = 0; k <= 20; ++k) {
@@ -81,13 +81,14 @@ struct Model {
     return L;
   }
   bool dead(uint32_t fc, uint32_t fm) const { return fc < cmin || fm < mmin; }
+  bool occ_now(uint32_t v) const { return ((o->run_count ? o->run_count[v] : 0) + st.acount[v]) != 0; }
 
   void tighten(uint32_t ch) {
     const Cls& c = cls[chunk_cls[ch]];
     const uint32_t p0 = c.off + (ch - c.chunk0) * CH, p1 = std::min(c.off + c.n, p0 + CH);
     for (int i = 0; i < LV; ++i) lv[ch][i] = 0;
     for (uint32_t q = p0; q < p1; ++q)
-      if (present[q])
+      if (present[q] && !(c.gk != 0 && occ_now(pid[q])))  // (a gpu host takes a gpu job only while nothing runs on it: constraints.clj:122-157)
         for (int i = 0; i < LV; ++i)
           if (pfc[q] >= t[i]) lv[ch][i] = std::max(lv[ch][i], pfm[q] + 1);
     stats[ST_TIGHTEN]++;
@@ -159,7 +160,12 @@ struct Model {
     if (g) st.ghost.resize(g->n), st.gattr.resize(g->n);
     // offers -> fixed point, classes
     Lc.resize(M), Lm.resize(M), oTc.resize(M), oTm.resize(M), ocls.resize(M), occupied.assign(M, 0);
-    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> cmap;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t> cmap;
+    std::map<std::tuple<uint32_t, uint32_t>, uint32_t> shape_n;
+    for (uint32_t v = 0; v < M; ++v) {
+      const double rc = o->run_cpus ? o->run_cpus[v] : 0.0, rm = o->run_mem ? o->run_mem[v] : 0.0;
+      shape_n[std::make_tuple((uint32_t)std::ldexp(o->cpus[v] + rc, kc), (uint32_t)std::ldexp(o->mem[v] + rm, km))]++;
+    }
     for (uint32_t v = 0; v < M; ++v) {
       const double rc = o->run_cpus ? o->run_cpus[v] : 0.0, rm = o->run_mem ? o->run_mem[v] : 0.0;
       const double Tc = o->cpus[v] + rc, Tm = o->mem[v] + rm;
@@ -174,7 +180,8 @@ struct Model {
         gk = 1 + (uint32_t)(it - sigs.begin());
         occupied[v] = (o->run_count ? o->run_count[v] : 0) != 0;
       }
-      auto key = std::make_tuple(oTc[v], oTm[v], gk);
+      const uint32_t nsub = (shape_n[std::make_tuple(oTc[v], oTm[v])] + 3583) / 3584;  // a wave's lanes hold at most 64 chunks
+      auto key = std::make_tuple(oTc[v], oTm[v], gk, gk == 0 ? v % nsub : 0u);
       auto it = cmap.find(key);
       if (it == cmap.end()) {
         Cls c{};
@@ -279,10 +286,15 @@ struct Model {
         if (!(jc <= min_fc_all && jm <= min_fm_all)) fail |= 1u;
         int32_t win = -1;
         if (!R[b]) {
-          // re-check the overlay (entries opened since the batch began came out of chunks the pre-check saw: still covered)
           stats[ST_PRESETTLED]++;
-          if (any_room(jc, jm, gk, false)) fail |= 2u;
-          if (any_room(jc, jm, gk, true)) std::abort();  // the pre-check must be conservative
+          // no relevant offer that could take it has room: every offer with room fails a constraint (class kind / occupied gpu host)
+          bool room_any = false;
+          for (uint32_t v = 0; v < M; ++v) {
+            if (!(cur_fc[v] >= jc && cur_fm[v] >= jm)) continue;
+            room_any = true;
+            if (cls[ocls[v]].gk == gk && !(gk != 0 && occ_now(v))) std::abort();  // the pre-check must be conservative
+          }
+          if (room_any) fail |= 2u;
         } else {
           stats[ST_WALKED]++;
           if (slow) stats[ST_SLOW_JOBS]++;
@@ -388,6 +400,12 @@ struct Model {
             } else {
               stats[ST_OPEN]++;
               present[w.src] = 0;
+              {  // summaries stay EXACT: recompute the chunk's levels the removed member was the maximum of
+                bool was_max = false;
+                for (int i = 0; i < LV; ++i)
+                  if (pfc[w.src] >= t[i] && lv[w.where][i] == pfm[w.src] + 1) was_max = true;
+                if (was_max) tighten(w.where);
+              }
               const uint32_t nfc = pfc[w.src] - jc, nfm = pfm[w.src] - jm;
               if (dead(nfc, nfm)) {
                 stats[ST_OPEN_DEAD]++;
@@ -410,7 +428,9 @@ struct Model {
             stats[ST_CRIT_SCANS_UNMATCHED] += crit;
             stats[ST_CRIT_STEPS_UNMATCHED] += 2 + crit;
             if (gk != 0) stats[ST_GPU_UNMATCHED]++;
-            if (room_cons_fail || any_room(jc, jm, gk, false)) fail |= 2u;
+            if (slow) stats[ST_SLOW_UNMATCHED]++;
+            // unmatched: every offer with room fails a constraint (the kernel: exact per-level maxima over all offers + the overlay lanes)
+            if (room_cons_fail || any_room(jc, jm, gk, false) || any_room(jc, jm, gk, true)) fail |= 2u;
           }
           stats[ST_MAX_CRIT] = std::max<uint64_t>(stats[ST_MAX_CRIT], crit);
         }

@@ -21,7 +21,7 @@ from oracle import pyoracle  # noqa: E402
 
 NAMES = ["walked", "presettled", "matched", "overlay_wins", "opens", "gpu_places", "epochs", "scans", "empty_scans", "crit_scans_matched", "band_events",
          "literal_evals", "tightens", "slow_jobs", "slow_scans", "classes", "chunks", "waves", "walked_unmatched", "crit_scans_unmatched", "max_crit_scans",
-         "dead_drops", "open_dead", "kc", "km", "gpu_unmatched", "crit_steps_matched", "crit_steps_unmatched"]
+         "dead_drops", "open_dead", "kc", "km", "gpu_unmatched", "crit_steps_matched", "crit_steps_unmatched", "slow_unmatched"]
 
 
 def lib():
@@ -76,7 +76,7 @@ def check(tag, params, jobs, offers, groups, reserved=(), verbose=True):
         wu = max(1, st["walked_unmatched"])
         print(f"{tag}: identical to the oracle ({jobs.n} jobs x {offers.n} offers; oracle {t1 - t0:.2f} s, model {t2 - t1:.2f} s)")
         print(f"   classes {st['classes']} chunks {st['chunks']} class waves {st['waves']} fixed point 2^-{st['kc']} / 2^-{st['km']}")
-        print(f"   walked {st['walked']} (matched {st['matched']}, unmatched {st['walked_unmatched']}), settled by the batch pre-check {st['presettled']}")
+        print(f"   walked {st['walked']} (matched {st['matched']}, unmatched {st['walked_unmatched']}: {st['gpu_unmatched']} gpu jobs, {st['slow_unmatched']} with host / attribute / group constraints), settled by the batch pre-check {st['presettled']}")
         print(f"   matched: overlay lane wins {st['overlay_wins']}, offers opened {st['opens']} (dead at once {st['open_dead']}), gpu-class placements {st['gpu_places']}, "
               f"dead lanes dropped {st['dead_drops']}, epochs {st['epochs']}")
         print(f"   chunk scans {st['scans']} (empty {st['empty_scans']}, by jobs with host / attribute / group constraints {st['slow_scans']} for {st['slow_jobs']} such jobs), "
