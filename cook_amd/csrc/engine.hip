@@ -22,6 +22,7 @@
 #include "considerable_kernels.hpp"
 #include "match_kernels.hpp"
 #include "match_v2.hpp"
+#include "classfit.hpp"
 #include "offers_kernels.hpp"
 #include "explain_kernels.hpp"
 #include "rank_kernels.hpp"
@@ -256,6 +257,19 @@ struct cook_engine {
   unsigned rlog_id = 0;  // suffix of this engine's COOK_ROUND_LOG file
   DArr<uint32_t> j_user;
   bool has_j_user = false;
+  // ---- class-ordered best fit (classfit.hpp)
+  DArr<CfCtl> cf_ctl;
+  DArr<uint64_t> cf_attr8;
+  DArr<uint32_t> cf_h2o, cf_pos[3], cf_scr[3], cf_gcount, cf_gmem;
+  DArr<CfJob> cf_jobs;
+  uint32_t cf_max_host = 0xFFFFFFFFu;   // greatest host id of the staged offers; 0xFFFFFFFF: not known (offers built on the device)
+  uint32_t cf_group_run_total = 0;      // running cotasks over all staged groups
+  bool has_deferred_cf = false;         // this engine's match is set up for cf_walk and waits for cook_cycle_match_multi
+  CfPoolCtx deferred_cf{};
+  unsigned last_form = 0;               // how the last match was placed: 0 window rounds, 1 serial sweep, 3 class-ordered best fit
+  unsigned cf_inelig = 0;               // why the last match that asked for class-ordered best fit did not get it (CF_X_* bits; 0x10000: switched off / the host's checks)
+  uint32_t cf_stats[32] = {};
+  char* h_cf = nullptr;                 // pinned: summaries and statistics of the pools of a cf_run led by this engine
 
   void fail(int code, const std::string& m) { throw cook_error(code, m); }
 };
@@ -1129,10 +1143,12 @@ void match_stage_offers(cook_engine* e, const cook_offers* o, bool offers_dev) {
   in.o_run_count = (offers_dev ? o->run_count : h2d_opt(e, e->o_run_count, o->run_count, M));
   // two offers on one host?  (offers built on the device are one per node: never)
   in.host_dup = 0;
+  e->cf_max_host = 0xFFFFFFFFu;
   if (!offers_dev && M) {
     std::vector<uint32_t> hs(o->host, o->host + M);
     std::sort(hs.begin(), hs.end());
     in.host_dup = std::adjacent_find(hs.begin(), hs.end()) != hs.end() ? 1u : 0u;
+    e->cf_max_host = hs.back();
   }
 }
 void match_stage_offers(cook_engine* e, const cook_offers* o) {
@@ -1160,6 +1176,7 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
   in.M = M;
   in.G = G;
   e->Kjobs = K;
+  e->cf_group_run_total = 0;
   in.j_cpus = h2d_opt(e, e->j_cpus, j->cpus, K);
   in.j_mem = h2d_opt(e, e->j_mem, j->mem, K);
   in.j_gpus = h2d_opt(e, e->j_gpus, j->gpus, K);
@@ -1209,6 +1226,7 @@ void match_stage_inputs(cook_engine* e, const cook_jobs* j, const cook_offers* o
     in.g_attr_key = h2d_opt(e, e->g_attr_key, g->attr_key, G);
     in.g_min = h2d_opt(e, e->g_min, g->minimum, G);
     if (!in.g_type || !in.g_attr_key || !in.g_min) e->fail(COOK_E_INVALID, "cook_match_stage: groups need type, attr_key, minimum");
+    e->cf_group_run_total = g->run_off ? g->run_off[G] : 0u;
     if (g->run_off) {
       in.g_run_off = h2d_opt(e, e->g_run_off, g->run_off, G + 1);
       const unsigned nr = g->run_off[G];
@@ -1293,6 +1311,100 @@ static void launch_round(cook_engine* e, const MatchIn& in, const MatchState& st
   KL("match_resolve2", match_resolve2<GE>, 1, MV_RTHREADS, st, vb);
 }
 
+// ---- class-ordered best fit (classfit.hpp): set-up, eligibility, launch --------------------------------------------------------------------
+// COOK_CLASSFIT=0: every match goes through the window rounds (A/B switch)
+static const bool g_classfit = env_switch_on_unless_zero("COOK_CLASSFIT");
+static size_t cf_lds_bytes_host(unsigned NP, unsigned M, bool eq, unsigned G, unsigned S) {
+  size_t n = (size_t)NP * 12u;
+  n = (n + 7u) & ~(size_t)7u;
+  if (eq) n += (size_t)M * 8u;
+  n += ((size_t)G + 1u) * 2u + (size_t)G * 2u + (size_t)S * 2u;
+  n = (n + 15u) & ~(size_t)15u;
+  n += 2u * 64u * sizeof(CfJob) + 3u * CF_WAVES * sizeof(CfPost);
+  n += (3u * CF_WAVES * CF_LV + CF_WAVES + CF_MAXKIND * CF_LV + 128u + 192u + 3u * CF_MAXCLS + 16u) * 4u + CF_MAXCLS * sizeof(CfClass);
+  return n + 64u;
+}
+// the three set-up kernels of a call and the look at what they found -> true: the call can be placed by cf_walk (ctx filled in)
+bool cf_setup(cook_engine* e, const MatchIn& in, const MatchIn* in_dev, const MatchState& st, const JobRec* jr, const JobCons* jcons, const OfferA* oa, const OfferB* ob,
+              CfPoolCtx& ctx) {
+  const unsigned K = in.K, M = in.M, G = in.G;
+  e->cf_inelig = 0x10000u;
+  if (!g_classfit || K == 0 || M == 0 || M > CF_SORT_N || G > CF_MAXG || in.good_enough < 1.0 || in.has_x || in.reserved_bits || in.host_dup) return false;
+  if (e->cf_max_host == 0xFFFFFFFFu || (size_t)e->cf_max_host > 8u * (size_t)M + 65536u) return false;
+  CfBuf b{};
+  b.ctl = e->cf_ctl.ensure(1);
+  b.jr = jr, b.jcons = jcons, b.oa = oa, b.ob = ob;
+  b.attr8 = e->cf_attr8.ensure(M);
+  b.max_host = e->cf_max_host;
+  b.h2o = e->cf_h2o.ensure((size_t)b.max_host + 1u);
+  b.pos_fc = e->cf_pos[0].ensure(M), b.pos_fm = e->cf_pos[1].ensure(M), b.pos_cid = e->cf_pos[2].ensure(M);
+  b.scr_fc = e->cf_scr[0].ensure(M), b.scr_fm = e->cf_scr[1].ensure(M), b.scr_cid = e->cf_scr[2].ensure(M);
+  b.jobs = e->cf_jobs.ensure(K);
+  b.gcount = e->cf_gcount.ensure(std::max(1u, G));
+  b.gmem = e->cf_gmem.ensure((size_t)std::max(1u, G) * CF_GMEM);
+  memset_async(e, b.ctl, 0, sizeof(CfCtl));
+  memset_async(e, b.h2o, 0xFF, ((size_t)b.max_host + 1u) * 4u);
+  memset_async(e, b.gcount, 0, (size_t)std::max(1u, G) * 4u);
+  KM<cf_scan, 256>(e, "cf_scan", div_up(std::max(K, M), 256), in_dev, b, K, M);
+  KM<cf_prepare, 1024>(e, "cf_prepare", 1u, in_dev, b, st.jmin, K, M, G, in.host_dup, in.reserved_bits ? 1u : 0u);
+  KM<cf_pack_jobs, 256>(e, "cf_pack_jobs", div_up(K, 256), in_dev, b, K);
+  static_assert(offsetof(CfCtl, t) <= 512, "the control block's head is read back through the 512-byte scratch");
+  pinned_copy(e, e->h_scratch, b.ctl, offsetof(CfCtl, t), hipMemcpyDeviceToHost);
+  sync(e);
+  CfCtl hc;
+  std::memcpy((void*)&hc, e->h_scratch, offsetof(CfCtl, t));
+  e->cf_inelig = hc.inelig;
+  if (hc.inelig) return false;
+  const unsigned NP = (M + 63u) & ~63u;
+  const unsigned S = hc.any_group ? e->cf_group_run_total + hc.n_grouped : 0u;
+  if (cf_lds_bytes_host(NP, M, hc.any_eq != 0u, hc.any_group ? G : 0u, S) > CF_LDS_BYTES || S > 60000u) {
+    e->cf_inelig = CF_X_SHAPE;
+    return false;
+  }
+  ctx.in = in_dev;
+  ctx.st = st;
+  ctx.b = b;
+  return true;
+}
+// cf_walk for the given engines (pools of one device) on `stream`, their group chains, the books of each
+void cf_run(cook_engine* lead, cook_engine* const* es, unsigned n, hipStream_t stream) {
+  cook_engine* e = lead;
+  for (unsigned i0 = 0; i0 < n; i0 += (unsigned)CF_PACK) {
+    const unsigned c = std::min<unsigned>(CF_PACK, n - i0);
+    CfPack pk{};
+    for (unsigned x = 0; x < (unsigned)CF_PACK; ++x) pk.c[x] = es[i0 + (x < c ? x : 0u)]->deferred_cf;
+    KLS("cf_walk", stream, cf_walk, c, CF_THREADS, pk);
+  }
+  for (unsigned i = 0; i < n; ++i) {
+    const CfPoolCtx& c = es[i]->deferred_cf;
+    const unsigned G = es[i]->last_in.G;
+    if (G) KLS("cf_group_chains", stream, cf_group_chains, div_up(G, 256), 256, c.b, c.st, G);
+  }
+  constexpr size_t SLOT = 16 + 32 * 4;  // a pool's summary words and statistics
+  if (!lead->h_cf) COOK_HIP(hipHostMalloc((void**)&lead->h_cf, 64 * SLOT, hipHostMallocDefault));
+  if (n > 64) lead->fail(COOK_E_INVALID, "cook_cycle_match_multi: at most 64 pools per call");
+  for (unsigned i = 0; i < n; ++i) {
+    char* slot = lead->h_cf + i * SLOT;
+    COOK_HIP(hipMemcpyAsync(slot, es[i]->deferred_cf.st.summary, 16, hipMemcpyDeviceToHost, stream));
+    COOK_HIP(hipMemcpyAsync(slot + 16, es[i]->deferred_cf.b.ctl->stats, 32 * 4, hipMemcpyDeviceToHost, stream));
+  }
+  COOK_HIP(hipStreamSynchronize(stream));
+  for (unsigned i = 0; i < n; ++i) {
+    cook_engine* x = es[i];
+    const unsigned* sum = (const unsigned*)(lead->h_cf + i * SLOT);
+    if (sum[3] == 0xDEADu) lead->fail(COOK_E_STATE, "cf_walk: the pool's tables do not fit the workgroup's LDS (the host's check let it through)");
+    std::memcpy(x->cf_stats, lead->h_cf + i * SLOT + 16, 32 * 4);
+    WinCtl c{};
+    c.matched = sum[0], c.head_matched = sum[1], c.rounds = sum[2], c.head = x->last_in.K, c.visited_sum = x->cf_stats[CFS_WALKED];
+    c.t_seq = x->cf_stats[CFS_TICKS_TOTAL], c.t_setup = x->cf_stats[CFS_TICKS_PROLOGUE];
+    x->last_ctl = c;
+    x->last_form = 3;
+    x->has_deferred_cf = false;
+    x->has_deferred = false;
+    x->match_done = true;
+  }
+}
+
 void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool defer = false) {
   MatchIn in = e->min;
   in.K = K;
@@ -1319,13 +1431,16 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
   st.cutoff = 0x7FFFFFFF;
   e->has_deferred = false;
   const int algo = e->params.match_algo;
-  if (!(algo == 0 || algo == 1 || algo == 2)) e->fail(COOK_E_INVALID, "cook_params.match_algo: 0 / 2 = window rounds, 1 = serial sweep");
+  if (!(algo == 0 || algo == 1 || algo == 2 || algo == 3))
+    e->fail(COOK_E_INVALID, "cook_params.match_algo: 0 = class-ordered best fit where the call allows it, else window rounds; 1 = serial sweep; 2 = window rounds; 3 = as 0");
   if (defer && !(algo != 1 && K > 0)) defer = false;  // only the window rounds run several pools in one launch
   const bool ge = in.good_enough < 1.0;
   if (algo == 1) {  // one-job-at-a-time sweep by a single workgroup (reference implementation of the chain)
     constexpr int SERIAL_THREADS = COOK_SHAPE(1024, 256);
     auto k_match = match_serial<SERIAL_THREADS>;
     KL("match_serial", k_match, 1, SERIAL_THREADS, in, st);
+    e->last_form = 1;
+    e->has_deferred_cf = false;
   } else if (K > 0) {  // window rounds: eval -> merge -> resolve (match_v2.hpp)
     match_check_offer_count(e, M);
     V2Buf vb;
@@ -1370,6 +1485,19 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     KM<match_pack_jobs, 256>(e, "match_pack_jobs", div_up(K, 256), (const MatchIn*)vb.in_dev, jr, jcons);
     KM<match_job_minima, 256>(e, "match_job_minima", std::min(div_up(K, 256), 256u), (const JobRec*)jr, K, e->m_jmin.ptr(), std::min(div_up(K, 256), 256u));
     if (M) KM<match_init_alive, 256>(e, "match_init_alive", div_up(M, 256), (const OfferA*)oa, M, st.jmin, st.alive);
+    e->last_form = 0;
+    e->has_deferred_cf = false;
+    if (algo == 0 || algo == 3) {  // class-ordered best fit when the call's numbers and constraints allow it (classfit.hpp)
+      if (cf_setup(e, in, (const MatchIn*)vb.in_dev, st, jr, jcons, oa, ob, e->deferred_cf)) {
+        e->cycle_considered = K;
+        e->match_done = false;
+        e->has_deferred_cf = true;
+        if (defer) return;  // cook_cycle_match_multi runs the walks of a device's pools in one launch
+        cook_engine* one[1] = {e};
+        cf_run(e, one, 1, e->stream);
+        return;
+      }
+    }
     WinCtl c0;
     std::memset(&c0, 0, sizeof(c0));
     // the first window: a call of few jobs (config.clj:113 ships fenzo-max-jobs-considered 1000) in one go — a round that stops early costs it
@@ -1929,7 +2057,8 @@ static std::vector<DBuf*> engine_bufs(cook_engine* e) {
                   &e->g_run_off.b, &e->g_run_host.b, &e->g_run_attr.b, &e->reserved_bits.b, &e->m_fail.b, &e->j_reserved_host.b,
                   &e->o_max_tasks.b, &e->o_num_tasks.b, &e->o_run_count.b, &e->g_min.b, &e->m_acount.b, &e->m_group_last.b,
                   &e->m_job_prev.b, &e->m_j2o.b, &e->j_est_end.b, &e->o_host_start.b, &e->o_k8s.b, &e->g_type.b, &e->m_summary.b, &e->v_oa.b, &e->v_ob.b, &e->v_ow.b, &e->v_jr.b, &e->v_prec.b, &e->v_cand_fit.b, &e->v_cand_idx.b, &e->v_ge_idx.b, &e->v_cinfo.b, &e->v_colbits.b, &e->w_ctl.b, &e->v_in.b,
-                  &e->dhead.b, &e->tie_ctl.b};
+                  &e->dhead.b, &e->tie_ctl.b, &e->cf_ctl.b, &e->cf_attr8.b, &e->cf_h2o.b, &e->cf_pos[0].b, &e->cf_pos[1].b, &e->cf_pos[2].b, &e->cf_scr[0].b,
+                  &e->cf_scr[1].b, &e->cf_scr[2].b, &e->cf_gcount.b, &e->cf_gmem.b, &e->cf_jobs.b};
 }
 extern "C" {
 
@@ -1987,6 +2116,7 @@ void cook_engine_destroy(cook_engine* e) {
   if (e->h_scratch) (void)hipHostFree(e->h_scratch);
   if (e->h_inbuf) (void)hipHostFree(e->h_inbuf);
   if (e->h_multi) (void)hipHostFree(e->h_multi);
+  if (e->h_cf) (void)hipHostFree(e->h_cf);
   if (e->h_serve) (void)hipHostFree(e->h_serve);
   if (e->s_walk) (void)hipStreamDestroy(e->s_walk);
   for (hipStream_t sv : e->s_serve)
@@ -2289,6 +2419,15 @@ int cook_cycle_match_multi(cook_engine** engines, uint32_t n) {
   cook_engine* lead = engines[0];
   return guarded(lead, [&] {
     StageTimer tm(lead, 2, &lead->match_ms);
+    // the pools that are placed by class-ordered best fit (classfit.hpp): ONE launch, a workgroup per pool
+    {
+      std::vector<cook_engine*> cf;
+      for (uint32_t i = 0; i < n; ++i) {
+        if (!engines[i] || engines[i]->device != lead->device) lead->fail(COOK_E_INVALID, "cook_cycle_match_multi: engines must share one device");
+        if (engines[i]->has_deferred_cf) cf.push_back(engines[i]);
+      }
+      if (!cf.empty()) cf_run(lead, cf.data(), (unsigned)cf.size(), lead->stream);
+    }
     // served walkers (one persistent walker workgroup per pool beside serve launches); lockstep launches when switched off, for more
     // pools than a served call takes, or to finish a served match that gave up
     if (!(served_enabled() && match_rounds_served(engines, n))) match_rounds_multi(engines, n);
@@ -2499,6 +2638,9 @@ int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap) {
   for (unsigned k = 0; k < 8u; ++k)
     if (e->upd_phase_us[k] > v[30]) v[29] = k, v[30] = e->upd_phase_us[k];
   for (unsigned k = 0; k < 5u; ++k) v[32 + k] = e->batch_stats[k];
+  v[37] = e->last_form, v[38] = e->cf_inelig;
+  if (e->last_form == 3u)
+    for (unsigned k = 0; k < 20u; ++k) v[40 + k] = e->cf_stats[k];
   if (g_guard) {  // COOK_GUARD=1: look at this engine's bands now; the count is process-wide and includes buffers already freed
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);

@@ -412,12 +412,14 @@ class Engine:
         return r.value, m.value
 
     def match_stats(self):
-        out = (C.c_uint32 * 40)()
-        n = self._lib.cook_match_stats_ex(self._h, out, 40)
+        out = (C.c_uint32 * 64)()
+        n = self._lib.cook_match_stats_ex(self._h, out, 64)
         keys = ("rounds", "matched", "stop_list", "stop_full", "stop_group", "stop_window", "segments", "resolved", "setup_us", "seq_us", "touched", "visited",
                 "_12", "_13", "_14", "_15", "trunc_lists", "served_mode", "served_pools", "serve_iterations", "serve_empty_iterations",
                 "serve_pool_windows", "serve_latch_wait_us", "served_fell_back", "serve_streams", "guard_hits", "update_us", "update_sync_us", "update_allocs", "update_slowest_phase", "update_slowest_phase_us", "_31",
-                "rank_batch_pools", "rank_batch_launches", "rank_batch_grouped_launches", "rank_batch_single_ops", "rank_batch_syncs")
+                "rank_batch_pools", "rank_batch_launches", "rank_batch_grouped_launches", "rank_batch_single_ops", "rank_batch_syncs",
+                "placement_form", "classfit_refused", "_39", "cf_walked", "cf_matched", "cf_overlay_wins", "cf_opened", "cf_opened_full", "cf_gpu_places", "cf_epochs",
+                "cf_scans", "cf_exact_turns", "cf_retightened", "_50", "cf_batches", "cf_dead_lanes", "cf_ticks", "cf_ticks_prologue", "cf_ticks_epochs", "cf_ticks_precheck")
         return {k: int(x) for k, x in zip(keys, out[:max(0, n)]) if not k.startswith("_")}
 
     def set_profiling(self, on: bool):

@@ -593,8 +593,17 @@ int cook_match_stats(cook_engine* e, uint32_t out[16]);
    stream synchronisations, device buffers it had to (re)allocate, [29..30] the phase of the call that took the host longest (0 checks, 1 the delta's block,
    2 marks and scans, 3 column compactions, 4 CSR columns, 5 the look at the device, 6 swaps and offers) and its microseconds; [31] reserved (0);
    [32..36] the last cook_cycle_run_rank_multi LED by this engine: pools, launches made, of them for more than one pool, operations
-   issued on their own (copies, fills, kernels outside the batched path), stream synchronisations; [37..39] reserved (0) */
-#define COOK_MATCH_STATS_EX_N 40
+   issued on their own (copies, fills, kernels outside the batched path), stream synchronisations; [37] how the last match was placed (0 window
+   rounds, 1 serial sweep, 3 class-ordered best fit), [38] why a match that could have been placed by class-ordered best fit was not (0 = it was; bits:
+   1 resources that are not multiples of 2^-20 below 2^30, 2 a job constraint outside {EQUALS on the first 8 attribute keys with values < 256, <= 4 novel
+   hosts, unique group, gpu}, 4 ports / named scalars, 8 balanced / attribute-equals groups or more than 16 pending members of a group, 16 gpu maps with
+   several entries / max-tasks-per-host / reserved hosts / two offers of one host / attribute values >= 256, 32 too many classes, gpu kinds or offers
+   for one workgroup's LDS, 64 job cpus values outside the 8 levels, 128 a job asking for nothing, 0x10000 good-enough-fitness < 1, COOK_CLASSFIT=0 or
+   offers built on the device), [39] reserved (0); [40..59] class-ordered best fit, the last match: jobs visited, matched, of them on an offer the call
+   had placed on before (overlay lane), offers opened, of them full at once, placements on gpu hosts, epochs, chunk scans, exact turns (several offers
+   within 2^-37 of the best: the literal fitness decided), summary re-computations, [50] reserved, batches of 64 jobs, overlay lanes dropped full,
+   [53..56] 100 MHz ticks: the launch, its prologue, the epochs' merges, the bookkeeper's batch pre-checks; [57..63] reserved (0) */
+#define COOK_MATCH_STATS_EX_N 64
 int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap);
 
 #if defined(__GNUC__)
