@@ -67,9 +67,10 @@ struct CfCtl {
   uint64_t kind_sig[CF_MAXKIND];  // gpu model << 32 | count
   CfClass cls[CF_MAXCLS];
   // cf_walk
-  uint32_t stats[32];
+  uint32_t stats[48];
 };
-enum { CFS_WALKED, CFS_MATCHED, CFS_OV_WIN, CFS_OPEN, CFS_OPEN_DEAD, CFS_GPU_PLACE, CFS_EPOCHS, CFS_SCANS, CFS_EXACT, CFS_TIGHTEN, CFS_PRESETTLED, CFS_BATCHES, CFS_DEAD_DROP,
+enum { CFS_SPINS = 17,
+       CFS_WALKED = 0, CFS_MATCHED, CFS_OV_WIN, CFS_OPEN, CFS_OPEN_DEAD, CFS_GPU_PLACE, CFS_EPOCHS, CFS_SCANS, CFS_EXACT, CFS_TIGHTEN, CFS_PRESETTLED, CFS_BATCHES, CFS_DEAD_DROP,
        CFS_TICKS_TOTAL, CFS_TICKS_PROLOGUE, CFS_TICKS_EPOCH, CFS_TICKS_PRECHECK };
 struct CfJob {  // one job as the walk reads it (32 B)
   uint32_t c, m;       // fixed point
@@ -453,6 +454,23 @@ __global__ void cf_group_chains(CfBuf b, MatchState st, unsigned G) {
 }
 
 // ---- 4. the walk ------------------------------------------------------------------------------------------------------------------------------------------
+#ifdef __HIP_EMU__  // CF_TRACE=1 in the environment of an emulated run: what the waves of the walk do, to stderr
+#include <cstdlib>
+static inline bool cf_trace_on() {
+  static const bool on = std::getenv("CF_TRACE") != nullptr;
+  return on;
+}
+#define CF_TRACE(...) do { if (cf_trace_on() && lane_id() == 0) std::fprintf(stderr, __VA_ARGS__); } while (0)
+#else
+#define CF_TRACE(...) ((void)0)
+#endif
+#ifdef CF_PROF  // timing-study build: ticks of the 100 MHz clock per phase of a step (query, wait at the barrier, verdict, commit) of waves 0 / 1..6 / 7
+#define CF_PROF_T(x) const unsigned long long x = cook_ticks()
+#define CF_PROF_ADD(i, d) prof[i] += (unsigned)(d)
+#else
+#define CF_PROF_T(x) ((void)0)
+#define CF_PROF_ADD(i, d) ((void)0)
+#endif
 struct CfPost {  // what a wave says about a job (32 B)
   double fa;     // approximate fitness of its best candidate, 0 = none
   uint32_t w0;   // offer | ambiguous << 31
@@ -462,55 +480,65 @@ struct CfPost {  // what a wave says about a job (32 B)
 struct CfJobU {  // the job of a step, wave-uniform
   unsigned c, m, kind, L, n_eq, n_nov, grouped, grp, eq0, eq1, nov0, nov1;
 };
+struct CfCand;
+struct CfCmd;
+struct CfVlog;
 struct CfLds {  // the workgroup's LDS, carved at run time
-  uint32_t *fc, *fm, *cid;
+  uint32_t *fc, *fm;
+  uint16_t* cid;        // occupied gpu host << 15 | offer (the class follows from the position)
+  CfCand* board;        // [CF_BOARD][CF_WAVES] the class waves' candidates for the steps ahead
+  CfCmd* cmd;           // [CF_WAVES] the decider's last command to a class wave
+  CfVlog* vlog;         // [CF_VLOG] the decider's verdicts for the bookkeeper
+  uint32_t* ack;        // [CF_WAVES] the step of the last command a class wave has obeyed
   uint64_t* attr8;
   uint16_t *goff, *gcnt, *gids;
   CfJob* ring;          // [2][64]
-  CfPost* post;         // [2][CF_WAVES]
   CfPost* post2;        // [CF_WAVES] exact turns
   CfClass* cls;         // [CF_MAXCLS] the class table (n / off as of the last epoch)
   uint32_t* pw;         // [CF_WAVES][CF_LV] greatest level summaries of a wave's chunks of hosts without gpus
-  uint32_t* aw;         // [2][CF_WAVES][CF_LV] ... of all its chunks, occupied gpu hosts included: two copies per wave, awcur[w] names the one in force
-                        //   (a wave writes the other one and switches at the top of the NEXT step, in front of that step's barrier: the bookkeeper reads rows
-                        //   that nobody is writing)
-  uint32_t* awcur;      // [CF_WAVES]
+  uint32_t* aw;         // [CF_WAVES][CF_LV] ... of all its chunks, occupied gpu hosts included (a wave re-writes its rows only once the bookkeeper has
+                        //   read the last change: CFX_BK_DONE)
   uint32_t* gk;         // [CF_MAXKIND][CF_LV] ... of a gpu kind's chunks
   uint32_t* ovm;        // [64][2] the overlay's free values as of the last batch end
   uint32_t* ovl;        // [64][3] an epoch's overlay list (cid, fc, fm), sorted
   uint32_t* ckept;      // [CF_MAXCLS] kept members / [CF_MAXCLS] inserted / [CF_MAXCLS] new offsets
   uint32_t* misc;       // [0..1] walk mask, [2] sequence number of the last change of level maxima, [6] the batch lane of the step that made it,
-                        // [3] overlay list length, [4..5] overlay valid mask as of the last batch end
+                        // [3] overlay list length, [4..5] overlay valid mask as of the last batch end, [7] an exact turn ends the epoch, [8..14] CFX_*
 };
-static __device__ __forceinline__ unsigned cf_lds_bytes(unsigned NP, unsigned M, bool eq, unsigned G, unsigned S) {
-  unsigned n = NP * 12u;
-  n = (n + 7u) & ~7u;
-  if (eq) n += M * 8u;
-  n += (G + 1u) * 2u + G * 2u + S * 2u;
-  n = (n + 15u) & ~15u;
-  n += 2u * 64u * (unsigned)sizeof(CfJob) + 3u * CF_WAVES * (unsigned)sizeof(CfPost);
-  n += (3u * CF_WAVES * CF_LV + CF_WAVES + CF_MAXKIND * CF_LV + 128u + 192u + 3u * CF_MAXCLS + 16u) * 4u + CF_MAXCLS * (unsigned)sizeof(CfClass);
-  return n;
-}
 static __device__ __forceinline__ unsigned cf_level_of(const uint32_t (&t)[CF_LV], uint32_t fc) {  // greatest level whose threshold fc reaches; CF_LV = none... 0-based count
   unsigned n = 0;
 #pragma unroll
   for (int i = 0; i < CF_LV; ++i) n += fc >= t[i] ? 1u : 0u;
   return n;  // members with n levels: levels 0 .. n-1 (t is ascending)
 }
-template <class T>
-static __device__ __forceinline__ T cf_sel8(const T (&a)[CF_LV], unsigned i) {  // a[i] for a wave-uniform i without indexing registers through memory
-  T r = a[0];
-#pragma unroll
-  for (int q = 1; q < CF_LV; ++q) r = i == (unsigned)q ? a[q] : r;
+
+// eight level values in eight REGISTERS: as an array inside a structure the compiler kept the whole structure in scratch memory and turned the
+// select chain into an indexed scratch load (~1 us each; seen in the ISA of the first build)
+struct CfLv8 {
+  uint32_t v0, v1, v2, v3, v4, v5, v6, v7;
+};
+#define CF_FOR8(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
+static __device__ __forceinline__ uint32_t cf_lv_get(const CfLv8& a, unsigned i) {  // a wave-uniform index
+  // (the values pass through OPAQUE_V: a select between LOADS of neighbouring members is folded into one indexed load, and the structure then
+  //  stays in scratch memory for good)
+  uint32_t x0 = a.v0, x1 = a.v1, x2 = a.v2, x3 = a.v3, x4 = a.v4, x5 = a.v5, x6 = a.v6, x7 = a.v7;
+  OPAQUE_V(x0);
+  OPAQUE_V(x1);
+  OPAQUE_V(x2);
+  OPAQUE_V(x3);
+  OPAQUE_V(x4);
+  OPAQUE_V(x5);
+  OPAQUE_V(x6);
+  OPAQUE_V(x7);
+  uint32_t r = x0;
+  r = i == 1u ? x1 : r, r = i == 2u ? x2 : r, r = i == 3u ? x3 : r, r = i == 4u ? x4 : r, r = i == 5u ? x5 : r, r = i == 6u ? x6 : r, r = i == 7u ? x7 : r;
   return r;
 }
-
 struct CfChunkLane {  // a class wave's lane = one chunk
   unsigned cls, kind, pos0, n, Tc, Tm;
   unsigned long long pres, dE;
   double hTc, hTm;
-  uint32_t lv[CF_LV], la[CF_LV];
+  CfLv8 lv, la;
 };
 
 // lanes of a class wave <- the chunks of the wave's classes, in class order
@@ -539,27 +567,33 @@ static __device__ __forceinline__ void cf_tighten(const CfLds& S, const uint32_t
   const uint32_t fc = S.fc[pos0 + lane], fm = S.fm[pos0 + lane], cid = S.cid[pos0 + lane];
   const unsigned nl = in ? cf_level_of(t, fc) : 0u;
   const bool free_host = !(cid & CF_OCC);
-#pragma unroll
-  for (int i = 0; i < CF_LV; ++i) {
-    const uint32_t va = wave_max_u32(nl > (unsigned)i ? fm + 1u : 0u);
-    const uint32_t vr = wave_max_u32((nl > (unsigned)i && free_host) ? fm + 1u : 0u);
-    if (lane == ch) c.la[i] = va, c.lv[i] = vr;
+#define CF_TIGHTEN_LEVEL(i)                                                                   \
+  {                                                                                           \
+    const uint32_t va = wave_max_u32(nl > (unsigned)i ? fm + 1u : 0u);                        \
+    const uint32_t vr = wave_max_u32((nl > (unsigned)i && free_host) ? fm + 1u : 0u);         \
+    if (lane == ch) c.la.v##i = va, c.lv.v##i = vr;                                           \
   }
+  CF_FOR8(CF_TIGHTEN_LEVEL)
+#undef CF_TIGHTEN_LEVEL
 }
 // the wave's rows of the level-maxima tables
-static __device__ __forceinline__ void cf_wave_tables(const CfLds& S, unsigned w, unsigned lane, const CfChunkLane& c, bool gpu_wave, unsigned n_kind, unsigned aw_buf) {
-#pragma unroll
-  for (int i = 0; i < CF_LV; ++i) {
-    const uint32_t p = wave_max_u32(c.kind == 0u ? c.lv[i] : 0u), a = wave_max_u32(c.kind < 0xFEu ? c.la[i] : 0u);
-    if (lane == 0) S.pw[w * CF_LV + i] = p, S.aw[(aw_buf * CF_WAVES + w) * CF_LV + i] = a;
+static __device__ __forceinline__ void cf_wave_tables(const CfLds& S, unsigned w, unsigned lane, const CfChunkLane& c, bool gpu_wave, unsigned n_kind) {
+#define CF_TABLE_LEVEL(i)                                                                                                          \
+  {                                                                                                                                \
+    const uint32_t p = wave_max_u32(c.kind == 0u ? c.lv.v##i : 0u), a = wave_max_u32(c.kind < 0xFEu ? c.la.v##i : 0u);            \
+    if (lane == 0) S.pw[w * CF_LV + i] = p, S.aw[w * CF_LV + i] = a;                                         \
   }
+  CF_FOR8(CF_TABLE_LEVEL)
+#undef CF_TABLE_LEVEL
   if (gpu_wave)
     for (unsigned k = 1; k < n_kind; ++k) {
-#pragma unroll
-      for (int i = 0; i < CF_LV; ++i) {
-        const uint32_t g = wave_max_u32(c.kind == k ? c.lv[i] : 0u);
-        if (lane == 0) S.gk[k * CF_LV + i] = g;
-      }
+#define CF_KIND_LEVEL(i)                                          \
+  {                                                               \
+    const uint32_t g = wave_max_u32(c.kind == k ? c.lv.v##i : 0u); \
+    if (lane == 0) S.gk[k * CF_LV + i] = g;                       \
+  }
+      CF_FOR8(CF_KIND_LEVEL)
+#undef CF_KIND_LEVEL
     }
 }
 
@@ -611,7 +645,7 @@ template <bool EXACT>
 static __device__ __forceinline__ void cf_class_query(const CfLds& S, const CfJobU& J, unsigned lane, const CfChunkLane& c, double fmax, double sc, double sm, CfPost& out,
                                                        unsigned& scans) {
   out.fa = 0.0, out.w0 = 0u, out.pos = 0u, out.fc = 0u, out.fm = 0u, out.cls = 0u, out.aux = 0u;
-  const uint32_t lvL = cf_sel8(c.lv, J.L);
+  const uint32_t lvL = cf_lv_get(c.lv, J.L);
   unsigned long long m = __ballot(c.kind == J.kind && lvL > J.m);
   bool amb = false;
   unsigned long long best_lit = 0ull;
@@ -745,9 +779,37 @@ static __device__ __forceinline__ CfVerdict cf_verdict(const CfPost* posts, unsi
 // the books of one job's "an offer of the cluster has room for it" from the class arrays' side: the level maxima over every chunk of every wave
 static __device__ __forceinline__ bool cf_chunks_have_room(const CfLds& S, unsigned L, unsigned m) {
   bool r = false;
-  for (unsigned x = 1; x <= (unsigned)CF_CW; ++x) r = r || S.aw[(S.awcur[x] * CF_WAVES + x) * CF_LV + L] > m;
+  for (unsigned x = 1; x <= (unsigned)CF_CW; ++x) r = r || S.aw[x * CF_LV + L] > m;
   return r;
 }
+// a word another wave of the workgroup writes, the same value in every lane (lane 0 reads it)
+static __device__ __forceinline__ unsigned cf_poll(const uint32_t* p) { return (unsigned)wave_read_lane((int)ld_wg(p), 0); }
+
+// ---- the walk ---------------------------------------------------------------------------------------------------------------------------------------------
+// Wave 0 DECIDES alone: its lanes 0..57 hold the overlay, lanes 58..63 take, for the job of the step, the candidate each class wave has PUBLISHED on
+// the board (LDS) — the class waves answer the walked jobs of the batch ahead of the decider, up to CF_BOARD steps, and answer again from the step
+// after every member the decider takes out of their arrays (a command + a version number per class wave; a candidate counts when it carries the
+// step and the version the decider expects).  One evaluation of 64 lanes, one wave maximum, the commit in registers: no barrier in a step.  The
+// bookkeeper (wave 7) follows the decider's verdict log.  Steps that need every wave in lockstep — several candidates inside the guard band (the
+// literal fitness decides), the end of an epoch, the end of the batch — are COLLECTIVE turns: the decider raises a mode word, every wave comes to a
+// barrier, the turn runs as in the first (lockstep) form of this kernel.
+constexpr unsigned CF_BOARD = 8;    // steps the class waves may run ahead of the decider (a power of two)
+constexpr unsigned CF_VLOG = 16;    // verdicts the bookkeeper may lag behind
+constexpr unsigned CF_OVL = 58;     // overlay lanes (lanes 58..63 are the candidates of class waves 1..6)
+constexpr unsigned CF_EPOCH_AT = COOK_SHAPE(58, 8);  // live overlay lanes that end an epoch
+enum : unsigned { CFM_EXACT = 1u, CFM_EPOCH = 2u, CFM_BATCH_END = 3u };
+enum : unsigned { CFC_REMOVE = 1u, CFC_GPU_PLACE = 2u, CFC_NONE = 3u };
+enum : unsigned { CFX_HEAD_SEQ = 8, CFX_MODE = 9, CFX_DRAIN = 10, CFX_BK_DONE = 11, CFX_EX_LANE = 12, CFX_FMAX_LO = 13, CFX_FMAX_HI = 14 };  // words of CfLds::misc
+struct CfCand {  // a class wave's answer for one step (48 B); tag = step << 8 | version, stored LAST
+  uint32_t tag, pos, fc, fm, cid, flags, Tc, Tm;  // flags: 1 another member may round to the same fitness, 2 no candidate
+  double hTc, hTm;
+};
+struct CfCmd {  // decider -> class wave (32 B); ver stored LAST
+  uint32_t ver, kind, pos, nfc, nfm, lane_s, seq, pad;
+};
+struct CfVlog {  // decider -> bookkeeper (32 B); seq stored LAST
+  uint32_t seq, info, id, ofc, ofm, nfc, nfm, pad;  // info: batch lane | matched << 8 | from the overlay << 9 | opens a lane << 10 | class wave << 12
+};
 
 static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __restrict__ inp, const MatchState& st, const CfBuf& b) {
   const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -766,6 +828,7 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
   constexpr unsigned GPT = CF_MAXG / CF_THREADS;
   unsigned gsz[GPT];
   unsigned gsum = 0;
+#pragma unroll
   for (unsigned x = 0; x < GPT; ++x) {
     const unsigned g = tid * GPT + x;
     unsigned sz = 0;
@@ -790,8 +853,8 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
     char* p = lds;
     S.fc = (uint32_t*)p, p += NP * 4u;
     S.fm = (uint32_t*)p, p += NP * 4u;
-    S.cid = (uint32_t*)p, p += NP * 4u;
-    p = lds + ((NP * 12u + 7u) & ~7u);
+    S.cid = (uint16_t*)p, p += NP * 2u;
+    p = lds + (((unsigned)(p - lds) + 7u) & ~7u);
     S.attr8 = (uint64_t*)p;
     if (any_eq) p += M * 8u;
     S.goff = (uint16_t*)p, p += (Gl + 1u) * 2u;
@@ -799,110 +862,147 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
     S.gids = (uint16_t*)p, p += Stot * 2u;
     p = lds + (((unsigned)(p - lds) + 15u) & ~15u);
     S.ring = (CfJob*)p, p += 2u * 64u * sizeof(CfJob);
-    S.post = (CfPost*)p, p += 2u * CF_WAVES * sizeof(CfPost);
+    S.board = (CfCand*)p, p += CF_BOARD * CF_WAVES * sizeof(CfCand);
+    S.cmd = (CfCmd*)p, p += CF_WAVES * sizeof(CfCmd);
+    S.vlog = (CfVlog*)p, p += CF_VLOG * sizeof(CfVlog);
     S.post2 = (CfPost*)p, p += CF_WAVES * sizeof(CfPost);
     S.cls = (CfClass*)p, p += CF_MAXCLS * sizeof(CfClass);
     S.pw = (uint32_t*)p, p += CF_WAVES * CF_LV * 4u;
-    S.aw = (uint32_t*)p, p += 2u * CF_WAVES * CF_LV * 4u;
-    S.awcur = (uint32_t*)p, p += CF_WAVES * 4u;
+    S.aw = (uint32_t*)p, p += CF_WAVES * CF_LV * 4u;
     S.gk = (uint32_t*)p, p += CF_MAXKIND * CF_LV * 4u;
+    S.ack = (uint32_t*)p, p += CF_WAVES * 4u;
     S.ovm = (uint32_t*)p, p += 128u * 4u;
     S.ovl = (uint32_t*)p, p += 192u * 4u;
     S.ckept = (uint32_t*)p, p += 3u * CF_MAXCLS * 4u;
     S.misc = (uint32_t*)p, p += 16u * 4u;
-    if ((unsigned)(p - lds) > CF_LDS_BYTES) {  // (the host checks the same sum before it launches: cf_lds_bytes)
+    if ((unsigned)(p - lds) > CF_LDS_BYTES) {  // (the host checks the same sum before it launches: cf_lds_bytes_host)
       if (tid == 0) atomicOr(&ctl->inelig, (unsigned)CF_X_SHAPE), st.summary[3] = 0xDEADu;
       return;
     }
   }
   // ---- prologue: class arrays, byte table, group table, job ring
   for (unsigned q = tid; q < NP; q += CF_THREADS) {
-    S.fc[q] = q < M ? b.pos_fc[q] : 0u, S.fm[q] = q < M ? b.pos_fm[q] : 0u, S.cid[q] = q < M ? b.pos_cid[q] : 0xFFFFFFFFu;
+    S.fc[q] = q < M ? b.pos_fc[q] : 0u, S.fm[q] = q < M ? b.pos_fm[q] : 0u, S.cid[q] = q < M ? (uint16_t)b.pos_cid[q] : (uint16_t)0xFFFFu;
   }
   if (any_eq)
     for (unsigned v = tid; v < M; v += CF_THREADS) S.attr8[v] = b.attr8[v];
   if (any_group) {
     unsigned off = wbase + incl - gsum;
+#pragma unroll
     for (unsigned x = 0; x < GPT; ++x) {
       const unsigned g = tid * GPT + x;
-      if (g > G) break;
-      S.goff[g] = (uint16_t)off;
-      if (g == G) break;
-      unsigned cnt = 0;
-      if (gsz[x]) {
-        const unsigned r0 = inp->g_run_off ? inp->g_run_off[g] : 0u, r1 = inp->g_run_off ? inp->g_run_off[g + 1] : 0u;
-        for (unsigned r = r0; r < r1; ++r) {
-          const uint32_t h = inp->g_run_host[r];
-          const uint32_t v = h <= b.max_host ? b.h2o[h] : 0xFFFFFFFFu;
-          if (v != 0xFFFFFFFFu) S.gids[off + cnt++] = (uint16_t)v;
+      if (g <= G) S.goff[g] = (uint16_t)off;
+      if (g < G) {
+        unsigned cnt = 0;
+        if (gsz[x]) {
+          const unsigned r0 = inp->g_run_off ? inp->g_run_off[g] : 0u, r1 = inp->g_run_off ? inp->g_run_off[g + 1] : 0u;
+          for (unsigned r = r0; r < r1; ++r) {
+            const uint32_t h = inp->g_run_host[r];
+            const uint32_t v = h <= b.max_host ? b.h2o[h] : 0xFFFFFFFFu;
+            if (v != 0xFFFFFFFFu) S.gids[off + cnt++] = (uint16_t)v;
+          }
         }
+        S.gcnt[g] = (uint16_t)cnt;
+        off += gsz[x];
       }
-      S.gcnt[g] = (uint16_t)cnt;
-      off += gsz[x];
     }
   }
   if (w == CF_WAVES - 1 && lane < cf_min(64u, K)) S.ring[lane] = b.jobs[lane];
   for (unsigned x = tid; x < n_cls; x += CF_THREADS) S.cls[x] = ctl->cls[x];
   for (unsigned x = tid; x < 16u; x += CF_THREADS) S.misc[x] = 0u;
-  for (unsigned x = tid; x < CF_WAVES * CF_LV; x += CF_THREADS) S.pw[x] = 0u, S.aw[x] = 0u, S.aw[CF_WAVES * CF_LV + x] = 0u;
-  for (unsigned x = tid; x < CF_WAVES; x += CF_THREADS) S.awcur[x] = 0u;
+  for (unsigned x = tid; x < CF_WAVES * CF_LV; x += CF_THREADS) S.pw[x] = 0u, S.aw[x] = 0u;
+  for (unsigned x = tid; x < CF_WAVES; x += CF_THREADS) S.ack[x] = 0u, S.cmd[x].ver = 0u;
   for (unsigned x = tid; x < CF_MAXKIND * CF_LV; x += CF_THREADS) S.gk[x] = 0u;
+  for (unsigned x = tid; x < CF_BOARD * CF_WAVES; x += CF_THREADS) S.board[x].tag = 0xFFFFFFFFu;
+  for (unsigned x = tid; x < CF_VLOG; x += CF_THREADS) S.vlog[x].seq = 0u;
   __syncthreads();
   // ---- wave state
   CfChunkLane c;
   unsigned nch_wave = 0;
   cf_setup_chunks(S.cls, n_cls, w, lane, c, nch_wave);
-#pragma unroll
-  for (int i = 0; i < CF_LV; ++i) c.lv[i] = 0u, c.la[i] = 0u;
+  c.lv = CfLv8{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, c.la = c.lv;
   unsigned gpu_wave = 0;  // the wave that holds the gpu classes
   for (unsigned ci = 0; ci < n_cls; ++ci)
     if (S.cls[ci].kind != 0u) gpu_wave = S.cls[ci].wave;
   const bool is_class_wave = w >= 1u && w <= (unsigned)CF_CW;
-  unsigned aw_mine = 0;  // the copy of this wave's `aw` rows that is in force
-  bool aw_pending = false;
-  unsigned aw_pending_lane = 0;
+  const bool is_books = w == (unsigned)CF_WAVES - 1u;
   if (is_class_wave) {
     for (unsigned ch = 0; ch < nch_wave; ++ch) cf_tighten(S, t, lane, ch, c);
-    cf_wave_tables(S, w, lane, c, w == gpu_wave, n_kind, 0u);
+    cf_wave_tables(S, w, lane, c, w == gpu_wave, n_kind);
   }
   CfOvLane o;
   o.valid = 0u, o.id = 0u, o.cls = 0u, o.fc = 0u, o.fm = 0u, o.Tc = 1u, o.Tm = 1u, o.hTc = 0.0, o.hTm = 0.0;
+  unsigned o_ver = 0;  // decider lanes 58..63 / class waves: the version a candidate must carry (commands AND collective turns move it on)
+  unsigned o_cmd = 0;  // decider lanes 58..63: commands given to "their" class wave so far; class waves: commands obeyed
+  unsigned retable_seq = 0;  // class wave: the step of its last change of level maxima (the next one waits until the bookkeeper has read this one)
   // bookkeeper (wave 7): lanes = the jobs of the batch
   unsigned bk_c = 0, bk_m = 0, bk_L = 0, bk_kind = 0, bk_cnt = 0;  // cnt: overlay lanes with room for the job
   bool bk_cha = false, bk_b1 = false, bk_walk = false;
   int bk_res = -1;
-  unsigned bk_seen = 0;
-  unsigned matched = 0, head = 0, gstep = 0;
+  unsigned bk_seen = 0, bk_done = 0;
+  unsigned matched = 0, head = 0;
   unsigned minfc_all = ctl->minfc_all, minfm_all = ctl->minfm_all;
-  unsigned st_scans = 0, st_exact = 0, st_open = 0, st_ovwin = 0, st_gpu = 0, st_epochs = 0, st_tight = 0, st_walked = 0, st_dead = 0, st_opendead = 0;
-  unsigned long long tk_epoch = 0, tk_pre = 0;
+  unsigned st_scans = 0, st_exact = 0, st_open = 0, st_ovwin = 0, st_gpu = 0, st_epochs = 0, st_tight = 0, st_walked = 0, st_dead = 0, st_opendead = 0, st_spins = 0;
+  unsigned long long tk_epoch = 0, tk_pre = 0, tk_wait = 0;
   __syncthreads();
   const unsigned long long t_loop = cook_ticks();
   CfJob nxt;  // the stager's registers: the job of lane `lane` in the next batch
   nxt.c = nxt.m = nxt.meta = nxt.grp = nxt.eq[0] = nxt.eq[1] = nxt.nov[0] = nxt.nov[1] = 0u;
-  unsigned step_parity = 0, last_placed_grp = 0xFFFFFFFEu;
-  // a class wave whose level maxima changed writes the OTHER copy of its rows and switches here, in front of a barrier
-  auto publish_tables = [&]() {
-    if (aw_pending) {
-      aw_mine ^= 1u;
-      if (lane == 0) S.awcur[w] = aw_mine, S.misc[6] = aw_pending_lane, S.misc[2] = gstep + 1u;
-      aw_pending = false;
-    }
-  };
-  // the bookkeeper follows a published change: the jobs BEHIND the step that made it see the new maxima
+  unsigned seq_base = 1;  // the step number of the batch's first walked job (steps count from 1 over the whole call)
+#ifdef CF_PROF
+  unsigned prof[4] = {0, 0, 0, 0};
+#endif
+  // the bookkeeper follows a change of level maxima: the jobs BEHIND the step that made it see the new ones
   auto follow_tables = [&]() {
-    const unsigned seq = S.misc[2];
-    if (seq != bk_seen) {
-      bk_seen = seq;
+    const unsigned sq = S.misc[2];
+    if (sq != bk_seen) {
+      bk_seen = sq;
       if (lane > S.misc[6]) bk_cha = cf_chunks_have_room(S, bk_L, bk_m);
     }
   };
+  // the books of the batch's jobs behind lane s after a placement (ofc, ofm) -> (nfc, nfm)
+  auto books_placement = [&](unsigned s, unsigned id, bool from_overlay, bool opens, unsigned ofc, unsigned ofm, unsigned nfc, unsigned nfm) {
+    minfc_all = cf_min(minfc_all, nfc), minfm_all = cf_min(minfm_all, nfm);  // (the bookkeeper's: it sees every placement)
+    if (lane == s) bk_res = (int)id;
+    if (lane > s) {
+      bk_b1 = bk_b1 || bk_c > nfc || bk_m > nfm;
+      if (from_overlay) bk_cnt -= (ofc >= bk_c && ofm >= bk_m && !(nfc >= bk_c && nfm >= bk_m)) ? 1u : 0u;
+      else if (opens) bk_cnt += (nfc >= bk_c && nfm >= bk_m) ? 1u : 0u;
+    }
+  };
+  // a class wave takes a member out of chunk lane `ch` (position pos; gpu hosts stay, occupied) and keeps its summaries exact
+  auto class_remove = [&](unsigned pos, unsigned ch, bool gpu_place, unsigned ofc, unsigned ofm, unsigned nfc, unsigned nfm, unsigned s, unsigned seq) {
+    bool retable = false;
+    if (gpu_place) {
+      if (lane == 0) S.fc[pos] = nfc, S.fm[pos] = nfm, S.cid[pos] = (uint16_t)(S.cid[pos] | CF_OCC);
+      wave_sync();
+      retable = true;
+    } else {
+      const unsigned q0 = pos - (unsigned)wave_read_lane((int)c.pos0, (int)ch);
+      if (lane == ch) c.pres &= ~(1ull << q0);
+      CF_TRACE("class wave %u: position %u leaves chunk lane %u (member %u): present %llx\n", w, pos, ch, q0, c.pres);
+      const unsigned nl = cf_level_of(t, ofc);
+#define CF_WAS_MAX(i) retable = retable || ((unsigned)i < nl && (unsigned)wave_read_lane((int)c.lv.v##i, (int)ch) == ofm + 1u);
+      CF_FOR8(CF_WAS_MAX)
+#undef CF_WAS_MAX
+    }
+    if (retable) {
+      while (retable_seq != 0u && cf_poll(&S.misc[CFX_BK_DONE]) < retable_seq) SPIN_PAUSE_NEAR();  // (the bookkeeper reads the rows of the last change)
+      cf_tighten(S, t, lane, ch, c);
+      cf_wave_tables(S, w, lane, c, w == gpu_wave, n_kind);
+      if (lane == 0) S.misc[6] = s, st_wg(&S.misc[2], seq);
+      retable_seq = seq;
+      ++st_tight;
+    }
+  };
+  // the chunk lane of a position of this class wave
+  auto chunk_of = [&](unsigned pos) -> unsigned { return (unsigned)__ffsll(__ballot(pos >= c.pos0 && pos < c.pos0 + c.n)) - 1u; };
 
   for (unsigned base = 0; base < K; base += 64u) {
     const unsigned bn = cf_min(64u, K - base);
     const unsigned slot = (base >> 6) & 1u;
     // ---- batch pre-check (bookkeeper): who must be visited?
-    if (w == CF_WAVES - 1) {
+    if (is_books) {
       const unsigned long long t0 = cook_ticks();
       if (base + 64u + lane < K) nxt = b.jobs[base + 64u + lane];  // (arrives while the batch is walked)
       const CfJob j = S.ring[slot * 64u + (lane < bn ? lane : 0u)];
@@ -930,123 +1030,321 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
     }
     EMU_SITE("classfit: batch");
     __syncthreads();
-    unsigned long long wm = wave_uniform_u64((unsigned long long)S.misc[0] | (unsigned long long)S.misc[1] << 32);
-    st_walked += (unsigned)__popcll(wm);
-    while (wm) {
-      const unsigned s = (unsigned)__ffsll(wm) - 1u;
-      wm &= wm - 1ull;
-      const CfJobU J = cf_job_uniform(&S.ring[slot * 64u + s]);
-      if (J.grouped && J.grp == last_placed_grp) {  // the previous step put a cotask on an offer: the overlay wave's entry in the group table first
-        EMU_SITE("classfit: group hand-over");
-        __syncthreads();
-      }
-      last_placed_grp = 0xFFFFFFFEu;
-      CfPost* posts = S.post + step_parity * CF_WAVES;
-      step_parity ^= 1u;
-      CfPost mine;
+    const unsigned long long walkmask = wave_uniform_u64((unsigned long long)S.misc[0] | (unsigned long long)S.misc[1] << 32);
+    const unsigned nw = (unsigned)__popcll(walkmask);
+    st_walked += nw;
+    auto seq_of = [&](unsigned s) -> unsigned { return seq_base + (unsigned)__popcll(walkmask & ((1ull << s) - 1ull)); };
+    unsigned long long todo = walkmask;       // decider: the walked jobs not decided yet; class waves: not answered yet
+    bool batch_done = false;
+    while (!batch_done) {
+      unsigned md = 0;  // the collective turn this wave leaves its loop for
       if (w == 0) {
-        cf_overlay_query<false>(S, J, lane, o, 0.0, sc, sm, mine);
-        if (lane == 0) posts[0] = mine;
+        // ================================================= the decider =================================================
+        while (md == 0u) {
+          if (todo == 0ull) {
+            md = (seq_base + nw - 1u) << 4 | CFM_BATCH_END;
+            if (lane == 0) S.misc[CFX_DRAIN] = seq_base + nw - 1u, st_wg(&S.misc[CFX_MODE], md);
+            break;
+          }
+          const unsigned s = (unsigned)__ffsll(todo) - 1u;
+          const unsigned seq = seq_of(s);
+          CF_TRACE("decider: step %u lane %u\n", seq, s);
+          CF_PROF_T(p0);
+          if (lane == 0) st_wg(&S.misc[CFX_HEAD_SEQ], seq);
+          const CfJobU J = cf_job_uniform(&S.ring[slot * 64u + s]);
+          // the candidates of the six class waves into lanes 58..63
+          unsigned cpos = 0, cflags = 2u;
+          if (lane >= CF_OVL) {
+            const CfCand* e = &S.board[(seq & (CF_BOARD - 1u)) * CF_WAVES + (lane - CF_OVL + 1u)];
+            const unsigned want = seq << 8 | (o_ver & 255u);
+            for (;;) {
+              const unsigned tg = ld_wg(&e->tag);
+              COMPILER_FENCE();
+              if (tg == want) break;
+              ++st_spins;
+              SPIN_PAUSE_NEAR();
+            }
+            const CfCand cd = *e;
+            cpos = cd.pos, cflags = cd.flags;
+            o.valid = (cd.flags & 2u) ? 0u : 1u, o.id = cd.cid & CF_IDMASK, o.cls = cd.cid >> 16, o.fc = cd.fc, o.fm = cd.fm, o.Tc = cd.Tc, o.Tm = cd.Tm, o.hTc = cd.hTc, o.hTm = cd.hTm;
+          }
+          wave_sync();
+          CF_TRACE("decider: step %u has its candidates\n", seq);
+          CF_PROF_T(p1);
+          // one evaluation of the 64 lanes
+          const bool isov = lane < CF_OVL;
+          const bool room = o.valid && o.fc >= J.c && o.fm >= J.m && (!isov || J.kind == 0u);
+          const bool ok = room && (!isov || cf_cons_ok(S, J, o.id, room));
+          const double fa = ok ? 1.0 - ((double)(o.fc - J.c) * o.hTc + (double)(o.fm - J.m) * o.hTm) : 0.0;
+          const float ff = (float)fa;
+          const float mx = wave_max_f32(ff);
+          unsigned l0 = 0;
+          bool amb = false, any = mx > 0.0f;
+          if (any) {
+            l0 = (unsigned)__ffsll(__ballot(ok && ff == mx)) - 1u;
+            const double f0 = wave_read_lane_f64(fa, (int)l0);
+            const unsigned long long near = __ballot(ok && fa >= f0 - CF_BAND);  // (a lane above f0 is in here too: one bit = l0 is the greatest alone)
+            amb = (near & (near - 1ull)) != 0ull || (__ballot(ok && !isov && (cflags & 1u) && fa >= f0 - CF_BAND) != 0ull);
+          }
+          CF_PROF_T(p2);
+#ifdef __HIP_EMU__
+          if (cf_trace_on() && (ok || (lane >= CF_OVL))) std::fprintf(stderr, "  decider lane %u: valid %u offer %u fc %u fm %u fa %.17g ff %.9g mx %.9g l0 %u\n", lane, o.valid, o.id, o.fc, o.fm, fa, (double)ff, (double)mx, l0);
+#endif
+          if (amb) {  // the literal fitness decides: every wave in lockstep
+            md = seq << 4 | CFM_EXACT;
+            const unsigned long long fb = (unsigned long long)__double_as_longlong(wave_read_lane_f64(fa, (int)l0));
+            if (lane == 0)
+              S.misc[CFX_EX_LANE] = s, S.misc[CFX_FMAX_LO] = (unsigned)fb, S.misc[CFX_FMAX_HI] = (unsigned)(fb >> 32), S.misc[CFX_DRAIN] = seq - 1u, st_wg(&S.misc[CFX_MODE], md);
+            break;
+          }
+          todo &= todo - 1ull;
+          // ---- commit
+          while (seq - cf_poll(&S.misc[CFX_BK_DONE]) >= CF_VLOG) SPIN_PAUSE_NEAR();  // (the bookkeeper is this far behind: never seen)
+          CfVlog* vl = &S.vlog[seq & (CF_VLOG - 1u)];
+          if (!any) {
+            if (lane == 0) vl->info = s, COMPILER_FENCE(), st_wg(&vl->seq, seq);
+          } else {
+            const unsigned ofc = (unsigned)wave_read_lane((int)o.fc, (int)l0), ofm = (unsigned)wave_read_lane((int)o.fm, (int)l0), id = (unsigned)wave_read_lane((int)o.id, (int)l0);
+            const unsigned nfc = ofc - J.c, nfm = ofm - J.m;
+            const bool dead = nfc < cmin || nfm < mmin;
+            const bool from_ov = l0 < CF_OVL;
+            const bool gpu_place = !from_ov && J.kind != 0u;
+            const bool opens = !from_ov && !gpu_place && !dead;
+            ++matched;
+            if (base + s == 0u) head = 1u;
+            unsigned live = (unsigned)__popcll(__ballot(isov && o.valid != 0u));
+            if (from_ov) {
+              ++st_ovwin;
+              if (lane == l0) {
+                o.fc = nfc, o.fm = nfm;
+                if (dead) o.valid = 0u;
+              }
+              if (dead) ++st_dead, --live;
+            } else {
+              // the member leaves its class wave's arrays: a command, and the wave's candidates for the later steps count no more
+              if (lane == l0) {
+                ++o_ver, ++o_cmd;
+                CfCmd* cm = &S.cmd[l0 - CF_OVL + 1u];
+                cm->kind = gpu_place ? CFC_GPU_PLACE : CFC_REMOVE, cm->pos = cpos, cm->nfc = nfc, cm->nfm = nfm, cm->lane_s = s, cm->seq = seq;
+                COMPILER_FENCE();
+                st_wg(&cm->ver, o_cmd);
+              }
+              if (opens) {
+                ++st_open;
+                const unsigned lf = (unsigned)__ffsll(~__ballot(o.valid != 0u || !isov)) - 1u;  // (a free overlay lane: a full overlay ended the epoch at once)
+                const unsigned cls2 = (unsigned)wave_read_lane((int)o.cls, (int)l0), Tc2 = (unsigned)wave_read_lane((int)o.Tc, (int)l0), Tm2 = (unsigned)wave_read_lane((int)o.Tm, (int)l0);
+                const double hTc2 = wave_read_lane_f64(o.hTc, (int)l0), hTm2 = wave_read_lane_f64(o.hTm, (int)l0);
+                if (lane == lf) o.valid = 1u, o.id = id, o.cls = cls2, o.fc = nfc, o.fm = nfm, o.Tc = Tc2, o.Tm = Tm2, o.hTc = hTc2, o.hTm = hTm2;
+                ++live;
+              } else if (gpu_place) {
+                ++st_gpu;
+              } else {
+                ++st_opendead;
+              }
+            }
+            if (J.grouped) {  // the group's next members must not land on this offer: the table, and EVERY class wave answers the later steps again
+              if (lane == 0) {
+                const unsigned g0 = S.goff[J.grp], gn = S.gcnt[J.grp];
+                S.gids[g0 + gn] = (uint16_t)id, S.gcnt[J.grp] = (uint16_t)(gn + 1u);
+              }
+              wave_sync();
+              if (lane >= CF_OVL && (from_ov || lane != l0)) {
+                ++o_ver, ++o_cmd;
+                CfCmd* cm = &S.cmd[lane - CF_OVL + 1u];
+                cm->kind = CFC_NONE, cm->pos = 0u, cm->nfc = 0u, cm->nfm = 0u, cm->lane_s = s, cm->seq = seq;
+                COMPILER_FENCE();
+                st_wg(&cm->ver, o_cmd);
+              }
+            }
+            if (lane == 0) {
+              vl->info = s | 1u << 8 | (from_ov ? 1u : 0u) << 9 | (opens ? 1u : 0u) << 10 | (from_ov ? 0u : l0 - CF_OVL + 1u) << 12 | (J.grouped ? 1u : 0u) << 16;
+              vl->id = id, vl->ofc = ofc, vl->ofm = ofm, vl->nfc = nfc, vl->nfm = nfm;
+              COMPILER_FENCE();
+              st_wg(&vl->seq, seq);
+            }
+            if (opens && live >= CF_EPOCH_AT) {  // the overlay is full of live offers: back into their classes' arrays, every wave in lockstep
+              md = seq << 4 | CFM_EPOCH;
+              if (lane == 0) S.misc[CFX_EX_LANE] = s, S.misc[CFX_DRAIN] = seq, st_wg(&S.misc[CFX_MODE], md);
+            }
+          }
+          CF_PROF_T(p3);
+          CF_PROF_ADD(0, p1 - p0);
+          CF_PROF_ADD(1, p2 - p1);
+          CF_PROF_ADD(2, p3 - p2);
+        }
       } else if (is_class_wave) {
-        publish_tables();
-        cf_class_query<false>(S, J, lane, c, 0.0, sc, sm, mine, st_scans);
-        if (lane == 0) posts[w] = mine;
+        // ================================================= a class wave: answers ahead of the decider =================================================
+        while (md == 0u) {
+          const unsigned ver = cf_poll(&S.cmd[w].ver);
+          if (ver != o_cmd) {  // a member of ours was taken (or the group table changed): obey, then answer the steps behind that one again
+            COMPILER_FENCE();
+            CF_TRACE("class wave %u: command %u\n", w, ver);
+            const unsigned kind = cf_poll(&S.cmd[w].kind), pos = cf_poll(&S.cmd[w].pos), nfc = cf_poll(&S.cmd[w].nfc), nfm = cf_poll(&S.cmd[w].nfm), cs = cf_poll(&S.cmd[w].lane_s),
+                           cseq = cf_poll(&S.cmd[w].seq);
+            if (kind != CFC_NONE) {
+              const unsigned ch = chunk_of(pos);
+              const unsigned ofc = S.fc[pos], ofm = S.fm[pos];
+              class_remove(pos, ch, kind == CFC_GPU_PLACE, ofc, ofm, nfc, nfm, cs, cseq);
+            }
+            o_cmd = ver, ++o_ver;
+            todo = walkmask & ~((2ull << cs) - 1ull);
+            if (lane == 0) st_wg(&S.ack[w], cseq);
+            CF_TRACE("class wave %u: command %u obeyed (step %u)\n", w, ver, cseq);
+            continue;
+          }
+          const unsigned mode = cf_poll(&S.misc[CFX_MODE]);
+          if (mode != 0u) {
+            if (cf_poll(&S.cmd[w].ver) != o_cmd) continue;  // (a command given before the mode was raised comes first)
+            md = mode;
+            break;
+          }
+          if (todo != 0ull) {
+            const unsigned s = (unsigned)__ffsll(todo) - 1u;
+            const unsigned seq = seq_of(s);
+            if (seq < cf_poll(&S.misc[CFX_HEAD_SEQ]) + CF_BOARD) {
+              const CfJobU J = cf_job_uniform(&S.ring[slot * 64u + s]);
+              CfPost mine;
+              cf_class_query<false>(S, J, lane, c, 0.0, sc, sm, mine, st_scans);
+              CF_TRACE("class wave %u: answer for step %u lane %u: fa %.17g offer %u\n", w, seq, s, mine.fa, mine.w0);
+              if (lane == 0) {
+                CfCand* e = &S.board[(seq & (CF_BOARD - 1u)) * CF_WAVES + w];
+                const bool none = !(mine.fa > 0.0);
+                const CfClass cl = S.cls[none ? 0u : mine.cls];
+                e->pos = mine.pos, e->fc = mine.fc, e->fm = mine.fm, e->cid = mine.cls << 16 | (mine.w0 & CF_IDMASK), e->flags = (mine.w0 >> 31) | (none ? 2u : 0u);
+                e->Tc = cl.Tc, e->Tm = cl.Tm, e->hTc = cl.hTc, e->hTm = cl.hTm;
+                COMPILER_FENCE();
+                st_wg(&e->tag, seq << 8 | (o_ver & 255u));
+              }
+              todo &= todo - 1ull;
+              continue;
+            }
+          }
+          SPIN_PAUSE_NEAR();
+        }
+      } else {
+        // ================================================= the bookkeeper: follows the verdict log =================================================
+        while (md == 0u) {
+          const unsigned nx = bk_done + 1u;
+          const CfVlog* vl = &S.vlog[nx & (CF_VLOG - 1u)];
+          if (cf_poll(&vl->seq) == nx) {
+            COMPILER_FENCE();
+            const unsigned info = cf_poll(&vl->info);
+            const unsigned s = info & 255u;
+            if ((info >> 8) & 1u) {
+              const unsigned cw = (info >> 12) & 15u;
+              if (cw != 0u) {  // a member left class wave cw: its summaries (and the level maxima) are up to date once it says so
+                while (cf_poll(&S.ack[cw]) < nx) SPIN_PAUSE_NEAR();
+              }
+              const unsigned id = cf_poll(&vl->id), ofc = cf_poll(&vl->ofc), ofm = cf_poll(&vl->ofm), nfc = cf_poll(&vl->nfc), nfm = cf_poll(&vl->nfm);
+              follow_tables();
+              books_placement(s, id, ((info >> 9) & 1u) != 0u, ((info >> 10) & 1u) != 0u, ofc, ofm, nfc, nfm);
+            }
+            bk_done = nx;
+            CF_TRACE("bookkeeper: step %u done (info %x)\n", nx, info);
+            if (lane == 0) st_wg(&S.misc[CFX_BK_DONE], nx);
+            continue;
+          }
+          const unsigned mode = cf_poll(&S.misc[CFX_MODE]);
+          if (mode != 0u && bk_done >= cf_poll(&S.misc[CFX_DRAIN])) {
+            md = mode;
+            break;
+          }
+          SPIN_PAUSE_NEAR();
+        }
       }
-      EMU_SITE("classfit: step");
+      // ================================================= a collective turn: every wave =================================================
+      CF_TRACE("wave %u: to the collective turn %x\n", w, md);
+      EMU_SITE("classfit: collective");
       __syncthreads();
-      ++gstep;
-      if (w == CF_WAVES - 1) follow_tables();
-      CfVerdict v = cf_verdict<false>(posts, lane);
-      if (v.amb) {  // several candidates inside the band: the literal fitness decides (every wave takes this branch)
+      md = wave_uniform_u32(md);  // (every wave left its loop with the mode word the decider raised)
+      const unsigned kind = md & 15u, cseq = md >> 4;
+      bool epoch = kind == CFM_EPOCH;
+      unsigned s = S.misc[CFX_EX_LANE];
+      if (kind == CFM_EXACT) {
         ++st_exact;
+        const CfJobU J = cf_job_uniform(&S.ring[slot * 64u + s]);
+        const double fmax = __longlong_as_double((long long)((unsigned long long)S.misc[CFX_FMAX_LO] | (unsigned long long)S.misc[CFX_FMAX_HI] << 32));
+        CfPost mine;
         if (w == 0) {
-          cf_overlay_query<true>(S, J, lane, o, v.fmax, sc, sm, mine);
+          CfOvLane ov = o;  // (lanes 58..63 hold this step's candidates: the class waves answer for their members themselves)
+          if (lane >= CF_OVL) ov.valid = 0u;
+          cf_overlay_query<true>(S, J, lane, ov, fmax, sc, sm, mine);
           if (lane == 0) S.post2[0] = mine;
         } else if (is_class_wave) {
-          cf_class_query<true>(S, J, lane, c, v.fmax, sc, sm, mine, st_scans);
+          cf_class_query<true>(S, J, lane, c, fmax, sc, sm, mine, st_scans);
           if (lane == 0) S.post2[w] = mine;
         }
         EMU_SITE("classfit: exact turn");
         __syncthreads();
-        const unsigned live = v.ov_live;
-        v = cf_verdict<true>(S.post2, lane);
-        v.ov_live = live;
-        __syncthreads();  // (post2 is free again)
-      }
-      bool epoch = false;
-      if (v.src >= 0) {
+        const CfVerdict v = cf_verdict<true>(S.post2, lane);
+        // (an exact turn is raised because candidates exist: v.src >= 0)
         const unsigned nfc = v.fc - J.c, nfm = v.fm - J.m;
         const bool dead = nfc < cmin || nfm < mmin;
-        const bool gpu_place = v.src > 0 && J.kind != 0u;
-        const bool opens = v.src > 0 && !gpu_place && !dead;
+        const bool from_ov = v.src == 0;
+        const bool gpu_place = !from_ov && J.kind != 0u;
+        const bool opens = !from_ov && !gpu_place && !dead;
         ++matched;
-        if (J.grouped) last_placed_grp = J.grp;
         if (base + s == 0u) head = 1u;
-        minfc_all = cf_min(minfc_all, nfc), minfm_all = cf_min(minfm_all, nfm);
-        if (w == 0) {  // ---- the overlay wave
-          if (v.src == 0) {
+        if (w == 0) {
+          unsigned live = (unsigned)__popcll(__ballot(lane < CF_OVL && o.valid != 0u));
+          if (from_ov) {
             ++st_ovwin;
             if (lane == v.pos) {
               o.fc = nfc, o.fm = nfm;
               if (dead) o.valid = 0u;
             }
-            if (dead) ++st_dead;
-          } else if (opens) {
-            ++st_open;
-            const unsigned long long freem = ~__ballot(o.valid != 0u);
-            const unsigned l = (unsigned)__ffsll(freem) - 1u;  // (a free lane exists: a full overlay ends the epoch at once)
-            const CfClass cl = S.cls[v.cls];
-            if (lane == l) o.valid = 1u, o.id = v.id, o.cls = v.cls, o.fc = nfc, o.fm = nfm, o.Tc = cl.Tc, o.Tm = cl.Tm, o.hTc = cl.hTc, o.hTm = cl.hTm;
-          } else if (gpu_place) {
-            ++st_gpu;
+            if (dead) ++st_dead, --live;
           } else {
-            ++st_opendead;
+            if (lane == CF_OVL - 1u + (unsigned)v.src) ++o_ver;  // (the class wave takes its member out itself, below; no command)
+            if (opens) {
+              ++st_open;
+              const unsigned lf = (unsigned)__ffsll(~__ballot(o.valid != 0u || lane >= CF_OVL)) - 1u;
+              const CfClass cl = S.cls[v.cls];
+              if (lane == lf) o.valid = 1u, o.id = v.id, o.cls = v.cls, o.fc = nfc, o.fm = nfm, o.Tc = cl.Tc, o.Tm = cl.Tm, o.hTc = cl.hTc, o.hTm = cl.hTm;
+              ++live;
+            } else if (gpu_place) {
+              ++st_gpu;
+            } else {
+              ++st_opendead;
+            }
           }
-          if (J.grouped && lane == 0) {  // the group's next members must not land on this offer
-            const unsigned g0 = S.goff[J.grp], gn = S.gcnt[J.grp];
-            S.gids[g0 + gn] = (uint16_t)v.id, S.gcnt[J.grp] = (uint16_t)(gn + 1u);
+          if (J.grouped) {
+            if (lane == 0) {
+              const unsigned g0 = S.goff[J.grp], gn = S.gcnt[J.grp];
+              S.gids[g0 + gn] = (uint16_t)v.id, S.gcnt[J.grp] = (uint16_t)(gn + 1u);
+            }
+            if (lane >= CF_OVL && (from_ov || lane != CF_OVL - 1u + (unsigned)v.src)) ++o_ver;
           }
-        } else if ((int)w == v.src) {  // ---- the class wave the member came from
-          const unsigned ch = v.aux, q0 = v.pos - (unsigned)wave_read_lane((int)c.pos0, (int)ch);
-          bool retable = false;
-          if (gpu_place) {  // in place: the host is occupied from now on (constraints.clj:122-157), its room still counts for the failure codes
-            if (lane == 0) S.fc[v.pos] = nfc, S.fm[v.pos] = nfm, S.cid[v.pos] |= CF_OCC;
-            wave_sync();
-            retable = true;
-          } else {
-            if (lane == ch) c.pres &= ~(1ull << q0);
-            // the summaries stay exact: was the member a level's maximum?
-            const unsigned nl = cf_level_of(t, v.fc);
-#pragma unroll
-            for (int i = 0; i < CF_LV; ++i) retable = retable || ((unsigned)i < nl && (unsigned)wave_read_lane((int)c.lv[i], (int)ch) == v.fm + 1u);
-          }
-          if (retable) {
-            cf_tighten(S, t, lane, ch, c);
-            cf_wave_tables(S, w, lane, c, w == gpu_wave, n_kind, aw_mine ^ 1u);
-            aw_pending = true, aw_pending_lane = s;
-            ++st_tight;
-          }
+          todo &= ~(1ull << s);
+          epoch = opens && live >= CF_EPOCH_AT;
+          if (lane == 0) S.misc[7] = epoch ? 1u : 0u;
+        } else if (is_class_wave) {
+          const bool mine_src = (int)w == v.src;
+          if (mine_src) class_remove(v.pos, v.aux, gpu_place, v.fc, v.fm, nfc, nfm, s, cseq);
+          if (mine_src || J.grouped) ++o_ver, todo = walkmask & ~((2ull << s) - 1ull);
+          if (lane == 0) st_wg(&S.ack[w], cseq);
+        } else {
+          follow_tables();
+          books_placement(s, v.id, from_ov, opens, v.fc, v.fm, nfc, nfm);
+          bk_done = cseq;
+          if (lane == 0) st_wg(&S.misc[CFX_BK_DONE], cseq);
         }
-        if (w == CF_WAVES - 1) {  // ---- the books of the batch's later jobs
-          if (lane == s) bk_res = (int)v.id;
-          if (lane > s) {
-            bk_b1 = bk_b1 || bk_c > nfc || bk_m > nfm;
-            if (v.src == 0) bk_cnt -= (v.fc >= bk_c && v.fm >= bk_m && !(nfc >= bk_c && nfm >= bk_m)) ? 1u : 0u;
-            else if (opens) bk_cnt += (nfc >= bk_c && nfm >= bk_m) ? 1u : 0u;
-          }
-        }
-        epoch = opens && v.ov_live + 1u >= CF_OV_CAP;
+        EMU_SITE("classfit: exact turn done");
+        __syncthreads();
+        epoch = S.misc[7] != 0u;
+        if (is_books) follow_tables();  // (a change of level maxima made in this turn)
       }
       if (epoch) {  // ---- the overlay is full of live offers: back into their classes' arrays
         const unsigned long long te = cook_ticks();
         ++st_epochs;
         // (1) the overlay's lanes, sorted by (class, E, offer), into LDS
         if (w == 0) {
-          const unsigned long long key = o.valid ? ((unsigned long long)o.cls << 58 | ((unsigned long long)o.fc * o.Tm + (unsigned long long)o.fm * o.Tc) << 13 | (unsigned long long)o.id) : ~0ull;
+          const bool live = lane < CF_OVL && o.valid != 0u;
+          const unsigned long long key = live ? ((unsigned long long)o.cls << 58 | ((unsigned long long)o.fc * o.Tm + (unsigned long long)o.fm * o.Tc) << 13 | (unsigned long long)o.id) : ~0ull;
           unsigned rank = 0;
           for (unsigned l = 0; l < 64u; ++l) rank += wave_read_lane_u64(key, (int)l) < key ? 1u : 0u;
-          if (o.valid) S.ovl[3u * rank] = o.cls << 16 | o.id, S.ovl[3u * rank + 1u] = o.fc, S.ovl[3u * rank + 2u] = o.fm;
-          const unsigned nlive = (unsigned)__popcll(__ballot(o.valid != 0u));
+          if (live) S.ovl[3u * rank] = o.cls << 16 | o.id, S.ovl[3u * rank + 1u] = o.fc, S.ovl[3u * rank + 2u] = o.fm;
+          const unsigned nlive = (unsigned)__popcll(__ballot(live));
           if (lane == 0) S.misc[3] = nlive;
           o.valid = 0u;
         }
@@ -1078,7 +1376,7 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
                 const unsigned long long pres = wave_read_lane_u64(c.pres, (int)ch);
                 const bool in = lane < n;
                 const bool keep = in && ((pres >> lane) & 1ull);
-                const uint32_t fc = S.fc[pos0 + lane], fm = S.fm[pos0 + lane], cid = S.cid[pos0 + lane];
+                const uint32_t fc = S.fc[pos0 + lane], fm = S.fm[pos0 + lane], cid = ci << 16 | (uint32_t)S.cid[pos0 + lane];
                 const unsigned long long E = (unsigned long long)fc * Tm + (unsigned long long)fm * Tc;
                 const unsigned idq = cid & CF_IDMASK;
                 const unsigned long long keepm = __ballot(keep);
@@ -1120,36 +1418,43 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
         for (unsigned ci = 0; ci < n_cls; ++ci) newM += S.ckept[ci] + S.ckept[CF_MAXCLS + ci];
         for (unsigned q = tid; q < NP; q += CF_THREADS) {
           const bool inq = q < newM;
-          S.fc[q] = inq ? ld_agent(&b.scr_fc[q]) : 0u, S.fm[q] = inq ? ld_agent(&b.scr_fm[q]) : 0u, S.cid[q] = inq ? ld_agent(&b.scr_cid[q]) : 0xFFFFFFFFu;
+          S.fc[q] = inq ? ld_agent(&b.scr_fc[q]) : 0u, S.fm[q] = inq ? ld_agent(&b.scr_fm[q]) : 0u, S.cid[q] = inq ? (uint16_t)ld_agent(&b.scr_cid[q]) : (uint16_t)0xFFFFu;
         }
         if (tid < n_cls) S.cls[tid].n = S.ckept[tid] + S.ckept[CF_MAXCLS + tid], S.cls[tid].off = S.ckept[2 * CF_MAXCLS + tid];
         EMU_SITE("classfit: epoch 4");
         __syncthreads();
-        // (5) lanes, summaries, tables, books
+        // (5) lanes, summaries, tables, books; every candidate on the board is void: a new version everywhere
         if (is_class_wave) {
           cf_setup_chunks(S.cls, n_cls, w, lane, c, nch_wave);
           for (unsigned ch = 0; ch < nch_wave; ++ch) cf_tighten(S, t, lane, ch, c);
-          aw_pending = false;  // (a change of this very step is part of what is written now)
-          cf_wave_tables(S, w, lane, c, w == gpu_wave, n_kind, aw_mine);
-          if (w == 1u && lane == 0) S.misc[6] = s, S.misc[2] = gstep + 0x40000000u;  // (a sequence number no step's publication uses)
+          cf_wave_tables(S, w, lane, c, w == gpu_wave, n_kind);
+          if (w == 1u && lane == 0) S.misc[6] = s, S.misc[2] = cseq + 0x40000000u;  // (a sequence number no step's change uses)
+          ++o_ver;
+          todo = walkmask & ~((2ull << s) - 1ull);
+          retable_seq = 0u;
         }
-        if (w == CF_WAVES - 1 && lane > s) bk_cnt = 0u;
+        if (w == 0 && lane >= CF_OVL) ++o_ver;
+        if (is_books && lane > s) bk_cnt = 0u;
         EMU_SITE("classfit: epoch 5");
         __syncthreads();
-        if (w == CF_WAVES - 1) follow_tables();
+        if (is_books) follow_tables();
         tk_epoch += cook_ticks() - te;
       }
+      if (kind == CFM_BATCH_END) batch_done = true;
+      if (tid == 0) st_wg(&S.misc[CFX_MODE], 0u);
+      EMU_SITE("classfit: collective done");
+      __syncthreads();
+      CF_TRACE("wave %u: collective turn done, batch_done %d\n", w, (int)batch_done);
     }
-    if (is_class_wave) publish_tables();
+    seq_base += nw;
     if (w == 0) {  // the overlay's free values for the next pre-check
-      S.ovm[2u * lane] = o.valid ? o.fc : 0u, S.ovm[2u * lane + 1u] = o.valid ? o.fm : 0u;
-      const unsigned long long vm = __ballot(o.valid != 0u);
+      const bool live = lane < CF_OVL && o.valid != 0u;
+      S.ovm[2u * lane] = live ? o.fc : 0u, S.ovm[2u * lane + 1u] = live ? o.fm : 0u;
+      const unsigned long long vm = __ballot(live);
       if (lane == 0) S.misc[4] = (unsigned)vm, S.misc[5] = (unsigned)(vm >> 32);
     }
-    EMU_SITE("classfit: batch end");
-    __syncthreads();
     // ---- batch end: results out, the next batch's jobs in
-    if (w == CF_WAVES - 1) {
+    if (is_books) {
       follow_tables();
       if (lane < bn) {
         const unsigned k = base + lane;
@@ -1165,20 +1470,31 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
       }
       if (base + 64u + lane < K) S.ring[(slot ^ 1u) * 64u + lane] = nxt;
     }
+    EMU_SITE("classfit: batch end");
+    __syncthreads();
+    CF_TRACE("wave %u: batch at %u ended\n", w, base);
   }
-  __syncthreads();
-  if (tid == 0) {
+  if (w == 0 && lane == 0) {
     st.summary[0] = matched;
     st.summary[1] = (matched == 0u || head) ? 1u : 0u;
     st.summary[2] = st_epochs;
     const unsigned long long t_end = cook_ticks();
     uint32_t* sx = ctl->stats;
     sx[CFS_MATCHED] = matched, sx[CFS_OV_WIN] = st_ovwin, sx[CFS_OPEN] = st_open, sx[CFS_OPEN_DEAD] = st_opendead, sx[CFS_GPU_PLACE] = st_gpu, sx[CFS_EPOCHS] = st_epochs,
-    sx[CFS_EXACT] = st_exact, sx[CFS_WALKED] = st_walked, sx[CFS_DEAD_DROP] = st_dead, sx[CFS_BATCHES] = (K + 63u) / 64u;
+    sx[CFS_EXACT] = st_exact, sx[CFS_WALKED] = st_walked, sx[CFS_DEAD_DROP] = st_dead, sx[CFS_BATCHES] = (K + 63u) / 64u, sx[CFS_PRESETTLED] = K - st_walked;
     sx[CFS_TICKS_TOTAL] = (uint32_t)(t_end - t_start), sx[CFS_TICKS_PROLOGUE] = (uint32_t)(t_loop - t_start), sx[CFS_TICKS_EPOCH] = (uint32_t)tk_epoch;
   }
+  if (w == 0) {
+    const unsigned sp = wave_max_u32(lane >= CF_OVL ? st_spins : 0u);
+    if (lane == 0) ctl->stats[CFS_SPINS] = sp;
+  }
   if (is_class_wave && lane == 0) atomicAdd(&ctl->stats[CFS_SCANS], st_scans), atomicAdd(&ctl->stats[CFS_TIGHTEN], st_tight);
-  if (w == CF_WAVES - 1 && lane == 0) ctl->stats[CFS_TICKS_PRECHECK] = (uint32_t)tk_pre;
+  if (is_books && lane == 0) ctl->stats[CFS_TICKS_PRECHECK] = (uint32_t)tk_pre;
+  (void)tk_wait;
+#ifdef CF_PROF
+  if (lane == 0 && w == 0)
+    for (int i = 0; i < 4; ++i) ctl->stats[20 + i] = prof[i];
+#endif
 }
 
 struct CfPoolCtx {  // one pool of a launch

@@ -268,7 +268,7 @@ struct cook_engine {
   CfPoolCtx deferred_cf{};
   unsigned last_form = 0;               // how the last match was placed: 0 window rounds, 1 serial sweep, 3 class-ordered best fit
   unsigned cf_inelig = 0;               // why the last match that asked for class-ordered best fit did not get it (CF_X_* bits; 0x10000: switched off / the host's checks)
-  uint32_t cf_stats[32] = {};
+  uint32_t cf_stats[48] = {};
   char* h_cf = nullptr;                 // pinned: summaries and statistics of the pools of a cf_run led by this engine
 
   void fail(int code, const std::string& m) { throw cook_error(code, m); }
@@ -1314,14 +1314,14 @@ static void launch_round(cook_engine* e, const MatchIn& in, const MatchState& st
 // ---- class-ordered best fit (classfit.hpp): set-up, eligibility, launch --------------------------------------------------------------------
 // COOK_CLASSFIT=0: every match goes through the window rounds (A/B switch)
 static const bool g_classfit = env_switch_on_unless_zero("COOK_CLASSFIT");
-static size_t cf_lds_bytes_host(unsigned NP, unsigned M, bool eq, unsigned G, unsigned S) {
-  size_t n = (size_t)NP * 12u;
+static size_t cf_lds_bytes_host(unsigned NP, unsigned M, bool eq, unsigned G, unsigned S) {  // the layout of cf_walk_pool
+  size_t n = (size_t)NP * 10u;
   n = (n + 7u) & ~(size_t)7u;
   if (eq) n += (size_t)M * 8u;
   n += ((size_t)G + 1u) * 2u + (size_t)G * 2u + (size_t)S * 2u;
   n = (n + 15u) & ~(size_t)15u;
-  n += 2u * 64u * sizeof(CfJob) + 3u * CF_WAVES * sizeof(CfPost);
-  n += (3u * CF_WAVES * CF_LV + CF_WAVES + CF_MAXKIND * CF_LV + 128u + 192u + 3u * CF_MAXCLS + 16u) * 4u + CF_MAXCLS * sizeof(CfClass);
+  n += 2u * 64u * sizeof(CfJob) + CF_BOARD * CF_WAVES * sizeof(CfCand) + CF_WAVES * sizeof(CfCmd) + CF_VLOG * sizeof(CfVlog) + CF_WAVES * sizeof(CfPost) + CF_MAXCLS * sizeof(CfClass);
+  n += (2u * CF_WAVES * CF_LV + CF_MAXKIND * CF_LV + CF_WAVES + 128u + 192u + 3u * CF_MAXCLS + 16u) * 4u;
   return n + 64u;
 }
 // the three set-up kernels of a call and the look at what they found -> true: the call can be placed by cf_walk (ctx filled in)
@@ -1380,20 +1380,23 @@ void cf_run(cook_engine* lead, cook_engine* const* es, unsigned n, hipStream_t s
     const unsigned G = es[i]->last_in.G;
     if (G) KLS("cf_group_chains", stream, cf_group_chains, div_up(G, 256), 256, c.b, c.st, G);
   }
-  constexpr size_t SLOT = 16 + 32 * 4;  // a pool's summary words and statistics
+  constexpr size_t SLOT = 16 + 48 * 4;  // a pool's summary words and statistics
   if (!lead->h_cf) COOK_HIP(hipHostMalloc((void**)&lead->h_cf, 64 * SLOT, hipHostMallocDefault));
   if (n > 64) lead->fail(COOK_E_INVALID, "cook_cycle_match_multi: at most 64 pools per call");
   for (unsigned i = 0; i < n; ++i) {
     char* slot = lead->h_cf + i * SLOT;
     COOK_HIP(hipMemcpyAsync(slot, es[i]->deferred_cf.st.summary, 16, hipMemcpyDeviceToHost, stream));
-    COOK_HIP(hipMemcpyAsync(slot + 16, es[i]->deferred_cf.b.ctl->stats, 32 * 4, hipMemcpyDeviceToHost, stream));
+    COOK_HIP(hipMemcpyAsync(slot + 16, es[i]->deferred_cf.b.ctl->stats, 48 * 4, hipMemcpyDeviceToHost, stream));
   }
   COOK_HIP(hipStreamSynchronize(stream));
   for (unsigned i = 0; i < n; ++i) {
     cook_engine* x = es[i];
     const unsigned* sum = (const unsigned*)(lead->h_cf + i * SLOT);
     if (sum[3] == 0xDEADu) lead->fail(COOK_E_STATE, "cf_walk: the pool's tables do not fit the workgroup's LDS (the host's check let it through)");
-    std::memcpy(x->cf_stats, lead->h_cf + i * SLOT + 16, 32 * 4);
+    std::memcpy(x->cf_stats, lead->h_cf + i * SLOT + 16, 48 * 4);
+#ifdef CF_PROF
+    std::fprintf(stderr, "CFPROF ticks (query, barrier wait, verdict, commit): overlay %u %u %u %u | class wave 1 %u %u %u %u | class wave 2 %u %u %u %u | bookkeeper %u %u %u %u\n", x->cf_stats[20], x->cf_stats[21], x->cf_stats[22], x->cf_stats[23], x->cf_stats[24], x->cf_stats[25], x->cf_stats[26], x->cf_stats[27], x->cf_stats[28], x->cf_stats[29], x->cf_stats[30], x->cf_stats[31], x->cf_stats[32], x->cf_stats[33], x->cf_stats[34], x->cf_stats[35]);
+#endif
     WinCtl c{};
     c.matched = sum[0], c.head_matched = sum[1], c.rounds = sum[2], c.head = x->last_in.K, c.visited_sum = x->cf_stats[CFS_WALKED];
     c.t_seq = x->cf_stats[CFS_TICKS_TOTAL], c.t_setup = x->cf_stats[CFS_TICKS_PROLOGUE];

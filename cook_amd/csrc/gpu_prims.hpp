@@ -27,6 +27,16 @@ static __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_l
 template <class T>
 static __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// words in LDS that one wave of a workgroup writes and another polls (classfit.hpp: the candidate board, commands, the verdict log).  Relaxed accesses the
+// compiler neither removes nor moves across COMPILER_FENCE(); the LDS executes one wave's operations in program order, so a reader that finds the
+// tag a writer stored LAST finds the fields the writer stored before it.
+template <class T>
+static __device__ __forceinline__ T ld_wg(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <class T>
+static __device__ __forceinline__ void st_wg(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define COMPILER_FENCE() asm volatile("" ::: "memory")
+#define SPIN_PAUSE_NEAR() __builtin_amdgcn_s_sleep(1)  // between polls of an LDS word
+
 // ---- hand-off between workgroups of DIFFERENT launches that run side by side (the served walkers, match_v2.hpp) ----------------------
 // The tested forms of MI355X_MICROARCH.md: producer = plain stores -> agent_release() -> relaxed agent-scope flag store; consumer =
 // relaxed poll of the flag -> ONE agent_acquire() -> plain loads.  The inline-asm wait is deliberate: ROCm 7.2 drops the s_waitcnt

@@ -27,6 +27,14 @@ static inline T ld_agent(const T* p) { return *p; }
 template <class T>
 static inline void st_agent(T* p, T v) { *p = v; emu::progress(); }
 
+// LDS words one wave writes and another polls (classfit.hpp): lanes are fibers that switch only at rendezvous points and in emu::yield()
+template <class T>
+static inline T ld_wg(const T* p) { return *p; }
+template <class T>
+static inline void st_wg(T* p, T v) { *p = v; emu::progress(); }
+#define COMPILER_FENCE() ((void)0)
+#define SPIN_PAUSE_NEAR() emu::yield()
+
 // hand-off between workgroups of different launches (the served walkers): memory is sequentially consistent here, and launches run
 // one after the other, so nothing ever waits — the served path runs in its STEPPING form (match_v2.hpp)
 static inline void agent_release() {}
