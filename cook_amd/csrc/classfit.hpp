@@ -33,7 +33,8 @@ constexpr unsigned CF_SORT_N = 8192;      // offers per call at most (the prepar
 constexpr unsigned CF_LDS_BYTES = 160u * 1024u - 2048u;
 constexpr unsigned CF_MAXG = 4096;        // groups per call
 constexpr unsigned CF_GMEM = 16;          // pending members per unique host-placement group
-constexpr unsigned CF_OCC = 0x8000u, CF_IDMASK = 0x7FFFu;  // pos_cid = class << 16 | occupied gpu host << 15 | offer
+constexpr unsigned CF_OCC = 0x8000u, CF_TIE = 0x4000u, CF_IDMASK = 0x3FFFu;  // pos_cid = class << 16 | occupied gpu host << 15 | the NEXT member of the
+                                                                             // class may round to the same fitness << 14 | offer
 constexpr unsigned CF_KIND_NONE = 0xFFu;
 constexpr double CF_BAND = 1.0 / 137438953472.0;  // 2^-37
 
@@ -197,7 +198,7 @@ COOK_KERNEL void cf_prepare(const MatchIn* __restrict__ inp, CfBuf b, const doub
   __shared__ unsigned s_pair_cls[256];
   __shared__ unsigned s_cnt[CF_MAXCLS], s_off[CF_MAXCLS];
   __shared__ unsigned s_bad, s_minfc, s_minfm, s_ncls;
-  __shared__ unsigned s_pkey[256];
+  __shared__ unsigned long long s_dE[CF_MAXCLS];
   const unsigned tid = threadIdx.x;
   CfCtl* ctl = b.ctl;
   if (tid == 0) {
@@ -296,6 +297,7 @@ COOK_KERNEL void cf_prepare(const MatchIn* __restrict__ inp, CfBuf b, const doub
       cl.Tc = (uint32_t)(shape >> 32), cl.Tm = (uint32_t)shape, cl.kind = (unsigned)ck[c], cl.n = 0u, cl.off = 0u, cl.wave = 0u, cl.pad0 = cl.pad1 = 0u;
       cl.hTc = 0.5 / (double)cl.Tc, cl.hTm = 0.5 / (double)cl.Tm;
       cl.dE = (uint64_t)(CF_BAND * 2.0 * (double)cl.Tc * (double)cl.Tm);
+      s_dE[c] = cl.dE;
       if (!(2.0 * (double)cl.Tc * (double)cl.Tm < 35184372088832.0)) s_bad |= CF_X_SHAPE;  // E below 2^45: the sort key is class | E | offer
     }
     s_ncls = nc;
@@ -346,7 +348,10 @@ COOK_KERNEL void cf_prepare(const MatchIn* __restrict__ inp, CfBuf b, const doub
     const OfferB o = b.ob[v];
     const bool gpu_host = (o.flags & 1u) && o.gpu_model != 0u;
     b.pos_fc[q] = cf_fx(a.oc, kc), b.pos_fm[q] = cf_fx(a.om, km);
-    b.pos_cid[q] = c << 16 | ((gpu_host && o.run_count != 0) ? CF_OCC : 0u) | v;
+    // the next member of the class inside the guard band of this one: whoever takes this one as the best must look at the literal fitness
+    const unsigned long long nk = q + 1u < M ? s_key[q + 1u] : ~0ull;
+    const bool tie = (unsigned)(nk >> 58) == c && ((nk >> 13) & ((1ull << 45) - 1ull)) <= ((key >> 13) & ((1ull << 45) - 1ull)) + s_dE[c];
+    b.pos_cid[q] = c << 16 | ((gpu_host && o.run_count != 0) ? CF_OCC : 0u) | (tie ? CF_TIE : 0u) | v;
   }
   if (tid == 0) {
     // offsets; waves: the classes of hosts without gpus first (a wave's lanes hold 64 chunks), all gpu classes in ONE wave
@@ -707,6 +712,49 @@ static __device__ __forceinline__ void cf_class_query(const CfLds& S, const CfJo
   if (!EXACT && amb) out.w0 |= 0x80000000u;
 }
 
+// A class wave's answer for the decider: per relevant class the FIRST feasible member of the first chunk that can hold one (sorted by E: the class's
+// best); of several classes of the wave the one of greatest approximate fitness.  w0 bit 31: another member / class may round to the same fitness.
+// Written for the decider's critical path: nothing is computed that only the winner needs, a wave with one relevant class computes no fitness at all.
+static __device__ __forceinline__ void cf_class_answer(const CfLds& S, const CfJobU& J, unsigned lane, const CfChunkLane& c, CfPost& out, unsigned& scans) {
+  out.fa = 0.0, out.w0 = 0u, out.pos = 0u, out.fc = 0u, out.fm = 0u, out.cls = 0u, out.aux = 0u;
+  const uint32_t lvL = cf_lv_get(c.lv, J.L);
+  unsigned long long m = __ballot(c.kind == J.kind && lvL > J.m);
+  bool amb = false, have = false;
+  while (m) {
+    const unsigned ch = (unsigned)__ffsll(m) - 1u;
+    ++scans;
+    const unsigned pos0 = (unsigned)wave_read_lane((int)c.pos0, (int)ch), n = (unsigned)wave_read_lane((int)c.n, (int)ch);
+    const unsigned long long pres = wave_read_lane_u64(c.pres, (int)ch);
+    const bool in = lane < n && ((pres >> lane) & 1ull);
+    const unsigned q = pos0 + lane;
+    const uint32_t fc = S.fc[q], fm = S.fm[q], cid = S.cid[q];
+    const bool room = in && fc >= J.c && fm >= J.m && !(cid & CF_OCC);
+    const bool ok = room && cf_cons_ok(S, J, cid & CF_IDMASK, room);
+    const unsigned long long b = __ballot(ok);
+    if (b == 0ull) {
+      m &= ~(1ull << ch);
+      continue;
+    }
+    const unsigned q0 = (unsigned)__ffsll(b) - 1u;
+    const unsigned fc0 = (unsigned)wave_read_lane((int)fc, (int)q0), fm0 = (unsigned)wave_read_lane((int)fm, (int)q0), cid0 = (unsigned)wave_read_lane((int)cid, (int)q0);
+    const unsigned cls = (unsigned)wave_read_lane((int)c.cls, (int)ch);
+    m &= ~__ballot(c.cls == cls);  // the class is answered
+    const bool tie = (cid0 & CF_TIE) != 0u;
+    if (!have && m == 0ull) {  // the wave's only class with a candidate: the decider works the fitness out itself
+      out.fa = 1.0, out.w0 = cid0 & CF_IDMASK, out.pos = pos0 + q0, out.fc = fc0, out.fm = fm0, out.cls = cls, out.aux = ch;
+      amb = tie;
+      break;
+    }
+    const double hTc = wave_read_lane_f64(c.hTc, (int)ch), hTm = wave_read_lane_f64(c.hTm, (int)ch);
+    const double f0 = 1.0 - ((double)(fc0 - J.c) * hTc + (double)(fm0 - J.m) * hTm);
+    if (!have || f0 > out.fa + CF_BAND) amb = tie;
+    else if (f0 >= out.fa - CF_BAND) amb = true;
+    if (!have || f0 > out.fa) out.fa = f0, out.w0 = cid0 & CF_IDMASK, out.pos = pos0 + q0, out.fc = fc0, out.fm = fm0, out.cls = cls, out.aux = ch;
+    have = true;
+  }
+  if (amb) out.w0 |= 0x80000000u;
+}
+
 struct CfOvLane {  // the overlay wave's lane = one offer this call has placed on
   unsigned valid, id, cls, fc, fm, Tc, Tm;
   double hTc, hTm;
@@ -800,8 +848,8 @@ constexpr unsigned CF_EPOCH_AT = COOK_SHAPE(58, 8);  // live overlay lanes that 
 enum : unsigned { CFM_EXACT = 1u, CFM_EPOCH = 2u, CFM_BATCH_END = 3u };
 enum : unsigned { CFC_REMOVE = 1u, CFC_GPU_PLACE = 2u, CFC_NONE = 3u };
 enum : unsigned { CFX_HEAD_SEQ = 8, CFX_MODE = 9, CFX_DRAIN = 10, CFX_BK_DONE = 11, CFX_EX_LANE = 12, CFX_FMAX_LO = 13, CFX_FMAX_HI = 14 };  // words of CfLds::misc
-struct CfCand {  // a class wave's answer for one step (48 B); tag = step << 8 | version, stored LAST
-  uint32_t tag, pos, fc, fm, cid, flags, Tc, Tm;  // flags: 1 another member may round to the same fitness, 2 no candidate
+struct CfCand {  // a class wave's answer for one step (40 B); tag = step << 8 | version, stored LAST
+  uint32_t tag, pos, fc, fm, cid, flags;  // flags: 1 another member may round to the same fitness, 2 no candidate
   double hTc, hTm;
 };
 struct CfCmd {  // decider -> class wave (32 B); ver stored LAST
@@ -926,6 +974,8 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
     if (S.cls[ci].kind != 0u) gpu_wave = S.cls[ci].wave;
   const bool is_class_wave = w >= 1u && w <= (unsigned)CF_CW;
   const bool is_books = w == (unsigned)CF_WAVES - 1u;
+  unsigned live_waves = 0;  // class waves that hold classes (the others sleep through the batches)
+  for (unsigned ci = 0; ci < n_cls; ++ci) live_waves |= 1u << S.cls[ci].wave;
   if (is_class_wave) {
     for (unsigned ch = 0; ch < nch_wave; ++ch) cf_tighten(S, t, lane, ch, c);
     cf_wave_tables(S, w, lane, c, w == gpu_wave, n_kind);
@@ -1054,7 +1104,7 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
           const CfJobU J = cf_job_uniform(&S.ring[slot * 64u + s]);
           // the candidates of the six class waves into lanes 58..63
           unsigned cpos = 0, cflags = 2u;
-          if (lane >= CF_OVL) {
+          if (lane >= CF_OVL && ((live_waves >> (lane - CF_OVL + 1u)) & 1u)) {
             const CfCand* e = &S.board[(seq & (CF_BOARD - 1u)) * CF_WAVES + (lane - CF_OVL + 1u)];
             const unsigned want = seq << 8 | (o_ver & 255u);
             for (;;) {
@@ -1066,8 +1116,9 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
             }
             const CfCand cd = *e;
             cpos = cd.pos, cflags = cd.flags;
-            o.valid = (cd.flags & 2u) ? 0u : 1u, o.id = cd.cid & CF_IDMASK, o.cls = cd.cid >> 16, o.fc = cd.fc, o.fm = cd.fm, o.Tc = cd.Tc, o.Tm = cd.Tm, o.hTc = cd.hTc, o.hTm = cd.hTm;
+            o.valid = (cd.flags & 2u) ? 0u : 1u, o.id = cd.cid & CF_IDMASK, o.cls = cd.cid >> 16, o.fc = cd.fc, o.fm = cd.fm, o.hTc = cd.hTc, o.hTm = cd.hTm;
           }
+          else if (lane >= CF_OVL) o.valid = 0u;
           wave_sync();
           CF_TRACE("decider: step %u has its candidates\n", seq);
           CF_PROF_T(p1);
@@ -1102,7 +1153,11 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
           while (seq - cf_poll(&S.misc[CFX_BK_DONE]) >= CF_VLOG) SPIN_PAUSE_NEAR();  // (the bookkeeper is this far behind: never seen)
           CfVlog* vl = &S.vlog[seq & (CF_VLOG - 1u)];
           if (!any) {
-            if (lane == 0) vl->info = s, COMPILER_FENCE(), st_wg(&vl->seq, seq);
+            if (lane == 0) {
+              vl->info = s;
+              COMPILER_FENCE();
+              st_wg(&vl->seq, seq);
+            }
           } else {
             const unsigned ofc = (unsigned)wave_read_lane((int)o.fc, (int)l0), ofm = (unsigned)wave_read_lane((int)o.fm, (int)l0), id = (unsigned)wave_read_lane((int)o.id, (int)l0);
             const unsigned nfc = ofc - J.c, nfm = ofm - J.m;
@@ -1132,9 +1187,9 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
               if (opens) {
                 ++st_open;
                 const unsigned lf = (unsigned)__ffsll(~__ballot(o.valid != 0u || !isov)) - 1u;  // (a free overlay lane: a full overlay ended the epoch at once)
-                const unsigned cls2 = (unsigned)wave_read_lane((int)o.cls, (int)l0), Tc2 = (unsigned)wave_read_lane((int)o.Tc, (int)l0), Tm2 = (unsigned)wave_read_lane((int)o.Tm, (int)l0);
+                const unsigned cls2 = (unsigned)wave_read_lane((int)o.cls, (int)l0);
                 const double hTc2 = wave_read_lane_f64(o.hTc, (int)l0), hTm2 = wave_read_lane_f64(o.hTm, (int)l0);
-                if (lane == lf) o.valid = 1u, o.id = id, o.cls = cls2, o.fc = nfc, o.fm = nfm, o.Tc = Tc2, o.Tm = Tm2, o.hTc = hTc2, o.hTm = hTm2;
+                if (lane == lf) o.valid = 1u, o.id = id, o.cls = cls2, o.fc = nfc, o.fm = nfm, o.Tc = S.cls[cls2].Tc, o.Tm = S.cls[cls2].Tm, o.hTc = hTc2, o.hTm = hTm2;
                 ++live;
               } else if (gpu_place) {
                 ++st_gpu;
@@ -1175,6 +1230,7 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
       } else if (is_class_wave) {
         // ================================================= a class wave: answers ahead of the decider =================================================
         while (md == 0u) {
+          CF_PROF_T(q0);
           const unsigned ver = cf_poll(&S.cmd[w].ver);
           if (ver != o_cmd) {  // a member of ours was taken (or the group table changed): obey, then answer the steps behind that one again
             COMPILER_FENCE();
@@ -1190,6 +1246,8 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
             todo = walkmask & ~((2ull << cs) - 1ull);
             if (lane == 0) st_wg(&S.ack[w], cseq);
             CF_TRACE("class wave %u: command %u obeyed (step %u)\n", w, ver, cseq);
+            CF_PROF_T(q4);
+            CF_PROF_ADD(3, q4 - q0);
             continue;
           }
           const unsigned mode = cf_poll(&S.misc[CFX_MODE]);
@@ -1198,28 +1256,35 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
             md = mode;
             break;
           }
-          if (todo != 0ull) {
+          if (todo != 0ull && ((live_waves >> w) & 1u)) {
             const unsigned s = (unsigned)__ffsll(todo) - 1u;
             const unsigned seq = seq_of(s);
             if (seq < cf_poll(&S.misc[CFX_HEAD_SEQ]) + CF_BOARD) {
+              CF_PROF_T(q1);
               const CfJobU J = cf_job_uniform(&S.ring[slot * 64u + s]);
               CfPost mine;
-              cf_class_query<false>(S, J, lane, c, 0.0, sc, sm, mine, st_scans);
+              cf_class_answer(S, J, lane, c, mine, st_scans);
+              CF_PROF_T(q2);
               CF_TRACE("class wave %u: answer for step %u lane %u: fa %.17g offer %u\n", w, seq, s, mine.fa, mine.w0);
               if (lane == 0) {
                 CfCand* e = &S.board[(seq & (CF_BOARD - 1u)) * CF_WAVES + w];
                 const bool none = !(mine.fa > 0.0);
-                const CfClass cl = S.cls[none ? 0u : mine.cls];
+                const CfClass* cl = &S.cls[none ? 0u : mine.cls];
                 e->pos = mine.pos, e->fc = mine.fc, e->fm = mine.fm, e->cid = mine.cls << 16 | (mine.w0 & CF_IDMASK), e->flags = (mine.w0 >> 31) | (none ? 2u : 0u);
-                e->Tc = cl.Tc, e->Tm = cl.Tm, e->hTc = cl.hTc, e->hTm = cl.hTm;
+                e->hTc = cl->hTc, e->hTm = cl->hTm;
                 COMPILER_FENCE();
                 st_wg(&e->tag, seq << 8 | (o_ver & 255u));
               }
               todo &= todo - 1ull;
+              CF_PROF_T(q3);
+              CF_PROF_ADD(0, q1 - q0);
+              CF_PROF_ADD(1, q2 - q1);
+              CF_PROF_ADD(2, q3 - q2);
               continue;
             }
           }
-          SPIN_PAUSE_NEAR();
+          if ((live_waves >> w) & 1u) SPIN_PAUSE_NEAR();
+          else SPIN_PAUSE_IDLE();
         }
       } else {
         // ================================================= the bookkeeper: follows the verdict log =================================================
@@ -1249,7 +1314,7 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
             md = mode;
             break;
           }
-          SPIN_PAUSE_NEAR();
+          SPIN_PAUSE_IDLE();
         }
       }
       // ================================================= a collective turn: every wave =================================================
@@ -1418,7 +1483,16 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
         for (unsigned ci = 0; ci < n_cls; ++ci) newM += S.ckept[ci] + S.ckept[CF_MAXCLS + ci];
         for (unsigned q = tid; q < NP; q += CF_THREADS) {
           const bool inq = q < newM;
-          S.fc[q] = inq ? ld_agent(&b.scr_fc[q]) : 0u, S.fm[q] = inq ? ld_agent(&b.scr_fm[q]) : 0u, S.cid[q] = inq ? (uint16_t)ld_agent(&b.scr_cid[q]) : (uint16_t)0xFFFFu;
+          const uint32_t fcq = inq ? ld_agent(&b.scr_fc[q]) : 0u, fmq = inq ? ld_agent(&b.scr_fm[q]) : 0u, cq = inq ? ld_agent(&b.scr_cid[q]) : 0xFFFFFFFFu;
+          bool tie = false;  // the next member of the class inside the guard band of this one
+          if (q + 1u < newM) {
+            const uint32_t fcn = ld_agent(&b.scr_fc[q + 1u]), fmn = ld_agent(&b.scr_fm[q + 1u]), cn = ld_agent(&b.scr_cid[q + 1u]);
+            if ((cn >> 16) == (cq >> 16)) {
+              const CfClass* cl = &S.cls[cq >> 16];
+              tie = (unsigned long long)fcn * cl->Tm + (unsigned long long)fmn * cl->Tc <= (unsigned long long)fcq * cl->Tm + (unsigned long long)fmq * cl->Tc + cl->dE;
+            }
+          }
+          S.fc[q] = fcq, S.fm[q] = fmq, S.cid[q] = inq ? (uint16_t)((cq & (CF_OCC | CF_IDMASK)) | (tie ? CF_TIE : 0u)) : (uint16_t)0xFFFFu;
         }
         if (tid < n_cls) S.cls[tid].n = S.ckept[tid] + S.ckept[CF_MAXCLS + tid], S.cls[tid].off = S.ckept[2 * CF_MAXCLS + tid];
         EMU_SITE("classfit: epoch 4");
@@ -1492,8 +1566,8 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
   if (is_books && lane == 0) ctl->stats[CFS_TICKS_PRECHECK] = (uint32_t)tk_pre;
   (void)tk_wait;
 #ifdef CF_PROF
-  if (lane == 0 && w == 0)
-    for (int i = 0; i < 4; ++i) ctl->stats[20 + i] = prof[i];
+  if (lane == 0 && w <= 2u)
+    for (int i = 0; i < 4; ++i) ctl->stats[20 + 4 * w + i] = prof[i];
 #endif
 }
 

@@ -1395,7 +1395,7 @@ void cf_run(cook_engine* lead, cook_engine* const* es, unsigned n, hipStream_t s
     if (sum[3] == 0xDEADu) lead->fail(COOK_E_STATE, "cf_walk: the pool's tables do not fit the workgroup's LDS (the host's check let it through)");
     std::memcpy(x->cf_stats, lead->h_cf + i * SLOT + 16, 48 * 4);
 #ifdef CF_PROF
-    std::fprintf(stderr, "CFPROF ticks (query, barrier wait, verdict, commit): overlay %u %u %u %u | class wave 1 %u %u %u %u | class wave 2 %u %u %u %u | bookkeeper %u %u %u %u\n", x->cf_stats[20], x->cf_stats[21], x->cf_stats[22], x->cf_stats[23], x->cf_stats[24], x->cf_stats[25], x->cf_stats[26], x->cf_stats[27], x->cf_stats[28], x->cf_stats[29], x->cf_stats[30], x->cf_stats[31], x->cf_stats[32], x->cf_stats[33], x->cf_stats[34], x->cf_stats[35]);
+    std::fprintf(stderr, "CFPROF ticks: decider (candidates, evaluation, commit) %u %u %u %u | class wave 1 (polls, answer, publish, commands) %u %u %u %u | class wave 2 %u %u %u %u | %u %u %u %u\n", x->cf_stats[20], x->cf_stats[21], x->cf_stats[22], x->cf_stats[23], x->cf_stats[24], x->cf_stats[25], x->cf_stats[26], x->cf_stats[27], x->cf_stats[28], x->cf_stats[29], x->cf_stats[30], x->cf_stats[31], x->cf_stats[32], x->cf_stats[33], x->cf_stats[34], x->cf_stats[35]);
 #endif
     WinCtl c{};
     c.matched = sum[0], c.head_matched = sum[1], c.rounds = sum[2], c.head = x->last_in.K, c.visited_sum = x->cf_stats[CFS_WALKED];

@@ -36,6 +36,7 @@ template <class T>
 static __device__ __forceinline__ void st_wg(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define COMPILER_FENCE() asm volatile("" ::: "memory")
 #define SPIN_PAUSE_NEAR() __builtin_amdgcn_s_sleep(1)  // between polls of an LDS word
+#define SPIN_PAUSE_IDLE() __builtin_amdgcn_s_sleep(16) // ... by a wave nobody waits for (its polls take issue slots and LDS cycles from the waves that are)
 
 // ---- hand-off between workgroups of DIFFERENT launches that run side by side (the served walkers, match_v2.hpp) ----------------------
 // The tested forms of MI355X_MICROARCH.md: producer = plain stores -> agent_release() -> relaxed agent-scope flag store; consumer =

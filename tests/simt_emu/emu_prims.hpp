@@ -34,6 +34,7 @@ template <class T>
 static inline void st_wg(T* p, T v) { *p = v; emu::progress(); }
 #define COMPILER_FENCE() ((void)0)
 #define SPIN_PAUSE_NEAR() emu::yield()
+#define SPIN_PAUSE_IDLE() emu::yield()
 
 // hand-off between workgroups of different launches (the served walkers): memory is sequentially consistent here, and launches run
 // one after the other, so nothing ever waits — the served path runs in its STEPPING form (match_v2.hpp)
