@@ -1314,14 +1314,14 @@ static void launch_round(cook_engine* e, const MatchIn& in, const MatchState& st
 // ---- class-ordered best fit (classfit.hpp): set-up, eligibility, launch --------------------------------------------------------------------
 // COOK_CLASSFIT=0: every match goes through the window rounds (A/B switch)
 static const bool g_classfit = env_switch_on_unless_zero("COOK_CLASSFIT");
-static size_t cf_lds_bytes_host(unsigned NP, unsigned M, bool eq, unsigned G, unsigned S) {  // the layout of cf_walk_pool
+static size_t cf_lds_bytes_host(unsigned NP, unsigned M, bool eq, unsigned G, unsigned S) {  // the layout of cf_walk_pool (classfit_walk.hpp)
   size_t n = (size_t)NP * 10u;
   n = (n + 7u) & ~(size_t)7u;
   if (eq) n += (size_t)M * 8u;
   n += ((size_t)G + 1u) * 2u + (size_t)G * 2u + (size_t)S * 2u;
   n = (n + 15u) & ~(size_t)15u;
-  n += 2u * 64u * sizeof(CfJob) + CF_BOARD * CF_WAVES * sizeof(CfCand) + CF_WAVES * sizeof(CfCmd) + CF_VLOG * sizeof(CfVlog) + CF_WAVES * sizeof(CfPost) + CF_MAXCLS * sizeof(CfClass);
-  n += (2u * CF_WAVES * CF_LV + CF_MAXKIND * CF_LV + CF_WAVES + 128u + 192u + 3u * CF_MAXCLS + 16u) * 4u;
+  n += 2u * 64u * sizeof(CfJob) + CF_BOARD * 8u * sizeof(CfEnt) + 64u * sizeof(CfLog) + 8u * sizeof(CfPost) + CF_MAXCLS * sizeof(CfClass);
+  n += (2u * 8u * CF_LV + CF_MAXKIND * CF_LV + CF_LV + 8u + 192u + 3u * CF_MAXCLS + CFX_N) * 4u;
   return n + 64u;
 }
 // the three set-up kernels of a call and the look at what they found -> true: the call can be placed by cf_walk (ctx filled in)
@@ -1394,9 +1394,6 @@ void cf_run(cook_engine* lead, cook_engine* const* es, unsigned n, hipStream_t s
     const unsigned* sum = (const unsigned*)(lead->h_cf + i * SLOT);
     if (sum[3] == 0xDEADu) lead->fail(COOK_E_STATE, "cf_walk: the pool's tables do not fit the workgroup's LDS (the host's check let it through)");
     std::memcpy(x->cf_stats, lead->h_cf + i * SLOT + 16, 48 * 4);
-#ifdef CF_PROF
-    std::fprintf(stderr, "CFPROF ticks: decider (candidates, evaluation, commit) %u %u %u %u | class wave 1 (polls, answer, publish, commands) %u %u %u %u | class wave 2 %u %u %u %u | %u %u %u %u\n", x->cf_stats[20], x->cf_stats[21], x->cf_stats[22], x->cf_stats[23], x->cf_stats[24], x->cf_stats[25], x->cf_stats[26], x->cf_stats[27], x->cf_stats[28], x->cf_stats[29], x->cf_stats[30], x->cf_stats[31], x->cf_stats[32], x->cf_stats[33], x->cf_stats[34], x->cf_stats[35]);
-#endif
     WinCtl c{};
     c.matched = sum[0], c.head_matched = sum[1], c.rounds = sum[2], c.head = x->last_in.K, c.visited_sum = x->cf_stats[CFS_WALKED];
     c.t_seq = x->cf_stats[CFS_TICKS_TOTAL], c.t_setup = x->cf_stats[CFS_TICKS_PROLOGUE];
@@ -2643,7 +2640,7 @@ int cook_match_stats_ex(cook_engine* e, uint32_t* out, uint32_t cap) {
   for (unsigned k = 0; k < 5u; ++k) v[32 + k] = e->batch_stats[k];
   v[37] = e->last_form, v[38] = e->cf_inelig;
   if (e->last_form == 3u)
-    for (unsigned k = 0; k < 20u; ++k) v[40 + k] = e->cf_stats[k];
+    for (unsigned k = 0; k < 24u; ++k) v[40 + k] = e->cf_stats[k];
   if (g_guard) {  // COOK_GUARD=1: look at this engine's bands now; the count is process-wide and includes buffers already freed
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);

@@ -139,6 +139,31 @@ static __device__ __forceinline__ float wave_max_f32(float x) {
       : "+v"(x));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
+// Eight wave-wide maxima at once (all 64 lanes active): the six DPP steps of eight independent values interleaved, so that no step waits
+// for its own predecessor (classfit_walk.hpp: the level summaries of a chunk).  Every lane of the result holds nothing useful but lane 63;
+// the values come back wave-uniform.
+static __device__ __forceinline__ void wave_max8_u32(unsigned& a0, unsigned& a1, unsigned& a2, unsigned& a3, unsigned& a4, unsigned& a5, unsigned& a6, unsigned& a7) {
+#define COOK_M8(ctrl)                                   \
+  "v_max_u32_dpp %0, %0, %0 " ctrl "\n\t"              \
+  "v_max_u32_dpp %1, %1, %1 " ctrl "\n\t"              \
+  "v_max_u32_dpp %2, %2, %2 " ctrl "\n\t"              \
+  "v_max_u32_dpp %3, %3, %3 " ctrl "\n\t"              \
+  "v_max_u32_dpp %4, %4, %4 " ctrl "\n\t"              \
+  "v_max_u32_dpp %5, %5, %5 " ctrl "\n\t"              \
+  "v_max_u32_dpp %6, %6, %6 " ctrl "\n\t"              \
+  "v_max_u32_dpp %7, %7, %7 " ctrl "\n\t"
+  asm volatile("s_nop 1\n\t" COOK_M8("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") COOK_M8("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                   COOK_M8("row_half_mirror row_mask:0xf bank_mask:0xf") COOK_M8("row_mirror row_mask:0xf bank_mask:0xf")
+                       COOK_M8("row_bcast:15 row_mask:0xa bank_mask:0xf") COOK_M8("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1\n\t"
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+#undef COOK_M8
+  a0 = (unsigned)__builtin_amdgcn_readlane((int)a0, 63), a1 = (unsigned)__builtin_amdgcn_readlane((int)a1, 63), a2 = (unsigned)__builtin_amdgcn_readlane((int)a2, 63),
+  a3 = (unsigned)__builtin_amdgcn_readlane((int)a3, 63), a4 = (unsigned)__builtin_amdgcn_readlane((int)a4, 63), a5 = (unsigned)__builtin_amdgcn_readlane((int)a5, 63),
+  a6 = (unsigned)__builtin_amdgcn_readlane((int)a6, 63), a7 = (unsigned)__builtin_amdgcn_readlane((int)a7, 63);
+}
+// the wave's hardware placement (HW_REG_HW_ID: bits 4..5 the SIMD of the CU), for the profile notes
+static __device__ __forceinline__ unsigned cook_hw_id() { return (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
+static __device__ __forceinline__ void cook_set_prio_high() { __builtin_amdgcn_s_setprio(3); }
 // value of v in lane src; src must be wave-uniform
 static __device__ __forceinline__ int wave_read_lane(int v, int src) {
   return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));

@@ -419,7 +419,8 @@ class Engine:
                 "serve_pool_windows", "serve_latch_wait_us", "served_fell_back", "serve_streams", "guard_hits", "update_us", "update_sync_us", "update_allocs", "update_slowest_phase", "update_slowest_phase_us", "_31",
                 "rank_batch_pools", "rank_batch_launches", "rank_batch_grouped_launches", "rank_batch_single_ops", "rank_batch_syncs",
                 "placement_form", "classfit_refused", "_39", "cf_walked", "cf_matched", "cf_overlay_wins", "cf_opened", "cf_opened_full", "cf_gpu_places", "cf_epochs",
-                "cf_scans", "cf_exact_turns", "cf_retightened", "_50", "cf_batches", "cf_dead_lanes", "cf_ticks", "cf_ticks_prologue", "cf_ticks_epochs", "cf_ticks_precheck")
+                "cf_scans", "cf_exact_turns", "cf_retightened", "_50", "cf_batches", "cf_dead_lanes", "cf_ticks", "cf_ticks_prologue", "cf_ticks_epochs", "cf_ticks_books",
+                "cf_spins", "cf_ticks_walk", "cf_ticks_phase1", "cf_rewinds", "cf_flips", "cf_hwid_decider", "cf_hwid_books")
         return {k: int(x) for k, x in zip(keys, out[:max(0, n)]) if not k.startswith("_")}
 
     def set_profiling(self, on: bool):

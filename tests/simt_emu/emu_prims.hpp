@@ -87,6 +87,12 @@ static inline unsigned long long wave_max_u64(unsigned long long x) {
   }
   return x;
 }
+static inline void wave_max8_u32(unsigned& a0, unsigned& a1, unsigned& a2, unsigned& a3, unsigned& a4, unsigned& a5, unsigned& a6, unsigned& a7) {
+  a0 = wave_max_u32(a0), a1 = wave_max_u32(a1), a2 = wave_max_u32(a2), a3 = wave_max_u32(a3), a4 = wave_max_u32(a4), a5 = wave_max_u32(a5), a6 = wave_max_u32(a6),
+  a7 = wave_max_u32(a7);
+}
+static inline unsigned cook_hw_id() { return 0u; }
+static inline void cook_set_prio_high() {}
 static inline int wave_read_lane(int v, int src) { return __shfl(v, src, COOK_WAVE); }
 static inline float wave_max_f32(float x) {
   for (int d = 32; d >= 1; d >>= 1) {
