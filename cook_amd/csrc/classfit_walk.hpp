@@ -18,13 +18,30 @@
 // removals from the decider's log there); a job without a place has room somewhere at its turn iff it has at the batch's end, or had at its start and
 // some LATER placement of the batch found room for it in the offer it took (the log's old values).
 #pragma once
+#if defined(CF_PROF) && !defined(CF_STATS)
+#define CF_STATS 1
+#endif
+#ifdef CF_STATS  // counters and phase timers of the walk's hot paths (a study build: each costs scalar registers the walk is short of)
+#define CF_STAT(x) x
+#define CF_TICKS() cook_ticks()
+#else
+#define CF_STAT(x) ((void)0)
+#define CF_TICKS() 0ull
+#endif
+#ifdef CF_PROF  // timing-study build: shader cycles (s_memtime) per phase of the decider's steps and of class wave 1's answers, to CfCtl::stats[24..]
+#define CF_PROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define CF_PROF_ADD(i, d) prof[i] += (unsigned long long)(d)
+#else
+#define CF_PROF_T(x) ((void)0)
+#define CF_PROF_ADD(i, d) ((void)0)
+#endif
 
 constexpr unsigned CF_BOARD = 4;    // steps the class waves may run ahead of the decider (a power of two)
 constexpr unsigned CF_OVL = 58;     // overlay lanes (lanes 58..63 are the candidates of logical class waves 1..6)
 constexpr unsigned CF_EPOCH_AT = COOK_SHAPE(58, 8);  // live overlay lanes that end an epoch
 constexpr unsigned CFW_BOOKS = 4;   // the bookkeeper's wave
 enum : unsigned { CFM_EXACT = 1u, CFM_EPOCH = 2u, CFM_BATCH_END = 3u };
-enum : unsigned { CFX_MODE = 0, CFX_HEAD, CFX_LOGN, CFX_LOG_APPLIED, CFX_WALK_LO, CFX_WALK_HI, CFX_EX_LANE, CFX_FMAX_LO, CFX_FMAX_HI, CFX_EPOCH, CFX_MATCH_LO, CFX_MATCH_HI,
+enum : unsigned { CFX_SPARE0 = 0, CFX_SPARE1, CFX_LOGN, CFX_LOG_APPLIED, CFX_WALK_LO, CFX_WALK_HI, CFX_EX_LANE, CFX_FMAX_LO, CFX_FMAX_HI, CFX_EPOCH, CFX_MATCH_LO, CFX_MATCH_HI,
                   CFX_B1_LO, CFX_B1_HI, CFX_OVN, CFX_MINFC, CFX_MINFM, CFX_N = 24 };  // words of CfLds::misc
 constexpr uint32_t CF_ENT_NONE = 0x80000000u, CF_ENT_AMB = 0x40000000u;  // CfEnt::cid: no candidate / another member or class may round to the same fitness
 
@@ -33,7 +50,7 @@ struct __attribute__((aligned(8))) CfFree {  // free cpus / mem of a position (f
 };
 struct CfEnt {  // a class wave's answer for one step (32 B).  tag = job << 12 | generation << 8 | the wave's removal count (mod 256) the answer knows;
                 // the writer voids the tag, stores the fields, stores the tag; the reader reads tag, fields, tag
-  uint32_t tag, pos, cid, pad;  // pos: position | chunk lane << 16; cid: offer | class << 16 | CF_ENT_*
+  uint32_t tag, pad, pos, cid;  // pos: position | chunk lane << 16; cid: offer | class << 16 | CF_ENT_*
   uint32_t fc, fm;
   double fa;                    // approximate fitness
 };
@@ -55,7 +72,7 @@ struct CfLds {  // the workgroup's LDS, carved at run time
   uint16_t* cid;        // [NP] occupied gpu host << 15 | the next member may round to the same fitness << 14 | offer
   CfEnt* board;         // [CF_BOARD][8]
   CfLog* log;           // [64]
-  uint32_t* rm;         // [8] removals per logical class wave
+  uint32_t* ctrl;       // [8] [0] the mode word of a collective turn, [1] the batch lane of the decider's step, [1 + w] removals from logical class wave w so far
   uint64_t* attr8;
   uint16_t *goff, *gcnt, *gids;
   CfJob* ring;          // [2][64]
@@ -68,32 +85,28 @@ struct CfLds {  // the workgroup's LDS, carved at run time
   uint32_t* ovl;        // [64][3] an epoch's overlay list (cid, fc, fm), sorted
   uint32_t* ckept;      // [CF_MAXCLS] kept members / [CF_MAXCLS] inserted / [CF_MAXCLS] new offsets
   uint32_t* misc;       // CFX_*
+  const uint32_t* t;    // [CF_LV] the call's cpus levels
+  const uint32_t* envw; // CFE_*: the call's constants
 };
 
-static __device__ __forceinline__ unsigned cf_level_of(const uint32_t (&t)[CF_LV], uint32_t fc) {  // how many of the levels fc reaches (t ascending)
+static __device__ __forceinline__ unsigned cf_level_of(const uint32_t* t, uint32_t fc) {  // (t: the call's levels, in LDS)
+   // how many of the levels fc reaches (t ascending)
   unsigned n = 0;
 #pragma unroll
   for (int i = 0; i < CF_LV; ++i) n += fc >= t[i] ? 1u : 0u;
   return n;
 }
-// eight level values in eight REGISTERS (as an array inside a structure the compiler kept the structure in scratch memory)
+// eight level values in eight REGISTERS (as an array inside a structure, or as a vector type indexed by a variable, the compiler keeps them in scratch
+// memory: a store of the whole set and an indexed load per access, seen in the ISA)
 struct CfLv8 {
   uint32_t v0, v1, v2, v3, v4, v5, v6, v7;
 };
 #define CF_FOR8(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
-static __device__ __forceinline__ uint32_t cf_lv_get(const CfLv8& a, unsigned i) {  // a wave-uniform index
-  uint32_t x0 = a.v0, x1 = a.v1, x2 = a.v2, x3 = a.v3, x4 = a.v4, x5 = a.v5, x6 = a.v6, x7 = a.v7;
-  OPAQUE_V(x0);
-  OPAQUE_V(x1);
-  OPAQUE_V(x2);
-  OPAQUE_V(x3);
-  OPAQUE_V(x4);
-  OPAQUE_V(x5);
-  OPAQUE_V(x6);
-  OPAQUE_V(x7);
-  uint32_t r = x0;
-  r = i == 1u ? x1 : r, r = i == 2u ? x2 : r, r = i == 3u ? x3 : r, r = i == 4u ? x4 : r, r = i == 5u ? x5 : r, r = i == 6u ? x6 : r, r = i == 7u ? x7 : r;
-  return r;
+static __device__ __forceinline__ uint32_t cf_lv_get(const CfLv8& a, unsigned i) {  // a wave-uniform index: a tree of selects on its three bits
+  const bool b0 = (i & 1u) != 0u, b1 = (i & 2u) != 0u, b2 = (i & 4u) != 0u;
+  const uint32_t r01 = b0 ? a.v1 : a.v0, r23 = b0 ? a.v3 : a.v2, r45 = b0 ? a.v5 : a.v4, r67 = b0 ? a.v7 : a.v6;
+  const uint32_t r03 = b1 ? r23 : r01, r47 = b1 ? r67 : r45;
+  return b2 ? r47 : r03;
 }
 struct CfChunkLane {  // a class wave's lane = one chunk
   unsigned cls, kind, pos0, n, Tc, Tm;
@@ -120,7 +133,8 @@ static __device__ __forceinline__ void cf_setup_chunks(const CfClass* cls, unsig
 }
 
 // the level summaries of chunk `ch` (wave-uniform) from its members; lanes = positions
-static __device__ __forceinline__ void cf_tighten(const CfLds& S, const uint32_t (&t)[CF_LV], unsigned lane, unsigned ch, CfChunkLane& c) {
+static __device__ __forceinline__ void cf_tighten(const CfLds& S, unsigned lane, unsigned ch, CfChunkLane& c) {
+  const uint32_t* t = S.t;
   const unsigned pos0 = (unsigned)wave_read_lane((int)c.pos0, (int)ch), n = (unsigned)wave_read_lane((int)c.n, (int)ch);
   const bool in = lane < n;
   const CfFree f = S.fcm[pos0 + lane];
@@ -206,7 +220,7 @@ struct CfAns {
   unsigned pos, ch, cid, fc, fm, cls;
   double fa;
 };
-static __device__ __forceinline__ void cf_class_answer(const CfLds& S, const uint32_t (&t)[CF_LV], const CfJobU& J, unsigned lane, CfChunkLane& c, CfAns& out, unsigned& scans,
+static __device__ __forceinline__ void cf_class_answer(const CfLds& S, const CfJobU& J, unsigned lane, CfChunkLane& c, CfAns& out, unsigned& scans,
                                                        unsigned& tightened) {
   out.have = false, out.amb = false, out.pos = 0u, out.ch = 0u, out.cid = 0u, out.fc = 0u, out.fm = 0u, out.cls = 0u, out.fa = 0.0;
   const uint32_t lvL = cf_lv_get(c.lv, J.L);
@@ -223,7 +237,7 @@ static __device__ __forceinline__ void cf_class_answer(const CfLds& S, const uin
     const unsigned long long b = __ballot(ok);
     if (b == 0ull) {
       if (__ballot(room) == 0ull) {  // a stale summary (members have left since): exact again
-        cf_tighten(S, t, lane, ch, c);
+        cf_tighten(S, lane, ch, c);
         ++tightened;
       }
       m &= ~(1ull << ch);
@@ -326,112 +340,36 @@ static __device__ __forceinline__ CfVerdict cf_verdict_exact(const CfPost* posts
 static __device__ __forceinline__ unsigned cf_poll(const uint32_t* p) { return (unsigned)wave_read_lane((int)ld_wg(p), 0); }
 static __device__ __forceinline__ unsigned long long cf_below(unsigned s) { return (1ull << s) - 1ull; }  // s < 64
 
-static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __restrict__ inp, const MatchState& st, const CfBuf& b) {
-  const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+// ---- the call's constants every role reads
+enum : unsigned { CFE_K = 0, CFE_M, CFE_NP, CFE_NCLS, CFE_NKIND, CFE_CMIN, CFE_MMIN, CFE_KC, CFE_KM, CFE_MINFC, CFE_MINFM, CFE_N = 12 };  // CfFixed::envw
+constexpr float CF_BAND32 = 1.0f / 2097152.0f;  // 2^-21: two fitness values this close as floats MAY be inside the 2^-37 band as doubles
+
+// fixed part of the LDS at constant offsets (the arrays whose size follows the call come behind it)
+struct CfFixed {
+  CfEnt board[CF_BOARD * 8u];
+  CfLog log[64];
+  CfJob ring[2u * 64u];
+  CfPost post2[8];
+  CfClass cls[CF_MAXCLS];
+  uint32_t pw[8u * CF_LV], aw[8u * CF_LV], gk[CF_MAXKIND * CF_LV], ovt[CF_LV];
+  uint32_t ctrl[8];
+  uint32_t ovl[192], ckept[3u * CF_MAXCLS], misc[CFX_N];
+  uint32_t env_t[CF_LV], envw[CFE_N];
+};
+static_assert(sizeof(CfFixed) % 16 == 0, "the arrays behind it are 16-byte aligned");
+
+template <int ROLE>  // 0 the decider, 1 a class wave, 2 the bookkeeper
+static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchState& st, const CfBuf& b, const unsigned lw, const unsigned long long t_start) {
+  constexpr bool is_decider = ROLE == 0, is_class_wave = ROLE == 1, is_books = ROLE == 2;
+  const unsigned tid = threadIdx.x, lane = lane_id();
   CfCtl* ctl = b.ctl;
-  const unsigned K = inp->K, M = ctl->M, G = inp->G;
-  const unsigned NP = (M + 63u) & ~63u;
-  const unsigned long long t_start = cook_ticks();
-  uint32_t t[CF_LV];
-#pragma unroll
-  for (int i = 0; i < CF_LV; ++i) t[i] = ctl->t[i];
-  const unsigned kc = ctl->kc, km = ctl->km, cmin = ctl->cmin, mmin = ctl->mmin, n_kind = ctl->n_kind, n_cls = ctl->n_cls;
-  const double sc = cf_pow2(-(int)kc), sm = cf_pow2(-(int)km);
-  const bool any_eq = ctl->any_eq != 0u, any_group = ctl->any_group != 0u;
-  // ---- group table sizes (needed for the layout): entries per unique group = running cotasks on hosts of this call + pending members
-  __shared__ unsigned s_total, s_wsum[CF_WAVES];
-  constexpr unsigned GPT = CF_MAXG / CF_THREADS;
-  unsigned gsz[GPT];
-  unsigned gsum = 0;
-#pragma unroll
-  for (unsigned x = 0; x < GPT; ++x) {
-    const unsigned g = tid * GPT + x;
-    unsigned sz = 0;
-    if (any_group && g < G && b.gcount[g] != 0u) sz = (inp->g_run_off ? inp->g_run_off[g + 1] - inp->g_run_off[g] : 0u) + b.gcount[g];
-    gsz[x] = sz, gsum += sz;
-  }
-  unsigned incl = gsum;  // inclusive scan over the workgroup
-  for (unsigned d = 1; d < 64u; d <<= 1) {
-    const unsigned y = shfl_up_t<unsigned>(incl, d);
-    if (lane >= d) incl += y;
-  }
-  if (lane == 63u) s_wsum[w] = incl;
-  __syncthreads();
-  unsigned wbase = 0;
-  for (unsigned x = 0; x < w; ++x) wbase += s_wsum[x];
-  if (tid == CF_THREADS - 1) s_total = wbase + incl;
-  __syncthreads();
-  const unsigned Stot = any_group ? s_total : 0u, Gl = any_group ? G : 0u;
-  // ---- layout (cf_lds_bytes_host in engine.hip computes the same sum)
-  CfLds S;
-  {
-    char* p = lds;
-    S.fcm = (CfFree*)p, p += NP * 8u;
-    S.cid = (uint16_t*)p, p += NP * 2u;
-    p = lds + (((unsigned)(p - lds) + 7u) & ~7u);
-    S.attr8 = (uint64_t*)p;
-    if (any_eq) p += M * 8u;
-    S.goff = (uint16_t*)p, p += (Gl + 1u) * 2u;
-    S.gcnt = (uint16_t*)p, p += Gl * 2u;
-    S.gids = (uint16_t*)p, p += Stot * 2u;
-    p = lds + (((unsigned)(p - lds) + 15u) & ~15u);
-    S.ring = (CfJob*)p, p += 2u * 64u * sizeof(CfJob);
-    S.board = (CfEnt*)p, p += CF_BOARD * 8u * sizeof(CfEnt);
-    S.log = (CfLog*)p, p += 64u * sizeof(CfLog);
-    S.post2 = (CfPost*)p, p += 8u * sizeof(CfPost);
-    S.cls = (CfClass*)p, p += CF_MAXCLS * sizeof(CfClass);
-    S.pw = (uint32_t*)p, p += 8u * CF_LV * 4u;
-    S.aw = (uint32_t*)p, p += 8u * CF_LV * 4u;
-    S.gk = (uint32_t*)p, p += CF_MAXKIND * CF_LV * 4u;
-    S.ovt = (uint32_t*)p, p += CF_LV * 4u;
-    S.rm = (uint32_t*)p, p += 8u * 4u;
-    S.ovl = (uint32_t*)p, p += 192u * 4u;
-    S.ckept = (uint32_t*)p, p += 3u * CF_MAXCLS * 4u;
-    S.misc = (uint32_t*)p, p += CFX_N * 4u;
-    if ((unsigned)(p - lds) > CF_LDS_BYTES) {  // (the host checks the same sum before it launches)
-      if (tid == 0) atomicOr(&ctl->inelig, (unsigned)CF_X_SHAPE), st.summary[3] = 0xDEADu;
-      return;
-    }
-  }
-  // ---- prologue: class arrays, byte table, group table
-  for (unsigned q = tid; q < NP; q += CF_THREADS) {
-    S.fcm[q] = q < M ? CfFree{b.pos_fc[q], b.pos_fm[q]} : CfFree{0u, 0u}, S.cid[q] = q < M ? (uint16_t)b.pos_cid[q] : (uint16_t)0u;
-  }
-  if (any_eq)
-    for (unsigned v = tid; v < M; v += CF_THREADS) S.attr8[v] = b.attr8[v];
-  if (any_group) {
-    unsigned off = wbase + incl - gsum;
-#pragma unroll
-    for (unsigned x = 0; x < GPT; ++x) {
-      const unsigned g = tid * GPT + x;
-      if (g <= G) S.goff[g] = (uint16_t)off;
-      if (g < G) {
-        unsigned cnt = 0;
-        if (gsz[x]) {
-          const unsigned r0 = inp->g_run_off ? inp->g_run_off[g] : 0u, r1 = inp->g_run_off ? inp->g_run_off[g + 1] : 0u;
-          for (unsigned r = r0; r < r1; ++r) {
-            const uint32_t h = inp->g_run_host[r];
-            const uint32_t v = h <= b.max_host ? b.h2o[h] : 0xFFFFFFFFu;
-            if (v != 0xFFFFFFFFu) S.gids[off + cnt++] = (uint16_t)v;
-          }
-        }
-        S.gcnt[g] = (uint16_t)cnt;
-        off += gsz[x];
-      }
-    }
-  }
-  for (unsigned x = tid; x < n_cls; x += CF_THREADS) S.cls[x] = ctl->cls[x];
-  for (unsigned x = tid; x < CFX_N; x += CF_THREADS) S.misc[x] = 0u;
-  for (unsigned x = tid; x < 8u * CF_LV; x += CF_THREADS) S.pw[x] = 0u, S.aw[x] = 0u;
-  for (unsigned x = tid; x < 8u; x += CF_THREADS) S.rm[x] = 0u;
-  for (unsigned x = tid; x < CF_MAXKIND * CF_LV; x += CF_THREADS) S.gk[x] = 0u;
-  for (unsigned x = tid; x < (unsigned)CF_LV; x += CF_THREADS) S.ovt[x] = 0u;
-  for (unsigned x = tid; x < CF_BOARD * 8u; x += CF_THREADS) S.board[x].tag = 0xFFFFFFFFu;
-  __syncthreads();
-  // ---- roles
-  const bool is_decider = w == 0u, is_books = w == CFW_BOOKS;
-  const bool is_class_wave = !is_decider && !is_books;
-  const unsigned lw = w < CFW_BOOKS ? w : w - 1u;  // a class wave's logical number 1..6
+  // (the call's constants live in LDS: what a rare path needs is read there, not kept in scalar registers across the walk)
+  const unsigned K = wave_uniform_u32(S.envw[CFE_K]), cmin = wave_uniform_u32(S.envw[CFE_CMIN]), mmin = wave_uniform_u32(S.envw[CFE_MMIN]);
+  const uint32_t* t = S.t;
+#define n_cls wave_uniform_u32(S.envw[CFE_NCLS])
+#define n_kind wave_uniform_u32(S.envw[CFE_NKIND])
+#define NP wave_uniform_u32(S.envw[CFE_NP])
+  // ---- role state
   CfChunkLane c;
   unsigned nch_wave = 0;
   cf_setup_chunks(S.cls, n_cls, is_class_wave ? lw : 0xFFu, lane, c, nch_wave);
@@ -443,35 +381,48 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
       if (S.cls[ci].wave == forw && S.cls[ci].kind < 32u) my_kinds |= 1u << S.cls[ci].kind;
   }
   const unsigned wk = is_class_wave ? wave_uniform_u32(my_kinds) : 0u;  // a class wave's kinds, in a scalar register
+  // a class wave whose lanes hold ONE class answers from scalar registers (the plain case: a wave per class of hosts without gpus)
+  unsigned one_cls = 0xFFFFFFFFu, u_off = 0, u_n = 0;
+  double u_hTc = 0.0, u_hTm = 0.0;
+  auto class_setup = [&] {
+    unsigned cnt = 0, ci0 = 0;
+    for (unsigned ci = 0; ci < n_cls; ++ci)
+      if (S.cls[ci].wave == lw) ++cnt, ci0 = ci;
+    one_cls = cnt == 1u ? ci0 : 0xFFFFFFFFu;
+    const CfClass* cl = &S.cls[ci0];
+    u_off = cl->off, u_n = cl->n, u_hTc = cl->hTc, u_hTm = cl->hTm;
+  };
   if (is_class_wave) {
-    for (unsigned ch = 0; ch < nch_wave; ++ch) cf_tighten(S, t, lane, ch, c);
+    class_setup();
+    for (unsigned ch = 0; ch < nch_wave; ++ch) cf_tighten(S, lane, ch, c);
     cf_wave_tables(S, lw, lane, c, wk, n_kind);
   }
   // the decider's lanes
   CfOvLane o;
   o.valid = 0u, o.id = 0u, o.cls = 0u, o.fc = 0u, o.fm = 0u, o.hTc = 0.0, o.hTm = 0.0;
   unsigned nrm = 0, rm1 = 0xFFFFFFFFu, rm2 = 0xFFFFFFFFu;  // lanes 58..63: removals from "their" class wave so far, the positions of the last two
-  unsigned minfc_all = ctl->minfc_all, minfm_all = ctl->minfm_all;
+  unsigned minfc_all = wave_uniform_u32(S.envw[CFE_MINFC]), minfm_all = wave_uniform_u32(S.envw[CFE_MINFM]);
   unsigned matched = 0, head = 0;
   // every wave: the jobs of the batch, lane = batch slot
   unsigned jc = 0, jm = 0, jmeta = 0, jgrp = 0, jeq0 = 0, jeq1 = 0, jnov0 = 0, jnov1 = 0;
   int res = -1;
-  bool b1 = false;
-  // class waves
+  unsigned long long b1m = 0ull;  // decider: the batch's jobs some offer lacks room for at their turn (one bit per batch lane)
   unsigned seen = 0, gen = 0;
   unsigned tight_applied = 0;  // st_tight as of the last time the wave's table rows were written (a summary recomputed since: the rows are stale)
-  // bookkeeper: this batch's and the next batch's jobs
   bool bk_room0 = false, nx_room0 = false, nx_walk = false;
   unsigned st_scans = 0, st_exact = 0, st_open = 0, st_ovwin = 0, st_gpu = 0, st_epochs = 0, st_tight = 0, st_walked = 0, st_dead = 0, st_opendead = 0, st_spins = 0, st_flips = 0,
            st_rewinds = 0;
-  unsigned long long tk_epoch = 0, tk_books = 0, tk_walk = 0, tk_phase1 = 0, tk_wait = 0;
+  unsigned long long tk_epoch = 0, tk_books = 0, tk_walk = 0, tk_phase1 = 0;
+#ifdef CF_PROF
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   auto job_of = [&](unsigned s) -> CfJobU {
     CfJobU J;
     J.c = (unsigned)wave_read_lane((int)jc, (int)s), J.m = (unsigned)wave_read_lane((int)jm, (int)s);
     const unsigned meta = (unsigned)wave_read_lane((int)jmeta, (int)s);
     J.kind = meta & 255u, J.L = (meta >> 8) & 15u, J.n_eq = (meta >> 12) & 15u, J.n_nov = (meta >> 16) & 15u, J.grouped = (meta >> 20) & 1u;
     J.grp = 0u, J.eq0 = J.eq1 = 0u, J.nov0 = J.nov1 = 0xFFFFFFFFu;
-    if (J.n_eq | J.n_nov | J.grouped) {
+    if (meta >> 12) {
       J.grp = (unsigned)wave_read_lane((int)jgrp, (int)s), J.eq0 = (unsigned)wave_read_lane((int)jeq0, (int)s), J.eq1 = (unsigned)wave_read_lane((int)jeq1, (int)s),
       J.nov0 = (unsigned)wave_read_lane((int)jnov0, (int)s), J.nov1 = (unsigned)wave_read_lane((int)jnov1, (int)s);
     }
@@ -507,7 +458,7 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
     const unsigned long long wm = __ballot(nx_walk);
     if (lane == 0)
       S.misc[CFX_WALK_LO] = (unsigned)wm, S.misc[CFX_WALK_HI] = (unsigned)(wm >> 32), S.misc[CFX_LOGN] = 0u, S.misc[CFX_LOG_APPLIED] = 0u,
-      S.misc[CFX_HEAD] = wm ? (unsigned)__ffsll(wm) - 1u : 0u;  // (the class waves run ahead of THIS step)
+      S.ctrl[1] = wm ? (unsigned)__ffsll(wm) - 1u : 0u;  // (the class waves run ahead of THIS step)
   };
   __syncthreads();  // (the tables of the prologue are written)
   if (is_books) {
@@ -519,6 +470,8 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
   if (is_decider) cook_set_prio_high();
   const unsigned long long t_loop = cook_ticks();
   __syncthreads();
+  const bool isov = lane < CF_OVL;
+  const unsigned clw = isov ? 0u : lane - CF_OVL + 1u;  // decider: the lane's column of the board
 
   for (unsigned base = 0; base < K; base += 64u) {
     const unsigned bn = cf_min(64u, K - base);
@@ -526,17 +479,19 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
     const unsigned long long walkmask = wave_uniform_u64((unsigned long long)S.misc[CFX_WALK_LO] | (unsigned long long)S.misc[CFX_WALK_HI] << 32);
     const unsigned nw = (unsigned)__popcll(walkmask);
     st_walked += nw;
-    {
+    if (!is_books) {
       const CfJob j = S.ring[slot * 64u + (lane < bn ? lane : 0u)];
       const bool in = lane < bn;
       jc = in ? j.c : 0u, jm = in ? j.m : 0u, jmeta = in ? j.meta : CF_KIND_NONE, jgrp = j.grp, jeq0 = j.eq[0], jeq1 = j.eq[1], jnov0 = j.nov[0], jnov1 = j.nov[1];
     }
     res = -1;
-    b1 = !(jc <= minfc_all && jm <= minfm_all);
+    if (is_decider) b1m = __ballot(!(jc <= minfc_all && jm <= minfm_all));
     unsigned logn = 0;  // decider: placements of the batch so far
     unsigned long long todo = walkmask;  // decider: the walked jobs not decided yet; class waves: not answered yet
+    unsigned cur_ord = 0;                // the walked ordinal (0, 1, ... over the batch's walked jobs) of the first job of todo
     bool batch_done = nw == 0u;
-    const unsigned long long tw0 = cook_ticks();
+    const unsigned long long tw0 = CF_TICKS();
+    CF_PROF_T(cw0);
     while (!batch_done) {
       unsigned md = 0;  // the collective turn this wave leaves its loop for
       if (is_decider) {
@@ -544,175 +499,241 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
         while (md == 0u) {
           if (todo == 0ull) {
             md = CFM_BATCH_END;
-            if (lane == 0) st_wg(&S.misc[CFX_MODE], md);
+            st_lane0_b32(&S.ctrl[0], md);
             break;
           }
+          CF_PROF_T(p0);
           const unsigned s = (unsigned)__ffsll(todo) - 1u;
-          if (lane == 0) st_wg(&S.misc[CFX_HEAD], s);
-          const CfJobU J = job_of(s);
-          const unsigned ord = (unsigned)__popcll(walkmask & cf_below(s));
+          const unsigned ord = cur_ord;
+          st_lane0_b32(&S.ctrl[1], s | ord << 8);
+          const unsigned Jc = (unsigned)wave_read_lane((int)jc, (int)s), Jm = (unsigned)wave_read_lane((int)jm, (int)s), meta = (unsigned)wave_read_lane((int)jmeta, (int)s);
+          const unsigned kind = meta & 255u;
           const unsigned want = (base + s) << 12 | (gen & 15u) << 8;
-          // the candidates of the class waves into lanes 58..63
-          unsigned cpos = 0, ccid = CF_ENT_NONE;
-          double cfa = 0.0;
-          const bool isov = lane < CF_OVL;
-          if (!isov) {
-            o.valid = 0u;
-            if (J.kind < 32u && ((my_kinds >> J.kind) & 1u)) {
-              const CfEnt* e = &S.board[(ord & (CF_BOARD - 1u)) * 8u + (lane - CF_OVL + 1u)];
-              for (;;) {
+          // the candidates of the class waves into lanes 58..63 (every lane reads an entry: no branch on the lane)
+          const CfEnt* e = &S.board[(ord & (CF_BOARD - 1u)) * 8u + clw];
+          const bool relevant = !isov && kind < 32u && ((my_kinds >> (kind & 31u)) & 1u);
+          unsigned cpos, ccid, cfc, cfm;
+          double cfa;
+          bool acc;
+          {
+            const unsigned t1 = ld_wg(&e->tag);
+            COMPILER_FENCE();
+            cpos = e->pos, ccid = e->cid, cfc = e->fc, cfm = e->fm, cfa = e->fa;
+            COMPILER_FENCE();
+            const unsigned t2 = ld_wg(&e->tag);
+            // behind: removals of the wave the answer does not know.  An answer that knows a removal cannot name its member (zeroed in LDS before the
+            // count moved), so: up to two unknown removals, and neither of the last two removed positions
+            const unsigned behind = (nrm - t1) & 255u, p = cpos & 0xFFFFu;
+            acc = (t1 == t2) & ((t1 & ~255u) == want) & (((ccid & CF_ENT_NONE) != 0u) | ((behind <= 2u) & (p != rm1) & (p != rm2)));
+          }
+          if (cook_ballot(relevant & !acc) != 0ull) {  // an answer is missing (or names a member taken since): wait for it
+            if (relevant) {
+              while (!acc) {
+                CF_STAT(++st_spins);
+                SPIN_PAUSE_NEAR();
                 const unsigned t1 = ld_wg(&e->tag);
                 COMPILER_FENCE();
-                const unsigned pos = e->pos, cid = e->cid, fc = e->fc, fm = e->fm;
-                const double fa = e->fa;
+                cpos = e->pos, ccid = e->cid, cfc = e->fc, cfm = e->fm, cfa = e->fa;
                 COMPILER_FENCE();
                 const unsigned t2 = ld_wg(&e->tag);
-                if (t1 == t2 && (t1 & ~255u) == want) {
-                  const unsigned behind = (nrm - t1) & 255u;  // removals of the wave the answer does not know
-                  const unsigned p = pos & 0xFFFFu;
-                  if ((cid & CF_ENT_NONE) || behind == 0u || (behind == 1u && p != rm1) || (behind == 2u && p != rm1 && p != rm2)) {
-                    cpos = pos, ccid = cid, cfa = fa;
-                    o.valid = (cid & CF_ENT_NONE) ? 0u : 1u, o.id = cid & CF_IDMASK, o.cls = (cid >> 16) & 255u, o.fc = fc, o.fm = fm;
-                    break;
-                  }
-                }
-                ++st_spins;
-                SPIN_PAUSE_NEAR();
+                const unsigned behind = (nrm - t1) & 255u, p = cpos & 0xFFFFu;
+                acc = (t1 == t2) & ((t1 & ~255u) == want) & (((ccid & CF_ENT_NONE) != 0u) | ((behind <= 2u) & (p != rm1) & (p != rm2)));
               }
-            }
-          }
-          wave_sync();
-          // one evaluation of the 64 lanes
-          const bool room = o.valid && o.fc >= J.c && o.fm >= J.m && (!isov || J.kind == 0u);
-          const bool ok = room && (!isov || cf_cons_ok(S, J, o.id, room));
-          const double fa = ok ? (isov ? 1.0 - ((double)(o.fc - J.c) * o.hTc + (double)(o.fm - J.m) * o.hTm) : cfa) : 0.0;
-          const float ff = (float)fa;
-          const float mx = wave_max_f32(ff);
-          unsigned l0 = 0;
-          bool amb = false;
-          const bool any = mx > 0.0f;
-          if (any) {
-            l0 = (unsigned)__ffsll(__ballot(ok && ff == mx)) - 1u;
-            const double f0 = wave_read_lane_f64(fa, (int)l0);
-            const unsigned long long near = __ballot(ok && fa >= f0 - CF_BAND);  // (a lane above f0 is in here too: one bit = l0 is the greatest alone)
-            amb = (near & (near - 1ull)) != 0ull || (__ballot(ok && !isov && (ccid & CF_ENT_AMB) && fa >= f0 - CF_BAND) != 0ull);
-          }
-          if (amb) {  // the literal fitness decides: every wave in lockstep
-            md = CFM_EXACT;
-            const unsigned long long fb = (unsigned long long)__double_as_longlong(wave_read_lane_f64(fa, (int)l0));
-            if (lane == 0) S.misc[CFX_EX_LANE] = s, S.misc[CFX_FMAX_LO] = (unsigned)fb, S.misc[CFX_FMAX_HI] = (unsigned)(fb >> 32), st_wg(&S.misc[CFX_MODE], md);
-            break;
-          }
-          todo &= todo - 1ull;
-          if (!any) continue;
-          // ---- commit
-          const unsigned ofc = (unsigned)wave_read_lane((int)o.fc, (int)l0), ofm = (unsigned)wave_read_lane((int)o.fm, (int)l0), id = (unsigned)wave_read_lane((int)o.id, (int)l0);
-          const unsigned nfc = ofc - J.c, nfm = ofm - J.m;
-          const bool dead = nfc < cmin || nfm < mmin;
-          const bool from_ov = l0 < CF_OVL;
-          const bool gpu_place = !from_ov && J.kind != 0u;
-          const bool opens = !from_ov && !gpu_place && !dead;
-          ++matched;
-          if (base + s == 0u) head = 1u;
-          if (lane == s) res = (int)id;
-          if (lane > s) b1 = b1 || jc > nfc || jm > nfm;
-          minfc_all = cf_min(minfc_all, nfc), minfm_all = cf_min(minfm_all, nfm);
-          unsigned live = (unsigned)__popcll(__ballot(isov && o.valid != 0u));
-          unsigned lpos = 0, linfo = s;
-          if (from_ov) {
-            ++st_ovwin;
-            if (lane == l0) {
-              o.fc = nfc, o.fm = nfm;
-              if (dead) o.valid = 0u;
-            }
-            if (dead) ++st_dead, --live;
-          } else {
-            // the member leaves its class wave's arrays (a gpu host stays, occupied): zeroed in place, the wave's removal count moves on
-            const unsigned pos = (unsigned)wave_read_lane((int)cpos, (int)l0);
-            const unsigned cls2 = (unsigned)wave_read_lane((int)o.cls, (int)l0);
-            lpos = pos & 0xFFFFu, linfo = s | (l0 - CF_OVL + 1u) << 8 | (pos >> 16) << 12 | (gpu_place ? 1u : 0u) << 20;
-            if (lane == l0) {
-              if (gpu_place) S.fcm[lpos] = CfFree{nfc, nfm}, S.cid[lpos] = (uint16_t)(S.cid[lpos] | CF_OCC);
-              else S.fcm[lpos] = CfFree{0u, 0u};
-              ++nrm, rm2 = rm1, rm1 = lpos;
-              COMPILER_FENCE();
-              st_wg(&S.rm[l0 - CF_OVL + 1u], nrm);
-            }
-            if (opens) {
-              ++st_open;
-              const unsigned lf = (unsigned)__ffsll(~__ballot(o.valid != 0u || !isov)) - 1u;  // (a free overlay lane: a full overlay ended the epoch at once)
-              const CfClass* cl = &S.cls[cls2];
-              const double hTc2 = cl->hTc, hTm2 = cl->hTm;
-              if (lane == lf) o.valid = 1u, o.id = id, o.cls = cls2, o.fc = nfc, o.fm = nfm, o.hTc = hTc2, o.hTm = hTm2;
-              ++live;
-            } else if (gpu_place) {
-              ++st_gpu;
-            } else {
-              ++st_opendead;
-            }
-          }
-          if (lane == 0) {
-            CfLog* lg = &S.log[logn];
-            lg->info = linfo, lg->pos = lpos, lg->ofc = ofc, lg->ofm = ofm, lg->nfc = nfc, lg->nfm = nfm;
-          }
-          ++logn;
-          if (J.grouped) {  // the group's next members must not land on this offer
-            if (lane == 0) {
-              const unsigned g0 = S.goff[J.grp], gn = S.gcnt[J.grp];
-              S.gids[g0 + gn] = (uint16_t)id;
-              COMPILER_FENCE();
-              st_wg(&S.gcnt[J.grp], (uint16_t)(gn + 1u));
             }
             wave_sync();
           }
-          if (opens && live >= CF_EPOCH_AT) {  // the overlay is full of live offers: back into their classes' arrays, every wave in lockstep
-            md = CFM_EPOCH;
-            if (lane == 0) S.misc[CFX_EX_LANE] = s, S.misc[CFX_LOGN] = logn, st_wg(&S.misc[CFX_MODE], md);
+          CF_PROF_T(p1);
+          CF_PROF_ADD(0, p1 - p0);
+          // one evaluation of the 64 lanes
+          const unsigned vfc = isov ? o.fc : cfc, vfm = isov ? o.fm : cfm, vid = isov ? o.id : (ccid & CF_IDMASK);
+          const bool vvalid = isov ? (o.valid != 0u && kind == 0u) : (relevant && !(ccid & CF_ENT_NONE));
+          const bool room = vvalid & (vfc >= Jc) & (vfm >= Jm);
+          bool ok = room;
+          if (meta >> 12) {  // constraints: the overlay's lanes (a class wave's candidate has passed them)
+            const CfJobU J = job_of(s);
+            const bool cons = cf_cons_ok(S, J, vid, room & isov);
+            ok = room & (cons | !isov);
           }
+          double fov = 1.0 - ((double)(vfc - Jc) * o.hTc + (double)(vfm - Jm) * o.hTm);
+          OPAQUE_V(fov);
+          const double fa = ok ? (isov ? fov : cfa) : 0.0;
+          const float ff = (float)fa;
+          const float mx = wave_max_f32(ff);
+          const unsigned long long eqm = cook_ballot(ok & (ff == mx)), nearm = cook_ballot(ok & (ff >= mx - CF_BAND32)),
+                                   ambm = cook_ballot(ok & !isov & ((ccid & CF_ENT_AMB) != 0u) & (ff >= mx - CF_BAND32));
+          CF_PROF_T(p2);
+          CF_PROF_ADD(1, p2 - p1);
+          CF_PROF_ADD(3, 1);
+          if (!(mx > 0.0f)) {  // nobody takes it
+            todo &= todo - 1ull, ++cur_ord;
+            continue;
+          }
+          unsigned l0 = (unsigned)__ffsll(eqm) - 1u;
+          if ((nearm & (nearm - 1ull)) != 0ull || ambm != 0ull) {  // rare: the doubles decide whether the guard band holds several
+            const unsigned long long mxb = wave_max_u64((unsigned long long)__double_as_longlong(fa));
+            const double f0 = __longlong_as_double((long long)mxb);
+            l0 = (unsigned)__ffsll(__ballot(ok && (unsigned long long)__double_as_longlong(fa) == mxb)) - 1u;
+            const unsigned long long near = __ballot(ok && fa >= f0 - CF_BAND);
+            const bool amb = (near & (near - 1ull)) != 0ull || (__ballot(ok && !isov && (ccid & CF_ENT_AMB) && fa >= f0 - CF_BAND) != 0ull);
+            if (amb) {  // the literal fitness decides: every wave in lockstep
+              md = CFM_EXACT;
+              if (lane == 0) S.misc[CFX_EX_LANE] = s, S.misc[CFX_FMAX_LO] = (unsigned)mxb, S.misc[CFX_FMAX_HI] = (unsigned)(mxb >> 32), st_wg(&S.ctrl[0], md);
+              break;
+            }
+          }
+          todo &= todo - 1ull, ++cur_ord;
+          // ---- commit
+          const unsigned ofc = (unsigned)wave_read_lane((int)vfc, (int)l0), ofm = (unsigned)wave_read_lane((int)vfm, (int)l0), id = (unsigned)wave_read_lane((int)vid, (int)l0);
+          const unsigned nfc = ofc - Jc, nfm = ofm - Jm;
+          const bool dead = nfc < cmin || nfm < mmin;
+          const bool from_ov = l0 < CF_OVL;
+          ++matched;
+          res = lane == s ? (int)id : res;
+          b1m |= cook_ballot((jc > nfc) | (jm > nfm)) & ~cf_below(s) & ~(1ull << s);
+          minfc_all = cf_min(minfc_all, nfc), minfm_all = cf_min(minfm_all, nfm);
+          unsigned lpos = 0, linfo = s;
+          if (from_ov) {
+            CF_STAT(++st_ovwin);
+            const bool me = lane == l0;
+            o.fc = me ? nfc : o.fc, o.fm = me ? nfm : o.fm, o.valid = (me && dead) ? 0u : o.valid;
+            if (dead) CF_STAT(++st_dead);
+          } else {
+            // the member leaves its class wave's arrays (a gpu host stays, occupied): zeroed in place, the wave's removal count moves on
+            const bool gpu_place = kind != 0u;
+            const unsigned pos = (unsigned)wave_read_lane((int)cpos, (int)l0);
+            const unsigned cls2 = ((unsigned)wave_read_lane((int)ccid, (int)l0) >> 16) & 255u;
+            const unsigned cw = l0 - CF_OVL + 1u;
+            const unsigned cnt2 = (unsigned)wave_read_lane((int)nrm, (int)l0) + 1u;
+            lpos = pos & 0xFFFFu, linfo = s | cw << 8 | (pos >> 16) << 12 | (gpu_place ? 1u : 0u) << 20;
+            if (gpu_place) {
+              st_lane0_b64(&S.fcm[lpos], nfc, nfm);
+              if (lane == 0) S.cid[lpos] = (uint16_t)(S.cid[lpos] | CF_OCC);
+              CF_STAT(++st_gpu);
+            } else {
+              st_lane0_b64(&S.fcm[lpos], 0u, 0u);
+            }
+            st_lane0_b32(&S.ctrl[1u + cw], cnt2);
+            const bool me = lane == l0;
+            rm2 = me ? rm1 : rm2, rm1 = me ? lpos : rm1, nrm = me ? cnt2 : nrm;
+            if (!gpu_place && !dead) {  // a new overlay lane
+              CF_STAT(++st_open);
+              const unsigned long long vm = cook_ballot(isov & (o.valid != 0u));
+              const unsigned lf = (unsigned)__ffsll(~(vm | ~cf_below(CF_OVL))) - 1u;  // (a free overlay lane: a full overlay ended the epoch at once)
+              const CfClass* cl = &S.cls[cls2];
+              const double hTc2 = cl->hTc, hTm2 = cl->hTm;
+              const bool nl = lane == lf;
+              o.valid = nl ? 1u : o.valid, o.id = nl ? id : o.id, o.cls = nl ? cls2 : o.cls, o.fc = nl ? nfc : o.fc, o.fm = nl ? nfm : o.fm, o.hTc = nl ? hTc2 : o.hTc,
+              o.hTm = nl ? hTm2 : o.hTm;
+              const unsigned live1 = wave_uniform_u32((unsigned)__popcll(vm) + 1u);
+              if (live1 >= CF_EPOCH_AT) md = CFM_EPOCH;  // the overlay is full of live offers: back into their classes' arrays
+            } else if (!gpu_place) {
+              CF_STAT(++st_opendead);
+            }
+          }
+          st_lane0_b128(&S.log[logn].info, linfo, lpos, ofc, ofm);
+          ++logn;
+          if ((meta >> 20) & 1u) {  // the group's next members must not land on this offer
+            const unsigned grp = (unsigned)wave_read_lane((int)jgrp, (int)s);
+            if (lane == 0) {
+              const unsigned g0 = S.goff[grp], gn = S.gcnt[grp];
+              S.gids[g0 + gn] = (uint16_t)id;
+              COMPILER_FENCE();
+              st_wg(&S.gcnt[grp], (uint16_t)(gn + 1u));
+            }
+            wave_sync();
+          }
+          md = wave_uniform_u32(md);  // (a scalar for the compiler too: as a vector value it makes this loop's exit divergent and every counter carried out of it a vector register)
+          if (md == CFM_EPOCH) {
+            if (lane == 0) S.misc[CFX_EX_LANE] = s, S.misc[CFX_LOGN] = logn, st_wg(&S.ctrl[0], md);
+          }
+          CF_PROF_T(p3);
+          CF_PROF_ADD(2, p3 - p2);
         }
       } else if (is_class_wave) {
         // ================================================= a class wave: answers ahead of the decider =================================================
         while (md == 0u) {
-          const unsigned mode = cf_poll(&S.misc[CFX_MODE]);
+          CF_PROF_T(q0);
+          unsigned mode, hw, cnt;
+          {  // one trip to the LDS for the three words the decider writes
+            const unsigned a0 = ld_wg(&S.ctrl[0]), a1 = ld_wg(&S.ctrl[1]), a2 = ld_wg(&S.ctrl[1u + lw]);
+            mode = (unsigned)wave_read_lane((int)a0, 0), hw = (unsigned)wave_read_lane((int)a1, 0), cnt = (unsigned)wave_read_lane((int)a2, 0);
+          }
           if (mode != 0u) {
             md = mode;
             break;
           }
-          const unsigned cnt = cf_poll(&S.rm[lw]);
-          const unsigned hs = cf_poll(&S.misc[CFX_HEAD]);
           COMPILER_FENCE();
           if (cnt != seen) {  // members of ours have left: the steps in flight are answered again
             seen = cnt;
-            todo = walkmask & ~cf_below(hs);
-            ++st_rewinds;
+            todo = walkmask & ~cf_below(hw & 255u);
+            cur_ord = hw >> 8;
+            CF_STAT(++st_rewinds);
           }
-          if (todo != 0ull && wk != 0u) {
+          if (todo != 0ull && wk != 0u && cur_ord < (hw >> 8) + CF_BOARD) {
             const unsigned s = (unsigned)__ffsll(todo) - 1u;
-            const unsigned ord = (unsigned)__popcll(walkmask & cf_below(s));
-            if (ord < (unsigned)__popcll(walkmask & cf_below(hs)) + CF_BOARD) {
-              const CfJobU J = job_of(s);
-              todo &= todo - 1ull;
-              if (!(J.kind < 32u && ((wk >> J.kind) & 1u))) continue;  // (none of our classes: the decider does not ask)
-              CfAns a;
-              cf_class_answer(S, t, J, lane, c, a, st_scans, st_tight);
-              if (lane == 0) {
-                CfEnt* e = &S.board[(ord & (CF_BOARD - 1u)) * 8u + lw];
-                st_wg(&e->tag, 0xFFFFFFFFu);
-                COMPILER_FENCE();
-                e->pos = a.pos | a.ch << 16, e->cid = a.have ? (a.cid | a.cls << 16 | (a.amb ? CF_ENT_AMB : 0u)) : CF_ENT_NONE, e->fc = a.fc, e->fm = a.fm, e->fa = a.fa;
-                COMPILER_FENCE();
-                st_wg(&e->tag, (base + s) << 12 | (gen & 15u) << 8 | (seen & 255u));
+            const unsigned ord = cur_ord;
+            todo &= todo - 1ull, ++cur_ord;
+            const unsigned Jc = (unsigned)wave_read_lane((int)jc, (int)s), Jm = (unsigned)wave_read_lane((int)jm, (int)s), meta = (unsigned)wave_read_lane((int)jmeta, (int)s);
+            const unsigned kind = meta & 255u;
+            if (!(kind < 32u && ((wk >> kind) & 1u))) continue;  // (none of our classes: the decider does not ask)
+            CF_PROF_T(q1);
+            CfEnt* e = &S.board[(ord & (CF_BOARD - 1u)) * 8u + lw];
+            const unsigned tag = (base + s) << 12 | (gen & 15u) << 8 | (seen & 255u);
+            bool done = false;
+            if ((meta >> 12) == 0u && one_cls != 0xFFFFFFFFu) {
+              // the plain case — one class, a job without constraints: the first member with room of the first chunk that promises one publishes itself
+              const uint32_t lvL = cf_lv_get(c.lv, (meta >> 8) & 15u);
+              const unsigned long long mk = cook_ballot(lvL > Jm);
+              if (mk == 0ull) {
+                st_lane0_b32(&e->tag, 0xFFFFFFFFu);
+                st_lane0_b64(&e->pos, 0u, CF_ENT_NONE);
+                st_lane0_b32(&e->tag, tag);
+                done = true;
+              } else {
+                const unsigned ch = (unsigned)__ffsll(mk) - 1u;
+                const unsigned pos0 = u_off + 64u * ch, n = u_n - 64u * ch;
+                const CfFree f = S.fcm[pos0 + lane];
+                const uint32_t cid = S.cid[pos0 + lane];
+                const unsigned long long bb = cook_ballot((lane < n) & (f.c >= Jc) & (f.m >= Jm) & !(cid & CF_OCC));
+                double fa = 1.0 - ((double)(f.c - Jc) * u_hTc + (double)(f.m - Jm) * u_hTm);
+                if (bb != 0ull) {
+                  const unsigned long long pm = bb & (0ull - bb);  // the first feasible lane
+                  const unsigned long long fb = (unsigned long long)__double_as_longlong(fa);
+                  st_mask_b32(&e->tag, pm, 0xFFFFFFFFu);
+                  st_mask_b128(&e->fc, pm, f.c, f.m, (unsigned)fb, (unsigned)(fb >> 32));
+                  st_mask_b64(&e->pos, pm, (pos0 + lane) | ch << 16, (cid & CF_IDMASK) | one_cls << 16 | ((cid & CF_TIE) ? CF_ENT_AMB : 0u));
+                  st_mask_b32(&e->tag, pm, tag);
+                  done = true;
+                  CF_STAT(++st_scans);
+                }
               }
-              continue;
             }
+            if (!done) {  // constraints, several classes, a chunk whose summary promised too much
+              const CfJobU J = job_of(s);
+              CfAns a;
+              cf_class_answer(S, J, lane, c, a, st_scans, st_tight);
+              const unsigned long long fb = (unsigned long long)__double_as_longlong(a.fa);
+              st_lane0_b32(&e->tag, 0xFFFFFFFFu);
+              st_lane0_b128(&e->fc, a.fc, a.fm, (unsigned)fb, (unsigned)(fb >> 32));
+              st_lane0_b64(&e->pos, a.pos | a.ch << 16, a.have ? (a.cid | a.cls << 16 | (a.amb ? CF_ENT_AMB : 0u)) : CF_ENT_NONE);
+              st_lane0_b32(&e->tag, tag);
+            }
+            CF_PROF_T(q2);
+            CF_PROF_ADD(0, q1 - q0);
+            CF_PROF_ADD(1, q2 - q1);
+            CF_PROF_ADD(3, 1);
+            continue;
           }
           if (wk != 0u) SPIN_PAUSE_NEAR();
           else SPIN_PAUSE_IDLE();
+          CF_PROF_T(q4);
+          CF_PROF_ADD(4, q4 - q0);
+          CF_PROF_ADD(5, 1);
         }
       } else {
         // ================================================= the bookkeeper sleeps through the walk =================================================
         while (md == 0u) {
-          const unsigned mode = cf_poll(&S.misc[CFX_MODE]);
+          const unsigned mode = cf_poll(&S.ctrl[0]);
           if (mode != 0u) {
             md = mode;
             break;
@@ -725,22 +746,24 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
       __syncthreads();
       md = wave_uniform_u32(md);  // (every wave left its loop with the mode word the decider raised)
       bool epoch = md == CFM_EPOCH;
-      const unsigned s = S.misc[CFX_EX_LANE];
+      const unsigned s = wave_uniform_u32(S.misc[CFX_EX_LANE]);
       if (md == CFM_EXACT) {
         ++st_exact;
-        const CfJobU J = job_of(s);
         const double fmax = __longlong_as_double((long long)((unsigned long long)S.misc[CFX_FMAX_LO] | (unsigned long long)S.misc[CFX_FMAX_HI] << 32));
         CfPost mine;
         if (is_decider) {
-          cf_overlay_query_exact(S, J, lane, o, fmax, sc, sm, mine);
+          const CfJobU J = job_of(s);
+          cf_overlay_query_exact(S, J, lane, o, fmax, cf_pow2(-(int)wave_uniform_u32(S.envw[CFE_KC])), cf_pow2(-(int)wave_uniform_u32(S.envw[CFE_KM])), mine);
           if (lane == 0) S.post2[0] = mine;
         } else if (is_class_wave) {
-          cf_class_query_exact(S, J, lane, c, fmax, sc, sm, mine, st_scans);
+          const CfJobU J = job_of(s);
+          cf_class_query_exact(S, J, lane, c, fmax, cf_pow2(-(int)wave_uniform_u32(S.envw[CFE_KC])), cf_pow2(-(int)wave_uniform_u32(S.envw[CFE_KM])), mine, st_scans);
           if (lane == 0) S.post2[lw] = mine;
         }
         EMU_SITE("classfit: exact turn");
         __syncthreads();
         if (is_decider) {
+          const CfJobU J = job_of(s);
           const CfVerdict v = cf_verdict_exact(S.post2, lane);
           // (an exact turn is raised because candidates exist: v.src >= 0)
           const unsigned nfc = v.fc - J.c, nfm = v.fm - J.m;
@@ -748,40 +771,38 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
           const bool from_ov = v.src == 0;
           const bool gpu_place = !from_ov && J.kind != 0u;
           const bool opens = !from_ov && !gpu_place && !dead;
-          const bool isov = lane < CF_OVL;
           ++matched;
-          if (base + s == 0u) head = 1u;
           if (lane == s) res = (int)v.id;
-          if (lane > s) b1 = b1 || jc > nfc || jm > nfm;
+          b1m |= __ballot((jc > nfc) | (jm > nfm)) & ~cf_below(s) & ~(1ull << s);
           minfc_all = cf_min(minfc_all, nfc), minfm_all = cf_min(minfm_all, nfm);
           unsigned live = (unsigned)__popcll(__ballot(isov && o.valid != 0u));
           unsigned lpos = 0, linfo = s;
           if (from_ov) {
-            ++st_ovwin;
+            CF_STAT(++st_ovwin);
             if (lane == v.pos) {
               o.fc = nfc, o.fm = nfm;
               if (dead) o.valid = 0u;
             }
-            if (dead) ++st_dead, --live;
+            if (dead) --live;
           } else {
             lpos = v.pos, linfo = s | (unsigned)v.src << 8 | v.aux << 12 | (gpu_place ? 1u : 0u) << 20;
             if (lane == CF_OVL - 1u + (unsigned)v.src) {
               if (gpu_place) S.fcm[lpos] = CfFree{nfc, nfm}, S.cid[lpos] = (uint16_t)(S.cid[lpos] | CF_OCC);
               else S.fcm[lpos] = CfFree{0u, 0u};
               ++nrm, rm2 = rm1, rm1 = lpos;
-              S.rm[v.src] = nrm;
+              S.ctrl[1u + (unsigned)v.src] = nrm;
             }
             if (opens) {
-              ++st_open;
+              CF_STAT(++st_open);
               const unsigned lf = (unsigned)__ffsll(~__ballot((isov && o.valid != 0u) || !isov)) - 1u;
               const CfClass* cl = &S.cls[v.cls];
               const double hTc2 = cl->hTc, hTm2 = cl->hTm;
               if (lane == lf) o.valid = 1u, o.id = v.id, o.cls = v.cls, o.fc = nfc, o.fm = nfm, o.hTc = hTc2, o.hTm = hTm2;
               ++live;
             } else if (gpu_place) {
-              ++st_gpu;
+              CF_STAT(++st_gpu);
             } else {
-              ++st_opendead;
+              CF_STAT(++st_opendead);
             }
           }
           if (lane == 0) {
@@ -793,20 +814,20 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
             const unsigned g0 = S.goff[J.grp], gn = S.gcnt[J.grp];
             S.gids[g0 + gn] = (uint16_t)v.id, S.gcnt[J.grp] = (uint16_t)(gn + 1u);
           }
-          todo &= ~(1ull << s);
+          todo &= ~(1ull << s), ++cur_ord;
           epoch = opens && live >= CF_EPOCH_AT;
           if (lane == 0) S.misc[CFX_EPOCH] = epoch ? 1u : 0u, S.misc[CFX_LOGN] = logn;
         }
         EMU_SITE("classfit: exact turn done");
         __syncthreads();
-        epoch = S.misc[CFX_EPOCH] != 0u;
+        epoch = wave_uniform_u32(S.misc[CFX_EPOCH]) != 0u;
       }
       if (epoch) {  // ---- the overlay is full of live offers: back into their classes' arrays
-        const unsigned long long te = cook_ticks();
+        const unsigned long long te = CF_TICKS();
         ++st_epochs;
         // (1) the overlay's lanes, sorted by (class, E, offer), into LDS
         if (is_decider) {
-          const bool live = lane < CF_OVL && o.valid != 0u;
+          const bool live = isov && o.valid != 0u;
           const CfClass* cl = &S.cls[live ? o.cls : 0u];
           const unsigned long long key = live ? ((unsigned long long)o.cls << 58 | ((unsigned long long)o.fc * cl->Tm + (unsigned long long)o.fm * cl->Tc) << 13 | (unsigned long long)o.id) : ~0ull;
           unsigned rank = 0;
@@ -814,7 +835,8 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
           if (live) S.ovl[3u * rank] = o.cls << 16 | o.id, S.ovl[3u * rank + 1u] = o.fc, S.ovl[3u * rank + 2u] = o.fm;
           const unsigned nlive = (unsigned)__popcll(__ballot(live));
           if (lane == 0) S.misc[CFX_OVN] = nlive;
-          if (lane < CF_OVL) o.valid = 0u;
+          if (isov) o.valid = 0u;
+          rm1 = rm2 = 0xFFFFFFFFu;  // (positions of the old arrays: an answer from the new ones may name any position)
         }
         for (unsigned x = tid; x < 3u * CF_MAXCLS; x += CF_THREADS) S.ckept[x] = 0u;
         EMU_SITE("classfit: epoch 1");
@@ -841,9 +863,9 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
         if (is_class_wave) {
           unsigned li = 0;  // first list entry of the class being merged
           for (unsigned ci = 0; ci < n_cls; ++ci) {
-            const unsigned ni = S.ckept[CF_MAXCLS + ci];
+            const unsigned ni = wave_uniform_u32(S.ckept[CF_MAXCLS + ci]);
             if (S.cls[ci].wave == lw) {
-              const unsigned noff = S.ckept[2 * CF_MAXCLS + ci];
+              const unsigned noff = wave_uniform_u32(S.ckept[2 * CF_MAXCLS + ci]);
               const unsigned Tc = S.cls[ci].Tc, Tm = S.cls[ci].Tm;
               unsigned kept_before = 0, ip = li;
               const unsigned long long chunks = __ballot(c.cls == ci);
@@ -854,14 +876,13 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
                 const CfFree f = S.fcm[pos0 + lane];
                 const uint32_t fc = f.c, fm = f.m, cid = ci << 16 | (uint32_t)S.cid[pos0 + lane];
                 const bool keep = in && (fc | fm) != 0u;
-                // (a member that has left keeps its place in the order with the key of the next kept member: nothing is compared with it)
-                const unsigned long long E = (unsigned long long)fc * Tm + (unsigned long long)fm * Tc;
+                const unsigned long long Ek = (unsigned long long)fc * Tm + (unsigned long long)fm * Tc;
                 const unsigned idq = cid & CF_IDMASK;
                 const unsigned long long keepm = __ballot(keep);
                 if (keepm == 0ull) continue;
                 // entries whose key is below the chunk's last kept member go in here
                 const unsigned lastk = 63u - (unsigned)__clzll(keepm);
-                const unsigned long long Elast = wave_read_lane_u64(E, (int)lastk);
+                const unsigned long long Elast = wave_read_lane_u64(Ek, (int)lastk);
                 const unsigned idlast = (unsigned)wave_read_lane((int)idq, (int)lastk);
                 unsigned ins_before = ip - li;  // list entries of the class in front of this member
                 while (ip < li + ni) {
@@ -869,7 +890,7 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
                   const unsigned long long Ee = (unsigned long long)efc * Tm + (unsigned long long)efm * Tc;
                   const unsigned ide = ecid & CF_IDMASK;
                   if (!(Ee < Elast || (Ee == Elast && ide < idlast))) break;
-                  const bool before = keep && (E < Ee || (E == Ee && idq < ide));  // the member stays in front of the entry
+                  const bool before = keep && (Ek < Ee || (Ek == Ee && idq < ide));  // the member stays in front of the entry
                   const unsigned long long bm = __ballot(before);
                   if (keep && !before) ++ins_before;
                   const unsigned np = noff + kept_before + (unsigned)__popcll(bm) + (ip - li);
@@ -915,36 +936,41 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
         // (5) lanes, summaries, tables; every removal of the batch so far is in the new arrays
         if (is_class_wave) {
           cf_setup_chunks(S.cls, n_cls, lw, lane, c, nch_wave);
-          for (unsigned ch = 0; ch < nch_wave; ++ch) cf_tighten(S, t, lane, ch, c);
+          class_setup();
+          for (unsigned ch = 0; ch < nch_wave; ++ch) cf_tighten(S, lane, ch, c);
           cf_wave_tables(S, lw, lane, c, wk, n_kind);
+          tight_applied = st_tight;
         }
         if (tid == 0) S.misc[CFX_LOG_APPLIED] = S.misc[CFX_LOGN];
-        tk_epoch += cook_ticks() - te;
+        tk_epoch += CF_TICKS() - te;
       }
       if (md == CFM_BATCH_END) batch_done = true;
       if (md != CFM_BATCH_END) {  // every answer on the board is void: a new generation; the class waves go on behind the step of the turn
         ++gen;
-        if (is_class_wave) todo = walkmask & ~cf_below(s) & ~(1ull << s);
+        if (is_class_wave) todo = walkmask & ~cf_below(s) & ~(1ull << s), cur_ord = (unsigned)__popcll(walkmask & cf_below(s)) + 1u;
       }
-      if (tid == 0) st_wg(&S.misc[CFX_MODE], 0u);
+      if (tid == 0) st_wg(&S.ctrl[0], 0u);
       EMU_SITE("classfit: collective done");
       __syncthreads();
-      if (is_class_wave) seen = cf_poll(&S.rm[lw]);
+      if (is_class_wave) seen = cf_poll(&S.ctrl[1u + lw]);
     }
-    tk_walk += cook_ticks() - tw0;
+    tk_walk += CF_TICKS() - tw0;
+    CF_PROF_T(cw1);
+    CF_PROF_ADD(7, cw1 - cw0);
     // ---- batch end, phase 1: the decider's books of the batch, the class waves make their summaries exact
-    const unsigned long long tp0 = cook_ticks();
+    const unsigned long long tp0 = CF_TICKS();
     if (is_decider) {
       if (lane < bn) st.job_to_offer[base + lane] = res;
-      const unsigned long long mm = __ballot(res >= 0), bb = __ballot(b1);
-      const bool live = lane < CF_OVL && o.valid != 0u;
+      const unsigned long long mm = __ballot(res >= 0);
+      if (base == 0u) head = (unsigned)(mm & 1ull);
+      const bool live = isov && o.valid != 0u;
       const unsigned nl = live ? cf_level_of(t, o.fc) : 0u;
 #define CF_OV_T(i) unsigned v##i = nl > (unsigned)i ? o.fm + 1u : 0u;
       CF_FOR8(CF_OV_T)
 #undef CF_OV_T
       wave_max8_u32(v0, v1, v2, v3, v4, v5, v6, v7);
       if (lane == 0) {
-        S.misc[CFX_MATCH_LO] = (unsigned)mm, S.misc[CFX_MATCH_HI] = (unsigned)(mm >> 32), S.misc[CFX_B1_LO] = (unsigned)bb, S.misc[CFX_B1_HI] = (unsigned)(bb >> 32);
+        S.misc[CFX_MATCH_LO] = (unsigned)mm, S.misc[CFX_MATCH_HI] = (unsigned)(mm >> 32), S.misc[CFX_B1_LO] = (unsigned)b1m, S.misc[CFX_B1_HI] = (unsigned)(b1m >> 32);
         S.misc[CFX_LOGN] = logn, S.misc[CFX_MINFC] = minfc_all, S.misc[CFX_MINFM] = minfm_all;
 #define CF_OV_S(i) S.ovt[i] = v##i;
         CF_FOR8(CF_OV_S)
@@ -955,8 +981,8 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
       EMU_SITE("classfit: phase 1");
       __syncthreads();
       if (is_class_wave) {  // the batch's removals from this wave's chunks: summaries a member that left was the maximum of are recomputed
-        const unsigned n_log = S.misc[CFX_LOGN], a0 = S.misc[CFX_LOG_APPLIED];
-        const bool mine_e = lane >= a0 && lane < n_log && ((S.log[lane < 64u ? lane : 0u].info >> 8) & 15u) == lw;
+        const unsigned n_log = wave_uniform_u32(S.misc[CFX_LOGN]), a0 = wave_uniform_u32(S.misc[CFX_LOG_APPLIED]);
+        const bool mine_e = lane >= a0 && lane < n_log && ((S.log[lane].info >> 8) & 15u) == lw;
         bool dirty = st_tight != tight_applied;
         for (unsigned long long mm = __ballot(mine_e); mm; mm &= mm - 1ull) {
           const unsigned x = (unsigned)__ffsll(mm) - 1u;
@@ -968,7 +994,7 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
           CF_FOR8(CF_WAS_MAX)
 #undef CF_WAS_MAX
           if (retable) {
-            cf_tighten(S, t, lane, ch, c);
+            cf_tighten(S, lane, ch, c);
             ++st_tight;
             dirty = true;
           }
@@ -979,13 +1005,13 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
     }
     EMU_SITE("classfit: phase 2");
     __syncthreads();
-    tk_phase1 += cook_ticks() - tp0;
+    tk_phase1 += CF_TICKS() - tp0;
     // ---- phase 2: the bookkeeper: failure codes of this batch, the next batch
     if (is_books) {
-      const unsigned long long tb0 = cook_ticks();
+      const unsigned long long tb0 = CF_TICKS();
       const unsigned long long mm = (unsigned long long)S.misc[CFX_MATCH_LO] | (unsigned long long)S.misc[CFX_MATCH_HI] << 32,
                                bb = (unsigned long long)S.misc[CFX_B1_LO] | (unsigned long long)S.misc[CFX_B1_HI] << 32;
-      const unsigned n_log = S.misc[CFX_LOGN];
+      const unsigned n_log = wave_uniform_u32(S.misc[CFX_LOGN]);
       const CfJob j = S.ring[slot * 64u + (lane < bn ? lane : 0u)];
       const bool unm = lane < bn && !((mm >> lane) & 1ull);
       const unsigned L = (j.meta >> 8) & 15u;
@@ -1011,29 +1037,134 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
       books_next(base + 64u);
       bk_room0 = nx_room0;
       if (base + 128u + lane < K) nxt = b.jobs[base + 128u + lane];
-      tk_books += cook_ticks() - tb0;
+      tk_books += CF_TICKS() - tb0;
     }
     EMU_SITE("classfit: batch end");
     __syncthreads();
   }
-  if (is_decider && lane == 0) {
-    st.summary[0] = matched;
-    st.summary[1] = (matched == 0u || head) ? 1u : 0u;
-    st.summary[2] = st_epochs;
-    const unsigned long long t_end = cook_ticks();
-    uint32_t* sx = ctl->stats;
-    sx[CFS_MATCHED] = matched, sx[CFS_OV_WIN] = st_ovwin, sx[CFS_OPEN] = st_open, sx[CFS_OPEN_DEAD] = st_opendead, sx[CFS_GPU_PLACE] = st_gpu, sx[CFS_EPOCHS] = st_epochs,
-    sx[CFS_EXACT] = st_exact, sx[CFS_WALKED] = st_walked, sx[CFS_DEAD_DROP] = st_dead, sx[CFS_BATCHES] = (K + 63u) / 64u, sx[CFS_PRESETTLED] = K - st_walked;
-    sx[CFS_TICKS_TOTAL] = (uint32_t)(t_end - t_start), sx[CFS_TICKS_PROLOGUE] = (uint32_t)(t_loop - t_start), sx[CFS_TICKS_EPOCH] = (uint32_t)tk_epoch;
-    sx[CFS_TICKS_WALK] = (uint32_t)tk_walk, sx[CFS_TICKS_PHASE1] = (uint32_t)tk_phase1;
-  }
   if (is_decider) {
-    const unsigned sp = wave_max_u32(lane >= CF_OVL ? st_spins : 0u);
+    if (lane == 0) {
+      st.summary[0] = matched;
+      st.summary[1] = (matched == 0u || head) ? 1u : 0u;
+      st.summary[2] = st_epochs;
+      const unsigned long long t_end = cook_ticks();
+      uint32_t* sx = ctl->stats;
+      sx[CFS_MATCHED] = matched, sx[CFS_OV_WIN] = st_ovwin, sx[CFS_OPEN] = st_open, sx[CFS_OPEN_DEAD] = st_opendead, sx[CFS_GPU_PLACE] = st_gpu, sx[CFS_EPOCHS] = st_epochs,
+      sx[CFS_EXACT] = st_exact, sx[CFS_WALKED] = st_walked, sx[CFS_DEAD_DROP] = st_dead, sx[CFS_BATCHES] = (K + 63u) / 64u, sx[CFS_PRESETTLED] = K - st_walked;
+      sx[CFS_TICKS_TOTAL] = (uint32_t)(t_end - t_start), sx[CFS_TICKS_PROLOGUE] = (uint32_t)(t_loop - t_start), sx[CFS_TICKS_EPOCH] = (uint32_t)tk_epoch;
+      sx[CFS_TICKS_WALK] = (uint32_t)tk_walk, sx[CFS_TICKS_PHASE1] = (uint32_t)tk_phase1;
+      sx[CFS_HWID_DECIDER] = cook_hw_id();
+    }
+    const unsigned sp = wave_max_u32(!isov ? st_spins : 0u);
     if (lane == 0) ctl->stats[CFS_SPINS] = sp;
   }
-  if (lane == 0 && is_decider) ctl->stats[CFS_HWID_DECIDER] = cook_hw_id();
-  if (lane == 0 && is_books) ctl->stats[CFS_HWID_BOOKS] = cook_hw_id();
   if (is_class_wave && lane == 0) atomicAdd(&ctl->stats[CFS_SCANS], st_scans), atomicAdd(&ctl->stats[CFS_TIGHTEN], st_tight), atomicAdd(&ctl->stats[CFS_REWINDS], st_rewinds);
-  if (is_books && lane == 0) ctl->stats[CFS_TICKS_PRECHECK] = (uint32_t)tk_books, ctl->stats[CFS_FLIPS] = st_flips;
-  (void)tk_wait;
+  if (is_books && lane == 0) ctl->stats[CFS_TICKS_PRECHECK] = (uint32_t)tk_books, ctl->stats[CFS_FLIPS] = st_flips, ctl->stats[CFS_HWID_BOOKS] = cook_hw_id();
+#ifdef CF_PROF
+  if (lane == 0 && (is_decider || (is_class_wave && lw <= 2u)))
+    for (int i = 0; i < 8; ++i) ctl->stats[24 + 8 * (is_decider ? 0u : lw) + i] = (uint32_t)(prof[i] >> 4);  // units of 16 cycles
+#endif
+#undef n_cls
+#undef n_kind
+#undef NP
+}
+
+static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __restrict__ inp, const MatchState& st, const CfBuf& b) {
+  const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  CfCtl* ctl = b.ctl;
+  const unsigned K = inp->K, M = ctl->M, G = inp->G;
+  const unsigned NP = (M + 63u) & ~63u;
+  const unsigned long long t_start = cook_ticks();
+  const bool any_eq = ctl->any_eq != 0u, any_group = ctl->any_group != 0u;
+  // ---- group table sizes (needed for the layout): entries per unique group = running cotasks on hosts of this call + pending members
+  __shared__ unsigned s_total, s_wsum[CF_WAVES];
+  constexpr unsigned GPT = CF_MAXG / CF_THREADS;
+  unsigned gsz[GPT];
+  unsigned gsum = 0;
+#pragma unroll
+  for (unsigned x = 0; x < GPT; ++x) {
+    const unsigned g = tid * GPT + x;
+    unsigned sz = 0;
+    if (any_group && g < G && b.gcount[g] != 0u) sz = (inp->g_run_off ? inp->g_run_off[g + 1] - inp->g_run_off[g] : 0u) + b.gcount[g];
+    gsz[x] = sz, gsum += sz;
+  }
+  unsigned incl = gsum;  // inclusive scan over the workgroup
+  for (unsigned d = 1; d < 64u; d <<= 1) {
+    const unsigned y = shfl_up_t<unsigned>(incl, d);
+    if (lane >= d) incl += y;
+  }
+  if (lane == 63u) s_wsum[w] = incl;
+  __syncthreads();
+  unsigned wbase = 0;
+  for (unsigned x = 0; x < w; ++x) wbase += s_wsum[x];
+  if (tid == CF_THREADS - 1) s_total = wbase + incl;
+  __syncthreads();
+  const unsigned Stot = any_group ? s_total : 0u, Gl = any_group ? G : 0u;
+  // ---- layout (cf_lds_bytes_host in engine.hip computes the same sum)
+  CfLds S;
+  {
+    CfFixed* F = (CfFixed*)lds;
+    S.board = F->board, S.log = F->log, S.ring = F->ring, S.post2 = F->post2, S.cls = F->cls, S.pw = F->pw, S.aw = F->aw, S.gk = F->gk, S.ovt = F->ovt, S.ctrl = F->ctrl, S.ovl = F->ovl,
+    S.ckept = F->ckept, S.misc = F->misc, S.t = F->env_t, S.envw = F->envw;
+    char* p = lds + sizeof(CfFixed);
+    S.fcm = (CfFree*)p, p += NP * 8u;
+    S.cid = (uint16_t*)p, p += NP * 2u;
+    p = lds + (((unsigned)(p - lds) + 7u) & ~7u);
+    S.attr8 = (uint64_t*)p;
+    if (any_eq) p += M * 8u;
+    S.goff = (uint16_t*)p, p += (Gl + 1u) * 2u;
+    S.gcnt = (uint16_t*)p, p += Gl * 2u;
+    S.gids = (uint16_t*)p, p += Stot * 2u;
+    if ((unsigned)(p - lds) > CF_LDS_BYTES) {  // (the host checks the same sum before it launches)
+      if (tid == 0) atomicOr(&ctl->inelig, (unsigned)CF_X_SHAPE), st.summary[3] = 0xDEADu;
+      return;
+    }
+  }
+  // ---- prologue: class arrays, byte table, group table
+  for (unsigned q = tid; q < NP; q += CF_THREADS) {
+    S.fcm[q] = q < M ? CfFree{b.pos_fc[q], b.pos_fm[q]} : CfFree{0u, 0u}, S.cid[q] = q < M ? (uint16_t)b.pos_cid[q] : (uint16_t)0u;
+  }
+  if (any_eq)
+    for (unsigned v = tid; v < M; v += CF_THREADS) S.attr8[v] = b.attr8[v];
+  if (any_group) {
+    unsigned off = wbase + incl - gsum;
+#pragma unroll
+    for (unsigned x = 0; x < GPT; ++x) {
+      const unsigned g = tid * GPT + x;
+      if (g <= G) S.goff[g] = (uint16_t)off;
+      if (g < G) {
+        unsigned cnt = 0;
+        if (gsz[x]) {
+          const unsigned r0 = inp->g_run_off ? inp->g_run_off[g] : 0u, r1 = inp->g_run_off ? inp->g_run_off[g + 1] : 0u;
+          for (unsigned r = r0; r < r1; ++r) {
+            const uint32_t h = inp->g_run_host[r];
+            const uint32_t v = h <= b.max_host ? b.h2o[h] : 0xFFFFFFFFu;
+            if (v != 0xFFFFFFFFu) S.gids[off + cnt++] = (uint16_t)v;
+          }
+        }
+        S.gcnt[g] = (uint16_t)cnt;
+        off += gsz[x];
+      }
+    }
+  }
+  {
+    CfFixed* F = (CfFixed*)lds;
+    if (tid < (unsigned)CF_LV) F->env_t[tid] = ctl->t[tid];
+    if (tid == 0) {
+      uint32_t* ew = F->envw;
+      ew[CFE_K] = K, ew[CFE_M] = M, ew[CFE_NP] = NP, ew[CFE_NCLS] = ctl->n_cls, ew[CFE_NKIND] = ctl->n_kind, ew[CFE_CMIN] = ctl->cmin, ew[CFE_MMIN] = ctl->mmin, ew[CFE_KC] = ctl->kc,
+      ew[CFE_KM] = ctl->km, ew[CFE_MINFC] = ctl->minfc_all, ew[CFE_MINFM] = ctl->minfm_all;
+    }
+  }
+  for (unsigned x = tid; x < ctl->n_cls; x += CF_THREADS) S.cls[x] = ctl->cls[x];
+  for (unsigned x = tid; x < CFX_N; x += CF_THREADS) S.misc[x] = 0u;
+  for (unsigned x = tid; x < 8u * CF_LV; x += CF_THREADS) S.pw[x] = 0u, S.aw[x] = 0u;
+  for (unsigned x = tid; x < 8u; x += CF_THREADS) S.ctrl[x] = 0u;
+  for (unsigned x = tid; x < CF_MAXKIND * CF_LV; x += CF_THREADS) S.gk[x] = 0u;
+  for (unsigned x = tid; x < (unsigned)CF_LV; x += CF_THREADS) S.ovt[x] = 0u;
+  for (unsigned x = tid; x < CF_BOARD * 8u; x += CF_THREADS) S.board[x].tag = 0xFFFFFFFFu;
+  __syncthreads();
+  if (w == 0u) cf_walk_role<0>(S, st, b, 0u, t_start);
+  else if (w == CFW_BOOKS) cf_walk_role<2>(S, st, b, 0u, t_start);
+  else cf_walk_role<1>(S, st, b, w < CFW_BOOKS ? w : w - 1u, t_start);
 }

@@ -1315,13 +1315,10 @@ static void launch_round(cook_engine* e, const MatchIn& in, const MatchState& st
 // COOK_CLASSFIT=0: every match goes through the window rounds (A/B switch)
 static const bool g_classfit = env_switch_on_unless_zero("COOK_CLASSFIT");
 static size_t cf_lds_bytes_host(unsigned NP, unsigned M, bool eq, unsigned G, unsigned S) {  // the layout of cf_walk_pool (classfit_walk.hpp)
-  size_t n = (size_t)NP * 10u;
+  size_t n = sizeof(CfFixed) + (size_t)NP * 10u;
   n = (n + 7u) & ~(size_t)7u;
   if (eq) n += (size_t)M * 8u;
   n += ((size_t)G + 1u) * 2u + (size_t)G * 2u + (size_t)S * 2u;
-  n = (n + 15u) & ~(size_t)15u;
-  n += 2u * 64u * sizeof(CfJob) + CF_BOARD * 8u * sizeof(CfEnt) + 64u * sizeof(CfLog) + 8u * sizeof(CfPost) + CF_MAXCLS * sizeof(CfClass);
-  n += (2u * 8u * CF_LV + CF_MAXKIND * CF_LV + CF_LV + 8u + 192u + 3u * CF_MAXCLS + CFX_N) * 4u;
   return n + 64u;
 }
 // the three set-up kernels of a call and the look at what they found -> true: the call can be placed by cf_walk (ctx filled in)
@@ -1394,6 +1391,12 @@ void cf_run(cook_engine* lead, cook_engine* const* es, unsigned n, hipStream_t s
     const unsigned* sum = (const unsigned*)(lead->h_cf + i * SLOT);
     if (sum[3] == 0xDEADu) lead->fail(COOK_E_STATE, "cf_walk: the pool's tables do not fit the workgroup's LDS (the host's check let it through)");
     std::memcpy(x->cf_stats, lead->h_cf + i * SLOT + 16, 48 * 4);
+#ifdef CF_PROF
+    {
+      const uint32_t* q = x->cf_stats;
+      std::fprintf(stderr, "CFPROF (x16 shader cycles) decider: candidates %u evaluation %u commit %u steps %u walk-total %u | class wave 1: poll %u answer %u publish %u answers %u idle %u idles %u | class wave 2: poll %u answer %u publish %u answers %u idle %u idles %u | walk ticks(100MHz) %u\n", q[24], q[25], q[26], q[27], q[31], q[32], q[33], q[34], q[35], q[36], q[37], q[40], q[41], q[42], q[43], q[44], q[45], q[CFS_TICKS_WALK]);
+    }
+#endif
     WinCtl c{};
     c.matched = sum[0], c.head_matched = sum[1], c.rounds = sum[2], c.head = x->last_in.K, c.visited_sum = x->cf_stats[CFS_WALKED];
     c.t_seq = x->cf_stats[CFS_TICKS_TOTAL], c.t_setup = x->cf_stats[CFS_TICKS_PROLOGUE];

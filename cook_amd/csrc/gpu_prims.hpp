@@ -164,6 +164,43 @@ static __device__ __forceinline__ void wave_max8_u32(unsigned& a0, unsigned& a1,
 // the wave's hardware placement (HW_REG_HW_ID: bits 4..5 the SIMD of the CU), for the profile notes
 static __device__ __forceinline__ unsigned cook_hw_id() { return (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
 static __device__ __forceinline__ void cook_set_prio_high() { __builtin_amdgcn_s_setprio(3); }
+// One lane's store of wave-uniform words to LDS WITHOUT a vector compare: `if (lane == 0) *p = v` costs a v_cmp, an exec save and a branch on it (a
+// VALU -> SALU -> branch hop of 50-80 cycles on a walk's critical path); here the exec mask is set from a constant.  All 64 lanes must be active.
+typedef __attribute__((address_space(3))) char* cook_lds_ptr;
+static __device__ __forceinline__ unsigned cook_lds_off(const void* p) { return (unsigned)(__SIZE_TYPE__)(cook_lds_ptr)(p); }
+static __device__ __forceinline__ void st_lane0_b32(void* p, unsigned a) {
+  unsigned long long sv;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(sv) : "v"(cook_lds_off(p)), "v"(a) : "memory");
+}
+static __device__ __forceinline__ void st_lane0_b64(void* p, unsigned a, unsigned b) {
+  unsigned long long sv;
+  const unsigned long long v = (unsigned long long)b << 32 | a;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b64 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(sv) : "v"(cook_lds_off(p)), "v"(v) : "memory");
+}
+static __device__ __forceinline__ void st_lane0_b128(void* p, unsigned a, unsigned b, unsigned c, unsigned d) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  unsigned long long sv;
+  const u32x4 v = {a, b, c, d};
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b128 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(sv) : "v"(cook_lds_off(p)), "v"(v) : "memory");
+}
+// the lanes of `mask` (wave-uniform, non-empty) store their own words to `p` (wave-uniform); all 64 lanes must be active
+static __device__ __forceinline__ void st_mask_b32(void* p, unsigned long long mask, unsigned a) {
+  unsigned long long sv;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(sv) : "v"(cook_lds_off(p)), "v"(a), "s"(mask) : "memory");
+}
+static __device__ __forceinline__ void st_mask_b64(void* p, unsigned long long mask, unsigned a, unsigned b) {
+  unsigned long long sv;
+  const unsigned long long v = (unsigned long long)b << 32 | a;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tds_write_b64 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(sv) : "v"(cook_lds_off(p)), "v"(v), "s"(mask) : "memory");
+}
+static __device__ __forceinline__ void st_mask_b128(void* p, unsigned long long mask, unsigned a, unsigned b, unsigned c, unsigned d) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  unsigned long long sv;
+  const u32x4 v = {a, b, c, d};
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\tds_write_b128 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(sv) : "v"(cook_lds_off(p)), "v"(v), "s"(mask) : "memory");
+}
+// ballot of a condition every active lane has computed (the builtin folds into the compare that made it; HIP's __ballot goes through a 0 / 1 register)
+static __device__ __forceinline__ unsigned long long cook_ballot(bool x) { return __builtin_amdgcn_ballot_w64(x); }
 // value of v in lane src; src must be wave-uniform
 static __device__ __forceinline__ int wave_read_lane(int v, int src) {
   return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));

@@ -91,6 +91,25 @@ static inline void wave_max8_u32(unsigned& a0, unsigned& a1, unsigned& a2, unsig
   a0 = wave_max_u32(a0), a1 = wave_max_u32(a1), a2 = wave_max_u32(a2), a3 = wave_max_u32(a3), a4 = wave_max_u32(a4), a5 = wave_max_u32(a5), a6 = wave_max_u32(a6),
   a7 = wave_max_u32(a7);
 }
+static inline void st_lane0_b32(void* p, unsigned a) {
+  if (lane_id() == 0) *(unsigned*)p = a, emu::progress();
+}
+static inline void st_lane0_b64(void* p, unsigned a, unsigned b) {
+  if (lane_id() == 0) ((unsigned*)p)[0] = a, ((unsigned*)p)[1] = b, emu::progress();
+}
+static inline void st_lane0_b128(void* p, unsigned a, unsigned b, unsigned c, unsigned d) {
+  if (lane_id() == 0) ((unsigned*)p)[0] = a, ((unsigned*)p)[1] = b, ((unsigned*)p)[2] = c, ((unsigned*)p)[3] = d, emu::progress();
+}
+static inline void st_mask_b32(void* p, unsigned long long mask, unsigned a) {
+  if ((mask >> lane_id()) & 1ull) *(unsigned*)p = a, emu::progress();
+}
+static inline void st_mask_b64(void* p, unsigned long long mask, unsigned a, unsigned b) {
+  if ((mask >> lane_id()) & 1ull) ((unsigned*)p)[0] = a, ((unsigned*)p)[1] = b, emu::progress();
+}
+static inline void st_mask_b128(void* p, unsigned long long mask, unsigned a, unsigned b, unsigned c, unsigned d) {
+  if ((mask >> lane_id()) & 1ull) ((unsigned*)p)[0] = a, ((unsigned*)p)[1] = b, ((unsigned*)p)[2] = c, ((unsigned*)p)[3] = d, emu::progress();
+}
+static inline unsigned long long cook_ballot(bool x) { return __ballot(x); }
 static inline unsigned cook_hw_id() { return 0u; }
 static inline void cook_set_prio_high() {}
 static inline int wave_read_lane(int v, int src) { return __shfl(v, src, COOK_WAVE); }
