@@ -357,6 +357,18 @@ struct CfFixed {
   uint32_t env_t[CF_LV], envw[CFE_N];
 };
 static_assert(sizeof(CfFixed) % 16 == 0, "the arrays behind it are 16-byte aligned");
+#if COOK_HAS_ASM_WALK
+#define CF_ASM_EPOCH_LIVE "57"
+#include "classfit_asm.hpp"
+static_assert(CF_EPOCH_AT == 58 && CF_OVL == 58, "classfit_asm.hpp: the overlay's size");
+static_assert(offsetof(CfFixed, ctrl) == 11680 && offsetof(CfFixed, cls) == 7424 && sizeof(CfFixed) == 13232 && sizeof(CfClass) == 56 && offsetof(CfClass, hTc) == 32 &&
+                  offsetof(CfClass, hTm) == 40 && offsetof(CfEnt, pos) == 8 && offsetof(CfEnt, cid) == 12 && offsetof(CfEnt, fc) == 16 && offsetof(CfEnt, fa) == 24 && sizeof(CfEnt) == 32 &&
+                  sizeof(CfLog) == 32 && offsetof(CfLog, ofc) == 8,
+              "classfit_asm.hpp: offsets of the LDS records");
+typedef unsigned cf_u32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned cf_u32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned cf_u32x4 __attribute__((ext_vector_type(4)));
+#endif
 
 template <int ROLE>  // 0 the decider, 1 a class wave, 2 the bookkeeper
 static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchState& st, const CfBuf& b, const unsigned lw, const unsigned long long t_start) {
@@ -496,7 +508,55 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
       unsigned md = 0;  // the collective turn this wave leaves its loop for
       if (is_decider) {
         // ================================================= the decider =================================================
+#if COOK_HAS_ASM_WALK
+        // the lane's state and the batch's jobs as the hand-placed step holds them (classfit_asm.hpp)
+        cf_u32x16 ST = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        cf_u32x8 JB = {jc, jm, jmeta, clw * 32u, lane, 0u, 0u, 0u};
+        const unsigned long long rel0 = cook_ballot(!isov & ((my_kinds & 1u) != 0u)), ovm = cf_below(CF_OVL);
+        const cf_u32x4 MK = {wave_uniform_u32((unsigned)rel0), wave_uniform_u32((unsigned)(rel0 >> 32)), wave_uniform_u32((unsigned)ovm), wave_uniform_u32((unsigned)(ovm >> 32))};
+        const unsigned a_board = wave_uniform_u32(cook_lds_off(S.board)), a_log = wave_uniform_u32(cook_lds_off(S.log));
+        auto st_pack = [&] {
+          const unsigned long long hc = (unsigned long long)__double_as_longlong(o.hTc), hm = (unsigned long long)__double_as_longlong(o.hTm);
+          ST[0] = o.valid, ST[1] = o.id, ST[2] = (unsigned)hc, ST[3] = (unsigned)(hc >> 32), ST[4] = (unsigned)hm, ST[5] = (unsigned)(hm >> 32), ST[6] = o.cls, ST[7] = o.fc, ST[8] = o.fm,
+          ST[9] = nrm, ST[10] = rm1, ST[11] = rm2, ST[12] = (unsigned)res;
+        };
+        auto st_unpack = [&] {
+          o.valid = ST[0], o.id = ST[1], o.hTc = __longlong_as_double((long long)((unsigned long long)ST[3] << 32 | ST[2])),
+          o.hTm = __longlong_as_double((long long)((unsigned long long)ST[5] << 32 | ST[4])), o.cls = ST[6], o.fc = ST[7], o.fm = ST[8], nrm = ST[9], rm1 = ST[10], rm2 = ST[11],
+          res = (int)ST[12];
+        };
+#endif
         while (md == 0u) {
+          // (scalars for the compiler too: one of them in a vector register turns this loop into an exec-mask loop and every counter into vector arithmetic)
+          todo = wave_uniform_u64(todo), cur_ord = wave_uniform_u32(cur_ord), logn = wave_uniform_u32(logn), matched = wave_uniform_u32(matched), gen = wave_uniform_u32(gen);
+          minfc_all = wave_uniform_u32(minfc_all), minfm_all = wave_uniform_u32(minfm_all), b1m = wave_uniform_u64(b1m);
+#if COOK_HAS_ASM_WALK
+          {  // plain steps, one behind the other, as long as they are plain (classfit_asm.hpp); the step that is not is the C++ step's below
+            st_pack();
+            while (todo != 0ull) {
+              const unsigned fs = (unsigned)__ffsll(todo) - 1u;
+#define CF_U(x) wave_uniform_u32((unsigned)(x))
+              cf_u32x8 SC = {CF_U(matched), CF_U(minfc_all), CF_U(b1m), CF_U(b1m >> 32), CF_U(minfm_all), 1u, 0u, 0u};
+              const cf_u32x8 AR = {CF_U(fs), CF_U((base + fs) << 12 | (gen & 15u) << 8), CF_U(a_board + (cur_ord & (CF_BOARD - 1u)) * 8u * (unsigned)sizeof(CfEnt)), CF_U(fs | cur_ord << 8),
+                                   CF_U(a_log + logn * (unsigned)sizeof(CfLog)), CF_U(cmin), CF_U(mmin), a_board};
+#undef CF_U
+              asm volatile(CF_ASM_DECIDER_STEP
+                           : "+{v[64:79]}"(ST), "+{s[36:43]}"(SC)
+                           : "{v[80:87]}"(JB), "{s[44:51]}"(AR), "{s[52:55]}"(MK)
+                           : "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",
+                             "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",
+                             "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "vcc", "scc", "memory");
+              const unsigned status = wave_uniform_u32(SC[5]);
+              if (status == 1u) break;
+              matched = wave_uniform_u32(SC[0]), minfc_all = wave_uniform_u32(SC[1]), minfm_all = wave_uniform_u32(SC[4]);
+              b1m = wave_uniform_u64((unsigned long long)SC[3] << 32 | SC[2]);
+              logn += status >> 1;
+              todo &= todo - 1ull, ++cur_ord;
+              CF_PROF_ADD(3, 1);
+            }
+            st_unpack();
+          }
+#endif
           if (todo == 0ull) {
             md = CFM_BATCH_END;
             st_lane0_b32(&S.ctrl[0], md);

@@ -11,6 +11,7 @@
 #define WALK_STAT(i, v) ((void)0)
 #define WALK_STAT_PREV_LANE(i, win_lane, win, nT) ((void)0)
 #define COOK_EMU_EXTRA_EXPORTS
+#define COOK_HAS_ASM_WALK 1  // classfit_asm.hpp: the hand-placed form of the class-ordered walk's plain step (the emulated build runs the C++ step only)
 
 // ---- wave-level rendezvous ---------------------------------------------------------------------------
 // On the GPU the 64 lanes of a wave run in lockstep and LDS operations of one wave retire in order, so this is a

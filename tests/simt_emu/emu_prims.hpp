@@ -13,6 +13,7 @@
 #define COOK_BUILD_NAME "simt-emu test build"
 #endif
 
+#define COOK_HAS_ASM_WALK 0
 #define COOK_WAVES_PER_SIMD(n)  // (an occupancy request to the GPU compiler: nothing to emulate)
 
 // ---- wave-level rendezvous ---------------------------------------------------------------------------
