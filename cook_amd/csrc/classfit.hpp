@@ -24,8 +24,11 @@
 #include "match_kernels.hpp"
 
 constexpr int CF_LV = 8;                  // level summaries per chunk
-constexpr int CF_THREADS = 512;           // wave 0 overlay, waves 1..CF_CW class waves, wave 7 bookkeeper
-constexpr int CF_CW = 6;
+#ifndef CF_NT
+#define CF_NT 1024
+#endif
+constexpr int CF_THREADS = COOK_SHAPE(CF_NT, 512);  // wave 0 the decider, wave 4 the bookkeeper, the others class waves (classfit_walk.hpp)
+constexpr int CF_CW = 6;                  // sets of classes (a set = the classes one class wave's lanes hold; several waves may share a set's jobs)
 constexpr int CF_WAVES = CF_THREADS / COOK_WAVE;
 constexpr int CF_MAXCLS = 48;             // classes per call (totals x gpu kind)
 constexpr int CF_MAXKIND = 32;            // gpu kinds incl. kind 0 = hosts without gpus

@@ -16,7 +16,7 @@
 //             head word, s48 LDS address of the log entry, s49 / s50 least cpus / mem any job asks for, s51 LDS address of the fixed records (CfFixed)
 //   s[52:55]  s[52:53] the candidate lanes whose class wave holds hosts without gpus, s[54:55] the overlay's lanes
 //   clobbered: v[88:119], s[56:79], vcc, scc
-// Offsets into CfFixed (static_asserts in classfit_walk.hpp): ctrl 11680, class table 7424 (56 bytes a class, 0.5 / Tc at 32), the arrays' start 13232.
+// Offsets into CfFixed (static_asserts in classfit_walk.hpp): ctrl 13728, class table 9472 (56 bytes a class, 0.5 / Tc at 32), the arrays' start 15280.
 #pragma once
 #define CF_ASM_MAX_STEP(ctrl) "v_max_f32_dpp v113, v113, v113 " ctrl "\n\ts_nop 1\n\t"
 #define CF_ASM_DECIDER_STEP                                                                                                             \
@@ -32,7 +32,7 @@
   "v_mov_b32_e32 v89, s51\n\t"                                                                                                          \
   "v_add_u32_e32 v100, s46, v83\n\t"                                                                                                    \
   "s_mov_b64 exec, 1\n\t"                                                                                                               \
-  "ds_write_b32 v89, v88 offset:11684\n\t"                                                                                              \
+  "ds_write_b32 v89, v88 offset:13732\n\t"                                                                                              \
   "s_mov_b64 exec, -1\n\t"                                                                                                              \
   "ds_read_b32 v92, v100\n\t"                                                                                                           \
   "ds_read_b64 v[94:95], v100 offset:8\n\t"                                                                                             \
@@ -167,8 +167,8 @@
   "v_mov_b32_e32 v91, s59\n\t"                                                                                                          \
   "v_mov_b32_e32 v100, s74\n\t"                                                                                                         \
   "s_mov_b64 exec, 1\n\t"                                                                                                               \
-  "ds_write_b64 v90, v[88:89] offset:13232\n\t"                                                                                         \
-  "ds_write_b32 v91, v100 offset:11684\n\t"                                                                                             \
+  "ds_write_b64 v90, v[88:89] offset:15280\n\t"                                                                                         \
+  "ds_write_b32 v91, v100 offset:13732\n\t"                                                                                             \
   "s_mov_b64 exec, -1\n\t"                                                                                                              \
   "v_cmp_eq_u32_e64 vcc, s78, v84\n\t"                                                                                                  \
   "v_mov_b32_e32 v101, s69\n\t"                                                                                                         \
@@ -185,7 +185,7 @@
   "s_mul_i32 s58, s75, 56\n\t"                                                                                                          \
   "s_add_u32 s58, s58, s51\n\t"                                                                                                         \
   "v_mov_b32_e32 v90, s58\n\t"                                                                                                          \
-  "ds_read_b128 v[116:119], v90 offset:7456\n\t"                                                                                        \
+  "ds_read_b128 v[116:119], v90 offset:9504\n\t"                                                                                        \
   "s_andn2_b64 s[58:59], s[54:55], s[64:65]\n\t"                                                                                        \
   "s_ff1_i32_b64 s79, s[58:59]\n\t"                                                                                                     \
   "v_cmp_eq_u32_e64 vcc, s79, v84\n\t"                                                                                                  \

@@ -36,7 +36,10 @@
 #define CF_PROF_ADD(i, d) ((void)0)
 #endif
 
-constexpr unsigned CF_BOARD = 4;    // steps the class waves may run ahead of the decider (a power of two)
+constexpr unsigned CF_BOARD = 4;    // steps the class waves may run ahead of the decider
+constexpr unsigned CF_SLOTS = 12;   // entries per column of the board: walked ordinal modulo 12.  The waves that share a set's jobs take the ordinals in turn and
+                                    // their number divides 12, so a slot has ONE writer: a late answer of a slow wave lands where only that wave's next one goes
+static __device__ __forceinline__ unsigned cf_slot(unsigned ord) { return ord - CF_SLOTS * ((ord * 43u) >> 9); }  // ord % 12 for ord < 64
 constexpr unsigned CF_OVL = 58;     // overlay lanes (lanes 58..63 are the candidates of logical class waves 1..6)
 constexpr unsigned CF_EPOCH_AT = COOK_SHAPE(58, 8);  // live overlay lanes that end an epoch
 constexpr unsigned CFW_BOOKS = 4;   // the bookkeeper's wave
@@ -70,7 +73,7 @@ struct CfJobU {  // the job of a step, wave-uniform
 struct CfLds {  // the workgroup's LDS, carved at run time
   CfFree* fcm;           // [NP] free cpus / mem of a position (0 / 0: the member has left, or padding)
   uint16_t* cid;        // [NP] occupied gpu host << 15 | the next member may round to the same fitness << 14 | offer
-  CfEnt* board;         // [CF_BOARD][8]
+  CfEnt* board;         // [CF_SLOTS][8]
   CfLog* log;           // [64]
   uint32_t* ctrl;       // [8] [0] the mode word of a collective turn, [1] the batch lane of the decider's step, [1 + w] removals from logical class wave w so far
   uint64_t* attr8;
@@ -319,9 +322,9 @@ struct CfVerdict {
   int src;
   unsigned id, pos, fc, fm, cls, aux;
 };
-static __device__ __forceinline__ CfVerdict cf_verdict_exact(const CfPost* posts, unsigned lane) {
+static __device__ __forceinline__ CfVerdict cf_verdict_exact(const CfPost* posts, unsigned lane, unsigned used_sets) {  // used_sets: bit g = set g has classes (and a wave that posts)
   CfVerdict v;
-  const bool has = lane < 7u;
+  const bool has = lane == 0u || (lane < 7u && ((used_sets >> lane) & 1u));
   CfPost p;
   p.fa = 0.0, p.w0 = 0u, p.pos = p.fc = p.fm = p.cls = p.aux = 0u;
   if (has) p = posts[lane];
@@ -346,7 +349,7 @@ constexpr float CF_BAND32 = 1.0f / 2097152.0f;  // 2^-21: two fitness values thi
 
 // fixed part of the LDS at constant offsets (the arrays whose size follows the call come behind it)
 struct CfFixed {
-  CfEnt board[CF_BOARD * 8u];
+  CfEnt board[CF_SLOTS * 8u];
   CfLog log[64];
   CfJob ring[2u * 64u];
   CfPost post2[8];
@@ -361,7 +364,7 @@ static_assert(sizeof(CfFixed) % 16 == 0, "the arrays behind it are 16-byte align
 #define CF_ASM_EPOCH_LIVE "57"
 #include "classfit_asm.hpp"
 static_assert(CF_EPOCH_AT == 58 && CF_OVL == 58, "classfit_asm.hpp: the overlay's size");
-static_assert(offsetof(CfFixed, ctrl) == 11680 && offsetof(CfFixed, cls) == 7424 && sizeof(CfFixed) == 13232 && sizeof(CfClass) == 56 && offsetof(CfClass, hTc) == 32 &&
+static_assert(offsetof(CfFixed, ctrl) == 13728 && offsetof(CfFixed, cls) == 9472 && sizeof(CfFixed) == 15280 && sizeof(CfClass) == 56 && offsetof(CfClass, hTc) == 32 &&
                   offsetof(CfClass, hTm) == 40 && offsetof(CfEnt, pos) == 8 && offsetof(CfEnt, cid) == 12 && offsetof(CfEnt, fc) == 16 && offsetof(CfEnt, fa) == 24 && sizeof(CfEnt) == 32 &&
                   sizeof(CfLog) == 32 && offsetof(CfLog, ofc) == 8,
               "classfit_asm.hpp: offsets of the LDS records");
@@ -371,7 +374,8 @@ typedef unsigned cf_u32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 template <int ROLE>  // 0 the decider, 1 a class wave, 2 the bookkeeper
-static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchState& st, const CfBuf& b, const unsigned lw, const unsigned long long t_start) {
+static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchState& st, const CfBuf& b, const unsigned lw, const unsigned rep, const unsigned nrep,
+                                                    const unsigned long long t_start) {
   constexpr bool is_decider = ROLE == 0, is_class_wave = ROLE == 1, is_books = ROLE == 2;
   const unsigned tid = threadIdx.x, lane = lane_id();
   CfCtl* ctl = b.ctl;
@@ -407,7 +411,7 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
   if (is_class_wave) {
     class_setup();
     for (unsigned ch = 0; ch < nch_wave; ++ch) cf_tighten(S, lane, ch, c);
-    cf_wave_tables(S, lw, lane, c, wk, n_kind);
+    if (rep == 0u && lw != 0u) cf_wave_tables(S, lw, lane, c, wk, n_kind);
   }
   // the decider's lanes
   CfOvLane o;
@@ -501,6 +505,7 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
     unsigned logn = 0;  // decider: placements of the batch so far
     unsigned long long todo = walkmask;  // decider: the walked jobs not decided yet; class waves: not answered yet
     unsigned cur_ord = 0;                // the walked ordinal (0, 1, ... over the batch's walked jobs) of the first job of todo
+    unsigned ph = 0;                     // class waves: cur_ord modulo the waves that share the set's jobs (wave `rep` of `nrep` answers the ordinals = rep)
     bool batch_done = nw == 0u;
     const unsigned long long tw0 = CF_TICKS();
     CF_PROF_T(cw0);
@@ -533,11 +538,12 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
 #if COOK_HAS_ASM_WALK
           {  // plain steps, one behind the other, as long as they are plain (classfit_asm.hpp); the step that is not is the C++ step's below
             st_pack();
+            CF_PROF_T(f0);
             while (todo != 0ull) {
               const unsigned fs = (unsigned)__ffsll(todo) - 1u;
 #define CF_U(x) wave_uniform_u32((unsigned)(x))
               cf_u32x8 SC = {CF_U(matched), CF_U(minfc_all), CF_U(b1m), CF_U(b1m >> 32), CF_U(minfm_all), 1u, 0u, 0u};
-              const cf_u32x8 AR = {CF_U(fs), CF_U((base + fs) << 12 | (gen & 15u) << 8), CF_U(a_board + (cur_ord & (CF_BOARD - 1u)) * 8u * (unsigned)sizeof(CfEnt)), CF_U(fs | cur_ord << 8),
+              const cf_u32x8 AR = {CF_U(fs), CF_U((base + fs) << 12 | (gen & 15u) << 8), CF_U(a_board + cf_slot(cur_ord) * 8u * (unsigned)sizeof(CfEnt)), CF_U(fs | cur_ord << 8),
                                    CF_U(a_log + logn * (unsigned)sizeof(CfLog)), CF_U(cmin), CF_U(mmin), a_board};
 #undef CF_U
               asm volatile(CF_ASM_DECIDER_STEP
@@ -546,14 +552,20 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
                            : "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",
                              "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",
                              "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "vcc", "scc", "memory");
+#ifdef CF_DELAY_D  // robustness study: a slow decider
+              __builtin_amdgcn_s_sleep(6);
+#endif
               const unsigned status = wave_uniform_u32(SC[5]);
               if (status == 1u) break;
               matched = wave_uniform_u32(SC[0]), minfc_all = wave_uniform_u32(SC[1]), minfm_all = wave_uniform_u32(SC[4]);
               b1m = wave_uniform_u64((unsigned long long)SC[3] << 32 | SC[2]);
               logn += status >> 1;
               todo &= todo - 1ull, ++cur_ord;
-              CF_PROF_ADD(3, 1);
+              CF_PROF_ADD(4, 1);
             }
+            CF_PROF_T(f1);
+            CF_PROF_ADD(5, f1 - f0);
+            WAIT_LDS();  // (the hand-placed step's LDS stores are not on the compiler's books: nothing of them is in flight behind this point)
             st_unpack();
           }
 #endif
@@ -570,7 +582,7 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
           const unsigned kind = meta & 255u;
           const unsigned want = (base + s) << 12 | (gen & 15u) << 8;
           // the candidates of the class waves into lanes 58..63 (every lane reads an entry: no branch on the lane)
-          const CfEnt* e = &S.board[(ord & (CF_BOARD - 1u)) * 8u + clw];
+          const CfEnt* e = &S.board[cf_slot(ord) * 8u + clw];
           const bool relevant = !isov && kind < 32u && ((my_kinds >> (kind & 31u)) & 1u);
           unsigned cpos, ccid, cfc, cfm;
           double cfa;
@@ -727,17 +739,28 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
             seen = cnt;
             todo = walkmask & ~cf_below(hw & 255u);
             cur_ord = hw >> 8;
+            ph = cur_ord;
+            while (ph >= nrep) ph -= nrep;
             CF_STAT(++st_rewinds);
+          }
+          while (todo != 0ull && ph != rep) {  // (the set's other waves answer these)
+            todo &= todo - 1ull, ++cur_ord;
+            ph = ph + 1u == nrep ? 0u : ph + 1u;
           }
           if (todo != 0ull && wk != 0u && cur_ord < (hw >> 8) + CF_BOARD) {
             const unsigned s = (unsigned)__ffsll(todo) - 1u;
             const unsigned ord = cur_ord;
             todo &= todo - 1ull, ++cur_ord;
+            ph = ph + 1u == nrep ? 0u : ph + 1u;
             const unsigned Jc = (unsigned)wave_read_lane((int)jc, (int)s), Jm = (unsigned)wave_read_lane((int)jm, (int)s), meta = (unsigned)wave_read_lane((int)jmeta, (int)s);
             const unsigned kind = meta & 255u;
             if (!(kind < 32u && ((wk >> kind) & 1u))) continue;  // (none of our classes: the decider does not ask)
             CF_PROF_T(q1);
-            CfEnt* e = &S.board[(ord & (CF_BOARD - 1u)) * 8u + lw];
+#ifdef CF_DELAY_C  // robustness study: slow class waves (every third answer of a wave very slow)
+            __builtin_amdgcn_s_sleep(4);
+            if ((ord + rep) % 3u == 0u) __builtin_amdgcn_s_sleep(40);
+#endif
+            CfEnt* e = &S.board[cf_slot(ord) * 8u + lw];
             const unsigned tag = (base + s) << 12 | (gen & 15u) << 8 | (seen & 255u);
             bool done = false;
             if ((meta >> 12) == 0u && one_cls != 0xFFFFFFFFu) {
@@ -803,6 +826,7 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
       }
       // ================================================= a collective turn: every wave =================================================
       EMU_SITE("classfit: collective");
+      WAIT_LDS();  // (stores issued by inline asm — st_lane0 / st_mask, the plain step — have landed before the barrier lets the other waves read)
       __syncthreads();
       md = wave_uniform_u32(md);  // (every wave left its loop with the mode word the decider raised)
       bool epoch = md == CFM_EPOCH;
@@ -815,7 +839,7 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
           const CfJobU J = job_of(s);
           cf_overlay_query_exact(S, J, lane, o, fmax, cf_pow2(-(int)wave_uniform_u32(S.envw[CFE_KC])), cf_pow2(-(int)wave_uniform_u32(S.envw[CFE_KM])), mine);
           if (lane == 0) S.post2[0] = mine;
-        } else if (is_class_wave) {
+        } else if (is_class_wave && rep == 0u && lw != 0u) {
           const CfJobU J = job_of(s);
           cf_class_query_exact(S, J, lane, c, fmax, cf_pow2(-(int)wave_uniform_u32(S.envw[CFE_KC])), cf_pow2(-(int)wave_uniform_u32(S.envw[CFE_KM])), mine, st_scans);
           if (lane == 0) S.post2[lw] = mine;
@@ -824,7 +848,9 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
         __syncthreads();
         if (is_decider) {
           const CfJobU J = job_of(s);
-          const CfVerdict v = cf_verdict_exact(S.post2, lane);
+          unsigned used_sets = 0;
+          for (unsigned ci = 0; ci < n_cls; ++ci) used_sets |= 1u << wave_uniform_u32(S.cls[ci].wave);
+          const CfVerdict v = cf_verdict_exact(S.post2, lane, used_sets);
           // (an exact turn is raised because candidates exist: v.src >= 0)
           const unsigned nfc = v.fc - J.c, nfm = v.fm - J.m;
           const bool dead = nfc < cmin || nfm < mmin;
@@ -902,7 +928,7 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
         EMU_SITE("classfit: epoch 1");
         __syncthreads();
         // (2) members kept / inserted per class
-        if (is_class_wave) {
+        if (is_class_wave && rep == 0u) {
           unsigned mykept = 0;
           for (unsigned ch = 0; ch < nch_wave; ++ch) {
             const unsigned pos0 = (unsigned)wave_read_lane((int)c.pos0, (int)ch), n = (unsigned)wave_read_lane((int)c.n, (int)ch);
@@ -919,8 +945,8 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
           for (unsigned ci = 0; ci < n_cls; ++ci) S.ckept[2 * CF_MAXCLS + ci] = off, off += S.ckept[ci] + S.ckept[CF_MAXCLS + ci];
         }
         __syncthreads();
-        // (3) every class wave merges its classes into the scratch arrays: kept members keep their order, the list's entries go between them
-        if (is_class_wave) {
+        // (3) the first wave of every set merges the set's classes into the scratch arrays: kept members keep their order, the list's entries go between them
+        if (is_class_wave && rep == 0u) {
           unsigned li = 0;  // first list entry of the class being merged
           for (unsigned ci = 0; ci < n_cls; ++ci) {
             const unsigned ni = wave_uniform_u32(S.ckept[CF_MAXCLS + ci]);
@@ -998,7 +1024,7 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
           cf_setup_chunks(S.cls, n_cls, lw, lane, c, nch_wave);
           class_setup();
           for (unsigned ch = 0; ch < nch_wave; ++ch) cf_tighten(S, lane, ch, c);
-          cf_wave_tables(S, lw, lane, c, wk, n_kind);
+          if (rep == 0u && lw != 0u) cf_wave_tables(S, lw, lane, c, wk, n_kind);
           tight_applied = st_tight;
         }
         if (tid == 0) S.misc[CFX_LOG_APPLIED] = S.misc[CFX_LOGN];
@@ -1007,7 +1033,11 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
       if (md == CFM_BATCH_END) batch_done = true;
       if (md != CFM_BATCH_END) {  // every answer on the board is void: a new generation; the class waves go on behind the step of the turn
         ++gen;
-        if (is_class_wave) todo = walkmask & ~cf_below(s) & ~(1ull << s), cur_ord = (unsigned)__popcll(walkmask & cf_below(s)) + 1u;
+        if (is_class_wave) {
+          todo = walkmask & ~cf_below(s) & ~(1ull << s), cur_ord = (unsigned)__popcll(walkmask & cf_below(s)) + 1u;
+          ph = cur_ord;
+          while (ph >= nrep) ph -= nrep;
+        }
       }
       if (tid == 0) st_wg(&S.ctrl[0], 0u);
       EMU_SITE("classfit: collective done");
@@ -1059,7 +1089,7 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
             dirty = true;
           }
         }
-        if (dirty) cf_wave_tables(S, lw, lane, c, wk, n_kind);
+        if (dirty && rep == 0u && lw != 0u) cf_wave_tables(S, lw, lane, c, wk, n_kind);
         tight_applied = st_tight;
       }
     }
@@ -1121,7 +1151,7 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
   if (is_class_wave && lane == 0) atomicAdd(&ctl->stats[CFS_SCANS], st_scans), atomicAdd(&ctl->stats[CFS_TIGHTEN], st_tight), atomicAdd(&ctl->stats[CFS_REWINDS], st_rewinds);
   if (is_books && lane == 0) ctl->stats[CFS_TICKS_PRECHECK] = (uint32_t)tk_books, ctl->stats[CFS_FLIPS] = st_flips, ctl->stats[CFS_HWID_BOOKS] = cook_hw_id();
 #ifdef CF_PROF
-  if (lane == 0 && (is_decider || (is_class_wave && lw <= 2u)))
+  if (lane == 0 && (is_decider || (is_class_wave && lw >= 1u && lw <= 2u && rep == 0u)))
     for (int i = 0; i < 8; ++i) ctl->stats[24 + 8 * (is_decider ? 0u : lw) + i] = (uint32_t)(prof[i] >> 4);  // units of 16 cycles
 #endif
 #undef n_cls
@@ -1180,6 +1210,10 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
       return;
     }
   }
+#ifdef CF_DIAG_CLEAR_LDS
+  for (unsigned x = tid; x < CF_LDS_BYTES / 4u; x += CF_THREADS) ((uint32_t*)lds)[x] = 0u;
+  __syncthreads();
+#endif
   // ---- prologue: class arrays, byte table, group table
   for (unsigned q = tid; q < NP; q += CF_THREADS) {
     S.fcm[q] = q < M ? CfFree{b.pos_fc[q], b.pos_fm[q]} : CfFree{0u, 0u}, S.cid[q] = q < M ? (uint16_t)b.pos_cid[q] : (uint16_t)0u;
@@ -1222,9 +1256,52 @@ static __device__ __forceinline__ void cf_walk_pool(char* lds, const MatchIn* __
   for (unsigned x = tid; x < 8u; x += CF_THREADS) S.ctrl[x] = 0u;
   for (unsigned x = tid; x < CF_MAXKIND * CF_LV; x += CF_THREADS) S.gk[x] = 0u;
   for (unsigned x = tid; x < (unsigned)CF_LV; x += CF_THREADS) S.ovt[x] = 0u;
-  for (unsigned x = tid; x < CF_BOARD * 8u; x += CF_THREADS) S.board[x].tag = 0xFFFFFFFFu;
+  for (unsigned x = tid; x < CF_SLOTS * 8u; x += CF_THREADS) S.board[x].tag = 0xFFFFFFFFu;
   __syncthreads();
-  if (w == 0u) cf_walk_role<0>(S, st, b, 0u, t_start);
-  else if (w == CFW_BOOKS) cf_walk_role<2>(S, st, b, 0u, t_start);
-  else cf_walk_role<1>(S, st, b, w < CFW_BOOKS ? w : w - 1u, t_start);
+  if (w == 0u) {
+    cf_walk_role<0>(S, st, b, 0u, 0u, 1u, t_start);
+  } else if (w == CFW_BOOKS) {
+    cf_walk_role<2>(S, st, b, 0u, 0u, 1u, t_start);
+  } else {
+    // the class waves: every set of classes (cf_prepare: CfClass::wave = 1..CF_CW) gets a wave; the waves left over go, one after the other, to the sets
+    // of hosts without gpus (every job asks them), else to all: the waves of a set take its jobs in turn
+    const unsigned p = w < CFW_BOOKS ? w - 1u : w - 2u, np = (unsigned)CF_WAVES - 2u;
+    unsigned used = 0, zsets = 0;
+    for (unsigned ci = 0; ci < ctl->n_cls; ++ci) {
+      const unsigned g = S.cls[ci].wave;
+      used |= 1u << g;
+      if (S.cls[ci].kind == 0u) zsets |= 1u << g;
+    }
+    used = wave_uniform_u32(used), zsets = wave_uniform_u32(zsets);
+    unsigned myset = 0, rep = 0, nrep = 0, k = 0;
+    for (unsigned pass = 0; pass < np && k < np; ++pass) {
+      const unsigned from = pass == 0u ? used : (zsets ? zsets : used);
+      if (from == 0u) break;
+      for (unsigned g = 1; g <= (unsigned)CF_CW && k < np; ++g)
+        if ((from >> g) & 1u) {
+          if (k == p) myset = g;
+          ++k;
+        }
+    }
+    k = 0;
+    for (unsigned pass = 0; pass < np && k < np; ++pass) {
+      const unsigned from = pass == 0u ? used : (zsets ? zsets : used);
+      if (from == 0u) break;
+      for (unsigned g = 1; g <= (unsigned)CF_CW && k < np; ++g)
+        if ((from >> g) & 1u) {
+          if (g == myset) {
+            if (k < p) ++rep;
+            ++nrep;
+          }
+          ++k;
+        }
+    }
+    if (nrep == 0u) nrep = 1u;
+    {  // the waves of a set: a divisor of CF_SLOTS (a wave beyond it idles)
+      const unsigned cap = nrep >= 12u ? 12u : nrep >= 6u ? 6u : nrep == 5u ? 4u : nrep;
+      if (rep >= cap) myset = 0u, rep = 0u, nrep = 1u;
+      else nrep = cap;
+    }
+    cf_walk_role<1>(S, st, b, wave_uniform_u32(myset), wave_uniform_u32(rep), wave_uniform_u32(nrep), t_start);
+  }
 }

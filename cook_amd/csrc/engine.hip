@@ -1394,7 +1394,7 @@ void cf_run(cook_engine* lead, cook_engine* const* es, unsigned n, hipStream_t s
 #ifdef CF_PROF
     {
       const uint32_t* q = x->cf_stats;
-      std::fprintf(stderr, "CFPROF (x16 shader cycles) decider: candidates %u evaluation %u commit %u steps %u walk-total %u | class wave 1: poll %u answer %u publish %u answers %u idle %u idles %u | class wave 2: poll %u answer %u publish %u answers %u idle %u idles %u | walk ticks(100MHz) %u\n", q[24], q[25], q[26], q[27], q[31], q[32], q[33], q[34], q[35], q[36], q[37], q[40], q[41], q[42], q[43], q[44], q[45], q[CFS_TICKS_WALK]);
+      std::fprintf(stderr, "CFPROF (x16 shader cycles) decider: slow steps %u (candidates %u evaluation %u commit %u) plain steps %u in %u walk-total %u | class wave 1: poll %u answer %u answers %u idle %u idles %u | class wave 2: poll %u answer %u answers %u idle %u idles %u | walk ticks(100MHz) %u\n", q[27], q[24], q[25], q[26], q[28], q[29], q[31], q[32], q[33], q[35], q[36], q[37], q[40], q[41], q[43], q[44], q[45], q[CFS_TICKS_WALK]);
     }
 #endif
     WinCtl c{};
