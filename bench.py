@@ -189,15 +189,67 @@ def extra_c5(device, check=True, steps=3, sizes=(1_000_000, 500_000, 10_000, 50_
     out["parity_checked"] = False
     if check:
         from oracle import pyoracle
+        c0 = time.perf_counter()
         o_ranked, o_dru = pyoracle.rank(params, pool.tasks, pool.users)
+        c1 = time.perf_counter()
         assert np.array_equal(ranked, o_ranked) and np.array_equal(dru, o_dru, equal_nan=True), "PARITY: C5 rank differs from the oracle"
+        c2 = time.perf_counter()
         want = pyoracle.rebalance(params, running, pending, t.job_id[head], t.priority[head], pool.users, spare, rp)
+        c3 = time.perf_counter()
+        out["cpu_baseline"] = {"rank_s": c1 - c0, "sweep_s": c3 - c2, "cycle_s": (c1 - c0) + (c3 - c2), "cores": 1, "kind": "port",
+                               "sample": "the oracle's rank and sweep on the same inputs, whole calls, one thread"}
+        out["speedup_vs_cpu_baseline"] = {"rank": (c1 - c0) * 1e3 / out["rank"]["ms"] if isinstance(out.get("rank"), dict) and out["rank"].get("ms") else None,
+                                          "sweep": (c3 - c2) * 1e3 / out["sweep"]["ms"], "total": ((c1 - c0) + (c3 - c2)) * 1e3 / out["ms_total"]}
         assert len(want["decisions"]) == len(got["decisions"]), "PARITY: C5 decisions differ from the oracle"
         for a, b in zip(got["decisions"], want["decisions"]):
             assert a == b, f"PARITY: C5 decision differs from the oracle: {a} / {b}"  # host, dru, resources (fp64 ==), preempted tasks
         assert np.array_equal(got["pending_dru"], want["pending_dru"], equal_nan=True), "PARITY: C5 pending DRUs differ from the oracle"
         out["parity_checked"] = True
     return out
+
+
+def host_core_budget():
+    """-> (cores this process may really use at once, logical CPUs, note): the affinity mask, cut to a container's CPU quota (the GPU boxes of this
+    pool: 256 logical CPUs, quota 16)."""
+    host_cores = os.cpu_count() or 1
+    try:
+        host_cores = min(host_cores, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    logical_cpus, quota_note = host_cores, None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+            if quota < host_cores:
+                host_cores, quota_note = quota, f"cgroup cpu.max {q} {per} = {quota} CPUs of {logical_cpus} logical"
+    except (OSError, ValueError):
+        pass
+    return host_cores, logical_cpus, quota_note
+
+
+def cpu_leg_pools(params_x, cluster, pools, my_pools, K_x, nt):
+    """The oracle's whole cycle (rank -> gather -> placement; one library call per pool, the pools side by side on threads of their own) for an
+    extra operating point of the line.  -> {cycle_s, rank_s, match_s (slowest pool's), cores, sample}"""
+    import threading
+    from oracle import pyoracle
+    quota = {p: cluster.quota_inputs(p, cluster.last_pool_usage[p], cluster.last_group_usage) for p in my_pools}
+    out = {}
+
+    def one(p):
+        out[p] = pyoracle.cycle(params_x, pools[p].tasks, pools[p].users, pools[p].pending_jobs, pools[p].offers, pools[p].groups, quota=quota[p], K=K_x, nthreads=nt)
+
+    ths = [threading.Thread(target=one, args=(p,)) for p in my_pools]
+    a = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    wall = time.perf_counter() - a
+    assert len(out) == len(my_pools), "an oracle thread failed"
+    return {"cycle_s": wall, "rank_s": max(o[2]["rank"] for o in out.values()), "match_s": max(o[2]["match"] for o in out.values()),
+            "cores": len(my_pools) * nt, "kind": "port",
+            "sample": f"the whole cycle (not a sample) of the {len(my_pools)} pools at once, {nt} evaluator thread(s) per pool, one library call per pool thread"}
 
 
 def cpu_baseline_leg(args, params, cluster, pools, my_pools, K, n_off):
@@ -212,20 +264,7 @@ def cpu_baseline_leg(args, params, cluster, pools, my_pools, K, n_off):
     it; the call's own clocks (rank / gather / match seconds per pool) are reported next to the wall time."""
     import threading
     from oracle import pyoracle
-    host_cores = os.cpu_count() or 1
-    try:
-        host_cores = min(host_cores, len(os.sched_getaffinity(0)))
-    except (AttributeError, OSError):
-        pass
-    logical_cpus, quota_note = host_cores, None
-    try:  # a container's CPU quota: the cores the process may really use at once (the GPU boxes of this pool: 256 logical CPUs, quota 16)
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            quota = max(1, int(float(q) / float(per)))
-            if quota < host_cores:
-                host_cores, quota_note = quota, f"cgroup cpu.max {q} {per} = {quota} CPUs of {logical_cpus} logical"
-    except (OSError, ValueError):
-        pass
+    host_cores, logical_cpus, quota_note = host_core_budget()
     P = len(my_pools)
     quota = {p: cluster.quota_inputs(p, cluster.last_pool_usage[p], cluster.last_group_usage) for p in my_pools}
     threaded_ok = args.good_enough >= 1.0  # (the oracle's host-bucketed form is best fit only)
@@ -578,12 +617,28 @@ def main():
         extra["K=1000"] = {"what": f"the same {P}-pool cluster, 1000 considerable jobs per pool (config.clj:113)", "cycles": len(ts),
                            "p50_cycle_us": pct(ts, 0.5) * 1e6, "p95_cycle_us": pct(ts, 0.95) * 1e6,
                            "stage_ms_pool0": dict(zip(("rank", "match"), engines[my_pools[0]].last_timing()))}
+        hc, _, _ = host_core_budget()
+        nt_small = max(1, min(hc // max(1, P), 4))
+
+        def with_cpu(row, gpu_s, leg):  # a CPU figure beside every operating point of the line (north_star: "next to the reference timed on the box's own host cores")
+            if leg is not None:
+                row["cpu_baseline"] = leg
+                row["speedup_vs_cpu_baseline"] = leg["cycle_s"] / gpu_s
+            return row
+
+        no_cpu = args.no_cpu_baseline
+        with_cpu(extra["K=1000"], pct(ts, 0.5), None if no_cpu else cpu_leg_pools(params, cluster, pools, my_pools, 1000, 1))
         ts = timed(lambda: cluster.cycle(100_000), 4)
         extra["K=1e5"] = {"what": f"the same cluster, 100000 considerable jobs per pool", "cycles": len(ts), "p50_cycle_ms": pct(ts, 0.5) * 1e3,
                           "p95_cycle_ms": pct(ts, 0.95) * 1e3}
+        with_cpu(extra["K=1e5"], pct(ts, 0.5), None if no_cpu else cpu_leg_pools(params, cluster, pools, my_pools, 100_000, nt_small))
         p08 = A.default_params(good_enough_fitness=0.8, match_algo=args.match_algo)
         for e in engines.values():
             e.set_params(p08)
+        ts = timed(lambda: cluster.cycle(1000), 40, warm=3)
+        extra["K=1000, good_enough=0.8"] = with_cpu({"what": f"the same cluster at the reference's shipped defaults (config.clj:110-116): 1000 considerable jobs per pool, good-enough-fitness 0.8",
+                                                     "cycles": len(ts), "p50_cycle_us": pct(ts, 0.5) * 1e6, "p95_cycle_us": pct(ts, 0.95) * 1e6}, pct(ts, 0.5),
+                                                    None if no_cpu else cpu_leg_pools(p08, cluster, pools, my_pools, 1000, 1))
         ts = timed(lambda: cluster.cycle(K), 3)
         f08 = {p: engines[p].cycle_fetch() for p in my_pools}
         m08 = sum(int((f08[p][1] >= 0).sum()) for p in my_pools)
@@ -591,6 +646,8 @@ def main():
                                             "the winner among equally good-enough hosts is oracle-defined: first in offer order)",
                                     "cycles": len(ts), "p50_cycle_ms": pct(ts, 0.5) * 1e3, "matched": m08, "parity_checked": False,
                                     "placement_stats_pool0": engines[my_pools[0]].match_stats()}
+        # (good-enough < 1: the oracle's placement is its single-thread form — the first offer in array order above the threshold, an oracle-defined rule)
+        with_cpu(extra["good_enough=0.8"], pct(ts, 0.5), None if no_cpu else cpu_leg_pools(p08, cluster, pools, my_pools, K, 1))
         if not args.no_check:  # the timed 0.8 cycle of rank 0's first pool against the single-thread oracle, every assignment
             from oracle import checks
             pc = my_pools[0]
@@ -613,6 +670,25 @@ def main():
                                "cycles": len(ts), "p50_cycle_ms": pct(ts, 0.5) * 1e3, "matched": int((j2o_x >= 0).sum()),
                                "pair_evaluations": int(len(j2o_x)) * kw["n_offers"],
                                "stage_ms": dict(zip(("rank", "match"), ex.last_timing())), "placement_stats": ex.match_stats()}
+                # the class-ordered best fit (match_algo 3) on the same pool, where the call is eligible (C3's 20 000 offers are not)
+                ex.set_params(A.default_params(good_enough_fitness=args.good_enough, match_algo=3))
+                ts3 = timed(lambda: ex.cycle_run(pool_x.n_pending), 3)
+                _, j2o_3, _ = ex.cycle_fetch()
+                st3 = ex.match_stats()
+                assert np.array_equal(j2o_3, j2o_x), f"PARITY: {name}: class-ordered best fit differs from the window rounds"
+                extra[name]["classfit"] = {"p50_cycle_ms": pct(ts3, 0.5) * 1e3, "placed_by_classfit": st3.get("placement_form") == 3, "refused_bits": st3.get("classfit_refused"),
+                                           "identical_to_window_rounds": True}
+            if not no_cpu:
+                from oracle import pyoracle
+                nt_x = max(1, min(hc, 16))
+                a = time.perf_counter()
+                o_r, o_j, o_ph = pyoracle.cycle(params, pool_x.tasks, pool_x.users, pool_x.pending_jobs, pool_x.offers, pool_x.groups, K=pool_x.n_pending, nthreads=nt_x)
+                cpu_s = time.perf_counter() - a
+                if not args.no_check:
+                    assert np.array_equal(o_j, j2o_x), f"PARITY: {name}: assignments differ from the oracle"
+                    extra[name]["parity_checked"] = True
+                with_cpu(extra[name], pct(ts, 0.5), {"cycle_s": cpu_s, "rank_s": o_ph["rank"], "match_s": o_ph["match"], "cores": nt_x, "kind": "port",
+                                                     "sample": f"the whole cycle (not a sample), one library call, {nt_x} evaluator threads"})
             del pool_x
         try:
             extra["C5"] = extra_c5(dev_index, check=not args.no_check)
@@ -620,6 +696,22 @@ def main():
             raise  # a parity failure must not produce a bench line
         except Exception as ex:  # (an extra must never cost the headline its line)
             extra["C5"] = {"error": repr(ex)}
+        # ---- the class-ordered best fit (match_algo 3) on the headline cluster: one launch, a workgroup per pool, no evaluation launches
+        p3 = A.default_params(good_enough_fitness=args.good_enough, match_algo=3)
+        for e in engines.values():
+            e.set_params(p3)
+        ts = timed(lambda: cluster.cycle(K), 3)
+        f3 = {p: engines[p].cycle_fetch() for p in my_pools}
+        st3 = engines[my_pools[0]].match_stats()
+        same = all(np.array_equal(f3[p][1], fetched[p][1]) for p in my_pools)
+        assert same, "PARITY: class-ordered best fit differs from the timed cycle's assignments"
+        extra["classfit"] = {"what": f"the same cluster and K = {K}, cook_params.match_algo = 3 (class-ordered best fit)", "cycles": len(ts), "p50_cycle_ms": pct(ts, 0.5) * 1e3,
+                             "placed_by_classfit_pool0": st3.get("placement_form") == 3, "identical_to_timed_cycle": True,
+                             "stage_ms_pool0": dict(zip(("rank", "match"), engines[my_pools[0]].last_timing())), "placement_stats_pool0": st3}
+        ts = timed(lambda: cluster.cycle(1000), 40, warm=3)
+        extra["classfit"]["K=1000"] = {"p50_cycle_us": pct(ts, 0.5) * 1e6, "p95_cycle_us": pct(ts, 0.95) * 1e6}
+        for e in engines.values():
+            e.set_params(params)
 
     # ---- the boundary, not just the core (never `value`): what a cycle costs when the host hands over what CHANGED since the last
     #      one and takes the assignments back.  cook_cycle_update per pool (1 % of the tasks leave, as many arrive — half of them new

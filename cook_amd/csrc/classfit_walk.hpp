@@ -36,7 +36,10 @@
 #define CF_PROF_ADD(i, d) ((void)0)
 #endif
 
-constexpr unsigned CF_BOARD = 4;    // steps the class waves may run ahead of the decider
+#ifndef CF_AHEAD
+#define CF_AHEAD 4
+#endif
+constexpr unsigned CF_BOARD = CF_AHEAD;  // steps the class waves may run ahead of the decider (at most CF_SLOTS - 2)
 constexpr unsigned CF_SLOTS = 12;   // entries per column of the board: walked ordinal modulo 12.  The waves that share a set's jobs take the ordinals in turn and
                                     // their number divides 12, so a slot has ONE writer: a late answer of a slow wave lands where only that wave's next one goes
 static __device__ __forceinline__ unsigned cf_slot(unsigned ord) { return ord - CF_SLOTS * ((ord * 43u) >> 9); }  // ord % 12 for ord < 64

@@ -1312,8 +1312,12 @@ static void launch_round(cook_engine* e, const MatchIn& in, const MatchState& st
 }
 
 // ---- class-ordered best fit (classfit.hpp): set-up, eligibility, launch --------------------------------------------------------------------
-// COOK_CLASSFIT=0: every match goes through the window rounds (A/B switch)
-static const bool g_classfit = env_switch_on_unless_zero("COOK_CLASSFIT");
+// match_algo 3 asks for the class-ordered best fit; COOK_CLASSFIT=1 makes it the default form (match_algo 0) too — measured on MI355X (profiles/r06*): ahead of the
+// window rounds on BASELINE's C2 (30.7 against 31.6 ms), behind on a C4 pool (48.1 against 38.7 ms), so the default stays with the window rounds
+static const bool g_classfit_default = [] {
+  const char* v = std::getenv("COOK_CLASSFIT");
+  return v && v[0] == '1';
+}();
 static size_t cf_lds_bytes_host(unsigned NP, unsigned M, bool eq, unsigned G, unsigned S) {  // the layout of cf_walk_pool (classfit_walk.hpp)
   size_t n = sizeof(CfFixed) + (size_t)NP * 10u;
   n = (n + 7u) & ~(size_t)7u;
@@ -1326,7 +1330,7 @@ bool cf_setup(cook_engine* e, const MatchIn& in, const MatchIn* in_dev, const Ma
               CfPoolCtx& ctx) {
   const unsigned K = in.K, M = in.M, G = in.G;
   e->cf_inelig = 0x10000u;
-  if (!g_classfit || K == 0 || M == 0 || M > CF_SORT_N || G > CF_MAXG || in.good_enough < 1.0 || in.has_x || in.reserved_bits || in.host_dup) return false;
+  if (K == 0 || M == 0 || M > CF_SORT_N || G > CF_MAXG || in.good_enough < 1.0 || in.has_x || in.reserved_bits || in.host_dup) return false;
   if (e->cf_max_host == 0xFFFFFFFFu || (size_t)e->cf_max_host > 8u * (size_t)M + 65536u) return false;
   CfBuf b{};
   b.ctl = e->cf_ctl.ensure(1);
@@ -1435,7 +1439,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
   e->has_deferred = false;
   const int algo = e->params.match_algo;
   if (!(algo == 0 || algo == 1 || algo == 2 || algo == 3))
-    e->fail(COOK_E_INVALID, "cook_params.match_algo: 0 = class-ordered best fit where the call allows it, else window rounds; 1 = serial sweep; 2 = window rounds; 3 = as 0");
+    e->fail(COOK_E_INVALID, "cook_params.match_algo: 0 = engine default (window rounds), 1 = serial sweep, 2 = window rounds, 3 = class-ordered best fit where the call allows it, else window rounds");
   if (defer && !(algo != 1 && K > 0)) defer = false;  // only the window rounds run several pools in one launch
   const bool ge = in.good_enough < 1.0;
   if (algo == 1) {  // one-job-at-a-time sweep by a single workgroup (reference implementation of the chain)
@@ -1490,7 +1494,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     if (M) KM<match_init_alive, 256>(e, "match_init_alive", div_up(M, 256), (const OfferA*)oa, M, st.jmin, st.alive);
     e->last_form = 0;
     e->has_deferred_cf = false;
-    if (algo == 0 || algo == 3) {  // class-ordered best fit when the call's numbers and constraints allow it (classfit.hpp)
+    if (algo == 3 || (algo == 0 && g_classfit_default)) {  // class-ordered best fit when the call's numbers and constraints allow it (classfit.hpp)
       if (cf_setup(e, in, (const MatchIn*)vb.in_dev, st, jr, jcons, oa, ob, e->deferred_cf)) {
         e->cycle_considered = K;
         e->match_done = false;

@@ -57,8 +57,9 @@ typedef struct cook_params {
   double good_enough_fitness;  /* config.clj:111 default 0.8; (> fitness x) at scheduler.clj:2312-2314; >=1 = off */
   int64_t host_lifetime_mins;  /* estimated-completion-config :host-lifetime-mins (constraints.clj:392-397)     */
   int32_t match_algo;          /* 0 = engine default (= 2), 1 serial sweep (one workgroup, one job at a time: the reference form of the
-                                  chain), 2 window rounds (eval / merge / resolve launches).  Other values: COOK_E_INVALID.
-                                  Identical results */
+                                  chain), 2 window rounds (eval / merge / resolve launches), 3 class-ordered best fit (one workgroup per pool,
+                                  no evaluation launches) where the call's numbers and constraints allow it, else as 2.
+                                  Other values: COOK_E_INVALID.  Identical results */
   int32_t reserved;
 } cook_params;
 

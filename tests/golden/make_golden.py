@@ -749,9 +749,38 @@ K8S_OFFERS = [
 ]
 
 
+
+# ---- why-unscheduled: the reducer of Fenzo's per-host results (fenzo_utils.clj:33-55), the reference's own six cases --------------------------------
+# test/cook/test/scheduler/fenzo_utils.clj:56-100 (test-summarize-placement-failures).  A host's result = (constraint that failed or null, resources
+# that failed); the test's failures carry the resource's name as their message (its helper at :36-45), which is what the reducer counts by.
+# "engine": the same hosts as inputs of a real placement where Fenzo can produce them — it evaluates hard constraints only on a host whose resources fit
+# (AssignableVirtualMachine.tryRequest), so a host that fails a constraint AND resources exists in the reducer's unit test only; the named resources
+# are named scalars (their failure's message is the name, fenzo_utils.clj:21-45; at most COOK_MAX_SCALARS = 3 per call), "other_constraint" (not a
+# constraint Cook has) stands for user_defined_constraint in the engine form.
+_EX = "scheduler/test/cook/test/scheduler/fenzo_utils.clj"
+EXPLAIN = [
+    dict(name="empty accumulator, a host that takes the job", ref=f"{_EX}:58-59", results=[[None, []]], expect={},
+         engine=dict(hosts=[dict()], scalars=[])),
+    dict(name="one host short of ports", ref=f"{_EX}:61-64", results=[[None, ["ports"]]], expect={":resources": {"ports": 1}},
+         engine=dict(hosts=[dict(lack=["ports"])], scalars=["ports"])),
+    dict(name="one host the job ran on", ref=f"{_EX}:66-69", results=[["novel_host_constraint", []]], expect={":constraints": {"novel_host_constraint": 1}},
+         engine=dict(hosts=[dict(constraint="novel_host_constraint")], scalars=[])),
+    dict(name="a constraint and two resources on one host", ref=f"{_EX}:71-76", results=[["novel_host_constraint", ["cpus", "mem"]]],
+         expect={":constraints": {"novel_host_constraint": 1}, ":resources": {"cpus": 1, "mem": 1}}),
+    dict(name="six hosts reduced", ref=f"{_EX}:78-96",
+         results=[["novel_host_constraint", []], ["other_constraint", ["cpus", "mem"]], [None, ["cpus"]], [None, ["gpus"]], [None, ["ports", "disk"]],
+                  ["novel_host_constraint", ["mem", "cpus", "ports"]]],
+         expect={":constraints": {"novel_host_constraint": 2, "other_constraint": 1}, ":resources": {"cpus": 3, "gpus": 1, "mem": 2, "ports": 2, "disk": 1}}),
+    dict(name="the six hosts' separable results as a placement", ref=f"{_EX}:78-96 (hosts 1, 3, 4, 5 and a host failing other_constraint alone)",
+         results=[["novel_host_constraint", []], ["other_constraint", []], [None, ["cpus"]], [None, ["gpus"]], [None, ["ports", "gpus"]]],
+         expect={":constraints": {"novel_host_constraint": 1, "other_constraint": 1}, ":resources": {"cpus": 1, "gpus": 2, "ports": 1}},
+         engine=dict(hosts=[dict(constraint="novel_host_constraint"), dict(constraint="other_constraint"), dict(lack=["cpus"]), dict(lack=["gpus"]), dict(lack=["ports", "gpus"])],
+                     scalars=["cpus", "gpus", "ports"])),
+]
+
 def main():
     out = dict(rank=RANK, rank_group=RANK_GROUP, quota_group_agg=QUOTA_GROUP_AGG, match=MATCH + CONSTRAINTS + GROUPS_FENZO + HRO, rebalance=REBALANCE, considerable=CONSIDERABLE,
-               offers=dict(consumption=K8S_CONSUMPTION, capacity=K8S_CAPACITY, schedulable=K8S_SCHEDULABLE, generate=K8S_OFFERS))
+               offers=dict(consumption=K8S_CONSUMPTION, capacity=K8S_CAPACITY, schedulable=K8S_SCHEDULABLE, generate=K8S_OFFERS), explain=EXPLAIN)
     for k, v in out.items():
         with open(os.path.join(HERE, f"{k}.json"), "w") as f:
             json.dump(v, f, indent=1, sort_keys=True)

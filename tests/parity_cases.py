@@ -1339,3 +1339,66 @@ def metrics_known_answers(make_engine):
             m = e.match_metrics()
         for k, v in want.items():
             assert m["jobs"][k] == v, (cpus, k, m["jobs"][k], v)
+
+
+# ---- the reference's own cases of the why-unscheduled reducer (tests/golden/explain.json <- test/cook/test/scheduler/fenzo_utils.clj:56-100) -------------
+_WHY_SLOT_OF = {name: slot for slot, (_, name) in A.WHY_NAMES.items()}
+
+
+def _explain_expect(case):
+    """the case's expected map with "other_constraint" (no constraint of Cook's) renamed to the one that stands for it"""
+    out = {k: dict(v) for k, v in case["expect"].items()}
+    if "other_constraint" in out.get(":constraints", {}):
+        out[":constraints"]["user_defined_constraint"] = out[":constraints"].pop("other_constraint")
+    return out
+
+
+def explain_golden_reduce(case):
+    """the reducer itself: every host's result counted into the COOK_WHY_* row the engine fills, the row turned into the reference's map"""
+    names = []
+    for _, lack in case["results"]:
+        for r in lack:
+            if r not in ("cpus", "mem") and r not in names:
+                names.append(r)
+    assert len(names) <= 3
+    row = np.zeros(A.WHY_SLOTS, np.uint32)
+    for cons, lack in case["results"]:
+        for r in lack:
+            row[{"cpus": 0, "mem": 1}.get(r, A.WHY_SCALAR0 + (names.index(r) if r in names else 0))] += 1
+        if cons:
+            row[_WHY_SLOT_OF["user_defined_constraint" if cons == "other_constraint" else cons]] += 1
+    assert A.why_summary(row, scalar_names=tuple(names)) == _explain_expect(case), case["ref"]
+
+
+def explain_golden_inputs(case):
+    """the case's hosts as a placement's inputs: one job, a host per result (see tests/golden/make_golden.py EXPLAIN) -> (jobs, offers, scalar names)"""
+    eng = case["engine"]
+    hosts, names = eng["hosts"], list(eng["scalars"])
+    H = len(hosts)
+    novel = [h for h, d in enumerate(hosts) if d.get("constraint") == "novel_host_constraint"]
+    other = [h for h, d in enumerate(hosts) if d.get("constraint") == "other_constraint"]
+    kw = {}
+    if names:
+        kw["scalars"] = np.ones((1, len(names)))
+    jobs = A.Jobs.with_constraints(np.array([1.0]), np.array([100.0]), equals=[[(0, 1)] if other else []], novel=[novel], **kw)
+    attr = np.ones((H, 1), np.uint32)
+    attr[other, 0] = 2
+    okw = dict(attr=attr) if other else {}
+    if names:
+        sc = np.full((H, len(names)), 5.0)
+        for h, d in enumerate(hosts):
+            for r in d.get("lack", []):
+                sc[h, names.index(r)] = 0.0
+        okw["scalars"] = sc
+    offers = A.Offers(cpus=np.full(H, 4.0), mem=np.full(H, 1000.0), host=np.arange(H, dtype=np.uint32), **okw)
+    return jobs, offers, tuple(names)
+
+
+def explain_golden_engine(make_engine, case):
+    """cook_match_explain on the case's inputs == the reference's expected map"""
+    jobs, offers, names = explain_golden_inputs(case)
+    with make_engine(A.default_params(good_enough_fitness=1.0)) as e:
+        j2o, _, _ = e.match(jobs, offers, None)
+        counts = e.match_explain(np.array([0], np.uint32))
+    assert (j2o[0] >= 0) == (case["expect"] == {}), case["ref"]
+    assert A.why_summary(counts[0], scalar_names=names) == _explain_expect(case), case["ref"]

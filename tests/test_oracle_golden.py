@@ -211,3 +211,19 @@ def test_resource_stats_known_answers():
     assert (s["p50_cpus"], s["p95_cpus"], s["p100_cpus"], s["largest_by_cpus"]) == (2.5, 2.5, 2.5, 0)
     s = pyoracle.resource_stats([], [])
     assert s["total_cpus"] == 0.0 and s["p50_cpus"] != s["p50_cpus"]
+
+
+EXPLAIN = G.load("explain")
+
+
+@pytest.mark.parametrize("case", EXPLAIN, ids=[c["name"] for c in EXPLAIN])
+def test_explain_reducer_golden(oracle, case):
+    # the reference's own test of summarize-placement-failure (test/cook/test/scheduler/fenzo_utils.clj:56-100): the reducer, and — where Fenzo can
+    # produce the hosts' results in a real placement — the oracle's summary of that placement
+    from tests import parity_cases as P
+    P.explain_golden_reduce(case)
+    if "engine" in case:
+        jobs, offers, names = P.explain_golden_inputs(case)
+        j2o, counts = oracle.match_explain(A.default_params(good_enough_fitness=1.0), jobs, offers, None, (), np.array([0], np.uint32))
+        assert (j2o[0] >= 0) == (case["expect"] == {}), case["ref"]
+        assert A.why_summary(counts[0], scalar_names=names) == P._explain_expect(case), case["ref"]

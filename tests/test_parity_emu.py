@@ -8,7 +8,10 @@ import pytest
 from cook_amd import _abi as A
 from cook_amd import synth
 from cook_amd.engine import Engine
+from tests import golden_util as _G
 from tests import parity_cases as P
+
+G_EXPLAIN = _G.load("explain")
 
 
 @pytest.fixture(scope="module")
@@ -88,7 +91,7 @@ def test_rank_edge_cases(make_engine):
     P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=0))
 
 
-ALGOS = pytest.mark.parametrize("algo", [0, 1], ids=["default", "serial"])  # window rounds (shipped) / the one-job-at-a-time sweep
+ALGOS = pytest.mark.parametrize("algo", [0, 1, 3], ids=["default", "serial", "classfit"])  # window rounds (shipped) / the one-job-at-a-time sweep / class-ordered best fit
 
 
 @ALGOS
@@ -759,3 +762,9 @@ print(json.dumps({"stats": {k: v for k, v in st.items() if k.startswith("rank_ba
     assert got["off"]["stats"]["rank_batch_pools"] == 0
     assert got["copies"]["stats"]["rank_batch_pools"] == 3 and got["copies"]["stats"]["rank_batch_single_ops"] > 0
     assert got["batch"]["out"] == got["off"]["out"] == got["copies"]["out"]
+
+
+@pytest.mark.parametrize("case", [c for c in G_EXPLAIN if "engine" in c], ids=[c["name"] for c in G_EXPLAIN if "engine" in c])
+def test_explain_reference_cases(make_engine, case):
+    # the reference's own cases of the why-unscheduled reducer (tests/golden/explain.json) through cook_match / cook_match_explain
+    P.explain_golden_engine(make_engine, case)

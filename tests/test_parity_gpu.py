@@ -10,7 +10,10 @@ from cook_amd import _abi as A
 from cook_amd import synth
 from cook_amd.engine import Engine
 from oracle import pyoracle
+from tests import golden_util as _G
 from tests import parity_cases as P
+
+G_EXPLAIN = _G.load("explain")
 
 pytestmark = pytest.mark.gpu
 
@@ -78,7 +81,7 @@ def test_rank_edge_cases(make_engine):
     P.rank_parity(make_engine, pool, A.default_params(max_over_quota_jobs=0))
 
 
-ALGOS = pytest.mark.parametrize("algo", [0, 1], ids=["default", "serial"])  # window rounds (shipped) / the one-job-at-a-time sweep
+ALGOS = pytest.mark.parametrize("algo", [0, 1, 3], ids=["default", "serial", "classfit"])  # window rounds (shipped) / the one-job-at-a-time sweep / class-ordered best fit
 
 
 @ALGOS
@@ -676,3 +679,9 @@ def test_bench_two_ranks_on_one_gpu():
     assert c["pools_of_rank"] == [[0, 2, 4, 6], [1, 3, 5, 7]]
     assert c["group_usage_equals_sum_over_all_pools"] is True
     assert d["last_cycle"]["considered"] > 900_000 and d["last_cycle"]["matched"] > 300_000
+
+
+@pytest.mark.parametrize("case", [c for c in G_EXPLAIN if "engine" in c], ids=[c["name"] for c in G_EXPLAIN if "engine" in c])
+def test_explain_reference_cases(make_engine, case):
+    # the reference's own cases of the why-unscheduled reducer (tests/golden/explain.json) through cook_match / cook_match_explain
+    P.explain_golden_engine(make_engine, case)
