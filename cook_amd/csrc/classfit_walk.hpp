@@ -37,7 +37,7 @@
 #endif
 
 #ifndef CF_AHEAD
-#define CF_AHEAD 4
+#define CF_AHEAD 8  // (measured: a C4 pool 50.4 ms at 4, 49.1 at 6, 48.1 at 8)
 #endif
 constexpr unsigned CF_BOARD = CF_AHEAD;  // steps the class waves may run ahead of the decider (at most CF_SLOTS - 2)
 constexpr unsigned CF_SLOTS = 12;   // entries per column of the board: walked ordinal modulo 12.  The waves that share a set's jobs take the ordinals in turn and
@@ -212,7 +212,7 @@ static __device__ __forceinline__ bool cf_cons_ok(const CfLds& S, const CfJobU& 
   return ok;
 }
 static __device__ __forceinline__ double cf_literal(unsigned Tc, unsigned Tm, unsigned fc, unsigned fm, unsigned jc, unsigned jm, double sc, double sm) {
-  // the oracle's expression (cook_oracle.cpp match_impl; match_kernels.hpp fitness_of) on the exact values the fixed-point numbers stand for:
+  // the literal expression of the placement (match_kernels.hpp fitness_of; the reference: cpuMemBinPacker, config.clj:108) on the exact values the fixed-point numbers stand for:
   // running + assigned = total - free, lease + running = total
   const double A = (double)(Tc - fc) * sc, Bm = (double)(Tm - fm) * sm, c = (double)jc * sc, m = (double)jm * sm;
   return ((A + c) / ((double)Tc * sc) + (Bm + m) / ((double)Tm * sm)) / 2.0;
@@ -519,9 +519,10 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
 #if COOK_HAS_ASM_WALK
         // the lane's state and the batch's jobs as the hand-placed step holds them (classfit_asm.hpp)
         cf_u32x16 ST = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-        cf_u32x8 JB = {jc, jm, jmeta, clw * 32u, lane, 0u, 0u, 0u};
+        cf_u32x8 JB = {jc, jm, jmeta, clw * 32u, lane, jeq0, jeq1, 0u};
         const unsigned long long rel0 = cook_ballot(!isov & ((my_kinds & 1u) != 0u)), ovm = cf_below(CF_OVL);
-        const cf_u32x4 MK = {wave_uniform_u32((unsigned)rel0), wave_uniform_u32((unsigned)(rel0 >> 32)), wave_uniform_u32((unsigned)ovm), wave_uniform_u32((unsigned)(ovm >> 32))};
+        const cf_u32x8 MK = {wave_uniform_u32((unsigned)rel0), wave_uniform_u32((unsigned)(rel0 >> 32)), wave_uniform_u32((unsigned)ovm), wave_uniform_u32((unsigned)(ovm >> 32)),
+                             wave_uniform_u32(cook_lds_off(S.attr8)), 0u, 0u, 0u};
         const unsigned a_board = wave_uniform_u32(cook_lds_off(S.board)), a_log = wave_uniform_u32(cook_lds_off(S.log));
         auto st_pack = [&] {
           const unsigned long long hc = (unsigned long long)__double_as_longlong(o.hTc), hm = (unsigned long long)__double_as_longlong(o.hTm);
@@ -551,10 +552,10 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
 #undef CF_U
               asm volatile(CF_ASM_DECIDER_STEP
                            : "+{v[64:79]}"(ST), "+{s[36:43]}"(SC)
-                           : "{v[80:87]}"(JB), "{s[44:51]}"(AR), "{s[52:55]}"(MK)
+                           : "{v[80:87]}"(JB), "{s[44:51]}"(AR), "{s[52:59]}"(MK)
                            : "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",
-                             "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",
-                             "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "vcc", "scc", "memory");
+                             "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
+                             "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "vcc", "scc", "memory");
 #ifdef CF_DELAY_D  // robustness study: a slow decider
               __builtin_amdgcn_s_sleep(6);
 #endif
@@ -727,6 +728,35 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
       } else if (is_class_wave) {
         // ================================================= a class wave: answers ahead of the decider =================================================
         while (md == 0u) {
+#if COOK_HAS_ASM_WALK
+          if (one_cls != 0xFFFFFFFFu) {  // plain answers, one behind the other (classfit_asm.hpp); what is not plain — and every event — is the C++ body's below
+            const cf_u32x8 LV = {c.lv.v0, c.lv.v1, c.lv.v2, c.lv.v3, c.lv.v4, c.lv.v5, c.lv.v6, c.lv.v7};
+            const cf_u32x8 JC = {jc, jm, jmeta, lane, 0u, 0u, 0u, 0u};
+#define CF_U(x) wave_uniform_u32((unsigned)(x))
+            const unsigned long long hcb = (unsigned long long)__double_as_longlong(u_hTc), hmb = (unsigned long long)__double_as_longlong(u_hTm);
+            const cf_u32x8 AR = {CF_U(cook_lds_off(S.board)), CF_U(lw), CF_U(base), CF_U((gen & 15u) << 8), CF_U(u_off), CF_U(u_n), CF_U(cook_lds_off(S.cid)), CF_U(one_cls << 16)};
+            const cf_u32x8 A2 = {CF_U(hcb), CF_U(hcb >> 32), CF_U(hmb), CF_U(hmb >> 32), CF_U(rep), CF_U(nrep), CF_U(S.cls[one_cls].kind), CF_BOARD};
+            for (;;) {
+              cf_u32x8 SC = {CF_U(todo), CF_U(todo >> 32), CF_U(cur_ord), CF_U(ph), CF_U(seen), 3u, 0u, 0u};
+              asm volatile(CF_ASM_CLASS_STEP
+                           : "+{s[36:43]}"(SC)
+                           : "{v[64:71]}"(LV), "{v[72:79]}"(JC), "{s[44:51]}"(AR), "{s[52:59]}"(A2)
+                           : "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "s60", "s61", "s62",
+                             "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "vcc", "scc",
+                             "memory");
+              todo = wave_uniform_u64((unsigned long long)SC[1] << 32 | SC[0]), cur_ord = wave_uniform_u32(SC[2]), ph = wave_uniform_u32(SC[3]);
+              const unsigned status = wave_uniform_u32(SC[5]);
+              if (status == 0u) continue;
+              if (status == 2u) {
+                SPIN_PAUSE_NEAR();
+                continue;
+              }
+              break;
+            }
+#undef CF_U
+            WAIT_LDS();
+          }
+#endif
           CF_PROF_T(q0);
           unsigned mode, hw, cnt;
           {  // one trip to the LDS for the three words the decider writes

@@ -1,6 +1,7 @@
 // engine.hip — libcookmatch.so: C ABI (include/cookmatch.h) + host orchestration of the HIP kernels.
 // One engine = one pool = one HIP stream.  Built by hipcc for gfx950 only (cook_amd/build.py).
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <ucontext.h>
 
 #include <algorithm>
@@ -570,18 +571,28 @@ static void flow_entry() {
   swapcontext(&f->ctx, &tl_batch->main_ctx);  // (never resumed)
 }
 constexpr size_t FLOW_STACK_BYTES = 2u << 20;
-static thread_local std::vector<char*> tl_flow_stacks;  // kept for the thread's next batch
+constexpr size_t FLOW_GUARD_BYTES = 64u << 10;  // below the stack, no access: an overflow faults instead of writing into the heap
+// a thread's flow stacks: kept for its next batch, unmapped when the thread ends (an executor's or a JVM's pool thread that once led a batch)
+struct FlowStacks {
+  std::vector<char*> maps;  // mapping = guard + stack
+  ~FlowStacks() {
+    for (char* m : maps) munmap(m, FLOW_GUARD_BYTES + FLOW_STACK_BYTES);
+  }
+  char* stack(size_t i) { return maps[i] + FLOW_GUARD_BYTES; }
+};
+static thread_local FlowStacks tl_flow_stacks;
 // runs the flows to completion; returns the first flow's error code that is not COOK_OK (every engine keeps its own message)
 static int batch_run(PoolBatch& b) {
   const unsigned P = (unsigned)b.flows.size();
-  while (tl_flow_stacks.size() < P) {
-    char* st = (char*)std::malloc(FLOW_STACK_BYTES);
-    if (!st) throw cook_error(COOK_E_NOMEM, "pool batch: no memory for a flow's stack");
-    tl_flow_stacks.push_back(st);
+  while (tl_flow_stacks.maps.size() < P) {
+    void* m = mmap(nullptr, FLOW_GUARD_BYTES + FLOW_STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+    if (m == MAP_FAILED) throw cook_error(COOK_E_NOMEM, "pool batch: no memory for a flow's stack");
+    (void)mprotect(m, FLOW_GUARD_BYTES, PROT_NONE);
+    tl_flow_stacks.maps.push_back((char*)m);
   }
   for (unsigned i = 0; i < P; ++i) {
     PoolFlow& f = b.flows[i];
-    f.stack = tl_flow_stacks[i];
+    f.stack = tl_flow_stacks.stack(i);
     f.state = 0;
     getcontext(&f.ctx);
     f.ctx.uc_stack.ss_sp = f.stack;
@@ -593,6 +604,18 @@ static int batch_run(PoolBatch& b) {
     ~Reset() { tl_batch = nullptr, tl_flow = nullptr; }
   } reset;
   tl_batch = &b;
+  // an error on the scheduler's own side (a flush, the synchronisation): the parked flows are never resumed — every engine of the batch is left
+  // failed, with the clean-up guarded() gives an engine whose own call threw
+  auto abandon = [&](int code, const std::string& msg) {
+    for (auto& f : b.flows) {
+      if (f.state == 2 && f.rc != COOK_OK) continue;  // (keeps its own message)
+      f.rc = code;
+      f.e->err = msg;
+      f.e->ev_pending.clear();
+      f.e->ev_used = 0;
+    }
+  };
+  try {
   for (;;) {
     for (auto& f : b.flows)
       if (f.state == 0) {
@@ -612,6 +635,13 @@ static int batch_run(PoolBatch& b) {
     if (!parked) break;
     for (auto& f : b.flows)
       if (f.state == 1) f.state = 0;
+  }
+  } catch (const cook_error& ce) {
+    abandon(ce.code, ce.msg);
+    throw;
+  } catch (const std::exception& ex) {
+    abandon(COOK_E_NOMEM, ex.what());
+    throw;
   }
   for (auto& f : b.flows)
     if (f.rc != COOK_OK) return f.rc;
@@ -714,6 +744,8 @@ void rank_stage(cook_engine* e, const cook_tasks* t, const cook_users* u) {
     pend_ord[i] = np;
     np += t->pending[i] ? 1u : 0u;
   }
+  // (nothing of the previous table counts from here on: a stage that fails half-way must not leave its usage or its rank behind)
+  e->rank_staged = false, e->pool_usage_known = false, e->rank_done = false;
   e->N = N;
   e->U = U;
   e->n_pending = np;
@@ -2376,6 +2408,9 @@ int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, const uint32_t*
   if (!engines || n == 0 || !num_considerable) return COOK_E_INVALID;
   for (uint32_t i = 0; i < n; ++i)
     if (!engines[i] || (user_usage && !user_usage[i])) return COOK_E_INVALID;
+  for (uint32_t i = 0; i < n; ++i)  // (an engine twice: two flows would record launches against one engine's buffers)
+    for (uint32_t k = 0; k < i; ++k)
+      if (engines[i] == engines[k]) return COOK_E_INVALID;
   cook_engine* lead = engines[0];
   bool same_device = true;
   for (uint32_t i = 1; i < n; ++i) same_device = same_device && engines[i]->device == lead->device;
@@ -2423,6 +2458,9 @@ int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, const uint32_t*
 }
 int cook_cycle_match_multi(cook_engine** engines, uint32_t n) {
   if (!engines || n == 0 || !engines[0]) return COOK_E_INVALID;
+  for (uint32_t i = 0; i < n; ++i)  // (an engine twice: its rounds would be run twice over one set of buffers)
+    for (uint32_t k = 0; k < i; ++k)
+      if (engines[i] && engines[i] == engines[k]) return COOK_E_INVALID;
   cook_engine* lead = engines[0];
   return guarded(lead, [&] {
     StageTimer tm(lead, 2, &lead->match_ms);

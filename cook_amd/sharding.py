@@ -287,7 +287,11 @@ class ShardedCluster:
                 one(0)
             else:  # (the calling thread takes a batch itself: handing one to the pool costs 30-45 us before its first launch, per-dispatch trace)
                 futs = [self._tp_rank.submit(one, b) for b in range(1, nb)]
-                one(0)
+                try:
+                    one(0)
+                finally:  # (no batch may still be running on its engines when an error leaves this call: the caller closes them)
+                    import concurrent.futures
+                    concurrent.futures.wait(futs)
                 for f in futs:
                     f.result()
             if want_users and not on_gpu:
@@ -299,6 +303,13 @@ class ShardedCluster:
             rank_all()
             t2 = time.perf_counter()
             cycle_match_multi([self.engines[p] for p in self.pools])  # (falls back to lockstep launches inside the library if it must)
+            lead_e = self.engines[self.pools[0]]
+            if hasattr(lead_e, "match_stats") and lead_e.match_stats().get("served_fell_back"):
+                # correct, but a latency spike of the walkers' time-out (250 ms): something stalled the serve launches — another engine of the device
+                # allocating or freeing, a descheduled host thread
+                self.served_fell_back_cycles = getattr(self, "served_fell_back_cycles", 0) + 1
+                import warnings
+                warnings.warn("cook_cycle_match_multi: the served walkers gave up and the cycle was redone in lockstep launches", RuntimeWarning)
         elif lockstep and self.chain_whole_cycle:
             # MI355X runs about four independent chains of small kernels at full speed (beyond that the hardware queues
             # share dispatch pipes: 4 pools 113 ms, 6 or 8 pools 186 ms per cycle), while pools in lockstep pay for the

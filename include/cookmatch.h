@@ -369,6 +369,7 @@ int cook_cycle_run_rank(cook_engine* e, uint32_t num_considerable);
  * have had its own.  user_usage != NULL: user_usage[i] also receives engine i's per-user running usage [U x 3] exactly as
  * cook_rank_user_usage(engines[i], user_usage[i], usage_is_device) would deliver it after the rank (the collective's payload), inside the
  * same joint sequence.  COOK_RANK_BATCH=0 in the environment: the engines one after another, as cook_cycle_run_rank (+ cook_rank_user_usage).
+ * Every engine ONCE: a handle twice in the array is COOK_E_INVALID (here and in cook_cycle_match_multi).
  * Returns the first engine's error that is not COOK_OK; every engine keeps its own message (cook_last_error). */
 int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, const uint32_t* num_considerable /* [n]: every pool its own K */,
                               double* const* user_usage, int usage_is_device);
