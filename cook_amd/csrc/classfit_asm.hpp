@@ -123,11 +123,34 @@
   "s_and_b64 s[74:75], s[74:75], s[76:77]\n\t"                                                                                          \
   "s_and_b64 s[74:75], s[74:75], s[78:79]\n\t"                                                                                          \
   "s_or_b64 s[74:75], s[74:75], s[80:81]\n\t"                                                                                           \
-  "s_and_b64 s[70:71], s[70:71], s[72:73]\n\t"                                                                                          \
-  "s_and_b64 s[70:71], s[70:71], s[74:75]\n\t"                                                                                          \
-  "s_andn2_b64 s[72:73], s[52:53], s[70:71]\n\t"                                                                                        \
-  "s_cmp_eq_u64 s[72:73], 0\n\t"                                                                                                        \
-  "s_cbranch_scc1 2f\n\t"                                                                                                               \
+  "s_and_b64 s[72:73], s[70:71], s[72:73]\n\t" /* the entry is this job's (and was read whole) */                                         \
+  "s_and_b64 s[70:71], s[72:73], s[74:75]\n\t"                                                                                            \
+  "s_andn2_b64 s[76:77], s[52:53], s[70:71]\n\t" /* answers missing */                                                                    \
+  "s_cmp_eq_u64 s[76:77], 0\n\t"                                                                                                          \
+  "s_cbranch_scc1 2f\n\t"                                                                                                                 \
+  /* an answer for this job that names a member taken since: the offer is in the overlay now, fuller than the answer knew it; if its lane can take */ \
+  /* the job it beats whatever the wave would answer today, and the step does not wait: the wave has no candidate (classfit_walk.hpp, the C++ step) */ \
+  "s_and_b64 s[78:79], s[76:77], s[72:73]\n\t"                                                                                            \
+  "s_cmp_eq_u64 s[78:79], 0\n\t"                                                                                                          \
+  "s_cbranch_scc1 4f\n\t"                                                                                                                 \
+  "v_and_b32_e32 v109, 0x3fff, v95\n\t"                                                                                                   \
+  "s_and_b64 s[72:73], s[64:65], s[54:55]\n\t" /* overlay lanes that can take the job */                                                  \
+  "10:\n\t"                                                                                                                               \
+  "s_ff1_i32_b64 s83, s[78:79]\n\t"                                                                                                       \
+  "v_readlane_b32 s63, v109, s83\n\t"                                                                                                     \
+  "s_bitset0_b64 s[78:79], s83\n\t"                                                                                                       \
+  "v_cmp_eq_u32_e64 vcc, s63, v65\n\t"                                                                                                    \
+  "s_and_b64 vcc, vcc, s[72:73]\n\t"                                                                                                      \
+  "s_cmp_eq_u64 vcc, 0\n\t"                                                                                                               \
+  "s_cbranch_scc1 11f\n\t"                                                                                                                \
+  "s_bitset1_b64 s[80:81], s83\n\t"                                                                                                       \
+  "s_bitset0_b64 s[76:77], s83\n\t"                                                                                                       \
+  "11:\n\t"                                                                                                                               \
+  "s_cmp_lg_u64 s[78:79], 0\n\t"                                                                                                          \
+  "s_cbranch_scc1 10b\n\t"                                                                                                                \
+  "s_cmp_eq_u64 s[76:77], 0\n\t"                                                                                                          \
+  "s_cbranch_scc1 2f\n\t"                                                                                                                 \
+  "4:\n\t"                                                                                                                                \
   "s_sub_u32 s82, s82, 1\n\t" /* an answer is missing: look again a few times (a class wave is about to publish it), then give up */     \
   "s_cmp_eq_u32 s82, 0\n\t"                                                                                                             \
   "s_cbranch_scc1 9f\n\t"                                                                                                               \
@@ -333,8 +356,13 @@
   "s_cmp_eq_u32 s39, s57\n\t"                                                                                                           \
   "s_cselect_b32 s39, 0, s39\n\t"                                                                                                       \
   "s_branch 1b\n\t"                                                                                                                     \
-  "2:\n\t"                                                                                                                              \
-  "s_lshr_b32 s60, s42, 8\n\t"                                                                                                          \
+  "2:\n\t"                                                                                                                                \
+  "s_lshr_b32 s60, s42, 8\n\t"                                                                                                            \
+  "s_cmp_lt_u32 s38, s60\n\t" /* the decider has gone past this wave: the C++ loop moves it on */                                         \
+  "s_cbranch_scc0 12f\n\t"                                                                                                                \
+  "s_mov_b32 s41, 3\n\t"                                                                                                                  \
+  "s_branch 9f\n\t"                                                                                                                       \
+  "12:\n\t"                                                                                                                               \
   "s_add_u32 s60, s60, s59\n\t"                                                                                                         \
   "s_cmp_ge_u32 s38, s60\n\t"                                                                                                           \
   "s_cbranch_scc1 9f\n\t" /* too far ahead of the decider */                                                                            \

@@ -591,7 +591,13 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
           unsigned cpos, ccid, cfc, cfm;
           double cfa;
           bool acc;
-          {
+          // the overlay's lanes that can take the job (room, and the job's constraints: a class wave's candidate has passed them)
+          bool ok_ov = isov & (o.valid != 0u) & (kind == 0u) & (o.fc >= Jc) & (o.fm >= Jm);
+          if (meta >> 12) {
+            const CfJobU J = job_of(s);
+            ok_ov = ok_ov & cf_cons_ok(S, J, o.id, ok_ov);
+          }
+          for (;;) {
             const unsigned t1 = ld_wg(&e->tag);
             COMPILER_FENCE();
             cpos = e->pos, ccid = e->cid, cfc = e->fc, cfm = e->fm, cfa = e->fa;
@@ -600,23 +606,20 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
             // behind: removals of the wave the answer does not know.  An answer that knows a removal cannot name its member (zeroed in LDS before the
             // count moved), so: up to two unknown removals, and neither of the last two removed positions
             const unsigned behind = (nrm - t1) & 255u, p = cpos & 0xFFFFu;
-            acc = (t1 == t2) & ((t1 & ~255u) == want) & (((ccid & CF_ENT_NONE) != 0u) | ((behind <= 2u) & (p != rm1) & (p != rm2)));
-          }
-          if (cook_ballot(relevant & !acc) != 0ull) {  // an answer is missing (or names a member taken since): wait for it
-            if (relevant) {
-              while (!acc) {
-                CF_STAT(++st_spins);
-                SPIN_PAUSE_NEAR();
-                const unsigned t1 = ld_wg(&e->tag);
-                COMPILER_FENCE();
-                cpos = e->pos, ccid = e->cid, cfc = e->fc, cfm = e->fm, cfa = e->fa;
-                COMPILER_FENCE();
-                const unsigned t2 = ld_wg(&e->tag);
-                const unsigned behind = (nrm - t1) & 255u, p = cpos & 0xFFFFu;
-                acc = (t1 == t2) & ((t1 & ~255u) == want) & (((ccid & CF_ENT_NONE) != 0u) | ((behind <= 2u) & (p != rm1) & (p != rm2)));
-              }
+            const bool ours = (t1 == t2) & ((t1 & ~255u) == want);
+            acc = ours & (((ccid & CF_ENT_NONE) != 0u) | ((behind <= 2u) & (p != rm1) & (p != rm2)));
+            if (cook_ballot(relevant & !acc) == 0ull) break;
+            // An answer for this job that names a member taken since: that offer is in the overlay now, FULLER than the answer knew it.  If its lane can
+            // take the job it beats whatever the wave would answer today (the members left are the ones the old answer ranked below the offer as it
+            // was), so the step does not wait: the wave has no candidate.  (within an epoch an offer only moves from the arrays to the overlay.)
+            for (unsigned long long rq = cook_ballot(relevant & !acc & ours); rq != 0ull; rq &= rq - 1ull) {
+              const unsigned L = (unsigned)__ffsll(rq) - 1u;
+              const unsigned xid = (unsigned)wave_read_lane((int)(ccid & CF_IDMASK), (int)L);
+              if (cook_ballot(ok_ov & (o.id == xid)) != 0ull && lane == L) acc = true, ccid = CF_ENT_NONE;
             }
-            wave_sync();
+            if (cook_ballot(relevant & !acc) == 0ull) break;
+            CF_STAT(++st_spins);
+            SPIN_PAUSE_NEAR();  // an answer is missing: wait for it
           }
           CF_PROF_T(p1);
           CF_PROF_ADD(0, p1 - p0);
@@ -624,12 +627,7 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
           const unsigned vfc = isov ? o.fc : cfc, vfm = isov ? o.fm : cfm, vid = isov ? o.id : (ccid & CF_IDMASK);
           const bool vvalid = isov ? (o.valid != 0u && kind == 0u) : (relevant && !(ccid & CF_ENT_NONE));
           const bool room = vvalid & (vfc >= Jc) & (vfm >= Jm);
-          bool ok = room;
-          if (meta >> 12) {  // constraints: the overlay's lanes (a class wave's candidate has passed them)
-            const CfJobU J = job_of(s);
-            const bool cons = cf_cons_ok(S, J, vid, room & isov);
-            ok = room & (cons | !isov);
-          }
+          const bool ok = isov ? ok_ov : room;
           double fov = 1.0 - ((double)(vfc - Jc) * o.hTc + (double)(vfm - Jm) * o.hTm);
           OPAQUE_V(fov);
           const double fa = ok ? (isov ? fov : cfa) : 0.0;
@@ -768,26 +766,13 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
             break;
           }
           COMPILER_FENCE();
-          if (cnt != seen) {  // members of ours have left: the steps in flight are answered again
-            seen = cnt;
-            todo = walkmask & ~cf_below(hw & 255u);
-            cur_ord = hw >> 8;
-            ph = cur_ord;
-            while (ph >= nrep) ph -= nrep;
-            CF_STAT(++st_rewinds);
-          }
-          while (todo != 0ull && ph != rep) {  // (the set's other waves answer these)
-            todo &= todo - 1ull, ++cur_ord;
-            ph = ph + 1u == nrep ? 0u : ph + 1u;
-          }
-          if (todo != 0ull && wk != 0u && cur_ord < (hw >> 8) + CF_BOARD) {
-            const unsigned s = (unsigned)__ffsll(todo) - 1u;
-            const unsigned ord = cur_ord;
-            todo &= todo - 1ull, ++cur_ord;
-            ph = ph + 1u == nrep ? 0u : ph + 1u;
+          // the answer of step (s, ord) onto the board.  again: the step was answered before members of ours left — an entry whose member is still in its
+          // array stands (the first feasible member of a sorted array stays the first when ANOTHER one leaves; "none" stays none: placements only take
+          // room away) and only gets the new count; one that names a member zeroed (or a gpu host occupied) since is computed anew
+          auto answer = [&](unsigned s, unsigned ord, bool again) {
             const unsigned Jc = (unsigned)wave_read_lane((int)jc, (int)s), Jm = (unsigned)wave_read_lane((int)jm, (int)s), meta = (unsigned)wave_read_lane((int)jmeta, (int)s);
             const unsigned kind = meta & 255u;
-            if (!(kind < 32u && ((wk >> kind) & 1u))) continue;  // (none of our classes: the decider does not ask)
+            if (!(kind < 32u && ((wk >> kind) & 1u))) return;  // (none of our classes: the decider does not ask)
             CF_PROF_T(q1);
 #ifdef CF_DELAY_C  // robustness study: slow class waves (every third answer of a wave very slow)
             __builtin_amdgcn_s_sleep(4);
@@ -795,6 +780,22 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
 #endif
             CfEnt* e = &S.board[cf_slot(ord) * 8u + lw];
             const unsigned tag = (base + s) << 12 | (gen & 15u) << 8 | (seen & 255u);
+            if (again) {
+              // (only this wave writes the slot; the decider zeroes members: lane 0's reading counts for the wave)
+              const unsigned t0 = ld_wg(&e->tag), p0 = e->pos & 0xFFFFu, c0 = e->cid;
+              if (((t0 ^ tag) & ~255u) == 0u) {  // (our entry for this job)
+                bool stands = (c0 & CF_ENT_NONE) != 0u;
+                if (!stands) {
+                  const CfFree f0 = S.fcm[p0];
+                  const uint32_t cd0 = S.cid[p0];
+                  stands = wave_read_lane(((f0.c | f0.m) != 0u && !(cd0 & CF_OCC)) ? 1 : 0, 0) != 0;
+                }
+                if (stands) {
+                  st_lane0_b32(&e->tag, tag);
+                  return;
+                }
+              }
+            }
             bool done = false;
             if ((meta >> 12) == 0u && one_cls != 0xFFFFFFFFu) {
               // the plain case — one class, a job without constraints: the first member with room of the first chunk that promises one publishes itself
@@ -838,6 +839,32 @@ static __device__ __forceinline__ void cf_walk_role(const CfLds& S, const MatchS
             CF_PROF_ADD(0, q1 - q0);
             CF_PROF_ADD(1, q2 - q1);
             CF_PROF_ADD(3, 1);
+          };
+          if (cnt != seen) {  // members of ours have left: this wave's steps in flight (from the decider's step up to where the wave stands) are looked at again
+            seen = cnt;
+            CF_STAT(++st_rewinds);
+            unsigned long long t2 = walkmask & ~cf_below(hw & 255u);
+            unsigned o2 = hw >> 8, p2 = o2;
+            while (p2 >= nrep) p2 -= nrep;
+            for (; t2 != 0ull && o2 < cur_ord; t2 &= t2 - 1ull, ++o2, p2 = p2 + 1u == nrep ? 0u : p2 + 1u)
+              if (p2 == rep && wk != 0u) answer((unsigned)__ffsll(t2) - 1u, o2, true);
+          }
+          if (cur_ord < (hw >> 8)) {  // the decider has gone past this wave (it takes a step without an answer that names a member it holds itself): on from its step
+            todo = walkmask & ~cf_below(hw & 255u);
+            cur_ord = hw >> 8;
+            ph = cur_ord;
+            while (ph >= nrep) ph -= nrep;
+          }
+          while (todo != 0ull && ph != rep) {  // (the set's other waves answer these)
+            todo &= todo - 1ull, ++cur_ord;
+            ph = ph + 1u == nrep ? 0u : ph + 1u;
+          }
+          if (todo != 0ull && wk != 0u && cur_ord < (hw >> 8) + CF_BOARD) {
+            const unsigned s = (unsigned)__ffsll(todo) - 1u;
+            const unsigned ord = cur_ord;
+            todo &= todo - 1ull, ++cur_ord;
+            ph = ph + 1u == nrep ? 0u : ph + 1u;
+            answer(s, ord, false);
             continue;
           }
           if (wk != 0u) SPIN_PAUSE_NEAR();
