@@ -5,6 +5,7 @@
 #pragma once
 
 constexpr unsigned RB_CHECK = 32;
+constexpr unsigned RB_FIRST_MIN = COOK_SHAPE(256u, 2u);  // hosts of the first phase of rebal_decide at least (rebalance_run)
 
 struct RebalBufs {
   bool staged = false, done = false;
@@ -62,8 +63,12 @@ struct RebalBufs {
   // dynamic
   DArr<uint32_t> x_pj, x_host, pre_hosts, co_val, hres_len, hres_base, srt_slot, gs_posB, gs_slot, gs_ord;
   DArr<uint8_t> x_known;
-  DArr<unsigned long long> hres_key, blk_key;
-  DArr<uint32_t> blk_host;
+  DArr<unsigned long long> hres_key, blk_key, hmax_key, best_key;
+  DArr<uint32_t> blk_host, h_host;
+  RebalIn in_host{};
+  DArr<RebalIn> in_dev;
+  unsigned long long thr_key = 0ull;  // this run's first-phase threshold (0: one phase)
+  std::vector<unsigned long long> hmax_h;
   DArr<double> hres_dru, hres_c, hres_m, hres_g, gs_dru, gs_cpus, gs_mem, gs_gpus, pending_dru;
   DArr<cook_preemption> decisions;
   DArr<uint32_t> preempted;
@@ -307,7 +312,8 @@ RebalIn rebalance_args(cook_engine* e, RebalBufs& b) {
   in.x_pj = b.x_pj.ptr(), in.x_host = b.x_host.ptr(), in.x_known = b.x_known.ptr();
   in.pre_hosts = b.pre_hosts.ptr(), in.co_val = b.co_val.ptr();
   in.hres_key = b.hres_key.ptr(), in.hres_len = b.hres_len.ptr(), in.hres_base = b.hres_base.ptr();
-  in.blk_key = b.blk_key.ptr(), in.blk_host = b.blk_host.ptr(), in.n_blk = in.H ? div_up(div_up(in.H, 2u), RB_WAVES) : 0u;
+  in.blk_key = b.blk_key.ptr(), in.blk_host = b.blk_host.ptr(), in.n_blk = in.H ? div_up(div_up(in.H, 2u), (unsigned)RB_PAIRS) : 0u;
+  in.hmax_key = b.hmax_key.ptr(), in.h_host = b.h_host.ptr(), in.best_key = b.best_key.ptr(), in.thr_key = b.thr_key;
   in.hres_dru = b.hres_dru.ptr(), in.hres_c = b.hres_c.ptr(), in.hres_m = b.hres_m.ptr(), in.hres_g = b.hres_g.ptr();
   in.srt_slot = b.srt_slot.ptr();
   in.gs_dru = b.gs_dru.ptr(), in.gs_cpus = b.gs_cpus.ptr(), in.gs_mem = b.gs_mem.ptr(), in.gs_gpus = b.gs_gpus.ptr();
@@ -471,8 +477,9 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   b.pre_hosts.ensure(S);
   b.co_val.ensure(b.co_cap);
   b.hres_key.ensure(std::max(1u, H));
-  b.blk_key.ensure(std::max(1u, div_up(div_up(std::max(1u, H), 2u), RB_WAVES)));
-  b.blk_host.ensure(std::max(1u, div_up(div_up(std::max(1u, H), 2u), RB_WAVES)));
+  b.blk_key.ensure(2u * std::max(1u, div_up(div_up(std::max(1u, H), 2u), (unsigned)RB_PAIRS)));  // (an entry per workgroup and phase of rebal_decide)
+  b.blk_host.ensure(2u * std::max(1u, div_up(div_up(std::max(1u, H), 2u), (unsigned)RB_PAIRS)));
+  b.hmax_key.ensure(std::max(1u, H)), b.h_host.ensure(std::max(1u, R)), b.best_key.ensure(4);
   b.hres_len.ensure(std::max(1u, H));
   b.hres_base.ensure(std::max(1u, H));
   b.hres_dru.ensure(std::max(1u, H));
@@ -503,19 +510,45 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
   if (H) KL("rebal_big_init", rebal_big_init, div_up(H, 256), 256, (const uint32_t*)b.hstart.ptr(), (const uint32_t*)b.hend.ptr(), H, b.big_list.ptr(), b.ctl.ptr());
   rebalance_rescore(e, b);  // every user once; after a decision only the users it touched (rebal_rescore_users)
   if (R) KL("rebal_mirror_dru", rebal_mirror_dru, div_up(R, 256), 256, (const uint32_t*)b.h_pb.ptr(), (const double*)b.dru.ptr(), R, b.h_dru.ptr());
+  // the hosts' bounds (the greatest DRU a host holds), and the threshold of the first phase of rebal_decide: the bound about 3 % of the hosts reach.
+  // Any threshold gives the same decisions (rebal_decide); this one makes the first phase small and its best key usually the decision's.
+  b.thr_key = 0ull;
+  memset_async(e, b.best_key.ptr(), 0, 32);
+  if (H) {
+    KL("rebal_host_bound_init", rebal_host_bound_init, div_up(H, 256), 256, (const uint32_t*)b.hstart.ptr(), (const uint32_t*)b.hend.ptr(), H,
+       (const double*)b.h_dru.ptr(), b.h_host.ptr(), b.hmax_key.ptr());
+    const unsigned n_first = std::max(RB_FIRST_MIN, H / 32u);
+    if (H > 4u * n_first && std::getenv("COOK_REBAL_ONE_PHASE") == nullptr) {
+      b.hmax_h.resize(H);
+      copy_async(e, b.hmax_h.data(), b.hmax_key.ptr(), (size_t)H * 8, hipMemcpyDeviceToHost);
+      sync(e);
+      std::nth_element(b.hmax_h.begin(), b.hmax_h.begin() + (n_first - 1u), b.hmax_h.end(), std::greater<unsigned long long>());
+      b.thr_key = b.hmax_h[n_first - 1u];
+    }
+  }
   // ---- the decision loop (rebalancer.clj:442-458) ---------------------------------------------------------------------------------
-  const RebalIn in = rebalance_args(e, b);
+  // the kernels' argument block lives on the device: a launch passes its address (the block by value is ~1 KB of kernel arguments per launch, and the
+  // decision loop is bound by the rate at which the host can enqueue)
+  b.in_host = rebalance_args(e, b);
+  b.in_dev.ensure(1);
+  copy_async(e, b.in_dev.ptr(), &b.in_host, sizeof(RebalIn), hipMemcpyHostToDevice);
+  const RebalIn* in = b.in_dev.ptr();
   unsigned known_max = b.max_seg, known_at = 0;  // items of the fullest host when the control block was last read back
   // every user safe (integer-valued resources, the usual case): the changed users are re-scored by ONE launch from the slots the decision
   // flipped (rebal_rs_delta) and rebal_apply prepares the next job itself — 3 launches per pending job instead of 7.  Otherwise the general
   // path: tile scans with exactness tracking, left-to-right redo of the users where an addition rounded.
   bool all_safe = std::getenv("COOK_REBAL_GENERAL") == nullptr;
   for (unsigned u = 0; u < U && all_safe; ++u) all_safe = b.user_safe_h[u] != 0u;
+  const bool trace_loop = std::getenv("COOK_REBAL_TRACE") != nullptr;
+  if (trace_loop) sync(e);
+  const auto t_loop0 = std::chrono::steady_clock::now();
   if (all_safe && P) KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, 0u);
   for (unsigned pj = 0; pj < P; ++pj) {
     if (!all_safe) KL("rebal_job_prep", rebal_job_prep, 1, COOK_WAVE, in, pj);
-    if (H && all_safe && b.spare_safe) KL("rebal_decide", rebal_decide<true>, div_up(div_up(H, 2u), RB_WAVES), COOK_WAVE * RB_WAVES, in);
-    else if (H) KL("rebal_decide", rebal_decide<false>, div_up(div_up(H, 2u), RB_WAVES), COOK_WAVE * RB_WAVES, in);
+    for (unsigned phase = 0; H && phase < (b.thr_key != 0ull ? 2u : 1u); ++phase) {
+      if (all_safe && b.spare_safe) KL("rebal_decide", rebal_decide<true>, div_up(div_up(H, 2u), (unsigned)RB_PAIRS), COOK_WAVE * RB_WAVES, in, phase);
+      else KL("rebal_decide", rebal_decide<false>, div_up(div_up(H, 2u), (unsigned)RB_PAIRS), COOK_WAVE * RB_WAVES, in, phase);
+    }
     // hosts beyond 64 items: only when one can exist (the fullest host as last read back + the jobs placed since then)
     if (H && known_max + (pj - known_at) > (unsigned)COOK_WAVE) KL("rebal_decide_big", rebal_decide_big, 32, COOK_WAVE * RB_WAVES, in);
     if (all_safe) {
@@ -538,9 +571,23 @@ void rebalance_run(cook_engine* e, RebalBufs& b) {
       known_at = pj + 1;
     }
   }
+  const auto t_loop1 = std::chrono::steady_clock::now();
   copy_async(e, e->h_scratch, b.ctl.ptr(), sizeof(RebalCtl), hipMemcpyDeviceToHost);
   sync(e);
+  if (trace_loop)
+    std::fprintf(stderr, "COOK_REBAL_TRACE: the decision loop: %.3f ms to enqueue, %.3f ms until the device is done (two-phase threshold %s)\n",
+                 std::chrono::duration<double, std::milli>(t_loop1 - t_loop0).count(),
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count(), b.thr_key ? "set" : "none");
   std::memcpy(&b.last, e->h_scratch, sizeof(RebalCtl));
+#ifdef RB_COUNT
+  {
+    unsigned long long cnt[4];
+    copy_async(e, cnt, b.best_key.ptr(), 32, hipMemcpyDeviceToHost);
+    sync(e);
+    std::fprintf(stderr, "RB_COUNT: waves that evaluated: first phase %llu, second phase %llu (of %u per phase and job; %u jobs), of them for jobs below quota %llu; threshold key %llx\n", cnt[1], cnt[2],
+                 div_up(H, 2u), P, cnt[3], b.thr_key);
+  }
+#endif
   b.done = true;
 }
 

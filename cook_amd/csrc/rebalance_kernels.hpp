@@ -27,7 +27,14 @@
 #include "scan.hpp"
 
 constexpr int RB_CAP = 128;    // candidates per host kept in LDS (larger hosts use the global scratch)
-constexpr int RB_WAVES = 4;    // hosts per decide block
+#ifndef RB_WAVES_N
+#define RB_WAVES_N 8  // (measured on the 50k-host sweep: 4 waves / 32 pairs 7.84 ms, 8 / 64 6.91, 16 / 128 6.90, 8 / 256 7.92)
+#endif
+#ifndef RB_PAIRS_N
+#define RB_PAIRS_N 64
+#endif
+constexpr int RB_WAVES = RB_WAVES_N;  // waves of a decide block
+constexpr int RB_PAIRS = RB_PAIRS_N;  // pairs of hosts a decide block looks at (a thread each), the ones to evaluate shared by its waves
 
 struct RebalCtl {
   int remaining;        // max-preemption budget left (rebalancer.clj:442)
@@ -133,6 +140,11 @@ struct RebalIn {
   unsigned long long* blk_key;
   uint32_t* blk_host;
   unsigned n_blk;
+  // pruning of the per-host evaluation (rebal_decide's two phases): an upper bound on the key a host can reach
+  unsigned long long* hmax_key;   // [H] f64_key of a value >= the DRU of every active item of the host (only ever raised; all ones: a job placed this cycle sits there)
+  const uint32_t* h_host;         // [R] host of a position in host order
+  unsigned long long* best_key;   // [1] greatest key a host evaluated so far for the current job reached (0 none; rebal_apply clears it)
+  unsigned long long thr_key;     // hosts whose bound is at least this are evaluated first (0: every host in one phase)
   uint32_t *hres_len, *hres_base;
   double *hres_dru, *hres_c, *hres_m, *hres_g;
   uint32_t* srt_slot;  // [S] the host's candidates in priority order at [hres_base ...]
@@ -320,6 +332,27 @@ __global__ void __launch_bounds__(256) rebal_mirror_dru(const uint32_t* __restri
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < R) h_dru[i] = dru[h_pb[i]];
 }
+// host of every position in host order, and the hosts' first bounds: the greatest DRU among a host's running tasks
+__global__ void __launch_bounds__(256) rebal_host_bound_init(const uint32_t* __restrict__ hstart, const uint32_t* __restrict__ hend, unsigned H,
+                                                             const double* __restrict__ h_dru, uint32_t* __restrict__ h_host,
+                                                             unsigned long long* __restrict__ hmax_key) {
+  const unsigned h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  unsigned long long k = 0ull;
+  for (unsigned i = hstart[h]; i < hend[h]; ++i) {
+    h_host[i] = h;
+    const unsigned long long ki = f64_key(h_dru[i]);
+    k = ki > k ? ki : k;
+  }
+  hmax_key[h] = k;
+}
+// a re-scored slot's DRU into the host-ordered mirror; the host's bound follows it upwards
+static __device__ __forceinline__ void rebal_mirror_store(const RebalIn& in, unsigned hi, double d) {
+  in.h_dru[hi] = d;
+  const unsigned h = in.h_host[hi];
+  const unsigned long long k = f64_key(d);
+  if (in.hmax_key[h] < k) atomicMax(&in.hmax_key[h], k);
+}
 
 // Re-scoring after a decision (dru.clj:128-144 recomputes the changed users only).  rebal_apply lists the users whose active
 // set changed (in.chg) and cuts their segments of the per-user order into tiles of RB_RS_TILE slots (in.chg_tile: first tile of
@@ -328,7 +361,10 @@ __global__ void __launch_bounds__(256) rebal_mirror_dru(const uint32_t* __restri
 // DRU) — any association is the left-to-right sum when no addition rounded; a user where one did is redone sequentially
 // (rebal_rs_fix, as rebal_fix_inexact does).  The DRUs also go to the host-ordered mirror.
 // (the emulated tests: few fibers per launch; small tiles = many-tile users in small tests)
-constexpr int RB_RS_TILE = COOK_SHAPE(1024, 256), RB_RS_GRID = COOK_SHAPE(256, 4), RB_RS_USERS = COOK_SHAPE(64, 4);
+#ifndef RB_RS_GRID_N
+#define RB_RS_GRID_N 256
+#endif
+constexpr int RB_RS_TILE = COOK_SHAPE(1024, 256), RB_RS_GRID = COOK_SHAPE(RB_RS_GRID_N, 4), RB_RS_USERS = COOK_SHAPE(64, 4);
 static __device__ __forceinline__ unsigned rebal_rs_user_of_tile(const RebalIn& in, unsigned n_chg, unsigned tile) {
   unsigned lo = 0, hi = n_chg;  // last x with chg_tile[x] <= tile
   while (hi - lo > 1) {
@@ -346,7 +382,8 @@ static __device__ __forceinline__ double rebal_dru_of(const RebalIn& in, unsigne
   return a > b ? a : b;
 }
 // step 1: tile-local masked inclusive scans -> pre (without the carry), tile totals
-__global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_local(RebalIn in) {
+__global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_local(const RebalIn* __restrict__ inp) {
+  const RebalIn& in = *inp;
   __shared__ SumU4 s_tot[RB_RS_TILE / COOK_WAVE];
   const unsigned n_chg = in.ctl->n_changed, n_tiles = in.ctl->n_tiles;
   if (n_chg == 0u) return;
@@ -368,7 +405,7 @@ __global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_local(RebalIn in) {
         const double d = rebal_dru_of(in, u, t);
         in.dru_w[i] = d;
         const unsigned hi = in.hidx[i];
-        if (hi != 0xFFFFFFFFu) in.h_dru[hi] = d;
+        if (hi != 0xFFFFFFFFu) rebal_mirror_store(in, hi, d);
       } else {
         in.pre_w[i] = t;
       }
@@ -379,7 +416,8 @@ __global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_local(RebalIn in) {
   }
 }
 // step 2: per changed user, exclusive scan of its tile totals (one wave; a user has few tiles)
-__global__ void __launch_bounds__(COOK_WAVE) rebal_rs_carry(RebalIn in) {
+__global__ void __launch_bounds__(COOK_WAVE) rebal_rs_carry(const RebalIn* __restrict__ inp) {
+  const RebalIn& in = *inp;
   const unsigned n_chg = in.ctl->n_changed;
   const unsigned lane = lane_id();
   for (unsigned x = blockIdx.x; x < n_chg; x += gridDim.x) {
@@ -402,7 +440,8 @@ __global__ void __launch_bounds__(COOK_WAVE) rebal_rs_carry(RebalIn in) {
   }
 }
 // step 3: carry + local prefix -> pre, DRU, host-ordered mirror
-__global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_finish(RebalIn in) {
+__global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_finish(const RebalIn* __restrict__ inp) {
+  const RebalIn& in = *inp;
   const unsigned n_chg = in.ctl->n_changed, n_tiles = in.ctl->n_tiles;
   if (n_chg == 0u) return;
   const unsigned tid = threadIdx.x;
@@ -417,11 +456,12 @@ __global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_finish(RebalIn in) {
     const double d = rebal_dru_of(in, u, t);
     in.dru_w[i] = d;
     const unsigned hi = in.hidx[i];
-    if (hi != 0xFFFFFFFFu) in.h_dru[hi] = d;
+    if (hi != 0xFFFFFFFFu) rebal_mirror_store(in, hi, d);
   }
 }
 // step 4: users where an addition rounded: left to right, exactly as the reference's reductions, then their DRUs again
-__global__ void __launch_bounds__(256) rebal_rs_fix(RebalIn in) {
+__global__ void __launch_bounds__(256) rebal_rs_fix(const RebalIn* __restrict__ inp) {
+  const RebalIn& in = *inp;
   const unsigned n_chg = in.ctl->n_changed;
   for (unsigned x = blockIdx.x; x < n_chg; x += gridDim.x) {
     if (!in.chg_bad[x]) continue;  // block-uniform
@@ -447,7 +487,7 @@ __global__ void __launch_bounds__(256) rebal_rs_fix(RebalIn in) {
       const double d = rebal_dru_of(in, u, in.pre_w[i]);
       in.dru_w[i] = d;
       const unsigned hi = in.hidx[i];
-      if (hi != 0xFFFFFFFFu) in.h_dru[hi] = d;
+      if (hi != 0xFFFFFFFFu) rebal_mirror_store(in, hi, d);
     }
     __syncthreads();
   }
@@ -472,7 +512,8 @@ static __device__ __forceinline__ SumU4 rebal_delta_upto(const RebalIn& in, cons
   }
   return add;
 }
-__global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_delta(RebalIn in) {
+__global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_delta(const RebalIn* __restrict__ inp) {
+  const RebalIn& in = *inp;
   __shared__ uint32_t s_pos[RB_DL_LDS];
   __shared__ int32_t s_sign[RB_DL_LDS];
   __shared__ SumU4 s_val[RB_DL_LDS];
@@ -519,7 +560,7 @@ __global__ void __launch_bounds__(RB_RS_TILE) rebal_rs_delta(RebalIn in) {
       const double d = rebal_dru_of(in, u, t);
       in.dru_w[i] = d;
       const unsigned hi = in.hidx[i];
-      if (hi != 0xFFFFFFFFu) in.h_dru[hi] = d;
+      if (hi != 0xFFFFFFFFu) rebal_mirror_store(in, hi, d);
     }
   }
 }
@@ -670,7 +711,8 @@ static __device__ __forceinline__ void rebal_job_prep_dev(const RebalIn& in, uns
     if (in.pending_dru) in.pending_dru[pj] = jb.pdru;
   }
 }
-__global__ void __launch_bounds__(COOK_WAVE) rebal_job_prep(RebalIn in, unsigned pj) {
+__global__ void __launch_bounds__(COOK_WAVE) rebal_job_prep(const RebalIn* __restrict__ inp, unsigned pj) {
+  const RebalIn& in = *inp;
   if (lane_id() == 0) in.ctl->n_changed = 0u, in.ctl->n_delta = 0u;  // nothing to re-score unless rebal_apply takes a decision
   rebal_job_prep_dev(in, pj, 0u);
 }
@@ -1019,85 +1061,124 @@ static __device__ __forceinline__ void rebal_host_pair(const RebalIn& in, const 
 // hosts with at most 64 items (running tasks + jobs placed this cycle): a wave takes two neighbouring hosts, half a wave each when
 // both hold at most 32 items (rebal_host_pair), else one after the other.  No LDS beyond 64 words per wave, few registers.  The launch
 // is bound by the instructions its waves issue.  Larger hosts are left to rebal_decide_big.
+// Two launches per job when in.thr_key != 0 (the decision is the arg-max of the hosts' keys, and a host's key is the DRU of one of its active items, or
+// the greatest key there is when its spare resources alone hold the job): phase 0 evaluates the hosts whose BOUND (in.hmax_key; all ones for a host
+// whose spare resources hold the job) reaches in.thr_key and raises in.best_key to the best key found; phase 1 evaluates the other hosts whose bound
+// reaches that key (an equal key still matters: the later host wins ties) — usually a few per cent of them.  A host left out cannot be the arg-max.
 template <bool SAFE>
-__global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(RebalIn in) {
+__global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide(const RebalIn* __restrict__ inp, unsigned phase) {
+  const RebalIn& in = *inp;
   __shared__ uint32_t l_rank[RB_WAVES][COOK_WAVE];
   __shared__ unsigned long long s_bk[RB_WAVES];
   __shared__ unsigned s_bh[RB_WAVES];
+  __shared__ unsigned s_q[RB_PAIRS], s_nq;
+  // the second phase has nothing to do when the first one's best key reaches the threshold (every host left has a bound below it): the usual case, and
+  // rebal_apply then does not read this phase's entries
+  if (phase != 0u && *in.best_key >= in.thr_key) return;
   const RebalJob jb = *in.job;
   if (!jb.active) return;
   const unsigned lane = lane_id(), w = wave_id();
-  const unsigned h0 = (blockIdx.x * RB_WAVES + w) * 2u;
-  // the wave's better host (the later one on ties), then the workgroup's: rebal_apply's arg-max reads one entry per workgroup
+  // (1) which of the workgroup's RB_PAIRS pairs of hosts are this phase's: a thread per pair, the pairs to evaluate into a list.  (Evaluating a host that
+  // is not this phase's does no harm — its result is the same — so a pair goes by its better host.)
+  if (threadIdx.x == 0) s_nq = 0u;
+  __syncthreads();
+  if (threadIdx.x < (unsigned)RB_PAIRS) {
+    const unsigned pr = blockIdx.x * (unsigned)RB_PAIRS + threadIdx.x;
+    bool mine = false;
+    if (2u * pr < in.H) {
+      if (in.thr_key == 0ull) {
+        mine = true;
+      } else {
+        const unsigned long long best = phase ? *in.best_key : 0ull;
+        for (unsigned q = 0; q < 2u && 2u * pr + q < in.H; ++q) {
+          const unsigned h = 2u * pr + q;
+          unsigned long long bd = in.hmax_key[h];
+          if (in.has_spare[h] != 0) {
+            const double sc = 0.0 + in.spare_c[h], sm = 0.0 + in.spare_m[h], sg = 0.0 + in.spare_g[h];
+            if (sm >= jb.m && sc >= jb.c && (jb.has_gpus != 0 ? sg >= jb.g : true)) bd = ~0ull;
+          }
+          mine = mine || (phase == 0u ? bd >= in.thr_key : (bd < in.thr_key && bd >= best && bd != 0ull));
+        }
+      }
+    }
+    if (mine) s_q[atomicAdd(&s_nq, 1u)] = pr;
+  }
+  __syncthreads();
+  const unsigned nq = s_nq;
+  // (2) the listed pairs, a wave each in turn.  The wave's better host (the later one on ties), then the workgroup's: rebal_apply's arg-max reads one
+  // entry per workgroup and phase
   unsigned long long wk = 0ull;
   unsigned wh = 0u;
-  auto publish = [&] {
-    if (lane == 0) s_bk[w] = wk, s_bh[w] = wh;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned long long bk = 0ull;
-      unsigned bh = 0u;
-      for (int k = 0; k < RB_WAVES; ++k)
-        if (s_bk[k] != 0ull && s_bk[k] >= bk) bk = s_bk[k], bh = s_bh[k];
-      in.blk_key[blockIdx.x] = bk;
-      in.blk_host[blockIdx.x] = bh;
+  auto take = [&](unsigned long long k, unsigned h) {
+    if (k != 0ull && (k > wk || (k == wk && h > wh))) wk = k, wh = h;  // (wave-uniform)
+  };
+  auto eval_pair = [&](unsigned h0) {
+    const bool two = h0 + 1u < in.H;
+#ifdef RB_COUNT  // study build: waves that evaluate, per phase (rebalance_run prints them)
+    if (lane == 0) atomicAdd(&in.best_key[1u + phase], 1ull);
+    if (lane == 0 && jb.below) atomicAdd(&in.best_key[3u], 1ull);
+#endif
+    const unsigned n0 = in.hend[h0] - in.hstart[h0] + in.x_cnt[h0];
+    const unsigned n1 = two ? in.hend[h0 + 1u] - in.hstart[h0 + 1u] + in.x_cnt[h0 + 1u] : 0u;
+    if (n0 <= 32u && n1 <= 32u && jb.gtype == 0u) {
+      HostBest hb;
+      rebal_host_pair<SAFE>(in, jb, h0, l_rank[w], hb);
+      if ((lane & 31u) == 0u && h0 + (lane >> 5) < in.H) {
+        const unsigned h = h0 + (lane >> 5);
+        in.hres_key[h] = hb.key;
+        if (hb.key != 0ull) {
+          in.hres_len[h] = hb.len;
+          in.hres_base[h] = 0xFFFFFFFFu;  // rebal_apply re-derives the preempted prefix of a small host itself
+          in.hres_dru[h] = hb.dru;
+          in.hres_c[h] = hb.c;
+          in.hres_m[h] = hb.m;
+          in.hres_g[h] = hb.g;
+        }
+      }
+      const unsigned long long k0 = wave_read_lane_u64(hb.key, 0), k1 = two ? wave_read_lane_u64(hb.key, 32) : 0ull;
+      take(k0, h0);
+      take(k1, h0 + 1u);
+      return;
+    }
+    for (unsigned q = 0; q < (two ? 2u : 1u); ++q) {
+      const unsigned h = h0 + q;
+      const unsigned hs = in.hstart[h], n_seg = in.hend[h] - hs;
+      const unsigned n_here = in.x_cnt[h];  // jobs placed on this host earlier in the cycle
+      const unsigned n = n_seg + n_here;
+      const bool sp = in.has_spare[h] != 0;
+      if (n > (unsigned)COOK_WAVE) continue;  // rebal_decide_big's
+      HostBest hb;
+      hb.key = 0ull;
+      if (n != 0 || sp) {
+        unsigned ss;
+        rebal_host_small<SAFE>(in, jb, h, hs, n_seg, n_here, sp, l_rank[w], hb, ss);
+      }
+      if (lane == 0) {
+        in.hres_key[h] = hb.key;
+        if (hb.key != 0ull) {
+          in.hres_len[h] = hb.len;
+          in.hres_base[h] = 0xFFFFFFFFu;
+          in.hres_dru[h] = hb.dru;
+          in.hres_c[h] = hb.c;
+          in.hres_m[h] = hb.m;
+          in.hres_g[h] = hb.g;
+        }
+      }
+      take(hb.key, h);
     }
   };
-  if (h0 >= in.H) {
-    publish();
-    return;
+  for (unsigned i = w; i < nq; i += (unsigned)RB_WAVES) eval_pair(2u * s_q[i]);
+  if (lane == 0) s_bk[w] = wk, s_bh[w] = wh;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long bk = 0ull;
+    unsigned bh = 0u;
+    for (int k = 0; k < RB_WAVES; ++k)
+      if (s_bk[k] != 0ull && (s_bk[k] > bk || (s_bk[k] == bk && s_bh[k] > bh))) bk = s_bk[k], bh = s_bh[k];
+    in.blk_key[phase * in.n_blk + blockIdx.x] = bk;
+    in.blk_host[phase * in.n_blk + blockIdx.x] = bh;
+    if (in.thr_key != 0ull && phase == 0u && bk != 0ull) atomicMax(in.best_key, bk);
   }
-  const bool two = h0 + 1u < in.H;
-  const unsigned n0 = in.hend[h0] - in.hstart[h0] + in.x_cnt[h0];
-  const unsigned n1 = two ? in.hend[h0 + 1u] - in.hstart[h0 + 1u] + in.x_cnt[h0 + 1u] : 0u;
-  if (n0 <= 32u && n1 <= 32u && jb.gtype == 0u) {
-    HostBest hb;
-    rebal_host_pair<SAFE>(in, jb, h0, l_rank[w], hb);
-    if ((lane & 31u) == 0u && h0 + (lane >> 5) < in.H) {
-      const unsigned h = h0 + (lane >> 5);
-      in.hres_key[h] = hb.key;
-      if (hb.key != 0ull) {
-        in.hres_len[h] = hb.len;
-        in.hres_base[h] = 0xFFFFFFFFu;  // rebal_apply re-derives the preempted prefix of a small host itself
-        in.hres_dru[h] = hb.dru;
-        in.hres_c[h] = hb.c;
-        in.hres_m[h] = hb.m;
-        in.hres_g[h] = hb.g;
-      }
-    }
-    const unsigned long long k0 = wave_read_lane_u64(hb.key, 0), k1 = two ? wave_read_lane_u64(hb.key, 32) : 0ull;
-    if (k1 != 0ull && k1 >= k0) wk = k1, wh = h0 + 1u;
-    else wk = k0, wh = h0;
-    publish();
-    return;
-  }
-  for (unsigned q = 0; q < (two ? 2u : 1u); ++q) {
-    const unsigned h = h0 + q;
-    const unsigned hs = in.hstart[h], n_seg = in.hend[h] - hs;
-    const unsigned n_here = in.x_cnt[h];  // jobs placed on this host earlier in the cycle
-    const unsigned n = n_seg + n_here;
-    const bool sp = in.has_spare[h] != 0;
-    if (n > (unsigned)COOK_WAVE) continue;  // rebal_decide_big's
-    HostBest hb;
-    hb.key = 0ull;
-    if (n != 0 || sp) {
-      unsigned ss;
-      rebal_host_small<SAFE>(in, jb, h, hs, n_seg, n_here, sp, l_rank[w], hb, ss);
-    }
-    if (lane == 0) {
-      in.hres_key[h] = hb.key;
-      if (hb.key != 0ull) {
-        in.hres_len[h] = hb.len;
-        in.hres_base[h] = 0xFFFFFFFFu;
-        in.hres_dru[h] = hb.dru;
-        in.hres_c[h] = hb.c;
-        in.hres_m[h] = hb.m;
-        in.hres_g[h] = hb.g;
-      }
-    }
-    if (hb.key != 0ull && hb.key >= wk) wk = hb.key, wh = h;  // (wave-uniform)
-  }
-  publish();
 }
 
 // hosts with more than 64 items: lists in LDS (<= RB_CAP) or in the host's region of the global scratch.  Such hosts are few or none
@@ -1288,7 +1369,8 @@ static __device__ void rebal_host_big(const RebalIn& in, const RebalJob& jb, uns
   }
 }
 
-__global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide_big(RebalIn in) {
+__global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide_big(const RebalIn* __restrict__ inp) {
+  const RebalIn& in = *inp;
   __shared__ BigLds s_l[RB_WAVES];
   const RebalJob jb = *in.job;
   if (!jb.active) return;
@@ -1304,29 +1386,35 @@ __global__ void __launch_bounds__(COOK_WAVE* RB_WAVES) rebal_decide_big(RebalIn 
 constexpr int RB_APPLY_THREADS = 1024;
 // pj_next != COOK_NONE (every user safe, rebalance_run): the workgroup goes on to prepare the NEXT pending job (rebal_job_prep_dev
 // with this decision's flips) — one launch less per pending job; the re-scoring of the changed users follows as rebal_rs_delta.
-__global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in, unsigned pj_next) {
+__global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(const RebalIn* __restrict__ inp, unsigned pj_next) {
+  const RebalIn& in = *inp;
   __shared__ unsigned long long s_key[RB_APPLY_THREADS / COOK_WAVE];
   __shared__ unsigned s_host[RB_APPLY_THREADS / COOK_WAVE];
   __shared__ uint32_t s_rank[COOK_WAVE], s_pre[COOK_WAVE];
   const RebalJob jb = *in.job;
   if (!jb.active) return;  // the budget is spent: the next job stays inactive too
   const unsigned tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  // (both phases of this job's rebal_decide are behind this launch: the next job's start from no best key)
+  const unsigned long long best0 = in.thr_key != 0ull ? *in.best_key : 0ull;
+  __syncthreads();
+  if (tid == 0 && in.thr_key != 0ull) *in.best_key = 0ull;
   // arg-max of the hosts' keys, the later host winning ties (max-key, rebalancer.clj:404).  Eight independent loads in flight per
   // thread: a dependent one-load-per-iteration loop over 50k hosts was the larger half of this kernel.
   unsigned long long bk = 0ull;
   unsigned bh = 0;
-  for (unsigned b0 = tid; b0 < in.n_blk; b0 += 8u * RB_APPLY_THREADS) {  // one entry per rebal_decide workgroup (eight hosts)
+  const unsigned n_ent = (in.thr_key != 0ull && best0 < in.thr_key) ? 2u * in.n_blk : in.n_blk;  // one entry per rebal_decide workgroup and phase that ran
+  for (unsigned b0 = tid; b0 < n_ent; b0 += 8u * RB_APPLY_THREADS) {
     unsigned long long k[8];
     unsigned hh[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const unsigned b = b0 + (unsigned)q * RB_APPLY_THREADS;
-      k[q] = b < in.n_blk ? in.blk_key[b] : 0ull;
-      hh[q] = b < in.n_blk ? in.blk_host[b] : 0u;
+      k[q] = b < n_ent ? in.blk_key[b] : 0ull;
+      hh[q] = b < n_ent ? in.blk_host[b] : 0u;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      if (k[q] != 0ull && k[q] >= bk) bk = k[q], bh = hh[q];  // workgroups ascend with their hosts: the later host wins ties
+      if (k[q] != 0ull && (k[q] > bk || (k[q] == bk && hh[q] >= bh))) bk = k[q], bh = hh[q];  // the later host wins ties
   }
   // hosts of more than 64 items are rebal_decide_big's: their keys are not in any workgroup's entry
   for (unsigned x = tid; x < in.ctl->n_big; x += RB_APPLY_THREADS) {
@@ -1411,6 +1499,7 @@ __global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(RebalIn in, unsi
       in.x_next[jb.pj] = in.x_head[h];  // joins the host's chain of placed jobs
       in.x_head[h] = jb.pj;
       in.x_cnt[h] += 1u;
+      in.hmax_key[h] = ~0ull;  // (the placed job's DRU is not in the host-ordered mirror: the host is evaluated for every job from now on)
       if (in.hend[h] - in.hstart[h] + in.x_cnt[h] > c.max_items) c.max_items = in.hend[h] - in.hstart[h] + in.x_cnt[h];
       if (in.hend[h] - in.hstart[h] <= (unsigned)COOK_WAVE && in.hend[h] - in.hstart[h] + in.x_cnt[h] == (unsigned)COOK_WAVE + 1u)
         in.big_list[c.n_big++] = h;  // this placement takes the host past 64 items
