@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip SURVEY.md §8d's reporting matrix (K = 1000 / 1e5, good-enough 0.8, C2, C3) under extra_configs")
     ap.add_argument("--boundary", action="store_true", help="run the boundary leg (cook_cycle_update from page-locked columns) even with --no-extras")
     ap.add_argument("--as-rank-of", type=int, default=0, help="single process: time only the pools rank 0 of an N-GPU job would hold (the per-GPU load behind DESIGN.md's scaling prediction; not a bench line)")
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
+                    help="strong: the cluster of --pools pools over N GPUs (the default: BASELINE's metric); weak: --pools pools PER GPU — a cluster of N x --pools "
+                         "pools with N x the jobs, tasks and offers (what uses a node: one pool is one chain, DESIGN.md 8)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of the timed configuration (rank 0's first and last pool vs the oracle, after the timed region)")
     # rehearsal of the multi-process path on a machine without GPUs (tests/test_sharding_gloo.py): the engines load the given build of
     # the library (the SIMT emulator, test infrastructure) and the collectives run over gloo.  Never a bench line: `data` says so.
@@ -378,6 +381,7 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    os.environ.setdefault("COOK_POOL_USAGE_MEMO", "0")  # the timed cycles sum the pools' running usage every time, as a live cycle (a new task table) does
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per pool stream (read at HIP initialisation; see cook_amd/engine.py)
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # (the default of this ROCm build; see cook_amd/engine.py)
     import torch
@@ -410,11 +414,13 @@ def main():
     from cook_amd import synth
     from cook_amd.engine import Engine
 
-    P = args.pools
+    weak = args.scaling == "weak"
+    grow = world if weak else 1  # weak scaling: every GPU brings --pools pools of the same size with it
+    P = args.pools * grow
     from cook_amd import workload
     from cook_amd.sharding import pools_of_rank
     my_pools = pools_of_rank(P, world, rank) if not args.as_rank_of else pools_of_rank(P, args.as_rank_of, 0)
-    spec = workload.ClusterSpec(pools=P, pending=args.pending, running=args.running, offers=args.offers, users=args.users,
+    spec = workload.ClusterSpec(pools=P, pending=args.pending * grow, running=args.running * grow, offers=args.offers * grow, users=args.users,
                                 constraints=not args.no_constraints)
     n_pend, n_run, n_off = spec.per_pool
     params = A.default_params(good_enough_fitness=args.good_enough, match_algo=args.match_algo)
@@ -836,9 +842,10 @@ def main():
         value = args.steps / elapsed
         lat_ms = sorted(x * 1e3 for x in lat)
         out = {
-            "metric": "match-cycles/sec at 1M pending x 50k offers", "value": value, "unit": "cycles/s",
+            "metric": "match-cycles/sec at 1M pending x 50k offers" if not weak else f"match-cycles/sec at {world}M pending x {50 * world}k offers (weak scaling: 1M x 50k per GPU)",
+            "value": value, "unit": "cycles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "p50_cycle_latency_ms": lat_ms[len(lat_ms) // 2], "higher_is_better": True, "scaling": "strong",
+            "p50_cycle_latency_ms": lat_ms[len(lat_ms) // 2], "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL on the SIMT emulator (CPU, gloo): plumbing only, not a measurement",
             "config": {"workload": f"{P} pools x ({n_pend} pending + {n_run} running tasks, {n_off} offers), {args.users} users; "
                                    f"rank all tasks + match K={K} per pool"
@@ -847,6 +854,8 @@ def main():
                        "users": args.users, "considerable_per_pool": K, "good_enough_fitness": args.good_enough, "match_algo": args.match_algo,
                        "parallelism": f"pools sharded over {world} GPU(s); per rank up to {cluster.max_chains} pools as launch chains of their own, more than that as served walkers "
                                       f"(one persistent walker workgroup per pool beside evaluation launches)" + ("" if cluster.served else "; COOK_MATCH_SERVED=0: lockstep groups instead"), "pair_evaluations_per_cycle": considered * n_off},
+            # (weak scaling: the cycle grows with the node — the figure that compares across N is pairs per second, not cycles)
+            "pair_evaluations_per_s": considered * n_off * value,
             "last_cycle": {"ranked": ranked_n, "considered": considered, "matched": matched,
                            "stage_ms_pool0": {"rank": stage_ms[my_pools[0]][0], "match": stage_ms[my_pools[0]][1]},
                            "placement_stats_pool0": engines[my_pools[0]].match_stats()},
@@ -855,7 +864,7 @@ def main():
             # the rank parts of the rank's pools as ONE joint sequence of launches (cook_cycle_run_rank_multi; COOK_RANK_BATCH=0: a thread and a
             # stream per pool): launches made, of them for more than one pool, operations issued on their own, stream synchronisations
             "rank_batch": rank_batch_report([engines[p].match_stats() for p in my_pools]),
-            "setup_s": gen_s,
+            "setup_s": gen_s, "pool_usage_memo": os.environ.get("COOK_POOL_USAGE_MEMO") != "0",
             "collective": collective, "roofline": roofline, "cpu_baseline": cpu, "adjacent_rows": adjacent, "extra_configs": extra, "boundary": boundary,
             "parity_checked": parity_checked, "parity": {"against": "oracle (bit-exact rank order + every assignment)", "pools": parity_pools},
         }

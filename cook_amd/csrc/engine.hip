@@ -775,7 +775,9 @@ void rank_stage(cook_engine* e, const cook_tasks* t, const cook_users* u) {
 
 void rank_pool_usage(cook_engine* e, cook_usage* out) {
   if (!e->rank_staged) e->fail(COOK_E_STATE, "cook_rank_pool_usage before cook_rank_stage");
-  if (e->pool_usage_known) {  // summed for this very table already (cook_rank_stage / cook_cycle_update forget it)
+  // (COOK_POOL_USAGE_MEMO=0: sum it every time — bench.py's timed cycles keep one table resident, a live cycle arrives with a new one)
+  static const bool memo = [] { const char* v = std::getenv("COOK_POOL_USAGE_MEMO"); return !(v && v[0] == '0'); }();
+  if (e->pool_usage_known && memo) {  // summed for this very table already (cook_rank_stage / cook_cycle_update forget it)
     *out = e->pool_usage_val;
     return;
   }

@@ -3,7 +3,7 @@
 the second run finds the first one's leftovers).  TEST TOOL (uses the oracle)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from cook_amd import _abi as A, synth
 from cook_amd.engine import Engine

@@ -4,7 +4,7 @@
 # usage: scripts/uniformity.sh <mangled kernel name> [extra hipcc flags]  ->  /tmp/uniformity_<name>.txt
 set -e
 KFN=$1; shift
-ROOT=$(cd "$(dirname "$0")/.." && pwd)
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 LL=/tmp/uniformity_$KFN.ll
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-fast-math -ffp-contract=off --cuda-device-only -emit-llvm -S -o /tmp/uniformity_all.ll \
   "$ROOT/cook_amd/csrc/engine.hip" "$@" 2>/dev/null

@@ -4,7 +4,7 @@ many times over, to catch the occasional slow update (one 8.9 ms call among fift
 account of the call (cook_match_stats_ex [26..28]) and the host's (per-thread wall time of every engine's call).
 usage: update_outliers8.py [iterations] [serial]     (serial: the updates one after the other in the main thread)"""
 import gc, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
 import torch

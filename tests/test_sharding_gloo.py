@@ -250,3 +250,11 @@ def test_bench_self_launches_world2_over_gloo():
     assert d1["collective"]["world_size"] == 1 and d1["collective"]["pools_of_rank"] == [[0, 1, 2, 3]]
     assert cb["value"] == max(v["cycles_per_s"] for v in cb["variants"]) and cb["cores"] >= 1
     assert d1["last_cycle"]["matched"] == doc["last_cycle"]["matched"]  # the sharded job places what the single process places
+    # weak scaling: --pools pools PER rank — two ranks hold a cluster of 8 pools with twice the jobs, tasks and offers; the collective's record lists them all
+    cmdw = cmd + ["--scaling", "weak", "--no-cpu-baseline"]
+    rw = subprocess.run(cmdw, env=env, capture_output=True, text=True, timeout=800)
+    assert rw.returncode == 0, rw.stderr[-3000:]
+    dw = json.loads([ln for ln in rw.stdout.splitlines() if ln.startswith("{")][0])
+    assert dw["scaling"] == "weak" and dw["n_gpus"] == 2 and dw["config"]["pools"] == 8 and dw["config"]["pending_total"] == 2 * doc["config"]["pending_total"]
+    assert dw["collective"]["pools_of_rank"] == [[0, 2, 4, 6], [1, 3, 5, 7]] and dw["collective"]["group_usage_equals_sum_over_all_pools"] is True
+    assert dw["parity_checked"] is True and dw["pair_evaluations_per_s"] > 0
