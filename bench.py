@@ -66,7 +66,7 @@ def parse():
 
 # match_walkers / match_serve_*: the served form of the same three phases (one persistent walker workgroup per pool, ONE launch per cycle,
 # beside evaluation + merge launches for the pools that asked: cook_amd/csrc/match_v2.hpp "served walkers")
-PLACEMENT_KERNELS = ("match_resolve2", "match_eval2", "match_merge2", "match_serial", "match_walkers", "match_serve_eval", "match_serve_merge")
+PLACEMENT_KERNELS = ("match_resolve2", "match_eval2", "match_merge2", "match_serial", "match_walkers", "match_serve_eval", "match_serve_merge", "cf_walk")
 
 
 def rank_batch_report(stats):
@@ -491,6 +491,8 @@ def main():
         considered += len(j2o)
         matched += int((j2o >= 0).sum())
         stage_ms[p] = engines[p].last_timing()
+    timed_stats = engines[my_pools[0]].match_stats()  # of the LAST TIMED cycle (the extras below run other forms)
+    timed_form = timed_stats.get("placement_form", 0)
     cnt = torch.tensor([matched, considered, ranked_n], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
@@ -548,6 +550,8 @@ def main():
             served_mode = engines[my_pools[0]].match_stats().get("served_mode", 0)
             if served_mode and dom == "match_walkers":
                 pools_per_launch = float(len(my_pools))  # ONE walker launch per cycle places every pool of the rank
+            if dom == "cf_walk":
+                pools_per_launch = 1.0 / max(1e-9, launches_per_match)  # class-ordered best fit: ONE ordinary launch, a workgroup per pool (blockIdx.x = pool)
             nbytes = algorithmic_bytes(dom, n_pend + n_run, min(K, n_pend), n_off, launches_per_match, pools_per_launch)
             achieved = (nbytes / (avg_ms * 1e-3) / 1e9) if (nbytes and avg_ms > 0) else None
             total_ms = sum(v[0] for v in agg.values())
@@ -560,7 +564,9 @@ def main():
                         "note": "placement is a sequential dependency chain (job i+1 sees job i's commitment): "
                                 "latency-bound, not bandwidth-bound; see DESIGN.md"
                                 + ("; match_walkers is ONE persistent launch per cycle (a walker workgroup per pool) whose duration includes the time its "
-                                   "walkers wait for their windows to be evaluated" if dom == "match_walkers" else ""),
+                                   "walkers wait for their windows to be evaluated" if dom == "match_walkers" else "")
+                                + ("; cf_walk (class-ordered best fit, DESIGN.md 4b) is ONE ordinary launch per cycle, one workgroup of 16 waves per pool, all state in "
+                                   "LDS: the K x M pair evaluation of the reference is never made, so the bytes it moves are far below the algorithmic figure" if dom == "cf_walk" else ""),
                         "kernels_ms_per_cycle": {k: round(v[0] / max(1, min(args.steps, 3)), 4) for k, v in
                                                  sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]}}
 
@@ -702,20 +708,24 @@ def main():
             raise  # a parity failure must not produce a bench line
         except Exception as ex:  # (an extra must never cost the headline its line)
             extra["C5"] = {"error": repr(ex)}
-        # ---- the class-ordered best fit (match_algo 3) on the headline cluster: one launch, a workgroup per pool, no evaluation launches
-        p3 = A.default_params(good_enough_fitness=args.good_enough, match_algo=3)
-        for e in engines.values():
-            e.set_params(p3)
-        ts = timed(lambda: cluster.cycle(K), 3)
-        f3 = {p: engines[p].cycle_fetch() for p in my_pools}
-        st3 = engines[my_pools[0]].match_stats()
-        same = all(np.array_equal(f3[p][1], fetched[p][1]) for p in my_pools)
-        assert same, "PARITY: class-ordered best fit differs from the timed cycle's assignments"
-        extra["classfit"] = {"what": f"the same cluster and K = {K}, cook_params.match_algo = 3 (class-ordered best fit)", "cycles": len(ts), "p50_cycle_ms": pct(ts, 0.5) * 1e3,
-                             "placed_by_classfit_pool0": st3.get("placement_form") == 3, "identical_to_timed_cycle": True,
-                             "stage_ms_pool0": dict(zip(("rank", "match"), engines[my_pools[0]].last_timing())), "placement_stats_pool0": st3}
-        ts = timed(lambda: cluster.cycle(1000), 40, warm=3)
-        extra["classfit"]["K=1000"] = {"p50_cycle_us": pct(ts, 0.5) * 1e6, "p95_cycle_us": pct(ts, 0.95) * 1e6}
+        # ---- both placement forms on the headline cluster, whichever the engine's own choice (match_algo 0) took in the timed cycles: class-ordered best fit
+        #      (match_algo 3; DESIGN.md §4b: one launch, a workgroup per pool, no evaluation launches) and the window rounds (2; served walkers)
+        for key, algo in (("classfit", 3), ("window_rounds", 2)):
+            px = A.default_params(good_enough_fitness=args.good_enough, match_algo=algo)
+            for e in engines.values():
+                e.set_params(px)
+            ts = timed(lambda: cluster.cycle(K), 3)
+            fx = {p: engines[p].cycle_fetch() for p in my_pools}
+            stx = engines[my_pools[0]].match_stats()
+            same = all(np.array_equal(fx[p][1], fetched[p][1]) for p in my_pools)
+            assert same, f"PARITY: match_algo {algo} differs from the timed cycle's assignments"
+            extra[key] = {"what": f"the same cluster and K = {K}, cook_params.match_algo = {algo} ({'class-ordered best fit' if algo == 3 else 'window rounds'})", "cycles": len(ts),
+                          "p50_cycle_ms": pct(ts, 0.5) * 1e3, "placement_form_pool0": stx.get("placement_form"), "identical_to_timed_cycle": True,
+                          "stage_ms_pool0": dict(zip(("rank", "match"), engines[my_pools[0]].last_timing())), "placement_stats_pool0": stx}
+            if algo == 3:
+                extra[key]["placed_by_classfit_pool0"] = stx.get("placement_form") == 3
+            ts = timed(lambda: cluster.cycle(1000), 40, warm=3)
+            extra[key]["K=1000"] = {"p50_cycle_us": pct(ts, 0.5) * 1e6, "p95_cycle_us": pct(ts, 0.95) * 1e6}
         for e in engines.values():
             e.set_params(params)
 
@@ -852,13 +862,15 @@ def main():
                                    + ("" if args.no_constraints else "; gpu dim + EQUALS/novel-host/unique-group constraints"),
                        "pools": P, "pending_total": n_pend * P, "running_total": n_run * P, "offers_total": n_off * P,
                        "users": args.users, "considerable_per_pool": K, "good_enough_fitness": args.good_enough, "match_algo": args.match_algo,
-                       "parallelism": f"pools sharded over {world} GPU(s); per rank up to {cluster.max_chains} pools as launch chains of their own, more than that as served walkers "
-                                      f"(one persistent walker workgroup per pool beside evaluation launches)" + ("" if cluster.served else "; COOK_MATCH_SERVED=0: lockstep groups instead"), "pair_evaluations_per_cycle": considered * n_off},
+                       "placement_form": {0: "window rounds", 1: "serial sweep", 3: "class-ordered best fit"}.get(timed_form, timed_form),
+                       "parallelism": f"pools sharded over {world} GPU(s); per rank up to {cluster.max_chains} pools as launch chains of window rounds of their own; five or more pools of a "
+                                      f"GPU by class-ordered best fit (ONE launch, a workgroup of 16 waves per pool, no evaluation launches) where a pool's numbers and constraints allow it, "
+                                      f"else as served walkers (one persistent walker workgroup per pool beside evaluation launches)" + ("" if cluster.served else "; COOK_MATCH_SERVED=0: lockstep groups instead"), "pair_evaluations_per_cycle": considered * n_off},
             # (weak scaling: the cycle grows with the node — the figure that compares across N is pairs per second, not cycles)
             "pair_evaluations_per_s": considered * n_off * value,
             "last_cycle": {"ranked": ranked_n, "considered": considered, "matched": matched,
                            "stage_ms_pool0": {"rank": stage_ms[my_pools[0]][0], "match": stage_ms[my_pools[0]][1]},
-                           "placement_stats_pool0": engines[my_pools[0]].match_stats()},
+                           "placement_stats_pool0": timed_stats},
             "phase_ms": dict(zip(("pool_usage_allreduce", "rank", "placement", "user_usage_allreduce"),
                                  (float(np.median([ph[x] for ph in phases])) for x in range(4)))),
             # the rank parts of the rank's pools as ONE joint sequence of launches (cook_cycle_run_rank_multi; COOK_RANK_BATCH=0: a thread and a

@@ -375,6 +375,18 @@ JNIEXPORT jint JNICALL Java_cook_hip_Native_cycleRunRankMulti(JNIEnv* env, jclas
   }
   return cook_cycle_run_rank_multi(es, (uint32_t)n, ks, 0, 0);
 }
+/* the running usage of n staged engines of one device in ONE call (cook_rank_pool_usage_multi): usage_out = direct buffer of n cook_usage */
+JNIEXPORT jint JNICALL Java_cook_hip_Native_rankPoolUsageMulti(JNIEnv* env, jclass c, jobject handles /* direct buffer of n jlong */, jint n, jobject usage_out) {
+  cook_engine* es[64];
+  int bad = 0;
+  const int64_t* hs = BUFN(const int64_t, handles, n > 0 ? n : 0);
+  cook_usage* out = BUFN(cook_usage, usage_out, n > 0 ? n : 0);
+  jint i;
+  (void)c;
+  if (bad || !hs || !out || n <= 0 || n > 64) return COOK_E_INVALID;
+  for (i = 0; i < n; ++i) es[i] = H(hs[i]);
+  return cook_rank_pool_usage_multi(es, (uint32_t)n, out);
+}
 JNIEXPORT jint JNICALL Java_cook_hip_Native_cycleMatchMulti(JNIEnv* env, jclass c, jobject handles /* direct buffer of n jlong */, jint n) {
   cook_engine* es[64];
   int bad = 0;

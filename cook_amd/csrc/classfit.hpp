@@ -141,7 +141,7 @@ COOK_KERNEL void cf_scan(const MatchIn* __restrict__ inp, CfBuf b, unsigned K, u
           if (c.eq_key[q] >= 8u || c.eq_val[q] >= 256u) inelig |= CF_X_JOB_SLOW;
           else keys |= 1u << c.eq_key[q];
         }
-      if (keys) atomicOr(&b.ctl->eq_keys, keys);
+      if (keys && (keys & ~ld_agent(&b.ctl->eq_keys))) atomicOr(&b.ctl->eq_keys, keys);  // (read first: every wave would queue at ONE address)
     }
   }
   if (i < M) {
@@ -165,15 +165,17 @@ COOK_KERNEL void cf_scan(const MatchIn* __restrict__ inp, CfBuf b, unsigned K, u
     else inelig |= CF_X_OFFER;
   }
   if (bad) inelig |= CF_X_NUMBERS;
-  if (inelig) atomicOr(&b.ctl->inelig, inelig);
+  if (inelig && (inelig & ~ld_agent(&b.ctl->inelig))) atomicOr(&b.ctl->inelig, inelig);
   // (positive doubles order like their bit patterns)
   fbc = wave_max_u32(fbc), fbm = wave_max_u32(fbm);
   const unsigned long long c64 = wave_max_u64((unsigned long long)__double_as_longlong(mxc)), m64 = wave_max_u64((unsigned long long)__double_as_longlong(mxm)),
                            j64 = wave_max_u64((unsigned long long)__double_as_longlong(jmx));
-  if (lane_id() == 0) {
-    atomicMax(&b.ctl->fb_c, fbc), atomicMax(&b.ctl->fb_m, fbm);
-    atomicMax((unsigned long long*)&b.ctl->max_c_bits, c64), atomicMax((unsigned long long*)&b.ctl->max_m_bits, m64);
-    atomicMax((unsigned long long*)&b.ctl->jmax_c_bits, j64);
+  if (lane_id() == 0) {  // (a maximum already there needs no atomic: after the first waves nearly none is issued; a stale read only costs one)
+    if (fbc > ld_agent(&b.ctl->fb_c)) atomicMax(&b.ctl->fb_c, fbc);
+    if (fbm > ld_agent(&b.ctl->fb_m)) atomicMax(&b.ctl->fb_m, fbm);
+    if (c64 > ld_agent((const unsigned long long*)&b.ctl->max_c_bits)) atomicMax((unsigned long long*)&b.ctl->max_c_bits, c64);
+    if (m64 > ld_agent((const unsigned long long*)&b.ctl->max_m_bits)) atomicMax((unsigned long long*)&b.ctl->max_m_bits, m64);
+    if (j64 > ld_agent((const unsigned long long*)&b.ctl->jmax_c_bits)) atomicMax((unsigned long long*)&b.ctl->jmax_c_bits, j64);
   }
 }
 
@@ -181,8 +183,13 @@ COOK_KERNEL void cf_scan(const MatchIn* __restrict__ inp, CfBuf b, unsigned K, u
 static __device__ __forceinline__ int cf_tab_find64(unsigned long long* tab, unsigned long long key) {  // wait-free insert-or-find, 64 slots
   unsigned s = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 58);
   for (unsigned probe = 0; probe < 64u; ++probe) {
-    const unsigned long long old = atomicCAS(&tab[s], ~0ull, key);
-    if (old == ~0ull || old == key) return (int)s;
+    // (a look first: a wave's lanes mostly ask for the same few keys, and 64 compare-and-swaps on ONE LDS word take their turns; a slot that holds a key keeps it)
+    unsigned long long cur = ld_wg(&tab[s]);
+    if (cur == ~0ull) {
+      cur = atomicCAS(&tab[s], ~0ull, key);
+      if (cur == ~0ull) return (int)s;
+    }
+    if (cur == key) return (int)s;
     s = (s + 1u) & 63u;
   }
   return -1;
@@ -203,6 +210,9 @@ COOK_KERNEL void cf_prepare(const MatchIn* __restrict__ inp, CfBuf b, const doub
   __shared__ unsigned s_cnt[CF_MAXCLS], s_off[CF_MAXCLS];
   __shared__ unsigned s_bad, s_minfc, s_minfm, s_ncls;
   __shared__ unsigned long long s_dE[CF_MAXCLS];
+  __shared__ unsigned s_kind[CF_MAXCLS], s_wave[CF_MAXCLS];  // (thread 0's wave assignment reads these, not ctl->cls in global memory)
+  __shared__ unsigned long long sigs[CF_MAXKIND];            // thread 0's small tables: indexed at run time, so as locals they would live in scratch = global memory
+  __shared__ unsigned ck[CF_MAXCLS], cslot[CF_MAXCLS], load[CF_CW + 1], cnt[CF_CW + 1];
   const unsigned tid = threadIdx.x;
   CfCtl* ctl = b.ctl;
   if (tid == 0) {
@@ -246,17 +256,18 @@ COOK_KERNEL void cf_prepare(const MatchIn* __restrict__ inp, CfBuf b, const doub
     unsigned s = (pk * 2654435761u) >> 24;
     bool placed = false;
     for (unsigned probe = 0; probe < 256u && !placed; ++probe) {
-      const unsigned old = atomicCAS(&s_pair[s], 0xFFFFFFFFu, pk);
+      unsigned old = ld_wg(&s_pair[s]);
+      if (old == 0xFFFFFFFFu) old = atomicCAS(&s_pair[s], 0xFFFFFFFFu, pk);
       if (old == 0xFFFFFFFFu || old == pk) placed = true;
       else s = (s + 1u) & 255u;
     }
     if (!placed) bad |= CF_X_SHAPE;
-    atomicMin(&s_minfc, Lc), atomicMin(&s_minfm, Lm);
+    if (Lc < ld_wg(&s_minfc)) atomicMin(&s_minfc, Lc);
+    if (Lm < ld_wg(&s_minfm)) atomicMin(&s_minfm, Lm);
   }
   if (bad) atomicOr(&s_bad, bad);
   __syncthreads();
   if (tid == 0 && !s_bad) {  // a canonical order: kinds by signature (0 = no gpus first), classes by (kind, totals)
-    unsigned long long sigs[CF_MAXKIND];
     unsigned nk = 1;
     sigs[0] = 0ull;
     for (unsigned x = 0; x < 64u; ++x)
@@ -272,8 +283,7 @@ COOK_KERNEL void cf_prepare(const MatchIn* __restrict__ inp, CfBuf b, const doub
     for (unsigned x = 0; x < nk; ++x) ctl->kind_sig[x] = sigs[x];
     ctl->n_kind = nk;
     unsigned nc = 0;
-    unsigned long long ck[CF_MAXCLS];  // kind << 56 is too little for sorting with the totals: sort the slots by (kind, Tc, Tm) directly
-    unsigned cslot[CF_MAXCLS];
+    // (ck = a class's kind; kind << 56 is too little for sorting with the totals: sort the slots by (kind, Tc, Tm) directly)
     for (unsigned x = 0; x < 256u && !s_bad; ++x)
       if (s_pair[x] != 0xFFFFFFFFu) {
         if (nc >= (unsigned)CF_MAXCLS) {
@@ -288,7 +298,7 @@ COOK_KERNEL void cf_prepare(const MatchIn* __restrict__ inp, CfBuf b, const doub
         // insertion by (kind, shape)
         while (p > 0u) {
           const unsigned long long pshape = s_shape[s_pair[cslot[p - 1u]] >> 8];
-          const unsigned pkind = (unsigned)ck[p - 1u];
+          const unsigned pkind = ck[p - 1u];
           if (pkind < kind || (pkind == kind && pshape < shape)) break;
           ck[p] = ck[p - 1u], cslot[p] = cslot[p - 1u], --p;
         }
@@ -302,6 +312,7 @@ COOK_KERNEL void cf_prepare(const MatchIn* __restrict__ inp, CfBuf b, const doub
       cl.hTc = 0.5 / (double)cl.Tc, cl.hTm = 0.5 / (double)cl.Tm;
       cl.dE = (uint64_t)(CF_BAND * 2.0 * (double)cl.Tc * (double)cl.Tm);
       s_dE[c] = cl.dE;
+      s_kind[c] = (unsigned)ck[c];
       if (!(2.0 * (double)cl.Tc * (double)cl.Tm < 35184372088832.0)) s_bad |= CF_X_SHAPE;  // E below 2^45: the sort key is class | E | offer
     }
     s_ncls = nc;
@@ -365,23 +376,19 @@ COOK_KERNEL void cf_prepare(const MatchIn* __restrict__ inp, CfBuf b, const doub
     const unsigned nc = s_ncls;
     unsigned n0 = 0, any_gpu = 0;
     for (unsigned c = 0; c < nc; ++c) {
-      CfClass& cl = ctl->cls[c];
-      cl.n = s_cnt[c], cl.off = off, cl.wave = 0u;
-      off += cl.n;
-      if ((cl.n + 63u) / 64u > 64u) bad2 |= CF_X_SHAPE;
-      if (cl.kind == 0u) ++n0;
+      s_off[c] = off, s_wave[c] = 0u;
+      off += s_cnt[c];
+      if ((s_cnt[c] + 63u) / 64u > 64u) bad2 |= CF_X_SHAPE;
+      if (s_kind[c] == 0u) ++n0;
       else any_gpu = 1u;
     }
     const unsigned gw = any_gpu ? ((n0 + 2u <= (unsigned)CF_CW && ctl->n_kind > 2u) ? 2u : 1u) : 0u;
     const unsigned zw = (unsigned)CF_CW - gw;
-    unsigned load[CF_CW + 1], cnt[CF_CW + 1];
     for (unsigned x = 0; x <= (unsigned)CF_CW; ++x) load[x] = 0u, cnt[x] = 0u;
     for (unsigned round = 0; round < n0 && !bad2; ++round) {
       unsigned best = 0xFFFFFFFFu, bn = 0;
-      for (unsigned c = 0; c < nc; ++c) {  // the largest class without a wave
-        const CfClass& cl = ctl->cls[c];
-        if (cl.kind == 0u && cl.wave == 0u && (best == 0xFFFFFFFFu || cl.n > bn)) best = c, bn = cl.n;
-      }
+      for (unsigned c = 0; c < nc; ++c)  // the largest class without a wave
+        if (s_kind[c] == 0u && s_wave[c] == 0u && (best == 0xFFFFFFFFu || s_cnt[c] > bn)) best = c, bn = s_cnt[c];
       const unsigned nch = (bn + 63u) / 64u;
       unsigned wsel = 0;
       for (unsigned x = 1; x <= zw; ++x)
@@ -390,14 +397,17 @@ COOK_KERNEL void cf_prepare(const MatchIn* __restrict__ inp, CfBuf b, const doub
         bad2 |= CF_X_SHAPE;
         break;
       }
-      ctl->cls[best].wave = wsel, load[wsel] += nch, ++cnt[wsel];
+      s_wave[best] = wsel, load[wsel] += nch, ++cnt[wsel];
     }
     for (unsigned c = 0; c < nc && !bad2; ++c) {
-      CfClass& cl = ctl->cls[c];
-      if (cl.kind == 0u) continue;
-      const unsigned wsel = zw + 1u + (cl.kind - 1u) % gw;
-      cl.wave = wsel, load[wsel] += (cl.n + 63u) / 64u;
+      if (s_kind[c] == 0u) continue;
+      const unsigned wsel = zw + 1u + (s_kind[c] - 1u) % gw;
+      s_wave[c] = wsel, load[wsel] += (s_cnt[c] + 63u) / 64u;
       if (load[wsel] > 64u) bad2 |= CF_X_SHAPE;
+    }
+    for (unsigned c = 0; c < nc; ++c) {
+      CfClass& cl = ctl->cls[c];
+      cl.n = s_cnt[c], cl.off = s_off[c], cl.wave = s_wave[c];
     }
     // levels: 8 values between the smallest and the greatest cpus request (exact for up to 8 evenly spaced values: 1..8 cores)
     const uint32_t cmin = cf_fx(jmin[0], kc), cmax = cf_fx(__longlong_as_double((long long)ctl->jmax_c_bits), kc);

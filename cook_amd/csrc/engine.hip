@@ -1346,12 +1346,22 @@ static void launch_round(cook_engine* e, const MatchIn& in, const MatchState& st
 }
 
 // ---- class-ordered best fit (classfit.hpp): set-up, eligibility, launch --------------------------------------------------------------------
-// match_algo 3 asks for the class-ordered best fit; COOK_CLASSFIT=1 makes it the default form (match_algo 0) too — measured on MI355X (profiles/r06*): ahead of the
-// window rounds on BASELINE's C2 (30.7 against 31.6 ms), behind on a C4 pool (48.1 against 38.7 ms), so the default stays with the window rounds
-static const bool g_classfit_default = [] {
-  const char* v = std::getenv("COOK_CLASSFIT");
-  return v && v[0] == '1';
-}();
+// match_algo 3 asks for the class-ordered best fit.  match_algo 0 (the engine's choice) takes it when five or more engines share the device: its walks need no
+// evaluation launches, so eight pools cost what one costs (measured on MI355X, profiles/r06*: eight C4 pools 48.5 against 49.8 ms as served walkers, K = 1000 4.95
+// against 5.11 ms), while a pool that has the GPU (nearly) to itself is faster in window rounds (one C4 pool 38.3 against 44.5 ms).  COOK_CLASSFIT=1 / 0 forces / forbids
+// it for match_algo 0.  (A plain function, not a namespace-scope lambda initialiser: hipcc gave the second such initialiser the body of the first)
+static int classfit_env() {
+  static const int v = [] {
+    const char* s = std::getenv("COOK_CLASSFIT");
+    return s && (s[0] == '0' || s[0] == '1') ? s[0] - '0' : -1;
+  }();
+  return v;
+}
+static bool classfit_by_default(const cook_engine* e) {
+  const int f = classfit_env();
+  if (f >= 0) return f == 1;
+  return g_engines_on_device[e->device & 63].load() >= 5;
+}
 static size_t cf_lds_bytes_host(unsigned NP, unsigned M, bool eq, unsigned G, unsigned S) {  // the layout of cf_walk_pool (classfit_walk.hpp)
   size_t n = sizeof(CfFixed) + (size_t)NP * 10u;
   n = (n + 7u) & ~(size_t)7u;
@@ -1473,7 +1483,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
   e->has_deferred = false;
   const int algo = e->params.match_algo;
   if (!(algo == 0 || algo == 1 || algo == 2 || algo == 3))
-    e->fail(COOK_E_INVALID, "cook_params.match_algo: 0 = engine default (window rounds), 1 = serial sweep, 2 = window rounds, 3 = class-ordered best fit where the call allows it, else window rounds");
+    e->fail(COOK_E_INVALID, "cook_params.match_algo: 0 = engine default (window rounds; class-ordered best fit where the call allows it when five or more engines share the device), 1 = serial sweep, 2 = window rounds, 3 = class-ordered best fit where the call allows it, else window rounds");
   if (defer && !(algo != 1 && K > 0)) defer = false;  // only the window rounds run several pools in one launch
   const bool ge = in.good_enough < 1.0;
   if (algo == 1) {  // one-job-at-a-time sweep by a single workgroup (reference implementation of the chain)
@@ -1528,7 +1538,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
     if (M) KM<match_init_alive, 256>(e, "match_init_alive", div_up(M, 256), (const OfferA*)oa, M, st.jmin, st.alive);
     e->last_form = 0;
     e->has_deferred_cf = false;
-    if (algo == 3 || (algo == 0 && g_classfit_default)) {  // class-ordered best fit when the call's numbers and constraints allow it (classfit.hpp)
+    if (algo == 3 || (algo == 0 && classfit_by_default(e))) {  // class-ordered best fit when the call's numbers and constraints allow it (classfit.hpp)
       if (cf_setup(e, in, (const MatchIn*)vb.in_dev, st, jr, jcons, oa, ob, e->deferred_cf)) {
         e->cycle_considered = K;
         e->match_done = false;
@@ -2456,6 +2466,46 @@ int cook_cycle_run_rank_multi(cook_engine** engines, uint32_t n, const uint32_t*
   });
   for (uint32_t i = 0; i < n; ++i)
     if (flow_err[i].first != COOK_OK) engines[i]->err = flow_err[i].second;  // every engine whose flow failed keeps its own message
+  return rc != COOK_OK ? rc : flows_rc;
+}
+int cook_rank_pool_usage_multi(cook_engine** engines, uint32_t n, cook_usage* out) {
+  if (!engines || n == 0 || !out) return COOK_E_INVALID;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!engines[i]) return COOK_E_INVALID;
+    for (uint32_t k = 0; k < i; ++k)
+      if (engines[i] == engines[k]) return COOK_E_INVALID;
+  }
+  cook_engine* lead = engines[0];
+  bool same_device = true;
+  for (uint32_t i = 1; i < n; ++i) same_device = same_device && engines[i]->device == lead->device;
+  if (n == 1 || !g_rank_batch || !same_device || g_sync_trace || tl_flow) {
+    int first = COOK_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+      const int rc = cook_rank_pool_usage(engines[i], &out[i]);
+      if (rc != COOK_OK && first == COOK_OK) first = rc;
+    }
+    return first;
+  }
+  int flows_rc = COOK_OK;
+  std::vector<std::pair<int, std::string>> flow_err(n, {COOK_OK, std::string()});
+  const int rc = guarded(lead, [&] {
+    for (uint32_t i = 0; i < n; ++i) COOK_HIP(hipStreamSynchronize(engines[i]->stream));
+    PoolBatch b;
+    b.lead = lead;
+    b.stream = lead->stream;
+    b.flows.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      cook_engine* e = engines[i];
+      cook_usage* o = &out[i];
+      b.flows[i].e = e;
+      b.flows[i].body = [e, o] { rank_pool_usage(e, o); };
+    }
+    flows_rc = batch_run(b);
+    for (uint32_t i = 0; i < n; ++i)
+      if (b.flows[i].rc != COOK_OK) flow_err[i] = {b.flows[i].rc, engines[i]->err};
+  });
+  for (uint32_t i = 0; i < n; ++i)
+    if (flow_err[i].first != COOK_OK) engines[i]->err = flow_err[i].second;
   return rc != COOK_OK ? rc : flows_rc;
 }
 int cook_cycle_match_multi(cook_engine** engines, uint32_t n) {

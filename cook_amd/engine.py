@@ -482,6 +482,22 @@ class PinnedArena:
         self.close()
 
 
+def rank_pool_usage_multi(engines: Sequence[Engine]):
+    """rank_pool_usage of several engines of one device in ONE call (cook_rank_pool_usage_multi: the pools' sums as pool batches, one stream
+    synchronisation) -> a list of (count, cpus, mem, gpus) tuples, engines' order."""
+    if not engines:
+        return []
+    arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    out = (A.CookUsage * len(engines))()
+    rc = engines[0]._lib.cook_rank_pool_usage_multi(arr, len(engines), out)
+    if rc != 0:
+        for e in engines:
+            if e._lib.cook_last_error(e._h):
+                e._chk(rc)
+        engines[0]._chk(rc)
+    return [u.as_tuple() for u in out]
+
+
 def cycle_run_rank_multi(engines: Sequence[Engine], num_considerable, user_usage_ptrs: Optional[Sequence[int]] = None,
                          n_users: int = 0):
     """cycle_run_rank of several engines (pools of one rank, same device) in ONE call: the pools' rank flows side by side on one stream,

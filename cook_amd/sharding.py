@@ -214,7 +214,11 @@ class ShardedCluster:
         t0 = time.perf_counter()
         # (the library keeps a pool's usage until its task table changes: after the first cycle on a table the calls return at once, and
         #  handing them to the thread pool would cost more than making them — 0.25 ms of the benchmark's cycle)
-        if self._usage_warm:
+        native = len(self.pools) > 1 and self.rank_batch and all(hasattr(self.engines[p], "_h") for p in self.pools)
+        if native:  # the pools' sums side by side in ONE call (cook_rank_pool_usage_multi: one launch per kernel, one synchronisation)
+            from .engine import rank_pool_usage_multi
+            usages = dict(zip(self.pools, rank_pool_usage_multi([self.engines[p] for p in self.pools])))
+        elif self._usage_warm:
             usages = {p: self.engines[p].rank_pool_usage().as_tuple() for p in self.pools}
         else:
             usages = dict(zip(self.pools, self._tp.map(lambda p: self.engines[p].rank_pool_usage().as_tuple(), self.pools)))

@@ -56,7 +56,8 @@ typedef struct cook_params {
   double offensive_max_cpus;   /* task-constraints :cpus (scheduler.clj:2198-2203); +inf disables               */
   double good_enough_fitness;  /* config.clj:111 default 0.8; (> fitness x) at scheduler.clj:2312-2314; >=1 = off */
   int64_t host_lifetime_mins;  /* estimated-completion-config :host-lifetime-mins (constraints.clj:392-397)     */
-  int32_t match_algo;          /* 0 = engine default (= 2), 1 serial sweep (one workgroup, one job at a time: the reference form of the
+  int32_t match_algo;          /* 0 = engine default (= 2; = 3 when five or more engines share the device, COOK_CLASSFIT=0 / 1 forbids /
+                                  forces that), 1 serial sweep (one workgroup, one job at a time: the reference form of the
                                   chain), 2 window rounds (eval / merge / resolve launches), 3 class-ordered best fit (one workgroup per pool,
                                   no evaluation launches) where the call's numbers and constraints allow it, else as 2.
                                   Other values: COOK_E_INVALID.  Identical results */
@@ -273,6 +274,10 @@ int cook_rank_stage(cook_engine* e, const cook_tasks* tasks, const cook_users* u
 int cook_rank_set_quota(cook_engine* e, const cook_pool_quota* quota);
 /* running usage of the pool {count,cpus,mem,gpus} (scheduler.clj:2118-2123, 2173): input to the cross-pool all-reduce */
 int cook_rank_pool_usage(cook_engine* e, cook_usage* out);
+/* ... of n engines of one device in ONE call from one thread: the pools' sums side by side as pool batches (one launch per kernel for all of them, one
+ * stream synchronisation; cook_cycle_run_rank_multi has the mechanism), out[i] for engines[i].  Same numbers as the calls one by one (the reduction order
+ * of a pool does not depend on its neighbours).  An engine twice: COOK_E_INVALID. */
+int cook_rank_pool_usage_multi(cook_engine** engines, uint32_t n, cook_usage* out /* [n] */);
 int cook_rank_run(cook_engine* e);
 /* per-user running usage of the pool after cook_rank_run / cook_cycle_run*: usage[u*3 + {0,1,2}] = {cpus, mem, gpus} summed over user
  * u's RUNNING tasks in the user's task order (tools.clj:614-641).  This is the [U x 3] vector BASELINE.json's north_star

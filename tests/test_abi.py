@@ -99,7 +99,7 @@ def test_ctypes_prototypes_are_generated_from_the_header():
 def test_jni_shim_binds_the_hot_path_entry_points():
     # every entry point of the rank -> considerable -> match -> rebalance path has a JNI export; buffers are size-checked
     txt = open(os.path.join(ROOT, "bindings", "jni", "cookmatch_jni.c")).read()
-    for fn in ("cook_rank", "cook_rank_user_usage", "cook_considerable", "cook_match", "cook_match_count", "cook_cycle_stage",
+    for fn in ("cook_rank", "cook_rank_user_usage", "cook_rank_pool_usage_multi", "cook_considerable", "cook_match", "cook_match_count", "cook_cycle_stage",
                "cook_cycle_update", "cook_cycle_run", "cook_cycle_run_rank", "cook_cycle_run_rank_multi", "cook_cycle_match_multi", "cook_cycle_fetch",
                "cook_rebalance", "cook_offers_build", "cook_match_explain", "cook_match_metrics", "cook_host_alloc", "cook_host_free"):
         assert re.search(r"\b%s\(" % fn, txt), fn

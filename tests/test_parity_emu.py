@@ -351,15 +351,20 @@ def test_multi_pool_context_forms(make_engine, n, ge, multi_mode):
     P.multi_pool_parity(make_engine, pools, A.default_params(good_enough_fitness=ge, match_algo=2), k=10 ** 9)
 
 
-@pytest.mark.parametrize("whole", [True, False, None], ids=["chain-runs-rank-and-placement", "rank-barrier-placement", "served-walkers"])
+@pytest.mark.parametrize("whole", [True, False, None, "engine-choice"], ids=["chain-runs-rank-and-placement", "rank-barrier-placement", "served-walkers", "engine-choice"])
 def test_sharded_cluster_lockstep_chains(make_engine, whole, monkeypatch):
     # ShardedCluster.cycle as bench.py drives it, five pools on two launch chains (slots 3 + 2): quota inputs, rank per pool,
     # lockstep placement per chain; every pool against the oracle, on a repeated cycle
     from cook_amd import sharding, workload
     from oracle import checks
+    # "engine-choice": match_algo 0 with five engines on the device = class-ordered best fit for every eligible pool (one cf_walk launch, a workgroup per pool), the
+    # others by the served walkers; the first three forms pin the window rounds (match_algo 2)
+    auto = whole == "engine-choice"
+    if auto:
+        whole = None
     monkeypatch.setenv("COOK_MATCH_SERVED", "1" if whole is None else "0")  # (read by ShardedCluster and by the library)
     spec = workload.ClusterSpec(pools=5, pending=1500, running=500, offers=400, users=40)
-    params = A.default_params(good_enough_fitness=1.0)
+    params = A.default_params(good_enough_fitness=1.0, match_algo=0 if auto else 2)
     pools = workload.make_pools(spec, range(spec.pools))
     engines = {}
     try:
@@ -379,7 +384,11 @@ def test_sharded_cluster_lockstep_chains(make_engine, whole, monkeypatch):
         cl.cycle(K)
         cl.cycle(K)
         assert cl.last_phase_ms[1] > 0.0
-        assert engines[0].match_stats()["served_mode"] == (2 if whole is None else 0)  # (2: the stepping form, all the emulator can run)
+        if auto:
+            forms = [engines[p].match_stats()["placement_form"] for p in pools]
+            assert forms.count(3) >= 3 and set(forms) <= {0, 3}, forms
+        else:
+            assert engines[0].match_stats()["served_mode"] == (2 if whole is None else 0)  # (2: the stepping form, all the emulator can run)
         for p in pools:
             ranked, j2o, _ = engines[p].cycle_fetch()
             q = cl.quota_inputs(p, cl.last_pool_usage[p], cl.last_group_usage)

@@ -454,16 +454,21 @@ def test_rank_c5_queue_size(make_engine):
     assert len(ranked) > 100_000
 
 
-def test_timed_configuration_parity(make_engine, multi_mode):
+@pytest.mark.parametrize("form", ["engine-choice", "served", "lockstep"])
+def test_timed_configuration_parity(make_engine, form, monkeypatch):
     """The configuration bench.py TIMES, driven exactly as bench.py drives it (cook_amd/workload.py builds it for both): the 8
     pools of configs[3] on one rank, ShardedCluster.cycle = quota-group all-reduce inputs + rank per pool + the placements of
     all pools through the rank's multi-pool path — served walkers (the default: ONE persistent walker launch for the eight pools
     beside three streams of evaluation launches, LIVE on the GPU) and launch chains x lockstep slots (COOK_MATCH_SERVED=0).
-    Checked bit-exact against the oracle on a repeated cycle: pools of different servers / chains, first and second slots."""
+    Checked bit-exact against the oracle on a repeated cycle: pools of different servers / chains, first and second slots.
+    "engine-choice" = match_algo 0, what bench.py times: with eight engines on the device the engine places every eligible pool by class-ordered
+    best fit (ONE cf_walk launch, a workgroup per pool); the other two forms pin the window rounds (match_algo 2)."""
     from cook_amd import sharding, workload
     from oracle import checks
+    multi_mode = "served" if form == "engine-choice" else form
+    monkeypatch.setenv("COOK_MATCH_SERVED", "1" if multi_mode == "served" else "0")
     spec = workload.ClusterSpec()
-    params = A.default_params(good_enough_fitness=1.0)
+    params = A.default_params(good_enough_fitness=1.0, match_algo=0 if form == "engine-choice" else 2)
     pools = workload.make_pools(spec, range(spec.pools))
     engines = {}
     try:
@@ -475,8 +480,12 @@ def test_timed_configuration_parity(make_engine, multi_mode):
         cl.cycle(K)
         cl.cycle(K)  # the timed region repeats cycles on resident inputs: check a repeat, not the first call
         st0 = engines[0].match_stats()
-        assert st0["served_mode"] == (1 if multi_mode == "served" else 0) and st0["served_fell_back"] == 0
-        assert st0["rank_batch_pools"] >= 2 and st0["rank_batch_single_ops"] == 0, st0  # the ranks ran as joint sequences of launches (read-backs too)
+        if form == "engine-choice":
+            assert all(e.match_stats()["placement_form"] == 3 for e in engines.values()), st0  # every pool of the benchmark's cluster is eligible
+            assert st0["rank_batch_pools"] >= 2 and st0["rank_batch_single_ops"] <= 3 * st0["rank_batch_pools"], st0  # (alone: the three fills of the class tables' set-up)
+        else:
+            assert st0["placement_form"] == 0 and st0["served_mode"] == (1 if multi_mode == "served" else 0) and st0["served_fell_back"] == 0
+            assert st0["rank_batch_pools"] >= 2 and st0["rank_batch_single_ops"] == 0, st0  # the ranks ran as joint sequences of launches (read-backs too)
         n_chains = min(spec.pools, cl.max_chains)
         check = sorted({0, 1 % spec.pools, (n_chains + 1) % spec.pools, spec.pools - 1})  # chains 0, 1, 1 (second slot), last (second slot)
         for p in check:
@@ -514,7 +523,7 @@ def test_served_walkers_ragged_pools_many_cycles(make_engine, monkeypatch):
     sizes = [(30000, 1500), (900, 60), (12000, 3000), (150, 20), (20000, 800), (5000, 5000)]
     pools = [synth.make_pool(seed=900 + i, n_pending=npd, n_running=npd // 4, n_users=200, n_offers=m, gpus=(i % 2 == 0), constraints=(i % 3 != 1))
              for i, (npd, m) in enumerate(sizes)]
-    params = A.default_params(good_enough_fitness=1.0)
+    params = A.default_params(good_enough_fitness=1.0, match_algo=2)  # (the window rounds: with six engines on the device match_algo 0 would pick class-ordered best fit)
     engines = [make_engine(params) for _ in pools]
     try:
         for e, pool in zip(engines, pools):
