@@ -19,8 +19,26 @@
 //   clobbered: v[88:119], s[60:83], vcc, scc
 // Offsets into CfFixed (static_asserts in classfit_walk.hpp): ctrl 13728, class table 9472 (56 bytes a class, 0.5 / Tc at 32), the arrays' start 15280.
 #pragma once
+// the board's rows (CF_SLOTS_N, classfit_walk.hpp) move everything behind the board in CfFixed: the offsets as strings, per row count
+#if CF_SLOTS_N == 12
+#define CF_O_CTRL "13728"
+#define CF_O_CTRL4 "13732"
+#define CF_O_ARR "15280"
+#define CF_O_CLS32 "9504"
+#define CF_SLOT_SHIFT "9"
+#define CF_SLOT_N "12"
+#elif CF_SLOTS_N == 24
+#define CF_O_CTRL "16800"
+#define CF_O_CTRL4 "16804"
+#define CF_O_ARR "18352"
+#define CF_O_CLS32 "12576"
+#define CF_SLOT_SHIFT "10"
+#define CF_SLOT_N "24"
+#else
+#error "CF_SLOTS_N: 12 or 24"
+#endif
 #ifndef CF_ASM_WAIT_READS
-#define CF_ASM_WAIT_READS "12"
+#define CF_ASM_WAIT_READS "30"  // (measured on a C4 pool: 44.64 / 44.05 / 43.86 ms at 4 / 12 / 30)
 #endif
 #define CF_ASM_MAX_STEP(ctrl) "v_max_f32_dpp v113, v113, v113 " ctrl "\n\ts_nop 1\n\t"
 #define CF_ASM_DECIDER_STEP                                                                                                             \
@@ -36,7 +54,7 @@
   "v_mov_b32_e32 v89, s51\n\t"                                                                                                          \
   "v_add_u32_e32 v100, s46, v83\n\t"                                                                                                    \
   "s_mov_b64 exec, 1\n\t"                                                                                                               \
-  "ds_write_b32 v89, v88 offset:13732\n\t"                                                                                              \
+  "ds_write_b32 v89, v88 offset:" CF_O_CTRL4 "\n\t"                                                                                              \
   "s_mov_b64 exec, -1\n\t"                                                                                                              \
   "s_mov_b32 s82, " CF_ASM_WAIT_READS "\n\t" /* reads of the entries before a missing answer makes this the C++ step's job */             \
   "1:\n\t"                                                                                                                              \
@@ -252,8 +270,8 @@
   "v_mov_b32_e32 v91, s63\n\t"                                                                                                          \
   "v_mov_b32_e32 v100, s78\n\t"                                                                                                         \
   "s_mov_b64 exec, 1\n\t"                                                                                                               \
-  "ds_write_b64 v90, v[88:89] offset:15280\n\t"                                                                                         \
-  "ds_write_b32 v91, v100 offset:13732\n\t"                                                                                             \
+  "ds_write_b64 v90, v[88:89] offset:" CF_O_ARR "\n\t"                                                                                         \
+  "ds_write_b32 v91, v100 offset:" CF_O_CTRL4 "\n\t"                                                                                             \
   "s_mov_b64 exec, -1\n\t"                                                                                                              \
   "v_cmp_eq_u32_e64 vcc, s82, v84\n\t"                                                                                                  \
   "v_mov_b32_e32 v101, s73\n\t"                                                                                                         \
@@ -270,7 +288,7 @@
   "s_mul_i32 s62, s79, 56\n\t"                                                                                                          \
   "s_add_u32 s62, s62, s51\n\t"                                                                                                         \
   "v_mov_b32_e32 v90, s62\n\t"                                                                                                          \
-  "ds_read_b128 v[116:119], v90 offset:9504\n\t"                                                                                        \
+  "ds_read_b128 v[116:119], v90 offset:" CF_O_CLS32 "\n\t"                                                                                        \
   "s_andn2_b64 s[62:63], s[54:55], s[68:69]\n\t"                                                                                        \
   "s_ff1_i32_b64 s83, s[62:63]\n\t"                                                                                                     \
   "v_cmp_eq_u32_e64 vcc, s83, v84\n\t"                                                                                                  \
@@ -330,8 +348,8 @@
   "s_lshl_b32 s60, s45, 2\n\t"                                                                                                          \
   "s_add_u32 s60, s60, s44\n\t"                                                                                                         \
   "v_mov_b32_e32 v81, s60\n\t"                                                                                                          \
-  "ds_read_b64 v[82:83], v80 offset:13728\n\t" /* mode, head word */                                                                    \
-  "ds_read_b32 v84, v81 offset:13732\n\t"      /* removals from this set */                                                             \
+  "ds_read_b64 v[82:83], v80 offset:" CF_O_CTRL "\n\t" /* mode, head word */                                                                    \
+  "ds_read_b32 v84, v81 offset:" CF_O_CTRL4 "\n\t"      /* removals from this set */                                                             \
   "s_mov_b32 s41, 3\n\t"                                                                                                                \
   "s_waitcnt lgkmcnt(0)\n\t"                                                                                                            \
   "v_readfirstlane_b32 s61, v82\n\t"                                                                                                    \
@@ -394,8 +412,8 @@
   "v_cndmask_b32_e32 v80, v80, v82, vcc\n\t"                                                                                            \
   /* the entry's address: column s45 of row (ordinal mod 12); the tag */                                                               \
   "s_mul_i32 s68, s38, 43\n\t"                                                                                                          \
-  "s_lshr_b32 s68, s68, 9\n\t"                                                                                                          \
-  "s_mul_i32 s68, s68, 12\n\t"                                                                                                          \
+  "s_lshr_b32 s68, s68, " CF_SLOT_SHIFT "\n\t"                                                                                                          \
+  "s_mul_i32 s68, s68, " CF_SLOT_N "\n\t"                                                                                                          \
   "s_sub_u32 s68, s38, s68\n\t"                                                                                                         \
   "s_lshl_b32 s68, s68, 8\n\t"                                                                                                          \
   "s_lshl_b32 s69, s45, 5\n\t"                                                                                                          \
@@ -421,7 +439,7 @@
   "v_add_u32_e32 v98, s44, v98\n\t"                                                                                                     \
   "v_lshlrev_b32_e32 v99, 1, v97\n\t"                                                                                                   \
   "v_add_u32_e32 v99, s50, v99\n\t"                                                                                                     \
-  "ds_read_b64 v[84:85], v98 offset:15280\n\t"                                                                                          \
+  "ds_read_b64 v[84:85], v98 offset:" CF_O_ARR "\n\t"                                                                                          \
   "ds_read_u16 v90, v99\n\t"                                                                                                            \
   "s_waitcnt lgkmcnt(0)\n\t"                                                                                                            \
   "v_cmp_le_u32_e64 s[76:77], s65, v84\n\t"                                                                                             \

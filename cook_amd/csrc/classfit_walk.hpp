@@ -37,12 +37,17 @@
 #endif
 
 #ifndef CF_AHEAD
-#define CF_AHEAD 8  // (measured: a C4 pool 50.4 ms at 4, 49.1 at 6, 48.1 at 8)
+#define CF_AHEAD 10  // (measured: a C4 pool 50.4 ms at 4, 49.1 at 6, 48.1 at 8; later 44.05 at 8, 43.5 at 10; with 24 rows 43.45 / 43.41 / 43.98 at 12 / 16 / 22: the decider is the limit)
 #endif
 constexpr unsigned CF_BOARD = CF_AHEAD;  // steps the class waves may run ahead of the decider (at most CF_SLOTS - 2)
-constexpr unsigned CF_SLOTS = 12;   // entries per column of the board: walked ordinal modulo 12.  The waves that share a set's jobs take the ordinals in turn and
-                                    // their number divides 12, so a slot has ONE writer: a late answer of a slow wave lands where only that wave's next one goes
-static __device__ __forceinline__ unsigned cf_slot(unsigned ord) { return ord - CF_SLOTS * ((ord * 43u) >> 9); }  // ord % 12 for ord < 64
+#ifndef CF_SLOTS_N
+#define CF_SLOTS_N 12
+#endif
+constexpr unsigned CF_SLOTS = CF_SLOTS_N;  // entries per column of the board: walked ordinal modulo 12 (24).  The waves that share a set's jobs take the ordinals in turn and
+                                           // their number divides it, so a slot has ONE writer: a late answer of a slow wave lands where only that wave's next one goes
+static_assert(CF_BOARD + 2u <= CF_SLOTS, "a slot is free again before its wave writes it two rows on");
+static_assert(CF_SLOTS == 12u || CF_SLOTS == 24u, "cf_slot and classfit_asm.hpp know these two");
+static __device__ __forceinline__ unsigned cf_slot(unsigned ord) { return ord - CF_SLOTS * ((ord * 43u) >> (CF_SLOTS == 12u ? 9 : 10)); }  // ord % CF_SLOTS for ord < 64
 constexpr unsigned CF_OVL = 58;     // overlay lanes (lanes 58..63 are the candidates of logical class waves 1..6)
 constexpr unsigned CF_EPOCH_AT = COOK_SHAPE(58, 8);  // live overlay lanes that end an epoch
 constexpr unsigned CFW_BOOKS = 4;   // the bookkeeper's wave
@@ -367,7 +372,7 @@ static_assert(sizeof(CfFixed) % 16 == 0, "the arrays behind it are 16-byte align
 #define CF_ASM_EPOCH_LIVE "57"
 #include "classfit_asm.hpp"
 static_assert(CF_EPOCH_AT == 58 && CF_OVL == 58, "classfit_asm.hpp: the overlay's size");
-static_assert(offsetof(CfFixed, ctrl) == 13728 && offsetof(CfFixed, cls) == 9472 && sizeof(CfFixed) == 15280 && sizeof(CfClass) == 56 && offsetof(CfClass, hTc) == 32 &&
+static_assert(offsetof(CfFixed, ctrl) == 13728 + (CF_SLOTS - 12) * 256 && offsetof(CfFixed, cls) == 9472 + (CF_SLOTS - 12) * 256 && sizeof(CfFixed) == 15280 + (CF_SLOTS - 12) * 256 && sizeof(CfClass) == 56 && offsetof(CfClass, hTc) == 32 &&
                   offsetof(CfClass, hTm) == 40 && offsetof(CfEnt, pos) == 8 && offsetof(CfEnt, cid) == 12 && offsetof(CfEnt, fc) == 16 && offsetof(CfEnt, fa) == 24 && sizeof(CfEnt) == 32 &&
                   sizeof(CfLog) == 32 && offsetof(CfLog, ofc) == 8,
               "classfit_asm.hpp: offsets of the LDS records");

@@ -1402,3 +1402,37 @@ def explain_golden_engine(make_engine, case):
         counts = e.match_explain(np.array([0], np.uint32))
     assert (j2o[0] >= 0) == (case["expect"] == {}), case["ref"]
     assert A.why_summary(counts[0], scalar_names=names) == _explain_expect(case), case["ref"]
+
+
+def pool_usage_multi_parity(make_engine, n=5):
+    """cook_rank_pool_usage_multi == cook_rank_pool_usage of every engine (bit for bit: a pool's reduction order does not depend on its
+    neighbours) == the running rows summed on the host; an engine twice is COOK_E_INVALID; an empty pool and a pool without running tasks."""
+    from cook_amd.engine import CookError, rank_pool_usage_multi
+    shapes = [(900, 700), (40, 0), (0, 0), (3000, 5000), (200, 1)] + [(150 * i, 90 * i) for i in range(5, n)]
+    pools = [synth.make_pool(seed=4100 + i, n_pending=npd, n_running=nr, n_users=25, n_offers=16, gpus=(i % 2 == 0), fractional=(i % 3 == 0))
+             for i, (npd, nr) in enumerate(shapes[:n])]
+    engines = [make_engine(A.default_params()) for _ in pools]
+    try:
+        for e, pl in zip(engines, pools):
+            e.rank_stage(pl.tasks, pl.users)
+        multi = rank_pool_usage_multi(engines)
+        for e in engines:  # (a second table: the memo of the first call must not answer for it)
+            e.rank_stage(pools[0].tasks, pools[0].users)
+        for e, pl in zip(engines, pools):
+            e.rank_stage(pl.tasks, pl.users)
+        single = [e.rank_pool_usage().as_tuple() for e in engines]
+        assert multi == single, (multi, single)
+        assert rank_pool_usage_multi(engines[::-1]) == single[::-1]
+        for u, pl in zip(multi, pools):
+            run = pl.tasks.pending == 0
+            assert u[0] == float(run.sum())
+            assert abs(u[1] - float(pl.tasks.cpus[run].sum())) <= 1e-9 * max(1.0, u[1])
+        try:
+            rank_pool_usage_multi([engines[0], engines[1], engines[0]])
+        except CookError as ex:
+            assert ex.code == -1, ex  # COOK_E_INVALID
+        else:
+            raise AssertionError("an engine twice in cook_rank_pool_usage_multi was accepted")
+    finally:
+        for e in engines:
+            e.close()

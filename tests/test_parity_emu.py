@@ -777,3 +777,41 @@ print(json.dumps({"stats": {k: v for k, v in st.items() if k.startswith("rank_ba
 def test_explain_reference_cases(make_engine, case):
     # the reference's own cases of the why-unscheduled reducer (tests/golden/explain.json) through cook_match / cook_match_explain
     P.explain_golden_engine(make_engine, case)
+
+
+def test_pool_usage_multi(make_engine):
+    P.pool_usage_multi_parity(make_engine)
+
+
+def test_engine_choice_of_the_placement_form_in_fresh_processes():
+    """match_algo 0 with five engines on the device: class-ordered best fit for the pools that allow it; COOK_CLASSFIT=0 (read once per process) keeps the
+    window rounds, COOK_CLASSFIT=1 takes the class-ordered form for ONE engine too — same assignments every way."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, sys
+sys.path.insert(0, %r)
+from cook_amd import _abi as A, synth
+from cook_amd.engine import Engine, cycle_run_rank_multi, cycle_match_multi
+from tests.simt_emu import build_emu
+so = build_emu.build()
+n = int(sys.argv[1])
+p = A.default_params(good_enough_fitness=1.0)
+pools = [synth.make_pool(seed=500 + i, n_pending=300 + 40 * i, n_running=100, n_users=20, n_offers=60 + 10 * i, gpus=(i %% 2 == 0), constraints=True) for i in range(n)]
+engines = [Engine(p, lib_path=so) for _ in pools]
+for e, pl in zip(engines, pools):
+    e.cycle_stage(pl.tasks, pl.users, pl.pending_jobs, pl.offers, pl.groups)
+cycle_run_rank_multi(engines, 10 ** 9)
+cycle_match_multi(engines)
+print(json.dumps({"forms": [e.match_stats()["placement_form"] for e in engines], "out": [e.cycle_fetch()[1].tolist() for e in engines]}))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, n, env in (("five", 5, {}), ("five-forbidden", 5, {"COOK_CLASSFIT": "0"}), ("one", 1, {}), ("one-forced", 1, {"COOK_CLASSFIT": "1"})):
+        envx = {k: v for k, v in os.environ.items() if k != "COOK_CLASSFIT"}
+        r = subprocess.run([sys.executable, "-c", code, str(n)], env={**envx, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["five"]["forms"].count(3) >= 3 and set(got["five"]["forms"]) <= {0, 3}, got["five"]["forms"]
+    assert set(got["five-forbidden"]["forms"]) == {0} and got["one"]["forms"] == [0] and got["one-forced"]["forms"] == [3]
+    assert got["five"]["out"] == got["five-forbidden"]["out"] and got["one"]["out"] == got["one-forced"]["out"] == got["five"]["out"][:1]

@@ -694,3 +694,7 @@ def test_bench_two_ranks_on_one_gpu():
 def test_explain_reference_cases(make_engine, case):
     # the reference's own cases of the why-unscheduled reducer (tests/golden/explain.json) through cook_match / cook_match_explain
     P.explain_golden_engine(make_engine, case)
+
+
+def test_pool_usage_multi(make_engine):
+    P.pool_usage_multi_parity(make_engine, n=8)
