@@ -423,9 +423,9 @@ COOK_KERNEL void cf_prepare(const MatchIn* __restrict__ inp, CfBuf b, const doub
 COOK_KERNEL void cf_pack_jobs(const MatchIn* __restrict__ inp, CfBuf b, unsigned K) {
   const MatchIn& in = *inp;
   const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
   CfCtl* ctl = b.ctl;
-  if (ctl->inelig) return;
+  unsigned grouped = 0;
+  if (k < K && ctl->inelig == 0u) {  // (no early exit: the wave counts its grouped jobs together below; a call found ineligible is not packed)
   const JobRec j = b.jr[k];
   CfJob o;
   o.c = cf_fx(j.c, ctl->kc), o.m = cf_fx(j.m, ctl->km);
@@ -441,7 +441,7 @@ COOK_KERNEL void cf_pack_jobs(const MatchIn* __restrict__ inp, CfBuf b, unsigned
         if (ctl->kind_sig[y] == sig) kind = y;
   }
   o.eq[0] = o.eq[1] = 0u, o.nov[0] = o.nov[1] = 0xFFFFFFFFu;
-  unsigned n_eq = 0, n_nov = 0, grouped = 0;
+  unsigned n_eq = 0, n_nov = 0;
   if (j.flags & JF_FASTC) {
     const JobCons c = b.jcons[k];
     n_eq = c.n_eq;
@@ -466,11 +466,14 @@ COOK_KERNEL void cf_pack_jobs(const MatchIn* __restrict__ inp, CfBuf b, unsigned
     if (slot < CF_GMEM) b.gmem[(size_t)j.group * CF_GMEM + slot] = k;
     else bad |= CF_X_GROUP;
     ctl->any_group = 1u;
-    atomicAdd(&ctl->n_grouped, 1u);
   }
   o.meta = kind | L << 8 | n_eq << 12 | n_nov << 16 | grouped << 20;
   b.jobs[k] = o;
   if (bad) atomicOr(&ctl->inelig, bad);
+  }
+  // one addition per wave (a few thousand grouped jobs would otherwise queue at ONE address)
+  const unsigned long long gm = cook_ballot(grouped != 0u);
+  if (gm != 0ull && lane_id() == (unsigned)__ffsll((long long)gm) - 1u) atomicAdd(&ctl->n_grouped, (unsigned)__popcll(gm));
   (void)in;
 }
 

@@ -1451,6 +1451,95 @@ __global__ void __launch_bounds__(RB_APPLY_THREADS) rebal_apply(const RebalIn* _
       s_pre[lane] = ss;
     }
     wave_sync();
+    if (len <= (unsigned)COOK_WAVE) {
+      // The usual case (a host of more than 64 items is rebal_decide_big's): FIRST every load the commit needs — lane k the facts of the k-th preempted task, lane 0
+      // the control block, the host's and the job's words; every one of these loads is in flight before the first store (the arrays behind RebalIn's pointers may
+      // alias for the compiler: a store between two loads made the old form a chain of ~25 dependent round trips by one lane) —, THEN lane 0 writes, in the old order.
+      unsigned g_slot = 0, g_pbk = 0, g_user = 0xFFFFFFFFu, g_hx = 0, g_nt = 0;
+      bool g_known = false;
+      if (lane < len) {
+        g_slot = base == 0xFFFFFFFFu ? s_pre[lane] : in.srt_slot[base + lane];
+        g_pbk = in.posB[g_slot];
+        g_user = in.slot_user[g_slot];
+        g_known = g_slot < in.R ? (in.attrs_cached ? in.attrs_cached[g_slot] != 0 : true) : in.x_known[g_slot - in.R] != 0;
+        g_hx = g_slot < in.R ? in.hidx[g_pbk] : 0u;
+        g_nt = (in.seg_end[g_user] - in.seg_start[g_user] + RB_RS_TILE - 1) / RB_RS_TILE;
+      }
+      RebalCtl c;
+      cook_preemption d;
+      unsigned pbj = 0, xh = 0, xc = 0, items0 = 0, nt_us = 0;
+      if (lane == 0) {
+        c = *in.ctl;
+        d.dru = in.hres_dru[h], d.cpus = in.hres_c[h], d.mem = in.hres_m[h], d.gpus = in.hres_g[h];
+        pbj = in.posB[in.R + jb.pj];
+        xh = in.x_head[h], xc = in.x_cnt[h];
+        items0 = in.hend[h] - in.hstart[h];
+        nt_us = (in.seg_end[jb.us] - in.seg_start[jb.us] + RB_RS_TILE - 1) / RB_RS_TILE;
+      }
+      // a user is listed once per decision: the job's own first, then the preempted tasks' in their order (the old form's stamps in chg_mark)
+      s_rank[lane] = g_user;  // (rebal_host_small is done with s_rank)
+      wave_sync();
+      bool g_dup = g_user == jb.us;
+      for (unsigned j = 0; j < lane && lane < len; ++j) g_dup = g_dup || s_rank[j] == g_user;
+      const unsigned long long m_dup = cook_ballot(g_dup), m_known = cook_ballot(g_known);
+      // lane 0 takes lane k's words from the registers they were loaded into (no staging: wave_read_lane of a uniform k)
+      bool first_known = false;
+      unsigned n_chg = 0, n_tiles = 0;
+      if (lane == 0) {
+        d.pending_index = jb.pj;
+        d.host = h;
+        d.task_off = c.np;
+        d.task_n = len;
+        in.decisions[c.nd++] = d;
+        in.chg[0] = jb.us, in.chg_bad[0] = 0u, in.chg_tile[0] = 0u;
+        n_chg = 1u, n_tiles = nt_us;
+      }
+      for (unsigned k = 0; k < len; ++k) {  // (wave-uniform trip count; the reads below are cross-lane, the writes lane 0's)
+        const unsigned slot = (unsigned)wave_read_lane((int)g_slot, (int)k), pbk = (unsigned)wave_read_lane((int)g_pbk, (int)k), u = (unsigned)wave_read_lane((int)g_user, (int)k),
+                       hx = (unsigned)wave_read_lane((int)g_hx, (int)k), nt = (unsigned)wave_read_lane((int)g_nt, (int)k);
+        const bool dup = (m_dup >> k) & 1ull, known = (m_known >> k) & 1ull;
+        if (lane == 0) {
+          in.act[pbk] = 0;
+          in.dl_pos[n_dl] = pbk, in.dl_sign[n_dl] = -1;
+          if (slot < in.R) in.h_act[hx] = 0;
+          if (!dup) {
+            in.chg[n_chg] = u, in.chg_bad[n_chg] = 0u, in.chg_tile[n_chg] = n_tiles;
+            n_tiles += nt;
+            ++n_chg;
+          }
+          in.preempted[c.np++] = slot < in.R ? slot : 0xFFFFFFFFu;  // a task placed this cycle is reported as NONE (rebalancer.clj:529)
+          if (k == 0) first_known = known;
+          if (known) in.pre_hosts[c.n_pre_hosts++] = h;
+        }
+        ++n_dl;
+      }
+      if (lane == 0) {
+        // the job becomes a task of its user on that host, carrying the slave id of the first preempted task (:279-281)
+        in.act[pbj] = 1;
+        in.dl_pos[n_dl] = pbj, in.dl_sign[n_dl] = 1;
+        in.x_host[jb.pj] = h;
+        in.x_known[jb.pj] = (len > 0 && first_known) ? 1 : 0;
+        in.x_next[jb.pj] = xh;  // joins the host's chain of placed jobs
+        in.x_head[h] = jb.pj;
+        in.x_cnt[h] = xc + 1u;
+        in.hmax_key[h] = ~0ull;  // (the placed job's DRU is not in the host-ordered mirror: the host is evaluated for every job from now on)
+        if (items0 + xc + 1u > c.max_items) c.max_items = items0 + xc + 1u;
+        if (items0 <= (unsigned)COOK_WAVE && items0 + xc + 1u == (unsigned)COOK_WAVE + 1u) in.big_list[c.n_big++] = h;  // this placement takes the host past 64 items
+        in.x_pj[c.n_x] = jb.pj;  // ... and the list of all of them (placement order)
+        c.n_x += 1;
+        in.spare_c[h] = d.cpus - jb.c;  // rebalancer.clj:302-305
+        in.spare_m[h] = d.mem - jb.m;
+        in.spare_g[h] = d.gpus - jb.g;
+        in.has_spare[h] = 1;
+        c.remaining -= 1;
+        in.chg_tile[n_chg] = n_tiles;
+        c.n_changed = n_chg;
+        c.n_tiles = n_tiles;
+        c.n_delta = n_dl + 1u;
+        *in.ctl = c;
+      }
+      ++n_dl;  // (the job's own flip; every lane counts alike)
+    } else
     if (lane == 0) {
       RebalCtl c = *in.ctl;
       cook_preemption d;
