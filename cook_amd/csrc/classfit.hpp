@@ -117,6 +117,15 @@ static __host__ __device__ __forceinline__ unsigned cf_max(unsigned a, unsigned 
 static __device__ __forceinline__ double cf_pow2(int k) { return __longlong_as_double((long long)(1023 + k) << 52); }
 static __device__ __forceinline__ uint32_t cf_fx(double v, unsigned k) { return (uint32_t)(v * cf_pow2((int)k)); }
 
+// ---- 0. the call's tables cleared (one launch for all of them — and for every pool of a batch — where three fills were issued alone)
+COOK_KERNEL void cf_init(CfBuf b, unsigned n_h2o, unsigned G) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  uint32_t* cw = reinterpret_cast<uint32_t*>(b.ctl);
+  for (unsigned x = i; x < (unsigned)(sizeof(CfCtl) / 4u); x += stride) cw[x] = 0u;
+  for (unsigned x = i; x < n_h2o; x += stride) b.h2o[x] = 0xFFFFFFFFu;
+  for (unsigned x = i; x < G; x += stride) b.gcount[x] = 0u;
+}
+
 // ---- 1. what the numbers of the call look like (grid over max(K, M)) ------------------------------------------------------------------------
 COOK_KERNEL void cf_scan(const MatchIn* __restrict__ inp, CfBuf b, unsigned K, unsigned M) {
   const MatchIn& in = *inp;

@@ -1387,9 +1387,8 @@ bool cf_setup(cook_engine* e, const MatchIn& in, const MatchIn* in_dev, const Ma
   b.jobs = e->cf_jobs.ensure(K);
   b.gcount = e->cf_gcount.ensure(std::max(1u, G));
   b.gmem = e->cf_gmem.ensure((size_t)std::max(1u, G) * CF_GMEM);
-  memset_async(e, b.ctl, 0, sizeof(CfCtl));
-  memset_async(e, b.h2o, 0xFF, ((size_t)b.max_host + 1u) * 4u);
-  memset_async(e, b.gcount, 0, (size_t)std::max(1u, G) * 4u);
+  static_assert(sizeof(CfCtl) % 4 == 0, "cf_init clears the control block word by word");
+  KM<cf_init, 256>(e, "cf_init", std::min(div_up(b.max_host + 1u, 1024u), 512u), b, b.max_host + 1u, std::max(1u, G));
   KM<cf_scan, 256>(e, "cf_scan", div_up(std::max(K, M), 256), in_dev, b, K, M);
   KM<cf_prepare, 1024>(e, "cf_prepare", 1u, in_dev, b, st.jmin, K, M, G, in.host_dup, in.reserved_bits ? 1u : 0u);
   KM<cf_pack_jobs, 256>(e, "cf_pack_jobs", div_up(K, 256), in_dev, b, K);
