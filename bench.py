@@ -863,7 +863,7 @@ def main():
                        "pools": P, "pending_total": n_pend * P, "running_total": n_run * P, "offers_total": n_off * P,
                        "users": args.users, "considerable_per_pool": K, "good_enough_fitness": args.good_enough, "match_algo": args.match_algo,
                        "placement_form": {0: "window rounds", 1: "serial sweep", 3: "class-ordered best fit"}.get(timed_form, timed_form),
-                       "parallelism": f"pools sharded over {world} GPU(s); per rank up to {cluster.max_chains} pools as launch chains of window rounds of their own; five or more pools of a "
+                       "parallelism": f"pools sharded over {world} GPU(s); per rank up to {cluster.max_chains} pools as launch chains of window rounds of their own; six or more pools of a "
                                       f"GPU by class-ordered best fit (ONE launch, a workgroup of 16 waves per pool, no evaluation launches) where a pool's numbers and constraints allow it, "
                                       f"else as served walkers (one persistent walker workgroup per pool beside evaluation launches)" + ("" if cluster.served else "; COOK_MATCH_SERVED=0: lockstep groups instead"), "pair_evaluations_per_cycle": considered * n_off},
             # (weak scaling: the cycle grows with the node — the figure that compares across N is pairs per second, not cycles)

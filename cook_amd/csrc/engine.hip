@@ -1346,9 +1346,10 @@ static void launch_round(cook_engine* e, const MatchIn& in, const MatchState& st
 }
 
 // ---- class-ordered best fit (classfit.hpp): set-up, eligibility, launch --------------------------------------------------------------------
-// match_algo 3 asks for the class-ordered best fit.  match_algo 0 (the engine's choice) takes it when five or more engines share the device: its walks need no
+// match_algo 3 asks for the class-ordered best fit.  match_algo 0 (the engine's choice) takes it when six or more engines share the device: its walks need no
 // evaluation launches, so eight pools cost what one costs (measured on MI355X, profiles/r06*: eight C4 pools 48.5 against 49.8 ms as served walkers, K = 1000 4.95
-// against 5.11 ms), while a pool that has the GPU (nearly) to itself is faster in window rounds (one C4 pool 38.3 against 44.5 ms).  COOK_CLASSFIT=1 / 0 forces / forbids
+// against 5.11 ms), while a pool that has the GPU (nearly) to itself is faster in window rounds (one C4 pool 38.3 against 44.5 ms).  Measured per pool count (profiles/r06n_pools_5_6_7.txt,
+// C4 pools, served walkers against class-ordered): 5 pools 45.4 / 46.1 ms, 6 pools 49.0 / 46.5, 7 pools 50.9 / 46.6, 8 pools 49.9 / 47.1: the rule turns at six.  COOK_CLASSFIT=1 / 0 forces / forbids
 // it for match_algo 0.  (A plain function, not a namespace-scope lambda initialiser: hipcc gave the second such initialiser the body of the first)
 static int classfit_env() {
   static const int v = [] {
@@ -1360,7 +1361,7 @@ static int classfit_env() {
 static bool classfit_by_default(const cook_engine* e) {
   const int f = classfit_env();
   if (f >= 0) return f == 1;
-  return g_engines_on_device[e->device & 63].load() >= 5;
+  return g_engines_on_device[e->device & 63].load() >= 6;
 }
 static size_t cf_lds_bytes_host(unsigned NP, unsigned M, bool eq, unsigned G, unsigned S) {  // the layout of cf_walk_pool (classfit_walk.hpp)
   size_t n = sizeof(CfFixed) + (size_t)NP * 10u;
@@ -1482,7 +1483,7 @@ void match_run_device(cook_engine* e, unsigned K, const uint32_t* j_index, bool 
   e->has_deferred = false;
   const int algo = e->params.match_algo;
   if (!(algo == 0 || algo == 1 || algo == 2 || algo == 3))
-    e->fail(COOK_E_INVALID, "cook_params.match_algo: 0 = engine default (window rounds; class-ordered best fit where the call allows it when five or more engines share the device), 1 = serial sweep, 2 = window rounds, 3 = class-ordered best fit where the call allows it, else window rounds");
+    e->fail(COOK_E_INVALID, "cook_params.match_algo: 0 = engine default (window rounds; class-ordered best fit where the call allows it when six or more engines share the device), 1 = serial sweep, 2 = window rounds, 3 = class-ordered best fit where the call allows it, else window rounds");
   if (defer && !(algo != 1 && K > 0)) defer = false;  // only the window rounds run several pools in one launch
   const bool ge = in.good_enough < 1.0;
   if (algo == 1) {  // one-job-at-a-time sweep by a single workgroup (reference implementation of the chain)

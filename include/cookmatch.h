@@ -56,7 +56,7 @@ typedef struct cook_params {
   double offensive_max_cpus;   /* task-constraints :cpus (scheduler.clj:2198-2203); +inf disables               */
   double good_enough_fitness;  /* config.clj:111 default 0.8; (> fitness x) at scheduler.clj:2312-2314; >=1 = off */
   int64_t host_lifetime_mins;  /* estimated-completion-config :host-lifetime-mins (constraints.clj:392-397)     */
-  int32_t match_algo;          /* 0 = engine default (= 2; = 3 when five or more engines share the device, COOK_CLASSFIT=0 / 1 forbids /
+  int32_t match_algo;          /* 0 = engine default (= 2; = 3 when six or more engines share the device, COOK_CLASSFIT=0 / 1 forbids /
                                   forces that), 1 serial sweep (one workgroup, one job at a time: the reference form of the
                                   chain), 2 window rounds (eval / merge / resolve launches), 3 class-ordered best fit (one workgroup per pool,
                                   no evaluation launches) where the call's numbers and constraints allow it, else as 2.

@@ -21,9 +21,14 @@ def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libcookoracle.so")
     src = os.path.join(_HERE, "cook_oracle.cpp")
     hdr = os.path.join(_HERE, "..", "include", "cookmatch.h")
-    stale = (not os.path.exists(so)) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in (src, hdr))
-    if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    def stale():
+        return (not os.path.exists(so)) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in (src, hdr))
+    if force or stale():
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lk:  # (pytest -n: several workers find the library stale at once; one builds, the others wait)
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if force or stale():
+                subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return so
 
 

@@ -93,7 +93,7 @@ def main():
             pools.append(synth.make_pool(seed=int(rng.integers(1, 1 << 30)), n_pending=npd, n_running=int(rng.integers(0, int(300 * sc))),
                                          n_users=int(rng.integers(1, 30)), n_offers=int(rng.integers(1, int(500 * sc))), gpus=bool(rng.integers(0, 2)),
                                          constraints=bool(rng.integers(0, 2)), fractional=bool(rng.integers(0, 2)), tie_heavy=bool(rng.integers(0, 2))))
-            # (the form per pool: window rounds, the engine's choice — class-ordered best fit from five engines on —, class-ordered best fit where the pool allows it:
+            # (the form per pool: window rounds, the engine's choice — class-ordered best fit from six engines on —, class-ordered best fit where the pool allows it:
             #  one call then holds pools of both forms)
             params.append(A.default_params(good_enough_fitness=float(rng.choice([1.0, 0.8, 0.5])) if mixed else ge_all, match_algo=int(rng.choice([2, 2, 0, 3]))))
             ks.append(int(rng.choice([10 ** 9, 10 ** 9, int(rng.integers(1, npd + 1))])))

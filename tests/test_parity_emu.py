@@ -357,13 +357,13 @@ def test_sharded_cluster_lockstep_chains(make_engine, whole, monkeypatch):
     # lockstep placement per chain; every pool against the oracle, on a repeated cycle
     from cook_amd import sharding, workload
     from oracle import checks
-    # "engine-choice": match_algo 0 with five engines on the device = class-ordered best fit for every eligible pool (one cf_walk launch, a workgroup per pool), the
+    # "engine-choice": match_algo 0 with six engines on the device = class-ordered best fit for every eligible pool (one cf_walk launch, a workgroup per pool), the
     # others by the served walkers; the first three forms pin the window rounds (match_algo 2)
     auto = whole == "engine-choice"
     if auto:
         whole = None
     monkeypatch.setenv("COOK_MATCH_SERVED", "1" if whole is None else "0")  # (read by ShardedCluster and by the library)
-    spec = workload.ClusterSpec(pools=5, pending=1500, running=500, offers=400, users=40)
+    spec = workload.ClusterSpec(pools=6 if auto else 5, pending=1500, running=500, offers=400, users=40)
     params = A.default_params(good_enough_fitness=1.0, match_algo=0 if auto else 2)
     pools = workload.make_pools(spec, range(spec.pools))
     engines = {}
@@ -784,7 +784,7 @@ def test_pool_usage_multi(make_engine):
 
 
 def test_engine_choice_of_the_placement_form_in_fresh_processes():
-    """match_algo 0 with five engines on the device: class-ordered best fit for the pools that allow it; COOK_CLASSFIT=0 (read once per process) keeps the
+    """match_algo 0 with six engines on the device: class-ordered best fit for the pools that allow it; COOK_CLASSFIT=0 (read once per process) keeps the
     window rounds, COOK_CLASSFIT=1 takes the class-ordered form for ONE engine too — same assignments every way."""
     import json
     import subprocess
@@ -807,11 +807,11 @@ cycle_match_multi(engines)
 print(json.dumps({"forms": [e.match_stats()["placement_form"] for e in engines], "out": [e.cycle_fetch()[1].tolist() for e in engines]}))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for name, n, env in (("five", 5, {}), ("five-forbidden", 5, {"COOK_CLASSFIT": "0"}), ("one", 1, {}), ("one-forced", 1, {"COOK_CLASSFIT": "1"})):
+    for name, n, env in (("six", 6, {}), ("six-forbidden", 6, {"COOK_CLASSFIT": "0"}), ("five", 5, {}), ("one", 1, {}), ("one-forced", 1, {"COOK_CLASSFIT": "1"})):
         envx = {k: v for k, v in os.environ.items() if k != "COOK_CLASSFIT"}
         r = subprocess.run([sys.executable, "-c", code, str(n)], env={**envx, **env}, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         got[name] = json.loads(r.stdout.strip().splitlines()[-1])
-    assert got["five"]["forms"].count(3) >= 3 and set(got["five"]["forms"]) <= {0, 3}, got["five"]["forms"]
-    assert set(got["five-forbidden"]["forms"]) == {0} and got["one"]["forms"] == [0] and got["one-forced"]["forms"] == [3]
-    assert got["five"]["out"] == got["five-forbidden"]["out"] and got["one"]["out"] == got["one-forced"]["out"] == got["five"]["out"][:1]
+    assert got["six"]["forms"].count(3) >= 3 and set(got["six"]["forms"]) <= {0, 3}, got["six"]["forms"]
+    assert set(got["six-forbidden"]["forms"]) == {0} and set(got["five"]["forms"]) == {0} and got["one"]["forms"] == [0] and got["one-forced"]["forms"] == [3]
+    assert got["six"]["out"] == got["six-forbidden"]["out"] and got["five"]["out"] == got["six"]["out"][:5] and got["one"]["out"] == got["one-forced"]["out"] == got["six"]["out"][:1]
